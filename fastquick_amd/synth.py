@@ -1,0 +1,210 @@
+"""Seeded synthetic inputs for the FASTQuick `align` hot path (tests + bench.py).
+
+Geometry follows SURVEY.md section 8(d): a uniform-random genome with one marker every
+`spacing` bp; the first `n_long` markers get the long flank (contig name suffix ``|L``), the
+rest the short flank, exactly like the reduced reference RefBuilder writes
+(reference: src/RefBuilder.cpp:585-613 -- header ``>CHR:POS@REF/ALT[|L]``, sequence
+``flank + REF + flank``).  Read pairs are fragments N(frag_mean, frag_sd) cut from the genome
+(on-target: overlapping a marker's flank region) or i.i.d. random sequence (off-target).
+
+Nothing here is on the product path; it only fabricates inputs.
+"""
+from __future__ import annotations
+
+import dataclasses
+import os
+from typing import Optional
+
+import numpy as np
+
+_ACGT = np.frombuffer(b"ACGT", dtype=np.uint8)
+_COMP = np.zeros(256, dtype=np.uint8)
+for _a, _b in zip(b"ACGTNacgtn", b"TGCANtgcan"):
+    _COMP[_a] = _b
+
+
+@dataclasses.dataclass
+class SynthRef:
+    """A reduced reference: contig names, sequences (ASCII uint8 arrays) and the source genome."""
+    names: list
+    seqs: list
+    genome: np.ndarray          # codes 0..3
+    marker_pos: np.ndarray      # 1-based marker coordinates in the genome
+    flank: np.ndarray           # flank length per marker
+
+    @property
+    def l_pac(self) -> int:
+        return int(sum(len(s) for s in self.seqs))
+
+    def write_fasta(self, path: str) -> None:
+        with open(path, "wb") as fh:
+            for n, s in zip(self.names, self.seqs):
+                fh.write(b">" + n.encode() + b"\n" + s.tobytes() + b"\n")
+
+
+def make_reference(n_markers: int = 40, n_long: int = 4, flank_short: int = 250, flank_long: int = 1000,
+                   spacing: int = 3000, seed: int = 12345, repeat_every: int = 0, repeat_div: float = 0.005,
+                   n_frac: float = 0.0, tandem_every: int = 0) -> SynthRef:
+    """Build a synthetic genome + reduced reference.
+
+    repeat_every>0 makes every `repeat_every`-th window a diverged copy of its predecessor
+    (repeat-rich variant, exercises c1>1 / drand48 / XA paths); n_frac sprinkles N into flanks.
+    """
+    rng = np.random.default_rng(seed)
+    glen = 2000 + spacing * n_markers + 2000
+    genome = rng.integers(0, 4, glen, dtype=np.uint8)
+    if repeat_every:
+        for k in range(1, n_markers):
+            if k % repeat_every == 0:
+                a = 2000 + spacing * (k - 1) - spacing // 2
+                b = a + spacing
+                seg = genome[a:a + spacing].copy()
+                mut = rng.random(spacing) < repeat_div
+                seg[mut] = (seg[mut] + rng.integers(1, 4, int(mut.sum()), dtype=np.uint8)) & 3
+                genome[b:b + spacing] = seg
+    if tandem_every:
+        for k in range(0, n_markers, tandem_every):
+            p = 2000 + spacing * k + 60
+            unit = genome[p:p + 40].copy()
+            for r in range(1, 3):
+                genome[p + 40 * r:p + 40 * (r + 1)] = unit
+    pos = 2000 + spacing * np.arange(n_markers, dtype=np.int64)   # 1-based
+    flank = np.where(np.arange(n_markers) < n_long, flank_long, flank_short).astype(np.int64)
+    names, seqs = [], []
+    for k in range(n_markers):
+        p, f = int(pos[k]), int(flank[k])
+        codes = genome[p - 1 - f:p + f]
+        s = _ACGT[codes].copy()
+        if n_frac > 0:
+            m = rng.random(len(s)) < n_frac
+            m[f] = False
+            s[m] = ord("N")
+        ref = int(genome[p - 1])
+        alt = (ref + 1 + k % 3) % 4
+        nm = "1:%d@%s/%s" % (p, "ACGT"[ref], "ACGT"[alt])
+        if f == flank_long:
+            nm += "|L"
+        names.append(nm)
+        seqs.append(s)
+    return SynthRef(names, seqs, genome, pos, flank)
+
+
+@dataclasses.dataclass
+class ReadBatch:
+    """n read pairs; seq/qual are (2, n, L) ASCII uint8, lens (2, n) int32, names list of bytes."""
+    seq: np.ndarray
+    qual: np.ndarray
+    lens: np.ndarray
+    names: list
+
+    @property
+    def n(self) -> int:
+        return self.seq.shape[1]
+
+    def write_fastq(self, prefix: str) -> tuple:
+        paths = []
+        for e in range(2):
+            path = "%s_%d.fq" % (prefix, e + 1)
+            with open(path, "wb") as fh:
+                for i in range(self.n):
+                    ln = int(self.lens[e, i])
+                    fh.write(b"@" + self.names[i] + b"\n" + self.seq[e, i, :ln].tobytes() + b"\n+\n"
+                             + self.qual[e, i, :ln].tobytes() + b"\n")
+            paths.append(path)
+        return tuple(paths)
+
+
+def _revcomp(a: np.ndarray) -> np.ndarray:
+    return _COMP[a[..., ::-1]]
+
+
+def make_reads(ref: SynthRef, n_pairs: int, read_len: int = 150, on_target: float = 1.0, seed: int = 7,
+               sub_rate: float = 0.005, del_frac: float = 0.02, ins_frac: float = 0.0, n_rate: float = 0.0,
+               frag_mean: float = 350.0, frag_sd: float = 30.0, qual_decay: bool = False,
+               name_prefix: str = "r", indel_len_max: int = 1, chimera_frac: float = 0.0,
+               name_offset: int = 0) -> ReadBatch:
+    """Vectorised read-pair synthesis.  Mates are randomly swapped (so read 1 is on either strand)."""
+    rng = np.random.default_rng(seed)
+    L = read_len
+    frag = np.clip(np.rint(rng.normal(frag_mean, frag_sd, n_pairs)).astype(np.int64), L + 10, None)
+    on = rng.random(n_pairs) < on_target
+    g = ref.genome
+    # on-target: fragment start such that the fragment lies inside a marker's flank window
+    k = rng.integers(0, len(ref.marker_pos), n_pairs)
+    lo = ref.marker_pos[k] - 1 - ref.flank[k]
+    hi = ref.marker_pos[k] + ref.flank[k]              # exclusive end of window
+    span = np.maximum(hi - lo - frag, 1)
+    start = lo + (rng.random(n_pairs) * span).astype(np.int64)
+    if chimera_frac > 0:   # mate from another marker window -> exercises unpaired / SW-rescue logic
+        ch = rng.random(n_pairs) < chimera_frac
+    else:
+        ch = np.zeros(n_pairs, dtype=bool)
+    idx = np.arange(L, dtype=np.int64)
+    extra = indel_len_max + 2
+    idxx = np.arange(L + extra, dtype=np.int64)
+    r1 = g[np.clip(start[:, None] + idxx[None, :], 0, len(g) - 1)]                 # forward strand, left end (+extra)
+    end = start + frag
+    k2 = rng.integers(0, len(ref.marker_pos), n_pairs)
+    end_ch = ref.marker_pos[k2] + 50
+    end = np.where(ch, end_ch, end)
+    r2f = g[np.clip(end[:, None] - 1 - idxx[None, :], 0, len(g) - 1)]              # reverse order from right end
+    r2 = (3 - r2f).astype(np.uint8)                                                # complement -> read 2 as sequenced
+    off = ~on
+    n_off = int(off.sum())
+    if n_off:
+        r1[off] = rng.integers(0, 4, (n_off, L + extra), dtype=np.uint8)
+        r2[off] = rng.integers(0, 4, (n_off, L + extra), dtype=np.uint8)
+    reads = [r1, r2]
+    out = np.empty((2, n_pairs, L), dtype=np.uint8)
+    for e in range(2):
+        r = reads[e]
+        # indels: delete or insert `d` bases at a random interior position
+        if del_frac > 0 or ins_frac > 0:
+            u = rng.random(n_pairs)
+            dsel = (u < del_frac) & on if e == 0 else (u < del_frac * 0.5) & on
+            isel = (u >= del_frac) & (u < del_frac + ins_frac) & on
+            ppos = rng.integers(20, L - 20, n_pairs)
+            dl = rng.integers(1, indel_len_max + 1, n_pairs)
+            col = idx[None, :].repeat(n_pairs, 0)
+            src = col.copy()
+            m = dsel[:, None] & (col >= ppos[:, None])
+            src[m] += dl[:, None].repeat(L, 1)[m]
+            m2 = isel[:, None] & (col >= ppos[:, None] + dl[:, None])
+            src[m2] -= dl[:, None].repeat(L, 1)[m2]
+            body = np.take_along_axis(r, src, axis=1)
+            m3 = isel[:, None] & (col >= ppos[:, None]) & (col < ppos[:, None] + dl[:, None])
+            body[m3] = rng.integers(0, 4, int(m3.sum()), dtype=np.uint8)
+        else:
+            body = r[:, :L].copy()
+        if sub_rate > 0:
+            m = rng.random((n_pairs, L)) < sub_rate
+            body[m] = (body[m] + rng.integers(1, 4, int(m.sum()), dtype=np.uint8)) & 3
+        asc = _ACGT[body]
+        if n_rate > 0:
+            m = rng.random((n_pairs, L)) < n_rate
+            asc[m] = ord("N")
+        out[e] = asc
+    swap = rng.random(n_pairs) < 0.5
+    tmp = out[0, swap].copy()
+    out[0, swap] = out[1, swap]
+    out[1, swap] = tmp
+    if qual_decay:
+        base = 40 - (np.arange(L) * 38 // L)
+        q = np.clip(base[None, None, :] + rng.integers(-3, 4, (2, n_pairs, L)), 2, 41).astype(np.uint8) + 33
+    else:
+        q = np.full((2, n_pairs, L), ord("I"), dtype=np.uint8)
+    lens = np.full((2, n_pairs), L, dtype=np.int32)
+    names = [("%s%09d" % (name_prefix, i + name_offset)).encode() for i in range(n_pairs)]
+    return ReadBatch(out, q, lens, names)
+
+
+def write_param(prefix_fa: str, ref: SynthRef, n_long: int) -> None:
+    """The 7-line .param file `align` expects next to the index (src/FASTQuick.cpp:145-151)."""
+    with open(prefix_fa + ".param", "w") as fh:
+        fh.write("REFERENCE_PATH\t%s\n" % (prefix_fa + ".genome.fa"))
+        fh.write("TARGET_REGION_PATH\tEmpty\n")
+        fh.write("DBSNP_VCF_PATH\tEmpty\n")
+        fh.write("NUM_VAR_LONG\t%d\n" % n_long)
+        fh.write("NUM_VAR_SHORT\t%d\n" % (len(ref.names) - n_long))
+        fh.write("SHORT_FLANK_LENGTH\t250\n")
+        fh.write("LONG_FLANK_LENGTH\t1000\n")

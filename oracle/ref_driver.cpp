@@ -1,0 +1,226 @@
+// oracle/ref_driver.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Thin driver around the REAL reference implementation (Griffan/FASTQuick, compiled in place
+// from /root/reference by oracle/Makefile `make ref`).  It contains no alignment logic of its
+// own: it calls the reference's hot-path functions in the order BwtMapper::PairEndMapper does
+// (src/BwtMapper.cpp:1796-2104) and dumps every stage in the canonical text format that
+// oracle/fq_oracle.c and the product's test harness also emit, so the three can be diffed.
+//
+// The file-static functions (bwa_read_seq_with_hash_dev :476, bwa_cal_sa_reg_gap :63,
+// bwa_cal_pac_pos_pe :721) are reached by including the reference translation unit from where
+// it lies -- nothing is copied into this repository.
+//
+//   fq_ref_driver index <ref.FASTQuick.fa>
+//       BwtIndexer::BuildIndex's steps (src/BwtIndexer.cpp:716-762) except that the dense
+//       3 GiB .rollhash dump is replaced by a sparse list of set bits (<fa>.rollhash.sparse).
+//   fq_ref_driver align <ref.FASTQuick.fa> <r1.fq> <r2.fq> <out_prefix> [--q Q] [--batch N] [--t T]
+//       writes <out>.stages (per-stage dump) and <out>.sam (bwa_print_sam1 text).
+#include "BwtMapper.cpp"   // resolved through -I$(REF)/src ; see Makefile
+
+#include <cinttypes>
+
+static void die(const char *m) { fprintf(stderr, "fq_ref_driver: %s\n", m); exit(2); }
+
+// ---- sparse bitmap I/O (ours; the bitmaps themselves come from the reference) -------------
+static void dump_sparse(BwtIndexer &ix, const std::string &path) {
+  FILE *fp = fopen(path.c_str(), "wb");
+  if (!fp) die("cannot write sparse rollhash");
+  for (int t = 0; t < 6; ++t) {
+    const uint64_t *w = (const uint64_t *)ix.roll_hash_table[t];
+    const uint64_t nw = (uint64_t)ix.hash_table_size / 8;
+    std::vector<uint32_t> bits;
+    for (uint64_t i = 0; i < nw; ++i) {
+      uint64_t x = w[i];
+      while (x) {
+        int b = __builtin_ctzll(x);
+        bits.push_back((uint32_t)(i * 64 + b));  // little endian: bit b of word i == bit (b&7) of byte i*8+(b>>3)
+        x &= x - 1;
+      }
+    }
+    uint64_t n = bits.size();
+    fwrite(&n, 8, 1, fp);
+    fwrite(bits.data(), 4, n, fp);
+  }
+  fclose(fp);
+}
+
+static void load_sparse(BwtIndexer &ix, const std::string &path) {
+  FILE *fp = fopen(path.c_str(), "rb");
+  if (!fp) die("cannot read sparse rollhash");
+  for (int t = 0; t < 6; ++t) {
+    uint64_t n;
+    if (fread(&n, 8, 1, fp) != 1) die("short sparse file");
+    std::vector<uint32_t> bits(n);
+    if (n && fread(bits.data(), 4, n, fp) != n) die("short sparse file");
+    for (uint64_t i = 0; i < n; ++i) ix.roll_hash_table[t][bits[i] >> 3] |= (unsigned char)(1u << (bits[i] & 7));
+  }
+  fclose(fp);
+}
+
+static int cmd_index(int argc, char **argv) {
+  if (argc < 3) die("usage: index <ref.FASTQuick.fa>");
+  std::string NewRef = argv[2], OldRef = argv[2], str;
+  gap_opt_t *opt = gap_init_opt();
+  BwtIndexer ix;  // allocates the six 2^32-bit tables (src/BwtIndexer.cpp:555)
+  // -- the body of BwtIndexer::BuildIndex (src/BwtIndexer.cpp:716-762), calling its public steps
+  ix.RefPath = OldRef;
+  ix.Fa2Pac(NewRef.c_str());
+  ix.Fa2RevPac(NewRef.c_str());
+  dump_sparse(ix, NewRef + ".rollhash.sparse");  // instead of DumpRollHashTable (3 GiB)
+  bns_dump(ix.bns, NewRef.c_str());
+  ix.bwt_d = ix.Pac2Bwt(ix.pac_buf);
+  ix.rbwt_d = ix.Pac2Bwt(ix.rpac_buf);
+  bwt_gen_cnt_table(ix.bwt_d);
+  bwt_gen_cnt_table(ix.rbwt_d);
+  ix.bwt_bwtupdate_core(ix.bwt_d);
+  ix.bwt_bwtupdate_core(ix.rbwt_d);
+  str = NewRef + ".bwt";  bwt_dump_bwt(str.c_str(), ix.bwt_d);
+  str = NewRef + ".rbwt"; bwt_dump_bwt(str.c_str(), ix.rbwt_d);
+  str = NewRef + ".sa";   ix.bwt_cal_sa(ix.bwt_d, 32);  bwt_dump_sa(str.c_str(), ix.bwt_d);
+  str = NewRef + ".rsa";  ix.bwt_cal_sa(ix.rbwt_d, 32); bwt_dump_sa(str.c_str(), ix.rbwt_d);
+  gap_free_opt(opt);
+  return 0;
+}
+
+// ---- canonical stage dump -----------------------------------------------------------------
+static void dump_cigar(FILE *fp, int n, const bwa_cigar_t *c) {
+  if (!c || n == 0) { fputs("*", fp); return; }
+  for (int i = 0; i < n; ++i) fprintf(fp, "%d%c", __cigar_len(c[i]), "MIDS"[__cigar_op(c[i])]);
+}
+
+static void dump_rec(FILE *fp, char tag, int end, int idx, const bwa_seq_t *p, int with_final) {
+  fprintf(fp, "%c %d %d type=%d strand=%d pos=%u sa=%u mapQ=%d seQ=%d c1=%d c2=%d flag=%d mm=%d go=%d ge=%d score=%d filt=%d len=%d",
+          tag, end, idx, p->type, p->strand, p->pos, p->sa, p->mapQ, (int)p->seQ, (int)p->c1, (int)p->c2,
+          p->extra_flag, p->n_mm, p->n_gapo, p->n_gape, p->score, p->filtered, p->len);
+  fprintf(fp, " cigar=");
+  dump_cigar(fp, p->n_cigar, p->cigar);
+  if (with_final) fprintf(fp, " nm=%d md=%s", p->nm, p->md ? p->md : "*");
+  fprintf(fp, " multi=%d", p->n_multi);
+  for (int k = 0; k < p->n_multi; ++k) {
+    const bwt_multi1_t *q = p->multi + k;
+    fprintf(fp, " [%u,%d,%d,%d,", q->pos, q->gap, q->mm, q->strand);
+    dump_cigar(fp, q->n_cigar, q->cigar);
+    fputs("]", fp);
+  }
+  fputc('\n', fp);
+}
+
+static void dump_ii(FILE *fp, const isize_info_t *ii) {
+  uint64_t a, s, p;
+  memcpy(&a, &ii->avg, 8); memcpy(&s, &ii->std, 8); memcpy(&p, &ii->ap_prior, 8);
+  fprintf(fp, "I avg=%016" PRIx64 " std=%016" PRIx64 " ap=%016" PRIx64 " low=%u high=%u hb=%u\n", a, s, p,
+          ii->low, ii->high, ii->high_bayesian);
+}
+
+static int cmd_align(int argc, char **argv) {
+  if (argc < 6) die("usage: align <ref.FASTQuick.fa> <r1.fq> <r2.fq> <out_prefix> [--q Q] [--batch N] [--thresh K]");
+  std::string NewRef = argv[2];
+  const char *fq1 = argv[3], *fq2 = argv[4];
+  std::string out = argv[5];
+  gap_opt_t *opt = gap_init_opt();
+  pe_opt_t *popt = bwa_init_pe_opt();
+  int batch = READ_BUFFER_SIZE, thresh = 3;
+  for (int i = 6; i + 1 < argc; i += 2) {
+    if (!strcmp(argv[i], "--q")) opt->trim_qual = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--batch")) batch = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--thresh")) thresh = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--n")) { opt->max_diff = atoi(argv[i + 1]); opt->fnr = -1.0; }
+    else if (!strcmp(argv[i], "--no_sw")) popt->is_sw = 0;
+    else die("unknown option");
+  }
+  if (batch > READ_BUFFER_SIZE) die("--batch too large");
+
+  // index load: BwtIndexer::LoadIndex (src/BwtIndexer.cpp:803-837) minus LoadContigSize/.param
+  // and with the bitmaps restored from the sparse list the `index` command wrote.
+  BwtIndexer ix(thresh);
+  {
+    std::string str;
+    load_sparse(ix, NewRef + ".rollhash.sparse");
+    str = NewRef + ".bwt";  ix.bwt_d = bwt_restore_bwt(str.c_str());
+    str = NewRef + ".sa";   bwt_restore_sa(str.c_str(), ix.bwt_d);
+    str = NewRef + ".rbwt"; ix.rbwt_d = bwt_restore_bwt(str.c_str());
+    str = NewRef + ".rsa";  bwt_restore_sa(str.c_str(), ix.rbwt_d);
+    ix.bns = bns_restore(NewRef.c_str());
+  }
+
+  FILE *st = fopen((out + ".stages").c_str(), "w");
+  if (!st) die("cannot open stages file");
+  if (!freopen((out + ".sam").c_str(), "w", stdout)) die("cannot redirect stdout");
+
+  // ---- the set-up part of BwtMapper::PairEndMapper (src/BwtMapper.cpp:1811-1834)
+  bwase_initialize();
+  srand48(ix.bns->seed);
+  kh_64_t *hash = kh_init(64);
+  bwa_seqio_t *ks[2] = {bwa_seq_open(fq1), bwa_seq_open(fq2)};
+  bwt_t *bwt[2] = {ix.bwt_d, ix.rbwt_d};
+  bwa_seq_t *seqs[2];
+  for (int j = 0; j < 2; ++j) {
+    seqs[j] = (bwa_seq_t *)calloc(batch, sizeof(bwa_seq_t));
+    bwa_init_read_seq(batch, seqs[j], opt);
+  }
+  isize_info_t last_ii; last_ii.avg = -1.0;
+  ubyte_t *pacseq = 0;
+  bwa_print_sam_SQ(ix.bns);
+  bwa_print_sam_PG();
+
+  uint32_t round = 0;
+  long long n_pairs_total = 0, n_filtered = 0, n_unmapped = 0;
+  for (int b = 0;; ++b) {
+    int n_seqs[2] = {0, 0};
+    int r0 = bwa_read_seq_with_hash_dev(&ix, ks[0], batch, &n_seqs[0], opt->mode, opt->trim_qual, opt->frac, round, seqs[0], opt->read_len);
+    int r1 = bwa_read_seq_with_hash_dev(&ix, ks[1], batch, &n_seqs[1], opt->mode, opt->trim_qual, opt->frac, round, seqs[1], opt->read_len);
+    if (r0 == 0 || r1 == 0) break;
+    if (n_seqs[0] != n_seqs[1]) die("unequal mate counts");
+    const int n = n_seqs[0];
+    fprintf(st, "B %d %d\n", b, n);
+    for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < n; ++i)
+        fprintf(st, "F %d %d filt=%d len=%d clip=%d full=%d\n", j, i, seqs[j][i].filtered, seqs[j][i].len, seqs[j][i].clip_len, seqs[j][i].full_len);
+    // stage A (src/BwtMapper.cpp:1933-1952; one slice per end)
+    for (int j = 0; j < 2; ++j) bwa_cal_sa_reg_gap(0, bwt, n, seqs[j], opt, &ix);
+    for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < n; ++i) {
+        const bwa_seq_t *p = seqs[j] + i;
+        fprintf(st, "A %d %d n=%d", j, i, p->n_aln);
+        for (int k = 0; k < p->n_aln; ++k)
+          fprintf(st, " %d,%d,%d,%d,%u,%u,%d", p->aln[k].n_mm, p->aln[k].n_gapo, p->aln[k].n_gape, p->aln[k].a, p->aln[k].k, p->aln[k].l, p->aln[k].score);
+        fputc('\n', st);
+      }
+    // stage B (PEworker, src/BwtMapper.cpp:654-684)
+    isize_info_t ii;
+    bwa_cal_pac_pos_pe(bwt, n, seqs, &ii, popt, opt, &last_ii, hash);
+    dump_ii(st, &ii);
+    for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < n; ++i) dump_rec(st, 'P', j, i, seqs[j] + i, 0);
+    pacseq = bwa_paired_sw(ix.bns, pacseq ? pacseq : ix.pac_buf, n, seqs, popt, &ii, opt->mode);
+    for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < n; ++i) dump_rec(st, 'S', j, i, seqs[j] + i, 0);
+    for (int j = 0; j < 2; ++j) bwa_refine_gapped(ix.bns, n, seqs[j], pacseq, 0);
+    for (int j = 0; j < 2; ++j)
+      for (int i = 0; i < n; ++i) dump_rec(st, 'R', j, i, seqs[j] + i, 1);
+    last_ii = ii;
+    // consumer side of the --sam_out branch (src/BwtMapper.cpp:2026-2052) minus StatCollector
+    for (int i = 0; i < n; ++i) {
+      bwa_seq_t *p[2] = {seqs[0] + i, seqs[1] + i};
+      if (p[0]->filtered && p[1]->filtered) { ++n_filtered; continue; }
+      if (p[0]->type == BWA_TYPE_NO_MATCH && p[1]->type == BWA_TYPE_NO_MATCH) { ++n_unmapped; continue; }
+      bwa_print_sam1(ix.bns, p[0], p[1], opt->mode, opt->max_top2);
+      bwa_print_sam1(ix.bns, p[1], p[0], opt->mode, opt->max_top2);
+    }
+    n_pairs_total += n;
+    for (int j = 0; j < 2; ++j) bwa_clean_read_seq(n, seqs[j]);
+    ++round;
+  }
+  fprintf(st, "E pairs=%lld filtered=%lld unmapped=%lld\n", n_pairs_total, n_filtered, n_unmapped);
+  fclose(st);
+  fflush(stdout);
+  return 0;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 2) die("usage: fq_ref_driver index|align ...");
+  if (!strcmp(argv[1], "index")) return cmd_index(argc, argv);
+  if (!strcmp(argv[1], "align")) return cmd_align(argc, argv);
+  die("unknown command");
+  return 2;
+}
