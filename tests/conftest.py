@@ -1,0 +1,21 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+    config.addinivalue_line("markers", "refbuild: needs oracle/_ref (the reference compiled in the build container)")
+
+
+@pytest.fixture(scope="session")
+def golden_cases(tmp_path_factory):
+    """Materialise every tests/golden/<case> (index files + sparse bitmap list + FASTQ) once per session."""
+    import golden_util
+    base = tmp_path_factory.mktemp("golden")
+    return {tag: golden_util.materialise(tag, str(base / tag)) for tag in golden_util.case_tags()}

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Regenerate tests/golden/* with the REAL reference (oracle/_ref/fq_ref_driver).
+
+Only runs in the build container (needs /root/reference to have been compiled by
+`make -C oracle ref`).  Everything written is DATA: synthetic inputs (seeded, from
+fastquick_amd/synth.py), the index files the reference built for them, and the reference's
+per-stage dumps / SAM text for those inputs.  No reference source is stored.
+
+    python tests/golden/make_golden.py
+"""
+import gzip
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from fastquick_amd import synth  # noqa: E402
+import oracle_binding as ob  # noqa: E402
+
+CASES = {
+    # tag: (reference kwargs, read kwargs, n_pairs, batch, trim_qual)
+    "basic": (dict(n_markers=16, n_long=2, seed=101),
+              dict(on_target=0.85, seed=201, sub_rate=0.01, del_frac=0.06, ins_frac=0.05, n_rate=0.003,
+                   indel_len_max=2, chimera_frac=0.08), 400, 150, 0),
+    "repeat": (dict(n_markers=24, n_long=2, seed=102, repeat_every=2, tandem_every=6),
+               dict(on_target=0.95, seed=202, sub_rate=0.03, del_frac=0.08, ins_frac=0.07, n_rate=0.003,
+                    indel_len_max=3, chimera_frac=0.05), 400, 400, 0),
+    "trim76": (dict(n_markers=16, n_long=2, seed=103, repeat_every=3),
+               dict(read_len=76, on_target=0.9, seed=203, sub_rate=0.01, del_frac=0.1, ins_frac=0.1,
+                    indel_len_max=2, frag_mean=200, frag_sd=20, qual_decay=True), 300, 128, 15),
+    "isize": (dict(n_markers=12, n_long=2, seed=104),
+              dict(on_target=0.7, seed=204, chimera_frac=0.3), 130, 100, 0),
+    "nref": (dict(n_markers=12, n_long=1, seed=105, n_frac=0.002),
+             dict(on_target=0.9, seed=205, n_rate=0.01, chimera_frac=0.1, qual_decay=True), 200, 200, 15),
+}
+INDEX_EXT = [".bwt", ".rbwt", ".sa", ".rsa", ".pac", ".ann", ".amb"]
+
+
+def sparse_to_npz(path_sparse: str, path_npz: str) -> None:
+    arrs = {}
+    with open(path_sparse, "rb") as fh:
+        for t in range(6):
+            n = int(np.frombuffer(fh.read(8), dtype=np.uint64)[0])
+            bits = np.frombuffer(fh.read(4 * n), dtype=np.uint32)
+            arrs["t%d" % t] = np.diff(bits.astype(np.int64), prepend=0).astype(np.uint32)   # delta coded
+    np.savez_compressed(path_npz, **arrs)
+
+
+def main() -> None:
+    if not os.path.exists(ob.REF_DRIVER):
+        sys.exit("oracle/_ref/fq_ref_driver missing: run `make -C oracle ref` in the build container")
+    for tag, (refkw, readkw, n, batch, q) in CASES.items():
+        out = os.path.join(HERE, tag)
+        shutil.rmtree(out, ignore_errors=True)
+        os.makedirs(out)
+        with tempfile.TemporaryDirectory() as tmp:
+            ref = synth.make_reference(**refkw)
+            pre = os.path.join(tmp, "ref.FASTQuick.fa")
+            ref.write_fasta(pre)
+            subprocess.check_call([ob.REF_DRIVER, "index", pre], stderr=subprocess.DEVNULL, cwd=tmp)
+            rb = synth.make_reads(ref, n, **readkw)
+            f1, f2 = rb.write_fastq(os.path.join(tmp, "reads"))
+            args = ["--batch", batch] + (["--q", q] if q else [])
+            ob.run_reference(pre, f1, f2, os.path.join(tmp, "ref_out"), *args)
+            shutil.copy(pre, os.path.join(out, "ref.FASTQuick.fa"))
+            for ext in INDEX_EXT:
+                shutil.copy(pre + ext, os.path.join(out, "ref.FASTQuick.fa" + ext))
+            sparse_to_npz(pre + ".rollhash.sparse", os.path.join(out, "rollhash_bits.npz"))
+            for src, dst in ((f1, "reads_1.fq.gz"), (f2, "reads_2.fq.gz"),
+                             (os.path.join(tmp, "ref_out.stages"), "ref.stages.gz"),
+                             (os.path.join(tmp, "ref_out.sam"), "ref.sam.gz")):
+                with open(src, "rb") as fi, gzip.GzipFile(os.path.join(out, dst), "wb", mtime=0) as fo:
+                    fo.write(fi.read())
+            with open(os.path.join(out, "case.txt"), "w") as fh:
+                fh.write("n_pairs=%d\nbatch=%d\ntrim_qual=%d\nref=%r\nreads=%r\n" % (n, batch, q, refkw, readkw))
+        print(tag, "->", sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,51 @@
+"""Helpers that unpack the committed golden fixtures (tests/golden/<case>/) into a scratch dir."""
+from __future__ import annotations
+
+import gzip
+import os
+import shutil
+
+import numpy as np
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+INDEX_EXT = [".bwt", ".rbwt", ".sa", ".rsa", ".pac", ".ann", ".amb"]
+
+
+def case_tags():
+    return sorted(d for d in os.listdir(GOLD) if os.path.isdir(os.path.join(GOLD, d)) and not d.startswith("_"))
+
+
+def case_params(tag: str) -> dict:
+    out = {}
+    with open(os.path.join(GOLD, tag, "case.txt")) as fh:
+        for line in fh:
+            k, v = line.rstrip("\n").split("=", 1)
+            out[k] = int(v) if k in ("n_pairs", "batch", "trim_qual") else v
+    return out
+
+
+def write_sparse(npz_path: str, out_path: str) -> None:
+    z = np.load(npz_path)
+    with open(out_path, "wb") as fh:
+        for t in range(6):
+            bits = np.cumsum(z["t%d" % t].astype(np.int64)).astype(np.uint32)
+            fh.write(np.uint64(len(bits)).tobytes())
+            fh.write(bits.tobytes())
+
+
+def materialise(tag: str, dst: str) -> dict:
+    src = os.path.join(GOLD, tag)
+    os.makedirs(dst, exist_ok=True)
+    pre = os.path.join(dst, "ref.FASTQuick.fa")
+    shutil.copy(os.path.join(src, "ref.FASTQuick.fa"), pre)
+    for ext in INDEX_EXT:
+        shutil.copy(os.path.join(src, "ref.FASTQuick.fa" + ext), pre + ext)
+    write_sparse(os.path.join(src, "rollhash_bits.npz"), pre + ".rollhash.sparse")
+    paths = {}
+    for name in ("reads_1.fq", "reads_2.fq", "ref.stages", "ref.sam"):
+        with gzip.open(os.path.join(src, name + ".gz"), "rb") as fi, open(os.path.join(dst, name), "wb") as fo:
+            fo.write(fi.read())
+        paths[name] = os.path.join(dst, name)
+    p = case_params(tag)
+    p.update(prefix=pre, fq1=paths["reads_1.fq"], fq2=paths["reads_2.fq"], stages=paths["ref.stages"], sam=paths["ref.sam"], dir=dst)
+    return p
