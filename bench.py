@@ -1,0 +1,175 @@
+#!/usr/bin/env python3
+"""bench.py -- paired 150 bp reads aligned per second through the whole `align` hot path on MI355X.
+
+A "step" is one pass of the hot path (encode+trim+filter -> gap search -> SA -> pairing -> mate SW -> refine/MD ->
+records) over one batch of 262,144 synthetic read pairs (the reference's READ_BUFFER_SIZE, src/BwtMapper.h:36)
+against the 10k-marker reduced reference of BASELINE.json configs[1] (1000 long + 9000 short flanks, l_pac
+6,510,000).  Inputs are resident in HBM when the timed region starts (fq_batch_upload outside, fq_align_resident
+inside).  Multi-GPU: one process per GPU, reads shard by batch, no data-path collective ("weak" scaling); the only
+collectives are the barrier and the MAX over ranks of the elapsed time.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+K_NAMES = ("prep", "width", "gap", "sa", "sw", "refine")
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=262144, help="pairs per batch (reference READ_BUFFER_SIZE)")
+    ap.add_argument("--markers", type=int, default=10000)
+    ap.add_argument("--mix", choices=("wgs", "ontarget"), default="wgs",
+                    help="wgs: on-target fraction l_pac/3.1e9 (SURVEY 8d); ontarget: every pair from a marker flank")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="pairs for the CPU baseline (0 = auto)")
+    ap.add_argument("--workdir", default=os.environ.get("FQ_BENCH_DIR", "/tmp/fq_bench"))
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+
+    from fastquick_amd import api, synth
+
+    # ---- workload (seeded synthetic; built once per node by rank 0) ------------------------------------------
+    os.makedirs(args.workdir, exist_ok=True)
+    pre = os.path.join(args.workdir, "m%d.FASTQuick.fa" % args.markers)
+    n_long = args.markers // 10
+    ref = synth.make_reference(n_markers=args.markers, n_long=n_long, seed=12345)
+    if rank == 0 and not os.path.exists(pre + ".rsa"):
+        ref.write_fasta(pre)
+        api.build_index(pre)
+    if world > 1:
+        dist.barrier()
+    on_frac = 1.0 if args.mix == "ontarget" else ref.l_pac / 3.1e9
+    n_ctx = 2
+    batches = [synth.make_reads(ref, args.pairs, on_target=on_frac, seed=1000 + 17 * rank + b, name_offset=b * args.pairs)
+               for b in range(n_ctx)]
+    ix = api.Index(pre, device=local_rank)
+    ctxs = []
+    for b in range(n_ctx):
+        al = api.Aligner(ix, max_pairs=args.pairs)
+        al.upload(batches[b].seq, batches[b].qual, batches[b].lens, batches[b].names)   # inputs resident in HBM
+        ctxs.append(al)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        ctxs[i % n_ctx].align_resident()
+    for al in ctxs:
+        al.reset_stats()
+    sync_all()
+    t0 = time.perf_counter()
+    n_records = 0
+    for i in range(args.steps):
+        res = ctxs[i % n_ctx].align_resident()
+        n_records += res.n_survivors
+    sync_all()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- per-kernel device time (HIP events inside the library, on its own stream) + algorithmic work --------
+    agg = None
+    for al in ctxs:
+        s = al.stats()
+        if agg is None:
+            agg = s
+        else:
+            for k, v in s.items():
+                agg[k] = [a + b for a, b in zip(agg[k], v)] if isinstance(v, list) else agg[k] + v
+    kms = agg["kernel_ms"]
+    dom = max(range(len(K_NAMES)), key=lambda k: kms[k])
+    seq_bytes = float(sum(int(b.lens.sum()) for b in batches)) / n_ctx * args.steps
+    if K_NAMES[dom] == "prep":
+        alg_bytes = 64.0 * agg["filter_probes"] + seq_bytes + 9.0 * 2 * args.pairs * args.steps
+        model = "64 B x bitmap probes + read bytes + 9 B/read flags"
+    elif K_NAMES[dom] == "gap":
+        alg_bytes = 48.0 * agg["gap_occ_touches"]
+        model = "48 B x Occ block touches (reference block definition, SURVEY 8d)"
+    else:
+        alg_bytes = 48.0 * agg["occ_block_touches"]
+        model = "48 B x Occ block touches"
+    launches = max(1, int(agg["kernel_launches"][dom]))
+    avg_ms = kms[dom] / launches
+    achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    roofline = {"bound": "hbm", "kernel": "fq_" + K_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                "alg_bytes_per_launch": round(alg_bytes / launches, 1), "model": model}
+
+    total_pairs = args.pairs * args.steps * world
+    value = total_pairs / elapsed
+    out = {
+        "metric": "paired_150bp_reads_aligned_per_sec", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {"workload": "10k-marker reduced ref (l_pac %d), %d x 2x150bp pairs/batch, %s mix (on-target %.4f)"
+                   % (ref.l_pac, args.pairs, args.mix, on_frac), "pairs_per_step": args.pairs, "markers": args.markers, "mix": args.mix,
+                   "sharding": "batches per rank, no data-path collective"},
+        "roofline": roofline,
+        "kernel_ms_per_step": {K_NAMES[k]: round(kms[k] / args.steps, 4) for k in range(len(K_NAMES))},
+        "host_ms_per_step": round(agg["host_ms_total"] / args.steps, 3),
+        "survivor_pairs_per_step": round(n_records / args.steps, 1),
+        "work_per_step": {k: round(agg[k] / args.steps, 1) for k in ("filter_probes", "occ_block_touches", "gap_occ_touches", "stack_pops",
+                                                                     "stack_pushes", "sa_rows", "reads_searched", "sw_tasks", "refine_tasks", "tier_retries")},
+    }
+
+    # ---- CPU baseline: the oracle (a port) on a bounded sample of the same workload, rank 0, N=1 only -----------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_binding as ob
+        b = batches[0]
+        n_cpu = args.cpu_sample_pairs or (args.pairs if args.mix == "wgs" else 8192)
+        n_cpu = min(n_cpu, args.pairs)
+        oa = ob.OracleAligner(pre)
+        t1 = time.perf_counter()
+        oa.align(b.names[:n_cpu], b.seq[:, :n_cpu], b.qual[:, :n_cpu], b.lens[:, :n_cpu], None, None, batch=n_cpu)
+        dt = time.perf_counter() - t1
+        reps = 1
+        while dt < 10.0 and reps < 64 and args.mix == "wgs":    # aim for >= 10 s of CPU work
+            t1 = time.perf_counter()
+            oa.align(b.names[:n_cpu], b.seq[:, :n_cpu], b.qual[:, :n_cpu], b.lens[:, :n_cpu], None, None, batch=n_cpu)
+            dt += time.perf_counter() - t1
+            reps += 1
+        out["cpu_baseline"] = {"value": round(n_cpu * reps / dt, 1), "unit": "pairs/s", "cores": 1, "kind": "port",
+                               "sample": "%d x %d pairs of the same %s-mix batch through oracle/fq_oracle.c (single thread), %.1f s"
+                                         % (reps, n_cpu, args.mix, dt)}
+        oa.close()
+    if rank == 0:
+        print(json.dumps(out))
+    for al in ctxs:
+        al.close()
+    ix.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,266 @@
+"""ctypes binding of the C ABI in include/fastquick_amd.h (plumbing for tests and bench.py).
+
+The product library is fastquick_amd/libfastquick_amd.so (HIP, gfx950).  There is no CPU fallback:
+if the library is missing or no HIP device is usable, loading / fq_index_load raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+DEFAULT_LIB = os.path.join(HERE, "libfastquick_amd.so")
+
+FQ_K_NAMES = ("prep", "width", "gap", "sa", "sw", "refine")
+
+
+class Opts(C.Structure):
+    _fields_ = [
+        ("s_mm", C.c_int32), ("s_gapo", C.c_int32), ("s_gape", C.c_int32), ("mode", C.c_int32),
+        ("indel_end_skip", C.c_int32), ("max_del_occ", C.c_int32), ("max_entries", C.c_int32),
+        ("fnr", C.c_double), ("max_diff", C.c_int32), ("max_gapo", C.c_int32), ("max_gape", C.c_int32),
+        ("max_seed_diff", C.c_int32), ("seed_len", C.c_int32), ("max_top2", C.c_int32), ("trim_qual", C.c_int32),
+        ("filter_thresh", C.c_int32), ("max_isize", C.c_int32), ("force_isize", C.c_int32), ("max_occ", C.c_uint32),
+        ("n_multi", C.c_int32), ("N_multi", C.c_int32), ("is_sw", C.c_int32), ("ap_prior", C.c_double),
+        ("host_threads", C.c_int32),
+    ]
+
+
+class ReadBatch(C.Structure):
+    _fields_ = [("n_pairs", C.c_int32), ("stride", C.c_int32), ("seq", C.c_void_p), ("qual", C.c_void_p),
+                ("len", C.c_void_p), ("names", C.c_void_p), ("name_stride", C.c_int32)]
+
+
+class Multi(C.Structure):
+    _fields_ = [("pos", C.c_uint32), ("cigar_off", C.c_uint32), ("n_cigar", C.c_uint16), ("gap", C.c_uint8),
+                ("mm", C.c_uint8), ("strand", C.c_uint8), ("pad", C.c_uint8 * 3)]
+
+
+class Result(C.Structure):
+    _fields_ = [("pos", C.c_uint32), ("sa", C.c_uint32), ("c1", C.c_uint32), ("c2", C.c_uint32), ("score", C.c_int32),
+                ("len", C.c_int32), ("full_len", C.c_int32), ("clip_len", C.c_int32),
+                ("type", C.c_uint8), ("strand", C.c_uint8), ("filtered", C.c_uint8), ("extra_flag", C.c_uint8),
+                ("n_mm", C.c_uint8), ("n_gapo", C.c_uint8), ("n_gape", C.c_uint8), ("mapQ", C.c_uint8),
+                ("seQ", C.c_uint8), ("pad0", C.c_uint8), ("nm", C.c_uint16), ("n_cigar", C.c_uint16),
+                ("n_multi", C.c_uint16), ("cigar_off", C.c_uint32), ("md_off", C.c_uint32), ("multi_off", C.c_uint32)]
+
+
+class Isize(C.Structure):
+    _fields_ = [("avg", C.c_double), ("std", C.c_double), ("ap_prior", C.c_double), ("low", C.c_uint32),
+                ("high", C.c_uint32), ("high_bayesian", C.c_uint32), ("pad", C.c_uint32)]
+
+
+class ResultBatch(C.Structure):
+    _fields_ = [("n_pairs", C.c_int32), ("n_survivors", C.c_int32), ("n_both_filtered", C.c_int32),
+                ("n_both_unmapped", C.c_int32), ("pair_idx", C.POINTER(C.c_int32)), ("rec", C.POINTER(Result)),
+                ("cigar", C.POINTER(C.c_uint16)), ("md", C.c_void_p), ("multi", C.POINTER(Multi)),
+                ("isize", Isize), ("n_bases", C.c_int64)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("kernel_ms", C.c_double * 6), ("kernel_launches", C.c_uint64 * 6),
+                ("occ_block_touches", C.c_uint64), ("gap_occ_touches", C.c_uint64), ("filter_probes", C.c_uint64),
+                ("stack_pops", C.c_uint64), ("stack_pushes", C.c_uint64), ("sa_rows", C.c_uint64),
+                ("reads_searched", C.c_uint64), ("pairs", C.c_uint64), ("sw_tasks", C.c_uint64),
+                ("refine_tasks", C.c_uint64), ("tier_retries", C.c_uint64),
+                ("host_ms_serial", C.c_double), ("host_ms_pair", C.c_double), ("host_ms_total", C.c_double),
+                ("wall_ms_total", C.c_double)]
+
+
+EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destroy", "fq_index_l_pac",
+           "fq_index_n_contigs", "fq_index_contig", "fq_ctx_create", "fq_ctx_destroy", "fq_ctx_last_error",
+           "fq_ctx_set_debug", "fq_align_batch", "fq_batch_upload", "fq_align_resident", "fq_sam_header",
+           "fq_sam_format_last", "fq_stage_dump_last", "fq_stats_get", "fq_stats_reset", "fq_version"]
+
+_libs = {}
+
+
+class FastquickError(RuntimeError):
+    pass
+
+
+def load_library(path: str | None = None):
+    path = path or DEFAULT_LIB
+    if path in _libs:
+        return _libs[path]
+    if not os.path.exists(path):
+        raise FastquickError("%s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                             "(there is no CPU fallback)" % path)
+    L = C.CDLL(path)
+    L.fq_default_opts.argtypes = [C.POINTER(Opts)]
+    L.fq_index_build.argtypes = [C.c_char_p, C.c_int]
+    L.fq_index_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.fq_index_destroy.argtypes = [C.c_void_p]
+    L.fq_index_l_pac.restype = C.c_int64
+    L.fq_index_l_pac.argtypes = [C.c_void_p]
+    L.fq_index_n_contigs.argtypes = [C.c_void_p]
+    L.fq_ctx_create.argtypes = [C.c_void_p, C.POINTER(Opts), C.c_int32, C.POINTER(C.c_void_p)]
+    L.fq_ctx_destroy.argtypes = [C.c_void_p]
+    L.fq_ctx_last_error.restype = C.c_char_p
+    L.fq_ctx_last_error.argtypes = [C.c_void_p]
+    L.fq_ctx_set_debug.argtypes = [C.c_void_p, C.c_int]
+    L.fq_align_batch.argtypes = [C.c_void_p, C.POINTER(ReadBatch), C.POINTER(ResultBatch)]
+    L.fq_batch_upload.argtypes = [C.c_void_p, C.POINTER(ReadBatch)]
+    L.fq_align_resident.argtypes = [C.c_void_p, C.POINTER(ResultBatch)]
+    L.fq_sam_header.restype = C.c_int64
+    L.fq_sam_header.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.fq_sam_format_last.restype = C.c_int64
+    L.fq_sam_format_last.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.fq_stage_dump_last.restype = C.c_int64
+    L.fq_stage_dump_last.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.fq_stats_get.argtypes = [C.c_void_p, C.POINTER(Stats)]
+    L.fq_stats_reset.argtypes = [C.c_void_p]
+    L.fq_version.restype = C.c_char_p
+    _libs[path] = L
+    return L
+
+
+def default_opts(lib=None, **kw) -> Opts:
+    L = lib or load_library()
+    o = Opts()
+    L.fq_default_opts(C.byref(o))
+    for k, v in kw.items():
+        setattr(o, k, v)
+    return o
+
+
+def build_index(fasta_path: str, write_rollhash: bool = False, lib=None) -> None:
+    L = lib or load_library()
+    rc = L.fq_index_build(fasta_path.encode(), int(write_rollhash))
+    if rc:
+        raise FastquickError("fq_index_build(%s) failed: %d" % (fasta_path, rc))
+
+
+class Index:
+    def __init__(self, prefix: str, device: int = 0, lib=None):
+        self.L = lib or load_library()
+        h = C.c_void_p()
+        rc = self.L.fq_index_load(prefix.encode(), device, C.byref(h))
+        if rc:
+            raise FastquickError("fq_index_load(%s) failed: %d (no usable HIP device?)" % (prefix, rc))
+        self.h = h
+        self.prefix = prefix
+
+    @property
+    def l_pac(self) -> int:
+        return int(self.L.fq_index_l_pac(self.h))
+
+    def sam_header(self) -> bytes:
+        n = self.L.fq_sam_header(self.h, None, 0)
+        buf = C.create_string_buffer(n + 1)
+        self.L.fq_sam_header(self.h, buf, n + 1)
+        return buf.raw[:n]
+
+    def close(self):
+        if self.h:
+            self.L.fq_index_destroy(self.h)
+            self.h = None
+
+
+def pack_names(names, stride: int = 64) -> np.ndarray:
+    buf = np.zeros((len(names), stride), dtype=np.uint8)
+    for i, nm in enumerate(names):
+        nm = nm[:stride - 1]
+        buf[i, :len(nm)] = np.frombuffer(nm, dtype=np.uint8)
+    return buf
+
+
+class Aligner:
+    """One alignment context == one FASTQ pair stream of the reference (drand48 / last_ii / cache carry over)."""
+
+    def __init__(self, index: Index, opts: Opts | None = None, max_pairs: int = 262144, debug: bool = False):
+        self.L = index.L
+        self.index = index
+        self.opts = opts or default_opts(self.L)
+        h = C.c_void_p()
+        rc = self.L.fq_ctx_create(index.h, C.byref(self.opts), max_pairs, C.byref(h))
+        if rc:
+            raise FastquickError("fq_ctx_create failed: %d" % rc)
+        self.h = h
+        if debug:
+            self.L.fq_ctx_set_debug(self.h, 1)
+        self._keep = None
+        self.result = ResultBatch()
+
+    def _batch(self, seq, qual, lens, names):
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        qual = np.ascontiguousarray(qual, dtype=np.uint8)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        nm = pack_names(names) if names is not None else None
+        b = ReadBatch(seq.shape[1], seq.shape[2], seq.ctypes.data, qual.ctypes.data, lens.ctypes.data,
+                      nm.ctypes.data if nm is not None else None, 64)
+        self._keep = (seq, qual, lens, nm, b)   # the library reads these until the next call
+        return b
+
+    def _check(self, rc, what):
+        if rc:
+            raise FastquickError("%s failed: %d (%s)" % (what, rc, self.L.fq_ctx_last_error(self.h).decode()))
+
+    def align(self, seq, qual, lens, names=None) -> ResultBatch:
+        b = self._batch(seq, qual, lens, names)
+        self._check(self.L.fq_align_batch(self.h, C.byref(b), C.byref(self.result)), "fq_align_batch")
+        return self.result
+
+    def upload(self, seq, qual, lens, names=None) -> None:
+        b = self._batch(seq, qual, lens, names)
+        self._check(self.L.fq_batch_upload(self.h, C.byref(b)), "fq_batch_upload")
+
+    def align_resident(self) -> ResultBatch:
+        self._check(self.L.fq_align_resident(self.h, C.byref(self.result)), "fq_align_resident")
+        return self.result
+
+    def _text(self, fn) -> bytes:
+        n = fn(self.h, None, 0)
+        if n < 0:
+            raise FastquickError("formatter failed: %d" % n)
+        buf = C.create_string_buffer(n + 1)
+        fn(self.h, buf, n + 1)
+        return buf.raw[:n]
+
+    def sam_text(self) -> bytes:
+        return self._text(self.L.fq_sam_format_last)
+
+    def stage_text(self) -> bytes:
+        return self._text(self.L.fq_stage_dump_last)
+
+    def stats(self) -> dict:
+        s = Stats()
+        self.L.fq_stats_get(self.h, C.byref(s))
+        d = {}
+        for name, _ in Stats._fields_:
+            v = getattr(s, name)
+            d[name] = list(v) if hasattr(v, "__len__") else v
+        return d
+
+    def reset_stats(self):
+        self.L.fq_stats_reset(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.fq_ctx_destroy(self.h)
+            self.h = None
+
+
+def align_stream(aligner: Aligner, names, seq, qual, lens, batch: int, stages_path=None, sam_path=None, header=True) -> int:
+    """Feed n pairs in batches of `batch` (mirrors PairEndMapper's loop); returns pairs with SAM records."""
+    n = seq.shape[1]
+    st = open(stages_path, "wb") if stages_path else None
+    sm = open(sam_path, "wb") if sam_path else None
+    if sm and header:
+        sm.write(aligner.index.sam_header())
+    total = 0
+    for b0 in range(0, n, batch):
+        b1 = min(n, b0 + batch)
+        res = aligner.align(seq[:, b0:b1], qual[:, b0:b1], lens[:, b0:b1], names[b0:b1])
+        total += res.n_survivors - res.n_both_unmapped
+        if st:
+            st.write(aligner.stage_text())
+        if sm:
+            sm.write(aligner.sam_text())
+    if st:
+        st.close()
+    if sm:
+        sm.close()
+    return total

@@ -1,0 +1,930 @@
+// fq_align.cpp -- host side of the per-batch hot path: stages the GPU kernels and carries the
+// order-dependent state exactly as BwtMapper::PairEndMapper / PEworker do
+// (src/BwtMapper.cpp:654-684, 1796-2104):
+//   * the glibc drand48 stream consumed by bwa_aln2seq_core (libbwa/bwase.c:19-95), seeded
+//     srand48(bns->seed) once per FASTQ pair (:1817)                                  [SURVEY Q2]
+//   * per-batch insert-size inference with the last_ii fallback (bwape.c:49-117, :780) [Q3]
+//   * the (k,l) -> positions cache for SA intervals >= 1000 wide (:815-843)            [Q6]
+// Everything data-parallel (filter, widths, gap search, SA walks, SW, global DP, MD) runs on the
+// GPU through fq_backend.h; libm-dependent scalar decisions stay on the host (Q4/Q5).
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "../../include/fastquick_amd.h"
+#include "fq_backend.h"
+#include "fq_index.h"
+#include "fq_pipeline.h"
+
+using std::vector;
+
+namespace {
+double now_ms() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+// bwa_cal_maxdiff, libbwa/bwtaln.c:58-70 (the int factorial wraps as in the reference)
+int cal_maxdiff(int l, double err, double thres) {
+  double elambda = exp(-l * err), sum = elambda, y = 1.0;
+  int x = 1;
+  for (int k = 1; k < 1000; ++k) {
+    y *= l * err;
+    x = (int)((unsigned)x * (unsigned)k);
+    sum += elambda * y / x;
+    if (1.0 - sum < thres) return k;
+  }
+  return 2;
+}
+inline uint64_t hash_64(uint64_t key) {   // libbwa/bwape.h:42-53
+  key += ~(key << 32); key ^= (key >> 22); key += ~(key << 13); key ^= (key >> 8);
+  key += (key << 3); key ^= (key >> 15); key += ~(key << 27); key ^= (key >> 31);
+  return key;
+}
+template <class T> struct DevBuf {
+  T *p = nullptr;
+  size_t cap = 0;
+  ~DevBuf() { fqdev::dfree(p); }
+  bool ensure(size_t n) {
+    if (n <= cap) return true;
+    fqdev::dfree(p);
+    cap = n + n / 4 + 64;
+    p = (T *)fqdev::dmalloc(cap * sizeof(T));
+    if (!p) { cap = 0; return false; }
+    return true;
+  }
+};
+}  // namespace
+
+struct fq_ctx {
+  const fq_index *ix = nullptr;
+  fq_opts_t o{};
+  FqKOpts ko{};
+  int max_pairs = 0;
+  int debug = 0;
+  std::string err;
+  // order-dependent state
+  uint64_t rng = 0;
+  fq_isize_t last_ii{};
+  std::unordered_map<uint64_t, vector<uint32_t>> kl_cache;
+  int g_log_n[256];
+  uint8_t maxdiff_lut[FQ_LMAX + 2];
+  // device-resident batch
+  int n_pairs = 0, stride = 0;
+  const fq_read_batch_t *host_batch_valid = nullptr;
+  fq_read_batch_t hb{};
+  DevBuf<uint8_t> d_seq, d_qual, d_filtered, d_maxdiff;
+  DevBuf<int32_t> d_len, d_len_trim, d_namb, d_read_list, d_sidx, d_pair_list, d_counts;
+  DevBuf<uint64_t> d_counters;
+  // search workspaces
+  DevBuf<int32_t> d_work;
+  DevBuf<uint32_t> d_wid_w, d_sw_w, d_heads, d_naln, d_status;
+  DevBuf<uint8_t> d_wid_bid, d_sw_bid;
+  DevBuf<FqEntry> d_pool;
+  DevBuf<FqAln> d_aln, d_packed;
+  DevBuf<uint64_t> d_off;
+  // SA
+  DevBuf<FqAln> d_qaln;
+  DevBuf<uint32_t> d_qlen, d_pos, d_qrow, d_qinfo;
+  DevBuf<uint64_t> d_qoff;
+  // DP
+  DevBuf<FqSwTask> d_swtask;
+  DevBuf<FqSwOut> d_swout;
+  DevBuf<FqRefTask> d_reftask;
+  DevBuf<FqRefOut> d_refout;
+  DevBuf<uint16_t> d_cig, d_cigarena;
+  DevBuf<uint8_t> d_scratch;
+  DevBuf<FqMdTask> d_mdtask;
+  DevBuf<char> d_md, d_mdpacked;
+  DevBuf<int32_t> d_mdlen, d_nm;
+  DevBuf<uint32_t> d_mdsz;
+  // host staging
+  vector<uint8_t> h_filtered;
+  vector<int32_t> h_len_trim, h_pair_list, h_read_list, h_sidx_surv;
+  // results of the last batch
+  FqBatchState st;
+  fq_stats_t stats{};
+};
+
+// ---- drand48 (glibc): X' = (0x5DEECE66D X + 0xB) mod 2^48, value X'/2^48 ------------------------------
+static inline double rng_next(fq_ctx *c) {
+  c->rng = (0x5DEECE66DULL * c->rng + 0xBULL) & 0xFFFFFFFFFFFFULL;
+  return (double)c->rng * (1.0 / 281474976710656.0);
+}
+
+extern "C" void fq_default_opts(fq_opts_t *o) {
+  memset(o, 0, sizeof *o);
+  o->s_mm = 3; o->s_gapo = 11; o->s_gape = 4;
+  o->mode = FQ_MODE_GAPE | FQ_MODE_COMPREAD;
+  o->indel_end_skip = 5; o->max_del_occ = 10; o->max_entries = 2000000;
+  o->fnr = 0.02; o->max_diff = -1; o->max_gapo = 1; o->max_gape = 6;
+  o->max_seed_diff = 2; o->seed_len = 32; o->max_top2 = 30; o->trim_qual = 0; o->filter_thresh = 3;
+  o->max_isize = 500; o->force_isize = 0; o->max_occ = 100000; o->n_multi = 3; o->N_multi = 10; o->is_sw = 1;
+  o->ap_prior = 1e-5; o->host_threads = 0;
+}
+
+extern "C" const char *fq_version(void) { return "fastquick_amd 0.1 (gfx950)"; }
+extern "C" const char *fq_ctx_last_error(const fq_ctx_t *c) { return c ? c->err.c_str() : "null context"; }
+
+extern "C" int fq_ctx_create(const fq_index_t *ix, const fq_opts_t *opts, int32_t max_pairs, fq_ctx_t **out) {
+  if (!ix || !opts || !out || max_pairs <= 0) return FQ_EINVAL;
+  *out = nullptr;
+  const fq_opts_t &o = *opts;
+  // limits imposed by the 32-bit entry packing / 128 score buckets (fq_common.h)
+  if (o.max_gapo < 0 || o.max_gapo > 3 || o.max_gape < 0 || o.max_gape > 15 || o.seed_len < 1 || o.seed_len > FQ_SEED_MAX) return FQ_EINVAL;
+  if (o.s_mm <= 0 || o.s_gapo <= 0 || o.s_gape <= 0) return FQ_EINVAL;   // children must score strictly more than parents (Q1)
+  if (o.fnr <= 0.0 && (o.max_diff < 0 || o.max_diff > 30)) return FQ_EINVAL;
+  std::unique_ptr<fq_ctx> c(new fq_ctx);
+  c->ix = ix; c->o = o; c->max_pairs = max_pairs;
+  int md_max = 0;
+  for (int l = 0; l <= FQ_LMAX; ++l) {
+    int md = o.fnr > 0.0 ? cal_maxdiff(l, 0.02, o.fnr) : o.max_diff;
+    if (md > 30) return FQ_EINVAL;
+    c->maxdiff_lut[l] = (uint8_t)md;
+    md_max = std::max(md_max, md);
+  }
+  if ((md_max + 1) * o.s_mm + o.max_gapo * o.s_gapo + o.max_gape * o.s_gape >= FQ_MAX_BUCKETS) return FQ_EINVAL;
+  if (o.max_gapo > c->maxdiff_lut[35]) return FQ_EINVAL;   // the per-slice max_gapo clamp (BwtMapper.cpp:80) must be a no-op
+  c->g_log_n[0] = 0;
+  for (int i = 1; i < 256; ++i) c->g_log_n[i] = (int)(4.343 * log(i) + 0.5);   // bwase_initialize, bwase.c:602
+  c->rng = ((uint64_t)ix->seed << 16) | 0x330EULL;                             // srand48(bns->seed)
+  c->last_ii.avg = -1.0;
+  FqKOpts &k = c->ko;
+  k.s_mm = o.s_mm; k.s_gapo = o.s_gapo; k.s_gape = o.s_gape; k.mode = o.mode;
+  k.indel_end_skip = o.indel_end_skip; k.max_del_occ = o.max_del_occ; k.max_entries = o.max_entries;
+  k.max_gapo = o.max_gapo; k.max_gape = o.max_gape; k.max_seed_diff = o.max_seed_diff; k.seed_len = o.seed_len;
+  k.max_top2 = o.max_top2; k.trim_qual = o.trim_qual; k.filter_thresh = o.filter_thresh; k.n_buckets = FQ_MAX_BUCKETS;
+  if (fqdev::init(ix->device)) { return FQ_ENODEV; }
+  if (!c->d_maxdiff.ensure(FQ_LMAX + 2) || !c->d_counters.ensure(FQ_C_COUNT) || !c->d_counts.ensure(4)) return FQ_ENOMEM;
+  if (fqdev::h2d(c->d_maxdiff.p, c->maxdiff_lut, FQ_LMAX + 2) || fqdev::dzero(c->d_counters.p, FQ_C_COUNT * 8) || fqdev::sync()) return FQ_ENODEV;
+  *out = c.release();
+  return FQ_OK;
+}
+extern "C" void fq_ctx_destroy(fq_ctx_t *c) { delete c; }
+
+extern "C" void fq_stats_get(const fq_ctx_t *c, fq_stats_t *out) { if (c && out) *out = c->stats; }
+extern "C" void fq_stats_reset(fq_ctx_t *c) { if (c) memset(&c->stats, 0, sizeof c->stats); }
+
+#define CK(expr)                                                  \
+  do {                                                            \
+    if ((expr)) { c->err = std::string(#expr) + ": " + fqdev::last_error(); return FQ_ENODEV; } \
+  } while (0)
+#define CKM(expr)                                                 \
+  do {                                                            \
+    if (!(expr)) { c->err = std::string("out of device memory: ") + #expr; return FQ_ENOMEM; } \
+  } while (0)
+
+extern "C" int fq_batch_upload(fq_ctx_t *c, const fq_read_batch_t *in) {
+  if (!c || !in || in->n_pairs < 0 || !in->seq || !in->qual || !in->len) return FQ_EINVAL;
+  if (in->n_pairs > c->max_pairs) { c->err = "batch larger than max_pairs_per_batch"; return FQ_ELIMIT; }
+  if (in->stride < 1 || in->stride > 4096) return FQ_EINVAL;
+  const size_t n2 = (size_t)in->n_pairs * 2;
+  for (size_t i = 0; i < n2; ++i)
+    if (in->len[i] < 35 || in->len[i] > FQ_LMAX || in->len[i] > in->stride) { c->err = "read length outside [35," + std::to_string(FQ_LMAX) + "]"; return FQ_ELIMIT; }
+  CKM(c->d_seq.ensure(n2 * in->stride + 64));
+  CKM(c->d_qual.ensure(n2 * in->stride + 64));
+  CKM(c->d_len.ensure(n2 + 1));
+  CK(fqdev::h2d(c->d_seq.p, in->seq, n2 * in->stride));
+  CK(fqdev::h2d(c->d_qual.p, in->qual, n2 * in->stride));
+  CK(fqdev::h2d(c->d_len.p, in->len, n2 * 4));
+  CK(fqdev::sync());
+  c->n_pairs = in->n_pairs;
+  c->stride = in->stride;
+  c->hb = *in;
+  return FQ_OK;
+}
+
+extern "C" int fq_align_batch(fq_ctx_t *c, const fq_read_batch_t *in, fq_result_batch_t *out) {
+  int rc = fq_batch_upload(c, in);
+  if (rc) return rc;
+  return fq_align_resident(c, out);
+}
+
+// ---- host-side scalar stages ----------------------------------------------------------------------------
+namespace {
+
+// bwa_aln2seq_core, libbwa/bwase.c:19-95
+void choose_hit(fq_ctx *c, int n_aln, const FqAln *aln, FqRead &s, bool set_main, int n_multi) {
+  if (n_aln == 0) { s.type = FQ_TYPE_NO_MATCH; s.c1 = s.c2 = 0; return; }
+  if (set_main) {
+    const int best = aln[0].score;
+    int i;
+    uint32_t cnt = 0;
+    for (i = 0; i < n_aln; ++i) {
+      const FqAln &p = aln[i];
+      if (p.score > best) break;
+      const uint32_t wdt = p.l - p.k + 1;
+      if (rng_next(c) * (double)(uint32_t)(wdt + cnt) > (double)(int)cnt) {
+        s.n_mm = p.info & 0xff; s.n_gapo = (p.info >> 8) & 0xff; s.n_gape = (p.info >> 16) & 0xff; s.strand = (p.info >> 24) & 1;
+        s.score = p.score;
+        s.sa = p.k + (uint32_t)((double)wdt * rng_next(c));
+        s.main_aln = i;
+      }
+      cnt += wdt;
+    }
+    s.c1 = cnt & 0xfffffff;
+    for (; i < n_aln; ++i) cnt += aln[i].l - aln[i].k + 1;
+    s.c2 = (cnt - s.c1) & 0xfffffff;
+    s.type = s.c1 > 1 ? FQ_TYPE_REPEAT : FQ_TYPE_UNIQUE;
+  }
+  if (n_multi) {
+    int n_occ = 0;
+    for (int k = 0; k < n_aln; ++k) n_occ += (int)(aln[k].l - aln[k].k + 1);
+    s.multi.clear();
+    if (n_occ > n_multi + 1) return;
+    for (int k = 0; k < n_aln; ++k) {
+      const FqAln &q = aln[k];
+      const uint32_t wdt = q.l - q.k + 1;
+      for (uint32_t t = 0; t < wdt; ++t) {
+        FqMulti m;
+        m.pos = q.k + t; m.gap = (int)((q.info >> 8) & 0xff) + (int)((q.info >> 16) & 0xff); m.mm = (int)(q.info & 0xff);
+        m.strand = (int)(q.info >> 24) & 1; m.aln = k; m.row_in_aln = t;
+        s.multi.push_back(m);
+      }
+    }
+    size_t keep = 0;
+    for (size_t k = 0; k < s.multi.size(); ++k) if (s.multi[k].pos != s.sa) s.multi[keep++] = s.multi[k];
+    s.multi.resize(std::min(keep, (size_t)n_multi));
+  }
+}
+
+int approx_mapq(const fq_ctx *c, const FqRead &p, int mm) {   // bwa_approx_mapQ, bwase.c:102-111
+  if (p.c1 == 0) return 23;
+  if (p.c1 > 1) return 0;
+  if (p.n_mm == mm) return 25;
+  if (p.c2 == 0) return 37;
+  const int n = p.c2 >= 255 ? 255 : (int)p.c2;
+  return 23 < c->g_log_n[n] ? 0 : 23 - c->g_log_n[n];
+}
+
+// infer_isize, libbwa/bwape.c:49-117
+void infer_isize(const vector<FqRead> &R, int n_surv, int max_len_all, fq_isize_t *ii, double ap_prior, int64_t L) {
+  ii->avg = ii->std = -1.0; ii->low = ii->high = ii->high_bayesian = 0; ii->ap_prior = 0;
+  vector<uint64_t> is;
+  for (int s = 0; s < n_surv; ++s) {
+    const FqRead &a = R[2 * s], &b = R[2 * s + 1];
+    if (a.mapQ >= 20 && b.mapQ >= 20) {
+      const uint64_t x = a.pos < b.pos ? (uint64_t)(uint32_t)(b.pos + (uint32_t)b.len - a.pos) : (uint64_t)(uint32_t)(a.pos + (uint32_t)a.len - b.pos);
+      if (x < 100000) is.push_back(x);
+    }
+  }
+  const int tot = (int)is.size();
+  int max_len = std::max(1, max_len_all);
+  if (tot < 20) return;
+  std::sort(is.begin(), is.end());
+  const int p25 = (int)is[(int)(tot * 0.25 + 0.5)], p75 = (int)is[(int)(tot * 0.75 + 0.5)];
+  const int tmp = (int)(p25 - 2.0 * (p75 - p25) + .499);
+  ii->low = (uint32_t)(tmp > max_len ? tmp : max_len);
+  ii->high = (uint32_t)(int)(p75 + 2.0 * (p75 - p25) + .499);
+  uint64_t x = 0;
+  int n = 0;
+  for (int i = 0; i < tot; ++i) if (is[i] >= ii->low && is[i] <= ii->high) { ++n; x += is[i]; }
+  ii->avg = (double)x / n;
+  for (int i = 0; i < tot; ++i)
+    if (is[i] >= ii->low && is[i] <= ii->high) { const double t = (is[i] - ii->avg) * (is[i] - ii->avg); ii->std += t; }   // sum starts at -1.0 as in the reference
+  ii->std = sqrt(ii->std / n);
+  double y;
+  for (y = 1.0; y < 10.0; y += 0.01) if (.5 * erfc(y / M_SQRT2) < ap_prior / L * (y * ii->std + ii->avg)) break;
+  ii->high_bayesian = (uint32_t)(y * ii->std + ii->avg + .499);
+  uint64_t n_ap = 0;
+  for (int i = 0; i < tot; ++i) if (is[i] > ii->high_bayesian) ++n_ap;
+  ii->ap_prior = .01 * (n_ap + .01) / tot;
+  if (ii->ap_prior < ap_prior) ii->ap_prior = ap_prior;
+  if (std::isnan(ii->std) || p75 > 100000) { ii->low = ii->high = ii->high_bayesian = 0; ii->avg = ii->std = -1.0; }
+}
+
+// pairing + __pairing_aux/__pairing_aux2, libbwa/bwape.c:119-213, bwape.h:55-82 (typo at :65 reproduced)
+struct PairAcc { uint64_t o_score, subo_score, o_pos[2]; int o_n, subo_n; };
+inline void pair_try(const fq_ctx *c, FqRead *p[2], const FqAln *aln[2], const fq_isize_t *ii, int max_len, uint64_t u, uint64_t v, PairAcc &A) {
+  if (u == (uint64_t)-1) return;
+  const uint32_t l = (uint32_t)(v >> 32) + (uint32_t)p[v & 1]->len - (uint32_t)(u >> 32);
+  if (!((v >> 32) > (u >> 32) && l >= (uint32_t)max_len &&
+        ((ii->high && l <= ii->high_bayesian) || (ii->high == 0 && l <= (uint32_t)c->o.max_isize)))) return;
+  uint64_t s = (uint64_t)(int64_t)(aln[v & 1][(uint32_t)v >> 1].score + aln[u & 1][(uint32_t)u >> 1].score);
+  s *= 10;
+  if (ii->high) s += (uint64_t)(int64_t)(int)(-4.343 * log(0.5 * erfc(M_SQRT1_2 * fabs(l - ii->avg) / ii->std)) + 0.499);
+  s = s << 32 | (uint32_t)hash_64((u >> 32 << 32) | (v >> 32));
+  if (s >> 32 == A.o_score >> 32) ++A.o_n;
+  else if (s >> 32 < A.o_score << 32) { A.subo_n += A.o_n; A.o_n = 1; }
+  else ++A.subo_n;
+  if (s < A.o_score) { A.subo_score = A.o_score; A.o_score = s; A.o_pos[u & 1] = u; A.o_pos[v & 1] = v; }
+  else if (s < A.subo_score) A.subo_score = s;
+}
+inline void pair_fix(FqRead &q, const FqAln *aln[2], uint64_t w) {
+  const FqAln &r = aln[w & 1][(uint32_t)w >> 1];
+  const int ra = (int)(r.info >> 24) & 1;
+  q.extra_flag |= 2;
+  if (q.pos != (uint32_t)(w >> 32) || q.strand != ra) {
+    q.n_mm = r.info & 0xff; q.n_gapo = (r.info >> 8) & 0xff; q.n_gape = (r.info >> 16) & 0xff; q.strand = ra; q.score = r.score;
+    q.pos = (uint32_t)(w >> 32);
+  }
+}
+void pair_hits(const fq_ctx *c, FqRead *p[2], const FqAln *aln[2], vector<uint64_t> &arr, const fq_isize_t *ii) {
+  PairAcc A;
+  A.o_score = A.subo_score = (uint64_t)-1; A.o_n = A.subo_n = 0; A.o_pos[0] = A.o_pos[1] = 0;
+  uint64_t last[2][2] = {{(uint64_t)-1, (uint64_t)-1}, {(uint64_t)-1, (uint64_t)-1}};
+  const int max_len = std::max(p[0]->full_len, p[1]->full_len);
+  std::sort(arr.begin(), arr.end());
+  for (uint64_t x : arr) {
+    if (((aln[x & 1][(uint32_t)x >> 1].info >> 24) & 1) == 1) {
+      const int y = 1 - (int)(x & 1);
+      pair_try(c, p, aln, ii, max_len, last[y][1], x, A);
+      pair_try(c, p, aln, ii, max_len, last[y][0], x, A);
+    } else { last[x & 1][0] = last[x & 1][1]; last[x & 1][1] = x; }
+  }
+  if (A.o_score == (uint64_t)-1) return;
+  int mapQ_p = 0;
+  if (A.o_n == 1) {
+    if (A.subo_score == (uint64_t)-1) mapQ_p = 29;
+    else if ((A.subo_score >> 32) - (A.o_score >> 32) > (uint64_t)(c->o.s_mm * 10)) mapQ_p = 23;
+    else {
+      const int nn = A.subo_n > 255 ? 255 : A.subo_n;
+      mapQ_p = (int)(((A.subo_score >> 32) - (A.o_score >> 32)) / 2) - c->g_log_n[nn];
+      if (mapQ_p < 0) mapQ_p = 0;
+    }
+  }
+  const int rr0 = (int)(aln[A.o_pos[0] & 1][(uint32_t)A.o_pos[0] >> 1].info >> 24) & 1, rr1 = (int)(aln[A.o_pos[1] & 1][(uint32_t)A.o_pos[1] >> 1].info >> 24) & 1;
+  const bool same0 = p[0]->pos == (uint32_t)(A.o_pos[0] >> 32) && p[0]->strand == rr0;
+  const bool same1 = p[1]->pos == (uint32_t)(A.o_pos[1] >> 32) && p[1]->strand == rr1;
+  if (same0 && same1) {
+    if (p[0]->mapQ > 0 && p[1]->mapQ > 0) {
+      int mq = p[0]->mapQ + p[1]->mapQ;
+      if (mq > 60) mq = 60;
+      p[0]->mapQ = p[1]->mapQ = mq;
+    } else {
+      if (p[0]->mapQ == 0) p[0]->mapQ = mapQ_p + 7 < p[1]->mapQ ? mapQ_p + 7 : p[1]->mapQ;
+      if (p[1]->mapQ == 0) p[1]->mapQ = mapQ_p + 7 < p[0]->mapQ ? mapQ_p + 7 : p[0]->mapQ;
+    }
+  } else if (same0) { p[1]->seQ = 0; p[1]->mapQ = p[0]->mapQ; if (p[1]->mapQ > mapQ_p) p[1]->mapQ = mapQ_p; }
+  else if (same1) { p[0]->seQ = 0; p[0]->mapQ = p[1]->mapQ; if (p[0]->mapQ > mapQ_p) p[0]->mapQ = mapQ_p; }
+  else { p[0]->seQ = p[1]->seQ = 0; mapQ_p -= 20; if (mapQ_p < 0) mapQ_p = 0; p[0]->mapQ = p[1]->mapQ = mapQ_p; }
+  pair_fix(*p[0], aln, A.o_pos[0]);
+  pair_fix(*p[1], aln, A.o_pos[1]);
+}
+
+}  // namespace
+
+// ---- the batch ------------------------------------------------------------------------------------------
+extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
+  if (!c || !out) return FQ_EINVAL;
+  const double t_wall0 = now_ms();
+  const fq_index *ix = c->ix;
+  const fq_opts_t &o = c->o;
+  const int n = c->n_pairs, n2 = 2 * n, stride = c->stride;
+  FqBatchState &S = c->st;
+  S.clear();
+  S.n_pairs = n;
+  memset(out, 0, sizeof *out);
+  out->n_pairs = n;
+  if (n == 0) return FQ_OK;
+
+  // ---- stage 0: encode + trim + filter + ordered compaction (GPU) -------------------------------------
+  CKM(c->d_len_trim.ensure(n2) && c->d_filtered.ensure(n2 + 64) && c->d_namb.ensure(n2) && c->d_read_list.ensure(n2) &&
+      c->d_sidx.ensure(n2) && c->d_pair_list.ensure(n));
+  {
+    FqPrepArgs a{};
+    a.ix = ix->dev; a.o = c->ko; a.seq = c->d_seq.p; a.qual = c->d_qual.p; a.len = c->d_len.p; a.stride = stride; a.n_reads = n2;
+    a.len_trim = c->d_len_trim.p; a.filtered = c->d_filtered.p; a.n_amb = c->d_namb.p; a.counters = c->d_counters.p;
+    fqdev::time_begin(FQ_K_PREP);
+    CK(fqdev::launch_prep(a));
+    CK(fqdev::launch_compact(c->d_filtered.p, n, c->d_read_list.p, c->d_sidx.p, c->d_pair_list.p, c->d_counts.p));
+    fqdev::time_end(FQ_K_PREP);
+  }
+  int32_t counts[2] = {0, 0};
+  c->h_filtered.resize(n2);
+  c->h_len_trim.resize(n2);
+  CK(fqdev::d2h(counts, c->d_counts.p, 8));
+  CK(fqdev::d2h(c->h_filtered.data(), c->d_filtered.p, n2));
+  CK(fqdev::d2h(c->h_len_trim.data(), c->d_len_trim.p, (size_t)n2 * 4));
+  CK(fqdev::sync());
+  const int n_search = counts[0], n_surv = counts[1];
+  c->h_pair_list.resize(n_surv);
+  c->h_read_list.resize(n_search);
+  CK(fqdev::d2h(c->h_pair_list.data(), c->d_pair_list.p, (size_t)n_surv * 4));
+  CK(fqdev::d2h(c->h_read_list.data(), c->d_read_list.p, (size_t)n_search * 4));
+  CK(fqdev::sync());
+  int64_t n_bases = 0;
+  int max_len_all = 1;
+  for (int r = 0; r < n2; ++r) { n_bases += c->hb.len[r]; if (c->h_len_trim[r] > max_len_all) max_len_all = c->h_len_trim[r]; }
+  S.n_surv = n_surv;
+  S.pair_idx = c->h_pair_list;
+
+  // ---- stage A: widths + gap search, tiered by stack-pool size (GPU) ----------------------------------
+  // h_aln: concatenated hit lists; per search index s: [aln_off[s], aln_off[s]+aln_n[s])
+  vector<FqAln> &h_aln = S.aln;
+  vector<uint64_t> aln_off(n_search + 1, 0);
+  vector<uint32_t> aln_n(n_search, 0);
+  {
+    const int Lpad = max_len_all + 1;
+    const FqGapTier tiers[3] = {{1024u, 16u, 0}, {32768u, 512u, 0}, {(uint32_t)o.max_entries + 64u, 8192u, 1}};
+    const size_t chunk_reads[3] = {(size_t)1 << 20, 8192, 64};
+    vector<int32_t> work(n_search), next_work;
+    for (int s = 0; s < n_search; ++s) work[s] = s;
+    vector<uint32_t> h_status, h_naln;
+    vector<FqAln> h_packed;
+    // tier 0 results are appended in s order directly
+    vector<int64_t> where(n_search, -1);   // offset of s's list in h_aln (filled as results arrive)
+    for (int tier = 0; tier < 3 && !work.empty(); ++tier) {
+      const FqGapTier T = tiers[tier];
+      next_work.clear();
+      for (size_t c0 = 0; c0 < work.size(); c0 += chunk_reads[tier]) {
+        const int nw = (int)std::min(chunk_reads[tier], work.size() - c0);
+        CKM(c->d_work.ensure(nw) && c->d_wid_w.ensure((size_t)nw * 2 * Lpad) && c->d_wid_bid.ensure((size_t)nw * 2 * Lpad) &&
+            c->d_sw_w.ensure((size_t)nw * 2 * (FQ_SEED_MAX + 1)) && c->d_sw_bid.ensure((size_t)nw * 2 * (FQ_SEED_MAX + 1)) &&
+            c->d_heads.ensure((size_t)nw * FQ_MAX_BUCKETS) && c->d_pool.ensure((size_t)nw * T.pool_cap) &&
+            c->d_aln.ensure((size_t)nw * T.aln_cap) && c->d_naln.ensure(nw) && c->d_status.ensure(nw) && c->d_off.ensure(nw + 1));
+        CK(fqdev::h2d(c->d_work.p, work.data() + c0, (size_t)nw * 4));
+        FqWidthArgs wa{};
+        wa.ix = ix->dev; wa.o = c->ko; wa.seq = c->d_seq.p; wa.stride = stride; wa.len_trim = c->d_len_trim.p; wa.read_list = c->d_read_list.p;
+        wa.work = c->d_work.p; wa.n_work = nw; wa.wid_w = c->d_wid_w.p; wa.wid_bid = c->d_wid_bid.p; wa.wstride = Lpad;
+        wa.sw_w = c->d_sw_w.p; wa.sw_bid = c->d_sw_bid.p; wa.counters = c->d_counters.p;
+        fqdev::time_begin(FQ_K_WIDTH);
+        CK(fqdev::launch_width(wa));
+        fqdev::time_end(FQ_K_WIDTH);
+        FqGapArgs ga{};
+        ga.ix = ix->dev; ga.o = c->ko; ga.seq = c->d_seq.p; ga.stride = stride; ga.len_trim = c->d_len_trim.p; ga.n_amb = c->d_namb.p;
+        ga.read_list = c->d_read_list.p; ga.work = c->d_work.p; ga.n_work = nw; ga.maxdiff_lut = c->d_maxdiff.p;
+        ga.wid_w = c->d_wid_w.p; ga.wid_bid = c->d_wid_bid.p; ga.wstride = Lpad; ga.sw_w = c->d_sw_w.p; ga.sw_bid = c->d_sw_bid.p;
+        ga.pool = c->d_pool.p; ga.heads = c->d_heads.p; ga.tier = T; ga.aln = c->d_aln.p; ga.n_aln = c->d_naln.p; ga.status = c->d_status.p;
+        ga.counters = c->d_counters.p;
+        fqdev::time_begin(FQ_K_GAP);
+        CK(fqdev::launch_gap(ga));
+        fqdev::time_end(FQ_K_GAP);
+        CK(fqdev::launch_scan(c->d_naln.p, c->d_off.p, (uint32_t)nw));
+        h_status.resize(nw); h_naln.resize(nw);
+        uint64_t total = 0;
+        CK(fqdev::d2h(h_status.data(), c->d_status.p, (size_t)nw * 4));
+        CK(fqdev::d2h(h_naln.data(), c->d_naln.p, (size_t)nw * 4));
+        CK(fqdev::d2h(&total, c->d_off.p + nw, 8));
+        CK(fqdev::sync());
+        CKM(c->d_packed.ensure(total + 1));
+        CK(fqdev::launch_pack_aln(c->d_aln.p, c->d_naln.p, c->d_off.p, T.aln_cap, (uint32_t)nw, c->d_packed.p));
+        h_packed.resize(total);
+        CK(fqdev::d2h(h_packed.data(), c->d_packed.p, total * sizeof(FqAln)));
+        CK(fqdev::sync());
+        uint64_t at = 0;
+        for (int w = 0; w < nw; ++w) {
+          const int s = work[c0 + w];
+          if (h_status[w]) { next_work.push_back(s); ++c->stats.tier_retries; continue; }
+          where[s] = (int64_t)h_aln.size();
+          aln_n[s] = h_naln[w];
+          h_aln.insert(h_aln.end(), h_packed.begin() + at, h_packed.begin() + at + h_naln[w]);
+          at += h_naln[w];
+        }
+      }
+      work.swap(next_work);
+    }
+    if (!work.empty()) { c->err = "gap search: exact tier exhausted its pool (internal limit)"; return FQ_ELIMIT; }
+    for (int s = 0; s < n_search; ++s) aln_off[s] = where[s] < 0 ? 0 : (uint64_t)where[s];
+  }
+  c->stats.reads_searched += n_search;
+
+  // ---- records for survivors -----------------------------------------------------------------------------
+  vector<FqRead> &R = S.reads;
+  R.assign((size_t)n_surv * 2, FqRead());
+  vector<int> s_of((size_t)n_surv * 2, -1);
+  {
+    vector<int32_t> sidx_of_read;   // only for survivors: derive from read_list
+    std::unordered_map<int, int> tmp;
+    tmp.reserve(n_search * 2 + 1);
+    for (int s = 0; s < n_search; ++s) tmp[c->h_read_list[s]] = s;
+    for (int sp = 0; sp < n_surv; ++sp)
+      for (int e = 0; e < 2; ++e) {
+        FqRead &p = R[2 * sp + e];
+        const int r = e * n + c->h_pair_list[sp];
+        p.r = r;
+        p.full_len = c->hb.len[r];
+        p.len = p.clip_len = c->h_len_trim[r];
+        p.filtered = c->h_filtered[r];
+        p.extra_flag = 1 | (e == 0 ? 64 : 128);   // SAM_FPD | SAM_FR1/FR2 (BwtMapper.cpp:749)
+        auto it = tmp.find(r);
+        s_of[2 * sp + e] = it == tmp.end() ? -1 : it->second;
+      }
+  }
+  auto aln_of = [&](int idx, int *n_out) -> const FqAln * {
+    const int s = s_of[idx];
+    if (s < 0) { *n_out = 0; return nullptr; }
+    *n_out = (int)aln_n[s];
+    return h_aln.data() + aln_off[s];
+  };
+
+  // ---- SA rows to resolve on the GPU: every row of every hit of reads that can need them ------------------
+  // eligible(read) = n_occ <= max(n_multi,N_multi)+1  (XA listing, bwase.c:47-55)  or
+  //                  both mates have hits and both n_occ <= max_occ (pair enumeration, BwtMapper.cpp:797-811)
+  vector<uint64_t> rows_off;           // per (survivor read): offset into pos[] of its first enumerated row, or ~0
+  vector<uint32_t> h_pos;
+  vector<uint64_t> read_nocc((size_t)n_surv * 2, 0);
+  vector<char> enumerated((size_t)n_surv * 2, 0);
+  vector<uint64_t> aln_row_off;        // per hit in h_aln order (by survivor read order) -> offset into h_pos
+  aln_row_off.assign(h_aln.size() + 1, ~0ull);
+  {
+    const uint32_t multi_cap = (uint32_t)std::max(o.n_multi, o.N_multi) + 1;
+    for (size_t idx = 0; idx < R.size(); ++idx) {
+      int na; const FqAln *a = aln_of((int)idx, &na);
+      uint64_t t = 0;
+      for (int k = 0; k < na; ++k) t += (uint64_t)(a[k].l - a[k].k) + 1;
+      read_nocc[idx] = t;
+    }
+    vector<FqAln> q_aln; vector<uint32_t> q_len; vector<uint64_t> q_off;
+    uint64_t rows = 0;
+    for (int sp = 0; sp < n_surv; ++sp) {
+      int na0, na1;
+      aln_of(2 * sp, &na0); aln_of(2 * sp + 1, &na1);
+      const bool pair_ok = na0 > 0 && na1 > 0 && read_nocc[2 * sp] <= o.max_occ && read_nocc[2 * sp + 1] <= o.max_occ;
+      for (int e = 0; e < 2; ++e) {
+        const int idx = 2 * sp + e;
+        int na; const FqAln *a = aln_of(idx, &na);
+        if (na == 0) continue;
+        if (!(pair_ok || read_nocc[idx] <= multi_cap)) continue;
+        enumerated[idx] = 1;
+        const uint64_t base = aln_off[s_of[idx]];
+        for (int k = 0; k < na; ++k) {
+          aln_row_off[base + k] = rows;
+          q_aln.push_back(a[k]); q_len.push_back((uint32_t)R[idx].len); q_off.push_back(rows);
+          rows += (uint64_t)(a[k].l - a[k].k) + 1;
+        }
+      }
+    }
+    q_off.push_back(rows);
+    h_pos.resize(rows);
+    if (rows) {
+      CKM(c->d_qaln.ensure(q_aln.size()) && c->d_qlen.ensure(q_len.size()) && c->d_qoff.ensure(q_off.size()) && c->d_pos.ensure(rows));
+      CK(fqdev::h2d(c->d_qaln.p, q_aln.data(), q_aln.size() * sizeof(FqAln)));
+      CK(fqdev::h2d(c->d_qlen.p, q_len.data(), q_len.size() * 4));
+      CK(fqdev::h2d(c->d_qoff.p, q_off.data(), q_off.size() * 8));
+      FqSaArgs sa{};
+      sa.ix = ix->dev; sa.aln = c->d_qaln.p; sa.aln_len = c->d_qlen.p; sa.row_off = c->d_qoff.p; sa.n_aln = (uint32_t)q_aln.size();
+      sa.n_rows = rows; sa.pos = c->d_pos.p; sa.counters = c->d_counters.p;
+      fqdev::time_begin(FQ_K_SA);
+      CK(fqdev::launch_sa(sa));
+      fqdev::time_end(FQ_K_SA);
+      CK(fqdev::d2h(h_pos.data(), c->d_pos.p, rows * 4));
+      CK(fqdev::sync());
+      c->stats.sa_rows += rows;
+    }
+  }
+
+  const double t_host0 = now_ms();
+  // ---- stage B1 (host, serial, read order): main hit choice consumes the drand48 stream (Q2) ------------
+  vector<uint32_t> dq_row, dq_info; vector<int> dq_idx;
+  for (int sp = 0; sp < n_surv; ++sp)
+    for (int e = 0; e < 2; ++e) {
+      const int idx = 2 * sp + e;
+      FqRead &p = R[idx];
+      if (p.filtered) continue;
+      int na; const FqAln *a = aln_of(idx, &na);
+      choose_hit(c, na, a, p, true, 0);
+      if (p.type == FQ_TYPE_UNIQUE || p.type == FQ_TYPE_REPEAT) {
+        if (enumerated[idx]) p.pos = h_pos[aln_row_off[aln_off[s_of[idx]] + p.main_aln] + (p.sa - a[p.main_aln].k)];
+        else { dq_row.push_back(p.sa); dq_info.push_back((uint32_t)p.strand << 31 | (uint32_t)p.len); dq_idx.push_back(idx); }
+        p.seQ = p.mapQ = approx_mapq(c, p, c->maxdiff_lut[p.len]);
+      }
+    }
+  if (!dq_row.empty()) {   // main hits of very repetitive reads whose rows were not enumerated
+    const size_t nq = dq_row.size();
+    CKM(c->d_qrow.ensure(nq) && c->d_qinfo.ensure(nq) && c->d_pos.ensure(nq));
+    CK(fqdev::h2d(c->d_qrow.p, dq_row.data(), nq * 4));
+    CK(fqdev::h2d(c->d_qinfo.p, dq_info.data(), nq * 4));
+    FqSaQueryArgs qa{};
+    qa.ix = ix->dev; qa.row = c->d_qrow.p; qa.info = c->d_qinfo.p; qa.n = (uint32_t)nq; qa.pos = c->d_pos.p; qa.counters = c->d_counters.p;
+    fqdev::time_begin(FQ_K_SA);
+    CK(fqdev::launch_saq(qa));
+    fqdev::time_end(FQ_K_SA);
+    vector<uint32_t> tmp(nq);
+    CK(fqdev::d2h(tmp.data(), c->d_pos.p, nq * 4));
+    CK(fqdev::sync());
+    for (size_t i = 0; i < nq; ++i) R[dq_idx[i]].pos = tmp[i];
+    c->stats.sa_rows += nq;
+  }
+  // ---- stage B2: insert size of this batch (Q3) ---------------------------------------------------------
+  fq_isize_t ii;
+  infer_isize(R, n_surv, max_len_all, &ii, o.ap_prior, (int64_t)ix->dev.fm[0].seq_len);
+  if (ii.avg < 0.0 && c->last_ii.avg > 0.0) ii = c->last_ii;
+  if (o.force_isize) { ii.low = ii.high = 0; ii.avg = ii.std = -1.0; }
+  const double t_serial1 = now_ms();
+
+  // ---- stage B3: pairing + XA lists (per pair) -------------------------------------------------------------
+  {
+    vector<uint64_t> arr;
+    for (int sp = 0; sp < n_surv; ++sp) {
+      FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
+      const FqAln *aln[2]; int na[2];
+      aln[0] = aln_of(2 * sp, &na[0]); aln[1] = aln_of(2 * sp + 1, &na[1]);
+      const bool m0 = p[0]->type == FQ_TYPE_UNIQUE || p[0]->type == FQ_TYPE_REPEAT, m1 = p[1]->type == FQ_TYPE_UNIQUE || p[1]->type == FQ_TYPE_REPEAT;
+      if (m0 && m1) {
+        if (read_nocc[2 * sp] > o.max_occ || read_nocc[2 * sp + 1] > o.max_occ) continue;
+        arr.clear();
+        for (int j = 0; j < 2; ++j) {
+          const uint64_t base = aln_off[s_of[2 * sp + j]];
+          for (int k = 0; k < na[j]; ++k) {
+            const FqAln &q = aln[j][k];
+            const uint32_t wdt = q.l - q.k + 1;
+            const uint32_t *ps = h_pos.data() + aln_row_off[base + k];
+            uint32_t np = wdt;
+            if (wdt >= 1000) {   // MIN_HASH_WIDTH: first requester's positions are reused verbatim (Q6)
+              auto ins = c->kl_cache.emplace((uint64_t)q.k << 32 | q.l, vector<uint32_t>());
+              if (ins.second) ins.first->second.assign(ps, ps + wdt);
+              ps = ins.first->second.data(); np = (uint32_t)ins.first->second.size();
+            }
+            for (uint32_t t = 0; t < np; ++t) arr.push_back((uint64_t)ps[t] << 32 | (uint64_t)(k << 1) | (uint64_t)j);
+          }
+        }
+        pair_hits(c, p, aln, arr, &ii);
+      }
+      if (o.N_multi || o.n_multi)
+        for (int j = 0; j < 2; ++j) {
+          if (p[j]->type == FQ_TYPE_NO_MATCH) continue;
+          int nm;
+          if (!(p[j]->extra_flag & 2) && p[1 - j]->type != FQ_TYPE_NO_MATCH) nm = (int)(p[j]->c1 + p[j]->c2) - 1 > o.N_multi ? o.n_multi : o.N_multi;
+          else nm = o.n_multi;
+          choose_hit(c, na[j], aln[j], *p[j], false, nm);
+          const uint64_t base = aln_off[s_of[2 * sp + j]];
+          for (auto &m : p[j]->multi) m.pos = h_pos[aln_row_off[base + m.aln] + m.row_in_aln];
+        }
+    }
+  }
+
+  if (c->debug) S.stage_P = R;   // snapshot for the stage dump (tests)
+
+  // ---- stage C: mate rescue by Smith-Waterman (bwa_paired_sw, libbwa/bwape.c:463-625) ---------------------
+  if (o.is_sw && ii.avg >= 0.0) {
+    struct Cand { int sp, k; };
+    vector<Cand> cands; vector<FqSwTask> tasks;
+    int max_reg = 0, max_q = 0;
+    for (int sp = 0; sp < n_surv; ++sp) {
+      FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
+      for (int j = 0; j < 2; ++j) if (p[j]->filtered) p[j]->filtered = 0;   // expand_seq: revived because its mate passed (:485-499)
+      if (!((p[0]->mapQ >= 17 || p[1]->mapQ >= 17) && (p[0]->extra_flag & 2) == 0)) continue;
+      for (int k = 0; k < 2; ++k) {
+        FqRead *pref = p[1 - k], *pm = p[k];
+        if (pref->type == FQ_TYPE_NO_MATCH) continue;
+        int64_t beg, end;
+        FqSwTask T{};
+        if (pref->strand == 0) {   // __set_rght_coor (:511-516)
+          beg = (int64_t)((int64_t)pref->pos + ii.avg - 3 * ii.std - pm->len * 1.5);
+          end = (int64_t)(beg + 6 * ii.std + 2 * pm->len);
+          if (beg < (int64_t)pref->pos + pref->len) beg = (int64_t)pref->pos + pref->len;
+          if (end > ix->l_pac) end = ix->l_pac;
+          T.use_rc = 1;
+        } else {                   // __set_left_coor (:518-523)
+          beg = (int64_t)((int64_t)pref->pos + pref->len - ii.avg - 3 * ii.std - pm->len * 0.5);
+          end = (int64_t)(beg + 6 * ii.std + 2 * pm->len);
+          if (beg < 0) beg = 0;
+          if (end > (int64_t)pref->pos) end = pref->pos;
+          T.use_rc = 0;
+        }
+        T.read = pm->r; T.beg = beg; T.reglen = (int)(end - beg);
+        cands.push_back({sp, k});
+        tasks.push_back(T);
+        max_reg = std::max(max_reg, T.reglen); max_q = std::max(max_q, pm->len);
+      }
+    }
+    vector<FqSwOut> souts(tasks.size());
+    vector<uint16_t> scig;
+    const int cig_cap = 64;
+    if (!tasks.empty()) {
+      const int RL = std::max(max_reg, 1), QL = std::max(max_q, 1);
+      const size_t sstride = fq_dp_scratch_bytes(RL, QL);
+      const size_t chunk = std::max<size_t>(64, ((size_t)6 << 30) / sstride);
+      scig.resize(tasks.size() * cig_cap);
+      for (size_t t0 = 0; t0 < tasks.size(); t0 += chunk) {
+        const int nt = (int)std::min(chunk, tasks.size() - t0);
+        CKM(c->d_swtask.ensure(nt) && c->d_swout.ensure(nt) && c->d_cig.ensure((size_t)nt * cig_cap) && c->d_scratch.ensure((size_t)nt * sstride));
+        CK(fqdev::h2d(c->d_swtask.p, tasks.data() + t0, (size_t)nt * sizeof(FqSwTask)));
+        FqSwArgs a{};
+        a.ix = ix->dev; a.seq = c->d_seq.p; a.stride = stride; a.len_trim = c->d_len_trim.p; a.task = c->d_swtask.p; a.n_task = nt;
+        a.out = c->d_swout.p; a.cigar = c->d_cig.p; a.cig_cap = cig_cap; a.scratch = c->d_scratch.p; a.scratch_stride = sstride; a.RL = RL; a.QL = QL;
+        fqdev::time_begin(FQ_K_SW);
+        CK(fqdev::launch_sw(a));
+        fqdev::time_end(FQ_K_SW);
+        CK(fqdev::d2h(souts.data() + t0, c->d_swout.p, (size_t)nt * sizeof(FqSwOut)));
+        CK(fqdev::d2h(scig.data() + t0 * cig_cap, c->d_cig.p, (size_t)nt * cig_cap * 2));
+        CK(fqdev::sync());
+      }
+      c->stats.sw_tasks += tasks.size();
+    }
+    // decisions (:556-617), per pair, using the kernel outputs
+    const double l_pac_d = (double)ix->l_pac; (void)l_pac_d;
+    size_t ti = 0;
+    while (ti < cands.size()) {
+      const int sp = cands[ti].sp;
+      FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
+      const uint16_t *cigar[2] = {nullptr, nullptr};
+      int n_cigar[2] = {0, 0}, mq_adjust[2] = {255, 255}, mapQ = 0;
+      int64_t beg[2] = {0, 0};
+      uint32_t cnt[2] = {0, 0};
+      for (; ti < cands.size() && cands[ti].sp == sp; ++ti) {
+        const int k = cands[ti].k;
+        const FqSwOut &O = souts[ti];
+        beg[k] = O.beg; cnt[k] = O.cnt;
+        if (O.n_cigar > 0) { cigar[k] = scig.data() + ti * cig_cap; n_cigar[k] = O.n_cigar; }
+        else beg[k] = tasks[ti].beg;
+        if (cigar[k] && p[k]->type != FQ_TYPE_NO_MATCH) {
+          int clip = 0;
+          if ((cigar[k][0] >> 14) == FQ_OP_S) clip += cigar[k][0] & 0x3fff;
+          if ((cigar[k][n_cigar[k] - 1] >> 14) == FQ_OP_S) clip += cigar[k][n_cigar[k] - 1] & 0x3fff;
+          int s_old = (int)((p[k]->n_mm * 9 + p[k]->n_gapo * 13 + p[k]->n_gape * 2) / 3. * 8. + .499);
+          int s_new = (int)(((cnt[k] >> 16) * 9 + (cnt[k] >> 8 & 0xff) * 13 + (cnt[k] & 0xff) * 2 + (uint32_t)clip * 3) / 3. * 8. + .499);
+          s_old = (int)(s_old + -4.343 * log(ii.ap_prior / ix->l_pac));
+          s_new += (int)(-4.343 * log(.5 * erfc(M_SQRT1_2 * 1.5) + .499));
+          if (s_old < s_new) { mq_adjust[k] = s_new - s_old; cigar[k] = nullptr; n_cigar[k] = 0; }
+          else mq_adjust[k] = s_old - s_new;
+        }
+      }
+      int k = -1;
+      if (cigar[0] && cigar[1]) { k = p[0]->mapQ < p[1]->mapQ ? 0 : 1; mapQ = abs(p[1]->mapQ - p[0]->mapQ); }
+      else if (cigar[0]) { k = 0; mapQ = p[1]->mapQ; }
+      else if (cigar[1]) { k = 1; mapQ = p[0]->mapQ; }
+      if (k >= 0 && (int64_t)p[k]->pos != beg[k]) {
+        int tmp = p[1 - k]->mapQ - p[k]->mapQ / 2 - 8;
+        if (tmp <= 0) tmp = 1;
+        if (mapQ > tmp) mapQ = tmp;
+        p[k]->mapQ = p[1 - k]->mapQ = mapQ;
+        p[k]->seQ = p[1 - k]->seQ = p[1 - k]->seQ < mapQ ? p[1 - k]->seQ : mapQ;
+        if (p[k]->mapQ > mq_adjust[k]) p[k]->mapQ = mq_adjust[k];
+        if (p[k]->seQ > mq_adjust[k]) p[k]->seQ = mq_adjust[k];
+        p[k]->cigar.assign(cigar[k], cigar[k] + n_cigar[k]);
+        p[k]->type = FQ_TYPE_MATESW; p[k]->pos = (uint32_t)beg[k]; p[k]->seQ = p[1 - k]->seQ;   // __set_fixed (:525-533)
+        p[k]->strand = 1 - p[1 - k]->strand;
+        p[k]->n_mm = (int)(cnt[k] >> 16) & 0xff; p[k]->n_gapo = (int)(cnt[k] >> 8 & 0xff); p[k]->n_gape = (int)(cnt[k] & 0xff);
+        p[k]->extra_flag |= 2; p[1 - k]->extra_flag |= 2;
+      }
+    }
+  }
+  if (c->debug) S.stage_S = R;
+
+  // ---- stage D: gapped refinement (bwa_refine_gapped, libbwa/bwase.c:339-418) ------------------------------
+  {
+    struct Tgt { int idx, multi; };
+    vector<Tgt> tgt; vector<FqRefTask> tasks;
+    int max_ref = 1, max_q = 1;
+    for (size_t idx = 0; idx < R.size(); ++idx) {
+      FqRead &s = R[idx];
+      if (s.filtered) continue;
+      for (size_t j = 0; j < s.multi.size(); ++j) {
+        FqMulti &q = s.multi[j];
+        if (q.gap == 0) continue;
+        tasks.push_back({s.r, q.strand, q.pos, (q.strand ? 1 : -1) * q.gap});
+        tgt.push_back({(int)idx, (int)j});
+        max_ref = std::max(max_ref, s.len + q.gap); max_q = std::max(max_q, s.len);
+      }
+      if (s.type == FQ_TYPE_NO_MATCH || s.type == FQ_TYPE_MATESW || s.n_gapo == 0) continue;
+      tasks.push_back({s.r, s.strand, s.pos, (s.strand ? 1 : -1) * (s.n_gapo + s.n_gape)});
+      tgt.push_back({(int)idx, -1});
+      max_ref = std::max(max_ref, s.len + s.n_gapo + s.n_gape); max_q = std::max(max_q, s.len);
+    }
+    if (!tasks.empty()) {
+      const int cig_cap = 64;
+      const size_t sstride = fq_dp_scratch_bytes(max_ref, max_q);
+      const size_t chunk = std::max<size_t>(64, ((size_t)6 << 30) / sstride);
+      vector<FqRefOut> outs(tasks.size());
+      vector<uint16_t> cg(tasks.size() * cig_cap);
+      for (size_t t0 = 0; t0 < tasks.size(); t0 += chunk) {
+        const int nt = (int)std::min(chunk, tasks.size() - t0);
+        CKM(c->d_reftask.ensure(nt) && c->d_refout.ensure(nt) && c->d_cig.ensure((size_t)nt * cig_cap) && c->d_scratch.ensure((size_t)nt * sstride));
+        CK(fqdev::h2d(c->d_reftask.p, tasks.data() + t0, (size_t)nt * sizeof(FqRefTask)));
+        FqRefineArgs a{};
+        a.ix = ix->dev; a.seq = c->d_seq.p; a.stride = stride; a.len_trim = c->d_len_trim.p; a.task = c->d_reftask.p; a.n_task = nt;
+        a.out = c->d_refout.p; a.cigar = c->d_cig.p; a.cig_cap = cig_cap; a.scratch = c->d_scratch.p; a.scratch_stride = sstride; a.RL = max_ref; a.QL = max_q;
+        fqdev::time_begin(FQ_K_REFINE);
+        CK(fqdev::launch_refine(a));
+        fqdev::time_end(FQ_K_REFINE);
+        CK(fqdev::d2h(outs.data() + t0, c->d_refout.p, (size_t)nt * sizeof(FqRefOut)));
+        CK(fqdev::d2h(cg.data() + t0 * cig_cap, c->d_cig.p, (size_t)nt * cig_cap * 2));
+        CK(fqdev::sync());
+      }
+      for (size_t t = 0; t < tasks.size(); ++t) {
+        FqRead &s = R[tgt[t].idx];
+        if (outs[t].n_cigar <= 0) { c->err = "refine: CIGAR longer than the device slot"; return FQ_ELIMIT; }
+        const uint16_t *g = cg.data() + t * cig_cap;
+        if (tgt[t].multi >= 0) { FqMulti &q = s.multi[tgt[t].multi]; q.pos = outs[t].pos; q.cigar.assign(g, g + outs[t].n_cigar); }
+        else { s.pos = outs[t].pos; s.cigar.assign(g, g + outs[t].n_cigar); }
+      }
+      c->stats.refine_tasks += tasks.size();
+    }
+    // MD / NM for every mapped read (bwa_cal_md1)
+    vector<FqMdTask> mt; vector<int> mi; vector<uint16_t> arena;
+    for (size_t idx = 0; idx < R.size(); ++idx) {
+      FqRead &s = R[idx];
+      if (s.type == FQ_TYPE_NO_MATCH) continue;
+      FqMdTask T{};
+      T.read = s.r; T.strand = s.strand; T.pos = s.pos; T.n_cigar = (int)s.cigar.size(); T.cigar_off = (uint32_t)arena.size(); T.len = s.len;
+      arena.insert(arena.end(), s.cigar.begin(), s.cigar.end());
+      mt.push_back(T); mi.push_back((int)idx);
+    }
+    if (!mt.empty()) {
+      const int md_cap = 3 * (max_len_all + 8) + 32;
+      const int nt = (int)mt.size();
+      CKM(c->d_mdtask.ensure(nt) && c->d_md.ensure((size_t)nt * md_cap) && c->d_mdlen.ensure(nt) && c->d_nm.ensure(nt) && c->d_mdsz.ensure(nt) &&
+          c->d_cigarena.ensure(arena.size() + 1) && c->d_off.ensure(nt + 1));
+      CK(fqdev::h2d(c->d_mdtask.p, mt.data(), (size_t)nt * sizeof(FqMdTask)));
+      CK(fqdev::h2d(c->d_cigarena.p, arena.data(), arena.size() * 2));
+      FqMdArgs a{};
+      a.ix = ix->dev; a.seq = c->d_seq.p; a.stride = stride; a.task = c->d_mdtask.p; a.n_task = nt; a.cigar = c->d_cigarena.p;
+      a.md = c->d_md.p; a.md_cap = md_cap; a.md_len = c->d_mdlen.p; a.md_sz = c->d_mdsz.p; a.nm = c->d_nm.p;
+      fqdev::time_begin(FQ_K_REFINE);
+      CK(fqdev::launch_md(a));
+      CK(fqdev::launch_scan(c->d_mdsz.p, c->d_off.p, (uint32_t)nt));
+      fqdev::time_end(FQ_K_REFINE);
+      uint64_t total = 0;
+      vector<int32_t> mdlen(nt), nm(nt);
+      vector<uint64_t> off(nt + 1);
+      CK(fqdev::d2h(off.data(), c->d_off.p, (size_t)(nt + 1) * 8));
+      CK(fqdev::d2h(mdlen.data(), c->d_mdlen.p, (size_t)nt * 4));
+      CK(fqdev::d2h(nm.data(), c->d_nm.p, (size_t)nt * 4));
+      CK(fqdev::sync());
+      total = off[nt];
+      CKM(c->d_mdpacked.ensure(total + 1));
+      CK(fqdev::launch_pack_md(c->d_md.p, c->d_mdlen.p, c->d_off.p, md_cap, nt, c->d_mdpacked.p));
+      vector<char> packed(total + 1);
+      CK(fqdev::d2h(packed.data(), c->d_mdpacked.p, total));
+      CK(fqdev::sync());
+      for (int t = 0; t < nt; ++t) {
+        FqRead &s = R[mi[t]];
+        if (mdlen[t] < 0) { c->err = "MD string longer than the device slot"; return FQ_ELIMIT; }
+        s.md.assign(packed.data() + off[t], (size_t)mdlen[t]);
+        s.has_md = true;
+        s.nm = nm[t] & 0xfff;
+      }
+    }
+    // bwa_correct_trimmed (bwase.c:298-337) for every record
+    for (auto &s : R) {
+      if (s.len == s.full_len) continue;
+      const int clip = s.full_len - s.len;
+      if (s.strand == 0) {
+        if (!s.cigar.empty() && (s.cigar.back() >> 14) == FQ_OP_S) s.cigar.back() = (uint16_t)(s.cigar.back() + clip);
+        else {
+          if (s.cigar.empty()) s.cigar.push_back((uint16_t)(FQ_OP_M << 14 | s.len));
+          s.cigar.push_back((uint16_t)(FQ_OP_S << 14 | clip));
+        }
+      } else {
+        if (!s.cigar.empty() && (s.cigar.front() >> 14) == FQ_OP_S) s.cigar.front() = (uint16_t)(s.cigar.front() + clip);
+        else {
+          if (s.cigar.empty()) s.cigar.push_back((uint16_t)(FQ_OP_M << 14 | s.len));
+          s.cigar.insert(s.cigar.begin(), (uint16_t)(FQ_OP_S << 14 | clip));
+        }
+      }
+      s.len = s.full_len;
+    }
+  }
+  c->last_ii = ii;
+  const double t_host1 = now_ms();
+
+  // ---- flatten into the C-ABI result arrays ------------------------------------------------------------------
+  S.isize = ii;
+  S.s_of = s_of;
+  S.aln_off = aln_off;
+  S.aln_n = aln_n;
+  S.flatten();
+  int n_both_unmapped = 0;
+  for (int sp = 0; sp < n_surv; ++sp) if (R[2 * sp].type == FQ_TYPE_NO_MATCH && R[2 * sp + 1].type == FQ_TYPE_NO_MATCH) ++n_both_unmapped;
+  out->n_survivors = n_surv;
+  out->n_both_filtered = n - n_surv;
+  out->n_both_unmapped = n_both_unmapped;
+  out->pair_idx = S.pair_idx.data();
+  out->rec = S.rec.data();
+  out->cigar = S.cigar.data();
+  out->md = S.md.data();
+  out->multi = S.multi.data();
+  out->isize = ii;
+  out->n_bases = n_bases;
+
+  // ---- measurement ----------------------------------------------------------------------------------------------
+  {
+    uint64_t cnt[FQ_C_COUNT];
+    CK(fqdev::d2h(cnt, c->d_counters.p, sizeof cnt));
+    CK(fqdev::sync());
+    CK(fqdev::dzero(c->d_counters.p, sizeof cnt));
+    fqdev::time_collect(c->stats.kernel_ms, c->stats.kernel_launches, FQ_K_COUNT);
+    c->stats.occ_block_touches += cnt[FQ_C_OCC_WIDTH] + cnt[FQ_C_OCC_GAP] + cnt[FQ_C_OCC_SA];
+    c->stats.gap_occ_touches += cnt[FQ_C_OCC_GAP];
+    c->stats.filter_probes += cnt[FQ_C_PROBES];
+    c->stats.stack_pops += cnt[FQ_C_POPS];
+    c->stats.stack_pushes += cnt[FQ_C_PUSHES];
+    c->stats.pairs += n;
+    c->stats.host_ms_serial += t_serial1 - t_host0;
+    c->stats.host_ms_pair += t_host1 - t_serial1;
+    c->stats.host_ms_total += t_host1 - t_host0;
+    c->stats.wall_ms_total += now_ms() - t_wall0;
+  }
+  return FQ_OK;
+}
+
+extern "C" int fq_ctx_set_debug(fq_ctx_t *c, int keep_stage_snapshots) {
+  if (!c) return FQ_EINVAL;
+  c->debug = keep_stage_snapshots;
+  return FQ_OK;
+}
+void fq_ctx_all_reads(const fq_ctx_t *c, const uint8_t **filtered, const int32_t **len_trim) {
+  *filtered = c->h_filtered.data();
+  *len_trim = c->h_len_trim.data();
+}
+// accessors used by fq_sam.cpp
+const FqBatchState *fq_ctx_state(const fq_ctx_t *c) { return &c->st; }
+const fq_index *fq_ctx_index(const fq_ctx_t *c) { return c->ix; }
+const fq_read_batch_t *fq_ctx_host_batch(const fq_ctx_t *c) { return &c->hb; }
+const fq_opts_t *fq_ctx_opts(const fq_ctx_t *c) { return &c->o; }

@@ -1,0 +1,48 @@
+// fq_backend.h -- the narrow device API the host pipeline (fq_align.cpp) drives.
+// Implemented for gfx950 in fq_device.hip (the product).  tests/emu/ carries a host-loop
+// implementation of the same interface for the CPU-only test tier; it is never part of the product.
+#pragma once
+#include "fq_kernels.h"
+
+namespace fqdev {
+
+int init(int device_ordinal);          // 0 or FQ_ENODEV-style negative
+const char *last_error();
+bool is_real_gpu();                    // true for the HIP backend
+
+void *dmalloc(size_t bytes);           // device memory (nullptr on failure)
+void dfree(void *p);
+void *hmalloc(size_t bytes);           // pinned host memory
+void hfree(void *p);
+int h2d(void *dst, const void *src, size_t bytes);
+int d2h(void *dst, const void *src, size_t bytes);
+int dzero(void *dst, size_t bytes);
+int sync();
+
+// HIP-event timing of everything enqueued between begin/end, accumulated per kernel id
+void time_begin(int kid);
+void time_end(int kid);
+void time_collect(double ms[], uint64_t launches[], int n_ids);   // after sync(); resets the pending list
+
+// launchers (asynchronous on the backend's stream unless stated)
+int launch_prep(const FqPrepArgs &a);
+// ordered stream compaction with wavefront ballot + prefix sums:
+//   pair_list[0..n_surv)   indices of pairs with at least one unfiltered mate, ascending
+//   read_list[0..n_search) unfiltered reads, ordered by (pair, end); sidx[r] = s or -1
+//   counts[0] = n_search, counts[1] = n_surv   (device memory)
+int launch_compact(const uint8_t *filtered, int n_pairs, int32_t *read_list, int32_t *sidx, int32_t *pair_list, int32_t *counts);
+int launch_width(const FqWidthArgs &a);
+int launch_gap(const FqGapArgs &a);
+// out[0..n] = exclusive prefix sums of in[0..n) (64-bit); out[n] = total
+int launch_scan(const uint32_t *in, uint64_t *out, uint32_t n);
+// packed[off[w] + j] = aln[w*cap + j]
+int launch_pack_aln(const FqAln *aln, const uint32_t *n_aln, const uint64_t *off, uint32_t cap, uint32_t n_work, FqAln *packed);
+int launch_sa(const FqSaArgs &a);
+int launch_saq(const FqSaQueryArgs &a);
+int launch_sw(const FqSwArgs &a);
+int launch_refine(const FqRefineArgs &a);
+int launch_md(const FqMdArgs &a);
+// dst[off[t] ..] = src[t*cap .. +len[t]+1] (NUL included), len<0 -> nothing
+int launch_pack_md(const char *src, const int32_t *len, const uint64_t *off, int32_t cap, int32_t n, char *dst);
+
+}  // namespace fqdev

@@ -1,0 +1,125 @@
+// fq_common.h -- structures shared by host code and HIP kernels of the FASTQuick-align hot path.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define FQ_HD __host__ __device__ __forceinline__
+#define FQ_D __device__ __forceinline__
+#else
+#define FQ_HD inline
+#define FQ_D inline
+#endif
+
+// ---- limits (validated in fq_ctx_create; exceeding them is FQ_EINVAL / FQ_ELIMIT, never silent) ----
+#define FQ_LMAX 500            // read length; entry packing below gives 9 bits to i / last_diff
+#define FQ_MAX_BUCKETS 128     // score buckets of the search stack (74 for 150 bp defaults)
+#define FQ_SEED_MAX 64         // seed_len upper bound (default 32)
+#define FQ_NIL 0xffffffffu
+
+// record vocabulary (libbwa/bwtaln.h)
+enum { FQ_ST_M = 0, FQ_ST_I = 1, FQ_ST_D = 2 };
+enum { FQ_OP_M = 0, FQ_OP_I = 1, FQ_OP_D = 2, FQ_OP_S = 3 };
+#define FQ_MODE_GAPE 1
+#define FQ_MODE_COMPREAD 2
+#define FQ_MODE_LOGGAP 4
+#define FQ_MODE_NONSTOP 0x10
+#define FQ_NEG_INF (-1073741823)
+
+// ---- FM index in HBM -----------------------------------------------------------------------
+// The file format interleaves 4 cumulative counts + 128 bases in 48 bytes (libbwa/bwt.h:56-63),
+// which straddles cache lines.  We re-lay each strand as 32-byte blocks of 64 bases: counts of
+// A/C/G/T before the block plus the low and high bit planes of its 64 symbols (base t of the
+// block at bit 63-t), so one aligned 32-byte fetch answers Occ for all four bases with four
+// popcounts.  Results are identical to bwt_occ/bwt_occ4 (bwt.h:98-222) by construction.
+struct FqOccBlk {
+  uint32_t cnt[4];
+  uint64_t lo, hi;
+};
+struct FqFM {
+  const FqOccBlk *blk;
+  const uint32_t *sa;      // sampled suffix array, sa[0] = 0xffffffff (libbwa/bwtio.c:29-49)
+  uint32_t primary, seq_len;
+  uint32_t L2[5];
+  uint32_t sa_intv, n_sa, n_blk;
+};
+struct FqDevIndex {
+  FqFM fm[2];              // [0] forward text (.bwt/.sa), [1] reversed text (.rbwt/.rsa)
+  const uint8_t *pac;      // 2 bits/base, MSB first (libbwa/bwtaln.h:26)
+  int64_t l_pac;
+  const uint8_t *bitmap[6];
+};
+
+// option block passed by value to kernels
+struct FqKOpts {
+  int32_t s_mm, s_gapo, s_gape, mode;
+  int32_t indel_end_skip, max_del_occ, max_entries;
+  int32_t max_gapo, max_gape, max_seed_diff, seed_len, max_top2;
+  int32_t trim_qual, filter_thresh;
+  int32_t n_buckets;
+};
+
+// bwt_aln1_t (libbwa/bwtaln.h:34-38)
+struct FqAln {
+  uint32_t info;   // n_mm | n_gapo<<8 | n_gape<<16 | a<<24
+  uint32_t k, l;
+  int32_t score;
+};
+
+// search-stack entry (gap_entry_t, libbwa/bwtgap.h:7-12) packed into 16 bytes; `next` links the
+// LIFO chain of its score bucket.
+struct FqEntry {
+  uint32_t k, l, pk, next;
+};
+// pk: i[0:9) a[9] state[10:12) n_mm[12:16) n_gapo[16:19) n_gape[19:23) last_diff[23:32)
+FQ_HD uint32_t fq_pack(int i, int a, int st, int mm, int go, int ge, int ld) {
+  return (uint32_t)i | (uint32_t)a << 9 | (uint32_t)st << 10 | (uint32_t)mm << 12 | (uint32_t)go << 16 | (uint32_t)ge << 19 |
+         (uint32_t)ld << 23;
+}
+
+// per-read search status flags
+#define FQ_SF_POOL_OVERFLOW 1u   // entry pool exhausted -> rerun in a larger tier
+#define FQ_SF_ALN_OVERFLOW 2u    // more hits than the aln slot holds -> rerun in a larger tier
+#define FQ_SF_ENTRY_LIMIT 4u     // conservative entry count crossed max_entries -> exact tier decides
+
+struct FqGapTier {       // one launch configuration of the gap-search kernel
+  uint32_t pool_cap;     // entries per read
+  uint32_t aln_cap;      // hits per read
+  int32_t exact;         // 1: no push-time pruning, n_entries tracked exactly (honours max_entries as the reference)
+};
+
+// SW / refine task descriptors
+struct FqSwTask {
+  int32_t read;          // global read index (e*n + i) of the mate being placed
+  int32_t use_rc;        // 1: align reverse complement (p->rseq), 0: forward read
+  int64_t beg;
+  int32_t reglen;
+  int32_t pad;
+};
+struct FqSwOut {
+  int64_t beg;
+  uint32_t cnt;          // n_mm<<16 | n_gapo<<8 | n_gape
+  int32_t n_cigar;       // 0 = no acceptable alignment
+};
+struct FqRefTask {
+  int32_t read;
+  int32_t strand;        // which sequence to align (1: rseq)
+  uint32_t pos;
+  int32_t ext;           // signed gap count, refine_gapped_core's `ext`
+};
+struct FqRefOut {
+  uint32_t pos;
+  int32_t n_cigar;
+};
+struct FqMdTask {
+  int32_t read;
+  int32_t strand;
+  uint32_t pos;
+  int32_t n_cigar;       // 0: ungapped
+  uint32_t cigar_off;    // into the device cigar arena
+  int32_t len;           // s->len at MD time
+};
+
+// work counters written by kernels (one u64 each, atomically accumulated per wave)
+enum { FQ_C_OCC_WIDTH = 0, FQ_C_OCC_GAP, FQ_C_OCC_SA, FQ_C_PROBES, FQ_C_POPS, FQ_C_PUSHES, FQ_C_COUNT };

@@ -1,0 +1,358 @@
+// fq_device.hip -- gfx950 (MI355X) backend: __global__ wrappers, stream compaction / scan kernels
+// with 64-wide wavefront ballots, memory + HIP-event timing.  Written for CDNA4 only.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "fq_backend.h"
+
+namespace fqdev {
+
+static hipStream_t g_stream = nullptr;
+static std::string g_err;
+static int g_device = -1;
+
+#define FQ_HIP(call)                                                                         \
+  do {                                                                                       \
+    hipError_t e_ = (call);                                                                  \
+    if (e_ != hipSuccess) {                                                                  \
+      g_err = std::string(#call) + ": " + hipGetErrorString(e_);                             \
+      return -3;                                                                             \
+    }                                                                                        \
+  } while (0)
+
+const char *last_error() { return g_err.c_str(); }
+bool is_real_gpu() { return true; }
+
+int init(int dev) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_err = "no HIP device visible"; return -3; }
+  if (dev < 0 || dev >= n) { g_err = "device ordinal out of range"; return -3; }
+  FQ_HIP(hipSetDevice(dev));
+  if (!g_stream || g_device != dev) {
+    FQ_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
+    g_device = dev;
+  }
+  return 0;
+}
+
+void *dmalloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipMalloc(&p, bytes ? bytes : 16) != hipSuccess) { g_err = "hipMalloc failed (" + std::to_string(bytes) + " B)"; return nullptr; }
+  return p;
+}
+void dfree(void *p) { if (p) (void)hipFree(p); }
+void *hmalloc(size_t bytes) {
+  void *p = nullptr;
+  if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) { g_err = "hipHostMalloc failed"; return nullptr; }
+  return p;
+}
+void hfree(void *p) { if (p) (void)hipHostFree(p); }
+int h2d(void *dst, const void *src, size_t bytes) { if (bytes) FQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream)); return 0; }
+int d2h(void *dst, const void *src, size_t bytes) { if (bytes) FQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream)); return 0; }
+int dzero(void *dst, size_t bytes) { if (bytes) FQ_HIP(hipMemsetAsync(dst, 0, bytes, g_stream)); return 0; }
+int sync() { FQ_HIP(hipStreamSynchronize(g_stream)); return 0; }
+
+// ---- timing ---------------------------------------------------------------------------------
+struct Pending { int kid; hipEvent_t a, b; };
+static std::vector<Pending> g_pending;
+static std::vector<hipEvent_t> g_free_events;
+static hipEvent_t g_open_begin[16];
+static hipEvent_t get_event() {
+  if (!g_free_events.empty()) { hipEvent_t e = g_free_events.back(); g_free_events.pop_back(); return e; }
+  hipEvent_t e;
+  (void)hipEventCreate(&e);
+  return e;
+}
+void time_begin(int kid) { hipEvent_t e = get_event(); (void)hipEventRecord(e, g_stream); g_open_begin[kid] = e; }
+void time_end(int kid) { hipEvent_t e = get_event(); (void)hipEventRecord(e, g_stream); g_pending.push_back({kid, g_open_begin[kid], e}); }
+void time_collect(double ms[], uint64_t launches[], int n_ids) {
+  for (auto &p : g_pending) {
+    float t = 0.f;
+    if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess && p.kid < n_ids) { ms[p.kid] += t; launches[p.kid] += 1; }
+    g_free_events.push_back(p.a);
+    g_free_events.push_back(p.b);
+  }
+  g_pending.clear();
+}
+
+// ---- kernels --------------------------------------------------------------------------------
+static inline unsigned nblk(uint64_t n, unsigned b) { return (unsigned)((n + b - 1) / b); }
+
+__global__ void __launch_bounds__(256) k_prep(FqPrepArgs a) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < a.n_reads) fq_prep_thread(a, r);
+}
+__global__ void __launch_bounds__(256) k_width(FqWidthArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < a.n_work * 4) fq_width_thread(a, t);
+}
+__global__ void __launch_bounds__(256) k_gap(FqGapArgs a) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < a.n_work) fq_gap_thread(a, w);
+}
+__global__ void __launch_bounds__(256) k_sa(FqSaArgs a) {
+  const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < a.n_rows) fq_sa_thread(a, q);
+}
+__global__ void __launch_bounds__(256) k_saq(FqSaQueryArgs a) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < a.n) fq_saq_thread(a, q);
+}
+__global__ void __launch_bounds__(64) k_sw(FqSwArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < a.n_task) fq_sw_thread(a, t);
+}
+__global__ void __launch_bounds__(64) k_refine(FqRefineArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < a.n_task) fq_refine_thread(a, t);
+}
+__global__ void __launch_bounds__(256) k_md(FqMdArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < a.n_task) fq_md_thread(a, t);
+}
+__global__ void __launch_bounds__(256) k_pack_aln(const FqAln *aln, const uint32_t *n_aln, const uint64_t *off, uint32_t cap, uint32_t n_work, FqAln *packed) {
+  const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w >= n_work) return;
+  const uint32_t n = n_aln[w];
+  const uint64_t o = off[w];
+  for (uint32_t j = 0; j < n; ++j) packed[o + j] = aln[(size_t)w * cap + j];
+}
+__global__ void __launch_bounds__(256) k_pack_md(const char *src, const int32_t *len, const uint64_t *off, int32_t cap, int32_t n, char *dst) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const int l = len[t];
+  if (l < 0) return;
+  const uint64_t o = off[t];
+  for (int j = 0; j <= l; ++j) dst[o + j] = src[(size_t)t * cap + j];
+}
+
+// ---- block-level exclusive scan built from 64-lane wavefront scans ------------------------------
+// returns the exclusive prefix of v within the 256-thread block and the block total in *total.
+__device__ __forceinline__ uint32_t block_excl_scan(uint32_t v, uint32_t *total) {
+  __shared__ uint32_t wsum[4];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  uint32_t x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  if (lane == 63) wsum[wid] = x;
+  __syncthreads();
+  uint32_t base = 0, tot = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) { if (k < wid) base += wsum[k]; tot += wsum[k]; }
+  __syncthreads();
+  *total = tot;
+  return base + x - v;
+}
+
+// generic 3-phase scan: phase A block totals, phase B scan of totals (one block), phase C final
+__global__ void __launch_bounds__(256) k_scan_a(const uint32_t *in, uint32_t n, uint64_t *blk_tot) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  uint32_t tot;
+  (void)block_excl_scan(i < n ? in[i] : 0u, &tot);
+  if (threadIdx.x == 0) blk_tot[blockIdx.x] = tot;
+}
+__global__ void __launch_bounds__(256) k_scan_b(uint64_t *blk_tot, uint32_t nb) {
+  // nb block totals -> exclusive prefix in place, total at blk_tot[nb]; processed in chunks of 256 by one block
+  __shared__ uint64_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nb; base += 256) {
+    const uint32_t i = base + threadIdx.x;
+    const uint64_t v = i < nb ? blk_tot[i] : 0;
+    // 64-bit wave scan
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    __shared__ uint64_t ws[4];
+    uint64_t x = v;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint64_t y = __shfl_up(x, d, 64);
+      if (lane >= d) x += y;
+    }
+    if (lane == 63) ws[wid] = x;
+    __syncthreads();
+    uint64_t b = carry, tot = 0;
+    for (int k = 0; k < 4; ++k) { if (k < wid) b += ws[k]; tot += ws[k]; }
+    if (i < nb) blk_tot[i] = b + x - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) blk_tot[nb] = carry;
+}
+__global__ void __launch_bounds__(256) k_scan_c(const uint32_t *in, uint32_t n, const uint64_t *blk_off, uint64_t *out) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  uint32_t tot;
+  const uint32_t e = block_excl_scan(i < n ? in[i] : 0u, &tot);
+  if (i < n) out[i] = blk_off[blockIdx.x] + e;
+  if (i == 0) out[n] = blk_off[gridDim.x];
+}
+
+static uint64_t *g_scan_tmp = nullptr;
+static size_t g_scan_tmp_n = 0;
+int launch_scan(const uint32_t *in, uint64_t *out, uint32_t n) {
+  if (n == 0) { uint64_t z = 0; return h2d(out, &z, 8) ? -3 : sync(); }
+  const unsigned nb = nblk(n, 256);
+  if (g_scan_tmp_n < nb + 1) {
+    dfree(g_scan_tmp);
+    g_scan_tmp_n = (size_t)nb * 2 + 64;
+    g_scan_tmp = (uint64_t *)dmalloc(g_scan_tmp_n * 8);
+    if (!g_scan_tmp) return -4;
+  }
+  hipLaunchKernelGGL(k_scan_a, dim3(nb), dim3(256), 0, g_stream, in, n, g_scan_tmp);
+  hipLaunchKernelGGL(k_scan_b, dim3(1), dim3(256), 0, g_stream, g_scan_tmp, nb);
+  hipLaunchKernelGGL(k_scan_c, dim3(nb), dim3(256), 0, g_stream, in, n, g_scan_tmp, out);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- ordered compaction of survivors --------------------------------------------------------------
+// per pair p: keep = !(f0 && f1); reads kept: (!f0) then (!f1).  Ballot + popcount give each lane its
+// rank inside the wavefront; LDS combines the four wavefronts of a block; a scanned array of block
+// totals gives the global offset.  Output order is ascending pair index (stable), which is the order the
+// consumers (StatCollector / BAM writer) require.
+__global__ void __launch_bounds__(256) k_compact_a(const uint8_t *filt, int n_pairs, uint32_t *pair_cnt, uint32_t *read_cnt) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  uint32_t keep = 0, nr = 0;
+  if (p < n_pairs) {
+    const uint32_t f0 = filt[p], f1 = filt[n_pairs + p];
+    keep = !(f0 && f1);
+    nr = (!f0) + (!f1);
+  }
+  const unsigned long long bal = __ballot(keep);
+  __shared__ uint32_t s_pairs[4], s_reads[4];
+  uint32_t x = nr;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+  if ((threadIdx.x & 63) == 0) { s_pairs[threadIdx.x >> 6] = (uint32_t)__popcll(bal); s_reads[threadIdx.x >> 6] = x; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    pair_cnt[blockIdx.x] = s_pairs[0] + s_pairs[1] + s_pairs[2] + s_pairs[3];
+    read_cnt[blockIdx.x] = s_reads[0] + s_reads[1] + s_reads[2] + s_reads[3];
+  }
+}
+__global__ void __launch_bounds__(256) k_compact_c(const uint8_t *filt, int n_pairs, const uint64_t *pair_off, const uint64_t *read_off,
+                                                   int32_t *read_list, int32_t *sidx, int32_t *pair_list, int32_t *counts) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  uint32_t keep = 0, f0 = 1, f1 = 1;
+  if (p < n_pairs) { f0 = filt[p]; f1 = filt[n_pairs + p]; keep = !(f0 && f1); }
+  const uint32_t nr = (!f0) + (!f1);
+  uint32_t tot_p, tot_r;
+  const uint32_t rank_p = block_excl_scan(keep, &tot_p);
+  const uint32_t rank_r = block_excl_scan(nr, &tot_r);
+  if (p < n_pairs) {
+    if (keep) pair_list[pair_off[blockIdx.x] + rank_p] = p;
+    uint32_t s = (uint32_t)read_off[blockIdx.x] + rank_r;
+    if (!f0) { read_list[s] = p; sidx[p] = (int32_t)s; ++s; } else sidx[p] = -1;
+    if (!f1) { read_list[s] = n_pairs + p; sidx[n_pairs + p] = (int32_t)s; } else sidx[n_pairs + p] = -1;
+  }
+  if (p == 0) { counts[0] = (int32_t)read_off[gridDim.x]; counts[1] = (int32_t)pair_off[gridDim.x]; }
+}
+static uint32_t *g_cmp_cnt = nullptr;
+static uint64_t *g_cmp_off = nullptr;
+static size_t g_cmp_n = 0;
+int launch_compact(const uint8_t *filtered, int n_pairs, int32_t *read_list, int32_t *sidx, int32_t *pair_list, int32_t *counts) {
+  if (n_pairs <= 0) return dzero(counts, 8);
+  const unsigned nb = nblk((uint64_t)n_pairs, 256);
+  if (g_cmp_n < nb) {
+    dfree(g_cmp_cnt); dfree(g_cmp_off);
+    g_cmp_n = (size_t)nb * 2 + 64;
+    g_cmp_cnt = (uint32_t *)dmalloc(g_cmp_n * 2 * 4);
+    g_cmp_off = (uint64_t *)dmalloc((g_cmp_n + 2) * 2 * 8);
+    if (!g_cmp_cnt || !g_cmp_off) return -4;
+  }
+  uint32_t *pc = g_cmp_cnt, *rc = g_cmp_cnt + g_cmp_n;
+  uint64_t *po = g_cmp_off, *ro = g_cmp_off + g_cmp_n + 2;
+  hipLaunchKernelGGL(k_compact_a, dim3(nb), dim3(256), 0, g_stream, filtered, n_pairs, pc, rc);
+  int rc1 = launch_scan(pc, po, nb);
+  if (rc1) return rc1;
+  rc1 = launch_scan(rc, ro, nb);
+  if (rc1) return rc1;
+  hipLaunchKernelGGL(k_compact_c, dim3(nb), dim3(256), 0, g_stream, filtered, n_pairs, po, ro, read_list, sidx, pair_list, counts);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- filter bitmap construction from a list of set bits (index load) ---------------------------------
+__global__ void __launch_bounds__(256) k_bitmap_scatter(uint8_t *bitmap, const uint32_t *bits, uint64_t n) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint32_t x = bits[i];
+  atomicOr((unsigned int *)(bitmap + ((x >> 5) << 2)), 1u << (x & 31));   // little endian: bit x&7 of byte x>>3
+}
+int launch_bitmap_scatter(uint8_t *bitmap, const uint32_t *bits, uint64_t n) {
+  if (!n) return 0;
+  hipLaunchKernelGGL(k_bitmap_scatter, dim3(nblk(n, 256)), dim3(256), 0, g_stream, bitmap, bits, n);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- launch wrappers ------------------------------------------------------------------------------
+int launch_prep(const FqPrepArgs &a) {
+  if (a.n_reads <= 0) return 0;
+  hipLaunchKernelGGL(k_prep, dim3(nblk((uint64_t)a.n_reads, 256)), dim3(256), 0, g_stream, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+int launch_width(const FqWidthArgs &a) {
+  if (a.n_work <= 0) return 0;
+  hipLaunchKernelGGL(k_width, dim3(nblk((uint64_t)a.n_work * 4, 256)), dim3(256), 0, g_stream, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+int launch_gap(const FqGapArgs &a) {
+  if (a.n_work <= 0) return 0;
+  hipLaunchKernelGGL(k_gap, dim3(nblk((uint64_t)a.n_work, 256)), dim3(256), 0, g_stream, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+int launch_pack_aln(const FqAln *aln, const uint32_t *n_aln, const uint64_t *off, uint32_t cap, uint32_t n_work, FqAln *packed) {
+  if (!n_work) return 0;
+  hipLaunchKernelGGL(k_pack_aln, dim3(nblk(n_work, 256)), dim3(256), 0, g_stream, aln, n_aln, off, cap, n_work, packed);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+int launch_sa(const FqSaArgs &a) {
+  if (!a.n_rows) return 0;
+  hipLaunchKernelGGL(k_sa, dim3(nblk(a.n_rows, 256)), dim3(256), 0, g_stream, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+int launch_saq(const FqSaQueryArgs &a) {
+  if (!a.n) return 0;
+  hipLaunchKernelGGL(k_saq, dim3(nblk(a.n, 256)), dim3(256), 0, g_stream, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+int launch_sw(const FqSwArgs &a) {
+  if (a.n_task <= 0) return 0;
+  hipLaunchKernelGGL(k_sw, dim3(nblk((uint64_t)a.n_task, 64)), dim3(64), 0, g_stream, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+int launch_refine(const FqRefineArgs &a) {
+  if (a.n_task <= 0) return 0;
+  hipLaunchKernelGGL(k_refine, dim3(nblk((uint64_t)a.n_task, 64)), dim3(64), 0, g_stream, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+int launch_md(const FqMdArgs &a) {
+  if (a.n_task <= 0) return 0;
+  hipLaunchKernelGGL(k_md, dim3(nblk((uint64_t)a.n_task, 256)), dim3(256), 0, g_stream, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+int launch_pack_md(const char *src, const int32_t *len, const uint64_t *off, int32_t cap, int32_t n, char *dst) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_pack_md, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, src, len, off, cap, n, dst);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace fqdev

@@ -1,0 +1,886 @@
+// fq_kernels.h -- per-thread bodies of the HIP kernels of the FASTQuick-align hot path.
+//
+// Every body is a FQ_HD function of (args, thread index); fq_device.hip wraps each in a
+// __global__ kernel for gfx950.  (tests/emu builds the same bodies into a host loop so that the
+// host-side pipeline logic can be exercised by the CPU-only test tier; that library is test
+// infrastructure and is never loaded by the product.)
+//
+// Reference citations are paths under the Griffan/FASTQuick tree.
+#pragma once
+#include "fq_common.h"
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FQ_POPC64(x) __popcll(x)
+#define FQ_CTZ32(x) (__ffs((int)(x)) - 1)
+#define FQ_ATOMIC_ADD64(p, v) atomicAdd((unsigned long long *)(p), (unsigned long long)(v))
+#else
+#define FQ_POPC64(x) __builtin_popcountll(x)
+#define FQ_CTZ32(x) __builtin_ctz(x)
+#define FQ_ATOMIC_ADD64(p, v) (*(p) += (v))
+#endif
+
+// nst_nt4_table, libbwa/bntseq.c:38-55 (A0 C1 G2 T3, '-' 5, anything else 4)
+FQ_HD int fq_nt4(uint8_t ch) {
+  switch (ch) {
+    case 'A': case 'a': return 0;
+    case 'C': case 'c': return 1;
+    case 'G': case 'g': return 2;
+    case 'T': case 't': return 3;
+    case '-': return 5;
+    default: return 4;
+  }
+}
+FQ_HD int fq_comp(int c) { return c < 4 ? 3 - c : c; }
+FQ_HD int fq_pac_base(const uint8_t *pac, int64_t k) { return pac[k >> 2] >> ((~k & 3) << 1) & 3; }
+
+// ---- Occ / rank: bwt_occ, bwt_occ4, bwt_2occ, bwt_2occ4 (libbwa/bwt.h:98-222) ---------------
+FQ_HD uint32_t fq_adj(const FqFM &f, uint32_t k) { return k >= f.primary ? k - 1 : k; }
+
+FQ_HD uint32_t fq_occ1(const FqFM &f, uint32_t k, int c) {
+  if (k == 0xffffffffu) return 0;
+  k = fq_adj(f, k);
+  const FqOccBlk *b = f.blk + (k >> 6);
+  const uint64_t hi = b->hi, lo = b->lo;
+  const uint64_t m = ~0ull << (63 - (k & 63));
+  const uint64_t x = ((c & 2) ? hi : ~hi) & ((c & 1) ? lo : ~lo) & m;
+  return b->cnt[c] + (uint32_t)FQ_POPC64(x);
+}
+FQ_HD void fq_occ4(const FqFM &f, uint32_t k, uint32_t o[4]) {
+  if (k == 0xffffffffu) { o[0] = o[1] = o[2] = o[3] = 0; return; }
+  k = fq_adj(f, k);
+  const FqOccBlk *b = f.blk + (k >> 6);
+  const uint64_t hi = b->hi, lo = b->lo;
+  const uint64_t m = ~0ull << (63 - (k & 63));
+  o[0] = b->cnt[0] + (uint32_t)FQ_POPC64(~hi & ~lo & m);
+  o[1] = b->cnt[1] + (uint32_t)FQ_POPC64(~hi & lo & m);
+  o[2] = b->cnt[2] + (uint32_t)FQ_POPC64(hi & ~lo & m);
+  o[3] = b->cnt[3] + (uint32_t)FQ_POPC64(hi & lo & m);
+}
+// reference-defined touch count of a paired lookup: distinct 128-row blocks read
+FQ_HD uint32_t fq_touch2(const FqFM &f, uint32_t k, uint32_t l, bool single_base) {
+  bool vk = k != 0xffffffffu && !(single_base && k == f.seq_len);
+  bool vl = l != 0xffffffffu && !(single_base && l == f.seq_len);
+  if (k == l) return vk ? 1u : 0u;
+  if (vk && vl) return (fq_adj(f, k) >> 7) == (fq_adj(f, l) >> 7) ? 1u : 2u;
+  return (vk ? 1u : 0u) + (vl ? 1u : 0u);
+}
+
+// bwt_invPsi (bwt.h:66-70) + bwt_sa (bwt.c:69-79): one block fetch yields both the symbol and its rank
+FQ_HD uint32_t fq_sa_lookup(const FqFM &f, uint32_t k, uint32_t *steps) {
+  uint32_t sa = 0;
+  while (k % f.sa_intv != 0) {
+    ++sa;
+    if (k == f.primary) { k = 0; continue; }
+    const uint32_t ka = fq_adj(f, k);
+    const FqOccBlk *b = f.blk + (ka >> 6);
+    const uint64_t hi = b->hi, lo = b->lo;
+    const int sh = 63 - (int)(ka & 63);
+    const int c = (int)((hi >> sh) & 1) << 1 | (int)((lo >> sh) & 1);
+    const uint64_t m = ~0ull << sh;
+    const uint64_t x = ((c & 2) ? hi : ~hi) & ((c & 1) ? lo : ~lo) & m;
+    k = f.L2[c] + b->cnt[c] + (uint32_t)FQ_POPC64(x);
+  }
+  *steps += sa;
+  return sa + f.sa[k / f.sa_intv];
+}
+
+// ---- K_prep: encode + quality trim + k-mer filter ----------------------------------------------
+// bwa_read_seq_with_hash_dev (src/BwtMapper.cpp:526-588), bwa_trim_read (libbwa/bwaseqio.c:75-88),
+// IsReadInHashByCountMoreChunck + CountKmerHitInHash (src/BwtIndexer.cpp:441-456, 261-313).
+struct FqPrepArgs {
+  FqDevIndex ix;
+  FqKOpts o;
+  const uint8_t *seq, *qual;
+  const int32_t *len;
+  int32_t stride, n_reads;
+  int32_t *len_trim;     // out: p->len (== clip_len)
+  uint8_t *filtered;     // out: 1 = filtered
+  int32_t *n_amb;        // out: N count over the trimmed read
+  uint64_t *counters;
+};
+FQ_HD uint32_t fq_kmer_project(uint64_t kmer, int t) {
+  switch (t) {
+    case 0: return (uint32_t)(kmer >> 32);
+    case 1: return (uint32_t)kmer;
+    case 2: return (uint32_t)(((kmer >> 48) << 16) | (kmer & 0xffff));
+    case 3: return (uint32_t)(kmer >> 16);
+    case 4: return (uint32_t)(((kmer >> 48) << 16) | ((kmer >> 16) & 0xffff));
+    default: return (uint32_t)((((kmer >> 32) & 0xffff) << 16) | (kmer & 0xffff));
+  }
+}
+FQ_HD void fq_prep_thread(const FqPrepArgs &A, int r) {
+  const uint8_t *row = A.seq + (size_t)r * (size_t)A.stride;
+  const int full = A.len[r];
+  int len = full;
+  if (A.o.trim_qual >= 1) {
+    const uint8_t *q = A.qual + (size_t)r * (size_t)A.stride;
+    int s = 0, mx = 0, max_l = full - 1;
+    for (int l = full - 1; l >= 34; --l) {
+      s += A.o.trim_qual - ((int)q[l] - 33);
+      if (s < 0) break;
+      if (s > mx) { mx = s; max_l = l; }
+    }
+    len = max_l + 1;
+  }
+  A.len_trim[r] = len;
+  int namb = 0;
+  for (int i = 0; i < len; ++i) namb += fq_nt4(row[i]) > 3;
+  A.n_amb[r] = namb;
+  uint8_t filt = 0;
+  if (A.o.filter_thresh != 0) {
+    int count = 0;
+    uint32_t probes = 0;
+    filt = 1;
+    for (int ch = 0; ch < 3 && filt; ++ch) {
+      uint64_t kmer = 0;
+      for (int j = 0; j < 32; ++j) {
+        const int p = 32 * ch + j;
+        const uint64_t c = p < full ? (uint64_t)fq_nt4(row[p]) : 0;  // beyond the read: zero (Q7 fence)
+        kmer = (kmer << 2) | c;                                     // N (4) OR-ed unmasked like the reference
+      }
+      for (int t = 0; t < 6; ++t) {
+        const uint32_t x = fq_kmer_project(kmer, t);
+        ++probes;
+        if (A.ix.bitmap[t][x >> 3] & (1u << (x & 7))) ++count;
+      }
+      if (count >= A.o.filter_thresh) filt = 0;
+    }
+    FQ_ATOMIC_ADD64(&A.counters[FQ_C_PROBES], probes);
+  }
+  A.filtered[r] = filt;
+}
+
+// ---- read access helpers: seq[0] is the reversed read, seq[1] its complement (reverse complement
+// of the read), exactly the two arrays bwa_read_seq_with_hash_dev leaves in p->seq / p->rseq ------
+struct FqReadView {
+  const uint8_t *row;
+  int len;
+};
+FQ_HD int fq_base(const FqReadView &v, int a, int i) {
+  const int c = fq_nt4(v.row[v.len - 1 - i]);
+  return a ? fq_comp(c) : c;
+}
+
+// ---- K_width: bwt_cal_width (libbwa/bwtaln.c:73-97), four chains per read -----------------------
+struct FqWidthArgs {
+  FqDevIndex ix;
+  FqKOpts o;
+  const uint8_t *seq;
+  int32_t stride;
+  const int32_t *len_trim;
+  const int32_t *read_list;   // s -> r
+  const int32_t *work;        // w -> s (NULL: identity)
+  int32_t n_work;
+  uint32_t *wid_w;            // [w][2][wstride]
+  uint8_t *wid_bid;
+  int32_t wstride;
+  uint32_t *sw_w;             // [w][2][FQ_SEED_MAX+1]
+  uint8_t *sw_bid;
+  uint64_t *counters;
+};
+FQ_HD void fq_width_thread(const FqWidthArgs &A, int t) {
+  const int w = t >> 2, which = t & 3, strand = which >> 1, seed = which & 1;
+  const int s = A.work ? A.work[w] : w;
+  const int r = A.read_list[s];
+  FqReadView v = {A.seq + (size_t)r * (size_t)A.stride, A.len_trim[r]};
+  if (seed && v.len <= A.o.seed_len) return;
+  const int n = seed ? A.o.seed_len : v.len;
+  const int off = seed ? v.len - A.o.seed_len : 0;
+  const FqFM &f = A.ix.fm[strand];
+  uint32_t *ow = seed ? A.sw_w + ((size_t)w * 2 + strand) * (FQ_SEED_MAX + 1) : A.wid_w + ((size_t)w * 2 + strand) * (size_t)A.wstride;
+  uint8_t *ob = seed ? A.sw_bid + ((size_t)w * 2 + strand) * (FQ_SEED_MAX + 1) : A.wid_bid + ((size_t)w * 2 + strand) * (size_t)A.wstride;
+  uint32_t k = 0, l = f.seq_len, touches = 0;
+  int bid = 0;
+  for (int i = 0; i < n; ++i) {
+    const int c = fq_base(v, strand, off + i);
+    if (c < 4) {
+      touches += fq_touch2(f, k - 1, l, true);
+      const uint32_t ok = fq_occ1(f, k - 1, c), ol = fq_occ1(f, l, c);
+      k = f.L2[c] + ok + 1;
+      l = f.L2[c] + ol;
+    }
+    if (k > l || c > 3) { k = 0; l = f.seq_len; ++bid; }
+    ow[i] = l - k + 1;
+    ob[i] = (uint8_t)bid;
+  }
+  ow[n] = 0;
+  ob[n] = (uint8_t)(bid + 1);
+  FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_WIDTH], touches);
+}
+
+// ---- K_gap: bwt_match_gap (libbwa/bwtgap.c:104-264) --------------------------------------------
+// One lane runs the whole bounded best-first search of one read.  The score-bucketed LIFO stack
+// (gap_stack_t, bwtgap.c:13-79) is a per-read pool of 16-byte entries in HBM with one linked
+// chain per score bucket; a 128-bit occupancy mask in registers replaces the "scan for the next
+// non-empty bucket" loop of gap_pop.  Pop order is identical to the reference's.
+//
+// Non-exact tiers drop, at push time, children that the reference would pop only to discard
+// (score > best_score + s_mm once a hit exists, or more differences than max_diff can ever allow);
+// both conditions are monotone, so the sequence of processed entries is unchanged.  The dropped
+// children still count in n_live, which therefore over-estimates stack->n_entries: if it ever
+// crosses max_entries the read is flagged and re-run in the exact tier, which keeps every entry.
+struct FqGapArgs {
+  FqDevIndex ix;
+  FqKOpts o;
+  const uint8_t *seq;
+  int32_t stride;
+  const int32_t *len_trim;
+  const int32_t *n_amb;
+  const int32_t *read_list;
+  const int32_t *work;
+  int32_t n_work;
+  const uint8_t *maxdiff_lut;
+  uint32_t *wid_w;
+  uint8_t *wid_bid;
+  int32_t wstride;
+  const uint32_t *sw_w;
+  const uint8_t *sw_bid;
+  FqEntry *pool;
+  uint32_t *heads;
+  FqGapTier tier;
+  FqAln *aln;
+  uint32_t *n_aln;
+  uint32_t *status;
+  uint64_t *counters;
+};
+
+FQ_HD void fq_gap_thread(const FqGapArgs &A, int w) {
+  const FqKOpts &o = A.o;
+  const int s = A.work ? A.work[w] : w;
+  const int r = A.read_list[s];
+  const FqReadView v = {A.seq + (size_t)r * (size_t)A.stride, A.len_trim[r]};
+  const int len = v.len;
+  const int max_diff_opt = A.maxdiff_lut[len];
+  const bool use_seed = len > o.seed_len;
+  const int seed_len = o.seed_len < len ? o.seed_len : 0x7fffffff;
+  const bool gape_mode = (o.mode & FQ_MODE_GAPE) != 0, nonstop = (o.mode & FQ_MODE_NONSTOP) != 0;
+  A.n_aln[w] = 0;
+  A.status[w] = 0;
+  if (A.n_amb[r] > max_diff_opt) return;
+
+  uint32_t *const head = A.heads + (size_t)w * FQ_MAX_BUCKETS;
+  FqEntry *const pool = A.pool + (size_t)w * (size_t)A.tier.pool_cap;
+  FqAln *const aln = A.aln + (size_t)w * (size_t)A.tier.aln_cap;
+  uint32_t *const wbase_w = A.wid_w + (size_t)w * 2 * (size_t)A.wstride;
+  uint8_t *const wbase_b = A.wid_bid + (size_t)w * 2 * (size_t)A.wstride;
+  const uint32_t *const sbase_w = A.sw_w + (size_t)w * 2 * (FQ_SEED_MAX + 1);
+  const uint8_t *const sbase_b = A.sw_bid + (size_t)w * 2 * (FQ_SEED_MAX + 1);
+
+  uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;   // bucket occupancy
+  uint32_t bump = 0, spare = FQ_NIL, status = 0;
+  int64_t n_live = 0;
+  int best_score = (max_diff_opt + 1) * o.s_mm + (o.max_gapo + 1) * o.s_gapo + (o.max_gape + 1) * o.s_gape;
+  int max_diff = max_diff_opt, best_cnt = 0;
+  uint32_t n_aln = 0;
+  uint32_t c_pops = 0, c_pushes = 0, c_touch = 0;
+  const bool exact = A.tier.exact != 0;
+
+#define FQ_BUCKET_TEST(b) ((((b) < 32 ? m0 : (b) < 64 ? m1 : (b) < 96 ? m2 : m3) >> ((b) & 31)) & 1u)
+#define FQ_BUCKET_SET(b)                                   \
+  do {                                                     \
+    const uint32_t bit_ = 1u << ((b) & 31);                \
+    if ((b) < 32) m0 |= bit_; else if ((b) < 64) m1 |= bit_; else if ((b) < 96) m2 |= bit_; else m3 |= bit_; \
+  } while (0)
+#define FQ_BUCKET_CLR(b)                                   \
+  do {                                                     \
+    const uint32_t bit_ = ~(1u << ((b) & 31));             \
+    if ((b) < 32) m0 &= bit_; else if ((b) < 64) m1 &= bit_; else if ((b) < 96) m2 &= bit_; else m3 &= bit_; \
+  } while (0)
+
+  auto push = [&](int a, int i, uint32_t k, uint32_t l, int mm, int go, int ge, int st, bool is_diff, int parent_ld) {
+    const int score = mm * o.s_mm + go * o.s_gapo + ge * o.s_gape;
+    ++n_live;
+    if (!exact) {
+      if (n_aln > 0 && !nonstop && score > best_score + o.s_mm) return;
+      if (max_diff - (mm + go + (gape_mode ? ge : 0)) < 0) return;
+    }
+    uint32_t slot;
+    if (spare != FQ_NIL) { slot = spare; spare = FQ_NIL; }
+    else {
+      if (bump >= A.tier.pool_cap) { status |= FQ_SF_POOL_OVERFLOW; return; }
+      slot = bump++;
+    }
+    ++c_pushes;
+    FqEntry e;
+    e.k = k; e.l = l;
+    e.pk = fq_pack(i, a, st, mm, go, ge, is_diff ? i : parent_ld);   // Q1: non-diff pushes inherit last_diff_pos
+    e.next = FQ_BUCKET_TEST(score) ? head[score] : FQ_NIL;
+    pool[slot] = e;
+    head[score] = slot;
+    FQ_BUCKET_SET(score);
+  };
+
+  push(0, len, 0, A.ix.fm[0].seq_len, 0, 0, 0, FQ_ST_M, false, 0);
+  push(1, len, 0, A.ix.fm[0].seq_len, 0, 0, 0, FQ_ST_M, false, 0);
+
+  while ((m0 | m1 | m2 | m3) != 0 && status == 0) {
+    if (n_live > (int64_t)o.max_entries) {
+      if (!exact) status |= FQ_SF_ENTRY_LIMIT;
+      break;
+    }
+    // gap_pop
+    const int b = m0 ? FQ_CTZ32(m0) : m1 ? 32 + FQ_CTZ32(m1) : m2 ? 64 + FQ_CTZ32(m2) : 96 + FQ_CTZ32(m3);
+    const uint32_t slot = head[b];
+    const FqEntry e = pool[slot];
+    if (e.next == FQ_NIL) FQ_BUCKET_CLR(b); else head[b] = e.next;
+    --n_live;
+    spare = slot;
+    ++c_pops;
+    uint32_t k = e.k, l = e.l;
+    int i = (int)(e.pk & 511);
+    const int a = (int)(e.pk >> 9) & 1, st = (int)(e.pk >> 10) & 3, n_mm = (int)(e.pk >> 12) & 15, n_gapo = (int)(e.pk >> 16) & 7,
+              n_gape = (int)(e.pk >> 19) & 15, last_diff = (int)(e.pk >> 23);
+    const int e_score = b;
+    if (!nonstop && e_score > best_score + o.s_mm) break;
+    int m = max_diff - (n_mm + n_gapo), m_seed = 0;
+    if (gape_mode) m -= n_gape;
+    if (m < 0) continue;
+    const FqFM &f = A.ix.fm[1 - a];
+    uint32_t *const ww = wbase_w + (size_t)a * (size_t)A.wstride;
+    uint8_t *const wb = wbase_b + (size_t)a * (size_t)A.wstride;
+    if (use_seed) {
+      m_seed = o.max_seed_diff - (n_mm + n_gapo);
+      if (gape_mode) m_seed -= n_gape;
+    }
+    if (i > 0 && m < (int)wb[i - 1]) continue;
+    bool hit = false;
+    if (i == 0) hit = true;
+    else if (m == 0 && (st == FQ_ST_M || gape_mode || n_gape == o.max_gape)) {
+      // bwt_match_exact_alt, libbwa/bwt.c:102-117
+      bool ok = true;
+      for (int t = i - 1; t >= 0; --t) {
+        const int c = fq_base(v, a, t);
+        if (c > 3) { ok = false; break; }
+        c_touch += fq_touch2(f, k - 1, l, true);
+        const uint32_t okk = fq_occ1(f, k - 1, c), oll = fq_occ1(f, l, c);
+        k = f.L2[c] + okk + 1;
+        l = f.L2[c] + oll;
+        if (k > l) { ok = false; break; }
+      }
+      if (!ok) continue;
+      hit = true;
+    }
+    if (hit) {
+      bool do_add = true;
+      if (n_aln == 0) {
+        best_score = e_score;
+        const int best_diff = n_mm + n_gapo + (gape_mode ? n_gape : 0);
+        if (!nonstop) max_diff = best_diff + 1 > max_diff_opt ? max_diff_opt : best_diff + 1;
+      }
+      if (e_score == best_score) best_cnt += (int)(l - k + 1);
+      else if (best_cnt > o.max_top2) break;
+      if (n_gapo)
+        for (uint32_t j = 0; j < n_aln; ++j)
+          if (aln[j].k == k && aln[j].l == l) { do_add = false; break; }
+      if (do_add) {
+        // gap_shadow, bwtgap.c:81-91
+        const uint32_t x = l - k + 1, mx = f.seq_len;
+        uint32_t jj = 0;
+        for (int t = 0; t < last_diff; ++t) {
+          const uint32_t cur = ww[t];
+          if (cur > x) ww[t] = cur - x;
+          else if (cur == x) { wb[t] = 1; ww[t] = mx - (++jj); }
+        }
+        if (n_aln >= A.tier.aln_cap) { status |= FQ_SF_ALN_OVERFLOW; break; }
+        FqAln h;
+        h.info = (uint32_t)n_mm | (uint32_t)n_gapo << 8 | (uint32_t)n_gape << 16 | (uint32_t)a << 24;
+        h.k = k; h.l = l; h.score = e_score;
+        aln[n_aln++] = h;
+      }
+      continue;
+    }
+    --i;
+    uint32_t ck[4], cl[4];
+    c_touch += fq_touch2(f, k - 1, l, false);
+    fq_occ4(f, k - 1, ck);
+    fq_occ4(f, l, cl);
+    const uint32_t occ = l - k + 1;
+    bool allow_diff = true, allow_M = true;
+    if (i > 0) {
+      const int ii = i - (len - seed_len);
+      const int b1 = wb[i - 1], b0 = wb[i];
+      if (b1 > m - 1) allow_diff = false;
+      else if (b1 == m - 1 && b0 == m - 1 && ww[i - 1] == ww[i]) allow_M = false;
+      if (use_seed && ii > 0) {
+        const uint8_t *sb = sbase_b + (size_t)a * (FQ_SEED_MAX + 1);
+        const uint32_t *sw = sbase_w + (size_t)a * (FQ_SEED_MAX + 1);
+        const int s1 = sb[ii - 1], s0 = sb[ii];
+        if (s1 > m_seed - 1) allow_diff = false;
+        else if (s1 == m_seed - 1 && s0 == m_seed - 1 && sw[ii - 1] == sw[ii]) allow_M = false;
+      }
+    }
+    int tmp;
+    if (o.mode & FQ_MODE_LOGGAP) { uint32_t vv = (uint32_t)(n_gape + n_gapo); int lg = 0; while (vv >>= 1) ++lg; tmp = lg / 2 + 1; }
+    else tmp = n_gapo + n_gape;
+    if (allow_diff && i >= o.indel_end_skip + tmp && len - i >= o.indel_end_skip + tmp) {
+      if (st == FQ_ST_M) {
+        if (n_gapo < o.max_gapo) {
+          push(a, i, k, l, n_mm, n_gapo + 1, n_gape, FQ_ST_I, true, last_diff);
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t kk = f.L2[j] + ck[j] + 1, ll = f.L2[j] + cl[j];
+            if (kk <= ll) push(a, i + 1, kk, ll, n_mm, n_gapo + 1, n_gape, FQ_ST_D, true, last_diff);
+          }
+        }
+      } else if (st == FQ_ST_I) {
+        if (n_gape < o.max_gape) push(a, i, k, l, n_mm, n_gapo, n_gape + 1, FQ_ST_I, true, last_diff);
+      } else {
+        if (n_gape < o.max_gape && (n_gape + n_gapo < max_diff || occ < (uint32_t)o.max_del_occ))
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t kk = f.L2[j] + ck[j] + 1, ll = f.L2[j] + cl[j];
+            if (kk <= ll) push(a, i + 1, kk, ll, n_mm, n_gapo, n_gape + 1, FQ_ST_D, true, last_diff);
+          }
+      }
+    }
+    const int ci = fq_base(v, a, i);
+    if (allow_diff && allow_M) {
+      for (int j = 1; j <= 4; ++j) {
+        const int cc = (ci + j) & 3;
+        const bool is_mm = (j != 4 || ci > 3);
+        const uint32_t kk = f.L2[cc] + ck[cc] + 1, ll = f.L2[cc] + cl[cc];
+        if (kk <= ll) push(a, i, kk, ll, n_mm + (is_mm ? 1 : 0), n_gapo, n_gape, FQ_ST_M, is_mm, last_diff);
+      }
+    } else if (ci < 4) {
+      const uint32_t kk = f.L2[ci] + ck[ci] + 1, ll = f.L2[ci] + cl[ci];
+      if (kk <= ll) push(a, i, kk, ll, n_mm, n_gapo, n_gape, FQ_ST_M, false, last_diff);
+    }
+  }
+#undef FQ_BUCKET_TEST
+#undef FQ_BUCKET_SET
+#undef FQ_BUCKET_CLR
+  A.n_aln[w] = status ? 0u : n_aln;   // failed reads are re-run in a larger tier; expose no partial list
+  A.status[w] = status;
+  FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS], c_pops);
+  FQ_ATOMIC_ADD64(&A.counters[FQ_C_PUSHES], c_pushes);
+  FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_GAP], c_touch);
+}
+
+// ---- K_sa: bwt_sa over enumerated SA rows (src/BwtMapper.cpp:770-772, 811-853) -------------------
+struct FqSaArgs {
+  FqDevIndex ix;
+  const FqAln *aln;          // packed hits
+  const uint32_t *aln_len;   // read length per packed hit (p[j]->len at enumeration time)
+  const uint64_t *row_off;   // exclusive prefix of enumerated widths per packed hit, [n_aln+1]
+  uint32_t n_aln;
+  uint64_t n_rows;
+  uint32_t *pos;             // out [n_rows]
+  uint64_t *counters;
+};
+FQ_HD void fq_sa_thread(const FqSaArgs &A, uint64_t q) {
+  // find hit g with row_off[g] <= q < row_off[g+1]
+  uint32_t lo = 0, hi = A.n_aln;
+  while (hi - lo > 1) {
+    const uint32_t mid = (lo + hi) >> 1;
+    if (A.row_off[mid] <= q) lo = mid; else hi = mid;
+  }
+  const FqAln h = A.aln[lo];
+  const uint32_t row = h.k + (uint32_t)(q - A.row_off[lo]);
+  const int a = (int)(h.info >> 24) & 1;
+  uint32_t steps = 0, p;
+  if (a) p = fq_sa_lookup(A.ix.fm[0], row, &steps);
+  else p = A.ix.fm[1].seq_len - (fq_sa_lookup(A.ix.fm[1], row, &steps) + A.aln_len[lo]);
+  A.pos[q] = p;
+  FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_SA], steps);
+}
+// stand-alone queries (main hits of reads whose rows were not enumerated)
+struct FqSaQueryArgs {
+  FqDevIndex ix;
+  const uint32_t *row;
+  const uint32_t *info;      // strand<<31 | len
+  uint32_t n;
+  uint32_t *pos;
+  uint64_t *counters;
+};
+FQ_HD void fq_saq_thread(const FqSaQueryArgs &A, uint32_t q) {
+  const int a = (int)(A.info[q] >> 31);
+  const uint32_t len = A.info[q] & 0x7fffffffu;
+  uint32_t steps = 0;
+  A.pos[q] = a ? fq_sa_lookup(A.ix.fm[0], A.row[q], &steps) : A.ix.fm[1].seq_len - (fq_sa_lookup(A.ix.fm[1], A.row[q], &steps) + len);
+  FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_SA], steps);
+}
+
+// ---- dynamic programming: libbwa/stdaln.c with aln_param_bwa {26,9,5,aln_sm_maq,5,50} (:227) ------
+#define FQ_GAP_O 26
+#define FQ_GAP_E 9
+#define FQ_GAP_END 5
+#define FQ_BAND 50
+FQ_HD int fq_sm_maq(int a, int b) { return (a > 3 || b > 3) ? -13 : (a == b ? 11 : -19); }  // aln_sm_maq, stdaln.c:206-212
+
+struct FqCell { int M, I, D; };
+// trace byte: Mt[0:2) It[2] (0=M,1=I) Dt[3] (0=M,1=D)
+FQ_HD int fq_pick_M(const FqCell &p, int sc, uint8_t &t) {   // set_M, stdaln.c:260-276
+  if (p.M >= p.I) { if (p.M >= p.D) { t = FQ_OP_M; return p.M + sc; } t = FQ_OP_D; return p.D + sc; }
+  if (p.I > p.D) { t = FQ_OP_I; return p.I + sc; }
+  t = FQ_OP_D; return p.D + sc;
+}
+FQ_HD int fq_pick_gap(int m, int g, int ext, uint8_t &from_m) {  // set_I / set_D / set_end_*, stdaln.c:277-319
+  if (m - FQ_GAP_O > g) { from_m = 1; return m - FQ_GAP_O - ext; }
+  from_m = 0; return g - ext;
+}
+
+// Banded global alignment with end-gap penalty (aln_global_core, stdaln.c:345-525).  s1/s2 are
+// 0-based code arrays; rows/trace are caller-provided scratch: rows = 2*(len1+1) cells, trace =
+// (len2+1)*(len1+1) bytes.  ops receives the path (end -> start), returns score, *n_ops = path_len,
+// (*fi,*fj) = coordinates of the last path element (path[path_len-1]).
+FQ_HD int fq_global_align(const uint8_t *s1, int len1, const uint8_t *s2, int len2, int band, int gap_end, FqCell *rows,
+                          uint8_t *trace, uint8_t *ops, int *n_ops, int *fi, int *fj) {
+  if (len1 == 0 || len2 == 0) { *n_ops = 0; return 0; }
+  int b1, b2;
+  if (len1 > len2) { b1 = len1 - len2 + band; b2 = band; } else { b1 = band; b2 = len2 - len1 + band; }
+  if (b1 > len1) b1 = len1;
+  if (b2 > len2) b2 = len2;
+  const int W = len1 + 1;
+  const int end_ext = gap_end >= 0 ? gap_end : FQ_GAP_E;
+  FqCell *cur = rows, *prev = rows + W;
+  uint8_t fm;
+  cur[0].M = 0; cur[0].I = cur[0].D = FQ_NEG_INF;
+  for (int i = 1; i < b1; ++i) {
+    cur[i].M = cur[i].I = FQ_NEG_INF;
+    cur[i].D = fq_pick_gap(cur[i - 1].M, cur[i - 1].D, end_ext, fm);
+    trace[i] = (uint8_t)(fm ? 0 : 8);
+  }
+  { FqCell *t = cur; cur = prev; prev = t; }
+  const int p1_end = b2 < len2 ? b2 : len2 - 1;
+  for (int j = 1; j <= len2; ++j) {
+    int phase;
+    if (j <= p1_end) phase = 1;
+    else if (j == p1_end + 1 && j == len2 && b2 != len2 - 1) phase = 5;
+    else if (j <= len2 - b2 + 1) phase = 2;
+    else if (j < len2) phase = 3;
+    else phase = 4;
+    const int c2 = s2[j - 1];
+    uint8_t *tr = trace + (size_t)j * (size_t)W;
+    const bool endD = (phase == 5 || phase == 4);
+    int lo, hi;
+    if (phase == 1 || phase == 5) {
+      lo = 1; hi = (j + b1 <= len1 + 1) ? j + b1 - 1 : len1;
+      cur[0].M = cur[0].D = FQ_NEG_INF;
+      cur[0].I = fq_pick_gap(prev[0].M, prev[0].I, end_ext, fm);
+      tr[0] = (uint8_t)(fm ? 0 : 4);
+    } else {
+      lo = j - b2 + 1; hi = (phase == 2) ? j + b1 - 1 : len1;
+      cur[j - b2].M = cur[j - b2].I = cur[j - b2].D = FQ_NEG_INF;
+    }
+    for (int i = lo; i <= hi; ++i) {
+      uint8_t tM, tb = 0;
+      cur[i].M = fq_pick_M(prev[i - 1], fq_sm_maq(s1[i - 1], c2), tM);
+      tb = tM;
+      if (i != hi) { cur[i].I = fq_pick_gap(prev[i].M, prev[i].I, FQ_GAP_E, fm); tb |= (uint8_t)(fm ? 0 : 4); }
+      else if (phase == 1 || phase == 5) {
+        if (j + b1 - 1 > len1) { cur[i].I = fq_pick_gap(prev[i].M, prev[i].I, end_ext, fm); tb |= (uint8_t)(fm ? 0 : 4); }
+        else cur[i].I = FQ_NEG_INF;
+      } else if (phase == 2) cur[i].I = FQ_NEG_INF;
+      else { cur[i].I = fq_pick_gap(prev[i].M, prev[i].I, end_ext, fm); tb |= (uint8_t)(fm ? 0 : 4); }
+      cur[i].D = fq_pick_gap(cur[i - 1].M, cur[i - 1].D, endD ? end_ext : FQ_GAP_E, fm);
+      tb |= (uint8_t)(fm ? 0 : 8);
+      tr[i] = tb;
+    }
+    { FqCell *t = cur; cur = prev; prev = t; }
+  }
+  // traceback (stdaln.c:484-512)
+  int i = len1, j = len2, mx = prev[len1].M;
+  uint8_t tb = trace[(size_t)j * W + i];
+  int type = tb & 3, ctype = FQ_OP_M;
+  if (prev[len1].I > mx) { mx = prev[len1].I; type = (tb & 4) ? FQ_OP_I : FQ_OP_M; ctype = FQ_OP_I; }
+  if (prev[len1].D > mx) { mx = prev[len1].D; type = (tb & 8) ? FQ_OP_D : FQ_OP_M; ctype = FQ_OP_D; }
+  int n = 0, li = i, lj = j;
+  ops[n++] = (uint8_t)ctype;
+  do {
+    if (ctype == FQ_OP_M) { --i; --j; } else if (ctype == FQ_OP_I) --j; else --i;
+    ctype = type;
+    tb = trace[(size_t)j * W + i];
+    type = type == FQ_OP_M ? (tb & 3) : type == FQ_OP_I ? ((tb & 4) ? FQ_OP_I : FQ_OP_M) : ((tb & 8) ? FQ_OP_D : FQ_OP_M);
+    if (i || j) { ops[n++] = (uint8_t)ctype; li = i; lj = j; }
+  } while (i || j);
+  *n_ops = n;
+  *fi = li; *fj = lj;
+  return mx;
+}
+
+// path -> run-length cigar in alignment order (aln_path2cigar32 stdaln.c:1010-1040 + bwa_aln_path2cigar bwtaln.c:352)
+FQ_HD int fq_ops_to_cigar(const uint8_t *ops, int n_ops, uint16_t *cg, int cap) {
+  int n = 0;
+  for (int t = n_ops - 1; t >= 0; --t) {
+    if (n && (cg[n - 1] >> 14) == ops[t]) ++cg[n - 1];
+    else { if (n >= cap) return -1; cg[n++] = (uint16_t)(ops[t] << 14 | 1); }
+  }
+  return n;
+}
+
+// per-task scratch carve-up shared by the SW and refine kernels
+struct FqDpScratch {
+  uint8_t *ref, *qry, *ops, *trace;
+  int *H, *E;
+  FqCell *rows;
+};
+FQ_HD size_t fq_dp_scratch_bytes(int RL, int QL) {
+  size_t b = 0;
+  b += ((size_t)RL + 16) & ~(size_t)15;                       // ref
+  b += ((size_t)QL + 16) & ~(size_t)15;                       // qry
+  b += ((size_t)RL + QL + 16) & ~(size_t)15;                  // ops
+  b += 2 * (((size_t)RL + 2) * sizeof(int) + 15 & ~(size_t)15);   // H, E
+  b += 2 * ((size_t)RL + 1) * sizeof(FqCell) + 16;            // rows
+  b += ((size_t)RL + 1) * ((size_t)QL + 1) + 16;              // trace
+  return (b + 63) & ~(size_t)63;
+}
+FQ_HD FqDpScratch fq_dp_carve(uint8_t *base, int RL, int QL) {
+  FqDpScratch s;
+  uint8_t *p = base;
+  s.ref = p; p += ((size_t)RL + 16) & ~(size_t)15;
+  s.qry = p; p += ((size_t)QL + 16) & ~(size_t)15;
+  s.ops = p; p += ((size_t)RL + QL + 16) & ~(size_t)15;
+  s.H = (int *)p; p += ((size_t)RL + 2) * sizeof(int) + 15 & ~(size_t)15;
+  s.E = (int *)p; p += ((size_t)RL + 2) * sizeof(int) + 15 & ~(size_t)15;
+  s.rows = (FqCell *)p; p += 2 * ((size_t)RL + 1) * sizeof(FqCell) + 16;
+  p = (uint8_t *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
+  s.trace = p;
+  return s;
+}
+
+// ---- K_sw: bwa_sw_core (libbwa/bwape.c:359-445) with aln_local_core (stdaln.c:529-761) ----------
+// Scores stay far below the 32000 re-basing threshold of stdaln.c:247 for reads <= FQ_LMAX
+// (11*500 = 5500), so the overflow arm is unreachable and omitted.
+struct FqSwArgs {
+  FqDevIndex ix;
+  const uint8_t *seq;
+  int32_t stride;
+  const int32_t *len_trim;
+  const FqSwTask *task;
+  int32_t n_task;
+  FqSwOut *out;
+  uint16_t *cigar;      // [n_task][cig_cap]
+  int32_t cig_cap;
+  uint8_t *scratch;
+  size_t scratch_stride;
+  int32_t RL, QL;       // scratch dimensions
+};
+FQ_HD void fq_sw_thread(const FqSwArgs &A, int t) {
+  const FqSwTask T = A.task[t];
+  FqSwOut O;
+  O.beg = T.beg; O.cnt = 0; O.n_cigar = 0;
+  const int len = A.len_trim[T.read];
+  const uint8_t *row = A.seq + (size_t)T.read * (size_t)A.stride;
+  const int64_t l_pac = A.ix.l_pac;
+  if (T.reglen < 20 || l_pac - T.beg < len) { A.out[t] = O; return; }
+  FqDpScratch S = fq_dp_carve(A.scratch + (size_t)t * A.scratch_stride, A.RL, A.QL);
+  int nn = 0;
+  for (int k = 0; k < len; ++k) {
+    const int c = T.use_rc ? fq_comp(fq_nt4(row[len - 1 - k])) : fq_nt4(row[k]);
+    S.qry[k] = (uint8_t)c;
+    nn += c >= 4;
+  }
+  if ((float)nn / len >= 0.25f || len - nn < 20) { A.out[t] = O; return; }
+  int l1 = 0;
+  for (int64_t k = T.beg; l1 < T.reglen && k < l_pac; ++k) S.ref[l1++] = (uint8_t)fq_pac_base(A.ix.pac, k);
+  const int len1 = l1, len2 = len, q = FQ_GAP_O, rr = FQ_GAP_E, qr = q + rr;
+  int *H = S.H, *E = S.E;
+  for (int i = 0; i <= len1 + 1; ++i) H[i] = E[i] = 0;
+  int score_f = 0, end_i = 0, end_j = 0;
+  for (int j = 1; j <= len2; ++j) {
+    int last_h = 0, f = 0, diag = H[0];
+    const int c2 = S.qry[j - 1];
+    for (int i = 1; i <= len1; ++i) {
+      int h = diag + fq_sm_maq(S.ref[i - 1], c2);
+      if (h < 0) h = 0;
+      if (last_h > 0) { f = f > last_h - q ? f - rr : last_h - qr; if (h < f) h = f; }
+      const int up = H[i];
+      if (up >= qr + 1) { const int e0 = E[i - 1]; const int e = e0 > up - q ? e0 - rr : up - qr; if (h < e) h = e; E[i - 1] = e; }
+      else E[i - 1] = 0;
+      diag = up;
+      H[i - 1] = last_h;
+      last_h = h;
+      if (score_f < h) { score_f = h; end_i = i; end_j = j; }
+    }
+    H[len1] = last_h; E[len1] = 0;
+  }
+  if (score_f < 1) { A.out[t] = O; return; }
+  for (int i = end_i; i >= 0; --i) H[i] = E[i] = 0;
+  int score_r = fq_sm_maq(S.ref[end_i - 1], S.qry[end_j - 1]);
+  int start_i = end_i, start_j = end_j;
+  H[end_i] = qr + score_r; E[end_i] = 0;
+  {
+    int start = end_i - 1, end = end_i - 3;
+    if (end <= 0) end = 0;
+    for (int j = end_j - 1; j != 0; --j) {
+      int last_h = 0, f = 0, i;
+      bool stop = false;
+      const int c2 = S.qry[j - 1];
+      for (i = start; i != end; --i) {
+        int h = H[i + 1] + fq_sm_maq(S.ref[i - 1], c2);
+        if (h < 0) h = 0;
+        if (last_h > 0) { f = f > last_h - q ? f - rr : last_h - qr; if (h < f) h = f; }
+        const int side = H[i];
+        int e = E[i + 1] > side - q ? E[i + 1] - rr : side - qr;
+        if (e < 0) e = 0;
+        if (h < e) h = e;
+        H[i + 1] = last_h; E[i + 1] = e;
+        last_h = h;
+        if (score_r < h) {
+          score_r = h; start_i = i; start_j = j;
+          if (score_r - qr == score_f) { stop = true; break; }
+        }
+      }
+      H[i + 1] = last_h; E[i + 1] = 0;
+      if (stop) break;
+      if (H[start] <= qr) --start;
+      if (start <= 0) start = 0;
+      end = start_i - (start_j - j) - (score_r + (start_j - j) * 11) / rr - 1;
+      if (end <= 0) end = 0;
+    }
+  }
+  score_r -= qr;
+  int n_ops = 0, fi = 0, fj = 0, score_g;
+  {
+    const int jmax = (end_i - start_i > end_j - start_j ? end_i - start_i : end_j - start_j) + 1;
+    for (int b = FQ_BAND;; b <<= 1) {
+      score_g = fq_global_align(S.ref + start_i - 1, end_i - start_i + 1, S.qry + start_j - 1, end_j - start_j + 1, b, -1, S.rows,
+                                S.trace, S.ops, &n_ops, &fi, &fj);
+      if (score_g == score_r || score_f == score_g) break;
+      if (b > jmax) break;
+    }
+    if (score_r > score_g && score_f > score_g) { A.out[t] = O; return; }   // "Potential bug" arm: ret < 0
+    fi += start_i - 1; fj += start_j - 1;
+  }
+  uint16_t *cg = A.cigar + (size_t)t * (size_t)A.cig_cap;
+  int n_cigar = fq_ops_to_cigar(S.ops, n_ops, cg + 1, A.cig_cap - 2);   // slot 0 reserved for a leading S
+  if (n_cigar <= 0) { A.out[t] = O; return; }
+  uint32_t x = 0, y = 0;
+  for (int k = 0; k < n_cigar; ++k) {
+    const int op = cg[1 + k] >> 14, ln = cg[1 + k] & 0x3fff;
+    if (op == FQ_OP_M) { x += ln; y += ln; } else if (op == FQ_OP_D) x += ln; else y += ln;
+  }
+  if (x < 20 || y < 20) { A.out[t] = O; return; }
+  const int start = (fj ? fj : 1) - 1, endq = end_j;   // path[0].j == end_j
+  O.beg = T.beg + ((fi ? fi : 1) - 1);
+  int off = 1;
+  if (start) { cg[0] = (uint16_t)(FQ_OP_S << 14 | start); off = 0; ++n_cigar; }
+  if (endq < len) { cg[off + n_cigar] = (uint16_t)(FQ_OP_S << 14 | (len - endq)); ++n_cigar; }
+  if (off) for (int k = 0; k < n_cigar; ++k) cg[k] = cg[k + 1];
+  int n_mm = 0, n_gapo = 0, n_gape = 0;
+  x = fi ? fi - 1 : 0; y = fj ? fj - 1 : 0;
+  for (int k = 0; k < n_cigar; ++k) {
+    const int op = cg[k] >> 14, ln = cg[k] & 0x3fff;
+    if (op == FQ_OP_M) {
+      for (int u = 0; u < ln; ++u) if (S.ref[x + u] < 4 && S.qry[y + u] < 4 && S.ref[x + u] != S.qry[y + u]) ++n_mm;
+      x += ln; y += ln;
+    } else if (op == FQ_OP_D) { x += ln; ++n_gapo; n_gape += ln - 1; }
+    else if (op == FQ_OP_I) { y += ln; ++n_gapo; n_gape += ln - 1; }
+  }
+  O.cnt = (uint32_t)n_mm << 16 | (uint32_t)n_gapo << 8 | (uint32_t)n_gape;
+  O.n_cigar = n_cigar;
+  A.out[t] = O;
+}
+
+// ---- K_refine: refine_gapped_core (libbwa/bwase.c:183-232, is_end_correct=1) ---------------------
+struct FqRefineArgs {
+  FqDevIndex ix;
+  const uint8_t *seq;
+  int32_t stride;
+  const int32_t *len_trim;
+  const FqRefTask *task;
+  int32_t n_task;
+  FqRefOut *out;
+  uint16_t *cigar;
+  int32_t cig_cap;
+  uint8_t *scratch;
+  size_t scratch_stride;
+  int32_t RL, QL;
+};
+FQ_HD void fq_refine_thread(const FqRefineArgs &A, int t) {
+  const FqRefTask T = A.task[t];
+  const int len = A.len_trim[T.read];
+  const uint8_t *row = A.seq + (size_t)T.read * (size_t)A.stride;
+  const int64_t l_pac = A.ix.l_pac;
+  FqDpScratch S = fq_dp_carve(A.scratch + (size_t)t * A.scratch_stride, A.RL, A.QL);
+  for (int k = 0; k < len; ++k) S.qry[k] = (uint8_t)(T.strand ? fq_comp(fq_nt4(row[len - 1 - k])) : fq_nt4(row[k]));
+  int64_t pos = (int64_t)T.pos > l_pac ? (int64_t)(int32_t)T.pos : (int64_t)T.pos;
+  const int aext = T.ext < 0 ? -T.ext : T.ext, ref_len = len + aext;
+  int l = 0;
+  if (T.ext > 0) { for (int64_t k = pos; k < pos + ref_len && k < l_pac; ++k) S.ref[l++] = (uint8_t)fq_pac_base(A.ix.pac, k); }
+  else {
+    const int64_t x = pos + len;
+    for (int64_t k = x - ref_len > 0 ? x - ref_len : 0; k < x && k < l_pac; ++k) S.ref[l++] = (uint8_t)fq_pac_base(A.ix.pac, k);
+  }
+  int n_ops = 0, fi, fj;
+  fq_global_align(S.ref, l, S.qry, len, FQ_BAND, FQ_GAP_END, S.rows, S.trace, S.ops, &n_ops, &fi, &fj);
+  uint16_t *cg = A.cigar + (size_t)t * (size_t)A.cig_cap;
+  int n = fq_ops_to_cigar(S.ops, n_ops, cg, A.cig_cap);
+  FqRefOut O;
+  if (n <= 0) { O.pos = T.pos; O.n_cigar = 0; A.out[t] = O; return; }
+  if (T.ext < 0) {
+    int d = 0;
+    for (int k = 0; k < n; ++k) { const int op = cg[k] >> 14, ln = cg[k] & 0x3fff; if (op == FQ_OP_D) d -= ln; else if (op == FQ_OP_I) d += ln; }
+    pos += d;
+  }
+  if ((cg[0] >> 14) == FQ_OP_D) { pos += cg[0] & 0x3fff; for (int k = 0; k < n - 1; ++k) cg[k] = cg[k + 1]; --n; }
+  if ((cg[n - 1] >> 14) == FQ_OP_D) --n;
+  if ((cg[n - 1] >> 14) == FQ_OP_I) cg[n - 1] = (uint16_t)(FQ_OP_S << 14 | (cg[n - 1] & 0x3fff));
+  if ((cg[0] >> 14) == FQ_OP_I) cg[0] = (uint16_t)(FQ_OP_S << 14 | (cg[0] & 0x3fff));
+  O.pos = (uint32_t)pos; O.n_cigar = n;
+  A.out[t] = O;
+}
+
+// ---- K_md: bwa_cal_md1 (libbwa/bwase.c:234-296) ---------------------------------------------------
+struct FqMdArgs {
+  FqDevIndex ix;
+  const uint8_t *seq;
+  int32_t stride;
+  const FqMdTask *task;
+  int32_t n_task;
+  const uint16_t *cigar;   // arena referenced by task.cigar_off
+  char *md;                // [n_task][md_cap]
+  int32_t md_cap;
+  int32_t *md_len;         // out (excluding NUL); -1 on overflow
+  uint32_t *md_sz;         // out: bytes to pack (len+1, or 0 on overflow)
+  int32_t *nm;             // out
+};
+FQ_HD int fq_put_int(char *dst, int at, int cap, int v) {
+  char tmp[12]; int n = 0;
+  if (v == 0) tmp[n++] = '0';
+  while (v > 0) { tmp[n++] = (char)('0' + v % 10); v /= 10; }
+  while (n > 0) { if (at < cap) dst[at] = tmp[n - 1]; ++at; --n; }
+  return at;
+}
+FQ_HD void fq_md_thread(const FqMdArgs &A, int t) {
+  const FqMdTask T = A.task[t];
+  const uint8_t *row = A.seq + (size_t)T.read * (size_t)A.stride;
+  char *dst = A.md + (size_t)t * (size_t)A.md_cap;
+  const int cap = A.md_cap - 1;
+  const int64_t l_pac = A.ix.l_pac;
+  // the sequence MD is computed against: s->strand ? s->rseq : s->seq, over the (trimmed) length at that time
+  const int slen = T.len;
+  uint32_t x = T.pos, y = 0;
+  int u = 0, nm = 0, at = 0;
+  if (T.n_cigar) {
+    const uint16_t *cg = A.cigar + T.cigar_off;
+    for (int k = 0; k < T.n_cigar; ++k) {
+      const int op = cg[k] >> 14, l = cg[k] & 0x3fff;
+      if (op == FQ_OP_M) {
+        for (int z = 0; z < l && (int64_t)(uint32_t)(x + z) < l_pac; ++z) {
+          const int c = fq_pac_base(A.ix.pac, (int64_t)(uint32_t)(x + z));
+          const int yy = (int)y + z;
+          const int sc = T.strand ? fq_comp(fq_nt4(row[slen - 1 - yy])) : fq_nt4(row[yy]);
+          if (sc > 3 || c != sc) { at = fq_put_int(dst, at, cap, u); if (at < cap) dst[at] = "ACGTN"[c]; ++at; ++nm; u = 0; }
+          else ++u;
+        }
+        x += l; y += l;
+      } else if (op == FQ_OP_I || op == FQ_OP_S) { y += l; if (op == FQ_OP_I) nm += l; }
+      else {
+        at = fq_put_int(dst, at, cap, u);
+        if (at < cap) dst[at] = '^'; ++at;
+        for (int z = 0; z < l && (int64_t)(uint32_t)(x + z) < l_pac; ++z) { if (at < cap) dst[at] = "ACGT"[fq_pac_base(A.ix.pac, (int64_t)(uint32_t)(x + z))]; ++at; }
+        u = 0; x += l; nm += l;
+      }
+    }
+  } else {
+    for (int z = 0; z < slen; ++z) {
+      const int c = fq_pac_base(A.ix.pac, (int64_t)(uint32_t)(x + z));
+      const int sc = T.strand ? fq_comp(fq_nt4(row[slen - 1 - z])) : fq_nt4(row[z]);
+      if (sc > 3 || c != sc) { at = fq_put_int(dst, at, cap, u); if (at < cap) dst[at] = "ACGTN"[c]; ++at; ++nm; u = 0; }
+      else ++u;
+    }
+  }
+  at = fq_put_int(dst, at, cap, u);
+  if (at > cap) { A.md_len[t] = -1; A.md_sz[t] = 0; dst[0] = 0; }
+  else { dst[at] = 0; A.md_len[t] = at; A.md_sz[t] = (uint32_t)at + 1; }
+  A.nm[t] = nm;
+}

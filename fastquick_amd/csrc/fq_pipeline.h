@@ -1,0 +1,87 @@
+// fq_pipeline.h -- host-side per-batch state shared by fq_align.cpp (producer) and fq_sam.cpp (consumers)
+#pragma once
+#include <string>
+#include <vector>
+
+#include "../../include/fastquick_amd.h"
+#include "fq_common.h"
+
+struct FqMulti {             // bwt_multi1_t while it is being built
+  uint32_t pos = 0;
+  int gap = 0, mm = 0, strand = 0;
+  int aln = 0;               // hit it came from, and which row of that hit
+  uint32_t row_in_aln = 0;
+  std::vector<uint16_t> cigar;
+};
+
+struct FqRead {              // the bwa_seq_t fields the hot path writes (libbwa/bwtaln.h:57-86)
+  int r = 0;                 // row in the input batch: end*n_pairs + pair
+  int len = 0, full_len = 0, clip_len = 0;
+  int filtered = 0, type = 0, strand = 0, extra_flag = 0;
+  int n_mm = 0, n_gapo = 0, n_gape = 0, mapQ = 0, seQ = 0, score = 0;
+  uint32_t sa = 0, pos = 0, c1 = 0, c2 = 0;
+  int main_aln = 0;
+  int nm = 0;
+  bool has_md = false;
+  std::vector<FqMulti> multi;
+  std::vector<uint16_t> cigar;
+  std::string md;
+};
+
+struct FqBatchState {
+  int n_pairs = 0, n_surv = 0;
+  std::vector<int32_t> pair_idx;
+  std::vector<FqRead> reads;            // 2 per survivor pair, final state
+  std::vector<FqRead> stage_P, stage_S; // snapshots after pairing / after mate SW (debug only)
+  std::vector<FqAln> aln;               // concatenated hit lists
+  std::vector<int> s_of;                // survivor read -> search index or -1
+  std::vector<uint64_t> aln_off;
+  std::vector<uint32_t> aln_n;
+  fq_isize_t isize{};
+  // flattened C-ABI view
+  std::vector<fq_result_t> rec;
+  std::vector<uint16_t> cigar;
+  std::vector<char> md;
+  std::vector<fq_multi_t> multi;
+
+  void clear() {
+    n_pairs = n_surv = 0;
+    pair_idx.clear(); reads.clear(); stage_P.clear(); stage_S.clear(); aln.clear(); s_of.clear(); aln_off.clear(); aln_n.clear();
+    rec.clear(); cigar.clear(); md.clear(); multi.clear();
+  }
+  void flatten() {
+    rec.resize(reads.size());
+    cigar.clear(); md.clear(); multi.clear();
+    for (size_t i = 0; i < reads.size(); ++i) {
+      const FqRead &s = reads[i];
+      fq_result_t &o = rec[i];
+      o.pos = s.pos; o.sa = s.sa; o.c1 = s.c1; o.c2 = s.c2; o.score = s.score;
+      o.len = s.len; o.full_len = s.full_len; o.clip_len = s.clip_len;
+      o.type = (uint8_t)s.type; o.strand = (uint8_t)s.strand; o.filtered = (uint8_t)s.filtered; o.extra_flag = (uint8_t)s.extra_flag;
+      o.n_mm = (uint8_t)s.n_mm; o.n_gapo = (uint8_t)s.n_gapo; o.n_gape = (uint8_t)s.n_gape; o.mapQ = (uint8_t)s.mapQ;
+      o.seQ = (uint8_t)s.seQ; o.pad0 = 0; o.nm = (uint16_t)s.nm;
+      o.n_cigar = (uint16_t)s.cigar.size(); o.n_multi = (uint16_t)s.multi.size();
+      o.cigar_off = (uint32_t)cigar.size();
+      cigar.insert(cigar.end(), s.cigar.begin(), s.cigar.end());
+      if (s.has_md) { o.md_off = (uint32_t)md.size(); md.insert(md.end(), s.md.begin(), s.md.end()); md.push_back(0); }
+      else o.md_off = 0xffffffffu;
+      o.multi_off = (uint32_t)multi.size();
+      for (const FqMulti &q : s.multi) {
+        fq_multi_t m{};
+        m.pos = q.pos; m.cigar_off = (uint32_t)cigar.size(); m.n_cigar = (uint16_t)q.cigar.size(); m.gap = (uint8_t)q.gap; m.mm = (uint8_t)q.mm;
+        m.strand = (uint8_t)q.strand;
+        cigar.insert(cigar.end(), q.cigar.begin(), q.cigar.end());
+        multi.push_back(m);
+      }
+    }
+    if (cigar.empty()) cigar.push_back(0);
+    if (md.empty()) md.push_back(0);
+    if (multi.empty()) multi.push_back(fq_multi_t{});
+  }
+};
+
+struct fq_index;
+const FqBatchState *fq_ctx_state(const fq_ctx_t *c);
+const fq_index *fq_ctx_index(const fq_ctx_t *c);
+const fq_read_batch_t *fq_ctx_host_batch(const fq_ctx_t *c);
+const fq_opts_t *fq_ctx_opts(const fq_ctx_t *c);

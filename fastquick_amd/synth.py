@@ -123,68 +123,68 @@ def make_reads(ref: SynthRef, n_pairs: int, read_len: int = 150, on_target: floa
                frag_mean: float = 350.0, frag_sd: float = 30.0, qual_decay: bool = False,
                name_prefix: str = "r", indel_len_max: int = 1, chimera_frac: float = 0.0,
                name_offset: int = 0) -> ReadBatch:
-    """Vectorised read-pair synthesis.  Mates are randomly swapped (so read 1 is on either strand)."""
+    """Vectorised read-pair synthesis.  Mates are randomly swapped (so read 1 is on either strand).
+
+    Off-target pairs are i.i.d. random sequence; on-target pairs are cut from the genome inside a marker
+    window and then mutated (substitutions, optional indels / N / chimeric mates)."""
     rng = np.random.default_rng(seed)
     L = read_len
-    frag = np.clip(np.rint(rng.normal(frag_mean, frag_sd, n_pairs)).astype(np.int64), L + 10, None)
     on = rng.random(n_pairs) < on_target
-    g = ref.genome
-    # on-target: fragment start such that the fragment lies inside a marker's flank window
-    k = rng.integers(0, len(ref.marker_pos), n_pairs)
-    lo = ref.marker_pos[k] - 1 - ref.flank[k]
-    hi = ref.marker_pos[k] + ref.flank[k]              # exclusive end of window
-    span = np.maximum(hi - lo - frag, 1)
-    start = lo + (rng.random(n_pairs) * span).astype(np.int64)
-    if chimera_frac > 0:   # mate from another marker window -> exercises unpaired / SW-rescue logic
-        ch = rng.random(n_pairs) < chimera_frac
-    else:
-        ch = np.zeros(n_pairs, dtype=bool)
-    idx = np.arange(L, dtype=np.int64)
-    extra = indel_len_max + 2
-    idxx = np.arange(L + extra, dtype=np.int64)
-    r1 = g[np.clip(start[:, None] + idxx[None, :], 0, len(g) - 1)]                 # forward strand, left end (+extra)
-    end = start + frag
-    k2 = rng.integers(0, len(ref.marker_pos), n_pairs)
-    end_ch = ref.marker_pos[k2] + 50
-    end = np.where(ch, end_ch, end)
-    r2f = g[np.clip(end[:, None] - 1 - idxx[None, :], 0, len(g) - 1)]              # reverse order from right end
-    r2 = (3 - r2f).astype(np.uint8)                                                # complement -> read 2 as sequenced
-    off = ~on
-    n_off = int(off.sum())
-    if n_off:
-        r1[off] = rng.integers(0, 4, (n_off, L + extra), dtype=np.uint8)
-        r2[off] = rng.integers(0, 4, (n_off, L + extra), dtype=np.uint8)
-    reads = [r1, r2]
+    on_idx = np.flatnonzero(on)
+    n_on = len(on_idx)
     out = np.empty((2, n_pairs, L), dtype=np.uint8)
-    for e in range(2):
-        r = reads[e]
-        # indels: delete or insert `d` bases at a random interior position
-        if del_frac > 0 or ins_frac > 0:
-            u = rng.random(n_pairs)
-            dsel = (u < del_frac) & on if e == 0 else (u < del_frac * 0.5) & on
-            isel = (u >= del_frac) & (u < del_frac + ins_frac) & on
-            ppos = rng.integers(20, L - 20, n_pairs)
-            dl = rng.integers(1, indel_len_max + 1, n_pairs)
-            col = idx[None, :].repeat(n_pairs, 0)
-            src = col.copy()
-            m = dsel[:, None] & (col >= ppos[:, None])
-            src[m] += dl[:, None].repeat(L, 1)[m]
-            m2 = isel[:, None] & (col >= ppos[:, None] + dl[:, None])
-            src[m2] -= dl[:, None].repeat(L, 1)[m2]
-            body = np.take_along_axis(r, src, axis=1)
-            m3 = isel[:, None] & (col >= ppos[:, None]) & (col < ppos[:, None] + dl[:, None])
-            body[m3] = rng.integers(0, 4, int(m3.sum()), dtype=np.uint8)
-        else:
-            body = r[:, :L].copy()
-        if sub_rate > 0:
-            m = rng.random((n_pairs, L)) < sub_rate
-            body[m] = (body[m] + rng.integers(1, 4, int(m.sum()), dtype=np.uint8)) & 3
-        asc = _ACGT[body]
-        if n_rate > 0:
-            m = rng.random((n_pairs, L)) < n_rate
-            asc[m] = ord("N")
-        out[e] = asc
-    swap = rng.random(n_pairs) < 0.5
+    # off-target (and default) content: uniform random bases, generated as bytes and mapped 2 bits -> base
+    raw = rng.integers(0, 256, (2, n_pairs, (L + 3) // 4), dtype=np.uint8)
+    codes = np.empty((2, n_pairs, ((L + 3) // 4) * 4), dtype=np.uint8)
+    for k in range(4):
+        codes[:, :, k::4] = (raw >> (2 * k)) & 3
+    out[:] = _ACGT[codes[:, :, :L]]
+    del raw, codes
+    if n_on:
+        g = ref.genome
+        frag = np.clip(np.rint(rng.normal(frag_mean, frag_sd, n_on)).astype(np.int64), L + 10, None)
+        k = rng.integers(0, len(ref.marker_pos), n_on)
+        lo = ref.marker_pos[k] - 1 - ref.flank[k]
+        hi = ref.marker_pos[k] + ref.flank[k]              # exclusive end of window
+        span = np.maximum(hi - lo - frag, 1)
+        start = lo + (rng.random(n_on) * span).astype(np.int64)
+        ch = rng.random(n_on) < chimera_frac if chimera_frac > 0 else np.zeros(n_on, dtype=bool)
+        idx = np.arange(L, dtype=np.int32)
+        extra = indel_len_max + 2
+        idxx = np.arange(L + extra, dtype=np.int32)
+        r1 = g[np.clip(start.astype(np.int32)[:, None] + idxx[None, :], 0, len(g) - 1)]             # forward strand, left end (+extra)
+        end = start + frag
+        k2 = rng.integers(0, len(ref.marker_pos), n_on)
+        end = np.where(ch, ref.marker_pos[k2] + 50, end)   # chimeric mate from another marker window
+        r2f = g[np.clip(end.astype(np.int32)[:, None] - 1 - idxx[None, :], 0, len(g) - 1)]          # reverse order from right end
+        r2 = (3 - r2f).astype(np.uint8)                                            # complement -> read 2 as sequenced
+        for e, r in enumerate((r1, r2)):
+            if del_frac > 0 or ins_frac > 0:
+                u = rng.random(n_on)
+                dsel = (u < del_frac) if e == 0 else (u < del_frac * 0.5)
+                isel = (u >= del_frac) & (u < del_frac + ins_frac)
+                ppos = rng.integers(20, L - 20, n_on).astype(np.int32)
+                dl = rng.integers(1, indel_len_max + 1, n_on).astype(np.int32)
+                col = np.broadcast_to(idx[None, :], (n_on, L))
+                src = col.copy()
+                m = dsel[:, None] & (col >= ppos[:, None])
+                src[m] += np.broadcast_to(dl[:, None], (n_on, L))[m]
+                m2 = isel[:, None] & (col >= ppos[:, None] + dl[:, None])
+                src[m2] -= np.broadcast_to(dl[:, None], (n_on, L))[m2]
+                body = np.take_along_axis(r, src, axis=1)
+                m3 = isel[:, None] & (col >= ppos[:, None]) & (col < ppos[:, None] + dl[:, None])
+                body[m3] = rng.integers(0, 4, int(m3.sum()), dtype=np.uint8)
+            else:
+                body = r[:, :L].copy()
+            if sub_rate > 0:
+                m = rng.random((n_on, L), dtype=np.float32) < sub_rate
+                body[m] = (body[m] + rng.integers(1, 4, int(m.sum()), dtype=np.uint8)) & 3
+            asc = _ACGT[body]
+            if n_rate > 0:
+                m = rng.random((n_on, L), dtype=np.float32) < n_rate
+                asc[m] = ord("N")
+            out[e, on_idx] = asc
+    swap = np.flatnonzero(rng.random(n_pairs) < 0.5)
     tmp = out[0, swap].copy()
     out[0, swap] = out[1, swap]
     out[1, swap] = tmp

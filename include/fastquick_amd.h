@@ -1,0 +1,197 @@
+/* fastquick_amd.h -- C ABI of the MI355X-native FASTQuick `align` hot path.
+ *
+ * Drop-in boundary: the reference has no FFI; its seam is the batch of
+ * bwa_seq_t records that BwtMapper::PairEndMapper hands from the producer stages to its two
+ * consumers.  Each entry point below names the reference interface it replaces
+ * (paths under the Griffan/FASTQuick tree).  Plain pointers and sizes only; no C++ or torch
+ * types cross this boundary.  All functions return 0 (or a handle) on success and a negative
+ * FQ_E* code on failure -- never exit(), never a silent CPU fallback: without a usable HIP
+ * device fq_index_load()/fq_ctx_create() fail with FQ_ENODEV.
+ */
+#ifndef FASTQUICK_AMD_H
+#define FASTQUICK_AMD_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FQ_OK 0
+#define FQ_EINVAL (-1)   /* bad argument / option out of the supported range */
+#define FQ_EIO (-2)      /* index file missing or malformed */
+#define FQ_ENODEV (-3)   /* no HIP device / HIP runtime error */
+#define FQ_ENOMEM (-4)
+#define FQ_ELIMIT (-5)   /* input exceeds a documented limit (read length, batch size) */
+
+/* record vocabulary: libbwa/bwtaln.h:6-22 */
+#define FQ_TYPE_NO_MATCH 0
+#define FQ_TYPE_UNIQUE 1
+#define FQ_TYPE_REPEAT 2
+#define FQ_TYPE_MATESW 3
+#define FQ_MAX_READ_LEN 500
+
+typedef struct fq_index fq_index_t;
+typedef struct fq_ctx fq_ctx_t;
+
+/* gap_opt_t (libbwa/bwtaln.h:98-119) + pe_opt_t (:124-130): the fields the hot path reads.
+ * fq_default_opts() fills gap_init_opt() (bwtaln.c:24-48) / bwa_init_pe_opt() (bwape.c:7-20). */
+typedef struct {
+  int32_t s_mm, s_gapo, s_gape;
+  int32_t mode;               /* BWA_MODE_GAPE(1) | BWA_MODE_COMPREAD(2) [| LOGGAP(4) | NONSTOP(0x10)] */
+  int32_t indel_end_skip, max_del_occ, max_entries;
+  double fnr;                 /* >0: max_diff from bwa_cal_maxdiff(len, 0.02, fnr) */
+  int32_t max_diff, max_gapo, max_gape;
+  int32_t max_seed_diff, seed_len;
+  int32_t max_top2;
+  int32_t trim_qual;          /* --q */
+  int32_t filter_thresh;      /* --kmer_thresh; BwtIndexer RollParam.thresh (src/BwtIndexer.cpp:558) */
+  int32_t max_isize, force_isize;
+  uint32_t max_occ;
+  int32_t n_multi, N_multi;
+  int32_t is_sw;
+  double ap_prior;
+  int32_t host_threads;       /* worker threads for the per-pair host phases (0 = auto) */
+} fq_opts_t;
+
+void fq_default_opts(fq_opts_t *o);
+
+/* One batch of read pairs as produced by the FASTQ tokenizer (replaces the output side of
+ * bwa_read_seq_with_hash_dev, src/BwtMapper.cpp:476-613, before encoding/trim/filter which now
+ * run on the GPU).  Row r of end e starts at seq + ((size_t)e*n_pairs + r)*stride; ASCII bases and
+ * Sanger qualities; names are NUL-terminated rows of name_stride bytes shared by both mates. */
+typedef struct {
+  int32_t n_pairs;
+  int32_t stride;
+  const uint8_t *seq;
+  const uint8_t *qual;
+  const int32_t *len;         /* [2*n_pairs] */
+  const char *names;          /* may be NULL when only records (no SAM text) are wanted */
+  int32_t name_stride;
+} fq_read_batch_t;
+
+/* XA hit: bwt_multi1_t (libbwa/bwtaln.h:51-55) */
+typedef struct {
+  uint32_t pos;
+  uint32_t cigar_off;         /* into fq_result_batch_t.cigar */
+  uint16_t n_cigar;
+  uint8_t gap, mm;
+  uint8_t strand, pad[3];
+} fq_multi_t;
+
+/* Alignment record: the bwa_seq_t fields consumers read (libbwa/bwtaln.h:57-86; list in
+ * SURVEY.md 8b).  pos is the 0-based offset in the concatenated reduced reference. */
+typedef struct {
+  uint32_t pos, sa;
+  uint32_t c1, c2;
+  int32_t score;
+  int32_t len, full_len, clip_len;
+  uint8_t type, strand, filtered, extra_flag;
+  uint8_t n_mm, n_gapo, n_gape, mapQ;
+  uint8_t seQ, pad0;
+  uint16_t nm;
+  uint16_t n_cigar, n_multi;
+  uint32_t cigar_off;         /* bwa_cigar_t (op<<14|len) entries in .cigar */
+  uint32_t md_off;            /* NUL-terminated MD string in .md ; 0xffffffff = none */
+  uint32_t multi_off;         /* into .multi */
+} fq_result_t;
+
+/* isize_info_t, libbwa/bwape.h:92-95 */
+typedef struct {
+  double avg, std, ap_prior;
+  uint32_t low, high, high_bayesian;
+  uint32_t pad;
+} fq_isize_t;
+
+/* Results of one batch.  Only pairs with at least one unfiltered mate ("survivors") get
+ * records: rec[2*s + e] for survivor s, whose index in the input batch is pair_idx[s].
+ * Storage is owned by the context and valid until the next fq_align_* call on it. */
+typedef struct {
+  int32_t n_pairs;
+  int32_t n_survivors;
+  int32_t n_both_filtered;    /* FileStatCollector.TotalFiltered increment (src/BwtMapper.cpp:2034) */
+  int32_t n_both_unmapped;    /* BwaUnmapped increment (:2038) */
+  const int32_t *pair_idx;
+  const fq_result_t *rec;
+  const uint16_t *cigar;
+  const char *md;
+  const fq_multi_t *multi;
+  fq_isize_t isize;
+  int64_t n_bases;            /* NumBase increment */
+} fq_result_batch_t;
+
+/* ---- index ------------------------------------------------------------------------------ */
+/* Builds <fa>.pac .rpac .ann .amb .bwt .rbwt .sa .rsa (and <fa>.rollhash when write_rollhash)
+ * from a reduced reference FASTA written by `FASTQuick index` (RefBuilder::PrepareRefSeq).
+ * Replaces BwtIndexer::BuildIndex, src/BwtIndexer.cpp:716-762.  Host-only. */
+int fq_index_build(const char *fasta_path, int write_rollhash);
+
+/* Parses the index files and stages them into HBM (Occ blocks re-laid out for 32-byte lookups,
+ * sampled SA, 2-bit pac, six 2^32-bit filter bitmaps).  Replaces BwtIndexer::LoadIndex,
+ * src/BwtIndexer.cpp:803-837.  Bitmaps come from <prefix>.rollhash if present, else
+ * <prefix>.rollhash.sparse, else they are rebuilt from the FASTA itself. */
+int fq_index_load(const char *prefix, int device_ordinal, fq_index_t **out);
+void fq_index_destroy(fq_index_t *ix);
+int64_t fq_index_l_pac(const fq_index_t *ix);
+int32_t fq_index_n_contigs(const fq_index_t *ix);
+/* contig of a concatenated-reference position: bns_coor_pac2real, libbwa/bntseq.c:268 */
+int fq_index_contig(const fq_index_t *ix, int32_t id, const char **name, int64_t *offset, int32_t *len);
+
+/* ---- alignment context (one per FASTQ pair; carries drand48 state, last_ii and the (k,l)
+ * position cache exactly like BwtMapper::PairEndMapper's locals, src/BwtMapper.cpp:1811-1871) */
+int fq_ctx_create(const fq_index_t *ix, const fq_opts_t *opts, int32_t max_pairs_per_batch, fq_ctx_t **out);
+void fq_ctx_destroy(fq_ctx_t *c);
+const char *fq_ctx_last_error(const fq_ctx_t *c);
+/* keep per-stage snapshots of the records so that fq_stage_dump_last() can print them (tests only) */
+int fq_ctx_set_debug(fq_ctx_t *c, int keep_stage_snapshots);
+
+/* The whole per-batch hot path: encode+trim+filter (bwa_read_seq_with_hash_dev), gap search
+ * (bwa_cal_sa_reg_gap :63), pairing (bwa_cal_pac_pos_pe :721), mate rescue (bwa_paired_sw
+ * bwape.c:463) and refinement (bwa_refine_gapped bwase.c:339). */
+int fq_align_batch(fq_ctx_t *c, const fq_read_batch_t *in, fq_result_batch_t *out);
+
+/* Same, split so that a caller (bench.py) can stage inputs into HBM outside its timed region:
+ * fq_batch_upload copies the batch to the device; fq_align_resident runs the path on it. */
+int fq_batch_upload(fq_ctx_t *c, const fq_read_batch_t *in);
+int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out);
+
+/* ---- consumers ---------------------------------------------------------------------------
+ * SAM text in the --sam_out dialect of bwa_print_sam1 (libbwa/bwase.c:455-581): header, then the
+ * records of the last batch.  Each returns the number of bytes written (excluding NUL) or the
+ * required size if buf is too small / NULL. */
+int64_t fq_sam_header(const fq_index_t *ix, char *buf, int64_t cap);
+int64_t fq_sam_format_last(fq_ctx_t *c, char *buf, int64_t cap);
+/* canonical per-stage text dump of the last batch (tests): same format as oracle/ref_driver.cpp */
+int64_t fq_stage_dump_last(fq_ctx_t *c, char *buf, int64_t cap);
+
+/* ---- measurement -------------------------------------------------------------------------
+ * Per-kernel device time (HIP events on the context's stream) and algorithmic work counters
+ * accumulated since the last reset.  Kernel ids: see FQ_K_*. */
+#define FQ_K_PREP 0      /* encode + trim + filter + compaction */
+#define FQ_K_WIDTH 1     /* bwt_cal_width x4 */
+#define FQ_K_GAP 2       /* bwt_match_gap (the Occ-lookup kernel) */
+#define FQ_K_SA 3        /* bwt_sa over enumerated rows */
+#define FQ_K_SW 4        /* mate-rescue Smith-Waterman */
+#define FQ_K_REFINE 5    /* banded global DP + MD/NM */
+#define FQ_K_COUNT 6
+typedef struct {
+  double kernel_ms[FQ_K_COUNT];
+  uint64_t kernel_launches[FQ_K_COUNT];
+  uint64_t occ_block_touches;   /* 32-byte Occ blocks fetched by FQ_K_WIDTH+FQ_K_GAP+FQ_K_SA */
+  uint64_t gap_occ_touches;     /* ... by FQ_K_GAP alone */
+  uint64_t filter_probes;       /* bitmap probes issued by FQ_K_PREP */
+  uint64_t stack_pops, stack_pushes;
+  uint64_t sa_rows;
+  uint64_t reads_searched, pairs, sw_tasks, refine_tasks;
+  uint64_t tier_retries;        /* reads re-run with a larger search pool */
+  double host_ms_serial, host_ms_pair, host_ms_total, wall_ms_total;
+} fq_stats_t;
+void fq_stats_get(const fq_ctx_t *c, fq_stats_t *out);
+void fq_stats_reset(fq_ctx_t *c);
+
+const char *fq_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FASTQUICK_AMD_H */

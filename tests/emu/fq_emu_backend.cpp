@@ -1,0 +1,63 @@
+// tests/emu/fq_emu_backend.cpp -- TEST INFRASTRUCTURE ONLY.
+//
+// Host-loop implementation of fastquick_amd/csrc/fq_backend.h so that the CPU-only test tier
+// (`pytest -m "not gpu"`, no GPU in the build container) can exercise the host pipeline and the very same
+// per-thread kernel bodies (fq_kernels.h).  It is built into tests/emu/libfq_emu.so by tests/emu/Makefile,
+// is never built by __graft_entry__.build(), and is never loaded by the product (fastquick_amd/api.py only
+// opens an explicitly passed path; its default is the HIP library, and loading fails loudly without it).
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "fq_backend.h"
+
+namespace fqdev {
+static std::string g_err;
+int init(int) { return 0; }
+const char *last_error() { return g_err.c_str(); }
+bool is_real_gpu() { return false; }
+void *dmalloc(size_t b) { return calloc(b ? b : 16, 1); }
+void dfree(void *p) { free(p); }
+void *hmalloc(size_t b) { return malloc(b ? b : 16); }
+void hfree(void *p) { free(p); }
+int h2d(void *d, const void *s, size_t n) { if (n) memcpy(d, s, n); return 0; }
+int d2h(void *d, const void *s, size_t n) { if (n) memcpy(d, s, n); return 0; }
+int dzero(void *d, size_t n) { if (n) memset(d, 0, n); return 0; }
+int sync() { return 0; }
+void time_begin(int) {}
+void time_end(int) {}
+void time_collect(double[], uint64_t[], int) {}
+
+int launch_prep(const FqPrepArgs &a) { for (int r = 0; r < a.n_reads; ++r) fq_prep_thread(a, r); return 0; }
+int launch_compact(const uint8_t *f, int n, int32_t *read_list, int32_t *sidx, int32_t *pair_list, int32_t *counts) {
+  int ns = 0, np = 0;
+  for (int p = 0; p < n; ++p) {
+    const int f0 = f[p], f1 = f[n + p];
+    if (!(f0 && f1)) pair_list[np++] = p;
+    if (!f0) { read_list[ns] = p; sidx[p] = ns++; } else sidx[p] = -1;
+    if (!f1) { read_list[ns] = n + p; sidx[n + p] = ns++; } else sidx[n + p] = -1;
+  }
+  counts[0] = ns; counts[1] = np;
+  return 0;
+}
+int launch_width(const FqWidthArgs &a) { for (int t = 0; t < a.n_work * 4; ++t) fq_width_thread(a, t); return 0; }
+int launch_gap(const FqGapArgs &a) { for (int w = 0; w < a.n_work; ++w) fq_gap_thread(a, w); return 0; }
+int launch_scan(const uint32_t *in, uint64_t *out, uint32_t n) { uint64_t s = 0; for (uint32_t i = 0; i < n; ++i) { out[i] = s; s += in[i]; } out[n] = s; return 0; }
+int launch_pack_aln(const FqAln *aln, const uint32_t *n_aln, const uint64_t *off, uint32_t cap, uint32_t n_work, FqAln *packed) {
+  for (uint32_t w = 0; w < n_work; ++w) for (uint32_t j = 0; j < n_aln[w]; ++j) packed[off[w] + j] = aln[(size_t)w * cap + j];
+  return 0;
+}
+int launch_sa(const FqSaArgs &a) { for (uint64_t q = 0; q < a.n_rows; ++q) fq_sa_thread(a, q); return 0; }
+int launch_saq(const FqSaQueryArgs &a) { for (uint32_t q = 0; q < a.n; ++q) fq_saq_thread(a, q); return 0; }
+int launch_sw(const FqSwArgs &a) { for (int t = 0; t < a.n_task; ++t) fq_sw_thread(a, t); return 0; }
+int launch_refine(const FqRefineArgs &a) { for (int t = 0; t < a.n_task; ++t) fq_refine_thread(a, t); return 0; }
+int launch_md(const FqMdArgs &a) { for (int t = 0; t < a.n_task; ++t) fq_md_thread(a, t); return 0; }
+int launch_pack_md(const char *src, const int32_t *len, const uint64_t *off, int32_t cap, int32_t n, char *dst) {
+  for (int t = 0; t < n; ++t) if (len[t] >= 0) memcpy(dst + off[t], src + (size_t)t * cap, (size_t)len[t] + 1);
+  return 0;
+}
+int launch_bitmap_scatter(uint8_t *bitmap, const uint32_t *bits, uint64_t n) {
+  for (uint64_t i = 0; i < n; ++i) bitmap[bits[i] >> 3] |= (uint8_t)(1u << (bits[i] & 7));
+  return 0;
+}
+}  // namespace fqdev

@@ -1,0 +1,68 @@
+"""Host pipeline + kernel bodies, run through the host-loop backend (tests/emu, test infrastructure), must reproduce
+the REAL reference's golden stage dumps and SAM text.  This is the CPU-tier check of the host logic; the GPU tier
+(test_gpu_parity.py) runs the same comparisons through the HIP library."""
+import filecmp
+import os
+import subprocess
+
+import pytest
+
+import golden_util
+import oracle_binding as ob
+from fastquick_amd import api
+
+EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR])
+    return api.load_library(os.path.join(EMU_DIR, "libfq_emu.so"))
+
+
+@pytest.mark.parametrize("tag", golden_util.case_tags())
+def test_emulated_pipeline_matches_reference_golden(tag, golden_cases, emu_lib):
+    g = golden_cases[tag]
+    names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
+    ix = api.Index(g["prefix"], lib=emu_lib)
+    al = api.Aligner(ix, api.default_opts(emu_lib, trim_qual=g["trim_qual"]), max_pairs=max(16, g["batch"]), debug=True)
+    st, sam = os.path.join(g["dir"], "emu.stages"), os.path.join(g["dir"], "emu.sam")
+    api.align_stream(al, names, seq, qual, lens, g["batch"], st, sam)
+    al.close()
+    ix.close()
+    diffs = [d for d in ob.diff_stage_files(g["stages"], st) if not d.startswith("line count")]
+    assert not diffs, "\n".join(diffs)
+    assert filecmp.cmp(g["sam"], sam, shallow=False)
+
+
+def test_option_limits_are_rejected(golden_cases, emu_lib):
+    import ctypes as C
+    ix = api.Index(golden_cases["basic"]["prefix"], lib=emu_lib)
+    for kw in (dict(max_gapo=4), dict(max_gape=16), dict(seed_len=65), dict(s_mm=0), dict(fnr=-1.0, max_diff=31)):
+        h = C.c_void_p()
+        assert emu_lib.fq_ctx_create(ix.h, C.byref(api.default_opts(emu_lib, **kw)), 16, C.byref(h)) == -1, kw
+    ix.close()
+
+
+def test_read_length_limit_is_loud(golden_cases, emu_lib):
+    import numpy as np
+    ix = api.Index(golden_cases["basic"]["prefix"], lib=emu_lib)
+    al = api.Aligner(ix, max_pairs=4)
+    seq = np.full((2, 2, 40), ord("A"), dtype=np.uint8)
+    lens = np.array([[40, 20], [40, 40]], dtype=np.int32)      # 20 < BWA_MIN_RDLEN
+    with pytest.raises(api.FastquickError):
+        al.align(seq, seq, lens, [b"a", b"b"])
+    with pytest.raises(api.FastquickError):                    # batch larger than the context was sized for
+        al.align(np.zeros((2, 8, 40), np.uint8), np.zeros((2, 8, 40), np.uint8), np.full((2, 8), 40, np.int32), [b"x"] * 8)
+    al.close()
+    ix.close()
+
+
+def test_empty_batch(golden_cases, emu_lib):
+    import numpy as np
+    ix = api.Index(golden_cases["basic"]["prefix"], lib=emu_lib)
+    al = api.Aligner(ix, max_pairs=4)
+    res = al.align(np.zeros((2, 0, 150), np.uint8), np.zeros((2, 0, 150), np.uint8), np.zeros((2, 0), np.int32), [])
+    assert res.n_pairs == 0 and res.n_survivors == 0
+    al.close()
+    ix.close()
