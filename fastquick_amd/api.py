@@ -24,7 +24,7 @@ class Opts(C.Structure):
         ("max_seed_diff", C.c_int32), ("seed_len", C.c_int32), ("max_top2", C.c_int32), ("trim_qual", C.c_int32),
         ("filter_thresh", C.c_int32), ("max_isize", C.c_int32), ("force_isize", C.c_int32), ("max_occ", C.c_uint32),
         ("n_multi", C.c_int32), ("N_multi", C.c_int32), ("is_sw", C.c_int32), ("ap_prior", C.c_double),
-        ("host_threads", C.c_int32),
+        ("host_threads", C.c_int32), ("batch_pairs", C.c_int32),
     ]
 
 
@@ -56,7 +56,7 @@ class ResultBatch(C.Structure):
     _fields_ = [("n_pairs", C.c_int32), ("n_survivors", C.c_int32), ("n_both_filtered", C.c_int32),
                 ("n_both_unmapped", C.c_int32), ("pair_idx", C.POINTER(C.c_int32)), ("rec", C.POINTER(Result)),
                 ("cigar", C.POINTER(C.c_uint16)), ("md", C.c_void_p), ("multi", C.POINTER(Multi)),
-                ("isize", Isize), ("n_bases", C.c_int64)]
+                ("isize", Isize), ("n_bases", C.c_int64), ("n_sub", C.c_int32), ("isize_sub", C.POINTER(Isize))]
 
 
 class Stats(C.Structure):

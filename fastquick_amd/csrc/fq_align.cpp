@@ -124,7 +124,7 @@ extern "C" void fq_default_opts(fq_opts_t *o) {
   o->fnr = 0.02; o->max_diff = -1; o->max_gapo = 1; o->max_gape = 6;
   o->max_seed_diff = 2; o->seed_len = 32; o->max_top2 = 30; o->trim_qual = 0; o->filter_thresh = 3;
   o->max_isize = 500; o->force_isize = 0; o->max_occ = 100000; o->n_multi = 3; o->N_multi = 10; o->is_sw = 1;
-  o->ap_prior = 1e-5; o->host_threads = 0;
+  o->ap_prior = 1e-5; o->host_threads = 0; o->batch_pairs = 262144;
 }
 
 extern "C" const char *fq_version(void) { return "fastquick_amd 0.1 (gfx950)"; }
@@ -138,6 +138,7 @@ extern "C" int fq_ctx_create(const fq_index_t *ix, const fq_opts_t *opts, int32_
   if (o.max_gapo < 0 || o.max_gapo > 3 || o.max_gape < 0 || o.max_gape > 15 || o.seed_len < 1 || o.seed_len > FQ_SEED_MAX) return FQ_EINVAL;
   if (o.s_mm <= 0 || o.s_gapo <= 0 || o.s_gape <= 0) return FQ_EINVAL;   // children must score strictly more than parents (Q1)
   if (o.fnr <= 0.0 && (o.max_diff < 0 || o.max_diff > 30)) return FQ_EINVAL;
+  if (o.batch_pairs < 1) return FQ_EINVAL;
   std::unique_ptr<fq_ctx> c(new fq_ctx);
   c->ix = ix; c->o = o; c->max_pairs = max_pairs;
   int md_max = 0;
@@ -262,10 +263,10 @@ int approx_mapq(const fq_ctx *c, const FqRead &p, int mm) {   // bwa_approx_mapQ
 }
 
 // infer_isize, libbwa/bwape.c:49-117
-void infer_isize(const vector<FqRead> &R, int n_surv, int max_len_all, fq_isize_t *ii, double ap_prior, int64_t L) {
+void infer_isize(const vector<FqRead> &R, int sp_lo, int sp_hi, int max_len_all, fq_isize_t *ii, double ap_prior, int64_t L) {
   ii->avg = ii->std = -1.0; ii->low = ii->high = ii->high_bayesian = 0; ii->ap_prior = 0;
   vector<uint64_t> is;
-  for (int s = 0; s < n_surv; ++s) {
+  for (int s = sp_lo; s < sp_hi; ++s) {
     const FqRead &a = R[2 * s], &b = R[2 * s + 1];
     if (a.mapQ >= 20 && b.mapQ >= 20) {
       const uint64_t x = a.pos < b.pos ? (uint64_t)(uint32_t)(b.pos + (uint32_t)b.len - a.pos) : (uint64_t)(uint32_t)(a.pos + (uint32_t)a.len - b.pos);
@@ -407,10 +408,27 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   CK(fqdev::d2h(c->h_pair_list.data(), c->d_pair_list.p, (size_t)n_surv * 4));
   CK(fqdev::d2h(c->h_read_list.data(), c->d_read_list.p, (size_t)n_search * 4));
   CK(fqdev::sync());
+  // The call may carry several reference batches (READ_BUFFER_SIZE pairs each, src/BwtMapper.h:36): the GPU stages run
+  // over all of them at once, the order-dependent host stages walk them one reference batch at a time.
+  const int B = o.batch_pairs, n_sub = (n + B - 1) / B;
   int64_t n_bases = 0;
   int max_len_all = 1;
-  for (int r = 0; r < n2; ++r) { n_bases += c->hb.len[r]; if (c->h_len_trim[r] > max_len_all) max_len_all = c->h_len_trim[r]; }
+  vector<int> sub_max_len(n_sub, 1), sub_lo(n_sub + 1, 0);
+  for (int e = 0; e < 2; ++e)
+    for (int i = 0; i < n; ++i) {
+      const int r = e * n + i, lt = c->h_len_trim[r];
+      n_bases += c->hb.len[r];
+      if (lt > max_len_all) max_len_all = lt;
+      if (lt > sub_max_len[i / B]) sub_max_len[i / B] = lt;
+    }
+  {
+    int sp = 0;
+    for (int sb = 0; sb < n_sub; ++sb) { sub_lo[sb] = sp; while (sp < n_surv && c->h_pair_list[sp] < (int64_t)(sb + 1) * B) ++sp; }
+    sub_lo[n_sub] = n_surv;
+  }
   S.n_surv = n_surv;
+  S.batch_pairs = B;
+  S.sub_lo = sub_lo;
   S.pair_idx = c->h_pair_list;
 
   // ---- stage A: widths + gap search, tiered by stack-pool size (GPU) ----------------------------------
@@ -420,7 +438,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   vector<uint32_t> aln_n(n_search, 0);
   {
     const int Lpad = max_len_all + 1;
-    const FqGapTier tiers[3] = {{1024u, 16u, 0}, {32768u, 512u, 0}, {(uint32_t)o.max_entries + 64u, 8192u, 1}};
+    const FqGapTier tiers[3] = {{4096u, 32u, 0}, {65536u, 512u, 0}, {(uint32_t)o.max_entries + 64u, 8192u, 1}};
     const size_t chunk_reads[3] = {(size_t)1 << 20, 8192, 64};
     vector<int32_t> work(n_search), next_work;
     for (int s = 0; s < n_search; ++s) work[s] = s;
@@ -600,17 +618,27 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
     for (size_t i = 0; i < nq; ++i) R[dq_idx[i]].pos = tmp[i];
     c->stats.sa_rows += nq;
   }
-  // ---- stage B2: insert size of this batch (Q3) ---------------------------------------------------------
-  fq_isize_t ii;
-  infer_isize(R, n_surv, max_len_all, &ii, o.ap_prior, (int64_t)ix->dev.fm[0].seq_len);
-  if (ii.avg < 0.0 && c->last_ii.avg > 0.0) ii = c->last_ii;
-  if (o.force_isize) { ii.low = ii.high = 0; ii.avg = ii.std = -1.0; }
+  // ---- stage B2: insert size per reference batch, with the last_ii fallback chain (Q3) -----------------------
+  vector<fq_isize_t> iis(n_sub);
+  {
+    fq_isize_t prev = c->last_ii;
+    for (int sb = 0; sb < n_sub; ++sb) {
+      fq_isize_t ii;
+      infer_isize(R, sub_lo[sb], sub_lo[sb + 1], sub_max_len[sb], &ii, o.ap_prior, (int64_t)ix->dev.fm[0].seq_len);
+      if (ii.avg < 0.0 && prev.avg > 0.0) ii = prev;
+      if (o.force_isize) { ii.low = ii.high = 0; ii.avg = ii.std = -1.0; }
+      iis[sb] = ii;
+      prev = ii;
+    }
+  }
   const double t_serial1 = now_ms();
 
   // ---- stage B3: pairing + XA lists (per pair) -------------------------------------------------------------
   {
     vector<uint64_t> arr;
-    for (int sp = 0; sp < n_surv; ++sp) {
+    for (int sb = 0; sb < n_sub; ++sb) {
+    const fq_isize_t ii = iis[sb];
+    for (int sp = sub_lo[sb]; sp < sub_lo[sb + 1]; ++sp) {
       FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
       const FqAln *aln[2]; int na[2];
       aln[0] = aln_of(2 * sp, &na[0]); aln[1] = aln_of(2 * sp + 1, &na[1]);
@@ -646,16 +674,20 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
           for (auto &m : p[j]->multi) m.pos = h_pos[aln_row_off[base + m.aln] + m.row_in_aln];
         }
     }
+    }
   }
 
   if (c->debug) S.stage_P = R;   // snapshot for the stage dump (tests)
 
   // ---- stage C: mate rescue by Smith-Waterman (bwa_paired_sw, libbwa/bwape.c:463-625) ---------------------
-  if (o.is_sw && ii.avg >= 0.0) {
+  if (o.is_sw) {
     struct Cand { int sp, k; };
     vector<Cand> cands; vector<FqSwTask> tasks;
     int max_reg = 0, max_q = 0;
-    for (int sp = 0; sp < n_surv; ++sp) {
+    for (int sb = 0; sb < n_sub; ++sb) {
+    const fq_isize_t ii = iis[sb];
+    if (ii.avg < 0.0) continue;   // bwa_paired_sw returns before touching anything (bwape.c:477)
+    for (int sp = sub_lo[sb]; sp < sub_lo[sb + 1]; ++sp) {
       FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
       for (int j = 0; j < 2; ++j) if (p[j]->filtered) p[j]->filtered = 0;   // expand_seq: revived because its mate passed (:485-499)
       if (!((p[0]->mapQ >= 17 || p[1]->mapQ >= 17) && (p[0]->extra_flag & 2) == 0)) continue;
@@ -682,6 +714,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
         tasks.push_back(T);
         max_reg = std::max(max_reg, T.reglen); max_q = std::max(max_q, pm->len);
       }
+    }
     }
     vector<FqSwOut> souts(tasks.size());
     vector<uint16_t> scig;
@@ -712,6 +745,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
     size_t ti = 0;
     while (ti < cands.size()) {
       const int sp = cands[ti].sp;
+      const fq_isize_t &ii = iis[c->h_pair_list[sp] / B];
       FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
       const uint16_t *cigar[2] = {nullptr, nullptr};
       int n_cigar[2] = {0, 0}, mq_adjust[2] = {255, 255}, mapQ = 0;
@@ -871,11 +905,12 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
       s.len = s.full_len;
     }
   }
-  c->last_ii = ii;
+  c->last_ii = iis[n_sub - 1];
   const double t_host1 = now_ms();
 
   // ---- flatten into the C-ABI result arrays ------------------------------------------------------------------
-  S.isize = ii;
+  S.isize_sub = iis;
+  S.isize = iis[n_sub - 1];
   S.s_of = s_of;
   S.aln_off = aln_off;
   S.aln_n = aln_n;
@@ -890,7 +925,9 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   out->cigar = S.cigar.data();
   out->md = S.md.data();
   out->multi = S.multi.data();
-  out->isize = ii;
+  out->isize = iis[n_sub - 1];
+  out->n_sub = n_sub;
+  out->isize_sub = S.isize_sub.data();
   out->n_bases = n_bases;
 
   // ---- measurement ----------------------------------------------------------------------------------------------

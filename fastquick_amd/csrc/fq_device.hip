@@ -102,11 +102,100 @@ __global__ void __launch_bounds__(256) k_saq(FqSaQueryArgs a) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < a.n) fq_saq_thread(a, q);
 }
-__global__ void __launch_bounds__(64) k_sw(FqSwArgs a) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < a.n_task) fq_sw_thread(a, t);
+// ---- mate-rescue Smith-Waterman: one 64-lane wavefront per task ---------------------------------------------
+// Forward pass of aln_local_core as an anti-diagonal wavefront: lane l owns query row j0+l+1 of a 64-row
+// stripe and walks the reference columns one step behind lane l-1; H/E of the row above arrive by a one-lane
+// shuffle, the diagonal value and the row's (last_h, f) state live in registers, so the 150 x ~480 cell matrix
+// costs ~3*(480+64) steps with no memory traffic except the stripe boundary kept in LDS.  The cell rule is the
+// reference's (fq_sw_cell), the end cell is the first strict maximum in row-major order exactly as the
+// sequential scan finds it.  Lane 0 then runs the (inherently serial, data-dependent band) reverse pass and the
+// banded global fill out of LDS.
+extern __shared__ __align__(16) unsigned char fq_dyn_lds[];
+
+__global__ void __launch_bounds__(64) k_sw_wave(FqSwArgs a) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const FqSwTask T = a.task[t];
+  const int RL = a.RL, QL = a.QL;
+  // LDS carve: Hb, Eb (RL+2 ints each), rows M/I/D (RL+1 ints each), ref (RL bytes), qry (QL bytes)
+  int *Hb = (int *)fq_dyn_lds;
+  int *Eb = Hb + (RL + 2);
+  int *rM = Eb + (RL + 2), *rI = rM + (RL + 1), *rD = rI + (RL + 1);
+  uint8_t *ref = (uint8_t *)(rD + (RL + 1));
+  uint8_t *qry = ref + ((RL + 16) & ~15);
+  __shared__ int s_ok, s_len1;
+  FqSwOut O;
+  O.beg = T.beg; O.cnt = 0; O.n_cigar = 0;
+  const int len = a.len_trim[T.read];
+  const uint8_t *row = a.seq + (size_t)T.read * (size_t)a.stride;
+  const int64_t l_pac = a.ix.l_pac;
+  bool ok = !(T.reglen < 20 || l_pac - T.beg < len);
+  int len1 = 0;
+  if (ok) {
+    int nn = 0;
+    for (int k = lane; k < len; k += 64) {
+      const int c = T.use_rc ? fq_comp(fq_nt4(row[len - 1 - k])) : fq_nt4(row[k]);
+      qry[k] = (uint8_t)c;
+      nn += c >= 4;
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) nn += __shfl_xor(nn, d, 64);
+    if ((float)nn / len >= 0.25f || len - nn < 20) ok = false;
+    const int64_t avail = l_pac - T.beg;
+    len1 = (int)(avail < (int64_t)T.reglen ? avail : (int64_t)T.reglen);
+    if (len1 < 0) len1 = 0;
+    for (int k = lane; k < len1; k += 64) ref[k] = (uint8_t)fq_pac_base(a.ix.pac, T.beg + k);
+    for (int k = lane; k <= len1 + 1; k += 64) { Hb[k] = 0; Eb[k] = 0; }
+  }
+  __syncthreads();
+  if (!ok) { if (lane == 0) a.out[t] = O; return; }
+  const int len2 = len;
+  int best_h = 0, best_i = 0, best_j = 0;
+  for (int j0 = 0; j0 < len2; j0 += 64) {
+    const int j = j0 + lane + 1;
+    const bool active = j <= len2;
+    const int c2 = active ? qry[j - 1] : 4;
+    const int nrows = len2 - j0 < 64 ? len2 - j0 : 64;
+    int last_h = 0, f = 0, diag = 0, out_h = 0, out_e = 0;
+    const int steps = len1 + nrows - 1;
+    for (int st = 1; st <= steps; ++st) {
+      int up_h = __shfl_up(out_h, 1, 64), up_e = __shfl_up(out_e, 1, 64);
+      const int i = st - lane;
+      const bool in = active && i >= 1 && i <= len1;
+      if (lane == 0 && in) { up_h = Hb[i]; up_e = Eb[i]; }
+      if (in) {
+        int e_out;
+        const int h = fq_sw_cell(diag, up_h, up_e, fq_sm_maq(ref[i - 1], c2), last_h, f, e_out);
+        diag = up_h;
+        out_h = h; out_e = e_out;
+        if (best_h < h) { best_h = h; best_i = i; best_j = j; }
+        if (lane == nrows - 1) { Hb[i] = h; Eb[i] = e_out; }   // boundary for the next stripe (lane 0 read column i >= nrows-1 steps ago)
+      }
+    }
+    __syncthreads();
+  }
+  // first strict maximum in row-major order == (max h, then min j); i is that row's first maximum
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const int oh = __shfl_xor(best_h, d, 64), oi = __shfl_xor(best_i, d, 64), oj = __shfl_xor(best_j, d, 64);
+    if (oh > best_h || (oh == best_h && oh > 0 && oj < best_j)) { best_h = oh; best_i = oi; best_j = oj; }
+  }
+  if (lane == 0) {
+    FqDpScratch S = fq_dp_carve(a.scratch + (size_t)t * a.scratch_stride, RL, QL);
+    FqRowsPlanar R = {rM, rI, rD, 1};
+    fq_sw_finish(T, ref, len1, qry, len, best_h, best_i, best_j, Hb, Eb, R, S.trace, S.ops, a.cigar + (size_t)t * (size_t)a.cig_cap, a.cig_cap, O);
+    a.out[t] = O;
+  }
 }
-__global__ void __launch_bounds__(64) k_refine(FqRefineArgs a) {
+
+// ---- gapped refinement: one lane per task, the DP row lives in lane-interleaved LDS ---------------------------------
+__global__ void __launch_bounds__(64) k_refine_lds(FqRefineArgs a) {
+  const int t = blockIdx.x * 64 + threadIdx.x;
+  int *base = (int *)fq_dyn_lds;
+  const int W = a.RL + 1;
+  FqRowsPlanar R = {base + threadIdx.x, base + (size_t)W * 64 + threadIdx.x, base + (size_t)2 * W * 64 + threadIdx.x, 64};
+  if (t < a.n_task) fq_refine_task(a, t, R);
+}
+__global__ void __launch_bounds__(64) k_refine(FqRefineArgs a) {   // long reads: DP row in global memory
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < a.n_task) fq_refine_thread(a, t);
 }
@@ -330,15 +419,27 @@ int launch_saq(const FqSaQueryArgs &a) {
   FQ_HIP(hipGetLastError());
   return 0;
 }
+static const size_t kLdsBudget = 150 * 1024;
 int launch_sw(const FqSwArgs &a) {
   if (a.n_task <= 0) return 0;
-  hipLaunchKernelGGL(k_sw, dim3(nblk((uint64_t)a.n_task, 64)), dim3(64), 0, g_stream, a);
+  const size_t lds = (size_t)(2 * (a.RL + 2) + 3 * (a.RL + 1)) * 4 + ((a.RL + 16) & ~15) + ((a.QL + 16) & ~15);
+  if (lds > kLdsBudget) { g_err = "SW window too large for LDS (" + std::to_string(a.RL) + " bases)"; return -5; }
+  static bool attr_set = false;
+  if (!attr_set) { FQ_HIP(hipFuncSetAttribute((const void *)k_sw_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget)); attr_set = true; }
+  hipLaunchKernelGGL(k_sw_wave, dim3((unsigned)a.n_task), dim3(64), lds, g_stream, a);
   FQ_HIP(hipGetLastError());
   return 0;
 }
 int launch_refine(const FqRefineArgs &a) {
   if (a.n_task <= 0) return 0;
-  hipLaunchKernelGGL(k_refine, dim3(nblk((uint64_t)a.n_task, 64)), dim3(64), 0, g_stream, a);
+  const size_t lds = (size_t)3 * (a.RL + 1) * 64 * 4;
+  if (lds <= kLdsBudget) {
+    static bool attr_set = false;
+    if (!attr_set) { FQ_HIP(hipFuncSetAttribute((const void *)k_refine_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget)); attr_set = true; }
+    hipLaunchKernelGGL(k_refine_lds, dim3(nblk((uint64_t)a.n_task, 64)), dim3(64), lds, g_stream, a);
+  } else {
+    hipLaunchKernelGGL(k_refine, dim3(nblk((uint64_t)a.n_task, 64)), dim3(64), 0, g_stream, a);
+  }
   FQ_HIP(hipGetLastError());
   return 0;
 }

@@ -313,18 +313,31 @@ FQ_HD void fq_gap_thread(const FqGapArgs &A, int w) {
   push(0, len, 0, A.ix.fm[0].seq_len, 0, 0, 0, FQ_ST_M, false, 0);
   push(1, len, 0, A.ix.fm[0].seq_len, 0, 0, 0, FQ_ST_M, false, 0);
 
-  while ((m0 | m1 | m2 | m3) != 0 && status == 0) {
+  // Register forwarding of the exact-match child: it is pushed last, into the bucket its parent was just
+  // popped from (every other child scores strictly more), so it is always the next entry gap_pop returns.
+  // Keeping it in registers removes the stack round trip from the exact-extension path.
+  bool fwd_valid = false;
+  FqEntry fwd;
+  fwd.k = fwd.l = fwd.pk = 0; fwd.next = FQ_NIL;
+  int fwd_score = 0;
+
+  while ((fwd_valid || (m0 | m1 | m2 | m3) != 0) && status == 0) {
     if (n_live > (int64_t)o.max_entries) {
       if (!exact) status |= FQ_SF_ENTRY_LIMIT;
       break;
     }
     // gap_pop
-    const int b = m0 ? FQ_CTZ32(m0) : m1 ? 32 + FQ_CTZ32(m1) : m2 ? 64 + FQ_CTZ32(m2) : 96 + FQ_CTZ32(m3);
-    const uint32_t slot = head[b];
-    const FqEntry e = pool[slot];
-    if (e.next == FQ_NIL) FQ_BUCKET_CLR(b); else head[b] = e.next;
+    int b;
+    FqEntry e;
+    if (fwd_valid) { e = fwd; b = fwd_score; fwd_valid = false; }
+    else {
+      b = m0 ? FQ_CTZ32(m0) : m1 ? 32 + FQ_CTZ32(m1) : m2 ? 64 + FQ_CTZ32(m2) : 96 + FQ_CTZ32(m3);
+      const uint32_t slot = head[b];
+      e = pool[slot];
+      if (e.next == FQ_NIL) FQ_BUCKET_CLR(b); else head[b] = e.next;
+      spare = slot;
+    }
     --n_live;
-    spare = slot;
     ++c_pops;
     uint32_t k = e.k, l = e.l;
     int i = (int)(e.pk & 511);
@@ -437,11 +450,14 @@ FQ_HD void fq_gap_thread(const FqGapArgs &A, int w) {
         const int cc = (ci + j) & 3;
         const bool is_mm = (j != 4 || ci > 3);
         const uint32_t kk = f.L2[cc] + ck[cc] + 1, ll = f.L2[cc] + cl[cc];
-        if (kk <= ll) push(a, i, kk, ll, n_mm + (is_mm ? 1 : 0), n_gapo, n_gape, FQ_ST_M, is_mm, last_diff);
+        if (kk <= ll) {
+          if (is_mm) push(a, i, kk, ll, n_mm + 1, n_gapo, n_gape, FQ_ST_M, true, last_diff);
+          else { ++n_live; ++c_pushes; fwd.k = kk; fwd.l = ll; fwd.pk = fq_pack(i, a, FQ_ST_M, n_mm, n_gapo, n_gape, last_diff); fwd_score = e_score; fwd_valid = true; }
+        }
       }
     } else if (ci < 4) {
       const uint32_t kk = f.L2[ci] + ck[ci] + 1, ll = f.L2[ci] + cl[ci];
-      if (kk <= ll) push(a, i, kk, ll, n_mm, n_gapo, n_gape, FQ_ST_M, false, last_diff);
+      if (kk <= ll) { ++n_live; ++c_pushes; fwd.k = kk; fwd.l = ll; fwd.pk = fq_pack(i, a, FQ_ST_M, n_mm, n_gapo, n_gape, last_diff); fwd_score = e_score; fwd_valid = true; }
     }
   }
 #undef FQ_BUCKET_TEST
@@ -517,11 +533,29 @@ FQ_HD int fq_pick_gap(int m, int g, int ext, uint8_t &from_m) {  // set_I / set_
   from_m = 0; return g - ext;
 }
 
+// Row storage for the banded DP: one row of (M,I,D) cells updated in place.  Two layouts: a plain
+// array in global memory, and lane-interleaved LDS words (element i of lane l at [i*stride + l], so a
+// wavefront whose lanes sit at the same column is bank-conflict free).
+struct FqRowsArr {
+  FqCell *c;
+  FQ_HD FqCell get(int i) const { return c[i]; }
+  FQ_HD void set(int i, const FqCell &v) const { c[i] = v; }
+};
+struct FqRowsPlanar {
+  int *M, *I, *D;
+  int stride;
+  FQ_HD FqCell get(int i) const { FqCell v; v.M = M[i * stride]; v.I = I[i * stride]; v.D = D[i * stride]; return v; }
+  FQ_HD void set(int i, const FqCell &v) const { M[i * stride] = v.M; I[i * stride] = v.I; D[i * stride] = v.D; }
+};
+
 // Banded global alignment with end-gap penalty (aln_global_core, stdaln.c:345-525).  s1/s2 are
-// 0-based code arrays; rows/trace are caller-provided scratch: rows = 2*(len1+1) cells, trace =
-// (len2+1)*(len1+1) bytes.  ops receives the path (end -> start), returns score, *n_ops = path_len,
-// (*fi,*fj) = coordinates of the last path element (path[path_len-1]).
-FQ_HD int fq_global_align(const uint8_t *s1, int len1, const uint8_t *s2, int len2, int band, int gap_end, FqCell *rows,
+// 0-based code arrays; R holds len1+1 cells (single row, updated in place: the cell above is read
+// before it is overwritten, the diagonal one is carried in registers); trace = (len2+1)*(len1+1)
+// bytes.  ops receives the path (end -> start), returns score, *n_ops = path_len, (*fi,*fj) =
+// coordinates of the last path element (path[path_len-1]).  Band geometry, edge rules (set_end_I /
+// set_end_D, "I = -inf" on the band's right edge) and move precedence follow the reference exactly.
+template <class Rows>
+FQ_HD int fq_global_align(const uint8_t *s1, int len1, const uint8_t *s2, int len2, int band, int gap_end, const Rows &R,
                           uint8_t *trace, uint8_t *ops, int *n_ops, int *fi, int *fj) {
   if (len1 == 0 || len2 == 0) { *n_ops = 0; return 0; }
   int b1, b2;
@@ -530,20 +564,25 @@ FQ_HD int fq_global_align(const uint8_t *s1, int len1, const uint8_t *s2, int le
   if (b2 > len2) b2 = len2;
   const int W = len1 + 1;
   const int end_ext = gap_end >= 0 ? gap_end : FQ_GAP_E;
-  FqCell *cur = rows, *prev = rows + W;
   uint8_t fm;
-  cur[0].M = 0; cur[0].I = cur[0].D = FQ_NEG_INF;
-  for (int i = 1; i < b1; ++i) {
-    cur[i].M = cur[i].I = FQ_NEG_INF;
-    cur[i].D = fq_pick_gap(cur[i - 1].M, cur[i - 1].D, end_ext, fm);
-    trace[i] = (uint8_t)(fm ? 0 : 8);
+  {
+    FqCell left;
+    left.M = 0; left.I = left.D = FQ_NEG_INF;
+    R.set(0, left);
+    for (int i = 1; i < b1; ++i) {
+      FqCell c;
+      c.M = c.I = FQ_NEG_INF;
+      c.D = fq_pick_gap(left.M, left.D, end_ext, fm);
+      trace[i] = (uint8_t)(fm ? 0 : 8);
+      R.set(i, c);
+      left = c;
+    }
   }
-  { FqCell *t = cur; cur = prev; prev = t; }
   const int p1_end = b2 < len2 ? b2 : len2 - 1;
   for (int j = 1; j <= len2; ++j) {
     int phase;
     if (j <= p1_end) phase = 1;
-    else if (j == p1_end + 1 && j == len2 && b2 != len2 - 1) phase = 5;
+    else if (j == p1_end + 1 && j == len2 && b2 != len2 - 1) phase = 5;   // "last row for part 1"
     else if (j <= len2 - b2 + 1) phase = 2;
     else if (j < len2) phase = 3;
     else phase = 4;
@@ -551,37 +590,47 @@ FQ_HD int fq_global_align(const uint8_t *s1, int len1, const uint8_t *s2, int le
     uint8_t *tr = trace + (size_t)j * (size_t)W;
     const bool endD = (phase == 5 || phase == 4);
     int lo, hi;
+    FqCell diag, left;
     if (phase == 1 || phase == 5) {
       lo = 1; hi = (j + b1 <= len1 + 1) ? j + b1 - 1 : len1;
-      cur[0].M = cur[0].D = FQ_NEG_INF;
-      cur[0].I = fq_pick_gap(prev[0].M, prev[0].I, end_ext, fm);
+      diag = R.get(0);
+      left.M = left.D = FQ_NEG_INF;
+      left.I = fq_pick_gap(diag.M, diag.I, end_ext, fm);
       tr[0] = (uint8_t)(fm ? 0 : 4);
+      R.set(0, left);
     } else {
       lo = j - b2 + 1; hi = (phase == 2) ? j + b1 - 1 : len1;
-      cur[j - b2].M = cur[j - b2].I = cur[j - b2].D = FQ_NEG_INF;
+      diag = R.get(j - b2);
+      left.M = left.I = left.D = FQ_NEG_INF;
+      R.set(j - b2, left);
     }
     for (int i = lo; i <= hi; ++i) {
-      uint8_t tM, tb = 0;
-      cur[i].M = fq_pick_M(prev[i - 1], fq_sm_maq(s1[i - 1], c2), tM);
+      const FqCell up = R.get(i);
+      FqCell c;
+      uint8_t tM, tb;
+      c.M = fq_pick_M(diag, fq_sm_maq(s1[i - 1], c2), tM);
       tb = tM;
-      if (i != hi) { cur[i].I = fq_pick_gap(prev[i].M, prev[i].I, FQ_GAP_E, fm); tb |= (uint8_t)(fm ? 0 : 4); }
+      if (i != hi) { c.I = fq_pick_gap(up.M, up.I, FQ_GAP_E, fm); tb |= (uint8_t)(fm ? 0 : 4); }
       else if (phase == 1 || phase == 5) {
-        if (j + b1 - 1 > len1) { cur[i].I = fq_pick_gap(prev[i].M, prev[i].I, end_ext, fm); tb |= (uint8_t)(fm ? 0 : 4); }
-        else cur[i].I = FQ_NEG_INF;
-      } else if (phase == 2) cur[i].I = FQ_NEG_INF;
-      else { cur[i].I = fq_pick_gap(prev[i].M, prev[i].I, end_ext, fm); tb |= (uint8_t)(fm ? 0 : 4); }
-      cur[i].D = fq_pick_gap(cur[i - 1].M, cur[i - 1].D, endD ? end_ext : FQ_GAP_E, fm);
+        if (j + b1 - 1 > len1) { c.I = fq_pick_gap(up.M, up.I, end_ext, fm); tb |= (uint8_t)(fm ? 0 : 4); }
+        else c.I = FQ_NEG_INF;
+      } else if (phase == 2) c.I = FQ_NEG_INF;
+      else { c.I = fq_pick_gap(up.M, up.I, end_ext, fm); tb |= (uint8_t)(fm ? 0 : 4); }
+      c.D = fq_pick_gap(left.M, left.D, endD ? end_ext : FQ_GAP_E, fm);
       tb |= (uint8_t)(fm ? 0 : 8);
       tr[i] = tb;
+      R.set(i, c);
+      diag = up;
+      left = c;
     }
-    { FqCell *t = cur; cur = prev; prev = t; }
   }
   // traceback (stdaln.c:484-512)
-  int i = len1, j = len2, mx = prev[len1].M;
+  const FqCell last = R.get(len1);
+  int i = len1, j = len2, mx = last.M;
   uint8_t tb = trace[(size_t)j * W + i];
   int type = tb & 3, ctype = FQ_OP_M;
-  if (prev[len1].I > mx) { mx = prev[len1].I; type = (tb & 4) ? FQ_OP_I : FQ_OP_M; ctype = FQ_OP_I; }
-  if (prev[len1].D > mx) { mx = prev[len1].D; type = (tb & 8) ? FQ_OP_D : FQ_OP_M; ctype = FQ_OP_D; }
+  if (last.I > mx) { mx = last.I; type = (tb & 4) ? FQ_OP_I : FQ_OP_M; ctype = FQ_OP_I; }
+  if (last.D > mx) { mx = last.D; type = (tb & 8) ? FQ_OP_D : FQ_OP_M; ctype = FQ_OP_D; }
   int n = 0, li = i, lj = j;
   ops[n++] = (uint8_t)ctype;
   do {
@@ -606,7 +655,7 @@ FQ_HD int fq_ops_to_cigar(const uint8_t *ops, int n_ops, uint16_t *cg, int cap) 
   return n;
 }
 
-// per-task scratch carve-up shared by the SW and refine kernels
+// per-task global-memory scratch shared by the SW and refine kernels
 struct FqDpScratch {
   uint8_t *ref, *qry, *ops, *trace;
   int *H, *E;
@@ -617,8 +666,8 @@ FQ_HD size_t fq_dp_scratch_bytes(int RL, int QL) {
   b += ((size_t)RL + 16) & ~(size_t)15;                       // ref
   b += ((size_t)QL + 16) & ~(size_t)15;                       // qry
   b += ((size_t)RL + QL + 16) & ~(size_t)15;                  // ops
-  b += 2 * (((size_t)RL + 2) * sizeof(int) + 15 & ~(size_t)15);   // H, E
-  b += 2 * ((size_t)RL + 1) * sizeof(FqCell) + 16;            // rows
+  b += 2 * ((((size_t)RL + 2) * sizeof(int) + 15) & ~(size_t)15);   // H, E
+  b += ((size_t)RL + 1) * sizeof(FqCell) + 16;                // rows
   b += ((size_t)RL + 1) * ((size_t)QL + 1) + 16;              // trace
   return (b + 63) & ~(size_t)63;
 }
@@ -628,9 +677,9 @@ FQ_HD FqDpScratch fq_dp_carve(uint8_t *base, int RL, int QL) {
   s.ref = p; p += ((size_t)RL + 16) & ~(size_t)15;
   s.qry = p; p += ((size_t)QL + 16) & ~(size_t)15;
   s.ops = p; p += ((size_t)RL + QL + 16) & ~(size_t)15;
-  s.H = (int *)p; p += ((size_t)RL + 2) * sizeof(int) + 15 & ~(size_t)15;
-  s.E = (int *)p; p += ((size_t)RL + 2) * sizeof(int) + 15 & ~(size_t)15;
-  s.rows = (FqCell *)p; p += 2 * ((size_t)RL + 1) * sizeof(FqCell) + 16;
+  s.H = (int *)p; p += (((size_t)RL + 2) * sizeof(int) + 15) & ~(size_t)15;
+  s.E = (int *)p; p += (((size_t)RL + 2) * sizeof(int) + 15) & ~(size_t)15;
+  s.rows = (FqCell *)p; p += ((size_t)RL + 1) * sizeof(FqCell) + 16;
   p = (uint8_t *)(((uintptr_t)p + 15) & ~(uintptr_t)15);
   s.trace = p;
   return s;
@@ -653,48 +702,50 @@ struct FqSwArgs {
   size_t scratch_stride;
   int32_t RL, QL;       // scratch dimensions
 };
-FQ_HD void fq_sw_thread(const FqSwArgs &A, int t) {
-  const FqSwTask T = A.task[t];
-  FqSwOut O;
-  O.beg = T.beg; O.cnt = 0; O.n_cigar = 0;
-  const int len = A.len_trim[T.read];
-  const uint8_t *row = A.seq + (size_t)T.read * (size_t)A.stride;
-  const int64_t l_pac = A.ix.l_pac;
-  if (T.reglen < 20 || l_pac - T.beg < len) { A.out[t] = O; return; }
-  FqDpScratch S = fq_dp_carve(A.scratch + (size_t)t * A.scratch_stride, A.RL, A.QL);
-  int nn = 0;
-  for (int k = 0; k < len; ++k) {
-    const int c = T.use_rc ? fq_comp(fq_nt4(row[len - 1 - k])) : fq_nt4(row[k]);
-    S.qry[k] = (uint8_t)c;
-    nn += c >= 4;
-  }
-  if ((float)nn / len >= 0.25f || len - nn < 20) { A.out[t] = O; return; }
-  int l1 = 0;
-  for (int64_t k = T.beg; l1 < T.reglen && k < l_pac; ++k) S.ref[l1++] = (uint8_t)fq_pac_base(A.ix.pac, k);
-  const int len1 = l1, len2 = len, q = FQ_GAP_O, rr = FQ_GAP_E, qr = q + rr;
-  int *H = S.H, *E = S.E;
+
+// one cell of the forward pass of aln_local_core (stdaln.c:585-612); state carried by the caller
+FQ_HD int fq_sw_cell(int diag, int up, int e_up, int sc, int &last_h, int &f, int &e_out) {
+  const int q = FQ_GAP_O, r = FQ_GAP_E, qr = q + r;
+  int h = diag + sc;
+  if (h < 0) h = 0;
+  if (last_h > 0) { f = f > last_h - q ? f - r : last_h - qr; if (h < f) h = f; }
+  if (up >= qr + 1) { const int e = e_up > up - q ? e_up - r : up - qr; if (h < e) h = e; e_out = e; }
+  else e_out = 0;
+  last_h = h;
+  return h;
+}
+
+// forward pass, sequential form (H[x] = H(row,x); E[x] = E for column x+1, as the packed eh[] of the reference)
+FQ_HD void fq_sw_forward_seq(const uint8_t *ref, int len1, const uint8_t *qry, int len2, int *H, int *E, int *score_f, int *end_i, int *end_j) {
   for (int i = 0; i <= len1 + 1; ++i) H[i] = E[i] = 0;
-  int score_f = 0, end_i = 0, end_j = 0;
+  int sf = 0, ei = 0, ej = 0;
   for (int j = 1; j <= len2; ++j) {
     int last_h = 0, f = 0, diag = H[0];
-    const int c2 = S.qry[j - 1];
+    const int c2 = qry[j - 1];
     for (int i = 1; i <= len1; ++i) {
-      int h = diag + fq_sm_maq(S.ref[i - 1], c2);
-      if (h < 0) h = 0;
-      if (last_h > 0) { f = f > last_h - q ? f - rr : last_h - qr; if (h < f) h = f; }
       const int up = H[i];
-      if (up >= qr + 1) { const int e0 = E[i - 1]; const int e = e0 > up - q ? e0 - rr : up - qr; if (h < e) h = e; E[i - 1] = e; }
-      else E[i - 1] = 0;
+      int e_out;
+      const int prev_h = last_h;
+      const int h = fq_sw_cell(diag, up, E[i - 1], fq_sm_maq(ref[i - 1], c2), last_h, f, e_out);
+      E[i - 1] = e_out;
       diag = up;
-      H[i - 1] = last_h;
-      last_h = h;
-      if (score_f < h) { score_f = h; end_i = i; end_j = j; }
+      H[i - 1] = prev_h;
+      if (sf < h) { sf = h; ei = i; ej = j; }
     }
     H[len1] = last_h; E[len1] = 0;
   }
-  if (score_f < 1) { A.out[t] = O; return; }
+  *score_f = sf; *end_i = ei; *end_j = ej;
+}
+
+// everything after the forward pass: banded reverse pass (stdaln.c:626-679), global fill with band doubling
+// (:709-727), CIGAR + clipping + mismatch/gap counts (bwape.c:389-443).  H/E: len1+2 ints of scratch.
+template <class Rows>
+FQ_HD void fq_sw_finish(const FqSwTask &T, const uint8_t *ref, int len1, const uint8_t *qry, int len, int score_f, int end_i, int end_j,
+                        int *H, int *E, const Rows &R, uint8_t *trace, uint8_t *ops, uint16_t *cg, int cig_cap, FqSwOut &O) {
+  const int q = FQ_GAP_O, rr = FQ_GAP_E, qr = q + rr;
+  if (score_f < 1) return;
   for (int i = end_i; i >= 0; --i) H[i] = E[i] = 0;
-  int score_r = fq_sm_maq(S.ref[end_i - 1], S.qry[end_j - 1]);
+  int score_r = fq_sm_maq(ref[end_i - 1], qry[end_j - 1]);
   int start_i = end_i, start_j = end_j;
   H[end_i] = qr + score_r; E[end_i] = 0;
   {
@@ -703,9 +754,9 @@ FQ_HD void fq_sw_thread(const FqSwArgs &A, int t) {
     for (int j = end_j - 1; j != 0; --j) {
       int last_h = 0, f = 0, i;
       bool stop = false;
-      const int c2 = S.qry[j - 1];
+      const int c2 = qry[j - 1];
       for (i = start; i != end; --i) {
-        int h = H[i + 1] + fq_sm_maq(S.ref[i - 1], c2);
+        int h = H[i + 1] + fq_sm_maq(ref[i - 1], c2);
         if (h < 0) h = 0;
         if (last_h > 0) { f = f > last_h - q ? f - rr : last_h - qr; if (h < f) h = f; }
         const int side = H[i];
@@ -732,23 +783,21 @@ FQ_HD void fq_sw_thread(const FqSwArgs &A, int t) {
   {
     const int jmax = (end_i - start_i > end_j - start_j ? end_i - start_i : end_j - start_j) + 1;
     for (int b = FQ_BAND;; b <<= 1) {
-      score_g = fq_global_align(S.ref + start_i - 1, end_i - start_i + 1, S.qry + start_j - 1, end_j - start_j + 1, b, -1, S.rows,
-                                S.trace, S.ops, &n_ops, &fi, &fj);
+      score_g = fq_global_align(ref + start_i - 1, end_i - start_i + 1, qry + start_j - 1, end_j - start_j + 1, b, -1, R, trace, ops, &n_ops, &fi, &fj);
       if (score_g == score_r || score_f == score_g) break;
       if (b > jmax) break;
     }
-    if (score_r > score_g && score_f > score_g) { A.out[t] = O; return; }   // "Potential bug" arm: ret < 0
+    if (score_r > score_g && score_f > score_g) return;   // "Potential bug" arm of the reference: ret < 0
     fi += start_i - 1; fj += start_j - 1;
   }
-  uint16_t *cg = A.cigar + (size_t)t * (size_t)A.cig_cap;
-  int n_cigar = fq_ops_to_cigar(S.ops, n_ops, cg + 1, A.cig_cap - 2);   // slot 0 reserved for a leading S
-  if (n_cigar <= 0) { A.out[t] = O; return; }
+  int n_cigar = fq_ops_to_cigar(ops, n_ops, cg + 1, cig_cap - 2);   // slot 0 reserved for a leading S
+  if (n_cigar <= 0) return;
   uint32_t x = 0, y = 0;
   for (int k = 0; k < n_cigar; ++k) {
     const int op = cg[1 + k] >> 14, ln = cg[1 + k] & 0x3fff;
     if (op == FQ_OP_M) { x += ln; y += ln; } else if (op == FQ_OP_D) x += ln; else y += ln;
   }
-  if (x < 20 || y < 20) { A.out[t] = O; return; }
+  if (x < 20 || y < 20) return;
   const int start = (fj ? fj : 1) - 1, endq = end_j;   // path[0].j == end_j
   O.beg = T.beg + ((fi ? fi : 1) - 1);
   int off = 1;
@@ -760,13 +809,49 @@ FQ_HD void fq_sw_thread(const FqSwArgs &A, int t) {
   for (int k = 0; k < n_cigar; ++k) {
     const int op = cg[k] >> 14, ln = cg[k] & 0x3fff;
     if (op == FQ_OP_M) {
-      for (int u = 0; u < ln; ++u) if (S.ref[x + u] < 4 && S.qry[y + u] < 4 && S.ref[x + u] != S.qry[y + u]) ++n_mm;
+      for (int u = 0; u < ln; ++u) if (ref[x + u] < 4 && qry[y + u] < 4 && ref[x + u] != qry[y + u]) ++n_mm;
       x += ln; y += ln;
     } else if (op == FQ_OP_D) { x += ln; ++n_gapo; n_gape += ln - 1; }
     else if (op == FQ_OP_I) { y += ln; ++n_gapo; n_gape += ln - 1; }
   }
   O.cnt = (uint32_t)n_mm << 16 | (uint32_t)n_gapo << 8 | (uint32_t)n_gape;
   O.n_cigar = n_cigar;
+}
+
+// task prologue shared by both forms of the kernel: early-outs of bwa_sw_core (:369-373) and operand staging.
+// returns false when the task is rejected.
+FQ_HD bool fq_sw_prologue(const FqSwArgs &A, const FqSwTask &T, uint8_t *ref, uint8_t *qry, int *len_out, int *len1_out) {
+  const int len = A.len_trim[T.read];
+  const uint8_t *row = A.seq + (size_t)T.read * (size_t)A.stride;
+  const int64_t l_pac = A.ix.l_pac;
+  *len_out = len;
+  if (T.reglen < 20 || l_pac - T.beg < len) return false;
+  int nn = 0;
+  for (int k = 0; k < len; ++k) {
+    const int c = T.use_rc ? fq_comp(fq_nt4(row[len - 1 - k])) : fq_nt4(row[k]);
+    qry[k] = (uint8_t)c;
+    nn += c >= 4;
+  }
+  if ((float)nn / len >= 0.25f || len - nn < 20) return false;
+  int l1 = 0;
+  for (int64_t k = T.beg; l1 < T.reglen && k < l_pac; ++k) ref[l1++] = (uint8_t)fq_pac_base(A.ix.pac, k);
+  *len1_out = l1;
+  return true;
+}
+
+// sequential form: one thread does the whole task (host-loop test backend; also the reference point for the wave kernel)
+FQ_HD void fq_sw_thread(const FqSwArgs &A, int t) {
+  const FqSwTask T = A.task[t];
+  FqSwOut O;
+  O.beg = T.beg; O.cnt = 0; O.n_cigar = 0;
+  FqDpScratch S = fq_dp_carve(A.scratch + (size_t)t * A.scratch_stride, A.RL, A.QL);
+  int len, len1;
+  if (fq_sw_prologue(A, T, S.ref, S.qry, &len, &len1)) {
+    int score_f, end_i, end_j;
+    fq_sw_forward_seq(S.ref, len1, S.qry, len, S.H, S.E, &score_f, &end_i, &end_j);
+    FqRowsArr R = {S.rows};
+    fq_sw_finish(T, S.ref, len1, S.qry, len, score_f, end_i, end_j, S.H, S.E, R, S.trace, S.ops, A.cigar + (size_t)t * (size_t)A.cig_cap, A.cig_cap, O);
+  }
   A.out[t] = O;
 }
 
@@ -785,7 +870,8 @@ struct FqRefineArgs {
   size_t scratch_stride;
   int32_t RL, QL;
 };
-FQ_HD void fq_refine_thread(const FqRefineArgs &A, int t) {
+template <class Rows>
+FQ_HD void fq_refine_task(const FqRefineArgs &A, int t, const Rows &R) {
   const FqRefTask T = A.task[t];
   const int len = A.len_trim[T.read];
   const uint8_t *row = A.seq + (size_t)T.read * (size_t)A.stride;
@@ -801,7 +887,7 @@ FQ_HD void fq_refine_thread(const FqRefineArgs &A, int t) {
     for (int64_t k = x - ref_len > 0 ? x - ref_len : 0; k < x && k < l_pac; ++k) S.ref[l++] = (uint8_t)fq_pac_base(A.ix.pac, k);
   }
   int n_ops = 0, fi, fj;
-  fq_global_align(S.ref, l, S.qry, len, FQ_BAND, FQ_GAP_END, S.rows, S.trace, S.ops, &n_ops, &fi, &fj);
+  fq_global_align(S.ref, l, S.qry, len, FQ_BAND, FQ_GAP_END, R, S.trace, S.ops, &n_ops, &fi, &fj);
   uint16_t *cg = A.cigar + (size_t)t * (size_t)A.cig_cap;
   int n = fq_ops_to_cigar(S.ops, n_ops, cg, A.cig_cap);
   FqRefOut O;
@@ -817,6 +903,11 @@ FQ_HD void fq_refine_thread(const FqRefineArgs &A, int t) {
   if ((cg[0] >> 14) == FQ_OP_I) cg[0] = (uint16_t)(FQ_OP_S << 14 | (cg[0] & 0x3fff));
   O.pos = (uint32_t)pos; O.n_cigar = n;
   A.out[t] = O;
+}
+FQ_HD void fq_refine_thread(const FqRefineArgs &A, int t) {
+  FqDpScratch S = fq_dp_carve(A.scratch + (size_t)t * A.scratch_stride, A.RL, A.QL);
+  FqRowsArr R = {S.rows};
+  fq_refine_task(A, t, R);
 }
 
 // ---- K_md: bwa_cal_md1 (libbwa/bwase.c:234-296) ---------------------------------------------------

@@ -38,6 +38,9 @@ struct FqBatchState {
   std::vector<uint64_t> aln_off;
   std::vector<uint32_t> aln_n;
   fq_isize_t isize{};
+  std::vector<fq_isize_t> isize_sub;
+  std::vector<int> sub_lo;              // first survivor of each reference batch (+ sentinel)
+  int batch_pairs = 262144;
   // flattened C-ABI view
   std::vector<fq_result_t> rec;
   std::vector<uint16_t> cigar;

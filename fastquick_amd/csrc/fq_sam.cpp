@@ -1,6 +1,7 @@
 // fq_sam.cpp -- consumers of the alignment records: SAM text in the --sam_out dialect of
 // bwa_print_sam1 (libbwa/bwase.c:455-581; header bwase.c:593-599 + bwase.h:27-30) and the canonical
 // per-stage dump used by the parity tests (same text as oracle/ref_driver.cpp).
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -169,40 +170,46 @@ extern "C" int64_t fq_stage_dump_last(fq_ctx_t *c, char *buf, int64_t cap) {
   Out o;
   std::vector<int> surv_of(n, -1);
   for (int sp = 0; sp < S->n_surv; ++sp) surv_of[S->pair_idx[sp]] = sp;
-  o.printf("B 0 %d\n", n);
-  for (int e = 0; e < 2; ++e)
-    for (int i = 0; i < n; ++i) o.printf("F %d %d filt=%d len=%d clip=%d full=%d\n", e, i, filt[e * n + i], ltrim[e * n + i], ltrim[e * n + i], hb->len[e * n + i]);
-  for (int e = 0; e < 2; ++e)
-    for (int i = 0; i < n; ++i) {
-      const int sp = surv_of[i];
-      const int s = sp < 0 ? -1 : S->s_of[2 * sp + e];
-      const int na = s < 0 ? 0 : (int)S->aln_n[s];
-      o.printf("A %d %d n=%d", e, i, na);
-      for (int k = 0; k < na; ++k) {
-        const FqAln &a = S->aln[S->aln_off[s] + k];
-        o.printf(" %d,%d,%d,%d,%u,%u,%d", a.info & 0xff, (a.info >> 8) & 0xff, (a.info >> 16) & 0xff, (a.info >> 24) & 1, a.k, a.l, a.score);
-      }
-      o.putc('\n');
-    }
-  uint64_t a, s, p;
-  memcpy(&a, &S->isize.avg, 8); memcpy(&s, &S->isize.std, 8); memcpy(&p, &S->isize.ap_prior, 8);
-  o.printf("I avg=%016llx std=%016llx ap=%016llx low=%u high=%u hb=%u\n", (unsigned long long)a, (unsigned long long)s, (unsigned long long)p,
-           S->isize.low, S->isize.high, S->isize.high_bayesian);
-  const std::vector<FqRead> *stages[3] = {&S->stage_P, &S->stage_S, &S->reads};
-  const char tags[3] = {'P', 'S', 'R'};
-  for (int st = 0; st < 3; ++st) {
-    if (stages[st]->size() != S->reads.size()) continue;   // snapshots are only kept in debug mode
+  const int Bp = S->batch_pairs > 0 ? S->batch_pairs : n;
+  const int n_sub = n ? (n + Bp - 1) / Bp : 0;
+  for (int sb = 0; sb < n_sub; ++sb) {
+    const int i0 = sb * Bp, i1 = std::min(n, i0 + Bp);
+    o.printf("B %d %d\n", sb, i1 - i0);
     for (int e = 0; e < 2; ++e)
-      for (int i = 0; i < n; ++i) {
+      for (int i = i0; i < i1; ++i) o.printf("F %d %d filt=%d len=%d clip=%d full=%d\n", e, i - i0, filt[e * n + i], ltrim[e * n + i], ltrim[e * n + i], hb->len[e * n + i]);
+    for (int e = 0; e < 2; ++e)
+      for (int i = i0; i < i1; ++i) {
         const int sp = surv_of[i];
-        if (sp >= 0) { dump_rec(o, tags[st], e, i, (*stages[st])[2 * sp + e], st == 2); continue; }
-        FqRead d;   // both mates filtered: untouched record (bwa_clean_read_seq state + flags of BwtMapper.cpp:749)
-        d.filtered = 1; d.extra_flag = 1 | (e == 0 ? 64 : 128); d.len = ltrim[e * n + i]; d.full_len = hb->len[e * n + i];
-        if (st == 2 && d.len != d.full_len) {   // bwa_correct_trimmed touches every record
-          d.cigar.push_back((uint16_t)(FQ_OP_M << 14 | d.len)); d.cigar.push_back((uint16_t)(FQ_OP_S << 14 | (d.full_len - d.len))); d.len = d.full_len;
+        const int s = sp < 0 ? -1 : S->s_of[2 * sp + e];
+        const int na = s < 0 ? 0 : (int)S->aln_n[s];
+        o.printf("A %d %d n=%d", e, i - i0, na);
+        for (int k = 0; k < na; ++k) {
+          const FqAln &a = S->aln[S->aln_off[s] + k];
+          o.printf(" %d,%d,%d,%d,%u,%u,%d", a.info & 0xff, (a.info >> 8) & 0xff, (a.info >> 16) & 0xff, (a.info >> 24) & 1, a.k, a.l, a.score);
         }
-        dump_rec(o, tags[st], e, i, d, st == 2);
+        o.putc('\n');
       }
+    const fq_isize_t &ii = S->isize_sub[sb];
+    uint64_t a, s, p;
+    memcpy(&a, &ii.avg, 8); memcpy(&s, &ii.std, 8); memcpy(&p, &ii.ap_prior, 8);
+    o.printf("I avg=%016llx std=%016llx ap=%016llx low=%u high=%u hb=%u\n", (unsigned long long)a, (unsigned long long)s, (unsigned long long)p,
+             ii.low, ii.high, ii.high_bayesian);
+    const std::vector<FqRead> *stages[3] = {&S->stage_P, &S->stage_S, &S->reads};
+    const char tags[3] = {'P', 'S', 'R'};
+    for (int st = 0; st < 3; ++st) {
+      if (stages[st]->size() != S->reads.size()) continue;   // snapshots are only kept in debug mode
+      for (int e = 0; e < 2; ++e)
+        for (int i = i0; i < i1; ++i) {
+          const int sp = surv_of[i];
+          if (sp >= 0) { dump_rec(o, tags[st], e, i - i0, (*stages[st])[2 * sp + e], st == 2); continue; }
+          FqRead d;   // both mates filtered: untouched record (bwa_clean_read_seq state + flags of BwtMapper.cpp:749)
+          d.filtered = 1; d.extra_flag = 1 | (e == 0 ? 64 : 128); d.len = ltrim[e * n + i]; d.full_len = hb->len[e * n + i];
+          if (st == 2 && d.len != d.full_len) {   // bwa_correct_trimmed touches every record
+            d.cigar.push_back((uint16_t)(FQ_OP_M << 14 | d.len)); d.cigar.push_back((uint16_t)(FQ_OP_S << 14 | (d.full_len - d.len))); d.len = d.full_len;
+          }
+          dump_rec(o, tags[st], e, i - i0, d, st == 2);
+        }
+    }
   }
   return emit(o.s, buf, cap);
 }

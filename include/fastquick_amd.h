@@ -52,6 +52,9 @@ typedef struct {
   int32_t is_sw;
   double ap_prior;
   int32_t host_threads;       /* worker threads for the per-pair host phases (0 = auto) */
+  int32_t batch_pairs;        /* reference batch size, READ_BUFFER_SIZE = 262144 (src/BwtMapper.h:36): insert-size
+                                 inference and the last_ii chain work on consecutive groups of this many pairs, so one
+                                 call may carry many reference batches and still reproduce the reference's output */
 } fq_opts_t;
 
 void fq_default_opts(fq_opts_t *o);
@@ -118,6 +121,8 @@ typedef struct {
   const fq_multi_t *multi;
   fq_isize_t isize;
   int64_t n_bases;            /* NumBase increment */
+  int32_t n_sub;              /* reference batches in this call */
+  const fq_isize_t *isize_sub; /* their insert-size estimates; .isize is the last one */
 } fq_result_batch_t;
 
 /* ---- index ------------------------------------------------------------------------------ */
