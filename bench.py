@@ -70,24 +70,30 @@ def main() -> None:
     def make_batch(n_pairs, seed):
         """Seeded synthetic batch.  Off-target pairs are i.i.d. random bases drawn on the GPU (fast), on-target
         pairs come from fastquick_amd.synth (fragments of the marker flanks with errors) at seeded random slots."""
+        STRIDE = 160   # 16-byte aligned rows: the filter kernel then loads each read with 16-byte vector loads
         if on_frac >= 1.0:
-            return synth.make_reads(ref, n_pairs, on_target=1.0, seed=seed)
+            rb = synth.make_reads(ref, n_pairs, on_target=1.0, seed=seed)
+            seq = np.zeros((2, n_pairs, STRIDE), dtype=np.uint8)
+            qual = np.zeros((2, n_pairs, STRIDE), dtype=np.uint8)
+            seq[:, :, :150] = rb.seq
+            qual[:, :, :150] = rb.qual
+            return synth.ReadBatch(seq, qual, rb.lens, None)
         rng = np.random.default_rng(seed)
         n_on = int(rng.binomial(n_pairs, on_frac))
         g = torch.Generator(device="cuda")
         g.manual_seed(seed)
         lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device="cuda")
-        seq = np.empty((2, n_pairs, 150), dtype=np.uint8)
+        seq = np.zeros((2, n_pairs, STRIDE), dtype=np.uint8)
         step = 1 << 20
         for e in range(2):
             for a in range(0, n_pairs, step):
                 b = min(n_pairs, a + step)
                 codes = torch.randint(0, 4, (b - a, 150), device="cuda", generator=g, dtype=torch.uint8)
-                seq[e, a:b] = lut[codes.long()].cpu().numpy()
+                seq[e, a:b, :150] = lut[codes.long()].cpu().numpy()
         on = synth.make_reads(ref, max(n_on, 1), on_target=1.0, seed=seed + 1)
         slots = np.sort(rng.choice(n_pairs, size=n_on, replace=False))
-        seq[:, slots] = on.seq[:, :n_on]
-        qual = np.full((2, n_pairs, 150), ord("I"), dtype=np.uint8)
+        seq[:, slots, :150] = on.seq[:, :n_on]
+        qual = np.full((2, n_pairs, STRIDE), ord("I"), dtype=np.uint8)
         lens = np.full((2, n_pairs), 150, dtype=np.int32)
         return synth.ReadBatch(seq, qual, lens, None)
 
@@ -165,7 +171,8 @@ def main() -> None:
         "host_ms_per_step": round(agg["host_ms_total"] / args.steps, 3),
         "survivor_pairs_per_step": round(n_records / args.steps, 1),
         "work_per_step": {k: round(agg[k] / args.steps, 1) for k in ("filter_probes", "occ_block_touches", "gap_occ_touches", "stack_pops",
-                                                                     "stack_pushes", "sa_rows", "reads_searched", "sw_tasks", "refine_tasks", "tier_retries")},
+                                                                     "stack_pushes", "sa_rows", "reads_searched", "sw_tasks", "refine_tasks", "tier_retries", "reads_over_4k_pops")},
+        "max_pops_per_read": agg["max_pops_per_read"],
     }
 
     # ---- CPU baseline: the oracle (a port) on a bounded sample of the same workload, rank 0, N=1 only -----------

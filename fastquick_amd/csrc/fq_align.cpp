@@ -384,12 +384,12 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   if (n == 0) return FQ_OK;
 
   // ---- stage 0: encode + trim + filter + ordered compaction (GPU) -------------------------------------
-  CKM(c->d_len_trim.ensure(n2) && c->d_filtered.ensure(n2 + 64) && c->d_namb.ensure(n2) && c->d_read_list.ensure(n2) &&
+  CKM(c->d_len_trim.ensure(n2) && c->d_filtered.ensure(n2 + 64) && c->d_read_list.ensure(n2) &&
       c->d_sidx.ensure(n2) && c->d_pair_list.ensure(n));
   {
     FqPrepArgs a{};
     a.ix = ix->dev; a.o = c->ko; a.seq = c->d_seq.p; a.qual = c->d_qual.p; a.len = c->d_len.p; a.stride = stride; a.n_reads = n2;
-    a.len_trim = c->d_len_trim.p; a.filtered = c->d_filtered.p; a.n_amb = c->d_namb.p; a.counters = c->d_counters.p;
+    a.len_trim = c->d_len_trim.p; a.filtered = c->d_filtered.p; a.counters = c->d_counters.p;
     fqdev::time_begin(FQ_K_PREP);
     CK(fqdev::launch_prep(a));
     CK(fqdev::launch_compact(c->d_filtered.p, n, c->d_read_list.p, c->d_sidx.p, c->d_pair_list.p, c->d_counts.p));
@@ -438,7 +438,9 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   vector<uint32_t> aln_n(n_search, 0);
   {
     const int Lpad = max_len_all + 1;
-    const FqGapTier tiers[3] = {{4096u, 32u, 0}, {65536u, 512u, 0}, {(uint32_t)o.max_entries + 64u, 8192u, 1}};
+    const FqGapTier tiers[3] = {{4096u, 32u, 0}, {65535u, 512u, 0}, {(uint32_t)o.max_entries + 64u, 8192u, 1}};
+    // scores that can occur for the longest read of this call (children may exceed max_diff by one difference)
+    const int nb_need = (c->maxdiff_lut[max_len_all] + 1) * o.s_mm + o.max_gapo * o.s_gapo + o.max_gape * o.s_gape + 1;
     const size_t chunk_reads[3] = {(size_t)1 << 20, 8192, 64};
     vector<int32_t> work(n_search), next_work;
     for (int s = 0; s < n_search; ++s) work[s] = s;
@@ -464,7 +466,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
         CK(fqdev::launch_width(wa));
         fqdev::time_end(FQ_K_WIDTH);
         FqGapArgs ga{};
-        ga.ix = ix->dev; ga.o = c->ko; ga.seq = c->d_seq.p; ga.stride = stride; ga.len_trim = c->d_len_trim.p; ga.n_amb = c->d_namb.p;
+        ga.ix = ix->dev; ga.o = c->ko; ga.o.n_buckets = nb_need; ga.seq = c->d_seq.p; ga.stride = stride; ga.len_trim = c->d_len_trim.p;
         ga.read_list = c->d_read_list.p; ga.work = c->d_work.p; ga.n_work = nw; ga.maxdiff_lut = c->d_maxdiff.p;
         ga.wid_w = c->d_wid_w.p; ga.wid_bid = c->d_wid_bid.p; ga.wstride = Lpad; ga.sw_w = c->d_sw_w.p; ga.sw_bid = c->d_sw_bid.p;
         ga.pool = c->d_pool.p; ga.heads = c->d_heads.p; ga.tier = T; ga.aln = c->d_aln.p; ga.n_aln = c->d_naln.p; ga.status = c->d_status.p;
@@ -942,6 +944,8 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
     c->stats.filter_probes += cnt[FQ_C_PROBES];
     c->stats.stack_pops += cnt[FQ_C_POPS];
     c->stats.stack_pushes += cnt[FQ_C_PUSHES];
+    if (cnt[FQ_C_MAXPOPS] > c->stats.max_pops_per_read) c->stats.max_pops_per_read = cnt[FQ_C_MAXPOPS];
+    c->stats.reads_over_4k_pops += cnt[FQ_C_POPS_GT4K];
     c->stats.pairs += n;
     c->stats.host_ms_serial += t_serial1 - t_host0;
     c->stats.host_ms_pair += t_host1 - t_serial1;

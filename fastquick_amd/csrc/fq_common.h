@@ -72,9 +72,10 @@ struct FqAln {
 struct FqEntry {
   uint32_t k, l, pk, next;
 };
-// pk: i[0:9) a[9] state[10:12) n_mm[12:16) n_gapo[16:19) n_gape[19:23) last_diff[23:32)
+// pk: i[0:9) a[9] state[10:12) n_mm[12:17) n_gapo[17:19) n_gape[19:23) last_diff[23:32)
+// (fq_ctx_create validates max_diff <= 30, max_gapo <= 3, max_gape <= 15, read length <= 500 accordingly)
 FQ_HD uint32_t fq_pack(int i, int a, int st, int mm, int go, int ge, int ld) {
-  return (uint32_t)i | (uint32_t)a << 9 | (uint32_t)st << 10 | (uint32_t)mm << 12 | (uint32_t)go << 16 | (uint32_t)ge << 19 |
+  return (uint32_t)i | (uint32_t)a << 9 | (uint32_t)st << 10 | (uint32_t)mm << 12 | (uint32_t)go << 17 | (uint32_t)ge << 19 |
          (uint32_t)ld << 23;
 }
 
@@ -122,4 +123,4 @@ struct FqMdTask {
 };
 
 // work counters written by kernels (one u64 each, atomically accumulated per wave)
-enum { FQ_C_OCC_WIDTH = 0, FQ_C_OCC_GAP, FQ_C_OCC_SA, FQ_C_PROBES, FQ_C_POPS, FQ_C_PUSHES, FQ_C_COUNT };
+enum { FQ_C_OCC_WIDTH = 0, FQ_C_OCC_GAP, FQ_C_OCC_SA, FQ_C_PROBES, FQ_C_POPS, FQ_C_PUSHES, FQ_C_MAXPOPS, FQ_C_POPS_GT4K, FQ_C_COUNT };

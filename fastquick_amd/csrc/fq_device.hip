@@ -94,6 +94,16 @@ __global__ void __launch_bounds__(256) k_gap(FqGapArgs a) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w < a.n_work) fq_gap_thread(a, w);
 }
+extern __shared__ __align__(16) unsigned char fq_dyn_lds[];
+// one wavefront per block; per lane: n_buckets 16-bit bucket heads + 2*(wlen) + 2*(slen) bid bytes, lane-interleaved
+__global__ void __launch_bounds__(64) k_gap_lds(FqGapArgs a, int n_buckets, int wlen, int slen) {
+  const int w = blockIdx.x * 64 + threadIdx.x;
+  uint16_t *heads = (uint16_t *)fq_dyn_lds;
+  uint8_t *wb = (uint8_t *)(heads + (size_t)n_buckets * 64);
+  uint8_t *sb = wb + (size_t)2 * wlen * 64;
+  FqGapStoreLds st = {heads + threadIdx.x, wb + threadIdx.x, sb + threadIdx.x, 64, wlen, slen};
+  if (w < a.n_work) fq_gap_thread_lds(a, w, st);
+}
 __global__ void __launch_bounds__(256) k_sa(FqSaArgs a) {
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q < a.n_rows) fq_sa_thread(a, q);
@@ -110,8 +120,6 @@ __global__ void __launch_bounds__(256) k_saq(FqSaQueryArgs a) {
 // reference's (fq_sw_cell), the end cell is the first strict maximum in row-major order exactly as the
 // sequential scan finds it.  Lane 0 then runs the (inherently serial, data-dependent band) reverse pass and the
 // banded global fill out of LDS.
-extern __shared__ __align__(16) unsigned char fq_dyn_lds[];
-
 __global__ void __launch_bounds__(64) k_sw_wave(FqSwArgs a) {
   const int t = blockIdx.x, lane = threadIdx.x;
   const FqSwTask T = a.task[t];
@@ -397,7 +405,16 @@ int launch_width(const FqWidthArgs &a) {
 }
 int launch_gap(const FqGapArgs &a) {
   if (a.n_work <= 0) return 0;
-  hipLaunchKernelGGL(k_gap, dim3(nblk((uint64_t)a.n_work, 256)), dim3(256), 0, g_stream, a);
+  // LDS-resident heads/bids when slot indices fit 16 bits and the per-wave footprint leaves >= 2 waves per CU
+  const int n_buckets = a.o.n_buckets, wlen = a.wstride, slen = a.o.seed_len + 1;
+  const size_t lds = (size_t)64 * ((size_t)n_buckets * 2 + 2 * (size_t)wlen + 2 * (size_t)slen);
+  if (a.tier.pool_cap <= 65535u && lds <= 72 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) { FQ_HIP(hipFuncSetAttribute((const void *)k_gap_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024)); attr_set = true; }
+    hipLaunchKernelGGL(k_gap_lds, dim3(nblk((uint64_t)a.n_work, 64)), dim3(64), lds, g_stream, a, n_buckets, wlen, slen);
+  } else {
+    hipLaunchKernelGGL(k_gap, dim3(nblk((uint64_t)a.n_work, 256)), dim3(256), 0, g_stream, a);
+  }
   FQ_HIP(hipGetLastError());
   return 0;
 }

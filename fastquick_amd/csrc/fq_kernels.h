@@ -13,7 +13,9 @@
 #define FQ_POPC64(x) __popcll(x)
 #define FQ_CTZ32(x) (__ffs((int)(x)) - 1)
 #define FQ_ATOMIC_ADD64(p, v) atomicAdd((unsigned long long *)(p), (unsigned long long)(v))
+#define FQ_ATOMIC_MAX64(p, v) atomicMax((unsigned long long *)(p), (unsigned long long)(v))
 #else
+#define FQ_ATOMIC_MAX64(p, v) (*(p) = *(p) > (uint64_t)(v) ? *(p) : (uint64_t)(v))
 #define FQ_POPC64(x) __builtin_popcountll(x)
 #define FQ_CTZ32(x) __builtin_ctz(x)
 #define FQ_ATOMIC_ADD64(p, v) (*(p) += (v))
@@ -95,7 +97,6 @@ struct FqPrepArgs {
   int32_t stride, n_reads;
   int32_t *len_trim;     // out: p->len (== clip_len)
   uint8_t *filtered;     // out: 1 = filtered
-  int32_t *n_amb;        // out: N count over the trimmed read
   uint64_t *counters;
 };
 FQ_HD uint32_t fq_kmer_project(uint64_t kmer, int t) {
@@ -108,6 +109,14 @@ FQ_HD uint32_t fq_kmer_project(uint64_t kmer, int t) {
     default: return (uint32_t)((((kmer >> 32) & 0xffff) << 16) | (kmer & 0xffff));
   }
 }
+// branch-free nst_nt4_table for one ASCII byte: A/a 0, C/c 1, G/g 2, T/t 3, '-' 5, anything else 4
+FQ_HD uint32_t fq_nt4_fast(uint32_t ch) {
+  const uint32_t u = ch & 0xDFu;                                  // fold case
+  const uint32_t code = ((ch >> 1) ^ (ch >> 2)) & 3u;              // A0 C1 G2 T3 for the four letters
+  const bool acgt = (u == 0x41u) | (u == 0x43u) | (u == 0x47u) | (u == 0x54u);
+  return acgt ? code : (ch == 0x2Du ? 5u : 4u);
+}
+
 FQ_HD void fq_prep_thread(const FqPrepArgs &A, int r) {
   const uint8_t *row = A.seq + (size_t)r * (size_t)A.stride;
   const int full = A.len[r];
@@ -123,28 +132,58 @@ FQ_HD void fq_prep_thread(const FqPrepArgs &A, int r) {
     len = max_l + 1;
   }
   A.len_trim[r] = len;
-  int namb = 0;
-  for (int i = 0; i < len; ++i) namb += fq_nt4(row[i]) > 3;
-  A.n_amb[r] = namb;
   uint8_t filt = 0;
   if (A.o.filter_thresh != 0) {
-    int count = 0;
-    uint32_t probes = 0;
-    filt = 1;
-    for (int ch = 0; ch < 3 && filt; ++ch) {
-      uint64_t kmer = 0;
-      for (int j = 0; j < 32; ++j) {
-        const int p = 32 * ch + j;
-        const uint64_t c = p < full ? (uint64_t)fq_nt4(row[p]) : 0;  // beyond the read: zero (Q7 fence)
-        kmer = (kmer << 2) | c;                                     // N (4) OR-ed unmasked like the reference
+    // the first 96 bases as 24 little-endian words: six 16-byte loads when rows are 16-byte aligned
+    uint32_t w[24];
+    if ((((uintptr_t)row) & 15) == 0 && full >= 96) {
+#if defined(__HIP_DEVICE_COMPILE__)
+      const uint4 *v = (const uint4 *)row;
+#pragma unroll
+      for (int j = 0; j < 6; ++j) { const uint4 t = v[j]; w[4 * j] = t.x; w[4 * j + 1] = t.y; w[4 * j + 2] = t.z; w[4 * j + 3] = t.w; }
+#else
+      for (int j = 0; j < 24; ++j) w[j] = (uint32_t)row[4 * j] | (uint32_t)row[4 * j + 1] << 8 | (uint32_t)row[4 * j + 2] << 16 | (uint32_t)row[4 * j + 3] << 24;
+#endif
+    } else {
+      for (int j = 0; j < 24; ++j) {
+        uint32_t x = 0;
+        for (int b = 0; b < 4; ++b) { const int p = 4 * j + b; x |= (uint32_t)(p < full ? row[p] : (uint8_t)'A') << (8 * b); }   // beyond the read: code 0 (Q7 fence)
+        w[j] = x;
       }
-      for (int t = 0; t < 6; ++t) {
-        const uint32_t x = fq_kmer_project(kmer, t);
-        ++probes;
-        if (A.ix.bitmap[t][x >> 3] & (1u << (x & 7))) ++count;
-      }
-      if (count >= A.o.filter_thresh) filt = 0;
     }
+    uint64_t kmer[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      uint64_t k = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t x = w[8 * ch + j];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) k = (k << 2) | (uint64_t)fq_nt4_fast((x >> (8 * b)) & 0xffu);   // N (4) is OR-ed unmasked, as the reference does
+      }
+      kmer[ch] = k;
+    }
+    // all 18 probes are issued before any is consumed (off-target reads need every one; memory-level parallelism)
+    uint8_t byte[18];
+    uint32_t bit[18];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        const uint32_t x = fq_kmer_project(kmer[ch], t);
+        byte[6 * ch + t] = A.ix.bitmap[t][x >> 3];
+        bit[6 * ch + t] = x & 7u;
+      }
+    int cnt[3] = {0, 0, 0};
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+      for (int t = 0; t < 6; ++t) cnt[ch] += (byte[6 * ch + t] >> bit[6 * ch + t]) & 1;
+    const int th = A.o.filter_thresh;
+    // early-exit semantics of IsReadInHashByCountMoreChunck: pass as soon as the running count reaches thresh
+    const bool p0 = cnt[0] >= th, p1 = cnt[0] + cnt[1] >= th, p2 = cnt[0] + cnt[1] + cnt[2] >= th;
+    filt = p2 ? 0 : 1;
+    const uint32_t probes = p0 ? 6u : p1 ? 12u : 18u;   // what the reference would have issued (algorithmic count)
     FQ_ATOMIC_ADD64(&A.counters[FQ_C_PROBES], probes);
   }
   A.filtered[r] = filt;
@@ -225,7 +264,6 @@ struct FqGapArgs {
   const uint8_t *seq;
   int32_t stride;
   const int32_t *len_trim;
-  const int32_t *n_amb;
   const int32_t *read_list;
   const int32_t *work;
   int32_t n_work;
@@ -244,7 +282,34 @@ struct FqGapArgs {
   uint64_t *counters;
 };
 
-FQ_HD void fq_gap_thread(const FqGapArgs &A, int w) {
+// Where a read's bucket heads and width "bid" bytes live during the search: HBM (any pool size / read length) or
+// lane-interleaved LDS (pool <= 65535 entries: 16-bit heads), which takes the head read-modify-write of every push
+// and the bid lookups of every pop off the global-memory latency chain.
+struct FqGapStoreGlobal {
+  uint32_t *head;
+  uint8_t *wb;          // [2][wstride]
+  const uint8_t *sb;    // [2][FQ_SEED_MAX+1]
+  int wstride;
+  FQ_HD uint32_t head_get(int b) const { return head[b]; }
+  FQ_HD void head_set(int b, uint32_t slot) const { head[b] = slot; }
+  FQ_HD int bid(int a, int i) const { return wb[(size_t)a * (size_t)wstride + i]; }
+  FQ_HD void bid_set(int a, int i, int v) const { wb[(size_t)a * (size_t)wstride + i] = (uint8_t)v; }
+  FQ_HD int sbid(int a, int i) const { return sb[a * (FQ_SEED_MAX + 1) + i]; }
+};
+struct FqGapStoreLds {
+  uint16_t *head;       // element b at head[b*stride]
+  uint8_t *wb;          // element (a,i) at wb[(a*wlen + i)*stride]
+  uint8_t *sb;          // element (a,i) at sb[(a*slen + i)*stride]
+  int stride, wlen, slen;
+  FQ_HD uint32_t head_get(int b) const { return head[b * stride]; }
+  FQ_HD void head_set(int b, uint32_t slot) const { head[b * stride] = (uint16_t)slot; }
+  FQ_HD int bid(int a, int i) const { return wb[(a * wlen + i) * stride]; }
+  FQ_HD void bid_set(int a, int i, int v) const { wb[(a * wlen + i) * stride] = (uint8_t)v; }
+  FQ_HD int sbid(int a, int i) const { return sb[(a * slen + i) * stride]; }
+};
+
+template <class St>
+FQ_HD void fq_gap_run(const FqGapArgs &A, int w, const St &store) {
   const FqKOpts &o = A.o;
   const int s = A.work ? A.work[w] : w;
   const int r = A.read_list[s];
@@ -256,15 +321,16 @@ FQ_HD void fq_gap_thread(const FqGapArgs &A, int w) {
   const bool gape_mode = (o.mode & FQ_MODE_GAPE) != 0, nonstop = (o.mode & FQ_MODE_NONSTOP) != 0;
   A.n_aln[w] = 0;
   A.status[w] = 0;
-  if (A.n_amb[r] > max_diff_opt) return;
+  {   // "too many N" early-out of bwt_match_gap (bwtgap.c:118-124)
+    int n_amb = 0;
+    for (int j = 0; j < len; ++j) n_amb += fq_nt4(v.row[j]) > 3;
+    if (n_amb > max_diff_opt) return;
+  }
 
-  uint32_t *const head = A.heads + (size_t)w * FQ_MAX_BUCKETS;
   FqEntry *const pool = A.pool + (size_t)w * (size_t)A.tier.pool_cap;
   FqAln *const aln = A.aln + (size_t)w * (size_t)A.tier.aln_cap;
   uint32_t *const wbase_w = A.wid_w + (size_t)w * 2 * (size_t)A.wstride;
-  uint8_t *const wbase_b = A.wid_bid + (size_t)w * 2 * (size_t)A.wstride;
   const uint32_t *const sbase_w = A.sw_w + (size_t)w * 2 * (FQ_SEED_MAX + 1);
-  const uint8_t *const sbase_b = A.sw_bid + (size_t)w * 2 * (FQ_SEED_MAX + 1);
 
   uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;   // bucket occupancy
   uint32_t bump = 0, spare = FQ_NIL, status = 0;
@@ -304,9 +370,9 @@ FQ_HD void fq_gap_thread(const FqGapArgs &A, int w) {
     FqEntry e;
     e.k = k; e.l = l;
     e.pk = fq_pack(i, a, st, mm, go, ge, is_diff ? i : parent_ld);   // Q1: non-diff pushes inherit last_diff_pos
-    e.next = FQ_BUCKET_TEST(score) ? head[score] : FQ_NIL;
+    e.next = FQ_BUCKET_TEST(score) ? store.head_get(score) : FQ_NIL;
     pool[slot] = e;
-    head[score] = slot;
+    store.head_set(score, slot);
     FQ_BUCKET_SET(score);
   };
 
@@ -332,16 +398,16 @@ FQ_HD void fq_gap_thread(const FqGapArgs &A, int w) {
     if (fwd_valid) { e = fwd; b = fwd_score; fwd_valid = false; }
     else {
       b = m0 ? FQ_CTZ32(m0) : m1 ? 32 + FQ_CTZ32(m1) : m2 ? 64 + FQ_CTZ32(m2) : 96 + FQ_CTZ32(m3);
-      const uint32_t slot = head[b];
+      const uint32_t slot = store.head_get(b);
       e = pool[slot];
-      if (e.next == FQ_NIL) FQ_BUCKET_CLR(b); else head[b] = e.next;
+      if (e.next == FQ_NIL) FQ_BUCKET_CLR(b); else store.head_set(b, e.next);
       spare = slot;
     }
     --n_live;
     ++c_pops;
     uint32_t k = e.k, l = e.l;
     int i = (int)(e.pk & 511);
-    const int a = (int)(e.pk >> 9) & 1, st = (int)(e.pk >> 10) & 3, n_mm = (int)(e.pk >> 12) & 15, n_gapo = (int)(e.pk >> 16) & 7,
+    const int a = (int)(e.pk >> 9) & 1, st = (int)(e.pk >> 10) & 3, n_mm = (int)(e.pk >> 12) & 31, n_gapo = (int)(e.pk >> 17) & 3,
               n_gape = (int)(e.pk >> 19) & 15, last_diff = (int)(e.pk >> 23);
     const int e_score = b;
     if (!nonstop && e_score > best_score + o.s_mm) break;
@@ -350,12 +416,11 @@ FQ_HD void fq_gap_thread(const FqGapArgs &A, int w) {
     if (m < 0) continue;
     const FqFM &f = A.ix.fm[1 - a];
     uint32_t *const ww = wbase_w + (size_t)a * (size_t)A.wstride;
-    uint8_t *const wb = wbase_b + (size_t)a * (size_t)A.wstride;
     if (use_seed) {
       m_seed = o.max_seed_diff - (n_mm + n_gapo);
       if (gape_mode) m_seed -= n_gape;
     }
-    if (i > 0 && m < (int)wb[i - 1]) continue;
+    if (i > 0 && m < store.bid(a, i - 1)) continue;
     bool hit = false;
     if (i == 0) hit = true;
     else if (m == 0 && (st == FQ_ST_M || gape_mode || n_gape == o.max_gape)) {
@@ -392,7 +457,7 @@ FQ_HD void fq_gap_thread(const FqGapArgs &A, int w) {
         for (int t = 0; t < last_diff; ++t) {
           const uint32_t cur = ww[t];
           if (cur > x) ww[t] = cur - x;
-          else if (cur == x) { wb[t] = 1; ww[t] = mx - (++jj); }
+          else if (cur == x) { store.bid_set(a, t, 1); ww[t] = mx - (++jj); }
         }
         if (n_aln >= A.tier.aln_cap) { status |= FQ_SF_ALN_OVERFLOW; break; }
         FqAln h;
@@ -411,13 +476,12 @@ FQ_HD void fq_gap_thread(const FqGapArgs &A, int w) {
     bool allow_diff = true, allow_M = true;
     if (i > 0) {
       const int ii = i - (len - seed_len);
-      const int b1 = wb[i - 1], b0 = wb[i];
+      const int b1 = store.bid(a, i - 1), b0 = store.bid(a, i);
       if (b1 > m - 1) allow_diff = false;
       else if (b1 == m - 1 && b0 == m - 1 && ww[i - 1] == ww[i]) allow_M = false;
       if (use_seed && ii > 0) {
-        const uint8_t *sb = sbase_b + (size_t)a * (FQ_SEED_MAX + 1);
         const uint32_t *sw = sbase_w + (size_t)a * (FQ_SEED_MAX + 1);
-        const int s1 = sb[ii - 1], s0 = sb[ii];
+        const int s1 = store.sbid(a, ii - 1), s0 = store.sbid(a, ii);
         if (s1 > m_seed - 1) allow_diff = false;
         else if (s1 == m_seed - 1 && s0 == m_seed - 1 && sw[ii - 1] == sw[ii]) allow_M = false;
       }
@@ -467,7 +531,27 @@ FQ_HD void fq_gap_thread(const FqGapArgs &A, int w) {
   A.status[w] = status;
   FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS], c_pops);
   FQ_ATOMIC_ADD64(&A.counters[FQ_C_PUSHES], c_pushes);
+  FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXPOPS], c_pops);
+  if (c_pops > 4096) FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS_GT4K], 1);
   FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_GAP], c_touch);
+}
+FQ_HD void fq_gap_thread(const FqGapArgs &A, int w) {   // everything in HBM
+  FqGapStoreGlobal st = {A.heads + (size_t)w * FQ_MAX_BUCKETS, A.wid_bid + (size_t)w * 2 * (size_t)A.wstride,
+                         A.sw_bid + (size_t)w * 2 * (FQ_SEED_MAX + 1), A.wstride};
+  fq_gap_run(A, w, st);
+}
+// LDS variant: the caller provides lane-interleaved LDS; bids are staged from the width kernel's output first
+FQ_HD void fq_gap_thread_lds(const FqGapArgs &A, int w, const FqGapStoreLds &st) {
+  const int s = A.work ? A.work[w] : w;
+  const int r = A.read_list[s];
+  const int len = A.len_trim[r];
+  const uint8_t *gb = A.wid_bid + (size_t)w * 2 * (size_t)A.wstride;
+  const uint8_t *gs = A.sw_bid + (size_t)w * 2 * (FQ_SEED_MAX + 1);
+  for (int a = 0; a < 2; ++a) {
+    for (int i = 0; i <= len; ++i) st.bid_set(a, i, gb[(size_t)a * A.wstride + i]);
+    if (len > A.o.seed_len) for (int i = 0; i <= A.o.seed_len; ++i) st.sb[(a * st.slen + i) * st.stride] = gs[a * (FQ_SEED_MAX + 1) + i];
+  }
+  fq_gap_run(A, w, st);
 }
 
 // ---- K_sa: bwt_sa over enumerated SA rows (src/BwtMapper.cpp:770-772, 811-853) -------------------

@@ -189,6 +189,7 @@ typedef struct {
   uint64_t sa_rows;
   uint64_t reads_searched, pairs, sw_tasks, refine_tasks;
   uint64_t tier_retries;        /* reads re-run with a larger search pool */
+  uint64_t max_pops_per_read, reads_over_4k_pops;   /* tail of the search-length distribution */
   double host_ms_serial, host_ms_pair, host_ms_total, wall_ms_total;
 } fq_stats_t;
 void fq_stats_get(const fq_ctx_t *c, fq_stats_t *out);

@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <vector>
 
 #include "fq_backend.h"
 
@@ -41,7 +42,20 @@ int launch_compact(const uint8_t *f, int n, int32_t *read_list, int32_t *sidx, i
   return 0;
 }
 int launch_width(const FqWidthArgs &a) { for (int t = 0; t < a.n_work * 4; ++t) fq_width_thread(a, t); return 0; }
-int launch_gap(const FqGapArgs &a) { for (int w = 0; w < a.n_work; ++w) fq_gap_thread(a, w); return 0; }
+int launch_gap(const FqGapArgs &a) {
+  if (a.tier.pool_cap <= 65535u) {   // same store policy the HIP launcher picks: 16-bit heads + bids in (here: emulated) LDS
+    const int wlen = a.wstride, slen = a.o.seed_len + 1;
+    std::vector<uint16_t> heads(a.o.n_buckets);
+    std::vector<uint8_t> wb(2 * (size_t)wlen), sb(2 * (size_t)slen);
+    for (int w = 0; w < a.n_work; ++w) {
+      FqGapStoreLds st = {heads.data(), wb.data(), sb.data(), 1, wlen, slen};
+      fq_gap_thread_lds(a, w, st);
+    }
+  } else {
+    for (int w = 0; w < a.n_work; ++w) fq_gap_thread(a, w);
+  }
+  return 0;
+}
 int launch_scan(const uint32_t *in, uint64_t *out, uint32_t n) { uint64_t s = 0; for (uint32_t i = 0; i < n; ++i) { out[i] = s; s += in[i]; } out[n] = s; return 0; }
 int launch_pack_aln(const FqAln *aln, const uint32_t *n_aln, const uint64_t *off, uint32_t cap, uint32_t n_work, FqAln *packed) {
   for (uint32_t w = 0; w < n_work; ++w) for (uint32_t j = 0; j < n_aln[w]; ++j) packed[off[w] + j] = aln[(size_t)w * cap + j];
