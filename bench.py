@@ -42,17 +42,11 @@ def main() -> None:
 
     import numpy as np
     import torch
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
-
     from fastquick_amd import api, synth
+    from fastquick_amd import dist as fqd
+    rank, local_rank, world = fqd.init("nccl")      # RCCL; one process per GPU
 
     # ---- workload (seeded synthetic; built once per node by rank 0) ------------------------------------------
     os.makedirs(args.workdir, exist_ok=True)
@@ -62,8 +56,7 @@ def main() -> None:
     if rank == 0 and not os.path.exists(pre + ".rsa"):
         ref.write_fasta(pre)
         api.build_index(pre)
-    if world > 1:
-        dist.barrier()
+    fqd.barrier()
     on_frac = 1.0 if args.mix == "ontarget" else ref.l_pac / 3.1e9
     n_ctx = 1
 
@@ -108,7 +101,7 @@ def main() -> None:
     def sync_all():
         torch.cuda.synchronize()
         if world > 1:
-            dist.barrier()
+            fqd.barrier()
             torch.cuda.synchronize()
 
     for i in range(args.warmup):
@@ -123,10 +116,7 @@ def main() -> None:
         n_records += res.n_survivors
     sync_all()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = fqd.max_over_ranks(elapsed)
 
     # ---- per-kernel device time (HIP events inside the library, on its own stream) + algorithmic work --------
     agg = None
@@ -204,6 +194,7 @@ def main() -> None:
         al.close()
     ix.close()
     if world > 1:
+        import torch.distributed as dist
         dist.destroy_process_group()
 
 
