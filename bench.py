@@ -142,8 +142,18 @@ def main() -> None:
     launches = max(1, int(agg["kernel_launches"][dom]))
     avg_ms = kms[dom] / launches
     achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    # HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected separately,
+    # tools/pmc_summarize.py), scaled by this run's units per launch; null when no measurement exists for this mix/kernel.
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[args.mix]["fq_" + K_NAMES[dom]]
+        unit_count = {"prep": 2.0 * args.pairs * args.steps, "gap": float(agg["reads_searched"])}.get(K_NAMES[dom])
+        if unit_count:
+            traffic = round(pmc["bytes_per_unit"] * unit_count / launches, 1)
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {"bound": "hbm", "kernel": "fq_" + K_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": None, "avg_launch_ms": round(avg_ms, 4),
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
                 "alg_bytes_per_launch": round(alg_bytes / launches, 1), "model": model}
 
     total_pairs = args.pairs * args.steps * world

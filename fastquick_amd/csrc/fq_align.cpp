@@ -80,6 +80,7 @@ struct fq_ctx {
   DevBuf<uint8_t> d_seq, d_qual, d_filtered, d_maxdiff;
   DevBuf<int32_t> d_len, d_len_trim, d_namb, d_read_list, d_sidx, d_pair_list, d_counts;
   DevBuf<uint64_t> d_counters;
+  DevBuf<uint32_t> d_queue;
   // search workspaces
   DevBuf<int32_t> d_work;
   DevBuf<uint32_t> d_wid_w, d_sw_w, d_heads, d_naln, d_status;
@@ -160,7 +161,7 @@ extern "C" int fq_ctx_create(const fq_index_t *ix, const fq_opts_t *opts, int32_
   k.max_gapo = o.max_gapo; k.max_gape = o.max_gape; k.max_seed_diff = o.max_seed_diff; k.seed_len = o.seed_len;
   k.max_top2 = o.max_top2; k.trim_qual = o.trim_qual; k.filter_thresh = o.filter_thresh; k.n_buckets = FQ_MAX_BUCKETS;
   if (fqdev::init(ix->device)) { return FQ_ENODEV; }
-  if (!c->d_maxdiff.ensure(FQ_LMAX + 2) || !c->d_counters.ensure(FQ_C_COUNT) || !c->d_counts.ensure(4)) return FQ_ENOMEM;
+  if (!c->d_maxdiff.ensure(FQ_LMAX + 2) || !c->d_counters.ensure(FQ_C_COUNT) || !c->d_counts.ensure(4) || !c->d_queue.ensure(4)) return FQ_ENOMEM;
   if (fqdev::h2d(c->d_maxdiff.p, c->maxdiff_lut, FQ_LMAX + 2) || fqdev::dzero(c->d_counters.p, FQ_C_COUNT * 8) || fqdev::sync()) return FQ_ENODEV;
   *out = c.release();
   return FQ_OK;
@@ -470,7 +471,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
         ga.read_list = c->d_read_list.p; ga.work = c->d_work.p; ga.n_work = nw; ga.maxdiff_lut = c->d_maxdiff.p;
         ga.wid_w = c->d_wid_w.p; ga.wid_bid = c->d_wid_bid.p; ga.wstride = Lpad; ga.sw_w = c->d_sw_w.p; ga.sw_bid = c->d_sw_bid.p;
         ga.pool = c->d_pool.p; ga.heads = c->d_heads.p; ga.tier = T; ga.aln = c->d_aln.p; ga.n_aln = c->d_naln.p; ga.status = c->d_status.p;
-        ga.counters = c->d_counters.p;
+        ga.counters = c->d_counters.p; ga.queue = c->d_queue.p;
         fqdev::time_begin(FQ_K_GAP);
         CK(fqdev::launch_gap(ga));
         fqdev::time_end(FQ_K_GAP);

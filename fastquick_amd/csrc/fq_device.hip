@@ -2,6 +2,7 @@
 // with 64-wide wavefront ballots, memory + HIP-event timing.  Written for CDNA4 only.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -90,19 +91,24 @@ __global__ void __launch_bounds__(256) k_width(FqWidthArgs a) {
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < a.n_work * 4) fq_width_thread(a, t);
 }
-__global__ void __launch_bounds__(256) k_gap(FqGapArgs a) {
-  const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w < a.n_work) fq_gap_thread(a, w);
-}
 extern __shared__ __align__(16) unsigned char fq_dyn_lds[];
-// one wavefront per block; per lane: n_buckets 16-bit bucket heads + 2*(wlen) + 2*(slen) bid bytes, lane-interleaved
-__global__ void __launch_bounds__(64) k_gap_lds(FqGapArgs a, int n_buckets, int wlen, int slen) {
-  const int w = blockIdx.x * 64 + threadIdx.x;
+struct FqQueueFetch {
+  uint32_t *cursor;
+  int n_work;
+  __device__ int operator()() const { const uint32_t w = atomicAdd(cursor, 1u); return w < (uint32_t)n_work ? (int)w : -1; }
+};
+// persistent wavefronts: every lane pulls reads from the queue until it is empty.  One wavefront per block.
+// LDS per lane: n_buckets 16-bit bucket heads + 2*wlen + 2*slen bid bytes, lane-interleaved.
+__global__ void __launch_bounds__(64) k_gap_persist_lds(FqGapArgs a, int n_buckets, int wlen, int slen) {
   uint16_t *heads = (uint16_t *)fq_dyn_lds;
   uint8_t *wb = (uint8_t *)(heads + (size_t)n_buckets * 64);
   uint8_t *sb = wb + (size_t)2 * wlen * 64;
   FqGapStoreLds st = {heads + threadIdx.x, wb + threadIdx.x, sb + threadIdx.x, 64, wlen, slen};
-  if (w < a.n_work) fq_gap_thread_lds(a, w, st);
+  fq_gap_lanes(a, st, FqQueueFetch{a.queue, a.n_work});
+}
+__global__ void __launch_bounds__(64) k_gap_persist(FqGapArgs a) {   // any pool size / read length: heads and bids in HBM
+  FqGapStoreGlobal st = {nullptr, nullptr, nullptr, 0};
+  fq_gap_lanes(a, st, FqQueueFetch{a.queue, a.n_work});
 }
 __global__ void __launch_bounds__(256) k_sa(FqSaArgs a) {
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -405,15 +411,20 @@ int launch_width(const FqWidthArgs &a) {
 }
 int launch_gap(const FqGapArgs &a) {
   if (a.n_work <= 0) return 0;
+  FQ_HIP(hipMemsetAsync(a.queue, 0, 4, g_stream));
   // LDS-resident heads/bids when slot indices fit 16 bits and the per-wave footprint leaves >= 2 waves per CU
   const int n_buckets = a.o.n_buckets, wlen = a.wstride, slen = a.o.seed_len + 1;
   const size_t lds = (size_t)64 * ((size_t)n_buckets * 2 + 2 * (size_t)wlen + 2 * (size_t)slen);
+  const unsigned need = nblk((uint64_t)a.n_work, 64);
   if (a.tier.pool_cap <= 65535u && lds <= 72 * 1024) {
     static bool attr_set = false;
-    if (!attr_set) { FQ_HIP(hipFuncSetAttribute((const void *)k_gap_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024)); attr_set = true; }
-    hipLaunchKernelGGL(k_gap_lds, dim3(nblk((uint64_t)a.n_work, 64)), dim3(64), lds, g_stream, a, n_buckets, wlen, slen);
+    if (!attr_set) { FQ_HIP(hipFuncSetAttribute((const void *)k_gap_persist_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024)); attr_set = true; }
+    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / lds));
+    const unsigned grid = std::min(need, 256u * per_cu);
+    hipLaunchKernelGGL(k_gap_persist_lds, dim3(grid), dim3(64), lds, g_stream, a, n_buckets, wlen, slen);
   } else {
-    hipLaunchKernelGGL(k_gap, dim3(nblk((uint64_t)a.n_work, 256)), dim3(256), 0, g_stream, a);
+    const unsigned grid = std::min(need, 256u * 8u);
+    hipLaunchKernelGGL(k_gap_persist, dim3(grid), dim3(64), 0, g_stream, a);
   }
   FQ_HIP(hipGetLastError());
   return 0;

@@ -280,6 +280,7 @@ struct FqGapArgs {
   uint32_t *n_aln;
   uint32_t *status;
   uint64_t *counters;
+  uint32_t *queue;       // work-queue cursor (zeroed before each launch)
 };
 
 // Where a read's bucket heads and width "bid" bytes live during the search: HBM (any pool size / read length) or
@@ -290,6 +291,12 @@ struct FqGapStoreGlobal {
   uint8_t *wb;          // [2][wstride]
   const uint8_t *sb;    // [2][FQ_SEED_MAX+1]
   int wstride;
+  FQ_HD void begin_read(const FqGapArgs &A, int w, int) {
+    head = A.heads + (size_t)w * FQ_MAX_BUCKETS;
+    wb = A.wid_bid + (size_t)w * 2 * (size_t)A.wstride;
+    sb = A.sw_bid + (size_t)w * 2 * (FQ_SEED_MAX + 1);
+    wstride = A.wstride;
+  }
   FQ_HD uint32_t head_get(int b) const { return head[b]; }
   FQ_HD void head_set(int b, uint32_t slot) const { head[b] = slot; }
   FQ_HD int bid(int a, int i) const { return wb[(size_t)a * (size_t)wstride + i]; }
@@ -301,6 +308,14 @@ struct FqGapStoreLds {
   uint8_t *wb;          // element (a,i) at wb[(a*wlen + i)*stride]
   uint8_t *sb;          // element (a,i) at sb[(a*slen + i)*stride]
   int stride, wlen, slen;
+  FQ_HD void begin_read(const FqGapArgs &A, int w, int len) {   // stage the width kernel's bid bytes into LDS
+    const uint8_t *gb = A.wid_bid + (size_t)w * 2 * (size_t)A.wstride;
+    const uint8_t *gs = A.sw_bid + (size_t)w * 2 * (FQ_SEED_MAX + 1);
+    for (int a = 0; a < 2; ++a) {
+      for (int i = 0; i <= len; ++i) wb[(a * wlen + i) * stride] = gb[(size_t)a * A.wstride + i];
+      if (len > A.o.seed_len) for (int i = 0; i <= A.o.seed_len; ++i) sb[(a * slen + i) * stride] = gs[a * (FQ_SEED_MAX + 1) + i];
+    }
+  }
   FQ_HD uint32_t head_get(int b) const { return head[b * stride]; }
   FQ_HD void head_set(int b, uint32_t slot) const { head[b * stride] = (uint16_t)slot; }
   FQ_HD int bid(int a, int i) const { return wb[(a * wlen + i) * stride]; }
@@ -308,38 +323,71 @@ struct FqGapStoreLds {
   FQ_HD int sbid(int a, int i) const { return sb[(a * slen + i) * stride]; }
 };
 
-template <class St>
-FQ_HD void fq_gap_run(const FqGapArgs &A, int w, const St &store) {
-  const FqKOpts &o = A.o;
-  const int s = A.work ? A.work[w] : w;
-  const int r = A.read_list[s];
-  const FqReadView v = {A.seq + (size_t)r * (size_t)A.stride, A.len_trim[r]};
-  const int len = v.len;
-  const int max_diff_opt = A.maxdiff_lut[len];
-  const bool use_seed = len > o.seed_len;
-  const int seed_len = o.seed_len < len ? o.seed_len : 0x7fffffff;
-  const bool gape_mode = (o.mode & FQ_MODE_GAPE) != 0, nonstop = (o.mode & FQ_MODE_NONSTOP) != 0;
-  A.n_aln[w] = 0;
-  A.status[w] = 0;
-  {   // "too many N" early-out of bwt_match_gap (bwtgap.c:118-124)
-    int n_amb = 0;
-    for (int j = 0; j < len; ++j) n_amb += fq_nt4(v.row[j]) > 3;
-    if (n_amb > max_diff_opt) return;
+// raw 32-byte Occ block fetch shared by the single-base and the four-base rank
+struct FqBlkRaw { uint32_t c0, c1, c2, c3; uint64_t lo, hi; uint32_t sh; bool valid; };
+FQ_HD FqBlkRaw fq_blk_load(const FqFM &f, uint32_t k) {
+  FqBlkRaw r;
+  r.valid = k != 0xffffffffu;
+  r.c0 = r.c1 = r.c2 = r.c3 = 0; r.lo = r.hi = 0; r.sh = 0;
+  if (r.valid) {
+    k = fq_adj(f, k);
+    const FqOccBlk *b = f.blk + (k >> 6);
+    r.c0 = b->cnt[0]; r.c1 = b->cnt[1]; r.c2 = b->cnt[2]; r.c3 = b->cnt[3];
+    r.lo = b->lo; r.hi = b->hi;
+    r.sh = 63 - (k & 63);
   }
+  return r;
+}
+FQ_HD uint32_t fq_blk_occ1(const FqBlkRaw &r, int c) {
+  if (!r.valid) return 0;
+  const uint64_t m = ~0ull << r.sh;
+  const uint64_t x = ((c & 2) ? r.hi : ~r.hi) & ((c & 1) ? r.lo : ~r.lo) & m;
+  const uint32_t base = c == 0 ? r.c0 : c == 1 ? r.c1 : c == 2 ? r.c2 : r.c3;
+  return base + (uint32_t)FQ_POPC64(x);
+}
+FQ_HD void fq_blk_occ4(const FqBlkRaw &r, uint32_t o[4]) {
+  if (!r.valid) { o[0] = o[1] = o[2] = o[3] = 0; return; }
+  const uint64_t m = ~0ull << r.sh;
+  o[0] = r.c0 + (uint32_t)FQ_POPC64(~r.hi & ~r.lo & m);
+  o[1] = r.c1 + (uint32_t)FQ_POPC64(~r.hi & r.lo & m);
+  o[2] = r.c2 + (uint32_t)FQ_POPC64(r.hi & ~r.lo & m);
+  o[3] = r.c3 + (uint32_t)FQ_POPC64(r.hi & r.lo & m);
+}
 
-  FqEntry *const pool = A.pool + (size_t)w * (size_t)A.tier.pool_cap;
-  FqAln *const aln = A.aln + (size_t)w * (size_t)A.tier.aln_cap;
-  uint32_t *const wbase_w = A.wid_w + (size_t)w * 2 * (size_t)A.wstride;
-  const uint32_t *const sbase_w = A.sw_w + (size_t)w * 2 * (FQ_SEED_MAX + 1);
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FQ_WAVE_COUNT(pred) ((int)__popcll(__ballot(pred)))
+#else
+#define FQ_WAVE_COUNT(pred) ((pred) ? 1 : 0)
+#endif
+#define FQ_REFILL_MIN 8   // idle lanes of a wavefront wait until this many can be (re)initialised together
 
-  uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;   // bucket occupancy
-  uint32_t bump = 0, spare = FQ_NIL, status = 0;
-  int64_t n_live = 0;
-  int best_score = (max_diff_opt + 1) * o.s_mm + (o.max_gapo + 1) * o.s_gapo + (o.max_gape + 1) * o.s_gape;
-  int max_diff = max_diff_opt, best_cnt = 0;
-  uint32_t n_aln = 0;
-  uint32_t c_pops = 0, c_pushes = 0, c_touch = 0;
+// One lane = one search at a time, but a lane that finishes pulls the next read from a queue, so a wavefront stays busy
+// whatever the spread of search lengths inside its packet of 64 reads.  Each loop iteration is one dependent Occ step for
+// every lane: either a pop+expand (two 4-base ranks) or one base of an exact-match tail (bwt_match_exact_alt turned
+// into a state machine so that a 150-step tail in one lane does not stall the other 63).  Both kinds fetch the same two
+// 32-byte blocks in a common phase between their (cheap) lane-specific phases.
+template <class St, class Fetch>
+FQ_HD void fq_gap_lanes(const FqGapArgs &A, St store, Fetch fetch) {
+  const FqKOpts &o = A.o;
+  const bool gape_mode = (o.mode & FQ_MODE_GAPE) != 0, nonstop = (o.mode & FQ_MODE_NONSTOP) != 0;
   const bool exact = A.tier.exact != 0;
+  // ---- per-read state (registers) ----
+  bool active = false, done = false;
+  int w = 0, len = 0, max_diff_opt = 0, seed_len = 0;
+  bool use_seed = false;
+  FqReadView v = {A.seq, 0};
+  FqEntry *pool = A.pool; FqAln *aln = A.aln; uint32_t *wbase_w = A.wid_w; const uint32_t *sbase_w = A.sw_w;
+  uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, bump = 0, spare = FQ_NIL, status = 0, n_aln = 0;
+  int64_t n_live = 0;
+  int best_score = 0, max_diff = 0, best_cnt = 0;
+  uint32_t c_pops = 0, c_pushes = 0, c_touch = 0;
+  bool fwd_valid = false;
+  uint32_t fwd_k = 0, fwd_l = 0, fwd_pk = 0;
+  int fwd_score = 0;
+  // exact-tail state
+  bool tail = false;
+  uint32_t tk = 0, tl = 0, tpk = 0;
+  int ti = 0, tscore = 0;
 
 #define FQ_BUCKET_TEST(b) ((((b) < 32 ? m0 : (b) < 64 ? m1 : (b) < 96 ? m2 : m3) >> ((b) & 31)) & 1u)
 #define FQ_BUCKET_SET(b)                                   \
@@ -375,183 +423,214 @@ FQ_HD void fq_gap_run(const FqGapArgs &A, int w, const St &store) {
     store.head_set(score, slot);
     FQ_BUCKET_SET(score);
   };
-
-  push(0, len, 0, A.ix.fm[0].seq_len, 0, 0, 0, FQ_ST_M, false, 0);
-  push(1, len, 0, A.ix.fm[0].seq_len, 0, 0, 0, FQ_ST_M, false, 0);
-
-  // Register forwarding of the exact-match child: it is pushed last, into the bucket its parent was just
-  // popped from (every other child scores strictly more), so it is always the next entry gap_pop returns.
-  // Keeping it in registers removes the stack round trip from the exact-extension path.
-  bool fwd_valid = false;
-  FqEntry fwd;
-  fwd.k = fwd.l = fwd.pk = 0; fwd.next = FQ_NIL;
-  int fwd_score = 0;
-
-  while ((fwd_valid || (m0 | m1 | m2 | m3) != 0) && status == 0) {
-    if (n_live > (int64_t)o.max_entries) {
-      if (!exact) status |= FQ_SF_ENTRY_LIMIT;
-      break;
-    }
-    // gap_pop
-    int b;
-    FqEntry e;
-    if (fwd_valid) { e = fwd; b = fwd_score; fwd_valid = false; }
-    else {
-      b = m0 ? FQ_CTZ32(m0) : m1 ? 32 + FQ_CTZ32(m1) : m2 ? 64 + FQ_CTZ32(m2) : 96 + FQ_CTZ32(m3);
-      const uint32_t slot = store.head_get(b);
-      e = pool[slot];
-      if (e.next == FQ_NIL) FQ_BUCKET_CLR(b); else store.head_set(b, e.next);
-      spare = slot;
-    }
-    --n_live;
-    ++c_pops;
-    uint32_t k = e.k, l = e.l;
-    int i = (int)(e.pk & 511);
-    const int a = (int)(e.pk >> 9) & 1, st = (int)(e.pk >> 10) & 3, n_mm = (int)(e.pk >> 12) & 31, n_gapo = (int)(e.pk >> 17) & 3,
-              n_gape = (int)(e.pk >> 19) & 15, last_diff = (int)(e.pk >> 23);
-    const int e_score = b;
-    if (!nonstop && e_score > best_score + o.s_mm) break;
-    int m = max_diff - (n_mm + n_gapo), m_seed = 0;
-    if (gape_mode) m -= n_gape;
-    if (m < 0) continue;
+  auto finish = [&]() {
+    A.n_aln[w] = status ? 0u : n_aln;   // failed reads are re-run in a larger tier; expose no partial list
+    A.status[w] = status;
+    FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS], c_pops);
+    FQ_ATOMIC_ADD64(&A.counters[FQ_C_PUSHES], c_pushes);
+    FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXPOPS], c_pops);
+    if (c_pops > 4096) FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS_GT4K], 1);
+    FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_GAP], c_touch);
+    active = false;
+  };
+  // a completed alignment (i == 0, or an exact tail that reached 0): bwtgap.c:166-198.  Returns false when the search ends.
+  auto on_hit = [&](uint32_t k, uint32_t l, uint32_t pk, int e_score) -> bool {
+    const int a = (int)(pk >> 9) & 1, n_mm = (int)(pk >> 12) & 31, n_gapo = (int)(pk >> 17) & 3, n_gape = (int)(pk >> 19) & 15, last_diff = (int)(pk >> 23);
     const FqFM &f = A.ix.fm[1 - a];
-    uint32_t *const ww = wbase_w + (size_t)a * (size_t)A.wstride;
-    if (use_seed) {
-      m_seed = o.max_seed_diff - (n_mm + n_gapo);
-      if (gape_mode) m_seed -= n_gape;
+    bool do_add = true;
+    if (n_aln == 0) {
+      best_score = e_score;
+      const int best_diff = n_mm + n_gapo + (gape_mode ? n_gape : 0);
+      if (!nonstop) max_diff = best_diff + 1 > max_diff_opt ? max_diff_opt : best_diff + 1;
     }
-    if (i > 0 && m < store.bid(a, i - 1)) continue;
-    bool hit = false;
-    if (i == 0) hit = true;
-    else if (m == 0 && (st == FQ_ST_M || gape_mode || n_gape == o.max_gape)) {
-      // bwt_match_exact_alt, libbwa/bwt.c:102-117
-      bool ok = true;
-      for (int t = i - 1; t >= 0; --t) {
-        const int c = fq_base(v, a, t);
-        if (c > 3) { ok = false; break; }
-        c_touch += fq_touch2(f, k - 1, l, true);
-        const uint32_t okk = fq_occ1(f, k - 1, c), oll = fq_occ1(f, l, c);
-        k = f.L2[c] + okk + 1;
-        l = f.L2[c] + oll;
-        if (k > l) { ok = false; break; }
+    if (e_score == best_score) best_cnt += (int)(l - k + 1);
+    else if (best_cnt > o.max_top2) return false;
+    if (n_gapo)
+      for (uint32_t j = 0; j < n_aln; ++j)
+        if (aln[j].k == k && aln[j].l == l) { do_add = false; break; }
+    if (do_add) {
+      uint32_t *const ww = wbase_w + (size_t)a * (size_t)A.wstride;
+      const uint32_t x = l - k + 1, mx = f.seq_len;   // gap_shadow, bwtgap.c:81-91
+      uint32_t jj = 0;
+      for (int t = 0; t < last_diff; ++t) {
+        const uint32_t cur = ww[t];
+        if (cur > x) ww[t] = cur - x;
+        else if (cur == x) { store.bid_set(a, t, 1); ww[t] = mx - (++jj); }
       }
-      if (!ok) continue;
-      hit = true;
+      if (n_aln >= A.tier.aln_cap) { status |= FQ_SF_ALN_OVERFLOW; return false; }
+      FqAln h;
+      h.info = (uint32_t)n_mm | (uint32_t)n_gapo << 8 | (uint32_t)n_gape << 16 | (uint32_t)a << 24;
+      h.k = k; h.l = l; h.score = e_score;
+      aln[n_aln++] = h;
     }
-    if (hit) {
-      bool do_add = true;
-      if (n_aln == 0) {
-        best_score = e_score;
-        const int best_diff = n_mm + n_gapo + (gape_mode ? n_gape : 0);
-        if (!nonstop) max_diff = best_diff + 1 > max_diff_opt ? max_diff_opt : best_diff + 1;
-      }
-      if (e_score == best_score) best_cnt += (int)(l - k + 1);
-      else if (best_cnt > o.max_top2) break;
-      if (n_gapo)
-        for (uint32_t j = 0; j < n_aln; ++j)
-          if (aln[j].k == k && aln[j].l == l) { do_add = false; break; }
-      if (do_add) {
-        // gap_shadow, bwtgap.c:81-91
-        const uint32_t x = l - k + 1, mx = f.seq_len;
-        uint32_t jj = 0;
-        for (int t = 0; t < last_diff; ++t) {
-          const uint32_t cur = ww[t];
-          if (cur > x) ww[t] = cur - x;
-          else if (cur == x) { store.bid_set(a, t, 1); ww[t] = mx - (++jj); }
+    return true;
+  };
+
+  for (;;) {
+    // ---- (re)fill idle lanes, in groups ----------------------------------------------------------------------------
+    const bool want = !active && !done;
+    const int n_want = FQ_WAVE_COUNT(want), n_active = FQ_WAVE_COUNT(active);
+    if (n_want == 0 && n_active == 0) break;
+    if (want && (n_want >= FQ_REFILL_MIN || n_active == 0)) {
+      w = fetch();
+      if (w < 0) done = true;
+      else {
+        const int s = A.work ? A.work[w] : w;
+        const int r = A.read_list[s];
+        v.row = A.seq + (size_t)r * (size_t)A.stride; v.len = A.len_trim[r];
+        len = v.len;
+        max_diff_opt = A.maxdiff_lut[len];
+        use_seed = len > o.seed_len;
+        seed_len = o.seed_len < len ? o.seed_len : 0x7fffffff;
+        pool = A.pool + (size_t)w * (size_t)A.tier.pool_cap;
+        aln = A.aln + (size_t)w * (size_t)A.tier.aln_cap;
+        wbase_w = A.wid_w + (size_t)w * 2 * (size_t)A.wstride;
+        sbase_w = A.sw_w + (size_t)w * 2 * (FQ_SEED_MAX + 1);
+        store.begin_read(A, w, len);
+        m0 = m1 = m2 = m3 = 0; bump = 0; spare = FQ_NIL; status = 0; n_aln = 0; n_live = 0;
+        best_score = (max_diff_opt + 1) * o.s_mm + (o.max_gapo + 1) * o.s_gapo + (o.max_gape + 1) * o.s_gape;
+        max_diff = max_diff_opt; best_cnt = 0;
+        c_pops = c_pushes = c_touch = 0;
+        fwd_valid = false; tail = false;
+        active = true;
+        int n_amb = 0;   // "too many N" early-out of bwt_match_gap (bwtgap.c:118-124)
+        for (int j = 0; j < len; ++j) n_amb += fq_nt4(v.row[j]) > 3;
+        if (n_amb > max_diff_opt) finish();
+        else {
+          push(0, len, 0, A.ix.fm[0].seq_len, 0, 0, 0, FQ_ST_M, false, 0);
+          push(1, len, 0, A.ix.fm[0].seq_len, 0, 0, 0, FQ_ST_M, false, 0);
         }
-        if (n_aln >= A.tier.aln_cap) { status |= FQ_SF_ALN_OVERFLOW; break; }
-        FqAln h;
-        h.info = (uint32_t)n_mm | (uint32_t)n_gapo << 8 | (uint32_t)n_gape << 16 | (uint32_t)a << 24;
-        h.k = k; h.l = l; h.score = e_score;
-        aln[n_aln++] = h;
       }
+    }
+    if (!active) continue;
+
+    // ---- phase 1 (lane specific, no global Occ access): decide which SA interval this iteration extends ------------------
+    uint32_t k = 0, l = 0, pk = 0;
+    int e_score = 0;
+    bool lookup = false;
+    if (tail) { k = tk; l = tl; pk = tpk; e_score = tscore; lookup = true; }
+    else {
+      if (!(fwd_valid || (m0 | m1 | m2 | m3) != 0) || status != 0) { finish(); continue; }
+      if (n_live > (int64_t)o.max_entries) { if (!exact) status |= FQ_SF_ENTRY_LIMIT; finish(); continue; }
+      if (fwd_valid) { k = fwd_k; l = fwd_l; pk = fwd_pk; e_score = fwd_score; fwd_valid = false; }
+      else {   // gap_pop
+        const int b = m0 ? FQ_CTZ32(m0) : m1 ? 32 + FQ_CTZ32(m1) : m2 ? 64 + FQ_CTZ32(m2) : 96 + FQ_CTZ32(m3);
+        const uint32_t slot = store.head_get(b);
+        const FqEntry e = pool[slot];
+        if (e.next == FQ_NIL) FQ_BUCKET_CLR(b); else store.head_set(b, e.next);
+        spare = slot;
+        k = e.k; l = e.l; pk = e.pk; e_score = b;
+      }
+      --n_live;
+      ++c_pops;
+      if (!nonstop && e_score > best_score + o.s_mm) { finish(); continue; }
+      const int i = (int)(pk & 511), a = (int)(pk >> 9) & 1, st = (int)(pk >> 10) & 3, n_mm = (int)(pk >> 12) & 31, n_gapo = (int)(pk >> 17) & 3,
+                n_gape = (int)(pk >> 19) & 15;
+      int m = max_diff - (n_mm + n_gapo);
+      if (gape_mode) m -= n_gape;
+      if (m < 0) continue;
+      if (i > 0 && m < store.bid(a, i - 1)) continue;
+      if (i == 0) { if (!on_hit(k, l, pk, e_score)) finish(); continue; }
+      if (m == 0 && (st == FQ_ST_M || gape_mode || n_gape == o.max_gape)) {   // no difference left: exact tail from here
+        tail = true; tk = k; tl = l; tpk = pk; ti = i; tscore = e_score;
+      }
+      lookup = true;
+    }
+    if (!lookup) continue;
+
+    // ---- phase 2 (common): the two 32-byte Occ blocks of rows k-1 and l -----------------------------------------------------
+    const int a = (int)(pk >> 9) & 1;
+    const FqFM &f = A.ix.fm[1 - a];
+    const FqBlkRaw bk = fq_blk_load(f, k - 1), bl = fq_blk_load(f, l);
+
+    // ---- phase 3 (lane specific) ----------------------------------------------------------------------------------------------
+    if (tail) {   // one base of bwt_match_exact_alt (libbwa/bwt.c:102-117)
+      const int t = ti - 1;
+      const int c = fq_base(v, a, t);
+      bool ok = c <= 3;
+      if (ok) {
+        c_touch += fq_touch2(f, k - 1, l, true);
+        uint32_t okk, oll;
+        // bwt_occ's k == seq_len shortcut returns the same value as the general formula; keep the general one
+        okk = fq_blk_occ1(bk, c); oll = fq_blk_occ1(bl, c);
+        tk = f.L2[c] + okk + 1;
+        tl = f.L2[c] + oll;
+        ok = tk <= tl;
+      }
+      if (!ok) { tail = false; continue; }
+      ti = t;
+      if (ti == 0) { tail = false; if (!on_hit(tk, tl, tpk, tscore)) finish(); }
       continue;
     }
-    --i;
-    uint32_t ck[4], cl[4];
-    c_touch += fq_touch2(f, k - 1, l, false);
-    fq_occ4(f, k - 1, ck);
-    fq_occ4(f, l, cl);
-    const uint32_t occ = l - k + 1;
-    bool allow_diff = true, allow_M = true;
-    if (i > 0) {
-      const int ii = i - (len - seed_len);
-      const int b1 = store.bid(a, i - 1), b0 = store.bid(a, i);
-      if (b1 > m - 1) allow_diff = false;
-      else if (b1 == m - 1 && b0 == m - 1 && ww[i - 1] == ww[i]) allow_M = false;
-      if (use_seed && ii > 0) {
-        const uint32_t *sw = sbase_w + (size_t)a * (FQ_SEED_MAX + 1);
-        const int s1 = store.sbid(a, ii - 1), s0 = store.sbid(a, ii);
-        if (s1 > m_seed - 1) allow_diff = false;
-        else if (s1 == m_seed - 1 && s0 == m_seed - 1 && sw[ii - 1] == sw[ii]) allow_M = false;
-      }
-    }
-    int tmp;
-    if (o.mode & FQ_MODE_LOGGAP) { uint32_t vv = (uint32_t)(n_gape + n_gapo); int lg = 0; while (vv >>= 1) ++lg; tmp = lg / 2 + 1; }
-    else tmp = n_gapo + n_gape;
-    if (allow_diff && i >= o.indel_end_skip + tmp && len - i >= o.indel_end_skip + tmp) {
-      if (st == FQ_ST_M) {
-        if (n_gapo < o.max_gapo) {
-          push(a, i, k, l, n_mm, n_gapo + 1, n_gape, FQ_ST_I, true, last_diff);
-          for (int j = 0; j < 4; ++j) {
-            const uint32_t kk = f.L2[j] + ck[j] + 1, ll = f.L2[j] + cl[j];
-            if (kk <= ll) push(a, i + 1, kk, ll, n_mm, n_gapo + 1, n_gape, FQ_ST_D, true, last_diff);
-          }
-        }
-      } else if (st == FQ_ST_I) {
-        if (n_gape < o.max_gape) push(a, i, k, l, n_mm, n_gapo, n_gape + 1, FQ_ST_I, true, last_diff);
-      } else {
-        if (n_gape < o.max_gape && (n_gape + n_gapo < max_diff || occ < (uint32_t)o.max_del_occ))
-          for (int j = 0; j < 4; ++j) {
-            const uint32_t kk = f.L2[j] + ck[j] + 1, ll = f.L2[j] + cl[j];
-            if (kk <= ll) push(a, i + 1, kk, ll, n_mm, n_gapo, n_gape + 1, FQ_ST_D, true, last_diff);
-          }
-      }
-    }
-    const int ci = fq_base(v, a, i);
-    if (allow_diff && allow_M) {
-      for (int j = 1; j <= 4; ++j) {
-        const int cc = (ci + j) & 3;
-        const bool is_mm = (j != 4 || ci > 3);
-        const uint32_t kk = f.L2[cc] + ck[cc] + 1, ll = f.L2[cc] + cl[cc];
-        if (kk <= ll) {
-          if (is_mm) push(a, i, kk, ll, n_mm + 1, n_gapo, n_gape, FQ_ST_M, true, last_diff);
-          else { ++n_live; ++c_pushes; fwd.k = kk; fwd.l = ll; fwd.pk = fq_pack(i, a, FQ_ST_M, n_mm, n_gapo, n_gape, last_diff); fwd_score = e_score; fwd_valid = true; }
+    {
+      int i = (int)(pk & 511);
+      const int st = (int)(pk >> 10) & 3, n_mm = (int)(pk >> 12) & 31, n_gapo = (int)(pk >> 17) & 3, n_gape = (int)(pk >> 19) & 15,
+                last_diff = (int)(pk >> 23);
+      int m = max_diff - (n_mm + n_gapo), m_seed = 0;
+      if (gape_mode) m -= n_gape;
+      if (use_seed) { m_seed = o.max_seed_diff - (n_mm + n_gapo); if (gape_mode) m_seed -= n_gape; }
+      const uint32_t *const ww = wbase_w + (size_t)a * (size_t)A.wstride;
+      --i;
+      uint32_t ck[4], cl[4];
+      c_touch += fq_touch2(f, k - 1, l, false);
+      fq_blk_occ4(bk, ck);
+      fq_blk_occ4(bl, cl);
+      const uint32_t occ = l - k + 1;
+      bool allow_diff = true, allow_M = true;
+      if (i > 0) {
+        const int ii = i - (len - seed_len);
+        const int b1 = store.bid(a, i - 1), b0 = store.bid(a, i);
+        if (b1 > m - 1) allow_diff = false;
+        else if (b1 == m - 1 && b0 == m - 1 && ww[i - 1] == ww[i]) allow_M = false;
+        if (use_seed && ii > 0) {
+          const uint32_t *sw = sbase_w + (size_t)a * (FQ_SEED_MAX + 1);
+          const int s1 = store.sbid(a, ii - 1), s0 = store.sbid(a, ii);
+          if (s1 > m_seed - 1) allow_diff = false;
+          else if (s1 == m_seed - 1 && s0 == m_seed - 1 && sw[ii - 1] == sw[ii]) allow_M = false;
         }
       }
-    } else if (ci < 4) {
-      const uint32_t kk = f.L2[ci] + ck[ci] + 1, ll = f.L2[ci] + cl[ci];
-      if (kk <= ll) { ++n_live; ++c_pushes; fwd.k = kk; fwd.l = ll; fwd.pk = fq_pack(i, a, FQ_ST_M, n_mm, n_gapo, n_gape, last_diff); fwd_score = e_score; fwd_valid = true; }
+      int tmp;
+      if (o.mode & FQ_MODE_LOGGAP) { uint32_t vv = (uint32_t)(n_gape + n_gapo); int lg = 0; while (vv >>= 1) ++lg; tmp = lg / 2 + 1; }
+      else tmp = n_gapo + n_gape;
+      if (allow_diff && i >= o.indel_end_skip + tmp && len - i >= o.indel_end_skip + tmp) {
+        if (st == FQ_ST_M) {
+          if (n_gapo < o.max_gapo) {
+            push(a, i, k, l, n_mm, n_gapo + 1, n_gape, FQ_ST_I, true, last_diff);
+            for (int j = 0; j < 4; ++j) {
+              const uint32_t kk = f.L2[j] + ck[j] + 1, ll = f.L2[j] + cl[j];
+              if (kk <= ll) push(a, i + 1, kk, ll, n_mm, n_gapo + 1, n_gape, FQ_ST_D, true, last_diff);
+            }
+          }
+        } else if (st == FQ_ST_I) {
+          if (n_gape < o.max_gape) push(a, i, k, l, n_mm, n_gapo, n_gape + 1, FQ_ST_I, true, last_diff);
+        } else {
+          if (n_gape < o.max_gape && (n_gape + n_gapo < max_diff || occ < (uint32_t)o.max_del_occ))
+            for (int j = 0; j < 4; ++j) {
+              const uint32_t kk = f.L2[j] + ck[j] + 1, ll = f.L2[j] + cl[j];
+              if (kk <= ll) push(a, i + 1, kk, ll, n_mm, n_gapo, n_gape + 1, FQ_ST_D, true, last_diff);
+            }
+        }
+      }
+      const int ci = fq_base(v, a, i);
+      if (allow_diff && allow_M) {
+        for (int j = 1; j <= 4; ++j) {
+          const int cc = (ci + j) & 3;
+          const bool is_mm = (j != 4 || ci > 3);
+          const uint32_t kk = f.L2[cc] + ck[cc] + 1, ll = f.L2[cc] + cl[cc];
+          if (kk <= ll) {
+            if (is_mm) push(a, i, kk, ll, n_mm + 1, n_gapo, n_gape, FQ_ST_M, true, last_diff);
+            else { ++n_live; ++c_pushes; fwd_k = kk; fwd_l = ll; fwd_pk = fq_pack(i, a, FQ_ST_M, n_mm, n_gapo, n_gape, last_diff); fwd_score = e_score; fwd_valid = true; }
+          }
+        }
+      } else if (ci < 4) {
+        const uint32_t kk = f.L2[ci] + ck[ci] + 1, ll = f.L2[ci] + cl[ci];
+        if (kk <= ll) { ++n_live; ++c_pushes; fwd_k = kk; fwd_l = ll; fwd_pk = fq_pack(i, a, FQ_ST_M, n_mm, n_gapo, n_gape, last_diff); fwd_score = e_score; fwd_valid = true; }
+      }
     }
   }
 #undef FQ_BUCKET_TEST
 #undef FQ_BUCKET_SET
 #undef FQ_BUCKET_CLR
-  A.n_aln[w] = status ? 0u : n_aln;   // failed reads are re-run in a larger tier; expose no partial list
-  A.status[w] = status;
-  FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS], c_pops);
-  FQ_ATOMIC_ADD64(&A.counters[FQ_C_PUSHES], c_pushes);
-  FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXPOPS], c_pops);
-  if (c_pops > 4096) FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS_GT4K], 1);
-  FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_GAP], c_touch);
-}
-FQ_HD void fq_gap_thread(const FqGapArgs &A, int w) {   // everything in HBM
-  FqGapStoreGlobal st = {A.heads + (size_t)w * FQ_MAX_BUCKETS, A.wid_bid + (size_t)w * 2 * (size_t)A.wstride,
-                         A.sw_bid + (size_t)w * 2 * (FQ_SEED_MAX + 1), A.wstride};
-  fq_gap_run(A, w, st);
-}
-// LDS variant: the caller provides lane-interleaved LDS; bids are staged from the width kernel's output first
-FQ_HD void fq_gap_thread_lds(const FqGapArgs &A, int w, const FqGapStoreLds &st) {
-  const int s = A.work ? A.work[w] : w;
-  const int r = A.read_list[s];
-  const int len = A.len_trim[r];
-  const uint8_t *gb = A.wid_bid + (size_t)w * 2 * (size_t)A.wstride;
-  const uint8_t *gs = A.sw_bid + (size_t)w * 2 * (FQ_SEED_MAX + 1);
-  for (int a = 0; a < 2; ++a) {
-    for (int i = 0; i <= len; ++i) st.bid_set(a, i, gb[(size_t)a * A.wstride + i]);
-    if (len > A.o.seed_len) for (int i = 0; i <= A.o.seed_len; ++i) st.sb[(a * st.slen + i) * st.stride] = gs[a * (FQ_SEED_MAX + 1) + i];
-  }
-  fq_gap_run(A, w, st);
 }
 
 // ---- K_sa: bwt_sa over enumerated SA rows (src/BwtMapper.cpp:770-772, 811-853) -------------------

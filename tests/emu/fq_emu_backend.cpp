@@ -42,17 +42,18 @@ int launch_compact(const uint8_t *f, int n, int32_t *read_list, int32_t *sidx, i
   return 0;
 }
 int launch_width(const FqWidthArgs &a) { for (int t = 0; t < a.n_work * 4; ++t) fq_width_thread(a, t); return 0; }
+struct SeqFetch { int *next; int n; int operator()() const { return *next < n ? (*next)++ : -1; } };
 int launch_gap(const FqGapArgs &a) {
+  int next = 0;
   if (a.tier.pool_cap <= 65535u) {   // same store policy the HIP launcher picks: 16-bit heads + bids in (here: emulated) LDS
     const int wlen = a.wstride, slen = a.o.seed_len + 1;
     std::vector<uint16_t> heads(a.o.n_buckets);
     std::vector<uint8_t> wb(2 * (size_t)wlen), sb(2 * (size_t)slen);
-    for (int w = 0; w < a.n_work; ++w) {
-      FqGapStoreLds st = {heads.data(), wb.data(), sb.data(), 1, wlen, slen};
-      fq_gap_thread_lds(a, w, st);
-    }
+    FqGapStoreLds st = {heads.data(), wb.data(), sb.data(), 1, wlen, slen};
+    fq_gap_lanes(a, st, SeqFetch{&next, a.n_work});
   } else {
-    for (int w = 0; w < a.n_work; ++w) fq_gap_thread(a, w);
+    FqGapStoreGlobal st = {nullptr, nullptr, nullptr, 0};
+    fq_gap_lanes(a, st, SeqFetch{&next, a.n_work});
   }
   return 0;
 }
