@@ -9,6 +9,7 @@
 #pragma once
 #include "fq_common.h"
 
+#define FQ_LAMBDA_INLINE __attribute__((always_inline))
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FQ_POPC64(x) __popcll(x)
 #define FQ_CTZ32(x) (__ffs((int)(x)) - 1)
@@ -323,6 +324,17 @@ struct FqGapStoreLds {
   FQ_HD int sbid(int a, int i) const { return sb[(a * slen + i) * stride]; }
 };
 
+// register-friendly 4-way select (a runtime-indexed local array would be placed in scratch memory)
+// Written with masks, not ?: -- hipcc turns "cond ? mem_a : mem_b" into a load from a *selected address*, and a variable
+// address into a local object pins that object (and everything around it) in scratch memory.
+FQ_HD uint32_t fq_pick2(uint32_t x1, uint32_t x0, int a) { const uint32_t m = 0u - (uint32_t)(a & 1); return (x1 & m) | (x0 & ~m); }   // a ? x1 : x0
+FQ_HD uint64_t fq_pick2p(uint64_t x1, uint64_t x0, int a) { const uint64_t m = 0ull - (uint64_t)(a & 1); return (x1 & m) | (x0 & ~m); }
+FQ_HD uint32_t fq_sel4v(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, int c) {
+  const uint32_t m0 = 0u - (uint32_t)(c == 0), m1 = 0u - (uint32_t)(c == 1), m2 = 0u - (uint32_t)(c == 2), m3 = 0u - (uint32_t)(c == 3);
+  return (v0 & m0) | (v1 & m1) | (v2 & m2) | (v3 & m3);
+}
+FQ_HD uint32_t fq_sel4(const uint32_t *v, int c) { return fq_sel4v(v[0], v[1], v[2], v[3], c & 3); }
+
 // raw 32-byte Occ block fetch shared by the single-base and the four-base rank
 struct FqBlkRaw { uint32_t c0, c1, c2, c3; uint64_t lo, hi; uint32_t sh; bool valid; };
 FQ_HD FqBlkRaw fq_blk_load(const FqFM &f, uint32_t k) {
@@ -341,8 +353,8 @@ FQ_HD FqBlkRaw fq_blk_load(const FqFM &f, uint32_t k) {
 FQ_HD uint32_t fq_blk_occ1(const FqBlkRaw &r, int c) {
   if (!r.valid) return 0;
   const uint64_t m = ~0ull << r.sh;
-  const uint64_t x = ((c & 2) ? r.hi : ~r.hi) & ((c & 1) ? r.lo : ~r.lo) & m;
-  const uint32_t base = c == 0 ? r.c0 : c == 1 ? r.c1 : c == 2 ? r.c2 : r.c3;
+  const uint64_t x = (r.hi ^ (0ull - (uint64_t)(((c >> 1) & 1) ^ 1))) & (r.lo ^ (0ull - (uint64_t)((c & 1) ^ 1))) & m;
+  const uint32_t base = fq_sel4v(r.c0, r.c1, r.c2, r.c3, c);
   return base + (uint32_t)FQ_POPC64(x);
 }
 FQ_HD void fq_blk_occ4(const FqBlkRaw &r, uint32_t o[4]) {
@@ -366,42 +378,60 @@ FQ_HD void fq_blk_occ4(const FqBlkRaw &r, uint32_t o[4]) {
 // every lane: either a pop+expand (two 4-base ranks) or one base of an exact-match tail (bwt_match_exact_alt turned
 // into a state machine so that a 150-step tail in one lane does not stall the other 63).  Both kinds fetch the same two
 // 32-byte blocks in a common phase between their (cheap) lane-specific phases.
-template <class St, class Fetch>
-FQ_HD void fq_gap_lanes(const FqGapArgs &A, St store, Fetch fetch) {
-  const FqKOpts &o = A.o;
-  const bool gape_mode = (o.mode & FQ_MODE_GAPE) != 0, nonstop = (o.mode & FQ_MODE_NONSTOP) != 0;
-  const bool exact = A.tier.exact != 0;
-  // ---- per-read state (registers) ----
-  bool active = false, done = false;
-  int w = 0, len = 0, max_diff_opt = 0, seed_len = 0;
-  bool use_seed = false;
-  FqReadView v = {A.seq, 0};
-  FqEntry *pool = A.pool; FqAln *aln = A.aln; uint32_t *wbase_w = A.wid_w; const uint32_t *sbase_w = A.sw_w;
-  uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0, bump = 0, spare = FQ_NIL, status = 0, n_aln = 0;
-  int64_t n_live = 0;
-  int best_score = 0, max_diff = 0, best_cnt = 0;
-  uint32_t c_pops = 0, c_pushes = 0, c_touch = 0;
-  bool fwd_valid = false;
-  uint32_t fwd_k = 0, fwd_l = 0, fwd_pk = 0;
-  int fwd_score = 0;
-  // exact-tail state
-  bool tail = false;
-  uint32_t tk = 0, tl = 0, tpk = 0;
-  int ti = 0, tscore = 0;
+//
+// The per-read state is a plain struct with inlined member functions and the two FM descriptors are held by value and
+// chosen with selects: closures capturing by reference, or a runtime index into the kernel-argument struct, make hipcc
+// keep the whole state in scratch memory (680 B/lane, every access a memory round trip).
+template <class St>
+struct FqGapLane {
+  const FqGapArgs &A;
+  St store;
+  FqFM fm0, fm1;
+  FqKOpts o;
+  bool gape_mode, nonstop, exact;
+  // per-read state
+  bool active, done;
+  int w, len, max_diff_opt, seed_len;
+  bool use_seed;
+  FqReadView v;
+  FqEntry *pool; FqAln *aln; uint32_t *wbase_w; const uint32_t *sbase_w;
+  uint32_t m0, m1, m2, m3, bump, spare, status, n_aln;
+  int64_t n_live;
+  int best_score, max_diff, best_cnt;
+  uint32_t c_pops, c_pushes, c_touch;
+  bool fwd_valid;
+  uint32_t fwd_k, fwd_l, fwd_pk;
+  int fwd_score;
+  bool tail;
+  uint32_t tk, tl, tpk;
+  int ti, tscore;
 
-#define FQ_BUCKET_TEST(b) ((((b) < 32 ? m0 : (b) < 64 ? m1 : (b) < 96 ? m2 : m3) >> ((b) & 31)) & 1u)
-#define FQ_BUCKET_SET(b)                                   \
-  do {                                                     \
-    const uint32_t bit_ = 1u << ((b) & 31);                \
-    if ((b) < 32) m0 |= bit_; else if ((b) < 64) m1 |= bit_; else if ((b) < 96) m2 |= bit_; else m3 |= bit_; \
-  } while (0)
-#define FQ_BUCKET_CLR(b)                                   \
-  do {                                                     \
-    const uint32_t bit_ = ~(1u << ((b) & 31));             \
-    if ((b) < 32) m0 &= bit_; else if ((b) < 64) m1 &= bit_; else if ((b) < 96) m2 &= bit_; else m3 &= bit_; \
-  } while (0)
+  FQ_HD FqGapLane(const FqGapArgs &A_, const St &st) : A(A_), store(st), fm0(A_.ix.fm[0]), fm1(A_.ix.fm[1]), o(A_.o) {
+    gape_mode = (o.mode & FQ_MODE_GAPE) != 0; nonstop = (o.mode & FQ_MODE_NONSTOP) != 0; exact = A_.tier.exact != 0;
+    active = done = false; w = len = max_diff_opt = seed_len = 0; use_seed = false;
+    v.row = A_.seq; v.len = 0;
+    pool = A_.pool; aln = A_.aln; wbase_w = A_.wid_w; sbase_w = A_.sw_w;
+    m0 = m1 = m2 = m3 = bump = status = n_aln = 0; spare = FQ_NIL; n_live = 0;
+    best_score = max_diff = best_cnt = 0; c_pops = c_pushes = c_touch = 0;
+    fwd_valid = false; fwd_k = fwd_l = fwd_pk = 0; fwd_score = 0;
+    tail = false; tk = tl = tpk = 0; ti = tscore = 0;
+  }
+  // search strand a runs on the other strand's BWT (bwtgap.c:148)
+  FQ_HD FqFM fm_for(int a) const {
+    FqFM f;
+    f.blk = (const FqOccBlk *)fq_pick2p((uint64_t)(uintptr_t)fm0.blk, (uint64_t)(uintptr_t)fm1.blk, a);
+    f.sa = nullptr;
+    f.primary = fq_pick2(fm0.primary, fm1.primary, a); f.seq_len = fq_pick2(fm0.seq_len, fm1.seq_len, a);
+    f.L2[0] = fq_pick2(fm0.L2[0], fm1.L2[0], a); f.L2[1] = fq_pick2(fm0.L2[1], fm1.L2[1], a); f.L2[2] = fq_pick2(fm0.L2[2], fm1.L2[2], a);
+    f.L2[3] = fq_pick2(fm0.L2[3], fm1.L2[3], a); f.L2[4] = fq_pick2(fm0.L2[4], fm1.L2[4], a);
+    f.sa_intv = fm0.sa_intv; f.n_sa = 0; f.n_blk = 0;
+    return f;
+  }
+  FQ_HD bool bucket_test(int b) const { return ((fq_sel4v(m0, m1, m2, m3, b >> 5) >> (b & 31)) & 1u) != 0; }
+  FQ_HD void bucket_set(int b) { const uint32_t bit = 1u << (b & 31); const int q = b >> 5; m0 |= bit & (0u - (uint32_t)(q == 0)); m1 |= bit & (0u - (uint32_t)(q == 1)); m2 |= bit & (0u - (uint32_t)(q == 2)); m3 |= bit & (0u - (uint32_t)(q == 3)); }
+  FQ_HD void bucket_clr(int b) { const uint32_t bit = 1u << (b & 31); const int q = b >> 5; m0 &= ~(bit & (0u - (uint32_t)(q == 0))); m1 &= ~(bit & (0u - (uint32_t)(q == 1))); m2 &= ~(bit & (0u - (uint32_t)(q == 2))); m3 &= ~(bit & (0u - (uint32_t)(q == 3))); }
 
-  auto push = [&](int a, int i, uint32_t k, uint32_t l, int mm, int go, int ge, int st, bool is_diff, int parent_ld) {
+  FQ_HD void push(int a, int i, uint32_t k, uint32_t l, int mm, int go, int ge, int st, bool is_diff, int parent_ld) {
     const int score = mm * o.s_mm + go * o.s_gapo + ge * o.s_gape;
     ++n_live;
     if (!exact) {
@@ -418,12 +448,16 @@ FQ_HD void fq_gap_lanes(const FqGapArgs &A, St store, Fetch fetch) {
     FqEntry e;
     e.k = k; e.l = l;
     e.pk = fq_pack(i, a, st, mm, go, ge, is_diff ? i : parent_ld);   // Q1: non-diff pushes inherit last_diff_pos
-    e.next = FQ_BUCKET_TEST(score) ? store.head_get(score) : FQ_NIL;
+    e.next = bucket_test(score) ? store.head_get(score) : FQ_NIL;
     pool[slot] = e;
     store.head_set(score, slot);
-    FQ_BUCKET_SET(score);
-  };
-  auto finish = [&]() {
+    bucket_set(score);
+  }
+  FQ_HD void forward(int a, int i, uint32_t k, uint32_t l, int mm, int go, int ge, int ld, int score) {
+    ++n_live; ++c_pushes;
+    fwd_k = k; fwd_l = l; fwd_pk = fq_pack(i, a, FQ_ST_M, mm, go, ge, ld); fwd_score = score; fwd_valid = true;
+  }
+  FQ_HD void finish() {
     A.n_aln[w] = status ? 0u : n_aln;   // failed reads are re-run in a larger tier; expose no partial list
     A.status[w] = status;
     FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS], c_pops);
@@ -432,11 +466,11 @@ FQ_HD void fq_gap_lanes(const FqGapArgs &A, St store, Fetch fetch) {
     if (c_pops > 4096) FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS_GT4K], 1);
     FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_GAP], c_touch);
     active = false;
-  };
+  }
   // a completed alignment (i == 0, or an exact tail that reached 0): bwtgap.c:166-198.  Returns false when the search ends.
-  auto on_hit = [&](uint32_t k, uint32_t l, uint32_t pk, int e_score) -> bool {
+  FQ_HD bool on_hit(uint32_t k, uint32_t l, uint32_t pk, int e_score) {
     const int a = (int)(pk >> 9) & 1, n_mm = (int)(pk >> 12) & 31, n_gapo = (int)(pk >> 17) & 3, n_gape = (int)(pk >> 19) & 15, last_diff = (int)(pk >> 23);
-    const FqFM &f = A.ix.fm[1 - a];
+    const uint32_t seq_len = fq_pick2(fm0.seq_len, fm1.seq_len, a);
     bool do_add = true;
     if (n_aln == 0) {
       best_score = e_score;
@@ -450,7 +484,7 @@ FQ_HD void fq_gap_lanes(const FqGapArgs &A, St store, Fetch fetch) {
         if (aln[j].k == k && aln[j].l == l) { do_add = false; break; }
     if (do_add) {
       uint32_t *const ww = wbase_w + (size_t)a * (size_t)A.wstride;
-      const uint32_t x = l - k + 1, mx = f.seq_len;   // gap_shadow, bwtgap.c:81-91
+      const uint32_t x = l - k + 1, mx = seq_len;   // gap_shadow, bwtgap.c:81-91
       uint32_t jj = 0;
       for (int t = 0; t < last_diff; ++t) {
         const uint32_t cur = ww[t];
@@ -464,83 +498,69 @@ FQ_HD void fq_gap_lanes(const FqGapArgs &A, St store, Fetch fetch) {
       aln[n_aln++] = h;
     }
     return true;
-  };
+  }
+  FQ_HD void begin(int w_) {
+    w = w_;
+    const int s = A.work ? A.work[w] : w;
+    const int r = A.read_list[s];
+    v.row = A.seq + (size_t)r * (size_t)A.stride; v.len = A.len_trim[r];
+    len = v.len;
+    max_diff_opt = A.maxdiff_lut[len];
+    use_seed = len > o.seed_len;
+    seed_len = o.seed_len < len ? o.seed_len : 0x7fffffff;
+    pool = A.pool + (size_t)w * (size_t)A.tier.pool_cap;
+    aln = A.aln + (size_t)w * (size_t)A.tier.aln_cap;
+    wbase_w = A.wid_w + (size_t)w * 2 * (size_t)A.wstride;
+    sbase_w = A.sw_w + (size_t)w * 2 * (FQ_SEED_MAX + 1);
+    store.begin_read(A, w, len);
+    m0 = m1 = m2 = m3 = 0; bump = 0; spare = FQ_NIL; status = 0; n_aln = 0; n_live = 0;
+    best_score = (max_diff_opt + 1) * o.s_mm + (o.max_gapo + 1) * o.s_gapo + (o.max_gape + 1) * o.s_gape;
+    max_diff = max_diff_opt; best_cnt = 0;
+    c_pops = c_pushes = c_touch = 0;
+    fwd_valid = false; tail = false;
+    active = true;
+    int n_amb = 0;   // "too many N" early-out of bwt_match_gap (bwtgap.c:118-124)
+    for (int j = 0; j < len; ++j) n_amb += fq_nt4(v.row[j]) > 3;
+    if (n_amb > max_diff_opt) { finish(); return; }
+    push(0, len, 0, fm0.seq_len, 0, 0, 0, FQ_ST_M, false, 0);
+    push(1, len, 0, fm0.seq_len, 0, 0, 0, FQ_ST_M, false, 0);
+  }
 
-  for (;;) {
-    // ---- (re)fill idle lanes, in groups ----------------------------------------------------------------------------
-    const bool want = !active && !done;
-    const int n_want = FQ_WAVE_COUNT(want), n_active = FQ_WAVE_COUNT(active);
-    if (n_want == 0 && n_active == 0) break;
-    if (want && (n_want >= FQ_REFILL_MIN || n_active == 0)) {
-      w = fetch();
-      if (w < 0) done = true;
-      else {
-        const int s = A.work ? A.work[w] : w;
-        const int r = A.read_list[s];
-        v.row = A.seq + (size_t)r * (size_t)A.stride; v.len = A.len_trim[r];
-        len = v.len;
-        max_diff_opt = A.maxdiff_lut[len];
-        use_seed = len > o.seed_len;
-        seed_len = o.seed_len < len ? o.seed_len : 0x7fffffff;
-        pool = A.pool + (size_t)w * (size_t)A.tier.pool_cap;
-        aln = A.aln + (size_t)w * (size_t)A.tier.aln_cap;
-        wbase_w = A.wid_w + (size_t)w * 2 * (size_t)A.wstride;
-        sbase_w = A.sw_w + (size_t)w * 2 * (FQ_SEED_MAX + 1);
-        store.begin_read(A, w, len);
-        m0 = m1 = m2 = m3 = 0; bump = 0; spare = FQ_NIL; status = 0; n_aln = 0; n_live = 0;
-        best_score = (max_diff_opt + 1) * o.s_mm + (o.max_gapo + 1) * o.s_gapo + (o.max_gape + 1) * o.s_gape;
-        max_diff = max_diff_opt; best_cnt = 0;
-        c_pops = c_pushes = c_touch = 0;
-        fwd_valid = false; tail = false;
-        active = true;
-        int n_amb = 0;   // "too many N" early-out of bwt_match_gap (bwtgap.c:118-124)
-        for (int j = 0; j < len; ++j) n_amb += fq_nt4(v.row[j]) > 3;
-        if (n_amb > max_diff_opt) finish();
-        else {
-          push(0, len, 0, A.ix.fm[0].seq_len, 0, 0, 0, FQ_ST_M, false, 0);
-          push(1, len, 0, A.ix.fm[0].seq_len, 0, 0, 0, FQ_ST_M, false, 0);
-        }
-      }
-    }
-    if (!active) continue;
-
+  // one iteration for an active lane
+  FQ_HD void step() {
     // ---- phase 1 (lane specific, no global Occ access): decide which SA interval this iteration extends ------------------
     uint32_t k = 0, l = 0, pk = 0;
     int e_score = 0;
-    bool lookup = false;
-    if (tail) { k = tk; l = tl; pk = tpk; e_score = tscore; lookup = true; }
+    if (tail) { k = tk; l = tl; pk = tpk; e_score = tscore; }
     else {
-      if (!(fwd_valid || (m0 | m1 | m2 | m3) != 0) || status != 0) { finish(); continue; }
-      if (n_live > (int64_t)o.max_entries) { if (!exact) status |= FQ_SF_ENTRY_LIMIT; finish(); continue; }
+      if (!(fwd_valid || (m0 | m1 | m2 | m3) != 0) || status != 0) { finish(); return; }
+      if (n_live > (int64_t)o.max_entries) { if (!exact) status |= FQ_SF_ENTRY_LIMIT; finish(); return; }
       if (fwd_valid) { k = fwd_k; l = fwd_l; pk = fwd_pk; e_score = fwd_score; fwd_valid = false; }
       else {   // gap_pop
         const int b = m0 ? FQ_CTZ32(m0) : m1 ? 32 + FQ_CTZ32(m1) : m2 ? 64 + FQ_CTZ32(m2) : 96 + FQ_CTZ32(m3);
         const uint32_t slot = store.head_get(b);
         const FqEntry e = pool[slot];
-        if (e.next == FQ_NIL) FQ_BUCKET_CLR(b); else store.head_set(b, e.next);
+        if (e.next == FQ_NIL) bucket_clr(b); else store.head_set(b, e.next);
         spare = slot;
         k = e.k; l = e.l; pk = e.pk; e_score = b;
       }
       --n_live;
       ++c_pops;
-      if (!nonstop && e_score > best_score + o.s_mm) { finish(); continue; }
+      if (!nonstop && e_score > best_score + o.s_mm) { finish(); return; }
       const int i = (int)(pk & 511), a = (int)(pk >> 9) & 1, st = (int)(pk >> 10) & 3, n_mm = (int)(pk >> 12) & 31, n_gapo = (int)(pk >> 17) & 3,
                 n_gape = (int)(pk >> 19) & 15;
       int m = max_diff - (n_mm + n_gapo);
       if (gape_mode) m -= n_gape;
-      if (m < 0) continue;
-      if (i > 0 && m < store.bid(a, i - 1)) continue;
-      if (i == 0) { if (!on_hit(k, l, pk, e_score)) finish(); continue; }
+      if (m < 0) return;
+      if (i > 0 && m < store.bid(a, i - 1)) return;
+      if (i == 0) { if (!on_hit(k, l, pk, e_score)) finish(); return; }
       if (m == 0 && (st == FQ_ST_M || gape_mode || n_gape == o.max_gape)) {   // no difference left: exact tail from here
         tail = true; tk = k; tl = l; tpk = pk; ti = i; tscore = e_score;
       }
-      lookup = true;
     }
-    if (!lookup) continue;
-
     // ---- phase 2 (common): the two 32-byte Occ blocks of rows k-1 and l -----------------------------------------------------
     const int a = (int)(pk >> 9) & 1;
-    const FqFM &f = A.ix.fm[1 - a];
+    const FqFM f = fm_for(a);
     const FqBlkRaw bk = fq_blk_load(f, k - 1), bl = fq_blk_load(f, l);
 
     // ---- phase 3 (lane specific) ----------------------------------------------------------------------------------------------
@@ -550,87 +570,100 @@ FQ_HD void fq_gap_lanes(const FqGapArgs &A, St store, Fetch fetch) {
       bool ok = c <= 3;
       if (ok) {
         c_touch += fq_touch2(f, k - 1, l, true);
-        uint32_t okk, oll;
-        // bwt_occ's k == seq_len shortcut returns the same value as the general formula; keep the general one
-        okk = fq_blk_occ1(bk, c); oll = fq_blk_occ1(bl, c);
-        tk = f.L2[c] + okk + 1;
-        tl = f.L2[c] + oll;
+        const uint32_t okk = fq_blk_occ1(bk, c), oll = fq_blk_occ1(bl, c);
+        tk = fq_sel4(f.L2, c) + okk + 1;
+        tl = fq_sel4(f.L2, c) + oll;
         ok = tk <= tl;
       }
-      if (!ok) { tail = false; continue; }
+      if (!ok) { tail = false; return; }
       ti = t;
       if (ti == 0) { tail = false; if (!on_hit(tk, tl, tpk, tscore)) finish(); }
-      continue;
+      return;
     }
-    {
-      int i = (int)(pk & 511);
-      const int st = (int)(pk >> 10) & 3, n_mm = (int)(pk >> 12) & 31, n_gapo = (int)(pk >> 17) & 3, n_gape = (int)(pk >> 19) & 15,
-                last_diff = (int)(pk >> 23);
-      int m = max_diff - (n_mm + n_gapo), m_seed = 0;
-      if (gape_mode) m -= n_gape;
-      if (use_seed) { m_seed = o.max_seed_diff - (n_mm + n_gapo); if (gape_mode) m_seed -= n_gape; }
-      const uint32_t *const ww = wbase_w + (size_t)a * (size_t)A.wstride;
-      --i;
-      uint32_t ck[4], cl[4];
-      c_touch += fq_touch2(f, k - 1, l, false);
-      fq_blk_occ4(bk, ck);
-      fq_blk_occ4(bl, cl);
-      const uint32_t occ = l - k + 1;
-      bool allow_diff = true, allow_M = true;
-      if (i > 0) {
-        const int ii = i - (len - seed_len);
-        const int b1 = store.bid(a, i - 1), b0 = store.bid(a, i);
-        if (b1 > m - 1) allow_diff = false;
-        else if (b1 == m - 1 && b0 == m - 1 && ww[i - 1] == ww[i]) allow_M = false;
-        if (use_seed && ii > 0) {
-          const uint32_t *sw = sbase_w + (size_t)a * (FQ_SEED_MAX + 1);
-          const int s1 = store.sbid(a, ii - 1), s0 = store.sbid(a, ii);
-          if (s1 > m_seed - 1) allow_diff = false;
-          else if (s1 == m_seed - 1 && s0 == m_seed - 1 && sw[ii - 1] == sw[ii]) allow_M = false;
-        }
+    int i = (int)(pk & 511);
+    const int st = (int)(pk >> 10) & 3, n_mm = (int)(pk >> 12) & 31, n_gapo = (int)(pk >> 17) & 3, n_gape = (int)(pk >> 19) & 15,
+              last_diff = (int)(pk >> 23);
+    int m = max_diff - (n_mm + n_gapo), m_seed = 0;
+    if (gape_mode) m -= n_gape;
+    if (use_seed) { m_seed = o.max_seed_diff - (n_mm + n_gapo); if (gape_mode) m_seed -= n_gape; }
+    const uint32_t *const ww = wbase_w + (size_t)a * (size_t)A.wstride;
+    --i;
+    uint32_t ck[4], cl[4];
+    c_touch += fq_touch2(f, k - 1, l, false);
+    fq_blk_occ4(bk, ck);
+    fq_blk_occ4(bl, cl);
+    const uint32_t occ = l - k + 1;
+    bool allow_diff = true, allow_M = true;
+    if (i > 0) {
+      const int ii = i - (len - seed_len);
+      const int b1 = store.bid(a, i - 1), b0 = store.bid(a, i);
+      if (b1 > m - 1) allow_diff = false;
+      else if (b1 == m - 1 && b0 == m - 1 && ww[i - 1] == ww[i]) allow_M = false;
+      if (use_seed && ii > 0) {
+        const uint32_t *sw = sbase_w + (size_t)a * (FQ_SEED_MAX + 1);
+        const int s1 = store.sbid(a, ii - 1), s0 = store.sbid(a, ii);
+        if (s1 > m_seed - 1) allow_diff = false;
+        else if (s1 == m_seed - 1 && s0 == m_seed - 1 && sw[ii - 1] == sw[ii]) allow_M = false;
       }
-      int tmp;
-      if (o.mode & FQ_MODE_LOGGAP) { uint32_t vv = (uint32_t)(n_gape + n_gapo); int lg = 0; while (vv >>= 1) ++lg; tmp = lg / 2 + 1; }
-      else tmp = n_gapo + n_gape;
-      if (allow_diff && i >= o.indel_end_skip + tmp && len - i >= o.indel_end_skip + tmp) {
-        if (st == FQ_ST_M) {
-          if (n_gapo < o.max_gapo) {
-            push(a, i, k, l, n_mm, n_gapo + 1, n_gape, FQ_ST_I, true, last_diff);
-            for (int j = 0; j < 4; ++j) {
-              const uint32_t kk = f.L2[j] + ck[j] + 1, ll = f.L2[j] + cl[j];
-              if (kk <= ll) push(a, i + 1, kk, ll, n_mm, n_gapo + 1, n_gape, FQ_ST_D, true, last_diff);
-            }
-          }
-        } else if (st == FQ_ST_I) {
-          if (n_gape < o.max_gape) push(a, i, k, l, n_mm, n_gapo, n_gape + 1, FQ_ST_I, true, last_diff);
-        } else {
-          if (n_gape < o.max_gape && (n_gape + n_gapo < max_diff || occ < (uint32_t)o.max_del_occ))
-            for (int j = 0; j < 4; ++j) {
-              const uint32_t kk = f.L2[j] + ck[j] + 1, ll = f.L2[j] + cl[j];
-              if (kk <= ll) push(a, i + 1, kk, ll, n_mm, n_gapo, n_gape + 1, FQ_ST_D, true, last_diff);
-            }
-        }
-      }
-      const int ci = fq_base(v, a, i);
-      if (allow_diff && allow_M) {
-        for (int j = 1; j <= 4; ++j) {
-          const int cc = (ci + j) & 3;
-          const bool is_mm = (j != 4 || ci > 3);
-          const uint32_t kk = f.L2[cc] + ck[cc] + 1, ll = f.L2[cc] + cl[cc];
-          if (kk <= ll) {
-            if (is_mm) push(a, i, kk, ll, n_mm + 1, n_gapo, n_gape, FQ_ST_M, true, last_diff);
-            else { ++n_live; ++c_pushes; fwd_k = kk; fwd_l = ll; fwd_pk = fq_pack(i, a, FQ_ST_M, n_mm, n_gapo, n_gape, last_diff); fwd_score = e_score; fwd_valid = true; }
+    }
+    int tmp;
+    if (o.mode & FQ_MODE_LOGGAP) { uint32_t vv = (uint32_t)(n_gape + n_gapo); int lg = 0; while (vv >>= 1) ++lg; tmp = lg / 2 + 1; }
+    else tmp = n_gapo + n_gape;
+    if (allow_diff && i >= o.indel_end_skip + tmp && len - i >= o.indel_end_skip + tmp) {
+      if (st == FQ_ST_M) {
+        if (n_gapo < o.max_gapo) {
+          push(a, i, k, l, n_mm, n_gapo + 1, n_gape, FQ_ST_I, true, last_diff);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t kk = f.L2[j] + ck[j] + 1, ll = f.L2[j] + cl[j];
+            if (kk <= ll) push(a, i + 1, kk, ll, n_mm, n_gapo + 1, n_gape, FQ_ST_D, true, last_diff);
           }
         }
-      } else if (ci < 4) {
-        const uint32_t kk = f.L2[ci] + ck[ci] + 1, ll = f.L2[ci] + cl[ci];
-        if (kk <= ll) { ++n_live; ++c_pushes; fwd_k = kk; fwd_l = ll; fwd_pk = fq_pack(i, a, FQ_ST_M, n_mm, n_gapo, n_gape, last_diff); fwd_score = e_score; fwd_valid = true; }
+      } else if (st == FQ_ST_I) {
+        if (n_gape < o.max_gape) push(a, i, k, l, n_mm, n_gapo, n_gape + 1, FQ_ST_I, true, last_diff);
+      } else {
+        if (n_gape < o.max_gape && (n_gape + n_gapo < max_diff || occ < (uint32_t)o.max_del_occ)) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const uint32_t kk = f.L2[j] + ck[j] + 1, ll = f.L2[j] + cl[j];
+            if (kk <= ll) push(a, i + 1, kk, ll, n_mm, n_gapo, n_gape + 1, FQ_ST_D, true, last_diff);
+          }
+        }
       }
+    }
+    const int ci = fq_base(v, a, i);
+    if (allow_diff && allow_M) {
+#pragma unroll
+      for (int j = 1; j <= 4; ++j) {
+        const int cc = (ci + j) & 3;
+        const bool is_mm = (j != 4 || ci > 3);
+        const uint32_t kk = fq_sel4(f.L2, cc) + fq_sel4(ck, cc) + 1, ll = fq_sel4(f.L2, cc) + fq_sel4(cl, cc);
+        if (kk <= ll) {
+          if (is_mm) push(a, i, kk, ll, n_mm + 1, n_gapo, n_gape, FQ_ST_M, true, last_diff);
+          else forward(a, i, kk, ll, n_mm, n_gapo, n_gape, last_diff, e_score);
+        }
+      }
+    } else if (ci < 4) {
+      const uint32_t kk = fq_sel4(f.L2, ci) + fq_sel4(ck, ci) + 1, ll = fq_sel4(f.L2, ci) + fq_sel4(cl, ci);
+      if (kk <= ll) forward(a, i, kk, ll, n_mm, n_gapo, n_gape, last_diff, e_score);
     }
   }
-#undef FQ_BUCKET_TEST
-#undef FQ_BUCKET_SET
-#undef FQ_BUCKET_CLR
+};
+
+template <class St, class Fetch>
+FQ_HD void fq_gap_lanes(const FqGapArgs &A, const St &store0, Fetch fetch) {
+  FqGapLane<St> L(A, store0);
+  for (;;) {
+    // (re)fill idle lanes, in groups
+    const bool want = !L.active && !L.done;
+    const int n_want = FQ_WAVE_COUNT(want), n_active = FQ_WAVE_COUNT(L.active);
+    if (n_want == 0 && n_active == 0) break;
+    if (want && (n_want >= FQ_REFILL_MIN || n_active == 0)) {
+      const int w = fetch();
+      if (w < 0) L.done = true; else L.begin(w);
+    }
+    if (L.active) L.step();
+  }
 }
 
 // ---- K_sa: bwt_sa over enumerated SA rows (src/BwtMapper.cpp:770-772, 811-853) -------------------
