@@ -183,6 +183,7 @@ extern "C" void fq_stats_reset(fq_ctx_t *c) { if (c) memset(&c->stats, 0, sizeof
 extern "C" int fq_batch_upload(fq_ctx_t *c, const fq_read_batch_t *in) {
   if (!c || !in || in->n_pairs < 0 || !in->seq || !in->qual || !in->len) return FQ_EINVAL;
   if (in->n_pairs > c->max_pairs) { c->err = "batch larger than max_pairs_per_batch"; return FQ_ELIMIT; }
+  if (fqdev::init(c->ix->device)) return FQ_ENODEV;   // per-thread stream
   if (in->stride < 1 || in->stride > 4096) return FQ_EINVAL;
   const size_t n2 = (size_t)in->n_pairs * 2;
   for (size_t i = 0; i < n2; ++i)
@@ -373,6 +374,7 @@ void pair_hits(const fq_ctx *c, FqRead *p[2], const FqAln *aln[2], vector<uint64
 // ---- the batch ------------------------------------------------------------------------------------------
 extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   if (!c || !out) return FQ_EINVAL;
+  if (fqdev::init(c->ix->device)) return FQ_ENODEV;   // the calling thread's own stream
   const double t_wall0 = now_ms();
   const fq_index *ix = c->ix;
   const fq_opts_t &o = c->o;

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -12,9 +13,11 @@
 
 namespace fqdev {
 
-static hipStream_t g_stream = nullptr;
-static std::string g_err;
-static int g_device = -1;
+// All backend state is per host thread: a thread that drives a context gets its own HIP stream, timing events and
+// scan/compaction temporaries, so several contexts can be driven concurrently (one thread each) and their kernels overlap.
+static thread_local hipStream_t g_stream = nullptr;
+static thread_local std::string g_err;
+static thread_local int g_device = -1;
 
 #define FQ_HIP(call)                                                                         \
   do {                                                                                       \
@@ -29,9 +32,11 @@ const char *last_error() { return g_err.c_str(); }
 bool is_real_gpu() { return true; }
 
 int init(int dev) {
+  if (g_stream && g_device == dev) return 0;
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_err = "no HIP device visible"; return -3; }
   if (dev < 0 || dev >= n) { g_err = "device ordinal out of range"; return -3; }
+  if (g_stream && g_device == dev) return 0;
   FQ_HIP(hipSetDevice(dev));
   if (!g_stream || g_device != dev) {
     FQ_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
@@ -59,9 +64,9 @@ int sync() { FQ_HIP(hipStreamSynchronize(g_stream)); return 0; }
 
 // ---- timing ---------------------------------------------------------------------------------
 struct Pending { int kid; hipEvent_t a, b; };
-static std::vector<Pending> g_pending;
-static std::vector<hipEvent_t> g_free_events;
-static hipEvent_t g_open_begin[16];
+static thread_local std::vector<Pending> g_pending;
+static thread_local std::vector<hipEvent_t> g_free_events;
+static thread_local hipEvent_t g_open_begin[16];
 static hipEvent_t get_event() {
   if (!g_free_events.empty()) { hipEvent_t e = g_free_events.back(); g_free_events.pop_back(); return e; }
   hipEvent_t e;
@@ -297,8 +302,8 @@ __global__ void __launch_bounds__(256) k_scan_c(const uint32_t *in, uint32_t n, 
   if (i == 0) out[n] = blk_off[gridDim.x];
 }
 
-static uint64_t *g_scan_tmp = nullptr;
-static size_t g_scan_tmp_n = 0;
+static thread_local uint64_t *g_scan_tmp = nullptr;
+static thread_local size_t g_scan_tmp_n = 0;
 int launch_scan(const uint32_t *in, uint64_t *out, uint32_t n) {
   if (n == 0) { uint64_t z = 0; return h2d(out, &z, 8) ? -3 : sync(); }
   const unsigned nb = nblk(n, 256);
@@ -357,9 +362,9 @@ __global__ void __launch_bounds__(256) k_compact_c(const uint8_t *filt, int n_pa
   }
   if (p == 0) { counts[0] = (int32_t)read_off[gridDim.x]; counts[1] = (int32_t)pair_off[gridDim.x]; }
 }
-static uint32_t *g_cmp_cnt = nullptr;
-static uint64_t *g_cmp_off = nullptr;
-static size_t g_cmp_n = 0;
+static thread_local uint32_t *g_cmp_cnt = nullptr;
+static thread_local uint64_t *g_cmp_off = nullptr;
+static thread_local size_t g_cmp_n = 0;
 int launch_compact(const uint8_t *filtered, int n_pairs, int32_t *read_list, int32_t *sidx, int32_t *pair_list, int32_t *counts) {
   if (n_pairs <= 0) return dzero(counts, 8);
   const unsigned nb = nblk((uint64_t)n_pairs, 256);
@@ -417,7 +422,7 @@ int launch_gap(const FqGapArgs &a) {
   const size_t lds = (size_t)64 * ((size_t)n_buckets * 2 + 2 * (size_t)wlen + 2 * (size_t)slen);
   const unsigned need = nblk((uint64_t)a.n_work, 64);
   if (a.tier.pool_cap <= 65535u && lds <= 72 * 1024) {
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};
     if (!attr_set) { FQ_HIP(hipFuncSetAttribute((const void *)k_gap_persist_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024)); attr_set = true; }
     const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / lds));
     const unsigned grid = std::min(need, 256u * per_cu);
@@ -452,7 +457,7 @@ int launch_sw(const FqSwArgs &a) {
   if (a.n_task <= 0) return 0;
   const size_t lds = (size_t)(2 * (a.RL + 2) + 3 * (a.RL + 1)) * 4 + ((a.RL + 16) & ~15) + ((a.QL + 16) & ~15);
   if (lds > kLdsBudget) { g_err = "SW window too large for LDS (" + std::to_string(a.RL) + " bases)"; return -5; }
-  static bool attr_set = false;
+  static std::atomic<bool> attr_set{false};
   if (!attr_set) { FQ_HIP(hipFuncSetAttribute((const void *)k_sw_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget)); attr_set = true; }
   hipLaunchKernelGGL(k_sw_wave, dim3((unsigned)a.n_task), dim3(64), lds, g_stream, a);
   FQ_HIP(hipGetLastError());
@@ -462,7 +467,7 @@ int launch_refine(const FqRefineArgs &a) {
   if (a.n_task <= 0) return 0;
   const size_t lds = (size_t)3 * (a.RL + 1) * 64 * 4;
   if (lds <= kLdsBudget) {
-    static bool attr_set = false;
+    static std::atomic<bool> attr_set{false};
     if (!attr_set) { FQ_HIP(hipFuncSetAttribute((const void *)k_refine_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget)); attr_set = true; }
     hipLaunchKernelGGL(k_refine_lds, dim3(nblk((uint64_t)a.n_task, 64)), dim3(64), lds, g_stream, a);
   } else {
