@@ -83,8 +83,8 @@ struct fq_ctx {
   DevBuf<uint32_t> d_queue;
   // search workspaces
   DevBuf<int32_t> d_work;
-  DevBuf<uint32_t> d_wid_w, d_sw_w, d_heads, d_naln, d_status;
-  DevBuf<uint8_t> d_wid_bid, d_sw_bid;
+  DevBuf<uint32_t> d_heads, d_naln, d_status;
+  DevBuf<FqWRec> d_wrec, d_srec;
   DevBuf<FqEntry> d_pool;
   DevBuf<FqAln> d_aln, d_packed;
   DevBuf<uint64_t> d_off;
@@ -456,22 +456,21 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
       next_work.clear();
       for (size_t c0 = 0; c0 < work.size(); c0 += chunk_reads[tier]) {
         const int nw = (int)std::min(chunk_reads[tier], work.size() - c0);
-        CKM(c->d_work.ensure(nw) && c->d_wid_w.ensure((size_t)nw * 2 * Lpad) && c->d_wid_bid.ensure((size_t)nw * 2 * Lpad) &&
-            c->d_sw_w.ensure((size_t)nw * 2 * (FQ_SEED_MAX + 1)) && c->d_sw_bid.ensure((size_t)nw * 2 * (FQ_SEED_MAX + 1)) &&
+        CKM(c->d_work.ensure(nw) && c->d_wrec.ensure((size_t)nw * 2 * Lpad) && c->d_srec.ensure((size_t)nw * 2 * (FQ_SEED_MAX + 1)) &&
             c->d_heads.ensure((size_t)nw * FQ_MAX_BUCKETS) && c->d_pool.ensure((size_t)nw * T.pool_cap) &&
             c->d_aln.ensure((size_t)nw * T.aln_cap) && c->d_naln.ensure(nw) && c->d_status.ensure(nw) && c->d_off.ensure(nw + 1));
         CK(fqdev::h2d(c->d_work.p, work.data() + c0, (size_t)nw * 4));
         FqWidthArgs wa{};
         wa.ix = ix->dev; wa.o = c->ko; wa.seq = c->d_seq.p; wa.stride = stride; wa.len_trim = c->d_len_trim.p; wa.read_list = c->d_read_list.p;
-        wa.work = c->d_work.p; wa.n_work = nw; wa.wid_w = c->d_wid_w.p; wa.wid_bid = c->d_wid_bid.p; wa.wstride = Lpad;
-        wa.sw_w = c->d_sw_w.p; wa.sw_bid = c->d_sw_bid.p; wa.counters = c->d_counters.p;
+        wa.work = c->d_work.p; wa.n_work = nw; wa.wrec = c->d_wrec.p; wa.wstride = Lpad;
+        wa.srec = c->d_srec.p; wa.counters = c->d_counters.p;
         fqdev::time_begin(FQ_K_WIDTH);
         CK(fqdev::launch_width(wa));
         fqdev::time_end(FQ_K_WIDTH);
         FqGapArgs ga{};
         ga.ix = ix->dev; ga.o = c->ko; ga.o.n_buckets = nb_need; ga.seq = c->d_seq.p; ga.stride = stride; ga.len_trim = c->d_len_trim.p;
         ga.read_list = c->d_read_list.p; ga.work = c->d_work.p; ga.n_work = nw; ga.maxdiff_lut = c->d_maxdiff.p;
-        ga.wid_w = c->d_wid_w.p; ga.wid_bid = c->d_wid_bid.p; ga.wstride = Lpad; ga.sw_w = c->d_sw_w.p; ga.sw_bid = c->d_sw_bid.p;
+        ga.wrec = c->d_wrec.p; ga.wstride = Lpad; ga.srec = c->d_srec.p;
         ga.pool = c->d_pool.p; ga.heads = c->d_heads.p; ga.tier = T; ga.aln = c->d_aln.p; ga.n_aln = c->d_naln.p; ga.status = c->d_status.p;
         ga.counters = c->d_counters.p; ga.queue = c->d_queue.p;
         fqdev::time_begin(FQ_K_GAP);

@@ -79,6 +79,12 @@ FQ_HD uint32_t fq_pack(int i, int a, int st, int mm, int go, int ge, int ld) {
          (uint32_t)ld << 23;
 }
 
+// bwt_width_t (libbwa/bwtaln.h:29-32): one record per read position so that the two neighbours the search needs come
+// back in a single 16-byte load
+struct FqWRec {
+  uint32_t w, bid;
+};
+
 // per-read search status flags
 #define FQ_SF_POOL_OVERFLOW 1u   // entry pool exhausted -> rerun in a larger tier
 #define FQ_SF_ALN_OVERFLOW 2u    // more hits than the aln slot holds -> rerun in a larger tier

@@ -103,16 +103,14 @@ struct FqQueueFetch {
   __device__ int operator()() const { const uint32_t w = atomicAdd(cursor, 1u); return w < (uint32_t)n_work ? (int)w : -1; }
 };
 // persistent wavefronts: every lane pulls reads from the queue until it is empty.  One wavefront per block.
-// LDS per lane: n_buckets 16-bit bucket heads + 2*wlen + 2*slen bid bytes, lane-interleaved.
-__global__ void __launch_bounds__(64) k_gap_persist_lds(FqGapArgs a, int n_buckets, int wlen, int slen) {
+// LDS per lane: n_buckets 16-bit bucket heads, lane-interleaved.
+__global__ void __launch_bounds__(64) k_gap_persist_lds(FqGapArgs a) {
   uint16_t *heads = (uint16_t *)fq_dyn_lds;
-  uint8_t *wb = (uint8_t *)(heads + (size_t)n_buckets * 64);
-  uint8_t *sb = wb + (size_t)2 * wlen * 64;
-  FqGapStoreLds st = {heads + threadIdx.x, wb + threadIdx.x, sb + threadIdx.x, 64, wlen, slen};
+  FqGapStoreLds st = {heads + threadIdx.x, 64};
   fq_gap_lanes(a, st, FqQueueFetch{a.queue, a.n_work});
 }
-__global__ void __launch_bounds__(64) k_gap_persist(FqGapArgs a) {   // any pool size / read length: heads and bids in HBM
-  FqGapStoreGlobal st = {nullptr, nullptr, nullptr, 0};
+__global__ void __launch_bounds__(64) k_gap_persist(FqGapArgs a) {   // any pool size: bucket heads in HBM
+  FqGapStoreGlobal st = {nullptr};
   fq_gap_lanes(a, st, FqQueueFetch{a.queue, a.n_work});
 }
 __global__ void __launch_bounds__(256) k_sa(FqSaArgs a) {
@@ -417,16 +415,13 @@ int launch_width(const FqWidthArgs &a) {
 int launch_gap(const FqGapArgs &a) {
   if (a.n_work <= 0) return 0;
   FQ_HIP(hipMemsetAsync(a.queue, 0, 4, g_stream));
-  // LDS-resident heads/bids when slot indices fit 16 bits and the per-wave footprint leaves >= 2 waves per CU
-  const int n_buckets = a.o.n_buckets, wlen = a.wstride, slen = a.o.seed_len + 1;
-  const size_t lds = (size_t)64 * ((size_t)n_buckets * 2 + 2 * (size_t)wlen + 2 * (size_t)slen);
+  // LDS-resident bucket heads when slot indices fit 16 bits
+  const size_t lds = (size_t)64 * (size_t)a.o.n_buckets * 2;
   const unsigned need = nblk((uint64_t)a.n_work, 64);
-  if (a.tier.pool_cap <= 65535u && lds <= 72 * 1024) {
-    static std::atomic<bool> attr_set{false};
-    if (!attr_set) { FQ_HIP(hipFuncSetAttribute((const void *)k_gap_persist_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024)); attr_set = true; }
-    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(8, (150 * 1024) / lds));
+  if (a.tier.pool_cap <= 65535u) {
+    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16, (150 * 1024) / lds));
     const unsigned grid = std::min(need, 256u * per_cu);
-    hipLaunchKernelGGL(k_gap_persist_lds, dim3(grid), dim3(64), lds, g_stream, a, n_buckets, wlen, slen);
+    hipLaunchKernelGGL(k_gap_persist_lds, dim3(grid), dim3(64), lds, g_stream, a);
   } else {
     const unsigned grid = std::min(need, 256u * 8u);
     hipLaunchKernelGGL(k_gap_persist, dim3(grid), dim3(64), 0, g_stream, a);

@@ -211,11 +211,9 @@ struct FqWidthArgs {
   const int32_t *read_list;   // s -> r
   const int32_t *work;        // w -> s (NULL: identity)
   int32_t n_work;
-  uint32_t *wid_w;            // [w][2][wstride]
-  uint8_t *wid_bid;
+  FqWRec *wrec;               // [w][2][wstride]   {w, bid} per position
   int32_t wstride;
-  uint32_t *sw_w;             // [w][2][FQ_SEED_MAX+1]
-  uint8_t *sw_bid;
+  FqWRec *srec;               // [w][2][FQ_SEED_MAX+1]
   uint64_t *counters;
 };
 FQ_HD void fq_width_thread(const FqWidthArgs &A, int t) {
@@ -227,8 +225,7 @@ FQ_HD void fq_width_thread(const FqWidthArgs &A, int t) {
   const int n = seed ? A.o.seed_len : v.len;
   const int off = seed ? v.len - A.o.seed_len : 0;
   const FqFM &f = A.ix.fm[strand];
-  uint32_t *ow = seed ? A.sw_w + ((size_t)w * 2 + strand) * (FQ_SEED_MAX + 1) : A.wid_w + ((size_t)w * 2 + strand) * (size_t)A.wstride;
-  uint8_t *ob = seed ? A.sw_bid + ((size_t)w * 2 + strand) * (FQ_SEED_MAX + 1) : A.wid_bid + ((size_t)w * 2 + strand) * (size_t)A.wstride;
+  FqWRec *orec = seed ? A.srec + ((size_t)w * 2 + strand) * (FQ_SEED_MAX + 1) : A.wrec + ((size_t)w * 2 + strand) * (size_t)A.wstride;
   uint32_t k = 0, l = f.seq_len, touches = 0;
   int bid = 0;
   for (int i = 0; i < n; ++i) {
@@ -240,11 +237,10 @@ FQ_HD void fq_width_thread(const FqWidthArgs &A, int t) {
       l = f.L2[c] + ol;
     }
     if (k > l || c > 3) { k = 0; l = f.seq_len; ++bid; }
-    ow[i] = l - k + 1;
-    ob[i] = (uint8_t)bid;
+    FqWRec rec; rec.w = l - k + 1; rec.bid = (uint32_t)bid;
+    orec[i] = rec;
   }
-  ow[n] = 0;
-  ob[n] = (uint8_t)(bid + 1);
+  { FqWRec rec; rec.w = 0; rec.bid = (uint32_t)(bid + 1); orec[n] = rec; }
   FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_WIDTH], touches);
 }
 
@@ -269,11 +265,9 @@ struct FqGapArgs {
   const int32_t *work;
   int32_t n_work;
   const uint8_t *maxdiff_lut;
-  uint32_t *wid_w;
-  uint8_t *wid_bid;
+  FqWRec *wrec;          // width records written by k_width; gap_shadow updates them in place
   int32_t wstride;
-  const uint32_t *sw_w;
-  const uint8_t *sw_bid;
+  const FqWRec *srec;
   FqEntry *pool;
   uint32_t *heads;
   FqGapTier tier;
@@ -284,44 +278,20 @@ struct FqGapArgs {
   uint32_t *queue;       // work-queue cursor (zeroed before each launch)
 };
 
-// Where a read's bucket heads and width "bid" bytes live during the search: HBM (any pool size / read length) or
-// lane-interleaved LDS (pool <= 65535 entries: 16-bit heads), which takes the head read-modify-write of every push
-// and the bid lookups of every pop off the global-memory latency chain.
+// Where a read's bucket heads live during the search: HBM (any pool size) or lane-interleaved LDS with 16-bit slots
+// (pool <= 65535 entries), which takes the head read-modify-write of every push off the global-memory latency chain.
 struct FqGapStoreGlobal {
   uint32_t *head;
-  uint8_t *wb;          // [2][wstride]
-  const uint8_t *sb;    // [2][FQ_SEED_MAX+1]
-  int wstride;
-  FQ_HD void begin_read(const FqGapArgs &A, int w, int) {
-    head = A.heads + (size_t)w * FQ_MAX_BUCKETS;
-    wb = A.wid_bid + (size_t)w * 2 * (size_t)A.wstride;
-    sb = A.sw_bid + (size_t)w * 2 * (FQ_SEED_MAX + 1);
-    wstride = A.wstride;
-  }
+  FQ_HD void begin_read(const FqGapArgs &A, int w) { head = A.heads + (size_t)w * FQ_MAX_BUCKETS; }
   FQ_HD uint32_t head_get(int b) const { return head[b]; }
   FQ_HD void head_set(int b, uint32_t slot) const { head[b] = slot; }
-  FQ_HD int bid(int a, int i) const { return wb[(size_t)a * (size_t)wstride + i]; }
-  FQ_HD void bid_set(int a, int i, int v) const { wb[(size_t)a * (size_t)wstride + i] = (uint8_t)v; }
-  FQ_HD int sbid(int a, int i) const { return sb[a * (FQ_SEED_MAX + 1) + i]; }
 };
 struct FqGapStoreLds {
   uint16_t *head;       // element b at head[b*stride]
-  uint8_t *wb;          // element (a,i) at wb[(a*wlen + i)*stride]
-  uint8_t *sb;          // element (a,i) at sb[(a*slen + i)*stride]
-  int stride, wlen, slen;
-  FQ_HD void begin_read(const FqGapArgs &A, int w, int len) {   // stage the width kernel's bid bytes into LDS
-    const uint8_t *gb = A.wid_bid + (size_t)w * 2 * (size_t)A.wstride;
-    const uint8_t *gs = A.sw_bid + (size_t)w * 2 * (FQ_SEED_MAX + 1);
-    for (int a = 0; a < 2; ++a) {
-      for (int i = 0; i <= len; ++i) wb[(a * wlen + i) * stride] = gb[(size_t)a * A.wstride + i];
-      if (len > A.o.seed_len) for (int i = 0; i <= A.o.seed_len; ++i) sb[(a * slen + i) * stride] = gs[a * (FQ_SEED_MAX + 1) + i];
-    }
-  }
+  int stride;
+  FQ_HD void begin_read(const FqGapArgs &, int) {}
   FQ_HD uint32_t head_get(int b) const { return head[b * stride]; }
   FQ_HD void head_set(int b, uint32_t slot) const { head[b * stride] = (uint16_t)slot; }
-  FQ_HD int bid(int a, int i) const { return wb[(a * wlen + i) * stride]; }
-  FQ_HD void bid_set(int a, int i, int v) const { wb[(a * wlen + i) * stride] = (uint8_t)v; }
-  FQ_HD int sbid(int a, int i) const { return sb[(a * slen + i) * stride]; }
 };
 
 // register-friendly 4-way select (a runtime-indexed local array would be placed in scratch memory)
@@ -394,7 +364,7 @@ struct FqGapLane {
   int w, len, max_diff_opt, seed_len;
   bool use_seed;
   FqReadView v;
-  FqEntry *pool; FqAln *aln; uint32_t *wbase_w; const uint32_t *sbase_w;
+  FqEntry *pool; FqAln *aln; FqWRec *wrec; const FqWRec *srec;
   uint32_t m0, m1, m2, m3, bump, spare, status, n_aln;
   int64_t n_live;
   int best_score, max_diff, best_cnt;
@@ -410,7 +380,7 @@ struct FqGapLane {
     gape_mode = (o.mode & FQ_MODE_GAPE) != 0; nonstop = (o.mode & FQ_MODE_NONSTOP) != 0; exact = A_.tier.exact != 0;
     active = done = false; w = len = max_diff_opt = seed_len = 0; use_seed = false;
     v.row = A_.seq; v.len = 0;
-    pool = A_.pool; aln = A_.aln; wbase_w = A_.wid_w; sbase_w = A_.sw_w;
+    pool = A_.pool; aln = A_.aln; wrec = A_.wrec; srec = A_.srec;
     m0 = m1 = m2 = m3 = bump = status = n_aln = 0; spare = FQ_NIL; n_live = 0;
     best_score = max_diff = best_cnt = 0; c_pops = c_pushes = c_touch = 0;
     fwd_valid = false; fwd_k = fwd_l = fwd_pk = 0; fwd_score = 0;
@@ -483,13 +453,13 @@ struct FqGapLane {
       for (uint32_t j = 0; j < n_aln; ++j)
         if (aln[j].k == k && aln[j].l == l) { do_add = false; break; }
     if (do_add) {
-      uint32_t *const ww = wbase_w + (size_t)a * (size_t)A.wstride;
+      FqWRec *const ww = wrec + (size_t)a * (size_t)A.wstride;
       const uint32_t x = l - k + 1, mx = seq_len;   // gap_shadow, bwtgap.c:81-91
       uint32_t jj = 0;
       for (int t = 0; t < last_diff; ++t) {
-        const uint32_t cur = ww[t];
-        if (cur > x) ww[t] = cur - x;
-        else if (cur == x) { store.bid_set(a, t, 1); ww[t] = mx - (++jj); }
+        const uint32_t cur = ww[t].w;
+        if (cur > x) ww[t].w = cur - x;
+        else if (cur == x) { FqWRec nr; nr.bid = 1; nr.w = mx - (++jj); ww[t] = nr; }
       }
       if (n_aln >= A.tier.aln_cap) { status |= FQ_SF_ALN_OVERFLOW; return false; }
       FqAln h;
@@ -510,9 +480,9 @@ struct FqGapLane {
     seed_len = o.seed_len < len ? o.seed_len : 0x7fffffff;
     pool = A.pool + (size_t)w * (size_t)A.tier.pool_cap;
     aln = A.aln + (size_t)w * (size_t)A.tier.aln_cap;
-    wbase_w = A.wid_w + (size_t)w * 2 * (size_t)A.wstride;
-    sbase_w = A.sw_w + (size_t)w * 2 * (FQ_SEED_MAX + 1);
-    store.begin_read(A, w, len);
+    wrec = A.wrec + (size_t)w * 2 * (size_t)A.wstride;
+    srec = A.srec + (size_t)w * 2 * (FQ_SEED_MAX + 1);
+    store.begin_read(A, w);
     m0 = m1 = m2 = m3 = 0; bump = 0; spare = FQ_NIL; status = 0; n_aln = 0; n_live = 0;
     best_score = (max_diff_opt + 1) * o.s_mm + (o.max_gapo + 1) * o.s_gapo + (o.max_gape + 1) * o.s_gape;
     max_diff = max_diff_opt; best_cnt = 0;
@@ -531,6 +501,7 @@ struct FqGapLane {
     // ---- phase 1 (lane specific, no global Occ access): decide which SA interval this iteration extends ------------------
     uint32_t k = 0, l = 0, pk = 0;
     int e_score = 0;
+    bool fresh = false;   // a just-popped entry (its width prune is still pending)
     if (tail) { k = tk; l = tl; pk = tpk; e_score = tscore; }
     else {
       if (!(fwd_valid || (m0 | m1 | m2 | m3) != 0) || status != 0) { finish(); return; }
@@ -552,21 +523,38 @@ struct FqGapLane {
       int m = max_diff - (n_mm + n_gapo);
       if (gape_mode) m -= n_gape;
       if (m < 0) return;
-      if (i > 0 && m < store.bid(a, i - 1)) return;
       if (i == 0) { if (!on_hit(k, l, pk, e_score)) finish(); return; }
-      if (m == 0 && (st == FQ_ST_M || gape_mode || n_gape == o.max_gape)) {   // no difference left: exact tail from here
-        tail = true; tk = k; tl = l; tpk = pk; ti = i; tscore = e_score;
-      }
+      // the width-based prune (m < width[i-1].bid) and the exact-tail decision need the width records: they are fetched
+      // together with the Occ blocks below (speculatively -- a pruned entry wastes two block loads but no round trip)
+      fresh = true;
     }
     // ---- phase 2 (common): the two 32-byte Occ blocks of rows k-1 and l -----------------------------------------------------
     const int a = (int)(pk >> 9) & 1;
     const FqFM f = fm_for(a);
     const FqBlkRaw bk = fq_blk_load(f, k - 1), bl = fq_blk_load(f, l);
+    const int i0 = fresh ? (int)(pk & 511) : ti;          // position before this step's base is consumed (>= 1)
+    const int cbase = fq_base(v, a, i0 - 1);               // the base this step consumes (tail) / branches on (expand)
+    FqWRec w1, w2, s1r, s2r;                                // width[i0-1], width[i0-2], seed_width[ii], seed_width[ii-1]
+    w1.w = w1.bid = w2.w = w2.bid = s1r.w = s1r.bid = s2r.w = s2r.bid = 0;
+    const int ii0 = (i0 - 1) - (len - seed_len);
+    if (fresh) {
+      const FqWRec *ww = wrec + (size_t)a * (size_t)A.wstride;
+      w1 = ww[i0 - 1];
+      if (i0 >= 2) w2 = ww[i0 - 2];
+      if (use_seed && ii0 > 0) { const FqWRec *sw = srec + (size_t)a * (FQ_SEED_MAX + 1); s1r = sw[ii0]; s2r = sw[ii0 - 1]; }
+      const int st0 = (int)(pk >> 10) & 3, n_mm0 = (int)(pk >> 12) & 31, n_gapo0 = (int)(pk >> 17) & 3, n_gape0 = (int)(pk >> 19) & 15;
+      int m0d = max_diff - (n_mm0 + n_gapo0);
+      if (gape_mode) m0d -= n_gape0;
+      if (m0d < (int)w1.bid) return;                        // bwtgap.c:155
+      if (m0d == 0 && (st0 == FQ_ST_M || gape_mode || n_gape0 == o.max_gape)) {   // no difference left: exact tail from here
+        tail = true; tk = k; tl = l; tpk = pk; ti = i0; tscore = e_score;
+      }
+    }
 
     // ---- phase 3 (lane specific) ----------------------------------------------------------------------------------------------
     if (tail) {   // one base of bwt_match_exact_alt (libbwa/bwt.c:102-117)
       const int t = ti - 1;
-      const int c = fq_base(v, a, t);
+      const int c = cbase;
       bool ok = c <= 3;
       if (ok) {
         c_touch += fq_touch2(f, k - 1, l, true);
@@ -586,7 +574,6 @@ struct FqGapLane {
     int m = max_diff - (n_mm + n_gapo), m_seed = 0;
     if (gape_mode) m -= n_gape;
     if (use_seed) { m_seed = o.max_seed_diff - (n_mm + n_gapo); if (gape_mode) m_seed -= n_gape; }
-    const uint32_t *const ww = wbase_w + (size_t)a * (size_t)A.wstride;
     --i;
     uint32_t ck[4], cl[4];
     c_touch += fq_touch2(f, k - 1, l, false);
@@ -596,14 +583,13 @@ struct FqGapLane {
     bool allow_diff = true, allow_M = true;
     if (i > 0) {
       const int ii = i - (len - seed_len);
-      const int b1 = store.bid(a, i - 1), b0 = store.bid(a, i);
+      const int b1 = (int)w2.bid, b0 = (int)w1.bid;   // width[i-1], width[i] of the decremented i
       if (b1 > m - 1) allow_diff = false;
-      else if (b1 == m - 1 && b0 == m - 1 && ww[i - 1] == ww[i]) allow_M = false;
+      else if (b1 == m - 1 && b0 == m - 1 && w2.w == w1.w) allow_M = false;
       if (use_seed && ii > 0) {
-        const uint32_t *sw = sbase_w + (size_t)a * (FQ_SEED_MAX + 1);
-        const int s1 = store.sbid(a, ii - 1), s0 = store.sbid(a, ii);
+        const int s1 = (int)s2r.bid, s0 = (int)s1r.bid;
         if (s1 > m_seed - 1) allow_diff = false;
-        else if (s1 == m_seed - 1 && s0 == m_seed - 1 && sw[ii - 1] == sw[ii]) allow_M = false;
+        else if (s1 == m_seed - 1 && s0 == m_seed - 1 && s2r.w == s1r.w) allow_M = false;
       }
     }
     int tmp;
@@ -631,7 +617,7 @@ struct FqGapLane {
         }
       }
     }
-    const int ci = fq_base(v, a, i);
+    const int ci = cbase;
     if (allow_diff && allow_M) {
 #pragma unroll
       for (int j = 1; j <= 4; ++j) {

@@ -45,14 +45,12 @@ int launch_width(const FqWidthArgs &a) { for (int t = 0; t < a.n_work * 4; ++t) 
 struct SeqFetch { int *next; int n; int operator()() const { return *next < n ? (*next)++ : -1; } };
 int launch_gap(const FqGapArgs &a) {
   int next = 0;
-  if (a.tier.pool_cap <= 65535u) {   // same store policy the HIP launcher picks: 16-bit heads + bids in (here: emulated) LDS
-    const int wlen = a.wstride, slen = a.o.seed_len + 1;
+  if (a.tier.pool_cap <= 65535u) {   // same store policy the HIP launcher picks: 16-bit heads in (here: emulated) LDS
     std::vector<uint16_t> heads(a.o.n_buckets);
-    std::vector<uint8_t> wb(2 * (size_t)wlen), sb(2 * (size_t)slen);
-    FqGapStoreLds st = {heads.data(), wb.data(), sb.data(), 1, wlen, slen};
+    FqGapStoreLds st = {heads.data(), 1};
     fq_gap_lanes(a, st, SeqFetch{&next, a.n_work});
   } else {
-    FqGapStoreGlobal st = {nullptr, nullptr, nullptr, 0};
+    FqGapStoreGlobal st = {nullptr};
     fq_gap_lanes(a, st, SeqFetch{&next, a.n_work});
   }
   return 0;
