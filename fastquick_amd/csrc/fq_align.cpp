@@ -9,6 +9,8 @@
 // GPU through fq_backend.h; libm-dependent scalar decisions stay on the host (Q4/Q5).
 #include <algorithm>
 #include <chrono>
+#include <climits>
+#include <cstdint>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -105,7 +107,8 @@ struct fq_ctx {
   DevBuf<uint32_t> d_mdsz;
   // host staging
   vector<uint8_t> h_filtered;
-  vector<int32_t> h_len_trim, h_pair_list, h_read_list, h_sidx_surv;
+  vector<int32_t> h_len_trim, h_pair_list, h_read_list, h_sidx;
+  vector<int> pen_lut;   // per reference batch: memo of the insert-size penalty per integer insert size
   // results of the last batch
   FqBatchState st;
   fq_stats_t stats{};
@@ -302,14 +305,19 @@ void infer_isize(const vector<FqRead> &R, int sp_lo, int sp_hi, int max_len_all,
 
 // pairing + __pairing_aux/__pairing_aux2, libbwa/bwape.c:119-213, bwape.h:55-82 (typo at :65 reproduced)
 struct PairAcc { uint64_t o_score, subo_score, o_pos[2]; int o_n, subo_n; };
-inline void pair_try(const fq_ctx *c, FqRead *p[2], const FqAln *aln[2], const fq_isize_t *ii, int max_len, uint64_t u, uint64_t v, PairAcc &A) {
+inline void pair_try(fq_ctx *c, FqRead *p[2], const FqAln *aln[2], const fq_isize_t *ii, int max_len, uint64_t u, uint64_t v, PairAcc &A) {
   if (u == (uint64_t)-1) return;
   const uint32_t l = (uint32_t)(v >> 32) + (uint32_t)p[v & 1]->len - (uint32_t)(u >> 32);
   if (!((v >> 32) > (u >> 32) && l >= (uint32_t)max_len &&
         ((ii->high && l <= ii->high_bayesian) || (ii->high == 0 && l <= (uint32_t)c->o.max_isize)))) return;
   uint64_t s = (uint64_t)(int64_t)(aln[v & 1][(uint32_t)v >> 1].score + aln[u & 1][(uint32_t)u >> 1].score);
   s *= 10;
-  if (ii->high) s += (uint64_t)(int64_t)(int)(-4.343 * log(0.5 * erfc(M_SQRT1_2 * fabs(l - ii->avg) / ii->std)) + 0.499);
+  if (ii->high) {
+    // same libm expression as bwape.h:62, evaluated once per distinct insert size of this reference batch (l <= high_bayesian here)
+    int &pen = c->pen_lut[l];
+    if (pen == INT32_MIN) pen = (int)(-4.343 * log(0.5 * erfc(M_SQRT1_2 * fabs(l - ii->avg) / ii->std)) + 0.499);
+    s += (uint64_t)(int64_t)pen;
+  }
   s = s << 32 | (uint32_t)hash_64((u >> 32 << 32) | (v >> 32));
   if (s >> 32 == A.o_score >> 32) ++A.o_n;
   else if (s >> 32 < A.o_score << 32) { A.subo_n += A.o_n; A.o_n = 1; }
@@ -326,7 +334,7 @@ inline void pair_fix(FqRead &q, const FqAln *aln[2], uint64_t w) {
     q.pos = (uint32_t)(w >> 32);
   }
 }
-void pair_hits(const fq_ctx *c, FqRead *p[2], const FqAln *aln[2], vector<uint64_t> &arr, const fq_isize_t *ii) {
+void pair_hits(fq_ctx *c, FqRead *p[2], const FqAln *aln[2], vector<uint64_t> &arr, const fq_isize_t *ii) {
   PairAcc A;
   A.o_score = A.subo_score = (uint64_t)-1; A.o_n = A.subo_n = 0; A.o_pos[0] = A.o_pos[1] = 0;
   uint64_t last[2][2] = {{(uint64_t)-1, (uint64_t)-1}, {(uint64_t)-1, (uint64_t)-1}};
@@ -374,6 +382,9 @@ void pair_hits(const fq_ctx *c, FqRead *p[2], const FqAln *aln[2], vector<uint64
 // ---- the batch ------------------------------------------------------------------------------------------
 extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   if (!c || !out) return FQ_EINVAL;
+  static const bool trace_on = getenv("FQ_TRACE") != nullptr;
+  double t_trace = now_ms();
+#define TRACE(label) do { if (trace_on) { const double t_ = now_ms(); fprintf(stderr, "[fq] %-22s %8.3f ms\n", label, t_ - t_trace); t_trace = t_; } } while (0)
   if (fqdev::init(c->ix->device)) return FQ_ENODEV;   // the calling thread's own stream
   const double t_wall0 = now_ms();
   const fq_index *ix = c->ix;
@@ -434,6 +445,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   S.sub_lo = sub_lo;
   S.pair_idx = c->h_pair_list;
 
+  TRACE("stage0 prep+compact");
   // ---- stage A: widths + gap search, tiered by stack-pool size (GPU) ----------------------------------
   // h_aln: concatenated hit lists; per search index s: [aln_off[s], aln_off[s]+aln_n[s])
   vector<FqAln> &h_aln = S.aln;
@@ -505,15 +517,15 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   }
   c->stats.reads_searched += n_search;
 
+  TRACE("stageA width+gap");
   // ---- records for survivors -----------------------------------------------------------------------------
   vector<FqRead> &R = S.reads;
   R.assign((size_t)n_surv * 2, FqRead());
   vector<int> s_of((size_t)n_surv * 2, -1);
   {
-    vector<int32_t> sidx_of_read;   // only for survivors: derive from read_list
-    std::unordered_map<int, int> tmp;
-    tmp.reserve(n_search * 2 + 1);
-    for (int s = 0; s < n_search; ++s) tmp[c->h_read_list[s]] = s;
+    c->h_sidx.resize(n2);   // read -> search index (or -1), built by the compaction kernel
+    CK(fqdev::d2h(c->h_sidx.data(), c->d_sidx.p, (size_t)n2 * 4));
+    CK(fqdev::sync());
     for (int sp = 0; sp < n_surv; ++sp)
       for (int e = 0; e < 2; ++e) {
         FqRead &p = R[2 * sp + e];
@@ -523,8 +535,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
         p.len = p.clip_len = c->h_len_trim[r];
         p.filtered = c->h_filtered[r];
         p.extra_flag = 1 | (e == 0 ? 64 : 128);   // SAM_FPD | SAM_FR1/FR2 (BwtMapper.cpp:749)
-        auto it = tmp.find(r);
-        s_of[2 * sp + e] = it == tmp.end() ? -1 : it->second;
+        s_of[2 * sp + e] = c->h_sidx[r];
       }
   }
   auto aln_of = [&](int idx, int *n_out) -> const FqAln * {
@@ -534,6 +545,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
     return h_aln.data() + aln_off[s];
   };
 
+  TRACE("records init");
   // ---- SA rows to resolve on the GPU: every row of every hit of reads that can need them ------------------
   // eligible(read) = n_occ <= max(n_multi,N_multi)+1  (XA listing, bwase.c:47-55)  or
   //                  both mates have hits and both n_occ <= max_occ (pair enumeration, BwtMapper.cpp:797-811)
@@ -590,6 +602,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
     }
   }
 
+  TRACE("SA enumerate+kernel");
   const double t_host0 = now_ms();
   // ---- stage B1 (host, serial, read order): main hit choice consumes the drand48 stream (Q2) ------------
   vector<uint32_t> dq_row, dq_info; vector<int> dq_idx;
@@ -622,6 +635,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
     for (size_t i = 0; i < nq; ++i) R[dq_idx[i]].pos = tmp[i];
     c->stats.sa_rows += nq;
   }
+  TRACE("B1 main hit (serial)");
   // ---- stage B2: insert size per reference batch, with the last_ii fallback chain (Q3) -----------------------
   vector<fq_isize_t> iis(n_sub);
   {
@@ -637,11 +651,13 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   }
   const double t_serial1 = now_ms();
 
+  TRACE("B2 isize");
   // ---- stage B3: pairing + XA lists (per pair) -------------------------------------------------------------
   {
     vector<uint64_t> arr;
     for (int sb = 0; sb < n_sub; ++sb) {
     const fq_isize_t ii = iis[sb];
+    c->pen_lut.assign((size_t)ii.high_bayesian + 2, INT32_MIN);
     for (int sp = sub_lo[sb]; sp < sub_lo[sb + 1]; ++sp) {
       FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
       const FqAln *aln[2]; int na[2];
@@ -681,6 +697,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
     }
   }
 
+  TRACE("B3 pairing+XA");
   if (c->debug) S.stage_P = R;   // snapshot for the stage dump (tests)
 
   // ---- stage C: mate rescue by Smith-Waterman (bwa_paired_sw, libbwa/bwape.c:463-625) ---------------------
@@ -793,6 +810,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
       }
     }
   }
+  TRACE("C mate SW");
   if (c->debug) S.stage_S = R;
 
   // ---- stage D: gapped refinement (bwa_refine_gapped, libbwa/bwase.c:339-418) ------------------------------
@@ -909,6 +927,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
       s.len = s.full_len;
     }
   }
+  TRACE("D refine+MD+trim");
   c->last_ii = iis[n_sub - 1];
   const double t_host1 = now_ms();
 
@@ -919,6 +938,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   S.aln_off = aln_off;
   S.aln_n = aln_n;
   S.flatten();
+  TRACE("flatten");
   int n_both_unmapped = 0;
   for (int sp = 0; sp < n_surv; ++sp) if (R[2 * sp].type == FQ_TYPE_NO_MATCH && R[2 * sp + 1].type == FQ_TYPE_NO_MATCH) ++n_both_unmapped;
   out->n_survivors = n_surv;
