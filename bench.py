@@ -28,11 +28,11 @@ K_NAMES = ("prep", "width", "gap", "sa", "sw", "refine")
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--pairs", type=int, default=16 * 262144,
                     help="pairs per step: one call carrying this many pairs = pairs/262144 reference batches (READ_BUFFER_SIZE)")
-    ap.add_argument("--ctxs", type=int, default=3,
+    ap.add_argument("--ctxs", type=int, default=8,
                     help="alignment contexts (independent FASTQ streams) driven concurrently, one host thread + HIP stream each")
     ap.add_argument("--markers", type=int, default=10000)
     ap.add_argument("--mix", choices=("wgs", "ontarget"), default="wgs",
@@ -153,14 +153,23 @@ def main() -> None:
     dom = max(range(len(K_NAMES)), key=lambda k: kms[k])
     seq_bytes = float(sum(int(b.lens.sum()) for b in batches)) / n_ctx * args.steps
     if K_NAMES[dom] == "prep":
-        alg_bytes = 64.0 * agg["filter_probes"] + seq_bytes + 9.0 * 2 * args.pairs * args.steps
-        model = "64 B x bitmap probes + read bytes + 9 B/read flags"
+        alg_bytes = 64.0 * agg["filter_probes"] + 96.0 * 2 * args.pairs * args.steps + 5.0 * 2 * args.pairs * args.steps
+        model = "64 B x bitmap probes + 96 B of bases/read + 5 B/read out"
     elif K_NAMES[dom] == "gap":
         alg_bytes = 48.0 * agg["gap_occ_touches"]
         model = "48 B x Occ block touches (reference block definition, SURVEY 8d)"
     else:
         alg_bytes = 48.0 * agg["occ_block_touches"]
         model = "48 B x Occ block touches"
+    # every kernel's algorithmic rate (the roofline object below repeats the dominant one)
+    per_kernel = {}
+    for kname, byts in (("prep", 64.0 * agg["filter_probes"] + 96.0 * 2 * args.pairs * args.steps + 5.0 * 2 * args.pairs * args.steps),
+                        ("gap", 48.0 * agg["gap_occ_touches"])):
+        ki = K_NAMES.index(kname)
+        nl = max(1, int(agg["kernel_launches"][ki]))
+        ms = kms[ki] / nl
+        per_kernel["fq_" + kname] = {"avg_launch_ms": round(ms, 4), "alg_GBps": round((byts / nl) / (ms * 1e-3) / 1e9, 2) if ms > 0 else 0.0,
+                                     "frac_of_hbm_peak": round((byts / nl) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else 0.0}
     launches = max(1, int(agg["kernel_launches"][dom]))
     avg_ms = kms[dom] / launches
     achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
@@ -189,6 +198,7 @@ def main() -> None:
                    "markers": args.markers, "mix": args.mix, "concurrent_streams": n_ctx,
                    "sharding": "batches per rank, no data-path collective"},
         "roofline": roofline,
+        "kernel_rooflines": per_kernel,
         "kernel_ms_per_step": {K_NAMES[k]: round(kms[k] / args.steps, 4) for k in range(len(K_NAMES))},
         "host_ms_per_step": round(agg["host_ms_total"] / args.steps, 3),
         "survivor_pairs_per_step": round(n_records / args.steps, 1),

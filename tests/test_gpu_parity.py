@@ -106,3 +106,32 @@ def test_full_batch_properties(lib, tmp_path):
     assert not [d for d in ob.diff_stage_files(str(tmp_path / "o.st"), str(tmp_path / "g.st")) if not d.startswith("line count")]
     assert filecmp.cmp(str(tmp_path / "o.sam"), str(tmp_path / "g.sam"), shallow=False)
     al.close(); oa.close(); ix.close()
+
+
+def test_cli_sam_out_matches_reference_golden(golden_cases, tmp_path):
+    """`FASTQuick_amd align --sam_out` (C++ front end: gz FASTQ tokenizer + C ABI) on the golden FASTQ files must print the
+    reference's SAM text.  --chunk_pairs is irrelevant here (one reference batch per golden case would need batch_pairs,
+    so only cases whose golden batch covers the whole input are used)."""
+    import gzip
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "fastquick_amd", "bin", "FASTQuick_amd")
+    assert os.path.exists(exe), "build() must produce the CLI"
+    for tag in ("repeat", "nref"):
+        g = golden_cases[tag]
+        assert g["batch"] >= g["n_pairs"]
+        fq = []
+        for k in ("fq1", "fq2"):      # exercise the gz path of the tokenizer
+            gz = str(tmp_path / (tag + os.path.basename(g[k]) + ".gz"))
+            with open(g[k], "rb") as fi, gzip.open(gz, "wb") as fo:
+                fo.write(fi.read())
+            fq.append(gz)
+        prefix = g["prefix"][:-len(".FASTQuick.fa")]
+        cmd = [exe, "align", "--index_prefix", prefix, "--fastq_1", fq[0], "--fastq_2", fq[1], "--out_prefix", str(tmp_path / tag), "--sam_out"]
+        if g["trim_qual"]:
+            cmd += ["--q", str(g["trim_qual"])]
+        out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
+        assert out == open(g["sam"], "rb").read()
+    # asking for the unbuilt BAM path is a loud error
+    r = subprocess.run([exe, "align", "--index_prefix", "x", "--fastq_1", "a", "--fastq_2", "b", "--out_prefix", "o"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert r.returncode != 0 and b"not built" in r.stderr
