@@ -65,7 +65,7 @@ class Stats(C.Structure):
                 ("stack_pops", C.c_uint64), ("stack_pushes", C.c_uint64), ("sa_rows", C.c_uint64),
                 ("reads_searched", C.c_uint64), ("pairs", C.c_uint64), ("sw_tasks", C.c_uint64),
                 ("refine_tasks", C.c_uint64), ("tier_retries", C.c_uint64),
-                ("max_pops_per_read", C.c_uint64), ("reads_over_4k_pops", C.c_uint64),
+                ("max_pops_per_read", C.c_uint64), ("reads_over_4k_pops", C.c_uint64), ("max_wave_trips", C.c_uint64),
                 ("host_ms_serial", C.c_double), ("host_ms_pair", C.c_double), ("host_ms_total", C.c_double),
                 ("wall_ms_total", C.c_double)]
 

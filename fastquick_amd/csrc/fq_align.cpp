@@ -456,7 +456,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
     const FqGapTier tiers[3] = {{4096u, 32u, 0}, {65535u, 512u, 0}, {(uint32_t)o.max_entries + 64u, 8192u, 1}};
     // scores that can occur for the longest read of this call (children may exceed max_diff by one difference)
     const int nb_need = (c->maxdiff_lut[max_len_all] + 1) * o.s_mm + o.max_gapo * o.s_gapo + o.max_gape * o.s_gape + 1;
-    const size_t chunk_reads[3] = {(size_t)1 << 20, 8192, 64};
+    const size_t chunk_reads[3] = {(size_t)8 << 20, (size_t)1 << 20, 64};   // pools are per persistent lane; only per-read outputs scale with the chunk
     vector<int32_t> work(n_search), next_work;
     for (int s = 0; s < n_search; ++s) work[s] = s;
     vector<uint32_t> h_status, h_naln;
@@ -468,23 +468,27 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
       next_work.clear();
       for (size_t c0 = 0; c0 < work.size(); c0 += chunk_reads[tier]) {
         const int nw = (int)std::min(chunk_reads[tier], work.size() - c0);
-        CKM(c->d_work.ensure(nw) && c->d_wrec.ensure((size_t)nw * 2 * Lpad) && c->d_srec.ensure((size_t)nw * 2 * (FQ_SEED_MAX + 1)) &&
-            c->d_heads.ensure((size_t)nw * FQ_MAX_BUCKETS) && c->d_pool.ensure((size_t)nw * T.pool_cap) &&
+        CKM(c->d_work.ensure(nw) && c->d_wrec.ensure((size_t)nw * 2 * Lpad) && c->d_srec.ensure((size_t)nw * 2 * (FQ_SEED_MAX + 1)) && c->d_namb.ensure(nw) &&
             c->d_aln.ensure((size_t)nw * T.aln_cap) && c->d_naln.ensure(nw) && c->d_status.ensure(nw) && c->d_off.ensure(nw + 1));
         CK(fqdev::h2d(c->d_work.p, work.data() + c0, (size_t)nw * 4));
         FqWidthArgs wa{};
         wa.ix = ix->dev; wa.o = c->ko; wa.seq = c->d_seq.p; wa.stride = stride; wa.len_trim = c->d_len_trim.p; wa.read_list = c->d_read_list.p;
         wa.work = c->d_work.p; wa.n_work = nw; wa.wrec = c->d_wrec.p; wa.wstride = Lpad;
-        wa.srec = c->d_srec.p; wa.counters = c->d_counters.p;
+        wa.srec = c->d_srec.p; wa.n_amb = c->d_namb.p; wa.counters = c->d_counters.p;
         fqdev::time_begin(FQ_K_WIDTH);
         CK(fqdev::launch_width(wa));
         fqdev::time_end(FQ_K_WIDTH);
         FqGapArgs ga{};
         ga.ix = ix->dev; ga.o = c->ko; ga.o.n_buckets = nb_need; ga.seq = c->d_seq.p; ga.stride = stride; ga.len_trim = c->d_len_trim.p;
         ga.read_list = c->d_read_list.p; ga.work = c->d_work.p; ga.n_work = nw; ga.maxdiff_lut = c->d_maxdiff.p;
-        ga.wrec = c->d_wrec.p; ga.wstride = Lpad; ga.srec = c->d_srec.p;
+        ga.wrec = c->d_wrec.p; ga.wstride = Lpad; ga.srec = c->d_srec.p; ga.n_amb = c->d_namb.p;
         ga.pool = c->d_pool.p; ga.heads = c->d_heads.p; ga.tier = T; ga.aln = c->d_aln.p; ga.n_aln = c->d_naln.p; ga.status = c->d_status.p;
         ga.counters = c->d_counters.p; ga.queue = c->d_queue.p;
+        {
+          const size_t slots = (size_t)fqdev::gap_lane_slots(ga);
+          CKM(c->d_heads.ensure(slots * FQ_MAX_BUCKETS) && c->d_pool.ensure(slots * T.pool_cap));
+          ga.pool = c->d_pool.p; ga.heads = c->d_heads.p;
+        }
         fqdev::time_begin(FQ_K_GAP);
         CK(fqdev::launch_gap(ga));
         fqdev::time_end(FQ_K_GAP);
@@ -968,6 +972,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
     c->stats.stack_pushes += cnt[FQ_C_PUSHES];
     if (cnt[FQ_C_MAXPOPS] > c->stats.max_pops_per_read) c->stats.max_pops_per_read = cnt[FQ_C_MAXPOPS];
     c->stats.reads_over_4k_pops += cnt[FQ_C_POPS_GT4K];
+    if (cnt[FQ_C_MAXTRIPS] > c->stats.max_wave_trips) c->stats.max_wave_trips = cnt[FQ_C_MAXTRIPS];
     c->stats.pairs += n;
     c->stats.host_ms_serial += t_serial1 - t_host0;
     c->stats.host_ms_pair += t_host1 - t_serial1;

@@ -32,6 +32,8 @@ int launch_prep(const FqPrepArgs &a);
 //   counts[0] = n_search, counts[1] = n_surv   (device memory)
 int launch_compact(const uint8_t *filtered, int n_pairs, int32_t *read_list, int32_t *sidx, int32_t *pair_list, int32_t *counts);
 int launch_width(const FqWidthArgs &a);
+// number of persistent lanes launch_gap() will start for these arguments (sizes a.pool / a.heads)
+int gap_lane_slots(const FqGapArgs &a);
 int launch_gap(const FqGapArgs &a);
 // out[0..n] = exclusive prefix sums of in[0..n) (64-bit); out[n] = total
 int launch_scan(const uint32_t *in, uint64_t *out, uint32_t n);

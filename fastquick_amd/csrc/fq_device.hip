@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <atomic>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -107,11 +108,11 @@ struct FqQueueFetch {
 __global__ void __launch_bounds__(64) k_gap_persist_lds(FqGapArgs a) {
   uint16_t *heads = (uint16_t *)fq_dyn_lds;
   FqGapStoreLds st = {heads + threadIdx.x, 64};
-  fq_gap_lanes(a, st, FqQueueFetch{a.queue, a.n_work});
+  fq_gap_lanes(a, st, FqQueueFetch{a.queue, a.n_work}, (int)(blockIdx.x * 64 + threadIdx.x));
 }
 __global__ void __launch_bounds__(64) k_gap_persist(FqGapArgs a) {   // any pool size: bucket heads in HBM
   FqGapStoreGlobal st = {nullptr};
-  fq_gap_lanes(a, st, FqQueueFetch{a.queue, a.n_work});
+  fq_gap_lanes(a, st, FqQueueFetch{a.queue, a.n_work}, (int)(blockIdx.x * 64 + threadIdx.x));
 }
 __global__ void __launch_bounds__(256) k_sa(FqSaArgs a) {
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -412,20 +413,30 @@ int launch_width(const FqWidthArgs &a) {
   FQ_HIP(hipGetLastError());
   return 0;
 }
-int launch_gap(const FqGapArgs &a) {
+int gap_lane_slots(const FqGapArgs &a) {
   if (a.n_work <= 0) return 0;
+  static const int env_waves = getenv("FQ_GAP_WAVES_PER_CU") ? atoi(getenv("FQ_GAP_WAVES_PER_CU")) : 0;
+  const unsigned need = nblk((uint64_t)a.n_work, 64);
+  unsigned per_cu = 8;
+  if (a.tier.pool_cap <= 65535u) {
+    const size_t lds = (size_t)64 * (size_t)a.o.n_buckets * 2;
+    per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16, (150 * 1024) / lds));
+  }
+  if (env_waves > 0) per_cu = std::min<unsigned>(per_cu, (unsigned)env_waves);
+  return (int)(std::min(need, 256u * per_cu) * 64u);
+}
+int launch_gap(const FqGapArgs &a_in) {
+  if (a_in.n_work <= 0) return 0;
+  FqGapArgs a = a_in;
+  static const int env_waves = getenv("FQ_GAP_WAVES_PER_CU") ? atoi(getenv("FQ_GAP_WAVES_PER_CU")) : 0;
+  static const int env_refill = getenv("FQ_GAP_REFILL_MIN") ? atoi(getenv("FQ_GAP_REFILL_MIN")) : 0;
+  a.refill_min = env_refill > 0 ? env_refill : FQ_REFILL_MIN;
   FQ_HIP(hipMemsetAsync(a.queue, 0, 4, g_stream));
   // LDS-resident bucket heads when slot indices fit 16 bits
   const size_t lds = (size_t)64 * (size_t)a.o.n_buckets * 2;
-  const unsigned need = nblk((uint64_t)a.n_work, 64);
-  if (a.tier.pool_cap <= 65535u) {
-    const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16, (150 * 1024) / lds));
-    const unsigned grid = std::min(need, 256u * per_cu);
-    hipLaunchKernelGGL(k_gap_persist_lds, dim3(grid), dim3(64), lds, g_stream, a);
-  } else {
-    const unsigned grid = std::min(need, 256u * 8u);
-    hipLaunchKernelGGL(k_gap_persist, dim3(grid), dim3(64), 0, g_stream, a);
-  }
+  const unsigned grid = (unsigned)gap_lane_slots(a) / 64u;
+  if (a.tier.pool_cap <= 65535u) hipLaunchKernelGGL(k_gap_persist_lds, dim3(grid), dim3(64), lds, g_stream, a);
+  else hipLaunchKernelGGL(k_gap_persist, dim3(grid), dim3(64), 0, g_stream, a);
   FQ_HIP(hipGetLastError());
   return 0;
 }

@@ -12,12 +12,14 @@
 #define FQ_LAMBDA_INLINE __attribute__((always_inline))
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FQ_POPC64(x) __popcll(x)
+#define FQ_POPC32(x) __popc(x)
 #define FQ_CTZ32(x) (__ffs((int)(x)) - 1)
 #define FQ_ATOMIC_ADD64(p, v) atomicAdd((unsigned long long *)(p), (unsigned long long)(v))
 #define FQ_ATOMIC_MAX64(p, v) atomicMax((unsigned long long *)(p), (unsigned long long)(v))
 #else
 #define FQ_ATOMIC_MAX64(p, v) (*(p) = *(p) > (uint64_t)(v) ? *(p) : (uint64_t)(v))
 #define FQ_POPC64(x) __builtin_popcountll(x)
+#define FQ_POPC32(x) __builtin_popcount(x)
 #define FQ_CTZ32(x) __builtin_ctz(x)
 #define FQ_ATOMIC_ADD64(p, v) (*(p) += (v))
 #endif
@@ -197,8 +199,8 @@ struct FqReadView {
   int len;
 };
 FQ_HD int fq_base(const FqReadView &v, int a, int i) {
-  const int c = fq_nt4(v.row[v.len - 1 - i]);
-  return a ? fq_comp(c) : c;
+  const int c = (int)fq_nt4_fast(v.row[v.len - 1 - i]);
+  return (a && c < 4) ? 3 - c : c;
 }
 
 // ---- K_width: bwt_cal_width (libbwa/bwtaln.c:73-97), four chains per read -----------------------
@@ -214,6 +216,7 @@ struct FqWidthArgs {
   FqWRec *wrec;               // [w][2][wstride]   {w, bid} per position
   int32_t wstride;
   FqWRec *srec;               // [w][2][FQ_SEED_MAX+1]
+  int32_t *n_amb;             // [w] number of non-ACGT bases of the (trimmed) read
   uint64_t *counters;
 };
 FQ_HD void fq_width_thread(const FqWidthArgs &A, int t) {
@@ -227,9 +230,10 @@ FQ_HD void fq_width_thread(const FqWidthArgs &A, int t) {
   const FqFM &f = A.ix.fm[strand];
   FqWRec *orec = seed ? A.srec + ((size_t)w * 2 + strand) * (FQ_SEED_MAX + 1) : A.wrec + ((size_t)w * 2 + strand) * (size_t)A.wstride;
   uint32_t k = 0, l = f.seq_len, touches = 0;
-  int bid = 0;
+  int bid = 0, namb = 0;
   for (int i = 0; i < n; ++i) {
     const int c = fq_base(v, strand, off + i);
+    namb += c > 3;
     if (c < 4) {
       touches += fq_touch2(f, k - 1, l, true);
       const uint32_t ok = fq_occ1(f, k - 1, c), ol = fq_occ1(f, l, c);
@@ -241,6 +245,7 @@ FQ_HD void fq_width_thread(const FqWidthArgs &A, int t) {
     orec[i] = rec;
   }
   { FqWRec rec; rec.w = 0; rec.bid = (uint32_t)(bid + 1); orec[n] = rec; }
+  if (which == 0) A.n_amb[w] = namb;
   FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_WIDTH], touches);
 }
 
@@ -268,21 +273,23 @@ struct FqGapArgs {
   FqWRec *wrec;          // width records written by k_width; gap_shadow updates them in place
   int32_t wstride;
   const FqWRec *srec;
-  FqEntry *pool;
-  uint32_t *heads;
+  const int32_t *n_amb;  // [w], from k_width
+  FqEntry *pool;         // [n_lane_slots][pool_cap]: one stack pool per persistent lane
+  uint32_t *heads;       // [n_lane_slots][FQ_MAX_BUCKETS] (HBM-heads variant)
   FqGapTier tier;
   FqAln *aln;
   uint32_t *n_aln;
   uint32_t *status;
   uint64_t *counters;
   uint32_t *queue;       // work-queue cursor (zeroed before each launch)
+  int32_t refill_min;    // idle lanes of a wavefront wait until this many can be (re)initialised together
 };
 
 // Where a read's bucket heads live during the search: HBM (any pool size) or lane-interleaved LDS with 16-bit slots
 // (pool <= 65535 entries), which takes the head read-modify-write of every push off the global-memory latency chain.
 struct FqGapStoreGlobal {
   uint32_t *head;
-  FQ_HD void begin_read(const FqGapArgs &A, int w) { head = A.heads + (size_t)w * FQ_MAX_BUCKETS; }
+  FQ_HD void begin_read(const FqGapArgs &A, int lane_slot) { head = A.heads + (size_t)lane_slot * FQ_MAX_BUCKETS; }
   FQ_HD uint32_t head_get(int b) const { return head[b]; }
   FQ_HD void head_set(int b, uint32_t slot) const { head[b] = slot; }
 };
@@ -305,35 +312,41 @@ FQ_HD uint32_t fq_sel4v(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, int 
 }
 FQ_HD uint32_t fq_sel4(const uint32_t *v, int c) { return fq_sel4v(v[0], v[1], v[2], v[3], c & 3); }
 
-// raw 32-byte Occ block fetch shared by the single-base and the four-base rank
-struct FqBlkRaw { uint32_t c0, c1, c2, c3; uint64_t lo, hi; uint32_t sh; bool valid; };
+// raw 32-byte Occ block fetch shared by the single-base and the four-base rank.  The two bit planes are kept as 32-bit
+// halves and the prefix mask is built from 32-bit shifts: 64-bit shifts are quarter-rate on CDNA4 and this code sits on the
+// dependent chain of every search step.
+struct FqBlkRaw { uint32_t c0, c1, c2, c3; uint32_t lo0, lo1, hi0, hi1; uint32_t mk0, mk1; bool valid; };   // *0 = bases 0..31 (bits 63..32 of the plane)
 FQ_HD FqBlkRaw fq_blk_load(const FqFM &f, uint32_t k) {
   FqBlkRaw r;
   r.valid = k != 0xffffffffu;
-  r.c0 = r.c1 = r.c2 = r.c3 = 0; r.lo = r.hi = 0; r.sh = 0;
+  r.c0 = r.c1 = r.c2 = r.c3 = 0; r.lo0 = r.lo1 = r.hi0 = r.hi1 = 0; r.mk0 = r.mk1 = 0;
   if (r.valid) {
     k = fq_adj(f, k);
     const FqOccBlk *b = f.blk + (k >> 6);
     r.c0 = b->cnt[0]; r.c1 = b->cnt[1]; r.c2 = b->cnt[2]; r.c3 = b->cnt[3];
-    r.lo = b->lo; r.hi = b->hi;
-    r.sh = 63 - (k & 63);
+    const uint64_t lo = b->lo, hi = b->hi;
+    r.lo0 = (uint32_t)(lo >> 32); r.lo1 = (uint32_t)lo; r.hi0 = (uint32_t)(hi >> 32); r.hi1 = (uint32_t)hi;
+    const uint32_t t = k & 63;                     // bases 0..t of the block are counted
+    const uint32_t t0 = t < 32 ? t : 31, t1 = t < 32 ? 0 : t - 32;
+    r.mk0 = 0xffffffffu << (31 - t0);
+    r.mk1 = t < 32 ? 0u : (0xffffffffu << (31 - t1));
   }
   return r;
 }
+FQ_HD uint32_t fq_popc2(uint32_t a, uint32_t b) { return (uint32_t)(FQ_POPC32(a) + FQ_POPC32(b)); }
 FQ_HD uint32_t fq_blk_occ1(const FqBlkRaw &r, int c) {
   if (!r.valid) return 0;
-  const uint64_t m = ~0ull << r.sh;
-  const uint64_t x = (r.hi ^ (0ull - (uint64_t)(((c >> 1) & 1) ^ 1))) & (r.lo ^ (0ull - (uint64_t)((c & 1) ^ 1))) & m;
-  const uint32_t base = fq_sel4v(r.c0, r.c1, r.c2, r.c3, c);
-  return base + (uint32_t)FQ_POPC64(x);
+  const uint32_t fh = 0u - (uint32_t)(((c >> 1) & 1) ^ 1), fl = 0u - (uint32_t)((c & 1) ^ 1);   // flip masks: select base c
+  const uint32_t x0 = (r.hi0 ^ fh) & (r.lo0 ^ fl) & r.mk0, x1 = (r.hi1 ^ fh) & (r.lo1 ^ fl) & r.mk1;
+  return fq_sel4v(r.c0, r.c1, r.c2, r.c3, c) + fq_popc2(x0, x1);
 }
 FQ_HD void fq_blk_occ4(const FqBlkRaw &r, uint32_t o[4]) {
   if (!r.valid) { o[0] = o[1] = o[2] = o[3] = 0; return; }
-  const uint64_t m = ~0ull << r.sh;
-  o[0] = r.c0 + (uint32_t)FQ_POPC64(~r.hi & ~r.lo & m);
-  o[1] = r.c1 + (uint32_t)FQ_POPC64(~r.hi & r.lo & m);
-  o[2] = r.c2 + (uint32_t)FQ_POPC64(r.hi & ~r.lo & m);
-  o[3] = r.c3 + (uint32_t)FQ_POPC64(r.hi & r.lo & m);
+  const uint32_t nh0 = ~r.hi0 & r.mk0, nh1 = ~r.hi1 & r.mk1, h0 = r.hi0 & r.mk0, h1 = r.hi1 & r.mk1;
+  o[0] = r.c0 + fq_popc2(nh0 & ~r.lo0, nh1 & ~r.lo1);
+  o[1] = r.c1 + fq_popc2(nh0 & r.lo0, nh1 & r.lo1);
+  o[2] = r.c2 + fq_popc2(h0 & ~r.lo0, h1 & ~r.lo1);
+  o[3] = r.c3 + fq_popc2(h0 & r.lo0, h1 & r.lo1);
 }
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -376,7 +389,8 @@ struct FqGapLane {
   uint32_t tk, tl, tpk;
   int ti, tscore;
 
-  FQ_HD FqGapLane(const FqGapArgs &A_, const St &st) : A(A_), store(st), fm0(A_.ix.fm[0]), fm1(A_.ix.fm[1]), o(A_.o) {
+  int lane_slot;
+  FQ_HD FqGapLane(const FqGapArgs &A_, const St &st, int lane_slot_) : A(A_), store(st), fm0(A_.ix.fm[0]), fm1(A_.ix.fm[1]), o(A_.o), lane_slot(lane_slot_) {
     gape_mode = (o.mode & FQ_MODE_GAPE) != 0; nonstop = (o.mode & FQ_MODE_NONSTOP) != 0; exact = A_.tier.exact != 0;
     active = done = false; w = len = max_diff_opt = seed_len = 0; use_seed = false;
     v.row = A_.seq; v.len = 0;
@@ -478,24 +492,38 @@ struct FqGapLane {
     max_diff_opt = A.maxdiff_lut[len];
     use_seed = len > o.seed_len;
     seed_len = o.seed_len < len ? o.seed_len : 0x7fffffff;
-    pool = A.pool + (size_t)w * (size_t)A.tier.pool_cap;
+    pool = A.pool + (size_t)lane_slot * (size_t)A.tier.pool_cap;   // stack storage belongs to the lane, not to the read
     aln = A.aln + (size_t)w * (size_t)A.tier.aln_cap;
     wrec = A.wrec + (size_t)w * 2 * (size_t)A.wstride;
     srec = A.srec + (size_t)w * 2 * (FQ_SEED_MAX + 1);
-    store.begin_read(A, w);
+    store.begin_read(A, lane_slot);
     m0 = m1 = m2 = m3 = 0; bump = 0; spare = FQ_NIL; status = 0; n_aln = 0; n_live = 0;
     best_score = (max_diff_opt + 1) * o.s_mm + (o.max_gapo + 1) * o.s_gapo + (o.max_gape + 1) * o.s_gape;
     max_diff = max_diff_opt; best_cnt = 0;
     c_pops = c_pushes = c_touch = 0;
     fwd_valid = false; tail = false;
     active = true;
-    int n_amb = 0;   // "too many N" early-out of bwt_match_gap (bwtgap.c:118-124)
-    for (int j = 0; j < len; ++j) n_amb += fq_nt4(v.row[j]) > 3;
-    if (n_amb > max_diff_opt) { finish(); return; }
+    if (A.n_amb[w] > max_diff_opt) { finish(); return; }   // "too many N" early-out of bwt_match_gap (bwtgap.c:118-124)
     push(0, len, 0, fm0.seq_len, 0, 0, 0, FQ_ST_M, false, 0);
     push(1, len, 0, fm0.seq_len, 0, 0, 0, FQ_ST_M, false, 0);
   }
 
+  // everything a just-popped entry needs from global memory: the two Occ blocks, its width / seed-width records and base
+  FQ_HD void load_entry_data(uint32_t k, uint32_t l, uint32_t pk, FqBlkRaw &bk, FqBlkRaw &bl, FqWRec &w1, FqWRec &w2, FqWRec &s1r, FqWRec &s2r, int &cbase) const {
+    const int a = (int)(pk >> 9) & 1, i0 = (int)(pk & 511);
+    const FqFM f = fm_for(a);
+    bk = fq_blk_load(f, k - 1); bl = fq_blk_load(f, l);
+    w1.w = w1.bid = w2.w = w2.bid = s1r.w = s1r.bid = s2r.w = s2r.bid = 0;
+    cbase = 0;
+    if (i0 >= 1) {
+      cbase = fq_base(v, a, i0 - 1);
+      const FqWRec *ww = wrec + (size_t)a * (size_t)A.wstride;
+      w1 = ww[i0 - 1];
+      if (i0 >= 2) w2 = ww[i0 - 2];
+      const int ii0 = (i0 - 1) - (len - seed_len);
+      if (use_seed && ii0 > 0) { const FqWRec *sw = srec + (size_t)a * (FQ_SEED_MAX + 1); s1r = sw[ii0]; s2r = sw[ii0 - 1]; }
+    }
+  }
   // one iteration for an active lane
   FQ_HD void step() {
     // ---- phase 1 (lane specific, no global Occ access): decide which SA interval this iteration extends ------------------
@@ -531,17 +559,18 @@ struct FqGapLane {
     // ---- phase 2 (common): the two 32-byte Occ blocks of rows k-1 and l -----------------------------------------------------
     const int a = (int)(pk >> 9) & 1;
     const FqFM f = fm_for(a);
-    const FqBlkRaw bk = fq_blk_load(f, k - 1), bl = fq_blk_load(f, l);
     const int i0 = fresh ? (int)(pk & 511) : ti;          // position before this step's base is consumed (>= 1)
-    const int cbase = fq_base(v, a, i0 - 1);               // the base this step consumes (tail) / branches on (expand)
+    FqBlkRaw bk, bl;
     FqWRec w1, w2, s1r, s2r;                                // width[i0-1], width[i0-2], seed_width[ii], seed_width[ii-1]
-    w1.w = w1.bid = w2.w = w2.bid = s1r.w = s1r.bid = s2r.w = s2r.bid = 0;
-    const int ii0 = (i0 - 1) - (len - seed_len);
+    int cbase;                                              // the base this step consumes (tail) / branches on (expand)
     if (fresh) {
-      const FqWRec *ww = wrec + (size_t)a * (size_t)A.wstride;
-      w1 = ww[i0 - 1];
-      if (i0 >= 2) w2 = ww[i0 - 2];
-      if (use_seed && ii0 > 0) { const FqWRec *sw = srec + (size_t)a * (FQ_SEED_MAX + 1); s1r = sw[ii0]; s2r = sw[ii0 - 1]; }
+      load_entry_data(k, l, pk, bk, bl, w1, w2, s1r, s2r, cbase);
+    } else {
+      bk = fq_blk_load(f, k - 1); bl = fq_blk_load(f, l);
+      cbase = fq_base(v, a, i0 - 1);
+      w1.w = w1.bid = w2.w = w2.bid = s1r.w = s1r.bid = s2r.w = s2r.bid = 0;
+    }
+    if (fresh) {
       const int st0 = (int)(pk >> 10) & 3, n_mm0 = (int)(pk >> 12) & 31, n_gapo0 = (int)(pk >> 17) & 3, n_gape0 = (int)(pk >> 19) & 15;
       int m0d = max_diff - (n_mm0 + n_gapo0);
       if (gape_mode) m0d -= n_gape0;
@@ -637,14 +666,15 @@ struct FqGapLane {
 };
 
 template <class St, class Fetch>
-FQ_HD void fq_gap_lanes(const FqGapArgs &A, const St &store0, Fetch fetch) {
-  FqGapLane<St> L(A, store0);
-  for (;;) {
+FQ_HD void fq_gap_lanes(const FqGapArgs &A, const St &store0, Fetch fetch, int lane_slot) {
+  FqGapLane<St> L(A, store0, lane_slot);
+  uint32_t trips = 0;
+  for (;; ++trips) {
     // (re)fill idle lanes, in groups
     const bool want = !L.active && !L.done;
     const int n_want = FQ_WAVE_COUNT(want), n_active = FQ_WAVE_COUNT(L.active);
-    if (n_want == 0 && n_active == 0) break;
-    if (want && (n_want >= FQ_REFILL_MIN || n_active == 0)) {
+    if (n_want == 0 && n_active == 0) { FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXTRIPS], trips); break; }
+    if (want && (n_want >= A.refill_min || n_active == 0)) {
       const int w = fetch();
       if (w < 0) L.done = true; else L.begin(w);
     }

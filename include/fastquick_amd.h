@@ -190,6 +190,7 @@ typedef struct {
   uint64_t reads_searched, pairs, sw_tasks, refine_tasks;
   uint64_t tier_retries;        /* reads re-run with a larger search pool */
   uint64_t max_pops_per_read, reads_over_4k_pops;   /* tail of the search-length distribution */
+  uint64_t max_wave_trips;      /* loop iterations of the busiest wavefront of the gap kernel (per launch, max) */
   double host_ms_serial, host_ms_pair, host_ms_total, wall_ms_total;
 } fq_stats_t;
 void fq_stats_get(const fq_ctx_t *c, fq_stats_t *out);

@@ -43,15 +43,18 @@ int launch_compact(const uint8_t *f, int n, int32_t *read_list, int32_t *sidx, i
 }
 int launch_width(const FqWidthArgs &a) { for (int t = 0; t < a.n_work * 4; ++t) fq_width_thread(a, t); return 0; }
 struct SeqFetch { int *next; int n; int operator()() const { return *next < n ? (*next)++ : -1; } };
-int launch_gap(const FqGapArgs &a) {
+int gap_lane_slots(const FqGapArgs &a) { return a.n_work > 0 ? 1 : 0; }
+int launch_gap(const FqGapArgs &a_in) {
+  FqGapArgs a = a_in;
+  a.refill_min = 1;
   int next = 0;
   if (a.tier.pool_cap <= 65535u) {   // same store policy the HIP launcher picks: 16-bit heads in (here: emulated) LDS
     std::vector<uint16_t> heads(a.o.n_buckets);
     FqGapStoreLds st = {heads.data(), 1};
-    fq_gap_lanes(a, st, SeqFetch{&next, a.n_work});
+    fq_gap_lanes(a, st, SeqFetch{&next, a.n_work}, 0);
   } else {
     FqGapStoreGlobal st = {nullptr};
-    fq_gap_lanes(a, st, SeqFetch{&next, a.n_work});
+    fq_gap_lanes(a, st, SeqFetch{&next, a.n_work}, 0);
   }
   return 0;
 }
