@@ -23,6 +23,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 K_NAMES = ("prep", "width", "gap", "sa", "sw", "refine")
+K_PREP_KERNEL, K_GAP_KERNEL = 6, 7     # single-kernel timings (kernel begin/end timestamps via hipExtLaunchKernelGGL events)
 
 
 def main() -> None:
@@ -151,6 +152,7 @@ def main() -> None:
                 agg[k] = [a + b for a, b in zip(agg[k], v)] if isinstance(v, list) else agg[k] + v
     kms = agg["kernel_ms"]
     dom = max(range(len(K_NAMES)), key=lambda k: kms[k])
+    KSRC = {"prep": K_PREP_KERNEL, "gap": K_GAP_KERNEL}   # stage -> the kernel whose own timestamps price it
     seq_bytes = float(sum(int(b.lens.sum()) for b in batches)) / n_ctx * args.steps
     if K_NAMES[dom] == "prep":
         alg_bytes = 64.0 * agg["filter_probes"] + 96.0 * 2 * args.pairs * args.steps + 5.0 * 2 * args.pairs * args.steps
@@ -165,13 +167,14 @@ def main() -> None:
     per_kernel = {}
     for kname, byts in (("prep", 64.0 * agg["filter_probes"] + 96.0 * 2 * args.pairs * args.steps + 5.0 * 2 * args.pairs * args.steps),
                         ("gap", 48.0 * agg["gap_occ_touches"])):
-        ki = K_NAMES.index(kname)
+        ki = KSRC[kname]
         nl = max(1, int(agg["kernel_launches"][ki]))
         ms = kms[ki] / nl
         per_kernel["fq_" + kname] = {"avg_launch_ms": round(ms, 4), "alg_GBps": round((byts / nl) / (ms * 1e-3) / 1e9, 2) if ms > 0 else 0.0,
                                      "frac_of_hbm_peak": round((byts / nl) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else 0.0}
-    launches = max(1, int(agg["kernel_launches"][dom]))
-    avg_ms = kms[dom] / launches
+    dsrc = KSRC.get(K_NAMES[dom], dom)
+    launches = max(1, int(agg["kernel_launches"][dsrc]))
+    avg_ms = kms[dsrc] / launches
     achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
     # HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected separately,
     # tools/pmc_summarize.py), scaled by this run's units per launch; null when no measurement exists for this mix/kernel.
@@ -199,7 +202,7 @@ def main() -> None:
                    "sharding": "batches per rank, no data-path collective"},
         "roofline": roofline,
         "kernel_rooflines": per_kernel,
-        "kernel_ms_per_step": {K_NAMES[k]: round(kms[k] / args.steps, 4) for k in range(len(K_NAMES))},
+        "stage_ms_per_step": {K_NAMES[k]: round(kms[k] / args.steps, 4) for k in range(len(K_NAMES))},
         "host_ms_per_step": round(agg["host_ms_total"] / args.steps, 3),
         "survivor_pairs_per_step": round(n_records / args.steps, 1),
         "work_per_step": {k: round(agg[k] / args.steps, 1) for k in ("filter_probes", "occ_block_touches", "gap_occ_touches", "stack_pops",

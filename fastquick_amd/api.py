@@ -13,7 +13,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 DEFAULT_LIB = os.path.join(HERE, "libfastquick_amd.so")
 
-FQ_K_NAMES = ("prep", "width", "gap", "sa", "sw", "refine")
+FQ_K_NAMES = ("prep", "width", "gap", "sa", "sw", "refine", "prep_kernel", "gap_kernel")
 
 
 class Opts(C.Structure):
@@ -60,7 +60,7 @@ class ResultBatch(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("kernel_ms", C.c_double * 6), ("kernel_launches", C.c_uint64 * 6),
+    _fields_ = [("kernel_ms", C.c_double * 8), ("kernel_launches", C.c_uint64 * 8),
                 ("occ_block_touches", C.c_uint64), ("gap_occ_touches", C.c_uint64), ("filter_probes", C.c_uint64),
                 ("stack_pops", C.c_uint64), ("stack_pushes", C.c_uint64), ("sa_rows", C.c_uint64),
                 ("reads_searched", C.c_uint64), ("pairs", C.c_uint64), ("sw_tasks", C.c_uint64),

@@ -1,6 +1,7 @@
 // fq_device.hip -- gfx950 (MI355X) backend: __global__ wrappers, stream compaction / scan kernels
 // with 64-wide wavefront ballots, memory + HIP-event timing.  Written for CDNA4 only.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <atomic>
@@ -76,6 +77,9 @@ static hipEvent_t get_event() {
 }
 void time_begin(int kid) { hipEvent_t e = get_event(); (void)hipEventRecord(e, g_stream); g_open_begin[kid] = e; }
 void time_end(int kid) { hipEvent_t e = get_event(); (void)hipEventRecord(e, g_stream); g_pending.push_back({kid, g_open_begin[kid], e}); }
+// start/stop events attached to one kernel (hipExtLaunchKernelGGL): the kernel's own begin/end timestamps, i.e. what
+// rocprofv3 --kernel-trace reports, unaffected by dispatch queueing when several streams share the GPU
+static void kernel_events(int kid, hipEvent_t *a, hipEvent_t *b) { *a = get_event(); *b = get_event(); g_pending.push_back({kid, *a, *b}); }
 void time_collect(double ms[], uint64_t launches[], int n_ids) {
   for (auto &p : g_pending) {
     float t = 0.f;
@@ -403,7 +407,9 @@ int launch_bitmap_scatter(uint8_t *bitmap, const uint32_t *bits, uint64_t n) {
 // ---- launch wrappers ------------------------------------------------------------------------------
 int launch_prep(const FqPrepArgs &a) {
   if (a.n_reads <= 0) return 0;
-  hipLaunchKernelGGL(k_prep, dim3(nblk((uint64_t)a.n_reads, 256)), dim3(256), 0, g_stream, a);
+  hipEvent_t e0, e1;
+  kernel_events(6, &e0, &e1);   // FQ_K_PREP_KERNEL
+  hipExtLaunchKernelGGL(k_prep, dim3(nblk((uint64_t)a.n_reads, 256)), dim3(256), 0, g_stream, e0, e1, 0, a);
   FQ_HIP(hipGetLastError());
   return 0;
 }
@@ -435,8 +441,10 @@ int launch_gap(const FqGapArgs &a_in) {
   // LDS-resident bucket heads when slot indices fit 16 bits
   const size_t lds = (size_t)64 * (size_t)a.o.n_buckets * 2;
   const unsigned grid = (unsigned)gap_lane_slots(a) / 64u;
-  if (a.tier.pool_cap <= 65535u) hipLaunchKernelGGL(k_gap_persist_lds, dim3(grid), dim3(64), lds, g_stream, a);
-  else hipLaunchKernelGGL(k_gap_persist, dim3(grid), dim3(64), 0, g_stream, a);
+  hipEvent_t e0, e1;
+  kernel_events(7, &e0, &e1);   // FQ_K_GAP_KERNEL
+  if (a.tier.pool_cap <= 65535u) hipExtLaunchKernelGGL(k_gap_persist_lds, dim3(grid), dim3(64), lds, g_stream, e0, e1, 0, a);
+  else hipExtLaunchKernelGGL(k_gap_persist, dim3(grid), dim3(64), 0, g_stream, e0, e1, 0, a);
   FQ_HIP(hipGetLastError());
   return 0;
 }

@@ -178,7 +178,9 @@ int64_t fq_stage_dump_last(fq_ctx_t *c, char *buf, int64_t cap);
 #define FQ_K_SA 3        /* bwt_sa over enumerated rows */
 #define FQ_K_SW 4        /* mate-rescue Smith-Waterman */
 #define FQ_K_REFINE 5    /* banded global DP + MD/NM */
-#define FQ_K_COUNT 6
+#define FQ_K_PREP_KERNEL 6   /* k_prep alone, kernel begin/end timestamps (hipExtLaunchKernelGGL events) */
+#define FQ_K_GAP_KERNEL 7    /* the gap-search kernel alone, same */
+#define FQ_K_COUNT 8
 typedef struct {
   double kernel_ms[FQ_K_COUNT];
   uint64_t kernel_launches[FQ_K_COUNT];
