@@ -80,7 +80,8 @@ struct fq_ctx {
   const fq_read_batch_t *host_batch_valid = nullptr;
   fq_read_batch_t hb{};
   DevBuf<uint8_t> d_seq, d_qual, d_filtered, d_maxdiff;
-  DevBuf<int32_t> d_len, d_len_trim, d_namb, d_read_list, d_sidx, d_pair_list, d_counts;
+  DevBuf<FqGapWork> d_winfo;
+  DevBuf<int32_t> d_len, d_len_trim, d_read_list, d_sidx, d_pair_list, d_counts;
   DevBuf<uint64_t> d_counters;
   DevBuf<uint32_t> d_queue;
   // search workspaces
@@ -143,6 +144,7 @@ extern "C" int fq_ctx_create(const fq_index_t *ix, const fq_opts_t *opts, int32_
   if (o.s_mm <= 0 || o.s_gapo <= 0 || o.s_gape <= 0) return FQ_EINVAL;   // children must score strictly more than parents (Q1)
   if (o.fnr <= 0.0 && (o.max_diff < 0 || o.max_diff > 30)) return FQ_EINVAL;
   if (o.batch_pairs < 1) return FQ_EINVAL;
+  if (o.max_entries < 1 || o.max_entries > (1 << 30)) return FQ_EINVAL;   // 32-bit live-entry counter in the search kernel
   std::unique_ptr<fq_ctx> c(new fq_ctx);
   c->ix = ix; c->o = o; c->max_pairs = max_pairs;
   int md_max = 0;
@@ -468,20 +470,20 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
       next_work.clear();
       for (size_t c0 = 0; c0 < work.size(); c0 += chunk_reads[tier]) {
         const int nw = (int)std::min(chunk_reads[tier], work.size() - c0);
-        CKM(c->d_work.ensure(nw) && c->d_wrec.ensure((size_t)nw * 2 * Lpad) && c->d_srec.ensure((size_t)nw * 2 * (FQ_SEED_MAX + 1)) && c->d_namb.ensure(nw) &&
+        CKM(c->d_work.ensure(nw) && c->d_wrec.ensure((size_t)nw * 2 * Lpad) && c->d_srec.ensure((size_t)nw * 2 * (FQ_SEED_MAX + 1)) && c->d_winfo.ensure(nw) &&
             c->d_aln.ensure((size_t)nw * T.aln_cap) && c->d_naln.ensure(nw) && c->d_status.ensure(nw) && c->d_off.ensure(nw + 1));
         CK(fqdev::h2d(c->d_work.p, work.data() + c0, (size_t)nw * 4));
         FqWidthArgs wa{};
         wa.ix = ix->dev; wa.o = c->ko; wa.seq = c->d_seq.p; wa.stride = stride; wa.len_trim = c->d_len_trim.p; wa.read_list = c->d_read_list.p;
         wa.work = c->d_work.p; wa.n_work = nw; wa.wrec = c->d_wrec.p; wa.wstride = Lpad;
-        wa.srec = c->d_srec.p; wa.n_amb = c->d_namb.p; wa.counters = c->d_counters.p;
+        wa.srec = c->d_srec.p; wa.winfo = c->d_winfo.p; wa.maxdiff_lut = c->d_maxdiff.p; wa.counters = c->d_counters.p;
         fqdev::time_begin(FQ_K_WIDTH);
         CK(fqdev::launch_width(wa));
         fqdev::time_end(FQ_K_WIDTH);
         FqGapArgs ga{};
-        ga.ix = ix->dev; ga.o = c->ko; ga.o.n_buckets = nb_need; ga.seq = c->d_seq.p; ga.stride = stride; ga.len_trim = c->d_len_trim.p;
-        ga.read_list = c->d_read_list.p; ga.work = c->d_work.p; ga.n_work = nw; ga.maxdiff_lut = c->d_maxdiff.p;
-        ga.wrec = c->d_wrec.p; ga.wstride = Lpad; ga.srec = c->d_srec.p; ga.n_amb = c->d_namb.p;
+        ga.ix = ix->dev; ga.o = c->ko; ga.o.n_buckets = nb_need; ga.seq = c->d_seq.p; ga.stride = stride;
+        ga.n_work = nw; ga.winfo = c->d_winfo.p;
+        ga.wrec = c->d_wrec.p; ga.wstride = Lpad; ga.srec = c->d_srec.p;
         ga.pool = c->d_pool.p; ga.heads = c->d_heads.p; ga.tier = T; ga.aln = c->d_aln.p; ga.n_aln = c->d_naln.p; ga.status = c->d_status.p;
         ga.counters = c->d_counters.p; ga.queue = c->d_queue.p;
         {

@@ -85,6 +85,12 @@ struct FqWRec {
   uint32_t w, bid;
 };
 
+// start-of-search record of work item w (k_width -> gap kernel)
+struct FqGapWork {
+  int32_t r;             // read index (row of the batch)
+  uint32_t meta;         // len[0:16) max_diff[16:24) too-many-N[24]
+};
+
 // per-read search status flags
 #define FQ_SF_POOL_OVERFLOW 1u   // entry pool exhausted -> rerun in a larger tier
 #define FQ_SF_ALN_OVERFLOW 2u    // more hits than the aln slot holds -> rerun in a larger tier

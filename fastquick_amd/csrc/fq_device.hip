@@ -105,7 +105,7 @@ extern __shared__ __align__(16) unsigned char fq_dyn_lds[];
 struct FqQueueFetch {
   uint32_t *cursor;
   int n_work;
-  __device__ int operator()() const { const uint32_t w = atomicAdd(cursor, 1u); return w < (uint32_t)n_work ? (int)w : -1; }
+  __device__ uint32_t operator()(uint32_t n) const { return atomicAdd(cursor, n); }
 };
 // persistent wavefronts: every lane pulls reads from the queue until it is empty.  One wavefront per block.
 // LDS per lane: n_buckets 16-bit bucket heads, lane-interleaved.

@@ -427,6 +427,8 @@ extern "C" int fq_index_load(const char *prefix_c, int device_ordinal, fq_index_
     fclose(fp);
   }
   if ((uint64_t)ix->l_pac != ix->dev.fm[0].seq_len || ix->dev.fm[0].seq_len != ix->dev.fm[1].seq_len) return fail(FQ_EIO);
+  for (int c = 0; c < 5; ++c)   // a text and its reversal have the same base counts; the search kernel relies on one C() array
+    if (ix->dev.fm[0].L2[c] != ix->dev.fm[1].L2[c]) return fail(FQ_EIO);
   if (!slurp(P + ".pac", ix->pac) || ix->pac.size() < (size_t)(ix->l_pac / 4)) return fail(FQ_EIO);
   ix->pac.resize((size_t)(ix->l_pac / 4) + 256, 0);
   ix->d_pac = fqdev::dmalloc(ix->pac.size());

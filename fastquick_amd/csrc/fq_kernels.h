@@ -70,6 +70,15 @@ FQ_HD uint32_t fq_touch2(const FqFM &f, uint32_t k, uint32_t l, bool single_base
   return (vk ? 1u : 0u) + (vl ? 1u : 0u);
 }
 
+FQ_HD uint32_t fq_touch2p(uint32_t primary, uint32_t seq_len, uint32_t k, uint32_t l, bool single_base) {
+  const bool vk = k != 0xffffffffu && !(single_base && k == seq_len);
+  const bool vl = l != 0xffffffffu && !(single_base && l == seq_len);
+  const uint32_t ak = k >= primary ? k - 1 : k, al = l >= primary ? l - 1 : l;
+  if (k == l) return vk ? 1u : 0u;
+  if (vk && vl) return (ak >> 7) == (al >> 7) ? 1u : 2u;
+  return (vk ? 1u : 0u) + (vl ? 1u : 0u);
+}
+
 // bwt_invPsi (bwt.h:66-70) + bwt_sa (bwt.c:69-79): one block fetch yields both the symbol and its rank
 FQ_HD uint32_t fq_sa_lookup(const FqFM &f, uint32_t k, uint32_t *steps) {
   uint32_t sa = 0;
@@ -216,7 +225,8 @@ struct FqWidthArgs {
   FqWRec *wrec;               // [w][2][wstride]   {w, bid} per position
   int32_t wstride;
   FqWRec *srec;               // [w][2][FQ_SEED_MAX+1]
-  int32_t *n_amb;             // [w] number of non-ACGT bases of the (trimmed) read
+  FqGapWork *winfo;           // [w] what the search kernel needs to start read w (one 8-byte load)
+  const uint8_t *maxdiff_lut; // [len] -> max_diff (bwa_cal_maxdiff, libbwa/bwtaln.c:43-58)
   uint64_t *counters;
 };
 FQ_HD void fq_width_thread(const FqWidthArgs &A, int t) {
@@ -245,7 +255,13 @@ FQ_HD void fq_width_thread(const FqWidthArgs &A, int t) {
     orec[i] = rec;
   }
   { FqWRec rec; rec.w = 0; rec.bid = (uint32_t)(bid + 1); orec[n] = rec; }
-  if (which == 0) A.n_amb[w] = namb;
+  if (which == 0) {
+    const uint32_t md = A.maxdiff_lut[v.len];
+    FqGapWork gw;
+    gw.r = r;
+    gw.meta = (uint32_t)v.len | md << 16 | (namb > (int)md ? 1u << 24 : 0u);
+    A.winfo[w] = gw;
+  }
   FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_WIDTH], touches);
 }
 
@@ -265,15 +281,11 @@ struct FqGapArgs {
   FqKOpts o;
   const uint8_t *seq;
   int32_t stride;
-  const int32_t *len_trim;
-  const int32_t *read_list;
-  const int32_t *work;
   int32_t n_work;
-  const uint8_t *maxdiff_lut;
+  const FqGapWork *winfo; // [w] read index, length, max_diff, too-many-N flag: written by k_width
   FqWRec *wrec;          // width records written by k_width; gap_shadow updates them in place
   int32_t wstride;
   const FqWRec *srec;
-  const int32_t *n_amb;  // [w], from k_width
   FqEntry *pool;         // [n_lane_slots][pool_cap]: one stack pool per persistent lane
   uint32_t *heads;       // [n_lane_slots][FQ_MAX_BUCKETS] (HBM-heads variant)
   FqGapTier tier;
@@ -289,14 +301,14 @@ struct FqGapArgs {
 // (pool <= 65535 entries), which takes the head read-modify-write of every push off the global-memory latency chain.
 struct FqGapStoreGlobal {
   uint32_t *head;
-  FQ_HD void begin_read(const FqGapArgs &A, int lane_slot) { head = A.heads + (size_t)lane_slot * FQ_MAX_BUCKETS; }
+  FQ_HD void begin_lane(const FqGapArgs &A, int lane_slot) { head = A.heads + (size_t)lane_slot * FQ_MAX_BUCKETS; }
   FQ_HD uint32_t head_get(int b) const { return head[b]; }
   FQ_HD void head_set(int b, uint32_t slot) const { head[b] = slot; }
 };
 struct FqGapStoreLds {
   uint16_t *head;       // element b at head[b*stride]
   int stride;
-  FQ_HD void begin_read(const FqGapArgs &, int) {}
+  FQ_HD void begin_lane(const FqGapArgs &, int) {}
   FQ_HD uint32_t head_get(int b) const { return head[b * stride]; }
   FQ_HD void head_set(int b, uint32_t slot) const { head[b * stride] = (uint16_t)slot; }
 };
@@ -316,13 +328,18 @@ FQ_HD uint32_t fq_sel4(const uint32_t *v, int c) { return fq_sel4v(v[0], v[1], v
 // halves and the prefix mask is built from 32-bit shifts: 64-bit shifts are quarter-rate on CDNA4 and this code sits on the
 // dependent chain of every search step.
 struct FqBlkRaw { uint32_t c0, c1, c2, c3; uint32_t lo0, lo1, hi0, hi1; uint32_t mk0, mk1; bool valid; };   // *0 = bases 0..31 (bits 63..32 of the plane)
-FQ_HD FqBlkRaw fq_blk_load(const FqFM &f, uint32_t k) {
+FQ_HD FqBlkRaw fq_blk_none() {
   FqBlkRaw r;
-  r.valid = k != 0xffffffffu;
+  r.valid = false;
   r.c0 = r.c1 = r.c2 = r.c3 = 0; r.lo0 = r.lo1 = r.hi0 = r.hi1 = 0; r.mk0 = r.mk1 = 0;
+  return r;
+}
+FQ_HD FqBlkRaw fq_blk_load(const FqOccBlk *blk, uint32_t primary, uint32_t k) {
+  FqBlkRaw r = fq_blk_none();
+  r.valid = k != 0xffffffffu;
   if (r.valid) {
-    k = fq_adj(f, k);
-    const FqOccBlk *b = f.blk + (k >> 6);
+    k = k >= primary ? k - 1 : k;
+    const FqOccBlk *b = blk + (k >> 6);
     r.c0 = b->cnt[0]; r.c1 = b->cnt[1]; r.c2 = b->cnt[2]; r.c3 = b->cnt[3];
     const uint64_t lo = b->lo, hi = b->hi;
     r.lo0 = (uint32_t)(lo >> 32); r.lo1 = (uint32_t)lo; r.hi0 = (uint32_t)(hi >> 32); r.hi1 = (uint32_t)hi;
@@ -333,6 +350,7 @@ FQ_HD FqBlkRaw fq_blk_load(const FqFM &f, uint32_t k) {
   }
   return r;
 }
+FQ_HD FqBlkRaw fq_blk_load(const FqFM &f, uint32_t k) { return fq_blk_load(f.blk, f.primary, k); }
 FQ_HD uint32_t fq_popc2(uint32_t a, uint32_t b) { return (uint32_t)(FQ_POPC32(a) + FQ_POPC32(b)); }
 FQ_HD uint32_t fq_blk_occ1(const FqBlkRaw &r, int c) {
   if (!r.valid) return 0;
@@ -349,98 +367,117 @@ FQ_HD void fq_blk_occ4(const FqBlkRaw &r, uint32_t o[4]) {
   o[3] = r.c3 + fq_popc2(h0 & r.lo0, h1 & r.lo1);
 }
 
+// wavefront-level helpers.  The host-loop build (tests/emu) runs one lane at a time: a "wavefront" of one.
 #if defined(__HIP_DEVICE_COMPILE__)
-#define FQ_WAVE_COUNT(pred) ((int)__popcll(__ballot(pred)))
+#define FQ_WAVE_SIZE 64
+#define FQ_LANE_ID() ((int)__lane_id())
+#define FQ_BALLOT(pred) ((uint64_t)__ballot(pred))
+#define FQ_READLANE32(x, l) ((uint32_t)__builtin_amdgcn_readlane((int)(x), (l)))
+#define FQ_CTZ64(x) (__ffsll((long long)(x)) - 1)
 #else
-#define FQ_WAVE_COUNT(pred) ((pred) ? 1 : 0)
+#define FQ_WAVE_SIZE 1
+#define FQ_LANE_ID() 0
+#define FQ_BALLOT(pred) ((uint64_t)((pred) ? 1 : 0))
+#define FQ_READLANE32(x, l) ((uint32_t)(x))
+#define FQ_CTZ64(x) __builtin_ctzll(x)
 #endif
 #define FQ_REFILL_MIN 8   // idle lanes of a wavefront wait until this many can be (re)initialised together
+// test-only instrumentation hooks (tests/emu builds may define FQ_PROFILE; empty in the product)
+#if defined(FQ_PROFILE) && !defined(__HIP_DEVICE_COMPILE__)
+extern unsigned long long fq_prof[64];
+#define FQ_PROF(i) (++fq_prof[i])
+#else
+#define FQ_PROF(i) ((void)0)
+#endif
 
-// One lane = one search at a time, but a lane that finishes pulls the next read from a queue, so a wavefront stays busy
-// whatever the spread of search lengths inside its packet of 64 reads.  Each loop iteration is one dependent Occ step for
-// every lane: either a pop+expand (two 4-base ranks) or one base of an exact-match tail (bwt_match_exact_alt turned
-// into a state machine so that a 150-step tail in one lane does not stall the other 63).  Both kinds fetch the same two
-// 32-byte blocks in a common phase between their (cheap) lane-specific phases.
+struct FqU4 { uint32_t x, y, z, w; };   // one 16-byte load
+
+// One lane = one search at a time; a lane that finishes pulls the next read from a queue, so a wavefront stays busy
+// whatever the spread of search lengths inside its packet of 64 reads.
 //
-// The per-read state is a plain struct with inlined member functions and the two FM descriptors are held by value and
-// chosen with selects: closures capturing by reference, or a runtime index into the kernel-argument struct, make hipcc
+// A loop iteration ("trip") costs every lane exactly one global-memory round trip, and all loads of a trip are issued
+// before any is consumed:
+//   * a lane that holds a current entry in registers (the exact-match child of the entry it expanded in the previous trip
+//     -- the reference pushes that child last, into the bucket its parent just left, so it is always the next one popped --
+//     or the running state of an exact-match tail, bwt_match_exact_alt as a state machine) fetches the two 32-byte Occ
+//     blocks of rows k-1 and l together with its width records, ranks all four bases once, and from the result takes the
+//     match child (next current entry) and, unless it is in a tail, the gap / mismatch children;
+//   * a lane without a current entry pops one: bucket head from LDS, 16-byte entry from its pool in HBM.
+// Children are written per group (gap children, mismatch children): the members of a group share their score bucket, the
+// push-time prune decision and all of the packed state word except position and state, so a child costs one slot
+// allocation and one 16-byte store; the bucket head and occupancy mask are updated once per group.
+// Completed alignments are collected in a wavefront-uniform section after the step: gap_shadow's sweep over the width
+// array (up to read-length dependent loads and stores in the reference's loop) is done by all 64 lanes together.
+//
+// The per-read state is a plain struct with inlined member functions; per-strand index fields are chosen with masks:
+// closures capturing by reference, "cond ? mem_a : mem_b", or a runtime index into the kernel-argument struct make hipcc
 // keep the whole state in scratch memory (680 B/lane, every access a memory round trip).
 template <class St>
 struct FqGapLane {
   const FqGapArgs &A;
   St store;
-  FqFM fm0, fm1;
   FqKOpts o;
   bool gape_mode, nonstop, exact;
-  // per-read state
+  uint32_t seq_len, L2_0, L2_1, L2_2, L2_3;          // identical for both strands (checked at index load)
+  const FqOccBlk *blk0, *blk1;
+  uint32_t primary0, primary1;
+  // per-read constants
   bool active, done;
-  int w, len, max_diff_opt, seed_len;
+  int w, len, max_diff_opt, seed_off;                 // seed_off = len - seed_len (position ii = i - seed_off inside the seed)
   bool use_seed;
-  FqReadView v;
-  FqEntry *pool; FqAln *aln; FqWRec *wrec; const FqWRec *srec;
+  const uint8_t *row;
+  FqEntry *pool; FqWRec *wrec;
+  // search state
   uint32_t m0, m1, m2, m3, bump, spare, status, n_aln;
-  int64_t n_live;
+  int32_t n_live;
   int best_score, max_diff, best_cnt;
   uint32_t c_pops, c_pushes, c_touch;
-  bool fwd_valid;
-  uint32_t fwd_k, fwd_l, fwd_pk;
-  int fwd_score;
-  bool tail;
-  uint32_t tk, tl, tpk;
-  int ti, tscore;
+  // current entry (valid when has_cur or hit_pending)
+  bool has_cur, tail, hit_pending;
+  uint32_t ck_, cl_, cpk;
+  int cscore;
 
-  int lane_slot;
-  FQ_HD FqGapLane(const FqGapArgs &A_, const St &st, int lane_slot_) : A(A_), store(st), fm0(A_.ix.fm[0]), fm1(A_.ix.fm[1]), o(A_.o), lane_slot(lane_slot_) {
+  FQ_HD FqGapLane(const FqGapArgs &A_, const St &st, int lane_slot) : A(A_), store(st), o(A_.o) {
     gape_mode = (o.mode & FQ_MODE_GAPE) != 0; nonstop = (o.mode & FQ_MODE_NONSTOP) != 0; exact = A_.tier.exact != 0;
-    active = done = false; w = len = max_diff_opt = seed_len = 0; use_seed = false;
-    v.row = A_.seq; v.len = 0;
-    pool = A_.pool; aln = A_.aln; wrec = A_.wrec; srec = A_.srec;
+    const FqFM &f0 = A_.ix.fm[0], &f1 = A_.ix.fm[1];
+    seq_len = f0.seq_len; L2_0 = f0.L2[0]; L2_1 = f0.L2[1]; L2_2 = f0.L2[2]; L2_3 = f0.L2[3];
+    blk0 = f0.blk; blk1 = f1.blk; primary0 = f0.primary; primary1 = f1.primary;
+    active = done = false; w = len = max_diff_opt = seed_off = 0; use_seed = false;
+    row = A_.seq; wrec = A_.wrec;
+    pool = A_.pool + (size_t)lane_slot * (size_t)A_.tier.pool_cap;   // stack storage belongs to the lane, not to the read
+    store.begin_lane(A_, lane_slot);
     m0 = m1 = m2 = m3 = bump = status = n_aln = 0; spare = FQ_NIL; n_live = 0;
     best_score = max_diff = best_cnt = 0; c_pops = c_pushes = c_touch = 0;
-    fwd_valid = false; fwd_k = fwd_l = fwd_pk = 0; fwd_score = 0;
-    tail = false; tk = tl = tpk = 0; ti = tscore = 0;
-  }
-  // search strand a runs on the other strand's BWT (bwtgap.c:148)
-  FQ_HD FqFM fm_for(int a) const {
-    FqFM f;
-    f.blk = (const FqOccBlk *)fq_pick2p((uint64_t)(uintptr_t)fm0.blk, (uint64_t)(uintptr_t)fm1.blk, a);
-    f.sa = nullptr;
-    f.primary = fq_pick2(fm0.primary, fm1.primary, a); f.seq_len = fq_pick2(fm0.seq_len, fm1.seq_len, a);
-    f.L2[0] = fq_pick2(fm0.L2[0], fm1.L2[0], a); f.L2[1] = fq_pick2(fm0.L2[1], fm1.L2[1], a); f.L2[2] = fq_pick2(fm0.L2[2], fm1.L2[2], a);
-    f.L2[3] = fq_pick2(fm0.L2[3], fm1.L2[3], a); f.L2[4] = fq_pick2(fm0.L2[4], fm1.L2[4], a);
-    f.sa_intv = fm0.sa_intv; f.n_sa = 0; f.n_blk = 0;
-    return f;
+    has_cur = tail = hit_pending = false; ck_ = cl_ = cpk = 0; cscore = 0;
   }
   FQ_HD bool bucket_test(int b) const { return ((fq_sel4v(m0, m1, m2, m3, b >> 5) >> (b & 31)) & 1u) != 0; }
   FQ_HD void bucket_set(int b) { const uint32_t bit = 1u << (b & 31); const int q = b >> 5; m0 |= bit & (0u - (uint32_t)(q == 0)); m1 |= bit & (0u - (uint32_t)(q == 1)); m2 |= bit & (0u - (uint32_t)(q == 2)); m3 |= bit & (0u - (uint32_t)(q == 3)); }
   FQ_HD void bucket_clr(int b) { const uint32_t bit = 1u << (b & 31); const int q = b >> 5; m0 &= ~(bit & (0u - (uint32_t)(q == 0))); m1 &= ~(bit & (0u - (uint32_t)(q == 1))); m2 &= ~(bit & (0u - (uint32_t)(q == 2))); m3 &= ~(bit & (0u - (uint32_t)(q == 3))); }
 
-  FQ_HD void push(int a, int i, uint32_t k, uint32_t l, int mm, int go, int ge, int st, bool is_diff, int parent_ld) {
-    const int score = mm * o.s_mm + go * o.s_gapo + ge * o.s_gape;
-    ++n_live;
+  // ---- grouped push: children that share a score bucket -----------------------------------------------------------------
+  // Non-exact tiers drop, at push time, children the reference would pop only to discard (see FqGapArgs).
+  FQ_HD bool group_open(int score, int diffs, uint32_t &prev) {
     if (!exact) {
-      if (n_aln > 0 && !nonstop && score > best_score + o.s_mm) return;
-      if (max_diff - (mm + go + (gape_mode ? ge : 0)) < 0) return;
+      if (n_aln > 0 && !nonstop && score > best_score + o.s_mm) { FQ_PROF(10); return false; }
+      if (max_diff - diffs < 0) { FQ_PROF(11); return false; }
     }
-    uint32_t slot;
-    if (spare != FQ_NIL) { slot = spare; spare = FQ_NIL; }
-    else {
-      if (bump >= A.tier.pool_cap) { status |= FQ_SF_POOL_OVERFLOW; return; }
-      slot = bump++;
-    }
-    ++c_pushes;
+    prev = FQ_NIL;
+    if (bucket_test(score)) prev = store.head_get(score);
+    return true;
+  }
+  FQ_HD void group_put(uint32_t k, uint32_t l, uint32_t pk, uint32_t &prev) {
+    const bool us = spare != FQ_NIL;
+    const uint32_t slot = us ? spare : bump;
+    bump += us ? 0u : 1u;
+    spare = FQ_NIL;
     FqEntry e;
-    e.k = k; e.l = l;
-    e.pk = fq_pack(i, a, st, mm, go, ge, is_diff ? i : parent_ld);   // Q1: non-diff pushes inherit last_diff_pos
-    e.next = bucket_test(score) ? store.head_get(score) : FQ_NIL;
+    e.k = k; e.l = l; e.pk = pk; e.next = prev;
     pool[slot] = e;
-    store.head_set(score, slot);
-    bucket_set(score);
+    prev = slot;
+    ++c_pushes; FQ_PROF(12);
   }
-  FQ_HD void forward(int a, int i, uint32_t k, uint32_t l, int mm, int go, int ge, int ld, int score) {
-    ++n_live; ++c_pushes;
-    fwd_k = k; fwd_l = l; fwd_pk = fq_pack(i, a, FQ_ST_M, mm, go, ge, ld); fwd_score = score; fwd_valid = true;
-  }
+  FQ_HD void group_close(int score, uint32_t prev) { store.head_set(score, prev); bucket_set(score); }
+
   FQ_HD void finish() {
     A.n_aln[w] = status ? 0u : n_aln;   // failed reads are re-run in a larger tier; expose no partial list
     A.status[w] = status;
@@ -449,238 +486,284 @@ struct FqGapLane {
     FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXPOPS], c_pops);
     if (c_pops > 4096) FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS_GT4K], 1);
     FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_GAP], c_touch);
-    active = false;
+    active = false; has_cur = false; tail = false; hit_pending = false;
   }
-  // a completed alignment (i == 0, or an exact tail that reached 0): bwtgap.c:166-198.  Returns false when the search ends.
-  FQ_HD bool on_hit(uint32_t k, uint32_t l, uint32_t pk, int e_score) {
-    const int a = (int)(pk >> 9) & 1, n_mm = (int)(pk >> 12) & 31, n_gapo = (int)(pk >> 17) & 3, n_gape = (int)(pk >> 19) & 15, last_diff = (int)(pk >> 23);
-    const uint32_t seq_len = fq_pick2(fm0.seq_len, fm1.seq_len, a);
-    bool do_add = true;
-    if (n_aln == 0) {
-      best_score = e_score;
-      const int best_diff = n_mm + n_gapo + (gape_mode ? n_gape : 0);
-      if (!nonstop) max_diff = best_diff + 1 > max_diff_opt ? max_diff_opt : best_diff + 1;
-    }
-    if (e_score == best_score) best_cnt += (int)(l - k + 1);
-    else if (best_cnt > o.max_top2) return false;
-    if (n_gapo)
-      for (uint32_t j = 0; j < n_aln; ++j)
-        if (aln[j].k == k && aln[j].l == l) { do_add = false; break; }
-    if (do_add) {
-      FqWRec *const ww = wrec + (size_t)a * (size_t)A.wstride;
-      const uint32_t x = l - k + 1, mx = seq_len;   // gap_shadow, bwtgap.c:81-91
-      uint32_t jj = 0;
-      for (int t = 0; t < last_diff; ++t) {
-        const uint32_t cur = ww[t].w;
-        if (cur > x) ww[t].w = cur - x;
-        else if (cur == x) { FqWRec nr; nr.bid = 1; nr.w = mx - (++jj); ww[t] = nr; }
-      }
-      if (n_aln >= A.tier.aln_cap) { status |= FQ_SF_ALN_OVERFLOW; return false; }
-      FqAln h;
-      h.info = (uint32_t)n_mm | (uint32_t)n_gapo << 8 | (uint32_t)n_gape << 16 | (uint32_t)a << 24;
-      h.k = k; h.l = l; h.score = e_score;
-      aln[n_aln++] = h;
-    }
-    return true;
-  }
+
   FQ_HD void begin(int w_) {
     w = w_;
-    const int s = A.work ? A.work[w] : w;
-    const int r = A.read_list[s];
-    v.row = A.seq + (size_t)r * (size_t)A.stride; v.len = A.len_trim[r];
-    len = v.len;
-    max_diff_opt = A.maxdiff_lut[len];
+    const FqGapWork gw = A.winfo[w];                 // written by k_width: read index, length, max_diff, "too many N"
+    len = (int)(gw.meta & 0xffffu);
+    max_diff_opt = (int)((gw.meta >> 16) & 0xffu);
+    row = A.seq + (size_t)gw.r * (size_t)A.stride;
     use_seed = len > o.seed_len;
-    seed_len = o.seed_len < len ? o.seed_len : 0x7fffffff;
-    pool = A.pool + (size_t)lane_slot * (size_t)A.tier.pool_cap;   // stack storage belongs to the lane, not to the read
-    aln = A.aln + (size_t)w * (size_t)A.tier.aln_cap;
+    seed_off = len - o.seed_len;
     wrec = A.wrec + (size_t)w * 2 * (size_t)A.wstride;
-    srec = A.srec + (size_t)w * 2 * (FQ_SEED_MAX + 1);
-    store.begin_read(A, lane_slot);
     m0 = m1 = m2 = m3 = 0; bump = 0; spare = FQ_NIL; status = 0; n_aln = 0; n_live = 0;
     best_score = (max_diff_opt + 1) * o.s_mm + (o.max_gapo + 1) * o.s_gapo + (o.max_gape + 1) * o.s_gape;
     max_diff = max_diff_opt; best_cnt = 0;
     c_pops = c_pushes = c_touch = 0;
-    fwd_valid = false; tail = false;
+    has_cur = tail = hit_pending = false;
     active = true;
-    if (A.n_amb[w] > max_diff_opt) { finish(); return; }   // "too many N" early-out of bwt_match_gap (bwtgap.c:118-124)
-    push(0, len, 0, fm0.seq_len, 0, 0, 0, FQ_ST_M, false, 0);
-    push(1, len, 0, fm0.seq_len, 0, 0, 0, FQ_ST_M, false, 0);
+    if ((gw.meta >> 24) & 1u) { finish(); return; }   // "too many N" early-out of bwt_match_gap (bwtgap.c:118-124)
+    // the two roots (bwtgap.c:139-140): strand 0 first, so strand 1 is popped first
+    uint32_t prev = FQ_NIL;
+    group_put(0, seq_len, fq_pack(len, 0, FQ_ST_M, 0, 0, 0, 0), prev);
+    group_put(0, seq_len, fq_pack(len, 1, FQ_ST_M, 0, 0, 0, 0), prev);
+    group_close(0, prev);
+    n_live = 2;
   }
 
-  // everything a just-popped entry needs from global memory: the two Occ blocks, its width / seed-width records and base
-  FQ_HD void load_entry_data(uint32_t k, uint32_t l, uint32_t pk, FqBlkRaw &bk, FqBlkRaw &bl, FqWRec &w1, FqWRec &w2, FqWRec &s1r, FqWRec &s2r, int &cbase) const {
-    const int a = (int)(pk >> 9) & 1, i0 = (int)(pk & 511);
-    const FqFM f = fm_for(a);
-    bk = fq_blk_load(f, k - 1); bl = fq_blk_load(f, l);
-    w1.w = w1.bid = w2.w = w2.bid = s1r.w = s1r.bid = s2r.w = s2r.bid = 0;
-    cbase = 0;
-    if (i0 >= 1) {
-      cbase = fq_base(v, a, i0 - 1);
-      const FqWRec *ww = wrec + (size_t)a * (size_t)A.wstride;
-      w1 = ww[i0 - 1];
-      if (i0 >= 2) w2 = ww[i0 - 2];
-      const int ii0 = (i0 - 1) - (len - seed_len);
-      if (use_seed && ii0 > 0) { const FqWRec *sw = srec + (size_t)a * (FQ_SEED_MAX + 1); s1r = sw[ii0]; s2r = sw[ii0 - 1]; }
-    }
-  }
-  // one iteration for an active lane
+  // one trip of an active lane
   FQ_HD void step() {
-    // ---- phase 1 (lane specific, no global Occ access): decide which SA interval this iteration extends ------------------
-    uint32_t k = 0, l = 0, pk = 0;
-    int e_score = 0;
-    bool fresh = false;   // a just-popped entry (its width prune is still pending)
-    if (tail) { k = tk; l = tl; pk = tpk; e_score = tscore; }
-    else {
-      if (!(fwd_valid || (m0 | m1 | m2 | m3) != 0) || status != 0) { finish(); return; }
-      if (n_live > (int64_t)o.max_entries) { if (!exact) status |= FQ_SF_ENTRY_LIMIT; finish(); return; }
-      if (fwd_valid) { k = fwd_k; l = fwd_l; pk = fwd_pk; e_score = fwd_score; fwd_valid = false; }
-      else {   // gap_pop
-        const int b = m0 ? FQ_CTZ32(m0) : m1 ? 32 + FQ_CTZ32(m1) : m2 ? 64 + FQ_CTZ32(m2) : 96 + FQ_CTZ32(m3);
-        const uint32_t slot = store.head_get(b);
-        const FqEntry e = pool[slot];
-        if (e.next == FQ_NIL) bucket_clr(b); else store.head_set(b, e.next);
-        spare = slot;
-        k = e.k; l = e.l; pk = e.pk; e_score = b;
-      }
-      --n_live;
-      ++c_pops;
-      if (!nonstop && e_score > best_score + o.s_mm) { finish(); return; }
-      const int i = (int)(pk & 511), a = (int)(pk >> 9) & 1, st = (int)(pk >> 10) & 3, n_mm = (int)(pk >> 12) & 31, n_gapo = (int)(pk >> 17) & 3,
-                n_gape = (int)(pk >> 19) & 15;
-      int m = max_diff - (n_mm + n_gapo);
-      if (gape_mode) m -= n_gape;
-      if (m < 0) return;
-      if (i == 0) { if (!on_hit(k, l, pk, e_score)) finish(); return; }
-      // the width-based prune (m < width[i-1].bid) and the exact-tail decision need the width records: they are fetched
-      // together with the Occ blocks below (speculatively -- a pruned entry wastes two block loads but no round trip)
-      fresh = true;
+    FQ_PROF(0);
+    const bool popping = !has_cur;
+    int b = 0;
+    uint32_t slot = 0;
+    if (popping) {
+      if ((m0 | m1 | m2 | m3) == 0) { finish(); return; }
+      if (n_live > o.max_entries) { if (!exact) status |= FQ_SF_ENTRY_LIMIT; finish(); return; }   // bwtgap.c:144
+      b = m0 ? FQ_CTZ32(m0) : m1 ? 32 + FQ_CTZ32(m1) : m2 ? 64 + FQ_CTZ32(m2) : 96 + FQ_CTZ32(m3);
+      slot = store.head_get(b);
     }
-    // ---- phase 2 (common): the two 32-byte Occ blocks of rows k-1 and l -----------------------------------------------------
-    const int a = (int)(pk >> 9) & 1;
-    const FqFM f = fm_for(a);
-    const int i0 = fresh ? (int)(pk & 511) : ti;          // position before this step's base is consumed (>= 1)
+    // ---- loads: every lane issues one 16-byte load (stack entry, or the width records of positions i0-2 and i0-1); lanes
+    //      with a current entry add the two Occ blocks, the seed-width records and their read base
+    const int a = (int)(cpk >> 9) & 1, i0 = (int)(cpk & 511u);            // i0 >= 1 whenever has_cur
+    const FqWRec *ww = wrec + (size_t)a * (size_t)A.wstride;
+    const int wi = i0 >= 2 ? i0 - 2 : 0;
+    const uintptr_t pa = (uintptr_t)fq_pick2p((uint64_t)(uintptr_t)(pool + slot), (uint64_t)(uintptr_t)(ww + wi), popping ? 1 : 0);
+    const FqU4 vA = *(const FqU4 *)pa;
     FqBlkRaw bk, bl;
-    FqWRec w1, w2, s1r, s2r;                                // width[i0-1], width[i0-2], seed_width[ii], seed_width[ii-1]
-    int cbase;                                              // the base this step consumes (tail) / branches on (expand)
-    if (fresh) {
-      load_entry_data(k, l, pk, bk, bl, w1, w2, s1r, s2r, cbase);
+    FqU4 vS;
+    vS.x = vS.y = vS.z = vS.w = 0;
+    int cbase = 4;
+    const int ii0 = (i0 - 1) - seed_off;                                    // seed position of the child
+    const bool seeded = use_seed && ii0 > 0;
+    if (!popping) {
+      const FqOccBlk *blk = (const FqOccBlk *)fq_pick2p((uint64_t)(uintptr_t)blk0, (uint64_t)(uintptr_t)blk1, a);   // strand a searches the other strand's BWT (bwtgap.c:148)
+      const uint32_t primary = fq_pick2(primary0, primary1, a);
+      bk = fq_blk_load(blk, primary, ck_ - 1);
+      bl = fq_blk_load(blk, primary, cl_);
+      const int c = (int)fq_nt4_fast(row[len - i0]);                         // seq[a][i0-1]
+      cbase = (a && c < 4) ? 3 - c : c;
+      if (!tail && seeded) {
+        const FqWRec *sw = A.srec + ((size_t)w * 2 + (size_t)a) * (FQ_SEED_MAX + 1);
+        vS = *(const FqU4 *)(sw + (ii0 - 1));                                // seed_width[ii0-1], seed_width[ii0]
+      }
     } else {
-      bk = fq_blk_load(f, k - 1); bl = fq_blk_load(f, l);
-      cbase = fq_base(v, a, i0 - 1);
-      w1.w = w1.bid = w2.w = w2.bid = s1r.w = s1r.bid = s2r.w = s2r.bid = 0;
+      bk = fq_blk_none(); bl = fq_blk_none();
     }
-    if (fresh) {
-      const int st0 = (int)(pk >> 10) & 3, n_mm0 = (int)(pk >> 12) & 31, n_gapo0 = (int)(pk >> 17) & 3, n_gape0 = (int)(pk >> 19) & 15;
-      int m0d = max_diff - (n_mm0 + n_gapo0);
-      if (gape_mode) m0d -= n_gape0;
-      if (m0d < (int)w1.bid) return;                        // bwtgap.c:155
-      if (m0d == 0 && (st0 == FQ_ST_M || gape_mode || n_gape0 == o.max_gape)) {   // no difference left: exact tail from here
-        tail = true; tk = k; tl = l; tpk = pk; ti = i0; tscore = e_score;
-      }
-    }
-
-    // ---- phase 3 (lane specific) ----------------------------------------------------------------------------------------------
-    if (tail) {   // one base of bwt_match_exact_alt (libbwa/bwt.c:102-117)
-      const int t = ti - 1;
-      const int c = cbase;
-      bool ok = c <= 3;
-      if (ok) {
-        c_touch += fq_touch2(f, k - 1, l, true);
-        const uint32_t okk = fq_blk_occ1(bk, c), oll = fq_blk_occ1(bl, c);
-        tk = fq_sel4(f.L2, c) + okk + 1;
-        tl = fq_sel4(f.L2, c) + oll;
-        ok = tk <= tl;
-      }
-      if (!ok) { tail = false; return; }
-      ti = t;
-      if (ti == 0) { tail = false; if (!on_hit(tk, tl, tpk, tscore)) finish(); }
+    if (popping) {   // ---- gap_pop (bwtgap.c:66-79) and the pop-time checks; the entry is expanded in the next trip ---------
+      FQ_PROF(3);
+      if (vA.w == FQ_NIL) bucket_clr(b); else store.head_set(b, vA.w);
+      spare = slot;
+      --n_live; ++c_pops;
+      if (!nonstop && b > best_score + o.s_mm) { finish(); return; }         // bwtgap.c:147
+      const int n_mm = (int)(vA.z >> 12) & 31, n_gapo = (int)(vA.z >> 17) & 3, n_gape = (int)(vA.z >> 19) & 15;
+      const int m = max_diff - (n_mm + n_gapo + (gape_mode ? n_gape : 0));
+      if (m < 0) { FQ_PROF(4); return; }
+      ck_ = vA.x; cl_ = vA.y; cpk = vA.z; cscore = b;
+      if ((vA.z & 511u) == 0) { FQ_PROF(5); hit_pending = true; return; }
+      has_cur = true;
       return;
     }
-    int i = (int)(pk & 511);
-    const int st = (int)(pk >> 10) & 3, n_mm = (int)(pk >> 12) & 31, n_gapo = (int)(pk >> 17) & 3, n_gape = (int)(pk >> 19) & 15,
-              last_diff = (int)(pk >> 23);
-    int m = max_diff - (n_mm + n_gapo), m_seed = 0;
-    if (gape_mode) m -= n_gape;
-    if (use_seed) { m_seed = o.max_seed_diff - (n_mm + n_gapo); if (gape_mode) m_seed -= n_gape; }
-    --i;
-    uint32_t ck[4], cl[4];
-    c_touch += fq_touch2(f, k - 1, l, false);
-    fq_blk_occ4(bk, ck);
-    fq_blk_occ4(bl, cl);
-    const uint32_t occ = l - k + 1;
+    // ---- a lane with a current entry ------------------------------------------------------------------------------------------
+    FqWRec w1, w2;                                                            // width[i0-1], width[i0-2]
+    if (i0 >= 2) { w2.w = vA.x; w2.bid = vA.y; w1.w = vA.z; w1.bid = vA.w; } else { w1.w = vA.x; w1.bid = vA.y; w2.w = w2.bid = 0; }
+    const int st = (int)(cpk >> 10) & 3, n_mm = (int)(cpk >> 12) & 31, n_gapo = (int)(cpk >> 17) & 3, n_gape = (int)(cpk >> 19) & 15;
+    const int diffs = n_mm + n_gapo + (gape_mode ? n_gape : 0);
+    const int m = max_diff - diffs;
+    if (!tail) {
+      if (m < (int)w1.bid) { FQ_PROF(6); has_cur = false; return; }        // bwtgap.c:155
+      if (m == 0 && (st == FQ_ST_M || gape_mode || n_gape == o.max_gape)) { tail = true; FQ_PROF(7); }   // no difference left: exact tail
+    }
+    uint32_t ok4[4], ol4[4];
+    fq_blk_occ4(bk, ok4);
+    fq_blk_occ4(bl, ol4);
+    const uint32_t kk0 = L2_0 + ok4[0] + 1, kk1 = L2_1 + ok4[1] + 1, kk2 = L2_2 + ok4[2] + 1, kk3 = L2_3 + ok4[3] + 1;
+    const uint32_t ll0 = L2_0 + ol4[0], ll1 = L2_1 + ol4[1], ll2 = L2_2 + ol4[2], ll3 = L2_3 + ol4[3];
+    const uint32_t vmask = (kk0 <= ll0 ? 1u : 0u) | (kk1 <= ll1 ? 2u : 0u) | (kk2 <= ll2 ? 4u : 0u) | (kk3 <= ll3 ? 8u : 0u);
+    const int i = i0 - 1;
+    const bool mvalid = cbase < 4 && ((vmask >> (cbase & 3)) & 1u) != 0;
+    const uint32_t mk = fq_sel4v(kk0, kk1, kk2, kk3, cbase & 3), ml = fq_sel4v(ll0, ll1, ll2, ll3, cbase & 3);
+    const uint32_t fpk = (cpk & ~0xC00u) - 1u;                                // the match child: same counts, position i, state M
+    const uint32_t pk_row = fq_pick2(primary0, primary1, a);
+    if (tail) {   // one base of bwt_match_exact_alt (libbwa/bwt.c:102-117)
+      FQ_PROF(1);
+      if (cbase < 4) c_touch += fq_touch2p(pk_row, seq_len, ck_ - 1, cl_, true);
+      if (!mvalid) { has_cur = false; tail = false; return; }
+      ck_ = mk; cl_ = ml; cpk = fpk;
+      if (i == 0) { has_cur = false; tail = false; hit_pending = true; }
+      return;
+    }
+    FQ_PROF(8);
+    c_touch += fq_touch2p(pk_row, seq_len, ck_ - 1, cl_, false);
+    const int last_diff = (int)(cpk >> 23);
     bool allow_diff = true, allow_M = true;
     if (i > 0) {
-      const int ii = i - (len - seed_len);
-      const int b1 = (int)w2.bid, b0 = (int)w1.bid;   // width[i-1], width[i] of the decremented i
+      const int b1 = (int)w2.bid, b0 = (int)w1.bid;   // width[i-1], width[i]
       if (b1 > m - 1) allow_diff = false;
       else if (b1 == m - 1 && b0 == m - 1 && w2.w == w1.w) allow_M = false;
-      if (use_seed && ii > 0) {
-        const int s1 = (int)s2r.bid, s0 = (int)s1r.bid;
+      if (seeded) {                                   // ii = i - seed_off > 0
+        const int m_seed = o.max_seed_diff - diffs;
+        const int s1 = (int)vS.y, s0 = (int)vS.w;     // seed_width[ii-1].bid, seed_width[ii].bid
         if (s1 > m_seed - 1) allow_diff = false;
-        else if (s1 == m_seed - 1 && s0 == m_seed - 1 && s2r.w == s1r.w) allow_M = false;
+        else if (s1 == m_seed - 1 && s0 == m_seed - 1 && vS.x == vS.z) allow_M = false;
       }
     }
-    int tmp;
-    if (o.mode & FQ_MODE_LOGGAP) { uint32_t vv = (uint32_t)(n_gape + n_gapo); int lg = 0; while (vv >>= 1) ++lg; tmp = lg / 2 + 1; }
-    else tmp = n_gapo + n_gape;
-    if (allow_diff && i >= o.indel_end_skip + tmp && len - i >= o.indel_end_skip + tmp) {
-      if (st == FQ_ST_M) {
-        if (n_gapo < o.max_gapo) {
-          push(a, i, k, l, n_mm, n_gapo + 1, n_gape, FQ_ST_I, true, last_diff);
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const uint32_t kk = f.L2[j] + ck[j] + 1, ll = f.L2[j] + cl[j];
-            if (kk <= ll) push(a, i + 1, kk, ll, n_mm, n_gapo + 1, n_gape, FQ_ST_D, true, last_diff);
+    if (bump + 10u > A.tier.pool_cap) { status |= FQ_SF_POOL_OVERFLOW; finish(); return; }   // room for every child of this entry
+    const uint32_t k = ck_, l = cl_;
+    if (allow_diff) {
+      int tmp;
+      if (o.mode & FQ_MODE_LOGGAP) { uint32_t vv = (uint32_t)(n_gape + n_gapo); int lg = 0; while (vv >>= 1) ++lg; tmp = lg / 2 + 1; }
+      else tmp = n_gapo + n_gape;
+      if (i >= o.indel_end_skip + tmp && len - i >= o.indel_end_skip + tmp) {   // ---- gap children (bwtgap.c:212-243)
+        const bool is_open = st == FQ_ST_M;
+        const bool can = is_open ? n_gapo < o.max_gapo : n_gape < o.max_gape;
+        const bool has_I = can && st != FQ_ST_D;
+        const bool has_D = can && st != FQ_ST_I && (is_open || n_gape + n_gapo < max_diff || (l - k + 1) < (uint32_t)o.max_del_occ);
+        const uint32_t cnt = (has_I ? 1u : 0u) + (has_D ? (uint32_t)FQ_POPC32(vmask) : 0u);
+        if (cnt) {
+          n_live += (int32_t)cnt;
+          const int go2 = n_gapo + (is_open ? 1 : 0), ge2 = n_gape + (is_open ? 0 : 1);
+          const int score = cscore + (is_open ? o.s_gapo : o.s_gape);
+          uint32_t prev;
+          if (group_open(score, n_mm + go2 + (gape_mode ? ge2 : 0), prev)) {
+            const uint32_t common = (cpk & ((1u << 9) | (31u << 12))) | (uint32_t)go2 << 17 | (uint32_t)ge2 << 19;
+            const uint32_t pkI = common | (uint32_t)i | (uint32_t)FQ_ST_I << 10 | (uint32_t)i << 23;
+            const uint32_t pkD = common | (uint32_t)(i + 1) | (uint32_t)FQ_ST_D << 10 | (uint32_t)(i + 1) << 23;
+            if (has_I) group_put(k, l, pkI, prev);
+            if (has_D) {
+              if (vmask & 1u) group_put(kk0, ll0, pkD, prev);
+              if (vmask & 2u) group_put(kk1, ll1, pkD, prev);
+              if (vmask & 4u) group_put(kk2, ll2, pkD, prev);
+              if (vmask & 8u) group_put(kk3, ll3, pkD, prev);
+            }
+            group_close(score, prev);
           }
         }
-      } else if (st == FQ_ST_I) {
-        if (n_gape < o.max_gape) push(a, i, k, l, n_mm, n_gapo, n_gape + 1, FQ_ST_I, true, last_diff);
-      } else {
-        if (n_gape < o.max_gape && (n_gape + n_gapo < max_diff || occ < (uint32_t)o.max_del_occ)) {
+      }
+      if (allow_M) {   // ---- mismatch children, bases (c+1)&3, (c+2)&3, (c+3)&3 and, for an ambiguous read base, (c+4)&3 (bwtgap.c:245-252)
+        const uint32_t mmask = cbase < 4 ? (vmask & ~(1u << cbase)) : vmask;
+        if (mmask) {
+          n_live += (int32_t)FQ_POPC32(mmask);
+          const int score = cscore + o.s_mm;
+          uint32_t prev;
+          if (group_open(score, diffs + 1, prev)) {
+            const uint32_t pkM = ((cpk & ((1u << 9) | (31u << 12) | (3u << 17) | (15u << 19))) + (1u << 12)) | (uint32_t)i | (uint32_t)i << 23;
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const uint32_t kk = f.L2[j] + ck[j] + 1, ll = f.L2[j] + cl[j];
-            if (kk <= ll) push(a, i + 1, kk, ll, n_mm, n_gapo, n_gape + 1, FQ_ST_D, true, last_diff);
+            for (int j = 1; j <= 4; ++j) {
+              const int cc = (cbase + j) & 3;
+              if ((mmask >> cc) & 1u) {
+                group_put(fq_sel4v(kk0, kk1, kk2, kk3, cc), fq_sel4v(ll0, ll1, ll2, ll3, cc), pkM, prev);
+              }
+            }
+            group_close(score, prev);
           }
         }
       }
     }
-    const int ci = cbase;
-    if (allow_diff && allow_M) {
-#pragma unroll
-      for (int j = 1; j <= 4; ++j) {
-        const int cc = (ci + j) & 3;
-        const bool is_mm = (j != 4 || ci > 3);
-        const uint32_t kk = fq_sel4(f.L2, cc) + fq_sel4(ck, cc) + 1, ll = fq_sel4(f.L2, cc) + fq_sel4(cl, cc);
-        if (kk <= ll) {
-          if (is_mm) push(a, i, kk, ll, n_mm + 1, n_gapo, n_gape, FQ_ST_M, true, last_diff);
-          else forward(a, i, kk, ll, n_mm, n_gapo, n_gape, last_diff, e_score);
+    // ---- the match child stays in registers (pushed last by the reference, hence popped next: bwtgap.c:246-258) ----
+    if (!mvalid) { has_cur = false; return; }
+    FQ_PROF(2);
+    ++c_pushes; ++c_pops;
+    if (n_live + 1 > o.max_entries) { if (!exact) status |= FQ_SF_ENTRY_LIMIT; finish(); return; }   // the loop-top check of its pop
+    ck_ = mk; cl_ = ml; cpk = fpk;
+    if (i == 0) { has_cur = false; hit_pending = true; }
+  }
+
+  // Completed alignments of this trip (bwtgap.c:166-198); called by every lane of the wavefront when any lane has one.
+  FQ_HD void collect_hits() {
+    bool keep_going = true, add = false;
+    uint32_t x = 0;
+    int ld = 0, a = 0;
+    if (hit_pending) {
+      a = (int)(cpk >> 9) & 1;
+      const int n_mm = (int)(cpk >> 12) & 31, n_gapo = (int)(cpk >> 17) & 3, n_gape = (int)(cpk >> 19) & 15;
+      if (n_aln == 0) {
+        best_score = cscore;
+        const int best_diff = n_mm + n_gapo + (gape_mode ? n_gape : 0);
+        if (!nonstop) max_diff = best_diff + 1 > max_diff_opt ? max_diff_opt : best_diff + 1;
+      }
+      if (cscore == best_score) best_cnt += (int)(cl_ - ck_ + 1);
+      else if (best_cnt > o.max_top2) keep_going = false;
+      if (keep_going) {
+        add = true;
+        if (n_gapo) {
+          const FqAln *al = A.aln + (size_t)w * (size_t)A.tier.aln_cap;
+          for (uint32_t j = 0; j < n_aln; ++j)
+            if (al[j].k == ck_ && al[j].l == cl_) { add = false; break; }
+        }
+        if (add) { x = cl_ - ck_ + 1; ld = (int)(cpk >> 23); }
+      }
+    }
+    // gap_shadow (bwtgap.c:81-91) over width[0..last_diff) of the hit's strand, one hit at a time, all lanes sweeping
+    uint64_t sm = FQ_BALLOT(add && ld > 0);
+    while (sm) {
+      const int L = FQ_CTZ64(sm);
+      sm &= sm - 1;
+      const FqWRec *mine = wrec + (size_t)a * (size_t)A.wstride;
+      const uint64_t p64 = (uint64_t)(uintptr_t)mine;
+      FqWRec *const ww = (FqWRec *)(uintptr_t)((uint64_t)FQ_READLANE32((uint32_t)p64, L) | (uint64_t)FQ_READLANE32((uint32_t)(p64 >> 32), L) << 32);
+      const int n = (int)FQ_READLANE32((uint32_t)ld, L);
+      const uint32_t xx = FQ_READLANE32(x, L);
+      uint32_t jj = 0;
+      for (int base = 0; base < n; base += FQ_WAVE_SIZE) {
+        const int t = base + FQ_LANE_ID();
+        const bool in = t < n;
+        const uint32_t cur = in ? ww[t].w : 0u;
+        const bool eq = in && cur == xx;
+        const uint64_t em = FQ_BALLOT(eq);
+        if (in && cur > xx) ww[t].w = cur - xx;
+        else if (eq) {
+          const uint32_t rank = (uint32_t)FQ_POPC64(em & (((uint64_t)1 << FQ_LANE_ID()) - 1));
+          FqWRec nr; nr.bid = 1; nr.w = seq_len - (jj + rank + 1);
+          ww[t] = nr;
+        }
+        jj += (uint32_t)FQ_POPC64(em);
+      }
+    }
+    if (hit_pending) {
+      hit_pending = false;
+      if (!keep_going) finish();
+      else if (add) {
+        if (n_aln >= A.tier.aln_cap) { status |= FQ_SF_ALN_OVERFLOW; finish(); }
+        else {
+          const int n_mm = (int)(cpk >> 12) & 31, n_gapo = (int)(cpk >> 17) & 3, n_gape = (int)(cpk >> 19) & 15;
+          FqAln h;
+          h.info = (uint32_t)n_mm | (uint32_t)n_gapo << 8 | (uint32_t)n_gape << 16 | (uint32_t)a << 24;
+          h.k = ck_; h.l = cl_; h.score = cscore;
+          A.aln[(size_t)w * (size_t)A.tier.aln_cap + n_aln++] = h;
         }
       }
-    } else if (ci < 4) {
-      const uint32_t kk = fq_sel4(f.L2, ci) + fq_sel4(ck, ci) + 1, ll = fq_sel4(f.L2, ci) + fq_sel4(cl, ci);
-      if (kk <= ll) forward(a, i, kk, ll, n_mm, n_gapo, n_gape, last_diff, e_score);
     }
   }
 };
 
+// fetch(n): reserves n consecutive queue positions and returns the first
 template <class St, class Fetch>
 FQ_HD void fq_gap_lanes(const FqGapArgs &A, const St &store0, Fetch fetch, int lane_slot) {
   FqGapLane<St> L(A, store0, lane_slot);
   uint32_t trips = 0;
   for (;; ++trips) {
-    // (re)fill idle lanes, in groups
+    // (re)fill idle lanes, in groups: one queue reservation per group
     const bool want = !L.active && !L.done;
-    const int n_want = FQ_WAVE_COUNT(want), n_active = FQ_WAVE_COUNT(L.active);
-    if (n_want == 0 && n_active == 0) { FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXTRIPS], trips); break; }
-    if (want && (n_want >= A.refill_min || n_active == 0)) {
-      const int w = fetch();
-      if (w < 0) L.done = true; else L.begin(w);
+    const uint64_t wm = FQ_BALLOT(want), am = FQ_BALLOT(L.active);
+    if (wm == 0 && am == 0) { FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXTRIPS], trips); break; }
+    if (wm != 0 && (FQ_POPC64(wm) >= A.refill_min || am == 0)) {
+      const int leader = FQ_CTZ64(wm);
+      uint32_t base_l = 0;
+      if (FQ_LANE_ID() == leader) base_l = fetch((uint32_t)FQ_POPC64(wm));
+      const uint32_t base = FQ_READLANE32(base_l, leader);
+      if (want) {
+        const uint32_t wq = base + (uint32_t)FQ_POPC64(wm & (((uint64_t)1 << FQ_LANE_ID()) - 1));
+        if (wq >= (uint32_t)A.n_work) L.done = true; else L.begin((int)wq);
+      }
     }
     if (L.active) L.step();
+    if (FQ_BALLOT(L.hit_pending) != 0) L.collect_hits();
   }
 }
+
 
 // ---- K_sa: bwt_sa over enumerated SA rows (src/BwtMapper.cpp:770-772, 811-853) -------------------
 struct FqSaArgs {

@@ -42,7 +42,7 @@ int launch_compact(const uint8_t *f, int n, int32_t *read_list, int32_t *sidx, i
   return 0;
 }
 int launch_width(const FqWidthArgs &a) { for (int t = 0; t < a.n_work * 4; ++t) fq_width_thread(a, t); return 0; }
-struct SeqFetch { int *next; int n; int operator()() const { return *next < n ? (*next)++ : -1; } };
+struct SeqFetch { int *next; int n; uint32_t operator()(uint32_t k) const { const uint32_t at = (uint32_t)*next; *next += (int)k; return at; } };
 int gap_lane_slots(const FqGapArgs &a) { return a.n_work > 0 ? 1 : 0; }
 int launch_gap(const FqGapArgs &a_in) {
   FqGapArgs a = a_in;
