@@ -208,6 +208,7 @@ def main() -> None:
         "work_per_step": {k: round(agg[k] / args.steps, 1) for k in ("filter_probes", "occ_block_touches", "gap_occ_touches", "stack_pops",
                                                                      "stack_pushes", "sa_rows", "reads_searched", "sw_tasks", "refine_tasks", "tier_retries", "reads_over_4k_pops")},
         "max_pops_per_read": agg["max_pops_per_read"], "max_wave_trips": agg["max_wave_trips"],
+        "gap_wave_trips_per_step": round(agg["wave_trips"] / args.steps, 1), "gap_lane_trips_per_step": round(agg["lane_trips"] / args.steps, 1),
     }
 
     # ---- CPU baseline: the oracle (a port) on a bounded sample of the same workload, rank 0, N=1 only -----------

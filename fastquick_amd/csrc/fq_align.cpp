@@ -87,7 +87,8 @@ struct fq_ctx {
   // search workspaces
   DevBuf<int32_t> d_work;
   DevBuf<uint32_t> d_heads, d_naln, d_status;
-  DevBuf<FqWRec> d_wrec, d_srec;
+  DevBuf<uint32_t> d_wfull;
+  DevBuf<FqPos> d_prec;
   DevBuf<FqEntry> d_pool;
   DevBuf<FqAln> d_aln, d_packed;
   DevBuf<uint64_t> d_off;
@@ -108,7 +109,11 @@ struct fq_ctx {
   DevBuf<uint32_t> d_mdsz;
   // host staging
   vector<uint8_t> h_filtered;
-  vector<int32_t> h_len_trim, h_pair_list, h_read_list, h_sidx;
+  vector<int32_t> h_len_trim, h_pair_list, h_read_list, h_sidx, h_sub_max;
+  vector<FqSurvInfo> h_surv;
+  DevBuf<FqSurvInfo> d_surv;
+  DevBuf<int32_t> d_sub_max;
+  int64_t n_bases_in = 0;
   vector<int> pen_lut;   // per reference batch: memo of the insert-size penalty per integer insert size
   // results of the last batch
   FqBatchState st;
@@ -144,6 +149,7 @@ extern "C" int fq_ctx_create(const fq_index_t *ix, const fq_opts_t *opts, int32_
   if (o.s_mm <= 0 || o.s_gapo <= 0 || o.s_gape <= 0) return FQ_EINVAL;   // children must score strictly more than parents (Q1)
   if (o.fnr <= 0.0 && (o.max_diff < 0 || o.max_diff > 30)) return FQ_EINVAL;
   if (o.batch_pairs < 1) return FQ_EINVAL;
+  if (o.max_seed_diff < 0 || o.max_seed_diff > 30) return FQ_EINVAL;       // 5-bit lower bounds in the packed position records
   if (o.max_entries < 1 || o.max_entries > (1 << 30)) return FQ_EINVAL;   // 32-bit live-entry counter in the search kernel
   std::unique_ptr<fq_ctx> c(new fq_ctx);
   c->ix = ix; c->o = o; c->max_pairs = max_pairs;
@@ -191,6 +197,9 @@ extern "C" int fq_batch_upload(fq_ctx_t *c, const fq_read_batch_t *in) {
   if (fqdev::init(c->ix->device)) return FQ_ENODEV;   // per-thread stream
   if (in->stride < 1 || in->stride > 4096) return FQ_EINVAL;
   const size_t n2 = (size_t)in->n_pairs * 2;
+  int64_t nb = 0;
+  for (size_t i = 0; i < n2; ++i) nb += in->len[i];
+  c->n_bases_in = nb;
   for (size_t i = 0; i < n2; ++i)
     if (in->len[i] < 35 || in->len[i] > FQ_LMAX || in->len[i] > in->stride) { c->err = "read length outside [35," + std::to_string(FQ_LMAX) + "]"; return FQ_ELIMIT; }
   CKM(c->d_seq.ensure(n2 * in->stride + 64));
@@ -400,43 +409,52 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   if (n == 0) return FQ_OK;
 
   // ---- stage 0: encode + trim + filter + ordered compaction (GPU) -------------------------------------
+  // The call may carry several reference batches (READ_BUFFER_SIZE pairs each, src/BwtMapper.h:36): the GPU stages run
+  // over all of them at once, the order-dependent host stages walk them one reference batch at a time.
+  const int B = o.batch_pairs, n_sub = (n + B - 1) / B;
   CKM(c->d_len_trim.ensure(n2) && c->d_filtered.ensure(n2 + 64) && c->d_read_list.ensure(n2) &&
-      c->d_sidx.ensure(n2) && c->d_pair_list.ensure(n));
+      c->d_sidx.ensure(n2) && c->d_pair_list.ensure(n) && c->d_sub_max.ensure(n_sub));
+  CK(fqdev::dzero(c->d_sub_max.p, (size_t)n_sub * 4));
   {
     FqPrepArgs a{};
     a.ix = ix->dev; a.o = c->ko; a.seq = c->d_seq.p; a.qual = c->d_qual.p; a.len = c->d_len.p; a.stride = stride; a.n_reads = n2;
-    a.len_trim = c->d_len_trim.p; a.filtered = c->d_filtered.p; a.counters = c->d_counters.p;
+    a.len_trim = c->d_len_trim.p; a.filtered = c->d_filtered.p; a.sub_max = c->d_sub_max.p; a.n_pairs = n; a.batch_pairs = B;
+    a.counters = c->d_counters.p;
     fqdev::time_begin(FQ_K_PREP);
     CK(fqdev::launch_prep(a));
     CK(fqdev::launch_compact(c->d_filtered.p, n, c->d_read_list.p, c->d_sidx.p, c->d_pair_list.p, c->d_counts.p));
     fqdev::time_end(FQ_K_PREP);
   }
+  // Only what concerns surviving pairs comes back to the host: in a WGS-like stream that is a fraction of a percent of the
+  // batch.  (Debug mode also fetches the per-read arrays of the whole batch for the stage dump.)
   int32_t counts[2] = {0, 0};
-  c->h_filtered.resize(n2);
-  c->h_len_trim.resize(n2);
+  c->h_sub_max.resize(n_sub);
   CK(fqdev::d2h(counts, c->d_counts.p, 8));
-  CK(fqdev::d2h(c->h_filtered.data(), c->d_filtered.p, n2));
-  CK(fqdev::d2h(c->h_len_trim.data(), c->d_len_trim.p, (size_t)n2 * 4));
+  CK(fqdev::d2h(c->h_sub_max.data(), c->d_sub_max.p, (size_t)n_sub * 4));
   CK(fqdev::sync());
   const int n_search = counts[0], n_surv = counts[1];
   c->h_pair_list.resize(n_surv);
   c->h_read_list.resize(n_search);
+  c->h_surv.resize((size_t)n_surv * 2);
+  CKM(c->d_surv.ensure((size_t)n_surv * 2 + 1));
+  CK(fqdev::launch_surv_gather(c->d_pair_list.p, n_surv, n, c->d_len_trim.p, c->d_filtered.p, c->d_sidx.p, c->d_surv.p));
   CK(fqdev::d2h(c->h_pair_list.data(), c->d_pair_list.p, (size_t)n_surv * 4));
   CK(fqdev::d2h(c->h_read_list.data(), c->d_read_list.p, (size_t)n_search * 4));
+  CK(fqdev::d2h(c->h_surv.data(), c->d_surv.p, (size_t)n_surv * 2 * sizeof(FqSurvInfo)));
+  if (c->debug) {
+    c->h_filtered.resize(n2);
+    c->h_len_trim.resize(n2);
+    CK(fqdev::d2h(c->h_filtered.data(), c->d_filtered.p, n2));
+    CK(fqdev::d2h(c->h_len_trim.data(), c->d_len_trim.p, (size_t)n2 * 4));
+  } else { c->h_filtered.clear(); c->h_len_trim.clear(); }
   CK(fqdev::sync());
-  // The call may carry several reference batches (READ_BUFFER_SIZE pairs each, src/BwtMapper.h:36): the GPU stages run
-  // over all of them at once, the order-dependent host stages walk them one reference batch at a time.
-  const int B = o.batch_pairs, n_sub = (n + B - 1) / B;
-  int64_t n_bases = 0;
+  const int64_t n_bases = c->n_bases_in;
   int max_len_all = 1;
   vector<int> sub_max_len(n_sub, 1), sub_lo(n_sub + 1, 0);
-  for (int e = 0; e < 2; ++e)
-    for (int i = 0; i < n; ++i) {
-      const int r = e * n + i, lt = c->h_len_trim[r];
-      n_bases += c->hb.len[r];
-      if (lt > max_len_all) max_len_all = lt;
-      if (lt > sub_max_len[i / B]) sub_max_len[i / B] = lt;
-    }
+  for (int sb = 0; sb < n_sub; ++sb) {
+    sub_max_len[sb] = std::max(1, c->h_sub_max[sb]);
+    max_len_all = std::max(max_len_all, sub_max_len[sb]);
+  }
   {
     int sp = 0;
     for (int sb = 0; sb < n_sub; ++sb) { sub_lo[sb] = sp; while (sp < n_surv && c->h_pair_list[sp] < (int64_t)(sb + 1) * B) ++sp; }
@@ -454,7 +472,8 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   vector<uint64_t> aln_off(n_search + 1, 0);
   vector<uint32_t> aln_n(n_search, 0);
   {
-    const int Lpad = max_len_all + 1;
+    const int Lpad = (max_len_all + 1 + 7) & ~7;                  // exact widths per strand; rows are written 8 positions at a time
+    const int Ppad = (max_len_all + 1 + FQ_POS_PAD + 7) & ~7;     // position records per strand (16-byte aligned rows)
     const FqGapTier tiers[3] = {{4096u, 32u, 0}, {65535u, 512u, 0}, {(uint32_t)o.max_entries + 64u, 8192u, 1}};
     // scores that can occur for the longest read of this call (children may exceed max_diff by one difference)
     const int nb_need = (c->maxdiff_lut[max_len_all] + 1) * o.s_mm + o.max_gapo * o.s_gapo + o.max_gape * o.s_gape + 1;
@@ -470,20 +489,19 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
       next_work.clear();
       for (size_t c0 = 0; c0 < work.size(); c0 += chunk_reads[tier]) {
         const int nw = (int)std::min(chunk_reads[tier], work.size() - c0);
-        CKM(c->d_work.ensure(nw) && c->d_wrec.ensure((size_t)nw * 2 * Lpad) && c->d_srec.ensure((size_t)nw * 2 * (FQ_SEED_MAX + 1)) && c->d_winfo.ensure(nw) &&
+        CKM(c->d_work.ensure(nw) && c->d_wfull.ensure((size_t)nw * 2 * Lpad) && c->d_prec.ensure((size_t)nw * 2 * Ppad) && c->d_winfo.ensure(nw) &&
             c->d_aln.ensure((size_t)nw * T.aln_cap) && c->d_naln.ensure(nw) && c->d_status.ensure(nw) && c->d_off.ensure(nw + 1));
         CK(fqdev::h2d(c->d_work.p, work.data() + c0, (size_t)nw * 4));
         FqWidthArgs wa{};
         wa.ix = ix->dev; wa.o = c->ko; wa.seq = c->d_seq.p; wa.stride = stride; wa.len_trim = c->d_len_trim.p; wa.read_list = c->d_read_list.p;
-        wa.work = c->d_work.p; wa.n_work = nw; wa.wrec = c->d_wrec.p; wa.wstride = Lpad;
-        wa.srec = c->d_srec.p; wa.winfo = c->d_winfo.p; wa.maxdiff_lut = c->d_maxdiff.p; wa.counters = c->d_counters.p;
+        wa.work = c->d_work.p; wa.n_work = nw; wa.wfull = c->d_wfull.p; wa.wstride = Lpad;
+        wa.prec = c->d_prec.p; wa.pstride = Ppad; wa.winfo = c->d_winfo.p; wa.maxdiff_lut = c->d_maxdiff.p; wa.counters = c->d_counters.p;
         fqdev::time_begin(FQ_K_WIDTH);
         CK(fqdev::launch_width(wa));
         fqdev::time_end(FQ_K_WIDTH);
         FqGapArgs ga{};
-        ga.ix = ix->dev; ga.o = c->ko; ga.o.n_buckets = nb_need; ga.seq = c->d_seq.p; ga.stride = stride;
-        ga.n_work = nw; ga.winfo = c->d_winfo.p;
-        ga.wrec = c->d_wrec.p; ga.wstride = Lpad; ga.srec = c->d_srec.p;
+        ga.ix = ix->dev; ga.o = c->ko; ga.o.n_buckets = nb_need; ga.n_work = nw; ga.winfo = c->d_winfo.p;
+        ga.wfull = c->d_wfull.p; ga.wstride = Lpad; ga.prec = c->d_prec.p; ga.pstride = Ppad;
         ga.pool = c->d_pool.p; ga.heads = c->d_heads.p; ga.tier = T; ga.aln = c->d_aln.p; ga.n_aln = c->d_naln.p; ga.status = c->d_status.p;
         ga.counters = c->d_counters.p; ga.queue = c->d_queue.p;
         {
@@ -529,19 +547,17 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   R.assign((size_t)n_surv * 2, FqRead());
   vector<int> s_of((size_t)n_surv * 2, -1);
   {
-    c->h_sidx.resize(n2);   // read -> search index (or -1), built by the compaction kernel
-    CK(fqdev::d2h(c->h_sidx.data(), c->d_sidx.p, (size_t)n2 * 4));
-    CK(fqdev::sync());
     for (int sp = 0; sp < n_surv; ++sp)
       for (int e = 0; e < 2; ++e) {
         FqRead &p = R[2 * sp + e];
         const int r = e * n + c->h_pair_list[sp];
+        const FqSurvInfo &si = c->h_surv[2 * sp + e];
         p.r = r;
         p.full_len = c->hb.len[r];
-        p.len = p.clip_len = c->h_len_trim[r];
-        p.filtered = c->h_filtered[r];
+        p.len = p.clip_len = si.len_trim;
+        p.filtered = (uint8_t)si.filtered;
         p.extra_flag = 1 | (e == 0 ? 64 : 128);   // SAM_FPD | SAM_FR1/FR2 (BwtMapper.cpp:749)
-        s_of[2 * sp + e] = c->h_sidx[r];
+        s_of[2 * sp + e] = si.sidx;
       }
   }
   auto aln_of = [&](int idx, int *n_out) -> const FqAln * {
@@ -975,6 +991,8 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
     if (cnt[FQ_C_MAXPOPS] > c->stats.max_pops_per_read) c->stats.max_pops_per_read = cnt[FQ_C_MAXPOPS];
     c->stats.reads_over_4k_pops += cnt[FQ_C_POPS_GT4K];
     if (cnt[FQ_C_MAXTRIPS] > c->stats.max_wave_trips) c->stats.max_wave_trips = cnt[FQ_C_MAXTRIPS];
+    c->stats.wave_trips += cnt[FQ_C_SUMTRIPS];
+    c->stats.lane_trips += cnt[FQ_C_LANETRIPS];
     c->stats.pairs += n;
     c->stats.host_ms_serial += t_serial1 - t_host0;
     c->stats.host_ms_pair += t_host1 - t_serial1;
@@ -990,8 +1008,8 @@ extern "C" int fq_ctx_set_debug(fq_ctx_t *c, int keep_stage_snapshots) {
   return FQ_OK;
 }
 void fq_ctx_all_reads(const fq_ctx_t *c, const uint8_t **filtered, const int32_t **len_trim) {
-  *filtered = c->h_filtered.data();
-  *len_trim = c->h_len_trim.data();
+  *filtered = c->h_filtered.empty() ? nullptr : c->h_filtered.data();
+  *len_trim = c->h_len_trim.empty() ? nullptr : c->h_len_trim.data();
 }
 // accessors used by fq_sam.cpp
 const FqBatchState *fq_ctx_state(const fq_ctx_t *c) { return &c->st; }

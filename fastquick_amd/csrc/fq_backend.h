@@ -31,6 +31,8 @@ int launch_prep(const FqPrepArgs &a);
 //   read_list[0..n_search) unfiltered reads, ordered by (pair, end); sidx[r] = s or -1
 //   counts[0] = n_search, counts[1] = n_surv   (device memory)
 int launch_compact(const uint8_t *filtered, int n_pairs, int32_t *read_list, int32_t *sidx, int32_t *pair_list, int32_t *counts);
+// out[2*sp+e] = {len_trim, filtered, sidx} of read e of surviving pair sp
+int launch_surv_gather(const int32_t *pair_list, int n_surv, int n_pairs, const int32_t *len_trim, const uint8_t *filtered, const int32_t *sidx, FqSurvInfo *out);
 int launch_width(const FqWidthArgs &a);
 // number of persistent lanes launch_gap() will start for these arguments (sizes a.pool / a.heads)
 int gap_lane_slots(const FqGapArgs &a);

@@ -79,11 +79,15 @@ FQ_HD uint32_t fq_pack(int i, int a, int st, int mm, int go, int ge, int ld) {
          (uint32_t)ld << 23;
 }
 
-// bwt_width_t (libbwa/bwtaln.h:29-32): one record per read position so that the two neighbours the search needs come
-// back in a single 16-byte load
-struct FqWRec {
-  uint32_t w, bid;
-};
+// What one search step needs to know about read position p of strand a, packed into 16 bits so that a 16-byte load
+// covers eight consecutive positions (the search walks p downwards one position per step):
+//   bid[0:5)   width[a][p].bid, clamped to 31 (max_diff <= 30: a clamped value compares like the exact one)
+//   eq[5]      p >= 1 && width[a][p-1].w == width[a][p].w
+//   sbid[6:11) seed_width[a][p - seed_off].bid (clamped), seq[11] the same equality for the seed widths
+//   base[12:15) seq[a][p] (0..3, 4 = N, 5 = '-')
+// Written by k_width; gap_shadow keeps bid/eq in step with the exact widths (wfull) it modifies.
+typedef uint16_t FqPos;
+#define FQ_POS_PAD 8   // slack behind each strand's array so that the 8-position window may start anywhere
 
 // start-of-search record of work item w (k_width -> gap kernel)
 struct FqGapWork {
@@ -135,4 +139,4 @@ struct FqMdTask {
 };
 
 // work counters written by kernels (one u64 each, atomically accumulated per wave)
-enum { FQ_C_OCC_WIDTH = 0, FQ_C_OCC_GAP, FQ_C_OCC_SA, FQ_C_PROBES, FQ_C_POPS, FQ_C_PUSHES, FQ_C_MAXPOPS, FQ_C_POPS_GT4K, FQ_C_MAXTRIPS, FQ_C_COUNT };
+enum { FQ_C_OCC_WIDTH = 0, FQ_C_OCC_GAP, FQ_C_OCC_SA, FQ_C_PROBES, FQ_C_POPS, FQ_C_PUSHES, FQ_C_MAXPOPS, FQ_C_POPS_GT4K, FQ_C_MAXTRIPS, FQ_C_SUMTRIPS, FQ_C_LANETRIPS, FQ_C_COUNT };

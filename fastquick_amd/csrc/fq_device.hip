@@ -98,8 +98,9 @@ __global__ void __launch_bounds__(256) k_prep(FqPrepArgs a) {
   if (r < a.n_reads) fq_prep_thread(a, r);
 }
 __global__ void __launch_bounds__(256) k_width(FqWidthArgs a) {
+  __shared__ uint8_t seed_bits[FQ_SEED_MAX * 256];   // [ii][thread]: lane-interleaved, conflict free
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < a.n_work * 4) fq_width_thread(a, t);
+  if (t < a.n_work * 2) fq_width_thread(a, t, seed_bits + threadIdx.x, 256);
 }
 extern __shared__ __align__(16) unsigned char fq_dyn_lds[];
 struct FqQueueFetch {
@@ -413,9 +414,19 @@ int launch_prep(const FqPrepArgs &a) {
   FQ_HIP(hipGetLastError());
   return 0;
 }
+__global__ void __launch_bounds__(256) k_surv_gather(const int32_t *pair_list, int n_surv, int n_pairs, const int32_t *len_trim, const uint8_t *filtered, const int32_t *sidx, FqSurvInfo *out) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 2 * n_surv) fq_surv_gather_thread(pair_list, n_pairs, len_trim, filtered, sidx, out, t);
+}
+int launch_surv_gather(const int32_t *pair_list, int n_surv, int n_pairs, const int32_t *len_trim, const uint8_t *filtered, const int32_t *sidx, FqSurvInfo *out) {
+  if (n_surv <= 0) return 0;
+  hipLaunchKernelGGL(k_surv_gather, dim3(nblk((uint64_t)n_surv * 2, 256)), dim3(256), 0, g_stream, pair_list, n_surv, n_pairs, len_trim, filtered, sidx, out);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
 int launch_width(const FqWidthArgs &a) {
   if (a.n_work <= 0) return 0;
-  hipLaunchKernelGGL(k_width, dim3(nblk((uint64_t)a.n_work * 4, 256)), dim3(256), 0, g_stream, a);
+  hipLaunchKernelGGL(k_width, dim3(nblk((uint64_t)a.n_work * 2, 256)), dim3(256), 0, g_stream, a);
   FQ_HIP(hipGetLastError());
   return 0;
 }

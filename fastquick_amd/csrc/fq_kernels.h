@@ -16,13 +16,17 @@
 #define FQ_CTZ32(x) (__ffs((int)(x)) - 1)
 #define FQ_ATOMIC_ADD64(p, v) atomicAdd((unsigned long long *)(p), (unsigned long long)(v))
 #define FQ_ATOMIC_MAX64(p, v) atomicMax((unsigned long long *)(p), (unsigned long long)(v))
+#define FQ_ATOMIC_MAX32(p, v) atomicMax((int *)(p), (int)(v))
 #else
+#define FQ_ATOMIC_MAX32(p, v) (*(p) = *(p) > (int32_t)(v) ? *(p) : (int32_t)(v))
 #define FQ_ATOMIC_MAX64(p, v) (*(p) = *(p) > (uint64_t)(v) ? *(p) : (uint64_t)(v))
 #define FQ_POPC64(x) __builtin_popcountll(x)
 #define FQ_POPC32(x) __builtin_popcount(x)
 #define FQ_CTZ32(x) __builtin_ctz(x)
 #define FQ_ATOMIC_ADD64(p, v) (*(p) += (v))
 #endif
+
+struct FqU4 { uint32_t x, y, z, w; };   // one 16-byte load / store
 
 // nst_nt4_table, libbwa/bntseq.c:38-55 (A0 C1 G2 T3, '-' 5, anything else 4)
 FQ_HD int fq_nt4(uint8_t ch) {
@@ -109,6 +113,8 @@ struct FqPrepArgs {
   int32_t stride, n_reads;
   int32_t *len_trim;     // out: p->len (== clip_len)
   uint8_t *filtered;     // out: 1 = filtered
+  int32_t *sub_max;      // out: [pair / batch_pairs] max trimmed length over both ends (zeroed by the caller)
+  int32_t n_pairs, batch_pairs;
   uint64_t *counters;
 };
 FQ_HD uint32_t fq_kmer_project(uint64_t kmer, int t) {
@@ -144,6 +150,20 @@ FQ_HD void fq_prep_thread(const FqPrepArgs &A, int r) {
     len = max_l + 1;
   }
   A.len_trim[r] = len;
+  {   // per-reference-batch maximum: one atomic per wavefront (its reads almost always belong to one batch)
+    const int slot = (r >= A.n_pairs ? r - A.n_pairs : r) / A.batch_pairs;
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int slot0 = __builtin_amdgcn_readfirstlane(slot);
+    if (__ballot(1) == ~0ull && __ballot(slot != slot0) == 0) {   // full wavefront, one slot
+      int mx = len;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+      if (__builtin_amdgcn_readfirstlane(r) == r) atomicMax(&A.sub_max[slot0], mx);
+    } else atomicMax(&A.sub_max[slot], len);
+#else
+    if (A.sub_max[slot] < len) A.sub_max[slot] = len;
+#endif
+  }
   uint8_t filt = 0;
   if (A.o.filter_thresh != 0) {
     // the first 96 bases as 24 little-endian words: six 16-byte loads when rows are 16-byte aligned
@@ -201,6 +221,16 @@ FQ_HD void fq_prep_thread(const FqPrepArgs &A, int r) {
   A.filtered[r] = filt;
 }
 
+// ---- what the host needs to know about the reads of surviving pairs (everything else stays on the device) ----
+struct FqSurvInfo { int32_t len_trim, filtered, sidx; };
+FQ_HD void fq_surv_gather_thread(const int32_t *pair_list, int n_pairs, const int32_t *len_trim, const uint8_t *filtered, const int32_t *sidx, FqSurvInfo *out, int t) {
+  const int sp = t >> 1, e = t & 1;
+  const int r = e * n_pairs + pair_list[sp];
+  FqSurvInfo v;
+  v.len_trim = len_trim[r]; v.filtered = filtered[r]; v.sidx = sidx[r];
+  out[t] = v;
+}
+
 // ---- read access helpers: seq[0] is the reversed read, seq[1] its complement (reverse complement
 // of the read), exactly the two arrays bwa_read_seq_with_hash_dev leaves in p->seq / p->rseq ------
 struct FqReadView {
@@ -212,7 +242,9 @@ FQ_HD int fq_base(const FqReadView &v, int a, int i) {
   return (a && c < 4) ? 3 - c : c;
 }
 
-// ---- K_width: bwt_cal_width (libbwa/bwtaln.c:73-97), four chains per read -----------------------
+// ---- K_width: bwt_cal_width (libbwa/bwtaln.c:73-97), one thread per (read, strand): seed chain, then full chain ---------
+// Outputs are written eight positions at a time (one 16-byte store of position records, two of widths): a thread's rows are
+// private, so narrower stores would reach HBM as partial lines.
 struct FqWidthArgs {
   FqDevIndex ix;
   FqKOpts o;
@@ -222,40 +254,77 @@ struct FqWidthArgs {
   const int32_t *read_list;   // s -> r
   const int32_t *work;        // w -> s (NULL: identity)
   int32_t n_work;
-  FqWRec *wrec;               // [w][2][wstride]   {w, bid} per position
+  uint32_t *wfull;            // [w][2][wstride]   width[a][p].w, exact (gap_shadow needs it); wstride % 8 == 0
   int32_t wstride;
-  FqWRec *srec;               // [w][2][FQ_SEED_MAX+1]
+  FqPos *prec;                // [w][2][pstride]   packed per-position records the search loop reads; pstride % 8 == 0
+  int32_t pstride;
   FqGapWork *winfo;           // [w] what the search kernel needs to start read w (one 8-byte load)
   const uint8_t *maxdiff_lut; // [len] -> max_diff (bwa_cal_maxdiff, libbwa/bwtaln.c:43-58)
   uint64_t *counters;
 };
-FQ_HD void fq_width_thread(const FqWidthArgs &A, int t) {
-  const int w = t >> 2, which = t & 3, strand = which >> 1, seed = which & 1;
+// seed_bits[ii * seed_bits_stride]: FQ_SEED_MAX bytes of thread-private scratch (LDS on the device)
+FQ_HD void fq_width_thread(const FqWidthArgs &A, int t, uint8_t *seed_bits, int seed_bits_stride) {
+  const int w = t >> 1, strand = t & 1;
   const int s = A.work ? A.work[w] : w;
   const int r = A.read_list[s];
   FqReadView v = {A.seq + (size_t)r * (size_t)A.stride, A.len_trim[r]};
-  if (seed && v.len <= A.o.seed_len) return;
-  const int n = seed ? A.o.seed_len : v.len;
-  const int off = seed ? v.len - A.o.seed_len : 0;
   const FqFM &f = A.ix.fm[strand];
-  FqWRec *orec = seed ? A.srec + ((size_t)w * 2 + strand) * (FQ_SEED_MAX + 1) : A.wrec + ((size_t)w * 2 + strand) * (size_t)A.wstride;
-  uint32_t k = 0, l = f.seq_len, touches = 0;
-  int bid = 0, namb = 0;
-  for (int i = 0; i < n; ++i) {
-    const int c = fq_base(v, strand, off + i);
-    namb += c > 3;
-    if (c < 4) {
-      touches += fq_touch2(f, k - 1, l, true);
-      const uint32_t ok = fq_occ1(f, k - 1, c), ol = fq_occ1(f, l, c);
-      k = f.L2[c] + ok + 1;
-      l = f.L2[c] + ol;
+  uint32_t *ow = A.wfull + ((size_t)w * 2 + strand) * (size_t)A.wstride;
+  FqPos *prec = A.prec + ((size_t)w * 2 + strand) * (size_t)A.pstride;
+  uint32_t touches = 0;
+  const bool use_seed = v.len > A.o.seed_len;
+  const int seed_off = v.len - A.o.seed_len;
+  if (use_seed) {   // bwt_cal_width over the last seed_len bases (src/BwtMapper.cpp:131-137)
+    uint32_t k = 0, l = f.seq_len, wprev = 0;
+    int bid = 0;
+    for (int i = 0; i < A.o.seed_len; ++i) {
+      const int c = fq_base(v, strand, seed_off + i);
+      if (c < 4) {
+        touches += fq_touch2(f, k - 1, l, true);
+        const uint32_t ok = fq_occ1(f, k - 1, c), ol = fq_occ1(f, l, c);
+        k = f.L2[c] + ok + 1;
+        l = f.L2[c] + ol;
+      }
+      if (k > l || c > 3) { k = 0; l = f.seq_len; ++bid; }
+      const uint32_t wcur = l - k + 1;
+      seed_bits[i * seed_bits_stride] = (uint8_t)((uint32_t)(bid < 31 ? bid : 31) | (i >= 1 && wcur == wprev ? 1u << 5 : 0u));
+      wprev = wcur;
     }
-    if (k > l || c > 3) { k = 0; l = f.seq_len; ++bid; }
-    FqWRec rec; rec.w = l - k + 1; rec.bid = (uint32_t)bid;
-    orec[i] = rec;
   }
-  { FqWRec rec; rec.w = 0; rec.bid = (uint32_t)(bid + 1); orec[n] = rec; }
-  if (which == 0) {
+  uint32_t k = 0, l = f.seq_len, wprev = 0;
+  int bid = 0, namb = 0;
+  for (int i0 = 0; i0 < v.len; i0 += 8) {
+    uint32_t wv[8], pv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = i0 + j;
+      wv[j] = 0; pv[j] = 0;
+      if (i < v.len) {
+        const int c = fq_base(v, strand, i);
+        namb += c > 3;
+        if (c < 4) {
+          touches += fq_touch2(f, k - 1, l, true);
+          const uint32_t ok = fq_occ1(f, k - 1, c), ol = fq_occ1(f, l, c);
+          k = f.L2[c] + ok + 1;
+          l = f.L2[c] + ol;
+        }
+        if (k > l || c > 3) { k = 0; l = f.seq_len; ++bid; }
+        const uint32_t wcur = l - k + 1;
+        const uint32_t seedbits = (use_seed && i >= seed_off) ? (uint32_t)seed_bits[(i - seed_off) * seed_bits_stride] << 6 : 0u;
+        wv[j] = wcur;
+        pv[j] = seedbits | (uint32_t)(bid < 31 ? bid : 31) | (i >= 1 && wcur == wprev ? 1u << 5 : 0u) | (uint32_t)c << 12;
+        wprev = wcur;
+      }
+    }
+    FqU4 q;
+    q.x = wv[0]; q.y = wv[1]; q.z = wv[2]; q.w = wv[3];
+    *(FqU4 *)(ow + i0) = q;
+    q.x = wv[4]; q.y = wv[5]; q.z = wv[6]; q.w = wv[7];
+    *(FqU4 *)(ow + i0 + 4) = q;
+    q.x = pv[0] | pv[1] << 16; q.y = pv[2] | pv[3] << 16; q.z = pv[4] | pv[5] << 16; q.w = pv[6] | pv[7] << 16;
+    *(FqU4 *)(prec + i0) = q;
+  }
+  if (strand == 0) {
     const uint32_t md = A.maxdiff_lut[v.len];
     FqGapWork gw;
     gw.r = r;
@@ -279,13 +348,12 @@ FQ_HD void fq_width_thread(const FqWidthArgs &A, int t) {
 struct FqGapArgs {
   FqDevIndex ix;
   FqKOpts o;
-  const uint8_t *seq;
-  int32_t stride;
   int32_t n_work;
   const FqGapWork *winfo; // [w] read index, length, max_diff, too-many-N flag: written by k_width
-  FqWRec *wrec;          // width records written by k_width; gap_shadow updates them in place
+  uint32_t *wfull;       // exact widths written by k_width; read and updated only by gap_shadow
   int32_t wstride;
-  const FqWRec *srec;
+  FqPos *prec;           // packed per-position records (fq_common.h): all the search loop reads about the read
+  int32_t pstride;
   FqEntry *pool;         // [n_lane_slots][pool_cap]: one stack pool per persistent lane
   uint32_t *heads;       // [n_lane_slots][FQ_MAX_BUCKETS] (HBM-heads variant)
   FqGapTier tier;
@@ -374,12 +442,14 @@ FQ_HD void fq_blk_occ4(const FqBlkRaw &r, uint32_t o[4]) {
 #define FQ_BALLOT(pred) ((uint64_t)__ballot(pred))
 #define FQ_READLANE32(x, l) ((uint32_t)__builtin_amdgcn_readlane((int)(x), (l)))
 #define FQ_CTZ64(x) (__ffsll((long long)(x)) - 1)
+#define FQ_SHFL_UP1(x) ((uint32_t)__shfl_up((int)(x), 1))
 #else
 #define FQ_WAVE_SIZE 1
 #define FQ_LANE_ID() 0
 #define FQ_BALLOT(pred) ((uint64_t)((pred) ? 1 : 0))
 #define FQ_READLANE32(x, l) ((uint32_t)(x))
 #define FQ_CTZ64(x) __builtin_ctzll(x)
+#define FQ_SHFL_UP1(x) ((uint32_t)(x))
 #endif
 #define FQ_REFILL_MIN 8   // idle lanes of a wavefront wait until this many can be (re)initialised together
 // test-only instrumentation hooks (tests/emu builds may define FQ_PROFILE; empty in the product)
@@ -390,7 +460,6 @@ extern unsigned long long fq_prof[64];
 #define FQ_PROF(i) ((void)0)
 #endif
 
-struct FqU4 { uint32_t x, y, z, w; };   // one 16-byte load
 
 // One lane = one search at a time; a lane that finishes pulls the next read from a queue, so a wavefront stays busy
 // whatever the spread of search lengths inside its packet of 64 reads.
@@ -425,8 +494,10 @@ struct FqGapLane {
   bool active, done;
   int w, len, max_diff_opt, seed_off;                 // seed_off = len - seed_len (position ii = i - seed_off inside the seed)
   bool use_seed;
-  const uint8_t *row;
-  FqEntry *pool; FqWRec *wrec;
+  FqEntry *pool;
+  FqPos *prec;                                        // this read's position records, strand 0 (strand 1 at + pstride)
+  uint32_t pw0, pw1, pw2, pw3;                        // window of eight position records, positions [wbase, wbase + 8)
+  int wbase;
   // search state
   uint32_t m0, m1, m2, m3, bump, spare, status, n_aln;
   int32_t n_live;
@@ -443,7 +514,7 @@ struct FqGapLane {
     seq_len = f0.seq_len; L2_0 = f0.L2[0]; L2_1 = f0.L2[1]; L2_2 = f0.L2[2]; L2_3 = f0.L2[3];
     blk0 = f0.blk; blk1 = f1.blk; primary0 = f0.primary; primary1 = f1.primary;
     active = done = false; w = len = max_diff_opt = seed_off = 0; use_seed = false;
-    row = A_.seq; wrec = A_.wrec;
+    prec = A_.prec; pw0 = pw1 = pw2 = pw3 = 0; wbase = 0x7fff;
     pool = A_.pool + (size_t)lane_slot * (size_t)A_.tier.pool_cap;   // stack storage belongs to the lane, not to the read
     store.begin_lane(A_, lane_slot);
     m0 = m1 = m2 = m3 = bump = status = n_aln = 0; spare = FQ_NIL; n_live = 0;
@@ -494,10 +565,10 @@ struct FqGapLane {
     const FqGapWork gw = A.winfo[w];                 // written by k_width: read index, length, max_diff, "too many N"
     len = (int)(gw.meta & 0xffffu);
     max_diff_opt = (int)((gw.meta >> 16) & 0xffu);
-    row = A.seq + (size_t)gw.r * (size_t)A.stride;
     use_seed = len > o.seed_len;
     seed_off = len - o.seed_len;
-    wrec = A.wrec + (size_t)w * 2 * (size_t)A.wstride;
+    prec = A.prec + (size_t)w * 2 * (size_t)A.pstride;
+    wbase = 0x7fff;
     m0 = m1 = m2 = m3 = 0; bump = 0; spare = FQ_NIL; status = 0; n_aln = 0; n_live = 0;
     best_score = (max_diff_opt + 1) * o.s_mm + (o.max_gapo + 1) * o.s_gapo + (o.max_gape + 1) * o.s_gape;
     max_diff = max_diff_opt; best_cnt = 0;
@@ -525,30 +596,23 @@ struct FqGapLane {
       b = m0 ? FQ_CTZ32(m0) : m1 ? 32 + FQ_CTZ32(m1) : m2 ? 64 + FQ_CTZ32(m2) : 96 + FQ_CTZ32(m3);
       slot = store.head_get(b);
     }
-    // ---- loads: every lane issues one 16-byte load (stack entry, or the width records of positions i0-2 and i0-1); lanes
-    //      with a current entry add the two Occ blocks, the seed-width records and their read base
+    // ---- loads: a popping lane fetches its 16-byte stack entry; a lane with a current entry fetches the two Occ blocks of
+    //      rows k-1 and l and, when positions i0-1 / i0-2 have left its window, the next eight position records
     const int a = (int)(cpk >> 9) & 1, i0 = (int)(cpk & 511u);            // i0 >= 1 whenever has_cur
-    const FqWRec *ww = wrec + (size_t)a * (size_t)A.wstride;
-    const int wi = i0 >= 2 ? i0 - 2 : 0;
-    const uintptr_t pa = (uintptr_t)fq_pick2p((uint64_t)(uintptr_t)(pool + slot), (uint64_t)(uintptr_t)(ww + wi), popping ? 1 : 0);
-    const FqU4 vA = *(const FqU4 *)pa;
+    const int need_lo = i0 >= 2 ? i0 - 2 : 0;
+    const bool reload = !popping && (need_lo < wbase || i0 - 1 > wbase + 7);
+    const int nb = i0 >= 8 ? ((i0 - 7) & ~1) : 0;                            // 4-byte aligned window holding i0-2 and i0-1
+    const FqPos *pp = prec + (size_t)a * (size_t)A.pstride + nb;
+    const uintptr_t pa = (uintptr_t)fq_pick2p((uint64_t)(uintptr_t)(pool + slot), (uint64_t)(uintptr_t)pp, popping ? 1 : 0);
+    FqU4 vA;
+    vA.x = vA.y = vA.z = vA.w = 0;
+    if (popping || reload) vA = *(const FqU4 *)pa;
     FqBlkRaw bk, bl;
-    FqU4 vS;
-    vS.x = vS.y = vS.z = vS.w = 0;
-    int cbase = 4;
-    const int ii0 = (i0 - 1) - seed_off;                                    // seed position of the child
-    const bool seeded = use_seed && ii0 > 0;
     if (!popping) {
       const FqOccBlk *blk = (const FqOccBlk *)fq_pick2p((uint64_t)(uintptr_t)blk0, (uint64_t)(uintptr_t)blk1, a);   // strand a searches the other strand's BWT (bwtgap.c:148)
       const uint32_t primary = fq_pick2(primary0, primary1, a);
       bk = fq_blk_load(blk, primary, ck_ - 1);
       bl = fq_blk_load(blk, primary, cl_);
-      const int c = (int)fq_nt4_fast(row[len - i0]);                         // seq[a][i0-1]
-      cbase = (a && c < 4) ? 3 - c : c;
-      if (!tail && seeded) {
-        const FqWRec *sw = A.srec + ((size_t)w * 2 + (size_t)a) * (FQ_SEED_MAX + 1);
-        vS = *(const FqU4 *)(sw + (ii0 - 1));                                // seed_width[ii0-1], seed_width[ii0]
-      }
     } else {
       bk = fq_blk_none(); bl = fq_blk_none();
     }
@@ -556,6 +620,7 @@ struct FqGapLane {
       FQ_PROF(3);
       if (vA.w == FQ_NIL) bucket_clr(b); else store.head_set(b, vA.w);
       spare = slot;
+      wbase = 0x7fff;                                                        // the next entry sits anywhere: drop the window
       --n_live; ++c_pops;
       if (!nonstop && b > best_score + o.s_mm) { finish(); return; }         // bwtgap.c:147
       const int n_mm = (int)(vA.z >> 12) & 31, n_gapo = (int)(vA.z >> 17) & 3, n_gape = (int)(vA.z >> 19) & 15;
@@ -567,13 +632,18 @@ struct FqGapLane {
       return;
     }
     // ---- a lane with a current entry ------------------------------------------------------------------------------------------
-    FqWRec w1, w2;                                                            // width[i0-1], width[i0-2]
-    if (i0 >= 2) { w2.w = vA.x; w2.bid = vA.y; w1.w = vA.z; w1.bid = vA.w; } else { w1.w = vA.x; w1.bid = vA.y; w2.w = w2.bid = 0; }
+    if (reload) { pw0 = vA.x; pw1 = vA.y; pw2 = vA.z; pw3 = vA.w; wbase = nb; }
+    const int o1 = (i0 - 1) - wbase, o2 = need_lo - wbase;
+    const uint32_t rec1 = (fq_sel4v(pw0, pw1, pw2, pw3, o1 >> 1) >> ((o1 & 1) << 4)) & 0xffffu;   // position i0-1
+    const uint32_t rec2 = (fq_sel4v(pw0, pw1, pw2, pw3, o2 >> 1) >> ((o2 & 1) << 4)) & 0xffffu;   // position i0-2 (if any)
+    const int cbase = (int)(rec1 >> 12) & 7;                                 // seq[a][i0-1]
+    const int b0 = (int)(rec1 & 31u), b1 = (int)(rec2 & 31u);                // width[i0-1].bid, width[i0-2].bid
+    const bool seeded = use_seed && (i0 - 1) - seed_off > 0;
     const int st = (int)(cpk >> 10) & 3, n_mm = (int)(cpk >> 12) & 31, n_gapo = (int)(cpk >> 17) & 3, n_gape = (int)(cpk >> 19) & 15;
     const int diffs = n_mm + n_gapo + (gape_mode ? n_gape : 0);
     const int m = max_diff - diffs;
     if (!tail) {
-      if (m < (int)w1.bid) { FQ_PROF(6); has_cur = false; return; }        // bwtgap.c:155
+      if (m < b0) { FQ_PROF(6); has_cur = false; return; }        // bwtgap.c:155
       if (m == 0 && (st == FQ_ST_M || gape_mode || n_gape == o.max_gape)) { tail = true; FQ_PROF(7); }   // no difference left: exact tail
     }
     uint32_t ok4[4], ol4[4];
@@ -600,14 +670,13 @@ struct FqGapLane {
     const int last_diff = (int)(cpk >> 23);
     bool allow_diff = true, allow_M = true;
     if (i > 0) {
-      const int b1 = (int)w2.bid, b0 = (int)w1.bid;   // width[i-1], width[i]
-      if (b1 > m - 1) allow_diff = false;
-      else if (b1 == m - 1 && b0 == m - 1 && w2.w == w1.w) allow_M = false;
+      if (b1 > m - 1) allow_diff = false;             // width[i-1].bid, width[i].bid of the child position i (bwtgap.c:200-210)
+      else if (b1 == m - 1 && b0 == m - 1 && ((rec1 >> 5) & 1u)) allow_M = false;
       if (seeded) {                                   // ii = i - seed_off > 0
         const int m_seed = o.max_seed_diff - diffs;
-        const int s1 = (int)vS.y, s0 = (int)vS.w;     // seed_width[ii-1].bid, seed_width[ii].bid
+        const int s1 = (int)(rec2 >> 6) & 31, s0 = (int)(rec1 >> 6) & 31;   // seed_width[ii-1].bid, seed_width[ii].bid
         if (s1 > m_seed - 1) allow_diff = false;
-        else if (s1 == m_seed - 1 && s0 == m_seed - 1 && vS.x == vS.z) allow_M = false;
+        else if (s1 == m_seed - 1 && s0 == m_seed - 1 && ((rec1 >> 11) & 1u)) allow_M = false;
       }
     }
     if (bump + 10u > A.tier.pool_cap) { status |= FQ_SF_POOL_OVERFLOW; finish(); return; }   // room for every child of this entry
@@ -616,6 +685,7 @@ struct FqGapLane {
       int tmp;
       if (o.mode & FQ_MODE_LOGGAP) { uint32_t vv = (uint32_t)(n_gape + n_gapo); int lg = 0; while (vv >>= 1) ++lg; tmp = lg / 2 + 1; }
       else tmp = n_gapo + n_gape;
+#ifndef FQ_ABL_GAP
       if (i >= o.indel_end_skip + tmp && len - i >= o.indel_end_skip + tmp) {   // ---- gap children (bwtgap.c:212-243)
         const bool is_open = st == FQ_ST_M;
         const bool can = is_open ? n_gapo < o.max_gapo : n_gape < o.max_gape;
@@ -623,11 +693,13 @@ struct FqGapLane {
         const bool has_D = can && st != FQ_ST_I && (is_open || n_gape + n_gapo < max_diff || (l - k + 1) < (uint32_t)o.max_del_occ);
         const uint32_t cnt = (has_I ? 1u : 0u) + (has_D ? (uint32_t)FQ_POPC32(vmask) : 0u);
         if (cnt) {
+          FQ_PROF(14);
           n_live += (int32_t)cnt;
           const int go2 = n_gapo + (is_open ? 1 : 0), ge2 = n_gape + (is_open ? 0 : 1);
           const int score = cscore + (is_open ? o.s_gapo : o.s_gape);
           uint32_t prev;
           if (group_open(score, n_mm + go2 + (gape_mode ? ge2 : 0), prev)) {
+            FQ_PROF(15);
             const uint32_t common = (cpk & ((1u << 9) | (31u << 12))) | (uint32_t)go2 << 17 | (uint32_t)ge2 << 19;
             const uint32_t pkI = common | (uint32_t)i | (uint32_t)FQ_ST_I << 10 | (uint32_t)i << 23;
             const uint32_t pkD = common | (uint32_t)(i + 1) | (uint32_t)FQ_ST_D << 10 | (uint32_t)(i + 1) << 23;
@@ -642,13 +714,17 @@ struct FqGapLane {
           }
         }
       }
+#endif
+#ifndef FQ_ABL_MM
       if (allow_M) {   // ---- mismatch children, bases (c+1)&3, (c+2)&3, (c+3)&3 and, for an ambiguous read base, (c+4)&3 (bwtgap.c:245-252)
         const uint32_t mmask = cbase < 4 ? (vmask & ~(1u << cbase)) : vmask;
         if (mmask) {
+          FQ_PROF(16);
           n_live += (int32_t)FQ_POPC32(mmask);
           const int score = cscore + o.s_mm;
           uint32_t prev;
           if (group_open(score, diffs + 1, prev)) {
+            FQ_PROF(17);
             const uint32_t pkM = ((cpk & ((1u << 9) | (31u << 12) | (3u << 17) | (15u << 19))) + (1u << 12)) | (uint32_t)i | (uint32_t)i << 23;
 #pragma unroll
             for (int j = 1; j <= 4; ++j) {
@@ -661,6 +737,7 @@ struct FqGapLane {
           }
         }
       }
+#endif
     }
     // ---- the match child stays in registers (pushed last by the reference, hence popped next: bwtgap.c:246-258) ----
     if (!mvalid) { has_cur = false; return; }
@@ -696,30 +773,37 @@ struct FqGapLane {
         if (add) { x = cl_ - ck_ + 1; ld = (int)(cpk >> 23); }
       }
     }
-    // gap_shadow (bwtgap.c:81-91) over width[0..last_diff) of the hit's strand, one hit at a time, all lanes sweeping
+    // gap_shadow (bwtgap.c:81-91) over width[0..last_diff) of the hit's strand, one hit at a time, all lanes sweeping; the
+    // packed position records (bid, and the "same width as the previous position" bit up to position last_diff) follow
     uint64_t sm = FQ_BALLOT(add && ld > 0);
     while (sm) {
       const int L = FQ_CTZ64(sm);
       sm &= sm - 1;
-      const FqWRec *mine = wrec + (size_t)a * (size_t)A.wstride;
-      const uint64_t p64 = (uint64_t)(uintptr_t)mine;
-      FqWRec *const ww = (FqWRec *)(uintptr_t)((uint64_t)FQ_READLANE32((uint32_t)p64, L) | (uint64_t)FQ_READLANE32((uint32_t)(p64 >> 32), L) << 32);
+      const uint64_t p64 = (uint64_t)(uintptr_t)(A.wfull + ((size_t)w * 2 + (size_t)a) * (size_t)A.wstride);
+      const uint64_t q64 = (uint64_t)(uintptr_t)(prec + (size_t)a * (size_t)A.pstride);
+      uint32_t *const ww = (uint32_t *)(uintptr_t)((uint64_t)FQ_READLANE32((uint32_t)p64, L) | (uint64_t)FQ_READLANE32((uint32_t)(p64 >> 32), L) << 32);
+      FqPos *const pr = (FqPos *)(uintptr_t)((uint64_t)FQ_READLANE32((uint32_t)q64, L) | (uint64_t)FQ_READLANE32((uint32_t)(q64 >> 32), L) << 32);
       const int n = (int)FQ_READLANE32((uint32_t)ld, L);
       const uint32_t xx = FQ_READLANE32(x, L);
-      uint32_t jj = 0;
-      for (int base = 0; base < n; base += FQ_WAVE_SIZE) {
+      uint32_t jj = 0, carry_w = 0;
+      for (int base = 0; base <= n; base += FQ_WAVE_SIZE) {
         const int t = base + FQ_LANE_ID();
-        const bool in = t < n;
-        const uint32_t cur = in ? ww[t].w : 0u;
-        const bool eq = in && cur == xx;
+        const bool in = t < n, in2 = t <= n;                                   // position n itself keeps its width, but not its neighbour's
+        uint32_t nw = in2 ? ww[t] : 0u;
+        const bool gt = in && nw > xx, eq = in && nw == xx;
         const uint64_t em = FQ_BALLOT(eq);
-        if (in && cur > xx) ww[t].w = cur - xx;
-        else if (eq) {
-          const uint32_t rank = (uint32_t)FQ_POPC64(em & (((uint64_t)1 << FQ_LANE_ID()) - 1));
-          FqWRec nr; nr.bid = 1; nr.w = seq_len - (jj + rank + 1);
-          ww[t] = nr;
-        }
+        if (gt) nw -= xx;
+        else if (eq) nw = seq_len - (jj + (uint32_t)FQ_POPC64(em & (((uint64_t)1 << FQ_LANE_ID()) - 1)) + 1);
+        if (gt || eq) ww[t] = nw;
         jj += (uint32_t)FQ_POPC64(em);
+        uint32_t wleft = FQ_SHFL_UP1(nw);                                      // new width of position t-1
+        if (FQ_LANE_ID() == 0) wleft = carry_w;
+        carry_w = FQ_READLANE32(nw, FQ_WAVE_SIZE - 1);
+        if (in2) {
+          uint32_t rec = (uint32_t)pr[t] & ~0x20u;
+          if (eq) rec = (rec & ~0x1fu) | 1u;                                   // bid = 1 (bwtgap.c:87)
+          pr[t] = (FqPos)(rec | ((t >= 1 && wleft == nw) ? 1u << 5 : 0u));
+        }
       }
     }
     if (hit_pending) {
@@ -743,12 +827,17 @@ struct FqGapLane {
 template <class St, class Fetch>
 FQ_HD void fq_gap_lanes(const FqGapArgs &A, const St &store0, Fetch fetch, int lane_slot) {
   FqGapLane<St> L(A, store0, lane_slot);
-  uint32_t trips = 0;
+  uint32_t trips = 0, lane_trips = 0;
   for (;; ++trips) {
     // (re)fill idle lanes, in groups: one queue reservation per group
     const bool want = !L.active && !L.done;
     const uint64_t wm = FQ_BALLOT(want), am = FQ_BALLOT(L.active);
-    if (wm == 0 && am == 0) { FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXTRIPS], trips); break; }
+    if (wm == 0 && am == 0) {
+      FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXTRIPS], trips);
+      if (FQ_LANE_ID() == 0) FQ_ATOMIC_ADD64(&A.counters[FQ_C_SUMTRIPS], trips);
+      FQ_ATOMIC_ADD64(&A.counters[FQ_C_LANETRIPS], lane_trips);
+      break;
+    }
     if (wm != 0 && (FQ_POPC64(wm) >= A.refill_min || am == 0)) {
       const int leader = FQ_CTZ64(wm);
       uint32_t base_l = 0;
@@ -759,8 +848,10 @@ FQ_HD void fq_gap_lanes(const FqGapArgs &A, const St &store0, Fetch fetch, int l
         if (wq >= (uint32_t)A.n_work) L.done = true; else L.begin((int)wq);
       }
     }
-    if (L.active) L.step();
+    if (L.active) { ++lane_trips; L.step(); }
+#ifndef FQ_ABL_HITS
     if (FQ_BALLOT(L.hit_pending) != 0) L.collect_hits();
+#endif
   }
 }
 

@@ -166,6 +166,7 @@ extern "C" int64_t fq_stage_dump_last(fq_ctx_t *c, char *buf, int64_t cap) {
   const fq_read_batch_t *hb = fq_ctx_host_batch(c);
   const uint8_t *filt; const int32_t *ltrim;
   fq_ctx_all_reads(c, &filt, &ltrim);
+  if (S->n_pairs > 0 && (!filt || !ltrim)) return FQ_EINVAL;   // per-read arrays of the whole batch are only fetched in debug mode
   const int n = S->n_pairs;
   Out o;
   std::vector<int> surv_of(n, -1);

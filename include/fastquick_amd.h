@@ -194,6 +194,8 @@ typedef struct {
   uint64_t max_pops_per_read, reads_over_4k_pops;   /* tail of the search-length distribution */
   uint64_t max_wave_trips;      /* loop iterations of the busiest wavefront of the gap kernel (per launch, max) */
   double host_ms_serial, host_ms_pair, host_ms_total, wall_ms_total;
+  uint64_t wave_trips;          /* loop iterations summed over the gap kernel's wavefronts */
+  uint64_t lane_trips;          /* ... summed over lanes that held a read in that iteration (wave_trips x 64 = all slots) */
 } fq_stats_t;
 void fq_stats_get(const fq_ctx_t *c, fq_stats_t *out);
 void fq_stats_reset(fq_ctx_t *c);

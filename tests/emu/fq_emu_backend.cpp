@@ -41,7 +41,11 @@ int launch_compact(const uint8_t *f, int n, int32_t *read_list, int32_t *sidx, i
   counts[0] = ns; counts[1] = np;
   return 0;
 }
-int launch_width(const FqWidthArgs &a) { for (int t = 0; t < a.n_work * 4; ++t) fq_width_thread(a, t); return 0; }
+int launch_surv_gather(const int32_t *pair_list, int n_surv, int n_pairs, const int32_t *len_trim, const uint8_t *filtered, const int32_t *sidx, FqSurvInfo *out) {
+  for (int t = 0; t < 2 * n_surv; ++t) fq_surv_gather_thread(pair_list, n_pairs, len_trim, filtered, sidx, out, t);
+  return 0;
+}
+int launch_width(const FqWidthArgs &a) { uint8_t seed_bits[FQ_SEED_MAX]; for (int t = 0; t < a.n_work * 2; ++t) fq_width_thread(a, t, seed_bits, 1); return 0; }
 struct SeqFetch { int *next; int n; uint32_t operator()(uint32_t k) const { const uint32_t at = (uint32_t)*next; *next += (int)k; return at; } };
 int gap_lane_slots(const FqGapArgs &a) { return a.n_work > 0 ? 1 : 0; }
 int launch_gap(const FqGapArgs &a_in) {
