@@ -17,6 +17,11 @@ import os
 import sys
 import time
 
+# One hardware queue per HIP stream: the library gives every alignment context its own stream, and the runtime's default of
+# four hardware queues would make eight or sixteen streams share queues (a 15 ms persistent search kernel then blocks another
+# stream's filter kernel).  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -33,7 +38,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--pairs", type=int, default=16 * 262144,
                     help="pairs per step: one call carrying this many pairs = pairs/262144 reference batches (READ_BUFFER_SIZE)")
-    ap.add_argument("--ctxs", type=int, default=8,
+    ap.add_argument("--ctxs", type=int, default=16,
                     help="alignment contexts (independent FASTQ streams) driven concurrently, one host thread + HIP stream each")
     ap.add_argument("--markers", type=int, default=10000)
     ap.add_argument("--mix", choices=("wgs", "ontarget"), default="wgs",
@@ -151,7 +156,17 @@ def main() -> None:
             for k, v in s.items():
                 agg[k] = [a + b for a, b in zip(agg[k], v)] if isinstance(v, list) else agg[k] + v
     kms = agg["kernel_ms"]
-    dom = max(range(len(K_NAMES)), key=lambda k: kms[k])
+    # Dominant kernel = the one that consumes the most of the device: summed device time x the share of the device's resident
+    # lanes one launch can occupy.  (Several streams run concurrently; a search launch over the few thousand on-target reads of
+    # a WGS-like batch occupies a few percent of the wavefront slots for as long as its longest search lasts, while the filter
+    # kernel fills the whole device.)
+    n_launch = [max(1, int(x)) for x in agg["kernel_launches"]]
+    items = {"prep": 2.0 * args.pairs * args.steps / n_launch[0], "width": 2.0 * agg["reads_searched"] / n_launch[1],
+             "gap": float(agg["reads_searched"]) / n_launch[2], "sa": float(agg["sa_rows"]) / n_launch[3],
+             "sw": float(agg["sw_tasks"]) / n_launch[4], "refine": float(agg["refine_tasks"]) / n_launch[5]}
+    capacity = {"prep": 524288.0, "width": 524288.0, "gap": 262144.0, "sa": 524288.0, "sw": 256.0, "refine": 16384.0}   # resident work items
+    share = {k: min(1.0, items[k] / capacity[k]) for k in items}
+    dom = max(range(len(K_NAMES)), key=lambda k: kms[k] * share[K_NAMES[k]])
     KSRC = {"prep": K_PREP_KERNEL, "gap": K_GAP_KERNEL}   # stage -> the kernel whose own timestamps price it
     seq_bytes = float(sum(int(b.lens.sum()) for b in batches)) / n_ctx * args.steps
     if K_NAMES[dom] == "prep":
@@ -188,7 +203,23 @@ def main() -> None:
         pass
     roofline = {"bound": "hbm", "kernel": "fq_" + K_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
-                "alg_bytes_per_launch": round(alg_bytes / launches, 1), "model": model}
+                "alg_bytes_per_launch": round(alg_bytes / launches, 1), "model": model,
+                "aggregate_achieved": round(alg_bytes / elapsed / 1e9, 3),   # all concurrent launches together, over the wall time
+                "dominance": "summed device ms x share of resident-lane capacity a launch occupies: " +
+                             ", ".join("%s %.2f" % (K_NAMES[k], kms[k] * share[K_NAMES[k]] / args.steps) for k in range(len(K_NAMES)))}
+    # the same kernel alone on the device (one stream, after the timed region): launch duration without other streams' kernels
+    if n_ctx > 1:
+        ctxs[0].reset_stats()
+        for _ in range(3):
+            ctxs[0].align_resident()
+        s1 = ctxs[0].stats()
+        nl1 = max(1, int(s1["kernel_launches"][dsrc]))
+        ms1 = s1["kernel_ms"][dsrc] / nl1
+        byts1 = (64.0 * s1["filter_probes"] + 101.0 * 2 * args.pairs * 3) if K_NAMES[dom] == "prep" else 48.0 * (s1["gap_occ_touches"] if K_NAMES[dom] == "gap" else s1["occ_block_touches"])
+        if ms1 > 0:
+            roofline["solo_avg_launch_ms"] = round(ms1, 4)
+            roofline["solo_achieved"] = round(byts1 / nl1 / (ms1 * 1e-3) / 1e9, 3)
+            roofline["solo_frac"] = round(byts1 / nl1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
 
     total_pairs = args.pairs * args.steps * world
     value = total_pairs / elapsed

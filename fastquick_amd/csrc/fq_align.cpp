@@ -474,10 +474,16 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   {
     const int Lpad = (max_len_all + 1 + 7) & ~7;                  // exact widths per strand; rows are written 8 positions at a time
     const int Ppad = (max_len_all + 1 + FQ_POS_PAD + 7) & ~7;     // position records per strand (16-byte aligned rows)
-    const FqGapTier tiers[3] = {{4096u, 32u, 0}, {65535u, 512u, 0}, {(uint32_t)o.max_entries + 64u, 8192u, 1}};
+    // tier 0: one read per lane, bounded stack and pop count; what it gives up on is searched again by one wavefront per read
+    // (tier 1 with push-time pruning, tier 2 exactly as the reference: no pruning, n_entries exact).  The wavefront kernel never
+    // reuses pool slots, so its pools hold every push of a search, not just the live entries.
+    const uint32_t long_pops = getenv("FQ_GAP_LONG_POPS") ? (uint32_t)atoi(getenv("FQ_GAP_LONG_POPS")) : 1024u;
+    const uint32_t exact_pool = (uint32_t)std::min<uint64_t>(4ull * (uint64_t)o.max_entries + 4096ull, 0x7fffffffull);
+    const int long_always = getenv("FQ_GAP_LONG_ALWAYS") ? atoi(getenv("FQ_GAP_LONG_ALWAYS")) : 0;   // test hook
+    const FqGapTier tiers[3] = {{4096u, 32u, 0, 0, long_pops, long_always}, {262144u, 512u, 0, 1, 0u, 0}, {exact_pool, 8192u, 1, 1, 0u, 0}};
     // scores that can occur for the longest read of this call (children may exceed max_diff by one difference)
     const int nb_need = (c->maxdiff_lut[max_len_all] + 1) * o.s_mm + o.max_gapo * o.s_gapo + o.max_gape * o.s_gape + 1;
-    const size_t chunk_reads[3] = {(size_t)8 << 20, (size_t)1 << 20, 64};   // pools are per persistent lane; only per-read outputs scale with the chunk
+    const size_t chunk_reads[3] = {(size_t)8 << 20, (size_t)1 << 20, 4096};   // pools are per lane / per wavefront; only per-read outputs scale with the chunk
     vector<int32_t> work(n_search), next_work;
     for (int s = 0; s < n_search; ++s) work[s] = s;
     vector<uint32_t> h_status, h_naln;

@@ -99,11 +99,15 @@ struct FqGapWork {
 #define FQ_SF_POOL_OVERFLOW 1u   // entry pool exhausted -> rerun in a larger tier
 #define FQ_SF_ALN_OVERFLOW 2u    // more hits than the aln slot holds -> rerun in a larger tier
 #define FQ_SF_ENTRY_LIMIT 4u     // conservative entry count crossed max_entries -> exact tier decides
+#define FQ_SF_LONG 8u            // lane-per-read kernel: more pops than tier.long_pops -> searched again by a whole wavefront
 
 struct FqGapTier {       // one launch configuration of the gap-search kernel
   uint32_t pool_cap;     // entries per read
   uint32_t aln_cap;      // hits per read
   int32_t exact;         // 1: no push-time pruning, n_entries tracked exactly (honours max_entries as the reference)
+  int32_t coop;          // 1: one read per wavefront (fq_gap_coop_wave), 0: one read per lane (fq_gap_lanes)
+  uint32_t long_pops;    // lane kernel: give up on a read after this many pops once the work queue is empty (0: never)
+  int32_t long_always;   // test hook: give up after long_pops pops whatever the state of the queue
 };
 
 // SW / refine task descriptors

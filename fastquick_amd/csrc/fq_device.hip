@@ -119,6 +119,11 @@ __global__ void __launch_bounds__(64) k_gap_persist(FqGapArgs a) {   // any pool
   FqGapStoreGlobal st = {nullptr};
   fq_gap_lanes(a, st, FqQueueFetch{a.queue, a.n_work}, (int)(blockIdx.x * 64 + threadIdx.x));
 }
+// one read per wavefront (long searches): run table of the read's score buckets in LDS
+__global__ void __launch_bounds__(64) k_gap_coop(FqGapArgs a) {
+  __shared__ uint32_t heads[2 * FQ_MAX_BUCKETS];
+  fq_gap_coop_wave(a, heads, FqQueueFetch{a.queue, a.n_work}, (int)blockIdx.x);
+}
 __global__ void __launch_bounds__(256) k_sa(FqSaArgs a) {
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q < a.n_rows) fq_sa_thread(a, q);
@@ -432,6 +437,7 @@ int launch_width(const FqWidthArgs &a) {
 }
 int gap_lane_slots(const FqGapArgs &a) {
   if (a.n_work <= 0) return 0;
+  if (a.tier.coop) return (int)std::min<unsigned>((unsigned)a.n_work, a.tier.exact ? 64u : 1024u);   // wavefronts, one pool each
   static const int env_waves = getenv("FQ_GAP_WAVES_PER_CU") ? atoi(getenv("FQ_GAP_WAVES_PER_CU")) : 0;
   const unsigned need = nblk((uint64_t)a.n_work, 64);
   unsigned per_cu = 8;
@@ -445,17 +451,20 @@ int gap_lane_slots(const FqGapArgs &a) {
 int launch_gap(const FqGapArgs &a_in) {
   if (a_in.n_work <= 0) return 0;
   FqGapArgs a = a_in;
-  static const int env_waves = getenv("FQ_GAP_WAVES_PER_CU") ? atoi(getenv("FQ_GAP_WAVES_PER_CU")) : 0;
   static const int env_refill = getenv("FQ_GAP_REFILL_MIN") ? atoi(getenv("FQ_GAP_REFILL_MIN")) : 0;
   a.refill_min = env_refill > 0 ? env_refill : FQ_REFILL_MIN;
   FQ_HIP(hipMemsetAsync(a.queue, 0, 4, g_stream));
-  // LDS-resident bucket heads when slot indices fit 16 bits
-  const size_t lds = (size_t)64 * (size_t)a.o.n_buckets * 2;
-  const unsigned grid = (unsigned)gap_lane_slots(a) / 64u;
   hipEvent_t e0, e1;
   kernel_events(7, &e0, &e1);   // FQ_K_GAP_KERNEL
-  if (a.tier.pool_cap <= 65535u) hipExtLaunchKernelGGL(k_gap_persist_lds, dim3(grid), dim3(64), lds, g_stream, e0, e1, 0, a);
-  else hipExtLaunchKernelGGL(k_gap_persist, dim3(grid), dim3(64), 0, g_stream, e0, e1, 0, a);
+  if (a.tier.coop) {
+    hipExtLaunchKernelGGL(k_gap_coop, dim3((unsigned)gap_lane_slots(a)), dim3(64), 0, g_stream, e0, e1, 0, a);
+  } else {
+    // LDS-resident bucket heads when slot indices fit 16 bits
+    const size_t lds = (size_t)64 * (size_t)a.o.n_buckets * 2;
+    const unsigned grid = (unsigned)gap_lane_slots(a) / 64u;
+    if (a.tier.pool_cap <= 65535u) hipExtLaunchKernelGGL(k_gap_persist_lds, dim3(grid), dim3(64), lds, g_stream, e0, e1, 0, a);
+    else hipExtLaunchKernelGGL(k_gap_persist, dim3(grid), dim3(64), 0, g_stream, e0, e1, 0, a);
+  }
   FQ_HIP(hipGetLastError());
   return 0;
 }

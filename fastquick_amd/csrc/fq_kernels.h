@@ -17,7 +17,9 @@
 #define FQ_ATOMIC_ADD64(p, v) atomicAdd((unsigned long long *)(p), (unsigned long long)(v))
 #define FQ_ATOMIC_MAX64(p, v) atomicMax((unsigned long long *)(p), (unsigned long long)(v))
 #define FQ_ATOMIC_MAX32(p, v) atomicMax((int *)(p), (int)(v))
+#define FQ_LOAD_RELAXED(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
 #else
+#define FQ_LOAD_RELAXED(p) (*(p))
 #define FQ_ATOMIC_MAX32(p, v) (*(p) = *(p) > (int32_t)(v) ? *(p) : (int32_t)(v))
 #define FQ_ATOMIC_MAX64(p, v) (*(p) = *(p) > (uint64_t)(v) ? *(p) : (uint64_t)(v))
 #define FQ_POPC64(x) __builtin_popcountll(x)
@@ -623,6 +625,11 @@ struct FqGapLane {
       wbase = 0x7fff;                                                        // the next entry sits anywhere: drop the window
       --n_live; ++c_pops;
       if (!nonstop && b > best_score + o.s_mm) { finish(); return; }         // bwtgap.c:147
+      // A long search is handed over to the wavefront-per-read kernel, but only once the work queue has run dry: before that a
+      // busy lane costs nothing, afterwards the whole launch waits for it.
+      if (A.tier.long_pops && c_pops > A.tier.long_pops && (A.tier.long_always || ((c_pops & 63u) == 0 && FQ_LOAD_RELAXED(A.queue) >= (uint32_t)A.n_work))) {
+        status |= FQ_SF_LONG; finish(); return;
+      }
       const int n_mm = (int)(vA.z >> 12) & 31, n_gapo = (int)(vA.z >> 17) & 3, n_gape = (int)(vA.z >> 19) & 15;
       const int m = max_diff - (n_mm + n_gapo + (gape_mode ? n_gape : 0));
       if (m < 0) { FQ_PROF(4); return; }
@@ -855,6 +862,423 @@ FQ_HD void fq_gap_lanes(const FqGapArgs &A, const St &store0, Fetch fetch, int l
   }
 }
 
+
+// ---- the same search, one read per wavefront ------------------------------------------------------------------------------
+// A search that pops tens of thousands of entries keeps one lane of the kernel above busy for that many dependent round
+// trips, long after the rest of its launch has drained.  Such reads (FQ_SF_LONG from the lane kernel) are searched again
+// here with the lanes of a wavefront working on ONE read.
+//
+// What makes that exact: all entries popped while bucket b is the lowest non-empty one were pushed before b was first
+// popped (children score strictly more than their parent, except the exact-match child, which is popped immediately after
+// its parent).  So the reference's pop sequence inside bucket b is: top entry, then its whole exact-match chain, then the
+// next entry and its chain, ...  The chains of different entries do not see each other -- except through a completed
+// alignment, which moves best_score / max_diff and lets gap_shadow edit the width array.  A round therefore gives the top
+// T <= 64 entries of bucket b to T lanes, runs every chain to its end twice (pass 1 counts the children each chain sends to
+// each higher bucket and notices alignments, pass 2 writes them), and commits only lanes 0..j*, j* being the first lane
+// whose chain completed an alignment; the entries of the lanes behind it stay on the stack and are redone after the
+// alignment has been recorded.  Children are appended per bucket in lane order, each lane's in step order: exactly the
+// order in which the reference pushes them.  A bucket is a stack of runs (contiguous arrays in the read's pool, the header
+// slot in front of each run links to the run below); it only grows while lower buckets are being worked on and only
+// shrinks afterwards, so runs are never appended to once popping has begun.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FQ_SHFL_UPN(x, d) ((uint32_t)__shfl_up((int)(x), (d)))
+#define FQ_SHFL_XORN(x, d) ((uint32_t)__shfl_xor((int)(x), (d)))
+#define FQ_WAVE_FENCE() __threadfence_block()
+#else
+#define FQ_SHFL_UPN(x, d) ((uint32_t)(x))
+#define FQ_SHFL_XORN(x, d) ((uint32_t)(x))
+#define FQ_WAVE_FENCE() ((void)0)
+#endif
+FQ_HD uint32_t fq_wave_sum(uint32_t x) {
+  for (int d = 1; d < FQ_WAVE_SIZE; d <<= 1) x += FQ_SHFL_XORN(x, d);
+  return x;
+}
+// inclusive prefix sum over the lanes of the wavefront
+FQ_HD uint32_t fq_wave_incl_scan(uint32_t x) {
+  for (int d = 1; d < FQ_WAVE_SIZE; d <<= 1) { const uint32_t y = FQ_SHFL_UPN(x, d); if (FQ_LANE_ID() >= d) x += y; }
+  return x;
+}
+
+struct FqGapCoop {
+  const FqGapArgs &A;
+  FqKOpts o;
+  bool gape_mode, nonstop, exact;
+  uint32_t seq_len, L2_0, L2_1, L2_2, L2_3;
+  const FqOccBlk *blk0, *blk1;
+  uint32_t primary0, primary1;
+  uint32_t *heads;       // LDS: [bucket] first entry of the top run (0 = empty), [FQ_MAX_BUCKETS + bucket] entries left in it
+  FqEntry *pool;
+  // per-read state, identical in every lane
+  int w, len, max_diff_opt, seed_off;
+  bool use_seed;
+  FqPos *prec;
+  uint32_t m0, m1, m2, m3, bump, status, n_aln;
+  int32_t n_live;
+  int best_score, max_diff, best_cnt;
+  uint32_t c_pops, c_pushes, c_touch;
+  // per-lane chain state
+  bool on, hit, tail, limit_hit;
+  uint32_t ck_, cl_, cpk;
+  uint32_t pw0, pw1, pw2, pw3;
+  int wbase;
+  uint32_t cnt0, cnt1, cnt2;          // children per slot: counted in pass 1, write cursor in pass 2
+  uint32_t live_add, ch_pops, ch_pushes, ch_touch;
+  int cur_b;                          // bucket of this round
+  int slot_open, slot_ext, slot_mm;   // which of the (at most three) target runs a class of children goes to
+  int32_t live_run;                   // sequential rounds only: stack->n_entries as the reference sees it
+
+  FQ_HD FqGapCoop(const FqGapArgs &A_, uint32_t *heads_, int wave_slot) : A(A_), o(A_.o), heads(heads_) {
+    gape_mode = (o.mode & FQ_MODE_GAPE) != 0; nonstop = (o.mode & FQ_MODE_NONSTOP) != 0; exact = A_.tier.exact != 0;
+    const FqFM &f0 = A_.ix.fm[0], &f1 = A_.ix.fm[1];
+    seq_len = f0.seq_len; L2_0 = f0.L2[0]; L2_1 = f0.L2[1]; L2_2 = f0.L2[2]; L2_3 = f0.L2[3];
+    blk0 = f0.blk; blk1 = f1.blk; primary0 = f0.primary; primary1 = f1.primary;
+    pool = A_.pool + (size_t)wave_slot * (size_t)A_.tier.pool_cap;
+    w = len = max_diff_opt = seed_off = 0; use_seed = false; prec = A_.prec;
+    m0 = m1 = m2 = m3 = bump = status = n_aln = 0; n_live = 0; best_score = max_diff = best_cnt = 0;
+    c_pops = c_pushes = c_touch = 0;
+    on = hit = tail = limit_hit = false; ck_ = cl_ = cpk = 0; pw0 = pw1 = pw2 = pw3 = 0; wbase = 0x7fff;
+    cnt0 = cnt1 = cnt2 = 0; live_add = ch_pops = ch_pushes = ch_touch = 0; cur_b = 0;
+    slot_open = 0; slot_ext = 1; slot_mm = 2; live_run = 0;
+    // classes of children whose scores coincide share a run, so that their relative order is kept
+    if (o.s_gape == o.s_gapo) slot_ext = slot_open;
+    if (o.s_mm == o.s_gapo) slot_mm = slot_open; else if (o.s_mm == o.s_gape) slot_mm = slot_ext;
+  }
+  FQ_HD void bucket_set(int b) { const uint32_t bit = 1u << (b & 31); const int q = b >> 5; if (q == 0) m0 |= bit; else if (q == 1) m1 |= bit; else if (q == 2) m2 |= bit; else m3 |= bit; }
+  FQ_HD void bucket_clr(int b) { const uint32_t bit = ~(1u << (b & 31)); const int q = b >> 5; if (q == 0) m0 &= bit; else if (q == 1) m1 &= bit; else if (q == 2) m2 &= bit; else m3 &= bit; }
+  FQ_HD void slot_add(int s, uint32_t n) { cnt0 += s == 0 ? n : 0u; cnt1 += s == 1 ? n : 0u; cnt2 += s == 2 ? n : 0u; }
+  FQ_HD uint32_t slot_take(int s) {   // returns the cursor of slot s and advances it
+    const uint32_t at = fq_sel4v(cnt0, cnt1, cnt2, 0u, s);   // (a ?: chain over members would pin the whole state in scratch memory)
+    slot_add(s, 1u);
+    return at;
+  }
+  // children of one group: counted, and in pass 2 written behind the lane's cursor of the group's run
+  FQ_HD bool group_kept(int score, int diffs) const {
+    if (exact) return true;
+    if (n_aln > 0 && !nonstop && score > best_score + o.s_mm) return false;
+    return max_diff - diffs >= 0;
+  }
+  FQ_HD void child(bool write, int slot, uint32_t k, uint32_t l, uint32_t pk) {
+    if (write) { FqEntry e; e.k = k; e.l = l; e.pk = pk; e.next = 0; pool[slot_take(slot)] = e; }
+    else slot_add(slot, 1u);
+    ++ch_pushes;
+  }
+
+  // one step of this lane's chain (bwtgap.c:149-258 for the entry in ck_/cl_/cpk)
+  FQ_HD void chain_step(bool write, bool sequential) {
+    const int a = (int)(cpk >> 9) & 1, i0 = (int)(cpk & 511u);
+    const int need_lo = i0 >= 2 ? i0 - 2 : 0;
+    const bool reload = need_lo < wbase || i0 - 1 > wbase + 7;
+    const int nb = i0 >= 8 ? ((i0 - 7) & ~1) : 0;
+    if (reload) {
+      const FqU4 v = *(const FqU4 *)(prec + (size_t)a * (size_t)A.pstride + nb);
+      pw0 = v.x; pw1 = v.y; pw2 = v.z; pw3 = v.w; wbase = nb;
+    }
+    const FqOccBlk *blk = (const FqOccBlk *)fq_pick2p((uint64_t)(uintptr_t)blk0, (uint64_t)(uintptr_t)blk1, a);
+    const uint32_t primary = fq_pick2(primary0, primary1, a);
+    const FqBlkRaw bk = fq_blk_load(blk, primary, ck_ - 1), bl = fq_blk_load(blk, primary, cl_);
+    const int o1 = (i0 - 1) - wbase, o2 = need_lo - wbase;
+    const uint32_t rec1 = (fq_sel4v(pw0, pw1, pw2, pw3, o1 >> 1) >> ((o1 & 1) << 4)) & 0xffffu;
+    const uint32_t rec2 = (fq_sel4v(pw0, pw1, pw2, pw3, o2 >> 1) >> ((o2 & 1) << 4)) & 0xffffu;
+    const int cbase = (int)(rec1 >> 12) & 7;
+    const int b0 = (int)(rec1 & 31u), b1 = (int)(rec2 & 31u);
+    const bool seeded = use_seed && (i0 - 1) - seed_off > 0;
+    const int st = (int)(cpk >> 10) & 3, n_mm = (int)(cpk >> 12) & 31, n_gapo = (int)(cpk >> 17) & 3, n_gape = (int)(cpk >> 19) & 15;
+    const int diffs = n_mm + n_gapo + (gape_mode ? n_gape : 0);
+    const int m = max_diff - diffs;
+    if (!tail) {
+      if (m < b0) { on = false; return; }
+      if (m == 0 && (st == FQ_ST_M || gape_mode || n_gape == o.max_gape)) tail = true;
+    }
+    uint32_t ok4[4], ol4[4];
+    fq_blk_occ4(bk, ok4);
+    fq_blk_occ4(bl, ol4);
+    const uint32_t kk0 = L2_0 + ok4[0] + 1, kk1 = L2_1 + ok4[1] + 1, kk2 = L2_2 + ok4[2] + 1, kk3 = L2_3 + ok4[3] + 1;
+    const uint32_t ll0 = L2_0 + ol4[0], ll1 = L2_1 + ol4[1], ll2 = L2_2 + ol4[2], ll3 = L2_3 + ol4[3];
+    const uint32_t vmask = (kk0 <= ll0 ? 1u : 0u) | (kk1 <= ll1 ? 2u : 0u) | (kk2 <= ll2 ? 4u : 0u) | (kk3 <= ll3 ? 8u : 0u);
+    const int i = i0 - 1;
+    const bool mvalid = cbase < 4 && ((vmask >> (cbase & 3)) & 1u) != 0;
+    const uint32_t mk = fq_sel4v(kk0, kk1, kk2, kk3, cbase & 3), ml = fq_sel4v(ll0, ll1, ll2, ll3, cbase & 3);
+    const uint32_t fpk = (cpk & ~0xC00u) - 1u;
+    if (tail) {
+      if (cbase < 4) ch_touch += fq_touch2p(primary, seq_len, ck_ - 1, cl_, true);
+      if (!mvalid) { on = false; return; }
+      ck_ = mk; cl_ = ml; cpk = fpk;
+      if (i == 0) { on = false; hit = true; }
+      return;
+    }
+    ch_touch += fq_touch2p(primary, seq_len, ck_ - 1, cl_, false);
+    bool allow_diff = true, allow_M = true;
+    if (i > 0) {
+      if (b1 > m - 1) allow_diff = false;
+      else if (b1 == m - 1 && b0 == m - 1 && ((rec1 >> 5) & 1u)) allow_M = false;
+      if (seeded) {
+        const int m_seed = o.max_seed_diff - diffs;
+        const int s1 = (int)(rec2 >> 6) & 31, s0 = (int)(rec1 >> 6) & 31;
+        if (s1 > m_seed - 1) allow_diff = false;
+        else if (s1 == m_seed - 1 && s0 == m_seed - 1 && ((rec1 >> 11) & 1u)) allow_M = false;
+      }
+    }
+    const uint32_t k = ck_, l = cl_;
+    if (allow_diff) {
+      int tmp;
+      if (o.mode & FQ_MODE_LOGGAP) { uint32_t vv = (uint32_t)(n_gape + n_gapo); int lg = 0; while (vv >>= 1) ++lg; tmp = lg / 2 + 1; }
+      else tmp = n_gapo + n_gape;
+      if (i >= o.indel_end_skip + tmp && len - i >= o.indel_end_skip + tmp) {
+        const bool is_open = st == FQ_ST_M;
+        const bool can = is_open ? n_gapo < o.max_gapo : n_gape < o.max_gape;
+        const bool has_I = can && st != FQ_ST_D;
+        const bool has_D = can && st != FQ_ST_I && (is_open || n_gape + n_gapo < max_diff || (l - k + 1) < (uint32_t)o.max_del_occ);
+        const uint32_t cnt = (has_I ? 1u : 0u) + (has_D ? (uint32_t)FQ_POPC32(vmask) : 0u);
+        if (cnt) {
+          live_add += cnt;
+          const int go2 = n_gapo + (is_open ? 1 : 0), ge2 = n_gape + (is_open ? 0 : 1);
+          const int score = cur_b + (is_open ? o.s_gapo : o.s_gape);
+          if (group_kept(score, n_mm + go2 + (gape_mode ? ge2 : 0))) {
+            const int slot = is_open ? slot_open : slot_ext;
+            const uint32_t common = (cpk & ((1u << 9) | (31u << 12))) | (uint32_t)go2 << 17 | (uint32_t)ge2 << 19;
+            const uint32_t pkI = common | (uint32_t)i | (uint32_t)FQ_ST_I << 10 | (uint32_t)i << 23;
+            const uint32_t pkD = common | (uint32_t)(i + 1) | (uint32_t)FQ_ST_D << 10 | (uint32_t)(i + 1) << 23;
+            if (has_I) child(write, slot, k, l, pkI);
+            if (has_D) {
+              if (vmask & 1u) child(write, slot, kk0, ll0, pkD);
+              if (vmask & 2u) child(write, slot, kk1, ll1, pkD);
+              if (vmask & 4u) child(write, slot, kk2, ll2, pkD);
+              if (vmask & 8u) child(write, slot, kk3, ll3, pkD);
+            }
+          }
+        }
+      }
+      if (allow_M) {
+        const uint32_t mmask = cbase < 4 ? (vmask & ~(1u << cbase)) : vmask;
+        if (mmask) {
+          live_add += (uint32_t)FQ_POPC32(mmask);
+          if (group_kept(cur_b + o.s_mm, diffs + 1)) {
+            const uint32_t pkM = ((cpk & ((1u << 9) | (31u << 12) | (3u << 17) | (15u << 19))) + (1u << 12)) | (uint32_t)i | (uint32_t)i << 23;
+            for (int j = 1; j <= 4; ++j) {
+              const int cc = (cbase + j) & 3;
+              if ((mmask >> cc) & 1u) child(write, slot_mm, fq_sel4v(kk0, kk1, kk2, kk3, cc), fq_sel4v(ll0, ll1, ll2, ll3, cc), pkM);
+            }
+          }
+        }
+      }
+    }
+    if (!mvalid) { on = false; return; }
+    ++ch_pushes; ++ch_pops;
+    if (sequential && live_run + (int32_t)live_add + 1 > o.max_entries) { on = false; limit_hit = true; return; }   // loop-top check of the child's pop
+    ck_ = mk; cl_ = ml; cpk = fpk;
+    if (i == 0) { on = false; hit = true; }
+  }
+
+  FQ_HD void finish() {
+    if (FQ_LANE_ID() == 0) {
+      A.n_aln[w] = status ? 0u : n_aln;
+      A.status[w] = status;
+      FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS], c_pops);
+      FQ_ATOMIC_ADD64(&A.counters[FQ_C_PUSHES], c_pushes);
+      FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXPOPS], c_pops);
+      if (c_pops > 4096) FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS_GT4K], 1);
+      FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_GAP], c_touch);
+    }
+  }
+
+  FQ_HD void start_chains(const FqEntry &e, bool active, uint32_t c0, uint32_t c1, uint32_t c2) {
+    on = active; hit = false; tail = false; limit_hit = false;
+    ck_ = e.k; cl_ = e.l; cpk = e.pk; wbase = 0x7fff;
+    live_add = 0; ch_pops = ch_pushes = ch_touch = 0;
+    cnt0 = c0; cnt1 = c1; cnt2 = c2;
+    live_run = n_live - 1;
+    if (on) {   // pop-time checks of the entry itself (bwtgap.c:150-166)
+      const int n_mm = (int)(cpk >> 12) & 31, n_gapo = (int)(cpk >> 17) & 3, n_gape = (int)(cpk >> 19) & 15;
+      if (max_diff - (n_mm + n_gapo + (gape_mode ? n_gape : 0)) < 0) on = false;
+      else if ((cpk & 511u) == 0) { on = false; hit = true; }
+    }
+  }
+  // lane 0: a run of n entries starting at pool[first] becomes the top of bucket B (header in front of it: size, run below)
+  FQ_HD void new_run(int B, uint32_t first, uint32_t n) {
+    FqEntry h;
+    h.k = 0; h.l = n; h.pk = 0; h.next = heads[B];
+    pool[first - 1] = h;
+    heads[B] = first; heads[FQ_MAX_BUCKETS + B] = n;
+  }
+
+  // the whole search of work item w_; returns the number of rounds
+  FQ_HD uint32_t run(int w_) {
+    const int lane = FQ_LANE_ID();
+    w = w_;
+    const FqGapWork gw = A.winfo[w];
+    len = (int)(gw.meta & 0xffffu);
+    max_diff_opt = (int)((gw.meta >> 16) & 0xffu);
+    use_seed = len > o.seed_len;
+    seed_off = len - o.seed_len;
+    prec = A.prec + (size_t)w * 2 * (size_t)A.pstride;
+    m0 = m1 = m2 = m3 = 0; status = 0; n_aln = 0;
+    best_score = (max_diff_opt + 1) * o.s_mm + (o.max_gapo + 1) * o.s_gapo + (o.max_gape + 1) * o.s_gape;
+    max_diff = max_diff_opt; best_cnt = 0;
+    c_pops = c_pushes = c_touch = 0;
+    if ((gw.meta >> 24) & 1u) { finish(); return 0; }
+    for (int b = lane; b < 2 * FQ_MAX_BUCKETS; b += FQ_WAVE_SIZE) heads[b] = 0;
+    // the two roots: one run of two entries in bucket 0, strand 1 on top (bwtgap.c:139-140)
+    if (lane == 0) {
+      FqEntry h; h.k = 0; h.l = 2; h.pk = 0; h.next = 0;          // header: l = size of the run, next = first entry of the run below (0: none)
+      pool[0] = h;
+      FqEntry e; e.k = 0; e.l = seq_len; e.next = 0;
+      e.pk = fq_pack(len, 0, FQ_ST_M, 0, 0, 0, 0); pool[1] = e;
+      e.pk = fq_pack(len, 1, FQ_ST_M, 0, 0, 0, 0); pool[2] = e;
+    }
+    FQ_WAVE_FENCE();
+    if (lane == 0) { heads[0] = 1; heads[FQ_MAX_BUCKETS] = 2; }
+    bump = 3; m0 = 1u; n_live = 2; c_pushes = 2;
+    uint32_t rounds = 0;
+    bool force_seq = false;
+    for (;; ++rounds) {
+      if ((m0 | m1 | m2 | m3) == 0) break;
+      if (n_live > o.max_entries) { if (!exact) status |= FQ_SF_ENTRY_LIMIT; break; }
+      const int b = m0 ? FQ_CTZ32(m0) : m1 ? 32 + FQ_CTZ32(m1) : m2 ? 64 + FQ_CTZ32(m2) : 96 + FQ_CTZ32(m3);
+      if (!nonstop && b > best_score + o.s_mm) { ++c_pops; break; }                    // bwtgap.c:147
+      cur_b = b;
+      const uint32_t start = heads[b], left = heads[FQ_MAX_BUCKETS + b];
+      const uint32_t T = force_seq ? 1u : (left < (uint32_t)FQ_WAVE_SIZE ? left : (uint32_t)FQ_WAVE_SIZE);
+      const bool mine = (uint32_t)lane < T;
+      FqEntry e;
+      e.k = e.l = e.pk = e.next = 0;
+      if (mine) e = pool[start + left - 1 - (uint32_t)lane];
+      // ---- two passes over the chains (one inlined copy of the step): pass 0 counts the children each chain sends to each run and
+      //      notices alignments, pass 1 runs the committed chains again and writes
+      uint32_t n_commit = 0, add_all = 0;
+      bool committed = false, redo = false, overflow = false;
+      uint32_t c0 = 0, c1 = 0, c2 = 0;
+      for (int pass = 0; pass < 2 && !redo && !overflow; ++pass) {
+        start_chains(e, pass == 0 ? mine : committed, c0, c1, c2);
+        while (FQ_BALLOT(on) != 0) { if (on) chain_step(pass == 1, T == 1u); }
+        if (pass == 1) break;
+        const uint64_t hm = FQ_BALLOT(hit || limit_hit);
+        n_commit = hm ? (uint32_t)FQ_CTZ64(hm) + 1u : T;                    // lanes behind the first alignment are redone later
+        committed = (uint32_t)lane < n_commit;
+        // The reference checks stack->n_entries > max_entries before every pop.  A parallel round skips those checks, which is
+        // sound only if the bound cannot have been crossed anywhere inside the round; otherwise redo it one entry at a time.
+        add_all = fq_wave_sum(committed ? live_add : 0u);
+        if (T > 1u && (int64_t)n_live + (int64_t)add_all + 1 > (int64_t)o.max_entries) { redo = true; break; }
+        const uint32_t my0 = committed ? cnt0 : 0u, my1 = committed ? cnt1 : 0u, my2 = committed ? cnt2 : 0u;
+        const uint32_t i0s = fq_wave_incl_scan(my0), i1s = fq_wave_incl_scan(my1), i2s = fq_wave_incl_scan(my2);
+        const uint32_t tot0 = FQ_READLANE32(i0s, FQ_WAVE_SIZE - 1), tot1 = FQ_READLANE32(i1s, FQ_WAVE_SIZE - 1), tot2 = FQ_READLANE32(i2s, FQ_WAVE_SIZE - 1);
+        if (bump + tot0 + tot1 + tot2 + 3u > A.tier.pool_cap) { overflow = true; break; }
+        // the runs of this round: a header slot, then the children of lanes 0..n_commit-1 in lane order
+        const uint32_t r0 = bump + 1, r1 = r0 + (tot0 ? tot0 + 1 : 0), r2 = r1 + (tot1 ? tot1 + 1 : 0);
+        bump = r2 + (tot2 ? tot2 + 1 : 0) - 1;
+        if (lane == 0) {
+          if (tot0) new_run(b + o.s_gapo, r0, tot0);
+          if (tot1) new_run(b + o.s_gape, r1, tot1);
+          if (tot2) new_run(b + o.s_mm, r2, tot2);
+        }
+        if (tot0) bucket_set(b + o.s_gapo);
+        if (tot1) bucket_set(b + o.s_gape);
+        if (tot2) bucket_set(b + o.s_mm);
+        c0 = r0 + (i0s - my0); c1 = r1 + (i1s - my1); c2 = r2 + (i2s - my2);
+      }
+      if (redo) { force_seq = true; continue; }
+      if (overflow) { status |= FQ_SF_POOL_OVERFLOW; break; }
+      FQ_WAVE_FENCE();
+      // ---- commit: entries popped, counters, the source run
+      {
+        const uint32_t pops = fq_wave_sum(committed ? ch_pops : 0u), pushes = fq_wave_sum(committed ? ch_pushes : 0u), touch = fq_wave_sum(committed ? ch_touch : 0u);
+        c_pops += n_commit + pops; c_pushes += pushes; c_touch += touch;
+        n_live += (int32_t)add_all - (int32_t)n_commit;
+        const uint32_t rest = left - n_commit;
+        if (rest) { if (lane == 0) heads[FQ_MAX_BUCKETS + b] = rest; }
+        else {
+          const uint32_t below = pool[start - 1].next;
+          const uint32_t below_n = below ? pool[below - 1].l : 0u;
+          if (lane == 0) { heads[b] = below; heads[FQ_MAX_BUCKETS + b] = below_n; }
+          if (!below) bucket_clr(b);
+        }
+      }
+      if (T == 1u) force_seq = false;
+      // ---- the last committed lane may have ended the round with an alignment or with the entry limit
+      const int jl = (int)n_commit - 1;
+      const bool was_limit = FQ_READLANE32(limit_hit ? 1u : 0u, jl) != 0, was_hit = FQ_READLANE32(hit ? 1u : 0u, jl) != 0;
+      if (was_limit) { if (!exact) status |= FQ_SF_ENTRY_LIMIT; break; }
+      if (was_hit) {
+        const uint32_t hk = FQ_READLANE32(ck_, jl), hl = FQ_READLANE32(cl_, jl), hpk = FQ_READLANE32(cpk, jl);
+        if (!record_hit(hk, hl, hpk, b)) break;
+      }
+    }
+    finish();
+    return rounds;
+  }
+
+  // bwtgap.c:166-198 for the alignment (hk, hl, hpk); false = the search ends
+  FQ_HD bool record_hit(uint32_t hk, uint32_t hl, uint32_t hpk, int e_score) {
+    const int a = (int)(hpk >> 9) & 1, n_mm = (int)(hpk >> 12) & 31, n_gapo = (int)(hpk >> 17) & 3, n_gape = (int)(hpk >> 19) & 15, ld = (int)(hpk >> 23);
+    if (n_aln == 0) {
+      best_score = e_score;
+      const int best_diff = n_mm + n_gapo + (gape_mode ? n_gape : 0);
+      if (!nonstop) max_diff = best_diff + 1 > max_diff_opt ? max_diff_opt : best_diff + 1;
+    }
+    if (e_score == best_score) best_cnt += (int)(hl - hk + 1);
+    else if (best_cnt > o.max_top2) return false;
+    FqAln *al = A.aln + (size_t)w * (size_t)A.tier.aln_cap;
+    if (n_gapo) {
+      bool dup = false;
+      for (uint32_t j0 = 0; j0 < n_aln; j0 += FQ_WAVE_SIZE) {
+        const uint32_t j = j0 + (uint32_t)FQ_LANE_ID();
+        const bool d = j < n_aln && al[j].k == hk && al[j].l == hl;
+        if (FQ_BALLOT(d) != 0) { dup = true; break; }
+      }
+      if (dup) return true;
+    }
+    if (ld > 0) {   // gap_shadow over width[0..ld) and the position records up to ld
+      uint32_t *const ww = A.wfull + ((size_t)w * 2 + (size_t)a) * (size_t)A.wstride;
+      FqPos *const pr = prec + (size_t)a * (size_t)A.pstride;
+      const uint32_t xx = hl - hk + 1;
+      uint32_t jj = 0, carry_w = 0;
+      for (int base = 0; base <= ld; base += FQ_WAVE_SIZE) {
+        const int t = base + FQ_LANE_ID();
+        const bool in = t < ld, in2 = t <= ld;
+        uint32_t nw = in2 ? ww[t] : 0u;
+        const bool gt = in && nw > xx, eq = in && nw == xx;
+        const uint64_t em = FQ_BALLOT(eq);
+        if (gt) nw -= xx;
+        else if (eq) nw = seq_len - (jj + (uint32_t)FQ_POPC64(em & (((uint64_t)1 << FQ_LANE_ID()) - 1)) + 1);
+        if (gt || eq) ww[t] = nw;
+        jj += (uint32_t)FQ_POPC64(em);
+        uint32_t wleft = FQ_SHFL_UP1(nw);
+        if (FQ_LANE_ID() == 0) wleft = carry_w;
+        carry_w = FQ_READLANE32(nw, FQ_WAVE_SIZE - 1);
+        if (in2) {
+          uint32_t rec = (uint32_t)pr[t] & ~0x20u;
+          if (eq) rec = (rec & ~0x1fu) | 1u;
+          pr[t] = (FqPos)(rec | ((t >= 1 && wleft == nw) ? 1u << 5 : 0u));
+        }
+      }
+      FQ_WAVE_FENCE();
+    }
+    if (n_aln >= A.tier.aln_cap) { status |= FQ_SF_ALN_OVERFLOW; return false; }
+    if (FQ_LANE_ID() == 0) {
+      FqAln h;
+      h.info = (uint32_t)n_mm | (uint32_t)n_gapo << 8 | (uint32_t)n_gape << 16 | (uint32_t)a << 24;
+      h.k = hk; h.l = hl; h.score = e_score;
+      al[n_aln] = h;
+    }
+    ++n_aln;
+    FQ_WAVE_FENCE();
+    return true;
+  }
+};
+
+// one wavefront: reads from the queue, one at a time
+template <class Fetch>
+FQ_HD void fq_gap_coop_wave(const FqGapArgs &A, uint32_t *heads, Fetch fetch, int wave_slot) {
+  FqGapCoop C(A, heads, wave_slot);
+  uint32_t rounds = 0;
+  for (;;) {
+    uint32_t wq = 0;
+    if (FQ_LANE_ID() == 0) wq = fetch(1u);
+    wq = FQ_READLANE32(wq, 0);
+    if (wq >= (uint32_t)A.n_work) break;
+    rounds += C.run((int)wq);
+  }
+  if (FQ_LANE_ID() == 0) { FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXTRIPS], rounds); FQ_ATOMIC_ADD64(&A.counters[FQ_C_SUMTRIPS], rounds); }
+}
 
 // ---- K_sa: bwt_sa over enumerated SA rows (src/BwtMapper.cpp:770-772, 811-853) -------------------
 struct FqSaArgs {

@@ -46,19 +46,22 @@ int launch_surv_gather(const int32_t *pair_list, int n_surv, int n_pairs, const 
   return 0;
 }
 int launch_width(const FqWidthArgs &a) { uint8_t seed_bits[FQ_SEED_MAX]; for (int t = 0; t < a.n_work * 2; ++t) fq_width_thread(a, t, seed_bits, 1); return 0; }
-struct SeqFetch { int *next; int n; uint32_t operator()(uint32_t k) const { const uint32_t at = (uint32_t)*next; *next += (int)k; return at; } };
+struct SeqFetch { uint32_t *next; int n; uint32_t operator()(uint32_t k) const { const uint32_t at = *next; *next += k; return at; } };
 int gap_lane_slots(const FqGapArgs &a) { return a.n_work > 0 ? 1 : 0; }
 int launch_gap(const FqGapArgs &a_in) {
   FqGapArgs a = a_in;
   a.refill_min = 1;
-  int next = 0;
-  if (a.tier.pool_cap <= 65535u) {   // same store policy the HIP launcher picks: 16-bit heads in (here: emulated) LDS
+  uint32_t *next_p = a.queue; *next_p = 0;   // the same cursor the device kernels advance
+  if (a.tier.coop) {
+    std::vector<uint32_t> heads(2 * FQ_MAX_BUCKETS);
+    fq_gap_coop_wave(a, heads.data(), SeqFetch{next_p, a.n_work}, 0);
+  } else if (a.tier.pool_cap <= 65535u) {   // same store policy the HIP launcher picks: 16-bit heads in (here: emulated) LDS
     std::vector<uint16_t> heads(a.o.n_buckets);
     FqGapStoreLds st = {heads.data(), 1};
-    fq_gap_lanes(a, st, SeqFetch{&next, a.n_work}, 0);
+    fq_gap_lanes(a, st, SeqFetch{next_p, a.n_work}, 0);
   } else {
     FqGapStoreGlobal st = {nullptr};
-    fq_gap_lanes(a, st, SeqFetch{&next, a.n_work}, 0);
+    fq_gap_lanes(a, st, SeqFetch{next_p, a.n_work}, 0);
   }
   return 0;
 }

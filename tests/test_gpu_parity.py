@@ -20,8 +20,21 @@ def lib():
     return L
 
 
+# search_mode: "lanes" = the default tiering (one read per lane; the wavefront-per-read kernel only takes over long searches
+# once the queue is dry), "wave1"/"wave64" = hand every search over to the wavefront-per-read kernel after 1 / 64 pops, so
+# that its parallel rounds, commit rule and run bookkeeping are exercised by every read of the case
+SEARCH_MODES = {"lanes": {}, "wave1": {"FQ_GAP_LONG_POPS": "1", "FQ_GAP_LONG_ALWAYS": "1"}, "wave64": {"FQ_GAP_LONG_POPS": "64", "FQ_GAP_LONG_ALWAYS": "1"}}
+
+
+@pytest.fixture(params=list(SEARCH_MODES))
+def search_mode(request, monkeypatch):
+    for k, v in SEARCH_MODES[request.param].items():
+        monkeypatch.setenv(k, v)
+    return request.param
+
+
 @pytest.mark.parametrize("tag", golden_util.case_tags())
-def test_gpu_matches_reference_golden(tag, golden_cases, lib):
+def test_gpu_matches_reference_golden(tag, golden_cases, lib, search_mode):
     g = golden_cases[tag]
     names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
     ix = api.Index(g["prefix"], device=0)
@@ -35,6 +48,8 @@ def test_gpu_matches_reference_golden(tag, golden_cases, lib):
     assert not diffs, "\n".join(diffs)
     assert filecmp.cmp(g["sam"], sam, shallow=False)
     assert stats["kernel_launches"][2] > 0, "the gap-search kernel did not run on the device"
+    if search_mode != "lanes":
+        assert stats["tier_retries"] > 0, "the wavefront-per-read kernel was not exercised"
 
 
 CASES = [
@@ -49,7 +64,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("tag,refkw,readkw,n,batch,q", CASES, ids=[c[0] for c in CASES])
-def test_gpu_matches_oracle_on_fresh_inputs(tag, refkw, readkw, n, batch, q, lib, tmp_path):
+def test_gpu_matches_oracle_on_fresh_inputs(tag, refkw, readkw, n, batch, q, lib, tmp_path, search_mode):
     ref = synth.make_reference(**refkw)
     pre = str(tmp_path / "ref.FASTQuick.fa")
     ref.write_fasta(pre)

@@ -20,8 +20,12 @@ def emu_lib():
     return api.load_library(os.path.join(EMU_DIR, "libfq_emu.so"))
 
 
+@pytest.mark.parametrize("mode", ["lanes", "wave"])
 @pytest.mark.parametrize("tag", golden_util.case_tags())
-def test_emulated_pipeline_matches_reference_golden(tag, golden_cases, emu_lib):
+def test_emulated_pipeline_matches_reference_golden(tag, mode, golden_cases, emu_lib, monkeypatch):
+    if mode == "wave":   # every search handed to the wavefront-per-read path (a one-lane wavefront here: its sequential rounds)
+        monkeypatch.setenv("FQ_GAP_LONG_POPS", "1")
+        monkeypatch.setenv("FQ_GAP_LONG_ALWAYS", "1")
     g = golden_cases[tag]
     names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
     ix = api.Index(g["prefix"], lib=emu_lib)
