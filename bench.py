@@ -34,8 +34,8 @@ K_PREP_KERNEL, K_GAP_KERNEL = 6, 7     # single-kernel timings (kernel begin/end
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=32)
     ap.add_argument("--pairs", type=int, default=16 * 262144,
                     help="pairs per step: one call carrying this many pairs = pairs/262144 reference batches (READ_BUFFER_SIZE)")
     ap.add_argument("--ctxs", type=int, default=16,
@@ -136,6 +136,8 @@ def main() -> None:
             raise errs[0]
         return sum(recs)
 
+    for al in ctxs:                 # set-up, like the upload: the first call of a context sizes its device buffers
+        al.align_resident()
     run_steps(max(args.warmup, 0))
     for al in ctxs:
         al.reset_stats()

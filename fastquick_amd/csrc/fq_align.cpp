@@ -491,7 +491,10 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
     // tier 0 results are appended in s order directly
     vector<int64_t> where(n_search, -1);   // offset of s's list in h_aln (filled as results arrive)
     for (int tier = 0; tier < 3 && !work.empty(); ++tier) {
-      const FqGapTier T = tiers[tier];
+      FqGapTier T = tiers[tier];
+      // Handing long searches to the wavefront-per-read kernel pays when the launch is latency-bound (few reads: its duration is
+      // its longest search); a launch that fills the device several times over hides its long searches behind the others.
+      if (tier == 0 && !long_always && work.size() > 65536) T.long_pops = 0;
       next_work.clear();
       for (size_t c0 = 0; c0 < work.size(); c0 += chunk_reads[tier]) {
         const int nw = (int)std::min(chunk_reads[tier], work.size() - c0);
