@@ -16,12 +16,12 @@ import json
 import os
 import sys
 
-KMAP = {"k_prep": "fq_prep", "k_gap_lds": "fq_gap", "k_gap": "fq_gap", "k_gap_persist": "fq_gap", "k_gap_persist_lds": "fq_gap", "k_width": "fq_width", "k_sa": "fq_sa",
+KMAP = {"k_prep": "fq_prep", "k_gap_lds": "fq_gap", "k_gap": "fq_gap", "k_gap_persist": "fq_gap", "k_gap_persist_lds": "fq_gap", "k_gap_coop": "fq_gap_wave", "k_width": "fq_width", "k_sa": "fq_sa",
         "k_sw_wave": "fq_sw", "k_refine_lds": "fq_refine"}
 
 
 def mean_kb(d):
-    f = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))[0]
+    f = (glob.glob(os.path.join(d, "*_counter_collection.csv")) + glob.glob(os.path.join(d, "*", "*_counter_collection.csv")))[0]
     agg = collections.defaultdict(list)
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"].split("(")[0].split("::")[-1]
@@ -33,7 +33,7 @@ def main():
     mix, units_path, dfetch, dwrite = sys.argv[1:5]
     bench = json.loads([l for l in open(units_path) if l.startswith("{")][-1])
     per_step = bench["work_per_step"]
-    units = {"fq_prep": 2 * bench["config"]["pairs_per_step"], "fq_gap": per_step["reads_searched"], "fq_width": per_step["reads_searched"],
+    units = {"fq_prep": 2 * bench["config"]["pairs_per_step"], "fq_gap": per_step["reads_searched"], "fq_gap_wave": max(1.0, per_step["tier_retries"]), "fq_width": per_step["reads_searched"],
              "fq_sa": max(1.0, per_step["sa_rows"]), "fq_sw": max(1.0, per_step["sw_tasks"]), "fq_refine": max(1.0, per_step["refine_tasks"])}
     fe, wr = mean_kb(dfetch), mean_kb(dwrite)
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
