@@ -132,6 +132,8 @@ __global__ void __launch_bounds__(256) k_saq(FqSaQueryArgs a) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < a.n) fq_saq_thread(a, q);
 }
+__device__ int fq_global_align_wave(const uint8_t *s1, int len1, const uint8_t *s2, int len2, int band, int gap_end,
+                                    int *RM, int *RI, int *RD, uint8_t *trace, uint8_t *ops, int *n_ops, int *fi, int *fj);
 // ---- mate-rescue Smith-Waterman: one 64-lane wavefront per task ---------------------------------------------
 // Forward pass of aln_local_core as an anti-diagonal wavefront: lane l owns query row j0+l+1 of a 64-row
 // stripe and walks the reference columns one step behind lane l-1; H/E of the row above arrive by a one-lane
@@ -207,10 +209,26 @@ __global__ void __launch_bounds__(64) k_sw_wave(FqSwArgs a) {
     const int oh = __shfl_xor(best_h, d, 64), oi = __shfl_xor(best_i, d, 64), oj = __shfl_xor(best_j, d, 64);
     if (oh > best_h || (oh == best_h && oh > 0 && oj < best_j)) { best_h = oh; best_i = oi; best_j = oj; }
   }
+  // reverse pass on lane 0 (its band follows the running maximum), banded global fill of the sub-rectangle by the whole
+  // wavefront (trace matrix in LDS when the launcher found room for it, else in the task's global scratch), the rest on lane 0
+  if (best_h < 1) { if (lane == 0) a.out[t] = O; return; }
+  FqDpScratch S = fq_dp_carve(a.scratch + (size_t)t * a.scratch_stride, RL, QL);
+  uint8_t *ops = qry + ((QL + 16) & ~15);
+  uint8_t *trace = a.trace_in_lds ? ops + ((RL + QL + 16) & ~15) : S.trace;
+  int start_i = 0, start_j = 0, score_r = 0;
+  if (lane == 0) fq_sw_reverse(ref, qry, best_h, best_i, best_j, Hb, Eb, &start_i, &start_j, &score_r);
+  start_i = __shfl(start_i, 0); start_j = __shfl(start_j, 0); score_r = __shfl(score_r, 0);
+  __syncthreads();
+  int n_ops = 0, fi = 0, fj = 0, score_g;
+  const int jmax = (best_i - start_i > best_j - start_j ? best_i - start_i : best_j - start_j) + 1;
+  for (int b = FQ_BAND;; b <<= 1) {   // doubling band (stdaln.c:705-716)
+    score_g = fq_global_align_wave(ref + start_i - 1, best_i - start_i + 1, qry + start_j - 1, best_j - start_j + 1, b, -1, rM, rI, rD, trace, ops, &n_ops, &fi, &fj);
+    if (score_g == score_r || best_h == score_g) break;
+    if (b > jmax) break;
+  }
   if (lane == 0) {
-    FqDpScratch S = fq_dp_carve(a.scratch + (size_t)t * a.scratch_stride, RL, QL);
-    FqRowsPlanar R = {rM, rI, rD, 1};
-    fq_sw_finish(T, ref, len1, qry, len, best_h, best_i, best_j, Hb, Eb, R, S.trace, S.ops, a.cigar + (size_t)t * (size_t)a.cig_cap, a.cig_cap, O);
+    if (!(score_r > score_g && best_h > score_g))   // else: the "Potential bug" arm of the reference, ret < 0
+      fq_sw_post(T, ref, qry, len, best_j, start_i, start_j, fi, fj, ops, n_ops, a.cigar + (size_t)t * (size_t)a.cig_cap, a.cig_cap, O);
     a.out[t] = O;
   }
 }
@@ -222,6 +240,152 @@ __global__ void __launch_bounds__(64) k_refine_lds(FqRefineArgs a) {
   const int W = a.RL + 1;
   FqRowsPlanar R = {base + threadIdx.x, base + (size_t)W * 64 + threadIdx.x, base + (size_t)2 * W * 64 + threadIdx.x, 64};
   if (t < a.n_task) fq_refine_task(a, t, R);
+}
+// ---- banded global alignment (aln_global_core, stdaln.c:345-525) by one wavefront -----------------------------------------
+// Same cells, same rules and the same trace bytes as fq_global_align (fq_kernels.h), filled along anti-diagonals: lane l owns
+// row j0+l of a 64-row stripe and is one column behind lane l-1, whose cell of the column above arrives by a one-lane
+// shuffle; the last row of a stripe is kept in LDS (RM/RI/RD) for the first lane of the next one -- the array the serial code
+// updates in place.  A row's first position (column 0 in phases 1/5, column j-b2 otherwise) is the serial code's "left"
+// initialisation.  Values of the row above outside its band are never consumed (the i == hi rules of each phase).  The
+// traceback is serial (lane 0, out of LDS).  Block = one wavefront.
+__device__ int fq_global_align_wave(const uint8_t *s1, int len1, const uint8_t *s2, int len2, int band, int gap_end,
+                                    int *RM, int *RI, int *RD, uint8_t *trace, uint8_t *ops, int *n_ops, int *fi, int *fj) {
+  const int lane = threadIdx.x;
+  if (len1 == 0 || len2 == 0) { *n_ops = 0; return 0; }
+  int b1, b2;
+  if (len1 > len2) { b1 = len1 - len2 + band; b2 = band; } else { b1 = band; b2 = len2 - len1 + band; }
+  if (b1 > len1) b1 = len1;
+  if (b2 > len2) b2 = len2;
+  const int W = len1 + 1;
+  const int end_ext = gap_end >= 0 ? gap_end : FQ_GAP_E;
+  if (lane == 0) {   // row 0
+    uint8_t fm;
+    int lM = 0, lD = FQ_NEG_INF;
+    RM[0] = 0; RI[0] = RD[0] = FQ_NEG_INF;
+    for (int i = 1; i < b1; ++i) {
+      const int d = fq_pick_gap(lM, lD, end_ext, fm);
+      trace[i] = (uint8_t)(fm ? 0 : 8);
+      RM[i] = RI[i] = FQ_NEG_INF; RD[i] = d;
+      lM = FQ_NEG_INF; lD = d;
+    }
+  }
+  __syncthreads();
+  const int p1_end = b2 < len2 ? b2 : len2 - 1;
+  for (int j0 = 1; j0 <= len2; j0 += 64) {
+    const int j = j0 + lane;
+    const bool row_on = j <= len2;
+    int phase;
+    if (j <= p1_end) phase = 1;
+    else if (j == p1_end + 1 && j == len2 && b2 != len2 - 1) phase = 5;
+    else if (j <= len2 - b2 + 1) phase = 2;
+    else if (j < len2) phase = 3;
+    else phase = 4;
+    const bool p15 = phase == 1 || phase == 5, endD = phase == 5 || phase == 4;
+    const int c0 = p15 ? 0 : j - b2;
+    const int hi = !row_on ? -1 : p15 ? ((j + b1 <= len1 + 1) ? j + b1 - 1 : len1) : (phase == 2 ? j + b1 - 1 : len1);
+    const int c2 = row_on ? s2[j - 1] : 0;
+    const bool keeps_row = row_on && (lane == 63 || j == len2);
+    uint8_t *tr = trace + (size_t)j * (size_t)W;
+    const int n_rows = len2 - j0 + 1 < 64 ? len2 - j0 + 1 : 64;
+    const int t0 = __shfl(c0, 0), t1 = len1 + n_rows - 1;
+    int oM = 0, oI = 0, oD = 0;
+    FqCell diag, left;
+    diag.M = diag.I = diag.D = 0; left = diag;
+    for (int t = t0; t <= t1; ++t) {
+      const int i = t - lane;
+      FqCell up;
+      up.M = __shfl_up(oM, 1); up.I = __shfl_up(oI, 1); up.D = __shfl_up(oD, 1);
+      if (lane == 0) { const int ii = i < 0 ? 0 : (i > len1 ? len1 : i); up.M = RM[ii]; up.I = RI[ii]; up.D = RD[ii]; }
+      if (row_on && i >= c0 && i <= hi) {
+        FqCell c;
+        uint8_t fm;
+        if (i == c0) {
+          c.M = c.I = c.D = FQ_NEG_INF;
+          if (p15) { c.I = fq_pick_gap(up.M, up.I, end_ext, fm); tr[0] = (uint8_t)(fm ? 0 : 4); }
+        } else {
+          uint8_t tM, tb;
+          c.M = fq_pick_M(diag, fq_sm_maq(s1[i - 1], c2), tM);
+          tb = tM;
+          if (i != hi) { c.I = fq_pick_gap(up.M, up.I, FQ_GAP_E, fm); tb |= (uint8_t)(fm ? 0 : 4); }
+          else if (p15) {
+            if (j + b1 - 1 > len1) { c.I = fq_pick_gap(up.M, up.I, end_ext, fm); tb |= (uint8_t)(fm ? 0 : 4); }
+            else c.I = FQ_NEG_INF;
+          } else if (phase == 2) c.I = FQ_NEG_INF;
+          else { c.I = fq_pick_gap(up.M, up.I, end_ext, fm); tb |= (uint8_t)(fm ? 0 : 4); }
+          c.D = fq_pick_gap(left.M, left.D, endD ? end_ext : FQ_GAP_E, fm);
+          tb |= (uint8_t)(fm ? 0 : 8);
+          tr[i] = tb;
+        }
+        diag = up; left = c;
+        oM = c.M; oI = c.I; oD = c.D;
+        if (keeps_row) { RM[i] = c.M; RI[i] = c.I; RD[i] = c.D; }
+      }
+    }
+    __syncthreads();
+  }
+  // traceback (stdaln.c:484-512), lane 0; every lane returns its results through LDS-resident ops / the broadcast below
+  int mx = 0, n = 0, li = 0, lj = 0;
+  if (lane == 0) {
+    int i = len1, j = len2;
+    mx = RM[len1];
+    uint8_t tb = trace[(size_t)j * W + i];
+    int type = tb & 3, ctype = FQ_OP_M;
+    if (RI[len1] > mx) { mx = RI[len1]; type = (tb & 4) ? FQ_OP_I : FQ_OP_M; ctype = FQ_OP_I; }
+    if (RD[len1] > mx) { mx = RD[len1]; type = (tb & 8) ? FQ_OP_D : FQ_OP_M; ctype = FQ_OP_D; }
+    li = i; lj = j;
+    ops[n++] = (uint8_t)ctype;
+    do {
+      if (ctype == FQ_OP_M) { --i; --j; } else if (ctype == FQ_OP_I) --j; else --i;
+      ctype = type;
+      tb = trace[(size_t)j * W + i];
+      type = type == FQ_OP_M ? (tb & 3) : type == FQ_OP_I ? ((tb & 4) ? FQ_OP_I : FQ_OP_M) : ((tb & 8) ? FQ_OP_D : FQ_OP_M);
+      if (i || j) { ops[n++] = (uint8_t)ctype; li = i; lj = j; }
+    } while (i || j);
+  }
+  __syncthreads();
+  *n_ops = __shfl(n, 0); *fi = __shfl(li, 0); *fj = __shfl(lj, 0);
+  return __shfl(mx, 0);
+}
+// refine_gapped_core (libbwa/bwase.c:183-232), one task per wavefront; LDS: RM/RI/RD, ref, qry, ops, trace
+__global__ void __launch_bounds__(64) k_refine_wave(FqRefineArgs a) {
+  const int t = blockIdx.x, lane = threadIdx.x;
+  const int RL = a.RL, QL = a.QL;
+  int *RM = (int *)fq_dyn_lds, *RI = RM + (RL + 1), *RD = RI + (RL + 1);
+  uint8_t *ref = (uint8_t *)(RD + (RL + 1));
+  uint8_t *qry = ref + ((RL + 16) & ~15);
+  uint8_t *ops = qry + ((QL + 16) & ~15);
+  uint8_t *trace = ops + ((RL + QL + 16) & ~15);
+  const FqRefTask T = a.task[t];
+  const int len = a.len_trim[T.read];
+  const uint8_t *row = a.seq + (size_t)T.read * (size_t)a.stride;
+  const int64_t l_pac = a.ix.l_pac;
+  for (int k = lane; k < len; k += 64) qry[k] = (uint8_t)(T.strand ? fq_comp(fq_nt4(row[len - 1 - k])) : fq_nt4(row[k]));
+  int64_t pos = (int64_t)T.pos > l_pac ? (int64_t)(int32_t)T.pos : (int64_t)T.pos;
+  const int aext = T.ext < 0 ? -T.ext : T.ext, ref_len = len + aext;
+  int64_t k0, k1;
+  if (T.ext > 0) { k0 = pos; k1 = pos + ref_len < l_pac ? pos + ref_len : l_pac; }
+  else { const int64_t x = pos + len; k0 = x - ref_len > 0 ? x - ref_len : 0; k1 = x < l_pac ? x : l_pac; }
+  const int l = k1 > k0 ? (int)(k1 - k0) : 0;
+  for (int k = lane; k < l; k += 64) ref[k] = (uint8_t)fq_pac_base(a.ix.pac, k0 + k);
+  __syncthreads();
+  int n_ops = 0, fi, fj;
+  fq_global_align_wave(ref, l, qry, len, FQ_BAND, FQ_GAP_END, RM, RI, RD, trace, ops, &n_ops, &fi, &fj);
+  if (lane != 0) return;
+  uint16_t *cg = a.cigar + (size_t)t * (size_t)a.cig_cap;
+  int n = fq_ops_to_cigar(ops, n_ops, cg, a.cig_cap);
+  FqRefOut O;
+  if (n <= 0) { O.pos = T.pos; O.n_cigar = 0; a.out[t] = O; return; }
+  if (T.ext < 0) {
+    int d = 0;
+    for (int k = 0; k < n; ++k) { const int op = cg[k] >> 14, ln = cg[k] & 0x3fff; if (op == FQ_OP_D) d -= ln; else if (op == FQ_OP_I) d += ln; }
+    pos += d;
+  }
+  if ((cg[0] >> 14) == FQ_OP_D) { pos += cg[0] & 0x3fff; for (int k = 0; k < n - 1; ++k) cg[k] = cg[k + 1]; --n; }
+  if ((cg[n - 1] >> 14) == FQ_OP_D) --n;
+  if ((cg[n - 1] >> 14) == FQ_OP_I) cg[n - 1] = (uint16_t)(FQ_OP_S << 14 | (cg[n - 1] & 0x3fff));
+  if ((cg[0] >> 14) == FQ_OP_I) cg[0] = (uint16_t)(FQ_OP_S << 14 | (cg[0] & 0x3fff));
+  O.pos = (uint32_t)pos; O.n_cigar = n;
+  a.out[t] = O;
 }
 __global__ void __launch_bounds__(64) k_refine(FqRefineArgs a) {   // long reads: DP row in global memory
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -489,16 +653,31 @@ int launch_saq(const FqSaQueryArgs &a) {
 static const size_t kLdsBudget = 150 * 1024;
 int launch_sw(const FqSwArgs &a) {
   if (a.n_task <= 0) return 0;
-  const size_t lds = (size_t)(2 * (a.RL + 2) + 3 * (a.RL + 1)) * 4 + ((a.RL + 16) & ~15) + ((a.QL + 16) & ~15);
+  size_t lds = (size_t)(2 * (a.RL + 2) + 3 * (a.RL + 1)) * 4 + ((a.RL + 16) & ~15) + ((a.QL + 16) & ~15) + ((a.RL + a.QL + 16) & ~15);
   if (lds > kLdsBudget) { g_err = "SW window too large for LDS (" + std::to_string(a.RL) + " bases)"; return -5; }
+  FqSwArgs b = a;
+  const size_t trace_bytes = (size_t)(a.RL + 1) * (a.QL + 1) + 16;
+  b.trace_in_lds = lds + trace_bytes <= kLdsBudget ? 1 : 0;   // else the fill keeps its trace matrix in the task's global scratch
+  if (b.trace_in_lds) lds += trace_bytes;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) { FQ_HIP(hipFuncSetAttribute((const void *)k_sw_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget)); attr_set = true; }
-  hipLaunchKernelGGL(k_sw_wave, dim3((unsigned)a.n_task), dim3(64), lds, g_stream, a);
+  hipLaunchKernelGGL(k_sw_wave, dim3((unsigned)a.n_task), dim3(64), lds, g_stream, b);
   FQ_HIP(hipGetLastError());
   return 0;
 }
 int launch_refine(const FqRefineArgs &a) {
   if (a.n_task <= 0) return 0;
+  // one task per wavefront while row arrays + sequences + trace matrix fit in LDS with several blocks per CU; longer reads
+  // fall back to one task per lane
+  const size_t wave_lds = (size_t)3 * (a.RL + 1) * 4 + ((a.RL + 16) & ~15) + ((a.QL + 16) & ~15) + ((a.RL + a.QL + 16) & ~15) + (size_t)(a.RL + 1) * (a.QL + 1) + 16;
+  static const bool no_wave = getenv("FQ_REFINE_LANES") != nullptr;   // test hook: force the lane-per-task kernels
+  if (wave_lds <= 64 * 1024 && !no_wave) {
+    static std::atomic<bool> attr_w{false};
+    if (!attr_w) { FQ_HIP(hipFuncSetAttribute((const void *)k_refine_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr_w = true; }
+    hipLaunchKernelGGL(k_refine_wave, dim3((unsigned)a.n_task), dim3(64), wave_lds, g_stream, a);
+    FQ_HIP(hipGetLastError());
+    return 0;
+  }
   const size_t lds = (size_t)3 * (a.RL + 1) * 64 * 4;
   if (lds <= kLdsBudget) {
     static std::atomic<bool> attr_set{false};

@@ -692,7 +692,6 @@ struct FqGapLane {
       int tmp;
       if (o.mode & FQ_MODE_LOGGAP) { uint32_t vv = (uint32_t)(n_gape + n_gapo); int lg = 0; while (vv >>= 1) ++lg; tmp = lg / 2 + 1; }
       else tmp = n_gapo + n_gape;
-#ifndef FQ_ABL_GAP
       if (i >= o.indel_end_skip + tmp && len - i >= o.indel_end_skip + tmp) {   // ---- gap children (bwtgap.c:212-243)
         const bool is_open = st == FQ_ST_M;
         const bool can = is_open ? n_gapo < o.max_gapo : n_gape < o.max_gape;
@@ -721,8 +720,6 @@ struct FqGapLane {
           }
         }
       }
-#endif
-#ifndef FQ_ABL_MM
       if (allow_M) {   // ---- mismatch children, bases (c+1)&3, (c+2)&3, (c+3)&3 and, for an ambiguous read base, (c+4)&3 (bwtgap.c:245-252)
         const uint32_t mmask = cbase < 4 ? (vmask & ~(1u << cbase)) : vmask;
         if (mmask) {
@@ -744,7 +741,6 @@ struct FqGapLane {
           }
         }
       }
-#endif
     }
     // ---- the match child stays in registers (pushed last by the reference, hence popped next: bwtgap.c:246-258) ----
     if (!mvalid) { has_cur = false; return; }
@@ -856,9 +852,7 @@ FQ_HD void fq_gap_lanes(const FqGapArgs &A, const St &store0, Fetch fetch, int l
       }
     }
     if (L.active) { ++lane_trips; L.step(); }
-#ifndef FQ_ABL_HITS
     if (FQ_BALLOT(L.hit_pending) != 0) L.collect_hits();
-#endif
   }
 }
 
@@ -1511,6 +1505,7 @@ struct FqSwArgs {
   uint8_t *scratch;
   size_t scratch_stride;
   int32_t RL, QL;       // scratch dimensions
+  int32_t trace_in_lds; // set by the HIP launcher: the wavefront kernel keeps the fill's trace matrix in LDS
 };
 
 // one cell of the forward pass of aln_local_core (stdaln.c:585-612); state carried by the caller
@@ -1549,11 +1544,10 @@ FQ_HD void fq_sw_forward_seq(const uint8_t *ref, int len1, const uint8_t *qry, i
 
 // everything after the forward pass: banded reverse pass (stdaln.c:626-679), global fill with band doubling
 // (:709-727), CIGAR + clipping + mismatch/gap counts (bwape.c:389-443).  H/E: len1+2 ints of scratch.
-template <class Rows>
-FQ_HD void fq_sw_finish(const FqSwTask &T, const uint8_t *ref, int len1, const uint8_t *qry, int len, int score_f, int end_i, int end_j,
-                        int *H, int *E, const Rows &R, uint8_t *trace, uint8_t *ops, uint16_t *cg, int cig_cap, FqSwOut &O) {
+// aln_local_core's reverse pass (stdaln.c:640-700): where the best local alignment starts.  Serial by nature: the band it
+// sweeps depends on the running maximum.
+FQ_HD void fq_sw_reverse(const uint8_t *ref, const uint8_t *qry, int score_f, int end_i, int end_j, int *H, int *E, int *start_i_out, int *start_j_out, int *score_r_out) {
   const int q = FQ_GAP_O, rr = FQ_GAP_E, qr = q + rr;
-  if (score_f < 1) return;
   for (int i = end_i; i >= 0; --i) H[i] = E[i] = 0;
   int score_r = fq_sm_maq(ref[end_i - 1], qry[end_j - 1]);
   int start_i = end_i, start_j = end_j;
@@ -1588,18 +1582,12 @@ FQ_HD void fq_sw_finish(const FqSwTask &T, const uint8_t *ref, int len1, const u
       if (end <= 0) end = 0;
     }
   }
-  score_r -= qr;
-  int n_ops = 0, fi = 0, fj = 0, score_g;
-  {
-    const int jmax = (end_i - start_i > end_j - start_j ? end_i - start_i : end_j - start_j) + 1;
-    for (int b = FQ_BAND;; b <<= 1) {
-      score_g = fq_global_align(ref + start_i - 1, end_i - start_i + 1, qry + start_j - 1, end_j - start_j + 1, b, -1, R, trace, ops, &n_ops, &fi, &fj);
-      if (score_g == score_r || score_f == score_g) break;
-      if (b > jmax) break;
-    }
-    if (score_r > score_g && score_f > score_g) return;   // "Potential bug" arm of the reference: ret < 0
-    fi += start_i - 1; fj += start_j - 1;
-  }
+  *start_i_out = start_i; *start_j_out = start_j; *score_r_out = score_r - qr;
+}
+// after the banded fill of the sub-rectangle: CIGAR with clips, position and difference counts (bwa_sw_core, bwape.c:393-445)
+FQ_HD void fq_sw_post(const FqSwTask &T, const uint8_t *ref, const uint8_t *qry, int len, int end_j, int start_i, int start_j, int fi, int fj,
+                      const uint8_t *ops, int n_ops, uint16_t *cg, int cig_cap, FqSwOut &O) {
+  fi += start_i - 1; fj += start_j - 1;
   int n_cigar = fq_ops_to_cigar(ops, n_ops, cg + 1, cig_cap - 2);   // slot 0 reserved for a leading S
   if (n_cigar <= 0) return;
   uint32_t x = 0, y = 0;
@@ -1627,9 +1615,22 @@ FQ_HD void fq_sw_finish(const FqSwTask &T, const uint8_t *ref, int len1, const u
   O.cnt = (uint32_t)n_mm << 16 | (uint32_t)n_gapo << 8 | (uint32_t)n_gape;
   O.n_cigar = n_cigar;
 }
-
-// task prologue shared by both forms of the kernel: early-outs of bwa_sw_core (:369-373) and operand staging.
-// returns false when the task is rejected.
+template <class Rows>
+FQ_HD void fq_sw_finish(const FqSwTask &T, const uint8_t *ref, int len1, const uint8_t *qry, int len, int score_f, int end_i, int end_j,
+                        int *H, int *E, const Rows &R, uint8_t *trace, uint8_t *ops, uint16_t *cg, int cig_cap, FqSwOut &O) {
+  if (score_f < 1) return;
+  int start_i, start_j, score_r;
+  fq_sw_reverse(ref, qry, score_f, end_i, end_j, H, E, &start_i, &start_j, &score_r);
+  int n_ops = 0, fi = 0, fj = 0, score_g;
+  const int jmax = (end_i - start_i > end_j - start_j ? end_i - start_i : end_j - start_j) + 1;
+  for (int b = FQ_BAND;; b <<= 1) {   // doubling band (stdaln.c:705-716)
+    score_g = fq_global_align(ref + start_i - 1, end_i - start_i + 1, qry + start_j - 1, end_j - start_j + 1, b, -1, R, trace, ops, &n_ops, &fi, &fj);
+    if (score_g == score_r || score_f == score_g) break;
+    if (b > jmax) break;
+  }
+  if (score_r > score_g && score_f > score_g) return;   // "Potential bug" arm of the reference: ret < 0
+  fq_sw_post(T, ref, qry, len, end_j, start_i, start_j, fi, fj, ops, n_ops, cg, cig_cap, O);
+}
 FQ_HD bool fq_sw_prologue(const FqSwArgs &A, const FqSwTask &T, uint8_t *ref, uint8_t *qry, int *len_out, int *len1_out) {
   const int len = A.len_trim[T.read];
   const uint8_t *row = A.seq + (size_t)T.read * (size_t)A.stride;
