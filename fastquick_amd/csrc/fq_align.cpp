@@ -89,6 +89,9 @@ struct fq_ctx {
   DevBuf<uint32_t> d_heads, d_naln, d_status;
   DevBuf<uint32_t> d_wfull;
   DevBuf<FqPos> d_prec;
+  DevBuf<uint8_t> d_bid_end;
+  DevBuf<int32_t> d_order;
+  DevBuf<uint32_t> d_order_cnt;
   DevBuf<FqEntry> d_pool;
   DevBuf<FqAln> d_aln, d_packed;
   DevBuf<uint64_t> d_off;
@@ -498,18 +501,19 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
       next_work.clear();
       for (size_t c0 = 0; c0 < work.size(); c0 += chunk_reads[tier]) {
         const int nw = (int)std::min(chunk_reads[tier], work.size() - c0);
-        CKM(c->d_work.ensure(nw) && c->d_wfull.ensure((size_t)nw * 2 * Lpad) && c->d_prec.ensure((size_t)nw * 2 * Ppad) && c->d_winfo.ensure(nw) &&
+        CKM(c->d_work.ensure(nw) && c->d_wfull.ensure((size_t)nw * 2 * Lpad) && c->d_prec.ensure((size_t)nw * 2 * Ppad) && c->d_winfo.ensure(nw) && c->d_bid_end.ensure((size_t)nw * 2) && c->d_order.ensure(nw) && c->d_order_cnt.ensure(2 * FQ_ORDER_KEYS) &&
             c->d_aln.ensure((size_t)nw * T.aln_cap) && c->d_naln.ensure(nw) && c->d_status.ensure(nw) && c->d_off.ensure(nw + 1));
         CK(fqdev::h2d(c->d_work.p, work.data() + c0, (size_t)nw * 4));
         FqWidthArgs wa{};
         wa.ix = ix->dev; wa.o = c->ko; wa.seq = c->d_seq.p; wa.stride = stride; wa.len_trim = c->d_len_trim.p; wa.read_list = c->d_read_list.p;
         wa.work = c->d_work.p; wa.n_work = nw; wa.wfull = c->d_wfull.p; wa.wstride = Lpad;
-        wa.prec = c->d_prec.p; wa.pstride = Ppad; wa.winfo = c->d_winfo.p; wa.maxdiff_lut = c->d_maxdiff.p; wa.counters = c->d_counters.p;
+        wa.prec = c->d_prec.p; wa.pstride = Ppad; wa.winfo = c->d_winfo.p; wa.maxdiff_lut = c->d_maxdiff.p; wa.bid_end = c->d_bid_end.p; wa.counters = c->d_counters.p;
         fqdev::time_begin(FQ_K_WIDTH);
         CK(fqdev::launch_width(wa));
+        CK(fqdev::launch_order(c->d_bid_end.p, nw, c->d_order.p, c->d_order_cnt.p));   // long searches first
         fqdev::time_end(FQ_K_WIDTH);
         FqGapArgs ga{};
-        ga.ix = ix->dev; ga.o = c->ko; ga.o.n_buckets = nb_need; ga.n_work = nw; ga.winfo = c->d_winfo.p;
+        ga.ix = ix->dev; ga.o = c->ko; ga.o.n_buckets = nb_need; ga.n_work = nw; ga.winfo = c->d_winfo.p; ga.order = getenv("FQ_GAP_NO_ORDER") ? nullptr : c->d_order.p;
         ga.wfull = c->d_wfull.p; ga.wstride = Lpad; ga.prec = c->d_prec.p; ga.pstride = Ppad;
         ga.pool = c->d_pool.p; ga.heads = c->d_heads.p; ga.tier = T; ga.aln = c->d_aln.p; ga.n_aln = c->d_naln.p; ga.status = c->d_status.p;
         ga.counters = c->d_counters.p; ga.queue = c->d_queue.p;

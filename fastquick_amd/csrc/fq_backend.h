@@ -34,6 +34,8 @@ int launch_compact(const uint8_t *filtered, int n_pairs, int32_t *read_list, int
 // out[2*sp+e] = {len_trim, filtered, sidx} of read e of surviving pair sp
 int launch_surv_gather(const int32_t *pair_list, int n_surv, int n_pairs, const int32_t *len_trim, const uint8_t *filtered, const int32_t *sidx, FqSurvInfo *out);
 int launch_width(const FqWidthArgs &a);
+// order[0..n) = the work items sorted by descending fq_order_key (any order inside a key); cnt: FQ_ORDER_KEYS*2 words of scratch
+int launch_order(const uint8_t *bid_end, int n, int32_t *order, uint32_t *cnt);
 // number of persistent lanes launch_gap() will start for these arguments (sizes a.pool / a.heads)
 int gap_lane_slots(const FqGapArgs &a);
 int launch_gap(const FqGapArgs &a);

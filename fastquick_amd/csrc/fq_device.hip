@@ -599,6 +599,43 @@ int launch_width(const FqWidthArgs &a) {
   FQ_HIP(hipGetLastError());
   return 0;
 }
+// counting sort of the work items by scheduling key: block-local counts in LDS, one global atomic per key and block
+__global__ void __launch_bounds__(256) k_order_count(const uint8_t *bid_end, int n, uint32_t *cnt) {
+  __shared__ uint32_t h[FQ_ORDER_KEYS];
+  if (threadIdx.x < FQ_ORDER_KEYS) h[threadIdx.x] = 0;
+  __syncthreads();
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < n) atomicAdd(&h[fq_order_key(bid_end, w)], 1u);
+  __syncthreads();
+  if (threadIdx.x < FQ_ORDER_KEYS && h[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], h[threadIdx.x]);
+}
+__global__ void __launch_bounds__(256) k_order_scatter(const uint8_t *bid_end, int n, uint32_t *cnt, int32_t *order, int asc) {
+  __shared__ uint32_t h[FQ_ORDER_KEYS], base[FQ_ORDER_KEYS];
+  if (threadIdx.x < FQ_ORDER_KEYS) h[threadIdx.x] = 0;
+  __syncthreads();
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  int key = 0;
+  uint32_t rank = 0;
+  if (w < n) { key = fq_order_key(bid_end, w); rank = atomicAdd(&h[key], 1u); }
+  __syncthreads();
+  if (threadIdx.x < FQ_ORDER_KEYS) {
+    // start of key k in the output = number of items with a larger key (descending order); cursors live behind the counts
+    uint32_t start = 0;
+    if (asc) { for (int k = 0; k < (int)threadIdx.x; ++k) start += cnt[k]; }
+    else { for (int k = FQ_ORDER_KEYS - 1; k > (int)threadIdx.x; --k) start += cnt[k]; }
+    base[threadIdx.x] = h[threadIdx.x] ? start + atomicAdd(&cnt[FQ_ORDER_KEYS + threadIdx.x], h[threadIdx.x]) : 0u;
+  }
+  __syncthreads();
+  if (w < n) order[base[key] + rank] = w;
+}
+int launch_order(const uint8_t *bid_end, int n, int32_t *order, uint32_t *cnt) {
+  if (n <= 0) return 0;
+  FQ_HIP(hipMemsetAsync(cnt, 0, 2 * FQ_ORDER_KEYS * 4, g_stream));
+  hipLaunchKernelGGL(k_order_count, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, bid_end, n, cnt);
+  hipLaunchKernelGGL(k_order_scatter, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, bid_end, n, cnt, order, getenv("FQ_GAP_ORDER_ASC") ? 1 : 0);   // (experiment hook: ascending)
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
 int gap_lane_slots(const FqGapArgs &a) {
   if (a.n_work <= 0) return 0;
   if (a.tier.coop) return (int)std::min<unsigned>((unsigned)a.n_work, a.tier.exact ? 64u : 1024u);   // wavefronts, one pool each

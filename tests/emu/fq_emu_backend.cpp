@@ -46,6 +46,12 @@ int launch_surv_gather(const int32_t *pair_list, int n_surv, int n_pairs, const 
   return 0;
 }
 int launch_width(const FqWidthArgs &a) { uint8_t seed_bits[FQ_SEED_MAX]; for (int t = 0; t < a.n_work * 2; ++t) fq_width_thread(a, t, seed_bits, 1); return 0; }
+int launch_order(const uint8_t *bid_end, int n, int32_t *order, uint32_t *) {
+  int at = 0;
+  for (int k = FQ_ORDER_KEYS - 1; k >= 0; --k)
+    for (int w = 0; w < n; ++w) if (fq_order_key(bid_end, w) == k) order[at++] = w;
+  return 0;
+}
 struct SeqFetch { uint32_t *next; int n; uint32_t operator()(uint32_t k) const { const uint32_t at = *next; *next += k; return at; } };
 int gap_lane_slots(const FqGapArgs &a) { return a.n_work > 0 ? 1 : 0; }
 int launch_gap(const FqGapArgs &a_in) {
