@@ -104,6 +104,76 @@ FQ_HD uint32_t fq_sa_lookup(const FqFM &f, uint32_t k, uint32_t *steps) {
   return sa + f.sa[k / f.sa_intv];
 }
 
+// register-friendly 4-way select (a runtime-indexed local array would be placed in scratch memory)
+// Written with masks, not ?: -- hipcc turns "cond ? mem_a : mem_b" into a load from a *selected address*, and a variable
+// address into a local object pins that object (and everything around it) in scratch memory.
+FQ_HD uint32_t fq_pick2(uint32_t x1, uint32_t x0, int a) { const uint32_t m = 0u - (uint32_t)(a & 1); return (x1 & m) | (x0 & ~m); }   // a ? x1 : x0
+FQ_HD uint64_t fq_pick2p(uint64_t x1, uint64_t x0, int a) { const uint64_t m = 0ull - (uint64_t)(a & 1); return (x1 & m) | (x0 & ~m); }
+FQ_HD uint32_t fq_sel4v(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, int c) {
+  const uint32_t m0 = 0u - (uint32_t)(c == 0), m1 = 0u - (uint32_t)(c == 1), m2 = 0u - (uint32_t)(c == 2), m3 = 0u - (uint32_t)(c == 3);
+  return (v0 & m0) | (v1 & m1) | (v2 & m2) | (v3 & m3);
+}
+FQ_HD uint32_t fq_sel4(const uint32_t *v, int c) { return fq_sel4v(v[0], v[1], v[2], v[3], c & 3); }
+
+// raw 32-byte Occ block fetch shared by the single-base and the four-base rank.  The two bit planes are kept as 32-bit
+// halves and the prefix mask is built from 32-bit shifts: 64-bit shifts are quarter-rate on CDNA4 and this code sits on the
+// dependent chain of every search step.
+struct FqBlkRaw { uint32_t c0, c1, c2, c3; uint32_t lo0, lo1, hi0, hi1; uint32_t mk0, mk1; bool valid; };   // *0 = bases 0..31 (bits 63..32 of the plane)
+FQ_HD FqBlkRaw fq_blk_none() {
+  FqBlkRaw r;
+  r.valid = false;
+  r.c0 = r.c1 = r.c2 = r.c3 = 0; r.lo0 = r.lo1 = r.hi0 = r.hi1 = 0; r.mk0 = r.mk1 = 0;
+  return r;
+}
+FQ_HD FqBlkRaw fq_blk_load(const FqOccBlk *blk, uint32_t primary, uint32_t k) {
+  FqBlkRaw r = fq_blk_none();
+  r.valid = k != 0xffffffffu;
+  if (r.valid) {
+    k = k >= primary ? k - 1 : k;
+    const FqOccBlk *b = blk + (k >> 6);
+    r.c0 = b->cnt[0]; r.c1 = b->cnt[1]; r.c2 = b->cnt[2]; r.c3 = b->cnt[3];
+    const uint64_t lo = b->lo, hi = b->hi;
+    r.lo0 = (uint32_t)(lo >> 32); r.lo1 = (uint32_t)lo; r.hi0 = (uint32_t)(hi >> 32); r.hi1 = (uint32_t)hi;
+    const uint32_t t = k & 63;                     // bases 0..t of the block are counted
+    const uint32_t t0 = t < 32 ? t : 31, t1 = t < 32 ? 0 : t - 32;
+    r.mk0 = 0xffffffffu << (31 - t0);
+    r.mk1 = t < 32 ? 0u : (0xffffffffu << (31 - t1));
+  }
+  return r;
+}
+FQ_HD FqBlkRaw fq_blk_load(const FqFM &f, uint32_t k) { return fq_blk_load(f.blk, f.primary, k); }
+FQ_HD uint32_t fq_popc2(uint32_t a, uint32_t b) { return (uint32_t)(FQ_POPC32(a) + FQ_POPC32(b)); }
+FQ_HD uint32_t fq_blk_occ1(const FqBlkRaw &r, int c) {
+  if (!r.valid) return 0;
+  const uint32_t fh = 0u - (uint32_t)(((c >> 1) & 1) ^ 1), fl = 0u - (uint32_t)((c & 1) ^ 1);   // flip masks: select base c
+  const uint32_t x0 = (r.hi0 ^ fh) & (r.lo0 ^ fl) & r.mk0, x1 = (r.hi1 ^ fh) & (r.lo1 ^ fl) & r.mk1;
+  return fq_sel4v(r.c0, r.c1, r.c2, r.c3, c) + fq_popc2(x0, x1);
+}
+FQ_HD void fq_blk_occ4(const FqBlkRaw &r, uint32_t o[4]) {
+  if (!r.valid) { o[0] = o[1] = o[2] = o[3] = 0; return; }
+  const uint32_t nh0 = ~r.hi0 & r.mk0, nh1 = ~r.hi1 & r.mk1, h0 = r.hi0 & r.mk0, h1 = r.hi1 & r.mk1;
+  o[0] = r.c0 + fq_popc2(nh0 & ~r.lo0, nh1 & ~r.lo1);
+  o[1] = r.c1 + fq_popc2(nh0 & r.lo0, nh1 & r.lo1);
+  o[2] = r.c2 + fq_popc2(h0 & ~r.lo0, h1 & ~r.lo1);
+  o[3] = r.c3 + fq_popc2(h0 & r.lo0, h1 & r.lo1);
+}
+// Occ(c, k-1) and Occ(c, l) of one backward-extension step.  Once the interval is narrow both rows sit in the same 64-base block
+// most of the time: the block is fetched once and only the prefix mask differs.
+FQ_HD void fq_occ1_pair(const FqFM &f, uint32_t km1, uint32_t l, int c, uint32_t *ok, uint32_t *ol) {
+  const FqBlkRaw bk = fq_blk_load(f, km1);
+  FqBlkRaw bl;
+  const uint32_t ak = km1 >= f.primary ? km1 - 1 : km1, al = l >= f.primary ? l - 1 : l;
+  if (bk.valid && l != 0xffffffffu && (ak >> 6) == (al >> 6)) {
+    bl = bk;
+    const uint32_t t = al & 63, t0 = t < 32 ? t : 31, t1 = t < 32 ? 0 : t - 32;
+    bl.mk0 = 0xffffffffu << (31 - t0);
+    bl.mk1 = t < 32 ? 0u : (0xffffffffu << (31 - t1));
+  } else bl = fq_blk_load(f, l);
+  *ok = fq_blk_occ1(bk, c);
+  *ol = fq_blk_occ1(bl, c);
+}
+
+
 // ---- K_prep: encode + quality trim + k-mer filter ----------------------------------------------
 // bwa_read_seq_with_hash_dev (src/BwtMapper.cpp:526-588), bwa_trim_read (libbwa/bwaseqio.c:75-88),
 // IsReadInHashByCountMoreChunck + CountKmerHitInHash (src/BwtIndexer.cpp:441-456, 261-313).
@@ -284,7 +354,8 @@ FQ_HD void fq_width_thread(const FqWidthArgs &A, int t, uint8_t *seed_bits, int 
       const int c = fq_base(v, strand, seed_off + i);
       if (c < 4) {
         touches += fq_touch2(f, k - 1, l, true);
-        const uint32_t ok = fq_occ1(f, k - 1, c), ol = fq_occ1(f, l, c);
+        uint32_t ok, ol;
+        fq_occ1_pair(f, k - 1, l, c, &ok, &ol);
         k = f.L2[c] + ok + 1;
         l = f.L2[c] + ol;
       }
@@ -307,7 +378,8 @@ FQ_HD void fq_width_thread(const FqWidthArgs &A, int t, uint8_t *seed_bits, int 
         namb += c > 3;
         if (c < 4) {
           touches += fq_touch2(f, k - 1, l, true);
-          const uint32_t ok = fq_occ1(f, k - 1, c), ol = fq_occ1(f, l, c);
+          uint32_t ok, ol;
+        fq_occ1_pair(f, k - 1, l, c, &ok, &ol);
           k = f.L2[c] + ok + 1;
           l = f.L2[c] + ol;
         }
@@ -400,60 +472,6 @@ struct FqGapStoreLds {
   FQ_HD uint32_t head_get(int b) const { return head[b * stride]; }
   FQ_HD void head_set(int b, uint32_t slot) const { head[b * stride] = (uint16_t)slot; }
 };
-
-// register-friendly 4-way select (a runtime-indexed local array would be placed in scratch memory)
-// Written with masks, not ?: -- hipcc turns "cond ? mem_a : mem_b" into a load from a *selected address*, and a variable
-// address into a local object pins that object (and everything around it) in scratch memory.
-FQ_HD uint32_t fq_pick2(uint32_t x1, uint32_t x0, int a) { const uint32_t m = 0u - (uint32_t)(a & 1); return (x1 & m) | (x0 & ~m); }   // a ? x1 : x0
-FQ_HD uint64_t fq_pick2p(uint64_t x1, uint64_t x0, int a) { const uint64_t m = 0ull - (uint64_t)(a & 1); return (x1 & m) | (x0 & ~m); }
-FQ_HD uint32_t fq_sel4v(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, int c) {
-  const uint32_t m0 = 0u - (uint32_t)(c == 0), m1 = 0u - (uint32_t)(c == 1), m2 = 0u - (uint32_t)(c == 2), m3 = 0u - (uint32_t)(c == 3);
-  return (v0 & m0) | (v1 & m1) | (v2 & m2) | (v3 & m3);
-}
-FQ_HD uint32_t fq_sel4(const uint32_t *v, int c) { return fq_sel4v(v[0], v[1], v[2], v[3], c & 3); }
-
-// raw 32-byte Occ block fetch shared by the single-base and the four-base rank.  The two bit planes are kept as 32-bit
-// halves and the prefix mask is built from 32-bit shifts: 64-bit shifts are quarter-rate on CDNA4 and this code sits on the
-// dependent chain of every search step.
-struct FqBlkRaw { uint32_t c0, c1, c2, c3; uint32_t lo0, lo1, hi0, hi1; uint32_t mk0, mk1; bool valid; };   // *0 = bases 0..31 (bits 63..32 of the plane)
-FQ_HD FqBlkRaw fq_blk_none() {
-  FqBlkRaw r;
-  r.valid = false;
-  r.c0 = r.c1 = r.c2 = r.c3 = 0; r.lo0 = r.lo1 = r.hi0 = r.hi1 = 0; r.mk0 = r.mk1 = 0;
-  return r;
-}
-FQ_HD FqBlkRaw fq_blk_load(const FqOccBlk *blk, uint32_t primary, uint32_t k) {
-  FqBlkRaw r = fq_blk_none();
-  r.valid = k != 0xffffffffu;
-  if (r.valid) {
-    k = k >= primary ? k - 1 : k;
-    const FqOccBlk *b = blk + (k >> 6);
-    r.c0 = b->cnt[0]; r.c1 = b->cnt[1]; r.c2 = b->cnt[2]; r.c3 = b->cnt[3];
-    const uint64_t lo = b->lo, hi = b->hi;
-    r.lo0 = (uint32_t)(lo >> 32); r.lo1 = (uint32_t)lo; r.hi0 = (uint32_t)(hi >> 32); r.hi1 = (uint32_t)hi;
-    const uint32_t t = k & 63;                     // bases 0..t of the block are counted
-    const uint32_t t0 = t < 32 ? t : 31, t1 = t < 32 ? 0 : t - 32;
-    r.mk0 = 0xffffffffu << (31 - t0);
-    r.mk1 = t < 32 ? 0u : (0xffffffffu << (31 - t1));
-  }
-  return r;
-}
-FQ_HD FqBlkRaw fq_blk_load(const FqFM &f, uint32_t k) { return fq_blk_load(f.blk, f.primary, k); }
-FQ_HD uint32_t fq_popc2(uint32_t a, uint32_t b) { return (uint32_t)(FQ_POPC32(a) + FQ_POPC32(b)); }
-FQ_HD uint32_t fq_blk_occ1(const FqBlkRaw &r, int c) {
-  if (!r.valid) return 0;
-  const uint32_t fh = 0u - (uint32_t)(((c >> 1) & 1) ^ 1), fl = 0u - (uint32_t)((c & 1) ^ 1);   // flip masks: select base c
-  const uint32_t x0 = (r.hi0 ^ fh) & (r.lo0 ^ fl) & r.mk0, x1 = (r.hi1 ^ fh) & (r.lo1 ^ fl) & r.mk1;
-  return fq_sel4v(r.c0, r.c1, r.c2, r.c3, c) + fq_popc2(x0, x1);
-}
-FQ_HD void fq_blk_occ4(const FqBlkRaw &r, uint32_t o[4]) {
-  if (!r.valid) { o[0] = o[1] = o[2] = o[3] = 0; return; }
-  const uint32_t nh0 = ~r.hi0 & r.mk0, nh1 = ~r.hi1 & r.mk1, h0 = r.hi0 & r.mk0, h1 = r.hi1 & r.mk1;
-  o[0] = r.c0 + fq_popc2(nh0 & ~r.lo0, nh1 & ~r.lo1);
-  o[1] = r.c1 + fq_popc2(nh0 & r.lo0, nh1 & r.lo1);
-  o[2] = r.c2 + fq_popc2(h0 & ~r.lo0, h1 & ~r.lo1);
-  o[3] = r.c3 + fq_popc2(h0 & r.lo0, h1 & r.lo1);
-}
 
 // wavefront-level helpers.  The host-loop build (tests/emu) runs one lane at a time: a "wavefront" of one.
 #if defined(__HIP_DEVICE_COMPILE__)
