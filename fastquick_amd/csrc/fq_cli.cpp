@@ -115,7 +115,7 @@ int main(int argc, char **argv) {
     else if (f == "--l") A.o.seed_len = atoi(need(""));
     else if (f == "--k") A.o.max_seed_diff = atoi(need(""));
     else if (f == "--m") A.o.max_entries = atoi(need(""));
-    else if (f == "--t") A.o.host_threads = atoi(need(""));
+    else if (f == "--t") A.o.host_threads = atoi(need(""));   // accepted for command-line compatibility (see fastquick_amd.h)
     else if (f == "--R") A.o.max_top2 = atoi(need(""));
     else if (f == "--q") A.o.trim_qual = atoi(need(""));
     else if (f == "--N") { A.o.mode |= 0x10; A.o.max_top2 = 0x7fffffff; }
