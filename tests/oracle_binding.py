@@ -124,9 +124,10 @@ def pack_names(names, stride: int = 64) -> bytes:
 class OracleAligner:
     """Stateful oracle context (drand48 stream, last_ii, (k,l) cache persist across batches)."""
 
-    def __init__(self, prefix: str, opts: Opts | None = None):
+    def __init__(self, prefix: str, opts: Opts | None = None, share: "OracleAligner | None" = None):
         self.L = lib()
-        self.ix = self.L.fqo_index_load(prefix.encode())
+        self.owns_index = share is None
+        self.ix = share.ix if share is not None else self.L.fqo_index_load(prefix.encode())   # the index is read-only: contexts may share it
         if not self.ix:
             raise RuntimeError("oracle: cannot load index %s" % prefix)
         self.opts = opts or default_opts()
@@ -135,7 +136,8 @@ class OracleAligner:
     def close(self):
         if self.ctx:
             self.L.fqo_ctx_free(self.ctx)
-            self.L.fqo_index_free(self.ix)
+            if self.owns_index:
+                self.L.fqo_index_free(self.ix)
             self.ctx = None
 
     def counters(self) -> dict:
