@@ -251,7 +251,7 @@ def main() -> None:
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle_binding as ob
         b = batches[0]
-        n_cpu = args.cpu_sample_pairs or (262144 if args.mix == "wgs" else 8192)
+        n_cpu = args.cpu_sample_pairs or (131072 if args.mix == "wgs" else 8192)
         n_cpu = min(n_cpu, args.pairs)
         T = max(1, min(args.cpu_threads, os.cpu_count() or 1, args.pairs // n_cpu))
         names = [b"r%09d" % i for i in range(n_cpu)]

@@ -694,7 +694,9 @@ int launch_sw(const FqSwArgs &a) {
   if (lds > kLdsBudget) { g_err = "SW window too large for LDS (" + std::to_string(a.RL) + " bases)"; return -5; }
   FqSwArgs b = a;
   const size_t trace_bytes = (size_t)(a.RL + 1) * (a.QL + 1) + 16;
-  b.trace_in_lds = lds + trace_bytes <= kLdsBudget ? 1 : 0;   // else the fill keeps its trace matrix in the task's global scratch
+  // The trace matrix in LDS makes a task faster but limits a CU to one block; with more tasks than CUs it is better to keep it in
+  // the task's global scratch and have every task resident at once (each spends most of its time in the serial reverse pass).
+  b.trace_in_lds = (lds + trace_bytes <= kLdsBudget && a.n_task <= 256) ? 1 : 0;
   if (b.trace_in_lds) lds += trace_bytes;
   static std::atomic<bool> attr_set{false};
   if (!attr_set) { FQ_HIP(hipFuncSetAttribute((const void *)k_sw_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget)); attr_set = true; }
