@@ -9,10 +9,13 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/fastquick_amd.h"
@@ -60,6 +63,36 @@ struct FastqReader {
   }
 };
 
+// One end of one chunk, in the layout fq_read_batch_t wants: fixed-stride rows, filled by that file's reader thread.
+struct EndChunk {
+  std::vector<uint8_t> seq, qual;
+  std::vector<int32_t> len;
+  std::vector<char> names;
+  int n = 0, stride = 0, name_stride = 0;
+  bool eof = false;
+  std::string error;
+};
+// Reads up to `cap` records of one FASTQ file into `c` (kseq_read3_fpc semantics, see FastqReader::next).  Rows are `stride`
+// bytes (a read longer than that is an error: the reference, too, wants reads of one length, kseq.h:362-365).
+void fill_chunk(FastqReader &r, EndChunk &c, long long cap, int stride, int name_stride) {
+  c.n = 0; c.stride = stride; c.name_stride = name_stride; c.error.clear();
+  c.seq.assign((size_t)cap * stride, 0); c.qual.assign((size_t)cap * stride, 0);
+  c.len.assign((size_t)cap, 0); c.names.assign((size_t)cap * name_stride, 0);
+  std::string nm, sq, ql;
+  while (c.n < cap) {
+    if (!r.next(nm, sq, ql)) { c.eof = true; break; }
+    const size_t t = nm.size();
+    if (t > 2 && nm[t - 2] == '/' && (nm[t - 1] == '1' || nm[t - 1] == '2')) nm.resize(t - 2);
+    if ((int)sq.size() > stride) { c.error = "read " + nm + " is longer than the first read of its file (" + std::to_string(sq.size()) + " > " + std::to_string(stride) + ")"; return; }
+    if ((int)nm.size() >= name_stride) nm.resize((size_t)name_stride - 1);
+    memcpy(&c.seq[(size_t)c.n * stride], sq.data(), sq.size());
+    memcpy(&c.qual[(size_t)c.n * stride], ql.data(), ql.size());
+    c.len[c.n] = (int32_t)sq.size();
+    memcpy(&c.names[(size_t)c.n * name_stride], nm.data(), nm.size());
+    ++c.n;
+  }
+}
+
 struct Args {
   std::string fq1, fq2, out_prefix = "Empty", index_prefix = "Empty";
   bool sam_out = false;
@@ -73,7 +106,7 @@ int usage() {
   fprintf(stderr, "Usage: FASTQuick_amd align --index_prefix P --fastq_1 R1.fq[.gz] --fastq_2 R2.fq[.gz] --out_prefix O --sam_out\n"
                   "                       [--q INT] [--n FLOAT|INT] [--kmer_thresh INT] [--o INT] [--e INT] [--i INT] [--d INT] [--l INT] [--k INT]\n"
                   "                       [--m INT] [--R INT] [--N] [--L] [--max_isize INT] [--max_occ INT] [--is_sw] [--n_multi INT] [--N_multi INT]\n"
-                  "                       [--ap_prior FLOAT] [--force_isize] [--t INT] [--chunk_pairs INT] [--device INT]\n"
+                  "                       [--ap_prior FLOAT] [--force_isize] [--t INT] [--chunk_pairs INT] [--batch_pairs INT] [--device INT]\n"
                   "       FASTQuick_amd index --ref REDUCED.FASTQuick.fa [--rollhash]\n");
   return 1;
 }
@@ -128,6 +161,7 @@ int main(int argc, char **argv) {
     else if (f == "--ap_prior") A.o.ap_prior = atof(need(""));
     else if (f == "--force_isize") A.o.force_isize = 1;
     else if (f == "--chunk_pairs") A.chunk_pairs = atoll(need(""));
+    else if (f == "--batch_pairs") A.o.batch_pairs = atoi(need(""));   // READ_BUFFER_SIZE of the run to reproduce (default 262144)
     else if (f == "--device") A.device = atoi(need(""));
     else if (f == "--RG" || f == "--frac_samp" || f == "--fq_list" || f == "--bam_in" || f == "--cal_dup" || f == "--I") die(f + " is not supported by this build");
     else die("unknown option " + f);
@@ -138,7 +172,8 @@ int main(int argc, char **argv) {
   if (A.index_prefix == "Empty") die("--index_prefix is required");
   if (A.fq1.empty() || A.fq2.empty()) die("--fastq_1 and --fastq_2 are required (paired-end path)");
   if (!A.sam_out) die("BAM output (genome-coordinate translation + BGZF; SURVEY 8f.2) is not built yet: pass --sam_out");
-  A.chunk_pairs = std::max<long long>(262144, A.chunk_pairs / 262144 * 262144);
+  if (A.o.batch_pairs < 1) die("--batch_pairs must be positive");
+  A.chunk_pairs = std::max<long long>(A.o.batch_pairs, A.chunk_pairs / A.o.batch_pairs * A.o.batch_pairs);   // whole reference batches per chunk
 
   fq_index_t *ix = nullptr;
   const std::string pre = A.index_prefix + ".FASTQuick.fa";
@@ -154,43 +189,50 @@ int main(int argc, char **argv) {
     fq_sam_header(ix, h.data(), n + 1);
     fwrite(h.data(), 1, (size_t)n, stdout);
   }
+  // FASTQ front end: one reader thread per file tokenises the next chunk into flat buffers while the device aligns the current
+  // one (the reference, too, decodes the two files on two IO threads: BwtMapper.cpp:1873-1935).
   FastqReader r1(A.fq1), r2(A.fq2);
-  std::string n1, s1, q1, n2, s2, q2;
+  int stride = 0;
+  {   // row stride from the first record of each file
+    std::string nm, sq, ql;
+    FastqReader p1(A.fq1), p2(A.fq2);
+    size_t l = 0;
+    if (p1.next(nm, sq, ql)) l = std::max(l, sq.size());
+    if (p2.next(nm, sq, ql)) l = std::max(l, sq.size());
+    stride = (int)((std::max<size_t>(l, 16) + 15) & ~(size_t)15);
+  }
+  const int name_stride = 256;   // the reference keeps up to 301 name bytes (bwaseqio.c:226); longer names are cut here
   long long num_read = 0, filtered = 0, unmapped = 0, num_base = 0;
   std::vector<char> sam;
-  bool more = true;
-  while (more) {
-    // one chunk = a whole number of reference batches (READ_BUFFER_SIZE pairs), so batch boundaries fall where the reference's do
-    std::vector<std::string> names, seqs[2], quals[2];
-    int stride = 16;
-    while ((long long)names.size() < A.chunk_pairs) {
-      const bool a = r1.next(n1, s1, q1), b = r2.next(n2, s2, q2);
-      if (!a || !b) { more = false; break; }
-      auto strip = [](std::string &nm) { const size_t t = nm.size(); if (t > 2 && nm[t - 2] == '/' && (nm[t - 1] == '1' || nm[t - 1] == '2')) nm.resize(t - 2); };
-      strip(n1); strip(n2);
-      if (names.size() % 262144 == 0 && n1 != n2)                                       // src/BwtMapper.cpp:2088-2092
-        die("Abort, please make sure input pair of fastq files are in the same order!");
-      names.push_back(n1);
-      seqs[0].push_back(s1); quals[0].push_back(q1);
-      seqs[1].push_back(s2); quals[1].push_back(q2);
-      stride = std::max<int>(stride, (int)std::max(s1.size(), s2.size()));
-    }
-    const int n = (int)names.size();
+  EndChunk bufs[2][2];   // [slot][end]
+  auto read_both = [&](int slot) {
+    std::thread t0(fill_chunk, std::ref(r1), std::ref(bufs[slot][0]), A.chunk_pairs, stride, name_stride);
+    std::thread t1(fill_chunk, std::ref(r2), std::ref(bufs[slot][1]), A.chunk_pairs, stride, name_stride);
+    t0.join(); t1.join();
+  };
+  read_both(0);
+  for (int slot = 0;; slot ^= 1) {
+    EndChunk &e0 = bufs[slot][0], &e1 = bufs[slot][1];
+    if (!e0.error.empty()) die(e0.error);
+    if (!e1.error.empty()) die(e1.error);
+    const int n = std::min(e0.n, e1.n);
     if (n == 0) break;
-    stride = (stride + 15) & ~15;
-    size_t name_stride = 8;
-    for (auto &nm : names) name_stride = std::max(name_stride, nm.size() + 1);
-    std::vector<uint8_t> seq((size_t)2 * n * stride, 0), qual((size_t)2 * n * stride, 0);
+    const bool last = e0.eof || e1.eof || e0.n != e1.n;
+    std::thread prefetch;
+    if (!last) prefetch = std::thread(read_both, slot ^ 1);          // next chunk while this one is on the device
+    for (int i = 0; i < n; i += A.o.batch_pairs)                     // src/BwtMapper.cpp:2088-2092: checked once per reference batch
+      if (strcmp(&e0.names[(size_t)i * name_stride], &e1.names[(size_t)i * name_stride]) != 0)
+        die("Abort, please make sure input pair of fastq files are in the same order!");
+    // the two ends back to back: [end][pair][stride]
+    std::vector<uint8_t> seq((size_t)2 * n * stride), qual((size_t)2 * n * stride);
     std::vector<int32_t> len((size_t)2 * n);
-    std::vector<char> nm((size_t)n * name_stride, 0);
-    for (int e = 0; e < 2; ++e)
-      for (int i = 0; i < n; ++i) {
-        memcpy(&seq[((size_t)e * n + i) * stride], seqs[e][i].data(), seqs[e][i].size());
-        memcpy(&qual[((size_t)e * n + i) * stride], quals[e][i].data(), quals[e][i].size());
-        len[(size_t)e * n + i] = (int32_t)seqs[e][i].size();
-      }
-    for (int i = 0; i < n; ++i) memcpy(&nm[(size_t)i * name_stride], names[i].data(), names[i].size());
-    fq_read_batch_t in = {n, stride, seq.data(), qual.data(), len.data(), nm.data(), (int32_t)name_stride};
+    for (int e = 0; e < 2; ++e) {
+      const EndChunk &c = bufs[slot][e];
+      memcpy(&seq[(size_t)e * n * stride], c.seq.data(), (size_t)n * stride);
+      memcpy(&qual[(size_t)e * n * stride], c.qual.data(), (size_t)n * stride);
+      memcpy(&len[(size_t)e * n], c.len.data(), (size_t)n * 4);
+    }
+    fq_read_batch_t in = {n, stride, seq.data(), qual.data(), len.data(), e0.names.data(), (int32_t)name_stride};
     fq_result_batch_t res;
     rc = fq_align_batch(ctx, &in, &res);
     if (rc) die(std::string("fq_align_batch failed: ") + fq_ctx_last_error(ctx));
@@ -200,6 +242,8 @@ int main(int argc, char **argv) {
     fwrite(sam.data(), 1, (size_t)sz, stdout);
     num_read += 2LL * n; filtered += res.n_both_filtered; unmapped += res.n_both_unmapped; num_base += res.n_bases;
     fprintf(stderr, "NOTICE - %lld sequences are processed.\n", num_read);
+    if (prefetch.joinable()) prefetch.join();
+    if (last) break;
   }
   fflush(stdout);
   notice("%lld sequences are loaded.", num_read);

@@ -125,16 +125,15 @@ def test_full_batch_properties(lib, tmp_path):
 
 def test_cli_sam_out_matches_reference_golden(golden_cases, tmp_path):
     """`FASTQuick_amd align --sam_out` (C++ front end: gz FASTQ tokenizer + C ABI) on the golden FASTQ files must print the
-    reference's SAM text.  --chunk_pairs is irrelevant here (one reference batch per golden case would need batch_pairs,
-    so only cases whose golden batch covers the whole input are used)."""
+    reference's SAM text, also when the input spans several chunks (reader threads prefetch the next chunk while the device
+    works on the current one)."""
     import gzip
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "fastquick_amd", "bin", "FASTQuick_amd")
     assert os.path.exists(exe), "build() must produce the CLI"
-    for tag in ("repeat", "nref"):
-        g = golden_cases[tag]
-        assert g["batch"] >= g["n_pairs"]
+    for tag, chunk_batches in (("repeat", 1), ("nref", 1), ("basic", 1), ("isize", 2)):
+        g = golden_cases[tag]   # several chunks per run where the golden batch is smaller than the input: the prefetching reader
         fq = []
         for k in ("fq1", "fq2"):      # exercise the gz path of the tokenizer
             gz = str(tmp_path / (tag + os.path.basename(g[k]) + ".gz"))
@@ -145,6 +144,7 @@ def test_cli_sam_out_matches_reference_golden(golden_cases, tmp_path):
         cmd = [exe, "align", "--index_prefix", prefix, "--fastq_1", fq[0], "--fastq_2", fq[1], "--out_prefix", str(tmp_path / tag), "--sam_out"]
         if g["trim_qual"]:
             cmd += ["--q", str(g["trim_qual"])]
+        cmd += ["--batch_pairs", str(g["batch"]), "--chunk_pairs", str(chunk_batches * g["batch"])]
         out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, check=True).stdout
         assert out == open(g["sam"], "rb").read()
     # asking for the unbuilt BAM path is a loud error
