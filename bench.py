@@ -99,7 +99,11 @@ def main() -> None:
         lens = np.full((2, n_pairs), 150, dtype=np.int32)
         return synth.ReadBatch(seq, qual, lens, None)
 
-    batches = [make_batch(args.pairs, 1000 + 17 * rank + b) for b in range(n_ctx)]
+    # distinct host batches are 2.7 GB each at the default size: at most four per rank, shared round-robin by the contexts (every
+    # context still owns its device copy, its stream state and its results)
+    n_distinct = min(n_ctx, 4)
+    distinct = [make_batch(args.pairs, 1000 + 17 * rank + b) for b in range(n_distinct)]
+    batches = [distinct[b % n_distinct] for b in range(n_ctx)]
     ix = api.Index(pre, device=local_rank)
     ctxs = []
     for b in range(n_ctx):
