@@ -150,3 +150,38 @@ def test_cli_sam_out_matches_reference_golden(golden_cases, tmp_path):
     # asking for the unbuilt BAM path is a loud error
     r = subprocess.run([exe, "align", "--index_prefix", "x", "--fastq_1", "a", "--fastq_2", "b", "--out_prefix", "o"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert r.returncode != 0 and b"not built" in r.stderr
+
+
+# Non-default options, each against the oracle run with the same options (the oracle itself is pinned against the reference with
+# the default options; these variants pin the GPU path to the oracle where the two could drift apart: the entry limit and the
+# exact tier behind it, non-stop mode, a fixed max_diff with more gaps, scores that make child classes share a bucket, XA limits).
+OPTION_VARIANTS = [
+    ("entry_limit", dict(max_entries=600)),
+    ("nonstop", dict(mode=1 | 2 | 0x10, max_top2=0x7fffffff)),
+    ("fixed_maxdiff", dict(fnr=-1.0, max_diff=4, max_gapo=2, max_gape=3, mode=2)),
+    ("shared_buckets", dict(s_mm=4, s_gapo=4, s_gape=4)),
+    ("loggap_multi", dict(mode=1 | 2 | 4, n_multi=8, N_multi=20, max_occ=50, is_sw=0)),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,okw", OPTION_VARIANTS, ids=[v[0] for v in OPTION_VARIANTS])
+def test_gpu_matches_oracle_with_option_variants(name, okw, lib, tmp_path, search_mode):
+    if search_mode == "wave64":
+        pytest.skip("covered by lanes and wave1")
+    ref = synth.make_reference(n_markers=120, n_long=12, seed=35, repeat_every=2, tandem_every=7)
+    pre = str(tmp_path / "ref.FASTQuick.fa")
+    ref.write_fasta(pre)
+    api.build_index(pre)
+    rb = synth.make_reads(ref, 2500, on_target=0.95, seed=45, sub_rate=0.03, del_frac=0.08, ins_frac=0.07, n_rate=0.004, indel_len_max=3, chimera_frac=0.06)
+    ix = api.Index(pre, device=0)
+    al = api.Aligner(ix, api.default_opts(lib, **okw), max_pairs=1000, debug=True)
+    api.align_stream(al, rb.names, rb.seq, rb.qual, rb.lens, 1000, str(tmp_path / "gpu.stages"), str(tmp_path / "gpu.sam"))
+    oa = ob.OracleAligner(pre, ob.default_opts(**okw))
+    oa.align(rb.names, rb.seq, rb.qual, rb.lens, str(tmp_path / "orc.stages"), str(tmp_path / "orc.sam"), batch=1000)
+    diffs = [d for d in ob.diff_stage_files(str(tmp_path / "orc.stages"), str(tmp_path / "gpu.stages")) if not d.startswith("line count")]
+    assert not diffs, "\n".join(diffs[:20])
+    assert filecmp.cmp(str(tmp_path / "orc.sam"), str(tmp_path / "gpu.sam"), shallow=False)
+    if name == "entry_limit":
+        assert al.stats()["tier_retries"] > 0, "the entry limit was meant to push reads into the exact tier"
+    al.close(); ix.close(); oa.close()

@@ -70,3 +70,32 @@ def test_empty_batch(golden_cases, emu_lib):
     assert res.n_pairs == 0 and res.n_survivors == 0
     al.close()
     ix.close()
+
+
+OPTION_VARIANTS = [
+    ("entry_limit", dict(max_entries=600)),
+    ("nonstop", dict(mode=1 | 2 | 0x10, max_top2=0x7fffffff)),
+    ("fixed_maxdiff", dict(fnr=-1.0, max_diff=4, max_gapo=2, max_gape=3, mode=2)),
+    ("shared_buckets", dict(s_mm=4, s_gapo=4, s_gape=4)),
+    ("loggap_multi", dict(mode=1 | 2 | 4, n_multi=8, N_multi=20, max_occ=50, is_sw=0)),
+]
+
+
+@pytest.mark.parametrize("name,okw", OPTION_VARIANTS, ids=[v[0] for v in OPTION_VARIANTS])
+def test_emulated_pipeline_matches_oracle_with_option_variants(name, okw, emu_lib, tmp_path):
+    """Non-default options: the host pipeline + kernel bodies against the oracle run with the same options."""
+    from fastquick_amd import synth
+    ref = synth.make_reference(n_markers=60, n_long=6, seed=35, repeat_every=2, tandem_every=7)
+    pre = str(tmp_path / "ref.FASTQuick.fa")
+    ref.write_fasta(pre)
+    api.build_index(pre, lib=emu_lib)
+    rb = synth.make_reads(ref, 700, on_target=0.95, seed=45, sub_rate=0.03, del_frac=0.08, ins_frac=0.07, n_rate=0.004, indel_len_max=3, chimera_frac=0.06)
+    ix = api.Index(pre, lib=emu_lib)
+    al = api.Aligner(ix, api.default_opts(emu_lib, **okw), max_pairs=400, debug=True)
+    api.align_stream(al, rb.names, rb.seq, rb.qual, rb.lens, 400, str(tmp_path / "emu.stages"), str(tmp_path / "emu.sam"))
+    oa = ob.OracleAligner(pre, ob.default_opts(**okw))
+    oa.align(rb.names, rb.seq, rb.qual, rb.lens, str(tmp_path / "orc.stages"), str(tmp_path / "orc.sam"), batch=400)
+    diffs = [d for d in ob.diff_stage_files(str(tmp_path / "orc.stages"), str(tmp_path / "emu.stages")) if not d.startswith("line count")]
+    assert not diffs, "\n".join(diffs[:20])
+    assert filecmp.cmp(str(tmp_path / "orc.sam"), str(tmp_path / "emu.sam"), shallow=False)
+    al.close(); ix.close(); oa.close()
