@@ -19,6 +19,7 @@
 #include <string>
 #include <unordered_map>
 #include <mutex>
+#include <thread>
 #include <vector>
 
 #include "../../include/fastquick_amd.h"
@@ -118,7 +119,6 @@ struct fq_ctx {
   DevBuf<FqSurvInfo> d_surv;
   DevBuf<int32_t> d_sub_max;
   int64_t n_bases_in = 0;
-  vector<int> pen_lut;   // per reference batch: memo of the insert-size penalty per integer insert size
   // results of the last batch
   FqBatchState st;
   fq_stats_t stats{};
@@ -228,6 +228,25 @@ extern "C" int fq_align_batch(fq_ctx_t *c, const fq_read_batch_t *in, fq_result_
 // ---- host-side scalar stages ----------------------------------------------------------------------------
 namespace {
 
+// The per-pair host phases are independent across pairs (everything order-dependent -- the drand48 stream, the insert-size
+// chain, the (k,l) position cache -- is handled serially before them), so large batches are split over a few threads.
+inline size_t par_min() {   // below this many items a phase stays on the calling thread (FQ_HOST_PAR_MIN: test hook)
+  const char *e = getenv("FQ_HOST_PAR_MIN");
+  return e ? (size_t)atoll(e) : (size_t)32768;
+}
+template <class F>
+void parallel_chunks(size_t n, int threads, F fn) {   // fn(lo, hi, thread index)
+  if (threads <= 1 || n < par_min()) { fn((size_t)0, n, 0); return; }
+  std::vector<std::thread> th;
+  const size_t per = (n + threads - 1) / threads;
+  for (int t = 0; t < threads; ++t) {
+    const size_t lo = (size_t)t * per, hi = std::min(n, lo + per);
+    if (lo >= hi) break;
+    th.emplace_back([=]() { fn(lo, hi, t); });
+  }
+  for (auto &x : th) x.join();
+}
+
 // bwa_aln2seq_core, libbwa/bwase.c:19-95
 void choose_hit(fq_ctx *c, int n_aln, const FqAln *aln, FqRead &s, bool set_main, int n_multi) {
   if (n_aln == 0) { s.type = FQ_TYPE_NO_MATCH; s.c1 = s.c2 = 0; return; }
@@ -320,7 +339,7 @@ void infer_isize(const vector<FqRead> &R, int sp_lo, int sp_hi, int max_len_all,
 
 // pairing + __pairing_aux/__pairing_aux2, libbwa/bwape.c:119-213, bwape.h:55-82 (typo at :65 reproduced)
 struct PairAcc { uint64_t o_score, subo_score, o_pos[2]; int o_n, subo_n; };
-inline void pair_try(fq_ctx *c, FqRead *p[2], const FqAln *aln[2], const fq_isize_t *ii, int max_len, uint64_t u, uint64_t v, PairAcc &A) {
+inline void pair_try(fq_ctx *c, vector<int> &pen_lut, FqRead *p[2], const FqAln *aln[2], const fq_isize_t *ii, int max_len, uint64_t u, uint64_t v, PairAcc &A) {
   if (u == (uint64_t)-1) return;
   const uint32_t l = (uint32_t)(v >> 32) + (uint32_t)p[v & 1]->len - (uint32_t)(u >> 32);
   if (!((v >> 32) > (u >> 32) && l >= (uint32_t)max_len &&
@@ -329,7 +348,7 @@ inline void pair_try(fq_ctx *c, FqRead *p[2], const FqAln *aln[2], const fq_isiz
   s *= 10;
   if (ii->high) {
     // same libm expression as bwape.h:62, evaluated once per distinct insert size of this reference batch (l <= high_bayesian here)
-    int &pen = c->pen_lut[l];
+    int &pen = pen_lut[l];
     if (pen == INT32_MIN) pen = (int)(-4.343 * log(0.5 * erfc(M_SQRT1_2 * fabs(l - ii->avg) / ii->std)) + 0.499);
     s += (uint64_t)(int64_t)pen;
   }
@@ -349,7 +368,7 @@ inline void pair_fix(FqRead &q, const FqAln *aln[2], uint64_t w) {
     q.pos = (uint32_t)(w >> 32);
   }
 }
-void pair_hits(fq_ctx *c, FqRead *p[2], const FqAln *aln[2], vector<uint64_t> &arr, const fq_isize_t *ii) {
+void pair_hits(fq_ctx *c, vector<int> &pen_lut, FqRead *p[2], const FqAln *aln[2], vector<uint64_t> &arr, const fq_isize_t *ii) {
   PairAcc A;
   A.o_score = A.subo_score = (uint64_t)-1; A.o_n = A.subo_n = 0; A.o_pos[0] = A.o_pos[1] = 0;
   uint64_t last[2][2] = {{(uint64_t)-1, (uint64_t)-1}, {(uint64_t)-1, (uint64_t)-1}};
@@ -358,8 +377,8 @@ void pair_hits(fq_ctx *c, FqRead *p[2], const FqAln *aln[2], vector<uint64_t> &a
   for (uint64_t x : arr) {
     if (((aln[x & 1][(uint32_t)x >> 1].info >> 24) & 1) == 1) {
       const int y = 1 - (int)(x & 1);
-      pair_try(c, p, aln, ii, max_len, last[y][1], x, A);
-      pair_try(c, p, aln, ii, max_len, last[y][0], x, A);
+      pair_try(c, pen_lut, p, aln, ii, max_len, last[y][1], x, A);
+      pair_try(c, pen_lut, p, aln, ii, max_len, last[y][0], x, A);
     } else { last[x & 1][0] = last[x & 1][1]; last[x & 1][1] = x; }
   }
   if (A.o_score == (uint64_t)-1) return;
@@ -564,10 +583,13 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
 
   TRACE("stageA width+gap");
   // ---- records for survivors -----------------------------------------------------------------------------
+  const int host_threads = getenv("FQ_HOST_THREADS") ? atoi(getenv("FQ_HOST_THREADS")) :
+                           o.host_threads > 0 ? o.host_threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
   vector<FqRead> &R = S.reads;
   R.assign((size_t)n_surv * 2, FqRead());
   vector<int> s_of((size_t)n_surv * 2, -1);
   {
+    // (kept on the calling thread: first touch decides which NUMA node the records live on, and the serial phases read them)
     for (int sp = 0; sp < n_surv; ++sp)
       for (int e = 0; e < 2; ++e) {
         FqRead &p = R[2 * sp + e];
@@ -600,12 +622,14 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   aln_row_off.assign(h_aln.size() + 1, ~0ull);
   {
     const uint32_t multi_cap = (uint32_t)std::max(o.n_multi, o.N_multi) + 1;
-    for (size_t idx = 0; idx < R.size(); ++idx) {
-      int na; const FqAln *a = aln_of((int)idx, &na);
-      uint64_t t = 0;
-      for (int k = 0; k < na; ++k) t += (uint64_t)(a[k].l - a[k].k) + 1;
-      read_nocc[idx] = t;
-    }
+    parallel_chunks(R.size(), host_threads, [&](size_t lo, size_t hi, int) {
+      for (size_t idx = lo; idx < hi; ++idx) {
+        int na; const FqAln *a = aln_of((int)idx, &na);
+        uint64_t t = 0;
+        for (int k = 0; k < na; ++k) t += (uint64_t)(a[k].l - a[k].k) + 1;
+        read_nocc[idx] = t;
+      }
+    });
     vector<FqAln> q_aln; vector<uint32_t> q_len; vector<uint64_t> q_off;
     uint64_t rows = 0;
     for (int sp = 0; sp < n_surv; ++sp) {
@@ -682,10 +706,19 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   // ---- stage B2: insert size per reference batch, with the last_ii fallback chain (Q3) -----------------------
   vector<fq_isize_t> iis(n_sub);
   {
+    // the inference of a reference batch depends on nothing but its records; only the fallback chain is sequential
+    vector<fq_isize_t> raw(n_sub);
+    {
+      std::vector<std::thread> th;
+      const int T = (size_t)n_surv >= par_min() ? std::min(host_threads, n_sub) : 1;
+      auto work = [&](int t) { for (int sb = t; sb < n_sub; sb += T) infer_isize(R, sub_lo[sb], sub_lo[sb + 1], sub_max_len[sb], &raw[sb], o.ap_prior, (int64_t)ix->dev.fm[0].seq_len); };
+      for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+      work(0);
+      for (auto &x : th) x.join();
+    }
     fq_isize_t prev = c->last_ii;
     for (int sb = 0; sb < n_sub; ++sb) {
-      fq_isize_t ii;
-      infer_isize(R, sub_lo[sb], sub_lo[sb + 1], sub_max_len[sb], &ii, o.ap_prior, (int64_t)ix->dev.fm[0].seq_len);
+      fq_isize_t ii = raw[sb];
       if (ii.avg < 0.0 && prev.avg > 0.0) ii = prev;
       if (o.force_isize) { ii.low = ii.high = 0; ii.avg = ii.std = -1.0; }
       iis[sb] = ii;
@@ -697,17 +730,38 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   TRACE("B2 isize");
   // ---- stage B3: pairing + XA lists (per pair) -------------------------------------------------------------
   {
-    vector<uint64_t> arr;
+    auto both_mapped = [&](int sp) {
+      const FqRead &a = R[2 * sp], &b = R[2 * sp + 1];
+      return (a.type == FQ_TYPE_UNIQUE || a.type == FQ_TYPE_REPEAT) && (b.type == FQ_TYPE_UNIQUE || b.type == FQ_TYPE_REPEAT) &&
+             read_nocc[2 * sp] <= o.max_occ && read_nocc[2 * sp + 1] <= o.max_occ;
+    };
+    // MIN_HASH_WIDTH: the positions of an interval >= 1000 wide are those of its first requester, in pair order (Q6): fill the
+    // cache serially, in that order, before the pairs are spread over threads (which then only look it up)
+    for (int sp = 0; sp < n_surv; ++sp) {
+      if (!both_mapped(sp)) continue;
+      for (int j = 0; j < 2; ++j) {
+        int na; const FqAln *a = aln_of(2 * sp + j, &na);
+        const uint64_t base = aln_off[s_of[2 * sp + j]];
+        for (int k = 0; k < na; ++k) {
+          const uint32_t wdt = a[k].l - a[k].k + 1;
+          if (wdt < 1000) continue;
+          auto ins = c->kl_cache.emplace((uint64_t)a[k].k << 32 | a[k].l, vector<uint32_t>());
+          if (ins.second) { const uint32_t *ps = h_pos.data() + aln_row_off[base + k]; ins.first->second.assign(ps, ps + wdt); }
+        }
+      }
+    }
     for (int sb = 0; sb < n_sub; ++sb) {
     const fq_isize_t ii = iis[sb];
-    c->pen_lut.assign((size_t)ii.high_bayesian + 2, INT32_MIN);
-    for (int sp = sub_lo[sb]; sp < sub_lo[sb + 1]; ++sp) {
+    parallel_chunks((size_t)(sub_lo[sb + 1] - sub_lo[sb]), host_threads, [&](size_t lo, size_t hi, int) {
+    vector<uint64_t> arr;
+    vector<int> pen_lut((size_t)ii.high_bayesian + 2, INT32_MIN);   // memo of the insert-size penalty (same libm expression per insert size)
+    for (int sp = sub_lo[sb] + (int)lo; sp < sub_lo[sb] + (int)hi; ++sp) {
       FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
       const FqAln *aln[2]; int na[2];
       aln[0] = aln_of(2 * sp, &na[0]); aln[1] = aln_of(2 * sp + 1, &na[1]);
       const bool m0 = p[0]->type == FQ_TYPE_UNIQUE || p[0]->type == FQ_TYPE_REPEAT, m1 = p[1]->type == FQ_TYPE_UNIQUE || p[1]->type == FQ_TYPE_REPEAT;
       if (m0 && m1) {
-        if (read_nocc[2 * sp] > o.max_occ || read_nocc[2 * sp + 1] > o.max_occ) continue;
+        if (read_nocc[2 * sp] > o.max_occ || read_nocc[2 * sp + 1] > o.max_occ) continue;   // BwtMapper.cpp:797-811: such a pair gets no XA list either
         arr.clear();
         for (int j = 0; j < 2; ++j) {
           const uint64_t base = aln_off[s_of[2 * sp + j]];
@@ -716,15 +770,11 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
             const uint32_t wdt = q.l - q.k + 1;
             const uint32_t *ps = h_pos.data() + aln_row_off[base + k];
             uint32_t np = wdt;
-            if (wdt >= 1000) {   // MIN_HASH_WIDTH: first requester's positions are reused verbatim (Q6)
-              auto ins = c->kl_cache.emplace((uint64_t)q.k << 32 | q.l, vector<uint32_t>());
-              if (ins.second) ins.first->second.assign(ps, ps + wdt);
-              ps = ins.first->second.data(); np = (uint32_t)ins.first->second.size();
-            }
+            if (wdt >= 1000) { const vector<uint32_t> &v = c->kl_cache.find((uint64_t)q.k << 32 | q.l)->second; ps = v.data(); np = (uint32_t)v.size(); }
             for (uint32_t t = 0; t < np; ++t) arr.push_back((uint64_t)ps[t] << 32 | (uint64_t)(k << 1) | (uint64_t)j);
           }
         }
-        pair_hits(c, p, aln, arr, &ii);
+        pair_hits(c, pen_lut, p, aln, arr, &ii);
       }
       if (o.N_multi || o.n_multi)
         for (int j = 0; j < 2; ++j) {
@@ -737,6 +787,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
           for (auto &m : p[j]->multi) m.pos = h_pos[aln_row_off[base + m.aln] + m.row_in_aln];
         }
     }
+    });
     }
   }
 
@@ -896,13 +947,16 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
         CK(fqdev::d2h(cg.data() + t0 * cig_cap, c->d_cig.p, (size_t)nt * cig_cap * 2));
         CK(fqdev::sync());
       }
-      for (size_t t = 0; t < tasks.size(); ++t) {
-        FqRead &s = R[tgt[t].idx];
+      for (size_t t = 0; t < tasks.size(); ++t)
         if (outs[t].n_cigar <= 0) { c->err = "refine: CIGAR longer than the device slot"; return FQ_ELIMIT; }
-        const uint16_t *g = cg.data() + t * cig_cap;
-        if (tgt[t].multi >= 0) { FqMulti &q = s.multi[tgt[t].multi]; q.pos = outs[t].pos; q.cigar.assign(g, g + outs[t].n_cigar); }
-        else { s.pos = outs[t].pos; s.cigar.assign(g, g + outs[t].n_cigar); }
-      }
+      parallel_chunks(tasks.size(), host_threads, [&](size_t lo, size_t hi, int) {   // a task owns its record's field
+        for (size_t t = lo; t < hi; ++t) {
+          FqRead &s = R[tgt[t].idx];
+          const uint16_t *g = cg.data() + t * cig_cap;
+          if (tgt[t].multi >= 0) { FqMulti &q = s.multi[tgt[t].multi]; q.pos = outs[t].pos; q.cigar.assign(g, g + outs[t].n_cigar); }
+          else { s.pos = outs[t].pos; s.cigar.assign(g, g + outs[t].n_cigar); }
+        }
+      });
       c->stats.refine_tasks += tasks.size();
     }
     // MD / NM for every mapped read (bwa_cal_md1)
@@ -942,16 +996,21 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
       vector<char> packed(total + 1);
       CK(fqdev::d2h(packed.data(), c->d_mdpacked.p, total));
       CK(fqdev::sync());
-      for (int t = 0; t < nt; ++t) {
-        FqRead &s = R[mi[t]];
+      for (int t = 0; t < nt; ++t)
         if (mdlen[t] < 0) { c->err = "MD string longer than the device slot"; return FQ_ELIMIT; }
-        s.md.assign(packed.data() + off[t], (size_t)mdlen[t]);
-        s.has_md = true;
-        s.nm = nm[t] & 0xfff;
-      }
+      parallel_chunks((size_t)nt, host_threads, [&](size_t lo, size_t hi, int) {
+        for (size_t t = lo; t < hi; ++t) {
+          FqRead &s = R[mi[t]];
+          s.md.assign(packed.data() + off[t], (size_t)mdlen[t]);
+          s.has_md = true;
+          s.nm = nm[t] & 0xfff;
+        }
+      });
     }
     // bwa_correct_trimmed (bwase.c:298-337) for every record
-    for (auto &s : R) {
+    parallel_chunks(R.size(), host_threads, [&](size_t lo, size_t hi, int) {
+    for (size_t idx = lo; idx < hi; ++idx) {
+      FqRead &s = R[idx];
       if (s.len == s.full_len) continue;
       const int clip = s.full_len - s.len;
       if (s.strand == 0) {
@@ -969,6 +1028,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
       }
       s.len = s.full_len;
     }
+    });
   }
   TRACE("D refine+MD+trim");
   c->last_ii = iis[n_sub - 1];
@@ -980,7 +1040,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   S.s_of = s_of;
   S.aln_off = aln_off;
   S.aln_n = aln_n;
-  S.flatten();
+  S.flatten(host_threads, par_min());
   TRACE("flatten");
   int n_both_unmapped = 0;
   for (int sp = 0; sp < n_surv; ++sp) if (R[2 * sp].type == FQ_TYPE_NO_MATCH && R[2 * sp + 1].type == FQ_TYPE_NO_MATCH) ++n_both_unmapped;

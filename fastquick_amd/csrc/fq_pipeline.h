@@ -1,5 +1,7 @@
 // fq_pipeline.h -- host-side per-batch state shared by fq_align.cpp (producer) and fq_sam.cpp (consumers)
 #pragma once
+#include <algorithm>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -52,34 +54,58 @@ struct FqBatchState {
     pair_idx.clear(); reads.clear(); stage_P.clear(); stage_S.clear(); aln.clear(); s_of.clear(); aln_off.clear(); aln_n.clear();
     rec.clear(); cigar.clear(); md.clear(); multi.clear();
   }
-  void flatten() {
-    rec.resize(reads.size());
-    cigar.clear(); md.clear(); multi.clear();
-    for (size_t i = 0; i < reads.size(); ++i) {
+  // C-ABI arrays from the per-read records.  Offsets into the side arenas are prefix sums of per-record sizes, so the copy
+  // itself splits over threads for large batches.
+  void flatten(int threads, size_t par_min) {
+    const size_t nrec = reads.size();
+    rec.resize(nrec);
+    std::vector<uint32_t> coff(nrec + 1), moff(nrec + 1), xoff(nrec + 1);
+    uint32_t cc = 0, mm = 0, xx = 0;
+    for (size_t i = 0; i < nrec; ++i) {
       const FqRead &s = reads[i];
-      fq_result_t &o = rec[i];
-      o.pos = s.pos; o.sa = s.sa; o.c1 = s.c1; o.c2 = s.c2; o.score = s.score;
-      o.len = s.len; o.full_len = s.full_len; o.clip_len = s.clip_len;
-      o.type = (uint8_t)s.type; o.strand = (uint8_t)s.strand; o.filtered = (uint8_t)s.filtered; o.extra_flag = (uint8_t)s.extra_flag;
-      o.n_mm = (uint8_t)s.n_mm; o.n_gapo = (uint8_t)s.n_gapo; o.n_gape = (uint8_t)s.n_gape; o.mapQ = (uint8_t)s.mapQ;
-      o.seQ = (uint8_t)s.seQ; o.pad0 = 0; o.nm = (uint16_t)s.nm;
-      o.n_cigar = (uint16_t)s.cigar.size(); o.n_multi = (uint16_t)s.multi.size();
-      o.cigar_off = (uint32_t)cigar.size();
-      cigar.insert(cigar.end(), s.cigar.begin(), s.cigar.end());
-      if (s.has_md) { o.md_off = (uint32_t)md.size(); md.insert(md.end(), s.md.begin(), s.md.end()); md.push_back(0); }
-      else o.md_off = 0xffffffffu;
-      o.multi_off = (uint32_t)multi.size();
-      for (const FqMulti &q : s.multi) {
-        fq_multi_t m{};
-        m.pos = q.pos; m.cigar_off = (uint32_t)cigar.size(); m.n_cigar = (uint16_t)q.cigar.size(); m.gap = (uint8_t)q.gap; m.mm = (uint8_t)q.mm;
-        m.strand = (uint8_t)q.strand;
-        cigar.insert(cigar.end(), q.cigar.begin(), q.cigar.end());
-        multi.push_back(m);
-      }
+      coff[i] = cc; moff[i] = mm; xoff[i] = xx;
+      cc += (uint32_t)s.cigar.size();
+      for (const FqMulti &q : s.multi) cc += (uint32_t)q.cigar.size();
+      if (s.has_md) mm += (uint32_t)s.md.size() + 1;
+      xx += (uint32_t)s.multi.size();
     }
-    if (cigar.empty()) cigar.push_back(0);
-    if (md.empty()) md.push_back(0);
-    if (multi.empty()) multi.push_back(fq_multi_t{});
+    coff[nrec] = cc; moff[nrec] = mm; xoff[nrec] = xx;
+    cigar.assign(cc ? cc : 1, 0); md.assign(mm ? mm : 1, 0); multi.assign(xx ? xx : 1, fq_multi_t{});
+    auto fill = [&](size_t lo, size_t hi) {
+      for (size_t i = lo; i < hi; ++i) {
+        const FqRead &s = reads[i];
+        fq_result_t &o = rec[i];
+        o.pos = s.pos; o.sa = s.sa; o.c1 = s.c1; o.c2 = s.c2; o.score = s.score;
+        o.len = s.len; o.full_len = s.full_len; o.clip_len = s.clip_len;
+        o.type = (uint8_t)s.type; o.strand = (uint8_t)s.strand; o.filtered = (uint8_t)s.filtered; o.extra_flag = (uint8_t)s.extra_flag;
+        o.n_mm = (uint8_t)s.n_mm; o.n_gapo = (uint8_t)s.n_gapo; o.n_gape = (uint8_t)s.n_gape; o.mapQ = (uint8_t)s.mapQ;
+        o.seQ = (uint8_t)s.seQ; o.pad0 = 0; o.nm = (uint16_t)s.nm;
+        o.n_cigar = (uint16_t)s.cigar.size(); o.n_multi = (uint16_t)s.multi.size();
+        uint32_t ca = coff[i];
+        o.cigar_off = ca;
+        std::copy(s.cigar.begin(), s.cigar.end(), cigar.begin() + ca);
+        ca += (uint32_t)s.cigar.size();
+        if (s.has_md) { o.md_off = moff[i]; std::copy(s.md.begin(), s.md.end(), md.begin() + moff[i]); md[moff[i] + s.md.size()] = 0; }
+        else o.md_off = 0xffffffffu;
+        o.multi_off = xoff[i];
+        uint32_t xa = xoff[i];
+        for (const FqMulti &q : s.multi) {
+          fq_multi_t m{};
+          m.pos = q.pos; m.cigar_off = ca; m.n_cigar = (uint16_t)q.cigar.size(); m.gap = (uint8_t)q.gap; m.mm = (uint8_t)q.mm;
+          m.strand = (uint8_t)q.strand;
+          std::copy(q.cigar.begin(), q.cigar.end(), cigar.begin() + ca);
+          ca += (uint32_t)q.cigar.size();
+          multi[xa++] = m;
+        }
+      }
+    };
+    if (threads <= 1 || nrec < par_min) fill(0, nrec);
+    else {
+      std::vector<std::thread> th;
+      const size_t per = (nrec + threads - 1) / threads;
+      for (int t = 0; t < threads; ++t) { const size_t lo = (size_t)t * per, hi = std::min(nrec, lo + per); if (lo < hi) th.emplace_back(fill, lo, hi); }
+      for (auto &x : th) x.join();
+    }
   }
 };
 

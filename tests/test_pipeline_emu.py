@@ -20,16 +20,18 @@ def emu_lib():
     return api.load_library(os.path.join(EMU_DIR, "libfq_emu.so"))
 
 
-@pytest.mark.parametrize("mode", ["lanes", "wave"])
+@pytest.mark.parametrize("mode", ["lanes", "wave", "threads"])
 @pytest.mark.parametrize("tag", golden_util.case_tags())
 def test_emulated_pipeline_matches_reference_golden(tag, mode, golden_cases, emu_lib, monkeypatch):
     if mode == "wave":   # every search handed to the wavefront-per-read path (a one-lane wavefront here: its sequential rounds)
         monkeypatch.setenv("FQ_GAP_LONG_POPS", "1")
         monkeypatch.setenv("FQ_GAP_LONG_ALWAYS", "1")
+    if mode == "threads":   # the per-pair host phases split over threads even for these small inputs
+        monkeypatch.setenv("FQ_HOST_PAR_MIN", "1")
     g = golden_cases[tag]
     names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
     ix = api.Index(g["prefix"], lib=emu_lib)
-    al = api.Aligner(ix, api.default_opts(emu_lib, trim_qual=g["trim_qual"]), max_pairs=max(16, g["batch"]), debug=True)
+    al = api.Aligner(ix, api.default_opts(emu_lib, trim_qual=g["trim_qual"], host_threads=3 if mode == "threads" else 0), max_pairs=max(16, g["batch"]), debug=True)
     st, sam = os.path.join(g["dir"], "emu.stages"), os.path.join(g["dir"], "emu.sam")
     api.align_stream(al, names, seq, qual, lens, g["batch"], st, sam)
     al.close()
