@@ -510,7 +510,8 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
     const uint32_t long_pops = getenv("FQ_GAP_LONG_POPS") ? (uint32_t)atoi(getenv("FQ_GAP_LONG_POPS")) : 1024u;
     const uint32_t exact_pool = (uint32_t)std::min<uint64_t>(4ull * (uint64_t)o.max_entries + 4096ull, 0x7fffffffull);
     const int long_always = getenv("FQ_GAP_LONG_ALWAYS") ? atoi(getenv("FQ_GAP_LONG_ALWAYS")) : 0;   // test hook
-    const FqGapTier tiers[3] = {{4096u, 32u, 0, 0, long_pops, long_always}, {262144u, 512u, 0, 1, 0u, 0}, {exact_pool, 8192u, 1, 1, 0u, 0}};
+    const uint32_t lane_pool = getenv("FQ_GAP_POOL") ? (uint32_t)atoi(getenv("FQ_GAP_POOL")) : 2048u;   // stack entries per lane of the lane kernel (32 KB; reads that need more go to the wavefront tier)
+    const FqGapTier tiers[3] = {{lane_pool, 32u, 0, 0, long_pops, long_always}, {262144u, 512u, 0, 1, 0u, 0}, {exact_pool, 8192u, 1, 1, 0u, 0}};
     // scores that can occur for the longest read of this call (children may exceed max_diff by one difference)
     const int nb_need = (c->maxdiff_lut[max_len_all] + 1) * o.s_mm + o.max_gapo * o.s_gapo + o.max_gape * o.s_gape + 1;
     const size_t chunk_reads[3] = {(size_t)8 << 20, (size_t)1 << 20, 4096};   // pools are per lane / per wavefront; only per-read outputs scale with the chunk
@@ -524,7 +525,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
       FqGapTier T = tiers[tier];
       // Handing long searches to the wavefront-per-read kernel pays when the launch is latency-bound (few reads: its duration is
       // its longest search); a launch that fills the device several times over hides its long searches behind the others.
-      if (tier == 0 && !long_always && work.size() > 65536) T.long_pops = 0;
+      if (tier == 0 && !long_always && work.size() > 524288) T.long_pops = 0;   // (two reads per resident lane)
       next_work.clear();
       for (size_t c0 = 0; c0 < work.size(); c0 += chunk_reads[tier]) {
         const int nw = (int)std::min(chunk_reads[tier], work.size() - c0);
