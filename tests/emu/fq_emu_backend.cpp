@@ -56,7 +56,7 @@ struct SeqFetch { uint32_t *next; int n; uint32_t operator()(uint32_t k) const {
 int gap_lane_slots(const FqGapArgs &a) { return a.n_work > 0 ? 1 : 0; }
 int launch_gap(const FqGapArgs &a_in) {
   FqGapArgs a = a_in;
-  a.refill_min = 1; a.refill_min_hard = 1;
+  a.refill_min = 1;
   uint32_t *next_p = a.queue; *next_p = 0;   // the same cursor the device kernels advance
   if (a.tier.coop) {
     std::vector<uint32_t> heads(2 * FQ_MAX_BUCKETS);
