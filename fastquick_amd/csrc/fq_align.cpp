@@ -56,8 +56,9 @@ template <class T> struct DevBuf {
   bool ensure(size_t n) {
     if (n <= cap) return true;
     fqdev::dfree(p);
-    cap = n + n / 4 + 64;
+    cap = n + std::min<size_t>(n / 4, (size_t)16 << 20) + 64;   // some slack against regrowth, bounded for the multi-GB buffers
     p = (T *)fqdev::dmalloc(cap * sizeof(T));
+    if (!p) { cap = n; p = (T *)fqdev::dmalloc(cap * sizeof(T)); }
     if (!p) { cap = 0; return false; }
     return true;
   }
@@ -546,8 +547,15 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
         ga.pool = c->d_pool.p; ga.heads = c->d_heads.p; ga.tier = T; ga.aln = c->d_aln.p; ga.n_aln = c->d_naln.p; ga.status = c->d_status.p;
         ga.counters = c->d_counters.p; ga.queue = c->d_queue.p;
         {
-          const size_t slots = (size_t)fqdev::gap_lane_slots(ga);
-          CKM(c->d_heads.ensure(slots * FQ_MAX_BUCKETS) && c->d_pool.ensure(slots * T.pool_cap));
+          // stack pools are the one large per-launch allocation (lanes x pool_cap x 16 B): when the device cannot hold them for
+          // as many wavefronts as it could run, run fewer (the persistent lanes simply take more reads each)
+          for (;;) {
+            const size_t slots = (size_t)fqdev::gap_lane_slots(ga);
+            if (c->d_heads.ensure(slots * FQ_MAX_BUCKETS) && c->d_pool.ensure(slots * T.pool_cap)) break;
+            const int waves = (int)(T.coop ? slots : slots / 64);
+            if (waves <= 1) { c->err = "out of device memory for the search pools"; return FQ_ENOMEM; }
+            ga.max_waves = waves / 2;
+          }
           ga.pool = c->d_pool.p; ga.heads = c->d_heads.p;
         }
         fqdev::time_begin(FQ_K_GAP);

@@ -638,7 +638,11 @@ int launch_order(const uint8_t *bid_end, int n, int32_t *order, uint32_t *cnt) {
 }
 int gap_lane_slots(const FqGapArgs &a) {
   if (a.n_work <= 0) return 0;
-  if (a.tier.coop) return (int)std::min<unsigned>((unsigned)a.n_work, a.tier.exact ? 64u : 1024u);   // wavefronts, one pool each
+  if (a.tier.coop) {   // wavefronts, one pool each
+    unsigned w = std::min<unsigned>((unsigned)a.n_work, a.tier.exact ? 64u : 1024u);
+    if (a.max_waves > 0) w = std::min<unsigned>(w, (unsigned)a.max_waves);
+    return (int)w;
+  }
   static const int env_waves = getenv("FQ_GAP_WAVES_PER_CU") ? atoi(getenv("FQ_GAP_WAVES_PER_CU")) : 0;
   const unsigned need = nblk((uint64_t)a.n_work, 64);
   unsigned per_cu = 8;
@@ -647,7 +651,9 @@ int gap_lane_slots(const FqGapArgs &a) {
     per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16, (150 * 1024) / lds));
   }
   if (env_waves > 0) per_cu = std::min<unsigned>(per_cu, (unsigned)env_waves);
-  return (int)(std::min(need, 256u * per_cu) * 64u);
+  unsigned waves = std::min(need, 256u * per_cu);
+  if (a.max_waves > 0) waves = std::min<unsigned>(waves, (unsigned)a.max_waves);
+  return (int)(waves * 64u);
 }
 int launch_gap(const FqGapArgs &a_in) {
   if (a_in.n_work <= 0) return 0;

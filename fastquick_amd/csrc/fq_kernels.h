@@ -455,6 +455,7 @@ struct FqGapArgs {
   const int32_t *order;  // queue position -> work item (NULL: identity): long searches first, see fq_order_key
   uint32_t *queue;       // work-queue cursor (zeroed before each launch)
   int32_t refill_min;    // idle lanes of a wavefront wait until this many can be (re)initialised together
+  int32_t max_waves;     // 0: as many wavefronts as the device holds; else a cap (the host lowers it when pool memory is short)
 };
 
 // Where a read's bucket heads live during the search: HBM (any pool size) or lane-interleaved LDS with 16-bit slots
