@@ -441,9 +441,8 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   CK(fqdev::dzero(c->d_sub_max.p, (size_t)n_sub * 4));
   // The filter kernel fills the device and is bound by its random probes; two of them at once only slow each other down (and
   // evict each other's lines).  Contexts therefore take turns for it, while their small, latency-bound kernels overlap freely.
-  static std::mutex filter_turn;
   static const bool take_turns = getenv("FQ_FILTER_NO_TURNS") == nullptr;
-  std::unique_lock<std::mutex> turn(filter_turn, std::defer_lock);
+  std::unique_lock<std::mutex> turn(ix->filter_turn, std::defer_lock);   // per index = per device
   if (take_turns) turn.lock();
   {
     FqPrepArgs a{};

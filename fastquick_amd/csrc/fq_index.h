@@ -1,5 +1,6 @@
 // fq_index.h -- host-side index object (parsed files + device-staged tables)
 #pragma once
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -26,6 +27,7 @@ struct fq_index {
   std::vector<uint8_t> pac;
   // device
   FqDevIndex dev{};
+  mutable std::mutex filter_turn;   // contexts on this device take turns for the device-filling filter kernel (fq_align.cpp)
   void *d_blk[2] = {nullptr, nullptr};
   void *d_sa[2] = {nullptr, nullptr};
   void *d_pac = nullptr;
