@@ -249,6 +249,16 @@ def main() -> None:
         "gap_wave_trips_per_step": round(agg["wave_trips"] / args.steps, 1), "gap_lane_trips_per_step": round(agg["lane_trips"] / args.steps, 1),
     }
 
+    # ---- what a multi-GPU run hands to rank 0 (outside the timed region): the SAM text of every rank's last call, in rank order, and
+    #      the summed stream counters (the reference's FileStatCollector sums); RCCL all_gather / all_reduce, a few MB per rank
+    last = ctxs[0].result
+    if last.n_survivors <= 65536:
+        parts = fqd.gather_bytes_to_rank0(ctxs[0].sam_text())
+        tot = fqd.sum_counters({"pairs": int(last.n_pairs), "survivor_pairs": int(last.n_survivors), "both_filtered": int(last.n_both_filtered),
+                                "both_unmapped": int(last.n_both_unmapped), "bases": int(last.n_bases)})
+        if rank == 0:
+            out["gather"] = {"ranks": len(parts), "sam_bytes": [len(p) for p in parts], "counters_sum": tot}
+
     # ---- CPU baseline: the oracle (a port) on a bounded sample of the same workload, rank 0, N=1 only -----------
     # Like the reference's thread pool over --fq_list lines: T independent streams (one oracle context each, shared read-only
     # index), every stream aligning consecutive slices of the same batch for about ten seconds.
