@@ -430,7 +430,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   S.n_pairs = n;
   memset(out, 0, sizeof *out);
   out->n_pairs = n;
-  if (n == 0) return FQ_OK;
+  if (n == 0) { S.reads.clear(); return FQ_OK; }
 
   // ---- stage 0: encode + trim + filter + ordered compaction (GPU) -------------------------------------
   // The call may carry several reference batches (READ_BUFFER_SIZE pairs each, src/BwtMapper.h:36): the GPU stages run
@@ -594,7 +594,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   const int host_threads = getenv("FQ_HOST_THREADS") ? atoi(getenv("FQ_HOST_THREADS")) :
                            o.host_threads > 0 ? o.host_threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
   vector<FqRead> &R = S.reads;
-  R.assign((size_t)n_surv * 2, FqRead());
+  R.resize((size_t)n_surv * 2);                      // reused storage: every record is reset below
   vector<int> s_of((size_t)n_surv * 2, -1);
   {
     // (kept on the calling thread: first touch decides which NUMA node the records live on, and the serial phases read them)
@@ -603,6 +603,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
         FqRead &p = R[2 * sp + e];
         const int r = e * n + c->h_pair_list[sp];
         const FqSurvInfo &si = c->h_surv[2 * sp + e];
+        p.reset();
         p.r = r;
         p.full_len = c->hb.len[r];
         p.len = p.clip_len = si.len_trim;

@@ -28,6 +28,11 @@ struct FqRead {              // the bwa_seq_t fields the hot path writes (libbwa
   std::vector<FqMulti> multi;
   std::vector<uint16_t> cigar;
   std::string md;
+  void reset() {             // back to a fresh record, keeping the containers' storage (records are reused from call to call)
+    r = 0; len = full_len = clip_len = 0; filtered = type = strand = extra_flag = 0;
+    n_mm = n_gapo = n_gape = mapQ = seQ = score = 0; sa = pos = c1 = c2 = 0; main_aln = 0; nm = 0; has_md = false;
+    multi.clear(); cigar.clear(); md.clear();
+  }
 };
 
 struct FqBatchState {
@@ -51,7 +56,7 @@ struct FqBatchState {
 
   void clear() {
     n_pairs = n_surv = 0;
-    pair_idx.clear(); reads.clear(); stage_P.clear(); stage_S.clear(); aln.clear(); s_of.clear(); aln_off.clear(); aln_n.clear();
+    pair_idx.clear(); stage_P.clear(); stage_S.clear(); aln.clear(); s_of.clear(); aln_off.clear(); aln_n.clear();
     rec.clear(); cigar.clear(); md.clear(); multi.clear();
   }
   // C-ABI arrays from the per-read records.  Offsets into the side arenas are prefix sums of per-record sizes, so the copy
