@@ -109,9 +109,9 @@ FQ_HD uint32_t fq_sa_lookup(const FqFM &f, uint32_t k, uint32_t *steps) {
 // address into a local object pins that object (and everything around it) in scratch memory.
 FQ_HD uint32_t fq_pick2(uint32_t x1, uint32_t x0, int a) { const uint32_t m = 0u - (uint32_t)(a & 1); return (x1 & m) | (x0 & ~m); }   // a ? x1 : x0
 FQ_HD uint64_t fq_pick2p(uint64_t x1, uint64_t x0, int a) { const uint64_t m = 0ull - (uint64_t)(a & 1); return (x1 & m) | (x0 & ~m); }
-FQ_HD uint32_t fq_sel4v(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, int c) {
-  const uint32_t m0 = 0u - (uint32_t)(c == 0), m1 = 0u - (uint32_t)(c == 1), m2 = 0u - (uint32_t)(c == 2), m3 = 0u - (uint32_t)(c == 3);
-  return (v0 & m0) | (v1 & m1) | (v2 & m2) | (v3 & m3);
+FQ_HD uint32_t fq_sel4v(uint32_t v0, uint32_t v1, uint32_t v2, uint32_t v3, int c) {   // c in 0..3; arguments are values (registers)
+  const uint32_t lo = (c & 1) ? v1 : v0, hi = (c & 1) ? v3 : v2;
+  return (c & 2) ? hi : lo;
 }
 FQ_HD uint32_t fq_sel4(const uint32_t *v, int c) { return fq_sel4v(v[0], v[1], v[2], v[3], c & 3); }
 
