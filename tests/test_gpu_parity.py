@@ -185,3 +185,46 @@ def test_gpu_matches_oracle_with_option_variants(name, okw, lib, tmp_path, searc
     if name == "entry_limit":
         assert al.stats()["tier_retries"] > 0, "the entry limit was meant to push reads into the exact tier"
     al.close(); ix.close(); oa.close()
+
+
+@pytest.mark.gpu
+def test_large_ontarget_call_matches_oracle_prefix_and_chunked_run(lib, tmp_path):
+    """BASELINE cfg 5 shape (2x76 bp, every pair on target, indel-rich) at a size that fills the device: one call of 49,152 pairs =
+    12 reference batches of 4,096 (98 k searched reads: sorted queue, whole-wavefront refill, threaded host phases).
+    (1) SAM text identical to the same stream fed in three calls of four batches (results do not depend on the chunking);
+    (2) the first three reference batches equal the oracle's run over that prefix (the stream is sequential: a prefix of the
+        input gives a prefix of the output), stage by stage."""
+    B, n = 4096, 12 * 4096
+    ref = synth.make_reference(n_markers=400, n_long=0, seed=61, repeat_every=5)
+    pre = str(tmp_path / "ref.FASTQuick.fa")
+    ref.write_fasta(pre)
+    api.build_index(pre)
+    rb = synth.make_reads(ref, n, read_len=76, on_target=1.0, seed=62, sub_rate=0.01, del_frac=0.05, ins_frac=0.05, indel_len_max=2, frag_mean=200, frag_sd=20)
+    ix = api.Index(pre, device=0)
+    opts = api.default_opts(lib, batch_pairs=B)
+    al = api.Aligner(ix, opts, max_pairs=n, debug=True)
+    al.align(rb.seq, rb.qual, rb.lens, rb.names)
+    sam_one, stages_one = al.sam_text(), al.stage_text()
+    assert al.stats()["reads_searched"] > 65536
+    al.close()
+    al = api.Aligner(ix, api.default_opts(lib, batch_pairs=B), max_pairs=4 * B)
+    parts = []
+    for b0 in range(0, n, 4 * B):
+        al.align(rb.seq[:, b0:b0 + 4 * B], rb.qual[:, b0:b0 + 4 * B], rb.lens[:, b0:b0 + 4 * B], rb.names[b0:b0 + 4 * B])
+        parts.append(al.sam_text())
+    al.close()
+    assert b"".join(parts) == sam_one
+    k = 3 * B
+    oa = ob.OracleAligner(pre)
+    oa.align(rb.names[:k], rb.seq[:, :k], rb.qual[:, :k], rb.lens[:, :k], str(tmp_path / "o.st"), str(tmp_path / "o.sam"), batch=B)
+    want = open(str(tmp_path / "o.st"), "rb").read()
+    # the device's dump numbers the batches of the call 0..11; the oracle's 0..2: the first three sections must be identical
+    cut = stages_one.find(b"B 3 ")
+    assert cut > 0
+    with open(str(tmp_path / "g.st"), "wb") as fh:
+        fh.write(stages_one[:cut])
+    assert not [d for d in ob.diff_stage_files(str(tmp_path / "o.st"), str(tmp_path / "g.st")) if not d.startswith("line count")]
+    body = open(str(tmp_path / "o.sam"), "rb").read()
+    body = body[len(ix.sam_header()):] if body.startswith(ix.sam_header()) else body
+    assert sam_one.startswith(body), "SAM text of the first three reference batches"
+    oa.close(); ix.close()
