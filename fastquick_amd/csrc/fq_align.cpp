@@ -844,23 +844,41 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
     vector<uint16_t> scig;
     const int cig_cap = 64;
     if (!tasks.empty()) {
-      const int RL = std::max(max_reg, 1), QL = std::max(max_q, 1);
-      const size_t sstride = fq_dp_scratch_bytes(RL, QL);
-      const size_t chunk = std::max<size_t>(64, ((size_t)6 << 30) / sstride);
+      // Windows are a few hundred bases when the insert-size estimate is sane; a poor estimate (chimeric libraries) can ask for tens
+      // of thousands.  Tasks whose window fits the wavefront kernel's LDS go there; the rest run one per lane out of global scratch.
+      const int kWaveMax = getenv("FQ_SW_WAVE_MAX") ? atoi(getenv("FQ_SW_WAVE_MAX")) : 4096;   // (test hook: send ordinary windows down the serial path)
       scig.resize(tasks.size() * cig_cap);
-      for (size_t t0 = 0; t0 < tasks.size(); t0 += chunk) {
-        const int nt = (int)std::min(chunk, tasks.size() - t0);
-        CKM(c->d_swtask.ensure(nt) && c->d_swout.ensure(nt) && c->d_cig.ensure((size_t)nt * cig_cap) && c->d_scratch.ensure((size_t)nt * sstride));
-        CK(fqdev::h2d(c->d_swtask.p, tasks.data() + t0, (size_t)nt * sizeof(FqSwTask)));
-        FqSwArgs a{};
-        a.ix = ix->dev; a.seq = c->d_seq.p; a.stride = stride; a.len_trim = c->d_len_trim.p; a.task = c->d_swtask.p; a.n_task = nt;
-        a.out = c->d_swout.p; a.cigar = c->d_cig.p; a.cig_cap = cig_cap; a.scratch = c->d_scratch.p; a.scratch_stride = sstride; a.RL = RL; a.QL = QL;
-        fqdev::time_begin(FQ_K_SW);
-        CK(fqdev::launch_sw(a));
-        fqdev::time_end(FQ_K_SW);
-        CK(fqdev::d2h(souts.data() + t0, c->d_swout.p, (size_t)nt * sizeof(FqSwOut)));
-        CK(fqdev::d2h(scig.data() + t0 * cig_cap, c->d_cig.p, (size_t)nt * cig_cap * 2));
-        CK(fqdev::sync());
+      for (int big = 0; big < 2; ++big) {
+        vector<int> sel;
+        int RL = 1;
+        const int QL = std::max(max_q, 1);
+        for (size_t t = 0; t < tasks.size(); ++t)
+          if ((tasks[t].reglen > kWaveMax) == (big != 0)) { sel.push_back((int)t); RL = std::max(RL, tasks[t].reglen); }
+        if (sel.empty()) continue;
+        vector<FqSwTask> sub(sel.size());
+        for (size_t q = 0; q < sel.size(); ++q) sub[q] = tasks[sel[q]];
+        vector<FqSwOut> sub_out(sel.size());
+        vector<uint16_t> sub_cig(sel.size() * cig_cap);
+        const size_t sstride = fq_dp_scratch_bytes(RL, QL);
+        const size_t chunk = std::max<size_t>(64, ((size_t)6 << 30) / sstride);
+        for (size_t t0 = 0; t0 < sub.size(); t0 += chunk) {
+          const int nt = (int)std::min(chunk, sub.size() - t0);
+          CKM(c->d_swtask.ensure(nt) && c->d_swout.ensure(nt) && c->d_cig.ensure((size_t)nt * cig_cap) && c->d_scratch.ensure((size_t)nt * sstride));
+          CK(fqdev::h2d(c->d_swtask.p, sub.data() + t0, (size_t)nt * sizeof(FqSwTask)));
+          FqSwArgs a{};
+          a.ix = ix->dev; a.seq = c->d_seq.p; a.stride = stride; a.len_trim = c->d_len_trim.p; a.task = c->d_swtask.p; a.n_task = nt;
+          a.out = c->d_swout.p; a.cigar = c->d_cig.p; a.cig_cap = cig_cap; a.scratch = c->d_scratch.p; a.scratch_stride = sstride; a.RL = RL; a.QL = QL;
+          fqdev::time_begin(FQ_K_SW);
+          CK(big ? fqdev::launch_sw_serial(a) : fqdev::launch_sw(a));
+          fqdev::time_end(FQ_K_SW);
+          CK(fqdev::d2h(sub_out.data() + t0, c->d_swout.p, (size_t)nt * sizeof(FqSwOut)));
+          CK(fqdev::d2h(sub_cig.data() + t0 * cig_cap, c->d_cig.p, (size_t)nt * cig_cap * 2));
+          CK(fqdev::sync());
+        }
+        for (size_t q = 0; q < sel.size(); ++q) {
+          souts[sel[q]] = sub_out[q];
+          memcpy(&scig[(size_t)sel[q] * cig_cap], &sub_cig[q * cig_cap], (size_t)cig_cap * 2);
+        }
       }
       c->stats.sw_tasks += tasks.size();
     }

@@ -710,6 +710,16 @@ int launch_sw(const FqSwArgs &a) {
   FQ_HIP(hipGetLastError());
   return 0;
 }
+__global__ void __launch_bounds__(64) k_sw_thread(FqSwArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < a.n_task) fq_sw_thread(a, t);
+}
+int launch_sw_serial(const FqSwArgs &a) {
+  if (a.n_task <= 0) return 0;
+  hipLaunchKernelGGL(k_sw_thread, dim3(nblk((uint64_t)a.n_task, 64)), dim3(64), 0, g_stream, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
 int launch_refine(const FqRefineArgs &a) {
   if (a.n_task <= 0) return 0;
   // one task per wavefront while row arrays + sequences + trace matrix fit in LDS with several blocks per CU; longer reads

@@ -23,7 +23,9 @@ def lib():
 # search_mode: "lanes" = the default tiering (one read per lane; the wavefront-per-read kernel only takes over long searches
 # once the queue is dry), "wave1"/"wave64" = hand every search over to the wavefront-per-read kernel after 1 / 64 pops, so
 # that its parallel rounds, commit rule and run bookkeeping are exercised by every read of the case
-SEARCH_MODES = {"lanes": {}, "wave1": {"FQ_GAP_LONG_POPS": "1", "FQ_GAP_LONG_ALWAYS": "1"}, "wave64": {"FQ_GAP_LONG_POPS": "64", "FQ_GAP_LONG_ALWAYS": "1"}}
+SEARCH_MODES = {"lanes": {}, "wave1": {"FQ_GAP_LONG_POPS": "1", "FQ_GAP_LONG_ALWAYS": "1"},
+                # wave64 also sends every mate-SW window above 300 bases down the one-task-per-lane kernel (the path of oversize windows)
+                "wave64": {"FQ_GAP_LONG_POPS": "64", "FQ_GAP_LONG_ALWAYS": "1", "FQ_SW_WAVE_MAX": "300"}}
 
 
 @pytest.fixture(params=list(SEARCH_MODES))

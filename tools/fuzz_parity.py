@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Randomised parity soak: seeded random references / read sets / options, device path vs the oracle, stage dumps and SAM text.
+
+    python tools/fuzz_parity.py --seeds 40 --start 0          # needs a GPU; prints one line per case, exits non-zero on a mismatch
+"""
+import argparse, filecmp, os, random, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from fastquick_amd import api, synth
+import oracle_binding as ob
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seeds", type=int, default=20)
+ap.add_argument("--start", type=int, default=0)
+args = ap.parse_args()
+lib = api.load_library()
+bad = 0
+for seed in range(args.start, args.start + args.seeds):
+    rnd = random.Random(seed)
+    d = tempfile.mkdtemp(prefix="fqfuzz%d_" % seed)
+    refkw = dict(n_markers=rnd.choice([30, 80, 200]), n_long=rnd.choice([0, 4, 10]), seed=1000 + seed,
+                 repeat_every=rnd.choice([0, 2, 5]), tandem_every=rnd.choice([0, 7]))   # (no N in the reference: without a .rollhash the bitmaps of such a reference depend on libc rand())
+    refkw["n_long"] = min(refkw["n_long"], refkw["n_markers"])
+    read_len = rnd.choice([76, 100, 150, 150])
+    readkw = dict(read_len=read_len, on_target=rnd.choice([0.5, 0.9, 1.0]), seed=2000 + seed, sub_rate=rnd.choice([0.005, 0.02, 0.04]),
+                  del_frac=rnd.choice([0.0, 0.05, 0.1]), ins_frac=rnd.choice([0.0, 0.05, 0.1]), n_rate=rnd.choice([0.0, 0.003, 0.01]),
+                  indel_len_max=rnd.choice([1, 2, 3]), chimera_frac=rnd.choice([0.0, 0.05, 0.2]), qual_decay=rnd.random() < 0.4)
+    if read_len < 150:
+        readkw.update(frag_mean=read_len + 120, frag_sd=20)
+    okw = {}
+    if readkw["qual_decay"]:
+        okw["trim_qual"] = 15
+    pick = rnd.random()
+    if pick < 0.15: okw.update(max_entries=rnd.choice([300, 1000, 5000]))
+    elif pick < 0.3: okw.update(mode=1 | 2 | 0x10, max_top2=0x7fffffff)
+    elif pick < 0.45: okw.update(fnr=-1.0, max_diff=rnd.choice([2, 4, 6]), max_gapo=rnd.choice([1, 2]), max_gape=rnd.choice([3, 6]), mode=rnd.choice([2, 3]))
+    elif pick < 0.55: okw.update(s_mm=4, s_gapo=4, s_gape=rnd.choice([2, 4]))
+    elif pick < 0.65: okw.update(n_multi=rnd.choice([0, 8]), N_multi=rnd.choice([0, 20]), max_occ=rnd.choice([10, 50, 100000]), is_sw=rnd.choice([0, 1]))
+    mode = rnd.choice(["lanes", "lanes", "wave1", "wave64"])
+    for k in ("FQ_GAP_LONG_POPS", "FQ_GAP_LONG_ALWAYS"):
+        os.environ.pop(k, None)
+    if mode != "lanes":
+        os.environ["FQ_GAP_LONG_POPS"] = "1" if mode == "wave1" else "64"
+        os.environ["FQ_GAP_LONG_ALWAYS"] = "1"
+    n, batch = rnd.choice([(1500, 600), (3000, 3000), (5000, 2048)])
+    t0 = time.time()
+    ref = synth.make_reference(**refkw)
+    pre = os.path.join(d, "ref.FASTQuick.fa")
+    ref.write_fasta(pre); api.build_index(pre)
+    rb = synth.make_reads(ref, n, **readkw)
+    ix = api.Index(pre, device=0)
+    al = api.Aligner(ix, api.default_opts(lib, **okw), max_pairs=batch, debug=True)
+    api.align_stream(al, rb.names, rb.seq, rb.qual, rb.lens, batch, d + "/g.st", d + "/g.sam")
+    oa = ob.OracleAligner(pre, ob.default_opts(**okw))
+    oa.align(rb.names, rb.seq, rb.qual, rb.lens, d + "/o.st", d + "/o.sam", batch=batch)
+    diffs = [x for x in ob.diff_stage_files(d + "/o.st", d + "/g.st") if not x.startswith("line count")]
+    same = filecmp.cmp(d + "/o.sam", d + "/g.sam", shallow=False)
+    ok = not diffs and same
+    bad += 0 if ok else 1
+    print("seed %3d %-6s len %3d n %4d %s retries %d  %.1fs  %s" % (seed, mode, read_len, n, "OK  " if ok else "FAIL", al.stats()["tier_retries"], time.time() - t0,
+                                                                    "" if ok else (str(refkw) + str(readkw) + str(okw) + " " + str(diffs[:3]))), flush=True)
+    al.close(); ix.close(); oa.close()
+sys.exit(1 if bad else 0)
