@@ -42,22 +42,27 @@ for seed in range(args.start, args.start + args.seeds):
     if mode != "lanes":
         os.environ["FQ_GAP_LONG_POPS"] = "1" if mode == "wave1" else "64"
         os.environ["FQ_GAP_LONG_ALWAYS"] = "1"
-    n, batch = rnd.choice([(1500, 600), (3000, 3000), (5000, 2048)])
+    n, batch = rnd.choice([(1500, 600), (3000, 3000), (5000, 2048), (12000, 4000)])
+    call = batch * rnd.choice([1, 1, 2, 3])            # several reference batches per call
+    threads = rnd.choice([0, 0, 3, 8])
+    os.environ.pop("FQ_HOST_PAR_MIN", None)
+    if threads:
+        os.environ["FQ_HOST_PAR_MIN"] = "1"
     t0 = time.time()
     ref = synth.make_reference(**refkw)
     pre = os.path.join(d, "ref.FASTQuick.fa")
     ref.write_fasta(pre); api.build_index(pre)
     rb = synth.make_reads(ref, n, **readkw)
     ix = api.Index(pre, device=0)
-    al = api.Aligner(ix, api.default_opts(lib, **okw), max_pairs=batch, debug=True)
-    api.align_stream(al, rb.names, rb.seq, rb.qual, rb.lens, batch, d + "/g.st", d + "/g.sam")
+    al = api.Aligner(ix, api.default_opts(lib, batch_pairs=batch, host_threads=threads, **okw), max_pairs=call, debug=True)
+    api.align_stream(al, rb.names, rb.seq, rb.qual, rb.lens, call, d + "/g.st", d + "/g.sam")
     oa = ob.OracleAligner(pre, ob.default_opts(**okw))
     oa.align(rb.names, rb.seq, rb.qual, rb.lens, d + "/o.st", d + "/o.sam", batch=batch)
     diffs = [x for x in ob.diff_stage_files(d + "/o.st", d + "/g.st") if not x.startswith("line count")]
     same = filecmp.cmp(d + "/o.sam", d + "/g.sam", shallow=False)
     ok = not diffs and same
     bad += 0 if ok else 1
-    print("seed %3d %-6s len %3d n %4d %s retries %d  %.1fs  %s" % (seed, mode, read_len, n, "OK  " if ok else "FAIL", al.stats()["tier_retries"], time.time() - t0,
+    print("seed %3d %-6s len %3d n %5d call %5d thr %d %s retries %d  %.1fs  %s" % (seed, mode, read_len, n, call, threads, "OK  " if ok else "FAIL", al.stats()["tier_retries"], time.time() - t0,
                                                                     "" if ok else (str(refkw) + str(readkw) + str(okw) + " " + str(diffs[:3]))), flush=True)
     al.close(); ix.close(); oa.close()
 sys.exit(1 if bad else 0)
