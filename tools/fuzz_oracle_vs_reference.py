@@ -1,0 +1,59 @@
+#!/usr/bin/env python3
+"""Randomised pin of the oracle against the REAL reference (oracle/_ref/fq_ref_driver, built in place from /root/reference by
+`make -C oracle ref`; only possible in the build container).  Seeded random references / read sets / the options the driver
+exposes; the oracle must reproduce the reference's per-stage dump and SAM text.
+
+    python tools/fuzz_oracle_vs_reference.py --seeds 40 --start 0
+"""
+import argparse, filecmp, os, random, subprocess, sys, tempfile, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+from fastquick_amd import synth
+import oracle_binding as ob
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seeds", type=int, default=20)
+ap.add_argument("--start", type=int, default=0)
+args = ap.parse_args()
+if not os.path.exists(ob.REF_DRIVER):
+    sys.exit("oracle/_ref/fq_ref_driver missing: run `make -C oracle ref` in the build container")
+bad = 0
+for seed in range(args.start, args.start + args.seeds):
+    rnd = random.Random(seed)
+    refkw = dict(n_markers=rnd.choice([20, 60, 150]), n_long=rnd.choice([0, 3, 8]), seed=3000 + seed, repeat_every=rnd.choice([0, 2, 5]), tandem_every=rnd.choice([0, 7]))
+    read_len = rnd.choice([76, 100, 150, 150])
+    readkw = dict(read_len=read_len, on_target=rnd.choice([0.5, 0.9, 1.0]), seed=4000 + seed, sub_rate=rnd.choice([0.005, 0.02, 0.04]),
+                  del_frac=rnd.choice([0.0, 0.05, 0.1]), ins_frac=rnd.choice([0.0, 0.05, 0.1]), n_rate=rnd.choice([0.0, 0.003, 0.01]),
+                  indel_len_max=rnd.choice([1, 2, 3]), chimera_frac=rnd.choice([0.0, 0.05, 0.2]), qual_decay=rnd.random() < 0.4)
+    if read_len < 150:
+        readkw.update(frag_mean=read_len + 120, frag_sd=20)
+    n, batch = rnd.choice([(600, 250), (1200, 1200), (2500, 1000)])
+    extra, okw = ["--batch", batch], {}
+    if readkw["qual_decay"]:
+        extra += ["--q", 15]; okw["trim_qual"] = 15
+    pick = rnd.random()
+    if pick < 0.25:
+        md = rnd.choice([2, 4, 6]); extra += ["--n", md]; okw.update(fnr=-1.0, max_diff=md)
+    elif pick < 0.4:
+        extra += ["--no_sw", 0]; okw.update(is_sw=0)
+    elif pick < 0.5:
+        th = rnd.choice([1, 5]); extra += ["--thresh", th]; okw.update(filter_thresh=th)
+    t0 = time.time()
+    with tempfile.TemporaryDirectory(prefix="fqref%d_" % seed) as d:
+        ref = synth.make_reference(**refkw)
+        pre = os.path.join(d, "ref.FASTQuick.fa")
+        ref.write_fasta(pre)
+        subprocess.check_call([ob.REF_DRIVER, "index", pre], stderr=subprocess.DEVNULL, cwd=d)
+        rb = synth.make_reads(ref, n, **readkw)
+        f1, f2 = rb.write_fastq(os.path.join(d, "reads"))
+        ob.run_reference(pre, f1, f2, os.path.join(d, "ref_out"), *extra)
+        oa = ob.OracleAligner(pre, ob.default_opts(**okw))
+        oa.align(rb.names, rb.seq, rb.qual, rb.lens, d + "/o.st", d + "/o.sam", batch=batch)
+        oa.close()
+        diffs = [x for x in ob.diff_stage_files(d + "/ref_out.stages", d + "/o.st") if not x.startswith("line count")]
+        same = filecmp.cmp(d + "/ref_out.sam", d + "/o.sam", shallow=False)
+    ok = not diffs and same
+    bad += 0 if ok else 1
+    print("seed %3d len %3d n %4d batch %4d %-28s %s %.1fs %s" % (seed, read_len, n, batch, " ".join(map(str, extra[2:])), "OK  " if ok else "FAIL", time.time() - t0,
+                                                                  "" if ok else str(refkw) + str(readkw) + str(diffs[:2])), flush=True)
+sys.exit(1 if bad else 0)
