@@ -3,11 +3,11 @@
 `make -C oracle ref`; only possible in the build container).  Seeded random references / read sets / the options the driver
 exposes; the oracle must reproduce the reference's per-stage dump and SAM text.
 
-    python tools/fuzz_oracle_vs_reference.py --seeds 40 --start 0
+    python tests/fuzz_oracle_vs_reference.py --seeds 40 --start 0
 """
 import argparse, filecmp, os, random, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # (this file lives in tests/: checkers are the only code that may touch oracle/)
 from fastquick_amd import synth
 import oracle_binding as ob
 

@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Randomised parity soak: seeded random references / read sets / options, device path vs the oracle, stage dumps and SAM text.
 
-    python tools/fuzz_parity.py --seeds 40 --start 0          # needs a GPU; prints one line per case, exits non-zero on a mismatch
+    python tests/fuzz_parity.py --seeds 40 --start 0          # needs a GPU; prints one line per case, exits non-zero on a mismatch
 """
 import argparse, filecmp, os, random, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))   # (this file lives in tests/: checkers are the only code that may touch oracle/)
 from fastquick_amd import api, synth
 import oracle_binding as ob
 
