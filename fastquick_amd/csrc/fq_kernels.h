@@ -267,23 +267,34 @@ FQ_HD void fq_prep_thread(const FqPrepArgs &A, int r) {
       }
       kmer[ch] = k;
     }
-    // all 18 probes are issued before any is consumed (off-target reads need every one; memory-level parallelism)
+    // The probes are issued before any is consumed (memory-level parallelism).  An off-target read needs the verdict "fewer than
+    // thresh hits among 18": with thresh >= 3 that is certain once the first 16 all miss, so the last two are only fetched for the
+    // few reads that have a hit by then.  (The probe count reported below stays the reference's.)
+    const int th = A.o.filter_thresh;
     uint8_t byte[18];
     uint32_t bit[18];
+    const uint8_t *addr[18];
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
       for (int t = 0; t < 6; ++t) {
         const uint32_t x = fq_kmer_project(kmer[ch], t);
-        byte[6 * ch + t] = A.ix.bitmap[t][x >> 3];
+        addr[6 * ch + t] = A.ix.bitmap[t] + (x >> 3);
         bit[6 * ch + t] = x & 7u;
       }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) byte[q] = *addr[q];
+    byte[16] = byte[17] = 0;
+    if (th < 3) { byte[16] = *addr[16]; byte[17] = *addr[17]; }
+    int c16 = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) c16 += (byte[q] >> bit[q]) & 1;
+    if (th >= 3 && c16 + 2 >= th) { byte[16] = *addr[16]; byte[17] = *addr[17]; }
     int cnt[3] = {0, 0, 0};
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
       for (int t = 0; t < 6; ++t) cnt[ch] += (byte[6 * ch + t] >> bit[6 * ch + t]) & 1;
-    const int th = A.o.filter_thresh;
     // early-exit semantics of IsReadInHashByCountMoreChunck: pass as soon as the running count reaches thresh
     const bool p0 = cnt[0] >= th, p1 = cnt[0] + cnt[1] >= th, p2 = cnt[0] + cnt[1] + cnt[2] >= th;
     filt = p2 ? 0 : 1;

@@ -36,6 +36,7 @@ for seed in range(args.start, args.start + args.seeds):
     elif pick < 0.45: okw.update(fnr=-1.0, max_diff=rnd.choice([2, 4, 6]), max_gapo=rnd.choice([1, 2]), max_gape=rnd.choice([3, 6]), mode=rnd.choice([2, 3]))
     elif pick < 0.55: okw.update(s_mm=4, s_gapo=4, s_gape=rnd.choice([2, 4]))
     elif pick < 0.65: okw.update(n_multi=rnd.choice([0, 8]), N_multi=rnd.choice([0, 20]), max_occ=rnd.choice([10, 50, 100000]), is_sw=rnd.choice([0, 1]))
+    if rnd.random() < 0.3: okw.update(filter_thresh=rnd.choice([1, 2, 4, 5]))
     mode = rnd.choice(["lanes", "lanes", "wave1", "wave64"])
     for k in ("FQ_GAP_LONG_POPS", "FQ_GAP_LONG_ALWAYS"):
         os.environ.pop(k, None)
