@@ -361,8 +361,13 @@ FQ_HD void fq_width_thread(const FqWidthArgs &A, int t, uint8_t *seed_bits, int 
   if (use_seed) {   // bwt_cal_width over the last seed_len bases (src/BwtMapper.cpp:131-137)
     uint32_t k = 0, l = f.seq_len, wprev = 0;
     int bid = 0;
+    uint64_t seed8 = 0;
     for (int i = 0; i < A.o.seed_len; ++i) {
-      const int c = fq_base(v, strand, seed_off + i);
+      // seed position i is byte seed_len-1-i of the row: eight positions per 8-byte load, as below
+      if ((i & 7) == 0 && i + 8 <= A.o.seed_len) memcpy(&seed8, v.row + (A.o.seed_len - 8 - i), 8);
+      int c;
+      if ((i | 7) < A.o.seed_len) { c = (int)fq_nt4_fast((uint32_t)(seed8 >> (8 * (7 - (i & 7)))) & 0xffu); if (strand && c < 4) c = 3 - c; }
+      else c = fq_base(v, strand, seed_off + i);
       if (c < 4) {
         touches += fq_touch2(f, k - 1, l, true);
         uint32_t ok, ol;
@@ -380,12 +385,18 @@ FQ_HD void fq_width_thread(const FqWidthArgs &A, int t, uint8_t *seed_bits, int 
   int bid = 0, namb = 0;
   for (int i0 = 0; i0 < v.len; i0 += 8) {
     uint32_t wv[8], pv[8];
+    // the eight bases of this group sit in eight consecutive bytes of the row (the search walks the read backwards): one load
+    uint64_t bases8 = 0;
+    const bool whole = i0 + 8 <= v.len;
+    if (whole) memcpy(&bases8, v.row + (v.len - 8 - i0), 8);
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int i = i0 + j;
       wv[j] = 0; pv[j] = 0;
       if (i < v.len) {
-        const int c = fq_base(v, strand, i);
+        int c;
+        if (whole) { c = (int)fq_nt4_fast((uint32_t)(bases8 >> (8 * (7 - j))) & 0xffu); if (strand && c < 4) c = 3 - c; }
+        else c = fq_base(v, strand, i);
         namb += c > 3;
         if (c < 4) {
           touches += fq_touch2(f, k - 1, l, true);
