@@ -1833,7 +1833,25 @@ FQ_HD void fq_md_thread(const FqMdArgs &A, int t) {
       }
     }
   } else {
-    for (int z = 0; z < slen; ++z) {
+    // ungapped (almost every read): eight positions per pair of loads -- 8 read bytes, 4 bytes of the 2-bit reference
+    int z = 0;
+    for (; z + 8 <= slen; z += 8) {
+      uint64_t rb;
+      uint32_t pb;
+      memcpy(&rb, T.strand ? row + (slen - 8 - z) : row + z, 8);
+      const uint32_t k0 = x + (uint32_t)z;
+      memcpy(&pb, A.ix.pac + (k0 >> 2), 4);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const uint32_t kk = k0 + (uint32_t)j;
+        const int c = (int)((pb >> (8 * ((kk >> 2) - (k0 >> 2)))) >> ((~kk & 3u) << 1)) & 3;
+        const int ch = (int)(rb >> (8 * (T.strand ? 7 - j : j))) & 0xff;
+        const int sc = T.strand ? fq_comp(fq_nt4((uint8_t)ch)) : fq_nt4((uint8_t)ch);
+        if (sc > 3 || c != sc) { at = fq_put_int(dst, at, cap, u); if (at < cap) dst[at] = "ACGTN"[c]; ++at; ++nm; u = 0; }
+        else ++u;
+      }
+    }
+    for (; z < slen; ++z) {
       const int c = fq_pac_base(A.ix.pac, (int64_t)(uint32_t)(x + z));
       const int sc = T.strand ? fq_comp(fq_nt4(row[slen - 1 - z])) : fq_nt4(row[z]);
       if (sc > 3 || c != sc) { at = fq_put_int(dst, at, cap, u); if (at < cap) dst[at] = "ACGTN"[c]; ++at; ++nm; u = 0; }
