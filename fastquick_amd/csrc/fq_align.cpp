@@ -439,11 +439,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   CKM(c->d_len_trim.ensure(n2) && c->d_filtered.ensure(n2 + 64) && c->d_read_list.ensure(n2) &&
       c->d_sidx.ensure(n2) && c->d_pair_list.ensure(n) && c->d_sub_max.ensure(n_sub));
   CK(fqdev::dzero(c->d_sub_max.p, (size_t)n_sub * 4));
-  // The filter kernel fills the device and is bound by its random probes; two of them at once only slow each other down (and
-  // evict each other's lines).  Contexts therefore take turns for it, while their small, latency-bound kernels overlap freely.
-  static const bool take_turns = getenv("FQ_FILTER_NO_TURNS") == nullptr;
-  std::unique_lock<std::mutex> turn(ix->filter_turn, std::defer_lock);   // per index = per device
-  if (take_turns) turn.lock();
+  // (the filter kernels of all contexts of a device are chained on the device: fqdev::launch_prep)
   {
     FqPrepArgs a{};
     a.ix = ix->dev; a.o = c->ko; a.seq = c->d_seq.p; a.qual = c->d_qual.p; a.len = c->d_len.p; a.stride = stride; a.n_reads = n2;
@@ -461,7 +457,6 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   CK(fqdev::d2h(counts, c->d_counts.p, 8));
   CK(fqdev::d2h(c->h_sub_max.data(), c->d_sub_max.p, (size_t)n_sub * 4));
   CK(fqdev::sync());
-  if (take_turns) turn.unlock();
   const int n_search = counts[0], n_surv = counts[1];
   c->h_pair_list.resize(n_surv);
   c->h_read_list.resize(n_search);

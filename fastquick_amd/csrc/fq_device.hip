@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -575,11 +576,32 @@ int launch_bitmap_scatter(uint8_t *bitmap, const uint32_t *bits, uint64_t n) {
 }
 
 // ---- launch wrappers ------------------------------------------------------------------------------
+// The filter kernel fills the device and is bound by its random probes: two of them at once only slow each other down.  The
+// launches of all streams (threads) of a device are therefore chained on the device: each waits for the previous one's
+// completion event, so they run back to back without a host round trip in between, while everything else a stream does
+// overlaps freely.  FQ_FILTER_NO_TURNS lets them overlap.
+static std::mutex g_prep_chain_mu;
+static hipEvent_t g_prep_last[64];     // per device: completion of the most recent filter kernel
+static bool g_prep_has[64];
 int launch_prep(const FqPrepArgs &a) {
   if (a.n_reads <= 0) return 0;
+  static const bool chain = getenv("FQ_FILTER_NO_TURNS") == nullptr;
+  static thread_local hipEvent_t my_done = nullptr;   // (never destroyed: another stream may still be waiting on it)
   hipEvent_t e0, e1;
   kernel_events(6, &e0, &e1);   // FQ_K_PREP_KERNEL
-  hipExtLaunchKernelGGL(k_prep, dim3(nblk((uint64_t)a.n_reads, 256)), dim3(256), 0, g_stream, e0, e1, 0, a);
+  if (chain) {
+    if (!my_done) FQ_HIP(hipEventCreateWithFlags(&my_done, hipEventDisableTiming));
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    std::lock_guard<std::mutex> lk(g_prep_chain_mu);
+    if (g_prep_has[dev]) FQ_HIP(hipStreamWaitEvent(g_stream, g_prep_last[dev], 0));
+    hipExtLaunchKernelGGL(k_prep, dim3(nblk((uint64_t)a.n_reads, 256)), dim3(256), 0, g_stream, e0, e1, 0, a);
+    FQ_HIP(hipEventRecord(my_done, g_stream));
+    g_prep_last[dev] = my_done; g_prep_has[dev] = true;
+  } else {
+    hipExtLaunchKernelGGL(k_prep, dim3(nblk((uint64_t)a.n_reads, 256)), dim3(256), 0, g_stream, e0, e1, 0, a);
+  }
   FQ_HIP(hipGetLastError());
   return 0;
 }

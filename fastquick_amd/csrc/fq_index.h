@@ -27,7 +27,6 @@ struct fq_index {
   std::vector<uint8_t> pac;
   // device
   FqDevIndex dev{};
-  mutable std::mutex filter_turn;   // contexts on this device take turns for the device-filling filter kernel (fq_align.cpp)
   void *d_blk[2] = {nullptr, nullptr};
   void *d_sa[2] = {nullptr, nullptr};
   void *d_pac = nullptr;
