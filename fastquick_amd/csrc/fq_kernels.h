@@ -272,24 +272,23 @@ FQ_HD void fq_prep_thread(const FqPrepArgs &A, int r) {
     // few reads that have a hit by then.  (The probe count reported below stays the reference's.)
     const int th = A.o.filter_thresh;
     uint8_t byte[18];
-    uint32_t bit[18];
-    const uint8_t *addr[18];
+    uint32_t bit[18], off[18];          // byte offsets into the six tables (their bases are kernel arguments: scalar registers)
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
 #pragma unroll
       for (int t = 0; t < 6; ++t) {
         const uint32_t x = fq_kmer_project(kmer[ch], t);
-        addr[6 * ch + t] = A.ix.bitmap[t] + (x >> 3);
+        off[6 * ch + t] = x >> 3;
         bit[6 * ch + t] = x & 7u;
       }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) byte[q] = *addr[q];
+    for (int q = 0; q < 16; ++q) byte[q] = A.ix.bitmap[q % 6][off[q]];
     byte[16] = byte[17] = 0;
-    if (th < 3) { byte[16] = *addr[16]; byte[17] = *addr[17]; }
+    if (th < 3) { byte[16] = A.ix.bitmap[4][off[16]]; byte[17] = A.ix.bitmap[5][off[17]]; }
     int c16 = 0;
 #pragma unroll
     for (int q = 0; q < 16; ++q) c16 += (byte[q] >> bit[q]) & 1;
-    if (th >= 3 && c16 + 2 >= th) { byte[16] = *addr[16]; byte[17] = *addr[17]; }
+    if (th >= 3 && c16 + 2 >= th) { byte[16] = A.ix.bitmap[4][off[16]]; byte[17] = A.ix.bitmap[5][off[17]]; }
     int cnt[3] = {0, 0, 0};
 #pragma unroll
     for (int ch = 0; ch < 3; ++ch)
