@@ -126,6 +126,7 @@ static int cmd_align(int argc, char **argv) {
     else if (!strcmp(argv[i], "--thresh")) thresh = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--n")) { opt->max_diff = atoi(argv[i + 1]); opt->fnr = -1.0; }
     else if (!strcmp(argv[i], "--no_sw")) popt->is_sw = 0;
+    else if (!strcmp(argv[i], "--read_len")) opt->read_len = atoi(argv[i + 1]);   // the reference's --read_len: its buffers are sized once from it
     else die("unknown option");
   }
   if (batch > READ_BUFFER_SIZE) die("--batch too large");
