@@ -39,6 +39,10 @@ CASES = {
               dict(on_target=0.7, seed=204, chimera_frac=0.3), 130, 100, 0),
     "nref": (dict(n_markers=12, n_long=1, seed=105, n_frac=0.002),
              dict(on_target=0.9, seed=205, n_rate=0.01, chimera_frac=0.1, qual_decay=True), 200, 200, 15),
+    # 250 bp reads: the reference needs --read_len (its buffers are sized once from it); longer DP windows on the device
+    "long250": (dict(n_markers=12, n_long=3, seed=106),
+                dict(read_len=250, on_target=0.9, seed=206, sub_rate=0.01, del_frac=0.06, ins_frac=0.05, indel_len_max=3,
+                     chimera_frac=0.08, frag_mean=430, frag_sd=30), 160, 160, 0),
 }
 INDEX_EXT = [".bwt", ".rbwt", ".sa", ".rsa", ".pac", ".ann", ".amb"]
 
@@ -56,7 +60,10 @@ def sparse_to_npz(path_sparse: str, path_npz: str) -> None:
 def main() -> None:
     if not os.path.exists(ob.REF_DRIVER):
         sys.exit("oracle/_ref/fq_ref_driver missing: run `make -C oracle ref` in the build container")
+    only = set(sys.argv[1:])   # optional: regenerate just these cases (inputs of the others are committed and stay as they are)
     for tag, (refkw, readkw, n, batch, q) in CASES.items():
+        if only and tag not in only:
+            continue
         out = os.path.join(HERE, tag)
         shutil.rmtree(out, ignore_errors=True)
         os.makedirs(out)
@@ -67,7 +74,7 @@ def main() -> None:
             subprocess.check_call([ob.REF_DRIVER, "index", pre], stderr=subprocess.DEVNULL, cwd=tmp)
             rb = synth.make_reads(ref, n, **readkw)
             f1, f2 = rb.write_fastq(os.path.join(tmp, "reads"))
-            args = ["--batch", batch] + (["--q", q] if q else [])
+            args = ["--batch", batch] + (["--q", q] if q else []) + (["--read_len", readkw["read_len"] + 1] if readkw.get("read_len", 150) > 150 else [])
             ob.run_reference(pre, f1, f2, os.path.join(tmp, "ref_out"), *args)
             shutil.copy(pre, os.path.join(out, "ref.FASTQuick.fa"))
             for ext in INDEX_EXT:
