@@ -818,7 +818,9 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
         if (pref->strand == 0) {   // __set_rght_coor (:511-516)
           beg = (int64_t)((int64_t)pref->pos + ii.avg - 3 * ii.std - pm->len * 1.5);
           end = (int64_t)(beg + 6 * ii.std + 2 * pm->len);
-          if (beg < (int64_t)pref->pos + pref->len) beg = (int64_t)pref->pos + pref->len;
+          // the macro assigns `_pref->pos + _pref->len` in 32-bit unsigned arithmetic (it wraps for a hit hanging over the start of the
+          // reference, pos = 2^32-1) after comparing in 64 bits
+          if (beg < (int64_t)pref->pos + pref->len) beg = (int64_t)(uint32_t)((uint32_t)pref->pos + (uint32_t)pref->len);
           if (end > ix->l_pac) end = ix->l_pac;
           T.use_rc = 1;
         } else {                   // __set_left_coor (:518-523)
