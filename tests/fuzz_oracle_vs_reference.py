@@ -14,6 +14,7 @@ import oracle_binding as ob
 ap = argparse.ArgumentParser()
 ap.add_argument("--seeds", type=int, default=20)
 ap.add_argument("--start", type=int, default=0)
+ap.add_argument("--adversarial", action="store_true", help="tiny, repeat-rich references and error-rich reads: edge and tie-breaking cases")
 args = ap.parse_args()
 if not os.path.exists(ob.REF_DRIVER):
     sys.exit("oracle/_ref/fq_ref_driver missing: run `make -C oracle ref` in the build container")
@@ -21,10 +22,14 @@ bad = 0
 for seed in range(args.start, args.start + args.seeds):
     rnd = random.Random(seed)
     refkw = dict(n_markers=rnd.choice([20, 60, 150]), n_long=rnd.choice([0, 3, 8]), seed=3000 + seed, repeat_every=rnd.choice([0, 2, 5]), tandem_every=rnd.choice([0, 7]))
+    if args.adversarial:
+        refkw.update(n_markers=rnd.choice([3, 5, 8]), n_long=rnd.choice([0, 1]), repeat_every=rnd.choice([1, 2, 3]), tandem_every=rnd.choice([0, 2, 5]))
     read_len = rnd.choice([76, 100, 150, 150, 250])
     readkw = dict(read_len=read_len, on_target=rnd.choice([0.5, 0.9, 1.0]), seed=4000 + seed, sub_rate=rnd.choice([0.005, 0.02, 0.04]),
                   del_frac=rnd.choice([0.0, 0.05, 0.1]), ins_frac=rnd.choice([0.0, 0.05, 0.1]), n_rate=rnd.choice([0.0, 0.003, 0.01]),
                   indel_len_max=rnd.choice([1, 2, 3]), chimera_frac=rnd.choice([0.0, 0.05, 0.2]), qual_decay=rnd.random() < 0.4)
+    if args.adversarial:
+        readkw.update(on_target=1.0, sub_rate=rnd.choice([0.01, 0.03, 0.06]), del_frac=rnd.choice([0.1, 0.2]), ins_frac=rnd.choice([0.1, 0.2]), chimera_frac=rnd.choice([0.1, 0.3]))
     if read_len < 150:
         readkw.update(frag_mean=read_len + 120, frag_sd=20)
     n, batch = rnd.choice([(600, 250), (1200, 1200), (2500, 1000)])
