@@ -12,6 +12,7 @@ import oracle_binding as ob
 ap = argparse.ArgumentParser()
 ap.add_argument("--seeds", type=int, default=20)
 ap.add_argument("--start", type=int, default=0)
+ap.add_argument("--adversarial", action="store_true", help="tiny, repeat-rich references and error-rich reads: edge and tie-breaking cases")
 args = ap.parse_args()
 lib = api.load_library()
 bad = 0
@@ -21,10 +22,14 @@ for seed in range(args.start, args.start + args.seeds):
     refkw = dict(n_markers=rnd.choice([30, 80, 200]), n_long=rnd.choice([0, 4, 10]), seed=1000 + seed,
                  repeat_every=rnd.choice([0, 2, 5]), tandem_every=rnd.choice([0, 7]))   # (no N in the reference: without a .rollhash the bitmaps of such a reference depend on libc rand())
     refkw["n_long"] = min(refkw["n_long"], refkw["n_markers"])
+    if args.adversarial:
+        refkw.update(n_markers=rnd.choice([3, 5, 8]), n_long=rnd.choice([0, 1]), repeat_every=rnd.choice([1, 2, 3]), tandem_every=rnd.choice([0, 2, 5]))
     read_len = rnd.choice([76, 100, 150, 150, 250])
     readkw = dict(read_len=read_len, on_target=rnd.choice([0.5, 0.9, 1.0]), seed=2000 + seed, sub_rate=rnd.choice([0.005, 0.02, 0.04]),
                   del_frac=rnd.choice([0.0, 0.05, 0.1]), ins_frac=rnd.choice([0.0, 0.05, 0.1]), n_rate=rnd.choice([0.0, 0.003, 0.01]),
                   indel_len_max=rnd.choice([1, 2, 3]), chimera_frac=rnd.choice([0.0, 0.05, 0.2]), qual_decay=rnd.random() < 0.4)
+    if args.adversarial:
+        readkw.update(on_target=1.0, sub_rate=rnd.choice([0.01, 0.03, 0.06]), del_frac=rnd.choice([0.1, 0.2]), ins_frac=rnd.choice([0.1, 0.2]), chimera_frac=rnd.choice([0.1, 0.3]))
     if read_len < 150:
         readkw.update(frag_mean=read_len + 120, frag_sd=20)
     okw = {}
