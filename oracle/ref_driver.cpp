@@ -126,7 +126,25 @@ static int cmd_align(int argc, char **argv) {
     else if (!strcmp(argv[i], "--thresh")) thresh = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--n")) { opt->max_diff = atoi(argv[i + 1]); opt->fnr = -1.0; }
     else if (!strcmp(argv[i], "--no_sw")) popt->is_sw = 0;
-    else if (!strcmp(argv[i], "--read_len")) opt->read_len = atoi(argv[i + 1]);   // the reference's --read_len: its buffers are sized once from it
+    else if (!strcmp(argv[i], "--read_len")) opt->read_len = atoi(argv[i + 1]);
+    // the remaining gap_opt_t / pe_opt_t fields, set the way runAlign sets them (src/FASTQuick.cpp:278-335)
+    else if (!strcmp(argv[i], "--o")) opt->max_gapo = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--e")) { opt->max_gape = atoi(argv[i + 1]); if (opt->max_gape > 0) opt->mode &= ~BWA_MODE_GAPE; }
+    else if (!strcmp(argv[i], "--i")) opt->indel_end_skip = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--d")) opt->max_del_occ = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--l")) opt->seed_len = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--k")) opt->max_seed_diff = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--m")) opt->max_entries = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--R")) opt->max_top2 = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--N")) { opt->mode |= BWA_MODE_NONSTOP; opt->max_top2 = 0x7fffffff; }
+    else if (!strcmp(argv[i], "--L")) opt->mode |= BWA_MODE_LOGGAP;
+    else if (!strcmp(argv[i], "--M")) opt->s_mm = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--O")) opt->s_gapo = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--E")) opt->s_gape = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--max_isize")) popt->max_isize = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--max_occ")) popt->max_occ = (uint32_t)atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--n_multi")) popt->n_multi = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--N_multi")) popt->N_multi = atoi(argv[i + 1]);   // the reference's --read_len: its buffers are sized once from it
     else die("unknown option");
   }
   if (batch > READ_BUFFER_SIZE) die("--batch too large");

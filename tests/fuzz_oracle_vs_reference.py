@@ -45,6 +45,28 @@ for seed in range(args.start, args.start + args.seeds):
         extra += ["--no_sw", 0]; okw.update(is_sw=0)
     elif pick < 0.5:
         th = rnd.choice([1, 5]); extra += ["--thresh", th]; okw.update(filter_thresh=th)
+    # the other gap_opt_t / pe_opt_t fields (driver options named after the reference's command line)
+    mode = 1 | 2        # BWA_MODE_GAPE | COMPREAD, the defaults
+    for _ in range(rnd.choice([0, 0, 1, 2, 3])):
+        o = rnd.choice(["o", "e", "i", "d", "l", "k", "m", "R", "N", "L", "scores", "max_isize", "max_occ", "multi"])
+        if o == "o": v = rnd.choice([0, 2]); extra += ["--o", v]; okw["max_gapo"] = v
+        elif o == "e": v = rnd.choice([2, 6]); extra += ["--e", v]; okw["max_gape"] = v; mode &= ~1
+        elif o == "i": v = rnd.choice([1, 10]); extra += ["--i", v]; okw["indel_end_skip"] = v
+        elif o == "d": v = rnd.choice([1, 100]); extra += ["--d", v]; okw["max_del_occ"] = v
+        elif o == "l": v = rnd.choice([20, 40]); extra += ["--l", v]; okw["seed_len"] = v
+        elif o == "k": v = rnd.choice([0, 1, 3]); extra += ["--k", v]; okw["max_seed_diff"] = v
+        elif o == "m": v = rnd.choice([200, 2000, 50000]); extra += ["--m", v]; okw["max_entries"] = v
+        elif o == "R": v = rnd.choice([1, 5]); extra += ["--R", v]; okw["max_top2"] = v
+        elif o == "N": extra += ["--N", 0]; mode |= 0x10; okw["max_top2"] = 0x7fffffff
+        elif o == "L": extra += ["--L", 0]; mode |= 4
+        elif o == "scores":
+            m_, o_, e_ = rnd.choice([(3, 11, 4), (4, 4, 4), (2, 8, 3), (5, 7, 5)])
+            extra += ["--M", m_, "--O", o_, "--E", e_]; okw.update(s_mm=m_, s_gapo=o_, s_gape=e_)
+        elif o == "max_isize": v = rnd.choice([200, 1000]); extra += ["--max_isize", v]; okw["max_isize"] = v
+        elif o == "max_occ": v = rnd.choice([2, 20]); extra += ["--max_occ", v]; okw["max_occ"] = v
+        elif o == "multi": a, b = rnd.choice([(0, 0), (8, 20), (1, 2)]); extra += ["--n_multi", a, "--N_multi", b]; okw.update(n_multi=a, N_multi=b)
+    if mode != (1 | 2):
+        okw["mode"] = mode
     t0 = time.time()
     with tempfile.TemporaryDirectory(prefix="fqref%d_" % seed) as d:
         ref = synth.make_reference(**refkw)
