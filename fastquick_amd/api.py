@@ -30,7 +30,7 @@ class Opts(C.Structure):
 
 class ReadBatch(C.Structure):
     _fields_ = [("n_pairs", C.c_int32), ("stride", C.c_int32), ("seq", C.c_void_p), ("qual", C.c_void_p),
-                ("len", C.c_void_p), ("names", C.c_void_p), ("name_stride", C.c_int32)]
+                ("len", C.c_void_p), ("names", C.c_void_p), ("name_stride", C.c_int32), ("names_mate", C.c_void_p)]
 
 
 class Multi(C.Structure):
@@ -160,6 +160,18 @@ class Index:
             self.h = None
 
 
+class PairNames(list):
+    """Read names of the first mates; `.mate` holds the second mates' names when they differ (else None)."""
+    mate = None
+
+    def __getitem__(self, k):
+        out = list.__getitem__(self, k)
+        if isinstance(k, slice):
+            out = PairNames(out)
+            out.mate = self.mate[k] if self.mate is not None else None
+        return out
+
+
 def pack_names(names, stride: int = 64) -> np.ndarray:
     buf = np.zeros((len(names), stride), dtype=np.uint8)
     for i, nm in enumerate(names):
@@ -189,10 +201,12 @@ class Aligner:
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
         qual = np.ascontiguousarray(qual, dtype=np.uint8)
         lens = np.ascontiguousarray(lens, dtype=np.int32)
+        mate = getattr(names, "mate", None)     # PairNames: the second mates' names where the two files disagree
         nm = pack_names(names) if names is not None else None
+        nm2 = pack_names(mate) if mate is not None else None
         b = ReadBatch(seq.shape[1], seq.shape[2], seq.ctypes.data, qual.ctypes.data, lens.ctypes.data,
-                      nm.ctypes.data if nm is not None else None, 64)
-        self._keep = (seq, qual, lens, nm, b)   # the library reads these until the next call
+                      nm.ctypes.data if nm is not None else None, 64, nm2.ctypes.data if nm2 is not None else None)
+        self._keep = (seq, qual, lens, nm, nm2, b)   # the library reads these until the next call
         return b
 
     def _check(self, rc, what):

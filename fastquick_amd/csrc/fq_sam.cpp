@@ -59,9 +59,9 @@ int64_t ref_end_multi(const FqMulti &q, int len) {
 }
 int64_t five_prime(const FqRead &p) { return p.type != FQ_TYPE_NO_MATCH ? (p.strand ? ref_end(p) : (int64_t)p.pos) : -1; }
 
-std::string read_name(const fq_read_batch_t *hb, int pair) {
+std::string read_name(const fq_read_batch_t *hb, int pair, int end) {
   if (!hb->names) return "*";
-  const char *nm = hb->names + (size_t)pair * (size_t)hb->name_stride;
+  const char *nm = (end && hb->names_mate ? hb->names_mate : hb->names) + (size_t)pair * (size_t)hb->name_stride;
   std::string s(nm, strnlen(nm, (size_t)hb->name_stride));
   const size_t t = s.size();
   if (t > 2 && s[t - 2] == '/' && (s[t - 1] == '1' || s[t - 1] == '2')) s.resize(t - 2);   // BwtMapper.cpp:565-570
@@ -71,7 +71,7 @@ std::string read_name(const fq_read_batch_t *hb, int pair) {
 void print_sam(const fq_index *ix, const fq_opts_t *o, const fq_read_batch_t *hb, int n_pairs, Out &out, FqRead p, const FqRead &mate) {
   const int pair = p.r % n_pairs;
   const uint8_t *seq = hb->seq + (size_t)p.r * (size_t)hb->stride, *qual = hb->qual + (size_t)p.r * (size_t)hb->stride;
-  const std::string name = read_name(hb, pair);
+  const std::string name = read_name(hb, pair, p.r / n_pairs);
   // only called when at least one mate is mapped (both-unmapped pairs are dropped before, BwtMapper.cpp:2038)
   int seqid, nn, am = 0, flag = p.extra_flag, j;
   if (p.type == FQ_TYPE_NO_MATCH) { p.pos = mate.pos; p.strand = mate.strand; flag |= 4; j = 1; }

@@ -44,7 +44,7 @@ class SynthRef:
 
 def make_reference(n_markers: int = 40, n_long: int = 4, flank_short: int = 250, flank_long: int = 1000,
                    spacing: int = 3000, seed: int = 12345, repeat_every: int = 0, repeat_div: float = 0.005,
-                   n_frac: float = 0.0, tandem_every: int = 0) -> SynthRef:
+                   n_frac: float = 0.0, tandem_every: int = 0, patch=None) -> SynthRef:
     """Build a synthetic genome + reduced reference.
 
     repeat_every>0 makes every `repeat_every`-th window a diverged copy of its predecessor
@@ -70,6 +70,8 @@ def make_reference(n_markers: int = 40, n_long: int = 4, flank_short: int = 250,
                 genome[p + 40 * r:p + 40 * (r + 1)] = unit
     pos = 2000 + spacing * np.arange(n_markers, dtype=np.int64)   # 1-based
     flank = np.where(np.arange(n_markers) < n_long, flank_long, flank_short).astype(np.int64)
+    if patch is not None:      # caller-supplied edit of the genome (codes 0..3) before the flanks are cut, e.g. to plant given reads
+        patch(genome, pos, flank, rng)
     names, seqs = [], []
     for k in range(n_markers):
         p, f = int(pos[k]), int(flank[k])

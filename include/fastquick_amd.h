@@ -62,7 +62,9 @@ void fq_default_opts(fq_opts_t *o);
 /* One batch of read pairs as produced by the FASTQ tokenizer (replaces the output side of
  * bwa_read_seq_with_hash_dev, src/BwtMapper.cpp:476-613, before encoding/trim/filter which now
  * run on the GPU).  Row r of end e starts at seq + ((size_t)e*n_pairs + r)*stride; ASCII bases and
- * Sanger qualities; names are NUL-terminated rows of name_stride bytes shared by both mates. */
+ * Sanger qualities; names are NUL-terminated rows of name_stride bytes.  The reference keeps one name per read
+ * (bwa_seq_t::name, libbwa/bwaseqio.c:210) and prints each record under its own: when the second mates' names differ from
+ * the first mates' pass them in names_mate (same stride), otherwise leave it NULL and both mates print `names`. */
 typedef struct {
   int32_t n_pairs;
   int32_t stride;
@@ -71,6 +73,7 @@ typedef struct {
   const int32_t *len;         /* [2*n_pairs] */
   const char *names;          /* may be NULL when only records (no SAM text) are wanted */
   int32_t name_stride;
+  const char *names_mate;     /* NULL: the second mates carry the same names */
 } fq_read_batch_t;
 
 /* XA hit: bwt_multi1_t (libbwa/bwtaln.h:51-55) */

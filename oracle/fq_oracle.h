@@ -52,10 +52,10 @@ fqo_ctx *fqo_ctx_create(const fqo_index *ix, const fqo_opts *o);
 void fqo_ctx_free(fqo_ctx *c);
 
 /* One batch of n pairs.  seq/qual: ASCII, row i of end e at base + (e*n + i)*stride; lens[e*n+i];
- * names: n rows of name_stride bytes, NUL terminated.  Writes the canonical stage dump to
+ * names: n rows of name_stride bytes, NUL terminated; names_mate: the second mates' names when they differ, else NULL.  Writes the canonical stage dump to
  * `stages` and reduced-coordinate SAM text (bwa_print_sam1 dialect) to `sam`; either may be NULL.
  * Returns number of pairs that produced SAM records, <0 on error. */
-int fqo_align_batch(fqo_ctx *c, int n, const char *names, int name_stride, const uint8_t *seq, const uint8_t *qual,
+int fqo_align_batch(fqo_ctx *c, int n, const char *names, const char *names_mate, int name_stride, const uint8_t *seq, const uint8_t *qual,
                     const int32_t *lens, int stride, FILE *stages, FILE *sam);
 void fqo_print_sam_header(const fqo_index *ix, FILE *sam);
 

@@ -44,6 +44,92 @@ CASES = {
                 dict(read_len=250, on_target=0.9, seed=206, sub_rate=0.01, del_frac=0.06, ins_frac=0.05, indel_len_max=3,
                      chimera_frac=0.08, frag_mean=430, frag_sd=30), 160, 160, 0),
 }
+# Real reads: the 251 pairs of 151 bp (one of 137 bp; lower-case bases, Illumina names with comments, real quality strings) that
+# the reference ships as its own example input (example/fq.test.list).  The reference FASTA its example.sh names is not in the
+# repository, so the reduced reference is synthetic with 118 of the pairs planted in marker flanks (lightly mutated copies).
+EXAMPLE_FQ = ("/root/reference/example/ERR013170_1.filt.fastq.gz.1000.fastq.gz",
+              "/root/reference/example/ERR013170_2.filt.fastq.gz.1000.fastq.gz")
+EXAMPLE_CASE = ("example151", dict(n_markers=100, n_long=6, seed=107), 128, 15)
+
+
+def read_fastq_raw(path):
+    with gzip.open(path, "rb") as fh:
+        lines = fh.read().split(b"\n")
+    return [(lines[i], lines[i + 1], lines[i + 3]) for i in range(0, len(lines) - 3, 4)]
+
+
+def plant_pairs(r1, r2):
+    code = np.full(256, 255, dtype=np.uint8)
+    for i, c in enumerate(b"ACGT"):
+        code[c] = i
+        code[c + 32] = i
+
+    def codes(seq, rng):
+        c = code[np.frombuffer(seq, dtype=np.uint8)].copy()
+        bad = c == 255
+        c[bad] = rng.integers(0, 4, int(bad.sum()), dtype=np.uint8)
+        return c
+
+    def patch(genome, pos, flank, rng):
+        nxt = 0
+        for k in range(len(pos)):
+            lo, hi = int(pos[k]) - 1 - int(flank[k]), int(pos[k]) + int(flank[k])
+            at = lo + int(rng.integers(0, 30))
+            while nxt < len(r1):
+                a = codes(r1[nxt][1], rng)
+                b = (3 - codes(r2[nxt][1], rng))[::-1]
+                frag = np.concatenate([a, rng.integers(0, 4, int(rng.integers(0, 140)), dtype=np.uint8), b])
+                if rng.random() < 0.5:
+                    frag = (3 - frag)[::-1]
+                m = rng.random(len(frag)) < 0.008                      # the planted copy differs a little from the reads
+                frag[m] = (frag[m] + rng.integers(1, 4, int(m.sum()), dtype=np.uint8)) & 3
+                if rng.random() < 0.25:
+                    q = int(rng.integers(20, len(frag) - 20))
+                    frag = np.delete(frag, [q, q + 1][:int(rng.integers(1, 3))]) if rng.random() < 0.5 else np.insert(frag, q, rng.integers(0, 4, 1, dtype=np.uint8))
+                if at + len(frag) > hi + 20:
+                    break
+                genome[at:at + len(frag)] = frag
+                at += len(frag) + int(rng.integers(0, 40))
+                nxt += 1
+    return patch
+
+
+def write_case(out, tmp, pre, f1, f2, n, batch, q, refkw, readkw):
+    shutil.copy(pre, os.path.join(out, "ref.FASTQuick.fa"))
+    for ext in INDEX_EXT:
+        shutil.copy(pre + ext, os.path.join(out, "ref.FASTQuick.fa" + ext))
+    sparse_to_npz(pre + ".rollhash.sparse", os.path.join(out, "rollhash_bits.npz"))
+    for src, dst in ((f1, "reads_1.fq.gz"), (f2, "reads_2.fq.gz"),
+                     (os.path.join(tmp, "ref_out.stages"), "ref.stages.gz"),
+                     (os.path.join(tmp, "ref_out.sam"), "ref.sam.gz")):
+        with open(src, "rb") as fi, gzip.GzipFile(os.path.join(out, dst), "wb", mtime=0) as fo:
+            fo.write(fi.read())
+    with open(os.path.join(out, "case.txt"), "w") as fh:
+        fh.write("n_pairs=%d\nbatch=%d\ntrim_qual=%d\nref=%r\nreads=%r\n" % (n, batch, q, refkw, readkw))
+
+
+def make_example_case():
+    tag, refkw, batch, q = EXAMPLE_CASE
+    out = os.path.join(HERE, tag)
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(out)
+    r1, r2 = read_fastq_raw(EXAMPLE_FQ[0]), read_fastq_raw(EXAMPLE_FQ[1])
+    with tempfile.TemporaryDirectory() as tmp:
+        ref = synth.make_reference(patch=plant_pairs(r1, r2), **refkw)
+        pre = os.path.join(tmp, "ref.FASTQuick.fa")
+        ref.write_fasta(pre)
+        subprocess.check_call([ob.REF_DRIVER, "index", pre], stderr=subprocess.DEVNULL, cwd=tmp)
+        fq = []
+        for e, src in enumerate(EXAMPLE_FQ):
+            dst = os.path.join(tmp, "reads_%d.fq" % (e + 1))
+            with gzip.open(src, "rb") as fi, open(dst, "wb") as fo:
+                fo.write(fi.read())
+            fq.append(dst)
+        ob.run_reference(pre, fq[0], fq[1], os.path.join(tmp, "ref_out"), "--batch", batch, "--q", q, "--read_len", 152)
+        write_case(out, tmp, pre, fq[0], fq[1], len(r1), batch, q, refkw, "reference example/fq.test.list")
+    print(tag, "->", sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) // 1024, "KiB")
+
+
 INDEX_EXT = [".bwt", ".rbwt", ".sa", ".rsa", ".pac", ".ann", ".amb"]
 
 
@@ -76,18 +162,10 @@ def main() -> None:
             f1, f2 = rb.write_fastq(os.path.join(tmp, "reads"))
             args = ["--batch", batch] + (["--q", q] if q else []) + (["--read_len", readkw["read_len"] + 1] if readkw.get("read_len", 150) > 150 else [])
             ob.run_reference(pre, f1, f2, os.path.join(tmp, "ref_out"), *args)
-            shutil.copy(pre, os.path.join(out, "ref.FASTQuick.fa"))
-            for ext in INDEX_EXT:
-                shutil.copy(pre + ext, os.path.join(out, "ref.FASTQuick.fa" + ext))
-            sparse_to_npz(pre + ".rollhash.sparse", os.path.join(out, "rollhash_bits.npz"))
-            for src, dst in ((f1, "reads_1.fq.gz"), (f2, "reads_2.fq.gz"),
-                             (os.path.join(tmp, "ref_out.stages"), "ref.stages.gz"),
-                             (os.path.join(tmp, "ref_out.sam"), "ref.sam.gz")):
-                with open(src, "rb") as fi, gzip.GzipFile(os.path.join(out, dst), "wb", mtime=0) as fo:
-                    fo.write(fi.read())
-            with open(os.path.join(out, "case.txt"), "w") as fh:
-                fh.write("n_pairs=%d\nbatch=%d\ntrim_qual=%d\nref=%r\nreads=%r\n" % (n, batch, q, refkw, readkw))
+            write_case(out, tmp, pre, f1, f2, n, batch, q, refkw, readkw)
         print(tag, "->", sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) // 1024, "KiB")
+    if not only or EXAMPLE_CASE[0] in only:
+        make_example_case()
 
 
 if __name__ == "__main__":

@@ -52,7 +52,7 @@ def lib():
         L.fqo_ctx_free.argtypes = [C.c_void_p]
         L.fqo_default_opts.argtypes = [C.POINTER(Opts)]
         L.fqo_align_batch.restype = C.c_int
-        L.fqo_align_batch.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+        L.fqo_align_batch.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                       C.c_int, C.c_void_p, C.c_void_p]
         L.fqo_print_sam_header.argtypes = [C.c_void_p, C.c_void_p]
         L.fqo_get_counters.argtypes = [C.c_void_p, C.POINTER(Counters)]
@@ -109,7 +109,11 @@ def read_fastq_pair(path1: str, path2: str):
             seq[e, i, :len(s)] = np.frombuffer(s, dtype=np.uint8)
             qual[e, i, :len(q)] = np.frombuffer(q, dtype=np.uint8)
             lens[e, i] = len(s)
-    names = [r[0] for r in recs[0]]
+    from fastquick_amd.api import PairNames
+    names = PairNames(r[0] for r in recs[0])
+    mate = [r[0] for r in recs[1]]
+    if mate != list(names):     # the reference prints every record under its own read's name
+        names.mate = mate
     return names, seq, qual, lens
 
 
@@ -162,7 +166,9 @@ class OracleAligner:
             q = np.ascontiguousarray(qual[:, b0:b1])
             ln = np.ascontiguousarray(lens[:, b0:b1])
             nm = pack_names(names[b0:b1])
-            rc = self.L.fqo_align_batch(self.ctx, b1 - b0, nm, 64, s.ctypes.data, q.ctypes.data, ln.ctypes.data, stride, st, sm)
+            mate = getattr(names, "mate", None)
+            nm2 = pack_names(mate[b0:b1]) if mate is not None else None
+            rc = self.L.fqo_align_batch(self.ctx, b1 - b0, nm, nm2, 64, s.ctypes.data, q.ctypes.data, ln.ctypes.data, stride, st, sm)
             if rc < 0:
                 raise RuntimeError("oracle align failed")
             total += rc

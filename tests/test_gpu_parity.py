@@ -134,7 +134,8 @@ def test_cli_sam_out_matches_reference_golden(golden_cases, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "fastquick_amd", "bin", "FASTQuick_amd")
     assert os.path.exists(exe), "build() must produce the CLI"
-    for tag, chunk_batches in (("repeat", 1), ("nref", 1), ("basic", 1), ("isize", 2)):
+    for tag, chunk_batches in (("repeat", 1), ("nref", 1), ("basic", 1), ("isize", 2), ("example151", 1)):   # example151: the
+        # reference's own example reads -- mates named differently, lower-case bases, a shorter read, 251 = 128 + 123 pairs
         g = golden_cases[tag]   # several chunks per run where the golden batch is smaller than the input: the prefetching reader
         fq = []
         for k in ("fq1", "fq2"):      # exercise the gz path of the tokenizer
