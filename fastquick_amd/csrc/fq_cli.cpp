@@ -83,7 +83,7 @@ void fill_chunk(FastqReader &r, EndChunk &c, long long cap, int stride, int name
     if (!r.next(nm, sq, ql)) { c.eof = true; break; }
     const size_t t = nm.size();
     if (t > 2 && nm[t - 2] == '/' && (nm[t - 1] == '1' || nm[t - 1] == '2')) nm.resize(t - 2);
-    if ((int)sq.size() > stride) { c.error = "read " + nm + " is longer than the first read of its file (" + std::to_string(sq.size()) + " > " + std::to_string(stride) + ")"; return; }
+    if ((int)sq.size() > stride) { c.error = "read " + nm + " is longer than the batch rows (" + std::to_string(sq.size()) + " > " + std::to_string(stride) + "): pass --read_len"; return; }
     if ((int)nm.size() >= name_stride) nm.resize((size_t)name_stride - 1);
     memcpy(&c.seq[(size_t)c.n * stride], sq.data(), sq.size());
     memcpy(&c.qual[(size_t)c.n * stride], ql.data(), ql.size());
@@ -100,13 +100,14 @@ struct Args {
   int opte = -1;
   long long chunk_pairs = 16LL * 262144;
   int device = 0;
+  int read_len = 151;   // gap_opt_t::read_len (libbwa/bwtaln.c:48): the reference sizes its read buffers from it and has no flag for it
 };
 
 int usage() {
   fprintf(stderr, "Usage: FASTQuick_amd align --index_prefix P --fastq_1 R1.fq[.gz] --fastq_2 R2.fq[.gz] --out_prefix O --sam_out\n"
                   "                       [--q INT] [--n FLOAT|INT] [--kmer_thresh INT] [--o INT] [--e INT] [--i INT] [--d INT] [--l INT] [--k INT]\n"
                   "                       [--m INT] [--R INT] [--N] [--L] [--max_isize INT] [--max_occ INT] [--is_sw] [--n_multi INT] [--N_multi INT]\n"
-                  "                       [--ap_prior FLOAT] [--force_isize] [--t INT] [--chunk_pairs INT] [--batch_pairs INT] [--device INT]\n"
+                  "                       [--ap_prior FLOAT] [--force_isize] [--t INT] [--chunk_pairs INT] [--batch_pairs INT] [--device INT] [--read_len INT]\n"
                   "       FASTQuick_amd index --ref REDUCED.FASTQuick.fa [--rollhash]\n");
   return 1;
 }
@@ -161,6 +162,7 @@ int main(int argc, char **argv) {
     else if (f == "--ap_prior") A.o.ap_prior = atof(need(""));
     else if (f == "--force_isize") A.o.force_isize = 1;
     else if (f == "--chunk_pairs") A.chunk_pairs = atoll(need(""));
+    else if (f == "--read_len") A.read_len = atoi(need(""));
     else if (f == "--batch_pairs") A.o.batch_pairs = atoi(need(""));   // READ_BUFFER_SIZE of the run to reproduce (default 262144)
     else if (f == "--device") A.device = atoi(need(""));
     else if (f == "--RG" || f == "--frac_samp" || f == "--fq_list" || f == "--bam_in" || f == "--cal_dup" || f == "--I") die(f + " is not supported by this build");
@@ -199,7 +201,7 @@ int main(int argc, char **argv) {
     size_t l = 0;
     if (p1.next(nm, sq, ql)) l = std::max(l, sq.size());
     if (p2.next(nm, sq, ql)) l = std::max(l, sq.size());
-    stride = (int)((std::max<size_t>(l, 16) + 15) & ~(size_t)15);
+    stride = (int)((std::max<size_t>(l, (size_t)std::max(A.read_len, 16)) + 15) & ~(size_t)15);   // rows hold read_len bases, or the first records if longer
   }
   const int name_stride = 256;   // the reference keeps up to 301 name bytes (bwaseqio.c:226); longer names are cut here
   long long num_read = 0, filtered = 0, unmapped = 0, num_base = 0, order_checked_reads = 0;
