@@ -44,6 +44,10 @@ struct FastqReader {
     }
     return buf[pos++];
   }
+  bool drop_last(const std::string &name) {
+    fprintf(stderr, "NOTICE - the last record (%s) has no line end after its quality string; like the reference's reader, it is not used\n", name.c_str());
+    return false;
+  }
   // returns false at end of file
   bool next(std::string &name, std::string &seq, std::string &qual) {
     int c;
@@ -56,9 +60,12 @@ struct FastqReader {
     if (c != '+') die("FASTA input is not supported by align (no quality line for " + name + ")");
     while ((c = getc()) != -1 && c != '\n') {}
     qual.resize(seq.size());
-    for (size_t i = 0; i < seq.size(); ++i) { c = getc(); if (c == -1) die("truncated quality string for " + name); qual[i] = (char)c; }
+    // ks_get_bulk (kseq.h:86-102) fails when the quality bytes reach the end of the file, also when they end exactly there: a last
+    // record without a line end (or with a short quality string) ends the input and is not returned.
+    for (size_t i = 0; i < seq.size(); ++i) { c = getc(); if (c == -1) return drop_last(name); qual[i] = (char)c; }
     c = getc();
-    if (c != -1 && c != '\n') die("Error:" + name + " this fastq file contains reads with different length");   // kseq.h:362-365
+    if (c == -1) return drop_last(name);
+    if (c != '\n') die("Error:" + name + " this fastq file contains reads with different length");   // kseq.h:362-365
     return true;
   }
 };
@@ -74,15 +81,39 @@ struct EndChunk {
 };
 // Reads up to `cap` records of one FASTQ file into `c` (kseq_read3_fpc semantics, see FastqReader::next).  Rows are `stride`
 // bytes (a read longer than that is an error: the reference, too, wants reads of one length, kseq.h:362-365).
-void fill_chunk(FastqReader &r, EndChunk &c, long long cap, int stride, int name_stride) {
+// The reference keeps one name buffer per read slot (calloc(2 * read_len), bwaseqio.c:233; two sets of READ_BUFFER_SIZE slots used
+// by alternate batches, src/BwtMapper.cpp:2094-2103) and copies a name into it without a terminator (strncpy(name, s, l), :564):
+// a name shorter than an earlier one of its slot keeps that one's tail.  Real Illumina names vary in length, so a run of more than
+// two batches prints such names; the slots are modelled here so that the read names come out the same (--clean_names: plain names).
+struct NameSlots {
+  std::vector<std::string> buf[2];   // buf[batch & 1][slot]: the slot's bytes up to the last one ever written (the rest is NUL)
+  long long pairs_seen = 0;
+  int batch_pairs = 0;
+  bool clean = false;
+  std::string put(const std::string &nm) {
+    const size_t l = nm.size();
+    const bool mate_suffix = l > 2 && nm[l - 2] == '/' && (nm[l - 1] == '1' || nm[l - 1] == '2');   // :565-570
+    const long long g = pairs_seen++;
+    if (clean) return mate_suffix ? nm.substr(0, l - 2) : nm;
+    std::vector<std::string> &set = buf[(g / batch_pairs) & 1];
+    if (set.empty()) set.resize((size_t)batch_pairs);
+    std::string &b = set[(size_t)(g % batch_pairs)];
+    if (b.size() < l) b.resize(l, '\0');
+    b.replace(0, l, nm);
+    if (mate_suffix) b[l - 2] = '\0';
+    return std::string(b.c_str());
+  }
+};
+
+void fill_chunk(FastqReader &r, NameSlots &slots, EndChunk &c, long long cap, int stride, int name_stride) {
   c.n = 0; c.stride = stride; c.name_stride = name_stride; c.error.clear();
   c.seq.assign((size_t)cap * stride, 0); c.qual.assign((size_t)cap * stride, 0);
   c.len.assign((size_t)cap, 0); c.names.assign((size_t)cap * name_stride, 0);
   std::string nm, sq, ql;
   while (c.n < cap) {
     if (!r.next(nm, sq, ql)) { c.eof = true; break; }
-    const size_t t = nm.size();
-    if (t > 2 && nm[t - 2] == '/' && (nm[t - 1] == '1' || nm[t - 1] == '2')) nm.resize(t - 2);
+    if (nm.size() > 301) nm.resize(301);   // the reference's buffer holds 2 * read_len = 302 bytes
+    nm = slots.put(nm);
     if ((int)sq.size() > stride) { c.error = "read " + nm + " is longer than the batch rows (" + std::to_string(sq.size()) + " > " + std::to_string(stride) + "): pass --read_len"; return; }
     if ((int)nm.size() >= name_stride) nm.resize((size_t)name_stride - 1);
     memcpy(&c.seq[(size_t)c.n * stride], sq.data(), sq.size());
@@ -100,6 +131,7 @@ struct Args {
   int opte = -1;
   long long chunk_pairs = 16LL * 262144;
   int device = 0;
+  bool clean_names = false;
   int read_len = 151;   // gap_opt_t::read_len (libbwa/bwtaln.c:48): the reference sizes its read buffers from it and has no flag for it
 };
 
@@ -107,7 +139,7 @@ int usage() {
   fprintf(stderr, "Usage: FASTQuick_amd align --index_prefix P --fastq_1 R1.fq[.gz] --fastq_2 R2.fq[.gz] --out_prefix O --sam_out\n"
                   "                       [--q INT] [--n FLOAT|INT] [--kmer_thresh INT] [--o INT] [--e INT] [--i INT] [--d INT] [--l INT] [--k INT]\n"
                   "                       [--m INT] [--R INT] [--N] [--L] [--max_isize INT] [--max_occ INT] [--is_sw] [--n_multi INT] [--N_multi INT]\n"
-                  "                       [--ap_prior FLOAT] [--force_isize] [--t INT] [--chunk_pairs INT] [--batch_pairs INT] [--device INT] [--read_len INT]\n"
+                  "                       [--ap_prior FLOAT] [--force_isize] [--t INT] [--chunk_pairs INT] [--batch_pairs INT] [--device INT] [--read_len INT] [--clean_names]\n"
                   "       FASTQuick_amd index --ref REDUCED.FASTQuick.fa [--rollhash]\n");
   return 1;
 }
@@ -163,6 +195,7 @@ int main(int argc, char **argv) {
     else if (f == "--force_isize") A.o.force_isize = 1;
     else if (f == "--chunk_pairs") A.chunk_pairs = atoll(need(""));
     else if (f == "--read_len") A.read_len = atoi(need(""));
+    else if (f == "--clean_names") A.clean_names = true;
     else if (f == "--batch_pairs") A.o.batch_pairs = atoi(need(""));   // READ_BUFFER_SIZE of the run to reproduce (default 262144)
     else if (f == "--device") A.device = atoi(need(""));
     else if (f == "--RG" || f == "--frac_samp" || f == "--fq_list" || f == "--bam_in" || f == "--cal_dup" || f == "--I") die(f + " is not supported by this build");
@@ -194,6 +227,8 @@ int main(int argc, char **argv) {
   // FASTQ front end: one reader thread per file tokenises the next chunk into flat buffers while the device aligns the current
   // one (the reference, too, decodes the two files on two IO threads: BwtMapper.cpp:1873-1935).
   FastqReader r1(A.fq1), r2(A.fq2);
+  NameSlots slots[2];
+  for (NameSlots &s : slots) { s.batch_pairs = A.o.batch_pairs; s.clean = A.clean_names; }
   int stride = 0;
   {   // row stride from the first record of each file
     std::string nm, sq, ql;
@@ -203,13 +238,13 @@ int main(int argc, char **argv) {
     if (p2.next(nm, sq, ql)) l = std::max(l, sq.size());
     stride = (int)((std::max<size_t>(l, (size_t)std::max(A.read_len, 16)) + 15) & ~(size_t)15);   // rows hold read_len bases, or the first records if longer
   }
-  const int name_stride = 256;   // the reference keeps up to 301 name bytes (bwaseqio.c:226); longer names are cut here
+  const int name_stride = 304;   // the reference's name buffers hold 302 bytes (bwaseqio.c:233)
   long long num_read = 0, filtered = 0, unmapped = 0, num_base = 0, order_checked_reads = 0;
   std::vector<char> sam;
   EndChunk bufs[2][2];   // [slot][end]
   auto read_both = [&](int slot) {
-    std::thread t0(fill_chunk, std::ref(r1), std::ref(bufs[slot][0]), A.chunk_pairs, stride, name_stride);
-    std::thread t1(fill_chunk, std::ref(r2), std::ref(bufs[slot][1]), A.chunk_pairs, stride, name_stride);
+    std::thread t0(fill_chunk, std::ref(r1), std::ref(slots[0]), std::ref(bufs[slot][0]), A.chunk_pairs, stride, name_stride);
+    std::thread t1(fill_chunk, std::ref(r2), std::ref(slots[1]), std::ref(bufs[slot][1]), A.chunk_pairs, stride, name_stride);
     t0.join(); t1.join();
   };
   read_both(0);

@@ -172,11 +172,14 @@ static int cmd_align(int argc, char **argv) {
   kh_64_t *hash = kh_init(64);
   bwa_seqio_t *ks[2] = {bwa_seq_open(fq1), bwa_seq_open(fq2)};
   bwt_t *bwt[2] = {ix.bwt_d, ix.rbwt_d};
-  bwa_seq_t *seqs[2];
-  for (int j = 0; j < 2; ++j) {
-    seqs[j] = (bwa_seq_t *)calloc(batch, sizeof(bwa_seq_t));
-    bwa_init_read_seq(batch, seqs[j], opt);
-  }
+  // two sets of read slots used by alternate batches, like seqs / seqs_buff (src/BwtMapper.cpp:1827-1834, 2094-2103): what a
+  // slot keeps of its earlier occupants (name tails, bases past a short read's end) then has the reference's cadence
+  bwa_seq_t *sets[2][2];
+  for (int k = 0; k < 2; ++k)
+    for (int j = 0; j < 2; ++j) {
+      sets[k][j] = (bwa_seq_t *)calloc(batch, sizeof(bwa_seq_t));
+      bwa_init_read_seq(batch, sets[k][j], opt);
+    }
   isize_info_t last_ii; last_ii.avg = -1.0;
   ubyte_t *pacseq = 0;
   bwa_print_sam_SQ(ix.bns);
@@ -186,6 +189,7 @@ static int cmd_align(int argc, char **argv) {
   long long n_pairs_total = 0, n_filtered = 0, n_unmapped = 0;
   for (int b = 0;; ++b) {
     int n_seqs[2] = {0, 0};
+    bwa_seq_t **seqs = sets[b & 1];
     int r0 = bwa_read_seq_with_hash_dev(&ix, ks[0], batch, &n_seqs[0], opt->mode, opt->trim_qual, opt->frac, round, seqs[0], opt->read_len);
     int r1 = bwa_read_seq_with_hash_dev(&ix, ks[1], batch, &n_seqs[1], opt->mode, opt->trim_qual, opt->frac, round, seqs[1], opt->read_len);
     if (r0 == 0 || r1 == 0) break;
@@ -227,6 +231,8 @@ static int cmd_align(int argc, char **argv) {
       bwa_print_sam1(ix.bns, p[1], p[0], opt->mode, opt->max_top2);
     }
     n_pairs_total += n;
+    if ((2 * n_pairs_total) % batch == 0 && std::strncmp(seqs[0]->name, seqs[1]->name, opt->read_len) != 0)   // src/BwtMapper.cpp:2087-2092
+      die("Abort, please make sure input pair of fastq files are in the same order!");
     for (int j = 0; j < 2; ++j) bwa_clean_read_seq(n, seqs[j]);
     ++round;
   }
