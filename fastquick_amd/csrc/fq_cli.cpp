@@ -85,19 +85,29 @@ struct EndChunk {
 // by alternate batches, src/BwtMapper.cpp:2094-2103) and copies a name into it without a terminator (strncpy(name, s, l), :564):
 // a name shorter than an earlier one of its slot keeps that one's tail.  Real Illumina names vary in length, so a run of more than
 // two batches prints such names; the slots are modelled here so that the read names come out the same (--clean_names: plain names).
-struct NameSlots {
-  std::vector<std::string> buf[2];   // buf[batch & 1][slot]: the slot's bytes up to the last one ever written (the rest is NUL)
+// The base buffers are reused the same way, and the read filter looks at 96 bases whatever the read's length: a read
+// shorter than 96 bp is judged together with what the earlier, longer reads of its slot left behind it.  Those bytes travel in the
+// row behind the read (fastquick_amd.h, fq_read_batch_t).
+struct ReadSlots {
+  std::vector<std::string> name[2];   // name[batch & 1][slot]: the slot's bytes up to the last one ever written (the rest is NUL)
+  std::vector<uint8_t> base[2];       // base[batch & 1][slot * 96 ...]: the first 96 bases the slot holds, 0 = never written
   long long pairs_seen = 0;
   int batch_pairs = 0;
   bool clean = false;
-  std::string put(const std::string &nm) {
+  // name to print for the next record of this file; `row` holds the record's bases (n of them) and receives the slot's leftovers
+  std::string put(const std::string &nm, uint8_t *row, size_t n, size_t stride) {
     const size_t l = nm.size();
     const bool mate_suffix = l > 2 && nm[l - 2] == '/' && (nm[l - 1] == '1' || nm[l - 1] == '2');   // :565-570
     const long long g = pairs_seen++;
+    const int set = (int)((g / batch_pairs) & 1);
+    const size_t slot = (size_t)(g % batch_pairs);
+    if (base[set].empty()) base[set].assign((size_t)batch_pairs * 96, 0);
+    uint8_t *h = &base[set][slot * 96];
+    for (size_t i = n; i < 96 && i < stride; ++i) row[i] = h[i];
+    memcpy(h, row, std::min<size_t>(n, 96));
     if (clean) return mate_suffix ? nm.substr(0, l - 2) : nm;
-    std::vector<std::string> &set = buf[(g / batch_pairs) & 1];
-    if (set.empty()) set.resize((size_t)batch_pairs);
-    std::string &b = set[(size_t)(g % batch_pairs)];
+    if (name[set].empty()) name[set].resize((size_t)batch_pairs);
+    std::string &b = name[set][slot];
     if (b.size() < l) b.resize(l, '\0');
     b.replace(0, l, nm);
     if (mate_suffix) b[l - 2] = '\0';
@@ -105,7 +115,7 @@ struct NameSlots {
   }
 };
 
-void fill_chunk(FastqReader &r, NameSlots &slots, EndChunk &c, long long cap, int stride, int name_stride) {
+void fill_chunk(FastqReader &r, ReadSlots &slots, EndChunk &c, long long cap, int stride, int name_stride) {
   c.n = 0; c.stride = stride; c.name_stride = name_stride; c.error.clear();
   c.seq.assign((size_t)cap * stride, 0); c.qual.assign((size_t)cap * stride, 0);
   c.len.assign((size_t)cap, 0); c.names.assign((size_t)cap * name_stride, 0);
@@ -113,10 +123,10 @@ void fill_chunk(FastqReader &r, NameSlots &slots, EndChunk &c, long long cap, in
   while (c.n < cap) {
     if (!r.next(nm, sq, ql)) { c.eof = true; break; }
     if (nm.size() > 301) nm.resize(301);   // the reference's buffer holds 2 * read_len = 302 bytes
-    nm = slots.put(nm);
     if ((int)sq.size() > stride) { c.error = "read " + nm + " is longer than the batch rows (" + std::to_string(sq.size()) + " > " + std::to_string(stride) + "): pass --read_len"; return; }
     if ((int)nm.size() >= name_stride) nm.resize((size_t)name_stride - 1);
     memcpy(&c.seq[(size_t)c.n * stride], sq.data(), sq.size());
+    nm = slots.put(nm, &c.seq[(size_t)c.n * stride], sq.size(), (size_t)stride);
     memcpy(&c.qual[(size_t)c.n * stride], ql.data(), ql.size());
     c.len[c.n] = (int32_t)sq.size();
     memcpy(&c.names[(size_t)c.n * name_stride], nm.data(), nm.size());
@@ -227,8 +237,8 @@ int main(int argc, char **argv) {
   // FASTQ front end: one reader thread per file tokenises the next chunk into flat buffers while the device aligns the current
   // one (the reference, too, decodes the two files on two IO threads: BwtMapper.cpp:1873-1935).
   FastqReader r1(A.fq1), r2(A.fq2);
-  NameSlots slots[2];
-  for (NameSlots &s : slots) { s.batch_pairs = A.o.batch_pairs; s.clean = A.clean_names; }
+  ReadSlots slots[2];
+  for (ReadSlots &s : slots) { s.batch_pairs = A.o.batch_pairs; s.clean = A.clean_names; }
   int stride = 0;
   {   // row stride from the first record of each file
     std::string nm, sq, ql;

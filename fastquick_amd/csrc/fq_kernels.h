@@ -251,7 +251,7 @@ FQ_HD void fq_prep_thread(const FqPrepArgs &A, int r) {
     } else {
       for (int j = 0; j < 24; ++j) {
         uint32_t x = 0;
-        for (int b = 0; b < 4; ++b) { const int p = 4 * j + b; x |= (uint32_t)(p < full ? row[p] : (uint8_t)'A') << (8 * b); }   // beyond the read: code 0 (Q7 fence)
+        for (int b = 0; b < 4; ++b) { const int p = 4 * j + b; x |= (uint32_t)(p < full || (p < A.stride && row[p]) ? row[p] : (uint8_t)'A') << (8 * b); }   // beyond the read: what the row holds (the slot's earlier bases), 0 = never written = code 0
         w[j] = x;
       }
     }

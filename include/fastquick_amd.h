@@ -62,7 +62,10 @@ void fq_default_opts(fq_opts_t *o);
 /* One batch of read pairs as produced by the FASTQ tokenizer (replaces the output side of
  * bwa_read_seq_with_hash_dev, src/BwtMapper.cpp:476-613, before encoding/trim/filter which now
  * run on the GPU).  Row r of end e starts at seq + ((size_t)e*n_pairs + r)*stride; ASCII bases and
- * Sanger qualities; names are NUL-terminated rows of name_stride bytes.  The reference keeps one name per read
+ * Sanger qualities.  The read filter looks at the first 96 bases of a row whatever the read's length, as the reference does
+ * (BwtIndexer.cpp:524-543): for a read shorter than 96 bp the bytes [len, min(96, stride)) of its row count -- leave them 0
+ * (a fresh read slot of the reference), or put there what the reference's reused slot would still hold of earlier, longer
+ * reads (the CLI does, fq_cli.cpp ReadSlots).  Names are NUL-terminated rows of name_stride bytes.  The reference keeps one name per read
  * (bwa_seq_t::name, libbwa/bwaseqio.c:210) and prints each record under its own: when the second mates' names differ from
  * the first mates' pass them in names_mate (same stride), otherwise leave it NULL and both mates print `names`. */
 typedef struct {

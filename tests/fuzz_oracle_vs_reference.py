@@ -86,7 +86,9 @@ for seed in range(args.start, args.start + args.seeds):
         rb = synth.make_reads(ref, n, **readkw)
         if args.ragged:
             import numpy as np
-            rb.lens[:] = np.random.default_rng(seed).integers(max(96, read_len - 54), read_len + 1, rb.lens.shape)
+            lo = 40 if seed % 2 else max(96, read_len - 54)      # odd seeds: reads under 96 bp too, rows carry the slot history (Q7)
+            rb.lens[:] = np.random.default_rng(seed).integers(lo, read_len + 1, rb.lens.shape)
+            ob.apply_slot_history(rb.seq, rb.lens, batch)
         f1, f2 = rb.write_fastq(os.path.join(d, "reads"))
         ob.run_reference(pre, f1, f2, os.path.join(d, "ref_out"), *extra)
         oa = ob.OracleAligner(pre, ob.default_opts(**okw))

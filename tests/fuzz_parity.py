@@ -13,6 +13,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--seeds", type=int, default=20)
 ap.add_argument("--start", type=int, default=0)
 ap.add_argument("--adversarial", action="store_true", help="tiny, repeat-rich references and error-rich reads: edge and tie-breaking cases")
+ap.add_argument("--ragged", action="store_true", help="reads of mixed length, 96 bp or more")
 args = ap.parse_args()
 lib = api.load_library()
 bad = 0
@@ -24,7 +25,7 @@ for seed in range(args.start, args.start + args.seeds):
     refkw["n_long"] = min(refkw["n_long"], refkw["n_markers"])
     if args.adversarial:
         refkw.update(n_markers=rnd.choice([3, 5, 8]), n_long=rnd.choice([0, 1]), repeat_every=rnd.choice([1, 2, 3]), tandem_every=rnd.choice([0, 2, 5]))
-    read_len = rnd.choice([76, 100, 150, 150, 250])
+    read_len = rnd.choice([150, 150, 250]) if args.ragged else rnd.choice([76, 100, 150, 150, 250])
     readkw = dict(read_len=read_len, on_target=rnd.choice([0.5, 0.9, 1.0]), seed=2000 + seed, sub_rate=rnd.choice([0.005, 0.02, 0.04]),
                   del_frac=rnd.choice([0.0, 0.05, 0.1]), ins_frac=rnd.choice([0.0, 0.05, 0.1]), n_rate=rnd.choice([0.0, 0.003, 0.01]),
                   indel_len_max=rnd.choice([1, 2, 3]), chimera_frac=rnd.choice([0.0, 0.05, 0.2]), qual_decay=rnd.random() < 0.4)
@@ -69,6 +70,11 @@ for seed in range(args.start, args.start + args.seeds):
     pre = os.path.join(d, "ref.FASTQuick.fa")
     ref.write_fasta(pre); api.build_index(pre)
     rb = synth.make_reads(ref, n, **readkw)
+    if args.ragged:
+        import numpy as np
+        lo = 40 if seed % 2 else max(96, read_len - 54)      # odd seeds: reads under 96 bp too, rows carry the slot history (Q7)
+        rb.lens[:] = np.random.default_rng(seed).integers(lo, read_len + 1, rb.lens.shape)
+        ob.apply_slot_history(rb.seq, rb.lens, batch)
     ix = api.Index(pre, device=0)
     al = api.Aligner(ix, api.default_opts(lib, batch_pairs=batch, host_threads=threads, **okw), max_pairs=call, debug=True)
     api.align_stream(al, rb.names, rb.seq, rb.qual, rb.lens, call, d + "/g.st", d + "/g.sam")

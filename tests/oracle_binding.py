@@ -117,6 +117,21 @@ def read_fastq_pair(path1: str, path2: str):
     return names, seq, qual, lens
 
 
+def apply_slot_history(seq, lens, batch: int) -> None:
+    """What `FASTQuick_amd align` (fq_cli.cpp, ReadSlots) does to rows: the reference reuses two sets of `batch` read slots, and the
+    filter sees, behind a read shorter than 96 bp, the bases earlier reads of its slot left.  In place."""
+    n, width = seq.shape[1], min(96, seq.shape[2])
+    for e in range(2):
+        hist = [np.zeros((batch, width), dtype=np.uint8) for _ in range(2)]
+        for g in range(n):
+            h = hist[(g // batch) & 1][g % batch]
+            ln = int(lens[e, g])
+            seq[e, g, ln:] = 0
+            if ln < width:
+                seq[e, g, ln:width] = h[ln:width]
+            h[:min(ln, width)] = seq[e, g, :min(ln, width)]
+
+
 def pack_names(names, stride: int = 64) -> bytes:
     buf = bytearray(stride * len(names))
     for i, nm in enumerate(names):
