@@ -148,7 +148,7 @@ struct Args {
 int usage() {
   fprintf(stderr, "Usage: FASTQuick_amd align --index_prefix P --fastq_1 R1.fq[.gz] --fastq_2 R2.fq[.gz] --out_prefix O --sam_out\n"
                   "                       [--q INT] [--n FLOAT|INT] [--kmer_thresh INT] [--o INT] [--e INT] [--i INT] [--d INT] [--l INT] [--k INT]\n"
-                  "                       [--m INT] [--R INT] [--N] [--L] [--max_isize INT] [--max_occ INT] [--is_sw] [--n_multi INT] [--N_multi INT]\n"
+                  "                       [--m INT] [--R INT] [--N] [--L] [--I] [--max_isize INT] [--max_occ INT] [--is_sw] [--n_multi INT] [--N_multi INT]\n"
                   "                       [--ap_prior FLOAT] [--force_isize] [--t INT] [--chunk_pairs INT] [--batch_pairs INT] [--device INT] [--read_len INT] [--clean_names]\n"
                   "       FASTQuick_amd index --ref REDUCED.FASTQuick.fa [--rollhash]\n");
   return 1;
@@ -196,6 +196,7 @@ int main(int argc, char **argv) {
     else if (f == "--q") A.o.trim_qual = atoi(need(""));
     else if (f == "--N") { A.o.mode |= 0x10; A.o.max_top2 = 0x7fffffff; }
     else if (f == "--L") A.o.mode |= 4;
+    else if (f == "--I") A.o.mode |= 0x200;   // BWA_MODE_IL13
     else if (f == "--max_isize") A.o.max_isize = atoi(need(""));
     else if (f == "--max_occ") A.o.max_occ = (uint32_t)atoi(need(""));
     else if (f == "--is_sw") A.o.is_sw = !A.o.is_sw;          // a bool flag on a default-1 int: it toggles (src/FASTQuick.cpp:278)
@@ -208,7 +209,7 @@ int main(int argc, char **argv) {
     else if (f == "--clean_names") A.clean_names = true;
     else if (f == "--batch_pairs") A.o.batch_pairs = atoi(need(""));   // READ_BUFFER_SIZE of the run to reproduce (default 262144)
     else if (f == "--device") A.device = atoi(need(""));
-    else if (f == "--RG" || f == "--frac_samp" || f == "--fq_list" || f == "--bam_in" || f == "--cal_dup" || f == "--I") die(f + " is not supported by this build");
+    else if (f == "--RG" || f == "--frac_samp" || f == "--fq_list" || f == "--bam_in" || f == "--cal_dup") die(f + " is not supported by this build");
     else die("unknown option " + f);
   }
   if (A.o.fnr >= 1.0) { A.o.max_diff = (int)A.o.fnr; A.o.fnr = -1.0; }                  // src/FASTQuick.cpp:312-315

@@ -25,6 +25,7 @@ enum { FQ_OP_M = 0, FQ_OP_I = 1, FQ_OP_D = 2, FQ_OP_S = 3 };
 #define FQ_MODE_COMPREAD 2
 #define FQ_MODE_LOGGAP 4
 #define FQ_MODE_NONSTOP 0x10
+#define FQ_MODE_IL13 0x200   /* Illumina 1.3+ qualities (Phred+64): 31 is taken off every quality byte on input, BwtMapper.cpp:549-553 */
 #define FQ_NEG_INF (-1073741823)
 
 // ---- FM index in HBM -----------------------------------------------------------------------

@@ -214,8 +214,9 @@ FQ_HD void fq_prep_thread(const FqPrepArgs &A, int r) {
   if (A.o.trim_qual >= 1) {
     const uint8_t *q = A.qual + (size_t)r * (size_t)A.stride;
     int s = 0, mx = 0, max_l = full - 1;
+    const int qsub = (A.o.mode & FQ_MODE_IL13) ? 31 : 0;
     for (int l = full - 1; l >= 34; --l) {
-      s += A.o.trim_qual - ((int)q[l] - 33);
+      s += A.o.trim_qual - ((int)(uint8_t)(q[l] - qsub) - 33);
       if (s < 0) break;
       if (s > mx) { mx = s; max_l = l; }
     }

@@ -96,8 +96,11 @@ void print_sam(const fq_index *ix, const fq_opts_t *o, const fq_read_batch_t *hb
   if (p.strand == 0) for (j = 0; j < p.full_len; ++j) out.putc("ACGTN"[fq_nt4(seq[j]) > 4 ? 4 : fq_nt4(seq[j])]);
   else for (j = 0; j < p.full_len; ++j) { const int cc = fq_nt4(seq[p.full_len - 1 - j]); out.putc("TGCAN"[cc > 4 ? 4 : cc]); }
   out.putc('\t');
-  if (p.strand) { for (j = 0; j < p.len; ++j) out.putc((char)qual[p.len - 1 - j]); for (; j < p.full_len; ++j) out.putc((char)qual[j]); }
-  else for (j = 0; j < p.full_len; ++j) out.putc((char)qual[j]);
+  // Phred+64 input: the reference takes 31 off every quality byte on input (BwtMapper.cpp:549-553) and puts it back on the first
+  // len bytes only when it prints (bwase.c:516-519), so the clipped tail of a trimmed read comes out 31 lower than it went in
+  const int qsub = (o->mode & FQ_MODE_IL13) ? 31 : 0;
+  if (p.strand) { for (j = 0; j < p.len; ++j) out.putc((char)qual[p.len - 1 - j]); for (; j < p.full_len; ++j) out.putc((char)(qual[j] - qsub)); }
+  else { for (j = 0; j < p.len; ++j) out.putc((char)qual[j]); for (; j < p.full_len; ++j) out.putc((char)(qual[j] - qsub)); }
   if (p.clip_len < p.full_len) out.printf("\tXC:i:%d", p.clip_len);
   if (p.type != FQ_TYPE_NO_MATCH) {
     char XT = "NURM"[p.type];

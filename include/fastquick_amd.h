@@ -38,7 +38,7 @@ typedef struct fq_ctx fq_ctx_t;
  * fq_default_opts() fills gap_init_opt() (bwtaln.c:24-48) / bwa_init_pe_opt() (bwape.c:7-20). */
 typedef struct {
   int32_t s_mm, s_gapo, s_gape;
-  int32_t mode;               /* BWA_MODE_GAPE(1) | BWA_MODE_COMPREAD(2) [| LOGGAP(4) | NONSTOP(0x10)] */
+  int32_t mode;               /* BWA_MODE_GAPE(1) | BWA_MODE_COMPREAD(2) [| LOGGAP(4) | NONSTOP(0x10) | IL13(0x200): Phred+64 qualities] */
   int32_t indel_end_skip, max_del_occ, max_entries;
   double fnr;                 /* >0: max_diff from bwa_cal_maxdiff(len, 0.02, fnr) */
   int32_t max_diff, max_gapo, max_gape;

@@ -138,6 +138,7 @@ static int cmd_align(int argc, char **argv) {
     else if (!strcmp(argv[i], "--R")) opt->max_top2 = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--N")) { opt->mode |= BWA_MODE_NONSTOP; opt->max_top2 = 0x7fffffff; }
     else if (!strcmp(argv[i], "--L")) opt->mode |= BWA_MODE_LOGGAP;
+    else if (!strcmp(argv[i], "--I")) opt->mode |= BWA_MODE_IL13;
     else if (!strcmp(argv[i], "--M")) opt->s_mm = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--O")) opt->s_gapo = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--E")) opt->s_gape = atoi(argv[i + 1]);

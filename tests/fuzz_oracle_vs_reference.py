@@ -58,7 +58,7 @@ for seed in range(args.start, args.start + args.seeds):
     # the other gap_opt_t / pe_opt_t fields (driver options named after the reference's command line)
     mode = 1 | 2        # BWA_MODE_GAPE | COMPREAD, the defaults
     for _ in range(rnd.choice([0, 0, 1, 2, 3])):
-        o = rnd.choice(["o", "e", "i", "d", "l", "k", "m", "R", "N", "L", "scores", "max_isize", "max_occ", "multi"])
+        o = rnd.choice(["o", "e", "i", "d", "l", "k", "m", "R", "N", "L", "I", "scores", "max_isize", "max_occ", "multi"])
         if o == "o": v = rnd.choice([0, 2]); extra += ["--o", v]; okw["max_gapo"] = v
         elif o == "e": v = rnd.choice([2, 6]); extra += ["--e", v]; okw["max_gape"] = v; mode &= ~1
         elif o == "i": v = rnd.choice([1, 10]); extra += ["--i", v]; okw["indel_end_skip"] = v
@@ -69,6 +69,7 @@ for seed in range(args.start, args.start + args.seeds):
         elif o == "R": v = rnd.choice([1, 5]); extra += ["--R", v]; okw["max_top2"] = v
         elif o == "N": extra += ["--N", 0]; mode |= 0x10; okw["max_top2"] = 0x7fffffff
         elif o == "L": extra += ["--L", 0]; mode |= 4
+        elif o == "I" and not (mode & 0x200): extra += ["--I", 0]; mode |= 0x200
         elif o == "scores":
             m_, o_, e_ = rnd.choice([(3, 11, 4), (4, 4, 4), (2, 8, 3), (5, 7, 5)])
             extra += ["--M", m_, "--O", o_, "--E", e_]; okw.update(s_mm=m_, s_gapo=o_, s_gape=e_)
@@ -89,6 +90,8 @@ for seed in range(args.start, args.start + args.seeds):
             lo = 40 if seed % 2 else max(96, read_len - 54)      # odd seeds: reads under 96 bp too, rows carry the slot history (Q7)
             rb.lens[:] = np.random.default_rng(seed).integers(lo, read_len + 1, rb.lens.shape)
             ob.apply_slot_history(rb.seq, rb.lens, batch)
+        if mode & 0x200:
+            rb.qual[rb.qual > 0] += 31          # the input then is Phred+64
         f1, f2 = rb.write_fastq(os.path.join(d, "reads"))
         ob.run_reference(pre, f1, f2, os.path.join(d, "ref_out"), *extra)
         oa = ob.OracleAligner(pre, ob.default_opts(**okw))

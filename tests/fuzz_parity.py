@@ -44,13 +44,14 @@ for seed in range(args.start, args.start + args.seeds):
     elif pick < 0.65: okw.update(n_multi=rnd.choice([0, 8]), N_multi=rnd.choice([0, 20]), max_occ=rnd.choice([10, 50, 100000]), is_sw=rnd.choice([0, 1]))
     if rnd.random() < 0.3: okw.update(filter_thresh=rnd.choice([1, 2, 4, 5]))
     for _ in range(rnd.choice([0, 0, 1, 2])):   # the remaining search / pairing options
-        o = rnd.choice(["i", "d", "l", "k", "R", "L", "max_isize", "e"])
+        o = rnd.choice(["i", "d", "l", "k", "R", "L", "max_isize", "e", "I"])
         if o == "i": okw["indel_end_skip"] = rnd.choice([1, 10])
         elif o == "d": okw["max_del_occ"] = rnd.choice([1, 100])
         elif o == "l": okw["seed_len"] = rnd.choice([20, 40])
         elif o == "k": okw["max_seed_diff"] = rnd.choice([0, 1, 3])
         elif o == "R": okw["max_top2"] = rnd.choice([1, 5])
         elif o == "L": okw["mode"] = okw.get("mode", 3) | 4
+        elif o == "I": okw["mode"] = okw.get("mode", 3) | 0x200
         elif o == "max_isize": okw["max_isize"] = rnd.choice([200, 1000])
         elif o == "e": okw["max_gape"] = rnd.choice([2, 6]); okw["mode"] = okw.get("mode", 3) & ~1
     mode = rnd.choice(["lanes", "lanes", "wave1", "wave64"])
@@ -70,6 +71,8 @@ for seed in range(args.start, args.start + args.seeds):
     pre = os.path.join(d, "ref.FASTQuick.fa")
     ref.write_fasta(pre); api.build_index(pre)
     rb = synth.make_reads(ref, n, **readkw)
+    if okw.get("mode", 0) & 0x200:
+        rb.qual[rb.qual > 0] += 31              # Phred+64 input
     if args.ragged:
         import numpy as np
         lo = 40 if seed % 2 else max(96, read_len - 54)      # odd seeds: reads under 96 bp too, rows carry the slot history (Q7)

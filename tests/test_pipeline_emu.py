@@ -80,6 +80,7 @@ OPTION_VARIANTS = [
     ("fixed_maxdiff", dict(fnr=-1.0, max_diff=4, max_gapo=2, max_gape=3, mode=2)),
     ("shared_buckets", dict(s_mm=4, s_gapo=4, s_gape=4)),
     ("loggap_multi", dict(mode=1 | 2 | 4, n_multi=8, N_multi=20, max_occ=50, is_sw=0)),
+    ("il13_trim", dict(mode=1 | 2 | 0x200, trim_qual=15)),      # Phred+64 input (`--I`) with quality trimming
 ]
 
 
@@ -91,7 +92,9 @@ def test_emulated_pipeline_matches_oracle_with_option_variants(name, okw, emu_li
     pre = str(tmp_path / "ref.FASTQuick.fa")
     ref.write_fasta(pre)
     api.build_index(pre, lib=emu_lib)
-    rb = synth.make_reads(ref, 700, on_target=0.95, seed=45, sub_rate=0.03, del_frac=0.08, ins_frac=0.07, n_rate=0.004, indel_len_max=3, chimera_frac=0.06)
+    rb = synth.make_reads(ref, 700, on_target=0.95, seed=45, sub_rate=0.03, del_frac=0.08, ins_frac=0.07, n_rate=0.004, indel_len_max=3, chimera_frac=0.06, qual_decay=name == "il13_trim")
+    if okw.get("mode", 0) & 0x200:
+        rb.qual[rb.qual > 0] += 31
     ix = api.Index(pre, lib=emu_lib)
     al = api.Aligner(ix, api.default_opts(emu_lib, **okw), max_pairs=400, debug=True)
     api.align_stream(al, rb.names, rb.seq, rb.qual, rb.lens, 400, str(tmp_path / "emu.stages"), str(tmp_path / "emu.sam"))
