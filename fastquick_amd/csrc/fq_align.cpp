@@ -166,7 +166,7 @@ extern "C" int fq_ctx_create(const fq_index_t *ix, const fq_opts_t *opts, int32_
     md_max = std::max(md_max, md);
   }
   if ((md_max + 1) * o.s_mm + o.max_gapo * o.s_gapo + o.max_gape * o.s_gape >= FQ_MAX_BUCKETS) return FQ_EINVAL;
-  if (o.max_gapo > c->maxdiff_lut[35]) return FQ_EINVAL;   // the per-slice max_gapo clamp (BwtMapper.cpp:80) must be a no-op
+  if (o.max_gapo > c->maxdiff_lut[FQ_LMIN]) return FQ_EINVAL;   // the per-slice max_gapo clamp (BwtMapper.cpp:79-80) must be a no-op whatever the reads of a slice
   c->g_log_n[0] = 0;
   for (int i = 1; i < 256; ++i) c->g_log_n[i] = (int)(4.343 * log(i) + 0.5);   // bwase_initialize, bwase.c:602
   c->rng = ((uint64_t)ix->seed << 16) | 0x330EULL;                             // srand48(bns->seed)
@@ -206,7 +206,7 @@ extern "C" int fq_batch_upload(fq_ctx_t *c, const fq_read_batch_t *in) {
   for (size_t i = 0; i < n2; ++i) nb += in->len[i];
   c->n_bases_in = nb;
   for (size_t i = 0; i < n2; ++i)
-    if (in->len[i] < 35 || in->len[i] > FQ_LMAX || in->len[i] > in->stride) { c->err = "read length outside [35," + std::to_string(FQ_LMAX) + "]"; return FQ_ELIMIT; }
+    if (in->len[i] < FQ_LMIN || in->len[i] > FQ_LMAX || in->len[i] > in->stride) { c->err = "read length outside [" + std::to_string(FQ_LMIN) + "," + std::to_string(FQ_LMAX) + "]"; return FQ_ELIMIT; }
   CKM(c->d_seq.ensure(n2 * in->stride + 64));
   CKM(c->d_qual.ensure(n2 * in->stride + 64));
   CKM(c->d_len.ensure(n2 + 1));

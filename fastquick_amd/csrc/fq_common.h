@@ -13,6 +13,7 @@
 #endif
 
 // ---- limits (validated in fq_ctx_create; exceeding them is FQ_EINVAL / FQ_ELIMIT, never silent) ----
+#define FQ_LMIN 15             // shortest read taken: bwa_cal_maxdiff(15..37) = 2 at the default fnr, so the per-slice max_gapo clamp stays a no-op
 #define FQ_LMAX 500            // read length; entry packing below gives 9 bits to i / last_diff
 #define FQ_MAX_BUCKETS 128     // score buckets of the search stack (74 for 150 bp defaults)
 #define FQ_SEED_MAX 64         // seed_len upper bound (default 32)

@@ -87,7 +87,7 @@ for seed in range(args.start, args.start + args.seeds):
         rb = synth.make_reads(ref, n, **readkw)
         if args.ragged:
             import numpy as np
-            lo = 40 if seed % 2 else max(96, read_len - 54)      # odd seeds: reads under 96 bp too, rows carry the slot history (Q7)
+            lo = (40 if seed % 4 == 1 else 12) if seed % 2 else max(96, read_len - 54)      # odd seeds: reads under 96 bp too (down to 12), rows carry the slot history (Q7)
             rb.lens[:] = np.random.default_rng(seed).integers(lo, read_len + 1, rb.lens.shape)
             ob.apply_slot_history(rb.seq, rb.lens, batch)
         if mode & 0x200:

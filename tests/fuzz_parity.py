@@ -75,7 +75,7 @@ for seed in range(args.start, args.start + args.seeds):
         rb.qual[rb.qual > 0] += 31              # Phred+64 input
     if args.ragged:
         import numpy as np
-        lo = 40 if seed % 2 else max(96, read_len - 54)      # odd seeds: reads under 96 bp too, rows carry the slot history (Q7)
+        lo = (40 if seed % 4 == 1 else 15) if seed % 2 else max(96, read_len - 54)      # odd seeds: reads under 96 bp too (down to FQ_LMIN), rows carry the slot history (Q7)
         rb.lens[:] = np.random.default_rng(seed).integers(lo, read_len + 1, rb.lens.shape)
         ob.apply_slot_history(rb.seq, rb.lens, batch)
     ix = api.Index(pre, device=0)

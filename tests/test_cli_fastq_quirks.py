@@ -63,8 +63,8 @@ def ragged(end, i, nm, s, q):               # read lengths 100..150 (>= 96: the 
     return b"@" + nm + b"\n" + s[:n] + b"\n+\n" + q[:n] + b"\n"
 
 
-def short_mixed(end, i, nm, s, q):          # 40..150 bp: under 96 bp the filter also sees what the slot's earlier reads left (Q7)
-    n = 40 + (i * 37 + (i // 60) * 29 + end * 13) % 111
+def short_mixed(end, i, nm, s, q):          # 15..150 bp: under 96 bp the filter also sees what the slot's earlier reads left (Q7)
+    n = 15 + (i * 37 + (i // 60) * 29 + end * 13) % 136
     return b"@" + nm + b"\n" + s[:n] + b"\n+\n" + q[:n] + b"\n"
 
 

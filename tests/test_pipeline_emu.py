@@ -55,7 +55,7 @@ def test_read_length_limit_is_loud(golden_cases, emu_lib):
     ix = api.Index(golden_cases["basic"]["prefix"], lib=emu_lib)
     al = api.Aligner(ix, max_pairs=4)
     seq = np.full((2, 2, 40), ord("A"), dtype=np.uint8)
-    lens = np.array([[40, 20], [40, 40]], dtype=np.int32)      # 20 < BWA_MIN_RDLEN
+    lens = np.array([[40, 10], [40, 40]], dtype=np.int32)      # 10 < FQ_LMIN (15)
     with pytest.raises(api.FastquickError):
         al.align(seq, seq, lens, [b"a", b"b"])
     with pytest.raises(api.FastquickError):                    # batch larger than the context was sized for
