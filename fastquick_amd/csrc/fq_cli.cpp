@@ -142,11 +142,12 @@ struct Args {
   long long chunk_pairs = 16LL * 262144;
   int device = 0;
   bool clean_names = false;
+  std::string fq_list;
   int read_len = 151;   // gap_opt_t::read_len (libbwa/bwtaln.c:48): the reference sizes its read buffers from it and has no flag for it
 };
 
 int usage() {
-  fprintf(stderr, "Usage: FASTQuick_amd align --index_prefix P --fastq_1 R1.fq[.gz] --fastq_2 R2.fq[.gz] --out_prefix O --sam_out\n"
+  fprintf(stderr, "Usage: FASTQuick_amd align --index_prefix P --fastq_1 R1.fq[.gz] --fastq_2 R2.fq[.gz] | --fq_list LIST  --out_prefix O --sam_out\n"
                   "                       [--q INT] [--n FLOAT|INT] [--kmer_thresh INT] [--o INT] [--e INT] [--i INT] [--d INT] [--l INT] [--k INT]\n"
                   "                       [--m INT] [--R INT] [--N] [--L] [--I] [--max_isize INT] [--max_occ INT] [--is_sw] [--n_multi INT] [--N_multi INT]\n"
                   "                       [--ap_prior FLOAT] [--force_isize] [--t INT] [--chunk_pairs INT] [--batch_pairs INT] [--device INT] [--read_len INT] [--clean_names]\n"
@@ -209,14 +210,34 @@ int main(int argc, char **argv) {
     else if (f == "--clean_names") A.clean_names = true;
     else if (f == "--batch_pairs") A.o.batch_pairs = atoi(need(""));   // READ_BUFFER_SIZE of the run to reproduce (default 262144)
     else if (f == "--device") A.device = atoi(need(""));
-    else if (f == "--RG" || f == "--frac_samp" || f == "--fq_list" || f == "--bam_in" || f == "--cal_dup") die(f + " is not supported by this build");
+    else if (f == "--fq_list") A.fq_list = need("");
+    else if (f == "--RG" || f == "--frac_samp" || f == "--bam_in" || f == "--cal_dup") die(f + " is not supported by this build");
     else die("unknown option " + f);
   }
   if (A.o.fnr >= 1.0) { A.o.max_diff = (int)A.o.fnr; A.o.fnr = -1.0; }                  // src/FASTQuick.cpp:312-315
   if (A.opte > 0) { A.o.max_gape = A.opte; A.o.mode &= ~1; }                             // :316-319
   if (A.out_prefix == "Empty") die("--out_prefix is required");
   if (A.index_prefix == "Empty") die("--index_prefix is required");
-  if (A.fq1.empty() || A.fq2.empty()) die("--fastq_1 and --fastq_2 are required (paired-end path)");
+  // --fq_list: one FASTQ pair per line, '#' lines skipped (src/BwtMapper.cpp:232-262); every pair is an independent stream
+  // (its own srand48, last_ii, position cache and read slots: PairEndMapper sets them up per call), all into one output
+  std::vector<std::pair<std::string, std::string>> inputs;
+  if (!A.fq_list.empty()) {
+    FILE *fl = fopen(A.fq_list.c_str(), "r");
+    if (!fl) die("Open file " + A.fq_list + " failed");
+    char line[8192];
+    while (fgets(line, sizeof line, fl)) {
+      if (line[0] == '#') continue;
+      char a[4096] = "", b[4096] = "";
+      const int got = sscanf(line, "%4095s %4095s", a, b);
+      if (got < 1) continue;
+      if (got < 2) die(std::string("single-end line in --fq_list (") + a + "): the single-end mapper is not built");
+      inputs.emplace_back(a, b);
+    }
+    fclose(fl);
+  } else {
+    if (A.fq1.empty() || A.fq2.empty()) die("--fastq_1 and --fastq_2 (or --fq_list) are required (paired-end path)");
+    inputs.emplace_back(A.fq1, A.fq2);
+  }
   if (!A.sam_out) die("BAM output (genome-coordinate translation + BGZF; SURVEY 8f.2) is not built yet: pass --sam_out");
   if (A.o.batch_pairs < 1) die("--batch_pairs must be positive");
   A.chunk_pairs = std::max<long long>(A.o.batch_pairs, A.chunk_pairs / A.o.batch_pairs * A.o.batch_pairs);   // whole reference batches per chunk
@@ -225,10 +246,6 @@ int main(int argc, char **argv) {
   const std::string pre = A.index_prefix + ".FASTQuick.fa";
   int rc = fq_index_load(pre.c_str(), A.device, &ix);
   if (rc) die("cannot load index " + pre + " onto HIP device " + std::to_string(A.device) + " (" + std::to_string(rc) + "); there is no CPU fallback");
-  fq_ctx_t *ctx = nullptr;
-  rc = fq_ctx_create(ix, &A.o, (int32_t)A.chunk_pairs, &ctx);
-  if (rc) die("fq_ctx_create failed (" + std::to_string(rc) + "): option outside the supported range");
-
   {
     const int64_t n = fq_sam_header(ix, nullptr, 0);
     std::vector<char> h((size_t)n + 1);
@@ -237,6 +254,12 @@ int main(int argc, char **argv) {
   }
   // FASTQ front end: one reader thread per file tokenises the next chunk into flat buffers while the device aligns the current
   // one (the reference, too, decodes the two files on two IO threads: BwtMapper.cpp:1873-1935).
+  for (const auto &input : inputs) {
+  A.fq1 = input.first; A.fq2 = input.second;
+  fprintf(stderr, "NOTICE - Processing Pair End mapping\t%s\t%s\n", A.fq1.c_str(), A.fq2.c_str());
+  fq_ctx_t *ctx = nullptr;
+  rc = fq_ctx_create(ix, &A.o, (int32_t)A.chunk_pairs, &ctx);
+  if (rc) die("fq_ctx_create failed (" + std::to_string(rc) + "): option outside the supported range");
   FastqReader r1(A.fq1), r2(A.fq2);
   ReadSlots slots[2];
   for (ReadSlots &s : slots) { s.batch_pairs = A.o.batch_pairs; s.clean = A.clean_names; }
@@ -308,6 +331,7 @@ int main(int argc, char **argv) {
   fprintf(stderr, "NOTICE - device time (ms): prep %.1f width %.1f gap %.1f sa %.1f sw %.1f refine %.1f ; host %.1f ; wall %.1f\n", st.kernel_ms[0],
           st.kernel_ms[1], st.kernel_ms[2], st.kernel_ms[3], st.kernel_ms[4], st.kernel_ms[5], st.host_ms_total, st.wall_ms_total);
   fq_ctx_destroy(ctx);
+  }
   fq_index_destroy(ix);
   return 0;
 }

@@ -125,3 +125,32 @@ def test_cli_tokenizer_matches_reference_reader(variant, golden_cases, emu_cli, 
         assert any(len(f[9]) != len(f[10]) for f in (ln.split(b"\t") for ln in want.split(b"\n")) if len(f) > 10)
         return
     assert run.stdout == want
+
+
+def test_cli_fq_list_runs_every_pair_as_its_own_stream(golden_cases, emu_cli, tmp_path):
+    """--fq_list (src/BwtMapper.cpp:232-262): one header, then every listed pair mapped as an independent stream (own drand48 seed,
+    insert-size history, read slots) -- the concatenation of the reference's outputs for the pairs run one by one."""
+    g = golden_cases["repeat"]          # repeats: the drand48 stream decides placements, so a stream that was not re-seeded would show
+    recs = [records(g[k]) for k in ("fq1", "fq2")]
+    n = len(recs[0])
+    parts, want = [], b""
+    for k, (lo, hi) in enumerate(((0, n // 3), (n // 3, n))):
+        fq = []
+        for end in range(2):
+            path = str(tmp_path / ("part%d_%d.fq" % (k, end + 1)))
+            with open(path, "wb") as fh:
+                fh.write(b"".join(blank_tail(end, i, nm, s, q) for i, (nm, s, q) in enumerate(recs[end][lo:hi])))
+            fq.append(path)
+        parts.append(fq)
+        ob.run_reference(g["prefix"], fq[0], fq[1], str(tmp_path / ("ref%d" % k)), "--batch", 100)
+        with open(str(tmp_path / ("ref%d.sam" % k)), "rb") as fh:
+            text = fh.read()
+        want += text if k == 0 else b"".join(ln + b"\n" for ln in text.split(b"\n") if ln and not ln.startswith(b"@"))
+    lst = str(tmp_path / "fq.list")
+    with open(lst, "w") as fh:
+        fh.write("# comment line\n%s\t%s\n%s %s\n" % (parts[0][0], parts[0][1], parts[1][0], parts[1][1]))
+    cmd = [emu_cli, "align", "--index_prefix", g["prefix"][:-len(".FASTQuick.fa")], "--fq_list", lst,
+           "--out_prefix", str(tmp_path / "cli"), "--sam_out", "--batch_pairs", "100", "--chunk_pairs", "200"]
+    run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert run.returncode == 0, run.stderr.decode(errors="replace")[-2000:]
+    assert run.stdout == want
