@@ -808,7 +808,7 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
     if (ii.avg < 0.0) continue;   // bwa_paired_sw returns before touching anything (bwape.c:477)
     for (int sp = sub_lo[sb]; sp < sub_lo[sb + 1]; ++sp) {
       FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
-      for (int j = 0; j < 2; ++j) if (p[j]->filtered) p[j]->filtered = 0;   // expand_seq: revived because its mate passed (:485-499)
+      for (int j = 0; j < 2; ++j) if (p[j]->filtered) { p[j]->filtered = 0; p[j]->revived = true; }   // expand_seq: revived because its mate passed (:485-499)
       if (!((p[0]->mapQ >= 17 || p[1]->mapQ >= 17) && (p[0]->extra_flag & 2) == 0)) continue;
       for (int k = 0; k < 2; ++k) {
         FqRead *pref = p[1 - k], *pm = p[k];

@@ -1827,7 +1827,8 @@ FQ_HD void fq_md_thread(const FqMdArgs &A, int t) {
       } else if (op == FQ_OP_I || op == FQ_OP_S) { y += l; if (op == FQ_OP_I) nm += l; }
       else {
         at = fq_put_int(dst, at, cap, u);
-        if (at < cap) dst[at] = '^'; ++at;
+        if (at < cap) dst[at] = '^';
+        ++at;
         for (int z = 0; z < l && (int64_t)(uint32_t)(x + z) < l_pac; ++z) { if (at < cap) dst[at] = "ACGT"[fq_pac_base(A.ix.pac, (int64_t)(uint32_t)(x + z))]; ++at; }
         u = 0; x += l; nm += l;
       }

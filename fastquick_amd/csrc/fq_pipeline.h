@@ -25,12 +25,13 @@ struct FqRead {              // the bwa_seq_t fields the hot path writes (libbwa
   int main_aln = 0;
   int nm = 0;
   bool has_md = false;
+  bool revived = false;        // filtered on input, brought back for the mate SW because its mate passed (expand_seq, bwape.c:447-462)
   std::vector<FqMulti> multi;
   std::vector<uint16_t> cigar;
   std::string md;
   void reset() {             // back to a fresh record, keeping the containers' storage (records are reused from call to call)
     r = 0; len = full_len = clip_len = 0; filtered = type = strand = extra_flag = 0;
-    n_mm = n_gapo = n_gape = mapQ = seQ = score = 0; sa = pos = c1 = c2 = 0; main_aln = 0; nm = 0; has_md = false;
+    n_mm = n_gapo = n_gape = mapQ = seQ = score = 0; sa = pos = c1 = c2 = 0; main_aln = 0; nm = 0; has_md = false; revived = false;
     multi.clear(); cigar.clear(); md.clear();
   }
 };

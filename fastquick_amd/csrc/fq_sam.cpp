@@ -59,10 +59,15 @@ int64_t ref_end_multi(const FqMulti &q, int len) {
 }
 int64_t five_prime(const FqRead &p) { return p.type != FQ_TYPE_NO_MATCH ? (p.strand ? ref_end(p) : (int64_t)p.pos) : -1; }
 
-std::string read_name(const fq_read_batch_t *hb, int pair, int end) {
+std::string read_name(const fq_read_batch_t *hb, int pair, int end, bool revived) {
   if (!hb->names) return "*";
   const char *nm = (end && hb->names_mate ? hb->names_mate : hb->names) + (size_t)pair * (size_t)hb->name_stride;
   std::string s(nm, strnlen(nm, (size_t)hb->name_stride));
+  if (revived && hb->names_mate) {   // expand_seq writes the mate's name over this read's, without a terminator (bwape.c:456)
+    const char *qn = (end ? hb->names : hb->names_mate) + (size_t)pair * (size_t)hb->name_stride;
+    const std::string q(qn, strnlen(qn, (size_t)hb->name_stride));
+    s = q.size() >= s.size() ? q : q + s.substr(q.size());
+  }
   const size_t t = s.size();
   if (t > 2 && s[t - 2] == '/' && (s[t - 1] == '1' || s[t - 1] == '2')) s.resize(t - 2);   // BwtMapper.cpp:565-570
   return s;
@@ -71,7 +76,7 @@ std::string read_name(const fq_read_batch_t *hb, int pair, int end) {
 void print_sam(const fq_index *ix, const fq_opts_t *o, const fq_read_batch_t *hb, int n_pairs, Out &out, FqRead p, const FqRead &mate) {
   const int pair = p.r % n_pairs;
   const uint8_t *seq = hb->seq + (size_t)p.r * (size_t)hb->stride, *qual = hb->qual + (size_t)p.r * (size_t)hb->stride;
-  const std::string name = read_name(hb, pair, p.r / n_pairs);
+  const std::string name = read_name(hb, pair, p.r / n_pairs, p.revived);
   // only called when at least one mate is mapped (both-unmapped pairs are dropped before, BwtMapper.cpp:2038)
   int seqid, nn, am = 0, flag = p.extra_flag, j;
   if (p.type == FQ_TYPE_NO_MATCH) { p.pos = mate.pos; p.strand = mate.strand; flag |= 4; j = 1; }
