@@ -2,9 +2,9 @@
 """bench.py -- paired 150 bp reads aligned per second through the whole `align` hot path on MI355X.
 
 A "step" is one pass of the hot path (encode+trim+filter -> gap search -> SA -> pairing -> mate SW -> refine/MD ->
-records) over one batch of 262,144 synthetic read pairs (the reference's READ_BUFFER_SIZE, src/BwtMapper.h:36)
-against the 10k-marker reduced reference of BASELINE.json configs[1] (1000 long + 9000 short flanks, l_pac
-6,510,000).  Inputs are resident in HBM when the timed region starts (fq_batch_upload outside, fq_align_resident
+records) over the resident input: one call on each of the --ctxs concurrent streams, a call being --pairs synthetic read
+pairs (16 reference batches of 262,144, the reference's READ_BUFFER_SIZE, src/BwtMapper.h:36) against the 10k-marker reduced
+reference of BASELINE.json configs[1] (1000 long + 9000 short flanks, l_pac 6,510,000).  Inputs are resident in HBM when the timed region starts (fq_batch_upload outside, fq_align_resident
 inside).  Multi-GPU: one process per GPU, reads shard by batch, no data-path collective ("weak" scaling); the only
 collectives are the barrier and the MAX over ranks of the elapsed time.
 
@@ -34,8 +34,8 @@ K_PREP_KERNEL, K_GAP_KERNEL = 6, 7     # single-kernel timings (kernel begin/end
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=128)
-    ap.add_argument("--warmup", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=32, help="timed steps; one step = one call on every concurrent stream (--ctxs)")
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--pairs", type=int, default=16 * 262144,
                     help="pairs per step: one call carrying this many pairs = pairs/262144 reference batches (READ_BUFFER_SIZE)")
     ap.add_argument("--ctxs", type=int, default=16,
@@ -67,7 +67,10 @@ def main() -> None:
         api.build_index(pre)
     fqd.barrier()
     on_frac = 1.0 if args.mix == "ontarget" else ref.l_pac / 3.1e9
-    n_ctx = max(1, min(args.ctxs, args.steps))
+    n_ctx = max(1, args.ctxs)
+    # One step = one call on every resident stream (n_ctx calls of args.pairs pairs each): the timed region then holds
+    # steps x n_ctx calls, so the pipeline of concurrent streams is in steady state for any K the caller picks.
+    calls = args.steps * n_ctx
 
     def make_batch(n_pairs, seed):
         """Seeded synthetic batch.  Off-target pairs are i.i.d. random bases drawn on the GPU (fast), on-target
@@ -143,12 +146,12 @@ def main() -> None:
 
     for al in ctxs:                 # set-up, like the upload: the first call of a context sizes its device buffers
         al.align_resident()
-    run_steps(max(args.warmup, 0))
+    run_steps(max(args.warmup, 0) * n_ctx)
     for al in ctxs:
         al.reset_stats()
     sync_all()
     t0 = time.perf_counter()
-    n_records = run_steps(args.steps)
+    n_records = run_steps(calls)
     sync_all()
     elapsed = time.perf_counter() - t0
     elapsed = fqd.max_over_ranks(elapsed)
@@ -168,16 +171,16 @@ def main() -> None:
     # a WGS-like batch occupies a few percent of the wavefront slots for as long as its longest search lasts, while the filter
     # kernel fills the whole device.)
     n_launch = [max(1, int(x)) for x in agg["kernel_launches"]]
-    items = {"prep": 2.0 * args.pairs * args.steps / n_launch[0], "width": 2.0 * agg["reads_searched"] / n_launch[1],
+    items = {"prep": 2.0 * args.pairs * calls / n_launch[0], "width": 2.0 * agg["reads_searched"] / n_launch[1],
              "gap": float(agg["reads_searched"]) / n_launch[2], "sa": float(agg["sa_rows"]) / n_launch[3],
              "sw": float(agg["sw_tasks"]) / n_launch[4], "refine": float(agg["refine_tasks"]) / n_launch[5]}
     capacity = {"prep": 524288.0, "width": 524288.0, "gap": 262144.0, "sa": 524288.0, "sw": 256.0, "refine": 16384.0}   # resident work items
     share = {k: min(1.0, items[k] / capacity[k]) for k in items}
     dom = max(range(len(K_NAMES)), key=lambda k: kms[k] * share[K_NAMES[k]])
     KSRC = {"prep": K_PREP_KERNEL, "gap": K_GAP_KERNEL}   # stage -> the kernel whose own timestamps price it
-    seq_bytes = float(sum(int(b.lens.sum()) for b in batches)) / n_ctx * args.steps
+    seq_bytes = float(sum(int(b.lens.sum()) for b in batches)) / n_ctx * calls
     if K_NAMES[dom] == "prep":
-        alg_bytes = 64.0 * agg["filter_probes"] + 96.0 * 2 * args.pairs * args.steps + 5.0 * 2 * args.pairs * args.steps
+        alg_bytes = 64.0 * agg["filter_probes"] + 96.0 * 2 * args.pairs * calls + 5.0 * 2 * args.pairs * calls
         model = "64 B x bitmap probes + 96 B of bases/read + 5 B/read out"
     elif K_NAMES[dom] == "gap":
         alg_bytes = 48.0 * agg["gap_occ_touches"]
@@ -187,7 +190,7 @@ def main() -> None:
         model = "48 B x Occ block touches"
     # every kernel's algorithmic rate (the roofline object below repeats the dominant one)
     per_kernel = {}
-    for kname, byts in (("prep", 64.0 * agg["filter_probes"] + 96.0 * 2 * args.pairs * args.steps + 5.0 * 2 * args.pairs * args.steps),
+    for kname, byts in (("prep", 64.0 * agg["filter_probes"] + 96.0 * 2 * args.pairs * calls + 5.0 * 2 * args.pairs * calls),
                         ("gap", 48.0 * agg["gap_occ_touches"])):
         ki = KSRC[kname]
         nl = max(1, int(agg["kernel_launches"][ki]))
@@ -203,7 +206,7 @@ def main() -> None:
     traffic = None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[args.mix]["fq_" + K_NAMES[dom]]
-        unit_count = {"prep": 2.0 * args.pairs * args.steps, "gap": float(agg["reads_searched"])}.get(K_NAMES[dom])
+        unit_count = {"prep": 2.0 * args.pairs * calls, "gap": float(agg["reads_searched"])}.get(K_NAMES[dom])
         if unit_count:
             traffic = round(pmc["bytes_per_unit"] * unit_count / launches, 1)
     except (OSError, KeyError, ValueError):
@@ -213,7 +216,7 @@ def main() -> None:
                 "alg_bytes_per_launch": round(alg_bytes / launches, 1), "model": model,
                 "aggregate_achieved": round(alg_bytes / elapsed / 1e9, 3),   # all concurrent launches together, over the wall time
                 "dominance": "summed device ms x share of resident-lane capacity a launch occupies: " +
-                             ", ".join("%s %.2f" % (K_NAMES[k], kms[k] * share[K_NAMES[k]] / args.steps) for k in range(len(K_NAMES)))}
+                             ", ".join("%s %.2f" % (K_NAMES[k], kms[k] * share[K_NAMES[k]] / calls) for k in range(len(K_NAMES)))}
     # the same kernel alone on the device (one stream, after the timed region): launch duration without other streams' kernels
     if n_ctx > 1:
         ctxs[0].reset_stats()
@@ -228,25 +231,26 @@ def main() -> None:
             roofline["solo_achieved"] = round(byts1 / nl1 / (ms1 * 1e-3) / 1e9, 3)
             roofline["solo_frac"] = round(byts1 / nl1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
 
-    total_pairs = args.pairs * args.steps * world
+    total_pairs = args.pairs * calls * world
     value = total_pairs / elapsed
     out = {
         "metric": "paired_150bp_reads_aligned_per_sec", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "10k-marker reduced ref (l_pac %d), %d x 2x150bp pairs/step = %d reference batches of 262144, %s mix (on-target %.4f)"
-                   % (ref.l_pac, args.pairs, (args.pairs + 262143) // 262144, args.mix, on_frac), "pairs_per_step": args.pairs,
+        "config": {"workload": "10k-marker reduced ref (l_pac %d), %d x 2x150bp pairs/step = %d concurrent streams x one call of %d pairs (%d reference batches of 262144), %s mix (on-target %.4f)"
+                   % (ref.l_pac, args.pairs * n_ctx, n_ctx, args.pairs, (args.pairs + 262143) // 262144, args.mix, on_frac),
+                   "pairs_per_step": args.pairs * n_ctx, "pairs_per_call": args.pairs, "calls_per_step": n_ctx,
                    "markers": args.markers, "mix": args.mix, "concurrent_streams": n_ctx,
                    "sharding": "batches per rank, no data-path collective"},
         "roofline": roofline,
         "kernel_rooflines": per_kernel,
-        "stage_ms_per_step": {K_NAMES[k]: round(kms[k] / args.steps, 4) for k in range(len(K_NAMES))},
-        "host_ms_per_step": round(agg["host_ms_total"] / args.steps, 3),
-        "survivor_pairs_per_step": round(n_records / args.steps, 1),
-        "work_per_step": {k: round(agg[k] / args.steps, 1) for k in ("filter_probes", "occ_block_touches", "gap_occ_touches", "stack_pops",
+        "stage_ms_per_call": {K_NAMES[k]: round(kms[k] / calls, 4) for k in range(len(K_NAMES))},
+        "host_ms_per_call": round(agg["host_ms_total"] / calls, 3),
+        "survivor_pairs_per_call": round(n_records / calls, 1),
+        "work_per_call": {k: round(agg[k] / calls, 1) for k in ("filter_probes", "occ_block_touches", "gap_occ_touches", "stack_pops",
                                                                      "stack_pushes", "sa_rows", "reads_searched", "sw_tasks", "refine_tasks", "tier_retries", "reads_over_4k_pops")},
         "max_pops_per_read": agg["max_pops_per_read"], "max_wave_trips": agg["max_wave_trips"],
-        "gap_wave_trips_per_step": round(agg["wave_trips"] / args.steps, 1), "gap_lane_trips_per_step": round(agg["lane_trips"] / args.steps, 1),
+        "gap_wave_trips_per_call": round(agg["wave_trips"] / calls, 1), "gap_lane_trips_per_call": round(agg["lane_trips"] / calls, 1),
     }
 
     # ---- what a multi-GPU run hands to rank 0 (outside the timed region): the SAM text of every rank's last call, in rank order, and

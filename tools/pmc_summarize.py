@@ -32,8 +32,8 @@ def mean_kb(d):
 def main():
     mix, units_path, dfetch, dwrite = sys.argv[1:5]
     bench = json.loads([l for l in open(units_path) if l.startswith("{")][-1])
-    per_step = bench["work_per_step"]
-    units = {"fq_prep": 2 * bench["config"]["pairs_per_step"], "fq_gap": per_step["reads_searched"], "fq_gap_wave": max(1.0, per_step["tier_retries"]), "fq_width": per_step["reads_searched"],
+    per_step = bench.get("work_per_call") or bench["work_per_step"]      # per call of one stream (older lines: a step was one call)
+    units = {"fq_prep": 2 * bench["config"].get("pairs_per_call", bench["config"]["pairs_per_step"]), "fq_gap": per_step["reads_searched"], "fq_gap_wave": max(1.0, per_step["tier_retries"]), "fq_width": per_step["reads_searched"],
              "fq_sa": max(1.0, per_step["sa_rows"]), "fq_sw": max(1.0, per_step["sw_tasks"]), "fq_refine": max(1.0, per_step["refine_tasks"])}
     fe, wr = mean_kb(dfetch), mean_kb(dwrite)
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
