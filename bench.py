@@ -2,10 +2,16 @@
 """bench.py -- paired 150 bp reads aligned per second through the whole `align` hot path on MI355X.
 
 A "step" is one pass of the hot path (encode+trim+filter -> gap search -> SA -> pairing -> mate SW -> refine/MD ->
-records) over the resident input: one call on each of the --ctxs concurrent streams, a call being --pairs synthetic read
+records) over one batch of synthetic input: one call on each of the --ctxs concurrent streams, a call being --pairs synthetic read
 pairs (16 reference batches of 262,144, the reference's READ_BUFFER_SIZE, src/BwtMapper.h:36) against the 10k-marker reduced
-reference of BASELINE.json configs[1] (1000 long + 9000 short flanks, l_pac 6,510,000).  Inputs are resident in HBM when the timed region starts (fq_batch_upload outside, fq_align_resident
-inside).  Multi-GPU: one process per GPU, reads shard by batch, no data-path collective ("weak" scaling); the only
+reference of BASELINE.json configs[1] (1000 long + 9000 short flanks, l_pac 6,510,000).
+
+Boundary of `value`: packed read batches in pinned host memory in -> result records in host memory out
+(fq_packed_prefetch + fq_align_packed: the 48 bytes of filter keys per pair cross PCIe for every pair, the reads themselves
+only for surviving pairs; the next batch's upload runs under this batch's kernels).  `resident_value` is the same workload
+with the ASCII batch already in HBM (fq_batch_upload outside, fq_align_resident inside): the device-side rate.  `ontarget`
+is a short second leg on the on-target-only mix, where the Occ-lookup (gap search) kernel fills the device.  Multi-GPU:
+one process per GPU, reads shard by batch, no data-path collective ("weak" scaling); the only
 collectives are the barrier and the MAX over ranks of the elapsed time.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
@@ -15,10 +21,11 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
-# One hardware queue per HIP stream: the library gives every alignment context its own stream, and the runtime's default of
-# four hardware queues would make eight or sixteen streams share queues (a 15 ms persistent search kernel then blocks another
+# One hardware queue per HIP stream: the library gives every alignment context its own streams, and the runtime's default of
+# four hardware queues would make sixteen contexts share queues (a 15 ms persistent search kernel then blocks another
 # stream's filter kernel).  Must be set before the HIP runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
@@ -29,6 +36,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 K_NAMES = ("prep", "width", "gap", "sa", "sw", "refine")
 K_PREP_KERNEL, K_GAP_KERNEL = 6, 7     # single-kernel timings (kernel begin/end timestamps via hipExtLaunchKernelGGL events)
+STRIDE_PAD = 16                # ASCII rows are padded to 16 bytes: the resident filter kernel loads rows with 16-byte vector loads
 
 
 def main() -> None:
@@ -37,15 +45,24 @@ def main() -> None:
     ap.add_argument("--steps", type=int, default=32, help="timed steps; one step = one call on every concurrent stream (--ctxs)")
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--pairs", type=int, default=16 * 262144,
-                    help="pairs per step: one call carrying this many pairs = pairs/262144 reference batches (READ_BUFFER_SIZE)")
+                    help="pairs per call: one call carrying this many pairs = pairs/262144 reference batches (READ_BUFFER_SIZE)")
     ap.add_argument("--ctxs", type=int, default=16,
-                    help="alignment contexts (independent FASTQ streams) driven concurrently, one host thread + HIP stream each")
+                    help="alignment contexts (independent FASTQ streams) driven concurrently, one host thread + HIP streams each")
     ap.add_argument("--markers", type=int, default=10000)
     ap.add_argument("--mix", choices=("wgs", "ontarget"), default="wgs",
                     help="wgs: on-target fraction l_pac/3.1e9 (SURVEY 8d); ontarget: every pair from a marker flank")
+    ap.add_argument("--read-len", type=int, default=150, help="150 (cfg 1-3) or 76 (cfg 4, exome: indel-rich reads)")
+    ap.add_argument("--boundary", choices=("host", "resident"), default="host",
+                    help="boundary of `value`: host = packed pinned batches in, records out (SURVEY 8d); resident = inputs already in HBM")
+    ap.add_argument("--no-resident", action="store_true", help="skip the resident (inputs in HBM) leg of a host-boundary run")
+    ap.add_argument("--no-ontarget", action="store_true", help="skip the short on-target leg of a wgs run")
+    ap.add_argument("--ontarget-pairs", type=int, default=1 << 20, help="pairs per call of the on-target leg (one device-filling search launch)")
+    ap.add_argument("--ontarget-ctxs", type=int, default=2)
+    ap.add_argument("--ontarget-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="pairs per slice for the CPU baseline (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=32, help="independent streams (threads) of the CPU baseline")
+    ap.add_argument("--tune", default="", help="key=value,... passed to fq_ctx_set_tuning on every context (experiments)")
     ap.add_argument("--workdir", default=os.environ.get("FQ_BENCH_DIR", "/tmp/fq_bench"))
     args = ap.parse_args()
 
@@ -56,8 +73,9 @@ def main() -> None:
     from fastquick_amd import api, synth
     from fastquick_amd import dist as fqd
     rank, local_rank, world = fqd.init("nccl")      # RCCL; one process per GPU
+    tuning = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune.split(",") if kv}
 
-    # ---- workload (seeded synthetic; built once per node by rank 0) ------------------------------------------
+    # ---- workload (seeded synthetic; the index is built once per node by rank 0) --------------------------------
     os.makedirs(args.workdir, exist_ok=True)
     pre = os.path.join(args.workdir, "m%d.FASTQuick.fa" % args.markers)
     n_long = args.markers // 10
@@ -66,53 +84,44 @@ def main() -> None:
         ref.write_fasta(pre)
         api.build_index(pre)
     fqd.barrier()
-    on_frac = 1.0 if args.mix == "ontarget" else ref.l_pac / 3.1e9
-    n_ctx = max(1, args.ctxs)
-    # One step = one call on every resident stream (n_ctx calls of args.pairs pairs each): the timed region then holds
-    # steps x n_ctx calls, so the pipeline of concurrent streams is in steady state for any K the caller picks.
-    calls = args.steps * n_ctx
+    L = args.read_len
+    stride = (L + STRIDE_PAD - 1) // STRIDE_PAD * STRIDE_PAD
+    ix = api.Index(pre, device=local_rank)
 
-    def make_batch(n_pairs, seed):
+    def reads_kw():
+        if L >= 150:
+            return {}
+        # cfg 4 (exome, 2x76): shorter fragments, indel-rich (10 % indel reads)
+        return dict(read_len=L, frag_mean=200, frag_sd=20, del_frac=0.05, ins_frac=0.05, indel_len_max=2)
+
+    def make_batch(n_pairs, seed, on_frac):
         """Seeded synthetic batch.  Off-target pairs are i.i.d. random bases drawn on the GPU (fast), on-target
         pairs come from fastquick_amd.synth (fragments of the marker flanks with errors) at seeded random slots."""
-        STRIDE = 160   # 16-byte aligned rows: the filter kernel then loads each read with 16-byte vector loads
         if on_frac >= 1.0:
-            rb = synth.make_reads(ref, n_pairs, on_target=1.0, seed=seed)
-            seq = np.zeros((2, n_pairs, STRIDE), dtype=np.uint8)
-            qual = np.zeros((2, n_pairs, STRIDE), dtype=np.uint8)
-            seq[:, :, :150] = rb.seq
-            qual[:, :, :150] = rb.qual
+            rb = synth.make_reads(ref, n_pairs, on_target=1.0, seed=seed, **reads_kw())
+            seq = np.zeros((2, n_pairs, stride), dtype=np.uint8)
+            qual = np.zeros((2, n_pairs, stride), dtype=np.uint8)
+            seq[:, :, :L] = rb.seq
+            qual[:, :, :L] = rb.qual
             return synth.ReadBatch(seq, qual, rb.lens, None)
         rng = np.random.default_rng(seed)
         n_on = int(rng.binomial(n_pairs, on_frac))
         g = torch.Generator(device="cuda")
         g.manual_seed(seed)
         lut = torch.tensor([65, 67, 71, 84], dtype=torch.uint8, device="cuda")
-        seq = np.zeros((2, n_pairs, STRIDE), dtype=np.uint8)
+        seq = np.zeros((2, n_pairs, stride), dtype=np.uint8)
         step = 1 << 20
         for e in range(2):
             for a in range(0, n_pairs, step):
                 b = min(n_pairs, a + step)
-                codes = torch.randint(0, 4, (b - a, 150), device="cuda", generator=g, dtype=torch.uint8)
-                seq[e, a:b, :150] = lut[codes.long()].cpu().numpy()
-        on = synth.make_reads(ref, max(n_on, 1), on_target=1.0, seed=seed + 1)
+                codes = torch.randint(0, 4, (b - a, L), device="cuda", generator=g, dtype=torch.uint8)
+                seq[e, a:b, :L] = lut[codes.long()].cpu().numpy()
+        on = synth.make_reads(ref, max(n_on, 1), on_target=1.0, seed=seed + 1, **reads_kw())
         slots = np.sort(rng.choice(n_pairs, size=n_on, replace=False))
-        seq[:, slots, :150] = on.seq[:, :n_on]
-        qual = np.full((2, n_pairs, STRIDE), ord("I"), dtype=np.uint8)
-        lens = np.full((2, n_pairs), 150, dtype=np.int32)
+        seq[:, slots, :L] = on.seq[:, :n_on]
+        qual = np.full((2, n_pairs, stride), ord("I"), dtype=np.uint8)
+        lens = np.full((2, n_pairs), L, dtype=np.int32)
         return synth.ReadBatch(seq, qual, lens, None)
-
-    # distinct host batches are 2.7 GB each at the default size: at most four per rank, shared round-robin by the contexts (every
-    # context still owns its device copy, its stream state and its results)
-    n_distinct = min(n_ctx, 4)
-    distinct = [make_batch(args.pairs, 1000 + 17 * rank + b) for b in range(n_distinct)]
-    batches = [distinct[b % n_distinct] for b in range(n_ctx)]
-    ix = api.Index(pre, device=local_rank)
-    ctxs = []
-    for b in range(n_ctx):
-        al = api.Aligner(ix, max_pairs=args.pairs)
-        al.upload(batches[b].seq, batches[b].qual, batches[b].lens, None)   # inputs resident in HBM
-        ctxs.append(al)
 
     def sync_all():
         torch.cuda.synchronize()
@@ -120,133 +129,181 @@ def main() -> None:
             fqd.barrier()
             torch.cuda.synchronize()
 
-    import threading
+    def sum_stats(ctxs):
+        agg = None
+        for al in ctxs:
+            s = al.stats()
+            if agg is None:
+                agg = s
+            else:
+                for k, v in s.items():
+                    agg[k] = [a + b for a, b in zip(agg[k], v)] if isinstance(v, list) else (max(agg[k], v) if k.startswith("max_") else agg[k] + v)
+        return agg
 
-    def run_steps(total):
-        """`total` steps spread round-robin over the contexts; each context is driven by its own host thread (its own
-        HIP stream inside the library), so the latency-bound stages of one stream overlap the others' work."""
-        counts = [total // n_ctx + (1 if c < total % n_ctx else 0) for c in range(n_ctx)]
-        recs = [0] * n_ctx
-        errs = []
-
-        def worker(c):
-            try:
-                for _ in range(counts[c]):
-                    recs[c] += ctxs[c].align_resident().n_survivors
-            except Exception as e:      # noqa: BLE001
-                errs.append(e)
-        th = [threading.Thread(target=worker, args=(c,)) for c in range(n_ctx)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join()
-        if errs:
-            raise errs[0]
-        return sum(recs)
-
-    for al in ctxs:                 # set-up, like the upload: the first call of a context sizes its device buffers
-        al.align_resident()
-    run_steps(max(args.warmup, 0) * n_ctx)
-    for al in ctxs:
-        al.reset_stats()
-    sync_all()
-    t0 = time.perf_counter()
-    n_records = run_steps(calls)
-    sync_all()
-    elapsed = time.perf_counter() - t0
-    elapsed = fqd.max_over_ranks(elapsed)
-
-    # ---- per-kernel device time (HIP events inside the library, on its own stream) + algorithmic work --------
-    agg = None
-    for al in ctxs:
-        s = al.stats()
-        if agg is None:
-            agg = s
+    def run_leg(mix, pairs, n_ctx, steps, warmup, boundary, seed0, keep=False, max_distinct=4):
+        """One measured leg: n_ctx contexts (independent FASTQ streams), each driven by its own host thread; a step = one call
+        of `pairs` pairs on every context.  boundary "host": every call takes a packed batch from pinned host memory (the next
+        one prefetched under it) and returns records in host memory; "resident": the ASCII batch was uploaded before."""
+        on_frac = 1.0 if mix == "ontarget" else ref.l_pac / 3.1e9
+        # distinct host batches are large (2.7 GB of ASCII each at the default size): at most four per rank, taken round-robin
+        n_distinct = min(n_ctx, max_distinct) if boundary == "resident" else min(max(n_ctx, 2), max_distinct)
+        distinct = [make_batch(pairs, seed0 + 17 * rank + b, on_frac) for b in range(n_distinct)]
+        packs = None
+        ctxs = [api.Aligner(ix, max_pairs=pairs, tuning=tuning) for _ in range(n_ctx)]
+        if boundary == "host":
+            packs = [api.HostPacked(b.seq, b.qual, b.lens, None) for b in distinct]
+            for b in distinct:
+                b.seq = None          # the ASCII bases are not needed any more (qualities stay: the packed batch refers to them)
         else:
-            for k, v in s.items():
-                agg[k] = [a + b for a, b in zip(agg[k], v)] if isinstance(v, list) else agg[k] + v
+            for c, al in enumerate(ctxs):
+                b = distinct[c % n_distinct]
+                al.upload(b.seq, b.qual, b.lens, None)   # inputs resident in HBM
+
+        def run_steps(k_steps):
+            recs = [0] * n_ctx
+            errs = []
+
+            def worker(c):
+                try:
+                    al = ctxs[c]
+                    if boundary == "host":
+                        cur = c % n_distinct
+                        for _ in range(k_steps):
+                            nxt = (cur + 1) % n_distinct
+                            al.prefetch(packs[nxt])          # next batch's upload runs under this batch's kernels
+                            recs[c] += al.align_packed(packs[cur]).n_survivors
+                            cur = nxt
+                    else:
+                        for _ in range(k_steps):
+                            recs[c] += al.align_resident().n_survivors
+                except Exception as e:      # noqa: BLE001
+                    errs.append(e)
+            th = [threading.Thread(target=worker, args=(c,)) for c in range(n_ctx)]
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            if errs:
+                raise errs[0]
+            return sum(recs)
+
+        run_steps(1)                    # set-up: the first call of a context sizes its device buffers
+        if warmup > 0:
+            run_steps(warmup)
+        for al in ctxs:
+            al.reset_stats()
+        sync_all()
+        t0 = time.perf_counter()
+        n_records = run_steps(steps)
+        sync_all()
+        elapsed = fqd.max_over_ranks(time.perf_counter() - t0)
+        agg = sum_stats(ctxs)
+        calls = steps * n_ctx
+        leg = {"elapsed": elapsed, "calls": calls, "agg": agg, "n_records": n_records, "on_frac": on_frac, "pairs": pairs, "n_ctx": n_ctx,
+               "value": pairs * calls * world / elapsed}
+        # the same kernels alone on the device (one stream, after the timed region): launch duration without other streams' kernels
+        if n_ctx > 1:
+            ctxs[0].reset_stats()
+            for _ in range(3):
+                if boundary == "host":
+                    ctxs[0].align_packed(packs[0])
+                else:
+                    ctxs[0].align_resident()
+            leg["solo"] = ctxs[0].stats()
+        if keep:
+            leg["ctxs"], leg["packs"], leg["distinct"] = ctxs, packs, distinct
+        else:
+            for al in ctxs:
+                al.close()
+            for p in packs or []:
+                p.free()
+        return leg
+
+    def prep_bytes(agg, pairs_total, boundary):
+        per_read = 24.0 + 1.0 if boundary == "host" else 96.0 + 5.0      # packed: 3 k-mers in, 1 verdict byte out; ASCII: 96 bases in, length + verdict out
+        return 64.0 * agg["filter_probes"] + per_read * 2 * pairs_total
+
+    def kernel_rooflines(agg, pairs_total, boundary):
+        out = {}
+        for kname, ki, byts in (("prep", K_PREP_KERNEL, prep_bytes(agg, pairs_total, boundary)), ("gap", K_GAP_KERNEL, 48.0 * agg["gap_occ_touches"])):
+            nl = max(1, int(agg["kernel_launches"][ki]))
+            ms = agg["kernel_ms"][ki] / nl
+            gbs = (byts / nl) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+            out["fq_" + kname] = {"avg_launch_ms": round(ms, 4), "launches": nl, "alg_bytes_per_launch": round(byts / nl, 1),
+                                  "alg_GBps": round(gbs, 2), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5)}
+        return out
+
+    # ---- the headline leg ---------------------------------------------------------------------------------------------
+    n_ctx = max(1, args.ctxs)
+    main_leg = run_leg(args.mix, args.pairs, n_ctx, args.steps, args.warmup, args.boundary, 1000, keep=True)
+    elapsed, calls, agg = main_leg["elapsed"], main_leg["calls"], main_leg["agg"]
+    pairs_total = args.pairs * calls
     kms = agg["kernel_ms"]
-    # Dominant kernel = the one that consumes the most of the device: summed device time x the share of the device's resident
-    # lanes one launch can occupy.  (Several streams run concurrently; a search launch over the few thousand on-target reads of
-    # a WGS-like batch occupies a few percent of the wavefront slots for as long as its longest search lasts, while the filter
-    # kernel fills the whole device.)
+    per_kernel = kernel_rooflines(agg, pairs_total, args.boundary)
+    # Dominant kernel: (a) by rocprof's measure -- summed device time of the kernel over the timed region; (b) weighted by the share
+    # of the device's resident lanes a launch can occupy (a search launch over the few thousand on-target reads of a WGS-like call
+    # holds a few percent of the wavefront slots for as long as its longest search lasts; the filter kernel fills the device).
+    # The roofline object is stated for (b); (a) is reported beside it.
     n_launch = [max(1, int(x)) for x in agg["kernel_launches"]]
-    items = {"prep": 2.0 * args.pairs * calls / n_launch[0], "width": 2.0 * agg["reads_searched"] / n_launch[1],
+    items = {"prep": 2.0 * pairs_total / n_launch[0], "width": 2.0 * agg["reads_searched"] / n_launch[1],
              "gap": float(agg["reads_searched"]) / n_launch[2], "sa": float(agg["sa_rows"]) / n_launch[3],
              "sw": float(agg["sw_tasks"]) / n_launch[4], "refine": float(agg["refine_tasks"]) / n_launch[5]}
     capacity = {"prep": 524288.0, "width": 524288.0, "gap": 262144.0, "sa": 524288.0, "sw": 256.0, "refine": 16384.0}   # resident work items
     share = {k: min(1.0, items[k] / capacity[k]) for k in items}
     dom = max(range(len(K_NAMES)), key=lambda k: kms[k] * share[K_NAMES[k]])
-    KSRC = {"prep": K_PREP_KERNEL, "gap": K_GAP_KERNEL}   # stage -> the kernel whose own timestamps price it
-    seq_bytes = float(sum(int(b.lens.sum()) for b in batches)) / n_ctx * calls
-    if K_NAMES[dom] == "prep":
-        alg_bytes = 64.0 * agg["filter_probes"] + 96.0 * 2 * args.pairs * calls + 5.0 * 2 * args.pairs * calls
-        model = "64 B x bitmap probes + 96 B of bases/read + 5 B/read out"
-    elif K_NAMES[dom] == "gap":
-        alg_bytes = 48.0 * agg["gap_occ_touches"]
-        model = "48 B x Occ block touches (reference block definition, SURVEY 8d)"
-    else:
-        alg_bytes = 48.0 * agg["occ_block_touches"]
-        model = "48 B x Occ block touches"
-    # every kernel's algorithmic rate (the roofline object below repeats the dominant one)
-    per_kernel = {}
-    for kname, byts in (("prep", 64.0 * agg["filter_probes"] + 96.0 * 2 * args.pairs * calls + 5.0 * 2 * args.pairs * calls),
-                        ("gap", 48.0 * agg["gap_occ_touches"])):
-        ki = KSRC[kname]
-        nl = max(1, int(agg["kernel_launches"][ki]))
-        ms = kms[ki] / nl
-        per_kernel["fq_" + kname] = {"avg_launch_ms": round(ms, 4), "alg_GBps": round((byts / nl) / (ms * 1e-3) / 1e9, 2) if ms > 0 else 0.0,
-                                     "frac_of_hbm_peak": round((byts / nl) / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if ms > 0 else 0.0}
-    dsrc = KSRC.get(K_NAMES[dom], dom)
-    launches = max(1, int(agg["kernel_launches"][dsrc]))
-    avg_ms = kms[dsrc] / launches
-    achieved = (alg_bytes / launches) / (avg_ms * 1e-3) / 1e9 if avg_ms > 0 else 0.0
+    dom_by_time = max(range(len(K_NAMES)), key=lambda k: kms[k])
+    dname = K_NAMES[dom] if K_NAMES[dom] in ("prep", "gap") else "prep"
+    pk = per_kernel["fq_" + dname]
     # HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected separately,
-    # tools/pmc_summarize.py), scaled by this run's units per launch; null when no measurement exists for this mix/kernel.
+    # tools/pmc_summarize.py), scaled by this run's units per launch; null when no measurement exists for this mix/kernel/boundary.
     traffic = None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))[args.mix]["fq_" + K_NAMES[dom]]
-        unit_count = {"prep": 2.0 * args.pairs * calls, "gap": float(agg["reads_searched"])}.get(K_NAMES[dom])
-        if unit_count:
-            traffic = round(pmc["bytes_per_unit"] * unit_count / launches, 1)
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+        pmc = pmc[args.mix + ("_packed" if args.boundary == "host" else "")]["fq_" + dname]
+        unit_count = {"prep": 2.0 * pairs_total, "gap": float(agg["reads_searched"])}[dname]
+        traffic = round(pmc["bytes_per_unit"] * unit_count / pk["launches"], 1)
     except (OSError, KeyError, ValueError):
         pass
-    roofline = {"bound": "hbm", "kernel": "fq_" + K_NAMES[dom], "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "avg_launch_ms": round(avg_ms, 4),
-                "alg_bytes_per_launch": round(alg_bytes / launches, 1), "model": model,
+    alg_bytes = pk["alg_bytes_per_launch"] * pk["launches"]
+    roofline = {"bound": "hbm", "kernel": "fq_" + dname, "achieved": pk["alg_GBps"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(pk["alg_GBps"] / HBM_PEAK_GBS, 6), "traffic": traffic, "avg_launch_ms": pk["avg_launch_ms"],
+                "alg_bytes_per_launch": pk["alg_bytes_per_launch"],
+                "model": ("64 B x bitmap probes + 24 B of filter keys/read + 1 B/read out" if args.boundary == "host" else "64 B x bitmap probes + 96 B of bases/read + 5 B/read out")
+                if dname == "prep" else "48 B x Occ block touches (reference block definition, SURVEY 8d)",
                 "aggregate_achieved": round(alg_bytes / elapsed / 1e9, 3),   # all concurrent launches together, over the wall time
-                "dominance": "summed device ms x share of resident-lane capacity a launch occupies: " +
-                             ", ".join("%s %.2f" % (K_NAMES[k], kms[k] * share[K_NAMES[k]] / calls) for k in range(len(K_NAMES)))}
-    # the same kernel alone on the device (one stream, after the timed region): launch duration without other streams' kernels
-    if n_ctx > 1:
-        ctxs[0].reset_stats()
-        for _ in range(3):
-            ctxs[0].align_resident()
-        s1 = ctxs[0].stats()
-        nl1 = max(1, int(s1["kernel_launches"][dsrc]))
-        ms1 = s1["kernel_ms"][dsrc] / nl1
-        byts1 = (64.0 * s1["filter_probes"] + 101.0 * 2 * args.pairs * 3) if K_NAMES[dom] == "prep" else 48.0 * (s1["gap_occ_touches"] if K_NAMES[dom] == "gap" else s1["occ_block_touches"])
+                "dominant_by_device_time": "fq_" + K_NAMES[dom_by_time],
+                "dominance": "summed device ms per call x share of resident-lane capacity a launch occupies: " +
+                             ", ".join("%s %.2f x %.2f" % (K_NAMES[k], kms[k] / calls, share[K_NAMES[k]]) for k in range(len(K_NAMES)))}
+    if "solo" in main_leg:
+        s1 = main_leg["solo"]
+        ki = K_PREP_KERNEL if dname == "prep" else K_GAP_KERNEL
+        nl1 = max(1, int(s1["kernel_launches"][ki]))
+        ms1 = s1["kernel_ms"][ki] / nl1
+        byts1 = prep_bytes(s1, args.pairs * 3, args.boundary) if dname == "prep" else 48.0 * s1["gap_occ_touches"]
         if ms1 > 0:
             roofline["solo_avg_launch_ms"] = round(ms1, 4)
             roofline["solo_achieved"] = round(byts1 / nl1 / (ms1 * 1e-3) / 1e9, 3)
             roofline["solo_frac"] = round(byts1 / nl1 / (ms1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6)
 
-    total_pairs = args.pairs * calls * world
-    value = total_pairs / elapsed
+    value = main_leg["value"]
     out = {
-        "metric": "paired_150bp_reads_aligned_per_sec", "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
+        "metric": "paired_%dbp_reads_aligned_per_sec" % L, "value": round(value, 1), "unit": "pairs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * elapsed / args.steps, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "config": {"workload": "10k-marker reduced ref (l_pac %d), %d x 2x150bp pairs/step = %d concurrent streams x one call of %d pairs (%d reference batches of 262144), %s mix (on-target %.4f)"
-                   % (ref.l_pac, args.pairs * n_ctx, n_ctx, args.pairs, (args.pairs + 262143) // 262144, args.mix, on_frac),
+        "config": {"workload": "%dk-marker reduced ref (l_pac %d), %d x 2x%dbp pairs/step = %d concurrent streams x one call of %d pairs (%d reference batches of 262144), %s mix (on-target %.4f)"
+                   % (args.markers // 1000, ref.l_pac, args.pairs * n_ctx, L, n_ctx, args.pairs, (args.pairs + 262143) // 262144, args.mix, main_leg["on_frac"]),
+                   "boundary": ("packed read batches in pinned host memory -> result records in host memory (H2D and D2H inside the timed region; next batch's upload overlapped)"
+                                if args.boundary == "host" else "inputs resident in HBM -> result records in host memory"),
                    "pairs_per_step": args.pairs * n_ctx, "pairs_per_call": args.pairs, "calls_per_step": n_ctx,
-                   "markers": args.markers, "mix": args.mix, "concurrent_streams": n_ctx,
+                   "markers": args.markers, "mix": args.mix, "read_len": L, "concurrent_streams": n_ctx,
                    "sharding": "batches per rank, no data-path collective"},
         "roofline": roofline,
         "kernel_rooflines": per_kernel,
+        "pcie": {"h2d_bytes_per_pair": round(agg["h2d_bytes"] / pairs_total, 2), "d2h_bytes_per_pair": round(agg["d2h_bytes"] / pairs_total, 3),
+                 "h2d_GBps": round(agg["h2d_bytes"] * world / elapsed / 1e9 / world, 2), "d2h_GBps": round(agg["d2h_bytes"] / elapsed / 1e9, 3)},
         "stage_ms_per_call": {K_NAMES[k]: round(kms[k] / calls, 4) for k in range(len(K_NAMES))},
         "host_ms_per_call": round(agg["host_ms_total"] / calls, 3),
-        "survivor_pairs_per_call": round(n_records / calls, 1),
+        "survivor_pairs_per_call": round(main_leg["n_records"] / calls, 1),
         "work_per_call": {k: round(agg[k] / calls, 1) for k in ("filter_probes", "occ_block_touches", "gap_occ_touches", "stack_pops",
                                                                      "stack_pushes", "sa_rows", "reads_searched", "sw_tasks", "refine_tasks", "tier_retries", "reads_over_4k_pops")},
         "max_pops_per_read": agg["max_pops_per_read"], "max_wave_trips": agg["max_wave_trips"],
@@ -254,21 +311,63 @@ def main() -> None:
     }
 
     # ---- what a multi-GPU run hands to rank 0 (outside the timed region): the SAM text of every rank's last call, in rank order, and
-    #      the summed stream counters (the reference's FileStatCollector sums); RCCL all_gather / all_reduce, a few MB per rank
-    last = ctxs[0].result
-    if last.n_survivors <= 65536:
+    #      the summed stream counters (the reference's FileStatCollector sums); RCCL all_gather / all_reduce, a few MB per rank.
+    #      Whether to gather is decided from the run's arguments, the same on every rank (a per-rank decision could leave some
+    #      ranks outside the collective).
+    ctxs = main_leg["ctxs"]
+    if args.mix == "wgs":
+        last = ctxs[0].result
         parts = fqd.gather_bytes_to_rank0(ctxs[0].sam_text())
         tot = fqd.sum_counters({"pairs": int(last.n_pairs), "survivor_pairs": int(last.n_survivors), "both_filtered": int(last.n_both_filtered),
                                 "both_unmapped": int(last.n_both_unmapped), "bases": int(last.n_bases)})
         if rank == 0:
-            out["gather"] = {"ranks": len(parts), "sam_bytes": [len(p) for p in parts], "counters_sum": tot}
+            out["gather"] = {"ranks": len(parts), "backend_world_size": fqd.world_size(), "sam_bytes": [len(p) for p in parts], "counters_sum": tot}
+            assert len(parts) == world and fqd.world_size() == args.gpus, "RCCL did not see every rank"
+    cpu_batch = main_leg["distinct"][0]
+    for al in ctxs:
+        al.close()
+    cpu_seq = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu_seq = cpu_batch.seq if cpu_batch.seq is not None else make_batch(args.pairs, 1000 + 17 * rank, main_leg["on_frac"]).seq
+    for p in main_leg["packs"] or []:
+        p.free()
+    main_leg["ctxs"] = main_leg["packs"] = None
+
+    # ---- the device-side rate of the same workload (inputs already in HBM), fewer steps --------------------------------------------
+    if args.boundary == "host" and not args.no_resident:
+        rs = max(2, args.steps // 4)
+        leg = run_leg(args.mix, args.pairs, n_ctx, rs, max(1, min(args.warmup, 2)), "resident", 1000)
+        out["resident_value"] = round(leg["value"], 1)
+        out["resident"] = {"steps": rs, "ms_per_step": round(1e3 * leg["elapsed"] / rs, 3),
+                           "kernel_rooflines": kernel_rooflines(leg["agg"], args.pairs * leg["calls"], "resident")}
+
+    # ---- on-target leg: every pair from a marker flank, one device-filling search launch per call (the >= 40 % criterion of
+    #      BASELINE.json is about this kernel on this mix) -------------------------------------------------------------------------------
+    if args.mix == "wgs" and not args.no_ontarget:
+        leg = run_leg("ontarget", args.ontarget_pairs, args.ontarget_ctxs, args.ontarget_steps, 1, args.boundary, 3000, max_distinct=1)
+        a2 = leg["agg"]
+        out["ontarget"] = {"value": round(leg["value"], 1), "unit": "pairs/s", "pairs_per_call": args.ontarget_pairs, "concurrent_streams": args.ontarget_ctxs,
+                           "steps": args.ontarget_steps, "ms_per_step": round(1e3 * leg["elapsed"] / args.ontarget_steps, 3),
+                           "kernel_rooflines": kernel_rooflines(a2, args.ontarget_pairs * leg["calls"], args.boundary),
+                           "stage_ms_per_call": {K_NAMES[k]: round(a2["kernel_ms"][k] / leg["calls"], 3) for k in range(len(K_NAMES))},
+                           "host_ms_per_call": round(a2["host_ms_total"] / leg["calls"], 3),
+                           "reads_searched_per_call": round(a2["reads_searched"] / leg["calls"], 1),
+                           "stack_pops_per_read": round(a2["stack_pops"] / max(1, a2["reads_searched"]), 1),
+                           "occ_touches_per_read": round(a2["gap_occ_touches"] / max(1, a2["reads_searched"]), 1)}
+        if "solo" in leg:
+            s1 = leg["solo"]
+            nl1 = max(1, int(s1["kernel_launches"][K_GAP_KERNEL]))
+            ms1 = s1["kernel_ms"][K_GAP_KERNEL] / nl1
+            if ms1 > 0:
+                g1 = 48.0 * s1["gap_occ_touches"] / nl1 / (ms1 * 1e-3) / 1e9
+                out["ontarget"]["gap_solo"] = {"avg_launch_ms": round(ms1, 4), "alg_GBps": round(g1, 2), "frac_of_hbm_peak": round(g1 / HBM_PEAK_GBS, 5)}
 
     # ---- CPU baseline: the oracle (a port) on a bounded sample of the same workload, rank 0, N=1 only -----------
     # Like the reference's thread pool over --fq_list lines: T independent streams (one oracle context each, shared read-only
     # index), every stream aligning consecutive slices of the same batch for about ten seconds.
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if cpu_seq is not None:
         import oracle_binding as ob
-        b = batches[0]
+        b = cpu_batch
         n_cpu = args.cpu_sample_pairs or (131072 if args.mix == "wgs" else 8192)
         n_cpu = min(n_cpu, args.pairs)
         T = max(1, min(args.cpu_threads, os.cpu_count() or 1, args.pairs // n_cpu))
@@ -284,7 +383,7 @@ def main() -> None:
             while time.perf_counter() < t_end:
                 if off + n_cpu > args.pairs:
                     off = 0
-                oas[t].align(names, b.seq[:, off:off + n_cpu], b.qual[:, off:off + n_cpu], b.lens[:, off:off + n_cpu], None, None, batch=n_cpu)
+                oas[t].align(names, cpu_seq[:, off:off + n_cpu], b.qual[:, off:off + n_cpu], b.lens[:, off:off + n_cpu], None, None, batch=n_cpu)
                 done[t] += n_cpu
                 off += n_cpu * T
         t1 = time.perf_counter()
@@ -302,8 +401,6 @@ def main() -> None:
         first.close()
     if rank == 0:
         print(json.dumps(out))
-    for al in ctxs:
-        al.close()
     ix.close()
     if world > 1:
         import torch.distributed as dist

@@ -33,6 +33,13 @@ class ReadBatch(C.Structure):
                 ("len", C.c_void_p), ("names", C.c_void_p), ("name_stride", C.c_int32), ("names_mate", C.c_void_p)]
 
 
+class PackedBatch(C.Structure):
+    _fields_ = [("n_pairs", C.c_int32), ("uniform_len", C.c_int32), ("head", C.c_void_p), ("body", C.c_void_p),
+                ("body_stride", C.c_int32), ("qual_stride", C.c_int32), ("len", C.c_void_p), ("exc", C.c_void_p),
+                ("n_exc", C.c_int64), ("qual", C.c_void_p), ("names", C.c_void_p), ("name_stride", C.c_int32),
+                ("names_mate", C.c_void_p)]
+
+
 class Multi(C.Structure):
     _fields_ = [("pos", C.c_uint32), ("cigar_off", C.c_uint32), ("n_cigar", C.c_uint16), ("gap", C.c_uint8),
                 ("mm", C.c_uint8), ("strand", C.c_uint8), ("pad", C.c_uint8 * 3)]
@@ -67,13 +74,16 @@ class Stats(C.Structure):
                 ("refine_tasks", C.c_uint64), ("tier_retries", C.c_uint64),
                 ("max_pops_per_read", C.c_uint64), ("reads_over_4k_pops", C.c_uint64), ("max_wave_trips", C.c_uint64),
                 ("host_ms_serial", C.c_double), ("host_ms_pair", C.c_double), ("host_ms_total", C.c_double),
-                ("wall_ms_total", C.c_double), ("wave_trips", C.c_uint64), ("lane_trips", C.c_uint64)]
+                ("wall_ms_total", C.c_double), ("wave_trips", C.c_uint64), ("lane_trips", C.c_uint64),
+                ("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64)]
 
 
 EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destroy", "fq_index_l_pac",
            "fq_index_n_contigs", "fq_index_contig", "fq_ctx_create", "fq_ctx_destroy", "fq_ctx_last_error",
            "fq_ctx_set_debug", "fq_align_batch", "fq_batch_upload", "fq_align_resident", "fq_sam_header",
-           "fq_sam_format_last", "fq_stage_dump_last", "fq_stats_get", "fq_stats_reset", "fq_version"]
+           "fq_sam_format_last", "fq_stage_dump_last", "fq_stats_get", "fq_stats_reset", "fq_version",
+           "fq_pinned_alloc", "fq_pinned_free", "fq_pack_reads", "fq_packed_free", "fq_packed_prefetch", "fq_align_packed",
+           "fq_ctx_set_tuning"]
 
 _libs = {}
 
@@ -114,6 +124,14 @@ def load_library(path: str | None = None):
     L.fq_stats_get.argtypes = [C.c_void_p, C.POINTER(Stats)]
     L.fq_stats_reset.argtypes = [C.c_void_p]
     L.fq_version.restype = C.c_char_p
+    L.fq_pinned_alloc.restype = C.c_void_p
+    L.fq_pinned_alloc.argtypes = [C.c_size_t]
+    L.fq_pinned_free.argtypes = [C.c_void_p]
+    L.fq_pack_reads.argtypes = [C.POINTER(ReadBatch), C.c_int, C.POINTER(C.POINTER(PackedBatch))]
+    L.fq_packed_free.argtypes = [C.POINTER(PackedBatch)]
+    L.fq_packed_prefetch.argtypes = [C.c_void_p, C.POINTER(PackedBatch)]
+    L.fq_align_packed.argtypes = [C.c_void_p, C.POINTER(PackedBatch), C.POINTER(ResultBatch)]
+    L.fq_ctx_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     _libs[path] = L
     return L
 
@@ -180,10 +198,41 @@ def pack_names(names, stride: int = 64) -> np.ndarray:
     return buf
 
 
+class HostPacked:
+    """A packed batch (fq_packed_batch_t) in pinned host memory, made by fq_pack_reads from ASCII rows.  Its qualities and
+    names alias the numpy arrays it was packed from, which this object keeps alive."""
+
+    def __init__(self, seq, qual, lens, names=None, threads: int = 0, lib=None):
+        self.L = lib or load_library()
+        seq = np.ascontiguousarray(seq, dtype=np.uint8)
+        qual = np.ascontiguousarray(qual, dtype=np.uint8)
+        lens = np.ascontiguousarray(lens, dtype=np.int32)
+        mate = getattr(names, "mate", None)
+        nm = pack_names(names) if names is not None else None
+        nm2 = pack_names(mate) if mate is not None else None
+        b = ReadBatch(seq.shape[1], seq.shape[2], seq.ctypes.data, qual.ctypes.data, lens.ctypes.data,
+                      nm.ctypes.data if nm is not None else None, 64, nm2.ctypes.data if nm2 is not None else None)
+        self._keep = (seq, qual, lens, nm, nm2, b)
+        self.p = C.POINTER(PackedBatch)()
+        rc = self.L.fq_pack_reads(C.byref(b), threads, C.byref(self.p))
+        if rc:
+            raise FastquickError("fq_pack_reads failed: %d" % rc)
+        self.n_pairs = seq.shape[1]
+
+    @property
+    def h2d_head_bytes(self) -> int:
+        return 48 * self.n_pairs
+
+    def free(self):
+        if self.p:
+            self.L.fq_packed_free(self.p)
+            self.p = None
+
+
 class Aligner:
     """One alignment context == one FASTQ pair stream of the reference (drand48 / last_ii / cache carry over)."""
 
-    def __init__(self, index: Index, opts: Opts | None = None, max_pairs: int = 262144, debug: bool = False):
+    def __init__(self, index: Index, opts: Opts | None = None, max_pairs: int = 262144, debug: bool = False, tuning: dict | None = None):
         self.L = index.L
         self.index = index
         self.opts = opts or default_opts(self.L)
@@ -194,7 +243,11 @@ class Aligner:
         self.h = h
         if debug:
             self.L.fq_ctx_set_debug(self.h, 1)
+        for k, v in (tuning or {}).items():
+            if self.L.fq_ctx_set_tuning(self.h, k.encode(), int(v)):
+                raise FastquickError("fq_ctx_set_tuning: unknown key %r" % k)
         self._keep = None
+        self._keep_packed = None
         self.result = ResultBatch()
 
     def _batch(self, seq, qual, lens, names):
@@ -221,6 +274,14 @@ class Aligner:
     def upload(self, seq, qual, lens, names=None) -> None:
         b = self._batch(seq, qual, lens, names)
         self._check(self.L.fq_batch_upload(self.h, C.byref(b)), "fq_batch_upload")
+
+    def prefetch(self, packed: HostPacked) -> None:
+        self._check(self.L.fq_packed_prefetch(self.h, packed.p), "fq_packed_prefetch")
+
+    def align_packed(self, packed: HostPacked) -> ResultBatch:
+        self._keep_packed = packed
+        self._check(self.L.fq_align_packed(self.h, packed.p, C.byref(self.result)), "fq_align_packed")
+        return self.result
 
     def align_resident(self) -> ResultBatch:
         self._check(self.L.fq_align_resident(self.h, C.byref(self.result)), "fq_align_resident")
@@ -258,22 +319,36 @@ class Aligner:
             self.h = None
 
 
-def align_stream(aligner: Aligner, names, seq, qual, lens, batch: int, stages_path=None, sam_path=None, header=True) -> int:
-    """Feed n pairs in batches of `batch` (mirrors PairEndMapper's loop); returns pairs with SAM records."""
+def align_stream(aligner: Aligner, names, seq, qual, lens, batch: int, stages_path=None, sam_path=None, header=True, packed: bool = False) -> int:
+    """Feed n pairs in batches of `batch` (mirrors PairEndMapper's loop); returns pairs with SAM records.  packed=True goes
+    through the packed-batch boundary (fq_pack_reads -> fq_packed_prefetch of the next chunk -> fq_align_packed)."""
     n = seq.shape[1]
     st = open(stages_path, "wb") if stages_path else None
     sm = open(sam_path, "wb") if sam_path else None
     if sm and header:
         sm.write(aligner.index.sam_header())
     total = 0
+    nxt = None
     for b0 in range(0, n, batch):
         b1 = min(n, b0 + batch)
-        res = aligner.align(seq[:, b0:b1], qual[:, b0:b1], lens[:, b0:b1], names[b0:b1])
+        if packed:
+            cur = nxt or HostPacked(seq[:, b0:b1], qual[:, b0:b1], lens[:, b0:b1], names[b0:b1], lib=aligner.L)
+            nxt = None
+            if b1 < n:
+                b2 = min(n, b1 + batch)
+                nxt = HostPacked(seq[:, b1:b2], qual[:, b1:b2], lens[:, b1:b2], names[b1:b2], lib=aligner.L)
+                aligner.prefetch(nxt)
+            res = aligner.align_packed(cur)
+        else:
+            res = aligner.align(seq[:, b0:b1], qual[:, b0:b1], lens[:, b0:b1], names[b0:b1])
         total += res.n_survivors - res.n_both_unmapped
         if st:
             st.write(aligner.stage_text())
         if sm:
             sm.write(aligner.sam_text())
+        if packed:
+            aligner._keep_packed = None
+            cur.free()
     if st:
         st.close()
     if sm:

@@ -65,10 +65,38 @@ template <class T> struct DevBuf {
 };
 }  // namespace
 
+template <class T> struct PinBuf {   // pinned host staging: device <-> host copies of per-call lists run at full PCIe rate and truly async
+  T *p = nullptr;
+  size_t cap = 0;
+  ~PinBuf() { fqdev::hfree(p); }
+  bool ensure(size_t n) {
+    if (n <= cap) return true;
+    fqdev::hfree(p);
+    cap = n + n / 4 + 64;
+    p = (T *)fqdev::hmalloc(cap * sizeof(T));
+    if (!p) { cap = 0; return false; }
+    return true;
+  }
+};
+
+struct FqKnobs {   // experiment / test knobs (fq_ctx_set_tuning); defaults are what DESIGN.md measures
+  uint32_t gap_long_pops = 1024;   // lane kernel hands a search to the wavefront-per-read kernel after this many pops (queue dry)
+  int gap_long_always = 0;         // ... whatever the state of the queue (tests)
+  uint32_t gap_pool = 2048;        // stack entries per lane of the lane kernel
+  int gap_no_order = 0;
+  int sw_wave_max = 4096;          // largest mate-SW window the wavefront kernel takes
+  int host_threads = -1;           // -1: fq_opts_t::host_threads
+  size_t host_par_min = 32768;     // below this many items a per-pair host phase stays on the calling thread
+  int64_t packed_bulk_min = -1;    // packed batches: upload the whole body instead of gathered survivor rows from this many survivor pairs (-1: n_pairs / 8)
+  int trace = 0;
+};
+
 struct fq_ctx {
   const fq_index *ix = nullptr;
   fq_opts_t o{};
   FqKOpts ko{};
+  FqKnobs kn;
+  fqdev::State *dev = nullptr;
   int max_pairs = 0;
   int debug = 0;
   std::string err;
@@ -78,10 +106,24 @@ struct fq_ctx {
   std::unordered_map<uint64_t, vector<uint32_t>> kl_cache;
   int g_log_n[256];
   uint8_t maxdiff_lut[FQ_LMAX + 2];
-  // device-resident batch
+  // the batch of the current call: ASCII rows resident in HBM (fq_batch_upload) or a packed host batch (fq_align_packed)
   int n_pairs = 0, stride = 0;
-  const fq_read_batch_t *host_batch_valid = nullptr;
+  int in_kind = 0;                      // 0 none, 1 ASCII, 2 packed
   fq_read_batch_t hb{};
+  fq_packed_batch_t pb{};
+  // packed input: two head buffers (the next batch's head uploads while this one is aligned)
+  DevBuf<uint64_t> d_head[2];
+  DevBuf<uint16_t> d_hlen[2];
+  int head_slot = 0;
+  const fq_packed_batch_t *prefetched = nullptr;   // batch whose head sits in slot 1 - head_slot
+  DevBuf<uint8_t> d_body, d_pqual;
+  DevBuf<uint64_t> d_exc;
+  DevBuf<int32_t> d_row_map, d_crow, d_len_c, d_len_all;
+  PinBuf<uint8_t> p_body, p_pqual;
+  PinBuf<uint64_t> p_exc;
+  PinBuf<uint16_t> p_hlen;
+  DevBuf<uint16_t> d_blen;
+  // device-resident reads (ASCII rows the kernels after the filter read): whole batch (ASCII input) or survivors only (packed)
   DevBuf<uint8_t> d_seq, d_qual, d_filtered, d_maxdiff;
   DevBuf<FqGapWork> d_winfo;
   DevBuf<int32_t> d_len, d_len_trim, d_read_list, d_sidx, d_pair_list, d_counts;
@@ -115,14 +157,19 @@ struct fq_ctx {
   DevBuf<uint32_t> d_mdsz;
   // host staging
   vector<uint8_t> h_filtered;
-  vector<int32_t> h_len_trim, h_pair_list, h_read_list, h_sidx, h_sub_max;
+  vector<int32_t> h_len_trim, h_pair_list, h_sub_max;
   vector<FqSurvInfo> h_surv;
+  PinBuf<int32_t> p_i32;
+  PinBuf<FqSurvInfo> p_surv;
+  PinBuf<uint32_t> p_u32a, p_u32b, p_pos;
+  PinBuf<FqAln> p_aln;
   DevBuf<FqSurvInfo> d_surv;
   DevBuf<int32_t> d_sub_max;
   int64_t n_bases_in = 0;
   // results of the last batch
   FqBatchState st;
   fq_stats_t stats{};
+  ~fq_ctx();
 };
 
 // ---- drand48 (glibc): X' = (0x5DEECE66D X + 0xB) mod 2^48, value X'/2^48 ------------------------------
@@ -176,13 +223,37 @@ extern "C" int fq_ctx_create(const fq_index_t *ix, const fq_opts_t *opts, int32_
   k.indel_end_skip = o.indel_end_skip; k.max_del_occ = o.max_del_occ; k.max_entries = o.max_entries;
   k.max_gapo = o.max_gapo; k.max_gape = o.max_gape; k.max_seed_diff = o.max_seed_diff; k.seed_len = o.seed_len;
   k.max_top2 = o.max_top2; k.trim_qual = o.trim_qual; k.filter_thresh = o.filter_thresh; k.n_buckets = FQ_MAX_BUCKETS;
-  if (fqdev::init(ix->device)) { return FQ_ENODEV; }
+  c->dev = fqdev::state_create(ix->device);
+  if (!c->dev || fqdev::bind(c->dev)) return FQ_ENODEV;
   if (!c->d_maxdiff.ensure(FQ_LMAX + 2) || !c->d_counters.ensure(FQ_C_COUNT) || !c->d_counts.ensure(4) || !c->d_queue.ensure(4)) return FQ_ENOMEM;
   if (fqdev::h2d(c->d_maxdiff.p, c->maxdiff_lut, FQ_LMAX + 2) || fqdev::dzero(c->d_counters.p, FQ_C_COUNT * 8) || fqdev::sync()) return FQ_ENODEV;
   *out = c.release();
   return FQ_OK;
 }
+fq_ctx::~fq_ctx() { fqdev::state_destroy(dev); }   // synchronises the context's streams before the buffers below are freed
 extern "C" void fq_ctx_destroy(fq_ctx_t *c) { delete c; }
+
+extern "C" int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t v) {
+  if (!c || !key) return FQ_EINVAL;
+  const std::string k = key;
+  fqdev::Tune *t = fqdev::tune(c->dev);
+  if (k == "gap_long_pops") c->kn.gap_long_pops = (uint32_t)v;
+  else if (k == "gap_long_always") c->kn.gap_long_always = (int)v;
+  else if (k == "gap_pool") c->kn.gap_pool = (uint32_t)v;
+  else if (k == "gap_no_order") c->kn.gap_no_order = (int)v;
+  else if (k == "sw_wave_max") c->kn.sw_wave_max = (int)v;
+  else if (k == "host_threads") c->kn.host_threads = (int)v;
+  else if (k == "host_par_min") c->kn.host_par_min = (size_t)v;
+  else if (k == "packed_bulk_min") c->kn.packed_bulk_min = v;
+  else if (k == "trace") c->kn.trace = (int)v;
+  else if (k == "gap_order_asc") t->gap_order_asc = (int)v;
+  else if (k == "gap_waves_per_cu") t->gap_waves_per_cu = (int)v;
+  else if (k == "gap_refill_min") t->gap_refill_min = (int)v;
+  else if (k == "filter_no_turns") t->filter_no_turns = (int)v;
+  else if (k == "refine_lanes") t->refine_lanes = (int)v;
+  else return FQ_EINVAL;
+  return FQ_OK;
+}
 
 extern "C" void fq_stats_get(const fq_ctx_t *c, fq_stats_t *out) { if (c && out) *out = c->stats; }
 extern "C" void fq_stats_reset(fq_ctx_t *c) { if (c) memset(&c->stats, 0, sizeof c->stats); }
@@ -199,7 +270,7 @@ extern "C" void fq_stats_reset(fq_ctx_t *c) { if (c) memset(&c->stats, 0, sizeof
 extern "C" int fq_batch_upload(fq_ctx_t *c, const fq_read_batch_t *in) {
   if (!c || !in || in->n_pairs < 0 || !in->seq || !in->qual || !in->len) return FQ_EINVAL;
   if (in->n_pairs > c->max_pairs) { c->err = "batch larger than max_pairs_per_batch"; return FQ_ELIMIT; }
-  if (fqdev::init(c->ix->device)) return FQ_ENODEV;   // per-thread stream
+  if (fqdev::bind(c->dev)) return FQ_ENODEV;
   if (in->stride < 1 || in->stride > 4096) return FQ_EINVAL;
   const size_t n2 = (size_t)in->n_pairs * 2;
   int64_t nb = 0;
@@ -217,6 +288,8 @@ extern "C" int fq_batch_upload(fq_ctx_t *c, const fq_read_batch_t *in) {
   c->n_pairs = in->n_pairs;
   c->stride = in->stride;
   c->hb = *in;
+  c->in_kind = 1;
+  c->stats.h2d_bytes += 2 * n2 * (size_t)in->stride + n2 * 4;
   return FQ_OK;
 }
 
@@ -231,13 +304,9 @@ namespace {
 
 // The per-pair host phases are independent across pairs (everything order-dependent -- the drand48 stream, the insert-size
 // chain, the (k,l) position cache -- is handled serially before them), so large batches are split over a few threads.
-inline size_t par_min() {   // below this many items a phase stays on the calling thread (FQ_HOST_PAR_MIN: test hook)
-  const char *e = getenv("FQ_HOST_PAR_MIN");
-  return e ? (size_t)atoll(e) : (size_t)32768;
-}
 template <class F>
-void parallel_chunks(size_t n, int threads, F fn) {   // fn(lo, hi, thread index)
-  if (threads <= 1 || n < par_min()) { fn((size_t)0, n, 0); return; }
+void parallel_chunks(size_t n, int threads, size_t par_min, F fn) {   // fn(lo, hi, thread index); below par_min items the phase stays on the calling thread
+  if (threads <= 1 || n < par_min) { fn((size_t)0, n, 0); return; }
   std::vector<std::thread> th;
   const size_t per = (n + threads - 1) / threads;
   for (int t = 0; t < threads; ++t) {
@@ -415,41 +484,88 @@ void pair_hits(fq_ctx *c, vector<int> &pen_lut, FqRead *p[2], const FqAln *aln[2
 }  // namespace
 
 // ---- the batch ------------------------------------------------------------------------------------------
-extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
-  if (!c || !out) return FQ_EINVAL;
-  static const bool trace_on = getenv("FQ_TRACE") != nullptr;
-  double t_trace = now_ms();
-#define TRACE(label) do { if (trace_on) { const double t_ = now_ms(); fprintf(stderr, "[fq] %-22s %8.3f ms\n", label, t_ - t_trace); t_trace = t_; } } while (0)
-  if (fqdev::init(c->ix->device)) return FQ_ENODEV;   // the calling thread's own stream
-  const double t_wall0 = now_ms();
-  const fq_index *ix = c->ix;
-  const fq_opts_t &o = c->o;
-  const int n = c->n_pairs, n2 = 2 * n, stride = c->stride;
-  FqBatchState &S = c->st;
-  S.clear();
-  S.n_pairs = n;
-  memset(out, 0, sizeof *out);
-  out->n_pairs = n;
-  if (n == 0) { S.reads.clear(); return FQ_OK; }
+// One call = stage 0 (filter + ordered compaction; the only stage that sees every read), then the stages below over the
+// reads of surviving pairs.  The stage functions share the per-call state in `Call`.
+namespace {
+struct Call {
+  fq_ctx *c = nullptr;
+  int n = 0, n2 = 0, B = 0, n_sub = 0, n_search = 0, n_surv = 0, max_len_all = 1, host_threads = 1;
+  size_t par_min = 32768;
+  // where the kernels after the filter find the reads: ASCII rows [row][dstride], trimmed lengths [row], search index -> row.
+  // ASCII input: row = the read's row in the batch; packed input: row = 2 * survivor pair + end (only those were unpacked).
+  const uint8_t *dseq = nullptr;
+  int dstride = 0;
+  const int32_t *dlen_trim = nullptr, *dread_list = nullptr;
+  vector<int> sub_max_len, sub_lo;
+  vector<uint64_t> aln_off;            // per search index s: its hit list is S.aln[aln_off[s] .. + aln_n[s])
+  vector<uint32_t> aln_n;
+  vector<int> s_of;                    // survivor read -> search index or -1
+  vector<uint64_t> read_nocc, aln_row_off;
+  vector<char> enumerated;
+  const uint32_t *h_pos = nullptr;     // positions of the enumerated SA rows (pinned staging of the context)
+  vector<fq_isize_t> iis;
+  double t_trace = 0, t_wall0 = 0, t_host0 = 0, t_serial1 = 0, t_host1 = 0;
+  const FqAln *aln_of(int idx, int *n_out) const {
+    const int s = s_of[idx];
+    if (s < 0) { *n_out = 0; return nullptr; }
+    *n_out = (int)aln_n[s];
+    return c->st.aln.data() + aln_off[s];
+  }
+  void trace(const char *label) {
+    if (!c->kn.trace) return;
+    const double t = now_ms();
+    fprintf(stderr, "[fq] %-22s %8.3f ms\n", label, t - t_trace);
+    t_trace = t;
+  }
+};
 
-  // ---- stage 0: encode + trim + filter + ordered compaction (GPU) -------------------------------------
-  // The call may carry several reference batches (READ_BUFFER_SIZE pairs each, src/BwtMapper.h:36): the GPU stages run
-  // over all of them at once, the order-dependent host stages walk them one reference batch at a time.
-  const int B = o.batch_pairs, n_sub = (n + B - 1) / B;
+// survivors of stage 0 -> host lists and the reference-batch boundaries among them
+int stage0_lists(Call &K, bool have_len_trim) {
+  fq_ctx *c = K.c;
+  const int n_surv = K.n_surv;
+  c->h_pair_list.resize(n_surv);
+  c->h_surv.resize((size_t)n_surv * 2);
+  CKM(c->p_i32.ensure((size_t)n_surv + 1) && c->p_surv.ensure((size_t)n_surv * 2 + 1));
+  CK(fqdev::d2h(c->p_i32.p, c->d_pair_list.p, (size_t)n_surv * 4));
+  CK(fqdev::d2h(c->p_surv.p, c->d_surv.p, (size_t)n_surv * 2 * sizeof(FqSurvInfo)));
+  CK(fqdev::sync());
+  c->stats.d2h_bytes += (size_t)n_surv * (4 + 2 * sizeof(FqSurvInfo));
+  if (n_surv) { memcpy(c->h_pair_list.data(), c->p_i32.p, (size_t)n_surv * 4); memcpy(c->h_surv.data(), c->p_surv.p, (size_t)n_surv * 2 * sizeof(FqSurvInfo)); }
+  (void)have_len_trim;
+  K.sub_lo.assign(K.n_sub + 1, 0);
+  int sp = 0;
+  for (int sb = 0; sb < K.n_sub; ++sb) { K.sub_lo[sb] = sp; while (sp < n_surv && c->h_pair_list[sp] < (int64_t)(sb + 1) * K.B) ++sp; }
+  K.sub_lo[K.n_sub] = n_surv;
+  return FQ_OK;
+}
+void stage0_sub_max(Call &K) {
+  K.max_len_all = 1;
+  K.sub_max_len.assign(K.n_sub, 1);
+  for (int sb = 0; sb < K.n_sub; ++sb) {
+    K.sub_max_len[sb] = std::max(1, K.c->h_sub_max[sb]);
+    K.max_len_all = std::max(K.max_len_all, K.sub_max_len[sb]);
+  }
+}
+
+// ---- stage 0, ASCII rows resident in HBM: encode + trim + filter + ordered compaction (GPU) ---------------------------
+// The call may carry several reference batches (READ_BUFFER_SIZE pairs each, src/BwtMapper.h:36): the GPU stages run
+// over all of them at once, the order-dependent host stages walk them one reference batch at a time.
+int stage0_ascii(Call &K) {
+  fq_ctx *c = K.c;
+  const fq_index *ix = c->ix;
+  const int n = K.n, n2 = K.n2, n_sub = K.n_sub, B = K.B;
   CKM(c->d_len_trim.ensure(n2) && c->d_filtered.ensure(n2 + 64) && c->d_read_list.ensure(n2) &&
       c->d_sidx.ensure(n2) && c->d_pair_list.ensure(n) && c->d_sub_max.ensure(n_sub));
   CK(fqdev::dzero(c->d_sub_max.p, (size_t)n_sub * 4));
   // (the filter kernels of all contexts of a device are chained on the device: fqdev::launch_prep)
-  {
-    FqPrepArgs a{};
-    a.ix = ix->dev; a.o = c->ko; a.seq = c->d_seq.p; a.qual = c->d_qual.p; a.len = c->d_len.p; a.stride = stride; a.n_reads = n2;
-    a.len_trim = c->d_len_trim.p; a.filtered = c->d_filtered.p; a.sub_max = c->d_sub_max.p; a.n_pairs = n; a.batch_pairs = B;
-    a.counters = c->d_counters.p;
-    fqdev::time_begin(FQ_K_PREP);
-    CK(fqdev::launch_prep(a));
-    CK(fqdev::launch_compact(c->d_filtered.p, n, c->d_read_list.p, c->d_sidx.p, c->d_pair_list.p, c->d_counts.p));
-    fqdev::time_end(FQ_K_PREP);
-  }
+  FqPrepArgs a{};
+  a.ix = ix->dev; a.o = c->ko; a.seq = c->d_seq.p; a.qual = c->d_qual.p; a.len = c->d_len.p; a.stride = c->stride; a.n_reads = n2;
+  a.len_trim = c->d_len_trim.p; a.filtered = c->d_filtered.p; a.sub_max = c->d_sub_max.p; a.n_pairs = n; a.batch_pairs = B;
+  a.counters = c->d_counters.p;
+  fqdev::time_begin(FQ_K_PREP);
+  CK(fqdev::launch_prep(a));
+  CK(fqdev::launch_compact(c->d_filtered.p, n, c->d_read_list.p, c->d_sidx.p, c->d_pair_list.p, c->d_counts.p));
+  fqdev::time_end(FQ_K_PREP);
   // Only what concerns surviving pairs comes back to the host: in a WGS-like stream that is a fraction of a percent of the
   // batch.  (Debug mode also fetches the per-read arrays of the whole batch for the stage dump.)
   int32_t counts[2] = {0, 0};
@@ -457,235 +573,405 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   CK(fqdev::d2h(counts, c->d_counts.p, 8));
   CK(fqdev::d2h(c->h_sub_max.data(), c->d_sub_max.p, (size_t)n_sub * 4));
   CK(fqdev::sync());
-  const int n_search = counts[0], n_surv = counts[1];
-  c->h_pair_list.resize(n_surv);
-  c->h_read_list.resize(n_search);
-  c->h_surv.resize((size_t)n_surv * 2);
-  CKM(c->d_surv.ensure((size_t)n_surv * 2 + 1));
-  CK(fqdev::launch_surv_gather(c->d_pair_list.p, n_surv, n, c->d_len_trim.p, c->d_filtered.p, c->d_sidx.p, c->d_surv.p));
-  CK(fqdev::d2h(c->h_pair_list.data(), c->d_pair_list.p, (size_t)n_surv * 4));
-  CK(fqdev::d2h(c->h_read_list.data(), c->d_read_list.p, (size_t)n_search * 4));
-  CK(fqdev::d2h(c->h_surv.data(), c->d_surv.p, (size_t)n_surv * 2 * sizeof(FqSurvInfo)));
+  K.n_search = counts[0]; K.n_surv = counts[1];
+  CKM(c->d_surv.ensure((size_t)K.n_surv * 2 + 1));
+  CK(fqdev::launch_surv_gather(c->d_pair_list.p, K.n_surv, n, c->d_len_trim.p, c->d_filtered.p, c->d_sidx.p, c->d_surv.p));
   if (c->debug) {
     c->h_filtered.resize(n2);
     c->h_len_trim.resize(n2);
     CK(fqdev::d2h(c->h_filtered.data(), c->d_filtered.p, n2));
     CK(fqdev::d2h(c->h_len_trim.data(), c->d_len_trim.p, (size_t)n2 * 4));
   } else { c->h_filtered.clear(); c->h_len_trim.clear(); }
+  int rc = stage0_lists(K, true);
+  if (rc) return rc;
+  stage0_sub_max(K);
+  K.dseq = c->d_seq.p; K.dstride = c->stride; K.dlen_trim = c->d_len_trim.p; K.dread_list = c->d_read_list.p;
+  return FQ_OK;
+}
+
+// ---- stage 0, packed host batch (SURVEY 8d boundary) ---------------------------------------------------------------------
+// Only the 24-byte filter key of every read crosses PCIe (its upload may have been started by fq_packed_prefetch and then
+// ran under the previous call's kernels); the full rows -- and, when --q trimming is on, the qualities -- follow for the
+// reads of surviving pairs only, and are unpacked into the compact ASCII rows the later kernels read.
+int head_upload(fq_ctx *c, const fq_packed_batch_t *b, int slot) {
+  const size_t n2 = (size_t)b->n_pairs * 2;
+  CKM(c->d_head[slot].ensure(n2 * 3 + 8));
+  CK(fqdev::h2d_copy(c->d_head[slot].p, b->head, n2 * 24));
+  c->stats.h2d_bytes += n2 * 24;
+  if (!b->uniform_len) {
+    CKM(c->d_hlen[slot].ensure(n2 + 8));
+    CK(fqdev::h2d_copy(c->d_hlen[slot].p, b->len, n2 * 2));
+    c->stats.h2d_bytes += n2 * 2;
+  }
+  CK(fqdev::copy_record(slot));
+  return FQ_OK;
+}
+int stage0_packed(Call &K) {
+  fq_ctx *c = K.c;
+  const fq_index *ix = c->ix;
+  const fq_packed_batch_t &pb = c->pb;
+  const int n = K.n, n2 = K.n2, n_sub = K.n_sub, B = K.B;
+  const bool ragged = pb.uniform_len <= 0;
+  const bool trim = c->o.trim_qual >= 1;
+  if (c->prefetched == &pb) c->head_slot ^= 1;   // its head is already on its way into the spare buffer (fq_packed_prefetch)
+  else { int rc = head_upload(c, &pb, c->head_slot); if (rc) return rc; }
+  c->prefetched = nullptr;
+  const int slot = c->head_slot;
+  CK(fqdev::compute_wait_copy(slot));
+  CKM(c->d_filtered.ensure(n2 + 64) && c->d_read_list.ensure(n2) && c->d_sidx.ensure(n2) && c->d_pair_list.ensure(n) && c->d_sub_max.ensure(n_sub));
+  CK(fqdev::dzero(c->d_sub_max.p, (size_t)n_sub * 4));
+  FqPrepPackedArgs a{};
+  a.ix = ix->dev; a.o = c->ko; a.head = c->d_head[slot].p; a.len = ragged ? c->d_hlen[slot].p : nullptr; a.uniform_len = pb.uniform_len;
+  a.n_reads = n2; a.filtered = c->d_filtered.p; a.sub_max = c->d_sub_max.p; a.n_pairs = n; a.batch_pairs = B; a.counters = c->d_counters.p;
+  fqdev::time_begin(FQ_K_PREP);
+  CK(fqdev::launch_prep_packed(a));
+  CK(fqdev::launch_compact(c->d_filtered.p, n, c->d_read_list.p, c->d_sidx.p, c->d_pair_list.p, c->d_counts.p));
+  fqdev::time_end(FQ_K_PREP);
+  int32_t counts[2] = {0, 0};
+  uint64_t lcnt[2] = {0, 0};   // FQ_C_BASES, FQ_C_BADLEN (ragged batches)
+  c->h_sub_max.assign(n_sub, pb.uniform_len);   // longest untrimmed read per reference batch
+  CK(fqdev::d2h(counts, c->d_counts.p, 8));
+  if (ragged) {
+    CK(fqdev::d2h(c->h_sub_max.data(), c->d_sub_max.p, (size_t)n_sub * 4));
+    CK(fqdev::d2h(lcnt, c->d_counters.p + FQ_C_BASES, 16));
+  }
   CK(fqdev::sync());
-  const int64_t n_bases = c->n_bases_in;
-  int max_len_all = 1;
-  vector<int> sub_max_len(n_sub, 1), sub_lo(n_sub + 1, 0);
-  for (int sb = 0; sb < n_sub; ++sb) {
-    sub_max_len[sb] = std::max(1, c->h_sub_max[sb]);
-    max_len_all = std::max(max_len_all, sub_max_len[sb]);
-  }
-  {
-    int sp = 0;
-    for (int sb = 0; sb < n_sub; ++sb) { sub_lo[sb] = sp; while (sp < n_surv && c->h_pair_list[sp] < (int64_t)(sb + 1) * B) ++sp; }
-    sub_lo[n_sub] = n_surv;
-  }
-  S.n_surv = n_surv;
-  S.batch_pairs = B;
-  S.sub_lo = sub_lo;
-  S.pair_idx = c->h_pair_list;
-
-  TRACE("stage0 prep+compact");
-  // ---- stage A: widths + gap search, tiered by stack-pool size (GPU) ----------------------------------
-  // h_aln: concatenated hit lists; per search index s: [aln_off[s], aln_off[s]+aln_n[s])
-  vector<FqAln> &h_aln = S.aln;
-  vector<uint64_t> aln_off(n_search + 1, 0);
-  vector<uint32_t> aln_n(n_search, 0);
-  {
-    const int Lpad = (max_len_all + 1 + 7) & ~7;                  // exact widths per strand; rows are written 8 positions at a time
-    const int Ppad = (max_len_all + 1 + FQ_POS_PAD + 7) & ~7;     // position records per strand (16-byte aligned rows)
-    // tier 0: one read per lane, bounded stack and pop count; what it gives up on is searched again by one wavefront per read
-    // (tier 1 with push-time pruning, tier 2 exactly as the reference: no pruning, n_entries exact).  The wavefront kernel never
-    // reuses pool slots, so its pools hold every push of a search, not just the live entries.
-    const uint32_t long_pops = getenv("FQ_GAP_LONG_POPS") ? (uint32_t)atoi(getenv("FQ_GAP_LONG_POPS")) : 1024u;
-    const uint32_t exact_pool = (uint32_t)std::min<uint64_t>(4ull * (uint64_t)o.max_entries + 4096ull, 0x7fffffffull);
-    const int long_always = getenv("FQ_GAP_LONG_ALWAYS") ? atoi(getenv("FQ_GAP_LONG_ALWAYS")) : 0;   // test hook
-    const uint32_t lane_pool = getenv("FQ_GAP_POOL") ? (uint32_t)atoi(getenv("FQ_GAP_POOL")) : 2048u;   // stack entries per lane of the lane kernel (32 KB; reads that need more go to the wavefront tier)
-    const FqGapTier tiers[3] = {{lane_pool, 32u, 0, 0, long_pops, long_always}, {262144u, 512u, 0, 1, 0u, 0}, {exact_pool, 8192u, 1, 1, 0u, 0}};
-    // scores that can occur for the longest read of this call (children may exceed max_diff by one difference)
-    const int nb_need = (c->maxdiff_lut[max_len_all] + 1) * o.s_mm + o.max_gapo * o.s_gapo + o.max_gape * o.s_gape + 1;
-    const size_t chunk_reads[3] = {(size_t)8 << 20, (size_t)1 << 20, 4096};   // pools are per lane / per wavefront; only per-read outputs scale with the chunk
-    vector<int32_t> work(n_search), next_work;
-    for (int s = 0; s < n_search; ++s) work[s] = s;
-    vector<uint32_t> h_status, h_naln;
-    vector<FqAln> h_packed;
-    // tier 0 results are appended in s order directly
-    vector<int64_t> where(n_search, -1);   // offset of s's list in h_aln (filled as results arrive)
-    for (int tier = 0; tier < 3 && !work.empty(); ++tier) {
-      FqGapTier T = tiers[tier];
-      // Handing long searches to the wavefront-per-read kernel pays when the launch is latency-bound (few reads: its duration is
-      // its longest search); a launch that fills the device several times over hides its long searches behind the others.
-      if (tier == 0 && !long_always && work.size() > 524288) T.long_pops = 0;   // (two reads per resident lane)
-      next_work.clear();
-      for (size_t c0 = 0; c0 < work.size(); c0 += chunk_reads[tier]) {
-        const int nw = (int)std::min(chunk_reads[tier], work.size() - c0);
-        CKM(c->d_work.ensure(nw) && c->d_wfull.ensure((size_t)nw * 2 * Lpad) && c->d_prec.ensure((size_t)nw * 2 * Ppad) && c->d_winfo.ensure(nw) && c->d_bid_end.ensure((size_t)nw * 2) && c->d_order.ensure(nw) && c->d_order_cnt.ensure(2 * FQ_ORDER_KEYS) &&
-            c->d_aln.ensure((size_t)nw * T.aln_cap) && c->d_naln.ensure(nw) && c->d_status.ensure(nw) && c->d_off.ensure(nw + 1));
-        CK(fqdev::h2d(c->d_work.p, work.data() + c0, (size_t)nw * 4));
-        FqWidthArgs wa{};
-        wa.ix = ix->dev; wa.o = c->ko; wa.seq = c->d_seq.p; wa.stride = stride; wa.len_trim = c->d_len_trim.p; wa.read_list = c->d_read_list.p;
-        wa.work = c->d_work.p; wa.n_work = nw; wa.wfull = c->d_wfull.p; wa.wstride = Lpad;
-        wa.prec = c->d_prec.p; wa.pstride = Ppad; wa.winfo = c->d_winfo.p; wa.maxdiff_lut = c->d_maxdiff.p; wa.bid_end = c->d_bid_end.p; wa.counters = c->d_counters.p;
-        fqdev::time_begin(FQ_K_WIDTH);
-        CK(fqdev::launch_width(wa));
-        CK(fqdev::launch_order(c->d_bid_end.p, nw, c->d_order.p, c->d_order_cnt.p));   // long searches first
-        fqdev::time_end(FQ_K_WIDTH);
-        FqGapArgs ga{};
-        ga.ix = ix->dev; ga.o = c->ko; ga.o.n_buckets = nb_need; ga.n_work = nw; ga.winfo = c->d_winfo.p; ga.order = getenv("FQ_GAP_NO_ORDER") ? nullptr : c->d_order.p;
-        ga.wfull = c->d_wfull.p; ga.wstride = Lpad; ga.prec = c->d_prec.p; ga.pstride = Ppad;
-        ga.pool = c->d_pool.p; ga.heads = c->d_heads.p; ga.tier = T; ga.aln = c->d_aln.p; ga.n_aln = c->d_naln.p; ga.status = c->d_status.p;
-        ga.counters = c->d_counters.p; ga.queue = c->d_queue.p;
-        {
-          // stack pools are the one large per-launch allocation (lanes x pool_cap x 16 B): when the device cannot hold them for
-          // as many wavefronts as it could run, run fewer (the persistent lanes simply take more reads each)
-          for (;;) {
-            const size_t slots = (size_t)fqdev::gap_lane_slots(ga);
-            if (c->d_heads.ensure(slots * FQ_MAX_BUCKETS) && c->d_pool.ensure(slots * T.pool_cap)) break;
-            const int waves = (int)(T.coop ? slots : slots / 64);
-            if (waves <= 1) { c->err = "out of device memory for the search pools"; return FQ_ENOMEM; }
-            ga.max_waves = waves / 2;
-          }
-          ga.pool = c->d_pool.p; ga.heads = c->d_heads.p;
-        }
-        fqdev::time_begin(FQ_K_GAP);
-        CK(fqdev::launch_gap(ga));
-        fqdev::time_end(FQ_K_GAP);
-        CK(fqdev::launch_scan(c->d_naln.p, c->d_off.p, (uint32_t)nw));
-        h_status.resize(nw); h_naln.resize(nw);
-        uint64_t total = 0;
-        CK(fqdev::d2h(h_status.data(), c->d_status.p, (size_t)nw * 4));
-        CK(fqdev::d2h(h_naln.data(), c->d_naln.p, (size_t)nw * 4));
-        CK(fqdev::d2h(&total, c->d_off.p + nw, 8));
-        CK(fqdev::sync());
-        CKM(c->d_packed.ensure(total + 1));
-        CK(fqdev::launch_pack_aln(c->d_aln.p, c->d_naln.p, c->d_off.p, T.aln_cap, (uint32_t)nw, c->d_packed.p));
-        h_packed.resize(total);
-        CK(fqdev::d2h(h_packed.data(), c->d_packed.p, total * sizeof(FqAln)));
-        CK(fqdev::sync());
-        uint64_t at = 0;
-        for (int w = 0; w < nw; ++w) {
-          const int s = work[c0 + w];
-          if (h_status[w]) { next_work.push_back(s); ++c->stats.tier_retries; continue; }
-          where[s] = (int64_t)h_aln.size();
-          aln_n[s] = h_naln[w];
-          h_aln.insert(h_aln.end(), h_packed.begin() + at, h_packed.begin() + at + h_naln[w]);
-          at += h_naln[w];
-        }
-      }
-      work.swap(next_work);
+  if (ragged) {
+    if (lcnt[1]) { c->err = "read length outside [" + std::to_string(FQ_LMIN) + "," + std::to_string(FQ_LMAX) + "]"; return FQ_ELIMIT; }
+    c->n_bases_in = (int64_t)lcnt[0];
+  } else c->n_bases_in = (int64_t)n2 * pb.uniform_len;
+  const int n_search = counts[0], n_surv = counts[1], nrow = 2 * n_surv;
+  K.n_search = n_search; K.n_surv = n_surv;
+  const int64_t bulk_min = c->kn.packed_bulk_min >= 0 ? c->kn.packed_bulk_min : (int64_t)n / 8;
+  const bool bulk = n_surv > 0 && (int64_t)n_surv >= bulk_min;   // many survivors: upload the whole body, gather on the device
+  CKM(c->d_surv.ensure((size_t)nrow + 1) && c->d_row_map.ensure((size_t)nrow + 1) && c->d_len_c.ensure((size_t)nrow + 1) && c->d_len_trim.ensure((size_t)nrow + 1));
+  const bool need_crow = bulk && pb.n_exc > 0;   // batch row -> compact row (-1: not unpacked), for the exception list of the whole batch
+  if (need_crow) { CKM(c->d_crow.ensure(n2)); CK(fqdev::dfill(c->d_crow.p, 0xff, (size_t)n2 * 4)); }
+  // d_read_list is rewritten as search index -> compact row
+  CK(fqdev::launch_surv_map(c->d_pair_list.p, n_surv, n, c->d_filtered.p, c->d_sidx.p, c->d_surv.p, c->d_row_map.p, c->d_read_list.p, need_crow ? c->d_crow.p : nullptr));
+  int rc = stage0_lists(K, false);
+  if (rc) return rc;
+  // ---- the reads of surviving pairs: body rows (+ exceptions, + qualities when trimming) -> compact ASCII rows ----
+  const int body_stride = pb.body_stride;
+  int max_full = 1;
+  for (int sb = 0; sb < n_sub; ++sb) max_full = std::max(max_full, c->h_sub_max[sb]);
+  const int cstride = (max_full + 15) & ~15;
+  CKM(c->d_seq.ensure((size_t)nrow * cstride + 64));
+  FqUnpackArgs ua{};
+  ua.body_stride = body_stride; ua.uniform_len = pb.uniform_len; ua.n_rows = nrow; ua.seq = c->d_seq.p; ua.stride = cstride;
+  ua.len_out = c->d_len_c.p; ua.len_trim = c->d_len_trim.p;
+  FqPatchArgs pa{};
+  pa.seq = c->d_seq.p; pa.stride = cstride;
+  FqTrimArgs ta{};
+  ta.o = c->ko; ta.qual_stride = pb.qual_stride; ta.len = c->d_len_c.p; ta.n_rows = nrow; ta.len_trim = c->d_len_trim.p;
+  if (nrow && bulk) {
+    CKM(c->d_body.ensure((size_t)n2 * body_stride + 64));
+    CK(fqdev::h2d(c->d_body.p, pb.body, (size_t)n2 * body_stride));
+    c->stats.h2d_bytes += (size_t)n2 * body_stride;
+    ua.body = c->d_body.p; ua.row_map = c->d_row_map.p;
+    if (ragged) ua.len = c->d_hlen[slot].p;
+    if (pb.n_exc) {
+      CKM(c->d_exc.ensure((size_t)pb.n_exc + 1));
+      CK(fqdev::h2d(c->d_exc.p, pb.exc, (size_t)pb.n_exc * 8));
+      c->stats.h2d_bytes += (size_t)pb.n_exc * 8;
+      pa.exc = c->d_exc.p; pa.n_exc = pb.n_exc; pa.crow_of = c->d_crow.p;
     }
-    if (!work.empty()) { c->err = "gap search: exact tier exhausted its pool (internal limit)"; return FQ_ELIMIT; }
-    for (int s = 0; s < n_search; ++s) aln_off[s] = where[s] < 0 ? 0 : (uint64_t)where[s];
-  }
-  c->stats.reads_searched += n_search;
-
-  TRACE("stageA width+gap");
-  // ---- records for survivors -----------------------------------------------------------------------------
-  const int host_threads = getenv("FQ_HOST_THREADS") ? atoi(getenv("FQ_HOST_THREADS")) :
-                           o.host_threads > 0 ? o.host_threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
-  vector<FqRead> &R = S.reads;
-  R.resize((size_t)n_surv * 2);                      // reused storage: every record is reset below
-  vector<int> s_of((size_t)n_surv * 2, -1);
-  {
-    // (kept on the calling thread: first touch decides which NUMA node the records live on, and the serial phases read them)
-    for (int sp = 0; sp < n_surv; ++sp)
-      for (int e = 0; e < 2; ++e) {
-        FqRead &p = R[2 * sp + e];
-        const int r = e * n + c->h_pair_list[sp];
-        const FqSurvInfo &si = c->h_surv[2 * sp + e];
-        p.reset();
-        p.r = r;
-        p.full_len = c->hb.len[r];
-        p.len = p.clip_len = si.len_trim;
-        p.filtered = (uint8_t)si.filtered;
-        p.extra_flag = 1 | (e == 0 ? 64 : 128);   // SAM_FPD | SAM_FR1/FR2 (BwtMapper.cpp:749)
-        s_of[2 * sp + e] = si.sidx;
-      }
-  }
-  auto aln_of = [&](int idx, int *n_out) -> const FqAln * {
-    const int s = s_of[idx];
-    if (s < 0) { *n_out = 0; return nullptr; }
-    *n_out = (int)aln_n[s];
-    return h_aln.data() + aln_off[s];
-  };
-
-  TRACE("records init");
-  // ---- SA rows to resolve on the GPU: every row of every hit of reads that can need them ------------------
-  // eligible(read) = n_occ <= max(n_multi,N_multi)+1  (XA listing, bwase.c:47-55)  or
-  //                  both mates have hits and both n_occ <= max_occ (pair enumeration, BwtMapper.cpp:797-811)
-  vector<uint64_t> rows_off;           // per (survivor read): offset into pos[] of its first enumerated row, or ~0
-  vector<uint32_t> h_pos;
-  vector<uint64_t> read_nocc((size_t)n_surv * 2, 0);
-  vector<char> enumerated((size_t)n_surv * 2, 0);
-  vector<uint64_t> aln_row_off;        // per hit in h_aln order (by survivor read order) -> offset into h_pos
-  aln_row_off.assign(h_aln.size() + 1, ~0ull);
-  {
-    const uint32_t multi_cap = (uint32_t)std::max(o.n_multi, o.N_multi) + 1;
-    parallel_chunks(R.size(), host_threads, [&](size_t lo, size_t hi, int) {
-      for (size_t idx = lo; idx < hi; ++idx) {
-        int na; const FqAln *a = aln_of((int)idx, &na);
-        uint64_t t = 0;
-        for (int k = 0; k < na; ++k) t += (uint64_t)(a[k].l - a[k].k) + 1;
-        read_nocc[idx] = t;
-      }
-    });
-    vector<FqAln> q_aln; vector<uint32_t> q_len; vector<uint64_t> q_off;
-    uint64_t rows = 0;
-    for (int sp = 0; sp < n_surv; ++sp) {
-      int na0, na1;
-      aln_of(2 * sp, &na0); aln_of(2 * sp + 1, &na1);
-      const bool pair_ok = na0 > 0 && na1 > 0 && read_nocc[2 * sp] <= o.max_occ && read_nocc[2 * sp + 1] <= o.max_occ;
-      for (int e = 0; e < 2; ++e) {
-        const int idx = 2 * sp + e;
-        int na; const FqAln *a = aln_of(idx, &na);
-        if (na == 0) continue;
-        if (!(pair_ok || read_nocc[idx] <= multi_cap)) continue;
-        enumerated[idx] = 1;
-        const uint64_t base = aln_off[s_of[idx]];
-        for (int k = 0; k < na; ++k) {
-          aln_row_off[base + k] = rows;
-          q_aln.push_back(a[k]); q_len.push_back((uint32_t)R[idx].len); q_off.push_back(rows);
-          rows += (uint64_t)(a[k].l - a[k].k) + 1;
-        }
+    if (trim) {
+      CKM(c->d_pqual.ensure((size_t)n2 * pb.qual_stride + 64));
+      CK(fqdev::h2d(c->d_pqual.p, pb.qual, (size_t)n2 * pb.qual_stride));
+      c->stats.h2d_bytes += (size_t)n2 * pb.qual_stride;
+      ta.qual = c->d_pqual.p; ta.row_map = c->d_row_map.p;
+    }
+  } else if (nrow) {
+    // few survivors: gather their rows into pinned staging on the host (a few thousand rows per reference batch in a WGS stream)
+    CKM(c->p_body.ensure((size_t)nrow * body_stride + 64) && c->d_body.ensure((size_t)nrow * body_stride + 64));
+    if (ragged) CKM(c->p_hlen.ensure((size_t)nrow + 8) && c->d_blen.ensure((size_t)nrow + 8));
+    if (trim) CKM(c->p_pqual.ensure((size_t)nrow * pb.qual_stride + 64) && c->d_pqual.ensure((size_t)nrow * pb.qual_stride + 64));
+    size_t ne = 0;
+    vector<std::pair<size_t, size_t>> erange;   // exceptions of each compact row: [lo, hi) in pb.exc
+    if (pb.n_exc) erange.resize(nrow);
+    for (int t = 0; t < nrow; ++t) {
+      const size_t r = (size_t)(t & 1) * (size_t)n + (size_t)c->h_pair_list[t >> 1];
+      memcpy(c->p_body.p + (size_t)t * body_stride, pb.body + r * (size_t)body_stride, (size_t)body_stride);
+      if (ragged) c->p_hlen.p[t] = pb.len[r];
+      if (trim) memcpy(c->p_pqual.p + (size_t)t * pb.qual_stride, pb.qual + r * (size_t)pb.qual_stride, (size_t)pb.qual_stride);
+      if (pb.n_exc) {
+        const uint64_t *lo = std::lower_bound(pb.exc, pb.exc + pb.n_exc, (uint64_t)r << 32);
+        const uint64_t *hi = std::lower_bound(lo, pb.exc + pb.n_exc, (uint64_t)(r + 1) << 32);
+        erange[t] = {(size_t)(lo - pb.exc), (size_t)(hi - pb.exc)};
+        ne += (size_t)(hi - lo);
       }
     }
-    q_off.push_back(rows);
-    h_pos.resize(rows);
-    if (rows) {
-      CKM(c->d_qaln.ensure(q_aln.size()) && c->d_qlen.ensure(q_len.size()) && c->d_qoff.ensure(q_off.size()) && c->d_pos.ensure(rows));
-      CK(fqdev::h2d(c->d_qaln.p, q_aln.data(), q_aln.size() * sizeof(FqAln)));
-      CK(fqdev::h2d(c->d_qlen.p, q_len.data(), q_len.size() * 4));
-      CK(fqdev::h2d(c->d_qoff.p, q_off.data(), q_off.size() * 8));
-      FqSaArgs sa{};
-      sa.ix = ix->dev; sa.aln = c->d_qaln.p; sa.aln_len = c->d_qlen.p; sa.row_off = c->d_qoff.p; sa.n_aln = (uint32_t)q_aln.size();
-      sa.n_rows = rows; sa.pos = c->d_pos.p; sa.counters = c->d_counters.p;
-      fqdev::time_begin(FQ_K_SA);
-      CK(fqdev::launch_sa(sa));
-      fqdev::time_end(FQ_K_SA);
-      CK(fqdev::d2h(h_pos.data(), c->d_pos.p, rows * 4));
+    CK(fqdev::h2d(c->d_body.p, c->p_body.p, (size_t)nrow * body_stride));
+    c->stats.h2d_bytes += (size_t)nrow * body_stride;
+    ua.body = c->d_body.p; ua.row_map = nullptr;
+    if (ragged) { CK(fqdev::h2d(c->d_blen.p, c->p_hlen.p, (size_t)nrow * 2)); ua.len = c->d_blen.p; c->stats.h2d_bytes += (size_t)nrow * 2; }
+    if (ne) {
+      CKM(c->p_exc.ensure(ne + 1) && c->d_exc.ensure(ne + 1));
+      size_t at = 0;
+      for (int t = 0; t < nrow; ++t)
+        for (size_t q = erange[t].first; q < erange[t].second; ++q) c->p_exc.p[at++] = ((uint64_t)t << 32) | (pb.exc[q] & 0xffffffffull);
+      CK(fqdev::h2d(c->d_exc.p, c->p_exc.p, ne * 8));
+      c->stats.h2d_bytes += ne * 8;
+      pa.exc = c->d_exc.p; pa.n_exc = (int64_t)ne; pa.crow_of = nullptr;
+    }
+    if (trim) {
+      CK(fqdev::h2d(c->d_pqual.p, c->p_pqual.p, (size_t)nrow * pb.qual_stride));
+      c->stats.h2d_bytes += (size_t)nrow * pb.qual_stride;
+      ta.qual = c->d_pqual.p; ta.row_map = nullptr;
+    }
+  }
+  fqdev::time_begin(FQ_K_PREP);
+  if (nrow) {
+    CK(fqdev::launch_unpack(ua));
+    if (pa.n_exc) CK(fqdev::launch_patch(pa));
+    if (trim) CK(fqdev::launch_trim(ta));
+  }
+  fqdev::time_end(FQ_K_PREP);
+  // lengths of the survivors' reads come back (full from the host's own arrays, trimmed from the device)
+  vector<int32_t> lt((size_t)nrow);
+  if (nrow && trim) { CK(fqdev::d2h(lt.data(), c->d_len_trim.p, (size_t)nrow * 4)); CK(fqdev::sync()); c->stats.d2h_bytes += (size_t)nrow * 4; }
+  vector<int> surv_max(n_sub, 0);
+  for (int t = 0; t < nrow; ++t) {
+    const size_t r = (size_t)(t & 1) * (size_t)n + (size_t)c->h_pair_list[t >> 1];
+    const int full = ragged ? (int)pb.len[r] : pb.uniform_len;
+    const int ltr = trim ? lt[t] : full;
+    c->h_surv[t].len_trim = ltr;
+    const int sb = c->h_pair_list[t >> 1] / B;
+    surv_max[sb] = std::max(surv_max[sb], ltr);
+  }
+  // infer_isize's max_len is the longest trimmed read of the whole reference batch, filtered reads included (bwape.c:60-61).
+  // Without trimming that is the longest read (known above).  With trimming it is the survivors' maximum whenever some survivor
+  // kept the batch's full length; otherwise -- and for the debug dump, which lists every read -- every read is trimmed.
+  bool need_all = trim && c->debug;
+  if (trim) for (int sb = 0; sb < n_sub; ++sb) if (surv_max[sb] < c->h_sub_max[sb]) need_all = true;
+  c->h_filtered.clear(); c->h_len_trim.clear();
+  if (need_all) {
+    CKM(c->d_pqual.ensure((size_t)n2 * pb.qual_stride + 64) && c->d_len_all.ensure(n2));
+    CK(fqdev::h2d(c->d_pqual.p, pb.qual, (size_t)n2 * pb.qual_stride));
+    c->stats.h2d_bytes += (size_t)n2 * pb.qual_stride;
+    CK(fqdev::dzero(c->d_sub_max.p, (size_t)n_sub * 4));
+    FqTrimAllArgs aa{};
+    aa.o = c->ko; aa.qual = c->d_pqual.p; aa.qual_stride = pb.qual_stride; aa.len = ragged ? c->d_hlen[slot].p : nullptr; aa.uniform_len = pb.uniform_len;
+    aa.n_reads = n2; aa.n_pairs = n; aa.batch_pairs = B; aa.len_trim = c->d_len_all.p; aa.sub_max = c->d_sub_max.p;
+    CK(fqdev::launch_trim_all(aa));
+    CK(fqdev::d2h(c->h_sub_max.data(), c->d_sub_max.p, (size_t)n_sub * 4));
+    if (c->debug) { c->h_len_trim.resize(n2); CK(fqdev::d2h(c->h_len_trim.data(), c->d_len_all.p, (size_t)n2 * 4)); }
+    CK(fqdev::sync());
+  } else if (trim) {
+    for (int sb = 0; sb < n_sub; ++sb) c->h_sub_max[sb] = surv_max[sb];
+  }
+  if (c->debug) {
+    c->h_filtered.resize(n2);
+    CK(fqdev::d2h(c->h_filtered.data(), c->d_filtered.p, n2));
+    CK(fqdev::sync());
+    if (c->h_len_trim.empty()) { c->h_len_trim.resize(n2); for (int r = 0; r < n2; ++r) c->h_len_trim[r] = ragged ? (int)pb.len[r] : pb.uniform_len; }
+  }
+  stage0_sub_max(K);
+  K.dseq = c->d_seq.p; K.dstride = cstride; K.dlen_trim = c->d_len_trim.p; K.dread_list = c->d_read_list.p;
+  return FQ_OK;
+}
+
+// ---- stage A: widths + gap search, tiered by stack-pool size (GPU) ----------------------------------
+// S.aln: concatenated hit lists; per search index s: [aln_off[s], aln_off[s]+aln_n[s])
+int stageA_search(Call &K) {
+  fq_ctx *c = K.c;
+  const fq_index *ix = c->ix;
+  const fq_opts_t &o = c->o;
+  const int n_search = K.n_search, max_len_all = K.max_len_all;
+  vector<FqAln> &h_aln = c->st.aln;
+  K.aln_off.assign((size_t)n_search + 1, 0);
+  K.aln_n.assign(n_search, 0);
+  const int Lpad = (max_len_all + 1 + 7) & ~7;                  // exact widths per strand; rows are written 8 positions at a time
+  const int Ppad = (max_len_all + 1 + FQ_POS_PAD + 7) & ~7;     // position records per strand (16-byte aligned rows)
+  // tier 0: one read per lane, bounded stack and pop count; what it gives up on is searched again by one wavefront per read
+  // (tier 1 with push-time pruning, tier 2 exactly as the reference: no pruning, n_entries exact).  The wavefront kernel never
+  // reuses pool slots, so its pools hold every push of a search, not just the live entries.
+  const uint32_t exact_pool = (uint32_t)std::min<uint64_t>(4ull * (uint64_t)o.max_entries + 4096ull, 0x7fffffffull);
+  const FqGapTier tiers[3] = {{c->kn.gap_pool, 32u, 0, 0, c->kn.gap_long_pops, c->kn.gap_long_always}, {262144u, 512u, 0, 1, 0u, 0}, {exact_pool, 8192u, 1, 1, 0u, 0}};
+  // scores that can occur for the longest read of this call (children may exceed max_diff by one difference)
+  const int nb_need = (c->maxdiff_lut[max_len_all] + 1) * o.s_mm + o.max_gapo * o.s_gapo + o.max_gape * o.s_gape + 1;
+  const size_t chunk_reads[3] = {(size_t)8 << 20, (size_t)1 << 20, 4096};   // pools are per lane / per wavefront; only per-read outputs scale with the chunk
+  vector<int32_t> work(n_search), next_work;
+  for (int s = 0; s < n_search; ++s) work[s] = s;
+  vector<int64_t> where(n_search, -1);   // offset of s's list in h_aln (filled as results arrive)
+  for (int tier = 0; tier < 3 && !work.empty(); ++tier) {
+    FqGapTier T = tiers[tier];
+    // Handing long searches to the wavefront-per-read kernel pays when the launch is latency-bound (few reads: its duration is
+    // its longest search); a launch that fills the device several times over hides its long searches behind the others.
+    if (tier == 0 && !T.long_always && work.size() > 524288) T.long_pops = 0;   // (two reads per resident lane)
+    next_work.clear();
+    for (size_t c0 = 0; c0 < work.size(); c0 += chunk_reads[tier]) {
+      const int nw = (int)std::min(chunk_reads[tier], work.size() - c0);
+      CKM(c->d_work.ensure(nw) && c->d_wfull.ensure((size_t)nw * 2 * Lpad) && c->d_prec.ensure((size_t)nw * 2 * Ppad) && c->d_winfo.ensure(nw) && c->d_bid_end.ensure((size_t)nw * 2) && c->d_order.ensure(nw) && c->d_order_cnt.ensure(2 * FQ_ORDER_KEYS) &&
+          c->d_aln.ensure((size_t)nw * T.aln_cap) && c->d_naln.ensure(nw) && c->d_status.ensure(nw) && c->d_off.ensure(nw + 1));
+      CKM(c->p_i32.ensure(nw));
+      memcpy(c->p_i32.p, work.data() + c0, (size_t)nw * 4);
+      CK(fqdev::h2d(c->d_work.p, c->p_i32.p, (size_t)nw * 4));
+      c->stats.h2d_bytes += (size_t)nw * 4;
+      FqWidthArgs wa{};
+      wa.ix = ix->dev; wa.o = c->ko; wa.seq = K.dseq; wa.stride = K.dstride; wa.len_trim = K.dlen_trim; wa.read_list = K.dread_list;
+      wa.work = c->d_work.p; wa.n_work = nw; wa.wfull = c->d_wfull.p; wa.wstride = Lpad;
+      wa.prec = c->d_prec.p; wa.pstride = Ppad; wa.winfo = c->d_winfo.p; wa.maxdiff_lut = c->d_maxdiff.p; wa.bid_end = c->d_bid_end.p; wa.counters = c->d_counters.p;
+      fqdev::time_begin(FQ_K_WIDTH);
+      CK(fqdev::launch_width(wa));
+      CK(fqdev::launch_order(c->d_bid_end.p, nw, c->d_order.p, c->d_order_cnt.p));   // long searches first
+      fqdev::time_end(FQ_K_WIDTH);
+      FqGapArgs ga{};
+      ga.ix = ix->dev; ga.o = c->ko; ga.o.n_buckets = nb_need; ga.n_work = nw; ga.winfo = c->d_winfo.p; ga.order = c->kn.gap_no_order ? nullptr : c->d_order.p;
+      ga.wfull = c->d_wfull.p; ga.wstride = Lpad; ga.prec = c->d_prec.p; ga.pstride = Ppad;
+      ga.pool = c->d_pool.p; ga.heads = c->d_heads.p; ga.tier = T; ga.aln = c->d_aln.p; ga.n_aln = c->d_naln.p; ga.status = c->d_status.p;
+      ga.counters = c->d_counters.p; ga.queue = c->d_queue.p;
+      // stack pools are the one large per-launch allocation (lanes x pool_cap x 16 B): when the device cannot hold them for
+      // as many wavefronts as it could run, run fewer (the persistent lanes simply take more reads each)
+      for (;;) {
+        const size_t slots = (size_t)fqdev::gap_lane_slots(ga);
+        if (c->d_heads.ensure(slots * FQ_MAX_BUCKETS) && c->d_pool.ensure(slots * T.pool_cap)) break;
+        const int waves = (int)(T.coop ? slots : slots / 64);
+        if (waves <= 1) { c->err = "out of device memory for the search pools"; return FQ_ENOMEM; }
+        ga.max_waves = waves / 2;
+      }
+      ga.pool = c->d_pool.p; ga.heads = c->d_heads.p;
+      fqdev::time_begin(FQ_K_GAP);
+      CK(fqdev::launch_gap(ga));
+      fqdev::time_end(FQ_K_GAP);
+      CK(fqdev::launch_scan(c->d_naln.p, c->d_off.p, (uint32_t)nw));
+      CKM(c->p_u32a.ensure((size_t)nw + 2) && c->p_u32b.ensure((size_t)nw + 2));
+      uint32_t *h_status = c->p_u32a.p, *h_naln = c->p_u32b.p;
+      uint64_t total = 0;
+      CK(fqdev::d2h(h_status, c->d_status.p, (size_t)nw * 4));
+      CK(fqdev::d2h(h_naln, c->d_naln.p, (size_t)nw * 4));
+      CK(fqdev::d2h(&total, c->d_off.p + nw, 8));
       CK(fqdev::sync());
-      c->stats.sa_rows += rows;
+      CKM(c->d_packed.ensure(total + 1) && c->p_aln.ensure(total + 1));
+      CK(fqdev::launch_pack_aln(c->d_aln.p, c->d_naln.p, c->d_off.p, T.aln_cap, (uint32_t)nw, c->d_packed.p));
+      FqAln *h_packed = c->p_aln.p;
+      CK(fqdev::d2h(h_packed, c->d_packed.p, total * sizeof(FqAln)));
+      CK(fqdev::sync());
+      c->stats.d2h_bytes += (size_t)nw * 8 + total * sizeof(FqAln);
+      uint64_t at = 0;
+      if (next_work.empty() && c0 == 0 && (size_t)nw == work.size() && h_aln.empty()) h_aln.reserve(total);
+      for (int w = 0; w < nw; ++w) {
+        const int s = work[c0 + w];
+        if (h_status[w]) { next_work.push_back(s); ++c->stats.tier_retries; continue; }
+        where[s] = (int64_t)h_aln.size();
+        K.aln_n[s] = h_naln[w];
+        h_aln.insert(h_aln.end(), h_packed + at, h_packed + at + h_naln[w]);
+        at += h_naln[w];
+      }
+    }
+    work.swap(next_work);
+  }
+  if (!work.empty()) { c->err = "gap search: exact tier exhausted its pool (internal limit)"; return FQ_ELIMIT; }
+  for (int s = 0; s < n_search; ++s) K.aln_off[s] = where[s] < 0 ? 0 : (uint64_t)where[s];
+  c->stats.reads_searched += n_search;
+  return FQ_OK;
+}
+
+// ---- records for survivors -----------------------------------------------------------------------------
+void stage_records(Call &K) {
+  fq_ctx *c = K.c;
+  const int n = K.n, n_surv = K.n_surv;
+  vector<FqRead> &R = c->st.reads;
+  R.resize((size_t)n_surv * 2);                      // reused storage: every record is reset below
+  K.s_of.assign((size_t)n_surv * 2, -1);
+  const bool packed = c->in_kind == 2;
+  // (kept on the calling thread: first touch decides which NUMA node the records live on, and the serial phases read them)
+  for (int sp = 0; sp < n_surv; ++sp)
+    for (int e = 0; e < 2; ++e) {
+      FqRead &p = R[2 * sp + e];
+      const int r = e * n + c->h_pair_list[sp];
+      const FqSurvInfo &si = c->h_surv[2 * sp + e];
+      p.reset();
+      p.r = r;
+      p.dr = packed ? 2 * sp + e : r;
+      p.full_len = packed ? (c->pb.uniform_len > 0 ? c->pb.uniform_len : (int)c->pb.len[r]) : c->hb.len[r];
+      p.len = p.clip_len = si.len_trim;
+      p.filtered = (uint8_t)si.filtered;
+      p.extra_flag = 1 | (e == 0 ? 64 : 128);   // SAM_FPD | SAM_FR1/FR2 (BwtMapper.cpp:749)
+      K.s_of[2 * sp + e] = si.sidx;
+    }
+}
+
+// ---- SA rows to resolve on the GPU: every row of every hit of reads that can need them ------------------
+// eligible(read) = n_occ <= max(n_multi,N_multi)+1  (XA listing, bwase.c:47-55)  or
+//                  both mates have hits and both n_occ <= max_occ (pair enumeration, BwtMapper.cpp:797-811)
+int stage_sa_rows(Call &K) {
+  fq_ctx *c = K.c;
+  const fq_index *ix = c->ix;
+  const fq_opts_t &o = c->o;
+  const int n_surv = K.n_surv;
+  vector<FqRead> &R = c->st.reads;
+  K.read_nocc.assign((size_t)n_surv * 2, 0);
+  K.enumerated.assign((size_t)n_surv * 2, 0);
+  K.aln_row_off.assign(c->st.aln.size() + 1, ~0ull);   // per hit in S.aln order -> offset into h_pos
+  const uint32_t multi_cap = (uint32_t)std::max(o.n_multi, o.N_multi) + 1;
+  parallel_chunks(R.size(), K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
+    for (size_t idx = lo; idx < hi; ++idx) {
+      int na; const FqAln *a = K.aln_of((int)idx, &na);
+      uint64_t t = 0;
+      for (int k = 0; k < na; ++k) t += (uint64_t)(a[k].l - a[k].k) + 1;
+      K.read_nocc[idx] = t;
+    }
+  });
+  vector<FqAln> q_aln; vector<uint32_t> q_len; vector<uint64_t> q_off;
+  uint64_t rows = 0;
+  for (int sp = 0; sp < n_surv; ++sp) {
+    int na0, na1;
+    K.aln_of(2 * sp, &na0); K.aln_of(2 * sp + 1, &na1);
+    const bool pair_ok = na0 > 0 && na1 > 0 && K.read_nocc[2 * sp] <= o.max_occ && K.read_nocc[2 * sp + 1] <= o.max_occ;
+    for (int e = 0; e < 2; ++e) {
+      const int idx = 2 * sp + e;
+      int na; const FqAln *a = K.aln_of(idx, &na);
+      if (na == 0) continue;
+      if (!(pair_ok || K.read_nocc[idx] <= multi_cap)) continue;
+      K.enumerated[idx] = 1;
+      const uint64_t base = K.aln_off[K.s_of[idx]];
+      for (int k = 0; k < na; ++k) {
+        K.aln_row_off[base + k] = rows;
+        q_aln.push_back(a[k]); q_len.push_back((uint32_t)R[idx].len); q_off.push_back(rows);
+        rows += (uint64_t)(a[k].l - a[k].k) + 1;
+      }
     }
   }
+  q_off.push_back(rows);
+  CKM(c->p_pos.ensure(rows + 1));
+  K.h_pos = c->p_pos.p;
+  if (rows) {
+    CKM(c->d_qaln.ensure(q_aln.size()) && c->d_qlen.ensure(q_len.size()) && c->d_qoff.ensure(q_off.size()) && c->d_pos.ensure(rows));
+    CK(fqdev::h2d(c->d_qaln.p, q_aln.data(), q_aln.size() * sizeof(FqAln)));
+    CK(fqdev::h2d(c->d_qlen.p, q_len.data(), q_len.size() * 4));
+    CK(fqdev::h2d(c->d_qoff.p, q_off.data(), q_off.size() * 8));
+    c->stats.h2d_bytes += q_aln.size() * (sizeof(FqAln) + 12);
+    FqSaArgs sa{};
+    sa.ix = ix->dev; sa.aln = c->d_qaln.p; sa.aln_len = c->d_qlen.p; sa.row_off = c->d_qoff.p; sa.n_aln = (uint32_t)q_aln.size();
+    sa.n_rows = rows; sa.pos = c->d_pos.p; sa.counters = c->d_counters.p;
+    fqdev::time_begin(FQ_K_SA);
+    CK(fqdev::launch_sa(sa));
+    fqdev::time_end(FQ_K_SA);
+    CK(fqdev::d2h(c->p_pos.p, c->d_pos.p, rows * 4));
+    CK(fqdev::sync());
+    c->stats.d2h_bytes += rows * 4;
+    c->stats.sa_rows += rows;
+  }
+  return FQ_OK;
+}
 
-  TRACE("SA enumerate+kernel");
-  const double t_host0 = now_ms();
-  // ---- stage B1 (host, serial, read order): main hit choice consumes the drand48 stream (Q2) ------------
+// ---- stage B1 (host, serial, read order): main hit choice consumes the drand48 stream (Q2) ------------
+int stageB1_main_hit(Call &K) {
+  fq_ctx *c = K.c;
+  const fq_index *ix = c->ix;
+  vector<FqRead> &R = c->st.reads;
   vector<uint32_t> dq_row, dq_info; vector<int> dq_idx;
-  for (int sp = 0; sp < n_surv; ++sp)
+  for (int sp = 0; sp < K.n_surv; ++sp)
     for (int e = 0; e < 2; ++e) {
       const int idx = 2 * sp + e;
       FqRead &p = R[idx];
       if (p.filtered) continue;
-      int na; const FqAln *a = aln_of(idx, &na);
+      int na; const FqAln *a = K.aln_of(idx, &na);
       choose_hit(c, na, a, p, true, 0);
       if (p.type == FQ_TYPE_UNIQUE || p.type == FQ_TYPE_REPEAT) {
-        if (enumerated[idx]) p.pos = h_pos[aln_row_off[aln_off[s_of[idx]] + p.main_aln] + (p.sa - a[p.main_aln].k)];
+        if (K.enumerated[idx]) p.pos = K.h_pos[K.aln_row_off[K.aln_off[K.s_of[idx]] + p.main_aln] + (p.sa - a[p.main_aln].k)];
         else { dq_row.push_back(p.sa); dq_info.push_back((uint32_t)p.strand << 31 | (uint32_t)p.len); dq_idx.push_back(idx); }
         p.seQ = p.mapQ = approx_mapq(c, p, c->maxdiff_lut[p.len]);
       }
@@ -706,107 +992,118 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
     for (size_t i = 0; i < nq; ++i) R[dq_idx[i]].pos = tmp[i];
     c->stats.sa_rows += nq;
   }
-  TRACE("B1 main hit (serial)");
-  // ---- stage B2: insert size per reference batch, with the last_ii fallback chain (Q3) -----------------------
-  vector<fq_isize_t> iis(n_sub);
-  {
-    // the inference of a reference batch depends on nothing but its records; only the fallback chain is sequential
-    vector<fq_isize_t> raw(n_sub);
-    {
-      std::vector<std::thread> th;
-      const int T = (size_t)n_surv >= par_min() ? std::min(host_threads, n_sub) : 1;
-      auto work = [&](int t) { for (int sb = t; sb < n_sub; sb += T) infer_isize(R, sub_lo[sb], sub_lo[sb + 1], sub_max_len[sb], &raw[sb], o.ap_prior, (int64_t)ix->dev.fm[0].seq_len); };
-      for (int t = 1; t < T; ++t) th.emplace_back(work, t);
-      work(0);
-      for (auto &x : th) x.join();
-    }
-    fq_isize_t prev = c->last_ii;
-    for (int sb = 0; sb < n_sub; ++sb) {
-      fq_isize_t ii = raw[sb];
-      if (ii.avg < 0.0 && prev.avg > 0.0) ii = prev;
-      if (o.force_isize) { ii.low = ii.high = 0; ii.avg = ii.std = -1.0; }
-      iis[sb] = ii;
-      prev = ii;
-    }
-  }
-  const double t_serial1 = now_ms();
+  return FQ_OK;
+}
 
-  TRACE("B2 isize");
-  // ---- stage B3: pairing + XA lists (per pair) -------------------------------------------------------------
+// ---- stage B2: insert size per reference batch, with the last_ii fallback chain (Q3) -----------------------
+void stageB2_isize(Call &K) {
+  fq_ctx *c = K.c;
+  const fq_opts_t &o = c->o;
+  const int n_sub = K.n_sub;
+  vector<FqRead> &R = c->st.reads;
+  K.iis.assign(n_sub, fq_isize_t{});
+  // the inference of a reference batch depends on nothing but its records; only the fallback chain is sequential
+  vector<fq_isize_t> raw(n_sub);
   {
-    auto both_mapped = [&](int sp) {
-      const FqRead &a = R[2 * sp], &b = R[2 * sp + 1];
-      return (a.type == FQ_TYPE_UNIQUE || a.type == FQ_TYPE_REPEAT) && (b.type == FQ_TYPE_UNIQUE || b.type == FQ_TYPE_REPEAT) &&
-             read_nocc[2 * sp] <= o.max_occ && read_nocc[2 * sp + 1] <= o.max_occ;
-    };
-    // MIN_HASH_WIDTH: the positions of an interval >= 1000 wide are those of its first requester, in pair order (Q6): fill the
-    // cache serially, in that order, before the pairs are spread over threads (which then only look it up)
-    for (int sp = 0; sp < n_surv; ++sp) {
-      if (!both_mapped(sp)) continue;
-      for (int j = 0; j < 2; ++j) {
-        int na; const FqAln *a = aln_of(2 * sp + j, &na);
-        const uint64_t base = aln_off[s_of[2 * sp + j]];
-        for (int k = 0; k < na; ++k) {
-          const uint32_t wdt = a[k].l - a[k].k + 1;
-          if (wdt < 1000) continue;
-          auto ins = c->kl_cache.emplace((uint64_t)a[k].k << 32 | a[k].l, vector<uint32_t>());
-          if (ins.second) { const uint32_t *ps = h_pos.data() + aln_row_off[base + k]; ins.first->second.assign(ps, ps + wdt); }
-        }
+    std::vector<std::thread> th;
+    const int T = (size_t)K.n_surv >= K.par_min ? std::min(K.host_threads, n_sub) : 1;
+    auto work = [&](int t) { for (int sb = t; sb < n_sub; sb += T) infer_isize(R, K.sub_lo[sb], K.sub_lo[sb + 1], K.sub_max_len[sb], &raw[sb], o.ap_prior, (int64_t)c->ix->dev.fm[0].seq_len); };
+    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+    work(0);
+    for (auto &x : th) x.join();
+  }
+  fq_isize_t prev = c->last_ii;
+  for (int sb = 0; sb < n_sub; ++sb) {
+    fq_isize_t ii = raw[sb];
+    if (ii.avg < 0.0 && prev.avg > 0.0) ii = prev;
+    if (o.force_isize) { ii.low = ii.high = 0; ii.avg = ii.std = -1.0; }
+    K.iis[sb] = ii;
+    prev = ii;
+  }
+}
+
+// ---- stage B3: pairing + XA lists (per pair) -------------------------------------------------------------
+void stageB3_pairing(Call &K) {
+  fq_ctx *c = K.c;
+  const fq_opts_t &o = c->o;
+  const int n_surv = K.n_surv;
+  vector<FqRead> &R = c->st.reads;
+  const uint32_t *h_pos = K.h_pos;
+  auto both_mapped = [&](int sp) {
+    const FqRead &a = R[2 * sp], &b = R[2 * sp + 1];
+    return (a.type == FQ_TYPE_UNIQUE || a.type == FQ_TYPE_REPEAT) && (b.type == FQ_TYPE_UNIQUE || b.type == FQ_TYPE_REPEAT) &&
+           K.read_nocc[2 * sp] <= o.max_occ && K.read_nocc[2 * sp + 1] <= o.max_occ;
+  };
+  // MIN_HASH_WIDTH: the positions of an interval >= 1000 wide are those of its first requester, in pair order (Q6): fill the
+  // cache serially, in that order, before the pairs are spread over threads (which then only look it up)
+  for (int sp = 0; sp < n_surv; ++sp) {
+    if (!both_mapped(sp)) continue;
+    for (int j = 0; j < 2; ++j) {
+      int na; const FqAln *a = K.aln_of(2 * sp + j, &na);
+      const uint64_t base = K.aln_off[K.s_of[2 * sp + j]];
+      for (int k = 0; k < na; ++k) {
+        const uint32_t wdt = a[k].l - a[k].k + 1;
+        if (wdt < 1000) continue;
+        auto ins = c->kl_cache.emplace((uint64_t)a[k].k << 32 | a[k].l, vector<uint32_t>());
+        if (ins.second) { const uint32_t *ps = h_pos + K.aln_row_off[base + k]; ins.first->second.assign(ps, ps + wdt); }
       }
     }
-    for (int sb = 0; sb < n_sub; ++sb) {
-    const fq_isize_t ii = iis[sb];
-    parallel_chunks((size_t)(sub_lo[sb + 1] - sub_lo[sb]), host_threads, [&](size_t lo, size_t hi, int) {
-    vector<uint64_t> arr;
-    vector<int> pen_lut((size_t)ii.high_bayesian + 2, INT32_MIN);   // memo of the insert-size penalty (same libm expression per insert size)
-    for (int sp = sub_lo[sb] + (int)lo; sp < sub_lo[sb] + (int)hi; ++sp) {
-      FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
-      const FqAln *aln[2]; int na[2];
-      aln[0] = aln_of(2 * sp, &na[0]); aln[1] = aln_of(2 * sp + 1, &na[1]);
-      const bool m0 = p[0]->type == FQ_TYPE_UNIQUE || p[0]->type == FQ_TYPE_REPEAT, m1 = p[1]->type == FQ_TYPE_UNIQUE || p[1]->type == FQ_TYPE_REPEAT;
-      if (m0 && m1) {
-        if (read_nocc[2 * sp] > o.max_occ || read_nocc[2 * sp + 1] > o.max_occ) continue;   // BwtMapper.cpp:797-811: such a pair gets no XA list either
-        arr.clear();
-        for (int j = 0; j < 2; ++j) {
-          const uint64_t base = aln_off[s_of[2 * sp + j]];
-          for (int k = 0; k < na[j]; ++k) {
-            const FqAln &q = aln[j][k];
-            const uint32_t wdt = q.l - q.k + 1;
-            const uint32_t *ps = h_pos.data() + aln_row_off[base + k];
-            uint32_t np = wdt;
-            if (wdt >= 1000) { const vector<uint32_t> &v = c->kl_cache.find((uint64_t)q.k << 32 | q.l)->second; ps = v.data(); np = (uint32_t)v.size(); }
-            for (uint32_t t = 0; t < np; ++t) arr.push_back((uint64_t)ps[t] << 32 | (uint64_t)(k << 1) | (uint64_t)j);
+  }
+  for (int sb = 0; sb < K.n_sub; ++sb) {
+    const fq_isize_t ii = K.iis[sb];
+    parallel_chunks((size_t)(K.sub_lo[sb + 1] - K.sub_lo[sb]), K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
+      vector<uint64_t> arr;
+      vector<int> pen_lut((size_t)ii.high_bayesian + 2, INT32_MIN);   // memo of the insert-size penalty (same libm expression per insert size)
+      for (int sp = K.sub_lo[sb] + (int)lo; sp < K.sub_lo[sb] + (int)hi; ++sp) {
+        FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
+        const FqAln *aln[2]; int na[2];
+        aln[0] = K.aln_of(2 * sp, &na[0]); aln[1] = K.aln_of(2 * sp + 1, &na[1]);
+        const bool m0 = p[0]->type == FQ_TYPE_UNIQUE || p[0]->type == FQ_TYPE_REPEAT, m1 = p[1]->type == FQ_TYPE_UNIQUE || p[1]->type == FQ_TYPE_REPEAT;
+        if (m0 && m1) {
+          if (K.read_nocc[2 * sp] > o.max_occ || K.read_nocc[2 * sp + 1] > o.max_occ) continue;   // BwtMapper.cpp:797-811: such a pair gets no XA list either
+          arr.clear();
+          for (int j = 0; j < 2; ++j) {
+            const uint64_t base = K.aln_off[K.s_of[2 * sp + j]];
+            for (int k = 0; k < na[j]; ++k) {
+              const FqAln &q = aln[j][k];
+              const uint32_t wdt = q.l - q.k + 1;
+              const uint32_t *ps = h_pos + K.aln_row_off[base + k];
+              uint32_t np = wdt;
+              if (wdt >= 1000) { const vector<uint32_t> &v = c->kl_cache.find((uint64_t)q.k << 32 | q.l)->second; ps = v.data(); np = (uint32_t)v.size(); }
+              for (uint32_t t = 0; t < np; ++t) arr.push_back((uint64_t)ps[t] << 32 | (uint64_t)(k << 1) | (uint64_t)j);
+            }
           }
+          pair_hits(c, pen_lut, p, aln, arr, &ii);
         }
-        pair_hits(c, pen_lut, p, aln, arr, &ii);
+        if (o.N_multi || o.n_multi)
+          for (int j = 0; j < 2; ++j) {
+            if (p[j]->type == FQ_TYPE_NO_MATCH) continue;
+            int nm;
+            if (!(p[j]->extra_flag & 2) && p[1 - j]->type != FQ_TYPE_NO_MATCH) nm = (int)(p[j]->c1 + p[j]->c2) - 1 > o.N_multi ? o.n_multi : o.N_multi;
+            else nm = o.n_multi;
+            choose_hit(c, na[j], aln[j], *p[j], false, nm);
+            const uint64_t base = K.aln_off[K.s_of[2 * sp + j]];
+            for (auto &m : p[j]->multi) m.pos = h_pos[K.aln_row_off[base + m.aln] + m.row_in_aln];
+          }
       }
-      if (o.N_multi || o.n_multi)
-        for (int j = 0; j < 2; ++j) {
-          if (p[j]->type == FQ_TYPE_NO_MATCH) continue;
-          int nm;
-          if (!(p[j]->extra_flag & 2) && p[1 - j]->type != FQ_TYPE_NO_MATCH) nm = (int)(p[j]->c1 + p[j]->c2) - 1 > o.N_multi ? o.n_multi : o.N_multi;
-          else nm = o.n_multi;
-          choose_hit(c, na[j], aln[j], *p[j], false, nm);
-          const uint64_t base = aln_off[s_of[2 * sp + j]];
-          for (auto &m : p[j]->multi) m.pos = h_pos[aln_row_off[base + m.aln] + m.row_in_aln];
-        }
-    }
     });
-    }
   }
+}
 
-  TRACE("B3 pairing+XA");
-  if (c->debug) S.stage_P = R;   // snapshot for the stage dump (tests)
-
-  // ---- stage C: mate rescue by Smith-Waterman (bwa_paired_sw, libbwa/bwape.c:463-625) ---------------------
-  if (o.is_sw) {
-    struct Cand { int sp, k; };
-    vector<Cand> cands; vector<FqSwTask> tasks;
-    int max_reg = 0, max_q = 0;
-    for (int sb = 0; sb < n_sub; ++sb) {
-    const fq_isize_t ii = iis[sb];
+// ---- stage C: mate rescue by Smith-Waterman (bwa_paired_sw, libbwa/bwape.c:463-625) ---------------------
+int stageC_mate_sw(Call &K) {
+  fq_ctx *c = K.c;
+  const fq_index *ix = c->ix;
+  const fq_opts_t &o = c->o;
+  vector<FqRead> &R = c->st.reads;
+  if (!o.is_sw) return FQ_OK;
+  struct Cand { int sp, k; };
+  vector<Cand> cands; vector<FqSwTask> tasks;
+  int max_reg = 0, max_q = 0;
+  for (int sb = 0; sb < K.n_sub; ++sb) {
+    const fq_isize_t ii = K.iis[sb];
     if (ii.avg < 0.0) continue;   // bwa_paired_sw returns before touching anything (bwape.c:477)
-    for (int sp = sub_lo[sb]; sp < sub_lo[sb + 1]; ++sp) {
+    for (int sp = K.sub_lo[sb]; sp < K.sub_lo[sb + 1]; ++sp) {
       FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
       for (int j = 0; j < 2; ++j) if (p[j]->filtered) { p[j]->filtered = 0; p[j]->revived = true; }   // expand_seq: revived because its mate passed (:485-499)
       if (!((p[0]->mapQ >= 17 || p[1]->mapQ >= 17) && (p[0]->extra_flag & 2) == 0)) continue;
@@ -830,209 +1127,212 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
           if (end > (int64_t)pref->pos) end = pref->pos;
           T.use_rc = 0;
         }
-        T.read = pm->r; T.beg = beg; T.reglen = (int)(end - beg);
+        T.read = pm->dr; T.beg = beg; T.reglen = (int)(end - beg);
         cands.push_back({sp, k});
         tasks.push_back(T);
         max_reg = std::max(max_reg, T.reglen); max_q = std::max(max_q, pm->len);
       }
     }
-    }
-    vector<FqSwOut> souts(tasks.size());
-    vector<uint16_t> scig;
-    const int cig_cap = 64;
-    if (!tasks.empty()) {
-      // Windows are a few hundred bases when the insert-size estimate is sane; a poor estimate (chimeric libraries) can ask for tens
-      // of thousands.  Tasks whose window fits the wavefront kernel's LDS go there; the rest run one per lane out of global scratch.
-      const int kWaveMax = getenv("FQ_SW_WAVE_MAX") ? atoi(getenv("FQ_SW_WAVE_MAX")) : 4096;   // (test hook: send ordinary windows down the serial path)
-      scig.resize(tasks.size() * cig_cap);
-      for (int big = 0; big < 2; ++big) {
-        vector<int> sel;
-        int RL = 1;
-        const int QL = std::max(max_q, 1);
-        for (size_t t = 0; t < tasks.size(); ++t)
-          if ((tasks[t].reglen > kWaveMax) == (big != 0)) { sel.push_back((int)t); RL = std::max(RL, tasks[t].reglen); }
-        if (sel.empty()) continue;
-        vector<FqSwTask> sub(sel.size());
-        for (size_t q = 0; q < sel.size(); ++q) sub[q] = tasks[sel[q]];
-        vector<FqSwOut> sub_out(sel.size());
-        vector<uint16_t> sub_cig(sel.size() * cig_cap);
-        const size_t sstride = fq_dp_scratch_bytes(RL, QL);
-        const size_t chunk = std::max<size_t>(64, ((size_t)6 << 30) / sstride);
-        for (size_t t0 = 0; t0 < sub.size(); t0 += chunk) {
-          const int nt = (int)std::min(chunk, sub.size() - t0);
-          CKM(c->d_swtask.ensure(nt) && c->d_swout.ensure(nt) && c->d_cig.ensure((size_t)nt * cig_cap) && c->d_scratch.ensure((size_t)nt * sstride));
-          CK(fqdev::h2d(c->d_swtask.p, sub.data() + t0, (size_t)nt * sizeof(FqSwTask)));
-          FqSwArgs a{};
-          a.ix = ix->dev; a.seq = c->d_seq.p; a.stride = stride; a.len_trim = c->d_len_trim.p; a.task = c->d_swtask.p; a.n_task = nt;
-          a.out = c->d_swout.p; a.cigar = c->d_cig.p; a.cig_cap = cig_cap; a.scratch = c->d_scratch.p; a.scratch_stride = sstride; a.RL = RL; a.QL = QL;
-          fqdev::time_begin(FQ_K_SW);
-          CK(big ? fqdev::launch_sw_serial(a) : fqdev::launch_sw(a));
-          fqdev::time_end(FQ_K_SW);
-          CK(fqdev::d2h(sub_out.data() + t0, c->d_swout.p, (size_t)nt * sizeof(FqSwOut)));
-          CK(fqdev::d2h(sub_cig.data() + t0 * cig_cap, c->d_cig.p, (size_t)nt * cig_cap * 2));
-          CK(fqdev::sync());
-        }
-        for (size_t q = 0; q < sel.size(); ++q) {
-          souts[sel[q]] = sub_out[q];
-          memcpy(&scig[(size_t)sel[q] * cig_cap], &sub_cig[q * cig_cap], (size_t)cig_cap * 2);
-        }
-      }
-      c->stats.sw_tasks += tasks.size();
-    }
-    // decisions (:556-617), per pair, using the kernel outputs
-    const double l_pac_d = (double)ix->l_pac; (void)l_pac_d;
-    size_t ti = 0;
-    while (ti < cands.size()) {
-      const int sp = cands[ti].sp;
-      const fq_isize_t &ii = iis[c->h_pair_list[sp] / B];
-      FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
-      const uint16_t *cigar[2] = {nullptr, nullptr};
-      int n_cigar[2] = {0, 0}, mq_adjust[2] = {255, 255}, mapQ = 0;
-      int64_t beg[2] = {0, 0};
-      uint32_t cnt[2] = {0, 0};
-      for (; ti < cands.size() && cands[ti].sp == sp; ++ti) {
-        const int k = cands[ti].k;
-        const FqSwOut &O = souts[ti];
-        beg[k] = O.beg; cnt[k] = O.cnt;
-        if (O.n_cigar > 0) { cigar[k] = scig.data() + ti * cig_cap; n_cigar[k] = O.n_cigar; }
-        else beg[k] = tasks[ti].beg;
-        if (cigar[k] && p[k]->type != FQ_TYPE_NO_MATCH) {
-          int clip = 0;
-          if ((cigar[k][0] >> 14) == FQ_OP_S) clip += cigar[k][0] & 0x3fff;
-          if ((cigar[k][n_cigar[k] - 1] >> 14) == FQ_OP_S) clip += cigar[k][n_cigar[k] - 1] & 0x3fff;
-          int s_old = (int)((p[k]->n_mm * 9 + p[k]->n_gapo * 13 + p[k]->n_gape * 2) / 3. * 8. + .499);
-          int s_new = (int)(((cnt[k] >> 16) * 9 + (cnt[k] >> 8 & 0xff) * 13 + (cnt[k] & 0xff) * 2 + (uint32_t)clip * 3) / 3. * 8. + .499);
-          s_old = (int)(s_old + -4.343 * log(ii.ap_prior / ix->l_pac));
-          s_new += (int)(-4.343 * log(.5 * erfc(M_SQRT1_2 * 1.5) + .499));
-          if (s_old < s_new) { mq_adjust[k] = s_new - s_old; cigar[k] = nullptr; n_cigar[k] = 0; }
-          else mq_adjust[k] = s_old - s_new;
-        }
-      }
-      int k = -1;
-      if (cigar[0] && cigar[1]) { k = p[0]->mapQ < p[1]->mapQ ? 0 : 1; mapQ = abs(p[1]->mapQ - p[0]->mapQ); }
-      else if (cigar[0]) { k = 0; mapQ = p[1]->mapQ; }
-      else if (cigar[1]) { k = 1; mapQ = p[0]->mapQ; }
-      if (k >= 0 && (int64_t)p[k]->pos != beg[k]) {
-        int tmp = p[1 - k]->mapQ - p[k]->mapQ / 2 - 8;
-        if (tmp <= 0) tmp = 1;
-        if (mapQ > tmp) mapQ = tmp;
-        p[k]->mapQ = p[1 - k]->mapQ = mapQ;
-        p[k]->seQ = p[1 - k]->seQ = p[1 - k]->seQ < mapQ ? p[1 - k]->seQ : mapQ;
-        if (p[k]->mapQ > mq_adjust[k]) p[k]->mapQ = mq_adjust[k];
-        if (p[k]->seQ > mq_adjust[k]) p[k]->seQ = mq_adjust[k];
-        p[k]->cigar.assign(cigar[k], cigar[k] + n_cigar[k]);
-        p[k]->type = FQ_TYPE_MATESW; p[k]->pos = (uint32_t)beg[k]; p[k]->seQ = p[1 - k]->seQ;   // __set_fixed (:525-533)
-        p[k]->strand = 1 - p[1 - k]->strand;
-        p[k]->n_mm = (int)(cnt[k] >> 16) & 0xff; p[k]->n_gapo = (int)(cnt[k] >> 8 & 0xff); p[k]->n_gape = (int)(cnt[k] & 0xff);
-        p[k]->extra_flag |= 2; p[1 - k]->extra_flag |= 2;
-      }
-    }
   }
-  TRACE("C mate SW");
-  if (c->debug) S.stage_S = R;
-
-  // ---- stage D: gapped refinement (bwa_refine_gapped, libbwa/bwase.c:339-418) ------------------------------
-  {
-    struct Tgt { int idx, multi; };
-    vector<Tgt> tgt; vector<FqRefTask> tasks;
-    int max_ref = 1, max_q = 1;
-    for (size_t idx = 0; idx < R.size(); ++idx) {
-      FqRead &s = R[idx];
-      if (s.filtered) continue;
-      for (size_t j = 0; j < s.multi.size(); ++j) {
-        FqMulti &q = s.multi[j];
-        if (q.gap == 0) continue;
-        tasks.push_back({s.r, q.strand, q.pos, (q.strand ? 1 : -1) * q.gap});
-        tgt.push_back({(int)idx, (int)j});
-        max_ref = std::max(max_ref, s.len + q.gap); max_q = std::max(max_q, s.len);
-      }
-      if (s.type == FQ_TYPE_NO_MATCH || s.type == FQ_TYPE_MATESW || s.n_gapo == 0) continue;
-      tasks.push_back({s.r, s.strand, s.pos, (s.strand ? 1 : -1) * (s.n_gapo + s.n_gape)});
-      tgt.push_back({(int)idx, -1});
-      max_ref = std::max(max_ref, s.len + s.n_gapo + s.n_gape); max_q = std::max(max_q, s.len);
-    }
-    if (!tasks.empty()) {
-      const int cig_cap = 64;
-      const size_t sstride = fq_dp_scratch_bytes(max_ref, max_q);
+  vector<FqSwOut> souts(tasks.size());
+  vector<uint16_t> scig;
+  const int cig_cap = 64;
+  if (!tasks.empty()) {
+    // Windows are a few hundred bases when the insert-size estimate is sane; a poor estimate (chimeric libraries) can ask for tens
+    // of thousands.  Tasks whose window fits the wavefront kernel's LDS go there; the rest run one per lane out of global scratch.
+    const int kWaveMax = c->kn.sw_wave_max;
+    scig.resize(tasks.size() * cig_cap);
+    for (int big = 0; big < 2; ++big) {
+      vector<int> sel;
+      int RL = 1;
+      const int QL = std::max(max_q, 1);
+      for (size_t t = 0; t < tasks.size(); ++t)
+        if ((tasks[t].reglen > kWaveMax) == (big != 0)) { sel.push_back((int)t); RL = std::max(RL, tasks[t].reglen); }
+      if (sel.empty()) continue;
+      vector<FqSwTask> sub(sel.size());
+      for (size_t q = 0; q < sel.size(); ++q) sub[q] = tasks[sel[q]];
+      vector<FqSwOut> sub_out(sel.size());
+      vector<uint16_t> sub_cig(sel.size() * cig_cap);
+      const size_t sstride = fq_dp_scratch_bytes(RL, QL);
       const size_t chunk = std::max<size_t>(64, ((size_t)6 << 30) / sstride);
-      vector<FqRefOut> outs(tasks.size());
-      vector<uint16_t> cg(tasks.size() * cig_cap);
-      for (size_t t0 = 0; t0 < tasks.size(); t0 += chunk) {
-        const int nt = (int)std::min(chunk, tasks.size() - t0);
-        CKM(c->d_reftask.ensure(nt) && c->d_refout.ensure(nt) && c->d_cig.ensure((size_t)nt * cig_cap) && c->d_scratch.ensure((size_t)nt * sstride));
-        CK(fqdev::h2d(c->d_reftask.p, tasks.data() + t0, (size_t)nt * sizeof(FqRefTask)));
-        FqRefineArgs a{};
-        a.ix = ix->dev; a.seq = c->d_seq.p; a.stride = stride; a.len_trim = c->d_len_trim.p; a.task = c->d_reftask.p; a.n_task = nt;
-        a.out = c->d_refout.p; a.cigar = c->d_cig.p; a.cig_cap = cig_cap; a.scratch = c->d_scratch.p; a.scratch_stride = sstride; a.RL = max_ref; a.QL = max_q;
-        fqdev::time_begin(FQ_K_REFINE);
-        CK(fqdev::launch_refine(a));
-        fqdev::time_end(FQ_K_REFINE);
-        CK(fqdev::d2h(outs.data() + t0, c->d_refout.p, (size_t)nt * sizeof(FqRefOut)));
-        CK(fqdev::d2h(cg.data() + t0 * cig_cap, c->d_cig.p, (size_t)nt * cig_cap * 2));
+      for (size_t t0 = 0; t0 < sub.size(); t0 += chunk) {
+        const int nt = (int)std::min(chunk, sub.size() - t0);
+        CKM(c->d_swtask.ensure(nt) && c->d_swout.ensure(nt) && c->d_cig.ensure((size_t)nt * cig_cap) && c->d_scratch.ensure((size_t)nt * sstride));
+        CK(fqdev::h2d(c->d_swtask.p, sub.data() + t0, (size_t)nt * sizeof(FqSwTask)));
+        FqSwArgs a{};
+        a.ix = ix->dev; a.seq = K.dseq; a.stride = K.dstride; a.len_trim = K.dlen_trim; a.task = c->d_swtask.p; a.n_task = nt;
+        a.out = c->d_swout.p; a.cigar = c->d_cig.p; a.cig_cap = cig_cap; a.scratch = c->d_scratch.p; a.scratch_stride = sstride; a.RL = RL; a.QL = QL;
+        fqdev::time_begin(FQ_K_SW);
+        CK(big ? fqdev::launch_sw_serial(a) : fqdev::launch_sw(a));
+        fqdev::time_end(FQ_K_SW);
+        CK(fqdev::d2h(sub_out.data() + t0, c->d_swout.p, (size_t)nt * sizeof(FqSwOut)));
+        CK(fqdev::d2h(sub_cig.data() + t0 * cig_cap, c->d_cig.p, (size_t)nt * cig_cap * 2));
         CK(fqdev::sync());
       }
-      for (size_t t = 0; t < tasks.size(); ++t)
-        if (outs[t].n_cigar <= 0) { c->err = "refine: CIGAR longer than the device slot"; return FQ_ELIMIT; }
-      parallel_chunks(tasks.size(), host_threads, [&](size_t lo, size_t hi, int) {   // a task owns its record's field
-        for (size_t t = lo; t < hi; ++t) {
-          FqRead &s = R[tgt[t].idx];
-          const uint16_t *g = cg.data() + t * cig_cap;
-          if (tgt[t].multi >= 0) { FqMulti &q = s.multi[tgt[t].multi]; q.pos = outs[t].pos; q.cigar.assign(g, g + outs[t].n_cigar); }
-          else { s.pos = outs[t].pos; s.cigar.assign(g, g + outs[t].n_cigar); }
-        }
-      });
-      c->stats.refine_tasks += tasks.size();
+      for (size_t q = 0; q < sel.size(); ++q) {
+        souts[sel[q]] = sub_out[q];
+        memcpy(&scig[(size_t)sel[q] * cig_cap], &sub_cig[q * cig_cap], (size_t)cig_cap * 2);
+      }
     }
-    // MD / NM for every mapped read (bwa_cal_md1)
-    vector<FqMdTask> mt; vector<int> mi; vector<uint16_t> arena;
-    for (size_t idx = 0; idx < R.size(); ++idx) {
-      FqRead &s = R[idx];
-      if (s.type == FQ_TYPE_NO_MATCH) continue;
-      FqMdTask T{};
-      T.read = s.r; T.strand = s.strand; T.pos = s.pos; T.n_cigar = (int)s.cigar.size(); T.cigar_off = (uint32_t)arena.size(); T.len = s.len;
-      arena.insert(arena.end(), s.cigar.begin(), s.cigar.end());
-      mt.push_back(T); mi.push_back((int)idx);
+    c->stats.sw_tasks += tasks.size();
+  }
+  // decisions (:556-617), per pair, using the kernel outputs
+  size_t ti = 0;
+  while (ti < cands.size()) {
+    const int sp = cands[ti].sp;
+    const fq_isize_t &ii = K.iis[c->h_pair_list[sp] / K.B];
+    FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
+    const uint16_t *cigar[2] = {nullptr, nullptr};
+    int n_cigar[2] = {0, 0}, mq_adjust[2] = {255, 255}, mapQ = 0;
+    int64_t beg[2] = {0, 0};
+    uint32_t cnt[2] = {0, 0};
+    for (; ti < cands.size() && cands[ti].sp == sp; ++ti) {
+      const int k = cands[ti].k;
+      const FqSwOut &O = souts[ti];
+      beg[k] = O.beg; cnt[k] = O.cnt;
+      if (O.n_cigar > 0) { cigar[k] = scig.data() + ti * cig_cap; n_cigar[k] = O.n_cigar; }
+      else beg[k] = tasks[ti].beg;
+      if (cigar[k] && p[k]->type != FQ_TYPE_NO_MATCH) {
+        int clip = 0;
+        if ((cigar[k][0] >> 14) == FQ_OP_S) clip += cigar[k][0] & 0x3fff;
+        if ((cigar[k][n_cigar[k] - 1] >> 14) == FQ_OP_S) clip += cigar[k][n_cigar[k] - 1] & 0x3fff;
+        int s_old = (int)((p[k]->n_mm * 9 + p[k]->n_gapo * 13 + p[k]->n_gape * 2) / 3. * 8. + .499);
+        int s_new = (int)(((cnt[k] >> 16) * 9 + (cnt[k] >> 8 & 0xff) * 13 + (cnt[k] & 0xff) * 2 + (uint32_t)clip * 3) / 3. * 8. + .499);
+        s_old = (int)(s_old + -4.343 * log(ii.ap_prior / ix->l_pac));
+        s_new += (int)(-4.343 * log(.5 * erfc(M_SQRT1_2 * 1.5) + .499));
+        if (s_old < s_new) { mq_adjust[k] = s_new - s_old; cigar[k] = nullptr; n_cigar[k] = 0; }
+        else mq_adjust[k] = s_old - s_new;
+      }
     }
-    if (!mt.empty()) {
-      const int md_cap = 3 * (max_len_all + 8) + 32;
-      const int nt = (int)mt.size();
-      CKM(c->d_mdtask.ensure(nt) && c->d_md.ensure((size_t)nt * md_cap) && c->d_mdlen.ensure(nt) && c->d_nm.ensure(nt) && c->d_mdsz.ensure(nt) &&
-          c->d_cigarena.ensure(arena.size() + 1) && c->d_off.ensure(nt + 1));
-      CK(fqdev::h2d(c->d_mdtask.p, mt.data(), (size_t)nt * sizeof(FqMdTask)));
-      CK(fqdev::h2d(c->d_cigarena.p, arena.data(), arena.size() * 2));
-      FqMdArgs a{};
-      a.ix = ix->dev; a.seq = c->d_seq.p; a.stride = stride; a.task = c->d_mdtask.p; a.n_task = nt; a.cigar = c->d_cigarena.p;
-      a.md = c->d_md.p; a.md_cap = md_cap; a.md_len = c->d_mdlen.p; a.md_sz = c->d_mdsz.p; a.nm = c->d_nm.p;
+    int k = -1;
+    if (cigar[0] && cigar[1]) { k = p[0]->mapQ < p[1]->mapQ ? 0 : 1; mapQ = abs(p[1]->mapQ - p[0]->mapQ); }
+    else if (cigar[0]) { k = 0; mapQ = p[1]->mapQ; }
+    else if (cigar[1]) { k = 1; mapQ = p[0]->mapQ; }
+    if (k >= 0 && (int64_t)p[k]->pos != beg[k]) {
+      int tmp = p[1 - k]->mapQ - p[k]->mapQ / 2 - 8;
+      if (tmp <= 0) tmp = 1;
+      if (mapQ > tmp) mapQ = tmp;
+      p[k]->mapQ = p[1 - k]->mapQ = mapQ;
+      p[k]->seQ = p[1 - k]->seQ = p[1 - k]->seQ < mapQ ? p[1 - k]->seQ : mapQ;
+      if (p[k]->mapQ > mq_adjust[k]) p[k]->mapQ = mq_adjust[k];
+      if (p[k]->seQ > mq_adjust[k]) p[k]->seQ = mq_adjust[k];
+      p[k]->cigar.assign(cigar[k], cigar[k] + n_cigar[k]);
+      p[k]->type = FQ_TYPE_MATESW; p[k]->pos = (uint32_t)beg[k]; p[k]->seQ = p[1 - k]->seQ;   // __set_fixed (:525-533)
+      p[k]->strand = 1 - p[1 - k]->strand;
+      p[k]->n_mm = (int)(cnt[k] >> 16) & 0xff; p[k]->n_gapo = (int)(cnt[k] >> 8 & 0xff); p[k]->n_gape = (int)(cnt[k] & 0xff);
+      p[k]->extra_flag |= 2; p[1 - k]->extra_flag |= 2;
+    }
+  }
+  return FQ_OK;
+}
+
+// ---- stage D: gapped refinement (bwa_refine_gapped, libbwa/bwase.c:339-418) ------------------------------
+int stageD_refine(Call &K) {
+  fq_ctx *c = K.c;
+  const fq_index *ix = c->ix;
+  vector<FqRead> &R = c->st.reads;
+  struct Tgt { int idx, multi; };
+  vector<Tgt> tgt; vector<FqRefTask> tasks;
+  int max_ref = 1, max_q = 1;
+  for (size_t idx = 0; idx < R.size(); ++idx) {
+    FqRead &s = R[idx];
+    if (s.filtered) continue;
+    for (size_t j = 0; j < s.multi.size(); ++j) {
+      FqMulti &q = s.multi[j];
+      if (q.gap == 0) continue;
+      tasks.push_back({s.dr, q.strand, q.pos, (q.strand ? 1 : -1) * q.gap});
+      tgt.push_back({(int)idx, (int)j});
+      max_ref = std::max(max_ref, s.len + q.gap); max_q = std::max(max_q, s.len);
+    }
+    if (s.type == FQ_TYPE_NO_MATCH || s.type == FQ_TYPE_MATESW || s.n_gapo == 0) continue;
+    tasks.push_back({s.dr, s.strand, s.pos, (s.strand ? 1 : -1) * (s.n_gapo + s.n_gape)});
+    tgt.push_back({(int)idx, -1});
+    max_ref = std::max(max_ref, s.len + s.n_gapo + s.n_gape); max_q = std::max(max_q, s.len);
+  }
+  if (!tasks.empty()) {
+    const int cig_cap = 64;
+    const size_t sstride = fq_dp_scratch_bytes(max_ref, max_q);
+    const size_t chunk = std::max<size_t>(64, ((size_t)6 << 30) / sstride);
+    vector<FqRefOut> outs(tasks.size());
+    vector<uint16_t> cg(tasks.size() * cig_cap);
+    for (size_t t0 = 0; t0 < tasks.size(); t0 += chunk) {
+      const int nt = (int)std::min(chunk, tasks.size() - t0);
+      CKM(c->d_reftask.ensure(nt) && c->d_refout.ensure(nt) && c->d_cig.ensure((size_t)nt * cig_cap) && c->d_scratch.ensure((size_t)nt * sstride));
+      CK(fqdev::h2d(c->d_reftask.p, tasks.data() + t0, (size_t)nt * sizeof(FqRefTask)));
+      FqRefineArgs a{};
+      a.ix = ix->dev; a.seq = K.dseq; a.stride = K.dstride; a.len_trim = K.dlen_trim; a.task = c->d_reftask.p; a.n_task = nt;
+      a.out = c->d_refout.p; a.cigar = c->d_cig.p; a.cig_cap = cig_cap; a.scratch = c->d_scratch.p; a.scratch_stride = sstride; a.RL = max_ref; a.QL = max_q;
       fqdev::time_begin(FQ_K_REFINE);
-      CK(fqdev::launch_md(a));
-      CK(fqdev::launch_scan(c->d_mdsz.p, c->d_off.p, (uint32_t)nt));
+      CK(fqdev::launch_refine(a));
       fqdev::time_end(FQ_K_REFINE);
-      uint64_t total = 0;
-      vector<int32_t> mdlen(nt), nm(nt);
-      vector<uint64_t> off(nt + 1);
-      CK(fqdev::d2h(off.data(), c->d_off.p, (size_t)(nt + 1) * 8));
-      CK(fqdev::d2h(mdlen.data(), c->d_mdlen.p, (size_t)nt * 4));
-      CK(fqdev::d2h(nm.data(), c->d_nm.p, (size_t)nt * 4));
+      CK(fqdev::d2h(outs.data() + t0, c->d_refout.p, (size_t)nt * sizeof(FqRefOut)));
+      CK(fqdev::d2h(cg.data() + t0 * cig_cap, c->d_cig.p, (size_t)nt * cig_cap * 2));
       CK(fqdev::sync());
-      total = off[nt];
-      CKM(c->d_mdpacked.ensure(total + 1));
-      CK(fqdev::launch_pack_md(c->d_md.p, c->d_mdlen.p, c->d_off.p, md_cap, nt, c->d_mdpacked.p));
-      vector<char> packed(total + 1);
-      CK(fqdev::d2h(packed.data(), c->d_mdpacked.p, total));
-      CK(fqdev::sync());
-      for (int t = 0; t < nt; ++t)
-        if (mdlen[t] < 0) { c->err = "MD string longer than the device slot"; return FQ_ELIMIT; }
-      parallel_chunks((size_t)nt, host_threads, [&](size_t lo, size_t hi, int) {
-        for (size_t t = lo; t < hi; ++t) {
-          FqRead &s = R[mi[t]];
-          s.md.assign(packed.data() + off[t], (size_t)mdlen[t]);
-          s.has_md = true;
-          s.nm = nm[t] & 0xfff;
-        }
-      });
     }
-    // bwa_correct_trimmed (bwase.c:298-337) for every record
-    parallel_chunks(R.size(), host_threads, [&](size_t lo, size_t hi, int) {
+    for (size_t t = 0; t < tasks.size(); ++t)
+      if (outs[t].n_cigar <= 0) { c->err = "refine: CIGAR longer than the device slot"; return FQ_ELIMIT; }
+    parallel_chunks(tasks.size(), K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {   // a task owns its record's field
+      for (size_t t = lo; t < hi; ++t) {
+        FqRead &s = R[tgt[t].idx];
+        const uint16_t *g = cg.data() + t * cig_cap;
+        if (tgt[t].multi >= 0) { FqMulti &q = s.multi[tgt[t].multi]; q.pos = outs[t].pos; q.cigar.assign(g, g + outs[t].n_cigar); }
+        else { s.pos = outs[t].pos; s.cigar.assign(g, g + outs[t].n_cigar); }
+      }
+    });
+    c->stats.refine_tasks += tasks.size();
+  }
+  // MD / NM for every mapped read (bwa_cal_md1)
+  vector<FqMdTask> mt; vector<int> mi; vector<uint16_t> arena;
+  for (size_t idx = 0; idx < R.size(); ++idx) {
+    FqRead &s = R[idx];
+    if (s.type == FQ_TYPE_NO_MATCH) continue;
+    FqMdTask T{};
+    T.read = s.dr; T.strand = s.strand; T.pos = s.pos; T.n_cigar = (int)s.cigar.size(); T.cigar_off = (uint32_t)arena.size(); T.len = s.len;
+    arena.insert(arena.end(), s.cigar.begin(), s.cigar.end());
+    mt.push_back(T); mi.push_back((int)idx);
+  }
+  if (!mt.empty()) {
+    const int md_cap = 3 * (K.max_len_all + 8) + 32;
+    const int nt = (int)mt.size();
+    CKM(c->d_mdtask.ensure(nt) && c->d_md.ensure((size_t)nt * md_cap) && c->d_mdlen.ensure(nt) && c->d_nm.ensure(nt) && c->d_mdsz.ensure(nt) &&
+        c->d_cigarena.ensure(arena.size() + 1) && c->d_off.ensure(nt + 1));
+    CK(fqdev::h2d(c->d_mdtask.p, mt.data(), (size_t)nt * sizeof(FqMdTask)));
+    CK(fqdev::h2d(c->d_cigarena.p, arena.data(), arena.size() * 2));
+    c->stats.h2d_bytes += (size_t)nt * sizeof(FqMdTask) + arena.size() * 2;
+    FqMdArgs a{};
+    a.ix = ix->dev; a.seq = K.dseq; a.stride = K.dstride; a.task = c->d_mdtask.p; a.n_task = nt; a.cigar = c->d_cigarena.p;
+    a.md = c->d_md.p; a.md_cap = md_cap; a.md_len = c->d_mdlen.p; a.md_sz = c->d_mdsz.p; a.nm = c->d_nm.p;
+    fqdev::time_begin(FQ_K_REFINE);
+    CK(fqdev::launch_md(a));
+    CK(fqdev::launch_scan(c->d_mdsz.p, c->d_off.p, (uint32_t)nt));
+    fqdev::time_end(FQ_K_REFINE);
+    uint64_t total = 0;
+    vector<int32_t> mdlen(nt), nm(nt);
+    vector<uint64_t> off(nt + 1);
+    CK(fqdev::d2h(off.data(), c->d_off.p, (size_t)(nt + 1) * 8));
+    CK(fqdev::d2h(mdlen.data(), c->d_mdlen.p, (size_t)nt * 4));
+    CK(fqdev::d2h(nm.data(), c->d_nm.p, (size_t)nt * 4));
+    CK(fqdev::sync());
+    total = off[nt];
+    CKM(c->d_mdpacked.ensure(total + 1));
+    CK(fqdev::launch_pack_md(c->d_md.p, c->d_mdlen.p, c->d_off.p, md_cap, nt, c->d_mdpacked.p));
+    vector<char> packed(total + 1);
+    CK(fqdev::d2h(packed.data(), c->d_mdpacked.p, total));
+    CK(fqdev::sync());
+    c->stats.d2h_bytes += (size_t)nt * 16 + total;
+    for (int t = 0; t < nt; ++t)
+      if (mdlen[t] < 0) { c->err = "MD string longer than the device slot"; return FQ_ELIMIT; }
+    parallel_chunks((size_t)nt, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
+      for (size_t t = lo; t < hi; ++t) {
+        FqRead &s = R[mi[t]];
+        s.md.assign(packed.data() + off[t], (size_t)mdlen[t]);
+        s.has_md = true;
+        s.nm = nm[t] & 0xfff;
+      }
+    });
+  }
+  // bwa_correct_trimmed (bwase.c:298-337) for every record
+  parallel_chunks(R.size(), K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
     for (size_t idx = lo; idx < hi; ++idx) {
       FqRead &s = R[idx];
       if (s.len == s.full_len) continue;
@@ -1052,59 +1352,144 @@ extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
       }
       s.len = s.full_len;
     }
-    });
-  }
-  TRACE("D refine+MD+trim");
-  c->last_ii = iis[n_sub - 1];
-  const double t_host1 = now_ms();
+  });
+  return FQ_OK;
+}
 
-  // ---- flatten into the C-ABI result arrays ------------------------------------------------------------------
-  S.isize_sub = iis;
-  S.isize = iis[n_sub - 1];
-  S.s_of = s_of;
-  S.aln_off = aln_off;
-  S.aln_n = aln_n;
-  S.flatten(host_threads, par_min());
-  TRACE("flatten");
+// ---- flatten into the C-ABI result arrays, collect the work counters ------------------------------------------------
+int stage_finish(Call &K, fq_result_batch_t *out) {
+  fq_ctx *c = K.c;
+  FqBatchState &S = c->st;
+  vector<FqRead> &R = S.reads;
+  const int n_sub = K.n_sub, n_surv = K.n_surv;
+  S.isize_sub = K.iis;
+  S.isize = K.iis[n_sub - 1];
+  S.s_of = K.s_of;
+  S.aln_off = K.aln_off;
+  S.aln_n = K.aln_n;
+  S.flatten(K.host_threads, K.par_min);
+  K.trace("flatten");
   int n_both_unmapped = 0;
   for (int sp = 0; sp < n_surv; ++sp) if (R[2 * sp].type == FQ_TYPE_NO_MATCH && R[2 * sp + 1].type == FQ_TYPE_NO_MATCH) ++n_both_unmapped;
   out->n_survivors = n_surv;
-  out->n_both_filtered = n - n_surv;
+  out->n_both_filtered = K.n - n_surv;
   out->n_both_unmapped = n_both_unmapped;
   out->pair_idx = S.pair_idx.data();
   out->rec = S.rec.data();
   out->cigar = S.cigar.data();
   out->md = S.md.data();
   out->multi = S.multi.data();
-  out->isize = iis[n_sub - 1];
+  out->isize = K.iis[n_sub - 1];
   out->n_sub = n_sub;
   out->isize_sub = S.isize_sub.data();
-  out->n_bases = n_bases;
-
-  // ---- measurement ----------------------------------------------------------------------------------------------
-  {
-    uint64_t cnt[FQ_C_COUNT];
-    CK(fqdev::d2h(cnt, c->d_counters.p, sizeof cnt));
-    CK(fqdev::sync());
-    CK(fqdev::dzero(c->d_counters.p, sizeof cnt));
-    fqdev::time_collect(c->stats.kernel_ms, c->stats.kernel_launches, FQ_K_COUNT);
-    c->stats.occ_block_touches += cnt[FQ_C_OCC_WIDTH] + cnt[FQ_C_OCC_GAP] + cnt[FQ_C_OCC_SA];
-    c->stats.gap_occ_touches += cnt[FQ_C_OCC_GAP];
-    c->stats.filter_probes += cnt[FQ_C_PROBES];
-    c->stats.stack_pops += cnt[FQ_C_POPS];
-    c->stats.stack_pushes += cnt[FQ_C_PUSHES];
-    if (cnt[FQ_C_MAXPOPS] > c->stats.max_pops_per_read) c->stats.max_pops_per_read = cnt[FQ_C_MAXPOPS];
-    c->stats.reads_over_4k_pops += cnt[FQ_C_POPS_GT4K];
-    if (cnt[FQ_C_MAXTRIPS] > c->stats.max_wave_trips) c->stats.max_wave_trips = cnt[FQ_C_MAXTRIPS];
-    c->stats.wave_trips += cnt[FQ_C_SUMTRIPS];
-    c->stats.lane_trips += cnt[FQ_C_LANETRIPS];
-    c->stats.pairs += n;
-    c->stats.host_ms_serial += t_serial1 - t_host0;
-    c->stats.host_ms_pair += t_host1 - t_serial1;
-    c->stats.host_ms_total += t_host1 - t_host0;
-    c->stats.wall_ms_total += now_ms() - t_wall0;
-  }
+  out->n_bases = c->n_bases_in;
+  uint64_t cnt[FQ_C_COUNT];
+  CK(fqdev::d2h(cnt, c->d_counters.p, sizeof cnt));
+  CK(fqdev::sync());
+  CK(fqdev::dzero(c->d_counters.p, sizeof cnt));
+  fqdev::time_collect(c->stats.kernel_ms, c->stats.kernel_launches, FQ_K_COUNT);
+  c->stats.occ_block_touches += cnt[FQ_C_OCC_WIDTH] + cnt[FQ_C_OCC_GAP] + cnt[FQ_C_OCC_SA];
+  c->stats.gap_occ_touches += cnt[FQ_C_OCC_GAP];
+  c->stats.filter_probes += cnt[FQ_C_PROBES];
+  c->stats.stack_pops += cnt[FQ_C_POPS];
+  c->stats.stack_pushes += cnt[FQ_C_PUSHES];
+  if (cnt[FQ_C_MAXPOPS] > c->stats.max_pops_per_read) c->stats.max_pops_per_read = cnt[FQ_C_MAXPOPS];
+  c->stats.reads_over_4k_pops += cnt[FQ_C_POPS_GT4K];
+  if (cnt[FQ_C_MAXTRIPS] > c->stats.max_wave_trips) c->stats.max_wave_trips = cnt[FQ_C_MAXTRIPS];
+  c->stats.wave_trips += cnt[FQ_C_SUMTRIPS];
+  c->stats.lane_trips += cnt[FQ_C_LANETRIPS];
+  c->stats.pairs += K.n;
+  c->stats.host_ms_serial += K.t_serial1 - K.t_host0;
+  c->stats.host_ms_pair += K.t_host1 - K.t_serial1;
+  c->stats.host_ms_total += K.t_host1 - K.t_host0;
+  c->stats.wall_ms_total += now_ms() - K.t_wall0;
   return FQ_OK;
+}
+
+int run_call(fq_ctx *c, fq_result_batch_t *out) {
+  Call K;
+  K.c = c;
+  K.t_trace = K.t_wall0 = now_ms();
+  const fq_opts_t &o = c->o;
+  FqBatchState &S = c->st;
+  S.clear();
+  S.n_pairs = c->n_pairs;
+  memset(out, 0, sizeof *out);
+  out->n_pairs = c->n_pairs;
+  if (c->n_pairs == 0) { S.reads.clear(); return FQ_OK; }
+  K.n = c->n_pairs; K.n2 = 2 * K.n; K.B = o.batch_pairs; K.n_sub = (K.n + K.B - 1) / K.B;
+  K.par_min = c->kn.host_par_min;
+  K.host_threads = c->kn.host_threads >= 0 ? c->kn.host_threads : o.host_threads > 0 ? o.host_threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+  int rc = c->in_kind == 2 ? stage0_packed(K) : stage0_ascii(K);
+  if (rc) return rc;
+  S.n_surv = K.n_surv;
+  S.batch_pairs = K.B;
+  S.sub_lo = K.sub_lo;
+  S.pair_idx = c->h_pair_list;
+  K.trace("stage0 prep+compact");
+  if ((rc = stageA_search(K))) return rc;
+  K.trace("stageA width+gap");
+  stage_records(K);
+  K.trace("records init");
+  if ((rc = stage_sa_rows(K))) return rc;
+  K.trace("SA enumerate+kernel");
+  K.t_host0 = now_ms();
+  if ((rc = stageB1_main_hit(K))) return rc;
+  K.trace("B1 main hit (serial)");
+  stageB2_isize(K);
+  K.t_serial1 = now_ms();
+  K.trace("B2 isize");
+  stageB3_pairing(K);
+  K.trace("B3 pairing+XA");
+  if (c->debug) S.stage_P = S.reads;   // snapshot for the stage dump (tests)
+  if ((rc = stageC_mate_sw(K))) return rc;
+  K.trace("C mate SW");
+  if (c->debug) S.stage_S = S.reads;
+  if ((rc = stageD_refine(K))) return rc;
+  K.trace("D refine+MD+trim");
+  c->last_ii = K.iis[K.n_sub - 1];
+  K.t_host1 = now_ms();
+  return stage_finish(K, out);
+}
+}  // namespace
+
+extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
+  if (!c || !out) return FQ_EINVAL;
+  if (c->in_kind != 1) { c->err = "fq_align_resident: no batch uploaded (fq_batch_upload)"; return FQ_EINVAL; }
+  if (fqdev::bind(c->dev)) return FQ_ENODEV;
+  return run_call(c, out);
+}
+
+static int packed_check(fq_ctx_t *c, const fq_packed_batch_t *in) {
+  if (!in || in->n_pairs < 0 || (in->n_pairs > 0 && (!in->head || !in->body || in->body_stride < 1 || (in->uniform_len <= 0 && !in->len)))) return FQ_EINVAL;
+  if (in->n_exc < 0 || (in->n_exc > 0 && !in->exc)) return FQ_EINVAL;
+  if (in->n_pairs > c->max_pairs) { c->err = "batch larger than max_pairs_per_batch"; return FQ_ELIMIT; }
+  if (in->uniform_len > 0 && (in->uniform_len < FQ_LMIN || in->uniform_len > FQ_LMAX || (in->uniform_len + 3) / 4 > in->body_stride)) { c->err = "read length outside [" + std::to_string(FQ_LMIN) + "," + std::to_string(FQ_LMAX) + "]"; return FQ_ELIMIT; }
+  if (c->o.trim_qual >= 1 && in->n_pairs > 0 && (!in->qual || in->qual_stride < 1)) { c->err = "quality trimming needs the batch's qualities"; return FQ_EINVAL; }
+  return FQ_OK;
+}
+extern "C" int fq_packed_prefetch(fq_ctx_t *c, const fq_packed_batch_t *next) {
+  if (!c) return FQ_EINVAL;
+  int rc = packed_check(c, next);
+  if (rc) return rc;
+  if (fqdev::bind(c->dev)) return FQ_ENODEV;
+  if (next->n_pairs == 0) return FQ_OK;
+  rc = head_upload(c, next, c->head_slot ^ 1);   // the spare buffer: the current one may still be read by a running call
+  if (rc) return rc;
+  c->prefetched = next;
+  return FQ_OK;
+}
+extern "C" int fq_align_packed(fq_ctx_t *c, const fq_packed_batch_t *in, fq_result_batch_t *out) {
+  if (!c || !out) return FQ_EINVAL;
+  int rc = packed_check(c, in);
+  if (rc) return rc;
+  if (fqdev::bind(c->dev)) return FQ_ENODEV;
+  c->pb = *in;
+  c->n_pairs = in->n_pairs;
+  c->in_kind = 2;
+  if (c->prefetched != in) c->prefetched = nullptr;   // a prefetch for some other batch is simply lost
+  else c->prefetched = &c->pb;
+  return run_call(c, out);
 }
 
 extern "C" int fq_ctx_set_debug(fq_ctx_t *c, int keep_stage_snapshots) {
@@ -1119,5 +1504,10 @@ void fq_ctx_all_reads(const fq_ctx_t *c, const uint8_t **filtered, const int32_t
 // accessors used by fq_sam.cpp
 const FqBatchState *fq_ctx_state(const fq_ctx_t *c) { return &c->st; }
 const fq_index *fq_ctx_index(const fq_ctx_t *c) { return c->ix; }
-const fq_read_batch_t *fq_ctx_host_batch(const fq_ctx_t *c) { return &c->hb; }
+FqHostReads fq_ctx_host_reads(const fq_ctx_t *c) {
+  FqHostReads h;
+  if (c->in_kind == 2) { h.p = &c->pb; h.n_pairs = c->pb.n_pairs; h.names = c->pb.names; h.names_mate = c->pb.names_mate; h.name_stride = c->pb.name_stride; }
+  else { h.a = &c->hb; h.n_pairs = c->hb.n_pairs; h.names = c->hb.names; h.names_mate = c->hb.names_mate; h.name_stride = c->hb.name_stride; }
+  return h;
+}
 const fq_opts_t *fq_ctx_opts(const fq_ctx_t *c) { return &c->o; }

@@ -6,7 +6,17 @@
 
 namespace fqdev {
 
-int init(int device_ordinal);          // 0 or FQ_ENODEV-style negative
+// Device state of one alignment context (or of an index load): compute stream, copy stream, timing events, scan / compaction
+// temporaries.  Created and destroyed with its owner; a host thread binds it on entry to the library and every call below acts
+// on the bound state.  Nothing device-side is kept per thread or per process.
+struct State;
+struct Tune {   // experiment / test knobs (fq_ctx_set_tuning); the defaults are what DESIGN.md measures
+  int gap_waves_per_cu = 0, gap_refill_min = 0, gap_order_asc = 0, filter_no_turns = 0, refine_lanes = 0;
+};
+State *state_create(int device_ordinal);   // nullptr on failure (last_error())
+void state_destroy(State *s);              // synchronises the state's streams, frees everything it owns
+int bind(State *s);                        // 0 or FQ_ENODEV-style negative
+Tune *tune(State *s);
 const char *last_error();
 bool is_real_gpu();                    // true for the HIP backend
 
@@ -17,7 +27,13 @@ void hfree(void *p);
 int h2d(void *dst, const void *src, size_t bytes);
 int d2h(void *dst, const void *src, size_t bytes);
 int dzero(void *dst, size_t bytes);
+int dfill(void *dst, int byte, size_t bytes);
 int sync();
+// input prefetch on the state's copy stream (runs under the compute stream's kernels): copies, then copy_record(slot);
+// compute_wait_copy(slot) makes everything enqueued afterwards on the compute stream wait for that slot's copies
+int h2d_copy(void *dst, const void *src, size_t bytes);
+int copy_record(int slot);
+int compute_wait_copy(int slot);
 
 // HIP-event timing of everything enqueued between begin/end, accumulated per kernel id
 void time_begin(int kid);
@@ -33,6 +49,14 @@ int launch_prep(const FqPrepArgs &a);
 int launch_compact(const uint8_t *filtered, int n_pairs, int32_t *read_list, int32_t *sidx, int32_t *pair_list, int32_t *counts);
 // out[2*sp+e] = {len_trim, filtered, sidx} of read e of surviving pair sp
 int launch_surv_gather(const int32_t *pair_list, int n_surv, int n_pairs, const int32_t *len_trim, const uint8_t *filtered, const int32_t *sidx, FqSurvInfo *out);
+// packed input (fq_packed_batch_t): filter over the uploaded k-mers; survivors' rows unpacked to ASCII afterwards
+int launch_prep_packed(const FqPrepPackedArgs &a);
+int launch_surv_map(const int32_t *pair_list, int n_surv, int n_pairs, const uint8_t *filtered, const int32_t *sidx, FqSurvInfo *out,
+                    int32_t *row_map, int32_t *read_list_c, int32_t *crow_of);
+int launch_unpack(const FqUnpackArgs &a);
+int launch_patch(const FqPatchArgs &a);
+int launch_trim(const FqTrimArgs &a);
+int launch_trim_all(const FqTrimAllArgs &a);
 int launch_width(const FqWidthArgs &a);
 // order[0..n) = the work items sorted by descending fq_order_key (any order inside a key); cnt: FQ_ORDER_KEYS*2 words of scratch
 int launch_order(const uint8_t *bid_end, int n, int32_t *order, uint32_t *cnt);

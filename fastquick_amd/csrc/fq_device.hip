@@ -16,11 +16,27 @@
 
 namespace fqdev {
 
-// All backend state is per host thread: a thread that drives a context gets its own HIP stream, timing events and
-// scan/compaction temporaries, so several contexts can be driven concurrently (one thread each) and their kernels overlap.
-static thread_local hipStream_t g_stream = nullptr;
+// Backend state belongs to an alignment context (fqdev::State, created by fq_ctx_create and freed by fq_ctx_destroy): the
+// compute stream, a copy stream for input prefetch, the timing events and the scan / compaction temporaries.  A host thread that
+// enters the library binds the context's state (fqdev::bind) and every call below works on the bound state, so several
+// contexts can be driven concurrently (one thread each) and their kernels overlap; nothing device-side lives in thread-local
+// storage or outlives its context.
+struct Pending { int kid; hipEvent_t a, b; };
+struct State {
+  int device = 0;
+  hipStream_t stream = nullptr, copy_stream = nullptr;
+  hipEvent_t copy_done[2] = {nullptr, nullptr};
+  hipEvent_t prep_done = nullptr;                 // completion of this context's most recent filter kernel (chained per device)
+  std::vector<Pending> pending;
+  std::vector<hipEvent_t> free_events;
+  hipEvent_t open_begin[16] = {};
+  uint64_t *scan_tmp = nullptr; size_t scan_tmp_n = 0;
+  uint32_t *cmp_cnt = nullptr; uint64_t *cmp_off = nullptr; size_t cmp_n = 0;
+  Tune tune;
+};
+static thread_local State *g_cur = nullptr;
 static thread_local std::string g_err;
-static thread_local int g_device = -1;
+#define g_stream (g_cur->stream)
 
 #define FQ_HIP(call)                                                                         \
   do {                                                                                       \
@@ -34,17 +50,59 @@ static thread_local int g_device = -1;
 const char *last_error() { return g_err.c_str(); }
 bool is_real_gpu() { return true; }
 
-int init(int dev) {
-  if (g_stream && g_device == dev) return 0;
+static int set_kernel_attributes();
+static std::mutex g_dev_mu;
+static bool g_dev_ready[64];
+// the filter kernels of all contexts of a device are chained (launch_prep): the most recent one's completion event, and the
+// state that owns it (an event must not be destroyed while another stream may still have to wait on it: state_destroy
+// synchronises its stream first and clears the slot)
+static hipEvent_t g_prep_last[64];
+static State *g_prep_owner[64];
+
+State *state_create(int dev) {
   int n = 0;
-  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_err = "no HIP device visible"; return -3; }
-  if (dev < 0 || dev >= n) { g_err = "device ordinal out of range"; return -3; }
-  if (g_stream && g_device == dev) return 0;
-  FQ_HIP(hipSetDevice(dev));
-  if (!g_stream || g_device != dev) {
-    FQ_HIP(hipStreamCreateWithFlags(&g_stream, hipStreamNonBlocking));
-    g_device = dev;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_err = "no HIP device visible"; return nullptr; }
+  if (dev < 0 || dev >= n || dev >= 64) { g_err = "device ordinal out of range"; return nullptr; }
+  if (hipSetDevice(dev) != hipSuccess) { g_err = "hipSetDevice failed"; return nullptr; }
+  {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (!g_dev_ready[dev]) { if (set_kernel_attributes()) return nullptr; g_dev_ready[dev] = true; }
   }
+  State *s = new State;
+  s->device = dev;
+  bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreateWithFlags(&s->copy_done[0], hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&s->copy_done[1], hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&s->prep_done, hipEventDisableTiming) == hipSuccess;
+  if (!ok) { g_err = "stream / event creation failed"; state_destroy(s); return nullptr; }
+  return s;
+}
+void state_destroy(State *s) {
+  if (!s) return;
+  (void)hipSetDevice(s->device);
+  if (s->stream) (void)hipStreamSynchronize(s->stream);
+  if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
+  {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (g_prep_owner[s->device] == s) { g_prep_owner[s->device] = nullptr; g_prep_last[s->device] = nullptr; }
+  }
+  for (auto &p : s->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+  for (auto e : s->free_events) (void)hipEventDestroy(e);
+  for (auto e : s->copy_done) if (e) (void)hipEventDestroy(e);
+  if (s->prep_done) (void)hipEventDestroy(s->prep_done);
+  if (s->scan_tmp) (void)hipFree(s->scan_tmp);
+  if (s->cmp_cnt) (void)hipFree(s->cmp_cnt);
+  if (s->cmp_off) (void)hipFree(s->cmp_off);
+  if (s->stream) (void)hipStreamDestroy(s->stream);
+  if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
+  if (g_cur == s) g_cur = nullptr;
+  delete s;
+}
+Tune *tune(State *s) { return &s->tune; }
+int bind(State *s) {
+  if (!s) { g_err = "no device state"; return -3; }
+  if (g_cur != s) { FQ_HIP(hipSetDevice(s->device)); g_cur = s; }
   return 0;
 }
 
@@ -63,32 +121,34 @@ void hfree(void *p) { if (p) (void)hipHostFree(p); }
 int h2d(void *dst, const void *src, size_t bytes) { if (bytes) FQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream)); return 0; }
 int d2h(void *dst, const void *src, size_t bytes) { if (bytes) FQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream)); return 0; }
 int dzero(void *dst, size_t bytes) { if (bytes) FQ_HIP(hipMemsetAsync(dst, 0, bytes, g_stream)); return 0; }
+int dfill(void *dst, int byte, size_t bytes) { if (bytes) FQ_HIP(hipMemsetAsync(dst, byte, bytes, g_stream)); return 0; }
 int sync() { FQ_HIP(hipStreamSynchronize(g_stream)); return 0; }
+// input prefetch: copies on the context's copy stream run under the compute stream's kernels; slot = which of the two input
+// buffers the copies since the previous copy_record() filled
+int h2d_copy(void *dst, const void *src, size_t bytes) { if (bytes) FQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_cur->copy_stream)); return 0; }
+int copy_record(int slot) { FQ_HIP(hipEventRecord(g_cur->copy_done[slot & 1], g_cur->copy_stream)); return 0; }
+int compute_wait_copy(int slot) { FQ_HIP(hipStreamWaitEvent(g_stream, g_cur->copy_done[slot & 1], 0)); return 0; }
 
 // ---- timing ---------------------------------------------------------------------------------
-struct Pending { int kid; hipEvent_t a, b; };
-static thread_local std::vector<Pending> g_pending;
-static thread_local std::vector<hipEvent_t> g_free_events;
-static thread_local hipEvent_t g_open_begin[16];
 static hipEvent_t get_event() {
-  if (!g_free_events.empty()) { hipEvent_t e = g_free_events.back(); g_free_events.pop_back(); return e; }
+  if (!g_cur->free_events.empty()) { hipEvent_t e = g_cur->free_events.back(); g_cur->free_events.pop_back(); return e; }
   hipEvent_t e;
   (void)hipEventCreate(&e);
   return e;
 }
-void time_begin(int kid) { hipEvent_t e = get_event(); (void)hipEventRecord(e, g_stream); g_open_begin[kid] = e; }
-void time_end(int kid) { hipEvent_t e = get_event(); (void)hipEventRecord(e, g_stream); g_pending.push_back({kid, g_open_begin[kid], e}); }
+void time_begin(int kid) { hipEvent_t e = get_event(); (void)hipEventRecord(e, g_stream); g_cur->open_begin[kid] = e; }
+void time_end(int kid) { hipEvent_t e = get_event(); (void)hipEventRecord(e, g_stream); g_cur->pending.push_back({kid, g_cur->open_begin[kid], e}); }
 // start/stop events attached to one kernel (hipExtLaunchKernelGGL): the kernel's own begin/end timestamps, i.e. what
 // rocprofv3 --kernel-trace reports, unaffected by dispatch queueing when several streams share the GPU
-static void kernel_events(int kid, hipEvent_t *a, hipEvent_t *b) { *a = get_event(); *b = get_event(); g_pending.push_back({kid, *a, *b}); }
+static void kernel_events(int kid, hipEvent_t *a, hipEvent_t *b) { *a = get_event(); *b = get_event(); g_cur->pending.push_back({kid, *a, *b}); }
 void time_collect(double ms[], uint64_t launches[], int n_ids) {
-  for (auto &p : g_pending) {
+  for (auto &p : g_cur->pending) {
     float t = 0.f;
     if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess && p.kid < n_ids) { ms[p.kid] += t; launches[p.kid] += 1; }
-    g_free_events.push_back(p.a);
-    g_free_events.push_back(p.b);
+    g_cur->free_events.push_back(p.a);
+    g_cur->free_events.push_back(p.b);
   }
-  g_pending.clear();
+  g_cur->pending.clear();
 }
 
 // ---- kernels --------------------------------------------------------------------------------
@@ -476,8 +536,8 @@ __global__ void __launch_bounds__(256) k_scan_c(const uint32_t *in, uint32_t n, 
   if (i == 0) out[n] = blk_off[gridDim.x];
 }
 
-static thread_local uint64_t *g_scan_tmp = nullptr;
-static thread_local size_t g_scan_tmp_n = 0;
+#define g_scan_tmp (g_cur->scan_tmp)
+#define g_scan_tmp_n (g_cur->scan_tmp_n)
 int launch_scan(const uint32_t *in, uint64_t *out, uint32_t n) {
   if (n == 0) { uint64_t z = 0; return h2d(out, &z, 8) ? -3 : sync(); }
   const unsigned nb = nblk(n, 256);
@@ -536,9 +596,9 @@ __global__ void __launch_bounds__(256) k_compact_c(const uint8_t *filt, int n_pa
   }
   if (p == 0) { counts[0] = (int32_t)read_off[gridDim.x]; counts[1] = (int32_t)pair_off[gridDim.x]; }
 }
-static thread_local uint32_t *g_cmp_cnt = nullptr;
-static thread_local uint64_t *g_cmp_off = nullptr;
-static thread_local size_t g_cmp_n = 0;
+#define g_cmp_cnt (g_cur->cmp_cnt)
+#define g_cmp_off (g_cur->cmp_off)
+#define g_cmp_n (g_cur->cmp_n)
 int launch_compact(const uint8_t *filtered, int n_pairs, int32_t *read_list, int32_t *sidx, int32_t *pair_list, int32_t *counts) {
   if (n_pairs <= 0) return dzero(counts, 8);
   const unsigned nb = nblk((uint64_t)n_pairs, 256);
@@ -580,25 +640,17 @@ int launch_bitmap_scatter(uint8_t *bitmap, const uint32_t *bits, uint64_t n) {
 // launches of all streams (threads) of a device are therefore chained on the device: each waits for the previous one's
 // completion event, so they run back to back without a host round trip in between, while everything else a stream does
 // overlaps freely.  FQ_FILTER_NO_TURNS lets them overlap.
-static std::mutex g_prep_chain_mu;
-static hipEvent_t g_prep_last[64];     // per device: completion of the most recent filter kernel
-static bool g_prep_has[64];
 int launch_prep(const FqPrepArgs &a) {
   if (a.n_reads <= 0) return 0;
-  static const bool chain = getenv("FQ_FILTER_NO_TURNS") == nullptr;
-  static thread_local hipEvent_t my_done = nullptr;   // (never destroyed: another stream may still be waiting on it)
   hipEvent_t e0, e1;
   kernel_events(6, &e0, &e1);   // FQ_K_PREP_KERNEL
-  if (chain) {
-    if (!my_done) FQ_HIP(hipEventCreateWithFlags(&my_done, hipEventDisableTiming));
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    dev &= 63;
-    std::lock_guard<std::mutex> lk(g_prep_chain_mu);
-    if (g_prep_has[dev]) FQ_HIP(hipStreamWaitEvent(g_stream, g_prep_last[dev], 0));
+  if (!g_cur->tune.filter_no_turns) {
+    const int dev = g_cur->device;
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (g_prep_last[dev] && g_prep_owner[dev] != g_cur) FQ_HIP(hipStreamWaitEvent(g_stream, g_prep_last[dev], 0));
     hipExtLaunchKernelGGL(k_prep, dim3(nblk((uint64_t)a.n_reads, 256)), dim3(256), 0, g_stream, e0, e1, 0, a);
-    FQ_HIP(hipEventRecord(my_done, g_stream));
-    g_prep_last[dev] = my_done; g_prep_has[dev] = true;
+    FQ_HIP(hipEventRecord(g_cur->prep_done, g_stream));
+    g_prep_last[dev] = g_cur->prep_done; g_prep_owner[dev] = g_cur;
   } else {
     hipExtLaunchKernelGGL(k_prep, dim3(nblk((uint64_t)a.n_reads, 256)), dim3(256), 0, g_stream, e0, e1, 0, a);
   }
@@ -612,6 +664,80 @@ __global__ void __launch_bounds__(256) k_surv_gather(const int32_t *pair_list, i
 int launch_surv_gather(const int32_t *pair_list, int n_surv, int n_pairs, const int32_t *len_trim, const uint8_t *filtered, const int32_t *sidx, FqSurvInfo *out) {
   if (n_surv <= 0) return 0;
   hipLaunchKernelGGL(k_surv_gather, dim3(nblk((uint64_t)n_surv * 2, 256)), dim3(256), 0, g_stream, pair_list, n_surv, n_pairs, len_trim, filtered, sidx, out);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+__global__ void __launch_bounds__(256) k_prep_packed(FqPrepPackedArgs a) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < a.n_reads) fq_prep_packed_thread(a, r);
+}
+int launch_prep_packed(const FqPrepPackedArgs &a) {
+  if (a.n_reads <= 0) return 0;
+  hipEvent_t e0, e1;
+  kernel_events(6, &e0, &e1);   // FQ_K_PREP_KERNEL
+  const dim3 grid(nblk((uint64_t)a.n_reads, 256));
+  if (!g_cur->tune.filter_no_turns) {   // chained per device like launch_prep
+    const int dev = g_cur->device;
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    if (g_prep_last[dev] && g_prep_owner[dev] != g_cur) FQ_HIP(hipStreamWaitEvent(g_stream, g_prep_last[dev], 0));
+    hipExtLaunchKernelGGL(k_prep_packed, grid, dim3(256), 0, g_stream, e0, e1, 0, a);
+    FQ_HIP(hipEventRecord(g_cur->prep_done, g_stream));
+    g_prep_last[dev] = g_cur->prep_done; g_prep_owner[dev] = g_cur;
+  } else {
+    hipExtLaunchKernelGGL(k_prep_packed, grid, dim3(256), 0, g_stream, e0, e1, 0, a);
+  }
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+__global__ void __launch_bounds__(256) k_surv_map(const int32_t *pair_list, int n_surv, int n_pairs, const uint8_t *filtered, const int32_t *sidx, FqSurvInfo *out,
+                                                  int32_t *row_map, int32_t *read_list_c, int32_t *crow_of) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < 2 * n_surv) fq_surv_map_thread(pair_list, n_pairs, filtered, sidx, out, row_map, read_list_c, crow_of, t);
+}
+int launch_surv_map(const int32_t *pair_list, int n_surv, int n_pairs, const uint8_t *filtered, const int32_t *sidx, FqSurvInfo *out,
+                    int32_t *row_map, int32_t *read_list_c, int32_t *crow_of) {
+  if (n_surv <= 0) return 0;
+  hipLaunchKernelGGL(k_surv_map, dim3(nblk((uint64_t)n_surv * 2, 256)), dim3(256), 0, g_stream, pair_list, n_surv, n_pairs, filtered, sidx, out, row_map, read_list_c, crow_of);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+__global__ void __launch_bounds__(256) k_unpack(FqUnpackArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < a.n_rows) fq_unpack_thread(a, t);
+}
+int launch_unpack(const FqUnpackArgs &a) {
+  if (a.n_rows <= 0) return 0;
+  hipLaunchKernelGGL(k_unpack, dim3(nblk((uint64_t)a.n_rows, 256)), dim3(256), 0, g_stream, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+__global__ void __launch_bounds__(256) k_patch(FqPatchArgs a) {
+  const int64_t q = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < a.n_exc) fq_patch_thread(a, q);
+}
+int launch_patch(const FqPatchArgs &a) {
+  if (a.n_exc <= 0) return 0;
+  hipLaunchKernelGGL(k_patch, dim3(nblk((uint64_t)a.n_exc, 256)), dim3(256), 0, g_stream, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+__global__ void __launch_bounds__(256) k_trim(FqTrimArgs a) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < a.n_rows) fq_trim_thread(a, t);
+}
+int launch_trim(const FqTrimArgs &a) {
+  if (a.n_rows <= 0) return 0;
+  hipLaunchKernelGGL(k_trim, dim3(nblk((uint64_t)a.n_rows, 256)), dim3(256), 0, g_stream, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+__global__ void __launch_bounds__(256) k_trim_all(FqTrimAllArgs a) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < a.n_reads) fq_trim_all_thread(a, r);
+}
+int launch_trim_all(const FqTrimAllArgs &a) {
+  if (a.n_reads <= 0) return 0;
+  hipLaunchKernelGGL(k_trim_all, dim3(nblk((uint64_t)a.n_reads, 256)), dim3(256), 0, g_stream, a);
   FQ_HIP(hipGetLastError());
   return 0;
 }
@@ -654,7 +780,7 @@ int launch_order(const uint8_t *bid_end, int n, int32_t *order, uint32_t *cnt) {
   if (n <= 0) return 0;
   FQ_HIP(hipMemsetAsync(cnt, 0, 2 * FQ_ORDER_KEYS * 4, g_stream));
   hipLaunchKernelGGL(k_order_count, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, bid_end, n, cnt);
-  hipLaunchKernelGGL(k_order_scatter, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, bid_end, n, cnt, order, getenv("FQ_GAP_ORDER_ASC") ? 1 : 0);   // (experiment hook: ascending)
+  hipLaunchKernelGGL(k_order_scatter, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, bid_end, n, cnt, order, g_cur->tune.gap_order_asc ? 1 : 0);   // (experiment knob: ascending)
   FQ_HIP(hipGetLastError());
   return 0;
 }
@@ -665,7 +791,7 @@ int gap_lane_slots(const FqGapArgs &a) {
     if (a.max_waves > 0) w = std::min<unsigned>(w, (unsigned)a.max_waves);
     return (int)w;
   }
-  static const int env_waves = getenv("FQ_GAP_WAVES_PER_CU") ? atoi(getenv("FQ_GAP_WAVES_PER_CU")) : 0;
+  const int env_waves = g_cur->tune.gap_waves_per_cu;
   const unsigned need = nblk((uint64_t)a.n_work, 64);
   unsigned per_cu = 8;
   if (a.tier.pool_cap <= 65535u) {
@@ -680,7 +806,7 @@ int gap_lane_slots(const FqGapArgs &a) {
 int launch_gap(const FqGapArgs &a_in) {
   if (a_in.n_work <= 0) return 0;
   FqGapArgs a = a_in;
-  static const int env_refill = getenv("FQ_GAP_REFILL_MIN") ? atoi(getenv("FQ_GAP_REFILL_MIN")) : 0;
+  const int env_refill = g_cur->tune.gap_refill_min;
   a.refill_min = env_refill > 0 ? env_refill : FQ_REFILL_MIN;
   FQ_HIP(hipMemsetAsync(a.queue, 0, 4, g_stream));
   hipEvent_t e0, e1;
@@ -726,8 +852,6 @@ int launch_sw(const FqSwArgs &a) {
   // the task's global scratch and have every task resident at once (each spends most of its time in the serial reverse pass).
   b.trace_in_lds = (lds + trace_bytes <= kLdsBudget && a.n_task <= 256) ? 1 : 0;
   if (b.trace_in_lds) lds += trace_bytes;
-  static std::atomic<bool> attr_set{false};
-  if (!attr_set) { FQ_HIP(hipFuncSetAttribute((const void *)k_sw_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget)); attr_set = true; }
   hipLaunchKernelGGL(k_sw_wave, dim3((unsigned)a.n_task), dim3(64), lds, g_stream, b);
   FQ_HIP(hipGetLastError());
   return 0;
@@ -747,18 +871,14 @@ int launch_refine(const FqRefineArgs &a) {
   // one task per wavefront while row arrays + sequences + trace matrix fit in LDS with several blocks per CU; longer reads
   // fall back to one task per lane
   const size_t wave_lds = (size_t)3 * (a.RL + 1) * 4 + ((a.RL + 16) & ~15) + ((a.QL + 16) & ~15) + ((a.RL + a.QL + 16) & ~15) + (size_t)(a.RL + 1) * (a.QL + 1) + 16;
-  static const bool no_wave = getenv("FQ_REFINE_LANES") != nullptr;   // test hook: force the lane-per-task kernels
+  const bool no_wave = g_cur->tune.refine_lanes != 0;   // test knob: force the lane-per-task kernels
   if (wave_lds <= 64 * 1024 && !no_wave) {
-    static std::atomic<bool> attr_w{false};
-    if (!attr_w) { FQ_HIP(hipFuncSetAttribute((const void *)k_refine_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024)); attr_w = true; }
     hipLaunchKernelGGL(k_refine_wave, dim3((unsigned)a.n_task), dim3(64), wave_lds, g_stream, a);
     FQ_HIP(hipGetLastError());
     return 0;
   }
   const size_t lds = (size_t)3 * (a.RL + 1) * 64 * 4;
   if (lds <= kLdsBudget) {
-    static std::atomic<bool> attr_set{false};
-    if (!attr_set) { FQ_HIP(hipFuncSetAttribute((const void *)k_refine_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget)); attr_set = true; }
     hipLaunchKernelGGL(k_refine_lds, dim3(nblk((uint64_t)a.n_task, 64)), dim3(64), lds, g_stream, a);
   } else {
     hipLaunchKernelGGL(k_refine, dim3(nblk((uint64_t)a.n_task, 64)), dim3(64), 0, g_stream, a);
@@ -776,6 +896,15 @@ int launch_pack_md(const char *src, const int32_t *len, const uint64_t *off, int
   if (n <= 0) return 0;
   hipLaunchKernelGGL(k_pack_md, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, src, len, off, cap, n, dst);
   FQ_HIP(hipGetLastError());
+  return 0;
+}
+
+// dynamic-LDS limits of the kernels that ask for more than the default 64 KB: once per device (state_create)
+static int set_kernel_attributes() {
+  FQ_HIP(hipFuncSetAttribute((const void *)k_sw_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+  FQ_HIP(hipFuncSetAttribute((const void *)k_refine_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+  FQ_HIP(hipFuncSetAttribute((const void *)k_refine_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
+  FQ_HIP(hipFuncSetAttribute((const void *)k_gap_persist_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
   return 0;
 }
 

@@ -392,7 +392,12 @@ int load_fm(const std::string &prefix, const char *bext, const char *sext, fq_in
 extern "C" int fq_index_load(const char *prefix_c, int device_ordinal, fq_index_t **out) {
   if (!prefix_c || !out) return FQ_EINVAL;
   *out = nullptr;
-  if (fqdev::init(device_ordinal)) return FQ_ENODEV;
+  // the load has its own short-lived device state (stream for the staging copies); it ends with the load
+  struct DevScope {
+    fqdev::State *s;
+    ~DevScope() { fqdev::state_destroy(s); }
+  } scope{fqdev::state_create(device_ordinal)};
+  if (!scope.s || fqdev::bind(scope.s)) return FQ_ENODEV;
   std::unique_ptr<fq_index> ix(new fq_index);
   ix->prefix = prefix_c;
   ix->device = device_ordinal;

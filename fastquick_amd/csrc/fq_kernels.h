@@ -304,6 +304,167 @@ FQ_HD void fq_prep_thread(const FqPrepArgs &A, int r) {
   A.filtered[r] = filt;
 }
 
+// ---- K_prep, packed input: the k-mer filter over the three 32-mers of a read's first 96 bases --------------------------------
+// A packed batch (fq_packed_batch_t) carries, for every read, the three 64-bit k-mers exactly as IsReadInHashByCountMoreChunck
+// forms them (kmer = kmer << 2 | code over S[32i .. 32i+31], a non-ACGT code OR-ed in unmasked: src/BwtIndexer.cpp:441-456): that
+// is the 2-bit packing of the first 96 bases in the filter's own bit order, 24 bytes per read, and all the filter needs.  The
+// full reads of the few surviving pairs follow later (fq_unpack_thread).  Layout: head[ch][r], ch = 0..2 (three arrays of n_reads
+// words, so that a wavefront's loads are contiguous).
+struct FqPrepPackedArgs {
+  FqDevIndex ix;
+  FqKOpts o;
+  const uint64_t *head;    // [3][n_reads]
+  const uint16_t *len;     // [n_reads] or NULL: every read has uniform_len bases
+  int32_t uniform_len;
+  int32_t n_reads;
+  uint8_t *filtered;       // out: 1 = filtered
+  int32_t *sub_max;        // out: [pair / batch_pairs] longest read (untrimmed) over both ends; only written when len != NULL
+  int32_t n_pairs, batch_pairs;
+  uint64_t *counters;      // FQ_C_PROBES, FQ_C_BASES (ragged), FQ_C_BADLEN (ragged)
+};
+FQ_HD void fq_prep_packed_thread(const FqPrepPackedArgs &A, int r) {
+  if (A.len) {
+    const int len = A.len[r];
+    const int slot = (r >= A.n_pairs ? r - A.n_pairs : r) / A.batch_pairs;
+    FQ_ATOMIC_MAX32(&A.sub_max[slot], len);
+    FQ_ATOMIC_ADD64(&A.counters[FQ_C_BASES], (uint64_t)len);
+    if (len < FQ_LMIN || len > FQ_LMAX) FQ_ATOMIC_ADD64(&A.counters[FQ_C_BADLEN], 1);
+  }
+  uint8_t filt = 0;
+  if (A.o.filter_thresh != 0) {
+    uint64_t kmer[3];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) kmer[ch] = A.head[(size_t)ch * (size_t)A.n_reads + (size_t)r];
+    const int th = A.o.filter_thresh;
+    uint8_t byte[18];
+    uint32_t bit[18], off[18];
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+      for (int t = 0; t < 6; ++t) {
+        const uint32_t x = fq_kmer_project(kmer[ch], t);
+        off[6 * ch + t] = x >> 3;
+        bit[6 * ch + t] = x & 7u;
+      }
+    // as in fq_prep_thread: 16 probes in flight, the last two only when they can change the verdict
+#pragma unroll
+    for (int q = 0; q < 16; ++q) byte[q] = A.ix.bitmap[q % 6][off[q]];
+    byte[16] = byte[17] = 0;
+    if (th < 3) { byte[16] = A.ix.bitmap[4][off[16]]; byte[17] = A.ix.bitmap[5][off[17]]; }
+    int c16 = 0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) c16 += (byte[q] >> bit[q]) & 1;
+    if (th >= 3 && c16 + 2 >= th) { byte[16] = A.ix.bitmap[4][off[16]]; byte[17] = A.ix.bitmap[5][off[17]]; }
+    int cnt[3] = {0, 0, 0};
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch)
+#pragma unroll
+      for (int t = 0; t < 6; ++t) cnt[ch] += (byte[6 * ch + t] >> bit[6 * ch + t]) & 1;
+    const bool p0 = cnt[0] >= th, p1 = cnt[0] + cnt[1] >= th, p2 = cnt[0] + cnt[1] + cnt[2] >= th;
+    filt = p2 ? 0 : 1;
+    const uint32_t probes = p0 ? 6u : p1 ? 12u : 18u;
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t ps = probes;   // one atomic per wavefront
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) ps += (uint32_t)__shfl_xor((int)ps, d);
+    if (__lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) FQ_ATOMIC_ADD64(&A.counters[FQ_C_PROBES], ps);
+#else
+    FQ_ATOMIC_ADD64(&A.counters[FQ_C_PROBES], probes);
+#endif
+  }
+  A.filtered[r] = filt;
+}
+
+// ---- survivors of a packed batch: 2-bit rows -> the ASCII rows every later kernel reads --------------------------------------------
+// Compact row t = 2*sp + e (survivor pair sp, end e).  Its packed row is body[src(t)], src(t) = row_map ? row_map[t] : t:
+// the host either gathered the survivors' rows into a staging buffer (few survivors: identity map) or uploaded the whole batch
+// (row_map = the read's row in the batch).  Base i of a row sits in byte i>>2 at bit 2*(i&3); a non-ACGT base holds 0 there and is
+// listed in the exception array, applied afterwards by fq_patch_thread.
+struct FqUnpackArgs {
+  const uint8_t *body;
+  int32_t body_stride;
+  const int32_t *row_map;   // NULL: identity
+  const uint16_t *len;      // indexed like body rows; NULL: uniform_len
+  int32_t uniform_len;
+  int32_t n_rows;           // compact rows
+  uint8_t *seq;             // out: [n_rows][stride] ASCII
+  int32_t stride;
+  int32_t *len_out;         // out: [n_rows] read length (also the untrimmed len_trim)
+  int32_t *len_trim;        // out: [n_rows]
+};
+FQ_HD void fq_unpack_thread(const FqUnpackArgs &A, int t) {
+  const size_t src = A.row_map ? (size_t)A.row_map[t] : (size_t)t;
+  const uint8_t *b = A.body + src * (size_t)A.body_stride;
+  const int len = A.len ? (int)A.len[src] : A.uniform_len;
+  uint8_t *row = A.seq + (size_t)t * (size_t)A.stride;
+  for (int i0 = 0; i0 < len; i0 += 4) {
+    const uint32_t v = b[i0 >> 2];
+    for (int j = 0; j < 4 && i0 + j < len; ++j) row[i0 + j] = (uint8_t)"ACGT"[(v >> (2 * j)) & 3u];
+  }
+  for (int i = len; i < A.stride; ++i) row[i] = 0;
+  A.len_out[t] = len;
+  A.len_trim[t] = len;
+}
+// exception e: row << 32 | pos << 8 | code (4: 'N', any other letter; 5: '-'); row is a batch row, mapped through crow_of (compact
+// row or -1) when given, else already a compact row
+struct FqPatchArgs {
+  const uint64_t *exc;
+  int64_t n_exc;
+  const int32_t *crow_of;
+  uint8_t *seq;
+  int32_t stride;
+};
+FQ_HD void fq_patch_thread(const FqPatchArgs &A, int64_t q) {
+  const uint64_t e = A.exc[q];
+  int64_t row = (int64_t)(e >> 32);
+  if (A.crow_of) row = A.crow_of[row];
+  if (row < 0) return;
+  const int pos = (int)((e >> 8) & 0xffffu), code = (int)(e & 0xffu);
+  if (pos < A.stride) A.seq[(size_t)row * (size_t)A.stride + (size_t)pos] = (uint8_t)(code == 5 ? '-' : 'N');
+}
+// bwa_trim_read (libbwa/bwaseqio.c:75-88) for the rows that were unpacked; qual rows are indexed like body rows
+struct FqTrimArgs {
+  FqKOpts o;
+  const uint8_t *qual;
+  int32_t qual_stride;
+  const int32_t *row_map;   // compact row -> qual row (NULL: identity)
+  const int32_t *len;       // [n_rows] compact
+  int32_t n_rows;
+  int32_t *len_trim;        // out [n_rows]
+};
+FQ_HD int fq_trim_len(const FqKOpts &o, const uint8_t *q, int full) {
+  int s = 0, mx = 0, max_l = full - 1;
+  const int qsub = (o.mode & FQ_MODE_IL13) ? 31 : 0;
+  for (int l = full - 1; l >= 34; --l) {
+    s += o.trim_qual - ((int)(uint8_t)(q[l] - qsub) - 33);
+    if (s < 0) break;
+    if (s > mx) { mx = s; max_l = l; }
+  }
+  return max_l + 1;
+}
+FQ_HD void fq_trim_thread(const FqTrimArgs &A, int t) {
+  const size_t src = A.row_map ? (size_t)A.row_map[t] : (size_t)t;
+  A.len_trim[t] = fq_trim_len(A.o, A.qual + src * (size_t)A.qual_stride, A.len[t]);
+}
+// the same over every read of a batch (debug dumps, and the rare call in which no surviving read of some reference batch kept its
+// full length, so that the batch's longest trimmed read may be a filtered one): len_trim[r] for all rows, sub_max per reference batch
+struct FqTrimAllArgs {
+  FqKOpts o;
+  const uint8_t *qual;
+  int32_t qual_stride;
+  const uint16_t *len;      // NULL: uniform_len
+  int32_t uniform_len;
+  int32_t n_reads, n_pairs, batch_pairs;
+  int32_t *len_trim;        // out [n_reads]
+  int32_t *sub_max;         // out (zeroed by the caller)
+};
+FQ_HD void fq_trim_all_thread(const FqTrimAllArgs &A, int r) {
+  const int full = A.len ? (int)A.len[r] : A.uniform_len;
+  const int lt = fq_trim_len(A.o, A.qual + (size_t)r * (size_t)A.qual_stride, full);
+  A.len_trim[r] = lt;
+  FQ_ATOMIC_MAX32(&A.sub_max[(r >= A.n_pairs ? r - A.n_pairs : r) / A.batch_pairs], lt);
+}
+
 // ---- what the host needs to know about the reads of surviving pairs (everything else stays on the device) ----
 struct FqSurvInfo { int32_t len_trim, filtered, sidx; };
 FQ_HD void fq_surv_gather_thread(const int32_t *pair_list, int n_pairs, const int32_t *len_trim, const uint8_t *filtered, const int32_t *sidx, FqSurvInfo *out, int t) {
@@ -312,6 +473,20 @@ FQ_HD void fq_surv_gather_thread(const int32_t *pair_list, int n_pairs, const in
   FqSurvInfo v;
   v.len_trim = len_trim[r]; v.filtered = filtered[r]; v.sidx = sidx[r];
   out[t] = v;
+}
+
+// packed batches: the same for compact rows -- out[t].len_trim is filled in later; row_map[t] = the read's row in the batch,
+// read_list_c[s] = t for searched reads (search index -> compact row), crow_of[r] = t when the whole batch was uploaded
+FQ_HD void fq_surv_map_thread(const int32_t *pair_list, int n_pairs, const uint8_t *filtered, const int32_t *sidx, FqSurvInfo *out,
+                              int32_t *row_map, int32_t *read_list_c, int32_t *crow_of, int t) {
+  const int sp = t >> 1, e = t & 1;
+  const int r = e * n_pairs + pair_list[sp];
+  FqSurvInfo v;
+  v.len_trim = 0; v.filtered = filtered[r]; v.sidx = sidx[r];
+  out[t] = v;
+  row_map[t] = r;
+  if (v.sidx >= 0) read_list_c[v.sidx] = t;
+  if (crow_of) crow_of[r] = t;
 }
 
 // ---- read access helpers: seq[0] is the reversed read, seq[1] its complement (reverse complement

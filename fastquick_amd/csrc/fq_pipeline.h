@@ -6,7 +6,7 @@
 #include <vector>
 
 #include "../../include/fastquick_amd.h"
-#include "fq_common.h"
+#include "fq_kernels.h"
 
 struct FqMulti {             // bwt_multi1_t while it is being built
   uint32_t pos = 0;
@@ -18,6 +18,7 @@ struct FqMulti {             // bwt_multi1_t while it is being built
 
 struct FqRead {              // the bwa_seq_t fields the hot path writes (libbwa/bwtaln.h:57-86)
   int r = 0;                 // row in the input batch: end*n_pairs + pair
+  int dr = 0;                // row of the read's ASCII copy on the device (= r for ASCII input; 2*survivor + end for packed input)
   int len = 0, full_len = 0, clip_len = 0;
   int filtered = 0, type = 0, strand = 0, extra_flag = 0;
   int n_mm = 0, n_gapo = 0, n_gape = 0, mapQ = 0, seQ = 0, score = 0;
@@ -30,7 +31,7 @@ struct FqRead {              // the bwa_seq_t fields the hot path writes (libbwa
   std::vector<uint16_t> cigar;
   std::string md;
   void reset() {             // back to a fresh record, keeping the containers' storage (records are reused from call to call)
-    r = 0; len = full_len = clip_len = 0; filtered = type = strand = extra_flag = 0;
+    r = dr = 0; len = full_len = clip_len = 0; filtered = type = strand = extra_flag = 0;
     n_mm = n_gapo = n_gape = mapQ = seQ = score = 0; sa = pos = c1 = c2 = 0; main_aln = 0; nm = 0; has_md = false; revived = false;
     multi.clear(); cigar.clear(); md.clear();
   }
@@ -118,5 +119,26 @@ struct FqBatchState {
 struct fq_index;
 const FqBatchState *fq_ctx_state(const fq_ctx_t *c);
 const fq_index *fq_ctx_index(const fq_ctx_t *c);
-const fq_read_batch_t *fq_ctx_host_batch(const fq_ctx_t *c);
+// The caller's batch as the host-side consumers read it: ASCII rows (fq_read_batch_t) or a packed batch (fq_packed_batch_t).
+struct FqHostReads {
+  const fq_read_batch_t *a = nullptr;
+  const fq_packed_batch_t *p = nullptr;
+  int n_pairs = 0;
+  const char *names = nullptr, *names_mate = nullptr;
+  int name_stride = 0;
+  int len(size_t r) const { return a ? a->len[r] : (p->uniform_len > 0 ? p->uniform_len : (int)p->len[r]); }
+  // nst_nt4_table codes of the first n bases of row r
+  void codes(size_t r, int n, uint8_t *out) const {
+    if (a) { const uint8_t *row = a->seq + r * (size_t)a->stride; for (int j = 0; j < n; ++j) out[j] = (uint8_t)fq_nt4(row[j]); return; }
+    const uint8_t *b = p->body + r * (size_t)p->body_stride;
+    for (int j = 0; j < n; ++j) out[j] = (uint8_t)((b[j >> 2] >> (2 * (j & 3))) & 3);
+    if (p->n_exc) {
+      const uint64_t *lo = std::lower_bound(p->exc, p->exc + p->n_exc, (uint64_t)r << 32);
+      for (; lo < p->exc + p->n_exc && (*lo >> 32) == (uint64_t)r; ++lo) { const int pos = (int)((*lo >> 8) & 0xffff); if (pos < n) out[pos] = (uint8_t)(*lo & 0xff); }
+    }
+  }
+  const uint8_t *qual(size_t r) const { return a ? a->qual + r * (size_t)a->stride : p->qual + r * (size_t)p->qual_stride; }
+  bool has_qual() const { return a ? a->qual != nullptr : p->qual != nullptr; }
+};
+FqHostReads fq_ctx_host_reads(const fq_ctx_t *c);
 const fq_opts_t *fq_ctx_opts(const fq_ctx_t *c);

@@ -59,7 +59,7 @@ int64_t ref_end_multi(const FqMulti &q, int len) {
 }
 int64_t five_prime(const FqRead &p) { return p.type != FQ_TYPE_NO_MATCH ? (p.strand ? ref_end(p) : (int64_t)p.pos) : -1; }
 
-std::string read_name(const fq_read_batch_t *hb, int pair, int end, bool revived) {
+std::string read_name(const FqHostReads *hb, int pair, int end, bool revived) {
   if (!hb->names) return "*";
   const char *nm = (end && hb->names_mate ? hb->names_mate : hb->names) + (size_t)pair * (size_t)hb->name_stride;
   std::string s(nm, strnlen(nm, (size_t)hb->name_stride));
@@ -73,9 +73,11 @@ std::string read_name(const fq_read_batch_t *hb, int pair, int end, bool revived
   return s;
 }
 
-void print_sam(const fq_index *ix, const fq_opts_t *o, const fq_read_batch_t *hb, int n_pairs, Out &out, FqRead p, const FqRead &mate) {
+void print_sam(const fq_index *ix, const fq_opts_t *o, const FqHostReads *hb, int n_pairs, Out &out, FqRead p, const FqRead &mate) {
   const int pair = p.r % n_pairs;
-  const uint8_t *seq = hb->seq + (size_t)p.r * (size_t)hb->stride, *qual = hb->qual + (size_t)p.r * (size_t)hb->stride;
+  uint8_t seq[FQ_LMAX + 8];
+  hb->codes((size_t)p.r, p.full_len, seq);
+  const uint8_t *qual = hb->qual((size_t)p.r);
   const std::string name = read_name(hb, pair, p.r / n_pairs, p.revived);
   // only called when at least one mate is mapped (both-unmapped pairs are dropped before, BwtMapper.cpp:2038)
   int seqid, nn, am = 0, flag = p.extra_flag, j;
@@ -98,8 +100,8 @@ void print_sam(const fq_index *ix, const fq_opts_t *o, const fq_read_batch_t *hb
     if (p.type == FQ_TYPE_NO_MATCH) isize = 0;
     out.printf("%d\t%lld\t", (int)(mate.pos - ix->contigs[m_seqid].offset + 1), isize);
   } else out.printf("\t=\t%d\t0\t", (int)(p.pos - ix->contigs[seqid].offset + 1));
-  if (p.strand == 0) for (j = 0; j < p.full_len; ++j) out.putc("ACGTN"[fq_nt4(seq[j]) > 4 ? 4 : fq_nt4(seq[j])]);
-  else for (j = 0; j < p.full_len; ++j) { const int cc = fq_nt4(seq[p.full_len - 1 - j]); out.putc("TGCAN"[cc > 4 ? 4 : cc]); }
+  if (p.strand == 0) for (j = 0; j < p.full_len; ++j) out.putc("ACGTN"[seq[j] > 4 ? 4 : seq[j]]);
+  else for (j = 0; j < p.full_len; ++j) { const int cc = seq[p.full_len - 1 - j]; out.putc("TGCAN"[cc > 4 ? 4 : cc]); }
   out.putc('\t');
   // Phred+64 input: the reference takes 31 off every quality byte on input (BwtMapper.cpp:549-553) and puts it back on the first
   // len bytes only when it prints (bwase.c:516-519), so the clipped tail of a trimmed read comes out 31 lower than it went in
@@ -155,8 +157,9 @@ extern "C" int64_t fq_sam_format_last(fq_ctx_t *c, char *buf, int64_t cap) {
   if (!c) return FQ_EINVAL;
   const FqBatchState *S = fq_ctx_state(c);
   const fq_index *ix = fq_ctx_index(c);
-  const fq_read_batch_t *hb = fq_ctx_host_batch(c);
+  const FqHostReads hbv = fq_ctx_host_reads(c), *hb = &hbv;
   const fq_opts_t *o = fq_ctx_opts(c);
+  if (S->n_surv > 0 && !hb->has_qual()) return FQ_EINVAL;
   Out out;
   out.s.reserve((size_t)S->n_surv * 900);
   for (int sp = 0; sp < S->n_surv; ++sp) {
@@ -171,7 +174,7 @@ extern "C" int64_t fq_sam_format_last(fq_ctx_t *c, char *buf, int64_t cap) {
 extern "C" int64_t fq_stage_dump_last(fq_ctx_t *c, char *buf, int64_t cap) {
   if (!c) return FQ_EINVAL;
   const FqBatchState *S = fq_ctx_state(c);
-  const fq_read_batch_t *hb = fq_ctx_host_batch(c);
+  const FqHostReads hbv = fq_ctx_host_reads(c), *hb = &hbv;
   const uint8_t *filt; const int32_t *ltrim;
   fq_ctx_all_reads(c, &filt, &ltrim);
   if (S->n_pairs > 0 && (!filt || !ltrim)) return FQ_EINVAL;   // per-read arrays of the whole batch are only fetched in debug mode
@@ -185,7 +188,7 @@ extern "C" int64_t fq_stage_dump_last(fq_ctx_t *c, char *buf, int64_t cap) {
     const int i0 = sb * Bp, i1 = std::min(n, i0 + Bp);
     o.printf("B %d %d\n", sb, i1 - i0);
     for (int e = 0; e < 2; ++e)
-      for (int i = i0; i < i1; ++i) o.printf("F %d %d filt=%d len=%d clip=%d full=%d\n", e, i - i0, filt[e * n + i], ltrim[e * n + i], ltrim[e * n + i], hb->len[e * n + i]);
+      for (int i = i0; i < i1; ++i) o.printf("F %d %d filt=%d len=%d clip=%d full=%d\n", e, i - i0, filt[e * n + i], ltrim[e * n + i], ltrim[e * n + i], hb->len((size_t)e * n + i));
     for (int e = 0; e < 2; ++e)
       for (int i = i0; i < i1; ++i) {
         const int sp = surv_of[i];
@@ -212,7 +215,7 @@ extern "C" int64_t fq_stage_dump_last(fq_ctx_t *c, char *buf, int64_t cap) {
           const int sp = surv_of[i];
           if (sp >= 0) { dump_rec(o, tags[st], e, i - i0, (*stages[st])[2 * sp + e], st == 2); continue; }
           FqRead d;   // both mates filtered: untouched record (bwa_clean_read_seq state + flags of BwtMapper.cpp:749)
-          d.filtered = 1; d.extra_flag = 1 | (e == 0 ? 64 : 128); d.len = ltrim[e * n + i]; d.full_len = hb->len[e * n + i];
+          d.filtered = 1; d.extra_flag = 1 | (e == 0 ? 64 : 128); d.len = ltrim[e * n + i]; d.full_len = hb->len((size_t)e * n + i);
           if (st == 2 && d.len != d.full_len) {   // bwa_correct_trimmed touches every record
             d.cigar.push_back((uint16_t)(FQ_OP_M << 14 | d.len)); d.cigar.push_back((uint16_t)(FQ_OP_S << 14 | (d.full_len - d.len))); d.len = d.full_len;
           }

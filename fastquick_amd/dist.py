@@ -39,6 +39,11 @@ def _dev():
     return "cuda" if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu"
 
 
+def world_size() -> int:
+    """Ranks the collective backend (RCCL / gloo) actually sees; 1 without a process group."""
+    return dist.get_world_size() if dist.is_initialized() else 1
+
+
 def barrier() -> None:
     if dist.is_initialized():
         dist.barrier()

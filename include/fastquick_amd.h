@@ -161,10 +161,59 @@ int fq_ctx_set_debug(fq_ctx_t *c, int keep_stage_snapshots);
  * bwape.c:463) and refinement (bwa_refine_gapped bwase.c:339). */
 int fq_align_batch(fq_ctx_t *c, const fq_read_batch_t *in, fq_result_batch_t *out);
 
-/* Same, split so that a caller (bench.py) can stage inputs into HBM outside its timed region:
- * fq_batch_upload copies the batch to the device; fq_align_resident runs the path on it. */
+/* Same, split so that a caller can stage inputs into HBM ahead of the run:
+ * fq_batch_upload copies the batch to the device; fq_align_resident runs the path on it.
+ * Lifetime: the records and the fq_*_last formatters refer to the caller's arrays (lengths, names, bases, qualities) -- they
+ * must stay valid and unchanged until the next fq_batch_upload / fq_align_* call on the context, or its destruction. */
 int fq_batch_upload(fq_ctx_t *c, const fq_read_batch_t *in);
 int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out);
+
+/* ---- packed batches: the measured boundary of SURVEY.md 8(d) -------------------------------------------------------------
+ * "Decoded read batch, packed, in pinned host memory" -> "result records in host memory".  A packed batch is what a FASTQ
+ * front end hands over instead of the bwa_seq_t::seq byte arrays of bwa_read_seq_with_hash_dev (src/BwtMapper.cpp:526-547):
+ *   head  the three 32-mers of every read's first 96 bases exactly as the read filter forms them
+ *         (IsReadInHashByCountMoreChunck, src/BwtIndexer.cpp:441-456: kmer = kmer << 2 | code, a non-ACGT code OR-ed in unmasked;
+ *         for a read shorter than 96 bp the row bytes behind it count as in fq_read_batch_t): 24 bytes per read, stored as
+ *         three arrays head[ch][row], ch = 0..2 -- all the filter needs, and the only part of a filtered read that crosses PCIe;
+ *   body  every read 2-bit packed (A0 C1 G2 T3; base i in byte i >> 2 at bit 2 * (i & 3)); a non-ACGT base holds 0 and is
+ *         listed in exc as row << 32 | position << 8 | code (nst_nt4_table: 4 = N / any other character, 5 = '-'), ascending;
+ *   qual  ASCII quality rows; len the read lengths (NULL when uniform_len > 0).
+ * Rows are numbered end * n_pairs + pair.  The library uploads head for all reads and body (+ qual when --q trimming is on)
+ * for the reads of surviving pairs only.  Arrays should be pinned (fq_pinned_alloc) for the upload to overlap compute; the
+ * lifetime rule of fq_batch_upload applies. */
+typedef struct {
+  int32_t n_pairs;
+  int32_t uniform_len;        /* > 0: every read has this many bases (len may be NULL) */
+  const uint64_t *head;       /* [3][2 * n_pairs] */
+  const uint8_t *body;        /* [2 * n_pairs][body_stride] */
+  int32_t body_stride;
+  int32_t qual_stride;
+  const uint16_t *len;        /* [2 * n_pairs] or NULL */
+  const uint64_t *exc;        /* [n_exc], ascending */
+  int64_t n_exc;
+  const uint8_t *qual;        /* [2 * n_pairs][qual_stride] */
+  const char *names;          /* as in fq_read_batch_t */
+  int32_t name_stride;
+  const char *names_mate;
+} fq_packed_batch_t;
+
+void *fq_pinned_alloc(size_t bytes);   /* page-locked host memory (hipHostMalloc); NULL on failure */
+void fq_pinned_free(void *p);
+/* Packs an ASCII batch (the tokenizer's output) on `threads` host threads into pinned storage.  qual / names of the result
+ * alias the input's arrays (they are only read for surviving pairs).  Free with fq_packed_free. */
+int fq_pack_reads(const fq_read_batch_t *in, int threads, fq_packed_batch_t **out);
+void fq_packed_free(fq_packed_batch_t *b);
+/* Starts the upload of `next`'s head on the context's copy stream and returns: it runs under the kernels of the
+ * fq_align_packed call that follows for the current batch -- the overlap the reference gets from its IO worker reading
+ * batch k+1 while batch k is aligned (IOworkerAlt, src/BwtMapper.cpp:1973-1980, 2095-2104).  Optional. */
+int fq_packed_prefetch(fq_ctx_t *c, const fq_packed_batch_t *next);
+/* The whole hot path on a packed batch, host memory in -> host memory out. */
+int fq_align_packed(fq_ctx_t *c, const fq_packed_batch_t *in, fq_result_batch_t *out);
+
+/* Experiment / test knobs by name (defaults are what DESIGN.md measures): gap_long_pops, gap_long_always, gap_pool,
+ * gap_no_order, gap_order_asc, gap_waves_per_cu, gap_refill_min, sw_wave_max, host_threads, host_par_min, filter_no_turns,
+ * refine_lanes, packed_bulk_min, trace.  FQ_EINVAL for an unknown key. */
+int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t value);
 
 /* ---- consumers ---------------------------------------------------------------------------
  * SAM text in the --sam_out dialect of bwa_print_sam1 (libbwa/bwase.c:455-581): header, then the
@@ -202,6 +251,7 @@ typedef struct {
   double host_ms_serial, host_ms_pair, host_ms_total, wall_ms_total;
   uint64_t wave_trips;          /* loop iterations summed over the gap kernel's wavefronts */
   uint64_t lane_trips;          /* ... summed over lanes that held a read in that iteration (wave_trips x 64 = all slots) */
+  uint64_t h2d_bytes, d2h_bytes; /* bytes the calls moved over PCIe (inputs, task lists; results) */
 } fq_stats_t;
 void fq_stats_get(const fq_ctx_t *c, fq_stats_t *out);
 void fq_stats_reset(fq_ctx_t *c);

@@ -14,7 +14,14 @@
 
 namespace fqdev {
 static std::string g_err;
-int init(int) { return 0; }
+struct State { Tune tune; };
+State *state_create(int) { return new State; }
+void state_destroy(State *s) { delete s; }
+int bind(State *) { return 0; }
+Tune *tune(State *s) { return &s->tune; }
+int h2d_copy(void *d, const void *s, size_t n) { if (n) memcpy(d, s, n); return 0; }
+int copy_record(int) { return 0; }
+int compute_wait_copy(int) { return 0; }
 const char *last_error() { return g_err.c_str(); }
 bool is_real_gpu() { return false; }
 void *dmalloc(size_t b) { return calloc(b ? b : 16, 1); }
@@ -24,6 +31,7 @@ void hfree(void *p) { free(p); }
 int h2d(void *d, const void *s, size_t n) { if (n) memcpy(d, s, n); return 0; }
 int d2h(void *d, const void *s, size_t n) { if (n) memcpy(d, s, n); return 0; }
 int dzero(void *d, size_t n) { if (n) memset(d, 0, n); return 0; }
+int dfill(void *d, int b, size_t n) { if (n) memset(d, b, n); return 0; }
 int sync() { return 0; }
 void time_begin(int) {}
 void time_end(int) {}
@@ -45,6 +53,16 @@ int launch_surv_gather(const int32_t *pair_list, int n_surv, int n_pairs, const 
   for (int t = 0; t < 2 * n_surv; ++t) fq_surv_gather_thread(pair_list, n_pairs, len_trim, filtered, sidx, out, t);
   return 0;
 }
+int launch_prep_packed(const FqPrepPackedArgs &a) { for (int r = 0; r < a.n_reads; ++r) fq_prep_packed_thread(a, r); return 0; }
+int launch_surv_map(const int32_t *pair_list, int n_surv, int n_pairs, const uint8_t *filtered, const int32_t *sidx, FqSurvInfo *out,
+                    int32_t *row_map, int32_t *read_list_c, int32_t *crow_of) {
+  for (int t = 0; t < 2 * n_surv; ++t) fq_surv_map_thread(pair_list, n_pairs, filtered, sidx, out, row_map, read_list_c, crow_of, t);
+  return 0;
+}
+int launch_unpack(const FqUnpackArgs &a) { for (int t = 0; t < a.n_rows; ++t) fq_unpack_thread(a, t); return 0; }
+int launch_patch(const FqPatchArgs &a) { for (int64_t q = 0; q < a.n_exc; ++q) fq_patch_thread(a, q); return 0; }
+int launch_trim(const FqTrimArgs &a) { for (int t = 0; t < a.n_rows; ++t) fq_trim_thread(a, t); return 0; }
+int launch_trim_all(const FqTrimAllArgs &a) { for (int r = 0; r < a.n_reads; ++r) fq_trim_all_thread(a, r); return 0; }
 int launch_width(const FqWidthArgs &a) { uint8_t seed_bits[FQ_SEED_MAX]; for (int t = 0; t < a.n_work * 2; ++t) fq_width_thread(a, t, seed_bits, 1); return 0; }
 int launch_order(const uint8_t *bid_end, int n, int32_t *order, uint32_t *) {
   int at = 0;

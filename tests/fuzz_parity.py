@@ -55,17 +55,17 @@ for seed in range(args.start, args.start + args.seeds):
         elif o == "max_isize": okw["max_isize"] = rnd.choice([200, 1000])
         elif o == "e": okw["max_gape"] = rnd.choice([2, 6]); okw["mode"] = okw.get("mode", 3) & ~1
     mode = rnd.choice(["lanes", "lanes", "wave1", "wave64"])
-    for k in ("FQ_GAP_LONG_POPS", "FQ_GAP_LONG_ALWAYS"):
-        os.environ.pop(k, None)
+    tuning = {}
     if mode != "lanes":
-        os.environ["FQ_GAP_LONG_POPS"] = "1" if mode == "wave1" else "64"
-        os.environ["FQ_GAP_LONG_ALWAYS"] = "1"
+        tuning = {"gap_long_pops": 1 if mode == "wave1" else 64, "gap_long_always": 1}
+    packed = rnd.random() < 0.5
+    if packed:
+        tuning["packed_bulk_min"] = rnd.choice([0, 1 << 30])
     n, batch = rnd.choice([(1500, 600), (3000, 3000), (5000, 2048), (12000, 4000)])
     call = batch * rnd.choice([1, 1, 2, 3])            # several reference batches per call
     threads = rnd.choice([0, 0, 3, 8])
-    os.environ.pop("FQ_HOST_PAR_MIN", None)
     if threads:
-        os.environ["FQ_HOST_PAR_MIN"] = "1"
+        tuning["host_par_min"] = 1
     t0 = time.time()
     ref = synth.make_reference(**refkw)
     pre = os.path.join(d, "ref.FASTQuick.fa")
@@ -79,15 +79,15 @@ for seed in range(args.start, args.start + args.seeds):
         rb.lens[:] = np.random.default_rng(seed).integers(lo, read_len + 1, rb.lens.shape)
         ob.apply_slot_history(rb.seq, rb.lens, batch)
     ix = api.Index(pre, device=0)
-    al = api.Aligner(ix, api.default_opts(lib, batch_pairs=batch, host_threads=threads, **okw), max_pairs=call, debug=True)
-    api.align_stream(al, rb.names, rb.seq, rb.qual, rb.lens, call, d + "/g.st", d + "/g.sam")
+    al = api.Aligner(ix, api.default_opts(lib, batch_pairs=batch, host_threads=threads, **okw), max_pairs=call, debug=True, tuning=tuning)
+    api.align_stream(al, rb.names, rb.seq, rb.qual, rb.lens, call, d + "/g.st", d + "/g.sam", packed=packed)
     oa = ob.OracleAligner(pre, ob.default_opts(**okw))
     oa.align(rb.names, rb.seq, rb.qual, rb.lens, d + "/o.st", d + "/o.sam", batch=batch)
     diffs = [x for x in ob.diff_stage_files(d + "/o.st", d + "/g.st") if not x.startswith("line count")]
     same = filecmp.cmp(d + "/o.sam", d + "/g.sam", shallow=False)
     ok = not diffs and same
     bad += 0 if ok else 1
-    print("seed %3d %-6s len %3d n %5d call %5d thr %d %s retries %d  %.1fs  %s" % (seed, mode, read_len, n, call, threads, "OK  " if ok else "FAIL", al.stats()["tier_retries"], time.time() - t0,
+    print("seed %3d %-6s%s len %3d n %5d call %5d thr %d %s retries %d  %.1fs  %s" % (seed, mode, "+pk" if packed else "   ", read_len, n, call, threads, "OK  " if ok else "FAIL", al.stats()["tier_retries"], time.time() - t0,
                                                                     "" if ok else (str(refkw) + str(readkw) + str(okw) + " " + str(diffs[:3]))), flush=True)
     al.close(); ix.close(); oa.close()
 sys.exit(1 if bad else 0)

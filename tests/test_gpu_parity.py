@@ -23,15 +23,16 @@ def lib():
 # search_mode: "lanes" = the default tiering (one read per lane; the wavefront-per-read kernel only takes over long searches
 # once the queue is dry), "wave1"/"wave64" = hand every search over to the wavefront-per-read kernel after 1 / 64 pops, so
 # that its parallel rounds, commit rule and run bookkeeping are exercised by every read of the case
-SEARCH_MODES = {"lanes": {}, "wave1": {"FQ_GAP_LONG_POPS": "1", "FQ_GAP_LONG_ALWAYS": "1"},
+SEARCH_MODES = {"lanes": {}, "wave1": {"gap_long_pops": 1, "gap_long_always": 1},
                 # wave64 also sends every mate-SW window above 300 bases down the one-task-per-lane kernel (the path of oversize windows)
-                "wave64": {"FQ_GAP_LONG_POPS": "64", "FQ_GAP_LONG_ALWAYS": "1", "FQ_SW_WAVE_MAX": "300"}}
+                "wave64": {"gap_long_pops": 64, "gap_long_always": 1, "sw_wave_max": 300},
+                # the packed-batch boundary (fq_pack_reads -> fq_packed_prefetch -> fq_align_packed): survivors' rows gathered on the
+                # host / the whole body uploaded and gathered on the device
+                "packed": {"packed_bulk_min": 1 << 30}, "packed_bulk": {"packed_bulk_min": 0}}
 
 
 @pytest.fixture(params=list(SEARCH_MODES))
-def search_mode(request, monkeypatch):
-    for k, v in SEARCH_MODES[request.param].items():
-        monkeypatch.setenv(k, v)
+def search_mode(request):
     return request.param
 
 
@@ -40,9 +41,9 @@ def test_gpu_matches_reference_golden(tag, golden_cases, lib, search_mode):
     g = golden_cases[tag]
     names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
     ix = api.Index(g["prefix"], device=0)
-    al = api.Aligner(ix, api.default_opts(lib, trim_qual=g["trim_qual"]), max_pairs=max(16, g["batch"]), debug=True)
+    al = api.Aligner(ix, api.default_opts(lib, trim_qual=g["trim_qual"]), max_pairs=max(16, g["batch"]), debug=True, tuning=SEARCH_MODES[search_mode])
     st, sam = os.path.join(g["dir"], "gpu.stages"), os.path.join(g["dir"], "gpu.sam")
-    api.align_stream(al, names, seq, qual, lens, g["batch"], st, sam)
+    api.align_stream(al, names, seq, qual, lens, g["batch"], st, sam, packed=search_mode.startswith("packed"))
     stats = al.stats()
     al.close()
     ix.close()
@@ -50,7 +51,7 @@ def test_gpu_matches_reference_golden(tag, golden_cases, lib, search_mode):
     assert not diffs, "\n".join(diffs)
     assert filecmp.cmp(g["sam"], sam, shallow=False)
     assert stats["kernel_launches"][2] > 0, "the gap-search kernel did not run on the device"
-    if search_mode != "lanes":
+    if search_mode.startswith("wave"):
         assert stats["tier_retries"] > 0, "the wavefront-per-read kernel was not exercised"
 
 
@@ -73,8 +74,8 @@ def test_gpu_matches_oracle_on_fresh_inputs(tag, refkw, readkw, n, batch, q, lib
     api.build_index(pre)
     rb = synth.make_reads(ref, n, **readkw)
     ix = api.Index(pre, device=0)
-    al = api.Aligner(ix, api.default_opts(lib, trim_qual=q), max_pairs=batch, debug=True)
-    api.align_stream(al, rb.names, rb.seq, rb.qual, rb.lens, batch, str(tmp_path / "gpu.stages"), str(tmp_path / "gpu.sam"))
+    al = api.Aligner(ix, api.default_opts(lib, trim_qual=q), max_pairs=batch, debug=True, tuning=SEARCH_MODES[search_mode])
+    api.align_stream(al, rb.names, rb.seq, rb.qual, rb.lens, batch, str(tmp_path / "gpu.stages"), str(tmp_path / "gpu.sam"), packed=search_mode.startswith("packed"))
     oa = ob.OracleAligner(pre, ob.default_opts(trim_qual=q))
     oa.align(rb.names, rb.seq, rb.qual, rb.lens, str(tmp_path / "orc.stages"), str(tmp_path / "orc.sam"), batch=batch)
     diffs = [d for d in ob.diff_stage_files(str(tmp_path / "orc.stages"), str(tmp_path / "gpu.stages")) if not d.startswith("line count")]
@@ -175,8 +176,8 @@ OPTION_VARIANTS = [
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,okw", OPTION_VARIANTS, ids=[v[0] for v in OPTION_VARIANTS])
 def test_gpu_matches_oracle_with_option_variants(name, okw, lib, tmp_path, search_mode):
-    if search_mode == "wave64":
-        pytest.skip("covered by lanes and wave1")
+    if search_mode in ("wave64", "packed_bulk"):
+        pytest.skip("covered by lanes, wave1 and packed")
     ref = synth.make_reference(n_markers=120, n_long=12, seed=35, repeat_every=2, tandem_every=7)
     pre = str(tmp_path / "ref.FASTQuick.fa")
     ref.write_fasta(pre)
@@ -185,8 +186,8 @@ def test_gpu_matches_oracle_with_option_variants(name, okw, lib, tmp_path, searc
     if okw.get("mode", 0) & 0x200:
         rb.qual[rb.qual > 0] += 31
     ix = api.Index(pre, device=0)
-    al = api.Aligner(ix, api.default_opts(lib, **okw), max_pairs=1000, debug=True)
-    api.align_stream(al, rb.names, rb.seq, rb.qual, rb.lens, 1000, str(tmp_path / "gpu.stages"), str(tmp_path / "gpu.sam"))
+    al = api.Aligner(ix, api.default_opts(lib, **okw), max_pairs=1000, debug=True, tuning=SEARCH_MODES[search_mode])
+    api.align_stream(al, rb.names, rb.seq, rb.qual, rb.lens, 1000, str(tmp_path / "gpu.stages"), str(tmp_path / "gpu.sam"), packed=search_mode.startswith("packed"))
     oa = ob.OracleAligner(pre, ob.default_opts(**okw))
     oa.align(rb.names, rb.seq, rb.qual, rb.lens, str(tmp_path / "orc.stages"), str(tmp_path / "orc.sam"), batch=1000)
     diffs = [d for d in ob.diff_stage_files(str(tmp_path / "orc.stages"), str(tmp_path / "gpu.stages")) if not d.startswith("line count")]
@@ -238,3 +239,46 @@ def test_large_ontarget_call_matches_oracle_prefix_and_chunked_run(lib, tmp_path
     body = body[len(ix.sam_header()):] if body.startswith(ix.sam_header()) else body
     assert sam_one.startswith(body), "SAM text of the first three reference batches"
     oa.close(); ix.close()
+
+
+def test_packed_boundary_properties(lib, tmp_path):
+    """The measured boundary: packed batches in pinned host memory in, records in host memory out, the next batch's
+    upload running under this one's kernels.  A WGS-like stream of four calls of 262,144 pairs with N bases, quality trimming
+    (--q 15) and decaying qualities must give byte-identical SAM text through fq_align_batch (ASCII rows) and through
+    fq_pack_reads / fq_packed_prefetch / fq_align_packed, with and without the prefetch; the H2D volume must be the 48 bytes of
+    filter keys per pair plus the survivors' rows (and qualities), not the batch."""
+    ref = synth.make_reference(n_markers=1500, n_long=150, seed=71)
+    pre = str(tmp_path / "ref.FASTQuick.fa")
+    ref.write_fasta(pre)
+    api.build_index(pre)
+    n, calls = 262144, 4
+    rb = synth.make_reads(ref, n * calls, on_target=0.004, seed=72, n_rate=0.002, qual_decay=True, sub_rate=0.01)
+    ix = api.Index(pre, device=0)
+    opts = lambda: api.default_opts(lib, trim_qual=15)
+    al = api.Aligner(ix, opts(), max_pairs=n)
+    want = []
+    for k in range(calls):
+        sl = slice(k * n, (k + 1) * n)
+        al.align(rb.seq[:, sl], rb.qual[:, sl], rb.lens[:, sl], rb.names[sl])
+        want.append(al.sam_text())
+    al.close()
+    assert sum(len(w) for w in want) > 100000
+    packs = [api.HostPacked(rb.seq[:, k * n:(k + 1) * n], rb.qual[:, k * n:(k + 1) * n], rb.lens[:, k * n:(k + 1) * n], rb.names[k * n:(k + 1) * n]) for k in range(calls)]
+    for prefetch in (True, False):
+        al = api.Aligner(ix, opts(), max_pairs=n)
+        got = []
+        for k in range(calls):
+            if prefetch and k + 1 < calls:
+                al.prefetch(packs[k + 1])
+            res = al.align_packed(packs[k])
+            got.append(al.sam_text())
+            assert res.n_bases == int(rb.lens[:, k * n:(k + 1) * n].sum())
+        st = al.stats()
+        al.close()
+        assert got == want, "packed boundary (prefetch=%s) differs from the ASCII boundary" % prefetch
+        surv = st["reads_searched"]
+        assert st["h2d_bytes"] < 48 * n * calls + 1200 * surv + (1 << 20), st["h2d_bytes"]
+        assert st["h2d_bytes"] >= 48 * n * calls
+    for p in packs:
+        p.free()
+    ix.close()

@@ -20,20 +20,24 @@ def emu_lib():
     return api.load_library(os.path.join(EMU_DIR, "libfq_emu.so"))
 
 
-@pytest.mark.parametrize("mode", ["lanes", "wave", "threads"])
+@pytest.mark.parametrize("mode", ["lanes", "wave", "threads", "packed", "packed_bulk"])
 @pytest.mark.parametrize("tag", golden_util.case_tags())
-def test_emulated_pipeline_matches_reference_golden(tag, mode, golden_cases, emu_lib, monkeypatch):
+def test_emulated_pipeline_matches_reference_golden(tag, mode, golden_cases, emu_lib):
+    tuning = {}
     if mode == "wave":   # every search handed to the wavefront-per-read path (a one-lane wavefront here: its sequential rounds)
-        monkeypatch.setenv("FQ_GAP_LONG_POPS", "1")
-        monkeypatch.setenv("FQ_GAP_LONG_ALWAYS", "1")
+        tuning = {"gap_long_pops": 1, "gap_long_always": 1}
     if mode == "threads":   # the per-pair host phases split over threads even for these small inputs
-        monkeypatch.setenv("FQ_HOST_PAR_MIN", "1")
+        tuning = {"host_par_min": 1}
+    if mode == "packed_bulk":   # packed input with the whole body uploaded and gathered on the device (many survivors)
+        tuning = {"packed_bulk_min": 0}
+    if mode == "packed":        # ... with the survivors' rows gathered on the host (few survivors)
+        tuning = {"packed_bulk_min": 1 << 30}
     g = golden_cases[tag]
     names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
     ix = api.Index(g["prefix"], lib=emu_lib)
-    al = api.Aligner(ix, api.default_opts(emu_lib, trim_qual=g["trim_qual"], host_threads=3 if mode == "threads" else 0), max_pairs=max(16, g["batch"]), debug=True)
+    al = api.Aligner(ix, api.default_opts(emu_lib, trim_qual=g["trim_qual"], host_threads=3 if mode == "threads" else 0), max_pairs=max(16, g["batch"]), debug=True, tuning=tuning)
     st, sam = os.path.join(g["dir"], "emu.stages"), os.path.join(g["dir"], "emu.sam")
-    api.align_stream(al, names, seq, qual, lens, g["batch"], st, sam)
+    api.align_stream(al, names, seq, qual, lens, g["batch"], st, sam, packed=mode.startswith("packed"))
     al.close()
     ix.close()
     diffs = [d for d in ob.diff_stage_files(g["stages"], st) if not d.startswith("line count")]
