@@ -36,7 +36,7 @@ class ReadBatch(C.Structure):
 class PackedBatch(C.Structure):
     _fields_ = [("n_pairs", C.c_int32), ("uniform_len", C.c_int32), ("head", C.c_void_p), ("body", C.c_void_p),
                 ("body_stride", C.c_int32), ("qual_stride", C.c_int32), ("len", C.c_void_p), ("exc", C.c_void_p),
-                ("n_exc", C.c_int64), ("qual", C.c_void_p), ("names", C.c_void_p), ("name_stride", C.c_int32),
+                ("n_exc", C.c_int64), ("qual", C.c_void_p), ("qual_last", C.c_void_p), ("names", C.c_void_p), ("name_stride", C.c_int32),
                 ("names_mate", C.c_void_p)]
 
 

@@ -114,8 +114,9 @@ struct fq_ctx {
   // packed input: two head buffers (the next batch's head uploads while this one is aligned)
   DevBuf<uint64_t> d_head[2];
   DevBuf<uint16_t> d_hlen[2];
-  int head_slot = 0;
-  const fq_packed_batch_t *prefetched = nullptr;   // batch whose head sits in slot 1 - head_slot
+  DevBuf<uint8_t> d_qlast[2];
+  int head_slot = 0;                               // buffer of the current call
+  const fq_packed_batch_t *pend[2] = {nullptr, nullptr};   // batch whose head was prefetched into buffer i and not yet aligned
   DevBuf<uint8_t> d_body, d_pqual;
   DevBuf<uint64_t> d_exc;
   DevBuf<int32_t> d_row_map, d_crow, d_len_c, d_len_all;
@@ -603,6 +604,11 @@ int head_upload(fq_ctx *c, const fq_packed_batch_t *b, int slot) {
     CK(fqdev::h2d_copy(c->d_hlen[slot].p, b->len, n2 * 2));
     c->stats.h2d_bytes += n2 * 2;
   }
+  if (c->o.trim_qual >= 1 && b->qual_last) {
+    CKM(c->d_qlast[slot].ensure(n2 + 8));
+    CK(fqdev::h2d_copy(c->d_qlast[slot].p, b->qual_last, n2));
+    c->stats.h2d_bytes += n2;
+  }
   CK(fqdev::copy_record(slot));
   return FQ_OK;
 }
@@ -613,14 +619,13 @@ int stage0_packed(Call &K) {
   const int n = K.n, n2 = K.n2, n_sub = K.n_sub, B = K.B;
   const bool ragged = pb.uniform_len <= 0;
   const bool trim = c->o.trim_qual >= 1;
-  if (c->prefetched == &pb) c->head_slot ^= 1;   // its head is already on its way into the spare buffer (fq_packed_prefetch)
-  else { int rc = head_upload(c, &pb, c->head_slot); if (rc) return rc; }
-  c->prefetched = nullptr;
-  const int slot = c->head_slot;
+  const int slot = c->head_slot;   // chosen by fq_align_packed: the buffer the batch was prefetched into, else a free one (uploaded now)
   CK(fqdev::compute_wait_copy(slot));
-  CKM(c->d_filtered.ensure(n2 + 64) && c->d_read_list.ensure(n2) && c->d_sidx.ensure(n2) && c->d_pair_list.ensure(n) && c->d_sub_max.ensure(n_sub));
-  CK(fqdev::dzero(c->d_sub_max.p, (size_t)n_sub * 4));
+  const bool have_qlast = trim && pb.qual_last != nullptr;
+  CKM(c->d_filtered.ensure(n2 + 64) && c->d_read_list.ensure(n2) && c->d_sidx.ensure(n2) && c->d_pair_list.ensure(n) && c->d_sub_max.ensure((size_t)2 * n_sub));
+  CK(fqdev::dzero(c->d_sub_max.p, (size_t)2 * n_sub * 4));
   FqPrepPackedArgs a{};
+  a.qual_last = have_qlast ? c->d_qlast[slot].p : nullptr; a.sub_whole = c->d_sub_max.p + n_sub;
   a.ix = ix->dev; a.o = c->ko; a.head = c->d_head[slot].p; a.len = ragged ? c->d_hlen[slot].p : nullptr; a.uniform_len = pb.uniform_len;
   a.n_reads = n2; a.filtered = c->d_filtered.p; a.sub_max = c->d_sub_max.p; a.n_pairs = n; a.batch_pairs = B; a.counters = c->d_counters.p;
   fqdev::time_begin(FQ_K_PREP);
@@ -630,7 +635,9 @@ int stage0_packed(Call &K) {
   int32_t counts[2] = {0, 0};
   uint64_t lcnt[2] = {0, 0};   // FQ_C_BASES, FQ_C_BADLEN (ragged batches)
   c->h_sub_max.assign(n_sub, pb.uniform_len);   // longest untrimmed read per reference batch
+  vector<int32_t> sub_whole(n_sub, 0);          // longest read trimming leaves whole (known without its quality row)
   CK(fqdev::d2h(counts, c->d_counts.p, 8));
+  if (have_qlast) CK(fqdev::d2h(sub_whole.data(), c->d_sub_max.p + n_sub, (size_t)n_sub * 4));
   if (ragged) {
     CK(fqdev::d2h(c->h_sub_max.data(), c->d_sub_max.p, (size_t)n_sub * 4));
     CK(fqdev::d2h(lcnt, c->d_counters.p + FQ_C_BASES, 16));
@@ -741,8 +748,11 @@ int stage0_packed(Call &K) {
     surv_max[sb] = std::max(surv_max[sb], ltr);
   }
   // infer_isize's max_len is the longest trimmed read of the whole reference batch, filtered reads included (bwape.c:60-61).
-  // Without trimming that is the longest read (known above).  With trimming it is the survivors' maximum whenever some survivor
-  // kept the batch's full length; otherwise -- and for the debug dump, which lists every read -- every read is trimmed.
+  // Without trimming that is the longest read (known above).  With trimming, the trimmed lengths of the survivors are known, and
+  // so is the length of every read that trimming leaves whole (from its last quality byte, fq_prep_packed_thread); every other
+  // read is shorter than the batch's longest.  When those known lengths reach the batch's longest read they are the maximum;
+  // otherwise -- and for the debug dump, which lists every read -- the qualities of all reads go to the device.
+  for (int sb = 0; sb < n_sub; ++sb) surv_max[sb] = std::max(surv_max[sb], (int)sub_whole[sb]);
   bool need_all = trim && c->debug;
   if (trim) for (int sb = 0; sb < n_sub; ++sb) if (surv_max[sb] < c->h_sub_max[sb]) need_all = true;
   c->h_filtered.clear(); c->h_len_trim.clear();
@@ -1473,10 +1483,14 @@ extern "C" int fq_packed_prefetch(fq_ctx_t *c, const fq_packed_batch_t *next) {
   int rc = packed_check(c, next);
   if (rc) return rc;
   if (fqdev::bind(c->dev)) return FQ_ENODEV;
-  if (next->n_pairs == 0) return FQ_OK;
-  rc = head_upload(c, next, c->head_slot ^ 1);   // the spare buffer: the current one may still be read by a running call
+  if (next->n_pairs == 0 || c->pend[0] == next || c->pend[1] == next) return FQ_OK;
+  // Calls are synchronous, so no kernel reads either buffer now: a buffer is free unless it holds a prefetched batch that has
+  // not been aligned yet.  Usual order: prefetch(k+1), align(k) -- batch k waits in one buffer, k+1 goes into the other.
+  const int slot = !c->pend[0] ? 0 : !c->pend[1] ? 1 : -1;
+  if (slot < 0) return FQ_OK;   // both hold pending batches: this one is uploaded when its call comes
+  rc = head_upload(c, next, slot);
   if (rc) return rc;
-  c->prefetched = next;
+  c->pend[slot] = next;
   return FQ_OK;
 }
 extern "C" int fq_align_packed(fq_ctx_t *c, const fq_packed_batch_t *in, fq_result_batch_t *out) {
@@ -1487,8 +1501,16 @@ extern "C" int fq_align_packed(fq_ctx_t *c, const fq_packed_batch_t *in, fq_resu
   c->pb = *in;
   c->n_pairs = in->n_pairs;
   c->in_kind = 2;
-  if (c->prefetched != in) c->prefetched = nullptr;   // a prefetch for some other batch is simply lost
-  else c->prefetched = &c->pb;
+  if (in->n_pairs > 0) {
+    if (c->pend[0] == in) { c->head_slot = 0; c->pend[0] = nullptr; }
+    else if (c->pend[1] == in) { c->head_slot = 1; c->pend[1] = nullptr; }
+    else {   // not prefetched: into a buffer that holds no pending batch (a pending one is dropped if both do)
+      c->head_slot = !c->pend[0] ? 0 : 1;
+      c->pend[c->head_slot] = nullptr;
+      rc = head_upload(c, in, c->head_slot);
+      if (rc) return rc;
+    }
+  }
   return run_call(c, out);
 }
 

@@ -319,10 +319,31 @@ struct FqPrepPackedArgs {
   int32_t n_reads;
   uint8_t *filtered;       // out: 1 = filtered
   int32_t *sub_max;        // out: [pair / batch_pairs] longest read (untrimmed) over both ends; only written when len != NULL
+  const uint8_t *qual_last;// [n_reads] quality of each read's last base, or NULL
+  int32_t *sub_whole;      // out: [pair / batch_pairs] longest read that bwa_trim_read leaves whole (written when qual_last != NULL)
   int32_t n_pairs, batch_pairs;
   uint64_t *counters;      // FQ_C_PROBES, FQ_C_BASES (ragged), FQ_C_BADLEN (ragged)
 };
 FQ_HD void fq_prep_packed_thread(const FqPrepPackedArgs &A, int r) {
+  if (A.qual_last) {
+    // bwa_trim_read (libbwa/bwaseqio.c:75-88) scans from the last base while the running sum of (trim_qual - q) stays >= 0: a read
+    // whose last base is above the threshold (or that is shorter than 35 bases) keeps its length
+    const int len = A.len ? (int)A.len[r] : A.uniform_len;
+    const int qsub = (A.o.mode & FQ_MODE_IL13) ? 31 : 0;
+    const bool whole = len - 1 < 34 || A.o.trim_qual - ((int)(uint8_t)(A.qual_last[r] - qsub) - 33) < 0;
+    const int slot = (r >= A.n_pairs ? r - A.n_pairs : r) / A.batch_pairs;
+#if defined(__HIP_DEVICE_COMPILE__)
+    int mx = whole ? len : 0;   // one atomic per wavefront and reference batch in the common case
+    const int slot0 = __builtin_amdgcn_readfirstlane(slot);
+    if (__ballot(slot != slot0) == 0) {
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
+      if (mx > 0 && __lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicMax(&A.sub_whole[slot0], mx);
+    } else if (mx > 0) atomicMax(&A.sub_whole[slot], mx);
+#else
+    if (whole && A.sub_whole[slot] < len) A.sub_whole[slot] = len;
+#endif
+  }
   if (A.len) {
     const int len = A.len[r];
     const int slot = (r >= A.n_pairs ? r - A.n_pairs : r) / A.batch_pairs;

@@ -14,7 +14,7 @@
 namespace {
 struct Owned {                 // a packed batch and the pinned storage behind it
   fq_packed_batch_t b{};
-  void *head = nullptr, *body = nullptr, *len = nullptr, *exc = nullptr;
+  void *head = nullptr, *body = nullptr, *len = nullptr, *exc = nullptr, *qlast = nullptr;
 };
 }  // namespace
 
@@ -24,7 +24,7 @@ extern "C" void fq_pinned_free(void *p) { fqdev::hfree(p); }
 extern "C" void fq_packed_free(fq_packed_batch_t *b) {
   if (!b) return;
   Owned *o = reinterpret_cast<Owned *>(b);   // b is the first member
-  fqdev::hfree(o->head); fqdev::hfree(o->body); fqdev::hfree(o->len); fqdev::hfree(o->exc);
+  fqdev::hfree(o->head); fqdev::hfree(o->body); fqdev::hfree(o->len); fqdev::hfree(o->exc); fqdev::hfree(o->qlast);
   delete o;
 }
 
@@ -48,7 +48,9 @@ extern "C" int fq_pack_reads(const fq_read_batch_t *in, int threads, fq_packed_b
   o->head = fqdev::hmalloc(n2 * 24 + 64);
   o->body = fqdev::hmalloc(n2 * (size_t)b.body_stride + 64);
   if (!b.uniform_len) o->len = fqdev::hmalloc(n2 * 2 + 64);
-  if (!o->head || !o->body || (!b.uniform_len && !o->len)) { fq_packed_free(&o->b); return FQ_ENOMEM; }
+  if (in->qual) o->qlast = fqdev::hmalloc(n2 + 64);
+  if (!o->head || !o->body || (!b.uniform_len && !o->len) || (in->qual && !o->qlast)) { fq_packed_free(&o->b); return FQ_ENOMEM; }
+  uint8_t *qlast = (uint8_t *)o->qlast;
   uint64_t *head = (uint64_t *)o->head;
   uint8_t *body = (uint8_t *)o->body;
   uint16_t *len = (uint16_t *)o->len;
@@ -63,6 +65,7 @@ extern "C" int fq_pack_reads(const fq_read_batch_t *in, int threads, fq_packed_b
       const uint8_t *row = in->seq + r * (size_t)stride;
       const int L = in->len[r];
       if (len) len[r] = (uint16_t)L;
+      if (qlast) qlast[r] = L > 0 ? in->qual[r * (size_t)stride + (size_t)(L - 1)] : 0;
       // the filter's view: the first 96 bytes of the row whatever the read's length; behind the read, what the row holds (the
       // reference's reused slot), 0 = never written = code 0
       for (int ch = 0; ch < 3; ++ch) {
@@ -95,6 +98,7 @@ extern "C" int fq_pack_reads(const fq_read_batch_t *in, int threads, fq_packed_b
   if (!o->exc) { fq_packed_free(&o->b); return FQ_ENOMEM; }
   uint64_t *e = (uint64_t *)o->exc;
   for (auto &v : exc_part) { memcpy(e, v.data(), v.size() * 8); e += v.size(); }   // thread ranges are ascending row ranges
+  b.qual_last = qlast;
   b.head = head; b.body = body; b.len = len; b.exc = (const uint64_t *)o->exc; b.n_exc = (int64_t)ne;
   *out = &o->b;
   return FQ_OK;

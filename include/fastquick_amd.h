@@ -177,7 +177,11 @@ int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out);
  *         three arrays head[ch][row], ch = 0..2 -- all the filter needs, and the only part of a filtered read that crosses PCIe;
  *   body  every read 2-bit packed (A0 C1 G2 T3; base i in byte i >> 2 at bit 2 * (i & 3)); a non-ACGT base holds 0 and is
  *         listed in exc as row << 32 | position << 8 | code (nst_nt4_table: 4 = N / any other character, 5 = '-'), ascending;
- *   qual  ASCII quality rows; len the read lengths (NULL when uniform_len > 0).
+ *   qual  ASCII quality rows; len the read lengths (NULL when uniform_len > 0);
+ *   qual_last  the quality byte of every read's last base (optional).  bwa_trim_read (libbwa/bwaseqio.c:75-88) leaves a read
+ *         whole when that base is above the --q threshold, and infer_isize needs the longest trimmed read of a reference batch,
+ *         filtered reads included (libbwa/bwape.c:60-61): with this byte per read the library can tell that from the device
+ *         without the quality rows of the filtered reads; without it (or when no read of a batch is left whole) it uploads them.
  * Rows are numbered end * n_pairs + pair.  The library uploads head for all reads and body (+ qual when --q trimming is on)
  * for the reads of surviving pairs only.  Arrays should be pinned (fq_pinned_alloc) for the upload to overlap compute; the
  * lifetime rule of fq_batch_upload applies. */
@@ -192,6 +196,7 @@ typedef struct {
   const uint64_t *exc;        /* [n_exc], ascending */
   int64_t n_exc;
   const uint8_t *qual;        /* [2 * n_pairs][qual_stride] */
+  const uint8_t *qual_last;   /* [2 * n_pairs] or NULL */
   const char *names;          /* as in fq_read_batch_t */
   int32_t name_stride;
   const char *names_mate;

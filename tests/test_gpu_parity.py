@@ -253,6 +253,8 @@ def test_packed_boundary_properties(lib, tmp_path):
     api.build_index(pre)
     n, calls = 262144, 4
     rb = synth.make_reads(ref, n * calls, on_target=0.004, seed=72, n_rate=0.002, qual_decay=True, sub_rate=0.01)
+    good = np.random.default_rng(73).random(rb.qual.shape[:2]) < 0.3      # three reads in ten keep good qualities to their end
+    rb.qual[good] = ord("I")
     ix = api.Index(pre, device=0)
     opts = lambda: api.default_opts(lib, trim_qual=15)
     al = api.Aligner(ix, opts(), max_pairs=n)
@@ -277,8 +279,13 @@ def test_packed_boundary_properties(lib, tmp_path):
         al.close()
         assert got == want, "packed boundary (prefetch=%s) differs from the ASCII boundary" % prefetch
         surv = st["reads_searched"]
-        assert st["h2d_bytes"] < 48 * n * calls + 1200 * surv + (1 << 20), st["h2d_bytes"]
+        assert st["h2d_bytes"] < 50 * n * calls + 1200 * surv + (1 << 20), st["h2d_bytes"]   # 48 B of filter keys + 2 last-quality bytes per pair
         assert st["h2d_bytes"] >= 48 * n * calls
     for p in packs:
         p.free()
     ix.close()
+
+
+def test_trimmed_max_len_of_filtered_reads_gpu(lib, tmp_path):
+    from test_pipeline_emu import trimmed_max_len_case
+    trimmed_max_len_case(lib, tmp_path, device=0)

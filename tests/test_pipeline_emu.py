@@ -108,3 +108,53 @@ def test_emulated_pipeline_matches_oracle_with_option_variants(name, okw, emu_li
     assert not diffs, "\n".join(diffs[:20])
     assert filecmp.cmp(str(tmp_path / "orc.sam"), str(tmp_path / "emu.sam"), shallow=False)
     al.close(); ix.close(); oa.close()
+
+
+def trimmed_max_len_case(lib, tmp_path, device=None):
+    """infer_isize's max_len is the longest TRIMMED read of the reference batch, filtered reads included (bwape.c:60-61).  Short
+    fragments make the estimate's lower bound equal to it (p25 - 2 IQR < max_len), so it shows in the result.  Every on-target
+    read is trimmed (decaying qualities, --q 15); a few off-target (filtered) reads keep their full length.  The packed
+    boundary must find that length (a) from the reads' last quality bytes and (b) without them, by uploading the qualities."""
+    import ctypes as C
+    import numpy as np
+    from fastquick_amd import synth
+    ref = synth.make_reference(n_markers=60, n_long=6, seed=81)
+    pre = str(tmp_path / "ref.FASTQuick.fa")
+    ref.write_fasta(pre)
+    api.build_index(pre, lib=lib)
+    n, L = 3000, 100
+    rb = synth.make_reads(ref, n, read_len=L, on_target=0.1, seed=82, qual_decay=True, frag_mean=115, frag_sd=10)
+    ix = api.Index(pre, lib=lib) if device is None else api.Index(pre, device=device, lib=lib)
+    opts = lambda: api.default_opts(lib, trim_qual=15, batch_pairs=1000)
+    al = api.Aligner(ix, opts(), max_pairs=n)
+    res = al.align(rb.seq, rb.qual, rb.lens, rb.names)
+    surv = set(np.ctypeslib.as_array(res.pair_idx, shape=(res.n_survivors,)).tolist())
+    trimmed_max = max(res.rec[i].clip_len for i in range(2 * res.n_survivors))
+    assert trimmed_max < L and res.n_survivors > 150
+    off = [p for p in range(n) if p not in surv]
+    for p in (off[3], off[len(off) // 2], off[-2]):       # one whole read in each reference batch of 1000, all in filtered pairs
+        rb.qual[0, p, :] = ord("I")
+    assert off[3] < 1000 <= off[len(off) // 2] < 2000 <= off[-2]
+    res = al.align(rb.seq, rb.qual, rb.lens, rb.names)
+    want = [(res.isize_sub[k].low, res.isize_sub[k].avg, res.isize_sub[k].std) for k in range(res.n_sub)]
+    want_sam = al.sam_text()
+    al.close()
+    assert all(w[0] == L for w in want), want          # the filtered whole read sets the bound, not the survivors' maximum
+    for drop_qlast in (False, True):
+        al = api.Aligner(ix, opts(), max_pairs=n)
+        hp = api.HostPacked(rb.seq, rb.qual, rb.lens, rb.names, lib=lib)
+        if drop_qlast:
+            hp.p.contents.qual_last = None
+        res = al.align_packed(hp)
+        got = [(res.isize_sub[k].low, res.isize_sub[k].avg, res.isize_sub[k].std) for k in range(res.n_sub)]
+        st = al.stats()
+        assert got == want and al.sam_text() == want_sam, (drop_qlast, got, want)
+        full_quals = 2 * n * rb.qual.shape[2]
+        assert (st["h2d_bytes"] > full_quals) == drop_qlast      # the quality rows of every read only travel when they must
+        al.close()
+        hp.free()
+    ix.close()
+
+
+def test_trimmed_max_len_of_filtered_reads(emu_lib, tmp_path):
+    trimmed_max_len_case(emu_lib, tmp_path)
