@@ -159,6 +159,8 @@ def main() -> None:
                 b = distinct[c % n_distinct]
                 al.upload(b.seq, b.qual, b.lens, None)   # inputs resident in HBM
 
+        cur_of = [c % n_distinct for c in range(n_ctx)]     # each context walks the batches round-robin, across run_steps calls
+
         def run_steps(k_steps):
             recs = [0] * n_ctx
             errs = []
@@ -167,12 +169,13 @@ def main() -> None:
                 try:
                     al = ctxs[c]
                     if boundary == "host":
-                        cur = c % n_distinct
+                        cur = cur_of[c]
                         for _ in range(k_steps):
                             nxt = (cur + 1) % n_distinct
                             al.prefetch(packs[nxt])          # next batch's upload runs under this batch's kernels
                             recs[c] += al.align_packed(packs[cur]).n_survivors
                             cur = nxt
+                        cur_of[c] = cur
                     else:
                         for _ in range(k_steps):
                             recs[c] += al.align_resident().n_survivors
@@ -206,7 +209,7 @@ def main() -> None:
             ctxs[0].reset_stats()
             for _ in range(3):
                 if boundary == "host":
-                    ctxs[0].align_packed(packs[0])
+                    ctxs[0].align_packed(packs[cur_of[0]])
                 else:
                     ctxs[0].align_resident()
             leg["solo"] = ctxs[0].stats()

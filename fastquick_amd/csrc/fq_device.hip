@@ -24,7 +24,8 @@ namespace fqdev {
 struct Pending { int kid; hipEvent_t a, b; };
 struct State {
   int device = 0;
-  hipStream_t stream = nullptr, copy_stream = nullptr;
+  hipStream_t stream = nullptr;
+  hipStream_t copy_stream = nullptr;              // one of the device's shared copy streams (not owned)
   hipEvent_t copy_done[2] = {nullptr, nullptr};
   hipEvent_t prep_done = nullptr;                 // completion of this context's most recent filter kernel (chained per device)
   std::vector<Pending> pending;
@@ -58,6 +59,11 @@ static bool g_dev_ready[64];
 // synchronises its stream first and clears the slot)
 static hipEvent_t g_prep_last[64];
 static State *g_prep_owner[64];
+// Input prefetch copies of all contexts of a device go through two shared copy streams, created at the first prefetch: a copy
+// stream per context would double the number of streams, and streams beyond the hardware queues (GPU_MAX_HW_QUEUES) share
+// queues -- a context's kernels then wait behind another context's long search kernel.
+static hipStream_t g_copy_streams[64][2];
+static unsigned g_copy_next[64];
 
 State *state_create(int dev) {
   int n = 0;
@@ -71,7 +77,6 @@ State *state_create(int dev) {
   State *s = new State;
   s->device = dev;
   bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess &&
-            hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreateWithFlags(&s->copy_done[0], hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&s->copy_done[1], hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&s->prep_done, hipEventDisableTiming) == hipSuccess;
@@ -82,7 +87,7 @@ void state_destroy(State *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
-  if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);
+  if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);   // (shared: also waits for other contexts' copies enqueued so far)
   {
     std::lock_guard<std::mutex> lk(g_dev_mu);
     if (g_prep_owner[s->device] == s) { g_prep_owner[s->device] = nullptr; g_prep_last[s->device] = nullptr; }
@@ -95,7 +100,6 @@ void state_destroy(State *s) {
   if (s->cmp_cnt) (void)hipFree(s->cmp_cnt);
   if (s->cmp_off) (void)hipFree(s->cmp_off);
   if (s->stream) (void)hipStreamDestroy(s->stream);
-  if (s->copy_stream) (void)hipStreamDestroy(s->copy_stream);
   if (g_cur == s) g_cur = nullptr;
   delete s;
 }
@@ -125,8 +129,21 @@ int dfill(void *dst, int byte, size_t bytes) { if (bytes) FQ_HIP(hipMemsetAsync(
 int sync() { FQ_HIP(hipStreamSynchronize(g_stream)); return 0; }
 // input prefetch: copies on the context's copy stream run under the compute stream's kernels; slot = which of the two input
 // buffers the copies since the previous copy_record() filled
-int h2d_copy(void *dst, const void *src, size_t bytes) { if (bytes) FQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_cur->copy_stream)); return 0; }
-int copy_record(int slot) { FQ_HIP(hipEventRecord(g_cur->copy_done[slot & 1], g_cur->copy_stream)); return 0; }
+static int copy_stream_get() {
+  if (g_cur->copy_stream) return 0;
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  const int dev = g_cur->device;
+  for (int k = 0; k < 2; ++k)
+    if (!g_copy_streams[dev][k]) FQ_HIP(hipStreamCreateWithFlags(&g_copy_streams[dev][k], hipStreamNonBlocking));
+  g_cur->copy_stream = g_copy_streams[dev][g_copy_next[dev]++ & 1];
+  return 0;
+}
+int h2d_copy(void *dst, const void *src, size_t bytes) {
+  if (copy_stream_get()) return -3;
+  if (bytes) FQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_cur->copy_stream));
+  return 0;
+}
+int copy_record(int slot) { if (copy_stream_get()) return -3; FQ_HIP(hipEventRecord(g_cur->copy_done[slot & 1], g_cur->copy_stream)); return 0; }
 int compute_wait_copy(int slot) { FQ_HIP(hipStreamWaitEvent(g_stream, g_cur->copy_done[slot & 1], 0)); return 0; }
 
 // ---- timing ---------------------------------------------------------------------------------
@@ -904,7 +921,6 @@ static int set_kernel_attributes() {
   FQ_HIP(hipFuncSetAttribute((const void *)k_sw_wave, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
   FQ_HIP(hipFuncSetAttribute((const void *)k_refine_wave, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
   FQ_HIP(hipFuncSetAttribute((const void *)k_refine_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
-  FQ_HIP(hipFuncSetAttribute((const void *)k_gap_persist_lds, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsBudget));
   return 0;
 }
 
