@@ -159,6 +159,7 @@ def main() -> None:
                 b = distinct[c % n_distinct]
                 al.upload(b.seq, b.qual, b.lens, None)   # inputs resident in HBM
 
+        t_run0 = [0.0]
         cur_of = [c % n_distinct for c in range(n_ctx)]     # each context walks the batches round-robin, across run_steps calls
 
         def run_steps(k_steps):
@@ -167,6 +168,7 @@ def main() -> None:
 
             def worker(c):
                 try:
+                    t_in = time.perf_counter()
                     al = ctxs[c]
                     if boundary == "host":
                         cur = cur_of[c]
@@ -179,8 +181,11 @@ def main() -> None:
                     else:
                         for _ in range(k_steps):
                             recs[c] += al.align_resident().n_survivors
+                    if os.environ.get("FQ_BENCH_DEBUG"):
+                        sys.stderr.write("worker %d: start +%.1f ms, end +%.1f ms\n" % (c, 1e3 * (t_in - t_run0[0]), 1e3 * (time.perf_counter() - t_run0[0])))
                 except Exception as e:      # noqa: BLE001
                     errs.append(e)
+            t_run0[0] = time.perf_counter()
             th = [threading.Thread(target=worker, args=(c,)) for c in range(n_ctx)]
             for t in th:
                 t.start()
@@ -305,7 +310,7 @@ def main() -> None:
         "pcie": {"h2d_bytes_per_pair": round(agg["h2d_bytes"] / pairs_total, 2), "d2h_bytes_per_pair": round(agg["d2h_bytes"] / pairs_total, 3),
                  "h2d_GBps": round(agg["h2d_bytes"] * world / elapsed / 1e9 / world, 2), "d2h_GBps": round(agg["d2h_bytes"] / elapsed / 1e9, 3)},
         "stage_ms_per_call": {K_NAMES[k]: round(kms[k] / calls, 4) for k in range(len(K_NAMES))},
-        "host_ms_per_call": round(agg["host_ms_total"] / calls, 3),
+        "host_ms_per_call": round(agg["host_ms_total"] / calls, 3), "wall_ms_per_call": round(agg["wall_ms_total"] / calls, 3),
         "survivor_pairs_per_call": round(main_leg["n_records"] / calls, 1),
         "work_per_call": {k: round(agg[k] / calls, 1) for k in ("filter_probes", "occ_block_touches", "gap_occ_touches", "stack_pops",
                                                                      "stack_pushes", "sa_rows", "reads_searched", "sw_tasks", "refine_tasks", "tier_retries", "reads_over_4k_pops")},

@@ -79,6 +79,43 @@ template <class T> struct PinBuf {   // pinned host staging: device <-> host cop
   }
 };
 
+// Every host <-> device copy of a call goes through pinned memory: a copy from or to pageable memory takes the runtime's
+// staged, blocking path, and mixing the two kinds on one stream made the pageable ones several times slower under load (the
+// refine stage of a call went from 4 to 14 ms with sixteen contexts).  The arena is a bump allocator over pinned blocks,
+// reset when a call starts; results of device -> host copies are handed to their (ordinary) destinations at the next sync.
+struct PinArena {
+  struct Block { uint8_t *p; size_t cap; };
+  std::vector<Block> blocks;
+  size_t used = 0, total = 0;
+  struct Out { void *dst; const void *src; size_t bytes; };
+  std::vector<Out> pending;
+  ~PinArena() { for (auto &b : blocks) fqdev::hfree(b.p); }
+  void reset() {
+    pending.clear();
+    if (blocks.size() > 1) {   // one block of the size the last call needed
+      for (auto &b : blocks) fqdev::hfree(b.p);
+      blocks.clear();
+      uint8_t *p = (uint8_t *)fqdev::hmalloc(total + total / 4);
+      if (p) blocks.push_back({p, total + total / 4});
+    }
+    used = 0; total = 0;
+  }
+  void *alloc(size_t bytes) {
+    bytes = (bytes + 63) & ~(size_t)63;
+    total += bytes;
+    if (blocks.empty() || used + bytes > blocks.back().cap) {
+      const size_t cap = std::max<size_t>(bytes, (size_t)4 << 20);
+      uint8_t *p = (uint8_t *)fqdev::hmalloc(cap);
+      if (!p) return nullptr;
+      blocks.push_back({p, cap});
+      used = 0;
+    }
+    void *r = blocks.back().p + used;
+    used += bytes;
+    return r;
+  }
+};
+
 struct FqKnobs {   // experiment / test knobs (fq_ctx_set_tuning); defaults are what DESIGN.md measures
   uint32_t gap_long_pops = 1024;   // lane kernel hands a search to the wavefront-per-read kernel after this many pops (queue dry)
   int gap_long_always = 0;         // ... whatever the state of the queue (tests)
@@ -160,6 +197,7 @@ struct fq_ctx {
   vector<uint8_t> h_filtered;
   vector<int32_t> h_len_trim, h_pair_list, h_sub_max;
   vector<FqSurvInfo> h_surv;
+  PinArena arena;
   PinBuf<int32_t> p_i32;
   PinBuf<FqSurvInfo> p_surv;
   PinBuf<uint32_t> p_u32a, p_u32b, p_pos;
@@ -267,6 +305,31 @@ extern "C" void fq_stats_reset(fq_ctx_t *c) { if (c) memset(&c->stats, 0, sizeof
   do {                                                            \
     if (!(expr)) { c->err = std::string("out of device memory: ") + #expr; return FQ_ENOMEM; } \
   } while (0)
+
+// small per-call copies, staged through the context's pinned arena (see PinArena)
+static int h2d_staged(fq_ctx *c, void *dst, const void *src, size_t bytes) {
+  if (!bytes) return 0;
+  void *p = c->arena.alloc(bytes);
+  if (!p) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
+  memcpy(p, src, bytes);
+  if (fqdev::copy_pinned(dst, p, bytes, 1)) { c->err = std::string("h2d: ") + fqdev::last_error(); return FQ_ENODEV; }
+  return 0;
+}
+static int d2h_staged(fq_ctx *c, void *dst, const void *src, size_t bytes) {   // dst is valid after the next sync_staged()
+  if (!bytes) return 0;
+  void *p = c->arena.alloc(bytes);
+  if (!p) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
+  if (fqdev::copy_pinned(p, src, bytes, 0)) { c->err = std::string("d2h: ") + fqdev::last_error(); return FQ_ENODEV; }
+  c->arena.pending.push_back({dst, p, bytes});
+  return 0;
+}
+static int sync_staged(fq_ctx *c) {
+  if (fqdev::sync()) { c->err = std::string("sync: ") + fqdev::last_error(); return FQ_ENODEV; }
+  for (auto &o : c->arena.pending) memcpy(o.dst, o.src, o.bytes);
+  c->arena.pending.clear();
+  return 0;
+}
+#define CKS(expr) do { const int rc_ = (expr); if (rc_) return rc_; } while (0)
 
 extern "C" int fq_batch_upload(fq_ctx_t *c, const fq_read_batch_t *in) {
   if (!c || !in || in->n_pairs < 0 || !in->seq || !in->qual || !in->len) return FQ_EINVAL;
@@ -527,9 +590,9 @@ int stage0_lists(Call &K, bool have_len_trim) {
   c->h_pair_list.resize(n_surv);
   c->h_surv.resize((size_t)n_surv * 2);
   CKM(c->p_i32.ensure((size_t)n_surv + 1) && c->p_surv.ensure((size_t)n_surv * 2 + 1));
-  CK(fqdev::d2h(c->p_i32.p, c->d_pair_list.p, (size_t)n_surv * 4));
-  CK(fqdev::d2h(c->p_surv.p, c->d_surv.p, (size_t)n_surv * 2 * sizeof(FqSurvInfo)));
-  CK(fqdev::sync());
+  CK(fqdev::copy_pinned(c->p_i32.p, c->d_pair_list.p, (size_t)n_surv * 4, 0));
+  CK(fqdev::copy_pinned(c->p_surv.p, c->d_surv.p, (size_t)n_surv * 2 * sizeof(FqSurvInfo), 0));
+  CKS(sync_staged(c));
   c->stats.d2h_bytes += (size_t)n_surv * (4 + 2 * sizeof(FqSurvInfo));
   if (n_surv) { memcpy(c->h_pair_list.data(), c->p_i32.p, (size_t)n_surv * 4); memcpy(c->h_surv.data(), c->p_surv.p, (size_t)n_surv * 2 * sizeof(FqSurvInfo)); }
   (void)have_len_trim;
@@ -571,17 +634,17 @@ int stage0_ascii(Call &K) {
   // batch.  (Debug mode also fetches the per-read arrays of the whole batch for the stage dump.)
   int32_t counts[2] = {0, 0};
   c->h_sub_max.resize(n_sub);
-  CK(fqdev::d2h(counts, c->d_counts.p, 8));
-  CK(fqdev::d2h(c->h_sub_max.data(), c->d_sub_max.p, (size_t)n_sub * 4));
-  CK(fqdev::sync());
+  CKS(d2h_staged(c, counts, c->d_counts.p, 8));
+  CKS(d2h_staged(c, c->h_sub_max.data(), c->d_sub_max.p, (size_t)n_sub * 4));
+  CKS(sync_staged(c));
   K.n_search = counts[0]; K.n_surv = counts[1];
   CKM(c->d_surv.ensure((size_t)K.n_surv * 2 + 1));
   CK(fqdev::launch_surv_gather(c->d_pair_list.p, K.n_surv, n, c->d_len_trim.p, c->d_filtered.p, c->d_sidx.p, c->d_surv.p));
   if (c->debug) {
     c->h_filtered.resize(n2);
     c->h_len_trim.resize(n2);
-    CK(fqdev::d2h(c->h_filtered.data(), c->d_filtered.p, n2));
-    CK(fqdev::d2h(c->h_len_trim.data(), c->d_len_trim.p, (size_t)n2 * 4));
+    CKS(d2h_staged(c, c->h_filtered.data(), c->d_filtered.p, n2));
+    CKS(d2h_staged(c, c->h_len_trim.data(), c->d_len_trim.p, (size_t)n2 * 4));
   } else { c->h_filtered.clear(); c->h_len_trim.clear(); }
   int rc = stage0_lists(K, true);
   if (rc) return rc;
@@ -636,13 +699,13 @@ int stage0_packed(Call &K) {
   uint64_t lcnt[2] = {0, 0};   // FQ_C_BASES, FQ_C_BADLEN (ragged batches)
   c->h_sub_max.assign(n_sub, pb.uniform_len);   // longest untrimmed read per reference batch
   vector<int32_t> sub_whole(n_sub, 0);          // longest read trimming leaves whole (known without its quality row)
-  CK(fqdev::d2h(counts, c->d_counts.p, 8));
-  if (have_qlast) CK(fqdev::d2h(sub_whole.data(), c->d_sub_max.p + n_sub, (size_t)n_sub * 4));
+  CKS(d2h_staged(c, counts, c->d_counts.p, 8));
+  if (have_qlast) CKS(d2h_staged(c, sub_whole.data(), c->d_sub_max.p + n_sub, (size_t)n_sub * 4));
   if (ragged) {
-    CK(fqdev::d2h(c->h_sub_max.data(), c->d_sub_max.p, (size_t)n_sub * 4));
-    CK(fqdev::d2h(lcnt, c->d_counters.p + FQ_C_BASES, 16));
+    CKS(d2h_staged(c, c->h_sub_max.data(), c->d_sub_max.p, (size_t)n_sub * 4));
+    CKS(d2h_staged(c, lcnt, c->d_counters.p + FQ_C_BASES, 16));
   }
-  CK(fqdev::sync());
+  CKS(sync_staged(c));
   if (ragged) {
     if (lcnt[1]) { c->err = "read length outside [" + std::to_string(FQ_LMIN) + "," + std::to_string(FQ_LMAX) + "]"; return FQ_ELIMIT; }
     c->n_bases_in = (int64_t)lcnt[0];
@@ -709,21 +772,21 @@ int stage0_packed(Call &K) {
         ne += (size_t)(hi - lo);
       }
     }
-    CK(fqdev::h2d(c->d_body.p, c->p_body.p, (size_t)nrow * body_stride));
+    CK(fqdev::copy_pinned(c->d_body.p, c->p_body.p, (size_t)nrow * body_stride, 1));
     c->stats.h2d_bytes += (size_t)nrow * body_stride;
     ua.body = c->d_body.p; ua.row_map = nullptr;
-    if (ragged) { CK(fqdev::h2d(c->d_blen.p, c->p_hlen.p, (size_t)nrow * 2)); ua.len = c->d_blen.p; c->stats.h2d_bytes += (size_t)nrow * 2; }
+    if (ragged) { CK(fqdev::copy_pinned(c->d_blen.p, c->p_hlen.p, (size_t)nrow * 2, 1)); ua.len = c->d_blen.p; c->stats.h2d_bytes += (size_t)nrow * 2; }
     if (ne) {
       CKM(c->p_exc.ensure(ne + 1) && c->d_exc.ensure(ne + 1));
       size_t at = 0;
       for (int t = 0; t < nrow; ++t)
         for (size_t q = erange[t].first; q < erange[t].second; ++q) c->p_exc.p[at++] = ((uint64_t)t << 32) | (pb.exc[q] & 0xffffffffull);
-      CK(fqdev::h2d(c->d_exc.p, c->p_exc.p, ne * 8));
+      CK(fqdev::copy_pinned(c->d_exc.p, c->p_exc.p, ne * 8, 1));
       c->stats.h2d_bytes += ne * 8;
       pa.exc = c->d_exc.p; pa.n_exc = (int64_t)ne; pa.crow_of = nullptr;
     }
     if (trim) {
-      CK(fqdev::h2d(c->d_pqual.p, c->p_pqual.p, (size_t)nrow * pb.qual_stride));
+      CK(fqdev::copy_pinned(c->d_pqual.p, c->p_pqual.p, (size_t)nrow * pb.qual_stride, 1));
       c->stats.h2d_bytes += (size_t)nrow * pb.qual_stride;
       ta.qual = c->d_pqual.p; ta.row_map = nullptr;
     }
@@ -737,7 +800,7 @@ int stage0_packed(Call &K) {
   fqdev::time_end(FQ_K_PREP);
   // lengths of the survivors' reads come back (full from the host's own arrays, trimmed from the device)
   vector<int32_t> lt((size_t)nrow);
-  if (nrow && trim) { CK(fqdev::d2h(lt.data(), c->d_len_trim.p, (size_t)nrow * 4)); CK(fqdev::sync()); c->stats.d2h_bytes += (size_t)nrow * 4; }
+  if (nrow && trim) { CKS(d2h_staged(c, lt.data(), c->d_len_trim.p, (size_t)nrow * 4)); CKS(sync_staged(c)); c->stats.d2h_bytes += (size_t)nrow * 4; }
   vector<int> surv_max(n_sub, 0);
   for (int t = 0; t < nrow; ++t) {
     const size_t r = (size_t)(t & 1) * (size_t)n + (size_t)c->h_pair_list[t >> 1];
@@ -765,16 +828,16 @@ int stage0_packed(Call &K) {
     aa.o = c->ko; aa.qual = c->d_pqual.p; aa.qual_stride = pb.qual_stride; aa.len = ragged ? c->d_hlen[slot].p : nullptr; aa.uniform_len = pb.uniform_len;
     aa.n_reads = n2; aa.n_pairs = n; aa.batch_pairs = B; aa.len_trim = c->d_len_all.p; aa.sub_max = c->d_sub_max.p;
     CK(fqdev::launch_trim_all(aa));
-    CK(fqdev::d2h(c->h_sub_max.data(), c->d_sub_max.p, (size_t)n_sub * 4));
-    if (c->debug) { c->h_len_trim.resize(n2); CK(fqdev::d2h(c->h_len_trim.data(), c->d_len_all.p, (size_t)n2 * 4)); }
-    CK(fqdev::sync());
+    CKS(d2h_staged(c, c->h_sub_max.data(), c->d_sub_max.p, (size_t)n_sub * 4));
+    if (c->debug) { c->h_len_trim.resize(n2); CKS(d2h_staged(c, c->h_len_trim.data(), c->d_len_all.p, (size_t)n2 * 4)); }
+    CKS(sync_staged(c));
   } else if (trim) {
     for (int sb = 0; sb < n_sub; ++sb) c->h_sub_max[sb] = surv_max[sb];
   }
   if (c->debug) {
     c->h_filtered.resize(n2);
-    CK(fqdev::d2h(c->h_filtered.data(), c->d_filtered.p, n2));
-    CK(fqdev::sync());
+    CKS(d2h_staged(c, c->h_filtered.data(), c->d_filtered.p, n2));
+    CKS(sync_staged(c));
     if (c->h_len_trim.empty()) { c->h_len_trim.resize(n2); for (int r = 0; r < n2; ++r) c->h_len_trim[r] = ragged ? (int)pb.len[r] : pb.uniform_len; }
   }
   stage0_sub_max(K);
@@ -817,7 +880,7 @@ int stageA_search(Call &K) {
           c->d_aln.ensure((size_t)nw * T.aln_cap) && c->d_naln.ensure(nw) && c->d_status.ensure(nw) && c->d_off.ensure(nw + 1));
       CKM(c->p_i32.ensure(nw));
       memcpy(c->p_i32.p, work.data() + c0, (size_t)nw * 4);
-      CK(fqdev::h2d(c->d_work.p, c->p_i32.p, (size_t)nw * 4));
+      CK(fqdev::copy_pinned(c->d_work.p, c->p_i32.p, (size_t)nw * 4, 1));
       c->stats.h2d_bytes += (size_t)nw * 4;
       FqWidthArgs wa{};
       wa.ix = ix->dev; wa.o = c->ko; wa.seq = K.dseq; wa.stride = K.dstride; wa.len_trim = K.dlen_trim; wa.read_list = K.dread_list;
@@ -849,15 +912,15 @@ int stageA_search(Call &K) {
       CKM(c->p_u32a.ensure((size_t)nw + 2) && c->p_u32b.ensure((size_t)nw + 2));
       uint32_t *h_status = c->p_u32a.p, *h_naln = c->p_u32b.p;
       uint64_t total = 0;
-      CK(fqdev::d2h(h_status, c->d_status.p, (size_t)nw * 4));
-      CK(fqdev::d2h(h_naln, c->d_naln.p, (size_t)nw * 4));
-      CK(fqdev::d2h(&total, c->d_off.p + nw, 8));
-      CK(fqdev::sync());
+      CK(fqdev::copy_pinned(h_status, c->d_status.p, (size_t)nw * 4, 0));
+      CK(fqdev::copy_pinned(h_naln, c->d_naln.p, (size_t)nw * 4, 0));
+      CKS(d2h_staged(c, &total, c->d_off.p + nw, 8));
+      CKS(sync_staged(c));
       CKM(c->d_packed.ensure(total + 1) && c->p_aln.ensure(total + 1));
       CK(fqdev::launch_pack_aln(c->d_aln.p, c->d_naln.p, c->d_off.p, T.aln_cap, (uint32_t)nw, c->d_packed.p));
       FqAln *h_packed = c->p_aln.p;
-      CK(fqdev::d2h(h_packed, c->d_packed.p, total * sizeof(FqAln)));
-      CK(fqdev::sync());
+      CK(fqdev::copy_pinned(h_packed, c->d_packed.p, total * sizeof(FqAln), 0));
+      CKS(sync_staged(c));
       c->stats.d2h_bytes += (size_t)nw * 8 + total * sizeof(FqAln);
       uint64_t at = 0;
       if (next_work.empty() && c0 == 0 && (size_t)nw == work.size() && h_aln.empty()) h_aln.reserve(total);
@@ -949,9 +1012,9 @@ int stage_sa_rows(Call &K) {
   K.h_pos = c->p_pos.p;
   if (rows) {
     CKM(c->d_qaln.ensure(q_aln.size()) && c->d_qlen.ensure(q_len.size()) && c->d_qoff.ensure(q_off.size()) && c->d_pos.ensure(rows));
-    CK(fqdev::h2d(c->d_qaln.p, q_aln.data(), q_aln.size() * sizeof(FqAln)));
-    CK(fqdev::h2d(c->d_qlen.p, q_len.data(), q_len.size() * 4));
-    CK(fqdev::h2d(c->d_qoff.p, q_off.data(), q_off.size() * 8));
+    CKS(h2d_staged(c, c->d_qaln.p, q_aln.data(), q_aln.size() * sizeof(FqAln)));
+    CKS(h2d_staged(c, c->d_qlen.p, q_len.data(), q_len.size() * 4));
+    CKS(h2d_staged(c, c->d_qoff.p, q_off.data(), q_off.size() * 8));
     c->stats.h2d_bytes += q_aln.size() * (sizeof(FqAln) + 12);
     FqSaArgs sa{};
     sa.ix = ix->dev; sa.aln = c->d_qaln.p; sa.aln_len = c->d_qlen.p; sa.row_off = c->d_qoff.p; sa.n_aln = (uint32_t)q_aln.size();
@@ -959,8 +1022,8 @@ int stage_sa_rows(Call &K) {
     fqdev::time_begin(FQ_K_SA);
     CK(fqdev::launch_sa(sa));
     fqdev::time_end(FQ_K_SA);
-    CK(fqdev::d2h(c->p_pos.p, c->d_pos.p, rows * 4));
-    CK(fqdev::sync());
+    CK(fqdev::copy_pinned(c->p_pos.p, c->d_pos.p, rows * 4, 0));
+    CKS(sync_staged(c));
     c->stats.d2h_bytes += rows * 4;
     c->stats.sa_rows += rows;
   }
@@ -989,16 +1052,16 @@ int stageB1_main_hit(Call &K) {
   if (!dq_row.empty()) {   // main hits of very repetitive reads whose rows were not enumerated
     const size_t nq = dq_row.size();
     CKM(c->d_qrow.ensure(nq) && c->d_qinfo.ensure(nq) && c->d_pos.ensure(nq));
-    CK(fqdev::h2d(c->d_qrow.p, dq_row.data(), nq * 4));
-    CK(fqdev::h2d(c->d_qinfo.p, dq_info.data(), nq * 4));
+    CKS(h2d_staged(c, c->d_qrow.p, dq_row.data(), nq * 4));
+    CKS(h2d_staged(c, c->d_qinfo.p, dq_info.data(), nq * 4));
     FqSaQueryArgs qa{};
     qa.ix = ix->dev; qa.row = c->d_qrow.p; qa.info = c->d_qinfo.p; qa.n = (uint32_t)nq; qa.pos = c->d_pos.p; qa.counters = c->d_counters.p;
     fqdev::time_begin(FQ_K_SA);
     CK(fqdev::launch_saq(qa));
     fqdev::time_end(FQ_K_SA);
     vector<uint32_t> tmp(nq);
-    CK(fqdev::d2h(tmp.data(), c->d_pos.p, nq * 4));
-    CK(fqdev::sync());
+    CKS(d2h_staged(c, tmp.data(), c->d_pos.p, nq * 4));
+    CKS(sync_staged(c));
     for (size_t i = 0; i < nq; ++i) R[dq_idx[i]].pos = tmp[i];
     c->stats.sa_rows += nq;
   }
@@ -1168,16 +1231,16 @@ int stageC_mate_sw(Call &K) {
       for (size_t t0 = 0; t0 < sub.size(); t0 += chunk) {
         const int nt = (int)std::min(chunk, sub.size() - t0);
         CKM(c->d_swtask.ensure(nt) && c->d_swout.ensure(nt) && c->d_cig.ensure((size_t)nt * cig_cap) && c->d_scratch.ensure((size_t)nt * sstride));
-        CK(fqdev::h2d(c->d_swtask.p, sub.data() + t0, (size_t)nt * sizeof(FqSwTask)));
+        CKS(h2d_staged(c, c->d_swtask.p, sub.data() + t0, (size_t)nt * sizeof(FqSwTask)));
         FqSwArgs a{};
         a.ix = ix->dev; a.seq = K.dseq; a.stride = K.dstride; a.len_trim = K.dlen_trim; a.task = c->d_swtask.p; a.n_task = nt;
         a.out = c->d_swout.p; a.cigar = c->d_cig.p; a.cig_cap = cig_cap; a.scratch = c->d_scratch.p; a.scratch_stride = sstride; a.RL = RL; a.QL = QL;
         fqdev::time_begin(FQ_K_SW);
         CK(big ? fqdev::launch_sw_serial(a) : fqdev::launch_sw(a));
         fqdev::time_end(FQ_K_SW);
-        CK(fqdev::d2h(sub_out.data() + t0, c->d_swout.p, (size_t)nt * sizeof(FqSwOut)));
-        CK(fqdev::d2h(sub_cig.data() + t0 * cig_cap, c->d_cig.p, (size_t)nt * cig_cap * 2));
-        CK(fqdev::sync());
+        CKS(d2h_staged(c, sub_out.data() + t0, c->d_swout.p, (size_t)nt * sizeof(FqSwOut)));
+        CKS(d2h_staged(c, sub_cig.data() + t0 * cig_cap, c->d_cig.p, (size_t)nt * cig_cap * 2));
+        CKS(sync_staged(c));
       }
       for (size_t q = 0; q < sel.size(); ++q) {
         souts[sel[q]] = sub_out[q];
@@ -1268,16 +1331,16 @@ int stageD_refine(Call &K) {
     for (size_t t0 = 0; t0 < tasks.size(); t0 += chunk) {
       const int nt = (int)std::min(chunk, tasks.size() - t0);
       CKM(c->d_reftask.ensure(nt) && c->d_refout.ensure(nt) && c->d_cig.ensure((size_t)nt * cig_cap) && c->d_scratch.ensure((size_t)nt * sstride));
-      CK(fqdev::h2d(c->d_reftask.p, tasks.data() + t0, (size_t)nt * sizeof(FqRefTask)));
+      CKS(h2d_staged(c, c->d_reftask.p, tasks.data() + t0, (size_t)nt * sizeof(FqRefTask)));
       FqRefineArgs a{};
       a.ix = ix->dev; a.seq = K.dseq; a.stride = K.dstride; a.len_trim = K.dlen_trim; a.task = c->d_reftask.p; a.n_task = nt;
       a.out = c->d_refout.p; a.cigar = c->d_cig.p; a.cig_cap = cig_cap; a.scratch = c->d_scratch.p; a.scratch_stride = sstride; a.RL = max_ref; a.QL = max_q;
       fqdev::time_begin(FQ_K_REFINE);
       CK(fqdev::launch_refine(a));
       fqdev::time_end(FQ_K_REFINE);
-      CK(fqdev::d2h(outs.data() + t0, c->d_refout.p, (size_t)nt * sizeof(FqRefOut)));
-      CK(fqdev::d2h(cg.data() + t0 * cig_cap, c->d_cig.p, (size_t)nt * cig_cap * 2));
-      CK(fqdev::sync());
+      CKS(d2h_staged(c, outs.data() + t0, c->d_refout.p, (size_t)nt * sizeof(FqRefOut)));
+      CKS(d2h_staged(c, cg.data() + t0 * cig_cap, c->d_cig.p, (size_t)nt * cig_cap * 2));
+      CKS(sync_staged(c));
     }
     for (size_t t = 0; t < tasks.size(); ++t)
       if (outs[t].n_cigar <= 0) { c->err = "refine: CIGAR longer than the device slot"; return FQ_ELIMIT; }
@@ -1306,8 +1369,8 @@ int stageD_refine(Call &K) {
     const int nt = (int)mt.size();
     CKM(c->d_mdtask.ensure(nt) && c->d_md.ensure((size_t)nt * md_cap) && c->d_mdlen.ensure(nt) && c->d_nm.ensure(nt) && c->d_mdsz.ensure(nt) &&
         c->d_cigarena.ensure(arena.size() + 1) && c->d_off.ensure(nt + 1));
-    CK(fqdev::h2d(c->d_mdtask.p, mt.data(), (size_t)nt * sizeof(FqMdTask)));
-    CK(fqdev::h2d(c->d_cigarena.p, arena.data(), arena.size() * 2));
+    CKS(h2d_staged(c, c->d_mdtask.p, mt.data(), (size_t)nt * sizeof(FqMdTask)));
+    CKS(h2d_staged(c, c->d_cigarena.p, arena.data(), arena.size() * 2));
     c->stats.h2d_bytes += (size_t)nt * sizeof(FqMdTask) + arena.size() * 2;
     FqMdArgs a{};
     a.ix = ix->dev; a.seq = K.dseq; a.stride = K.dstride; a.task = c->d_mdtask.p; a.n_task = nt; a.cigar = c->d_cigarena.p;
@@ -1319,16 +1382,16 @@ int stageD_refine(Call &K) {
     uint64_t total = 0;
     vector<int32_t> mdlen(nt), nm(nt);
     vector<uint64_t> off(nt + 1);
-    CK(fqdev::d2h(off.data(), c->d_off.p, (size_t)(nt + 1) * 8));
-    CK(fqdev::d2h(mdlen.data(), c->d_mdlen.p, (size_t)nt * 4));
-    CK(fqdev::d2h(nm.data(), c->d_nm.p, (size_t)nt * 4));
-    CK(fqdev::sync());
+    CKS(d2h_staged(c, off.data(), c->d_off.p, (size_t)(nt + 1) * 8));
+    CKS(d2h_staged(c, mdlen.data(), c->d_mdlen.p, (size_t)nt * 4));
+    CKS(d2h_staged(c, nm.data(), c->d_nm.p, (size_t)nt * 4));
+    CKS(sync_staged(c));
     total = off[nt];
     CKM(c->d_mdpacked.ensure(total + 1));
     CK(fqdev::launch_pack_md(c->d_md.p, c->d_mdlen.p, c->d_off.p, md_cap, nt, c->d_mdpacked.p));
     vector<char> packed(total + 1);
-    CK(fqdev::d2h(packed.data(), c->d_mdpacked.p, total));
-    CK(fqdev::sync());
+    CKS(d2h_staged(c, packed.data(), c->d_mdpacked.p, total));
+    CKS(sync_staged(c));
     c->stats.d2h_bytes += (size_t)nt * 16 + total;
     for (int t = 0; t < nt; ++t)
       if (mdlen[t] < 0) { c->err = "MD string longer than the device slot"; return FQ_ELIMIT; }
@@ -1394,8 +1457,8 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
   out->isize_sub = S.isize_sub.data();
   out->n_bases = c->n_bases_in;
   uint64_t cnt[FQ_C_COUNT];
-  CK(fqdev::d2h(cnt, c->d_counters.p, sizeof cnt));
-  CK(fqdev::sync());
+  CKS(d2h_staged(c, cnt, c->d_counters.p, sizeof cnt));
+  CKS(sync_staged(c));
   CK(fqdev::dzero(c->d_counters.p, sizeof cnt));
   fqdev::time_collect(c->stats.kernel_ms, c->stats.kernel_launches, FQ_K_COUNT);
   c->stats.occ_block_touches += cnt[FQ_C_OCC_WIDTH] + cnt[FQ_C_OCC_GAP] + cnt[FQ_C_OCC_SA];
@@ -1413,6 +1476,7 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
   c->stats.host_ms_pair += K.t_host1 - K.t_serial1;
   c->stats.host_ms_total += K.t_host1 - K.t_host0;
   c->stats.wall_ms_total += now_ms() - K.t_wall0;
+  K.trace("counters+timers");
   return FQ_OK;
 }
 
@@ -1420,6 +1484,7 @@ int run_call(fq_ctx *c, fq_result_batch_t *out) {
   Call K;
   K.c = c;
   K.t_trace = K.t_wall0 = now_ms();
+  c->arena.reset();
   const fq_opts_t &o = c->o;
   FqBatchState &S = c->st;
   S.clear();

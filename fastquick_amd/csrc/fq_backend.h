@@ -26,6 +26,8 @@ void *hmalloc(size_t bytes);           // pinned host memory
 void hfree(void *p);
 int h2d(void *dst, const void *src, size_t bytes);
 int d2h(void *dst, const void *src, size_t bytes);
+// host side pinned (hmalloc): small sizes are copied by a kernel on the compute stream, large ones by hipMemcpyAsync
+int copy_pinned(void *dst, const void *src, size_t bytes, int to_device);
 int dzero(void *dst, size_t bytes);
 int dfill(void *dst, int byte, size_t bytes);
 int sync();

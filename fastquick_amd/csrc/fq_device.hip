@@ -146,6 +146,25 @@ int h2d_copy(void *dst, const void *src, size_t bytes) {
 int copy_record(int slot) { if (copy_stream_get()) return -3; FQ_HIP(hipEventRecord(g_cur->copy_done[slot & 1], g_cur->copy_stream)); return 0; }
 int compute_wait_copy(int slot) { FQ_HIP(hipStreamWaitEvent(g_stream, g_cur->copy_done[slot & 1], 0)); return 0; }
 
+// Small copies between pinned host memory and device memory by a kernel on the compute stream (the pinned range is mapped into
+// the device's address space): no DMA engine, no staging, one kernel launch of latency -- the per-stage lists of a call are a
+// few KB to a few hundred KB, and under load a hipMemcpyAsync + synchronize round trip for them cost milliseconds.
+__global__ void __launch_bounds__(256) k_copy_bytes(uint8_t *dst, const uint8_t *src, size_t bytes) {
+  const size_t n16 = ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0) ? bytes / 16 : 0;
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+  for (size_t i = t; i < n16; i += stride) ((uint4 *)dst)[i] = ((const uint4 *)src)[i];
+  for (size_t i = n16 * 16 + t; i < bytes; i += stride) dst[i] = src[i];
+}
+static const size_t kSmallCopy = (size_t)8 << 20;
+int copy_pinned(void *dst, const void *src, size_t bytes, int to_device) {
+  if (!bytes) return 0;
+  if (bytes > kSmallCopy) { FQ_HIP(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, g_stream)); return 0; }
+  const unsigned blocks = (unsigned)std::min<size_t>(256, (bytes / 16 + 255) / 256 + 1);
+  hipLaunchKernelGGL(k_copy_bytes, dim3(blocks), dim3(256), 0, g_stream, (uint8_t *)dst, (const uint8_t *)src, bytes);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---- timing ---------------------------------------------------------------------------------
 static hipEvent_t get_event() {
   if (!g_cur->free_events.empty()) { hipEvent_t e = g_cur->free_events.back(); g_cur->free_events.pop_back(); return e; }

@@ -30,6 +30,7 @@ void *hmalloc(size_t b) { return malloc(b ? b : 16); }
 void hfree(void *p) { free(p); }
 int h2d(void *d, const void *s, size_t n) { if (n) memcpy(d, s, n); return 0; }
 int d2h(void *d, const void *s, size_t n) { if (n) memcpy(d, s, n); return 0; }
+int copy_pinned(void *d, const void *s, size_t n, int) { if (n) memcpy(d, s, n); return 0; }
 int dzero(void *d, size_t n) { if (n) memset(d, 0, n); return 0; }
 int dfill(void *d, int b, size_t n) { if (n) memset(d, b, n); return 0; }
 int sync() { return 0; }
