@@ -24,10 +24,12 @@ import sys
 import threading
 import time
 
-# One hardware queue per HIP stream: the library gives every alignment context its own streams, and the runtime's default of
-# four hardware queues would make sixteen contexts share queues (a 15 ms persistent search kernel then blocks another
-# stream's filter kernel).  Must be set before the HIP runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+# One hardware queue per HIP stream: the library gives every alignment context its own stream (plus two shared copy streams per
+# device), and the runtime's default of four hardware queues would make sixteen contexts share queues (a 15 ms persistent
+# search kernel then blocks another stream's filter kernel).  Sixteen context streams + two copy streams + the null stream need
+# more than sixteen queues: with exactly 16 the last two contexts shared queues and finished 25 % after the others; 32 or more
+# oversubscribe the hardware queues and halve the throughput.  Must be set before the HIP runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)

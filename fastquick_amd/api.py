@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-DEFAULT_LIB = os.path.join(HERE, "libfastquick_amd.so")
+DEFAULT_LIB = os.environ.get("FQ_LIB_EXPERIMENT") or os.path.join(HERE, "libfastquick_amd.so")   # (FQ_LIB_EXPERIMENT: an instrumented build of the same library)
 
 FQ_K_NAMES = ("prep", "width", "gap", "sa", "sw", "refine", "prep_kernel", "gap_kernel")
 
@@ -75,7 +75,7 @@ class Stats(C.Structure):
                 ("max_pops_per_read", C.c_uint64), ("reads_over_4k_pops", C.c_uint64), ("max_wave_trips", C.c_uint64),
                 ("host_ms_serial", C.c_double), ("host_ms_pair", C.c_double), ("host_ms_total", C.c_double),
                 ("wall_ms_total", C.c_double), ("wave_trips", C.c_uint64), ("lane_trips", C.c_uint64),
-                ("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64)]
+                ("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("dbg", C.c_uint64 * 16)]
 
 
 EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destroy", "fq_index_l_pac",

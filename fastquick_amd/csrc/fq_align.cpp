@@ -119,6 +119,7 @@ struct PinArena {
 struct FqKnobs {   // experiment / test knobs (fq_ctx_set_tuning); defaults are what DESIGN.md measures
   uint32_t gap_long_pops = 1024;   // lane kernel hands a search to the wavefront-per-read kernel after this many pops (queue dry)
   int gap_long_always = 0;         // ... whatever the state of the queue (tests)
+  int64_t gap_nogap_min = 131072;  // launches of at least this many reads begin with the round that searches without gap children (-1: never)
   uint32_t gap_pool = 2048;        // stack entries per lane of the lane kernel
   int gap_no_order = 0;
   int sw_wave_max = 4096;          // largest mate-SW window the wavefront kernel takes
@@ -279,6 +280,7 @@ extern "C" int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t v) {
   if (k == "gap_long_pops") c->kn.gap_long_pops = (uint32_t)v;
   else if (k == "gap_long_always") c->kn.gap_long_always = (int)v;
   else if (k == "gap_pool") c->kn.gap_pool = (uint32_t)v;
+  else if (k == "gap_nogap_min") c->kn.gap_nogap_min = v;
   else if (k == "gap_no_order") c->kn.gap_no_order = (int)v;
   else if (k == "sw_wave_max") c->kn.sw_wave_max = (int)v;
   else if (k == "host_threads") c->kn.host_threads = (int)v;
@@ -861,22 +863,34 @@ int stageA_search(Call &K) {
   // (tier 1 with push-time pruning, tier 2 exactly as the reference: no pruning, n_entries exact).  The wavefront kernel never
   // reuses pool slots, so its pools hold every push of a search, not just the live entries.
   const uint32_t exact_pool = (uint32_t)std::min<uint64_t>(4ull * (uint64_t)o.max_entries + 4096ull, 0x7fffffffull);
-  const FqGapTier tiers[3] = {{c->kn.gap_pool, 32u, 0, 0, c->kn.gap_long_pops, c->kn.gap_long_always}, {262144u, 512u, 0, 1, 0u, 0}, {exact_pool, 8192u, 1, 1, 0u, 0}};
+  const FqGapTier lane_tier = {c->kn.gap_pool, 32u, 0, 0, c->kn.gap_long_pops, c->kn.gap_long_always, 0};
+  const FqGapTier wave_tier = {262144u, 512u, 0, 1, 0u, 0, 0}, exact_tier = {exact_pool, 8192u, 1, 1, 0u, 0, 0};
   // scores that can occur for the longest read of this call (children may exceed max_diff by one difference)
   const int nb_need = (c->maxdiff_lut[max_len_all] + 1) * o.s_mm + o.max_gapo * o.s_gapo + o.max_gape * o.s_gape + 1;
-  const size_t chunk_reads[3] = {(size_t)8 << 20, (size_t)1 << 20, 4096};   // pools are per lane / per wavefront; only per-read outputs scale with the chunk
+  // A launch that fills the device begins with the round that searches without gap children (FqGapLane, NOGAP): the reads it
+  // cannot settle are searched in full by the next round.
+  vector<FqGapTier> tiers;
+  vector<size_t> chunk_reads;   // pools are per lane / per wavefront; only per-read outputs scale with the chunk
+  if (c->kn.gap_nogap_min >= 0 && !c->kn.gap_long_always && !(o.mode & FQ_MODE_NONSTOP) && c->kn.gap_pool <= 65535u) {
+    FqGapTier t = lane_tier; t.nogap = 1; t.long_pops = 0; tiers.push_back(t); chunk_reads.push_back((size_t)8 << 20);
+  }
+  const size_t n_first_tiers = tiers.size();
+  tiers.push_back(lane_tier); chunk_reads.push_back((size_t)8 << 20);
+  tiers.push_back(wave_tier); chunk_reads.push_back((size_t)1 << 20);
+  tiers.push_back(exact_tier); chunk_reads.push_back(4096);
   vector<int32_t> work(n_search), next_work;
   for (int s = 0; s < n_search; ++s) work[s] = s;
   vector<int64_t> where(n_search, -1);   // offset of s's list in h_aln (filled as results arrive)
-  for (int tier = 0; tier < 3 && !work.empty(); ++tier) {
+  for (size_t tier = 0; tier < tiers.size() && !work.empty(); ++tier) {
     FqGapTier T = tiers[tier];
+    if (T.nogap && (int64_t)work.size() < c->kn.gap_nogap_min) continue;   // a small launch is bound by its longest search: one round
     // Handing long searches to the wavefront-per-read kernel pays when the launch is latency-bound (few reads: its duration is
     // its longest search); a launch that fills the device several times over hides its long searches behind the others.
-    if (tier == 0 && !T.long_always && work.size() > 524288) T.long_pops = 0;   // (two reads per resident lane)
+    if (!T.coop && !T.long_always && n_search > 524288) T.long_pops = 0;   // (two reads per resident lane; also what the first round of such a launch leaves)
     next_work.clear();
     for (size_t c0 = 0; c0 < work.size(); c0 += chunk_reads[tier]) {
       const int nw = (int)std::min(chunk_reads[tier], work.size() - c0);
-      CKM(c->d_work.ensure(nw) && c->d_wfull.ensure((size_t)nw * 2 * Lpad) && c->d_prec.ensure((size_t)nw * 2 * Ppad) && c->d_winfo.ensure(nw) && c->d_bid_end.ensure((size_t)nw * 2) && c->d_order.ensure(nw) && c->d_order_cnt.ensure(2 * FQ_ORDER_KEYS) &&
+      CKM(c->d_work.ensure(nw) && c->d_wfull.ensure((size_t)nw * 2 * Lpad) && c->d_prec.ensure((size_t)nw * 2 * Ppad) && c->d_winfo.ensure(nw) && c->d_bid_end.ensure((size_t)nw * 2) && c->d_order.ensure(nw) && c->d_order_cnt.ensure(2 * FQ_ORDER_KEYS + 2) &&
           c->d_aln.ensure((size_t)nw * T.aln_cap) && c->d_naln.ensure(nw) && c->d_status.ensure(nw) && c->d_off.ensure(nw + 1));
       CKM(c->p_i32.ensure(nw));
       memcpy(c->p_i32.p, work.data() + c0, (size_t)nw * 4);
@@ -891,7 +905,7 @@ int stageA_search(Call &K) {
       CK(fqdev::launch_order(c->d_bid_end.p, nw, c->d_order.p, c->d_order_cnt.p));   // long searches first
       fqdev::time_end(FQ_K_WIDTH);
       FqGapArgs ga{};
-      ga.ix = ix->dev; ga.o = c->ko; ga.o.n_buckets = nb_need; ga.n_work = nw; ga.winfo = c->d_winfo.p; ga.order = c->kn.gap_no_order ? nullptr : c->d_order.p;
+      ga.ix = ix->dev; ga.o = c->ko; ga.o.n_buckets = T.nogap ? std::min(nb_need, o.s_gapo + o.s_mm + 1) : nb_need; /* (no-gap round: parents below s_gapo only) */ ga.n_work = nw; ga.winfo = c->d_winfo.p; ga.order = c->kn.gap_no_order ? nullptr : c->d_order.p; ga.split = c->kn.gap_no_order ? nullptr : c->d_order_cnt.p + 2 * FQ_ORDER_KEYS;
       ga.wfull = c->d_wfull.p; ga.wstride = Lpad; ga.prec = c->d_prec.p; ga.pstride = Ppad;
       ga.pool = c->d_pool.p; ga.heads = c->d_heads.p; ga.tier = T; ga.aln = c->d_aln.p; ga.n_aln = c->d_naln.p; ga.status = c->d_status.p;
       ga.counters = c->d_counters.p; ga.queue = c->d_queue.p;
@@ -1471,6 +1485,7 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
   if (cnt[FQ_C_MAXTRIPS] > c->stats.max_wave_trips) c->stats.max_wave_trips = cnt[FQ_C_MAXTRIPS];
   c->stats.wave_trips += cnt[FQ_C_SUMTRIPS];
   c->stats.lane_trips += cnt[FQ_C_LANETRIPS];
+  for (int k = 0; k < 16; ++k) c->stats.dbg[k] += cnt[FQ_C_DBG0 + k];
   c->stats.pairs += K.n;
   c->stats.host_ms_serial += K.t_serial1 - K.t_host0;
   c->stats.host_ms_pair += K.t_host1 - K.t_serial1;

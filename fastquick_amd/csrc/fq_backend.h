@@ -60,7 +60,8 @@ int launch_patch(const FqPatchArgs &a);
 int launch_trim(const FqTrimArgs &a);
 int launch_trim_all(const FqTrimAllArgs &a);
 int launch_width(const FqWidthArgs &a);
-// order[0..n) = the work items sorted by descending fq_order_key (any order inside a key); cnt: FQ_ORDER_KEYS*2 words of scratch
+// order[0..n) = the work items sorted by descending fq_order_key (any order inside a key); cnt: FQ_ORDER_KEYS*2 + 1 words of scratch,
+// cnt[2 * FQ_ORDER_KEYS] = length of the first block of the queue (the keys of the upper half) on return
 int launch_order(const uint8_t *bid_end, int n, int32_t *order, uint32_t *cnt);
 // number of persistent lanes launch_gap() will start for these arguments (sizes a.pool / a.heads)
 int gap_lane_slots(const FqGapArgs &a);

@@ -102,6 +102,7 @@ struct FqGapWork {
 #define FQ_SF_ALN_OVERFLOW 2u    // more hits than the aln slot holds -> rerun in a larger tier
 #define FQ_SF_ENTRY_LIMIT 4u     // conservative entry count crossed max_entries -> exact tier decides
 #define FQ_SF_LONG 8u            // lane-per-read kernel: more pops than tier.long_pops -> searched again by a whole wavefront
+#define FQ_SF_NEEDGAP 16u        // search without gap children (tier.nogap): the full search could pop one -> searched again in full
 
 struct FqGapTier {       // one launch configuration of the gap-search kernel
   uint32_t pool_cap;     // entries per read
@@ -110,6 +111,8 @@ struct FqGapTier {       // one launch configuration of the gap-search kernel
   int32_t coop;          // 1: one read per wavefront (fq_gap_coop_wave), 0: one read per lane (fq_gap_lanes)
   uint32_t long_pops;    // lane kernel: give up on a read after this many pops once the work queue is empty (0: never)
   int32_t long_always;   // test hook: give up after long_pops pops whatever the state of the queue
+  int32_t nogap;         // lane kernel: 1 = first round of a large launch, the search without its gap children (see FqGapLane):
+                         // a read whose result could depend on them is flagged FQ_SF_NEEDGAP and searched in full by the next round
 };
 
 // SW / refine task descriptors
@@ -145,4 +148,4 @@ struct FqMdTask {
 };
 
 // work counters written by kernels (one u64 each, atomically accumulated per wave)
-enum { FQ_C_OCC_WIDTH = 0, FQ_C_OCC_GAP, FQ_C_OCC_SA, FQ_C_PROBES, FQ_C_POPS, FQ_C_PUSHES, FQ_C_MAXPOPS, FQ_C_POPS_GT4K, FQ_C_MAXTRIPS, FQ_C_SUMTRIPS, FQ_C_LANETRIPS, FQ_C_BASES, FQ_C_BADLEN, FQ_C_COUNT };
+enum { FQ_C_OCC_WIDTH = 0, FQ_C_OCC_GAP, FQ_C_OCC_SA, FQ_C_PROBES, FQ_C_POPS, FQ_C_PUSHES, FQ_C_MAXPOPS, FQ_C_POPS_GT4K, FQ_C_MAXTRIPS, FQ_C_SUMTRIPS, FQ_C_LANETRIPS, FQ_C_BASES, FQ_C_BADLEN, FQ_C_DBG0, FQ_C_DBG_END = FQ_C_DBG0 + 16, FQ_C_COUNT = FQ_C_DBG_END };

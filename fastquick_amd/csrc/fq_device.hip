@@ -205,16 +205,44 @@ struct FqQueueFetch {
   int n_work;
   __device__ uint32_t operator()(uint32_t n) const { return atomicAdd(cursor, n); }
 };
+// The lane kernels' queue is two blocks (fq_order_key): a wavefront draws from the block of its XCD's half first -- workgroups are
+// dealt round-robin over the 8 XCDs, so blockIdx % 8 tells which workgroups share an XCD (MI355X_MICROARCH.md, workgroup
+// dispatch) -- and from the other block when its own is exhausted.
+struct FqQueueFetch2 {
+  uint32_t *cursor;
+  const uint32_t *split;
+  uint32_t n_work;
+  int pref;
+  __device__ uint64_t operator()(uint32_t n) const {
+    const uint32_t sp = split ? *split : n_work;
+    const uint32_t start[2] = {0u, sp}, len[2] = {sp, n_work - sp};
+    for (int t = 0; t < 2; ++t) {
+      const int b = t == 0 ? pref : 1 - pref;
+      if (len[b] == 0) continue;
+      if (__hip_atomic_load(&cursor[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= len[b]) continue;
+      const uint32_t base = atomicAdd(&cursor[b], n);
+      if (base < len[b]) return (uint64_t)(start[b] + base) | (uint64_t)(start[b] + len[b]) << 32;
+    }
+    return 0;
+  }
+};
+#define FQ_LANE_FETCH(a) FqQueueFetch2{(a).queue, (a).split, (uint32_t)(a).n_work, (int)((blockIdx.x & 7u) >> 2)}
 // persistent wavefronts: every lane pulls reads from the queue until it is empty.  One wavefront per block.
 // LDS per lane: n_buckets 16-bit bucket heads, lane-interleaved.
 __global__ void __launch_bounds__(64) k_gap_persist_lds(FqGapArgs a) {
   uint16_t *heads = (uint16_t *)fq_dyn_lds;
   FqGapStoreLds st = {heads + threadIdx.x, 64};
-  fq_gap_lanes(a, st, FqQueueFetch{a.queue, a.n_work}, (int)(blockIdx.x * 64 + threadIdx.x));
+  fq_gap_lanes<false>(a, st, FQ_LANE_FETCH(a), (int)(blockIdx.x * 64 + threadIdx.x));
+}
+// first round of a device-filling launch: the search without its gap children (FqGapLane, NOGAP)
+__global__ void __launch_bounds__(64) k_gap_nogap_lds(FqGapArgs a) {
+  uint16_t *heads = (uint16_t *)fq_dyn_lds;
+  FqGapStoreLds st = {heads + threadIdx.x, 64};
+  fq_gap_lanes<true>(a, st, FQ_LANE_FETCH(a), (int)(blockIdx.x * 64 + threadIdx.x));
 }
 __global__ void __launch_bounds__(64) k_gap_persist(FqGapArgs a) {   // any pool size: bucket heads in HBM
   FqGapStoreGlobal st = {nullptr};
-  fq_gap_lanes(a, st, FqQueueFetch{a.queue, a.n_work}, (int)(blockIdx.x * 64 + threadIdx.x));
+  fq_gap_lanes<false>(a, st, FQ_LANE_FETCH(a), (int)(blockIdx.x * 64 + threadIdx.x));
 }
 // one read per wavefront (long searches): run table of the read's score buckets in LDS
 __global__ void __launch_bounds__(64) k_gap_coop(FqGapArgs a) {
@@ -811,10 +839,16 @@ __global__ void __launch_bounds__(256) k_order_scatter(const uint8_t *bid_end, i
   }
   __syncthreads();
   if (w < n) order[base[key] + rank] = w;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {   // length of the first block of the queue (keys of the upper half; descending order)
+    uint32_t sp = 0;
+    if (asc) { for (int k = 0; k < FQ_ORDER_KEYS / 2; ++k) sp += cnt[k]; }
+    else { for (int k = FQ_ORDER_KEYS / 2; k < FQ_ORDER_KEYS; ++k) sp += cnt[k]; }
+    cnt[2 * FQ_ORDER_KEYS] = sp;
+  }
 }
 int launch_order(const uint8_t *bid_end, int n, int32_t *order, uint32_t *cnt) {
   if (n <= 0) return 0;
-  FQ_HIP(hipMemsetAsync(cnt, 0, 2 * FQ_ORDER_KEYS * 4, g_stream));
+  FQ_HIP(hipMemsetAsync(cnt, 0, (2 * FQ_ORDER_KEYS + 1) * 4, g_stream));
   hipLaunchKernelGGL(k_order_count, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, bid_end, n, cnt);
   hipLaunchKernelGGL(k_order_scatter, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, bid_end, n, cnt, order, g_cur->tune.gap_order_asc ? 1 : 0);   // (experiment knob: ascending)
   FQ_HIP(hipGetLastError());
@@ -844,7 +878,7 @@ int launch_gap(const FqGapArgs &a_in) {
   FqGapArgs a = a_in;
   const int env_refill = g_cur->tune.gap_refill_min;
   a.refill_min = env_refill > 0 ? env_refill : FQ_REFILL_MIN;
-  FQ_HIP(hipMemsetAsync(a.queue, 0, 4, g_stream));
+  FQ_HIP(hipMemsetAsync(a.queue, 0, 8, g_stream));
   hipEvent_t e0, e1;
   kernel_events(7, &e0, &e1);   // FQ_K_GAP_KERNEL
   if (a.tier.coop) {
@@ -853,7 +887,8 @@ int launch_gap(const FqGapArgs &a_in) {
     // LDS-resident bucket heads when slot indices fit 16 bits
     const size_t lds = (size_t)64 * (size_t)a.o.n_buckets * 2;
     const unsigned grid = (unsigned)gap_lane_slots(a) / 64u;
-    if (a.tier.pool_cap <= 65535u) hipExtLaunchKernelGGL(k_gap_persist_lds, dim3(grid), dim3(64), lds, g_stream, e0, e1, 0, a);
+    if (a.tier.pool_cap <= 65535u && a.tier.nogap) hipExtLaunchKernelGGL(k_gap_nogap_lds, dim3(grid), dim3(64), lds, g_stream, e0, e1, 0, a);
+    else if (a.tier.pool_cap <= 65535u) hipExtLaunchKernelGGL(k_gap_persist_lds, dim3(grid), dim3(64), lds, g_stream, e0, e1, 0, a);
     else hipExtLaunchKernelGGL(k_gap_persist, dim3(grid), dim3(64), 0, g_stream, e0, e1, 0, a);
   }
   FQ_HIP(hipGetLastError());

@@ -173,6 +173,19 @@ FQ_HD void fq_occ1_pair(const FqFM &f, uint32_t km1, uint32_t l, int c, uint32_t
   *ol = fq_blk_occ1(bl, c);
 }
 
+// The two blocks of one search step (rows k-1 and l).  A request for a block is what the search kernels are bound by (their time
+// follows the number of busy lanes x requests, not the number of loop iterations): once the interval is narrow -- after the first
+// dozen bases of a read -- both rows sit in the same 64-base block, which is then fetched once and only re-masked.
+FQ_HD void fq_blk_load_pair(const FqOccBlk *blk, uint32_t primary, uint32_t km1, uint32_t l, FqBlkRaw &bk, FqBlkRaw &bl) {
+  bk = fq_blk_load(blk, primary, km1);
+  const uint32_t ak = km1 >= primary ? km1 - 1 : km1, al = l >= primary ? l - 1 : l;
+  if (bk.valid && l != 0xffffffffu && (ak >> 6) == (al >> 6)) {
+    bl = bk;
+    const uint32_t t = al & 63, t0 = t < 32 ? t : 31, t1 = t < 32 ? 0 : t - 32;
+    bl.mk0 = 0xffffffffu << (31 - t0);
+    bl.mk1 = t < 32 ? 0u : (0xffffffffu << (31 - t1));
+  } else bl = fq_blk_load(blk, primary, l);
+}
 
 // ---- K_prep: encode + quality trim + k-mer filter ----------------------------------------------
 // bwa_read_seq_with_hash_dev (src/BwtMapper.cpp:526-588), bwa_trim_read (libbwa/bwaseqio.c:75-88),
@@ -635,12 +648,16 @@ FQ_HD void fq_width_thread(const FqWidthArgs &A, int t, uint8_t *seed_bits, int 
 // every divergent path of the loop is then executed for many lanes or not at all.  (The kernel is instruction-issue bound; on
 // the on-target workload this ordering took it from 94 to 62 ms.)  Descending order: the long, irregular searches run while
 // the device is full, the launch ends on the uniform ones.
+// The key's top bit is the better strand: the queue is two blocks, reads that will walk mostly the reverse BWT and reads that will
+// walk mostly the forward one (strand a searches bwt[1 - a]), each sorted by bound.  The wavefronts of half of the XCDs draw from
+// one block first, the others from the other (fq_gap_lanes): an XCD's 4 MB L2 then serves mostly one 3.3 MB Occ table instead of
+// being shared by two.
 #define FQ_ORDER_KEYS 16
 FQ_HD int fq_order_key(const uint8_t *bid_end, int w) {
   const int a = bid_end[2 * w], b = bid_end[2 * w + 1];
   int k = a < b ? a : b;
   if (k > FQ_ORDER_KEYS / 2 - 1) k = FQ_ORDER_KEYS / 2 - 1;
-  return 2 * k + (b <= a ? 0 : 1);   // within a bound: reads whose better strand is strand 1 (the root that is popped first) together
+  return (b <= a ? 0 : FQ_ORDER_KEYS / 2) + k;
 }
 
 // ---- K_gap: bwt_match_gap (libbwa/bwtgap.c:104-264) --------------------------------------------
@@ -670,8 +687,9 @@ struct FqGapArgs {
   uint32_t *n_aln;
   uint32_t *status;
   uint64_t *counters;
-  const int32_t *order;  // queue position -> work item (NULL: identity): long searches first, see fq_order_key
-  uint32_t *queue;       // work-queue cursor (zeroed before each launch)
+  const int32_t *order;  // queue position -> work item (NULL: identity): two blocks by better strand, long searches first (fq_order_key)
+  const uint32_t *split; // *split = length of the first block of `order` (NULL: one block)
+  uint32_t *queue;       // work-queue cursors, one per block (zeroed before each launch)
   int32_t refill_min;    // idle lanes of a wavefront wait until this many can be (re)initialised together
   int32_t max_waves;     // 0: as many wavefronts as the device holds; else a cap (the host lowers it when pool memory is short)
 };
@@ -738,7 +756,16 @@ extern unsigned long long fq_prof[64];
 // The per-read state is a plain struct with inlined member functions; per-strand index fields are chosen with masks:
 // closures capturing by reference, "cond ? mem_a : mem_b", or a runtime index into the kernel-argument struct make hipcc
 // keep the whole state in scratch memory (680 B/lane, every access a memory round trip).
-template <class St>
+// NOGAP: the first round of a device-filling launch searches without the gap children.  Children of a gap cost at least s_gapo
+// more than their parent, so every entry the search pops from a bucket below s_gapo is an M-state entry reached by matches and
+// mismatches only, and those buckets hold the same entries in the same order whether gap children are pushed or not.  If the
+// first alignment is found there and best_score + s_mm < s_gapo, the reference stops (bwtgap.c:147) before it could pop a gap
+// child: the hit list is complete -- for a 150 bp read with up to two mismatches, nine reads in ten of an on-target set.  The
+// gap children it would have pushed in the meantime (five per step at most) only count towards max_entries, so they are added to
+// n_live; any other read (no hit below s_gapo, a pop from a bucket >= s_gapo, non-stop mode) is flagged FQ_SF_NEEDGAP and
+// searched again, in full, by the next round.  The step of this round has no gap group: three quarters of the pushes and a
+// third of the instructions of the first walk down a read are gone.
+template <class St, bool NOGAP = false>
 struct FqGapLane {
   const FqGapArgs &A;
   St store;
@@ -761,9 +788,39 @@ struct FqGapLane {
   int best_score, max_diff, best_cnt;
   uint32_t c_pops, c_pushes, c_touch;
   // current entry (valid when has_cur or hit_pending)
-  bool has_cur, tail, hit_pending;
+  bool has_cur, tail, hit_pending, too_many_n;
   uint32_t ck_, cl_, cpk;
   int cscore;
+  uint32_t t_pops = 0, t_pushes = 0, t_touch = 0;   // totals over this lane's completed searches (a lane's share of a launch: 32 bits)
+  uint32_t t_maxpops = 0, t_gt4k = 0;
+  FQ_HD void flush_counters() {   // at the end of the wavefront's life
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint64_t v[3] = {t_pops, t_pushes, t_touch};
+    uint32_t mx = t_maxpops, g4 = t_gt4k;
+    for (int d = 32; d >= 1; d >>= 1) {
+      for (int q = 0; q < 3; ++q) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v[q], d), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v[q] >> 32), d);
+        v[q] += (uint64_t)lo | (uint64_t)hi << 32;
+      }
+      const uint32_t om = (uint32_t)__shfl_xor((int)mx, d);
+      mx = om > mx ? om : mx;
+      g4 += (uint32_t)__shfl_xor((int)g4, d);
+    }
+    if (FQ_LANE_ID() == 0) {
+      FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS], v[0]);
+      FQ_ATOMIC_ADD64(&A.counters[FQ_C_PUSHES], v[1]);
+      FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_GAP], v[2]);
+      FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXPOPS], mx);
+      if (g4) FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS_GT4K], g4);
+    }
+#else
+    FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS], t_pops);
+    FQ_ATOMIC_ADD64(&A.counters[FQ_C_PUSHES], t_pushes);
+    FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_GAP], t_touch);
+    FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXPOPS], t_maxpops);
+    if (t_gt4k) FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS_GT4K], t_gt4k);
+#endif
+  }
 
   FQ_HD FqGapLane(const FqGapArgs &A_, const St &st, int lane_slot) : A(A_), store(st), o(A_.o) {
     gape_mode = (o.mode & FQ_MODE_GAPE) != 0; nonstop = (o.mode & FQ_MODE_NONSTOP) != 0; exact = A_.tier.exact != 0;
@@ -776,7 +833,7 @@ struct FqGapLane {
     store.begin_lane(A_, lane_slot);
     m0 = m1 = m2 = m3 = bump = status = n_aln = 0; spare = FQ_NIL; n_live = 0;
     best_score = max_diff = best_cnt = 0; c_pops = c_pushes = c_touch = 0;
-    has_cur = tail = hit_pending = false; ck_ = cl_ = cpk = 0; cscore = 0;
+    has_cur = tail = hit_pending = too_many_n = false; ck_ = cl_ = cpk = 0; cscore = 0;
   }
   FQ_HD bool bucket_test(int b) const { return ((fq_sel4v(m0, m1, m2, m3, b >> 5) >> (b & 31)) & 1u) != 0; }
   FQ_HD void bucket_set(int b) { const uint32_t bit = 1u << (b & 31); const int q = b >> 5; m0 |= bit & (0u - (uint32_t)(q == 0)); m1 |= bit & (0u - (uint32_t)(q == 1)); m2 |= bit & (0u - (uint32_t)(q == 2)); m3 |= bit & (0u - (uint32_t)(q == 3)); }
@@ -800,20 +857,35 @@ struct FqGapLane {
     spare = FQ_NIL;
     FqEntry e;
     e.k = k; e.l = l; e.pk = pk; e.next = prev;
+    // Stack entries stream out (two in three are never read back): a non-temporal store keeps them from displacing the Occ blocks
+    // from the 4 MB L2 of the XCD, which every step of every lane reads.
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+      typedef uint32_t fq_v4u __attribute__((ext_vector_type(4)));
+      fq_v4u v;
+      v.x = e.k; v.y = e.l; v.z = e.pk; v.w = e.next;
+      __builtin_nontemporal_store(v, (fq_v4u *)(pool + slot));
+    }
+#else
     pool[slot] = e;
+#endif
     prev = slot;
     ++c_pushes; FQ_PROF(12);
   }
   FQ_HD void group_close(int score, uint32_t prev) { store.head_set(score, prev); bucket_set(score); }
 
   FQ_HD void finish() {
-    A.n_aln[w] = status ? 0u : n_aln;   // failed reads are re-run in a larger tier; expose no partial list
+    // failed reads are re-run in a larger tier; expose no partial list
+    if (NOGAP && status == 0 && !(n_aln > 0 && !nonstop && best_score + o.s_mm < o.s_gapo) && !too_many_n) status |= FQ_SF_NEEDGAP;
+    A.n_aln[w] = status ? 0u : n_aln;
     A.status[w] = status;
-    FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS], c_pops);
-    FQ_ATOMIC_ADD64(&A.counters[FQ_C_PUSHES], c_pushes);
-    FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXPOPS], c_pops);
-    if (c_pops > 4096) FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS_GT4K], 1);
-    FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_GAP], c_touch);
+    if (status == 0) {   // work counters describe completed searches only: a read that is searched again (larger tier, next round) counts once.
+      // They are summed per lane here and reach the global counters once per wavefront (flush_counters): five atomics per read on
+      // five shared addresses cost an on-target launch 12 % of its time.
+      t_pops += c_pops; t_pushes += c_pushes; t_touch += c_touch;
+      if (c_pops > t_maxpops) t_maxpops = c_pops;
+      if (c_pops > 4096) ++t_gt4k;
+    }
     active = false; has_cur = false; tail = false; hit_pending = false;
   }
 
@@ -832,7 +904,8 @@ struct FqGapLane {
     c_pops = c_pushes = c_touch = 0;
     has_cur = tail = hit_pending = false;
     active = true;
-    if ((gw.meta >> 24) & 1u) { finish(); return; }   // "too many N" early-out of bwt_match_gap (bwtgap.c:118-124)
+    too_many_n = ((gw.meta >> 24) & 1u) != 0;
+    if (too_many_n) { finish(); return; }   // "too many N" early-out of bwt_match_gap (bwtgap.c:118-124)
     // the two roots (bwtgap.c:139-140): strand 0 first, so strand 1 is popped first
     uint32_t prev = FQ_NIL;
     group_put(0, seq_len, fq_pack(len, 0, FQ_ST_M, 0, 0, 0, 0), prev);
@@ -851,6 +924,7 @@ struct FqGapLane {
       if ((m0 | m1 | m2 | m3) == 0) { finish(); return; }
       if (n_live > o.max_entries) { if (!exact) status |= FQ_SF_ENTRY_LIMIT; finish(); return; }   // bwtgap.c:144
       b = m0 ? FQ_CTZ32(m0) : m1 ? 32 + FQ_CTZ32(m1) : m2 ? 64 + FQ_CTZ32(m2) : 96 + FQ_CTZ32(m3);
+      if (NOGAP && b >= o.s_gapo) { status |= FQ_SF_NEEDGAP; finish(); return; }   // the full search may hold a gap child at or below this bucket
       slot = store.head_get(b);
     }
     // ---- loads: a popping lane fetches its 16-byte stack entry; a lane with a current entry fetches the two Occ blocks of
@@ -868,8 +942,7 @@ struct FqGapLane {
     if (!popping) {
       const FqOccBlk *blk = (const FqOccBlk *)fq_pick2p((uint64_t)(uintptr_t)blk0, (uint64_t)(uintptr_t)blk1, a);   // strand a searches the other strand's BWT (bwtgap.c:148)
       const uint32_t primary = fq_pick2(primary0, primary1, a);
-      bk = fq_blk_load(blk, primary, ck_ - 1);
-      bl = fq_blk_load(blk, primary, cl_);
+      fq_blk_load_pair(blk, primary, ck_ - 1, cl_, bk, bl);
     } else {
       bk = fq_blk_none(); bl = fq_blk_none();
     }
@@ -947,7 +1020,8 @@ struct FqGapLane {
       int tmp;
       if (o.mode & FQ_MODE_LOGGAP) { uint32_t vv = (uint32_t)(n_gape + n_gapo); int lg = 0; while (vv >>= 1) ++lg; tmp = lg / 2 + 1; }
       else tmp = n_gapo + n_gape;
-      if (i >= o.indel_end_skip + tmp && len - i >= o.indel_end_skip + tmp) {   // ---- gap children (bwtgap.c:212-243)
+      if (NOGAP) n_live += 5;   // what the gap group below would have pushed at most (they only count towards max_entries)
+      if (!NOGAP && i >= o.indel_end_skip + tmp && len - i >= o.indel_end_skip + tmp) {   // ---- gap children (bwtgap.c:212-243)
         const bool is_open = st == FQ_ST_M;
         const bool can = is_open ? n_gapo < o.max_gapo : n_gape < o.max_gape;
         const bool has_I = can && st != FQ_ST_D;
@@ -1081,33 +1155,58 @@ struct FqGapLane {
   }
 };
 
-// fetch(n): reserves n consecutive queue positions and returns the first
-template <class St, class Fetch>
+// fetch(n): reserves n consecutive queue positions of one block of the queue; returns first | limit << 32 -- positions below
+// `limit` are valid, limit == 0: the queue is exhausted
+template <bool NOGAP, class St, class Fetch>
 FQ_HD void fq_gap_lanes(const FqGapArgs &A, const St &store0, Fetch fetch, int lane_slot) {
-  FqGapLane<St> L(A, store0, lane_slot);
+  FqGapLane<St, NOGAP> L(A, store0, lane_slot);
   uint32_t trips = 0, lane_trips = 0;
+#if defined(FQ_GAP_INSTR) && defined(__HIP_DEVICE_COMPILE__)
+  uint32_t ib[16];
+  for (int q = 0; q < 16; ++q) ib[q] = 0;
+#endif
   for (;; ++trips) {
     // (re)fill idle lanes, in groups: one queue reservation per group
     const bool want = !L.active && !L.done;
     const uint64_t wm = FQ_BALLOT(want), am = FQ_BALLOT(L.active);
     if (wm == 0 && am == 0) {
-      FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXTRIPS], trips);
-      if (FQ_LANE_ID() == 0) FQ_ATOMIC_ADD64(&A.counters[FQ_C_SUMTRIPS], trips);
+#if defined(FQ_GAP_INSTR) && defined(__HIP_DEVICE_COMPILE__)
+      if (FQ_LANE_ID() == 0) for (int q = 0; q < 16; ++q) FQ_ATOMIC_ADD64(&A.counters[FQ_C_DBG0 + q], ib[q]);
+#endif
+      L.flush_counters();
+      if (FQ_LANE_ID() == 0) { FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXTRIPS], trips); FQ_ATOMIC_ADD64(&A.counters[FQ_C_SUMTRIPS], trips); }
       FQ_ATOMIC_ADD64(&A.counters[FQ_C_LANETRIPS], lane_trips);
       break;
     }
     if (wm != 0 && (FQ_POPC64(wm) >= A.refill_min || am == 0)) {
       const int leader = FQ_CTZ64(wm);
-      uint32_t base_l = 0;
-      if (FQ_LANE_ID() == leader) base_l = fetch((uint32_t)FQ_POPC64(wm));
-      const uint32_t base = FQ_READLANE32(base_l, leader);
+      uint64_t got_l = 0;
+      if (FQ_LANE_ID() == leader) got_l = fetch((uint32_t)FQ_POPC64(wm));
+      const uint32_t base = FQ_READLANE32((uint32_t)got_l, leader), limit = FQ_READLANE32((uint32_t)(got_l >> 32), leader);
       if (want) {
         const uint32_t wq = base + (uint32_t)FQ_POPC64(wm & (((uint64_t)1 << FQ_LANE_ID()) - 1));
-        if (wq >= (uint32_t)A.n_work) L.done = true; else L.begin(A.order ? A.order[wq] : (int)wq);
+        if (limit == 0) L.done = true;
+        else if (wq < limit) L.begin(A.order ? A.order[wq] : (int)wq);   // (a lane past the end of the block asks again with the next group)
       }
     }
+#if defined(FQ_GAP_INSTR) && defined(__HIP_DEVICE_COMPILE__)
+    {   // which paths this trip will execute, and for how many lanes
+      const uint64_t a2 = FQ_BALLOT(L.active);
+      const int na = (int)FQ_POPC64(a2);
+      ib[0] += 1; ib[1] += (uint32_t)na;
+      ib[2 + (na == 0 ? 0 : na <= 8 ? 1 : na <= 16 ? 2 : na <= 32 ? 3 : na <= 48 ? 4 : 5)] += 1;     // 2..7: trips by active lanes (0, 1-8, 9-16, 17-32, 33-48, 49-64)
+      const uint64_t pop = FQ_BALLOT(L.active && !L.has_cur), tl = FQ_BALLOT(L.active && L.has_cur && L.tail), ex = FQ_BALLOT(L.active && L.has_cur && !L.tail);
+      ib[8] += pop != 0; ib[9] += tl != 0; ib[10] += ex != 0;
+      ib[11] += (uint32_t)FQ_POPC64(pop); ib[12] += (uint32_t)FQ_POPC64(tl); ib[13] += (uint32_t)FQ_POPC64(ex);
+      ib[14] += (pop != 0) + (tl != 0) + (ex != 0) == 3;
+    }
+#endif
     if (L.active) { ++lane_trips; L.step(); }
-    if (FQ_BALLOT(L.hit_pending) != 0) L.collect_hits();
+    const bool any_hit = FQ_BALLOT(L.hit_pending) != 0;
+#if defined(FQ_GAP_INSTR) && defined(__HIP_DEVICE_COMPILE__)
+    ib[15] += any_hit;
+#endif
+    if (any_hit) L.collect_hits();
   }
 }
 
@@ -1224,7 +1323,8 @@ struct FqGapCoop {
     }
     const FqOccBlk *blk = (const FqOccBlk *)fq_pick2p((uint64_t)(uintptr_t)blk0, (uint64_t)(uintptr_t)blk1, a);
     const uint32_t primary = fq_pick2(primary0, primary1, a);
-    const FqBlkRaw bk = fq_blk_load(blk, primary, ck_ - 1), bl = fq_blk_load(blk, primary, cl_);
+    FqBlkRaw bk, bl;
+    fq_blk_load_pair(blk, primary, ck_ - 1, cl_, bk, bl);
     const int o1 = (i0 - 1) - wbase, o2 = need_lo - wbase;
     const uint32_t rec1 = (fq_sel4v(pw0, pw1, pw2, pw3, o1 >> 1) >> ((o1 & 1) << 4)) & 0xffffu;
     const uint32_t rec2 = (fq_sel4v(pw0, pw1, pw2, pw3, o2 >> 1) >> ((o2 & 1) << 4)) & 0xffffu;
@@ -1322,11 +1422,13 @@ struct FqGapCoop {
     if (FQ_LANE_ID() == 0) {
       A.n_aln[w] = status ? 0u : n_aln;
       A.status[w] = status;
-      FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS], c_pops);
-      FQ_ATOMIC_ADD64(&A.counters[FQ_C_PUSHES], c_pushes);
-      FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXPOPS], c_pops);
-      if (c_pops > 4096) FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS_GT4K], 1);
-      FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_GAP], c_touch);
+      if (status == 0) {
+        FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS], c_pops);
+        FQ_ATOMIC_ADD64(&A.counters[FQ_C_PUSHES], c_pushes);
+        FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXPOPS], c_pops);
+        if (c_pops > 4096) FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS_GT4K], 1);
+        FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_GAP], c_touch);
+      }
     }
   }
 

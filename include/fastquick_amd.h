@@ -216,7 +216,7 @@ int fq_packed_prefetch(fq_ctx_t *c, const fq_packed_batch_t *next);
 int fq_align_packed(fq_ctx_t *c, const fq_packed_batch_t *in, fq_result_batch_t *out);
 
 /* Experiment / test knobs by name (defaults are what DESIGN.md measures): gap_long_pops, gap_long_always, gap_pool,
- * gap_no_order, gap_order_asc, gap_waves_per_cu, gap_refill_min, sw_wave_max, host_threads, host_par_min, filter_no_turns,
+ * gap_nogap_min, gap_no_order, gap_order_asc, gap_waves_per_cu, gap_refill_min, sw_wave_max, host_threads, host_par_min, filter_no_turns,
  * refine_lanes, packed_bulk_min, trace.  FQ_EINVAL for an unknown key. */
 int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t value);
 
@@ -257,6 +257,7 @@ typedef struct {
   uint64_t wave_trips;          /* loop iterations summed over the gap kernel's wavefronts */
   uint64_t lane_trips;          /* ... summed over lanes that held a read in that iteration (wave_trips x 64 = all slots) */
   uint64_t h2d_bytes, d2h_bytes; /* bytes the calls moved over PCIe (inputs, task lists; results) */
+  uint64_t dbg[16];             /* experiment counters of instrumented builds (-DFQ_GAP_INSTR), zero otherwise */
 } fq_stats_t;
 void fq_stats_get(const fq_ctx_t *c, fq_stats_t *out);
 void fq_stats_reset(fq_ctx_t *c);

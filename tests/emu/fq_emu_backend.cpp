@@ -65,13 +65,18 @@ int launch_patch(const FqPatchArgs &a) { for (int64_t q = 0; q < a.n_exc; ++q) f
 int launch_trim(const FqTrimArgs &a) { for (int t = 0; t < a.n_rows; ++t) fq_trim_thread(a, t); return 0; }
 int launch_trim_all(const FqTrimAllArgs &a) { for (int r = 0; r < a.n_reads; ++r) fq_trim_all_thread(a, r); return 0; }
 int launch_width(const FqWidthArgs &a) { uint8_t seed_bits[FQ_SEED_MAX]; for (int t = 0; t < a.n_work * 2; ++t) fq_width_thread(a, t, seed_bits, 1); return 0; }
-int launch_order(const uint8_t *bid_end, int n, int32_t *order, uint32_t *) {
+int launch_order(const uint8_t *bid_end, int n, int32_t *order, uint32_t *cnt) {
   int at = 0;
-  for (int k = FQ_ORDER_KEYS - 1; k >= 0; --k)
+  cnt[2 * FQ_ORDER_KEYS] = 0;
+  for (int k = FQ_ORDER_KEYS - 1; k >= 0; --k) {
     for (int w = 0; w < n; ++w) if (fq_order_key(bid_end, w) == k) order[at++] = w;
+    if (k == FQ_ORDER_KEYS / 2) cnt[2 * FQ_ORDER_KEYS] = (uint32_t)at;
+  }
   return 0;
 }
 struct SeqFetch { uint32_t *next; int n; uint32_t operator()(uint32_t k) const { const uint32_t at = *next; *next += k; return at; } };
+// the lane kernels' two-block queue, walked front to back by the single host "wavefront"
+struct SeqFetch2 { uint32_t *next; uint32_t n; uint64_t operator()(uint32_t k) const { const uint32_t at = *next; *next += k; return at < n ? (uint64_t)at | (uint64_t)n << 32 : 0; } };
 int gap_lane_slots(const FqGapArgs &a) { return a.n_work > 0 ? 1 : 0; }
 int launch_gap(const FqGapArgs &a_in) {
   FqGapArgs a = a_in;
@@ -83,10 +88,11 @@ int launch_gap(const FqGapArgs &a_in) {
   } else if (a.tier.pool_cap <= 65535u) {   // same store policy the HIP launcher picks: 16-bit heads in (here: emulated) LDS
     std::vector<uint16_t> heads(a.o.n_buckets);
     FqGapStoreLds st = {heads.data(), 1};
-    fq_gap_lanes(a, st, SeqFetch{next_p, a.n_work}, 0);
+    if (a.tier.nogap) fq_gap_lanes<true>(a, st, SeqFetch2{next_p, (uint32_t)a.n_work}, 0);
+    else fq_gap_lanes<false>(a, st, SeqFetch2{next_p, (uint32_t)a.n_work}, 0);
   } else {
     FqGapStoreGlobal st = {nullptr};
-    fq_gap_lanes(a, st, SeqFetch{next_p, a.n_work}, 0);
+    fq_gap_lanes<false>(a, st, SeqFetch2{next_p, (uint32_t)a.n_work}, 0);
   }
   return 0;
 }

@@ -1,0 +1,40 @@
+#!/usr/bin/env python3
+"""Path statistics of the lane search kernel on the on-target mix (instrumented build: `make -C fastquick_amd/csrc instr`,
+FQ_LIB_EXPERIMENT=fastquick_amd/libfastquick_amd_instr.so).  Prints how often each path of a loop iteration ("trip") is
+executed by a wavefront and for how many lanes."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+from fastquick_amd import api, synth
+
+pairs = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 19
+tune = dict(kv.split("=") for kv in sys.argv[2].split(",")) if len(sys.argv) > 2 else {}
+wd = os.environ.get("FQ_BENCH_DIR", "/tmp/fq_bench")
+os.makedirs(wd, exist_ok=True)
+pre = os.path.join(wd, "m10000.FASTQuick.fa")
+ref = synth.make_reference(n_markers=10000, n_long=1000, seed=12345)
+if not os.path.exists(pre + ".rsa"):
+    ref.write_fasta(pre)
+    api.build_index(pre)
+rb = synth.make_reads(ref, pairs, on_target=1.0, seed=3000)
+ix = api.Index(pre, device=0)
+al = api.Aligner(ix, max_pairs=pairs, tuning={k: int(v) for k, v in tune.items()})
+al.upload(rb.seq, rb.qual, rb.lens, None)
+al.align_resident()
+al.reset_stats()
+t0 = time.perf_counter()
+al.align_resident()
+dt = time.perf_counter() - t0
+s = al.stats()
+d = s["dbg"]
+reads = s["reads_searched"]
+print("pairs %d reads %d call %.1f ms gap kernel %.2f ms  pops/read %.1f pushes/read %.1f" % (pairs, reads, 1e3 * dt, s["kernel_ms"][7], s["stack_pops"] / reads, s["stack_pushes"] / reads))
+print("wave trips %d (%.1f per 64 reads)  lane trips %d  active lanes / trip %.1f" % (s["wave_trips"], s["wave_trips"] / (reads / 64.0), s["lane_trips"], s["lane_trips"] / max(1, s["wave_trips"])))
+if d[0]:
+    print("instrumented trips %d, mean active %.1f" % (d[0], d[1] / d[0]))
+    for name, k in (("0", 2), ("1-8", 3), ("9-16", 4), ("17-32", 5), ("33-48", 6), ("49-64", 7)):
+        print("  trips with %5s active lanes: %5.1f %%" % (name, 100.0 * d[k] / d[0]))
+    for name, k in (("pop", 8), ("tail", 9), ("expand", 10)):
+        print("  %-6s path executed in %5.1f %% of trips, %5.1f lanes when executed (%.1f lane-trips per read)" % (name, 100.0 * d[k] / d[0], d[k + 3] / max(1, d[k]), d[k + 3] / reads))
+    print("  all three paths in %.1f %% of trips; hit collection in %.1f %%" % (100.0 * d[14] / d[0], 100.0 * d[15] / d[0]))
