@@ -73,12 +73,39 @@ std::string read_name(const FqHostReads *hb, int pair, int end, bool revived) {
   return s;
 }
 
+// StatCollector::AddAlignment runs before the records are printed (src/BwtMapper.cpp:2047-2050, 2075-2079) and turns a hit that hangs
+// over the end of its contig into NO_MATCH (src/StatCollector.cpp:955-971); every consumer sees the record after that.
+void bridge_mutation(const fq_index *ix, FqRead &p) {
+  if (p.type == FQ_TYPE_NO_MATCH) return;
+  int seqid;
+  const int j = (int)(ref_end(p) - p.pos);
+  fq_coor_pac2real(ix, p.pos, j, &seqid);
+  if ((int64_t)p.pos + j - ix->contigs[seqid].offset > ix->contigs[seqid].len) p.type = FQ_TYPE_NO_MATCH;
+}
+
 void print_sam(const fq_index *ix, const fq_opts_t *o, const FqHostReads *hb, int n_pairs, Out &out, FqRead p, const FqRead &mate) {
   const int pair = p.r % n_pairs;
   uint8_t seq[FQ_LMAX + 8];
   hb->codes((size_t)p.r, p.full_len, seq);
   const uint8_t *qual = hb->qual((size_t)p.r);
   const std::string name = read_name(hb, pair, p.r / n_pairs, p.revived);
+  if (p.type == FQ_TYPE_NO_MATCH && mate.type == FQ_TYPE_NO_MATCH) {
+    // both hits of the pair hung over a contig end: the record of a read without a match (bwase.c:563-579).  It prints p->len bases
+    // of p->seq, or of p->rseq when the lost hit was on the reverse strand: the reverse complement of the (trimmed) read, and past a
+    // trimmed read's end whatever the reference's slot buffer holds -- code 0 here (not modelled, like the other slot leftovers).
+    out.printf("%s\t%d\t*\t0\t0\t*\t*\t0\t0\t", name.c_str(), p.extra_flag | 4 | 8);
+    for (int j = 0; j < p.len; ++j) {
+      int cc = seq[j];
+      if (p.strand) { cc = j < p.clip_len ? seq[p.clip_len - 1 - j] : 3; cc = cc < 4 ? 3 - cc : cc; }
+      out.putc("ACGTN"[cc > 4 ? 4 : cc]);
+    }
+    out.putc('\t');
+    const int qsub0 = (o->mode & FQ_MODE_IL13) ? 31 : 0;
+    for (int j = 0; j < p.full_len; ++j) out.putc((char)(qual[(p.strand && j < p.len) ? p.len - 1 - j : j] - qsub0));   // (no +31 on this branch)
+    if (p.clip_len < p.full_len) out.printf("\tXC:i:%d", p.clip_len);
+    out.putc('\n');
+    return;
+  }
   // only called when at least one mate is mapped (both-unmapped pairs are dropped before, BwtMapper.cpp:2038)
   int seqid, nn, am = 0, flag = p.extra_flag, j;
   if (p.type == FQ_TYPE_NO_MATCH) { p.pos = mate.pos; p.strand = mate.strand; flag |= 4; j = 1; }
@@ -163,8 +190,10 @@ extern "C" int64_t fq_sam_format_last(fq_ctx_t *c, char *buf, int64_t cap) {
   Out out;
   out.s.reserve((size_t)S->n_surv * 900);
   for (int sp = 0; sp < S->n_surv; ++sp) {
-    const FqRead &a = S->reads[2 * sp], &b = S->reads[2 * sp + 1];
-    if (a.type == FQ_TYPE_NO_MATCH && b.type == FQ_TYPE_NO_MATCH) continue;
+    if (S->reads[2 * sp].type == FQ_TYPE_NO_MATCH && S->reads[2 * sp + 1].type == FQ_TYPE_NO_MATCH) continue;   // src/BwtMapper.cpp:2038-2042
+    FqRead a = S->reads[2 * sp], b = S->reads[2 * sp + 1];
+    bridge_mutation(ix, a);
+    bridge_mutation(ix, b);
     print_sam(ix, o, hb, S->n_pairs, out, a, b);
     print_sam(ix, o, hb, S->n_pairs, out, b, a);
   }

@@ -44,7 +44,7 @@ class SynthRef:
 
 def make_reference(n_markers: int = 40, n_long: int = 4, flank_short: int = 250, flank_long: int = 1000,
                    spacing: int = 3000, seed: int = 12345, repeat_every: int = 0, repeat_div: float = 0.005,
-                   n_frac: float = 0.0, tandem_every: int = 0, patch=None) -> SynthRef:
+                   n_frac: float = 0.0, tandem_every: int = 0, patch=None, sex_every: int = 0) -> SynthRef:
     """Build a synthetic genome + reduced reference.
 
     repeat_every>0 makes every `repeat_every`-th window a diverged copy of its predecessor
@@ -83,7 +83,8 @@ def make_reference(n_markers: int = 40, n_long: int = 4, flank_short: int = 250,
             s[m] = ord("N")
         ref = int(genome[p - 1])
         alt = (ref + 1 + k % 3) % 4
-        nm = "1:%d@%s/%s" % (p, "ACGT"[ref], "ACGT"[alt])
+        chrom = "1" if not sex_every or k % sex_every else ("X" if (k // sex_every) % 2 == 0 else "Y")   # a few markers on the sex chromosomes (StatCollector's .SexChromInfo)
+        nm = "%s:%d@%s/%s" % (chrom, p, "ACGT"[ref], "ACGT"[alt])
         if f == flank_long:
             nm += "|L"
         names.append(nm)
@@ -124,11 +125,16 @@ def make_reads(ref: SynthRef, n_pairs: int, read_len: int = 150, on_target: floa
                sub_rate: float = 0.005, del_frac: float = 0.02, ins_frac: float = 0.0, n_rate: float = 0.0,
                frag_mean: float = 350.0, frag_sd: float = 30.0, qual_decay: bool = False,
                name_prefix: str = "r", indel_len_max: int = 1, chimera_frac: float = 0.0,
-               name_offset: int = 0) -> ReadBatch:
+               name_offset: int = 0, edge_frac: float = 0.0, dup_frac: float = 0.0, adapter_frac: float = 0.0) -> ReadBatch:
     """Vectorised read-pair synthesis.  Mates are randomly swapped (so read 1 is on either strand).
 
     Off-target pairs are i.i.d. random sequence; on-target pairs are cut from the genome inside a marker
-    window and then mutated (substitutions, optional indels / N / chimeric mates)."""
+    window and then mutated (substitutions, optional indels / N / chimeric mates).
+
+    "Real-shaped" extras (SURVEY 8d cfg 4; each draws from its own generator, so the defaults leave earlier fixtures as they were):
+    edge_frac -- fragments that begin up to 60 bp before / end up to 60 bp behind their marker window, so that a mate hangs over the
+    end of its contig; dup_frac -- pairs that are exact copies of the pair before them (PCR duplicates); adapter_frac -- reads whose
+    last 5..40 bases are adapter sequence."""
     rng = np.random.default_rng(seed)
     L = read_len
     on = rng.random(n_pairs) < on_target
@@ -150,6 +156,12 @@ def make_reads(ref: SynthRef, n_pairs: int, read_len: int = 150, on_target: floa
         hi = ref.marker_pos[k] + ref.flank[k]              # exclusive end of window
         span = np.maximum(hi - lo - frag, 1)
         start = lo + (rng.random(n_on) * span).astype(np.int64)
+        if edge_frac > 0:
+            rng_e = np.random.default_rng(seed + 7919)
+            sel = rng_e.random(n_on) < edge_frac
+            over = rng_e.integers(1, 61, n_on)
+            left = rng_e.random(n_on) < 0.5
+            start = np.where(sel & left, lo - over, np.where(sel & ~left, hi - frag + over, start))
         ch = rng.random(n_on) < chimera_frac if chimera_frac > 0 else np.zeros(n_on, dtype=bool)
         idx = np.arange(L, dtype=np.int32)
         extra = indel_len_max + 2
@@ -190,14 +202,62 @@ def make_reads(ref: SynthRef, n_pairs: int, read_len: int = 150, on_target: floa
     tmp = out[0, swap].copy()
     out[0, swap] = out[1, swap]
     out[1, swap] = tmp
+    if adapter_frac > 0:
+        rng_a = np.random.default_rng(seed + 104729)
+        adapter = np.frombuffer(b"AGATCGGAAGAGCACACGTCTGAACTCCAGTCACGATCTCGTATGCCGTCTTCTGCTTG", dtype=np.uint8)
+        for e in range(2):
+            for i in np.flatnonzero(rng_a.random(n_pairs) < adapter_frac):
+                k = int(rng_a.integers(5, 41))
+                out[e, i, L - k:] = adapter[:k]
     if qual_decay:
         base = 40 - (np.arange(L) * 38 // L)
         q = np.clip(base[None, None, :] + rng.integers(-3, 4, (2, n_pairs, L)), 2, 41).astype(np.uint8) + 33
     else:
         q = np.full((2, n_pairs, L), ord("I"), dtype=np.uint8)
+    if dup_frac > 0:
+        rng_d = np.random.default_rng(seed + 15485863)
+        for i in np.flatnonzero(rng_d.random(n_pairs) < dup_frac):
+            if i > 0:
+                out[:, i] = out[:, i - 1]
+                q[:, i] = q[:, i - 1]
     lens = np.full((2, n_pairs), L, dtype=np.int32)
     names = [("%s%09d" % (name_prefix, i + name_offset)).encode() for i in range(n_pairs)]
     return ReadBatch(out, q, lens, names)
+
+
+def write_qc_inputs(prefix_fa: str, ref: SynthRef, dbsnp_extra: int = 3, seed: int = 5) -> None:
+    """The files StatCollector reads next to the reduced reference (src/StatCollector.cpp:1742-1839), as `FASTQuick index` leaves
+    them: <fa>.SelectedSite.vcf (one record per marker, ID ending in `L` for long-flank markers, src/RefBuilder.cpp:408),
+    <fa>.dbSNP.subset.vcf (known variant sites: the markers plus a few positions inside their flanks) and <fa>.gc (per marker a
+    u32 length 2*flank+1 and that many bytes: G/C count of the 100 bp genome window [i-50, i+49] around each flank position,
+    src/RefBuilder.cpp:38-54).  Records in position order per chromosome, the order RefBuilder::PrepareRefSeq writes them."""
+    rng = np.random.default_rng(seed)
+    g = ref.genome
+    is_gc = ((g == 1) | (g == 2)).astype(np.int64)
+    csum = np.concatenate([[0], np.cumsum(is_gc)])
+    order = sorted(range(len(ref.names)), key=lambda k: (ref.names[k].split(":")[0], int(ref.marker_pos[k])))
+    hdr = "##fileformat=VCFv4.1\n#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\n"
+    with open(prefix_fa + ".SelectedSite.vcf", "w") as fv, open(prefix_fa + ".dbSNP.subset.vcf", "w") as fd, open(prefix_fa + ".gc", "wb") as fg:
+        fv.write(hdr)
+        fd.write(hdr)
+        for k in order:
+            nm = ref.names[k]
+            chrom, rest = nm.split(":")
+            pos = int(ref.marker_pos[k])
+            alleles = rest.split("@")[1].split("|")[0]
+            r, a = alleles.split("/")
+            long_ = nm.endswith("|L")
+            fv.write("%s\t%d\trs%d%s\t%s\t%s\t.\tPASS\tAF=%.4f\n" % (chrom, pos, 1000 + k, "|L" if long_ else "", r, a, 0.05 + 0.9 * ((k * 37) % 100) / 100.0))
+            f = int(ref.flank[k])
+            sites = sorted(set([pos] + [int(x) for x in rng.integers(pos - f, pos + f + 1, dbsnp_extra)]))
+            for sp in sites:
+                fd.write("%s\t%d\t.\tA\tC\t.\tPASS\t.\n" % (chrom, sp))
+            gc = np.zeros(2 * f + 1, dtype=np.uint8)
+            for t, i in enumerate(range(pos - f, pos + f + 1)):          # window [i-50, i+49], 1-based, clipped to the genome
+                lo, hi = max(i - 50, 1), min(i + 49, len(g))
+                gc[t] = csum[hi] - csum[lo - 1] if hi >= lo else 0
+            fg.write(np.uint32(2 * f + 1).tobytes())
+            fg.write(gc.tobytes())
 
 
 def write_param(prefix_fa: str, ref: SynthRef, n_long: int) -> None:

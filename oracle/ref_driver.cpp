@@ -14,7 +14,11 @@
 //       BwtIndexer::BuildIndex's steps (src/BwtIndexer.cpp:716-762) except that the dense
 //       3 GiB .rollhash dump is replaced by a sparse list of set bits (<fa>.rollhash.sparse).
 //   fq_ref_driver align <ref.FASTQuick.fa> <r1.fq> <r2.fq> <out_prefix> [--q Q] [--batch N] [--t T]
-//       writes <out>.stages (per-stage dump) and <out>.sam (bwa_print_sam1 text).
+//       writes <out>.stages (per-stage dump), <out>.sam (bwa_print_sam1 text) and -- through the reference's own
+//       StatCollector, fed exactly as PairEndMapper feeds it (AddAlignment before bwa_print_sam1, src/BwtMapper.cpp:2047-2050;
+//       ProcessCore at the end, :288) -- the QC files <out>.InsertSizeTable .DepthDist .GCDist .EmpRepDist .EmpCycleDist
+//       .RawInsertSizeDist .AdjustedInsertSizeDist .SexChromInfo .Pileup .FASTQ.csv .Sequence.csv .Summary .vcf.
+//       Needs <fa>.SelectedSite.vcf, <fa>.dbSNP.subset.vcf and <fa>.gc (fastquick_amd/synth.py write_qc_inputs).
 #include "BwtMapper.cpp"   // resolved through -I$(REF)/src ; see Makefile
 
 #include <cinttypes>
@@ -120,9 +124,15 @@ static int cmd_align(int argc, char **argv) {
   gap_opt_t *opt = gap_init_opt();
   pe_opt_t *popt = bwa_init_pe_opt();
   int batch = READ_BUFFER_SIZE, thresh = 3;
+  long long genome_size = 0, genome_n_size = 0;
   for (int i = 6; i + 1 < argc; i += 2) {
     if (!strcmp(argv[i], "--q")) opt->trim_qual = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--batch")) batch = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--genome_size")) genome_size = atoll(argv[i + 1]);      // BwtIndexer::LoadContigSize's sums (original .fai / .amb)
+    else if (!strcmp(argv[i], "--genome_n_size")) genome_n_size = atoll(argv[i + 1]);
+    else if (!strcmp(argv[i], "--flank")) opt->flank_len = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--flank_long")) opt->flank_long_len = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--cal_dup")) opt->cal_dup = (char)atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--thresh")) thresh = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--n")) { opt->max_diff = atoi(argv[i + 1]); opt->fnr = -1.0; }
     else if (!strcmp(argv[i], "--no_sw")) popt->is_sw = 0;
@@ -162,6 +172,13 @@ static int cmd_align(int argc, char **argv) {
     str = NewRef + ".rsa";  bwt_restore_sa(str.c_str(), ix.rbwt_d);
     ix.bns = bns_restore(NewRef.c_str());
   }
+
+  // the consumer BwtMapper owns (BwtMapper::collector), set up as the constructor does (src/BwtMapper.cpp:218-224)
+  StatCollector collector;
+  collector.RestoreVcfSites(NewRef, opt);
+  collector.SetGenomeSize(genome_size, genome_n_size);
+  std::ofstream fout(out + ".InsertSizeTable");
+  FileStatCollector FSC(fq1, fq2);
 
   FILE *st = fopen((out + ".stages").c_str(), "w");
   if (!st) die("cannot open stages file");
@@ -223,15 +240,20 @@ static int cmd_align(int argc, char **argv) {
     for (int j = 0; j < 2; ++j)
       for (int i = 0; i < n; ++i) dump_rec(st, 'R', j, i, seqs[j] + i, 1);
     last_ii = ii;
-    // consumer side of the --sam_out branch (src/BwtMapper.cpp:2026-2052) minus StatCollector
+    // consumer side of the --sam_out branch (src/BwtMapper.cpp:2026-2052), StatCollector included: AddAlignment may turn a hit
+    // that hangs over the end of its contig into NO_MATCH before the record is printed (src/StatCollector.cpp:955-971)
     for (int i = 0; i < n; ++i) {
       bwa_seq_t *p[2] = {seqs[0] + i, seqs[1] + i};
-      if (p[0]->filtered && p[1]->filtered) { ++n_filtered; continue; }
-      if (p[0]->type == BWA_TYPE_NO_MATCH && p[1]->type == BWA_TYPE_NO_MATCH) { ++n_unmapped; continue; }
+      FSC.NumBase += p[0]->full_len;
+      FSC.NumBase += p[1]->full_len;
+      if (p[0]->filtered && p[1]->filtered) { ++n_filtered; ++FSC.TotalFiltered; continue; }
+      if (p[0]->type == BWA_TYPE_NO_MATCH && p[1]->type == BWA_TYPE_NO_MATCH) { ++n_unmapped; FSC.BwaUnmapped++; continue; }
+      FSC.TotalRetained += collector.AddAlignment(ix.bns, p[0], p[1], opt, fout, FSC.TotalMAPQ);
       bwa_print_sam1(ix.bns, p[0], p[1], opt->mode, opt->max_top2);
       bwa_print_sam1(ix.bns, p[1], p[0], opt->mode, opt->max_top2);
     }
     n_pairs_total += n;
+    FSC.NumRead += 2 * n;
     if ((2 * n_pairs_total) % batch == 0 && std::strncmp(seqs[0]->name, seqs[1]->name, opt->read_len) != 0)   // src/BwtMapper.cpp:2087-2092
       die("Abort, please make sure input pair of fastq files are in the same order!");
     for (int j = 0; j < 2; ++j) bwa_clean_read_seq(n, seqs[j]);
@@ -240,6 +262,9 @@ static int cmd_align(int argc, char **argv) {
   fprintf(st, "E pairs=%lld filtered=%lld unmapped=%lld\n", n_pairs_total, n_filtered, n_unmapped);
   fclose(st);
   fflush(stdout);
+  collector.AddFSC(FSC);
+  fout.close();
+  collector.ProcessCore(out, opt);   // src/BwtMapper.cpp:288
   return 0;
 }
 

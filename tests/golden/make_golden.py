@@ -40,6 +40,14 @@ CASES = {
     "nref": (dict(n_markers=12, n_long=1, seed=105, n_frac=0.002),
              dict(on_target=0.9, seed=205, n_rate=0.01, chimera_frac=0.1, qual_decay=True), 200, 200, 15),
     # 250 bp reads: the reference needs --read_len (its buffers are sized once from it); longer DP windows on the device
+    # reads that hang over the ends of their contigs (fragments start up to 60 bp before a flank): StatCollector::AddAlignment
+    # turns such hits into NO_MATCH before the records are printed
+    "edge": (dict(n_markers=14, n_long=2, seed=108),
+             dict(on_target=0.9, seed=208, sub_rate=0.01, del_frac=0.03, ins_frac=0.03, edge_frac=0.35), 300, 300, 0),
+    # the QC consumer's case: more pairs per marker (depth, pileups, duplicates), markers on X and Y, trimming
+    "qc": (dict(n_markers=40, n_long=4, seed=109, sex_every=7),
+           dict(on_target=0.95, seed=209, sub_rate=0.01, del_frac=0.03, ins_frac=0.03, n_rate=0.002, chimera_frac=0.05, qual_decay=True,
+                dup_frac=0.08, edge_frac=0.1), 3000, 1024, 15),
     "long250": (dict(n_markers=12, n_long=3, seed=106),
                 dict(read_len=250, on_target=0.9, seed=206, sub_rate=0.01, del_frac=0.06, ins_frac=0.05, indel_len_max=3,
                      chimera_frac=0.08, frag_mean=430, frag_sd=30), 160, 160, 0),
@@ -101,9 +109,10 @@ def write_case(out, tmp, pre, f1, f2, n, batch, q, refkw, readkw):
     for ext in INDEX_EXT:
         shutil.copy(pre + ext, os.path.join(out, "ref.FASTQuick.fa" + ext))
     sparse_to_npz(pre + ".rollhash.sparse", os.path.join(out, "rollhash_bits.npz"))
-    for src, dst in ((f1, "reads_1.fq.gz"), (f2, "reads_2.fq.gz"),
+    qc = [(pre + ext, "ref.FASTQuick.fa" + ext + ".gz") for ext in QC_IN_EXT] + [(os.path.join(tmp, "ref_out" + ext), "ref.qc" + ext + ".gz") for ext in QC_OUT_EXT]
+    for src, dst in [(f1, "reads_1.fq.gz"), (f2, "reads_2.fq.gz"),
                      (os.path.join(tmp, "ref_out.stages"), "ref.stages.gz"),
-                     (os.path.join(tmp, "ref_out.sam"), "ref.sam.gz")):
+                     (os.path.join(tmp, "ref_out.sam"), "ref.sam.gz")] + qc:
         with open(src, "rb") as fi, gzip.GzipFile(os.path.join(out, dst), "wb", mtime=0) as fo:
             fo.write(fi.read())
     with open(os.path.join(out, "case.txt"), "w") as fh:
@@ -121,18 +130,23 @@ def make_example_case():
         pre = os.path.join(tmp, "ref.FASTQuick.fa")
         ref.write_fasta(pre)
         subprocess.check_call([ob.REF_DRIVER, "index", pre], stderr=subprocess.DEVNULL, cwd=tmp)
+        synth.write_qc_inputs(pre, ref)
         fq = []
         for e, src in enumerate(EXAMPLE_FQ):
             dst = os.path.join(tmp, "reads_%d.fq" % (e + 1))
             with gzip.open(src, "rb") as fi, open(dst, "wb") as fo:
                 fo.write(fi.read())
             fq.append(dst)
-        ob.run_reference(pre, fq[0], fq[1], os.path.join(tmp, "ref_out"), "--batch", batch, "--q", q, "--read_len", 152)
+        ob.run_reference(pre, fq[0], fq[1], os.path.join(tmp, "ref_out"), "--batch", batch, "--q", q, "--read_len", 152, "--genome_size", len(ref.genome))
         write_case(out, tmp, pre, fq[0], fq[1], len(r1), batch, q, refkw, "reference example/fq.test.list")
     print(tag, "->", sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) // 1024, "KiB")
 
 
 INDEX_EXT = [".bwt", ".rbwt", ".sa", ".rsa", ".pac", ".ann", ".amb"]
+# what StatCollector reads beside the reduced reference (inputs), and the files it writes (expected outputs)
+QC_IN_EXT = [".SelectedSite.vcf", ".dbSNP.subset.vcf", ".gc"]
+QC_OUT_EXT = [".InsertSizeTable", ".DepthDist", ".GCDist", ".EmpRepDist", ".EmpCycleDist", ".RawInsertSizeDist", ".AdjustedInsertSizeDist",
+              ".SexChromInfo", ".Pileup", ".FASTQ.csv", ".Sequence.csv", ".Summary", ".vcf"]
 
 
 def sparse_to_npz(path_sparse: str, path_npz: str) -> None:
@@ -160,10 +174,11 @@ def main() -> None:
             pre = os.path.join(tmp, "ref.FASTQuick.fa")
             ref.write_fasta(pre)
             subprocess.check_call([ob.REF_DRIVER, "index", pre], stderr=subprocess.DEVNULL, cwd=tmp)
+            synth.write_qc_inputs(pre, ref)
             rb = synth.make_reads(ref, n, **readkw)
             f1, f2 = rb.write_fastq(os.path.join(tmp, "reads"))
             args = ["--batch", batch] + (["--q", q] if q else []) + (["--read_len", readkw["read_len"] + 1] if readkw.get("read_len", 150) > 150 else [])
-            ob.run_reference(pre, f1, f2, os.path.join(tmp, "ref_out"), *args)
+            ob.run_reference(pre, f1, f2, os.path.join(tmp, "ref_out"), "--genome_size", len(ref.genome), *args)
             write_case(out, tmp, pre, f1, f2, n, batch, q, refkw, readkw)
         print(tag, "->", sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) // 1024, "KiB")
     if not only or EXAMPLE_CASE[0] in only:

@@ -46,6 +46,10 @@ def materialise(tag: str, dst: str) -> dict:
         with gzip.open(os.path.join(src, name + ".gz"), "rb") as fi, open(os.path.join(dst, name), "wb") as fo:
             fo.write(fi.read())
         paths[name] = os.path.join(dst, name)
+    for name in sorted(os.listdir(src)):      # StatCollector inputs next to the reference, and the QC files the reference wrote
+        if name.startswith("ref.FASTQuick.fa.") and name.endswith(".gz") or name.startswith("ref.qc."):
+            with gzip.open(os.path.join(src, name), "rb") as fi, open(os.path.join(dst, name[:-3]), "wb") as fo:
+                fo.write(fi.read())
     p = case_params(tag)
     p.update(prefix=pre, fq1=paths["reads_1.fq"], fq2=paths["reads_2.fq"], stages=paths["ref.stages"], sam=paths["ref.sam"], dir=dst)
     return p
