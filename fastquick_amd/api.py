@@ -40,6 +40,11 @@ class PackedBatch(C.Structure):
                 ("names_mate", C.c_void_p)]
 
 
+class QcOpts(C.Structure):
+    _fields_ = [("flank_len", C.c_int32), ("flank_long_len", C.c_int32), ("read_len", C.c_int32), ("cal_dup", C.c_int32),
+                ("genome_size", C.c_int64), ("genome_n_size", C.c_int64), ("mode", C.c_int32), ("pad", C.c_int32)]
+
+
 class Multi(C.Structure):
     _fields_ = [("pos", C.c_uint32), ("cigar_off", C.c_uint32), ("n_cigar", C.c_uint16), ("gap", C.c_uint8),
                 ("mm", C.c_uint8), ("strand", C.c_uint8), ("pad", C.c_uint8 * 3)]
@@ -83,7 +88,8 @@ EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destr
            "fq_ctx_set_debug", "fq_align_batch", "fq_batch_upload", "fq_align_resident", "fq_sam_header",
            "fq_sam_format_last", "fq_stage_dump_last", "fq_stats_get", "fq_stats_reset", "fq_version",
            "fq_pinned_alloc", "fq_pinned_free", "fq_pack_reads", "fq_packed_free", "fq_packed_prefetch", "fq_align_packed",
-           "fq_ctx_set_tuning"]
+           "fq_ctx_set_tuning", "fq_qc_default_opts", "fq_qc_create", "fq_qc_destroy", "fq_qc_last_error", "fq_qc_begin_file",
+           "fq_qc_add_last", "fq_qc_end_file", "fq_qc_write"]
 
 _libs = {}
 
@@ -132,6 +138,15 @@ def load_library(path: str | None = None):
     L.fq_packed_prefetch.argtypes = [C.c_void_p, C.POINTER(PackedBatch)]
     L.fq_align_packed.argtypes = [C.c_void_p, C.POINTER(PackedBatch), C.POINTER(ResultBatch)]
     L.fq_ctx_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.fq_qc_default_opts.argtypes = [C.POINTER(QcOpts)]
+    L.fq_qc_create.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(QcOpts), C.POINTER(C.c_void_p)]
+    L.fq_qc_destroy.argtypes = [C.c_void_p]
+    L.fq_qc_last_error.restype = C.c_char_p
+    L.fq_qc_last_error.argtypes = [C.c_void_p]
+    L.fq_qc_begin_file.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p]
+    L.fq_qc_add_last.argtypes = [C.c_void_p, C.c_void_p]
+    L.fq_qc_end_file.argtypes = [C.c_void_p]
+    L.fq_qc_write.argtypes = [C.c_void_p]
     _libs[path] = L
     return L
 
@@ -319,7 +334,44 @@ class Aligner:
             self.h = None
 
 
-def align_stream(aligner: Aligner, names, seq, qual, lens, batch: int, stages_path=None, sam_path=None, header=True, packed: bool = False) -> int:
+class QC:
+    """The QC consumer (StatCollector's side): feed it every batch of a stream, then write()."""
+
+    def __init__(self, index: Index, ref_prefix: str, out_prefix: str, **kw):
+        self.L = index.L
+        o = QcOpts()
+        self.L.fq_qc_default_opts(C.byref(o))
+        for k, v in kw.items():
+            setattr(o, k, v)
+        h = C.c_void_p()
+        rc = self.L.fq_qc_create(index.h, ref_prefix.encode(), out_prefix.encode(), C.byref(o), C.byref(h))
+        if rc:
+            raise FastquickError("fq_qc_create failed: %d" % rc)
+        self.h = h
+
+    def _ck(self, rc, what):
+        if rc:
+            raise FastquickError("%s failed: %d (%s)" % (what, rc, self.L.fq_qc_last_error(self.h).decode()))
+
+    def begin_file(self, fq1: str, fq2: str):
+        self._ck(self.L.fq_qc_begin_file(self.h, fq1.encode(), fq2.encode()), "fq_qc_begin_file")
+
+    def add(self, aligner: "Aligner"):
+        self._ck(self.L.fq_qc_add_last(self.h, aligner.h), "fq_qc_add_last")
+
+    def end_file(self):
+        self._ck(self.L.fq_qc_end_file(self.h), "fq_qc_end_file")
+
+    def write(self):
+        self._ck(self.L.fq_qc_write(self.h), "fq_qc_write")
+
+    def close(self):
+        if self.h:
+            self.L.fq_qc_destroy(self.h)
+            self.h = None
+
+
+def align_stream(aligner: Aligner, names, seq, qual, lens, batch: int, stages_path=None, sam_path=None, header=True, packed: bool = False, qc: "QC | None" = None) -> int:
     """Feed n pairs in batches of `batch` (mirrors PairEndMapper's loop); returns pairs with SAM records.  packed=True goes
     through the packed-batch boundary (fq_pack_reads -> fq_packed_prefetch of the next chunk -> fq_align_packed)."""
     n = seq.shape[1]
@@ -346,6 +398,8 @@ def align_stream(aligner: Aligner, names, seq, qual, lens, batch: int, stages_pa
             st.write(aligner.stage_text())
         if sm:
             sm.write(aligner.sam_text())
+        if qc is not None:
+            qc.add(aligner)
         if packed:
             aligner._keep_packed = None
             cur.free()

@@ -1613,3 +1613,4 @@ FqHostReads fq_ctx_host_reads(const fq_ctx_t *c) {
   return h;
 }
 const fq_opts_t *fq_ctx_opts(const fq_ctx_t *c) { return &c->o; }
+int64_t fq_ctx_last_bases(const fq_ctx_t *c) { return c->n_bases_in; }

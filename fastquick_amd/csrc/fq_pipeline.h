@@ -141,4 +141,7 @@ struct FqHostReads {
   bool has_qual() const { return a ? a->qual != nullptr : p->qual != nullptr; }
 };
 FqHostReads fq_ctx_host_reads(const fq_ctx_t *c);
+int64_t fq_ctx_last_bases(const fq_ctx_t *c);   // sum of the read lengths of the last batch (NumBase increment)
+// the name a record prints under (fq_sam.cpp): `/1` `/2` stripped, a revived mate under its partner's name
+std::string fq_read_name(const FqHostReads *hb, int pair, int end, bool revived);
 const fq_opts_t *fq_ctx_opts(const fq_ctx_t *c);

@@ -1,0 +1,648 @@
+// fq_qc.cpp -- the QC consumer of the alignment records: what StatCollector does with every pair that
+// BwtMapper::PairEndMapper hands it (src/BwtMapper.cpp:2047-2050 / 2075-2079) and the files its ProcessCore writes
+// (src/StatCollector.cpp:2012-2028).  Restated from the reference's behaviour, function by function:
+//   RestoreVcfSites      src/StatCollector.cpp:1742-1839   marker / dbSNP / GC tables, flank regions
+//   AddAlignment         :950-1101     contig-end un-mapping (Q10), which mates are added, sex-chromosome counters
+//   AddSingleAlignment   :424-620      per-base depth / quality / cycle statistics and marker pileups
+//   ProcessPairStatus    :623-921      one .InsertSizeTable line per pair, insert sizes, PCR duplicates
+//   GetDepthDist .. SummaryOutput  :1858-2028, 2343-2483   the output files
+// Containers whose iteration order reaches an output (.SexChromInfo: an unordered_map walked in bucket order) are the same
+// standard containers, filled in the same order, so the files come out byte for byte; the others are order-free sums.
+// Not restated: .AdjustedInsertSizeDist (InsertSizeEstimator, a separate estimator fed from the .InsertSizeTable file) and the
+// genotype .vcf (GetVCF) -- both read only what is written here.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <sstream>
+#include <string>
+#include <unordered_map>
+#include <unordered_set>
+#include <vector>
+
+#include "../../include/fastquick_amd.h"
+#include "fq_index.h"
+#include "fq_kernels.h"
+#include "fq_pipeline.h"
+
+namespace {
+const int kInsertLimit = 4096;                 // INSERT_SIZE_LIMIT
+const char kSign[2] = {1, -1};
+
+std::string chrom_key(std::string chr) {       // upper case, a name containing "CHR" loses its first three characters (:1760-1764)
+  std::transform(chr.begin(), chr.end(), chr.begin(), ::toupper);
+  if (chr.find("CHR") != std::string::npos) chr = chr.substr(3);
+  return chr;
+}
+
+// RegionList (src/RegionList.cpp): start -> end per chromosome, inclusive
+struct Regions {
+  std::map<std::string, std::map<int, int>> list;
+  uint64_t length = 0;
+  void add(const std::string &chr, int start, int end) { list[chrom_key(chr)][start] = end; }
+  void collapse() {                            // RegionList::Collapse, :73-113
+    std::map<std::string, std::map<int, int>> tmp;
+    for (auto kv : list) {
+      auto holder = kv.second.begin();
+      for (auto iter = kv.second.begin(); iter != kv.second.end(); ++iter) {
+        const int beg1 = holder->first, end1 = holder->second, beg2 = iter->first, end2 = iter->second;
+        if (end1 >= end2) continue;
+        else if (end1 < beg2) { tmp[kv.first][beg1] = end1; holder = iter; }
+        else { tmp[kv.first][beg1] = end2; holder->second = end2; }
+      }
+      tmp[kv.first][holder->first] = holder->second;
+    }
+    list = tmp;
+    length = 0;
+    for (const auto &kv : list) for (const auto &kv2 : kv.second) length += (uint64_t)(kv2.second - kv2.first) + 1;
+  }
+  bool overlapped(const std::string &chr, int pos) const {   // RegionList::IsOverlapped, :48-66
+    auto it = list.find(chr);
+    if (it == list.end()) return false;
+    auto lo = it->second.lower_bound(pos);
+    if (lo != it->second.end() && lo->first <= pos && lo->second >= pos) return true;
+    if (lo != it->second.begin()) { --lo; if (lo->first <= pos && lo->second >= pos) return true; }
+    return false;
+  }
+};
+
+struct ContigStatus { int overlapped = 0, fully = 0, pair_overlapped = 0, fully_paired = 0; };
+
+struct FileStat {                               // FileStatCollector, src/StatCollector.h:46-62
+  long long NumRead = 0, NumBase = 0, TotalFiltered = 0, BwaUnmapped = 0, TotalMAPQ = 0, TotalRetained = 0;
+  std::string f1, f2;
+};
+
+// a record as AddAlignment sees it: the bwa_seq_t fields it reads
+struct Rec {
+  const FqRead *r = nullptr;
+  int type = 0;
+  std::string name;
+  int64_t end() const {                         // pos_end, libbwa/bwase.c:420-432
+    if (!r->cigar.empty()) { int64_t x = r->pos; for (uint16_t g : r->cigar) { const int op = g >> 14; if (op == FQ_OP_M || op == FQ_OP_D) x += g & 0x3fff; } return x; }
+    return (int64_t)r->pos + r->len;
+  }
+};
+
+std::string cigar_string(const FqRead &p) {     // Cigar2String, :58-72
+  std::string s;
+  for (uint16_t g : p.cigar) { s += std::to_string(g & 0x3fff); s.push_back("MIDS"[g >> 14]); }
+  if (p.cigar.empty()) s = std::to_string(p.len) + "M";
+  return s;
+}
+
+// RecoverRefseqByMDandCigar, :98-205
+std::string recover_ref(const std::string &read, std::string md, const std::vector<uint16_t> &cigar) {
+  std::transform(md.begin(), md.end(), md.begin(), ::toupper);
+  if (md.find_first_of("ATCGN") == std::string::npos && atol(md.c_str()) == (long)read.size()) return read;
+  std::string ref;
+  if (!cigar.empty()) {
+    int at = 0;
+    for (uint16_t g : cigar) {
+      const int cl = g & 0x3fff, op = g >> 14;
+      if (op == FQ_OP_M) { ref += read.substr(at, cl); at += cl; }
+      else if (op == FQ_OP_S || op == FQ_OP_I) at += cl;
+    }
+  } else ref = read;
+  int last = 0, total = 0;
+  for (uint32_t i = 0; i != md.size(); ++i) {
+    if (isdigit((unsigned char)md[i])) continue;
+    if (md[i] == '^') {
+      const int len = atoi(md.substr(last, i - last).c_str());
+      total += len;
+      const int start_on_read = total;
+      ++i;
+      std::string del;
+      while (!isdigit((unsigned char)md[i])) { del += md[i]; ++i; ++total; }
+      const std::string left = ref.substr(0, start_on_read);
+      const std::string right = (size_t)start_on_read <= ref.size() ? ref.substr(start_on_read, ref.length() - start_on_read + 1) : std::string();
+      ref = left + del + right;
+      last = i;
+    } else {
+      const int len = atoi(md.substr(last, i - last).c_str()) + 1;
+      total += len;
+      if (total - 1 >= 0 && (size_t)(total - 1) < ref.size()) ref[total - 1] = md[i];
+      last = i + 1;
+    }
+  }
+  return ref;
+}
+}  // namespace
+
+struct fq_qc {
+  const fq_index *ix = nullptr;
+  fq_qc_opts_t o{};
+  std::string err;
+  // RestoreVcfSites
+  struct Marker { std::string chrom_raw, id, ref, alt, qual, filter, info; int pos = 0; };
+  std::vector<Marker> markers;
+  std::map<std::string, std::map<int, unsigned>> vcf_table;
+  std::unordered_map<std::string, std::unordered_map<int, unsigned>> gc, dbsnp, position_table;
+  Regions flank;
+  uint64_t NumXorY = 0, NumShort = 0, NumLong = 0;
+  // statistics
+  uint64_t NumPCRDup = 0, NumPairReads = 0, NumBaseMapped = 0, NumCov = 0, NumCov2 = 0, NumCov5 = 0, NumCov10 = 0, total_region_size = 0;
+  unsigned index = 0;
+  std::vector<uint32_t> depth, q20, q30;
+  std::vector<std::string> seq_vec, qual_vec;
+  std::vector<std::vector<int>> cycle_vec;
+  std::vector<std::vector<unsigned char>> maq_vec;
+  std::vector<std::vector<bool>> strand_vec;
+  std::vector<size_t> DepthDist = std::vector<size_t>(1024, 0), CycleDist = std::vector<size_t>(512, 0), GCDist = std::vector<size_t>(256, 0),
+                      PosNum = std::vector<size_t>(101, 0), EmpRep = std::vector<size_t>(256, 0), misEmpRep = std::vector<size_t>(256, 0),
+                      EmpCycle = std::vector<size_t>(256, 0), misEmpCycle = std::vector<size_t>(256, 0), InsertDist = std::vector<size_t>(kInsertLimit, 0);
+  std::unordered_set<std::string> dup_table;
+  std::unordered_map<std::string, ContigStatus> contig_status;
+  std::vector<FileStat> files;
+  FileStat cur;
+  bool file_open = false;
+  std::string out_prefix;
+  std::ofstream table;
+
+  int restore(const std::string &ref_prefix);
+  bool add_single(const Rec &p, const FqHostReads &hb);
+  int pair_status(const Rec *p, const Rec *q, int type);
+  int add_alignment(Rec &p, Rec &q, const FqHostReads &hb, long long &total_add_failed);
+  const char *contig_name(int seqid) const { return ix->contigs[seqid].name.c_str(); }
+};
+
+int fq_qc::restore(const std::string &ref_prefix) {
+  std::ifstream vcf(ref_prefix + ".SelectedSite.vcf"), gcf(ref_prefix + ".gc", std::ios_base::binary), db(ref_prefix + ".dbSNP.subset.vcf");
+  if (!vcf.is_open() || !gcf.is_open() || !db.is_open()) { err = "cannot open " + ref_prefix + ".SelectedSite.vcf / .gc / .dbSNP.subset.vcf"; return FQ_EIO; }
+  const int chopped = (int)std::floor(o.read_len * 0.65f + 0.5);   // FLANK_EDGE, :28, :1754
+  std::string line;
+  while (std::getline(vcf, line)) {
+    if (line.empty() || line[0] == '#') continue;
+    std::stringstream ss(line);
+    Marker m;
+    std::string pos;
+    std::getline(ss, m.chrom_raw, '\t'); std::getline(ss, pos, '\t'); std::getline(ss, m.id, '\t'); std::getline(ss, m.ref, '\t');
+    std::getline(ss, m.alt, '\t'); std::getline(ss, m.qual, '\t'); std::getline(ss, m.filter, '\t'); std::getline(ss, m.info, '\t');
+    m.pos = atoi(pos.c_str());
+    markers.push_back(m);
+    const std::string chr = chrom_key(m.chrom_raw);
+    vcf_table[chr][m.pos] = (unsigned)markers.size() - 1;
+    uint32_t glen = 0;
+    gcf.read(reinterpret_cast<char *>(&glen), 4);
+    std::vector<unsigned char> g(glen);
+    gcf.read(reinterpret_cast<char *>(g.data()), glen);
+    if (!gcf) { err = "short .gc file"; return FQ_EIO; }
+    const int tmp_pos = m.pos - ((int)glen - 1) / 2;
+    for (uint32_t i = 0; i != glen; ++i) gc[chr][tmp_pos + (int)i] = g[i];
+    if (chr == "X" || chr == "Y") { ++NumXorY; flank.add(chr, m.pos - o.flank_len + chopped, m.pos + o.flank_len - chopped); }
+    else if (!m.id.empty() && m.id.back() == 'L') { ++NumLong; flank.add(chr, m.pos - o.flank_long_len + chopped, m.pos + o.flank_long_len - chopped); }
+    else { ++NumShort; flank.add(chr, m.pos - o.flank_len + chopped, m.pos + o.flank_len - chopped); }
+    seq_vec.emplace_back(""); qual_vec.emplace_back(""); cycle_vec.emplace_back(0); maq_vec.emplace_back(0); strand_vec.emplace_back(0);
+  }
+  flank.collapse();
+  while (std::getline(db, line)) {
+    if (line.empty() || line[0] == '#') continue;
+    std::stringstream ss(line);
+    std::string c, pos;
+    std::getline(ss, c, '\t'); std::getline(ss, pos, '\t');
+    dbsnp[chrom_key(c)][atoi(pos.c_str())] = 1;
+  }
+  return FQ_OK;
+}
+
+// AddSingleAlignment, :424-620 (the reduced-reference branch: contig names `CHR:POS@REF/ALT[|L]`)
+bool fq_qc::add_single(const Rec &P, const FqHostReads &hb) {
+  const FqRead &p = *P.r;
+  if (P.type == FQ_TYPE_NO_MATCH || p.mapQ < 20) return false;
+  int seqid = 0;
+  fq_coor_pac2real(ix, p.pos, (int)(P.end() - p.pos), &seqid);
+  uint8_t codes[FQ_LMAX + 8];
+  hb.codes((size_t)p.r, p.full_len, codes);
+  const uint8_t *hq = hb.qual((size_t)p.r);
+  const int qsub = (o.mode & FQ_MODE_IL13) ? 31 : 0;    // qualities are kept 31 lower in --I mode (src/BwtMapper.cpp:549-553)
+  std::string seq, qual;
+  if (p.strand == 0) for (int j = 0; j != p.full_len; ++j) { seq += "ACGTN"[codes[j] > 4 ? 4 : codes[j]]; qual += (char)(hq[j] - qsub - 33); }
+  else for (int j = 0; j != p.full_len; ++j) { const int c = codes[p.full_len - 1 - j]; seq += "TGCAN"[c > 4 ? 4 : c]; qual += (char)(hq[p.full_len - 1 - j] - qsub - 33); }
+  const std::string chrName = ix->contigs[seqid].name;
+  const int pos = (int)((int64_t)p.pos - ix->contigs[seqid].offset + 1);
+  const size_t colon = chrName.find(':');
+  if (colon == std::string::npos) return false;          // (external alignments are not this path)
+  const size_t at = chrName.find('@');
+  const std::string chrom_raw = chrName.substr(0, colon);
+  const int refCoord = (int)strtol(chrName.substr(colon + 1, at - colon + 1).c_str(), nullptr, 10);
+  const int fl = chrName[chrName.size() - 1] == 'L' ? o.flank_long_len : o.flank_len;
+  const int readRealStart = refCoord - fl + pos - 1;
+  const std::string refSeq = recover_ref(seq, p.md, p.cigar);
+  const std::string chrom = chrom_key(chrom_raw);         // AddMatchBaseInfo, :362-379
+
+  auto match_block = [&](int absoluteSite, int cl, int tmpCycle, int onRead, int onRef) {
+    // UpdateInfoVecAtMarker, :339-360
+    auto vt = vcf_table.find(chrom);
+    if (vt != vcf_table.end()) {
+      int cyc = tmpCycle, rr = onRead;
+      for (int i = absoluteSite; i != absoluteSite + cl; ++i, cyc += kSign[p.strand], ++rr) {
+        auto hit = vt->second.find(i);
+        if (hit == vt->second.end()) continue;
+        const unsigned k = hit->second;
+        seq_vec[k] += seq[rr]; qual_vec[k] += qual[rr];
+        cycle_vec[k].push_back(cyc); maq_vec[k].push_back((unsigned char)(p.mapQ + 33)); strand_vec[k].push_back(p.strand != 0);
+      }
+    }
+    // UpdateInfoVecAtRegularSite, :381-422
+    int cyc = tmpCycle, rr = onRead, rf = onRef;
+    for (int i = absoluteSite; i != absoluteSite + cl; ++i, cyc += kSign[p.strand], ++rr, ++rf) {
+      if (!flank.overlapped(chrom, i)) continue;
+      const char refBase = rf >= 0 && (size_t)rf < refSeq.size() ? refSeq[rf] : 0, readBase = seq[rr], baseQual = qual[rr];
+      auto &pt = position_table[chrom];
+      auto f = pt.find(i);
+      unsigned k;
+      if (f != pt.end()) k = f->second;
+      else { depth.push_back(0); q20.push_back(0); q30.push_back(0); k = index; pt[i] = index++; }
+      ++depth[k];
+      if (baseQual >= 20) { ++q20[k]; if (baseQual >= 30) ++q30[k]; }
+      // StatVecDistUpdate, :304-317
+      ++EmpRep[(unsigned char)baseQual];
+      ++EmpCycle[(unsigned char)cyc];
+      if (readBase != 'N' && refBase != readBase && refBase != 'N' && dbsnp[chrom].find(i) == dbsnp[chrom].end()) {
+        ++misEmpRep[(unsigned char)baseQual];
+        ++misEmpCycle[(unsigned char)cyc];
+      }
+    }
+  };
+  int absoluteSite = readRealStart, tmpCycle = p.strand != 0 ? p.full_len - 1 : 0, onRead = 0, onRef = 0;
+  if (!p.cigar.empty()) {
+    for (uint16_t g : p.cigar) {
+      const int cl = g & 0x3fff, op = g >> 14;
+      if (op == FQ_OP_M) { match_block(absoluteSite, cl, tmpCycle, onRead, onRef); absoluteSite += cl; tmpCycle += cl * kSign[p.strand]; onRead += cl; onRef += cl; }
+      else if (op == FQ_OP_S) { tmpCycle += cl * kSign[p.strand]; onRead += cl; }
+      else if (op == FQ_OP_D) { absoluteSite += cl; onRef += cl; }
+      else { tmpCycle += cl * kSign[p.strand]; onRead += cl; }
+    }
+  } else match_block(absoluteSite, p.len, tmpCycle, onRead, onRef);
+  return true;
+}
+
+// ProcessPairStatus, :623-921; type: 0 FirstOnly, 1 Both, 2 SecondOnly
+int fq_qc::pair_status(const Rec *P, const Rec *Q, int type) {
+  int maxInsert = -1, maxInsert2 = -1, seqid_p = -1, seqid_q = -1, flag1 = 0, flag2 = 0;
+  const int threshQual = 0;
+  std::string status;
+  int cl1 = 0, cl2 = 0, cl3 = 0, cl4 = 0;
+  const FqRead *p = P ? P->r : nullptr, *q = Q ? Q->r : nullptr;
+  if (p) { flag1 = p->extra_flag; if (P->type == FQ_TYPE_NO_MATCH) flag1 |= 4; if (p->strand) flag1 |= 16; }
+  if (q) { flag2 = q->extra_flag; if (Q->type == FQ_TYPE_NO_MATCH) flag2 |= 4; if (q->strand) flag2 |= 16; }
+  auto off = [&](int id) { return ix->contigs[id].offset; };
+  auto len = [&](int id) { return (int64_t)ix->contigs[id].len; };
+  auto clips = [&](const FqRead *r, int &left, int &right) {
+    if (r->cigar.empty()) return;
+    if ((r->cigar.front() >> 14) == FQ_OP_S) left = r->cigar.front() & 0x3fff;
+    if ((r->cigar.back() >> 14) == FQ_OP_S) right = r->cigar.back() & 0x3fff;
+  };
+  std::ostream &fout = table;
+  if (type == 2) {
+    fq_coor_pac2real(ix, q->pos, (int)(Q->end() - q->pos), &seqid_q);
+    const std::string cg = cigar_string(*q);
+    if (q->mapQ > threshQual) {
+      status = "RevOnly";
+      clips(q, cl3, cl4);
+      if (q->strand) {
+        if (off(seqid_q) + len(seqid_q) >= (int64_t)(uint32_t)(q->pos - (uint32_t)cl3 + (uint32_t)q->len)) maxInsert2 = (int)((int64_t)(uint32_t)(q->pos - (uint32_t)cl3 + (uint32_t)q->len) - off(seqid_q));
+        else return 2;
+      } else {
+        if ((int64_t)(uint32_t)(q->pos - cl3) >= off(seqid_q)) maxInsert = (int)(off(seqid_q) + len(seqid_q) - (int64_t)(uint32_t)(q->pos - cl3));
+        else return 2;
+        status = "FwdOnly";
+      }
+      fout << Q->name << "\t" << maxInsert << "\t" << maxInsert2 << "\t" << -1 << "\t*\t*\t" << flag1 << "\t" << 0 << "\t*\t" << contig_name(seqid_q) << "\t"
+           << (int64_t)q->pos - off(seqid_q) + 1 << "\t" << flag2 << "\t" << q->len << "\t" << cg << "\t" << status << std::endl;
+      return 0;
+    }
+    fout << Q->name << "\t" << maxInsert << "\t" << maxInsert2 << "\t" << -1 << "\t*\t*\t" << flag1 << "\t" << 0 << "\t*\t" << contig_name(seqid_q) << "\t"
+         << (int64_t)q->pos - off(seqid_q) + 1 << "\t" << flag2 << "\t" << q->len << "\t" << cg << "\tLowQual" << std::endl;
+    return 2;
+  }
+  if (type == 0) {
+    fq_coor_pac2real(ix, p->pos, (int)(P->end() - p->pos), &seqid_p);
+    const std::string cg = cigar_string(*p);
+    if (p->mapQ > threshQual) {
+      status = "FwdOnly";
+      clips(p, cl1, cl2);
+      if (p->strand) {
+        if (off(seqid_p) + len(seqid_p) >= (int64_t)(uint32_t)(p->pos - (uint32_t)cl1 + (uint32_t)p->len)) maxInsert2 = (int)((int64_t)(uint32_t)(p->pos - (uint32_t)cl1 + (uint32_t)p->len) - off(seqid_p));
+        else return 2;
+        status = "RevOnly";
+      } else {
+        if ((int64_t)(uint32_t)(p->pos - cl1) >= off(seqid_p)) maxInsert = (int)(off(seqid_p) + len(seqid_p) - (int64_t)(uint32_t)(p->pos - cl1));
+        else return 2;
+      }
+      fout << P->name << "\t" << maxInsert << "\t" << maxInsert2 << "\t" << -1 << "\t" << contig_name(seqid_p) << "\t" << (int64_t)p->pos - off(seqid_p) + 1 << "\t"
+           << flag1 << "\t" << p->len << "\t" << cg << "\t*\t*\t" << flag2 << "\t" << 0 << "\t*\t" << status << std::endl;
+      return 0;
+    }
+    fout << P->name << "\t" << maxInsert << "\t" << maxInsert2 << "\t" << -1 << "\t" << contig_name(seqid_p) << "\t" << (int64_t)p->pos - off(seqid_p) + 1 << "\t"
+         << flag1 << "\t" << p->len << "\t" << cg << "\t*\t*\t" << flag2 << "\t" << 0 << "\t*\tLowQual" << std::endl;
+    return 2;
+  }
+  // both aligned
+  fq_coor_pac2real(ix, p->pos, (int)(P->end() - p->pos), &seqid_p);
+  fq_coor_pac2real(ix, q->pos, (int)(Q->end() - q->pos), &seqid_q);
+  clips(p, cl1, cl2);
+  clips(q, cl3, cl4);
+  const std::string cgp = cigar_string(*p), cgq = cigar_string(*q);
+  auto both_line = [&](int actual, const char *st) {
+    fout << P->name << "\t" << maxInsert << "\t" << maxInsert2 << "\t" << actual << "\t" << contig_name(seqid_p) << "\t" << (int64_t)p->pos - off(seqid_p) + 1 << "\t"
+         << flag1 << "\t" << p->len << "\t" << cgp << "\t" << contig_name(seqid_q) << "\t" << (int64_t)q->pos - off(seqid_q) + 1 << "\t" << flag2 << "\t" << q->len
+         << "\t" << cgq << "\t" << st << std::endl;
+  };
+  // (positions are bwtint_t in the reference: pos - clip wraps in 32 bits before it is compared with the 64-bit offsets)
+  const int64_t pl = (int64_t)(uint32_t)(p->pos - (uint32_t)cl1), ql = (int64_t)(uint32_t)(q->pos - (uint32_t)cl3);
+  const int64_t pe = (int64_t)(uint32_t)(p->pos - (uint32_t)cl1 + (uint32_t)p->len), qe = (int64_t)(uint32_t)(q->pos - (uint32_t)cl3 + (uint32_t)q->len);
+  if (!p->strand && q->strand && p->pos < q->pos) {
+    maxInsert = pl >= off(seqid_p) ? (int)(off(seqid_p) + len(seqid_p) - pl) : -1;
+    maxInsert2 = off(seqid_q) + len(seqid_q) >= qe ? (int)(qe - off(seqid_q)) : -1;
+  } else if (!q->strand && p->strand && q->pos < p->pos) {
+    maxInsert = ql >= off(seqid_q) ? (int)(off(seqid_q) + len(seqid_q) - ql) : -1;
+    maxInsert2 = off(seqid_p) + len(seqid_p) >= pe ? (int)(pe - off(seqid_p)) : -1;
+  } else { both_line(-1, "NotPair"); return 0; }
+  if (maxInsert >= kInsertLimit) maxInsert = kInsertLimit - 1;
+  if (maxInsert2 >= kInsertLimit) maxInsert2 = kInsertLimit - 1;
+  if (seqid_p != seqid_q && seqid_p != -1 && seqid_q != -1) { ++InsertDist[0]; both_line(-1, "NotPair"); return 0; }
+  if (p->mapQ > threshQual && q->mapQ > threshQual) {
+    bool noClip = false, propPair = false;
+    int ActualInsert = -1, start = 0, end = 0;
+    status = "PartialPair";
+    if (!p->strand && q->strand && p->pos < q->pos) {
+      start = (int)(uint32_t)(p->pos - (uint32_t)cl1); end = (int)(uint32_t)(q->pos - (uint32_t)cl3 + (uint32_t)q->len);
+      ActualInsert = end - start;
+      if (cl1 == 0 && cl4 == 0) noClip = true;
+    } else if (!q->strand && p->strand && q->pos < p->pos) {
+      start = (int)(uint32_t)(q->pos - (uint32_t)cl3); end = (int)(uint32_t)(p->pos - (uint32_t)cl1 + (uint32_t)p->len);
+      ActualInsert = end - start;
+      if (cl3 == 0 && cl2 == 0) noClip = true;
+    }
+    if (maxInsert != -1 && maxInsert2 != -1) { status = "PropPair"; propPair = true; }
+    if (ActualInsert >= 0 && ActualInsert < kInsertLimit) ++InsertDist[ActualInsert];   // (the reference indexes unchecked; inserts beyond the table are out of its bounds)
+    both_line(ActualInsert, status.c_str());
+    if (propPair && noClip) {
+      char key[1024];
+      snprintf(key, sizeof key, "%d:%d:%d", seqid_p, start, end);
+      if (!dup_table.insert(std::string(key)).second) NumPCRDup += 2;
+      NumPairReads += 2;
+    }
+  } else { both_line(-1, "LowQual"); return 2; }
+  return 0;
+}
+
+// AddAlignment, :950-1101
+int fq_qc::add_alignment(Rec &P, Rec &Q, const FqHostReads &hb, long long &failed) {
+  int seqid = 0, seqid2 = 0;
+  auto bridge = [&](Rec &R, int &id) {
+    if (R.type == FQ_TYPE_NO_MATCH) return;
+    const int j = (int)(R.end() - R.r->pos);
+    fq_coor_pac2real(ix, R.r->pos, j, &id);
+    if ((int64_t)R.r->pos + j - ix->contigs[id].offset > ix->contigs[id].len) R.type = FQ_TYPE_NO_MATCH;
+  };
+  bridge(P, seqid);
+  bridge(Q, seqid2);
+  auto partial = [](const Rec &R) { for (uint16_t g : R.r->cigar) if ((g >> 14) == FQ_OP_S) return true; return false; };
+  auto sex = [](const std::string &n) { return n.find('Y') != std::string::npos || n.find('X') != std::string::npos; };
+  const std::string qname = contig_name(seqid2);
+  if (P.type == FQ_TYPE_NO_MATCH) {
+    if (add_single(Q, hb)) {
+      if (sex(qname)) { ++contig_status[qname].overlapped; if (!partial(Q)) ++contig_status[qname].fully; }
+      pair_status(&P, &Q, 2);
+      failed += 1;
+      return 1;
+    }
+    failed += 2;
+    return 0;
+  }
+  const std::string pname = contig_name(seqid);
+  if (Q.type == FQ_TYPE_NO_MATCH) {
+    if (add_single(P, hb)) {
+      if (sex(pname)) { ++contig_status[pname].overlapped; if (!partial(P)) ++contig_status[pname].fully; }
+      pair_status(&P, &Q, 0);
+      failed += 1;
+      return 1;
+    }
+    failed += 2;
+    return 0;
+  }
+  if (partial(P)) {
+    if (sex(qname)) {
+      if (partial(Q)) ++contig_status[qname].overlapped;
+      else { ++contig_status[qname].overlapped; ++contig_status[qname].fully; }
+      if (pname == qname) ++contig_status[qname].pair_overlapped;
+      ++contig_status[pname].overlapped;
+    }
+  } else if (sex(qname)) {
+    if (partial(Q)) { ++contig_status[qname].overlapped; if (pname == qname) ++contig_status[qname].pair_overlapped; }
+    else {
+      ++contig_status[qname].overlapped; ++contig_status[qname].fully;
+      if (pname == qname) { ++contig_status[qname].pair_overlapped; ++contig_status[qname].fully_paired; }
+    }
+    ++contig_status[pname].overlapped; ++contig_status[pname].fully;
+  }
+  if (pair_status(&P, &Q, 1) != 1 || o.cal_dup) {
+    if (add_single(P, hb)) {
+      if (add_single(Q, hb)) return 2;
+      failed += 1;
+      return 1;
+    }
+    if (add_single(Q, hb)) { failed += 1; return 1; }
+    failed += 2;
+    return 0;
+  }
+  failed += 2;
+  return 0;
+}
+
+// ---- C ABI ------------------------------------------------------------------------------------------------------------------
+extern "C" void fq_qc_default_opts(fq_qc_opts_t *o) {
+  memset(o, 0, sizeof *o);
+  o->flank_len = 250; o->flank_long_len = 1000; o->read_len = 151; o->cal_dup = 1;   // gap_init_opt, libbwa/bwtaln.c:39-48
+}
+extern "C" int fq_qc_create(const fq_index_t *ix, const char *ref_prefix, const char *out_prefix, const fq_qc_opts_t *o, fq_qc_t **out) {
+  if (!ix || !ref_prefix || !out_prefix || !o || !out) return FQ_EINVAL;
+  *out = nullptr;
+  fq_qc *q = new fq_qc;
+  q->ix = ix; q->o = *o; q->out_prefix = out_prefix;
+  const int rc = q->restore(ref_prefix);
+  if (rc) { delete q; return rc; }
+  q->table.open(q->out_prefix + ".InsertSizeTable");
+  if (!q->table.is_open()) { delete q; return FQ_EIO; }
+  *out = q;
+  return FQ_OK;
+}
+extern "C" void fq_qc_destroy(fq_qc_t *q) { delete q; }
+extern "C" const char *fq_qc_last_error(const fq_qc_t *q) { return q ? q->err.c_str() : "null"; }
+extern "C" int fq_qc_begin_file(fq_qc_t *q, const char *fq1, const char *fq2) {
+  if (!q || !fq1) return FQ_EINVAL;
+  q->cur = FileStat();
+  q->cur.f1 = fq1; q->cur.f2 = fq2 ? fq2 : fq1;
+  q->file_open = true;
+  return FQ_OK;
+}
+extern "C" int fq_qc_end_file(fq_qc_t *q) {
+  if (!q || !q->file_open) return FQ_EINVAL;
+  q->files.push_back(q->cur);     // StatCollector::AddFSC
+  q->file_open = false;
+  return FQ_OK;
+}
+
+// the consumer loop of PairEndMapper over one batch (src/BwtMapper.cpp:2026-2052): counters, then AddAlignment per surviving pair
+extern "C" int fq_qc_add_last(fq_qc_t *q, fq_ctx_t *c) {
+  if (!q || !c || !q->file_open) return FQ_EINVAL;
+  const FqBatchState *S = fq_ctx_state(c);
+  const FqHostReads hb = fq_ctx_host_reads(c);
+  const fq_opts_t *ao = fq_ctx_opts(c);
+  q->o.mode = ao->mode;
+  if (S->n_surv > 0 && !hb.has_qual()) { q->err = "the batch carries no qualities"; return FQ_EINVAL; }
+  FileStat &F = q->cur;
+  F.NumBase += fq_ctx_last_bases(c);
+  F.NumRead += 2LL * S->n_pairs;
+  F.TotalFiltered += S->n_pairs - S->n_surv;
+  for (int sp = 0; sp < S->n_surv; ++sp) {
+    const FqRead &a = S->reads[2 * sp], &b = S->reads[2 * sp + 1];
+    if (a.type == FQ_TYPE_NO_MATCH && b.type == FQ_TYPE_NO_MATCH) { ++F.BwaUnmapped; continue; }
+    Rec P, Q;
+    P.r = &a; P.type = a.type; P.name = fq_read_name(&hb, a.r % S->n_pairs, a.r / S->n_pairs, a.revived);
+    Q.r = &b; Q.type = b.type; Q.name = fq_read_name(&hb, b.r % S->n_pairs, b.r / S->n_pairs, b.revived);
+    F.TotalRetained += q->add_alignment(P, Q, hb, F.TotalMAPQ);
+  }
+  return FQ_OK;
+}
+
+// ProcessCore, :2012-2028
+extern "C" int fq_qc_write(fq_qc_t *q) {
+  if (!q) return FQ_EINVAL;
+  q->table.flush();
+  const std::string &pre = q->out_prefix;
+  {   // GetDepthDist, :1858-1918
+    for (auto &chr : q->position_table)
+      for (auto &site : chr.second) {
+        const int d = (int)q->depth[site.second];
+        q->NumBaseMapped += d;
+        ++q->DepthDist[d > 1023 ? 1023 : d];
+        const unsigned g = q->gc[chr.first][site.first];
+        q->GCDist[g] += d;
+        ++q->PosNum[g];
+      }
+    for (size_t i = 1; i != q->DepthDist.size(); ++i) {
+      q->NumCov += q->DepthDist[i];
+      if (i >= 2) q->NumCov2 += q->DepthDist[i];
+      if (i >= 5) q->NumCov5 += q->DepthDist[i];
+      if (i >= 10) q->NumCov10 += q->DepthDist[i];
+    }
+    const int chopped = (int)std::floor(q->o.read_len * 0.65f + 0.5);
+    q->total_region_size = (uint64_t)(((q->o.flank_len - chopped) * 2 + 1) * (int64_t)q->NumShort + ((q->o.flank_long_len - chopped) * 2 + 1) * (int64_t)q->NumLong +
+                                      ((q->o.flank_len - chopped) * 2 + 1) * (int64_t)q->NumXorY);
+    std::ofstream f(pre + ".DepthDist");
+    q->DepthDist[0] = q->total_region_size - q->NumCov;
+    for (uint32_t i = 0; i != q->DepthDist.size(); ++i) f << i << "\t" << q->DepthDist[i] << std::endl;
+  }
+  {   // GetGCDist, :1920-1937
+    std::ofstream f(pre + ".GCDist");
+    const double MeanDepth = q->NumBaseMapped / (double)q->NumCov;
+    for (uint32_t i = 0; i != 101; ++i) {
+      f << i << "\t" << q->GCDist[i] << "\t" << q->PosNum[i] << "\t";
+      if (q->PosNum[i] == 0) f << 0; else f << (double(q->GCDist[i]) / q->PosNum[i]) / MeanDepth;
+      f << std::endl;
+    }
+  }
+  {   // GetEmpRepDist, :1939-1953
+    std::ofstream f(pre + ".EmpRepDist");
+    for (uint32_t i = 0; i != q->EmpRep.size(); ++i) {
+      f << i << "\t" << q->misEmpRep[i] << "\t" << q->EmpRep[i] << "\t";
+      if (q->EmpRep[i] == 0) f << 0; else f << (-10) * log10((double)(q->misEmpRep[i] + 1) / (q->EmpRep[i] + 2));
+      f << std::endl;
+    }
+  }
+  {   // GetEmpCycleDist, :1955-1972
+    std::ofstream f(pre + ".EmpCycleDist");
+    double prevQual = 0;
+    for (uint32_t i = 0; i != q->EmpCycle.size(); ++i) {
+      const double ph = (-10) * log10((double)(q->misEmpCycle[i] + 1e-6) / (q->EmpCycle[i] + 1e-6));
+      f << i + 1 << "\t" << q->misEmpCycle[i] << "\t" << q->EmpCycle[i] << "\t" << (q->misEmpCycle[i] == 0 ? prevQual : ph) << "\t" << q->CycleDist[i] << std::endl;
+      if (q->misEmpCycle[i] != 0) prevQual = ph;
+    }
+  }
+  {   // GetInsertSizeDist's raw table, :1998-2002
+    std::ofstream f(pre + ".RawInsertSizeDist");
+    for (uint32_t i = 0; i != q->InsertDist.size(); ++i) f << i << "\t" << q->InsertDist[i] << std::endl;
+  }
+  {   // GetSexChromInfo, :2004-2015
+    std::ofstream f(pre + ".SexChromInfo");
+    for (auto &kv : q->contig_status)
+      f << kv.first << "\t" << kv.second.overlapped << "\t" << kv.second.fully << "\t" << kv.second.pair_overlapped << "\t" << kv.second.fully_paired << std::endl;
+  }
+  {   // GetPileup, :2030-2065
+    std::ofstream f(pre + ".Pileup");
+    const int qualoffset = (q->o.mode & FQ_MODE_IL13) ? 64 : 33;
+    for (auto &chr : q->vcf_table)
+      for (auto &site : chr.second) {
+        const unsigned k = site.second;
+        if (q->seq_vec[k].empty()) continue;
+        f << chr.first << "\t" << site.first << "\t.\t" << q->strand_vec[k].size() << "\t";
+        for (uint32_t t = 0; t != q->strand_vec[k].size(); ++t) f << (char)(q->strand_vec[k][t] ? toupper(q->seq_vec[k][t]) : tolower(q->seq_vec[k][t]));
+        f << "\t";
+        for (uint32_t t = 0; t != q->qual_vec[k].size(); ++t) f << char(q->qual_vec[k][t] + qualoffset);
+        f << "\t";
+        for (uint32_t t = 0; t != q->maq_vec[k].size(); ++t) f << q->maq_vec[k][t];
+        f << "\t";
+        for (uint32_t t = 0; t != q->cycle_vec[k].size(); ++t) { f << q->cycle_vec[k][t]; if (t != q->cycle_vec[k].size() - 1) f << ","; }
+        f << std::endl;
+      }
+  }
+  {   // SummaryOutput, :2343-2483
+    std::ofstream fq(pre + ".FASTQ.csv");
+    fq << "FileIndex,PairEnd1,PairEnd2" << std::endl;
+    for (size_t i = 0; i != q->files.size(); ++i) {
+      for (std::string *s : {&q->files[i].f1, &q->files[i].f2}) { const size_t sl = s->find_last_of("\\/"); if (sl != std::string::npos) s->erase(0, sl + 1); }
+      fq << i + 1 << "," << q->files[i].f1 << "," << q->files[i].f2 << "\n";
+    }
+    fq.close();
+    std::ofstream fc(pre + ".Sequence.csv");
+    long long total_base = 0, total_reads = 0, total_retained = 0, total_unmapped = 0, total_low = 0;
+    fc << "FileIndex,NumOfBases,NumOfReads,NumOfUmappedReads,NumOfLowMAPQReads,NumOfQCPassReads,ReadLength" << std::endl;
+    for (size_t i = 0; i != q->files.size(); ++i) {
+      const FileStat &F = q->files[i];
+      fc << i + 1 << "," << F.NumBase << "," << F.NumRead << "," << F.BwaUnmapped << "," << F.TotalMAPQ << "," << F.TotalRetained << ",";
+      fc << ((F.NumRead == 0) ? 0 : (F.NumBase / F.NumRead)) << std::endl;
+      total_base += F.NumBase; total_reads += F.NumRead; total_retained += F.TotalRetained; total_unmapped += F.BwaUnmapped; total_low += F.TotalMAPQ;
+    }
+    const double avgReadLen = std::floor(0.5 + ((total_reads == 0) ? 0 : ((double)total_base / total_reads)));
+    fc << "Total," << total_base << "," << total_reads << "," << total_unmapped << "," << total_low << "," << total_retained << ",";
+    fc << avgReadLen << std::endl;
+    fc.close();
+    std::ofstream f(pre + ".Summary");
+    f << "Statistics : " << "Value\n";
+    const uint64_t ref_genome_size = (uint64_t)q->o.genome_size, ref_N_size = (uint64_t)q->o.genome_n_size;
+    const auto report_genome_size = ref_genome_size - ref_N_size;
+    const double est = (double)q->NumBaseMapped / avgReadLen * report_genome_size / q->total_region_size;
+    f << "Estimated Read Mapping Rate : " << est / total_reads << "\n";
+    f << "Estimated Read PCR Duplication Rate : " << q->NumPCRDup / ((double)q->NumPairReads) << "[" << q->NumPCRDup << "/" << (double)q->NumPairReads << "]\n";
+    f << "Whole Genome Coverage : " << (double)total_base / ref_genome_size << "[" << total_base << "/" << ref_genome_size << "]\n";
+    f << "Expected Read Depth : " << (double)total_base / report_genome_size << "[" << total_base << "/" << report_genome_size << "]\n";
+    f << "Estimated Read Depth : ";
+    f << ((q->NumCov == 0) ? 0 : q->NumBaseMapped / (double)q->total_region_size) << "[" << q->NumBaseMapped << "/" << q->total_region_size << "]\n";
+    f << "Reduced Genome Size : " << q->total_region_size << std::endl;
+    f << "Depth 1 or above position fraction : " << q->NumCov / (double)q->total_region_size << std::endl;
+    f << "Depth 2 or above position fraction : " << q->NumCov2 / (double)q->total_region_size << std::endl;
+    f << "Depth 5 or above position fraction : " << q->NumCov5 / (double)q->total_region_size << std::endl;
+    f << "Depth 10 or above position fraction : " << q->NumCov10 / (double)q->total_region_size << std::endl;
+    long long s20 = 0, s30 = 0;
+    for (uint32_t v : q->q20) s20 += v;
+    for (uint32_t v : q->q30) s30 += v;
+    f << "Q20 Base Fraction : " << (q->NumBaseMapped == 0 ? 0 : double(s20) / q->NumBaseMapped) << std::endl;
+    f << "Q30 Base Fraction : " << (q->NumBaseMapped == 0 ? 0 : double(s30) / q->NumBaseMapped) << std::endl;
+    f << "Estimated AvgDepth for Q20 bases : " << double(s20) / q->NumCov << std::endl;
+    f << "Estimated AvgDepth for Q30 bases : " << double(s30) / q->NumCov << std::endl;
+    auto median_from = [&](size_t lo) -> size_t {
+      long long tmp = 0, total = 0;
+      for (size_t i = lo; i != q->InsertDist.size(); ++i) total += (long long)q->InsertDist[i];
+      for (size_t i = lo; i != q->InsertDist.size(); ++i) { tmp += (long long)q->InsertDist[i]; if (tmp > total / 2) return i; }
+      return 0;
+    };
+    f << "Median Insert Size(>=500bp) : " << median_from(500) << std::endl;
+    f << "Median Insert Size(>=300bp) : " << median_from(300) << std::endl;
+  }
+  return FQ_OK;
+}

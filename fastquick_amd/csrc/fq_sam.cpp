@@ -159,6 +159,9 @@ void print_sam(const fq_index *ix, const fq_opts_t *o, const FqHostReads *hb, in
   out.putc('\n');
 }
 
+}  // namespace
+std::string fq_read_name(const FqHostReads *hb, int pair, int end, bool revived) { return read_name(hb, pair, end, revived); }
+namespace {
 void dump_cigar(Out &o, const std::vector<uint16_t> &cg) { if (cg.empty()) o.putc('*'); else put_cigar(o, cg); }
 void dump_rec(Out &o, char tag, int end, int idx, const FqRead &p, bool fin) {
   o.printf("%c %d %d type=%d strand=%d pos=%u sa=%u mapQ=%d seQ=%d c1=%d c2=%d flag=%d mm=%d go=%d ge=%d score=%d filt=%d len=%d", tag, end, idx,

@@ -229,6 +229,30 @@ int64_t fq_sam_format_last(fq_ctx_t *c, char *buf, int64_t cap);
 /* canonical per-stage text dump of the last batch (tests): same format as oracle/ref_driver.cpp */
 int64_t fq_stage_dump_last(fq_ctx_t *c, char *buf, int64_t cap);
 
+/* ---- QC consumer --------------------------------------------------------------------------------------------------------
+ * StatCollector's side of the boundary (src/StatCollector.h:151, src/BwtMapper.cpp:2047-2050): every surviving pair of a batch
+ * goes through AddAlignment in input order, and ProcessCore writes <out>.InsertSizeTable .DepthDist .GCDist .EmpRepDist
+ * .EmpCycleDist .RawInsertSizeDist .SexChromInfo .Pileup .FASTQ.csv .Sequence.csv .Summary, byte for byte the reference's.
+ * ref_prefix is the reduced reference (<index_prefix>.FASTQuick.fa): <ref_prefix>.SelectedSite.vcf, .dbSNP.subset.vcf and .gc as
+ * `FASTQuick index` writes them.  One fq_qc_begin_file / fq_qc_end_file bracket per FASTQ pair (FileStatCollector). */
+typedef struct fq_qc fq_qc_t;
+typedef struct {
+  int32_t flank_len, flank_long_len;   /* SHORT_FLANK_LENGTH / LONG_FLANK_LENGTH of the index's .param (250 / 1000) */
+  int32_t read_len;                    /* gap_opt_t::read_len (151): the flank edge that is not counted is 0.65 x this */
+  int32_t cal_dup;                     /* gap_opt_t::cal_dup (1) */
+  int64_t genome_size, genome_n_size;  /* BwtIndexer::LoadContigSize: sums over the original reference's .fai / .amb */
+  int32_t mode;                        /* taken from the alignment context (Phred+64 input) */
+  int32_t pad;
+} fq_qc_opts_t;
+void fq_qc_default_opts(fq_qc_opts_t *o);
+int fq_qc_create(const fq_index_t *ix, const char *ref_prefix, const char *out_prefix, const fq_qc_opts_t *o, fq_qc_t **out);
+void fq_qc_destroy(fq_qc_t *q);
+const char *fq_qc_last_error(const fq_qc_t *q);
+int fq_qc_begin_file(fq_qc_t *q, const char *fastq_1, const char *fastq_2);
+int fq_qc_add_last(fq_qc_t *q, fq_ctx_t *c);   /* the records of the context's last batch; call before the next fq_align_* on it */
+int fq_qc_end_file(fq_qc_t *q);
+int fq_qc_write(fq_qc_t *q);                   /* ProcessCore: writes the files (once, at the end) */
+
 /* ---- measurement -------------------------------------------------------------------------
  * Per-kernel device time (HIP events on the context's stream) and algorithmic work counters
  * accumulated since the last reset.  Kernel ids: see FQ_K_*. */

@@ -104,7 +104,7 @@ def plant_pairs(r1, r2):
     return patch
 
 
-def write_case(out, tmp, pre, f1, f2, n, batch, q, refkw, readkw):
+def write_case(out, tmp, pre, f1, f2, n, batch, q, refkw, readkw, genome_size, qc_read_len=151):
     shutil.copy(pre, os.path.join(out, "ref.FASTQuick.fa"))
     for ext in INDEX_EXT:
         shutil.copy(pre + ext, os.path.join(out, "ref.FASTQuick.fa" + ext))
@@ -116,7 +116,7 @@ def write_case(out, tmp, pre, f1, f2, n, batch, q, refkw, readkw):
         with open(src, "rb") as fi, gzip.GzipFile(os.path.join(out, dst), "wb", mtime=0) as fo:
             fo.write(fi.read())
     with open(os.path.join(out, "case.txt"), "w") as fh:
-        fh.write("n_pairs=%d\nbatch=%d\ntrim_qual=%d\nref=%r\nreads=%r\n" % (n, batch, q, refkw, readkw))
+        fh.write("n_pairs=%d\nbatch=%d\ntrim_qual=%d\ngenome_size=%d\nqc_read_len=%d\nref=%r\nreads=%r\n" % (n, batch, q, genome_size, qc_read_len, refkw, readkw))
 
 
 def make_example_case():
@@ -138,7 +138,7 @@ def make_example_case():
                 fo.write(fi.read())
             fq.append(dst)
         ob.run_reference(pre, fq[0], fq[1], os.path.join(tmp, "ref_out"), "--batch", batch, "--q", q, "--read_len", 152, "--genome_size", len(ref.genome))
-        write_case(out, tmp, pre, fq[0], fq[1], len(r1), batch, q, refkw, "reference example/fq.test.list")
+        write_case(out, tmp, pre, fq[0], fq[1], len(r1), batch, q, refkw, "reference example/fq.test.list", len(ref.genome), 152)
     print(tag, "->", sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) // 1024, "KiB")
 
 
@@ -179,7 +179,7 @@ def main() -> None:
             f1, f2 = rb.write_fastq(os.path.join(tmp, "reads"))
             args = ["--batch", batch] + (["--q", q] if q else []) + (["--read_len", readkw["read_len"] + 1] if readkw.get("read_len", 150) > 150 else [])
             ob.run_reference(pre, f1, f2, os.path.join(tmp, "ref_out"), "--genome_size", len(ref.genome), *args)
-            write_case(out, tmp, pre, f1, f2, n, batch, q, refkw, readkw)
+            write_case(out, tmp, pre, f1, f2, n, batch, q, refkw, readkw, len(ref.genome), readkw["read_len"] + 1 if readkw.get("read_len", 150) > 150 else 151)
         print(tag, "->", sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) // 1024, "KiB")
     if not only or EXAMPLE_CASE[0] in only:
         make_example_case()

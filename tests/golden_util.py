@@ -20,7 +20,7 @@ def case_params(tag: str) -> dict:
     with open(os.path.join(GOLD, tag, "case.txt")) as fh:
         for line in fh:
             k, v = line.rstrip("\n").split("=", 1)
-            out[k] = int(v) if k in ("n_pairs", "batch", "trim_qual") else v
+            out[k] = int(v) if k in ("n_pairs", "batch", "trim_qual", "genome_size", "qc_read_len") else v
     return out
 
 

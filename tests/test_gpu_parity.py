@@ -294,3 +294,13 @@ def test_packed_boundary_properties(lib, tmp_path):
 def test_trimmed_max_len_of_filtered_reads_gpu(lib, tmp_path):
     from test_pipeline_emu import trimmed_max_len_case
     trimmed_max_len_case(lib, tmp_path, device=0)
+
+
+@pytest.mark.parametrize("packed", [False, True], ids=["ascii", "packed"])
+@pytest.mark.parametrize("tag", golden_util.case_tags())
+def test_qc_files_match_reference_golden(tag, packed, golden_cases, lib):
+    """StatCollector's files (.InsertSizeTable .Pileup .DepthDist .GCDist .EmpRepDist .EmpCycleDist .RawInsertSizeDist .SexChromInfo
+    .FASTQ.csv .Sequence.csv .Summary) from the QC consumer fed by the HIP path, byte for byte the REAL reference's."""
+    from test_qc_consumer import qc_case, explain
+    bad = qc_case(golden_cases[tag], lib, device=0, packed=packed)
+    assert not bad, explain(bad)

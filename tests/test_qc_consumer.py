@@ -1,0 +1,59 @@
+"""The QC consumer (fq_qc_*: StatCollector's side of the boundary) against the QC files the REAL reference wrote for every golden
+case (tests/golden/<case>/ref.qc.*, made by oracle/_ref/fq_ref_driver with the reference's own StatCollector in the loop).
+CPU tier: the host pipeline on the host-loop backend feeds the consumer; the GPU tier runs the same comparison through the HIP
+library (test_gpu_parity.py::test_qc_files_match_reference_golden)."""
+import os
+import subprocess
+
+import pytest
+
+import golden_util
+import oracle_binding as ob
+from fastquick_amd import api
+
+EMU_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+QC_FILES = ["InsertSizeTable", "DepthDist", "GCDist", "EmpRepDist", "EmpCycleDist", "RawInsertSizeDist", "SexChromInfo", "Pileup",
+            "FASTQ.csv", "Sequence.csv", "Summary"]
+
+
+@pytest.fixture(scope="module")
+def emu_lib():
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR])
+    return api.load_library(os.path.join(EMU_DIR, "libfq_emu.so"))
+
+
+def qc_case(g, lib, device=None, packed=False, tuning=None):
+    """Runs case g through the pipeline + QC consumer; returns {file: (got, want)} for the files that differ."""
+    names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
+    ix = api.Index(g["prefix"], lib=lib) if device is None else api.Index(g["prefix"], device=device, lib=lib)
+    al = api.Aligner(ix, api.default_opts(lib, trim_qual=g["trim_qual"]), max_pairs=max(16, g["batch"]), tuning=tuning or {})
+    out = os.path.join(g["dir"], "got_qc")
+    qc = api.QC(ix, g["prefix"], out, genome_size=g["genome_size"], read_len=g["qc_read_len"])
+    qc.begin_file(g["fq1"], g["fq2"])
+    api.align_stream(al, names, seq, qual, lens, g["batch"], None, None, qc=qc, packed=packed)
+    qc.end_file()
+    qc.write()
+    qc.close(); al.close(); ix.close()
+    bad = {}
+    for f in QC_FILES:
+        got = open(out + "." + f, "rb").read()
+        want = open(os.path.join(g["dir"], "ref.qc." + f), "rb").read()
+        if got != want:
+            bad[f] = (got, want)
+    return bad
+
+
+def explain(bad):
+    msg = []
+    for f, (got, want) in bad.items():
+        gl, wl = got.split(b"\n"), want.split(b"\n")
+        first = next((i for i, (a, b) in enumerate(zip(gl, wl)) if a != b), min(len(gl), len(wl)))
+        msg.append("%s: %d vs %d lines, first difference at line %d:\n  got  %r\n  want %r" % (
+            f, len(gl), len(wl), first + 1, gl[first][:200] if first < len(gl) else None, wl[first][:200] if first < len(wl) else None))
+    return "\n".join(msg)
+
+
+@pytest.mark.parametrize("tag", golden_util.case_tags())
+def test_qc_files_match_reference(tag, golden_cases, emu_lib):
+    bad = qc_case(golden_cases[tag], emu_lib)
+    assert not bad, explain(bad)
