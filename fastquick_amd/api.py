@@ -88,9 +88,10 @@ EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destr
            "fq_ctx_set_debug", "fq_align_batch", "fq_batch_upload", "fq_align_resident", "fq_sam_header",
            "fq_sam_format_last", "fq_stage_dump_last", "fq_stats_get", "fq_stats_reset", "fq_version",
            "fq_pinned_alloc", "fq_pinned_free", "fq_pack_reads", "fq_packed_free", "fq_packed_prefetch", "fq_align_packed",
-           "fq_ctx_set_tuning", "fq_qc_default_opts", "fq_qc_create", "fq_qc_destroy", "fq_qc_last_error", "fq_qc_begin_file",
+           "fq_ctx_set_tuning", "fq_ctx_set_serial_hooks", "fq_ctx_state_export", "fq_ctx_state_import", "fq_qc_default_opts", "fq_qc_create", "fq_qc_destroy", "fq_qc_last_error", "fq_qc_begin_file",
            "fq_qc_add_last", "fq_qc_end_file", "fq_qc_write"]
 
+SERIAL_HOOK = C.CFUNCTYPE(None, C.c_void_p)
 _libs = {}
 
 
@@ -138,6 +139,10 @@ def load_library(path: str | None = None):
     L.fq_packed_prefetch.argtypes = [C.c_void_p, C.POINTER(PackedBatch)]
     L.fq_align_packed.argtypes = [C.c_void_p, C.POINTER(PackedBatch), C.POINTER(ResultBatch)]
     L.fq_ctx_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+    L.fq_ctx_set_serial_hooks.argtypes = [C.c_void_p, SERIAL_HOOK, SERIAL_HOOK, C.c_void_p]
+    L.fq_ctx_state_export.restype = C.c_int64
+    L.fq_ctx_state_export.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.fq_ctx_state_import.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.fq_qc_default_opts.argtypes = [C.POINTER(QcOpts)]
     L.fq_qc_create.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(QcOpts), C.POINTER(C.c_void_p)]
     L.fq_qc_destroy.argtypes = [C.c_void_p]
@@ -289,6 +294,20 @@ class Aligner:
     def upload(self, seq, qual, lens, names=None) -> None:
         b = self._batch(seq, qual, lens, names)
         self._check(self.L.fq_batch_upload(self.h, C.byref(b)), "fq_batch_upload")
+
+    def export_state(self) -> bytes:
+        n = self.L.fq_ctx_state_export(self.h, None, 0)
+        buf = C.create_string_buffer(int(n))
+        self.L.fq_ctx_state_export(self.h, buf, n)
+        return buf.raw[:n]
+
+    def import_state(self, blob: bytes) -> None:
+        self._check(self.L.fq_ctx_state_import(self.h, blob, len(blob)), "fq_ctx_state_import")
+
+    def set_serial_hooks(self, before, after) -> None:
+        """before() / after(): Python callables run around the order-dependent part of every call (None clears)."""
+        self._hooks = (SERIAL_HOOK(lambda _u: before()) if before else SERIAL_HOOK(0), SERIAL_HOOK(lambda _u: after()) if after else SERIAL_HOOK(0))
+        self._check(self.L.fq_ctx_set_serial_hooks(self.h, self._hooks[0], self._hooks[1], None), "fq_ctx_set_serial_hooks")
 
     def prefetch(self, packed: HostPacked) -> None:
         self._check(self.L.fq_packed_prefetch(self.h, packed.p), "fq_packed_prefetch")

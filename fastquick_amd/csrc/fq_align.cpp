@@ -138,6 +138,9 @@ struct fq_ctx {
   int max_pairs = 0;
   int debug = 0;
   std::string err;
+  // single-stream sharding: callbacks around the order-dependent part of a call (fq_ctx_set_serial_hooks)
+  fq_serial_hook before_serial = nullptr, after_serial = nullptr;
+  void *hook_user = nullptr;
   // order-dependent state
   uint64_t rng = 0;
   fq_isize_t last_ii{};
@@ -1109,8 +1112,8 @@ void stageB2_isize(Call &K) {
   }
 }
 
-// ---- stage B3: pairing + XA lists (per pair) -------------------------------------------------------------
-void stageB3_pairing(Call &K) {
+// ---- (k,l) position cache, filled in pair order (serial; part of the order-dependent state of the stream, Q6) ---------------
+void stage_kl_cache(Call &K) {
   fq_ctx *c = K.c;
   const fq_opts_t &o = c->o;
   const int n_surv = K.n_surv;
@@ -1136,6 +1139,20 @@ void stageB3_pairing(Call &K) {
       }
     }
   }
+}
+
+// ---- stage B3: pairing + XA lists (per pair) -------------------------------------------------------------
+void stageB3_pairing(Call &K) {
+  fq_ctx *c = K.c;
+  const fq_opts_t &o = c->o;
+  const int n_surv = K.n_surv;
+  vector<FqRead> &R = c->st.reads;
+  const uint32_t *h_pos = K.h_pos;
+  auto both_mapped = [&](int sp) {
+    const FqRead &a = R[2 * sp], &b = R[2 * sp + 1];
+    return (a.type == FQ_TYPE_UNIQUE || a.type == FQ_TYPE_REPEAT) && (b.type == FQ_TYPE_UNIQUE || b.type == FQ_TYPE_REPEAT) &&
+           K.read_nocc[2 * sp] <= o.max_occ && K.read_nocc[2 * sp + 1] <= o.max_occ;
+  };
   for (int sb = 0; sb < K.n_sub; ++sb) {
     const fq_isize_t ii = K.iis[sb];
     parallel_chunks((size_t)(K.sub_lo[sb + 1] - K.sub_lo[sb]), K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
@@ -1524,9 +1541,15 @@ int run_call(fq_ctx *c, fq_result_batch_t *out) {
   if ((rc = stage_sa_rows(K))) return rc;
   K.trace("SA enumerate+kernel");
   K.t_host0 = now_ms();
+  // ---- the order-dependent part of the call: drand48 stream, last_ii chain, (k,l) cache.  A stream sharded over ranks by
+  //      reference batch hands this state from the owner of one batch to the owner of the next around it (fq_ctx_set_serial_hooks)
+  if (c->before_serial) c->before_serial(c->hook_user);
   if ((rc = stageB1_main_hit(K))) return rc;
   K.trace("B1 main hit (serial)");
   stageB2_isize(K);
+  c->last_ii = K.iis[K.n_sub - 1];
+  stage_kl_cache(K);
+  if (c->after_serial) c->after_serial(c->hook_user);
   K.t_serial1 = now_ms();
   K.trace("B2 isize");
   stageB3_pairing(K);
@@ -1537,7 +1560,6 @@ int run_call(fq_ctx *c, fq_result_batch_t *out) {
   if (c->debug) S.stage_S = S.reads;
   if ((rc = stageD_refine(K))) return rc;
   K.trace("D refine+MD+trim");
-  c->last_ii = K.iis[K.n_sub - 1];
   K.t_host1 = now_ms();
   return stage_finish(K, out);
 }
@@ -1592,6 +1614,52 @@ extern "C" int fq_align_packed(fq_ctx_t *c, const fq_packed_batch_t *in, fq_resu
     }
   }
   return run_call(c, out);
+}
+
+// ---- order-dependent state of a stream, for sharding ONE FASTQ stream over ranks by reference batch -------------
+// Layout: u64 rng | fq_isize_t last_ii | u64 n_entries | per entry: u64 key, u64 n, u32 pos[n]
+extern "C" int64_t fq_ctx_state_export(const fq_ctx_t *c, void *buf, int64_t cap) {
+  if (!c) return FQ_EINVAL;
+  int64_t need = 8 + (int64_t)sizeof(fq_isize_t) + 8;
+  for (const auto &kv : c->kl_cache) need += 16 + 4 * (int64_t)kv.second.size();
+  if (!buf || cap < need) return need;
+  uint8_t *p = (uint8_t *)buf;
+  memcpy(p, &c->rng, 8); p += 8;
+  memcpy(p, &c->last_ii, sizeof(fq_isize_t)); p += sizeof(fq_isize_t);
+  const uint64_t n = c->kl_cache.size();
+  memcpy(p, &n, 8); p += 8;
+  for (const auto &kv : c->kl_cache) {
+    const uint64_t m = kv.second.size();
+    memcpy(p, &kv.first, 8); p += 8;
+    memcpy(p, &m, 8); p += 8;
+    memcpy(p, kv.second.data(), 4 * m); p += 4 * m;
+  }
+  return need;
+}
+extern "C" int fq_ctx_state_import(fq_ctx_t *c, const void *buf, int64_t len) {
+  if (!c || !buf || len < (int64_t)(16 + sizeof(fq_isize_t))) return FQ_EINVAL;
+  const uint8_t *p = (const uint8_t *)buf, *end = p + len;
+  memcpy(&c->rng, p, 8); p += 8;
+  memcpy(&c->last_ii, p, sizeof(fq_isize_t)); p += sizeof(fq_isize_t);
+  uint64_t n;
+  memcpy(&n, p, 8); p += 8;
+  c->kl_cache.clear();
+  for (uint64_t i = 0; i < n; ++i) {
+    if (end - p < 16) return FQ_EINVAL;
+    uint64_t key, m;
+    memcpy(&key, p, 8); p += 8;
+    memcpy(&m, p, 8); p += 8;
+    if ((uint64_t)(end - p) < 4 * m) return FQ_EINVAL;
+    vector<uint32_t> v(m);
+    memcpy(v.data(), p, 4 * m); p += 4 * m;
+    c->kl_cache.emplace(key, std::move(v));
+  }
+  return FQ_OK;
+}
+extern "C" int fq_ctx_set_serial_hooks(fq_ctx_t *c, fq_serial_hook before, fq_serial_hook after, void *user) {
+  if (!c) return FQ_EINVAL;
+  c->before_serial = before; c->after_serial = after; c->hook_user = user;
+  return FQ_OK;
 }
 
 extern "C" int fq_ctx_set_debug(fq_ctx_t *c, int keep_stage_snapshots) {

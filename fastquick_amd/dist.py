@@ -1,4 +1,11 @@
-"""Multi-GPU plumbing: one process per GPU, each rank aligns its own FASTQ stream(s); no data-path collective.
+"""Multi-GPU plumbing: one process per GPU; no data-path collective.
+
+Two partitionings: (1) independent FASTQ streams per rank -- below; (2) ONE stream sharded by reference
+batch (StreamShard): rank r aligns batches r, r+W, ...; the order-dependent state of the stream (drand48, last_ii, (k,l) cache: a
+few dozen bytes) travels from the owner of batch b to the owner of batch b+1 by point-to-point send/recv around the short serial
+part of each call, and rank 0 gathers the per-batch outputs in batch order.
+
+(1): each rank aligns its own FASTQ stream(s).
 
 The reference treats every `--fq_list` line as an independent stream (own srand48(11), own last_ii chain,
 src/BwtMapper.cpp:1817), so streams shard across ranks without any exchange.  What is exchanged is bookkeeping only:
@@ -86,3 +93,83 @@ def gather_bytes_to_rank0(buf: bytes):
     if rank != 0:
         return None
     return [bytes(p[:s].cpu().numpy().tobytes()) for p, s in zip(parts, sizes)]
+
+
+def _send_bytes(blob: bytes, dst: int) -> None:
+    dev = _dev()
+    dist.send(torch.tensor([len(blob)], dtype=torch.int64, device=dev), dst)
+    if blob:
+        dist.send(torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev), dst)
+
+
+def _recv_bytes(src: int) -> bytes:
+    dev = _dev()
+    n = torch.zeros(1, dtype=torch.int64, device=dev)
+    dist.recv(n, src)
+    buf = torch.zeros(int(n.item()), dtype=torch.uint8, device=dev)
+    if buf.numel():
+        dist.recv(buf, src)
+    return bytes(buf.cpu().numpy().tobytes())
+
+
+class StreamShard:
+    """ONE FASTQ stream over `world` ranks, sharded by reference batch.  Rank r owns batches r, r + world, ...; every
+    rank drives its own Aligner.  The hooks the library calls around the order-dependent part of a call receive the stream state
+    from the owner of the previous batch and pass it on to the owner of the next (fq_ctx_set_serial_hooks /
+    fq_ctx_state_export / _import), so that the outputs are those of the single sequential stream -- the reference's."""
+
+    def __init__(self, aligner, rank: int, world: int):
+        self.al, self.rank, self.world = aligner, rank, world
+        self.batch_index = 0
+        self.n_batches = 0
+        aligner.set_serial_hooks(self._before, self._after)
+
+    def _before(self):
+        if self.world > 1 and self.batch_index > 0:
+            self.al.import_state(_recv_bytes((self.batch_index - 1) % self.world))
+
+    def _after(self):
+        if self.world > 1 and self.batch_index + 1 < self.n_batches:
+            _send_bytes(self.al.export_state(), (self.batch_index + 1) % self.world)
+
+    def owns(self, b: int) -> bool:
+        return b % self.world == self.rank
+
+    def align_stream(self, names, seq, qual, lens, batch: int, packed: bool = False, want_sam: bool = True, qc=None):
+        """Aligns this rank's batches of the stream; returns [(batch index, SAM text of the batch)] (header not included)."""
+        from . import api
+        n = seq.shape[1]
+        self.n_batches = (n + batch - 1) // batch
+        out = []
+        for b in range(self.n_batches):
+            if not self.owns(b):
+                continue
+            self.batch_index = b
+            lo, hi = b * batch, min(n, (b + 1) * batch)
+            if packed:
+                hp = api.HostPacked(seq[:, lo:hi], qual[:, lo:hi], lens[:, lo:hi], names[lo:hi], lib=self.al.L)
+                self.al.align_packed(hp)
+            else:
+                self.al.align(seq[:, lo:hi], qual[:, lo:hi], lens[:, lo:hi], names[lo:hi])
+            if qc is not None:
+                qc.add(self.al)
+            out.append((b, self.al.sam_text() if want_sam else b""))
+            if packed:
+                self.al._keep_packed = None
+                hp.free()
+        return out
+
+    def gather_in_batch_order(self, parts):
+        """parts: this rank's [(batch index, bytes)]; rank 0 returns the stream's bytes in batch order, others None."""
+        blob = b"".join(len(p).to_bytes(8, "little") + b.to_bytes(8, "little") + p for b, p in parts)
+        got = gather_bytes_to_rank0(blob)
+        if got is None:
+            return None
+        items = []
+        for g in got:
+            at = 0
+            while at < len(g):
+                ln, b = int.from_bytes(g[at:at + 8], "little"), int.from_bytes(g[at + 8:at + 16], "little")
+                items.append((b, g[at + 16:at + 16 + ln]))
+                at += 16 + ln
+        return b"".join(p for _b, p in sorted(items, key=lambda t: t[0]))

@@ -215,6 +215,19 @@ int fq_packed_prefetch(fq_ctx_t *c, const fq_packed_batch_t *next);
 /* The whole hot path on a packed batch, host memory in -> host memory out. */
 int fq_align_packed(fq_ctx_t *c, const fq_packed_batch_t *in, fq_result_batch_t *out);
 
+/* ---- one FASTQ stream over several ranks -------------------------------------------------------------------------------
+ * A stream shards by reference batch: everything per-read of a batch is independent, and three pieces of state
+ * are handed on in batch order -- the drand48 stream (bwa_aln2seq_core, srand48 once per FASTQ pair, src/BwtMapper.cpp:1817), the
+ * last_ii fallback (:780-781) and the (k,l) position cache (:815-843).  Every rank aligns its own batches on its own context;
+ * the hooks run inside a call around its short order-dependent part: `before` -- receive the state from the owner of the
+ * previous batch and fq_ctx_state_import it; `after` -- fq_ctx_state_export and send it to the owner of the next.  Filter, gap
+ * search and SA walks of a rank's batch run before `before`, pairing, mate rescue and refinement after `after`, so the ranks
+ * overlap everywhere else.  (fastquick_amd/dist.py StreamShard does this over torch.distributed: RCCL or gloo.) */
+typedef void (*fq_serial_hook)(void *user);
+int fq_ctx_set_serial_hooks(fq_ctx_t *c, fq_serial_hook before, fq_serial_hook after, void *user);
+int64_t fq_ctx_state_export(const fq_ctx_t *c, void *buf, int64_t cap);   /* bytes written, or needed when buf is NULL / too small */
+int fq_ctx_state_import(fq_ctx_t *c, const void *buf, int64_t len);
+
 /* Experiment / test knobs by name (defaults are what DESIGN.md measures): gap_long_pops, gap_long_always, gap_pool,
  * gap_nogap_min, gap_no_order, gap_order_asc, gap_waves_per_cu, gap_refill_min, sw_wave_max, host_threads, host_par_min, filter_no_turns,
  * refine_lanes, packed_bulk_min, trace.  FQ_EINVAL for an unknown key. */

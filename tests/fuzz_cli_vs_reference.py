@@ -36,6 +36,7 @@ for seed in range(args.start, args.start + args.seeds):
         pre = os.path.join(d, "ref.FASTQuick.fa")
         ref.write_fasta(pre)
         subprocess.check_call([ob.REF_DRIVER, "index", pre], stderr=subprocess.DEVNULL, cwd=d)
+        synth.write_qc_inputs(pre, ref)   # the reference driver runs the real StatCollector: it needs its input files
         n = rnd.choice([300, 700])
         batch = rnd.choice([64, 100, 256, 1024])
         il13 = rnd.random() < 0.25

@@ -84,6 +84,7 @@ for seed in range(args.start, args.start + args.seeds):
         pre = os.path.join(d, "ref.FASTQuick.fa")
         ref.write_fasta(pre)
         subprocess.check_call([ob.REF_DRIVER, "index", pre], stderr=subprocess.DEVNULL, cwd=d)
+        synth.write_qc_inputs(pre, ref)   # the reference driver runs the real StatCollector: it needs its input files
         rb = synth.make_reads(ref, n, **readkw)
         if args.ragged:
             import numpy as np

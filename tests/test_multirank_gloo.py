@@ -61,3 +61,45 @@ def test_two_ranks_gloo(tmp_path):
     assert got == want, "rank-ordered gather of per-rank SAM must equal the reference's records for the same streams"
     tot = (tmp_path / "totals.txt").read_text().split()
     assert int(tot[0]) == n_pairs and int(tot[1]) == want.count(b"\n") // 2
+
+
+SHARD_WORKER = r'''
+import os, sys
+sys.path.insert(0, %(root)r); sys.path.insert(0, %(here)r)
+import golden_util, oracle_binding as ob
+from fastquick_amd import api, dist as fqd
+rank, local_rank, world = fqd.init("gloo")
+assert world == 2
+L = api.load_library(os.path.join(%(here)r, "emu", "libfq_emu.so"))
+for tag in ["isize", "basic", "qc", "edge"]:
+    g = golden_util.materialise(tag, os.path.join(%(tmp)r, "s%%d_%%s" %% (rank, tag)))
+    names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
+    ix = api.Index(g["prefix"], lib=L)
+    al = api.Aligner(ix, api.default_opts(L, trim_qual=g["trim_qual"]), max_pairs=max(16, g["batch"]))
+    sh = fqd.StreamShard(al, rank, world)
+    parts = sh.align_stream(names, seq, qual, lens, g["batch"], packed=(tag == "qc"))
+    assert len(parts) == len([b for b in range(sh.n_batches) if b %% world == rank])
+    sam = sh.gather_in_batch_order(parts)
+    if rank == 0:
+        open(os.path.join(%(tmp)r, "shard_%%s.sam" %% tag), "wb").write(sam)
+    fqd.barrier()
+    al.close(); ix.close()
+'''
+
+
+def test_one_stream_sharded_over_two_ranks(tmp_path):
+    """ONE FASTQ stream split by reference batch over two ranks (batches 0, 2, ... on rank 0; 1, 3, ... on rank 1), the drand48
+    state, the last_ii fallback and the (k,l) cache handed from batch to batch by send/recv: the SAM text gathered in batch order
+    must be the reference's for the sequential stream.  `isize` has a failed insert-size inference that falls back on the previous
+    batch's (which lives on the other rank); `basic` and `qc` have three batches (drand48 crosses ranks twice)."""
+    subprocess.check_call(["make", "-s", "-C", os.path.join(HERE, "emu")])
+    script = tmp_path / "shard_worker.py"
+    script.write_text(SHARD_WORKER % dict(root=ROOT, here=HERE, tmp=str(tmp_path)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29541")
+    subprocess.check_call([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                           "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)], env=env, timeout=900)
+    for tag in ["isize", "basic", "qc", "edge"]:
+        with gzip.open(os.path.join(golden_util.GOLD, tag, "ref.sam.gz"), "rb") as fh:
+            want = b"".join(l for l in fh.read().splitlines(keepends=True) if not l.startswith(b"@"))
+        got = (tmp_path / ("shard_%s.sam" % tag)).read_bytes()
+        assert got == want, tag
