@@ -89,7 +89,7 @@ EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destr
            "fq_sam_format_last", "fq_stage_dump_last", "fq_stats_get", "fq_stats_reset", "fq_version",
            "fq_pinned_alloc", "fq_pinned_free", "fq_pack_reads", "fq_packed_free", "fq_packed_prefetch", "fq_align_packed",
            "fq_ctx_set_tuning", "fq_ctx_set_serial_hooks", "fq_ctx_state_export", "fq_ctx_state_import", "fq_qc_default_opts", "fq_qc_create", "fq_qc_destroy", "fq_qc_last_error", "fq_qc_begin_file",
-           "fq_qc_add_last", "fq_qc_end_file", "fq_qc_write"]
+           "fq_qc_add_last", "fq_qc_end_file", "fq_qc_write", "fq_bam_create", "fq_bam_add_last", "fq_bam_close"]
 
 SERIAL_HOOK = C.CFUNCTYPE(None, C.c_void_p)
 _libs = {}
@@ -152,6 +152,9 @@ def load_library(path: str | None = None):
     L.fq_qc_add_last.argtypes = [C.c_void_p, C.c_void_p]
     L.fq_qc_end_file.argtypes = [C.c_void_p]
     L.fq_qc_write.argtypes = [C.c_void_p]
+    L.fq_bam_create.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.c_char_p, C.POINTER(QcOpts), C.POINTER(C.c_void_p)]
+    L.fq_bam_add_last.argtypes = [C.c_void_p, C.c_void_p]
+    L.fq_bam_close.argtypes = [C.c_void_p]
     _libs[path] = L
     return L
 
@@ -390,7 +393,36 @@ class QC:
             self.h = None
 
 
-def align_stream(aligner: Aligner, names, seq, qual, lens, batch: int, stages_path=None, sam_path=None, header=True, packed: bool = False, qc: "QC | None" = None) -> int:
+class BamWriter:
+    """The BAM consumer (SetSamRecord / SetSamFileHeader): genome-coordinate records of every batch of a stream."""
+
+    def __init__(self, index: Index, fai_path: str, bam_path: str, rg: str = "@RG\\tID:foo\\tSM:bar", **kw):
+        self.L = index.L
+        o = QcOpts()
+        self.L.fq_qc_default_opts(C.byref(o))
+        for k, v in kw.items():
+            setattr(o, k, v)
+        h = C.c_void_p()
+        rc = self.L.fq_bam_create(index.h, fai_path.encode(), bam_path.encode(), rg.encode(), C.byref(o), C.byref(h))
+        if rc:
+            raise FastquickError("fq_bam_create failed: %d" % rc)
+        self.h = h
+
+    def add(self, aligner: "Aligner"):
+        rc = self.L.fq_bam_add_last(self.h, aligner.h)
+        if rc:
+            raise FastquickError("fq_bam_add_last failed: %d" % rc)
+
+    def close(self):
+        if self.h:
+            rc = self.L.fq_bam_close(self.h)
+            self.h = None
+            if rc:
+                raise FastquickError("fq_bam_close failed: %d" % rc)
+
+
+def align_stream(aligner: Aligner, names, seq, qual, lens, batch: int, stages_path=None, sam_path=None, header=True, packed: bool = False, qc: "QC | None" = None,
+                 bam: "BamWriter | None" = None) -> int:
     """Feed n pairs in batches of `batch` (mirrors PairEndMapper's loop); returns pairs with SAM records.  packed=True goes
     through the packed-batch boundary (fq_pack_reads -> fq_packed_prefetch of the next chunk -> fq_align_packed)."""
     n = seq.shape[1]
@@ -419,6 +451,8 @@ def align_stream(aligner: Aligner, names, seq, qual, lens, batch: int, stages_pa
             sm.write(aligner.sam_text())
         if qc is not None:
             qc.add(aligner)
+        if bam is not None:
+            bam.add(aligner)
         if packed:
             aligner._keep_packed = None
             cur.free()

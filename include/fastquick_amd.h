@@ -266,6 +266,15 @@ int fq_qc_add_last(fq_qc_t *q, fq_ctx_t *c);   /* the records of the context's l
 int fq_qc_end_file(fq_qc_t *q);
 int fq_qc_write(fq_qc_t *q);                   /* ProcessCore: writes the files (once, at the end) */
 
+/* ---- BAM consumer ---------------------------------------------------------------------------------------------------------
+ * BwtMapper::SetSamRecord / SetSamFileHeader (src/BwtMapper.cpp:947-1264) as a BAM file (own BGZF layer): genome coordinates
+ * (contig CHR:POS@REF/ALT[|L] -> RNAME CHR, POS - flank + offset - 1), @SQ from the original reference's .fai, RG:Z on every
+ * record.  flank_len / flank_long_len of `o` are the index's; rg_line is --RG ("@RG\tID:foo\tSM:bar" is runAlign's default). */
+typedef struct fq_bam fq_bam_t;
+int fq_bam_create(const fq_index_t *ix, const char *fai_path, const char *bam_path, const char *rg_line, const fq_qc_opts_t *o, fq_bam_t **out);
+int fq_bam_add_last(fq_bam_t *b, fq_ctx_t *c);   /* the records of the context's last batch, in input order */
+int fq_bam_close(fq_bam_t *b);                   /* writes the BGZF end-of-file block, closes and frees */
+
 /* ---- measurement -------------------------------------------------------------------------
  * Per-kernel device time (HIP events on the context's stream) and algorithmic work counters
  * accumulated since the last reset.  Kernel ids: see FQ_K_*. */

@@ -19,6 +19,9 @@
 //       ProcessCore at the end, :288) -- the QC files <out>.InsertSizeTable .DepthDist .GCDist .EmpRepDist .EmpCycleDist
 //       .RawInsertSizeDist .AdjustedInsertSizeDist .SexChromInfo .Pileup .FASTQ.csv .Sequence.csv .Summary .vcf.
 //       Needs <fa>.SelectedSite.vcf, <fa>.dbSNP.subset.vcf and <fa>.gc (fastquick_amd/synth.py write_qc_inputs).
+//       With --bam_dump 1 --fai <genome.fai> [--RG "@RG\tID:.."] the consumer loop is the BAM branch instead
+//       (src/BwtMapper.cpp:2054-2085): BwtMapper::SetSamRecord for both mates, and every SamRecord it fills is written as one text
+//       line to <out>.bamtxt (fields read back through SamRecord's own getters), the header of SetSamFileHeader to <out>.bamhdr.
 #include "BwtMapper.cpp"   // resolved through -I$(REF)/src ; see Makefile
 
 #include <cinttypes>
@@ -125,6 +128,8 @@ static int cmd_align(int argc, char **argv) {
   pe_opt_t *popt = bwa_init_pe_opt();
   int batch = READ_BUFFER_SIZE, thresh = 3;
   long long genome_size = 0, genome_n_size = 0;
+  int bam_dump = 0;
+  std::string fai_path, rg = "@RG\tID:foo\tSM:bar";   // runAlign's default --RG (src/FASTQuick.cpp:170)
   for (int i = 6; i + 1 < argc; i += 2) {
     if (!strcmp(argv[i], "--q")) opt->trim_qual = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--batch")) batch = atoi(argv[i + 1]);
@@ -133,6 +138,9 @@ static int cmd_align(int argc, char **argv) {
     else if (!strcmp(argv[i], "--flank")) opt->flank_len = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--flank_long")) opt->flank_long_len = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--cal_dup")) opt->cal_dup = (char)atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--bam_dump")) bam_dump = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--fai")) fai_path = argv[i + 1];
+    else if (!strcmp(argv[i], "--RG")) rg = argv[i + 1];
     else if (!strcmp(argv[i], "--thresh")) thresh = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--n")) { opt->max_diff = atoi(argv[i + 1]); opt->fnr = -1.0; }
     else if (!strcmp(argv[i], "--no_sw")) popt->is_sw = 0;
@@ -179,6 +187,34 @@ static int cmd_align(int argc, char **argv) {
   collector.SetGenomeSize(genome_size, genome_n_size);
   std::ofstream fout(out + ".InsertSizeTable");
   FileStatCollector FSC(fq1, fq2);
+
+  // BAM branch: the record builder and header of the reference, on its own SamRecord / SamFileHeader classes
+  BwtMapper mapper;
+  SamFileHeader SFH;
+  FILE *fb = 0;
+  if (bam_dump) {
+    opt->RG = strdup(rg.c_str());
+    mapper.bwa_set_rg(opt->RG);
+    std::ifstream fai(fai_path);                       // BwtIndexer::LoadContigSize's first half (src/BwtIndexer.cpp:764-783)
+    if (!fai.is_open()) die("--bam_dump needs --fai");
+    std::string line, chr, length;
+    while (getline(fai, line)) {
+      std::stringstream ss(line);
+      ss >> chr;
+      if (chr.find("chr") != std::string::npos or chr.find("CHR") != std::string::npos) chr = chr.substr(3);
+      ss >> length;
+      ix.contigSize.emplace_back(chr, atoi(length.c_str()));
+    }
+    mapper.SetSamFileHeader(SFH, ix);
+    std::string hdr;
+    SFH.getHeaderString(hdr);
+    FILE *fh = fopen((out + ".bamhdr").c_str(), "w");
+    if (!fh) die("cannot open bamhdr");
+    fputs(hdr.c_str(), fh);
+    fclose(fh);
+    fb = fopen((out + ".bamtxt").c_str(), "w");
+    if (!fb) die("cannot open bamtxt");
+  }
 
   FILE *st = fopen((out + ".stages").c_str(), "w");
   if (!st) die("cannot open stages file");
@@ -249,6 +285,26 @@ static int cmd_align(int argc, char **argv) {
       if (p[0]->filtered && p[1]->filtered) { ++n_filtered; ++FSC.TotalFiltered; continue; }
       if (p[0]->type == BWA_TYPE_NO_MATCH && p[1]->type == BWA_TYPE_NO_MATCH) { ++n_unmapped; FSC.BwaUnmapped++; continue; }
       FSC.TotalRetained += collector.AddAlignment(ix.bns, p[0], p[1], opt, fout, FSC.TotalMAPQ);
+      if (bam_dump) {
+        SamRecord SR[2];
+        mapper.SetSamRecord(ix.bns, p[0], p[1], SFH, SR[0], opt);
+        mapper.SetSamRecord(ix.bns, p[1], p[0], SFH, SR[1], opt);
+        for (int k = 0; k < 2; ++k) {
+          SamRecord &R = SR[k];
+          fprintf(fb, "%s\t%d\t%s\t%d\t%d\t%s\t%s\t%d\t%d\t%s\t%s", R.getReadName(), (int)R.getFlag(), R.getReferenceName(), (int)R.get1BasedPosition(),
+                  (int)R.getMapQuality(), R.getCigar(), R.getMateReferenceNameOrEqual(), (int)R.get1BasedMatePosition(), (int)R.getInsertSize(), R.getSequence(), R.getQuality());
+          char tag[3]; char vtype; void *value;
+          R.resetTagIter();
+          while (R.getNextSamTag(tag, vtype, &value)) {
+            if (vtype == 'Z') fprintf(fb, "\t%s:Z:%s", tag, ((String *)value)->c_str());
+            else if (vtype == 'A') fprintf(fb, "\t%s:A:%c", tag, *(char *)value);
+            else if (vtype == 'f') fprintf(fb, "\t%s:f:%g", tag, *(float *)value);
+            else fprintf(fb, "\t%s:i:%d", tag, *(int *)value);
+          }
+          fputc('\n', fb);
+        }
+        continue;
+      }
       bwa_print_sam1(ix.bns, p[0], p[1], opt->mode, opt->max_top2);
       bwa_print_sam1(ix.bns, p[1], p[0], opt->mode, opt->max_top2);
     }
@@ -261,6 +317,7 @@ static int cmd_align(int argc, char **argv) {
   }
   fprintf(st, "E pairs=%lld filtered=%lld unmapped=%lld\n", n_pairs_total, n_filtered, n_unmapped);
   fclose(st);
+  if (fb) fclose(fb);
   fflush(stdout);
   collector.AddFSC(FSC);
   fout.close();

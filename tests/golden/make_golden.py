@@ -104,12 +104,21 @@ def plant_pairs(r1, r2):
     return patch
 
 
+def run_bam_dump(tmp, pre, f1, f2, ref, *args):
+    """The reference's BAM branch (SetSamRecord / SetSamFileHeader) on the same input: one text line per record, and the header."""
+    with open(os.path.join(tmp, "genome.fai"), "w") as fh:      # the original reference's .fai: one contig per chromosome name in use
+        for chrom in sorted({nm.split(":")[0] for nm in ref.names}):
+            fh.write("%s\t%d\t%d\t60\t61\n" % (chrom, len(ref.genome), len(chrom) + 2))
+    ob.run_reference(pre, f1, f2, os.path.join(tmp, "bam_out"), "--bam_dump", 1, "--fai", os.path.join(tmp, "genome.fai"), *args)
+
+
 def write_case(out, tmp, pre, f1, f2, n, batch, q, refkw, readkw, genome_size, qc_read_len=151):
     shutil.copy(pre, os.path.join(out, "ref.FASTQuick.fa"))
     for ext in INDEX_EXT:
         shutil.copy(pre + ext, os.path.join(out, "ref.FASTQuick.fa" + ext))
     sparse_to_npz(pre + ".rollhash.sparse", os.path.join(out, "rollhash_bits.npz"))
     qc = [(pre + ext, "ref.FASTQuick.fa" + ext + ".gz") for ext in QC_IN_EXT] + [(os.path.join(tmp, "ref_out" + ext), "ref.qc" + ext + ".gz") for ext in QC_OUT_EXT]
+    qc += [(os.path.join(tmp, "bam_out.bamtxt"), "ref.bamtxt.gz"), (os.path.join(tmp, "bam_out.bamhdr"), "ref.bamhdr.gz"), (os.path.join(tmp, "genome.fai"), "genome.fai.gz")]
     for src, dst in [(f1, "reads_1.fq.gz"), (f2, "reads_2.fq.gz"),
                      (os.path.join(tmp, "ref_out.stages"), "ref.stages.gz"),
                      (os.path.join(tmp, "ref_out.sam"), "ref.sam.gz")] + qc:
@@ -138,6 +147,7 @@ def make_example_case():
                 fo.write(fi.read())
             fq.append(dst)
         ob.run_reference(pre, fq[0], fq[1], os.path.join(tmp, "ref_out"), "--batch", batch, "--q", q, "--read_len", 152, "--genome_size", len(ref.genome))
+        run_bam_dump(tmp, pre, fq[0], fq[1], ref, "--batch", batch, "--q", q, "--read_len", 152)
         write_case(out, tmp, pre, fq[0], fq[1], len(r1), batch, q, refkw, "reference example/fq.test.list", len(ref.genome), 152)
     print(tag, "->", sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) // 1024, "KiB")
 
@@ -179,6 +189,7 @@ def main() -> None:
             f1, f2 = rb.write_fastq(os.path.join(tmp, "reads"))
             args = ["--batch", batch] + (["--q", q] if q else []) + (["--read_len", readkw["read_len"] + 1] if readkw.get("read_len", 150) > 150 else [])
             ob.run_reference(pre, f1, f2, os.path.join(tmp, "ref_out"), "--genome_size", len(ref.genome), *args)
+            run_bam_dump(tmp, pre, f1, f2, ref, *args)
             write_case(out, tmp, pre, f1, f2, n, batch, q, refkw, readkw, len(ref.genome), readkw["read_len"] + 1 if readkw.get("read_len", 150) > 150 else 151)
         print(tag, "->", sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) // 1024, "KiB")
     if not only or EXAMPLE_CASE[0] in only:

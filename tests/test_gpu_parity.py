@@ -304,3 +304,11 @@ def test_qc_files_match_reference_golden(tag, packed, golden_cases, lib):
     from test_qc_consumer import qc_case, explain
     bad = qc_case(golden_cases[tag], lib, device=0, packed=packed)
     assert not bad, explain(bad)
+
+
+@pytest.mark.parametrize("tag", golden_util.case_tags())
+def test_bam_records_match_reference_golden(tag, golden_cases, lib):
+    """The BAM file written from the HIP path's records (genome coordinates, @SQ from the .fai, RG) decodes to the fields the REAL
+    reference's SetSamRecord puts into its SamRecords."""
+    from test_bam_writer import bam_case
+    bam_case(golden_cases[tag], lib, device=0, packed=(tag in ("qc", "edge")))
