@@ -4,8 +4,11 @@
 // index prefix convention (<index_prefix>.FASTQuick.fa.*), SAM text on stdout in the --sam_out dialect, the summary
 // notices on stderr.  The FASTQ tokenizer follows kseq_read3_fpc (libbwa/kseq.h:327-370): name up to the first white
 // space, bases = printable characters up to the '+' line, quality = exactly as many characters as bases.
-// Not built yet: BAM output with genome-coordinate translation, StatCollector QC files -- asking for them
-// is an error, not a silent downgrade.
+// Without --sam_out the records go to <out_prefix>.bam in genome coordinates (fq_bam_*: SetSamRecord / SetSamFileHeader); the QC
+// files of StatCollector (<out_prefix>.InsertSizeTable .Pileup .DepthDist ... .Summary) are written in both modes (fq_qc_*) when the
+// index carries its .SelectedSite.vcf / .dbSNP.subset.vcf / .gc.  Flank lengths and the original reference (for @SQ and the genome
+// size) come from <index_prefix>.FASTQuick.fa.param as `FASTQuick index` wrote it (src/FASTQuick.cpp:376-465).
+#include <sys/stat.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -117,11 +120,15 @@ struct ReadSlots {
 
 void fill_chunk(FastqReader &r, ReadSlots &slots, EndChunk &c, long long cap, int stride, int name_stride) {
   c.n = 0; c.stride = stride; c.name_stride = name_stride; c.error.clear();
-  c.seq.assign((size_t)cap * stride, 0); c.qual.assign((size_t)cap * stride, 0);
-  c.len.assign((size_t)cap, 0); c.names.assign((size_t)cap * name_stride, 0);
+  // (rows are cleared as records arrive: a chunk of the default size is 2.7 GB of rows, a small input touches a few of them)
+  if (c.seq.size() < (size_t)cap * stride) { c.seq.resize((size_t)cap * stride); c.qual.resize((size_t)cap * stride); }
+  if (c.len.size() < (size_t)cap) c.len.resize((size_t)cap);
+  if (c.names.size() < (size_t)cap * name_stride) c.names.resize((size_t)cap * name_stride);
   std::string nm, sq, ql;
   while (c.n < cap) {
     if (!r.next(nm, sq, ql)) { c.eof = true; break; }
+    memset(&c.seq[(size_t)c.n * stride], 0, (size_t)stride); memset(&c.qual[(size_t)c.n * stride], 0, (size_t)stride);
+    memset(&c.names[(size_t)c.n * name_stride], 0, (size_t)name_stride);
     if (nm.size() > 301) nm.resize(301);   // the reference's buffer holds 2 * read_len = 302 bytes
     if ((int)sq.size() > stride) { c.error = "read " + nm + " is longer than the batch rows (" + std::to_string(sq.size()) + " > " + std::to_string(stride) + "): pass --read_len"; return; }
     if ((int)nm.size() >= name_stride) nm.resize((size_t)name_stride - 1);
@@ -142,12 +149,13 @@ struct Args {
   long long chunk_pairs = 16LL * 262144;
   int device = 0;
   bool clean_names = false;
-  std::string fq_list;
+  std::string fq_list, rg = "@RG\\tID:foo\\tSM:bar";   // runAlign's default --RG (src/FASTQuick.cpp:170)
+  bool cal_dup = true;
   int read_len = 151;   // gap_opt_t::read_len (libbwa/bwtaln.c:48): the reference sizes its read buffers from it and has no flag for it
 };
 
 int usage() {
-  fprintf(stderr, "Usage: FASTQuick_amd align --index_prefix P --fastq_1 R1.fq[.gz] --fastq_2 R2.fq[.gz] | --fq_list LIST  --out_prefix O --sam_out\n"
+  fprintf(stderr, "Usage: FASTQuick_amd align --index_prefix P --fastq_1 R1.fq[.gz] --fastq_2 R2.fq[.gz] | --fq_list LIST  --out_prefix O [--sam_out] [--RG STR] [--cal_dup]\n"
                   "                       [--q INT] [--n FLOAT|INT] [--kmer_thresh INT] [--o INT] [--e INT] [--i INT] [--d INT] [--l INT] [--k INT]\n"
                   "                       [--m INT] [--R INT] [--N] [--L] [--I] [--max_isize INT] [--max_occ INT] [--is_sw] [--n_multi INT] [--N_multi INT]\n"
                   "                       [--ap_prior FLOAT] [--force_isize] [--t INT] [--chunk_pairs INT] [--batch_pairs INT] [--device INT] [--read_len INT] [--clean_names]\n"
@@ -211,7 +219,9 @@ int main(int argc, char **argv) {
     else if (f == "--batch_pairs") A.o.batch_pairs = atoi(need(""));   // READ_BUFFER_SIZE of the run to reproduce (default 262144)
     else if (f == "--device") A.device = atoi(need(""));
     else if (f == "--fq_list") A.fq_list = need("");
-    else if (f == "--RG" || f == "--frac_samp" || f == "--bam_in" || f == "--cal_dup") die(f + " is not supported by this build");
+    else if (f == "--RG") A.rg = need("");
+    else if (f == "--cal_dup") A.cal_dup = !A.cal_dup;        // (a bool flag on a default-1 field, like --is_sw)
+    else if (f == "--frac_samp" || f == "--bam_in") die(f + " is not supported by this build");
     else die("unknown option " + f);
   }
   if (A.o.fnr >= 1.0) { A.o.max_diff = (int)A.o.fnr; A.o.fnr = -1.0; }                  // src/FASTQuick.cpp:312-315
@@ -238,7 +248,6 @@ int main(int argc, char **argv) {
     if (A.fq1.empty() || A.fq2.empty()) die("--fastq_1 and --fastq_2 (or --fq_list) are required (paired-end path)");
     inputs.emplace_back(A.fq1, A.fq2);
   }
-  if (!A.sam_out) die("BAM output (genome-coordinate translation + BGZF; SURVEY 8f.2) is not built yet: pass --sam_out");
   if (A.o.batch_pairs < 1) die("--batch_pairs must be positive");
   A.chunk_pairs = std::max<long long>(A.o.batch_pairs, A.chunk_pairs / A.o.batch_pairs * A.o.batch_pairs);   // whole reference batches per chunk
 
@@ -246,17 +255,49 @@ int main(int argc, char **argv) {
   const std::string pre = A.index_prefix + ".FASTQuick.fa";
   int rc = fq_index_load(pre.c_str(), A.device, &ix);
   if (rc) die("cannot load index " + pre + " onto HIP device " + std::to_string(A.device) + " (" + std::to_string(rc) + "); there is no CPU fallback");
+  // <index>.param: REFERENCE_PATH, TARGET_REGION_PATH, DBSNP_VCF_PATH, NUM_VAR_LONG, NUM_VAR_SHORT, SHORT_FLANK_LENGTH, LONG_FLANK_LENGTH
+  fq_qc_opts_t qo;
+  fq_qc_default_opts(&qo);
+  qo.read_len = A.read_len; qo.cal_dup = A.cal_dup ? 1 : 0;
+  std::string ref_path;
   {
+    FILE *fp = fopen((pre + ".param").c_str(), "r");
+    char key[256], val[4096];
+    while (fp && fscanf(fp, "%255s %4095s", key, val) == 2) {
+      if (!strcmp(key, "REFERENCE_PATH")) ref_path = val;
+      else if (!strcmp(key, "SHORT_FLANK_LENGTH")) qo.flank_len = atoi(val);
+      else if (!strcmp(key, "LONG_FLANK_LENGTH")) qo.flank_long_len = atoi(val);
+    }
+    if (fp) fclose(fp);
+    if (!ref_path.empty()) {   // BwtIndexer::LoadContigSize (src/BwtIndexer.cpp:764-802): sums of column 2 of the .fai and of EVERY line of the .amb
+      char line[8192], a[4096], b[4096];
+      if (FILE *ff = fopen((ref_path + ".fai").c_str(), "r")) { while (fgets(line, sizeof line, ff)) if (sscanf(line, "%4095s %4095s", a, b) == 2) qo.genome_size += atoi(b); fclose(ff); }
+      if (FILE *fa = fopen((ref_path + ".amb").c_str(), "r")) { while (fgets(line, sizeof line, fa)) if (sscanf(line, "%4095s %4095s", a, b) == 2) qo.genome_n_size += atoi(b); fclose(fa); }
+    }
+  }
+  struct stat sb;
+  fq_qc_t *qc = nullptr;
+  if (stat((pre + ".SelectedSite.vcf").c_str(), &sb) == 0) {
+    rc = fq_qc_create(ix, pre.c_str(), A.out_prefix.c_str(), &qo, &qc);
+    if (rc) die("cannot set up the QC consumer from " + pre + ".SelectedSite.vcf / .dbSNP.subset.vcf / .gc (" + std::to_string(rc) + ")");
+  } else fprintf(stderr, "NOTICE - %s.SelectedSite.vcf not found: the QC files are not written\n", pre.c_str());
+  fq_bam_t *bam = nullptr;
+  if (A.sam_out) {
     const int64_t n = fq_sam_header(ix, nullptr, 0);
     std::vector<char> h((size_t)n + 1);
     fq_sam_header(ix, h.data(), n + 1);
     fwrite(h.data(), 1, (size_t)n, stdout);
+  } else {
+    if (ref_path.empty()) die("BAM output needs the original reference's .fai: " + pre + ".param (REFERENCE_PATH) is missing; or pass --sam_out");
+    rc = fq_bam_create(ix, (ref_path + ".fai").c_str(), (A.out_prefix + ".bam").c_str(), A.rg.c_str(), &qo, &bam);
+    if (rc) die("cannot open " + A.out_prefix + ".bam / " + ref_path + ".fai (" + std::to_string(rc) + ")");
   }
   // FASTQ front end: one reader thread per file tokenises the next chunk into flat buffers while the device aligns the current
   // one (the reference, too, decodes the two files on two IO threads: BwtMapper.cpp:1873-1935).
   for (const auto &input : inputs) {
   A.fq1 = input.first; A.fq2 = input.second;
   fprintf(stderr, "NOTICE - Processing Pair End mapping\t%s\t%s\n", A.fq1.c_str(), A.fq2.c_str());
+  if (qc) fq_qc_begin_file(qc, A.fq1.c_str(), A.fq2.c_str());
   fq_ctx_t *ctx = nullptr;
   rc = fq_ctx_create(ix, &A.o, (int32_t)A.chunk_pairs, &ctx);
   if (rc) die("fq_ctx_create failed (" + std::to_string(rc) + "): option outside the supported range");
@@ -264,13 +305,17 @@ int main(int argc, char **argv) {
   ReadSlots slots[2];
   for (ReadSlots &s : slots) { s.batch_pairs = A.o.batch_pairs; s.clean = A.clean_names; }
   int stride = 0;
-  {   // row stride from the first record of each file
+  {   // rows hold read_len bases, or the first records' if those are longer -- probed only in regular files (a pipe cannot be read twice:
+      // there a longer read is an error that asks for --read_len)
     std::string nm, sq, ql;
-    FastqReader p1(A.fq1), p2(A.fq2);
     size_t l = 0;
-    if (p1.next(nm, sq, ql)) l = std::max(l, sq.size());
-    if (p2.next(nm, sq, ql)) l = std::max(l, sq.size());
-    stride = (int)((std::max<size_t>(l, (size_t)std::max(A.read_len, 16)) + 15) & ~(size_t)15);   // rows hold read_len bases, or the first records if longer
+    struct stat s1, s2;
+    if (stat(A.fq1.c_str(), &s1) == 0 && S_ISREG(s1.st_mode) && stat(A.fq2.c_str(), &s2) == 0 && S_ISREG(s2.st_mode)) {
+      FastqReader p1(A.fq1), p2(A.fq2);
+      if (p1.next(nm, sq, ql)) l = std::max(l, sq.size());
+      if (p2.next(nm, sq, ql)) l = std::max(l, sq.size());
+    }
+    stride = (int)((std::max<size_t>(l, (size_t)std::max(A.read_len, 16)) + 15) & ~(size_t)15);
   }
   const int name_stride = 304;   // the reference's name buffers hold 302 bytes (bwaseqio.c:233)
   long long num_read = 0, filtered = 0, unmapped = 0, num_base = 0, order_checked_reads = 0;
@@ -297,7 +342,7 @@ int main(int argc, char **argv) {
     for (int i = 0; i < n; i += A.o.batch_pairs) {
       order_checked_reads += 2LL * std::min<long long>(A.o.batch_pairs, n - i);
       if (order_checked_reads % A.o.batch_pairs == 0 &&
-          strncmp(&e0.names[(size_t)i * name_stride], &e1.names[(size_t)i * name_stride], 151) != 0)
+          strncmp(&e0.names[(size_t)i * name_stride], &e1.names[(size_t)i * name_stride], (size_t)A.read_len) != 0)
         die("Abort, please make sure input pair of fastq files are in the same order!");
     }
     // the two ends back to back: [end][pair][stride]
@@ -313,10 +358,14 @@ int main(int argc, char **argv) {
     fq_result_batch_t res;
     rc = fq_align_batch(ctx, &in, &res);
     if (rc) die(std::string("fq_align_batch failed: ") + fq_ctx_last_error(ctx));
-    const int64_t sz = fq_sam_format_last(ctx, nullptr, 0);
-    sam.resize((size_t)sz + 1);
-    fq_sam_format_last(ctx, sam.data(), sz + 1);
-    fwrite(sam.data(), 1, (size_t)sz, stdout);
+    // the consumers, in the reference's order: StatCollector, then the record writer (src/BwtMapper.cpp:2047-2050, 2075-2085)
+    if (qc && (rc = fq_qc_add_last(qc, ctx))) die(std::string("QC consumer failed: ") + fq_qc_last_error(qc));
+    if (A.sam_out) {
+      const int64_t sz = fq_sam_format_last(ctx, nullptr, 0);
+      sam.resize((size_t)sz + 1);
+      fq_sam_format_last(ctx, sam.data(), sz + 1);
+      fwrite(sam.data(), 1, (size_t)sz, stdout);
+    } else if ((rc = fq_bam_add_last(bam, ctx))) die("writing " + A.out_prefix + ".bam failed");
     num_read += 2LL * n; filtered += res.n_both_filtered; unmapped += res.n_both_unmapped; num_base += res.n_bases;
     fprintf(stderr, "NOTICE - %lld sequences are processed.\n", num_read);
     if (prefetch.joinable()) prefetch.join();
@@ -330,7 +379,13 @@ int main(int argc, char **argv) {
   fq_stats_get(ctx, &st);
   fprintf(stderr, "NOTICE - device time (ms): prep %.1f width %.1f gap %.1f sa %.1f sw %.1f refine %.1f ; host %.1f ; wall %.1f\n", st.kernel_ms[0],
           st.kernel_ms[1], st.kernel_ms[2], st.kernel_ms[3], st.kernel_ms[4], st.kernel_ms[5], st.host_ms_total, st.wall_ms_total);
+  if (qc) fq_qc_end_file(qc);
   fq_ctx_destroy(ctx);
+  }
+  if (bam && fq_bam_close(bam)) die("closing " + A.out_prefix + ".bam failed");
+  if (qc) {
+    if (fq_qc_write(qc)) die("writing the QC files failed");
+    fq_qc_destroy(qc);
   }
   fq_index_destroy(ix);
   return 0;

@@ -1,0 +1,42 @@
+"""`FASTQuick align` without --sam_out, as the pipeline script calls it: records to <out>.bam in genome coordinates and the QC
+files of StatCollector next to it, from the C++ front end (fq_cli.cpp) through the C ABI.  Checked against the REAL reference's
+SamRecords and QC files of the golden case `qc` (CPU tier: the front end linked against the host-loop library)."""
+import os
+import subprocess
+
+import golden_util  # noqa: F401  (fixtures)
+from test_bam_writer import check_bgzf, decode_bam
+from test_qc_consumer import QC_FILES
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def cli_bam_and_qc(exe, g, out):
+    prefix = g["prefix"][:-len(".FASTQuick.fa")]
+    genome = os.path.join(g["dir"], "genome")               # <REFERENCE_PATH>.fai is the golden's genome.fai
+    with open(g["prefix"] + ".param", "w") as fh:           # the 7 lines `FASTQuick index` writes (src/FASTQuick.cpp:145-151)
+        fh.write("REFERENCE_PATH\t%s\nTARGET_REGION_PATH\tEmpty\nDBSNP_VCF_PATH\tEmpty\nNUM_VAR_LONG\t4\nNUM_VAR_SHORT\t36\n"
+                 "SHORT_FLANK_LENGTH\t250\nLONG_FLANK_LENGTH\t1000\n" % genome)
+    cmd = [exe, "align", "--index_prefix", prefix, "--fastq_1", g["fq1"], "--fastq_2", g["fq2"], "--out_prefix", out,
+           "--batch_pairs", str(g["batch"]), "--chunk_pairs", str(2 * g["batch"])]
+    if g["trim_qual"]:
+        cmd += ["--q", str(g["trim_qual"])]
+    run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert run.returncode == 0, run.stderr.decode(errors="replace")[-2000:]
+    assert run.stdout == b"", "no SAM text on stdout in BAM mode"
+    check_bgzf(out + ".bam")
+    text, _refs, recs = decode_bam(out + ".bam")
+    assert text == open(os.path.join(g["dir"], "ref.bamhdr")).read()
+    want = [(lambda f: f[:11] + sorted(f[11:]))(l.rstrip("\n").split("\t")) for l in open(os.path.join(g["dir"], "ref.bamtxt"))]
+    assert recs == want
+    for f in QC_FILES:
+        if f in ("Summary", "FASTQ.csv"):    # (genome size: the three contigs of the .fai here, one genome in the golden run; file names)
+            continue
+        assert open(out + "." + f, "rb").read() == open(os.path.join(g["dir"], "ref.qc." + f), "rb").read(), f
+    assert os.path.getsize(out + ".Summary") > 100
+
+
+def test_cli_writes_bam_and_qc_files(golden_cases, tmp_path):
+    emu = os.path.join(HERE, "emu")
+    subprocess.check_call(["make", "-s", "-C", emu, "libfq_emu.so", "FASTQuick_emu"])
+    cli_bam_and_qc(os.path.join(emu, "FASTQuick_emu"), golden_cases["qc"], str(tmp_path / "cli_qc"))

@@ -157,9 +157,9 @@ def test_cli_sam_out_matches_reference_golden(golden_cases, tmp_path):
         if tag == "example151":   # with full batches the reference's mate-name check fires on the first pair (TestRead_1 / TestRead_2)
             run = subprocess.run(cmd[:-4] + ["--batch_pairs", "128", "--chunk_pairs", "128"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             assert run.returncode != 0 and b"same order" in run.stderr
-    # asking for the unbuilt BAM path is a loud error
-    r = subprocess.run([exe, "align", "--index_prefix", "x", "--fastq_1", "a", "--fastq_2", "b", "--out_prefix", "o"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
-    assert r.returncode != 0 and b"not built" in r.stderr
+    # without --sam_out: <out>.bam in genome coordinates and StatCollector's QC files, against the reference's
+    from test_cli_consumers import cli_bam_and_qc
+    cli_bam_and_qc(exe, golden_cases["qc"], str(tmp_path / "cli_qc"))
 
 
 # Non-default options, each against the oracle run with the same options (the oracle itself is pinned against the reference with
