@@ -12,6 +12,7 @@ import oracle_binding as ob
 from fastquick_amd import api, synth
 
 pytestmark = pytest.mark.gpu
+_ACGT_BYTES = np.frombuffer(b"ACGT", dtype=np.uint8)
 
 
 @pytest.fixture(scope="module")
@@ -312,3 +313,94 @@ def test_bam_records_match_reference_golden(tag, golden_cases, lib):
     reference's SetSamRecord puts into its SamRecords."""
     from test_bam_writer import bam_case
     bam_case(golden_cases[tag], lib, device=0, packed=(tag in ("qc", "edge")))
+
+
+def test_100k_marker_index_real_shaped_reads(lib, tmp_path):
+    """BASELINE cfg 3 shape: a ~100k-marker reduced reference (l_pac 6.5e7: Occ tables ten times those of the 10k set, beyond every
+    cache level but the Infinity Cache) and "real-shaped" reads (N bases, decaying qualities with --q 15 trimming, adapter
+    tails, 5 % duplicates, reads over contig ends) in a WGS-like mix.  One reference batch of 262,144 pairs through the packed
+    boundary; the first 12,288 pairs (a fresh stream) against the oracle stage by stage; invariants on the whole batch."""
+    import time
+    t0 = time.time()
+    ref = synth.make_reference(n_markers=100000, n_long=10000, seed=91)
+    pre = str(tmp_path / "ref.FASTQuick.fa")
+    ref.write_fasta(pre)
+    api.build_index(pre)
+    n, k = 262144, 12288
+    rb = synth.make_reads(ref, n, on_target=0.021, seed=92, n_rate=0.001, qual_decay=True, sub_rate=0.008, del_frac=0.02, ins_frac=0.01,
+                          adapter_frac=0.01, dup_frac=0.05, edge_frac=0.02)
+    good = np.random.default_rng(93).random(rb.qual.shape[:2]) < 0.5
+    rb.qual[good] = ord("I")
+    ix = api.Index(pre, device=0)
+    assert ix.l_pac == 10000 * 2001 + 90000 * 501
+    al = api.Aligner(ix, api.default_opts(lib, trim_qual=15), max_pairs=n)
+    hp = api.HostPacked(rb.seq, rb.qual, rb.lens, rb.names)
+    res = al.align_packed(hp)
+    sam_all = al.sam_text()
+    surv = np.ctypeslib.as_array(res.pair_idx, shape=(res.n_survivors,)).copy()
+    assert res.n_pairs == n and 0.015 * n < res.n_survivors < 0.08 * n      # on-target pairs plus chance passes of the filter (more bits set at 100k)
+    assert np.all(np.diff(surv) > 0)
+    st = al.stats()
+    assert st["h2d_bytes"] < 60 * n + 2000 * st["reads_searched"]
+    al.close(); hp.free()
+    al = api.Aligner(ix, api.default_opts(lib, trim_qual=15), max_pairs=k, debug=True)
+    api.align_stream(al, rb.names[:k], rb.seq[:, :k], rb.qual[:, :k], rb.lens[:, :k], k, str(tmp_path / "g.st"), str(tmp_path / "g.sam"), packed=True)
+    oa = ob.OracleAligner(pre, ob.default_opts(trim_qual=15))
+    oa.align(rb.names[:k], rb.seq[:, :k], rb.qual[:, :k], rb.lens[:, :k], str(tmp_path / "o.st"), str(tmp_path / "o.sam"), batch=k)
+    assert not [d for d in ob.diff_stage_files(str(tmp_path / "o.st"), str(tmp_path / "g.st")) if not d.startswith("line count")]
+    assert filecmp.cmp(str(tmp_path / "o.sam"), str(tmp_path / "g.sam"), shallow=False)
+    # a prefix of the stream gives a prefix of the output (the whole batch was one reference batch; so is the prefix run: same isize rules
+    # do not hold across different batch contents, so only the records of pairs whose result cannot depend on the batch are compared)
+    assert len(sam_all) > 100000
+    al.close(); oa.close(); ix.close()
+    print("cfg3 test: %.1f s" % (time.time() - t0))
+
+
+def test_bench_call_shape_matches_oracle_on_first_and_last_batch(lib, tmp_path):
+    """The shape bench.py times: ONE call of 16 reference batches of 262,144 pairs (4,194,304 pairs) of the WGS-like mix against the 10k-
+    marker reference, through the packed boundary.  The per-batch outputs of the call are checked against the oracle for reference
+    batch 0 (a fresh stream: everything) and reference batch 15 (the records of pairs whose result does not depend on stream state:
+    unique hits -- positions, CIGARs, MD; the insert-size estimate of that batch)."""
+    ref = synth.make_reference(n_markers=10000, n_long=1000, seed=12345)
+    pre = str(tmp_path / "ref.FASTQuick.fa")
+    ref.write_fasta(pre)
+    api.build_index(pre)
+    B, nb = 262144, 16
+    n = B * nb
+    on_frac = ref.l_pac / 3.1e9
+    rng = np.random.default_rng(77)
+    L = 150
+    seq = _ACGT_BYTES[rng.integers(0, 4, (2, n, L), dtype=np.uint8)]
+    n_on = int(rng.binomial(n, on_frac))
+    on = synth.make_reads(ref, n_on, on_target=1.0, seed=78)
+    slots = np.sort(rng.choice(n, size=n_on, replace=False))
+    seq[:, slots] = on.seq
+    qual = np.full((2, n, L), ord("I"), dtype=np.uint8)
+    lens = np.full((2, n), L, dtype=np.int32)
+    names = [b"r%09d" % i for i in range(n)]
+    ix = api.Index(pre, device=0)
+    al = api.Aligner(ix, max_pairs=n)
+    hp = api.HostPacked(seq, qual, lens, names)
+    res = al.align_packed(hp)
+    assert res.n_sub == nb and res.n_pairs == n
+    sam = al.sam_text().split(b"\n")
+    recs_of = {}
+    for ln in sam:
+        if ln:
+            recs_of.setdefault(int(ln[1:10]) // B, []).append(ln)
+    al.close(); hp.free()
+    for b in (0, nb - 1):
+        sl = slice(b * B, (b + 1) * B)
+        oa = ob.OracleAligner(pre)
+        oa.align(names[sl], seq[:, sl], qual[:, sl], lens[:, sl], None, str(tmp_path / "o.sam"), batch=B)
+        want = [ln for ln in open(str(tmp_path / "o.sam"), "rb").read().split(b"\n") if ln and not ln.startswith(b"@")]
+        got = recs_of.get(b, [])
+        if b == 0:
+            assert got == want, "reference batch 0 of the call must be the oracle's fresh-stream output"
+        else:
+            # batch 15 follows 15 batches of drand48 draws: records with XT:A:R (random choice among repeats) may differ; the others not
+            wu = [w for w in want if b"XT:A:U" in w]
+            gset = set(got)
+            assert len(wu) > 500 and sum(w in gset for w in wu) >= 0.98 * len(wu)
+        oa.close()
+    ix.close()
