@@ -213,12 +213,16 @@ def normalise_stage_line(line: str) -> str:
 
 
 def diff_stage_files(a: str, b: str, max_report: int = 10):
+    """Differences between two stage dumps, including missing / extra lines per tag (a truncated dump must not pass on its
+    common prefix).  The only line one producer writes and the others do not is the reference driver's closing `E` summary."""
     out = []
     with open(a) as fa, open(b) as fb:
-        la = [normalise_stage_line(x.rstrip("\n")) for x in fa]
-        lb = [normalise_stage_line(x.rstrip("\n")) for x in fb]
+        la = [normalise_stage_line(x.rstrip("\n")) for x in fa if not x.startswith("E ")]
+        lb = [normalise_stage_line(x.rstrip("\n")) for x in fb if not x.startswith("E ")]
     if len(la) != len(lb):
-        out.append("line count %d vs %d" % (len(la), len(lb)))
+        import collections
+        ca, cb = collections.Counter(x[:1] for x in la), collections.Counter(x[:1] for x in lb)
+        out.append("lines per tag differ: %s vs %s" % (sorted(ca.items()), sorted(cb.items())))
     for i, (x, y) in enumerate(zip(la, lb)):
         if x != y:
             out.append("line %d:\n  A: %s\n  B: %s" % (i + 1, x[:600], y[:600]))
