@@ -58,6 +58,9 @@ void fqo_ctx_free(fqo_ctx *c);
 int fqo_align_batch(fqo_ctx *c, int n, const char *names, const char *names_mate, int name_stride, const uint8_t *seq, const uint8_t *qual,
                     const int32_t *lens, int stride, FILE *stages, FILE *sam);
 void fqo_print_sam_header(const fqo_index *ix, FILE *sam);
+/* --t of the reference: stage A (cal_width + match_gap) of every following batch runs on n_threads workers sliced as
+ * src/BwtMapper.cpp:1490-1513 does (rounded up to even; half per end); <=1 = serial.  Results do not depend on it. */
+void fqo_ctx_set_threads(fqo_ctx *c, int n_threads);
 
 /* counters for the algorithmic-byte model: accumulated over the ctx lifetime */
 typedef struct {

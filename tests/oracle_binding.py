@@ -152,6 +152,12 @@ class OracleAligner:
         self.opts = opts or default_opts()
         self.ctx = self.L.fqo_ctx_create(self.ix, C.byref(self.opts))
 
+    def set_threads(self, n_threads: int) -> None:
+        """--t of the reference: stage A on n_threads workers sliced as src/BwtMapper.cpp:1490-1513 (results unchanged)."""
+        self.L.fqo_ctx_set_threads.argtypes = [C.c_void_p, C.c_int]
+        self.L.fqo_ctx_set_threads.restype = None
+        self.L.fqo_ctx_set_threads(self.ctx, int(n_threads))
+
     def close(self):
         if self.ctx:
             self.L.fqo_ctx_free(self.ctx)

@@ -16,17 +16,20 @@ import json
 import os
 import sys
 
-KMAP = {"k_prep": "fq_prep", "k_gap_lds": "fq_gap", "k_gap": "fq_gap", "k_gap_persist": "fq_gap", "k_gap_persist_lds": "fq_gap", "k_gap_coop": "fq_gap_wave", "k_width": "fq_width", "k_sa": "fq_sa",
+KMAP = {"k_prep": "fq_prep", "k_prep_packed": "fq_prep", "k_gap_nogap_lds": "fq_gap", "k_gap_lds": "fq_gap", "k_gap": "fq_gap", "k_gap_persist": "fq_gap", "k_gap_persist_lds": "fq_gap", "k_gap_coop": "fq_gap_wave", "k_width": "fq_width", "k_sa": "fq_sa",
         "k_sw_wave": "fq_sw", "k_refine_lds": "fq_refine"}
 
 
 def mean_kb(d):
+    """KB per launch of each kernel GROUP (KMAP): the sum over the group's launches / their number -- the same "per launch"
+    as bench.py's, which counts the gap-free first round and the full round of the search as launches of one stage."""
     f = (glob.glob(os.path.join(d, "*_counter_collection.csv")) + glob.glob(os.path.join(d, "*", "*_counter_collection.csv")))[0]
     agg = collections.defaultdict(list)
     for row in csv.DictReader(open(f)):
         name = row["Kernel_Name"].split("(")[0].split("::")[-1]
-        agg[name].append(float(row["Counter_Value"]))
-    return {k: sum(v) / len(v) for k, v in agg.items()}
+        if name in KMAP:
+            agg[KMAP[name]].append(float(row["Counter_Value"]))
+    return {k: (sum(v), len(v)) for k, v in agg.items()}
 
 
 def main():
@@ -38,11 +41,15 @@ def main():
     fe, wr = mean_kb(dfetch), mean_kb(dwrite)
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     out = json.load(open(path)) if os.path.exists(path) else {}
-    for k, name in KMAP.items():
-        if k in fe:
-            b = (fe[k] + wr.get(k, 0.0)) * 1024.0
-            out.setdefault(mix, {})[name] = {"bytes_per_launch": b, "units_per_launch": units[name], "bytes_per_unit": b / units[name],
-                                             "fetch_KB": fe[k], "write_KB": wr.get(k, 0.0), "correction": "uncorrected (see tools/pmc_summarize.py)"}
+    n_calls = fe["fq_prep"][1]          # one filter launch per call: units below are per call, so is the byte total
+    for name in sorted(set(KMAP.values())):
+        if name in fe:
+            per_call = (fe[name][0] + wr.get(name, (0.0, 0))[0]) * 1024.0 / n_calls
+            nl = fe[name][1] / n_calls
+            out.setdefault(mix, {})[name] = {"bytes_per_launch": per_call / nl, "launches_per_call": nl, "units_per_launch": units[name] / nl,
+                                             "bytes_per_unit": per_call / units[name], "fetch_KB": fe[name][0] / fe[name][1],
+                                             "write_KB": wr.get(name, (0.0, 1))[0] / max(1, wr.get(name, (0.0, 1))[1]),
+                                             "correction": "uncorrected (see tools/pmc_summarize.py)"}
     json.dump(out, open(path, "w"), indent=1, sort_keys=True)
     print(json.dumps(out.get(mix, {}), indent=1))
 
