@@ -119,6 +119,7 @@ struct PinArena {
 struct FqKnobs {   // experiment / test knobs (fq_ctx_set_tuning); defaults are what DESIGN.md measures
   uint32_t gap_long_pops = 1024;   // lane kernel hands a search to the wavefront-per-read kernel after this many pops (queue dry)
   int gap_long_always = 0;         // ... whatever the state of the queue (tests)
+  int64_t gap_split_hard = 0;      // experiment: after the round without gap children, search reads whose lower bound is >= this in a launch of their own (0: off)
   int64_t gap_nogap_min = 131072;  // launches of at least this many reads begin with the round that searches without gap children (-1: never)
   uint32_t gap_pool = 2048;        // stack entries per lane of the lane kernel
   int gap_no_order = 0;
@@ -284,6 +285,7 @@ extern "C" int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t v) {
   else if (k == "gap_long_always") c->kn.gap_long_always = (int)v;
   else if (k == "gap_pool") c->kn.gap_pool = (uint32_t)v;
   else if (k == "gap_nogap_min") c->kn.gap_nogap_min = v;
+  else if (k == "gap_split_hard") c->kn.gap_split_hard = v;
   else if (k == "gap_no_order") c->kn.gap_no_order = (int)v;
   else if (k == "sw_wave_max") c->kn.sw_wave_max = (int)v;
   else if (k == "host_threads") c->kn.host_threads = (int)v;
@@ -884,15 +886,25 @@ int stageA_search(Call &K) {
   vector<int32_t> work(n_search), next_work;
   for (int s = 0; s < n_search; ++s) work[s] = s;
   vector<int64_t> where(n_search, -1);   // offset of s's list in h_aln (filled as results arrive)
+  vector<uint8_t> bound_of;               // experiment: min over strands of k_width's lower bound, per read
   for (size_t tier = 0; tier < tiers.size() && !work.empty(); ++tier) {
     FqGapTier T = tiers[tier];
     if (T.nogap && (int64_t)work.size() < c->kn.gap_nogap_min) continue;   // a small launch is bound by its longest search: one round
     // Handing long searches to the wavefront-per-read kernel pays when the launch is latency-bound (few reads: its duration is
     // its longest search); a launch that fills the device several times over hides its long searches behind the others.
-    if (!T.coop && !T.long_always && n_search > 524288) T.long_pops = 0;   // (two reads per resident lane; also what the first round of such a launch leaves)
+    // The second round of such a call is a small launch, but of hard reads only: handing them over at 1,024 pops sends tens of
+    // thousands of them to the wavefront kernel (12 + 30 ms instead of 19.5 ms for the 114 k reads an on-target call of 2.1 M leaves),
+    // at 2,048 / 3,072 / 4,096 pops 15 + 14 / 17 + 12 / 20 + 9 ms: the rule stays with the size of the call.
+    if (!T.coop && !T.long_always && n_search > 524288) T.long_pops = 0;
     next_work.clear();
-    for (size_t c0 = 0; c0 < work.size(); c0 += chunk_reads[tier]) {
-      const int nw = (int)std::min(chunk_reads[tier], work.size() - c0);
+    size_t first_chunk = 0;   // experiment (gap_split_hard): the predicted-hard reads lead the work list and get a launch of their own
+    if (!T.nogap && !T.coop && c->kn.gap_split_hard > 0 && !bound_of.empty()) {
+      std::stable_partition(work.begin(), work.end(), [&](int32_t sidx) { return (int64_t)bound_of[sidx] >= c->kn.gap_split_hard; });
+      while (first_chunk < work.size() && (int64_t)bound_of[work[first_chunk]] >= c->kn.gap_split_hard) ++first_chunk;
+    }
+    for (size_t c0 = 0, step_c = 0; c0 < work.size(); c0 += step_c) {
+      step_c = c0 == 0 && first_chunk > 0 ? first_chunk : chunk_reads[tier];
+      const int nw = (int)std::min(step_c, work.size() - c0);
       CKM(c->d_work.ensure(nw) && c->d_wfull.ensure((size_t)nw * 2 * Lpad) && c->d_prec.ensure((size_t)nw * 2 * Ppad) && c->d_winfo.ensure(nw) && c->d_bid_end.ensure((size_t)nw * 2) && c->d_order.ensure(nw) && c->d_order_cnt.ensure(2 * FQ_ORDER_KEYS + 2) &&
           c->d_aln.ensure((size_t)nw * T.aln_cap) && c->d_naln.ensure(nw) && c->d_status.ensure(nw) && c->d_off.ensure(nw + 1));
       CKM(c->p_i32.ensure(nw));
@@ -932,7 +944,13 @@ int stageA_search(Call &K) {
       CK(fqdev::copy_pinned(h_status, c->d_status.p, (size_t)nw * 4, 0));
       CK(fqdev::copy_pinned(h_naln, c->d_naln.p, (size_t)nw * 4, 0));
       CKS(d2h_staged(c, &total, c->d_off.p + nw, 8));
+      vector<uint8_t> h_bid;
+      if (T.nogap && c->kn.gap_split_hard > 0) { h_bid.resize((size_t)nw * 2); CKS(d2h_staged(c, h_bid.data(), c->d_bid_end.p, (size_t)nw * 2)); }
       CKS(sync_staged(c));
+      if (!h_bid.empty()) {
+        bound_of.assign(n_search, 0);
+        for (int w = 0; w < nw; ++w) bound_of[work[c0 + w]] = std::min(h_bid[2 * w], h_bid[2 * w + 1]);
+      }
       CKM(c->d_packed.ensure(total + 1) && c->p_aln.ensure(total + 1));
       CK(fqdev::launch_pack_aln(c->d_aln.p, c->d_naln.p, c->d_off.p, T.aln_cap, (uint32_t)nw, c->d_packed.p));
       FqAln *h_packed = c->p_aln.p;

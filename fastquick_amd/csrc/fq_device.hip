@@ -208,6 +208,12 @@ struct FqQueueFetch {
 // The lane kernels' queue is two blocks (fq_order_key): a wavefront draws from the block of its XCD's half first -- workgroups are
 // dealt round-robin over the 8 XCDs, so blockIdx % 8 tells which workgroups share an XCD (MI355X_MICROARCH.md, workgroup
 // dispatch) -- and from the other block when its own is exhausted.
+// -DFQ_GAP_WPE=n: ask for n wavefronts per SIMD in the lane search kernels (register budget 512 / n)
+#if defined(FQ_GAP_WPE)
+#define FQ_GAP_OCC __attribute__((amdgpu_waves_per_eu(FQ_GAP_WPE, FQ_GAP_WPE)))
+#else
+#define FQ_GAP_OCC
+#endif
 struct FqQueueFetch2 {
   uint32_t *cursor;
   const uint32_t *split;
@@ -229,13 +235,13 @@ struct FqQueueFetch2 {
 #define FQ_LANE_FETCH(a) FqQueueFetch2{(a).queue, (a).split, (uint32_t)(a).n_work, (int)((blockIdx.x & 7u) >> 2)}
 // persistent wavefronts: every lane pulls reads from the queue until it is empty.  One wavefront per block.
 // LDS per lane: n_buckets 16-bit bucket heads, lane-interleaved.
-__global__ void __launch_bounds__(64) k_gap_persist_lds(FqGapArgs a) {
+__global__ void __launch_bounds__(64) FQ_GAP_OCC k_gap_persist_lds(FqGapArgs a) {
   uint16_t *heads = (uint16_t *)fq_dyn_lds;
   FqGapStoreLds st = {heads + threadIdx.x, 64};
   fq_gap_lanes<false>(a, st, FQ_LANE_FETCH(a), (int)(blockIdx.x * 64 + threadIdx.x));
 }
 // first round of a device-filling launch: the search without its gap children (FqGapLane, NOGAP)
-__global__ void __launch_bounds__(64) k_gap_nogap_lds(FqGapArgs a) {
+__global__ void __launch_bounds__(64) FQ_GAP_OCC k_gap_nogap_lds(FqGapArgs a) {
   uint16_t *heads = (uint16_t *)fq_dyn_lds;
   FqGapStoreLds st = {heads + threadIdx.x, 64};
   fq_gap_lanes<true>(a, st, FQ_LANE_FETCH(a), (int)(blockIdx.x * 64 + threadIdx.x));

@@ -791,6 +791,13 @@ struct FqGapLane {
   bool has_cur, tail, hit_pending, too_many_n;
   uint32_t ck_, cl_, cpk;
   int cscore;
+  // The entry below the one popped last (its `next`), fetched ahead: consecutive pops of a bucket find their entry in registers,
+  // cost no trip of their own and are expanded at once.  A pool slot keeps its content for as long as it is on the stack, so the
+  // copy is good whenever the bucket's head still names that slot.
+  // (Not in the round without gap children: its searches are short, and the registers cost it a wavefront per SIMD.)
+  // (Fetching the entry's window of position records ahead as well was tried: loads return in order, so the extra request only
+  // moves the wait into the next trip -- 19.1 -> 21.7 ms for the second round of an on-target call.)
+  uint32_t pf_slot = FQ_NIL, pfk = 0, pfl = 0, pfpk = 0, pfnext = 0;
   uint32_t t_pops = 0, t_pushes = 0, t_touch = 0;   // totals over this lane's completed searches (a lane's share of a launch: 32 bits)
   uint32_t t_maxpops = 0, t_gt4k = 0;
   FQ_HD void flush_counters() {   // at the end of the wavefront's life
@@ -829,11 +836,20 @@ struct FqGapLane {
     blk0 = f0.blk; blk1 = f1.blk; primary0 = f0.primary; primary1 = f1.primary;
     active = done = false; w = len = max_diff_opt = seed_off = 0; use_seed = false;
     prec = A_.prec; pw0 = pw1 = pw2 = pw3 = 0; wbase = 0x7fff;
-    pool = A_.pool + (size_t)lane_slot * (size_t)A_.tier.pool_cap;   // stack storage belongs to the lane, not to the read
+    // Stack storage belongs to the lane, not to the read.  The pools of a wavefront's lanes are interleaved entry by entry (slot s of
+    // lane t at [s * 64 + t]): lanes that started together push and pop the same slots at about the same time, so a 128-byte line
+    // holds one slot of eight neighbouring lanes instead of eight slots of one lane -- the pushes of a step reach memory as whole
+    // lines, and the line a lane's pop brings in serves its neighbours' pops from the cache.
+    pool = A_.pool + (size_t)(lane_slot / FQ_WAVE_SIZE) * (size_t)A_.tier.pool_cap * FQ_WAVE_SIZE + (size_t)(lane_slot % FQ_WAVE_SIZE);
     store.begin_lane(A_, lane_slot);
     m0 = m1 = m2 = m3 = bump = status = n_aln = 0; spare = FQ_NIL; n_live = 0;
     best_score = max_diff = best_cnt = 0; c_pops = c_pushes = c_touch = 0;
     has_cur = tail = hit_pending = too_many_n = false; ck_ = cl_ = cpk = 0; cscore = 0;
+  }
+  // both blocks of the work queue handed out (the cursors overshoot their block's length once it is exhausted)
+  FQ_HD bool queue_dry() const {
+    const uint32_t sp = A.split ? *A.split : (uint32_t)A.n_work;
+    return FQ_LOAD_RELAXED(A.queue) >= sp && FQ_LOAD_RELAXED(A.queue + 1) >= (uint32_t)A.n_work - sp;
   }
   FQ_HD bool bucket_test(int b) const { return ((fq_sel4v(m0, m1, m2, m3, b >> 5) >> (b & 31)) & 1u) != 0; }
   FQ_HD void bucket_set(int b) { const uint32_t bit = 1u << (b & 31); const int q = b >> 5; m0 |= bit & (0u - (uint32_t)(q == 0)); m1 |= bit & (0u - (uint32_t)(q == 1)); m2 |= bit & (0u - (uint32_t)(q == 2)); m3 |= bit & (0u - (uint32_t)(q == 3)); }
@@ -859,15 +875,15 @@ struct FqGapLane {
     e.k = k; e.l = l; e.pk = pk; e.next = prev;
     // Stack entries stream out (two in three are never read back): a non-temporal store keeps them from displacing the Occ blocks
     // from the 4 MB L2 of the XCD, which every step of every lane reads.
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(FQ_POOL_PLAIN_STORE)
     {
       typedef uint32_t fq_v4u __attribute__((ext_vector_type(4)));
       fq_v4u v;
       v.x = e.k; v.y = e.l; v.z = e.pk; v.w = e.next;
-      __builtin_nontemporal_store(v, (fq_v4u *)(pool + slot));
+      __builtin_nontemporal_store(v, (fq_v4u *)(pool + (size_t)slot * FQ_WAVE_SIZE));
     }
 #else
-    pool[slot] = e;
+    pool[(size_t)slot * FQ_WAVE_SIZE] = e;
 #endif
     prev = slot;
     ++c_pushes; FQ_PROF(12);
@@ -886,7 +902,7 @@ struct FqGapLane {
       if (c_pops > t_maxpops) t_maxpops = c_pops;
       if (c_pops > 4096) ++t_gt4k;
     }
-    active = false; has_cur = false; tail = false; hit_pending = false;
+    active = false; has_cur = false; tail = false; hit_pending = false; pf_slot = FQ_NIL;
   }
 
   FQ_HD void begin(int w_) {
@@ -902,7 +918,7 @@ struct FqGapLane {
     best_score = (max_diff_opt + 1) * o.s_mm + (o.max_gapo + 1) * o.s_gapo + (o.max_gape + 1) * o.s_gape;
     max_diff = max_diff_opt; best_cnt = 0;
     c_pops = c_pushes = c_touch = 0;
-    has_cur = tail = hit_pending = false;
+    has_cur = tail = hit_pending = false; pf_slot = FQ_NIL;
     active = true;
     too_many_n = ((gw.meta >> 24) & 1u) != 0;
     if (too_many_n) { finish(); return; }   // "too many N" early-out of bwt_match_gap (bwtgap.c:118-124)
@@ -914,10 +930,42 @@ struct FqGapLane {
     n_live = 2;
   }
 
+  // gap_pop (bwtgap.c:66-79) of entry (ek, el, epk) from slot `slot` of bucket b, and the checks between a pop and its expansion
+  // (bwtgap.c:147-165).  True: the entry is the lane's current entry; false: the search ended, the entry was discarded, or it is
+  // a completed alignment (hit_pending).
+  FQ_HD bool take_entry(int b, uint32_t slot, uint32_t ek, uint32_t el, uint32_t epk, uint32_t enext) {
+    if (enext == FQ_NIL) bucket_clr(b); else store.head_set(b, enext);
+    spare = slot;
+    pf_slot = FQ_NIL;
+    wbase = 0x7fff;                                                        // the next entry sits anywhere: drop the window
+    --n_live; ++c_pops;
+    if (!nonstop && b > best_score + o.s_mm) { finish(); return false; }   // bwtgap.c:147
+    // A long search is handed over to the wavefront-per-read kernel, but only once the work queue has run dry: before that a
+    // busy lane costs nothing, afterwards the whole launch waits for it.
+    if (A.tier.long_pops && c_pops > A.tier.long_pops && (A.tier.long_always || ((c_pops & 63u) == 0 && queue_dry()))) {
+      status |= FQ_SF_LONG; finish(); return false;
+    }
+    const int n_mm = (int)(epk >> 12) & 31, n_gapo = (int)(epk >> 17) & 3, n_gape = (int)(epk >> 19) & 15;
+    const int m = max_diff - (n_mm + n_gapo + (gape_mode ? n_gape : 0));
+    if (m < 0) { FQ_PROF(4); return false; }
+    ck_ = ek; cl_ = el; cpk = epk; cscore = b;
+    if ((epk & 511u) == 0) { FQ_PROF(5); hit_pending = true; return false; }
+    has_cur = true;
+    return true;
+  }
+  FQ_HD void fetch_ahead(uint32_t nslot) {
+    if (NOGAP) return;
+    pf_slot = nslot;
+    if (nslot != FQ_NIL) {
+      const FqU4 v = *(const FqU4 *)(pool + (size_t)nslot * FQ_WAVE_SIZE);
+      pfk = v.x; pfl = v.y; pfpk = v.z; pfnext = v.w;
+    }
+  }
+
   // one trip of an active lane
   FQ_HD void step() {
     FQ_PROF(0);
-    const bool popping = !has_cur;
+    bool popping = !has_cur;
     int b = 0;
     uint32_t slot = 0;
     if (popping) {
@@ -926,6 +974,13 @@ struct FqGapLane {
       b = m0 ? FQ_CTZ32(m0) : m1 ? 32 + FQ_CTZ32(m1) : m2 ? 64 + FQ_CTZ32(m2) : 96 + FQ_CTZ32(m3);
       if (NOGAP && b >= o.s_gapo) { status |= FQ_SF_NEEDGAP; finish(); return; }   // the full search may hold a gap child at or below this bucket
       slot = store.head_get(b);
+      if (slot == pf_slot) {   // the entry was fetched ahead: pop it now and expand it in this same trip
+        const uint32_t ek = pfk, el = pfl, epk = pfpk, enext = pfnext;
+        const bool go = take_entry(b, slot, ek, el, epk, enext);
+        if (active) fetch_ahead(enext);
+        if (!go) return;
+        popping = false;
+      }
     }
     // ---- loads: a popping lane fetches its 16-byte stack entry; a lane with a current entry fetches the two Occ blocks of
     //      rows k-1 and l and, when positions i0-1 / i0-2 have left its window, the next eight position records
@@ -934,7 +989,7 @@ struct FqGapLane {
     const bool reload = !popping && (need_lo < wbase || i0 - 1 > wbase + 7);
     const int nb = i0 >= 8 ? ((i0 - 7) & ~1) : 0;                            // 4-byte aligned window holding i0-2 and i0-1
     const FqPos *pp = prec + (size_t)a * (size_t)A.pstride + nb;
-    const uintptr_t pa = (uintptr_t)fq_pick2p((uint64_t)(uintptr_t)(pool + slot), (uint64_t)(uintptr_t)pp, popping ? 1 : 0);
+    const uintptr_t pa = (uintptr_t)fq_pick2p((uint64_t)(uintptr_t)(pool + (size_t)slot * FQ_WAVE_SIZE), (uint64_t)(uintptr_t)pp, popping ? 1 : 0);
     FqU4 vA;
     vA.x = vA.y = vA.z = vA.w = 0;
     if (popping || reload) vA = *(const FqU4 *)pa;
@@ -946,24 +1001,10 @@ struct FqGapLane {
     } else {
       bk = fq_blk_none(); bl = fq_blk_none();
     }
-    if (popping) {   // ---- gap_pop (bwtgap.c:66-79) and the pop-time checks; the entry is expanded in the next trip ---------
+    if (popping) {   // ---- the entry arrives from the pool; it is expanded in the next trip -------------------------------------
       FQ_PROF(3);
-      if (vA.w == FQ_NIL) bucket_clr(b); else store.head_set(b, vA.w);
-      spare = slot;
-      wbase = 0x7fff;                                                        // the next entry sits anywhere: drop the window
-      --n_live; ++c_pops;
-      if (!nonstop && b > best_score + o.s_mm) { finish(); return; }         // bwtgap.c:147
-      // A long search is handed over to the wavefront-per-read kernel, but only once the work queue has run dry: before that a
-      // busy lane costs nothing, afterwards the whole launch waits for it.
-      if (A.tier.long_pops && c_pops > A.tier.long_pops && (A.tier.long_always || ((c_pops & 63u) == 0 && FQ_LOAD_RELAXED(A.queue) >= (uint32_t)A.n_work))) {
-        status |= FQ_SF_LONG; finish(); return;
-      }
-      const int n_mm = (int)(vA.z >> 12) & 31, n_gapo = (int)(vA.z >> 17) & 3, n_gape = (int)(vA.z >> 19) & 15;
-      const int m = max_diff - (n_mm + n_gapo + (gape_mode ? n_gape : 0));
-      if (m < 0) { FQ_PROF(4); return; }
-      ck_ = vA.x; cl_ = vA.y; cpk = vA.z; cscore = b;
-      if ((vA.z & 511u) == 0) { FQ_PROF(5); hit_pending = true; return; }
-      has_cur = true;
+      take_entry(b, slot, vA.x, vA.y, vA.z, vA.w);
+      if (active) fetch_ahead(vA.w);
       return;
     }
     // ---- a lane with a current entry ------------------------------------------------------------------------------------------
@@ -1164,6 +1205,7 @@ FQ_HD void fq_gap_lanes(const FqGapArgs &A, const St &store0, Fetch fetch, int l
 #if defined(FQ_GAP_INSTR) && defined(__HIP_DEVICE_COMPILE__)
   uint32_t ib[16];
   for (int q = 0; q < 16; ++q) ib[q] = 0;
+  const uint64_t t_life0 = clock64();
 #endif
   for (;; ++trips) {
     // (re)fill idle lanes, in groups: one queue reservation per group
@@ -1171,6 +1213,9 @@ FQ_HD void fq_gap_lanes(const FqGapArgs &A, const St &store0, Fetch fetch, int l
     const uint64_t wm = FQ_BALLOT(want), am = FQ_BALLOT(L.active);
     if (wm == 0 && am == 0) {
 #if defined(FQ_GAP_INSTR) && defined(__HIP_DEVICE_COMPILE__)
+#if FQ_GAP_INSTR == 2
+      ib[14] = (uint32_t)((clock64() - t_life0) >> 4);   // lifetime of this wavefront
+#endif
       if (FQ_LANE_ID() == 0) for (int q = 0; q < 16; ++q) FQ_ATOMIC_ADD64(&A.counters[FQ_C_DBG0 + q], ib[q]);
 #endif
       L.flush_counters();
@@ -1194,19 +1239,47 @@ FQ_HD void fq_gap_lanes(const FqGapArgs &A, const St &store0, Fetch fetch, int l
       const uint64_t a2 = FQ_BALLOT(L.active);
       const int na = (int)FQ_POPC64(a2);
       ib[0] += 1; ib[1] += (uint32_t)na;
+#if FQ_GAP_INSTR != 2
       ib[2 + (na == 0 ? 0 : na <= 8 ? 1 : na <= 16 ? 2 : na <= 32 ? 3 : na <= 48 ? 4 : 5)] += 1;     // 2..7: trips by active lanes (0, 1-8, 9-16, 17-32, 33-48, 49-64)
+#endif
+#if FQ_GAP_INSTR != 2
       const uint64_t pop = FQ_BALLOT(L.active && !L.has_cur), tl = FQ_BALLOT(L.active && L.has_cur && L.tail), ex = FQ_BALLOT(L.active && L.has_cur && !L.tail);
       ib[8] += pop != 0; ib[9] += tl != 0; ib[10] += ex != 0;
       ib[11] += (uint32_t)FQ_POPC64(pop); ib[12] += (uint32_t)FQ_POPC64(tl); ib[13] += (uint32_t)FQ_POPC64(ex);
       ib[14] += (pop != 0) + (tl != 0) + (ex != 0) == 3;
+#endif
     }
 #endif
+#if defined(FQ_GAP_INSTR) && FQ_GAP_INSTR == 2 && defined(__HIP_DEVICE_COMPILE__)
+    // timing mode: shader-clock cycles a wavefront spends in the step and in hit collection (dbg[2..7] instead of the histogram)
+    const bool pop_any = FQ_BALLOT(L.active && !L.has_cur) != 0;
+    bool rl_any;
+    {   // will a lane fetch a new window of position records in this trip (the condition of FqGapLane::step)
+      const int i0_ = (int)(L.cpk & 511u), lo_ = i0_ >= 2 ? i0_ - 2 : 0;
+      rl_any = FQ_BALLOT(L.active && L.has_cur && (lo_ < L.wbase || i0_ - 1 > L.wbase + 7)) != 0;
+    }
+    const uint64_t tc0 = clock64();
+    if (L.active) { ++lane_trips; L.step(); }
+    const bool any_hit = FQ_BALLOT(L.hit_pending) != 0;
+    const uint64_t tc1 = clock64();
+    const uint64_t shm = FQ_BALLOT(L.hit_pending && (L.cpk >> 23) > 0);
+    if (any_hit) L.collect_hits();
+    const uint64_t tc2 = clock64();
+    ib[15] += any_hit;
+    ib[2] += (uint32_t)((tc1 - tc0) >> 4); ib[3] += (uint32_t)((tc2 - tc1) >> 4);
+    if (pop_any) { ib[6] += (uint32_t)((tc1 - tc0) >> 4); ib[7] += 1; }     // trips in which at least one lane pops a stack entry
+    else if (rl_any) { ib[10] += (uint32_t)((tc1 - tc0) >> 4); ib[11] += 1; }   // no pop, but a window of position records is fetched
+    else { ib[8] += (uint32_t)((tc1 - tc0) >> 4); ib[9] += 1; }                 // only Occ blocks
+    if (pop_any && rl_any) { ib[12] += (uint32_t)((tc1 - tc0) >> 4); ib[13] += 1; }
+    ib[4] += (uint32_t)FQ_POPC64(shm); ib[5] += shm != 0;
+#else
     if (L.active) { ++lane_trips; L.step(); }
     const bool any_hit = FQ_BALLOT(L.hit_pending) != 0;
 #if defined(FQ_GAP_INSTR) && defined(__HIP_DEVICE_COMPILE__)
     ib[15] += any_hit;
 #endif
     if (any_hit) L.collect_hits();
+#endif
   }
 }
 

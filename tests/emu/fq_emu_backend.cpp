@@ -81,6 +81,7 @@ int gap_lane_slots(const FqGapArgs &a) { return a.n_work > 0 ? 1 : 0; }
 int launch_gap(const FqGapArgs &a_in) {
   FqGapArgs a = a_in;
   a.refill_min = 1;
+  a.split = nullptr;   // one cursor over the whole order here: FqGapLane::queue_dry then looks at it alone
   uint32_t *next_p = a.queue; *next_p = 0;   // the same cursor the device kernels advance
   if (a.tier.coop) {
     std::vector<uint32_t> heads(2 * FQ_MAX_BUCKETS);

@@ -31,7 +31,10 @@ SEARCH_MODES = {"lanes": {}, "wave1": {"gap_long_pops": 1, "gap_long_always": 1}
                 # host / the whole body uploaded and gathered on the device
                 "packed": {"packed_bulk_min": 1 << 30}, "packed_bulk": {"packed_bulk_min": 0},
                 # every launch begins with the round that searches without gap children, as device-filling launches do
-                "nogap": {"gap_nogap_min": 0}}
+                "nogap": {"gap_nogap_min": 0},
+                # the hand-over rule of small launches with a low threshold: a search still running after 8 pops once the work queue
+                # is dry (both of its blocks) goes to the wavefront-per-read kernel
+                "handover": {"gap_long_pops": 8}}
 
 
 @pytest.fixture(params=list(SEARCH_MODES))
@@ -54,7 +57,7 @@ def test_gpu_matches_reference_golden(tag, golden_cases, lib, search_mode):
     assert not diffs, "\n".join(diffs)
     assert filecmp.cmp(g["sam"], sam, shallow=False)
     assert stats["kernel_launches"][2] > 0, "the gap-search kernel did not run on the device"
-    if search_mode.startswith("wave"):
+    if search_mode.startswith("wave") or search_mode == "handover":
         assert stats["tier_retries"] > 0, "the wavefront-per-read kernel was not exercised"
 
 
