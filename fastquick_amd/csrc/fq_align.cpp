@@ -119,6 +119,7 @@ struct PinArena {
 struct FqKnobs {   // experiment / test knobs (fq_ctx_set_tuning); defaults are what DESIGN.md measures
   uint32_t gap_long_pops = 1024;   // lane kernel hands a search to the wavefront-per-read kernel after this many pops (queue dry)
   int gap_long_always = 0;         // ... whatever the state of the queue (tests)
+  uint32_t gap_long_pops2 = 0;     // hand-over threshold of the second round of a device-filling call (0: no hand-over)
   int64_t gap_split_hard = 0;      // experiment: after the round without gap children, search reads whose lower bound is >= this in a launch of their own (0: off)
   int64_t gap_nogap_min = 131072;  // launches of at least this many reads begin with the round that searches without gap children (-1: never)
   uint32_t gap_pool = 2048;        // stack entries per lane of the lane kernel
@@ -286,6 +287,7 @@ extern "C" int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t v) {
   else if (k == "gap_pool") c->kn.gap_pool = (uint32_t)v;
   else if (k == "gap_nogap_min") c->kn.gap_nogap_min = v;
   else if (k == "gap_split_hard") c->kn.gap_split_hard = v;
+  else if (k == "gap_long_pops2") c->kn.gap_long_pops2 = (uint32_t)v;
   else if (k == "gap_no_order") c->kn.gap_no_order = (int)v;
   else if (k == "sw_wave_max") c->kn.sw_wave_max = (int)v;
   else if (k == "host_threads") c->kn.host_threads = (int)v;
@@ -294,6 +296,7 @@ extern "C" int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t v) {
   else if (k == "trace") c->kn.trace = (int)v;
   else if (k == "gap_order_asc") t->gap_order_asc = (int)v;
   else if (k == "gap_waves_per_cu") t->gap_waves_per_cu = (int)v;
+  else if (k == "gap_coop_waves") t->gap_coop_waves = (int)v;
   else if (k == "gap_refill_min") t->gap_refill_min = (int)v;
   else if (k == "filter_no_turns") t->filter_no_turns = (int)v;
   else if (k == "refine_lanes") t->refine_lanes = (int)v;
@@ -895,7 +898,7 @@ int stageA_search(Call &K) {
     // The second round of such a call is a small launch, but of hard reads only: handing them over at 1,024 pops sends tens of
     // thousands of them to the wavefront kernel (12 + 30 ms instead of 19.5 ms for the 114 k reads an on-target call of 2.1 M leaves),
     // at 2,048 / 3,072 / 4,096 pops 15 + 14 / 17 + 12 / 20 + 9 ms: the rule stays with the size of the call.
-    if (!T.coop && !T.long_always && n_search > 524288) T.long_pops = 0;
+    if (!T.coop && !T.long_always && n_search > 524288) T.long_pops = tier >= n_first_tiers && n_first_tiers > 0 && !work.empty() && work.size() <= 524288 ? c->kn.gap_long_pops2 : 0u;
     next_work.clear();
     size_t first_chunk = 0;   // experiment (gap_split_hard): the predicted-hard reads lead the work list and get a launch of their own
     if (!T.nogap && !T.coop && c->kn.gap_split_hard > 0 && !bound_of.empty()) {

@@ -11,6 +11,7 @@ namespace fqdev {
 // on the bound state.  Nothing device-side is kept per thread or per process.
 struct State;
 struct Tune {   // experiment / test knobs (fq_ctx_set_tuning); the defaults are what DESIGN.md measures
+  int gap_coop_waves = 0;   // wavefronts of the wavefront-per-read search kernel (0: 1,024)
   int gap_waves_per_cu = 0, gap_refill_min = 0, gap_order_asc = 0, filter_no_turns = 0, refine_lanes = 0;
 };
 State *state_create(int device_ordinal);   // nullptr on failure (last_error())

@@ -863,7 +863,8 @@ int launch_order(const uint8_t *bid_end, int n, int32_t *order, uint32_t *cnt) {
 int gap_lane_slots(const FqGapArgs &a) {
   if (a.n_work <= 0) return 0;
   if (a.tier.coop) {   // wavefronts, one pool each
-    unsigned w = std::min<unsigned>((unsigned)a.n_work, a.tier.exact ? 64u : 1024u);
+    const unsigned cw = g_cur->tune.gap_coop_waves > 0 ? (unsigned)g_cur->tune.gap_coop_waves : 1024u;
+    unsigned w = std::min<unsigned>((unsigned)a.n_work, a.tier.exact ? 64u : cw);
     if (a.max_waves > 0) w = std::min<unsigned>(w, (unsigned)a.max_waves);
     return (int)w;
   }
