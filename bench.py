@@ -37,7 +37,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 K_NAMES = ("prep", "width", "gap", "sa", "sw", "refine")
-K_PREP_KERNEL, K_GAP_KERNEL = 6, 7     # single-kernel timings (kernel begin/end timestamps via hipExtLaunchKernelGGL events)
+K_PREP_KERNEL, K_GAP_KERNEL, K_GAP_NOGAP = 6, 7, 8     # single-kernel timings (kernel begin/end timestamps via hipExtLaunchKernelGGL events);
+#   7 = the full search kernels (one read per lane / per wavefront), 8 = the first round of a device-filling launch (search without gap children)
 STRIDE_PAD = 16                # ASCII rows are padded to 16 bytes: the resident filter kernel loads rows with 16-byte vector loads
 
 
@@ -219,7 +220,7 @@ def main() -> None:
                     ctxs[0].align_packed(packs[cur_of[0]])
                 else:
                     ctxs[0].align_resident()
-            leg["solo"] = ctxs[0].stats()
+            leg["solo"] = dict(ctxs[0].stats(), calls=3)
         if keep:
             leg["ctxs"], leg["packs"], leg["distinct"] = ctxs, packs, distinct
         else:
@@ -233,11 +234,22 @@ def main() -> None:
         per_read = 24.0 + 1.0 if boundary == "host" else 96.0 + 5.0      # packed: 3 k-mers in, 1 verdict byte out; ASCII: 96 bases in, length + verdict out
         return 64.0 * agg["filter_probes"] + per_read * 2 * pairs_total
 
+    def gap_parts(st):
+        """(name, summed ms, launches, algorithmic bytes) of the search stage and of its two kernels: a device-filling launch runs the search
+        without gap children first (k_gap_nogap_lds) and the full search (k_gap_persist_lds, k_gap_coop) on what that leaves."""
+        ms_f, ms_n = st["kernel_ms"][K_GAP_KERNEL], st["kernel_ms"][K_GAP_NOGAP]
+        nl_f, nl_n = int(st["kernel_launches"][K_GAP_KERNEL]), int(st["kernel_launches"][K_GAP_NOGAP])
+        b_all, b_n = 48.0 * st["gap_occ_touches"], 48.0 * st["gap_nogap_touches"]
+        return [("gap", ms_f + ms_n, nl_f + nl_n, b_all), ("gap_nogap", ms_n, nl_n, b_n), ("gap_full", ms_f, nl_f, b_all - b_n)]
+
     def kernel_rooflines(agg, pairs_total, boundary):
         out = {}
-        for kname, ki, byts in (("prep", K_PREP_KERNEL, prep_bytes(agg, pairs_total, boundary)), ("gap", K_GAP_KERNEL, 48.0 * agg["gap_occ_touches"])):
-            nl = max(1, int(agg["kernel_launches"][ki]))
-            ms = agg["kernel_ms"][ki] / nl
+        parts = [("prep", agg["kernel_ms"][K_PREP_KERNEL], int(agg["kernel_launches"][K_PREP_KERNEL]), prep_bytes(agg, pairs_total, boundary))] + gap_parts(agg)
+        for kname, ms_sum, nl, byts in parts:
+            if nl == 0 and kname != "prep" and kname != "gap":
+                continue
+            nl = max(1, nl)
+            ms = ms_sum / nl
             gbs = (byts / nl) / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
             out["fq_" + kname] = {"avg_launch_ms": round(ms, 4), "launches": nl, "alg_bytes_per_launch": round(byts / nl, 1),
                                   "alg_GBps": round(gbs, 2), "frac_of_hbm_peak": round(gbs / HBM_PEAK_GBS, 5)}
@@ -286,10 +298,12 @@ def main() -> None:
                              ", ".join("%s %.2f x %.2f" % (K_NAMES[k], kms[k] / calls, share[K_NAMES[k]]) for k in range(len(K_NAMES)))}
     if "solo" in main_leg:
         s1 = main_leg["solo"]
-        ki = K_PREP_KERNEL if dname == "prep" else K_GAP_KERNEL
-        nl1 = max(1, int(s1["kernel_launches"][ki]))
-        ms1 = s1["kernel_ms"][ki] / nl1
-        byts1 = prep_bytes(s1, args.pairs * 3, args.boundary) if dname == "prep" else 48.0 * s1["gap_occ_touches"]
+        if dname == "prep":
+            nl1, ms_sum1, byts1 = int(s1["kernel_launches"][K_PREP_KERNEL]), s1["kernel_ms"][K_PREP_KERNEL], prep_bytes(s1, args.pairs * 3, args.boundary)
+        else:
+            _, ms_sum1, nl1, byts1 = gap_parts(s1)[0]
+        nl1 = max(1, nl1)
+        ms1 = ms_sum1 / nl1
         if ms1 > 0:
             roofline["solo_avg_launch_ms"] = round(ms1, 4)
             roofline["solo_achieved"] = round(byts1 / nl1 / (ms1 * 1e-3) / 1e9, 3)
@@ -314,7 +328,7 @@ def main() -> None:
         "stage_ms_per_call": {K_NAMES[k]: round(kms[k] / calls, 4) for k in range(len(K_NAMES))},
         "host_ms_per_call": round(agg["host_ms_total"] / calls, 3), "wall_ms_per_call": round(agg["wall_ms_total"] / calls, 3),
         "survivor_pairs_per_call": round(main_leg["n_records"] / calls, 1),
-        "work_per_call": {k: round(agg[k] / calls, 1) for k in ("filter_probes", "occ_block_touches", "gap_occ_touches", "stack_pops",
+        "work_per_call": {k: round(agg[k] / calls, 1) for k in ("filter_probes", "occ_block_touches", "gap_occ_touches", "gap_nogap_touches", "stack_pops",
                                                                      "stack_pushes", "sa_rows", "reads_searched", "sw_tasks", "refine_tasks", "tier_retries", "reads_over_4k_pops")},
         "max_pops_per_read": agg["max_pops_per_read"], "max_wave_trips": agg["max_wave_trips"],
         "gap_wave_trips_per_call": round(agg["wave_trips"] / calls, 1), "gap_lane_trips_per_call": round(agg["lane_trips"] / calls, 1),
@@ -364,13 +378,16 @@ def main() -> None:
                            "reads_searched_per_call": round(a2["reads_searched"] / leg["calls"], 1),
                            "stack_pops_per_read": round(a2["stack_pops"] / max(1, a2["reads_searched"]), 1),
                            "occ_touches_per_read": round(a2["gap_occ_touches"] / max(1, a2["reads_searched"]), 1)}
-        if "solo" in leg:
+        if "solo" in leg:     # the search kernels with nothing else on the device
             s1 = leg["solo"]
-            nl1 = max(1, int(s1["kernel_launches"][K_GAP_KERNEL]))
-            ms1 = s1["kernel_ms"][K_GAP_KERNEL] / nl1
-            if ms1 > 0:
-                g1 = 48.0 * s1["gap_occ_touches"] / nl1 / (ms1 * 1e-3) / 1e9
-                out["ontarget"]["gap_solo"] = {"avg_launch_ms": round(ms1, 4), "alg_GBps": round(g1, 2), "frac_of_hbm_peak": round(g1 / HBM_PEAK_GBS, 5)}
+            solo = {}
+            for kname, ms_sum, nl, byts in gap_parts(s1):
+                if nl and ms_sum > 0:
+                    g1 = byts / (ms_sum * 1e-3) / 1e9
+                    solo["fq_" + kname] = {"avg_launch_ms": round(ms_sum / nl, 4), "launches_per_call": round(nl / max(1, s1["calls"]), 2) if "calls" in s1 else None,
+                                           "alg_GBps": round(g1, 2), "frac_of_hbm_peak": round(g1 / HBM_PEAK_GBS, 5)}
+            if "fq_gap" in solo:
+                out["ontarget"]["gap_solo"] = dict(solo["fq_gap"], kernels={k: v for k, v in solo.items() if k != "fq_gap"})
 
     # ---- CPU baseline: the oracle (a port) on a bounded sample of the same workload, rank 0, N=1 only -----------
     # Three geometries, a few seconds each:

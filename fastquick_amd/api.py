@@ -72,8 +72,8 @@ class ResultBatch(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("kernel_ms", C.c_double * 8), ("kernel_launches", C.c_uint64 * 8),
-                ("occ_block_touches", C.c_uint64), ("gap_occ_touches", C.c_uint64), ("filter_probes", C.c_uint64),
+    _fields_ = [("kernel_ms", C.c_double * 9), ("kernel_launches", C.c_uint64 * 9),
+                ("occ_block_touches", C.c_uint64), ("gap_occ_touches", C.c_uint64), ("gap_nogap_touches", C.c_uint64), ("filter_probes", C.c_uint64),
                 ("stack_pops", C.c_uint64), ("stack_pushes", C.c_uint64), ("sa_rows", C.c_uint64),
                 ("reads_searched", C.c_uint64), ("pairs", C.c_uint64), ("sw_tasks", C.c_uint64),
                 ("refine_tasks", C.c_uint64), ("tier_retries", C.c_uint64),

@@ -887,7 +887,7 @@ int launch_gap(const FqGapArgs &a_in) {
   a.refill_min = env_refill > 0 ? env_refill : FQ_REFILL_MIN;
   FQ_HIP(hipMemsetAsync(a.queue, 0, 8, g_stream));
   hipEvent_t e0, e1;
-  kernel_events(7, &e0, &e1);   // FQ_K_GAP_KERNEL
+  kernel_events(a.tier.nogap ? 8 : 7, &e0, &e1);   // FQ_K_GAP_NOGAP / FQ_K_GAP_KERNEL
   if (a.tier.coop) {
     hipExtLaunchKernelGGL(k_gap_coop, dim3((unsigned)gap_lane_slots(a)), dim3(64), 0, g_stream, e0, e1, 0, a);
   } else {

@@ -817,6 +817,7 @@ struct FqGapLane {
       FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS], v[0]);
       FQ_ATOMIC_ADD64(&A.counters[FQ_C_PUSHES], v[1]);
       FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_GAP], v[2]);
+      if (NOGAP) FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_NOGAP], v[2]);
       FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXPOPS], mx);
       if (g4) FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS_GT4K], g4);
     }
@@ -824,6 +825,7 @@ struct FqGapLane {
     FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS], t_pops);
     FQ_ATOMIC_ADD64(&A.counters[FQ_C_PUSHES], t_pushes);
     FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_GAP], t_touch);
+    if (NOGAP) FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_NOGAP], t_touch);
     FQ_ATOMIC_MAX64(&A.counters[FQ_C_MAXPOPS], t_maxpops);
     if (t_gt4k) FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS_GT4K], t_gt4k);
 #endif

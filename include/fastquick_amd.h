@@ -285,13 +285,15 @@ int fq_bam_close(fq_bam_t *b);                   /* writes the BGZF end-of-file 
 #define FQ_K_SW 4        /* mate-rescue Smith-Waterman */
 #define FQ_K_REFINE 5    /* banded global DP + MD/NM */
 #define FQ_K_PREP_KERNEL 6   /* k_prep alone, kernel begin/end timestamps (hipExtLaunchKernelGGL events) */
-#define FQ_K_GAP_KERNEL 7    /* the gap-search kernel alone, same */
-#define FQ_K_COUNT 8
+#define FQ_K_GAP_KERNEL 7    /* the gap-search kernels alone, same: the full search (one read per lane / per wavefront) */
+#define FQ_K_GAP_NOGAP 8     /* ... the first round of a device-filling launch (the search without gap children) */
+#define FQ_K_COUNT 9
 typedef struct {
   double kernel_ms[FQ_K_COUNT];
   uint64_t kernel_launches[FQ_K_COUNT];
   uint64_t occ_block_touches;   /* 32-byte Occ blocks fetched by FQ_K_WIDTH+FQ_K_GAP+FQ_K_SA */
   uint64_t gap_occ_touches;     /* ... by FQ_K_GAP alone */
+  uint64_t gap_nogap_touches;   /* ... of which by searches the first round (FQ_K_GAP_NOGAP) completed */
   uint64_t filter_probes;       /* bitmap probes issued by FQ_K_PREP */
   uint64_t stack_pops, stack_pushes;
   uint64_t sa_rows;
