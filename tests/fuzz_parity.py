@@ -54,9 +54,13 @@ for seed in range(args.start, args.start + args.seeds):
         elif o == "I": okw["mode"] = okw.get("mode", 3) | 0x200
         elif o == "max_isize": okw["max_isize"] = rnd.choice([200, 1000])
         elif o == "e": okw["max_gape"] = rnd.choice([2, 6]); okw["mode"] = okw.get("mode", 3) & ~1
-    mode = rnd.choice(["lanes", "lanes", "wave1", "wave64"])
+    mode = rnd.choice(["lanes", "nogap", "handover", "wave1", "wave64"])
     tuning = {}
-    if mode != "lanes":
+    if mode == "nogap":          # every launch begins with the round that searches without gap children
+        tuning = {"gap_nogap_min": 0}
+    elif mode == "handover":     # searches still running after 8 pops once the queue is dry go to the wavefront-per-read kernel
+        tuning = {"gap_long_pops": 8}
+    elif mode != "lanes":
         tuning = {"gap_long_pops": 1 if mode == "wave1" else 64, "gap_long_always": 1}
     packed = rnd.random() < 0.5
     if packed:
@@ -87,7 +91,7 @@ for seed in range(args.start, args.start + args.seeds):
     same = filecmp.cmp(d + "/o.sam", d + "/g.sam", shallow=False)
     ok = not diffs and same
     bad += 0 if ok else 1
-    print("seed %3d %-6s%s len %3d n %5d call %5d thr %d %s retries %d  %.1fs  %s" % (seed, mode, "+pk" if packed else "   ", read_len, n, call, threads, "OK  " if ok else "FAIL", al.stats()["tier_retries"], time.time() - t0,
+    print("seed %3d %-8s%s len %3d n %5d call %5d thr %d %s retries %d  %.1fs  %s" % (seed, mode, "+pk" if packed else "   ", read_len, n, call, threads, "OK  " if ok else "FAIL", al.stats()["tier_retries"], time.time() - t0,
                                                                     "" if ok else (str(refkw) + str(readkw) + str(okw) + " " + str(diffs[:3]))), flush=True)
     al.close(); ix.close(); oa.close()
 sys.exit(1 if bad else 0)

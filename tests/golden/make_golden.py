@@ -54,7 +54,7 @@ CASES = {
 }
 # Real reads: the 251 pairs of 151 bp (one of 137 bp; lower-case bases, Illumina names with comments, real quality strings) that
 # the reference ships as its own example input (example/fq.test.list).  The reference FASTA its example.sh names is not in the
-# repository, so the reduced reference is synthetic with 118 of the pairs planted in marker flanks (lightly mutated copies).
+# example can build here (see make_cfg0_case), so the reduced reference is synthetic with 118 of the pairs planted in marker flanks (lightly mutated copies).
 EXAMPLE_FQ = ("/root/reference/example/ERR013170_1.filt.fastq.gz.1000.fastq.gz",
               "/root/reference/example/ERR013170_2.filt.fastq.gz.1000.fastq.gz")
 # One batch: with full batches the reference's mate-name check (src/BwtMapper.cpp:2087-2092) would abort on the first pair
@@ -152,6 +152,58 @@ def make_example_case():
     print(tag, "->", sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) // 1024, "KiB")
 
 
+# configs[0] on the repository's own data: example/ref.test.fa (one 50 kb contig "22"), example/hapmap.test.vcf.gz (candidate sites),
+# example/fq.test.list (251 pairs).  `FASTQuick index` itself cannot run here (RefBuilder shells out to bcftools, absent:
+# src/RefBuilder.cpp:451-459), so the marker windows are cut by this script -- candidate SNPs whose REF agrees with the FASTA,
+# left to right, windows of 2 x 250 + 1 bases that do not overlap, named as RefBuilder names them -- and everything from there on
+# (index build, align, StatCollector, SetSamRecord) is the reference's own code on the reference's own reads.
+CFG0_FA = "/root/reference/example/ref.test.fa"
+CFG0_VCF = "/root/reference/example/hapmap.test.vcf.gz"
+
+
+def make_cfg0_case():
+    tag, batch, q = "cfg0_example", 256, 15
+    out = os.path.join(HERE, tag)
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(out)
+    lines = open(CFG0_FA, "rb").read().split(b"\n")
+    chrom = lines[0][1:].split()[0].decode()
+    text = np.frombuffer(b"".join(lines[1:]), dtype=np.uint8)
+    code = np.zeros(256, dtype=np.uint8)
+    for i, c in enumerate(b"ACGT"):
+        code[c] = code[c + 32] = i
+    genome = code[text]
+    flank = 250
+    pos, names, seqs, last_end = [], [], [], 0
+    with gzip.open(CFG0_VCF, "rt") as fh:
+        recs = sorted((int(f[1]), f[3], f[4]) for f in (ln.split("\t") for ln in fh if not ln.startswith("#")) if len(f[3]) == 1 and len(f[4]) == 1)
+    for p1, r, a in recs:
+        if p1 - flank <= last_end or p1 + flank > len(text) or chr(text[p1 - 1]).upper() != r:
+            continue
+        pos.append(p1)
+        names.append("%s:%d@%s/%s" % (chrom, p1, r, a))
+        seqs.append(text[p1 - 1 - flank:p1 + flank].copy())
+        last_end = p1 + flank
+    ref = synth.SynthRef(names, seqs, genome, np.array(pos, dtype=np.int64), np.full(len(pos), flank, dtype=np.int64))
+    r1 = read_fastq_raw(EXAMPLE_FQ[0])
+    with tempfile.TemporaryDirectory() as tmp:
+        pre = os.path.join(tmp, "ref.FASTQuick.fa")
+        ref.write_fasta(pre)
+        subprocess.check_call([ob.REF_DRIVER, "index", pre], stderr=subprocess.DEVNULL, cwd=tmp)
+        synth.write_qc_inputs(pre, ref)
+        fq = []
+        for e, src in enumerate(EXAMPLE_FQ):
+            dst = os.path.join(tmp, "reads_%d.fq" % (e + 1))
+            with gzip.open(src, "rb") as fi, open(dst, "wb") as fo:
+                fo.write(fi.read())
+            fq.append(dst)
+        ob.run_reference(pre, fq[0], fq[1], os.path.join(tmp, "ref_out"), "--batch", batch, "--q", q, "--read_len", 152, "--genome_size", len(genome))
+        run_bam_dump(tmp, pre, fq[0], fq[1], ref, "--batch", batch, "--q", q, "--read_len", 152)
+        write_case(out, tmp, pre, fq[0], fq[1], len(r1), batch, q, "reference example/ref.test.fa, %d marker windows cut at example/hapmap.test.vcf.gz sites" % len(pos),
+                   "reference example/fq.test.list", len(genome), 152)
+    print(tag, "->", len(pos), "markers,", sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) // 1024, "KiB")
+
+
 INDEX_EXT = [".bwt", ".rbwt", ".sa", ".rsa", ".pac", ".ann", ".amb"]
 # what StatCollector reads beside the reduced reference (inputs), and the files it writes (expected outputs)
 QC_IN_EXT = [".SelectedSite.vcf", ".dbSNP.subset.vcf", ".gc"]
@@ -194,6 +246,8 @@ def main() -> None:
         print(tag, "->", sum(os.path.getsize(os.path.join(out, f)) for f in os.listdir(out)) // 1024, "KiB")
     if not only or EXAMPLE_CASE[0] in only:
         make_example_case()
+    if not only or "cfg0_example" in only:
+        make_cfg0_case()
 
 
 if __name__ == "__main__":
