@@ -8,12 +8,13 @@
 //   GetDepthDist .. SummaryOutput  :1858-2028, 2343-2483   the output files
 // Containers whose iteration order reaches an output (.SexChromInfo: an unordered_map walked in bucket order) are the same
 // standard containers, filled in the same order, so the files come out byte for byte; the others are order-free sums.
-// Not restated: .AdjustedInsertSizeDist (InsertSizeEstimator, a separate estimator fed from the .InsertSizeTable file) and the
-// genotype .vcf (GetVCF) -- both read only what is written here.
+//   GetInsertSizeDist    :1969-2002 + src/InsertSizeEstimator.cpp:43-173   the censoring-adjusted insert-size density
+//   GetVCF               :2113-2155, 2185-2275   genotype likelihoods of the marker pileups (float arithmetic as there)
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <ctime>
 #include <fstream>
 #include <map>
 #include <sstream>
@@ -564,6 +565,57 @@ extern "C" int fq_qc_write(fq_qc_t *q) {
       if (q->misEmpCycle[i] != 0) prevQual = ph;
     }
   }
+  {   // GetInsertSizeDist, :1969-1996: the estimator of src/InsertSizeEstimator.cpp reads the .InsertSizeTable file back, once with the
+      // "FwdOnly" pairs left out and once with the "RevOnly" ones (InputInsertSizeTable :43-143), and UpdateWeight (:145-173) turns
+      // observed (ObsDist) and censored (MisDist) counts per insert size into a density; the two densities are added.
+    const int kLimit = 4096;   // INSERT_LIMIT, InsertSizeEstimator.h
+    std::vector<double> fsum(2000, 0.);
+    for (int pass = 0; pass < 2; ++pass) {
+      const std::string skip = pass == 0 ? "FwdOnly" : "RevOnly";
+      std::vector<double> Obs(kLimit, 1e-6), Mis(kLimit, 1e-6);
+      int totalPair = 0;
+      std::ifstream fin(pre + ".InsertSizeTable");
+      std::string line;
+      while (std::getline(fin, line)) {
+        std::vector<std::string> v;
+        for (size_t start = 0;;) {
+          const size_t end = line.find('\t', start);
+          v.push_back(line.substr(start, end == std::string::npos ? std::string::npos : end - start));
+          if (end == std::string::npos) break;
+          start = end + 1;
+        }
+        if (v.size() < 15) continue;
+        int Max = atoi(v[1].c_str()), Max2 = atoi(v[2].c_str()), ObsI = atoi(v[3].c_str());
+        const int Flag1 = atoi(v[6].c_str()), Flag2 = atoi(v[11].c_str());
+        const std::string &Cigar1 = v[8], &Cigar2 = v[13], &Status = v[14];
+        if (Max >= kLimit || Max == -1) Max = kLimit - 1;
+        if (Max2 >= kLimit || Max2 == -1) Max2 = kLimit - 1;
+        if (ObsI >= kLimit || ObsI == -1) ObsI = kLimit - 1;
+        if (Status == "Abnormal" || Status == "LowQual" || Status == "NotPair" || Status == skip) continue;
+        else if (Status == "FwdOnly") Mis[Max] += 1.;
+        else if (Status == "RevOnly") Mis[Max2] += 1.;
+        else if (Status == "PropPair") Obs[ObsI] += 1.;
+        else if (Status == "PartialPair") {
+          const bool s1 = Cigar1.find('S') != std::string::npos, s2 = Cigar2.find('S') != std::string::npos;
+          if (!s1 && s2) Mis[(Flag1 & 16) ? Max2 : Max] += 1.;          // read 1 whole: censored on the side it maps to
+          else if (s1 && !s2) Mis[(Flag2 & 16) ? Max2 : Max] += 1.;
+          else continue;
+        } else continue;   // (the reference exits on an unknown status; its own writer produces none)
+        ++totalPair;
+      }
+      std::vector<double> F(2000, 0.), f(2000, 0.), G(2000, 0.), g(2000, 0.);
+      for (int k = 0; k < 2000; ++k) {
+        const double m = Mis[k], n = Obs[k];
+        if (k != 0) { f[k] = n / (1 - G[k - 1]) * 1 / double(totalPair); F[k] = F[k - 1] + f[k]; }
+        else { f[k] = n / double(totalPair); F[k] = f[k]; }
+        if (k != 0) { g[k] = m / (1 - F[k]) * 1 / double(totalPair); G[k] = G[k - 1] + g[k]; }
+        else { g[k] = m / double(totalPair); G[k] = g[k]; }
+      }
+      for (int k = 0; k < 2000; ++k) fsum[k] = pass == 0 ? f[k] : (fsum[k] + f[k]);
+    }
+    std::ofstream f(pre + ".AdjustedInsertSizeDist");
+    for (size_t i = 0; i < fsum.size(); ++i) f << i << "\t" << fsum[i] << std::endl;
+  }
   {   // GetInsertSizeDist's raw table, :1998-2002
     std::ofstream f(pre + ".RawInsertSizeDist");
     for (uint32_t i = 0; i != q->InsertDist.size(); ++i) f << i << "\t" << q->InsertDist[i] << std::endl;
@@ -643,6 +695,58 @@ extern "C" int fq_qc_write(fq_qc_t *q) {
     };
     f << "Median Insert Size(>=500bp) : " << median_from(500) << std::endl;
     f << "Median Insert Size(>=300bp) : " << median_from(300) << std::endl;
+  }
+  {   // GetVCF, :2185-2275 (CalLikelihood :2113-2155).  The arithmetic types are the reference's: float accumulators and priors,
+      // pow / the 0.5-minus term in double, every other log10 on a float (std::log10(float)), PHRED = (-10) * log10(x), REV_PHRED =
+      // pow(10.0, x / -10.0); the file carries the day it was written in its second line.
+    std::ofstream f(pre + ".vcf");
+    char day[100] = {0};
+    { const time_t now = time(nullptr); strftime(day, sizeof day, "%Y%m%d", localtime(&now)); }
+    f << "##fileformat=VCFv4.2\n" << "##fileDate=" << day << "\n" << "##source=VerifyBamID2\n";
+    f << "##INFO=<ID=AF,Number=A,Type=Float,Description=\"Allele Frequency, for each ALT allele, in the same order as listed\">\n";
+    f << "##FORMAT=<ID=GT,Number=1,Type=String,Description=\"Genotype\">\n";
+    f << "##FORMAT=<ID=GP,Number=1,Type=String,Description=\"Genotype\">\n";
+    f << "##FORMAT=<ID=PL,Number=G,Type=Integer,Description=\"Normalized, Phred-scaled likelihoods for genotypes as defined in the VCF specification\">\n";
+    f << "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tIntendedSample\n";
+    float alleleFrq = 0.;
+    for (auto &chr : q->vcf_table)
+      for (auto &site : chr.second) {
+        const unsigned k = site.second;
+        const fq_qc::Marker &m = q->markers[k];
+        std::string af;   // value of the INFO key AF
+        bool has_af = false;
+        for (size_t at = 0; at < m.info.size();) {
+          size_t end = m.info.find(';', at);
+          if (end == std::string::npos) end = m.info.size();
+          if (m.info.compare(at, 3, "AF=") == 0) { af = m.info.substr(at + 3, end - at - 3); has_af = true; break; }
+          at = end + 1;
+        }
+        if (!has_af) continue;
+        alleleFrq = (float)atof(af.c_str());
+        const std::string &seq = q->seq_vec[k], &qual = q->qual_vec[k];
+        if (seq.empty()) continue;
+        f << m.chrom_raw << "\t" << m.pos << "\t" << m.id << "\t" << m.ref << "\t" << m.alt << "\t" << m.qual << "\t" << m.filter << "\t";
+        f << "AF=" << af << ";AC=" << seq.size() << "\t" << "GT:PL:GP\t";
+        const char maj = m.ref[0], mnr = m.alt[0];
+        float GL0(0), GL1(0), GL2(0);
+        for (uint32_t i = 0; i != seq.size(); ++i) {
+          float seq_error = pow(10.0, (qual[i] / (-10.0)));
+          if (seq[i] == maj) { GL0 += std::log10(1 - seq_error); GL1 += std::log10(0.5 - seq_error / 3); GL2 += std::log10(seq_error / 3); }
+          else if (seq[i] == mnr) { GL0 += std::log10(seq_error / 3); GL1 += std::log10(0.5 - seq_error / 3); GL2 += std::log10(1 - seq_error); }
+          else { GL0 += std::log10(2 * seq_error / 3); GL1 += std::log10(2 * seq_error / 3); GL2 += std::log10(2 * seq_error / 3); }
+        }
+        float PL[3];
+        PL[0] = std::floor(GL0 * (-10) + 0.5); PL[1] = std::floor(GL1 * (-10) + 0.5); PL[2] = std::floor(GL2 * (-10) + 0.5);
+        float prior[3], post[3], sum;
+        prior[0] = (-10) * std::log10((1 - alleleFrq) * (1 - alleleFrq));
+        prior[1] = (-10) * std::log10(2 * alleleFrq * (1 - alleleFrq));
+        prior[2] = (-10) * std::log10(alleleFrq * alleleFrq);
+        post[0] = prior[0] + PL[0]; post[1] = prior[1] + PL[1]; post[2] = prior[2] + PL[2];
+        sum = (-10) * std::log10(pow(10.0, (post[0] / (-10.0))) + pow(10.0, (post[1] / (-10.0))) + pow(10.0, (post[2] / (-10.0))));
+        post[0] = std::floor(post[0] - sum + 0.5); post[1] = std::floor(post[1] - sum + 0.5); post[2] = std::floor(post[2] - sum + 0.5);
+        const char *gt = post[0] < post[1] ? (post[0] < post[2] ? "0/0:" : "1/1:") : (post[1] < post[2] ? "0/1:" : "1/1:");
+        f << gt << PL[0] << "," << PL[1] << "," << PL[2] << ":" << post[0] << "," << post[1] << "," << post[2] << "\n";
+      }
   }
   return FQ_OK;
 }

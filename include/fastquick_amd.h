@@ -245,7 +245,8 @@ int64_t fq_stage_dump_last(fq_ctx_t *c, char *buf, int64_t cap);
 /* ---- QC consumer --------------------------------------------------------------------------------------------------------
  * StatCollector's side of the boundary (src/StatCollector.h:151, src/BwtMapper.cpp:2047-2050): every surviving pair of a batch
  * goes through AddAlignment in input order, and ProcessCore writes <out>.InsertSizeTable .DepthDist .GCDist .EmpRepDist
- * .EmpCycleDist .RawInsertSizeDist .SexChromInfo .Pileup .FASTQ.csv .Sequence.csv .Summary, byte for byte the reference's.
+ * .EmpCycleDist .RawInsertSizeDist .AdjustedInsertSizeDist .SexChromInfo .Pileup .FASTQ.csv .Sequence.csv .Summary .vcf, byte for byte
+ * the reference's (the .vcf but for its ##fileDate line).
  * ref_prefix is the reduced reference (<index_prefix>.FASTQuick.fa): <ref_prefix>.SelectedSite.vcf, .dbSNP.subset.vcf and .gc as
  * `FASTQuick index` writes them.  One fq_qc_begin_file / fq_qc_end_file bracket per FASTQ pair (FileStatCollector). */
 typedef struct fq_qc fq_qc_t;

@@ -6,7 +6,7 @@ import subprocess
 
 import golden_util  # noqa: F401  (fixtures)
 from test_bam_writer import check_bgzf, decode_bam
-from test_qc_consumer import QC_FILES
+from test_qc_consumer import QC_FILES, qc_bytes
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -32,7 +32,7 @@ def cli_bam_and_qc(exe, g, out):
     for f in QC_FILES:
         if f in ("Summary", "FASTQ.csv"):    # (genome size: the three contigs of the .fai here, one genome in the golden run; file names)
             continue
-        assert open(out + "." + f, "rb").read() == open(os.path.join(g["dir"], "ref.qc." + f), "rb").read(), f
+        assert qc_bytes(out + "." + f) == qc_bytes(os.path.join(g["dir"], "ref.qc." + f)), f
     assert os.path.getsize(out + ".Summary") > 100
 
 
