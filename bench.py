@@ -59,7 +59,8 @@ def main() -> None:
                     help="boundary of `value`: host = packed pinned batches in, records out (SURVEY 8d); resident = inputs already in HBM")
     ap.add_argument("--no-resident", action="store_true", help="skip the resident (inputs in HBM) leg of a host-boundary run")
     ap.add_argument("--no-ontarget", action="store_true", help="skip the short on-target leg of a wgs run")
-    ap.add_argument("--ontarget-pairs", type=int, default=1 << 20, help="pairs per call of the on-target leg (one device-filling search launch)")
+    ap.add_argument("--ontarget-pairs", type=int, default=0, help="pairs per call of the on-target leg (0: the call shape of the headline leg, --pairs; the search "
+                    "stage's second round is a fixed tail plus a term in the number of reads, so its roofline fraction grows with the call: DESIGN.md 9)")
     ap.add_argument("--ontarget-ctxs", type=int, default=2)
     ap.add_argument("--ontarget-steps", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -368,6 +369,8 @@ def main() -> None:
     # ---- on-target leg: every pair from a marker flank, one device-filling search launch per call (the >= 40 % criterion of
     #      BASELINE.json is about this kernel on this mix) -------------------------------------------------------------------------------
     if args.mix == "wgs" and not args.no_ontarget:
+        if args.ontarget_pairs <= 0:
+            args.ontarget_pairs = args.pairs
         leg = run_leg("ontarget", args.ontarget_pairs, args.ontarget_ctxs, args.ontarget_steps, 1, args.boundary, 3000, max_distinct=1)
         a2 = leg["agg"]
         out["ontarget"] = {"value": round(leg["value"], 1), "unit": "pairs/s", "pairs_per_call": args.ontarget_pairs, "concurrent_streams": args.ontarget_ctxs,

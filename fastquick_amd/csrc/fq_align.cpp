@@ -889,10 +889,12 @@ int stageA_search(Call &K) {
   vector<int32_t> work(n_search), next_work;
   for (int s = 0; s < n_search; ++s) work[s] = s;
   vector<int64_t> where(n_search, -1);   // offset of s's list in h_aln (filled as results arrive)
+  bool ran_nogap = false;
   vector<uint8_t> bound_of;               // experiment: min over strands of k_width's lower bound, per read
   for (size_t tier = 0; tier < tiers.size() && !work.empty(); ++tier) {
     FqGapTier T = tiers[tier];
     if (T.nogap && (int64_t)work.size() < c->kn.gap_nogap_min) continue;   // a small launch is bound by its longest search: one round
+    if (T.nogap) ran_nogap = true;
     // Handing long searches to the wavefront-per-read kernel pays when the launch is latency-bound (few reads: its duration is
     // its longest search); a launch that fills the device several times over hides its long searches behind the others.
     // The second round of such a call is a small launch, but of hard reads only: handing them over at 1,024 pops sends tens of
@@ -927,6 +929,10 @@ int stageA_search(Call &K) {
       ga.wfull = c->d_wfull.p; ga.wstride = Lpad; ga.prec = c->d_prec.p; ga.pstride = Ppad;
       ga.pool = c->d_pool.p; ga.heads = c->d_heads.p; ga.tier = T; ga.aln = c->d_aln.p; ga.n_aln = c->d_naln.p; ga.status = c->d_status.p;
       ga.counters = c->d_counters.p; ga.queue = c->d_queue.p;
+      // The round after the one without gap children holds the hard reads only: their lengths differ by orders of magnitude, so a
+      // wavefront that waits for all 64 lanes before it refills idles most of them (28.9 -> 24.2 ms for the 228 k reads a 4.2 M-read
+      // call leaves); the first round keeps whole-wavefront refill, its reads finish together (refill by 16: 23.8 -> 25.8 ms).
+      ga.refill_min = ran_nogap && !T.nogap && !T.coop ? 16 : 0;
       // stack pools are the one large per-launch allocation (lanes x pool_cap x 16 B): when the device cannot hold them for
       // as many wavefronts as it could run, run fewer (the persistent lanes simply take more reads each)
       for (;;) {

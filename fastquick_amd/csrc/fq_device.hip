@@ -884,7 +884,7 @@ int launch_gap(const FqGapArgs &a_in) {
   if (a_in.n_work <= 0) return 0;
   FqGapArgs a = a_in;
   const int env_refill = g_cur->tune.gap_refill_min;
-  a.refill_min = env_refill > 0 ? env_refill : FQ_REFILL_MIN;
+  a.refill_min = env_refill > 0 ? env_refill : a_in.refill_min > 0 ? a_in.refill_min : FQ_REFILL_MIN;   // (tuning key, else the caller's choice for this round, else 64)
   FQ_HIP(hipMemsetAsync(a.queue, 0, 8, g_stream));
   hipEvent_t e0, e1;
   kernel_events(a.tier.nogap ? 8 : 7, &e0, &e1);   // FQ_K_GAP_NOGAP / FQ_K_GAP_KERNEL
