@@ -80,7 +80,7 @@ class Stats(C.Structure):
                 ("max_pops_per_read", C.c_uint64), ("reads_over_4k_pops", C.c_uint64), ("max_wave_trips", C.c_uint64),
                 ("host_ms_serial", C.c_double), ("host_ms_pair", C.c_double), ("host_ms_total", C.c_double),
                 ("wall_ms_total", C.c_double), ("wave_trips", C.c_uint64), ("lane_trips", C.c_uint64),
-                ("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("dbg", C.c_uint64 * 16)]
+                ("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("pairs_on_device", C.c_uint64), ("dbg", C.c_uint64 * 16)]
 
 
 EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destroy", "fq_index_l_pac",

@@ -44,11 +44,6 @@ int cal_maxdiff(int l, double err, double thres) {
   }
   return 2;
 }
-inline uint64_t hash_64(uint64_t key) {   // libbwa/bwape.h:42-53
-  key += ~(key << 32); key ^= (key >> 22); key += ~(key << 13); key ^= (key >> 8);
-  key += (key << 3); key ^= (key >> 15); key += ~(key << 27); key ^= (key >> 31);
-  return key;
-}
 template <class T> struct DevBuf {
   T *p = nullptr;
   size_t cap = 0;
@@ -186,7 +181,8 @@ struct fq_ctx {
   DevBuf<uint64_t> d_off;
   // SA
   DevBuf<FqAln> d_qaln;
-  DevBuf<uint32_t> d_qlen, d_pos, d_qrow, d_qinfo;
+  DevBuf<uint32_t> d_qlen, d_pos, d_qpos, d_qrow, d_qinfo;
+  DevBuf<FqPairJob> d_pjobs; DevBuf<FqPairRead> d_preads; DevBuf<FqPairOut> d_pout; DevBuf<FqPairIsize> d_pisize; DevBuf<int32_t> d_plut, d_glogn; DevBuf<uint64_t> d_pscratch;
   DevBuf<uint64_t> d_qoff;
   // DP
   DevBuf<FqSwTask> d_swtask;
@@ -481,78 +477,36 @@ void infer_isize(const vector<FqRead> &R, int sp_lo, int sp_hi, int max_len_all,
   if (std::isnan(ii->std) || p75 > 100000) { ii->low = ii->high = ii->high_bayesian = 0; ii->avg = ii->std = -1.0; }
 }
 
-// pairing + __pairing_aux/__pairing_aux2, libbwa/bwape.c:119-213, bwape.h:55-82 (typo at :65 reproduced)
-struct PairAcc { uint64_t o_score, subo_score, o_pos[2]; int o_n, subo_n; };
-inline void pair_try(fq_ctx *c, vector<int> &pen_lut, FqRead *p[2], const FqAln *aln[2], const fq_isize_t *ii, int max_len, uint64_t u, uint64_t v, PairAcc &A) {
-  if (u == (uint64_t)-1) return;
-  const uint32_t l = (uint32_t)(v >> 32) + (uint32_t)p[v & 1]->len - (uint32_t)(u >> 32);
-  if (!((v >> 32) > (u >> 32) && l >= (uint32_t)max_len &&
-        ((ii->high && l <= ii->high_bayesian) || (ii->high == 0 && l <= (uint32_t)c->o.max_isize)))) return;
-  uint64_t s = (uint64_t)(int64_t)(aln[v & 1][(uint32_t)v >> 1].score + aln[u & 1][(uint32_t)u >> 1].score);
-  s *= 10;
-  if (ii->high) {
-    // same libm expression as bwape.h:62, evaluated once per distinct insert size of this reference batch (l <= high_bayesian here)
-    int &pen = pen_lut[l];
-    if (pen == INT32_MIN) pen = (int)(-4.343 * log(0.5 * erfc(M_SQRT1_2 * fabs(l - ii->avg) / ii->std)) + 0.499);
-    s += (uint64_t)(int64_t)pen;
-  }
-  s = s << 32 | (uint32_t)hash_64((u >> 32 << 32) | (v >> 32));
-  if (s >> 32 == A.o_score >> 32) ++A.o_n;
-  else if (s >> 32 < A.o_score << 32) { A.subo_n += A.o_n; A.o_n = 1; }
-  else ++A.subo_n;
-  if (s < A.o_score) { A.subo_score = A.o_score; A.o_score = s; A.o_pos[u & 1] = u; A.o_pos[v & 1] = v; }
-  else if (s < A.subo_score) A.subo_score = s;
+// pairing + __pairing_aux/__pairing_aux2, libbwa/bwape.c:119-213, bwape.h:55-82: fq_pair_sweep (fq_kernels.h) is the one
+// implementation -- k_pair runs it per lane, and the host runs it for the pairs the kernel does not take.
+inline FqPairRead pair_read_of(const FqRead &p) {
+  FqPairRead r;
+  r.pos = p.pos; r.len = p.len; r.full_len = p.full_len; r.bits = (uint32_t)(p.strand & 1) | (uint32_t)(p.mapQ & 0xff) << 8 | (uint32_t)(p.seQ & 0xff) << 16;
+  return r;
 }
-inline void pair_fix(FqRead &q, const FqAln *aln[2], uint64_t w) {
-  const FqAln &r = aln[w & 1][(uint32_t)w >> 1];
-  const int ra = (int)(r.info >> 24) & 1;
+inline void pair_apply(FqRead &q, const FqPairOut &o) {
+  if (!((o.bits >> 24) & 1u)) return;            // no proper pair: the records stay as they are
+  q.mapQ = (int)(o.bits & 0xffu); q.seQ = (int)((o.bits >> 8) & 0xffu);
   q.extra_flag |= 2;
-  if (q.pos != (uint32_t)(w >> 32) || q.strand != ra) {
-    q.n_mm = r.info & 0xff; q.n_gapo = (r.info >> 8) & 0xff; q.n_gape = (r.info >> 16) & 0xff; q.strand = ra; q.score = r.score;
-    q.pos = (uint32_t)(w >> 32);
+  if ((o.bits >> 25) & 1u) {                     // the pair's hit is not the read's main hit: the record moves (bwape.c:196-211)
+    q.n_mm = o.info & 0xff; q.n_gapo = (o.info >> 8) & 0xff; q.n_gape = (o.info >> 16) & 0xff; q.strand = (int)((o.bits >> 16) & 1u); q.score = o.score;
+    q.pos = o.pos;
   }
 }
-void pair_hits(fq_ctx *c, vector<int> &pen_lut, FqRead *p[2], const FqAln *aln[2], vector<uint64_t> &arr, const fq_isize_t *ii) {
-  PairAcc A;
-  A.o_score = A.subo_score = (uint64_t)-1; A.o_n = A.subo_n = 0; A.o_pos[0] = A.o_pos[1] = 0;
-  uint64_t last[2][2] = {{(uint64_t)-1, (uint64_t)-1}, {(uint64_t)-1, (uint64_t)-1}};
-  const int max_len = std::max(p[0]->full_len, p[1]->full_len);
+// the insert-size term of bwape.h:62 for every insert size of one reference batch (libm, as the reference evaluates it per candidate)
+void pair_penalty_lut(const fq_isize_t &ii, vector<int32_t> &lut) {
+  if (!ii.high) return;
+  for (uint32_t l = 0; l <= ii.high_bayesian; ++l) {
+    const double v = -4.343 * log(0.5 * erfc(M_SQRT1_2 * fabs(l - ii.avg) / ii.std)) + 0.499;
+    lut.push_back(v >= 2147483648.0 || v != v ? INT32_MIN : (int32_t)v);   // (what the x86 conversion leaves for an infinite value)
+  }
+}
+void pair_hits(fq_ctx *c, const FqPairIsize &pi, const int32_t *lut, FqRead *p[2], const FqAln *aln[2], vector<uint64_t> &arr) {
   std::sort(arr.begin(), arr.end());
-  for (uint64_t x : arr) {
-    if (((aln[x & 1][(uint32_t)x >> 1].info >> 24) & 1) == 1) {
-      const int y = 1 - (int)(x & 1);
-      pair_try(c, pen_lut, p, aln, ii, max_len, last[y][1], x, A);
-      pair_try(c, pen_lut, p, aln, ii, max_len, last[y][0], x, A);
-    } else { last[x & 1][0] = last[x & 1][1]; last[x & 1][1] = x; }
-  }
-  if (A.o_score == (uint64_t)-1) return;
-  int mapQ_p = 0;
-  if (A.o_n == 1) {
-    if (A.subo_score == (uint64_t)-1) mapQ_p = 29;
-    else if ((A.subo_score >> 32) - (A.o_score >> 32) > (uint64_t)(c->o.s_mm * 10)) mapQ_p = 23;
-    else {
-      const int nn = A.subo_n > 255 ? 255 : A.subo_n;
-      mapQ_p = (int)(((A.subo_score >> 32) - (A.o_score >> 32)) / 2) - c->g_log_n[nn];
-      if (mapQ_p < 0) mapQ_p = 0;
-    }
-  }
-  const int rr0 = (int)(aln[A.o_pos[0] & 1][(uint32_t)A.o_pos[0] >> 1].info >> 24) & 1, rr1 = (int)(aln[A.o_pos[1] & 1][(uint32_t)A.o_pos[1] >> 1].info >> 24) & 1;
-  const bool same0 = p[0]->pos == (uint32_t)(A.o_pos[0] >> 32) && p[0]->strand == rr0;
-  const bool same1 = p[1]->pos == (uint32_t)(A.o_pos[1] >> 32) && p[1]->strand == rr1;
-  if (same0 && same1) {
-    if (p[0]->mapQ > 0 && p[1]->mapQ > 0) {
-      int mq = p[0]->mapQ + p[1]->mapQ;
-      if (mq > 60) mq = 60;
-      p[0]->mapQ = p[1]->mapQ = mq;
-    } else {
-      if (p[0]->mapQ == 0) p[0]->mapQ = mapQ_p + 7 < p[1]->mapQ ? mapQ_p + 7 : p[1]->mapQ;
-      if (p[1]->mapQ == 0) p[1]->mapQ = mapQ_p + 7 < p[0]->mapQ ? mapQ_p + 7 : p[0]->mapQ;
-    }
-  } else if (same0) { p[1]->seQ = 0; p[1]->mapQ = p[0]->mapQ; if (p[1]->mapQ > mapQ_p) p[1]->mapQ = mapQ_p; }
-  else if (same1) { p[0]->seQ = 0; p[0]->mapQ = p[1]->mapQ; if (p[0]->mapQ > mapQ_p) p[0]->mapQ = mapQ_p; }
-  else { p[0]->seQ = p[1]->seQ = 0; mapQ_p -= 20; if (mapQ_p < 0) mapQ_p = 0; p[0]->mapQ = p[1]->mapQ = mapQ_p; }
-  pair_fix(*p[0], aln, A.o_pos[0]);
-  pair_fix(*p[1], aln, A.o_pos[1]);
+  FqPairRead r[2] = {pair_read_of(*p[0]), pair_read_of(*p[1])};
+  FqPairOut out[2];
+  fq_pair_sweep(aln[0], aln[1], r, arr.data(), (uint32_t)arr.size(), pi, lut, c->g_log_n, c->o.max_isize, c->o.s_mm, out);
+  pair_apply(*p[0], out[0]); pair_apply(*p[1], out[1]);
 }
 
 }  // namespace
@@ -575,6 +529,8 @@ struct Call {
   vector<uint32_t> aln_n;
   vector<int> s_of;                    // survivor read -> search index or -1
   vector<uint64_t> read_nocc, aln_row_off;
+  vector<uint32_t> q_first;            // survivor read -> its first hit in the list k_sa enumerated (valid when enumerated)
+  uint64_t n_rows = 0;
   vector<char> enumerated;
   const uint32_t *h_pos = nullptr;     // positions of the enumerated SA rows (pinned staging of the context)
   vector<fq_isize_t> iis;
@@ -1021,6 +977,7 @@ int stage_sa_rows(Call &K) {
   vector<FqRead> &R = c->st.reads;
   K.read_nocc.assign((size_t)n_surv * 2, 0);
   K.enumerated.assign((size_t)n_surv * 2, 0);
+  K.q_first.assign((size_t)n_surv * 2, 0);
   K.aln_row_off.assign(c->st.aln.size() + 1, ~0ull);   // per hit in S.aln order -> offset into h_pos
   const uint32_t multi_cap = (uint32_t)std::max(o.n_multi, o.N_multi) + 1;
   parallel_chunks(R.size(), K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
@@ -1043,6 +1000,7 @@ int stage_sa_rows(Call &K) {
       if (na == 0) continue;
       if (!(pair_ok || K.read_nocc[idx] <= multi_cap)) continue;
       K.enumerated[idx] = 1;
+      K.q_first[idx] = (uint32_t)q_aln.size();
       const uint64_t base = K.aln_off[K.s_of[idx]];
       for (int k = 0; k < na; ++k) {
         K.aln_row_off[base + k] = rows;
@@ -1052,6 +1010,7 @@ int stage_sa_rows(Call &K) {
     }
   }
   q_off.push_back(rows);
+  K.n_rows = rows;
   CKM(c->p_pos.ensure(rows + 1));
   K.h_pos = c->p_pos.p;
   if (rows) {
@@ -1095,16 +1054,16 @@ int stageB1_main_hit(Call &K) {
     }
   if (!dq_row.empty()) {   // main hits of very repetitive reads whose rows were not enumerated
     const size_t nq = dq_row.size();
-    CKM(c->d_qrow.ensure(nq) && c->d_qinfo.ensure(nq) && c->d_pos.ensure(nq));
+    CKM(c->d_qrow.ensure(nq) && c->d_qinfo.ensure(nq) && c->d_qpos.ensure(nq));   // (d_pos keeps the enumerated rows: k_pair reads them)
     CKS(h2d_staged(c, c->d_qrow.p, dq_row.data(), nq * 4));
     CKS(h2d_staged(c, c->d_qinfo.p, dq_info.data(), nq * 4));
     FqSaQueryArgs qa{};
-    qa.ix = ix->dev; qa.row = c->d_qrow.p; qa.info = c->d_qinfo.p; qa.n = (uint32_t)nq; qa.pos = c->d_pos.p; qa.counters = c->d_counters.p;
+    qa.ix = ix->dev; qa.row = c->d_qrow.p; qa.info = c->d_qinfo.p; qa.n = (uint32_t)nq; qa.pos = c->d_qpos.p; qa.counters = c->d_counters.p;
     fqdev::time_begin(FQ_K_SA);
     CK(fqdev::launch_saq(qa));
     fqdev::time_end(FQ_K_SA);
     vector<uint32_t> tmp(nq);
-    CKS(d2h_staged(c, tmp.data(), c->d_pos.p, nq * 4));
+    CKS(d2h_staged(c, tmp.data(), c->d_qpos.p, nq * 4));
     CKS(sync_staged(c));
     for (size_t i = 0; i < nq; ++i) R[dq_idx[i]].pos = tmp[i];
     c->stats.sa_rows += nq;
@@ -1169,28 +1128,87 @@ void stage_kl_cache(Call &K) {
 }
 
 // ---- stage B3: pairing + XA lists (per pair) -------------------------------------------------------------
-void stageB3_pairing(Call &K) {
+int stageB3_pairing(Call &K) {
   fq_ctx *c = K.c;
   const fq_opts_t &o = c->o;
   const int n_surv = K.n_surv;
   vector<FqRead> &R = c->st.reads;
   const uint32_t *h_pos = K.h_pos;
-  auto both_mapped = [&](int sp) {
-    const FqRead &a = R[2 * sp], &b = R[2 * sp + 1];
-    return (a.type == FQ_TYPE_UNIQUE || a.type == FQ_TYPE_REPEAT) && (b.type == FQ_TYPE_UNIQUE || b.type == FQ_TYPE_REPEAT) &&
-           K.read_nocc[2 * sp] <= o.max_occ && K.read_nocc[2 * sp + 1] <= o.max_occ;
-  };
+  auto mapped = [&](const FqRead &a) { return a.type == FQ_TYPE_UNIQUE || a.type == FQ_TYPE_REPEAT; };
+  // insert-size penalty tables, one per reference batch
+  vector<FqPairIsize> pis(K.n_sub);
+  vector<int32_t> lut;
   for (int sb = 0; sb < K.n_sub; ++sb) {
-    const fq_isize_t ii = K.iis[sb];
+    pis[sb].high = K.iis[sb].high; pis[sb].high_bayesian = K.iis[sb].high_bayesian; pis[sb].lut_off = (int32_t)lut.size(); pis[sb].pad = 0;
+    pair_penalty_lut(K.iis[sb], lut);
+  }
+  // ---- the pairs k_pair takes: both reads mapped and enumerated, no interval of 1,000 rows or more (those take their positions from
+  //      the (k,l) cache, Q6), at most kPairLaneRows rows together.  Everything k_pair needs but the reads' current records is on
+  //      the device already: the hits and their rows' positions as k_sa left them.
+  const uint32_t kPairLaneRows = 64;
+  vector<char> on_device((size_t)n_surv, 0);
+  vector<uint32_t> job_of((size_t)n_surv + 1, 0);   // exclusive prefix count of on_device
+  vector<uint8_t> sub_of;                            // reference batch of a survivor pair
+  sub_of.resize((size_t)n_surv);
+  for (int sb = 0; sb < K.n_sub; ++sb) std::fill(sub_of.begin() + K.sub_lo[sb], sub_of.begin() + K.sub_lo[sb + 1], (uint8_t)sb);
+  parallel_chunks((size_t)n_surv, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
+    for (size_t sp = lo; sp < hi; ++sp) {
+      const FqRead &p0 = R[2 * sp], &p1 = R[2 * sp + 1];
+      on_device[sp] = mapped(p0) && mapped(p1) && K.read_nocc[2 * sp] <= o.max_occ && K.read_nocc[2 * sp + 1] <= o.max_occ &&
+                      K.enumerated[2 * sp] && K.enumerated[2 * sp + 1] && K.read_nocc[2 * sp] + K.read_nocc[2 * sp + 1] <= kPairLaneRows;
+    }
+  });
+  for (int sp = 0; sp < n_surv; ++sp) job_of[sp + 1] = job_of[sp] + (on_device[sp] ? 1u : 0u);
+  const size_t nj = job_of[n_surv];
+  if (nj) {
+    CKM(c->d_pjobs.ensure(nj) && c->d_preads.ensure(2 * nj) && c->d_pout.ensure(2 * nj) && c->d_pisize.ensure(pis.size()) && c->d_plut.ensure(lut.size() + 1) &&
+        c->d_glogn.ensure(256) && c->d_pscratch.ensure(K.n_rows + 1));
+    FqPairJob *jobs = (FqPairJob *)c->arena.alloc(nj * sizeof(FqPairJob));          // filled where the copy engine reads them
+    FqPairRead *jreads = (FqPairRead *)c->arena.alloc(2 * nj * sizeof(FqPairRead));
+    FqPairOut *jout = (FqPairOut *)c->arena.alloc(2 * nj * sizeof(FqPairOut));
+    if (!jobs || !jreads || !jout) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
+    parallel_chunks((size_t)n_surv, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
+      for (size_t sp = lo; sp < hi; ++sp) {
+        if (!on_device[sp]) continue;
+        const size_t t = job_of[sp];
+        FqPairJob &jb = jobs[t];
+        jb.q0 = K.q_first[2 * sp]; jb.na0 = K.aln_n[K.s_of[2 * sp]]; jb.q1 = K.q_first[2 * sp + 1]; jb.na1 = K.aln_n[K.s_of[2 * sp + 1]]; jb.batch = sub_of[sp];
+        jreads[2 * t] = pair_read_of(R[2 * sp]); jreads[2 * t + 1] = pair_read_of(R[2 * sp + 1]);
+      }
+    });
+    CK(fqdev::copy_pinned(c->d_pjobs.p, jobs, nj * sizeof(FqPairJob), 1));
+    CK(fqdev::copy_pinned(c->d_preads.p, jreads, 2 * nj * sizeof(FqPairRead), 1));
+    CKS(h2d_staged(c, c->d_pisize.p, pis.data(), pis.size() * sizeof(FqPairIsize)));
+    if (!lut.empty()) CKS(h2d_staged(c, c->d_plut.p, lut.data(), lut.size() * 4));
+    CKS(h2d_staged(c, c->d_glogn.p, c->g_log_n, 256 * 4));
+    c->stats.h2d_bytes += nj * (sizeof(FqPairJob) + 2 * sizeof(FqPairRead)) + lut.size() * 4;
+    FqPairArgs pa{};
+    pa.jobs = c->d_pjobs.p; pa.n_jobs = (int32_t)nj; pa.reads = c->d_preads.p; pa.aln = c->d_qaln.p; pa.row_off = c->d_qoff.p; pa.pos = c->d_pos.p;
+    pa.scratch = c->d_pscratch.p; pa.isize = c->d_pisize.p; pa.lut = c->d_plut.p; pa.g_log_n = c->d_glogn.p; pa.max_isize = o.max_isize; pa.s_mm = o.s_mm;
+    pa.out = c->d_pout.p;
+    fqdev::time_begin(FQ_K_SA);       // (counted with the stage that enumerates the hits' positions)
+    CK(fqdev::launch_pair(pa));
+    fqdev::time_end(FQ_K_SA);
+    CK(fqdev::copy_pinned(jout, c->d_pout.p, 2 * nj * sizeof(FqPairOut), 0));
+    CKS(sync_staged(c));
+    c->stats.d2h_bytes += 2 * nj * sizeof(FqPairOut);
+    c->stats.pairs_on_device += nj;
+    parallel_chunks((size_t)n_surv, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
+      for (size_t sp = lo; sp < hi; ++sp)
+        if (on_device[sp]) { const size_t t = job_of[sp]; pair_apply(R[2 * sp], jout[2 * t]); pair_apply(R[2 * sp + 1], jout[2 * t + 1]); }
+    });
+  }
+  // ---- the other pairs (host, the same routine), and the XA lists of every read
+  for (int sb = 0; sb < K.n_sub; ++sb) {
+    const FqPairIsize pi = pis[sb];
     parallel_chunks((size_t)(K.sub_lo[sb + 1] - K.sub_lo[sb]), K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
       vector<uint64_t> arr;
-      vector<int> pen_lut((size_t)ii.high_bayesian + 2, INT32_MIN);   // memo of the insert-size penalty (same libm expression per insert size)
       for (int sp = K.sub_lo[sb] + (int)lo; sp < K.sub_lo[sb] + (int)hi; ++sp) {
         FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
         const FqAln *aln[2]; int na[2];
         aln[0] = K.aln_of(2 * sp, &na[0]); aln[1] = K.aln_of(2 * sp + 1, &na[1]);
-        const bool m0 = p[0]->type == FQ_TYPE_UNIQUE || p[0]->type == FQ_TYPE_REPEAT, m1 = p[1]->type == FQ_TYPE_UNIQUE || p[1]->type == FQ_TYPE_REPEAT;
-        if (m0 && m1) {
+        const bool m0 = mapped(*p[0]), m1 = mapped(*p[1]);
+        if (m0 && m1 && !on_device[sp]) {
           if (K.read_nocc[2 * sp] > o.max_occ || K.read_nocc[2 * sp + 1] > o.max_occ) continue;   // BwtMapper.cpp:797-811: such a pair gets no XA list either
           arr.clear();
           for (int j = 0; j < 2; ++j) {
@@ -1204,7 +1222,7 @@ void stageB3_pairing(Call &K) {
               for (uint32_t t = 0; t < np; ++t) arr.push_back((uint64_t)ps[t] << 32 | (uint64_t)(k << 1) | (uint64_t)j);
             }
           }
-          pair_hits(c, pen_lut, p, aln, arr, &ii);
+          pair_hits(c, pi, lut.data(), p, aln, arr);
         }
         if (o.N_multi || o.n_multi)
           for (int j = 0; j < 2; ++j) {
@@ -1219,6 +1237,7 @@ void stageB3_pairing(Call &K) {
       }
     });
   }
+  return FQ_OK;
 }
 
 // ---- stage C: mate rescue by Smith-Waterman (bwa_paired_sw, libbwa/bwape.c:463-625) ---------------------
@@ -1580,7 +1599,7 @@ int run_call(fq_ctx *c, fq_result_batch_t *out) {
   if (c->after_serial) c->after_serial(c->hook_user);
   K.t_serial1 = now_ms();
   K.trace("B2 isize");
-  stageB3_pairing(K);
+  if ((rc = stageB3_pairing(K))) return rc;
   K.trace("B3 pairing+XA");
   if (c->debug) S.stage_P = S.reads;   // snapshot for the stage dump (tests)
   if ((rc = stageC_mate_sw(K))) return rc;

@@ -73,6 +73,7 @@ int launch_scan(const uint32_t *in, uint64_t *out, uint32_t n);
 int launch_pack_aln(const FqAln *aln, const uint32_t *n_aln, const uint64_t *off, uint32_t cap, uint32_t n_work, FqAln *packed);
 int launch_sa(const FqSaArgs &a);
 int launch_saq(const FqSaQueryArgs &a);
+int launch_pair(const FqPairArgs &a);   // pairing of both-mapped pairs (fq_pair_thread)
 int launch_sw(const FqSwArgs &a);          // one task per wavefront (window + query in LDS)
 int launch_sw_serial(const FqSwArgs &a);   // one task per lane out of the task's global scratch: any window size
 int launch_refine(const FqRefineArgs &a);

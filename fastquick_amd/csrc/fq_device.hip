@@ -259,6 +259,10 @@ __global__ void __launch_bounds__(256) k_sa(FqSaArgs a) {
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q < a.n_rows) fq_sa_thread(a, q);
 }
+__global__ void __launch_bounds__(256) k_pair(FqPairArgs a) {   // one pair per lane
+  const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
+  if (t < a.n_jobs) fq_pair_thread(a, t);
+}
 __global__ void __launch_bounds__(256) k_saq(FqSaQueryArgs a) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < a.n) fq_saq_thread(a, q);
@@ -916,6 +920,12 @@ int launch_sa(const FqSaArgs &a) {
 int launch_saq(const FqSaQueryArgs &a) {
   if (!a.n) return 0;
   hipLaunchKernelGGL(k_saq, dim3(nblk(a.n, 256)), dim3(256), 0, g_stream, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+int launch_pair(const FqPairArgs &a) {
+  if (a.n_jobs <= 0) return 0;
+  hipLaunchKernelGGL(k_pair, dim3(nblk((uint64_t)a.n_jobs, 256)), dim3(256), 0, g_stream, a);
   FQ_HIP(hipGetLastError());
   return 0;
 }

@@ -2237,3 +2237,123 @@ FQ_HD void fq_md_thread(const FqMdArgs &A, int t) {
   else { dst[at] = 0; A.md_len[t] = at; A.md_sz[t] = (uint32_t)at + 1; }
   A.nm[t] = nm;
 }
+
+// ---- K_pair: paired-end pairing (pairing, libbwa/bwape.c:119-213; __pairing_aux / __pairing_aux2, bwape.h:55-82) --------------
+// One lane per pair whose two reads are both mapped: every position of every hit of both reads (the rows k_sa resolved) becomes
+// x = pos << 32 | hit index << 1 | end, the list is sorted, and one sweep keeps the last two forward hits of each end and tries
+// them against every reverse hit of the other.  The insert-size term of a pair's score is (int)(-4.343 * log(.5 * erfc(...)) + .499),
+// an integer-valued function of the insert size for one reference batch: the host evaluates it with its libm for every insert size
+// up to high_bayesian and the kernel looks it up, so the scores are the reference's to the last bit.  The same routine is what
+// the host runs for the pairs the kernel does not take (an interval of >= 1,000 rows: its positions are those of the (k,l)
+// cache's first requester; more rows than a lane's scratch).
+struct FqPairRead { uint32_t pos; int32_t len, full_len; uint32_t bits; };   // bits: strand | mapQ << 8 | seQ << 16
+struct FqPairOut { uint32_t pos, info; int32_t score; uint32_t bits; };      // info: n_mm | n_gapo << 8 | n_gape << 16; bits: mapQ | seQ << 8 | strand << 16 | paired << 24 | moved << 25
+struct FqPairIsize { uint32_t high, high_bayesian; int32_t lut_off, pad; };  // of one reference batch; lut[lut_off + l], l <= high_bayesian
+struct FqPairJob { uint32_t q0, na0, q1, na1, batch; };                       // the reads' hits: aln[q0 .. q0 + na0), aln[q1 .. q1 + na1)
+struct FqPairArgs {
+  const FqPairJob *jobs;
+  int32_t n_jobs;
+  const FqPairRead *reads;    // [2 * n_jobs]
+  const FqAln *aln;           // the hits k_sa enumerated, reads' lists consecutive
+  const uint64_t *row_off;    // per hit: its first row in pos
+  const uint32_t *pos;
+  uint64_t *scratch;          // as long as pos: a pair's list is built where its rows are
+  const FqPairIsize *isize;
+  const int32_t *lut, *g_log_n;
+  int32_t max_isize, s_mm;
+  FqPairOut *out;             // [2 * n_jobs]
+};
+FQ_HD uint64_t fq_hash_64(uint64_t key) {   // libbwa/bwape.h:42-53
+  key += ~(key << 32); key ^= (key >> 22); key += ~(key << 13); key ^= (key >> 8);
+  key += (key << 3); key ^= (key >> 15); key += ~(key << 27); key ^= (key >> 31);
+  return key;
+}
+struct FqPairAcc { uint64_t o_score, subo_score, o_pos0, o_pos1; int o_n, subo_n; };
+FQ_HD void fq_pair_try(const FqAln *aln0, const FqAln *aln1, const FqPairRead *r, const FqPairIsize &ii, const int32_t *lut, int max_isize, int max_len,
+                       uint64_t u, uint64_t v, FqPairAcc &A) {
+  if (u == (uint64_t)-1) return;
+  const uint32_t l = (uint32_t)(v >> 32) + (uint32_t)r[v & 1].len - (uint32_t)(u >> 32);
+  if (!((v >> 32) > (u >> 32) && l >= (uint32_t)max_len && ((ii.high && l <= ii.high_bayesian) || (ii.high == 0 && l <= (uint32_t)max_isize)))) return;
+  const FqAln &av = ((v & 1) ? aln1 : aln0)[(uint32_t)v >> 1], &au = ((u & 1) ? aln1 : aln0)[(uint32_t)u >> 1];
+  uint64_t s = (uint64_t)(int64_t)(av.score + au.score);
+  s *= 10;
+  if (ii.high) s += (uint64_t)(int64_t)lut[ii.lut_off + (int32_t)l];   // bwape.h:62
+  s = s << 32 | (uint32_t)fq_hash_64((u >> 32 << 32) | (v >> 32));
+  if (s >> 32 == A.o_score >> 32) ++A.o_n;
+  else if (s >> 32 < A.o_score << 32) { A.subo_n += A.o_n; A.o_n = 1; }   // (the typo of bwape.h:65, reproduced)
+  else ++A.subo_n;
+  if (s < A.o_score) { A.subo_score = A.o_score; A.o_score = s; if (u & 1) A.o_pos1 = u; else A.o_pos0 = u; if (v & 1) A.o_pos1 = v; else A.o_pos0 = v; }
+  else if (s < A.subo_score) A.subo_score = s;
+}
+// arr: the pair's sorted list.  out[e].bits bit 24 clear: no proper pair, the records stay as they are.
+FQ_HD void fq_pair_sweep(const FqAln *aln0, const FqAln *aln1, const FqPairRead *r, const uint64_t *arr, uint32_t n, const FqPairIsize &ii,
+                         const int32_t *lut, const int32_t *g_log_n, int max_isize, int s_mm, FqPairOut *out) {
+  FqPairAcc A;
+  A.o_score = A.subo_score = (uint64_t)-1; A.o_n = A.subo_n = 0; A.o_pos0 = A.o_pos1 = 0;
+  uint64_t l00 = (uint64_t)-1, l01 = (uint64_t)-1, l10 = (uint64_t)-1, l11 = (uint64_t)-1;   // last[end][0..1]
+  const int max_len = r[0].full_len > r[1].full_len ? r[0].full_len : r[1].full_len;
+  for (uint32_t i = 0; i < n; ++i) {
+    const uint64_t x = arr[i];
+    const FqAln &ax = ((x & 1) ? aln1 : aln0)[(uint32_t)x >> 1];
+    if (((ax.info >> 24) & 1u) == 1u) {
+      const bool other1 = (x & 1) == 0;      // try against the other end's forward hits
+      fq_pair_try(aln0, aln1, r, ii, lut, max_isize, max_len, other1 ? l11 : l01, x, A);
+      fq_pair_try(aln0, aln1, r, ii, lut, max_isize, max_len, other1 ? l10 : l00, x, A);
+    } else if (x & 1) { l10 = l11; l11 = x; }
+    else { l00 = l01; l01 = x; }
+  }
+  out[0].bits = out[1].bits = 0; out[0].pos = out[1].pos = 0; out[0].info = out[1].info = 0; out[0].score = out[1].score = 0;
+  if (A.o_score == (uint64_t)-1) return;
+  int mapQ_p = 0;
+  if (A.o_n == 1) {
+    if (A.subo_score == (uint64_t)-1) mapQ_p = 29;
+    else if ((A.subo_score >> 32) - (A.o_score >> 32) > (uint64_t)(s_mm * 10)) mapQ_p = 23;
+    else {
+      const int nn = A.subo_n > 255 ? 255 : A.subo_n;
+      mapQ_p = (int)(((A.subo_score >> 32) - (A.o_score >> 32)) / 2) - g_log_n[nn];
+      if (mapQ_p < 0) mapQ_p = 0;
+    }
+  }
+  const FqAln &b0 = aln0[(uint32_t)A.o_pos0 >> 1], &b1 = aln1[(uint32_t)A.o_pos1 >> 1];
+  const int rr0 = (int)(b0.info >> 24) & 1, rr1 = (int)(b1.info >> 24) & 1;
+  int mq0 = (int)(r[0].bits >> 8) & 0xff, mq1 = (int)(r[1].bits >> 8) & 0xff, sq0 = (int)(r[0].bits >> 16) & 0xff, sq1 = (int)(r[1].bits >> 16) & 0xff;
+  const bool same0 = r[0].pos == (uint32_t)(A.o_pos0 >> 32) && (int)(r[0].bits & 1u) == rr0;
+  const bool same1 = r[1].pos == (uint32_t)(A.o_pos1 >> 32) && (int)(r[1].bits & 1u) == rr1;
+  if (same0 && same1) {
+    if (mq0 > 0 && mq1 > 0) {
+      int mq = mq0 + mq1;
+      if (mq > 60) mq = 60;
+      mq0 = mq1 = mq;
+    } else {
+      if (mq0 == 0) mq0 = mapQ_p + 7 < mq1 ? mapQ_p + 7 : mq1;
+      if (mq1 == 0) mq1 = mapQ_p + 7 < mq0 ? mapQ_p + 7 : mq0;
+    }
+  } else if (same0) { sq1 = 0; mq1 = mq0; if (mq1 > mapQ_p) mq1 = mapQ_p; }
+  else if (same1) { sq0 = 0; mq0 = mq1; if (mq0 > mapQ_p) mq0 = mapQ_p; }
+  else { sq0 = sq1 = 0; mapQ_p -= 20; if (mapQ_p < 0) mapQ_p = 0; mq0 = mq1 = mapQ_p; }
+  out[0].pos = (uint32_t)(A.o_pos0 >> 32); out[0].info = b0.info & 0xffffffu; out[0].score = b0.score;
+  out[0].bits = (uint32_t)mq0 | (uint32_t)sq0 << 8 | (uint32_t)rr0 << 16 | 1u << 24 | (same0 ? 0u : 1u << 25);
+  out[1].pos = (uint32_t)(A.o_pos1 >> 32); out[1].info = b1.info & 0xffffffu; out[1].score = b1.score;
+  out[1].bits = (uint32_t)mq1 | (uint32_t)sq1 << 8 | (uint32_t)rr1 << 16 | 1u << 24 | (same1 ? 0u : 1u << 25);
+}
+// one pair: list its rows, sort (a handful of entries for all but repeats: insertion sort where the rows lie), sweep
+FQ_HD void fq_pair_thread(const FqPairArgs &A, int t) {
+  const FqPairJob jb = A.jobs[t];
+  const FqAln *aln0 = A.aln + jb.q0, *aln1 = A.aln + jb.q1;
+  uint64_t *arr = A.scratch + A.row_off[jb.q0];
+  uint32_t n = 0;
+  for (int j = 0; j < 2; ++j) {
+    const uint32_t q = j ? jb.q1 : jb.q0, na = j ? jb.na1 : jb.na0;
+    for (uint32_t k = 0; k < na; ++k) {
+      const uint32_t wdt = A.aln[q + k].l - A.aln[q + k].k + 1;
+      const uint32_t *ps = A.pos + A.row_off[q + k];
+      for (uint32_t z = 0; z < wdt; ++z) {
+        const uint64_t x = (uint64_t)ps[z] << 32 | (uint64_t)(k << 1) | (uint64_t)j;
+        uint32_t at = n++;
+        while (at > 0 && arr[at - 1] > x) { arr[at] = arr[at - 1]; --at; }
+        arr[at] = x;
+      }
+    }
+  }
+  fq_pair_sweep(aln0, aln1, A.reads + 2 * (size_t)t, arr, n, A.isize[jb.batch], A.lut, A.g_log_n, A.max_isize, A.s_mm, A.out + 2 * (size_t)t);
+}

@@ -306,6 +306,7 @@ typedef struct {
   uint64_t wave_trips;          /* loop iterations summed over the gap kernel's wavefronts */
   uint64_t lane_trips;          /* ... summed over lanes that held a read in that iteration (wave_trips x 64 = all slots) */
   uint64_t h2d_bytes, d2h_bytes; /* bytes the calls moved over PCIe (inputs, task lists; results) */
+  uint64_t pairs_on_device;     /* both-mapped pairs whose pairing (libbwa/bwape.c:119-213) ran in k_pair; the rest ran the same routine on the host */
   uint64_t dbg[16];             /* experiment counters of instrumented builds (-DFQ_GAP_INSTR), zero otherwise */
 } fq_stats_t;
 void fq_stats_get(const fq_ctx_t *c, fq_stats_t *out);

@@ -104,6 +104,7 @@ int launch_pack_aln(const FqAln *aln, const uint32_t *n_aln, const uint64_t *off
 }
 int launch_sa(const FqSaArgs &a) { for (uint64_t q = 0; q < a.n_rows; ++q) fq_sa_thread(a, q); return 0; }
 int launch_saq(const FqSaQueryArgs &a) { for (uint32_t q = 0; q < a.n; ++q) fq_saq_thread(a, q); return 0; }
+int launch_pair(const FqPairArgs &a) { for (int t = 0; t < a.n_jobs; ++t) fq_pair_thread(a, t); return 0; }
 int launch_sw(const FqSwArgs &a) { for (int t = 0; t < a.n_task; ++t) fq_sw_thread(a, t); return 0; }
 int launch_sw_serial(const FqSwArgs &a) { return launch_sw(a); }
 int launch_refine(const FqRefineArgs &a) { for (int t = 0; t < a.n_task; ++t) fq_refine_thread(a, t); return 0; }

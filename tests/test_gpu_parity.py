@@ -57,6 +57,8 @@ def test_gpu_matches_reference_golden(tag, golden_cases, lib, search_mode):
     assert not diffs, "\n".join(diffs)
     assert filecmp.cmp(g["sam"], sam, shallow=False)
     assert stats["kernel_launches"][2] > 0, "the gap-search kernel did not run on the device"
+    if tag in ("basic", "repeat", "qc"):
+        assert stats["pairs_on_device"] > 0, "k_pair did not run"
     if search_mode.startswith("wave") or (search_mode == "handover" and tag != "cfg0_example"):   # (cfg0_example searches one pair: its reads stop before the 64-pop check)
         assert stats["tier_retries"] > 0, "the wavefront-per-read kernel was not exercised"
 

@@ -40,11 +40,14 @@ def test_emulated_pipeline_matches_reference_golden(tag, mode, golden_cases, emu
     al = api.Aligner(ix, api.default_opts(emu_lib, trim_qual=g["trim_qual"], host_threads=3 if mode == "threads" else 0), max_pairs=max(16, g["batch"]), debug=True, tuning=tuning)
     st, sam = os.path.join(g["dir"], "emu.stages"), os.path.join(g["dir"], "emu.sam")
     api.align_stream(al, names, seq, qual, lens, g["batch"], st, sam, packed=mode.startswith("packed"))
+    stats = al.stats()
     al.close()
     ix.close()
     diffs = [d for d in ob.diff_stage_files(g["stages"], st)]
     assert not diffs, "\n".join(diffs)
     assert filecmp.cmp(g["sam"], sam, shallow=False)
+    if tag in ("basic", "repeat", "qc"):
+        assert stats["pairs_on_device"] > 0, "the pairing kernel body (fq_pair_thread) was not exercised"
 
 
 def test_option_limits_are_rejected(golden_cases, emu_lib):
