@@ -63,6 +63,7 @@ def main() -> None:
                     "stage's second round is a fixed tail plus a term in the number of reads, so its roofline fraction grows with the call: DESIGN.md 9)")
     ap.add_argument("--ontarget-ctxs", type=int, default=2)
     ap.add_argument("--ontarget-steps", type=int, default=3)
+    ap.add_argument("--ontarget-tput-ctxs", type=int, default=16, help="streams of the on-target throughput leg (1,048,576 pairs per call; 0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="pairs per slice for the CPU baseline (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=32, help="independent streams (threads) of the CPU baseline")
@@ -391,6 +392,13 @@ def main() -> None:
                                            "alg_GBps": round(g1, 2), "frac_of_hbm_peak": round(g1 / HBM_PEAK_GBS, 5)}
             if "fq_gap" in solo:
                 out["ontarget"]["gap_solo"] = dict(solo["fq_gap"], kernels={k: v for k, v in solo.items() if k != "fq_gap"})
+        # the same mix as a throughput job: many streams of ordinary calls, so that one stream's host phases (main-hit choice in read
+        # order, insert-size inference, record assembly) run under the kernels of the others
+        if args.ontarget_tput_ctxs > 0:
+            leg = run_leg("ontarget", 1 << 20, args.ontarget_tput_ctxs, 2, 1, args.boundary, 3000, max_distinct=1)
+            out["ontarget"]["throughput"] = {"value": round(leg["value"], 1), "unit": "pairs/s", "pairs_per_call": 1 << 20, "concurrent_streams": args.ontarget_tput_ctxs,
+                                             "steps": 2, "ms_per_step": round(1e3 * leg["elapsed"] / 2, 3),
+                                             "host_ms_per_call": round(leg["agg"]["host_ms_total"] / leg["calls"], 3)}
 
     # ---- CPU baseline: the oracle (a port) on a bounded sample of the same workload, rank 0, N=1 only -----------
     # Three geometries, a few seconds each:

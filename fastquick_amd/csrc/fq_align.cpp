@@ -21,6 +21,8 @@
 #include <mutex>
 #include <thread>
 #include <vector>
+#include <pthread.h>
+#include <sched.h>
 
 #include "../../include/fastquick_amd.h"
 #include "fq_backend.h"
@@ -374,6 +376,51 @@ namespace {
 
 // The per-pair host phases are independent across pairs (everything order-dependent -- the drand48 stream, the insert-size
 // chain, the (k,l) position cache -- is handled serially before them), so large batches are split over a few threads.
+// The worker threads of a call stay on the NUMA node of the thread that drives it: the per-read records are walked serially (main
+// hit choice in read order, insert sizes) right after phases that touch them in parallel, and on a two-socket host every record a
+// worker on the other socket touched comes back over the socket link (main-hit phase of a 1 M-pair on-target call: 26 vs 78 ms).
+struct NodeCpus { std::vector<cpu_set_t> sets; std::vector<int> node_of_cpu; };
+static const NodeCpus &node_cpus() {
+  static const NodeCpus nc = [] {
+    NodeCpus r;
+    for (int node = 0; node < 64; ++node) {
+      char path[96];
+      snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+      FILE *f = fopen(path, "r");
+      if (!f) break;
+      char buf[4096];
+      cpu_set_t set; CPU_ZERO(&set);
+      if (fgets(buf, sizeof buf, f))
+        for (char *tok = strtok(buf, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+          int a = 0, b = 0;
+          const int k = sscanf(tok, "%d-%d", &a, &b);
+          if (k == 1) b = a;
+          if (k >= 1) for (int cpu = a; cpu <= b && cpu < CPU_SETSIZE; ++cpu) { CPU_SET(cpu, &set); if ((int)r.node_of_cpu.size() <= cpu) r.node_of_cpu.resize(cpu + 1, -1); r.node_of_cpu[cpu] = node; }
+        }
+      fclose(f);
+      r.sets.push_back(set);
+    }
+    return r;
+  }();
+  return nc;
+}
+// For the duration of a call the driving thread narrows its affinity to the CPUs of the node it is on (within the mask it was
+// given), and restores it on return; threads it creates inherit the mask.
+struct NodePin {
+  cpu_set_t old;
+  bool changed = false;
+  NodePin() {
+    const NodeCpus &nc = node_cpus();
+    const int cpu = sched_getcpu();
+    if (nc.sets.size() < 2 || cpu < 0 || cpu >= (int)nc.node_of_cpu.size() || nc.node_of_cpu[cpu] < 0) return;
+    if (pthread_getaffinity_np(pthread_self(), sizeof old, &old) != 0) return;
+    cpu_set_t want;
+    CPU_AND(&want, &old, &nc.sets[nc.node_of_cpu[cpu]]);
+    if (CPU_COUNT(&want) == 0 || CPU_EQUAL(&want, &old)) return;
+    changed = pthread_setaffinity_np(pthread_self(), sizeof want, &want) == 0;
+  }
+  ~NodePin() { if (changed) pthread_setaffinity_np(pthread_self(), sizeof old, &old); }
+};
 template <class F>
 void parallel_chunks(size_t n, int threads, size_t par_min, F fn) {   // fn(lo, hi, thread index); below par_min items the phase stays on the calling thread
   if (threads <= 1 || n < par_min) { fn((size_t)0, n, 0); return; }
@@ -455,7 +502,13 @@ void infer_isize(const vector<FqRead> &R, int sp_lo, int sp_hi, int max_len_all,
   const int tot = (int)is.size();
   int max_len = std::max(1, max_len_all);
   if (tot < 20) return;
-  std::sort(is.begin(), is.end());
+  if (tot < 4096) std::sort(is.begin(), is.end());
+  else {   // every value is below 100,000: a counting sort leaves the same sorted array
+    vector<uint32_t> cnt(100000, 0);
+    for (uint64_t v : is) ++cnt[v];
+    size_t at = 0;
+    for (uint32_t v = 0; v < 100000; ++v) for (uint32_t k = cnt[v]; k; --k) is[at++] = v;
+  }
   const int p25 = (int)is[(int)(tot * 0.25 + 0.5)], p75 = (int)is[(int)(tot * 0.75 + 0.5)];
   const int tmp = (int)(p25 - 2.0 * (p75 - p25) + .499);
   ii->low = (uint32_t)(tmp > max_len ? tmp : max_len);
@@ -603,6 +656,7 @@ int stage0_ascii(Call &K) {
   CKS(d2h_staged(c, counts, c->d_counts.p, 8));
   CKS(d2h_staged(c, c->h_sub_max.data(), c->d_sub_max.p, (size_t)n_sub * 4));
   CKS(sync_staged(c));
+  K.trace("  stage0: filter + compaction on the device");
   K.n_search = counts[0]; K.n_surv = counts[1];
   CKM(c->d_surv.ensure((size_t)K.n_surv * 2 + 1));
   CK(fqdev::launch_surv_gather(c->d_pair_list.p, K.n_surv, n, c->d_len_trim.p, c->d_filtered.p, c->d_sidx.p, c->d_surv.p));
@@ -949,8 +1003,9 @@ void stage_records(Call &K) {
   R.resize((size_t)n_surv * 2);                      // reused storage: every record is reset below
   K.s_of.assign((size_t)n_surv * 2, -1);
   const bool packed = c->in_kind == 2;
-  // (kept on the calling thread: first touch decides which NUMA node the records live on, and the serial phases read them)
-  for (int sp = 0; sp < n_surv; ++sp)
+  // (R.resize above touches new storage on the calling thread, which also runs the serial phases; resetting reused records is spread)
+  parallel_chunks((size_t)n_surv, K.host_threads, K.par_min, [&](size_t lo_sp, size_t hi_sp, int) {
+  for (int sp = (int)lo_sp; sp < (int)hi_sp; ++sp)
     for (int e = 0; e < 2; ++e) {
       FqRead &p = R[2 * sp + e];
       const int r = e * n + c->h_pair_list[sp];
@@ -964,6 +1019,7 @@ void stage_records(Call &K) {
       p.extra_flag = 1 | (e == 0 ? 64 : 128);   // SAM_FPD | SAM_FR1/FR2 (BwtMapper.cpp:749)
       K.s_of[2 * sp + e] = si.sidx;
     }
+  });
 }
 
 // ---- SA rows to resolve on the GPU: every row of every hit of reads that can need them ------------------
@@ -988,39 +1044,63 @@ int stage_sa_rows(Call &K) {
       K.read_nocc[idx] = t;
     }
   });
-  vector<FqAln> q_aln; vector<uint32_t> q_len; vector<uint64_t> q_off;
-  uint64_t rows = 0;
-  for (int sp = 0; sp < n_surv; ++sp) {
-    int na0, na1;
-    K.aln_of(2 * sp, &na0); K.aln_of(2 * sp + 1, &na1);
-    const bool pair_ok = na0 > 0 && na1 > 0 && K.read_nocc[2 * sp] <= o.max_occ && K.read_nocc[2 * sp + 1] <= o.max_occ;
-    for (int e = 0; e < 2; ++e) {
-      const int idx = 2 * sp + e;
-      int na; const FqAln *a = K.aln_of(idx, &na);
-      if (na == 0) continue;
-      if (!(pair_ok || K.read_nocc[idx] <= multi_cap)) continue;
-      K.enumerated[idx] = 1;
-      K.q_first[idx] = (uint32_t)q_aln.size();
-      const uint64_t base = K.aln_off[K.s_of[idx]];
-      for (int k = 0; k < na; ++k) {
-        K.aln_row_off[base + k] = rows;
-        q_aln.push_back(a[k]); q_len.push_back((uint32_t)R[idx].len); q_off.push_back(rows);
-        rows += (uint64_t)(a[k].l - a[k].k) + 1;
+  // which reads are enumerated and where their hits and rows go: counts per pair (parallel), one prefix sum, then the lists are
+  // written where the copy engine reads them (parallel)
+  vector<uint32_t> pq((size_t)n_surv + 1, 0);       // hits enumerated before pair sp
+  vector<uint64_t> prow((size_t)n_surv + 1, 0);     // rows before pair sp
+  parallel_chunks((size_t)n_surv, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
+    for (size_t sp = lo; sp < hi; ++sp) {
+      int na0, na1;
+      K.aln_of((int)(2 * sp), &na0); K.aln_of((int)(2 * sp + 1), &na1);
+      const bool pair_ok = na0 > 0 && na1 > 0 && K.read_nocc[2 * sp] <= o.max_occ && K.read_nocc[2 * sp + 1] <= o.max_occ;
+      uint32_t nq = 0; uint64_t nr = 0;
+      for (int e = 0; e < 2; ++e) {
+        const size_t idx = 2 * sp + e;
+        const int na = e ? na1 : na0;
+        if (na == 0 || !(pair_ok || K.read_nocc[idx] <= multi_cap)) continue;
+        K.enumerated[idx] = 1;
+        nq += (uint32_t)na; nr += K.read_nocc[idx];
       }
+      pq[sp + 1] = nq; prow[sp + 1] = nr;
     }
+  });
+  for (int sp = 0; sp < n_surv; ++sp) { pq[sp + 1] += pq[sp]; prow[sp + 1] += prow[sp]; }
+  const size_t n_q = pq[n_surv];
+  const uint64_t rows = prow[n_surv];
+  FqAln *q_aln = nullptr; uint32_t *q_len = nullptr; uint64_t *q_off = nullptr;
+  if (n_q) {
+    q_aln = (FqAln *)c->arena.alloc(n_q * sizeof(FqAln)); q_len = (uint32_t *)c->arena.alloc(n_q * 4); q_off = (uint64_t *)c->arena.alloc((n_q + 1) * 8);
+    if (!q_aln || !q_len || !q_off) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
+    parallel_chunks((size_t)n_surv, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
+      for (size_t sp = lo; sp < hi; ++sp) {
+        uint32_t q = pq[sp]; uint64_t r0 = prow[sp];
+        for (int e = 0; e < 2; ++e) {
+          const size_t idx = 2 * sp + e;
+          if (!K.enumerated[idx]) continue;
+          int na; const FqAln *a = K.aln_of((int)idx, &na);
+          K.q_first[idx] = q;
+          const uint64_t base = K.aln_off[K.s_of[idx]];
+          for (int k = 0; k < na; ++k) {
+            K.aln_row_off[base + k] = r0;
+            q_aln[q] = a[k]; q_len[q] = (uint32_t)R[idx].len; q_off[q] = r0;
+            ++q; r0 += (uint64_t)(a[k].l - a[k].k) + 1;
+          }
+        }
+      }
+    });
+    q_off[n_q] = rows;
   }
-  q_off.push_back(rows);
   K.n_rows = rows;
   CKM(c->p_pos.ensure(rows + 1));
   K.h_pos = c->p_pos.p;
   if (rows) {
-    CKM(c->d_qaln.ensure(q_aln.size()) && c->d_qlen.ensure(q_len.size()) && c->d_qoff.ensure(q_off.size()) && c->d_pos.ensure(rows));
-    CKS(h2d_staged(c, c->d_qaln.p, q_aln.data(), q_aln.size() * sizeof(FqAln)));
-    CKS(h2d_staged(c, c->d_qlen.p, q_len.data(), q_len.size() * 4));
-    CKS(h2d_staged(c, c->d_qoff.p, q_off.data(), q_off.size() * 8));
-    c->stats.h2d_bytes += q_aln.size() * (sizeof(FqAln) + 12);
+    CKM(c->d_qaln.ensure(n_q) && c->d_qlen.ensure(n_q) && c->d_qoff.ensure(n_q + 1) && c->d_pos.ensure(rows));
+    CK(fqdev::copy_pinned(c->d_qaln.p, q_aln, n_q * sizeof(FqAln), 1));
+    CK(fqdev::copy_pinned(c->d_qlen.p, q_len, n_q * 4, 1));
+    CK(fqdev::copy_pinned(c->d_qoff.p, q_off, (n_q + 1) * 8, 1));
+    c->stats.h2d_bytes += n_q * (sizeof(FqAln) + 12);
     FqSaArgs sa{};
-    sa.ix = ix->dev; sa.aln = c->d_qaln.p; sa.aln_len = c->d_qlen.p; sa.row_off = c->d_qoff.p; sa.n_aln = (uint32_t)q_aln.size();
+    sa.ix = ix->dev; sa.aln = c->d_qaln.p; sa.aln_len = c->d_qlen.p; sa.row_off = c->d_qoff.p; sa.n_aln = (uint32_t)n_q;
     sa.n_rows = rows; sa.pos = c->d_pos.p; sa.counters = c->d_counters.p;
     fqdev::time_begin(FQ_K_SA);
     CK(fqdev::launch_sa(sa));
@@ -1280,7 +1360,7 @@ int stageC_mate_sw(Call &K) {
         T.read = pm->dr; T.beg = beg; T.reglen = (int)(end - beg);
         cands.push_back({sp, k});
         tasks.push_back(T);
-        max_reg = std::max(max_reg, T.reglen); max_q = std::max(max_q, pm->len);
+        max_reg = std::max(max_reg, T.reglen); max_q = std::max(max_q, (int)pm->len);
       }
     }
   }
@@ -1392,12 +1472,12 @@ int stageD_refine(Call &K) {
       if (q.gap == 0) continue;
       tasks.push_back({s.dr, q.strand, q.pos, (q.strand ? 1 : -1) * q.gap});
       tgt.push_back({(int)idx, (int)j});
-      max_ref = std::max(max_ref, s.len + q.gap); max_q = std::max(max_q, s.len);
+      max_ref = std::max(max_ref, s.len + q.gap); max_q = std::max(max_q, (int)s.len);
     }
     if (s.type == FQ_TYPE_NO_MATCH || s.type == FQ_TYPE_MATESW || s.n_gapo == 0) continue;
     tasks.push_back({s.dr, s.strand, s.pos, (s.strand ? 1 : -1) * (s.n_gapo + s.n_gape)});
     tgt.push_back({(int)idx, -1});
-    max_ref = std::max(max_ref, s.len + s.n_gapo + s.n_gape); max_q = std::max(max_q, s.len);
+    max_ref = std::max(max_ref, s.len + s.n_gapo + s.n_gape); max_q = std::max(max_q, (int)s.len);
   }
   if (!tasks.empty()) {
     const int cig_cap = 64;
@@ -1432,23 +1512,39 @@ int stageD_refine(Call &K) {
     c->stats.refine_tasks += tasks.size();
   }
   // MD / NM for every mapped read (bwa_cal_md1)
-  vector<FqMdTask> mt; vector<int> mi; vector<uint16_t> arena;
+  // (task list and CIGAR arena are laid out by prefix sums and written, in parallel, where the copy engine reads them)
+  vector<uint32_t> t_of(R.size() + 1, 0), cg_of(R.size() + 1, 0);
   for (size_t idx = 0; idx < R.size(); ++idx) {
-    FqRead &s = R[idx];
-    if (s.type == FQ_TYPE_NO_MATCH) continue;
-    FqMdTask T{};
-    T.read = s.dr; T.strand = s.strand; T.pos = s.pos; T.n_cigar = (int)s.cigar.size(); T.cigar_off = (uint32_t)arena.size(); T.len = s.len;
-    arena.insert(arena.end(), s.cigar.begin(), s.cigar.end());
-    mt.push_back(T); mi.push_back((int)idx);
+    const bool on = R[idx].type != FQ_TYPE_NO_MATCH;
+    t_of[idx + 1] = t_of[idx] + (on ? 1u : 0u);
+    cg_of[idx + 1] = cg_of[idx] + (on ? (uint32_t)R[idx].cigar.size() : 0u);
   }
-  if (!mt.empty()) {
+  const int nt_all = (int)t_of[R.size()];
+  const size_t arena_n = cg_of[R.size()];
+  FqMdTask *mt = nullptr; uint16_t *arena = nullptr;
+  vector<int> mi((size_t)nt_all);
+  if (nt_all) {
+    mt = (FqMdTask *)c->arena.alloc((size_t)nt_all * sizeof(FqMdTask)); arena = (uint16_t *)c->arena.alloc((arena_n + 1) * 2);
+    if (!mt || !arena) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
+    parallel_chunks(R.size(), K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
+      for (size_t idx = lo; idx < hi; ++idx) {
+        FqRead &s = R[idx];
+        if (s.type == FQ_TYPE_NO_MATCH) continue;
+        FqMdTask T{};
+        T.read = s.dr; T.strand = s.strand; T.pos = s.pos; T.n_cigar = (int)s.cigar.size(); T.cigar_off = cg_of[idx]; T.len = s.len;
+        if (!s.cigar.empty()) memcpy(arena + cg_of[idx], s.cigar.data(), s.cigar.size() * 2);
+        mt[t_of[idx]] = T; mi[t_of[idx]] = (int)idx;
+      }
+    });
+  }
+  if (nt_all) {
     const int md_cap = 3 * (K.max_len_all + 8) + 32;
-    const int nt = (int)mt.size();
+    const int nt = nt_all;
     CKM(c->d_mdtask.ensure(nt) && c->d_md.ensure((size_t)nt * md_cap) && c->d_mdlen.ensure(nt) && c->d_nm.ensure(nt) && c->d_mdsz.ensure(nt) &&
-        c->d_cigarena.ensure(arena.size() + 1) && c->d_off.ensure(nt + 1));
-    CKS(h2d_staged(c, c->d_mdtask.p, mt.data(), (size_t)nt * sizeof(FqMdTask)));
-    CKS(h2d_staged(c, c->d_cigarena.p, arena.data(), arena.size() * 2));
-    c->stats.h2d_bytes += (size_t)nt * sizeof(FqMdTask) + arena.size() * 2;
+        c->d_cigarena.ensure(arena_n + 1) && c->d_off.ensure(nt + 1));
+    CK(fqdev::copy_pinned(c->d_mdtask.p, mt, (size_t)nt * sizeof(FqMdTask), 1));
+    if (arena_n) CK(fqdev::copy_pinned(c->d_cigarena.p, arena, arena_n * 2, 1));
+    c->stats.h2d_bytes += (size_t)nt * sizeof(FqMdTask) + arena_n * 2;
     FqMdArgs a{};
     a.ix = ix->dev; a.seq = K.dseq; a.stride = K.dstride; a.task = c->d_mdtask.p; a.n_task = nt; a.cigar = c->d_cigarena.p;
     a.md = c->d_md.p; a.md_cap = md_cap; a.md_len = c->d_mdlen.p; a.md_sz = c->d_mdsz.p; a.nm = c->d_nm.p;
@@ -1457,17 +1553,19 @@ int stageD_refine(Call &K) {
     CK(fqdev::launch_scan(c->d_mdsz.p, c->d_off.p, (uint32_t)nt));
     fqdev::time_end(FQ_K_REFINE);
     uint64_t total = 0;
-    vector<int32_t> mdlen(nt), nm(nt);
-    vector<uint64_t> off(nt + 1);
-    CKS(d2h_staged(c, off.data(), c->d_off.p, (size_t)(nt + 1) * 8));
-    CKS(d2h_staged(c, mdlen.data(), c->d_mdlen.p, (size_t)nt * 4));
-    CKS(d2h_staged(c, nm.data(), c->d_nm.p, (size_t)nt * 4));
+    int32_t *mdlen = (int32_t *)c->arena.alloc((size_t)nt * 4), *nm = (int32_t *)c->arena.alloc((size_t)nt * 4);   // results are read where they land
+    uint64_t *off = (uint64_t *)c->arena.alloc((size_t)(nt + 1) * 8);
+    if (!mdlen || !nm || !off) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
+    CK(fqdev::copy_pinned(off, c->d_off.p, (size_t)(nt + 1) * 8, 0));
+    CK(fqdev::copy_pinned(mdlen, c->d_mdlen.p, (size_t)nt * 4, 0));
+    CK(fqdev::copy_pinned(nm, c->d_nm.p, (size_t)nt * 4, 0));
     CKS(sync_staged(c));
     total = off[nt];
     CKM(c->d_mdpacked.ensure(total + 1));
     CK(fqdev::launch_pack_md(c->d_md.p, c->d_mdlen.p, c->d_off.p, md_cap, nt, c->d_mdpacked.p));
-    vector<char> packed(total + 1);
-    CKS(d2h_staged(c, packed.data(), c->d_mdpacked.p, total));
+    char *packed = (char *)c->arena.alloc(total + 1);
+    if (!packed) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
+    if (total) CK(fqdev::copy_pinned(packed, c->d_mdpacked.p, total, 0));
     CKS(sync_staged(c));
     c->stats.d2h_bytes += (size_t)nt * 16 + total;
     for (int t = 0; t < nt; ++t)
@@ -1475,7 +1573,7 @@ int stageD_refine(Call &K) {
     parallel_chunks((size_t)nt, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
       for (size_t t = lo; t < hi; ++t) {
         FqRead &s = R[mi[t]];
-        s.md.assign(packed.data() + off[t], (size_t)mdlen[t]);
+        s.md.assign(packed + off[t], (size_t)mdlen[t]);
         s.has_md = true;
         s.nm = nm[t] & 0xfff;
       }
@@ -1563,10 +1661,14 @@ int run_call(fq_ctx *c, fq_result_batch_t *out) {
   Call K;
   K.c = c;
   K.t_trace = K.t_wall0 = now_ms();
+  NodePin pin;
+  if (c->kn.trace) { fprintf(stderr, "[fq]   arena: %zu blocks, last call used %zu bytes:", c->arena.blocks.size(), c->arena.total); for (auto &b : c->arena.blocks) fprintf(stderr, " %zu", b.cap); fprintf(stderr, "\n"); }
   c->arena.reset();
   const fq_opts_t &o = c->o;
   FqBatchState &S = c->st;
+  K.trace("  pinned arena reset");
   S.clear();
+  K.trace("  state clear");
   S.n_pairs = c->n_pairs;
   memset(out, 0, sizeof *out);
   out->n_pairs = c->n_pairs;

@@ -16,15 +16,18 @@ struct FqMulti {             // bwt_multi1_t while it is being built
   std::vector<uint16_t> cigar;
 };
 
-struct FqRead {              // the bwa_seq_t fields the hot path writes (libbwa/bwtaln.h:57-86)
+struct alignas(64) FqRead {  // the bwa_seq_t fields the hot path writes (libbwa/bwtaln.h:57-86)
+  // Everything the order-dependent host phases read and write sits in the record's first cache line (records are 64-byte aligned):
+  // they walk two million records serially, and a record used to span three lines.
   int r = 0;                 // row in the input batch: end*n_pairs + pair
   int dr = 0;                // row of the read's ASCII copy on the device (= r for ASCII input; 2*survivor + end for packed input)
-  int len = 0, full_len = 0, clip_len = 0;
-  int filtered = 0, type = 0, strand = 0, extra_flag = 0;
-  int n_mm = 0, n_gapo = 0, n_gape = 0, mapQ = 0, seQ = 0, score = 0;
+  int score = 0;
   uint32_t sa = 0, pos = 0, c1 = 0, c2 = 0;
-  int main_aln = 0;
-  int nm = 0;
+  int16_t len = 0, full_len = 0, clip_len = 0;
+  int16_t main_aln = 0;      // (a hit list holds at most 8,192 hits: the exact tier's cap)
+  int16_t nm = 0;
+  uint8_t filtered = 0, type = 0, strand = 0, extra_flag = 0;
+  uint8_t n_mm = 0, n_gapo = 0, n_gape = 0, mapQ = 0, seQ = 0;
   bool has_md = false;
   bool revived = false;        // filtered on input, brought back for the mate SW because its mate passed (expand_seq, bwape.c:447-462)
   std::vector<FqMulti> multi;

@@ -23,6 +23,7 @@ ix = api.Index(pre, device=0)
 al = api.Aligner(ix, max_pairs=pairs, tuning={k: int(v) for k, v in tune.items()})
 al.upload(rb.seq, rb.qual, rb.lens, None)
 al.align_resident()
+al.align_resident()     # (the second call consolidates the pinned staging arena: not a steady-state call either)
 al.reset_stats()
 t0 = time.perf_counter()
 al.align_resident()
