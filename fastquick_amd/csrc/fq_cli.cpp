@@ -148,6 +148,7 @@ struct Args {
   int opte = -1;
   long long chunk_pairs = 16LL * 262144;
   int device = 0;
+  int pack_threads = 8;     // host threads of the packer (fq_pack_reads)
   bool clean_names = false;
   std::string fq_list, rg = "@RG\\tID:foo\\tSM:bar";   // runAlign's default --RG (src/FASTQuick.cpp:170)
   bool cal_dup = true;
@@ -200,7 +201,7 @@ int main(int argc, char **argv) {
     else if (f == "--l") A.o.seed_len = atoi(need(""));
     else if (f == "--k") A.o.max_seed_diff = atoi(need(""));
     else if (f == "--m") A.o.max_entries = atoi(need(""));
-    else if (f == "--t") A.o.host_threads = atoi(need(""));   // accepted for command-line compatibility (see fastquick_amd.h)
+    else if (f == "--t") { A.o.host_threads = atoi(need("")); if (A.o.host_threads > 0) A.pack_threads = A.o.host_threads; }   // accepted for command-line compatibility (see fastquick_amd.h)
     else if (f == "--R") A.o.max_top2 = atoi(need(""));
     else if (f == "--q") A.o.trim_qual = atoi(need(""));
     else if (f == "--N") { A.o.mode |= 0x10; A.o.max_top2 = 0x7fffffff; }
@@ -356,8 +357,12 @@ int main(int argc, char **argv) {
     }
     fq_read_batch_t in = {n, stride, seq.data(), qual.data(), len.data(), e0.names.data(), (int32_t)name_stride, e1.names.data()};
     fq_result_batch_t res;
-    rc = fq_align_batch(ctx, &in, &res);
-    if (rc) die(std::string("fq_align_batch failed: ") + fq_ctx_last_error(ctx));
+    // the packed boundary: 24 bytes of filter keys per read cross PCIe, full rows only for the surviving pairs
+    fq_packed_batch_t *pk = nullptr;
+    rc = fq_pack_reads(&in, A.pack_threads, &pk);
+    if (rc) die("fq_pack_reads failed (" + std::to_string(rc) + ")");
+    rc = fq_align_packed(ctx, pk, &res);
+    if (rc) die(std::string("fq_align_packed failed: ") + fq_ctx_last_error(ctx));
     // the consumers, in the reference's order: StatCollector, then the record writer (src/BwtMapper.cpp:2047-2050, 2075-2085)
     if (qc && (rc = fq_qc_add_last(qc, ctx))) die(std::string("QC consumer failed: ") + fq_qc_last_error(qc));
     if (A.sam_out) {
@@ -368,6 +373,7 @@ int main(int argc, char **argv) {
     } else if ((rc = fq_bam_add_last(bam, ctx))) die("writing " + A.out_prefix + ".bam failed");
     num_read += 2LL * n; filtered += res.n_both_filtered; unmapped += res.n_both_unmapped; num_base += res.n_bases;
     fprintf(stderr, "NOTICE - %lld sequences are processed.\n", num_read);
+    fq_packed_free(pk);
     if (prefetch.joinable()) prefetch.join();
     if (last) break;
   }
