@@ -216,9 +216,9 @@ struct fq_ctx {
 };
 
 // ---- drand48 (glibc): X' = (0x5DEECE66D X + 0xB) mod 2^48, value X'/2^48 ------------------------------
-static inline double rng_next(fq_ctx *c) {
-  c->rng = (0x5DEECE66DULL * c->rng + 0xBULL) & 0xFFFFFFFFFFFFULL;
-  return (double)c->rng * (1.0 / 281474976710656.0);
+static inline double rng_step(uint64_t &x) {   // glibc drand48: X' = (0x5DEECE66D X + 0xB) mod 2^48, result X' / 2^48
+  x = (0x5DEECE66DULL * x + 0xBULL) & 0xFFFFFFFFFFFFULL;
+  return (double)x * (1.0 / 281474976710656.0);
 }
 
 extern "C" void fq_default_opts(fq_opts_t *o) {
@@ -435,7 +435,7 @@ void parallel_chunks(size_t n, int threads, size_t par_min, F fn) {   // fn(lo, 
 }
 
 // bwa_aln2seq_core, libbwa/bwase.c:19-95
-void choose_hit(fq_ctx *c, int n_aln, const FqAln *aln, FqRead &s, bool set_main, int n_multi) {
+void choose_hit(uint64_t &rng, int n_aln, const FqAln *aln, FqRead &s, bool set_main, int n_multi) {
   if (n_aln == 0) { s.type = FQ_TYPE_NO_MATCH; s.c1 = s.c2 = 0; return; }
   if (set_main) {
     const int best = aln[0].score;
@@ -445,10 +445,10 @@ void choose_hit(fq_ctx *c, int n_aln, const FqAln *aln, FqRead &s, bool set_main
       const FqAln &p = aln[i];
       if (p.score > best) break;
       const uint32_t wdt = p.l - p.k + 1;
-      if (rng_next(c) * (double)(uint32_t)(wdt + cnt) > (double)(int)cnt) {
+      if (rng_step(rng) * (double)(uint32_t)(wdt + cnt) > (double)(int)cnt) {
         s.n_mm = p.info & 0xff; s.n_gapo = (p.info >> 8) & 0xff; s.n_gape = (p.info >> 16) & 0xff; s.strand = (p.info >> 24) & 1;
         s.score = p.score;
-        s.sa = p.k + (uint32_t)((double)wdt * rng_next(c));
+        s.sa = p.k + (uint32_t)((double)wdt * rng_step(rng));
         s.main_aln = i;
       }
       cnt += wdt;
@@ -1118,20 +1118,69 @@ int stageB1_main_hit(Call &K) {
   fq_ctx *c = K.c;
   const fq_index *ix = c->ix;
   vector<FqRead> &R = c->st.reads;
-  vector<uint32_t> dq_row, dq_info; vector<int> dq_idx;
-  for (int sp = 0; sp < K.n_surv; ++sp)
-    for (int e = 0; e < 2; ++e) {
-      const int idx = 2 * sp + e;
+  // The drand48 stream is consumed in read order, but one read depends on the others only through HOW MANY numbers they drew: one per
+  // hit that shares the best score, plus one each time such a hit is taken (bwase.c:29-41) -- two for a read with a single best
+  // hit.  So: count the best hits of every read (parallel), replay the draws alone in read order to learn the state each chunk of
+  // reads starts from (serial, one byte per read; the hit lists only of reads with several best hits), then choose (parallel).
+  const size_t N = R.size();
+  vector<uint16_t> ntop(N, 0);
+  parallel_chunks(N, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
+    for (size_t idx = lo; idx < hi; ++idx) {
+      if (R[idx].filtered) continue;
+      int na; const FqAln *a = K.aln_of((int)idx, &na);
+      int t = 0;
+      while (t < na && a[t].score <= a[0].score) ++t;     // (lists are in discovery order: best score first)
+      ntop[idx] = (uint16_t)std::min(t, 65535);
+    }
+  });
+  const int T = N >= K.par_min ? std::max(1, K.host_threads) : 1;
+  const size_t per = (N + T - 1) / T;
+  vector<uint64_t> start((size_t)T + 1, 0);
+  {
+    uint64_t x = c->rng;
+    size_t next_chunk = 0;
+    for (size_t idx = 0; idx < N; ++idx) {
+      if (next_chunk < (size_t)T && idx == next_chunk * per) start[next_chunk++] = x;
+      const int t = ntop[idx];
+      if (t == 0) continue;
+      if (t == 1) { if (rng_step(x) != 0.0) rng_step(x); continue; }        // wdt >= 1: taken unless the draw is exactly 0
+      int na; const FqAln *a = K.aln_of((int)idx, &na);
+      uint32_t cnt = 0;
+      for (int i = 0; i < na && a[i].score <= a[0].score; ++i) {             // (all of them when there are more than 65,535)
+        const uint32_t wdt = a[i].l - a[i].k + 1;
+        if (rng_step(x) * (double)(uint32_t)(wdt + cnt) > (double)(int)cnt) rng_step(x);
+        cnt += wdt;
+      }
+    }
+    while (next_chunk <= (size_t)T) start[next_chunk++] = x;
+    c->rng = x;
+  }
+  vector<vector<uint32_t>> dq_row_t(T), dq_info_t(T); vector<vector<int>> dq_idx_t(T);
+  auto choose = [&](size_t lo, size_t hi, int t) {
+    uint64_t x = start[t];
+    for (size_t idx = lo; idx < hi; ++idx) {
       FqRead &p = R[idx];
       if (p.filtered) continue;
-      int na; const FqAln *a = K.aln_of(idx, &na);
-      choose_hit(c, na, a, p, true, 0);
+      int na; const FqAln *a = K.aln_of((int)idx, &na);
+      choose_hit(x, na, a, p, true, 0);
       if (p.type == FQ_TYPE_UNIQUE || p.type == FQ_TYPE_REPEAT) {
         if (K.enumerated[idx]) p.pos = K.h_pos[K.aln_row_off[K.aln_off[K.s_of[idx]] + p.main_aln] + (p.sa - a[p.main_aln].k)];
-        else { dq_row.push_back(p.sa); dq_info.push_back((uint32_t)p.strand << 31 | (uint32_t)p.len); dq_idx.push_back(idx); }
+        else { dq_row_t[t].push_back(p.sa); dq_info_t[t].push_back((uint32_t)p.strand << 31 | (uint32_t)p.len); dq_idx_t[t].push_back((int)idx); }
         p.seQ = p.mapQ = approx_mapq(c, p, c->maxdiff_lut[p.len]);
       }
     }
+  };
+  if (T == 1) choose(0, N, 0);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; ++t) { const size_t lo = (size_t)t * per, hi = std::min(N, lo + per); if (lo < hi) th.emplace_back(choose, lo, hi, t); }
+    for (auto &y : th) y.join();
+  }
+  vector<uint32_t> dq_row, dq_info; vector<int> dq_idx;
+  for (int t = 0; t < T; ++t) {
+    dq_row.insert(dq_row.end(), dq_row_t[t].begin(), dq_row_t[t].end()); dq_info.insert(dq_info.end(), dq_info_t[t].begin(), dq_info_t[t].end());
+    dq_idx.insert(dq_idx.end(), dq_idx_t[t].begin(), dq_idx_t[t].end());
+  }
   if (!dq_row.empty()) {   // main hits of very repetitive reads whose rows were not enumerated
     const size_t nq = dq_row.size();
     CKM(c->d_qrow.ensure(nq) && c->d_qinfo.ensure(nq) && c->d_qpos.ensure(nq));   // (d_pos keeps the enumerated rows: k_pair reads them)
@@ -1310,7 +1359,7 @@ int stageB3_pairing(Call &K) {
             int nm;
             if (!(p[j]->extra_flag & 2) && p[1 - j]->type != FQ_TYPE_NO_MATCH) nm = (int)(p[j]->c1 + p[j]->c2) - 1 > o.N_multi ? o.n_multi : o.N_multi;
             else nm = o.n_multi;
-            choose_hit(c, na[j], aln[j], *p[j], false, nm);
+            { uint64_t no_rng = 0; choose_hit(no_rng, na[j], aln[j], *p[j], false, nm); }   // (XA selection draws no random numbers, bwase.c:47-95)
             const uint64_t base = K.aln_off[K.s_of[2 * sp + j]];
             for (auto &m : p[j]->multi) m.pos = h_pos[K.aln_row_off[base + m.aln] + m.row_in_aln];
           }
