@@ -57,6 +57,9 @@ void fqo_ctx_free(fqo_ctx *c);
  * Returns number of pairs that produced SAM records, <0 on error. */
 int fqo_align_batch(fqo_ctx *c, int n, const char *names, const char *names_mate, int name_stride, const uint8_t *seq, const uint8_t *qual,
                     const int32_t *lens, int stride, FILE *stages, FILE *sam);
+/* single-end reads (BwtMapper::SingleEndMapper): rows [n][stride], one file */
+int fqo_align_batch_se(fqo_ctx *c, int n, const char *names, int name_stride, const uint8_t *seq, const uint8_t *qual, const int32_t *lens, int stride,
+                       FILE *st, FILE *sam);
 void fqo_print_sam_header(const fqo_index *ix, FILE *sam);
 /* --t of the reference: stage A (cal_width + match_gap) of every following batch runs on n_threads workers sliced as
  * src/BwtMapper.cpp:1490-1513 does (rounded up to even; half per end); <=1 = serial.  Results do not depend on it. */

@@ -128,7 +128,7 @@ static int cmd_align(int argc, char **argv) {
   pe_opt_t *popt = bwa_init_pe_opt();
   int batch = READ_BUFFER_SIZE, thresh = 3;
   long long genome_size = 0, genome_n_size = 0;
-  int bam_dump = 0;
+  int bam_dump = 0, se = 0;
   std::string fai_path, rg = "@RG\tID:foo\tSM:bar";   // runAlign's default --RG (src/FASTQuick.cpp:170)
   for (int i = 6; i + 1 < argc; i += 2) {
     if (!strcmp(argv[i], "--q")) opt->trim_qual = atoi(argv[i + 1]);
@@ -139,6 +139,7 @@ static int cmd_align(int argc, char **argv) {
     else if (!strcmp(argv[i], "--flank_long")) opt->flank_long_len = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--cal_dup")) opt->cal_dup = (char)atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--bam_dump")) bam_dump = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--se")) se = atoi(argv[i + 1]);      // single-end: <r2.fq> is ignored (BwtMapper::SingleEndMapper)
     else if (!strcmp(argv[i], "--fai")) fai_path = argv[i + 1];
     else if (!strcmp(argv[i], "--RG")) rg = argv[i + 1];
     else if (!strcmp(argv[i], "--thresh")) thresh = atoi(argv[i + 1]);
@@ -220,6 +221,77 @@ static int cmd_align(int argc, char **argv) {
   if (!st) die("cannot open stages file");
   if (!freopen((out + ".sam").c_str(), "w", stdout)) die("cannot redirect stdout");
 
+  if (se) {
+    // ---- BwtMapper::SingleEndMapper (src/BwtMapper.cpp:1266-1407): its own statements in its own order; the loop around them, the
+    //      stage dumps and the BAM-record text are the driver's
+    FileStatCollector FSE(fq1);
+    bwase_initialize();
+    srand48(ix.bns->seed);
+    bwa_seqio_t *k1 = bwa_seq_open(fq1);
+    bwt_t *bwt1[2] = {ix.bwt_d, ix.rbwt_d};
+    ubyte_t *pacseq1 = 0;
+    bwa_print_sam_SQ(ix.bns);
+    bwa_print_sam_PG();
+    long long n_total = 0, n_filt = 0, n_unm = 0;
+    bwa_seq_t *seqs;
+    int n = 0;
+    for (int b = 0; (seqs = bwa_read_seq_with_hash(&ix, k1, batch, &n, opt->mode, opt->trim_qual, opt->frac, 0)) != 0; ++b) {
+      FSE.NumRead += n;
+      fprintf(st, "B %d %d\n", b, n);
+      for (int i = 0; i < n; ++i) fprintf(st, "F 0 %d filt=%d len=%d clip=%d full=%d\n", i, seqs[i].filtered, seqs[i].len, seqs[i].clip_len, seqs[i].full_len);
+      bwa_cal_sa_reg_gap(0, bwt1, n, seqs, opt, &ix);
+      for (int i = 0; i < n; ++i) {
+        const bwa_seq_t *p = seqs + i;
+        fprintf(st, "A 0 %d n=%d", i, p->n_aln);
+        for (int k = 0; k < p->n_aln; ++k)
+          fprintf(st, " %d,%d,%d,%d,%u,%u,%d", p->aln[k].n_mm, p->aln[k].n_gapo, p->aln[k].n_gape, p->aln[k].a, p->aln[k].k, p->aln[k].l, p->aln[k].score);
+        fputc('\n', st);
+      }
+      for (int i = 0; i < n; ++i) {
+        bwa_seq_t *p = seqs + i;
+        FSE.NumBase += p->full_len;
+        if (p->filtered) continue;
+        bwa_aln2seq_core(p->n_aln, p->aln, p, 1, N_OCC);
+      }
+      mapper.bwa_cal_pac_pos(ix, n, seqs, opt->max_diff, opt->fnr);
+      for (int i = 0; i < n; ++i) dump_rec(st, 'P', 0, i, seqs + i, 0);
+      pacseq1 = bwa_refine_gapped(ix.bns, n, seqs, pacseq1 ? pacseq1 : ix.pac_buf, 0);
+      for (int i = 0; i < n; ++i) dump_rec(st, 'R', 0, i, seqs + i, 1);
+      for (int i = 0; i < n; ++i) {
+        bwa_seq_t *p = seqs + i;
+        if (p->filtered) { ++n_filt; FSE.TotalFiltered++; continue; }
+        if (p->type == BWA_TYPE_NO_MATCH) { ++n_unm; FSE.BwaUnmapped++; continue; }
+        FSE.TotalRetained += collector.AddAlignment(ix.bns, p, 0, opt, fout, FSE.TotalMAPQ);
+        if (bam_dump) {
+          SamRecord R;
+          mapper.SetSamRecord(ix.bns, p, 0, SFH, R, opt);
+          fprintf(fb, "%s\t%d\t%s\t%d\t%d\t%s\t%s\t%d\t%d\t%s\t%s", R.getReadName(), (int)R.getFlag(), R.getReferenceName(), (int)R.get1BasedPosition(),
+                  (int)R.getMapQuality(), R.getCigar(), R.getMateReferenceNameOrEqual(), (int)R.get1BasedMatePosition(), (int)R.getInsertSize(), R.getSequence(), R.getQuality());
+          char tag[3]; char vtype; void *value;
+          R.resetTagIter();
+          while (R.getNextSamTag(tag, vtype, &value)) {
+            if (vtype == 'Z') fprintf(fb, "\t%s:Z:%s", tag, ((String *)value)->c_str());
+            else if (vtype == 'A') fprintf(fb, "\t%s:A:%c", tag, *(char *)value);
+            else if (vtype == 'f') fprintf(fb, "\t%s:f:%g", tag, *(float *)value);
+            else fprintf(fb, "\t%s:i:%d", tag, *(int *)value);
+          }
+          fputc('\n', fb);
+          continue;
+        }
+        bwa_print_sam1(ix.bns, p, 0, opt->mode, opt->max_top2);
+      }
+      n_total += n;
+      bwa_free_read_seq(n, seqs);
+    }
+    fprintf(st, "E pairs=%lld filtered=%lld unmapped=%lld\n", n_total, n_filt, n_unm);
+    fclose(st);
+    if (fb) fclose(fb);
+    fflush(stdout);
+    collector.AddFSC(FSE);
+    fout.close();
+    collector.ProcessCore(out, opt);
+    return 0;
+  }
   // ---- the set-up part of BwtMapper::PairEndMapper (src/BwtMapper.cpp:1811-1834)
   bwase_initialize();
   srand48(ix.bns->seed);

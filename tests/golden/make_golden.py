@@ -221,6 +221,25 @@ def sparse_to_npz(path_sparse: str, path_npz: str) -> None:
     np.savez_compressed(path_npz, **arrs)
 
 
+SE_CASES = ("basic", "repeat", "trim76", "edge", "long250", "nref", "example151")
+
+
+def add_se_outputs(tag):
+    """The reference's single-end mapper (BwtMapper::SingleEndMapper, driver option --se 1) on the first FASTQ of an existing case:
+    ref_se.stages / ref_se.sam next to the paired-end goldens (the case's inputs stay as they are)."""
+    import golden_util
+    out = os.path.join(HERE, tag)
+    with tempfile.TemporaryDirectory() as tmp:
+        g = golden_util.materialise(tag, tmp)
+        args = ["--se", 1, "--batch", g["batch"], "--genome_size", g["genome_size"]] + (["--q", g["trim_qual"]] if g["trim_qual"] else []) + \
+               (["--read_len", g["qc_read_len"]] if g["qc_read_len"] != 151 else [])
+        ob.run_reference(g["prefix"], g["fq1"], g["fq2"], os.path.join(tmp, "se_out"), *args)
+        for src, dst in (("se_out.stages", "ref_se.stages.gz"), ("se_out.sam", "ref_se.sam.gz")):
+            with open(os.path.join(tmp, src), "rb") as fi, gzip.GzipFile(os.path.join(out, dst), "wb", mtime=0) as fo:
+                fo.write(fi.read())
+    print(tag, "-> single-end goldens")
+
+
 def main() -> None:
     if not os.path.exists(ob.REF_DRIVER):
         sys.exit("oracle/_ref/fq_ref_driver missing: run `make -C oracle ref` in the build container")
@@ -248,6 +267,9 @@ def main() -> None:
         make_example_case()
     if not only or "cfg0_example" in only:
         make_cfg0_case()
+    for tag in SE_CASES:
+        if not only or tag in only or "se" in only:
+            add_se_outputs(tag)
 
 
 if __name__ == "__main__":

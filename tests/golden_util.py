@@ -47,9 +47,15 @@ def materialise(tag: str, dst: str) -> dict:
             fo.write(fi.read())
         paths[name] = os.path.join(dst, name)
     for name in sorted(os.listdir(src)):      # StatCollector inputs next to the reference, and the QC files the reference wrote
-        if name.startswith("ref.FASTQuick.fa.") and name.endswith(".gz") or name.startswith(("ref.qc.", "ref.bam", "genome.fai")):
+        if name.startswith("ref.FASTQuick.fa.") and name.endswith(".gz") or name.startswith(("ref.qc.", "ref.bam", "genome.fai", "ref_se.")):
             with gzip.open(os.path.join(src, name), "rb") as fi, open(os.path.join(dst, name[:-3]), "wb") as fo:
                 fo.write(fi.read())
     p = case_params(tag)
     p.update(prefix=pre, fq1=paths["reads_1.fq"], fq2=paths["reads_2.fq"], stages=paths["ref.stages"], sam=paths["ref.sam"], dir=dst)
+    if os.path.exists(os.path.join(dst, "ref_se.sam")):      # the reference's single-end mapper on reads_1.fq alone
+        p.update(se_stages=os.path.join(dst, "ref_se.stages"), se_sam=os.path.join(dst, "ref_se.sam"))
     return p
+
+
+def se_case_tags() -> list:
+    return [t for t in case_tags() if os.path.exists(os.path.join(GOLD, t, "ref_se.sam.gz"))]

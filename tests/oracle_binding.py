@@ -200,6 +200,35 @@ class OracleAligner:
         return total
 
 
+    def align_se(self, names, seq, qual, lens, stages_path=None, sam_path=None, batch=None, header=True) -> int:
+        """Single-end reads (BwtMapper::SingleEndMapper): seq / qual [n][stride], lens [n]."""
+        n = seq.shape[0]
+        batch = batch or n
+        libc = self.L._libc
+        st = libc.fopen(stages_path.encode(), b"w") if stages_path else None
+        sm = libc.fopen(sam_path.encode(), b"w") if sam_path else None
+        if sm and header:
+            self.L.fqo_print_sam_header(self.ix, sm)
+        self.L.fqo_align_batch_se.restype = C.c_int
+        self.L.fqo_align_batch_se.argtypes = [C.c_void_p, C.c_int, C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
+        total = 0
+        stride = seq.shape[1]
+        for b0 in range(0, n, batch):
+            b1 = min(n, b0 + batch)
+            s = np.ascontiguousarray(seq[b0:b1])
+            q = np.ascontiguousarray(qual[b0:b1])
+            ln = np.ascontiguousarray(lens[b0:b1])
+            rc = self.L.fqo_align_batch_se(self.ctx, b1 - b0, pack_names(names[b0:b1]), 64, s.ctypes.data, q.ctypes.data, ln.ctypes.data, stride, st, sm)
+            if rc < 0:
+                raise RuntimeError("oracle align failed")
+            total += rc
+        if st:
+            libc.fclose(st)
+        if sm:
+            libc.fclose(sm)
+        return total
+
+
 def run_reference(prefix: str, fq1: str, fq2: str, out_prefix: str, *extra) -> None:
     """Run the real reference (only possible where oracle/_ref was built, i.e. the build container)."""
     subprocess.check_call([REF_DRIVER, "align", prefix, fq1, fq2, out_prefix, *map(str, extra)],
