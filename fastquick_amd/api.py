@@ -24,7 +24,7 @@ class Opts(C.Structure):
         ("max_seed_diff", C.c_int32), ("seed_len", C.c_int32), ("max_top2", C.c_int32), ("trim_qual", C.c_int32),
         ("filter_thresh", C.c_int32), ("max_isize", C.c_int32), ("force_isize", C.c_int32), ("max_occ", C.c_uint32),
         ("n_multi", C.c_int32), ("N_multi", C.c_int32), ("is_sw", C.c_int32), ("ap_prior", C.c_double),
-        ("host_threads", C.c_int32), ("batch_pairs", C.c_int32),
+        ("host_threads", C.c_int32), ("batch_pairs", C.c_int32), ("single_end", C.c_int32), ("pad_opts", C.c_int32),
     ]
 
 

@@ -229,7 +229,7 @@ extern "C" void fq_default_opts(fq_opts_t *o) {
   o->fnr = 0.02; o->max_diff = -1; o->max_gapo = 1; o->max_gape = 6;
   o->max_seed_diff = 2; o->seed_len = 32; o->max_top2 = 30; o->trim_qual = 0; o->filter_thresh = 3;
   o->max_isize = 500; o->force_isize = 0; o->max_occ = 100000; o->n_multi = 3; o->N_multi = 10; o->is_sw = 1;
-  o->ap_prior = 1e-5; o->host_threads = 0; o->batch_pairs = 262144;
+  o->ap_prior = 1e-5; o->host_threads = 0; o->batch_pairs = 262144; o->single_end = 0; o->pad_opts = 0;
 }
 
 extern "C" const char *fq_version(void) { return "fastquick_amd 0.1 (gfx950)"; }
@@ -344,15 +344,15 @@ extern "C" int fq_batch_upload(fq_ctx_t *c, const fq_read_batch_t *in) {
   if (in->n_pairs > c->max_pairs) { c->err = "batch larger than max_pairs_per_batch"; return FQ_ELIMIT; }
   if (fqdev::bind(c->dev)) return FQ_ENODEV;
   if (in->stride < 1 || in->stride > 4096) return FQ_EINVAL;
-  const size_t n2 = (size_t)in->n_pairs * 2;
+  const size_t n2 = (size_t)in->n_pairs * (c->o.single_end ? 1 : 2);   // rows the caller provides
   int64_t nb = 0;
   for (size_t i = 0; i < n2; ++i) nb += in->len[i];
   c->n_bases_in = nb;
   for (size_t i = 0; i < n2; ++i)
     if (in->len[i] < FQ_LMIN || in->len[i] > FQ_LMAX || in->len[i] > in->stride) { c->err = "read length outside [" + std::to_string(FQ_LMIN) + "," + std::to_string(FQ_LMAX) + "]"; return FQ_ELIMIT; }
-  CKM(c->d_seq.ensure(n2 * in->stride + 64));
-  CKM(c->d_qual.ensure(n2 * in->stride + 64));
-  CKM(c->d_len.ensure(n2 + 1));
+  CKM(c->d_seq.ensure((size_t)in->n_pairs * 2 * in->stride + 64));
+  CKM(c->d_qual.ensure((size_t)in->n_pairs * 2 * in->stride + 64));
+  CKM(c->d_len.ensure((size_t)in->n_pairs * 2 + 1));
   CK(fqdev::h2d(c->d_seq.p, in->seq, n2 * in->stride));
   CK(fqdev::h2d(c->d_qual.p, in->qual, n2 * in->stride));
   CK(fqdev::h2d(c->d_len.p, in->len, n2 * 4));
@@ -642,7 +642,11 @@ int stage0_ascii(Call &K) {
   CK(fqdev::dzero(c->d_sub_max.p, (size_t)n_sub * 4));
   // (the filter kernels of all contexts of a device are chained on the device: fqdev::launch_prep)
   FqPrepArgs a{};
-  a.ix = ix->dev; a.o = c->ko; a.seq = c->d_seq.p; a.qual = c->d_qual.p; a.len = c->d_len.p; a.stride = c->stride; a.n_reads = n2;
+  a.ix = ix->dev; a.o = c->ko; a.seq = c->d_seq.p; a.qual = c->d_qual.p; a.len = c->d_len.p; a.stride = c->stride; a.n_reads = c->o.single_end ? n : n2;
+  if (c->o.single_end) {   // the rows of the absent mates: filtered, so that the pair machinery carries each read alone
+    CK(fqdev::dfill(c->d_filtered.p + n, 1, (size_t)n));
+    CK(fqdev::dzero(c->d_len_trim.p + n, (size_t)n * 4));
+  }
   a.len_trim = c->d_len_trim.p; a.filtered = c->d_filtered.p; a.sub_max = c->d_sub_max.p; a.n_pairs = n; a.batch_pairs = B;
   a.counters = c->d_counters.p;
   fqdev::time_begin(FQ_K_PREP);
@@ -1013,10 +1017,10 @@ void stage_records(Call &K) {
       p.reset();
       p.r = r;
       p.dr = packed ? 2 * sp + e : r;
-      p.full_len = packed ? (c->pb.uniform_len > 0 ? c->pb.uniform_len : (int)c->pb.len[r]) : c->hb.len[r];
+      p.full_len = packed ? (c->pb.uniform_len > 0 ? c->pb.uniform_len : (int)c->pb.len[r]) : (c->o.single_end && e == 1 ? 0 : c->hb.len[r]);
       p.len = p.clip_len = si.len_trim;
       p.filtered = (uint8_t)si.filtered;
-      p.extra_flag = 1 | (e == 0 ? 64 : 128);   // SAM_FPD | SAM_FR1/FR2 (BwtMapper.cpp:749)
+      p.extra_flag = c->o.single_end ? 0 : (1 | (e == 0 ? 64 : 128));   // SAM_FPD | SAM_FR1/FR2 (BwtMapper.cpp:749); the single-end mapper sets none
       K.s_of[2 * sp + e] = si.sidx;
     }
   });
@@ -1035,7 +1039,7 @@ int stage_sa_rows(Call &K) {
   K.enumerated.assign((size_t)n_surv * 2, 0);
   K.q_first.assign((size_t)n_surv * 2, 0);
   K.aln_row_off.assign(c->st.aln.size() + 1, ~0ull);   // per hit in S.aln order -> offset into h_pos
-  const uint32_t multi_cap = (uint32_t)std::max(o.n_multi, o.N_multi) + 1;
+  const uint32_t multi_cap = o.single_end ? 4u : (uint32_t)std::max(o.n_multi, o.N_multi) + 1;   // (single-end: N_OCC + 1, src/BwtMapper.cpp:33, 1344)
   parallel_chunks(R.size(), K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
     for (size_t idx = lo; idx < hi; ++idx) {
       int na; const FqAln *a = K.aln_of((int)idx, &na);
@@ -1155,6 +1159,7 @@ int stageB1_main_hit(Call &K) {
     while (next_chunk <= (size_t)T) start[next_chunk++] = x;
     c->rng = x;
   }
+  const int se_n_occ = c->o.single_end ? 3 : 0;   // N_OCC: the single-end mapper selects main and alternative hits in one call (src/BwtMapper.cpp:1344)
   vector<vector<uint32_t>> dq_row_t(T), dq_info_t(T); vector<vector<int>> dq_idx_t(T);
   auto choose = [&](size_t lo, size_t hi, int t) {
     uint64_t x = start[t];
@@ -1162,7 +1167,11 @@ int stageB1_main_hit(Call &K) {
       FqRead &p = R[idx];
       if (p.filtered) continue;
       int na; const FqAln *a = K.aln_of((int)idx, &na);
-      choose_hit(x, na, a, p, true, 0);
+      choose_hit(x, na, a, p, true, se_n_occ);
+      if (se_n_occ) {   // bwa_cal_pac_pos: the alternative hits' SA rows become positions (their rows are enumerated: n_occ <= N_OCC + 1)
+        const uint64_t base = K.aln_off[K.s_of[idx]];
+        for (auto &m : p.multi) m.pos = K.h_pos[K.aln_row_off[base + m.aln] + m.row_in_aln];
+      }
       if (p.type == FQ_TYPE_UNIQUE || p.type == FQ_TYPE_REPEAT) {
         if (K.enumerated[idx]) p.pos = K.h_pos[K.aln_row_off[K.aln_off[K.s_of[idx]] + p.main_aln] + (p.sa - a[p.main_aln].k)];
         else { dq_row_t[t].push_back(p.sa); dq_info_t[t].push_back((uint32_t)p.strand << 31 | (uint32_t)p.len); dq_idx_t[t].push_back((int)idx); }
@@ -1744,16 +1753,19 @@ int run_call(fq_ctx *c, fq_result_batch_t *out) {
   if (c->before_serial) c->before_serial(c->hook_user);
   if ((rc = stageB1_main_hit(K))) return rc;
   K.trace("B1 main hit (serial)");
-  stageB2_isize(K);
-  c->last_ii = K.iis[K.n_sub - 1];
-  stage_kl_cache(K);
+  if (o.single_end) K.iis.assign(K.n_sub, fq_isize_t{});     // no pairs: no insert sizes, no (k,l) cache, no pairing, no mate rescue
+  else {
+    stageB2_isize(K);
+    c->last_ii = K.iis[K.n_sub - 1];
+    stage_kl_cache(K);
+  }
   if (c->after_serial) c->after_serial(c->hook_user);
   K.t_serial1 = now_ms();
   K.trace("B2 isize");
-  if ((rc = stageB3_pairing(K))) return rc;
+  if (!o.single_end && (rc = stageB3_pairing(K))) return rc;
   K.trace("B3 pairing+XA");
   if (c->debug) S.stage_P = S.reads;   // snapshot for the stage dump (tests)
-  if ((rc = stageC_mate_sw(K))) return rc;
+  if (!o.single_end && (rc = stageC_mate_sw(K))) return rc;
   K.trace("C mate SW");
   if (c->debug) S.stage_S = S.reads;
   if ((rc = stageD_refine(K))) return rc;
@@ -1794,6 +1806,7 @@ extern "C" int fq_packed_prefetch(fq_ctx_t *c, const fq_packed_batch_t *next) {
   return FQ_OK;
 }
 extern "C" int fq_align_packed(fq_ctx_t *c, const fq_packed_batch_t *in, fq_result_batch_t *out) {
+  if (c && c->o.single_end) { c->err = "single-end contexts take ASCII batches (fq_align_batch)"; return FQ_EINVAL; }
   if (!c || !out) return FQ_EINVAL;
   int rc = packed_check(c, in);
   if (rc) return rc;

@@ -83,17 +83,18 @@ void bridge_mutation(const fq_index *ix, FqRead &p) {
   if ((int64_t)p.pos + j - ix->contigs[seqid].offset > ix->contigs[seqid].len) p.type = FQ_TYPE_NO_MATCH;
 }
 
-void print_sam(const fq_index *ix, const fq_opts_t *o, const FqHostReads *hb, int n_pairs, Out &out, FqRead p, const FqRead &mate) {
+// se: bwa_print_sam1(p, mate = 0), the single-end mapper's call (src/BwtMapper.cpp:1369)
+void print_sam(const fq_index *ix, const fq_opts_t *o, const FqHostReads *hb, int n_pairs, Out &out, FqRead p, const FqRead &mate, bool se = false) {
   const int pair = p.r % n_pairs;
   uint8_t seq[FQ_LMAX + 8];
   hb->codes((size_t)p.r, p.full_len, seq);
   const uint8_t *qual = hb->qual((size_t)p.r);
   const std::string name = read_name(hb, pair, p.r / n_pairs, p.revived);
-  if (p.type == FQ_TYPE_NO_MATCH && mate.type == FQ_TYPE_NO_MATCH) {
+  if (p.type == FQ_TYPE_NO_MATCH && (se || mate.type == FQ_TYPE_NO_MATCH)) {
     // both hits of the pair hung over a contig end: the record of a read without a match (bwase.c:563-579).  It prints p->len bases
     // of p->seq, or of p->rseq when the lost hit was on the reverse strand: the reverse complement of the (trimmed) read, and past a
     // trimmed read's end whatever the reference's slot buffer holds -- code 0 here (not modelled, like the other slot leftovers).
-    out.printf("%s\t%d\t*\t0\t0\t*\t*\t0\t0\t", name.c_str(), p.extra_flag | 4 | 8);
+    out.printf("%s\t%d\t*\t0\t0\t*\t*\t0\t0\t", name.c_str(), p.extra_flag | 4 | (se ? 0 : 8));
     for (int j = 0; j < p.len; ++j) {
       int cc = seq[j];
       if (p.strand) { cc = j < p.clip_len ? seq[p.clip_len - 1 - j] : 3; cc = cc < 4 ? 3 - cc : cc; }
@@ -113,12 +114,13 @@ void print_sam(const fq_index *ix, const fq_opts_t *o, const FqHostReads *hb, in
   nn = fq_coor_pac2real(ix, p.pos, j, &seqid);
   if (p.type != FQ_TYPE_NO_MATCH && (int64_t)p.pos + j - ix->contigs[seqid].offset > ix->contigs[seqid].len) flag |= 4;
   if (p.strand) flag |= 16;
-  if (mate.type != FQ_TYPE_NO_MATCH) { if (mate.strand) flag |= 32; } else flag |= 8;
+  if (!se) { if (mate.type != FQ_TYPE_NO_MATCH) { if (mate.strand) flag |= 32; } else flag |= 8; }
   out.printf("%s\t%d\t%s\t%d\t%d\t", name.c_str(), flag, ix->contigs[seqid].name.c_str(), (int)(p.pos - ix->contigs[seqid].offset + 1), p.mapQ);
   if (!p.cigar.empty()) put_cigar(out, p.cigar);
   else if (p.type == FQ_TYPE_NO_MATCH) out.putc('*');
   else out.printf("%dM", p.len);
-  if (mate.type != FQ_TYPE_NO_MATCH) {
+  if (se) out.s.append("\t*\t0\t0\t");
+  else if (mate.type != FQ_TYPE_NO_MATCH) {
     int m_seqid;
     am = mate.seQ < p.seQ ? mate.seQ : p.seQ;
     fq_coor_pac2real(ix, mate.pos, mate.len, &m_seqid);
@@ -141,7 +143,7 @@ void print_sam(const fq_index *ix, const fq_opts_t *o, const FqHostReads *hb, in
     if (nn > 10) XT = 'N';
     out.printf("\tXT:A:%c\t%s:i:%d", XT, (o->mode & FQ_MODE_COMPREAD) ? "NM" : "CM", p.nm);
     if (nn) out.printf("\tXN:i:%d", nn);
-    out.printf("\tSM:i:%d\tAM:i:%d", p.seQ, am);
+    if (!se) out.printf("\tSM:i:%d\tAM:i:%d", p.seQ, am);
     if (p.type != FQ_TYPE_MATESW) { out.printf("\tX0:i:%d", (int)p.c1); if ((int)p.c1 <= o->max_top2) out.printf("\tX1:i:%d", (int)p.c2); }
     out.printf("\tXM:i:%d\tXO:i:%d\tXG:i:%d", p.n_mm, p.n_gapo, p.n_gapo + p.n_gape);
     if (p.has_md) { out.s.append("\tMD:Z:"); out.s.append(p.md); }
@@ -194,6 +196,12 @@ extern "C" int64_t fq_sam_format_last(fq_ctx_t *c, char *buf, int64_t cap) {
   out.s.reserve((size_t)S->n_surv * 900);
   for (int sp = 0; sp < S->n_surv; ++sp) {
     if (S->reads[2 * sp].type == FQ_TYPE_NO_MATCH && S->reads[2 * sp + 1].type == FQ_TYPE_NO_MATCH) continue;   // src/BwtMapper.cpp:2038-2042
+    if (o->single_end) {   // src/BwtMapper.cpp:1355-1370: AddAlignment(p, 0), then bwa_print_sam1(p, 0)
+      FqRead a = S->reads[2 * sp];
+      bridge_mutation(ix, a);
+      print_sam(ix, o, hb, S->n_pairs, out, a, a, true);
+      continue;
+    }
     FqRead a = S->reads[2 * sp], b = S->reads[2 * sp + 1];
     bridge_mutation(ix, a);
     bridge_mutation(ix, b);
@@ -211,6 +219,8 @@ extern "C" int64_t fq_stage_dump_last(fq_ctx_t *c, char *buf, int64_t cap) {
   fq_ctx_all_reads(c, &filt, &ltrim);
   if (S->n_pairs > 0 && (!filt || !ltrim)) return FQ_EINVAL;   // per-read arrays of the whole batch are only fetched in debug mode
   const int n = S->n_pairs;
+  const fq_opts_t *opts = fq_ctx_opts(c);
+  const int n_ends = opts->single_end ? 1 : 2;   // the single-end mapper's dump has one end, no insert-size line and no mate-rescue stage
   Out o;
   std::vector<int> surv_of(n, -1);
   for (int sp = 0; sp < S->n_surv; ++sp) surv_of[S->pair_idx[sp]] = sp;
@@ -219,9 +229,9 @@ extern "C" int64_t fq_stage_dump_last(fq_ctx_t *c, char *buf, int64_t cap) {
   for (int sb = 0; sb < n_sub; ++sb) {
     const int i0 = sb * Bp, i1 = std::min(n, i0 + Bp);
     o.printf("B %d %d\n", sb, i1 - i0);
-    for (int e = 0; e < 2; ++e)
+    for (int e = 0; e < n_ends; ++e)
       for (int i = i0; i < i1; ++i) o.printf("F %d %d filt=%d len=%d clip=%d full=%d\n", e, i - i0, filt[e * n + i], ltrim[e * n + i], ltrim[e * n + i], hb->len((size_t)e * n + i));
-    for (int e = 0; e < 2; ++e)
+    for (int e = 0; e < n_ends; ++e)
       for (int i = i0; i < i1; ++i) {
         const int sp = surv_of[i];
         const int s = sp < 0 ? -1 : S->s_of[2 * sp + e];
@@ -236,18 +246,20 @@ extern "C" int64_t fq_stage_dump_last(fq_ctx_t *c, char *buf, int64_t cap) {
     const fq_isize_t &ii = S->isize_sub[sb];
     uint64_t a, s, p;
     memcpy(&a, &ii.avg, 8); memcpy(&s, &ii.std, 8); memcpy(&p, &ii.ap_prior, 8);
-    o.printf("I avg=%016llx std=%016llx ap=%016llx low=%u high=%u hb=%u\n", (unsigned long long)a, (unsigned long long)s, (unsigned long long)p,
-             ii.low, ii.high, ii.high_bayesian);
+    if (n_ends == 2)
+      o.printf("I avg=%016llx std=%016llx ap=%016llx low=%u high=%u hb=%u\n", (unsigned long long)a, (unsigned long long)s, (unsigned long long)p,
+               ii.low, ii.high, ii.high_bayesian);
     const std::vector<FqRead> *stages[3] = {&S->stage_P, &S->stage_S, &S->reads};
     const char tags[3] = {'P', 'S', 'R'};
     for (int st = 0; st < 3; ++st) {
       if (stages[st]->size() != S->reads.size()) continue;   // snapshots are only kept in debug mode
-      for (int e = 0; e < 2; ++e)
+      if (n_ends == 1 && st == 1) continue;
+      for (int e = 0; e < n_ends; ++e)
         for (int i = i0; i < i1; ++i) {
           const int sp = surv_of[i];
           if (sp >= 0) { dump_rec(o, tags[st], e, i - i0, (*stages[st])[2 * sp + e], st == 2); continue; }
           FqRead d;   // both mates filtered: untouched record (bwa_clean_read_seq state + flags of BwtMapper.cpp:749)
-          d.filtered = 1; d.extra_flag = 1 | (e == 0 ? 64 : 128); d.len = ltrim[e * n + i]; d.full_len = hb->len((size_t)e * n + i);
+          d.filtered = 1; d.extra_flag = n_ends == 1 ? 0 : (1 | (e == 0 ? 64 : 128)); d.len = ltrim[e * n + i]; d.full_len = hb->len((size_t)e * n + i);
           if (st == 2 && d.len != d.full_len) {   // bwa_correct_trimmed touches every record
             d.cigar.push_back((uint16_t)(FQ_OP_M << 14 | d.len)); d.cigar.push_back((uint16_t)(FQ_OP_S << 14 | (d.full_len - d.len))); d.len = d.full_len;
           }

@@ -55,6 +55,11 @@ typedef struct {
   int32_t batch_pairs;        /* reference batch size, READ_BUFFER_SIZE = 262144 (src/BwtMapper.h:36): insert-size
                                  inference and the last_ii chain work on consecutive groups of this many pairs, so one
                                  call may carry many reference batches and still reproduce the reference's output */
+  int32_t single_end;         /* 1: BwtMapper::SingleEndMapper (src/BwtMapper.cpp:1266-1407) -- reads of one file.  A batch then
+                                 holds n_pairs READS (rows [n_pairs][stride], len [n_pairs]; names_mate unused); a result keeps
+                                 the pair layout with an empty record at 2*s+1; main hit and up to three alternative hits per read
+                                 (N_OCC, :33), no pairing, no mate rescue.  ASCII batches only (fq_align_batch / fq_batch_upload). */
+  int32_t pad_opts;
 } fq_opts_t;
 
 void fq_default_opts(fq_opts_t *o);

@@ -409,3 +409,22 @@ def test_bench_call_shape_matches_oracle_on_first_and_last_batch(lib, tmp_path):
             assert len(wu) > 500 and sum(w in gset for w in wu) >= 0.98 * len(wu)
         oa.close()
     ix.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", golden_util.se_case_tags())
+def test_gpu_single_end_matches_reference_golden(tag, golden_cases, lib):
+    """BwtMapper::SingleEndMapper (fq_opts_t::single_end) on the device: the first FASTQ of the case alone."""
+    g = golden_cases[tag]
+    names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
+    ix = api.Index(g["prefix"], device=0)
+    al = api.Aligner(ix, api.default_opts(lib, trim_qual=g["trim_qual"], single_end=1), max_pairs=max(16, g["batch"]), debug=True)
+    st, sam = os.path.join(g["dir"], "gpu_se.stages"), os.path.join(g["dir"], "gpu_se.sam")
+    api.align_stream(al, list(names), seq[:1], qual[:1], lens[:1], g["batch"], st, sam)
+    stats = al.stats()
+    al.close()
+    ix.close()
+    diffs = [d for d in ob.diff_stage_files(g["se_stages"], st)]
+    assert not diffs, "\n".join(diffs)
+    assert filecmp.cmp(g["se_sam"], sam, shallow=False)
+    assert stats["kernel_launches"][2] > 0
