@@ -114,11 +114,11 @@ struct fq_bam {
     *start = refCoord - (name.back() == 'L' ? o.flank_long_len : o.flank_len) + pos1 - 1;
   }
   int id_of(const std::string &chrom) const { auto it = ref_id.find(chrom); return it == ref_id.end() ? -1 : it->second; }
-  void record(const fq_opts_t *ao, const FqHostReads &hb, int n_pairs, FqRead p, const FqRead &mate);
+  void record(const fq_opts_t *ao, const FqHostReads &hb, int n_pairs, FqRead p, const FqRead &mate, bool se = false);   // se: SetSamRecord(p, mate = 0)
 };
 
 // SetSamRecord, src/BwtMapper.cpp:977-1264
-void fq_bam::record(const fq_opts_t *ao, const FqHostReads &hb, int n_pairs, FqRead p, const FqRead &mate) {
+void fq_bam::record(const fq_opts_t *ao, const FqHostReads &hb, int n_pairs, FqRead p, const FqRead &mate, bool se) {
   const std::string name = fq_read_name(&hb, p.r % n_pairs, p.r / n_pairs, p.revived);
   uint8_t codes[FQ_LMAX + 8];
   hb.codes((size_t)p.r, p.full_len, codes);
@@ -130,7 +130,7 @@ void fq_bam::record(const fq_opts_t *ao, const FqHostReads &hb, int n_pairs, FqR
   std::string seq, qual;
   Tags T;
   bool mate_same = false;
-  if (p.type != FQ_TYPE_NO_MATCH || mate.type != FQ_TYPE_NO_MATCH) {
+  if (p.type != FQ_TYPE_NO_MATCH || (!se && mate.type != FQ_TYPE_NO_MATCH)) {
     int seqid, nn, am = 0, j, readRealStart = 0;
     flag = p.extra_flag;
     if (p.type == FQ_TYPE_NO_MATCH) { p.pos = mate.pos; p.strand = mate.strand; flag |= 4; j = 1; }
@@ -138,13 +138,14 @@ void fq_bam::record(const fq_opts_t *ao, const FqHostReads &hb, int n_pairs, FqR
     nn = fq_coor_pac2real(ix, p.pos, j, &seqid);
     if (p.type != FQ_TYPE_NO_MATCH && (int64_t)p.pos + j - ix->contigs[seqid].offset > ix->contigs[seqid].len) flag |= 4;
     if (p.strand) flag |= 16;
-    if (mate.type != FQ_TYPE_NO_MATCH) { if (mate.strand) flag |= 32; } else flag |= 8;
+    if (!se) { if (mate.type != FQ_TYPE_NO_MATCH) { if (mate.strand) flag |= 32; } else flag |= 8; }
     std::string chrom;
     if (p.type == FQ_TYPE_NO_MATCH) { rid = -1; pos1 = 0; }
     else { genome_coord(seqid, (int)((int64_t)p.pos - ix->contigs[seqid].offset + 1), &chrom, &readRealStart); rid = id_of(chrom); pos1 = readRealStart; }
     mapq = p.mapQ;
     if (p.type != FQ_TYPE_NO_MATCH) { if (!p.cigar.empty()) cigar = p.cigar; else cigar.push_back((uint16_t)(FQ_OP_M << 14 | p.len)); }
-    if (mate.type != FQ_TYPE_NO_MATCH) {
+    if (se) { mrid = -1; mpos1 = 0; isize = 0; }      // no mate: "*", 0, 0 (:1118-1122)
+    else if (mate.type != FQ_TYPE_NO_MATCH) {
       int m_seqid, mstart;
       am = mate.seQ < p.seQ ? mate.seQ : p.seQ;
       fq_coor_pac2real(ix, mate.pos, mate.len, &m_seqid);
@@ -171,7 +172,7 @@ void fq_bam::record(const fq_opts_t *ao, const FqHostReads &hb, int n_pairs, FqR
       T.a("XT", XT);
       T.i((ao->mode & FQ_MODE_COMPREAD) ? "NM" : "CM", p.nm);
       if (nn) T.i("XN", nn);
-      T.i("SM", p.seQ); T.i("AM", am);
+      if (!se) { T.i("SM", p.seQ); T.i("AM", am); }
       if (p.type != FQ_TYPE_MATESW) { T.i("X0", p.c1); if ((int)p.c1 <= ao->max_top2) T.i("X1", p.c2); }
       T.i("XM", p.n_mm); T.i("XO", p.n_gapo); T.i("XG", p.n_gapo + p.n_gape);
       if (p.has_md) T.z("MD", p.md);
@@ -188,7 +189,7 @@ void fq_bam::record(const fq_opts_t *ao, const FqHostReads &hb, int n_pairs, FqR
       }
     }
   } else {   // no match on either mate (:1225-1257)
-    flag = p.extra_flag | 4 | 8;
+    flag = p.extra_flag | 4 | (se ? 0 : 8);
     for (int j = 0; j != p.len; ++j) {
       int cc = codes[j];
       if (p.strand) { cc = j < p.clip_len ? codes[p.clip_len - 1 - j] : 3; cc = cc < 4 ? 3 - cc : cc; }
@@ -290,6 +291,15 @@ extern "C" int fq_bam_add_last(fq_bam_t *b, fq_ctx_t *c) {
   if (S->n_surv > 0 && !hb.has_qual()) { b->err = "the batch carries no qualities"; return FQ_EINVAL; }
   for (int sp = 0; sp < S->n_surv; ++sp) {
     if (S->reads[2 * sp].type == FQ_TYPE_NO_MATCH && S->reads[2 * sp + 1].type == FQ_TYPE_NO_MATCH) continue;
+    if (ao->single_end) {   // SingleEndMapper's BAM branch (src/BwtMapper.cpp:1372-1387): AddAlignment(p, 0), SetSamRecord(p, 0)
+      FqRead p = S->reads[2 * sp];
+      int seqid;
+      const int j = (int)(ref_end(p) - p.pos);
+      fq_coor_pac2real(b->ix, p.pos, j, &seqid);
+      if ((int64_t)p.pos + j - b->ix->contigs[seqid].offset > b->ix->contigs[seqid].len) p.type = FQ_TYPE_NO_MATCH;
+      b->record(ao, hb, S->n_pairs, p, p, true);
+      continue;
+    }
     FqRead p = S->reads[2 * sp], q = S->reads[2 * sp + 1];
     for (FqRead *r : {&p, &q})   // StatCollector::AddAlignment first (src/StatCollector.cpp:955-971)
       if (r->type != FQ_TYPE_NO_MATCH) {

@@ -97,10 +97,12 @@ struct ReadSlots {
   long long pairs_seen = 0;
   int batch_pairs = 0;
   bool clean = false;
+  bool fresh = false;                 // the single-end reader's buffers are new and zeroed for every read: nothing lingers
   // name to print for the next record of this file; `row` holds the record's bases (n of them) and receives the slot's leftovers
   std::string put(const std::string &nm, uint8_t *row, size_t n, size_t stride) {
     const size_t l = nm.size();
     const bool mate_suffix = l > 2 && nm[l - 2] == '/' && (nm[l - 1] == '1' || nm[l - 1] == '2');   // :565-570
+    if (fresh) return mate_suffix ? nm.substr(0, l - 2) : nm;
     const long long g = pairs_seen++;
     const int set = (int)((g / batch_pairs) & 1);
     const size_t slot = (size_t)(g % batch_pairs);
@@ -241,12 +243,11 @@ int main(int argc, char **argv) {
       char a[4096] = "", b[4096] = "";
       const int got = sscanf(line, "%4095s %4095s", a, b);
       if (got < 1) continue;
-      if (got < 2) die(std::string("single-end line in --fq_list (") + a + "): the single-end mapper is not built");
-      inputs.emplace_back(a, b);
+      inputs.emplace_back(a, got < 2 ? "" : b);      // one column: single-end (src/BwtMapper.cpp:255-262)
     }
     fclose(fl);
   } else {
-    if (A.fq1.empty() || A.fq2.empty()) die("--fastq_1 and --fastq_2 (or --fq_list) are required (paired-end path)");
+    if (A.fq1.empty()) die("--fastq_1 (and --fastq_2 for paired-end reads), or --fq_list, is required");
     inputs.emplace_back(A.fq1, A.fq2);
   }
   if (A.o.batch_pairs < 1) die("--batch_pairs must be positive");
@@ -297,6 +298,63 @@ int main(int argc, char **argv) {
   // one (the reference, too, decodes the two files on two IO threads: BwtMapper.cpp:1873-1935).
   for (const auto &input : inputs) {
   A.fq1 = input.first; A.fq2 = input.second;
+  if (A.fq2.empty() || A.fq2 == "Empty") {
+    // ---- BwtMapper::SingleEndMapper (src/BwtMapper.cpp:1266-1407): one file, its own srand48 stream; the reader hands out fresh zeroed
+    //      buffers (bwa_read_seq_with_hash, :350-475), so neither bases nor name tails of earlier reads linger
+    fprintf(stderr, "NOTICE - Processing Single End mapping\t%s\n", A.fq1.c_str());
+    if (qc) fq_qc_begin_file(qc, A.fq1.c_str(), A.fq1.c_str());      // FileStatCollector(fq1): both names are the one file
+    fq_opts_t so = A.o;
+    so.single_end = 1;
+    fq_ctx_t *ctx = nullptr;
+    rc = fq_ctx_create(ix, &so, (int32_t)A.chunk_pairs, &ctx);
+    if (rc) die("fq_ctx_create failed (" + std::to_string(rc) + "): option outside the supported range");
+    FastqReader r1(A.fq1);
+    ReadSlots slot1;
+    slot1.batch_pairs = A.o.batch_pairs; slot1.clean = true; slot1.fresh = true;
+    int stride = 0;
+    {
+      std::string nm, sq, ql;
+      size_t l = 0;
+      struct stat s1;
+      if (stat(A.fq1.c_str(), &s1) == 0 && S_ISREG(s1.st_mode)) { FastqReader p1(A.fq1); if (p1.next(nm, sq, ql)) l = sq.size(); }
+      stride = (int)((std::max<size_t>(l, (size_t)std::max(A.read_len, 16)) + 15) & ~(size_t)15);
+    }
+    const int name_stride = 304;
+    long long num_read = 0, filtered = 0, unmapped = 0;
+    std::vector<char> sam;
+    EndChunk bufs1[2];
+    fill_chunk(r1, slot1, bufs1[0], A.chunk_pairs, stride, name_stride);
+    for (int slot = 0;; slot ^= 1) {
+      EndChunk &e0 = bufs1[slot];
+      if (!e0.error.empty()) die(e0.error);
+      const int n = e0.n;
+      if (n == 0) break;
+      const bool last = e0.eof;
+      std::thread prefetch;
+      if (!last) prefetch = std::thread(fill_chunk, std::ref(r1), std::ref(slot1), std::ref(bufs1[slot ^ 1]), A.chunk_pairs, stride, name_stride);
+      fq_read_batch_t in = {n, stride, e0.seq.data(), e0.qual.data(), e0.len.data(), e0.names.data(), (int32_t)name_stride, nullptr};
+      fq_result_batch_t res;
+      rc = fq_align_batch(ctx, &in, &res);
+      if (rc) die(std::string("fq_align_batch failed: ") + fq_ctx_last_error(ctx));
+      if (qc && (rc = fq_qc_add_last(qc, ctx))) die(std::string("QC consumer failed: ") + fq_qc_last_error(qc));
+      if (A.sam_out) {
+        const int64_t sz = fq_sam_format_last(ctx, nullptr, 0);
+        sam.resize((size_t)sz + 1);
+        fq_sam_format_last(ctx, sam.data(), sz + 1);
+        fwrite(sam.data(), 1, (size_t)sz, stdout);
+      } else if ((rc = fq_bam_add_last(bam, ctx))) die("writing " + A.out_prefix + ".bam failed");
+      num_read += n; filtered += res.n_both_filtered; unmapped += res.n_both_unmapped;
+      fprintf(stderr, "NOTICE - %lld sequences are loaded.\n", num_read);
+      if (prefetch.joinable()) prefetch.join();
+      if (last) break;
+    }
+    fflush(stdout);
+    notice("%lld sequences are filtered.", filtered);
+    notice("%lld sequences are unmapped.", unmapped);
+    if (qc) fq_qc_end_file(qc);
+    fq_ctx_destroy(ctx);
+    continue;
+  }
   fprintf(stderr, "NOTICE - Processing Pair End mapping\t%s\t%s\n", A.fq1.c_str(), A.fq2.c_str());
   if (qc) fq_qc_begin_file(qc, A.fq1.c_str(), A.fq2.c_str());
   fq_ctx_t *ctx = nullptr;

@@ -166,6 +166,7 @@ struct fq_qc {
   bool add_single(const Rec &p, const FqHostReads &hb);
   int pair_status(const Rec *p, const Rec *q, int type);
   int add_alignment(Rec &p, Rec &q, const FqHostReads &hb, long long &total_add_failed);
+  int add_alignment_se(Rec &p, const FqHostReads &hb, long long &total_add_failed);   // AddAlignment(p, q = 0): the single-end mapper's call
   const char *contig_name(int seqid) const { return ix->contigs[seqid].name.c_str(); }
 };
 
@@ -488,6 +489,27 @@ extern "C" int fq_qc_end_file(fq_qc_t *q) {
   return FQ_OK;
 }
 
+// AddAlignment(p, 0), :950-1000 with q == nullptr
+int fq_qc::add_alignment_se(Rec &P, const FqHostReads &hb, long long &failed) {
+  int seqid = 0;
+  if (P.type != FQ_TYPE_NO_MATCH) {
+    const int j = (int)(P.end() - P.r->pos);
+    fq_coor_pac2real(ix, P.r->pos, j, &seqid);
+    if ((int64_t)P.r->pos + j - ix->contigs[seqid].offset > ix->contigs[seqid].len) P.type = FQ_TYPE_NO_MATCH;
+  }
+  if (P.type == FQ_TYPE_NO_MATCH) { failed += 2; return 0; }
+  auto partial = [](const Rec &R) { for (uint16_t g : R.r->cigar) if ((g >> 14) == FQ_OP_S) return true; return false; };
+  const std::string pname = contig_name(seqid);
+  if (add_single(P, hb)) {
+    if (pname.find('Y') != std::string::npos || pname.find('X') != std::string::npos) { ++contig_status[pname].overlapped; if (!partial(P)) ++contig_status[pname].fully; }
+    pair_status(&P, nullptr, 0);
+    failed += 1;
+    return 1;
+  }
+  failed += 2;
+  return 0;
+}
+
 // the consumer loop of PairEndMapper over one batch (src/BwtMapper.cpp:2026-2052): counters, then AddAlignment per surviving pair
 extern "C" int fq_qc_add_last(fq_qc_t *q, fq_ctx_t *c) {
   if (!q || !c || !q->file_open) return FQ_EINVAL;
@@ -498,11 +520,17 @@ extern "C" int fq_qc_add_last(fq_qc_t *q, fq_ctx_t *c) {
   if (S->n_surv > 0 && !hb.has_qual()) { q->err = "the batch carries no qualities"; return FQ_EINVAL; }
   FileStat &F = q->cur;
   F.NumBase += fq_ctx_last_bases(c);
-  F.NumRead += 2LL * S->n_pairs;
+  F.NumRead += (ao->single_end ? 1LL : 2LL) * S->n_pairs;
   F.TotalFiltered += S->n_pairs - S->n_surv;
   for (int sp = 0; sp < S->n_surv; ++sp) {
     const FqRead &a = S->reads[2 * sp], &b = S->reads[2 * sp + 1];
     if (a.type == FQ_TYPE_NO_MATCH && b.type == FQ_TYPE_NO_MATCH) { ++F.BwaUnmapped; continue; }
+    if (ao->single_end) {   // SingleEndMapper's consumer loop, src/BwtMapper.cpp:1355-1370
+      Rec P;
+      P.r = &a; P.type = a.type; P.name = fq_read_name(&hb, a.r % S->n_pairs, a.r / S->n_pairs, a.revived);
+      F.TotalRetained += q->add_alignment_se(P, hb, F.TotalMAPQ);
+      continue;
+    }
     Rec P, Q;
     P.r = &a; P.type = a.type; P.name = fq_read_name(&hb, a.r % S->n_pairs, a.r / S->n_pairs, a.revived);
     Q.r = &b; Q.type = b.type; Q.name = fq_read_name(&hb, b.r % S->n_pairs, b.r / S->n_pairs, b.revived);

@@ -222,6 +222,7 @@ def sparse_to_npz(path_sparse: str, path_npz: str) -> None:
 
 
 SE_CASES = ("basic", "repeat", "trim76", "edge", "long250", "nref", "example151")
+SE_CONSUMER_CASES = ("basic", "trim76", "edge")
 
 
 def add_se_outputs(tag):
@@ -234,7 +235,11 @@ def add_se_outputs(tag):
         args = ["--se", 1, "--batch", g["batch"], "--genome_size", g["genome_size"]] + (["--q", g["trim_qual"]] if g["trim_qual"] else []) + \
                (["--read_len", g["qc_read_len"]] if g["qc_read_len"] != 151 else [])
         ob.run_reference(g["prefix"], g["fq1"], g["fq2"], os.path.join(tmp, "se_out"), *args)
-        for src, dst in (("se_out.stages", "ref_se.stages.gz"), ("se_out.sam", "ref_se.sam.gz")):
+        files = [("se_out.stages", "ref_se.stages.gz"), ("se_out.sam", "ref_se.sam.gz")]
+        if tag in SE_CONSUMER_CASES:     # StatCollector's files and the BAM branch (SetSamRecord(p, 0)) of the same single-end run
+            ob.run_reference(g["prefix"], g["fq1"], g["fq2"], os.path.join(tmp, "se_bam"), "--bam_dump", 1, "--fai", os.path.join(tmp, "genome.fai"), *args)
+            files += [("se_out" + ext, "ref_se.qc" + ext + ".gz") for ext in QC_OUT_EXT] + [("se_bam.bamtxt", "ref_se.bamtxt.gz"), ("se_bam.bamhdr", "ref_se.bamhdr.gz")]
+        for src, dst in files:
             with open(os.path.join(tmp, src), "rb") as fi, gzip.GzipFile(os.path.join(out, dst), "wb", mtime=0) as fo:
                 fo.write(fi.read())
     print(tag, "-> single-end goldens")

@@ -85,22 +85,27 @@ def decode_bam(path):
     return text, refs, recs
 
 
-def bam_case(g, lib, device=None, packed=False):
+def bam_case(g, lib, device=None, packed=False, se=False):
+    """se: the single-end mapper on the first FASTQ alone (SetSamRecord(p, 0)), against the ref_se.* goldens."""
     names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
     ix = api.Index(g["prefix"], lib=lib) if device is None else api.Index(g["prefix"], device=device, lib=lib)
-    al = api.Aligner(ix, api.default_opts(lib, trim_qual=g["trim_qual"]), max_pairs=max(16, g["batch"]))
-    path = os.path.join(g["dir"], "got.bam")
+    al = api.Aligner(ix, api.default_opts(lib, trim_qual=g["trim_qual"], single_end=1 if se else 0), max_pairs=max(16, g["batch"]))
+    path = os.path.join(g["dir"], "got_se.bam" if se else "got.bam")
     bam = api.BamWriter(ix, os.path.join(g["dir"], "genome.fai"), path)
-    api.align_stream(al, names, seq, qual, lens, g["batch"], None, None, bam=bam, packed=packed)
+    if se:
+        api.align_stream(al, list(names), seq[:1], qual[:1], lens[:1], g["batch"], None, None, bam=bam)
+    else:
+        api.align_stream(al, names, seq, qual, lens, g["batch"], None, None, bam=bam, packed=packed)
     bam.close()
     al.close(); ix.close()
     check_bgzf(path)
     text, refs, recs = decode_bam(path)
-    want_hdr = open(os.path.join(g["dir"], "ref.bamhdr")).read()
+    stem = "ref_se" if se else "ref"
+    want_hdr = open(os.path.join(g["dir"], stem + ".bamhdr")).read()
     assert text == want_hdr, "header:\n%s\nvs the reference's\n%s" % (text, want_hdr)
     assert [r[0] for r in refs] == [l.split("\t")[1][3:] for l in want_hdr.splitlines() if l.startswith("@SQ")]
     want = []
-    for line in open(os.path.join(g["dir"], "ref.bamtxt")):
+    for line in open(os.path.join(g["dir"], stem + ".bamtxt")):
         f = line.rstrip("\n").split("\t")
         want.append(f[:11] + sorted(f[11:]))
     assert len(recs) == len(want), "%d records vs %d" % (len(recs), len(want))
@@ -111,3 +116,11 @@ def bam_case(g, lib, device=None, packed=False):
 @pytest.mark.parametrize("tag", golden_util.case_tags())
 def test_bam_records_match_reference(tag, golden_cases, emu_lib):
     bam_case(golden_cases[tag], emu_lib)
+
+
+SE_CONSUMER_TAGS = [t for t in golden_util.se_case_tags() if os.path.exists(os.path.join(golden_util.GOLD, t, "ref_se.bamtxt.gz"))]
+
+
+@pytest.mark.parametrize("tag", SE_CONSUMER_TAGS)
+def test_single_end_bam_records_match_reference(tag, golden_cases, emu_lib):
+    bam_case(golden_cases[tag], emu_lib, se=True)

@@ -11,14 +11,16 @@ from test_qc_consumer import QC_FILES, qc_bytes
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def cli_bam_and_qc(exe, g, out):
+def cli_bam_and_qc(exe, g, out, se=False):
+    """se: only --fastq_1 is given (BwtMapper::SingleEndMapper), checked against the ref_se.* goldens."""
     prefix = g["prefix"][:-len(".FASTQuick.fa")]
     genome = os.path.join(g["dir"], "genome")               # <REFERENCE_PATH>.fai is the golden's genome.fai
     with open(g["prefix"] + ".param", "w") as fh:           # the 7 lines `FASTQuick index` writes (src/FASTQuick.cpp:145-151)
         fh.write("REFERENCE_PATH\t%s\nTARGET_REGION_PATH\tEmpty\nDBSNP_VCF_PATH\tEmpty\nNUM_VAR_LONG\t4\nNUM_VAR_SHORT\t36\n"
                  "SHORT_FLANK_LENGTH\t250\nLONG_FLANK_LENGTH\t1000\n" % genome)
-    cmd = [exe, "align", "--index_prefix", prefix, "--fastq_1", g["fq1"], "--fastq_2", g["fq2"], "--out_prefix", out,
+    cmd = [exe, "align", "--index_prefix", prefix, "--fastq_1", g["fq1"]] + ([] if se else ["--fastq_2", g["fq2"]]) + ["--out_prefix", out,
            "--batch_pairs", str(g["batch"]), "--chunk_pairs", str(2 * g["batch"])]
+    stem = "ref_se" if se else "ref"
     if g["trim_qual"]:
         cmd += ["--q", str(g["trim_qual"])]
     run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
@@ -26,13 +28,13 @@ def cli_bam_and_qc(exe, g, out):
     assert run.stdout == b"", "no SAM text on stdout in BAM mode"
     check_bgzf(out + ".bam")
     text, _refs, recs = decode_bam(out + ".bam")
-    assert text == open(os.path.join(g["dir"], "ref.bamhdr")).read()
-    want = [(lambda f: f[:11] + sorted(f[11:]))(l.rstrip("\n").split("\t")) for l in open(os.path.join(g["dir"], "ref.bamtxt"))]
+    assert text == open(os.path.join(g["dir"], stem + ".bamhdr")).read()
+    want = [(lambda f: f[:11] + sorted(f[11:]))(l.rstrip("\n").split("\t")) for l in open(os.path.join(g["dir"], stem + ".bamtxt"))]
     assert recs == want
     for f in QC_FILES:
         if f in ("Summary", "FASTQ.csv"):    # (genome size: the three contigs of the .fai here, one genome in the golden run; file names)
             continue
-        assert qc_bytes(out + "." + f) == qc_bytes(os.path.join(g["dir"], "ref.qc." + f)), f
+        assert qc_bytes(out + "." + f) == qc_bytes(os.path.join(g["dir"], stem + ".qc." + f)), f
     assert os.path.getsize(out + ".Summary") > 100
 
 
@@ -40,3 +42,22 @@ def test_cli_writes_bam_and_qc_files(golden_cases, tmp_path):
     emu = os.path.join(HERE, "emu")
     subprocess.check_call(["make", "-s", "-C", emu, "libfq_emu.so", "FASTQuick_emu"])
     cli_bam_and_qc(os.path.join(emu, "FASTQuick_emu"), golden_cases["qc"], str(tmp_path / "cli_qc"))
+
+
+def test_cli_single_end_writes_bam_and_qc_files(golden_cases, tmp_path):
+    emu = os.path.join(HERE, "emu")
+    subprocess.check_call(["make", "-s", "-C", emu, "libfq_emu.so", "FASTQuick_emu"])
+    cli_bam_and_qc(os.path.join(emu, "FASTQuick_emu"), golden_cases["edge"], str(tmp_path / "cli_se"), se=True)
+
+
+def test_cli_single_end_sam_text(golden_cases, tmp_path):
+    """--sam_out with --fastq_1 alone: the single-end mapper's SAM text."""
+    emu = os.path.join(HERE, "emu")
+    subprocess.check_call(["make", "-s", "-C", emu, "libfq_emu.so", "FASTQuick_emu"])
+    g = golden_cases["trim76"]
+    prefix = g["prefix"][:-len(".FASTQuick.fa")]
+    cmd = [os.path.join(emu, "FASTQuick_emu"), "align", "--index_prefix", prefix, "--fastq_1", g["fq1"], "--out_prefix", str(tmp_path / "se"), "--sam_out",
+           "--batch_pairs", str(g["batch"]), "--q", str(g["trim_qual"])]
+    run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert run.returncode == 0, run.stderr.decode(errors="replace")[-2000:]
+    assert run.stdout == open(g["se_sam"], "rb").read()

@@ -428,3 +428,14 @@ def test_gpu_single_end_matches_reference_golden(tag, golden_cases, lib):
     assert not diffs, "\n".join(diffs)
     assert filecmp.cmp(g["se_sam"], sam, shallow=False)
     assert stats["kernel_launches"][2] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["basic", "trim76", "edge"])
+def test_gpu_single_end_consumers_match_reference(tag, golden_cases, lib):
+    """The single-end mapper's StatCollector files (AddAlignment(p, 0)) and BAM records (SetSamRecord(p, 0)) from the device path."""
+    from test_qc_consumer import qc_case, explain
+    from test_bam_writer import bam_case
+    bad = qc_case(golden_cases[tag], lib, device=0, se=True)
+    assert not bad, explain(bad)
+    bam_case(golden_cases[tag], lib, device=0, se=True)
