@@ -158,7 +158,7 @@ struct Args {
 };
 
 int usage() {
-  fprintf(stderr, "Usage: FASTQuick_amd align --index_prefix P --fastq_1 R1.fq[.gz] --fastq_2 R2.fq[.gz] | --fq_list LIST  --out_prefix O [--sam_out] [--RG STR] [--cal_dup]\n"
+  fprintf(stderr, "Usage: FASTQuick_amd align --index_prefix P --fastq_1 R1.fq[.gz] [--fastq_2 R2.fq[.gz]] | --fq_list LIST  --out_prefix O [--sam_out] [--RG STR] [--cal_dup]\n"
                   "                       [--q INT] [--n FLOAT|INT] [--kmer_thresh INT] [--o INT] [--e INT] [--i INT] [--d INT] [--l INT] [--k INT]\n"
                   "                       [--m INT] [--R INT] [--N] [--L] [--I] [--max_isize INT] [--max_occ INT] [--is_sw] [--n_multi INT] [--N_multi INT]\n"
                   "                       [--ap_prior FLOAT] [--force_isize] [--t INT] [--chunk_pairs INT] [--batch_pairs INT] [--device INT] [--read_len INT] [--clean_names]\n"

@@ -17,6 +17,7 @@ ap.add_argument("--start", type=int, default=0)
 ap.add_argument("--adversarial", action="store_true", help="tiny, repeat-rich references and error-rich reads: edge and tie-breaking cases")
 ap.add_argument("--ragged", action="store_true", help="reads of mixed length (96 bp or more: DESIGN.md section 6); the SAM QUAL column, which the "
                 "reference prints with the tail of an earlier longer read, is left out of the comparison")
+ap.add_argument("--se", action="store_true", help="the single-end mapper (BwtMapper::SingleEndMapper) on the first file alone")
 args = ap.parse_args()
 
 
@@ -90,16 +91,24 @@ for seed in range(args.start, args.start + args.seeds):
             import numpy as np
             lo = (40 if seed % 4 == 1 else 12) if seed % 2 else max(96, read_len - 54)      # odd seeds: reads under 96 bp too (down to 12), rows carry the slot history (Q7)
             rb.lens[:] = np.random.default_rng(seed).integers(lo, read_len + 1, rb.lens.shape)
-            ob.apply_slot_history(rb.seq, rb.lens, batch)
+            if args.se:      # the single-end reader hands out fresh zeroed buffers: nothing behind a short read
+                for e in range(2):
+                    for i in range(rb.seq.shape[1]):
+                        rb.seq[e, i, rb.lens[e, i]:] = 0
+            else:
+                ob.apply_slot_history(rb.seq, rb.lens, batch)
         if mode & 0x200:
             rb.qual[rb.qual > 0] += 31          # the input then is Phred+64
         f1, f2 = rb.write_fastq(os.path.join(d, "reads"))
-        ob.run_reference(pre, f1, f2, os.path.join(d, "ref_out"), *extra)
+        ob.run_reference(pre, f1, f2, os.path.join(d, "ref_out"), *(extra + (["--se", 1] if args.se else [])))
         oa = ob.OracleAligner(pre, ob.default_opts(**okw))
-        oa.align(rb.names, rb.seq, rb.qual, rb.lens, d + "/o.st", d + "/o.sam", batch=batch)
+        if args.se:
+            oa.align_se(list(rb.names), rb.seq[0], rb.qual[0], rb.lens[0], d + "/o.st", d + "/o.sam", batch=batch)
+        else:
+            oa.align(rb.names, rb.seq, rb.qual, rb.lens, d + "/o.st", d + "/o.sam", batch=batch)
         oa.close()
         diffs = [x for x in ob.diff_stage_files(d + "/ref_out.stages", d + "/o.st")]
-        if args.ragged:
+        if args.ragged and not args.se:
             same = sam_without_qual(d + "/ref_out.sam") == sam_without_qual(d + "/o.sam")
         else:
             same = filecmp.cmp(d + "/ref_out.sam", d + "/o.sam", shallow=False)

@@ -14,6 +14,7 @@ ap.add_argument("--seeds", type=int, default=20)
 ap.add_argument("--start", type=int, default=0)
 ap.add_argument("--adversarial", action="store_true", help="tiny, repeat-rich references and error-rich reads: edge and tie-breaking cases")
 ap.add_argument("--ragged", action="store_true", help="reads of mixed length, 96 bp or more")
+ap.add_argument("--se", action="store_true", help="single-end contexts (fq_opts_t::single_end) against the oracle's single-end mapper")
 args = ap.parse_args()
 lib = api.load_library()
 bad = 0
@@ -81,12 +82,23 @@ for seed in range(args.start, args.start + args.seeds):
         import numpy as np
         lo = (40 if seed % 4 == 1 else 15) if seed % 2 else max(96, read_len - 54)      # odd seeds: reads under 96 bp too (down to FQ_LMIN), rows carry the slot history (Q7)
         rb.lens[:] = np.random.default_rng(seed).integers(lo, read_len + 1, rb.lens.shape)
-        ob.apply_slot_history(rb.seq, rb.lens, batch)
+        if args.se:
+            for e in range(2):
+                for i in range(rb.seq.shape[1]):
+                    rb.seq[e, i, rb.lens[e, i]:] = 0
+        else:
+            ob.apply_slot_history(rb.seq, rb.lens, batch)
     ix = api.Index(pre, device=0)
-    al = api.Aligner(ix, api.default_opts(lib, batch_pairs=batch, host_threads=threads, **okw), max_pairs=call, debug=True, tuning=tuning)
-    api.align_stream(al, rb.names, rb.seq, rb.qual, rb.lens, call, d + "/g.st", d + "/g.sam", packed=packed)
+    if args.se:
+        packed = False
+    al = api.Aligner(ix, api.default_opts(lib, batch_pairs=batch, host_threads=threads, single_end=1 if args.se else 0, **okw), max_pairs=call, debug=True, tuning=tuning)
     oa = ob.OracleAligner(pre, ob.default_opts(**okw))
-    oa.align(rb.names, rb.seq, rb.qual, rb.lens, d + "/o.st", d + "/o.sam", batch=batch)
+    if args.se:
+        api.align_stream(al, list(rb.names), rb.seq[:1], rb.qual[:1], rb.lens[:1], call, d + "/g.st", d + "/g.sam")
+        oa.align_se(list(rb.names), rb.seq[0], rb.qual[0], rb.lens[0], d + "/o.st", d + "/o.sam", batch=batch)
+    else:
+        api.align_stream(al, rb.names, rb.seq, rb.qual, rb.lens, call, d + "/g.st", d + "/g.sam", packed=packed)
+        oa.align(rb.names, rb.seq, rb.qual, rb.lens, d + "/o.st", d + "/o.sam", batch=batch)
     diffs = [x for x in ob.diff_stage_files(d + "/o.st", d + "/g.st")]
     same = filecmp.cmp(d + "/o.sam", d + "/g.sam", shallow=False)
     ok = not diffs and same
