@@ -966,10 +966,13 @@ int stageA_search(Call &K) {
       uint64_t total = 0;
       CK(fqdev::copy_pinned(h_status, c->d_status.p, (size_t)nw * 4, 0));
       CK(fqdev::copy_pinned(h_naln, c->d_naln.p, (size_t)nw * 4, 0));
-      CKS(d2h_staged(c, &total, c->d_off.p + nw, 8));
+      uint64_t *h_off = (uint64_t *)c->arena.alloc(((size_t)nw + 1) * 8);      // exclusive prefix sums of the hit counts (launch_scan)
+      if (!h_off) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
+      CK(fqdev::copy_pinned(h_off, c->d_off.p, ((size_t)nw + 1) * 8, 0));
       vector<uint8_t> h_bid;
       if (T.nogap && c->kn.gap_split_hard > 0) { h_bid.resize((size_t)nw * 2); CKS(d2h_staged(c, h_bid.data(), c->d_bid_end.p, (size_t)nw * 2)); }
       CKS(sync_staged(c));
+      total = h_off[nw];
       if (!h_bid.empty()) {
         bound_of.assign(n_search, 0);
         for (int w = 0; w < nw; ++w) bound_of[work[c0 + w]] = std::min(h_bid[2 * w], h_bid[2 * w + 1]);
@@ -980,21 +983,26 @@ int stageA_search(Call &K) {
       CK(fqdev::copy_pinned(h_packed, c->d_packed.p, total * sizeof(FqAln), 0));
       CKS(sync_staged(c));
       c->stats.d2h_bytes += (size_t)nw * 8 + total * sizeof(FqAln);
-      uint64_t at = 0;
-      if (next_work.empty() && c0 == 0 && (size_t)nw == work.size() && h_aln.empty()) h_aln.reserve(total);
-      for (int w = 0; w < nw; ++w) {
-        const int s = work[c0 + w];
-        if (h_status[w]) { next_work.push_back(s); ++c->stats.tier_retries; continue; }
-        where[s] = (int64_t)h_aln.size();
-        K.aln_n[s] = h_naln[w];
-        h_aln.insert(h_aln.end(), h_packed + at, h_packed + at + h_naln[w]);
-        at += h_naln[w];
-      }
+      // the packed array holds exactly the lists of the reads that completed, in work order (a failed read reports no hits): it is
+      // appended in one piece, and every read finds its list at the offset the device's prefix sum gave it
+      const int64_t base = (int64_t)h_aln.size();
+      h_aln.insert(h_aln.end(), h_packed, h_packed + total);
+      const int32_t *wk = work.data() + c0;
+      parallel_chunks((size_t)nw, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
+        for (size_t w = lo; w < hi; ++w) {
+          if (h_status[w]) continue;
+          const int s = wk[w];
+          where[s] = base + (int64_t)h_off[w];
+          K.aln_n[s] = h_naln[w];
+        }
+      });
+      for (int w = 0; w < nw; ++w)
+        if (h_status[w]) { next_work.push_back(wk[w]); ++c->stats.tier_retries; }
     }
     work.swap(next_work);
   }
   if (!work.empty()) { c->err = "gap search: exact tier exhausted its pool (internal limit)"; return FQ_ELIMIT; }
-  for (int s = 0; s < n_search; ++s) K.aln_off[s] = where[s] < 0 ? 0 : (uint64_t)where[s];
+  parallel_chunks((size_t)n_search, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) { for (size_t s = lo; s < hi; ++s) K.aln_off[s] = where[s] < 0 ? 0 : (uint64_t)where[s]; });
   c->stats.reads_searched += n_search;
   return FQ_OK;
 }
