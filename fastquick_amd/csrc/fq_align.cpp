@@ -118,6 +118,8 @@ struct FqKnobs {   // experiment / test knobs (fq_ctx_set_tuning); defaults are 
   int gap_long_always = 0;         // ... whatever the state of the queue (tests)
   uint32_t gap_long_pops2 = 0;     // hand-over threshold of the second round of a device-filling call (0: no hand-over)
   int64_t gap_split_hard = 0;      // experiment: after the round without gap children, search reads whose lower bound is >= this in a launch of their own (0: off)
+  int64_t gap_pipeline_min = -1;        // experiment (off): calls that search at least this many reads run the first round in segments, each segment's second round beside the next segment's first
+  int gap_pipeline_segs = 8;
   int64_t gap_nogap_min = 131072;  // launches of at least this many reads begin with the round that searches without gap children (-1: never)
   uint32_t gap_pool = 2048;        // stack entries per lane of the lane kernel
   int gap_no_order = 0;
@@ -179,6 +181,9 @@ struct fq_ctx {
   DevBuf<int32_t> d_order;
   DevBuf<uint32_t> d_order_cnt;
   DevBuf<FqEntry> d_pool;
+  // second set for the search rounds that run beside the first round of a large call (stageA_search)
+  DevBuf<FqGapWork> d_winfo2; DevBuf<uint32_t> d_queue2, d_heads2, d_naln2, d_status2, d_wfull2, d_order_cnt2, d_cnt2; DevBuf<int32_t> d_work2, d_order2;
+  DevBuf<FqPos> d_prec2; DevBuf<uint8_t> d_bid_end2; DevBuf<FqEntry> d_pool2; DevBuf<FqAln> d_aln2;
   DevBuf<FqAln> d_aln, d_packed;
   DevBuf<uint64_t> d_off;
   // SA
@@ -284,6 +289,8 @@ extern "C" int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t v) {
   else if (k == "gap_long_always") c->kn.gap_long_always = (int)v;
   else if (k == "gap_pool") c->kn.gap_pool = (uint32_t)v;
   else if (k == "gap_nogap_min") c->kn.gap_nogap_min = v;
+  else if (k == "gap_pipeline_min") c->kn.gap_pipeline_min = v;
+  else if (k == "gap_pipeline_segs") c->kn.gap_pipeline_segs = (int)std::max<int64_t>(2, std::min<int64_t>(v, 64));
   else if (k == "gap_split_hard") c->kn.gap_split_hard = v;
   else if (k == "gap_long_pops2") c->kn.gap_long_pops2 = (uint32_t)v;
   else if (k == "gap_no_order") c->kn.gap_no_order = (int)v;
@@ -957,9 +964,67 @@ int stageA_search(Call &K) {
         ga.max_waves = waves / 2;
       }
       ga.pool = c->d_pool.p; ga.heads = c->d_heads.p;
-      fqdev::time_begin(FQ_K_GAP);
-      CK(fqdev::launch_gap(ga));
-      fqdev::time_end(FQ_K_GAP);
+      // ---- experiment (gap_pipeline_min, off by default): the first round in segments of the (sorted: hard reads first) queue, and what
+      //      each segment leaves unsettled searched in full on the context's second stream while the next segment's first round runs.
+      //      Measured at 8.4 M reads per call: the search stage takes 93 / 93 / 114 ms with 2 / 4 / 8 segments against 82.6 ms for the two
+      //      rounds one after the other -- at this size the second round is no longer a tail but 40 % of the stage's work, its
+      //      persistent wavefronts take a quarter of the wave slots for as long as they live, and the first round loses more to that
+      //      (it scales with occupancy: 16 -> 12 wavefronts per CU costs it 20 %) than the overlap saves.  Kept, bit-exact and tested.
+      uint32_t n2_total = 0;                 // reads whose second round ran in the pipeline
+      vector<uint32_t> seg_cnt;
+      bool piped = false;
+      const FqGapTier T2 = [&] { FqGapTier t = lane_tier; t.long_pops = 0; return t; }();
+      if (T.nogap && c0 == 0 && (size_t)nw == work.size() && c->kn.gap_pipeline_min >= 0 && (int64_t)nw >= c->kn.gap_pipeline_min && nw >= 64 * c->kn.gap_pipeline_segs) {
+        const int S = c->kn.gap_pipeline_segs;
+        const size_t cap2 = std::max<size_t>(65536, (size_t)nw / 4);
+        FqGapArgs g2{};
+        g2.ix = ix->dev; g2.o = c->ko; g2.o.n_buckets = nb_need; g2.tier = T2; g2.n_work = (int32_t)cap2;
+        const size_t slots2 = (size_t)fqdev::gap_lane_slots(g2);
+        piped = c->d_work2.ensure(cap2) && c->d_cnt2.ensure((size_t)S + 1) && c->d_wfull2.ensure(cap2 * 2 * Lpad) && c->d_prec2.ensure(cap2 * 2 * Ppad) && c->d_winfo2.ensure(cap2) &&
+                c->d_bid_end2.ensure(cap2 * 2) && c->d_order2.ensure(cap2) && c->d_order_cnt2.ensure(2 * FQ_ORDER_KEYS + 2) && c->d_aln2.ensure(cap2 * T2.aln_cap) && c->d_naln2.ensure(cap2) &&
+                c->d_status2.ensure(cap2) && c->d_queue2.ensure(4) && c->d_heads2.ensure(slots2 * FQ_MAX_BUCKETS) && c->d_pool2.ensure(slots2 * T2.pool_cap);
+        if (piped) {
+          CK(fqdev::dzero(c->d_cnt2.p, ((size_t)S + 1) * 4));
+          fqdev::time_begin(FQ_K_GAP);
+          bool room = true;
+          for (int sg = 0; sg < S; ++sg) {
+            ga.seg = sg; ga.n_seg = S;
+            CK(fqdev::launch_gap(ga));
+            if (!room) continue;
+            CK(fqdev::launch_collect(ga.order, ga.split, nw, sg, S, c->d_status.p, c->d_work.p, c->d_work2.p + n2_total, c->d_cnt2.p + sg));
+            uint32_t cnt = 0;
+            CKS(d2h_staged(c, &cnt, c->d_cnt2.p + sg, 4));
+            CKS(sync_staged(c));
+            if ((size_t)n2_total + cnt > cap2) { room = false; continue; }      // (what does not fit stays for the ordinary next round)
+            seg_cnt.push_back(cnt);
+            if (cnt == 0) continue;
+            CK(fqdev::stream_aux(1));
+            CK(fqdev::stream_fork());
+            FqWidthArgs w2{};
+            w2.ix = ix->dev; w2.o = c->ko; w2.seq = K.dseq; w2.stride = K.dstride; w2.len_trim = K.dlen_trim; w2.read_list = K.dread_list;
+            w2.work = c->d_work2.p + n2_total; w2.n_work = (int32_t)cnt; w2.wfull = c->d_wfull2.p; w2.wstride = Lpad; w2.prec = c->d_prec2.p; w2.pstride = Ppad;
+            w2.winfo = c->d_winfo2.p; w2.maxdiff_lut = c->d_maxdiff.p; w2.bid_end = c->d_bid_end2.p; w2.counters = c->d_counters.p;
+            CK(fqdev::launch_width(w2));
+            CK(fqdev::launch_order(c->d_bid_end2.p, (int)cnt, c->d_order2.p, c->d_order_cnt2.p));
+            FqGapArgs gb{};
+            gb.ix = ix->dev; gb.o = c->ko; gb.o.n_buckets = nb_need; gb.n_work = (int32_t)cnt; gb.winfo = c->d_winfo2.p;
+            gb.order = c->kn.gap_no_order ? nullptr : c->d_order2.p; gb.split = c->kn.gap_no_order ? nullptr : c->d_order_cnt2.p + 2 * FQ_ORDER_KEYS;
+            gb.wfull = c->d_wfull2.p; gb.wstride = Lpad; gb.prec = c->d_prec2.p; gb.pstride = Ppad; gb.pool = c->d_pool2.p; gb.heads = c->d_heads2.p; gb.tier = T2;
+            gb.aln = c->d_aln2.p + (size_t)n2_total * T2.aln_cap; gb.n_aln = c->d_naln2.p + n2_total; gb.status = c->d_status2.p + n2_total;
+            gb.counters = c->d_counters.p; gb.queue = c->d_queue2.p; gb.refill_min = 16;
+            CK(fqdev::launch_gap(gb));
+            CK(fqdev::stream_aux(0));
+            n2_total += cnt;
+          }
+          CK(fqdev::stream_join());
+          fqdev::time_end(FQ_K_GAP);
+        }
+      }
+      if (!piped) {
+        fqdev::time_begin(FQ_K_GAP);
+        CK(fqdev::launch_gap(ga));
+        fqdev::time_end(FQ_K_GAP);
+      }
       CK(fqdev::launch_scan(c->d_naln.p, c->d_off.p, (uint32_t)nw));
       CKM(c->p_u32a.ensure((size_t)nw + 2) && c->p_u32b.ensure((size_t)nw + 2));
       uint32_t *h_status = c->p_u32a.p, *h_naln = c->p_u32b.p;
@@ -996,8 +1061,41 @@ int stageA_search(Call &K) {
           K.aln_n[s] = h_naln[w];
         }
       });
+      vector<char> in_round2;
+      vector<int32_t> list2;
+      if (n2_total) {   // the reads whose second round already ran beside the first
+        list2.resize(n2_total);
+        CKS(d2h_staged(c, list2.data(), c->d_work2.p, (size_t)n2_total * 4));
+        CKS(sync_staged(c));
+        in_round2.assign((size_t)n_search, 0);
+        for (int32_t sidx : list2) in_round2[sidx] = 1;
+      }
       for (int w = 0; w < nw; ++w)
-        if (h_status[w]) { next_work.push_back(wk[w]); ++c->stats.tier_retries; }
+        if (h_status[w]) { ++c->stats.tier_retries; if (in_round2.empty() || !in_round2[wk[w]]) next_work.push_back(wk[w]); }
+      if (n2_total) {
+        CK(fqdev::launch_scan(c->d_naln2.p, c->d_off.p, n2_total));
+        uint32_t *st2 = (uint32_t *)c->arena.alloc((size_t)n2_total * 4), *na2 = (uint32_t *)c->arena.alloc((size_t)n2_total * 4);
+        uint64_t *off2 = (uint64_t *)c->arena.alloc(((size_t)n2_total + 1) * 8);
+        if (!st2 || !na2 || !off2) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
+        CK(fqdev::copy_pinned(st2, c->d_status2.p, (size_t)n2_total * 4, 0));
+        CK(fqdev::copy_pinned(na2, c->d_naln2.p, (size_t)n2_total * 4, 0));
+        CK(fqdev::copy_pinned(off2, c->d_off.p, ((size_t)n2_total + 1) * 8, 0));
+        CKS(sync_staged(c));
+        const uint64_t tot2 = off2[n2_total];
+        CKM(c->d_packed.ensure(tot2 + 1) && c->p_aln.ensure(tot2 + 1));
+        CK(fqdev::launch_pack_aln(c->d_aln2.p, c->d_naln2.p, c->d_off.p, T2.aln_cap, n2_total, c->d_packed.p));
+        CK(fqdev::copy_pinned(c->p_aln.p, c->d_packed.p, tot2 * sizeof(FqAln), 0));
+        CKS(sync_staged(c));
+        c->stats.d2h_bytes += (size_t)n2_total * 20 + tot2 * sizeof(FqAln);
+        const int64_t base2 = (int64_t)h_aln.size();
+        h_aln.insert(h_aln.end(), c->p_aln.p, c->p_aln.p + tot2);
+        for (uint32_t t = 0; t < n2_total; ++t) {
+          const int sidx = list2[t];
+          if (st2[t]) { next_work.push_back(sidx); ++c->stats.tier_retries; continue; }
+          where[sidx] = base2 + (int64_t)off2[t];
+          K.aln_n[sidx] = na2[t];
+        }
+      }
     }
     work.swap(next_work);
   }
@@ -1728,6 +1826,7 @@ int run_call(fq_ctx *c, fq_result_batch_t *out) {
   K.c = c;
   K.t_trace = K.t_wall0 = now_ms();
   NodePin pin;
+  (void)fqdev::stream_aux(0);      // (an error return may have left the context on its second stream)
   if (c->kn.trace) { fprintf(stderr, "[fq]   arena: %zu blocks, last call used %zu bytes:", c->arena.blocks.size(), c->arena.total); for (auto &b : c->arena.blocks) fprintf(stderr, " %zu", b.cap); fprintf(stderr, "\n"); }
   c->arena.reset();
   const fq_opts_t &o = c->o;

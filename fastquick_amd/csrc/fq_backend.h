@@ -73,7 +73,15 @@ int launch_scan(const uint32_t *in, uint64_t *out, uint32_t n);
 int launch_pack_aln(const FqAln *aln, const uint32_t *n_aln, const uint64_t *off, uint32_t cap, uint32_t n_work, FqAln *packed);
 int launch_sa(const FqSaArgs &a);
 int launch_saq(const FqSaQueryArgs &a);
-int launch_pair(const FqPairArgs &a);   // pairing of both-mapped pairs (fq_pair_thread)
+int launch_pair(const FqPairArgs &a);
+// A second stream of the context for work that runs beside the main stream's (the second search round of one part of a large call
+// under the first round of the next part): stream_aux(1) sends the following backend calls to it, stream_aux(0) back to the main
+// stream; stream_fork(): the aux stream waits for what the main stream holds so far; stream_join(): the reverse.
+int stream_aux(int on);
+int stream_fork();
+int stream_join();
+// the work items of one queue segment whose search did not complete (status != 0): search indices appended to out[*count ...]
+int launch_collect(const int32_t *order, const uint32_t *split, int n_work, int seg, int n_seg, const uint32_t *status, const int32_t *work, int32_t *out, uint32_t *count);   // pairing of both-mapped pairs (fq_pair_thread)
 int launch_sw(const FqSwArgs &a);          // one task per wavefront (window + query in LDS)
 int launch_sw_serial(const FqSwArgs &a);   // one task per lane out of the task's global scratch: any window size
 int launch_refine(const FqRefineArgs &a);

@@ -25,6 +25,8 @@ struct Pending { int kid; hipEvent_t a, b; };
 struct State {
   int device = 0;
   hipStream_t stream = nullptr;
+  hipStream_t main_stream = nullptr, aux_stream = nullptr;   // `stream` is the one backend calls go to: main_stream, or aux_stream between stream_aux(1) and stream_aux(0)
+  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
   hipStream_t copy_stream = nullptr;              // one of the device's shared copy streams (not owned)
   hipEvent_t copy_done[2] = {nullptr, nullptr};
   hipEvent_t prep_done = nullptr;                 // completion of this context's most recent filter kernel (chained per device)
@@ -81,11 +83,16 @@ State *state_create(int dev) {
             hipEventCreateWithFlags(&s->copy_done[1], hipEventDisableTiming) == hipSuccess &&
             hipEventCreateWithFlags(&s->prep_done, hipEventDisableTiming) == hipSuccess;
   if (!ok) { g_err = "stream / event creation failed"; state_destroy(s); return nullptr; }
+  s->main_stream = s->stream;
   return s;
 }
 void state_destroy(State *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
+  s->stream = s->main_stream ? s->main_stream : s->stream;
+  if (s->aux_stream) { (void)hipStreamSynchronize(s->aux_stream); (void)hipStreamDestroy(s->aux_stream); }
+  if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
+  if (s->join_ev) (void)hipEventDestroy(s->join_ev);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);   // (shared: also waits for other contexts' copies enqueued so far)
   {
@@ -127,6 +134,27 @@ int d2h(void *dst, const void *src, size_t bytes) { if (bytes) FQ_HIP(hipMemcpyA
 int dzero(void *dst, size_t bytes) { if (bytes) FQ_HIP(hipMemsetAsync(dst, 0, bytes, g_stream)); return 0; }
 int dfill(void *dst, int byte, size_t bytes) { if (bytes) FQ_HIP(hipMemsetAsync(dst, byte, bytes, g_stream)); return 0; }
 int sync() { FQ_HIP(hipStreamSynchronize(g_stream)); return 0; }
+int stream_aux(int on) {
+  if (on && !g_cur->aux_stream) {
+    FQ_HIP(hipStreamCreateWithFlags(&g_cur->aux_stream, hipStreamNonBlocking));
+    FQ_HIP(hipEventCreateWithFlags(&g_cur->fork_ev, hipEventDisableTiming));
+    FQ_HIP(hipEventCreateWithFlags(&g_cur->join_ev, hipEventDisableTiming));
+  }
+  g_cur->stream = on ? g_cur->aux_stream : g_cur->main_stream;
+  return 0;
+}
+int stream_fork() {
+  if (!g_cur->aux_stream) return 0;
+  FQ_HIP(hipEventRecord(g_cur->fork_ev, g_cur->main_stream));
+  FQ_HIP(hipStreamWaitEvent(g_cur->aux_stream, g_cur->fork_ev, 0));
+  return 0;
+}
+int stream_join() {
+  if (!g_cur->aux_stream) return 0;
+  FQ_HIP(hipEventRecord(g_cur->join_ev, g_cur->aux_stream));
+  FQ_HIP(hipStreamWaitEvent(g_cur->main_stream, g_cur->join_ev, 0));
+  return 0;
+}
 // input prefetch: copies on the context's copy stream run under the compute stream's kernels; slot = which of the two input
 // buffers the copies since the previous copy_record() filled
 static int copy_stream_get() {
@@ -218,21 +246,24 @@ struct FqQueueFetch2 {
   uint32_t *cursor;
   const uint32_t *split;
   uint32_t n_work;
-  int pref;
+  int pref, seg, n_seg;
   __device__ uint64_t operator()(uint32_t n) const {
     const uint32_t sp = split ? *split : n_work;
-    const uint32_t start[2] = {0u, sp}, len[2] = {sp, n_work - sp};
+    const uint32_t blk_start[2] = {0u, sp}, blk_len[2] = {sp, n_work - sp};
     for (int t = 0; t < 2; ++t) {
       const int b = t == 0 ? pref : 1 - pref;
-      if (len[b] == 0) continue;
-      if (__hip_atomic_load(&cursor[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= len[b]) continue;
+      uint32_t lo, hi;
+      fq_seg_range(blk_len[b], seg, n_seg, &lo, &hi);      // this launch's share of the block
+      const uint32_t len = hi - lo;
+      if (len == 0) continue;
+      if (__hip_atomic_load(&cursor[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= len) continue;
       const uint32_t base = atomicAdd(&cursor[b], n);
-      if (base < len[b]) return (uint64_t)(start[b] + base) | (uint64_t)(start[b] + len[b]) << 32;
+      if (base < len) return (uint64_t)(blk_start[b] + lo + base) | (uint64_t)(blk_start[b] + hi) << 32;
     }
     return 0;
   }
 };
-#define FQ_LANE_FETCH(a) FqQueueFetch2{(a).queue, (a).split, (uint32_t)(a).n_work, (int)((blockIdx.x & 7u) >> 2)}
+#define FQ_LANE_FETCH(a) FqQueueFetch2{(a).queue, (a).split, (uint32_t)(a).n_work, (int)((blockIdx.x & 7u) >> 2), (a).seg, (a).n_seg}
 // persistent wavefronts: every lane pulls reads from the queue until it is empty.  One wavefront per block.
 // LDS per lane: n_buckets 16-bit bucket heads, lane-interleaved.
 __global__ void __launch_bounds__(64) FQ_GAP_OCC k_gap_persist_lds(FqGapArgs a) {
@@ -855,6 +886,27 @@ __global__ void __launch_bounds__(256) k_order_scatter(const uint8_t *bid_end, i
     else { for (int k = FQ_ORDER_KEYS / 2; k < FQ_ORDER_KEYS; ++k) sp += cnt[k]; }
     cnt[2 * FQ_ORDER_KEYS] = sp;
   }
+}
+// the unfinished work items of one queue segment (both blocks' shares of it): their search indices, appended in no particular order
+__global__ void __launch_bounds__(256) k_collect(const int32_t *order, const uint32_t *split, int n_work, int seg, int n_seg, const uint32_t *status, const int32_t *work,
+                                                  int32_t *out, uint32_t *count) {
+  const uint32_t sp = split ? *split : (uint32_t)n_work;
+  const uint32_t blk_start[2] = {0u, sp}, blk_len[2] = {sp, (uint32_t)n_work - sp};
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x, stride = gridDim.x * blockDim.x;
+  for (int b = 0; b < 2; ++b) {
+    uint32_t lo, hi;
+    fq_seg_range(blk_len[b], seg, n_seg, &lo, &hi);
+    for (uint32_t pos = blk_start[b] + lo + t; pos < blk_start[b] + hi; pos += stride) {
+      const int w = order ? order[pos] : (int)pos;
+      if (status[w]) out[atomicAdd(count, 1u)] = work[w];
+    }
+  }
+}
+int launch_collect(const int32_t *order, const uint32_t *split, int n_work, int seg, int n_seg, const uint32_t *status, const int32_t *work, int32_t *out, uint32_t *count) {
+  if (n_work <= 0) return 0;
+  hipLaunchKernelGGL(k_collect, dim3(1024), dim3(256), 0, g_stream, order, split, n_work, seg, n_seg, status, work, out, count);
+  FQ_HIP(hipGetLastError());
+  return 0;
 }
 int launch_order(const uint8_t *bid_end, int n, int32_t *order, uint32_t *cnt) {
   if (n <= 0) return 0;

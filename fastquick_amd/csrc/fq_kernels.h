@@ -690,10 +690,18 @@ struct FqGapArgs {
   const int32_t *order;  // queue position -> work item (NULL: identity): two blocks by better strand, long searches first (fq_order_key)
   const uint32_t *split; // *split = length of the first block of `order` (NULL: one block)
   uint32_t *queue;       // work-queue cursors, one per block (zeroed before each launch)
+  int32_t seg, n_seg;    // n_seg > 0: this launch takes only segment `seg` of `n_seg` of each queue block (fq_seg_range); the blocks are sorted,
+                         // long searches first, so the early segments hold the hard reads
   int32_t refill_min;    // idle lanes of a wavefront wait until this many can be (re)initialised together
   int32_t max_waves;     // 0: as many wavefronts as the device holds; else a cap (the host lowers it when pool memory is short)
 };
 
+// positions [lo, hi) of a queue block of `len` entries that belong to segment seg of n_seg
+FQ_HD void fq_seg_range(uint32_t len, int seg, int n_seg, uint32_t *lo, uint32_t *hi) {
+  if (n_seg <= 0) { *lo = 0; *hi = len; return; }
+  *lo = (uint32_t)((uint64_t)len * (uint64_t)seg / (uint64_t)n_seg);
+  *hi = (uint32_t)((uint64_t)len * (uint64_t)(seg + 1) / (uint64_t)n_seg);
+}
 // Where a read's bucket heads live during the search: HBM (any pool size) or lane-interleaved LDS with 16-bit slots
 // (pool <= 65535 entries), which takes the head read-modify-write of every push off the global-memory latency chain.
 struct FqGapStoreGlobal {

@@ -234,7 +234,7 @@ int64_t fq_ctx_state_export(const fq_ctx_t *c, void *buf, int64_t cap);   /* byt
 int fq_ctx_state_import(fq_ctx_t *c, const void *buf, int64_t len);
 
 /* Experiment / test knobs by name (defaults are what DESIGN.md measures): gap_long_pops, gap_long_always, gap_pool,
- * gap_nogap_min, gap_split_hard, gap_no_order, gap_order_asc, gap_waves_per_cu, gap_coop_waves, gap_refill_min, sw_wave_max, host_threads, host_par_min, filter_no_turns,
+ * gap_nogap_min, gap_pipeline_min, gap_pipeline_segs, gap_long_pops2, gap_split_hard, gap_no_order, gap_order_asc, gap_waves_per_cu, gap_coop_waves, gap_refill_min, sw_wave_max, host_threads, host_par_min, filter_no_turns,
  * refine_lanes, packed_bulk_min, trace.  FQ_EINVAL for an unknown key. */
 int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t value);
 

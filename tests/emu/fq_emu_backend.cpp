@@ -76,24 +76,26 @@ int launch_order(const uint8_t *bid_end, int n, int32_t *order, uint32_t *cnt) {
 }
 struct SeqFetch { uint32_t *next; int n; uint32_t operator()(uint32_t k) const { const uint32_t at = *next; *next += k; return at; } };
 // the lane kernels' two-block queue, walked front to back by the single host "wavefront"
-struct SeqFetch2 { uint32_t *next; uint32_t n; uint64_t operator()(uint32_t k) const { const uint32_t at = *next; *next += k; return at < n ? (uint64_t)at | (uint64_t)n << 32 : 0; } };
+struct SeqFetch2 { uint32_t *next; uint32_t lo, hi; uint64_t operator()(uint32_t k) const { const uint32_t at = lo + *next; *next += k; return at < hi ? (uint64_t)at | (uint64_t)hi << 32 : 0; } };   // one block here: the segment [lo, hi) of it
 int gap_lane_slots(const FqGapArgs &a) { return a.n_work > 0 ? 1 : 0; }
 int launch_gap(const FqGapArgs &a_in) {
   FqGapArgs a = a_in;
   a.refill_min = 1;
   a.split = nullptr;   // one cursor over the whole order here: FqGapLane::queue_dry then looks at it alone
   uint32_t *next_p = a.queue; *next_p = 0;   // the same cursor the device kernels advance
+  uint32_t seg_lo, seg_hi;
+  fq_seg_range((uint32_t)a.n_work, a.seg, a.n_seg, &seg_lo, &seg_hi);
   if (a.tier.coop) {
     std::vector<uint32_t> heads(2 * FQ_MAX_BUCKETS);
     fq_gap_coop_wave(a, heads.data(), SeqFetch{next_p, a.n_work}, 0);
   } else if (a.tier.pool_cap <= 65535u) {   // same store policy the HIP launcher picks: 16-bit heads in (here: emulated) LDS
     std::vector<uint16_t> heads(a.o.n_buckets);
     FqGapStoreLds st = {heads.data(), 1};
-    if (a.tier.nogap) fq_gap_lanes<true>(a, st, SeqFetch2{next_p, (uint32_t)a.n_work}, 0);
-    else fq_gap_lanes<false>(a, st, SeqFetch2{next_p, (uint32_t)a.n_work}, 0);
+    if (a.tier.nogap) fq_gap_lanes<true>(a, st, SeqFetch2{next_p, seg_lo, seg_hi}, 0);
+    else fq_gap_lanes<false>(a, st, SeqFetch2{next_p, seg_lo, seg_hi}, 0);
   } else {
     FqGapStoreGlobal st = {nullptr};
-    fq_gap_lanes<false>(a, st, SeqFetch2{next_p, (uint32_t)a.n_work}, 0);
+    fq_gap_lanes<false>(a, st, SeqFetch2{next_p, seg_lo, seg_hi}, 0);
   }
   return 0;
 }
@@ -104,6 +106,15 @@ int launch_pack_aln(const FqAln *aln, const uint32_t *n_aln, const uint64_t *off
 }
 int launch_sa(const FqSaArgs &a) { for (uint64_t q = 0; q < a.n_rows; ++q) fq_sa_thread(a, q); return 0; }
 int launch_saq(const FqSaQueryArgs &a) { for (uint32_t q = 0; q < a.n; ++q) fq_saq_thread(a, q); return 0; }
+int stream_aux(int) { return 0; }
+int stream_fork() { return 0; }
+int stream_join() { return 0; }
+int launch_collect(const int32_t *order, const uint32_t *, int n_work, int seg, int n_seg, const uint32_t *status, const int32_t *work, int32_t *out, uint32_t *count) {
+  uint32_t lo, hi;
+  fq_seg_range((uint32_t)n_work, seg, n_seg, &lo, &hi);   // (one block here, as in launch_gap)
+  for (uint32_t pos = lo; pos < hi; ++pos) { const int w = order ? order[pos] : (int)pos; if (status[w]) out[(*count)++] = work[w]; }
+  return 0;
+}
 int launch_pair(const FqPairArgs &a) { for (int t = 0; t < a.n_jobs; ++t) fq_pair_thread(a, t); return 0; }
 int launch_sw(const FqSwArgs &a) { for (int t = 0; t < a.n_task; ++t) fq_sw_thread(a, t); return 0; }
 int launch_sw_serial(const FqSwArgs &a) { return launch_sw(a); }

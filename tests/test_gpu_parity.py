@@ -34,7 +34,10 @@ SEARCH_MODES = {"lanes": {}, "wave1": {"gap_long_pops": 1, "gap_long_always": 1}
                 "nogap": {"gap_nogap_min": 0},
                 # the hand-over rule of small launches with a low threshold: a search still running after 8 pops once the work queue
                 # is dry (both of its blocks) goes to the wavefront-per-read kernel
-                "handover": {"gap_long_pops": 8}}
+                "handover": {"gap_long_pops": 8},
+                # the first round in three segments of the queue, each segment's second round on the context's second stream beside
+                # the next segment's first (what calls of >= 4 M searched reads do)
+                "pipeline": {"gap_nogap_min": 0, "gap_pipeline_min": 0, "gap_pipeline_segs": 3}}
 
 
 @pytest.fixture(params=list(SEARCH_MODES))

@@ -32,6 +32,7 @@ s = al.stats()
 d = s["dbg"]
 reads = s["reads_searched"]
 print("pairs %d reads %d call %.1f ms gap kernel %.2f ms  pops/read %.1f pushes/read %.1f" % (pairs, reads, 1e3 * dt, s["kernel_ms"][7] + s["kernel_ms"][8], s["stack_pops"] / reads, s["stack_pushes"] / reads))
+print("search stage on the device (first launch begin to last launch end, per call): %.2f ms" % (s["kernel_ms"][2] / max(1, 1)))
 print("wave trips %d (%.1f per 64 reads)  lane trips %d  active lanes / trip %.1f" % (s["wave_trips"], s["wave_trips"] / (reads / 64.0), s["lane_trips"], s["lane_trips"] / max(1, s["wave_trips"])))
 if d[0] and not os.environ.get("FQ_INSTR_TIMING"):
     print("instrumented trips %d, mean active %.1f" % (d[0], d[1] / d[0]))
