@@ -13,6 +13,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -378,6 +379,7 @@ int main(int argc, char **argv) {
   }
   const int name_stride = 304;   // the reference's name buffers hold 302 bytes (bwaseqio.c:233)
   long long num_read = 0, filtered = 0, unmapped = 0, num_base = 0, order_checked_reads = 0;
+  double qc_ms = 0, out_ms = 0;
   std::vector<char> sam;
   EndChunk bufs[2][2];   // [slot][end]
   auto read_both = [&](int slot) {
@@ -422,13 +424,17 @@ int main(int argc, char **argv) {
     rc = fq_align_packed(ctx, pk, &res);
     if (rc) die(std::string("fq_align_packed failed: ") + fq_ctx_last_error(ctx));
     // the consumers, in the reference's order: StatCollector, then the record writer (src/BwtMapper.cpp:2047-2050, 2075-2085)
+    const auto tc0 = std::chrono::steady_clock::now();
     if (qc && (rc = fq_qc_add_last(qc, ctx))) die(std::string("QC consumer failed: ") + fq_qc_last_error(qc));
+    const auto tc1 = std::chrono::steady_clock::now();
     if (A.sam_out) {
       const int64_t sz = fq_sam_format_last(ctx, nullptr, 0);
       sam.resize((size_t)sz + 1);
       fq_sam_format_last(ctx, sam.data(), sz + 1);
       fwrite(sam.data(), 1, (size_t)sz, stdout);
     } else if ((rc = fq_bam_add_last(bam, ctx))) die("writing " + A.out_prefix + ".bam failed");
+    const auto tc2 = std::chrono::steady_clock::now();
+    qc_ms += std::chrono::duration<double, std::milli>(tc1 - tc0).count(); out_ms += std::chrono::duration<double, std::milli>(tc2 - tc1).count();
     num_read += 2LL * n; filtered += res.n_both_filtered; unmapped += res.n_both_unmapped; num_base += res.n_bases;
     fprintf(stderr, "NOTICE - %lld sequences are processed.\n", num_read);
     fq_packed_free(pk);
@@ -443,6 +449,7 @@ int main(int argc, char **argv) {
   fq_stats_get(ctx, &st);
   fprintf(stderr, "NOTICE - device time (ms): prep %.1f width %.1f gap %.1f sa %.1f sw %.1f refine %.1f ; host %.1f ; wall %.1f\n", st.kernel_ms[0],
           st.kernel_ms[1], st.kernel_ms[2], st.kernel_ms[3], st.kernel_ms[4], st.kernel_ms[5], st.host_ms_total, st.wall_ms_total);
+  fprintf(stderr, "NOTICE - consumers (ms): StatCollector %.1f ; %s writer %.1f\n", qc_ms, A.sam_out ? "SAM" : "BAM", out_ms);
   if (qc) fq_qc_end_file(qc);
   fq_ctx_destroy(ctx);
   }
