@@ -12,6 +12,7 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/fastquick_amd.h"
@@ -26,38 +27,65 @@
 namespace {
 // ---- BGZF (SAM/BAM specification 4.1): gzip members with a BC extra field, at most 64 KB of payload each ----------------------
 struct Bgzf {
+  // BGZF blocks are compressed independently (a fresh deflate stream each), so a run of them goes through zlib on several threads and
+  // comes out byte for byte what one thread would write: the block boundaries (every 0xff00 bytes of the record stream) do not move.
   FILE *fp = nullptr;
   std::vector<uint8_t> buf;
   bool ok = true;
   static const size_t kBlock = 0xff00;
-  void flush_block(const uint8_t *data, size_t n) {
-    uint8_t out[0x10000 + 64];
+  static const int kThreads = 8;
+  struct Out { uint8_t d[0x10000 + 64]; size_t n = 0; };
+  static bool compress_block(const uint8_t *data, size_t n, Out &o) {
     z_stream zs;
     memset(&zs, 0, sizeof zs);
-    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) { ok = false; return; }
+    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -15, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
     zs.next_in = const_cast<uint8_t *>(data); zs.avail_in = (uInt)n;
-    zs.next_out = out + 18; zs.avail_out = sizeof out - 18 - 8;
-    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { ok = false; deflateEnd(&zs); return; }
+    zs.next_out = o.d + 18; zs.avail_out = sizeof o.d - 18 - 8;
+    if (deflate(&zs, Z_FINISH) != Z_STREAM_END) { deflateEnd(&zs); return false; }
     const size_t clen = zs.total_out;
     deflateEnd(&zs);
     const size_t bsize = clen + 18 + 8;
     const uint8_t hdr[18] = {31, 139, 8, 4, 0, 0, 0, 0, 0, 255, 6, 0, 'B', 'C', 2, 0, (uint8_t)((bsize - 1) & 0xff), (uint8_t)((bsize - 1) >> 8)};
-    memcpy(out, hdr, 18);
+    memcpy(o.d, hdr, 18);
     const uint32_t crc = (uint32_t)crc32(crc32(0L, Z_NULL, 0), data, (uInt)n), isz = (uint32_t)n;
-    memcpy(out + 18 + clen, &crc, 4);
-    memcpy(out + 18 + clen + 4, &isz, 4);
-    if (fwrite(out, 1, bsize, fp) != bsize) ok = false;
+    memcpy(o.d + 18 + clen, &crc, 4);
+    memcpy(o.d + 18 + clen + 4, &isz, 4);
+    o.n = bsize;
+    return true;
+  }
+  void flush_blocks(size_t n_blocks, size_t last_len) {   // the first n_blocks - 1 blocks are full; the last holds last_len bytes
+    if (!n_blocks) return;
+    std::vector<Out> outs(n_blocks);
+    std::vector<char> good(n_blocks, 0);
+    auto work = [&](size_t lo, size_t hi) {
+      for (size_t b = lo; b < hi; ++b) good[b] = compress_block(buf.data() + b * kBlock, b + 1 == n_blocks ? last_len : kBlock, outs[b]);
+    };
+    const size_t T = std::min<size_t>(kThreads, n_blocks);
+    if (T <= 1) work(0, n_blocks);
+    else {
+      std::vector<std::thread> th;
+      const size_t per = (n_blocks + T - 1) / T;
+      for (size_t t = 0; t < T; ++t) { const size_t lo = t * per, hi = std::min(n_blocks, lo + per); if (lo < hi) th.emplace_back(work, lo, hi); }
+      for (auto &x : th) x.join();
+    }
+    for (size_t b = 0; b < n_blocks; ++b) { if (!good[b] || fwrite(outs[b].d, 1, outs[b].n, fp) != outs[b].n) ok = false; }
   }
   void write(const void *p, size_t n) {
     const uint8_t *s = (const uint8_t *)p;
     buf.insert(buf.end(), s, s + n);
-    while (buf.size() >= kBlock) { flush_block(buf.data(), kBlock); buf.erase(buf.begin(), buf.begin() + kBlock); }
+    if (buf.size() >= kBlock * 64) {                    // a few MB at a time
+      const size_t nb = buf.size() / kBlock;
+      flush_blocks(nb, kBlock);
+      buf.erase(buf.begin(), buf.begin() + nb * kBlock);
+    }
   }
   void close() {
     if (!fp) return;
-    if (!buf.empty()) flush_block(buf.data(), buf.size());
+    const size_t nb = (buf.size() + kBlock - 1) / kBlock;
+    if (nb) flush_blocks(nb, buf.size() - (nb - 1) * kBlock);
     buf.clear();
-    flush_block(nullptr, 0);   // the empty end-of-file block
+    Out eof;
+    if (!compress_block(nullptr, 0, eof) || fwrite(eof.d, 1, eof.n, fp) != eof.n) ok = false;   // the empty end-of-file block
     fclose(fp);
     fp = nullptr;
   }
@@ -103,7 +131,6 @@ struct fq_bam {
   std::string err, rg_id, header_text;
   std::vector<std::pair<std::string, int>> contigs;      // BwtIndexer::contigSize
   std::map<std::string, int> ref_id;
-  int64_t n_records = 0;
 
   // genome coordinate of offset `pos1` (1-based) in reduced contig `seqid` (:1026-1043)
   void genome_coord(int seqid, int pos1, std::string *chrom, int *start) const {
@@ -114,11 +141,12 @@ struct fq_bam {
     *start = refCoord - (name.back() == 'L' ? o.flank_long_len : o.flank_len) + pos1 - 1;
   }
   int id_of(const std::string &chrom) const { auto it = ref_id.find(chrom); return it == ref_id.end() ? -1 : it->second; }
-  void record(const fq_opts_t *ao, const FqHostReads &hb, int n_pairs, FqRead p, const FqRead &mate, bool se = false);   // se: SetSamRecord(p, mate = 0)
+  // appends one BAM record to `dst`; se: SetSamRecord(p, mate = 0)
+  void record(std::vector<uint8_t> &dst, const fq_opts_t *ao, const FqHostReads &hb, int n_pairs, FqRead p, const FqRead &mate, bool se = false) const;
 };
 
 // SetSamRecord, src/BwtMapper.cpp:977-1264
-void fq_bam::record(const fq_opts_t *ao, const FqHostReads &hb, int n_pairs, FqRead p, const FqRead &mate, bool se) {
+void fq_bam::record(std::vector<uint8_t> &dst, const fq_opts_t *ao, const FqHostReads &hb, int n_pairs, FqRead p, const FqRead &mate, bool se) const {
   const std::string name = fq_read_name(&hb, p.r % n_pairs, p.r / n_pairs, p.revived);
   uint8_t codes[FQ_LMAX + 8];
   hb.codes((size_t)p.r, p.full_len, codes);
@@ -220,9 +248,8 @@ void fq_bam::record(const fq_opts_t *ao, const FqHostReads &hb, int n_pairs, FqR
   for (size_t j = 0; j < seq.size(); ++j) rec.push_back((uint8_t)(j < qual.size() ? qual[j] - 33 : 0xff));
   rec.insert(rec.end(), T.b.begin(), T.b.end());
   const int32_t bs = (int32_t)rec.size();
-  z.write(&bs, 4);
-  z.write(rec.data(), rec.size());
-  ++n_records;
+  dst.insert(dst.end(), (const uint8_t *)&bs, (const uint8_t *)&bs + 4);
+  dst.insert(dst.end(), rec.begin(), rec.end());
   (void)mate_same;
 }
 
@@ -289,7 +316,9 @@ extern "C" int fq_bam_add_last(fq_bam_t *b, fq_ctx_t *c) {
   const FqHostReads hb = fq_ctx_host_reads(c);
   const fq_opts_t *ao = fq_ctx_opts(c);
   if (S->n_surv > 0 && !hb.has_qual()) { b->err = "the batch carries no qualities"; return FQ_EINVAL; }
-  for (int sp = 0; sp < S->n_surv; ++sp) {
+  // records are independent of each other: ranges of pairs are formatted on several threads and handed to the BGZF layer in order
+  auto format_range = [&](int lo, int hi, std::vector<uint8_t> &dst) {
+  for (int sp = lo; sp < hi; ++sp) {
     if (S->reads[2 * sp].type == FQ_TYPE_NO_MATCH && S->reads[2 * sp + 1].type == FQ_TYPE_NO_MATCH) continue;
     if (ao->single_end) {   // SingleEndMapper's BAM branch (src/BwtMapper.cpp:1372-1387): AddAlignment(p, 0), SetSamRecord(p, 0)
       FqRead p = S->reads[2 * sp];
@@ -297,7 +326,7 @@ extern "C" int fq_bam_add_last(fq_bam_t *b, fq_ctx_t *c) {
       const int j = (int)(ref_end(p) - p.pos);
       fq_coor_pac2real(b->ix, p.pos, j, &seqid);
       if ((int64_t)p.pos + j - b->ix->contigs[seqid].offset > b->ix->contigs[seqid].len) p.type = FQ_TYPE_NO_MATCH;
-      b->record(ao, hb, S->n_pairs, p, p, true);
+      b->record(dst, ao, hb, S->n_pairs, p, p, true);
       continue;
     }
     FqRead p = S->reads[2 * sp], q = S->reads[2 * sp + 1];
@@ -308,10 +337,21 @@ extern "C" int fq_bam_add_last(fq_bam_t *b, fq_ctx_t *c) {
         fq_coor_pac2real(b->ix, r->pos, j, &seqid);
         if ((int64_t)r->pos + j - b->ix->contigs[seqid].offset > b->ix->contigs[seqid].len) r->type = FQ_TYPE_NO_MATCH;
       }
-    b->record(ao, hb, S->n_pairs, p, q);
+    b->record(dst, ao, hb, S->n_pairs, p, q);
     if (p.type == FQ_TYPE_NO_MATCH && q.type != FQ_TYPE_NO_MATCH) { p.pos = q.pos; p.strand = q.strand; }   // what the first call left in p (:991-994)
-    b->record(ao, hb, S->n_pairs, q, p);
+    b->record(dst, ao, hb, S->n_pairs, q, p);
   }
+  };
+  const int T = S->n_surv >= 256 ? 8 : 1;
+  std::vector<std::vector<uint8_t>> parts((size_t)T);
+  if (T == 1) format_range(0, S->n_surv, parts[0]);
+  else {
+    std::vector<std::thread> th;
+    const int per = (S->n_surv + T - 1) / T;
+    for (int t = 0; t < T; ++t) { const int lo = t * per, hi = std::min(S->n_surv, lo + per); if (lo < hi) th.emplace_back(format_range, lo, hi, std::ref(parts[(size_t)t])); }
+    for (auto &x : th) x.join();
+  }
+  for (auto &part : parts) if (!part.empty()) b->z.write(part.data(), part.size());
   return b->z.ok ? FQ_OK : FQ_EIO;
 }
 extern "C" int fq_bam_close(fq_bam_t *b) {

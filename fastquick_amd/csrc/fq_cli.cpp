@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <chrono>
 #include <cstdio>
+#include <memory>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -75,10 +76,22 @@ struct FastqReader {
 };
 
 // One end of one chunk, in the layout fq_read_batch_t wants: fixed-stride rows, filled by that file's reader thread.
+// grow-only byte storage that is not cleared on allocation: a chunk of the default size is 2.7 GB of rows, rows are cleared as
+// records arrive, and value-initialising the rest cost seconds per run
+template <class T> struct RawBuf {
+  std::unique_ptr<T[]> p;
+  size_t n = 0;
+  void resize(size_t m) { if (m > n) { p.reset(new T[m]); n = m; } }     // (contents are not kept: callers fill what they use)
+  size_t size() const { return n; }
+  T *data() { return p.get(); }
+  const T *data() const { return p.get(); }
+  T &operator[](size_t i) { return p[i]; }
+  const T &operator[](size_t i) const { return p[i]; }
+};
 struct EndChunk {
-  std::vector<uint8_t> seq, qual;
+  RawBuf<uint8_t> seq, qual;
   std::vector<int32_t> len;
-  std::vector<char> names;
+  RawBuf<char> names;
   int n = 0, stride = 0, name_stride = 0;
   bool eof = false;
   std::string error;
@@ -407,7 +420,8 @@ int main(int argc, char **argv) {
         die("Abort, please make sure input pair of fastq files are in the same order!");
     }
     // the two ends back to back: [end][pair][stride]
-    std::vector<uint8_t> seq((size_t)2 * n * stride), qual((size_t)2 * n * stride);
+    RawBuf<uint8_t> seq, qual;
+    seq.resize((size_t)2 * n * stride); qual.resize((size_t)2 * n * stride);
     std::vector<int32_t> len((size_t)2 * n);
     for (int e = 0; e < 2; ++e) {
       const EndChunk &c = bufs[slot][e];

@@ -140,12 +140,14 @@ struct fq_qc {
   struct Marker { std::string chrom_raw, id, ref, alt, qual, filter, info; int pos = 0; };
   std::vector<Marker> markers;
   std::map<std::string, std::map<int, unsigned>> vcf_table;
-  std::unordered_map<std::string, std::unordered_map<int, unsigned>> gc, dbsnp, position_table;
+  std::unordered_map<std::string, std::unordered_map<int, unsigned>> gc, dbsnp;
   Regions flank;
   uint64_t NumXorY = 0, NumShort = 0, NumLong = 0;
   // statistics
   uint64_t NumPCRDup = 0, NumPairReads = 0, NumBaseMapped = 0, NumCov = 0, NumCov2 = 0, NumCov5 = 0, NumCov10 = 0, total_region_size = 0;
-  unsigned index = 0;
+  // Depth tables are dense over the flank regions (PositionTable of the reference: a hash of the positions touched so far, whose
+  // members all have depth >= 1 -- so the untouched entries of a dense table are exactly its non-members, and every use is a sum)
+  std::map<std::string, std::map<int, std::pair<int, size_t>>> flank_idx;   // chrom -> region start -> (region end, first table index)
   std::vector<uint32_t> depth, q20, q30;
   std::vector<std::string> seq_vec, qual_vec;
   std::vector<std::vector<int>> cycle_vec;
@@ -199,6 +201,11 @@ int fq_qc::restore(const std::string &ref_prefix) {
     seq_vec.emplace_back(""); qual_vec.emplace_back(""); cycle_vec.emplace_back(0); maq_vec.emplace_back(0); strand_vec.emplace_back(0);
   }
   flank.collapse();
+  {
+    size_t at = 0;
+    for (const auto &kv : flank.list) for (const auto &r : kv.second) { flank_idx[kv.first][r.first] = std::make_pair(r.second, at); at += (size_t)(r.second - r.first) + 1; }
+    depth.assign(at, 0); q20.assign(at, 0); q30.assign(at, 0);
+  }
   while (std::getline(db, line)) {
     if (line.empty() || line[0] == '#') continue;
     std::stringstream ss(line);
@@ -234,37 +241,47 @@ bool fq_qc::add_single(const Rec &P, const FqHostReads &hb) {
   const std::string refSeq = recover_ref(seq, p.md, p.cigar);
   const std::string chrom = chrom_key(chrom_raw);         // AddMatchBaseInfo, :362-379
 
+  // (the per-chromosome containers are looked up once per read, when first needed, instead of once per base: same containers, same
+  //  insertions, same order -- a StatCollector pass over an on-target batch was 40x the batch's alignment time)
+  const auto vt = vcf_table.find(chrom);
+  const auto fl_it = flank_idx.find(chrom);
+  std::unordered_map<int, unsigned> *db = nullptr;
+  int f_lo = 1, f_hi = 0;          // the region the previous position fell into (consecutive positions mostly share it)
+  size_t f_base = 0;
+  auto in_flank = [&](int pos) {   // RegionList::IsOverlapped, :48-66
+    if (pos >= f_lo && pos <= f_hi) return true;
+    if (fl_it == flank_idx.end()) return false;
+    auto lo = fl_it->second.lower_bound(pos);
+    if (lo != fl_it->second.end() && lo->first <= pos && lo->second.first >= pos) { f_lo = lo->first; f_hi = lo->second.first; f_base = lo->second.second; return true; }
+    if (lo != fl_it->second.begin()) { --lo; if (lo->first <= pos && lo->second.first >= pos) { f_lo = lo->first; f_hi = lo->second.first; f_base = lo->second.second; return true; } }
+    return false;
+  };
   auto match_block = [&](int absoluteSite, int cl, int tmpCycle, int onRead, int onRef) {
-    // UpdateInfoVecAtMarker, :339-360
-    auto vt = vcf_table.find(chrom);
-    if (vt != vcf_table.end()) {
-      int cyc = tmpCycle, rr = onRead;
-      for (int i = absoluteSite; i != absoluteSite + cl; ++i, cyc += kSign[p.strand], ++rr) {
-        auto hit = vt->second.find(i);
-        if (hit == vt->second.end()) continue;
+    // UpdateInfoVecAtMarker, :339-360: the markers inside [absoluteSite, absoluteSite + cl), in increasing position
+    if (vt != vcf_table.end())
+      for (auto hit = vt->second.lower_bound(absoluteSite); hit != vt->second.end() && hit->first < absoluteSite + cl; ++hit) {
+        const int d = hit->first - absoluteSite, cyc = tmpCycle + d * kSign[p.strand], rr = onRead + d;
         const unsigned k = hit->second;
         seq_vec[k] += seq[rr]; qual_vec[k] += qual[rr];
         cycle_vec[k].push_back(cyc); maq_vec[k].push_back((unsigned char)(p.mapQ + 33)); strand_vec[k].push_back(p.strand != 0);
       }
-    }
     // UpdateInfoVecAtRegularSite, :381-422
     int cyc = tmpCycle, rr = onRead, rf = onRef;
     for (int i = absoluteSite; i != absoluteSite + cl; ++i, cyc += kSign[p.strand], ++rr, ++rf) {
-      if (!flank.overlapped(chrom, i)) continue;
+      if (!in_flank(i)) continue;
       const char refBase = rf >= 0 && (size_t)rf < refSeq.size() ? refSeq[rf] : 0, readBase = seq[rr], baseQual = qual[rr];
-      auto &pt = position_table[chrom];
-      auto f = pt.find(i);
-      unsigned k;
-      if (f != pt.end()) k = f->second;
-      else { depth.push_back(0); q20.push_back(0); q30.push_back(0); k = index; pt[i] = index++; }
+      const size_t k = f_base + (size_t)(i - f_lo);
       ++depth[k];
       if (baseQual >= 20) { ++q20[k]; if (baseQual >= 30) ++q30[k]; }
       // StatVecDistUpdate, :304-317
       ++EmpRep[(unsigned char)baseQual];
       ++EmpCycle[(unsigned char)cyc];
-      if (readBase != 'N' && refBase != readBase && refBase != 'N' && dbsnp[chrom].find(i) == dbsnp[chrom].end()) {
-        ++misEmpRep[(unsigned char)baseQual];
-        ++misEmpCycle[(unsigned char)cyc];
+      if (readBase != 'N' && refBase != readBase && refBase != 'N') {
+        if (!db) db = &dbsnp[chrom];
+        if (db->find(i) == db->end()) {
+          ++misEmpRep[(unsigned char)baseQual];
+          ++misEmpCycle[(unsigned char)cyc];
+        }
       }
     }
   };
@@ -545,15 +562,19 @@ extern "C" int fq_qc_write(fq_qc_t *q) {
   q->table.flush();
   const std::string &pre = q->out_prefix;
   {   // GetDepthDist, :1858-1918
-    for (auto &chr : q->position_table)
-      for (auto &site : chr.second) {
-        const int d = (int)q->depth[site.second];
-        q->NumBaseMapped += d;
-        ++q->DepthDist[d > 1023 ? 1023 : d];
-        const unsigned g = q->gc[chr.first][site.first];
-        q->GCDist[g] += d;
-        ++q->PosNum[g];
-      }
+    for (auto &chr : q->flank_idx) {
+      auto &gc_chr = q->gc[chr.first];
+      for (auto &reg : chr.second)
+        for (int pos = reg.first; pos <= reg.second.first; ++pos) {
+          const int d = (int)q->depth[reg.second.second + (size_t)(pos - reg.first)];
+          if (d == 0) continue;                 // never touched: not in the reference's PositionTable
+          q->NumBaseMapped += d;
+          ++q->DepthDist[d > 1023 ? 1023 : d];
+          const unsigned g = gc_chr[pos];
+          q->GCDist[g] += d;
+          ++q->PosNum[g];
+        }
+    }
     for (size_t i = 1; i != q->DepthDist.size(); ++i) {
       q->NumCov += q->DepthDist[i];
       if (i >= 2) q->NumCov2 += q->DepthDist[i];

@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/fastquick_amd.h"
@@ -192,9 +193,10 @@ extern "C" int64_t fq_sam_format_last(fq_ctx_t *c, char *buf, int64_t cap) {
   const FqHostReads hbv = fq_ctx_host_reads(c), *hb = &hbv;
   const fq_opts_t *o = fq_ctx_opts(c);
   if (S->n_surv > 0 && !hb->has_qual()) return FQ_EINVAL;
-  Out out;
-  out.s.reserve((size_t)S->n_surv * 900);
-  for (int sp = 0; sp < S->n_surv; ++sp) {
+  // records are independent of each other: ranges of pairs are formatted on several threads and concatenated in order
+  auto format_range = [&](int lo, int hi, Out &out) {
+  out.s.reserve((size_t)(hi - lo) * 900);
+  for (int sp = lo; sp < hi; ++sp) {
     if (S->reads[2 * sp].type == FQ_TYPE_NO_MATCH && S->reads[2 * sp + 1].type == FQ_TYPE_NO_MATCH) continue;   // src/BwtMapper.cpp:2038-2042
     if (o->single_end) {   // src/BwtMapper.cpp:1355-1370: AddAlignment(p, 0), then bwa_print_sam1(p, 0)
       FqRead a = S->reads[2 * sp];
@@ -208,7 +210,23 @@ extern "C" int64_t fq_sam_format_last(fq_ctx_t *c, char *buf, int64_t cap) {
     print_sam(ix, o, hb, S->n_pairs, out, a, b);
     print_sam(ix, o, hb, S->n_pairs, out, b, a);
   }
-  return emit(out.s, buf, cap);
+  };
+  const int T = S->n_surv >= 256 ? 8 : 1;
+  std::vector<Out> parts((size_t)T);
+  if (T == 1) format_range(0, S->n_surv, parts[0]);
+  else {
+    std::vector<std::thread> th;
+    const int per = (S->n_surv + T - 1) / T;
+    for (int t = 0; t < T; ++t) { const int lo = t * per, hi = std::min(S->n_surv, lo + per); if (lo < hi) th.emplace_back(format_range, lo, hi, std::ref(parts[(size_t)t])); }
+    for (auto &x : th) x.join();
+  }
+  if (T == 1) return emit(parts[0].s, buf, cap);
+  std::string all;
+  size_t total = 0;
+  for (auto &p : parts) total += p.s.size();
+  all.reserve(total);
+  for (auto &p : parts) all += p.s;
+  return emit(all, buf, cap);
 }
 
 extern "C" int64_t fq_stage_dump_last(fq_ctx_t *c, char *buf, int64_t cap) {
