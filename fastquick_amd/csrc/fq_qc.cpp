@@ -19,6 +19,7 @@
 #include <map>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <unordered_map>
 #include <unordered_set>
 #include <vector>
@@ -167,6 +168,12 @@ struct fq_qc {
   int restore(const std::string &ref_prefix);
   bool add_single(const Rec &p, const FqHostReads &hb);
   int pair_status(const Rec *p, const Rec *q, int type);
+  struct ReadGeom;
+  struct StatHist { size_t EmpRep[256] = {}, EmpCycle[256] = {}, misEmpRep[256] = {}, misEmpCycle[256] = {}; };
+  std::vector<const FqRead *> stat_jobs;   // reads whose per-base statistics are still to be added (valid until the batch's records go away)
+  bool read_geom(const Rec &P, ReadGeom &g) const;
+  void read_stats(const FqRead &p, const FqHostReads &hb, StatHist &h);
+  void run_stat_jobs(const FqHostReads &hb, int threads);
   int add_alignment(Rec &p, Rec &q, const FqHostReads &hb, long long &total_add_failed);
   int add_alignment_se(Rec &p, const FqHostReads &hb, long long &total_add_failed);   // AddAlignment(p, q = 0): the single-end mapper's call
   const char *contig_name(int seqid) const { return ix->contigs[seqid].name.c_str(); }
@@ -216,36 +223,85 @@ int fq_qc::restore(const std::string &ref_prefix) {
   return FQ_OK;
 }
 
-// AddSingleAlignment, :424-620 (the reduced-reference branch: contig names `CHR:POS@REF/ALT[|L]`)
-bool fq_qc::add_single(const Rec &P, const FqHostReads &hb) {
+// AddSingleAlignment, :424-620 (the reduced-reference branch: contig names `CHR:POS@REF/ALT[|L]`), in two parts:
+//  * what depends on the order of the reads -- the pileup strings of the markers a read covers (UpdateInfoVecAtMarker) -- here,
+//    in input order;
+//  * the per-base statistics (UpdateInfoVecAtRegularSite / StatVecDistUpdate: depth, Q20 / Q30 depth, quality and cycle
+//    histograms, mismatch counts) are sums, so the reads are queued (stat_jobs) and fq_qc_add_last spreads them over threads once
+//    the batch has been walked.  A StatCollector pass over an on-target batch was 40x the batch's alignment time.
+struct fq_qc::ReadGeom { int seqid, readRealStart; std::string chrom; };
+bool fq_qc::read_geom(const Rec &P, ReadGeom &g) const {
   const FqRead &p = *P.r;
-  if (P.type == FQ_TYPE_NO_MATCH || p.mapQ < 20) return false;
-  int seqid = 0;
-  fq_coor_pac2real(ix, p.pos, (int)(P.end() - p.pos), &seqid);
-  uint8_t codes[FQ_LMAX + 8];
-  hb.codes((size_t)p.r, p.full_len, codes);
-  const uint8_t *hq = hb.qual((size_t)p.r);
-  const int qsub = (o.mode & FQ_MODE_IL13) ? 31 : 0;    // qualities are kept 31 lower in --I mode (src/BwtMapper.cpp:549-553)
-  std::string seq, qual;
-  if (p.strand == 0) for (int j = 0; j != p.full_len; ++j) { seq += "ACGTN"[codes[j] > 4 ? 4 : codes[j]]; qual += (char)(hq[j] - qsub - 33); }
-  else for (int j = 0; j != p.full_len; ++j) { const int c = codes[p.full_len - 1 - j]; seq += "TGCAN"[c > 4 ? 4 : c]; qual += (char)(hq[p.full_len - 1 - j] - qsub - 33); }
-  const std::string chrName = ix->contigs[seqid].name;
-  const int pos = (int)((int64_t)p.pos - ix->contigs[seqid].offset + 1);
+  g.seqid = 0;
+  fq_coor_pac2real(ix, p.pos, (int)(P.end() - p.pos), &g.seqid);
+  const std::string &chrName = ix->contigs[g.seqid].name;
+  const int pos = (int)((int64_t)p.pos - ix->contigs[g.seqid].offset + 1);
   const size_t colon = chrName.find(':');
   if (colon == std::string::npos) return false;          // (external alignments are not this path)
   const size_t at = chrName.find('@');
-  const std::string chrom_raw = chrName.substr(0, colon);
   const int refCoord = (int)strtol(chrName.substr(colon + 1, at - colon + 1).c_str(), nullptr, 10);
   const int fl = chrName[chrName.size() - 1] == 'L' ? o.flank_long_len : o.flank_len;
-  const int readRealStart = refCoord - fl + pos - 1;
+  g.readRealStart = refCoord - fl + pos - 1;
+  g.chrom = chrom_key(chrName.substr(0, colon));         // AddMatchBaseInfo, :362-379
+  return true;
+}
+template <class F> static void for_match_blocks(const FqRead &p, int readRealStart, F f) {   // f(absoluteSite, length, cycle, onRead, onRef) per M block
+  int absoluteSite = readRealStart, tmpCycle = p.strand != 0 ? p.full_len - 1 : 0, onRead = 0, onRef = 0;
+  if (!p.cigar.empty()) {
+    for (uint16_t g : p.cigar) {
+      const int cl = g & 0x3fff, op = g >> 14;
+      if (op == FQ_OP_M) { f(absoluteSite, cl, tmpCycle, onRead, onRef); absoluteSite += cl; tmpCycle += cl * kSign[p.strand]; onRead += cl; onRef += cl; }
+      else if (op == FQ_OP_S) { tmpCycle += cl * kSign[p.strand]; onRead += cl; }
+      else if (op == FQ_OP_D) { absoluteSite += cl; onRef += cl; }
+      else { tmpCycle += cl * kSign[p.strand]; onRead += cl; }
+    }
+  } else f(absoluteSite, (int)p.len, tmpCycle, onRead, onRef);
+}
+bool fq_qc::add_single(const Rec &P, const FqHostReads &hb) {
+  const FqRead &p = *P.r;
+  if (P.type == FQ_TYPE_NO_MATCH || p.mapQ < 20) return false;
+  ReadGeom g;
+  if (!read_geom(P, g)) return false;
+  const auto vt = vcf_table.find(g.chrom);
+  if (vt != vcf_table.end()) {
+    uint8_t codes[FQ_LMAX + 8];
+    bool have = false;
+    const uint8_t *hq = nullptr;
+    const int qsub = (o.mode & FQ_MODE_IL13) ? 31 : 0;    // qualities are kept 31 lower in --I mode (src/BwtMapper.cpp:549-553)
+    for_match_blocks(p, g.readRealStart, [&](int absoluteSite, int cl, int tmpCycle, int onRead, int) {
+      // UpdateInfoVecAtMarker, :339-360: the markers inside [absoluteSite, absoluteSite + cl), in increasing position
+      for (auto hit = vt->second.lower_bound(absoluteSite); hit != vt->second.end() && hit->first < absoluteSite + cl; ++hit) {
+        if (!have) { hb.codes((size_t)p.r, p.full_len, codes); hq = hb.qual((size_t)p.r); have = true; }
+        const int d = hit->first - absoluteSite, cyc = tmpCycle + d * kSign[p.strand], rr = onRead + d;
+        const unsigned k = hit->second;
+        char base, ql;      // the read in the orientation of the reference (SetSamRecord's strings)
+        if (p.strand == 0) { const int cc = codes[rr]; base = "ACGTN"[cc > 4 ? 4 : cc]; ql = (char)(hq[rr] - qsub - 33); }
+        else { const int cc = codes[p.full_len - 1 - rr]; base = "TGCAN"[cc > 4 ? 4 : cc]; ql = (char)(hq[p.full_len - 1 - rr] - qsub - 33); }
+        seq_vec[k] += base; qual_vec[k] += ql;
+        cycle_vec[k].push_back(cyc); maq_vec[k].push_back((unsigned char)(p.mapQ + 33)); strand_vec[k].push_back(p.strand != 0);
+      }
+    });
+  }
+  stat_jobs.push_back(P.r);
+  return true;
+}
+// the per-base statistics of one queued read; `h` = this thread's quality / cycle histograms (summed afterwards), the depth tables
+// are shared and updated atomically
+void fq_qc::read_stats(const FqRead &p, const FqHostReads &hb, StatHist &h) {
+  Rec P; P.r = &p; P.type = p.type;
+  ReadGeom g;
+  if (!read_geom(P, g)) return;
+  uint8_t codes[FQ_LMAX + 8];
+  hb.codes((size_t)p.r, p.full_len, codes);
+  const uint8_t *hq = hb.qual((size_t)p.r);
+  const int qsub = (o.mode & FQ_MODE_IL13) ? 31 : 0;
+  std::string seq, qual;
+  seq.reserve((size_t)p.full_len); qual.reserve((size_t)p.full_len);
+  if (p.strand == 0) for (int j = 0; j != p.full_len; ++j) { seq += "ACGTN"[codes[j] > 4 ? 4 : codes[j]]; qual += (char)(hq[j] - qsub - 33); }
+  else for (int j = 0; j != p.full_len; ++j) { const int c = codes[p.full_len - 1 - j]; seq += "TGCAN"[c > 4 ? 4 : c]; qual += (char)(hq[p.full_len - 1 - j] - qsub - 33); }
   const std::string refSeq = recover_ref(seq, p.md, p.cigar);
-  const std::string chrom = chrom_key(chrom_raw);         // AddMatchBaseInfo, :362-379
-
-  // (the per-chromosome containers are looked up once per read, when first needed, instead of once per base: same containers, same
-  //  insertions, same order -- a StatCollector pass over an on-target batch was 40x the batch's alignment time)
-  const auto vt = vcf_table.find(chrom);
-  const auto fl_it = flank_idx.find(chrom);
-  std::unordered_map<int, unsigned> *db = nullptr;
+  const auto fl_it = flank_idx.find(g.chrom);
+  const auto db_it = dbsnp.find(g.chrom);
   int f_lo = 1, f_hi = 0;          // the region the previous position fell into (consecutive positions mostly share it)
   size_t f_base = 0;
   auto in_flank = [&](int pos) {   // RegionList::IsOverlapped, :48-66
@@ -256,46 +312,42 @@ bool fq_qc::add_single(const Rec &P, const FqHostReads &hb) {
     if (lo != fl_it->second.begin()) { --lo; if (lo->first <= pos && lo->second.first >= pos) { f_lo = lo->first; f_hi = lo->second.first; f_base = lo->second.second; return true; } }
     return false;
   };
-  auto match_block = [&](int absoluteSite, int cl, int tmpCycle, int onRead, int onRef) {
-    // UpdateInfoVecAtMarker, :339-360: the markers inside [absoluteSite, absoluteSite + cl), in increasing position
-    if (vt != vcf_table.end())
-      for (auto hit = vt->second.lower_bound(absoluteSite); hit != vt->second.end() && hit->first < absoluteSite + cl; ++hit) {
-        const int d = hit->first - absoluteSite, cyc = tmpCycle + d * kSign[p.strand], rr = onRead + d;
-        const unsigned k = hit->second;
-        seq_vec[k] += seq[rr]; qual_vec[k] += qual[rr];
-        cycle_vec[k].push_back(cyc); maq_vec[k].push_back((unsigned char)(p.mapQ + 33)); strand_vec[k].push_back(p.strand != 0);
-      }
+  for_match_blocks(p, g.readRealStart, [&](int absoluteSite, int cl, int tmpCycle, int onRead, int onRef) {
     // UpdateInfoVecAtRegularSite, :381-422
     int cyc = tmpCycle, rr = onRead, rf = onRef;
     for (int i = absoluteSite; i != absoluteSite + cl; ++i, cyc += kSign[p.strand], ++rr, ++rf) {
       if (!in_flank(i)) continue;
       const char refBase = rf >= 0 && (size_t)rf < refSeq.size() ? refSeq[rf] : 0, readBase = seq[rr], baseQual = qual[rr];
       const size_t k = f_base + (size_t)(i - f_lo);
-      ++depth[k];
-      if (baseQual >= 20) { ++q20[k]; if (baseQual >= 30) ++q30[k]; }
+      __atomic_fetch_add(&depth[k], 1u, __ATOMIC_RELAXED);
+      if (baseQual >= 20) { __atomic_fetch_add(&q20[k], 1u, __ATOMIC_RELAXED); if (baseQual >= 30) __atomic_fetch_add(&q30[k], 1u, __ATOMIC_RELAXED); }
       // StatVecDistUpdate, :304-317
-      ++EmpRep[(unsigned char)baseQual];
-      ++EmpCycle[(unsigned char)cyc];
-      if (readBase != 'N' && refBase != readBase && refBase != 'N') {
-        if (!db) db = &dbsnp[chrom];
-        if (db->find(i) == db->end()) {
-          ++misEmpRep[(unsigned char)baseQual];
-          ++misEmpCycle[(unsigned char)cyc];
-        }
+      ++h.EmpRep[(unsigned char)baseQual];
+      ++h.EmpCycle[(unsigned char)cyc];
+      if (readBase != 'N' && refBase != readBase && refBase != 'N' && (db_it == dbsnp.end() || db_it->second.find(i) == db_it->second.end())) {
+        ++h.misEmpRep[(unsigned char)baseQual];
+        ++h.misEmpCycle[(unsigned char)cyc];
       }
     }
-  };
-  int absoluteSite = readRealStart, tmpCycle = p.strand != 0 ? p.full_len - 1 : 0, onRead = 0, onRef = 0;
-  if (!p.cigar.empty()) {
-    for (uint16_t g : p.cigar) {
-      const int cl = g & 0x3fff, op = g >> 14;
-      if (op == FQ_OP_M) { match_block(absoluteSite, cl, tmpCycle, onRead, onRef); absoluteSite += cl; tmpCycle += cl * kSign[p.strand]; onRead += cl; onRef += cl; }
-      else if (op == FQ_OP_S) { tmpCycle += cl * kSign[p.strand]; onRead += cl; }
-      else if (op == FQ_OP_D) { absoluteSite += cl; onRef += cl; }
-      else { tmpCycle += cl * kSign[p.strand]; onRead += cl; }
-    }
-  } else match_block(absoluteSite, p.len, tmpCycle, onRead, onRef);
-  return true;
+  });
+}
+// the queued reads of a batch over `threads` threads
+void fq_qc::run_stat_jobs(const FqHostReads &hb, int threads) {
+  const size_t n = stat_jobs.size();
+  if (!n) return;
+  const int T = n >= 512 ? std::max(1, threads) : 1;
+  std::vector<StatHist> hist((size_t)T);
+  auto work = [&](size_t lo, size_t hi, int t) { for (size_t j = lo; j < hi; ++j) read_stats(*stat_jobs[j], hb, hist[(size_t)t]); };
+  if (T == 1) work(0, n, 0);
+  else {
+    std::vector<std::thread> th;
+    const size_t per = (n + (size_t)T - 1) / (size_t)T;
+    for (int t = 0; t < T; ++t) { const size_t lo = (size_t)t * per, hi = std::min(n, lo + per); if (lo < hi) th.emplace_back(work, lo, hi, t); }
+    for (auto &x : th) x.join();
+  }
+  for (const StatHist &h : hist)
+    for (int v = 0; v < 256; ++v) { EmpRep[v] += h.EmpRep[v]; EmpCycle[v] += h.EmpCycle[v]; misEmpRep[v] += h.misEmpRep[v]; misEmpCycle[v] += h.misEmpCycle[v]; }
+  stat_jobs.clear();
 }
 
 // ProcessPairStatus, :623-921; type: 0 FirstOnly, 1 Both, 2 SecondOnly
@@ -553,6 +605,7 @@ extern "C" int fq_qc_add_last(fq_qc_t *q, fq_ctx_t *c) {
     Q.r = &b; Q.type = b.type; Q.name = fq_read_name(&hb, b.r % S->n_pairs, b.r / S->n_pairs, b.revived);
     F.TotalRetained += q->add_alignment(P, Q, hb, F.TotalMAPQ);
   }
+  q->run_stat_jobs(hb, 8);
   return FQ_OK;
 }
 
