@@ -269,7 +269,9 @@ int main(int argc, char **argv) {
 
   fq_index_t *ix = nullptr;
   const std::string pre = A.index_prefix + ".FASTQuick.fa";
+  const auto t_ix0 = std::chrono::steady_clock::now();
   int rc = fq_index_load(pre.c_str(), A.device, &ix);
+  fprintf(stderr, "NOTICE - index staged on the device in %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ix0).count());
   if (rc) die("cannot load index " + pre + " onto HIP device " + std::to_string(A.device) + " (" + std::to_string(rc) + "); there is no CPU fallback");
   // <index>.param: REFERENCE_PATH, TARGET_REGION_PATH, DBSNP_VCF_PATH, NUM_VAR_LONG, NUM_VAR_SHORT, SHORT_FLANK_LENGTH, LONG_FLANK_LENGTH
   fq_qc_opts_t qo;
@@ -400,7 +402,8 @@ int main(int argc, char **argv) {
     std::thread t1(fill_chunk, std::ref(r2), std::ref(slots[1]), std::ref(bufs[slot][1]), A.chunk_pairs, stride, name_stride);
     t0.join(); t1.join();
   };
-  read_both(0);
+  double read_ms = 0, pack_ms = 0;
+  { const auto t0 = std::chrono::steady_clock::now(); read_both(0); read_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
   for (int slot = 0;; slot ^= 1) {
     EndChunk &e0 = bufs[slot][0], &e1 = bufs[slot][1];
     if (!e0.error.empty()) die(e0.error);
@@ -433,7 +436,9 @@ int main(int argc, char **argv) {
     fq_result_batch_t res;
     // the packed boundary: 24 bytes of filter keys per read cross PCIe, full rows only for the surviving pairs
     fq_packed_batch_t *pk = nullptr;
+    const auto tp0 = std::chrono::steady_clock::now();
     rc = fq_pack_reads(&in, A.pack_threads, &pk);
+    pack_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
     if (rc) die("fq_pack_reads failed (" + std::to_string(rc) + ")");
     rc = fq_align_packed(ctx, pk, &res);
     if (rc) die(std::string("fq_align_packed failed: ") + fq_ctx_last_error(ctx));
@@ -463,7 +468,7 @@ int main(int argc, char **argv) {
   fq_stats_get(ctx, &st);
   fprintf(stderr, "NOTICE - device time (ms): prep %.1f width %.1f gap %.1f sa %.1f sw %.1f refine %.1f ; host %.1f ; wall %.1f\n", st.kernel_ms[0],
           st.kernel_ms[1], st.kernel_ms[2], st.kernel_ms[3], st.kernel_ms[4], st.kernel_ms[5], st.host_ms_total, st.wall_ms_total);
-  fprintf(stderr, "NOTICE - consumers (ms): StatCollector %.1f ; %s writer %.1f\n", qc_ms, A.sam_out ? "SAM" : "BAM", out_ms);
+  fprintf(stderr, "NOTICE - consumers (ms): StatCollector %.1f ; %s writer %.1f ; first chunk read %.1f ; packing %.1f\n", qc_ms, A.sam_out ? "SAM" : "BAM", out_ms, read_ms, pack_ms);
   if (qc) fq_qc_end_file(qc);
   fq_ctx_destroy(ctx);
   }

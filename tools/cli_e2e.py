@@ -28,5 +28,5 @@ for extra in ([], ["--sam_out"]):
     t0 = time.perf_counter()
     run = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
     dt = time.perf_counter() - t0
-    note = [l for l in run.stderr.decode(errors="replace").splitlines() if "device time" in l or "consumers" in l]
+    note = [l for l in run.stderr.decode(errors="replace").splitlines() if "device time" in l or "consumers" in l or "index staged" in l]
     print("%-10s rc %d  %d pairs in %.2f s = %.0f pairs/s   %s" % (" ".join(extra) or "BAM", run.returncode, pairs, dt, pairs / dt, " | ".join(note)))
