@@ -181,3 +181,30 @@ def test_emulated_single_end_matches_reference_golden(tag, golden_cases, emu_lib
     diffs = [d for d in ob.diff_stage_files(g["se_stages"], st)]
     assert not diffs, "\n".join(diffs)
     assert filecmp.cmp(g["se_sam"], sam, shallow=False)
+
+
+def test_single_end_edge_batches(golden_cases, emu_lib):
+    """Single-end contexts: an empty batch; a batch whose reads are all filtered (random sequence); the packed entry refuses."""
+    import numpy as np
+    g = golden_cases["basic"]
+    ix = api.Index(g["prefix"], lib=emu_lib)
+    al = api.Aligner(ix, api.default_opts(emu_lib, single_end=1), max_pairs=64)
+    res = al.align(np.zeros((1, 0, 160), np.uint8), np.zeros((1, 0, 160), np.uint8), np.zeros((1, 0), np.int32), [])
+    assert res.n_pairs == 0 and res.n_survivors == 0
+    rng = np.random.default_rng(5)
+    seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, (1, 40, 160))].copy()
+    qual = np.full((1, 40, 160), ord("I"), np.uint8)
+    lens = np.full((1, 40), 150, np.int32)
+    seq[:, :, 150:] = 0; qual[:, :, 150:] = 0
+    res = al.align(seq, qual, lens, [b"r%d" % i for i in range(40)])
+    assert res.n_pairs == 40 and res.n_survivors == 0 and res.n_both_filtered == 40
+    assert al.sam_text() == b""
+    names, s2, q2, l2 = ob.read_fastq_pair(g["fq1"], g["fq2"])
+    with pytest.raises(api.FastquickError):
+        hp = api.HostPacked(s2[:, :16], q2[:, :16], l2[:, :16], names[:16], lib=emu_lib)
+        try:
+            al.align_packed(hp)
+        finally:
+            hp.free()
+    al.close()
+    ix.close()
