@@ -114,7 +114,7 @@ struct PinArena {
 };
 
 struct FqKnobs {   // experiment / test knobs (fq_ctx_set_tuning); defaults are what DESIGN.md measures
-  uint32_t gap_long_pops = 1024;   // lane kernel hands a search to the wavefront-per-read kernel after this many pops (queue dry)
+  uint32_t gap_long_pops = 256;    // lane kernel hands a search to the wavefront-per-read kernel after this many pops (queue dry); 1,024 -> 256: single-stream WGS call 19.4 -> 17.3 ms, search stage 8.0 -> 5.7 ms
   int gap_long_always = 0;         // ... whatever the state of the queue (tests)
   uint32_t gap_long_pops2 = 0;     // hand-over threshold of the second round of a device-filling call (0: no hand-over)
   int64_t gap_split_hard = 0;      // experiment: after the round without gap children, search reads whose lower bound is >= this in a launch of their own (0: off)
