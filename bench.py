@@ -382,6 +382,12 @@ def main() -> None:
                            "reads_searched_per_call": round(a2["reads_searched"] / leg["calls"], 1),
                            "stack_pops_per_read": round(a2["stack_pops"] / max(1, a2["reads_searched"]), 1),
                            "occ_touches_per_read": round(a2["gap_occ_touches"] / max(1, a2["reads_searched"]), 1)}
+        try:      # HBM-side bytes of the search stage from the committed PMC passes (FETCH_SIZE + WRITE_SIZE per searched read)
+            pmc2 = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["ontarget" + ("_packed" if args.boundary == "host" else "")]["fq_gap"]
+            out["ontarget"]["kernel_rooflines"]["fq_gap"]["traffic_per_call"] = round(pmc2["bytes_per_unit"] * a2["reads_searched"] / leg["calls"], 1)
+            out["ontarget"]["kernel_rooflines"]["fq_gap"]["alg_bytes_per_call"] = round(48.0 * a2["gap_occ_touches"] / leg["calls"], 1)
+        except (OSError, KeyError, ValueError):
+            pass
         if "solo" in leg:     # the search kernels with nothing else on the device
             s1 = leg["solo"]
             solo = {}
