@@ -1226,6 +1226,9 @@ FQ_HD void fq_gap_lanes(const FqGapArgs &A, const St &store0, Fetch fetch, int l
 #if FQ_GAP_INSTR == 2
       ib[14] = (uint32_t)((clock64() - t_life0) >> 4);   // lifetime of this wavefront
 #endif
+#if defined(FQ_GAP_INSTR_ROUND2)
+      if (!NOGAP)      // (statistics of the full search only: what the first round left)
+#endif
       if (FQ_LANE_ID() == 0) for (int q = 0; q < 16; ++q) FQ_ATOMIC_ADD64(&A.counters[FQ_C_DBG0 + q], ib[q]);
 #endif
       L.flush_counters();
