@@ -883,15 +883,16 @@ struct FqGapLane {
     spare = FQ_NIL;
     FqEntry e;
     e.k = k; e.l = l; e.pk = pk; e.next = prev;
-    // Stack entries stream out (two in three are never read back): a non-temporal store keeps them from displacing the Occ blocks
-    // from the 4 MB L2 of the XCD, which every step of every lane reads.
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(FQ_POOL_PLAIN_STORE)
-    {
+    // In the round without gap children the stack entries stream out (most are never read back): a non-temporal store keeps them
+    // from displacing the Occ blocks from the 4 MB L2 of the XCD.  The full search pops what it pushes, soon: plain stores leave
+    // the entries where the pops find them (second round of an 8.4 M-read call 35.6 -> 34.2 ms).
+#if defined(__HIP_DEVICE_COMPILE__)
+    if (NOGAP) {
       typedef uint32_t fq_v4u __attribute__((ext_vector_type(4)));
       fq_v4u v;
       v.x = e.k; v.y = e.l; v.z = e.pk; v.w = e.next;
       __builtin_nontemporal_store(v, (fq_v4u *)(pool + (size_t)slot * FQ_WAVE_SIZE));
-    }
+    } else pool[(size_t)slot * FQ_WAVE_SIZE] = e;
 #else
     pool[(size_t)slot * FQ_WAVE_SIZE] = e;
 #endif
