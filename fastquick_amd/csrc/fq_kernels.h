@@ -948,8 +948,7 @@ struct FqGapLane {
     if (enext == FQ_NIL) bucket_clr(b); else store.head_set(b, enext);
     spare = slot;
     pf_slot = FQ_NIL;
-    wbase = 0x7fff;                                                        // the next entry sits anywhere: drop the window
-    --n_live; ++c_pops;
+    --n_live; ++c_pops;                                                    // the window stays: siblings popped back to back share it
     if (!nonstop && b > best_score + o.s_mm) { finish(); return false; }   // bwtgap.c:147
     // A long search is handed over to the wavefront-per-read kernel, but only once the work queue has run dry: before that a
     // busy lane costs nothing, afterwards the whole launch waits for it.
@@ -997,7 +996,8 @@ struct FqGapLane {
     //      rows k-1 and l and, when positions i0-1 / i0-2 have left its window, the next eight position records
     const int a = (int)(cpk >> 9) & 1, i0 = (int)(cpk & 511u);            // i0 >= 1 whenever has_cur
     const int need_lo = i0 >= 2 ? i0 - 2 : 0;
-    const bool reload = !popping && (need_lo < wbase || i0 - 1 > wbase + 7);
+    const int sa = a << 10;                                                  // wbase carries the window's strand in bit 10
+    const bool reload = !popping && (need_lo + sa < wbase || i0 - 1 + sa > wbase + 7);
     const int nb = i0 >= 8 ? ((i0 - 7) & ~1) : 0;                            // 4-byte aligned window holding i0-2 and i0-1
     const FqPos *pp = prec + (size_t)a * (size_t)A.pstride + nb;
     const uintptr_t pa = (uintptr_t)fq_pick2p((uint64_t)(uintptr_t)(pool + (size_t)slot * FQ_WAVE_SIZE), (uint64_t)(uintptr_t)pp, popping ? 1 : 0);
@@ -1019,8 +1019,8 @@ struct FqGapLane {
       return;
     }
     // ---- a lane with a current entry ------------------------------------------------------------------------------------------
-    if (reload) { pw0 = vA.x; pw1 = vA.y; pw2 = vA.z; pw3 = vA.w; wbase = nb; }
-    const int o1 = (i0 - 1) - wbase, o2 = need_lo - wbase;
+    if (reload) { pw0 = vA.x; pw1 = vA.y; pw2 = vA.z; pw3 = vA.w; wbase = nb + sa; }
+    const int o1 = (i0 - 1 + sa) - wbase, o2 = need_lo + sa - wbase;
     const uint32_t rec1 = (fq_sel4v(pw0, pw1, pw2, pw3, o1 >> 1) >> ((o1 & 1) << 4)) & 0xffffu;   // position i0-1
     const uint32_t rec2 = (fq_sel4v(pw0, pw1, pw2, pw3, o2 >> 1) >> ((o2 & 1) << 4)) & 0xffffu;   // position i0-2 (if any)
     const int cbase = (int)(rec1 >> 12) & 7;                                 // seq[a][i0-1]
@@ -1160,6 +1160,7 @@ struct FqGapLane {
     // gap_shadow (bwtgap.c:81-91) over width[0..last_diff) of the hit's strand, one hit at a time, all lanes sweeping; the
     // packed position records (bid, and the "same width as the previous position" bit up to position last_diff) follow
     uint64_t sm = FQ_BALLOT(add && ld > 0);
+    if (add && ld > 0) wbase = 0x7fff;                                        // the records change under the window
     while (sm) {
       const int L = FQ_CTZ64(sm);
       sm &= sm - 1;
@@ -1269,8 +1270,8 @@ FQ_HD void fq_gap_lanes(const FqGapArgs &A, const St &store0, Fetch fetch, int l
     const bool pop_any = FQ_BALLOT(L.active && !L.has_cur) != 0;
     bool rl_any;
     {   // will a lane fetch a new window of position records in this trip (the condition of FqGapLane::step)
-      const int i0_ = (int)(L.cpk & 511u), lo_ = i0_ >= 2 ? i0_ - 2 : 0;
-      rl_any = FQ_BALLOT(L.active && L.has_cur && (lo_ < L.wbase || i0_ - 1 > L.wbase + 7)) != 0;
+      const int i0_ = (int)(L.cpk & 511u), sa_ = (int)((L.cpk >> 9) & 1u) << 10, lo_ = (i0_ >= 2 ? i0_ - 2 : 0) + sa_;
+      rl_any = FQ_BALLOT(L.active && L.has_cur && (lo_ < L.wbase || i0_ - 1 + sa_ > L.wbase + 7)) != 0;
     }
     const uint64_t tc0 = clock64();
     if (L.active) { ++lane_trips; L.step(); }
