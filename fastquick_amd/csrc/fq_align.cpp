@@ -216,6 +216,11 @@ struct fq_ctx {
   int64_t n_bases_in = 0;
   // results of the last batch
   FqBatchState st;
+  struct CallVecs {            // per-call host arrays of one entry per read: kept here so that a call reuses the last call's pages
+    std::vector<uint64_t> read_nocc, aln_row_off;
+    std::vector<uint32_t> q_first;
+    std::vector<char> enumerated;
+  } cv;
   fq_stats_t stats{};
   ~fq_ctx();
 };
@@ -576,7 +581,9 @@ void pair_hits(fq_ctx *c, const FqPairIsize &pi, const int32_t *lut, FqRead *p[2
 // reads of surviving pairs.  The stage functions share the per-call state in `Call`.
 namespace {
 struct Call {
-  fq_ctx *c = nullptr;
+  fq_ctx *c;
+  explicit Call(fq_ctx *ctx) : c(ctx), aln_off(ctx->st.aln_off), aln_n(ctx->st.aln_n), s_of(ctx->st.s_of), read_nocc(ctx->cv.read_nocc),
+                               aln_row_off(ctx->cv.aln_row_off), q_first(ctx->cv.q_first), enumerated(ctx->cv.enumerated) {}
   int n = 0, n2 = 0, B = 0, n_sub = 0, n_search = 0, n_surv = 0, max_len_all = 1, host_threads = 1;
   size_t par_min = 32768;
   // where the kernels after the filter find the reads: ASCII rows [row][dstride], trimmed lengths [row], search index -> row.
@@ -585,13 +592,14 @@ struct Call {
   int dstride = 0;
   const int32_t *dlen_trim = nullptr, *dread_list = nullptr;
   vector<int> sub_max_len, sub_lo;
-  vector<uint64_t> aln_off;            // per search index s: its hit list is S.aln[aln_off[s] .. + aln_n[s])
-  vector<uint32_t> aln_n;
-  vector<int> s_of;                    // survivor read -> search index or -1
-  vector<uint64_t> read_nocc, aln_row_off;
-  vector<uint32_t> q_first;            // survivor read -> its first hit in the list k_sa enumerated (valid when enumerated)
+  // (the arrays of one entry per read live in the context -- the batch state's for the ones the consumers read -- and keep their pages)
+  vector<uint64_t> &aln_off;           // per search index s: its hit list is S.aln[aln_off[s] .. + aln_n[s])
+  vector<uint32_t> &aln_n;
+  vector<int> &s_of;                   // survivor read -> search index or -1
+  vector<uint64_t> &read_nocc, &aln_row_off;
+  vector<uint32_t> &q_first;           // survivor read -> its first hit in the list k_sa enumerated (valid when enumerated)
   uint64_t n_rows = 0;
-  vector<char> enumerated;
+  vector<char> &enumerated;
   const uint32_t *h_pos = nullptr;     // positions of the enumerated SA rows (pinned staging of the context)
   vector<fq_isize_t> iis;
   double t_trace = 0, t_wall0 = 0, t_host0 = 0, t_serial1 = 0, t_host1 = 0;
@@ -1628,20 +1636,35 @@ int stageD_refine(Call &K) {
   struct Tgt { int idx, multi; };
   vector<Tgt> tgt; vector<FqRefTask> tasks;
   int max_ref = 1, max_q = 1;
-  for (size_t idx = 0; idx < R.size(); ++idx) {
-    FqRead &s = R[idx];
-    if (s.filtered) continue;
-    for (size_t j = 0; j < s.multi.size(); ++j) {
-      FqMulti &q = s.multi[j];
-      if (q.gap == 0) continue;
-      tasks.push_back({s.dr, q.strand, q.pos, (q.strand ? 1 : -1) * q.gap});
-      tgt.push_back({(int)idx, (int)j});
-      max_ref = std::max(max_ref, s.len + q.gap); max_q = std::max(max_q, (int)s.len);
+  {   // the task list in record order: every thread lists its range of records, the lists are joined in range order
+    const int TT = std::max(1, K.host_threads);
+    struct Part { vector<Tgt> tgt; vector<FqRefTask> tasks; int max_ref = 1, max_q = 1; };
+    vector<Part> part((size_t)TT);
+    parallel_chunks(R.size(), TT, K.par_min, [&](size_t lo, size_t hi, int t) {
+      Part &P = part[t];
+      for (size_t idx = lo; idx < hi; ++idx) {
+        FqRead &s = R[idx];
+        if (s.filtered) continue;
+        for (size_t j = 0; j < s.multi.size(); ++j) {
+          FqMulti &q = s.multi[j];
+          if (q.gap == 0) continue;
+          P.tasks.push_back({s.dr, q.strand, q.pos, (q.strand ? 1 : -1) * q.gap});
+          P.tgt.push_back({(int)idx, (int)j});
+          P.max_ref = std::max(P.max_ref, s.len + q.gap); P.max_q = std::max(P.max_q, (int)s.len);
+        }
+        if (s.type == FQ_TYPE_NO_MATCH || s.type == FQ_TYPE_MATESW || s.n_gapo == 0) continue;
+        P.tasks.push_back({s.dr, s.strand, s.pos, (s.strand ? 1 : -1) * (s.n_gapo + s.n_gape)});
+        P.tgt.push_back({(int)idx, -1});
+        P.max_ref = std::max(P.max_ref, s.len + s.n_gapo + s.n_gape); P.max_q = std::max(P.max_q, (int)s.len);
+      }
+    });
+    size_t total = 0;
+    for (const Part &P : part) total += P.tasks.size();
+    tasks.reserve(total); tgt.reserve(total);
+    for (const Part &P : part) {
+      tasks.insert(tasks.end(), P.tasks.begin(), P.tasks.end()); tgt.insert(tgt.end(), P.tgt.begin(), P.tgt.end());
+      max_ref = std::max(max_ref, P.max_ref); max_q = std::max(max_q, P.max_q);
     }
-    if (s.type == FQ_TYPE_NO_MATCH || s.type == FQ_TYPE_MATESW || s.n_gapo == 0) continue;
-    tasks.push_back({s.dr, s.strand, s.pos, (s.strand ? 1 : -1) * (s.n_gapo + s.n_gape)});
-    tgt.push_back({(int)idx, -1});
-    max_ref = std::max(max_ref, s.len + s.n_gapo + s.n_gape); max_q = std::max(max_q, (int)s.len);
   }
   if (!tasks.empty()) {
     const int cig_cap = 64;
@@ -1677,27 +1700,36 @@ int stageD_refine(Call &K) {
   }
   // MD / NM for every mapped read (bwa_cal_md1)
   // (task list and CIGAR arena are laid out by prefix sums and written, in parallel, where the copy engine reads them)
-  vector<uint32_t> t_of(R.size() + 1, 0), cg_of(R.size() + 1, 0);
-  for (size_t idx = 0; idx < R.size(); ++idx) {
-    const bool on = R[idx].type != FQ_TYPE_NO_MATCH;
-    t_of[idx + 1] = t_of[idx] + (on ? 1u : 0u);
-    cg_of[idx + 1] = cg_of[idx] + (on ? (uint32_t)R[idx].cigar.size() : 0u);
-  }
-  const int nt_all = (int)t_of[R.size()];
-  const size_t arena_n = cg_of[R.size()];
+  // (every thread counts the tasks and CIGAR entries of its range of records; the ranges' first slots follow from those counts)
+  const int TT = std::max(1, K.host_threads);
+  struct Cnt { uint64_t t = 0, cg = 0; char pad[48]; };
+  vector<Cnt> first((size_t)TT + 1);
+  parallel_chunks(R.size(), TT, K.par_min, [&](size_t lo, size_t hi, int t) {
+    Cnt a;
+    for (size_t idx = lo; idx < hi; ++idx)
+      if (R[idx].type != FQ_TYPE_NO_MATCH) { ++a.t; a.cg += R[idx].cigar.size(); }
+    first[(size_t)t + 1] = a;
+  });
+  for (int t = 1; t <= TT; ++t) { first[t].t += first[t - 1].t; first[t].cg += first[t - 1].cg; }
+  if (first[TT].t > 0x7fffffffull || first[TT].cg > 0xffffffffull) { c->err = "MD tasks exceed 32-bit offsets"; return FQ_ELIMIT; }
+  const int nt_all = (int)first[TT].t;
+  const size_t arena_n = (size_t)first[TT].cg;
   FqMdTask *mt = nullptr; uint16_t *arena = nullptr;
-  vector<int> mi((size_t)nt_all);
+  int *mi = nullptr;
   if (nt_all) {
     mt = (FqMdTask *)c->arena.alloc((size_t)nt_all * sizeof(FqMdTask)); arena = (uint16_t *)c->arena.alloc((arena_n + 1) * 2);
-    if (!mt || !arena) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
-    parallel_chunks(R.size(), K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
+    mi = (int *)c->arena.alloc((size_t)nt_all * sizeof(int));
+    if (!mt || !arena || !mi) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
+    parallel_chunks(R.size(), TT, K.par_min, [&](size_t lo, size_t hi, int t) {
+      uint32_t ti = (uint32_t)first[t].t, cgi = (uint32_t)first[t].cg;
       for (size_t idx = lo; idx < hi; ++idx) {
         FqRead &s = R[idx];
         if (s.type == FQ_TYPE_NO_MATCH) continue;
         FqMdTask T{};
-        T.read = s.dr; T.strand = s.strand; T.pos = s.pos; T.n_cigar = (int)s.cigar.size(); T.cigar_off = cg_of[idx]; T.len = s.len;
-        if (!s.cigar.empty()) memcpy(arena + cg_of[idx], s.cigar.data(), s.cigar.size() * 2);
-        mt[t_of[idx]] = T; mi[t_of[idx]] = (int)idx;
+        T.read = s.dr; T.strand = s.strand; T.pos = s.pos; T.n_cigar = (int)s.cigar.size(); T.cigar_off = cgi; T.len = s.len;
+        if (!s.cigar.empty()) memcpy(arena + cgi, s.cigar.data(), s.cigar.size() * 2);
+        mt[ti] = T; mi[ti] = (int)idx;
+        ++ti; cgi += (uint32_t)s.cigar.size();
       }
     });
   }
@@ -1776,13 +1808,9 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
   const int n_sub = K.n_sub, n_surv = K.n_surv;
   S.isize_sub = K.iis;
   S.isize = K.iis[n_sub - 1];
-  S.s_of = K.s_of;
-  S.aln_off = K.aln_off;
-  S.aln_n = K.aln_n;
   S.flatten(K.host_threads, K.par_min);
   K.trace("flatten");
-  int n_both_unmapped = 0;
-  for (int sp = 0; sp < n_surv; ++sp) if (R[2 * sp].type == FQ_TYPE_NO_MATCH && R[2 * sp + 1].type == FQ_TYPE_NO_MATCH) ++n_both_unmapped;
+  const int n_both_unmapped = S.n_both_unmapped;
   out->n_survivors = n_surv;
   out->n_both_filtered = K.n - n_surv;
   out->n_both_unmapped = n_both_unmapped;
@@ -1822,8 +1850,7 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
 }
 
 int run_call(fq_ctx *c, fq_result_batch_t *out) {
-  Call K;
-  K.c = c;
+  Call K(c);
   K.t_trace = K.t_wall0 = now_ms();
   NodePin pin;
   (void)fqdev::stream_aux(0);      // (an error return may have left the context on its second stream)

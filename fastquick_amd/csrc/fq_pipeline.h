@@ -1,6 +1,9 @@
 // fq_pipeline.h -- host-side per-batch state shared by fq_align.cpp (producer) and fq_sam.cpp (consumers)
 #pragma once
 #include <algorithm>
+#include <cstdlib>
+#include <new>
+#include <stdexcept>
 #include <thread>
 #include <string>
 #include <vector>
@@ -53,69 +56,106 @@ struct FqBatchState {
   std::vector<fq_isize_t> isize_sub;
   std::vector<int> sub_lo;              // first survivor of each reference batch (+ sentinel)
   int batch_pairs = 262144;
-  // flattened C-ABI view
-  std::vector<fq_result_t> rec;
-  std::vector<uint16_t> cigar;
-  std::vector<char> md;
-  std::vector<fq_multi_t> multi;
+  // flattened C-ABI view (grow-only buffers, never value-initialised: flatten() writes every element it publishes)
+  template <class T> struct Flat {
+    T *p = nullptr;
+    size_t cap = 0;
+    Flat() = default;
+    Flat(const Flat &) = delete;
+    Flat &operator=(const Flat &) = delete;
+    ~Flat() { std::free(p); }
+    T *data() const { return p; }
+    void reserve(size_t n) {
+      if (n <= cap) return;
+      std::free(p);
+      cap = n + n / 8 + 16;
+      p = (T *)std::malloc(cap * sizeof(T));
+      if (!p) { cap = 0; throw std::bad_alloc(); }
+    }
+  };
+  Flat<fq_result_t> rec;
+  Flat<uint16_t> cigar;
+  Flat<char> md;
+  Flat<fq_multi_t> multi;
+  int n_both_unmapped = 0;              // pairs with both ends FQ_TYPE_NO_MATCH (counted by flatten)
 
   void clear() {
     n_pairs = n_surv = 0;
     pair_idx.clear(); stage_P.clear(); stage_S.clear(); aln.clear(); s_of.clear(); aln_off.clear(); aln_n.clear();
-    rec.clear(); cigar.clear(); md.clear(); multi.clear();
   }
-  // C-ABI arrays from the per-read records.  Offsets into the side arenas are prefix sums of per-record sizes, so the copy
-  // itself splits over threads for large batches.
+  // C-ABI arrays from the per-read records.  Offsets into the side arenas are prefix sums of per-record sizes: every thread sums
+  // the sizes of its range of pairs, the ranges' first offsets follow from those sums, then every thread copies its range.
   void flatten(int threads, size_t par_min) {
-    const size_t nrec = reads.size();
-    rec.resize(nrec);
-    std::vector<uint32_t> coff(nrec + 1), moff(nrec + 1), xoff(nrec + 1);
-    uint32_t cc = 0, mm = 0, xx = 0;
-    for (size_t i = 0; i < nrec; ++i) {
-      const FqRead &s = reads[i];
-      coff[i] = cc; moff[i] = mm; xoff[i] = xx;
-      cc += (uint32_t)s.cigar.size();
-      for (const FqMulti &q : s.multi) cc += (uint32_t)q.cigar.size();
-      if (s.has_md) mm += (uint32_t)s.md.size() + 1;
-      xx += (uint32_t)s.multi.size();
-    }
-    coff[nrec] = cc; moff[nrec] = mm; xoff[nrec] = xx;
-    cigar.assign(cc ? cc : 1, 0); md.assign(mm ? mm : 1, 0); multi.assign(xx ? xx : 1, fq_multi_t{});
-    auto fill = [&](size_t lo, size_t hi) {
+    const size_t nrec = reads.size(), npair = nrec / 2;
+    const int T = (threads <= 1 || nrec < par_min) ? 1 : threads;
+    struct Sum { uint64_t cc = 0, mm = 0, xx = 0; int unm = 0; char pad[36]; };
+    std::vector<Sum> sums((size_t)T + 1);
+    auto range = [&](int t, size_t &lo, size_t &hi) {   // whole pairs; an odd last record (there is none today) goes to the last range
+      const size_t per = (npair + (size_t)T - 1) / (size_t)T;
+      lo = std::min(npair, (size_t)t * per) * 2; hi = t == T - 1 ? nrec : std::min(npair, ((size_t)t + 1) * per) * 2;
+    };
+    auto run = [&](auto fn) {
+      if (T == 1) { fn(0); return; }
+      std::vector<std::thread> th;
+      for (int t = 1; t < T; ++t) th.emplace_back(fn, t);
+      fn(0);
+      for (auto &x : th) x.join();
+    };
+    run([&](int t) {
+      size_t lo, hi;
+      range(t, lo, hi);
+      Sum a;
       for (size_t i = lo; i < hi; ++i) {
         const FqRead &s = reads[i];
-        fq_result_t &o = rec[i];
+        a.cc += s.cigar.size();
+        for (const FqMulti &q : s.multi) a.cc += q.cigar.size();
+        if (s.has_md) a.mm += s.md.size() + 1;
+        a.xx += s.multi.size();
+        if ((i & 1) && s.type == FQ_TYPE_NO_MATCH && reads[i - 1].type == FQ_TYPE_NO_MATCH) ++a.unm;
+      }
+      sums[(size_t)t + 1] = a;
+    });
+    n_both_unmapped = 0;
+    for (int t = 1; t <= T; ++t) {   // sums[t] becomes the first offsets of range t
+      n_both_unmapped += sums[t].unm;
+      sums[t].cc += sums[t - 1].cc; sums[t].mm += sums[t - 1].mm; sums[t].xx += sums[t - 1].xx;
+    }
+    const uint64_t cc = sums[T].cc, mm = sums[T].mm, xx = sums[T].xx;
+    if (cc > 0xffffffffull || mm > 0xfffffffeull || xx > 0xffffffffull) throw std::length_error("fq: result arenas exceed 32-bit offsets");
+    rec.reserve(nrec ? nrec : 1); cigar.reserve(cc ? cc : 1); md.reserve(mm ? mm : 1); multi.reserve(xx ? xx : 1);
+    if (!cc) cigar.p[0] = 0;
+    if (!mm) md.p[0] = 0;
+    if (!xx) multi.p[0] = fq_multi_t{};
+    run([&](int t) {
+      size_t lo, hi;
+      range(t, lo, hi);
+      uint32_t ca = (uint32_t)sums[t].cc, ma = (uint32_t)sums[t].mm, xa = (uint32_t)sums[t].xx;
+      for (size_t i = lo; i < hi; ++i) {
+        const FqRead &s = reads[i];
+        fq_result_t o{};
         o.pos = s.pos; o.sa = s.sa; o.c1 = s.c1; o.c2 = s.c2; o.score = s.score;
         o.len = s.len; o.full_len = s.full_len; o.clip_len = s.clip_len;
         o.type = (uint8_t)s.type; o.strand = (uint8_t)s.strand; o.filtered = (uint8_t)s.filtered; o.extra_flag = (uint8_t)s.extra_flag;
         o.n_mm = (uint8_t)s.n_mm; o.n_gapo = (uint8_t)s.n_gapo; o.n_gape = (uint8_t)s.n_gape; o.mapQ = (uint8_t)s.mapQ;
         o.seQ = (uint8_t)s.seQ; o.pad0 = 0; o.nm = (uint16_t)s.nm;
         o.n_cigar = (uint16_t)s.cigar.size(); o.n_multi = (uint16_t)s.multi.size();
-        uint32_t ca = coff[i];
         o.cigar_off = ca;
-        std::copy(s.cigar.begin(), s.cigar.end(), cigar.begin() + ca);
+        std::copy(s.cigar.begin(), s.cigar.end(), cigar.p + ca);
         ca += (uint32_t)s.cigar.size();
-        if (s.has_md) { o.md_off = moff[i]; std::copy(s.md.begin(), s.md.end(), md.begin() + moff[i]); md[moff[i] + s.md.size()] = 0; }
+        if (s.has_md) { o.md_off = ma; std::copy(s.md.begin(), s.md.end(), md.p + ma); md.p[ma + s.md.size()] = 0; ma += (uint32_t)s.md.size() + 1; }
         else o.md_off = 0xffffffffu;
-        o.multi_off = xoff[i];
-        uint32_t xa = xoff[i];
+        o.multi_off = xa;
         for (const FqMulti &q : s.multi) {
           fq_multi_t m{};
           m.pos = q.pos; m.cigar_off = ca; m.n_cigar = (uint16_t)q.cigar.size(); m.gap = (uint8_t)q.gap; m.mm = (uint8_t)q.mm;
           m.strand = (uint8_t)q.strand;
-          std::copy(q.cigar.begin(), q.cigar.end(), cigar.begin() + ca);
+          std::copy(q.cigar.begin(), q.cigar.end(), cigar.p + ca);
           ca += (uint32_t)q.cigar.size();
-          multi[xa++] = m;
+          multi.p[xa++] = m;
         }
+        rec.p[i] = o;
       }
-    };
-    if (threads <= 1 || nrec < par_min) fill(0, nrec);
-    else {
-      std::vector<std::thread> th;
-      const size_t per = (nrec + threads - 1) / threads;
-      for (int t = 0; t < threads; ++t) { const size_t lo = (size_t)t * per, hi = std::min(nrec, lo + per); if (lo < hi) th.emplace_back(fill, lo, hi); }
-      for (auto &x : th) x.join();
-    }
+    });
   }
 };
 
