@@ -74,6 +74,16 @@ template <class T> struct PinBuf {   // pinned host staging: device <-> host cop
     if (!p) { cap = 0; return false; }
     return true;
   }
+  bool ensure_keep(size_t n, size_t keep) {   // as ensure, but the first `keep` elements survive a reallocation
+    if (n <= cap) return true;
+    const size_t ncap = n + n / 4 + 64;
+    T *q = (T *)fqdev::hmalloc(ncap * sizeof(T));
+    if (!q) return false;
+    if (keep) memcpy(q, p, keep * sizeof(T));
+    fqdev::hfree(p);
+    p = q; cap = ncap;
+    return true;
+  }
 };
 
 // Every host <-> device copy of a call goes through pinned memory: a copy from or to pageable memory takes the runtime's
@@ -220,6 +230,7 @@ struct fq_ctx {
     std::vector<uint64_t> read_nocc, aln_row_off;
     std::vector<uint32_t> q_first;
     std::vector<char> enumerated;
+    std::vector<int32_t> work, next_work;
   } cv;
   fq_stats_t stats{};
   ~fq_ctx();
@@ -891,7 +902,8 @@ int stageA_search(Call &K) {
   const fq_index *ix = c->ix;
   const fq_opts_t &o = c->o;
   const int n_search = K.n_search, max_len_all = K.max_len_all;
-  vector<FqAln> &h_aln = c->st.aln;
+  // the hit lists stay where the copy engine lands them (the context's pinned buffer): S.aln is a view of it
+  c->st.aln.p = c->p_aln.p; c->st.aln.n = 0;
   K.aln_off.assign((size_t)n_search + 1, 0);
   K.aln_n.assign(n_search, 0);
   const int Lpad = (max_len_all + 1 + 7) & ~7;                  // exact widths per strand; rows are written 8 positions at a time
@@ -915,9 +927,9 @@ int stageA_search(Call &K) {
   tiers.push_back(lane_tier); chunk_reads.push_back((size_t)8 << 20);
   tiers.push_back(wave_tier); chunk_reads.push_back((size_t)1 << 20);
   tiers.push_back(exact_tier); chunk_reads.push_back(4096);
-  vector<int32_t> work(n_search), next_work;
-  for (int s = 0; s < n_search; ++s) work[s] = s;
-  vector<int64_t> where(n_search, -1);   // offset of s's list in h_aln (filled as results arrive)
+  vector<int32_t> &work = c->cv.work, &next_work = c->cv.next_work;
+  work.resize((size_t)n_search);
+  parallel_chunks((size_t)n_search, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) { for (size_t s = lo; s < hi; ++s) work[s] = (int32_t)s; });
   bool ran_nogap = false;
   vector<uint8_t> bound_of;               // experiment: min over strands of k_width's lower bound, per read
   for (size_t tier = 0; tier < tiers.size() && !work.empty(); ++tier) {
@@ -1050,22 +1062,21 @@ int stageA_search(Call &K) {
         bound_of.assign(n_search, 0);
         for (int w = 0; w < nw; ++w) bound_of[work[c0 + w]] = std::min(h_bid[2 * w], h_bid[2 * w + 1]);
       }
-      CKM(c->d_packed.ensure(total + 1) && c->p_aln.ensure(total + 1));
+      // the packed array holds exactly the lists of the reads that completed, in work order (a failed read reports no hits): it
+      // lands behind the lists of the earlier launches, and every read finds its list at the offset the device's prefix sum gave it
+      const uint64_t base = c->st.aln.n;
+      CKM(c->d_packed.ensure(total + 1) && c->p_aln.ensure_keep(base + total + 1, base));
       CK(fqdev::launch_pack_aln(c->d_aln.p, c->d_naln.p, c->d_off.p, T.aln_cap, (uint32_t)nw, c->d_packed.p));
-      FqAln *h_packed = c->p_aln.p;
-      CK(fqdev::copy_pinned(h_packed, c->d_packed.p, total * sizeof(FqAln), 0));
+      CK(fqdev::copy_pinned(c->p_aln.p + base, c->d_packed.p, total * sizeof(FqAln), 0));
       CKS(sync_staged(c));
       c->stats.d2h_bytes += (size_t)nw * 8 + total * sizeof(FqAln);
-      // the packed array holds exactly the lists of the reads that completed, in work order (a failed read reports no hits): it is
-      // appended in one piece, and every read finds its list at the offset the device's prefix sum gave it
-      const int64_t base = (int64_t)h_aln.size();
-      h_aln.insert(h_aln.end(), h_packed, h_packed + total);
+      c->st.aln.p = c->p_aln.p; c->st.aln.n = base + total;
       const int32_t *wk = work.data() + c0;
       parallel_chunks((size_t)nw, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
         for (size_t w = lo; w < hi; ++w) {
           if (h_status[w]) continue;
           const int s = wk[w];
-          where[s] = base + (int64_t)h_off[w];
+          K.aln_off[s] = base + h_off[w];
           K.aln_n[s] = h_naln[w];
         }
       });
@@ -1090,17 +1101,17 @@ int stageA_search(Call &K) {
         CK(fqdev::copy_pinned(off2, c->d_off.p, ((size_t)n2_total + 1) * 8, 0));
         CKS(sync_staged(c));
         const uint64_t tot2 = off2[n2_total];
-        CKM(c->d_packed.ensure(tot2 + 1) && c->p_aln.ensure(tot2 + 1));
+        const uint64_t base2 = c->st.aln.n;
+        CKM(c->d_packed.ensure(tot2 + 1) && c->p_aln.ensure_keep(base2 + tot2 + 1, base2));
         CK(fqdev::launch_pack_aln(c->d_aln2.p, c->d_naln2.p, c->d_off.p, T2.aln_cap, n2_total, c->d_packed.p));
-        CK(fqdev::copy_pinned(c->p_aln.p, c->d_packed.p, tot2 * sizeof(FqAln), 0));
+        CK(fqdev::copy_pinned(c->p_aln.p + base2, c->d_packed.p, tot2 * sizeof(FqAln), 0));
         CKS(sync_staged(c));
         c->stats.d2h_bytes += (size_t)n2_total * 20 + tot2 * sizeof(FqAln);
-        const int64_t base2 = (int64_t)h_aln.size();
-        h_aln.insert(h_aln.end(), c->p_aln.p, c->p_aln.p + tot2);
+        c->st.aln.p = c->p_aln.p; c->st.aln.n = base2 + tot2;
         for (uint32_t t = 0; t < n2_total; ++t) {
           const int sidx = list2[t];
           if (st2[t]) { next_work.push_back(sidx); ++c->stats.tier_retries; continue; }
-          where[sidx] = base2 + (int64_t)off2[t];
+          K.aln_off[sidx] = base2 + off2[t];
           K.aln_n[sidx] = na2[t];
         }
       }
@@ -1108,7 +1119,6 @@ int stageA_search(Call &K) {
     work.swap(next_work);
   }
   if (!work.empty()) { c->err = "gap search: exact tier exhausted its pool (internal limit)"; return FQ_ELIMIT; }
-  parallel_chunks((size_t)n_search, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) { for (size_t s = lo; s < hi; ++s) K.aln_off[s] = where[s] < 0 ? 0 : (uint64_t)where[s]; });
   c->stats.reads_searched += n_search;
   return FQ_OK;
 }
@@ -1364,19 +1374,32 @@ void stage_kl_cache(Call &K) {
   };
   // MIN_HASH_WIDTH: the positions of an interval >= 1000 wide are those of its first requester, in pair order (Q6): fill the
   // cache serially, in that order, before the pairs are spread over threads (which then only look it up)
-  for (int sp = 0; sp < n_surv; ++sp) {
-    if (!both_mapped(sp)) continue;
-    for (int j = 0; j < 2; ++j) {
-      int na; const FqAln *a = K.aln_of(2 * sp + j, &na);
-      const uint64_t base = K.aln_off[K.s_of[2 * sp + j]];
-      for (int k = 0; k < na; ++k) {
-        const uint32_t wdt = a[k].l - a[k].k + 1;
-        if (wdt < 1000) continue;
-        auto ins = c->kl_cache.emplace((uint64_t)a[k].k << 32 | a[k].l, vector<uint32_t>());
-        if (ins.second) { const uint32_t *ps = h_pos + K.aln_row_off[base + k]; ins.first->second.assign(ps, ps + wdt); }
+  // (such intervals are rare: all threads look for the pairs that hold one, the serial pass visits only those)
+  const int T = std::max(1, K.host_threads);
+  vector<vector<int>> wide((size_t)T);
+  parallel_chunks((size_t)n_surv, T, K.par_min, [&](size_t lo, size_t hi, int t) {
+    for (size_t sp = lo; sp < hi; ++sp) {
+      if (!both_mapped((int)sp)) continue;
+      bool any = false;
+      for (int j = 0; j < 2 && !any; ++j) {
+        int na; const FqAln *a = K.aln_of(2 * (int)sp + j, &na);
+        for (int k = 0; k < na; ++k) if (a[k].l - a[k].k + 1 >= 1000) { any = true; break; }
       }
+      if (any) wide[t].push_back((int)sp);
     }
-  }
+  });
+  for (int t = 0; t < T; ++t)
+    for (const int sp : wide[t])
+      for (int j = 0; j < 2; ++j) {
+        int na; const FqAln *a = K.aln_of(2 * sp + j, &na);
+        const uint64_t base = K.aln_off[K.s_of[2 * sp + j]];
+        for (int k = 0; k < na; ++k) {
+          const uint32_t wdt = a[k].l - a[k].k + 1;
+          if (wdt < 1000) continue;
+          auto ins = c->kl_cache.emplace((uint64_t)a[k].k << 32 | a[k].l, vector<uint32_t>());
+          if (ins.second) { const uint32_t *ps = h_pos + K.aln_row_off[base + k]; ins.first->second.assign(ps, ps + wdt); }
+        }
+      }
 }
 
 // ---- stage B3: pairing + XA lists (per pair) -------------------------------------------------------------

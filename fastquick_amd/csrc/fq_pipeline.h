@@ -48,7 +48,14 @@ struct FqBatchState {
   std::vector<int32_t> pair_idx;
   std::vector<FqRead> reads;            // 2 per survivor pair, final state
   std::vector<FqRead> stage_P, stage_S; // snapshots after pairing / after mate SW (debug only)
-  std::vector<FqAln> aln;               // concatenated hit lists
+  struct AlnView {                      // concatenated hit lists: a view of the context's pinned buffer the device's lists land in
+    const FqAln *p = nullptr;
+    size_t n = 0;
+    const FqAln *data() const { return p; }
+    size_t size() const { return n; }
+    const FqAln &operator[](size_t i) const { return p[i]; }
+    void clear() { n = 0; }
+  } aln;
   std::vector<int> s_of;                // survivor read -> search index or -1
   std::vector<uint64_t> aln_off;
   std::vector<uint32_t> aln_n;
