@@ -1057,6 +1057,7 @@ int stageA_search(Call &K) {
       vector<uint8_t> h_bid;
       if (T.nogap && c->kn.gap_split_hard > 0) { h_bid.resize((size_t)nw * 2); CKS(d2h_staged(c, h_bid.data(), c->d_bid_end.p, (size_t)nw * 2)); }
       CKS(sync_staged(c));
+      K.trace("  A: width + search kernels, counts D2H");
       total = h_off[nw];
       if (!h_bid.empty()) {
         bound_of.assign(n_search, 0);
@@ -1071,6 +1072,7 @@ int stageA_search(Call &K) {
       CKS(sync_staged(c));
       c->stats.d2h_bytes += (size_t)nw * 8 + total * sizeof(FqAln);
       c->st.aln.p = c->p_aln.p; c->st.aln.n = base + total;
+      K.trace("  A: hit lists D2H");
       const int32_t *wk = work.data() + c0;
       parallel_chunks((size_t)nw, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
         for (size_t w = lo; w < hi; ++w) {
@@ -1117,6 +1119,7 @@ int stageA_search(Call &K) {
       }
     }
     work.swap(next_work);
+    K.trace("  A: round bookkeeping");
   }
   if (!work.empty()) { c->err = "gap search: exact tier exhausted its pool (internal limit)"; return FQ_ELIMIT; }
   c->stats.reads_searched += n_search;
@@ -1525,38 +1528,56 @@ int stageC_mate_sw(Call &K) {
   struct Cand { int sp, k; };
   vector<Cand> cands; vector<FqSwTask> tasks;
   int max_reg = 0, max_q = 0;
-  for (int sb = 0; sb < K.n_sub; ++sb) {
-    const fq_isize_t ii = K.iis[sb];
-    if (ii.avg < 0.0) continue;   // bwa_paired_sw returns before touching anything (bwape.c:477)
-    for (int sp = K.sub_lo[sb]; sp < K.sub_lo[sb + 1]; ++sp) {
-      FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
-      for (int j = 0; j < 2; ++j) if (p[j]->filtered) { p[j]->filtered = 0; p[j]->revived = true; }   // expand_seq: revived because its mate passed (:485-499)
-      if (!((p[0]->mapQ >= 17 || p[1]->mapQ >= 17) && (p[0]->extra_flag & 2) == 0)) continue;
-      for (int k = 0; k < 2; ++k) {
-        FqRead *pref = p[1 - k], *pm = p[k];
-        if (pref->type == FQ_TYPE_NO_MATCH) continue;
-        int64_t beg, end;
-        FqSwTask T{};
-        if (pref->strand == 0) {   // __set_rght_coor (:511-516)
-          beg = (int64_t)((int64_t)pref->pos + ii.avg - 3 * ii.std - pm->len * 1.5);
-          end = (int64_t)(beg + 6 * ii.std + 2 * pm->len);
-          // the macro assigns `_pref->pos + _pref->len` in 32-bit unsigned arithmetic (it wraps for a hit hanging over the start of the
-          // reference, pos = 2^32-1) after comparing in 64 bits
-          if (beg < (int64_t)pref->pos + pref->len) beg = (int64_t)(uint32_t)((uint32_t)pref->pos + (uint32_t)pref->len);
-          if (end > ix->l_pac) end = ix->l_pac;
-          T.use_rc = 1;
-        } else {                   // __set_left_coor (:518-523)
-          beg = (int64_t)((int64_t)pref->pos + pref->len - ii.avg - 3 * ii.std - pm->len * 0.5);
-          end = (int64_t)(beg + 6 * ii.std + 2 * pm->len);
-          if (beg < 0) beg = 0;
-          if (end > (int64_t)pref->pos) end = pref->pos;
-          T.use_rc = 0;
+  // candidates in pair order: every thread lists its range of pairs (a pair's candidates depend on its two records and on its
+  // reference batch's insert sizes only), the lists are joined in range order
+  const int TT = std::max(1, K.host_threads);
+  struct Part { vector<Cand> cands; vector<FqSwTask> tasks; int max_reg = 0, max_q = 0; };
+  vector<Part> part((size_t)TT);
+  parallel_chunks((size_t)K.n_surv, TT, K.par_min, [&](size_t lo, size_t hi, int t) {
+    Part &P = part[t];
+    for (int sb = 0; sb < K.n_sub; ++sb) {
+      const fq_isize_t ii = K.iis[sb];
+      if (ii.avg < 0.0) continue;   // bwa_paired_sw returns before touching anything (bwape.c:477)
+      const int sp_lo = std::max((int)lo, K.sub_lo[sb]), sp_hi = std::min((int)hi, K.sub_lo[sb + 1]);
+      for (int sp = sp_lo; sp < sp_hi; ++sp) {
+        FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
+        for (int j = 0; j < 2; ++j) if (p[j]->filtered) { p[j]->filtered = 0; p[j]->revived = true; }   // expand_seq: revived because its mate passed (:485-499)
+        if (!((p[0]->mapQ >= 17 || p[1]->mapQ >= 17) && (p[0]->extra_flag & 2) == 0)) continue;
+        for (int k = 0; k < 2; ++k) {
+          FqRead *pref = p[1 - k], *pm = p[k];
+          if (pref->type == FQ_TYPE_NO_MATCH) continue;
+          int64_t beg, end;
+          FqSwTask T{};
+          if (pref->strand == 0) {   // __set_rght_coor (:511-516)
+            beg = (int64_t)((int64_t)pref->pos + ii.avg - 3 * ii.std - pm->len * 1.5);
+            end = (int64_t)(beg + 6 * ii.std + 2 * pm->len);
+            // the macro assigns `_pref->pos + _pref->len` in 32-bit unsigned arithmetic (it wraps for a hit hanging over the start of the
+            // reference, pos = 2^32-1) after comparing in 64 bits
+            if (beg < (int64_t)pref->pos + pref->len) beg = (int64_t)(uint32_t)((uint32_t)pref->pos + (uint32_t)pref->len);
+            if (end > ix->l_pac) end = ix->l_pac;
+            T.use_rc = 1;
+          } else {                   // __set_left_coor (:518-523)
+            beg = (int64_t)((int64_t)pref->pos + pref->len - ii.avg - 3 * ii.std - pm->len * 0.5);
+            end = (int64_t)(beg + 6 * ii.std + 2 * pm->len);
+            if (beg < 0) beg = 0;
+            if (end > (int64_t)pref->pos) end = pref->pos;
+            T.use_rc = 0;
+          }
+          T.read = pm->dr; T.beg = beg; T.reglen = (int)(end - beg);
+          P.cands.push_back({sp, k});
+          P.tasks.push_back(T);
+          P.max_reg = std::max(P.max_reg, T.reglen); P.max_q = std::max(P.max_q, (int)pm->len);
         }
-        T.read = pm->dr; T.beg = beg; T.reglen = (int)(end - beg);
-        cands.push_back({sp, k});
-        tasks.push_back(T);
-        max_reg = std::max(max_reg, T.reglen); max_q = std::max(max_q, (int)pm->len);
       }
+    }
+  });
+  {
+    size_t total = 0;
+    for (const Part &P : part) total += P.tasks.size();
+    cands.reserve(total); tasks.reserve(total);
+    for (const Part &P : part) {
+      cands.insert(cands.end(), P.cands.begin(), P.cands.end()); tasks.insert(tasks.end(), P.tasks.begin(), P.tasks.end());
+      max_reg = std::max(max_reg, P.max_reg); max_q = std::max(max_q, P.max_q);
     }
   }
   vector<FqSwOut> souts(tasks.size());
@@ -1689,6 +1710,7 @@ int stageD_refine(Call &K) {
       max_ref = std::max(max_ref, P.max_ref); max_q = std::max(max_q, P.max_q);
     }
   }
+  K.trace("  D: refine task list");
   if (!tasks.empty()) {
     const int cig_cap = 64;
     const size_t sstride = fq_dp_scratch_bytes(max_ref, max_q);
@@ -1721,6 +1743,7 @@ int stageD_refine(Call &K) {
     });
     c->stats.refine_tasks += tasks.size();
   }
+  K.trace("  D: refine kernel + apply");
   // MD / NM for every mapped read (bwa_cal_md1)
   // (task list and CIGAR arena are laid out by prefix sums and written, in parallel, where the copy engine reads them)
   // (every thread counts the tasks and CIGAR entries of its range of records; the ranges' first slots follow from those counts)
@@ -1756,6 +1779,7 @@ int stageD_refine(Call &K) {
       }
     });
   }
+  K.trace("  D: MD task list");
   if (nt_all) {
     const int md_cap = 3 * (K.max_len_all + 8) + 32;
     const int nt = nt_all;
@@ -1780,6 +1804,7 @@ int stageD_refine(Call &K) {
     CK(fqdev::copy_pinned(nm, c->d_nm.p, (size_t)nt * 4, 0));
     CKS(sync_staged(c));
     total = off[nt];
+    K.trace("  D: MD kernel + sizes");
     CKM(c->d_mdpacked.ensure(total + 1));
     CK(fqdev::launch_pack_md(c->d_md.p, c->d_mdlen.p, c->d_off.p, md_cap, nt, c->d_mdpacked.p));
     char *packed = (char *)c->arena.alloc(total + 1);
@@ -1787,6 +1812,7 @@ int stageD_refine(Call &K) {
     if (total) CK(fqdev::copy_pinned(packed, c->d_mdpacked.p, total, 0));
     CKS(sync_staged(c));
     c->stats.d2h_bytes += (size_t)nt * 16 + total;
+    K.trace("  D: MD strings D2H");
     for (int t = 0; t < nt; ++t)
       if (mdlen[t] < 0) { c->err = "MD string longer than the device slot"; return FQ_ELIMIT; }
     parallel_chunks((size_t)nt, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
@@ -1798,6 +1824,7 @@ int stageD_refine(Call &K) {
       }
     });
   }
+  K.trace("  D: MD apply");
   // bwa_correct_trimmed (bwase.c:298-337) for every record
   parallel_chunks(R.size(), K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
     for (size_t idx = lo; idx < hi; ++idx) {
