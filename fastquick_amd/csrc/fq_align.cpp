@@ -231,6 +231,7 @@ struct fq_ctx {
     std::vector<uint32_t> q_first;
     std::vector<char> enumerated;
     std::vector<int32_t> work, next_work;
+    std::vector<uint16_t> ntop;
   } cv;
   fq_stats_t stats{};
   ~fq_ctx();
@@ -444,6 +445,13 @@ struct NodePin {
   }
   ~NodePin() { if (changed) pthread_setaffinity_np(pthread_self(), sizeof old, &old); }
 };
+// Threads of a call's host phases when neither the options nor the tuning say: the phases stream over the per-read records and stop
+// scaling where the memory system does -- 8 threads on a small host, 16 where there are 32 cores or more (one on-target call of
+// 4.2 M pairs on the 32-core host of an MI355X: 419 / 365 / 354 ms with 8 / 16 / 24 threads).
+inline int default_host_threads() {
+  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+  return (int)(hw >= 32 ? 16u : std::min(8u, hw));
+}
 template <class F>
 void parallel_chunks(size_t n, int threads, size_t par_min, F fn) {   // fn(lo, hi, thread index); below par_min items the phase stays on the calling thread
   if (threads <= 1 || n < par_min) { fn((size_t)0, n, 0); return; }
@@ -613,6 +621,10 @@ struct Call {
   vector<char> &enumerated;
   const uint32_t *h_pos = nullptr;     // positions of the enumerated SA rows (pinned staging of the context)
   vector<fq_isize_t> iis;
+  // the main-hit stage's plan (stageB1_plan): where every range of reads enters the drand48 stream
+  struct B1Plan { int T = 1; size_t per = 0; vector<uint64_t> start; uint64_t rng_end = 0; } plan;
+  std::thread plan_thread;             // the plan is drawn up beside the SA stage when nothing else can move the stream's state
+  ~Call() { if (plan_thread.joinable()) plan_thread.join(); }
   double t_trace = 0, t_wall0 = 0, t_host0 = 0, t_serial1 = 0, t_host1 = 0;
   const FqAln *aln_of(int idx, int *n_out) const {
     const int s = s_of[idx];
@@ -1244,6 +1256,57 @@ int stage_sa_rows(Call &K) {
   return FQ_OK;
 }
 
+// ---- the plan of stage B1: the state of the drand48 stream at the first read of every range of reads --------
+// One read depends on the others only through HOW MANY numbers they drew: one per hit that shares the best score, plus one each
+// time such a hit is taken (bwase.c:29-41) -- two for a read with a single best hit, unless the first of them is exactly 0.  Counting
+// the best hits of every read is parallel; the replay of the draws is serial, one 16-bit count per read (and the hit lists of the
+// reads with several best hits).  It reads the records' `filtered` flag and the hit lists only, so it can run beside the SA stage.
+void stageB1_plan(Call &K, uint64_t rng0) {
+  fq_ctx *c = K.c;
+  const vector<FqRead> &R = c->st.reads;
+  const size_t N = R.size();
+  vector<uint16_t> &ntop = c->cv.ntop;
+  ntop.resize(N);
+  parallel_chunks(N, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
+    for (size_t idx = lo; idx < hi; ++idx) {
+      int t = 0;
+      if (!R[idx].filtered) {
+        int na; const FqAln *a = K.aln_of((int)idx, &na);
+        while (t < na && a[t].score <= a[0].score) ++t;     // (lists are in discovery order: best score first)
+      }
+      ntop[idx] = (uint16_t)std::min(t, 65535);
+    }
+  });
+  const int T = N >= K.par_min ? std::max(1, K.host_threads) : 1;
+  const size_t per = (N + T - 1) / T;
+  K.plan.T = T; K.plan.per = per;
+  vector<uint64_t> &start = K.plan.start;
+  start.assign((size_t)T + 1, 0);
+  // two steps of the generator at once: X'' = A2 X + C2 (mod 2^48); the step between them matters only when it lands on 0
+  constexpr uint64_t A1 = 0x5DEECE66DULL, C1 = 0xBULL, M48 = 0xFFFFFFFFFFFFULL, A2 = (A1 * A1) & M48, C2 = (A1 * C1 + C1) & M48;
+  uint64_t x = rng0;
+  size_t next_chunk = 0;
+  for (size_t idx = 0; idx < N; ++idx) {
+    if (next_chunk < (size_t)T && idx == next_chunk * per) start[next_chunk++] = x;
+    const int t = ntop[idx];
+    if (t == 0) continue;
+    if (t == 1) {                                                          // wdt >= 1: taken unless the draw is exactly 0
+      const uint64_t x1 = (A1 * x + C1) & M48;
+      x = x1 == 0 ? x1 : (A2 * x + C2) & M48;
+      continue;
+    }
+    int na; const FqAln *a = K.aln_of((int)idx, &na);
+    uint32_t cnt = 0;
+    for (int i = 0; i < na && a[i].score <= a[0].score; ++i) {             // (all of them when there are more than 65,535)
+      const uint32_t wdt = a[i].l - a[i].k + 1;
+      if (rng_step(x) * (double)(uint32_t)(wdt + cnt) > (double)(int)cnt) rng_step(x);
+      cnt += wdt;
+    }
+  }
+  while (next_chunk <= (size_t)T) start[next_chunk++] = x;
+  K.plan.rng_end = x;
+}
+
 // ---- stage B1 (host, serial, read order): main hit choice consumes the drand48 stream (Q2) ------------
 int stageB1_main_hit(Call &K) {
   fq_ctx *c = K.c;
@@ -1254,38 +1317,12 @@ int stageB1_main_hit(Call &K) {
   // hit.  So: count the best hits of every read (parallel), replay the draws alone in read order to learn the state each chunk of
   // reads starts from (serial, one byte per read; the hit lists only of reads with several best hits), then choose (parallel).
   const size_t N = R.size();
-  vector<uint16_t> ntop(N, 0);
-  parallel_chunks(N, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
-    for (size_t idx = lo; idx < hi; ++idx) {
-      if (R[idx].filtered) continue;
-      int na; const FqAln *a = K.aln_of((int)idx, &na);
-      int t = 0;
-      while (t < na && a[t].score <= a[0].score) ++t;     // (lists are in discovery order: best score first)
-      ntop[idx] = (uint16_t)std::min(t, 65535);
-    }
-  });
-  const int T = N >= K.par_min ? std::max(1, K.host_threads) : 1;
-  const size_t per = (N + T - 1) / T;
-  vector<uint64_t> start((size_t)T + 1, 0);
-  {
-    uint64_t x = c->rng;
-    size_t next_chunk = 0;
-    for (size_t idx = 0; idx < N; ++idx) {
-      if (next_chunk < (size_t)T && idx == next_chunk * per) start[next_chunk++] = x;
-      const int t = ntop[idx];
-      if (t == 0) continue;
-      if (t == 1) { if (rng_step(x) != 0.0) rng_step(x); continue; }        // wdt >= 1: taken unless the draw is exactly 0
-      int na; const FqAln *a = K.aln_of((int)idx, &na);
-      uint32_t cnt = 0;
-      for (int i = 0; i < na && a[i].score <= a[0].score; ++i) {             // (all of them when there are more than 65,535)
-        const uint32_t wdt = a[i].l - a[i].k + 1;
-        if (rng_step(x) * (double)(uint32_t)(wdt + cnt) > (double)(int)cnt) rng_step(x);
-        cnt += wdt;
-      }
-    }
-    while (next_chunk <= (size_t)T) start[next_chunk++] = x;
-    c->rng = x;
-  }
+  if (K.plan_thread.joinable()) K.plan_thread.join();
+  else stageB1_plan(K, c->rng);
+  c->rng = K.plan.rng_end;
+  const int T = K.plan.T;
+  const size_t per = K.plan.per;
+  const vector<uint64_t> &start = K.plan.start;
   const int se_n_occ = c->o.single_end ? 3 : 0;   // N_OCC: the single-end mapper selects main and alternative hits in one call (src/BwtMapper.cpp:1344)
   vector<vector<uint32_t>> dq_row_t(T), dq_info_t(T); vector<vector<int>> dq_idx_t(T);
   auto choose = [&](size_t lo, size_t hi, int t) {
@@ -1917,7 +1954,7 @@ int run_call(fq_ctx *c, fq_result_batch_t *out) {
   if (c->n_pairs == 0) { S.reads.clear(); return FQ_OK; }
   K.n = c->n_pairs; K.n2 = 2 * K.n; K.B = o.batch_pairs; K.n_sub = (K.n + K.B - 1) / K.B;
   K.par_min = c->kn.host_par_min;
-  K.host_threads = c->kn.host_threads >= 0 ? c->kn.host_threads : o.host_threads > 0 ? o.host_threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+  K.host_threads = c->kn.host_threads >= 0 ? c->kn.host_threads : o.host_threads > 0 ? o.host_threads : default_host_threads();
   int rc = c->in_kind == 2 ? stage0_packed(K) : stage0_ascii(K);
   if (rc) return rc;
   S.n_surv = K.n_surv;
@@ -1929,6 +1966,8 @@ int run_call(fq_ctx *c, fq_result_batch_t *out) {
   K.trace("stageA width+gap");
   stage_records(K);
   K.trace("records init");
+  // (a sharded stream's hook may still hand this context the stream's state: then the plan waits for it)
+  if (!c->before_serial && (size_t)K.n_surv * 2 >= K.par_min) K.plan_thread = std::thread([&K, c] { stageB1_plan(K, c->rng); });
   if ((rc = stage_sa_rows(K))) return rc;
   K.trace("SA enumerate+kernel");
   K.t_host0 = now_ms();
