@@ -8,6 +8,7 @@
 // Everything data-parallel (filter, widths, gap search, SA walks, SW, global DP, MD) runs on the
 // GPU through fq_backend.h; libm-dependent scalar decisions stay on the host (Q4/Q5).
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <climits>
 #include <cstdint>
@@ -445,12 +446,22 @@ struct NodePin {
   }
   ~NodePin() { if (changed) pthread_setaffinity_np(pthread_self(), sizeof old, &old); }
 };
-// Threads of a call's host phases when neither the options nor the tuning say: the phases stream over the per-read records and stop
-// scaling where the memory system does -- 8 threads on a small host, 16 where there are 32 cores or more (one on-target call of
-// 4.2 M pairs on the 32-core host of an MI355X: 419 / 365 / 354 ms with 8 / 16 / 24 threads).
+// Threads of a call's host phases when neither the options nor the tuning say.  The phases stream over the per-read records and
+// stop scaling where the memory system does: at most 8 threads on a small host, 16 where there are 32 cores or more (one on-target
+// call of 4.2 M pairs on the 32-core host of an MI355X: 419 / 365 / 354 ms with 8 / 16 / 24 threads).  Calls of other contexts
+// in flight in this process share the cores: sixteen streams of 1 M-pair calls run 16.3 / 12.7 / 8.8 M pairs/s with 4 / 8 / 16
+// threads each, two streams of 4.2 M-pair calls 15.2 / 16.6 / 13.3 M pairs/s with 8 / 16 / 24 -- so the cores are divided by the
+// number of calls in flight when the call starts.  (Results do not depend on the number of threads.)
+static std::atomic<int> g_calls_in_flight{0};
+struct CallInFlight {
+  CallInFlight() { g_calls_in_flight.fetch_add(1, std::memory_order_relaxed); }
+  ~CallInFlight() { g_calls_in_flight.fetch_sub(1, std::memory_order_relaxed); }
+};
 inline int default_host_threads() {
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  return (int)(hw >= 32 ? 16u : std::min(8u, hw));
+  const unsigned cap = hw >= 32 ? 16u : std::min(8u, hw);
+  const unsigned share = hw / (unsigned)std::max(1, g_calls_in_flight.load(std::memory_order_relaxed));
+  return (int)std::max(std::min(2u, cap), std::min(cap, share));
 }
 template <class F>
 void parallel_chunks(size_t n, int threads, size_t par_min, F fn) {   // fn(lo, hi, thread index); below par_min items the phase stays on the calling thread
@@ -1937,6 +1948,7 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
 }
 
 int run_call(fq_ctx *c, fq_result_batch_t *out) {
+  CallInFlight in_flight;
   Call K(c);
   K.t_trace = K.t_wall0 = now_ms();
   NodePin pin;

@@ -51,7 +51,7 @@ typedef struct {
   int32_t n_multi, N_multi;
   int32_t is_sw;
   double ap_prior;
-  int32_t host_threads;       /* threads for the per-pair host phases of large batches (0 = up to 8, 16 on hosts of 32 cores or more) */
+  int32_t host_threads;       /* threads for the per-pair host phases of large batches (0 = up to 8, 16 on hosts of 32 cores or more, divided among the calls in flight) */
   int32_t batch_pairs;        /* reference batch size, READ_BUFFER_SIZE = 262144 (src/BwtMapper.h:36): insert-size
                                  inference and the last_ii chain work on consecutive groups of this many pairs, so one
                                  call may carry many reference batches and still reproduce the reference's output */
