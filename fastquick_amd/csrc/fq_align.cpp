@@ -450,8 +450,8 @@ struct NodePin {
 // stop scaling where the memory system does: at most 8 threads on a small host, 16 where there are 32 cores or more (one on-target
 // call of 4.2 M pairs on the 32-core host of an MI355X: 419 / 365 / 354 ms with 8 / 16 / 24 threads).  Calls of other contexts
 // in flight in this process share the cores: sixteen streams of 1 M-pair calls run 16.3 / 12.7 / 8.8 M pairs/s with 4 / 8 / 16
-// threads each, two streams of 4.2 M-pair calls 15.2 / 16.6 / 13.3 M pairs/s with 8 / 16 / 24 -- so the cores are divided by the
-// number of calls in flight when the call starts.  (Results do not depend on the number of threads.)
+// threads each, two streams of 4.2 M-pair calls 15.2 / 16.6 / 13.3 M pairs/s with 8 / 16 / 24 -- so twice the cores (a call waits for the device about half
+// of its time) are divided by the number of calls in flight when the call starts.  (Results do not depend on the number of threads.)
 static std::atomic<int> g_calls_in_flight{0};
 struct CallInFlight {
   CallInFlight() { g_calls_in_flight.fetch_add(1, std::memory_order_relaxed); }
@@ -460,7 +460,7 @@ struct CallInFlight {
 inline int default_host_threads() {
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   const unsigned cap = hw >= 32 ? 16u : std::min(8u, hw);
-  const unsigned share = hw / (unsigned)std::max(1, g_calls_in_flight.load(std::memory_order_relaxed));
+  const unsigned share = 2 * hw / (unsigned)std::max(1, g_calls_in_flight.load(std::memory_order_relaxed));   // (a call waits for the device about half of its time)
   return (int)std::max(std::min(2u, cap), std::min(cap, share));
 }
 template <class F>
