@@ -223,9 +223,9 @@ __global__ void __launch_bounds__(256) k_prep(FqPrepArgs a) {
   if (r < a.n_reads) fq_prep_thread(a, r);
 }
 __global__ void __launch_bounds__(256) k_width(FqWidthArgs a) {
-  __shared__ uint8_t seed_bits[FQ_SEED_MAX * 256];   // [ii][thread]: lane-interleaved, conflict free
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < a.n_work * 2) fq_width_thread(a, t, seed_bits + threadIdx.x, 256);
+  __shared__ uint8_t seed_bits[2 * FQ_SEED_MAX * 256];   // [strand][ii][thread]: lane-interleaved, conflict free
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < a.n_work) fq_width_read(a, w, seed_bits + threadIdx.x, 256);
 }
 extern __shared__ __align__(16) unsigned char fq_dyn_lds[];
 struct FqQueueFetch {
@@ -848,7 +848,7 @@ int launch_trim_all(const FqTrimAllArgs &a) {
 }
 int launch_width(const FqWidthArgs &a) {
   if (a.n_work <= 0) return 0;
-  hipLaunchKernelGGL(k_width, dim3(nblk((uint64_t)a.n_work * 2, 256)), dim3(256), 0, g_stream, a);
+  hipLaunchKernelGGL(k_width, dim3(nblk((uint64_t)a.n_work, 256)), dim3(256), 0, g_stream, a);
   FQ_HIP(hipGetLastError());
   return 0;
 }

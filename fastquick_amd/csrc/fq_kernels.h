@@ -534,7 +534,7 @@ FQ_HD int fq_base(const FqReadView &v, int a, int i) {
   return (a && c < 4) ? 3 - c : c;
 }
 
-// ---- K_width: bwt_cal_width (libbwa/bwtaln.c:73-97), one thread per (read, strand): seed chain, then full chain ---------
+// ---- K_width: bwt_cal_width (libbwa/bwtaln.c:73-97), one thread per read: the seed chains, then the full chains, of both strands ----
 // Outputs are written eight positions at a time (one 16-byte store of position records, two of widths): a thread's rows are
 // private, so narrower stores would reach HBM as partial lines.
 struct FqWidthArgs {
@@ -555,45 +555,54 @@ struct FqWidthArgs {
   uint8_t *bid_end;           // [w][2] lower bound on the differences of the whole read, per strand (width[len-1].bid): scheduling hint
   uint64_t *counters;
 };
-// seed_bits[ii * seed_bits_stride]: FQ_SEED_MAX bytes of thread-private scratch (LDS on the device)
-FQ_HD void fq_width_thread(const FqWidthArgs &A, int t, uint8_t *seed_bits, int seed_bits_stride) {
-  const int w = t >> 1, strand = t & 1;
+// One thread walks both strands of its read: the two chains (and the two seed chains before them) are independent, so every step
+// has two Occ requests in flight instead of one -- the kernel is bound by the latency of a dependent step, not by requests.
+// seed_bits[(strand * FQ_SEED_MAX + ii) * seed_bits_stride]: 2 * FQ_SEED_MAX bytes of thread-private scratch (LDS on the device)
+FQ_HD void fq_width_read(const FqWidthArgs &A, int w, uint8_t *seed_bits, int seed_bits_stride) {
   const int s = A.work ? A.work[w] : w;
   const int r = A.read_list[s];
   FqReadView v = {A.seq + (size_t)r * (size_t)A.stride, A.len_trim[r]};
-  const FqFM &f = A.ix.fm[strand];
-  uint32_t *ow = A.wfull + ((size_t)w * 2 + strand) * (size_t)A.wstride;
-  FqPos *prec = A.prec + ((size_t)w * 2 + strand) * (size_t)A.pstride;
+  uint32_t *ow = A.wfull + (size_t)w * 2 * (size_t)A.wstride;
+  FqPos *prec = A.prec + (size_t)w * 2 * (size_t)A.pstride;
   uint32_t touches = 0;
   const bool use_seed = v.len > A.o.seed_len;
   const int seed_off = v.len - A.o.seed_len;
+  uint32_t k[2], l[2], wprev[2];
+  int bid[2];
   if (use_seed) {   // bwt_cal_width over the last seed_len bases (src/BwtMapper.cpp:131-137)
-    uint32_t k = 0, l = f.seq_len, wprev = 0;
-    int bid = 0;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) { k[a] = 0; l[a] = A.ix.fm[a].seq_len; wprev[a] = 0; bid[a] = 0; }
     uint64_t seed8 = 0;
     for (int i = 0; i < A.o.seed_len; ++i) {
       // seed position i is byte seed_len-1-i of the row: eight positions per 8-byte load, as below
       if ((i & 7) == 0 && i + 8 <= A.o.seed_len) memcpy(&seed8, v.row + (A.o.seed_len - 8 - i), 8);
-      int c;
-      if ((i | 7) < A.o.seed_len) { c = (int)fq_nt4_fast((uint32_t)(seed8 >> (8 * (7 - (i & 7)))) & 0xffu); if (strand && c < 4) c = 3 - c; }
-      else c = fq_base(v, strand, seed_off + i);
-      if (c < 4) {
-        touches += fq_touch2(f, k - 1, l, true);
-        uint32_t ok, ol;
-        fq_occ1_pair(f, k - 1, l, c, &ok, &ol);
-        k = f.L2[c] + ok + 1;
-        l = f.L2[c] + ol;
+      const bool fast = (i | 7) < A.o.seed_len;
+      const int c0 = fast ? (int)fq_nt4_fast((uint32_t)(seed8 >> (8 * (7 - (i & 7)))) & 0xffu) : 0;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        const FqFM &f = A.ix.fm[a];
+        int c;
+        if (fast) c = (a && c0 < 4) ? 3 - c0 : c0;
+        else c = fq_base(v, a, seed_off + i);
+        if (c < 4) {
+          touches += fq_touch2(f, k[a] - 1, l[a], true);
+          uint32_t ok, ol;
+          fq_occ1_pair(f, k[a] - 1, l[a], c, &ok, &ol);
+          k[a] = f.L2[c] + ok + 1;
+          l[a] = f.L2[c] + ol;
+        }
+        if (k[a] > l[a] || c > 3) { k[a] = 0; l[a] = f.seq_len; ++bid[a]; }
+        const uint32_t wcur = l[a] - k[a] + 1;
+        seed_bits[(a * FQ_SEED_MAX + i) * seed_bits_stride] = (uint8_t)((uint32_t)(bid[a] < 31 ? bid[a] : 31) | (i >= 1 && wcur == wprev[a] ? 1u << 5 : 0u));
+        wprev[a] = wcur;
       }
-      if (k > l || c > 3) { k = 0; l = f.seq_len; ++bid; }
-      const uint32_t wcur = l - k + 1;
-      seed_bits[i * seed_bits_stride] = (uint8_t)((uint32_t)(bid < 31 ? bid : 31) | (i >= 1 && wcur == wprev ? 1u << 5 : 0u));
-      wprev = wcur;
     }
   }
-  uint32_t k = 0, l = f.seq_len, wprev = 0;
-  int bid = 0, namb = 0;
+#pragma unroll
+  for (int a = 0; a < 2; ++a) { k[a] = 0; l[a] = A.ix.fm[a].seq_len; wprev[a] = 0; bid[a] = 0; }
+  int namb = 0;
   for (int i0 = 0; i0 < v.len; i0 += 8) {
-    uint32_t wv[8], pv[8];
+    uint32_t wv[2][8], pv[2][8];
     // the eight bases of this group sit in eight consecutive bytes of the row (the search walks the read backwards): one load
     uint64_t bases8 = 0;
     const bool whole = i0 + 8 <= v.len;
@@ -601,43 +610,52 @@ FQ_HD void fq_width_thread(const FqWidthArgs &A, int t, uint8_t *seed_bits, int 
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       const int i = i0 + j;
-      wv[j] = 0; pv[j] = 0;
-      if (i < v.len) {
-        int c;
-        if (whole) { c = (int)fq_nt4_fast((uint32_t)(bases8 >> (8 * (7 - j))) & 0xffu); if (strand && c < 4) c = 3 - c; }
-        else c = fq_base(v, strand, i);
-        namb += c > 3;
-        if (c < 4) {
-          touches += fq_touch2(f, k - 1, l, true);
-          uint32_t ok, ol;
-        fq_occ1_pair(f, k - 1, l, c, &ok, &ol);
-          k = f.L2[c] + ok + 1;
-          l = f.L2[c] + ol;
+      const int c0 = whole ? (int)fq_nt4_fast((uint32_t)(bases8 >> (8 * (7 - j))) & 0xffu) : 0;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        wv[a][j] = 0; pv[a][j] = 0;
+        if (i < v.len) {
+          const FqFM &f = A.ix.fm[a];
+          int c;
+          if (whole) c = (a && c0 < 4) ? 3 - c0 : c0;
+          else c = fq_base(v, a, i);
+          if (a == 0) namb += c > 3;
+          if (c < 4) {
+            touches += fq_touch2(f, k[a] - 1, l[a], true);
+            uint32_t ok, ol;
+            fq_occ1_pair(f, k[a] - 1, l[a], c, &ok, &ol);
+            k[a] = f.L2[c] + ok + 1;
+            l[a] = f.L2[c] + ol;
+          }
+          if (k[a] > l[a] || c > 3) { k[a] = 0; l[a] = f.seq_len; ++bid[a]; }
+          const uint32_t wcur = l[a] - k[a] + 1;
+          const uint32_t seedbits = (use_seed && i >= seed_off) ? (uint32_t)seed_bits[(a * FQ_SEED_MAX + (i - seed_off)) * seed_bits_stride] << 6 : 0u;
+          wv[a][j] = wcur;
+          pv[a][j] = seedbits | (uint32_t)(bid[a] < 31 ? bid[a] : 31) | (i >= 1 && wcur == wprev[a] ? 1u << 5 : 0u) | (uint32_t)c << 12;
+          wprev[a] = wcur;
         }
-        if (k > l || c > 3) { k = 0; l = f.seq_len; ++bid; }
-        const uint32_t wcur = l - k + 1;
-        const uint32_t seedbits = (use_seed && i >= seed_off) ? (uint32_t)seed_bits[(i - seed_off) * seed_bits_stride] << 6 : 0u;
-        wv[j] = wcur;
-        pv[j] = seedbits | (uint32_t)(bid < 31 ? bid : 31) | (i >= 1 && wcur == wprev ? 1u << 5 : 0u) | (uint32_t)c << 12;
-        wprev = wcur;
       }
     }
-    FqU4 q;
-    q.x = wv[0]; q.y = wv[1]; q.z = wv[2]; q.w = wv[3];
-    *(FqU4 *)(ow + i0) = q;
-    q.x = wv[4]; q.y = wv[5]; q.z = wv[6]; q.w = wv[7];
-    *(FqU4 *)(ow + i0 + 4) = q;
-    q.x = pv[0] | pv[1] << 16; q.y = pv[2] | pv[3] << 16; q.z = pv[4] | pv[5] << 16; q.w = pv[6] | pv[7] << 16;
-    *(FqU4 *)(prec + i0) = q;
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+      uint32_t *owa = ow + (size_t)a * (size_t)A.wstride;
+      FqPos *pra = prec + (size_t)a * (size_t)A.pstride;
+      FqU4 q;
+      q.x = wv[a][0]; q.y = wv[a][1]; q.z = wv[a][2]; q.w = wv[a][3];
+      *(FqU4 *)(owa + i0) = q;
+      q.x = wv[a][4]; q.y = wv[a][5]; q.z = wv[a][6]; q.w = wv[a][7];
+      *(FqU4 *)(owa + i0 + 4) = q;
+      q.x = pv[a][0] | pv[a][1] << 16; q.y = pv[a][2] | pv[a][3] << 16; q.z = pv[a][4] | pv[a][5] << 16; q.w = pv[a][6] | pv[a][7] << 16;
+      *(FqU4 *)(pra + i0) = q;
+    }
   }
-  A.bid_end[t] = (uint8_t)(bid < 255 ? bid : 255);
-  if (strand == 0) {
-    const uint32_t md = A.maxdiff_lut[v.len];
-    FqGapWork gw;
-    gw.r = r;
-    gw.meta = (uint32_t)v.len | md << 16 | (namb > (int)md ? 1u << 24 : 0u);
-    A.winfo[w] = gw;
-  }
+  A.bid_end[2 * w] = (uint8_t)(bid[0] < 255 ? bid[0] : 255);
+  A.bid_end[2 * w + 1] = (uint8_t)(bid[1] < 255 ? bid[1] : 255);
+  const uint32_t md = A.maxdiff_lut[v.len];
+  FqGapWork gw;
+  gw.r = r;
+  gw.meta = (uint32_t)v.len | md << 16 | (namb > (int)md ? 1u << 24 : 0u);
+  A.winfo[w] = gw;
   FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_WIDTH], touches);
 }
 
