@@ -233,6 +233,10 @@ struct fq_ctx {
     std::vector<char> enumerated;
     std::vector<int32_t> work, next_work;
     std::vector<uint16_t> ntop;
+    std::vector<uint32_t> pq, job_of;
+    std::vector<uint64_t> prow;
+    std::vector<char> on_device;
+    std::vector<uint8_t> sub_of;
   } cv;
   fq_stats_t stats{};
   ~fq_ctx();
@@ -1114,8 +1118,16 @@ int stageA_search(Call &K) {
         in_round2.assign((size_t)n_search, 0);
         for (int32_t sidx : list2) in_round2[sidx] = 1;
       }
-      for (int w = 0; w < nw; ++w)
-        if (h_status[w]) { ++c->stats.tier_retries; if (in_round2.empty() || !in_round2[wk[w]]) next_work.push_back(wk[w]); }
+      {   // the reads this launch left unsettled, in work order: listed per range of the launch, joined in range order
+        const int TT = std::max(1, K.host_threads);
+        vector<vector<int32_t>> left((size_t)TT);
+        vector<uint64_t> n_left((size_t)TT * 8, 0);
+        parallel_chunks((size_t)nw, TT, K.par_min, [&](size_t lo, size_t hi, int t) {
+          for (size_t w = lo; w < hi; ++w)
+            if (h_status[w]) { ++n_left[(size_t)t * 8]; if (in_round2.empty() || !in_round2[wk[w]]) left[t].push_back(wk[w]); }
+        });
+        for (int t = 0; t < TT; ++t) { c->stats.tier_retries += n_left[(size_t)t * 8]; next_work.insert(next_work.end(), left[t].begin(), left[t].end()); }
+      }
       if (n2_total) {
         CK(fqdev::launch_scan(c->d_naln2.p, c->d_off.p, n2_total));
         uint32_t *st2 = (uint32_t *)c->arena.alloc((size_t)n2_total * 4), *na2 = (uint32_t *)c->arena.alloc((size_t)n2_total * 4);
@@ -1200,8 +1212,10 @@ int stage_sa_rows(Call &K) {
   });
   // which reads are enumerated and where their hits and rows go: counts per pair (parallel), one prefix sum, then the lists are
   // written where the copy engine reads them (parallel)
-  vector<uint32_t> pq((size_t)n_surv + 1, 0);       // hits enumerated before pair sp
-  vector<uint64_t> prow((size_t)n_surv + 1, 0);     // rows before pair sp
+  vector<uint32_t> &pq = c->cv.pq;                  // hits enumerated before pair sp
+  vector<uint64_t> &prow = c->cv.prow;              // rows before pair sp
+  pq.resize((size_t)n_surv + 1); prow.resize((size_t)n_surv + 1);   // (every element is written below)
+  pq[0] = 0; prow[0] = 0;
   parallel_chunks((size_t)n_surv, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
     for (size_t sp = lo; sp < hi; ++sp) {
       int na0, na1;
@@ -1472,10 +1486,11 @@ int stageB3_pairing(Call &K) {
   //      the (k,l) cache, Q6), at most kPairLaneRows rows together.  Everything k_pair needs but the reads' current records is on
   //      the device already: the hits and their rows' positions as k_sa left them.
   const uint32_t kPairLaneRows = 64;
-  vector<char> on_device((size_t)n_surv, 0);
-  vector<uint32_t> job_of((size_t)n_surv + 1, 0);   // exclusive prefix count of on_device
-  vector<uint8_t> sub_of;                            // reference batch of a survivor pair
-  sub_of.resize((size_t)n_surv);
+  vector<char> &on_device = c->cv.on_device;
+  vector<uint32_t> &job_of = c->cv.job_of;           // exclusive prefix count of on_device
+  vector<uint8_t> &sub_of = c->cv.sub_of;            // reference batch of a survivor pair
+  on_device.resize((size_t)n_surv); job_of.resize((size_t)n_surv + 1); sub_of.resize((size_t)n_surv);   // (every element is written below)
+  job_of[0] = 0;
   for (int sb = 0; sb < K.n_sub; ++sb) std::fill(sub_of.begin() + K.sub_lo[sb], sub_of.begin() + K.sub_lo[sb + 1], (uint8_t)sb);
   parallel_chunks((size_t)n_surv, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
     for (size_t sp = lo; sp < hi; ++sp) {
