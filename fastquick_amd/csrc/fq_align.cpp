@@ -1989,10 +1989,14 @@ int run_call(fq_ctx *c, fq_result_batch_t *out) {
   S.sub_lo = K.sub_lo;
   S.pair_idx = c->h_pair_list;
   K.trace("stage0 prep+compact");
-  if ((rc = stageA_search(K))) return rc;
-  K.trace("stageA width+gap");
-  stage_records(K);
-  K.trace("records init");
+  {   // the survivors' records depend on stage 0 only: they are set up while the device searches
+    std::thread rec_thread;
+    if ((size_t)K.n_surv * 2 >= K.par_min) rec_thread = std::thread([&K] { stage_records(K); });
+    rc = stageA_search(K);
+    if (rec_thread.joinable()) rec_thread.join(); else if (!rc) stage_records(K);
+    if (rc) return rc;
+  }
+  K.trace("stageA width+gap, records init");
   // (a sharded stream's hook may still hand this context the stream's state: then the plan waits for it)
   if (!c->before_serial && (size_t)K.n_surv * 2 >= K.par_min) K.plan_thread = std::thread([&K, c] { stageB1_plan(K, c->rng); });
   if ((rc = stage_sa_rows(K))) return rc;
