@@ -134,6 +134,10 @@ struct FqKnobs {   // experiment / test knobs (fq_ctx_set_tuning); defaults are 
   int64_t gap_nogap_min = 131072;  // launches of at least this many reads begin with the round that searches without gap children (-1: never)
   uint32_t gap_pool = 2048;        // stack entries per lane of the lane kernel
   int gap_no_order = 0;
+  int device_turns = 2;            // calls that search at least gap_nogap_min reads take turns on the device: 1 = the search kernels, 2 = the width kernel too, 0 = off.
+                                   // Two streams of 4.2 M-pair on-target calls: search kernels 54.1 / 41.7 / 38.8 ms per launch with 0 / 1 / 2 (38.8 alone), 16.8 / 16.3 / 16.7 M pairs/s
+  int gap_round2_waves = 2048;     // wavefronts of the round after the one without gap children (0: as many as fit): its reads are long searches, a trip of a
+                                   // wavefront costs more the more wavefronts share its SIMD, and the launch lasts as long as its longest search
   int sw_wave_max = 4096;          // largest mate-SW window the wavefront kernel takes
   int host_threads = -1;           // -1: fq_opts_t::host_threads
   size_t host_par_min = 32768;     // below this many items a per-pair host phase stays on the calling thread
@@ -316,6 +320,8 @@ extern "C" int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t v) {
   else if (k == "gap_split_hard") c->kn.gap_split_hard = v;
   else if (k == "gap_long_pops2") c->kn.gap_long_pops2 = (uint32_t)v;
   else if (k == "gap_no_order") c->kn.gap_no_order = (int)v;
+  else if (k == "device_turns") c->kn.device_turns = (int)v;
+  else if (k == "gap_round2_waves") c->kn.gap_round2_waves = (int)v;
   else if (k == "sw_wave_max") c->kn.sw_wave_max = (int)v;
   else if (k == "host_threads") c->kn.host_threads = (int)v;
   else if (k == "host_par_min") c->kn.host_par_min = (size_t)v;
@@ -958,6 +964,7 @@ int stageA_search(Call &K) {
   work.resize((size_t)n_search);
   parallel_chunks((size_t)n_search, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) { for (size_t s = lo; s < hi; ++s) work[s] = (int32_t)s; });
   bool ran_nogap = false;
+  size_t n_hard = 0;                      // leading items of `work` that the round without gap children left without any hit (fq_order_key)
   vector<uint8_t> bound_of;               // experiment: min over strands of k_width's lower bound, per read
   for (size_t tier = 0; tier < tiers.size() && !work.empty(); ++tier) {
     FqGapTier T = tiers[tier];
@@ -970,6 +977,7 @@ int stageA_search(Call &K) {
     // at 2,048 / 3,072 / 4,096 pops 15 + 14 / 17 + 12 / 20 + 9 ms: the rule stays with the size of the call.
     if (!T.coop && !T.long_always && n_search > 524288) T.long_pops = tier >= n_first_tiers && n_first_tiers > 0 && !work.empty() && work.size() <= 524288 ? c->kn.gap_long_pops2 : 0u;
     next_work.clear();
+    vector<int32_t> next_easy;            // what a round without gap children leaves: reads with a hit already (short full searches) go behind the others
     size_t first_chunk = 0;   // experiment (gap_split_hard): the predicted-hard reads lead the work list and get a launch of their own
     if (!T.nogap && !T.coop && c->kn.gap_split_hard > 0 && !bound_of.empty()) {
       std::stable_partition(work.begin(), work.end(), [&](int32_t sidx) { return (int64_t)bound_of[sidx] >= c->kn.gap_split_hard; });
@@ -988,9 +996,13 @@ int stageA_search(Call &K) {
       wa.ix = ix->dev; wa.o = c->ko; wa.seq = K.dseq; wa.stride = K.dstride; wa.len_trim = K.dlen_trim; wa.read_list = K.dread_list;
       wa.work = c->d_work.p; wa.n_work = nw; wa.wfull = c->d_wfull.p; wa.wstride = Lpad;
       wa.prec = c->d_prec.p; wa.pstride = Ppad; wa.winfo = c->d_winfo.p; wa.maxdiff_lut = c->d_maxdiff.p; wa.bid_end = c->d_bid_end.p; wa.counters = c->d_counters.p;
+      // device-filling launches of several contexts take turns (fqdev::device_turn_begin)
+      struct Turn { bool held = false; void take() { if (!held) { fqdev::device_turn_begin(); held = true; } } void drop() { if (held) { fqdev::device_turn_end(); held = false; } } ~Turn() { drop(); } } turn;
+      const bool big_call = c->kn.device_turns > 0 && !T.coop && c->kn.gap_nogap_min >= 0 && (int64_t)n_search >= c->kn.gap_nogap_min;
+      if (big_call && c->kn.device_turns >= 2) turn.take();
       fqdev::time_begin(FQ_K_WIDTH);
       CK(fqdev::launch_width(wa));
-      CK(fqdev::launch_order(c->d_bid_end.p, nw, c->d_order.p, c->d_order_cnt.p));   // long searches first
+      CK(fqdev::launch_order(c->d_bid_end.p, nw, (int)(n_hard > c0 ? std::min<size_t>(n_hard - c0, (size_t)nw) : 0), c->d_order.p, c->d_order_cnt.p));   // long searches first
       fqdev::time_end(FQ_K_WIDTH);
       FqGapArgs ga{};
       ga.ix = ix->dev; ga.o = c->ko; ga.o.n_buckets = T.nogap ? std::min(nb_need, o.s_gapo + o.s_mm + 1) : nb_need; /* (no-gap round: parents below s_gapo only) */ ga.n_work = nw; ga.winfo = c->d_winfo.p; ga.order = c->kn.gap_no_order ? nullptr : c->d_order.p; ga.split = c->kn.gap_no_order ? nullptr : c->d_order_cnt.p + 2 * FQ_ORDER_KEYS;
@@ -1001,6 +1013,7 @@ int stageA_search(Call &K) {
       // wavefront that waits for all 64 lanes before it refills idles most of them (28.9 -> 24.2 ms for the 228 k reads a 4.2 M-read
       // call leaves); the first round keeps whole-wavefront refill, its reads finish together (refill by 16: 23.8 -> 25.8 ms).
       ga.refill_min = ran_nogap && !T.nogap && !T.coop ? 16 : 0;
+      if (ran_nogap && !T.nogap && !T.coop && c->kn.gap_round2_waves > 0) ga.max_waves = c->kn.gap_round2_waves;
       // stack pools are the one large per-launch allocation (lanes x pool_cap x 16 B): when the device cannot hold them for
       // as many wavefronts as it could run, run fewer (the persistent lanes simply take more reads each)
       for (;;) {
@@ -1017,6 +1030,7 @@ int stageA_search(Call &K) {
       //      rounds one after the other -- at this size the second round is no longer a tail but 40 % of the stage's work, its
       //      persistent wavefronts take a quarter of the wave slots for as long as they live, and the first round loses more to that
       //      (it scales with occupancy: 16 -> 12 wavefronts per CU costs it 20 %) than the overlap saves.  Kept, bit-exact and tested.
+      if (big_call) turn.take();
       uint32_t n2_total = 0;                 // reads whose second round ran in the pipeline
       vector<uint32_t> seg_cnt;
       bool piped = false;
@@ -1052,7 +1066,7 @@ int stageA_search(Call &K) {
             w2.work = c->d_work2.p + n2_total; w2.n_work = (int32_t)cnt; w2.wfull = c->d_wfull2.p; w2.wstride = Lpad; w2.prec = c->d_prec2.p; w2.pstride = Ppad;
             w2.winfo = c->d_winfo2.p; w2.maxdiff_lut = c->d_maxdiff.p; w2.bid_end = c->d_bid_end2.p; w2.counters = c->d_counters.p;
             CK(fqdev::launch_width(w2));
-            CK(fqdev::launch_order(c->d_bid_end2.p, (int)cnt, c->d_order2.p, c->d_order_cnt2.p));
+            CK(fqdev::launch_order(c->d_bid_end2.p, (int)cnt, 0, c->d_order2.p, c->d_order_cnt2.p));
             FqGapArgs gb{};
             gb.ix = ix->dev; gb.o = c->ko; gb.o.n_buckets = nb_need; gb.n_work = (int32_t)cnt; gb.winfo = c->d_winfo2.p;
             gb.order = c->kn.gap_no_order ? nullptr : c->d_order2.p; gb.split = c->kn.gap_no_order ? nullptr : c->d_order_cnt2.p + 2 * FQ_ORDER_KEYS;
@@ -1084,6 +1098,7 @@ int stageA_search(Call &K) {
       vector<uint8_t> h_bid;
       if (T.nogap && c->kn.gap_split_hard > 0) { h_bid.resize((size_t)nw * 2); CKS(d2h_staged(c, h_bid.data(), c->d_bid_end.p, (size_t)nw * 2)); }
       CKS(sync_staged(c));
+      turn.drop();
       K.trace("  A: width + search kernels, counts D2H");
       total = h_off[nw];
       if (!h_bid.empty()) {
@@ -1120,13 +1135,21 @@ int stageA_search(Call &K) {
       }
       {   // the reads this launch left unsettled, in work order: listed per range of the launch, joined in range order
         const int TT = std::max(1, K.host_threads);
-        vector<vector<int32_t>> left((size_t)TT);
+        vector<vector<int32_t>> left((size_t)TT), left_easy((size_t)TT);
         vector<uint64_t> n_left((size_t)TT * 8, 0);
+        const bool by_class = T.nogap != 0;
         parallel_chunks((size_t)nw, TT, K.par_min, [&](size_t lo, size_t hi, int t) {
           for (size_t w = lo; w < hi; ++w)
-            if (h_status[w]) { ++n_left[(size_t)t * 8]; if (in_round2.empty() || !in_round2[wk[w]]) left[t].push_back(wk[w]); }
+            if (h_status[w]) {
+              ++n_left[(size_t)t * 8];
+              if (in_round2.empty() || !in_round2[wk[w]]) (by_class && !(h_status[w] & FQ_SF_NOHIT) ? left_easy[t] : left[t]).push_back(wk[w]);
+            }
         });
-        for (int t = 0; t < TT; ++t) { c->stats.tier_retries += n_left[(size_t)t * 8]; next_work.insert(next_work.end(), left[t].begin(), left[t].end()); }
+        for (int t = 0; t < TT; ++t) {
+          c->stats.tier_retries += n_left[(size_t)t * 8];
+          next_work.insert(next_work.end(), left[t].begin(), left[t].end());
+          next_easy.insert(next_easy.end(), left_easy[t].begin(), left_easy[t].end());
+        }
       }
       if (n2_total) {
         CK(fqdev::launch_scan(c->d_naln2.p, c->d_off.p, n2_total));
@@ -1153,6 +1176,8 @@ int stageA_search(Call &K) {
         }
       }
     }
+    n_hard = T.nogap ? next_work.size() : 0;
+    next_work.insert(next_work.end(), next_easy.begin(), next_easy.end());
     work.swap(next_work);
     K.trace("  A: round bookkeeping");
   }

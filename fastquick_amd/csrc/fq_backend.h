@@ -20,6 +20,11 @@ int bind(State *s);                        // 0 or FQ_ENODEV-style negative
 Tune *tune(State *s);
 const char *last_error();
 bool is_real_gpu();                    // true for the HIP backend
+// Device-filling stages of different contexts take turns: a per-device lock held by the context whose search stage owns the
+// device.  (Two such launches side by side share wave slots and L2 and both last longer than they would one after the other; what
+// the other contexts' host threads do meanwhile -- their host phases, their small kernels -- is not held up.)
+void device_turn_begin();
+void device_turn_end();
 
 void *dmalloc(size_t bytes);           // device memory (nullptr on failure)
 void dfree(void *p);
@@ -63,7 +68,7 @@ int launch_trim_all(const FqTrimAllArgs &a);
 int launch_width(const FqWidthArgs &a);
 // order[0..n) = the work items sorted by descending fq_order_key (any order inside a key); cnt: FQ_ORDER_KEYS*2 + 1 words of scratch,
 // cnt[2 * FQ_ORDER_KEYS] = length of the first block of the queue (the keys of the upper half) on return
-int launch_order(const uint8_t *bid_end, int n, int32_t *order, uint32_t *cnt);
+int launch_order(const uint8_t *bid_end, int n, int n_hard, int32_t *order, uint32_t *cnt);   // n_hard: fq_order_key
 // number of persistent lanes launch_gap() will start for these arguments (sizes a.pool / a.heads)
 int gap_lane_slots(const FqGapArgs &a);
 int launch_gap(const FqGapArgs &a);

@@ -102,6 +102,7 @@ struct FqGapWork {
 #define FQ_SF_ALN_OVERFLOW 2u    // more hits than the aln slot holds -> rerun in a larger tier
 #define FQ_SF_ENTRY_LIMIT 4u     // conservative entry count crossed max_entries -> exact tier decides
 #define FQ_SF_LONG 8u            // lane-per-read kernel: more pops than tier.long_pops -> searched again by a whole wavefront
+#define FQ_SF_NOHIT 32u          // with FQ_SF_NEEDGAP: the round without gap children found no hit at all (the full search will be a long one)
 #define FQ_SF_NEEDGAP 16u        // search without gap children (tier.nogap): the full search could pop one -> searched again in full
 
 struct FqGapTier {       // one launch configuration of the gap-search kernel

@@ -66,12 +66,17 @@ static State *g_prep_owner[64];
 // queues -- a context's kernels then wait behind another context's long search kernel.
 static hipStream_t g_copy_streams[64][2];
 static unsigned g_copy_next[64];
+static std::mutex g_turn_mu[64];   // device_turn_begin / device_turn_end
+
+void device_turn_begin() { g_turn_mu[g_cur->device].lock(); }
+void device_turn_end() { g_turn_mu[g_cur->device].unlock(); }
 
 State *state_create(int dev) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_err = "no HIP device visible"; return nullptr; }
   if (dev < 0 || dev >= n || dev >= 64) { g_err = "device ordinal out of range"; return nullptr; }
   if (hipSetDevice(dev) != hipSuccess) { g_err = "hipSetDevice failed"; return nullptr; }
+  g_cur = nullptr;   // the thread's current device may have changed: the next bind() sets it again
   {
     std::lock_guard<std::mutex> lk(g_dev_mu);
     if (!g_dev_ready[dev]) { if (set_kernel_attributes()) return nullptr; g_dev_ready[dev] = true; }
@@ -89,6 +94,7 @@ State *state_create(int dev) {
 void state_destroy(State *s) {
   if (!s) return;
   (void)hipSetDevice(s->device);
+  g_cur = nullptr;   // (as in state_create; also drops a pointer to the state being freed)
   s->stream = s->main_stream ? s->main_stream : s->stream;
   if (s->aux_stream) { (void)hipStreamSynchronize(s->aux_stream); (void)hipStreamDestroy(s->aux_stream); }
   if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
@@ -107,7 +113,6 @@ void state_destroy(State *s) {
   if (s->cmp_cnt) (void)hipFree(s->cmp_cnt);
   if (s->cmp_off) (void)hipFree(s->cmp_off);
   if (s->stream) (void)hipStreamDestroy(s->stream);
-  if (g_cur == s) g_cur = nullptr;
   delete s;
 }
 Tune *tune(State *s) { return &s->tune; }
@@ -853,23 +858,23 @@ int launch_width(const FqWidthArgs &a) {
   return 0;
 }
 // counting sort of the work items by scheduling key: block-local counts in LDS, one global atomic per key and block
-__global__ void __launch_bounds__(256) k_order_count(const uint8_t *bid_end, int n, uint32_t *cnt) {
+__global__ void __launch_bounds__(256) k_order_count(const uint8_t *bid_end, int n, int n_hard, uint32_t *cnt) {
   __shared__ uint32_t h[FQ_ORDER_KEYS];
   if (threadIdx.x < FQ_ORDER_KEYS) h[threadIdx.x] = 0;
   __syncthreads();
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
-  if (w < n) atomicAdd(&h[fq_order_key(bid_end, w)], 1u);
+  if (w < n) atomicAdd(&h[fq_order_key(bid_end, w, n_hard)], 1u);
   __syncthreads();
   if (threadIdx.x < FQ_ORDER_KEYS && h[threadIdx.x]) atomicAdd(&cnt[threadIdx.x], h[threadIdx.x]);
 }
-__global__ void __launch_bounds__(256) k_order_scatter(const uint8_t *bid_end, int n, uint32_t *cnt, int32_t *order, int asc) {
+__global__ void __launch_bounds__(256) k_order_scatter(const uint8_t *bid_end, int n, int n_hard, uint32_t *cnt, int32_t *order, int asc) {
   __shared__ uint32_t h[FQ_ORDER_KEYS], base[FQ_ORDER_KEYS];
   if (threadIdx.x < FQ_ORDER_KEYS) h[threadIdx.x] = 0;
   __syncthreads();
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   int key = 0;
   uint32_t rank = 0;
-  if (w < n) { key = fq_order_key(bid_end, w); rank = atomicAdd(&h[key], 1u); }
+  if (w < n) { key = fq_order_key(bid_end, w, n_hard); rank = atomicAdd(&h[key], 1u); }
   __syncthreads();
   if (threadIdx.x < FQ_ORDER_KEYS) {
     // start of key k in the output = number of items with a larger key (descending order); cursors live behind the counts
@@ -908,11 +913,11 @@ int launch_collect(const int32_t *order, const uint32_t *split, int n_work, int 
   FQ_HIP(hipGetLastError());
   return 0;
 }
-int launch_order(const uint8_t *bid_end, int n, int32_t *order, uint32_t *cnt) {
+int launch_order(const uint8_t *bid_end, int n, int n_hard, int32_t *order, uint32_t *cnt) {
   if (n <= 0) return 0;
   FQ_HIP(hipMemsetAsync(cnt, 0, (2 * FQ_ORDER_KEYS + 1) * 4, g_stream));
-  hipLaunchKernelGGL(k_order_count, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, bid_end, n, cnt);
-  hipLaunchKernelGGL(k_order_scatter, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, bid_end, n, cnt, order, g_cur->tune.gap_order_asc ? 1 : 0);   // (experiment knob: ascending)
+  hipLaunchKernelGGL(k_order_count, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, bid_end, n, n_hard, cnt);
+  hipLaunchKernelGGL(k_order_scatter, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, bid_end, n, n_hard, cnt, order, g_cur->tune.gap_order_asc ? 1 : 0);   // (experiment knob: ascending)
   FQ_HIP(hipGetLastError());
   return 0;
 }

@@ -670,12 +670,17 @@ FQ_HD void fq_width_read(const FqWidthArgs &A, int w, uint8_t *seed_bits, int se
 // walk mostly the forward one (strand a searches bwt[1 - a]), each sorted by bound.  The wavefronts of half of the XCDs draw from
 // one block first, the others from the other (fq_gap_lanes): an XCD's 4 MB L2 then serves mostly one 3.3 MB Occ table instead of
 // being shared by two.
-#define FQ_ORDER_KEYS 16
-FQ_HD int fq_order_key(const uint8_t *bid_end, int w) {
+// Second round of a device-filling call (the reads the round without gap children could not settle): the first n_hard work items
+// are the reads that round left WITHOUT a hit below s_gapo (FQ_SF_NOHIT).  Their full searches are the long ones -- three quarters
+// of the round's pops, up to 5.5 k pops each, against at most 1.2 k for a read that already has a three-mismatch hit -- and nothing
+// the width kernel knows tells them apart, so the class leads the key inside each strand block: every long search starts when the
+// launch does and the launch ends on the short ones, instead of lasting as long as a late long search.
+#define FQ_ORDER_KEYS 32
+FQ_HD int fq_order_key(const uint8_t *bid_end, int w, int n_hard) {
   const int a = bid_end[2 * w], b = bid_end[2 * w + 1];
   int k = a < b ? a : b;
-  if (k > FQ_ORDER_KEYS / 2 - 1) k = FQ_ORDER_KEYS / 2 - 1;
-  return (b <= a ? 0 : FQ_ORDER_KEYS / 2) + k;
+  if (k > FQ_ORDER_KEYS / 4 - 1) k = FQ_ORDER_KEYS / 4 - 1;
+  return (b <= a ? 0 : FQ_ORDER_KEYS / 2) + (w < n_hard ? FQ_ORDER_KEYS / 4 : 0) + k;
 }
 
 // ---- K_gap: bwt_match_gap (libbwa/bwtgap.c:104-264) --------------------------------------------
@@ -922,6 +927,7 @@ struct FqGapLane {
   FQ_HD void finish() {
     // failed reads are re-run in a larger tier; expose no partial list
     if (NOGAP && status == 0 && !(n_aln > 0 && !nonstop && best_score + o.s_mm < o.s_gapo) && !too_many_n) status |= FQ_SF_NEEDGAP;
+    if (NOGAP && (status & FQ_SF_NEEDGAP) && n_aln == 0) status |= FQ_SF_NOHIT;   // scheduling hint for the next round (fq_order_key)
     A.n_aln[w] = status ? 0u : n_aln;
     A.status[w] = status;
     if (status == 0) {   // work counters describe completed searches only: a read that is searched again (larger tier, next round) counts once.
@@ -1303,7 +1309,7 @@ FQ_HD void fq_gap_lanes(const FqGapArgs &A, const St &store0, Fetch fetch, int l
     if (pop_any) { ib[6] += (uint32_t)((tc1 - tc0) >> 4); ib[7] += 1; }     // trips in which at least one lane pops a stack entry
     else if (rl_any) { ib[10] += (uint32_t)((tc1 - tc0) >> 4); ib[11] += 1; }   // no pop, but a window of position records is fetched
     else { ib[8] += (uint32_t)((tc1 - tc0) >> 4); ib[9] += 1; }                 // only Occ blocks
-    if (pop_any && rl_any) { ib[12] += (uint32_t)((tc1 - tc0) >> 4); ib[13] += 1; }
+    if (FQ_POPC64(FQ_BALLOT(L.active || L.hit_pending)) <= 2 && !any_hit) { ib[12] += (uint32_t)((tc1 - tc0) >> 4); ib[13] += 1; }   // sparse wavefronts (the tail of a launch): at most two lanes at work
     ib[4] += (uint32_t)FQ_POPC64(shm); ib[5] += shm != 0;
 #else
     if (L.active) { ++lane_trips; L.step(); }

@@ -19,6 +19,8 @@ State *state_create(int) { return new State; }
 void state_destroy(State *s) { delete s; }
 int bind(State *) { return 0; }
 Tune *tune(State *s) { return &s->tune; }
+void device_turn_begin() {}
+void device_turn_end() {}
 int h2d_copy(void *d, const void *s, size_t n) { if (n) memcpy(d, s, n); return 0; }
 int copy_record(int) { return 0; }
 int compute_wait_copy(int) { return 0; }
@@ -65,11 +67,11 @@ int launch_patch(const FqPatchArgs &a) { for (int64_t q = 0; q < a.n_exc; ++q) f
 int launch_trim(const FqTrimArgs &a) { for (int t = 0; t < a.n_rows; ++t) fq_trim_thread(a, t); return 0; }
 int launch_trim_all(const FqTrimAllArgs &a) { for (int r = 0; r < a.n_reads; ++r) fq_trim_all_thread(a, r); return 0; }
 int launch_width(const FqWidthArgs &a) { uint8_t seed_bits[2 * FQ_SEED_MAX]; for (int w = 0; w < a.n_work; ++w) fq_width_read(a, w, seed_bits, 1); return 0; }
-int launch_order(const uint8_t *bid_end, int n, int32_t *order, uint32_t *cnt) {
+int launch_order(const uint8_t *bid_end, int n, int n_hard, int32_t *order, uint32_t *cnt) {
   int at = 0;
   cnt[2 * FQ_ORDER_KEYS] = 0;
   for (int k = FQ_ORDER_KEYS - 1; k >= 0; --k) {
-    for (int w = 0; w < n; ++w) if (fq_order_key(bid_end, w) == k) order[at++] = w;
+    for (int w = 0; w < n; ++w) if (fq_order_key(bid_end, w, n_hard) == k) order[at++] = w;
     if (k == FQ_ORDER_KEYS / 2) cnt[2 * FQ_ORDER_KEYS] = (uint32_t)at;
   }
   return 0;
