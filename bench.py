@@ -21,6 +21,7 @@ import argparse
 import json
 import os
 import sys
+import subprocess
 import threading
 import time
 
@@ -65,6 +66,8 @@ def main() -> None:
     ap.add_argument("--ontarget-steps", type=int, default=3)
     ap.add_argument("--ontarget-tput-ctxs", type=int, default=16, help="streams of the on-target throughput leg (1,048,576 pairs per call; 0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-front-end", action="store_true", help="skip the front-end leg (packer, FASTQ reader, command line end to end)")
+    ap.add_argument("--front-end-pairs", type=int, default=1 << 20, help="pairs of the FASTQ files of the front-end leg")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="pairs per slice for the CPU baseline (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=32, help="independent streams (threads) of the CPU baseline")
     ap.add_argument("--tune", default="", help="key=value,... passed to fq_ctx_set_tuning on every context (experiments)")
@@ -405,6 +408,70 @@ def main() -> None:
             out["ontarget"]["throughput"] = {"value": round(leg["value"], 1), "unit": "pairs/s", "pairs_per_call": 1 << 20, "concurrent_streams": args.ontarget_tput_ctxs,
                                              "steps": 2, "ms_per_step": round(1e3 * leg["elapsed"] / 2, 3),
                                              "host_ms_per_call": round(leg["agg"]["host_ms_total"] / leg["calls"], 3)}
+
+    # ---- front end: what feeds the packed boundary, measured on this box's host cores beside `value` -----------------
+    #   pack_pairs_per_s              fq_pack_reads_into on the headline call's batch (ASCII rows -> packed batch in reused pinned storage)
+    #   tokenise_inflate_pairs_per_s  two BGZF FASTQ files -> ASCII rows (fq_fastq_read: member-parallel inflate + tokeniser), both files at once
+    #   cli_e2e_pairs_per_s           the command line on those files: FASTQ -> SAM text, whole-process wall time (index staging included)
+    if rank == 0 and world == 1 and not args.no_front_end:
+        if cpu_batch.seq is None:     # (the headline leg dropped its ASCII rows once they were packed)
+            cpu_batch.seq = cpu_seq if cpu_seq is not None else make_batch(args.pairs, 1000 + 17 * rank, main_leg["on_frac"]).seq
+        cores = os.cpu_count() or 1
+        fe = {"cores": cores}
+        pt = min(cores, 64)
+        hp = api.HostPacked(cpu_batch.seq, cpu_batch.qual, cpu_batch.lens, None, threads=pt)
+        best = 1e9
+        for _ in range(4):
+            t0 = time.perf_counter()
+            hp.repack(pt)
+            best = min(best, time.perf_counter() - t0)
+        hp.free()
+        fe["pack_pairs_per_s"] = round(args.pairs / best, 1)
+        fe["pack"] = {"threads": pt, "pairs": args.pairs, "ms": round(1e3 * best, 2), "read_len": L}
+        nfe = min(args.front_end_pairs, args.pairs)
+        fdir = os.path.join(args.workdir, "front_end")
+        os.makedirs(fdir, exist_ok=True)
+        paths = [os.path.join(fdir, "reads_%d.fq.gz" % (e + 1)) for e in range(2)]
+        t0 = time.perf_counter()
+        # qualities as a NovaSeq writes them (four bins), so that the files inflate at a realistic rate (the batches above carry a constant)
+        qual_fe = np.frombuffer(b"F:,#", dtype=np.uint8)[np.random.default_rng(99).choice(4, size=(2, nfe, L), p=[0.7, 0.15, 0.1, 0.05])]
+        text_bytes = sum(synth.write_fastq_uniform(cpu_batch.seq[e, :nfe], qual_fe[e], L, paths[e], threads=pt) for e in range(2))
+        fe["fastq_files"] = {"pairs": nfe, "text_bytes": text_bytes, "file_bytes": sum(os.path.getsize(p) for p in paths), "container": "BGZF (zlib level 1)", "qualities": "4 bins",
+                             "write_s": round(time.perf_counter() - t0, 1)}
+        rows = [(np.zeros((nfe, stride), np.uint8), np.zeros((nfe, stride), np.uint8), np.zeros(nfe, np.int32), np.zeros((nfe, 64), np.uint8)) for _ in range(2)]
+        for r_ in rows:        # (pages touched before the timed region: the command line reuses its buffers, too)
+            for a_ in r_:
+                a_.fill(1)
+        rt = max(1, pt // 2)
+        got = [0, 0]
+
+        def read_file(e):
+            f = api.FastqFile(paths[e], threads=rt, stride=stride, name_stride=64)
+            got[e] = f.read_into(*rows[e])
+            f.close()
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=read_file, args=(e,)) for e in range(2)]
+        for x in th:
+            x.start()
+        for x in th:
+            x.join()
+        dt = time.perf_counter() - t0
+        assert got == [nfe, nfe] and np.array_equal(rows[0][0][:, :L], cpu_batch.seq[0, :nfe, :L]) and np.array_equal(rows[1][1][:, :L], qual_fe[1])
+        fe["tokenise_inflate_pairs_per_s"] = round(nfe / dt, 1)
+        fe["tokenise_inflate"] = {"threads_per_file": rt, "s": round(dt, 3), "text_GBps": round(text_bytes / dt / 1e9, 3)}
+        del rows
+        exe = os.path.join(ROOT, "fastquick_amd", "bin", "FASTQuick_amd")
+        if os.path.exists(exe):
+            cmd = [exe, "align", "--index_prefix", pre[:-len(".FASTQuick.fa")], "--fastq_1", paths[0], "--fastq_2", paths[1], "--out_prefix", os.path.join(fdir, "out"),
+                   "--sam_out", "--read_len", str(L), "--t", str(pt)]
+            t0 = time.perf_counter()
+            with open(os.path.join(fdir, "out.sam"), "wb") as so:
+                run = subprocess.run(cmd, stdout=so, stderr=subprocess.PIPE)
+            dt = time.perf_counter() - t0
+            notes = [l for l in run.stderr.decode(errors="replace").splitlines() if "device time" in l or "consumers" in l or "index staged" in l]
+            fe["cli_e2e_pairs_per_s"] = round(nfe / dt, 1) if run.returncode == 0 else None
+            fe["cli_e2e"] = {"rc": run.returncode, "pairs": nfe, "wall_s": round(dt, 2), "mix": args.mix, "output": "SAM text", "notices": notes}
+        out["front_end"] = fe
 
     # ---- CPU baseline: the oracle (a port) on a bounded sample of the same workload, rank 0, N=1 only -----------
     # Three geometries, a few seconds each:

@@ -37,7 +37,11 @@ class PackedBatch(C.Structure):
     _fields_ = [("n_pairs", C.c_int32), ("uniform_len", C.c_int32), ("head", C.c_void_p), ("body", C.c_void_p),
                 ("body_stride", C.c_int32), ("qual_stride", C.c_int32), ("len", C.c_void_p), ("exc", C.c_void_p),
                 ("n_exc", C.c_int64), ("qual", C.c_void_p), ("qual_last", C.c_void_p), ("names", C.c_void_p), ("name_stride", C.c_int32),
-                ("names_mate", C.c_void_p)]
+                ("names_mate", C.c_void_p), ("serial", C.c_uint64)]
+
+
+class FastqRows(C.Structure):
+    _fields_ = [("stride", C.c_int32), ("name_stride", C.c_int32), ("seq", C.c_void_p), ("qual", C.c_void_p), ("len", C.c_void_p), ("names", C.c_void_p)]
 
 
 class QcOpts(C.Structure):
@@ -87,9 +91,10 @@ EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destr
            "fq_index_n_contigs", "fq_index_contig", "fq_ctx_create", "fq_ctx_destroy", "fq_ctx_last_error",
            "fq_ctx_set_debug", "fq_align_batch", "fq_batch_upload", "fq_align_resident", "fq_sam_header",
            "fq_sam_format_last", "fq_stage_dump_last", "fq_stats_get", "fq_stats_reset", "fq_version",
-           "fq_pinned_alloc", "fq_pinned_free", "fq_pack_reads", "fq_packed_free", "fq_packed_prefetch", "fq_align_packed",
+           "fq_pinned_alloc", "fq_pinned_free", "fq_pack_reads", "fq_packed_free", "fq_packed_create", "fq_pack_reads_into", "fq_packed_prefetch", "fq_packed_cancel", "fq_align_packed",
            "fq_ctx_set_tuning", "fq_ctx_set_serial_hooks", "fq_ctx_state_export", "fq_ctx_state_import", "fq_qc_default_opts", "fq_qc_create", "fq_qc_destroy", "fq_qc_last_error", "fq_qc_begin_file",
-           "fq_qc_add_last", "fq_qc_end_file", "fq_qc_write", "fq_bam_create", "fq_bam_add_last", "fq_bam_close"]
+           "fq_qc_add_last", "fq_qc_end_file", "fq_qc_write", "fq_bam_create", "fq_bam_add_last", "fq_bam_close",
+           "fq_fastq_open", "fq_fastq_configure", "fq_fastq_read", "fq_fastq_last_error", "fq_fastq_dropped_record", "fq_fastq_is_bgzf", "fq_fastq_close"]
 
 SERIAL_HOOK = C.CFUNCTYPE(None, C.c_void_p)
 _libs = {}
@@ -136,8 +141,21 @@ def load_library(path: str | None = None):
     L.fq_pinned_free.argtypes = [C.c_void_p]
     L.fq_pack_reads.argtypes = [C.POINTER(ReadBatch), C.c_int, C.POINTER(C.POINTER(PackedBatch))]
     L.fq_packed_free.argtypes = [C.POINTER(PackedBatch)]
+    L.fq_packed_create.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.POINTER(PackedBatch))]
+    L.fq_pack_reads_into.argtypes = [C.POINTER(ReadBatch), C.c_int, C.POINTER(PackedBatch)]
+    L.fq_packed_cancel.argtypes = [C.c_void_p, C.POINTER(PackedBatch)]
     L.fq_packed_prefetch.argtypes = [C.c_void_p, C.POINTER(PackedBatch)]
     L.fq_align_packed.argtypes = [C.c_void_p, C.POINTER(PackedBatch), C.POINTER(ResultBatch)]
+    L.fq_fastq_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.fq_fastq_configure.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64]
+    L.fq_fastq_read.restype = C.c_int64
+    L.fq_fastq_read.argtypes = [C.c_void_p, C.c_int64, C.POINTER(FastqRows)]
+    L.fq_fastq_last_error.restype = C.c_char_p
+    L.fq_fastq_last_error.argtypes = [C.c_void_p]
+    L.fq_fastq_dropped_record.restype = C.c_char_p
+    L.fq_fastq_dropped_record.argtypes = [C.c_void_p]
+    L.fq_fastq_is_bgzf.argtypes = [C.c_void_p]
+    L.fq_fastq_close.argtypes = [C.c_void_p]
     L.fq_ctx_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.fq_ctx_set_serial_hooks.argtypes = [C.c_void_p, SERIAL_HOOK, SERIAL_HOOK, C.c_void_p]
     L.fq_ctx_state_export.restype = C.c_int64
@@ -242,6 +260,12 @@ class HostPacked:
             raise FastquickError("fq_pack_reads failed: %d" % rc)
         self.n_pairs = seq.shape[1]
 
+    def repack(self, threads: int = 0) -> None:
+        """Packs the same rows again into the batch's storage (fq_pack_reads_into): what a front end does with every new chunk."""
+        rc = self.L.fq_pack_reads_into(C.byref(self._keep[5]), threads, self.p)
+        if rc:
+            raise FastquickError("fq_pack_reads_into failed: %d" % rc)
+
     @property
     def h2d_head_bytes(self) -> int:
         return 48 * self.n_pairs
@@ -250,6 +274,52 @@ class HostPacked:
         if self.p:
             self.L.fq_packed_free(self.p)
             self.p = None
+
+
+class FastqFile:
+    """One FASTQ file through the library's front end (fq_fastq_*): read(max_reads) -> (seq, qual, lens, names) numpy rows."""
+    SLOTS_REUSED, SLOTS_CLEAN_NAMES, SLOTS_FRESH = 0, 1, 2
+
+    def __init__(self, path: str, threads: int = 0, batch_pairs: int = 262144, slot_mode: int = 1, block_bytes: int = 0,
+                 stride: int = 160, name_stride: int = 64, lib=None):
+        self.L = lib or load_library()
+        self.h = C.c_void_p()
+        rc = self.L.fq_fastq_open(path.encode(), threads, C.byref(self.h))
+        if rc:
+            raise FastquickError("fq_fastq_open(%s) failed: %d" % (path, rc))
+        rc = self.L.fq_fastq_configure(self.h, batch_pairs, slot_mode, block_bytes)
+        if rc:
+            raise FastquickError("fq_fastq_configure failed: %d" % rc)
+        self.stride, self.name_stride = stride, name_stride
+
+    @property
+    def is_bgzf(self) -> bool:
+        return bool(self.L.fq_fastq_is_bgzf(self.h))
+
+    def read_into(self, seq, qual, lens, names) -> int:
+        """rows of preallocated arrays [cap][stride] / [cap] / [cap][name_stride]; returns the number of records"""
+        rows = FastqRows(seq.shape[1], names.shape[1], seq.ctypes.data, qual.ctypes.data, lens.ctypes.data, names.ctypes.data)
+        n = self.L.fq_fastq_read(self.h, seq.shape[0], C.byref(rows))
+        if n < 0:
+            raise FastquickError("fq_fastq_read failed: %d (%s)" % (n, self.L.fq_fastq_last_error(self.h).decode()))
+        return int(n)
+
+    def read(self, max_reads: int):
+        seq = np.empty((max_reads, self.stride), dtype=np.uint8)
+        qual = np.empty((max_reads, self.stride), dtype=np.uint8)
+        lens = np.empty(max_reads, dtype=np.int32)
+        names = np.empty((max_reads, self.name_stride), dtype=np.uint8)
+        n = self.read_into(seq, qual, lens, names)
+        return seq[:n], qual[:n], lens[:n], names[:n]
+
+    def dropped_record(self):
+        p = self.L.fq_fastq_dropped_record(self.h)
+        return p.decode() if p else None
+
+    def close(self):
+        if self.h:
+            self.L.fq_fastq_close(self.h)
+            self.h = None
 
 
 class Aligner:

@@ -174,6 +174,8 @@ struct fq_ctx {
   DevBuf<uint8_t> d_qlast[2];
   int head_slot = 0;                               // buffer of the current call
   const fq_packed_batch_t *pend[2] = {nullptr, nullptr};   // batch whose head was prefetched into buffer i and not yet aligned
+  uint64_t pend_serial[2] = {0, 0};                        // ... and the serial of its content (a batch object that was packed again is another batch)
+  bool is_pending(int i, const fq_packed_batch_t *b) const { return pend[i] == b && pend_serial[i] == b->serial; }
   DevBuf<uint8_t> d_body, d_pqual;
   DevBuf<uint64_t> d_exc;
   DevBuf<int32_t> d_row_map, d_crow, d_len_c, d_len_all;
@@ -791,6 +793,8 @@ int stage0_packed(Call &K) {
   CKS(sync_staged(c));
   if (ragged) {
     if (lcnt[1]) { c->err = "read length outside [" + std::to_string(FQ_LMIN) + "," + std::to_string(FQ_LMAX) + "]"; return FQ_ELIMIT; }
+    for (int sb = 0; sb < n_sub; ++sb)   // a ragged row longer than its packed row would be unpacked from its neighbour's bytes
+      if (((int64_t)c->h_sub_max[sb] + 3) / 4 > (int64_t)pb.body_stride) { c->err = "a read is longer than body_stride holds"; return FQ_EINVAL; }
     c->n_bases_in = (int64_t)lcnt[0];
   } else c->n_bases_in = (int64_t)n2 * pb.uniform_len;
   const int n_search = counts[0], n_surv = counts[1], nrow = 2 * n_surv;
@@ -1987,7 +1991,18 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
   return FQ_OK;
 }
 
+int run_call_stages(fq_ctx *c, fq_result_batch_t *out);
 int run_call(fq_ctx *c, fq_result_batch_t *out) {
+  const int rc = run_call_stages(c, out);
+  if (rc) {   // stage_finish zeroes the device counters after it has read them: a call that ends early must not leave its counts (lengths
+              // out of range, bases, work counters) to the next one
+    (void)fqdev::stream_aux(0);
+    (void)fqdev::dzero(c->d_counters.p, FQ_C_COUNT * 8);
+    (void)fqdev::sync();
+  }
+  return rc;
+}
+int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
   CallInFlight in_flight;
   Call K(c);
   K.t_trace = K.t_wall0 = now_ms();
@@ -2067,6 +2082,7 @@ static int packed_check(fq_ctx_t *c, const fq_packed_batch_t *in) {
   if (in->n_pairs > c->max_pairs) { c->err = "batch larger than max_pairs_per_batch"; return FQ_ELIMIT; }
   if (in->uniform_len > 0 && (in->uniform_len < FQ_LMIN || in->uniform_len > FQ_LMAX || (in->uniform_len + 3) / 4 > in->body_stride)) { c->err = "read length outside [" + std::to_string(FQ_LMIN) + "," + std::to_string(FQ_LMAX) + "]"; return FQ_ELIMIT; }
   if (c->o.trim_qual >= 1 && in->n_pairs > 0 && (!in->qual || in->qual_stride < 1)) { c->err = "quality trimming needs the batch's qualities"; return FQ_EINVAL; }
+  if (in->n_pairs > 0 && in->qual_last && !in->qual) { c->err = "qual_last without the quality rows"; return FQ_EINVAL; }
   return FQ_OK;
 }
 extern "C" int fq_packed_prefetch(fq_ctx_t *c, const fq_packed_batch_t *next) {
@@ -2074,14 +2090,25 @@ extern "C" int fq_packed_prefetch(fq_ctx_t *c, const fq_packed_batch_t *next) {
   int rc = packed_check(c, next);
   if (rc) return rc;
   if (fqdev::bind(c->dev)) return FQ_ENODEV;
-  if (next->n_pairs == 0 || c->pend[0] == next || c->pend[1] == next) return FQ_OK;
+  if (next->n_pairs == 0 || c->is_pending(0, next) || c->is_pending(1, next)) return FQ_OK;
+  for (int i = 0; i < 2; ++i) if (c->pend[i] == next) c->pend[i] = nullptr;   // the object was packed again since: what the buffer holds is stale
   // Calls are synchronous, so no kernel reads either buffer now: a buffer is free unless it holds a prefetched batch that has
   // not been aligned yet.  Usual order: prefetch(k+1), align(k) -- batch k waits in one buffer, k+1 goes into the other.
   const int slot = !c->pend[0] ? 0 : !c->pend[1] ? 1 : -1;
   if (slot < 0) return FQ_OK;   // both hold pending batches: this one is uploaded when its call comes
   rc = head_upload(c, next, slot);
   if (rc) return rc;
-  c->pend[slot] = next;
+  c->pend[slot] = next; c->pend_serial[slot] = next->serial;
+  return FQ_OK;
+}
+extern "C" int fq_packed_cancel(fq_ctx_t *c, const fq_packed_batch_t *b) {
+  if (!c || !b) return FQ_EINVAL;
+  for (int i = 0; i < 2; ++i)
+    if (c->pend[i] == b) {
+      if (fqdev::bind(c->dev)) return FQ_ENODEV;
+      CK(fqdev::copy_wait(i));        // the copy engine reads the batch's arrays until its upload has finished
+      c->pend[i] = nullptr;
+    }
   return FQ_OK;
 }
 extern "C" int fq_align_packed(fq_ctx_t *c, const fq_packed_batch_t *in, fq_result_batch_t *out) {
@@ -2094,9 +2121,10 @@ extern "C" int fq_align_packed(fq_ctx_t *c, const fq_packed_batch_t *in, fq_resu
   c->n_pairs = in->n_pairs;
   c->in_kind = 2;
   if (in->n_pairs > 0) {
-    if (c->pend[0] == in) { c->head_slot = 0; c->pend[0] = nullptr; }
-    else if (c->pend[1] == in) { c->head_slot = 1; c->pend[1] = nullptr; }
+    if (c->is_pending(0, in)) { c->head_slot = 0; c->pend[0] = nullptr; }
+    else if (c->is_pending(1, in)) { c->head_slot = 1; c->pend[1] = nullptr; }
     else {   // not prefetched: into a buffer that holds no pending batch (a pending one is dropped if both do)
+      for (int i = 0; i < 2; ++i) if (c->pend[i] == in) c->pend[i] = nullptr;   // (same object, older content)
       c->head_slot = !c->pend[0] ? 0 : 1;
       c->pend[c->head_slot] = nullptr;
       rc = head_upload(c, in, c->head_slot);

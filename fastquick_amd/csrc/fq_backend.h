@@ -41,6 +41,7 @@ int sync();
 // compute_wait_copy(slot) makes everything enqueued afterwards on the compute stream wait for that slot's copies
 int h2d_copy(void *dst, const void *src, size_t bytes);
 int copy_record(int slot);
+int copy_wait(int slot);                 // host waits for the copies recorded for `slot`
 int compute_wait_copy(int slot);
 
 // HIP-event timing of everything enqueued between begin/end, accumulated per kernel id

@@ -9,7 +9,6 @@
 // index carries its .SelectedSite.vcf / .dbSNP.subset.vcf / .gc.  Flank lengths and the original reference (for @SQ and the genome
 // size) come from <index_prefix>.FASTQuick.fa.param as `FASTQuick index` wrote it (src/FASTQuick.cpp:376-465).
 #include <sys/stat.h>
-#include <zlib.h>
 
 #include <algorithm>
 #include <condition_variable>
@@ -29,51 +28,31 @@ namespace {
 [[noreturn]] void die(const std::string &m) { fprintf(stderr, "FATAL ERROR - \n%s\n", m.c_str()); exit(EXIT_FAILURE); }
 void notice(const char *fmt, long long a) { fprintf(stderr, "NOTICE - "); fprintf(stderr, fmt, a); fputc('\n', stderr); }
 
+// One FASTQ file through the library's front end (fq_fastq_*: parallel inflate + tokeniser with kseq_read3_fpc's tokens)
 struct FastqReader {
-  gzFile fp = nullptr;
-  std::vector<unsigned char> buf;
-  size_t pos = 0, end = 0;
-  bool eof = false;
-  explicit FastqReader(const std::string &path) : buf(1 << 20) {
-    fp = gzopen(path.c_str(), "rb");
-    if (!fp) die("Open " + path + " failed!");
-    gzbuffer(fp, 1 << 20);
+  fq_fastq_t *h = nullptr;
+  std::string path;
+  bool told_dropped = false;
+  FastqReader(const std::string &p, int threads, int batch_pairs, int slot_mode) : path(p) {
+    if (fq_fastq_open(p.c_str(), threads, &h)) die("Open " + p + " failed!");
+    fq_fastq_configure(h, batch_pairs, slot_mode, 0);
   }
-  ~FastqReader() { if (fp) gzclose(fp); }
-  int getc() {
-    if (pos == end) {
-      if (eof) return -1;
-      const int n = gzread(fp, buf.data(), (unsigned)buf.size());
-      if (n <= 0) { eof = true; return -1; }
-      pos = 0; end = (size_t)n;
-    }
-    return buf[pos++];
-  }
-  bool drop_last(const std::string &name) {
-    fprintf(stderr, "NOTICE - the last record (%s) has no line end after its quality string; like the reference's reader, it is not used\n", name.c_str());
-    return false;
-  }
-  // returns false at end of file
-  bool next(std::string &name, std::string &seq, std::string &qual) {
-    int c;
-    while ((c = getc()) != -1 && c != '@' && c != '>') {}
-    if (c == -1) return false;
-    name.clear(); seq.clear(); qual.clear();
-    while ((c = getc()) != -1 && !isspace(c)) name.push_back((char)c);
-    if (c != '\n') while ((c = getc()) != -1 && c != '\n') {}
-    while ((c = getc()) != -1 && c != '+' && c != '>' && c != '@') if (isgraph(c)) seq.push_back((char)c);
-    if (c != '+') die("FASTA input is not supported by align (no quality line for " + name + ")");
-    while ((c = getc()) != -1 && c != '\n') {}
-    qual.resize(seq.size());
-    // ks_get_bulk (kseq.h:86-102) fails when the quality bytes reach the end of the file, also when they end exactly there: a last
-    // record without a line end (or with a short quality string) ends the input and is not returned.
-    for (size_t i = 0; i < seq.size(); ++i) { c = getc(); if (c == -1) return drop_last(name); qual[i] = (char)c; }
-    c = getc();
-    if (c == -1) return drop_last(name);
-    if (c != '\n') die("Error:" + name + " this fastq file contains reads with different length");   // kseq.h:362-365
-    return true;
-  }
+  ~FastqReader() { if (h) fq_fastq_close(h); }
+  FastqReader(const FastqReader &) = delete;
 };
+// length of a file's first read (0: none), to size the rows
+size_t first_read_len(const std::string &path) {
+  fq_fastq_t *h = nullptr;
+  if (fq_fastq_open(path.c_str(), 1, &h)) return 0;
+  fq_fastq_configure(h, 1, FQ_FASTQ_SLOTS_FRESH, 1 << 16);
+  std::vector<uint8_t> seq(65536), qual(65536);
+  std::vector<char> nm(512);
+  int32_t len = 0;
+  fq_fastq_rows_t rows = {65536, 512, seq.data(), qual.data(), &len, nm.data()};
+  const int64_t n = fq_fastq_read(h, 1, &rows);
+  fq_fastq_close(h);
+  return n == 1 ? (size_t)len : 0;
+}
 
 // One end of one chunk, in the layout fq_read_batch_t wants: fixed-stride rows, filled by that file's reader thread.
 // grow-only byte storage that is not cleared on allocation: a chunk of the default size is 2.7 GB of rows, rows are cleared as
@@ -90,70 +69,30 @@ template <class T> struct RawBuf {
 };
 struct EndChunk {
   RawBuf<uint8_t> seq, qual;
+  uint8_t *ext_seq = nullptr, *ext_qual = nullptr;   // rows elsewhere (the shared buffer of a pair chunk) instead of seq / qual
   std::vector<int32_t> len;
   RawBuf<char> names;
   int n = 0, stride = 0, name_stride = 0;
   bool eof = false;
   std::string error;
 };
-// Reads up to `cap` records of one FASTQ file into `c` (kseq_read3_fpc semantics, see FastqReader::next).  Rows are `stride`
-// bytes (a read longer than that is an error: the reference, too, wants reads of one length, kseq.h:362-365).
-// The reference keeps one name buffer per read slot (calloc(2 * read_len), bwaseqio.c:233; two sets of READ_BUFFER_SIZE slots used
-// by alternate batches, src/BwtMapper.cpp:2094-2103) and copies a name into it without a terminator (strncpy(name, s, l), :564):
-// a name shorter than an earlier one of its slot keeps that one's tail.  Real Illumina names vary in length, so a run of more than
-// two batches prints such names; the slots are modelled here so that the read names come out the same (--clean_names: plain names).
-// The base buffers are reused the same way, and the read filter looks at 96 bases whatever the read's length: a read
-// shorter than 96 bp is judged together with what the earlier, longer reads of its slot left behind it.  Those bytes travel in the
-// row behind the read (fastquick_amd.h, fq_read_batch_t).
-struct ReadSlots {
-  std::vector<std::string> name[2];   // name[batch & 1][slot]: the slot's bytes up to the last one ever written (the rest is NUL)
-  std::vector<uint8_t> base[2];       // base[batch & 1][slot * 96 ...]: the first 96 bases the slot holds, 0 = never written
-  long long pairs_seen = 0;
-  int batch_pairs = 0;
-  bool clean = false;
-  bool fresh = false;                 // the single-end reader's buffers are new and zeroed for every read: nothing lingers
-  // name to print for the next record of this file; `row` holds the record's bases (n of them) and receives the slot's leftovers
-  std::string put(const std::string &nm, uint8_t *row, size_t n, size_t stride) {
-    const size_t l = nm.size();
-    const bool mate_suffix = l > 2 && nm[l - 2] == '/' && (nm[l - 1] == '1' || nm[l - 1] == '2');   // :565-570
-    if (fresh) return mate_suffix ? nm.substr(0, l - 2) : nm;
-    const long long g = pairs_seen++;
-    const int set = (int)((g / batch_pairs) & 1);
-    const size_t slot = (size_t)(g % batch_pairs);
-    if (base[set].empty()) base[set].assign((size_t)batch_pairs * 96, 0);
-    uint8_t *h = &base[set][slot * 96];
-    for (size_t i = n; i < 96 && i < stride; ++i) row[i] = h[i];
-    memcpy(h, row, std::min<size_t>(n, 96));
-    if (clean) return mate_suffix ? nm.substr(0, l - 2) : nm;
-    if (name[set].empty()) name[set].resize((size_t)batch_pairs);
-    std::string &b = name[set][slot];
-    if (b.size() < l) b.resize(l, '\0');
-    b.replace(0, l, nm);
-    if (mate_suffix) b[l - 2] = '\0';
-    return std::string(b.c_str());
-  }
-};
-
-void fill_chunk(FastqReader &r, ReadSlots &slots, EndChunk &c, long long cap, int stride, int name_stride) {
+// Reads up to `cap` records of one FASTQ file into `c` (rows of `stride` bytes; a read longer than that is an error: the
+// reference, too, wants reads of one length, kseq.h:362-365).  The read-slot history of the reference (names without terminator,
+// bases behind a short read: SURVEY Q7 / Q8) is modelled by the reader (fq_fastq_configure).
+void fill_chunk(FastqReader &r, EndChunk &c, long long cap, int stride, int name_stride) {
   c.n = 0; c.stride = stride; c.name_stride = name_stride; c.error.clear();
   // (rows are cleared as records arrive: a chunk of the default size is 2.7 GB of rows, a small input touches a few of them)
-  if (c.seq.size() < (size_t)cap * stride) { c.seq.resize((size_t)cap * stride); c.qual.resize((size_t)cap * stride); }
+  if (!c.ext_seq && c.seq.size() < (size_t)cap * stride) { c.seq.resize((size_t)cap * stride); c.qual.resize((size_t)cap * stride); }
   if (c.len.size() < (size_t)cap) c.len.resize((size_t)cap);
   if (c.names.size() < (size_t)cap * name_stride) c.names.resize((size_t)cap * name_stride);
-  std::string nm, sq, ql;
-  while (c.n < cap) {
-    if (!r.next(nm, sq, ql)) { c.eof = true; break; }
-    memset(&c.seq[(size_t)c.n * stride], 0, (size_t)stride); memset(&c.qual[(size_t)c.n * stride], 0, (size_t)stride);
-    memset(&c.names[(size_t)c.n * name_stride], 0, (size_t)name_stride);
-    if (nm.size() > 301) nm.resize(301);   // the reference's buffer holds 2 * read_len = 302 bytes
-    if ((int)sq.size() > stride) { c.error = "read " + nm + " is longer than the batch rows (" + std::to_string(sq.size()) + " > " + std::to_string(stride) + "): pass --read_len"; return; }
-    if ((int)nm.size() >= name_stride) nm.resize((size_t)name_stride - 1);
-    memcpy(&c.seq[(size_t)c.n * stride], sq.data(), sq.size());
-    nm = slots.put(nm, &c.seq[(size_t)c.n * stride], sq.size(), (size_t)stride);
-    memcpy(&c.qual[(size_t)c.n * stride], ql.data(), ql.size());
-    c.len[c.n] = (int32_t)sq.size();
-    memcpy(&c.names[(size_t)c.n * name_stride], nm.data(), nm.size());
-    ++c.n;
+  fq_fastq_rows_t rows = {stride, name_stride, c.ext_seq ? c.ext_seq : c.seq.data(), c.ext_qual ? c.ext_qual : c.qual.data(), c.len.data(), c.names.data()};
+  const int64_t n = fq_fastq_read(r.h, cap, &rows);
+  if (n < 0) { c.error = fq_fastq_last_error(r.h); if (c.error.empty()) c.error = "reading " + r.path + " failed (" + std::to_string(n) + ")"; return; }
+  c.n = (int)n;
+  if (n < cap) c.eof = true;
+  if (!r.told_dropped && fq_fastq_dropped_record(r.h)) {
+    r.told_dropped = true;
+    fprintf(stderr, "NOTICE - the last record (%s) has no line end after its quality string; like the reference's reader, it is not used\n", fq_fastq_dropped_record(r.h));
   }
 }
 
@@ -164,7 +103,7 @@ struct Args {
   int opte = -1;
   long long chunk_pairs = 16LL * 262144;
   int device = 0;
-  int pack_threads = 8;     // host threads of the packer (fq_pack_reads)
+  int pack_threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));     // host threads of the FASTQ readers (half per file) and of the packer; --t sets it
   bool clean_names = false;
   std::string fq_list, rg = "@RG\\tID:foo\\tSM:bar";   // runAlign's default --RG (src/FASTQuick.cpp:170)
   bool cal_dup = true;
@@ -324,22 +263,19 @@ int main(int argc, char **argv) {
     fq_ctx_t *ctx = nullptr;
     rc = fq_ctx_create(ix, &so, (int32_t)A.chunk_pairs, &ctx);
     if (rc) die("fq_ctx_create failed (" + std::to_string(rc) + "): option outside the supported range");
-    FastqReader r1(A.fq1);
-    ReadSlots slot1;
-    slot1.batch_pairs = A.o.batch_pairs; slot1.clean = true; slot1.fresh = true;
+    FastqReader r1(A.fq1, A.pack_threads, A.o.batch_pairs, FQ_FASTQ_SLOTS_FRESH);
     int stride = 0;
     {
-      std::string nm, sq, ql;
       size_t l = 0;
       struct stat s1;
-      if (stat(A.fq1.c_str(), &s1) == 0 && S_ISREG(s1.st_mode)) { FastqReader p1(A.fq1); if (p1.next(nm, sq, ql)) l = sq.size(); }
+      if (stat(A.fq1.c_str(), &s1) == 0 && S_ISREG(s1.st_mode)) l = first_read_len(A.fq1);
       stride = (int)((std::max<size_t>(l, (size_t)std::max(A.read_len, 16)) + 15) & ~(size_t)15);
     }
     const int name_stride = 304;
     long long num_read = 0, filtered = 0, unmapped = 0;
     std::vector<char> sam;
     EndChunk bufs1[2];
-    fill_chunk(r1, slot1, bufs1[0], A.chunk_pairs, stride, name_stride);
+    fill_chunk(r1, bufs1[0], A.chunk_pairs, stride, name_stride);
     for (int slot = 0;; slot ^= 1) {
       EndChunk &e0 = bufs1[slot];
       if (!e0.error.empty()) die(e0.error);
@@ -347,7 +283,7 @@ int main(int argc, char **argv) {
       if (n == 0) break;
       const bool last = e0.eof;
       std::thread prefetch;
-      if (!last) prefetch = std::thread(fill_chunk, std::ref(r1), std::ref(slot1), std::ref(bufs1[slot ^ 1]), A.chunk_pairs, stride, name_stride);
+      if (!last) prefetch = std::thread(fill_chunk, std::ref(r1), std::ref(bufs1[slot ^ 1]), A.chunk_pairs, stride, name_stride);
       fq_read_batch_t in = {n, stride, e0.seq.data(), e0.qual.data(), e0.len.data(), e0.names.data(), (int32_t)name_stride, nullptr};
       fq_result_batch_t res;
       rc = fq_align_batch(ctx, &in, &res);
@@ -376,20 +312,15 @@ int main(int argc, char **argv) {
   fq_ctx_t *ctx = nullptr;
   rc = fq_ctx_create(ix, &A.o, (int32_t)A.chunk_pairs, &ctx);
   if (rc) die("fq_ctx_create failed (" + std::to_string(rc) + "): option outside the supported range");
-  FastqReader r1(A.fq1), r2(A.fq2);
-  ReadSlots slots[2];
-  for (ReadSlots &s : slots) { s.batch_pairs = A.o.batch_pairs; s.clean = A.clean_names; }
+  const int slot_mode = A.clean_names ? FQ_FASTQ_SLOTS_CLEAN_NAMES : FQ_FASTQ_SLOTS_REUSED;
+  FastqReader r1(A.fq1, std::max(1, A.pack_threads / 2), A.o.batch_pairs, slot_mode), r2(A.fq2, std::max(1, A.pack_threads / 2), A.o.batch_pairs, slot_mode);
   int stride = 0;
   {   // rows hold read_len bases, or the first records' if those are longer -- probed only in regular files (a pipe cannot be read twice:
       // there a longer read is an error that asks for --read_len)
-    std::string nm, sq, ql;
     size_t l = 0;
     struct stat s1, s2;
-    if (stat(A.fq1.c_str(), &s1) == 0 && S_ISREG(s1.st_mode) && stat(A.fq2.c_str(), &s2) == 0 && S_ISREG(s2.st_mode)) {
-      FastqReader p1(A.fq1), p2(A.fq2);
-      if (p1.next(nm, sq, ql)) l = std::max(l, sq.size());
-      if (p2.next(nm, sq, ql)) l = std::max(l, sq.size());
-    }
+    if (stat(A.fq1.c_str(), &s1) == 0 && S_ISREG(s1.st_mode) && stat(A.fq2.c_str(), &s2) == 0 && S_ISREG(s2.st_mode))
+      l = std::max(first_read_len(A.fq1), first_read_len(A.fq2));
     stride = (int)((std::max<size_t>(l, (size_t)std::max(A.read_len, 16)) + 15) & ~(size_t)15);
   }
   const int name_stride = 304;   // the reference's name buffers hold 302 bytes (bwaseqio.c:233)
@@ -397,11 +328,20 @@ int main(int argc, char **argv) {
   double qc_ms = 0, out_ms = 0;
   std::vector<char> sam;
   EndChunk bufs[2][2];   // [slot][end]
+  // the two ends of a chunk back to back in one buffer, as fq_read_batch_t wants them ([end][pair][stride]): each file's reader
+  // fills its half in place (end 1 behind the chunk_pairs rows of end 0; a short last chunk moves it down)
+  RawBuf<uint8_t> pair_seq[2], pair_qual[2];
+  for (int sl = 0; sl < 2; ++sl) {
+    pair_seq[sl].resize((size_t)2 * A.chunk_pairs * stride); pair_qual[sl].resize((size_t)2 * A.chunk_pairs * stride);
+    for (int e = 0; e < 2; ++e) { bufs[sl][e].ext_seq = pair_seq[sl].data() + (size_t)e * A.chunk_pairs * stride; bufs[sl][e].ext_qual = pair_qual[sl].data() + (size_t)e * A.chunk_pairs * stride; }
+  }
   auto read_both = [&](int slot) {
-    std::thread t0(fill_chunk, std::ref(r1), std::ref(slots[0]), std::ref(bufs[slot][0]), A.chunk_pairs, stride, name_stride);
-    std::thread t1(fill_chunk, std::ref(r2), std::ref(slots[1]), std::ref(bufs[slot][1]), A.chunk_pairs, stride, name_stride);
+    std::thread t0(fill_chunk, std::ref(r1), std::ref(bufs[slot][0]), A.chunk_pairs, stride, name_stride);
+    std::thread t1(fill_chunk, std::ref(r2), std::ref(bufs[slot][1]), A.chunk_pairs, stride, name_stride);
     t0.join(); t1.join();
   };
+  fq_packed_batch_t *pk = nullptr;   // packed-batch storage, reused from chunk to chunk (pinned once)
+  if (fq_packed_create((int32_t)A.chunk_pairs, stride, &pk)) die("out of pinned host memory for the packed batch");
   double read_ms = 0, pack_ms = 0;
   { const auto t0 = std::chrono::steady_clock::now(); read_both(0); read_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
   for (int slot = 0;; slot ^= 1) {
@@ -422,22 +362,17 @@ int main(int argc, char **argv) {
           strncmp(&e0.names[(size_t)i * name_stride], &e1.names[(size_t)i * name_stride], (size_t)A.read_len) != 0)
         die("Abort, please make sure input pair of fastq files are in the same order!");
     }
-    // the two ends back to back: [end][pair][stride]
-    RawBuf<uint8_t> seq, qual;
-    seq.resize((size_t)2 * n * stride); qual.resize((size_t)2 * n * stride);
-    std::vector<int32_t> len((size_t)2 * n);
-    for (int e = 0; e < 2; ++e) {
-      const EndChunk &c = bufs[slot][e];
-      memcpy(&seq[(size_t)e * n * stride], c.seq.data(), (size_t)n * stride);
-      memcpy(&qual[(size_t)e * n * stride], c.qual.data(), (size_t)n * stride);
-      memcpy(&len[(size_t)e * n], c.len.data(), (size_t)n * 4);
+    if ((long long)n < A.chunk_pairs) {   // a short (last) chunk: end 1 moves down behind the n rows of end 0
+      memmove(pair_seq[slot].data() + (size_t)n * stride, pair_seq[slot].data() + (size_t)A.chunk_pairs * stride, (size_t)n * stride);
+      memmove(pair_qual[slot].data() + (size_t)n * stride, pair_qual[slot].data() + (size_t)A.chunk_pairs * stride, (size_t)n * stride);
     }
-    fq_read_batch_t in = {n, stride, seq.data(), qual.data(), len.data(), e0.names.data(), (int32_t)name_stride, e1.names.data()};
+    std::vector<int32_t> len((size_t)2 * n);
+    for (int e = 0; e < 2; ++e) memcpy(&len[(size_t)e * n], bufs[slot][e].len.data(), (size_t)n * 4);
+    fq_read_batch_t in = {n, stride, pair_seq[slot].data(), pair_qual[slot].data(), len.data(), e0.names.data(), (int32_t)name_stride, e1.names.data()};
     fq_result_batch_t res;
     // the packed boundary: 24 bytes of filter keys per read cross PCIe, full rows only for the surviving pairs
-    fq_packed_batch_t *pk = nullptr;
     const auto tp0 = std::chrono::steady_clock::now();
-    rc = fq_pack_reads(&in, A.pack_threads, &pk);
+    rc = fq_pack_reads_into(&in, A.pack_threads, pk);
     pack_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
     if (rc) die("fq_pack_reads failed (" + std::to_string(rc) + ")");
     rc = fq_align_packed(ctx, pk, &res);
@@ -456,7 +391,6 @@ int main(int argc, char **argv) {
     qc_ms += std::chrono::duration<double, std::milli>(tc1 - tc0).count(); out_ms += std::chrono::duration<double, std::milli>(tc2 - tc1).count();
     num_read += 2LL * n; filtered += res.n_both_filtered; unmapped += res.n_both_unmapped; num_base += res.n_bases;
     fprintf(stderr, "NOTICE - %lld sequences are processed.\n", num_read);
-    fq_packed_free(pk);
     if (prefetch.joinable()) prefetch.join();
     if (last) break;
   }
@@ -471,6 +405,7 @@ int main(int argc, char **argv) {
   fprintf(stderr, "NOTICE - consumers (ms): StatCollector %.1f ; %s writer %.1f ; first chunk read %.1f ; packing %.1f\n", qc_ms, A.sam_out ? "SAM" : "BAM", out_ms, read_ms, pack_ms);
   if (qc) fq_qc_end_file(qc);
   fq_ctx_destroy(ctx);
+  fq_packed_free(pk);
   }
   if (bam && fq_bam_close(bam)) die("closing " + A.out_prefix + ".bam failed");
   if (qc) {

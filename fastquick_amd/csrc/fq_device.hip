@@ -177,6 +177,7 @@ int h2d_copy(void *dst, const void *src, size_t bytes) {
   return 0;
 }
 int copy_record(int slot) { if (copy_stream_get()) return -3; FQ_HIP(hipEventRecord(g_cur->copy_done[slot & 1], g_cur->copy_stream)); return 0; }
+int copy_wait(int slot) { FQ_HIP(hipEventSynchronize(g_cur->copy_done[slot & 1])); return 0; }
 int compute_wait_copy(int slot) { FQ_HIP(hipStreamWaitEvent(g_stream, g_cur->copy_done[slot & 1], 0)); return 0; }
 
 // Small copies between pinned host memory and device memory by a kernel on the compute stream (the pinned range is mapped into

@@ -1,0 +1,513 @@
+// fq_fastq.cpp -- the FASTQ front end: inflate + tokenise + read-slot history, on many threads.
+//
+// Replaces, for one FASTQ file, the reader side of bwa_read_seq_with_hash_dev (src/BwtMapper.cpp:476-613): kseq_read3_fpc
+// (libbwa/kseq.h:327-371) over a gzFile, one record at a time on one IO thread per file (IOworkerAlt, src/BwtMapper.cpp:1973-1980).
+// Here:
+//   * the inflated text arrives in blocks from a producer thread.  BGZF files (bgzip: gzip members with a 'BC' extra field that
+//     states each member's size) are inflated member-parallel straight into place -- the sizes give every member its output offset
+//     before a byte is inflated; any other gzip stream (one member or many) and plain text go through zlib's gzread on that thread,
+//     which overlaps with the tokenising of the previous block;
+//   * a block is cut into lines by all threads (memchr), and records are emitted by all threads under the assumption that the
+//     file is what sequencers write -- four lines per record.  Every record is checked against exactly the conditions under which
+//     kseq_read3_fpc would return the same tokens ('@' first, name up to the first white space, a base line of printable characters
+//     without '+', '>' or '@', a '+' line, a quality line as long as the base line); the first record that fails them, and
+//     everything behind it in the block, goes through the byte-wise restatement of kseq_read3_fpc instead, so that odd files
+//     (wrapped bases, blank lines, a last record without line end, quality strings of the wrong length) come out as the reference
+//     reads them or are refused with its message;
+//   * the reference's reused read slots (names without terminator, bases behind a short read: SURVEY Q7/Q8) are modelled per
+//     slot; the slots of 2 * batch_pairs consecutive records are distinct, so a window of that many records updates them in parallel.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <deque>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/fastquick_amd.h"
+
+namespace {
+template <class F>
+void par_for(int threads, size_t n, size_t min_per_thread, F fn) {   // fn(lo, hi, t) over [0, n)
+  int T = (int)std::min<size_t>((size_t)std::max(1, threads), std::max<size_t>(1, n / std::max<size_t>(1, min_per_thread)));
+  if (T <= 1) { fn((size_t)0, n, 0); return; }
+  std::vector<std::thread> th;
+  const size_t per = (n + T - 1) / T;
+  for (int t = 0; t < T; ++t) {
+    const size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per);
+    if (lo >= hi) break;
+    th.emplace_back([=]() { fn(lo, hi, t); });
+  }
+  for (auto &x : th) x.join();
+}
+
+struct Block {                        // inflated text [data + head, data + head + n); `head` bytes of room in front for the carry
+  std::unique_ptr<uint8_t[]> data;
+  size_t cap = 0, head = 0, n = 0;
+  bool last = false;
+  std::string err;                    // the source failed while filling this block
+};
+const size_t kHeadroom = 1 << 20;
+}  // namespace
+
+struct fq_fastq {
+  std::string path, err;
+  int threads = 1;
+  size_t block_bytes = (size_t)16 << 20;
+  // ---- source ----
+  int fd = -1;
+  gzFile gz = nullptr;
+  bool bgzf = false, src_eof = false;
+  std::vector<uint8_t> cbuf;          // BGZF: compressed bytes not yet inflated
+  size_t cpos = 0, cend = 0;
+  bool file_eof = false;
+  // ---- producer thread ----
+  std::thread producer;
+  std::mutex mu;
+  std::condition_variable cv_full, cv_free;
+  std::deque<Block> ready;            // filled blocks
+  std::vector<Block> spare;           // storage to reuse
+  bool stop = false, started = false;
+  std::string src_err;                // (producer thread only)
+  // ---- tokeniser ----
+  Block cur;                          // block being consumed: [cur_pos, cur_end)
+  size_t cur_pos = 0, cur_end = 0;
+  bool have_cur = false, at_eof = false;
+  std::vector<uint8_t> carry;         // bytes of an incomplete record at the end of the previous block
+  bool notice_dropped = false;
+  std::string dropped_name;
+  // ---- slots ----
+  int batch_pairs = 262144;
+  int slot_mode = FQ_FASTQ_SLOTS_REUSED;
+  std::vector<std::string> slot_name[2];
+  std::vector<uint8_t> slot_base[2];
+  long long records_seen = 0;
+
+  ~fq_fastq() {
+    {
+      std::lock_guard<std::mutex> lk(mu);
+      stop = true;
+    }
+    cv_free.notify_all(); cv_full.notify_all();
+    if (producer.joinable()) producer.join();
+    if (gz) gzclose(gz);
+    if (fd >= 0) close(fd);
+  }
+};
+
+namespace {
+// ---- source: BGZF member-parallel, anything else through gzread ---------------------------------------------------------------
+bool looks_bgzf(const uint8_t *h, size_t n) {   // RFC 1952 header with FEXTRA and a 'B','C' subfield of length 2 (SAM spec 4.1)
+  if (n < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return false;
+  const size_t xlen = h[10] | (size_t)h[11] << 8;
+  size_t p = 12;
+  while (p + 4 <= 12 + xlen && p + 4 <= n) {
+    const size_t sl = h[p + 2] | (size_t)h[p + 3] << 8;
+    if (h[p] == 'B' && h[p + 1] == 'C' && sl == 2) return true;
+    p += 4 + sl;
+  }
+  return false;
+}
+// size of the member that starts at h (needs >= 18 bytes), 0 if it is not a BGZF member
+size_t bgzf_member_size(const uint8_t *h, size_t n, size_t *hdr_len) {
+  if (n < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || !(h[3] & 4)) return 0;
+  const size_t xlen = h[10] | (size_t)h[11] << 8;
+  if (12 + xlen > n) return 0;
+  size_t p = 12;
+  while (p + 4 <= 12 + xlen) {
+    const size_t sl = h[p + 2] | (size_t)h[p + 3] << 8;
+    if (h[p] == 'B' && h[p + 1] == 'C' && sl == 2 && p + 6 <= 12 + xlen) { *hdr_len = 12 + xlen; return (size_t)(h[p + 4] | (size_t)h[p + 5] << 8) + 1; }
+    p += 4 + sl;
+  }
+  return 0;
+}
+struct Member { size_t in_off, in_len, hdr, out_off, out_len; };
+
+bool fill_bgzf(fq_fastq *r, Block &b) {
+  b.n = 0;
+  std::vector<Member> ms;
+  size_t out = 0;
+  for (;;) {
+    // complete members in the compressed buffer
+    while (r->cend - r->cpos >= 18) {
+      size_t hdr = 0;
+      const size_t sz = bgzf_member_size(r->cbuf.data() + r->cpos, r->cend - r->cpos, &hdr);
+      if (sz == 0) {
+        const uint8_t *h = r->cbuf.data() + r->cpos;
+        const bool gzip_hdr = h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && (h[3] & 4);
+        if (gzip_hdr && 12 + ((size_t)h[10] | (size_t)h[11] << 8) > r->cend - r->cpos && !r->file_eof) break;   // a long extra field: read on
+        r->src_err = "not a BGZF member at a member boundary (a bgzip file followed by something else?)"; return false;
+      }
+      if (sz < hdr + 8) { r->src_err = "BGZF member too short"; return false; }
+      if (r->cend - r->cpos < sz) break;
+      const uint8_t *m = r->cbuf.data() + r->cpos;
+      const size_t isize = m[sz - 4] | (size_t)m[sz - 3] << 8 | (size_t)m[sz - 2] << 16 | (size_t)m[sz - 1] << 24;
+      if (out + isize > b.cap - b.head) {
+        if (!ms.empty()) goto inflate;
+        // (a member larger than a block: blocks of a few hundred bytes are a test setting) -- the block grows to hold it
+        std::unique_ptr<uint8_t[]> bigger(new uint8_t[b.head + isize + 16]);
+        b.data = std::move(bigger); b.cap = b.head + isize + 16;
+      }
+      ms.push_back({r->cpos, sz, hdr, out, isize});
+      out += isize;
+      r->cpos += sz;
+    }
+    if (r->file_eof) {
+      if (r->cend != r->cpos) { r->src_err = "truncated BGZF member at the end of the file"; return false; }
+      break;
+    }
+    {   // read on
+      if (r->cpos > 0 && ms.empty()) { memmove(r->cbuf.data(), r->cbuf.data() + r->cpos, r->cend - r->cpos); r->cend -= r->cpos; r->cpos = 0; }
+      if (r->cend == r->cbuf.size()) {
+        if (!ms.empty()) goto inflate;     // buffer full of members waiting to be inflated
+        r->cbuf.resize(r->cbuf.size() * 2);
+      }
+      const ssize_t got = read(r->fd, r->cbuf.data() + r->cend, r->cbuf.size() - r->cend);
+      if (got < 0) { r->src_err = "read error"; return false; }
+      if (got == 0) r->file_eof = true;
+      r->cend += (size_t)got;
+    }
+  }
+inflate:
+  std::atomic<int> bad{0};
+  uint8_t *dst = b.data.get() + b.head;
+  const uint8_t *src = r->cbuf.data();
+  par_for(r->threads, ms.size(), 4, [&](size_t lo, size_t hi, int) {
+    z_stream zs;
+    memset(&zs, 0, sizeof zs);
+    if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
+    for (size_t i = lo; i < hi; ++i) {
+      const Member &m = ms[i];
+      if (m.out_len == 0) continue;      // (the empty end-of-file member)
+      inflateReset(&zs);
+      zs.next_in = const_cast<Bytef *>(src + m.in_off + m.hdr); zs.avail_in = (uInt)(m.in_len - m.hdr - 8);
+      zs.next_out = dst + m.out_off; zs.avail_out = (uInt)m.out_len;
+      const int rc = inflate(&zs, Z_FINISH);
+      if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = 1; break; }
+      const uint8_t *t = src + m.in_off + m.in_len - 8;
+      const uint32_t crc = t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+      if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), dst + m.out_off, (uInt)m.out_len) != crc) { bad = 1; break; }
+    }
+    inflateEnd(&zs);
+  });
+  if (bad) { r->src_err = "corrupt BGZF member (inflate or CRC failed)"; return false; }
+  b.n = out;
+  if (r->cpos == r->cend) { r->cpos = r->cend = 0; }
+  b.last = r->file_eof && r->cpos == r->cend;
+  return true;
+}
+bool fill_gz(fq_fastq *r, Block &b) {
+  b.n = 0;
+  const size_t room = b.cap - b.head;
+  while (b.n < room) {
+    const int got = gzread(r->gz, b.data.get() + b.head + b.n, (unsigned)std::min<size_t>(room - b.n, (size_t)1 << 30));
+    if (got < 0) { int en = 0; r->src_err = std::string("gzread: ") + gzerror(r->gz, &en); return false; }
+    if (got == 0) { b.last = true; break; }
+    b.n += (size_t)got;
+  }
+  return true;
+}
+void producer_main(fq_fastq *r) {
+  for (;;) {
+    Block b;
+    {
+      std::unique_lock<std::mutex> lk(r->mu);
+      r->cv_free.wait(lk, [&] { return r->stop || r->ready.size() < 2; });
+      if (r->stop) return;
+      if (!r->spare.empty()) { b = std::move(r->spare.back()); r->spare.pop_back(); }
+    }
+    if (b.cap < r->block_bytes + kHeadroom) { b.cap = r->block_bytes + kHeadroom; b.data.reset(new uint8_t[b.cap]); }
+    b.head = kHeadroom; b.n = 0; b.last = false;
+    const bool ok = r->bgzf ? fill_bgzf(r, b) : fill_gz(r, b);
+    if (!ok) { b.last = true; b.err = r->src_err; }
+    const bool done = b.last;
+    {
+      std::lock_guard<std::mutex> lk(r->mu);
+      r->ready.push_back(std::move(b));
+    }
+    r->cv_full.notify_all();
+    if (done) return;
+  }
+}
+
+// ---- tokeniser ---------------------------------------------------------------------------------------------------------------------
+struct Rows {
+  const fq_fastq_rows_t *o;
+  int64_t base;       // row index of the first record of this call's current block
+};
+inline bool is_space(int c) { return c == ' ' || (c >= 9 && c <= 13); }
+inline bool is_graph(int c) { return c > 32 && c < 127; }
+
+// what fill_chunk did per record: rows cleared, truncation rules of the reference's buffers
+inline int emit(const fq_fastq_rows_t *o, int64_t row, const uint8_t *name, size_t nl, const uint8_t *seq, const uint8_t *qual, size_t L, std::string *err) {
+  if ((int64_t)L > (int64_t)o->stride) {
+    *err = "read " + std::string((const char *)name, std::min<size_t>(nl, 301)) + " is longer than the batch rows (" + std::to_string(L) + " > " + std::to_string(o->stride) + "): pass --read_len";
+    return -1;
+  }
+  uint8_t *sr = o->seq + (size_t)row * (size_t)o->stride, *qr = o->qual + (size_t)row * (size_t)o->stride;
+  memcpy(sr, seq, L); memset(sr + L, 0, (size_t)o->stride - L);
+  memcpy(qr, qual, L); memset(qr + L, 0, (size_t)o->stride - L);
+  o->len[row] = (int32_t)L;
+  if (nl > 301) nl = 301;                                  // the reference's name buffer holds 2 * read_len = 302 bytes
+  if ((int64_t)nl >= (int64_t)o->name_stride) nl = (size_t)o->name_stride - 1;
+  char *nr = o->names + (size_t)row * (size_t)o->name_stride;
+  memcpy(nr, name, nl); memset(nr + nl, 0, (size_t)o->name_stride - nl);
+  return 0;
+}
+
+// ReadSlots::put of round 2's command line, per record g of the file (the name printed for a record and the bytes the filter sees
+// behind a short read depend on what earlier records left in the record's slot)
+void slot_apply(fq_fastq *r, const fq_fastq_rows_t *o, int64_t row, long long g) {
+  char *nr = o->names + (size_t)row * (size_t)o->name_stride;
+  size_t l = strlen(nr);
+  const bool mate_suffix = l > 2 && nr[l - 2] == '/' && (nr[l - 1] == '1' || nr[l - 1] == '2');   // src/BwtMapper.cpp:565-570
+  if (r->slot_mode == FQ_FASTQ_SLOTS_FRESH) { if (mate_suffix) memset(nr + l - 2, 0, 2); return; }
+  const int set = (int)((g / r->batch_pairs) & 1);
+  const size_t slot = (size_t)(g % r->batch_pairs);
+  uint8_t *sr = o->seq + (size_t)row * (size_t)o->stride;
+  const size_t n = (size_t)o->len[row];
+  uint8_t *h = &r->slot_base[set][slot * 96];
+  for (size_t i = n; i < 96 && i < (size_t)o->stride; ++i) sr[i] = h[i];
+  memcpy(h, sr, std::min<size_t>(n, 96));
+  if (r->slot_mode == FQ_FASTQ_SLOTS_CLEAN_NAMES) { if (mate_suffix) memset(nr + l - 2, 0, 2); return; }
+  std::string &b = r->slot_name[set][slot];
+  if (b.size() < l) b.resize(l, '\0');
+  b.replace(0, l, nr, l);
+  if (mate_suffix) b[l - 2] = '\0';
+  const size_t pl = strlen(b.c_str());
+  const size_t keep = std::min<size_t>(pl, (size_t)o->name_stride - 1);
+  memcpy(nr, b.data(), keep); memset(nr + keep, 0, (size_t)o->name_stride - keep);
+}
+
+// kseq_read3_fpc (libbwa/kseq.h:327-371) over memory.  Returns 1: a record (tokens set, *pp behind it); 0: end of input (final) or
+// more bytes needed (!final; *pp unchanged -- the caller carries [*pp, end) over); -1: error (r->err).  -2: a last record that the
+// reference's reader drops (no line end after its quality string).
+int exact_next(fq_fastq *r, const uint8_t **pp, const uint8_t *end, bool final, std::string &name, std::string &seq, std::string &qual) {
+  const uint8_t *p = *pp;
+  while (p < end && *p != '@' && *p != '>') ++p;
+  if (p == end) { *pp = end; return 0; }   // (what precedes a record is skipped for good)
+  const uint8_t *rec = p;
+  ++p;
+  name.clear(); seq.clear();
+  while (p < end && !is_space(*p)) name.push_back((char)*p++);
+  if (p == end) { if (!final) { *pp = rec; return 0; } }
+  if (p < end && *p != '\n') { while (p < end && *p != '\n') ++p; }
+  if (p < end) ++p;                                             // the line end of the name line
+  else if (!final) { *pp = rec; return 0; }
+  int c = -1;
+  while (p < end && (c = *p) != '+' && c != '>' && c != '@') { if (is_graph(c)) seq.push_back((char)c); ++p; }
+  if (p == end) {
+    if (!final) { *pp = rec; return 0; }
+    c = -1;
+  }
+  if (c != '+') { r->err = "FASTA input is not supported by align (no quality line for " + name + ")"; return -1; }
+  while (p < end && *p != '\n') ++p;
+  if (p < end) ++p; else if (!final) { *pp = rec; return 0; }
+  // ks_get_bulk (kseq.h:86-102) fails when the quality bytes reach the end of the file, also when they end exactly there: a last
+  // record without a line end (or with a short quality string) ends the input and is not returned
+  if ((size_t)(end - p) < seq.size() + 1) {
+    if (!final) { *pp = rec; return 0; }
+    r->dropped_name = name; *pp = end; return -2;
+  }
+  qual.assign((const char *)p, seq.size());
+  p += seq.size();
+  if (*p != '\n') { r->err = "Error:" + name + " this fastq file contains reads with different length"; return -1; }   // kseq.h:362-365
+  *pp = p + 1;
+  return 1;
+}
+
+// next block from the producer (with the carry in front of it)
+bool next_block(fq_fastq *r) {
+  if (r->have_cur) {
+    std::lock_guard<std::mutex> lk(r->mu);
+    r->spare.push_back(std::move(r->cur));
+    r->have_cur = false;
+  }
+  if (!r->started) { r->started = true; r->producer = std::thread(producer_main, r); }
+  Block b;
+  {
+    std::unique_lock<std::mutex> lk(r->mu);
+    r->cv_full.wait(lk, [&] { return !r->ready.empty(); });
+    b = std::move(r->ready.front());
+    r->ready.pop_front();
+  }
+  r->cv_free.notify_all();
+  if (!b.err.empty()) { r->err = r->path + ": " + b.err; return false; }
+  if (r->carry.size() > b.head) {   // (a carry larger than the room in front: a record of more than a megabyte)
+    Block nb;
+    nb.cap = r->carry.size() + b.n + 16; nb.data.reset(new uint8_t[nb.cap]); nb.head = r->carry.size(); nb.n = b.n; nb.last = b.last;
+    memcpy(nb.data.get() + nb.head, b.data.get() + b.head, b.n);
+    b = std::move(nb);
+  }
+  memcpy(b.data.get() + b.head - r->carry.size(), r->carry.data(), r->carry.size());
+  r->cur_pos = b.head - r->carry.size();
+  r->cur_end = b.head + b.n;
+  r->carry.clear();
+  r->cur = std::move(b);
+  r->have_cur = true;
+  return true;
+}
+}  // namespace
+
+extern "C" int fq_fastq_open(const char *path, int threads, fq_fastq_t **out) {
+  if (!path || !out) return FQ_EINVAL;
+  *out = nullptr;
+  std::unique_ptr<fq_fastq> r(new fq_fastq);
+  r->path = path;
+  r->threads = threads > 0 ? threads : (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
+  uint8_t h[4096];
+  struct stat sb;
+  const bool regular = stat(path, &sb) == 0 && S_ISREG(sb.st_mode);
+  size_t hn = 0;
+  if (regular) {   // (a pipe cannot be looked at twice: it goes through gzread, which detects gzip by itself)
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return FQ_EIO;
+    const ssize_t got = read(fd, h, sizeof h);
+    hn = got > 0 ? (size_t)got : 0;
+    if (looks_bgzf(h, hn)) { r->bgzf = true; r->fd = fd; lseek(fd, 0, SEEK_SET); }
+    else close(fd);
+  }
+  if (r->bgzf) r->cbuf.resize((size_t)32 << 20);
+  else {
+    r->gz = gzopen(path, "rb");
+    if (!r->gz) return FQ_EIO;
+    gzbuffer(r->gz, 1 << 20);
+  }
+  *out = r.release();
+  return FQ_OK;
+}
+extern "C" void fq_fastq_close(fq_fastq_t *r) { delete r; }
+extern "C" const char *fq_fastq_last_error(const fq_fastq_t *r) { return r ? r->err.c_str() : ""; }
+extern "C" int fq_fastq_is_bgzf(const fq_fastq_t *r) { return r && r->bgzf ? 1 : 0; }
+extern "C" int fq_fastq_configure(fq_fastq_t *r, int32_t batch_pairs, int32_t slot_mode, int64_t block_bytes) {
+  if (!r || r->started || batch_pairs < 1 || slot_mode < 0 || slot_mode > 2) return FQ_EINVAL;
+  r->batch_pairs = batch_pairs; r->slot_mode = slot_mode;
+  if (block_bytes > 0) r->block_bytes = (size_t)std::max<int64_t>(block_bytes, 256);
+  return FQ_OK;
+}
+extern "C" const char *fq_fastq_dropped_record(const fq_fastq_t *r) { return r && r->notice_dropped ? r->dropped_name.c_str() : nullptr; }
+
+extern "C" int64_t fq_fastq_read(fq_fastq_t *r, int64_t max_reads, const fq_fastq_rows_t *o) {
+  if (!r || !o || max_reads < 0 || !o->seq || !o->qual || !o->len || !o->names || o->stride < 1 || o->name_stride < 2) return FQ_EINVAL;
+  if (!r->err.empty()) return FQ_EIO;
+  int64_t produced = 0;
+  if (r->slot_mode != FQ_FASTQ_SLOTS_FRESH) {
+    for (int s = 0; s < 2; ++s) {
+      if (r->slot_base[s].empty()) r->slot_base[s].assign((size_t)r->batch_pairs * 96, 0);
+      if (r->slot_mode == FQ_FASTQ_SLOTS_REUSED && r->slot_name[s].empty()) r->slot_name[s].resize((size_t)r->batch_pairs);
+    }
+  }
+  std::string nm, sq, ql;
+  while (produced < max_reads && !r->at_eof) {
+    if (!r->have_cur || r->cur_pos == r->cur_end) {
+      if (r->have_cur && r->cur.last) { r->at_eof = true; break; }
+      if (!next_block(r)) return FQ_EIO;
+      if (r->cur_pos == r->cur_end && r->cur.last) { r->at_eof = true; break; }
+    }
+    const uint8_t *base = r->cur.data.get();
+    const uint8_t *p0 = base + r->cur_pos, *end = base + r->cur_end;
+    const bool final = r->cur.last;
+    // ---- lines of the block, by all threads ----
+    std::vector<std::vector<uint32_t>> part;
+    {
+      const size_t n = (size_t)(end - p0);
+      const int T = (int)std::min<size_t>((size_t)r->threads, std::max<size_t>(1, n >> 20));
+      part.resize((size_t)T);
+      par_for(T, (size_t)T, 1, [&](size_t lo, size_t hi, int) {
+        for (size_t t = lo; t < hi; ++t) {
+          const size_t per = (n + T - 1) / T, a = std::min(n, t * per), b = std::min(n, a + per);
+          std::vector<uint32_t> &v = part[t];
+          v.reserve((b - a) / 64 + 16);
+          const uint8_t *q = p0 + a, *e = p0 + b;
+          while (q < e && (q = (const uint8_t *)memchr(q, '\n', (size_t)(e - q))) != nullptr) { v.push_back((uint32_t)(q - p0)); ++q; }
+        }
+      });
+    }
+    std::vector<size_t> part_off(part.size() + 1, 0);
+    for (size_t t = 0; t < part.size(); ++t) part_off[t + 1] = part_off[t] + part[t].size();
+    const size_t n_lines = part_off.back();
+    // one array of line ends (random access by record below)
+    std::vector<uint32_t> flat;
+    const uint32_t *nl = nullptr;
+    if (part.size() == 1) nl = part[0].data();
+    else { flat.resize(n_lines); for (size_t t = 0; t < part.size(); ++t) if (!part[t].empty()) memcpy(flat.data() + part_off[t], part[t].data(), part[t].size() * 4); nl = flat.data(); }
+    const size_t n_fast = (size_t)std::min<int64_t>((int64_t)(n_lines / 4), max_reads - produced);
+    // ---- four-line records, checked and emitted by all threads ----
+    std::atomic<size_t> first_bad{n_fast};
+    std::mutex err_mu;
+    std::string emit_err;
+    size_t emit_err_at = n_fast;
+    par_for(r->threads, n_fast, 2048, [&](size_t lo, size_t hi, int) {
+      std::string lerr;
+      for (size_t i = lo; i < hi; ++i) {
+        if (i >= first_bad.load(std::memory_order_relaxed)) break;
+        const uint8_t *l0 = p0 + (i == 0 ? 0 : (size_t)nl[4 * i - 1] + 1);
+        const uint8_t *e0 = p0 + nl[4 * i], *e1 = p0 + nl[4 * i + 1], *e2 = p0 + nl[4 * i + 2], *e3 = p0 + nl[4 * i + 3];
+        const uint8_t *l1 = e0 + 1, *l2 = e1 + 1, *l3 = e2 + 1;
+        bool ok = l0 < e0 && *l0 == '@' && l2 < e2 && *l2 == '+' && (e1 - l1) == (e3 - l3);
+        if (ok) for (const uint8_t *q = l1; q < e1; ++q) { const int c = *q; if (!is_graph(c) || c == '+' || c == '>' || c == '@') { ok = false; break; } }
+        if (!ok) { size_t cur = first_bad.load(); while (i < cur && !first_bad.compare_exchange_weak(cur, i)) {} break; }
+        const uint8_t *nb = l0 + 1, *ne = nb;
+        while (ne < e0 && !is_space(*ne)) ++ne;
+        if (emit(o, produced + (int64_t)i, nb, (size_t)(ne - nb), l1, l3, (size_t)(e1 - l1), &lerr)) {
+          std::lock_guard<std::mutex> lk(err_mu);
+          if (i < emit_err_at) { emit_err_at = i; emit_err = lerr; }
+          size_t cur = first_bad.load(); while (i < cur && !first_bad.compare_exchange_weak(cur, i)) {}
+          break;
+        }
+      }
+    });
+    const size_t n_ok = first_bad.load();
+    if (emit_err_at == n_ok && !emit_err.empty()) r->err = emit_err;   // (an odd record in front of it goes the byte-wise way first)
+    // ---- slot history for the records emitted so far: windows of 2 * batch_pairs records have distinct slots ----
+    auto apply_slots = [&](int64_t row0, size_t count) {
+      const size_t W = (size_t)2 * (size_t)r->batch_pairs;
+      size_t done = 0;
+      while (done < count) {
+        const long long g0 = r->records_seen + (long long)done;
+        const size_t w = std::min(count - done, W - (size_t)(g0 % (long long)W));
+        par_for(r->threads, w, 4096, [&](size_t lo, size_t hi, int) { for (size_t k = lo; k < hi; ++k) slot_apply(r, o, row0 + (int64_t)(done + k), g0 + (long long)k); });
+        done += w;
+      }
+      r->records_seen += (long long)count;
+    };
+    apply_slots(produced, n_ok);
+    if (!r->err.empty()) return FQ_EIO;
+    produced += (int64_t)n_ok;
+    const uint8_t *p = p0 + (n_ok == 0 ? 0 : (size_t)nl[4 * n_ok - 1] + 1);
+    // ---- what the four-line reading did not take: byte-wise, as kseq_read3_fpc reads it ----
+    const bool fast_complete = n_ok == n_fast;
+    if (!fast_complete || (n_fast == n_lines / 4 && produced < max_reads)) {
+      // either an odd record (then the rest of the block goes this way), or fewer than four lines are left in the block
+      while (produced < max_reads) {
+        const uint8_t *q = p;
+        const int rc = exact_next(r, &q, end, final, nm, sq, ql);
+        if (rc == 1) {
+          std::string lerr;
+          if (emit(o, produced, (const uint8_t *)nm.data(), nm.size(), (const uint8_t *)sq.data(), (const uint8_t *)ql.data(), sq.size(), &lerr)) { r->err = lerr; return FQ_EIO; }
+          apply_slots(produced, 1);
+          ++produced;
+          p = q;
+          continue;
+        }
+        if (rc == -1) return FQ_EIO;
+        if (rc == -2) { r->notice_dropped = true; p = end; r->at_eof = true; break; }
+        // rc == 0: end of input, or the record continues in the next block
+        if (final) { p = end; r->at_eof = true; }
+        else { r->carry.assign(q, end); p = end; }
+        break;
+      }
+    }
+    r->cur_pos = (size_t)(p - base);
+  }
+  return produced;
+}

@@ -117,6 +117,50 @@ class ReadBatch:
         return tuple(paths)
 
 
+def bgzf_compress(data: bytes, threads: int = 8, level: int = 1, member: int = 65280) -> bytes:
+    """BGZF as bgzip writes it (SAM spec 4.1): gzip members of at most 64 KiB of text with a BC extra field, then the empty
+    end-of-file member.  Members are compressed on a thread pool (zlib releases the GIL)."""
+    import struct
+    import zlib
+    from concurrent.futures import ThreadPoolExecutor
+
+    def one(ch: bytes) -> bytes:
+        co = zlib.compressobj(level, zlib.DEFLATED, -15)
+        comp = co.compress(ch) + co.flush()
+        return (struct.pack("<4BI2BH", 0x1f, 0x8b, 8, 4, 0, 0, 0xff, 6) + b"BC" + struct.pack("<HH", 2, 12 + 6 + len(comp) + 8 - 1)
+                + comp + struct.pack("<II", zlib.crc32(ch) & 0xffffffff, len(ch)))
+    view = memoryview(data)
+    chunks = [view[i:i + member] for i in range(0, len(data), member)]
+    with ThreadPoolExecutor(max(1, threads)) as ex:
+        parts = list(ex.map(lambda c: one(bytes(c)), chunks))
+    return b"".join(parts) + one(b"")
+
+
+def write_fastq_uniform(seq: np.ndarray, qual: np.ndarray, read_len: int, path: str, name_prefix: bytes = b"r", bgzf: bool = True, threads: int = 8) -> int:
+    """One FASTQ file of n reads of one length from rows seq / qual [n][>= read_len], names <prefix>%09d: the text is laid out with
+    numpy (a record is a row of a byte matrix), then written as BGZF or plain text.  Returns the bytes of text."""
+    n = seq.shape[0]
+    nw = 1 + len(name_prefix) + 9
+    rec = nw + 1 + read_len + 3 + read_len + 1
+    m = np.empty((n, rec), dtype=np.uint8)
+    m[:, 0] = ord("@")
+    m[:, 1:1 + len(name_prefix)] = np.frombuffer(name_prefix, dtype=np.uint8)
+    idx = np.arange(n, dtype=np.int64)
+    for d in range(9):
+        m[:, nw - 1 - d] = (idx // 10 ** d % 10 + 48).astype(np.uint8)
+    m[:, nw] = 10
+    m[:, nw + 1:nw + 1 + read_len] = seq[:, :read_len]
+    m[:, nw + 1 + read_len] = 10
+    m[:, nw + 2 + read_len] = ord("+")
+    m[:, nw + 3 + read_len] = 10
+    m[:, nw + 4 + read_len:nw + 4 + 2 * read_len] = qual[:, :read_len]
+    m[:, rec - 1] = 10
+    text = m.tobytes()
+    with open(path, "wb") as fh:
+        fh.write(bgzf_compress(text, threads) if bgzf else text)
+    return len(text)
+
+
 def _revcomp(a: np.ndarray) -> np.ndarray:
     return _COMP[a[..., ::-1]]
 

@@ -205,6 +205,9 @@ typedef struct {
   const char *names;          /* as in fq_read_batch_t */
   int32_t name_stride;
   const char *names_mate;
+  uint64_t serial;            /* identity of the CONTENT: the packer gives every packing a new value, so a batch object that is
+                                 packed again is a new batch to fq_packed_prefetch / fq_align_packed.  A caller that fills a batch by
+                                 hand sets a new non-zero value whenever it changes the arrays (0 = the object's address alone). */
 } fq_packed_batch_t;
 
 void *fq_pinned_alloc(size_t bytes);   /* page-locked host memory (hipHostMalloc); NULL on failure */
@@ -213,12 +216,51 @@ void fq_pinned_free(void *p);
  * alias the input's arrays (they are only read for surviving pairs).  Free with fq_packed_free. */
 int fq_pack_reads(const fq_read_batch_t *in, int threads, fq_packed_batch_t **out);
 void fq_packed_free(fq_packed_batch_t *b);
+/* The same with the pinned storage kept from batch to batch (page-locking a few hundred MB per batch costs more than packing
+ * them): fq_packed_create sizes a batch object for max_pairs pairs of max_len bases (it grows when a batch needs more),
+ * fq_pack_reads_into packs into it.  The object must not be packed again, nor freed, while a prefetch of it is pending on a
+ * context: align it (fq_align_packed) or fq_packed_cancel it first. */
+int fq_packed_create(int32_t max_pairs, int32_t max_len, fq_packed_batch_t **out);
+int fq_pack_reads_into(const fq_read_batch_t *in, int threads, fq_packed_batch_t *dst);
 /* Starts the upload of `next`'s head on the context's copy stream and returns: it runs under the kernels of the
  * fq_align_packed call that follows for the current batch -- the overlap the reference gets from its IO worker reading
  * batch k+1 while batch k is aligned (IOworkerAlt, src/BwtMapper.cpp:1973-1980, 2095-2104).  Optional. */
 int fq_packed_prefetch(fq_ctx_t *c, const fq_packed_batch_t *next);
+/* Forgets a prefetched batch that will not be aligned: waits for its upload to finish (the copy engine reads the batch's pinned
+ * arrays until then) and releases the buffer.  FQ_OK also when the batch is not pending on the context. */
+int fq_packed_cancel(fq_ctx_t *c, const fq_packed_batch_t *b);
 /* The whole hot path on a packed batch, host memory in -> host memory out. */
 int fq_align_packed(fq_ctx_t *c, const fq_packed_batch_t *in, fq_result_batch_t *out);
+
+/* ---- FASTQ front end ---------------------------------------------------------------------------------------------------------
+ * One FASTQ file -> rows of a fq_read_batch_t, with the tokens of kseq_read3_fpc (libbwa/kseq.h:327-371) as
+ * bwa_read_seq_with_hash_dev consumes them (src/BwtMapper.cpp:476-613) -- on `threads` threads: BGZF files are inflated
+ * member-parallel, any other gzip stream / plain text on one thread beside the tokenising; four-line records are emitted by all
+ * threads, anything else byte-wise exactly as the reference's reader takes it (or refuses it: fq_fastq_last_error carries its
+ * message).  Replaces the IO worker of a file (IOworkerAlt, src/BwtMapper.cpp:1973-1980).
+ * fq_fastq_configure (before the first read): batch_pairs = READ_BUFFER_SIZE of the run; slot_mode = how the reference's reused
+ * read slots are modelled -- REUSED: names keep the tails of longer earlier names of their slot and a read
+ * shorter than 96 bp gets the slot's earlier bases behind it in its row (PairEndMapper); CLEAN_NAMES: bases only; FRESH: nothing
+ * lingers (SingleEndMapper's reader hands out zeroed buffers).  block_bytes: inflated text per block (0: 16 MiB). */
+typedef struct fq_fastq fq_fastq_t;
+typedef struct {
+  int32_t stride, name_stride;
+  uint8_t *seq, *qual;        /* [max_reads][stride], cleared behind each read */
+  int32_t *len;               /* [max_reads] */
+  char *names;                /* [max_reads][name_stride], NUL padded */
+} fq_fastq_rows_t;
+#define FQ_FASTQ_SLOTS_REUSED 0
+#define FQ_FASTQ_SLOTS_CLEAN_NAMES 1
+#define FQ_FASTQ_SLOTS_FRESH 2
+int fq_fastq_open(const char *path, int threads, fq_fastq_t **out);
+int fq_fastq_configure(fq_fastq_t *r, int32_t batch_pairs, int32_t slot_mode, int64_t block_bytes);
+/* up to max_reads records into rows 0..; returns their number (0: end of file) or a negative FQ_E* code */
+int64_t fq_fastq_read(fq_fastq_t *r, int64_t max_reads, const fq_fastq_rows_t *rows);
+const char *fq_fastq_last_error(const fq_fastq_t *r);
+/* name of a last record without line end behind its quality string, which the reference's reader does not return (NULL: none) */
+const char *fq_fastq_dropped_record(const fq_fastq_t *r);
+int fq_fastq_is_bgzf(const fq_fastq_t *r);
+void fq_fastq_close(fq_fastq_t *r);
 
 /* ---- one FASTQ stream over several ranks -------------------------------------------------------------------------------
  * A stream shards by reference batch: everything per-read of a batch is independent, and three pieces of state

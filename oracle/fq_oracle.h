@@ -68,6 +68,7 @@ void fqo_ctx_set_threads(fqo_ctx *c, int n_threads);
 /* counters for the algorithmic-byte model: accumulated over the ctx lifetime */
 typedef struct {
   uint64_t occ_block_touches, filter_probes, stack_pops, sa_calls, sa_steps, reads_aligned, pairs;
+  uint64_t occ_gap_touches;   /* the part of occ_block_touches made inside bwt_match_gap (incl. bwt_match_exact_alt) */
 } fqo_counters;
 void fqo_get_counters(const fqo_ctx *c, fqo_counters *out);
 

@@ -26,7 +26,7 @@ class Opts(C.Structure):
 
 class Counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in
-                ("occ_block_touches", "filter_probes", "stack_pops", "sa_calls", "sa_steps", "reads_aligned", "pairs")]
+                ("occ_block_touches", "filter_probes", "stack_pops", "sa_calls", "sa_steps", "reads_aligned", "pairs", "occ_gap_touches")]
 
 
 _lib = None

@@ -54,6 +54,33 @@ def test_emulated_pipeline_matches_reference_golden(tag, mode, golden_cases, emu
         assert stats["pairs_on_device"] > 0, "the pairing kernel body (fq_pair_thread) was not exercised"
 
 
+@pytest.mark.parametrize("mode,tuning", [("lanes", {}), ("nogap", {"gap_nogap_min": 0}), ("wave", {"gap_long_pops": 1, "gap_long_always": 1}), ("handover", {"gap_long_pops": 8})])
+def test_work_counters_match_the_oracle(mode, tuning, emu_lib, tmp_path):
+    """What bench.py prices the search kernels with (48 B x gap_occ_touches) is the number of blocks bwt_match_gap reads in the
+    reference, whatever the scheduling; pops are the reference's too (the round without gap children: at most one fewer per read)."""
+    from fastquick_amd import synth
+    ref = synth.make_reference(n_markers=60, n_long=6, seed=32, repeat_every=2, tandem_every=7)
+    pre = str(tmp_path / "ref.FASTQuick.fa")
+    ref.write_fasta(pre)
+    api.build_index(pre)
+    rb = synth.make_reads(ref, 600, on_target=0.95, seed=42, sub_rate=0.03, del_frac=0.08, ins_frac=0.07, n_rate=0.004, indel_len_max=3, chimera_frac=0.06)
+    oa = ob.OracleAligner(pre)
+    oa.align(rb.names, rb.seq, rb.qual, rb.lens, None, None, batch=200)
+    oc = oa.counters()
+    oa.close()
+    ix = api.Index(pre, lib=emu_lib)
+    al = api.Aligner(ix, max_pairs=200, tuning=tuning)
+    api.align_stream(al, rb.names, rb.seq, rb.qual, rb.lens, 200, None, None)
+    gs = al.stats()
+    al.close(); ix.close()
+    assert gs["gap_occ_touches"] == oc["occ_gap_touches"] > 0
+    assert gs["filter_probes"] == oc["filter_probes"]
+    if mode == "nogap":
+        assert oc["stack_pops"] - gs["reads_searched"] <= gs["stack_pops"] <= oc["stack_pops"]
+    else:
+        assert gs["stack_pops"] == oc["stack_pops"]
+
+
 def test_option_limits_are_rejected(golden_cases, emu_lib):
     import ctypes as C
     ix = api.Index(golden_cases["basic"]["prefix"], lib=emu_lib)
