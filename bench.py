@@ -66,6 +66,8 @@ def main() -> None:
     ap.add_argument("--ontarget-steps", type=int, default=3)
     ap.add_argument("--ontarget-tput-ctxs", type=int, default=16, help="streams of the on-target throughput leg (1,048,576 pairs per call; 0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stream-shard", type=int, default=4, help="with --gpus N > 1: also time ONE FASTQ stream sharded over the ranks by reference batch "
+                    "(dist.StreamShard; this many batches of 262,144 pairs per rank, 0: skip)")
     ap.add_argument("--no-front-end", action="store_true", help="skip the front-end leg (packer, FASTQ reader, command line end to end)")
     ap.add_argument("--front-end-pairs", type=int, default=1 << 20, help="pairs of the FASTQ files of the front-end leg")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="pairs per slice for the CPU baseline (0 = auto)")
@@ -354,6 +356,36 @@ def main() -> None:
             assert len(parts) == world and fqd.world_size() == args.gpus, "RCCL did not see every rank"
     cpu_batch = main_leg["distinct"][0]
     for al in ctxs:
+        al.close()
+
+    # ---- the other partitioning: ONE stream over the ranks, sharded by reference batch; the stream state (drand48, last_ii,
+    #      (k,l) cache) goes from the owner of batch b to the owner of b + 1 around the short order-dependent part of each call.  No
+    #      data-path collective: point-to-point tokens of a few hundred bytes.  Reported beside `value`, never instead of it.
+    if world > 1 and args.stream_shard > 0 and args.mix == "wgs":
+        Bs = 262144
+        nb = args.stream_shard * world
+        al = api.Aligner(ix, max_pairs=Bs, tuning=tuning)
+        sh = fqd.StreamShard(al, rank, world)
+        sh.n_batches = nb
+        mine = [b for b in range(nb) if sh.owns(b)]
+        sp = {}
+        for b in mine:
+            bt = make_batch(Bs, 5000 + b, main_leg["on_frac"])
+            sp[b] = api.HostPacked(bt.seq, bt.qual, bt.lens, None)
+        recs = 0
+        sync_all()
+        t0 = time.perf_counter()
+        for b in mine:
+            sh.batch_index = b
+            recs += al.align_packed(sp[b]).n_survivors
+        sync_all()
+        el = fqd.max_over_ranks(time.perf_counter() - t0)
+        tot = fqd.sum_counters({"survivor_pairs": recs})
+        if rank == 0:
+            out["stream_shard"] = {"value": round(nb * Bs / el, 1), "unit": "pairs/s", "batches": nb, "pairs_per_batch": Bs, "ranks": world, "s": round(el, 4),
+                                   "survivor_pairs": tot["survivor_pairs"], "note": "one FASTQ stream, batches dealt round-robin, state tokens over a gloo group"}
+        for p_ in sp.values():
+            p_.free()
         al.close()
     cpu_seq = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

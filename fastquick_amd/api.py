@@ -93,8 +93,8 @@ EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destr
            "fq_sam_format_last", "fq_stage_dump_last", "fq_stats_get", "fq_stats_reset", "fq_version",
            "fq_pinned_alloc", "fq_pinned_free", "fq_pack_reads", "fq_packed_free", "fq_packed_create", "fq_pack_reads_into", "fq_packed_prefetch", "fq_packed_cancel", "fq_align_packed",
            "fq_ctx_set_tuning", "fq_ctx_set_serial_hooks", "fq_ctx_state_export", "fq_ctx_state_import", "fq_qc_default_opts", "fq_qc_create", "fq_qc_destroy", "fq_qc_last_error", "fq_qc_begin_file",
-           "fq_qc_add_last", "fq_qc_end_file", "fq_qc_write", "fq_bam_create", "fq_bam_add_last", "fq_bam_close",
-           "fq_fastq_open", "fq_fastq_configure", "fq_fastq_read", "fq_fastq_last_error", "fq_fastq_dropped_record", "fq_fastq_is_bgzf", "fq_fastq_close"]
+           "fq_qc_add_last", "fq_qc_end_file", "fq_qc_write", "fq_qc_state_reset", "fq_qc_state_export", "fq_qc_merge", "fq_bam_create", "fq_bam_add_last", "fq_bam_close",
+           "fq_fastq_open", "fq_fastq_configure", "fq_fastq_set_sampling", "fq_fastq_read", "fq_fastq_last_error", "fq_fastq_dropped_record", "fq_fastq_is_bgzf", "fq_fastq_close"]
 
 SERIAL_HOOK = C.CFUNCTYPE(None, C.c_void_p)
 _libs = {}
@@ -148,6 +148,7 @@ def load_library(path: str | None = None):
     L.fq_align_packed.argtypes = [C.c_void_p, C.POINTER(PackedBatch), C.POINTER(ResultBatch)]
     L.fq_fastq_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     L.fq_fastq_configure.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64]
+    L.fq_fastq_set_sampling.argtypes = [C.c_void_p, C.c_double]
     L.fq_fastq_read.restype = C.c_int64
     L.fq_fastq_read.argtypes = [C.c_void_p, C.c_int64, C.POINTER(FastqRows)]
     L.fq_fastq_last_error.restype = C.c_char_p
@@ -281,7 +282,7 @@ class FastqFile:
     SLOTS_REUSED, SLOTS_CLEAN_NAMES, SLOTS_FRESH = 0, 1, 2
 
     def __init__(self, path: str, threads: int = 0, batch_pairs: int = 262144, slot_mode: int = 1, block_bytes: int = 0,
-                 stride: int = 160, name_stride: int = 64, lib=None):
+                 stride: int = 160, name_stride: int = 64, lib=None, frac: float = 1.0):
         self.L = lib or load_library()
         self.h = C.c_void_p()
         rc = self.L.fq_fastq_open(path.encode(), threads, C.byref(self.h))
@@ -290,6 +291,8 @@ class FastqFile:
         rc = self.L.fq_fastq_configure(self.h, batch_pairs, slot_mode, block_bytes)
         if rc:
             raise FastquickError("fq_fastq_configure failed: %d" % rc)
+        if frac != 1.0 and self.L.fq_fastq_set_sampling(self.h, frac):
+            raise FastquickError("fq_fastq_set_sampling failed")
         self.stride, self.name_stride = stride, name_stride
 
     @property
@@ -356,6 +359,10 @@ class Aligner:
         return b
 
     def _check(self, rc, what):
+        err = getattr(self, "_hook_error", None)
+        if err is not None:
+            self._hook_error = None
+            raise FastquickError("%s: a serial hook raised %r" % (what, err)) from err
         if rc:
             raise FastquickError("%s failed: %d (%s)" % (what, rc, self.L.fq_ctx_last_error(self.h).decode()))
 
@@ -379,7 +386,18 @@ class Aligner:
 
     def set_serial_hooks(self, before, after) -> None:
         """before() / after(): Python callables run around the order-dependent part of every call (None clears)."""
-        self._hooks = (SERIAL_HOOK(lambda _u: before()) if before else SERIAL_HOOK(0), SERIAL_HOOK(lambda _u: after()) if after else SERIAL_HOOK(0))
+        # an exception inside a hook cannot cross the C frames above it: it is kept and raised when the call has returned
+        self._hook_error = None
+
+        def guard(fn):
+            def run(_u):
+                try:
+                    fn()
+                except BaseException as e:      # noqa: BLE001 -- re-raised by _check
+                    if self._hook_error is None:
+                        self._hook_error = e
+            return run
+        self._hooks = (SERIAL_HOOK(guard(before)) if before else SERIAL_HOOK(0), SERIAL_HOOK(guard(after)) if after else SERIAL_HOOK(0))
         self._check(self.L.fq_ctx_set_serial_hooks(self.h, self._hooks[0], self._hooks[1], None), "fq_ctx_set_serial_hooks")
 
     def prefetch(self, packed: HostPacked) -> None:
@@ -456,6 +474,26 @@ class QC:
 
     def write(self):
         self._ck(self.L.fq_qc_write(self.h), "fq_qc_write")
+
+    def state_reset(self):
+        """Makes this a shard consumer and starts a segment (fq_qc_state_reset)."""
+        self._ck(self.L.fq_qc_state_reset(self.h), "fq_qc_state_reset")
+
+    def state_export(self) -> bytes:
+        self.L.fq_qc_state_export.restype = C.c_int64
+        self.L.fq_qc_state_export.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+        n = self.L.fq_qc_state_export(self.h, None, 0)
+        if n < 0:
+            self._ck(int(n), "fq_qc_state_export")
+        buf = C.create_string_buffer(int(n))
+        n2 = self.L.fq_qc_state_export(self.h, buf, n)
+        if n2 != n:
+            raise FastquickError("fq_qc_state_export: size changed between calls")
+        return buf.raw[:n]
+
+    def merge(self, blob: bytes):
+        self.L.fq_qc_merge.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        self._ck(self.L.fq_qc_merge(self.h, blob, len(blob)), "fq_qc_merge")
 
     def close(self):
         if self.h:

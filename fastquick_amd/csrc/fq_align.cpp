@@ -157,6 +157,8 @@ struct fq_ctx {
   // single-stream sharding: callbacks around the order-dependent part of a call (fq_ctx_set_serial_hooks)
   fq_serial_hook before_serial = nullptr, after_serial = nullptr;
   void *hook_user = nullptr;
+  bool serial_open = false, serial_done = false;   // this call's `before` hook has run / its `after` hook has run
+  bool stream_broken = false;   // a call of this stream failed (here or on the rank a state came from): exported states say so, and the ranks behind fail too instead of waiting or going on with a stale state
   // order-dependent state
   uint64_t rng = 0;
   fq_isize_t last_ii{};
@@ -402,9 +404,20 @@ extern "C" int fq_batch_upload(fq_ctx_t *c, const fq_read_batch_t *in) {
   return FQ_OK;
 }
 
+// A call of a sharded stream (fq_ctx_set_serial_hooks) that fails before its order-dependent part has begun -- here, in the checks of
+// the batch -- still takes the stream's state from the rank before it and hands it on, marked: nobody waits for a state that
+// never comes, nobody goes on with a stale one (run_call does the same for failures further on).
+static int broken_stream_call(fq_ctx_t *c, int rc) {
+  if (rc && c && (c->before_serial || c->after_serial)) {
+    c->stream_broken = true;
+    if (c->before_serial) c->before_serial(c->hook_user);
+    if (c->after_serial) c->after_serial(c->hook_user);
+  }
+  return rc;
+}
 extern "C" int fq_align_batch(fq_ctx_t *c, const fq_read_batch_t *in, fq_result_batch_t *out) {
   int rc = fq_batch_upload(c, in);
-  if (rc) return rc;
+  if (rc) return broken_stream_call(c, rc);
   return fq_align_resident(c, out);
 }
 
@@ -1993,7 +2006,16 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
 
 int run_call_stages(fq_ctx *c, fq_result_batch_t *out);
 int run_call(fq_ctx *c, fq_result_batch_t *out) {
+  c->serial_open = c->serial_done = false;
   const int rc = run_call_stages(c, out);
+  if (rc && (c->before_serial || c->after_serial)) {
+    // a sharded stream: the owner of the next batch waits for this call's state.  It gets one -- marked broken -- whether the call
+    // failed before its order-dependent part, inside it or after it (then the next owner already has a good state, and the mark
+    // reaches the ranks with the state after that)
+    c->stream_broken = true;
+    if (!c->serial_open && !c->serial_done && c->before_serial) c->before_serial(c->hook_user);
+    if (!c->serial_done && c->after_serial) c->after_serial(c->hook_user);
+  }
   if (rc) {   // stage_finish zeroes the device counters after it has read them: a call that ends early must not leave its counts (lengths
               // out of range, bases, work counters) to the next one
     (void)fqdev::stream_aux(0);
@@ -2045,6 +2067,8 @@ int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
   // ---- the order-dependent part of the call: drand48 stream, last_ii chain, (k,l) cache.  A stream sharded over ranks by
   //      reference batch hands this state from the owner of one batch to the owner of the next around it (fq_ctx_set_serial_hooks)
   if (c->before_serial) c->before_serial(c->hook_user);
+  c->serial_open = true;
+  if (c->stream_broken) { c->err = "the stream's state comes from a call that failed (on this rank or on the one before)"; return FQ_EIO; }
   if ((rc = stageB1_main_hit(K))) return rc;
   K.trace("B1 main hit (serial)");
   if (o.single_end) K.iis.assign(K.n_sub, fq_isize_t{});     // no pairs: no insert sizes, no (k,l) cache, no pairing, no mate rescue
@@ -2054,6 +2078,7 @@ int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
     stage_kl_cache(K);
   }
   if (c->after_serial) c->after_serial(c->hook_user);
+  c->serial_done = true;
   K.t_serial1 = now_ms();
   K.trace("B2 isize");
   if (!o.single_end && (rc = stageB3_pairing(K))) return rc;
@@ -2115,7 +2140,7 @@ extern "C" int fq_align_packed(fq_ctx_t *c, const fq_packed_batch_t *in, fq_resu
   if (c && c->o.single_end) { c->err = "single-end contexts take ASCII batches (fq_align_batch)"; return FQ_EINVAL; }
   if (!c || !out) return FQ_EINVAL;
   int rc = packed_check(c, in);
-  if (rc) return rc;
+  if (rc) return broken_stream_call(c, rc);
   if (fqdev::bind(c->dev)) return FQ_ENODEV;
   c->pb = *in;
   c->n_pairs = in->n_pairs;
@@ -2128,20 +2153,23 @@ extern "C" int fq_align_packed(fq_ctx_t *c, const fq_packed_batch_t *in, fq_resu
       c->head_slot = !c->pend[0] ? 0 : 1;
       c->pend[c->head_slot] = nullptr;
       rc = head_upload(c, in, c->head_slot);
-      if (rc) return rc;
+      if (rc) return broken_stream_call(c, rc);
     }
   }
   return run_call(c, out);
 }
 
+static const uint64_t kStateGood = 0x31545351465full, kStateBroken = 0x58545351465full;   // "_FQST1" / "_FQSTX"
 // ---- order-dependent state of a stream, for sharding ONE FASTQ stream over ranks by reference batch -------------
-// Layout: u64 rng | fq_isize_t last_ii | u64 n_entries | per entry: u64 key, u64 n, u32 pos[n]
+// Layout: u64 mark (good / broken) | u64 rng | fq_isize_t last_ii | u64 n_entries | per entry: u64 key, u64 n, u32 pos[n]
 extern "C" int64_t fq_ctx_state_export(const fq_ctx_t *c, void *buf, int64_t cap) {
   if (!c) return FQ_EINVAL;
-  int64_t need = 8 + (int64_t)sizeof(fq_isize_t) + 8;
+  int64_t need = 8 + 8 + (int64_t)sizeof(fq_isize_t) + 8;
   for (const auto &kv : c->kl_cache) need += 16 + 4 * (int64_t)kv.second.size();
   if (!buf || cap < need) return need;
   uint8_t *p = (uint8_t *)buf;
+  const uint64_t mark = c->stream_broken ? kStateBroken : kStateGood;
+  memcpy(p, &mark, 8); p += 8;
   memcpy(p, &c->rng, 8); p += 8;
   memcpy(p, &c->last_ii, sizeof(fq_isize_t)); p += sizeof(fq_isize_t);
   const uint64_t n = c->kl_cache.size();
@@ -2155,8 +2183,12 @@ extern "C" int64_t fq_ctx_state_export(const fq_ctx_t *c, void *buf, int64_t cap
   return need;
 }
 extern "C" int fq_ctx_state_import(fq_ctx_t *c, const void *buf, int64_t len) {
-  if (!c || !buf || len < (int64_t)(16 + sizeof(fq_isize_t))) return FQ_EINVAL;
+  if (!c || !buf || len < (int64_t)(24 + sizeof(fq_isize_t))) return FQ_EINVAL;
   const uint8_t *p = (const uint8_t *)buf, *end = p + len;
+  uint64_t mark;
+  memcpy(&mark, p, 8); p += 8;
+  if (mark == kStateBroken) { c->stream_broken = true; c->err = "the stream's state comes from a call that failed on another rank"; return FQ_EIO; }
+  if (mark != kStateGood) return FQ_EINVAL;
   memcpy(&c->rng, p, 8); p += 8;
   memcpy(&c->last_ii, p, sizeof(fq_isize_t)); p += sizeof(fq_isize_t);
   uint64_t n;

@@ -33,9 +33,10 @@ struct FastqReader {
   fq_fastq_t *h = nullptr;
   std::string path;
   bool told_dropped = false;
-  FastqReader(const std::string &p, int threads, int batch_pairs, int slot_mode) : path(p) {
+  FastqReader(const std::string &p, int threads, int batch_pairs, int slot_mode, double frac) : path(p) {
     if (fq_fastq_open(p.c_str(), threads, &h)) die("Open " + p + " failed!");
     fq_fastq_configure(h, batch_pairs, slot_mode, 0);
+    if (fq_fastq_set_sampling(h, frac)) die("--frac_samp must not be negative");
   }
   ~FastqReader() { if (h) fq_fastq_close(h); }
   FastqReader(const FastqReader &) = delete;
@@ -107,6 +108,7 @@ struct Args {
   bool clean_names = false;
   std::string fq_list, rg = "@RG\\tID:foo\\tSM:bar";   // runAlign's default --RG (src/FASTQuick.cpp:170)
   bool cal_dup = true;
+  double frac = 1.0;    // --frac_samp: gap_opt_t::frac (libbwa/bwtaln.c:47), the share of the records that is kept
   int read_len = 151;   // gap_opt_t::read_len (libbwa/bwtaln.c:48): the reference sizes its read buffers from it and has no flag for it
 };
 
@@ -114,7 +116,7 @@ int usage() {
   fprintf(stderr, "Usage: FASTQuick_amd align --index_prefix P --fastq_1 R1.fq[.gz] [--fastq_2 R2.fq[.gz]] | --fq_list LIST  --out_prefix O [--sam_out] [--RG STR] [--cal_dup]\n"
                   "                       [--q INT] [--n FLOAT|INT] [--kmer_thresh INT] [--o INT] [--e INT] [--i INT] [--d INT] [--l INT] [--k INT]\n"
                   "                       [--m INT] [--R INT] [--N] [--L] [--I] [--max_isize INT] [--max_occ INT] [--is_sw] [--n_multi INT] [--N_multi INT]\n"
-                  "                       [--ap_prior FLOAT] [--force_isize] [--t INT] [--chunk_pairs INT] [--batch_pairs INT] [--device INT] [--read_len INT] [--clean_names]\n"
+                  "                       [--ap_prior FLOAT] [--force_isize] [--frac_samp FLOAT] [--t INT] [--chunk_pairs INT] [--batch_pairs INT] [--device INT] [--read_len INT] [--clean_names]\n"
                   "       FASTQuick_amd index --ref REDUCED.FASTQuick.fa [--rollhash]\n");
   return 1;
 }
@@ -177,7 +179,8 @@ int main(int argc, char **argv) {
     else if (f == "--fq_list") A.fq_list = need("");
     else if (f == "--RG") A.rg = need("");
     else if (f == "--cal_dup") A.cal_dup = !A.cal_dup;        // (a bool flag on a default-1 field, like --is_sw)
-    else if (f == "--frac_samp" || f == "--bam_in") die(f + " is not supported by this build");
+    else if (f == "--frac_samp") A.frac = atof(need(""));
+    else if (f == "--bam_in") die(f + " is not supported (the reference's BAM input is disabled, too)");
     else die("unknown option " + f);
   }
   if (A.o.fnr >= 1.0) { A.o.max_diff = (int)A.o.fnr; A.o.fnr = -1.0; }                  // src/FASTQuick.cpp:312-315
@@ -263,7 +266,7 @@ int main(int argc, char **argv) {
     fq_ctx_t *ctx = nullptr;
     rc = fq_ctx_create(ix, &so, (int32_t)A.chunk_pairs, &ctx);
     if (rc) die("fq_ctx_create failed (" + std::to_string(rc) + "): option outside the supported range");
-    FastqReader r1(A.fq1, A.pack_threads, A.o.batch_pairs, FQ_FASTQ_SLOTS_FRESH);
+    FastqReader r1(A.fq1, A.pack_threads, A.o.batch_pairs, FQ_FASTQ_SLOTS_FRESH, A.frac);
     int stride = 0;
     {
       size_t l = 0;
@@ -313,7 +316,7 @@ int main(int argc, char **argv) {
   rc = fq_ctx_create(ix, &A.o, (int32_t)A.chunk_pairs, &ctx);
   if (rc) die("fq_ctx_create failed (" + std::to_string(rc) + "): option outside the supported range");
   const int slot_mode = A.clean_names ? FQ_FASTQ_SLOTS_CLEAN_NAMES : FQ_FASTQ_SLOTS_REUSED;
-  FastqReader r1(A.fq1, std::max(1, A.pack_threads / 2), A.o.batch_pairs, slot_mode), r2(A.fq2, std::max(1, A.pack_threads / 2), A.o.batch_pairs, slot_mode);
+  FastqReader r1(A.fq1, std::max(1, A.pack_threads / 2), A.o.batch_pairs, slot_mode, A.frac), r2(A.fq2, std::max(1, A.pack_threads / 2), A.o.batch_pairs, slot_mode, A.frac);
   int stride = 0;
   {   // rows hold read_len bases, or the first records' if those are longer -- probed only in regular files (a pipe cannot be read twice:
       // there a longer read is an error that asks for --read_len)

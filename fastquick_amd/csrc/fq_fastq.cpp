@@ -29,6 +29,7 @@
 #include <deque>
 #include <memory>
 #include <mutex>
+#include <random>
 #include <string>
 #include <thread>
 #include <vector>
@@ -91,6 +92,24 @@ struct fq_fastq {
   std::vector<std::string> slot_name[2];
   std::vector<uint8_t> slot_base[2];
   long long records_seen = 0;
+  // ---- --frac_samp (src/BwtMapper.cpp:483, 500-507): every reference batch draws from Random(seed = the batch's number) -- the
+  //      Mersenne twister of VerifyBamID/Random.cpp, Next() = (y + 0.5) / 2^32 -- one number per record met; a record whose number is
+  //      above the fraction is read and dropped (kseq_read4_fpc), the batch ends with its batch_pairs-th kept record.  The batch's
+  //      number is PairEndMapper's `round` at the time the batch is read: the first batch is read with 0, every later one by the IO
+  //      worker that is started BEFORE round is incremented (:1973-1985) -- seeds 0, 0, 1, 2, ...  (SingleEndMapper seeds with
+  //      clock(), :1286: its sampling is not reproducible; FRESH slots use the same seeds as pairs.)
+  double frac = 1.0;
+  struct Sampler {
+    std::mt19937 gen{0};
+    long long round = 0, in_batch = 0;
+    bool keep(double frac, int batch_pairs) {     // the draw for the next record met
+      if (in_batch == batch_pairs) { ++round; in_batch = 0; gen.seed((uint32_t)(round - 1)); }
+      const double x = ((double)gen() + 0.5) * (1.0 / 4294967296.0);
+      if (x > frac) return false;
+      ++in_batch;
+      return true;
+    }
+  } sampler;
 
   ~fq_fastq() {
     {
@@ -325,6 +344,39 @@ int exact_next(fq_fastq *r, const uint8_t **pp, const uint8_t *end, bool final, 
   return 1;
 }
 
+// kseq_read4_fpc (libbwa/kseq.h:371-402) over memory: the record --frac_samp drops.  It counts every byte between the name line and
+// the '+' (line ends included), skips the '+' line and then that count minus one bytes (ks_shift_bulk advances len - 1), and wants
+// a line end next.  Returns as exact_next: 1 dropped, 0 end / more bytes needed, -1 error.
+int exact_skip(fq_fastq *r, const uint8_t **pp, const uint8_t *end, bool final) {
+  const uint8_t *p = *pp;
+  while (p < end && *p != '@' && *p != '>') ++p;
+  if (p == end) { *pp = end; return 0; }
+  const uint8_t *rec = p;
+  ++p;
+  std::string name;
+  while (p < end && !is_space(*p)) name.push_back((char)*p++);
+  if (p == end && !final) { *pp = rec; return 0; }
+  while (p < end && *p != '\n') ++p;
+  if (p < end) ++p; else if (!final) { *pp = rec; return 0; }
+  size_t count = 0;
+  int c = -1;
+  while (p < end && (c = *p) != '+' && c != '>' && c != '@') { ++count; ++p; }
+  if (p == end) { if (!final) { *pp = rec; return 0; } c = -1; }
+  if (c != '+') { *pp = p; return 1; }                     // (FASTA-shaped: returned as it is there; the next call starts at the '>' / '@')
+  while (p < end && *p != '\n') ++p;
+  if (p == end) { if (!final) { *pp = rec; return 0; } *pp = end; return 0; }
+  ++p;
+  const size_t skip = count ? count - 1 : 0;
+  if ((size_t)(end - p) < skip + 1) {
+    if (!final) { *pp = rec; return 0; }
+    *pp = end; return 0;                                  // the bytes run out inside the quality string: the reader stops (-2 there)
+  }
+  p += skip;
+  if (*p != '\n') { r->err = "Error:" + name + " this fastq file contains reads with different length"; return -1; }
+  *pp = p + 1;
+  return 1;
+}
+
 // next block from the producer (with the carry in front of it)
 bool next_block(fq_fastq *r) {
   if (r->have_cur) {
@@ -394,6 +446,11 @@ extern "C" int fq_fastq_configure(fq_fastq_t *r, int32_t batch_pairs, int32_t sl
   if (block_bytes > 0) r->block_bytes = (size_t)std::max<int64_t>(block_bytes, 256);
   return FQ_OK;
 }
+extern "C" int fq_fastq_set_sampling(fq_fastq_t *r, double frac) {
+  if (!r || r->started || !(frac >= 0.0)) return FQ_EINVAL;
+  r->frac = frac;
+  return FQ_OK;
+}
 extern "C" const char *fq_fastq_dropped_record(const fq_fastq_t *r) { return r && r->notice_dropped ? r->dropped_name.c_str() : nullptr; }
 
 extern "C" int64_t fq_fastq_read(fq_fastq_t *r, int64_t max_reads, const fq_fastq_rows_t *o) {
@@ -440,8 +497,21 @@ extern "C" int64_t fq_fastq_read(fq_fastq_t *r, int64_t max_reads, const fq_fast
     const uint32_t *nl = nullptr;
     if (part.size() == 1) nl = part[0].data();
     else { flat.resize(n_lines); for (size_t t = 0; t < part.size(); ++t) if (!part[t].empty()) memcpy(flat.data() + part_off[t], part[t].data(), part[t].size() * 4); nl = flat.data(); }
-    const size_t n_fast = (size_t)std::min<int64_t>((int64_t)(n_lines / 4), max_reads - produced);
+    // ---- --frac_samp: which of the block's records are kept is a serial walk of the batch's generator (a draw per record met)
+    const bool sampling = r->frac < 1.0;
+    std::vector<uint32_t> kept;                  // record index of the j-th kept record of this block (sampling only)
+    size_t n_met = n_lines / 4;                   // records of the block this call looks at
+    const fq_fastq::Sampler sampler0 = r->sampler;
+    if (sampling) {
+      const size_t want = (size_t)(max_reads - produced);
+      size_t i = 0;
+      for (; i < n_lines / 4 && kept.size() < want; ++i) if (r->sampler.keep(r->frac, r->batch_pairs)) kept.push_back((uint32_t)i);
+      n_met = i;
+    }
+    const size_t n_fast = sampling ? n_met : (size_t)std::min<int64_t>((int64_t)(n_lines / 4), max_reads - produced);
     // ---- four-line records, checked and emitted by all threads ----
+    std::vector<int64_t> row_of;                  // sampling: output row of record i, or -1 for a dropped one
+    if (sampling) { row_of.assign(n_fast, -1); for (size_t j = 0; j < kept.size(); ++j) row_of[kept[j]] = (int64_t)j; }
     std::atomic<size_t> first_bad{n_fast};
     std::mutex err_mu;
     std::string emit_err;
@@ -458,7 +528,8 @@ extern "C" int64_t fq_fastq_read(fq_fastq_t *r, int64_t max_reads, const fq_fast
         if (!ok) { size_t cur = first_bad.load(); while (i < cur && !first_bad.compare_exchange_weak(cur, i)) {} break; }
         const uint8_t *nb = l0 + 1, *ne = nb;
         while (ne < e0 && !is_space(*ne)) ++ne;
-        if (emit(o, produced + (int64_t)i, nb, (size_t)(ne - nb), l1, l3, (size_t)(e1 - l1), &lerr)) {
+        if (sampling && row_of[i] < 0) continue;            // dropped: a well-formed record is skipped whole by kseq_read4_fpc too
+        if (emit(o, produced + (sampling ? row_of[i] : (int64_t)i), nb, (size_t)(ne - nb), l1, l3, (size_t)(e1 - l1), &lerr)) {
           std::lock_guard<std::mutex> lk(err_mu);
           if (i < emit_err_at) { emit_err_at = i; emit_err = lerr; }
           size_t cur = first_bad.load(); while (i < cur && !first_bad.compare_exchange_weak(cur, i)) {}
@@ -480,16 +551,32 @@ extern "C" int64_t fq_fastq_read(fq_fastq_t *r, int64_t max_reads, const fq_fast
       }
       r->records_seen += (long long)count;
     };
-    apply_slots(produced, n_ok);
+    size_t n_emit = n_ok;
+    if (sampling) {   // records 0 .. n_ok-1 were met; the generator goes back to where it stood in front of record n_ok
+      n_emit = (size_t)(std::lower_bound(kept.begin(), kept.end(), (uint32_t)n_ok) - kept.begin());
+      if (n_ok < n_met) { r->sampler = sampler0; for (size_t i = 0; i < n_ok; ++i) (void)r->sampler.keep(r->frac, r->batch_pairs); }
+    }
+    apply_slots(produced, n_emit);
     if (!r->err.empty()) return FQ_EIO;
-    produced += (int64_t)n_ok;
+    produced += (int64_t)n_emit;
     const uint8_t *p = p0 + (n_ok == 0 ? 0 : (size_t)nl[4 * n_ok - 1] + 1);
     // ---- what the four-line reading did not take: byte-wise, as kseq_read3_fpc reads it ----
     const bool fast_complete = n_ok == n_fast;
     if (!fast_complete || (n_fast == n_lines / 4 && produced < max_reads)) {
+      fq_fastq::Sampler before_draw = r->sampler;
       // either an odd record (then the rest of the block goes this way), or fewer than four lines are left in the block
       while (produced < max_reads) {
         const uint8_t *q = p;
+        before_draw = r->sampler;
+        if (sampling && !r->sampler.keep(r->frac, r->batch_pairs)) {
+          const int rs = exact_skip(r, &q, end, final);
+          if (rs == 1) { p = q; continue; }
+          if (rs == -1) return FQ_EIO;
+          r->sampler = before_draw;            // the record is met again with the next block (or there was none)
+          if (final) { p = end; r->at_eof = true; }
+          else { r->carry.assign(q, end); p = end; }
+          break;
+        }
         const int rc = exact_next(r, &q, end, final, nm, sq, ql);
         if (rc == 1) {
           std::string lerr;
@@ -502,6 +589,7 @@ extern "C" int64_t fq_fastq_read(fq_fastq_t *r, int64_t max_reads, const fq_fast
         if (rc == -1) return FQ_EIO;
         if (rc == -2) { r->notice_dropped = true; p = end; r->at_eof = true; break; }
         // rc == 0: end of input, or the record continues in the next block
+        r->sampler = before_draw;
         if (final) { p = end; r->at_eof = true; }
         else { r->carry.assign(q, end); p = end; }
         break;

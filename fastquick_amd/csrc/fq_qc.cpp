@@ -44,21 +44,24 @@ struct Regions {
   std::map<std::string, std::map<int, int>> list;
   uint64_t length = 0;
   void add(const std::string &chr, int start, int end) { list[chrom_key(chr)][start] = end; }
-  void collapse() {                            // RegionList::Collapse, :73-113
-    std::map<std::string, std::map<int, int>> tmp;
-    for (auto kv : list) {
-      auto holder = kv.second.begin();
-      for (auto iter = kv.second.begin(); iter != kv.second.end(); ++iter) {
-        const int beg1 = holder->first, end1 = holder->second, beg2 = iter->first, end2 = iter->second;
-        if (end1 >= end2) continue;
-        else if (end1 < beg2) { tmp[kv.first][beg1] = end1; holder = iter; }
-        else { tmp[kv.first][beg1] = end2; holder->second = end2; }
-      }
-      tmp[kv.first][holder->first] = holder->second;
-    }
-    list = tmp;
+  // Union of the regions of each chromosome (what RegionList::Collapse leaves, src/RegionList.cpp:73-113): one sweep over the
+  // regions in order of their start, a region that begins inside or at the end of the current one extends it (regions that merely
+  // touch -- end + 1 == next start -- stay apart, as there)
+  void collapse() {
     length = 0;
-    for (const auto &kv : list) for (const auto &kv2 : kv.second) length += (uint64_t)(kv2.second - kv2.first) + 1;
+    for (auto &chr : list) {
+      std::map<int, int> merged;
+      bool open = false;
+      int lo = 0, hi = 0;
+      for (const auto &reg : chr.second) {
+        if (open && reg.first <= hi) { hi = std::max(hi, reg.second); continue; }
+        if (open) merged[lo] = hi;
+        lo = reg.first; hi = reg.second; open = true;
+      }
+      if (open) merged[lo] = hi;
+      chr.second.swap(merged);
+      for (const auto &reg : chr.second) length += (uint64_t)(reg.second - reg.first) + 1;
+    }
   }
   bool overlapped(const std::string &chr, int pos) const {   // RegionList::IsOverlapped, :48-66
     auto it = list.find(chr);
@@ -95,38 +98,39 @@ std::string cigar_string(const FqRead &p) {     // Cigar2String, :58-72
   return s;
 }
 
-// RecoverRefseqByMDandCigar, :98-205
+// The reference bases under a read's aligned blocks, from the read, its CIGAR and its MD tag (what RecoverRefseqByMDandCigar
+// returns, src/StatCollector.cpp:98-205): the bases of the M blocks in order, then the MD tag walked left to right -- a number
+// skips that many matching bases, a letter replaces the base it stands for, '^' + letters puts deleted reference bases back in.
+// An MD tag that is one number equal to the read's length means "the read is the reference".
 std::string recover_ref(const std::string &read, std::string md, const std::vector<uint16_t> &cigar) {
-  std::transform(md.begin(), md.end(), md.begin(), ::toupper);
+  for (char &ch : md) ch = (char)toupper((unsigned char)ch);
   if (md.find_first_of("ATCGN") == std::string::npos && atol(md.c_str()) == (long)read.size()) return read;
   std::string ref;
-  if (!cigar.empty()) {
-    int at = 0;
+  if (cigar.empty()) ref = read;
+  else {
+    size_t on_read = 0;
     for (uint16_t g : cigar) {
-      const int cl = g & 0x3fff, op = g >> 14;
-      if (op == FQ_OP_M) { ref += read.substr(at, cl); at += cl; }
-      else if (op == FQ_OP_S || op == FQ_OP_I) at += cl;
+      const size_t n = g & 0x3fff;
+      const int op = g >> 14;
+      if (op == FQ_OP_M) ref.append(read, on_read, n);
+      if (op != FQ_OP_D) on_read += n;
     }
-  } else ref = read;
-  int last = 0, total = 0;
-  for (uint32_t i = 0; i != md.size(); ++i) {
-    if (isdigit((unsigned char)md[i])) continue;
+  }
+  size_t at = 0;                       // bases of `ref` the tag has accounted for
+  for (size_t i = 0; i < md.size();) {
+    size_t run = 0;
+    while (i < md.size() && isdigit((unsigned char)md[i])) run = run * 10 + (size_t)(md[i++] - '0');
+    if (i >= md.size()) break;
+    at += run;
     if (md[i] == '^') {
-      const int len = atoi(md.substr(last, i - last).c_str());
-      total += len;
-      const int start_on_read = total;
-      ++i;
-      std::string del;
-      while (!isdigit((unsigned char)md[i])) { del += md[i]; ++i; ++total; }
-      const std::string left = ref.substr(0, start_on_read);
-      const std::string right = (size_t)start_on_read <= ref.size() ? ref.substr(start_on_read, ref.length() - start_on_read + 1) : std::string();
-      ref = left + del + right;
-      last = i;
+      size_t j = ++i;
+      while (j < md.size() && !isdigit((unsigned char)md[j])) ++j;
+      ref.insert(std::min(at, ref.size()), md, i, j - i);
+      at += j - i;
+      i = j;
     } else {
-      const int len = atoi(md.substr(last, i - last).c_str()) + 1;
-      total += len;
-      if (total - 1 >= 0 && (size_t)(total - 1) < ref.size()) ref[total - 1] = md[i];
-      last = i + 1;
+      if (at < ref.size()) ref[at] = md[i];
+      ++at; ++i;
     }
   }
   return ref;
@@ -162,6 +166,18 @@ struct fq_qc {
   std::vector<FileStat> files;
   FileStat cur;
   bool file_open = false;
+  // ---- shard consumers (fq_qc_state_reset / _export / fq_qc_merge): what the order-dependent outputs need to be put together again
+  bool shard = false;                              // logs below are kept since the last reset
+  bool cur_continues = false;                      // the open file was begun before the last reset (its counters here are a part of it)
+  std::vector<char> files_continue;                // per closed file of this segment: the same
+  std::vector<std::string> contig_order;           // sex-chromosome contigs in the order they were first counted (the file walks an unordered_map)
+  std::vector<std::string> dup_log;                // key of every proper pair, in order (the duplicate count needs the keys of all shards)
+  std::streamoff table_mark = 0;                   // .InsertSizeTable bytes written before the last reset
+  ContigStatus &cs(const std::string &name) {
+    auto it = contig_status.find(name);
+    if (it == contig_status.end()) { if (shard) contig_order.push_back(name); it = contig_status.emplace(name, ContigStatus()).first; }
+    return it->second;
+  }
   std::string out_prefix;
   std::ofstream table;
 
@@ -456,6 +472,7 @@ int fq_qc::pair_status(const Rec *P, const Rec *Q, int type) {
       snprintf(key, sizeof key, "%d:%d:%d", seqid_p, start, end);
       if (!dup_table.insert(std::string(key)).second) NumPCRDup += 2;
       NumPairReads += 2;
+      if (shard) dup_log.emplace_back(key);
     }
   } else { both_line(-1, "LowQual"); return 2; }
   return 0;
@@ -477,7 +494,7 @@ int fq_qc::add_alignment(Rec &P, Rec &Q, const FqHostReads &hb, long long &faile
   const std::string qname = contig_name(seqid2);
   if (P.type == FQ_TYPE_NO_MATCH) {
     if (add_single(Q, hb)) {
-      if (sex(qname)) { ++contig_status[qname].overlapped; if (!partial(Q)) ++contig_status[qname].fully; }
+      if (sex(qname)) { ++cs(qname).overlapped; if (!partial(Q)) ++cs(qname).fully; }
       pair_status(&P, &Q, 2);
       failed += 1;
       return 1;
@@ -488,7 +505,7 @@ int fq_qc::add_alignment(Rec &P, Rec &Q, const FqHostReads &hb, long long &faile
   const std::string pname = contig_name(seqid);
   if (Q.type == FQ_TYPE_NO_MATCH) {
     if (add_single(P, hb)) {
-      if (sex(pname)) { ++contig_status[pname].overlapped; if (!partial(P)) ++contig_status[pname].fully; }
+      if (sex(pname)) { ++cs(pname).overlapped; if (!partial(P)) ++cs(pname).fully; }
       pair_status(&P, &Q, 0);
       failed += 1;
       return 1;
@@ -498,18 +515,18 @@ int fq_qc::add_alignment(Rec &P, Rec &Q, const FqHostReads &hb, long long &faile
   }
   if (partial(P)) {
     if (sex(qname)) {
-      if (partial(Q)) ++contig_status[qname].overlapped;
-      else { ++contig_status[qname].overlapped; ++contig_status[qname].fully; }
-      if (pname == qname) ++contig_status[qname].pair_overlapped;
-      ++contig_status[pname].overlapped;
+      if (partial(Q)) ++cs(qname).overlapped;
+      else { ++cs(qname).overlapped; ++cs(qname).fully; }
+      if (pname == qname) ++cs(qname).pair_overlapped;
+      ++cs(pname).overlapped;
     }
   } else if (sex(qname)) {
-    if (partial(Q)) { ++contig_status[qname].overlapped; if (pname == qname) ++contig_status[qname].pair_overlapped; }
+    if (partial(Q)) { ++cs(qname).overlapped; if (pname == qname) ++cs(qname).pair_overlapped; }
     else {
-      ++contig_status[qname].overlapped; ++contig_status[qname].fully;
-      if (pname == qname) { ++contig_status[qname].pair_overlapped; ++contig_status[qname].fully_paired; }
+      ++cs(qname).overlapped; ++cs(qname).fully;
+      if (pname == qname) { ++cs(qname).pair_overlapped; ++cs(qname).fully_paired; }
     }
-    ++contig_status[pname].overlapped; ++contig_status[pname].fully;
+    ++cs(pname).overlapped; ++cs(pname).fully;
   }
   if (pair_status(&P, &Q, 1) != 1 || o.cal_dup) {
     if (add_single(P, hb)) {
@@ -549,11 +566,13 @@ extern "C" int fq_qc_begin_file(fq_qc_t *q, const char *fq1, const char *fq2) {
   q->cur = FileStat();
   q->cur.f1 = fq1; q->cur.f2 = fq2 ? fq2 : fq1;
   q->file_open = true;
+  q->cur_continues = false;
   return FQ_OK;
 }
 extern "C" int fq_qc_end_file(fq_qc_t *q) {
   if (!q || !q->file_open) return FQ_EINVAL;
   q->files.push_back(q->cur);     // StatCollector::AddFSC
+  q->files_continue.push_back(q->cur_continues ? 1 : 0);
   q->file_open = false;
   return FQ_OK;
 }
@@ -570,7 +589,7 @@ int fq_qc::add_alignment_se(Rec &P, const FqHostReads &hb, long long &failed) {
   auto partial = [](const Rec &R) { for (uint16_t g : R.r->cigar) if ((g >> 14) == FQ_OP_S) return true; return false; };
   const std::string pname = contig_name(seqid);
   if (add_single(P, hb)) {
-    if (pname.find('Y') != std::string::npos || pname.find('X') != std::string::npos) { ++contig_status[pname].overlapped; if (!partial(P)) ++contig_status[pname].fully; }
+    if (pname.find('Y') != std::string::npos || pname.find('X') != std::string::npos) { ++cs(pname).overlapped; if (!partial(P)) ++cs(pname).fully; }
     pair_status(&P, nullptr, 0);
     failed += 1;
     return 1;
@@ -850,5 +869,170 @@ extern "C" int fq_qc_write(fq_qc_t *q) {
         f << gt << PL[0] << "," << PL[1] << "," << PL[2] << ":" << post[0] << "," << post[1] << "," << post[2] << "\n";
       }
   }
+  return FQ_OK;
+}
+
+// ---- the consumer over several ranks -----------------------------------------------------------------------------------------
+// Every rank feeds the records of its shard of the input to a consumer of its own; what those consumers have gathered is put
+// together on one of them (fq_qc_merge), in the order of the input, and written there (fq_qc_write).  Most of the state is sums
+// (FileStatCollector's counters, src/StatCollector.h:46-62; the depth / quality / cycle / insert-size tables of AddSingleAlignment
+// and ProcessPairStatus, src/StatCollector.cpp:424-921): those add.  What depends on the order of the records is kept as a log
+// and replayed: the .InsertSizeTable lines and the pileup strings of the markers are appended, the duplicate keys of a shard's
+// proper pairs are looked up in the union of all shards seen so far (the count of duplicates among N pairs is N minus the distinct
+// keys, whatever the order), and the sex-chromosome contigs are entered in the order they were first counted -- .SexChromInfo walks
+// an unordered_map, whose order is that of its insertions.
+namespace {
+struct Out {
+  std::vector<uint8_t> b;
+  template <class T> void put(const T &v) { const uint8_t *p = (const uint8_t *)&v; b.insert(b.end(), p, p + sizeof(T)); }
+  void bytes(const void *p, size_t n) { put<uint64_t>(n); const uint8_t *q = (const uint8_t *)p; b.insert(b.end(), q, q + n); }
+  void str(const std::string &s) { bytes(s.data(), s.size()); }
+  template <class T> void vec(const std::vector<T> &v) { bytes(v.data(), v.size() * sizeof(T)); }
+};
+struct In {
+  const uint8_t *p, *end;
+  bool ok = true;
+  template <class T> T get() { T v{}; if ((size_t)(end - p) < sizeof(T)) { ok = false; return v; } memcpy(&v, p, sizeof(T)); p += sizeof(T); return v; }
+  const uint8_t *bytes(size_t *n) { *n = (size_t)get<uint64_t>(); if (!ok || (size_t)(end - p) < *n) { ok = false; *n = 0; return p; } const uint8_t *q = p; p += *n; return q; }
+  std::string str() { size_t n; const uint8_t *q = bytes(&n); return std::string((const char *)q, n); }
+  template <class T> bool vec(std::vector<T> &v) { size_t n; const uint8_t *q = bytes(&n); if (!ok || n % sizeof(T)) { ok = false; return false; } v.resize(n / sizeof(T)); if (n) memcpy(v.data(), q, n); return true; }
+};
+const uint64_t kStateMagic = 0x3153435146ull;   // "FQCS1"
+void put_file(Out &o, const FileStat &F) { o.put(F.NumRead); o.put(F.NumBase); o.put(F.TotalFiltered); o.put(F.BwaUnmapped); o.put(F.TotalMAPQ); o.put(F.TotalRetained); o.str(F.f1); o.str(F.f2); }
+FileStat get_file(In &in) { FileStat F; F.NumRead = in.get<long long>(); F.NumBase = in.get<long long>(); F.TotalFiltered = in.get<long long>(); F.BwaUnmapped = in.get<long long>(); F.TotalMAPQ = in.get<long long>(); F.TotalRetained = in.get<long long>(); F.f1 = in.str(); F.f2 = in.str(); return F; }
+void add_file(FileStat &a, const FileStat &b) { a.NumRead += b.NumRead; a.NumBase += b.NumBase; a.TotalFiltered += b.TotalFiltered; a.BwaUnmapped += b.BwaUnmapped; a.TotalMAPQ += b.TotalMAPQ; a.TotalRetained += b.TotalRetained; }
+}  // namespace
+
+extern "C" int fq_qc_state_reset(fq_qc_t *q) {
+  if (!q) return FQ_EINVAL;
+  q->shard = true;
+  std::fill(q->depth.begin(), q->depth.end(), 0u); std::fill(q->q20.begin(), q->q20.end(), 0u); std::fill(q->q30.begin(), q->q30.end(), 0u);
+  for (auto *v : {&q->EmpRep, &q->misEmpRep, &q->EmpCycle, &q->misEmpCycle, &q->InsertDist, &q->CycleDist}) std::fill(v->begin(), v->end(), (size_t)0);
+  for (size_t k = 0; k < q->seq_vec.size(); ++k) { q->seq_vec[k].clear(); q->qual_vec[k].clear(); q->cycle_vec[k].clear(); q->maq_vec[k].clear(); q->strand_vec[k].clear(); }
+  q->NumPCRDup = q->NumPairReads = 0;
+  q->dup_log.clear();
+  q->contig_status.clear(); q->contig_order.clear();
+  q->files.clear(); q->files_continue.clear();
+  if (q->file_open) { const std::string f1 = q->cur.f1, f2 = q->cur.f2; q->cur = FileStat(); q->cur.f1 = f1; q->cur.f2 = f2; q->cur_continues = true; }
+  q->table.flush();
+  q->table_mark = (std::streamoff)q->table.tellp();
+  return FQ_OK;
+}
+
+extern "C" int64_t fq_qc_state_export(fq_qc_t *q, void *buf, int64_t cap) {
+  if (!q) return FQ_EINVAL;
+  if (!q->shard) { q->err = "fq_qc_state_export: not a shard consumer (call fq_qc_state_reset before its first batch)"; return FQ_EINVAL; }
+  Out o;
+  o.put(kStateMagic);
+  o.put<int32_t>(q->o.mode);
+  o.put<uint64_t>(q->depth.size());
+  {   // depth tables: the touched positions (index, depth, Q20, Q30), or the whole tables when most are
+    size_t nz = 0;
+    for (uint32_t d : q->depth) nz += d != 0;
+    const bool dense = nz * 16 > q->depth.size() * 12;
+    o.put<uint8_t>(dense ? 1 : 0);
+    if (dense) { o.vec(q->depth); o.vec(q->q20); o.vec(q->q30); }
+    else {
+      std::vector<uint32_t> sp;
+      sp.reserve(nz * 4);
+      for (size_t k = 0; k < q->depth.size(); ++k) if (q->depth[k]) { sp.push_back((uint32_t)k); sp.push_back(q->depth[k]); sp.push_back(q->q20[k]); sp.push_back(q->q30[k]); }
+      o.vec(sp);
+    }
+  }
+  for (auto *v : {&q->EmpRep, &q->misEmpRep, &q->EmpCycle, &q->misEmpCycle, &q->InsertDist, &q->CycleDist}) o.vec(*v);
+  {   // pileups: the markers this shard's reads covered
+    uint64_t n = 0;
+    for (const auto &sq : q->seq_vec) n += !sq.empty();
+    o.put(n);
+    for (size_t k = 0; k < q->seq_vec.size(); ++k) {
+      if (q->seq_vec[k].empty()) continue;
+      o.put<uint32_t>((uint32_t)k);
+      o.str(q->seq_vec[k]); o.str(q->qual_vec[k]); o.vec(q->cycle_vec[k]); o.vec(q->maq_vec[k]);
+      std::vector<uint8_t> st(q->strand_vec[k].begin(), q->strand_vec[k].end());
+      o.vec(st);
+    }
+  }
+  o.put<uint64_t>(q->dup_log.size());
+  for (const auto &k : q->dup_log) o.str(k);
+  o.put<uint64_t>(q->contig_order.size());
+  for (const auto &name : q->contig_order) { const ContigStatus &c = q->contig_status[name]; o.str(name); o.put(c.overlapped); o.put(c.fully); o.put(c.pair_overlapped); o.put(c.fully_paired); }
+  o.put<uint64_t>(q->files.size());
+  for (size_t i = 0; i < q->files.size(); ++i) { o.put<uint8_t>((uint8_t)q->files_continue[i]); put_file(o, q->files[i]); }
+  o.put<uint8_t>(q->file_open ? 1 : 0);
+  if (q->file_open) { o.put<uint8_t>(q->cur_continues ? 1 : 0); put_file(o, q->cur); }
+  {   // the .InsertSizeTable lines of this segment
+    q->table.flush();
+    std::ifstream fin(q->out_prefix + ".InsertSizeTable", std::ios_base::binary);
+    std::string text;
+    if (fin.is_open()) { fin.seekg(q->table_mark); text.assign(std::istreambuf_iterator<char>(fin), std::istreambuf_iterator<char>()); }
+    o.str(text);
+  }
+  if (!buf || cap < (int64_t)o.b.size()) return (int64_t)o.b.size();
+  memcpy(buf, o.b.data(), o.b.size());
+  return (int64_t)o.b.size();
+}
+
+extern "C" int fq_qc_merge(fq_qc_t *q, const void *buf, int64_t len) {
+  if (!q || !buf || len < 8) return FQ_EINVAL;
+  In in{(const uint8_t *)buf, (const uint8_t *)buf + len};
+  if (in.get<uint64_t>() != kStateMagic) { q->err = "fq_qc_merge: not an exported consumer state"; return FQ_EINVAL; }
+  q->o.mode = in.get<int32_t>();
+  if (in.get<uint64_t>() != q->depth.size()) { q->err = "fq_qc_merge: the state belongs to another marker set"; return FQ_EINVAL; }
+  if (in.get<uint8_t>()) {
+    std::vector<uint32_t> d, a, b;
+    if (!in.vec(d) || !in.vec(a) || !in.vec(b) || d.size() != q->depth.size() || a.size() != d.size() || b.size() != d.size()) { q->err = "fq_qc_merge: truncated state"; return FQ_EINVAL; }
+    for (size_t k = 0; k < d.size(); ++k) { q->depth[k] += d[k]; q->q20[k] += a[k]; q->q30[k] += b[k]; }
+  } else {
+    std::vector<uint32_t> sp;
+    if (!in.vec(sp) || sp.size() % 4) { q->err = "fq_qc_merge: truncated state"; return FQ_EINVAL; }
+    for (size_t t = 0; t < sp.size(); t += 4) { if (sp[t] >= q->depth.size()) { q->err = "fq_qc_merge: corrupt state"; return FQ_EINVAL; } q->depth[sp[t]] += sp[t + 1]; q->q20[sp[t]] += sp[t + 2]; q->q30[sp[t]] += sp[t + 3]; }
+  }
+  for (auto *v : {&q->EmpRep, &q->misEmpRep, &q->EmpCycle, &q->misEmpCycle, &q->InsertDist, &q->CycleDist}) {
+    std::vector<size_t> w;
+    if (!in.vec(w) || w.size() != v->size()) { q->err = "fq_qc_merge: truncated state"; return FQ_EINVAL; }
+    for (size_t k = 0; k < w.size(); ++k) (*v)[k] += w[k];
+  }
+  for (uint64_t n = in.get<uint64_t>(); n > 0 && in.ok; --n) {
+    const uint32_t k = in.get<uint32_t>();
+    const std::string sq = in.str(), ql = in.str();
+    std::vector<int> cyc; std::vector<unsigned char> mq; std::vector<uint8_t> st;
+    if (!in.vec(cyc) || !in.vec(mq) || !in.vec(st) || k >= q->seq_vec.size()) { q->err = "fq_qc_merge: corrupt state"; return FQ_EINVAL; }
+    q->seq_vec[k] += sq; q->qual_vec[k] += ql;
+    q->cycle_vec[k].insert(q->cycle_vec[k].end(), cyc.begin(), cyc.end());
+    q->maq_vec[k].insert(q->maq_vec[k].end(), mq.begin(), mq.end());
+    for (uint8_t v : st) q->strand_vec[k].push_back(v != 0);
+  }
+  for (uint64_t n = in.get<uint64_t>(); n > 0 && in.ok; --n) {   // the shard's proper pairs against the keys of everything merged so far
+    const std::string key = in.str();
+    if (!q->dup_table.insert(key).second) q->NumPCRDup += 2;
+    q->NumPairReads += 2;
+    if (q->shard) q->dup_log.push_back(key);
+  }
+  for (uint64_t n = in.get<uint64_t>(); n > 0 && in.ok; --n) {
+    const std::string name = in.str();
+    ContigStatus &c = q->cs(name);
+    c.overlapped += in.get<int>(); c.fully += in.get<int>(); c.pair_overlapped += in.get<int>(); c.fully_paired += in.get<int>();
+  }
+  for (uint64_t n = in.get<uint64_t>(); n > 0 && in.ok; --n) {
+    const bool continues = in.get<uint8_t>() != 0;
+    const FileStat F = get_file(in);
+    if (continues) {
+      if (!q->file_open) { q->err = "fq_qc_merge: the state continues a file that is not open here (fq_qc_begin_file)"; return FQ_EINVAL; }
+      add_file(q->cur, F);
+      q->files.push_back(q->cur); q->files_continue.push_back(q->cur_continues ? 1 : 0);
+      q->file_open = false;
+    } else { q->files.push_back(F); q->files_continue.push_back(0); }
+  }
+  if (in.get<uint8_t>()) {
+    const bool continues = in.get<uint8_t>() != 0;
+    const FileStat F = get_file(in);
+    if (continues) {
+      if (!q->file_open) { q->err = "fq_qc_merge: the state continues a file that is not open here (fq_qc_begin_file)"; return FQ_EINVAL; }
+      add_file(q->cur, F);
+    } else { q->cur = F; q->file_open = true; q->cur_continues = false; }
+  }
+  const std::string text = in.str();
+  if (!in.ok) { q->err = "fq_qc_merge: truncated state"; return FQ_EINVAL; }
+  q->table.write(text.data(), (std::streamsize)text.size());
   return FQ_OK;
 }

@@ -46,6 +46,19 @@ def _dev():
     return "cuda" if dist.is_initialized() and dist.get_backend() == "nccl" else "cpu"
 
 
+_token_group = None
+
+
+def token_group():
+    """The group the stream tokens of StreamShard travel over: host buffers of a few hundred bytes, sent from inside a library
+    call's hook.  Under RCCL they go over a gloo group of the same ranks -- plain sockets, no device tensors, nothing enqueued on
+    a GPU stream that a kernel of the sending call could be ordered behind -- and under gloo over the default group."""
+    global _token_group
+    if dist.is_initialized() and dist.get_backend() == "nccl" and _token_group is None:
+        _token_group = dist.new_group(backend="gloo")
+    return _token_group
+
+
 def world_size() -> int:
     """Ranks the collective backend (RCCL / gloo) actually sees; 1 without a process group."""
     return dist.get_world_size() if dist.is_initialized() else 1
@@ -96,20 +109,47 @@ def gather_bytes_to_rank0(buf: bytes):
 
 
 def _send_bytes(blob: bytes, dst: int) -> None:
-    dev = _dev()
-    dist.send(torch.tensor([len(blob)], dtype=torch.int64, device=dev), dst)
+    g = token_group()
+    dist.send(torch.tensor([len(blob)], dtype=torch.int64), dst, group=g)
     if blob:
-        dist.send(torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(dev), dst)
+        dist.send(torch.frombuffer(bytearray(blob), dtype=torch.uint8), dst, group=g)
 
 
 def _recv_bytes(src: int) -> bytes:
-    dev = _dev()
-    n = torch.zeros(1, dtype=torch.int64, device=dev)
-    dist.recv(n, src)
-    buf = torch.zeros(int(n.item()), dtype=torch.uint8, device=dev)
+    g = token_group()
+    n = torch.zeros(1, dtype=torch.int64)
+    dist.recv(n, src, group=g)
+    buf = torch.zeros(int(n.item()), dtype=torch.uint8)
     if buf.numel():
-        dist.recv(buf, src)
-    return bytes(buf.cpu().numpy().tobytes())
+        dist.recv(buf, src, group=g)
+    return bytes(buf.numpy().tobytes())
+
+
+def gather_keyed_to_rank0(items):
+    """items: this rank's [(key, bytes)]; rank 0 returns all ranks' items sorted by key, the others None."""
+    blob = b"".join(len(p).to_bytes(8, "little") + int(k).to_bytes(8, "little") + p for k, p in items)
+    got = gather_bytes_to_rank0(blob)
+    if got is None:
+        return None
+    out = []
+    for g in got:
+        at = 0
+        while at < len(g):
+            ln, k = int.from_bytes(g[at:at + 8], "little"), int.from_bytes(g[at + 8:at + 16], "little")
+            out.append((k, g[at + 16:at + 16 + ln]))
+            at += 16 + ln
+    return sorted(out, key=lambda t: t[0])
+
+
+def merge_qc_on_rank0(segments, root_qc) -> None:
+    """segments: this rank's [(order key, exported consumer state)] (QC.state_export of a shard consumer, per reference batch or per
+    FASTQ pair).  Rank 0 merges every rank's segments into root_qc in key order -- the order of the input -- so that root_qc.write()
+    gives the files of the single-process run (fq_qc_merge).  A trivial gather: the states are sums and logs, no rank needs another's."""
+    got = gather_keyed_to_rank0(segments)
+    if got is None:
+        return
+    for _k, blob in got:
+        root_qc.merge(blob)
 
 
 class StreamShard:
@@ -122,6 +162,8 @@ class StreamShard:
         self.al, self.rank, self.world = aligner, rank, world
         self.batch_index = 0
         self.n_batches = 0
+        self.qc_segments = []
+        token_group()            # (collective: created by every rank at the same point)
         aligner.set_serial_hooks(self._before, self._after)
 
     def _before(self):
@@ -151,8 +193,10 @@ class StreamShard:
                 self.al.align_packed(hp)
             else:
                 self.al.align(seq[:, lo:hi], qual[:, lo:hi], lens[:, lo:hi], names[lo:hi])
-            if qc is not None:
+            if qc is not None:      # a shard consumer (QC.state_reset called): one exported segment per batch, merged in batch order later
                 qc.add(self.al)
+                self.qc_segments.append((b, qc.state_export()))
+                qc.state_reset()
             out.append((b, self.al.sam_text() if want_sam else b""))
             if packed:
                 self.al._keep_packed = None
@@ -161,15 +205,5 @@ class StreamShard:
 
     def gather_in_batch_order(self, parts):
         """parts: this rank's [(batch index, bytes)]; rank 0 returns the stream's bytes in batch order, others None."""
-        blob = b"".join(len(p).to_bytes(8, "little") + b.to_bytes(8, "little") + p for b, p in parts)
-        got = gather_bytes_to_rank0(blob)
-        if got is None:
-            return None
-        items = []
-        for g in got:
-            at = 0
-            while at < len(g):
-                ln, b = int.from_bytes(g[at:at + 8], "little"), int.from_bytes(g[at + 8:at + 16], "little")
-                items.append((b, g[at + 16:at + 16 + ln]))
-                at += 16 + ln
-        return b"".join(p for _b, p in sorted(items, key=lambda t: t[0]))
+        items = gather_keyed_to_rank0(parts)
+        return None if items is None else b"".join(p for _b, p in items)

@@ -254,6 +254,10 @@ typedef struct {
 #define FQ_FASTQ_SLOTS_FRESH 2
 int fq_fastq_open(const char *path, int threads, fq_fastq_t **out);
 int fq_fastq_configure(fq_fastq_t *r, int32_t batch_pairs, int32_t slot_mode, int64_t block_bytes);
+/* --frac_samp (src/BwtMapper.cpp:483, 500-507): every reference batch draws from the reference's Random(seed = number of the batch),
+ * one number per record it meets, and a record whose number is above `frac` is read and dropped; both files of a pair drop the same
+ * records.  1.0 (the default): every record is kept. */
+int fq_fastq_set_sampling(fq_fastq_t *r, double frac);
 /* up to max_reads records into rows 0..; returns their number (0: end of file) or a negative FQ_E* code */
 int64_t fq_fastq_read(fq_fastq_t *r, int64_t max_reads, const fq_fastq_rows_t *rows);
 const char *fq_fastq_last_error(const fq_fastq_t *r);
@@ -313,6 +317,19 @@ int fq_qc_begin_file(fq_qc_t *q, const char *fastq_1, const char *fastq_2);
 int fq_qc_add_last(fq_qc_t *q, fq_ctx_t *c);   /* the records of the context's last batch; call before the next fq_align_* on it */
 int fq_qc_end_file(fq_qc_t *q);
 int fq_qc_write(fq_qc_t *q);                   /* ProcessCore: writes the files (once, at the end) */
+/* The consumer over several ranks (StatCollector is one object per run in the reference: FileStatCollector sums per FASTQ pair,
+ * src/StatCollector.h:46-62, AddFSC; tables filled by AddSingleAlignment / ProcessPairStatus, src/StatCollector.cpp:424-921).
+ * Each rank feeds its shard of the input -- whole FASTQ pairs of a --fq_list, or reference batches of one pair -- to a consumer of
+ * its own (any out_prefix of its own: the .InsertSizeTable lines are kept there).  fq_qc_state_reset makes a consumer a shard
+ * consumer and starts a segment (call it before the first batch, and after every export); fq_qc_state_export serialises what the
+ * segment gathered (returns the bytes written, or needed when buf is NULL / too small); fq_qc_merge adds a segment to a consumer AS
+ * IF its records had been fed after everything that consumer holds: sums add, .InsertSizeTable lines, pileup strings and
+ * first-seen sex-chromosome contigs append, duplicate keys are looked up in the union.  Merging the segments in input order into
+ * one consumer and writing there gives the files of the single-process run. A segment that ends inside a FASTQ pair carries that
+ * pair's partial counters: the merging consumer must have the pair open (fq_qc_begin_file) or get it from an earlier segment. */
+int fq_qc_state_reset(fq_qc_t *q);
+int64_t fq_qc_state_export(fq_qc_t *q, void *buf, int64_t cap);
+int fq_qc_merge(fq_qc_t *q, const void *buf, int64_t len);
 
 /* ---- BAM consumer ---------------------------------------------------------------------------------------------------------
  * BwtMapper::SetSamRecord / SetSamFileHeader (src/BwtMapper.cpp:947-1264) as a BAM file (own BGZF layer): genome coordinates

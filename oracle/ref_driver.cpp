@@ -129,6 +129,7 @@ static int cmd_align(int argc, char **argv) {
   int batch = READ_BUFFER_SIZE, thresh = 3;
   long long genome_size = 0, genome_n_size = 0;
   int bam_dump = 0, se = 0;
+  std::vector<std::pair<std::string, std::string>> more;
   std::string fai_path, rg = "@RG\tID:foo\tSM:bar";   // runAlign's default --RG (src/FASTQuick.cpp:170)
   for (int i = 6; i + 1 < argc; i += 2) {
     if (!strcmp(argv[i], "--q")) opt->trim_qual = atoi(argv[i + 1]);
@@ -143,6 +144,13 @@ static int cmd_align(int argc, char **argv) {
     else if (!strcmp(argv[i], "--fai")) fai_path = argv[i + 1];
     else if (!strcmp(argv[i], "--RG")) rg = argv[i + 1];
     else if (!strcmp(argv[i], "--thresh")) thresh = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--frac_samp")) opt->frac = atof(argv[i + 1]);      // gap_opt_t::frac, runAlign's --frac_samp (src/FASTQuick.cpp:299)
+    else if (!strcmp(argv[i], "--more")) {   // a further FASTQ pair "r1,r2": the next line of a --fq_list (BwtMapper's constructor calls PairEndMapper once per line, src/BwtMapper.cpp:232-262)
+      const std::string v = argv[i + 1];
+      const size_t comma = v.find(',');
+      if (comma == std::string::npos) die("--more takes r1.fq,r2.fq");
+      more.emplace_back(v.substr(0, comma), v.substr(comma + 1));
+    }
     else if (!strcmp(argv[i], "--n")) { opt->max_diff = atoi(argv[i + 1]); opt->fnr = -1.0; }
     else if (!strcmp(argv[i], "--no_sw")) popt->is_sw = 0;
     else if (!strcmp(argv[i], "--read_len")) opt->read_len = atoi(argv[i + 1]);
@@ -187,7 +195,6 @@ static int cmd_align(int argc, char **argv) {
   collector.RestoreVcfSites(NewRef, opt);
   collector.SetGenomeSize(genome_size, genome_n_size);
   std::ofstream fout(out + ".InsertSizeTable");
-  FileStatCollector FSC(fq1, fq2);
 
   // BAM branch: the record builder and header of the reference, on its own SamRecord / SamFileHeader classes
   BwtMapper mapper;
@@ -292,11 +299,19 @@ static int cmd_align(int argc, char **argv) {
     collector.ProcessCore(out, opt);
     return 0;
   }
-  // ---- the set-up part of BwtMapper::PairEndMapper (src/BwtMapper.cpp:1811-1834)
+  std::vector<std::pair<std::string, std::string>> all_pairs;
+  all_pairs.emplace_back(fq1, fq2);
+  all_pairs.insert(all_pairs.end(), more.begin(), more.end());
+  bwa_print_sam_SQ(ix.bns);
+  bwa_print_sam_PG();
+  int b = 0;   // batches are numbered through all pairs in the stage dump
+  for (const auto &fq_pair : all_pairs) {
+  FileStatCollector FSC(fq_pair.first.c_str(), fq_pair.second.c_str());
+  // ---- the set-up part of BwtMapper::PairEndMapper (src/BwtMapper.cpp:1811-1834), once per FASTQ pair
   bwase_initialize();
   srand48(ix.bns->seed);
   kh_64_t *hash = kh_init(64);
-  bwa_seqio_t *ks[2] = {bwa_seq_open(fq1), bwa_seq_open(fq2)};
+  bwa_seqio_t *ks[2] = {bwa_seq_open(fq_pair.first.c_str()), bwa_seq_open(fq_pair.second.c_str())};
   bwt_t *bwt[2] = {ix.bwt_d, ix.rbwt_d};
   // two sets of read slots used by alternate batches, like seqs / seqs_buff (src/BwtMapper.cpp:1827-1834, 2094-2103): what a
   // slot keeps of its earlier occupants (name tails, bases past a short read's end) then has the reference's cadence
@@ -308,16 +323,17 @@ static int cmd_align(int argc, char **argv) {
     }
   isize_info_t last_ii; last_ii.avg = -1.0;
   ubyte_t *pacseq = 0;
-  bwa_print_sam_SQ(ix.bns);
-  bwa_print_sam_PG();
 
   uint32_t round = 0;
   long long n_pairs_total = 0, n_filtered = 0, n_unmapped = 0;
-  for (int b = 0;; ++b) {
+  for (;; ++b) {
     int n_seqs[2] = {0, 0};
-    bwa_seq_t **seqs = sets[b & 1];
-    int r0 = bwa_read_seq_with_hash_dev(&ix, ks[0], batch, &n_seqs[0], opt->mode, opt->trim_qual, opt->frac, round, seqs[0], opt->read_len);
-    int r1 = bwa_read_seq_with_hash_dev(&ix, ks[1], batch, &n_seqs[1], opt->mode, opt->trim_qual, opt->frac, round, seqs[1], opt->read_len);
+    bwa_seq_t **seqs = sets[round & 1];
+    // the seed of --frac_samp's generator is PairEndMapper's `round` when the batch is READ: 0 for the first batch, and for every later
+    // one the value before the increment that follows the IO workers' start (src/BwtMapper.cpp:1973-1985): 0, 0, 1, 2, ...
+    const uint32_t read_round = round == 0 ? 0 : round - 1;
+    int r0 = bwa_read_seq_with_hash_dev(&ix, ks[0], batch, &n_seqs[0], opt->mode, opt->trim_qual, opt->frac, read_round, seqs[0], opt->read_len);
+    int r1 = bwa_read_seq_with_hash_dev(&ix, ks[1], batch, &n_seqs[1], opt->mode, opt->trim_qual, opt->frac, read_round, seqs[1], opt->read_len);
     if (r0 == 0 || r1 == 0) break;
     if (n_seqs[0] != n_seqs[1]) die("unequal mate counts");
     const int n = n_seqs[0];
@@ -388,10 +404,11 @@ static int cmd_align(int argc, char **argv) {
     ++round;
   }
   fprintf(st, "E pairs=%lld filtered=%lld unmapped=%lld\n", n_pairs_total, n_filtered, n_unmapped);
+  collector.AddFSC(FSC);
+  }
   fclose(st);
   if (fb) fclose(fb);
   fflush(stdout);
-  collector.AddFSC(FSC);
   fout.close();
   collector.ProcessCore(out, opt);   // src/BwtMapper.cpp:288
   return 0;

@@ -245,6 +245,28 @@ def add_se_outputs(tag):
     print(tag, "-> single-end goldens")
 
 
+FQLIST_CASES = ("qc",)
+
+
+def add_fqlist_outputs(tag):
+    """The reference on TWO FASTQ pairs in one run (a --fq_list of two lines: one StatCollector, one FileStatCollector per pair; driver
+    option --more): the case's reads cut in two halves, half_a_[12].fq and half_b_[12].fq (golden_util.split_halves).  Stored:
+    ref_fqlist.sam and the 13 QC files ref_fqlist.qc.* -- what a run sharded over two ranks by FASTQ pair must put together."""
+    import golden_util
+    out = os.path.join(HERE, tag)
+    with tempfile.TemporaryDirectory() as tmp:
+        g = golden_util.materialise(tag, tmp)
+        (a1, a2), (b1, b2) = golden_util.split_halves(g, tmp)
+        args = ["--batch", g["batch"], "--genome_size", g["genome_size"]] + (["--q", g["trim_qual"]] if g["trim_qual"] else []) + \
+               (["--read_len", g["qc_read_len"]] if g["qc_read_len"] != 151 else [])
+        ob.run_reference(g["prefix"], a1, a2, os.path.join(tmp, "fl_out"), "--more", b1 + "," + b2, *args)
+        files = [("fl_out.sam", "ref_fqlist.sam.gz")] + [("fl_out" + ext, "ref_fqlist.qc" + ext + ".gz") for ext in QC_OUT_EXT]
+        for src, dst in files:
+            with open(os.path.join(tmp, src), "rb") as fi, gzip.GzipFile(os.path.join(out, dst), "wb", mtime=0) as fo:
+                fo.write(fi.read())
+    print(tag, "-> two-pair (--fq_list) goldens")
+
+
 def main() -> None:
     if not os.path.exists(ob.REF_DRIVER):
         sys.exit("oracle/_ref/fq_ref_driver missing: run `make -C oracle ref` in the build container")
@@ -275,6 +297,9 @@ def main() -> None:
     for tag in SE_CASES:
         if not only or tag in only or "se" in only:
             add_se_outputs(tag)
+    for tag in FQLIST_CASES:
+        if not only or tag in only or "fqlist" in only:
+            add_fqlist_outputs(tag)
 
 
 if __name__ == "__main__":

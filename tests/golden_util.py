@@ -47,7 +47,7 @@ def materialise(tag: str, dst: str) -> dict:
             fo.write(fi.read())
         paths[name] = os.path.join(dst, name)
     for name in sorted(os.listdir(src)):      # StatCollector inputs next to the reference, and the QC files the reference wrote
-        if name.startswith("ref.FASTQuick.fa.") and name.endswith(".gz") or name.startswith(("ref.qc.", "ref.bam", "genome.fai", "ref_se.")):
+        if name.startswith("ref.FASTQuick.fa.") and name.endswith(".gz") or name.startswith(("ref.qc.", "ref.bam", "genome.fai", "ref_se.", "ref_fqlist.")):
             with gzip.open(os.path.join(src, name), "rb") as fi, open(os.path.join(dst, name[:-3]), "wb") as fo:
                 fo.write(fi.read())
     p = case_params(tag)
@@ -55,6 +55,23 @@ def materialise(tag: str, dst: str) -> dict:
     if os.path.exists(os.path.join(dst, "ref_se.sam")):      # the reference's single-end mapper on reads_1.fq alone
         p.update(se_stages=os.path.join(dst, "ref_se.stages"), se_sam=os.path.join(dst, "ref_se.sam"))
     return p
+
+
+def split_halves(g: dict, dst: str):
+    """The case's FASTQ pair cut into two pairs of files (first half of the records, the rest): the two lines of a --fq_list."""
+    out = []
+    texts = [open(g[k], "rb").read().split(b"\n") for k in ("fq1", "fq2")]
+    n = (len(texts[0]) - 1) // 4
+    cut = n // 2
+    for half, (lo, hi) in (("a", (0, cut)), ("b", (cut, n))):
+        paths = []
+        for e in range(2):
+            path = os.path.join(dst, "half_%s_%d.fq" % (half, e + 1))
+            with open(path, "wb") as fh:
+                fh.write(b"\n".join(texts[e][4 * lo:4 * hi]) + b"\n")
+            paths.append(path)
+        out.append(tuple(paths))
+    return out
 
 
 def se_case_tags() -> list:

@@ -78,3 +78,75 @@ SE_CONSUMER_TAGS = [t for t in golden_util.se_case_tags() if os.path.exists(os.p
 def test_single_end_qc_files_match_reference(tag, golden_cases, emu_lib):
     bad = qc_case(golden_cases[tag], emu_lib, se=True)
     assert not bad, explain(bad)
+
+
+def _diff(out, g, prefix):
+    bad = {}
+    for f in QC_FILES:
+        got, want = qc_bytes(out + "." + f), qc_bytes(os.path.join(g["dir"], prefix + f))
+        if got != want:
+            bad[f] = (got, want)
+    return bad
+
+
+@pytest.mark.parametrize("tag", ["qc", "basic", "edge"])
+def test_segments_of_one_stream_merge_to_the_references_files(tag, golden_cases, emu_lib):
+    """ONE FASTQ pair whose reference batches go to two shard consumers in turn (what two ranks of a sharded stream hold): every
+    batch's segment is exported, and the segments merged in batch order into a third consumer give the reference's 13 files."""
+    g = golden_cases[tag]
+    names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
+    ix = api.Index(g["prefix"], lib=emu_lib)
+    al = api.Aligner(ix, api.default_opts(emu_lib, trim_qual=g["trim_qual"]), max_pairs=max(16, g["batch"]))
+    kw = dict(genome_size=g["genome_size"], read_len=g["qc_read_len"])
+    shards = [api.QC(ix, g["prefix"], os.path.join(g["dir"], "shard%d" % r), **kw) for r in range(2)]
+    for q in shards:
+        q.begin_file(g["fq1"], g["fq2"])
+        q.state_reset()
+    root = api.QC(ix, g["prefix"], os.path.join(g["dir"], "merged"), **kw)
+    root.begin_file(g["fq1"], g["fq2"])
+    n, B = seq.shape[1], g["batch"]
+    for b, lo in enumerate(range(0, n, B)):
+        hi = min(n, lo + B)
+        al.align(seq[:, lo:hi], qual[:, lo:hi], lens[:, lo:hi], names[lo:hi])
+        q = shards[b % 2]
+        q.add(al)
+        root.merge(q.state_export())
+        q.state_reset()
+    root.end_file()
+    root.write()
+    bad = _diff(os.path.join(g["dir"], "merged"), g, "ref.qc.")
+    for q in shards + [root]:
+        q.close()
+    al.close(); ix.close()
+    assert not bad, explain(bad)
+
+
+def test_two_fastq_pairs_merge_to_the_references_files(golden_cases, emu_lib):
+    """The two lines of a --fq_list on two shard consumers (one FASTQ pair each, closed there); their states merged in list order
+    give what the reference writes for the two-pair run (tests/golden/qc/ref_fqlist.*)."""
+    g = golden_cases["qc"]
+    halves = golden_util.split_halves(g, g["dir"])
+    ix = api.Index(g["prefix"], lib=emu_lib)
+    kw = dict(genome_size=g["genome_size"], read_len=g["qc_read_len"])
+    root = api.QC(ix, g["prefix"], os.path.join(g["dir"], "merged_fl"), **kw)
+    sam = b""
+    for r, (f1, f2) in enumerate(halves):
+        names, seq, qual, lens = ob.read_fastq_pair(f1, f2)
+        al = api.Aligner(ix, api.default_opts(emu_lib, trim_qual=g["trim_qual"]), max_pairs=max(16, g["batch"]))
+        q = api.QC(ix, g["prefix"], os.path.join(g["dir"], "fl_shard%d" % r), **kw)
+        q.state_reset()
+        q.begin_file(f1, f2)
+        for lo in range(0, seq.shape[1], g["batch"]):
+            hi = min(seq.shape[1], lo + g["batch"])
+            al.align(seq[:, lo:hi], qual[:, lo:hi], lens[:, lo:hi], names[lo:hi])
+            q.add(al)
+            sam += al.sam_text()
+        q.end_file()
+        root.merge(q.state_export())
+        q.close(); al.close()
+    root.write()
+    bad = _diff(os.path.join(g["dir"], "merged_fl"), g, "ref_fqlist.qc.")
+    root.close(); ix.close()
+    assert not bad, explain(bad)
+    want = b"".join(l for l in open(os.path.join(g["dir"], "ref_fqlist.sam"), "rb").read().splitlines(keepends=True) if not l.startswith(b"@"))
+    assert sam == want
