@@ -37,7 +37,7 @@ class PackedBatch(C.Structure):
     _fields_ = [("n_pairs", C.c_int32), ("uniform_len", C.c_int32), ("head", C.c_void_p), ("body", C.c_void_p),
                 ("body_stride", C.c_int32), ("qual_stride", C.c_int32), ("len", C.c_void_p), ("exc", C.c_void_p),
                 ("n_exc", C.c_int64), ("qual", C.c_void_p), ("qual_last", C.c_void_p), ("names", C.c_void_p), ("name_stride", C.c_int32),
-                ("names_mate", C.c_void_p), ("serial", C.c_uint64)]
+                ("names_mate", C.c_void_p), ("serial", C.c_uint64), ("single_end", C.c_int32), ("pad_packed", C.c_int32)]
 
 
 class FastqRows(C.Structure):
@@ -91,7 +91,7 @@ EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destr
            "fq_index_n_contigs", "fq_index_contig", "fq_ctx_create", "fq_ctx_destroy", "fq_ctx_last_error",
            "fq_ctx_set_debug", "fq_align_batch", "fq_batch_upload", "fq_align_resident", "fq_sam_header",
            "fq_sam_format_last", "fq_stage_dump_last", "fq_stats_get", "fq_stats_reset", "fq_version",
-           "fq_pinned_alloc", "fq_pinned_free", "fq_pack_reads", "fq_packed_free", "fq_packed_create", "fq_pack_reads_into", "fq_packed_prefetch", "fq_packed_cancel", "fq_align_packed",
+           "fq_pinned_alloc", "fq_pinned_free", "fq_pack_reads", "fq_packed_free", "fq_packed_create", "fq_pack_reads_into", "fq_pack_single_reads_into", "fq_packed_prefetch", "fq_packed_cancel", "fq_align_packed",
            "fq_ctx_set_tuning", "fq_ctx_set_serial_hooks", "fq_ctx_state_export", "fq_ctx_state_import", "fq_qc_default_opts", "fq_qc_create", "fq_qc_destroy", "fq_qc_last_error", "fq_qc_begin_file",
            "fq_qc_add_last", "fq_qc_end_file", "fq_qc_write", "fq_qc_state_reset", "fq_qc_state_export", "fq_qc_merge", "fq_bam_create", "fq_bam_add_last", "fq_bam_close",
            "fq_fastq_open", "fq_fastq_configure", "fq_fastq_set_sampling", "fq_fastq_read", "fq_fastq_last_error", "fq_fastq_dropped_record", "fq_fastq_is_bgzf", "fq_fastq_close"]
@@ -143,6 +143,7 @@ def load_library(path: str | None = None):
     L.fq_packed_free.argtypes = [C.POINTER(PackedBatch)]
     L.fq_packed_create.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.POINTER(PackedBatch))]
     L.fq_pack_reads_into.argtypes = [C.POINTER(ReadBatch), C.c_int, C.POINTER(PackedBatch)]
+    L.fq_pack_single_reads_into.argtypes = [C.POINTER(ReadBatch), C.c_int, C.POINTER(PackedBatch)]
     L.fq_packed_cancel.argtypes = [C.c_void_p, C.POINTER(PackedBatch)]
     L.fq_packed_prefetch.argtypes = [C.c_void_p, C.POINTER(PackedBatch)]
     L.fq_align_packed.argtypes = [C.c_void_p, C.POINTER(PackedBatch), C.POINTER(ResultBatch)]
@@ -255,15 +256,20 @@ class HostPacked:
         b = ReadBatch(seq.shape[1], seq.shape[2], seq.ctypes.data, qual.ctypes.data, lens.ctypes.data,
                       nm.ctypes.data if nm is not None else None, 64, nm2.ctypes.data if nm2 is not None else None)
         self._keep = (seq, qual, lens, nm, nm2, b)
+        self.single_end = seq.shape[0] == 1          # rows [1][n][stride]: the reads of one file (BwtMapper::SingleEndMapper)
         self.p = C.POINTER(PackedBatch)()
-        rc = self.L.fq_pack_reads(C.byref(b), threads, C.byref(self.p))
+        if self.single_end:
+            rc = self.L.fq_packed_create(0, 0, C.byref(self.p)) or self.L.fq_pack_single_reads_into(C.byref(b), threads, self.p)
+        else:
+            rc = self.L.fq_pack_reads(C.byref(b), threads, C.byref(self.p))
         if rc:
             raise FastquickError("fq_pack_reads failed: %d" % rc)
         self.n_pairs = seq.shape[1]
 
     def repack(self, threads: int = 0) -> None:
         """Packs the same rows again into the batch's storage (fq_pack_reads_into): what a front end does with every new chunk."""
-        rc = self.L.fq_pack_reads_into(C.byref(self._keep[5]), threads, self.p)
+        fn = self.L.fq_pack_single_reads_into if self.single_end else self.L.fq_pack_reads_into
+        rc = fn(C.byref(self._keep[5]), threads, self.p)
         if rc:
             raise FastquickError("fq_pack_reads_into failed: %d" % rc)
 

@@ -756,7 +756,7 @@ int stage0_ascii(Call &K) {
 // ran under the previous call's kernels); the full rows -- and, when --q trimming is on, the qualities -- follow for the
 // reads of surviving pairs only, and are unpacked into the compact ASCII rows the later kernels read.
 int head_upload(fq_ctx *c, const fq_packed_batch_t *b, int slot) {
-  const size_t n2 = (size_t)b->n_pairs * 2;
+  const size_t n2 = (size_t)b->n_pairs * (b->single_end ? 1 : 2);   // rows the batch holds
   CKM(c->d_head[slot].ensure(n2 * 3 + 8));
   CK(fqdev::h2d_copy(c->d_head[slot].p, b->head, n2 * 24));
   c->stats.h2d_bytes += n2 * 24;
@@ -778,6 +778,10 @@ int stage0_packed(Call &K) {
   const fq_index *ix = c->ix;
   const fq_packed_batch_t &pb = c->pb;
   const int n = K.n, n2 = K.n2, n_sub = K.n_sub, B = K.B;
+  // A single-end batch (BwtMapper::SingleEndMapper) holds n reads in n rows; the pair machinery carries each read alone, the rows
+  // of the absent mates (n .. 2n-1) are filtered, empty reads, as in the ASCII path.
+  const bool se = c->o.single_end != 0;
+  const int n_in = se ? n : n2;                  // rows of the batch's arrays
   const bool ragged = pb.uniform_len <= 0;
   const bool trim = c->o.trim_qual >= 1;
   const int slot = c->head_slot;   // chosen by fq_align_packed: the buffer the batch was prefetched into, else a free one (uploaded now)
@@ -785,10 +789,11 @@ int stage0_packed(Call &K) {
   const bool have_qlast = trim && pb.qual_last != nullptr;
   CKM(c->d_filtered.ensure(n2 + 64) && c->d_read_list.ensure(n2) && c->d_sidx.ensure(n2) && c->d_pair_list.ensure(n) && c->d_sub_max.ensure((size_t)2 * n_sub));
   CK(fqdev::dzero(c->d_sub_max.p, (size_t)2 * n_sub * 4));
+  if (se) CK(fqdev::dfill(c->d_filtered.p + n, 1, (size_t)n));
   FqPrepPackedArgs a{};
   a.qual_last = have_qlast ? c->d_qlast[slot].p : nullptr; a.sub_whole = c->d_sub_max.p + n_sub;
   a.ix = ix->dev; a.o = c->ko; a.head = c->d_head[slot].p; a.len = ragged ? c->d_hlen[slot].p : nullptr; a.uniform_len = pb.uniform_len;
-  a.n_reads = n2; a.filtered = c->d_filtered.p; a.sub_max = c->d_sub_max.p; a.n_pairs = n; a.batch_pairs = B; a.counters = c->d_counters.p;
+  a.n_reads = n_in; a.filtered = c->d_filtered.p; a.sub_max = c->d_sub_max.p; a.n_pairs = n; a.batch_pairs = B; a.counters = c->d_counters.p;
   fqdev::time_begin(FQ_K_PREP);
   CK(fqdev::launch_prep_packed(a));
   CK(fqdev::launch_compact(c->d_filtered.p, n, c->d_read_list.p, c->d_sidx.p, c->d_pair_list.p, c->d_counts.p));
@@ -809,11 +814,11 @@ int stage0_packed(Call &K) {
     for (int sb = 0; sb < n_sub; ++sb)   // a ragged row longer than its packed row would be unpacked from its neighbour's bytes
       if (((int64_t)c->h_sub_max[sb] + 3) / 4 > (int64_t)pb.body_stride) { c->err = "a read is longer than body_stride holds"; return FQ_EINVAL; }
     c->n_bases_in = (int64_t)lcnt[0];
-  } else c->n_bases_in = (int64_t)n2 * pb.uniform_len;
+  } else c->n_bases_in = (int64_t)n_in * pb.uniform_len;
   const int n_search = counts[0], n_surv = counts[1], nrow = 2 * n_surv;
   K.n_search = n_search; K.n_surv = n_surv;
   const int64_t bulk_min = c->kn.packed_bulk_min >= 0 ? c->kn.packed_bulk_min : (int64_t)n / 8;
-  const bool bulk = n_surv > 0 && (int64_t)n_surv >= bulk_min;   // many survivors: upload the whole body, gather on the device
+  const bool bulk = !se && n_surv > 0 && (int64_t)n_surv >= bulk_min;   // many survivors: upload the whole body, gather on the device (single-end batches: rows gathered on the host, the absent mates' among them as empty rows)
   CKM(c->d_surv.ensure((size_t)nrow + 1) && c->d_row_map.ensure((size_t)nrow + 1) && c->d_len_c.ensure((size_t)nrow + 1) && c->d_len_trim.ensure((size_t)nrow + 1));
   const bool need_crow = bulk && pb.n_exc > 0;   // batch row -> compact row (-1: not unpacked), for the exception list of the whole batch
   if (need_crow) { CKM(c->d_crow.ensure(n2)); CK(fqdev::dfill(c->d_crow.p, 0xff, (size_t)n2 * 4)); }
@@ -855,15 +860,23 @@ int stage0_packed(Call &K) {
   } else if (nrow) {
     // few survivors: gather their rows into pinned staging on the host (a few thousand rows per reference batch in a WGS stream)
     CKM(c->p_body.ensure((size_t)nrow * body_stride + 64) && c->d_body.ensure((size_t)nrow * body_stride + 64));
-    if (ragged) CKM(c->p_hlen.ensure((size_t)nrow + 8) && c->d_blen.ensure((size_t)nrow + 8));
+    const bool row_lens = ragged || se;   // per-row lengths travel with the rows (single-end: the absent mates' rows have none)
+    if (row_lens) CKM(c->p_hlen.ensure((size_t)nrow + 8) && c->d_blen.ensure((size_t)nrow + 8));
     if (trim) CKM(c->p_pqual.ensure((size_t)nrow * pb.qual_stride + 64) && c->d_pqual.ensure((size_t)nrow * pb.qual_stride + 64));
     size_t ne = 0;
     vector<std::pair<size_t, size_t>> erange;   // exceptions of each compact row: [lo, hi) in pb.exc
     if (pb.n_exc) erange.resize(nrow);
     for (int t = 0; t < nrow; ++t) {
       const size_t r = (size_t)(t & 1) * (size_t)n + (size_t)c->h_pair_list[t >> 1];
+      if (se && (t & 1)) {   // the absent mate of a single-end read: an empty row
+        memset(c->p_body.p + (size_t)t * body_stride, 0, (size_t)body_stride);
+        c->p_hlen.p[t] = 0;
+        if (trim) memset(c->p_pqual.p + (size_t)t * pb.qual_stride, 0, (size_t)pb.qual_stride);
+        if (pb.n_exc) erange[t] = {0, 0};
+        continue;
+      }
       memcpy(c->p_body.p + (size_t)t * body_stride, pb.body + r * (size_t)body_stride, (size_t)body_stride);
-      if (ragged) c->p_hlen.p[t] = pb.len[r];
+      if (row_lens) c->p_hlen.p[t] = ragged ? pb.len[r] : (uint16_t)pb.uniform_len;
       if (trim) memcpy(c->p_pqual.p + (size_t)t * pb.qual_stride, pb.qual + r * (size_t)pb.qual_stride, (size_t)pb.qual_stride);
       if (pb.n_exc) {
         const uint64_t *lo = std::lower_bound(pb.exc, pb.exc + pb.n_exc, (uint64_t)r << 32);
@@ -875,7 +888,7 @@ int stage0_packed(Call &K) {
     CK(fqdev::copy_pinned(c->d_body.p, c->p_body.p, (size_t)nrow * body_stride, 1));
     c->stats.h2d_bytes += (size_t)nrow * body_stride;
     ua.body = c->d_body.p; ua.row_map = nullptr;
-    if (ragged) { CK(fqdev::copy_pinned(c->d_blen.p, c->p_hlen.p, (size_t)nrow * 2, 1)); ua.len = c->d_blen.p; c->stats.h2d_bytes += (size_t)nrow * 2; }
+    if (row_lens) { CK(fqdev::copy_pinned(c->d_blen.p, c->p_hlen.p, (size_t)nrow * 2, 1)); ua.len = c->d_blen.p; c->stats.h2d_bytes += (size_t)nrow * 2; }
     if (ne) {
       CKM(c->p_exc.ensure(ne + 1) && c->d_exc.ensure(ne + 1));
       size_t at = 0;
@@ -904,7 +917,7 @@ int stage0_packed(Call &K) {
   vector<int> surv_max(n_sub, 0);
   for (int t = 0; t < nrow; ++t) {
     const size_t r = (size_t)(t & 1) * (size_t)n + (size_t)c->h_pair_list[t >> 1];
-    const int full = ragged ? (int)pb.len[r] : pb.uniform_len;
+    const int full = se && (t & 1) ? 0 : ragged ? (int)pb.len[r] : pb.uniform_len;
     const int ltr = trim ? lt[t] : full;
     c->h_surv[t].len_trim = ltr;
     const int sb = c->h_pair_list[t >> 1] / B;
@@ -920,13 +933,14 @@ int stage0_packed(Call &K) {
   if (trim) for (int sb = 0; sb < n_sub; ++sb) if (surv_max[sb] < c->h_sub_max[sb]) need_all = true;
   c->h_filtered.clear(); c->h_len_trim.clear();
   if (need_all) {
-    CKM(c->d_pqual.ensure((size_t)n2 * pb.qual_stride + 64) && c->d_len_all.ensure(n2));
-    CK(fqdev::h2d(c->d_pqual.p, pb.qual, (size_t)n2 * pb.qual_stride));
-    c->stats.h2d_bytes += (size_t)n2 * pb.qual_stride;
+    CKM(c->d_pqual.ensure((size_t)n_in * pb.qual_stride + 64) && c->d_len_all.ensure(n2));
+    CK(fqdev::h2d(c->d_pqual.p, pb.qual, (size_t)n_in * pb.qual_stride));
+    c->stats.h2d_bytes += (size_t)n_in * pb.qual_stride;
     CK(fqdev::dzero(c->d_sub_max.p, (size_t)n_sub * 4));
+    if (se) CK(fqdev::dzero(c->d_len_all.p + n, (size_t)n * 4));
     FqTrimAllArgs aa{};
     aa.o = c->ko; aa.qual = c->d_pqual.p; aa.qual_stride = pb.qual_stride; aa.len = ragged ? c->d_hlen[slot].p : nullptr; aa.uniform_len = pb.uniform_len;
-    aa.n_reads = n2; aa.n_pairs = n; aa.batch_pairs = B; aa.len_trim = c->d_len_all.p; aa.sub_max = c->d_sub_max.p;
+    aa.n_reads = n_in; aa.n_pairs = n; aa.batch_pairs = B; aa.len_trim = c->d_len_all.p; aa.sub_max = c->d_sub_max.p;
     CK(fqdev::launch_trim_all(aa));
     CKS(d2h_staged(c, c->h_sub_max.data(), c->d_sub_max.p, (size_t)n_sub * 4));
     if (c->debug) { c->h_len_trim.resize(n2); CKS(d2h_staged(c, c->h_len_trim.data(), c->d_len_all.p, (size_t)n2 * 4)); }
@@ -938,7 +952,7 @@ int stage0_packed(Call &K) {
     c->h_filtered.resize(n2);
     CKS(d2h_staged(c, c->h_filtered.data(), c->d_filtered.p, n2));
     CKS(sync_staged(c));
-    if (c->h_len_trim.empty()) { c->h_len_trim.resize(n2); for (int r = 0; r < n2; ++r) c->h_len_trim[r] = ragged ? (int)pb.len[r] : pb.uniform_len; }
+    if (c->h_len_trim.empty()) { c->h_len_trim.resize(n2); for (int r = 0; r < n2; ++r) c->h_len_trim[r] = r >= n_in ? 0 : ragged ? (int)pb.len[r] : pb.uniform_len; }
   }
   stage0_sub_max(K);
   K.dseq = c->d_seq.p; K.dstride = cstride; K.dlen_trim = c->d_len_trim.p; K.dread_list = c->d_read_list.p;
@@ -1221,7 +1235,7 @@ void stage_records(Call &K) {
       p.reset();
       p.r = r;
       p.dr = packed ? 2 * sp + e : r;
-      p.full_len = packed ? (c->pb.uniform_len > 0 ? c->pb.uniform_len : (int)c->pb.len[r]) : (c->o.single_end && e == 1 ? 0 : c->hb.len[r]);
+      p.full_len = c->o.single_end && e == 1 ? 0 : packed ? (c->pb.uniform_len > 0 ? c->pb.uniform_len : (int)c->pb.len[r]) : c->hb.len[r];
       p.len = p.clip_len = si.len_trim;
       p.filtered = (uint8_t)si.filtered;
       p.extra_flag = c->o.single_end ? 0 : (1 | (e == 0 ? 64 : 128));   // SAM_FPD | SAM_FR1/FR2 (BwtMapper.cpp:749); the single-end mapper sets none
@@ -2108,6 +2122,7 @@ static int packed_check(fq_ctx_t *c, const fq_packed_batch_t *in) {
   if (in->uniform_len > 0 && (in->uniform_len < FQ_LMIN || in->uniform_len > FQ_LMAX || (in->uniform_len + 3) / 4 > in->body_stride)) { c->err = "read length outside [" + std::to_string(FQ_LMIN) + "," + std::to_string(FQ_LMAX) + "]"; return FQ_ELIMIT; }
   if (c->o.trim_qual >= 1 && in->n_pairs > 0 && (!in->qual || in->qual_stride < 1)) { c->err = "quality trimming needs the batch's qualities"; return FQ_EINVAL; }
   if (in->n_pairs > 0 && in->qual_last && !in->qual) { c->err = "qual_last without the quality rows"; return FQ_EINVAL; }
+  if ((in->single_end != 0) != (c->o.single_end != 0)) { c->err = c->o.single_end ? "a single-end context takes single-end batches (fq_pack_single_reads_into)" : "a paired-end context takes paired batches"; return FQ_EINVAL; }
   return FQ_OK;
 }
 extern "C" int fq_packed_prefetch(fq_ctx_t *c, const fq_packed_batch_t *next) {
@@ -2137,7 +2152,6 @@ extern "C" int fq_packed_cancel(fq_ctx_t *c, const fq_packed_batch_t *b) {
   return FQ_OK;
 }
 extern "C" int fq_align_packed(fq_ctx_t *c, const fq_packed_batch_t *in, fq_result_batch_t *out) {
-  if (c && c->o.single_end) { c->err = "single-end contexts take ASCII batches (fq_align_batch)"; return FQ_EINVAL; }
   if (!c || !out) return FQ_EINVAL;
   int rc = packed_check(c, in);
   if (rc) return broken_stream_call(c, rc);

@@ -278,6 +278,8 @@ int main(int argc, char **argv) {
     long long num_read = 0, filtered = 0, unmapped = 0;
     std::vector<char> sam;
     EndChunk bufs1[2];
+    fq_packed_batch_t *pk1 = nullptr;
+    if (fq_packed_create((int32_t)((A.chunk_pairs + 1) / 2), stride, &pk1)) die("out of pinned host memory for the packed batch");
     fill_chunk(r1, bufs1[0], A.chunk_pairs, stride, name_stride);
     for (int slot = 0;; slot ^= 1) {
       EndChunk &e0 = bufs1[slot];
@@ -289,8 +291,11 @@ int main(int argc, char **argv) {
       if (!last) prefetch = std::thread(fill_chunk, std::ref(r1), std::ref(bufs1[slot ^ 1]), A.chunk_pairs, stride, name_stride);
       fq_read_batch_t in = {n, stride, e0.seq.data(), e0.qual.data(), e0.len.data(), e0.names.data(), (int32_t)name_stride, nullptr};
       fq_result_batch_t res;
-      rc = fq_align_batch(ctx, &in, &res);
-      if (rc) die(std::string("fq_align_batch failed: ") + fq_ctx_last_error(ctx));
+      // the packed boundary, as for pairs: filter keys of every read cross PCIe, full rows of the surviving reads only
+      rc = fq_pack_single_reads_into(&in, A.pack_threads, pk1);
+      if (rc) die("fq_pack_single_reads_into failed (" + std::to_string(rc) + ")");
+      rc = fq_align_packed(ctx, pk1, &res);
+      if (rc) die(std::string("fq_align_packed failed: ") + fq_ctx_last_error(ctx));
       if (qc && (rc = fq_qc_add_last(qc, ctx))) die(std::string("QC consumer failed: ") + fq_qc_last_error(qc));
       if (A.sam_out) {
         const int64_t sz = fq_sam_format_last(ctx, nullptr, 0);
@@ -308,6 +313,7 @@ int main(int argc, char **argv) {
     notice("%lld sequences are unmapped.", unmapped);
     if (qc) fq_qc_end_file(qc);
     fq_ctx_destroy(ctx);
+    fq_packed_free(pk1);
     continue;
   }
   fprintf(stderr, "NOTICE - Processing Pair End mapping\t%s\t%s\n", A.fq1.c_str(), A.fq2.c_str());

@@ -143,10 +143,13 @@ extern "C" int fq_packed_create(int32_t max_pairs, int32_t max_len, fq_packed_ba
   return FQ_OK;
 }
 
-extern "C" int fq_pack_reads_into(const fq_read_batch_t *in, int threads, fq_packed_batch_t *dst) {
+static int pack_into(const fq_read_batch_t *in, int threads, fq_packed_batch_t *dst, int rows_per_pair);
+extern "C" int fq_pack_reads_into(const fq_read_batch_t *in, int threads, fq_packed_batch_t *dst) { return pack_into(in, threads, dst, 2); }
+extern "C" int fq_pack_single_reads_into(const fq_read_batch_t *in, int threads, fq_packed_batch_t *dst) { return pack_into(in, threads, dst, 1); }
+static int pack_into(const fq_read_batch_t *in, int threads, fq_packed_batch_t *dst, int rows_per_pair) {
   if (!in || !dst || in->n_pairs < 0 || !in->seq || !in->len || in->stride < 1) return FQ_EINVAL;
   Owned *o = reinterpret_cast<Owned *>(dst);
-  const size_t n2 = (size_t)in->n_pairs * 2;
+  const size_t n2 = (size_t)in->n_pairs * (size_t)rows_per_pair;   // rows of the batch
   if (threads < 1) threads = (int)std::min<unsigned>(8u, std::max(1u, std::thread::hardware_concurrency()));
   if (n2 < 65536) threads = 1;
   const int stride = in->stride;
@@ -208,6 +211,7 @@ extern "C" int fq_pack_reads_into(const fq_read_batch_t *in, int threads, fq_pac
   b.qual_last = qlast;
   b.head = head; b.body = body; b.len = len; b.exc = (const uint64_t *)o->exc; b.n_exc = (int64_t)ne;
   b.serial = g_serial.fetch_add(1, std::memory_order_relaxed);
+  b.single_end = rows_per_pair == 1 ? 1 : 0;
   return FQ_OK;
 }
 

@@ -58,7 +58,7 @@ typedef struct {
   int32_t single_end;         /* 1: BwtMapper::SingleEndMapper (src/BwtMapper.cpp:1266-1407) -- reads of one file.  A batch then
                                  holds n_pairs READS (rows [n_pairs][stride], len [n_pairs]; names_mate unused); a result keeps
                                  the pair layout with an empty record at 2*s+1; main hit and up to three alternative hits per read
-                                 (N_OCC, :33), no pairing, no mate rescue.  ASCII batches only (fq_align_batch / fq_batch_upload). */
+                                 (N_OCC, :33), no pairing, no mate rescue.  Packed batches: fq_pack_single_reads_into. */
   int32_t pad_opts;
 } fq_opts_t;
 
@@ -208,6 +208,8 @@ typedef struct {
   uint64_t serial;            /* identity of the CONTENT: the packer gives every packing a new value, so a batch object that is
                                  packed again is a new batch to fq_packed_prefetch / fq_align_packed.  A caller that fills a batch by
                                  hand sets a new non-zero value whenever it changes the arrays (0 = the object's address alone). */
+  int32_t single_end;         /* 1: a batch of n_pairs READS of one file (BwtMapper::SingleEndMapper): every array has n_pairs rows */
+  int32_t pad_packed;
 } fq_packed_batch_t;
 
 void *fq_pinned_alloc(size_t bytes);   /* page-locked host memory (hipHostMalloc); NULL on failure */
@@ -222,6 +224,8 @@ void fq_packed_free(fq_packed_batch_t *b);
  * context: align it (fq_align_packed) or fq_packed_cancel it first. */
 int fq_packed_create(int32_t max_pairs, int32_t max_len, fq_packed_batch_t **out);
 int fq_pack_reads_into(const fq_read_batch_t *in, int threads, fq_packed_batch_t *dst);
+/* The same for a batch of single-end reads (in->n_pairs reads in in->n_pairs rows): what a single-end context aligns. */
+int fq_pack_single_reads_into(const fq_read_batch_t *in, int threads, fq_packed_batch_t *dst);
 /* Starts the upload of `next`'s head on the context's copy stream and returns: it runs under the kernels of the
  * fq_align_packed call that follows for the current batch -- the overlap the reference gets from its IO worker reading
  * batch k+1 while batch k is aligned (IOworkerAlt, src/BwtMapper.cpp:1973-1980, 2095-2104).  Optional. */

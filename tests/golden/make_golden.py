@@ -267,6 +267,24 @@ def add_fqlist_outputs(tag):
     print(tag, "-> two-pair (--fq_list) goldens")
 
 
+FRAC_CASES = {"qc": 0.8}
+
+
+def add_frac_outputs(tag):
+    """The reference with --frac_samp (gap_opt_t::frac): its reader draws a number per record from Random(round) and drops the records
+    above the fraction (src/BwtMapper.cpp:500-507).  Stored: ref_frac.sam and the 13 QC files ref_frac.qc.* of the down-sampled run."""
+    import golden_util
+    out = os.path.join(HERE, tag)
+    with tempfile.TemporaryDirectory() as tmp:
+        g = golden_util.materialise(tag, tmp)
+        args = ["--batch", g["batch"], "--genome_size", g["genome_size"], "--frac_samp", FRAC_CASES[tag]] + (["--q", g["trim_qual"]] if g["trim_qual"] else [])
+        ob.run_reference(g["prefix"], g["fq1"], g["fq2"], os.path.join(tmp, "fr_out"), *args)
+        for src, dst in [("fr_out.sam", "ref_frac.sam.gz")] + [("fr_out" + ext, "ref_frac.qc" + ext + ".gz") for ext in QC_OUT_EXT]:
+            with open(os.path.join(tmp, src), "rb") as fi, gzip.GzipFile(os.path.join(out, dst), "wb", mtime=0) as fo:
+                fo.write(fi.read())
+    print(tag, "-> --frac_samp %g goldens" % FRAC_CASES[tag])
+
+
 def main() -> None:
     if not os.path.exists(ob.REF_DRIVER):
         sys.exit("oracle/_ref/fq_ref_driver missing: run `make -C oracle ref` in the build container")
@@ -297,6 +315,9 @@ def main() -> None:
     for tag in SE_CASES:
         if not only or tag in only or "se" in only:
             add_se_outputs(tag)
+    for tag in FRAC_CASES:
+        if not only or tag in only or "frac" in only:
+            add_frac_outputs(tag)
     for tag in FQLIST_CASES:
         if not only or tag in only or "fqlist" in only:
             add_fqlist_outputs(tag)

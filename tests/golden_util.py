@@ -47,7 +47,7 @@ def materialise(tag: str, dst: str) -> dict:
             fo.write(fi.read())
         paths[name] = os.path.join(dst, name)
     for name in sorted(os.listdir(src)):      # StatCollector inputs next to the reference, and the QC files the reference wrote
-        if name.startswith("ref.FASTQuick.fa.") and name.endswith(".gz") or name.startswith(("ref.qc.", "ref.bam", "genome.fai", "ref_se.", "ref_fqlist.")):
+        if name.startswith("ref.FASTQuick.fa.") and name.endswith(".gz") or name.startswith(("ref.qc.", "ref.bam", "genome.fai", "ref_se.", "ref_fqlist.", "ref_frac.")):
             with gzip.open(os.path.join(src, name), "rb") as fi, open(os.path.join(dst, name[:-3]), "wb") as fo:
                 fo.write(fi.read())
     p = case_params(tag)

@@ -61,3 +61,25 @@ def test_cli_single_end_sam_text(golden_cases, tmp_path):
     run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert run.returncode == 0, run.stderr.decode(errors="replace")[-2000:]
     assert run.stdout == open(g["se_sam"], "rb").read()
+
+
+def cli_frac_samp(exe, g, out, frac=0.8):
+    """--frac_samp: the reader drops the records the reference's generator drops; SAM text and QC files of the down-sampled run."""
+    prefix = g["prefix"][:-len(".FASTQuick.fa")]
+    cmd = [exe, "align", "--index_prefix", prefix, "--fastq_1", g["fq1"], "--fastq_2", g["fq2"], "--out_prefix", out, "--sam_out", "--frac_samp", str(frac),
+           "--batch_pairs", str(g["batch"]), "--chunk_pairs", str(2 * g["batch"]), "--q", str(g["trim_qual"])]
+    run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert run.returncode == 0, run.stderr.decode(errors="replace")[-2000:]
+    want = open(os.path.join(g["dir"], "ref_frac.sam"), "rb").read()
+    assert 0.6 * len(open(g["sam"], "rb").read()) < len(want) < 0.95 * len(open(g["sam"], "rb").read())
+    assert run.stdout == want
+    for f in QC_FILES:
+        if f in ("Summary", "FASTQ.csv"):
+            continue
+        assert qc_bytes(out + "." + f) == qc_bytes(os.path.join(g["dir"], "ref_frac.qc." + f)), f
+
+
+def test_cli_frac_samp(golden_cases, tmp_path):
+    emu = os.path.join(HERE, "emu")
+    subprocess.check_call(["make", "-s", "-C", emu, "libfq_emu.so", "FASTQuick_emu"])
+    cli_frac_samp(os.path.join(emu, "FASTQuick_emu"), golden_cases["qc"], str(tmp_path / "frac"))

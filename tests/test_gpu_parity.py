@@ -180,8 +180,9 @@ def test_cli_sam_out_matches_reference_golden(golden_cases, tmp_path):
             run = subprocess.run(cmd[:-4] + ["--batch_pairs", "128", "--chunk_pairs", "128"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
             assert run.returncode != 0 and b"same order" in run.stderr
     # without --sam_out: <out>.bam in genome coordinates and StatCollector's QC files, against the reference's
-    from test_cli_consumers import cli_bam_and_qc
+    from test_cli_consumers import cli_bam_and_qc, cli_frac_samp
     cli_bam_and_qc(exe, golden_cases["qc"], str(tmp_path / "cli_qc"))
+    cli_frac_samp(exe, golden_cases["qc"], str(tmp_path / "cli_frac"))      # --frac_samp 0.8 against the reference's down-sampled run
 
 
 # Non-default options, each against the oracle run with the same options (the oracle itself is pinned against the reference with
@@ -451,15 +452,17 @@ def test_ontarget_call_matches_oracle_on_a_prefix_of_two_batches(lib, tmp_path):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("packed", [False, True], ids=["ascii", "packed"])
 @pytest.mark.parametrize("tag", golden_util.se_case_tags())
-def test_gpu_single_end_matches_reference_golden(tag, golden_cases, lib):
-    """BwtMapper::SingleEndMapper (fq_opts_t::single_end) on the device: the first FASTQ of the case alone."""
+def test_gpu_single_end_matches_reference_golden(tag, packed, golden_cases, lib):
+    """BwtMapper::SingleEndMapper (fq_opts_t::single_end) on the device: the first FASTQ of the case alone, as ASCII batches and
+    through the packed boundary."""
     g = golden_cases[tag]
     names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
     ix = api.Index(g["prefix"], device=0)
     al = api.Aligner(ix, api.default_opts(lib, trim_qual=g["trim_qual"], single_end=1), max_pairs=max(16, g["batch"]), debug=True)
     st, sam = os.path.join(g["dir"], "gpu_se.stages"), os.path.join(g["dir"], "gpu_se.sam")
-    api.align_stream(al, list(names), seq[:1], qual[:1], lens[:1], g["batch"], st, sam)
+    api.align_stream(al, list(names), seq[:1], qual[:1], lens[:1], g["batch"], st, sam, packed=packed)
     stats = al.stats()
     al.close()
     ix.close()

@@ -196,15 +196,17 @@ def test_trimmed_max_len_of_filtered_reads(emu_lib, tmp_path):
     trimmed_max_len_case(emu_lib, tmp_path)
 
 
+@pytest.mark.parametrize("packed", [False, True], ids=["ascii", "packed"])
 @pytest.mark.parametrize("tag", golden_util.se_case_tags())
-def test_emulated_single_end_matches_reference_golden(tag, golden_cases, emu_lib):
-    """BwtMapper::SingleEndMapper (fq_opts_t::single_end): the first FASTQ of the case alone, against the reference's single-end run."""
+def test_emulated_single_end_matches_reference_golden(tag, packed, golden_cases, emu_lib):
+    """BwtMapper::SingleEndMapper (fq_opts_t::single_end): the first FASTQ of the case alone, against the reference's single-end run;
+    ASCII batches and the packed boundary (fq_pack_single_reads_into -> fq_align_packed)."""
     g = golden_cases[tag]
     names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
     ix = api.Index(g["prefix"], lib=emu_lib)
     al = api.Aligner(ix, api.default_opts(emu_lib, trim_qual=g["trim_qual"], single_end=1), max_pairs=max(16, g["batch"]), debug=True)
     st, sam = os.path.join(g["dir"], "emu_se.stages"), os.path.join(g["dir"], "emu_se.sam")
-    api.align_stream(al, list(names), seq[:1], qual[:1], lens[:1], g["batch"], st, sam)
+    api.align_stream(al, list(names), seq[:1], qual[:1], lens[:1], g["batch"], st, sam, packed=packed)
     al.close()
     ix.close()
     diffs = [d for d in ob.diff_stage_files(g["se_stages"], st)]

@@ -40,7 +40,7 @@ def qc_case(g, lib, device=None, packed=False, tuning=None, se=False):
     qc = api.QC(ix, g["prefix"], out, genome_size=g["genome_size"], read_len=g["qc_read_len"])
     qc.begin_file(g["fq1"], g["fq1"] if se else g["fq2"])     # FileStatCollector(fq1) names the one file twice
     if se:
-        api.align_stream(al, list(names), seq[:1], qual[:1], lens[:1], g["batch"], None, None, qc=qc)
+        api.align_stream(al, list(names), seq[:1], qual[:1], lens[:1], g["batch"], None, None, qc=qc, packed=packed)
     else:
         api.align_stream(al, names, seq, qual, lens, g["batch"], None, None, qc=qc, packed=packed)
     qc.end_file()
@@ -74,9 +74,10 @@ def test_qc_files_match_reference(tag, golden_cases, emu_lib):
 SE_CONSUMER_TAGS = [t for t in golden_util.se_case_tags() if os.path.exists(os.path.join(golden_util.GOLD, t, "ref_se.qc.Summary.gz"))]
 
 
+@pytest.mark.parametrize("packed", [False, True], ids=["ascii", "packed"])
 @pytest.mark.parametrize("tag", SE_CONSUMER_TAGS)
-def test_single_end_qc_files_match_reference(tag, golden_cases, emu_lib):
-    bad = qc_case(golden_cases[tag], emu_lib, se=True)
+def test_single_end_qc_files_match_reference(tag, packed, golden_cases, emu_lib):
+    bad = qc_case(golden_cases[tag], emu_lib, se=True, packed=packed)
     assert not bad, explain(bad)
 
 
