@@ -476,16 +476,16 @@ struct NodePin {
 // call of 4.2 M pairs on the 32-core host of an MI355X: 419 / 365 / 354 ms with 8 / 16 / 24 threads).  Calls of other contexts
 // in flight in this process share the cores: sixteen streams of 1 M-pair calls run 16.3 / 12.7 / 8.8 M pairs/s with 4 / 8 / 16
 // threads each, two streams of 4.2 M-pair calls 15.2 / 16.6 / 13.3 M pairs/s with 8 / 16 / 24 -- so twice the cores (a call waits for the device about half
-// of its time) are divided by the number of calls in flight when the call starts.  (Results do not depend on the number of threads.)
-static std::atomic<int> g_calls_in_flight{0};
-struct CallInFlight {
-  CallInFlight() { g_calls_in_flight.fetch_add(1, std::memory_order_relaxed); }
-  ~CallInFlight() { g_calls_in_flight.fetch_sub(1, std::memory_order_relaxed); }
+// of its time) are divided by the number of calls in flight (on the contexts of the same index) when the call starts.  (Results do not depend on the number of threads.)
+struct CallInFlight {      // counted on the index the contexts share: no process-wide state
+  const fq_index *ix;
+  explicit CallInFlight(const fq_index *i) : ix(i) { ix->calls_in_flight.fetch_add(1, std::memory_order_relaxed); }
+  ~CallInFlight() { ix->calls_in_flight.fetch_sub(1, std::memory_order_relaxed); }
 };
-inline int default_host_threads() {
+inline int default_host_threads(const fq_index *ix) {
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
   const unsigned cap = hw >= 32 ? 16u : std::min(8u, hw);
-  const unsigned share = 2 * hw / (unsigned)std::max(1, g_calls_in_flight.load(std::memory_order_relaxed));   // (a call waits for the device about half of its time)
+  const unsigned share = 2 * hw / (unsigned)std::max(1, ix->calls_in_flight.load(std::memory_order_relaxed));   // (a call waits for the device about half of its time)
   return (int)std::max(std::min(2u, cap), std::min(cap, share));
 }
 template <class F>
@@ -2039,7 +2039,7 @@ int run_call(fq_ctx *c, fq_result_batch_t *out) {
   return rc;
 }
 int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
-  CallInFlight in_flight;
+  CallInFlight in_flight(c->ix);
   Call K(c);
   K.t_trace = K.t_wall0 = now_ms();
   NodePin pin;
@@ -2057,7 +2057,7 @@ int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
   if (c->n_pairs == 0) { S.reads.clear(); return FQ_OK; }
   K.n = c->n_pairs; K.n2 = 2 * K.n; K.B = o.batch_pairs; K.n_sub = (K.n + K.B - 1) / K.B;
   K.par_min = c->kn.host_par_min;
-  K.host_threads = c->kn.host_threads >= 0 ? c->kn.host_threads : o.host_threads > 0 ? o.host_threads : default_host_threads();
+  K.host_threads = c->kn.host_threads >= 0 ? c->kn.host_threads : o.host_threads > 0 ? o.host_threads : default_host_threads(c->ix);
   int rc = c->in_kind == 2 ? stage0_packed(K) : stage0_ascii(K);
   if (rc) return rc;
   S.n_surv = K.n_surv;

@@ -109,17 +109,49 @@ int reg2bin(int64_t beg, int64_t end) {   // SAM specification 5.3
   if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
   return 0;
 }
+// The optional fields of a record.  The reference keeps them in SamRecord's hash of tags (LongHash<int> extras, 32 slots, slot =
+// key & mask with linear probing, key = type << 16 | tag[1] << 8 | tag[0]: misc/bam/SamRecord.h:629, VerifyBamID/statgen/LongHash.h)
+// and writes them to the record in slot order (setTagsInBuffer, misc/bam/SamRecord.cpp:3308-3340), not in the order SetSamRecord
+// adds them: AM MD NM RG SM, then the X? tags in the order they were added.  bytes() replays the insertions and walks the slots.
 struct Tags {
-  std::vector<uint8_t> b;
-  void key(const char *t, char type) { b.push_back((uint8_t)t[0]); b.push_back((uint8_t)t[1]); b.push_back((uint8_t)type); }
-  void z(const char *t, const std::string &v) { key(t, 'Z'); b.insert(b.end(), v.begin(), v.end()); b.push_back(0); }
-  void a(const char *t, char v) { key(t, 'A'); b.push_back((uint8_t)v); }
+  struct Entry { uint8_t t0, t1; std::vector<uint8_t> b; };
+  std::vector<Entry> list;           // in the order SetSamRecord adds them
+  std::vector<uint8_t> *cur = nullptr;
+  void key(const char *t, char type) {
+    list.push_back(Entry{(uint8_t)t[0], (uint8_t)t[1], {}});
+    cur = &list.back().b;
+    cur->push_back((uint8_t)t[0]); cur->push_back((uint8_t)t[1]); cur->push_back((uint8_t)type);
+  }
+  void z(const char *t, const std::string &v) { key(t, 'Z'); cur->insert(cur->end(), v.begin(), v.end()); cur->push_back(0); }
+  void a(const char *t, char v) { key(t, 'A'); cur->push_back((uint8_t)v); }
   void i(const char *t, long long v) {   // smallest integer type that holds the value
-    if (v >= 0 && v <= 255) { key(t, 'C'); b.push_back((uint8_t)v); }
-    else if (v >= -128 && v <= 127) { key(t, 'c'); b.push_back((uint8_t)(int8_t)v); }
-    else if (v >= 0 && v <= 65535) { key(t, 'S'); const uint16_t x = (uint16_t)v; b.insert(b.end(), (const uint8_t *)&x, (const uint8_t *)&x + 2); }
-    else if (v >= -32768 && v <= 32767) { key(t, 's'); const int16_t x = (int16_t)v; b.insert(b.end(), (const uint8_t *)&x, (const uint8_t *)&x + 2); }
-    else { key(t, 'i'); const int32_t x = (int32_t)v; b.insert(b.end(), (const uint8_t *)&x, (const uint8_t *)&x + 4); }
+    if (v >= 0 && v <= 255) { key(t, 'C'); cur->push_back((uint8_t)v); }
+    else if (v >= -128 && v <= 127) { key(t, 'c'); cur->push_back((uint8_t)(int8_t)v); }
+    else if (v >= 0 && v <= 65535) { key(t, 'S'); const uint16_t x = (uint16_t)v; cur->insert(cur->end(), (const uint8_t *)&x, (const uint8_t *)&x + 2); }
+    else if (v >= -32768 && v <= 32767) { key(t, 's'); const int16_t x = (int16_t)v; cur->insert(cur->end(), (const uint8_t *)&x, (const uint8_t *)&x + 2); }
+    else { key(t, 'i'); const int32_t x = (int32_t)v; cur->insert(cur->end(), (const uint8_t *)&x, (const uint8_t *)&x + 4); }
+  }
+  std::vector<uint8_t> bytes() const {
+    std::vector<int> slot(32, -1);
+    auto place = [&](std::vector<int> &tab, int e) {
+      const size_t mask = tab.size() - 1;
+      size_t h = list[(size_t)e].t0 & mask;      // (the table never outgrows 256 slots here: the key's low byte is the tag's first letter)
+      while (tab[h] >= 0) h = (h + 1) & mask;
+      tab[h] = e;
+    };
+    size_t count = 0;
+    for (size_t e = 0; e < list.size(); ++e) {
+      if (count * 2 > slot.size()) {               // LongHash::Add grows before it inserts; SetSize re-inserts in slot order
+        std::vector<int> bigger(slot.size() * 2, -1);
+        for (int old : slot) if (old >= 0) place(bigger, old);
+        slot.swap(bigger);
+      }
+      place(slot, (int)e);
+      ++count;
+    }
+    std::vector<uint8_t> out;
+    for (int e : slot) if (e >= 0) out.insert(out.end(), list[(size_t)e].b.begin(), list[(size_t)e].b.end());
+    return out;
   }
 };
 }  // namespace
@@ -246,7 +278,7 @@ void fq_bam::record(std::vector<uint8_t> &dst, const fq_opts_t *ao, const FqHost
     rec.push_back((uint8_t)(nib(seq[j]) << 4 | (j + 1 < seq.size() ? nib(seq[j + 1]) : 0)));
   }
   for (size_t j = 0; j < seq.size(); ++j) rec.push_back((uint8_t)(j < qual.size() ? qual[j] - 33 : 0xff));
-  rec.insert(rec.end(), T.b.begin(), T.b.end());
+  { const std::vector<uint8_t> tb = T.bytes(); rec.insert(rec.end(), tb.begin(), tb.end()); }
   const int32_t bs = (int32_t)rec.size();
   dst.insert(dst.end(), (const uint8_t *)&bs, (const uint8_t *)&bs + 4);
   dst.insert(dst.end(), rec.begin(), rec.end());

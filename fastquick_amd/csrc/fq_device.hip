@@ -67,6 +67,14 @@ static State *g_prep_owner[64];
 static hipStream_t g_copy_streams[64][2];
 static unsigned g_copy_next[64];
 static std::mutex g_turn_mu[64];   // device_turn_begin / device_turn_end
+// Hardware queues: every context drives a stream of its own, and the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware
+// queues (4 unless the variable says otherwise, read when the runtime initialises).  Contexts that share a queue wait for each
+// other's long kernels (16 streams on 16 queues: two share, and straggle by 25 %; 32 or more queues halve the throughput of 16
+// streams).  The library asks for 20 when it is loaded -- 16 contexts, two copy streams, two spare -- unless the caller has set a
+// value, and says so once when more contexts are created on a device than the queues in effect can keep apart.
+static int g_ctx_count[64];
+static bool g_queue_warned = false;
+__attribute__((constructor)) static void fq_queue_policy() { setenv("GPU_MAX_HW_QUEUES", "20", 0); }
 
 void device_turn_begin() { g_turn_mu[g_cur->device].lock(); }
 void device_turn_end() { g_turn_mu[g_cur->device].unlock(); }
@@ -80,6 +88,13 @@ State *state_create(int dev) {
   {
     std::lock_guard<std::mutex> lk(g_dev_mu);
     if (!g_dev_ready[dev]) { if (set_kernel_attributes()) return nullptr; g_dev_ready[dev] = true; }
+    const char *q = getenv("GPU_MAX_HW_QUEUES");
+    const int queues = q && atoi(q) > 0 ? atoi(q) : 4;
+    if (++g_ctx_count[dev] + 2 > queues && !g_queue_warned) {
+      g_queue_warned = true;
+      fprintf(stderr, "fastquick_amd: %d alignment contexts on device %d with GPU_MAX_HW_QUEUES=%d: contexts will share hardware queues and wait for each other's kernels "
+                      "(export GPU_MAX_HW_QUEUES = contexts + 4 before the process makes its first HIP call)\n", g_ctx_count[dev], dev, queues);
+    }
   }
   State *s = new State;
   s->device = dev;
@@ -104,6 +119,7 @@ void state_destroy(State *s) {
   {
     std::lock_guard<std::mutex> lk(g_dev_mu);
     if (g_prep_owner[s->device] == s) { g_prep_owner[s->device] = nullptr; g_prep_last[s->device] = nullptr; }
+    if (g_ctx_count[s->device] > 0) --g_ctx_count[s->device];
   }
   for (auto &p : s->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
   for (auto e : s->free_events) (void)hipEventDestroy(e);

@@ -1,5 +1,6 @@
 // fq_index.h -- host-side index object (parsed files + device-staged tables)
 #pragma once
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -32,6 +33,8 @@ struct fq_index {
   void *d_pac = nullptr;
   void *d_bitmap = nullptr;   // 6 x 2^29 bytes, contiguous
   int device = 0;
+  // calls in flight on the contexts of this index (they share the host's cores: fq_align.cpp, default_host_threads)
+  mutable std::atomic<int> calls_in_flight{0};
 };
 
 // bns_coor_pac2real (libbwa/bntseq.c:268-302)

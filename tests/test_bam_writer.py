@@ -36,7 +36,7 @@ def check_bgzf(path):
     assert raw[-28:] == bytes.fromhex("1f8b08040000000000ff0600424302001b0003000000000000000000"), "BGZF end-of-file block missing"
 
 
-def decode_bam(path):
+def decode_bam(path, sort_tags=True):
     data = gzip.open(path, "rb").read()      # concatenated gzip members
     assert data[:4] == b"BAM\x01"
     l_text = struct.unpack_from("<i", data, 4)[0]
@@ -80,7 +80,7 @@ def decode_bam(path):
                 p += struct.calcsize(fmt)
         rname = refs[rid][0] if rid >= 0 else "*"
         rnext = "*" if mrid < 0 else ("=" if mrid == rid else refs[mrid][0])
-        recs.append([name, str(flag), rname, str(pos + 1), str(mapq), cig, rnext, str(mpos + 1), str(tlen), seq, qual] + sorted(tags))
+        recs.append([name, str(flag), rname, str(pos + 1), str(mapq), cig, rnext, str(mpos + 1), str(tlen), seq, qual] + (sorted(tags) if sort_tags else tags))
         at = end
     return text, refs, recs
 
@@ -99,15 +99,14 @@ def bam_case(g, lib, device=None, packed=False, se=False):
     bam.close()
     al.close(); ix.close()
     check_bgzf(path)
-    text, refs, recs = decode_bam(path)
+    text, refs, recs = decode_bam(path, sort_tags=False)      # tags in file order: the reference writes them in its tag hash's slot order
     stem = "ref_se" if se else "ref"
     want_hdr = open(os.path.join(g["dir"], stem + ".bamhdr")).read()
     assert text == want_hdr, "header:\n%s\nvs the reference's\n%s" % (text, want_hdr)
     assert [r[0] for r in refs] == [l.split("\t")[1][3:] for l in want_hdr.splitlines() if l.startswith("@SQ")]
     want = []
     for line in open(os.path.join(g["dir"], stem + ".bamtxt")):
-        f = line.rstrip("\n").split("\t")
-        want.append(f[:11] + sorted(f[11:]))
+        want.append(line.rstrip("\n").split("\t"))
     assert len(recs) == len(want), "%d records vs %d" % (len(recs), len(want))
     for i, (a, b) in enumerate(zip(recs, want)):
         assert a == b, "record %d:\n got  %s\n want %s" % (i, "\t".join(a)[:400], "\t".join(b)[:400])

@@ -27,9 +27,9 @@ def cli_bam_and_qc(exe, g, out, se=False):
     assert run.returncode == 0, run.stderr.decode(errors="replace")[-2000:]
     assert run.stdout == b"", "no SAM text on stdout in BAM mode"
     check_bgzf(out + ".bam")
-    text, _refs, recs = decode_bam(out + ".bam")
+    text, _refs, recs = decode_bam(out + ".bam", sort_tags=False)
     assert text == open(os.path.join(g["dir"], stem + ".bamhdr")).read()
-    want = [(lambda f: f[:11] + sorted(f[11:]))(l.rstrip("\n").split("\t")) for l in open(os.path.join(g["dir"], stem + ".bamtxt"))]
+    want = [l.rstrip("\n").split("\t") for l in open(os.path.join(g["dir"], stem + ".bamtxt"))]
     assert recs == want
     for f in QC_FILES:
         if f in ("Summary", "FASTQ.csv"):    # (genome size: the three contigs of the .fai here, one genome in the golden run; file names)

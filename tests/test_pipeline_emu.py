@@ -81,6 +81,39 @@ def test_work_counters_match_the_oracle(mode, tuning, emu_lib, tmp_path):
         assert gs["stack_pops"] == oc["stack_pops"]
 
 
+def test_a_rejected_ragged_packed_batch_leaves_nothing_behind(golden_cases, emu_lib):
+    """A ragged packed batch with a read below the supported length is refused (FQ_ELIMIT); the batches after it on the same context
+    align as if it had never been seen (the device counters of the refused call are cleared), and a packed batch object that is
+    packed again is a new batch to the context (its serial changes)."""
+    g = golden_cases["trim76"]
+    names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
+    n = 64
+    seq, qual, lens, names = seq[:, :n].copy(), qual[:, :n].copy(), lens[:, :n].copy(), list(names[:n])
+    lens[0, 5] -= 3      # ragged
+    ix = api.Index(g["prefix"], lib=emu_lib)
+    al = api.Aligner(ix, api.default_opts(emu_lib, trim_qual=g["trim_qual"]), max_pairs=n)
+    good = api.HostPacked(seq, qual, lens, names, lib=emu_lib)
+    res = al.align_packed(good)
+    sam0, bases0 = al.sam_text(), res.n_bases
+    bad_lens = lens.copy()
+    bad_lens[1, 7] = 10
+    bad = api.HostPacked(seq, qual, bad_lens, names, lib=emu_lib)
+    with pytest.raises(api.FastquickError) as e:
+        al.align_packed(bad)
+    assert "read length outside" in str(e.value)
+    al2 = api.Aligner(ix, api.default_opts(emu_lib, trim_qual=g["trim_qual"]), max_pairs=n)     # a fresh stream for comparison
+    for _ in range(2):
+        al.prefetch(good)
+        good.repack()                                     # same object, packed again: the prefetched copy must not be taken for it
+        res = al.align_packed(good)
+        assert res.n_bases == bases0
+        res2 = al2.align_packed(good)
+        assert res2.n_bases == bases0
+    bad.free(); good.free()
+    al.close(); al2.close(); ix.close()
+    assert len(sam0) > 0
+
+
 def test_option_limits_are_rejected(golden_cases, emu_lib):
     import ctypes as C
     ix = api.Index(golden_cases["basic"]["prefix"], lib=emu_lib)
