@@ -419,7 +419,13 @@ def main() -> None:
                            "stack_pops_per_read": round(a2["stack_pops"] / max(1, a2["reads_searched"]), 1),
                            "occ_touches_per_read": round(a2["gap_occ_touches"] / max(1, a2["reads_searched"]), 1)}
         try:      # HBM-side bytes of the search stage from the committed PMC passes (FETCH_SIZE + WRITE_SIZE per searched read)
-            pmc2 = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["ontarget" + ("_packed" if args.boundary == "host" else "")]["fq_gap"]
+            pmc_all = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            key = "ontarget" + ("_packed" if args.boundary == "host" else "")
+            key4 = key + "_4m"      # the pass made at the headline call shape (4,194,304 pairs per call); smaller calls use the 1 M-pair pass
+            if args.ontarget_pairs >= 4194304 and key4 in pmc_all:
+                key = key4
+            pmc2 = pmc_all[key]["fq_gap"]
+            out["ontarget"]["kernel_rooflines"]["fq_gap"]["traffic_source"] = "profiles/pmc_traffic.json[%s]: FETCH_SIZE + WRITE_SIZE per searched read, measured at %d reads per launch" % (key, int(pmc2["units_per_launch"]))
             out["ontarget"]["kernel_rooflines"]["fq_gap"]["traffic_per_call"] = round(pmc2["bytes_per_unit"] * a2["reads_searched"] / leg["calls"], 1)
             out["ontarget"]["kernel_rooflines"]["fq_gap"]["alg_bytes_per_call"] = round(48.0 * a2["gap_occ_touches"] / leg["calls"], 1)
         except (OSError, KeyError, ValueError):

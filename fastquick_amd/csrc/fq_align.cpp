@@ -2032,6 +2032,7 @@ int run_call(fq_ctx *c, fq_result_batch_t *out) {
   }
   if (rc) {   // stage_finish zeroes the device counters after it has read them: a call that ends early must not leave its counts (lengths
               // out of range, bases, work counters) to the next one
+    fqdev::copy_discard();
     (void)fqdev::stream_aux(0);
     (void)fqdev::dzero(c->d_counters.p, FQ_C_COUNT * 8);
     (void)fqdev::sync();

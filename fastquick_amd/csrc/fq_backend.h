@@ -42,6 +42,7 @@ int sync();
 int h2d_copy(void *dst, const void *src, size_t bytes);
 int copy_record(int slot);
 int copy_wait(int slot);                 // host waits for the copies recorded for `slot`
+void copy_discard();                     // forget copy_pinned copies that were queued and not yet launched (a call that ends early)
 int compute_wait_copy(int slot);
 
 // HIP-event timing of everything enqueued between begin/end, accumulated per kernel id

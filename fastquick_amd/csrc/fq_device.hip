@@ -33,6 +33,9 @@ struct State {
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;
   hipEvent_t open_begin[16] = {};
+  struct SmallCopy { uint8_t *dst; const uint8_t *src; size_t bytes; };
+  SmallCopy small[8];                              // copy_pinned calls waiting for the next launch on the stream (copy_flush)
+  int n_small = 0;
   uint64_t *scan_tmp = nullptr; size_t scan_tmp_n = 0;
   uint32_t *cmp_cnt = nullptr; uint64_t *cmp_off = nullptr; size_t cmp_n = 0;
   Tune tune;
@@ -49,6 +52,10 @@ static thread_local std::string g_err;
       return -3;                                                                             \
     }                                                                                        \
   } while (0)
+
+int copy_flush();
+#define FQ_PRE() do { if (copy_flush()) return -3; } while (0)      // the queued small copies go first (copy_pinned)
+void copy_discard() { if (g_cur) g_cur->n_small = 0; }
 
 const char *last_error() { return g_err.c_str(); }
 bool is_real_gpu() { return true; }
@@ -150,12 +157,13 @@ void *hmalloc(size_t bytes) {
   return p;
 }
 void hfree(void *p) { if (p) (void)hipHostFree(p); }
-int h2d(void *dst, const void *src, size_t bytes) { if (bytes) FQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream)); return 0; }
-int d2h(void *dst, const void *src, size_t bytes) { if (bytes) FQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream)); return 0; }
-int dzero(void *dst, size_t bytes) { if (bytes) FQ_HIP(hipMemsetAsync(dst, 0, bytes, g_stream)); return 0; }
-int dfill(void *dst, int byte, size_t bytes) { if (bytes) FQ_HIP(hipMemsetAsync(dst, byte, bytes, g_stream)); return 0; }
-int sync() { FQ_HIP(hipStreamSynchronize(g_stream)); return 0; }
+int h2d(void *dst, const void *src, size_t bytes) { FQ_PRE(); if (bytes) FQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream)); return 0; }
+int d2h(void *dst, const void *src, size_t bytes) { FQ_PRE(); if (bytes) FQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream)); return 0; }
+int dzero(void *dst, size_t bytes) { FQ_PRE(); if (bytes) FQ_HIP(hipMemsetAsync(dst, 0, bytes, g_stream)); return 0; }
+int dfill(void *dst, int byte, size_t bytes) { FQ_PRE(); if (bytes) FQ_HIP(hipMemsetAsync(dst, byte, bytes, g_stream)); return 0; }
+int sync() { FQ_PRE(); FQ_HIP(hipStreamSynchronize(g_stream)); return 0; }
 int stream_aux(int on) {
+  FQ_PRE();
   if (on && !g_cur->aux_stream) {
     FQ_HIP(hipStreamCreateWithFlags(&g_cur->aux_stream, hipStreamNonBlocking));
     FQ_HIP(hipEventCreateWithFlags(&g_cur->fork_ev, hipEventDisableTiming));
@@ -165,12 +173,14 @@ int stream_aux(int on) {
   return 0;
 }
 int stream_fork() {
+  FQ_PRE();
   if (!g_cur->aux_stream) return 0;
   FQ_HIP(hipEventRecord(g_cur->fork_ev, g_cur->main_stream));
   FQ_HIP(hipStreamWaitEvent(g_cur->aux_stream, g_cur->fork_ev, 0));
   return 0;
 }
 int stream_join() {
+  FQ_PRE();
   if (!g_cur->aux_stream) return 0;
   FQ_HIP(hipEventRecord(g_cur->join_ev, g_cur->aux_stream));
   FQ_HIP(hipStreamWaitEvent(g_cur->main_stream, g_cur->join_ev, 0));
@@ -194,24 +204,47 @@ int h2d_copy(void *dst, const void *src, size_t bytes) {
 }
 int copy_record(int slot) { if (copy_stream_get()) return -3; FQ_HIP(hipEventRecord(g_cur->copy_done[slot & 1], g_cur->copy_stream)); return 0; }
 int copy_wait(int slot) { FQ_HIP(hipEventSynchronize(g_cur->copy_done[slot & 1])); return 0; }
-int compute_wait_copy(int slot) { FQ_HIP(hipStreamWaitEvent(g_stream, g_cur->copy_done[slot & 1], 0)); return 0; }
+int compute_wait_copy(int slot) { FQ_PRE(); FQ_HIP(hipStreamWaitEvent(g_stream, g_cur->copy_done[slot & 1], 0)); return 0; }
 
 // Small copies between pinned host memory and device memory by a kernel on the compute stream (the pinned range is mapped into
 // the device's address space): no DMA engine, no staging, one kernel launch of latency -- the per-stage lists of a call are a
 // few KB to a few hundred KB, and under load a hipMemcpyAsync + synchronize round trip for them cost milliseconds.
-__global__ void __launch_bounds__(256) k_copy_bytes(uint8_t *dst, const uint8_t *src, size_t bytes) {
+// The copies queued since the last launch go out as ONE kernel (blockIdx.y = which copy): a call makes a few dozen of them, and a
+// launch apiece was a dispatch slot each -- under sixteen streams they queued behind the other streams' long kernels.
+struct FqCopySet { uint8_t *dst[8]; const uint8_t *src[8]; size_t bytes[8]; };
+__global__ void __launch_bounds__(256) k_copy_bytes(FqCopySet cs) {
+  uint8_t *dst = cs.dst[blockIdx.y];
+  const uint8_t *src = cs.src[blockIdx.y];
+  const size_t bytes = cs.bytes[blockIdx.y];
   const size_t n16 = ((((uintptr_t)dst | (uintptr_t)src) & 15) == 0) ? bytes / 16 : 0;
   const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
   for (size_t i = t; i < n16; i += stride) ((uint4 *)dst)[i] = ((const uint4 *)src)[i];
   for (size_t i = n16 * 16 + t; i < bytes; i += stride) dst[i] = src[i];
 }
 static const size_t kSmallCopy = (size_t)8 << 20;
+// every entry point that puts work on the stream calls this first: the queued copies keep their place in stream order
+int copy_flush() {
+  State *s = g_cur;
+  if (!s || s->n_small == 0) return 0;
+  FqCopySet cs;
+  size_t most = 0;
+  for (int k = 0; k < 8; ++k) {
+    const bool on = k < s->n_small;
+    cs.dst[k] = on ? s->small[k].dst : nullptr; cs.src[k] = on ? s->small[k].src : nullptr; cs.bytes[k] = on ? s->small[k].bytes : 0;
+    if (on) most = std::max(most, s->small[k].bytes);
+  }
+  const int n = s->n_small;
+  s->n_small = 0;
+  const unsigned blocks = (unsigned)std::min<size_t>(256, (most / 16 + 255) / 256 + 1);
+  hipLaunchKernelGGL(k_copy_bytes, dim3(blocks, (unsigned)n), dim3(256), 0, s->stream, cs);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
 int copy_pinned(void *dst, const void *src, size_t bytes, int to_device) {
   if (!bytes) return 0;
-  if (bytes > kSmallCopy) { FQ_HIP(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, g_stream)); return 0; }
-  const unsigned blocks = (unsigned)std::min<size_t>(256, (bytes / 16 + 255) / 256 + 1);
-  hipLaunchKernelGGL(k_copy_bytes, dim3(blocks), dim3(256), 0, g_stream, (uint8_t *)dst, (const uint8_t *)src, bytes);
-  FQ_HIP(hipGetLastError());
+  if (bytes > kSmallCopy) { FQ_PRE(); FQ_HIP(hipMemcpyAsync(dst, src, bytes, to_device ? hipMemcpyHostToDevice : hipMemcpyDeviceToHost, g_stream)); return 0; }
+  if (g_cur->n_small == 8) FQ_PRE();
+  g_cur->small[g_cur->n_small++] = {(uint8_t *)dst, (const uint8_t *)src, bytes};
   return 0;
 }
 
@@ -222,8 +255,8 @@ static hipEvent_t get_event() {
   (void)hipEventCreate(&e);
   return e;
 }
-void time_begin(int kid) { hipEvent_t e = get_event(); (void)hipEventRecord(e, g_stream); g_cur->open_begin[kid] = e; }
-void time_end(int kid) { hipEvent_t e = get_event(); (void)hipEventRecord(e, g_stream); g_cur->pending.push_back({kid, g_cur->open_begin[kid], e}); }
+void time_begin(int kid) { (void)copy_flush(); hipEvent_t e = get_event(); (void)hipEventRecord(e, g_stream); g_cur->open_begin[kid] = e; }
+void time_end(int kid) { (void)copy_flush(); hipEvent_t e = get_event(); (void)hipEventRecord(e, g_stream); g_cur->pending.push_back({kid, g_cur->open_begin[kid], e}); }
 // start/stop events attached to one kernel (hipExtLaunchKernelGGL): the kernel's own begin/end timestamps, i.e. what
 // rocprofv3 --kernel-trace reports, unaffected by dispatch queueing when several streams share the GPU
 static void kernel_events(int kid, hipEvent_t *a, hipEvent_t *b) { *a = get_event(); *b = get_event(); g_cur->pending.push_back({kid, *a, *b}); }
@@ -666,6 +699,7 @@ __global__ void __launch_bounds__(256) k_scan_c(const uint32_t *in, uint32_t n, 
 #define g_scan_tmp (g_cur->scan_tmp)
 #define g_scan_tmp_n (g_cur->scan_tmp_n)
 int launch_scan(const uint32_t *in, uint64_t *out, uint32_t n) {
+  FQ_PRE();
   if (n == 0) { uint64_t z = 0; return h2d(out, &z, 8) ? -3 : sync(); }
   const unsigned nb = nblk(n, 256);
   if (g_scan_tmp_n < nb + 1) {
@@ -727,6 +761,7 @@ __global__ void __launch_bounds__(256) k_compact_c(const uint8_t *filt, int n_pa
 #define g_cmp_off (g_cur->cmp_off)
 #define g_cmp_n (g_cur->cmp_n)
 int launch_compact(const uint8_t *filtered, int n_pairs, int32_t *read_list, int32_t *sidx, int32_t *pair_list, int32_t *counts) {
+  FQ_PRE();
   if (n_pairs <= 0) return dzero(counts, 8);
   const unsigned nb = nblk((uint64_t)n_pairs, 256);
   if (g_cmp_n < nb) {
@@ -756,6 +791,7 @@ __global__ void __launch_bounds__(256) k_bitmap_scatter(uint8_t *bitmap, const u
   atomicOr((unsigned int *)(bitmap + ((x >> 5) << 2)), 1u << (x & 31));   // little endian: bit x&7 of byte x>>3
 }
 int launch_bitmap_scatter(uint8_t *bitmap, const uint32_t *bits, uint64_t n) {
+  FQ_PRE();
   if (!n) return 0;
   hipLaunchKernelGGL(k_bitmap_scatter, dim3(nblk(n, 256)), dim3(256), 0, g_stream, bitmap, bits, n);
   FQ_HIP(hipGetLastError());
@@ -768,6 +804,7 @@ int launch_bitmap_scatter(uint8_t *bitmap, const uint32_t *bits, uint64_t n) {
 // completion event, so they run back to back without a host round trip in between, while everything else a stream does
 // overlaps freely.  FQ_FILTER_NO_TURNS lets them overlap.
 int launch_prep(const FqPrepArgs &a) {
+  FQ_PRE();
   if (a.n_reads <= 0) return 0;
   hipEvent_t e0, e1;
   kernel_events(6, &e0, &e1);   // FQ_K_PREP_KERNEL
@@ -789,6 +826,7 @@ __global__ void __launch_bounds__(256) k_surv_gather(const int32_t *pair_list, i
   if (t < 2 * n_surv) fq_surv_gather_thread(pair_list, n_pairs, len_trim, filtered, sidx, out, t);
 }
 int launch_surv_gather(const int32_t *pair_list, int n_surv, int n_pairs, const int32_t *len_trim, const uint8_t *filtered, const int32_t *sidx, FqSurvInfo *out) {
+  FQ_PRE();
   if (n_surv <= 0) return 0;
   hipLaunchKernelGGL(k_surv_gather, dim3(nblk((uint64_t)n_surv * 2, 256)), dim3(256), 0, g_stream, pair_list, n_surv, n_pairs, len_trim, filtered, sidx, out);
   FQ_HIP(hipGetLastError());
@@ -799,6 +837,7 @@ __global__ void __launch_bounds__(256) k_prep_packed(FqPrepPackedArgs a) {
   if (r < a.n_reads) fq_prep_packed_thread(a, r);
 }
 int launch_prep_packed(const FqPrepPackedArgs &a) {
+  FQ_PRE();
   if (a.n_reads <= 0) return 0;
   hipEvent_t e0, e1;
   kernel_events(6, &e0, &e1);   // FQ_K_PREP_KERNEL
@@ -823,6 +862,7 @@ __global__ void __launch_bounds__(256) k_surv_map(const int32_t *pair_list, int 
 }
 int launch_surv_map(const int32_t *pair_list, int n_surv, int n_pairs, const uint8_t *filtered, const int32_t *sidx, FqSurvInfo *out,
                     int32_t *row_map, int32_t *read_list_c, int32_t *crow_of) {
+  FQ_PRE();
   if (n_surv <= 0) return 0;
   hipLaunchKernelGGL(k_surv_map, dim3(nblk((uint64_t)n_surv * 2, 256)), dim3(256), 0, g_stream, pair_list, n_surv, n_pairs, filtered, sidx, out, row_map, read_list_c, crow_of);
   FQ_HIP(hipGetLastError());
@@ -833,6 +873,7 @@ __global__ void __launch_bounds__(256) k_unpack(FqUnpackArgs a) {
   if (t < a.n_rows) fq_unpack_thread(a, t);
 }
 int launch_unpack(const FqUnpackArgs &a) {
+  FQ_PRE();
   if (a.n_rows <= 0) return 0;
   hipLaunchKernelGGL(k_unpack, dim3(nblk((uint64_t)a.n_rows, 256)), dim3(256), 0, g_stream, a);
   FQ_HIP(hipGetLastError());
@@ -843,6 +884,7 @@ __global__ void __launch_bounds__(256) k_patch(FqPatchArgs a) {
   if (q < a.n_exc) fq_patch_thread(a, q);
 }
 int launch_patch(const FqPatchArgs &a) {
+  FQ_PRE();
   if (a.n_exc <= 0) return 0;
   hipLaunchKernelGGL(k_patch, dim3(nblk((uint64_t)a.n_exc, 256)), dim3(256), 0, g_stream, a);
   FQ_HIP(hipGetLastError());
@@ -853,6 +895,7 @@ __global__ void __launch_bounds__(256) k_trim(FqTrimArgs a) {
   if (t < a.n_rows) fq_trim_thread(a, t);
 }
 int launch_trim(const FqTrimArgs &a) {
+  FQ_PRE();
   if (a.n_rows <= 0) return 0;
   hipLaunchKernelGGL(k_trim, dim3(nblk((uint64_t)a.n_rows, 256)), dim3(256), 0, g_stream, a);
   FQ_HIP(hipGetLastError());
@@ -863,12 +906,14 @@ __global__ void __launch_bounds__(256) k_trim_all(FqTrimAllArgs a) {
   if (r < a.n_reads) fq_trim_all_thread(a, r);
 }
 int launch_trim_all(const FqTrimAllArgs &a) {
+  FQ_PRE();
   if (a.n_reads <= 0) return 0;
   hipLaunchKernelGGL(k_trim_all, dim3(nblk((uint64_t)a.n_reads, 256)), dim3(256), 0, g_stream, a);
   FQ_HIP(hipGetLastError());
   return 0;
 }
 int launch_width(const FqWidthArgs &a) {
+  FQ_PRE();
   if (a.n_work <= 0) return 0;
   hipLaunchKernelGGL(k_width, dim3(nblk((uint64_t)a.n_work, 256)), dim3(256), 0, g_stream, a);
   FQ_HIP(hipGetLastError());
@@ -925,12 +970,14 @@ __global__ void __launch_bounds__(256) k_collect(const int32_t *order, const uin
   }
 }
 int launch_collect(const int32_t *order, const uint32_t *split, int n_work, int seg, int n_seg, const uint32_t *status, const int32_t *work, int32_t *out, uint32_t *count) {
+  FQ_PRE();
   if (n_work <= 0) return 0;
   hipLaunchKernelGGL(k_collect, dim3(1024), dim3(256), 0, g_stream, order, split, n_work, seg, n_seg, status, work, out, count);
   FQ_HIP(hipGetLastError());
   return 0;
 }
 int launch_order(const uint8_t *bid_end, int n, int n_hard, int32_t *order, uint32_t *cnt) {
+  FQ_PRE();
   if (n <= 0) return 0;
   FQ_HIP(hipMemsetAsync(cnt, 0, (2 * FQ_ORDER_KEYS + 1) * 4, g_stream));
   hipLaunchKernelGGL(k_order_count, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, bid_end, n, n_hard, cnt);
@@ -959,6 +1006,7 @@ int gap_lane_slots(const FqGapArgs &a) {
   return (int)(waves * 64u);
 }
 int launch_gap(const FqGapArgs &a_in) {
+  FQ_PRE();
   if (a_in.n_work <= 0) return 0;
   FqGapArgs a = a_in;
   const int env_refill = g_cur->tune.gap_refill_min;
@@ -980,24 +1028,28 @@ int launch_gap(const FqGapArgs &a_in) {
   return 0;
 }
 int launch_pack_aln(const FqAln *aln, const uint32_t *n_aln, const uint64_t *off, uint32_t cap, uint32_t n_work, FqAln *packed) {
+  FQ_PRE();
   if (!n_work) return 0;
   hipLaunchKernelGGL(k_pack_aln, dim3(nblk(n_work, 256)), dim3(256), 0, g_stream, aln, n_aln, off, cap, n_work, packed);
   FQ_HIP(hipGetLastError());
   return 0;
 }
 int launch_sa(const FqSaArgs &a) {
+  FQ_PRE();
   if (!a.n_rows) return 0;
   hipLaunchKernelGGL(k_sa, dim3(nblk(a.n_rows, 256)), dim3(256), 0, g_stream, a);
   FQ_HIP(hipGetLastError());
   return 0;
 }
 int launch_saq(const FqSaQueryArgs &a) {
+  FQ_PRE();
   if (!a.n) return 0;
   hipLaunchKernelGGL(k_saq, dim3(nblk(a.n, 256)), dim3(256), 0, g_stream, a);
   FQ_HIP(hipGetLastError());
   return 0;
 }
 int launch_pair(const FqPairArgs &a) {
+  FQ_PRE();
   if (a.n_jobs <= 0) return 0;
   hipLaunchKernelGGL(k_pair, dim3(nblk((uint64_t)a.n_jobs, 256)), dim3(256), 0, g_stream, a);
   FQ_HIP(hipGetLastError());
@@ -1005,6 +1057,7 @@ int launch_pair(const FqPairArgs &a) {
 }
 static const size_t kLdsBudget = 150 * 1024;
 int launch_sw(const FqSwArgs &a) {
+  FQ_PRE();
   if (a.n_task <= 0) return 0;
   size_t lds = (size_t)(2 * (a.RL + 2) + 3 * (a.RL + 1)) * 4 + ((a.RL + 16) & ~15) + ((a.QL + 16) & ~15) + ((a.RL + a.QL + 16) & ~15);
   if (lds > kLdsBudget) { g_err = "SW window too large for LDS (" + std::to_string(a.RL) + " bases)"; return -5; }
@@ -1023,12 +1076,14 @@ __global__ void __launch_bounds__(64) k_sw_thread(FqSwArgs a) {
   if (t < a.n_task) fq_sw_thread(a, t);
 }
 int launch_sw_serial(const FqSwArgs &a) {
+  FQ_PRE();
   if (a.n_task <= 0) return 0;
   hipLaunchKernelGGL(k_sw_thread, dim3(nblk((uint64_t)a.n_task, 64)), dim3(64), 0, g_stream, a);
   FQ_HIP(hipGetLastError());
   return 0;
 }
 int launch_refine(const FqRefineArgs &a) {
+  FQ_PRE();
   if (a.n_task <= 0) return 0;
   // one task per wavefront while row arrays + sequences + trace matrix fit in LDS with several blocks per CU; longer reads
   // fall back to one task per lane
@@ -1049,12 +1104,14 @@ int launch_refine(const FqRefineArgs &a) {
   return 0;
 }
 int launch_md(const FqMdArgs &a) {
+  FQ_PRE();
   if (a.n_task <= 0) return 0;
   hipLaunchKernelGGL(k_md, dim3(nblk((uint64_t)a.n_task, 256)), dim3(256), 0, g_stream, a);
   FQ_HIP(hipGetLastError());
   return 0;
 }
 int launch_pack_md(const char *src, const int32_t *len, const uint64_t *off, int32_t cap, int32_t n, char *dst) {
+  FQ_PRE();
   if (n <= 0) return 0;
   hipLaunchKernelGGL(k_pack_md, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, src, len, off, cap, n, dst);
   FQ_HIP(hipGetLastError());

@@ -2015,6 +2015,10 @@ FQ_HD void fq_sw_forward_seq(const uint8_t *ref, int len1, const uint8_t *qry, i
 // (:709-727), CIGAR + clipping + mismatch/gap counts (bwape.c:389-443).  H/E: len1+2 ints of scratch.
 // aln_local_core's reverse pass (stdaln.c:640-700): where the best local alignment starts.  Serial by nature: the band it
 // sweeps depends on the running maximum.
+// A row is walked four cells at a time: the cells' inputs from the row before (H[i], E[i + 1]) do not depend on the cells being
+// computed -- a cell writes H[i + 1] / E[i + 1], behind the ones still to be read -- so they are fetched together and the chain
+// through last_h / f runs out of registers; on the device the rows live in LDS, and a load per cell on the dependent chain was
+// most of the kernel's time (one lane walks this pass while the wavefront waits).
 FQ_HD void fq_sw_reverse(const uint8_t *ref, const uint8_t *qry, int score_f, int end_i, int end_j, int *H, int *E, int *start_i_out, int *start_j_out, int *score_r_out) {
   const int q = FQ_GAP_O, rr = FQ_GAP_E, qr = q + rr;
   for (int i = end_i; i >= 0; --i) H[i] = E[i] = 0;
@@ -2025,24 +2029,54 @@ FQ_HD void fq_sw_reverse(const uint8_t *ref, const uint8_t *qry, int score_f, in
     int start = end_i - 1, end = end_i - 3;
     if (end <= 0) end = 0;
     for (int j = end_j - 1; j != 0; --j) {
-      int last_h = 0, f = 0, i;
+      int last_h = 0, f = 0, i = start;
       bool stop = false;
       const int c2 = qry[j - 1];
-      for (i = start; i != end; --i) {
-        int h = H[i + 1] + fq_sm_maq(ref[i - 1], c2);
+      // one cell (stdaln.c:650-668): diag = H[i + 1], side = H[i], e_in = E[i + 1] of the row before
+      auto cell = [&](int ii, int diag, int side, int e_in, int &e_out) {
+        int h = diag + fq_sm_maq(ref[ii - 1], c2);
         if (h < 0) h = 0;
         if (last_h > 0) { f = f > last_h - q ? f - rr : last_h - qr; if (h < f) h = f; }
-        const int side = H[i];
-        int e = E[i + 1] > side - q ? E[i + 1] - rr : side - qr;
+        int e = e_in > side - q ? e_in - rr : side - qr;
         if (e < 0) e = 0;
         if (h < e) h = e;
-        H[i + 1] = last_h; E[i + 1] = e;
-        last_h = h;
-        if (score_r < h) {
-          score_r = h; start_i = i; start_j = j;
-          if (score_r - qr == score_f) { stop = true; break; }
+        e_out = e;
+        return h;
+      };
+      while (i - end >= 4 && !stop) {
+        const int d0 = H[i + 1], s0 = H[i], s1 = H[i - 1], s2 = H[i - 2], s3 = H[i - 3];
+        const int e0 = E[i + 1], e1 = E[i], e2 = E[i - 1], e3 = E[i - 2];
+        const int diag[4] = {d0, s0, s1, s2}, side[4] = {s0, s1, s2, s3}, ein[4] = {e0, e1, e2, e3};
+        int wh[4], we[4], done = 0;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (stop) break;
+          const int ii = i - u;
+          int e;
+          const int h = cell(ii, diag[u], side[u], ein[u], e);
+          wh[u] = last_h; we[u] = e;
+          last_h = h;
+          done = u + 1;
+          if (score_r < h) {
+            score_r = h; start_i = ii; start_j = j;
+            if (score_r - qr == score_f) stop = true;
+          }
         }
+        for (int u = 0; u < done; ++u) { H[i - u + 1] = wh[u]; E[i - u + 1] = we[u]; }
+        if (stop) { i -= done - 1; break; }      // (i = the cell that ended the pass, as the cell-by-cell loop leaves it)
+        i -= 4;
       }
+      if (!stop)
+        for (; i != end; --i) {
+          int e;
+          const int h = cell(i, H[i + 1], H[i], E[i + 1], e);
+          H[i + 1] = last_h; E[i + 1] = e;
+          last_h = h;
+          if (score_r < h) {
+            score_r = h; start_i = i; start_j = j;
+            if (score_r - qr == score_f) { stop = true; break; }
+          }
+        }
       H[i + 1] = last_h; E[i + 1] = 0;
       if (stop) break;
       if (H[start] <= qr) --start;

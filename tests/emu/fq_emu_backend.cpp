@@ -24,6 +24,7 @@ void device_turn_end() {}
 int h2d_copy(void *d, const void *s, size_t n) { if (n) memcpy(d, s, n); return 0; }
 int copy_record(int) { return 0; }
 int copy_wait(int) { return 0; }
+void copy_discard() {}
 int compute_wait_copy(int) { return 0; }
 const char *last_error() { return g_err.c_str(); }
 bool is_real_gpu() { return false; }
