@@ -136,7 +136,9 @@ struct FqKnobs {   // experiment / test knobs (fq_ctx_set_tuning); defaults are 
   int gap_no_order = 0;
   int device_turns = 2;            // calls that search at least gap_nogap_min reads take turns on the device: 1 = the search kernels, 2 = the width kernel too, 0 = off.
                                    // Two streams of 4.2 M-pair on-target calls: search kernels 54.1 / 41.7 / 38.8 ms per launch with 0 / 1 / 2 (38.8 alone), 16.8 / 16.3 / 16.7 M pairs/s
-  int gap_round2_waves = 2048;     // wavefronts of the round after the one without gap children (0: as many as fit): its reads are long searches, a trip of a
+  int gap_round1_refill = 0;       // experiment: refill group of the round without gap children (0: whole wavefronts)
+  int gap_round2_lane_major = 1;   // ... with every lane's stack pool contiguous (FqGapTier::lane_major)
+  int gap_round2_waves = 2560;     // wavefronts of the round after the one without gap children (0: as many as fit): its reads are long searches, a trip of a
                                    // wavefront costs more the more wavefronts share its SIMD, and the launch lasts as long as its longest search
   int sw_wave_max = 4096;          // largest mate-SW window the wavefront kernel takes
   int host_threads = -1;           // -1: fq_opts_t::host_threads
@@ -326,6 +328,8 @@ extern "C" int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t v) {
   else if (k == "gap_no_order") c->kn.gap_no_order = (int)v;
   else if (k == "device_turns") c->kn.device_turns = (int)v;
   else if (k == "gap_round2_waves") c->kn.gap_round2_waves = (int)v;
+  else if (k == "gap_round2_lane_major") c->kn.gap_round2_lane_major = (int)v;
+  else if (k == "gap_round1_refill") c->kn.gap_round1_refill = (int)v;
   else if (k == "sw_wave_max") c->kn.sw_wave_max = (int)v;
   else if (k == "host_threads") c->kn.host_threads = (int)v;
   else if (k == "host_par_min") c->kn.host_par_min = (size_t)v;
@@ -976,8 +980,8 @@ int stageA_search(Call &K) {
   // (tier 1 with push-time pruning, tier 2 exactly as the reference: no pruning, n_entries exact).  The wavefront kernel never
   // reuses pool slots, so its pools hold every push of a search, not just the live entries.
   const uint32_t exact_pool = (uint32_t)std::min<uint64_t>(4ull * (uint64_t)o.max_entries + 4096ull, 0x7fffffffull);
-  const FqGapTier lane_tier = {c->kn.gap_pool, 32u, 0, 0, c->kn.gap_long_pops, c->kn.gap_long_always, 0};
-  const FqGapTier wave_tier = {262144u, 512u, 0, 1, 0u, 0, 0}, exact_tier = {exact_pool, 8192u, 1, 1, 0u, 0, 0};
+  const FqGapTier lane_tier = {c->kn.gap_pool, 32u, 0, 0, c->kn.gap_long_pops, c->kn.gap_long_always, 0, 0};
+  const FqGapTier wave_tier = {262144u, 512u, 0, 1, 0u, 0, 0, 0}, exact_tier = {exact_pool, 8192u, 1, 1, 0u, 0, 0, 0};
   // scores that can occur for the longest read of this call (children may exceed max_diff by one difference)
   const int nb_need = (c->maxdiff_lut[max_len_all] + 1) * o.s_mm + o.max_gapo * o.s_gapo + o.max_gape * o.s_gape + 1;
   // A launch that fills the device begins with the round that searches without gap children (FqGapLane, NOGAP): the reads it
@@ -1043,8 +1047,9 @@ int stageA_search(Call &K) {
       // The round after the one without gap children holds the hard reads only: their lengths differ by orders of magnitude, so a
       // wavefront that waits for all 64 lanes before it refills idles most of them (28.9 -> 24.2 ms for the 228 k reads a 4.2 M-read
       // call leaves); the first round keeps whole-wavefront refill, its reads finish together (refill by 16: 23.8 -> 25.8 ms).
-      ga.refill_min = ran_nogap && !T.nogap && !T.coop ? 16 : 0;
+      ga.refill_min = ran_nogap && !T.nogap && !T.coop ? 16 : T.nogap ? c->kn.gap_round1_refill : 0;
       if (ran_nogap && !T.nogap && !T.coop && c->kn.gap_round2_waves > 0) ga.max_waves = c->kn.gap_round2_waves;
+      if (ran_nogap && !T.nogap && !T.coop) ga.tier.lane_major = c->kn.gap_round2_lane_major;
       // stack pools are the one large per-launch allocation (lanes x pool_cap x 16 B): when the device cannot hold them for
       // as many wavefronts as it could run, run fewer (the persistent lanes simply take more reads each)
       for (;;) {

@@ -114,6 +114,7 @@ struct FqGapTier {       // one launch configuration of the gap-search kernel
   int32_t long_always;   // test hook: give up after long_pops pops whatever the state of the queue
   int32_t nogap;         // lane kernel: 1 = first round of a large launch, the search without its gap children (see FqGapLane):
                          // a read whose result could depend on them is flagged FQ_SF_NEEDGAP and searched in full by the next round
+  int32_t lane_major;    // lane kernel: 1 = a lane's pool is contiguous (slot s at [s]) instead of interleaved with its wavefront's (slot s at [s * 64])
 };
 
 // SW / refine task descriptors

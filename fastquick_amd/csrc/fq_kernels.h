@@ -810,6 +810,7 @@ struct FqGapLane {
   int w, len, max_diff_opt, seed_off;                 // seed_off = len - seed_len (position ii = i - seed_off inside the seed)
   bool use_seed;
   FqEntry *pool;
+  uint32_t pstep = 1;                                 // pool slot s at pool[s * pstep]
   FqPos *prec;                                        // this read's position records, strand 0 (strand 1 at + pstride)
   uint32_t pw0, pw1, pw2, pw3;                        // window of eight position records, positions [wbase, wbase + 8)
   int wbase;
@@ -873,7 +874,13 @@ struct FqGapLane {
     // lane t at [s * 64 + t]): lanes that started together push and pop the same slots at about the same time, so a 128-byte line
     // holds one slot of eight neighbouring lanes instead of eight slots of one lane -- the pushes of a step reach memory as whole
     // lines, and the line a lane's pop brings in serves its neighbours' pops from the cache.
-    pool = A_.pool + (size_t)(lane_slot / FQ_WAVE_SIZE) * (size_t)A_.tier.pool_cap * FQ_WAVE_SIZE + (size_t)(lane_slot % FQ_WAVE_SIZE);
+    // (The round after the one without gap children holds unlike reads: their lanes do not push and pop in step, a slot's line is
+    // one lane's alone, and every 16-byte push and pop moved a line to or from HBM -- at the rate of random HBM accesses the round
+    // ran at.  There a lane's pool is contiguous (tier.lane_major): the children of a step share a line, and so do the entries
+    // popped after each other.)
+    pstep = A_.tier.lane_major ? 1u : (uint32_t)FQ_WAVE_SIZE;
+    pool = A_.tier.lane_major ? A_.pool + (size_t)lane_slot * (size_t)A_.tier.pool_cap
+                              : A_.pool + (size_t)(lane_slot / FQ_WAVE_SIZE) * (size_t)A_.tier.pool_cap * FQ_WAVE_SIZE + (size_t)(lane_slot % FQ_WAVE_SIZE);
     store.begin_lane(A_, lane_slot);
     m0 = m1 = m2 = m3 = bump = status = n_aln = 0; spare = FQ_NIL; n_live = 0;
     best_score = max_diff = best_cnt = 0; c_pops = c_pushes = c_touch = 0;
@@ -914,10 +921,10 @@ struct FqGapLane {
       typedef uint32_t fq_v4u __attribute__((ext_vector_type(4)));
       fq_v4u v;
       v.x = e.k; v.y = e.l; v.z = e.pk; v.w = e.next;
-      __builtin_nontemporal_store(v, (fq_v4u *)(pool + (size_t)slot * FQ_WAVE_SIZE));
-    } else pool[(size_t)slot * FQ_WAVE_SIZE] = e;
+      __builtin_nontemporal_store(v, (fq_v4u *)(pool + (size_t)slot * pstep));
+    } else pool[(size_t)slot * pstep] = e;
 #else
-    pool[(size_t)slot * FQ_WAVE_SIZE] = e;
+    pool[(size_t)slot * pstep] = e;
 #endif
     prev = slot;
     ++c_pushes; FQ_PROF(12);
@@ -991,7 +998,7 @@ struct FqGapLane {
     if (NOGAP) return;
     pf_slot = nslot;
     if (nslot != FQ_NIL) {
-      const FqU4 v = *(const FqU4 *)(pool + (size_t)nslot * FQ_WAVE_SIZE);
+      const FqU4 v = *(const FqU4 *)(pool + (size_t)nslot * pstep);
       pfk = v.x; pfl = v.y; pfpk = v.z; pfnext = v.w;
     }
   }
@@ -1024,7 +1031,7 @@ struct FqGapLane {
     const bool reload = !popping && (need_lo + sa < wbase || i0 - 1 + sa > wbase + 7);
     const int nb = i0 >= 8 ? ((i0 - 7) & ~1) : 0;                            // 4-byte aligned window holding i0-2 and i0-1
     const FqPos *pp = prec + (size_t)a * (size_t)A.pstride + nb;
-    const uintptr_t pa = (uintptr_t)fq_pick2p((uint64_t)(uintptr_t)(pool + (size_t)slot * FQ_WAVE_SIZE), (uint64_t)(uintptr_t)pp, popping ? 1 : 0);
+    const uintptr_t pa = (uintptr_t)fq_pick2p((uint64_t)(uintptr_t)(pool + (size_t)slot * pstep), (uint64_t)(uintptr_t)pp, popping ? 1 : 0);
     FqU4 vA;
     vA.x = vA.y = vA.z = vA.w = 0;
     if (popping || reload) vA = *(const FqU4 *)pa;
