@@ -365,29 +365,35 @@ def main() -> None:
     if world > 1 and args.stream_shard > 0 and args.mix == "wgs":
         Bs = 262144
         nb = args.stream_shard * world
-        al = api.Aligner(ix, max_pairs=Bs, tuning=tuning)
-        sh = fqd.StreamShard(al, rank, world)
-        sh.n_batches = nb
-        mine = [b for b in range(nb) if sh.owns(b)]
-        sp = {}
-        for b in mine:
-            bt = make_batch(Bs, 5000 + b, main_leg["on_frac"])
-            sp[b] = api.HostPacked(bt.seq, bt.qual, bt.lens, None)
-        recs = 0
+        shard_err, el, recs, sp, al = "", 0.0, 0, {}, None
+        try:      # (an extra leg: whatever goes wrong in it must not cost the run its headline line -- every rank reaches the barrier below)
+            al = api.Aligner(ix, max_pairs=Bs, tuning=tuning)
+            sh = fqd.StreamShard(al, rank, world)
+            sh.n_batches = nb
+            mine = [b for b in range(nb) if sh.owns(b)]
+            for b in mine:
+                bt = make_batch(Bs, 5000 + b, main_leg["on_frac"])
+                sp[b] = api.HostPacked(bt.seq, bt.qual, bt.lens, None)
+            sync_all()
+            t0 = time.perf_counter()
+            for b in mine:
+                sh.batch_index = b
+                recs += al.align_packed(sp[b]).n_survivors
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+        except Exception as e:      # noqa: BLE001
+            shard_err = repr(e)[:300]
         sync_all()
-        t0 = time.perf_counter()
-        for b in mine:
-            sh.batch_index = b
-            recs += al.align_packed(sp[b]).n_survivors
-        sync_all()
-        el = fqd.max_over_ranks(time.perf_counter() - t0)
-        tot = fqd.sum_counters({"survivor_pairs": recs})
+        el = fqd.max_over_ranks(el)
+        tot = fqd.sum_counters({"survivor_pairs": recs, "failed_ranks": 1 if shard_err else 0})
         if rank == 0:
-            out["stream_shard"] = {"value": round(nb * Bs / el, 1), "unit": "pairs/s", "batches": nb, "pairs_per_batch": Bs, "ranks": world, "s": round(el, 4),
-                                   "survivor_pairs": tot["survivor_pairs"], "note": "one FASTQ stream, batches dealt round-robin, state tokens over a gloo group"}
+            out["stream_shard"] = {"value": round(nb * Bs / el, 1) if el > 0 and not tot["failed_ranks"] else None, "unit": "pairs/s", "batches": nb, "pairs_per_batch": Bs,
+                                   "ranks": world, "s": round(el, 4), "survivor_pairs": tot["survivor_pairs"], "failed_ranks": tot["failed_ranks"], "error": shard_err,
+                                   "note": "one FASTQ stream, batches dealt round-robin, state tokens over a gloo group"}
         for p_ in sp.values():
             p_.free()
-        al.close()
+        if al is not None:
+            al.close()
     cpu_seq = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu_seq = cpu_batch.seq if cpu_batch.seq is not None else make_batch(args.pairs, 1000 + 17 * rank, main_leg["on_frac"]).seq

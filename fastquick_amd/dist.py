@@ -55,7 +55,8 @@ def token_group():
     a GPU stream that a kernel of the sending call could be ordered behind -- and under gloo over the default group."""
     global _token_group
     if dist.is_initialized() and dist.get_backend() == "nccl" and _token_group is None:
-        _token_group = dist.new_group(backend="gloo")
+        import datetime
+        _token_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=120))     # (a lost token raises instead of waiting for ever)
     return _token_group
 
 
