@@ -29,6 +29,7 @@
 #include "fq_backend.h"
 #include "fq_index.h"
 #include "fq_pipeline.h"
+#include "fq_pool.h"
 
 using std::vector;
 
@@ -148,6 +149,7 @@ struct FqKnobs {   // experiment / test knobs (fq_ctx_set_tuning); defaults are 
 };
 
 struct fq_ctx {
+  FqWorkPool pool;                     // the workers of this context's host phases (parallel_chunks on the calling thread)
   const fq_index *ix = nullptr;
   fq_opts_t o{};
   FqKOpts ko{};
@@ -488,15 +490,23 @@ struct CallInFlight {      // counted on the index the contexts share: no proces
 };
 inline int default_host_threads(const fq_index *ix) {
   const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  const unsigned cap = hw >= 32 ? 16u : std::min(8u, hw);
+  const unsigned cap = hw >= 128 ? 32u : hw >= 32 ? 16u : std::min(8u, hw);   // (one 4.2 M-pair call on a 2 x 64-core host: 430 / 331 / 339 / 614 ms with 24 / 32 / 48 / 64 threads, 354 with 16)
   const unsigned share = 2 * hw / (unsigned)std::max(1, ix->calls_in_flight.load(std::memory_order_relaxed));   // (a call waits for the device about half of its time)
   return (int)std::max(std::min(2u, cap), std::min(cap, share));
 }
+// The calling thread of a call hands its passes to the context's worker pool (run_call sets tl_pool); the side threads a call
+// starts (record set-up, the drand48 plan) have none and fork their own helpers, so that they never queue behind the main thread's.
+static thread_local FqWorkPool *tl_pool = nullptr;
 template <class F>
 void parallel_chunks(size_t n, int threads, size_t par_min, F fn) {   // fn(lo, hi, thread index); below par_min items the phase stays on the calling thread
   if (threads <= 1 || n < par_min) { fn((size_t)0, n, 0); return; }
-  std::vector<std::thread> th;
   const size_t per = (n + threads - 1) / threads;
+  const int chunks = (int)((n + per - 1) / per);
+  if (tl_pool) {
+    tl_pool->run(chunks, [&](int t) { const size_t lo = (size_t)t * per, hi = std::min(n, lo + per); if (lo < hi) fn(lo, hi, t); });
+    return;
+  }
+  std::vector<std::thread> th;
   for (int t = 0; t < threads; ++t) {
     const size_t lo = (size_t)t * per, hi = std::min(n, lo + per);
     if (lo >= hi) break;
@@ -1430,6 +1440,7 @@ int stageB1_main_hit(Call &K) {
     }
   };
   if (T == 1) choose(0, N, 0);
+  else if (tl_pool) tl_pool->run(T, [&](int t) { const size_t lo = (size_t)t * per, hi = std::min(N, lo + per); if (lo < hi) choose(lo, hi, t); });
   else {
     std::vector<std::thread> th;
     for (int t = 0; t < T; ++t) { const size_t lo = (size_t)t * per, hi = std::min(N, lo + per); if (lo < hi) th.emplace_back(choose, lo, hi, t); }
@@ -1472,9 +1483,12 @@ void stageB2_isize(Call &K) {
     std::vector<std::thread> th;
     const int T = (size_t)K.n_surv >= K.par_min ? std::min(K.host_threads, n_sub) : 1;
     auto work = [&](int t) { for (int sb = t; sb < n_sub; sb += T) infer_isize(R, K.sub_lo[sb], K.sub_lo[sb + 1], K.sub_max_len[sb], &raw[sb], o.ap_prior, (int64_t)c->ix->dev.fm[0].seq_len); };
-    for (int t = 1; t < T; ++t) th.emplace_back(work, t);
-    work(0);
-    for (auto &x : th) x.join();
+    if (tl_pool && T > 1) tl_pool->run(T, work);
+    else {
+      for (int t = 1; t < T; ++t) th.emplace_back(work, t);
+      work(0);
+      for (auto &x : th) x.join();
+    }
   }
   fq_isize_t prev = c->last_ii;
   for (int sb = 0; sb < n_sub; ++sb) {
@@ -2049,6 +2063,7 @@ int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
   Call K(c);
   K.t_trace = K.t_wall0 = now_ms();
   NodePin pin;
+  struct PoolScope { FqWorkPool *prev; explicit PoolScope(FqWorkPool *p) : prev(tl_pool) { tl_pool = p; } ~PoolScope() { tl_pool = prev; } } pool_scope(&c->pool);
   (void)fqdev::stream_aux(0);      // (an error return may have left the context on its second stream)
   if (c->kn.trace) { fprintf(stderr, "[fq]   arena: %zu blocks, last call used %zu bytes:", c->arena.blocks.size(), c->arena.total); for (auto &b : c->arena.blocks) fprintf(stderr, " %zu", b.cap); fprintf(stderr, "\n"); }
   c->arena.reset();

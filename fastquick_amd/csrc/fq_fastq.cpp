@@ -35,20 +35,15 @@
 #include <vector>
 
 #include "../../include/fastquick_amd.h"
+#include "fq_pool.h"
 
 namespace {
 template <class F>
-void par_for(int threads, size_t n, size_t min_per_thread, F fn) {   // fn(lo, hi, t) over [0, n)
-  int T = (int)std::min<size_t>((size_t)std::max(1, threads), std::max<size_t>(1, n / std::max<size_t>(1, min_per_thread)));
+void par_for(FqWorkPool &pool, int threads, size_t n, size_t min_per_thread, F fn) {   // fn(lo, hi, t) over [0, n), on the pool's workers
+  const int T = (int)std::min<size_t>((size_t)std::max(1, threads), std::max<size_t>(1, n / std::max<size_t>(1, min_per_thread)));
   if (T <= 1) { fn((size_t)0, n, 0); return; }
-  std::vector<std::thread> th;
   const size_t per = (n + T - 1) / T;
-  for (int t = 0; t < T; ++t) {
-    const size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per);
-    if (lo >= hi) break;
-    th.emplace_back([=]() { fn(lo, hi, t); });
-  }
-  for (auto &x : th) x.join();
+  pool.run(T, [&](int t) { const size_t lo = std::min(n, (size_t)t * per), hi = std::min(n, lo + per); if (lo < hi) fn(lo, hi, t); });
 }
 
 struct Block {                        // inflated text [data + head, data + head + n); `head` bytes of room in front for the carry
@@ -62,6 +57,7 @@ const size_t kHeadroom = 1 << 20;
 
 struct fq_fastq {
   std::string path, err;
+  FqWorkPool pool_in, pool_tok;       // workers of the producer thread's inflate and of the caller's tokenising (a pool runs one pass at a time)
   int threads = 1;
   size_t block_bytes = (size_t)16 << 20;
   // ---- source ----
@@ -200,7 +196,7 @@ inflate:
   std::atomic<int> bad{0};
   uint8_t *dst = b.data.get() + b.head;
   const uint8_t *src = r->cbuf.data();
-  par_for(r->threads, ms.size(), 4, [&](size_t lo, size_t hi, int) {
+  par_for(r->pool_in, r->threads, ms.size(), 4, [&](size_t lo, size_t hi, int) {
     z_stream zs;
     memset(&zs, 0, sizeof zs);
     if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
@@ -479,7 +475,7 @@ extern "C" int64_t fq_fastq_read(fq_fastq_t *r, int64_t max_reads, const fq_fast
       const size_t n = (size_t)(end - p0);
       const int T = (int)std::min<size_t>((size_t)r->threads, std::max<size_t>(1, n >> 20));
       part.resize((size_t)T);
-      par_for(T, (size_t)T, 1, [&](size_t lo, size_t hi, int) {
+      par_for(r->pool_tok, T, (size_t)T, 1, [&](size_t lo, size_t hi, int) {
         for (size_t t = lo; t < hi; ++t) {
           const size_t per = (n + T - 1) / T, a = std::min(n, t * per), b = std::min(n, a + per);
           std::vector<uint32_t> &v = part[t];
@@ -516,7 +512,7 @@ extern "C" int64_t fq_fastq_read(fq_fastq_t *r, int64_t max_reads, const fq_fast
     std::mutex err_mu;
     std::string emit_err;
     size_t emit_err_at = n_fast;
-    par_for(r->threads, n_fast, 2048, [&](size_t lo, size_t hi, int) {
+    par_for(r->pool_tok, r->threads, n_fast, 2048, [&](size_t lo, size_t hi, int) {
       std::string lerr;
       for (size_t i = lo; i < hi; ++i) {
         if (i >= first_bad.load(std::memory_order_relaxed)) break;
@@ -546,7 +542,7 @@ extern "C" int64_t fq_fastq_read(fq_fastq_t *r, int64_t max_reads, const fq_fast
       while (done < count) {
         const long long g0 = r->records_seen + (long long)done;
         const size_t w = std::min(count - done, W - (size_t)(g0 % (long long)W));
-        par_for(r->threads, w, 4096, [&](size_t lo, size_t hi, int) { for (size_t k = lo; k < hi; ++k) slot_apply(r, o, row0 + (int64_t)(done + k), g0 + (long long)k); });
+        par_for(r->pool_tok, r->threads, w, 4096, [&](size_t lo, size_t hi, int) { for (size_t k = lo; k < hi; ++k) slot_apply(r, o, row0 + (int64_t)(done + k), g0 + (long long)k); });
         done += w;
       }
       r->records_seen += (long long)count;

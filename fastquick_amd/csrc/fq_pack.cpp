@@ -17,12 +17,14 @@
 
 #include "../../include/fastquick_amd.h"
 #include "fq_backend.h"
+#include "fq_pool.h"
 
 namespace {
 struct Owned {                 // a packed batch and the pinned storage behind it
   fq_packed_batch_t b{};
   void *head = nullptr, *body = nullptr, *len = nullptr, *exc = nullptr, *qlast = nullptr;
   size_t cap_reads = 0, cap_body = 0, cap_exc = 0;   // capacities: reads (head, len, qlast), body bytes, exception entries
+  FqWorkPool pool;                                   // the packer's workers stay with the batch object it packs into
 };
 std::atomic<uint64_t> g_serial{1};   // every packing gets a new serial (fq_packed_batch_t::serial)
 
@@ -157,12 +159,7 @@ static int pack_into(const fq_read_batch_t *in, int threads, fq_packed_batch_t *
   std::vector<int> tmax((size_t)threads, 0), tmin((size_t)threads, 1 << 30);
   auto range = [&](int t, size_t *lo, size_t *hi) { const size_t per = (n2 + threads - 1) / threads; *lo = std::min(n2, (size_t)t * per); *hi = std::min(n2, *lo + per); };
   auto scan = [&](int t) { size_t lo, hi; range(t, &lo, &hi); int mx = 0, mn = 1 << 30; for (size_t r = lo; r < hi; ++r) { const int L = in->len[r]; mx = std::max(mx, L); mn = std::min(mn, L); } tmax[t] = mx; tmin[t] = mn; };
-  auto run = [&](auto fn) {
-    if (threads == 1) { fn(0); return; }
-    std::vector<std::thread> th;
-    for (int t = 0; t < threads; ++t) th.emplace_back(fn, t);
-    for (auto &x : th) x.join();
-  };
+  auto run = [&](auto fn) { o->pool.run(threads, fn); };
   run(scan);
   int max_len = 0, min_len = 1 << 30;
   for (int t = 0; t < threads; ++t) { max_len = std::max(max_len, tmax[t]); min_len = std::min(min_len, tmin[t]); }

@@ -28,6 +28,7 @@
 #include "fq_index.h"
 #include "fq_kernels.h"
 #include "fq_pipeline.h"
+#include "fq_pool.h"
 
 namespace {
 const int kInsertLimit = 4096;                 // INSERT_SIZE_LIMIT
@@ -187,6 +188,7 @@ struct fq_qc {
   struct ReadGeom;
   struct StatHist { size_t EmpRep[256] = {}, EmpCycle[256] = {}, misEmpRep[256] = {}, misEmpCycle[256] = {}; };
   std::vector<const FqRead *> stat_jobs;   // reads whose per-base statistics are still to be added (valid until the batch's records go away)
+  FqWorkPool pool;                         // ... and the workers they are spread over
   bool read_geom(const Rec &P, ReadGeom &g) const;
   void read_stats(const FqRead &p, const FqHostReads &hb, StatHist &h);
   void run_stat_jobs(const FqHostReads &hb, int threads);
@@ -356,10 +358,8 @@ void fq_qc::run_stat_jobs(const FqHostReads &hb, int threads) {
   auto work = [&](size_t lo, size_t hi, int t) { for (size_t j = lo; j < hi; ++j) read_stats(*stat_jobs[j], hb, hist[(size_t)t]); };
   if (T == 1) work(0, n, 0);
   else {
-    std::vector<std::thread> th;
     const size_t per = (n + (size_t)T - 1) / (size_t)T;
-    for (int t = 0; t < T; ++t) { const size_t lo = (size_t)t * per, hi = std::min(n, lo + per); if (lo < hi) th.emplace_back(work, lo, hi, t); }
-    for (auto &x : th) x.join();
+    pool.run(T, [&](int t) { const size_t lo = (size_t)t * per, hi = std::min(n, lo + per); if (lo < hi) work(lo, hi, t); });
   }
   for (const StatHist &h : hist)
     for (int v = 0; v < 256; ++v) { EmpRep[v] += h.EmpRep[v]; EmpCycle[v] += h.EmpCycle[v]; misEmpRep[v] += h.misEmpRep[v]; misEmpCycle[v] += h.misEmpCycle[v]; }
