@@ -297,6 +297,14 @@ struct FqQueueFetch {
 #else
 #define FQ_GAP_OCC
 #endif
+// -DFQ_NOGAP_WPE=n: the same for the round without gap children only (its lane state is smaller)
+#if defined(FQ_NOGAP_WPE)
+#define FQ_NOGAP_OCC __attribute__((amdgpu_waves_per_eu(FQ_NOGAP_WPE, FQ_NOGAP_WPE)))
+#define FQ_NOGAP_WAVES_PER_CU (4 * FQ_NOGAP_WPE)
+#else
+#define FQ_NOGAP_OCC FQ_GAP_OCC
+#define FQ_NOGAP_WAVES_PER_CU 16
+#endif
 struct FqQueueFetch2 {
   uint32_t *cursor;
   const uint32_t *split;
@@ -323,17 +331,28 @@ struct FqQueueFetch2 {
 // LDS per lane: n_buckets 16-bit bucket heads, lane-interleaved.
 __global__ void __launch_bounds__(64) FQ_GAP_OCC k_gap_persist_lds(FqGapArgs a) {
   uint16_t *heads = (uint16_t *)fq_dyn_lds;
-  FqGapStoreLds st = {heads + threadIdx.x, 64};
+  FqGapStoreLds st = {heads + threadIdx.x, 64, (uint32_t *)(heads + 64 * a.o.n_buckets) + threadIdx.x};
   fq_gap_lanes<false>(a, st, FQ_LANE_FETCH(a), (int)(blockIdx.x * 64 + threadIdx.x));
 }
 // first round of a device-filling launch: the search without its gap children (FqGapLane, NOGAP)
-__global__ void __launch_bounds__(64) FQ_GAP_OCC k_gap_nogap_lds(FqGapArgs a) {
+__global__ void __launch_bounds__(64) FQ_NOGAP_OCC k_gap_nogap_lds(FqGapArgs a) {
   uint16_t *heads = (uint16_t *)fq_dyn_lds;
-  FqGapStoreLds st = {heads + threadIdx.x, 64};
+  FqGapStoreLds st = {heads + threadIdx.x, 64, (uint32_t *)(heads + 64 * a.o.n_buckets) + threadIdx.x};
   fq_gap_lanes<true>(a, st, FQ_LANE_FETCH(a), (int)(blockIdx.x * 64 + threadIdx.x));
 }
+// the same two kernels for FASTQuick's own option block (FqOptsStock): options as constants
+__global__ void __launch_bounds__(64) FQ_GAP_OCC k_gap_persist_stock(FqGapArgs a) {
+  uint16_t *heads = (uint16_t *)fq_dyn_lds;
+  FqGapStoreLds st = {heads + threadIdx.x, 64, (uint32_t *)(heads + 64 * a.o.n_buckets) + threadIdx.x};
+  fq_gap_lanes<false, FqOptsStock>(a, st, FQ_LANE_FETCH(a), (int)(blockIdx.x * 64 + threadIdx.x));
+}
+__global__ void __launch_bounds__(64) FQ_NOGAP_OCC k_gap_nogap_stock(FqGapArgs a) {
+  uint16_t *heads = (uint16_t *)fq_dyn_lds;
+  FqGapStoreLds st = {heads + threadIdx.x, 64, (uint32_t *)(heads + 64 * a.o.n_buckets) + threadIdx.x};
+  fq_gap_lanes<true, FqOptsStock>(a, st, FQ_LANE_FETCH(a), (int)(blockIdx.x * 64 + threadIdx.x));
+}
 __global__ void __launch_bounds__(64) k_gap_persist(FqGapArgs a) {   // any pool size: bucket heads in HBM
-  FqGapStoreGlobal st = {nullptr};
+  FqGapStoreGlobal st = {nullptr, {}};
   fq_gap_lanes<false>(a, st, FQ_LANE_FETCH(a), (int)(blockIdx.x * 64 + threadIdx.x));
 }
 // one read per wavefront (long searches): run table of the read's score buckets in LDS
@@ -997,8 +1016,8 @@ int gap_lane_slots(const FqGapArgs &a) {
   const unsigned need = nblk((uint64_t)a.n_work, 64);
   unsigned per_cu = 8;
   if (a.tier.pool_cap <= 65535u) {
-    const size_t lds = (size_t)64 * (size_t)a.o.n_buckets * 2;
-    per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16, (150 * 1024) / lds));
+    const size_t lds = (size_t)64 * (size_t)a.o.n_buckets * 2 + (size_t)64 * FQ_COLD_N * 4;   // bucket heads + the lanes' cold words
+    per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(a.tier.nogap ? FQ_NOGAP_WAVES_PER_CU : 16, (150 * 1024) / lds));
   }
   if (env_waves > 0) per_cu = std::min<unsigned>(per_cu, (unsigned)env_waves);
   unsigned waves = std::min(need, 256u * per_cu);
@@ -1018,10 +1037,12 @@ int launch_gap(const FqGapArgs &a_in) {
     hipExtLaunchKernelGGL(k_gap_coop, dim3((unsigned)gap_lane_slots(a)), dim3(64), 0, g_stream, e0, e1, 0, a);
   } else {
     // LDS-resident bucket heads when slot indices fit 16 bits
-    const size_t lds = (size_t)64 * (size_t)a.o.n_buckets * 2;
+    const size_t lds = (size_t)64 * (size_t)a.o.n_buckets * 2 + (size_t)64 * FQ_COLD_N * 4;   // bucket heads + the lanes' cold words
     const unsigned grid = (unsigned)gap_lane_slots(a) / 64u;
-    if (a.tier.pool_cap <= 65535u && a.tier.nogap) hipExtLaunchKernelGGL(k_gap_nogap_lds, dim3(grid), dim3(64), lds, g_stream, e0, e1, 0, a);
-    else if (a.tier.pool_cap <= 65535u) hipExtLaunchKernelGGL(k_gap_persist_lds, dim3(grid), dim3(64), lds, g_stream, e0, e1, 0, a);
+    if (a.tier.exact) { g_err = "launch_gap: the exact tier is the wavefront kernel's"; return -1; }
+    const bool stock = FqOptsStock::matches(a.o) && !g_cur->tune.gap_generic_opts;
+    if (a.tier.pool_cap <= 65535u && a.tier.nogap) hipExtLaunchKernelGGL(stock ? k_gap_nogap_stock : k_gap_nogap_lds, dim3(grid), dim3(64), lds, g_stream, e0, e1, 0, a);
+    else if (a.tier.pool_cap <= 65535u) hipExtLaunchKernelGGL(stock ? k_gap_persist_stock : k_gap_persist_lds, dim3(grid), dim3(64), lds, g_stream, e0, e1, 0, a);
     else hipExtLaunchKernelGGL(k_gap_persist, dim3(grid), dim3(64), 0, g_stream, e0, e1, 0, a);
   }
   FQ_HIP(hipGetLastError());

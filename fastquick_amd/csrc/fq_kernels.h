@@ -727,8 +727,13 @@ FQ_HD void fq_seg_range(uint32_t len, int seg, int n_seg, uint32_t *lo, uint32_t
 }
 // Where a read's bucket heads live during the search: HBM (any pool size) or lane-interleaved LDS with 16-bit slots
 // (pool <= 65535 entries), which takes the head read-modify-write of every push off the global-memory latency chain.
+// The lane's seldom-touched state lives beside the heads (FqGapLane: store.cold(i)): a register each in the HBM-heads variant,
+// lane-interleaved LDS words in the other.
+enum { FQ_COLD_TPOPS, FQ_COLD_TPUSHES, FQ_COLD_TTOUCH, FQ_COLD_TMAXPOPS, FQ_COLD_TGT4K, FQ_COLD_W, FQ_COLD_MAXDIFF_OPT, FQ_COLD_BEST_CNT, FQ_COLD_N };
 struct FqGapStoreGlobal {
   uint32_t *head;
+  uint32_t cold_[FQ_COLD_N];
+  FQ_HD uint32_t &cold(int i) { return cold_[i]; }
   FQ_HD void begin_lane(const FqGapArgs &A, int lane_slot) { head = A.heads + (size_t)lane_slot * FQ_MAX_BUCKETS; }
   FQ_HD uint32_t head_get(int b) const { return head[b]; }
   FQ_HD void head_set(int b, uint32_t slot) const { head[b] = slot; }
@@ -736,6 +741,8 @@ struct FqGapStoreGlobal {
 struct FqGapStoreLds {
   uint16_t *head;       // element b at head[b*stride]
   int stride;
+  uint32_t *coldp;      // word i at coldp[i*stride]
+  FQ_HD uint32_t &cold(int i) const { return coldp[i * stride]; }
   FQ_HD void begin_lane(const FqGapArgs &, int) {}
   FQ_HD uint32_t head_get(int b) const { return head[b * stride]; }
   FQ_HD void head_set(int b, uint32_t slot) const { head[b * stride] = (uint16_t)slot; }
@@ -760,8 +767,9 @@ struct FqGapStoreLds {
 #define FQ_REFILL_MIN 64  // idle lanes of a wavefront wait until this many can be (re)initialised together (64: whole wavefront)
 // test-only instrumentation hooks (tests/emu builds may define FQ_PROFILE; empty in the product)
 #if defined(FQ_PROFILE) && !defined(__HIP_DEVICE_COMPILE__)
-extern unsigned long long fq_prof[64];
-#define FQ_PROF(i) (++fq_prof[i])
+extern unsigned long long fq_prof[128];
+extern int fq_prof_off;   // 0: full search, 32: the round without gap children, 64: wavefront-per-read kernel
+#define FQ_PROF(i) (++fq_prof[fq_prof_off + (i)])
 #else
 #define FQ_PROF(i) ((void)0)
 #endif
@@ -796,19 +804,42 @@ extern unsigned long long fq_prof[64];
 // n_live; any other read (no hit below s_gapo, a pop from a bucket >= s_gapo, non-stop mode) is flagged FQ_SF_NEEDGAP and
 // searched again, in full, by the next round.  The step of this round has no gap group: three quarters of the pushes and a
 // third of the instructions of the first walk down a read are gone.
-template <class St, bool NOGAP = false>
+// Opt: where the lane reads the search options from.  FqKOpts: the launch's option block (any options).  FqOptsStock: FASTQuick's own
+// option block (fq_default_opts; BwtMapper's defaults) as compile-time constants -- the command line has no switch for most of
+// them, so this is the kernel a FASTQuick run executes.  The options then cost no scalar registers (the generic kernel keeps ~100
+// uniform values alive across its loop and spills 70-90 of them to vector-register lanes) and their tests fold away.
+struct FqOptsStock {
+  static constexpr int32_t s_mm = 3, s_gapo = 11, s_gape = 4, mode = FQ_MODE_GAPE | FQ_MODE_COMPREAD;
+  static constexpr int32_t indel_end_skip = 5, max_del_occ = 10, max_entries = 2000000;
+  static constexpr int32_t max_gapo = 1, max_gape = 6, max_seed_diff = 2, seed_len = 32, max_top2 = 30;
+  FQ_HD FqOptsStock() {}
+  FQ_HD FqOptsStock(const FqKOpts &) {}
+  static bool matches(const FqKOpts &k) {   // host side: may this launch use the stock kernel?
+    return k.s_mm == s_mm && k.s_gapo == s_gapo && k.s_gape == s_gape && (k.mode & (FQ_MODE_GAPE | FQ_MODE_LOGGAP | FQ_MODE_NONSTOP)) == (mode & (FQ_MODE_GAPE | FQ_MODE_LOGGAP | FQ_MODE_NONSTOP)) &&
+           k.indel_end_skip == indel_end_skip && k.max_del_occ == max_del_occ && k.max_entries == max_entries && k.max_gapo == max_gapo && k.max_gape == max_gape &&
+           k.max_seed_diff == max_seed_diff && k.seed_len == seed_len && k.max_top2 == max_top2;
+  }
+};
+// In the round without gap children only buckets below s_gapo + s_mm are ever occupied: with the stock options one mask word.
+template <class O> struct FqNogapOneWord { static constexpr bool value = false; };
+template <> struct FqNogapOneWord<FqOptsStock> { static constexpr bool value = FqOptsStock::s_gapo + FqOptsStock::s_mm <= 32; };
+template <class St, bool NOGAP = false, class Opt = FqKOpts>
 struct FqGapLane {
+  static constexpr bool kOneWord = NOGAP && FqNogapOneWord<Opt>::value;
   const FqGapArgs &A;
   St store;
-  FqKOpts o;
-  bool gape_mode, nonstop, exact;
+  Opt o;
+  bool gape_mode, nonstop;
+  static constexpr bool exact = false;   // the exact tier (no push-time pruning) is the wavefront kernel's: launch_gap refuses it here
   uint32_t seq_len, L2_0, L2_1, L2_2, L2_3;          // identical for both strands (checked at index load)
-  const FqOccBlk *blk0, *blk1;
+  const FqOccBlk *blk_s0;                             // the table strand 0 walks (the reversed text's: bwtgap.c:148)
+  ptrdiff_t blk_delta;                                // strand 1's table, in bytes from blk_s0
   uint32_t primary0, primary1;
   // per-read constants
   bool active, done;
-  int w, len, max_diff_opt, seed_off;                 // seed_off = len - seed_len (position ii = i - seed_off inside the seed)
-  bool use_seed;
+  int len;                                            // (position ii = i - (len - seed_len) inside the seed)
+  // (the work item, max_diff as the options give it, best_cnt and the lane's totals are touched once or twice per read: they live with
+  //  the bucket heads -- store.cold(FQ_COLD_*) -- and leave their registers to the loop)
   FqEntry *pool;
   uint32_t pstep = 1;                                 // pool slot s at pool[s * pstep]
   FqPos *prec;                                        // this read's position records, strand 0 (strand 1 at + pstride)
@@ -817,7 +848,7 @@ struct FqGapLane {
   // search state
   uint32_t m0, m1, m2, m3, bump, spare, status, n_aln;
   int32_t n_live;
-  int best_score, max_diff, best_cnt;
+  int best_score, max_diff;
   uint32_t c_pops, c_pushes, c_touch;
   // current entry (valid when has_cur or hit_pending)
   bool has_cur, tail, hit_pending, too_many_n;
@@ -830,10 +861,10 @@ struct FqGapLane {
   // (Fetching the entry's window of position records ahead as well was tried: loads return in order, so the extra request only
   // moves the wait into the next trip -- 19.1 -> 21.7 ms for the second round of an on-target call.)
   uint32_t pf_slot = FQ_NIL, pfk = 0, pfl = 0, pfpk = 0, pfnext = 0;
-  uint32_t t_pops = 0, t_pushes = 0, t_touch = 0;   // totals over this lane's completed searches (a lane's share of a launch: 32 bits)
-  uint32_t t_maxpops = 0, t_gt4k = 0;
   FQ_HD void flush_counters() {   // at the end of the wavefront's life
 #if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t t_pops = store.cold(FQ_COLD_TPOPS), t_pushes = store.cold(FQ_COLD_TPUSHES), t_touch = store.cold(FQ_COLD_TTOUCH);
+    const uint32_t t_maxpops = store.cold(FQ_COLD_TMAXPOPS), t_gt4k = store.cold(FQ_COLD_TGT4K);
     uint64_t v[3] = {t_pops, t_pushes, t_touch};
     uint32_t mx = t_maxpops, g4 = t_gt4k;
     for (int d = 32; d >= 1; d >>= 1) {
@@ -854,6 +885,8 @@ struct FqGapLane {
       if (g4) FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS_GT4K], g4);
     }
 #else
+    const uint32_t t_pops = store.cold(FQ_COLD_TPOPS), t_pushes = store.cold(FQ_COLD_TPUSHES), t_touch = store.cold(FQ_COLD_TTOUCH);
+    const uint32_t t_maxpops = store.cold(FQ_COLD_TMAXPOPS), t_gt4k = store.cold(FQ_COLD_TGT4K);
     FQ_ATOMIC_ADD64(&A.counters[FQ_C_POPS], t_pops);
     FQ_ATOMIC_ADD64(&A.counters[FQ_C_PUSHES], t_pushes);
     FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_GAP], t_touch);
@@ -864,11 +897,12 @@ struct FqGapLane {
   }
 
   FQ_HD FqGapLane(const FqGapArgs &A_, const St &st, int lane_slot) : A(A_), store(st), o(A_.o) {
-    gape_mode = (o.mode & FQ_MODE_GAPE) != 0; nonstop = (o.mode & FQ_MODE_NONSTOP) != 0; exact = A_.tier.exact != 0;
+    gape_mode = (o.mode & FQ_MODE_GAPE) != 0; nonstop = (o.mode & FQ_MODE_NONSTOP) != 0;
     const FqFM &f0 = A_.ix.fm[0], &f1 = A_.ix.fm[1];
     seq_len = f0.seq_len; L2_0 = f0.L2[0]; L2_1 = f0.L2[1]; L2_2 = f0.L2[2]; L2_3 = f0.L2[3];
-    blk0 = f0.blk; blk1 = f1.blk; primary0 = f0.primary; primary1 = f1.primary;
-    active = done = false; w = len = max_diff_opt = seed_off = 0; use_seed = false;
+    blk_s0 = f1.blk; blk_delta = (const char *)f0.blk - (const char *)f1.blk; primary0 = f0.primary; primary1 = f1.primary;
+    active = done = false; len = 0;
+    for (int q = 0; q < FQ_COLD_N; ++q) store.cold(q) = 0;
     prec = A_.prec; pw0 = pw1 = pw2 = pw3 = 0; wbase = 0x7fff;
     // Stack storage belongs to the lane, not to the read.  The pools of a wavefront's lanes are interleaved entry by entry (slot s of
     // lane t at [s * 64 + t]): lanes that started together push and pop the same slots at about the same time, so a 128-byte line
@@ -883,7 +917,7 @@ struct FqGapLane {
                               : A_.pool + (size_t)(lane_slot / FQ_WAVE_SIZE) * (size_t)A_.tier.pool_cap * FQ_WAVE_SIZE + (size_t)(lane_slot % FQ_WAVE_SIZE);
     store.begin_lane(A_, lane_slot);
     m0 = m1 = m2 = m3 = bump = status = n_aln = 0; spare = FQ_NIL; n_live = 0;
-    best_score = max_diff = best_cnt = 0; c_pops = c_pushes = c_touch = 0;
+    best_score = max_diff = 0; c_pops = c_pushes = c_touch = 0;
     has_cur = tail = hit_pending = too_many_n = false; ck_ = cl_ = cpk = 0; cscore = 0;
   }
   // both blocks of the work queue handed out (the cursors overshoot their block's length once it is exhausted)
@@ -891,9 +925,17 @@ struct FqGapLane {
     const uint32_t sp = A.split ? *A.split : (uint32_t)A.n_work;
     return FQ_LOAD_RELAXED(A.queue) >= sp && FQ_LOAD_RELAXED(A.queue + 1) >= (uint32_t)A.n_work - sp;
   }
-  FQ_HD bool bucket_test(int b) const { return ((fq_sel4v(m0, m1, m2, m3, b >> 5) >> (b & 31)) & 1u) != 0; }
-  FQ_HD void bucket_set(int b) { const uint32_t bit = 1u << (b & 31); const int q = b >> 5; m0 |= bit & (0u - (uint32_t)(q == 0)); m1 |= bit & (0u - (uint32_t)(q == 1)); m2 |= bit & (0u - (uint32_t)(q == 2)); m3 |= bit & (0u - (uint32_t)(q == 3)); }
-  FQ_HD void bucket_clr(int b) { const uint32_t bit = 1u << (b & 31); const int q = b >> 5; m0 &= ~(bit & (0u - (uint32_t)(q == 0))); m1 &= ~(bit & (0u - (uint32_t)(q == 1))); m2 &= ~(bit & (0u - (uint32_t)(q == 2))); m3 &= ~(bit & (0u - (uint32_t)(q == 3))); }
+  FQ_HD bool bucket_test(int b) const { if constexpr (kOneWord) return ((m0 >> b) & 1u) != 0; else return ((fq_sel4v(m0, m1, m2, m3, b >> 5) >> (b & 31)) & 1u) != 0; }
+  FQ_HD void bucket_set(int b) {
+    if constexpr (kOneWord) m0 |= 1u << b;
+    else { const uint32_t bit = 1u << (b & 31); const int q = b >> 5; m0 |= bit & (0u - (uint32_t)(q == 0)); m1 |= bit & (0u - (uint32_t)(q == 1)); m2 |= bit & (0u - (uint32_t)(q == 2)); m3 |= bit & (0u - (uint32_t)(q == 3)); }
+  }
+  FQ_HD void bucket_clr(int b) {
+    if constexpr (kOneWord) m0 &= ~(1u << b);
+    else { const uint32_t bit = 1u << (b & 31); const int q = b >> 5; m0 &= ~(bit & (0u - (uint32_t)(q == 0))); m1 &= ~(bit & (0u - (uint32_t)(q == 1))); m2 &= ~(bit & (0u - (uint32_t)(q == 2))); m3 &= ~(bit & (0u - (uint32_t)(q == 3))); }
+  }
+  FQ_HD bool stack_empty() const { if constexpr (kOneWord) return m0 == 0; else return (m0 | m1 | m2 | m3) == 0; }
+  FQ_HD int lowest_bucket() const { if constexpr (kOneWord) return FQ_CTZ32(m0); else return m0 ? FQ_CTZ32(m0) : m1 ? 32 + FQ_CTZ32(m1) : m2 ? 64 + FQ_CTZ32(m2) : 96 + FQ_CTZ32(m3); }
 
   // ---- grouped push: children that share a score bucket -----------------------------------------------------------------
   // Non-exact tiers drop, at push time, children the reference would pop only to discard (see FqGapArgs).
@@ -935,30 +977,30 @@ struct FqGapLane {
     // failed reads are re-run in a larger tier; expose no partial list
     if (NOGAP && status == 0 && !(n_aln > 0 && !nonstop && best_score + o.s_mm < o.s_gapo) && !too_many_n) status |= FQ_SF_NEEDGAP;
     if (NOGAP && (status & FQ_SF_NEEDGAP) && n_aln == 0) status |= FQ_SF_NOHIT;   // scheduling hint for the next round (fq_order_key)
+    const int w = (int)store.cold(FQ_COLD_W);
     A.n_aln[w] = status ? 0u : n_aln;
     A.status[w] = status;
     if (status == 0) {   // work counters describe completed searches only: a read that is searched again (larger tier, next round) counts once.
       // They are summed per lane here and reach the global counters once per wavefront (flush_counters): five atomics per read on
       // five shared addresses cost an on-target launch 12 % of its time.
-      t_pops += c_pops; t_pushes += c_pushes; t_touch += c_touch;
-      if (c_pops > t_maxpops) t_maxpops = c_pops;
-      if (c_pops > 4096) ++t_gt4k;
+      store.cold(FQ_COLD_TPOPS) += c_pops; store.cold(FQ_COLD_TPUSHES) += c_pushes; store.cold(FQ_COLD_TTOUCH) += c_touch;
+      if (c_pops > store.cold(FQ_COLD_TMAXPOPS)) store.cold(FQ_COLD_TMAXPOPS) = c_pops;
+      if (c_pops > 4096) store.cold(FQ_COLD_TGT4K) += 1;
     }
     active = false; has_cur = false; tail = false; hit_pending = false; pf_slot = FQ_NIL;
   }
 
-  FQ_HD void begin(int w_) {
-    w = w_;
+  FQ_HD void begin(int w) {
+    store.cold(FQ_COLD_W) = (uint32_t)w;
     const FqGapWork gw = A.winfo[w];                 // written by k_width: read index, length, max_diff, "too many N"
     len = (int)(gw.meta & 0xffffu);
-    max_diff_opt = (int)((gw.meta >> 16) & 0xffu);
-    use_seed = len > o.seed_len;
-    seed_off = len - o.seed_len;
+    const int max_diff_opt = (int)((gw.meta >> 16) & 0xffu);
+    store.cold(FQ_COLD_MAXDIFF_OPT) = (uint32_t)max_diff_opt;
     prec = A.prec + (size_t)w * 2 * (size_t)A.pstride;
     wbase = 0x7fff;
     m0 = m1 = m2 = m3 = 0; bump = 0; spare = FQ_NIL; status = 0; n_aln = 0; n_live = 0;
     best_score = (max_diff_opt + 1) * o.s_mm + (o.max_gapo + 1) * o.s_gapo + (o.max_gape + 1) * o.s_gape;
-    max_diff = max_diff_opt; best_cnt = 0;
+    max_diff = max_diff_opt; store.cold(FQ_COLD_BEST_CNT) = 0;
     c_pops = c_pushes = c_touch = 0;
     has_cur = tail = hit_pending = false; pf_slot = FQ_NIL;
     active = true;
@@ -1010,9 +1052,9 @@ struct FqGapLane {
     int b = 0;
     uint32_t slot = 0;
     if (popping) {
-      if ((m0 | m1 | m2 | m3) == 0) { finish(); return; }
+      if (stack_empty()) { finish(); return; }
       if (n_live > o.max_entries) { if (!exact) status |= FQ_SF_ENTRY_LIMIT; finish(); return; }   // bwtgap.c:144
-      b = m0 ? FQ_CTZ32(m0) : m1 ? 32 + FQ_CTZ32(m1) : m2 ? 64 + FQ_CTZ32(m2) : 96 + FQ_CTZ32(m3);
+      b = lowest_bucket();
       if (NOGAP && b >= o.s_gapo) { status |= FQ_SF_NEEDGAP; finish(); return; }   // the full search may hold a gap child at or below this bucket
       slot = store.head_get(b);
       if (slot == pf_slot) {   // the entry was fetched ahead: pop it now and expand it in this same trip
@@ -1028,6 +1070,7 @@ struct FqGapLane {
     const int a = (int)(cpk >> 9) & 1, i0 = (int)(cpk & 511u);            // i0 >= 1 whenever has_cur
     const int need_lo = i0 >= 2 ? i0 - 2 : 0;
     const int sa = a << 10;                                                  // wbase carries the window's strand in bit 10
+    const uint32_t primary = fq_pick2(primary0, primary1, a);
     const bool reload = !popping && (need_lo + sa < wbase || i0 - 1 + sa > wbase + 7);
     const int nb = i0 >= 8 ? ((i0 - 7) & ~1) : 0;                            // 4-byte aligned window holding i0-2 and i0-1
     const FqPos *pp = prec + (size_t)a * (size_t)A.pstride + nb;
@@ -1037,8 +1080,9 @@ struct FqGapLane {
     if (popping || reload) vA = *(const FqU4 *)pa;
     FqBlkRaw bk, bl;
     if (!popping) {
-      const FqOccBlk *blk = (const FqOccBlk *)fq_pick2p((uint64_t)(uintptr_t)blk0, (uint64_t)(uintptr_t)blk1, a);   // strand a searches the other strand's BWT (bwtgap.c:148)
-      const uint32_t primary = fq_pick2(primary0, primary1, a);
+      // strand a searches the other strand's BWT (bwtgap.c:148); an offset from one table rather than a choice of two pointers: the
+      // address stays a global-memory address (a pointer rebuilt from an integer is loaded with flat instructions)
+      const FqOccBlk *blk = (const FqOccBlk *)((const char *)blk_s0 + (a ? blk_delta : (ptrdiff_t)0));
       fq_blk_load_pair(blk, primary, ck_ - 1, cl_, bk, bl);
     } else {
       bk = fq_blk_none(); bl = fq_blk_none();
@@ -1056,7 +1100,7 @@ struct FqGapLane {
     const uint32_t rec2 = (fq_sel4v(pw0, pw1, pw2, pw3, o2 >> 1) >> ((o2 & 1) << 4)) & 0xffffu;   // position i0-2 (if any)
     const int cbase = (int)(rec1 >> 12) & 7;                                 // seq[a][i0-1]
     const int b0 = (int)(rec1 & 31u), b1 = (int)(rec2 & 31u);                // width[i0-1].bid, width[i0-2].bid
-    const bool seeded = use_seed && (i0 - 1) - seed_off > 0;
+    const bool seeded = (i0 - 1) - (len - o.seed_len) > 0 && len > o.seed_len;   // (use_seed and the seed's offset, from len: a register each otherwise)
     const int st = (int)(cpk >> 10) & 3, n_mm = (int)(cpk >> 12) & 31, n_gapo = (int)(cpk >> 17) & 3, n_gape = (int)(cpk >> 19) & 15;
     const int diffs = n_mm + n_gapo + (gape_mode ? n_gape : 0);
     const int m = max_diff - diffs;
@@ -1070,21 +1114,21 @@ struct FqGapLane {
     const uint32_t kk0 = L2_0 + ok4[0] + 1, kk1 = L2_1 + ok4[1] + 1, kk2 = L2_2 + ok4[2] + 1, kk3 = L2_3 + ok4[3] + 1;
     const uint32_t ll0 = L2_0 + ol4[0], ll1 = L2_1 + ol4[1], ll2 = L2_2 + ol4[2], ll3 = L2_3 + ol4[3];
     const uint32_t vmask = (kk0 <= ll0 ? 1u : 0u) | (kk1 <= ll1 ? 2u : 0u) | (kk2 <= ll2 ? 4u : 0u) | (kk3 <= ll3 ? 8u : 0u);
+    const uint32_t touch = fq_touch2p(primary, seq_len, ck_ - 1, cl_, tail);
     const int i = i0 - 1;
     const bool mvalid = cbase < 4 && ((vmask >> (cbase & 3)) & 1u) != 0;
     const uint32_t mk = fq_sel4v(kk0, kk1, kk2, kk3, cbase & 3), ml = fq_sel4v(ll0, ll1, ll2, ll3, cbase & 3);
     const uint32_t fpk = (cpk & ~0xC00u) - 1u;                                // the match child: same counts, position i, state M
-    const uint32_t pk_row = fq_pick2(primary0, primary1, a);
     if (tail) {   // one base of bwt_match_exact_alt (libbwa/bwt.c:102-117)
       FQ_PROF(1);
-      if (cbase < 4) c_touch += fq_touch2p(pk_row, seq_len, ck_ - 1, cl_, true);
+      if (cbase < 4) c_touch += touch;
       if (!mvalid) { has_cur = false; tail = false; return; }
       ck_ = mk; cl_ = ml; cpk = fpk;
       if (i == 0) { has_cur = false; tail = false; hit_pending = true; }
       return;
     }
     FQ_PROF(8);
-    c_touch += fq_touch2p(pk_row, seq_len, ck_ - 1, cl_, false);
+    c_touch += touch;
     const int last_diff = (int)(cpk >> 23);
     bool allow_diff = true, allow_M = true;
     if (i > 0) {
@@ -1168,16 +1212,18 @@ struct FqGapLane {
     bool keep_going = true, add = false;
     uint32_t x = 0;
     int ld = 0, a = 0;
+    const int w = (int)store.cold(FQ_COLD_W);
     if (hit_pending) {
       a = (int)(cpk >> 9) & 1;
       const int n_mm = (int)(cpk >> 12) & 31, n_gapo = (int)(cpk >> 17) & 3, n_gape = (int)(cpk >> 19) & 15;
       if (n_aln == 0) {
         best_score = cscore;
         const int best_diff = n_mm + n_gapo + (gape_mode ? n_gape : 0);
+        const int max_diff_opt = (int)store.cold(FQ_COLD_MAXDIFF_OPT);
         if (!nonstop) max_diff = best_diff + 1 > max_diff_opt ? max_diff_opt : best_diff + 1;
       }
-      if (cscore == best_score) best_cnt += (int)(cl_ - ck_ + 1);
-      else if (best_cnt > o.max_top2) keep_going = false;
+      if (cscore == best_score) store.cold(FQ_COLD_BEST_CNT) += cl_ - ck_ + 1;
+      else if ((int)store.cold(FQ_COLD_BEST_CNT) > o.max_top2) keep_going = false;
       if (keep_going) {
         add = true;
         if (n_gapo) {
@@ -1241,9 +1287,9 @@ struct FqGapLane {
 
 // fetch(n): reserves n consecutive queue positions of one block of the queue; returns first | limit << 32 -- positions below
 // `limit` are valid, limit == 0: the queue is exhausted
-template <bool NOGAP, class St, class Fetch>
+template <bool NOGAP, class Opt = FqKOpts, class St, class Fetch>
 FQ_HD void fq_gap_lanes(const FqGapArgs &A, const St &store0, Fetch fetch, int lane_slot) {
-  FqGapLane<St, NOGAP> L(A, store0, lane_slot);
+  FqGapLane<St, NOGAP, Opt> L(A, store0, lane_slot);
   uint32_t trips = 0, lane_trips = 0;
 #if defined(FQ_GAP_INSTR) && defined(__HIP_DEVICE_COMPILE__)
   uint32_t ib[16];

@@ -82,8 +82,18 @@ struct SeqFetch { uint32_t *next; int n; uint32_t operator()(uint32_t k) const {
 // the lane kernels' two-block queue, walked front to back by the single host "wavefront"
 struct SeqFetch2 { uint32_t *next; uint32_t lo, hi; uint64_t operator()(uint32_t k) const { const uint32_t at = lo + *next; *next += k; return at < hi ? (uint64_t)at | (uint64_t)hi << 32 : 0; } };   // one block here: the segment [lo, hi) of it
 int gap_lane_slots(const FqGapArgs &a) { return a.n_work > 0 ? 1 : 0; }
+#if defined(FQ_PROFILE)
+}  // namespace fqdev
+unsigned long long fq_prof[128];
+int fq_prof_off = 0;
+extern "C" unsigned long long *fq_emu_prof() { return fq_prof; }
+namespace fqdev {
+#endif
 int launch_gap(const FqGapArgs &a_in) {
   FqGapArgs a = a_in;
+#if defined(FQ_PROFILE)
+  fq_prof_off = a.tier.coop ? 64 : a.tier.nogap ? 32 : 0;
+#endif
   a.refill_min = 1;
   a.split = nullptr;   // one cursor over the whole order here: FqGapLane::queue_dry then looks at it alone
   uint32_t *next_p = a.queue; *next_p = 0;   // the same cursor the device kernels advance
@@ -94,11 +104,12 @@ int launch_gap(const FqGapArgs &a_in) {
     fq_gap_coop_wave(a, heads.data(), SeqFetch{next_p, a.n_work}, 0);
   } else if (a.tier.pool_cap <= 65535u) {   // same store policy the HIP launcher picks: 16-bit heads in (here: emulated) LDS
     std::vector<uint16_t> heads(a.o.n_buckets);
-    FqGapStoreLds st = {heads.data(), 1};
+    std::vector<uint32_t> cold(FQ_COLD_N);
+    FqGapStoreLds st = {heads.data(), 1, cold.data()};
     if (a.tier.nogap) fq_gap_lanes<true>(a, st, SeqFetch2{next_p, seg_lo, seg_hi}, 0);
     else fq_gap_lanes<false>(a, st, SeqFetch2{next_p, seg_lo, seg_hi}, 0);
   } else {
-    FqGapStoreGlobal st = {nullptr};
+    FqGapStoreGlobal st = {nullptr, {}};
     fq_gap_lanes<false>(a, st, SeqFetch2{next_p, seg_lo, seg_hi}, 0);
   }
   return 0;

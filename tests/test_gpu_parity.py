@@ -32,6 +32,8 @@ SEARCH_MODES = {"lanes": {}, "wave1": {"gap_long_pops": 1, "gap_long_always": 1}
                 "packed": {"packed_bulk_min": 1 << 30}, "packed_bulk": {"packed_bulk_min": 0},
                 # every launch begins with the round that searches without gap children, as device-filling launches do
                 "nogap": {"gap_nogap_min": 0},
+                # ... with the kernels that read the options from the launch instead of the ones compiled for FASTQuick's own option block
+                "generic_opts": {"gap_nogap_min": 0, "gap_generic_opts": 1},
                 # the hand-over rule of small launches with a low threshold: a search still running after 8 pops once the work queue
                 # is dry (both of its blocks) goes to the wavefront-per-read kernel
                 "handover": {"gap_long_pops": 8},
@@ -99,7 +101,7 @@ def test_gpu_matches_oracle_on_fresh_inputs(tag, refkw, readkw, n, batch, q, lib
     # the numerator of the search kernels' roofline (48 B x gap_occ_touches, bench.py): the blocks bwt_match_gap reads, however the
     # search was scheduled (rounds, tiers, hand-overs: a read counts once, in the launch that completed it)
     assert gs["gap_occ_touches"] == oc["occ_gap_touches"]
-    if search_mode in ("nogap", "pipeline"):
+    if search_mode in ("nogap", "generic_opts", "pipeline"):
         # a read the round without gap children settles ends when its stack runs empty; the reference pops one more entry -- a gap
         # child that round never pushed -- and stops on it: at most one pop per searched read fewer
         assert oc["stack_pops"] - gs["reads_searched"] <= gs["stack_pops"] <= oc["stack_pops"]
@@ -201,7 +203,7 @@ OPTION_VARIANTS = [
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,okw", OPTION_VARIANTS, ids=[v[0] for v in OPTION_VARIANTS])
 def test_gpu_matches_oracle_with_option_variants(name, okw, lib, tmp_path, search_mode):
-    if search_mode in ("wave64", "packed_bulk") or (search_mode == "nogap" and name == "nonstop"):
+    if search_mode in ("wave64", "packed_bulk", "generic_opts") or (search_mode == "nogap" and name == "nonstop"):
         pytest.skip("covered by lanes, wave1 and packed")
     ref = synth.make_reference(n_markers=120, n_long=12, seed=35, repeat_every=2, tandem_every=7)
     pre = str(tmp_path / "ref.FASTQuick.fa")
