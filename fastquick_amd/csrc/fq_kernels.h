@@ -857,7 +857,8 @@ struct FqGapLane {
   // The entry below the one popped last (its `next`), fetched ahead: consecutive pops of a bucket find their entry in registers,
   // cost no trip of their own and are expanded at once.  A pool slot keeps its content for as long as it is on the stack, so the
   // copy is good whenever the bucket's head still names that slot.
-  // (Not in the round without gap children: its searches are short, and the registers cost it a wavefront per SIMD.)
+  // (The round without gap children does it too since its kernel fits 128 VGPRs with them: 33 of a read's 36 pops there are consecutive
+  // pops of one bucket -- the mismatch children of the walk down the read -- and each was a trip of its own: 42.0 -> 39.9 ms.)
   // (Fetching the entry's window of position records ahead as well was tried: loads return in order, so the extra request only
   // moves the wait into the next trip -- 19.1 -> 21.7 ms for the second round of an on-target call.)
   uint32_t pf_slot = FQ_NIL, pfk = 0, pfl = 0, pfpk = 0, pfnext = 0;
@@ -1037,7 +1038,6 @@ struct FqGapLane {
     return true;
   }
   FQ_HD void fetch_ahead(uint32_t nslot) {
-    if (NOGAP) return;
     pf_slot = nslot;
     if (nslot != FQ_NIL) {
       const FqU4 v = *(const FqU4 *)(pool + (size_t)nslot * pstep);

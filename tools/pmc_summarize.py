@@ -16,7 +16,7 @@ import json
 import os
 import sys
 
-KMAP = {"k_prep": "fq_prep", "k_prep_packed": "fq_prep", "k_gap_nogap_lds": "fq_gap", "k_gap_lds": "fq_gap", "k_gap": "fq_gap", "k_gap_persist": "fq_gap", "k_gap_persist_lds": "fq_gap", "k_gap_coop": "fq_gap_wave", "k_width": "fq_width", "k_sa": "fq_sa",
+KMAP = {"k_prep": "fq_prep", "k_prep_packed": "fq_prep", "k_gap_nogap_lds": "fq_gap", "k_gap_nogap_stock": "fq_gap", "k_gap_persist_stock": "fq_gap", "k_gap_lds": "fq_gap", "k_gap": "fq_gap", "k_gap_persist": "fq_gap", "k_gap_persist_lds": "fq_gap", "k_gap_coop": "fq_gap_wave", "k_width": "fq_width", "k_sa": "fq_sa",
         "k_sw_wave": "fq_sw", "k_refine_lds": "fq_refine"}
 
 
