@@ -516,6 +516,28 @@ void parallel_chunks(size_t n, int threads, size_t par_min, F fn) {   // fn(lo, 
   for (auto &x : th) x.join();
 }
 
+// v = n copies of val, written by the call's host threads (a serial vector::assign of the per-read arrays of a 4 M-pair call is 20-30 ms
+// of one core per call; the vectors live with the context, so resize() itself initialises nothing after the first call)
+template <class T>
+void par_assign(std::vector<T> &v, size_t n, T val, int threads, size_t par_min) {
+  v.resize(n);
+  T *p = v.data();
+  parallel_chunks(n, threads, par_min, [=](size_t lo, size_t hi, int) { std::fill(p + lo, p + hi, val); });
+}
+// in place: v[i] = v[0] + ... + v[i] (v[0] is the caller's start value); chunk sums, their serial prefix, then the chunks again
+template <class T>
+void par_prefix(std::vector<T> &v, int threads, size_t par_min) {
+  const size_t n = v.size();
+  if (threads <= 1 || n < par_min) { for (size_t i = 1; i < n; ++i) v[i] += v[i - 1]; return; }
+  const size_t per = (n + threads - 1) / threads;
+  std::vector<T> tot((size_t)threads + 1, T(0));
+  T *p = v.data();
+  parallel_chunks(n, threads, par_min, [&](size_t lo, size_t hi, int t) { T a = T(0); for (size_t i = lo; i < hi; ++i) a += p[i]; tot[(size_t)t + 1] = a; });
+  for (int t = 0; t < threads; ++t) tot[(size_t)t + 1] += tot[t];
+  parallel_chunks(n, threads, par_min, [&](size_t lo, size_t hi, int t) { T a = tot[t]; for (size_t i = lo; i < hi; ++i) { a += p[i]; p[i] = a; } });
+  (void)per;
+}
+
 // bwa_aln2seq_core, libbwa/bwase.c:19-95
 void choose_hit(uint64_t &rng, int n_aln, const FqAln *aln, FqRead &s, bool set_main, int n_multi) {
   if (n_aln == 0) { s.type = FQ_TYPE_NO_MATCH; s.c1 = s.c2 = 0; return; }
@@ -983,8 +1005,8 @@ int stageA_search(Call &K) {
   const int n_search = K.n_search, max_len_all = K.max_len_all;
   // the hit lists stay where the copy engine lands them (the context's pinned buffer): S.aln is a view of it
   c->st.aln.p = c->p_aln.p; c->st.aln.n = 0;
-  K.aln_off.assign((size_t)n_search + 1, 0);
-  K.aln_n.assign(n_search, 0);
+  par_assign(K.aln_off, (size_t)n_search + 1, (uint64_t)0, K.host_threads, K.par_min);
+  par_assign(K.aln_n, (size_t)n_search, (uint32_t)0, K.host_threads, K.par_min);
   const int Lpad = (max_len_all + 1 + 7) & ~7;                  // exact widths per strand; rows are written 8 positions at a time
   const int Ppad = (max_len_all + 1 + FQ_POS_PAD + 7) & ~7;     // position records per strand (16-byte aligned rows)
   // tier 0: one read per lane, bounded stack and pop count; what it gives up on is searched again by one wavefront per read
@@ -1239,7 +1261,7 @@ void stage_records(Call &K) {
   const int n = K.n, n_surv = K.n_surv;
   vector<FqRead> &R = c->st.reads;
   R.resize((size_t)n_surv * 2);                      // reused storage: every record is reset below
-  K.s_of.assign((size_t)n_surv * 2, -1);
+  par_assign(K.s_of, (size_t)n_surv * 2, (int)-1, K.host_threads, K.par_min);
   const bool packed = c->in_kind == 2;
   // (R.resize above touches new storage on the calling thread, which also runs the serial phases; resetting reused records is spread)
   parallel_chunks((size_t)n_surv, K.host_threads, K.par_min, [&](size_t lo_sp, size_t hi_sp, int) {
@@ -1269,10 +1291,10 @@ int stage_sa_rows(Call &K) {
   const fq_opts_t &o = c->o;
   const int n_surv = K.n_surv;
   vector<FqRead> &R = c->st.reads;
-  K.read_nocc.assign((size_t)n_surv * 2, 0);
-  K.enumerated.assign((size_t)n_surv * 2, 0);
-  K.q_first.assign((size_t)n_surv * 2, 0);
-  K.aln_row_off.assign(c->st.aln.size() + 1, ~0ull);   // per hit in S.aln order -> offset into h_pos
+  par_assign(K.read_nocc, (size_t)n_surv * 2, (uint64_t)0, K.host_threads, K.par_min);
+  par_assign(K.enumerated, (size_t)n_surv * 2, (char)0, K.host_threads, K.par_min);
+  par_assign(K.q_first, (size_t)n_surv * 2, (uint32_t)0, K.host_threads, K.par_min);
+  par_assign(K.aln_row_off, (size_t)c->st.aln.size() + 1, ~(uint64_t)0, K.host_threads, K.par_min);   // per hit in S.aln order -> offset into h_pos
   const uint32_t multi_cap = o.single_end ? 4u : (uint32_t)std::max(o.n_multi, o.N_multi) + 1;   // (single-end: N_OCC + 1, src/BwtMapper.cpp:33, 1344)
   parallel_chunks(R.size(), K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
     for (size_t idx = lo; idx < hi; ++idx) {
@@ -1304,7 +1326,8 @@ int stage_sa_rows(Call &K) {
       pq[sp + 1] = nq; prow[sp + 1] = nr;
     }
   });
-  for (int sp = 0; sp < n_surv; ++sp) { pq[sp + 1] += pq[sp]; prow[sp + 1] += prow[sp]; }
+  par_prefix(pq, K.host_threads, K.par_min);
+  par_prefix(prow, K.host_threads, K.par_min);
   const size_t n_q = pq[n_surv];
   const uint64_t rows = prow[n_surv];
   FqAln *q_aln = nullptr; uint32_t *q_len = nullptr; uint64_t *q_off = nullptr;
@@ -1573,9 +1596,10 @@ int stageB3_pairing(Call &K) {
       const FqRead &p0 = R[2 * sp], &p1 = R[2 * sp + 1];
       on_device[sp] = mapped(p0) && mapped(p1) && K.read_nocc[2 * sp] <= o.max_occ && K.read_nocc[2 * sp + 1] <= o.max_occ &&
                       K.enumerated[2 * sp] && K.enumerated[2 * sp + 1] && K.read_nocc[2 * sp] + K.read_nocc[2 * sp + 1] <= kPairLaneRows;
+      job_of[sp + 1] = on_device[sp] ? 1u : 0u;
     }
   });
-  for (int sp = 0; sp < n_surv; ++sp) job_of[sp + 1] = job_of[sp] + (on_device[sp] ? 1u : 0u);
+  par_prefix(job_of, K.host_threads, K.par_min);
   const size_t nj = job_of[n_surv];
   if (nj) {
     CKM(c->d_pjobs.ensure(nj) && c->d_preads.ensure(2 * nj) && c->d_pout.ensure(2 * nj) && c->d_pisize.ensure(pis.size()) && c->d_plut.ensure(lut.size() + 1) &&

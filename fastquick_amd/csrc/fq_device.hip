@@ -277,12 +277,14 @@ __global__ void __launch_bounds__(256) k_prep(FqPrepArgs a) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r < a.n_reads) fq_prep_thread(a, r);
 }
+extern __shared__ __align__(16) unsigned char fq_dyn_lds[];
+// (LDS per block: 2 x seed_len x 256 bytes, 16 KB at the default seed length.  94 VGPRs = 5 wavefronts per SIMD; asking the compiler for 6 / 8
+//  (13 / 30 registers spilled) gave 45.6 / 54.3 ms against 40.7 per on-target call of 8.4 M reads: more wavefronts do not help it)
 __global__ void __launch_bounds__(256) k_width(FqWidthArgs a) {
-  __shared__ uint8_t seed_bits[2 * FQ_SEED_MAX * 256];   // [strand][ii][thread]: lane-interleaved, conflict free
+  uint8_t *seed_bits = (uint8_t *)fq_dyn_lds;   // [strand][ii][thread]: lane-interleaved, conflict free
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w < a.n_work) fq_width_read(a, w, seed_bits + threadIdx.x, 256);
 }
-extern __shared__ __align__(16) unsigned char fq_dyn_lds[];
 struct FqQueueFetch {
   uint32_t *cursor;
   int n_work;
@@ -934,7 +936,7 @@ int launch_trim_all(const FqTrimAllArgs &a) {
 int launch_width(const FqWidthArgs &a) {
   FQ_PRE();
   if (a.n_work <= 0) return 0;
-  hipLaunchKernelGGL(k_width, dim3(nblk((uint64_t)a.n_work, 256)), dim3(256), 0, g_stream, a);
+  hipLaunchKernelGGL(k_width, dim3(nblk((uint64_t)a.n_work, 256)), dim3(256), (size_t)2 * (size_t)a.o.seed_len * 256, g_stream, a);
   FQ_HIP(hipGetLastError());
   return 0;
 }

@@ -557,7 +557,7 @@ struct FqWidthArgs {
 };
 // One thread walks both strands of its read: the two chains (and the two seed chains before them) are independent, so every step
 // has two Occ requests in flight instead of one -- the kernel is bound by the latency of a dependent step, not by requests.
-// seed_bits[(strand * FQ_SEED_MAX + ii) * seed_bits_stride]: 2 * FQ_SEED_MAX bytes of thread-private scratch (LDS on the device)
+// seed_bits[(strand * seed_len + ii) * seed_bits_stride]: 2 * seed_len bytes of thread-private scratch (LDS on the device)
 FQ_HD void fq_width_read(const FqWidthArgs &A, int w, uint8_t *seed_bits, int seed_bits_stride) {
   const int s = A.work ? A.work[w] : w;
   const int r = A.read_list[s];
@@ -593,7 +593,7 @@ FQ_HD void fq_width_read(const FqWidthArgs &A, int w, uint8_t *seed_bits, int se
         }
         if (k[a] > l[a] || c > 3) { k[a] = 0; l[a] = f.seq_len; ++bid[a]; }
         const uint32_t wcur = l[a] - k[a] + 1;
-        seed_bits[(a * FQ_SEED_MAX + i) * seed_bits_stride] = (uint8_t)((uint32_t)(bid[a] < 31 ? bid[a] : 31) | (i >= 1 && wcur == wprev[a] ? 1u << 5 : 0u));
+        seed_bits[(a * A.o.seed_len + i) * seed_bits_stride] = (uint8_t)((uint32_t)(bid[a] < 31 ? bid[a] : 31) | (i >= 1 && wcur == wprev[a] ? 1u << 5 : 0u));
         wprev[a] = wcur;
       }
     }
@@ -629,7 +629,7 @@ FQ_HD void fq_width_read(const FqWidthArgs &A, int w, uint8_t *seed_bits, int se
           }
           if (k[a] > l[a] || c > 3) { k[a] = 0; l[a] = f.seq_len; ++bid[a]; }
           const uint32_t wcur = l[a] - k[a] + 1;
-          const uint32_t seedbits = (use_seed && i >= seed_off) ? (uint32_t)seed_bits[(a * FQ_SEED_MAX + (i - seed_off)) * seed_bits_stride] << 6 : 0u;
+          const uint32_t seedbits = (use_seed && i >= seed_off) ? (uint32_t)seed_bits[(a * A.o.seed_len + (i - seed_off)) * seed_bits_stride] << 6 : 0u;
           wv[a][j] = wcur;
           pv[a][j] = seedbits | (uint32_t)(bid[a] < 31 ? bid[a] : 31) | (i >= 1 && wcur == wprev[a] ? 1u << 5 : 0u) | (uint32_t)c << 12;
           wprev[a] = wcur;
@@ -1007,12 +1007,17 @@ struct FqGapLane {
     active = true;
     too_many_n = ((gw.meta >> 24) & 1u) != 0;
     if (too_many_n) { finish(); return; }   // "too many N" early-out of bwt_match_gap (bwtgap.c:118-124)
-    // the two roots (bwtgap.c:139-140): strand 0 first, so strand 1 is popped first
+    // the two roots (bwtgap.c:139-140): strand 0 is pushed first, so strand 1 is popped first.  Its push and pop are done here --
+    // the entry becomes the lane's current entry without a trip through the pool -- and strand 0's root, the only entry bucket 0
+    // will ever hold, is what a fetch ahead would have brought: two trips fewer per read.
     uint32_t prev = FQ_NIL;
-    group_put(0, seq_len, fq_pack(len, 0, FQ_ST_M, 0, 0, 0, 0), prev);
-    group_put(0, seq_len, fq_pack(len, 1, FQ_ST_M, 0, 0, 0, 0), prev);
+    const uint32_t root0 = fq_pack(len, 0, FQ_ST_M, 0, 0, 0, 0);
+    group_put(0, seq_len, root0, prev);
     group_close(0, prev);
+    ++c_pushes; FQ_PROF(12);
     n_live = 2;
+    take_entry(0, FQ_NIL, 0, seq_len, fq_pack(len, 1, FQ_ST_M, 0, 0, 0, 0), prev);
+    if (active) { pf_slot = prev; pfk = 0; pfl = seq_len; pfpk = root0; pfnext = FQ_NIL; }
   }
 
   // gap_pop (bwtgap.c:66-79) of entry (ek, el, epk) from slot `slot` of bucket b, and the checks between a pop and its expansion
