@@ -243,6 +243,7 @@ struct fq_ctx {
     std::vector<uint64_t> read_nocc, aln_row_off;
     std::vector<uint32_t> q_first;
     std::vector<char> enumerated;
+    std::vector<uint32_t> isz;           // one insert-size sample per survivor pair (stageB2_isize)
     std::vector<int32_t> work, next_work;
     std::vector<uint16_t> ntop;
     std::vector<uint32_t> pq, job_of;
@@ -593,16 +594,20 @@ int approx_mapq(const fq_ctx *c, const FqRead &p, int mm) {   // bwa_approx_mapQ
 }
 
 // infer_isize, libbwa/bwape.c:49-117
-void infer_isize(const vector<FqRead> &R, int sp_lo, int sp_hi, int max_len_all, fq_isize_t *ii, double ap_prior, int64_t L) {
+// the insert size infer_isize looks at for one pair, or ~0 (bwape.c:62-71: both ends mapQ >= 20, below 100,000)
+static inline uint32_t pair_isize_sample(const FqRead &a, const FqRead &b) {
+  if (a.mapQ >= 20 && b.mapQ >= 20) {
+    const uint64_t x = a.pos < b.pos ? (uint64_t)(uint32_t)(b.pos + (uint32_t)b.len - a.pos) : (uint64_t)(uint32_t)(a.pos + (uint32_t)a.len - b.pos);
+    if (x < 100000) return (uint32_t)x;
+  }
+  return ~0u;
+}
+// (isz: one sample per survivor pair, written by all of the call's threads -- the scan of the records is what this stage costs, and a
+// reference batch per thread leaves most of them idle)
+void infer_isize(const uint32_t *isz, int sp_lo, int sp_hi, int max_len_all, fq_isize_t *ii, double ap_prior, int64_t L) {
   ii->avg = ii->std = -1.0; ii->low = ii->high = ii->high_bayesian = 0; ii->ap_prior = 0;
   vector<uint64_t> is;
-  for (int s = sp_lo; s < sp_hi; ++s) {
-    const FqRead &a = R[2 * s], &b = R[2 * s + 1];
-    if (a.mapQ >= 20 && b.mapQ >= 20) {
-      const uint64_t x = a.pos < b.pos ? (uint64_t)(uint32_t)(b.pos + (uint32_t)b.len - a.pos) : (uint64_t)(uint32_t)(a.pos + (uint32_t)a.len - b.pos);
-      if (x < 100000) is.push_back(x);
-    }
-  }
+  for (int s = sp_lo; s < sp_hi; ++s) if (isz[s] != ~0u) is.push_back(isz[s]);
   const int tot = (int)is.size();
   int max_len = std::max(1, max_len_all);
   if (tot < 20) return;
@@ -1506,7 +1511,10 @@ void stageB2_isize(Call &K) {
   {
     std::vector<std::thread> th;
     const int T = (size_t)K.n_surv >= K.par_min ? std::min(K.host_threads, n_sub) : 1;
-    auto work = [&](int t) { for (int sb = t; sb < n_sub; sb += T) infer_isize(R, K.sub_lo[sb], K.sub_lo[sb + 1], K.sub_max_len[sb], &raw[sb], o.ap_prior, (int64_t)c->ix->dev.fm[0].seq_len); };
+    vector<uint32_t> &isz = c->cv.isz;
+    isz.resize((size_t)K.n_surv);
+    parallel_chunks((size_t)K.n_surv, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) { for (size_t sp = lo; sp < hi; ++sp) isz[sp] = pair_isize_sample(R[2 * sp], R[2 * sp + 1]); });
+    auto work = [&](int t) { for (int sb = t; sb < n_sub; sb += T) infer_isize(isz.data(), K.sub_lo[sb], K.sub_lo[sb + 1], K.sub_max_len[sb], &raw[sb], o.ap_prior, (int64_t)c->ix->dev.fm[0].seq_len); };
     if (tl_pool && T > 1) tl_pool->run(T, work);
     else {
       for (int t = 1; t < T; ++t) th.emplace_back(work, t);
@@ -1976,16 +1984,17 @@ int stageD_refine(Call &K) {
     CKS(sync_staged(c));
     c->stats.d2h_bytes += (size_t)nt * 16 + total;
     K.trace("  D: MD strings D2H");
-    for (int t = 0; t < nt; ++t)
-      if (mdlen[t] < 0) { c->err = "MD string longer than the device slot"; return FQ_ELIMIT; }
+    std::atomic<int> too_long{0};
     parallel_chunks((size_t)nt, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
       for (size_t t = lo; t < hi; ++t) {
+        if (mdlen[t] < 0) { too_long.store(1, std::memory_order_relaxed); continue; }
         FqRead &s = R[mi[t]];
         s.md.assign(packed + off[t], (size_t)mdlen[t]);
         s.has_md = true;
         s.nm = nm[t] & 0xfff;
       }
     });
+    if (too_long.load()) { c->err = "MD string longer than the device slot"; return FQ_ELIMIT; }
   }
   K.trace("  D: MD apply");
   // bwa_correct_trimmed (bwase.c:298-337) for every record

@@ -889,14 +889,15 @@ int launch_surv_map(const int32_t *pair_list, int n_surv, int n_pairs, const uin
   FQ_HIP(hipGetLastError());
   return 0;
 }
-__global__ void __launch_bounds__(256) k_unpack(FqUnpackArgs a) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < a.n_rows) fq_unpack_thread(a, t);
+__global__ void __launch_bounds__(256) k_unpack(FqUnpackArgs a) {   // one 16-byte piece of the output per thread
+  const int64_t g = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < (int64_t)a.n_rows * (a.stride >> 4)) fq_unpack_piece(a, g);
 }
 int launch_unpack(const FqUnpackArgs &a) {
   FQ_PRE();
   if (a.n_rows <= 0) return 0;
-  hipLaunchKernelGGL(k_unpack, dim3(nblk((uint64_t)a.n_rows, 256)), dim3(256), 0, g_stream, a);
+  if (a.stride & 15) { g_err = "launch_unpack: the compact row stride must be a multiple of 16"; return -1; }
+  hipLaunchKernelGGL(k_unpack, dim3(nblk((uint64_t)a.n_rows * (uint64_t)(a.stride >> 4), 256)), dim3(256), 0, g_stream, a);
   FQ_HIP(hipGetLastError());
   return 0;
 }

@@ -426,18 +426,40 @@ struct FqUnpackArgs {
   int32_t *len_out;         // out: [n_rows] read length (also the untrimmed len_trim)
   int32_t *len_trim;        // out: [n_rows]
 };
-FQ_HD void fq_unpack_thread(const FqUnpackArgs &A, int t) {
+// One 16-byte piece of the output: bases [16 c, 16 c + 16) of compact row t = four bytes of the packed row.  The output rows are
+// dense (stride a multiple of 16, fq_align.cpp), so consecutive pieces are consecutive 16-byte stores: the kernel writes whole lines
+// (a thread per row wrote its row byte by byte, 64 rows per store instruction: 14.8 ms for 8.4 M rows against 1.6 ms).
+FQ_HD void fq_unpack_piece(const FqUnpackArgs &A, int64_t g) {
+  const int per_row = A.stride >> 4;
+  const int t = (int)(g / per_row), cidx = (int)(g - (int64_t)t * per_row);
   const size_t src = A.row_map ? (size_t)A.row_map[t] : (size_t)t;
-  const uint8_t *b = A.body + src * (size_t)A.body_stride;
   const int len = A.len ? (int)A.len[src] : A.uniform_len;
-  uint8_t *row = A.seq + (size_t)t * (size_t)A.stride;
-  for (int i0 = 0; i0 < len; i0 += 4) {
-    const uint32_t v = b[i0 >> 2];
-    for (int j = 0; j < 4 && i0 + j < len; ++j) row[i0 + j] = (uint8_t)"ACGT"[(v >> (2 * j)) & 3u];
+  const uint8_t *b = A.body + src * (size_t)A.body_stride + 4 * (size_t)cidx;
+  const int p0 = 16 * cidx;
+  uint32_t v = 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) if (p0 + 4 * j < len) v |= (uint32_t)b[j] << (8 * j);     // (bytes past the row's last base are not read)
+  FqU4 o;
+  uint32_t w[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    uint32_t x = 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = p0 + 4 * q + j;
+      const uint32_t code = (v >> (8 * q + 2 * j)) & 3u;
+      const uint32_t ch = p < len ? (0x54474341u >> (8 * code)) & 0xffu : 0u;            // "ACGT"[code]
+      x |= ch << (8 * j);
+    }
+    w[q] = x;
   }
-  for (int i = len; i < A.stride; ++i) row[i] = 0;
-  A.len_out[t] = len;
-  A.len_trim[t] = len;
+  o.x = w[0]; o.y = w[1]; o.z = w[2]; o.w = w[3];
+  *(FqU4 *)(A.seq + (size_t)t * (size_t)A.stride + (size_t)p0) = o;
+  if (cidx == 0) { A.len_out[t] = len; A.len_trim[t] = len; }
+}
+FQ_HD void fq_unpack_thread(const FqUnpackArgs &A, int t) {      // a whole row (host-loop build)
+  const int per_row = A.stride >> 4;
+  for (int cidx = 0; cidx < per_row; ++cidx) fq_unpack_piece(A, (int64_t)t * per_row + cidx);
 }
 // exception e: row << 32 | pos << 8 | code (4: 'N', any other letter; 5: '-'); row is a batch row, mapped through crow_of (compact
 // row or -1) when given, else already a compact row
@@ -1007,17 +1029,14 @@ struct FqGapLane {
     active = true;
     too_many_n = ((gw.meta >> 24) & 1u) != 0;
     if (too_many_n) { finish(); return; }   // "too many N" early-out of bwt_match_gap (bwtgap.c:118-124)
-    // the two roots (bwtgap.c:139-140): strand 0 is pushed first, so strand 1 is popped first.  Its push and pop are done here --
-    // the entry becomes the lane's current entry without a trip through the pool -- and strand 0's root, the only entry bucket 0
-    // will ever hold, is what a fetch ahead would have brought: two trips fewer per read.
+    // the two roots (bwtgap.c:139-140): strand 0 first, so strand 1 is popped first
+    // (Starting on strand 1's root without its trip through the pool -- push and pop done here, strand 0's root left as fetched-ahead
+    // content -- saves two of a read's ~350 trips and was 1.3 ms SLOWER per 8.4 M reads, A/B on one device: 41.2 against 39.9 ms.)
     uint32_t prev = FQ_NIL;
-    const uint32_t root0 = fq_pack(len, 0, FQ_ST_M, 0, 0, 0, 0);
-    group_put(0, seq_len, root0, prev);
+    group_put(0, seq_len, fq_pack(len, 0, FQ_ST_M, 0, 0, 0, 0), prev);
+    group_put(0, seq_len, fq_pack(len, 1, FQ_ST_M, 0, 0, 0, 0), prev);
     group_close(0, prev);
-    ++c_pushes; FQ_PROF(12);
     n_live = 2;
-    take_entry(0, FQ_NIL, 0, seq_len, fq_pack(len, 1, FQ_ST_M, 0, 0, 0, 0), prev);
-    if (active) { pf_slot = prev; pfk = 0; pfl = seq_len; pfpk = root0; pfnext = FQ_NIL; }
   }
 
   // gap_pop (bwtgap.c:66-79) of entry (ek, el, epk) from slot `slot` of bucket b, and the checks between a pop and its expansion
