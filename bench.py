@@ -244,7 +244,7 @@ def main() -> None:
 
     def gap_parts(st):
         """(name, summed ms, launches, algorithmic bytes) of the search stage and of its two kernels: a device-filling launch runs the search
-        without gap children first (k_gap_nogap_lds) and the full search (k_gap_persist_lds, k_gap_coop) on what that leaves."""
+        without gap children first (k_gap_nogap_stock / _lds) and the full search (k_gap_persist_stock / _lds, k_gap_coop) on what that leaves."""
         ms_f, ms_n = st["kernel_ms"][K_GAP_KERNEL], st["kernel_ms"][K_GAP_NOGAP]
         nl_f, nl_n = int(st["kernel_launches"][K_GAP_KERNEL]), int(st["kernel_launches"][K_GAP_NOGAP])
         b_all, b_n = 48.0 * st["gap_occ_touches"], 48.0 * st["gap_nogap_touches"]
