@@ -568,6 +568,7 @@ void choose_hit(uint64_t &rng, int n_aln, const FqAln *aln, FqRead &s, bool set_
     for (int k = 0; k < n_aln; ++k) n_occ += (int)(aln[k].l - aln[k].k + 1);
     s.multi.clear();
     if (n_occ > n_multi + 1) return;
+    if (n_occ == 1 && aln[0].k == s.sa) return;   // (the one row is the main hit: the list stays empty -- most reads of an on-target set)
     for (int k = 0; k < n_aln; ++k) {
       const FqAln &q = aln[k];
       const uint32_t wdt = q.l - q.k + 1;
