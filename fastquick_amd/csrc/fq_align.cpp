@@ -9,6 +9,7 @@
 // GPU through fq_backend.h; libm-dependent scalar decisions stay on the host (Q4/Q5).
 #include <algorithm>
 #include <atomic>
+#include <ctime>
 #include <chrono>
 #include <climits>
 #include <cstdint>
@@ -345,6 +346,7 @@ extern "C" int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t v) {
   else if (k == "filter_no_turns") t->filter_no_turns = (int)v;
   else if (k == "refine_lanes") t->refine_lanes = (int)v;
   else if (k == "gap_generic_opts") t->gap_generic_opts = (int)v;
+  else if (k == "spin_sync") t->spin_sync = (int)v;
   else return FQ_EINVAL;
   return FQ_OK;
 }
@@ -490,9 +492,32 @@ struct CallInFlight {      // counted on the index the contexts share: no proces
   explicit CallInFlight(const fq_index *i) : ix(i) { ix->calls_in_flight.fetch_add(1, std::memory_order_relaxed); }
   ~CallInFlight() { ix->calls_in_flight.fetch_sub(1, std::memory_order_relaxed); }
 };
+// CPUs this process may actually use: the hardware threads it sees, cut to the cgroup's CPU quota when there is one (a container
+// that shows 256 hardware threads and is throttled to 16 CPUs runs 32 threads per call SLOWER than 16 and burns half as much again:
+// 3.0 against 1.9 core-seconds per 4.2 M-pair on-target call, profiles/round3_host_quota_and_threads.txt)
+inline unsigned effective_cpus() {
+  static const unsigned n = [] {
+    unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                       // cgroup v2: "<quota> <period>" or "max <period>"
+      char q[64]; long long period = 0;
+      if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+        const long long quota = atoll(q);
+        if (quota > 0) hw = std::min<unsigned>(hw, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+      }
+      fclose(f);
+    } else {
+      long long quota = -1, period = 0;                                         // cgroup v1
+      if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lld", &quota) != 1) quota = -1; fclose(g); }
+      if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = 0; fclose(g); }
+      if (quota > 0 && period > 0) hw = std::min<unsigned>(hw, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+    }
+    return hw;
+  }();
+  return n;
+}
 inline int default_host_threads(const fq_index *ix) {
-  const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-  const unsigned cap = hw >= 128 ? 32u : hw >= 32 ? 16u : std::min(8u, hw);   // (one 4.2 M-pair call on a 2 x 64-core host: 430 / 331 / 339 / 614 ms with 24 / 32 / 48 / 64 threads, 354 with 16)
+  const unsigned hw = effective_cpus();
+  const unsigned cap = hw >= 128 ? 32u : hw >= 16 ? 16u : std::min(8u, hw);   // (one 4.2 M-pair call on a 2 x 64-core host under a quota of 16 CPUs: 430 / 331 / 339 / 614 ms with 24 / 32 / 48 / 64 threads, 301-354 with 16)
   const unsigned share = 2 * hw / (unsigned)std::max(1, ix->calls_in_flight.load(std::memory_order_relaxed));   // (a call waits for the device about half of its time)
   return (int)std::max(std::min(2u, cap), std::min(cap, share));
 }
@@ -704,18 +729,21 @@ struct Call {
   struct B1Plan { int T = 1; size_t per = 0; vector<uint64_t> start; uint64_t rng_end = 0; } plan;
   std::thread plan_thread;             // the plan is drawn up beside the SA stage when nothing else can move the stream's state
   ~Call() { if (plan_thread.joinable()) plan_thread.join(); }
-  double t_trace = 0, t_wall0 = 0, t_host0 = 0, t_serial1 = 0, t_host1 = 0;
+  double t_trace = 0, t_wall0 = 0, t_host0 = 0, t_serial1 = 0, t_host1 = 0, cpu_trace = 0;
   const FqAln *aln_of(int idx, int *n_out) const {
     const int s = s_of[idx];
     if (s < 0) { *n_out = 0; return nullptr; }
     *n_out = (int)aln_n[s];
     return c->st.aln.data() + aln_off[s];
   }
-  void trace(const char *label) {
+  void trace(const char *label) {   // wall time since the previous mark, and the CPU time the whole process used meanwhile (all threads: core-ms)
     if (!c->kn.trace) return;
     const double t = now_ms();
-    fprintf(stderr, "[fq] %-22s %8.3f ms\n", label, t - t_trace);
-    t_trace = t;
+    timespec ts;
+    clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts);
+    const double cpu = 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
+    fprintf(stderr, "[fq] %-22s %8.3f ms   cpu %8.1f core-ms\n", label, t - t_trace, cpu - cpu_trace);
+    t_trace = t; cpu_trace = cpu;
   }
 };
 

@@ -13,6 +13,7 @@ struct State;
 struct Tune {   // experiment / test knobs (fq_ctx_set_tuning); the defaults are what DESIGN.md measures
   int gap_coop_waves = 0;   // wavefronts of the wavefront-per-read search kernel (0: 1,024)
   int gap_waves_per_cu = 0, gap_refill_min = 0, gap_order_asc = 0, filter_no_turns = 0, refine_lanes = 0;
+  int spin_sync = 0;        // 1: sync() spins (hipStreamSynchronize) instead of sleeping on a blocking event
   int gap_generic_opts = 0; // 1: never the kernels specialised for FASTQuick's own option block (FqOptsStock)
 };
 State *state_create(int device_ordinal);   // nullptr on failure (last_error())

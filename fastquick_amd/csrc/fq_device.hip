@@ -30,6 +30,7 @@ struct State {
   hipStream_t copy_stream = nullptr;              // one of the device's shared copy streams (not owned)
   hipEvent_t copy_done[2] = {nullptr, nullptr};
   hipEvent_t prep_done = nullptr;                 // completion of this context's most recent filter kernel (chained per device)
+  hipEvent_t sync_ev = nullptr;                   // what sync() sleeps on (hipEventBlockingSync)
   std::vector<Pending> pending;
   std::vector<hipEvent_t> free_events;
   hipEvent_t open_begin[16] = {};
@@ -94,7 +95,13 @@ State *state_create(int dev) {
   g_cur = nullptr;   // the thread's current device may have changed: the next bind() sets it again
   {
     std::lock_guard<std::mutex> lk(g_dev_mu);
-    if (!g_dev_ready[dev]) { if (set_kernel_attributes()) return nullptr; g_dev_ready[dev] = true; }
+    if (!g_dev_ready[dev]) {
+      // waits on this device sleep instead of spinning (see sync()); a process that has already fixed the device's flags keeps its choice
+      if (!getenv("FASTQUICK_SPIN_WAIT")) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
+      (void)hipGetLastError();
+      if (set_kernel_attributes()) return nullptr;
+      g_dev_ready[dev] = true;
+    }
     const char *q = getenv("GPU_MAX_HW_QUEUES");
     const int queues = q && atoi(q) > 0 ? atoi(q) : 4;
     if (++g_ctx_count[dev] + 2 > queues && !g_queue_warned) {
@@ -106,9 +113,10 @@ State *state_create(int dev) {
   State *s = new State;
   s->device = dev;
   bool ok = hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking) == hipSuccess &&
-            hipEventCreateWithFlags(&s->copy_done[0], hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&s->copy_done[1], hipEventDisableTiming) == hipSuccess &&
-            hipEventCreateWithFlags(&s->prep_done, hipEventDisableTiming) == hipSuccess;
+            hipEventCreateWithFlags(&s->copy_done[0], hipEventDisableTiming | hipEventBlockingSync) == hipSuccess &&
+            hipEventCreateWithFlags(&s->copy_done[1], hipEventDisableTiming | hipEventBlockingSync) == hipSuccess &&
+            hipEventCreateWithFlags(&s->prep_done, hipEventDisableTiming) == hipSuccess &&
+            hipEventCreateWithFlags(&s->sync_ev, hipEventDisableTiming | hipEventBlockingSync) == hipSuccess;
   if (!ok) { g_err = "stream / event creation failed"; state_destroy(s); return nullptr; }
   s->main_stream = s->stream;
   return s;
@@ -119,6 +127,7 @@ void state_destroy(State *s) {
   g_cur = nullptr;   // (as in state_create; also drops a pointer to the state being freed)
   s->stream = s->main_stream ? s->main_stream : s->stream;
   if (s->aux_stream) { (void)hipStreamSynchronize(s->aux_stream); (void)hipStreamDestroy(s->aux_stream); }
+  if (s->sync_ev) (void)hipEventDestroy(s->sync_ev);
   if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
   if (s->join_ev) (void)hipEventDestroy(s->join_ev);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
@@ -161,7 +170,16 @@ int h2d(void *dst, const void *src, size_t bytes) { FQ_PRE(); if (bytes) FQ_HIP(
 int d2h(void *dst, const void *src, size_t bytes) { FQ_PRE(); if (bytes) FQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream)); return 0; }
 int dzero(void *dst, size_t bytes) { FQ_PRE(); if (bytes) FQ_HIP(hipMemsetAsync(dst, 0, bytes, g_stream)); return 0; }
 int dfill(void *dst, int byte, size_t bytes) { FQ_PRE(); if (bytes) FQ_HIP(hipMemsetAsync(dst, byte, bytes, g_stream)); return 0; }
-int sync() { FQ_PRE(); FQ_HIP(hipStreamSynchronize(g_stream)); return 0; }
+// The calling thread SLEEPS until the stream has drained (an event with hipEventBlockingSync): hipStreamSynchronize spins, one core per
+// waiting stream -- sixteen WGS streams, or the ranks of a node, then burn the host's cores (and, in a container with a CPU quota, its
+// whole allowance) on waiting.  -DFQ_SPIN_SYNC / tuning key spin_sync=1: the spinning wait.
+int sync() {
+  FQ_PRE();
+  if (g_cur->tune.spin_sync || !g_cur->sync_ev) { FQ_HIP(hipStreamSynchronize(g_stream)); return 0; }
+  FQ_HIP(hipEventRecord(g_cur->sync_ev, g_stream));
+  FQ_HIP(hipEventSynchronize(g_cur->sync_ev));
+  return 0;
+}
 int stream_aux(int on) {
   FQ_PRE();
   if (on && !g_cur->aux_stream) {
