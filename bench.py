@@ -462,8 +462,9 @@ def main() -> None:
         if cpu_batch.seq is None:     # (the headline leg dropped its ASCII rows once they were packed)
             cpu_batch.seq = cpu_seq if cpu_seq is not None else make_batch(args.pairs, 1000 + 17 * rank, main_leg["on_frac"]).seq
         cores = os.cpu_count() or 1
-        fe = {"cores": cores}
-        pt = min(cores, 64)
+        usable = int(api.load_library().fq_host_cpus())     # (the container's CPU quota, not the hardware threads it shows)
+        fe = {"cores": cores, "cpus_usable": usable}
+        pt = max(2, min(2 * usable, 64))
         hp = api.HostPacked(cpu_batch.seq, cpu_batch.qual, cpu_batch.lens, None, threads=pt)
         best = 1e9
         for _ in range(4):
@@ -571,7 +572,7 @@ def main() -> None:
             x.join()
         dt = time.perf_counter() - t1
         cpu_model = next((ln.split(":", 1)[1].strip() for ln in open("/proc/cpuinfo") if ln.startswith("model name")), "unknown") if os.path.exists("/proc/cpuinfo") else "unknown"
-        out["cpu_baseline"] = {"value": round(d_pool / dt_pool, 1), "unit": "pairs/s", "cores": pool_t, "kind": "port", "cpu_model": cpu_model, "host_cpus": cores,
+        out["cpu_baseline"] = {"value": round(d_pool / dt_pool, 1), "unit": "pairs/s", "cores": pool_t, "kind": "port", "cpu_model": cpu_model, "host_cpus": cores, "cpus_usable": int(api.load_library().fq_host_cpus()),
                                "sample": "%d pairs of the same %s-mix input through oracle/fq_oracle.c, one stream in batches of %d pairs under the "
                                          "reference's pool geometry (stage A sliced over --t %d workers as src/BwtMapper.cpp:1490-1513, the rest on "
                                          "one thread), %.1f s" % (d_pool, args.mix, n_cpu, pool_t, dt_pool),

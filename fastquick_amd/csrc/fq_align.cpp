@@ -2192,6 +2192,8 @@ int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
 }
 }  // namespace
 
+extern "C" int fq_host_cpus(void) { return (int)effective_cpus(); }
+
 extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   if (!c || !out) return FQ_EINVAL;
   if (c->in_kind != 1) { c->err = "fq_align_resident: no batch uploaded (fq_batch_upload)"; return FQ_EINVAL; }

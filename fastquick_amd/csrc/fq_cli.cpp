@@ -104,7 +104,7 @@ struct Args {
   int opte = -1;
   long long chunk_pairs = 16LL * 262144;
   int device = 0;
-  int pack_threads = (int)std::min(32u, std::max(1u, std::thread::hardware_concurrency()));     // host threads of the FASTQ readers (half per file) and of the packer; --t sets it
+  int pack_threads = std::min(32, std::max(1, fq_host_cpus()));     // host threads of the FASTQ readers (half per file) and of the packer, from the CPUs the process may use; --t sets it
   bool clean_names = false;
   std::string fq_list, rg = "@RG\\tID:foo\\tSM:bar";   // runAlign's default --RG (src/FASTQuick.cpp:170)
   bool cal_dup = true;
