@@ -23,6 +23,28 @@ def test_library_exports_every_declared_symbol():
     assert set(api.EXPORTS) <= declared
 
 
+def test_host_cpus_respects_the_cgroup_quota():
+    """fq_host_cpus(): the hardware threads the process sees, cut to its cgroup's CPU quota when there is one (what the library sizes a
+    call's host threads by)."""
+    lib = api.load_library()
+    n = int(lib.fq_host_cpus())
+    assert 1 <= n <= (os.cpu_count() or 1)
+    quota = None
+    if os.path.exists("/sys/fs/cgroup/cpu.max"):
+        q, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = -(-int(q) // int(period))
+    else:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0 and period > 0:
+                quota = -(-q // period)
+        except OSError:
+            pass
+    if quota is not None:
+        assert n == max(1, min(os.cpu_count() or 1, quota))
+
+
 @pytest.mark.parametrize("tag", golden_util.case_tags())
 def test_index_builder_matches_reference_files(tag, golden_cases, tmp_path):
     g = golden_cases[tag]

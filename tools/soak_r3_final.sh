@@ -8,11 +8,11 @@ run() { # name, cmd...
   timeout 600 "$@" > $O/soak_$name.log 2>&1
   echo "$name: rc=$? OK=$(grep -c ' OK ' $O/soak_$name.log) FAIL=$(grep -c 'FAIL' $O/soak_$name.log) last: $(tail -1 $O/soak_$name.log | cut -c1-100)"
 }
-{ run parity python tests/fuzz_parity.py --seeds 200 --start 160000
-  run adversarial python tests/fuzz_parity.py --seeds 60 --start 161000 --adversarial
-  run ragged python tests/fuzz_parity.py --seeds 40 --start 161500 --ragged
-  run se python tests/fuzz_parity.py --seeds 120 --start 162000 --se
-  run consumers python tests/fuzz_consumers_vs_reference.py --seeds 400 --start 170000 --device 0 --budget 300
+{ run parity python tests/fuzz_parity.py --seeds 200 --start ${SOAK_BASE:-160000}
+  run adversarial python tests/fuzz_parity.py --seeds 60 --start $((${SOAK_BASE:-160000}+1000)) --adversarial
+  run ragged python tests/fuzz_parity.py --seeds 40 --start $((${SOAK_BASE:-160000}+1500)) --ragged
+  run se python tests/fuzz_parity.py --seeds 120 --start $((${SOAK_BASE:-160000}+2000)) --se
+  run consumers python tests/fuzz_consumers_vs_reference.py --seeds 400 --start $((${SOAK_BASE:-160000}+10000)) --device 0 --budget 300
 } > $O/soak_final.txt 2>&1
 cat $O/soak_final.txt
 timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | tail -2
