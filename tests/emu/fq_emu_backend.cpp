@@ -15,9 +15,10 @@
 namespace fqdev {
 static std::string g_err;
 struct State { Tune tune; };
+static thread_local State *g_bound = nullptr;   // (for the launcher's choice of search kernel: the tuning of the bound context)
 State *state_create(int) { return new State; }
-void state_destroy(State *s) { delete s; }
-int bind(State *) { return 0; }
+void state_destroy(State *s) { if (g_bound == s) g_bound = nullptr; delete s; }
+int bind(State *s) { g_bound = s; return 0; }
 Tune *tune(State *s) { return &s->tune; }
 void device_turn_begin() {}
 void device_turn_end() {}
@@ -106,8 +107,10 @@ int launch_gap(const FqGapArgs &a_in) {
     std::vector<uint16_t> heads(a.o.n_buckets);
     std::vector<uint32_t> cold(FQ_COLD_N);
     FqGapStoreLds st = {heads.data(), 1, cold.data()};
-    if (a.tier.nogap) fq_gap_lanes<true>(a, st, SeqFetch2{next_p, seg_lo, seg_hi}, 0);
-    else fq_gap_lanes<false>(a, st, SeqFetch2{next_p, seg_lo, seg_hi}, 0);
+    // the HIP launcher's rule: the kernels compiled for FASTQuick's own option block when the options match (FqOptsStock)
+    const bool stock = FqOptsStock::matches(a.o) && !(g_bound && g_bound->tune.gap_generic_opts);
+    if (a.tier.nogap) { if (stock) fq_gap_lanes<true, FqOptsStock>(a, st, SeqFetch2{next_p, seg_lo, seg_hi}, 0); else fq_gap_lanes<true>(a, st, SeqFetch2{next_p, seg_lo, seg_hi}, 0); }
+    else { if (stock) fq_gap_lanes<false, FqOptsStock>(a, st, SeqFetch2{next_p, seg_lo, seg_hi}, 0); else fq_gap_lanes<false>(a, st, SeqFetch2{next_p, seg_lo, seg_hi}, 0); }
   } else {
     FqGapStoreGlobal st = {nullptr, {}};
     fq_gap_lanes<false>(a, st, SeqFetch2{next_p, seg_lo, seg_hi}, 0);

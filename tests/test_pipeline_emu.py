@@ -20,7 +20,7 @@ def emu_lib():
     return api.load_library(os.path.join(EMU_DIR, "libfq_emu.so"))
 
 
-@pytest.mark.parametrize("mode", ["lanes", "wave", "threads", "packed", "packed_bulk", "nogap", "pipeline"])
+@pytest.mark.parametrize("mode", ["lanes", "wave", "threads", "packed", "packed_bulk", "nogap", "generic_opts", "pipeline"])
 @pytest.mark.parametrize("tag", golden_util.case_tags())
 def test_emulated_pipeline_matches_reference_golden(tag, mode, golden_cases, emu_lib):
     if mode not in ("lanes", "wave") and tag not in ("basic", "repeat", "edge", "qc", "trim76", "isize"):
@@ -34,6 +34,8 @@ def test_emulated_pipeline_matches_reference_golden(tag, mode, golden_cases, emu
         tuning = {"packed_bulk_min": 0}
     if mode == "nogap":         # every launch begins with the round that searches without gap children (device-filling launches do)
         tuning = {"gap_nogap_min": 0}
+    if mode == "generic_opts":  # ... with the search kernels that read the options from the launch (the default ones are compiled for FASTQuick's option block)
+        tuning = {"gap_nogap_min": 0, "gap_generic_opts": 1}
     if mode == "pipeline":      # ... in segments, each segment's second round issued beside the next segment's first (large calls do)
         tuning = {"gap_nogap_min": 0, "gap_pipeline_min": 0, "gap_pipeline_segs": 3}
     if mode == "packed":        # ... with the survivors' rows gathered on the host (few survivors)
