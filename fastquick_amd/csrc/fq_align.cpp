@@ -1708,6 +1708,10 @@ int stageB3_pairing(Call &K) {
             int nm;
             if (!(p[j]->extra_flag & 2) && p[1 - j]->type != FQ_TYPE_NO_MATCH) nm = (int)(p[j]->c1 + p[j]->c2) - 1 > o.N_multi ? o.n_multi : o.N_multi;
             else nm = o.n_multi;
+            // A read whose one hit is one row -- the main hit -- gets an empty list (choose_hit would build and drop the one entry); its
+            // list is empty already (records are reset per call and nothing else writes it in a paired call): most reads of an on-target
+            // set, and the record's second cache line stays untouched.
+            if (na[j] == 1 && aln[j][0].k == aln[j][0].l && aln[j][0].k == p[j]->sa) continue;
             { uint64_t no_rng = 0; choose_hit(no_rng, na[j], aln[j], *p[j], false, nm); }   // (XA selection draws no random numbers, bwase.c:47-95)
             const uint64_t base = K.aln_off[K.s_of[2 * sp + j]];
             for (auto &m : p[j]->multi) m.pos = h_pos[K.aln_row_off[base + m.aln] + m.row_in_aln];
