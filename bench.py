@@ -29,7 +29,8 @@ import time
 # device), and the runtime's default of four hardware queues would make sixteen contexts share queues (a 15 ms persistent
 # search kernel then blocks another stream's filter kernel).  Sixteen context streams + two copy streams + the null stream need
 # more than sixteen queues: with exactly 16 the last two contexts shared queues and finished 25 % after the others; 32 or more
-# oversubscribe the hardware queues and halve the throughput.  Must be set before the HIP runtime initialises.
+# oversubscribe the hardware queues and halve the throughput.  Must be set before the HIP runtime initialises: main() asks the library
+# for it (fq_runtime_configure) before anything touches the device; the variable is set here too because `import torch` may come first.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "20")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

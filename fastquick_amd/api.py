@@ -59,7 +59,7 @@ class Result(C.Structure):
                 ("len", C.c_int32), ("full_len", C.c_int32), ("clip_len", C.c_int32),
                 ("type", C.c_uint8), ("strand", C.c_uint8), ("filtered", C.c_uint8), ("extra_flag", C.c_uint8),
                 ("n_mm", C.c_uint8), ("n_gapo", C.c_uint8), ("n_gape", C.c_uint8), ("mapQ", C.c_uint8),
-                ("seQ", C.c_uint8), ("pad0", C.c_uint8), ("nm", C.c_uint16), ("n_cigar", C.c_uint16),
+                ("seQ", C.c_uint8), ("revived", C.c_uint8), ("nm", C.c_uint16), ("n_cigar", C.c_uint16),
                 ("n_multi", C.c_uint16), ("cigar_off", C.c_uint32), ("md_off", C.c_uint32), ("multi_off", C.c_uint32)]
 
 
@@ -90,10 +90,10 @@ class Stats(C.Structure):
 EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destroy", "fq_index_l_pac",
            "fq_index_n_contigs", "fq_index_contig", "fq_ctx_create", "fq_ctx_destroy", "fq_ctx_last_error",
            "fq_ctx_set_debug", "fq_align_batch", "fq_batch_upload", "fq_align_resident", "fq_sam_header",
-           "fq_sam_format_last", "fq_stage_dump_last", "fq_stats_get", "fq_stats_reset", "fq_version", "fq_host_cpus",
+           "fq_sam_format_last", "fq_stage_dump_last", "fq_stats_get", "fq_stats_reset", "fq_version", "fq_host_cpus", "fq_runtime_configure",
            "fq_pinned_alloc", "fq_pinned_free", "fq_pack_reads", "fq_packed_free", "fq_packed_create", "fq_pack_reads_into", "fq_pack_single_reads_into", "fq_packed_prefetch", "fq_packed_cancel", "fq_align_packed",
-           "fq_ctx_set_tuning", "fq_ctx_set_serial_hooks", "fq_ctx_state_export", "fq_ctx_state_import", "fq_qc_default_opts", "fq_qc_create", "fq_qc_destroy", "fq_qc_last_error", "fq_qc_begin_file",
-           "fq_qc_add_last", "fq_qc_end_file", "fq_qc_write", "fq_qc_state_reset", "fq_qc_state_export", "fq_qc_merge", "fq_bam_create", "fq_bam_add_last", "fq_bam_close",
+           "fq_ctx_set_tuning", "fq_ctx_set_serial_hooks", "fq_ctx_mark_stream_broken", "fq_ctx_state_export", "fq_ctx_state_import", "fq_qc_default_opts", "fq_qc_create", "fq_qc_destroy", "fq_qc_last_error", "fq_qc_begin_file",
+           "fq_qc_add_last", "fq_qc_end_file", "fq_qc_write", "fq_qc_state_reset", "fq_qc_state_export", "fq_qc_merge", "fq_bam_create", "fq_bam_add_last", "fq_bam_format_last", "fq_bam_write_records", "fq_bam_close",
            "fq_fastq_open", "fq_fastq_configure", "fq_fastq_set_sampling", "fq_fastq_read", "fq_fastq_last_error", "fq_fastq_dropped_record", "fq_fastq_is_bgzf", "fq_fastq_close"]
 
 SERIAL_HOOK = C.CFUNCTYPE(None, C.c_void_p)
@@ -161,6 +161,7 @@ def load_library(path: str | None = None):
     L.fq_fastq_close.argtypes = [C.c_void_p]
     L.fq_ctx_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.fq_ctx_set_serial_hooks.argtypes = [C.c_void_p, SERIAL_HOOK, SERIAL_HOOK, C.c_void_p]
+    L.fq_ctx_mark_stream_broken.argtypes = [C.c_void_p]
     L.fq_ctx_state_export.restype = C.c_int64
     L.fq_ctx_state_export.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.fq_ctx_state_import.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
@@ -403,6 +404,9 @@ class Aligner:
                 except BaseException as e:      # noqa: BLE001 -- re-raised by _check
                     if self._hook_error is None:
                         self._hook_error = e
+                    # tell the library: the call must not go on from a state this hook failed to bring in, and whatever is
+                    # exported from now on is marked broken for the ranks behind
+                    self.L.fq_ctx_mark_stream_broken(self.h)
             return run
         self._hooks = (SERIAL_HOOK(guard(before)) if before else SERIAL_HOOK(0), SERIAL_HOOK(guard(after)) if after else SERIAL_HOOK(0))
         self._check(self.L.fq_ctx_set_serial_hooks(self.h, self._hooks[0], self._hooks[1], None), "fq_ctx_set_serial_hooks")

@@ -62,6 +62,16 @@ template <class T> struct DevBuf {
     if (!p) { cap = 0; return false; }
     return true;
   }
+  bool ensure_keep(size_t n, size_t keep) {   // as ensure, but the first `keep` elements survive a reallocation (copied on the compute stream)
+    if (n <= cap) return true;
+    const size_t ncap = n + std::min<size_t>(n / 4, (size_t)16 << 20) + 64;
+    T *q = (T *)fqdev::dmalloc(ncap * sizeof(T));
+    if (!q) return false;
+    if (keep && (fqdev::d2d(q, p, keep * sizeof(T)) || fqdev::sync())) { fqdev::dfree(q); return false; }
+    fqdev::dfree(p);
+    p = q; cap = ncap;
+    return true;
+  }
 };
 }  // namespace
 
@@ -208,12 +218,31 @@ struct fq_ctx {
   // second set for the search rounds that run beside the first round of a large call (stageA_search)
   DevBuf<FqGapWork> d_winfo2; DevBuf<uint32_t> d_queue2, d_heads2, d_naln2, d_status2, d_wfull2, d_order_cnt2, d_cnt2; DevBuf<int32_t> d_work2, d_order2;
   DevBuf<FqPos> d_prec2; DevBuf<uint8_t> d_bid_end2; DevBuf<FqEntry> d_pool2; DevBuf<FqAln> d_aln2;
-  DevBuf<FqAln> d_aln, d_packed;
+  DevBuf<FqAln> d_aln;
+  DevBuf<FqAln> d_hits;                   // the hit lists of the call, every launch's behind the earlier ones'; by search index: d_aoff / d_an
+  DevBuf<uint64_t> d_aoff; DevBuf<uint32_t> d_an;
   DevBuf<uint64_t> d_off;
+  // the records of the call and their side arrays (fq_records.h)
+  DevBuf<FqDRec> d_rec, d_grec;
+  DevBuf<uint32_t> d_nocc, d_qfirst, d_cnt[3], d_isz;
+  DevBuf<uint16_t> d_ntop;
+  DevBuf<uint8_t> d_enum, d_cls;
+  DevBuf<uint64_t> d_row0, d_scan[3], d_rng, d_grow0;
+  DevBuf<int32_t> d_list, d_refmax;
+  DevBuf<fq_multi_t> d_multi, d_omulti;
+  DevBuf<FqSwTask> d_swslot; DevBuf<FqSwCand> d_swcand;
+  DevBuf<FqPairRead> d_greads; DevBuf<FqPairOut> d_gout;
+  DevBuf<FqRefTgt> d_reftgt;
+  DevBuf<uint16_t> d_cigs, d_ocig;
+  DevBuf<fq_isize_t> d_iis;
+  DevBuf<fq_result_t> d_orec;
+  DevBuf<char> d_omd;
+  PinBuf<fq_result_t> p_orec; PinBuf<uint16_t> p_ocig; PinBuf<char> p_omd; PinBuf<fq_multi_t> p_omulti;   // the C-ABI arrays land here
+  PinBuf<uint16_t> p_ntop; PinBuf<uint32_t> p_isz; PinBuf<int32_t> p_pairs;
   // SA
   DevBuf<FqAln> d_qaln;
   DevBuf<uint32_t> d_qlen, d_pos, d_qpos, d_qrow, d_qinfo;
-  DevBuf<FqPairJob> d_pjobs; DevBuf<FqPairRead> d_preads; DevBuf<FqPairOut> d_pout; DevBuf<FqPairIsize> d_pisize; DevBuf<int32_t> d_plut, d_glogn; DevBuf<uint64_t> d_pscratch;
+  DevBuf<FqPairIsize> d_pisize; DevBuf<int32_t> d_plut, d_glogn; DevBuf<uint64_t> d_pscratch;
   DevBuf<uint64_t> d_qoff;
   // DP
   DevBuf<FqSwTask> d_swtask;
@@ -222,14 +251,12 @@ struct fq_ctx {
   DevBuf<FqRefOut> d_refout;
   DevBuf<uint16_t> d_cig, d_cigarena;
   DevBuf<uint8_t> d_scratch;
-  DevBuf<FqMdTask> d_mdtask;
-  DevBuf<char> d_md, d_mdpacked;
-  DevBuf<int32_t> d_mdlen, d_nm;
-  DevBuf<uint32_t> d_mdsz;
+  DevBuf<char> d_md;
   // host staging
   vector<uint8_t> h_filtered;
-  vector<int32_t> h_len_trim, h_pair_list, h_sub_max;
-  vector<FqSurvInfo> h_surv;
+  vector<int32_t> h_len_trim, h_sub_max;
+  const int32_t *h_pair_list = nullptr;   // survivor pair -> pair of the batch (p_pairs, where the copy engine lands it)
+  const FqSurvInfo *h_surv = nullptr;     // ... and the survivors' search indices (p_surv)
   PinArena arena;
   PinBuf<int32_t> p_i32;
   PinBuf<FqSurvInfo> p_surv;
@@ -240,27 +267,12 @@ struct fq_ctx {
   int64_t n_bases_in = 0;
   // results of the last batch
   FqBatchState st;
-  struct CallVecs {            // per-call host arrays of one entry per read: kept here so that a call reuses the last call's pages
-    std::vector<uint64_t> read_nocc, aln_row_off;
-    std::vector<uint32_t> q_first;
-    std::vector<char> enumerated;
-    std::vector<uint32_t> isz;           // one insert-size sample per survivor pair (stageB2_isize)
+  struct CallVecs {            // per-call host arrays of one entry per searched read: kept here so that a call reuses the last call's pages
     std::vector<int32_t> work, next_work;
-    std::vector<uint16_t> ntop;
-    std::vector<uint32_t> pq, job_of;
-    std::vector<uint64_t> prow;
-    std::vector<char> on_device;
-    std::vector<uint8_t> sub_of;
   } cv;
   fq_stats_t stats{};
   ~fq_ctx();
 };
-
-// ---- drand48 (glibc): X' = (0x5DEECE66D X + 0xB) mod 2^48, value X'/2^48 ------------------------------
-static inline double rng_step(uint64_t &x) {   // glibc drand48: X' = (0x5DEECE66D X + 0xB) mod 2^48, result X' / 2^48
-  x = (0x5DEECE66DULL * x + 0xBULL) & 0xFFFFFFFFFFFFULL;
-  return (double)x * (1.0 / 281474976710656.0);
-}
 
 extern "C" void fq_default_opts(fq_opts_t *o) {
   memset(o, 0, sizeof *o);
@@ -287,6 +299,7 @@ extern "C" int fq_ctx_create(const fq_index_t *ix, const fq_opts_t *opts, int32_
   if (o.batch_pairs < 1) return FQ_EINVAL;
   if (o.max_seed_diff < 0 || o.max_seed_diff > 30) return FQ_EINVAL;       // 5-bit lower bounds in the packed position records
   if (o.max_entries < 1 || o.max_entries > (1 << 30)) return FQ_EINVAL;   // 32-bit live-entry counter in the search kernel
+  if (o.max_occ > (1u << 30) || o.n_multi < 0 || o.N_multi < 0 || o.n_multi > 4096 || o.N_multi > 4096) return FQ_EINVAL;   // 32-bit row counts per pair (fq_enum_plan_thread)
   std::unique_ptr<fq_ctx> c(new fq_ctx);
   c->ix = ix; c->o = o; c->max_pairs = max_pairs;
   int md_max = 0;
@@ -309,8 +322,8 @@ extern "C" int fq_ctx_create(const fq_index_t *ix, const fq_opts_t *opts, int32_
   k.max_top2 = o.max_top2; k.trim_qual = o.trim_qual; k.filter_thresh = o.filter_thresh; k.n_buckets = FQ_MAX_BUCKETS;
   c->dev = fqdev::state_create(ix->device);
   if (!c->dev || fqdev::bind(c->dev)) return FQ_ENODEV;
-  if (!c->d_maxdiff.ensure(FQ_LMAX + 2) || !c->d_counters.ensure(FQ_C_COUNT) || !c->d_counts.ensure(4) || !c->d_queue.ensure(4)) return FQ_ENOMEM;
-  if (fqdev::h2d(c->d_maxdiff.p, c->maxdiff_lut, FQ_LMAX + 2) || fqdev::dzero(c->d_counters.p, FQ_C_COUNT * 8) || fqdev::sync()) return FQ_ENODEV;
+  if (!c->d_maxdiff.ensure(FQ_LMAX + 2) || !c->d_counters.ensure(FQ_C_COUNT) || !c->d_counts.ensure(4) || !c->d_queue.ensure(4) || !c->d_glogn.ensure(256)) return FQ_ENOMEM;
+  if (fqdev::h2d(c->d_maxdiff.p, c->maxdiff_lut, FQ_LMAX + 2) || fqdev::h2d(c->d_glogn.p, c->g_log_n, 256 * 4) || fqdev::dzero(c->d_counters.p, FQ_C_COUNT * 8) || fqdev::sync()) return FQ_ENODEV;
   *out = c.release();
   return FQ_OK;
 }
@@ -564,70 +577,7 @@ void par_prefix(std::vector<T> &v, int threads, size_t par_min) {
   (void)per;
 }
 
-// bwa_aln2seq_core, libbwa/bwase.c:19-95
-void choose_hit(uint64_t &rng, int n_aln, const FqAln *aln, FqRead &s, bool set_main, int n_multi) {
-  if (n_aln == 0) { s.type = FQ_TYPE_NO_MATCH; s.c1 = s.c2 = 0; return; }
-  if (set_main) {
-    const int best = aln[0].score;
-    int i;
-    uint32_t cnt = 0;
-    for (i = 0; i < n_aln; ++i) {
-      const FqAln &p = aln[i];
-      if (p.score > best) break;
-      const uint32_t wdt = p.l - p.k + 1;
-      if (rng_step(rng) * (double)(uint32_t)(wdt + cnt) > (double)(int)cnt) {
-        s.n_mm = p.info & 0xff; s.n_gapo = (p.info >> 8) & 0xff; s.n_gape = (p.info >> 16) & 0xff; s.strand = (p.info >> 24) & 1;
-        s.score = p.score;
-        s.sa = p.k + (uint32_t)((double)wdt * rng_step(rng));
-        s.main_aln = i;
-      }
-      cnt += wdt;
-    }
-    s.c1 = cnt & 0xfffffff;
-    for (; i < n_aln; ++i) cnt += aln[i].l - aln[i].k + 1;
-    s.c2 = (cnt - s.c1) & 0xfffffff;
-    s.type = s.c1 > 1 ? FQ_TYPE_REPEAT : FQ_TYPE_UNIQUE;
-  }
-  if (n_multi) {
-    int n_occ = 0;
-    for (int k = 0; k < n_aln; ++k) n_occ += (int)(aln[k].l - aln[k].k + 1);
-    s.multi.clear();
-    if (n_occ > n_multi + 1) return;
-    if (n_occ == 1 && aln[0].k == s.sa) return;   // (the one row is the main hit: the list stays empty -- most reads of an on-target set)
-    for (int k = 0; k < n_aln; ++k) {
-      const FqAln &q = aln[k];
-      const uint32_t wdt = q.l - q.k + 1;
-      for (uint32_t t = 0; t < wdt; ++t) {
-        FqMulti m;
-        m.pos = q.k + t; m.gap = (int)((q.info >> 8) & 0xff) + (int)((q.info >> 16) & 0xff); m.mm = (int)(q.info & 0xff);
-        m.strand = (int)(q.info >> 24) & 1; m.aln = k; m.row_in_aln = t;
-        s.multi.push_back(m);
-      }
-    }
-    size_t keep = 0;
-    for (size_t k = 0; k < s.multi.size(); ++k) if (s.multi[k].pos != s.sa) s.multi[keep++] = s.multi[k];
-    s.multi.resize(std::min(keep, (size_t)n_multi));
-  }
-}
-
-int approx_mapq(const fq_ctx *c, const FqRead &p, int mm) {   // bwa_approx_mapQ, bwase.c:102-111
-  if (p.c1 == 0) return 23;
-  if (p.c1 > 1) return 0;
-  if (p.n_mm == mm) return 25;
-  if (p.c2 == 0) return 37;
-  const int n = p.c2 >= 255 ? 255 : (int)p.c2;
-  return 23 < c->g_log_n[n] ? 0 : 23 - c->g_log_n[n];
-}
-
 // infer_isize, libbwa/bwape.c:49-117
-// the insert size infer_isize looks at for one pair, or ~0 (bwape.c:62-71: both ends mapQ >= 20, below 100,000)
-static inline uint32_t pair_isize_sample(const FqRead &a, const FqRead &b) {
-  if (a.mapQ >= 20 && b.mapQ >= 20) {
-    const uint64_t x = a.pos < b.pos ? (uint64_t)(uint32_t)(b.pos + (uint32_t)b.len - a.pos) : (uint64_t)(uint32_t)(a.pos + (uint32_t)a.len - b.pos);
-    if (x < 100000) return (uint32_t)x;
-  }
-  return ~0u;
-}
 // (isz: one sample per survivor pair, written by all of the call's threads -- the scan of the records is what this stage costs, and a
 // reference batch per thread leaves most of them idle)
 void infer_isize(const uint32_t *isz, int sp_lo, int sp_hi, int max_len_all, fq_isize_t *ii, double ap_prior, int64_t L) {
@@ -666,21 +616,7 @@ void infer_isize(const uint32_t *isz, int sp_lo, int sp_hi, int max_len_all, fq_
 }
 
 // pairing + __pairing_aux/__pairing_aux2, libbwa/bwape.c:119-213, bwape.h:55-82: fq_pair_sweep (fq_kernels.h) is the one
-// implementation -- k_pair runs it per lane, and the host runs it for the pairs the kernel does not take.
-inline FqPairRead pair_read_of(const FqRead &p) {
-  FqPairRead r;
-  r.pos = p.pos; r.len = p.len; r.full_len = p.full_len; r.bits = (uint32_t)(p.strand & 1) | (uint32_t)(p.mapQ & 0xff) << 8 | (uint32_t)(p.seQ & 0xff) << 16;
-  return r;
-}
-inline void pair_apply(FqRead &q, const FqPairOut &o) {
-  if (!((o.bits >> 24) & 1u)) return;            // no proper pair: the records stay as they are
-  q.mapQ = (int)(o.bits & 0xffu); q.seQ = (int)((o.bits >> 8) & 0xffu);
-  q.extra_flag |= 2;
-  if ((o.bits >> 25) & 1u) {                     // the pair's hit is not the read's main hit: the record moves (bwape.c:196-211)
-    q.n_mm = o.info & 0xff; q.n_gapo = (o.info >> 8) & 0xff; q.n_gape = (o.info >> 16) & 0xff; q.strand = (int)((o.bits >> 16) & 1u); q.score = o.score;
-    q.pos = o.pos;
-  }
-}
+// implementation -- fq_pair_rec_thread runs it per lane, and the host runs it for the pairs the kernel does not take.
 // the insert-size term of bwape.h:62 for every insert size of one reference batch (libm, as the reference evaluates it per candidate)
 void pair_penalty_lut(const fq_isize_t &ii, vector<int32_t> &lut) {
   if (!ii.high) return;
@@ -689,24 +625,15 @@ void pair_penalty_lut(const fq_isize_t &ii, vector<int32_t> &lut) {
     lut.push_back(v >= 2147483648.0 || v != v ? INT32_MIN : (int32_t)v);   // (what the x86 conversion leaves for an infinite value)
   }
 }
-void pair_hits(fq_ctx *c, const FqPairIsize &pi, const int32_t *lut, FqRead *p[2], const FqAln *aln[2], vector<uint64_t> &arr) {
-  std::sort(arr.begin(), arr.end());
-  FqPairRead r[2] = {pair_read_of(*p[0]), pair_read_of(*p[1])};
-  FqPairOut out[2];
-  fq_pair_sweep(aln[0], aln[1], r, arr.data(), (uint32_t)arr.size(), pi, lut, c->g_log_n, c->o.max_isize, c->o.s_mm, out);
-  pair_apply(*p[0], out[0]); pair_apply(*p[1], out[1]);
-}
-
 }  // namespace
 
 // ---- the batch ------------------------------------------------------------------------------------------
-// One call = stage 0 (filter + ordered compaction; the only stage that sees every read), then the stages below over the
-// reads of surviving pairs.  The stage functions share the per-call state in `Call`.
+// One call = stage 0 (filter + ordered compaction; the only stage that sees every read), the search over the reads of surviving
+// pairs, then the record stages (fq_records.h) over device-resident records.  The stage functions share the per-call state in `Call`.
 namespace {
 struct Call {
   fq_ctx *c;
-  explicit Call(fq_ctx *ctx) : c(ctx), aln_off(ctx->st.aln_off), aln_n(ctx->st.aln_n), s_of(ctx->st.s_of), read_nocc(ctx->cv.read_nocc),
-                               aln_row_off(ctx->cv.aln_row_off), q_first(ctx->cv.q_first), enumerated(ctx->cv.enumerated) {}
+  explicit Call(fq_ctx *ctx) : c(ctx), aln_off(ctx->st.aln_off), aln_n(ctx->st.aln_n) {}
   int n = 0, n2 = 0, B = 0, n_sub = 0, n_search = 0, n_surv = 0, max_len_all = 1, host_threads = 1;
   size_t par_min = 32768;
   // where the kernels after the filter find the reads: ASCII rows [row][dstride], trimmed lengths [row], search index -> row.
@@ -715,23 +642,29 @@ struct Call {
   int dstride = 0;
   const int32_t *dlen_trim = nullptr, *dread_list = nullptr;
   vector<int> sub_max_len, sub_lo;
-  // (the arrays of one entry per read live in the context -- the batch state's for the ones the consumers read -- and keep their pages)
+  // (the arrays of one entry per searched read live in the batch state and keep their pages)
   vector<uint64_t> &aln_off;           // per search index s: its hit list is S.aln[aln_off[s] .. + aln_n[s])
   vector<uint32_t> &aln_n;
-  vector<int> &s_of;                   // survivor read -> search index or -1
-  vector<uint64_t> &read_nocc, &aln_row_off;
-  vector<uint32_t> &q_first;           // survivor read -> its first hit in the list k_sa enumerated (valid when enumerated)
-  uint64_t n_rows = 0;
-  vector<char> &enumerated;
-  const uint32_t *h_pos = nullptr;     // positions of the enumerated SA rows (pinned staging of the context)
+  FqRecArgs ra{};                      // the record stages' arguments, filled in as the stages go
+  uint64_t n_q = 0, n_rows = 0;        // hits / SA rows enumerated
+  const uint32_t *h_pos = nullptr;     // positions of the enumerated SA rows (pinned staging of the context; fetched when the host pairs)
+  bool have_pos = false;
   vector<fq_isize_t> iis;
-  // the main-hit stage's plan (stageB1_plan): where every range of reads enters the drand48 stream
-  struct B1Plan { int T = 1; size_t per = 0; vector<uint64_t> start; uint64_t rng_end = 0; } plan;
+  vector<FqPairIsize> pis;             // insert-size penalty tables, one per reference batch
+  vector<int32_t> lut;
+  int64_t n_host_pairs = 0;            // pairs the host pairs (FqRecArgs::cls == 2), listed in c->d_list / host_list
+  const int32_t *host_list = nullptr;
+  const FqPairRead *host_reads = nullptr;
+  const uint64_t *host_row0 = nullptr;
+  uint64_t n_multi = 0, n_sw = 0, n_ref = 0, cig_used = 0;   // XA entries, mate-rescue tasks, refine tasks, CIGAR arena entries in use
+  // the main-hit stage's plan (stageB1_plan): where every chunk of pairs enters the drand48 stream
+  struct B1Plan { uint64_t *start = nullptr; size_t n_chunks = 0; uint64_t rng_end = 0; } plan;
   std::thread plan_thread;             // the plan is drawn up beside the SA stage when nothing else can move the stream's state
   ~Call() { if (plan_thread.joinable()) plan_thread.join(); }
   double t_trace = 0, t_wall0 = 0, t_host0 = 0, t_serial1 = 0, t_host1 = 0, cpu_trace = 0;
-  const FqAln *aln_of(int idx, int *n_out) const {
-    const int s = s_of[idx];
+  int sidx(size_t idx) const { return c->h_surv[idx].sidx; }
+  const FqAln *aln_of(size_t idx, int *n_out) const {
+    const int s = sidx(idx);
     if (s < 0) { *n_out = 0; return nullptr; }
     *n_out = (int)aln_n[s];
     return c->st.aln.data() + aln_off[s];
@@ -751,18 +684,16 @@ struct Call {
 int stage0_lists(Call &K, bool have_len_trim) {
   fq_ctx *c = K.c;
   const int n_surv = K.n_surv;
-  c->h_pair_list.resize(n_surv);
-  c->h_surv.resize((size_t)n_surv * 2);
-  CKM(c->p_i32.ensure((size_t)n_surv + 1) && c->p_surv.ensure((size_t)n_surv * 2 + 1));
-  CK(fqdev::copy_pinned(c->p_i32.p, c->d_pair_list.p, (size_t)n_surv * 4, 0));
+  CKM(c->p_pairs.ensure((size_t)n_surv + 1) && c->p_surv.ensure((size_t)n_surv * 2 + 1));
+  CK(fqdev::copy_pinned(c->p_pairs.p, c->d_pair_list.p, (size_t)n_surv * 4, 0));
   CK(fqdev::copy_pinned(c->p_surv.p, c->d_surv.p, (size_t)n_surv * 2 * sizeof(FqSurvInfo), 0));
   CKS(sync_staged(c));
   c->stats.d2h_bytes += (size_t)n_surv * (4 + 2 * sizeof(FqSurvInfo));
-  if (n_surv) { memcpy(c->h_pair_list.data(), c->p_i32.p, (size_t)n_surv * 4); memcpy(c->h_surv.data(), c->p_surv.p, (size_t)n_surv * 2 * sizeof(FqSurvInfo)); }
+  c->h_pair_list = c->p_pairs.p; c->h_surv = c->p_surv.p;   // read where they land
   (void)have_len_trim;
   K.sub_lo.assign(K.n_sub + 1, 0);
-  int sp = 0;
-  for (int sb = 0; sb < K.n_sub; ++sb) { K.sub_lo[sb] = sp; while (sp < n_surv && c->h_pair_list[sp] < (int64_t)(sb + 1) * K.B) ++sp; }
+  for (int sb = 0; sb <= K.n_sub; ++sb)   // (the list is ascending)
+    K.sub_lo[sb] = (int)(std::lower_bound(c->h_pair_list, c->h_pair_list + n_surv, (int32_t)std::min<int64_t>((int64_t)sb * K.B, INT32_MAX)) - c->h_pair_list);
   K.sub_lo[K.n_sub] = n_surv;
   return FQ_OK;
 }
@@ -858,8 +789,8 @@ int stage0_packed(Call &K) {
   const int slot = c->head_slot;   // chosen by fq_align_packed: the buffer the batch was prefetched into, else a free one (uploaded now)
   CK(fqdev::compute_wait_copy(slot));
   const bool have_qlast = trim && pb.qual_last != nullptr;
-  CKM(c->d_filtered.ensure(n2 + 64) && c->d_read_list.ensure(n2) && c->d_sidx.ensure(n2) && c->d_pair_list.ensure(n) && c->d_sub_max.ensure((size_t)2 * n_sub));
-  CK(fqdev::dzero(c->d_sub_max.p, (size_t)2 * n_sub * 4));
+  CKM(c->d_filtered.ensure(n2 + 64) && c->d_read_list.ensure(n2) && c->d_sidx.ensure(n2) && c->d_pair_list.ensure(n) && c->d_sub_max.ensure((size_t)3 * n_sub));
+  CK(fqdev::dzero(c->d_sub_max.p, (size_t)3 * n_sub * 4));
   if (se) CK(fqdev::dfill(c->d_filtered.p + n, 1, (size_t)n));
   FqPrepPackedArgs a{};
   a.qual_last = have_qlast ? c->d_qlast[slot].p : nullptr; a.sub_whole = c->d_sub_max.p + n_sub;
@@ -910,6 +841,7 @@ int stage0_packed(Call &K) {
   pa.seq = c->d_seq.p; pa.stride = cstride;
   FqTrimArgs ta{};
   ta.o = c->ko; ta.qual_stride = pb.qual_stride; ta.len = c->d_len_c.p; ta.n_rows = nrow; ta.len_trim = c->d_len_trim.p;
+  ta.pair_list = c->d_pair_list.p; ta.batch_pairs = B; ta.sub_max = c->d_sub_max.p + 2 * n_sub;
   if (nrow && bulk) {
     CKM(c->d_body.ensure((size_t)n2 * body_stride + 64));
     CK(fqdev::h2d(c->d_body.p, pb.body, (size_t)n2 * body_stride));
@@ -982,18 +914,9 @@ int stage0_packed(Call &K) {
     if (trim) CK(fqdev::launch_trim(ta));
   }
   fqdev::time_end(FQ_K_PREP);
-  // lengths of the survivors' reads come back (full from the host's own arrays, trimmed from the device)
-  vector<int32_t> lt((size_t)nrow);
-  if (nrow && trim) { CKS(d2h_staged(c, lt.data(), c->d_len_trim.p, (size_t)nrow * 4)); CKS(sync_staged(c)); c->stats.d2h_bytes += (size_t)nrow * 4; }
-  vector<int> surv_max(n_sub, 0);
-  for (int t = 0; t < nrow; ++t) {
-    const size_t r = (size_t)(t & 1) * (size_t)n + (size_t)c->h_pair_list[t >> 1];
-    const int full = se && (t & 1) ? 0 : ragged ? (int)pb.len[r] : pb.uniform_len;
-    const int ltr = trim ? lt[t] : full;
-    c->h_surv[t].len_trim = ltr;
-    const int sb = c->h_pair_list[t >> 1] / B;
-    surv_max[sb] = std::max(surv_max[sb], ltr);
-  }
+  // the longest trimmed read among the survivors of every reference batch (the records themselves are set up on the device)
+  vector<int32_t> surv_max(n_sub, 0);
+  if (nrow && trim) { CKS(d2h_staged(c, surv_max.data(), c->d_sub_max.p + 2 * n_sub, (size_t)n_sub * 4)); CKS(sync_staged(c)); c->stats.d2h_bytes += (size_t)n_sub * 4; }
   // infer_isize's max_len is the longest trimmed read of the whole reference batch, filtered reads included (bwape.c:60-61).
   // Without trimming that is the longest read (known above).  With trimming, the trimmed lengths of the survivors are known, and
   // so is the length of every read that trimming leaves whole (from its last quality byte, fq_prep_packed_thread); every other
@@ -1041,6 +964,8 @@ int stageA_search(Call &K) {
   c->st.aln.p = c->p_aln.p; c->st.aln.n = 0;
   par_assign(K.aln_off, (size_t)n_search + 1, (uint64_t)0, K.host_threads, K.par_min);
   par_assign(K.aln_n, (size_t)n_search, (uint32_t)0, K.host_threads, K.par_min);
+  CKM(c->d_aoff.ensure((size_t)n_search + 1) && c->d_an.ensure((size_t)n_search + 1) && c->d_hits.ensure(1));
+  CK(fqdev::dzero(c->d_an.p, ((size_t)n_search + 1) * 4));
   const int Lpad = (max_len_all + 1 + 7) & ~7;                  // exact widths per strand; rows are written 8 positions at a time
   const int Ppad = (max_len_all + 1 + FQ_POS_PAD + 7) & ~7;     // position records per strand (16-byte aligned rows)
   // tier 0: one read per lane, bounded stack and pop count; what it gives up on is searched again by one wavefront per read
@@ -1211,9 +1136,10 @@ int stageA_search(Call &K) {
       // the packed array holds exactly the lists of the reads that completed, in work order (a failed read reports no hits): it
       // lands behind the lists of the earlier launches, and every read finds its list at the offset the device's prefix sum gave it
       const uint64_t base = c->st.aln.n;
-      CKM(c->d_packed.ensure(total + 1) && c->p_aln.ensure_keep(base + total + 1, base));
-      CK(fqdev::launch_pack_aln(c->d_aln.p, c->d_naln.p, c->d_off.p, T.aln_cap, (uint32_t)nw, c->d_packed.p));
-      CK(fqdev::copy_pinned(c->p_aln.p + base, c->d_packed.p, total * sizeof(FqAln), 0));
+      CKM(c->d_hits.ensure_keep(base + total + 1, base) && c->p_aln.ensure_keep(base + total + 1, base));
+      CK(fqdev::launch_pack_aln(c->d_aln.p, c->d_naln.p, c->d_off.p, T.aln_cap, (uint32_t)nw, c->d_hits.p + base));
+      CK(fqdev::launch_aln_index(c->d_work.p, c->d_status.p, c->d_off.p, c->d_naln.p, base, c->d_aoff.p, c->d_an.p, nw));   // the device's own index of the lists (the records stay there)
+      CK(fqdev::copy_pinned(c->p_aln.p + base, c->d_hits.p + base, total * sizeof(FqAln), 0));
       CKS(sync_staged(c));
       c->stats.d2h_bytes += (size_t)nw * 8 + total * sizeof(FqAln);
       c->st.aln.p = c->p_aln.p; c->st.aln.n = base + total;
@@ -1265,9 +1191,10 @@ int stageA_search(Call &K) {
         CKS(sync_staged(c));
         const uint64_t tot2 = off2[n2_total];
         const uint64_t base2 = c->st.aln.n;
-        CKM(c->d_packed.ensure(tot2 + 1) && c->p_aln.ensure_keep(base2 + tot2 + 1, base2));
-        CK(fqdev::launch_pack_aln(c->d_aln2.p, c->d_naln2.p, c->d_off.p, T2.aln_cap, n2_total, c->d_packed.p));
-        CK(fqdev::copy_pinned(c->p_aln.p + base2, c->d_packed.p, tot2 * sizeof(FqAln), 0));
+        CKM(c->d_hits.ensure_keep(base2 + tot2 + 1, base2) && c->p_aln.ensure_keep(base2 + tot2 + 1, base2));
+        CK(fqdev::launch_pack_aln(c->d_aln2.p, c->d_naln2.p, c->d_off.p, T2.aln_cap, n2_total, c->d_hits.p + base2));
+        CK(fqdev::launch_aln_index(c->d_work2.p, c->d_status2.p, c->d_off.p, c->d_naln2.p, base2, c->d_aoff.p, c->d_an.p, (int)n2_total));
+        CK(fqdev::copy_pinned(c->p_aln.p + base2, c->d_hits.p + base2, tot2 * sizeof(FqAln), 0));
         CKS(sync_staged(c));
         c->stats.d2h_bytes += (size_t)n2_total * 20 + tot2 * sizeof(FqAln);
         c->st.aln.p = c->p_aln.p; c->st.aln.n = base2 + tot2;
@@ -1289,159 +1216,82 @@ int stageA_search(Call &K) {
   return FQ_OK;
 }
 
-// ---- records for survivors -----------------------------------------------------------------------------
-void stage_records(Call &K) {
-  fq_ctx *c = K.c;
-  const int n = K.n, n_surv = K.n_surv;
-  vector<FqRead> &R = c->st.reads;
-  R.resize((size_t)n_surv * 2);                      // reused storage: every record is reset below
-  par_assign(K.s_of, (size_t)n_surv * 2, (int)-1, K.host_threads, K.par_min);
-  const bool packed = c->in_kind == 2;
-  // (R.resize above touches new storage on the calling thread, which also runs the serial phases; resetting reused records is spread)
-  parallel_chunks((size_t)n_surv, K.host_threads, K.par_min, [&](size_t lo_sp, size_t hi_sp, int) {
-  for (int sp = (int)lo_sp; sp < (int)hi_sp; ++sp)
-    for (int e = 0; e < 2; ++e) {
-      FqRead &p = R[2 * sp + e];
-      const int r = e * n + c->h_pair_list[sp];
-      const FqSurvInfo &si = c->h_surv[2 * sp + e];
-      p.reset();
-      p.r = r;
-      p.dr = packed ? 2 * sp + e : r;
-      p.full_len = c->o.single_end && e == 1 ? 0 : packed ? (c->pb.uniform_len > 0 ? c->pb.uniform_len : (int)c->pb.len[r]) : c->hb.len[r];
-      p.len = p.clip_len = si.len_trim;
-      p.filtered = (uint8_t)si.filtered;
-      p.extra_flag = c->o.single_end ? 0 : (1 | (e == 0 ? 64 : 128));   // SAM_FPD | SAM_FR1/FR2 (BwtMapper.cpp:749); the single-end mapper sets none
-      K.s_of[2 * sp + e] = si.sidx;
-    }
-  });
-}
+// ---- the record stages (fq_records.h): the reads' records live on the device from here to the result arrays ------------------------
+#define REC(op, n) CK(fqdev::launch_rec((op), K.ra, (int64_t)(n)))
+// one 64-bit total of a device-side prefix sum (launch_scan leaves it behind the sums), valid after the next sync_staged
+static int fetch_u64(fq_ctx *c, uint64_t *dst, const uint64_t *src) { return d2h_staged(c, dst, src, 8); }
 
-// ---- SA rows to resolve on the GPU: every row of every hit of reads that can need them ------------------
-// eligible(read) = n_occ <= max(n_multi,N_multi)+1  (XA listing, bwase.c:47-55)  or
-//                  both mates have hits and both n_occ <= max_occ (pair enumeration, BwtMapper.cpp:797-811)
-int stage_sa_rows(Call &K) {
+// fresh records, the rows of every read's hits, the plan of the SA enumeration; what the drand48 replay needs comes back
+int stage_records(Call &K) {
   fq_ctx *c = K.c;
-  const fq_index *ix = c->ix;
   const fq_opts_t &o = c->o;
   const int n_surv = K.n_surv;
-  vector<FqRead> &R = c->st.reads;
-  par_assign(K.read_nocc, (size_t)n_surv * 2, (uint64_t)0, K.host_threads, K.par_min);
-  par_assign(K.enumerated, (size_t)n_surv * 2, (char)0, K.host_threads, K.par_min);
-  par_assign(K.q_first, (size_t)n_surv * 2, (uint32_t)0, K.host_threads, K.par_min);
-  par_assign(K.aln_row_off, (size_t)c->st.aln.size() + 1, ~(uint64_t)0, K.host_threads, K.par_min);   // per hit in S.aln order -> offset into h_pos
-  const uint32_t multi_cap = o.single_end ? 4u : (uint32_t)std::max(o.n_multi, o.N_multi) + 1;   // (single-end: N_OCC + 1, src/BwtMapper.cpp:33, 1344)
-  parallel_chunks(R.size(), K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
-    for (size_t idx = lo; idx < hi; ++idx) {
-      int na; const FqAln *a = K.aln_of((int)idx, &na);
-      uint64_t t = 0;
-      for (int k = 0; k < na; ++k) t += (uint64_t)(a[k].l - a[k].k) + 1;
-      K.read_nocc[idx] = t;
-    }
-  });
-  // which reads are enumerated and where their hits and rows go: counts per pair (parallel), one prefix sum, then the lists are
-  // written where the copy engine reads them (parallel)
-  vector<uint32_t> &pq = c->cv.pq;                  // hits enumerated before pair sp
-  vector<uint64_t> &prow = c->cv.prow;              // rows before pair sp
-  pq.resize((size_t)n_surv + 1); prow.resize((size_t)n_surv + 1);   // (every element is written below)
-  pq[0] = 0; prow[0] = 0;
-  parallel_chunks((size_t)n_surv, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
-    for (size_t sp = lo; sp < hi; ++sp) {
-      int na0, na1;
-      K.aln_of((int)(2 * sp), &na0); K.aln_of((int)(2 * sp + 1), &na1);
-      const bool pair_ok = na0 > 0 && na1 > 0 && K.read_nocc[2 * sp] <= o.max_occ && K.read_nocc[2 * sp + 1] <= o.max_occ;
-      uint32_t nq = 0; uint64_t nr = 0;
-      for (int e = 0; e < 2; ++e) {
-        const size_t idx = 2 * sp + e;
-        const int na = e ? na1 : na0;
-        if (na == 0 || !(pair_ok || K.read_nocc[idx] <= multi_cap)) continue;
-        K.enumerated[idx] = 1;
-        nq += (uint32_t)na; nr += K.read_nocc[idx];
-      }
-      pq[sp + 1] = nq; prow[sp + 1] = nr;
-    }
-  });
-  par_prefix(pq, K.host_threads, K.par_min);
-  par_prefix(prow, K.host_threads, K.par_min);
-  const size_t n_q = pq[n_surv];
-  const uint64_t rows = prow[n_surv];
-  FqAln *q_aln = nullptr; uint32_t *q_len = nullptr; uint64_t *q_off = nullptr;
-  if (n_q) {
-    q_aln = (FqAln *)c->arena.alloc(n_q * sizeof(FqAln)); q_len = (uint32_t *)c->arena.alloc(n_q * 4); q_off = (uint64_t *)c->arena.alloc((n_q + 1) * 8);
-    if (!q_aln || !q_len || !q_off) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
-    parallel_chunks((size_t)n_surv, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
-      for (size_t sp = lo; sp < hi; ++sp) {
-        uint32_t q = pq[sp]; uint64_t r0 = prow[sp];
-        for (int e = 0; e < 2; ++e) {
-          const size_t idx = 2 * sp + e;
-          if (!K.enumerated[idx]) continue;
-          int na; const FqAln *a = K.aln_of((int)idx, &na);
-          K.q_first[idx] = q;
-          const uint64_t base = K.aln_off[K.s_of[idx]];
-          for (int k = 0; k < na; ++k) {
-            K.aln_row_off[base + k] = r0;
-            q_aln[q] = a[k]; q_len[q] = (uint32_t)R[idx].len; q_off[q] = r0;
-            ++q; r0 += (uint64_t)(a[k].l - a[k].k) + 1;
-          }
-        }
-      }
-    });
-    q_off[n_q] = rows;
-  }
-  K.n_rows = rows;
-  CKM(c->p_pos.ensure(rows + 1));
-  K.h_pos = c->p_pos.p;
+  const size_t N = (size_t)n_surv * 2;
+  FqRecArgs &A = K.ra;
+  CKM(c->d_rec.ensure(N + 1) && c->d_nocc.ensure(N + 1) && c->d_ntop.ensure(N + 1) && c->d_enum.ensure(N + 1) && c->d_qfirst.ensure(N + 1) && c->d_row0.ensure(N + 1) &&
+      c->d_cls.ensure((size_t)n_surv + 1) && c->d_isz.ensure((size_t)n_surv + 1) && c->d_cigs.ensure(64));
+  for (int k = 0; k < 3; ++k) CKM(c->d_cnt[k].ensure(N + 1) && c->d_scan[k].ensure(N + 2));
+  A.ix = c->ix->dev; A.n_surv = n_surv; A.n_pairs = K.n; A.batch_pairs = K.B; A.packed = c->in_kind == 2 ? 1 : 0; A.single_end = o.single_end ? 1 : 0;
+  A.max_occ = o.max_occ; A.multi_cap = o.single_end ? 4u : (uint32_t)std::max(o.n_multi, o.N_multi) + 1;   // (single-end: N_OCC + 1, src/BwtMapper.cpp:33, 1344)
+  A.n_multi = o.n_multi; A.N_multi = o.N_multi; A.max_isize = o.max_isize; A.s_mm = o.s_mm; A.is_sw = o.is_sw;
+  A.pair_list = c->d_pair_list.p; A.surv = c->d_surv.p; A.len_trim = K.dlen_trim; A.full_len = A.packed ? c->d_len_c.p : c->d_len.p;
+  A.hits = c->d_hits.p; A.aoff = c->d_aoff.p; A.an = c->d_an.p; A.maxdiff_lut = c->d_maxdiff.p; A.g_log_n = c->d_glogn.p;
+  A.rec = c->d_rec.p; A.nocc = c->d_nocc.p; A.ntop = c->d_ntop.p; A.enumerated = c->d_enum.p; A.qfirst = c->d_qfirst.p; A.row0 = c->d_row0.p;
+  A.pq_cnt = c->d_cnt[0].p; A.prow_cnt = c->d_cnt[1].p; A.pq = c->d_scan[0].p; A.prow = c->d_scan[1].p;
+  A.counters = c->d_counters.p; A.cigs = c->d_cigs.p;
+  REC(FQ_ROP_INIT, N);
+  REC(FQ_ROP_NOCC, N);
+  REC(FQ_ROP_ENUM_PLAN, n_surv);
+  CK(fqdev::launch_scan(c->d_cnt[0].p, c->d_scan[0].p, (uint32_t)n_surv));
+  CK(fqdev::launch_scan(c->d_cnt[1].p, c->d_scan[1].p, (uint32_t)n_surv));
+  CKM(c->p_ntop.ensure(N + 1));
+  CK(fqdev::copy_pinned(c->p_ntop.p, c->d_ntop.p, N * 2, 0));
+  uint64_t tot[2] = {0, 0};
+  CKS(fetch_u64(c, &tot[0], c->d_scan[0].p + n_surv));
+  CKS(fetch_u64(c, &tot[1], c->d_scan[1].p + n_surv));
+  CKS(sync_staged(c));
+  c->stats.d2h_bytes += N * 2 + 16;
+  K.n_q = tot[0]; K.n_rows = tot[1];
+  if (K.n_q > 0xfffffff0ull) { c->err = "more than 2^32 hits to enumerate in one call"; return FQ_ELIMIT; }
+  return FQ_OK;
+}
+
+// ---- SA rows -> positions for every enumerated row (GPU) -----------------------------------------------------------------
+int stage_sa_rows(Call &K) {
+  fq_ctx *c = K.c;
+  FqRecArgs &A = K.ra;
+  const uint64_t n_q = K.n_q, rows = K.n_rows;
+  CKM(c->d_qaln.ensure(n_q + 1) && c->d_qlen.ensure(n_q + 1) && c->d_qoff.ensure(n_q + 2) && c->d_pos.ensure(rows + 1) && c->d_pscratch.ensure(rows + 1));
+  A.qaln = c->d_qaln.p; A.qlen = c->d_qlen.p; A.qoff = c->d_qoff.p; A.n_q = n_q; A.n_rows = rows; A.pos = c->d_pos.p; A.pscratch = c->d_pscratch.p;
+  REC(FQ_ROP_ENUM_FILL, K.n_surv);
   if (rows) {
-    CKM(c->d_qaln.ensure(n_q) && c->d_qlen.ensure(n_q) && c->d_qoff.ensure(n_q + 1) && c->d_pos.ensure(rows));
-    CK(fqdev::copy_pinned(c->d_qaln.p, q_aln, n_q * sizeof(FqAln), 1));
-    CK(fqdev::copy_pinned(c->d_qlen.p, q_len, n_q * 4, 1));
-    CK(fqdev::copy_pinned(c->d_qoff.p, q_off, (n_q + 1) * 8, 1));
-    c->stats.h2d_bytes += n_q * (sizeof(FqAln) + 12);
     FqSaArgs sa{};
-    sa.ix = ix->dev; sa.aln = c->d_qaln.p; sa.aln_len = c->d_qlen.p; sa.row_off = c->d_qoff.p; sa.n_aln = (uint32_t)n_q;
+    sa.ix = c->ix->dev; sa.aln = c->d_qaln.p; sa.aln_len = c->d_qlen.p; sa.row_off = c->d_qoff.p; sa.n_aln = (uint32_t)n_q;
     sa.n_rows = rows; sa.pos = c->d_pos.p; sa.counters = c->d_counters.p;
     fqdev::time_begin(FQ_K_SA);
     CK(fqdev::launch_sa(sa));
     fqdev::time_end(FQ_K_SA);
-    CK(fqdev::copy_pinned(c->p_pos.p, c->d_pos.p, rows * 4, 0));
-    CKS(sync_staged(c));
-    c->stats.d2h_bytes += rows * 4;
     c->stats.sa_rows += rows;
   }
   return FQ_OK;
 }
 
-// ---- the plan of stage B1: the state of the drand48 stream at the first read of every range of reads --------
+// ---- the plan of stage B1: the state of the drand48 stream at the first read of every chunk of pairs --------
 // One read depends on the others only through HOW MANY numbers they drew: one per hit that shares the best score, plus one each
 // time such a hit is taken (bwase.c:29-41) -- two for a read with a single best hit, unless the first of them is exactly 0.  Counting
-// the best hits of every read is parallel; the replay of the draws is serial, one 16-bit count per read (and the hit lists of the
-// reads with several best hits).  It reads the records' `filtered` flag and the hit lists only, so it can run beside the SA stage.
+// the best hits of every read is the device's work (fq_rec_nocc_thread); the replay of the draws is serial, one 16-bit count per
+// read (and the hit lists of the reads with several best hits).  It can run beside the SA stage.
 void stageB1_plan(Call &K, uint64_t rng0) {
   fq_ctx *c = K.c;
-  const vector<FqRead> &R = c->st.reads;
-  const size_t N = R.size();
-  vector<uint16_t> &ntop = c->cv.ntop;
-  ntop.resize(N);
-  parallel_chunks(N, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
-    for (size_t idx = lo; idx < hi; ++idx) {
-      int t = 0;
-      if (!R[idx].filtered) {
-        int na; const FqAln *a = K.aln_of((int)idx, &na);
-        while (t < na && a[t].score <= a[0].score) ++t;     // (lists are in discovery order: best score first)
-      }
-      ntop[idx] = (uint16_t)std::min(t, 65535);
-    }
-  });
-  const int T = N >= K.par_min ? std::max(1, K.host_threads) : 1;
-  const size_t per = (N + T - 1) / T;
-  K.plan.T = T; K.plan.per = per;
-  vector<uint64_t> &start = K.plan.start;
-  start.assign((size_t)T + 1, 0);
+  const size_t N = (size_t)K.n_surv * 2;
+  const uint16_t *ntop = c->p_ntop.p;
+  uint64_t *start = K.plan.start;
+  const size_t per = 2 * FQ_RNG_CHUNK_PAIRS;
   // two steps of the generator at once: X'' = A2 X + C2 (mod 2^48); the step between them matters only when it lands on 0
   constexpr uint64_t A1 = 0x5DEECE66DULL, C1 = 0xBULL, M48 = 0xFFFFFFFFFFFFULL, A2 = (A1 * A1) & M48, C2 = (A1 * C1 + C1) & M48;
   uint64_t x = rng0;
-  size_t next_chunk = 0;
   for (size_t idx = 0; idx < N; ++idx) {
-    if (next_chunk < (size_t)T && idx == next_chunk * per) start[next_chunk++] = x;
+    if (idx % per == 0) start[idx / per] = x;
     const int t = ntop[idx];
     if (t == 0) continue;
     if (t == 1) {                                                          // wdt >= 1: taken unless the draw is exactly 0
@@ -1449,81 +1299,36 @@ void stageB1_plan(Call &K, uint64_t rng0) {
       x = x1 == 0 ? x1 : (A2 * x + C2) & M48;
       continue;
     }
-    int na; const FqAln *a = K.aln_of((int)idx, &na);
-    uint32_t cnt = 0;
-    for (int i = 0; i < na && a[i].score <= a[0].score; ++i) {             // (all of them when there are more than 65,535)
-      const uint32_t wdt = a[i].l - a[i].k + 1;
-      if (rng_step(x) * (double)(uint32_t)(wdt + cnt) > (double)(int)cnt) rng_step(x);
-      cnt += wdt;
-    }
+    int na; const FqAln *a = K.aln_of(idx, &na);
+    fq_main_draws(x, a, (uint32_t)na);
   }
-  while (next_chunk <= (size_t)T) start[next_chunk++] = x;
   K.plan.rng_end = x;
 }
 
-// ---- stage B1 (host, serial, read order): main hit choice consumes the drand48 stream (Q2) ------------
+// ---- stage B1: main hit choice consumes the drand48 stream in read order (Q2); the choice itself is the device's ------------
 int stageB1_main_hit(Call &K) {
   fq_ctx *c = K.c;
-  const fq_index *ix = c->ix;
-  vector<FqRead> &R = c->st.reads;
-  // The drand48 stream is consumed in read order, but one read depends on the others only through HOW MANY numbers they drew: one per
-  // hit that shares the best score, plus one each time such a hit is taken (bwase.c:29-41) -- two for a read with a single best
-  // hit.  So: count the best hits of every read (parallel), replay the draws alone in read order to learn the state each chunk of
-  // reads starts from (serial, one byte per read; the hit lists only of reads with several best hits), then choose (parallel).
-  const size_t N = R.size();
+  FqRecArgs &A = K.ra;
+  const int n_surv = K.n_surv;
   if (K.plan_thread.joinable()) K.plan_thread.join();
   else stageB1_plan(K, c->rng);
   c->rng = K.plan.rng_end;
-  const int T = K.plan.T;
-  const size_t per = K.plan.per;
-  const vector<uint64_t> &start = K.plan.start;
-  const int se_n_occ = c->o.single_end ? 3 : 0;   // N_OCC: the single-end mapper selects main and alternative hits in one call (src/BwtMapper.cpp:1344)
-  vector<vector<uint32_t>> dq_row_t(T), dq_info_t(T); vector<vector<int>> dq_idx_t(T);
-  auto choose = [&](size_t lo, size_t hi, int t) {
-    uint64_t x = start[t];
-    for (size_t idx = lo; idx < hi; ++idx) {
-      FqRead &p = R[idx];
-      if (p.filtered) continue;
-      int na; const FqAln *a = K.aln_of((int)idx, &na);
-      choose_hit(x, na, a, p, true, se_n_occ);
-      if (se_n_occ) {   // bwa_cal_pac_pos: the alternative hits' SA rows become positions (their rows are enumerated: n_occ <= N_OCC + 1)
-        const uint64_t base = K.aln_off[K.s_of[idx]];
-        for (auto &m : p.multi) m.pos = K.h_pos[K.aln_row_off[base + m.aln] + m.row_in_aln];
-      }
-      if (p.type == FQ_TYPE_UNIQUE || p.type == FQ_TYPE_REPEAT) {
-        if (K.enumerated[idx]) p.pos = K.h_pos[K.aln_row_off[K.aln_off[K.s_of[idx]] + p.main_aln] + (p.sa - a[p.main_aln].k)];
-        else { dq_row_t[t].push_back(p.sa); dq_info_t[t].push_back((uint32_t)p.strand << 31 | (uint32_t)p.len); dq_idx_t[t].push_back((int)idx); }
-        p.seQ = p.mapQ = approx_mapq(c, p, c->maxdiff_lut[p.len]);
-      }
-    }
-  };
-  if (T == 1) choose(0, N, 0);
-  else if (tl_pool) tl_pool->run(T, [&](int t) { const size_t lo = (size_t)t * per, hi = std::min(N, lo + per); if (lo < hi) choose(lo, hi, t); });
-  else {
-    std::vector<std::thread> th;
-    for (int t = 0; t < T; ++t) { const size_t lo = (size_t)t * per, hi = std::min(N, lo + per); if (lo < hi) th.emplace_back(choose, lo, hi, t); }
-    for (auto &y : th) y.join();
-  }
-  vector<uint32_t> dq_row, dq_info; vector<int> dq_idx;
-  for (int t = 0; t < T; ++t) {
-    dq_row.insert(dq_row.end(), dq_row_t[t].begin(), dq_row_t[t].end()); dq_info.insert(dq_info.end(), dq_info_t[t].begin(), dq_info_t[t].end());
-    dq_idx.insert(dq_idx.end(), dq_idx_t[t].begin(), dq_idx_t[t].end());
-  }
-  if (!dq_row.empty()) {   // main hits of very repetitive reads whose rows were not enumerated
-    const size_t nq = dq_row.size();
-    CKM(c->d_qrow.ensure(nq) && c->d_qinfo.ensure(nq) && c->d_qpos.ensure(nq));   // (d_pos keeps the enumerated rows: k_pair reads them)
-    CKS(h2d_staged(c, c->d_qrow.p, dq_row.data(), nq * 4));
-    CKS(h2d_staged(c, c->d_qinfo.p, dq_info.data(), nq * 4));
-    FqSaQueryArgs qa{};
-    qa.ix = ix->dev; qa.row = c->d_qrow.p; qa.info = c->d_qinfo.p; qa.n = (uint32_t)nq; qa.pos = c->d_qpos.p; qa.counters = c->d_counters.p;
-    fqdev::time_begin(FQ_K_SA);
-    CK(fqdev::launch_saq(qa));
-    fqdev::time_end(FQ_K_SA);
-    vector<uint32_t> tmp(nq);
-    CKS(d2h_staged(c, tmp.data(), c->d_qpos.p, nq * 4));
+  CKM(c->d_rng.ensure(K.plan.n_chunks + 1));
+  CK(fqdev::copy_pinned(c->d_rng.p, K.plan.start, K.plan.n_chunks * 8, 1));
+  c->stats.h2d_bytes += K.plan.n_chunks * 8;
+  A.rng_start = c->d_rng.p; A.isz = c->d_isz.p; A.cls = c->d_cls.p; A.flag32 = c->d_cnt[2].p; A.off64 = c->d_scan[2].p;
+  fqdev::time_begin(FQ_K_SA);       // (counted with the stage that enumerates the hits' positions)
+  REC(FQ_ROP_MAIN_HIT, n_surv);
+  fqdev::time_end(FQ_K_SA);
+  if (!c->o.single_end) {
+    CK(fqdev::launch_scan(c->d_cnt[2].p, c->d_scan[2].p, (uint32_t)n_surv));
+    CKM(c->p_isz.ensure((size_t)n_surv + 1));
+    CK(fqdev::copy_pinned(c->p_isz.p, c->d_isz.p, (size_t)n_surv * 4, 0));
+    uint64_t n2 = 0;
+    CKS(fetch_u64(c, &n2, c->d_scan[2].p + n_surv));
     CKS(sync_staged(c));
-    for (size_t i = 0; i < nq; ++i) R[dq_idx[i]].pos = tmp[i];
-    c->stats.sa_rows += nq;
+    c->stats.d2h_bytes += (size_t)n_surv * 4 + 8;
+    K.n_host_pairs = (int64_t)n2;
   }
   return FQ_OK;
 }
@@ -1533,17 +1338,15 @@ void stageB2_isize(Call &K) {
   fq_ctx *c = K.c;
   const fq_opts_t &o = c->o;
   const int n_sub = K.n_sub;
-  vector<FqRead> &R = c->st.reads;
   K.iis.assign(n_sub, fq_isize_t{});
-  // the inference of a reference batch depends on nothing but its records; only the fallback chain is sequential
+  // the inference of a reference batch depends on nothing but its pairs' samples (one per survivor pair, written by fq_main_hit_thread);
+  // only the fallback chain is sequential
   vector<fq_isize_t> raw(n_sub);
   {
     std::vector<std::thread> th;
     const int T = (size_t)K.n_surv >= K.par_min ? std::min(K.host_threads, n_sub) : 1;
-    vector<uint32_t> &isz = c->cv.isz;
-    isz.resize((size_t)K.n_surv);
-    parallel_chunks((size_t)K.n_surv, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) { for (size_t sp = lo; sp < hi; ++sp) isz[sp] = pair_isize_sample(R[2 * sp], R[2 * sp + 1]); });
-    auto work = [&](int t) { for (int sb = t; sb < n_sub; sb += T) infer_isize(isz.data(), K.sub_lo[sb], K.sub_lo[sb + 1], K.sub_max_len[sb], &raw[sb], o.ap_prior, (int64_t)c->ix->dev.fm[0].seq_len); };
+    const uint32_t *isz = c->p_isz.p;
+    auto work = [&](int t) { for (int sb = t; sb < n_sub; sb += T) infer_isize(isz, K.sub_lo[sb], K.sub_lo[sb + 1], K.sub_max_len[sb], &raw[sb], o.ap_prior, (int64_t)c->ix->dev.fm[0].seq_len); };
     if (tl_pool && T > 1) tl_pool->run(T, work);
     else {
       for (int t = 1; t < T; ++t) th.emplace_back(work, t);
@@ -1561,242 +1364,168 @@ void stageB2_isize(Call &K) {
   }
 }
 
-// ---- (k,l) position cache, filled in pair order (serial; part of the order-dependent state of the stream, Q6) ---------------
-void stage_kl_cache(Call &K) {
+// ---- the pairs the host pairs, and the (k,l) position cache, filled in pair order (serial; part of the order-dependent state, Q6) -----
+// fq_main_hit_thread marks the pairs a lane does not take (an interval of 1,000 rows or more, or more than FQ_PAIR_LANE_ROWS rows):
+// their list, the fields of their records the pairing reads and their rows' positions come to the host.
+int stage_kl_cache(Call &K) {
   fq_ctx *c = K.c;
-  const fq_opts_t &o = c->o;
-  const int n_surv = K.n_surv;
-  vector<FqRead> &R = c->st.reads;
-  const uint32_t *h_pos = K.h_pos;
-  auto both_mapped = [&](int sp) {
-    const FqRead &a = R[2 * sp], &b = R[2 * sp + 1];
-    return (a.type == FQ_TYPE_UNIQUE || a.type == FQ_TYPE_REPEAT) && (b.type == FQ_TYPE_UNIQUE || b.type == FQ_TYPE_REPEAT) &&
-           K.read_nocc[2 * sp] <= o.max_occ && K.read_nocc[2 * sp + 1] <= o.max_occ;
-  };
-  // MIN_HASH_WIDTH: the positions of an interval >= 1000 wide are those of its first requester, in pair order (Q6): fill the
-  // cache serially, in that order, before the pairs are spread over threads (which then only look it up)
-  // (such intervals are rare: all threads look for the pairs that hold one, the serial pass visits only those)
-  const int T = std::max(1, K.host_threads);
-  vector<vector<int>> wide((size_t)T);
-  parallel_chunks((size_t)n_surv, T, K.par_min, [&](size_t lo, size_t hi, int t) {
-    for (size_t sp = lo; sp < hi; ++sp) {
-      if (!both_mapped((int)sp)) continue;
-      bool any = false;
-      for (int j = 0; j < 2 && !any; ++j) {
-        int na; const FqAln *a = K.aln_of(2 * (int)sp + j, &na);
-        for (int k = 0; k < na; ++k) if (a[k].l - a[k].k + 1 >= 1000) { any = true; break; }
-      }
-      if (any) wide[t].push_back((int)sp);
-    }
-  });
-  for (int t = 0; t < T; ++t)
-    for (const int sp : wide[t])
-      for (int j = 0; j < 2; ++j) {
-        int na; const FqAln *a = K.aln_of(2 * sp + j, &na);
-        const uint64_t base = K.aln_off[K.s_of[2 * sp + j]];
-        for (int k = 0; k < na; ++k) {
-          const uint32_t wdt = a[k].l - a[k].k + 1;
-          if (wdt < 1000) continue;
+  FqRecArgs &A = K.ra;
+  const int64_t n2 = K.n_host_pairs;
+  if (!n2) return FQ_OK;
+  CKM(c->d_list.ensure((size_t)n2 + 1) && c->d_greads.ensure((size_t)2 * n2) && c->d_grow0.ensure((size_t)2 * n2) && c->p_pos.ensure(K.n_rows + 1));
+  A.list = c->d_list.p; A.g_reads = c->d_greads.p; A.g_row0 = c->d_grow0.p; A.n_list = (int32_t)n2;
+  REC(FQ_ROP_COMPACT, K.n_surv);
+  REC(FQ_ROP_PAIR_GATHER, n2);
+  int32_t *list = (int32_t *)c->arena.alloc((size_t)n2 * 4);
+  FqPairRead *reads = (FqPairRead *)c->arena.alloc((size_t)2 * n2 * sizeof(FqPairRead));
+  uint64_t *row0 = (uint64_t *)c->arena.alloc((size_t)2 * n2 * 8);
+  if (!list || !reads || !row0) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
+  CK(fqdev::copy_pinned(list, c->d_list.p, (size_t)n2 * 4, 0));
+  CK(fqdev::copy_pinned(reads, c->d_greads.p, (size_t)2 * n2 * sizeof(FqPairRead), 0));
+  CK(fqdev::copy_pinned(row0, c->d_grow0.p, (size_t)2 * n2 * 8, 0));
+  CK(fqdev::copy_pinned(c->p_pos.p, c->d_pos.p, K.n_rows * 4, 0));
+  CKS(sync_staged(c));
+  c->stats.d2h_bytes += (size_t)n2 * (4 + 2 * sizeof(FqPairRead) + 16) + K.n_rows * 4;
+  K.host_list = list; K.host_reads = reads; K.host_row0 = row0; K.h_pos = c->p_pos.p; K.have_pos = true;
+  // MIN_HASH_WIDTH: the positions of an interval >= 1000 wide are those of its first requester, in pair order (Q6)
+  for (int64_t t = 0; t < n2; ++t)
+    for (int j = 0; j < 2; ++j) {
+      int na; const FqAln *a = K.aln_of((size_t)2 * list[t] + j, &na);
+      uint64_t row = row0[2 * t + j];
+      for (int k = 0; k < na; ++k) {
+        const uint32_t wdt = a[k].l - a[k].k + 1;
+        if (wdt >= 1000) {
           auto ins = c->kl_cache.emplace((uint64_t)a[k].k << 32 | a[k].l, vector<uint32_t>());
-          if (ins.second) { const uint32_t *ps = h_pos + K.aln_row_off[base + k]; ins.first->second.assign(ps, ps + wdt); }
+          if (ins.second) ins.first->second.assign(K.h_pos + row, K.h_pos + row + wdt);
         }
+        row += wdt;
       }
+    }
+  return FQ_OK;
 }
 
-// ---- stage B3: pairing + XA lists (per pair) -------------------------------------------------------------
+// ---- stage B3: pairing (a lane per pair; the host for the pairs listed above) + XA lists ------------------------------------
 int stageB3_pairing(Call &K) {
   fq_ctx *c = K.c;
   const fq_opts_t &o = c->o;
+  FqRecArgs &A = K.ra;
   const int n_surv = K.n_surv;
-  vector<FqRead> &R = c->st.reads;
-  const uint32_t *h_pos = K.h_pos;
-  auto mapped = [&](const FqRead &a) { return a.type == FQ_TYPE_UNIQUE || a.type == FQ_TYPE_REPEAT; };
-  // insert-size penalty tables, one per reference batch
-  vector<FqPairIsize> pis(K.n_sub);
-  vector<int32_t> lut;
-  for (int sb = 0; sb < K.n_sub; ++sb) {
-    pis[sb].high = K.iis[sb].high; pis[sb].high_bayesian = K.iis[sb].high_bayesian; pis[sb].lut_off = (int32_t)lut.size(); pis[sb].pad = 0;
-    pair_penalty_lut(K.iis[sb], lut);
-  }
-  // ---- the pairs k_pair takes: both reads mapped and enumerated, no interval of 1,000 rows or more (those take their positions from
-  //      the (k,l) cache, Q6), at most kPairLaneRows rows together.  Everything k_pair needs but the reads' current records is on
-  //      the device already: the hits and their rows' positions as k_sa left them.
-  const uint32_t kPairLaneRows = 64;
-  vector<char> &on_device = c->cv.on_device;
-  vector<uint32_t> &job_of = c->cv.job_of;           // exclusive prefix count of on_device
-  vector<uint8_t> &sub_of = c->cv.sub_of;            // reference batch of a survivor pair
-  on_device.resize((size_t)n_surv); job_of.resize((size_t)n_surv + 1); sub_of.resize((size_t)n_surv);   // (every element is written below)
-  job_of[0] = 0;
-  for (int sb = 0; sb < K.n_sub; ++sb) std::fill(sub_of.begin() + K.sub_lo[sb], sub_of.begin() + K.sub_lo[sb + 1], (uint8_t)sb);
-  parallel_chunks((size_t)n_surv, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
-    for (size_t sp = lo; sp < hi; ++sp) {
-      const FqRead &p0 = R[2 * sp], &p1 = R[2 * sp + 1];
-      on_device[sp] = mapped(p0) && mapped(p1) && K.read_nocc[2 * sp] <= o.max_occ && K.read_nocc[2 * sp + 1] <= o.max_occ &&
-                      K.enumerated[2 * sp] && K.enumerated[2 * sp + 1] && K.read_nocc[2 * sp] + K.read_nocc[2 * sp + 1] <= kPairLaneRows;
-      job_of[sp + 1] = on_device[sp] ? 1u : 0u;
+  const size_t N = (size_t)n_surv * 2;
+  if (!o.single_end) {
+    // insert-size penalty tables, one per reference batch
+    K.pis.assign(K.n_sub, FqPairIsize{});
+    K.lut.clear();
+    for (int sb = 0; sb < K.n_sub; ++sb) {
+      K.pis[sb].high = K.iis[sb].high; K.pis[sb].high_bayesian = K.iis[sb].high_bayesian; K.pis[sb].lut_off = (int32_t)K.lut.size(); K.pis[sb].pad = 0;
+      pair_penalty_lut(K.iis[sb], K.lut);
     }
-  });
-  par_prefix(job_of, K.host_threads, K.par_min);
-  const size_t nj = job_of[n_surv];
-  if (nj) {
-    CKM(c->d_pjobs.ensure(nj) && c->d_preads.ensure(2 * nj) && c->d_pout.ensure(2 * nj) && c->d_pisize.ensure(pis.size()) && c->d_plut.ensure(lut.size() + 1) &&
-        c->d_glogn.ensure(256) && c->d_pscratch.ensure(K.n_rows + 1));
-    FqPairJob *jobs = (FqPairJob *)c->arena.alloc(nj * sizeof(FqPairJob));          // filled where the copy engine reads them
-    FqPairRead *jreads = (FqPairRead *)c->arena.alloc(2 * nj * sizeof(FqPairRead));
-    FqPairOut *jout = (FqPairOut *)c->arena.alloc(2 * nj * sizeof(FqPairOut));
-    if (!jobs || !jreads || !jout) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
-    parallel_chunks((size_t)n_surv, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
-      for (size_t sp = lo; sp < hi; ++sp) {
-        if (!on_device[sp]) continue;
-        const size_t t = job_of[sp];
-        FqPairJob &jb = jobs[t];
-        jb.q0 = K.q_first[2 * sp]; jb.na0 = K.aln_n[K.s_of[2 * sp]]; jb.q1 = K.q_first[2 * sp + 1]; jb.na1 = K.aln_n[K.s_of[2 * sp + 1]]; jb.batch = sub_of[sp];
-        jreads[2 * t] = pair_read_of(R[2 * sp]); jreads[2 * t + 1] = pair_read_of(R[2 * sp + 1]);
-      }
-    });
-    CK(fqdev::copy_pinned(c->d_pjobs.p, jobs, nj * sizeof(FqPairJob), 1));
-    CK(fqdev::copy_pinned(c->d_preads.p, jreads, 2 * nj * sizeof(FqPairRead), 1));
-    CKS(h2d_staged(c, c->d_pisize.p, pis.data(), pis.size() * sizeof(FqPairIsize)));
-    if (!lut.empty()) CKS(h2d_staged(c, c->d_plut.p, lut.data(), lut.size() * 4));
-    CKS(h2d_staged(c, c->d_glogn.p, c->g_log_n, 256 * 4));
-    c->stats.h2d_bytes += nj * (sizeof(FqPairJob) + 2 * sizeof(FqPairRead)) + lut.size() * 4;
-    FqPairArgs pa{};
-    pa.jobs = c->d_pjobs.p; pa.n_jobs = (int32_t)nj; pa.reads = c->d_preads.p; pa.aln = c->d_qaln.p; pa.row_off = c->d_qoff.p; pa.pos = c->d_pos.p;
-    pa.scratch = c->d_pscratch.p; pa.isize = c->d_pisize.p; pa.lut = c->d_plut.p; pa.g_log_n = c->d_glogn.p; pa.max_isize = o.max_isize; pa.s_mm = o.s_mm;
-    pa.out = c->d_pout.p;
-    fqdev::time_begin(FQ_K_SA);       // (counted with the stage that enumerates the hits' positions)
-    CK(fqdev::launch_pair(pa));
+    CKM(c->d_pisize.ensure(K.pis.size()) && c->d_plut.ensure(K.lut.size() + 1));
+    CKS(h2d_staged(c, c->d_pisize.p, K.pis.data(), K.pis.size() * sizeof(FqPairIsize)));
+    if (!K.lut.empty()) CKS(h2d_staged(c, c->d_plut.p, K.lut.data(), K.lut.size() * 4));
+    c->stats.h2d_bytes += K.lut.size() * 4;
+    A.pisize = c->d_pisize.p; A.plut = c->d_plut.p;
+    fqdev::time_begin(FQ_K_SA);
+    REC(FQ_ROP_PAIR, n_surv);
     fqdev::time_end(FQ_K_SA);
-    CK(fqdev::copy_pinned(jout, c->d_pout.p, 2 * nj * sizeof(FqPairOut), 0));
-    CKS(sync_staged(c));
-    c->stats.d2h_bytes += 2 * nj * sizeof(FqPairOut);
-    c->stats.pairs_on_device += nj;
-    parallel_chunks((size_t)n_surv, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
-      for (size_t sp = lo; sp < hi; ++sp)
-        if (on_device[sp]) { const size_t t = job_of[sp]; pair_apply(R[2 * sp], jout[2 * t]); pair_apply(R[2 * sp + 1], jout[2 * t + 1]); }
-    });
-  }
-  // ---- the other pairs (host, the same routine), and the XA lists of every read
-  for (int sb = 0; sb < K.n_sub; ++sb) {
-    const FqPairIsize pi = pis[sb];
-    parallel_chunks((size_t)(K.sub_lo[sb + 1] - K.sub_lo[sb]), K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
-      vector<uint64_t> arr;
-      for (int sp = K.sub_lo[sb] + (int)lo; sp < K.sub_lo[sb] + (int)hi; ++sp) {
-        FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
-        const FqAln *aln[2]; int na[2];
-        aln[0] = K.aln_of(2 * sp, &na[0]); aln[1] = K.aln_of(2 * sp + 1, &na[1]);
-        const bool m0 = mapped(*p[0]), m1 = mapped(*p[1]);
-        if (m0 && m1 && !on_device[sp]) {
-          if (K.read_nocc[2 * sp] > o.max_occ || K.read_nocc[2 * sp + 1] > o.max_occ) continue;   // BwtMapper.cpp:797-811: such a pair gets no XA list either
+    if (K.n_host_pairs) {   // the same routine on the host, over the rows the (k,l) cache stands for
+      const int64_t n2 = K.n_host_pairs;
+      FqPairOut *outs = (FqPairOut *)c->arena.alloc((size_t)2 * n2 * sizeof(FqPairOut));
+      if (!outs) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
+      parallel_chunks((size_t)n2, K.host_threads, 64, [&](size_t lo, size_t hi, int) {
+        vector<uint64_t> arr;
+        for (size_t t = lo; t < hi; ++t) {
+          const int sp = K.host_list[t];
+          const FqAln *aln[2]; int na[2];
+          aln[0] = K.aln_of((size_t)2 * sp, &na[0]); aln[1] = K.aln_of((size_t)2 * sp + 1, &na[1]);
           arr.clear();
           for (int j = 0; j < 2; ++j) {
-            const uint64_t base = K.aln_off[K.s_of[2 * sp + j]];
+            uint64_t row = K.host_row0[2 * t + j];
             for (int k = 0; k < na[j]; ++k) {
               const FqAln &q = aln[j][k];
               const uint32_t wdt = q.l - q.k + 1;
-              const uint32_t *ps = h_pos + K.aln_row_off[base + k];
+              const uint32_t *ps = K.h_pos + row;
               uint32_t np = wdt;
               if (wdt >= 1000) { const vector<uint32_t> &v = c->kl_cache.find((uint64_t)q.k << 32 | q.l)->second; ps = v.data(); np = (uint32_t)v.size(); }
-              for (uint32_t t = 0; t < np; ++t) arr.push_back((uint64_t)ps[t] << 32 | (uint64_t)(k << 1) | (uint64_t)j);
+              for (uint32_t z = 0; z < np; ++z) arr.push_back((uint64_t)ps[z] << 32 | (uint64_t)(k << 1) | (uint64_t)j);
+              row += wdt;
             }
           }
-          pair_hits(c, pi, lut.data(), p, aln, arr);
+          std::sort(arr.begin(), arr.end());
+          fq_pair_sweep(aln[0], aln[1], K.host_reads + 2 * t, arr.data(), (uint32_t)arr.size(), K.pis[c->h_pair_list[sp] / K.B], K.lut.data(), c->g_log_n, o.max_isize, o.s_mm, outs + 2 * t);
         }
-        if (o.N_multi || o.n_multi)
-          for (int j = 0; j < 2; ++j) {
-            if (p[j]->type == FQ_TYPE_NO_MATCH) continue;
-            int nm;
-            if (!(p[j]->extra_flag & 2) && p[1 - j]->type != FQ_TYPE_NO_MATCH) nm = (int)(p[j]->c1 + p[j]->c2) - 1 > o.N_multi ? o.n_multi : o.N_multi;
-            else nm = o.n_multi;
-            // A read whose one hit is one row -- the main hit -- gets an empty list (choose_hit would build and drop the one entry); its
-            // list is empty already (records are reset per call and nothing else writes it in a paired call): most reads of an on-target
-            // set, and the record's second cache line stays untouched.
-            if (na[j] == 1 && aln[j][0].k == aln[j][0].l && aln[j][0].k == p[j]->sa) continue;
-            { uint64_t no_rng = 0; choose_hit(no_rng, na[j], aln[j], *p[j], false, nm); }   // (XA selection draws no random numbers, bwase.c:47-95)
-            const uint64_t base = K.aln_off[K.s_of[2 * sp + j]];
-            for (auto &m : p[j]->multi) m.pos = h_pos[K.aln_row_off[base + m.aln] + m.row_in_aln];
-          }
-      }
-    });
+      });
+      CKM(c->d_gout.ensure((size_t)2 * n2));
+      CK(fqdev::copy_pinned(c->d_gout.p, outs, (size_t)2 * n2 * sizeof(FqPairOut), 1));
+      c->stats.h2d_bytes += (size_t)2 * n2 * sizeof(FqPairOut);
+      A.g_out = c->d_gout.p;
+      REC(FQ_ROP_PAIR_SCATTER, n2);
+    }
   }
+  // XA lists of every read (the single-end mapper's alternative hits)
+  A.xcnt = c->d_cnt[0].p; A.xoff = c->d_scan[0].p;
+  REC(FQ_ROP_XA_COUNT, N);
+  CK(fqdev::launch_scan(c->d_cnt[0].p, c->d_scan[0].p, (uint32_t)N));
+  uint64_t total = 0;
+  CKS(fetch_u64(c, &total, c->d_scan[0].p + N));
+  CKS(sync_staged(c));
+  if (total > 0xfffffff0ull) { c->err = "XA entries exceed 32-bit offsets"; return FQ_ELIMIT; }
+  CKM(c->d_multi.ensure(total + 1));
+  A.multi = c->d_multi.p;
+  REC(FQ_ROP_XA_FILL, N);
+  K.n_multi = total;
   return FQ_OK;
 }
 
 // ---- stage C: mate rescue by Smith-Waterman (bwa_paired_sw, libbwa/bwape.c:463-625) ---------------------
+// Windows and candidates on the device (fq_sw_plan_thread); the candidates' records come to the host for the accept / reject
+// arithmetic (libm) and go back.
 int stageC_mate_sw(Call &K) {
   fq_ctx *c = K.c;
   const fq_index *ix = c->ix;
   const fq_opts_t &o = c->o;
-  vector<FqRead> &R = c->st.reads;
+  FqRecArgs &A = K.ra;
   if (!o.is_sw) return FQ_OK;
-  struct Cand { int sp, k; };
-  vector<Cand> cands; vector<FqSwTask> tasks;
-  int max_reg = 0, max_q = 0;
-  // candidates in pair order: every thread lists its range of pairs (a pair's candidates depend on its two records and on its
-  // reference batch's insert sizes only), the lists are joined in range order
-  const int TT = std::max(1, K.host_threads);
-  struct Part { vector<Cand> cands; vector<FqSwTask> tasks; int max_reg = 0, max_q = 0; };
-  vector<Part> part((size_t)TT);
-  parallel_chunks((size_t)K.n_surv, TT, K.par_min, [&](size_t lo, size_t hi, int t) {
-    Part &P = part[t];
-    for (int sb = 0; sb < K.n_sub; ++sb) {
-      const fq_isize_t ii = K.iis[sb];
-      if (ii.avg < 0.0) continue;   // bwa_paired_sw returns before touching anything (bwape.c:477)
-      const int sp_lo = std::max((int)lo, K.sub_lo[sb]), sp_hi = std::min((int)hi, K.sub_lo[sb + 1]);
-      for (int sp = sp_lo; sp < sp_hi; ++sp) {
-        FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
-        for (int j = 0; j < 2; ++j) if (p[j]->filtered) { p[j]->filtered = 0; p[j]->revived = true; }   // expand_seq: revived because its mate passed (:485-499)
-        if (!((p[0]->mapQ >= 17 || p[1]->mapQ >= 17) && (p[0]->extra_flag & 2) == 0)) continue;
-        for (int k = 0; k < 2; ++k) {
-          FqRead *pref = p[1 - k], *pm = p[k];
-          if (pref->type == FQ_TYPE_NO_MATCH) continue;
-          int64_t beg, end;
-          FqSwTask T{};
-          if (pref->strand == 0) {   // __set_rght_coor (:511-516)
-            beg = (int64_t)((int64_t)pref->pos + ii.avg - 3 * ii.std - pm->len * 1.5);
-            end = (int64_t)(beg + 6 * ii.std + 2 * pm->len);
-            // the macro assigns `_pref->pos + _pref->len` in 32-bit unsigned arithmetic (it wraps for a hit hanging over the start of the
-            // reference, pos = 2^32-1) after comparing in 64 bits
-            if (beg < (int64_t)pref->pos + pref->len) beg = (int64_t)(uint32_t)((uint32_t)pref->pos + (uint32_t)pref->len);
-            if (end > ix->l_pac) end = ix->l_pac;
-            T.use_rc = 1;
-          } else {                   // __set_left_coor (:518-523)
-            beg = (int64_t)((int64_t)pref->pos + pref->len - ii.avg - 3 * ii.std - pm->len * 0.5);
-            end = (int64_t)(beg + 6 * ii.std + 2 * pm->len);
-            if (beg < 0) beg = 0;
-            if (end > (int64_t)pref->pos) end = pref->pos;
-            T.use_rc = 0;
-          }
-          T.read = pm->dr; T.beg = beg; T.reglen = (int)(end - beg);
-          P.cands.push_back({sp, k});
-          P.tasks.push_back(T);
-          P.max_reg = std::max(P.max_reg, T.reglen); P.max_q = std::max(P.max_q, (int)pm->len);
-        }
-      }
-    }
-  });
-  {
-    size_t total = 0;
-    for (const Part &P : part) total += P.tasks.size();
-    cands.reserve(total); tasks.reserve(total);
-    for (const Part &P : part) {
-      cands.insert(cands.end(), P.cands.begin(), P.cands.end()); tasks.insert(tasks.end(), P.tasks.begin(), P.tasks.end());
-      max_reg = std::max(max_reg, P.max_reg); max_q = std::max(max_q, P.max_q);
-    }
-  }
-  vector<FqSwOut> souts(tasks.size());
+  const int n_surv = K.n_surv;
+  CKM(c->d_iis.ensure(K.n_sub) && c->d_swslot.ensure((size_t)2 * n_surv + 1));
+  CKS(h2d_staged(c, c->d_iis.p, K.iis.data(), (size_t)K.n_sub * sizeof(fq_isize_t)));
+  A.iis = c->d_iis.p; A.swslot = c->d_swslot.p; A.swcnt = c->d_cnt[1].p; A.swoff = c->d_scan[1].p;
+  REC(FQ_ROP_SW_PLAN, n_surv);
+  CK(fqdev::launch_scan(c->d_cnt[1].p, c->d_scan[1].p, (uint32_t)n_surv));
+  uint64_t total = 0;
+  CKS(fetch_u64(c, &total, c->d_scan[1].p + n_surv));
+  CKS(sync_staged(c));
+  if (!total) return FQ_OK;
+  if (total > 0x7ffffff0ull) { c->err = "mate-rescue tasks exceed 31-bit indices"; return FQ_ELIMIT; }
+  const size_t nt_all = (size_t)total;
+  K.n_sw = total;
+  CKM(c->d_swtask.ensure(nt_all) && c->d_swcand.ensure(nt_all) && c->d_list.ensure(nt_all + 1) && c->d_grec.ensure(2 * nt_all));
+  A.swtask = c->d_swtask.p; A.swcand = c->d_swcand.p; A.list = c->d_list.p; A.g_rec = c->d_grec.p; A.n_list = (int32_t)nt_all;
+  REC(FQ_ROP_SW_FILL, n_surv);
+  REC(FQ_ROP_REC_GATHER, nt_all);
+  FqSwTask *tasks = (FqSwTask *)c->arena.alloc(nt_all * sizeof(FqSwTask));
+  FqSwCand *cands = (FqSwCand *)c->arena.alloc(nt_all * sizeof(FqSwCand));
+  FqDRec *grec = (FqDRec *)c->arena.alloc(2 * nt_all * sizeof(FqDRec));
+  if (!tasks || !cands || !grec) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
+  CK(fqdev::copy_pinned(tasks, c->d_swtask.p, nt_all * sizeof(FqSwTask), 0));
+  CK(fqdev::copy_pinned(cands, c->d_swcand.p, nt_all * sizeof(FqSwCand), 0));
+  CK(fqdev::copy_pinned(grec, c->d_grec.p, 2 * nt_all * sizeof(FqDRec), 0));
+  CKS(sync_staged(c));
+  c->stats.d2h_bytes += nt_all * (sizeof(FqSwTask) + sizeof(FqSwCand) + 2 * sizeof(FqDRec));
+  int max_q = 0;
+  for (size_t t = 0; t < nt_all; ++t) max_q = std::max(max_q, (int)grec[2 * t + cands[t].k].len);
+  vector<FqSwOut> souts(nt_all);
   vector<uint16_t> scig;
-  const int cig_cap = 64;
-  if (!tasks.empty()) {
+  const int cig_cap = FQ_CIG_CAP;
+  {
     // Windows are a few hundred bases when the insert-size estimate is sane; a poor estimate (chimeric libraries) can ask for tens
     // of thousands.  Tasks whose window fits the wavefront kernel's LDS go there; the rest run one per lane out of global scratch.
     const int kWaveMax = c->kn.sw_wave_max;
-    scig.resize(tasks.size() * cig_cap);
+    scig.resize(nt_all * cig_cap);
     for (int big = 0; big < 2; ++big) {
       vector<int> sel;
       int RL = 1;
       const int QL = std::max(max_q, 1);
-      for (size_t t = 0; t < tasks.size(); ++t)
+      for (size_t t = 0; t < nt_all; ++t)
         if ((tasks[t].reglen > kWaveMax) == (big != 0)) { sel.push_back((int)t); RL = std::max(RL, tasks[t].reglen); }
       if (sel.empty()) continue;
       vector<FqSwTask> sub(sel.size());
@@ -1824,19 +1553,21 @@ int stageC_mate_sw(Call &K) {
         memcpy(&scig[(size_t)sel[q] * cig_cap], &sub_cig[q * cig_cap], (size_t)cig_cap * 2);
       }
     }
-    c->stats.sw_tasks += tasks.size();
+    c->stats.sw_tasks += nt_all;
   }
-  // decisions (:556-617), per pair, using the kernel outputs
+  // decisions (:556-617), per pair, using the kernel outputs; an accepted CIGAR goes into the call's device CIGAR arena
+  vector<uint16_t> new_cigs;
   size_t ti = 0;
-  while (ti < cands.size()) {
+  while (ti < nt_all) {
     const int sp = cands[ti].sp;
+    const size_t first = ti;
     const fq_isize_t &ii = K.iis[c->h_pair_list[sp] / K.B];
-    FqRead *p[2] = {&R[2 * sp], &R[2 * sp + 1]};
+    FqDRec *p[2] = {&grec[2 * first], &grec[2 * first + 1]};
     const uint16_t *cigar[2] = {nullptr, nullptr};
     int n_cigar[2] = {0, 0}, mq_adjust[2] = {255, 255}, mapQ = 0;
     int64_t beg[2] = {0, 0};
     uint32_t cnt[2] = {0, 0};
-    for (; ti < cands.size() && cands[ti].sp == sp; ++ti) {
+    for (; ti < nt_all && cands[ti].sp == sp; ++ti) {
       const int k = cands[ti].k;
       const FqSwOut &O = souts[ti];
       beg[k] = O.beg; cnt[k] = O.cnt;
@@ -1855,233 +1586,178 @@ int stageC_mate_sw(Call &K) {
       }
     }
     int k = -1;
-    if (cigar[0] && cigar[1]) { k = p[0]->mapQ < p[1]->mapQ ? 0 : 1; mapQ = abs(p[1]->mapQ - p[0]->mapQ); }
+    if (cigar[0] && cigar[1]) { k = p[0]->mapQ < p[1]->mapQ ? 0 : 1; mapQ = abs((int)p[1]->mapQ - (int)p[0]->mapQ); }
     else if (cigar[0]) { k = 0; mapQ = p[1]->mapQ; }
     else if (cigar[1]) { k = 1; mapQ = p[0]->mapQ; }
     if (k >= 0 && (int64_t)p[k]->pos != beg[k]) {
-      int tmp = p[1 - k]->mapQ - p[k]->mapQ / 2 - 8;
+      int tmp = (int)p[1 - k]->mapQ - (int)p[k]->mapQ / 2 - 8;
       if (tmp <= 0) tmp = 1;
       if (mapQ > tmp) mapQ = tmp;
-      p[k]->mapQ = p[1 - k]->mapQ = mapQ;
-      p[k]->seQ = p[1 - k]->seQ = p[1 - k]->seQ < mapQ ? p[1 - k]->seQ : mapQ;
-      if (p[k]->mapQ > mq_adjust[k]) p[k]->mapQ = mq_adjust[k];
-      if (p[k]->seQ > mq_adjust[k]) p[k]->seQ = mq_adjust[k];
-      p[k]->cigar.assign(cigar[k], cigar[k] + n_cigar[k]);
+      p[k]->mapQ = p[1 - k]->mapQ = (uint8_t)mapQ;
+      p[k]->seQ = p[1 - k]->seQ = (uint8_t)(p[1 - k]->seQ < mapQ ? p[1 - k]->seQ : mapQ);
+      if (p[k]->mapQ > mq_adjust[k]) p[k]->mapQ = (uint8_t)mq_adjust[k];
+      if (p[k]->seQ > mq_adjust[k]) p[k]->seQ = (uint8_t)mq_adjust[k];
+      p[k]->cig_off = (uint32_t)(K.cig_used + new_cigs.size()); p[k]->n_cigar = (uint16_t)n_cigar[k];
+      new_cigs.insert(new_cigs.end(), cigar[k], cigar[k] + n_cigar[k]);
       p[k]->type = FQ_TYPE_MATESW; p[k]->pos = (uint32_t)beg[k]; p[k]->seQ = p[1 - k]->seQ;   // __set_fixed (:525-533)
-      p[k]->strand = 1 - p[1 - k]->strand;
-      p[k]->n_mm = (int)(cnt[k] >> 16) & 0xff; p[k]->n_gapo = (int)(cnt[k] >> 8 & 0xff); p[k]->n_gape = (int)(cnt[k] & 0xff);
+      p[k]->strand = (uint8_t)(1 - p[1 - k]->strand);
+      p[k]->n_mm = (uint8_t)((cnt[k] >> 16) & 0xff); p[k]->n_gapo = (uint8_t)(cnt[k] >> 8 & 0xff); p[k]->n_gape = (uint8_t)(cnt[k] & 0xff);
       p[k]->extra_flag |= 2; p[1 - k]->extra_flag |= 2;
     }
+    for (size_t q = first + 1; q < ti; ++q) { grec[2 * q] = grec[2 * first]; grec[2 * q + 1] = grec[2 * first + 1]; }   // (a pair with two tasks is listed twice)
   }
+  if (!new_cigs.empty()) {
+    CKM(c->d_cigs.ensure_keep(K.cig_used + new_cigs.size() + 1, K.cig_used));
+    CKS(h2d_staged(c, c->d_cigs.p + K.cig_used, new_cigs.data(), new_cigs.size() * 2));
+    K.cig_used += new_cigs.size();
+    A.cigs = c->d_cigs.p;
+  }
+  CK(fqdev::copy_pinned(c->d_grec.p, grec, 2 * nt_all * sizeof(FqDRec), 1));
+  c->stats.h2d_bytes += 2 * nt_all * sizeof(FqDRec) + new_cigs.size() * 2;
+  REC(FQ_ROP_REC_SCATTER, nt_all);
   return FQ_OK;
 }
 
-// ---- stage D: gapped refinement (bwa_refine_gapped, libbwa/bwase.c:339-418) ------------------------------
+// ---- stage D: gapped refinement (bwa_refine_gapped, libbwa/bwase.c:339-418), MD / NM ------------------------------
 int stageD_refine(Call &K) {
   fq_ctx *c = K.c;
   const fq_index *ix = c->ix;
-  vector<FqRead> &R = c->st.reads;
-  struct Tgt { int idx, multi; };
-  vector<Tgt> tgt; vector<FqRefTask> tasks;
-  int max_ref = 1, max_q = 1;
-  {   // the task list in record order: every thread lists its range of records, the lists are joined in range order
-    const int TT = std::max(1, K.host_threads);
-    struct Part { vector<Tgt> tgt; vector<FqRefTask> tasks; int max_ref = 1, max_q = 1; };
-    vector<Part> part((size_t)TT);
-    parallel_chunks(R.size(), TT, K.par_min, [&](size_t lo, size_t hi, int t) {
-      Part &P = part[t];
-      for (size_t idx = lo; idx < hi; ++idx) {
-        FqRead &s = R[idx];
-        if (s.filtered) continue;
-        for (size_t j = 0; j < s.multi.size(); ++j) {
-          FqMulti &q = s.multi[j];
-          if (q.gap == 0) continue;
-          P.tasks.push_back({s.dr, q.strand, q.pos, (q.strand ? 1 : -1) * q.gap});
-          P.tgt.push_back({(int)idx, (int)j});
-          P.max_ref = std::max(P.max_ref, s.len + q.gap); P.max_q = std::max(P.max_q, (int)s.len);
-        }
-        if (s.type == FQ_TYPE_NO_MATCH || s.type == FQ_TYPE_MATESW || s.n_gapo == 0) continue;
-        P.tasks.push_back({s.dr, s.strand, s.pos, (s.strand ? 1 : -1) * (s.n_gapo + s.n_gape)});
-        P.tgt.push_back({(int)idx, -1});
-        P.max_ref = std::max(P.max_ref, s.len + s.n_gapo + s.n_gape); P.max_q = std::max(P.max_q, (int)s.len);
-      }
-    });
-    size_t total = 0;
-    for (const Part &P : part) total += P.tasks.size();
-    tasks.reserve(total); tgt.reserve(total);
-    for (const Part &P : part) {
-      tasks.insert(tasks.end(), P.tasks.begin(), P.tasks.end()); tgt.insert(tgt.end(), P.tgt.begin(), P.tgt.end());
-      max_ref = std::max(max_ref, P.max_ref); max_q = std::max(max_q, P.max_q);
-    }
-  }
-  K.trace("  D: refine task list");
-  if (!tasks.empty()) {
-    const int cig_cap = 64;
+  FqRecArgs &A = K.ra;
+  const size_t N = (size_t)K.n_surv * 2;
+  A.rcnt = c->d_cnt[0].p; A.roff = c->d_scan[0].p;
+  CKM(c->d_refmax.ensure(2));
+  CK(fqdev::dzero(c->d_refmax.p, 8));
+  REC(FQ_ROP_REF_COUNT, N);
+  CK(fqdev::launch_scan(c->d_cnt[0].p, c->d_scan[0].p, (uint32_t)N));
+  uint64_t total = 0;
+  CKS(fetch_u64(c, &total, c->d_scan[0].p + N));
+  CKS(sync_staged(c));
+  K.trace("  D: refine task count");
+  if (total) {
+    if (K.cig_used + total * FQ_CIG_CAP > 0xfffffff0ull) { c->err = "refine tasks exceed 32-bit CIGAR offsets"; return FQ_ELIMIT; }
+    const size_t nt_all = (size_t)total;
+    CKM(c->d_reftask.ensure(nt_all) && c->d_reftgt.ensure(nt_all) && c->d_refout.ensure(nt_all) && c->d_cigs.ensure_keep(K.cig_used + nt_all * FQ_CIG_CAP + 1, K.cig_used));
+    A.reftask = c->d_reftask.p; A.reftgt = c->d_reftgt.p; A.ref_max = c->d_refmax.p; A.refout = c->d_refout.p; A.ref_cig_base = (uint32_t)K.cig_used; A.n_ref = (int32_t)nt_all;
+    A.cigs = c->d_cigs.p;
+    REC(FQ_ROP_REF_FILL, N);
+    int32_t mx[2] = {1, 1};
+    CKS(d2h_staged(c, mx, c->d_refmax.p, 8));
+    CKS(sync_staged(c));
+    const int max_ref = std::max(1, mx[0]), max_q = std::max(1, mx[1]);
     const size_t sstride = fq_dp_scratch_bytes(max_ref, max_q);
     const size_t chunk = std::max<size_t>(64, ((size_t)6 << 30) / sstride);
-    vector<FqRefOut> outs(tasks.size());
-    vector<uint16_t> cg(tasks.size() * cig_cap);
-    for (size_t t0 = 0; t0 < tasks.size(); t0 += chunk) {
-      const int nt = (int)std::min(chunk, tasks.size() - t0);
-      CKM(c->d_reftask.ensure(nt) && c->d_refout.ensure(nt) && c->d_cig.ensure((size_t)nt * cig_cap) && c->d_scratch.ensure((size_t)nt * sstride));
-      CKS(h2d_staged(c, c->d_reftask.p, tasks.data() + t0, (size_t)nt * sizeof(FqRefTask)));
+    for (size_t t0 = 0; t0 < nt_all; t0 += chunk) {
+      const int nt = (int)std::min(chunk, nt_all - t0);
+      CKM(c->d_scratch.ensure((size_t)nt * sstride));
       FqRefineArgs a{};
-      a.ix = ix->dev; a.seq = K.dseq; a.stride = K.dstride; a.len_trim = K.dlen_trim; a.task = c->d_reftask.p; a.n_task = nt;
-      a.out = c->d_refout.p; a.cigar = c->d_cig.p; a.cig_cap = cig_cap; a.scratch = c->d_scratch.p; a.scratch_stride = sstride; a.RL = max_ref; a.QL = max_q;
+      a.ix = ix->dev; a.seq = K.dseq; a.stride = K.dstride; a.len_trim = K.dlen_trim; a.task = c->d_reftask.p + t0; a.n_task = nt;
+      a.out = c->d_refout.p + t0; a.cigar = c->d_cigs.p + K.cig_used + t0 * FQ_CIG_CAP; a.cig_cap = FQ_CIG_CAP; a.scratch = c->d_scratch.p; a.scratch_stride = sstride; a.RL = max_ref; a.QL = max_q;
       fqdev::time_begin(FQ_K_REFINE);
       CK(fqdev::launch_refine(a));
       fqdev::time_end(FQ_K_REFINE);
-      CKS(d2h_staged(c, outs.data() + t0, c->d_refout.p, (size_t)nt * sizeof(FqRefOut)));
-      CKS(d2h_staged(c, cg.data() + t0 * cig_cap, c->d_cig.p, (size_t)nt * cig_cap * 2));
-      CKS(sync_staged(c));
     }
-    for (size_t t = 0; t < tasks.size(); ++t)
-      if (outs[t].n_cigar <= 0) { c->err = "refine: CIGAR longer than the device slot"; return FQ_ELIMIT; }
-    parallel_chunks(tasks.size(), K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {   // a task owns its record's field
-      for (size_t t = lo; t < hi; ++t) {
-        FqRead &s = R[tgt[t].idx];
-        const uint16_t *g = cg.data() + t * cig_cap;
-        if (tgt[t].multi >= 0) { FqMulti &q = s.multi[tgt[t].multi]; q.pos = outs[t].pos; q.cigar.assign(g, g + outs[t].n_cigar); }
-        else { s.pos = outs[t].pos; s.cigar.assign(g, g + outs[t].n_cigar); }
-      }
-    });
-    c->stats.refine_tasks += tasks.size();
+    REC(FQ_ROP_REF_APPLY, nt_all);
+    K.cig_used += nt_all * FQ_CIG_CAP;
+    K.n_ref = total;
+    c->stats.refine_tasks += nt_all;
   }
-  K.trace("  D: refine kernel + apply");
-  // MD / NM for every mapped read (bwa_cal_md1)
-  // (task list and CIGAR arena are laid out by prefix sums and written, in parallel, where the copy engine reads them)
-  // (every thread counts the tasks and CIGAR entries of its range of records; the ranges' first slots follow from those counts)
-  const int TT = std::max(1, K.host_threads);
-  struct Cnt { uint64_t t = 0, cg = 0; char pad[48]; };
-  vector<Cnt> first((size_t)TT + 1);
-  parallel_chunks(R.size(), TT, K.par_min, [&](size_t lo, size_t hi, int t) {
-    Cnt a;
-    for (size_t idx = lo; idx < hi; ++idx)
-      if (R[idx].type != FQ_TYPE_NO_MATCH) { ++a.t; a.cg += R[idx].cigar.size(); }
-    first[(size_t)t + 1] = a;
-  });
-  for (int t = 1; t <= TT; ++t) { first[t].t += first[t - 1].t; first[t].cg += first[t - 1].cg; }
-  if (first[TT].t > 0x7fffffffull || first[TT].cg > 0xffffffffull) { c->err = "MD tasks exceed 32-bit offsets"; return FQ_ELIMIT; }
-  const int nt_all = (int)first[TT].t;
-  const size_t arena_n = (size_t)first[TT].cg;
-  FqMdTask *mt = nullptr; uint16_t *arena = nullptr;
-  int *mi = nullptr;
-  if (nt_all) {
-    mt = (FqMdTask *)c->arena.alloc((size_t)nt_all * sizeof(FqMdTask)); arena = (uint16_t *)c->arena.alloc((arena_n + 1) * 2);
-    mi = (int *)c->arena.alloc((size_t)nt_all * sizeof(int));
-    if (!mt || !arena || !mi) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
-    parallel_chunks(R.size(), TT, K.par_min, [&](size_t lo, size_t hi, int t) {
-      uint32_t ti = (uint32_t)first[t].t, cgi = (uint32_t)first[t].cg;
-      for (size_t idx = lo; idx < hi; ++idx) {
-        FqRead &s = R[idx];
-        if (s.type == FQ_TYPE_NO_MATCH) continue;
-        FqMdTask T{};
-        T.read = s.dr; T.strand = s.strand; T.pos = s.pos; T.n_cigar = (int)s.cigar.size(); T.cigar_off = cgi; T.len = s.len;
-        if (!s.cigar.empty()) memcpy(arena + cgi, s.cigar.data(), s.cigar.size() * 2);
-        mt[ti] = T; mi[ti] = (int)idx;
-        ++ti; cgi += (uint32_t)s.cigar.size();
-      }
-    });
-  }
-  K.trace("  D: MD task list");
-  if (nt_all) {
-    const int md_cap = 3 * (K.max_len_all + 8) + 32;
-    const int nt = nt_all;
-    CKM(c->d_mdtask.ensure(nt) && c->d_md.ensure((size_t)nt * md_cap) && c->d_mdlen.ensure(nt) && c->d_nm.ensure(nt) && c->d_mdsz.ensure(nt) &&
-        c->d_cigarena.ensure(arena_n + 1) && c->d_off.ensure(nt + 1));
-    CK(fqdev::copy_pinned(c->d_mdtask.p, mt, (size_t)nt * sizeof(FqMdTask), 1));
-    if (arena_n) CK(fqdev::copy_pinned(c->d_cigarena.p, arena, arena_n * 2, 1));
-    c->stats.h2d_bytes += (size_t)nt * sizeof(FqMdTask) + arena_n * 2;
-    FqMdArgs a{};
-    a.ix = ix->dev; a.seq = K.dseq; a.stride = K.dstride; a.task = c->d_mdtask.p; a.n_task = nt; a.cigar = c->d_cigarena.p;
-    a.md = c->d_md.p; a.md_cap = md_cap; a.md_len = c->d_mdlen.p; a.md_sz = c->d_mdsz.p; a.nm = c->d_nm.p;
-    fqdev::time_begin(FQ_K_REFINE);
-    CK(fqdev::launch_md(a));
-    CK(fqdev::launch_scan(c->d_mdsz.p, c->d_off.p, (uint32_t)nt));
-    fqdev::time_end(FQ_K_REFINE);
-    uint64_t total = 0;
-    int32_t *mdlen = (int32_t *)c->arena.alloc((size_t)nt * 4), *nm = (int32_t *)c->arena.alloc((size_t)nt * 4);   // results are read where they land
-    uint64_t *off = (uint64_t *)c->arena.alloc((size_t)(nt + 1) * 8);
-    if (!mdlen || !nm || !off) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
-    CK(fqdev::copy_pinned(off, c->d_off.p, (size_t)(nt + 1) * 8, 0));
-    CK(fqdev::copy_pinned(mdlen, c->d_mdlen.p, (size_t)nt * 4, 0));
-    CK(fqdev::copy_pinned(nm, c->d_nm.p, (size_t)nt * 4, 0));
-    CKS(sync_staged(c));
-    total = off[nt];
-    K.trace("  D: MD kernel + sizes");
-    CKM(c->d_mdpacked.ensure(total + 1));
-    CK(fqdev::launch_pack_md(c->d_md.p, c->d_mdlen.p, c->d_off.p, md_cap, nt, c->d_mdpacked.p));
-    char *packed = (char *)c->arena.alloc(total + 1);
-    if (!packed) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
-    if (total) CK(fqdev::copy_pinned(packed, c->d_mdpacked.p, total, 0));
-    CKS(sync_staged(c));
-    c->stats.d2h_bytes += (size_t)nt * 16 + total;
-    K.trace("  D: MD strings D2H");
-    std::atomic<int> too_long{0};
-    parallel_chunks((size_t)nt, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
-      for (size_t t = lo; t < hi; ++t) {
-        if (mdlen[t] < 0) { too_long.store(1, std::memory_order_relaxed); continue; }
-        FqRead &s = R[mi[t]];
-        s.md.assign(packed + off[t], (size_t)mdlen[t]);
-        s.has_md = true;
-        s.nm = nm[t] & 0xfff;
-      }
-    });
-    if (too_long.load()) { c->err = "MD string longer than the device slot"; return FQ_ELIMIT; }
-  }
-  K.trace("  D: MD apply");
-  // bwa_correct_trimmed (bwase.c:298-337) for every record
-  parallel_chunks(R.size(), K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
-    for (size_t idx = lo; idx < hi; ++idx) {
-      FqRead &s = R[idx];
-      if (s.len == s.full_len) continue;
-      const int clip = s.full_len - s.len;
-      if (s.strand == 0) {
-        if (!s.cigar.empty() && (s.cigar.back() >> 14) == FQ_OP_S) s.cigar.back() = (uint16_t)(s.cigar.back() + clip);
-        else {
-          if (s.cigar.empty()) s.cigar.push_back((uint16_t)(FQ_OP_M << 14 | s.len));
-          s.cigar.push_back((uint16_t)(FQ_OP_S << 14 | clip));
-        }
-      } else {
-        if (!s.cigar.empty() && (s.cigar.front() >> 14) == FQ_OP_S) s.cigar.front() = (uint16_t)(s.cigar.front() + clip);
-        else {
-          if (s.cigar.empty()) s.cigar.push_back((uint16_t)(FQ_OP_M << 14 | s.len));
-          s.cigar.insert(s.cigar.begin(), (uint16_t)(FQ_OP_S << 14 | clip));
-        }
-      }
-      s.len = s.full_len;
-    }
-  });
+  // MD / NM for every mapped read (bwa_cal_md1), straight from the records into one slot per read
+  const int md_cap = 3 * (K.max_len_all + 8) + 32;
+  CKM(c->d_md.ensure(N * (size_t)md_cap + 1));
+  A.seq = K.dseq; A.stride = K.dstride; A.md = c->d_md.p; A.md_cap = md_cap; A.cigs = c->d_cigs.p;
+  fqdev::time_begin(FQ_K_REFINE);
+  REC(FQ_ROP_MD, N);
+  fqdev::time_end(FQ_K_REFINE);
   return FQ_OK;
 }
 
-// ---- flatten into the C-ABI result arrays, collect the work counters ------------------------------------------------
+// the records as they are now, in the host's vocabulary (debug: the stage dumps of the parity tests)
+int snapshot_records(Call &K, vector<FqRead> &dst) {
+  fq_ctx *c = K.c;
+  const size_t N = (size_t)K.n_surv * 2;
+  vector<FqDRec> rec(N);
+  vector<fq_multi_t> multi((size_t)K.n_multi);
+  vector<uint16_t> cigs((size_t)K.cig_used);
+  CKS(d2h_staged(c, rec.data(), c->d_rec.p, N * sizeof(FqDRec)));
+  CKS(d2h_staged(c, multi.data(), c->d_multi.p, multi.size() * sizeof(fq_multi_t)));
+  CKS(d2h_staged(c, cigs.data(), c->d_cigs.p, cigs.size() * 2));
+  CKS(sync_staged(c));
+  dst.assign(N, FqRead());
+  for (size_t i = 0; i < N; ++i) {
+    const FqDRec &s = rec[i];
+    FqRead &p = dst[i];
+    p.r = (int)(i & 1) * K.n + c->h_pair_list[i >> 1];
+    p.score = s.score; p.sa = s.sa; p.pos = s.pos; p.c1 = s.c1; p.c2 = s.c2; p.len = s.len; p.full_len = s.full_len; p.clip_len = s.clip_len;
+    p.nm = (int16_t)s.nm; p.filtered = s.filtered; p.type = s.type; p.strand = s.strand; p.extra_flag = s.extra_flag;
+    p.n_mm = s.n_mm; p.n_gapo = s.n_gapo; p.n_gape = s.n_gape; p.mapQ = s.mapQ; p.seQ = s.seQ; p.revived = s.revived != 0;
+    p.cigar.assign(cigs.data() + (s.n_cigar ? s.cig_off : 0), cigs.data() + (s.n_cigar ? s.cig_off : 0) + s.n_cigar);
+    for (uint32_t j = 0; j < s.n_multi; ++j) {
+      const fq_multi_t &m = multi[s.multi_off + j];
+      FqMulti q;
+      q.pos = m.pos; q.gap = m.gap; q.mm = m.mm; q.strand = m.strand;
+      if (m.n_cigar) q.cigar.assign(cigs.data() + m.cigar_off, cigs.data() + m.cigar_off + m.n_cigar);
+      p.multi.push_back(q);
+    }
+  }
+  return FQ_OK;
+}
+
+// ---- the C-ABI result arrays (written on the device, landed in pinned host memory), the work counters ---------------------------
 int stage_finish(Call &K, fq_result_batch_t *out) {
   fq_ctx *c = K.c;
   FqBatchState &S = c->st;
-  vector<FqRead> &R = S.reads;
+  FqRecArgs &A = K.ra;
   const int n_sub = K.n_sub, n_surv = K.n_surv;
+  const size_t N = (size_t)n_surv * 2;
   S.isize_sub = K.iis;
   S.isize = K.iis[n_sub - 1];
-  S.flatten(K.host_threads, K.par_min);
-  K.trace("flatten");
-  const int n_both_unmapped = S.n_both_unmapped;
-  out->n_survivors = n_surv;
-  out->n_both_filtered = K.n - n_surv;
-  out->n_both_unmapped = n_both_unmapped;
-  out->pair_idx = S.pair_idx.data();
-  out->rec = S.rec.data();
-  out->cigar = S.cigar.data();
-  out->md = S.md.data();
-  out->multi = S.multi.data();
-  out->isize = K.iis[n_sub - 1];
-  out->n_sub = n_sub;
-  out->isize_sub = S.isize_sub.data();
-  out->n_bases = c->n_bases_in;
+  uint64_t cc = 0, mm = 0, xx = 0;
+  if (N) {
+    A.fc_cnt = c->d_cnt[0].p; A.fm_cnt = c->d_cnt[1].p; A.fx_cnt = c->d_cnt[2].p;
+    A.fc_off = c->d_scan[0].p; A.fm_off = c->d_scan[1].p; A.fx_off = c->d_scan[2].p;
+    REC(FQ_ROP_FLAT_COUNT, N);
+    for (int k = 0; k < 3; ++k) CK(fqdev::launch_scan(c->d_cnt[k].p, c->d_scan[k].p, (uint32_t)N));
+    CKS(fetch_u64(c, &cc, c->d_scan[0].p + N));
+    CKS(fetch_u64(c, &mm, c->d_scan[1].p + N));
+    CKS(fetch_u64(c, &xx, c->d_scan[2].p + N));
+    CKS(sync_staged(c));
+    if (cc > 0xffffffffull || mm > 0xfffffffeull || xx > 0xffffffffull) { c->err = "result arenas exceed 32-bit offsets"; return FQ_ELIMIT; }
+  }
+  CKM(c->d_orec.ensure(N + 1) && c->d_ocig.ensure(cc + 1) && c->d_omd.ensure(mm + 1) && c->d_omulti.ensure(xx + 1) &&
+      c->p_orec.ensure(N + 1) && c->p_ocig.ensure(cc + 1) && c->p_omd.ensure(mm + 1) && c->p_omulti.ensure(xx + 1));
+  if (N) {
+    A.o_rec = c->d_orec.p; A.o_cigar = c->d_ocig.p; A.o_md = c->d_omd.p; A.o_multi = c->d_omulti.p;
+    REC(FQ_ROP_FLAT_FILL, N);
+    CK(fqdev::copy_pinned(c->p_orec.p, c->d_orec.p, N * sizeof(fq_result_t), 0));
+    CK(fqdev::copy_pinned(c->p_ocig.p, c->d_ocig.p, cc * 2, 0));
+    CK(fqdev::copy_pinned(c->p_omd.p, c->d_omd.p, mm, 0));
+    CK(fqdev::copy_pinned(c->p_omulti.p, c->d_omulti.p, xx * sizeof(fq_multi_t), 0));
+    c->stats.d2h_bytes += N * sizeof(fq_result_t) + cc * 2 + mm + xx * sizeof(fq_multi_t);
+  }
   uint64_t cnt[FQ_C_COUNT];
   CKS(d2h_staged(c, cnt, c->d_counters.p, sizeof cnt));
   CKS(sync_staged(c));
   CK(fqdev::dzero(c->d_counters.p, sizeof cnt));
+  if (!cc) c->p_ocig.p[0] = 0;
+  if (!mm) c->p_omd.p[0] = 0;
+  if (!xx) c->p_omulti.p[0] = fq_multi_t{};
+  K.trace("result arrays D2H");
+  if (cnt[FQ_C_ERR_CIGAR]) { c->err = "refine: CIGAR longer than the device slot"; return FQ_ELIMIT; }
+  if (cnt[FQ_C_ERR_MD]) { c->err = "MD string longer than the device slot"; return FQ_ELIMIT; }
+  S.rec = c->p_orec.p; S.cigar = c->p_ocig.p; S.md = c->p_omd.p; S.multi = c->p_omulti.p;
+  S.n_both_unmapped = (int)cnt[FQ_C_UNMAPPED];
+  out->n_survivors = n_surv;
+  out->n_both_filtered = K.n - n_surv;
+  out->n_both_unmapped = S.n_both_unmapped;
+  out->pair_idx = S.pair_idx;
+  out->rec = S.rec;
+  out->cigar = S.cigar;
+  out->md = S.md;
+  out->multi = S.multi;
+  out->isize = K.iis[n_sub - 1];
+  out->n_sub = n_sub;
+  out->isize_sub = S.isize_sub.data();
+  out->n_bases = c->n_bases_in;
   fqdev::time_collect(c->stats.kernel_ms, c->stats.kernel_launches, FQ_K_COUNT);
   c->stats.occ_block_touches += cnt[FQ_C_OCC_WIDTH] + cnt[FQ_C_OCC_GAP] + cnt[FQ_C_OCC_SA];
   c->stats.gap_occ_touches += cnt[FQ_C_OCC_GAP];
@@ -2094,6 +1770,8 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
   if (cnt[FQ_C_MAXTRIPS] > c->stats.max_wave_trips) c->stats.max_wave_trips = cnt[FQ_C_MAXTRIPS];
   c->stats.wave_trips += cnt[FQ_C_SUMTRIPS];
   c->stats.lane_trips += cnt[FQ_C_LANETRIPS];
+  c->stats.sa_rows += cnt[FQ_C_SA_DIRECT];
+  c->stats.pairs_on_device += cnt[FQ_C_PAIRS_DEV];
   for (int k = 0; k < 16; ++k) c->stats.dbg[k] += cnt[FQ_C_DBG0 + k];
   c->stats.pairs += K.n;
   c->stats.host_ms_serial += K.t_serial1 - K.t_host0;
@@ -2103,6 +1781,7 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
   K.trace("counters+timers");
   return FQ_OK;
 }
+#undef REC
 
 int run_call_stages(fq_ctx *c, fq_result_batch_t *out);
 int run_call(fq_ctx *c, fq_result_batch_t *out) {
@@ -2122,6 +1801,10 @@ int run_call(fq_ctx *c, fq_result_batch_t *out) {
     (void)fqdev::stream_aux(0);
     (void)fqdev::dzero(c->d_counters.p, FQ_C_COUNT * 8);
     (void)fqdev::sync();
+    // uploads from the caller's pinned batch may still be in flight on the shared copy stream (a prefetched head):
+    // the caller is free to repack or free that storage as soon as the failed call has returned
+    (void)fqdev::copy_wait(0);
+    (void)fqdev::copy_wait(1);
   }
   return rc;
 }
@@ -2136,13 +1819,11 @@ int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
   c->arena.reset();
   const fq_opts_t &o = c->o;
   FqBatchState &S = c->st;
-  K.trace("  pinned arena reset");
   S.clear();
-  K.trace("  state clear");
   S.n_pairs = c->n_pairs;
   memset(out, 0, sizeof *out);
   out->n_pairs = c->n_pairs;
-  if (c->n_pairs == 0) { S.reads.clear(); return FQ_OK; }
+  if (c->n_pairs == 0) return FQ_OK;
   K.n = c->n_pairs; K.n2 = 2 * K.n; K.B = o.batch_pairs; K.n_sub = (K.n + K.B - 1) / K.B;
   K.par_min = c->kn.host_par_min;
   K.host_threads = c->kn.host_threads >= 0 ? c->kn.host_threads : o.host_threads > 0 ? o.host_threads : default_host_threads(c->ix);
@@ -2152,16 +1833,17 @@ int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
   S.batch_pairs = K.B;
   S.sub_lo = K.sub_lo;
   S.pair_idx = c->h_pair_list;
+  S.surv = c->h_surv;
   K.trace("stage0 prep+compact");
-  {   // the survivors' records depend on stage 0 only: they are set up while the device searches
-    std::thread rec_thread;
-    if ((size_t)K.n_surv * 2 >= K.par_min) rec_thread = std::thread([&K] { stage_records(K); });
-    rc = stageA_search(K);
-    if (rec_thread.joinable()) rec_thread.join(); else if (!rc) stage_records(K);
-    if (rc) return rc;
-  }
-  K.trace("stageA width+gap, records init");
+  if ((rc = stageA_search(K))) return rc;
+  K.trace("stageA width+gap");
+  if ((rc = stage_records(K))) return rc;
+  K.trace("records, SA plan, best-hit counts D2H");
+  // where every chunk of pairs enters the drand48 stream: drawn up beside the SA stage
   // (a sharded stream's hook may still hand this context the stream's state: then the plan waits for it)
+  K.plan.n_chunks = ((size_t)K.n_surv + FQ_RNG_CHUNK_PAIRS - 1) / FQ_RNG_CHUNK_PAIRS;
+  K.plan.start = (uint64_t *)c->arena.alloc((K.plan.n_chunks + 1) * 8);
+  if (!K.plan.start) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
   if (!c->before_serial && (size_t)K.n_surv * 2 >= K.par_min) K.plan_thread = std::thread([&K, c] { stageB1_plan(K, c->rng); });
   if ((rc = stage_sa_rows(K))) return rc;
   K.trace("SA enumerate+kernel");
@@ -2172,31 +1854,33 @@ int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
   c->serial_open = true;
   if (c->stream_broken) { c->err = "the stream's state comes from a call that failed (on this rank or on the one before)"; return FQ_EIO; }
   if ((rc = stageB1_main_hit(K))) return rc;
-  K.trace("B1 main hit (serial)");
+  K.trace("B1 replay + main hit");
   if (o.single_end) K.iis.assign(K.n_sub, fq_isize_t{});     // no pairs: no insert sizes, no (k,l) cache, no pairing, no mate rescue
   else {
     stageB2_isize(K);
     c->last_ii = K.iis[K.n_sub - 1];
-    stage_kl_cache(K);
+    if ((rc = stage_kl_cache(K))) return rc;
   }
   if (c->after_serial) c->after_serial(c->hook_user);
   c->serial_done = true;
+  if (c->stream_broken) { c->err = "the hook that hands the stream's state on failed (fq_ctx_mark_stream_broken)"; return FQ_EIO; }
   K.t_serial1 = now_ms();
-  K.trace("B2 isize");
-  if (!o.single_end && (rc = stageB3_pairing(K))) return rc;
+  K.trace("B2 isize, (k,l) cache");
+  if ((rc = stageB3_pairing(K))) return rc;
   K.trace("B3 pairing+XA");
-  if (c->debug) S.stage_P = S.reads;   // snapshot for the stage dump (tests)
+  if (c->debug && (rc = snapshot_records(K, S.stage_P))) return rc;   // snapshot for the stage dump (tests)
   if (!o.single_end && (rc = stageC_mate_sw(K))) return rc;
   K.trace("C mate SW");
-  if (c->debug) S.stage_S = S.reads;
+  if (c->debug && (rc = snapshot_records(K, S.stage_S))) return rc;
   if ((rc = stageD_refine(K))) return rc;
-  K.trace("D refine+MD+trim");
+  K.trace("D refine+MD");
   K.t_host1 = now_ms();
   return stage_finish(K, out);
 }
 }  // namespace
 
 extern "C" int fq_host_cpus(void) { return (int)effective_cpus(); }
+extern "C" int fq_runtime_configure(int hw_queues, int blocking_waits) { return fqdev::runtime_configure(hw_queues, blocking_waits); }
 
 extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   if (!c || !out) return FQ_EINVAL;
@@ -2308,6 +1992,13 @@ extern "C" int fq_ctx_state_import(fq_ctx_t *c, const void *buf, int64_t len) {
     memcpy(v.data(), p, 4 * m); p += 4 * m;
     c->kl_cache.emplace(key, std::move(v));
   }
+  return FQ_OK;
+}
+// A hook that could not do its work (its transport failed, its language raised) says so here, from inside the hook: the call stops
+// after `before`, and the state `after` exports carries the broken mark -- nobody goes on with a stale state.
+extern "C" int fq_ctx_mark_stream_broken(fq_ctx_t *c) {
+  if (!c) return FQ_EINVAL;
+  c->stream_broken = true;
   return FQ_OK;
 }
 extern "C" int fq_ctx_set_serial_hooks(fq_ctx_t *c, fq_serial_hook before, fq_serial_hook after, void *user) {

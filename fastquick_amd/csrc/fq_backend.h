@@ -3,6 +3,7 @@
 // implementation of the same interface for the CPU-only test tier; it is never part of the product.
 #pragma once
 #include "fq_kernels.h"
+#include "fq_records.h"
 
 namespace fqdev {
 
@@ -16,6 +17,7 @@ struct Tune {   // experiment / test knobs (fq_ctx_set_tuning); the defaults are
   int spin_sync = 0;        // 1: sync() spins (hipStreamSynchronize) instead of sleeping on a blocking event
   int gap_generic_opts = 0; // 1: never the kernels specialised for FASTQuick's own option block (FqOptsStock)
 };
+int runtime_configure(int hw_queues, int blocking_waits);   // fq_runtime_configure: before the process's first HIP call
 State *state_create(int device_ordinal);   // nullptr on failure (last_error())
 void state_destroy(State *s);              // synchronises the state's streams, frees everything it owns
 int bind(State *s);                        // 0 or FQ_ENODEV-style negative
@@ -36,6 +38,7 @@ int h2d(void *dst, const void *src, size_t bytes);
 int d2h(void *dst, const void *src, size_t bytes);
 // host side pinned (hmalloc): small sizes are copied by a kernel on the compute stream, large ones by hipMemcpyAsync
 int copy_pinned(void *dst, const void *src, size_t bytes, int to_device);
+int d2d(void *dst, const void *src, size_t bytes);   // device to device, on the compute stream
 int dzero(void *dst, size_t bytes);
 int dfill(void *dst, int byte, size_t bytes);
 int sync();
@@ -91,6 +94,10 @@ int stream_fork();
 int stream_join();
 // the work items of one queue segment whose search did not complete (status != 0): search indices appended to out[*count ...]
 int launch_collect(const int32_t *order, const uint32_t *split, int n_work, int seg, int n_seg, const uint32_t *status, const int32_t *work, int32_t *out, uint32_t *count);   // pairing of both-mapped pairs (fq_pair_thread)
+// the stages over the device-resident records (fq_records.h): operation FQ_ROP_*, one thread per item
+int launch_rec(int op, const FqRecArgs &a, int64_t n);
+// by search index: aoff[work[w]] = base + off[w], an[work[w]] = naln[w] for the work items of a launch that completed (status 0)
+int launch_aln_index(const int32_t *work, const uint32_t *status, const uint64_t *off, const uint32_t *naln, uint64_t base, uint64_t *aoff, uint32_t *an, int n);
 int launch_sw(const FqSwArgs &a);          // one task per wavefront (window + query in LDS)
 int launch_sw_serial(const FqSwArgs &a);   // one task per lane out of the task's global scratch: any window size
 int launch_refine(const FqRefineArgs &a);

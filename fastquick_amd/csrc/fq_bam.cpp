@@ -160,6 +160,7 @@ struct fq_bam {
   const fq_index *ix = nullptr;
   fq_qc_opts_t o{};
   Bgzf z;
+  std::vector<uint8_t> last;                             // fq_bam_format_last: the records of the last batch it formatted
   std::string err, rg_id, header_text;
   std::vector<std::pair<std::string, int>> contigs;      // BwtIndexer::contigSize
   std::map<std::string, int> ref_id;
@@ -286,7 +287,7 @@ void fq_bam::record(std::vector<uint8_t> &dst, const fq_opts_t *ao, const FqHost
 }
 
 extern "C" int fq_bam_create(const fq_index_t *ix, const char *fai_path, const char *bam_path, const char *rg_line, const fq_qc_opts_t *o, fq_bam_t **out) {
-  if (!ix || !fai_path || !bam_path || !o || !out) return FQ_EINVAL;
+  if (!ix || !fai_path || !o || !out) return FQ_EINVAL;
   *out = nullptr;
   fq_bam *b = new fq_bam;
   b->ix = ix; b->o = *o;
@@ -324,6 +325,7 @@ extern "C" int fq_bam_create(const fq_index_t *ix, const char *fai_path, const c
     b->ref_id.emplace(b->contigs[i].first, (int)i);   // (a repeated name keeps its first id)
   }
   b->header_text = h.str();
+  if (!bam_path) { *out = b; return FQ_OK; }          // a formatter without a file (fq_bam_format_last)
   b->z.fp = fopen(bam_path, "wb");
   if (!b->z.fp) { delete b; return FQ_EIO; }
   const int32_t l_text = (int32_t)b->header_text.size(), n_ref = (int32_t)b->contigs.size();
@@ -341,9 +343,8 @@ extern "C" int fq_bam_create(const fq_index_t *ix, const char *fai_path, const c
   return FQ_OK;
 }
 
-// the BAM branch of PairEndMapper's consumer loop over one batch (src/BwtMapper.cpp:2054-2085)
-extern "C" int fq_bam_add_last(fq_bam_t *b, fq_ctx_t *c) {
-  if (!b || !c || !b->z.fp) return FQ_EINVAL;
+// the BAM branch of PairEndMapper's consumer loop over one batch (src/BwtMapper.cpp:2054-2085): the batch's records, in input order
+static int format_last(fq_bam_t *b, fq_ctx_t *c, std::vector<std::vector<uint8_t>> &parts) {
   const FqBatchState *S = fq_ctx_state(c);
   const FqHostReads hb = fq_ctx_host_reads(c);
   const fq_opts_t *ao = fq_ctx_opts(c);
@@ -351,9 +352,9 @@ extern "C" int fq_bam_add_last(fq_bam_t *b, fq_ctx_t *c) {
   // records are independent of each other: ranges of pairs are formatted on several threads and handed to the BGZF layer in order
   auto format_range = [&](int lo, int hi, std::vector<uint8_t> &dst) {
   for (int sp = lo; sp < hi; ++sp) {
-    if (S->reads[2 * sp].type == FQ_TYPE_NO_MATCH && S->reads[2 * sp + 1].type == FQ_TYPE_NO_MATCH) continue;
+    if (S->rec[2 * (size_t)sp].type == FQ_TYPE_NO_MATCH && S->rec[2 * (size_t)sp + 1].type == FQ_TYPE_NO_MATCH) continue;
     if (ao->single_end) {   // SingleEndMapper's BAM branch (src/BwtMapper.cpp:1372-1387): AddAlignment(p, 0), SetSamRecord(p, 0)
-      FqRead p = S->reads[2 * sp];
+      FqRead p = S->read(2 * (size_t)sp);
       int seqid;
       const int j = (int)(ref_end(p) - p.pos);
       fq_coor_pac2real(b->ix, p.pos, j, &seqid);
@@ -361,7 +362,7 @@ extern "C" int fq_bam_add_last(fq_bam_t *b, fq_ctx_t *c) {
       b->record(dst, ao, hb, S->n_pairs, p, p, true);
       continue;
     }
-    FqRead p = S->reads[2 * sp], q = S->reads[2 * sp + 1];
+    FqRead p = S->read(2 * (size_t)sp), q = S->read(2 * (size_t)sp + 1);
     for (FqRead *r : {&p, &q})   // StatCollector::AddAlignment first (src/StatCollector.cpp:955-971)
       if (r->type != FQ_TYPE_NO_MATCH) {
         int seqid;
@@ -375,7 +376,7 @@ extern "C" int fq_bam_add_last(fq_bam_t *b, fq_ctx_t *c) {
   }
   };
   const int T = S->n_surv >= 256 ? 8 : 1;
-  std::vector<std::vector<uint8_t>> parts((size_t)T);
+  parts.assign((size_t)T, std::vector<uint8_t>());
   if (T == 1) format_range(0, S->n_surv, parts[0]);
   else {
     std::vector<std::thread> th;
@@ -383,7 +384,31 @@ extern "C" int fq_bam_add_last(fq_bam_t *b, fq_ctx_t *c) {
     for (int t = 0; t < T; ++t) { const int lo = t * per, hi = std::min(S->n_surv, lo + per); if (lo < hi) th.emplace_back(format_range, lo, hi, std::ref(parts[(size_t)t])); }
     for (auto &x : th) x.join();
   }
+  return FQ_OK;
+}
+extern "C" int fq_bam_add_last(fq_bam_t *b, fq_ctx_t *c) {
+  if (!b || !c || !b->z.fp) return FQ_EINVAL;
+  std::vector<std::vector<uint8_t>> parts;
+  const int rc = format_last(b, c, parts);
+  if (rc) return rc;
   for (auto &part : parts) if (!part.empty()) b->z.write(part.data(), part.size());
+  return b->z.ok ? FQ_OK : FQ_EIO;
+}
+// The same records as bytes (uncompressed BAM records, block_size first), for a caller that writes them itself or elsewhere: several
+// devices format the batches of their FASTQ pairs at once and one writer appends them in input order (fq_bam_write_records).
+extern "C" int fq_bam_format_last(fq_bam_t *b, fq_ctx_t *c, const void **data, int64_t *len) {
+  if (!b || !c || !data || !len) return FQ_EINVAL;
+  std::vector<std::vector<uint8_t>> parts;
+  const int rc = format_last(b, c, parts);
+  if (rc) return rc;
+  b->last.clear();
+  for (auto &part : parts) b->last.insert(b->last.end(), part.begin(), part.end());
+  *data = b->last.data(); *len = (int64_t)b->last.size();
+  return FQ_OK;
+}
+extern "C" int fq_bam_write_records(fq_bam_t *b, const void *data, int64_t len) {
+  if (!b || !b->z.fp || len < 0 || (len > 0 && !data)) return FQ_EINVAL;
+  if (len) b->z.write(data, (size_t)len);
   return b->z.ok ? FQ_OK : FQ_EIO;
 }
 extern "C" int fq_bam_close(fq_bam_t *b) {

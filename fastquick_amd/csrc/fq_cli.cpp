@@ -11,6 +11,7 @@
 #include <sys/stat.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <chrono>
 #include <cstdio>
@@ -104,6 +105,7 @@ struct Args {
   int opte = -1;
   long long chunk_pairs = 16LL * 262144;
   int device = 0;
+  std::string devices;   // --devices: several devices, the lines of --fq_list dealt over them
   int pack_threads = std::min(32, std::max(1, fq_host_cpus()));     // host threads of the FASTQ readers (half per file) and of the packer, from the CPUs the process may use; --t sets it
   bool clean_names = false;
   std::string fq_list, rg = "@RG\\tID:foo\\tSM:bar";   // runAlign's default --RG (src/FASTQuick.cpp:170)
@@ -116,145 +118,62 @@ int usage() {
   fprintf(stderr, "Usage: FASTQuick_amd align --index_prefix P --fastq_1 R1.fq[.gz] [--fastq_2 R2.fq[.gz]] | --fq_list LIST  --out_prefix O [--sam_out] [--RG STR] [--cal_dup]\n"
                   "                       [--q INT] [--n FLOAT|INT] [--kmer_thresh INT] [--o INT] [--e INT] [--i INT] [--d INT] [--l INT] [--k INT]\n"
                   "                       [--m INT] [--R INT] [--N] [--L] [--I] [--max_isize INT] [--max_occ INT] [--is_sw] [--n_multi INT] [--N_multi INT]\n"
-                  "                       [--ap_prior FLOAT] [--force_isize] [--frac_samp FLOAT] [--t INT] [--chunk_pairs INT] [--batch_pairs INT] [--device INT] [--read_len INT] [--clean_names]\n"
+                  "                       [--ap_prior FLOAT] [--force_isize] [--frac_samp FLOAT] [--t INT] [--chunk_pairs INT] [--batch_pairs INT] [--device INT | --devices LIST] [--read_len INT] [--clean_names]\n"
                   "       FASTQuick_amd index --ref REDUCED.FASTQuick.fa [--rollhash]\n");
   return 1;
 }
-}  // namespace
 
-int main(int argc, char **argv) {
-  if (argc < 2) return usage();
-  const std::string cmd = argv[1];
-  if (cmd == "index") {
-    std::string ref;
-    int rollhash = 0;
-    for (int i = 2; i < argc; ++i) {
-      if (!strcmp(argv[i], "--ref") && i + 1 < argc) ref = argv[++i];
-      else if (!strcmp(argv[i], "--rollhash")) rollhash = 1;
-      else return usage();
-    }
-    if (ref.empty()) return usage();
-    const int rc = fq_index_build(ref.c_str(), rollhash);
-    if (rc) die("fq_index_build failed (" + std::to_string(rc) + ")");
-    return 0;
+// Where a worker's records go.  One device: straight to stdout / the BAM file, as they are produced.  Several devices: every FASTQ pair
+// into part files of its own (SAM text; BAM records as bytes), which the main thread appends to the output in input order.
+struct Sink {
+  bool sam_out = false;
+  FILE *sam_fp = nullptr;        // stdout, or the input's part file
+  fq_bam_t *bam = nullptr;       // the file's writer (direct), or a formatter without a file
+  FILE *bam_fp = nullptr;        // the input's part file of BAM records (null: direct)
+  std::string what;
+  void sam(const char *p, size_t n) { if (fwrite(p, 1, n, sam_fp) != n) die("writing " + what + " failed"); }
+  void bam_add(fq_ctx_t *ctx) {
+    if (!bam_fp) { if (fq_bam_add_last(bam, ctx)) die("writing " + what + " failed"); return; }
+    const void *data = nullptr; int64_t len = 0;
+    if (fq_bam_format_last(bam, ctx, &data, &len) || (len && fwrite(data, 1, (size_t)len, bam_fp) != (size_t)len)) die("writing " + what + " failed");
   }
-  if (cmd != "align") return usage();
-  Args A;
-  fq_default_opts(&A.o);
-  for (int i = 2; i < argc; ++i) {
-    const std::string f = argv[i];
-    auto need = [&](const char *) -> const char * { if (i + 1 >= argc) die("missing value for " + f); return argv[++i]; };
-    if (f == "--fastq_1") A.fq1 = need("");
-    else if (f == "--fastq_2") A.fq2 = need("");
-    else if (f == "--out_prefix") A.out_prefix = need("");
-    else if (f == "--index_prefix") A.index_prefix = need("");
-    else if (f == "--sam_out") A.sam_out = true;
-    else if (f == "--kmer_thresh") A.o.filter_thresh = atoi(need(""));
-    else if (f == "--n") A.o.fnr = atof(need(""));
-    else if (f == "--o") A.o.max_gapo = atoi(need(""));
-    else if (f == "--e") A.opte = atoi(need(""));
-    else if (f == "--i") A.o.indel_end_skip = atoi(need(""));
-    else if (f == "--d") A.o.max_del_occ = atoi(need(""));
-    else if (f == "--l") A.o.seed_len = atoi(need(""));
-    else if (f == "--k") A.o.max_seed_diff = atoi(need(""));
-    else if (f == "--m") A.o.max_entries = atoi(need(""));
-    else if (f == "--t") { A.o.host_threads = atoi(need("")); if (A.o.host_threads > 0) A.pack_threads = A.o.host_threads; }   // accepted for command-line compatibility (see fastquick_amd.h)
-    else if (f == "--R") A.o.max_top2 = atoi(need(""));
-    else if (f == "--q") A.o.trim_qual = atoi(need(""));
-    else if (f == "--N") { A.o.mode |= 0x10; A.o.max_top2 = 0x7fffffff; }
-    else if (f == "--L") A.o.mode |= 4;
-    else if (f == "--I") A.o.mode |= 0x200;   // BWA_MODE_IL13
-    else if (f == "--max_isize") A.o.max_isize = atoi(need(""));
-    else if (f == "--max_occ") A.o.max_occ = (uint32_t)atoi(need(""));
-    else if (f == "--is_sw") A.o.is_sw = !A.o.is_sw;          // a bool flag on a default-1 int: it toggles (src/FASTQuick.cpp:278)
-    else if (f == "--n_multi") A.o.n_multi = atoi(need(""));
-    else if (f == "--N_multi") A.o.N_multi = atoi(need(""));
-    else if (f == "--ap_prior") A.o.ap_prior = atof(need(""));
-    else if (f == "--force_isize") A.o.force_isize = 1;
-    else if (f == "--chunk_pairs") A.chunk_pairs = atoll(need(""));
-    else if (f == "--read_len") A.read_len = atoi(need(""));
-    else if (f == "--clean_names") A.clean_names = true;
-    else if (f == "--batch_pairs") A.o.batch_pairs = atoi(need(""));   // READ_BUFFER_SIZE of the run to reproduce (default 262144)
-    else if (f == "--device") A.device = atoi(need(""));
-    else if (f == "--fq_list") A.fq_list = need("");
-    else if (f == "--RG") A.rg = need("");
-    else if (f == "--cal_dup") A.cal_dup = !A.cal_dup;        // (a bool flag on a default-1 field, like --is_sw)
-    else if (f == "--frac_samp") A.frac = atof(need(""));
-    else if (f == "--bam_in") die(f + " is not supported (the reference's BAM input is disabled, too)");
-    else die("unknown option " + f);
+  void flush() { if (sam_fp) fflush(sam_fp); if (bam_fp) fflush(bam_fp); }
+};
+// "0-3", "0,2,5", "0,0": the devices of --devices (a device named twice gets two workers)
+std::vector<int> parse_devices(const std::string &v) {
+  std::vector<int> d;
+  size_t at = 0;
+  while (at < v.size()) {
+    size_t end = v.find(',', at);
+    if (end == std::string::npos) end = v.size();
+    const std::string tok = v.substr(at, end - at);
+    const size_t dash = tok.find('-');
+    if (tok.empty()) die("--devices: empty entry in " + v);
+    if (dash == std::string::npos) d.push_back(atoi(tok.c_str()));
+    else { const int a = atoi(tok.substr(0, dash).c_str()), b = atoi(tok.substr(dash + 1).c_str()); if (b < a) die("--devices: bad range " + tok); for (int x = a; x <= b; ++x) d.push_back(x); }
+    at = end + 1;
   }
-  if (A.o.fnr >= 1.0) { A.o.max_diff = (int)A.o.fnr; A.o.fnr = -1.0; }                  // src/FASTQuick.cpp:312-315
-  if (A.opte > 0) { A.o.max_gape = A.opte; A.o.mode &= ~1; }                             // :316-319
-  if (A.out_prefix == "Empty") die("--out_prefix is required");
-  if (A.index_prefix == "Empty") die("--index_prefix is required");
-  // --fq_list: one FASTQ pair per line, '#' lines skipped (src/BwtMapper.cpp:232-262); every pair is an independent stream
-  // (its own srand48, last_ii, position cache and read slots: PairEndMapper sets them up per call), all into one output
-  std::vector<std::pair<std::string, std::string>> inputs;
-  if (!A.fq_list.empty()) {
-    FILE *fl = fopen(A.fq_list.c_str(), "r");
-    if (!fl) die("Open file " + A.fq_list + " failed");
-    char line[8192];
-    while (fgets(line, sizeof line, fl)) {
-      if (line[0] == '#') continue;
-      char a[4096] = "", b[4096] = "";
-      const int got = sscanf(line, "%4095s %4095s", a, b);
-      if (got < 1) continue;
-      inputs.emplace_back(a, got < 2 ? "" : b);      // one column: single-end (src/BwtMapper.cpp:255-262)
-    }
-    fclose(fl);
-  } else {
-    if (A.fq1.empty()) die("--fastq_1 (and --fastq_2 for paired-end reads), or --fq_list, is required");
-    inputs.emplace_back(A.fq1, A.fq2);
+  for (int x : d) if (x < 0 || x > 63) die("--devices: device ordinal out of range in " + v);
+  return d;
+}
+void append_file(const std::string &path, FILE *to, fq_bam_t *bam) {   // a part file onto the output (SAM text to `to`, BAM records to `bam`), then gone
+  FILE *f = fopen(path.c_str(), "rb");
+  if (!f) die("cannot reopen " + path);
+  std::vector<char> buf((size_t)8 << 20);
+  size_t n;
+  while ((n = fread(buf.data(), 1, buf.size(), f)) > 0) {
+    if (to ? fwrite(buf.data(), 1, n, to) != n : fq_bam_write_records(bam, buf.data(), (int64_t)n) != 0) die("appending " + path + " to the output failed");
   }
-  if (A.o.batch_pairs < 1) die("--batch_pairs must be positive");
-  A.chunk_pairs = std::max<long long>(A.o.batch_pairs, A.chunk_pairs / A.o.batch_pairs * A.o.batch_pairs);   // whole reference batches per chunk
+  fclose(f);
+  remove(path.c_str());
+}
 
-  fq_index_t *ix = nullptr;
-  const std::string pre = A.index_prefix + ".FASTQuick.fa";
-  const auto t_ix0 = std::chrono::steady_clock::now();
-  int rc = fq_index_load(pre.c_str(), A.device, &ix);
-  fprintf(stderr, "NOTICE - index staged on the device in %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ix0).count());
-  if (rc) die("cannot load index " + pre + " onto HIP device " + std::to_string(A.device) + " (" + std::to_string(rc) + "); there is no CPU fallback");
-  // <index>.param: REFERENCE_PATH, TARGET_REGION_PATH, DBSNP_VCF_PATH, NUM_VAR_LONG, NUM_VAR_SHORT, SHORT_FLANK_LENGTH, LONG_FLANK_LENGTH
-  fq_qc_opts_t qo;
-  fq_qc_default_opts(&qo);
-  qo.read_len = A.read_len; qo.cal_dup = A.cal_dup ? 1 : 0;
-  std::string ref_path;
-  {
-    FILE *fp = fopen((pre + ".param").c_str(), "r");
-    char key[256], val[4096];
-    while (fp && fscanf(fp, "%255s %4095s", key, val) == 2) {
-      if (!strcmp(key, "REFERENCE_PATH")) ref_path = val;
-      else if (!strcmp(key, "SHORT_FLANK_LENGTH")) qo.flank_len = atoi(val);
-      else if (!strcmp(key, "LONG_FLANK_LENGTH")) qo.flank_long_len = atoi(val);
-    }
-    if (fp) fclose(fp);
-    if (!ref_path.empty()) {   // BwtIndexer::LoadContigSize (src/BwtIndexer.cpp:764-802): sums of column 2 of the .fai and of EVERY line of the .amb
-      char line[8192], a[4096], b[4096];
-      if (FILE *ff = fopen((ref_path + ".fai").c_str(), "r")) { while (fgets(line, sizeof line, ff)) if (sscanf(line, "%4095s %4095s", a, b) == 2) qo.genome_size += atoi(b); fclose(ff); }
-      if (FILE *fa = fopen((ref_path + ".amb").c_str(), "r")) { while (fgets(line, sizeof line, fa)) if (sscanf(line, "%4095s %4095s", a, b) == 2) qo.genome_n_size += atoi(b); fclose(fa); }
-    }
-  }
-  struct stat sb;
-  fq_qc_t *qc = nullptr;
-  if (stat((pre + ".SelectedSite.vcf").c_str(), &sb) == 0) {
-    rc = fq_qc_create(ix, pre.c_str(), A.out_prefix.c_str(), &qo, &qc);
-    if (rc) die("cannot set up the QC consumer from " + pre + ".SelectedSite.vcf / .dbSNP.subset.vcf / .gc (" + std::to_string(rc) + ")");
-  } else fprintf(stderr, "NOTICE - %s.SelectedSite.vcf not found: the QC files are not written\n", pre.c_str());
-  fq_bam_t *bam = nullptr;
-  if (A.sam_out) {
-    const int64_t n = fq_sam_header(ix, nullptr, 0);
-    std::vector<char> h((size_t)n + 1);
-    fq_sam_header(ix, h.data(), n + 1);
-    fwrite(h.data(), 1, (size_t)n, stdout);
-  } else {
-    if (ref_path.empty()) die("BAM output needs the original reference's .fai: " + pre + ".param (REFERENCE_PATH) is missing; or pass --sam_out");
-    rc = fq_bam_create(ix, (ref_path + ".fai").c_str(), (A.out_prefix + ".bam").c_str(), A.rg.c_str(), &qo, &bam);
-    if (rc) die("cannot open " + A.out_prefix + ".bam / " + ref_path + ".fai (" + std::to_string(rc) + ")");
-  }
-  // FASTQ front end: one reader thread per file tokenises the next chunk into flat buffers while the device aligns the current
-  // one (the reference, too, decodes the two files on two IO threads: BwtMapper.cpp:1873-1935).
-  for (const auto &input : inputs) {
+// One FASTQ pair (or one single-end file) through a device: an independent stream -- its own context (srand48, last_ii, position cache)
+// and read slots, as PairEndMapper / SingleEndMapper set them up per call (src/BwtMapper.cpp:232-262).
+// FASTQ front end: one reader thread per file tokenises the next chunk into flat buffers while the device aligns the current
+// one (the reference, too, decodes the two files on two IO threads: BwtMapper.cpp:1873-1935).
+void align_input(Args A, const std::pair<std::string, std::string> &input, fq_index_t *ix, fq_qc_t *qc, Sink &out) {
+  int rc;
   A.fq1 = input.first; A.fq2 = input.second;
   if (A.fq2.empty() || A.fq2 == "Empty") {
     // ---- BwtMapper::SingleEndMapper (src/BwtMapper.cpp:1266-1407): one file, its own srand48 stream; the reader hands out fresh zeroed
@@ -301,20 +220,20 @@ int main(int argc, char **argv) {
         const int64_t sz = fq_sam_format_last(ctx, nullptr, 0);
         sam.resize((size_t)sz + 1);
         fq_sam_format_last(ctx, sam.data(), sz + 1);
-        fwrite(sam.data(), 1, (size_t)sz, stdout);
-      } else if ((rc = fq_bam_add_last(bam, ctx))) die("writing " + A.out_prefix + ".bam failed");
+        out.sam(sam.data(), (size_t)sz);
+      } else out.bam_add(ctx);
       num_read += n; filtered += res.n_both_filtered; unmapped += res.n_both_unmapped;
       fprintf(stderr, "NOTICE - %lld sequences are loaded.\n", num_read);
       if (prefetch.joinable()) prefetch.join();
       if (last) break;
     }
-    fflush(stdout);
+    out.flush();
     notice("%lld sequences are filtered.", filtered);
     notice("%lld sequences are unmapped.", unmapped);
     if (qc) fq_qc_end_file(qc);
     fq_ctx_destroy(ctx);
     fq_packed_free(pk1);
-    continue;
+    return;
   }
   fprintf(stderr, "NOTICE - Processing Pair End mapping\t%s\t%s\n", A.fq1.c_str(), A.fq2.c_str());
   if (qc) fq_qc_begin_file(qc, A.fq1.c_str(), A.fq2.c_str());
@@ -394,8 +313,8 @@ int main(int argc, char **argv) {
       const int64_t sz = fq_sam_format_last(ctx, nullptr, 0);
       sam.resize((size_t)sz + 1);
       fq_sam_format_last(ctx, sam.data(), sz + 1);
-      fwrite(sam.data(), 1, (size_t)sz, stdout);
-    } else if ((rc = fq_bam_add_last(bam, ctx))) die("writing " + A.out_prefix + ".bam failed");
+      out.sam(sam.data(), (size_t)sz);
+    } else out.bam_add(ctx);
     const auto tc2 = std::chrono::steady_clock::now();
     qc_ms += std::chrono::duration<double, std::milli>(tc1 - tc0).count(); out_ms += std::chrono::duration<double, std::milli>(tc2 - tc1).count();
     num_read += 2LL * n; filtered += res.n_both_filtered; unmapped += res.n_both_unmapped; num_base += res.n_bases;
@@ -403,7 +322,7 @@ int main(int argc, char **argv) {
     if (prefetch.joinable()) prefetch.join();
     if (last) break;
   }
-  fflush(stdout);
+  out.flush();
   notice("%lld sequences are loaded.", num_read);
   notice("%lld sequences are filtered.", filtered * 2);
   notice("%lld sequences are unmapped.", unmapped * 2);
@@ -416,11 +335,227 @@ int main(int argc, char **argv) {
   fq_ctx_destroy(ctx);
   fq_packed_free(pk);
   }
-  if (bam && fq_bam_close(bam)) die("closing " + A.out_prefix + ".bam failed");
-  if (qc) {
-    if (fq_qc_write(qc)) die("writing the QC files failed");
-    fq_qc_destroy(qc);
+}  // namespace
+
+int main(int argc, char **argv) {
+  if (argc < 2) return usage();
+  const std::string cmd = argv[1];
+  if (cmd == "index") {
+    std::string ref;
+    int rollhash = 0;
+    for (int i = 2; i < argc; ++i) {
+      if (!strcmp(argv[i], "--ref") && i + 1 < argc) ref = argv[++i];
+      else if (!strcmp(argv[i], "--rollhash")) rollhash = 1;
+      else return usage();
+    }
+    if (ref.empty()) return usage();
+    const int rc = fq_index_build(ref.c_str(), rollhash);
+    if (rc) die("fq_index_build failed (" + std::to_string(rc) + ")");
+    return 0;
   }
-  fq_index_destroy(ix);
+  if (cmd != "align") return usage();
+  Args A;
+  fq_default_opts(&A.o);
+  for (int i = 2; i < argc; ++i) {
+    const std::string f = argv[i];
+    auto need = [&](const char *) -> const char * { if (i + 1 >= argc) die("missing value for " + f); return argv[++i]; };
+    if (f == "--fastq_1") A.fq1 = need("");
+    else if (f == "--fastq_2") A.fq2 = need("");
+    else if (f == "--out_prefix") A.out_prefix = need("");
+    else if (f == "--index_prefix") A.index_prefix = need("");
+    else if (f == "--sam_out") A.sam_out = true;
+    else if (f == "--kmer_thresh") A.o.filter_thresh = atoi(need(""));
+    else if (f == "--n") A.o.fnr = atof(need(""));
+    else if (f == "--o") A.o.max_gapo = atoi(need(""));
+    else if (f == "--e") A.opte = atoi(need(""));
+    else if (f == "--i") A.o.indel_end_skip = atoi(need(""));
+    else if (f == "--d") A.o.max_del_occ = atoi(need(""));
+    else if (f == "--l") A.o.seed_len = atoi(need(""));
+    else if (f == "--k") A.o.max_seed_diff = atoi(need(""));
+    else if (f == "--m") A.o.max_entries = atoi(need(""));
+    else if (f == "--t") { A.o.host_threads = atoi(need("")); if (A.o.host_threads > 0) A.pack_threads = A.o.host_threads; }   // accepted for command-line compatibility (see fastquick_amd.h)
+    else if (f == "--R") A.o.max_top2 = atoi(need(""));
+    else if (f == "--q") A.o.trim_qual = atoi(need(""));
+    else if (f == "--N") { A.o.mode |= 0x10; A.o.max_top2 = 0x7fffffff; }
+    else if (f == "--L") A.o.mode |= 4;
+    else if (f == "--I") A.o.mode |= 0x200;   // BWA_MODE_IL13
+    else if (f == "--max_isize") A.o.max_isize = atoi(need(""));
+    else if (f == "--max_occ") A.o.max_occ = (uint32_t)atoi(need(""));
+    else if (f == "--is_sw") A.o.is_sw = !A.o.is_sw;          // a bool flag on a default-1 int: it toggles (src/FASTQuick.cpp:278)
+    else if (f == "--n_multi") A.o.n_multi = atoi(need(""));
+    else if (f == "--N_multi") A.o.N_multi = atoi(need(""));
+    else if (f == "--ap_prior") A.o.ap_prior = atof(need(""));
+    else if (f == "--force_isize") A.o.force_isize = 1;
+    else if (f == "--chunk_pairs") A.chunk_pairs = atoll(need(""));
+    else if (f == "--read_len") A.read_len = atoi(need(""));
+    else if (f == "--clean_names") A.clean_names = true;
+    else if (f == "--batch_pairs") A.o.batch_pairs = atoi(need(""));   // READ_BUFFER_SIZE of the run to reproduce (default 262144)
+    else if (f == "--device") A.device = atoi(need(""));
+    else if (f == "--devices") A.devices = need("");
+    else if (f == "--fq_list") A.fq_list = need("");
+    else if (f == "--RG") A.rg = need("");
+    else if (f == "--cal_dup") A.cal_dup = !A.cal_dup;        // (a bool flag on a default-1 field, like --is_sw)
+    else if (f == "--frac_samp") A.frac = atof(need(""));
+    else if (f == "--bam_in") die(f + " is not supported (the reference's BAM input is disabled, too)");
+    else die("unknown option " + f);
+  }
+  if (A.o.fnr >= 1.0) { A.o.max_diff = (int)A.o.fnr; A.o.fnr = -1.0; }                  // src/FASTQuick.cpp:312-315
+  if (A.opte > 0) { A.o.max_gape = A.opte; A.o.mode &= ~1; }                             // :316-319
+  if (A.out_prefix == "Empty") die("--out_prefix is required");
+  if (A.index_prefix == "Empty") die("--index_prefix is required");
+  // --fq_list: one FASTQ pair per line, '#' lines skipped (src/BwtMapper.cpp:232-262); every pair is an independent stream
+  // (its own srand48, last_ii, position cache and read slots: PairEndMapper sets them up per call), all into one output
+  std::vector<std::pair<std::string, std::string>> inputs;
+  if (!A.fq_list.empty()) {
+    FILE *fl = fopen(A.fq_list.c_str(), "r");
+    if (!fl) die("Open file " + A.fq_list + " failed");
+    char line[8192];
+    while (fgets(line, sizeof line, fl)) {
+      if (line[0] == '#') continue;
+      char a[4096] = "", b[4096] = "";
+      const int got = sscanf(line, "%4095s %4095s", a, b);
+      if (got < 1) continue;
+      inputs.emplace_back(a, got < 2 ? "" : b);      // one column: single-end (src/BwtMapper.cpp:255-262)
+    }
+    fclose(fl);
+  } else {
+    if (A.fq1.empty()) die("--fastq_1 (and --fastq_2 for paired-end reads), or --fq_list, is required");
+    inputs.emplace_back(A.fq1, A.fq2);
+  }
+  if (A.o.batch_pairs < 1) die("--batch_pairs must be positive");
+  A.chunk_pairs = std::max<long long>(A.o.batch_pairs, A.chunk_pairs / A.o.batch_pairs * A.o.batch_pairs);   // whole reference batches per chunk
+
+  fq_runtime_configure(20, 1);   // hardware queues for the contexts' streams, sleeping waits: before the first HIP call (fastquick_amd.h)
+  const std::string pre = A.index_prefix + ".FASTQuick.fa";
+  // <index>.param: REFERENCE_PATH, TARGET_REGION_PATH, DBSNP_VCF_PATH, NUM_VAR_LONG, NUM_VAR_SHORT, SHORT_FLANK_LENGTH, LONG_FLANK_LENGTH
+  fq_qc_opts_t qo;
+  fq_qc_default_opts(&qo);
+  qo.read_len = A.read_len; qo.cal_dup = A.cal_dup ? 1 : 0;
+  std::string ref_path;
+  {
+    FILE *fp = fopen((pre + ".param").c_str(), "r");
+    char key[256], val[4096];
+    while (fp && fscanf(fp, "%255s %4095s", key, val) == 2) {
+      if (!strcmp(key, "REFERENCE_PATH")) ref_path = val;
+      else if (!strcmp(key, "SHORT_FLANK_LENGTH")) qo.flank_len = atoi(val);
+      else if (!strcmp(key, "LONG_FLANK_LENGTH")) qo.flank_long_len = atoi(val);
+    }
+    if (fp) fclose(fp);
+    if (!ref_path.empty()) {   // BwtIndexer::LoadContigSize (src/BwtIndexer.cpp:764-802): sums of column 2 of the .fai and of EVERY line of the .amb
+      char line[8192], a[4096], b[4096];
+      if (FILE *ff = fopen((ref_path + ".fai").c_str(), "r")) { while (fgets(line, sizeof line, ff)) if (sscanf(line, "%4095s %4095s", a, b) == 2) qo.genome_size += atoi(b); fclose(ff); }
+      if (FILE *fa = fopen((ref_path + ".amb").c_str(), "r")) { while (fgets(line, sizeof line, fa)) if (sscanf(line, "%4095s %4095s", a, b) == 2) qo.genome_n_size += atoi(b); fclose(fa); }
+    }
+  }
+  struct stat sb;
+  const bool have_qc = stat((pre + ".SelectedSite.vcf").c_str(), &sb) == 0;
+  if (!have_qc) fprintf(stderr, "NOTICE - %s.SelectedSite.vcf not found: the QC files are not written\n", pre.c_str());
+  if (!A.sam_out && ref_path.empty()) die("BAM output needs the original reference's .fai: " + pre + ".param (REFERENCE_PATH) is missing; or pass --sam_out");
+  const std::string fai = ref_path + ".fai";
+  // one worker per entry of --devices: its own copy of the index on its device, its own consumers
+  struct Worker { int device = 0; fq_index_t *ix = nullptr; fq_qc_t *qc = nullptr; fq_bam_t *bam = nullptr; std::thread th; };
+  std::vector<int> devices = A.devices.empty() ? std::vector<int>{A.device} : parse_devices(A.devices);
+  if (devices.size() > inputs.size()) devices.resize(std::max<size_t>(1, inputs.size()));   // (a worker per FASTQ pair at most)
+  const size_t W = devices.size();
+  std::vector<Worker> wk(W);
+  auto open_worker = [&](size_t w, const std::string &qc_prefix, const char *bam_path) {
+    Worker &K = wk[w];
+    K.device = devices[w];
+    const auto t_ix0 = std::chrono::steady_clock::now();
+    int rc = fq_index_load(pre.c_str(), K.device, &K.ix);
+    fprintf(stderr, "NOTICE - index staged on device %d in %.1f ms\n", K.device, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ix0).count());
+    if (rc) die("cannot load index " + pre + " onto HIP device " + std::to_string(K.device) + " (" + std::to_string(rc) + "); there is no CPU fallback");
+    if (have_qc) {
+      rc = fq_qc_create(K.ix, pre.c_str(), qc_prefix.c_str(), &qo, &K.qc);
+      if (rc) die("cannot set up the QC consumer from " + pre + ".SelectedSite.vcf / .dbSNP.subset.vcf / .gc (" + std::to_string(rc) + ")");
+    }
+    if (!A.sam_out) {
+      rc = fq_bam_create(K.ix, fai.c_str(), bam_path, A.rg.c_str(), &qo, &K.bam);
+      if (rc) die("cannot open " + A.out_prefix + ".bam / " + fai + " (" + std::to_string(rc) + ")");
+    }
+  };
+  if (W == 1) {
+    // ---- one device: the records go out as they are produced ----
+    open_worker(0, A.out_prefix, A.sam_out ? nullptr : (A.out_prefix + ".bam").c_str());
+    Worker &K = wk[0];
+    if (A.sam_out) {
+      const int64_t n = fq_sam_header(K.ix, nullptr, 0);
+      std::vector<char> h((size_t)n + 1);
+      fq_sam_header(K.ix, h.data(), n + 1);
+      fwrite(h.data(), 1, (size_t)n, stdout);
+    }
+    Sink out;
+    out.sam_out = A.sam_out; out.sam_fp = A.sam_out ? stdout : nullptr; out.bam = K.bam; out.what = A.sam_out ? "the SAM text" : A.out_prefix + ".bam";
+    for (const auto &input : inputs) align_input(A, input, K.ix, K.qc, out);
+    if (K.bam && fq_bam_close(K.bam)) die("closing " + A.out_prefix + ".bam failed");
+    if (K.qc) {
+      if (fq_qc_write(K.qc)) die("writing the QC files failed");
+      fq_qc_destroy(K.qc);
+    }
+    fq_index_destroy(K.ix);
+    return 0;
+  }
+  // ---- several devices: the lines of --fq_list are dealt over them (the next free worker takes the next pair); every pair's records go
+  //      to part files of its own and its StatCollector state to a segment (fq_qc_state_export); the main thread puts the parts behind
+  //      each other and merges the segments (fq_qc_merge) in input order -- the files of the one-device run (src/BwtMapper.cpp:232-262,
+  //      src/StatCollector.h:46-62: one StatCollector over all pairs of the list)
+  {
+    const size_t n_in = inputs.size();
+    std::vector<std::vector<char>> segment(n_in);
+    std::atomic<size_t> next{0};
+    Args AW = A;
+    AW.pack_threads = std::max(1, A.pack_threads / (int)W);                 // the host's CPUs are shared by the workers
+    if (AW.o.host_threads <= 0) AW.o.host_threads = std::max(2, std::min(16, 2 * fq_host_cpus() / (int)W));
+    auto part = [&](size_t i, const char *ext) { return A.out_prefix + ".part" + std::to_string(i) + ext; };
+    auto work = [&](size_t w) {
+      open_worker(w, A.out_prefix + ".worker" + std::to_string(w), nullptr);
+      Worker &K = wk[w];
+      if (K.qc && fq_qc_state_reset(K.qc)) die("QC consumer: cannot start a segment");
+      for (size_t i; (i = next.fetch_add(1)) < n_in;) {
+        Sink out;
+        out.sam_out = A.sam_out; out.bam = K.bam;
+        out.what = part(i, A.sam_out ? ".sam" : ".bamrec");
+        FILE *f = fopen(out.what.c_str(), "wb");
+        if (!f) die("cannot create " + out.what);
+        if (A.sam_out) out.sam_fp = f; else out.bam_fp = f;
+        fprintf(stderr, "NOTICE - device %d takes line %zu of the list\n", K.device, i + 1);
+        align_input(AW, inputs[i], K.ix, K.qc, out);
+        if (fclose(f)) die("writing " + out.what + " failed");
+        if (K.qc) {
+          const int64_t need = fq_qc_state_export(K.qc, nullptr, 0);
+          if (need < 0) die(std::string("QC consumer: export failed: ") + fq_qc_last_error(K.qc));
+          segment[i].resize((size_t)need);
+          if (fq_qc_state_export(K.qc, segment[i].data(), need) != need || fq_qc_state_reset(K.qc)) die("QC consumer: export failed");
+        }
+      }
+    };
+    for (size_t w = 0; w < W; ++w) wk[w].th = std::thread(work, w);
+    for (auto &K : wk) K.th.join();
+    // the output, in input order
+    fq_bam_t *bam = nullptr;
+    fq_qc_t *qc = nullptr;
+    if (A.sam_out) {
+      const int64_t n = fq_sam_header(wk[0].ix, nullptr, 0);
+      std::vector<char> h((size_t)n + 1);
+      fq_sam_header(wk[0].ix, h.data(), n + 1);
+      fwrite(h.data(), 1, (size_t)n, stdout);
+    } else if (fq_bam_create(wk[0].ix, fai.c_str(), (A.out_prefix + ".bam").c_str(), A.rg.c_str(), &qo, &bam)) die("cannot open " + A.out_prefix + ".bam / " + fai);
+    if (have_qc && fq_qc_create(wk[0].ix, pre.c_str(), A.out_prefix.c_str(), &qo, &qc)) die("cannot set up the QC consumer");
+    for (size_t i = 0; i < n_in; ++i) {
+      append_file(part(i, A.sam_out ? ".sam" : ".bamrec"), A.sam_out ? stdout : nullptr, bam);
+      if (qc && fq_qc_merge(qc, segment[i].data(), (int64_t)segment[i].size())) die(std::string("QC consumer: merge failed: ") + fq_qc_last_error(qc));
+    }
+    fflush(stdout);
+    if (bam && fq_bam_close(bam)) die("closing " + A.out_prefix + ".bam failed");
+    if (qc) {
+      if (fq_qc_write(qc)) die("writing the QC files failed");
+      fq_qc_destroy(qc);
+    }
+    for (size_t w = 0; w < W; ++w) {
+      if (wk[w].bam) fq_bam_close(wk[w].bam);
+      if (wk[w].qc) { fq_qc_destroy(wk[w].qc); remove((A.out_prefix + ".worker" + std::to_string(w) + ".InsertSizeTable").c_str()); }
+      fq_index_destroy(wk[w].ix);
+    }
+  }
   return 0;
 }

@@ -78,11 +78,21 @@ static std::mutex g_turn_mu[64];   // device_turn_begin / device_turn_end
 // Hardware queues: every context drives a stream of its own, and the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware
 // queues (4 unless the variable says otherwise, read when the runtime initialises).  Contexts that share a queue wait for each
 // other's long kernels (16 streams on 16 queues: two share, and straggle by 25 %; 32 or more queues halve the throughput of 16
-// streams).  The library asks for 20 when it is loaded -- 16 contexts, two copy streams, two spare -- unless the caller has set a
-// value, and says so once when more contexts are created on a device than the queues in effect can keep apart.
+// streams).  The library changes nothing of the process on its own: a host program that wants more queues, or sleeping waits on
+// the devices the library opens, says so with fq_runtime_configure() before its first HIP call (the command line and bench.py do);
+// the library says once when more contexts are created on a device than the queues in effect can keep apart.
 static int g_ctx_count[64];
 static bool g_queue_warned = false;
-__attribute__((constructor)) static void fq_queue_policy() { setenv("GPU_MAX_HW_QUEUES", "20", 0); }
+static int g_rt_blocking_waits = 0;
+int runtime_configure(int hw_queues, int blocking_waits) {
+  if (hw_queues > 0) {
+    char b[16];
+    snprintf(b, sizeof b, "%d", hw_queues);
+    setenv("GPU_MAX_HW_QUEUES", b, 0);   // (a value the caller's environment already holds stands)
+  }
+  g_rt_blocking_waits = blocking_waits ? 1 : 0;
+  return 0;
+}
 
 void device_turn_begin() { g_turn_mu[g_cur->device].lock(); }
 void device_turn_end() { g_turn_mu[g_cur->device].unlock(); }
@@ -96,9 +106,9 @@ State *state_create(int dev) {
   {
     std::lock_guard<std::mutex> lk(g_dev_mu);
     if (!g_dev_ready[dev]) {
-      // waits on this device sleep instead of spinning (see sync()); a process that has already fixed the device's flags keeps its choice
-      if (!getenv("FASTQUICK_SPIN_WAIT")) (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync);
-      (void)hipGetLastError();
+      // fq_runtime_configure(.., blocking_waits = 1): every wait of the runtime on this device sleeps instead of spinning (the library's own
+      // waits sleep on blocking events whatever the flag: sync()); a process that has already fixed the device's flags keeps its choice
+      if (g_rt_blocking_waits) { (void)hipSetDeviceFlags(hipDeviceScheduleBlockingSync); (void)hipGetLastError(); }
       if (set_kernel_attributes()) return nullptr;
       g_dev_ready[dev] = true;
     }
@@ -107,7 +117,7 @@ State *state_create(int dev) {
     if (++g_ctx_count[dev] + 2 > queues && !g_queue_warned) {
       g_queue_warned = true;
       fprintf(stderr, "fastquick_amd: %d alignment contexts on device %d with GPU_MAX_HW_QUEUES=%d: contexts will share hardware queues and wait for each other's kernels "
-                      "(export GPU_MAX_HW_QUEUES = contexts + 4 before the process makes its first HIP call)\n", g_ctx_count[dev], dev, queues);
+                      "(fq_runtime_configure(contexts + 4, ..) or GPU_MAX_HW_QUEUES before the process makes its first HIP call)\n", g_ctx_count[dev], dev, queues);
     }
   }
   State *s = new State;
@@ -168,6 +178,7 @@ void *hmalloc(size_t bytes) {
 void hfree(void *p) { if (p) (void)hipHostFree(p); }
 int h2d(void *dst, const void *src, size_t bytes) { FQ_PRE(); if (bytes) FQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream)); return 0; }
 int d2h(void *dst, const void *src, size_t bytes) { FQ_PRE(); if (bytes) FQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream)); return 0; }
+int d2d(void *dst, const void *src, size_t bytes) { FQ_PRE(); if (bytes) FQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream)); return 0; }
 int dzero(void *dst, size_t bytes) { FQ_PRE(); if (bytes) FQ_HIP(hipMemsetAsync(dst, 0, bytes, g_stream)); return 0; }
 int dfill(void *dst, int byte, size_t bytes) { FQ_PRE(); if (bytes) FQ_HIP(hipMemsetAsync(dst, byte, bytes, g_stream)); return 0; }
 // The calling thread SLEEPS until the stream has drained (an event with hipEventBlockingSync): hipStreamSynchronize spins, one core per
@@ -1156,6 +1167,58 @@ int launch_pack_md(const char *src, const int32_t *len, const uint64_t *off, int
   FQ_PRE();
   if (n <= 0) return 0;
   hipLaunchKernelGGL(k_pack_md, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, src, len, off, cap, n, dst);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+
+// ---- the record stages (fq_records.h): one thread per read, pair or task ------------------------------------------------------
+#define FQ_REC_KERNEL(name, body)                                                    \
+  __global__ void __launch_bounds__(256) name(FqRecArgs a, int n) {                  \
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;                             \
+    if (i < n) body(a, i);                                                           \
+  }
+FQ_REC_KERNEL(k_rec_init, fq_rec_init_thread)
+FQ_REC_KERNEL(k_rec_nocc, fq_rec_nocc_thread)
+FQ_REC_KERNEL(k_enum_plan, fq_enum_plan_thread)
+FQ_REC_KERNEL(k_enum_fill, fq_enum_fill_thread)
+FQ_REC_KERNEL(k_main_hit, fq_main_hit_thread)
+FQ_REC_KERNEL(k_compact_idx, fq_compact_thread)
+FQ_REC_KERNEL(k_pair_rec, fq_pair_rec_thread)
+FQ_REC_KERNEL(k_pair_gather, fq_pair_gather_thread)
+FQ_REC_KERNEL(k_pair_scatter, fq_pair_scatter_thread)
+FQ_REC_KERNEL(k_xa_count, fq_xa_count_thread)
+FQ_REC_KERNEL(k_xa_fill, fq_xa_fill_thread)
+FQ_REC_KERNEL(k_sw_plan, fq_sw_plan_thread)
+FQ_REC_KERNEL(k_sw_fill, fq_sw_fill_thread)
+FQ_REC_KERNEL(k_rec_gather, fq_rec_gather_thread)
+FQ_REC_KERNEL(k_rec_scatter, fq_rec_scatter_thread)
+FQ_REC_KERNEL(k_ref_count, fq_ref_count_thread)
+FQ_REC_KERNEL(k_ref_fill, fq_ref_fill_thread)
+FQ_REC_KERNEL(k_ref_apply, fq_ref_apply_thread)
+FQ_REC_KERNEL(k_md_rec, fq_md_rec_thread)
+FQ_REC_KERNEL(k_flat_count, fq_flat_count_thread)
+FQ_REC_KERNEL(k_flat_fill, fq_flat_fill_thread)
+int launch_rec(int op, const FqRecArgs &a, int64_t n) {
+  FQ_PRE();
+  if (n <= 0) return 0;
+  if (n > 0x7fffffff) { g_err = "record stage: more than 2^31 items"; return -5; }
+  typedef void (*Kern)(FqRecArgs, int);
+  static const Kern kerns[FQ_ROP_COUNT] = {k_rec_init, k_rec_nocc, k_enum_plan, k_enum_fill, k_main_hit, k_compact_idx, k_pair_rec, k_pair_gather, k_pair_scatter,
+                                           k_xa_count, k_xa_fill, k_sw_plan, k_sw_fill, k_rec_gather, k_rec_scatter, k_ref_count, k_ref_fill, k_ref_apply,
+                                           k_md_rec, k_flat_count, k_flat_fill};
+  if (op < 0 || op >= FQ_ROP_COUNT) { g_err = "record stage: unknown operation"; return -1; }
+  hipLaunchKernelGGL(kerns[op], dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, a, (int)n);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+__global__ void __launch_bounds__(256) k_aln_index(const int32_t *work, const uint32_t *status, const uint64_t *off, const uint32_t *naln, uint64_t base, uint64_t *aoff, uint32_t *an, int n) {
+  const int w = blockIdx.x * blockDim.x + threadIdx.x;
+  if (w < n) fq_aln_index_thread(work, status, off, naln, base, aoff, an, w);
+}
+int launch_aln_index(const int32_t *work, const uint32_t *status, const uint64_t *off, const uint32_t *naln, uint64_t base, uint64_t *aoff, uint32_t *an, int n) {
+  FQ_PRE();
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_aln_index, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, work, status, off, naln, base, aoff, an, n);
   FQ_HIP(hipGetLastError());
   return 0;
 }

@@ -487,6 +487,9 @@ struct FqTrimArgs {
   const int32_t *len;       // [n_rows] compact
   int32_t n_rows;
   int32_t *len_trim;        // out [n_rows]
+  const int32_t *pair_list; // compact row t belongs to survivor pair t >> 1, pair pair_list[t >> 1] of the batch
+  int32_t batch_pairs;
+  int32_t *sub_max;         // out (zeroed by the caller): longest trimmed survivor per reference batch
 };
 FQ_HD int fq_trim_len(const FqKOpts &o, const uint8_t *q, int full) {
   int s = 0, mx = 0, max_l = full - 1;
@@ -500,7 +503,9 @@ FQ_HD int fq_trim_len(const FqKOpts &o, const uint8_t *q, int full) {
 }
 FQ_HD void fq_trim_thread(const FqTrimArgs &A, int t) {
   const size_t src = A.row_map ? (size_t)A.row_map[t] : (size_t)t;
-  A.len_trim[t] = fq_trim_len(A.o, A.qual + src * (size_t)A.qual_stride, A.len[t]);
+  const int lt = fq_trim_len(A.o, A.qual + src * (size_t)A.qual_stride, A.len[t]);
+  A.len_trim[t] = lt;
+  if (A.sub_max) FQ_ATOMIC_MAX32(&A.sub_max[A.pair_list[t >> 1] / A.batch_pairs], lt);
 }
 // the same over every read of a batch (debug dumps, and the rare call in which no surviving read of some reference batch kept its
 // full length, so that the batch's longest trimmed read may be a filtered one): len_trim[r] for all rows, sub_max per reference batch
@@ -2322,23 +2327,20 @@ FQ_HD int fq_put_int(char *dst, int at, int cap, int v) {
   while (n > 0) { if (at < cap) dst[at] = tmp[n - 1]; ++at; --n; }
   return at;
 }
-FQ_HD void fq_md_thread(const FqMdArgs &A, int t) {
-  const FqMdTask T = A.task[t];
-  const uint8_t *row = A.seq + (size_t)T.read * (size_t)A.stride;
-  char *dst = A.md + (size_t)t * (size_t)A.md_cap;
-  const int cap = A.md_cap - 1;
-  const int64_t l_pac = A.ix.l_pac;
+// the MD string of one read into dst (at most cap characters are written; *at_out is the length it has, which may exceed cap) and its NM
+FQ_HD void fq_md_core(const FqDevIndex &ix, const uint8_t *row, const FqMdTask &T, const uint16_t *cigar_arena, char *dst, int cap, int *at_out, int *nm_out) {
+  const int64_t l_pac = ix.l_pac;
   // the sequence MD is computed against: s->strand ? s->rseq : s->seq, over the (trimmed) length at that time
   const int slen = T.len;
   uint32_t x = T.pos, y = 0;
   int u = 0, nm = 0, at = 0;
   if (T.n_cigar) {
-    const uint16_t *cg = A.cigar + T.cigar_off;
+    const uint16_t *cg = cigar_arena + T.cigar_off;
     for (int k = 0; k < T.n_cigar; ++k) {
       const int op = cg[k] >> 14, l = cg[k] & 0x3fff;
       if (op == FQ_OP_M) {
         for (int z = 0; z < l && (int64_t)(uint32_t)(x + z) < l_pac; ++z) {
-          const int c = fq_pac_base(A.ix.pac, (int64_t)(uint32_t)(x + z));
+          const int c = fq_pac_base(ix.pac, (int64_t)(uint32_t)(x + z));
           const int yy = (int)y + z;
           const int sc = T.strand ? fq_comp(fq_nt4(row[slen - 1 - yy])) : fq_nt4(row[yy]);
           if (sc > 3 || c != sc) { at = fq_put_int(dst, at, cap, u); if (at < cap) dst[at] = "ACGTN"[c]; ++at; ++nm; u = 0; }
@@ -2350,7 +2352,7 @@ FQ_HD void fq_md_thread(const FqMdArgs &A, int t) {
         at = fq_put_int(dst, at, cap, u);
         if (at < cap) dst[at] = '^';
         ++at;
-        for (int z = 0; z < l && (int64_t)(uint32_t)(x + z) < l_pac; ++z) { if (at < cap) dst[at] = "ACGT"[fq_pac_base(A.ix.pac, (int64_t)(uint32_t)(x + z))]; ++at; }
+        for (int z = 0; z < l && (int64_t)(uint32_t)(x + z) < l_pac; ++z) { if (at < cap) dst[at] = "ACGT"[fq_pac_base(ix.pac, (int64_t)(uint32_t)(x + z))]; ++at; }
         u = 0; x += l; nm += l;
       }
     }
@@ -2362,7 +2364,7 @@ FQ_HD void fq_md_thread(const FqMdArgs &A, int t) {
       uint32_t pb;
       memcpy(&rb, T.strand ? row + (slen - 8 - z) : row + z, 8);
       const uint32_t k0 = x + (uint32_t)z;
-      memcpy(&pb, A.ix.pac + (k0 >> 2), 4);
+      memcpy(&pb, ix.pac + (k0 >> 2), 4);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const uint32_t kk = k0 + (uint32_t)j;
@@ -2374,13 +2376,21 @@ FQ_HD void fq_md_thread(const FqMdArgs &A, int t) {
       }
     }
     for (; z < slen; ++z) {
-      const int c = fq_pac_base(A.ix.pac, (int64_t)(uint32_t)(x + z));
+      const int c = fq_pac_base(ix.pac, (int64_t)(uint32_t)(x + z));
       const int sc = T.strand ? fq_comp(fq_nt4(row[slen - 1 - z])) : fq_nt4(row[z]);
       if (sc > 3 || c != sc) { at = fq_put_int(dst, at, cap, u); if (at < cap) dst[at] = "ACGTN"[c]; ++at; ++nm; u = 0; }
       else ++u;
     }
   }
   at = fq_put_int(dst, at, cap, u);
+  *at_out = at; *nm_out = nm;
+}
+FQ_HD void fq_md_thread(const FqMdArgs &A, int t) {
+  const FqMdTask T = A.task[t];
+  char *dst = A.md + (size_t)t * (size_t)A.md_cap;
+  const int cap = A.md_cap - 1;
+  int at = 0, nm = 0;
+  fq_md_core(A.ix, A.seq + (size_t)T.read * (size_t)A.stride, T, A.cigar, dst, cap, &at, &nm);
   if (at > cap) { A.md_len[t] = -1; A.md_sz[t] = 0; dst[0] = 0; }
   else { dst[at] = 0; A.md_len[t] = at; A.md_sz[t] = (uint32_t)at + 1; }
   A.nm[t] = nm;

@@ -7,6 +7,7 @@
 #include <condition_variable>
 #include <mutex>
 #include <thread>
+#include <type_traits>
 #include <vector>
 
 class FqWorkPool {
@@ -26,7 +27,11 @@ class FqWorkPool {
   template <class F>
   void run(int T, F &&f) {
     if (T <= 1) { f(0); return; }
+    // a pass started from inside a pass of the same pool (by the calling thread's chunk or by a worker) runs on its own thread, in
+    // order: the pool's workers are all part of the outer pass, and waiting for them here would never end
+    if (in_pass() == this) { for (int t = 0; t < T; ++t) f(t); return; }
     std::lock_guard<std::mutex> one(run_mu_);
+    struct Mark { FqWorkPool *&slot, *prev; Mark(FqWorkPool *&s, FqWorkPool *p) : slot(s), prev(s) { slot = p; } ~Mark() { slot = prev; } } mark(in_pass(), this);
     {
       std::unique_lock<std::mutex> lk(mu_);
       while ((int)th_.size() < T - 1) { const int idx = (int)th_.size(); th_.emplace_back([this, idx] { worker(idx); }); }
@@ -42,6 +47,7 @@ class FqWorkPool {
   }
 
  private:
+  static FqWorkPool *&in_pass() { static thread_local FqWorkPool *p = nullptr; return p; }   // the pool whose pass this thread is running a chunk of
   void worker(int idx) {
     unsigned long seen = 0;
     for (;;) {
@@ -53,7 +59,9 @@ class FqWorkPool {
       void *ctx = ctx_;
       const int T = T_;
       lk.unlock();
+      in_pass() = this;
       if (idx + 1 < T) call(ctx, idx + 1);
+      in_pass() = nullptr;
       lk.lock();
       if (--remaining_ == 0) cv_done_.notify_one();
     }

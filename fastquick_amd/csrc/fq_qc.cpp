@@ -610,8 +610,17 @@ extern "C" int fq_qc_add_last(fq_qc_t *q, fq_ctx_t *c) {
   F.NumBase += fq_ctx_last_bases(c);
   F.NumRead += (ao->single_end ? 1LL : 2LL) * S->n_pairs;
   F.TotalFiltered += S->n_pairs - S->n_surv;
+  // the batch's records in the host's vocabulary, from the C-ABI arrays (all threads); they live until the per-base statistics have run
+  std::vector<FqRead> recs((size_t)S->n_surv * 2);
+  {
+    const size_t n = recs.size();
+    const int T = n >= 4096 ? 8 : 1;
+    const size_t per = (n + (size_t)T - 1) / (size_t)T;
+    auto fill = [&](int t) { const size_t lo = (size_t)t * per, hi = std::min(n, lo + per); for (size_t i = lo; i < hi; ++i) recs[i] = S->read(i); };
+    if (T == 1) fill(0); else q->pool.run(T, fill);
+  }
   for (int sp = 0; sp < S->n_surv; ++sp) {
-    const FqRead &a = S->reads[2 * sp], &b = S->reads[2 * sp + 1];
+    const FqRead &a = recs[2 * (size_t)sp], &b = recs[2 * (size_t)sp + 1];
     if (a.type == FQ_TYPE_NO_MATCH && b.type == FQ_TYPE_NO_MATCH) { ++F.BwaUnmapped; continue; }
     if (ao->single_end) {   // SingleEndMapper's consumer loop, src/BwtMapper.cpp:1355-1370
       Rec P;

@@ -197,14 +197,14 @@ extern "C" int64_t fq_sam_format_last(fq_ctx_t *c, char *buf, int64_t cap) {
   auto format_range = [&](int lo, int hi, Out &out) {
   out.s.reserve((size_t)(hi - lo) * 900);
   for (int sp = lo; sp < hi; ++sp) {
-    if (S->reads[2 * sp].type == FQ_TYPE_NO_MATCH && S->reads[2 * sp + 1].type == FQ_TYPE_NO_MATCH) continue;   // src/BwtMapper.cpp:2038-2042
+    if (S->rec[2 * (size_t)sp].type == FQ_TYPE_NO_MATCH && S->rec[2 * (size_t)sp + 1].type == FQ_TYPE_NO_MATCH) continue;   // src/BwtMapper.cpp:2038-2042
     if (o->single_end) {   // src/BwtMapper.cpp:1355-1370: AddAlignment(p, 0), then bwa_print_sam1(p, 0)
-      FqRead a = S->reads[2 * sp];
+      FqRead a = S->read(2 * (size_t)sp);
       bridge_mutation(ix, a);
       print_sam(ix, o, hb, S->n_pairs, out, a, a, true);
       continue;
     }
-    FqRead a = S->reads[2 * sp], b = S->reads[2 * sp + 1];
+    FqRead a = S->read(2 * (size_t)sp), b = S->read(2 * (size_t)sp + 1);
     bridge_mutation(ix, a);
     bridge_mutation(ix, b);
     print_sam(ix, o, hb, S->n_pairs, out, a, b);
@@ -252,7 +252,7 @@ extern "C" int64_t fq_stage_dump_last(fq_ctx_t *c, char *buf, int64_t cap) {
     for (int e = 0; e < n_ends; ++e)
       for (int i = i0; i < i1; ++i) {
         const int sp = surv_of[i];
-        const int s = sp < 0 ? -1 : S->s_of[2 * sp + e];
+        const int s = sp < 0 ? -1 : S->s_of(2 * (size_t)sp + e);
         const int na = s < 0 ? 0 : (int)S->aln_n[s];
         o.printf("A %d %d n=%d", e, i - i0, na);
         for (int k = 0; k < na; ++k) {
@@ -267,15 +267,15 @@ extern "C" int64_t fq_stage_dump_last(fq_ctx_t *c, char *buf, int64_t cap) {
     if (n_ends == 2)
       o.printf("I avg=%016llx std=%016llx ap=%016llx low=%u high=%u hb=%u\n", (unsigned long long)a, (unsigned long long)s, (unsigned long long)p,
                ii.low, ii.high, ii.high_bayesian);
-    const std::vector<FqRead> *stages[3] = {&S->stage_P, &S->stage_S, &S->reads};
+    const std::vector<FqRead> *stages[3] = {&S->stage_P, &S->stage_S, nullptr};   // (the final records: from the C-ABI arrays)
     const char tags[3] = {'P', 'S', 'R'};
     for (int st = 0; st < 3; ++st) {
-      if (stages[st]->size() != S->reads.size()) continue;   // snapshots are only kept in debug mode
+      if (stages[st] && stages[st]->size() != (size_t)S->n_surv * 2) continue;   // snapshots are only kept in debug mode
       if (n_ends == 1 && st == 1) continue;
       for (int e = 0; e < n_ends; ++e)
         for (int i = i0; i < i1; ++i) {
           const int sp = surv_of[i];
-          if (sp >= 0) { dump_rec(o, tags[st], e, i - i0, (*stages[st])[2 * sp + e], st == 2); continue; }
+          if (sp >= 0) { dump_rec(o, tags[st], e, i - i0, stages[st] ? (*stages[st])[2 * (size_t)sp + e] : S->read(2 * (size_t)sp + e), st == 2); continue; }
           FqRead d;   // both mates filtered: untouched record (bwa_clean_read_seq state + flags of BwtMapper.cpp:749)
           d.filtered = 1; d.extra_flag = n_ends == 1 ? 0 : (1 | (e == 0 ? 64 : 128)); d.len = ltrim[e * n + i]; d.full_len = hb->len((size_t)e * n + i);
           if (st == 2 && d.len != d.full_len) {   // bwa_correct_trimmed touches every record

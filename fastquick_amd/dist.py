@@ -56,7 +56,10 @@ def token_group():
     global _token_group
     if dist.is_initialized() and dist.get_backend() == "nccl" and _token_group is None:
         import datetime
-        _token_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=120))     # (a lost token raises instead of waiting for ever)
+        # a lost token raises instead of waiting for ever (and the stream is then marked broken: api.Aligner.set_serial_hooks); the wait
+        # must outlast a predecessor that is legitimately slow -- its first call stages the index -- so it is generous and configurable
+        secs = float(os.environ.get("FASTQUICK_TOKEN_TIMEOUT_S", "1800"))
+        _token_group = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=secs))
     return _token_group
 
 

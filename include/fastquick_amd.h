@@ -102,7 +102,9 @@ typedef struct {
   int32_t len, full_len, clip_len;
   uint8_t type, strand, filtered, extra_flag;
   uint8_t n_mm, n_gapo, n_gape, mapQ;
-  uint8_t seQ, pad0;
+  uint8_t seQ;
+  uint8_t revived;            /* 1: filtered on input, brought back for the mate rescue because its mate passed (expand_seq, libbwa/bwape.c:447-462):
+                                 the record prints under its mate's name */
   uint16_t nm;
   uint16_t n_cigar, n_multi;
   uint32_t cigar_off;         /* bwa_cigar_t (op<<14|len) entries in .cigar */
@@ -280,6 +282,10 @@ void fq_fastq_close(fq_fastq_t *r);
  * overlap everywhere else.  (fastquick_amd/dist.py StreamShard does this over torch.distributed: RCCL or gloo.) */
 typedef void (*fq_serial_hook)(void *user);
 int fq_ctx_set_serial_hooks(fq_ctx_t *c, fq_serial_hook before, fq_serial_hook after, void *user);
+/* Called from inside a hook that failed (a receive timed out, the host language raised): the call returns FQ_EIO right after the
+ * hook instead of computing from a stale state, and every state exported from now on carries the broken mark, so the ranks behind
+ * fail too. */
+int fq_ctx_mark_stream_broken(fq_ctx_t *c);
 int64_t fq_ctx_state_export(const fq_ctx_t *c, void *buf, int64_t cap);   /* bytes written, or needed when buf is NULL / too small */
 int fq_ctx_state_import(fq_ctx_t *c, const void *buf, int64_t len);
 
@@ -342,6 +348,11 @@ int fq_qc_merge(fq_qc_t *q, const void *buf, int64_t len);
 typedef struct fq_bam fq_bam_t;
 int fq_bam_create(const fq_index_t *ix, const char *fai_path, const char *bam_path, const char *rg_line, const fq_qc_opts_t *o, fq_bam_t **out);
 int fq_bam_add_last(fq_bam_t *b, fq_ctx_t *c);   /* the records of the context's last batch, in input order */
+/* For several producers and one file: a writer created with bam_path = NULL has no file and only formats -- fq_bam_format_last hands
+ * out the last batch's records as bytes (owned by the writer, valid until its next call); fq_bam_write_records appends such bytes to
+ * a writer that has a file.  The BGZF stream does not depend on how the bytes were cut: the file is the one fq_bam_add_last writes. */
+int fq_bam_format_last(fq_bam_t *b, fq_ctx_t *c, const void **data, int64_t *len);
+int fq_bam_write_records(fq_bam_t *b, const void *data, int64_t len);
 int fq_bam_close(fq_bam_t *b);                   /* writes the BGZF end-of-file block, closes and frees */
 
 /* ---- measurement -------------------------------------------------------------------------
@@ -385,6 +396,14 @@ const char *fq_version(void);
  * library sizes a call's host threads by (opts.host_threads = 0) and what a caller should size its packer / reader threads by.
  * (No reference counterpart: bwa's --t is the caller's number.) */
 int fq_host_cpus(void);
+/* Process-level settings, made only when the host program asks -- before its first HIP call (loading the library changes nothing):
+ *   hw_queues > 0       GPU_MAX_HW_QUEUES = hw_queues for the HIP runtime, unless the environment already holds a value.  Every
+ *                       alignment context drives a stream of its own; contexts that share a hardware queue (the runtime's default
+ *                       is 4) wait for each other's long kernels.  contexts + 4 is the measured optimum (16 streams: 20).
+ *   blocking_waits != 0 devices the library opens get hipDeviceScheduleBlockingSync: every wait of the runtime on them sleeps instead
+ *                       of spinning (the library's own waits sleep on blocking events either way).
+ * The library warns once on stderr when more contexts are created on a device than the queues in effect keep apart. */
+int fq_runtime_configure(int hw_queues, int blocking_waits);
 
 #ifdef __cplusplus
 }

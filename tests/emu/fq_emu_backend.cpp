@@ -16,6 +16,7 @@ namespace fqdev {
 static std::string g_err;
 struct State { Tune tune; };
 static thread_local State *g_bound = nullptr;   // (for the launcher's choice of search kernel: the tuning of the bound context)
+int runtime_configure(int, int) { return 0; }
 State *state_create(int) { return new State; }
 void state_destroy(State *s) { if (g_bound == s) g_bound = nullptr; delete s; }
 int bind(State *s) { g_bound = s; return 0; }
@@ -36,6 +37,7 @@ void hfree(void *p) { free(p); }
 int h2d(void *d, const void *s, size_t n) { if (n) memcpy(d, s, n); return 0; }
 int d2h(void *d, const void *s, size_t n) { if (n) memcpy(d, s, n); return 0; }
 int copy_pinned(void *d, const void *s, size_t n, int) { if (n) memcpy(d, s, n); return 0; }
+int d2d(void *d, const void *s, size_t n) { if (n) memmove(d, s, n); return 0; }
 int dzero(void *d, size_t n) { if (n) memset(d, 0, n); return 0; }
 int dfill(void *d, int b, size_t n) { if (n) memset(d, b, n); return 0; }
 int sync() { return 0; }
@@ -134,6 +136,19 @@ int launch_collect(const int32_t *order, const uint32_t *, int n_work, int seg, 
   return 0;
 }
 int launch_pair(const FqPairArgs &a) { for (int t = 0; t < a.n_jobs; ++t) fq_pair_thread(a, t); return 0; }
+int launch_rec(int op, const FqRecArgs &a, int64_t n) {
+  typedef void (*Body)(const FqRecArgs &, int);
+  static const Body bodies[FQ_ROP_COUNT] = {fq_rec_init_thread, fq_rec_nocc_thread, fq_enum_plan_thread, fq_enum_fill_thread, fq_main_hit_thread, fq_compact_thread, fq_pair_rec_thread,
+                                            fq_pair_gather_thread, fq_pair_scatter_thread, fq_xa_count_thread, fq_xa_fill_thread, fq_sw_plan_thread, fq_sw_fill_thread, fq_rec_gather_thread,
+                                            fq_rec_scatter_thread, fq_ref_count_thread, fq_ref_fill_thread, fq_ref_apply_thread, fq_md_rec_thread, fq_flat_count_thread, fq_flat_fill_thread};
+  if (op < 0 || op >= FQ_ROP_COUNT) return -1;
+  for (int64_t i = 0; i < n; ++i) bodies[op](a, (int)i);
+  return 0;
+}
+int launch_aln_index(const int32_t *work, const uint32_t *status, const uint64_t *off, const uint32_t *naln, uint64_t base, uint64_t *aoff, uint32_t *an, int n) {
+  for (int w = 0; w < n; ++w) fq_aln_index_thread(work, status, off, naln, base, aoff, an, w);
+  return 0;
+}
 int launch_sw(const FqSwArgs &a) { for (int t = 0; t < a.n_task; ++t) fq_sw_thread(a, t); return 0; }
 int launch_sw_serial(const FqSwArgs &a) { return launch_sw(a); }
 int launch_refine(const FqRefineArgs &a) { for (int t = 0; t < a.n_task; ++t) fq_refine_thread(a, t); return 0; }

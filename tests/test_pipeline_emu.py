@@ -274,3 +274,32 @@ def test_single_end_edge_batches(golden_cases, emu_lib):
             hp.free()
     al.close()
     ix.close()
+
+
+def test_a_hook_that_raises_stops_the_call_and_marks_the_stream_broken(golden_cases, emu_lib):
+    """an exception in the `before` hook (a receive that timed out) used to be swallowed until the C call returned -- which
+    had meanwhile computed from the stale state and exported it as good.  The guard now tells the library (fq_ctx_mark_stream_broken):
+    the call stops after the hook, and the state handed on carries the broken mark."""
+    g = golden_cases["basic"]
+    names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
+    ix = api.Index(g["prefix"], lib=emu_lib)
+    al = api.Aligner(ix, api.default_opts(emu_lib), max_pairs=max(16, g["batch"]))
+    exported = []
+
+    def before():
+        raise TimeoutError("recv timed out")
+
+    def after():
+        exported.append(al.export_state())
+
+    al.set_serial_hooks(before, after)
+    n = min(seq.shape[1], g["batch"])
+    with pytest.raises(api.FastquickError, match="serial hook raised"):
+        al.align(seq[:, :n], qual[:, :n], lens[:, :n], names[:n])
+    assert len(exported) == 1 and exported[0][:6] == b"_FQSTX", "the state handed on must carry the broken mark"
+    other = api.Aligner(ix, api.default_opts(emu_lib), max_pairs=max(16, g["batch"]))
+    with pytest.raises(api.FastquickError):
+        other.import_state(exported[0])
+    other.close()
+    al.close()
+    ix.close()
