@@ -500,10 +500,12 @@ struct NodePin {
 // in flight in this process share the cores: sixteen streams of 1 M-pair calls run 16.3 / 12.7 / 8.8 M pairs/s with 4 / 8 / 16
 // threads each, two streams of 4.2 M-pair calls 15.2 / 16.6 / 13.3 M pairs/s with 8 / 16 / 24 -- so twice the cores (a call waits for the device about half
 // of its time) are divided by the number of calls in flight (on the contexts of the same index) when the call starts.  (Results do not depend on the number of threads.)
-struct CallInFlight {      // counted on the index the contexts share: no process-wide state
-  const fq_index *ix;
-  explicit CallInFlight(const fq_index *i) : ix(i) { ix->calls_in_flight.fetch_add(1, std::memory_order_relaxed); }
-  ~CallInFlight() { ix->calls_in_flight.fetch_sub(1, std::memory_order_relaxed); }
+// (counted per process: the calls of all contexts, whatever index and device they belong to, share the host's cores -- the command
+// line's --devices drives one index per device from one process)
+static std::atomic<int> g_calls_in_flight{0};
+struct CallInFlight {
+  explicit CallInFlight(const fq_index *) { g_calls_in_flight.fetch_add(1, std::memory_order_relaxed); }
+  ~CallInFlight() { g_calls_in_flight.fetch_sub(1, std::memory_order_relaxed); }
 };
 // CPUs this process may actually use: the hardware threads it sees, cut to the cgroup's CPU quota when there is one (a container
 // that shows 256 hardware threads and is throttled to 16 CPUs runs 32 threads per call SLOWER than 16 and burns half as much again:
@@ -524,6 +526,10 @@ inline unsigned effective_cpus() {
       if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lld", &period) != 1) period = 0; fclose(g); }
       if (quota > 0 && period > 0) hw = std::min<unsigned>(hw, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
     }
+    // The ranks of one node share the host (one process per GPU: torchrun exports LOCAL_WORLD_SIZE): each sizes its threads by its share,
+    // not by the whole allowance.  FASTQUICK_HOST_CPUS states the share outright.
+    if (const char *e = getenv("FASTQUICK_HOST_CPUS")) { const int v = atoi(e); if (v > 0) return std::min(hw, (unsigned)v); }
+    if (const char *e = getenv("LOCAL_WORLD_SIZE")) { const int v = atoi(e); if (v > 1) hw = std::max(1u, hw / (unsigned)v); }
     return hw;
   }();
   return n;
@@ -531,7 +537,8 @@ inline unsigned effective_cpus() {
 inline int default_host_threads(const fq_index *ix) {
   const unsigned hw = effective_cpus();
   const unsigned cap = hw >= 128 ? 32u : hw >= 16 ? 16u : std::min(8u, hw);   // (one 4.2 M-pair call on a 2 x 64-core host under a quota of 16 CPUs: 430 / 331 / 339 / 614 ms with 24 / 32 / 48 / 64 threads, 301-354 with 16)
-  const unsigned share = 2 * hw / (unsigned)std::max(1, ix->calls_in_flight.load(std::memory_order_relaxed));   // (a call waits for the device about half of its time)
+  (void)ix;
+  const unsigned share = 2 * hw / (unsigned)std::max(1, g_calls_in_flight.load(std::memory_order_relaxed));   // (a call waits for the device about half of its time)
   return (int)std::max(std::min(2u, cap), std::min(cap, share));
 }
 // The calling thread of a call hands its passes to the context's worker pool (run_call sets tl_pool); the side threads a call

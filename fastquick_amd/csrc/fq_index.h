@@ -33,8 +33,6 @@ struct fq_index {
   void *d_pac = nullptr;
   void *d_bitmap = nullptr;   // 6 x 2^29 bytes, contiguous
   int device = 0;
-  // calls in flight on the contexts of this index (they share the host's cores: fq_align.cpp, default_host_threads)
-  mutable std::atomic<int> calls_in_flight{0};
 };
 
 // bns_coor_pac2real (libbwa/bntseq.c:268-302)

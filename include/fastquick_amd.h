@@ -392,7 +392,8 @@ void fq_stats_get(const fq_ctx_t *c, fq_stats_t *out);
 void fq_stats_reset(fq_ctx_t *c);
 
 const char *fq_version(void);
-/* CPUs this process may use: the hardware threads it sees, cut to its cgroup's CPU quota (cpu.max) when there is one -- what the
+/* CPUs this process may use: the hardware threads it sees, cut to its cgroup's CPU quota (cpu.max) when there is one, and divided by
+ * LOCAL_WORLD_SIZE when the process is one of several ranks of a node (FASTQUICK_HOST_CPUS states the share outright) -- what the
  * library sizes a call's host threads by (opts.host_threads = 0) and what a caller should size its packer / reader threads by.
  * (No reference counterpart: bwa's --t is the caller's number.) */
 int fq_host_cpus(void);

@@ -1,0 +1,77 @@
+"""`FASTQuick_amd align --devices LIST`: the lines of a --fq_list dealt over several devices from ONE process (no Python, no torch) --
+one copy of the index, one alignment context chain and one shard consumer per device; SAM text / BAM records appended and the
+StatCollector segments merged (fq_qc_merge) in input order.  The output must be the one-device run's, byte for byte, and that is the
+REAL reference's two-pair run (tests/golden/qc/ref_fqlist.*; src/BwtMapper.cpp:232-262, src/StatCollector.h:46-62).
+CPU tier: the front end over the host-loop library, whose "devices" are virtual; GPU tier: two workers on one device, and -- where the
+box has them -- two devices."""
+import os
+import subprocess
+
+import pytest
+
+import golden_util
+from test_qc_consumer import QC_FILES, qc_bytes
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+
+
+def run_list(exe, g, tmp, tag, devices=None, sam=True):
+    halves = golden_util.split_halves(g, str(tmp))
+    lst = os.path.join(str(tmp), "two_pairs.list")
+    with open(lst, "w") as fh:
+        fh.write("# the two halves of the case's FASTQ pair\n" + "".join("%s\t%s\n" % h for h in halves))
+    prefix = g["prefix"][:-len(".FASTQuick.fa")]
+    with open(g["prefix"] + ".param", "w") as fh:
+        fh.write("REFERENCE_PATH\t%s\nTARGET_REGION_PATH\tEmpty\nDBSNP_VCF_PATH\tEmpty\nNUM_VAR_LONG\t4\nNUM_VAR_SHORT\t36\n"
+                 "SHORT_FLANK_LENGTH\t250\nLONG_FLANK_LENGTH\t1000\n" % os.path.join(g["dir"], "genome"))
+    out = os.path.join(str(tmp), tag)
+    cmd = [exe, "align", "--index_prefix", prefix, "--fq_list", lst, "--out_prefix", out, "--batch_pairs", str(g["batch"]),
+           "--chunk_pairs", str(2 * g["batch"]), "--q", str(g["trim_qual"]), "--read_len", str(g["qc_read_len"])]
+    if sam:
+        cmd.append("--sam_out")
+    if devices:
+        cmd += ["--devices", devices]
+    run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert run.returncode == 0, run.stderr.decode(errors="replace")[-3000:]
+    return run, out
+
+
+def check_against_one_device(exe, g, tmp, devices):
+    one, out1 = run_list(exe, g, tmp, "one")
+    many, outn = run_list(exe, g, tmp, "many", devices=devices)
+    assert many.stderr.count(b"takes line") == 2, "both lines of the list must have been dealt to a worker"
+    assert many.stdout == one.stdout
+    assert many.stdout == open(os.path.join(g["dir"], "ref_fqlist.sam"), "rb").read(), "SAM text of the reference's two-pair run"
+    for f in QC_FILES:
+        assert qc_bytes(outn + "." + f).replace(outn.encode(), b"OUT") == qc_bytes(out1 + "." + f).replace(out1.encode(), b"OUT"), f
+        if f not in ("Summary", "FASTQ.csv"):    # (genome size: the three contigs of the .fai here, one genome in the golden run; file names)
+            assert qc_bytes(outn + "." + f) == qc_bytes(os.path.join(g["dir"], "ref_fqlist.qc." + f)), f
+    left = [n for n in os.listdir(str(tmp)) if ".part" in n or ".worker" in n]
+    assert not left, "part files and worker files must be gone: %s" % left
+    one, out1 = run_list(exe, g, tmp, "one_bam", sam=False)
+    many, outn = run_list(exe, g, tmp, "many_bam", devices=devices, sam=False)
+    assert open(outn + ".bam", "rb").read() == open(out1 + ".bam", "rb").read(), "the BAM file does not depend on how its records were produced"
+
+
+def test_fq_list_over_two_virtual_devices(golden_cases, tmp_path):
+    emu = os.path.join(HERE, "emu")
+    subprocess.check_call(["make", "-s", "-C", emu, "libfq_emu.so", "FASTQuick_emu"])
+    check_against_one_device(os.path.join(emu, "FASTQuick_emu"), golden_cases["qc"], tmp_path, "0,1")
+
+
+def _hip_devices():
+    import torch
+    return torch.cuda.device_count()
+
+
+@pytest.mark.gpu
+def test_fq_list_over_two_workers_on_one_gpu(golden_cases, tmp_path):
+    check_against_one_device(os.path.join(ROOT, "fastquick_amd", "bin", "FASTQuick_amd"), golden_cases["qc"], tmp_path, "0,0")
+
+
+@pytest.mark.gpu
+def test_fq_list_over_two_gpus(golden_cases, tmp_path):
+    if _hip_devices() < 2:
+        pytest.skip("one HIP device on this box")
+    check_against_one_device(os.path.join(ROOT, "fastquick_amd", "bin", "FASTQuick_amd"), golden_cases["qc"], tmp_path, "0-1")
