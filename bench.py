@@ -40,6 +40,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_PEAK_GBS = 6290.0     # ... and what a streaming copy reaches on the device (the guide's measured figure): fractions are stated against both
 K_NAMES = ("prep", "width", "gap", "sa", "sw", "refine")
+K_WIDTH_KERNEL, K_SA_KERNEL, K_SW_KERNEL, K_REFINE_KERNEL, K_MD_KERNEL, K_REC_KERNEL = 9, 10, 11, 12, 13, 14
+KERNEL_IDS = {"prep": 6, "gap_full": 7, "gap_nogap": 8, "width": 9, "sa": 10, "sw": 11, "refine": 12, "md": 13, "records": 14}
 K_PREP_KERNEL, K_GAP_KERNEL, K_GAP_NOGAP = 6, 7, 8     # single-kernel timings (kernel begin/end timestamps via hipExtLaunchKernelGGL events);
 #   7 = the full search kernels (one read per lane / per wavefront), 8 = the first round of a device-filling launch (search without gap children)
 STRIDE_PAD = 16                # ASCII rows are padded to 16 bytes: the resident filter kernel loads rows with 16-byte vector loads
@@ -84,6 +86,7 @@ def main() -> None:
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
     from fastquick_amd import api, synth
     from fastquick_amd import dist as fqd
+    api.load_library().fq_runtime_configure(20, 1)   # hardware queues for the contexts' streams, sleeping waits (include/fastquick_amd.h)
     rank, local_rank, world = fqd.init("nccl")      # RCCL; one process per GPU
     tuning = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune.split(",") if kv}
 
@@ -219,7 +222,7 @@ def main() -> None:
         elapsed = fqd.max_over_ranks(time.perf_counter() - t0)
         agg = sum_stats(ctxs)
         calls = steps * n_ctx
-        leg = {"elapsed": elapsed, "calls": calls, "agg": agg, "n_records": n_records, "on_frac": on_frac, "pairs": pairs, "n_ctx": n_ctx,
+        leg = {"elapsed": elapsed, "calls": calls, "agg": agg, "n_records": n_records, "on_frac": on_frac, "pairs": pairs, "n_ctx": n_ctx, "n_distinct": n_distinct,
                "value": pairs * calls * world / elapsed}
         # the same kernels alone on the device (one stream, after the timed region): launch duration without other streams' kernels
         if n_ctx > 1:
@@ -251,9 +254,24 @@ def main() -> None:
         b_all, b_n = 48.0 * st["gap_occ_touches"], 48.0 * st["gap_nogap_touches"]
         return [("gap", ms_f + ms_n, nl_f + nl_n, b_all), ("gap_nogap", ms_n, nl_n, b_n), ("gap_full", ms_f, nl_f, b_all - b_n)]
 
+    def dp_parts(st):
+        """(name, summed ms, launches, algorithmic bytes) of the kernels that are neither the filter nor the search: widths (48 B per Occ
+        block touch, as the search), refinement (per task: the read's row, the 2-bit reference window, task + result + CIGAR) and
+        MD / NM (per mapped read: the row, the window, the record in and out, the string).  The last two compute on chip; their
+        byte figures say how far from the memory roofline such kernels sit, nothing else."""
+        ref_b = (L + (L + 3) // 4 + 16 + 8 + 8) * float(st["refine_tasks"])
+        md_b = (L + (L + 3) // 4 + 64 + 64 + 8) * float(st["md_reads"])
+        return [("width", st["kernel_ms"][K_WIDTH_KERNEL], int(st["kernel_launches"][K_WIDTH_KERNEL]), 48.0 * st["width_occ_touches"]),
+                ("refine", st["kernel_ms"][K_REFINE_KERNEL], int(st["kernel_launches"][K_REFINE_KERNEL]), ref_b),
+                ("md", st["kernel_ms"][K_MD_KERNEL], int(st["kernel_launches"][K_MD_KERNEL]), md_b)]
+
+    def device_ms(st, calls):
+        """summed kernel time per call by kernel (begin / end timestamps of every launch: what rocprofv3 --kernel-trace sums)"""
+        return {k: round(st["kernel_ms"][i] / max(1, calls), 4) for k, i in KERNEL_IDS.items()}
+
     def kernel_rooflines(agg, pairs_total, boundary):
         out = {}
-        parts = [("prep", agg["kernel_ms"][K_PREP_KERNEL], int(agg["kernel_launches"][K_PREP_KERNEL]), prep_bytes(agg, pairs_total, boundary))] + gap_parts(agg)
+        parts = [("prep", agg["kernel_ms"][K_PREP_KERNEL], int(agg["kernel_launches"][K_PREP_KERNEL]), prep_bytes(agg, pairs_total, boundary))] + gap_parts(agg) + dp_parts(agg)
         for kname, ms_sum, nl, byts in parts:
             if nl == 0 and kname != "prep" and kname != "gap":
                 continue
@@ -282,7 +300,8 @@ def main() -> None:
     capacity = {"prep": 524288.0, "width": 524288.0, "gap": 262144.0, "sa": 524288.0, "sw": 256.0, "refine": 16384.0}   # resident work items
     share = {k: min(1.0, items[k] / capacity[k]) for k in items}
     dom = max(range(len(K_NAMES)), key=lambda k: kms[k] * share[K_NAMES[k]])
-    dom_by_time = max(range(len(K_NAMES)), key=lambda k: kms[k])
+    dev_ms = device_ms(agg, calls)
+    dom_by_time = max(dev_ms, key=lambda k: dev_ms[k])
     dname = K_NAMES[dom] if K_NAMES[dom] in ("prep", "gap") else "prep"
     pk = per_kernel["fq_" + dname]
     # HBM-side bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE collected separately,
@@ -302,7 +321,8 @@ def main() -> None:
                 "model": ("64 B x bitmap probes + 24 B of filter keys/read + 1 B/read out" if args.boundary == "host" else "64 B x bitmap probes + 96 B of bases/read + 5 B/read out")
                 if dname == "prep" else "48 B x Occ block touches (reference block definition, SURVEY 8d)",
                 "aggregate_achieved": round(alg_bytes / elapsed / 1e9, 3),   # all concurrent launches together, over the wall time
-                "dominant_by_device_time": "fq_" + K_NAMES[dom_by_time],
+                "dominant_by_device_time": "fq_" + dom_by_time,      # summed kernel begin-to-end time over the timed region, per kernel
+                "device_ms_per_call": dev_ms,
                 "dominance": "summed device ms per call x share of resident-lane capacity a launch occupies: " +
                              ", ".join("%s %.2f x %.2f" % (K_NAMES[k], kms[k] / calls, share[K_NAMES[k]]) for k in range(len(K_NAMES)))}
     if "solo" in main_leg:
@@ -415,12 +435,14 @@ def main() -> None:
     if args.mix == "wgs" and not args.no_ontarget:
         if args.ontarget_pairs <= 0:
             args.ontarget_pairs = args.pairs
-        leg = run_leg("ontarget", args.ontarget_pairs, args.ontarget_ctxs, args.ontarget_steps, 1, args.boundary, 3000, max_distinct=1)
+        leg = run_leg("ontarget", args.ontarget_pairs, args.ontarget_ctxs, args.ontarget_steps, 1, args.boundary, 3000, max_distinct=2)
         a2 = leg["agg"]
         out["ontarget"] = {"value": round(leg["value"], 1), "unit": "pairs/s", "pairs_per_call": args.ontarget_pairs, "concurrent_streams": args.ontarget_ctxs,
                            "steps": args.ontarget_steps, "ms_per_step": round(1e3 * leg["elapsed"] / args.ontarget_steps, 3),
                            "kernel_rooflines": kernel_rooflines(a2, args.ontarget_pairs * leg["calls"], args.boundary),
                            "stage_ms_per_call": {K_NAMES[k]: round(a2["kernel_ms"][k] / leg["calls"], 3) for k in range(len(K_NAMES))},
+                           "device_ms_per_call": device_ms(a2, leg["calls"]),
+                           "distinct_batches": leg["n_distinct"],
                            "host_ms_per_call": round(a2["host_ms_total"] / leg["calls"], 3),
                            "reads_searched_per_call": round(a2["reads_searched"] / leg["calls"], 1),
                            "stack_pops_per_read": round(a2["stack_pops"] / max(1, a2["reads_searched"]), 1),
@@ -450,7 +472,7 @@ def main() -> None:
         # the same mix as a throughput job: many streams of ordinary calls, so that one stream's host phases (main-hit choice in read
         # order, insert-size inference, record assembly) run under the kernels of the others
         if args.ontarget_tput_ctxs > 0:
-            leg = run_leg("ontarget", 1 << 20, args.ontarget_tput_ctxs, 2, 1, args.boundary, 3000, max_distinct=1)
+            leg = run_leg("ontarget", 1 << 20, args.ontarget_tput_ctxs, 2, 1, args.boundary, 3000, max_distinct=2)
             out["ontarget"]["throughput"] = {"value": round(leg["value"], 1), "unit": "pairs/s", "pairs_per_call": 1 << 20, "concurrent_streams": args.ontarget_tput_ctxs,
                                              "steps": 2, "ms_per_step": round(1e3 * leg["elapsed"] / 2, 3),
                                              "host_ms_per_call": round(leg["agg"]["host_ms_total"] / leg["calls"], 3)}

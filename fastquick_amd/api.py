@@ -76,7 +76,7 @@ class ResultBatch(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("kernel_ms", C.c_double * 9), ("kernel_launches", C.c_uint64 * 9),
+    _fields_ = [("kernel_ms", C.c_double * 15), ("kernel_launches", C.c_uint64 * 15),
                 ("occ_block_touches", C.c_uint64), ("gap_occ_touches", C.c_uint64), ("gap_nogap_touches", C.c_uint64), ("filter_probes", C.c_uint64),
                 ("stack_pops", C.c_uint64), ("stack_pushes", C.c_uint64), ("sa_rows", C.c_uint64),
                 ("reads_searched", C.c_uint64), ("pairs", C.c_uint64), ("sw_tasks", C.c_uint64),
@@ -84,7 +84,8 @@ class Stats(C.Structure):
                 ("max_pops_per_read", C.c_uint64), ("reads_over_4k_pops", C.c_uint64), ("max_wave_trips", C.c_uint64),
                 ("host_ms_serial", C.c_double), ("host_ms_pair", C.c_double), ("host_ms_total", C.c_double),
                 ("wall_ms_total", C.c_double), ("wave_trips", C.c_uint64), ("lane_trips", C.c_uint64),
-                ("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("pairs_on_device", C.c_uint64), ("dbg", C.c_uint64 * 16)]
+                ("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("pairs_on_device", C.c_uint64), ("dbg", C.c_uint64 * 16),
+                ("width_occ_touches", C.c_uint64), ("md_reads", C.c_uint64), ("host_pairs", C.c_uint64)]
 
 
 EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destroy", "fq_index_l_pac",

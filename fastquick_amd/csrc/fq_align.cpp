@@ -1768,6 +1768,9 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
   fqdev::time_collect(c->stats.kernel_ms, c->stats.kernel_launches, FQ_K_COUNT);
   c->stats.occ_block_touches += cnt[FQ_C_OCC_WIDTH] + cnt[FQ_C_OCC_GAP] + cnt[FQ_C_OCC_SA];
   c->stats.gap_occ_touches += cnt[FQ_C_OCC_GAP];
+  c->stats.width_occ_touches += cnt[FQ_C_OCC_WIDTH];
+  c->stats.md_reads += cnt[FQ_C_MD_READS];
+  c->stats.host_pairs += (uint64_t)K.n_host_pairs;
   c->stats.gap_nogap_touches += cnt[FQ_C_OCC_NOGAP];
   c->stats.filter_probes += cnt[FQ_C_PROBES];
   c->stats.stack_pops += cnt[FQ_C_POPS];

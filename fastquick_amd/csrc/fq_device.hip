@@ -857,7 +857,7 @@ int launch_prep(const FqPrepArgs &a) {
   FQ_PRE();
   if (a.n_reads <= 0) return 0;
   hipEvent_t e0, e1;
-  kernel_events(6, &e0, &e1);   // FQ_K_PREP_KERNEL
+  kernel_events(FQ_K_PREP_KERNEL, &e0, &e1);
   if (!g_cur->tune.filter_no_turns) {
     const int dev = g_cur->device;
     std::lock_guard<std::mutex> lk(g_dev_mu);
@@ -890,7 +890,7 @@ int launch_prep_packed(const FqPrepPackedArgs &a) {
   FQ_PRE();
   if (a.n_reads <= 0) return 0;
   hipEvent_t e0, e1;
-  kernel_events(6, &e0, &e1);   // FQ_K_PREP_KERNEL
+  kernel_events(FQ_K_PREP_KERNEL, &e0, &e1);
   const dim3 grid(nblk((uint64_t)a.n_reads, 256));
   if (!g_cur->tune.filter_no_turns) {   // chained per device like launch_prep
     const int dev = g_cur->device;
@@ -966,7 +966,9 @@ int launch_trim_all(const FqTrimAllArgs &a) {
 int launch_width(const FqWidthArgs &a) {
   FQ_PRE();
   if (a.n_work <= 0) return 0;
-  hipLaunchKernelGGL(k_width, dim3(nblk((uint64_t)a.n_work, 256)), dim3(256), (size_t)2 * (size_t)a.o.seed_len * 256, g_stream, a);
+  hipEvent_t e0, e1;
+  kernel_events(FQ_K_WIDTH_KERNEL, &e0, &e1);
+  hipExtLaunchKernelGGL(k_width, dim3(nblk((uint64_t)a.n_work, 256)), dim3(256), (size_t)2 * (size_t)a.o.seed_len * 256, g_stream, e0, e1, 0, a);
   FQ_HIP(hipGetLastError());
   return 0;
 }
@@ -1064,7 +1066,7 @@ int launch_gap(const FqGapArgs &a_in) {
   a.refill_min = env_refill > 0 ? env_refill : a_in.refill_min > 0 ? a_in.refill_min : FQ_REFILL_MIN;   // (tuning key, else the caller's choice for this round, else 64)
   FQ_HIP(hipMemsetAsync(a.queue, 0, 8, g_stream));
   hipEvent_t e0, e1;
-  kernel_events(a.tier.nogap ? 8 : 7, &e0, &e1);   // FQ_K_GAP_NOGAP / FQ_K_GAP_KERNEL
+  kernel_events(a.tier.nogap ? FQ_K_GAP_NOGAP : FQ_K_GAP_KERNEL, &e0, &e1);
   if (a.tier.coop) {
     hipExtLaunchKernelGGL(k_gap_coop, dim3((unsigned)gap_lane_slots(a)), dim3(64), 0, g_stream, e0, e1, 0, a);
   } else {
@@ -1090,7 +1092,9 @@ int launch_pack_aln(const FqAln *aln, const uint32_t *n_aln, const uint64_t *off
 int launch_sa(const FqSaArgs &a) {
   FQ_PRE();
   if (!a.n_rows) return 0;
-  hipLaunchKernelGGL(k_sa, dim3(nblk(a.n_rows, 256)), dim3(256), 0, g_stream, a);
+  hipEvent_t e0, e1;
+  kernel_events(FQ_K_SA_KERNEL, &e0, &e1);
+  hipExtLaunchKernelGGL(k_sa, dim3(nblk(a.n_rows, 256)), dim3(256), 0, g_stream, e0, e1, 0, a);
   FQ_HIP(hipGetLastError());
   return 0;
 }
@@ -1120,7 +1124,9 @@ int launch_sw(const FqSwArgs &a) {
   // the task's global scratch and have every task resident at once (each spends most of its time in the serial reverse pass).
   b.trace_in_lds = (lds + trace_bytes <= kLdsBudget && a.n_task <= 256) ? 1 : 0;
   if (b.trace_in_lds) lds += trace_bytes;
-  hipLaunchKernelGGL(k_sw_wave, dim3((unsigned)a.n_task), dim3(64), lds, g_stream, b);
+  hipEvent_t e0, e1;
+  kernel_events(FQ_K_SW_KERNEL, &e0, &e1);
+  hipExtLaunchKernelGGL(k_sw_wave, dim3((unsigned)a.n_task), dim3(64), lds, g_stream, e0, e1, 0, b);
   FQ_HIP(hipGetLastError());
   return 0;
 }
@@ -1131,7 +1137,9 @@ __global__ void __launch_bounds__(64) k_sw_thread(FqSwArgs a) {
 int launch_sw_serial(const FqSwArgs &a) {
   FQ_PRE();
   if (a.n_task <= 0) return 0;
-  hipLaunchKernelGGL(k_sw_thread, dim3(nblk((uint64_t)a.n_task, 64)), dim3(64), 0, g_stream, a);
+  hipEvent_t e0, e1;
+  kernel_events(FQ_K_SW_KERNEL, &e0, &e1);
+  hipExtLaunchKernelGGL(k_sw_thread, dim3(nblk((uint64_t)a.n_task, 64)), dim3(64), 0, g_stream, e0, e1, 0, a);
   FQ_HIP(hipGetLastError());
   return 0;
 }
@@ -1142,16 +1150,18 @@ int launch_refine(const FqRefineArgs &a) {
   // fall back to one task per lane
   const size_t wave_lds = (size_t)3 * (a.RL + 1) * 4 + ((a.RL + 16) & ~15) + ((a.QL + 16) & ~15) + ((a.RL + a.QL + 16) & ~15) + (size_t)(a.RL + 1) * (a.QL + 1) + 16;
   const bool no_wave = g_cur->tune.refine_lanes != 0;   // test knob: force the lane-per-task kernels
+  hipEvent_t e0, e1;
+  kernel_events(FQ_K_REFINE_KERNEL, &e0, &e1);
   if (wave_lds <= 64 * 1024 && !no_wave) {
-    hipLaunchKernelGGL(k_refine_wave, dim3((unsigned)a.n_task), dim3(64), wave_lds, g_stream, a);
+    hipExtLaunchKernelGGL(k_refine_wave, dim3((unsigned)a.n_task), dim3(64), wave_lds, g_stream, e0, e1, 0, a);
     FQ_HIP(hipGetLastError());
     return 0;
   }
   const size_t lds = (size_t)3 * (a.RL + 1) * 64 * 4;
   if (lds <= kLdsBudget) {
-    hipLaunchKernelGGL(k_refine_lds, dim3(nblk((uint64_t)a.n_task, 64)), dim3(64), lds, g_stream, a);
+    hipExtLaunchKernelGGL(k_refine_lds, dim3(nblk((uint64_t)a.n_task, 64)), dim3(64), lds, g_stream, e0, e1, 0, a);
   } else {
-    hipLaunchKernelGGL(k_refine, dim3(nblk((uint64_t)a.n_task, 64)), dim3(64), 0, g_stream, a);
+    hipExtLaunchKernelGGL(k_refine, dim3(nblk((uint64_t)a.n_task, 64)), dim3(64), 0, g_stream, e0, e1, 0, a);
   }
   FQ_HIP(hipGetLastError());
   return 0;
@@ -1207,7 +1217,9 @@ int launch_rec(int op, const FqRecArgs &a, int64_t n) {
                                            k_xa_count, k_xa_fill, k_sw_plan, k_sw_fill, k_rec_gather, k_rec_scatter, k_ref_count, k_ref_fill, k_ref_apply,
                                            k_md_rec, k_flat_count, k_flat_fill};
   if (op < 0 || op >= FQ_ROP_COUNT) { g_err = "record stage: unknown operation"; return -1; }
-  hipLaunchKernelGGL(kerns[op], dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, a, (int)n);
+  hipEvent_t e0, e1;
+  kernel_events(op == FQ_ROP_MD ? FQ_K_MD_KERNEL : FQ_K_REC_KERNEL, &e0, &e1);
+  hipExtLaunchKernelGGL(kerns[op], dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
   FQ_HIP(hipGetLastError());
   return 0;
 }

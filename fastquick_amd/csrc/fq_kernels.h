@@ -18,7 +18,14 @@
 #define FQ_ATOMIC_MAX64(p, v) atomicMax((unsigned long long *)(p), (unsigned long long)(v))
 #define FQ_ATOMIC_MAX32(p, v) atomicMax((int *)(p), (int)(v))
 #define FQ_LOAD_RELAXED(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// counter += number of active lanes for which pred holds: one atomic per wavefront instead of one per lane
+#define FQ_WAVE_COUNT(p, pred)                                                                                      \
+  do {                                                                                                              \
+    const unsigned long long m_ = __ballot((pred) ? 1 : 0);                                                         \
+    if ((pred) && __lane_id() == (unsigned)(__ffsll((long long)m_) - 1)) atomicAdd((unsigned long long *)(p), (unsigned long long)__popcll(m_)); \
+  } while (0)
 #else
+#define FQ_WAVE_COUNT(p, pred) do { if (pred) *(p) += 1; } while (0)
 #define FQ_LOAD_RELAXED(p) (*(p))
 #define FQ_ATOMIC_MAX32(p, v) (*(p) = *(p) > (int32_t)(v) ? *(p) : (int32_t)(v))
 #define FQ_ATOMIC_MAX64(p, v) (*(p) = *(p) > (uint64_t)(v) ? *(p) : (uint64_t)(v))

@@ -288,7 +288,7 @@ FQ_HD void fq_main_hit_thread(const FqRecArgs &A, int sp) {
     cls = (A.enumerated[2 * sp] && A.enumerated[2 * sp + 1] && (uint64_t)o0 + o1 <= FQ_PAIR_LANE_ROWS) ? 1 : 2;
   A.cls[sp] = cls;
   A.flag32[sp] = cls == 2 ? 1u : 0u;
-  if (cls == 1) FQ_ATOMIC_ADD64(&A.counters[FQ_C_PAIRS_DEV], 1);
+  FQ_WAVE_COUNT(&A.counters[FQ_C_PAIRS_DEV], cls == 1);
 }
 
 // out[off[i] ..] = i for every i with cnt[i] != 0 (ordered compaction; off = exclusive prefix sums of cnt != 0 ? 1 : 0 -- callers
@@ -523,6 +523,7 @@ FQ_HD void fq_md_rec_thread(const FqRecArgs &A, int idx) {
   if (at > A.md_cap - 1) { FQ_ATOMIC_ADD64(&A.counters[FQ_C_ERR_MD], 1); at = 0; }
   s.has_md = 1; s.md_len = at; s.nm = (uint16_t)(nm & 0xfff);
   A.rec[idx] = s;
+  FQ_WAVE_COUNT(&A.counters[FQ_C_MD_READS], true);
 }
 
 // ---- the C-ABI arrays, with bwa_correct_trimmed (libbwa/bwase.c:298-337) applied to every record as they are written ----------------
@@ -599,7 +600,7 @@ FQ_HD void fq_flat_fill_thread(const FqRecArgs &A, int idx) {
     A.o_multi[xa++] = m;
   }
   A.o_rec[idx] = o;
-  if ((idx & 1) && s.type == FQ_TYPE_NO_MATCH && A.rec[idx - 1].type == FQ_TYPE_NO_MATCH) FQ_ATOMIC_ADD64(&A.counters[FQ_C_UNMAPPED], 1);
+  FQ_WAVE_COUNT(&A.counters[FQ_C_UNMAPPED], (idx & 1) && s.type == FQ_TYPE_NO_MATCH && A.rec[idx - 1].type == FQ_TYPE_NO_MATCH);
 }
 
 // by search index: where a read's hit list lies in the call's list arena (work item w of a launch completed with status 0)

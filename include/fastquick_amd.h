@@ -367,7 +367,13 @@ int fq_bam_close(fq_bam_t *b);                   /* writes the BGZF end-of-file 
 #define FQ_K_PREP_KERNEL 6   /* k_prep alone, kernel begin/end timestamps (hipExtLaunchKernelGGL events) */
 #define FQ_K_GAP_KERNEL 7    /* the gap-search kernels alone, same: the full search (one read per lane / per wavefront) */
 #define FQ_K_GAP_NOGAP 8     /* ... the first round of a device-filling launch (the search without gap children) */
-#define FQ_K_COUNT 9
+#define FQ_K_WIDTH_KERNEL 9  /* k_width alone (kernel begin/end timestamps, like the three above) */
+#define FQ_K_SA_KERNEL 10    /* k_sa */
+#define FQ_K_SW_KERNEL 11    /* the mate-rescue kernels */
+#define FQ_K_REFINE_KERNEL 12 /* the banded global DP kernels */
+#define FQ_K_MD_KERNEL 13    /* MD / NM of every mapped read */
+#define FQ_K_REC_KERNEL 14   /* the record stages (fq_records.h): set-up, main hit, pairing, XA, task lists, flattening */
+#define FQ_K_COUNT 15
 typedef struct {
   double kernel_ms[FQ_K_COUNT];
   uint64_t kernel_launches[FQ_K_COUNT];
@@ -387,6 +393,9 @@ typedef struct {
   uint64_t h2d_bytes, d2h_bytes; /* bytes the calls moved over PCIe (inputs, task lists; results) */
   uint64_t pairs_on_device;     /* both-mapped pairs whose pairing (libbwa/bwape.c:119-213) ran in k_pair; the rest ran the same routine on the host */
   uint64_t dbg[16];             /* experiment counters of instrumented builds (-DFQ_GAP_INSTR), zero otherwise */
+  uint64_t width_occ_touches;   /* 32-byte Occ blocks fetched by FQ_K_WIDTH alone */
+  uint64_t md_reads;            /* mapped reads FQ_K_MD_KERNEL wrote an MD string for */
+  uint64_t host_pairs;          /* both-mapped pairs the host paired (Q6 intervals, many rows): pairs_on_device counts the others */
 } fq_stats_t;
 void fq_stats_get(const fq_ctx_t *c, fq_stats_t *out);
 void fq_stats_reset(fq_ctx_t *c);

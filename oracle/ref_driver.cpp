@@ -414,10 +414,268 @@ static int cmd_align(int argc, char **argv) {
   return 0;
 }
 
+// ---- the reference-side binding, compiled and run --------------------------------------------------------------
+//   fq_ref_driver via_lib <libfq_emu.so | libfastquick_amd.so> <ref.FASTQuick.fa> <r1.fq> <r2.fq | -> <out_prefix> [options of `align`]
+// The producer side of PairEndMapper / SingleEndMapper -- FASTQ reader, filter, search, pairing, mate rescue, refinement -- is the
+// library behind include/fastquick_amd.h (its C ABI only: the host-loop build of the CPU test tier or the HIP product); the CONSUMER
+// side is the reference's own code, unchanged: every record the library returns is copied field by field into a bwa_seq_t
+// (fill_bwa_seq, the adapter INTEGRATION.md spells out) and handed to StatCollector::AddAlignment, then to bwa_print_sam1 or
+// BwtMapper::SetSamRecord, exactly where PairEndMapper does it (src/BwtMapper.cpp:2026-2085); ProcessCore writes the QC files.
+// "- " as <r2.fq> with --se 1: BwtMapper::SingleEndMapper's consumer loop (:1355-1387).
+#include <dlfcn.h>
+#include "../include/fastquick_amd.h"
+namespace vialib {
+#define FQ_FN(name) decltype(&::name) name = nullptr
+struct Lib {
+  FQ_FN(fq_default_opts); FQ_FN(fq_index_load); FQ_FN(fq_index_destroy); FQ_FN(fq_ctx_create); FQ_FN(fq_ctx_destroy); FQ_FN(fq_ctx_last_error);
+  FQ_FN(fq_align_batch); FQ_FN(fq_fastq_open); FQ_FN(fq_fastq_configure); FQ_FN(fq_fastq_set_sampling); FQ_FN(fq_fastq_read); FQ_FN(fq_fastq_close);
+  FQ_FN(fq_fastq_last_error);
+  void load(const char *path) {
+    void *h = dlopen(path, RTLD_NOW | RTLD_LOCAL);
+    if (!h) { fprintf(stderr, "%s\n", dlerror()); die("cannot load the library"); }
+#define FQ_SYM(name) do { name = (decltype(name))dlsym(h, #name); if (!name) die("the library lacks " #name); } while (0)
+    FQ_SYM(fq_default_opts); FQ_SYM(fq_index_load); FQ_SYM(fq_index_destroy); FQ_SYM(fq_ctx_create); FQ_SYM(fq_ctx_destroy); FQ_SYM(fq_ctx_last_error);
+    FQ_SYM(fq_align_batch); FQ_SYM(fq_fastq_open); FQ_SYM(fq_fastq_configure); FQ_SYM(fq_fastq_set_sampling); FQ_SYM(fq_fastq_read); FQ_SYM(fq_fastq_close);
+    FQ_SYM(fq_fastq_last_error);
+  }
+};
+// the name a record prints under: `/1` `/2` cut off as the reference's reader does when it stores it (src/BwtMapper.cpp:565-570); a read
+// that expand_seq revived carries its mate's name written over its own, without a terminator (libbwa/bwape.c:456)
+static std::string rec_name(const fq_read_batch_t *in, int pair, int end, bool revived) {
+  const char *nm = (end && in->names_mate ? in->names_mate : in->names) + (size_t)pair * (size_t)in->name_stride;
+  std::string s(nm, strnlen(nm, (size_t)in->name_stride));
+  if (revived && in->names_mate) {
+    const char *qn = (end ? in->names : in->names_mate) + (size_t)pair * (size_t)in->name_stride;
+    const std::string q(qn, strnlen(qn, (size_t)in->name_stride));
+    s = q.size() >= s.size() ? q : q + s.substr(q.size());
+  }
+  const size_t t = s.size();
+  if (t > 2 && s[t - 2] == '/' && (s[t - 1] == '1' || s[t - 1] == '2')) s.resize(t - 2);
+  return s;
+}
+// One record's storage, owned by the adapter like a read slot of the reference.
+struct Slot {
+  bwa_seq_t p;
+  std::vector<ubyte_t> seq, rseq, qual;
+  std::vector<bwt_multi1_t> multi;
+  std::string name;
+};
+// rec index i = 2*s + end; in = the batch that was aligned; res = its result: every field AddAlignment, SetSamRecord and bwa_print_sam1 read
+static void fill_bwa_seq(Slot &S, const fq_read_batch_t *in, const fq_result_batch_t *res, int i, int mode) {
+  bwa_seq_t *p = &S.p;
+  memset(p, 0, sizeof *p);
+  const fq_result_t *r = &res->rec[i];
+  const int end = i & 1, pair = res->pair_idx[i >> 1];
+  const size_t row = (size_t)end * in->n_pairs + pair;
+  S.name = rec_name(in, pair, end, r->revived != 0);
+  p->name = (char *)S.name.c_str();
+  p->len = r->len; p->full_len = r->full_len; p->clip_len = r->clip_len;
+  p->strand = r->strand; p->type = r->type; p->filtered = r->filtered; p->extra_flag = r->extra_flag;
+  p->n_mm = r->n_mm; p->n_gapo = r->n_gapo; p->n_gape = r->n_gape; p->mapQ = r->mapQ; p->seQ = r->seQ;
+  p->score = r->score; p->c1 = r->c1; p->c2 = r->c2; p->pos = r->pos; p->sa = r->sa; p->nm = r->nm;
+  // seq: nt4 codes in read orientation (what bwa_refine_gapped leaves, bwase.c:360); rseq: the reverse complement of the (trimmed) read,
+  // which bwa_print_sam1 prints for a record that lost its hit on the reverse strand; qual: a terminated copy of the caller's ASCII row
+  // (Phred+64 input: 31 taken off, as the reference's reader stores it, BwtMapper.cpp:549-553)
+  const int L = r->full_len;
+  S.seq.assign((size_t)L + 1, 0); S.rseq.assign((size_t)L + 1, 0); S.qual.assign((size_t)L + 1, 0);
+  for (int k = 0; k < L; ++k) S.seq[k] = nst_nt4_table[in->seq[row * in->stride + k]];
+  for (int k = 0; k < L; ++k) { const int c = k < r->clip_len ? S.seq[r->clip_len - 1 - k] : 3; S.rseq[k] = (ubyte_t)(c < 4 ? 3 - c : c); }
+  const int qsub = (mode & BWA_MODE_IL13) ? 31 : 0;
+  for (int k = 0; k < L; ++k) S.qual[k] = (ubyte_t)(in->qual[row * in->stride + k] - qsub);
+  p->seq = S.seq.data(); p->rseq = S.rseq.data(); p->qual = S.qual.data();
+  p->n_cigar = r->n_cigar; p->cigar = r->n_cigar ? (bwa_cigar_t *)(res->cigar + r->cigar_off) : 0;
+  p->md = r->md_off == 0xffffffffu ? 0 : (char *)(res->md + r->md_off);
+  p->n_multi = r->n_multi;
+  S.multi.assign((size_t)r->n_multi + 1, bwt_multi1_t());
+  for (int k = 0; k < r->n_multi; ++k) {
+    const fq_multi_t *m = &res->multi[r->multi_off + k];
+    S.multi[k].pos = m->pos; S.multi[k].gap = m->gap; S.multi[k].mm = m->mm; S.multi[k].strand = m->strand;
+    S.multi[k].n_cigar = m->n_cigar; S.multi[k].cigar = m->n_cigar ? (bwa_cigar_t *)(res->cigar + m->cigar_off) : 0;
+  }
+  p->multi = S.multi.data();
+}
+static void dump_sam_record(FILE *fb, SamRecord &R) {
+  fprintf(fb, "%s\t%d\t%s\t%d\t%d\t%s\t%s\t%d\t%d\t%s\t%s", R.getReadName(), (int)R.getFlag(), R.getReferenceName(), (int)R.get1BasedPosition(),
+          (int)R.getMapQuality(), R.getCigar(), R.getMateReferenceNameOrEqual(), (int)R.get1BasedMatePosition(), (int)R.getInsertSize(), R.getSequence(), R.getQuality());
+  char tag[3]; char vtype; void *value;
+  R.resetTagIter();
+  while (R.getNextSamTag(tag, vtype, &value)) {
+    if (vtype == 'Z') fprintf(fb, "\t%s:Z:%s", tag, ((String *)value)->c_str());
+    else if (vtype == 'A') fprintf(fb, "\t%s:A:%c", tag, *(char *)value);
+    else if (vtype == 'f') fprintf(fb, "\t%s:f:%g", tag, *(float *)value);
+    else fprintf(fb, "\t%s:i:%d", tag, *(int *)value);
+  }
+  fputc('\n', fb);
+}
+}  // namespace vialib
+
+static int cmd_via_lib(int argc, char **argv) {
+  using namespace vialib;
+  if (argc < 7) die("usage: via_lib <library.so> <ref.FASTQuick.fa> <r1.fq> <r2.fq | -> <out_prefix> [--q Q] [--batch N] [--se 1] [--bam_dump 1 --fai F] [--more r1,r2] ...");
+  Lib L;
+  L.load(argv[2]);
+  std::string NewRef = argv[3];
+  std::string out = argv[6];
+  gap_opt_t *opt = gap_init_opt();
+  pe_opt_t *popt = bwa_init_pe_opt();
+  int batch = READ_BUFFER_SIZE, thresh = 3, bam_dump = 0, se = 0, chunk_batches = 2;
+  long long genome_size = 0, genome_n_size = 0;
+  std::vector<std::pair<std::string, std::string>> pairs;
+  pairs.emplace_back(argv[4], argv[5]);
+  std::string fai_path, rg = "@RG\tID:foo\tSM:bar";
+  for (int i = 7; i + 1 < argc; i += 2) {
+    if (!strcmp(argv[i], "--q")) opt->trim_qual = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--batch")) batch = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--chunk_batches")) chunk_batches = atoi(argv[i + 1]);   // reference batches per call of the library
+    else if (!strcmp(argv[i], "--genome_size")) genome_size = atoll(argv[i + 1]);
+    else if (!strcmp(argv[i], "--genome_n_size")) genome_n_size = atoll(argv[i + 1]);
+    else if (!strcmp(argv[i], "--flank")) opt->flank_len = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--flank_long")) opt->flank_long_len = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--cal_dup")) opt->cal_dup = (char)atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--bam_dump")) bam_dump = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--se")) se = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--fai")) fai_path = argv[i + 1];
+    else if (!strcmp(argv[i], "--RG")) rg = argv[i + 1];
+    else if (!strcmp(argv[i], "--thresh")) thresh = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--frac_samp")) opt->frac = atof(argv[i + 1]);
+    else if (!strcmp(argv[i], "--read_len")) opt->read_len = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--I")) opt->mode |= BWA_MODE_IL13;
+    else if (!strcmp(argv[i], "--more")) {
+      const std::string v = argv[i + 1];
+      const size_t comma = v.find(',');
+      if (comma == std::string::npos) die("--more takes r1.fq,r2.fq");
+      pairs.emplace_back(v.substr(0, comma), v.substr(comma + 1));
+    }
+    else die("unknown option");
+  }
+  // the reference's side: annotations for the consumers (bns), its StatCollector, its record builder
+  BwtIndexer ix(thresh);
+  ix.bns = bns_restore(NewRef.c_str());
+  StatCollector collector;
+  collector.RestoreVcfSites(NewRef, opt);
+  collector.SetGenomeSize(genome_size, genome_n_size);
+  std::ofstream fout(out + ".InsertSizeTable");
+  BwtMapper mapper;
+  SamFileHeader SFH;
+  FILE *fb = 0;
+  if (bam_dump) {
+    opt->RG = strdup(rg.c_str());
+    mapper.bwa_set_rg(opt->RG);
+    std::ifstream fai(fai_path);
+    if (!fai.is_open()) die("--bam_dump needs --fai");
+    std::string line, chr, length;
+    while (getline(fai, line)) {
+      std::stringstream ss(line);
+      ss >> chr;
+      if (chr.find("chr") != std::string::npos or chr.find("CHR") != std::string::npos) chr = chr.substr(3);
+      ss >> length;
+      ix.contigSize.emplace_back(chr, atoi(length.c_str()));
+    }
+    mapper.SetSamFileHeader(SFH, ix);
+    std::string hdr;
+    SFH.getHeaderString(hdr);
+    FILE *fh = fopen((out + ".bamhdr").c_str(), "w");
+    if (!fh) die("cannot open bamhdr");
+    fputs(hdr.c_str(), fh);
+    fclose(fh);
+    fb = fopen((out + ".bamtxt").c_str(), "w");
+    if (!fb) die("cannot open bamtxt");
+  }
+  if (!freopen((out + ".sam").c_str(), "w", stdout)) die("cannot redirect stdout");
+  // the library's side: the index on its device, one context per FASTQ pair, options 1:1 from gap_opt_t / pe_opt_t
+  fq_index_t *gix = nullptr;
+  if (L.fq_index_load(NewRef.c_str(), 0, &gix) != FQ_OK) die("fq_index_load failed");
+  fq_opts_t fo;
+  L.fq_default_opts(&fo);
+  fo.s_mm = opt->s_mm; fo.s_gapo = opt->s_gapo; fo.s_gape = opt->s_gape; fo.mode = opt->mode; fo.indel_end_skip = opt->indel_end_skip; fo.max_del_occ = opt->max_del_occ;
+  fo.max_entries = opt->max_entries; fo.fnr = opt->fnr; fo.max_diff = opt->max_diff; fo.max_gapo = opt->max_gapo; fo.max_gape = opt->max_gape;
+  fo.max_seed_diff = opt->max_seed_diff; fo.seed_len = opt->seed_len; fo.max_top2 = opt->max_top2; fo.trim_qual = opt->trim_qual; fo.filter_thresh = thresh;
+  fo.max_isize = popt->max_isize; fo.force_isize = popt->force_isize; fo.max_occ = popt->max_occ; fo.n_multi = popt->n_multi; fo.N_multi = popt->N_multi;
+  fo.is_sw = popt->is_sw; fo.ap_prior = popt->ap_prior; fo.batch_pairs = batch; fo.single_end = se ? 1 : 0;
+  bwa_print_sam_SQ(ix.bns);
+  bwa_print_sam_PG();
+  const int n_ends = se ? 1 : 2;
+  const int chunk = batch * std::max(1, chunk_batches);
+  const int stride = (std::max(opt->read_len, 16) + 15) & ~15, name_stride = 304;
+  std::vector<uint8_t> seq((size_t)2 * chunk * stride), qual((size_t)2 * chunk * stride);
+  std::vector<int32_t> len((size_t)2 * chunk);
+  std::vector<char> names[2] = {std::vector<char>((size_t)chunk * name_stride), std::vector<char>((size_t)chunk * name_stride)};
+  Slot slot[2];
+  for (const auto &fq_pair : pairs) {
+    FileStatCollector FSC = se ? FileStatCollector(fq_pair.first.c_str()) : FileStatCollector(fq_pair.first.c_str(), fq_pair.second.c_str());
+    fq_ctx_t *gctx = nullptr;
+    if (L.fq_ctx_create(gix, &fo, chunk, &gctx) != FQ_OK) die("fq_ctx_create failed");
+    fq_fastq_t *fr[2] = {nullptr, nullptr};
+    for (int e = 0; e < n_ends; ++e) {
+      if (L.fq_fastq_open((e ? fq_pair.second : fq_pair.first).c_str(), 2, &fr[e]) != FQ_OK) die("cannot open a FASTQ file");
+      L.fq_fastq_configure(fr[e], batch, se ? FQ_FASTQ_SLOTS_FRESH : FQ_FASTQ_SLOTS_REUSED, 0);
+      L.fq_fastq_set_sampling(fr[e], opt->frac);
+    }
+    for (;;) {
+      int64_t n = -1;
+      for (int e = 0; e < n_ends; ++e) {
+        fq_fastq_rows_t rows = {stride, name_stride, seq.data() + (size_t)e * chunk * stride, qual.data() + (size_t)e * chunk * stride, len.data() + (size_t)e * chunk, names[e].data()};
+        const int64_t got = L.fq_fastq_read(fr[e], chunk, &rows);
+        if (got < 0) { fprintf(stderr, "%s\n", L.fq_fastq_last_error(fr[e])); die("reading a FASTQ file failed"); }
+        if (n >= 0 && got != n) die("unequal mate counts");
+        n = got;
+      }
+      if (n <= 0) break;
+      if (n < chunk && !se) {   // a short last chunk: end 1 moves down behind the n rows of end 0
+        memmove(seq.data() + (size_t)n * stride, seq.data() + (size_t)chunk * stride, (size_t)n * stride);
+        memmove(qual.data() + (size_t)n * stride, qual.data() + (size_t)chunk * stride, (size_t)n * stride);
+        memmove(len.data() + n, len.data() + chunk, (size_t)n * 4);
+      }
+      fq_read_batch_t in = {(int32_t)n, stride, seq.data(), qual.data(), len.data(), names[0].data(), name_stride, se ? nullptr : names[1].data()};
+      fq_result_batch_t res;
+      if (L.fq_align_batch(gctx, &in, &res) != FQ_OK) { fprintf(stderr, "%s\n", L.fq_ctx_last_error(gctx)); die("fq_align_batch failed"); }
+      // ---- the reference's consumer loop (src/BwtMapper.cpp:2026-2085; single-end: :1355-1387), on adapted records
+      FSC.NumBase += res.n_bases;
+      FSC.NumRead += n_ends * n;
+      FSC.TotalFiltered += res.n_both_filtered;
+      for (int s = 0; s < res.n_survivors; ++s) {
+        const fq_result_t *r0 = &res.rec[2 * s], *r1 = &res.rec[2 * s + 1];
+        if (r0->type == FQ_TYPE_NO_MATCH && r1->type == FQ_TYPE_NO_MATCH) { FSC.BwaUnmapped++; continue; }
+        fill_bwa_seq(slot[0], &in, &res, 2 * s, opt->mode);
+        if (se) {
+          bwa_seq_t *p = &slot[0].p;
+          FSC.TotalRetained += collector.AddAlignment(ix.bns, p, 0, opt, fout, FSC.TotalMAPQ);
+          if (bam_dump) { SamRecord R; mapper.SetSamRecord(ix.bns, p, 0, SFH, R, opt); dump_sam_record(fb, R); }
+          else bwa_print_sam1(ix.bns, p, 0, opt->mode, opt->max_top2);
+          continue;
+        }
+        fill_bwa_seq(slot[1], &in, &res, 2 * s + 1, opt->mode);
+        bwa_seq_t *p[2] = {&slot[0].p, &slot[1].p};
+        FSC.TotalRetained += collector.AddAlignment(ix.bns, p[0], p[1], opt, fout, FSC.TotalMAPQ);
+        if (bam_dump) {
+          SamRecord SR[2];
+          mapper.SetSamRecord(ix.bns, p[0], p[1], SFH, SR[0], opt);
+          mapper.SetSamRecord(ix.bns, p[1], p[0], SFH, SR[1], opt);
+          dump_sam_record(fb, SR[0]); dump_sam_record(fb, SR[1]);
+          continue;
+        }
+        bwa_print_sam1(ix.bns, p[0], p[1], opt->mode, opt->max_top2);
+        bwa_print_sam1(ix.bns, p[1], p[0], opt->mode, opt->max_top2);
+      }
+      if (n < chunk) break;
+    }
+    for (int e = 0; e < n_ends; ++e) L.fq_fastq_close(fr[e]);
+    L.fq_ctx_destroy(gctx);
+    collector.AddFSC(FSC);
+  }
+  if (fb) fclose(fb);
+  fflush(stdout);
+  fout.close();
+  collector.ProcessCore(out, opt);
+  L.fq_index_destroy(gix);
+  return 0;
+}
+
 int main(int argc, char **argv) {
-  if (argc < 2) die("usage: fq_ref_driver index|align ...");
+  if (argc < 2) die("usage: fq_ref_driver index|align|via_lib ...");
   if (!strcmp(argv[1], "index")) return cmd_index(argc, argv);
   if (!strcmp(argv[1], "align")) return cmd_align(argc, argv);
+  if (!strcmp(argv[1], "via_lib")) return cmd_via_lib(argc, argv);
   die("unknown command");
   return 2;
 }
