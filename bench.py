@@ -88,6 +88,11 @@ def main() -> None:
     from fastquick_amd import dist as fqd
     api.load_library().fq_runtime_configure(20, 1)   # hardware queues for the contexts' streams, sleeping waits (include/fastquick_amd.h)
     rank, local_rank, world = fqd.init("nccl")      # RCCL; one process per GPU
+    if world > 1 and args.stream_shard > 0 and args.mix == "wgs":
+        # the gloo group the stream tokens of the stream-shard leg travel over: new_group is a collective, so every rank creates it HERE,
+        # unconditionally and before anything rank-specific can fail (created inside that leg's try block, a rank that failed before it
+        # left the others waiting in the collective)
+        fqd.token_group()
     tuning = {kv.split("=")[0]: int(kv.split("=")[1]) for kv in args.tune.split(",") if kv}
 
     # ---- workload (seeded synthetic; the index is built once per node by rank 0) --------------------------------

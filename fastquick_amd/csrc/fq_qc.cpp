@@ -184,6 +184,8 @@ struct fq_qc {
 
   int restore(const std::string &ref_prefix);
   bool add_single(const Rec &p, const FqHostReads &hb);
+  struct MateSpan;
+  MateSpan mate_span(const Rec *R, bool placed) const;
   int pair_status(const Rec *p, const Rec *q, int type);
   struct ReadGeom;
   struct StatHist { size_t EmpRep[256] = {}, EmpCycle[256] = {}, misEmpRep[256] = {}, misEmpCycle[256] = {}; };
@@ -366,115 +368,83 @@ void fq_qc::run_stat_jobs(const FqHostReads &hb, int threads) {
   stat_jobs.clear();
 }
 
-// ProcessPairStatus, :623-921; type: 0 FirstOnly, 1 Both, 2 SecondOnly
+// ---- one .InsertSizeTable line per pair, and what it feeds: the insert-size histogram and the duplicate set -----------------------
+// (the semantics are ProcessPairStatus', src/StatCollector.cpp:623-921: the file format, the histogram and the duplicate key are fixed
+// by byte-for-byte output; the arrangement below is this file's)
+//
+// A mate as the table sees it: where its alignment starts and stops on the concatenated reference once the left soft clip is taken
+// back (32-bit arithmetic, as the reference's bwtint_t: it wraps for a hit hanging over the start), on which contig, and how much
+// room that contig leaves on the side the insert grows to.
+struct fq_qc::MateSpan {
+  const FqRead *r = nullptr;
+  const std::string *name = nullptr;
+  int contig = -1, flag = 0, clip_left = 0, clip_right = 0;
+  int64_t start = 0, stop = 0, contig_lo = 0, contig_hi = 0;
+  std::string cigar;
+  bool present() const { return r != nullptr; }
+  bool reverse() const { return r->strand != 0; }
+  // upper bound of an insert that starts at this forward mate / ends at this reverse mate; -1: the mate itself leaves the contig
+  int room() const { return reverse() ? (contig_hi >= stop ? (int)(stop - contig_lo) : -1) : (start >= contig_lo ? (int)(contig_hi - start) : -1); }
+  void columns(std::ostream &o, bool placed) const {        // contig, 1-based position, flag, length, CIGAR -- or the row of an absent / unplaced mate
+    if (placed) o << "\t" << contig_name << "\t" << (int64_t)r->pos - contig_lo + 1 << "\t" << flag << "\t" << r->len << "\t" << cigar;
+    else o << "\t*\t*\t" << flag << "\t" << 0 << "\t*";
+  }
+  const char *contig_name = "";
+};
+fq_qc::MateSpan fq_qc::mate_span(const Rec *R, bool placed) const {
+  MateSpan m;
+  if (!R) return m;
+  m.r = R->r; m.name = &R->name;
+  m.flag = m.r->extra_flag | (R->type == FQ_TYPE_NO_MATCH ? 4 : 0) | (m.r->strand ? 16 : 0);
+  if (!placed) return m;
+  fq_coor_pac2real(ix, m.r->pos, (int)(R->end() - m.r->pos), &m.contig);
+  m.contig_name = contig_name(m.contig);
+  m.contig_lo = ix->contigs[m.contig].offset; m.contig_hi = m.contig_lo + (int64_t)ix->contigs[m.contig].len;
+  if (!m.r->cigar.empty()) {
+    if ((m.r->cigar.front() >> 14) == FQ_OP_S) m.clip_left = m.r->cigar.front() & 0x3fff;
+    if ((m.r->cigar.back() >> 14) == FQ_OP_S) m.clip_right = m.r->cigar.back() & 0x3fff;
+  }
+  m.start = (int64_t)(uint32_t)(m.r->pos - (uint32_t)m.clip_left);
+  m.stop = (int64_t)(uint32_t)(m.r->pos - (uint32_t)m.clip_left + (uint32_t)m.r->len);
+  m.cigar = cigar_string(*m.r);
+  return m;
+}
+// type: 0 only the first mate is placed, 1 both, 2 only the second.  Returns 2 when the pair counts as low quality (TotalMAPQ), else 0.
 int fq_qc::pair_status(const Rec *P, const Rec *Q, int type) {
-  int maxInsert = -1, maxInsert2 = -1, seqid_p = -1, seqid_q = -1, flag1 = 0, flag2 = 0;
-  const int threshQual = 0;
-  std::string status;
-  int cl1 = 0, cl2 = 0, cl3 = 0, cl4 = 0;
-  const FqRead *p = P ? P->r : nullptr, *q = Q ? Q->r : nullptr;
-  if (p) { flag1 = p->extra_flag; if (P->type == FQ_TYPE_NO_MATCH) flag1 |= 4; if (p->strand) flag1 |= 16; }
-  if (q) { flag2 = q->extra_flag; if (Q->type == FQ_TYPE_NO_MATCH) flag2 |= 4; if (q->strand) flag2 |= 16; }
-  auto off = [&](int id) { return ix->contigs[id].offset; };
-  auto len = [&](int id) { return (int64_t)ix->contigs[id].len; };
-  auto clips = [&](const FqRead *r, int &left, int &right) {
-    if (r->cigar.empty()) return;
-    if ((r->cigar.front() >> 14) == FQ_OP_S) left = r->cigar.front() & 0x3fff;
-    if ((r->cigar.back() >> 14) == FQ_OP_S) right = r->cigar.back() & 0x3fff;
+  const MateSpan a = mate_span(P, type != 2), b = mate_span(Q, type != 0);
+  auto line = [&](const std::string &name, int lim_fwd, int lim_rev, int insert, const char *outcome) {
+    table << name << "\t" << lim_fwd << "\t" << lim_rev << "\t" << insert;
+    a.columns(table, type != 2);
+    b.columns(table, type != 0);
+    table << "\t" << outcome << std::endl;
   };
-  std::ostream &fout = table;
-  if (type == 2) {
-    fq_coor_pac2real(ix, q->pos, (int)(Q->end() - q->pos), &seqid_q);
-    const std::string cg = cigar_string(*q);
-    if (q->mapQ > threshQual) {
-      status = "RevOnly";
-      clips(q, cl3, cl4);
-      if (q->strand) {
-        if (off(seqid_q) + len(seqid_q) >= (int64_t)(uint32_t)(q->pos - (uint32_t)cl3 + (uint32_t)q->len)) maxInsert2 = (int)((int64_t)(uint32_t)(q->pos - (uint32_t)cl3 + (uint32_t)q->len) - off(seqid_q));
-        else return 2;
-      } else {
-        if ((int64_t)(uint32_t)(q->pos - cl3) >= off(seqid_q)) maxInsert = (int)(off(seqid_q) + len(seqid_q) - (int64_t)(uint32_t)(q->pos - cl3));
-        else return 2;
-        status = "FwdOnly";
-      }
-      fout << Q->name << "\t" << maxInsert << "\t" << maxInsert2 << "\t" << -1 << "\t*\t*\t" << flag1 << "\t" << 0 << "\t*\t" << contig_name(seqid_q) << "\t"
-           << (int64_t)q->pos - off(seqid_q) + 1 << "\t" << flag2 << "\t" << q->len << "\t" << cg << "\t" << status << std::endl;
-      return 0;
-    }
-    fout << Q->name << "\t" << maxInsert << "\t" << maxInsert2 << "\t" << -1 << "\t*\t*\t" << flag1 << "\t" << 0 << "\t*\t" << contig_name(seqid_q) << "\t"
-         << (int64_t)q->pos - off(seqid_q) + 1 << "\t" << flag2 << "\t" << q->len << "\t" << cg << "\tLowQual" << std::endl;
-    return 2;
+  if (type != 1) {                                  // one mate placed: its own room on its contig is all the table can say
+    const MateSpan &m = type == 0 ? a : b;
+    if (m.r->mapQ == 0) { line(*m.name, -1, -1, -1, "LowQual"); return 2; }
+    const int room = m.room();
+    if (room < 0) return 2;                         // (no line either: the reference returns before it writes one)
+    line(*m.name, m.reverse() ? -1 : room, m.reverse() ? room : -1, -1, m.reverse() ? "RevOnly" : "FwdOnly");
+    return 0;
   }
-  if (type == 0) {
-    fq_coor_pac2real(ix, p->pos, (int)(P->end() - p->pos), &seqid_p);
-    const std::string cg = cigar_string(*p);
-    if (p->mapQ > threshQual) {
-      status = "FwdOnly";
-      clips(p, cl1, cl2);
-      if (p->strand) {
-        if (off(seqid_p) + len(seqid_p) >= (int64_t)(uint32_t)(p->pos - (uint32_t)cl1 + (uint32_t)p->len)) maxInsert2 = (int)((int64_t)(uint32_t)(p->pos - (uint32_t)cl1 + (uint32_t)p->len) - off(seqid_p));
-        else return 2;
-        status = "RevOnly";
-      } else {
-        if ((int64_t)(uint32_t)(p->pos - cl1) >= off(seqid_p)) maxInsert = (int)(off(seqid_p) + len(seqid_p) - (int64_t)(uint32_t)(p->pos - cl1));
-        else return 2;
-      }
-      fout << P->name << "\t" << maxInsert << "\t" << maxInsert2 << "\t" << -1 << "\t" << contig_name(seqid_p) << "\t" << (int64_t)p->pos - off(seqid_p) + 1 << "\t"
-           << flag1 << "\t" << p->len << "\t" << cg << "\t*\t*\t" << flag2 << "\t" << 0 << "\t*\t" << status << std::endl;
-      return 0;
-    }
-    fout << P->name << "\t" << maxInsert << "\t" << maxInsert2 << "\t" << -1 << "\t" << contig_name(seqid_p) << "\t" << (int64_t)p->pos - off(seqid_p) + 1 << "\t"
-         << flag1 << "\t" << p->len << "\t" << cg << "\t*\t*\t" << flag2 << "\t" << 0 << "\t*\tLowQual" << std::endl;
-    return 2;
+  // both placed: a pair is a forward mate followed by a reverse mate
+  const MateSpan *fwd = nullptr, *rev = nullptr;
+  if (!a.reverse() && b.reverse() && a.r->pos < b.r->pos) { fwd = &a; rev = &b; }
+  else if (!b.reverse() && a.reverse() && b.r->pos < a.r->pos) { fwd = &b; rev = &a; }
+  if (!fwd) { line(*a.name, -1, -1, -1, "NotPair"); return 0; }
+  const int lim_fwd = std::min(fwd->room(), kInsertLimit - 1), lim_rev = std::min(rev->room(), kInsertLimit - 1);
+  if (a.contig != b.contig) { ++InsertDist[0]; line(*a.name, lim_fwd, lim_rev, -1, "NotPair"); return 0; }
+  if (a.r->mapQ == 0 || b.r->mapQ == 0) { line(*a.name, lim_fwd, lim_rev, -1, "LowQual"); return 2; }
+  const int start = (int)(uint32_t)fwd->start, end = (int)(uint32_t)rev->stop, insert = end - start;
+  const bool proper = lim_fwd != -1 && lim_rev != -1, unclipped = fwd->clip_left == 0 && rev->clip_right == 0;
+  if (insert >= 0 && insert < kInsertLimit) ++InsertDist[insert];   // (the reference indexes unchecked; inserts beyond the table are out of its bounds)
+  line(*a.name, lim_fwd, lim_rev, insert, proper ? "PropPair" : "PartialPair");
+  if (proper && unclipped) {                        // the duplicate key: contig and both outer ends
+    char key[1024];
+    snprintf(key, sizeof key, "%d:%d:%d", a.contig, start, end);
+    if (!dup_table.insert(std::string(key)).second) NumPCRDup += 2;
+    NumPairReads += 2;
+    if (shard) dup_log.emplace_back(key);
   }
-  // both aligned
-  fq_coor_pac2real(ix, p->pos, (int)(P->end() - p->pos), &seqid_p);
-  fq_coor_pac2real(ix, q->pos, (int)(Q->end() - q->pos), &seqid_q);
-  clips(p, cl1, cl2);
-  clips(q, cl3, cl4);
-  const std::string cgp = cigar_string(*p), cgq = cigar_string(*q);
-  auto both_line = [&](int actual, const char *st) {
-    fout << P->name << "\t" << maxInsert << "\t" << maxInsert2 << "\t" << actual << "\t" << contig_name(seqid_p) << "\t" << (int64_t)p->pos - off(seqid_p) + 1 << "\t"
-         << flag1 << "\t" << p->len << "\t" << cgp << "\t" << contig_name(seqid_q) << "\t" << (int64_t)q->pos - off(seqid_q) + 1 << "\t" << flag2 << "\t" << q->len
-         << "\t" << cgq << "\t" << st << std::endl;
-  };
-  // (positions are bwtint_t in the reference: pos - clip wraps in 32 bits before it is compared with the 64-bit offsets)
-  const int64_t pl = (int64_t)(uint32_t)(p->pos - (uint32_t)cl1), ql = (int64_t)(uint32_t)(q->pos - (uint32_t)cl3);
-  const int64_t pe = (int64_t)(uint32_t)(p->pos - (uint32_t)cl1 + (uint32_t)p->len), qe = (int64_t)(uint32_t)(q->pos - (uint32_t)cl3 + (uint32_t)q->len);
-  if (!p->strand && q->strand && p->pos < q->pos) {
-    maxInsert = pl >= off(seqid_p) ? (int)(off(seqid_p) + len(seqid_p) - pl) : -1;
-    maxInsert2 = off(seqid_q) + len(seqid_q) >= qe ? (int)(qe - off(seqid_q)) : -1;
-  } else if (!q->strand && p->strand && q->pos < p->pos) {
-    maxInsert = ql >= off(seqid_q) ? (int)(off(seqid_q) + len(seqid_q) - ql) : -1;
-    maxInsert2 = off(seqid_p) + len(seqid_p) >= pe ? (int)(pe - off(seqid_p)) : -1;
-  } else { both_line(-1, "NotPair"); return 0; }
-  if (maxInsert >= kInsertLimit) maxInsert = kInsertLimit - 1;
-  if (maxInsert2 >= kInsertLimit) maxInsert2 = kInsertLimit - 1;
-  if (seqid_p != seqid_q && seqid_p != -1 && seqid_q != -1) { ++InsertDist[0]; both_line(-1, "NotPair"); return 0; }
-  if (p->mapQ > threshQual && q->mapQ > threshQual) {
-    bool noClip = false, propPair = false;
-    int ActualInsert = -1, start = 0, end = 0;
-    status = "PartialPair";
-    if (!p->strand && q->strand && p->pos < q->pos) {
-      start = (int)(uint32_t)(p->pos - (uint32_t)cl1); end = (int)(uint32_t)(q->pos - (uint32_t)cl3 + (uint32_t)q->len);
-      ActualInsert = end - start;
-      if (cl1 == 0 && cl4 == 0) noClip = true;
-    } else if (!q->strand && p->strand && q->pos < p->pos) {
-      start = (int)(uint32_t)(q->pos - (uint32_t)cl3); end = (int)(uint32_t)(p->pos - (uint32_t)cl1 + (uint32_t)p->len);
-      ActualInsert = end - start;
-      if (cl3 == 0 && cl2 == 0) noClip = true;
-    }
-    if (maxInsert != -1 && maxInsert2 != -1) { status = "PropPair"; propPair = true; }
-    if (ActualInsert >= 0 && ActualInsert < kInsertLimit) ++InsertDist[ActualInsert];   // (the reference indexes unchecked; inserts beyond the table are out of its bounds)
-    both_line(ActualInsert, status.c_str());
-    if (propPair && noClip) {
-      char key[1024];
-      snprintf(key, sizeof key, "%d:%d:%d", seqid_p, start, end);
-      if (!dup_table.insert(std::string(key)).second) NumPCRDup += 2;
-      NumPairReads += 2;
-      if (shard) dup_log.emplace_back(key);
-    }
-  } else { both_line(-1, "LowQual"); return 2; }
   return 0;
 }
 
