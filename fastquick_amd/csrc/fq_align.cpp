@@ -155,6 +155,7 @@ struct FqKnobs {   // experiment / test knobs (fq_ctx_set_tuning); defaults are 
   int sw_wave_max = 4096;          // largest mate-SW window the wavefront kernel takes
   int host_threads = -1;           // -1: fq_opts_t::host_threads
   size_t host_par_min = 32768;     // below this many items a per-pair host phase stays on the calling thread
+  int64_t md_mask_min = 4096;      // calls with at least this many records of compact rows compare them with the reference piece-wise before MD (fq_md_mask_piece)
   int64_t packed_bulk_min = -1;    // packed batches: upload the whole body instead of gathered survivor rows from this many survivor pairs (-1: n_pairs / 8)
   int trace = 0;
 };
@@ -252,6 +253,7 @@ struct fq_ctx {
   DevBuf<uint16_t> d_cig, d_cigarena;
   DevBuf<uint8_t> d_scratch;
   DevBuf<char> d_md;
+  DevBuf<uint16_t> d_mdmask;
   // host staging
   vector<uint8_t> h_filtered;
   vector<int32_t> h_len_trim, h_sub_max;
@@ -351,6 +353,7 @@ extern "C" int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t v) {
   else if (k == "host_threads") c->kn.host_threads = (int)v;
   else if (k == "host_par_min") c->kn.host_par_min = (size_t)v;
   else if (k == "packed_bulk_min") c->kn.packed_bulk_min = v;
+  else if (k == "md_mask_min") c->kn.md_mask_min = v;
   else if (k == "trace") c->kn.trace = (int)v;
   else if (k == "gap_order_asc") t->gap_order_asc = (int)v;
   else if (k == "gap_waves_per_cu") t->gap_waves_per_cu = (int)v;
@@ -1673,6 +1676,15 @@ int stageD_refine(Call &K) {
   CKM(c->d_md.ensure(N * (size_t)md_cap + 1));
   A.seq = K.dseq; A.stride = K.dstride; A.md = c->d_md.p; A.md_cap = md_cap; A.cigs = c->d_cigs.p;
   fqdev::time_begin(FQ_K_REFINE);
+  A.mdmask = nullptr;
+  if (A.packed && (K.dstride & 15) == 0 && (int64_t)N >= c->kn.md_mask_min) {   // compact rows (device row = record index): the rows compared piece-wise first
+    const size_t per_row = (size_t)K.dstride >> 4;
+    if (N * per_row < 0x7fffffffull) {
+      CKM(c->d_mdmask.ensure(N * per_row + 8));
+      A.mdmask = c->d_mdmask.p;
+      REC(FQ_ROP_MD_MASK, N * per_row);
+    }
+  }
   REC(FQ_ROP_MD, N);
   fqdev::time_end(FQ_K_REFINE);
   return FQ_OK;

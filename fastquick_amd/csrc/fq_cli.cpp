@@ -108,6 +108,7 @@ struct Args {
   std::string devices;   // --devices: several devices, the lines of --fq_list dealt over them
   int pack_threads = std::min(32, std::max(1, fq_host_cpus()));     // host threads of the FASTQ readers (half per file) and of the packer, from the CPUs the process may use; --t sets it
   bool clean_names = false;
+  bool strict = false;   // --strict_reference: stop where the output could differ from the reference's bytes (today: QUAL of reads of unequal lengths)
   std::string fq_list, rg = "@RG\\tID:foo\\tSM:bar";   // runAlign's default --RG (src/FASTQuick.cpp:170)
   bool cal_dup = true;
   double frac = 1.0;    // --frac_samp: gap_opt_t::frac (libbwa/bwtaln.c:47), the share of the records that is kept
@@ -118,7 +119,7 @@ int usage() {
   fprintf(stderr, "Usage: FASTQuick_amd align --index_prefix P --fastq_1 R1.fq[.gz] [--fastq_2 R2.fq[.gz]] | --fq_list LIST  --out_prefix O [--sam_out] [--RG STR] [--cal_dup]\n"
                   "                       [--q INT] [--n FLOAT|INT] [--kmer_thresh INT] [--o INT] [--e INT] [--i INT] [--d INT] [--l INT] [--k INT]\n"
                   "                       [--m INT] [--R INT] [--N] [--L] [--I] [--max_isize INT] [--max_occ INT] [--is_sw] [--n_multi INT] [--N_multi INT]\n"
-                  "                       [--ap_prior FLOAT] [--force_isize] [--frac_samp FLOAT] [--t INT] [--chunk_pairs INT] [--batch_pairs INT] [--device INT | --devices LIST] [--read_len INT] [--clean_names]\n"
+                  "                       [--ap_prior FLOAT] [--force_isize] [--frac_samp FLOAT] [--t INT] [--chunk_pairs INT] [--batch_pairs INT] [--device INT | --devices LIST] [--read_len INT] [--clean_names] [--strict_reference]\n"
                   "       FASTQuick_amd index --ref REDUCED.FASTQuick.fa [--rollhash]\n");
   return 1;
 }
@@ -168,6 +169,15 @@ void append_file(const std::string &path, FILE *to, fq_bam_t *bam) {   // a part
   remove(path.c_str());
 }
 
+// The one column of the reference's output that is not reproduced: said loudly, or refused.
+void unequal_lengths_notice(const Args &A, const fq_fastq_t *a, const fq_fastq_t *b) {
+  if (!fq_fastq_unequal_lengths(a) && !(b && fq_fastq_unequal_lengths(b))) return;
+  const char *msg = "reads of unequal lengths: the reference prints the QUAL column of a read that follows a longer read in its read slot with that read's "
+                    "tail behind it (an unterminated buffer: src/BwtMapper.cpp:549-558, libbwa/bwase.c:401; longer than SEQ, not valid SAM); here QUAL has "
+                    "the read's own length -- every other column, and every QC file, is the reference's";
+  if (A.strict) die(std::string("--strict_reference: ") + msg);
+  fprintf(stderr, "WARNING - %s\n", msg);
+}
 // One FASTQ pair (or one single-end file) through a device: an independent stream -- its own context (srand48, last_ii, position cache)
 // and read slots, as PairEndMapper / SingleEndMapper set them up per call (src/BwtMapper.cpp:232-262).
 // FASTQ front end: one reader thread per file tokenises the next chunk into flat buffers while the device aligns the current
@@ -323,6 +333,7 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
     if (last) break;
   }
   out.flush();
+  unequal_lengths_notice(A, r1.h, r2.h);
   notice("%lld sequences are loaded.", num_read);
   notice("%lld sequences are filtered.", filtered * 2);
   notice("%lld sequences are unmapped.", unmapped * 2);
@@ -389,6 +400,7 @@ int main(int argc, char **argv) {
     else if (f == "--chunk_pairs") A.chunk_pairs = atoll(need(""));
     else if (f == "--read_len") A.read_len = atoi(need(""));
     else if (f == "--clean_names") A.clean_names = true;
+    else if (f == "--strict_reference") A.strict = true;
     else if (f == "--batch_pairs") A.o.batch_pairs = atoi(need(""));   // READ_BUFFER_SIZE of the run to reproduce (default 262144)
     else if (f == "--device") A.device = atoi(need(""));
     else if (f == "--devices") A.devices = need("");
@@ -401,6 +413,10 @@ int main(int argc, char **argv) {
   }
   if (A.o.fnr >= 1.0) { A.o.max_diff = (int)A.o.fnr; A.o.fnr = -1.0; }                  // src/FASTQuick.cpp:312-315
   if (A.opte > 0) { A.o.max_gape = A.opte; A.o.mode &= ~1; }                             // :316-319
+  // The reference re-allocates a read slot when a read longer than read_len arrives (src/BwtMapper.cpp:536-546).  That read then fills the
+  // whole slot, so with read_len >= 96 -- the reference's own value is 151 -- nothing an earlier read left can reach the 96-base window the
+  // read filter looks at, and the re-allocation is invisible; a smaller --read_len would make it visible, and is refused.
+  if (A.read_len < 96) die("--read_len must be at least 96 (the reference's is 151): below that its slot re-allocation (src/BwtMapper.cpp:536-546) would show in the read filter, and it is not modelled");
   if (A.out_prefix == "Empty") die("--out_prefix is required");
   if (A.index_prefix == "Empty") die("--index_prefix is required");
   // --fq_list: one FASTQ pair per line, '#' lines skipped (src/BwtMapper.cpp:232-262); every pair is an independent stream

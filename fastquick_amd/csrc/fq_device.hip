@@ -403,6 +403,7 @@ __global__ void __launch_bounds__(256) k_saq(FqSaQueryArgs a) {
   const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < a.n) fq_saq_thread(a, q);
 }
+template <bool PACKED>
 __device__ int fq_global_align_wave(const uint8_t *s1, int len1, const uint8_t *s2, int len2, int band, int gap_end,
                                     int *RM, int *RI, int *RD, uint8_t *trace, uint8_t *ops, int *n_ops, int *fi, int *fj);
 // ---- mate-rescue Smith-Waterman: one 64-lane wavefront per task ---------------------------------------------
@@ -493,7 +494,7 @@ __global__ void __launch_bounds__(64) k_sw_wave(FqSwArgs a) {
   int n_ops = 0, fi = 0, fj = 0, score_g;
   const int jmax = (best_i - start_i > best_j - start_j ? best_i - start_i : best_j - start_j) + 1;
   for (int b = FQ_BAND;; b <<= 1) {   // doubling band (stdaln.c:705-716)
-    score_g = fq_global_align_wave(ref + start_i - 1, best_i - start_i + 1, qry + start_j - 1, best_j - start_j + 1, b, -1, rM, rI, rD, trace, ops, &n_ops, &fi, &fj);
+    score_g = fq_global_align_wave<false>(ref + start_i - 1, best_i - start_i + 1, qry + start_j - 1, best_j - start_j + 1, b, -1, rM, rI, rD, trace, ops, &n_ops, &fi, &fj);
     if (score_g == score_r || best_h == score_g) break;
     if (b > jmax) break;
   }
@@ -519,6 +520,15 @@ __global__ void __launch_bounds__(64) k_refine_lds(FqRefineArgs a) {
 // updates in place.  A row's first position (column 0 in phases 1/5, column j-b2 otherwise) is the serial code's "left"
 // initialisation.  Values of the row above outside its band are never consumed (the i == hi rules of each phase).  The
 // traceback is serial (lane 0, out of LDS).  Block = one wavefront.
+// PACKED: the trace matrix holds two cells per byte (a cell's trace is four bits; a row's cells are written by one lane, left to
+// right, so the lane keeps the low half of a byte until its neighbour arrives): the refine kernel's LDS drops from 27 to 15 KB per
+// wavefront, twice the wavefronts per CU -- the kernel is bound by the issue of dependent instructions, which more wavefronts per SIMD hide.
+template <bool PACKED>
+__device__ __forceinline__ uint8_t fq_trace_get(const uint8_t *trace, int W, int j, int i) {
+  if (!PACKED) return trace[(size_t)j * W + i];
+  return (uint8_t)((trace[(size_t)j * ((W + 1) >> 1) + (i >> 1)] >> (4 * (i & 1))) & 15);
+}
+template <bool PACKED>
 __device__ int fq_global_align_wave(const uint8_t *s1, int len1, const uint8_t *s2, int len2, int band, int gap_end,
                                     int *RM, int *RI, int *RD, uint8_t *trace, uint8_t *ops, int *n_ops, int *fi, int *fj) {
   const int lane = threadIdx.x;
@@ -535,7 +545,8 @@ __device__ int fq_global_align_wave(const uint8_t *s1, int len1, const uint8_t *
     RM[0] = 0; RI[0] = RD[0] = FQ_NEG_INF;
     for (int i = 1; i < b1; ++i) {
       const int d = fq_pick_gap(lM, lD, end_ext, fm);
-      trace[i] = (uint8_t)(fm ? 0 : 8);
+      if (PACKED) { uint8_t *b = trace + (i >> 1); *b = (uint8_t)((i & 1) ? ((*b & 15) | ((fm ? 0 : 8) << 4)) : (fm ? 0 : 8)); }
+      else trace[i] = (uint8_t)(fm ? 0 : 8);
       RM[i] = RI[i] = FQ_NEG_INF; RD[i] = d;
       lM = FQ_NEG_INF; lD = d;
     }
@@ -556,7 +567,8 @@ __device__ int fq_global_align_wave(const uint8_t *s1, int len1, const uint8_t *
     const int hi = !row_on ? -1 : p15 ? ((j + b1 <= len1 + 1) ? j + b1 - 1 : len1) : (phase == 2 ? j + b1 - 1 : len1);
     const int c2 = row_on ? s2[j - 1] : 0;
     const bool keeps_row = row_on && (lane == 63 || j == len2);
-    uint8_t *tr = trace + (size_t)j * (size_t)W;
+    uint8_t *tr = trace + (size_t)j * (size_t)(PACKED ? (W + 1) >> 1 : W);
+    uint32_t half = 0;      // PACKED: the trace of this row's last even column
     const int n_rows = len2 - j0 + 1 < 64 ? len2 - j0 + 1 : 64;
     const int t0 = __shfl(c0, 0), t1 = len1 + n_rows - 1;
     int oM = 0, oI = 0, oD = 0;
@@ -572,7 +584,11 @@ __device__ int fq_global_align_wave(const uint8_t *s1, int len1, const uint8_t *
         uint8_t fm;
         if (i == c0) {
           c.M = c.I = c.D = FQ_NEG_INF;
-          if (p15) { c.I = fq_pick_gap(up.M, up.I, end_ext, fm); tr[0] = (uint8_t)(fm ? 0 : 4); }
+          uint8_t tb0 = 0;
+          if (p15) { c.I = fq_pick_gap(up.M, up.I, end_ext, fm); tb0 = (uint8_t)(fm ? 0 : 4); }
+          if (!PACKED) { if (p15) tr[0] = tb0; }
+          else if (i & 1) tr[i >> 1] = (uint8_t)(tb0 << 4);      // (a row that starts at an odd column: the low half belongs to no cell of it)
+          else { half = tb0; tr[i >> 1] = tb0; }
         } else {
           uint8_t tM, tb;
           c.M = fq_pick_M(diag, fq_sm_maq(s1[i - 1], c2), tM);
@@ -585,7 +601,9 @@ __device__ int fq_global_align_wave(const uint8_t *s1, int len1, const uint8_t *
           else { c.I = fq_pick_gap(up.M, up.I, end_ext, fm); tb |= (uint8_t)(fm ? 0 : 4); }
           c.D = fq_pick_gap(left.M, left.D, endD ? end_ext : FQ_GAP_E, fm);
           tb |= (uint8_t)(fm ? 0 : 8);
-          tr[i] = tb;
+          if (!PACKED) tr[i] = tb;
+          else if (i & 1) tr[i >> 1] = (uint8_t)(half | (uint32_t)tb << 4);
+          else { half = tb; tr[i >> 1] = tb; }
         }
         diag = up; left = c;
         oM = c.M; oI = c.I; oD = c.D;
@@ -599,7 +617,7 @@ __device__ int fq_global_align_wave(const uint8_t *s1, int len1, const uint8_t *
   if (lane == 0) {
     int i = len1, j = len2;
     mx = RM[len1];
-    uint8_t tb = trace[(size_t)j * W + i];
+    uint8_t tb = fq_trace_get<PACKED>(trace, W, j, i);
     int type = tb & 3, ctype = FQ_OP_M;
     if (RI[len1] > mx) { mx = RI[len1]; type = (tb & 4) ? FQ_OP_I : FQ_OP_M; ctype = FQ_OP_I; }
     if (RD[len1] > mx) { mx = RD[len1]; type = (tb & 8) ? FQ_OP_D : FQ_OP_M; ctype = FQ_OP_D; }
@@ -608,7 +626,7 @@ __device__ int fq_global_align_wave(const uint8_t *s1, int len1, const uint8_t *
     do {
       if (ctype == FQ_OP_M) { --i; --j; } else if (ctype == FQ_OP_I) --j; else --i;
       ctype = type;
-      tb = trace[(size_t)j * W + i];
+      tb = fq_trace_get<PACKED>(trace, W, j, i);
       type = type == FQ_OP_M ? (tb & 3) : type == FQ_OP_I ? ((tb & 4) ? FQ_OP_I : FQ_OP_M) : ((tb & 8) ? FQ_OP_D : FQ_OP_M);
       if (i || j) { ops[n++] = (uint8_t)ctype; li = i; lj = j; }
     } while (i || j);
@@ -640,7 +658,7 @@ __global__ void __launch_bounds__(64) k_refine_wave(FqRefineArgs a) {
   for (int k = lane; k < l; k += 64) ref[k] = (uint8_t)fq_pac_base(a.ix.pac, k0 + k);
   __syncthreads();
   int n_ops = 0, fi, fj;
-  fq_global_align_wave(ref, l, qry, len, FQ_BAND, FQ_GAP_END, RM, RI, RD, trace, ops, &n_ops, &fi, &fj);
+  fq_global_align_wave<true>(ref, l, qry, len, FQ_BAND, FQ_GAP_END, RM, RI, RD, trace, ops, &n_ops, &fi, &fj);
   if (lane != 0) return;
   uint16_t *cg = a.cigar + (size_t)t * (size_t)a.cig_cap;
   int n = fq_ops_to_cigar(ops, n_ops, cg, a.cig_cap);
@@ -1148,7 +1166,7 @@ int launch_refine(const FqRefineArgs &a) {
   if (a.n_task <= 0) return 0;
   // one task per wavefront while row arrays + sequences + trace matrix fit in LDS with several blocks per CU; longer reads
   // fall back to one task per lane
-  const size_t wave_lds = (size_t)3 * (a.RL + 1) * 4 + ((a.RL + 16) & ~15) + ((a.QL + 16) & ~15) + ((a.RL + a.QL + 16) & ~15) + (size_t)(a.RL + 1) * (a.QL + 1) + 16;
+  const size_t wave_lds = (size_t)3 * (a.RL + 1) * 4 + ((a.RL + 16) & ~15) + ((a.QL + 16) & ~15) + ((a.RL + a.QL + 16) & ~15) + (size_t)((a.RL + 2) >> 1) * (a.QL + 1) + 16;   // (trace: two cells per byte)
   const bool no_wave = g_cur->tune.refine_lanes != 0;   // test knob: force the lane-per-task kernels
   hipEvent_t e0, e1;
   kernel_events(FQ_K_REFINE_KERNEL, &e0, &e1);
@@ -1206,6 +1224,7 @@ FQ_REC_KERNEL(k_ref_count, fq_ref_count_thread)
 FQ_REC_KERNEL(k_ref_fill, fq_ref_fill_thread)
 FQ_REC_KERNEL(k_ref_apply, fq_ref_apply_thread)
 FQ_REC_KERNEL(k_md_rec, fq_md_rec_thread)
+FQ_REC_KERNEL(k_md_mask, fq_md_mask_piece)
 FQ_REC_KERNEL(k_flat_count, fq_flat_count_thread)
 FQ_REC_KERNEL(k_flat_fill, fq_flat_fill_thread)
 int launch_rec(int op, const FqRecArgs &a, int64_t n) {
@@ -1215,10 +1234,10 @@ int launch_rec(int op, const FqRecArgs &a, int64_t n) {
   typedef void (*Kern)(FqRecArgs, int);
   static const Kern kerns[FQ_ROP_COUNT] = {k_rec_init, k_rec_nocc, k_enum_plan, k_enum_fill, k_main_hit, k_compact_idx, k_pair_rec, k_pair_gather, k_pair_scatter,
                                            k_xa_count, k_xa_fill, k_sw_plan, k_sw_fill, k_rec_gather, k_rec_scatter, k_ref_count, k_ref_fill, k_ref_apply,
-                                           k_md_rec, k_flat_count, k_flat_fill};
+                                           k_md_rec, k_md_mask, k_flat_count, k_flat_fill};
   if (op < 0 || op >= FQ_ROP_COUNT) { g_err = "record stage: unknown operation"; return -1; }
   hipEvent_t e0, e1;
-  kernel_events(op == FQ_ROP_MD ? FQ_K_MD_KERNEL : FQ_K_REC_KERNEL, &e0, &e1);
+  kernel_events(op == FQ_ROP_MD || op == FQ_ROP_MD_MASK ? FQ_K_MD_KERNEL : FQ_K_REC_KERNEL, &e0, &e1);
   hipExtLaunchKernelGGL(kerns[op], dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
   FQ_HIP(hipGetLastError());
   return 0;

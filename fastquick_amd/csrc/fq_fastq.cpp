@@ -87,6 +87,8 @@ struct fq_fastq {
   int slot_mode = FQ_FASTQ_SLOTS_REUSED;
   std::vector<std::string> slot_name[2];
   std::vector<uint8_t> slot_base[2];
+  std::vector<uint16_t> slot_len[2];      // longest read the slot has held
+  std::atomic<int> shorter_after_longer{0};   // a read came to a slot that has held a longer one (fq_fastq_unequal_lengths)
   long long records_seen = 0;
   // ---- --frac_samp (src/BwtMapper.cpp:483, 500-507): every reference batch draws from Random(seed = the batch's number) -- the
   //      Mersenne twister of VerifyBamID/Random.cpp, Next() = (y + 0.5) / 2^32 -- one number per record met; a record whose number is
@@ -291,6 +293,9 @@ void slot_apply(fq_fastq *r, const fq_fastq_rows_t *o, int64_t row, long long g)
   uint8_t *sr = o->seq + (size_t)row * (size_t)o->stride;
   const size_t n = (size_t)o->len[row];
   uint8_t *h = &r->slot_base[set][slot * 96];
+  uint16_t &longest = r->slot_len[set][slot];
+  if (n < longest) r->shorter_after_longer.store(1, std::memory_order_relaxed);
+  else longest = (uint16_t)std::min<size_t>(n, 65535);
   for (size_t i = n; i < 96 && i < (size_t)o->stride; ++i) sr[i] = h[i];
   memcpy(h, sr, std::min<size_t>(n, 96));
   if (r->slot_mode == FQ_FASTQ_SLOTS_CLEAN_NAMES) { if (mate_suffix) memset(nr + l - 2, 0, 2); return; }
@@ -447,6 +452,7 @@ extern "C" int fq_fastq_set_sampling(fq_fastq_t *r, double frac) {
   r->frac = frac;
   return FQ_OK;
 }
+extern "C" int fq_fastq_unequal_lengths(const fq_fastq_t *r) { return r ? r->shorter_after_longer.load(std::memory_order_relaxed) : 0; }
 extern "C" const char *fq_fastq_dropped_record(const fq_fastq_t *r) { return r && r->notice_dropped ? r->dropped_name.c_str() : nullptr; }
 
 extern "C" int64_t fq_fastq_read(fq_fastq_t *r, int64_t max_reads, const fq_fastq_rows_t *o) {
@@ -456,6 +462,7 @@ extern "C" int64_t fq_fastq_read(fq_fastq_t *r, int64_t max_reads, const fq_fast
   if (r->slot_mode != FQ_FASTQ_SLOTS_FRESH) {
     for (int s = 0; s < 2; ++s) {
       if (r->slot_base[s].empty()) r->slot_base[s].assign((size_t)r->batch_pairs * 96, 0);
+      if (r->slot_len[s].empty()) r->slot_len[s].assign((size_t)r->batch_pairs, 0);
       if (r->slot_mode == FQ_FASTQ_SLOTS_REUSED && r->slot_name[s].empty()) r->slot_name[s].resize((size_t)r->batch_pairs);
     }
   }

@@ -103,6 +103,7 @@ struct FqRecArgs {
   // MD
   const uint8_t *seq; int32_t stride;
   char *md; int32_t md_cap;
+  uint16_t *mdmask;              // [2 n_surv][stride / 16] mismatch bits of ungapped reads (NULL: every read walks its row)
   // flatten
   uint32_t *fc_cnt, *fm_cnt, *fx_cnt;          // [2 n_surv] CIGAR entries, MD bytes, XA entries of a record
   const uint64_t *fc_off, *fm_off, *fx_off;
@@ -495,8 +496,8 @@ FQ_HD void fq_ref_fill_thread(const FqRecArgs &A, int idx) {
     A.reftask[t] = T; A.reftgt[t] = g;
     if (s.len + s.n_gapo + s.n_gape > max_ref) max_ref = s.len + s.n_gapo + s.n_gape;
   }
-  FQ_ATOMIC_MAX32(&A.ref_max[0], max_ref);
-  FQ_ATOMIC_MAX32(&A.ref_max[1], (int)s.len);
+  if (max_ref > FQ_LOAD_RELAXED(&A.ref_max[0])) FQ_ATOMIC_MAX32(&A.ref_max[0], max_ref);     // (almost every lane finds the maximum in place already)
+  if ((int)s.len > FQ_LOAD_RELAXED(&A.ref_max[1])) FQ_ATOMIC_MAX32(&A.ref_max[1], (int)s.len);
 }
 FQ_HD void fq_ref_apply_thread(const FqRecArgs &A, int t) {   // a task owns its record's field
   const FqRefOut O = A.refout[t];
@@ -513,9 +514,58 @@ FQ_HD void fq_ref_apply_thread(const FqRecArgs &A, int t) {   // a task owns its
 }
 
 // ---- MD / NM of every mapped read (bwa_cal_md1), straight from the records ------------------------------------------------------
+// Almost every read is ungapped, and a thread that walks its own 150-byte row touches a cache line per lane and load.  So the rows
+// are compared with the reference by one thread per 16-base piece (consecutive threads, consecutive 16-byte loads: whole lines), which
+// leaves one mismatch bit per base; the read's thread then only visits the set bits.  (Compact rows only: device row = record index.)
+FQ_HD void fq_md_mask_piece(const FqRecArgs &A, int g) {
+  const int per_row = A.stride >> 4;
+  const int idx = g / per_row, cidx = g - idx * per_row;
+  const FqDRec s = A.rec[idx];
+  uint32_t m = 0;
+  const int slen = s.len, j0 = 16 * cidx;
+  if (s.type != FQ_TYPE_NO_MATCH && s.n_cigar == 0 && j0 < slen) {
+    const FqU4 v = *(const FqU4 *)(A.seq + (size_t)idx * (size_t)A.stride + (size_t)j0);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int jj = j0 + j;
+      if (jj < slen) {
+        const int code = (int)fq_nt4_fast((w[j >> 2] >> (8 * (j & 3))) & 0xffu);
+        const int sc = s.strand ? fq_comp(code) : code;
+        const int c = fq_pac_base(A.ix.pac, (int64_t)(uint32_t)(s.pos + (uint32_t)(s.strand ? slen - 1 - jj : jj)));
+        if (sc > 3 || c != sc) m |= 1u << j;
+      }
+    }
+  }
+  A.mdmask[g] = (uint16_t)m;
+}
 FQ_HD void fq_md_rec_thread(const FqRecArgs &A, int idx) {
   FqDRec s = A.rec[idx];
   if (s.type == FQ_TYPE_NO_MATCH) return;
+  if (A.mdmask && s.n_cigar == 0) {             // ungapped, mismatch bits ready: <matches><ref base><matches>... in alignment order
+    const int per_row = A.stride >> 4, slen = s.len, cap = A.md_cap - 1;
+    const uint16_t *mk = A.mdmask + (size_t)idx * (size_t)per_row;
+    char *dst = A.md + (size_t)idx * (size_t)A.md_cap;
+    int at = 0, nm = 0, prev = -1;
+    for (int t = 0; t < per_row; ++t) {
+      const int cidx = s.strand ? per_row - 1 - t : t;
+      uint32_t m = mk[cidx];
+      while (m) {
+        const int b = s.strand ? 31 - __builtin_clz(m) : FQ_CTZ32(m);
+        m &= ~(1u << b);
+        const int jj = 16 * cidx + b, yy = s.strand ? slen - 1 - jj : jj;
+        at = fq_put_int(dst, at, cap, yy - prev - 1);
+        if (at < cap) dst[at] = "ACGTN"[fq_pac_base(A.ix.pac, (int64_t)(uint32_t)(s.pos + (uint32_t)yy))];
+        ++at; ++nm; prev = yy;
+      }
+    }
+    at = fq_put_int(dst, at, cap, slen - 1 - prev);
+    if (at > cap) { FQ_ATOMIC_ADD64(&A.counters[FQ_C_ERR_MD], 1); at = 0; }
+    s.has_md = 1; s.md_len = at; s.nm = (uint16_t)(nm & 0xfff);
+    A.rec[idx] = s;
+    FQ_WAVE_COUNT(&A.counters[FQ_C_MD_READS], true);
+    return;
+  }
   FqMdTask T;
   T.read = fq_rec_row(A, idx); T.strand = s.strand; T.pos = s.pos; T.n_cigar = s.n_cigar; T.cigar_off = s.cig_off; T.len = s.len;
   int at = 0, nm = 0;
@@ -614,5 +664,5 @@ FQ_HD void fq_aln_index_thread(const int32_t *work, const uint32_t *status, cons
 enum {
   FQ_ROP_INIT = 0, FQ_ROP_NOCC, FQ_ROP_ENUM_PLAN, FQ_ROP_ENUM_FILL, FQ_ROP_MAIN_HIT, FQ_ROP_COMPACT, FQ_ROP_PAIR, FQ_ROP_PAIR_GATHER, FQ_ROP_PAIR_SCATTER,
   FQ_ROP_XA_COUNT, FQ_ROP_XA_FILL, FQ_ROP_SW_PLAN, FQ_ROP_SW_FILL, FQ_ROP_REC_GATHER, FQ_ROP_REC_SCATTER, FQ_ROP_REF_COUNT, FQ_ROP_REF_FILL, FQ_ROP_REF_APPLY,
-  FQ_ROP_MD, FQ_ROP_FLAT_COUNT, FQ_ROP_FLAT_FILL, FQ_ROP_COUNT
+  FQ_ROP_MD, FQ_ROP_MD_MASK, FQ_ROP_FLAT_COUNT, FQ_ROP_FLAT_FILL, FQ_ROP_COUNT
 };

@@ -269,6 +269,11 @@ int64_t fq_fastq_read(fq_fastq_t *r, int64_t max_reads, const fq_fastq_rows_t *r
 const char *fq_fastq_last_error(const fq_fastq_t *r);
 /* name of a last record without line end behind its quality string, which the reference's reader does not return (NULL: none) */
 const char *fq_fastq_dropped_record(const fq_fastq_t *r);
+/* 1 once a record has come to a read slot that held a longer read before (slot modes REUSED / CLEAN_NAMES).  The reference prints
+ * QUAL as a C string out of the slot's unterminated buffer (src/BwtMapper.cpp:549-558, libbwa/bwase.c:401): such a record's QUAL column
+ * carries the tail of the longer read (longer than SEQ: not valid SAM) -- the one column of its output this library does not
+ * reproduce (QUAL always has the read's length); a caller that promises the reference's bytes warns or stops on it. */
+int fq_fastq_unequal_lengths(const fq_fastq_t *r);
 int fq_fastq_is_bgzf(const fq_fastq_t *r);
 void fq_fastq_close(fq_fastq_t *r);
 

@@ -140,7 +140,7 @@ int launch_rec(int op, const FqRecArgs &a, int64_t n) {
   typedef void (*Body)(const FqRecArgs &, int);
   static const Body bodies[FQ_ROP_COUNT] = {fq_rec_init_thread, fq_rec_nocc_thread, fq_enum_plan_thread, fq_enum_fill_thread, fq_main_hit_thread, fq_compact_thread, fq_pair_rec_thread,
                                             fq_pair_gather_thread, fq_pair_scatter_thread, fq_xa_count_thread, fq_xa_fill_thread, fq_sw_plan_thread, fq_sw_fill_thread, fq_rec_gather_thread,
-                                            fq_rec_scatter_thread, fq_ref_count_thread, fq_ref_fill_thread, fq_ref_apply_thread, fq_md_rec_thread, fq_flat_count_thread, fq_flat_fill_thread};
+                                            fq_rec_scatter_thread, fq_ref_count_thread, fq_ref_fill_thread, fq_ref_apply_thread, fq_md_rec_thread, fq_md_mask_piece, fq_flat_count_thread, fq_flat_fill_thread};
   if (op < 0 || op >= FQ_ROP_COUNT) return -1;
   for (int64_t i = 0; i < n; ++i) bodies[op](a, (int)i);
   return 0;

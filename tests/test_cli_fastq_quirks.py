@@ -130,8 +130,23 @@ def test_cli_tokenizer_matches_reference_reader(variant, golden_cases, emu_cli, 
         assert cols(run.stdout) == cols(want)
         assert all(len(f[9]) == len(f[10]) for f in (ln.split(b"\t") for ln in run.stdout.split(b"\n")) if len(f) > 10)
         assert any(len(f[9]) != len(f[10]) for f in (ln.split(b"\t") for ln in want.split(b"\n")) if len(f) > 10)
+        # ... and the command line says so, loudly; with --strict_reference it stops instead (the fence was silent)
+        assert b"WARNING - reads of unequal lengths" in run.stderr
+        strict = subprocess.run(cmd + ["--strict_reference"], stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert strict.returncode != 0 and b"--strict_reference: reads of unequal lengths" in strict.stderr
         return
     assert run.stdout == want
+    assert b"WARNING - reads of unequal lengths" not in run.stderr, "reads of one length: nothing to warn about"
+
+
+def test_cli_refuses_a_read_len_that_would_expose_slot_reallocation(golden_cases, emu_cli, tmp_path):
+    """The other fence (src/BwtMapper.cpp:536-546: a read longer than read_len makes the reference re-allocate its slot): invisible while
+    read_len >= 96, the read filter's window -- the reference's own value is 151 -- and refused below that."""
+    g = golden_cases["basic"]
+    cmd = [emu_cli, "align", "--index_prefix", g["prefix"][:-len(".FASTQuick.fa")], "--fastq_1", g["fq1"], "--fastq_2", g["fq2"],
+           "--out_prefix", str(tmp_path / "cli"), "--sam_out", "--read_len", "80"]
+    run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert run.returncode != 0 and b"--read_len must be at least 96" in run.stderr
 
 
 def test_cli_fq_list_runs_every_pair_as_its_own_stream(golden_cases, emu_cli, tmp_path):

@@ -29,7 +29,7 @@ SEARCH_MODES = {"lanes": {}, "wave1": {"gap_long_pops": 1, "gap_long_always": 1}
                 "wave64": {"gap_long_pops": 64, "gap_long_always": 1, "sw_wave_max": 300},
                 # the packed-batch boundary (fq_pack_reads -> fq_packed_prefetch -> fq_align_packed): survivors' rows gathered on the
                 # host / the whole body uploaded and gathered on the device
-                "packed": {"packed_bulk_min": 1 << 30}, "packed_bulk": {"packed_bulk_min": 0},
+                "packed": {"packed_bulk_min": 1 << 30, "md_mask_min": 0}, "packed_bulk": {"packed_bulk_min": 0, "md_mask_min": 0},
                 # every launch begins with the round that searches without gap children, as device-filling launches do
                 "nogap": {"gap_nogap_min": 0},
                 # ... with the kernels that read the options from the launch instead of the ones compiled for FASTQuick's own option block

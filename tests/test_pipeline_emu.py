@@ -31,7 +31,7 @@ def test_emulated_pipeline_matches_reference_golden(tag, mode, golden_cases, emu
     if mode == "threads":   # the per-pair host phases split over threads even for these small inputs
         tuning = {"host_par_min": 1}
     if mode == "packed_bulk":   # packed input with the whole body uploaded and gathered on the device (many survivors)
-        tuning = {"packed_bulk_min": 0}
+        tuning = {"packed_bulk_min": 0, "md_mask_min": 0}      # (and the rows compared with the reference piece-wise before MD, as large calls do)
     if mode == "nogap":         # every launch begins with the round that searches without gap children (device-filling launches do)
         tuning = {"gap_nogap_min": 0}
     if mode == "generic_opts":  # ... with the search kernels that read the options from the launch (the default ones are compiled for FASTQuick's option block)
@@ -39,7 +39,7 @@ def test_emulated_pipeline_matches_reference_golden(tag, mode, golden_cases, emu
     if mode == "pipeline":      # ... in segments, each segment's second round issued beside the next segment's first (large calls do)
         tuning = {"gap_nogap_min": 0, "gap_pipeline_min": 0, "gap_pipeline_segs": 3}
     if mode == "packed":        # ... with the survivors' rows gathered on the host (few survivors)
-        tuning = {"packed_bulk_min": 1 << 30}
+        tuning = {"packed_bulk_min": 1 << 30, "md_mask_min": 0}
     g = golden_cases[tag]
     names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
     ix = api.Index(g["prefix"], lib=emu_lib)
