@@ -15,6 +15,7 @@
 #include <condition_variable>
 #include <chrono>
 #include <cstdio>
+#include <map>
 #include <memory>
 #include <cstdlib>
 #include <cstring>
@@ -346,6 +347,182 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
   fq_ctx_destroy(ctx);
   fq_packed_free(pk);
   }
+
+// ---- ONE FASTQ pair over several devices: chunks of whole reference batches are dealt round-robin; every device runs filter,
+//      search and SA walks of its chunk at once; the stream's order-dependent state -- the drand48 stream (srand48 once per FASTQ pair,
+//      src/BwtMapper.cpp:1817), last_ii (:780-781), the (k,l) cache (:815-843) -- goes from the context that owns chunk b to the one that
+//      owns b + 1 around the short serial part of each call (fq_ctx_set_serial_hooks / fq_ctx_state_export / _import).  The records come
+//      out in chunk order through one writer; every chunk's StatCollector state is a segment, merged in order.
+struct ShardRun {
+  std::mutex mu;
+  std::condition_variable cv;
+  struct Chunk { RawBuf<uint8_t> seq, qual; EndChunk e[2]; std::vector<int32_t> len; int n = 0; long long index = -1; };   // index: -1 free, -2 being read
+  std::vector<Chunk> slots;
+  long long n_chunks = -1;                 // known once the reader has seen the end
+  long long token_of = -1;                 // the stream's state after chunk token_of
+  std::vector<char> token;
+  struct Result { std::string sam; std::vector<char> bam, qc; long long pairs = 0, filtered = 0, unmapped = 0; };
+  std::map<long long, Result> results;
+};
+struct ShardHook { ShardRun *run; fq_ctx_t *ctx; long long b; };
+void shard_before(void *u) {
+  ShardHook *h = (ShardHook *)u;
+  if (h->b == 0) return;
+  std::unique_lock<std::mutex> lk(h->run->mu);
+  h->run->cv.wait(lk, [&] { return h->run->token_of == h->b - 1; });
+  if (fq_ctx_state_import(h->ctx, h->run->token.data(), (int64_t)h->run->token.size())) fq_ctx_mark_stream_broken(h->ctx);
+}
+void shard_after(void *u) {
+  ShardHook *h = (ShardHook *)u;
+  const int64_t need = fq_ctx_state_export(h->ctx, nullptr, 0);
+  std::vector<char> t((size_t)std::max<int64_t>(need, 0));
+  if (need > 0) fq_ctx_state_export(h->ctx, t.data(), need);
+  { std::lock_guard<std::mutex> lk(h->run->mu); h->run->token.swap(t); h->run->token_of = h->b; }
+  h->run->cv.notify_all();
+}
+template <class W>
+void align_pair_sharded(const Args &A, const std::pair<std::string, std::string> &input, std::vector<W> &wk, FILE *sam_fp, fq_bam_t *bam, fq_qc_t *qc) {
+  const size_t NW = wk.size();
+  fprintf(stderr, "NOTICE - Processing Pair End mapping on %zu devices\t%s\t%s\n", NW, input.first.c_str(), input.second.c_str());
+  const int slot_mode = A.clean_names ? FQ_FASTQ_SLOTS_CLEAN_NAMES : FQ_FASTQ_SLOTS_REUSED;
+  FastqReader r1(input.first, std::max(1, A.pack_threads / 2), A.o.batch_pairs, slot_mode, A.frac), r2(input.second, std::max(1, A.pack_threads / 2), A.o.batch_pairs, slot_mode, A.frac);
+  int stride = 0;
+  {
+    size_t l = 0;
+    struct stat s1, s2;
+    if (stat(input.first.c_str(), &s1) == 0 && S_ISREG(s1.st_mode) && stat(input.second.c_str(), &s2) == 0 && S_ISREG(s2.st_mode))
+      l = std::max(first_read_len(input.first), first_read_len(input.second));
+    stride = (int)((std::max<size_t>(l, (size_t)std::max(A.read_len, 16)) + 15) & ~(size_t)15);
+  }
+  const int name_stride = 304;
+  ShardRun R;
+  R.slots.resize(NW + 1);
+  for (auto &c : R.slots) {
+    c.seq.resize((size_t)2 * A.chunk_pairs * stride); c.qual.resize((size_t)2 * A.chunk_pairs * stride);
+    for (int e = 0; e < 2; ++e) { c.e[e].ext_seq = c.seq.data() + (size_t)e * A.chunk_pairs * stride; c.e[e].ext_qual = c.qual.data() + (size_t)e * A.chunk_pairs * stride; }
+  }
+  if (qc) fq_qc_begin_file(qc, input.first.c_str(), input.second.c_str());
+  // the reader: chunks in file order into free slots
+  std::thread reader([&] {
+    long long order_checked_reads = 0;
+    for (long long b = 0;; ++b) {
+      ShardRun::Chunk *c = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(R.mu);
+        R.cv.wait(lk, [&] { for (auto &s : R.slots) if (s.index == -1) { c = &s; return true; } return false; });
+        c->index = -2;
+      }
+      std::thread t0(fill_chunk, std::ref(r1), std::ref(c->e[0]), A.chunk_pairs, stride, name_stride);
+      fill_chunk(r2, c->e[1], A.chunk_pairs, stride, name_stride);
+      t0.join();
+      if (!c->e[0].error.empty()) die(c->e[0].error);
+      if (!c->e[1].error.empty()) die(c->e[1].error);
+      const int n = std::min(c->e[0].n, c->e[1].n);
+      const bool last = n == 0 || c->e[0].eof || c->e[1].eof || c->e[0].n != c->e[1].n;
+      if (n) {
+        for (int i = 0; i < n; i += A.o.batch_pairs) {      // the name check of src/BwtMapper.cpp:2087-2092, at the reference's cadence
+          order_checked_reads += 2LL * std::min<long long>(A.o.batch_pairs, n - i);
+          if (order_checked_reads % A.o.batch_pairs == 0 &&
+              strncmp(&c->e[0].names[(size_t)i * name_stride], &c->e[1].names[(size_t)i * name_stride], (size_t)A.read_len) != 0)
+            die("Abort, please make sure input pair of fastq files are in the same order!");
+        }
+        if ((long long)n < A.chunk_pairs) {
+          memmove(c->seq.data() + (size_t)n * stride, c->seq.data() + (size_t)A.chunk_pairs * stride, (size_t)n * stride);
+          memmove(c->qual.data() + (size_t)n * stride, c->qual.data() + (size_t)A.chunk_pairs * stride, (size_t)n * stride);
+        }
+        c->len.resize((size_t)2 * n);
+        for (int e = 0; e < 2; ++e) memcpy(&c->len[(size_t)e * n], c->e[e].len.data(), (size_t)n * 4);
+      }
+      {
+        std::lock_guard<std::mutex> lk(R.mu);
+        c->n = n;
+        c->index = n ? b : -1;
+        if (last) R.n_chunks = n ? b + 1 : b;
+      }
+      R.cv.notify_all();
+      if (last) break;
+    }
+  });
+  // the workers: chunk b goes to device b mod NW
+  auto work = [&](size_t w) {
+    W &K = wk[w];
+    fq_ctx_t *ctx = nullptr;
+    if (fq_ctx_create(K.ix, &A.o, (int32_t)A.chunk_pairs, &ctx)) die("fq_ctx_create failed: option outside the supported range");
+    fq_packed_batch_t *pk = nullptr;
+    if (fq_packed_create((int32_t)A.chunk_pairs, stride, &pk)) die("out of pinned host memory for the packed batch");
+    if (K.qc) { fq_qc_begin_file(K.qc, input.first.c_str(), input.second.c_str()); if (fq_qc_state_reset(K.qc)) die("QC consumer: cannot start a segment"); }
+    std::vector<char> sam;
+    for (long long b = (long long)w;; b += (long long)NW) {
+      ShardRun::Chunk *c = nullptr;
+      {
+        std::unique_lock<std::mutex> lk(R.mu);
+        R.cv.wait(lk, [&] { for (auto &s : R.slots) if (s.index == b) { c = &s; return true; } return R.n_chunks >= 0 && b >= R.n_chunks; });
+        if (!c) break;
+      }
+      const int n = c->n;
+      fq_read_batch_t in = {n, stride, c->seq.data(), c->qual.data(), c->len.data(), c->e[0].names.data(), (int32_t)name_stride, c->e[1].names.data()};
+      if (fq_pack_reads_into(&in, std::max(1, A.pack_threads / (int)NW), pk)) die("fq_pack_reads failed");
+      ShardHook hook{&R, ctx, b};
+      fq_ctx_set_serial_hooks(ctx, shard_before, shard_after, &hook);
+      fq_result_batch_t res;
+      if (fq_align_packed(ctx, pk, &res)) die(std::string("fq_align_packed failed on device ") + std::to_string(K.device) + ": " + fq_ctx_last_error(ctx));
+      ShardRun::Result out;
+      out.pairs = n; out.filtered = res.n_both_filtered; out.unmapped = res.n_both_unmapped;
+      if (K.qc) {
+        if (fq_qc_add_last(K.qc, ctx)) die(std::string("QC consumer failed: ") + fq_qc_last_error(K.qc));
+        const int64_t need = fq_qc_state_export(K.qc, nullptr, 0);
+        out.qc.resize((size_t)std::max<int64_t>(need, 0));
+        if (need < 0 || fq_qc_state_export(K.qc, out.qc.data(), need) != need || fq_qc_state_reset(K.qc)) die("QC consumer: export failed");
+      }
+      if (A.sam_out) {
+        const int64_t sz = fq_sam_format_last(ctx, nullptr, 0);
+        sam.resize((size_t)sz + 1);
+        fq_sam_format_last(ctx, sam.data(), sz + 1);
+        out.sam.assign(sam.data(), (size_t)sz);
+      } else {
+        const void *data = nullptr; int64_t len = 0;
+        if (fq_bam_format_last(K.bam, ctx, &data, &len)) die("formatting BAM records failed");
+        out.bam.assign((const char *)data, (const char *)data + len);
+      }
+      {
+        std::lock_guard<std::mutex> lk(R.mu);
+        c->index = -1;                       // the chunk's rows are free again (the consumers above were the last to read them)
+        R.results.emplace(b, std::move(out));
+      }
+      R.cv.notify_all();
+    }
+    fq_ctx_destroy(ctx);
+    fq_packed_free(pk);
+  };
+  std::vector<std::thread> th;
+  for (size_t w = 0; w < NW; ++w) th.emplace_back(work, w);
+  // the writer: results in chunk order
+  long long num_read = 0, filtered = 0, unmapped = 0;
+  for (long long b = 0;; ++b) {
+    ShardRun::Result res;
+    {
+      std::unique_lock<std::mutex> lk(R.mu);
+      R.cv.wait(lk, [&] { return R.results.count(b) || (R.n_chunks >= 0 && b >= R.n_chunks); });
+      auto it = R.results.find(b);
+      if (it == R.results.end()) break;
+      res = std::move(it->second);
+      R.results.erase(it);
+    }
+    if (A.sam_out) { if (fwrite(res.sam.data(), 1, res.sam.size(), sam_fp) != res.sam.size()) die("writing the SAM text failed"); }
+    else if (fq_bam_write_records(bam, res.bam.data(), (int64_t)res.bam.size())) die("writing " + A.out_prefix + ".bam failed");
+    if (qc && fq_qc_merge(qc, res.qc.data(), (int64_t)res.qc.size())) die(std::string("QC consumer: merge failed: ") + fq_qc_last_error(qc));
+    num_read += 2 * res.pairs; filtered += res.filtered; unmapped += res.unmapped;
+    fprintf(stderr, "NOTICE - %lld sequences are processed.\n", num_read);
+  }
+  reader.join();
+  for (auto &t : th) t.join();
+  if (sam_fp) fflush(sam_fp);
+  unequal_lengths_notice(A, r1.h, r2.h);
+  notice("%lld sequences are loaded.", num_read);
+  notice("%lld sequences are filtered.", filtered * 2);
+  notice("%lld sequences are unmapped.", unmapped * 2);
+  if (qc) fq_qc_end_file(qc);
+}
 }  // namespace
 
 int main(int argc, char **argv) {
@@ -471,7 +648,8 @@ int main(int argc, char **argv) {
   // one worker per entry of --devices: its own copy of the index on its device, its own consumers
   struct Worker { int device = 0; fq_index_t *ix = nullptr; fq_qc_t *qc = nullptr; fq_bam_t *bam = nullptr; std::thread th; };
   std::vector<int> devices = A.devices.empty() ? std::vector<int>{A.device} : parse_devices(A.devices);
-  if (devices.size() > inputs.size()) devices.resize(std::max<size_t>(1, inputs.size()));   // (a worker per FASTQ pair at most)
+  const bool shard_one_pair = devices.size() > 1 && inputs.size() == 1 && !inputs[0].second.empty() && inputs[0].second != "Empty";   // one pair, several devices
+  if (!shard_one_pair && devices.size() > inputs.size()) devices.resize(std::max<size_t>(1, inputs.size()));   // (a worker per FASTQ pair at most)
   const size_t W = devices.size();
   std::vector<Worker> wk(W);
   auto open_worker = [&](size_t w, const std::string &qc_prefix, const char *bam_path) {
@@ -509,6 +687,35 @@ int main(int argc, char **argv) {
       fq_qc_destroy(K.qc);
     }
     fq_index_destroy(K.ix);
+    return 0;
+  }
+  if (shard_one_pair) {
+    // ---- one FASTQ pair over several devices: chunks dealt round-robin, the stream's state handed from context to context (align_pair_sharded)
+    std::vector<std::thread> opn;
+    for (size_t w = 0; w < W; ++w) opn.emplace_back([&, w] { open_worker(w, A.out_prefix + ".worker" + std::to_string(w), nullptr); });
+    for (auto &t : opn) t.join();
+    fq_bam_t *bam = nullptr;
+    fq_qc_t *qc = nullptr;
+    if (A.sam_out) {
+      const int64_t n = fq_sam_header(wk[0].ix, nullptr, 0);
+      std::vector<char> h((size_t)n + 1);
+      fq_sam_header(wk[0].ix, h.data(), n + 1);
+      fwrite(h.data(), 1, (size_t)n, stdout);
+    } else if (fq_bam_create(wk[0].ix, fai.c_str(), (A.out_prefix + ".bam").c_str(), A.rg.c_str(), &qo, &bam)) die("cannot open " + A.out_prefix + ".bam / " + fai);
+    if (have_qc && fq_qc_create(wk[0].ix, pre.c_str(), A.out_prefix.c_str(), &qo, &qc)) die("cannot set up the QC consumer");
+    Args AW = A;
+    if (AW.o.host_threads <= 0) AW.o.host_threads = std::max(2, std::min(16, 2 * fq_host_cpus() / (int)W));
+    align_pair_sharded(AW, inputs[0], wk, A.sam_out ? stdout : nullptr, bam, qc);
+    if (bam && fq_bam_close(bam)) die("closing " + A.out_prefix + ".bam failed");
+    if (qc) {
+      if (fq_qc_write(qc)) die("writing the QC files failed");
+      fq_qc_destroy(qc);
+    }
+    for (size_t w = 0; w < W; ++w) {
+      if (wk[w].bam) fq_bam_close(wk[w].bam);
+      if (wk[w].qc) { fq_qc_destroy(wk[w].qc); remove((A.out_prefix + ".worker" + std::to_string(w) + ".InsertSizeTable").c_str()); }
+      fq_index_destroy(wk[w].ix);
+    }
     return 0;
   }
   // ---- several devices: the lines of --fq_list are dealt over them (the next free worker takes the next pair); every pair's records go

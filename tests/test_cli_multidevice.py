@@ -54,6 +54,52 @@ def check_against_one_device(exe, g, tmp, devices):
     assert open(outn + ".bam", "rb").read() == open(out1 + ".bam", "rb").read(), "the BAM file does not depend on how its records were produced"
 
 
+def run_pair(exe, g, tmp, tag, devices=None, sam=True):
+    prefix = g["prefix"][:-len(".FASTQuick.fa")]
+    with open(g["prefix"] + ".param", "w") as fh:
+        fh.write("REFERENCE_PATH\t%s\nTARGET_REGION_PATH\tEmpty\nDBSNP_VCF_PATH\tEmpty\nNUM_VAR_LONG\t4\nNUM_VAR_SHORT\t36\n"
+                 "SHORT_FLANK_LENGTH\t250\nLONG_FLANK_LENGTH\t1000\n" % os.path.join(g["dir"], "genome"))
+    out = os.path.join(str(tmp), tag)
+    cmd = [exe, "align", "--index_prefix", prefix, "--fastq_1", g["fq1"], "--fastq_2", g["fq2"], "--out_prefix", out, "--batch_pairs", str(g["batch"]),
+           "--chunk_pairs", str(g["batch"]), "--q", str(g["trim_qual"]), "--read_len", str(g["qc_read_len"])]
+    if sam:
+        cmd.append("--sam_out")
+    if devices:
+        cmd += ["--devices", devices]
+    run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert run.returncode == 0, run.stderr.decode(errors="replace")[-3000:]
+    return run, out
+
+
+def check_one_pair_sharded(exe, g, tmp, devices):
+    """ONE FASTQ pair over several devices (chunks dealt round-robin, the drand48 stream / last_ii / (k,l) cache handed from context to
+    context around each call's serial part): the output of the one-device run, which is the reference's for the case."""
+    assert g["n_pairs"] > 2 * g["batch"], "the case must span several chunks"
+    one, out1 = run_pair(exe, g, tmp, "one")
+    many, outn = run_pair(exe, g, tmp, "many", devices=devices)
+    assert b"mapping on 2 devices" in many.stderr
+    assert many.stdout == one.stdout == open(g["sam"], "rb").read(), "SAM text of the reference's run of the pair"
+    for f in QC_FILES:
+        assert qc_bytes(outn + "." + f).replace(outn.encode(), b"OUT") == qc_bytes(out1 + "." + f).replace(out1.encode(), b"OUT"), f
+        if f not in ("Summary", "FASTQ.csv"):
+            assert qc_bytes(outn + "." + f) == qc_bytes(os.path.join(g["dir"], "ref.qc." + f)), f
+    one, out1 = run_pair(exe, g, tmp, "one_bam", sam=False)
+    many, outn = run_pair(exe, g, tmp, "many_bam", devices=devices, sam=False)
+    assert open(outn + ".bam", "rb").read() == open(out1 + ".bam", "rb").read()
+
+
+@pytest.mark.parametrize("tag", ["basic", "trim76", "qc"])      # three chunks each: both workers get work, the state crosses contexts twice
+def test_one_pair_sharded_over_two_virtual_devices(tag, golden_cases, tmp_path):
+    emu = os.path.join(HERE, "emu")
+    subprocess.check_call(["make", "-s", "-C", emu, "libfq_emu.so", "FASTQuick_emu"])
+    check_one_pair_sharded(os.path.join(emu, "FASTQuick_emu"), golden_cases[tag], tmp_path, "0,1")
+
+
+@pytest.mark.gpu
+def test_one_pair_sharded_over_two_workers_on_one_gpu(golden_cases, tmp_path):
+    check_one_pair_sharded(os.path.join(ROOT, "fastquick_amd", "bin", "FASTQuick_amd"), golden_cases["qc"], tmp_path, "0,0")
+
+
 def test_fq_list_over_two_virtual_devices(golden_cases, tmp_path):
     emu = os.path.join(HERE, "emu")
     subprocess.check_call(["make", "-s", "-C", emu, "libfq_emu.so", "FASTQuick_emu"])
