@@ -414,6 +414,93 @@ __device__ int fq_global_align_wave(const uint8_t *s1, int len1, const uint8_t *
 // reference's (fq_sw_cell), the end cell is the first strict maximum in row-major order exactly as the
 // sequential scan finds it.  Lane 0 then runs the (inherently serial, data-dependent band) reverse pass and the
 // banded global fill out of LDS.
+//
+// aln_local_core's reverse pass (stdaln.c:626-679; fq_sw_reverse is the serial statement) by the whole wavefront, a row at a time.
+// The band of a row depends on the rows before it (it follows the running maximum), so rows stay sequential; inside a row the only
+// chain is the horizontal gap, f_g = max(f_{g-1} - r, h_{g-1} - q - r) applied when h_{g-1} > 0.  Every h is >= 0, so a non-positive f
+// never changes a cell, and a positive one always stems from the current run of positive cells: the cells of a row are
+// h_g = max(a_g, max_{k<g}(a_k - q - (g - k) r)) with a_g the cell without its horizontal gap -- a prefix maximum of a_k - q + k r over
+// the lanes (carried from one group of 64 cells to the next).  The running maximum, "the first cell that reaches score_f" (where the
+// pass stops) and the start cell come from a second prefix maximum in the order the serial loop visits the cells.  The arrays end up as
+// the serial loop leaves them: H[x] = h(x) for the row's columns, H[start + 1] = 0, E[x + 1] = e(x), E[end + 1] = 0 -- a cell's inputs
+// are all read before anything of its row is written (the next group's are fetched before this group's are stored).
+__device__ __forceinline__ int fq_wave_incl_max(int x, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(x, d, 64); if (lane >= d) x = x > y ? x : y; }
+  return x;
+}
+__device__ void fq_sw_reverse_wave(const uint8_t *ref, const uint8_t *qry, int score_f, int end_i, int end_j, int *H, int *E, int *start_i_out, int *start_j_out, int *score_r_out) {
+  const int lane = threadIdx.x;
+  const int q = FQ_GAP_O, rr = FQ_GAP_E, qr = q + rr;
+  const int kNeg = -(1 << 29);
+  for (int i = lane; i <= end_i; i += 64) { H[i] = 0; E[i] = 0; }
+  __syncthreads();
+  int score_r = fq_sm_maq(ref[end_i - 1], qry[end_j - 1]);
+  int start_i = end_i, start_j = end_j;
+  if (lane == 0) { H[end_i] = qr + score_r; E[end_i] = 0; }
+  __syncthreads();
+  int start = end_i - 1, end = end_i - 3;
+  if (end <= 0) end = 0;
+  bool stop = false;
+  for (int j = end_j - 1; j != 0; --j) {
+    const int c2 = qry[j - 1];
+    const int n = start - end;                       // the row's cells: columns start, start - 1, ..., end + 1 (traversal index g = 0 ..)
+    int carry_b = kNeg, carry_m = score_r;
+    int d_in = 0, s_in = 0, e_in = 0;
+    if (lane < n) { const int i = start - lane; d_in = H[i + 1]; s_in = H[i]; e_in = E[i + 1]; }
+    for (int g0 = 0; g0 < n; g0 += 64) {
+      const int g = g0 + lane, i = start - g;
+      const bool act = g < n;
+      int d_nx = 0, s_nx = 0, e_nx = 0;
+      if (g + 64 < n) { const int i2 = i - 64; d_nx = H[i2 + 1]; s_nx = H[i2]; e_nx = E[i2 + 1]; }
+      int e = e_in - rr > s_in - qr ? e_in - rr : s_in - qr;
+      if (e < 0) e = 0;
+      int a0 = act ? d_in + fq_sm_maq(ref[i - 1], c2) : 0;
+      if (a0 < 0) a0 = 0;
+      if (a0 < e) a0 = e;
+      const int b = act ? a0 - q + g * rr : kNeg;
+      const int bi = fq_wave_incl_max(b, lane);
+      int bx = __shfl_up(bi, 1, 64);
+      if (lane == 0) bx = kNeg;
+      if (bx < carry_b) bx = carry_b;
+      const int fpos = bx - g * rr;
+      const int h = a0 > fpos ? a0 : fpos;
+      const int b_last = __shfl(bi, 63, 64);
+      if (carry_b < b_last) carry_b = b_last;
+      // the running maximum in visiting order
+      const int mi = fq_wave_incl_max(act ? h : kNeg, lane);
+      int mx = __shfl_up(mi, 1, 64);
+      if (lane == 0) mx = kNeg;
+      if (mx < carry_m) mx = carry_m;
+      const bool improve = act && h > mx;
+      const unsigned long long stops = __ballot(improve && h - qr == score_f);
+      if (stops) {                                   // the pass ends at the first such cell; nothing of the arrays is read again
+        const int ls = __ffsll((long long)stops) - 1;
+        score_r = __shfl(h, ls, 64); start_i = start - (g0 + ls); start_j = j;
+        stop = true;
+        break;
+      }
+      const int m_last = __shfl(mi, 63, 64);
+      if (m_last > carry_m) {
+        const unsigned long long at = __ballot(act && h == m_last);
+        start_i = start - (g0 + (__ffsll((long long)at) - 1)); start_j = j;
+        carry_m = m_last;
+      }
+      if (act) { H[i] = h; E[i + 1] = e; }
+      d_in = d_nx; s_in = s_nx; e_in = e_nx;
+    }
+    if (stop) break;
+    score_r = carry_m;
+    if (lane == 0) { H[start + 1] = 0; E[end + 1] = 0; }
+    __syncthreads();
+    if (H[start] <= qr) --start;
+    if (start <= 0) start = 0;
+    end = start_i - (start_j - j) - (score_r + (start_j - j) * 11) / rr - 1;
+    if (end <= 0) end = 0;
+    __syncthreads();
+  }
+  *start_i_out = start_i; *start_j_out = start_j; *score_r_out = score_r - qr;
+}
 __global__ void __launch_bounds__(64) k_sw_wave(FqSwArgs a) {
   const int t = blockIdx.x, lane = threadIdx.x;
   const FqSwTask T = a.task[t];
@@ -488,8 +575,10 @@ __global__ void __launch_bounds__(64) k_sw_wave(FqSwArgs a) {
   uint8_t *ops = qry + ((QL + 16) & ~15);
   uint8_t *trace = a.trace_in_lds ? ops + ((RL + QL + 16) & ~15) : S.trace;
   int start_i = 0, start_j = 0, score_r = 0;
-  if (lane == 0) fq_sw_reverse(ref, qry, best_h, best_i, best_j, Hb, Eb, &start_i, &start_j, &score_r);
-  start_i = __shfl(start_i, 0); start_j = __shfl(start_j, 0); score_r = __shfl(score_r, 0);
+  if (a.serial_reverse) {                            // (test knob sw_serial_reverse: the serial statement on lane 0)
+    if (lane == 0) fq_sw_reverse(ref, qry, best_h, best_i, best_j, Hb, Eb, &start_i, &start_j, &score_r);
+    start_i = __shfl(start_i, 0); start_j = __shfl(start_j, 0); score_r = __shfl(score_r, 0);
+  } else fq_sw_reverse_wave(ref, qry, best_h, best_i, best_j, Hb, Eb, &start_i, &start_j, &score_r);
   __syncthreads();
   int n_ops = 0, fi = 0, fj = 0, score_g;
   const int jmax = (best_i - start_i > best_j - start_j ? best_i - start_i : best_j - start_j) + 1;
@@ -1141,6 +1230,7 @@ int launch_sw(const FqSwArgs &a) {
   // The trace matrix in LDS makes a task faster but limits a CU to one block; with more tasks than CUs it is better to keep it in
   // the task's global scratch and have every task resident at once (each spends most of its time in the serial reverse pass).
   b.trace_in_lds = (lds + trace_bytes <= kLdsBudget && a.n_task <= 256) ? 1 : 0;
+  b.serial_reverse = g_cur->tune.sw_serial_reverse;
   if (b.trace_in_lds) lds += trace_bytes;
   hipEvent_t e0, e1;
   kernel_events(FQ_K_SW_KERNEL, &e0, &e1);

@@ -2064,6 +2064,7 @@ struct FqSwArgs {
   size_t scratch_stride;
   int32_t RL, QL;       // scratch dimensions
   int32_t trace_in_lds; // set by the HIP launcher: the wavefront kernel keeps the fill's trace matrix in LDS
+  int32_t serial_reverse; // ... and whether aln_local_core's reverse pass runs as the serial statement on one lane (test knob)
 };
 
 // one cell of the forward pass of aln_local_core (stdaln.c:585-612); state carried by the caller

@@ -37,6 +37,8 @@ SEARCH_MODES = {"lanes": {}, "wave1": {"gap_long_pops": 1, "gap_long_always": 1}
                 # the hand-over rule of small launches with a low threshold: a search still running after 8 pops once the work queue
                 # is dry (both of its blocks) goes to the wavefront-per-read kernel
                 "handover": {"gap_long_pops": 8},
+                # the mate-rescue kernel's reverse pass as the serial statement on one lane (the default walks a row with the whole wavefront)
+                "sw_serial": {"sw_serial_reverse": 1},
                 # the first round in three segments of the queue, each segment's second round on the context's second stream beside
                 # the next segment's first (what calls of >= 4 M searched reads do)
                 "pipeline": {"gap_nogap_min": 0, "gap_pipeline_min": 0, "gap_pipeline_segs": 3}}
