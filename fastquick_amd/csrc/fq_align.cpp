@@ -366,6 +366,7 @@ extern "C" int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t v) {
   else if (k == "refine_lanes") t->refine_lanes = (int)v;
   else if (k == "gap_generic_opts") t->gap_generic_opts = (int)v;
   else if (k == "sw_serial_reverse") t->sw_serial_reverse = (int)v;
+  else if (k == "width_both_strands") t->width_both_strands = (int)v;
   else if (k == "spin_sync") t->spin_sync = (int)v;
   else return FQ_EINVAL;
   return FQ_OK;

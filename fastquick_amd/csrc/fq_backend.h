@@ -16,6 +16,7 @@ struct Tune {   // experiment / test knobs (fq_ctx_set_tuning); the defaults are
   int gap_waves_per_cu = 0, gap_refill_min = 0, gap_order_asc = 0, filter_no_turns = 0, refine_lanes = 0;
   int spin_sync = 0;        // 1: sync() spins (hipStreamSynchronize) instead of sleeping on a blocking event
   int gap_generic_opts = 0; // 1: never the kernels specialised for FASTQuick's own option block (FqOptsStock)
+  int width_both_strands = 0; // 1: the width kernel with one thread per read walking both strands (round 3's); default: one thread per (read, strand), strands apart by XCD
   int sw_serial_reverse = 0; // 1: the mate-rescue kernel's reverse pass as the serial statement on one lane (the wavefront form is the default)
 };
 int runtime_configure(int hw_queues, int blocking_waits);   // fq_runtime_configure: before the process's first HIP call

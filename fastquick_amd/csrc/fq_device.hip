@@ -314,6 +314,15 @@ __global__ void __launch_bounds__(256) k_width(FqWidthArgs a) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w < a.n_work) fq_width_read(a, w, seed_bits + threadIdx.x, 256);
 }
+// One thread per (read, strand); the workgroups of XCDs 0..3 take strand 0, those of XCDs 4..7 strand 1 (workgroups are dealt
+// round-robin over the 8 XCDs: blockIdx % 8 names the XCD), so that an XCD's 4 MB L2 holds one strand's Occ table, not two halves.
+__global__ void __launch_bounds__(256) k_width_strand(FqWidthArgs a) {
+  uint8_t *seed_bits = (uint8_t *)fq_dyn_lds;   // [ii][thread]
+  const int xcd = blockIdx.x & 7, strand = xcd >> 2;
+  const int q = (int)(blockIdx.x >> 3) * 4 + (xcd & 3);      // this workgroup's number among its strand's
+  const int w = q * 256 + threadIdx.x;
+  if (w < a.n_work) fq_width_strand(a, w, strand, seed_bits + threadIdx.x, 256);
+}
 struct FqQueueFetch {
   uint32_t *cursor;
   int n_work;
@@ -1075,6 +1084,11 @@ int launch_width(const FqWidthArgs &a) {
   if (a.n_work <= 0) return 0;
   hipEvent_t e0, e1;
   kernel_events(FQ_K_WIDTH_KERNEL, &e0, &e1);
+  if (!g_cur->tune.width_both_strands) {
+    const unsigned per_strand = nblk((uint64_t)a.n_work, 256);
+    const unsigned grid = ((per_strand + 3) / 4) * 8;      // groups of 8 workgroups: 4 per strand
+    hipExtLaunchKernelGGL(k_width_strand, dim3(grid), dim3(256), (size_t)a.o.seed_len * 256, g_stream, e0, e1, 0, a);
+  } else
   hipExtLaunchKernelGGL(k_width, dim3(nblk((uint64_t)a.n_work, 256)), dim3(256), (size_t)2 * (size_t)a.o.seed_len * 256, g_stream, e0, e1, 0, a);
   FQ_HIP(hipGetLastError());
   return 0;

@@ -693,6 +693,93 @@ FQ_HD void fq_width_read(const FqWidthArgs &A, int w, uint8_t *seed_bits, int se
   FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_WIDTH], touches);
 }
 
+// The same for ONE strand of the read (the device's default since round 4): the two strands walk two different Occ tables of 3.3 MB each
+// (10k markers) and an XCD's L2 holds 4 MB -- a thread that interleaves both chains makes every XCD cache both tables and miss in half of
+// its lookups.  One thread per (read, strand), the threads of strand a in workgroups that share XCDs (fq_device.hip, k_width_strand):
+// each XCD's L2 then serves one table.  Same arithmetic, same outputs; strand 0's thread also writes the read's start record.
+FQ_HD void fq_width_strand(const FqWidthArgs &A, int w, int a, uint8_t *seed_bits, int seed_bits_stride) {
+  const int s = A.work ? A.work[w] : w;
+  const int r = A.read_list[s];
+  FqReadView v = {A.seq + (size_t)r * (size_t)A.stride, A.len_trim[r]};
+  uint32_t *owa = A.wfull + (size_t)w * 2 * (size_t)A.wstride + (size_t)a * (size_t)A.wstride;
+  FqPos *pra = A.prec + (size_t)w * 2 * (size_t)A.pstride + (size_t)a * (size_t)A.pstride;
+  const FqFM &f = A.ix.fm[a];
+  uint32_t touches = 0;
+  const bool use_seed = v.len > A.o.seed_len;
+  const int seed_off = v.len - A.o.seed_len;
+  uint32_t k = 0, l = f.seq_len, wprev = 0;
+  int bid = 0;
+  if (use_seed) {   // bwt_cal_width over the last seed_len bases (src/BwtMapper.cpp:131-137)
+    uint64_t seed8 = 0;
+    for (int i = 0; i < A.o.seed_len; ++i) {
+      if ((i & 7) == 0 && i + 8 <= A.o.seed_len) memcpy(&seed8, v.row + (A.o.seed_len - 8 - i), 8);
+      const bool fast = (i | 7) < A.o.seed_len;
+      int c;
+      if (fast) { const int c0 = (int)fq_nt4_fast((uint32_t)(seed8 >> (8 * (7 - (i & 7)))) & 0xffu); c = (a && c0 < 4) ? 3 - c0 : c0; }
+      else c = fq_base(v, a, seed_off + i);
+      if (c < 4) {
+        touches += fq_touch2(f, k - 1, l, true);
+        uint32_t ok, ol;
+        fq_occ1_pair(f, k - 1, l, c, &ok, &ol);
+        k = f.L2[c] + ok + 1;
+        l = f.L2[c] + ol;
+      }
+      if (k > l || c > 3) { k = 0; l = f.seq_len; ++bid; }
+      const uint32_t wcur = l - k + 1;
+      seed_bits[i * seed_bits_stride] = (uint8_t)((uint32_t)(bid < 31 ? bid : 31) | (i >= 1 && wcur == wprev ? 1u << 5 : 0u));
+      wprev = wcur;
+    }
+  }
+  k = 0; l = f.seq_len; wprev = 0; bid = 0;
+  int namb = 0;
+  for (int i0 = 0; i0 < v.len; i0 += 8) {
+    uint32_t wv[8], pv[8];
+    uint64_t bases8 = 0;
+    const bool whole = i0 + 8 <= v.len;
+    if (whole) memcpy(&bases8, v.row + (v.len - 8 - i0), 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int i = i0 + j;
+      wv[j] = 0; pv[j] = 0;
+      if (i < v.len) {
+        int c;
+        if (whole) { const int c0 = (int)fq_nt4_fast((uint32_t)(bases8 >> (8 * (7 - j))) & 0xffu); c = (a && c0 < 4) ? 3 - c0 : c0; }
+        else c = fq_base(v, a, i);
+        namb += c > 3;
+        if (c < 4) {
+          touches += fq_touch2(f, k - 1, l, true);
+          uint32_t ok, ol;
+          fq_occ1_pair(f, k - 1, l, c, &ok, &ol);
+          k = f.L2[c] + ok + 1;
+          l = f.L2[c] + ol;
+        }
+        if (k > l || c > 3) { k = 0; l = f.seq_len; ++bid; }
+        const uint32_t wcur = l - k + 1;
+        const uint32_t seedbits = (use_seed && i >= seed_off) ? (uint32_t)seed_bits[(i - seed_off) * seed_bits_stride] << 6 : 0u;
+        wv[j] = wcur;
+        pv[j] = seedbits | (uint32_t)(bid < 31 ? bid : 31) | (i >= 1 && wcur == wprev ? 1u << 5 : 0u) | (uint32_t)c << 12;
+        wprev = wcur;
+      }
+    }
+    FqU4 q;
+    q.x = wv[0]; q.y = wv[1]; q.z = wv[2]; q.w = wv[3];
+    *(FqU4 *)(owa + i0) = q;
+    q.x = wv[4]; q.y = wv[5]; q.z = wv[6]; q.w = wv[7];
+    *(FqU4 *)(owa + i0 + 4) = q;
+    q.x = pv[0] | pv[1] << 16; q.y = pv[2] | pv[3] << 16; q.z = pv[4] | pv[5] << 16; q.w = pv[6] | pv[7] << 16;
+    *(FqU4 *)(pra + i0) = q;
+  }
+  A.bid_end[2 * w + a] = (uint8_t)(bid < 255 ? bid : 255);
+  if (a == 0) {
+    const uint32_t md = A.maxdiff_lut[v.len];
+    FqGapWork gw;
+    gw.r = r;
+    gw.meta = (uint32_t)v.len | md << 16 | (namb > (int)md ? 1u << 24 : 0u);
+    A.winfo[w] = gw;
+  }
+  FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_WIDTH], touches);
+}
+
 // Scheduling key for the search kernel: the smaller of the two strands' lower bounds on the number of differences, and which
 // strand it belongs to.  A read whose bound is 0 has an exact match and a search of nearly constant shape (~180 pops at 150 bp);
 // mean and tail of the search length grow with the bound.  The queue hands out reads sorted by key and a wavefront refills all

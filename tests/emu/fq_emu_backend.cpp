@@ -71,7 +71,14 @@ int launch_unpack(const FqUnpackArgs &a) { for (int t = 0; t < a.n_rows; ++t) fq
 int launch_patch(const FqPatchArgs &a) { for (int64_t q = 0; q < a.n_exc; ++q) fq_patch_thread(a, q); return 0; }
 int launch_trim(const FqTrimArgs &a) { for (int t = 0; t < a.n_rows; ++t) fq_trim_thread(a, t); return 0; }
 int launch_trim_all(const FqTrimAllArgs &a) { for (int r = 0; r < a.n_reads; ++r) fq_trim_all_thread(a, r); return 0; }
-int launch_width(const FqWidthArgs &a) { uint8_t seed_bits[2 * FQ_SEED_MAX]; for (int w = 0; w < a.n_work; ++w) fq_width_read(a, w, seed_bits, 1); return 0; }
+int launch_width(const FqWidthArgs &a) {
+  uint8_t seed_bits[2 * FQ_SEED_MAX];
+  for (int w = 0; w < a.n_work; ++w) {
+    if (g_bound && g_bound->tune.width_both_strands) fq_width_read(a, w, seed_bits, 1);
+    else { fq_width_strand(a, w, 1, seed_bits, 1); fq_width_strand(a, w, 0, seed_bits, 1); }      // (one strand at a time, as the device's kernel)
+  }
+  return 0;
+}
 int launch_order(const uint8_t *bid_end, int n, int n_hard, int32_t *order, uint32_t *cnt) {
   int at = 0;
   cnt[2 * FQ_ORDER_KEYS] = 0;
