@@ -1296,6 +1296,28 @@ int stage_sa_rows(Call &K) {
 // time such a hit is taken (bwase.c:29-41) -- two for a read with a single best hit, unless the first of them is exactly 0.  Counting
 // the best hits of every read is the device's work (fq_rec_nocc_thread); the replay of the draws is serial, one 16-bit count per
 // read (and the hit lists of the reads with several best hits).  It can run beside the SA stage.
+// x -> a x + c (mod 2^48): the generator's step, its powers, and how many steps a state is away from the state 0
+struct Lcg48 { uint64_t a, c; };
+static constexpr uint64_t kM48 = 0xFFFFFFFFFFFFULL;
+static inline Lcg48 lcg_then(const Lcg48 &f, const Lcg48 &g) { return {(g.a * f.a) & kM48, (g.a * f.c + g.c) & kM48}; }   // f, then g
+static Lcg48 lcg_pow(uint64_t n) {
+  Lcg48 r{1, 0}, b{0x5DEECE66DULL, 0xBULL};
+  for (; n; n >>= 1) { if (n & 1) r = lcg_then(r, b); b = lcg_then(b, b); }
+  return r;
+}
+// The smallest n >= 1 with step^n(x) == 0.  The low k bits of the state sequence have period 2^k (a = 1 mod 4, c odd), so n is found bit
+// by bit: of the two candidates that agree on the bits so far, one brings the low k bits to zero.
+static uint64_t steps_to_zero(uint64_t x) {
+  uint64_t n = 0;
+  for (int k = 1; k <= 48; ++k) {
+    const Lcg48 p = lcg_pow(n);
+    const uint64_t xn = (p.a * x + p.c) & kM48;
+    if (xn & ((1ULL << k) - 1)) n |= 1ULL << (k - 1);
+  }
+  const Lcg48 p = lcg_pow(n);
+  if (((p.a * x + p.c) & kM48) != 0) return 0;          // (cannot happen; the caller then replays read by read)
+  return n ? n : (1ULL << 48);
+}
 void stageB1_plan(Call &K, uint64_t rng0) {
   fq_ctx *c = K.c;
   const size_t N = (size_t)K.n_surv * 2;
@@ -1303,19 +1325,47 @@ void stageB1_plan(Call &K, uint64_t rng0) {
   uint64_t *start = K.plan.start;
   const size_t per = 2 * FQ_RNG_CHUNK_PAIRS;
   // two steps of the generator at once: X'' = A2 X + C2 (mod 2^48); the step between them matters only when it lands on 0
-  constexpr uint64_t A1 = 0x5DEECE66DULL, C1 = 0xBULL, M48 = 0xFFFFFFFFFFFFULL, A2 = (A1 * A1) & M48, C2 = (A1 * C1 + C1) & M48;
+  constexpr uint64_t A1 = 0x5DEECE66DULL, C1 = 0xBULL, M48 = kM48, A2 = (A1 * A1) & M48, C2 = (A1 * C1 + C1) & M48;
+  // A chunk whose reads all have exactly one best hit draws 2 * per numbers -- unless one of the first draws is exactly 0, i.e. unless
+  // the stream passes through the state 0 inside the chunk.  How far the state 0 is away is known (steps_to_zero, kept up to date), so
+  // such a chunk is one multiply-add instead of a chain of `per` dependent ones: almost every chunk of an on-target call.
+  const Lcg48 jump = lcg_pow(2 * per);
+  uint64_t to_zero = steps_to_zero(rng0);
+  const bool can_jump = to_zero != 0 && per == 32;
   uint64_t x = rng0;
-  for (size_t idx = 0; idx < N; ++idx) {
-    if (idx % per == 0) start[idx / per] = x;
-    const int t = ntop[idx];
-    if (t == 0) continue;
-    if (t == 1) {                                                          // wdt >= 1: taken unless the draw is exactly 0
-      const uint64_t x1 = (A1 * x + C1) & M48;
-      x = x1 == 0 ? x1 : (A2 * x + C2) & M48;
-      continue;
+  auto advanced = [&](uint64_t steps) { if (to_zero) to_zero = to_zero > steps ? to_zero - steps : to_zero + (1ULL << 48) - steps; };
+  for (size_t c0 = 0; c0 < N; c0 += per) {
+    start[c0 / per] = x;
+    const size_t c1 = std::min(N, c0 + per);
+    if (can_jump && c1 - c0 == per && to_zero > 2 * per) {
+      uint64_t w[8];
+      memcpy(w, ntop + c0, 64);
+      bool ones = true;
+      for (int q = 0; q < 8; ++q) ones &= w[q] == 0x0001000100010001ULL;
+      if (ones) { x = (jump.a * x + jump.c) & M48; advanced(2 * per); continue; }
     }
-    int na; const FqAln *a = K.aln_of(idx, &na);
-    fq_main_draws(x, a, (uint32_t)na);
+    for (size_t idx = c0; idx < c1; ++idx) {
+      const int t = ntop[idx];
+      if (t == 0) continue;
+      if (t == 1) {                                                          // wdt >= 1: taken unless the draw is exactly 0
+        const uint64_t x1 = (A1 * x + C1) & M48;
+        x = x1 == 0 ? x1 : (A2 * x + C2) & M48;
+        advanced(x1 == 0 ? 1 : 2);
+        continue;
+      }
+      int na; const FqAln *a = K.aln_of(idx, &na);
+      const int best = a[0].score;                                           // (fq_main_draws, counting the draws)
+      uint32_t cnt = 0;
+      uint64_t steps = 0;
+      for (int i = 0; i < na; ++i) {
+        if (a[i].score > best) break;
+        const uint32_t wdt = a[i].l - a[i].k + 1;
+        ++steps;
+        if (fq_rng_step(x) * (double)(uint32_t)(wdt + cnt) > (double)(int)cnt) { (void)fq_rng_step(x); ++steps; }
+        cnt += wdt;
+      }
+      advanced(steps);
+    }
   }
   K.plan.rng_end = x;
 }

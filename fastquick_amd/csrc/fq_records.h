@@ -264,7 +264,9 @@ FQ_HD void fq_main_hit_thread(const FqRecArgs &A, int sp) {
     const uint32_t na = s >= 0 ? A.an[s] : 0u;
     fq_main_choose(x, a, na, p[e]);
     if (fq_rec_mapped(p[e])) {
-      if (A.enumerated[idx]) {
+      // (a main hit's row lies in its hit's interval -- unless no hit was taken at all: the one draw of a one-hit read was exactly 0,
+      //  once in 2^48 draws; the record then keeps sa = 0 and the reference resolves that row like any other)
+      if (A.enumerated[idx] && p[e].sa >= a[p[e].main_aln].k && p[e].sa <= a[p[e].main_aln].l) {
         uint64_t row = A.row0[idx];
         for (int k = 0; k < p[e].main_aln; ++k) row += (uint64_t)(a[k].l - a[k].k) + 1;
         p[e].pos = A.pos[row + (p[e].sa - a[p[e].main_aln].k)];

@@ -64,6 +64,7 @@ void fqo_print_sam_header(const fqo_index *ix, FILE *sam);
 /* --t of the reference: stage A (cal_width + match_gap) of every following batch runs on n_threads workers sliced as
  * src/BwtMapper.cpp:1490-1513 does (rounded up to even; half per end); <=1 = serial.  Results do not depend on it. */
 void fqo_ctx_set_threads(fqo_ctx *c, int n_threads);
+void fqo_ctx_set_rng(fqo_ctx *c, uint64_t state);   /* the drand48 state (X of X' = 0x5DEECE66D X + 0xB mod 2^48) */
 
 /* counters for the algorithmic-byte model: accumulated over the ctx lifetime */
 typedef struct {

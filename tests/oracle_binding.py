@@ -158,6 +158,12 @@ class OracleAligner:
         self.L.fqo_ctx_set_threads.restype = None
         self.L.fqo_ctx_set_threads(self.ctx, int(n_threads))
 
+    def set_rng(self, state: int) -> None:
+        """The drand48 state of the stream, as fq_ctx_state_import sets it on the library's side."""
+        self.L.fqo_ctx_set_rng.argtypes = [C.c_void_p, C.c_uint64]
+        self.L.fqo_ctx_set_rng.restype = None
+        self.L.fqo_ctx_set_rng(self.ctx, int(state))
+
     def close(self):
         if self.ctx:
             self.L.fqo_ctx_free(self.ctx)

@@ -503,3 +503,12 @@ def test_gpu_single_end_consumers_match_reference(tag, golden_cases, lib):
     bad = qc_case(golden_cases[tag], lib, device=0, se=True)
     assert not bad, explain(bad)
     bam_case(golden_cases[tag], lib, device=0, se=True)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("steps_before_zero", [1, 3, 100])
+def test_gpu_drand48_stream_through_its_state_zero(steps_before_zero, golden_cases, lib, tmp_path):
+    """The once-in-2^48 arm of bwa_aln2seq_core ("taken unless the draw is exactly 0"), reached by importing a stream state that is a
+    few steps before the generator's state 0: k_main_hit's draws and the host's replay against the oracle (see test_pipeline_emu.py)."""
+    from test_pipeline_emu import zero_state_case
+    zero_state_case(steps_before_zero, golden_cases["basic"], lib, tmp_path, device=0)

@@ -303,3 +303,42 @@ def test_a_hook_that_raises_stops_the_call_and_marks_the_stream_broken(golden_ca
     other.close()
     al.close()
     ix.close()
+
+
+def _stream_state(rng: int) -> bytes:
+    """fq_ctx_state_export's layout for a fresh stream whose drand48 state is `rng`: mark, rng, last_ii (avg = std = -1, rest 0), no (k,l) entries."""
+    import struct
+    return b"_FQST1\x00\x00" + struct.pack("<Q", rng) + struct.pack("<dddIIII", -1.0, -1.0, 0.0, 0, 0, 0, 0) + struct.pack("<Q", 0)
+
+
+@pytest.mark.parametrize("steps_before_zero", [1, 2, 3, 7, 40, 65, 100])
+def test_the_drand48_stream_through_its_state_zero(steps_before_zero, golden_cases, emu_lib, tmp_path):
+    zero_state_case(steps_before_zero, golden_cases["basic"], emu_lib, tmp_path)
+
+
+def zero_state_case(steps_before_zero, g, lib, tmp_path, device=None):
+    """bwa_aln2seq_core takes a read's only best hit "unless the draw is exactly 0" (libbwa/bwase.c:29-41): then it draws once, not twice,
+    and every read behind it sees a stream shifted by one.  That happens once in 2^48 draws -- unless the stream is put there: the state
+    that is k steps before the state 0 is imported (fq_ctx_state_import / the oracle's set_rng), for k odd and even, inside the first chunk
+    of 16 pairs and behind it.  The host's replay (which skips over chunks of one-hit reads with one multiply-add, but not across the
+    state 0), the device's draws for the pairs before its own and the choice itself must all agree with the oracle."""
+    a_inv = pow(0x5DEECE66D, -1, 1 << 48)
+    x = 0
+    for _ in range(steps_before_zero):
+        x = (a_inv * (x - 0xB)) % (1 << 48)
+    names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
+    ix = api.Index(g["prefix"], lib=lib) if device is None else api.Index(g["prefix"], device=device, lib=lib)
+    al = api.Aligner(ix, api.default_opts(lib), max_pairs=seq.shape[1], debug=True)
+    al.import_state(_stream_state(x))
+    st, sam = str(tmp_path / "emu.stages"), str(tmp_path / "emu.sam")
+    api.align_stream(al, names, seq, qual, lens, seq.shape[1], st, sam)
+    al.close(); ix.close()
+    oa = ob.OracleAligner(g["prefix"])
+    oa.set_rng(x)
+    oa.align(names, seq, qual, lens, str(tmp_path / "o.stages"), str(tmp_path / "o.sam"), batch=seq.shape[1])
+    oa.close()
+    diffs = [d for d in ob.diff_stage_files(str(tmp_path / "o.stages"), st)]
+    assert not diffs, "\n".join(diffs)
+    assert filecmp.cmp(str(tmp_path / "o.sam"), sam, shallow=False)
+    if steps_before_zero == 1:      # the first read's only draw is 0: its hit is not taken, and the text is not the ordinary seed's
+        assert open(sam, "rb").read() != open(g["sam"], "rb").read()

@@ -22,7 +22,7 @@ case $WHAT in
 timeline)
   N=${1:?ctxs}; shift
   rm -rf $O/${TAG}_tl$N
-  timeout 900 rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_tl$N -o p -- python3 $R/bench.py --mix ontarget --pairs 4194304 --ctxs $N --steps 3 --warmup 1 $Q "$@" > $O/${TAG}_tl$N.json 2> $O/${TAG}_tl$N.err
+  timeout 900 rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_tl$N -o p -- python3 $R/bench.py --mix ontarget --pairs 4194304 --ctxs $N --steps 6 --warmup 2 $Q "$@" > $O/${TAG}_tl$N.json 2> $O/${TAG}_tl$N.err
   python3 - <<PY > $O/${TAG}_timeline_$N.txt
 import csv, glob, json, collections
 f = glob.glob("$O/${TAG}_tl$N/**/*kernel_trace.csv", recursive=True)[0]
@@ -31,11 +31,13 @@ sk = [k for k in rows[0] if "Start" in k][0]; ek = [k for k in rows[0] if "End" 
 qk = [k for k in rows[0] if "Queue" in k or "Stream" in k]
 ev = sorted(((int(r[sk]), int(r[ek]), r["Kernel_Name"].split("(")[0].split("::")[-1], r.get(qk[0], "") if qk else "") for r in rows))
 d = json.loads(open("$O/${TAG}_tl$N.json").read().strip().splitlines()[-1])
-print("# kernel timeline of $N on-target streams, 4,194,304 pairs per call (rocprofv3 --kernel-trace around bench.py --mix ontarget --ctxs $N --steps 3 --warmup 1)")
+print("# kernel timeline of $N on-target streams, 4,194,304 pairs per call (rocprofv3 --kernel-trace around bench.py --mix ontarget --ctxs $N --steps 6 --warmup 2)")
 print("ctxs $N value %.4g pairs/s ms_per_step %.1f host_ms_per_call %s" % (d["value"], d["ms_per_step"], d.get("host_ms_per_call")))
-t0 = ev[0][0]; t1 = max(e[1] for e in ev)
-lo = t0 + int(0.45 * (t1 - t0))          # the last 55 % of the trace ~ the timed region
-sel = [e for e in ev if e[0] >= lo]
+# the timed region: a call starts with its filter kernel; the run ends with 3 solo calls (bench.py's "same kernels alone" leg) behind the
+# 6 timed steps of $N calls each
+preps = [e[0] for e in ev if e[2].startswith("k_prep")]
+lo, hi = preps[-(3 + 6 * $N)], preps[-3]
+sel = [e for e in ev if lo <= e[0] < hi]
 busy = 0; cur_s, cur_e = sel[0][0], sel[0][1]
 gaps = []
 for s, e, nme, q in sel[1:]:
