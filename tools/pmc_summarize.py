@@ -16,8 +16,8 @@ import json
 import os
 import sys
 
-KMAP = {"k_prep": "fq_prep", "k_prep_packed": "fq_prep", "k_gap_nogap_lds": "fq_gap", "k_gap_nogap_stock": "fq_gap", "k_gap_persist_stock": "fq_gap", "k_gap_lds": "fq_gap", "k_gap": "fq_gap", "k_gap_persist": "fq_gap", "k_gap_persist_lds": "fq_gap", "k_gap_coop": "fq_gap_wave", "k_width": "fq_width", "k_sa": "fq_sa",
-        "k_sw_wave": "fq_sw", "k_refine_lds": "fq_refine"}
+KMAP = {"k_prep": "fq_prep", "k_prep_packed": "fq_prep", "k_gap_nogap_lds": "fq_gap", "k_gap_nogap_stock": "fq_gap", "k_gap_persist_stock": "fq_gap", "k_gap_lds": "fq_gap", "k_gap": "fq_gap", "k_gap_persist": "fq_gap", "k_gap_persist_lds": "fq_gap", "k_gap_coop": "fq_gap_wave", "k_width": "fq_width", "k_width_strand": "fq_width", "k_sa": "fq_sa",
+        "k_sw_wave": "fq_sw", "k_refine_lds": "fq_refine", "k_refine_wave": "fq_refine", "k_md_rec": "fq_md", "k_md_mask": "fq_md"}
 
 
 def mean_kb(d):
@@ -37,7 +37,8 @@ def main():
     bench = json.loads([l for l in open(units_path) if l.startswith("{")][-1])
     per_step = bench.get("work_per_call") or bench["work_per_step"]      # per call of one stream (older lines: a step was one call)
     units = {"fq_prep": 2 * bench["config"].get("pairs_per_call", bench["config"]["pairs_per_step"]), "fq_gap": per_step["reads_searched"], "fq_gap_wave": max(1.0, per_step["tier_retries"]), "fq_width": per_step["reads_searched"],
-             "fq_sa": max(1.0, per_step["sa_rows"]), "fq_sw": max(1.0, per_step["sw_tasks"]), "fq_refine": max(1.0, per_step["refine_tasks"])}
+             "fq_sa": max(1.0, per_step["sa_rows"]), "fq_sw": max(1.0, per_step["sw_tasks"]), "fq_refine": max(1.0, per_step["refine_tasks"]),
+             "fq_md": max(1.0, per_step["reads_searched"])}      # (MD: one string per mapped read; searched reads are the closest count the bench line carries)
     fe, wr = mean_kb(dfetch), mean_kb(dwrite)
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "pmc_traffic.json")
     out = json.load(open(path)) if os.path.exists(path) else {}
