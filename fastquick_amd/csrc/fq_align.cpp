@@ -1040,7 +1040,8 @@ int stageA_search(Call &K) {
       wa.prec = c->d_prec.p; wa.pstride = Ppad; wa.winfo = c->d_winfo.p; wa.maxdiff_lut = c->d_maxdiff.p; wa.bid_end = c->d_bid_end.p; wa.counters = c->d_counters.p;
       // device-filling launches of several contexts take turns (fqdev::device_turn_begin)
       struct Turn { bool held = false; void take() { if (!held) { fqdev::device_turn_begin(); held = true; } } void drop() { if (held) { fqdev::device_turn_end(); held = false; } } ~Turn() { drop(); } } turn;
-      const bool big_call = c->kn.device_turns > 0 && !T.coop && c->kn.gap_nogap_min >= 0 && (int64_t)n_search >= std::max(c->kn.gap_nogap_min, c->kn.device_turn_min);
+      const bool big_call = c->kn.device_turns > 0 && !T.coop && c->kn.gap_nogap_min >= 0 && (int64_t)n_search >= std::max(c->kn.gap_nogap_min, c->kn.device_turn_min) &&
+                            (c->kn.device_turns != 3 || T.nogap);   // 3: the round after the one without gap children runs beside the other contexts' stages
       if (big_call && c->kn.device_turns >= 2) turn.take();
       fqdev::time_begin(FQ_K_WIDTH);
       CK(fqdev::launch_width(wa));
@@ -1816,6 +1817,11 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
   if (!mm) c->p_omd.p[0] = 0;
   if (!xx) c->p_omulti.p[0] = fq_multi_t{};
   K.trace("result arrays D2H");
+  if (cnt[FQ_C_ERR_DRAW0]) {
+    c->err = "the drand48 stream drew exactly 0 for the first best hit of a read (once in 2^48 draws): bwa_aln2seq_core then takes no hit and the reference's "
+             "record keeps the SA row of the read slot's previous occupant (libbwa/bwase.c:29-41) -- its result is undefined, and so this call is refused";
+    return FQ_ELIMIT;
+  }
   if (cnt[FQ_C_ERR_CIGAR]) { c->err = "refine: CIGAR longer than the device slot"; return FQ_ELIMIT; }
   if (cnt[FQ_C_ERR_MD]) { c->err = "MD string longer than the device slot"; return FQ_ELIMIT; }
   S.rec = c->p_orec.p; S.cigar = c->p_ocig.p; S.md = c->p_omd.p; S.multi = c->p_omulti.p;

@@ -152,4 +152,4 @@ struct FqMdTask {
 // work counters written by kernels (one u64 each, atomically accumulated per wave)
 enum { FQ_C_OCC_WIDTH = 0, FQ_C_OCC_GAP, FQ_C_OCC_SA, FQ_C_PROBES, FQ_C_POPS, FQ_C_PUSHES, FQ_C_MAXPOPS, FQ_C_POPS_GT4K, FQ_C_MAXTRIPS, FQ_C_SUMTRIPS, FQ_C_LANETRIPS, FQ_C_BASES, FQ_C_BADLEN, FQ_C_OCC_NOGAP, FQ_C_DBG0, FQ_C_DBG_END = FQ_C_DBG0 + 16,
        // record stages (fq_records.h): pairs a lane paired, pairs with both ends unmapped, main hits resolved without enumeration, refine / MD slots that were too small
-       FQ_C_PAIRS_DEV = FQ_C_DBG_END, FQ_C_UNMAPPED, FQ_C_SA_DIRECT, FQ_C_ERR_CIGAR, FQ_C_ERR_MD, FQ_C_MD_READS, FQ_C_COUNT };
+       FQ_C_PAIRS_DEV = FQ_C_DBG_END, FQ_C_UNMAPPED, FQ_C_SA_DIRECT, FQ_C_ERR_CIGAR, FQ_C_ERR_MD, FQ_C_MD_READS, FQ_C_ERR_DRAW0, FQ_C_COUNT };

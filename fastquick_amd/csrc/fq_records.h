@@ -199,10 +199,14 @@ FQ_HD void fq_main_draws(uint64_t &x, const FqAln *a, uint32_t na) {
     cnt += wdt;
   }
 }
-FQ_HD void fq_main_choose(uint64_t &x, const FqAln *a, uint32_t na, FqDRec &s) {
-  if (na == 0) { s.type = FQ_TYPE_NO_MATCH; s.c1 = s.c2 = 0; return; }
+// Returns false when NO hit was taken: the first best hit is taken "unless the draw is exactly 0" -- once in 2^48 draws -- and then the
+// reference's record keeps the SA row its read slot held before (unmodellable), which it resolves and reads the reference at, wherever
+// that is.  The caller un-maps the record (no kernel may follow a wild position) and the call fails, loudly (FQ_C_ERR_DRAW0).
+FQ_HD bool fq_main_choose(uint64_t &x, const FqAln *a, uint32_t na, FqDRec &s) {
+  if (na == 0) { s.type = FQ_TYPE_NO_MATCH; s.c1 = s.c2 = 0; return true; }
   const int best = a[0].score;
   uint32_t i, cnt = 0;
+  bool taken = false;
   for (i = 0; i < na; ++i) {
     const FqAln p = a[i];
     if (p.score > best) break;
@@ -212,6 +216,7 @@ FQ_HD void fq_main_choose(uint64_t &x, const FqAln *a, uint32_t na, FqDRec &s) {
       s.score = p.score;
       s.sa = p.k + (uint32_t)((double)wdt * fq_rng_step(x));
       s.main_aln = (int16_t)i;
+      taken = true;
     }
     cnt += wdt;
   }
@@ -219,6 +224,7 @@ FQ_HD void fq_main_choose(uint64_t &x, const FqAln *a, uint32_t na, FqDRec &s) {
   for (; i < na; ++i) cnt += a[i].l - a[i].k + 1;
   s.c2 = (cnt - s.c1) & 0xfffffff;
   s.type = s.c1 > 1 ? FQ_TYPE_REPEAT : FQ_TYPE_UNIQUE;
+  return taken;
 }
 FQ_HD int fq_approx_mapq(const FqRecArgs &A, const FqDRec &p) {
   const int mm = A.maxdiff_lut[p.len];
@@ -262,11 +268,12 @@ FQ_HD void fq_main_hit_thread(const FqRecArgs &A, int sp) {
     const int s = p[e].sidx;
     const FqAln *a = s >= 0 ? A.hits + A.aoff[s] : nullptr;
     const uint32_t na = s >= 0 ? A.an[s] : 0u;
-    fq_main_choose(x, a, na, p[e]);
+    if (!fq_main_choose(x, a, na, p[e])) {
+      p[e].type = FQ_TYPE_NO_MATCH; p[e].c1 = p[e].c2 = 0;
+      FQ_ATOMIC_ADD64(&A.counters[FQ_C_ERR_DRAW0], 1);
+    }
     if (fq_rec_mapped(p[e])) {
-      // (a main hit's row lies in its hit's interval -- unless no hit was taken at all: the one draw of a one-hit read was exactly 0,
-      //  once in 2^48 draws; the record then keeps sa = 0 and the reference resolves that row like any other)
-      if (A.enumerated[idx] && p[e].sa >= a[p[e].main_aln].k && p[e].sa <= a[p[e].main_aln].l) {
+      if (A.enumerated[idx]) {
         uint64_t row = A.row0[idx];
         for (int k = 0; k < p[e].main_aln; ++k) row += (uint64_t)(a[k].l - a[k].k) + 1;
         p[e].pos = A.pos[row + (p[e].sa - a[p[e].main_aln].k)];
