@@ -362,6 +362,7 @@ def main() -> None:
                  "h2d_GBps": round(agg["h2d_bytes"] * world / elapsed / 1e9 / world, 2), "d2h_GBps": round(agg["d2h_bytes"] / elapsed / 1e9, 3)},
         "stage_ms_per_call": {K_NAMES[k]: round(kms[k] / calls, 4) for k in range(len(K_NAMES))},
         "host_ms_per_call": round(agg["host_ms_total"] / calls, 3), "wall_ms_per_call": round(agg["wall_ms_total"] / calls, 3),
+        "host_cpu_ms_per_call": round(agg["host_cpu_ms"] / calls, 3), "device_wait_ms_per_call": round(agg["device_wait_ms"] / calls, 3),
         "survivor_pairs_per_call": round(main_leg["n_records"] / calls, 1),
         "work_per_call": {k: round(agg[k] / calls, 1) for k in ("filter_probes", "occ_block_touches", "gap_occ_touches", "gap_nogap_touches", "stack_pops",
                                                                      "stack_pushes", "sa_rows", "reads_searched", "sw_tasks", "refine_tasks", "tier_retries", "reads_over_4k_pops")},
@@ -450,6 +451,7 @@ def main() -> None:
                            "device_ms_per_call": device_ms(a2, leg["calls"]),
                            "distinct_batches": leg["n_distinct"],
                            "host_ms_per_call": round(a2["host_ms_total"] / leg["calls"], 3),
+                           "host_cpu_ms_per_call": round(a2["host_cpu_ms"] / leg["calls"], 3), "device_wait_ms_per_call": round(a2["device_wait_ms"] / leg["calls"], 3),
                            "reads_searched_per_call": round(a2["reads_searched"] / leg["calls"], 1),
                            "stack_pops_per_read": round(a2["stack_pops"] / max(1, a2["reads_searched"]), 1),
                            "occ_touches_per_read": round(a2["gap_occ_touches"] / max(1, a2["reads_searched"]), 1)}

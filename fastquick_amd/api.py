@@ -85,7 +85,8 @@ class Stats(C.Structure):
                 ("host_ms_serial", C.c_double), ("host_ms_pair", C.c_double), ("host_ms_total", C.c_double),
                 ("wall_ms_total", C.c_double), ("wave_trips", C.c_uint64), ("lane_trips", C.c_uint64),
                 ("h2d_bytes", C.c_uint64), ("d2h_bytes", C.c_uint64), ("pairs_on_device", C.c_uint64), ("dbg", C.c_uint64 * 16),
-                ("width_occ_touches", C.c_uint64), ("md_reads", C.c_uint64), ("host_pairs", C.c_uint64)]
+                ("width_occ_touches", C.c_uint64), ("md_reads", C.c_uint64), ("host_pairs", C.c_uint64),
+                ("device_wait_ms", C.c_double), ("host_cpu_ms", C.c_double)]
 
 
 EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destroy", "fq_index_l_pac",

@@ -275,6 +275,7 @@ struct fq_ctx {
     std::vector<int32_t> work, next_work;
   } cv;
   fq_stats_t stats{};
+  double wait_ms = 0;                  // time the calling thread has spent waiting for the device (sync_staged)
   ~fq_ctx();
 };
 
@@ -402,7 +403,9 @@ static int d2h_staged(fq_ctx *c, void *dst, const void *src, size_t bytes) {   /
   return 0;
 }
 static int sync_staged(fq_ctx *c) {
+  const double t_wait = now_ms();
   if (fqdev::sync()) { c->err = std::string("sync: ") + fqdev::last_error(); return FQ_ENODEV; }
+  c->wait_ms += now_ms() - t_wait;       // (the thread sleeps here: fq_stats_t::device_wait_ms)
   for (auto &o : c->arena.pending) memcpy(o.dst, o.src, o.bytes);
   c->arena.pending.clear();
   return 0;
@@ -677,6 +680,7 @@ struct Call {
   std::thread plan_thread;             // the plan is drawn up beside the SA stage when nothing else can move the stream's state
   ~Call() { if (plan_thread.joinable()) plan_thread.join(); }
   double t_trace = 0, t_wall0 = 0, t_host0 = 0, t_serial1 = 0, t_host1 = 0, cpu_trace = 0;
+  double w_call0 = 0, w_host0 = 0, w_serial1 = 0, w_host1 = 0, cpu_call0 = 0;   // the context's wait_ms at those marks; the calling thread's CPU time at the start
   int sidx(size_t idx) const { return c->h_surv[idx].sidx; }
   const FqAln *aln_of(size_t idx, int *n_out) const {
     const int s = sidx(idx);
@@ -1041,7 +1045,11 @@ int stageA_search(Call &K) {
       // device-filling launches of several contexts take turns (fqdev::device_turn_begin)
       struct Turn { bool held = false; void take() { if (!held) { fqdev::device_turn_begin(); held = true; } } void drop() { if (held) { fqdev::device_turn_end(); held = false; } } ~Turn() { drop(); } } turn;
       const bool big_call = c->kn.device_turns > 0 && !T.coop && c->kn.gap_nogap_min >= 0 && (int64_t)n_search >= std::max(c->kn.gap_nogap_min, c->kn.device_turn_min) &&
-                            (c->kn.device_turns != 3 || T.nogap);   // 3: the round after the one without gap children runs beside the other contexts' stages
+                            (T.nogap || !(c->kn.device_turns == 3 || (c->kn.device_turns == 2 && g_calls_in_flight.load(std::memory_order_relaxed) >= 3)));
+      // (The round after the one without gap children is latency-bound -- half of the vector ALUs idle -- and shares the device well: with three or
+      //  more calls in flight there is always another context's stage to run beside it, and it leaves the turn to them: 3.2 -> 3.45 / 3.3 -> 3.6 x 10^7
+      //  pairs/s with three / four on-target streams.  With two streams it keeps its turn: +3 % is not worth timing the kernel under a neighbour.
+      //  device_turns = 3: never takes it.)
       if (big_call && c->kn.device_turns >= 2) turn.take();
       fqdev::time_begin(FQ_K_WIDTH);
       CK(fqdev::launch_width(wa));
@@ -1857,10 +1865,16 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
   c->stats.pairs_on_device += cnt[FQ_C_PAIRS_DEV];
   for (int k = 0; k < 16; ++k) c->stats.dbg[k] += cnt[FQ_C_DBG0 + k];
   c->stats.pairs += K.n;
-  c->stats.host_ms_serial += K.t_serial1 - K.t_host0;
-  c->stats.host_ms_pair += K.t_host1 - K.t_serial1;
-  c->stats.host_ms_total += K.t_host1 - K.t_host0;
+  // host_ms_*: the host's own time between the SA stage and the result arrays -- the order-dependent part (drand48 replay, insert sizes, (k,l)
+  // cache) and what follows it -- WITHOUT the waits for the device inside those sections (round 3 and before: host work with a few waits
+  // in it; since the records live on the device: waits with a little host work in them, and under sixteen streams the waits are queueing
+  // behind the other streams' kernels).  device_wait_ms: all the time the call's thread slept in waits; host_cpu_ms: the CPU time it used.
+  c->stats.host_ms_serial += (K.t_serial1 - K.t_host0) - (K.w_serial1 - K.w_host0);
+  c->stats.host_ms_pair += (K.t_host1 - K.t_serial1) - (K.w_host1 - K.w_serial1);
+  c->stats.host_ms_total += (K.t_host1 - K.t_host0) - (K.w_host1 - K.w_host0);
   c->stats.wall_ms_total += now_ms() - K.t_wall0;
+  c->stats.device_wait_ms += c->wait_ms - K.w_call0;
+  { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); c->stats.host_cpu_ms += 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec - K.cpu_call0; }
   K.trace("counters+timers");
   return FQ_OK;
 }
@@ -1895,6 +1909,8 @@ int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
   CallInFlight in_flight(c->ix);
   Call K(c);
   K.t_trace = K.t_wall0 = now_ms();
+  K.w_call0 = c->wait_ms;
+  { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); K.cpu_call0 = 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec; }
   NodePin pin;
   struct PoolScope { FqWorkPool *prev; explicit PoolScope(FqWorkPool *p) : prev(tl_pool) { tl_pool = p; } ~PoolScope() { tl_pool = prev; } } pool_scope(&c->pool);
   (void)fqdev::stream_aux(0);      // (an error return may have left the context on its second stream)
@@ -1930,7 +1946,7 @@ int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
   if (!c->before_serial && (size_t)K.n_surv * 2 >= K.par_min) K.plan_thread = std::thread([&K, c] { stageB1_plan(K, c->rng); });
   if ((rc = stage_sa_rows(K))) return rc;
   K.trace("SA enumerate+kernel");
-  K.t_host0 = now_ms();
+  K.t_host0 = now_ms(); K.w_host0 = c->wait_ms;
   // ---- the order-dependent part of the call: drand48 stream, last_ii chain, (k,l) cache.  A stream sharded over ranks by
   //      reference batch hands this state from the owner of one batch to the owner of the next around it (fq_ctx_set_serial_hooks)
   if (c->before_serial) c->before_serial(c->hook_user);
@@ -1947,7 +1963,7 @@ int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
   if (c->after_serial) c->after_serial(c->hook_user);
   c->serial_done = true;
   if (c->stream_broken) { c->err = "the hook that hands the stream's state on failed (fq_ctx_mark_stream_broken)"; return FQ_EIO; }
-  K.t_serial1 = now_ms();
+  K.t_serial1 = now_ms(); K.w_serial1 = c->wait_ms;
   K.trace("B2 isize, (k,l) cache");
   if ((rc = stageB3_pairing(K))) return rc;
   K.trace("B3 pairing+XA");
@@ -1957,7 +1973,7 @@ int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
   if (c->debug && (rc = snapshot_records(K, S.stage_S))) return rc;
   if ((rc = stageD_refine(K))) return rc;
   K.trace("D refine+MD");
-  K.t_host1 = now_ms();
+  K.t_host1 = now_ms(); K.w_host1 = c->wait_ms;
   return stage_finish(K, out);
 }
 }  // namespace

@@ -392,7 +392,7 @@ typedef struct {
   uint64_t tier_retries;        /* reads re-run with a larger search pool */
   uint64_t max_pops_per_read, reads_over_4k_pops;   /* tail of the search-length distribution */
   uint64_t max_wave_trips;      /* loop iterations of the busiest wavefront of the gap kernel (per launch, max) */
-  double host_ms_serial, host_ms_pair, host_ms_total, wall_ms_total;
+  double host_ms_serial, host_ms_pair, host_ms_total, wall_ms_total;   /* host_ms_*: the host's own time in the order-dependent part / behind it / both, waits for the device excluded */
   uint64_t wave_trips;          /* loop iterations summed over the gap kernel's wavefronts */
   uint64_t lane_trips;          /* ... summed over lanes that held a read in that iteration (wave_trips x 64 = all slots) */
   uint64_t h2d_bytes, d2h_bytes; /* bytes the calls moved over PCIe (inputs, task lists; results) */
@@ -401,6 +401,8 @@ typedef struct {
   uint64_t width_occ_touches;   /* 32-byte Occ blocks fetched by FQ_K_WIDTH alone */
   uint64_t md_reads;            /* mapped reads FQ_K_MD_KERNEL wrote an MD string for */
   uint64_t host_pairs;          /* both-mapped pairs the host paired (Q6 intervals, many rows): pairs_on_device counts the others */
+  double device_wait_ms;        /* time the calls' threads slept waiting for the device (host_ms_* exclude the waits inside their sections) */
+  double host_cpu_ms;           /* CPU time the calls' own threads used, set-up to result arrays (the pooled workers of the few parallel passes not included) */
 } fq_stats_t;
 void fq_stats_get(const fq_ctx_t *c, fq_stats_t *out);
 void fq_stats_reset(fq_ctx_t *c);

@@ -88,7 +88,7 @@ def check_one_pair_sharded(exe, g, tmp, devices):
     assert open(outn + ".bam", "rb").read() == open(out1 + ".bam", "rb").read()
 
 
-@pytest.mark.parametrize("tag", ["basic", "trim76", "qc"])      # three chunks each: both workers get work, the state crosses contexts twice
+@pytest.mark.parametrize("tag", ["basic", "qc"])      # three chunks each: both workers get work, the state crosses contexts twice
 def test_one_pair_sharded_over_two_virtual_devices(tag, golden_cases, tmp_path):
     emu = os.path.join(HERE, "emu")
     subprocess.check_call(["make", "-s", "-C", emu, "libfq_emu.so", "FASTQuick_emu"])
