@@ -86,8 +86,6 @@ int launch_scan(const uint32_t *in, uint64_t *out, uint32_t n);
 // packed[off[w] + j] = aln[w*cap + j]
 int launch_pack_aln(const FqAln *aln, const uint32_t *n_aln, const uint64_t *off, uint32_t cap, uint32_t n_work, FqAln *packed);
 int launch_sa(const FqSaArgs &a);
-int launch_saq(const FqSaQueryArgs &a);
-int launch_pair(const FqPairArgs &a);
 // A second stream of the context for work that runs beside the main stream's (the second search round of one part of a large call
 // under the first round of the next part): stream_aux(1) sends the following backend calls to it, stream_aux(0) back to the main
 // stream; stream_fork(): the aux stream waits for what the main stream holds so far; stream_join(): the reverse.
@@ -103,8 +101,5 @@ int launch_aln_index(const int32_t *work, const uint32_t *status, const uint64_t
 int launch_sw(const FqSwArgs &a);          // one task per wavefront (window + query in LDS)
 int launch_sw_serial(const FqSwArgs &a);   // one task per lane out of the task's global scratch: any window size
 int launch_refine(const FqRefineArgs &a);
-int launch_md(const FqMdArgs &a);
-// dst[off[t] ..] = src[t*cap .. +len[t]+1] (NUL included), len<0 -> nothing
-int launch_pack_md(const char *src, const int32_t *len, const uint64_t *off, int32_t cap, int32_t n, char *dst);
 
 }  // namespace fqdev

@@ -404,14 +404,6 @@ __global__ void __launch_bounds__(256) k_sa(FqSaArgs a) {
   const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (q < a.n_rows) fq_sa_thread(a, q);
 }
-__global__ void __launch_bounds__(256) k_pair(FqPairArgs a) {   // one pair per lane
-  const int t = (int)(blockIdx.x * blockDim.x + threadIdx.x);
-  if (t < a.n_jobs) fq_pair_thread(a, t);
-}
-__global__ void __launch_bounds__(256) k_saq(FqSaQueryArgs a) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
-  if (q < a.n) fq_saq_thread(a, q);
-}
 template <bool PACKED>
 __device__ int fq_global_align_wave(const uint8_t *s1, int len1, const uint8_t *s2, int len2, int band, int gap_end,
                                     int *RM, int *RI, int *RD, uint8_t *trace, uint8_t *ops, int *n_ops, int *fi, int *fj);
@@ -778,24 +770,12 @@ __global__ void __launch_bounds__(64) k_refine(FqRefineArgs a) {   // long reads
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   if (t < a.n_task) fq_refine_thread(a, t);
 }
-__global__ void __launch_bounds__(256) k_md(FqMdArgs a) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < a.n_task) fq_md_thread(a, t);
-}
 __global__ void __launch_bounds__(256) k_pack_aln(const FqAln *aln, const uint32_t *n_aln, const uint64_t *off, uint32_t cap, uint32_t n_work, FqAln *packed) {
   const uint32_t w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w >= n_work) return;
   const uint32_t n = n_aln[w];
   const uint64_t o = off[w];
   for (uint32_t j = 0; j < n; ++j) packed[o + j] = aln[(size_t)w * cap + j];
-}
-__global__ void __launch_bounds__(256) k_pack_md(const char *src, const int32_t *len, const uint64_t *off, int32_t cap, int32_t n, char *dst) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const int l = len[t];
-  if (l < 0) return;
-  const uint64_t o = off[t];
-  for (int j = 0; j <= l; ++j) dst[o + j] = src[(size_t)t * cap + j];
 }
 
 // ---- block-level exclusive scan built from 64-lane wavefront scans ------------------------------
@@ -1219,20 +1199,6 @@ int launch_sa(const FqSaArgs &a) {
   FQ_HIP(hipGetLastError());
   return 0;
 }
-int launch_saq(const FqSaQueryArgs &a) {
-  FQ_PRE();
-  if (!a.n) return 0;
-  hipLaunchKernelGGL(k_saq, dim3(nblk(a.n, 256)), dim3(256), 0, g_stream, a);
-  FQ_HIP(hipGetLastError());
-  return 0;
-}
-int launch_pair(const FqPairArgs &a) {
-  FQ_PRE();
-  if (a.n_jobs <= 0) return 0;
-  hipLaunchKernelGGL(k_pair, dim3(nblk((uint64_t)a.n_jobs, 256)), dim3(256), 0, g_stream, a);
-  FQ_HIP(hipGetLastError());
-  return 0;
-}
 static const size_t kLdsBudget = 150 * 1024;
 int launch_sw(const FqSwArgs &a) {
   FQ_PRE();
@@ -1285,20 +1251,6 @@ int launch_refine(const FqRefineArgs &a) {
   } else {
     hipExtLaunchKernelGGL(k_refine, dim3(nblk((uint64_t)a.n_task, 64)), dim3(64), 0, g_stream, e0, e1, 0, a);
   }
-  FQ_HIP(hipGetLastError());
-  return 0;
-}
-int launch_md(const FqMdArgs &a) {
-  FQ_PRE();
-  if (a.n_task <= 0) return 0;
-  hipLaunchKernelGGL(k_md, dim3(nblk((uint64_t)a.n_task, 256)), dim3(256), 0, g_stream, a);
-  FQ_HIP(hipGetLastError());
-  return 0;
-}
-int launch_pack_md(const char *src, const int32_t *len, const uint64_t *off, int32_t cap, int32_t n, char *dst) {
-  FQ_PRE();
-  if (n <= 0) return 0;
-  hipLaunchKernelGGL(k_pack_md, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, src, len, off, cap, n, dst);
   FQ_HIP(hipGetLastError());
   return 0;
 }

@@ -983,6 +983,12 @@ struct FqGapLane {
   // (Fetching the entry's window of position records ahead as well was tried: loads return in order, so the extra request only
   // moves the wait into the next trip -- 19.1 -> 21.7 ms for the second round of an on-target call.)
   uint32_t pf_slot = FQ_NIL, pfk = 0, pfl = 0, pfpk = 0, pfnext = 0;
+#if defined(FQ_GAP_INSTR)
+  uint32_t ran = 0;   // instrumented builds: which paths the lane's last trip took (1 entry load, 2 tail, 4 general step, 8 fetched-ahead pop, 16 ended at a check)
+#define FQ_RAN(x) (ran |= (x))
+#else
+#define FQ_RAN(x) ((void)0)
+#endif
   FQ_HD void flush_counters() {   // at the end of the wavefront's life
 #if defined(__HIP_DEVICE_COMPILE__)
     const uint32_t t_pops = store.cold(FQ_COLD_TPOPS), t_pushes = store.cold(FQ_COLD_TPUSHES), t_touch = store.cold(FQ_COLD_TTOUCH);
@@ -1171,6 +1177,9 @@ struct FqGapLane {
   // one trip of an active lane
   FQ_HD void step() {
     FQ_PROF(0);
+#if defined(FQ_GAP_INSTR)
+    ran = 0;
+#endif
     bool popping = !has_cur;
     int b = 0;
     uint32_t slot = 0;
@@ -1183,6 +1192,7 @@ struct FqGapLane {
       if (slot == pf_slot) {   // the entry was fetched ahead: pop it now and expand it in this same trip
         const uint32_t ek = pfk, el = pfl, epk = pfpk, enext = pfnext;
         const bool go = take_entry(b, slot, ek, el, epk, enext);
+        FQ_RAN(8);
         if (active) fetch_ahead(enext);
         if (!go) return;
         popping = false;
@@ -1211,7 +1221,7 @@ struct FqGapLane {
       bk = fq_blk_none(); bl = fq_blk_none();
     }
     if (popping) {   // ---- the entry arrives from the pool; it is expanded in the next trip -------------------------------------
-      FQ_PROF(3);
+      FQ_PROF(3); FQ_RAN(1);
       take_entry(b, slot, vA.x, vA.y, vA.z, vA.w);
       if (active) fetch_ahead(vA.w);
       return;
@@ -1228,7 +1238,7 @@ struct FqGapLane {
     const int diffs = n_mm + n_gapo + (gape_mode ? n_gape : 0);
     const int m = max_diff - diffs;
     if (!tail) {
-      if (m < b0) { FQ_PROF(6); has_cur = false; return; }        // bwtgap.c:155
+      if (m < b0) { FQ_PROF(6); FQ_RAN(16); has_cur = false; return; }        // bwtgap.c:155
       if (m == 0 && (st == FQ_ST_M || gape_mode || n_gape == o.max_gape)) { tail = true; FQ_PROF(7); }   // no difference left: exact tail
     }
     uint32_t ok4[4], ol4[4];
@@ -1243,14 +1253,14 @@ struct FqGapLane {
     const uint32_t mk = fq_sel4v(kk0, kk1, kk2, kk3, cbase & 3), ml = fq_sel4v(ll0, ll1, ll2, ll3, cbase & 3);
     const uint32_t fpk = (cpk & ~0xC00u) - 1u;                                // the match child: same counts, position i, state M
     if (tail) {   // one base of bwt_match_exact_alt (libbwa/bwt.c:102-117)
-      FQ_PROF(1);
+      FQ_PROF(1); FQ_RAN(2);
       if (cbase < 4) c_touch += touch;
       if (!mvalid) { has_cur = false; tail = false; return; }
       ck_ = mk; cl_ = ml; cpk = fpk;
       if (i == 0) { has_cur = false; tail = false; hit_pending = true; }
       return;
     }
-    FQ_PROF(8);
+    FQ_PROF(8); FQ_RAN(4);
     c_touch += touch;
     const int last_diff = (int)(cpk >> 23);
     bool allow_diff = true, allow_M = true;
@@ -1430,6 +1440,8 @@ FQ_HD void fq_gap_lanes(const FqGapArgs &A, const St &store0, Fetch fetch, int l
 #endif
 #if defined(FQ_GAP_INSTR_ROUND2)
       if (!NOGAP)      // (statistics of the full search only: what the first round left)
+#elif defined(FQ_GAP_INSTR_ROUND1)
+      if (NOGAP)
 #endif
       if (FQ_LANE_ID() == 0) for (int q = 0; q < 16; ++q) FQ_ATOMIC_ADD64(&A.counters[FQ_C_DBG0 + q], ib[q]);
 #endif
@@ -1454,10 +1466,10 @@ FQ_HD void fq_gap_lanes(const FqGapArgs &A, const St &store0, Fetch fetch, int l
       const uint64_t a2 = FQ_BALLOT(L.active);
       const int na = (int)FQ_POPC64(a2);
       ib[0] += 1; ib[1] += (uint32_t)na;
-#if FQ_GAP_INSTR != 2
+#if FQ_GAP_INSTR == 1
       ib[2 + (na == 0 ? 0 : na <= 8 ? 1 : na <= 16 ? 2 : na <= 32 ? 3 : na <= 48 ? 4 : 5)] += 1;     // 2..7: trips by active lanes (0, 1-8, 9-16, 17-32, 33-48, 49-64)
 #endif
-#if FQ_GAP_INSTR != 2
+#if FQ_GAP_INSTR == 1
       const uint64_t pop = FQ_BALLOT(L.active && !L.has_cur), tl = FQ_BALLOT(L.active && L.has_cur && L.tail), ex = FQ_BALLOT(L.active && L.has_cur && !L.tail);
       ib[8] += pop != 0; ib[9] += tl != 0; ib[10] += ex != 0;
       ib[11] += (uint32_t)FQ_POPC64(pop); ib[12] += (uint32_t)FQ_POPC64(tl); ib[13] += (uint32_t)FQ_POPC64(ex);
@@ -1488,10 +1500,21 @@ FQ_HD void fq_gap_lanes(const FqGapArgs &A, const St &store0, Fetch fetch, int l
     if (FQ_POPC64(FQ_BALLOT(L.active || L.hit_pending)) <= 2 && !any_hit) { ib[12] += (uint32_t)((tc1 - tc0) >> 4); ib[13] += 1; }   // sparse wavefronts (the tail of a launch): at most two lanes at work
     ib[4] += (uint32_t)FQ_POPC64(shm); ib[5] += shm != 0;
 #else
+#if defined(FQ_GAP_INSTR) && FQ_GAP_INSTR == 3 && defined(__HIP_DEVICE_COMPILE__)
+    const bool was_active = L.active;
+#endif
     if (L.active) { ++lane_trips; L.step(); }
     const bool any_hit = FQ_BALLOT(L.hit_pending) != 0;
 #if defined(FQ_GAP_INSTR) && defined(__HIP_DEVICE_COMPILE__)
     ib[15] += any_hit;
+#if FQ_GAP_INSTR == 3
+    {   // the set of paths this trip ran (entry load / tail / general step) and the lanes on each
+      const uint32_t rn = was_active ? L.ran : 0u;
+      const uint64_t mp = FQ_BALLOT((rn & 1u) != 0), mt = FQ_BALLOT((rn & 2u) != 0), mg = FQ_BALLOT((rn & 4u) != 0), mf = FQ_BALLOT((rn & 8u) != 0), md = FQ_BALLOT((rn & 16u) != 0);
+      ib[2 + ((mp | mf) != 0) + 2 * (mt != 0) + 4 * (mg != 0)] += 1;
+      ib[10] += (uint32_t)FQ_POPC64(mp); ib[11] += (uint32_t)FQ_POPC64(mt); ib[12] += (uint32_t)FQ_POPC64(mg); ib[13] += (uint32_t)FQ_POPC64(mf); ib[14] += (uint32_t)FQ_POPC64(md);
+    }
+#endif
 #endif
     if (any_hit) L.collect_hits();
 #endif
@@ -1946,23 +1969,6 @@ FQ_HD void fq_sa_thread(const FqSaArgs &A, uint64_t q) {
   A.pos[q] = p;
   FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_SA], steps);
 }
-// stand-alone queries (main hits of reads whose rows were not enumerated)
-struct FqSaQueryArgs {
-  FqDevIndex ix;
-  const uint32_t *row;
-  const uint32_t *info;      // strand<<31 | len
-  uint32_t n;
-  uint32_t *pos;
-  uint64_t *counters;
-};
-FQ_HD void fq_saq_thread(const FqSaQueryArgs &A, uint32_t q) {
-  const int a = (int)(A.info[q] >> 31);
-  const uint32_t len = A.info[q] & 0x7fffffffu;
-  uint32_t steps = 0;
-  A.pos[q] = a ? fq_sa_lookup(A.ix.fm[0], A.row[q], &steps) : A.ix.fm[1].seq_len - (fq_sa_lookup(A.ix.fm[1], A.row[q], &steps) + len);
-  FQ_ATOMIC_ADD64(&A.counters[FQ_C_OCC_SA], steps);
-}
-
 // ---- dynamic programming: libbwa/stdaln.c with aln_param_bwa {26,9,5,aln_sm_maq,5,50} (:227) ------
 #define FQ_GAP_O 26
 #define FQ_GAP_E 9
@@ -2402,19 +2408,6 @@ FQ_HD void fq_refine_thread(const FqRefineArgs &A, int t) {
 }
 
 // ---- K_md: bwa_cal_md1 (libbwa/bwase.c:234-296) ---------------------------------------------------
-struct FqMdArgs {
-  FqDevIndex ix;
-  const uint8_t *seq;
-  int32_t stride;
-  const FqMdTask *task;
-  int32_t n_task;
-  const uint16_t *cigar;   // arena referenced by task.cigar_off
-  char *md;                // [n_task][md_cap]
-  int32_t md_cap;
-  int32_t *md_len;         // out (excluding NUL); -1 on overflow
-  uint32_t *md_sz;         // out: bytes to pack (len+1, or 0 on overflow)
-  int32_t *nm;             // out
-};
 FQ_HD int fq_put_int(char *dst, int at, int cap, int v) {
   char tmp[12]; int n = 0;
   if (v == 0) tmp[n++] = '0';
@@ -2480,16 +2473,6 @@ FQ_HD void fq_md_core(const FqDevIndex &ix, const uint8_t *row, const FqMdTask &
   at = fq_put_int(dst, at, cap, u);
   *at_out = at; *nm_out = nm;
 }
-FQ_HD void fq_md_thread(const FqMdArgs &A, int t) {
-  const FqMdTask T = A.task[t];
-  char *dst = A.md + (size_t)t * (size_t)A.md_cap;
-  const int cap = A.md_cap - 1;
-  int at = 0, nm = 0;
-  fq_md_core(A.ix, A.seq + (size_t)T.read * (size_t)A.stride, T, A.cigar, dst, cap, &at, &nm);
-  if (at > cap) { A.md_len[t] = -1; A.md_sz[t] = 0; dst[0] = 0; }
-  else { dst[at] = 0; A.md_len[t] = at; A.md_sz[t] = (uint32_t)at + 1; }
-  A.nm[t] = nm;
-}
 
 // ---- K_pair: paired-end pairing (pairing, libbwa/bwape.c:119-213; __pairing_aux / __pairing_aux2, bwape.h:55-82) --------------
 // One lane per pair whose two reads are both mapped: every position of every hit of both reads (the rows k_sa resolved) becomes
@@ -2502,20 +2485,6 @@ FQ_HD void fq_md_thread(const FqMdArgs &A, int t) {
 struct FqPairRead { uint32_t pos; int32_t len, full_len; uint32_t bits; };   // bits: strand | mapQ << 8 | seQ << 16
 struct FqPairOut { uint32_t pos, info; int32_t score; uint32_t bits; };      // info: n_mm | n_gapo << 8 | n_gape << 16; bits: mapQ | seQ << 8 | strand << 16 | paired << 24 | moved << 25
 struct FqPairIsize { uint32_t high, high_bayesian; int32_t lut_off, pad; };  // of one reference batch; lut[lut_off + l], l <= high_bayesian
-struct FqPairJob { uint32_t q0, na0, q1, na1, batch; };                       // the reads' hits: aln[q0 .. q0 + na0), aln[q1 .. q1 + na1)
-struct FqPairArgs {
-  const FqPairJob *jobs;
-  int32_t n_jobs;
-  const FqPairRead *reads;    // [2 * n_jobs]
-  const FqAln *aln;           // the hits k_sa enumerated, reads' lists consecutive
-  const uint64_t *row_off;    // per hit: its first row in pos
-  const uint32_t *pos;
-  uint64_t *scratch;          // as long as pos: a pair's list is built where its rows are
-  const FqPairIsize *isize;
-  const int32_t *lut, *g_log_n;
-  int32_t max_isize, s_mm;
-  FqPairOut *out;             // [2 * n_jobs]
-};
 FQ_HD uint64_t fq_hash_64(uint64_t key) {   // libbwa/bwape.h:42-53
   key += ~(key << 32); key ^= (key >> 22); key += ~(key << 13); key ^= (key >> 8);
   key += (key << 3); key ^= (key >> 15); key += ~(key << 27); key ^= (key >> 31);
@@ -2588,25 +2557,4 @@ FQ_HD void fq_pair_sweep(const FqAln *aln0, const FqAln *aln1, const FqPairRead 
   out[0].bits = (uint32_t)mq0 | (uint32_t)sq0 << 8 | (uint32_t)rr0 << 16 | 1u << 24 | (same0 ? 0u : 1u << 25);
   out[1].pos = (uint32_t)(A.o_pos1 >> 32); out[1].info = b1.info & 0xffffffu; out[1].score = b1.score;
   out[1].bits = (uint32_t)mq1 | (uint32_t)sq1 << 8 | (uint32_t)rr1 << 16 | 1u << 24 | (same1 ? 0u : 1u << 25);
-}
-// one pair: list its rows, sort (a handful of entries for all but repeats: insertion sort where the rows lie), sweep
-FQ_HD void fq_pair_thread(const FqPairArgs &A, int t) {
-  const FqPairJob jb = A.jobs[t];
-  const FqAln *aln0 = A.aln + jb.q0, *aln1 = A.aln + jb.q1;
-  uint64_t *arr = A.scratch + A.row_off[jb.q0];
-  uint32_t n = 0;
-  for (int j = 0; j < 2; ++j) {
-    const uint32_t q = j ? jb.q1 : jb.q0, na = j ? jb.na1 : jb.na0;
-    for (uint32_t k = 0; k < na; ++k) {
-      const uint32_t wdt = A.aln[q + k].l - A.aln[q + k].k + 1;
-      const uint32_t *ps = A.pos + A.row_off[q + k];
-      for (uint32_t z = 0; z < wdt; ++z) {
-        const uint64_t x = (uint64_t)ps[z] << 32 | (uint64_t)(k << 1) | (uint64_t)j;
-        uint32_t at = n++;
-        while (at > 0 && arr[at - 1] > x) { arr[at] = arr[at - 1]; --at; }
-        arr[at] = x;
-      }
-    }
-  }
-  fq_pair_sweep(aln0, aln1, A.reads + 2 * (size_t)t, arr, n, A.isize[jb.batch], A.lut, A.g_log_n, A.max_isize, A.s_mm, A.out + 2 * (size_t)t);
 }

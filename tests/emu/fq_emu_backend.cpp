@@ -132,7 +132,6 @@ int launch_pack_aln(const FqAln *aln, const uint32_t *n_aln, const uint64_t *off
   return 0;
 }
 int launch_sa(const FqSaArgs &a) { for (uint64_t q = 0; q < a.n_rows; ++q) fq_sa_thread(a, q); return 0; }
-int launch_saq(const FqSaQueryArgs &a) { for (uint32_t q = 0; q < a.n; ++q) fq_saq_thread(a, q); return 0; }
 int stream_aux(int) { return 0; }
 int stream_fork() { return 0; }
 int stream_join() { return 0; }
@@ -142,7 +141,6 @@ int launch_collect(const int32_t *order, const uint32_t *, int n_work, int seg, 
   for (uint32_t pos = lo; pos < hi; ++pos) { const int w = order ? order[pos] : (int)pos; if (status[w]) out[(*count)++] = work[w]; }
   return 0;
 }
-int launch_pair(const FqPairArgs &a) { for (int t = 0; t < a.n_jobs; ++t) fq_pair_thread(a, t); return 0; }
 int launch_rec(int op, const FqRecArgs &a, int64_t n) {
   typedef void (*Body)(const FqRecArgs &, int);
   static const Body bodies[FQ_ROP_COUNT] = {fq_rec_init_thread, fq_rec_nocc_thread, fq_enum_plan_thread, fq_enum_fill_thread, fq_main_hit_thread, fq_compact_thread, fq_pair_rec_thread,
@@ -159,11 +157,6 @@ int launch_aln_index(const int32_t *work, const uint32_t *status, const uint64_t
 int launch_sw(const FqSwArgs &a) { for (int t = 0; t < a.n_task; ++t) fq_sw_thread(a, t); return 0; }
 int launch_sw_serial(const FqSwArgs &a) { return launch_sw(a); }
 int launch_refine(const FqRefineArgs &a) { for (int t = 0; t < a.n_task; ++t) fq_refine_thread(a, t); return 0; }
-int launch_md(const FqMdArgs &a) { for (int t = 0; t < a.n_task; ++t) fq_md_thread(a, t); return 0; }
-int launch_pack_md(const char *src, const int32_t *len, const uint64_t *off, int32_t cap, int32_t n, char *dst) {
-  for (int t = 0; t < n; ++t) if (len[t] >= 0) memcpy(dst + off[t], src + (size_t)t * cap, (size_t)len[t] + 1);
-  return 0;
-}
 int launch_bitmap_scatter(uint8_t *bitmap, const uint32_t *bits, uint64_t n) {
   for (uint64_t i = 0; i < n; ++i) bitmap[bits[i] >> 3] |= (uint8_t)(1u << (bits[i] & 7));
   return 0;

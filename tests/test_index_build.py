@@ -62,3 +62,19 @@ def test_no_device_is_a_loud_error(golden_cases):
         pytest.skip("a GPU is present")
     with pytest.raises(api.FastquickError):
         api.Index(golden_cases["basic"]["prefix"], device=0)
+
+
+def test_host_cpus_follow_the_ranks_of_a_node():
+    """fq_host_cpus(): the CPUs the process may use -- its cgroup quota -- divided among the ranks of a node (torchrun's LOCAL_WORLD_SIZE),
+    or stated outright (FASTQUICK_HOST_CPUS): eight ranks must not each size their host threads for the whole allowance."""
+    import subprocess
+    import sys
+    code = "import sys; sys.path.insert(0, %r); from fastquick_amd import api; print(api.load_library().fq_host_cpus())" % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("LOCAL_WORLD_SIZE", "FASTQUICK_HOST_CPUS")}
+    whole = int(subprocess.check_output([sys.executable, "-c", code], env=env))
+    assert whole >= 1
+    if whole >= 2:
+        half = int(subprocess.check_output([sys.executable, "-c", code], env=dict(env, LOCAL_WORLD_SIZE="2")))
+        assert half == max(1, whole // 2)
+    one = int(subprocess.check_output([sys.executable, "-c", code], env=dict(env, FASTQUICK_HOST_CPUS="1", LOCAL_WORLD_SIZE="8")))
+    assert one == 1

@@ -42,7 +42,9 @@ for var in variants:
           % (var, 1e3 * dt, km[8], kl[8], km[7], kl[7], km[2], km[1], s["stack_pops"] / max(1, reads), s["gap_occ_touches"], s["gap_nogap_touches"],
              s["max_wave_trips"], s["wave_trips"], s["lane_trips"], s["tier_retries"], dig), flush=True)
     d = s["dbg"]
-    if d[0]:
+    if d[0] and os.environ.get("FQ_INSTR_RAW"):
+        print("   INSTR raw", list(d[:16]), flush=True)
+    elif d[0]:
         print("   INSTR trips %d  step clocks/trip %.0f | pop trips %d: %.0f clk | occ-only %d: %.0f | rec-fetch %d: %.0f | sparse(<=2 lanes) %d: %.0f clk | lifetime sum %.0f Mclk"
               % (d[0], 16.0 * d[2] / max(1, d[0]), d[7], 16.0 * d[6] / max(1, d[7]), d[9], 16.0 * d[8] / max(1, d[9]), d[11], 16.0 * d[10] / max(1, d[11]), d[13], 16.0 * d[12] / max(1, d[13]), 16.0 * d[14] / 1e6), flush=True)
     al.close()
