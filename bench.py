@@ -545,7 +545,7 @@ def main() -> None:
             with open(os.path.join(fdir, "out.sam"), "wb") as so:
                 run = subprocess.run(cmd, stdout=so, stderr=subprocess.PIPE)
             dt = time.perf_counter() - t0
-            notes = [l for l in run.stderr.decode(errors="replace").splitlines() if "device time" in l or "consumers" in l or "index staged" in l]
+            notes = [l for l in run.stderr.decode(errors="replace").splitlines() if "device time" in l or "consumers" in l or "index staged" in l or "reading (ms)" in l]
             fe["cli_e2e_pairs_per_s"] = round(nfe / dt, 1) if run.returncode == 0 else None
             fe["cli_e2e"] = {"rc": run.returncode, "pairs": nfe, "wall_s": round(dt, 2), "mix": args.mix, "output": "SAM text", "notices": notes}
             # ---- the same at a steady state: the two BGZF files concatenated `--front-end-copies` times (BGZF members concatenate), so that index
@@ -576,7 +576,7 @@ def main() -> None:
                     run2 = subprocess.run(cmd2, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
                     dt2 = time.perf_counter() - t0
                     steady[label] = {"rc": run2.returncode, "wall_s": round(dt2, 2), "pairs_per_s": round(nfe * copies / dt2, 1) if run2.returncode == 0 else None,
-                                     "notices": [l for l in run2.stderr.decode(errors="replace").splitlines() if "consumers" in l or "index staged" in l][-2:]}
+                                     "notices": [l for l in run2.stderr.decode(errors="replace").splitlines() if "consumers" in l or "index staged" in l or "reading (ms)" in l][-3:]}
                 for b_ in big:
                     os.remove(b_)
                 for ext in (".SelectedSite.vcf", ".dbSNP.subset.vcf", ".gc", ".param", ".genome.fa.fai"):      # (the other legs run without the QC consumer)

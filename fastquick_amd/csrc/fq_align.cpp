@@ -139,6 +139,7 @@ struct PinArena {
 struct FqKnobs {   // experiment / test knobs (fq_ctx_set_tuning); defaults are what DESIGN.md measures
   uint32_t gap_long_pops = 256;    // lane kernel hands a search to the wavefront-per-read kernel after this many pops (queue dry); 1,024 -> 256: single-stream WGS call 19.4 -> 17.3 ms, search stage 8.0 -> 5.7 ms
   int gap_long_always = 0;         // ... whatever the state of the queue (tests)
+  int64_t gap_skip_bound = -1;     // first round: reads whose lower bound on the differences (both strands) is at least this go straight to the full search; -1: the smallest bound that rules out a hit the round could settle, 0: none
   uint32_t gap_long_pops2 = 0;     // hand-over threshold of the second round of a device-filling call (0: no hand-over)
   int64_t gap_split_hard = 0;      // experiment: after the round without gap children, search reads whose lower bound is >= this in a launch of their own (0: off)
   int64_t gap_pipeline_min = -1;        // experiment (off): calls that search at least this many reads run the first round in segments, each segment's second round beside the next segment's first
@@ -347,6 +348,7 @@ extern "C" int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t v) {
   else if (k == "gap_pipeline_segs") c->kn.gap_pipeline_segs = (int)std::max<int64_t>(2, std::min<int64_t>(v, 64));
   else if (k == "gap_split_hard") c->kn.gap_split_hard = v;
   else if (k == "gap_long_pops2") c->kn.gap_long_pops2 = (uint32_t)v;
+  else if (k == "gap_skip_bound") c->kn.gap_skip_bound = v;
   else if (k == "gap_no_order") c->kn.gap_no_order = (int)v;
   else if (k == "device_turns") c->kn.device_turns = (int)v;
   else if (k == "device_turn_min") c->kn.device_turn_min = v;
@@ -1060,6 +1062,11 @@ int stageA_search(Call &K) {
       ga.wfull = c->d_wfull.p; ga.wstride = Lpad; ga.prec = c->d_prec.p; ga.pstride = Ppad;
       ga.pool = c->d_pool.p; ga.heads = c->d_heads.p; ga.tier = T; ga.aln = c->d_aln.p; ga.n_aln = c->d_naln.p; ga.status = c->d_status.p;
       ga.counters = c->d_counters.p; ga.queue = c->d_queue.p;
+      if (T.nogap) {   // a hit of b mismatches settles a read only if (b + 1) * s_mm < s_gapo (FqGapLane::finish)
+        ga.bid_end = c->d_bid_end.p;
+        // (-1: calls of up to 4 M searched reads, where the next round is all tail and starts its long searches at once anyway; see FqGapArgs::skip_bound)
+        ga.skip_bound = c->kn.gap_skip_bound >= 0 ? (int32_t)c->kn.gap_skip_bound : o.s_mm > 0 && n_search <= ((int64_t)4 << 20) ? std::max(1, (o.s_gapo + o.s_mm - 1) / o.s_mm - 1) : 0;
+      }
       // The round after the one without gap children holds the hard reads only: their lengths differ by orders of magnitude, so a
       // wavefront that waits for all 64 lanes before it refills idles most of them (28.9 -> 24.2 ms for the 228 k reads a 4.2 M-read
       // call leaves); the first round keeps whole-wavefront refill, its reads finish together (refill by 16: 23.8 -> 25.8 ms).

@@ -274,10 +274,13 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
     pair_seq[sl].resize((size_t)2 * A.chunk_pairs * stride); pair_qual[sl].resize((size_t)2 * A.chunk_pairs * stride);
     for (int e = 0; e < 2; ++e) { bufs[sl][e].ext_seq = pair_seq[sl].data() + (size_t)e * A.chunk_pairs * stride; bufs[sl][e].ext_qual = pair_qual[sl].data() + (size_t)e * A.chunk_pairs * stride; }
   }
+  double read_all_ms = 0, read_wait_ms = 0, align_ms = 0;   // every chunk's read (on the prefetch thread), and what of it the loop had to wait for
   auto read_both = [&](int slot) {
+    const auto tr0 = std::chrono::steady_clock::now();
     std::thread t0(fill_chunk, std::ref(r1), std::ref(bufs[slot][0]), A.chunk_pairs, stride, name_stride);
     std::thread t1(fill_chunk, std::ref(r2), std::ref(bufs[slot][1]), A.chunk_pairs, stride, name_stride);
     t0.join(); t1.join();
+    read_all_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count();
   };
   fq_packed_batch_t *pk = nullptr;   // packed-batch storage, reused from chunk to chunk (pinned once)
   if (fq_packed_create((int32_t)A.chunk_pairs, stride, &pk)) die("out of pinned host memory for the packed batch");
@@ -314,8 +317,10 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
     rc = fq_pack_reads_into(&in, A.pack_threads, pk);
     pack_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
     if (rc) die("fq_pack_reads failed (" + std::to_string(rc) + ")");
+    const auto ta0 = std::chrono::steady_clock::now();
     rc = fq_align_packed(ctx, pk, &res);
     if (rc) die(std::string("fq_align_packed failed: ") + fq_ctx_last_error(ctx));
+    align_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta0).count();
     // the consumers, in the reference's order: StatCollector, then the record writer (src/BwtMapper.cpp:2047-2050, 2075-2085)
     const auto tc0 = std::chrono::steady_clock::now();
     if (qc && (rc = fq_qc_add_last(qc, ctx))) die(std::string("QC consumer failed: ") + fq_qc_last_error(qc));
@@ -330,7 +335,9 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
     qc_ms += std::chrono::duration<double, std::milli>(tc1 - tc0).count(); out_ms += std::chrono::duration<double, std::milli>(tc2 - tc1).count();
     num_read += 2LL * n; filtered += res.n_both_filtered; unmapped += res.n_both_unmapped; num_base += res.n_bases;
     fprintf(stderr, "NOTICE - %lld sequences are processed.\n", num_read);
+    const auto tw0 = std::chrono::steady_clock::now();
     if (prefetch.joinable()) prefetch.join();
+    read_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
     if (last) break;
   }
   out.flush();
@@ -343,6 +350,7 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
   fprintf(stderr, "NOTICE - device time (ms): prep %.1f width %.1f gap %.1f sa %.1f sw %.1f refine %.1f ; host %.1f ; wall %.1f\n", st.kernel_ms[0],
           st.kernel_ms[1], st.kernel_ms[2], st.kernel_ms[3], st.kernel_ms[4], st.kernel_ms[5], st.host_ms_total, st.wall_ms_total);
   fprintf(stderr, "NOTICE - consumers (ms): StatCollector %.1f ; %s writer %.1f ; first chunk read %.1f ; packing %.1f\n", qc_ms, A.sam_out ? "SAM" : "BAM", out_ms, read_ms, pack_ms);
+  fprintf(stderr, "NOTICE - reading (ms): all chunks %.1f ; waited for %.1f ; alignment calls %.1f\n", read_all_ms, read_wait_ms, align_ms);
   if (qc) fq_qc_end_file(qc);
   fq_ctx_destroy(ctx);
   fq_packed_free(pk);

@@ -36,6 +36,7 @@
 
 #include "../../include/fastquick_amd.h"
 #include "fq_pool.h"
+#include "fq_inflate.h"
 
 namespace {
 template <class F>
@@ -198,23 +199,35 @@ inflate:
   std::atomic<int> bad{0};
   uint8_t *dst = b.data.get() + b.head;
   const uint8_t *src = r->cbuf.data();
+  // Members go through the front end's own decoder (fq_inflate.h); one it refuses is given to zlib, whose verdict stands -- what is
+  // accepted and what is reported as corrupt is what gzread / inflate() decide (FASTQUICK_ZLIB_INFLATE=1: zlib for everything, to compare).
+  static const bool zlib_only = [] { const char *e = getenv("FASTQUICK_ZLIB_INFLATE"); return e && *e && *e != '0'; }();
   par_for(r->pool_in, r->threads, ms.size(), 4, [&](size_t lo, size_t hi, int) {
+    std::unique_ptr<fqz::Inflater> fz(zlib_only ? nullptr : new fqz::Inflater);
     z_stream zs;
-    memset(&zs, 0, sizeof zs);
-    if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; return; }
+    bool zs_ready = false;
     for (size_t i = lo; i < hi; ++i) {
       const Member &m = ms[i];
       if (m.out_len == 0) continue;      // (the empty end-of-file member)
+      const uint8_t *t = src + m.in_off + m.in_len - 8;
+      const uint32_t crc = t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
+      if (fz && fqz::inflate_raw(*fz, src + m.in_off + m.hdr, m.in_len - m.hdr - 8, dst + m.out_off, m.out_len)) {
+        if (fqz::crc32(dst + m.out_off, m.out_len) != crc) { bad = 1; break; }
+        continue;
+      }
+      if (!zs_ready) {
+        memset(&zs, 0, sizeof zs);
+        if (inflateInit2(&zs, -15) != Z_OK) { bad = 1; break; }
+        zs_ready = true;
+      }
       inflateReset(&zs);
       zs.next_in = const_cast<Bytef *>(src + m.in_off + m.hdr); zs.avail_in = (uInt)(m.in_len - m.hdr - 8);
       zs.next_out = dst + m.out_off; zs.avail_out = (uInt)m.out_len;
       const int rc = inflate(&zs, Z_FINISH);
       if (rc != Z_STREAM_END || zs.avail_out != 0) { bad = 1; break; }
-      const uint8_t *t = src + m.in_off + m.in_len - 8;
-      const uint32_t crc = t[0] | (uint32_t)t[1] << 8 | (uint32_t)t[2] << 16 | (uint32_t)t[3] << 24;
       if ((uint32_t)crc32(crc32(0L, Z_NULL, 0), dst + m.out_off, (uInt)m.out_len) != crc) { bad = 1; break; }
     }
-    inflateEnd(&zs);
+    if (zs_ready) inflateEnd(&zs);
   });
   if (bad) { r->src_err = "corrupt BGZF member (inflate or CRC failed)"; return false; }
   b.n = out;
@@ -452,6 +465,13 @@ extern "C" int fq_fastq_set_sampling(fq_fastq_t *r, double frac) {
   r->frac = frac;
   return FQ_OK;
 }
+// the member decoder and the checksum on their own (tests compare them with zlib's)
+extern "C" int fq_inflate_raw(const uint8_t *src, size_t n, uint8_t *dst, size_t out_len) {
+  if ((!src && n) || (!dst && out_len)) return FQ_EINVAL;
+  std::unique_ptr<fqz::Inflater> z(new fqz::Inflater);
+  return fqz::inflate_raw(*z, src, n, dst, out_len) ? FQ_OK : FQ_EIO;
+}
+extern "C" uint32_t fq_crc32(const uint8_t *p, size_t n) { return p || !n ? fqz::crc32(p, n) : 0u; }
 extern "C" int fq_fastq_unequal_lengths(const fq_fastq_t *r) { return r ? r->shorter_after_longer.load(std::memory_order_relaxed) : 0; }
 extern "C" const char *fq_fastq_dropped_record(const fq_fastq_t *r) { return r && r->notice_dropped ? r->dropped_name.c_str() : nullptr; }
 
@@ -527,7 +547,12 @@ extern "C" int64_t fq_fastq_read(fq_fastq_t *r, int64_t max_reads, const fq_fast
         const uint8_t *e0 = p0 + nl[4 * i], *e1 = p0 + nl[4 * i + 1], *e2 = p0 + nl[4 * i + 2], *e3 = p0 + nl[4 * i + 3];
         const uint8_t *l1 = e0 + 1, *l2 = e1 + 1, *l3 = e2 + 1;
         bool ok = l0 < e0 && *l0 == '@' && l2 < e2 && *l2 == '+' && (e1 - l1) == (e3 - l3);
-        if (ok) for (const uint8_t *q = l1; q < e1; ++q) { const int c = *q; if (!is_graph(c) || c == '+' || c == '>' || c == '@') { ok = false; break; } }
+        if (ok) {   // a base line kseq reads as one token: printable, none of the record markers (no early exit: one table look-up per byte)
+          static const struct Bad { uint8_t t[256]; Bad() { for (int c = 0; c < 256; ++c) t[c] = (uint8_t)(!is_graph(c) || c == '+' || c == '>' || c == '@'); } } bad;
+          unsigned any = 0;
+          for (const uint8_t *q = l1; q < e1; ++q) any |= bad.t[*q];
+          ok = any == 0;
+        }
         if (!ok) { size_t cur = first_bad.load(); while (i < cur && !first_bad.compare_exchange_weak(cur, i)) {} break; }
         const uint8_t *nb = l0 + 1, *ne = nb;
         while (ne < e0 && !is_space(*ne)) ++ne;

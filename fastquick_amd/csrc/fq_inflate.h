@@ -1,0 +1,347 @@
+// fq_inflate.h -- raw DEFLATE (RFC 1951) decoder and CRC-32 for the FASTQ front end's BGZF members.
+//
+// The reference reads its FASTQ files through zlib's gzread (libbwa/bwaseqio.c:41-52, kseq.h:327-371); a member-parallel reader spends
+// most of its time in inflate() and crc32().  This is a from-scratch decoder for the case the front end has -- the whole member in
+// memory, the output size known from the member's trailer -- built the way fast software decoders are: a 64-bit bit buffer refilled
+// without branches, one table look-up per literal/length symbol (11 bits, second-level tables behind longer codes), one per distance
+// (8 bits), match copies in 8-byte words.  It decodes exactly what inflate() decodes or fails; the caller checks CRC-32 and ISIZE as
+// gzread does, and hands any member this decoder refuses to zlib, so what is accepted and what is reported as corrupt does not change.
+#pragma once
+#include <cstddef>
+#include <cstdint>
+#include <cstring>
+
+namespace fqz {
+
+// ---- CRC-32 (IEEE 802.3, the gzip trailer's), sixteen bytes per step -------------------------------------------------------------
+struct CrcTables {
+  uint32_t t[16][256];
+  CrcTables() {
+    for (uint32_t i = 0; i < 256; ++i) {
+      uint32_t c = i;
+      for (int k = 0; k < 8; ++k) c = (c & 1) ? 0xEDB88320u ^ (c >> 1) : c >> 1;
+      t[0][i] = c;
+    }
+    for (uint32_t i = 0; i < 256; ++i)
+      for (int s = 1; s < 16; ++s) t[s][i] = (t[s - 1][i] >> 8) ^ t[0][t[s - 1][i] & 0xff];
+  }
+};
+inline const CrcTables &crc_tables() { static const CrcTables T; return T; }
+inline uint32_t crc32(const uint8_t *p, size_t n, uint32_t crc = 0) {
+  const CrcTables &T = crc_tables();
+  uint32_t c = ~crc;
+  while (n && ((uintptr_t)p & 7)) { c = T.t[0][(c ^ *p++) & 0xff] ^ (c >> 8); --n; }
+  while (n >= 16) {
+    uint64_t a, b;
+    memcpy(&a, p, 8); memcpy(&b, p + 8, 8);
+    a ^= c;
+    c = T.t[15][a & 0xff] ^ T.t[14][(a >> 8) & 0xff] ^ T.t[13][(a >> 16) & 0xff] ^ T.t[12][(a >> 24) & 0xff] ^
+        T.t[11][(a >> 32) & 0xff] ^ T.t[10][(a >> 40) & 0xff] ^ T.t[9][(a >> 48) & 0xff] ^ T.t[8][a >> 56] ^
+        T.t[7][b & 0xff] ^ T.t[6][(b >> 8) & 0xff] ^ T.t[5][(b >> 16) & 0xff] ^ T.t[4][(b >> 24) & 0xff] ^
+        T.t[3][(b >> 32) & 0xff] ^ T.t[2][(b >> 40) & 0xff] ^ T.t[1][(b >> 48) & 0xff] ^ T.t[0][b >> 56];
+    p += 16; n -= 16;
+  }
+  while (n--) c = T.t[0][(c ^ *p++) & 0xff] ^ (c >> 8);
+  return ~c;
+}
+
+// ---- decode tables -----------------------------------------------------------------------------------------------------------------
+// entry: bits 0-7 the bits to consume -- code length (second-level entries: the length beyond the first level's bits) plus, for lengths and
+// distances, their extra bits, so that a symbol costs the bit buffer one shift; bits 8-12 the code length alone (lengths, distances: the extra
+// bits are read out of a copy of the buffer) or the second level's index bits (pointers); bits 13-15 kind; bits 16-31 literal / base value /
+// second-level offset
+// (literal entries: bit 8 set = two literals, the first in bits 16-23, the second in bits 24-31, the length that of both codes)
+enum : uint32_t { K_LIT2 = 1u << 8, K_LIT = 1u << 13, K_BASE = 1u << 14, K_EOB = 1u << 15, K_SUB = 3u << 14, K_MASK = 7u << 13 };   // (K_LIT is a bit of literals only)
+constexpr int LIT_BITS = 11, DIST_BITS = 8, MAX_CODE = 15;
+constexpr int LIT_TABLE = (1 << LIT_BITS) + 1024, DIST_TABLE = (1 << DIST_BITS) + 512;   // room for the second-level tables (enough: checked while building)
+
+struct Inflater {
+  uint32_t lit[LIT_TABLE], dist[DIST_TABLE];
+  uint8_t lens[288 + 32];
+  bool fixed_built = false;
+  uint32_t fixed_lit[LIT_TABLE], fixed_dist[DIST_TABLE];
+};
+
+inline uint32_t rev_bits(uint32_t v, int n) {
+  uint32_t r = 0;
+  for (int i = 0; i < n; ++i) { r = (r << 1) | (v & 1); v >>= 1; }
+  return r;
+}
+
+// canonical Huffman code of `n` symbols with lengths `len` -> table (first level `tb` bits).  `sym_entry(s)` = the entry of symbol s
+// without its code length.  False: over-subscribed or incomplete code (zlib accepts an incomplete distance code of one symbol, and an
+// incomplete literal/length code never; a lone distance symbol is filled in, its unused codeword left invalid).
+template <class F>
+inline bool build_table(const uint8_t *len, int n, int tb, uint32_t *table, int cap, bool allow_incomplete_single, F sym_entry) {
+  int count[MAX_CODE + 1] = {0};
+  for (int s = 0; s < n; ++s) ++count[len[s]];
+  if (count[0] == n) {   // no symbol at all: every look-up is invalid (a block without distance codes may still be all literals)
+    for (int i = 0; i < (1 << tb); ++i) table[i] = 0;
+    return allow_incomplete_single;
+  }
+  int left = 1;
+  for (int l = 1; l <= MAX_CODE; ++l) { left = (left << 1) - count[l]; if (left < 0) return false; }
+  if (left > 0 && !(allow_incomplete_single && n - count[0] == 1 && count[1] == 1)) return false;
+  uint32_t next[MAX_CODE + 2];
+  next[1] = 0;
+  for (int l = 1; l <= MAX_CODE; ++l) next[l + 1] = (next[l] + (uint32_t)count[l]) << 1;
+  for (int i = 0; i < (1 << tb); ++i) table[i] = 0;
+  // second-level tables: one per first-level prefix of the codes longer than tb bits, sized for the longest code under that prefix
+  int used = 1 << tb;
+  // (pass 1: the longest code under each long prefix)
+  uint8_t sub_bits[1 << LIT_BITS];
+  bool any_long = false;
+  for (int l = tb + 1; l <= MAX_CODE; ++l) if (count[l]) any_long = true;
+  if (any_long) {
+    memset(sub_bits, 0, (size_t)1 << tb);
+    uint32_t nx[MAX_CODE + 2];
+    memcpy(nx, next, sizeof nx);
+    for (int s = 0; s < n; ++s) {
+      const int l = len[s];
+      if (l == 0) continue;
+      const uint32_t code = nx[l]++;
+      if (l > tb) { const uint32_t pre = rev_bits(code >> (l - tb), tb); if (l - tb > sub_bits[pre]) sub_bits[pre] = (uint8_t)(l - tb); }
+    }
+    for (int pre = 0; pre < (1 << tb); ++pre) {
+      if (!sub_bits[pre]) continue;
+      if (used + (1 << sub_bits[pre]) > cap) return false;
+      table[pre] = K_SUB | (uint32_t)used << 16 | (uint32_t)sub_bits[pre] << 8 | (uint32_t)tb;
+      for (int i = 0; i < (1 << sub_bits[pre]); ++i) table[used + i] = 0;
+      used += 1 << sub_bits[pre];
+    }
+  }
+  for (int s = 0; s < n; ++s) {
+    const int l = len[s];
+    if (l == 0) continue;
+    const uint32_t code = next[l]++;
+    const uint32_t e = sym_entry(s);
+    if (l <= tb) {
+      const uint32_t r = rev_bits(code, l);
+      const uint32_t ent = (e & K_MASK) == K_BASE ? ((e & ~(31u << 8)) | (uint32_t)l << 8 | ((uint32_t)l + ((e >> 8) & 31))) : (e | (uint32_t)l);
+      for (uint32_t i = r; i < (1u << tb); i += 1u << l) table[i] = ent;
+    } else {
+      const uint32_t pre = rev_bits(code >> (l - tb), tb);
+      const uint32_t p = table[pre];
+      const int sb = (int)(p >> 8) & 31;
+      const uint32_t off = p >> 16;
+      const uint32_t r = rev_bits(code & ((1u << (l - tb)) - 1), l - tb);
+      const uint32_t l2 = (uint32_t)(l - tb);
+      const uint32_t ent = (e & K_MASK) == K_BASE ? ((e & ~(31u << 8)) | l2 << 8 | (l2 + ((e >> 8) & 31))) : (e | l2);
+      for (uint32_t i = r; i < (1u << sb); i += 1u << (l - tb)) table[off + i] = ent;
+    }
+  }
+  return true;
+}
+
+// Two literals per look-up where both codes fit the first level's bits: FASTQ text is mostly literals of two to five bits.
+inline void pair_literals(uint32_t *table, int tb) {
+  static thread_local uint32_t base[1 << LIT_BITS];
+  memcpy(base, table, sizeof(uint32_t) << tb);
+  for (uint32_t i = 0; i < (1u << tb); ++i) {
+    const uint32_t e = base[i];
+    if (!(e & K_LIT)) continue;
+    const int l1 = (int)(e & 0xff);
+    if (l1 >= tb) continue;
+    const uint32_t f = base[i >> l1];
+    if (!(f & K_LIT) || l1 + (int)(f & 0xff) > tb) continue;
+    table[i] = K_LIT | K_LIT2 | ((e >> 16) & 0xff) << 16 | ((f >> 16) & 0xff) << 24 | (uint32_t)(l1 + (int)(f & 0xff));
+  }
+}
+
+inline uint32_t lit_entry(int s) {
+  static const uint16_t base[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+  static const uint8_t extra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+  if (s < 256) return K_LIT | (uint32_t)s << 16;
+  if (s == 256) return K_EOB;
+  if (s > 285) return 0;   // 286, 287: in the fixed code, never valid in data
+  return K_BASE | (uint32_t)base[s - 257] << 16 | (uint32_t)extra[s - 257] << 8;
+}
+inline uint32_t dist_entry(int s) {
+  static const uint16_t base[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+  static const uint8_t extra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+  if (s > 29) return 0;
+  return K_BASE | (uint32_t)base[s] << 16 | (uint32_t)extra[s] << 8;
+}
+
+// ---- the decoder ---------------------------------------------------------------------------------------------------------------------
+// Decodes one complete raw DEFLATE stream of n bytes at src into dst; true when the stream ends exactly after out_len bytes of output
+// (the BGZF trailer's ISIZE) without reading past src + n.  False for anything else -- the caller asks zlib what it thinks of such a
+// member.
+inline bool inflate_raw(Inflater &Z, const uint8_t *src, size_t n, uint8_t *dst, size_t out_len) {
+  const uint8_t *in = src, *const in_end = src + n;
+  uint8_t *out = dst, *const out_end = dst + out_len;
+  uint64_t bb = 0;   // bit buffer, next bit at bit 0
+  int bc = 0;        // valid bits in bb
+  // bytes beyond the end of the input read as zero (a stream that needs them is truncated: caught by the position check at the end)
+  size_t over = 0;   // zero bytes supplied beyond in_end
+  auto refill = [&]() {
+    if (in_end - in >= 8) {
+      uint64_t w;
+      memcpy(&w, in, 8);
+      bb |= w << bc;
+      in += (63 - bc) >> 3;
+      bc |= 56;
+    } else {
+      while (bc <= 56) {
+        if (in < in_end) bb |= (uint64_t)*in++ << bc; else ++over;
+        bc += 8;
+      }
+    }
+  };
+#define FQZ_TAKE(nb) (bb >>= (nb), bc -= (nb))
+  bool last = false;
+  while (!last) {
+    refill();
+    last = (bb & 1) != 0;
+    const int type = (int)(bb >> 1) & 3;
+    FQZ_TAKE(3);
+    const uint32_t *LT, *DT;
+    if (type == 0) {   // stored: skip to the byte boundary, LEN, NLEN, bytes
+      FQZ_TAKE(bc & 7);
+      // return the whole bytes of the bit buffer to the input
+      const size_t back = (size_t)bc >> 3;
+      if (over > back) return false;
+      in -= back - over; over = 0; bb = 0; bc = 0;
+      if (in_end - in < 4) return false;
+      const uint32_t len = in[0] | (uint32_t)in[1] << 8, nlen = in[2] | (uint32_t)in[3] << 8;
+      in += 4;
+      if ((len ^ nlen) != 0xffffu || (size_t)(in_end - in) < len || (size_t)(out_end - out) < len) return false;
+      memcpy(out, in, len);
+      in += len; out += len;
+      continue;
+    } else if (type == 1) {
+      if (!Z.fixed_built) {
+        uint8_t l[288 + 32];
+        for (int s = 0; s < 144; ++s) l[s] = 8;
+        for (int s = 144; s < 256; ++s) l[s] = 9;
+        for (int s = 256; s < 280; ++s) l[s] = 7;
+        for (int s = 280; s < 288; ++s) l[s] = 8;
+        for (int s = 0; s < 32; ++s) l[288 + s] = 5;
+        if (!build_table(l, 288, LIT_BITS, Z.fixed_lit, LIT_TABLE, false, lit_entry)) return false;
+        pair_literals(Z.fixed_lit, LIT_BITS);
+        if (!build_table(l + 288, 32, DIST_BITS, Z.fixed_dist, DIST_TABLE, false, dist_entry)) return false;
+        Z.fixed_built = true;
+      }
+      LT = Z.fixed_lit; DT = Z.fixed_dist;
+    } else if (type == 2) {
+      const int hlit = (int)(bb & 31) + 257, hdist = (int)((bb >> 5) & 31) + 1, hclen = (int)((bb >> 10) & 15) + 4;
+      FQZ_TAKE(14);
+      if (hlit > 286 || hdist > 30) return false;
+      static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+      uint8_t cl[19] = {0};
+      for (int i = 0; i < hclen; ++i) {
+        if (bc < 3) refill();
+        cl[order[i]] = (uint8_t)(bb & 7);
+        FQZ_TAKE(3);
+      }
+      uint32_t ct[1 << 7];
+      if (!build_table(cl, 19, 7, ct, 1 << 7, false, [](int s) { return (uint32_t)s << 16 | K_LIT; })) return false;
+      int i = 0;
+      while (i < hlit + hdist) {
+        refill();
+        const uint32_t e = ct[bb & 127];
+        if (!(e & K_MASK)) return false;
+        FQZ_TAKE((int)(e & 0xff));
+        const int s = (int)(e >> 16);
+        if (s < 16) { Z.lens[i++] = (uint8_t)s; continue; }
+        int rep, val = 0;
+        if (s == 16) { if (i == 0) return false; val = Z.lens[i - 1]; rep = 3 + (int)(bb & 3); FQZ_TAKE(2); }
+        else if (s == 17) { rep = 3 + (int)(bb & 7); FQZ_TAKE(3); }
+        else { rep = 11 + (int)(bb & 127); FQZ_TAKE(7); }
+        if (i + rep > hlit + hdist) return false;
+        while (rep--) Z.lens[i++] = (uint8_t)val;
+      }
+      if (Z.lens[256] == 0) return false;   // no end-of-block code
+      if (!build_table(Z.lens, hlit, LIT_BITS, Z.lit, LIT_TABLE, false, lit_entry)) return false;
+      pair_literals(Z.lit, LIT_BITS);
+      if (!build_table(Z.lens + hlit, hdist, DIST_BITS, Z.dist, DIST_TABLE, true, dist_entry)) return false;
+      LT = Z.lit; DT = Z.dist;
+    } else return false;
+
+    // ---- symbols of a Huffman block ----
+    for (;;) {
+      // fast loop: room for the longest match plus a run of literals on the output side, sixteen readable bytes on the input side
+      while (in_end - in >= 16 && out_end - out >= 258 + 72) {
+        {   // refill: >= 56 bits
+          uint64_t w;
+          memcpy(&w, in, 8);
+          bb |= w << bc;
+          in += (63 - bc) >> 3;
+          bc |= 56;
+        }
+        uint32_t e = LT[bb & ((1u << LIT_BITS) - 1)];
+        if (e & K_LIT) {                            // literals for as long as the buffer holds a whole first-level index (<= 2 bytes per >= 2 bits: <= 56 bytes)
+          do {
+            FQZ_TAKE((int)(e & 0xff));
+            out[0] = (uint8_t)(e >> 16); out[1] = (uint8_t)(e >> 24);
+            out += 1 + ((e >> 8) & 1);
+            e = LT[bb & ((1u << LIT_BITS) - 1)];
+          } while ((e & K_LIT) && bc >= LIT_BITS);
+          continue;                                 // (what follows is decoded after the refill)
+        }
+        if ((e & K_MASK) == K_SUB) { FQZ_TAKE(LIT_BITS); e = LT[(e >> 16) + (bb & ((1u << ((e >> 8) & 31)) - 1))]; }
+        uint64_t saved = bb;
+        FQZ_TAKE((int)(e & 0xff));                  // code and extra bits at once: <= 15 + 5 = 20 of >= 56 bits
+        if (e & K_LIT) { *out++ = (uint8_t)(e >> 16); continue; }   // (a literal with a long code)
+        if ((e & K_MASK) != K_BASE) {
+          if ((e & K_MASK) == K_EOB) goto block_done;
+          return false;
+        }
+        const uint32_t length = (e >> 16) + (uint32_t)((saved >> ((e >> 8) & 31)) & ((1u << ((e & 0xff) - ((e >> 8) & 31))) - 1));
+        uint32_t d = DT[bb & ((1u << DIST_BITS) - 1)];
+        if ((d & K_MASK) == K_SUB) { FQZ_TAKE(DIST_BITS); d = DT[(d >> 16) + (bb & ((1u << ((d >> 8) & 31)) - 1))]; }
+        if ((d & K_MASK) != K_BASE) return false;
+        saved = bb;
+        FQZ_TAKE((int)(d & 0xff));                  // <= 15 + 13 bits: <= 48 of >= 56
+        const uint32_t distance = (d >> 16) + (uint32_t)((saved >> ((d >> 8) & 31)) & ((1u << ((d & 0xff) - ((d >> 8) & 31))) - 1));
+        if (distance > (size_t)(out - dst)) return false;
+        const uint8_t *from = out - distance;
+        uint8_t *const stop = out + length;
+        if (distance >= 8) {
+          do { uint64_t w; memcpy(&w, from, 8); memcpy(out, &w, 8); from += 8; out += 8; } while (out < stop);
+        } else if (distance == 1) {
+          memset(out, *from, length);
+        } else {
+          do { *out++ = *from++; } while (out < stop);
+        }
+        out = stop;
+      }
+      // careful loop: one symbol at a time with every bound checked
+      {
+        refill();
+        uint32_t e = LT[bb & ((1u << LIT_BITS) - 1)];
+        if ((e & K_MASK) == K_SUB) { FQZ_TAKE(LIT_BITS); e = LT[(e >> 16) + (bb & ((1u << ((e >> 8) & 31)) - 1))]; }
+        const uint64_t saved = bb;
+        FQZ_TAKE((int)(e & 0xff));
+        if (e & K_LIT) {
+          const size_t nl = 1 + ((e >> 8) & 1);
+          if ((size_t)(out_end - out) < nl) return false;
+          *out++ = (uint8_t)(e >> 16);
+          if (nl == 2) *out++ = (uint8_t)(e >> 24);
+        } else if ((e & K_MASK) == K_EOB) {
+          goto block_done;
+        } else if ((e & K_MASK) == K_BASE) {
+          const uint32_t length = (e >> 16) + (uint32_t)((saved >> ((e >> 8) & 31)) & ((1u << ((e & 0xff) - ((e >> 8) & 31))) - 1));
+          uint32_t d = DT[bb & ((1u << DIST_BITS) - 1)];
+          if ((d & K_MASK) == K_SUB) { FQZ_TAKE(DIST_BITS); d = DT[(d >> 16) + (bb & ((1u << ((d >> 8) & 31)) - 1))]; }
+          if ((d & K_MASK) != K_BASE) return false;
+          const uint64_t saved_d = bb;
+          FQZ_TAKE((int)(d & 0xff));
+          const uint32_t distance = (d >> 16) + (uint32_t)((saved_d >> ((d >> 8) & 31)) & ((1u << ((d & 0xff) - ((d >> 8) & 31))) - 1));
+          if (distance > (size_t)(out - dst) || length > (size_t)(out_end - out)) return false;
+          const uint8_t *from = out - distance;
+          for (uint32_t i = 0; i < length; ++i) out[i] = from[i];
+          out += length;
+        } else return false;
+        if (bc < 0) return false;   // (cannot happen: refill() supplies zero bytes; kept as a guard)
+      }
+    }
+  block_done:;
+  }
+#undef FQZ_TAKE
+  // the stream must end inside the input: bits left in the buffer belong to the last byte(s) read
+  if (over > ((size_t)bc >> 3)) return false;   // the decoder consumed bytes that do not exist
+  return out == out_end;
+}
+
+}  // namespace fqz

@@ -838,6 +838,13 @@ struct FqGapArgs {
                          // long searches first, so the early segments hold the hard reads
   int32_t refill_min;    // idle lanes of a wavefront wait until this many can be (re)initialised together
   int32_t max_waves;     // 0: as many wavefronts as the device holds; else a cap (the host lowers it when pool memory is short)
+  const uint8_t *bid_end; // [w][2] k_width's lower bound on the differences of each strand (the sort key's source); used with skip_bound
+  int32_t skip_bound;    // round without gap children: a read whose bound on BOTH strands is at least this cannot be settled there (its best
+                         // possible hit scores skip_bound * s_mm, and (skip_bound + 1) * s_mm >= s_gapo): it is flagged for the full search
+                         // at once instead of being searched twice.  0: every read is searched.  (Any choice is exact: the full search decides.)
+                         // Measured (profiles/round4_search_loop_experiments.txt): first round 39.9 -> 37.6 ms at 8.4 M reads, but the next round
+                         // loses the first round's knowledge of which of these reads have a hit at all (its long searches no longer all start
+                         // first): 21.5 -> 24.0 ms, stage 61.4 -> 61.9; at 2.1 M reads per call the stage goes 26.4 -> 24.6 ms.
 };
 
 // positions [lo, hi) of a queue block of `len` entries that belong to segment seg of n_seg
@@ -1134,6 +1141,10 @@ struct FqGapLane {
     active = true;
     too_many_n = ((gw.meta >> 24) & 1u) != 0;
     if (too_many_n) { finish(); return; }   // "too many N" early-out of bwt_match_gap (bwtgap.c:118-124)
+    if (NOGAP && A.skip_bound > 0) {
+      const int ba = A.bid_end[2 * (size_t)w], bb = A.bid_end[2 * (size_t)w + 1];
+      if ((ba < bb ? ba : bb) >= A.skip_bound) { status |= FQ_SF_NEEDGAP; finish(); return; }   // (finish() adds FQ_SF_NOHIT: a long search of the next round)
+    }
     // the two roots (bwtgap.c:139-140): strand 0 first, so strand 1 is popped first
     // (Starting on strand 1's root without its trip through the pool -- push and pop done here, strand 0's root left as fetched-ahead
     // content -- saves two of a read's ~350 trips and was 1.3 ms SLOWER per 8.4 M reads, A/B on one device: 41.2 against 39.9 ms.)

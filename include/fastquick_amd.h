@@ -276,6 +276,11 @@ const char *fq_fastq_dropped_record(const fq_fastq_t *r);
 int fq_fastq_unequal_lengths(const fq_fastq_t *r);
 int fq_fastq_is_bgzf(const fq_fastq_t *r);
 void fq_fastq_close(fq_fastq_t *r);
+/* The front end's decoder of one BGZF member's payload and the checksum of its trailer, on their own (the reference reads gzip through
+ * zlib's gzread: libbwa/bwaseqio.c:41-52; kseq.h:327-371).  fq_inflate_raw: one complete raw DEFLATE stream (RFC 1951) of n bytes -> exactly
+ * out_len bytes at dst; FQ_OK, or FQ_EIO for a stream it does not accept (the reader then lets zlib decide).  fq_crc32: CRC-32 as gzip's. */
+int fq_inflate_raw(const uint8_t *src, size_t n, uint8_t *dst, size_t out_len);
+uint32_t fq_crc32(const uint8_t *p, size_t n);
 
 /* ---- one FASTQ stream over several ranks -------------------------------------------------------------------------------
  * A stream shards by reference batch: everything per-read of a batch is independent, and three pieces of state
