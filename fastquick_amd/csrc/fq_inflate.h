@@ -164,52 +164,60 @@ inline uint32_t dist_entry(int s) {
 }
 
 // ---- the decoder ---------------------------------------------------------------------------------------------------------------------
-// Decodes one complete raw DEFLATE stream of n bytes at src into dst; true when the stream ends exactly after out_len bytes of output
-// (the BGZF trailer's ISIZE) without reading past src + n.  False for anything else -- the caller asks zlib what it thinks of such a
-// member.
-inline bool inflate_raw(Inflater &Z, const uint8_t *src, size_t n, uint8_t *dst, size_t out_len) {
-  const uint8_t *in = src, *const in_end = src + n;
-  uint8_t *out = dst, *const out_end = dst + out_len;
-  uint64_t bb = 0;   // bit buffer, next bit at bit 0
-  int bc = 0;        // valid bits in bb
-  // bytes beyond the end of the input read as zero (a stream that needs them is truncated: caught by the position check at the end)
-  size_t over = 0;   // zero bytes supplied beyond in_end
-  auto refill = [&]() {
-    if (in_end - in >= 8) {
-      uint64_t w;
-      memcpy(&w, in, 8);
-      bb |= w << bc;
-      in += (63 - bc) >> 3;
-      bc |= 56;
-    } else {
-      while (bc <= 56) {
-        if (in < in_end) bb |= (uint64_t)*in++ << bc; else ++over;
-        bc += 8;
-      }
+// One member being decoded.  (Two members decoded side by side by one thread -- two independent bit-buffer chains -- were measured: + 5 %;
+// the loop is bound by its ~60 instructions per match, not by the latency of its look-ups.)
+struct Dec {
+  const uint8_t *in, *in_end;
+  uint8_t *out, *out_end, *dst;
+  uint64_t bb;      // bit buffer, next bit at bit 0
+  int bc;           // valid bits in bb
+  size_t over;      // zero bytes supplied beyond in_end (a stream that needs them is truncated: caught when it ends)
+  const uint32_t *LT, *DT;
+  bool last;
+  Inflater *Z;
+  void begin(Inflater &z, const uint8_t *src, size_t n, uint8_t *d, size_t out_len) {
+    in = src; in_end = src + n; out = d; out_end = d + out_len; dst = d; bb = 0; bc = 0; over = 0; LT = DT = nullptr; last = false; Z = &z;
+  }
+};
+#define FQZ_TAKE(D, nb) ((D).bb >>= (nb), (D).bc -= (nb))
+inline void dec_refill(Dec &d) {
+  if (d.in_end - d.in >= 8) {
+    uint64_t w;
+    memcpy(&w, d.in, 8);
+    d.bb |= w << d.bc;
+    d.in += (63 - d.bc) >> 3;
+    d.bc |= 56;
+  } else {
+    while (d.bc <= 56) {
+      if (d.in < d.in_end) d.bb |= (uint64_t)*d.in++ << d.bc; else ++d.over;
+      d.bc += 8;
     }
-  };
-#define FQZ_TAKE(nb) (bb >>= (nb), bc -= (nb))
-  bool last = false;
-  while (!last) {
-    refill();
-    last = (bb & 1) != 0;
-    const int type = (int)(bb >> 1) & 3;
-    FQZ_TAKE(3);
-    const uint32_t *LT, *DT;
+  }
+}
+// Block headers up to the next Huffman block (stored blocks are copied here).  0: a Huffman block begins (LT / DT set); 1: the stream has
+// ended; -1: not a stream this decoder accepts.
+inline int dec_next_block(Dec &d) {
+  Inflater &Z = *d.Z;
+  for (;;) {
+    if (d.last) return 1;
+    dec_refill(d);
+    d.last = (d.bb & 1) != 0;
+    const int type = (int)(d.bb >> 1) & 3;
+    FQZ_TAKE(d, 3);
     if (type == 0) {   // stored: skip to the byte boundary, LEN, NLEN, bytes
-      FQZ_TAKE(bc & 7);
-      // return the whole bytes of the bit buffer to the input
-      const size_t back = (size_t)bc >> 3;
-      if (over > back) return false;
-      in -= back - over; over = 0; bb = 0; bc = 0;
-      if (in_end - in < 4) return false;
-      const uint32_t len = in[0] | (uint32_t)in[1] << 8, nlen = in[2] | (uint32_t)in[3] << 8;
-      in += 4;
-      if ((len ^ nlen) != 0xffffu || (size_t)(in_end - in) < len || (size_t)(out_end - out) < len) return false;
-      memcpy(out, in, len);
-      in += len; out += len;
+      FQZ_TAKE(d, d.bc & 7);
+      const size_t back = (size_t)d.bc >> 3;     // the whole bytes of the bit buffer go back to the input
+      if (d.over > back) return -1;
+      d.in -= back - d.over; d.over = 0; d.bb = 0; d.bc = 0;
+      if (d.in_end - d.in < 4) return -1;
+      const uint32_t len = d.in[0] | (uint32_t)d.in[1] << 8, nlen = d.in[2] | (uint32_t)d.in[3] << 8;
+      d.in += 4;
+      if ((len ^ nlen) != 0xffffu || (size_t)(d.in_end - d.in) < len || (size_t)(d.out_end - d.out) < len) return -1;
+      memcpy(d.out, d.in, len);
+      d.in += len; d.out += len;
       continue;
-    } else if (type == 1) {
+    }
+    if (type == 1) {
       if (!Z.fixed_built) {
         uint8_t l[288 + 32];
         for (int s = 0; s < 144; ++s) l[s] = 8;
@@ -217,131 +225,151 @@ inline bool inflate_raw(Inflater &Z, const uint8_t *src, size_t n, uint8_t *dst,
         for (int s = 256; s < 280; ++s) l[s] = 7;
         for (int s = 280; s < 288; ++s) l[s] = 8;
         for (int s = 0; s < 32; ++s) l[288 + s] = 5;
-        if (!build_table(l, 288, LIT_BITS, Z.fixed_lit, LIT_TABLE, false, lit_entry)) return false;
+        if (!build_table(l, 288, LIT_BITS, Z.fixed_lit, LIT_TABLE, false, lit_entry)) return -1;
         pair_literals(Z.fixed_lit, LIT_BITS);
-        if (!build_table(l + 288, 32, DIST_BITS, Z.fixed_dist, DIST_TABLE, false, dist_entry)) return false;
+        if (!build_table(l + 288, 32, DIST_BITS, Z.fixed_dist, DIST_TABLE, false, dist_entry)) return -1;
         Z.fixed_built = true;
       }
-      LT = Z.fixed_lit; DT = Z.fixed_dist;
-    } else if (type == 2) {
-      const int hlit = (int)(bb & 31) + 257, hdist = (int)((bb >> 5) & 31) + 1, hclen = (int)((bb >> 10) & 15) + 4;
-      FQZ_TAKE(14);
-      if (hlit > 286 || hdist > 30) return false;
-      static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-      uint8_t cl[19] = {0};
-      for (int i = 0; i < hclen; ++i) {
-        if (bc < 3) refill();
-        cl[order[i]] = (uint8_t)(bb & 7);
-        FQZ_TAKE(3);
-      }
-      uint32_t ct[1 << 7];
-      if (!build_table(cl, 19, 7, ct, 1 << 7, false, [](int s) { return (uint32_t)s << 16 | K_LIT; })) return false;
-      int i = 0;
-      while (i < hlit + hdist) {
-        refill();
-        const uint32_t e = ct[bb & 127];
-        if (!(e & K_MASK)) return false;
-        FQZ_TAKE((int)(e & 0xff));
-        const int s = (int)(e >> 16);
-        if (s < 16) { Z.lens[i++] = (uint8_t)s; continue; }
-        int rep, val = 0;
-        if (s == 16) { if (i == 0) return false; val = Z.lens[i - 1]; rep = 3 + (int)(bb & 3); FQZ_TAKE(2); }
-        else if (s == 17) { rep = 3 + (int)(bb & 7); FQZ_TAKE(3); }
-        else { rep = 11 + (int)(bb & 127); FQZ_TAKE(7); }
-        if (i + rep > hlit + hdist) return false;
-        while (rep--) Z.lens[i++] = (uint8_t)val;
-      }
-      if (Z.lens[256] == 0) return false;   // no end-of-block code
-      if (!build_table(Z.lens, hlit, LIT_BITS, Z.lit, LIT_TABLE, false, lit_entry)) return false;
-      pair_literals(Z.lit, LIT_BITS);
-      if (!build_table(Z.lens + hlit, hdist, DIST_BITS, Z.dist, DIST_TABLE, true, dist_entry)) return false;
-      LT = Z.lit; DT = Z.dist;
-    } else return false;
-
-    // ---- symbols of a Huffman block ----
-    for (;;) {
-      // fast loop: room for the longest match plus a run of literals on the output side, sixteen readable bytes on the input side
-      while (in_end - in >= 16 && out_end - out >= 258 + 72) {
-        {   // refill: >= 56 bits
-          uint64_t w;
-          memcpy(&w, in, 8);
-          bb |= w << bc;
-          in += (63 - bc) >> 3;
-          bc |= 56;
-        }
-        uint32_t e = LT[bb & ((1u << LIT_BITS) - 1)];
-        if (e & K_LIT) {                            // literals for as long as the buffer holds a whole first-level index (<= 2 bytes per >= 2 bits: <= 56 bytes)
-          do {
-            FQZ_TAKE((int)(e & 0xff));
-            out[0] = (uint8_t)(e >> 16); out[1] = (uint8_t)(e >> 24);
-            out += 1 + ((e >> 8) & 1);
-            e = LT[bb & ((1u << LIT_BITS) - 1)];
-          } while ((e & K_LIT) && bc >= LIT_BITS);
-          continue;                                 // (what follows is decoded after the refill)
-        }
-        if ((e & K_MASK) == K_SUB) { FQZ_TAKE(LIT_BITS); e = LT[(e >> 16) + (bb & ((1u << ((e >> 8) & 31)) - 1))]; }
-        uint64_t saved = bb;
-        FQZ_TAKE((int)(e & 0xff));                  // code and extra bits at once: <= 15 + 5 = 20 of >= 56 bits
-        if (e & K_LIT) { *out++ = (uint8_t)(e >> 16); continue; }   // (a literal with a long code)
-        if ((e & K_MASK) != K_BASE) {
-          if ((e & K_MASK) == K_EOB) goto block_done;
-          return false;
-        }
-        const uint32_t length = (e >> 16) + (uint32_t)((saved >> ((e >> 8) & 31)) & ((1u << ((e & 0xff) - ((e >> 8) & 31))) - 1));
-        uint32_t d = DT[bb & ((1u << DIST_BITS) - 1)];
-        if ((d & K_MASK) == K_SUB) { FQZ_TAKE(DIST_BITS); d = DT[(d >> 16) + (bb & ((1u << ((d >> 8) & 31)) - 1))]; }
-        if ((d & K_MASK) != K_BASE) return false;
-        saved = bb;
-        FQZ_TAKE((int)(d & 0xff));                  // <= 15 + 13 bits: <= 48 of >= 56
-        const uint32_t distance = (d >> 16) + (uint32_t)((saved >> ((d >> 8) & 31)) & ((1u << ((d & 0xff) - ((d >> 8) & 31))) - 1));
-        if (distance > (size_t)(out - dst)) return false;
-        const uint8_t *from = out - distance;
-        uint8_t *const stop = out + length;
-        if (distance >= 8) {
-          do { uint64_t w; memcpy(&w, from, 8); memcpy(out, &w, 8); from += 8; out += 8; } while (out < stop);
-        } else if (distance == 1) {
-          memset(out, *from, length);
-        } else {
-          do { *out++ = *from++; } while (out < stop);
-        }
-        out = stop;
-      }
-      // careful loop: one symbol at a time with every bound checked
-      {
-        refill();
-        uint32_t e = LT[bb & ((1u << LIT_BITS) - 1)];
-        if ((e & K_MASK) == K_SUB) { FQZ_TAKE(LIT_BITS); e = LT[(e >> 16) + (bb & ((1u << ((e >> 8) & 31)) - 1))]; }
-        const uint64_t saved = bb;
-        FQZ_TAKE((int)(e & 0xff));
-        if (e & K_LIT) {
-          const size_t nl = 1 + ((e >> 8) & 1);
-          if ((size_t)(out_end - out) < nl) return false;
-          *out++ = (uint8_t)(e >> 16);
-          if (nl == 2) *out++ = (uint8_t)(e >> 24);
-        } else if ((e & K_MASK) == K_EOB) {
-          goto block_done;
-        } else if ((e & K_MASK) == K_BASE) {
-          const uint32_t length = (e >> 16) + (uint32_t)((saved >> ((e >> 8) & 31)) & ((1u << ((e & 0xff) - ((e >> 8) & 31))) - 1));
-          uint32_t d = DT[bb & ((1u << DIST_BITS) - 1)];
-          if ((d & K_MASK) == K_SUB) { FQZ_TAKE(DIST_BITS); d = DT[(d >> 16) + (bb & ((1u << ((d >> 8) & 31)) - 1))]; }
-          if ((d & K_MASK) != K_BASE) return false;
-          const uint64_t saved_d = bb;
-          FQZ_TAKE((int)(d & 0xff));
-          const uint32_t distance = (d >> 16) + (uint32_t)((saved_d >> ((d >> 8) & 31)) & ((1u << ((d & 0xff) - ((d >> 8) & 31))) - 1));
-          if (distance > (size_t)(out - dst) || length > (size_t)(out_end - out)) return false;
-          const uint8_t *from = out - distance;
-          for (uint32_t i = 0; i < length; ++i) out[i] = from[i];
-          out += length;
-        } else return false;
-        if (bc < 0) return false;   // (cannot happen: refill() supplies zero bytes; kept as a guard)
-      }
+      d.LT = Z.fixed_lit; d.DT = Z.fixed_dist;
+      return 0;
     }
-  block_done:;
+    if (type != 2) return -1;
+    const int hlit = (int)(d.bb & 31) + 257, hdist = (int)((d.bb >> 5) & 31) + 1, hclen = (int)((d.bb >> 10) & 15) + 4;
+    FQZ_TAKE(d, 14);
+    if (hlit > 286 || hdist > 30) return -1;
+    static const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint8_t cl[19] = {0};
+    for (int i = 0; i < hclen; ++i) {
+      if (d.bc < 3) dec_refill(d);
+      cl[order[i]] = (uint8_t)(d.bb & 7);
+      FQZ_TAKE(d, 3);
+    }
+    uint32_t ct[1 << 7];
+    if (!build_table(cl, 19, 7, ct, 1 << 7, false, [](int s) { return (uint32_t)s << 16 | K_LIT; })) return -1;
+    int i = 0;
+    while (i < hlit + hdist) {
+      dec_refill(d);
+      const uint32_t e = ct[d.bb & 127];
+      if (!(e & K_MASK)) return -1;
+      FQZ_TAKE(d, (int)(e & 0xff));
+      const int s = (int)(e >> 16);
+      if (s < 16) { Z.lens[i++] = (uint8_t)s; continue; }
+      int rep, val = 0;
+      if (s == 16) { if (i == 0) return -1; val = Z.lens[i - 1]; rep = 3 + (int)(d.bb & 3); FQZ_TAKE(d, 2); }
+      else if (s == 17) { rep = 3 + (int)(d.bb & 7); FQZ_TAKE(d, 3); }
+      else { rep = 11 + (int)(d.bb & 127); FQZ_TAKE(d, 7); }
+      if (i + rep > hlit + hdist) return -1;
+      while (rep--) Z.lens[i++] = (uint8_t)val;
+    }
+    if (Z.lens[256] == 0) return -1;   // no end-of-block code
+    if (!build_table(Z.lens, hlit, LIT_BITS, Z.lit, LIT_TABLE, false, lit_entry)) return -1;
+    pair_literals(Z.lit, LIT_BITS);
+    if (!build_table(Z.lens + hlit, hdist, DIST_BITS, Z.dist, DIST_TABLE, true, dist_entry)) return -1;
+    d.LT = Z.lit; d.DT = Z.dist;
+    return 0;
   }
-#undef FQZ_TAKE
-  // the stream must end inside the input: bits left in the buffer belong to the last byte(s) read
-  if (over > ((size_t)bc >> 3)) return false;   // the decoder consumed bytes that do not exist
-  return out == out_end;
 }
+// room for the longest match plus a run of literals on the output side, sixteen readable bytes on the input side
+inline bool dec_fast_ok(const Dec &d) { return d.in_end - d.in >= 16 && d.out_end - d.out >= 258 + 72; }
+// One turn of the fast loop (dec_fast_ok holds): a run of literals, or one match.  0: go on; 1: end of block; -1: refused.
+inline int dec_fast_turn(Dec &d) {
+  {   // refill: >= 56 bits
+    uint64_t w;
+    memcpy(&w, d.in, 8);
+    d.bb |= w << d.bc;
+    d.in += (63 - d.bc) >> 3;
+    d.bc |= 56;
+  }
+  const uint32_t *const LT = d.LT, *const DT = d.DT;
+  uint32_t e = LT[d.bb & ((1u << LIT_BITS) - 1)];
+  if (e & K_LIT) {                            // literals for as long as the buffer holds a whole first-level index (<= 2 bytes per >= 2 bits: <= 56 bytes)
+    do {
+      FQZ_TAKE(d, (int)(e & 0xff));
+      d.out[0] = (uint8_t)(e >> 16); d.out[1] = (uint8_t)(e >> 24);
+      d.out += 1 + ((e >> 8) & 1);
+      e = LT[d.bb & ((1u << LIT_BITS) - 1)];
+    } while ((e & K_LIT) && d.bc >= LIT_BITS);
+    return 0;                                 // (what follows is decoded after the refill)
+  }
+  if ((e & K_MASK) == K_SUB) { FQZ_TAKE(d, LIT_BITS); e = LT[(e >> 16) + (d.bb & ((1u << ((e >> 8) & 31)) - 1))]; }
+  uint64_t saved = d.bb;
+  FQZ_TAKE(d, (int)(e & 0xff));               // code and extra bits at once: <= 15 + 5 = 20 of >= 56 bits
+  if (e & K_LIT) { *d.out++ = (uint8_t)(e >> 16); return 0; }   // (a literal with a long code)
+  if ((e & K_MASK) != K_BASE) return (e & K_MASK) == K_EOB ? 1 : -1;
+  const uint32_t length = (e >> 16) + (uint32_t)((saved >> ((e >> 8) & 31)) & ((1u << ((e & 0xff) - ((e >> 8) & 31))) - 1));
+  uint32_t dd = DT[d.bb & ((1u << DIST_BITS) - 1)];
+  if ((dd & K_MASK) == K_SUB) { FQZ_TAKE(d, DIST_BITS); dd = DT[(dd >> 16) + (d.bb & ((1u << ((dd >> 8) & 31)) - 1))]; }
+  if ((dd & K_MASK) != K_BASE) return -1;
+  saved = d.bb;
+  FQZ_TAKE(d, (int)(dd & 0xff));              // <= 15 + 13 bits: <= 48 of >= 56
+  const uint32_t distance = (dd >> 16) + (uint32_t)((saved >> ((dd >> 8) & 31)) & ((1u << ((dd & 0xff) - ((dd >> 8) & 31))) - 1));
+  if (distance > (size_t)(d.out - d.dst)) return -1;
+  const uint8_t *from = d.out - distance;
+  uint8_t *out = d.out, *const stop = out + length;
+  if (distance >= 8) {
+    do { uint64_t w; memcpy(&w, from, 8); memcpy(out, &w, 8); from += 8; out += 8; } while (out < stop);
+  } else if (distance == 1) {
+    memset(out, *from, length);
+  } else {
+    do { *out++ = *from++; } while (out < stop);
+  }
+  d.out = stop;
+  return 0;
+}
+// One symbol with every bound checked (the ends of the input and of the output).  Returns as dec_fast_turn.
+inline int dec_careful_turn(Dec &d) {
+  dec_refill(d);
+  const uint32_t *const LT = d.LT, *const DT = d.DT;
+  uint32_t e = LT[d.bb & ((1u << LIT_BITS) - 1)];
+  if ((e & K_MASK) == K_SUB) { FQZ_TAKE(d, LIT_BITS); e = LT[(e >> 16) + (d.bb & ((1u << ((e >> 8) & 31)) - 1))]; }
+  const uint64_t saved = d.bb;
+  FQZ_TAKE(d, (int)(e & 0xff));
+  if (e & K_LIT) {
+    const size_t nl = 1 + ((e >> 8) & 1);
+    if ((size_t)(d.out_end - d.out) < nl) return -1;
+    *d.out++ = (uint8_t)(e >> 16);
+    if (nl == 2) *d.out++ = (uint8_t)(e >> 24);
+    return 0;
+  }
+  if ((e & K_MASK) == K_EOB) return 1;
+  if ((e & K_MASK) != K_BASE) return -1;
+  const uint32_t length = (e >> 16) + (uint32_t)((saved >> ((e >> 8) & 31)) & ((1u << ((e & 0xff) - ((e >> 8) & 31))) - 1));
+  uint32_t dd = DT[d.bb & ((1u << DIST_BITS) - 1)];
+  if ((dd & K_MASK) == K_SUB) { FQZ_TAKE(d, DIST_BITS); dd = DT[(dd >> 16) + (d.bb & ((1u << ((dd >> 8) & 31)) - 1))]; }
+  if ((dd & K_MASK) != K_BASE) return -1;
+  const uint64_t saved_d = d.bb;
+  FQZ_TAKE(d, (int)(dd & 0xff));
+  const uint32_t distance = (dd >> 16) + (uint32_t)((saved_d >> ((dd >> 8) & 31)) & ((1u << ((dd & 0xff) - ((dd >> 8) & 31))) - 1));
+  if (distance > (size_t)(d.out - d.dst) || length > (size_t)(d.out_end - d.out)) return -1;
+  const uint8_t *from = d.out - distance;
+  for (uint32_t i = 0; i < length; ++i) d.out[i] = from[i];
+  d.out += length;
+  return 0;
+}
+// the stream has ended: inside the input (bits left in the buffer belong to the last bytes read), after exactly the promised output
+inline bool dec_finished_well(const Dec &d) { return d.over <= ((size_t)d.bc >> 3) && d.out == d.out_end; }
+// the symbols of the current Huffman block, alone.  1: end of block; -1: refused.
+inline int dec_block_alone(Dec &d) {
+  for (;;) {
+    int r = 0;
+    while (dec_fast_ok(d)) { r = dec_fast_turn(d); if (r) return r; }
+    r = dec_careful_turn(d);
+    if (r) return r;
+  }
+}
+
+// Decodes one complete raw DEFLATE stream of n bytes at src into dst; true when the stream ends exactly after out_len bytes of output
+// (the BGZF trailer's ISIZE) without reading past src + n.  False for anything else -- the caller asks zlib what it thinks of such a
+// member.
+inline bool inflate_raw(Inflater &Z, const uint8_t *src, size_t n, uint8_t *dst, size_t out_len) {
+  Dec d;
+  d.begin(Z, src, n, dst, out_len);
+  for (;;) {
+    const int b = dec_next_block(d);
+    if (b) return b == 1 && dec_finished_well(d);
+    if (dec_block_alone(d) < 0) return false;
+  }
+}
+#undef FQZ_TAKE
 
 }  // namespace fqz
