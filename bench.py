@@ -535,7 +535,8 @@ def main() -> None:
         dt = time.perf_counter() - t0
         assert got == [nfe, nfe] and np.array_equal(rows[0][0][:, :L], cpu_batch.seq[0, :nfe, :L]) and np.array_equal(rows[1][1][:, :L], qual_fe[1])
         fe["tokenise_inflate_pairs_per_s"] = round(nfe / dt, 1)
-        fe["tokenise_inflate"] = {"threads_per_file": rt, "s": round(dt, 3), "text_GBps": round(text_bytes / dt / 1e9, 3)}
+        fe["tokenise_inflate"] = {"threads_per_file": rt, "s": round(dt, 3), "text_GBps": round(text_bytes / dt / 1e9, 3),
+                                  "inflate": "zlib" if os.environ.get("FASTQUICK_ZLIB_INFLATE", "0") not in ("", "0") else "fq_inflate.h (zlib for members it refuses)"}
         del rows
         exe = os.path.join(ROOT, "fastquick_amd", "bin", "FASTQuick_amd")
         if os.path.exists(exe):
