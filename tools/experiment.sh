@@ -11,6 +11,12 @@
 #                                          (--kernel-trace only)                                       -> gpurun_out/<tag>_counters.txt
 #   stats <tag> <name> [bench args]        rocprofv3 --kernel-trace --stats of one bench run           -> gpurun_out/<tag>_<name>_kernel_stats.csv + _bench.json
 #   trace <tag> <pairs> [tuning]           host phases of one on-target call (tools/gap_paths.py trace=1) -> gpurun_out/<tag>_trace_<pairs>.txt
+#   streams <tag> "<ctxs> [k=v,..]" ...    on-target throughput (4.2 M-pair calls) per (streams, tuning): value, per-launch times of the search
+#                                          rounds and the width kernel in the timed region                -> gpurun_out/<tag>_streams.txt
+#   libs <tag> <pairs> <lib.so> ... -- "<k=v,..>" ...   the `knobs` experiment for several builds of the library (compile-time variants:
+#                                          make -C fastquick_amd/csrc OUT=../libfq_x.so BUILD=build_x EXTRA=-D...)  -> gpurun_out/<tag>_libs.txt
+#   reader <tag>                           the FASTQ reader and the command line at a steady state, zlib's inflate against the front end's own
+#                                          decoder (FASTQUICK_ZLIB_INFLATE=1 / 0) on the same box          -> gpurun_out/<tag>_reader.txt
 set -u
 WHAT=${1:?what}; TAG=${2:?tag}; shift; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
@@ -106,5 +112,44 @@ trace)
   P=${1:?pairs}; shift
   cd $R && timeout 600 python tools/gap_paths.py $P trace=1${1:+,$1} 2>&1 | tail -34 | grep -v arena > $O/${TAG}_trace_$P.txt
   cat $O/${TAG}_trace_$P.txt ;;
+streams)
+  cd $R
+  : > $O/${TAG}_streams.txt
+  for cfg in "$@"; do
+    set -- $cfg
+    T=""; [ -n "${2:-}" ] && T="--tune $2"
+    timeout 600 python bench.py --mix ontarget --pairs 4194304 --ctxs $1 --steps 4 --warmup 1 $Q $T > $O/${TAG}_str.json 2>> $O/${TAG}_streams.err
+    python3 -c "
+import json
+d = json.loads(open('$O/${TAG}_str.json').read().strip().splitlines()[-1])
+k = d['kernel_rooflines']
+print('ctxs $1 tuning ${2:--}: value %.4g pairs/s ms/step %.1f host_ms/call %s | first round %.2f second %.2f width %.2f ms per launch | fq_gap %.3f of 8 TB/s' % (d['value'], d['ms_per_step'], d.get('host_ms_per_call'), k['fq_gap_nogap']['avg_launch_ms'], k['fq_gap_full']['avg_launch_ms'], k['fq_width']['avg_launch_ms'], k['fq_gap']['frac_of_hbm_peak']))" >> $O/${TAG}_streams.txt
+  done
+  cat $O/${TAG}_streams.txt ;;
+libs)
+  P=${1:?pairs}; shift
+  LIBS=(); while [ $# -gt 0 ] && [ "$1" != "--" ]; do LIBS+=("$1"); shift; done
+  [ "${1:-}" = "--" ] && shift
+  cd $R
+  : > $O/${TAG}_libs.txt
+  for L in "${LIBS[@]}"; do
+    echo "## $L" >> $O/${TAG}_libs.txt
+    FQ_LIB_EXPERIMENT=$R/$L timeout 900 python tools/exp_gap.py $P "${@:--}" 2>&1 | grep -v "^reads made" | cut -c1-330 >> $O/${TAG}_libs.txt
+  done
+  cat $O/${TAG}_libs.txt ;;
+reader)
+  cd $R
+  : > $O/${TAG}_reader.txt
+  for z in 1 0; do
+    FASTQUICK_ZLIB_INFLATE=$z timeout 1200 python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-resident --no-ontarget > $O/${TAG}_rd_$z.json 2> $O/${TAG}_rd_$z.err
+    python3 -c "
+import json
+d = json.loads(open('$O/${TAG}_rd_$z.json').read().strip().splitlines()[-1])
+fe = d['front_end']
+print('zlib_only=$z tokenise_inflate', fe.get('tokenise_inflate_pairs_per_s'), fe.get('tokenise_inflate'))
+for k, v in (fe.get('cli_e2e_steady') or {}).items():
+    if isinstance(v, dict): print('  ', k, v.get('pairs_per_s'), v.get('wall_s'), v.get('notices'))" >> $O/${TAG}_reader.txt
+  done
+  cat $O/${TAG}_reader.txt ;;
 *) echo "unknown experiment $WHAT"; exit 2 ;;
 esac
