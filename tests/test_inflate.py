@@ -142,3 +142,13 @@ def test_random_mixtures_of_literals_and_repeats(lib):
         comp = raw_deflate(data, level, rng.choice((zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED)), mem=rng.choice((1, 8, 9)))
         rc, out = inflate(lib, comp, len(data))
         assert rc == 0 and out == data, (it, len(data), level)
+
+
+def test_decoder_under_address_and_ub_sanitizers(tmp_path):
+    """exact-size heap buffers: an overrun on any of 4,000 valid and damaged streams stops the run (CPU build only: no sanitizer on the device)"""
+    exe = str(tmp_path / "inflate_fuzz")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I", os.path.join(ROOT, "fastquick_amd", "csrc"), "-o", exe, os.path.join(ROOT, "tests", "emu", "inflate_fuzz.cpp"), "-lz"])
+    out = subprocess.run([exe, "4000"], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert "mismatches 0" in out.stdout
