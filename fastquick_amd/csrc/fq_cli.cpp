@@ -16,6 +16,7 @@
 #include <chrono>
 #include <cstdio>
 #include <map>
+#include <functional>
 #include <memory>
 #include <cstdlib>
 #include <cstring>
@@ -183,10 +184,15 @@ void unequal_lengths_notice(const Args &A, const fq_fastq_t *a, const fq_fastq_t
 // and read slots, as PairEndMapper / SingleEndMapper set them up per call (src/BwtMapper.cpp:232-262).
 // FASTQ front end: one reader thread per file tokenises the next chunk into flat buffers while the device aligns the current
 // one (the reference, too, decodes the two files on two IO threads: BwtMapper.cpp:1873-1935).
-void align_input(Args A, const std::pair<std::string, std::string> &input, fq_index_t *ix, fq_qc_t *qc, Sink &out) {
+// `ready`: called once the input's first chunk has been read and before anything needs the index, the QC consumer or the sink -- the
+// one-device command line stages the index (about a second: the filter bitmaps are built on the device) on another thread meanwhile.
+void align_input(Args A, const std::pair<std::string, std::string> &input, fq_index_t *const &ix_ref, fq_qc_t *const &qc_ref, Sink &out, const std::function<void()> &ready) {
   int rc;
   A.fq1 = input.first; A.fq2 = input.second;
   if (A.fq2.empty() || A.fq2 == "Empty") {
+    ready();
+    fq_index_t *const ix = ix_ref;
+    fq_qc_t *const qc = qc_ref;
     // ---- BwtMapper::SingleEndMapper (src/BwtMapper.cpp:1266-1407): one file, its own srand48 stream; the reader hands out fresh zeroed
     //      buffers (bwa_read_seq_with_hash, :350-475), so neither bases nor name tails of earlier reads linger
     fprintf(stderr, "NOTICE - Processing Single End mapping\t%s\n", A.fq1.c_str());
@@ -247,10 +253,6 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
     return;
   }
   fprintf(stderr, "NOTICE - Processing Pair End mapping\t%s\t%s\n", A.fq1.c_str(), A.fq2.c_str());
-  if (qc) fq_qc_begin_file(qc, A.fq1.c_str(), A.fq2.c_str());
-  fq_ctx_t *ctx = nullptr;
-  rc = fq_ctx_create(ix, &A.o, (int32_t)A.chunk_pairs, &ctx);
-  if (rc) die("fq_ctx_create failed (" + std::to_string(rc) + "): option outside the supported range");
   const int slot_mode = A.clean_names ? FQ_FASTQ_SLOTS_CLEAN_NAMES : FQ_FASTQ_SLOTS_REUSED;
   FastqReader r1(A.fq1, std::max(1, A.pack_threads / 2), A.o.batch_pairs, slot_mode, A.frac), r2(A.fq2, std::max(1, A.pack_threads / 2), A.o.batch_pairs, slot_mode, A.frac);
   int stride = 0;
@@ -282,10 +284,17 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
     t0.join(); t1.join();
     read_all_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count();
   };
-  fq_packed_batch_t *pk = nullptr;   // packed-batch storage, reused from chunk to chunk (pinned once)
-  if (fq_packed_create((int32_t)A.chunk_pairs, stride, &pk)) die("out of pinned host memory for the packed batch");
   double read_ms = 0, pack_ms = 0;
   { const auto t0 = std::chrono::steady_clock::now(); read_both(0); read_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+  ready();                           // from here on: the index, the QC consumer, the sink
+  fq_index_t *const ix = ix_ref;
+  fq_qc_t *const qc = qc_ref;
+  if (qc) fq_qc_begin_file(qc, A.fq1.c_str(), A.fq2.c_str());
+  fq_ctx_t *ctx = nullptr;
+  rc = fq_ctx_create(ix, &A.o, (int32_t)A.chunk_pairs, &ctx);
+  if (rc) die("fq_ctx_create failed (" + std::to_string(rc) + "): option outside the supported range");
+  fq_packed_batch_t *pk = nullptr;   // packed-batch storage, reused from chunk to chunk (pinned once)
+  if (fq_packed_create((int32_t)A.chunk_pairs, stride, &pk)) die("out of pinned host memory for the packed batch");
   for (int slot = 0;; slot ^= 1) {
     EndChunk &e0 = bufs[slot][0], &e1 = bufs[slot][1];
     if (!e0.error.empty()) die(e0.error);
@@ -678,17 +687,27 @@ int main(int argc, char **argv) {
   };
   if (W == 1) {
     // ---- one device: the records go out as they are produced ----
-    open_worker(0, A.out_prefix, A.sam_out ? nullptr : (A.out_prefix + ".bam").c_str());
+    // The index is staged, and the consumers are set up, while the first input's first chunk is read and tokenised.
     Worker &K = wk[0];
-    if (A.sam_out) {
-      const int64_t n = fq_sam_header(K.ix, nullptr, 0);
-      std::vector<char> h((size_t)n + 1);
-      fq_sam_header(K.ix, h.data(), n + 1);
-      fwrite(h.data(), 1, (size_t)n, stdout);
-    }
+    const std::string bam_path = A.out_prefix + ".bam";
+    std::thread opener([&] { open_worker(0, A.out_prefix, A.sam_out ? nullptr : bam_path.c_str()); });
     Sink out;
-    out.sam_out = A.sam_out; out.sam_fp = A.sam_out ? stdout : nullptr; out.bam = K.bam; out.what = A.sam_out ? "the SAM text" : A.out_prefix + ".bam";
-    for (const auto &input : inputs) align_input(A, input, K.ix, K.qc, out);
+    out.sam_out = A.sam_out; out.sam_fp = A.sam_out ? stdout : nullptr; out.what = A.sam_out ? "the SAM text" : bam_path;
+    bool opened = false;
+    const std::function<void()> ready = [&] {
+      if (opened) return;
+      opened = true;
+      opener.join();
+      out.bam = K.bam;
+      if (A.sam_out) {
+        const int64_t n = fq_sam_header(K.ix, nullptr, 0);
+        std::vector<char> h((size_t)n + 1);
+        fq_sam_header(K.ix, h.data(), n + 1);
+        fwrite(h.data(), 1, (size_t)n, stdout);
+      }
+    };
+    for (const auto &input : inputs) align_input(A, input, K.ix, K.qc, out, ready);
+    ready();
     if (K.bam && fq_bam_close(K.bam)) die("closing " + A.out_prefix + ".bam failed");
     if (K.qc) {
       if (fq_qc_write(K.qc)) die("writing the QC files failed");
@@ -750,7 +769,7 @@ int main(int argc, char **argv) {
         if (!f) die("cannot create " + out.what);
         if (A.sam_out) out.sam_fp = f; else out.bam_fp = f;
         fprintf(stderr, "NOTICE - device %d takes line %zu of the list\n", K.device, i + 1);
-        align_input(AW, inputs[i], K.ix, K.qc, out);
+        align_input(AW, inputs[i], K.ix, K.qc, out, [] {});
         if (fclose(f)) die("writing " + out.what + " failed");
         if (K.qc) {
           const int64_t need = fq_qc_state_export(K.qc, nullptr, 0);
