@@ -9,6 +9,7 @@
 // index carries its .SelectedSite.vcf / .dbSNP.subset.vcf / .gc.  Flank lengths and the original reference (for @SQ and the genome
 // size) come from <index_prefix>.FASTQuick.fa.param as `FASTQuick index` wrote it (src/FASTQuick.cpp:376-465).
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -28,7 +29,9 @@
 #include "../../include/fastquick_amd.h"
 
 namespace {
-[[noreturn]] void die(const std::string &m) { fprintf(stderr, "FATAL ERROR - \n%s\n", m.c_str()); exit(EXIT_FAILURE); }
+// (_exit after flushing: other threads may be inside the HIP runtime -- the index is staged beside the first read -- and must not meet the
+//  process's static destructors half-way)
+[[noreturn]] void die(const std::string &m) { fprintf(stderr, "FATAL ERROR - \n%s\n", m.c_str()); fflush(nullptr); _exit(EXIT_FAILURE); }
 void notice(const char *fmt, long long a) { fprintf(stderr, "NOTICE - "); fprintf(stderr, fmt, a); fputc('\n', stderr); }
 
 // One FASTQ file through the library's front end (fq_fastq_*: parallel inflate + tokeniser with kseq_read3_fpc's tokens)
