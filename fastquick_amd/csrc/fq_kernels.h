@@ -761,18 +761,6 @@ FQ_HD void fq_width_strand(const FqWidthArgs &A, int w, int a, uint8_t *seed_bit
         wprev = wcur;
       }
     }
-    // The widths and position records stream out (15 GB per 8.4 M reads; the search reads them back much later): non-temporal stores keep
-    // them from displacing the strand's Occ table from the XCD's 4 MB L2, which every step of every chain reads.
-#if defined(__HIP_DEVICE_COMPILE__)
-    typedef uint32_t fq_v4u __attribute__((ext_vector_type(4)));
-    fq_v4u q;
-    q.x = wv[0]; q.y = wv[1]; q.z = wv[2]; q.w = wv[3];
-    __builtin_nontemporal_store(q, (fq_v4u *)(owa + i0));
-    q.x = wv[4]; q.y = wv[5]; q.z = wv[6]; q.w = wv[7];
-    __builtin_nontemporal_store(q, (fq_v4u *)(owa + i0 + 4));
-    q.x = pv[0] | pv[1] << 16; q.y = pv[2] | pv[3] << 16; q.z = pv[4] | pv[5] << 16; q.w = pv[6] | pv[7] << 16;
-    __builtin_nontemporal_store(q, (fq_v4u *)(pra + i0));
-#else
     FqU4 q;
     q.x = wv[0]; q.y = wv[1]; q.z = wv[2]; q.w = wv[3];
     *(FqU4 *)(owa + i0) = q;
@@ -780,7 +768,6 @@ FQ_HD void fq_width_strand(const FqWidthArgs &A, int w, int a, uint8_t *seed_bit
     *(FqU4 *)(owa + i0 + 4) = q;
     q.x = pv[0] | pv[1] << 16; q.y = pv[2] | pv[3] << 16; q.z = pv[4] | pv[5] << 16; q.w = pv[6] | pv[7] << 16;
     *(FqU4 *)(pra + i0) = q;
-#endif
   }
   A.bid_end[2 * w + a] = (uint8_t)(bid < 255 ? bid : 255);
   if (a == 0) {
