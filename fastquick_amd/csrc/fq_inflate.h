@@ -27,8 +27,69 @@ struct CrcTables {
   }
 };
 inline const CrcTables &crc_tables() { static const CrcTables T; return T; }
-inline uint32_t crc32(const uint8_t *p, size_t n, uint32_t crc = 0) {
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#define FQZ_HAVE_CLMUL 1
+// Carry-less multiplication folds 64 bytes per step (the method of Intel's "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ",
+// constants for the reflected polynomial 0xEDB88320): state in, state out, len >= 64 and a multiple of 16.  Chosen at run time where the CPU
+// has it; tests/test_inflate.py holds both paths to zlib's crc32.
+__attribute__((target("pclmul,sse4.1"))) inline uint32_t crc32_clmul(const uint8_t *buf, size_t len, uint32_t state) {
+  const __m128i k1k2 = _mm_set_epi64x(0x01c6e41596LL, 0x0154442bd4LL), k3k4 = _mm_set_epi64x(0x00ccaa009eLL, 0x01751997d0LL);
+  const __m128i k5k0 = _mm_set_epi64x(0, 0x0163cd6124LL), poly = _mm_set_epi64x(0x01f7011641LL, 0x01db710641LL);
+  __m128i x1 = _mm_loadu_si128((const __m128i *)(buf + 0)), x2 = _mm_loadu_si128((const __m128i *)(buf + 16));
+  __m128i x3 = _mm_loadu_si128((const __m128i *)(buf + 32)), x4 = _mm_loadu_si128((const __m128i *)(buf + 48));
+  x1 = _mm_xor_si128(x1, _mm_cvtsi32_si128((int)state));
+  __m128i x0 = k1k2;
+  buf += 64; len -= 64;
+  while (len >= 64) {
+    const __m128i x5 = _mm_clmulepi64_si128(x1, x0, 0x00), x6 = _mm_clmulepi64_si128(x2, x0, 0x00);
+    const __m128i x7 = _mm_clmulepi64_si128(x3, x0, 0x00), x8 = _mm_clmulepi64_si128(x4, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x2 = _mm_clmulepi64_si128(x2, x0, 0x11);
+    x3 = _mm_clmulepi64_si128(x3, x0, 0x11); x4 = _mm_clmulepi64_si128(x4, x0, 0x11);
+    x1 = _mm_xor_si128(_mm_xor_si128(x1, x5), _mm_loadu_si128((const __m128i *)(buf + 0)));
+    x2 = _mm_xor_si128(_mm_xor_si128(x2, x6), _mm_loadu_si128((const __m128i *)(buf + 16)));
+    x3 = _mm_xor_si128(_mm_xor_si128(x3, x7), _mm_loadu_si128((const __m128i *)(buf + 32)));
+    x4 = _mm_xor_si128(_mm_xor_si128(x4, x8), _mm_loadu_si128((const __m128i *)(buf + 48)));
+    buf += 64; len -= 64;
+  }
+  x0 = k3k4;   // four lanes -> one
+  __m128i x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x3), x5);
+  x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x4), x5);
+  while (len >= 16) {
+    x2 = _mm_loadu_si128((const __m128i *)buf);
+    x5 = _mm_clmulepi64_si128(x1, x0, 0x00);
+    x1 = _mm_clmulepi64_si128(x1, x0, 0x11); x1 = _mm_xor_si128(_mm_xor_si128(x1, x2), x5);
+    buf += 16; len -= 16;
+  }
+  // 128 -> 64 bits, then Barrett reduction to 32
+  x2 = _mm_clmulepi64_si128(x1, x0, 0x10);
+  const __m128i m32 = _mm_setr_epi32(~0, 0, ~0, 0);
+  x1 = _mm_srli_si128(x1, 8); x1 = _mm_xor_si128(x1, x2);
+  x0 = k5k0;
+  x2 = _mm_srli_si128(x1, 4); x1 = _mm_and_si128(x1, m32);
+  x1 = _mm_clmulepi64_si128(x1, x0, 0x00); x1 = _mm_xor_si128(x1, x2);
+  x0 = poly;
+  x2 = _mm_and_si128(x1, m32); x2 = _mm_clmulepi64_si128(x2, x0, 0x10);
+  x2 = _mm_and_si128(x2, m32); x2 = _mm_clmulepi64_si128(x2, x0, 0x00);
+  x1 = _mm_xor_si128(x1, x2);
+  return (uint32_t)_mm_extract_epi32(x1, 1);
+}
+inline bool have_clmul() { static const bool h = __builtin_cpu_supports("pclmul") && __builtin_cpu_supports("sse4.1"); return h; }
+#endif
+inline uint32_t crc32(const uint8_t *p, size_t n, uint32_t crc = 0, bool tables_only = false) {
   const CrcTables &T = crc_tables();
+#if defined(FQZ_HAVE_CLMUL)
+  if (n >= 64 && !tables_only && have_clmul()) {
+    const size_t body = n & ~(size_t)15;
+    const uint32_t st = crc32_clmul(p, body, ~crc);
+    crc = ~st; p += body; n -= body;
+    if (!n) return crc;
+  }
+#endif
   uint32_t c = ~crc;
   while (n && ((uintptr_t)p & 7)) { c = T.t[0][(c ^ *p++) & 0xff] ^ (c >> 8); --n; }
   while (n >= 16) {

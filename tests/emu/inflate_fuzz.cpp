@@ -33,6 +33,12 @@ int main(int argc, char **argv) {
     // exact-size heap buffers: the sanitizer sees every overrun
     uint8_t *src = (uint8_t *)malloc(cn ? cn : 1); memcpy(src, c2.data(), cn);
     uint8_t *dst = (uint8_t *)malloc(out_len ? out_len : 1);
+    {   // the checksum, both ways (carry-less multiplication where the CPU has it; the tables), against zlib's
+      const uint32_t want = (uint32_t)crc32(0L, data.data(), (uInt)n);
+      if (fqz::crc32(data.data(), n) != want || fqz::crc32(data.data(), n, 0, true) != want) ++mism;
+      const size_t o = n > 3 ? 1 + rng() % 3 : 0;   // (an unaligned start)
+      if (fqz::crc32(data.data() + o, n - o) != (uint32_t)crc32(0L, data.data() + o, (uInt)(n - o))) ++mism;
+    }
     const bool r = fqz::inflate_raw(*Z, src, cn, dst, out_len);
     if (r) { ++ok; if (dmg == 0 || dmg == 3) { if (out_len != n || memcmp(dst, data.data(), n)) ++mism; } } else { ++refused; if (dmg == 0 || dmg == 3) ++mism; }
     free(src); free(dst);
