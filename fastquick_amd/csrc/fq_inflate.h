@@ -330,54 +330,65 @@ inline int dec_next_block(Dec &d) {
     return 0;
   }
 }
-// room for the longest match plus a run of literals on the output side, sixteen readable bytes on the input side
-inline bool dec_fast_ok(const Dec &d) { return d.in_end - d.in >= 16 && d.out_end - d.out >= 258 + 72; }
-// One turn of the fast loop (dec_fast_ok holds): a run of literals, or one match.  0: go on; 1: end of block; -1: refused.
-inline int dec_fast_turn(Dec &d) {
-  {   // refill: >= 56 bits
-    uint64_t w;
-    memcpy(&w, d.in, 8);
-    d.bb |= w << d.bc;
-    d.in += (63 - d.bc) >> 3;
-    d.bc |= 56;
-  }
+// The fast loop of a Huffman block: runs of literals and matches while there is room for the longest match plus a run of literals on the
+// output side and sixteen readable bytes on the input side.  The state lives in locals here (a decoder that kept it in the struct, behind
+// a reference, lost a third of its speed under clang: every byte stored could have been a field).  0: the margins ended (the careful
+// loop takes over); 1: end of block; -1: refused.
+inline int dec_fast_loop(Dec &d) {
+  const uint8_t *in = d.in, *const in_end = d.in_end;
+  uint8_t *out = d.out, *const out_end = d.out_end, *const dst = d.dst;
+  uint64_t bb = d.bb;
+  int bc = d.bc;
   const uint32_t *const LT = d.LT, *const DT = d.DT;
-  uint32_t e = LT[d.bb & ((1u << LIT_BITS) - 1)];
-  if (e & K_LIT) {                            // literals for as long as the buffer holds a whole first-level index (<= 2 bytes per >= 2 bits: <= 56 bytes)
-    do {
-      FQZ_TAKE(d, (int)(e & 0xff));
-      d.out[0] = (uint8_t)(e >> 16); d.out[1] = (uint8_t)(e >> 24);
-      d.out += 1 + ((e >> 8) & 1);
-      e = LT[d.bb & ((1u << LIT_BITS) - 1)];
-    } while ((e & K_LIT) && d.bc >= LIT_BITS);
-    return 0;                                 // (what follows is decoded after the refill)
+  int r = 0;
+#define FQZ_T(nb) (bb >>= (nb), bc -= (nb))
+  while (in_end - in >= 16 && out_end - out >= 258 + 72) {
+    {   // refill: >= 56 bits
+      uint64_t w;
+      memcpy(&w, in, 8);
+      bb |= w << bc;
+      in += (63 - bc) >> 3;
+      bc |= 56;
+    }
+    uint32_t e = LT[bb & ((1u << LIT_BITS) - 1)];
+    if (e & K_LIT) {                            // literals for as long as the buffer holds a whole first-level index (<= 2 bytes per >= 2 bits: <= 56 bytes)
+      do {
+        FQZ_T((int)(e & 0xff));
+        out[0] = (uint8_t)(e >> 16); out[1] = (uint8_t)(e >> 24);
+        out += 1 + ((e >> 8) & 1);
+        e = LT[bb & ((1u << LIT_BITS) - 1)];
+      } while ((e & K_LIT) && bc >= LIT_BITS);
+      continue;                                 // (what follows is decoded after the refill)
+    }
+    if ((e & K_MASK) == K_SUB) { FQZ_T(LIT_BITS); e = LT[(e >> 16) + (bb & ((1u << ((e >> 8) & 31)) - 1))]; }
+    uint64_t saved = bb;
+    FQZ_T((int)(e & 0xff));                     // code and extra bits at once: <= 15 + 5 = 20 of >= 56 bits
+    if (e & K_LIT) { *out++ = (uint8_t)(e >> 16); continue; }   // (a literal with a long code)
+    if ((e & K_MASK) != K_BASE) { r = (e & K_MASK) == K_EOB ? 1 : -1; break; }
+    const uint32_t length = (e >> 16) + (uint32_t)((saved >> ((e >> 8) & 31)) & ((1u << ((e & 0xff) - ((e >> 8) & 31))) - 1));
+    uint32_t dd = DT[bb & ((1u << DIST_BITS) - 1)];
+    if ((dd & K_MASK) == K_SUB) { FQZ_T(DIST_BITS); dd = DT[(dd >> 16) + (bb & ((1u << ((dd >> 8) & 31)) - 1))]; }
+    if ((dd & K_MASK) != K_BASE) { r = -1; break; }
+    saved = bb;
+    FQZ_T((int)(dd & 0xff));                    // <= 15 + 13 bits: <= 48 of >= 56
+    const uint32_t distance = (dd >> 16) + (uint32_t)((saved >> ((dd >> 8) & 31)) & ((1u << ((dd & 0xff) - ((dd >> 8) & 31))) - 1));
+    if (distance > (size_t)(out - dst)) { r = -1; break; }
+    const uint8_t *from = out - distance;
+    uint8_t *const stop = out + length;
+    if (distance >= 8) {
+      do { uint64_t w; memcpy(&w, from, 8); memcpy(out, &w, 8); from += 8; out += 8; } while (out < stop);
+    } else if (distance == 1) {
+      memset(out, *from, length);
+    } else {
+      do { *out++ = *from++; } while (out < stop);
+    }
+    out = stop;
   }
-  if ((e & K_MASK) == K_SUB) { FQZ_TAKE(d, LIT_BITS); e = LT[(e >> 16) + (d.bb & ((1u << ((e >> 8) & 31)) - 1))]; }
-  uint64_t saved = d.bb;
-  FQZ_TAKE(d, (int)(e & 0xff));               // code and extra bits at once: <= 15 + 5 = 20 of >= 56 bits
-  if (e & K_LIT) { *d.out++ = (uint8_t)(e >> 16); return 0; }   // (a literal with a long code)
-  if ((e & K_MASK) != K_BASE) return (e & K_MASK) == K_EOB ? 1 : -1;
-  const uint32_t length = (e >> 16) + (uint32_t)((saved >> ((e >> 8) & 31)) & ((1u << ((e & 0xff) - ((e >> 8) & 31))) - 1));
-  uint32_t dd = DT[d.bb & ((1u << DIST_BITS) - 1)];
-  if ((dd & K_MASK) == K_SUB) { FQZ_TAKE(d, DIST_BITS); dd = DT[(dd >> 16) + (d.bb & ((1u << ((dd >> 8) & 31)) - 1))]; }
-  if ((dd & K_MASK) != K_BASE) return -1;
-  saved = d.bb;
-  FQZ_TAKE(d, (int)(dd & 0xff));              // <= 15 + 13 bits: <= 48 of >= 56
-  const uint32_t distance = (dd >> 16) + (uint32_t)((saved >> ((dd >> 8) & 31)) & ((1u << ((dd & 0xff) - ((dd >> 8) & 31))) - 1));
-  if (distance > (size_t)(d.out - d.dst)) return -1;
-  const uint8_t *from = d.out - distance;
-  uint8_t *out = d.out, *const stop = out + length;
-  if (distance >= 8) {
-    do { uint64_t w; memcpy(&w, from, 8); memcpy(out, &w, 8); from += 8; out += 8; } while (out < stop);
-  } else if (distance == 1) {
-    memset(out, *from, length);
-  } else {
-    do { *out++ = *from++; } while (out < stop);
-  }
-  d.out = stop;
-  return 0;
+#undef FQZ_T
+  d.in = in; d.out = out; d.bb = bb; d.bc = bc;
+  return r;
 }
-// One symbol with every bound checked (the ends of the input and of the output).  Returns as dec_fast_turn.
+// One symbol with every bound checked (the ends of the input and of the output).  Returns as dec_fast_loop, for one symbol.
 inline int dec_careful_turn(Dec &d) {
   dec_refill(d);
   const uint32_t *const LT = d.LT, *const DT = d.DT;
@@ -409,11 +420,11 @@ inline int dec_careful_turn(Dec &d) {
 }
 // the stream has ended: inside the input (bits left in the buffer belong to the last bytes read), after exactly the promised output
 inline bool dec_finished_well(const Dec &d) { return d.over <= ((size_t)d.bc >> 3) && d.out == d.out_end; }
-// the symbols of the current Huffman block, alone.  1: end of block; -1: refused.
-inline int dec_block_alone(Dec &d) {
+// the symbols of the current Huffman block.  1: end of block; -1: refused.
+inline int dec_block(Dec &d) {
   for (;;) {
-    int r = 0;
-    while (dec_fast_ok(d)) { r = dec_fast_turn(d); if (r) return r; }
+    int r = dec_fast_loop(d);
+    if (r) return r;
     r = dec_careful_turn(d);
     if (r) return r;
   }
@@ -428,7 +439,7 @@ inline bool inflate_raw(Inflater &Z, const uint8_t *src, size_t n, uint8_t *dst,
   for (;;) {
     const int b = dec_next_block(d);
     if (b) return b == 1 && dec_finished_well(d);
-    if (dec_block_alone(d) < 0) return false;
+    if (dec_block(d) < 0) return false;
   }
 }
 #undef FQZ_TAKE
