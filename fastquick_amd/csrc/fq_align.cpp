@@ -151,6 +151,7 @@ struct FqKnobs {   // experiment / test knobs (fq_ctx_set_tuning); defaults are 
                                    // Two streams of 4.2 M-pair on-target calls: search kernels 54.1 / 41.7 / 38.8 ms per launch with 0 / 1 / 2 (38.8 alone), 16.8 / 16.3 / 16.7 M pairs/s
   int64_t device_turn_min = 1 << 20; // ... calls that search at least this many reads (launches that fill the device several times over; sixteen streams of a 100k-marker
                                    // WGS mix search 176 k reads per call: one residency of the first round, and taking turns for it serialised the streams)
+  int gap_round2_refill = 16;      // refill group of the round after it (see the launch)
   int gap_round1_refill = 0;       // experiment: refill group of the round without gap children (0: whole wavefronts)
   int gap_round2_lane_major = 1;   // ... with every lane's stack pool contiguous (FqGapTier::lane_major)
   int gap_round2_waves = 2560;     // wavefronts of the round after the one without gap children (0: as many as fit): its reads are long searches, a trip of a
@@ -355,6 +356,7 @@ extern "C" int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t v) {
   else if (k == "gap_round2_waves") c->kn.gap_round2_waves = (int)v;
   else if (k == "gap_round2_lane_major") c->kn.gap_round2_lane_major = (int)v;
   else if (k == "gap_round1_refill") c->kn.gap_round1_refill = (int)v;
+  else if (k == "gap_round2_refill") c->kn.gap_round2_refill = (int)v;
   else if (k == "sw_wave_max") c->kn.sw_wave_max = (int)v;
   else if (k == "host_threads") c->kn.host_threads = (int)v;
   else if (k == "host_par_min") c->kn.host_par_min = (size_t)v;
@@ -1070,7 +1072,7 @@ int stageA_search(Call &K) {
       // The round after the one without gap children holds the hard reads only: their lengths differ by orders of magnitude, so a
       // wavefront that waits for all 64 lanes before it refills idles most of them (28.9 -> 24.2 ms for the 228 k reads a 4.2 M-read
       // call leaves); the first round keeps whole-wavefront refill, its reads finish together (refill by 16: 23.8 -> 25.8 ms).
-      ga.refill_min = ran_nogap && !T.nogap && !T.coop ? 16 : T.nogap ? c->kn.gap_round1_refill : 0;
+      ga.refill_min = ran_nogap && !T.nogap && !T.coop ? c->kn.gap_round2_refill : T.nogap ? c->kn.gap_round1_refill : 0;
       if (ran_nogap && !T.nogap && !T.coop && c->kn.gap_round2_waves > 0) ga.max_waves = c->kn.gap_round2_waves;
       if (ran_nogap && !T.nogap && !T.coop) ga.tier.lane_major = c->kn.gap_round2_lane_major;
       // stack pools are the one large per-launch allocation (lanes x pool_cap x 16 B): when the device cannot hold them for
