@@ -93,7 +93,7 @@ int stream_aux(int on);
 int stream_fork();
 int stream_join();
 // the work items of one queue segment whose search did not complete (status != 0): search indices appended to out[*count ...]
-int launch_collect(const int32_t *order, const uint32_t *split, int n_work, int seg, int n_seg, const uint32_t *status, const int32_t *work, int32_t *out, uint32_t *count);   // pairing of both-mapped pairs (fq_pair_thread)
+int launch_collect(const int32_t *order, const uint32_t *split, int n_work, int seg, int n_seg, const uint32_t *status, const int32_t *work, int32_t *out, uint32_t *count);
 // the stages over the device-resident records (fq_records.h): operation FQ_ROP_*, one thread per item
 int launch_rec(int op, const FqRecArgs &a, int64_t n);
 // by search index: aoff[work[w]] = base + off[w], an[work[w]] = naln[w] for the work items of a launch that completed (status 0)
