@@ -194,7 +194,8 @@ inline bool build_table(const uint8_t *len, int n, int tb, uint32_t *table, int 
   return true;
 }
 
-// Two literals per look-up where both codes fit the first level's bits: FASTQ text is mostly literals of two to five bits.
+// Two literals per look-up where both codes fit the first level's bits (sequence lines that the compressor left as literals cost two to
+// five bits a base; zlib level 1 leaves few -- there the text is matches of 4.6 bytes on average -- higher levels and other writers more).
 inline void pair_literals(uint32_t *table, int tb) {
   static thread_local uint32_t base[1 << LIT_BITS];
   memcpy(base, table, sizeof(uint32_t) << tb);
