@@ -1989,6 +1989,7 @@ int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
 
 extern "C" int fq_host_cpus(void) { return (int)effective_cpus(); }
 extern "C" int fq_runtime_configure(int hw_queues, int blocking_waits) { return fqdev::runtime_configure(hw_queues, blocking_waits); }
+extern "C" int fq_device_count(void) { return fqdev::device_count(); }
 
 extern "C" int fq_align_resident(fq_ctx_t *c, fq_result_batch_t *out) {
   if (!c || !out) return FQ_EINVAL;
@@ -2085,21 +2086,28 @@ extern "C" int fq_ctx_state_import(fq_ctx_t *c, const void *buf, int64_t len) {
   memcpy(&mark, p, 8); p += 8;
   if (mark == kStateBroken) { c->stream_broken = true; c->err = "the stream's state comes from a call that failed on another rank"; return FQ_EIO; }
   if (mark != kStateGood) return FQ_EINVAL;
-  memcpy(&c->rng, p, 8); p += 8;
-  memcpy(&c->last_ii, p, sizeof(fq_isize_t)); p += sizeof(fq_isize_t);
-  uint64_t n;
+  // the whole token is parsed into temporaries and committed at the end: a malformed one (it comes from another rank) leaves the
+  // context as it was -- and marks the stream broken, since the state it should have continued from never arrived
+  uint64_t rng, n;
+  fq_isize_t ii;
+  memcpy(&rng, p, 8); p += 8;
+  memcpy(&ii, p, sizeof(fq_isize_t)); p += sizeof(fq_isize_t);
   memcpy(&n, p, 8); p += 8;
-  c->kl_cache.clear();
-  for (uint64_t i = 0; i < n; ++i) {
-    if (end - p < 16) return FQ_EINVAL;
+  std::unordered_map<uint64_t, vector<uint32_t>> cache;
+  bool ok = n <= (uint64_t)(end - p) / 16;
+  for (uint64_t i = 0; ok && i < n; ++i) {
+    if (end - p < 16) { ok = false; break; }
     uint64_t key, m;
     memcpy(&key, p, 8); p += 8;
     memcpy(&m, p, 8); p += 8;
-    if ((uint64_t)(end - p) < 4 * m) return FQ_EINVAL;
-    vector<uint32_t> v(m);
-    memcpy(v.data(), p, 4 * m); p += 4 * m;
-    c->kl_cache.emplace(key, std::move(v));
+    if (m > (uint64_t)(end - p) / 4) { ok = false; break; }      // (not 4 * m > ...: that wraps for m >= 2^62)
+    vector<uint32_t> v((size_t)m);
+    if (m) memcpy(v.data(), p, 4 * (size_t)m);
+    p += 4 * (size_t)m;
+    cache.emplace(key, std::move(v));
   }
+  if (!ok) { c->stream_broken = true; c->err = "malformed stream state (fq_ctx_state_import)"; return FQ_EINVAL; }
+  c->rng = rng; c->last_ii = ii; c->kl_cache.swap(cache);
   return FQ_OK;
 }
 // A hook that could not do its work (its transport failed, its language raised) says so here, from inside the hook: the call stops

@@ -20,6 +20,7 @@ struct Tune {   // experiment / test knobs (fq_ctx_set_tuning); the defaults are
   int sw_serial_reverse = 0; // 1: the mate-rescue kernel's reverse pass as the serial statement on one lane (the wavefront form is the default)
 };
 int runtime_configure(int hw_queues, int blocking_waits);   // fq_runtime_configure: before the process's first HIP call
+int device_count();                        // devices the process sees (0: none)
 State *state_create(int device_ordinal);   // nullptr on failure (last_error())
 void state_destroy(State *s);              // synchronises the state's streams, frees everything it owns
 int bind(State *s);                        // 0 or FQ_ENODEV-style negative

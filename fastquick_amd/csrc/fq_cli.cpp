@@ -31,7 +31,16 @@
 namespace {
 // (_exit after flushing: other threads may be inside the HIP runtime -- the index is staged beside the first read -- and must not meet the
 //  process's static destructors half-way)
-[[noreturn]] void die(const std::string &m) { fprintf(stderr, "FATAL ERROR - \n%s\n", m.c_str()); fflush(nullptr); _exit(EXIT_FAILURE); }
+// part / worker files of a multi-device run: removed when the run dies (a finished run appends and removes them itself)
+std::mutex g_tmp_mu;
+std::vector<std::string> g_tmp_files;
+void tmp_file(const std::string &p) { std::lock_guard<std::mutex> lk(g_tmp_mu); g_tmp_files.push_back(p); }
+[[noreturn]] void die(const std::string &m) {
+  fprintf(stderr, "FATAL ERROR - \n%s\n", m.c_str());
+  { std::lock_guard<std::mutex> lk(g_tmp_mu); for (const auto &p : g_tmp_files) remove(p.c_str()); }
+  fflush(nullptr);
+  _exit(EXIT_FAILURE);
+}
 void notice(const char *fmt, long long a) { fprintf(stderr, "NOTICE - "); fprintf(stderr, fmt, a); fputc('\n', stderr); }
 
 // One FASTQ file through the library's front end (fq_fastq_*: parallel inflate + tokeniser with kseq_read3_fpc's tokens)
@@ -148,6 +157,12 @@ struct Sink {
 // "0-3", "0,2,5", "0,0": the devices of --devices (a device named twice gets two workers)
 std::vector<int> parse_devices(const std::string &v) {
   std::vector<int> d;
+  auto ordinal = [&](const std::string &t) -> int {       // digits only: "a", "0-x", "1.5" are errors, not device 0
+    char *e = nullptr;
+    const long x = t.empty() ? -1 : strtol(t.c_str(), &e, 10);
+    if (t.empty() || !e || *e || t.find_first_not_of("0123456789") != std::string::npos || x < 0 || x > 63) die("--devices: bad device ordinal '" + t + "' in " + v);
+    return (int)x;
+  };
   size_t at = 0;
   while (at < v.size()) {
     size_t end = v.find(',', at);
@@ -155,11 +170,11 @@ std::vector<int> parse_devices(const std::string &v) {
     const std::string tok = v.substr(at, end - at);
     const size_t dash = tok.find('-');
     if (tok.empty()) die("--devices: empty entry in " + v);
-    if (dash == std::string::npos) d.push_back(atoi(tok.c_str()));
-    else { const int a = atoi(tok.substr(0, dash).c_str()), b = atoi(tok.substr(dash + 1).c_str()); if (b < a) die("--devices: bad range " + tok); for (int x = a; x <= b; ++x) d.push_back(x); }
+    if (dash == std::string::npos) d.push_back(ordinal(tok));
+    else { const int a = ordinal(tok.substr(0, dash)), b = ordinal(tok.substr(dash + 1)); if (b < a) die("--devices: bad range " + tok); for (int x = a; x <= b; ++x) d.push_back(x); }
     at = end + 1;
   }
-  for (int x : d) if (x < 0 || x > 63) die("--devices: device ordinal out of range in " + v);
+  if (d.empty() || (!v.empty() && v.back() == ',')) die("--devices: empty entry in " + v);
   return d;
 }
 void append_file(const std::string &path, FILE *to, fq_bam_t *bam) {   // a part file onto the output (SAM text to `to`, BAM records to `bam`), then gone
@@ -670,6 +685,11 @@ int main(int argc, char **argv) {
   std::vector<int> devices = A.devices.empty() ? std::vector<int>{A.device} : parse_devices(A.devices);
   const bool shard_one_pair = devices.size() > 1 && inputs.size() == 1 && !inputs[0].second.empty() && inputs[0].second != "Empty";   // one pair, several devices
   if (!shard_one_pair && devices.size() > inputs.size()) devices.resize(std::max<size_t>(1, inputs.size()));   // (a worker per FASTQ pair at most)
+  {   // every ordinal is checked before anything is started (a worker that fails to load its index would take the run down half-way)
+    const int n_dev = fq_device_count();
+    if (n_dev <= 0) die("no HIP device is visible; there is no CPU fallback");
+    for (int d : devices) if (d >= n_dev) die("device " + std::to_string(d) + " does not exist (" + std::to_string(n_dev) + " visible)");
+  }
   const size_t W = devices.size();
   std::vector<Worker> wk(W);
   auto open_worker = [&](size_t w, const std::string &qc_prefix, const char *bam_path) {
@@ -680,6 +700,7 @@ int main(int argc, char **argv) {
     fprintf(stderr, "NOTICE - index staged on device %d in %.1f ms\n", K.device, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_ix0).count());
     if (rc) die("cannot load index " + pre + " onto HIP device " + std::to_string(K.device) + " (" + std::to_string(rc) + "); there is no CPU fallback");
     if (have_qc) {
+      if (qc_prefix != A.out_prefix) tmp_file(qc_prefix + ".InsertSizeTable");
       rc = fq_qc_create(K.ix, pre.c_str(), qc_prefix.c_str(), &qo, &K.qc);
       if (rc) die("cannot set up the QC consumer from " + pre + ".SelectedSite.vcf / .dbSNP.subset.vcf / .gc (" + std::to_string(rc) + ")");
     }
@@ -768,6 +789,7 @@ int main(int argc, char **argv) {
         Sink out;
         out.sam_out = A.sam_out; out.bam = K.bam;
         out.what = part(i, A.sam_out ? ".sam" : ".bamrec");
+        tmp_file(out.what);
         FILE *f = fopen(out.what.c_str(), "wb");
         if (!f) die("cannot create " + out.what);
         if (A.sam_out) out.sam_fp = f; else out.bam_fp = f;

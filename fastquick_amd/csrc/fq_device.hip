@@ -94,6 +94,7 @@ int runtime_configure(int hw_queues, int blocking_waits) {
   return 0;
 }
 
+int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n < 0 ? 0 : n; }
 void device_turn_begin() { g_turn_mu[g_cur->device].lock(); }
 void device_turn_end() { g_turn_mu[g_cur->device].unlock(); }
 
@@ -487,6 +488,9 @@ __device__ void fq_sw_reverse_wave(const uint8_t *ref, const uint8_t *qry, int s
         start_i = start - (g0 + (__ffsll((long long)at) - 1)); start_j = j;
         carry_m = m_last;
       }
+      // lane 0's fetch for the next group (H[start - g0 - 63], above) is the cell lane 63 stores below: the fetches of all lanes are
+      // complete before any lane stores (shuffles and ballots order nothing in memory; the block is one wavefront, so the barrier is a wait)
+      __syncthreads();
       if (act) { H[i] = h; E[i + 1] = e; }
       d_in = d_nx; s_in = s_nx; e_in = e_nx;
     }

@@ -10,6 +10,10 @@
 #include <cstddef>
 #include <cstdint>
 #include <cstring>
+#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
+#include <immintrin.h>
+#define FQZ_HAVE_CLMUL 1
+#endif
 
 namespace fqz {
 
@@ -27,12 +31,14 @@ struct CrcTables {
   }
 };
 inline const CrcTables &crc_tables() { static const CrcTables T; return T; }
-#if defined(__x86_64__) && !defined(__HIP_DEVICE_COMPILE__)
-#include <immintrin.h>
-#define FQZ_HAVE_CLMUL 1
-// Carry-less multiplication folds 64 bytes per step (the method of Intel's "Fast CRC Computation for Generic Polynomials Using PCLMULQDQ",
-// constants for the reflected polynomial 0xEDB88320): state in, state out, len >= 64 and a multiple of 16.  Chosen at run time where the CPU
-// has it; tests/test_inflate.py holds both paths to zlib's crc32.
+#if defined(FQZ_HAVE_CLMUL)
+// Carry-less multiplication folds 64 bytes per step: the method of V. Gopal, E. Ozturk et al., "Fast CRC Computation for Generic Polynomials
+// Using PCLMULQDQ Instruction" (Intel white paper 323102, 2009).  The folding / reduction constants for the reflected polynomial 0xEDB88320
+// (k1..k5 = x^(4*128+32), x^(4*128-32), x^(128+32), x^(128-32), x^64 mod P, bit-reflected; Barrett mu and P) and the four-accumulator
+// schedule are those of the widely published routine that follows the paper -- zlib's x86 forks (Intel's crc_folding.c of 2013, Chromium's
+// crc32_simd.c, zlib-ng's crc32_pclmulqdq) all carry the same values, as any implementation of the paper for this polynomial must.
+// State in, state out, len >= 64 and a multiple of 16.  Chosen at run time where the CPU has it; tests/test_inflate.py holds both
+// paths to zlib's crc32.
 __attribute__((target("pclmul,sse4.1"))) inline uint32_t crc32_clmul(const uint8_t *buf, size_t len, uint32_t state) {
   const __m128i k1k2 = _mm_set_epi64x(0x01c6e41596LL, 0x0154442bd4LL), k3k4 = _mm_set_epi64x(0x00ccaa009eLL, 0x01751997d0LL);
   const __m128i k5k0 = _mm_set_epi64x(0, 0x0163cd6124LL), poly = _mm_set_epi64x(0x01f7011641LL, 0x01db710641LL);

@@ -426,6 +426,9 @@ int fq_host_cpus(void);
  *                       of spinning (the library's own waits sleep on blocking events either way).
  * The library warns once on stderr when more contexts are created on a device than the queues in effect keep apart. */
 int fq_runtime_configure(int hw_queues, int blocking_waits);
+/* HIP devices the process sees (0: none, or no usable runtime): what a device ordinal of fq_index_load is checked against before
+ * anything is started on it.  (No reference counterpart.) */
+int fq_device_count(void);
 
 #ifdef __cplusplus
 }

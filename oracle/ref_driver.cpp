@@ -119,6 +119,20 @@ static void dump_ii(FILE *fp, const isize_info_t *ii) {
           ii->low, ii->high, ii->high_bayesian);
 }
 
+// one SamRecord as text: the fields SetSamRecord filled, then its tags in the order the record holds them (--bam_dump, all three drivers)
+static void dump_sam_record(FILE *fb, SamRecord &R) {
+  fprintf(fb, "%s\t%d\t%s\t%d\t%d\t%s\t%s\t%d\t%d\t%s\t%s", R.getReadName(), (int)R.getFlag(), R.getReferenceName(), (int)R.get1BasedPosition(),
+          (int)R.getMapQuality(), R.getCigar(), R.getMateReferenceNameOrEqual(), (int)R.get1BasedMatePosition(), (int)R.getInsertSize(), R.getSequence(), R.getQuality());
+  char tag[3]; char vtype; void *value;
+  R.resetTagIter();
+  while (R.getNextSamTag(tag, vtype, &value)) {
+    if (vtype == 'Z') fprintf(fb, "\t%s:Z:%s", tag, ((String *)value)->c_str());
+    else if (vtype == 'A') fprintf(fb, "\t%s:A:%c", tag, *(char *)value);
+    else if (vtype == 'f') fprintf(fb, "\t%s:f:%g", tag, *(float *)value);
+    else fprintf(fb, "\t%s:i:%d", tag, *(int *)value);
+  }
+  fputc('\n', fb);
+}
 static int cmd_align(int argc, char **argv) {
   if (argc < 6) die("usage: align <ref.FASTQuick.fa> <r1.fq> <r2.fq> <out_prefix> [--q Q] [--batch N] [--thresh K]");
   std::string NewRef = argv[2];
@@ -272,17 +286,7 @@ static int cmd_align(int argc, char **argv) {
         if (bam_dump) {
           SamRecord R;
           mapper.SetSamRecord(ix.bns, p, 0, SFH, R, opt);
-          fprintf(fb, "%s\t%d\t%s\t%d\t%d\t%s\t%s\t%d\t%d\t%s\t%s", R.getReadName(), (int)R.getFlag(), R.getReferenceName(), (int)R.get1BasedPosition(),
-                  (int)R.getMapQuality(), R.getCigar(), R.getMateReferenceNameOrEqual(), (int)R.get1BasedMatePosition(), (int)R.getInsertSize(), R.getSequence(), R.getQuality());
-          char tag[3]; char vtype; void *value;
-          R.resetTagIter();
-          while (R.getNextSamTag(tag, vtype, &value)) {
-            if (vtype == 'Z') fprintf(fb, "\t%s:Z:%s", tag, ((String *)value)->c_str());
-            else if (vtype == 'A') fprintf(fb, "\t%s:A:%c", tag, *(char *)value);
-            else if (vtype == 'f') fprintf(fb, "\t%s:f:%g", tag, *(float *)value);
-            else fprintf(fb, "\t%s:i:%d", tag, *(int *)value);
-          }
-          fputc('\n', fb);
+          dump_sam_record(fb, R);
           continue;
         }
         bwa_print_sam1(ix.bns, p, 0, opt->mode, opt->max_top2);
@@ -379,17 +383,7 @@ static int cmd_align(int argc, char **argv) {
         mapper.SetSamRecord(ix.bns, p[1], p[0], SFH, SR[1], opt);
         for (int k = 0; k < 2; ++k) {
           SamRecord &R = SR[k];
-          fprintf(fb, "%s\t%d\t%s\t%d\t%d\t%s\t%s\t%d\t%d\t%s\t%s", R.getReadName(), (int)R.getFlag(), R.getReferenceName(), (int)R.get1BasedPosition(),
-                  (int)R.getMapQuality(), R.getCigar(), R.getMateReferenceNameOrEqual(), (int)R.get1BasedMatePosition(), (int)R.getInsertSize(), R.getSequence(), R.getQuality());
-          char tag[3]; char vtype; void *value;
-          R.resetTagIter();
-          while (R.getNextSamTag(tag, vtype, &value)) {
-            if (vtype == 'Z') fprintf(fb, "\t%s:Z:%s", tag, ((String *)value)->c_str());
-            else if (vtype == 'A') fprintf(fb, "\t%s:A:%c", tag, *(char *)value);
-            else if (vtype == 'f') fprintf(fb, "\t%s:f:%g", tag, *(float *)value);
-            else fprintf(fb, "\t%s:i:%d", tag, *(int *)value);
-          }
-          fputc('\n', fb);
+          dump_sam_record(fb, R);
         }
         continue;
       }
@@ -493,19 +487,6 @@ static void fill_bwa_seq(Slot &S, const fq_read_batch_t *in, const fq_result_bat
     S.multi[k].n_cigar = m->n_cigar; S.multi[k].cigar = m->n_cigar ? (bwa_cigar_t *)(res->cigar + m->cigar_off) : 0;
   }
   p->multi = S.multi.data();
-}
-static void dump_sam_record(FILE *fb, SamRecord &R) {
-  fprintf(fb, "%s\t%d\t%s\t%d\t%d\t%s\t%s\t%d\t%d\t%s\t%s", R.getReadName(), (int)R.getFlag(), R.getReferenceName(), (int)R.get1BasedPosition(),
-          (int)R.getMapQuality(), R.getCigar(), R.getMateReferenceNameOrEqual(), (int)R.get1BasedMatePosition(), (int)R.getInsertSize(), R.getSequence(), R.getQuality());
-  char tag[3]; char vtype; void *value;
-  R.resetTagIter();
-  while (R.getNextSamTag(tag, vtype, &value)) {
-    if (vtype == 'Z') fprintf(fb, "\t%s:Z:%s", tag, ((String *)value)->c_str());
-    else if (vtype == 'A') fprintf(fb, "\t%s:A:%c", tag, *(char *)value);
-    else if (vtype == 'f') fprintf(fb, "\t%s:f:%g", tag, *(float *)value);
-    else fprintf(fb, "\t%s:i:%d", tag, *(int *)value);
-  }
-  fputc('\n', fb);
 }
 }  // namespace vialib
 

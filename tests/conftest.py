@@ -19,3 +19,12 @@ def golden_cases(tmp_path_factory):
     import golden_util
     base = tmp_path_factory.mktemp("golden")
     return {tag: golden_util.materialise(tag, str(base / tag)) for tag in golden_util.case_tags()}
+
+
+@pytest.fixture(scope="session")
+def emu_cli():
+    """the command line over the host-loop library (CPU tier; test infrastructure only)"""
+    import subprocess
+    emu = os.path.join(ROOT, "tests", "emu")
+    subprocess.check_call(["make", "-s", "-C", emu, "libfq_emu.so", "FASTQuick_emu"])
+    return os.path.join(emu, "FASTQuick_emu")

@@ -17,7 +17,8 @@ static std::string g_err;
 struct State { Tune tune; };
 static thread_local State *g_bound = nullptr;   // (for the launcher's choice of search kernel: the tuning of the bound context)
 int runtime_configure(int, int) { return 0; }
-State *state_create(int) { return new State; }
+int device_count() { return 4; }            // four virtual devices (the CPU tier's multi-device tests use two)
+State *state_create(int dev) { if (dev < 0 || dev >= device_count()) { g_err = "device ordinal out of range"; return nullptr; } return new State; }
 void state_destroy(State *s) { if (g_bound == s) g_bound = nullptr; delete s; }
 int bind(State *s) { g_bound = s; return 0; }
 Tune *tune(State *s) { return &s->tune; }

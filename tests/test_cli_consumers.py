@@ -83,3 +83,14 @@ def test_cli_frac_samp(golden_cases, tmp_path):
     emu = os.path.join(HERE, "emu")
     subprocess.check_call(["make", "-s", "-C", emu, "libfq_emu.so", "FASTQuick_emu"])
     cli_frac_samp(os.path.join(emu, "FASTQuick_emu"), golden_cases["qc"], str(tmp_path / "frac"))
+
+
+def test_cli_76bp_pairs_with_the_default_read_len(golden_cases, emu_cli, tmp_path):
+    """ADVICE r4: the command line refuses --read_len < 96, and the reference has no such flag (gap_opt_t::read_len is 151 whatever the
+    reads' length): 2x76 reads -- BASELINE cfg 5's shape -- run with the default, rows sized from the first record; the reference's SAM text."""
+    g = golden_cases["trim76"]
+    cmd = [emu_cli, "align", "--index_prefix", g["prefix"][:-len(".FASTQuick.fa")], "--fastq_1", g["fq1"], "--fastq_2", g["fq2"], "--out_prefix", str(tmp_path / "pe76"),
+           "--sam_out", "--batch_pairs", str(g["batch"]), "--q", str(g["trim_qual"])]
+    run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert run.returncode == 0, run.stderr.decode(errors="replace")[-2000:]
+    assert run.stdout == open(g["sam"], "rb").read()

@@ -121,3 +121,21 @@ def test_fq_list_over_two_gpus(golden_cases, tmp_path):
     if _hip_devices() < 2:
         pytest.skip("one HIP device on this box")
     check_against_one_device(os.path.join(ROOT, "fastquick_amd", "bin", "FASTQuick_amd"), golden_cases["qc"], tmp_path, "0-1")
+
+
+@pytest.mark.parametrize("devices,msg", [("a,b", b"bad device ordinal"), ("0-x", b"bad device ordinal"), ("0,,1", b"empty entry"), ("0,1,", b"empty entry"), ("1.5", b"bad device ordinal"),
+                                         ("0,63", b"does not exist")])
+def test_devices_option_is_parsed_strictly_and_checked_before_any_worker_starts(devices, msg, golden_cases, emu_cli, tmp_path):
+    """`--devices a,b` / `0-x` went through atoi and became device 0; an ordinal beyond the visible devices failed inside a
+    worker thread and left part files behind."""
+    g = golden_cases["qc"]
+    halves = golden_util.split_halves(g, str(tmp_path))
+    lst = os.path.join(str(tmp_path), "two_pairs.list")
+    with open(lst, "w") as fh:
+        fh.write("".join("%s\t%s\n" % h for h in halves))
+    out = os.path.join(str(tmp_path), "out")
+    cmd = [emu_cli, "align", "--index_prefix", g["prefix"][:-len(".FASTQuick.fa")], "--fq_list", lst, "--out_prefix", out, "--sam_out", "--devices", devices]
+    run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert run.returncode != 0 and msg in run.stderr, run.stderr.decode(errors="replace")[-1000:]
+    left = [n for n in os.listdir(str(tmp_path)) if ".part" in n or ".worker" in n]
+    assert not left, "nothing may be left behind: %s" % left

@@ -305,6 +305,28 @@ def test_a_hook_that_raises_stops_the_call_and_marks_the_stream_broken(golden_ca
     ix.close()
 
 
+def test_a_malformed_stream_state_is_refused_whole_and_breaks_the_stream(golden_cases, emu_lib):
+    """a (k,l) entry that claims 2^62 positions made `4 * m` wrap, passed the bound check and threw through the C entry; and a
+    token refused half-way had already overwritten the drand48 state and the cache.  Now the token is parsed into temporaries: refused
+    tokens change nothing but the broken mark (the state the stream should have continued from never arrived)."""
+    import struct
+    g = golden_cases["basic"]
+    ix = api.Index(g["prefix"], lib=emu_lib)
+    al = api.Aligner(ix, api.default_opts(emu_lib), max_pairs=16)
+    good = al.export_state()
+    head = _stream_state(12345)[:-8]
+    for bad in (head + struct.pack("<Q", 1) + struct.pack("<QQ", 7, 1 << 62),              # 4 * m wraps to 0
+                head + struct.pack("<Q", 1) + struct.pack("<QQ", 7, 3) + b"\x00" * 8,       # three positions promised, two present
+                head + struct.pack("<Q", 1 << 60),                                          # more entries than bytes
+                head + struct.pack("<Q", 2) + struct.pack("<QQI", 7, 1, 9)):                # second entry missing
+        with pytest.raises(api.FastquickError):
+            al.import_state(bad)
+        rest = al.export_state()
+        assert rest[:6] == b"_FQSTX" and rest[8:] == good[8:], "a refused token must leave the state untouched, marked broken"
+    al.close()
+    ix.close()
+
+
 def _stream_state(rng: int) -> bytes:
     """fq_ctx_state_export's layout for a fresh stream whose drand48 state is `rng`: mark, rng, last_ii (avg = std = -1, rest 0), no (k,l) entries."""
     import struct
