@@ -44,11 +44,13 @@ class SynthRef:
 
 def make_reference(n_markers: int = 40, n_long: int = 4, flank_short: int = 250, flank_long: int = 1000,
                    spacing: int = 3000, seed: int = 12345, repeat_every: int = 0, repeat_div: float = 0.005,
-                   n_frac: float = 0.0, tandem_every: int = 0, patch=None, sex_every: int = 0) -> SynthRef:
+                   n_frac: float = 0.0, tandem_every: int = 0, patch=None, sex_every: int = 0, identical_from: int = 0) -> SynthRef:
     """Build a synthetic genome + reduced reference.
 
     repeat_every>0 makes every `repeat_every`-th window a diverged copy of its predecessor
     (repeat-rich variant, exercises c1>1 / drand48 / XA paths); n_frac sprinkles N into flanks.
+    identical_from>0 makes the windows of the markers behind that one exact copies of its window: a read from any of them hits an SA
+    interval as wide as their number (the (k,l) position cache of src/BwtMapper.cpp:815-843 takes intervals of >= 1000 rows).
     """
     rng = np.random.default_rng(seed)
     glen = 2000 + spacing * n_markers + 2000
@@ -70,6 +72,10 @@ def make_reference(n_markers: int = 40, n_long: int = 4, flank_short: int = 250,
                 genome[p + 40 * r:p + 40 * (r + 1)] = unit
     pos = 2000 + spacing * np.arange(n_markers, dtype=np.int64)   # 1-based
     flank = np.where(np.arange(n_markers) < n_long, flank_long, flank_short).astype(np.int64)
+    if identical_from:
+        p0, f0 = int(pos[identical_from]), int(flank[identical_from])
+        for k in range(identical_from + 1, n_markers):
+            genome[int(pos[k]) - 1 - f0:int(pos[k]) + f0] = genome[p0 - 1 - f0:p0 + f0]
     if patch is not None:      # caller-supplied edit of the genome (codes 0..3) before the flanks are cut, e.g. to plant given reads
         patch(genome, pos, flank, rng)
     names, seqs = [], []

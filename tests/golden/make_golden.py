@@ -48,6 +48,14 @@ CASES = {
     "qc": (dict(n_markers=40, n_long=4, seed=109, sex_every=7),
            dict(on_target=0.95, seed=209, sub_rate=0.01, del_frac=0.03, ins_frac=0.03, n_rate=0.002, chimera_frac=0.05, qual_decay=True,
                 dup_frac=0.08, edge_frac=0.1), 3000, 1024, 15),
+    # SA intervals of >= 1000 rows (MIN_HASH_WIDTH, libbwa/bwape.h:105): 1,292 markers with one and the same window, so that a read from any of
+    # them has 1,292 equally good places -- the (k,l) -> positions cache of src/BwtMapper.cpp:815-843, keyed by interval, holding the positions
+    # computed with the length of the FIRST read that asked; --q 15 on decaying qualities gives the reads ragged trimmed lengths,
+    # so later requesters of an interval differ in length from the first.  A few unique windows in front keep insert-size inference alive.
+    # The reads are drawn with the eight unique windows weighted 50-fold (`front_weight`: about a quarter of the on-target pairs), so that
+    # insert-size inference succeeds and the pairing sweep scores the 1,292 x 1,292 candidate places of a repeat pair with a real estimate.
+    "wide": (dict(n_markers=1300, n_long=2, seed=110, identical_from=8),
+             dict(on_target=0.9, seed=210, sub_rate=0.01, del_frac=0.03, ins_frac=0.03, qual_decay=True, front_weight=(8, 50)), 600, 256, 15),
     "long250": (dict(n_markers=12, n_long=3, seed=106),
                 dict(read_len=250, on_target=0.9, seed=206, sub_rate=0.01, del_frac=0.06, ins_frac=0.05, indel_len_max=3,
                      chimera_frac=0.08, frag_mean=430, frag_sd=30), 160, 160, 0),
@@ -301,7 +309,13 @@ def main() -> None:
             ref.write_fasta(pre)
             subprocess.check_call([ob.REF_DRIVER, "index", pre], stderr=subprocess.DEVNULL, cwd=tmp)
             synth.write_qc_inputs(pre, ref)
-            rb = synth.make_reads(ref, n, **readkw)
+            rkw = dict(readkw)
+            read_ref = ref
+            if "front_weight" in rkw:      # the first n_front markers drawn `times` as often as the others
+                n_front, times = rkw.pop("front_weight")
+                sel = np.concatenate([np.tile(np.arange(n_front), times), np.arange(n_front, len(ref.marker_pos))])
+                read_ref = synth.SynthRef(ref.names, ref.seqs, ref.genome, ref.marker_pos[sel], ref.flank[sel])
+            rb = synth.make_reads(read_ref, n, **rkw)
             f1, f2 = rb.write_fastq(os.path.join(tmp, "reads"))
             args = ["--batch", batch] + (["--q", q] if q else []) + (["--read_len", readkw["read_len"] + 1] if readkw.get("read_len", 150) > 150 else [])
             ob.run_reference(pre, f1, f2, os.path.join(tmp, "ref_out"), "--genome_size", len(ref.genome), *args)

@@ -66,6 +66,8 @@ def test_gpu_matches_reference_golden(tag, golden_cases, lib, search_mode):
     assert stats["kernel_launches"][2] > 0, "the gap-search kernel did not run on the device"
     if tag in ("basic", "repeat", "qc"):
         assert stats["pairs_on_device"] > 0, "k_pair did not run"
+    if tag == "wide":      # SA intervals of >= 1000 rows: paired on the host through the (k,l) cache (libbwa/bwape.h:105, src/BwtMapper.cpp:815-843)
+        assert stats["host_pairs"] > 300, "the pairs of the 1,292-fold repeat must have gone through the position cache"
     if search_mode.startswith("wave") or (search_mode == "handover" and tag != "cfg0_example"):   # (cfg0_example searches one pair: its reads stop before the 64-pop check)
         assert stats["tier_retries"] > 0, "the wavefront-per-read kernel was not exercised"
 

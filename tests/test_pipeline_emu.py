@@ -23,8 +23,8 @@ def emu_lib():
 @pytest.mark.parametrize("mode", ["lanes", "wave", "threads", "packed", "packed_bulk", "nogap", "generic_opts", "pipeline"])
 @pytest.mark.parametrize("tag", golden_util.case_tags())
 def test_emulated_pipeline_matches_reference_golden(tag, mode, golden_cases, emu_lib):
-    if mode not in ("lanes", "wave") and tag not in ("basic", "repeat", "edge", "qc", "trim76", "isize"):
-        pytest.skip("this mode runs on six of the cases here (CPU tier budget); the GPU tier runs every mode on every case")
+    if mode not in ("lanes", "wave") and tag not in ("basic", "repeat", "edge", "qc", "trim76", "isize", "wide"):
+        pytest.skip("this mode runs on seven of the cases here (CPU tier budget); the GPU tier runs every mode on every case")
     tuning = {}
     if mode == "wave":   # every search handed to the wavefront-per-read path (a one-lane wavefront here: its sequential rounds)
         tuning = {"gap_long_pops": 1, "gap_long_always": 1}
@@ -54,6 +54,8 @@ def test_emulated_pipeline_matches_reference_golden(tag, mode, golden_cases, emu
     assert filecmp.cmp(g["sam"], sam, shallow=False)
     if tag in ("basic", "repeat", "qc"):
         assert stats["pairs_on_device"] > 0, "the pairing kernel body (fq_pair_thread) was not exercised"
+    if tag == "wide":      # SA intervals of >= 1000 rows: paired on the host through the (k,l) cache (libbwa/bwape.h:105, src/BwtMapper.cpp:815-843)
+        assert stats["host_pairs"] > 300, "the pairs of the 1,292-fold repeat must have gone through the position cache"
 
 
 @pytest.mark.parametrize("mode,tuning", [("lanes", {}), ("nogap", {"gap_nogap_min": 0}), ("wave", {"gap_long_pops": 1, "gap_long_always": 1}), ("handover", {"gap_long_pops": 8})])
