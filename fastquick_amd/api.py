@@ -96,7 +96,7 @@ EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destr
            "fq_pinned_alloc", "fq_pinned_free", "fq_pack_reads", "fq_packed_free", "fq_packed_create", "fq_pack_reads_into", "fq_pack_single_reads_into", "fq_packed_prefetch", "fq_packed_cancel", "fq_align_packed",
            "fq_ctx_set_tuning", "fq_ctx_set_serial_hooks", "fq_ctx_mark_stream_broken", "fq_ctx_state_export", "fq_ctx_state_import", "fq_qc_default_opts", "fq_qc_create", "fq_qc_destroy", "fq_qc_last_error", "fq_qc_begin_file",
            "fq_qc_add_last", "fq_qc_end_file", "fq_qc_write", "fq_qc_state_reset", "fq_qc_state_export", "fq_qc_merge", "fq_bam_create", "fq_bam_add_last", "fq_bam_format_last", "fq_bam_write_records", "fq_bam_close",
-           "fq_fastq_open", "fq_fastq_configure", "fq_fastq_set_sampling", "fq_fastq_read", "fq_fastq_last_error", "fq_fastq_dropped_record", "fq_fastq_unequal_lengths", "fq_fastq_is_bgzf", "fq_fastq_close", "fq_inflate_raw", "fq_crc32"]
+           "fq_fastq_open", "fq_fastq_configure", "fq_fastq_set_sampling", "fq_fastq_read", "fq_fastq_last_error", "fq_fastq_dropped_record", "fq_fastq_unequal_lengths", "fq_fastq_is_bgzf", "fq_fastq_close", "fq_inflate_raw", "fq_crc32", "fq_inflate_device", "fq_bgzf_inflate_device"]
 
 SERIAL_HOOK = C.CFUNCTYPE(None, C.c_void_p)
 _libs = {}
@@ -164,6 +164,9 @@ def load_library(path: str | None = None):
     L.fq_inflate_raw.restype = C.c_int
     L.fq_crc32.argtypes = [C.c_void_p, C.c_size_t]
     L.fq_crc32.restype = C.c_uint32
+    L.fq_inflate_device.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
+                                    C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_double)]
+    L.fq_bgzf_inflate_device.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)]
     L.fq_fastq_close.argtypes = [C.c_void_p]
     L.fq_ctx_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
     L.fq_ctx_set_serial_hooks.argtypes = [C.c_void_p, SERIAL_HOOK, SERIAL_HOOK, C.c_void_p]
@@ -586,3 +589,37 @@ def align_stream(aligner: Aligner, names, seq, qual, lens, batch: int, stages_pa
     if sm:
         sm.close()
     return total
+
+
+def inflate_device(streams, device: int = 0, lib=None, repeats: int = 1):
+    """The device front end's member decoder on raw DEFLATE streams: streams = [(comp, out_len, crc32)], one wavefront each.
+    Returns ([(status, bytes)], kernel_ms)."""
+    L = lib or load_library()
+    n = len(streams)
+    keep = [C.create_string_buffer(bytes(c), max(1, len(c))) for c, _, _ in streams]
+    outs = [C.create_string_buffer(max(1, ol)) for _, ol, _ in streams]
+    src = (C.c_void_p * max(1, n))(*[C.cast(k, C.c_void_p) for k in keep])
+    dst = (C.c_void_p * max(1, n))(*[C.cast(o, C.c_void_p) for o in outs])
+    lens = (C.c_size_t * max(1, n))(*[len(c) for c, _, _ in streams])
+    olen = (C.c_uint32 * max(1, n))(*[ol for _, ol, _ in streams])
+    crc = (C.c_uint32 * max(1, n))(*[cr & 0xffffffff for _, _, cr in streams])
+    st = (C.c_uint32 * max(1, n))()
+    ms = C.c_double(0)
+    rc = L.fq_inflate_device(device, n, src, lens, dst, olen, crc, st, repeats, C.byref(ms))
+    if rc:
+        raise FastquickError("fq_inflate_device failed: %d" % rc)
+    return [(int(st[k]), outs[k].raw[:streams[k][1]]) for k in range(n)], ms.value
+
+
+def bgzf_inflate_device(blob: bytes, text_cap: int, device: int = 0, lib=None, repeats: int = 1):
+    """A run of whole BGZF members inflated by the device: (text, statuses, kernel_ms)."""
+    L = lib or load_library()
+    out = np.empty(max(1, text_cap), dtype=np.uint8)
+    nm, tl, ms = C.c_int64(0), C.c_int64(0), C.c_double(0)
+    cap = len(blob) // 28 + 8
+    st = (C.c_uint32 * cap)()
+    buf = np.frombuffer(blob, dtype=np.uint8)
+    rc = L.fq_bgzf_inflate_device(device, buf.ctypes.data, len(blob), out.ctypes.data, out.size, C.byref(nm), C.byref(tl), st, cap, repeats, C.byref(ms))
+    if rc:
+        raise FastquickError("fq_bgzf_inflate_device failed: %d" % rc)
+    return out[:tl.value], [int(st[k]) for k in range(nm.value)], ms.value

@@ -4,6 +4,7 @@
 #pragma once
 #include "fq_kernels.h"
 #include "fq_records.h"
+#include "fq_frontend.h"
 
 namespace fqdev {
 
@@ -102,5 +103,10 @@ int launch_aln_index(const int32_t *work, const uint32_t *status, const uint64_t
 int launch_sw(const FqSwArgs &a);          // one task per wavefront (window + query in LDS)
 int launch_sw_serial(const FqSwArgs &a);   // one task per lane out of the task's global scratch: any window size
 int launch_refine(const FqRefineArgs &a);
+
+// ---- FASTQ front end (fq_frontend.h) ----
+// the CRC tables and powers the member decoder reads, resident on the bound state's device (made once per device)
+const FqzCrcConst *crc_const();
+int launch_inflate(const FqInflateArgs &a);     // one wavefront per BGZF member
 
 }  // namespace fqdev

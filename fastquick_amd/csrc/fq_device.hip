@@ -948,6 +948,36 @@ int launch_bitmap_scatter(uint8_t *bitmap, const uint32_t *bits, uint64_t n) {
   return 0;
 }
 
+// ---- FASTQ front end (fq_frontend.h) ----------------------------------------------------------------------------------
+static FqzCrcConst *g_crc_const[64];
+const FqzCrcConst *crc_const() {
+  std::lock_guard<std::mutex> lk(g_dev_mu);
+  const int dev = g_cur->device;
+  if (!g_crc_const[dev]) {
+    FqzCrcConst *h = new FqzCrcConst;
+    fqz_crc_const_make(h);
+    void *d = nullptr;
+    if (hipMalloc(&d, sizeof(FqzCrcConst)) != hipSuccess || hipMemcpy(d, h, sizeof(FqzCrcConst), hipMemcpyHostToDevice) != hipSuccess) { g_err = "crc_const: hipMalloc / hipMemcpy failed"; delete h; return nullptr; }
+    delete h;
+    g_crc_const[dev] = (FqzCrcConst *)d;
+  }
+  return g_crc_const[dev];
+}
+// One wavefront per BGZF member: tables and the output ring in LDS (10.6 KB per wavefront: fifteen wavefronts per CU).
+__global__ void __launch_bounds__(64) k_inflate_bgzf(FqInflateArgs a) {
+  __shared__ FqzLds lds;
+  const int m = blockIdx.x;
+  const uint32_t st = fqz_inflate_member(a, m, lds);
+  if (threadIdx.x == 0) a.status[m] = st;
+}
+int launch_inflate(const FqInflateArgs &a) {
+  FQ_PRE();
+  if (a.n_mem <= 0) return 0;
+  hipLaunchKernelGGL(k_inflate_bgzf, dim3((unsigned)a.n_mem), dim3(64), 0, g_stream, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---- launch wrappers ------------------------------------------------------------------------------
 // The filter kernel fills the device and is bound by its random probes: two of them at once only slow each other down.  The
 // launches of all streams (threads) of a device are therefore chained on the device: each waits for the previous one's

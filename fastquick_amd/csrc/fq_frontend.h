@@ -1,0 +1,653 @@
+// fq_frontend.h -- bodies of the FASTQ front end's device kernels: BGZF members inflated in HBM, the inflated text cut
+// into lines and records, the read filter's keys formed from the text, the reference's read-slot history, the surviving reads' rows.
+//
+// What they replace: the reader side of bwa_read_seq_with_hash_dev (src/BwtMapper.cpp:476-613) -- gzread (libbwa/bwaseqio.c:41-52) under
+// kseq_read3_fpc (libbwa/kseq.h:327-371), one record at a time on one IO thread per file (IOworkerAlt, src/BwtMapper.cpp:1973-1980) -- for
+// the files sequencers write: BGZF containers of four-line records.  Anything else is refused here, record by record and member by member,
+// and goes the host's byte-wise way (fq_fastq.cpp, fq_inflate.h, zlib), whose verdicts stand.
+//
+// The bodies are written for a wavefront of FQ_WAVE_SIZE lanes: 64 on the device; the host-loop build (tests/emu, test infrastructure) runs
+// the same code with a wavefront of one.
+#pragma once
+#include "fq_kernels.h"
+
+// Per-lane code is written between FQF_LANES / FQF_LANES_END: on the device the block runs once, for the lane the thread is; in the host-loop
+// build (tests/emu, test infrastructure) it is a loop over the 64 lanes of the emulated wavefront, and a per-lane register (FQF_LVAR) is an
+// array of 64.  Code between such blocks is the wavefront's uniform part.  Blocks are written so that no lane reads what another lane of the
+// same block writes (then the order of the lanes does not matter).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FQF_LANES { const int lane = (int)(threadIdx.x & 63);
+#define FQF_LANES_END }
+#define FQF_LVAR(T, name) T name
+#define FQF_LV(name) name
+#define FQF_RL(name, idx) ((uint32_t)__builtin_amdgcn_readlane((int)(name), (int)(idx)))
+#define FQF_NOINLINE __attribute__((noinline))
+#else
+#define FQF_LANES for (int lane = 0; lane < 64; ++lane) {
+#define FQF_LANES_END }
+#define FQF_LVAR(T, name) T name[64]
+#define FQF_LV(name) name[lane]
+#define FQF_RL(name, idx) (name[idx])
+#define FQF_NOINLINE
+#endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define FQF_UNIFORM32(x) ((uint32_t)__builtin_amdgcn_readfirstlane((int)(x)))
+#define FQF_BREV32(x) __brev((unsigned)(x))
+// Lanes of one wavefront hand bytes to each other through LDS and through the text in HBM.  The hardware keeps one wavefront's LDS operations,
+// and its vector-memory operations, in issue order; what has to be pinned is the compiler: no memory operation moves across this point
+// (the asm's memory clobber), and the point is not moved into or out of divergent code (wave_barrier is convergent).  No instruction is emitted.
+#define FQF_WAVE_FENCE() do { __asm__ volatile("" ::: "memory"); __builtin_amdgcn_wave_barrier(); } while (0)
+#define FQF_WAVE_XOR32(x) fqf_wave_xor32(x)
+__device__ __forceinline__ uint32_t fqf_wave_xor32(uint32_t x) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) x ^= (uint32_t)__shfl_xor((int)x, d, 64);
+  return x;
+}
+#define FQF_ATOMIC_MIN32(p, v) atomicMin((unsigned *)(p), (unsigned)(v))
+#define FQF_ATOMIC_MAX32(p, v) atomicMax((unsigned *)(p), (unsigned)(v))
+#define FQF_ATOMIC_OR32(p, v) atomicOr((unsigned *)(p), (unsigned)(v))
+#else
+#define FQF_UNIFORM32(x) ((uint32_t)(x))
+inline uint32_t fqf_brev32(uint32_t v) {
+  v = (v >> 16) | (v << 16);
+  v = ((v & 0xff00ff00u) >> 8) | ((v & 0x00ff00ffu) << 8);
+  v = ((v & 0xf0f0f0f0u) >> 4) | ((v & 0x0f0f0f0fu) << 4);
+  v = ((v & 0xccccccccu) >> 2) | ((v & 0x33333333u) << 2);
+  v = ((v & 0xaaaaaaaau) >> 1) | ((v & 0x55555555u) << 1);
+  return v;
+}
+#define FQF_BREV32(x) fqf_brev32((uint32_t)(x))
+#define FQF_WAVE_FENCE() do { } while (0)
+#define FQF_WAVE_XOR32(x) (x)
+#define FQF_ATOMIC_MIN32(p, v) (*(p) = *(p) < (uint32_t)(v) ? *(p) : (uint32_t)(v))
+#define FQF_ATOMIC_MAX32(p, v) (*(p) = *(p) > (uint32_t)(v) ? *(p) : (uint32_t)(v))
+#define FQF_ATOMIC_OR32(p, v) (*(p) |= (uint32_t)(v))
+#endif
+
+// =====================================================================================================================================
+// CRC-32 (IEEE 802.3, the gzip trailer's) of a member's output by a whole wavefront: every lane takes a contiguous piece, the pieces' values
+// are put together with crc(A || B) = crc(A) * x^(8 |B|) + crc(B) in GF(2)[x] / P (the identity zlib's crc32_combine rests on; bit 31 of a
+// word is the coefficient of x^0 in the reflected representation the gzip CRC uses).
+// =====================================================================================================================================
+#define FQZ_POLY 0xEDB88320u
+FQ_HD uint32_t fqz_mulmod(uint32_t a, uint32_t b) {      // a * b mod P
+  uint32_t p = 0;
+  for (int i = 0; i < 32; ++i) {
+    p ^= (0u - ((a >> (31 - i)) & 1u)) & b;
+    b = (b >> 1) ^ ((0u - (b & 1u)) & FQZ_POLY);          // b * x
+  }
+  return p;
+}
+// tables of the host and of the device: slice-by-4 CRC tables t[4][256], and pow8[k] = x^(8 * 2^k) mod P
+struct FqzCrcConst { uint32_t t[4][256]; uint32_t pow8[32]; };
+inline void fqz_crc_const_make(FqzCrcConst *c) {
+  for (uint32_t i = 0; i < 256; ++i) {
+    uint32_t v = i;
+    for (int k = 0; k < 8; ++k) v = (v >> 1) ^ ((0u - (v & 1u)) & FQZ_POLY);
+    c->t[0][i] = v;
+  }
+  for (uint32_t i = 0; i < 256; ++i)
+    for (int s = 1; s < 4; ++s) c->t[s][i] = (c->t[s - 1][i] >> 8) ^ c->t[0][c->t[s - 1][i] & 0xff];
+  uint32_t p = 0x80000000u >> 8;                          // x^8
+  for (int k = 0; k < 32; ++k) { c->pow8[k] = p; p = fqz_mulmod(p, p); }
+}
+FQ_HD uint32_t fqz_xpow8(const uint32_t *pow8, uint32_t n) {   // x^(8 n) mod P
+  uint32_t p = 0x80000000u;
+  for (int k = 0; n; ++k, n >>= 1) if (n & 1u) p = fqz_mulmod(pow8[k], p);
+  return p;
+}
+
+// =====================================================================================================================================
+// One BGZF member (a raw DEFLATE stream, RFC 1951, of at most 64 KiB of text) per wavefront.
+//   * The compressed bytes are read 256 at a time into three registers per lane (the block being read and the two behind it); the bit buffer
+//     is refilled a dword at a time from them (readlane), so the symbol loop makes no memory access for its input.
+//   * Decode tables in LDS: a 10-bit root table for literal / length codes and an 8-bit one for distances, one look-up per symbol; a code
+//     longer than the root is found by its canonical position (first code and count per length, symbols sorted by code).  Tables are built
+//     by all lanes (a lane per table slot).
+//   * The symbol loop is uniform over the wavefront (every lane holds the same bit buffer): its arithmetic is scalar work for the compiler.
+//     The kernel is bound by the number of instructions a symbol costs (measured: the SIMDs' issue slots are 90 % taken), so the loop has
+//     a FAST form -- no change of the input registers, the table entries laid out for one bit-field extract per value, one pass of the
+//     lanes per match -- and a GENERAL step (fqz_general_symbol) for what the fast form leaves: the end of an input block, codes longer than
+//     the root, matches longer than 64 bytes, the member's first line of text.
+//   * Output goes to an LDS ring indexed by the absolute output position; matches are copied by all lanes, from the ring while the distance
+//     is inside it, from the text already in HBM otherwise; every completed 256-byte line of the ring goes out as one coalesced store.
+//   * The CRC-32 of the output is computed by the wavefront afterwards and compared with the member's trailer.
+// status: 0 = inflated and checked; 1 = not a stream this decoder takes (the host's decoder, then zlib, decide); 2 = CRC mismatch.
+// =====================================================================================================================================
+#define FQZ_RING 4096
+#define FQZ_LROOT 10
+#define FQZ_DROOT 8
+enum { FQZ_OK = 0, FQZ_REFUSED = 1, FQZ_BADCRC = 2 };
+struct FqzMember { uint64_t in_off; uint32_t out_off, in_len, out_len, crc; uint32_t pad[2]; };   // payload [in_off, in_off + in_len) of `comp`; text at out + out_off (a launch writes at most 4 GiB)
+struct FqInflateArgs {
+  const uint8_t *comp;          // compressed bytes, 4-byte aligned, at least 1 KiB of readable slack behind the last member
+  const FqzMember *mem;
+  int32_t n_mem;
+  uint8_t *out;                 // 256-byte aligned
+  uint32_t *status;             // [n_mem]
+  const FqzCrcConst *crc;
+};
+struct FqzLds {
+  uint32_t lt[1 << FQZ_LROOT];  // literal / length root table; the CRC's slice tables afterwards
+  uint32_t dt[1 << FQZ_DROOT];
+  uint32_t clt[128];            // the code-length code's table
+  uint16_t lsort[288], dsort[32], csort[20];
+  uint16_t lfirst[16], lcount[16], loffs[16];
+  uint16_t dfirst[16], dcount[16], doffs[16];
+  uint16_t cfirst[16], ccount[16], coffs[16];
+  uint8_t lens[320], cl[32];
+  uint32_t ring32[FQZ_RING / 4];
+};
+// Table entries, laid out so that S_BFE_U32(bit buffer, entry) IS the symbol's extra bits (the instruction reads its offset from bits 0-4
+// and its width from bits 16-22 of its second operand and ignores the rest):
+//   bits 0-4   code length            bits 16-19 extra bits (20-22 zero)
+//   bits 5-9   bits the whole symbol takes (code + extra; 0: not in the root table)
+//   bit 10 literal, bit 11 length / distance, bit 12 end of block
+//   bits 23-31 literal / length base (<= 258);  distances: bits 13-14 k with base = (k << extra) + 1
+enum { FQZ_K_LIT = 1u << 10, FQZ_K_BASE = 1u << 11, FQZ_K_EOB = 1u << 12 };
+FQ_HD uint32_t fqz_take_of(uint32_t e) { return (e >> 5) & 31; }
+FQ_HD uint32_t fqz_extra_of(uint64_t bb, uint32_t e) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  uint32_t r;
+  __asm__("s_bfe_u32 %0, %1, %2" : "=s"(r) : "s"((uint32_t)bb), "s"(e) : "scc");
+  return r;
+#else
+  return ((uint32_t)bb >> (e & 31)) & ((1u << ((e >> 16) & 15)) - 1);
+#endif
+}
+FQ_HD uint32_t fqz_lit_entry(uint32_t s, uint32_t l) {
+  if (s < 256) return FQZ_K_LIT | s << 23 | l << 5 | l;
+  if (s == 256) return FQZ_K_EOB | l << 5 | l;
+  if (s > 285) return 0;                                     // 286, 287: in the fixed code, never valid in data
+  const uint32_t k = s - 257;
+  uint32_t base, xb = 0;
+  if (k < 8) base = 3 + k;
+  else if (k == 28) base = 258;
+  else { xb = (k >> 2) - 1; base = 3 + ((4 + (k & 3)) << xb); }
+  return FQZ_K_BASE | base << 23 | xb << 16 | (l + xb) << 5 | l;
+}
+FQ_HD uint32_t fqz_dist_entry(uint32_t s, uint32_t l) {
+  if (s > 29) return 0;
+  const uint32_t xb = s < 4 ? 0 : (s >> 1) - 1, k = s < 4 ? s : 2 + (s & 1);
+  return FQZ_K_BASE | k << 13 | xb << 16 | (l + xb) << 5 | l;
+}
+FQ_HD uint32_t fqz_dist_of(uint64_t bb, uint32_t f) { return (((f >> 13) & 3) << ((f >> 16) & 15)) + 1 + fqz_extra_of(bb, f); }
+FQ_HD uint32_t fqz_cl_entry(uint32_t s, uint32_t l) { return FQZ_K_LIT | s << 23 | l << 5 | l; }
+
+// Canonical Huffman code of n symbols with lengths len[] (0: unused): count / first code / offset per length, the symbols sorted by
+// (length, symbol).  Returns 0: complete; 1: incomplete (code words unused); -1: over-subscribed.  *n_used: symbols in use.
+FQ_HD int fqz_canon(const uint8_t *len, int n, uint16_t *sorted, uint16_t *first, uint16_t *count, uint16_t *offs, int *n_used) {
+  FQF_LANES
+    if (lane < 16) {                                         // (a lane per length)
+      int c = 0;
+      for (int s = 0; s < n; ++s) c += len[s] == lane;
+      count[lane] = (uint16_t)c;
+    }
+  FQF_LANES_END
+  FQF_WAVE_FENCE();
+  int left = 1, used = 0;
+  uint32_t code = 0, off = 0;
+  int over = 0;
+  for (int l = 1; l <= 15; ++l) {
+    const int c = (int)FQF_UNIFORM32(count[l]);
+    if (!over) { left = left * 2 - c; if (left < 0) over = 1; }
+    first[l] = (uint16_t)code; offs[l] = (uint16_t)off;      // (every lane the same values)
+    code = (code + (uint32_t)c) << 1;
+    off += (uint32_t)c;
+    used += c;
+  }
+  FQF_WAVE_FENCE();
+  *n_used = used;
+  if (over) return -1;
+  FQF_LANES
+    if (lane >= 1 && lane < 16) {
+      uint32_t at = offs[lane];
+      for (int s = 0; s < n; ++s) if (len[s] == lane) sorted[at++] = (uint16_t)s;
+    }
+  FQF_LANES_END
+  FQF_WAVE_FENCE();
+  return left > 0 ? 1 : 0;
+}
+// root table of 2^root slots: every lane looks its slots' bit patterns up in the canonical code
+template <class Entry>
+FQ_HD void fqz_fill_root(uint32_t *table, int root, const uint16_t *sorted, const uint16_t *first, const uint16_t *count, const uint16_t *offs, Entry entry) {
+  FQF_LANES
+    for (uint32_t i = (uint32_t)lane; i < (1u << root); i += 64) {
+      const uint32_t r = FQF_BREV32(i);
+      uint32_t e = 0;
+      for (int l = 1; l <= root; ++l) {
+        const uint32_t idx = (r >> (32 - l)) - first[l];
+        if (idx < count[l]) { e = entry(sorted[offs[l] + idx], (uint32_t)l); break; }
+      }
+      table[i] = e;
+    }
+  FQF_LANES_END
+  FQF_WAVE_FENCE();
+}
+// a code longer than the root: by its canonical position (0: no such code)
+template <class Entry>
+FQ_HD uint32_t fqz_long_code(uint64_t bb, int root, const uint16_t *sorted, const uint16_t *first, const uint16_t *count, const uint16_t *offs, Entry entry) {
+  const uint32_t r = FQF_BREV32((uint32_t)bb);
+  for (int l = root + 1; l <= 15; ++l) {
+    const uint32_t idx = (r >> (32 - l)) - first[l];
+    if (idx < count[l]) return entry(sorted[offs[l] + idx], (uint32_t)l);
+  }
+  return 0;
+}
+
+// the decoder's state: uniform over the wavefront but for the three input registers
+struct FqzSt {
+  // ---- input ----
+  const uint32_t *base;      // the payload's first dword (aligned down)
+  FQF_LVAR(uint32_t, wcur);  // dwords [blk * 64 + lane] of the block being read ...
+  FQF_LVAR(uint32_t, wnext); // ... of the one behind it ...
+  FQF_LVAR(uint32_t, wfar);  // ... and of the one behind that (asked for when `blk` began)
+  uint32_t blk, di;          // the block; the next dword of it to take (0 .. 64)
+  uint32_t blk_top;          // blocks behind this one are not read (the slack the payload is promised ends there)
+  uint64_t bb;               // bit buffer, next bit at bit 0
+  int bc;
+  uint64_t bits_end;         // bit position (from base) behind the payload
+  bool overrun;              // the stream asked for bytes behind the payload's slack
+  // ---- output: absolute positions in the text buffer ----
+  uint8_t *out;
+  uint32_t g0, g, g_end;     // the member's first byte, the next byte, the byte behind its last
+  uint32_t flushed;          // whole lines below this are in HBM (a multiple of 256)
+  uint8_t *ring;
+};
+FQ_HD void fqz_load_blocks(FqzSt &D, uint32_t blk) {         // the three input registers for reading at block blk
+  D.blk = blk;
+  FQF_LANES
+    const uint32_t b1 = blk + 1 < D.blk_top ? blk + 1 : D.blk_top, b2 = blk + 2 < D.blk_top ? blk + 2 : D.blk_top, b0 = blk < D.blk_top ? blk : D.blk_top;
+    FQF_LV(D.wcur) = D.base[(size_t)b0 * 64 + (uint32_t)lane];
+    FQF_LV(D.wnext) = D.base[(size_t)b1 * 64 + (uint32_t)lane];
+    FQF_LV(D.wfar) = D.base[(size_t)b2 * 64 + (uint32_t)lane];
+  FQF_LANES_END
+}
+FQ_HD void fqz_rotate(FqzSt &D) {                            // block D.blk is used up
+  ++D.blk; D.di = 0;
+  if (D.blk > D.blk_top) D.overrun = true;
+  FQF_LANES
+    const uint32_t b2 = D.blk + 2 < D.blk_top ? D.blk + 2 : D.blk_top;
+    FQF_LV(D.wcur) = FQF_LV(D.wnext); FQF_LV(D.wnext) = FQF_LV(D.wfar);
+    FQF_LV(D.wfar) = D.base[(size_t)b2 * 64 + (uint32_t)lane];
+  FQF_LANES_END
+}
+FQ_HD void fqz_refill(FqzSt &D) {                            // called with bc <= 32: 32 more bits (general form: may end a block)
+  if (D.di == 64) fqz_rotate(D);
+  const uint32_t v = FQF_UNIFORM32(FQF_RL(D.wcur, D.di));
+  D.bb |= (uint64_t)v << D.bc;
+  D.bc += 32;
+  ++D.di;
+}
+FQ_HD void fqz_need32(FqzSt &D) { if (D.bc <= 32) fqz_refill(D); }
+FQ_HD void fqz_take(FqzSt &D, int n) { D.bb >>= n; D.bc -= n; }
+FQ_HD uint64_t fqz_bit_pos(const FqzSt &D) { return ((uint64_t)D.blk * 64 + D.di) * 32 - (uint64_t)D.bc; }
+FQ_HD void fqz_seek(FqzSt &D, uint64_t byte_pos) {           // byte_pos from base
+  const uint32_t dw = (uint32_t)(byte_pos >> 2);
+  fqz_load_blocks(D, dw / 64);
+  D.di = dw % 64;
+  D.bb = 0; D.bc = 0;
+  fqz_refill(D);
+  fqz_take(D, (int)(byte_pos & 3) * 8);
+}
+// the whole 256-byte lines below D.g go to HBM (general form: the member's first line may begin inside a line)
+FQ_HD void fqz_flush_lines(FqzSt &D) {
+  while ((D.flushed >> 8) < (D.g >> 8)) {
+    const uint32_t seg = D.flushed;
+    if (seg >= D.g0) {
+      FQF_LANES
+        *(uint32_t *)(D.out + seg + 4 * (uint32_t)lane) = *(const uint32_t *)(D.ring + ((seg + 4 * (uint32_t)lane) & (FQZ_RING - 1)));
+      FQF_LANES_END
+    } else {
+      FQF_LANES
+        for (uint32_t p = D.g0 + (uint32_t)lane; p < seg + 256; p += 64) D.out[p] = D.ring[p & (FQZ_RING - 1)];
+      FQF_LANES_END
+    }
+    D.flushed = seg + 256;
+  }
+  FQF_WAVE_FENCE();
+}
+FQ_HD void fqz_flush_rest(FqzSt &D) {
+  const uint32_t lo = D.flushed > D.g0 ? D.flushed : D.g0;
+  FQF_LANES
+    for (uint32_t p = lo + (uint32_t)lane; p < D.g; p += 64) D.out[p] = D.ring[p & (FQZ_RING - 1)];
+  FQF_LANES_END
+  D.flushed = D.g;
+  FQF_WAVE_FENCE();
+}
+// one pass of the lanes over bytes [c, c + 64) of a match of len bytes from `dist` back: byte i of a match is byte i mod dist of the dist bytes
+// in front of it, which are complete -- so no lane reads what a lane of the same pass writes
+FQ_HD void fqz_copy_pass(FqzSt &D, uint32_t len, uint32_t dist, uint32_t c) {
+  const uint32_t g = D.g, s = g - dist;
+  if (dist >= len) {
+    if (dist <= FQZ_RING - 2 * 64) {                         // inside the ring (the bytes being written do not land on the ones they are copied from)
+      FQF_LANES
+        const uint32_t i = c + (uint32_t)lane;
+        if (i < len) { const uint8_t b = D.ring[(s + i) & (FQZ_RING - 1)]; D.ring[(g + i) & (FQZ_RING - 1)] = b; }
+      FQF_LANES_END
+    } else {                                                 // from the text in HBM (stored when its line was completed)
+      FQF_LANES
+        const uint32_t i = c + (uint32_t)lane;
+        if (i < len) { const uint8_t b = D.out[s + i]; D.ring[(g + i) & (FQZ_RING - 1)] = b; }
+      FQF_LANES_END
+    }
+  } else {                                                   // the match runs into its own bytes: a period of dist
+#if defined(__HIP_DEVICE_COMPILE__)
+    const float rd = __builtin_amdgcn_rcpf((float)dist);
+#else
+    const float rd = 1.0f / (float)dist;
+#endif
+    const bool near = dist <= FQZ_RING - 2 * 64;
+    FQF_LANES
+      const uint32_t i = c + (uint32_t)lane;
+      const uint32_t q = (uint32_t)((float)i * rd);          // i / dist, one too many or too few at most (i < 512)
+      int32_t r = (int32_t)(i - q * dist);
+      if (r < 0) r += (int32_t)dist;
+      if (r >= (int32_t)dist) r -= (int32_t)dist;
+      if (i < len) { const uint8_t b = near ? D.ring[(s + (uint32_t)r) & (FQZ_RING - 1)] : D.out[s + (uint32_t)r]; D.ring[(g + i) & (FQZ_RING - 1)] = b; }
+    FQF_LANES_END
+  }
+  FQF_WAVE_FENCE();
+}
+
+// The general forms: everything the fast loop leaves.  0: go on; 1: end of block; 2: refused.
+// fqz_general_dist: a length has been taken, the distance and the copy follow.
+template <class DE>
+FQ_HD int fqz_general_dist(FqzSt &D, FqzLds &S, uint32_t len, DE dent) {
+  fqz_need32(D);
+  uint32_t f = FQF_UNIFORM32(S.dt[D.bb & ((1u << FQZ_DROOT) - 1)]);
+  if (!fqz_take_of(f)) f = FQF_UNIFORM32(fqz_long_code(D.bb, FQZ_DROOT, S.dsort, S.dfirst, S.dcount, S.doffs, dent));
+  if (!fqz_take_of(f) || D.overrun) return 2;
+  const uint32_t dist = fqz_dist_of(D.bb, f);
+  fqz_take(D, (int)fqz_take_of(f));
+  if (dist > D.g - D.g0 || len > D.g_end - D.g) return 2;
+  for (uint32_t c = 0; c < len; c += 64) fqz_copy_pass(D, len, dist, c);
+  const uint32_t g1 = D.g + len;
+  const bool crossed = ((D.g ^ g1) >> 8) != 0;
+  D.g = g1;
+  if (crossed) fqz_flush_lines(D);
+  return 0;
+}
+template <class LE, class DE>
+FQ_HD int fqz_general_symbol(FqzSt &D, FqzLds &S, LE lent, DE dent) {
+  fqz_need32(D);
+  uint32_t e = FQF_UNIFORM32(S.lt[D.bb & ((1u << FQZ_LROOT) - 1)]);
+  if (!fqz_take_of(e)) e = FQF_UNIFORM32(fqz_long_code(D.bb, FQZ_LROOT, S.lsort, S.lfirst, S.lcount, S.loffs, lent));
+  if (!fqz_take_of(e) || D.overrun) return 2;
+  if (e & FQZ_K_LIT) {
+    fqz_take(D, (int)fqz_take_of(e));
+    if (D.g >= D.g_end) return 2;
+    FQF_LANES
+      D.ring[D.g & (FQZ_RING - 1)] = (uint8_t)(e >> 23);     // (every lane stores the same byte at the same place)
+    FQF_LANES_END
+    FQF_WAVE_FENCE();
+    ++D.g;
+    if ((D.g & 255) == 0) fqz_flush_lines(D);
+    return 0;
+  }
+  if (e & FQZ_K_EOB) { fqz_take(D, (int)fqz_take_of(e)); return 1; }
+  const uint32_t len = (e >> 23) + fqz_extra_of(D.bb, e);
+  fqz_take(D, (int)fqz_take_of(e));
+  return fqz_general_dist(D, S, len, dent);
+}
+// len bytes of the input, byte-aligned at byte position p from base (a stored block)
+FQ_HD void fqz_copy_stored(FqzSt &D, uint64_t p, uint32_t len) {
+  const uint8_t *src = (const uint8_t *)D.base + p;
+  for (uint32_t c = 0; c < len; c += 64) {
+    FQF_LANES
+      const uint32_t i = c + (uint32_t)lane;
+      if (i < len) D.ring[(D.g + (uint32_t)lane) & (FQZ_RING - 1)] = src[i];
+    FQF_LANES_END
+    FQF_WAVE_FENCE();
+    D.g += len - c < 64 ? len - c : 64;
+    fqz_flush_lines(D);
+  }
+}
+
+// the member's CRC-32 from the text in HBM: a piece per lane, 4 bytes per step (slice tables in LDS), the pieces put together
+FQ_HD uint32_t fqz_crc_wave(const uint8_t *p, uint32_t n, const FqzCrcConst *cc, uint32_t *tab /* LDS, 1024 words */) {
+  FQF_LANES
+    for (int i = lane; i < 1024; i += 64) tab[i] = cc->t[i >> 8][i & 255];
+  FQF_LANES_END
+  FQF_WAVE_FENCE();
+  const uint32_t *T0 = tab, *T1 = tab + 256, *T2 = tab + 512, *T3 = tab + 768;
+  // pieces: head bytes up to a 4-byte boundary, 64 runs of whole dwords, tail bytes
+  const uint32_t head = n < 4 ? n : (uint32_t)((4 - ((uintptr_t)p & 3)) & 3);
+  const uint32_t n_dw = (n - head) / 4, tail = (n - head) & 3;
+  const uint32_t per = (n_dw + 63) / 64;
+  uint32_t sum = 0;
+  FQF_LANES
+    uint32_t total = 0;
+    for (int v = lane; v < 66; v += 64) {                    // pieces 0 .. 65: head, 64 runs, tail (one run per lane, the first two lanes a second piece)
+      uint32_t lo, len_b;                                    // byte range of the piece
+      if (v == 0) { lo = 0; len_b = head; }
+      else if (v == 65) { lo = head + 4 * n_dw; len_b = tail; }
+      else {
+        const uint32_t a = (uint32_t)(v - 1) * per < n_dw ? (uint32_t)(v - 1) * per : n_dw;
+        const uint32_t b = a + per < n_dw ? a + per : n_dw;
+        lo = head + 4 * a; len_b = 4 * (b - a);
+      }
+      uint32_t c = 0xffffffffu;
+      const uint8_t *q = p + lo;
+      if (v == 0 || v == 65) { for (uint32_t i = 0; i < len_b; ++i) c = T0[(c ^ q[i]) & 0xff] ^ (c >> 8); }
+      else {
+        const uint32_t *qw = (const uint32_t *)q;
+        for (uint32_t i = 0; i < len_b / 4; ++i) {
+          c ^= qw[i];
+          c = T3[c & 0xff] ^ T2[(c >> 8) & 0xff] ^ T1[(c >> 16) & 0xff] ^ T0[c >> 24];
+        }
+      }
+      c = len_b ? ~c : 0;                                    // crc32 of the piece (an empty piece: 0)
+      const uint32_t after = n - lo - len_b;
+      total ^= fqz_mulmod(fqz_xpow8(cc->pow8, after), c);
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    sum = FQF_WAVE_XOR32(total);
+#else
+    sum ^= total;
+#endif
+  FQF_LANES_END
+  return sum;
+}
+
+FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
+  const FqzMember M = A.mem[m];
+  FqzSt D;
+  D.out = A.out; D.g0 = M.out_off; D.g = M.out_off; D.g_end = M.out_off + M.out_len; D.flushed = M.out_off & ~255u; D.ring = (uint8_t *)S.ring32;
+  const uint64_t a0 = M.in_off & ~(uint64_t)3;
+  D.base = (const uint32_t *)(A.comp + a0);
+  D.bits_end = ((M.in_off & 3) + (uint64_t)M.in_len) * 8;
+  D.blk_top = (uint32_t)((D.bits_end + 31) / 32 / 64) + 1;  // (the block behind the payload's last: inside the 1 KiB of slack)
+  D.overrun = false;
+  fqz_seek(D, M.in_off & 3);
+  int tables = 0;                                           // 0: none built, 1: the fixed code's, 2: a dynamic block's
+  int status = FQZ_OK;
+  auto lent = [](uint32_t s, uint32_t l) { return fqz_lit_entry(s, l); };
+  auto dent = [](uint32_t s, uint32_t l) { return fqz_dist_entry(s, l); };
+  auto cent = [](uint32_t s, uint32_t l) { return fqz_cl_entry(s, l); };
+  for (bool last = false; !last && status == FQZ_OK;) {
+    fqz_need32(D);
+    if (D.overrun) { status = FQZ_REFUSED; break; }
+    last = (D.bb & 1) != 0;
+    const uint32_t type = (uint32_t)(D.bb >> 1) & 3;
+    fqz_take(D, 3);
+    if (type == 0) {                                         // stored: to the byte boundary, LEN, NLEN, bytes
+      fqz_take(D, D.bc & 7);
+      fqz_need32(D);
+      const uint32_t len = (uint32_t)D.bb & 0xffff, nlen = (uint32_t)(D.bb >> 16) & 0xffff;
+      fqz_take(D, 32);
+      const uint64_t p = fqz_bit_pos(D) >> 3;
+      if ((len ^ nlen) != 0xffffu || (p + len) * 8 > D.bits_end || len > D.g_end - D.g) { status = FQZ_REFUSED; break; }
+      fqz_copy_stored(D, p, len);
+      fqz_seek(D, p + len);
+      continue;
+    }
+    if (type == 3) { status = FQZ_REFUSED; break; }
+    int nl = 288, nd = 32;
+    if (type == 1) {
+      if (tables != 1) {
+        FQF_LANES
+          for (int s = lane; s < 320; s += 64) S.lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
+        FQF_LANES_END
+        FQF_WAVE_FENCE();
+      }
+    } else {
+      const int hlit = (int)(D.bb & 31) + 257, hdist = (int)((D.bb >> 5) & 31) + 1, hclen = (int)((D.bb >> 10) & 15) + 4;
+      fqz_take(D, 14);
+      if (hlit > 286 || hdist > 30) { status = FQZ_REFUSED; break; }
+      // the code-length code: up to 19 lengths of 3 bits, in the order 16 17 18 0 8 7 9 6 10 5 11 4 12 3 13 2 14 1 15 (RFC 1951, 3.2.7)
+      FQF_LANES
+        if (lane < 32) S.cl[lane] = 0;
+      FQF_LANES_END
+      FQF_WAVE_FENCE();
+      for (int i = 0; i < hclen; ++i) {
+        fqz_need32(D);
+        const uint32_t sym = i < 3 ? 16u + (uint32_t)i : i == 3 ? 0u : (i & 1) ? 7u - (uint32_t)((i - 5) / 2) : 8u + (uint32_t)((i - 4) / 2);
+        S.cl[sym] = (uint8_t)(D.bb & 7);                     // (every lane the same byte)
+        fqz_take(D, 3);
+      }
+      FQF_WAVE_FENCE();
+      int used;
+      if (FQF_UNIFORM32((uint32_t)fqz_canon(S.cl, 19, S.csort, S.cfirst, S.ccount, S.coffs, &used)) != 0) { status = FQZ_REFUSED; break; }   // (zlib: the code-length code must be complete)
+      fqz_fill_root(S.clt, 7, S.csort, S.cfirst, S.ccount, S.coffs, cent);
+      // the literal / length and distance code lengths, run-length coded with that code
+      int i = 0;
+      bool bad = false;
+      while (i < hlit + hdist) {
+        fqz_need32(D);
+        if (D.overrun) { bad = true; break; }
+        const uint32_t e = FQF_UNIFORM32(S.clt[D.bb & 127]);
+        if (!fqz_take_of(e)) { bad = true; break; }
+        fqz_take(D, (int)fqz_take_of(e));
+        const int s = (int)(e >> 23);
+        if (s < 16) { S.lens[i] = (uint8_t)s; ++i; continue; }
+        int rep;
+        uint32_t val = 0;
+        if (s == 16) {
+          if (i == 0) { bad = true; break; }
+          FQF_WAVE_FENCE();
+          val = FQF_UNIFORM32(S.lens[i - 1]); rep = 3 + (int)(D.bb & 3); fqz_take(D, 2);
+        } else if (s == 17) { rep = 3 + (int)(D.bb & 7); fqz_take(D, 3); }
+        else { rep = 11 + (int)(D.bb & 127); fqz_take(D, 7); }
+        if (i + rep > hlit + hdist) { bad = true; break; }
+        for (int k = 0; k < rep; ++k) S.lens[i + k] = (uint8_t)val;      // (every lane the same bytes)
+        i += rep;
+      }
+      FQF_WAVE_FENCE();
+      if (bad) { status = FQZ_REFUSED; break; }
+      nl = hlit; nd = hdist;
+      if (FQF_UNIFORM32(S.lens[256]) == 0) { status = FQZ_REFUSED; break; }   // no end-of-block code
+    }
+    if (type == 2 || tables != 1) {
+      const uint8_t *dl = S.lens + (type == 1 ? 288 : nl);
+      int used;
+      int rc = (int)FQF_UNIFORM32((uint32_t)fqz_canon(S.lens, nl, S.lsort, S.lfirst, S.lcount, S.loffs, &used));
+      if (rc != 0) { status = FQZ_REFUSED; break; }          // an incomplete literal / length code: zlib takes one case of it (a single one-bit code); left to it
+      fqz_fill_root(S.lt, FQZ_LROOT, S.lsort, S.lfirst, S.lcount, S.loffs, lent);
+      rc = (int)FQF_UNIFORM32((uint32_t)fqz_canon(dl, nd, S.dsort, S.dfirst, S.dcount, S.doffs, &used));
+      used = (int)FQF_UNIFORM32((uint32_t)used);
+      if (rc < 0 || (rc > 0 && !(used == 0 || (used == 1 && FQF_UNIFORM32(S.dcount[1]) == 1)))) { status = FQZ_REFUSED; break; }   // zlib's rule: incomplete only as no code at all or one one-bit code
+      fqz_fill_root(S.dt, FQZ_DROOT, S.dsort, S.dfirst, S.dcount, S.doffs, dent);
+      tables = type == 1 ? 1 : 2;
+    }
+    // ---- the block's symbols ----
+    // The fast form runs while it meets nothing but root-table codes, matches of up to 64 bytes and input left in the block being read; its
+    // state is the real state at every point, so whatever it meets it leaves the loop and the general form goes on from there:
+    //   why 0: at a symbol's start (the block of input is used up, a code longer than the root, the end of the block, the promised size reached)
+    //   why 1: a length has been taken (`len`); the distance needs the general form (input block used up, longer code, long match, bad distance)
+    for (;;) {
+      int why = 0;
+      uint32_t len = 0;
+      if (D.flushed > D.g0 || (D.g0 & 255) == 0) {           // (the member's first line of text, which may begin inside a line, is out)
+        uint64_t bb = D.bb;
+        int bc = D.bc;
+        uint32_t di = D.di, g = D.g;
+        const uint32_t g0 = D.g0, g_end = D.g_end;
+        uint8_t *const ring = D.ring, *const out = D.out;
+        for (;;) {
+          if (bc <= 32) {
+            if (di == 64) break;
+            bb |= (uint64_t)FQF_UNIFORM32(FQF_RL(D.wcur, di)) << bc; bc += 32; ++di;
+          }
+          const uint32_t e = FQF_UNIFORM32(S.lt[bb & ((1u << FQZ_LROOT) - 1)]);
+          if (e & FQZ_K_BASE) {
+            len = (e >> 23) + fqz_extra_of(bb, e);
+            const uint32_t t1 = fqz_take_of(e);
+            bb >>= t1; bc -= (int)t1;
+            why = 1;
+            if (bc <= 32) {
+              if (di == 64) break;
+              bb |= (uint64_t)FQF_UNIFORM32(FQF_RL(D.wcur, di)) << bc; bc += 32; ++di;
+            }
+            const uint32_t f = FQF_UNIFORM32(S.dt[bb & ((1u << FQZ_DROOT) - 1)]);
+            if (!(f & FQZ_K_BASE)) break;
+            if (len > 64) break;
+            const uint32_t dist = fqz_dist_of(bb, f);
+            if (dist > g - g0) break;
+            const uint32_t g1 = g + len;
+            if (g1 > g_end) break;
+            const uint32_t t2 = fqz_take_of(f);
+            bb >>= t2; bc -= (int)t2;
+            why = 0;
+            const uint32_t s = g - dist;
+            if (dist >= len) {
+              if (dist <= FQZ_RING - 2 * 64) {
+                FQF_LANES
+                  if ((uint32_t)lane < len) { const uint8_t b = ring[(s + (uint32_t)lane) & (FQZ_RING - 1)]; ring[(g + (uint32_t)lane) & (FQZ_RING - 1)] = b; }
+                FQF_LANES_END
+              } else {
+                FQF_LANES
+                  if ((uint32_t)lane < len) { const uint8_t b = out[s + (uint32_t)lane]; ring[(g + (uint32_t)lane) & (FQZ_RING - 1)] = b; }
+                FQF_LANES_END
+              }
+              FQF_WAVE_FENCE();
+            } else {
+              D.g = g;
+              fqz_copy_pass(D, len, dist, 0);
+            }
+            if ((g ^ g1) >> 8) {                             // a line is complete
+              const uint32_t seg = (g1 & ~255u) - 256;
+              FQF_LANES
+                *(uint32_t *)(out + seg + 4 * (uint32_t)lane) = *(const uint32_t *)(ring + ((seg + 4 * (uint32_t)lane) & (FQZ_RING - 1)));
+              FQF_LANES_END
+              FQF_WAVE_FENCE();
+              D.flushed = seg + 256;
+            }
+            g = g1;
+            continue;
+          }
+          if (!(e & FQZ_K_LIT)) break;                       // the end of the block, a longer code
+          if (g >= g_end) break;
+          {
+            const uint32_t t1 = fqz_take_of(e);
+            bb >>= t1; bc -= (int)t1;
+            FQF_LANES
+              ring[g & (FQZ_RING - 1)] = (uint8_t)(e >> 23);
+            FQF_LANES_END
+            FQF_WAVE_FENCE();
+            ++g;
+            if ((g & 255) == 0) {
+              FQF_LANES
+                *(uint32_t *)(out + g - 256 + 4 * (uint32_t)lane) = *(const uint32_t *)(ring + ((g - 256 + 4 * (uint32_t)lane) & (FQZ_RING - 1)));
+              FQF_LANES_END
+              FQF_WAVE_FENCE();
+              D.flushed = g;
+            }
+          }
+        }
+        D.bb = bb; D.bc = bc; D.di = di; D.g = g;
+      }
+      const int r = why ? fqz_general_dist(D, S, len, dent) : fqz_general_symbol(D, S, lent, dent);
+      if (r == 1) break;
+      if (r == 2) { status = FQZ_REFUSED; break; }
+    }
+  }
+  // the stream has ended: inside the payload, after exactly the promised output
+  if (status == FQZ_OK && (D.overrun || fqz_bit_pos(D) > D.bits_end || D.g != D.g_end)) status = FQZ_REFUSED;
+  if (status == FQZ_OK) {
+    fqz_flush_rest(D);
+    const uint32_t crc = fqz_crc_wave(A.out + M.out_off, M.out_len, A.crc, S.lt);
+    if (crc != M.crc) status = FQZ_BADCRC;
+  }
+  return (uint32_t)status;
+}

@@ -282,6 +282,17 @@ void fq_fastq_close(fq_fastq_t *r);
 int fq_inflate_raw(const uint8_t *src, size_t n, uint8_t *dst, size_t out_len);
 uint32_t fq_crc32(const uint8_t *p, size_t n);
 
+/* ---- FASTQ front end on the device ---------------------------------------------------------------------------------------------
+ * The member decoder of the device front end on its own (the reference reads gzip through zlib's gzread: libbwa/bwaseqio.c:41-52): n_streams
+ * raw DEFLATE streams, one wavefront each, into dst[k] (out_len[k] bytes promised, CRC-32 crc[k] expected).  status[k]: 0 inflated and
+ * checked; 1 a stream the device's decoder does not take (the reader gives such a member to fq_inflate_raw, then zlib: their verdict
+ * stands); 2 CRC mismatch.  repeats > 1 launches the kernel that often (measurement); *kernel_ms = one launch.
+ * fq_bgzf_inflate_device: the same for a run of whole BGZF members (a file image): their text back to back in `out`. */
+int fq_inflate_device(int device, int n_streams, const uint8_t *const *src, const size_t *n, uint8_t *const *dst, const uint32_t *out_len, const uint32_t *crc,
+                      uint32_t *status, int repeats, double *kernel_ms);
+int fq_bgzf_inflate_device(int device, const uint8_t *file, size_t n, uint8_t *out, size_t out_cap, int64_t *n_members, int64_t *text_len, uint32_t *status, int64_t status_cap,
+                           int repeats, double *kernel_ms);
+
 /* ---- one FASTQ stream over several ranks -------------------------------------------------------------------------------
  * A stream shards by reference batch: everything per-read of a batch is independent, and three pieces of state
  * are handed on in batch order -- the drand48 stream (bwa_aln2seq_core, srand48 once per FASTQ pair, src/BwtMapper.cpp:1817), the

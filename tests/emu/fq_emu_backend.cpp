@@ -158,6 +158,13 @@ int launch_aln_index(const int32_t *work, const uint32_t *status, const uint64_t
 int launch_sw(const FqSwArgs &a) { for (int t = 0; t < a.n_task; ++t) fq_sw_thread(a, t); return 0; }
 int launch_sw_serial(const FqSwArgs &a) { return launch_sw(a); }
 int launch_refine(const FqRefineArgs &a) { for (int t = 0; t < a.n_task; ++t) fq_refine_thread(a, t); return 0; }
+const FqzCrcConst *crc_const() { static const FqzCrcConst *c = [] { FqzCrcConst *p = new FqzCrcConst; fqz_crc_const_make(p); return p; }(); return c; }
+int launch_inflate(const FqInflateArgs &a) {
+  FqzLds *lds = new FqzLds;
+  for (int m = 0; m < a.n_mem; ++m) a.status[m] = fqz_inflate_member(a, m, *lds);
+  delete lds;
+  return 0;
+}
 int launch_bitmap_scatter(uint8_t *bitmap, const uint32_t *bits, uint64_t n) {
   for (uint64_t i = 0; i < n; ++i) bitmap[bits[i] >> 3] |= (uint8_t)(1u << (bits[i] & 7));
   return 0;

@@ -1,0 +1,145 @@
+"""The FASTQ front end on the device (fastquick_amd/csrc/fq_frontend.h / fq_frontend.cpp): the BGZF member decoder (`k_inflate_bgzf`, one
+wavefront per member) against zlib -- the reference reads its input through zlib's gzread (libbwa/bwaseqio.c:41-52).  Same bytes for every
+stream zlib produces, refusal (never wrong bytes) for damaged ones: a member the device refuses goes to the host's decoder and then to zlib,
+whose verdict stands.
+CPU tier: the same kernel body as a wavefront of one lane through the host-loop library (tests/emu, test infrastructure), and a fuzz of it
+under AddressSanitizer / UBSan; GPU tier: the HIP kernel."""
+import os
+import random
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+from fastquick_amd import api, synth
+from test_inflate import raw_deflate, samples
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMU_DIR = os.path.join(ROOT, "tests", "emu")
+
+
+def emu():
+    subprocess.check_call(["make", "-s", "-C", EMU_DIR, "libfq_emu.so"])
+    return api.load_library(os.path.join(EMU_DIR, "libfq_emu.so"))
+
+
+TIERS = [pytest.param("emu", id="host-loop"), pytest.param("hip", id="gpu", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=TIERS)
+def lib(request):
+    return emu() if request.param == "emu" else api.load_library()
+
+
+def test_every_level_and_strategy_decodes_to_zlibs_bytes(lib):
+    streams, datas = [], []
+    for data in samples():
+        for level in (0, 1, 2, 6, 9):
+            for strategy in (zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FILTERED):
+                streams.append((raw_deflate(data, level, strategy), len(data), zlib.crc32(data)))
+                datas.append(data)
+    assert len(streams) > 400
+    res, _ = api.inflate_device(streams, lib=lib)
+    for k, (st, out) in enumerate(res):
+        assert st == 0 and out == datas[k], (k, st, len(datas[k]))
+
+
+def test_flushed_streams_of_many_blocks(lib):
+    rng = random.Random(11)
+    data = bytes(rng.choice(b"ACGT\nF:#@+") for _ in range(200000))
+    c = zlib.compressobj(6, zlib.DEFLATED, -15)
+    parts = []
+    for i in range(0, len(data), 7001):                              # sync / full flushes: empty stored blocks between Huffman blocks
+        parts.append(c.compress(data[i:i + 7001]))
+        parts.append(c.flush(zlib.Z_SYNC_FLUSH if (i // 7001) % 2 else zlib.Z_FULL_FLUSH))
+    parts.append(c.flush())
+    (st, out), = api.inflate_device([(b"".join(parts), len(data), zlib.crc32(data))], lib=lib)[0]
+    assert st == 0 and out == data
+
+
+def test_wrong_size_truncation_and_damage_are_refused_or_decode_to_what_zlib_says(lib):
+    rng = random.Random(3)
+    data = b"".join(b"@r%d\n" % i + bytes(rng.choice(b"ACGT") for _ in range(100)) + b"\n+\n" + b"F" * 100 + b"\n" for i in range(300))
+    comp = raw_deflate(data, 1)
+    crc = zlib.crc32(data)
+    cases = [(comp, len(data), crc), (comp, len(data) - 1, zlib.crc32(data[:-1])), (comp, len(data) + 1, crc), (comp, len(data), crc ^ 0x10)]
+    cases += [(comp[:cut], len(data), crc) for cut in (1, 2, 5, len(comp) // 2, len(comp) - 1)]
+    cases.append((comp + b"\x00\x00garbage", len(data), crc))          # bytes behind the end of the stream are the caller's business (as with inflate())
+    res, _ = api.inflate_device(cases, lib=lib)
+    assert [st for st, _ in res[:4]] == [0, 1, 1, 2] and res[0][1] == data
+    assert all(st == 1 for st, _ in res[4:9])
+    assert res[9][0] == 0 and res[9][1] == data
+    # flipped bits: the decoder either refuses, or returns exactly what zlib's inflate() returns for the same bytes
+    flips = []
+    for _ in range(400):
+        b = bytearray(comp)
+        b[rng.randrange(len(b))] ^= 1 << rng.randrange(8)
+        flips.append(bytes(b))
+    res, _ = api.inflate_device([(f, len(data), crc) for f in flips], lib=lib)
+    agree = refused = 0
+    for f, (st, out) in zip(flips, res):
+        d = zlib.decompressobj(-15)
+        try:
+            ref = d.decompress(f) + d.flush()
+            ok = d.eof and len(ref) == len(data)
+        except zlib.error:
+            ref, ok = None, False
+        if st == 0:
+            assert ok and ref == out and zlib.crc32(out) == crc
+            agree += 1
+        else:
+            assert st in (1, 2) and not (ok and zlib.crc32(ref) == crc), "refused a stream zlib decodes to the promised size and CRC"
+            refused += 1
+    assert agree + refused == 400 and refused > 300
+
+
+def test_random_mixtures_of_literals_and_repeats(lib):
+    """seeded streams built from random literals and copies at every distance class (inside one wavefront's width, inside the LDS ring, beyond it)"""
+    rng = random.Random(2024)
+    streams, datas = [], []
+    for it in range(300):
+        buf = bytearray()
+        target = rng.choice((50, 700, 5000, 40000, 66000))
+        alpha = rng.choice((b"ACGT", b"ACGTN\n@+F:,#", bytes(range(256))))
+        while len(buf) < target:
+            if buf and rng.random() < 0.6:
+                d = min(len(buf), rng.choice((1, 2, 3, 5, 7, 8, 9, 16, 63, 64, 65, 150, 302, 3900, 3968, 3969, 4000, 4096, 4097, 32768)))
+                n = rng.choice((3, 4, 8, 17, 63, 64, 65, 150, 258, 259, 1000))
+                start = len(buf) - d
+                for i in range(n):
+                    buf.append(buf[start + i])
+            else:
+                buf += bytes(rng.choice(alpha) for _ in range(rng.choice((1, 2, 10, 100))))
+        data = bytes(buf)
+        streams.append((raw_deflate(data, rng.choice((1, 1, 6, 9)), rng.choice((zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED)), mem=rng.choice((1, 8, 9))), len(data), zlib.crc32(data)))
+        datas.append(data)
+    res, _ = api.inflate_device(streams, lib=lib)
+    for k, (st, out) in enumerate(res):
+        assert st == 0 and out == datas[k], (k, len(datas[k]))
+
+
+def test_a_bgzf_file_image_comes_out_as_its_text(lib):
+    rng = np.random.default_rng(5)
+    n, L = 3000, 150
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, (n, L))]
+    qual = np.frombuffer(b"F:,#", dtype=np.uint8)[rng.choice(4, size=(n, L), p=[0.7, 0.15, 0.1, 0.05])]
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        for level in (1, 6):
+            path = os.path.join(tmp, "r.fq")
+            nbytes = synth.write_fastq_uniform(seq, qual, L, path, bgzf=False)
+            text = open(path, "rb").read()
+            blob = synth.bgzf_compress(text, level=level)
+            out, status, _ = api.bgzf_inflate_device(blob, nbytes + 16, lib=lib)
+            assert status and not any(status) and out.tobytes() == text
+
+
+def test_device_decoder_under_address_and_ub_sanitizers(tmp_path):
+    """the kernel body as a wavefront of one lane, exact-size heap buffers: valid and damaged members back to back at every alignment"""
+    exe = str(tmp_path / "devinflate_fuzz")
+    subprocess.check_call(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                           "-I", os.path.join(ROOT, "fastquick_amd", "csrc"), "-I", os.path.join(ROOT, "include"), "-o", exe, os.path.join(EMU_DIR, "devinflate_fuzz.cpp"), "-lz"])
+    out = subprocess.run([exe, "1500"], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
+    assert out.returncode == 0, (out.stdout + out.stderr)[-2000:]
+    assert "mismatches 0" in out.stdout
