@@ -89,6 +89,11 @@ class Stats(C.Structure):
                 ("device_wait_ms", C.c_double), ("host_cpu_ms", C.c_double)]
 
 
+class FrontEndStats(C.Structure):
+    _fields_ = [("ms_inflate", C.c_double), ("ms_tokenise", C.c_double), ("members", C.c_int64), ("refused", C.c_int64),
+                ("text_bytes", C.c_int64), ("comp_bytes", C.c_int64), ("pairs", C.c_int64)]
+
+
 EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destroy", "fq_index_l_pac",
            "fq_index_n_contigs", "fq_index_contig", "fq_ctx_create", "fq_ctx_destroy", "fq_ctx_last_error",
            "fq_ctx_set_debug", "fq_align_batch", "fq_batch_upload", "fq_align_resident", "fq_sam_header",
@@ -96,7 +101,9 @@ EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destr
            "fq_pinned_alloc", "fq_pinned_free", "fq_pack_reads", "fq_packed_free", "fq_packed_create", "fq_pack_reads_into", "fq_pack_single_reads_into", "fq_packed_prefetch", "fq_packed_cancel", "fq_align_packed",
            "fq_ctx_set_tuning", "fq_ctx_set_serial_hooks", "fq_ctx_mark_stream_broken", "fq_ctx_state_export", "fq_ctx_state_import", "fq_qc_default_opts", "fq_qc_create", "fq_qc_destroy", "fq_qc_last_error", "fq_qc_begin_file",
            "fq_qc_add_last", "fq_qc_end_file", "fq_qc_write", "fq_qc_state_reset", "fq_qc_state_export", "fq_qc_merge", "fq_bam_create", "fq_bam_add_last", "fq_bam_format_last", "fq_bam_write_records", "fq_bam_close",
-           "fq_fastq_open", "fq_fastq_configure", "fq_fastq_set_sampling", "fq_fastq_read", "fq_fastq_last_error", "fq_fastq_dropped_record", "fq_fastq_unequal_lengths", "fq_fastq_is_bgzf", "fq_fastq_close", "fq_inflate_raw", "fq_crc32", "fq_inflate_device", "fq_bgzf_inflate_device"]
+           "fq_fastq_open", "fq_fastq_configure", "fq_fastq_set_sampling", "fq_fastq_read", "fq_fastq_last_error", "fq_fastq_dropped_record", "fq_fastq_unequal_lengths", "fq_fastq_is_bgzf", "fq_fastq_close", "fq_inflate_raw", "fq_crc32", "fq_inflate_device", "fq_bgzf_inflate_device",
+           "fq_frontend_open", "fq_frontend_next", "fq_frontend_release", "fq_frontend_handover", "fq_frontend_unequal_lengths", "fq_frontend_stats", "fq_frontend_last_error", "fq_frontend_close",
+           "fq_text_batch_pairs", "fq_text_batch_first_name", "fq_align_text", "fq_text_batch_fetch"]
 
 SERIAL_HOOK = C.CFUNCTYPE(None, C.c_void_p)
 _libs = {}
@@ -166,6 +173,24 @@ def load_library(path: str | None = None):
     L.fq_crc32.restype = C.c_uint32
     L.fq_inflate_device.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t), C.POINTER(C.c_void_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32),
                                     C.POINTER(C.c_uint32), C.c_int, C.POINTER(C.c_double)]
+    L.fq_frontend_open.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_int32, C.c_int64, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    L.fq_frontend_next.restype = C.c_int64
+    L.fq_frontend_next.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    L.fq_frontend_release.restype = None
+    L.fq_frontend_release.argtypes = [C.c_void_p, C.c_void_p]
+    L.fq_frontend_handover.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]
+    L.fq_frontend_unequal_lengths.argtypes = [C.c_void_p]
+    L.fq_frontend_stats.restype = None
+    L.fq_frontend_stats.argtypes = [C.c_void_p, C.POINTER(FrontEndStats)]
+    L.fq_frontend_last_error.restype = C.c_char_p
+    L.fq_frontend_last_error.argtypes = [C.c_void_p]
+    L.fq_frontend_close.restype = None
+    L.fq_frontend_close.argtypes = [C.c_void_p]
+    L.fq_text_batch_pairs.argtypes = [C.c_void_p]
+    L.fq_text_batch_first_name.restype = C.c_char_p
+    L.fq_text_batch_first_name.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+    L.fq_align_text.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(ResultBatch)]
+    L.fq_text_batch_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
     L.fq_bgzf_inflate_device.argtypes = [C.c_int, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.c_void_p, C.c_int64, C.c_int, C.POINTER(C.c_double)]
     L.fq_fastq_close.argtypes = [C.c_void_p]
     L.fq_ctx_set_tuning.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
@@ -428,6 +453,11 @@ class Aligner:
         self._check(self.L.fq_align_packed(self.h, packed.p, C.byref(self.result)), "fq_align_packed")
         return self.result
 
+    def align_text(self, batch) -> ResultBatch:
+        """a batch of the device front end (DeviceFrontEnd.next): nothing of the input crosses PCIe"""
+        self._check(self.L.fq_align_text(self.h, batch, C.byref(self.result)), "fq_align_text")
+        return self.result
+
     def align_resident(self) -> ResultBatch:
         self._check(self.L.fq_align_resident(self.h, C.byref(self.result)), "fq_align_resident")
         return self.result
@@ -623,3 +653,71 @@ def bgzf_inflate_device(blob: bytes, text_cap: int, device: int = 0, lib=None, r
     if rc:
         raise FastquickError("fq_bgzf_inflate_device failed: %d" % rc)
     return out[:tl.value], [int(st[k]) for k in range(nm.value)], ms.value
+
+
+FQ_EFALLBACK = -6
+
+
+class DeviceFrontEnd:
+    """One FASTQ pair (or one single-end file) of BGZF files through the front end on the device (fq_frontend_*): next() -> (n_pairs, batch)
+    with the reads resident in HBM; 0 at the end; FQ_EFALLBACK when the rest of the stream is the host readers' (handover())."""
+
+    def __init__(self, fq1: str, fq2: str | None, batch_pairs: int = 262144, chunk_pairs: int = 16 * 262144, slot_mode: int = 0, max_read_len: int = 160,
+                 device: int = 0, lib=None):
+        self.L = lib or load_library()
+        self.h = C.c_void_p()
+        rc = self.L.fq_frontend_open(device, fq1.encode(), fq2.encode() if fq2 else None, batch_pairs, chunk_pairs, slot_mode, max_read_len, C.byref(self.h))
+        if rc:
+            raise FastquickError("fq_frontend_open failed: %d" % rc)
+        self.batch_pairs, self.slot_mode = batch_pairs, slot_mode
+
+    def next(self):
+        b = C.c_void_p()
+        n = self.L.fq_frontend_next(self.h, C.byref(b))
+        if n < 0 and n != FQ_EFALLBACK:
+            raise FastquickError("fq_frontend_next failed: %d (%s)" % (n, self.L.fq_frontend_last_error(self.h).decode(errors="replace")))
+        return int(n), b
+
+    def release(self, b) -> None:
+        self.L.fq_frontend_release(self.h, b)
+
+    def first_name(self, b, sub_batch: int, end: int) -> bytes:
+        return self.L.fq_text_batch_first_name(b, sub_batch, end)
+
+    def fetch(self, b, n_pairs: int, single_end: bool = False):
+        """(head[3][rows] uint64, len[rows] uint16, names[rows][stride] uint8) of a batch, copied to the host (tests)"""
+        rows = n_pairs * (1 if single_end else 2)
+        head = np.zeros((3, rows), dtype=np.uint64)
+        lens = np.zeros(rows, dtype=np.uint16)
+        names = np.zeros((rows, 304), dtype=np.uint8)
+        ns = self.L.fq_text_batch_fetch(self.h, b, head.ctypes.data, lens.ctypes.data, names.ctypes.data, names.size)
+        if ns < 0:
+            raise FastquickError("fq_text_batch_fetch failed: %d" % ns)
+        return head, lens, names.reshape(-1)[:rows * ns].reshape(rows, ns)
+
+    def handover(self, threads: int = 2, stride: int = 160, name_stride: int = 304):
+        """the host readers (FastqFile) standing where the device's part of the stream ended"""
+        hs = (C.c_void_p * 2)()
+        rc = self.L.fq_frontend_handover(self.h, threads, hs)
+        if rc:
+            raise FastquickError("fq_frontend_handover failed: %d" % rc)
+        out = []
+        for h in hs:
+            if h:
+                f = FastqFile.__new__(FastqFile)
+                f.L, f.h, f.stride, f.name_stride = self.L, C.c_void_p(h), stride, name_stride
+                out.append(f)
+        return out
+
+    def stats(self) -> dict:
+        s = FrontEndStats()
+        self.L.fq_frontend_stats(self.h, C.byref(s))
+        return {k: getattr(s, k) for k, _ in FrontEndStats._fields_}
+
+    def unequal_lengths(self) -> bool:
+        return bool(self.L.fq_frontend_unequal_lengths(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.fq_frontend_close(self.h)
+            self.h = None

@@ -31,6 +31,7 @@
 #include "fq_index.h"
 #include "fq_pipeline.h"
 #include "fq_pool.h"
+#include "fq_text_batch.h"
 
 using std::vector;
 
@@ -187,9 +188,16 @@ struct fq_ctx {
   uint8_t maxdiff_lut[FQ_LMAX + 2];
   // the batch of the current call: ASCII rows resident in HBM (fq_batch_upload) or a packed host batch (fq_align_packed)
   int n_pairs = 0, stride = 0;
-  int in_kind = 0;                      // 0 none, 1 ASCII, 2 packed
+  int in_kind = 0;                      // 0 none, 1 ASCII, 2 packed, 3 FASTQ text resident in HBM (fq_align_text)
   fq_read_batch_t hb{};
   fq_packed_batch_t pb{};
+  const fq_text_batch *tb = nullptr;    // the text batch of the current call: valid until the next call (the caller releases it after the consumers have run)
+  PinBuf<uint8_t> p_cseq, p_cqual;      // ... its surviving reads' rows on the host, compact (FqHostReads::compact)
+  PinBuf<int32_t> p_clen;
+  PinBuf<char> p_cnames;
+  DevBuf<char> d_cnames;
+  vector<uint16_t> h_len_all;           // every row's length (debug dumps of a text batch)
+  int c_stride = 0, c_name_stride = 0;
   // packed input: two head buffers (the next batch's head uploads while this one is aligned)
   DevBuf<uint64_t> d_head[2];
   DevBuf<uint16_t> d_hlen[2];
@@ -976,6 +984,104 @@ int stage0_packed(Call &K) {
   return FQ_OK;
 }
 
+// ---- stage 0, FASTQ text resident in HBM (the device front end's batches, fq_frontend.cpp) --------------------------------------------
+// The filter's keys are in place (fqt_piece_thread / fqt_slot_bases_thread wrote what fq_pack_reads_into writes on the host), so the filter
+// and the compaction run as for a packed batch without an upload; the reads of surviving pairs are gathered from the text into the
+// compact rows every later kernel reads, and come to the host for the consumers (bases, qualities, names of the survivors only).
+int stage0_text(Call &K) {
+  fq_ctx *c = K.c;
+  const fq_index *ix = c->ix;
+  const fq_text_batch &tb = *c->tb;
+  const int n = K.n, n2 = K.n2, n_sub = K.n_sub, B = K.B;
+  const bool se = c->o.single_end != 0;
+  const int n_in = se ? n : n2;
+  const bool ragged = tb.uniform_len <= 0;
+  const bool trim = c->o.trim_qual >= 1;
+  CKM(c->d_filtered.ensure(n2 + 64) && c->d_read_list.ensure(n2) && c->d_sidx.ensure(n2) && c->d_pair_list.ensure(n) && c->d_sub_max.ensure((size_t)3 * n_sub));
+  CK(fqdev::dzero(c->d_sub_max.p, (size_t)3 * n_sub * 4));
+  if (se) CK(fqdev::dfill(c->d_filtered.p + n, 1, (size_t)n));
+  FqPrepPackedArgs a{};
+  a.qual_last = nullptr; a.sub_whole = nullptr;
+  a.ix = ix->dev; a.o = c->ko; a.head = tb.d_head; a.len = ragged ? tb.d_hlen : nullptr; a.uniform_len = tb.uniform_len;
+  a.n_reads = n_in; a.filtered = c->d_filtered.p; a.sub_max = c->d_sub_max.p; a.n_pairs = n; a.batch_pairs = B; a.counters = c->d_counters.p;
+  fqdev::time_begin(FQ_K_PREP);
+  CK(fqdev::launch_prep_packed(a));
+  CK(fqdev::launch_compact(c->d_filtered.p, n, c->d_read_list.p, c->d_sidx.p, c->d_pair_list.p, c->d_counts.p));
+  fqdev::time_end(FQ_K_PREP);
+  int32_t counts[2] = {0, 0};
+  uint64_t lcnt[2] = {0, 0};
+  c->h_sub_max.assign(n_sub, tb.uniform_len);
+  CKS(d2h_staged(c, counts, c->d_counts.p, 8));
+  if (ragged) {
+    CKS(d2h_staged(c, c->h_sub_max.data(), c->d_sub_max.p, (size_t)n_sub * 4));
+    CKS(d2h_staged(c, lcnt, c->d_counters.p + FQ_C_BASES, 16));
+  }
+  CKS(sync_staged(c));
+  if (ragged) {
+    if (lcnt[1]) { c->err = "read length outside [" + std::to_string(FQ_LMIN) + "," + std::to_string(FQ_LMAX) + "]"; return FQ_ELIMIT; }
+    c->n_bases_in = (int64_t)lcnt[0];
+  } else c->n_bases_in = (int64_t)n_in * tb.uniform_len;
+  const int n_search = counts[0], n_surv = counts[1], nrow = 2 * n_surv;
+  K.n_search = n_search; K.n_surv = n_surv;
+  CKM(c->d_surv.ensure((size_t)nrow + 1) && c->d_row_map.ensure((size_t)nrow + 1) && c->d_len_c.ensure((size_t)nrow + 1) && c->d_len_trim.ensure((size_t)nrow + 1));
+  CK(fqdev::launch_surv_map(c->d_pair_list.p, n_surv, n, c->d_filtered.p, c->d_sidx.p, c->d_surv.p, c->d_row_map.p, c->d_read_list.p, nullptr));
+  int rc = stage0_lists(K, false);
+  if (rc) return rc;
+  // ---- the reads of surviving pairs: rows, qualities and names out of the text ----
+  int max_full = 1;
+  for (int sb = 0; sb < n_sub; ++sb) max_full = std::max(max_full, c->h_sub_max[sb]);
+  const int cstride = (max_full + 15) & ~15;
+  const int ns = tb.name_stride;
+  c->c_stride = cstride; c->c_name_stride = ns;
+  CKM(c->d_seq.ensure((size_t)nrow * cstride + 64) && c->d_pqual.ensure((size_t)nrow * cstride + 64) && c->d_cnames.ensure((size_t)nrow * ns + 64));
+  CKM(c->p_cseq.ensure((size_t)nrow * cstride + 64) && c->p_cqual.ensure((size_t)nrow * cstride + 64) && c->p_clen.ensure((size_t)nrow + 8) && c->p_cnames.ensure((size_t)nrow * ns + 64));
+  fqdev::time_begin(FQ_K_PREP);
+  if (nrow) {
+    FqTextGatherArgs g{};
+    g.text[0] = tb.d_text[0]; g.text[1] = tb.d_text[1]; g.rec = tb.d_rec; g.names = tb.d_names; g.name_stride = ns; g.n_pairs = n; g.single_end = se ? 1 : 0;
+    g.pair_list = c->d_pair_list.p; g.n_out = nrow; g.seq = c->d_seq.p; g.qual = c->d_pqual.p; g.stride = cstride;
+    g.len_out = c->d_len_c.p; g.len_trim = c->d_len_trim.p; g.names_out = c->d_cnames.p;
+    CK(fqdev::launch_text_gather(g));
+    if (trim) {
+      FqTrimArgs ta{};
+      ta.o = c->ko; ta.qual = c->d_pqual.p; ta.qual_stride = cstride; ta.row_map = nullptr; ta.len = c->d_len_c.p; ta.n_rows = nrow; ta.len_trim = c->d_len_trim.p;
+      ta.pair_list = c->d_pair_list.p; ta.batch_pairs = B; ta.sub_max = c->d_sub_max.p + 2 * n_sub;
+      CK(fqdev::launch_trim(ta));
+    }
+    CK(fqdev::copy_pinned(c->p_cseq.p, c->d_seq.p, (size_t)nrow * cstride, 0));
+    CK(fqdev::copy_pinned(c->p_cqual.p, c->d_pqual.p, (size_t)nrow * cstride, 0));
+    CK(fqdev::copy_pinned(c->p_clen.p, c->d_len_c.p, (size_t)nrow * 4, 0));
+    CK(fqdev::copy_pinned(c->p_cnames.p, c->d_cnames.p, (size_t)nrow * ns, 0));
+    c->stats.d2h_bytes += (size_t)nrow * (2 * (size_t)cstride + 4 + (size_t)ns);
+  }
+  fqdev::time_end(FQ_K_PREP);
+  // infer_isize's max_len is the longest trimmed read of the whole reference batch, filtered reads included (libbwa/bwape.c:60-61): every
+  // read's qualities are in HBM, so bwa_trim_read runs over all of them where they lie
+  c->h_filtered.clear(); c->h_len_trim.clear(); c->h_len_all.clear();
+  if (trim) {
+    CKM(c->d_len_all.ensure(n2));
+    CK(fqdev::dzero(c->d_sub_max.p, (size_t)n_sub * 4));
+    if (se) CK(fqdev::dzero(c->d_len_all.p + n, (size_t)n * 4));
+    FqTextTrimArgs aa{};
+    aa.o = c->ko; aa.text[0] = tb.d_text[0]; aa.text[1] = tb.d_text[1]; aa.rec = tb.d_rec; aa.n_rows = n_in; aa.n_pairs = n; aa.batch_pairs = B;
+    aa.len_trim = c->d_len_all.p; aa.sub_max = c->d_sub_max.p;
+    CK(fqdev::launch_text_trim_all(aa));
+    CKS(d2h_staged(c, c->h_sub_max.data(), c->d_sub_max.p, (size_t)n_sub * 4));
+    if (c->debug) { c->h_len_trim.resize(n2); CKS(d2h_staged(c, c->h_len_trim.data(), c->d_len_all.p, (size_t)n2 * 4)); }
+  }
+  if (c->debug) {
+    c->h_filtered.resize(n2);
+    CKS(d2h_staged(c, c->h_filtered.data(), c->d_filtered.p, n2));
+    c->h_len_all.assign(n2, 0);
+    CKS(d2h_staged(c, c->h_len_all.data(), tb.d_hlen, (size_t)n_in * 2));
+  }
+  CKS(sync_staged(c));
+  if (c->debug && c->h_len_trim.empty()) { c->h_len_trim.resize(n2); for (int r = 0; r < n2; ++r) c->h_len_trim[r] = r >= n_in ? 0 : (int)c->h_len_all[r]; }
+  stage0_sub_max(K);
+  K.dseq = c->d_seq.p; K.dstride = cstride; K.dlen_trim = c->d_len_trim.p; K.dread_list = c->d_read_list.p;
+  return FQ_OK;
+}
+
 // ---- stage A: widths + gap search, tiered by stack-pool size (GPU) ----------------------------------
 // S.aln: concatenated hit lists; per search index s: [aln_off[s], aln_off[s]+aln_n[s])
 int stageA_search(Call &K) {
@@ -1264,7 +1370,7 @@ int stage_records(Call &K) {
   CKM(c->d_rec.ensure(N + 1) && c->d_nocc.ensure(N + 1) && c->d_ntop.ensure(N + 1) && c->d_enum.ensure(N + 1) && c->d_qfirst.ensure(N + 1) && c->d_row0.ensure(N + 1) &&
       c->d_cls.ensure((size_t)n_surv + 1) && c->d_isz.ensure((size_t)n_surv + 1) && c->d_cigs.ensure(64));
   for (int k = 0; k < 3; ++k) CKM(c->d_cnt[k].ensure(N + 1) && c->d_scan[k].ensure(N + 2));
-  A.ix = c->ix->dev; A.n_surv = n_surv; A.n_pairs = K.n; A.batch_pairs = K.B; A.packed = c->in_kind == 2 ? 1 : 0; A.single_end = o.single_end ? 1 : 0;
+  A.ix = c->ix->dev; A.n_surv = n_surv; A.n_pairs = K.n; A.batch_pairs = K.B; A.packed = c->in_kind >= 2 ? 1 : 0;      // (compact rows: a packed batch, a text batch) A.single_end = o.single_end ? 1 : 0;
   A.max_occ = o.max_occ; A.multi_cap = o.single_end ? 4u : (uint32_t)std::max(o.n_multi, o.N_multi) + 1;   // (single-end: N_OCC + 1, src/BwtMapper.cpp:33, 1344)
   A.n_multi = o.n_multi; A.N_multi = o.N_multi; A.max_isize = o.max_isize; A.s_mm = o.s_mm; A.is_sw = o.is_sw;
   A.pair_list = c->d_pair_list.p; A.surv = c->d_surv.p; A.len_trim = K.dlen_trim; A.full_len = A.packed ? c->d_len_c.p : c->d_len.p;
@@ -1935,7 +2041,7 @@ int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
   K.n = c->n_pairs; K.n2 = 2 * K.n; K.B = o.batch_pairs; K.n_sub = (K.n + K.B - 1) / K.B;
   K.par_min = c->kn.host_par_min;
   K.host_threads = c->kn.host_threads >= 0 ? c->kn.host_threads : o.host_threads > 0 ? o.host_threads : default_host_threads(c->ix);
-  int rc = c->in_kind == 2 ? stage0_packed(K) : stage0_ascii(K);
+  int rc = c->in_kind == 3 ? stage0_text(K) : c->in_kind == 2 ? stage0_packed(K) : stage0_ascii(K);
   if (rc) return rc;
   S.n_surv = K.n_surv;
   S.batch_pairs = K.B;
@@ -2056,6 +2162,24 @@ extern "C" int fq_align_packed(fq_ctx_t *c, const fq_packed_batch_t *in, fq_resu
   return run_call(c, out);
 }
 
+// The whole hot path on a batch of the device front end (fq_frontend_next): nothing of the input crosses PCIe.  The batch must stay
+// unreleased until the consumers of this call's records (fq_sam_format_last, fq_qc_add_last, fq_bam_*) have run.
+extern "C" int fq_align_text(fq_ctx_t *c, const fq_text_batch *tb, fq_result_batch_t *out) {
+  if (!c || !out || !tb) return FQ_EINVAL;
+  int rc = FQ_OK;
+  if (tb->n_pairs < 0 || (tb->n_pairs > 0 && (!tb->d_head || !tb->d_rec || !tb->d_text[0] || !tb->d_names))) rc = FQ_EINVAL;
+  else if (tb->n_pairs > c->max_pairs) { c->err = "batch larger than max_pairs_per_batch"; rc = FQ_ELIMIT; }
+  else if ((tb->single_end != 0) != (c->o.single_end != 0)) { c->err = "single-end / paired-end batch on a context of the other kind"; rc = FQ_EINVAL; }
+  else if (tb->device != c->ix->device) { c->err = "the batch lives on another device than the context's index"; rc = FQ_EINVAL; }
+  else if (tb->uniform_len > 0 && (tb->uniform_len < FQ_LMIN || tb->uniform_len > FQ_LMAX)) { c->err = "read length outside [" + std::to_string(FQ_LMIN) + "," + std::to_string(FQ_LMAX) + "]"; rc = FQ_ELIMIT; }
+  if (rc) return broken_stream_call(c, rc);
+  if (fqdev::bind(c->dev)) return FQ_ENODEV;
+  c->tb = tb;
+  c->n_pairs = tb->n_pairs;
+  c->in_kind = 3;
+  return run_call(c, out);
+}
+
 static const uint64_t kStateGood = 0x31545351465full, kStateBroken = 0x58545351465full;   // "_FQST1" / "_FQSTX"
 // ---- order-dependent state of a stream, for sharding ONE FASTQ stream over ranks by reference batch -------------
 // Layout: u64 mark (good / broken) | u64 rng | fq_isize_t last_ii | u64 n_entries | per entry: u64 key, u64 n, u32 pos[n]
@@ -2137,7 +2261,11 @@ const FqBatchState *fq_ctx_state(const fq_ctx_t *c) { return &c->st; }
 const fq_index *fq_ctx_index(const fq_ctx_t *c) { return c->ix; }
 FqHostReads fq_ctx_host_reads(const fq_ctx_t *c) {
   FqHostReads h;
-  if (c->in_kind == 2) { h.p = &c->pb; h.n_pairs = c->pb.n_pairs; h.names = c->pb.names; h.names_mate = c->pb.names_mate; h.name_stride = c->pb.name_stride; }
+  if (c->in_kind == 3) {
+    h.compact = true; h.n_pairs = c->n_pairs; h.name_stride = c->c_name_stride; h.c_stride = c->c_stride; h.c_n_surv = c->st.n_surv;
+    h.c_seq = c->p_cseq.p; h.c_qual = c->p_cqual.p; h.c_len = c->p_clen.p; h.c_names = c->p_cnames.p; h.c_pair_idx = c->st.pair_idx;
+    h.c_len_all = c->h_len_all.empty() ? nullptr : c->h_len_all.data(); h.c_uniform_len = c->tb ? c->tb->uniform_len : 0;
+  } else if (c->in_kind == 2) { h.p = &c->pb; h.n_pairs = c->pb.n_pairs; h.names = c->pb.names; h.names_mate = c->pb.names_mate; h.name_stride = c->pb.name_stride; }
   else { h.a = &c->hb; h.n_pairs = c->hb.n_pairs; h.names = c->hb.names; h.names_mate = c->hb.names_mate; h.name_stride = c->hb.name_stride; }
   return h;
 }

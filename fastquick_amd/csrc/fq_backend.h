@@ -108,5 +108,14 @@ int launch_refine(const FqRefineArgs &a);
 // the CRC tables and powers the member decoder reads, resident on the bound state's device (made once per device)
 const FqzCrcConst *crc_const();
 int launch_inflate(const FqInflateArgs &a);     // one wavefront per BGZF member
+// positions of the line ends of text[0, n): nl[0 .. min(count, cap)) ascending, *count (device memory) = how many there are
+int launch_nl_index(const uint8_t *text, uint32_t n, uint32_t *nl, uint32_t cap, uint32_t *count);
+int launch_tok_rec(const FqTokArgs &a);         // a thread per record
+int launch_tok_pieces(const FqTokArgs &a);      // a thread per (record, 32 bases)
+int launch_slot_bases(const FqSlotArgs &a);     // a thread per read slot
+int launch_slot_names(const FqSlotArgs &a);
+int launch_text_gather(const FqTextGatherArgs &a);   // a thread per 16 bytes of a surviving read's row
+int launch_text_trim_all(const FqTextTrimArgs &a);   // a thread per read
+int dfill32(void *dst, uint32_t v, size_t n_words);  // (hipMemsetD32 on the state's stream)
 
 }  // namespace fqdev

@@ -978,6 +978,144 @@ int launch_inflate(const FqInflateArgs &a) {
   return 0;
 }
 
+// Line ends of a text: every thread looks at 16 bytes (one aligned load), a block at 4 KiB; the blocks' counts are scanned (launch_scan)
+// and the positions written in order: ballot-free ranks from a prefix sum over the block's 256 counts in LDS.
+__device__ __forceinline__ uint32_t fqt_nl_mask16(const uint8_t *text, uint32_t n, uint32_t at) {   // bit j: text[at + j] is a line end (at a multiple of 16)
+  if (at >= n) return 0;
+  const FqU4 v = *(const FqU4 *)(text + at);
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  uint32_t m = 0;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m |= (uint32_t)(((w[q] >> (8 * j)) & 0xffu) == 0x0au) << (4 * q + j);
+  if (at + 16 > n) m &= (1u << (n - at)) - 1u;
+  return m;
+}
+__global__ void __launch_bounds__(256) k_nl_count(const uint8_t *text, uint32_t n, uint32_t *blk_cnt) {
+  const uint32_t at = (blockIdx.x * 256u + threadIdx.x) * 16u;
+  uint32_t c = (uint32_t)__popc(fqt_nl_mask16(text, n, at));
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d, 64);
+  __shared__ uint32_t s[4];
+  if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+__global__ void __launch_bounds__(256) k_nl_fill(const uint8_t *text, uint32_t n, const uint64_t *blk_off, uint32_t *nl, uint32_t cap) {
+  const uint32_t at = (blockIdx.x * 256u + threadIdx.x) * 16u;
+  uint32_t m = fqt_nl_mask16(text, n, at);
+  const uint32_t c = (uint32_t)__popc(m);
+  // exclusive prefix of the counts inside the block: inside the wavefront by shuffles, across the four wavefronts through LDS
+  uint32_t x = c;
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const uint32_t y = (uint32_t)__shfl_up((int)x, d, 64); if (lane >= d) x += y; }
+  __shared__ uint32_t s[4];
+  if (lane == 63) s[threadIdx.x >> 6] = x;
+  __syncthreads();
+  uint32_t base = 0;
+  for (int w = 0; w < (int)(threadIdx.x >> 6); ++w) base += s[w];
+  uint64_t rank = blk_off[blockIdx.x] + base + (x - c);
+  while (m) {
+    const int j = __ffs((int)m) - 1;
+    m &= m - 1;
+    if (rank < cap) nl[rank] = at + (uint32_t)j;
+    ++rank;
+  }
+}
+__global__ void __launch_bounds__(64) k_nl_total(const uint64_t *blk_off, uint32_t nb, uint32_t *count) {
+  if (threadIdx.x == 0) { const uint64_t t = blk_off[nb]; *count = t > 0xffffffffull ? 0xffffffffu : (uint32_t)t; }
+}
+int launch_nl_index(const uint8_t *text, uint32_t n, uint32_t *nl, uint32_t cap, uint32_t *count) {
+  FQ_PRE();
+  const unsigned nb = nblk((uint64_t)n, 4096);
+  if (nb == 0) { FQ_HIP(hipMemsetAsync(count, 0, 4, g_stream)); return 0; }
+  if (g_cmp_n < (size_t)nb + 1) {
+    dfree(g_cmp_cnt); dfree(g_cmp_off);
+    g_cmp_n = (size_t)nb * 2 + 64;
+    g_cmp_cnt = (uint32_t *)dmalloc(g_cmp_n * 2 * 4);      // (launch_compact keeps two count arrays here)
+    g_cmp_off = (uint64_t *)dmalloc((g_cmp_n + 2) * 2 * 8);
+    if (!g_cmp_cnt || !g_cmp_off) { g_cmp_n = 0; return -4; }
+  }
+  hipLaunchKernelGGL(k_nl_count, dim3(nb), dim3(256), 0, g_stream, text, n, g_cmp_cnt);
+  FQ_HIP(hipGetLastError());
+  if (launch_scan(g_cmp_cnt, g_cmp_off, nb)) return -3;
+  hipLaunchKernelGGL(k_nl_fill, dim3(nb), dim3(256), 0, g_stream, text, n, (const uint64_t *)g_cmp_off, nl, cap);
+  hipLaunchKernelGGL(k_nl_total, dim3(1), dim3(64), 0, g_stream, (const uint64_t *)g_cmp_off, nb, count);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+__global__ void __launch_bounds__(256) k_tok_rec(FqTokArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < a.n_rec) fqt_rec_thread(a, i);
+}
+__global__ void __launch_bounds__(256) k_tok_pieces(FqTokArgs a, int64_t n) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g < n) fqt_piece_thread(a, g);
+}
+__global__ void __launch_bounds__(256) k_slot_bases(FqSlotArgs a) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s < a.n_slots) fqt_slot_bases_thread(a, s);
+}
+__global__ void __launch_bounds__(256) k_slot_names(FqSlotArgs a) {
+  const int s = blockIdx.x * 256 + threadIdx.x;
+  if (s < a.n_slots) fqt_slot_names_thread(a, s);
+}
+__global__ void __launch_bounds__(256) k_text_gather(FqTextGatherArgs a, int64_t n) {
+  const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (g < n) fqt_gather_piece(a, g);
+}
+__global__ void __launch_bounds__(256) k_text_trim_all(FqTextTrimArgs a) {
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r < a.n_rows) fqt_trim_all_thread(a, r);
+}
+int launch_tok_rec(const FqTokArgs &a) {
+  FQ_PRE();
+  if (a.n_rec <= 0) return 0;
+  hipLaunchKernelGGL(k_tok_rec, dim3(nblk((uint64_t)a.n_rec, 256)), dim3(256), 0, g_stream, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+int launch_tok_pieces(const FqTokArgs &a) {
+  FQ_PRE();
+  const int64_t n = (int64_t)a.n_rec * ((a.max_len + 31) >> 5);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_tok_pieces, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, a, n);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+int launch_slot_bases(const FqSlotArgs &a) {
+  FQ_PRE();
+  if (a.n_rec <= 0) return 0;
+  hipLaunchKernelGGL(k_slot_bases, dim3(nblk((uint64_t)a.n_slots, 256)), dim3(256), 0, g_stream, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+int launch_slot_names(const FqSlotArgs &a) {
+  FQ_PRE();
+  if (a.n_rec <= 0) return 0;
+  hipLaunchKernelGGL(k_slot_names, dim3(nblk((uint64_t)a.n_slots, 256)), dim3(256), 0, g_stream, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+int launch_text_gather(const FqTextGatherArgs &a) {
+  FQ_PRE();
+  const int64_t n = (int64_t)a.n_out * (a.stride >> 4);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(k_text_gather, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, a, n);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+int launch_text_trim_all(const FqTextTrimArgs &a) {
+  FQ_PRE();
+  if (a.n_rows <= 0) return 0;
+  hipLaunchKernelGGL(k_text_trim_all, dim3(nblk((uint64_t)a.n_rows, 256)), dim3(256), 0, g_stream, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+int dfill32(void *dst, uint32_t v, size_t n_words) { FQ_PRE(); if (n_words) FQ_HIP(hipMemsetD32Async((hipDeviceptr_t)dst, (int)v, n_words, g_stream)); return 0; }
+
 // ---- launch wrappers ------------------------------------------------------------------------------
 // The filter kernel fills the device and is bound by its random probes: two of them at once only slow each other down.  The
 // launches of all streams (threads) of a device are therefore chained on the device: each waits for the previous one's

@@ -37,6 +37,7 @@
 #include "../../include/fastquick_amd.h"
 #include "fq_pool.h"
 #include "fq_inflate.h"
+#include "fq_fastq_internal.h"
 
 namespace {
 template <class F>
@@ -458,6 +459,36 @@ extern "C" int fq_fastq_configure(fq_fastq_t *r, int32_t batch_pairs, int32_t sl
   if (!r || r->started || batch_pairs < 1 || slot_mode < 0 || slot_mode > 2) return FQ_EINVAL;
   r->batch_pairs = batch_pairs; r->slot_mode = slot_mode;
   if (block_bytes > 0) r->block_bytes = (size_t)std::max<int64_t>(block_bytes, 256);
+  return FQ_OK;
+}
+int fq_fastq_resume(fq_fastq_t *r, int64_t file_offset, const uint8_t *text, size_t n_text, int64_t records_seen,
+                    const uint8_t *slot_names, const uint8_t *slot_bases, const uint16_t *slot_lens, int shorter_after_longer) {
+  if (!r || r->started || !r->bgzf || file_offset < 0 || (n_text && !text)) return FQ_EINVAL;
+  if (lseek(r->fd, (off_t)file_offset, SEEK_SET) < 0) return FQ_EIO;
+  r->cpos = r->cend = 0; r->file_eof = false;
+  r->carry.assign(text, text + n_text);
+  r->records_seen = records_seen;
+  if (shorter_after_longer) r->shorter_after_longer.store(1, std::memory_order_relaxed);
+  if (r->slot_mode != FQ_FASTQ_SLOTS_FRESH && (slot_names || slot_bases || slot_lens)) {
+    const size_t B = (size_t)r->batch_pairs;
+    for (int s = 0; s < 2; ++s) {
+      r->slot_base[s].assign(B * 96, 0);
+      r->slot_len[s].assign(B, 0);
+      if (r->slot_mode == FQ_FASTQ_SLOTS_REUSED) r->slot_name[s].assign(B, std::string());
+      for (size_t k = 0; k < B; ++k) {
+        const size_t slot = (size_t)s * B + k;
+        if (slot_bases) memcpy(&r->slot_base[s][k * 96], slot_bases + slot * 96, 96);
+        if (slot_lens) r->slot_len[s][k] = slot_lens[slot];
+        if (slot_names && r->slot_mode == FQ_FASTQ_SLOTS_REUSED) {
+          // the slot's buffer as the reader keeps it: every byte up to the last one ever written (bytes behind a terminator included)
+          const uint8_t *b = slot_names + slot * 304;
+          size_t used = 304;
+          while (used > 0 && b[used - 1] == 0) --used;
+          r->slot_name[s][k].assign((const char *)b, used);
+        }
+      }
+    }
+  }
   return FQ_OK;
 }
 extern "C" int fq_fastq_set_sampling(fq_fastq_t *r, double frac) {

@@ -134,3 +134,638 @@ extern "C" int fq_bgzf_inflate_device(int device, const uint8_t *file, size_t n,
   if (status) memcpy(status, st.data(), 4 * (size_t)std::min<int64_t>(status_cap, (int64_t)src.size()));
   return FQ_OK;
 }
+
+// =====================================================================================================================================
+// The reader: one FASTQ pair (or one single-end file) -> batches whose text, records, filter keys and names are resident in HBM.
+//
+//   reader threads (one per file)   pread the compressed bytes of the next chunk into pinned staging, walk the members' headers, upload
+//   the producer thread             inflates the chunk's members (k_inflate_bgzf; a member the device refuses: fq_inflate.h, then zlib),
+//                                   indexes the line ends, checks and cuts the records, forms the filter's keys, walks the read slots,
+//                                   writes the names -- and queues the batch
+//   fq_frontend_next()              hands the next batch to the caller (who gives it to fq_align_text)
+//
+// A chunk holds whole reference batches (batch_pairs: insert sizes are inferred per reference batch, libbwa/bwape.c:49-117) unless it is
+// the stream's last.  Text behind a chunk's last record stays in HBM and leads the next chunk.  Whatever the device does not take -- a
+// record that is not four plain lines, a file that ends inside a record, a member neither decoder accepts -- ends the device's part of the
+// stream at a reference-batch boundary: fq_frontend_next() returns FQ_EFALLBACK and fq_frontend_handover() gives the host readers
+// (fq_fastq.cpp) standing exactly there, read slots included; their verdicts stand.
+// =====================================================================================================================================
+#include <atomic>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
+#include <zlib.h>
+
+#include "fq_fastq_internal.h"
+
+#include "fq_text_batch.h"
+
+namespace {
+template <class T> struct DBuf {
+  T *p = nullptr; size_t cap = 0;
+  ~DBuf() { fqdev::dfree(p); }
+  bool ensure(size_t n) {
+    if (n <= cap) return true;
+    fqdev::dfree(p);
+    cap = n + n / 8 + 256;
+    p = (T *)fqdev::dmalloc(cap * sizeof(T));
+    if (!p) cap = 0;
+    return p != nullptr;
+  }
+  bool ensure_keep(size_t n, size_t keep) {   // the first `keep` elements survive (copied on the bound state's stream, then waited for)
+    if (n <= cap) return true;
+    const size_t ncap = n + n / 8 + 256;
+    T *q = (T *)fqdev::dmalloc(ncap * sizeof(T));
+    if (!q) return false;
+    if (keep && (fqdev::d2d(q, p, keep * sizeof(T)) || fqdev::sync())) { fqdev::dfree(q); return false; }
+    fqdev::dfree(p); p = q; cap = ncap;
+    return true;
+  }
+};
+template <class T> struct HBuf {
+  T *p = nullptr; size_t cap = 0;
+  ~HBuf() { fqdev::hfree(p); }
+  bool ensure(size_t n) {
+    if (n <= cap) return true;
+    fqdev::hfree(p);
+    cap = n + n / 8 + 256;
+    p = (T *)fqdev::hmalloc(cap * sizeof(T));
+    if (!p) cap = 0;
+    return p != nullptr;
+  }
+};
+const size_t kPiece = (size_t)32 << 20;       // pinned staging pieces of the compressed stream
+const uint64_t kMaxText = (uint64_t)3500 << 20;   // text positions are 32-bit inside a launch
+
+struct CompChunk {                             // one file's compressed bytes of one chunk, in HBM, with their member table
+  DBuf<uint8_t> d_comp;
+  DBuf<FqzMember> d_mem;
+  DBuf<uint32_t> d_status;
+  std::vector<FqzMember> mem;                  // out_off relative to the chunk's first new byte of text
+  size_t comp_len = 0;
+  uint64_t text_len = 0;
+  int64_t file_off_end = 0;                    // file offset behind the chunk's last member
+  bool eof = false;
+  std::string err;
+};
+struct FileSide {
+  std::string path;
+  int fd = -1;
+  int64_t file_off = 0;                        // next byte to read
+  bool file_eof = false;
+  std::vector<uint8_t> tail;                   // bytes of an incomplete member at the end of what was read
+  fqdev::State *st = nullptr;                  // the reader thread's device state (its stream carries the uploads)
+  HBuf<uint8_t> pin[2];
+  CompChunk chunk[3];                          // the reader runs up to two chunks ahead of the inflation
+  std::thread th;
+  // hand-shake with the producer: chunk slots are filled by the reader in turn and released by the producer in the same order
+  std::mutex mu;
+  std::condition_variable cv;
+  bool filled[3] = {false, false, false};
+  uint64_t want_text = 0;                      // text a chunk should hold (the producer's latest estimate)
+  bool stop = false;
+  int64_t inflated_file_off = 0;               // the file offset behind the last chunk that has been inflated
+  // text
+  DBuf<uint8_t> d_text[3];                     // one per batch slot
+  DBuf<uint32_t> d_nl;
+  uint64_t carry_off = 0, carry_len = 0;       // the text behind the last chunk's records: in d_text[carry_slot]
+  int carry_slot = -1;
+  int64_t carry_records = 0;                   // (whole records among it, as far as known)
+  int64_t records_done = 0;                    // records of this file in batches so far
+  double text_per_record = 0;
+  bool all_read = false;                       // every member of the file has been inflated
+  // slots
+  DBuf<uint8_t> d_slot_base, d_slot_name;
+  DBuf<uint16_t> d_slot_len;
+  DBuf<uint32_t> d_stat;
+  int shorter_after_longer = 0;
+};
+}  // namespace
+
+struct fq_frontend {
+  int device = 0, n_files = 0, slot_mode = FQ_FASTQ_SLOTS_REUSED, batch_pairs = 262144;
+  int64_t chunk_pairs = 16 * 262144;
+  int max_len = 160;                           // rows the aligner sizes: a longer read ends the device's part
+  FileSide f[2];
+  fqdev::State *st = nullptr;                  // the producer's
+  std::thread producer;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<fq_text_batch *> ready;
+  bool slot_free[3] = {true, true, true};
+  bool done = false, fallback = false, stop = false;
+  std::string err;
+  int rc = FQ_OK;
+  fq_text_batch batch[3];
+  DBuf<FqTextRec> d_rec[3];
+  DBuf<uint64_t> d_head[3];
+  DBuf<uint16_t> d_hlen[3];
+  DBuf<char> d_names[3];
+  HBuf<uint32_t> h_stat;
+  int max_name_ever = 0;
+  int64_t pairs_done = 0;
+  int next_slot = 0;
+  // totals (fq_frontend_stats)
+  double ms_inflate = 0, ms_tokenise = 0;
+  int64_t n_members = 0, n_refused = 0, text_bytes = 0, comp_bytes = 0;
+  ~fq_frontend();
+};
+
+namespace {
+#define FE_FAIL(fe, code, msg) do { (fe)->rc = (code); (fe)->err = (msg); return false; } while (0)
+
+// ---- reader thread: the next chunk's compressed bytes -> pinned staging -> HBM, with the member table -------------------------------
+void reader_main(fq_frontend *fe, int e) {
+  FileSide &F = fe->f[e];
+  if (fqdev::bind(F.st)) { std::lock_guard<std::mutex> lk(F.mu); for (int k = 0; k < 3; ++k) { F.chunk[k].err = "no device"; F.filled[k] = true; } F.cv.notify_all(); return; }
+  for (int k = 0;; k = (k + 1) % 3) {
+    uint64_t want;
+    {
+      std::unique_lock<std::mutex> lk(F.mu);
+      F.cv.wait(lk, [&] { return F.stop || !F.filled[k]; });
+      if (F.stop) return;
+      want = F.want_text;
+    }
+    CompChunk &C = F.chunk[k];
+    C.mem.clear(); C.comp_len = 0; C.text_len = 0; C.err.clear(); C.eof = false;
+    // pieces: [tail of the previous read | new bytes] -> whole members go to the device, the rest is the next tail
+    uint64_t text = 0;
+    size_t dev_at = 0;
+    int pin_i = 0;
+    bool more = true;
+    while (more && C.err.empty()) {
+      HBuf<uint8_t> &P = F.pin[pin_i];
+      size_t have = F.tail.size();
+      if (!P.ensure(have + kPiece + (1 << 17))) { C.err = "out of pinned host memory"; break; }
+      if (have) memcpy(P.p, F.tail.data(), have);
+      F.tail.clear();
+      if (!F.file_eof && have < kPiece) {                    // (a long tail -- the rest of a piece whose chunk was full -- is used up first)
+        const ssize_t got = pread(F.fd, P.p + have, kPiece, (off_t)F.file_off);
+        if (got < 0) { C.err = "read error"; break; }
+        if (got == 0) F.file_eof = true;
+        F.file_off += got;
+        have += (size_t)got;
+      }
+      // whole members of the piece
+      size_t at = 0;
+      while (have - at >= 18) {
+        size_t hdr = 0;
+        const size_t sz = bgzf_member(P.p + at, have - at, &hdr);
+        if (sz == 0 || sz < hdr + 8) { C.err = "not a BGZF member at a member boundary (a bgzip file followed by something else?)"; break; }
+        if (have - at < sz) break;
+        const uint32_t isize = le32(P.p + at + sz - 4);
+        if (isize) {
+          FqzMember m{};
+          m.in_off = dev_at + at + hdr; m.in_len = (uint32_t)(sz - hdr - 8); m.out_off = (uint32_t)text; m.out_len = isize; m.crc = le32(P.p + at + sz - 8);
+          C.mem.push_back(m);
+          text += isize;
+        }
+        at += sz;
+        if (text >= want || text >= kMaxText) { more = false; break; }
+      }
+      if (!C.err.empty()) break;
+      // the members' bytes go up; what is behind them waits for the next piece
+      if (at) {
+        if (!C.d_comp.ensure_keep(dev_at + at + 2048, dev_at)) { C.err = "out of device memory"; break; }
+        if (fqdev::h2d(C.d_comp.p + dev_at, P.p, at) || fqdev::sync()) { C.err = "upload failed"; break; }
+        dev_at += at;
+      }
+      F.tail.assign(P.p + at, P.p + have);
+      if (more && F.file_eof) {                              // the file has ended: every whole member has been taken, nothing may be left
+        if (!F.tail.empty()) C.err = "truncated BGZF member at the end of the file";
+        more = false;
+      }
+      pin_i ^= 1;
+    }
+    if (C.err.empty()) {
+      C.file_off_end = F.file_off - (int64_t)F.tail.size();      // the first byte of the file that is not in this chunk
+      C.comp_len = dev_at;
+      C.text_len = text;
+      C.eof = F.file_eof && F.tail.empty();
+      if (!C.d_mem.ensure(C.mem.size() + 1) || !C.d_status.ensure(C.mem.size() + 1)) C.err = "out of device memory";
+      if (C.err.empty() && dev_at && (fqdev::dzero(C.d_comp.p + dev_at, 1024) || fqdev::sync())) C.err = "upload failed";
+    }
+    const bool done = !C.err.empty() || C.eof;
+    {
+      std::lock_guard<std::mutex> lk(F.mu);
+      F.filled[k] = true;
+    }
+    F.cv.notify_all();
+    if (done) return;
+  }
+}
+
+struct ChunkPlan { int n = 0; bool last = false, fall = false; };
+
+// the producer: chunk after chunk until the end of the stream, a failure, or something the device does not take
+void producer_main(fq_frontend *fe) {
+  auto finish = [&](int rc, const std::string &err, bool fallback) {
+    std::lock_guard<std::mutex> lk(fe->mu);
+    if (rc) { fe->rc = rc; fe->err = err; }
+    fe->fallback = fallback;
+    fe->done = true;
+    fe->cv.notify_all();
+  };
+  if (fqdev::bind(fe->st)) { finish(FQ_ENODEV, "no device", false); return; }
+  const int NF = fe->n_files;
+  const int B = fe->batch_pairs;
+  const int n_slots = 2 * B;
+  int comp_k = 0;
+  for (;;) {
+    // ---- a free batch slot ----
+    int slot;
+    {
+      std::unique_lock<std::mutex> lk(fe->mu);
+      fe->cv.wait(lk, [&] { return fe->stop || fe->slot_free[fe->next_slot]; });
+      if (fe->stop) return;
+      slot = fe->next_slot;
+      fe->slot_free[slot] = false;
+      fe->next_slot = (slot + 1) % 3;
+    }
+    fq_text_batch &TB = fe->batch[slot];
+    TB = fq_text_batch();
+    TB.slot = slot; TB.device = fe->device; TB.single_end = NF == 1; TB.batch_pairs = B; TB.row_cap = fe->max_len;
+    uint32_t n_lines[2] = {0, 0};
+    uint64_t n_text[2] = {0, 0};
+    bool at_eof[2] = {true, true};
+    // ---- inflate both files' chunks behind their carried text ----
+    double t_ms[FQ_K_COUNT] = {0};
+    uint64_t t_n[FQ_K_COUNT] = {0};
+    for (int e = 0; e < NF; ++e) {
+      FileSide &F = fe->f[e];
+      CompChunk *C = nullptr;
+      if (!F.all_read) {
+        std::unique_lock<std::mutex> lk(F.mu);
+        F.cv.wait(lk, [&] { return F.filled[comp_k]; });
+        C = &F.chunk[comp_k];
+      }
+      if (C && !C->err.empty()) { finish(FQ_EIO, F.path + ": " + C->err, false); return; }
+      const uint64_t new_text = C ? C->text_len : 0;
+      n_text[e] = F.carry_len + new_text;
+      if (n_text[e] > 0xfff00000ull) { finish(FQ_ELIMIT, "a chunk's text exceeds 4 GiB", false); return; }
+      if (!F.d_text[slot].ensure((size_t)n_text[e] + 4096)) { finish(FQ_ENOMEM, "out of device memory (text)", false); return; }
+      if (F.carry_len && fqdev::d2d(F.d_text[slot].p, F.d_text[F.carry_slot].p + F.carry_off, (size_t)F.carry_len)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+      if (C) F.inflated_file_off = C->file_off_end;
+      if (C && !C->mem.empty()) {
+        // the members' text begins behind the carried text: out_off is rebased by giving the kernel a shifted buffer (256-byte alignment
+        // of the buffer's base is what the decoder's stores rely on: the shift goes into the members' offsets instead)
+        for (auto &m : C->mem) m.out_off += (uint32_t)F.carry_len;
+        if (fqdev::h2d(C->d_mem.p, C->mem.data(), C->mem.size() * sizeof(FqzMember))) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+        FqInflateArgs a{};
+        a.comp = C->d_comp.p; a.mem = C->d_mem.p; a.n_mem = (int)C->mem.size(); a.out = F.d_text[slot].p; a.status = C->d_status.p; a.crc = fqdev::crc_const();
+        if (!a.crc) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+        fqdev::time_begin(0);
+        if (fqdev::launch_inflate(a)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+        fqdev::time_end(0);
+      }
+      at_eof[e] = C ? C->eof : true;
+    }
+    // ---- members the device refused: the host's decoder, then zlib, whose verdict stands ----
+    for (int e = 0; e < NF; ++e) {
+      FileSide &F = fe->f[e];
+      if (F.all_read) continue;
+      CompChunk &C = F.chunk[comp_k];
+      if (C.mem.empty()) continue;
+      std::vector<uint32_t> status(C.mem.size());
+      if (fqdev::d2h(status.data(), C.d_status.p, status.size() * 4) || fqdev::sync()) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+      std::unique_ptr<fqz::Inflater> fz;
+      std::vector<uint8_t> tmp, cbytes;
+      for (size_t k = 0; k < status.size(); ++k) {
+        if (status[k] == FQZ_OK) continue;
+        ++TB.refused;
+        const FqzMember &m = C.mem[k];
+        cbytes.resize(m.in_len + 8);
+        if (fqdev::d2h(cbytes.data(), C.d_comp.p + m.in_off, m.in_len) || fqdev::sync()) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+        const uint8_t *src = cbytes.data();
+        tmp.resize(m.out_len);
+        bool ok = false;
+        if (!fz) fz.reset(new fqz::Inflater);
+        if (fqz::inflate_raw(*fz, src, m.in_len, tmp.data(), m.out_len)) ok = fqz::crc32(tmp.data(), m.out_len) == m.crc;
+        else {
+          z_stream zs;
+          memset(&zs, 0, sizeof zs);
+          if (inflateInit2(&zs, -15) == Z_OK) {
+            zs.next_in = const_cast<Bytef *>(src); zs.avail_in = m.in_len; zs.next_out = tmp.data(); zs.avail_out = m.out_len;
+            const int zr = inflate(&zs, Z_FINISH);
+            ok = zr == Z_STREAM_END && zs.avail_out == 0 && (uint32_t)crc32(crc32(0L, Z_NULL, 0), tmp.data(), m.out_len) == m.crc;
+            inflateEnd(&zs);
+          }
+        }
+        if (!ok) { finish(FQ_EIO, F.path + ": corrupt BGZF member (inflate or CRC failed)", false); return; }
+        if (fqdev::h2d(F.d_text[slot].p + m.out_off, tmp.data(), m.out_len) || fqdev::sync()) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+      }
+      TB.members += (int64_t)C.mem.size(); TB.comp_bytes += (int64_t)C.comp_len; TB.text_bytes += (int64_t)C.text_len;
+    }
+    // ---- the compressed slot is free again: the reader threads run up to two chunks ahead ----
+    for (int e = 0; e < NF; ++e) {
+      FileSide &F = fe->f[e];
+      if (F.all_read) continue;
+      const bool eof = F.chunk[comp_k].eof;
+      std::lock_guard<std::mutex> lk(F.mu);
+      F.filled[comp_k] = false;
+      if (eof) F.all_read = true;
+      F.cv.notify_all();
+    }
+    comp_k = (comp_k + 1) % 3;
+    // ---- line ends ----
+    fqdev::time_begin(1);
+    for (int e = 0; e < NF; ++e) {
+      FileSide &F = fe->f[e];
+      const size_t cap = (size_t)(4 * (fe->chunk_pairs + B) + 64);
+      if (!F.d_nl.ensure(cap) || !F.d_stat.ensure(FQT_N_STAT + 8)) { finish(FQ_ENOMEM, "out of device memory (line index)", false); return; }
+      if (fqdev::dzero(F.d_text[slot].p + n_text[e], 256)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+      if (fqdev::launch_nl_index(F.d_text[slot].p, (uint32_t)n_text[e], F.d_nl.p, (uint32_t)cap, F.d_stat.p + FQT_N_STAT)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+    }
+    if (!fe->h_stat.ensure(64)) { finish(FQ_ENOMEM, "out of pinned host memory", false); return; }
+    for (int e = 0; e < NF; ++e) if (fqdev::copy_pinned(fe->h_stat.p + 32 * e, fe->f[e].d_stat.p + FQT_N_STAT, 4, 0)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+    if (fqdev::sync()) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+    for (int e = 0; e < NF; ++e) n_lines[e] = fe->h_stat.p[32 * e];
+    // ---- how many pairs this chunk holds ----
+    int64_t n = fe->chunk_pairs;
+    bool all_eof = true;
+    for (int e = 0; e < NF; ++e) {
+      const size_t cap_lines = (size_t)(4 * (fe->chunk_pairs + B));
+      n = std::min<int64_t>(n, (int64_t)(std::min<size_t>(n_lines[e], cap_lines) / 4));
+      all_eof = all_eof && at_eof[e];
+    }
+    bool last = false;
+    if (all_eof) {
+      // the stream's end is in sight: every whole record that is left goes into this chunk when they fit it
+      int64_t rest = INT64_MAX;
+      for (int e = 0; e < NF; ++e) rest = std::min<int64_t>(rest, (int64_t)(n_lines[e] / 4));
+      if (rest <= fe->chunk_pairs) { n = rest; last = true; }
+    }
+    if (!last) n = n / B * B;
+    bool fall = false;
+    // ---- records, keys (again after a cut: the rows of the second file begin at n) ----
+    int n_rows = (int)(NF * n);
+    while (n > 0) {
+      n_rows = (int)(NF * n);
+      if (!fe->d_rec[slot].ensure((size_t)n_rows + 1) || !fe->d_head[slot].ensure((size_t)n_rows * 3 + 8) || !fe->d_hlen[slot].ensure((size_t)n_rows + 8)) { finish(FQ_ENOMEM, "out of device memory (records)", false); return; }
+      for (int e = 0; e < NF; ++e) {
+        FileSide &F = fe->f[e];
+        const uint32_t init[FQT_N_STAT] = {0xffffffffu, 0, 0xffffffffu, 0, 0, 0, 0, 0};
+        if (fqdev::h2d(F.d_stat.p, init, sizeof init)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+        FqTokArgs a{};
+        a.text = F.d_text[slot].p; a.nl = F.d_nl.p; a.n_rec = (int)n; a.row0 = (int)(e * n); a.n_rows = n_rows; a.max_len = fe->max_len;
+        a.rec = fe->d_rec[slot].p; a.head = fe->d_head[slot].p; a.hlen = fe->d_hlen[slot].p; a.stat = F.d_stat.p;
+        if (fqdev::launch_tok_rec(a) || fqdev::launch_tok_pieces(a)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+        if (fqdev::copy_pinned(fe->h_stat.p + 32 * e, F.d_stat.p, 4 * FQT_N_STAT, 0)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+      }
+      if (fqdev::sync()) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+      int64_t first_bad = INT64_MAX;
+      for (int e = 0; e < NF; ++e) if (fe->h_stat.p[32 * e + FQT_FIRST_BAD] != 0xffffffffu) first_bad = std::min<int64_t>(first_bad, (int64_t)fe->h_stat.p[32 * e + FQT_FIRST_BAD]);
+      if (first_bad >= n) break;
+      // a record the device does not take: its reference batch, and everything behind it, goes the host's way; the batches in front of it
+      // are good (the same launch checked them)
+      n = first_bad / B * B;
+      fall = true; last = false;
+    }
+    if (n > 0) {
+      // (min / max over the records that are in the chunk: the statistics above cover records [0, n_checked) of which the chunk may hold
+      //  fewer after a cut -- a longer maximum only sizes a buffer more generously; lengths are told apart per row by the aligner)
+      int min_len = INT32_MAX, max_len = 0, max_name = 0;
+      for (int e = 0; e < NF; ++e) {
+        min_len = std::min<int>(min_len, (int)std::min<uint32_t>(fe->h_stat.p[32 * e + FQT_MIN_LEN], 0x7fffffffu));
+        max_len = std::max<int>(max_len, (int)fe->h_stat.p[32 * e + FQT_MAX_LEN]);
+        max_name = std::max<int>(max_name, (int)fe->h_stat.p[32 * e + FQT_MAX_NAME]);
+      }
+      fe->max_name_ever = std::max(fe->max_name_ever, max_name);
+      const int name_stride = std::min(304, (fe->max_name_ever + 1 + 15) & ~15);
+      TB.n_pairs = (int)n; TB.uniform_len = (!fall && min_len == max_len) ? max_len : 0; TB.max_len = max_len; TB.name_stride = name_stride;
+      if (!fe->d_names[slot].ensure((size_t)n_rows * (size_t)name_stride + 64)) { finish(FQ_ENOMEM, "out of device memory (names)", false); return; }
+      // ---- the read slots: bases behind short reads, names ----
+      for (int e = 0; e < NF; ++e) {
+        FileSide &F = fe->f[e];
+        FqSlotArgs s{};
+        s.text = F.d_text[slot].p; s.rec = fe->d_rec[slot].p; s.n_rec = (int)n; s.row0 = (int)(e * n); s.n_rows = n_rows; s.g0 = F.records_done;
+        s.n_slots = n_slots; s.mode = fe->slot_mode; s.slot_base = F.d_slot_base.p; s.slot_len = F.d_slot_len.p; s.slot_name = F.d_slot_name.p;
+        s.head = fe->d_head[slot].p; s.names = fe->d_names[slot].p; s.name_stride = name_stride; s.stat = F.d_stat.p;
+        if (fe->slot_mode != FQ_FASTQ_SLOTS_FRESH && fqdev::launch_slot_bases(s)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+        if (fqdev::launch_slot_names(s)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+        if (fqdev::copy_pinned(fe->h_stat.p + 32 * e, F.d_stat.p, 4 * FQT_N_STAT, 0)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+      }
+      // the names of every reference batch's first pair, for the caller's order check
+      const int n_sub = (int)((n + B - 1) / B);
+      TB.first_names.assign((size_t)n_sub * 2 * (size_t)name_stride, 0);
+      std::vector<char> &fn = TB.first_names;
+      for (int sb = 0; sb < n_sub; ++sb)
+        for (int e = 0; e < NF; ++e)
+          if (fqdev::d2h(&fn[((size_t)sb * 2 + e) * name_stride], fe->d_names[slot].p + ((size_t)e * n + (size_t)sb * B) * name_stride, (size_t)name_stride)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+      if (fqdev::sync()) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+      for (int e = 0; e < NF; ++e) if (fe->h_stat.p[32 * e + FQT_SHORTER_AFTER_LONGER]) fe->f[e].shorter_after_longer = 1;
+      TB.d_text[0] = fe->f[0].d_text[slot].p; TB.d_text[1] = NF > 1 ? fe->f[1].d_text[slot].p : nullptr;
+      TB.d_rec = fe->d_rec[slot].p; TB.d_head = fe->d_head[slot].p; TB.d_hlen = fe->d_hlen[slot].p; TB.d_names = fe->d_names[slot].p;
+    }
+    fqdev::time_end(1);
+    // ---- what stays for the next chunk: the text behind record n ----
+    for (int e = 0; e < NF; ++e) {
+      FileSide &F = fe->f[e];
+      uint32_t cut = 0;
+      if (n > 0) {
+        if (fqdev::d2h(&cut, F.d_nl.p + 4 * (size_t)n - 1, 4) || fqdev::sync()) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+        cut += 1;
+      }
+      F.carry_slot = slot; F.carry_off = cut; F.carry_len = n_text[e] - cut;
+      const int64_t recs = (int64_t)(n_lines[e] / 4);
+      if (recs > 0 && n_text[e] > 0) {
+        uint32_t last_nl = 0;
+        const size_t cap_lines = (size_t)(4 * (fe->chunk_pairs + B));
+        const size_t idx = std::min<size_t>((size_t)recs * 4, cap_lines) - 1;
+        if (fqdev::d2h(&last_nl, F.d_nl.p + idx, 4) || fqdev::sync()) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+        F.text_per_record = (double)(last_nl + 1) / (double)((idx + 1) / 4);
+      }
+      F.records_done += n;
+      {
+        std::lock_guard<std::mutex> lk(F.mu);
+        F.want_text = (uint64_t)std::min<double>((double)kMaxText, (double)fe->chunk_pairs * F.text_per_record * 1.005 + (256 << 10));
+      }
+    }
+    fe->pairs_done += n;
+    fqdev::time_collect(t_ms, t_n, FQ_K_COUNT);
+    fe->ms_inflate += t_ms[0]; fe->ms_tokenise += t_ms[1];
+    fe->n_members += TB.members; fe->n_refused += TB.refused; fe->text_bytes += TB.text_bytes; fe->comp_bytes += TB.comp_bytes;
+    // ---- the end of the stream, or of the device's part of it ----
+    bool stream_end = false;
+    if (last) {
+      // nothing but whole records may be left: otherwise the host's reader says what the rest is (a last record without line end, blank
+      // lines, a partner file that goes on)
+      bool clean = true;
+      for (int e = 0; e < NF; ++e) if (fe->f[e].carry_len != 0) clean = false;
+      if (clean) stream_end = true; else fall = true;
+    }
+    if (!last && !fall && n == 0) {
+      // not one whole reference batch in a chunk's worth of text (reads of many kilobytes): not the device's case
+      fall = true;
+    }
+    {
+      std::lock_guard<std::mutex> lk(fe->mu);
+      if (n > 0) fe->ready.push_back(&TB); else fe->slot_free[slot] = true;
+      if (stream_end || fall) { fe->done = true; fe->fallback = fall; }
+      fe->cv.notify_all();
+    }
+    if (stream_end || fall) return;
+  }
+}
+}  // namespace
+
+fq_frontend::~fq_frontend() {
+  { std::lock_guard<std::mutex> lk(mu); stop = true; }
+  cv.notify_all();
+  for (int e = 0; e < 2; ++e) {
+    { std::lock_guard<std::mutex> lk(f[e].mu); f[e].stop = true; }
+    f[e].cv.notify_all();
+  }
+  if (producer.joinable()) producer.join();
+  for (int e = 0; e < 2; ++e) {
+    if (f[e].th.joinable()) f[e].th.join();
+    if (f[e].fd >= 0) close(f[e].fd);
+  }
+  // (device buffers are freed by the members' destructors; the states last)
+  if (st) { fqdev::bind(st); }
+}
+
+
+// fq2 NULL / "": a single-end file (BwtMapper::SingleEndMapper's reader hands out fresh buffers: slot_mode is FRESH whatever is asked).
+extern "C" int fq_frontend_open(int device, const char *fq1, const char *fq2, int32_t batch_pairs, int64_t chunk_pairs, int32_t slot_mode, int32_t max_read_len, fq_frontend_t **out) {
+  if (!fq1 || !out || batch_pairs < 1 || chunk_pairs < batch_pairs || slot_mode < 0 || slot_mode > 2 || max_read_len < 16 || max_read_len > 4096) return FQ_EINVAL;
+  *out = nullptr;
+  std::unique_ptr<fq_frontend> fe(new fq_frontend);
+  fe->device = device; fe->batch_pairs = batch_pairs; fe->chunk_pairs = chunk_pairs / batch_pairs * batch_pairs; fe->max_len = max_read_len;
+  fe->n_files = (fq2 && *fq2) ? 2 : 1;
+  fe->slot_mode = fe->n_files == 1 ? FQ_FASTQ_SLOTS_FRESH : slot_mode;
+  const char *paths[2] = {fq1, fq2};
+  for (int e = 0; e < fe->n_files; ++e) {
+    FileSide &F = fe->f[e];
+    F.path = paths[e];
+    struct stat sb;
+    if (stat(paths[e], &sb) != 0 || !S_ISREG(sb.st_mode)) return FQ_EIO;           // (a pipe cannot be looked at twice: the host reader's case)
+    F.fd = open(paths[e], O_RDONLY);
+    if (F.fd < 0) return FQ_EIO;
+    uint8_t h[1 << 16];
+    const ssize_t got = pread(F.fd, h, sizeof h, 0);
+    size_t hdr = 0;
+    const size_t sz = got >= 18 ? bgzf_member(h, (size_t)got, &hdr) : 0;
+    if (sz == 0) return FQ_EIO;                                                     // not BGZF: the host reader's case
+    // the text a record takes, from the file's first member (inflated here, on the host: 64 KiB)
+    F.text_per_record = 320.0;
+    if ((size_t)got >= sz && sz >= hdr + 8) {
+      const uint32_t isize = le32(h + sz - 4);
+      std::vector<uint8_t> t(isize + 1);
+      std::unique_ptr<fqz::Inflater> fz(new fqz::Inflater);
+      if (isize && fqz::inflate_raw(*fz, h + hdr, sz - hdr - 8, t.data(), isize)) {
+        size_t lines = 0, last = 0;
+        for (size_t i = 0; i < isize; ++i) if (t[i] == '\n') { ++lines; if (lines % 4 == 0) last = i + 1; }
+        if (lines >= 4) F.text_per_record = (double)last / (double)(lines / 4);
+      }
+    }
+  }
+  // device side
+  fe->st = fqdev::state_create(device);
+  if (!fe->st || fqdev::bind(fe->st)) return FQ_ENODEV;
+  const size_t n_slots = (size_t)2 * (size_t)batch_pairs;
+  for (int e = 0; e < fe->n_files; ++e) {
+    FileSide &F = fe->f[e];
+    F.st = fqdev::state_create(device);
+    if (!F.st) return FQ_ENODEV;
+    if (fqdev::bind(fe->st)) return FQ_ENODEV;
+    if (!F.d_slot_base.ensure(n_slots * 96) || !F.d_slot_len.ensure(n_slots) || !F.d_slot_name.ensure(n_slots * 304) || !F.d_stat.ensure(FQT_N_STAT + 8)) return FQ_ENOMEM;
+    if (fqdev::dzero(F.d_slot_base.p, n_slots * 96) || fqdev::dzero(F.d_slot_len.p, n_slots * 2) || fqdev::dzero(F.d_slot_name.p, n_slots * 304)) return FQ_ENODEV;
+  }
+  if (fqdev::sync()) return FQ_ENODEV;
+  for (int e = 0; e < fe->n_files; ++e) {
+    fe->f[e].want_text = (uint64_t)std::min<double>((double)kMaxText, (double)fe->chunk_pairs * fe->f[e].text_per_record * 1.005 + (256 << 10));
+    fe->f[e].th = std::thread(reader_main, fe.get(), e);
+  }
+  fe->producer = std::thread(producer_main, fe.get());
+  *out = fe.release();
+  return FQ_OK;
+}
+extern "C" void fq_frontend_close(fq_frontend_t *fe) {
+  if (!fe) return;
+  fqdev::State *states[3] = {fe->st, fe->f[0].st, fe->f[1].st};
+  const int device = fe->device;
+  (void)device;
+  delete fe;            // joins the threads, frees the buffers
+  for (fqdev::State *s : states) if (s) fqdev::state_destroy(s);
+}
+extern "C" const char *fq_frontend_last_error(const fq_frontend_t *fe) { return fe ? fe->err.c_str() : ""; }
+// The next batch (*out; it stays valid until fq_frontend_release).  Returns its number of pairs; 0 at the end of the stream; FQ_EFALLBACK when
+// the rest of the stream is the host reader's (fq_frontend_handover); another negative code on failure (fq_frontend_last_error).
+extern "C" int64_t fq_frontend_next(fq_frontend_t *fe, fq_text_batch_t **out) {
+  if (!fe || !out) return FQ_EINVAL;
+  *out = nullptr;
+  std::unique_lock<std::mutex> lk(fe->mu);
+  fe->cv.wait(lk, [&] { return !fe->ready.empty() || fe->done; });
+  if (!fe->ready.empty()) {
+    fq_text_batch *b = fe->ready.front();
+    fe->ready.pop_front();
+    *out = b;
+    return b->n_pairs;
+  }
+  if (fe->rc) return fe->rc;
+  return fe->fallback ? FQ_EFALLBACK : 0;
+}
+extern "C" void fq_frontend_release(fq_frontend_t *fe, fq_text_batch_t *b) {
+  if (!fe || !b || b->slot < 0) return;
+  { std::lock_guard<std::mutex> lk(fe->mu); fe->slot_free[b->slot] = true; }
+  fe->cv.notify_all();
+}
+// Host readers standing where the device's part of the stream ended (after fq_frontend_next returned FQ_EFALLBACK and every batch has been
+// released): out[e] for each file, opened with `threads` threads each.
+extern "C" int fq_frontend_handover(fq_frontend_t *fe, int threads, fq_fastq_t **out) {
+  if (!fe || !out) return FQ_EINVAL;
+  { std::lock_guard<std::mutex> lk(fe->mu); if (!fe->done || !fe->fallback) return FQ_EINVAL; }
+  if (fe->producer.joinable()) fe->producer.join();
+  if (fqdev::bind(fe->st)) return FQ_ENODEV;
+  const size_t n_slots = (size_t)2 * (size_t)fe->batch_pairs;
+  for (int e = 0; e < fe->n_files; ++e) {
+    FileSide &F = fe->f[e];
+    { std::lock_guard<std::mutex> lk(F.mu); F.stop = true; }
+    F.cv.notify_all();
+    if (F.th.joinable()) F.th.join();
+    const int64_t file_off = F.inflated_file_off;          // behind the last chunk that was inflated (a chunk the reader thread filled ahead has not been used)
+    std::vector<uint8_t> text((size_t)F.carry_len), names, bases;
+    std::vector<uint16_t> lens;
+    if (F.carry_len && fqdev::d2h(text.data(), F.d_text[F.carry_slot].p + F.carry_off, (size_t)F.carry_len)) return FQ_ENODEV;
+    if (fe->slot_mode != FQ_FASTQ_SLOTS_FRESH) {
+      names.resize(n_slots * 304); bases.resize(n_slots * 96); lens.resize(n_slots);
+      if (fqdev::d2h(names.data(), F.d_slot_name.p, names.size()) || fqdev::d2h(bases.data(), F.d_slot_base.p, bases.size()) || fqdev::d2h(lens.data(), F.d_slot_len.p, lens.size() * 2)) return FQ_ENODEV;
+    }
+    if (fqdev::sync()) return FQ_ENODEV;
+    fq_fastq_t *r = nullptr;
+    int rc = fq_fastq_open(F.path.c_str(), threads, &r);
+    if (rc) return rc;
+    fq_fastq_configure(r, fe->batch_pairs, fe->slot_mode, 0);
+    rc = fq_fastq_resume(r, file_off, text.data(), text.size(), F.records_done, names.empty() ? nullptr : names.data(), bases.empty() ? nullptr : bases.data(), lens.empty() ? nullptr : lens.data(), F.shorter_after_longer);
+    if (rc) { fq_fastq_close(r); return rc; }
+    out[e] = r;
+  }
+  return FQ_OK;
+}
+extern "C" int fq_frontend_unequal_lengths(const fq_frontend_t *fe) { return fe && (fe->f[0].shorter_after_longer || fe->f[1].shorter_after_longer) ? 1 : 0; }
+extern "C" void fq_frontend_stats(const fq_frontend_t *fe, fq_frontend_stats_t *s) {
+  if (!fe || !s) return;
+  s->ms_inflate = fe->ms_inflate; s->ms_tokenise = fe->ms_tokenise; s->members = fe->n_members; s->refused = fe->n_refused;
+  s->text_bytes = fe->text_bytes; s->comp_bytes = fe->comp_bytes; s->pairs = fe->pairs_done;
+}
+// batch accessors
+extern "C" int32_t fq_text_batch_pairs(const fq_text_batch_t *b) { return b ? b->n_pairs : 0; }
+extern "C" const char *fq_text_batch_first_name(const fq_text_batch_t *b, int32_t sub_batch, int32_t end) {
+  if (!b || sub_batch < 0 || end < 0 || end > 1 || (size_t)(((size_t)sub_batch * 2 + end + 1) * b->name_stride) > b->first_names.size()) return nullptr;
+  return &b->first_names[((size_t)sub_batch * 2 + end) * b->name_stride];
+}
+
+// The batch's per-read arrays copied to the host (tests): head [3][rows] as fq_packed_batch_t::head, len [rows], names [rows][name_stride];
+// rows = 2 * pairs (pairs for a single-end batch).  Returns the name stride, or a negative code.
+extern "C" int fq_text_batch_fetch(fq_frontend_t *fe, const fq_text_batch_t *b, uint64_t *head, uint16_t *len, char *names, int64_t names_cap) {
+  if (!fe || !b) return FQ_EINVAL;
+  const size_t rows = (size_t)b->n_pairs * (b->single_end ? 1 : 2);
+  if (fqdev::bind(fe->f[0].st)) return FQ_ENODEV;             // (a state of this thread's own: the producer's is its thread's)
+  if (head && fqdev::d2h(head, b->d_head, rows * 24)) return FQ_ENODEV;
+  if (len && fqdev::d2h(len, b->d_hlen, rows * 2)) return FQ_ENODEV;
+  if (names) { if ((int64_t)(rows * (size_t)b->name_stride) > names_cap) return FQ_ELIMIT; if (fqdev::d2h(names, b->d_names, rows * (size_t)b->name_stride)) return FQ_ENODEV; }
+  if (fqdev::sync()) return FQ_ENODEV;
+  return b->name_stride;
+}

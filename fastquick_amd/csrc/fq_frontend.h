@@ -651,3 +651,211 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
   }
   return (uint32_t)status;
 }
+
+// =====================================================================================================================================
+// Inflated text in HBM -> what the alignment call takes: the read filter's keys, lengths, the reference's read-slot history, names.
+// kseq_read3_fpc (libbwa/kseq.h:327-371) as bwa_read_seq_with_hash_dev consumes it (src/BwtMapper.cpp:526-588), for text that is what
+// sequencers write: four lines per record.  Every record is held to exactly the conditions under which kseq_read3_fpc returns the same
+// tokens -- '@' first; the name up to the first white space; a base line of printable characters without '+', '>', '@'; a '+' line; a quality
+// line as long as the base line -- the same conditions fq_fastq.cpp's record loop checks on the host; the first record of a file's text that
+// fails them is reported (stat[FQT_FIRST_BAD]) and everything from there on goes the host's byte-wise way.
+// =====================================================================================================================================
+struct FqTextRec { uint32_t name_off, seq_off, qual_off; uint16_t len, name_len; };   // offsets into the file's text buffer
+enum { FQT_FIRST_BAD = 0, FQT_MAX_NAME = 1, FQT_MIN_LEN = 2, FQT_MAX_LEN = 3, FQT_SHORTER_AFTER_LONGER = 4, FQT_N_STAT = 8 };
+FQ_HD bool fqt_is_space(uint32_t c) { return c == ' ' || (c >= 9 && c <= 13); }
+FQ_HD bool fqt_bad_base(uint32_t c) { return !(c > 32 && c < 127) || c == '+' || c == '>' || c == '@'; }   // what kseq would not read as one token of bases
+FQ_HD uint32_t fqt_load32(const uint8_t *p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }            // (any alignment: gfx950 reads unaligned dwords)
+
+struct FqTokArgs {
+  const uint8_t *text;       // one file's text (a whole number of records from its start on; readable 64 bytes behind n_text)
+  const uint32_t *nl;        // positions of its line ends, ascending
+  int32_t n_rec;             // records of this chunk (4 n_rec line ends are there)
+  int32_t row0;              // the file's first row in the batch's arrays: end * n_pairs
+  int32_t n_rows;            // rows of the batch (2 n_pairs; n for a single-end batch)
+  int32_t max_len;           // a read longer than this is not taken (the rows the aligner sizes)
+  FqTextRec *rec;            // [n_rows]
+  uint64_t *head;            // [3][n_rows]: the filter's 32-mers (src/BwtIndexer.cpp:441-456), bases behind a short read as 'A' (fqt_slot_bases_thread puts the slot's there)
+  uint16_t *hlen;            // [n_rows]
+  uint32_t *stat;            // [FQT_N_STAT] of this file: first bad record (min), longest name (max), shortest / longest read
+};
+// one thread per record: the four lines, the name, the lengths
+FQ_HD void fqt_rec_thread(const FqTokArgs &A, int i) {
+  const uint8_t *T = A.text;
+  const uint32_t l0 = i ? A.nl[4 * (size_t)i - 1] + 1 : 0;
+  const uint32_t e0 = A.nl[4 * (size_t)i], e1 = A.nl[4 * (size_t)i + 1], e2 = A.nl[4 * (size_t)i + 2], e3 = A.nl[4 * (size_t)i + 3];
+  const uint32_t l1 = e0 + 1, l2 = e1 + 1, l3 = e2 + 1;
+  bool ok = l0 < e0 && T[l0] == '@' && l2 < e2 && T[l2] == '+' && (e1 - l1) == (e3 - l3) && (e1 - l1) <= (uint32_t)A.max_len;
+  uint32_t ne = l0 + 1;
+  if (ok) while (ne < e0 && !fqt_is_space(T[ne])) ++ne;
+  uint32_t name_len = ok ? ne - (l0 + 1) : 0;
+  if (name_len > 301) name_len = 301;                        // the reference's name buffer holds 2 * read_len = 302 bytes (libbwa/bwaseqio.c:233)
+  const uint32_t L = ok ? e1 - l1 : 0;
+  FqTextRec r;
+  r.name_off = l0 + 1; r.seq_off = l1; r.qual_off = l3; r.len = (uint16_t)L; r.name_len = (uint16_t)name_len;
+  A.rec[A.row0 + i] = r;
+  A.hlen[A.row0 + i] = (uint16_t)L;
+  if (!ok) { FQF_ATOMIC_MIN32(&A.stat[FQT_FIRST_BAD], (uint32_t)i); return; }
+  FQF_ATOMIC_MAX32(&A.stat[FQT_MAX_NAME], name_len);
+  FQF_ATOMIC_MAX32(&A.stat[FQT_MAX_LEN], L);
+  FQF_ATOMIC_MIN32(&A.stat[FQT_MIN_LEN], L);
+}
+// one thread per (record, piece of 32 bases): the base line's characters checked; pieces 0 .. 2 are the filter's three 32-mers
+FQ_HD void fqt_piece_thread(const FqTokArgs &A, int64_t idx) {
+  const int P = (A.max_len + 31) >> 5;
+  const int i = (int)(idx / P), p = (int)(idx - (int64_t)i * P);
+  const FqTextRec r = A.rec[A.row0 + i];
+  const int L = r.len, p0 = 32 * p;
+  if (p0 >= L && p >= 3) return;
+  const uint8_t *s = A.text + r.seq_off;
+  uint64_t k = 0;
+  bool bad = false;
+  for (int q = 0; q < 8; ++q) {
+    const int at = p0 + 4 * q;
+    uint32_t w = at < L ? fqt_load32(s + at) : 0;            // (reads up to three bytes behind the read: the line end and the '+' line are there)
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t c = (w >> (8 * j)) & 0xff;
+      const bool in = at + j < L;
+      bad |= in && fqt_bad_base(c);
+      k = (k << 2) | (in ? (uint64_t)fq_nt4_fast(c) : 0);    // (a non-ACGT code is OR-ed in unmasked and smears into the base before it, as in the reference)
+    }
+  }
+  if (p < 3) A.head[(size_t)p * (size_t)A.n_rows + (size_t)(A.row0 + i)] = k;
+  if (bad) FQF_ATOMIC_MIN32(&A.stat[FQT_FIRST_BAD], (uint32_t)i);
+}
+
+// ---- the reference's reused read slots (fq_fastq.cpp slot_apply) -----------------------------------------------------
+// bwa_read_seq_with_hash_dev fills two sets of batch_pairs read slots in turn and never clears them: the filter sees, behind a read shorter
+// than 96 bp, the bases earlier reads of its slot left (src/BwtIndexer.cpp:441-456 reads 96 bytes whatever the length), and a name keeps the
+// tail of a longer earlier name of its slot (strncpy without terminator, src/BwtMapper.cpp:564).  The slots' state lives in HBM; a thread
+// per slot walks the chunk's records of its slot in order (record g of the file has slot g mod 2 batch_pairs).
+struct FqSlotArgs {
+  const uint8_t *text;
+  const FqTextRec *rec;      // the batch's records; this file's begin at row0
+  int32_t n_rec, row0, n_rows;
+  int64_t g0;                // records of the file before this chunk
+  int32_t n_slots;           // 2 * batch_pairs
+  int32_t mode;              // FQ_FASTQ_SLOTS_*: 0 reused (names and bases), 1 clean names (bases), 2 fresh (nothing lingers)
+  uint8_t *slot_base;        // [n_slots][96], zero = never written
+  uint16_t *slot_len;        // [n_slots] longest read the slot has held
+  uint8_t *slot_name;        // [n_slots][304], NUL padded
+  uint64_t *head;            // [3][n_rows]
+  char *names;               // out: [n_rows][name_stride], NUL padded: the name each record prints under
+  int32_t name_stride;
+  uint32_t *stat;
+};
+FQ_HD void fqt_slot_bases_thread(const FqSlotArgs &A, int slot) {
+  int64_t first = (int64_t)slot - A.g0 % A.n_slots;
+  if (first < 0) first += A.n_slots;
+  uint8_t *h = A.slot_base + (size_t)slot * 96;
+  uint32_t longest = A.slot_len[slot];
+  for (int64_t i = first; i < A.n_rec; i += A.n_slots) {
+    const FqTextRec r = A.rec[A.row0 + i];
+    const uint32_t n = r.len;
+    if (n < longest) A.stat[FQT_SHORTER_AFTER_LONGER] = 1; else longest = n;
+    const uint8_t *s = A.text + r.seq_off;
+    if (n < 96) {                                            // the slot's earlier bases stand behind the read: the filter's keys again, with them
+      for (int ch = 0; ch < 3; ++ch) {
+        uint64_t k = 0;
+        for (int j = 0; j < 32; ++j) {
+          const uint32_t p = 32 * (uint32_t)ch + (uint32_t)j;
+          const uint32_t c = p < n ? s[p] : (h[p] ? h[p] : (uint32_t)'A');
+          k = (k << 2) | (uint64_t)fq_nt4_fast(c);
+        }
+        A.head[(size_t)ch * (size_t)A.n_rows + (size_t)(A.row0 + i)] = k;
+      }
+    }
+    const uint32_t m = n < 96 ? n : 96;
+    for (uint32_t p = 0; p < m; ++p) h[p] = s[p];
+  }
+  A.slot_len[slot] = (uint16_t)(longest > 65535 ? 65535 : longest);
+}
+FQ_HD void fqt_slot_names_thread(const FqSlotArgs &A, int slot) {
+  int64_t first = (int64_t)slot - A.g0 % A.n_slots;
+  if (first < 0) first += A.n_slots;
+  uint8_t *b = A.slot_name + (size_t)slot * 304;
+  for (int64_t i = first; i < A.n_rec; i += A.n_slots) {
+    const FqTextRec r = A.rec[A.row0 + i];
+    const uint8_t *nm = A.text + r.name_off;
+    const uint32_t l = r.name_len;
+    const bool mate_suffix = l > 2 && nm[l - 2] == '/' && (nm[l - 1] == '1' || nm[l - 1] == '2');   // src/BwtMapper.cpp:565-570
+    char *o = A.names + (size_t)(A.row0 + i) * (size_t)A.name_stride;
+    uint32_t keep;
+    if (A.mode != 0) {                                       // fresh buffers / clean names: the record's own name
+      keep = mate_suffix ? l - 2 : l;
+      if (keep > (uint32_t)A.name_stride - 1) keep = (uint32_t)A.name_stride - 1;
+      for (uint32_t p = 0; p < keep; ++p) o[p] = (char)nm[p];
+    } else {
+      for (uint32_t p = 0; p < l; ++p) b[p] = nm[p];
+      if (mate_suffix) b[l - 2] = 0;
+      uint32_t pl = 0;
+      while (pl < 303 && b[pl]) ++pl;
+      keep = pl < (uint32_t)A.name_stride - 1 ? pl : (uint32_t)A.name_stride - 1;
+      for (uint32_t p = 0; p < keep; ++p) o[p] = (char)b[p];
+    }
+    for (uint32_t p = keep; p < (uint32_t)A.name_stride; ++p) o[p] = 0;
+  }
+}
+
+// ---- the reads of surviving pairs: rows gathered from the text ------------------------------------------------------------------------
+// Compact row t = 2 * survivor pair + end.  The bases go out as the packed path leaves them (fq_unpack_piece + fq_patch_thread): "ACGT" by
+// code, 'N' for any other character, '-' kept, zero behind the read -- so every later kernel sees the same rows whichever way a batch came.
+struct FqTextGatherArgs {
+  const uint8_t *text[2];
+  const FqTextRec *rec;      // [n_rows] batch rows: end * n_pairs + pair
+  const char *names;         // [n_rows][name_stride]
+  int32_t name_stride, n_pairs, single_end;
+  const int32_t *pair_list;  // survivor pair -> pair of the batch
+  int32_t n_out;             // compact rows (2 * survivors)
+  uint8_t *seq, *qual;       // out: [n_out][stride]
+  int32_t stride;            // a multiple of 16
+  int32_t *len_out, *len_trim;
+  char *names_out;           // out: [n_out][name_stride]
+};
+FQ_HD void fqt_gather_piece(const FqTextGatherArgs &A, int64_t g) {
+  const int per_row = A.stride >> 4;
+  const int t = (int)(g / per_row), c = (int)(g - (int64_t)t * per_row);
+  const int e = t & 1, p0 = 16 * c;
+  uint8_t *so = A.seq + (size_t)t * (size_t)A.stride + (size_t)p0, *qo = A.qual + (size_t)t * (size_t)A.stride + (size_t)p0;
+  if (A.single_end && e) {                                   // the absent mate of a single-end read: an empty row
+    for (int j = 0; j < 16; ++j) { so[j] = 0; qo[j] = 0; }
+    if (c == 0) { A.len_out[t] = 0; A.len_trim[t] = 0; for (int j = 0; j < A.name_stride; ++j) A.names_out[(size_t)t * A.name_stride + j] = 0; }
+    return;
+  }
+  const size_t row = (size_t)e * (size_t)A.n_pairs + (size_t)A.pair_list[t >> 1];
+  const FqTextRec r = A.rec[row];
+  const uint8_t *T = A.text[e];
+  const int L = r.len;
+  for (int j = 0; j < 16; ++j) {
+    const int p = p0 + j;
+    uint8_t b = 0, q = 0;
+    if (p < L) {
+      const uint32_t code = fq_nt4_fast(T[r.seq_off + p]);
+      b = code < 4 ? (uint8_t)((0x54474341u >> (8 * code)) & 0xffu) : code == 5 ? (uint8_t)'-' : (uint8_t)'N';
+      q = T[r.qual_off + p];
+    }
+    so[j] = b; qo[j] = q;
+  }
+  if (c == 0) {
+    A.len_out[t] = L; A.len_trim[t] = L;
+    const char *nm = A.names + row * (size_t)A.name_stride;
+    char *no = A.names_out + (size_t)t * (size_t)A.name_stride;
+    for (int j = 0; j < A.name_stride; ++j) no[j] = nm[j];
+  }
+}
+// bwa_trim_read (libbwa/bwaseqio.c:75-88) over every read of the batch, the qualities read where they lie in the text: len_trim[row], and the
+// longest trimmed read per reference batch (infer_isize's max_len counts filtered reads too, libbwa/bwape.c:60-61)
+struct FqTextTrimArgs {
+  FqKOpts o;
+  const uint8_t *text[2];
+  const FqTextRec *rec;
+  int32_t n_rows, n_pairs, batch_pairs;
+  int32_t *len_trim;         // out [n_rows]
+  int32_t *sub_max;          // out (zeroed by the caller)
+};
+FQ_HD void fqt_trim_all_thread(const FqTextTrimArgs &A, int r) {
+  const int e = r >= A.n_pairs ? 1 : 0;
+  const FqTextRec R = A.rec[r];
+  const int lt = fq_trim_len(A.o, A.text[e] + R.qual_off, R.len);
+  A.len_trim[r] = lt;
+  FQ_ATOMIC_MAX32(&A.sub_max[(r >= A.n_pairs ? r - A.n_pairs : r) / A.batch_pairs], lt);
+}

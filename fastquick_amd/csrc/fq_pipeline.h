@@ -100,9 +100,26 @@ struct FqHostReads {
   int n_pairs = 0;
   const char *names = nullptr, *names_mate = nullptr;
   int name_stride = 0;
-  int len(size_t r) const { return a ? a->len[r] : (p->uniform_len > 0 ? p->uniform_len : (int)p->len[r]); }
+  // a text-resident batch (fq_align_text): only the reads of surviving pairs have come to the host, as compact rows t = 2 * survivor + end
+  // (bases as the device's rows hold them: "ACGT", 'N', '-'), found through the ascending list of the survivors' pairs
+  bool compact = false;
+  const uint8_t *c_seq = nullptr, *c_qual = nullptr;
+  const int32_t *c_len = nullptr, *c_pair_idx = nullptr;
+  const char *c_names = nullptr;
+  const uint16_t *c_len_all = nullptr;   // every row's length (debug dumps), or NULL: c_uniform_len
+  int c_stride = 0, c_n_surv = 0, c_uniform_len = 0;
+  long crow(size_t r) const {            // compact row of batch row r, -1: not a surviving pair's
+    const int pair = (int)(r % (size_t)n_pairs), e = (int)(r / (size_t)n_pairs);
+    const int32_t *it = std::lower_bound(c_pair_idx, c_pair_idx + c_n_surv, pair);
+    return it != c_pair_idx + c_n_surv && *it == pair ? 2 * (long)(it - c_pair_idx) + e : -1;
+  }
+  int len(size_t r) const {
+    if (compact) { if (c_len_all) return c_len_all[r]; const long t = crow(r); return t >= 0 ? c_len[t] : c_uniform_len; }
+    return a ? a->len[r] : (p->uniform_len > 0 ? p->uniform_len : (int)p->len[r]);
+  }
   // nst_nt4_table codes of the first n bases of row r
   void codes(size_t r, int n, uint8_t *out) const {
+    if (compact) { const long t = crow(r); const uint8_t *row = c_seq + (size_t)t * (size_t)c_stride; for (int j = 0; j < n; ++j) out[j] = (uint8_t)fq_nt4(row[j]); return; }
     if (a) { const uint8_t *row = a->seq + r * (size_t)a->stride; for (int j = 0; j < n; ++j) out[j] = (uint8_t)fq_nt4(row[j]); return; }
     const uint8_t *b = p->body + r * (size_t)p->body_stride;
     for (int j = 0; j < n; ++j) out[j] = (uint8_t)((b[j >> 2] >> (2 * (j & 3))) & 3);
@@ -111,8 +128,17 @@ struct FqHostReads {
       for (; lo < p->exc + p->n_exc && (*lo >> 32) == (uint64_t)r; ++lo) { const int pos = (int)((*lo >> 8) & 0xffff); if (pos < n) out[pos] = (uint8_t)(*lo & 0xff); }
     }
   }
-  const uint8_t *qual(size_t r) const { return a ? a->qual + r * (size_t)a->stride : p->qual + r * (size_t)p->qual_stride; }
-  bool has_qual() const { return a ? a->qual != nullptr : p->qual != nullptr; }
+  const uint8_t *qual(size_t r) const {
+    if (compact) return c_qual + (size_t)crow(r) * (size_t)c_stride;
+    return a ? a->qual + r * (size_t)a->stride : p->qual + r * (size_t)p->qual_stride;
+  }
+  bool has_qual() const { return compact ? c_qual != nullptr : a ? a->qual != nullptr : p->qual != nullptr; }
+  bool has_names() const { return compact ? c_names != nullptr : names != nullptr; }
+  bool mates_named() const { return compact || names_mate != nullptr; }      // the second mates carry names of their own
+  const char *name_of(int pair, int end) const {
+    if (compact) { const long t = crow((size_t)end * (size_t)n_pairs + (size_t)pair); return t >= 0 ? c_names + (size_t)t * (size_t)name_stride : ""; }
+    return (end && names_mate ? names_mate : names) + (size_t)pair * (size_t)name_stride;
+  }
 };
 FqHostReads fq_ctx_host_reads(const fq_ctx_t *c);
 int64_t fq_ctx_last_bases(const fq_ctx_t *c);   // sum of the read lengths of the last batch (NumBase increment)

@@ -61,11 +61,11 @@ int64_t ref_end_multi(const FqMulti &q, int len) {
 int64_t five_prime(const FqRead &p) { return p.type != FQ_TYPE_NO_MATCH ? (p.strand ? ref_end(p) : (int64_t)p.pos) : -1; }
 
 std::string read_name(const FqHostReads *hb, int pair, int end, bool revived) {
-  if (!hb->names) return "*";
-  const char *nm = (end && hb->names_mate ? hb->names_mate : hb->names) + (size_t)pair * (size_t)hb->name_stride;
+  if (!hb->has_names()) return "*";
+  const char *nm = hb->name_of(pair, end);
   std::string s(nm, strnlen(nm, (size_t)hb->name_stride));
-  if (revived && hb->names_mate) {   // expand_seq writes the mate's name over this read's, without a terminator (bwape.c:456)
-    const char *qn = (end ? hb->names : hb->names_mate) + (size_t)pair * (size_t)hb->name_stride;
+  if (revived && hb->mates_named()) {   // expand_seq writes the mate's name over this read's, without a terminator (bwape.c:456)
+    const char *qn = hb->name_of(pair, end ^ 1);
     const std::string q(qn, strnlen(qn, (size_t)hb->name_stride));
     s = q.size() >= s.size() ? q : q + s.substr(q.size());
   }

@@ -293,6 +293,40 @@ int fq_inflate_device(int device, int n_streams, const uint8_t *const *src, cons
 int fq_bgzf_inflate_device(int device, const uint8_t *file, size_t n, uint8_t *out, size_t out_cap, int64_t *n_members, int64_t *text_len, uint32_t *status, int64_t status_cap,
                            int repeats, double *kernel_ms);
 
+/* The front end itself: one FASTQ pair (fq2 NULL or "": one single-end file) of BGZF files -> batches whose reads are resident in HBM, with
+ * the tokens of kseq_read3_fpc (libbwa/kseq.h:327-371) as bwa_read_seq_with_hash_dev consumes them (src/BwtMapper.cpp:476-613) and the
+ * reference's read-slot history (slot_mode as in fq_fastq_configure; a single-end file always reads into fresh slots).
+ * Replaces the two IO workers of a pair (IOworkerAlt, src/BwtMapper.cpp:1973-1980) and fq_fastq_read + fq_pack_reads_into of the host path.
+ * The host reads compressed bytes and walks member headers; inflating (k_inflate_bgzf), cutting lines and records, the filter's keys, slot
+ * history and names happen on the device.  Chunks hold whole reference batches (batch_pairs) -- up to chunk_pairs pairs -- but for the
+ * stream's last.  max_read_len: the longest read taken (the reference's read_len: 151; a longer read ends the device's part).
+ * fq_frontend_open: FQ_EIO when a file is not a regular BGZF file (the host reader's case: fq_fastq_open).
+ * fq_frontend_next: the next batch in *out and its number of pairs; 0 at the end of the stream; FQ_EFALLBACK when the rest of the stream is
+ *   the host reader's -- a record that is not four plain lines, a file that ends inside a record, a read longer than max_read_len: the
+ *   device's part ends at a reference-batch boundary and fq_frontend_handover gives readers (fq_fastq_*) standing exactly there, read
+ *   slots included, whose verdicts (tokens, refusals, messages) are the host path's; another negative code on failure.
+ * fq_align_text: the whole hot path on such a batch.  fq_frontend_release: the batch's buffers may be reused -- after the consumers of the
+ *   call's records (fq_sam_format_last, fq_qc_add_last, fq_bam_*) have run; at most three batches are out at a time. */
+#define FQ_EFALLBACK (-6)
+typedef struct fq_frontend fq_frontend_t;
+typedef struct fq_text_batch fq_text_batch_t;
+typedef struct { double ms_inflate, ms_tokenise; int64_t members, refused, text_bytes, comp_bytes, pairs; } fq_frontend_stats_t;
+int fq_frontend_open(int device, const char *fq1, const char *fq2, int32_t batch_pairs, int64_t chunk_pairs, int32_t slot_mode, int32_t max_read_len, fq_frontend_t **out);
+int64_t fq_frontend_next(fq_frontend_t *fe, fq_text_batch_t **out);
+void fq_frontend_release(fq_frontend_t *fe, fq_text_batch_t *b);
+int fq_frontend_handover(fq_frontend_t *fe, int threads, fq_fastq_t **out /* [2] */);
+int fq_frontend_unequal_lengths(const fq_frontend_t *fe);      /* as fq_fastq_unequal_lengths */
+void fq_frontend_stats(const fq_frontend_t *fe, fq_frontend_stats_t *s);
+const char *fq_frontend_last_error(const fq_frontend_t *fe);
+void fq_frontend_close(fq_frontend_t *fe);
+int32_t fq_text_batch_pairs(const fq_text_batch_t *b);
+/* the name the first pair of the batch's sub_batch-th reference batch prints under, end 0 / 1 (src/BwtMapper.cpp:2087-2092 compares them) */
+const char *fq_text_batch_first_name(const fq_text_batch_t *b, int32_t sub_batch, int32_t end);
+int fq_align_text(fq_ctx_t *c, const fq_text_batch_t *b, fq_result_batch_t *out);
+/* the batch's per-read arrays copied to the host (tests): head [3][rows] as fq_packed_batch_t::head, len [rows], names [rows][stride];
+ * rows = 2 * pairs (pairs for a single-end batch).  Returns the name stride, or a negative code. */
+int fq_text_batch_fetch(fq_frontend_t *fe, const fq_text_batch_t *b, uint64_t *head, uint16_t *len, char *names, int64_t names_cap);
+
 /* ---- one FASTQ stream over several ranks -------------------------------------------------------------------------------
  * A stream shards by reference batch: everything per-read of a batch is independent, and three pieces of state
  * are handed on in batch order -- the drand48 stream (bwa_aln2seq_core, srand48 once per FASTQ pair, src/BwtMapper.cpp:1817), the

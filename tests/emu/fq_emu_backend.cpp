@@ -165,6 +165,19 @@ int launch_inflate(const FqInflateArgs &a) {
   delete lds;
   return 0;
 }
+int launch_nl_index(const uint8_t *text, uint32_t n, uint32_t *nl, uint32_t cap, uint32_t *count) {
+  uint32_t c = 0;
+  for (uint32_t i = 0; i < n; ++i) if (text[i] == '\n') { if (c < cap) nl[c] = i; ++c; }
+  *count = c;
+  return 0;
+}
+int launch_tok_rec(const FqTokArgs &a) { for (int i = 0; i < a.n_rec; ++i) fqt_rec_thread(a, i); return 0; }
+int launch_tok_pieces(const FqTokArgs &a) { const int64_t n = (int64_t)a.n_rec * ((a.max_len + 31) >> 5); for (int64_t g = 0; g < n; ++g) fqt_piece_thread(a, g); return 0; }
+int launch_slot_bases(const FqSlotArgs &a) { if (a.n_rec > 0) for (int s = 0; s < a.n_slots; ++s) fqt_slot_bases_thread(a, s); return 0; }
+int launch_slot_names(const FqSlotArgs &a) { if (a.n_rec > 0) for (int s = 0; s < a.n_slots; ++s) fqt_slot_names_thread(a, s); return 0; }
+int launch_text_gather(const FqTextGatherArgs &a) { const int64_t n = (int64_t)a.n_out * (a.stride >> 4); for (int64_t g = 0; g < n; ++g) fqt_gather_piece(a, g); return 0; }
+int launch_text_trim_all(const FqTextTrimArgs &a) { for (int r = 0; r < a.n_rows; ++r) fqt_trim_all_thread(a, r); return 0; }
+int dfill32(void *dst, uint32_t v, size_t n_words) { for (size_t i = 0; i < n_words; ++i) ((uint32_t *)dst)[i] = v; return 0; }
 int launch_bitmap_scatter(uint8_t *bitmap, const uint32_t *bits, uint64_t n) {
   for (uint64_t i = 0; i < n; ++i) bitmap[bits[i] >> 3] |= (uint8_t)(1u << (bits[i] & 7));
   return 0;

@@ -143,3 +143,58 @@ def test_device_decoder_under_address_and_ub_sanitizers(tmp_path):
     out = subprocess.run([exe, "1500"], capture_output=True, text=True, env=dict(os.environ, ASAN_OPTIONS="detect_leaks=0"))
     assert out.returncode == 0, (out.stdout + out.stderr)[-2000:]
     assert "mismatches 0" in out.stdout
+
+
+# ---- the whole front end: BGZF files -> batches resident on the device -> fq_align_text ------------------------------------------------
+import golden_util  # noqa: E402
+import oracle_binding as ob  # noqa: E402
+
+
+def bgzf_pair(g, tmp, level=6, member=3000):
+    """the case's FASTQ pair as BGZF files of small members (many members, records cut anywhere by their borders)"""
+    out = []
+    for k in ("fq1", "fq2"):
+        path = os.path.join(str(tmp), os.path.basename(g[k]) + ".gz")
+        with open(path, "wb") as fh:
+            fh.write(synth.bgzf_compress(open(g[k], "rb").read(), threads=2, level=level, member=member))
+        out.append(path)
+    return out
+
+
+def run_front_end(lib, g, fq, stages, sam, chunk_batches=2, slot_mode=0, max_read_len=None, se=False, device=0):
+    max_len = max_read_len or max(160, (g["qc_read_len"] + 15) // 16 * 16)
+    fe = api.DeviceFrontEnd(fq[0], None if se else fq[1], batch_pairs=g["batch"], chunk_pairs=chunk_batches * g["batch"], slot_mode=slot_mode, max_read_len=max_len, device=device, lib=lib)
+    ix = api.Index(g["prefix"], lib=lib) if lib is not None and getattr(lib, "_name", "").endswith("libfq_emu.so") else api.Index(g["prefix"], device=device, lib=lib)
+    al = api.Aligner(ix, api.default_opts(lib, trim_qual=g["trim_qual"], batch_pairs=g["batch"], single_end=1 if se else 0), max_pairs=chunk_batches * g["batch"], debug=True)
+    n_total, calls = 0, 0
+    with open(stages, "wb") as st, open(sam, "wb") as sm:
+        sm.write(ix.sam_header())
+        while True:
+            n, b = fe.next()
+            if n <= 0:
+                break
+            al.align_text(b)
+            st.write(al.stage_text())
+            sm.write(al.sam_text())
+            fe.release(b)
+            n_total += n
+            calls += 1
+    stats = fe.stats()
+    al.close(); ix.close(); fe.close()
+    return n, n_total, calls, stats
+
+
+@pytest.mark.parametrize("tag", golden_util.case_tags())
+def test_front_end_batches_align_to_the_references_output(tag, golden_cases, lib, tmp_path):
+    """FASTQ.gz in, the reference's stage dumps and SAM text out, with nothing of the reads' text touched by the host: inflate, lines,
+    records, filter keys, read slots and names on the device (the same kernel bodies in the host-loop tier)."""
+    g = golden_cases[tag]
+    fq = bgzf_pair(g, tmp_path)
+    st, sam = str(tmp_path / "fe.stages"), str(tmp_path / "fe.sam")
+    end, n_total, calls, stats = run_front_end(lib, g, fq, st, sam)
+    assert end == 0, "a well-formed file must be the device's from its first record to its last"
+    assert n_total == g["n_pairs"] and calls == -(-g["n_pairs"] // (2 * g["batch"]))
+    assert stats["members"] > 10 and stats["refused"] == 0
+    diffs = [d for d in ob.diff_stage_files(g["stages"], st)]
+    assert not diffs, "\n".join(diffs)
+    assert open(sam, "rb").read() == open(g["sam"], "rb").read()
