@@ -1370,7 +1370,7 @@ int stage_records(Call &K) {
   CKM(c->d_rec.ensure(N + 1) && c->d_nocc.ensure(N + 1) && c->d_ntop.ensure(N + 1) && c->d_enum.ensure(N + 1) && c->d_qfirst.ensure(N + 1) && c->d_row0.ensure(N + 1) &&
       c->d_cls.ensure((size_t)n_surv + 1) && c->d_isz.ensure((size_t)n_surv + 1) && c->d_cigs.ensure(64));
   for (int k = 0; k < 3; ++k) CKM(c->d_cnt[k].ensure(N + 1) && c->d_scan[k].ensure(N + 2));
-  A.ix = c->ix->dev; A.n_surv = n_surv; A.n_pairs = K.n; A.batch_pairs = K.B; A.packed = c->in_kind >= 2 ? 1 : 0;      // (compact rows: a packed batch, a text batch) A.single_end = o.single_end ? 1 : 0;
+  A.ix = c->ix->dev; A.n_surv = n_surv; A.n_pairs = K.n; A.batch_pairs = K.B; A.packed = c->in_kind >= 2 ? 1 : 0 /* compact rows: a packed batch, a text batch */; A.single_end = o.single_end ? 1 : 0;
   A.max_occ = o.max_occ; A.multi_cap = o.single_end ? 4u : (uint32_t)std::max(o.n_multi, o.N_multi) + 1;   // (single-end: N_OCC + 1, src/BwtMapper.cpp:33, 1344)
   A.n_multi = o.n_multi; A.N_multi = o.N_multi; A.max_isize = o.max_isize; A.s_mm = o.s_mm; A.is_sw = o.is_sw;
   A.pair_list = c->d_pair_list.p; A.surv = c->d_surv.p; A.len_trim = K.dlen_trim; A.full_len = A.packed ? c->d_len_c.p : c->d_len.p;

@@ -53,6 +53,7 @@ struct FastqReader {
     fq_fastq_configure(h, batch_pairs, slot_mode, 0);
     if (fq_fastq_set_sampling(h, frac)) die("--frac_samp must not be negative");
   }
+  FastqReader(const std::string &p, fq_fastq_t *adopt) : h(adopt), path(p) {}      // a reader the device front end handed over (fq_frontend_handover)
   ~FastqReader() { if (h) fq_fastq_close(h); }
   FastqReader(const FastqReader &) = delete;
 };
@@ -122,6 +123,7 @@ struct Args {
   std::string devices;   // --devices: several devices, the lines of --fq_list dealt over them
   int pack_threads = std::min(32, std::max(1, fq_host_cpus()));     // host threads of the FASTQ readers (half per file) and of the packer, from the CPUs the process may use; --t sets it
   bool clean_names = false;
+  bool host_reader = false;   // --host_reader: the FASTQ front end on the host's threads also for BGZF files (the default inflates and tokenises them on the device)
   bool strict = false;   // --strict_reference: stop where the output could differ from the reference's bytes (today: QUAL of reads of unequal lengths)
   std::string fq_list, rg = "@RG\\tID:foo\\tSM:bar";   // runAlign's default --RG (src/FASTQuick.cpp:170)
   bool cal_dup = true;
@@ -133,7 +135,7 @@ int usage() {
   fprintf(stderr, "Usage: FASTQuick_amd align --index_prefix P --fastq_1 R1.fq[.gz] [--fastq_2 R2.fq[.gz]] | --fq_list LIST  --out_prefix O [--sam_out] [--RG STR] [--cal_dup]\n"
                   "                       [--q INT] [--n FLOAT|INT] [--kmer_thresh INT] [--o INT] [--e INT] [--i INT] [--d INT] [--l INT] [--k INT]\n"
                   "                       [--m INT] [--R INT] [--N] [--L] [--I] [--max_isize INT] [--max_occ INT] [--is_sw] [--n_multi INT] [--N_multi INT]\n"
-                  "                       [--ap_prior FLOAT] [--force_isize] [--frac_samp FLOAT] [--t INT] [--chunk_pairs INT] [--batch_pairs INT] [--device INT | --devices LIST] [--read_len INT] [--clean_names] [--strict_reference]\n"
+                  "                       [--ap_prior FLOAT] [--force_isize] [--frac_samp FLOAT] [--t INT] [--chunk_pairs INT] [--batch_pairs INT] [--device INT | --devices LIST] [--read_len INT] [--clean_names] [--strict_reference] [--host_reader]\n"
                   "       FASTQuick_amd index --ref REDUCED.FASTQuick.fa [--rollhash]\n");
   return 1;
 }
@@ -190,8 +192,8 @@ void append_file(const std::string &path, FILE *to, fq_bam_t *bam) {   // a part
 }
 
 // The one column of the reference's output that is not reproduced: said loudly, or refused.
-void unequal_lengths_notice(const Args &A, const fq_fastq_t *a, const fq_fastq_t *b) {
-  if (!fq_fastq_unequal_lengths(a) && !(b && fq_fastq_unequal_lengths(b))) return;
+void unequal_lengths_notice(const Args &A, const fq_fastq_t *a, const fq_fastq_t *b, bool seen_on_device = false) {
+  if (!seen_on_device && !(a && fq_fastq_unequal_lengths(a)) && !(b && fq_fastq_unequal_lengths(b))) return;
   const char *msg = "reads of unequal lengths: the reference prints the QUAL column of a read that follows a longer read in its read slot with that read's "
                     "tail behind it (an unterminated buffer: src/BwtMapper.cpp:549-558, libbwa/bwase.c:401; longer than SEQ, not valid SAM); here QUAL has "
                     "the read's own length -- every other column, and every QC file, is the reference's";
@@ -204,151 +206,69 @@ void unequal_lengths_notice(const Args &A, const fq_fastq_t *a, const fq_fastq_t
 // one (the reference, too, decodes the two files on two IO threads: BwtMapper.cpp:1873-1935).
 // `ready`: called once the input's first chunk has been read and before anything needs the index, the QC consumer or the sink -- the
 // one-device command line stages the index (about a second: the filter bitmaps are built on the device) on another thread meanwhile.
-void align_input(Args A, const std::pair<std::string, std::string> &input, fq_index_t *const &ix_ref, fq_qc_t *const &qc_ref, Sink &out, const std::function<void()> &ready) {
+// The front end of an input: on the device for BGZF files (fq_frontend_*: the host reads compressed bytes, everything per byte of text
+// happens in HBM), on the host's threads for anything else (fq_fastq_*) -- and from the record on at which the device hands over (a
+// record that is not four plain lines, a file that ends inside a record: fq_frontend_handover gives host readers standing exactly there).
+fq_frontend_t *open_device_front_end(const Args &A, const std::string &f1, const std::string &f2, int device, int slot_mode, int stride) {
+  if (A.host_reader || A.frac < 1.0) return nullptr;       // (--frac_samp: the reference's generator is walked record by record, on the host)
+  fq_frontend_t *fe = nullptr;
+  const int rc = fq_frontend_open(device, f1.c_str(), f2.empty() ? nullptr : f2.c_str(), A.o.batch_pairs, A.chunk_pairs, slot_mode, stride, &fe);
+  if (rc == FQ_EIO) return nullptr;                          // not a regular BGZF file: the host reader's
+  if (rc) die("cannot start the front end on device " + std::to_string(device) + " (" + std::to_string(rc) + ")");
+  return fe;
+}
+void front_end_notice(fq_frontend_t *fe) {
+  fq_frontend_stats_t st;
+  fq_frontend_stats(fe, &st);
+  fprintf(stderr, "NOTICE - front end on the device: %lld pairs, %lld BGZF members (%lld left to the host's decoder), %.1f MB -> %.1f MB of text; inflate %.1f ms ; lines, records, keys, slots %.1f ms\n",
+          (long long)st.pairs, (long long)st.members, (long long)st.refused, 1e-6 * (double)st.comp_bytes, 1e-6 * (double)st.text_bytes, st.ms_inflate, st.ms_tokenise);
+}
+
+// One FASTQ pair (or one single-end file) through a device: an independent stream -- its own context (srand48, last_ii, position cache)
+// and read slots, as PairEndMapper / SingleEndMapper set them up per call (src/BwtMapper.cpp:232-262).
+// `ready`: called once the input's first chunk has been read and before anything needs the index, the QC consumer or the sink -- the
+// one-device command line stages the index (about a second: the filter bitmaps are built on the device) on another thread meanwhile.
+void align_input(Args A, const std::pair<std::string, std::string> &input, fq_index_t *const &ix_ref, fq_qc_t *const &qc_ref, Sink &out, const std::function<void()> &ready, int device) {
   int rc;
   A.fq1 = input.first; A.fq2 = input.second;
-  if (A.fq2.empty() || A.fq2 == "Empty") {
-    ready();
-    fq_index_t *const ix = ix_ref;
-    fq_qc_t *const qc = qc_ref;
-    // ---- BwtMapper::SingleEndMapper (src/BwtMapper.cpp:1266-1407): one file, its own srand48 stream; the reader hands out fresh zeroed
-    //      buffers (bwa_read_seq_with_hash, :350-475), so neither bases nor name tails of earlier reads linger
-    fprintf(stderr, "NOTICE - Processing Single End mapping\t%s\n", A.fq1.c_str());
-    if (qc) fq_qc_begin_file(qc, A.fq1.c_str(), A.fq1.c_str());      // FileStatCollector(fq1): both names are the one file
-    fq_opts_t so = A.o;
-    so.single_end = 1;
-    fq_ctx_t *ctx = nullptr;
-    rc = fq_ctx_create(ix, &so, (int32_t)A.chunk_pairs, &ctx);
-    if (rc) die("fq_ctx_create failed (" + std::to_string(rc) + "): option outside the supported range");
-    FastqReader r1(A.fq1, A.pack_threads, A.o.batch_pairs, FQ_FASTQ_SLOTS_FRESH, A.frac);
-    int stride = 0;
-    {
-      size_t l = 0;
-      struct stat s1;
-      if (stat(A.fq1.c_str(), &s1) == 0 && S_ISREG(s1.st_mode)) l = first_read_len(A.fq1);
-      stride = (int)((std::max<size_t>(l, (size_t)std::max(A.read_len, 16)) + 15) & ~(size_t)15);
-    }
-    const int name_stride = 304;
-    long long num_read = 0, filtered = 0, unmapped = 0;
-    std::vector<char> sam;
-    EndChunk bufs1[2];
-    fq_packed_batch_t *pk1 = nullptr;
-    if (fq_packed_create((int32_t)((A.chunk_pairs + 1) / 2), stride, &pk1)) die("out of pinned host memory for the packed batch");
-    fill_chunk(r1, bufs1[0], A.chunk_pairs, stride, name_stride);
-    for (int slot = 0;; slot ^= 1) {
-      EndChunk &e0 = bufs1[slot];
-      if (!e0.error.empty()) die(e0.error);
-      const int n = e0.n;
-      if (n == 0) break;
-      const bool last = e0.eof;
-      std::thread prefetch;
-      if (!last) prefetch = std::thread(fill_chunk, std::ref(r1), std::ref(bufs1[slot ^ 1]), A.chunk_pairs, stride, name_stride);
-      fq_read_batch_t in = {n, stride, e0.seq.data(), e0.qual.data(), e0.len.data(), e0.names.data(), (int32_t)name_stride, nullptr};
-      fq_result_batch_t res;
-      // the packed boundary, as for pairs: filter keys of every read cross PCIe, full rows of the surviving reads only
-      rc = fq_pack_single_reads_into(&in, A.pack_threads, pk1);
-      if (rc) die("fq_pack_single_reads_into failed (" + std::to_string(rc) + ")");
-      rc = fq_align_packed(ctx, pk1, &res);
-      if (rc) die(std::string("fq_align_packed failed: ") + fq_ctx_last_error(ctx));
-      if (qc && (rc = fq_qc_add_last(qc, ctx))) die(std::string("QC consumer failed: ") + fq_qc_last_error(qc));
-      if (A.sam_out) {
-        const int64_t sz = fq_sam_format_last(ctx, nullptr, 0);
-        sam.resize((size_t)sz + 1);
-        fq_sam_format_last(ctx, sam.data(), sz + 1);
-        out.sam(sam.data(), (size_t)sz);
-      } else out.bam_add(ctx);
-      num_read += n; filtered += res.n_both_filtered; unmapped += res.n_both_unmapped;
-      fprintf(stderr, "NOTICE - %lld sequences are loaded.\n", num_read);
-      if (prefetch.joinable()) prefetch.join();
-      if (last) break;
-    }
-    out.flush();
-    notice("%lld sequences are filtered.", filtered);
-    notice("%lld sequences are unmapped.", unmapped);
-    if (qc) fq_qc_end_file(qc);
-    fq_ctx_destroy(ctx);
-    fq_packed_free(pk1);
-    return;
-  }
-  fprintf(stderr, "NOTICE - Processing Pair End mapping\t%s\t%s\n", A.fq1.c_str(), A.fq2.c_str());
-  const int slot_mode = A.clean_names ? FQ_FASTQ_SLOTS_CLEAN_NAMES : FQ_FASTQ_SLOTS_REUSED;
-  FastqReader r1(A.fq1, std::max(1, A.pack_threads / 2), A.o.batch_pairs, slot_mode, A.frac), r2(A.fq2, std::max(1, A.pack_threads / 2), A.o.batch_pairs, slot_mode, A.frac);
+  const bool se = A.fq2.empty() || A.fq2 == "Empty";
+  if (se) A.fq2.clear();
+  if (se) fprintf(stderr, "NOTICE - Processing Single End mapping\t%s\n", A.fq1.c_str());
+  else fprintf(stderr, "NOTICE - Processing Pair End mapping\t%s\t%s\n", A.fq1.c_str(), A.fq2.c_str());
+  // BwtMapper::SingleEndMapper (src/BwtMapper.cpp:1266-1407): its reader hands out fresh zeroed buffers (bwa_read_seq_with_hash, :350-475),
+  // so neither bases nor name tails of earlier reads linger
+  const int slot_mode = se ? FQ_FASTQ_SLOTS_FRESH : A.clean_names ? FQ_FASTQ_SLOTS_CLEAN_NAMES : FQ_FASTQ_SLOTS_REUSED;
   int stride = 0;
   {   // rows hold read_len bases, or the first records' if those are longer -- probed only in regular files (a pipe cannot be read twice:
       // there a longer read is an error that asks for --read_len)
     size_t l = 0;
     struct stat s1, s2;
-    if (stat(A.fq1.c_str(), &s1) == 0 && S_ISREG(s1.st_mode) && stat(A.fq2.c_str(), &s2) == 0 && S_ISREG(s2.st_mode))
-      l = std::max(first_read_len(A.fq1), first_read_len(A.fq2));
+    if (stat(A.fq1.c_str(), &s1) == 0 && S_ISREG(s1.st_mode) && (se || (stat(A.fq2.c_str(), &s2) == 0 && S_ISREG(s2.st_mode))))
+      l = std::max(first_read_len(A.fq1), se ? (size_t)0 : first_read_len(A.fq2));
     stride = (int)((std::max<size_t>(l, (size_t)std::max(A.read_len, 16)) + 15) & ~(size_t)15);
   }
   const int name_stride = 304;   // the reference's name buffers hold 302 bytes (bwaseqio.c:233)
-  long long num_read = 0, filtered = 0, unmapped = 0, num_base = 0, order_checked_reads = 0;
-  double qc_ms = 0, out_ms = 0;
+  const int reader_threads = se ? A.pack_threads : std::max(1, A.pack_threads / 2);
+  long long num_read = 0, filtered = 0, unmapped = 0, order_checked_reads = 0;
+  double qc_ms = 0, out_ms = 0, read_all_ms = 0, read_wait_ms = 0, align_ms = 0, read_ms = 0, pack_ms = 0;
   std::vector<char> sam;
-  EndChunk bufs[2][2];   // [slot][end]
-  // the two ends of a chunk back to back in one buffer, as fq_read_batch_t wants them ([end][pair][stride]): each file's reader
-  // fills its half in place (end 1 behind the chunk_pairs rows of end 0; a short last chunk moves it down)
-  RawBuf<uint8_t> pair_seq[2], pair_qual[2];
-  for (int sl = 0; sl < 2; ++sl) {
-    pair_seq[sl].resize((size_t)2 * A.chunk_pairs * stride); pair_qual[sl].resize((size_t)2 * A.chunk_pairs * stride);
-    for (int e = 0; e < 2; ++e) { bufs[sl][e].ext_seq = pair_seq[sl].data() + (size_t)e * A.chunk_pairs * stride; bufs[sl][e].ext_qual = pair_qual[sl].data() + (size_t)e * A.chunk_pairs * stride; }
-  }
-  double read_all_ms = 0, read_wait_ms = 0, align_ms = 0;   // every chunk's read (on the prefetch thread), and what of it the loop had to wait for
-  auto read_both = [&](int slot) {
-    const auto tr0 = std::chrono::steady_clock::now();
-    std::thread t0(fill_chunk, std::ref(r1), std::ref(bufs[slot][0]), A.chunk_pairs, stride, name_stride);
-    std::thread t1(fill_chunk, std::ref(r2), std::ref(bufs[slot][1]), A.chunk_pairs, stride, name_stride);
-    t0.join(); t1.join();
-    read_all_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count();
-  };
-  double read_ms = 0, pack_ms = 0;
-  { const auto t0 = std::chrono::steady_clock::now(); read_both(0); read_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
-  ready();                           // from here on: the index, the QC consumer, the sink
-  fq_index_t *const ix = ix_ref;
-  fq_qc_t *const qc = qc_ref;
-  if (qc) fq_qc_begin_file(qc, A.fq1.c_str(), A.fq2.c_str());
+  fq_index_t *ix = nullptr;
+  fq_qc_t *qc = nullptr;
   fq_ctx_t *ctx = nullptr;
-  rc = fq_ctx_create(ix, &A.o, (int32_t)A.chunk_pairs, &ctx);
-  if (rc) die("fq_ctx_create failed (" + std::to_string(rc) + "): option outside the supported range");
-  fq_packed_batch_t *pk = nullptr;   // packed-batch storage, reused from chunk to chunk (pinned once)
-  if (fq_packed_create((int32_t)A.chunk_pairs, stride, &pk)) die("out of pinned host memory for the packed batch");
-  for (int slot = 0;; slot ^= 1) {
-    EndChunk &e0 = bufs[slot][0], &e1 = bufs[slot][1];
-    if (!e0.error.empty()) die(e0.error);
-    if (!e1.error.empty()) die(e1.error);
-    const int n = std::min(e0.n, e1.n);
-    if (n == 0) break;
-    const bool last = e0.eof || e1.eof || e0.n != e1.n;
-    std::thread prefetch;
-    if (!last) prefetch = std::thread(read_both, slot ^ 1);          // next chunk while this one is on the device
-    // src/BwtMapper.cpp:2087-2092: the first pair of a reference batch is compared when the running read count is a
-    // multiple of the batch size (every full batch; a short last batch normally is not checked), over read_len name bytes.
-    // Mates whose names differ elsewhere pass, each printed under its own name (the reference's example input has such pairs).
-    for (int i = 0; i < n; i += A.o.batch_pairs) {
-      order_checked_reads += 2LL * std::min<long long>(A.o.batch_pairs, n - i);
-      if (order_checked_reads % A.o.batch_pairs == 0 &&
-          strncmp(&e0.names[(size_t)i * name_stride], &e1.names[(size_t)i * name_stride], (size_t)A.read_len) != 0)
-        die("Abort, please make sure input pair of fastq files are in the same order!");
-    }
-    if ((long long)n < A.chunk_pairs) {   // a short (last) chunk: end 1 moves down behind the n rows of end 0
-      memmove(pair_seq[slot].data() + (size_t)n * stride, pair_seq[slot].data() + (size_t)A.chunk_pairs * stride, (size_t)n * stride);
-      memmove(pair_qual[slot].data() + (size_t)n * stride, pair_qual[slot].data() + (size_t)A.chunk_pairs * stride, (size_t)n * stride);
-    }
-    std::vector<int32_t> len((size_t)2 * n);
-    for (int e = 0; e < 2; ++e) memcpy(&len[(size_t)e * n], bufs[slot][e].len.data(), (size_t)n * 4);
-    fq_read_batch_t in = {n, stride, pair_seq[slot].data(), pair_qual[slot].data(), len.data(), e0.names.data(), (int32_t)name_stride, e1.names.data()};
-    fq_result_batch_t res;
-    // the packed boundary: 24 bytes of filter keys per read cross PCIe, full rows only for the surviving pairs
-    const auto tp0 = std::chrono::steady_clock::now();
-    rc = fq_pack_reads_into(&in, A.pack_threads, pk);
-    pack_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
-    if (rc) die("fq_pack_reads failed (" + std::to_string(rc) + ")");
-    const auto ta0 = std::chrono::steady_clock::now();
-    rc = fq_align_packed(ctx, pk, &res);
-    if (rc) die(std::string("fq_align_packed failed: ") + fq_ctx_last_error(ctx));
-    align_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta0).count();
-    // the consumers, in the reference's order: StatCollector, then the record writer (src/BwtMapper.cpp:2047-2050, 2075-2085)
+  bool started = false;
+  auto start = [&] {                    // from here on: the index, the QC consumer, the sink
+    if (started) return;
+    started = true;
+    ready();
+    ix = ix_ref; qc = qc_ref;
+    if (qc) fq_qc_begin_file(qc, A.fq1.c_str(), se ? A.fq1.c_str() : A.fq2.c_str());      // FileStatCollector(fq1[, fq2]): a single file is named twice
+    fq_opts_t o = A.o;
+    o.single_end = se ? 1 : 0;
+    const int crc = fq_ctx_create(ix, &o, (int32_t)A.chunk_pairs, &ctx);
+    if (crc) die("fq_ctx_create failed (" + std::to_string(crc) + "): option outside the supported range");
+  };
+  // the consumers of a call's records, in the reference's order: StatCollector, then the record writer (src/BwtMapper.cpp:2047-2050, 2075-2085)
+  auto consume = [&](const fq_result_batch_t &res, long long n_reads) {
     const auto tc0 = std::chrono::steady_clock::now();
     if (qc && (rc = fq_qc_add_last(qc, ctx))) die(std::string("QC consumer failed: ") + fq_qc_last_error(qc));
     const auto tc1 = std::chrono::steady_clock::now();
@@ -360,18 +280,152 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
     } else out.bam_add(ctx);
     const auto tc2 = std::chrono::steady_clock::now();
     qc_ms += std::chrono::duration<double, std::milli>(tc1 - tc0).count(); out_ms += std::chrono::duration<double, std::milli>(tc2 - tc1).count();
-    num_read += 2LL * n; filtered += res.n_both_filtered; unmapped += res.n_both_unmapped; num_base += res.n_bases;
-    fprintf(stderr, "NOTICE - %lld sequences are processed.\n", num_read);
-    const auto tw0 = std::chrono::steady_clock::now();
-    if (prefetch.joinable()) prefetch.join();
-    read_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
-    if (last) break;
+    num_read += n_reads; filtered += res.n_both_filtered; unmapped += res.n_both_unmapped;
+    fprintf(stderr, se ? "NOTICE - %lld sequences are loaded.\n" : "NOTICE - %lld sequences are processed.\n", num_read);
+  };
+  // src/BwtMapper.cpp:2087-2092: the first pair of a reference batch is compared when the running read count is a multiple of the batch
+  // size (every full batch; a short last batch normally is not checked), over read_len name bytes.  Mates whose names differ elsewhere
+  // pass, each printed under its own name (the reference's example input has such pairs).
+  auto order_check = [&](int n, const std::function<const char *(int, int)> &first_name) {
+    for (int i = 0; i < n; i += A.o.batch_pairs) {
+      order_checked_reads += 2LL * std::min<long long>(A.o.batch_pairs, n - i);
+      if (order_checked_reads % A.o.batch_pairs == 0 && strncmp(first_name(i / A.o.batch_pairs, 0), first_name(i / A.o.batch_pairs, 1), (size_t)A.read_len) != 0)
+        die("Abort, please make sure input pair of fastq files are in the same order!");
+    }
+  };
+
+  // ---- the device's part of the stream ----
+  std::unique_ptr<FastqReader> r1, r2;
+  bool unequal_on_device = false;
+  fq_frontend_t *fe = open_device_front_end(A, A.fq1, A.fq2, device, slot_mode, stride);
+  if (fe) {
+    for (;;) {
+      const auto tr0 = std::chrono::steady_clock::now();
+      fq_text_batch_t *tb = nullptr;
+      const int64_t n = fq_frontend_next(fe, &tb);
+      const double waited = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count();
+      if (!started) read_ms += waited; else read_wait_ms += waited;
+      if (n == FQ_EFALLBACK) {
+        fq_fastq_t *h[2] = {nullptr, nullptr};
+        if ((rc = fq_frontend_handover(fe, reader_threads, h))) die("the device front end could not hand " + A.fq1 + " over to the host reader (" + std::to_string(rc) + ")");
+        r1.reset(new FastqReader(A.fq1, h[0]));
+        if (!se) r2.reset(new FastqReader(A.fq2, h[1]));
+        if (A.frac < 1.0) die("internal: sampling on the device path");
+        fprintf(stderr, "NOTICE - the FASTQ text from record %lld on is not four plain lines per record: read on by the host's reader\n", num_read / (se ? 1 : 2) + 1);
+        break;
+      }
+      if (n < 0) die(std::string(fq_frontend_last_error(fe)).empty() ? "the device front end failed (" + std::to_string(n) + ")" : fq_frontend_last_error(fe));
+      if (n == 0) break;
+      start();
+      if (!se) order_check((int)n, [&](int sb, int e) { const char *nm = fq_text_batch_first_name(tb, sb, e); return nm ? nm : ""; });
+      fq_result_batch_t res;
+      const auto ta0 = std::chrono::steady_clock::now();
+      if ((rc = fq_align_text(ctx, tb, &res))) die(std::string("fq_align_text failed: ") + fq_ctx_last_error(ctx));
+      align_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta0).count();
+      consume(res, se ? n : 2 * n);
+      fq_frontend_release(fe, tb);
+    }
+    unequal_on_device = fq_frontend_unequal_lengths(fe) != 0;
+    front_end_notice(fe);
+  } else {
+    r1.reset(new FastqReader(A.fq1, reader_threads, A.o.batch_pairs, slot_mode, A.frac));
+    if (!se) r2.reset(new FastqReader(A.fq2, reader_threads, A.o.batch_pairs, slot_mode, A.frac));
   }
+
+  // ---- the host readers' part (all of it for files that are not BGZF): one reader thread per file tokenises the next chunk into flat
+  //      buffers while the device aligns the current one (the reference, too, decodes the two files on two IO threads: BwtMapper.cpp:1873-1935)
+  if (r1 && se) {
+    EndChunk bufs1[2];
+    fq_packed_batch_t *pk1 = nullptr;
+    if (fq_packed_create((int32_t)((A.chunk_pairs + 1) / 2), stride, &pk1)) die("out of pinned host memory for the packed batch");
+    fill_chunk(*r1, bufs1[0], A.chunk_pairs, stride, name_stride);
+    for (int slot = 0;; slot ^= 1) {
+      EndChunk &e0 = bufs1[slot];
+      if (!e0.error.empty()) die(e0.error);
+      const int n = e0.n;
+      if (n == 0) break;
+      start();
+      const bool last = e0.eof;
+      std::thread prefetch;
+      if (!last) prefetch = std::thread(fill_chunk, std::ref(*r1), std::ref(bufs1[slot ^ 1]), A.chunk_pairs, stride, name_stride);
+      fq_read_batch_t in = {n, stride, e0.seq.data(), e0.qual.data(), e0.len.data(), e0.names.data(), (int32_t)name_stride, nullptr};
+      fq_result_batch_t res;
+      // the packed boundary, as for pairs: filter keys of every read cross PCIe, full rows of the surviving reads only
+      rc = fq_pack_single_reads_into(&in, A.pack_threads, pk1);
+      if (rc) die("fq_pack_single_reads_into failed (" + std::to_string(rc) + ")");
+      rc = fq_align_packed(ctx, pk1, &res);
+      if (rc) die(std::string("fq_align_packed failed: ") + fq_ctx_last_error(ctx));
+      consume(res, n);
+      if (prefetch.joinable()) prefetch.join();
+      if (last) break;
+    }
+    fq_packed_free(pk1);
+  } else if (r1) {
+    EndChunk bufs[2][2];   // [slot][end]
+    // the two ends of a chunk back to back in one buffer, as fq_read_batch_t wants them ([end][pair][stride]): each file's reader
+    // fills its half in place (end 1 behind the chunk_pairs rows of end 0; a short last chunk moves it down)
+    RawBuf<uint8_t> pair_seq[2], pair_qual[2];
+    for (int sl = 0; sl < 2; ++sl) {
+      pair_seq[sl].resize((size_t)2 * A.chunk_pairs * stride); pair_qual[sl].resize((size_t)2 * A.chunk_pairs * stride);
+      for (int e = 0; e < 2; ++e) { bufs[sl][e].ext_seq = pair_seq[sl].data() + (size_t)e * A.chunk_pairs * stride; bufs[sl][e].ext_qual = pair_qual[sl].data() + (size_t)e * A.chunk_pairs * stride; }
+    }
+    auto read_both = [&](int slot) {
+      const auto tr0 = std::chrono::steady_clock::now();
+      std::thread t0(fill_chunk, std::ref(*r1), std::ref(bufs[slot][0]), A.chunk_pairs, stride, name_stride);
+      std::thread t1(fill_chunk, std::ref(*r2), std::ref(bufs[slot][1]), A.chunk_pairs, stride, name_stride);
+      t0.join(); t1.join();
+      read_all_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count();
+    };
+    { const auto t0 = std::chrono::steady_clock::now(); read_both(0); read_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
+    fq_packed_batch_t *pk = nullptr;   // packed-batch storage, reused from chunk to chunk (pinned once)
+    for (int slot = 0;; slot ^= 1) {
+      EndChunk &e0 = bufs[slot][0], &e1 = bufs[slot][1];
+      if (!e0.error.empty()) die(e0.error);
+      if (!e1.error.empty()) die(e1.error);
+      const int n = std::min(e0.n, e1.n);
+      if (n == 0) break;
+      start();
+      if (!pk && fq_packed_create((int32_t)A.chunk_pairs, stride, &pk)) die("out of pinned host memory for the packed batch");
+      const bool last = e0.eof || e1.eof || e0.n != e1.n;
+      std::thread prefetch;
+      if (!last) prefetch = std::thread(read_both, slot ^ 1);          // next chunk while this one is on the device
+      order_check(n, [&](int sb, int e) { return (const char *)&(e ? e1 : e0).names[(size_t)sb * A.o.batch_pairs * name_stride]; });
+      if ((long long)n < A.chunk_pairs) {   // a short (last) chunk: end 1 moves down behind the n rows of end 0
+        memmove(pair_seq[slot].data() + (size_t)n * stride, pair_seq[slot].data() + (size_t)A.chunk_pairs * stride, (size_t)n * stride);
+        memmove(pair_qual[slot].data() + (size_t)n * stride, pair_qual[slot].data() + (size_t)A.chunk_pairs * stride, (size_t)n * stride);
+      }
+      std::vector<int32_t> len((size_t)2 * n);
+      for (int e = 0; e < 2; ++e) memcpy(&len[(size_t)e * n], bufs[slot][e].len.data(), (size_t)n * 4);
+      fq_read_batch_t in = {n, stride, pair_seq[slot].data(), pair_qual[slot].data(), len.data(), e0.names.data(), (int32_t)name_stride, e1.names.data()};
+      fq_result_batch_t res;
+      // the packed boundary: 24 bytes of filter keys per read cross PCIe, full rows only for the surviving pairs
+      const auto tp0 = std::chrono::steady_clock::now();
+      rc = fq_pack_reads_into(&in, A.pack_threads, pk);
+      pack_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp0).count();
+      if (rc) die("fq_pack_reads failed (" + std::to_string(rc) + ")");
+      const auto ta0 = std::chrono::steady_clock::now();
+      rc = fq_align_packed(ctx, pk, &res);
+      if (rc) die(std::string("fq_align_packed failed: ") + fq_ctx_last_error(ctx));
+      align_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta0).count();
+      consume(res, 2LL * n);
+      const auto tw0 = std::chrono::steady_clock::now();
+      if (prefetch.joinable()) prefetch.join();
+      read_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tw0).count();
+      if (last) break;
+    }
+    if (pk) fq_packed_free(pk);
+  }
+  start();                              // (an input without a record: the consumers and the index are needed all the same)
   out.flush();
-  unequal_lengths_notice(A, r1.h, r2.h);
-  notice("%lld sequences are loaded.", num_read);
-  notice("%lld sequences are filtered.", filtered * 2);
-  notice("%lld sequences are unmapped.", unmapped * 2);
+  unequal_lengths_notice(A, r1 ? r1->h : nullptr, r2 ? r2->h : nullptr, unequal_on_device);
+  if (se) {
+    notice("%lld sequences are filtered.", filtered);
+    notice("%lld sequences are unmapped.", unmapped);
+  } else {
+    notice("%lld sequences are loaded.", num_read);
+    notice("%lld sequences are filtered.", filtered * 2);
+    notice("%lld sequences are unmapped.", unmapped * 2);
+  }
   fq_stats_t st;
   fq_stats_get(ctx, &st);
   fprintf(stderr, "NOTICE - device time (ms): prep %.1f width %.1f gap %.1f sa %.1f sw %.1f refine %.1f ; host %.1f ; wall %.1f\n", st.kernel_ms[0],
@@ -380,8 +434,8 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
   fprintf(stderr, "NOTICE - reading (ms): all chunks %.1f ; waited for %.1f ; alignment calls %.1f\n", read_all_ms, read_wait_ms, align_ms);
   if (qc) fq_qc_end_file(qc);
   fq_ctx_destroy(ctx);
-  fq_packed_free(pk);
-  }
+  if (fe) fq_frontend_close(fe);
+}
 
 // ---- ONE FASTQ pair over several devices: chunks of whole reference batches are dealt round-robin; every device runs filter,
 //      search and SA walks of its chunk at once; the stream's order-dependent state -- the drand48 stream (srand48 once per FASTQ pair,
@@ -613,6 +667,7 @@ int main(int argc, char **argv) {
     else if (f == "--read_len") A.read_len = atoi(need(""));
     else if (f == "--clean_names") A.clean_names = true;
     else if (f == "--strict_reference") A.strict = true;
+    else if (f == "--host_reader") A.host_reader = true;
     else if (f == "--batch_pairs") A.o.batch_pairs = atoi(need(""));   // READ_BUFFER_SIZE of the run to reproduce (default 262144)
     else if (f == "--device") A.device = atoi(need(""));
     else if (f == "--devices") A.devices = need("");
@@ -730,7 +785,7 @@ int main(int argc, char **argv) {
         fwrite(h.data(), 1, (size_t)n, stdout);
       }
     };
-    for (const auto &input : inputs) align_input(A, input, K.ix, K.qc, out, ready);
+    for (const auto &input : inputs) align_input(A, input, K.ix, K.qc, out, ready, K.device);
     ready();
     if (K.bam && fq_bam_close(K.bam)) die("closing " + A.out_prefix + ".bam failed");
     if (K.qc) {
@@ -794,7 +849,7 @@ int main(int argc, char **argv) {
         if (!f) die("cannot create " + out.what);
         if (A.sam_out) out.sam_fp = f; else out.bam_fp = f;
         fprintf(stderr, "NOTICE - device %d takes line %zu of the list\n", K.device, i + 1);
-        align_input(AW, inputs[i], K.ix, K.qc, out, [] {});
+        align_input(AW, inputs[i], K.ix, K.qc, out, [] {}, K.device);
         if (fclose(f)) die("writing " + out.what + " failed");
         if (K.qc) {
           const int64_t need = fq_qc_state_export(K.qc, nullptr, 0);
