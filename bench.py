@@ -537,9 +537,9 @@ def main() -> None:
             x.join()
         dt = time.perf_counter() - t0
         assert got == [nfe, nfe] and np.array_equal(rows[0][0][:, :L], cpu_batch.seq[0, :nfe, :L]) and np.array_equal(rows[1][1][:, :L], qual_fe[1])
-        fe["tokenise_inflate_pairs_per_s"] = round(nfe / dt, 1)
-        fe["tokenise_inflate"] = {"threads_per_file": rt, "s": round(dt, 3), "text_GBps": round(text_bytes / dt / 1e9, 3),
-                                  "inflate": "zlib" if os.environ.get("FASTQUICK_ZLIB_INFLATE", "0") not in ("", "0") else "fq_inflate.h (zlib for members it refuses)"}
+        fe["host_reader_pairs_per_s"] = round(nfe / dt, 1)        # (round 4's tokenise_inflate_pairs_per_s: the front end on the host's threads)
+        fe["host_reader"] = {"threads_per_file": rt, "s": round(dt, 3), "text_GBps": round(text_bytes / dt / 1e9, 3),
+                             "inflate": "zlib" if os.environ.get("FASTQUICK_ZLIB_INFLATE", "0") not in ("", "0") else "fq_inflate.h (zlib for members it refuses)"}
         del rows
         exe = os.path.join(ROOT, "fastquick_amd", "bin", "FASTQuick_amd")
         if os.path.exists(exe):
@@ -572,6 +572,39 @@ def main() -> None:
                 synth.write_param(pre, ref, 1000)
                 with open(pre + ".genome.fa.fai", "w") as fh:
                     fh.write("1\t%d\t3\t60\t61\n" % len(ref.genome))
+                # ---- the front end on the device (fq_frontend_*): BGZF files -> filter keys, lengths, names of every read resident in HBM, with
+                #      nothing of the text touched by the host (it reads compressed bytes and walks member headers).  tokenise_inflate_pairs_per_s =
+                #      pairs / wall time from opening the two files to the last batch (batches released as they come: no alignment beside it)
+                import ctypes
+                dfe = api.DeviceFrontEnd(big[0], big[1], batch_pairs=262144, chunk_pairs=16 * 262144, slot_mode=0, max_read_len=stride)
+                t0 = time.perf_counter()
+                got_pairs = 0
+                while True:
+                    m_, b_ = dfe.next()
+                    if m_ <= 0:
+                        break
+                    got_pairs += m_
+                    dfe.release(b_)
+                dt_fe = time.perf_counter() - t0
+                fst = dfe.stats()
+                dfe.close()
+                assert m_ == 0 and got_pairs == nfe * copies, (m_, got_pairs)
+                fe["tokenise_inflate_pairs_per_s"] = round(got_pairs / dt_fe, 1)
+                tb_, cb_ = float(fst["text_bytes"]), float(fst["comp_bytes"])
+
+                def fe_roof(ms, byts, launches):
+                    g_ = byts / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                    return {"ms_total": round(ms, 2), "launch_groups": int(launches), "bytes": int(byts), "GBps": round(g_, 2), "frac_of_hbm_peak": round(g_ / HBM_PEAK_GBS, 5)}
+                rows_ = 2.0 * got_pairs
+                fe["tokenise_inflate"] = {"where": "device (k_inflate_bgzf + line index + record / key / slot kernels)", "pairs": got_pairs, "s": round(dt_fe, 3),
+                                          "text_GBps": round(tb_ / dt_fe / 1e9, 3), "file_GBps": round(cb_ / dt_fe / 1e9, 3),
+                                          "members": fst["members"], "members_left_to_the_host_decoder": fst["refused"], "chunks": fst["chunks"],
+                                          # bytes in + out of each kernel group / its summed device time (HIP events on the front end's stream)
+                                          "kernel_rooflines": {
+                                              "fq_inflate": dict(fe_roof(fst["ms_inflate"], tb_ + cb_, fst["inflate_launches"]), model="compressed bytes in + text bytes out; bound by instruction issue (one wavefront decodes one member's symbols in order), not by HBM"),
+                                              "fq_lines": dict(fe_roof(fst["ms_lines"], 2 * tb_ + 4 * 4 * rows_, fst["chunks"]), model="text read twice (count, fill) + 4 B per line end out"),
+                                              "fq_records": dict(fe_roof(fst["ms_records"], 16 * rows_ + 16 * rows_ + (150 + 12) * rows_ + 26 * rows_, fst["chunks"]), model="4 line ends in, 16 B record + 2 B length out; base line + name in, 24 B of filter keys out"),
+                                              "fq_slots": dict(fe_roof(fst["ms_slots"], (16 + 96 + 96 + 12 + 12 + 16) * rows_, fst["chunks"]), model="record in, 96 B of the slot's bases in and out, name in, slot name + printed name out")}}
                 steady = {"pairs": nfe * copies, "copies": copies, "requested_bytes": need}
                 for label, extra in (("sam_out", ["--sam_out"]), ("bam_and_qc", [])):
                     cmd2 = [exe, "align", "--index_prefix", pre[:-len(".FASTQuick.fa")], "--fastq_1", big[0], "--fastq_2", big[1], "--out_prefix", os.path.join(fdir, "big_out"),

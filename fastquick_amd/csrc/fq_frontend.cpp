@@ -267,8 +267,8 @@ struct fq_frontend {
   int64_t pairs_done = 0;
   int next_slot = 0;
   // totals (fq_frontend_stats)
-  double ms_inflate = 0, ms_tokenise = 0;
-  int64_t n_members = 0, n_refused = 0, text_bytes = 0, comp_bytes = 0;
+  double ms_inflate = 0, ms_tokenise = 0, ms_lines = 0, ms_records = 0, ms_slots = 0;
+  int64_t n_members = 0, n_refused = 0, text_bytes = 0, comp_bytes = 0, n_launch_inflate = 0, n_chunks = 0;
   ~fq_frontend();
 };
 
@@ -470,6 +470,7 @@ void producer_main(fq_frontend *fe) {
     comp_k = (comp_k + 1) % 3;
     // ---- line ends ----
     fqdev::time_begin(1);
+    bool t1_open = true;
     for (int e = 0; e < NF; ++e) {
       FileSide &F = fe->f[e];
       const size_t cap = (size_t)(4 * (fe->chunk_pairs + B) + 64);
@@ -477,6 +478,7 @@ void producer_main(fq_frontend *fe) {
       if (fqdev::dzero(F.d_text[slot].p + n_text[e], 256)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
       if (fqdev::launch_nl_index(F.d_text[slot].p, (uint32_t)n_text[e], F.d_nl.p, (uint32_t)cap, F.d_stat.p + FQT_N_STAT)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
     }
+    fqdev::time_end(1); t1_open = false; (void)t1_open;
     if (!fe->h_stat.ensure(64)) { finish(FQ_ENOMEM, "out of pinned host memory", false); return; }
     for (int e = 0; e < NF; ++e) if (fqdev::copy_pinned(fe->h_stat.p + 32 * e, fe->f[e].d_stat.p + FQT_N_STAT, 4, 0)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
     if (fqdev::sync()) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
@@ -510,7 +512,9 @@ void producer_main(fq_frontend *fe) {
         FqTokArgs a{};
         a.text = F.d_text[slot].p; a.nl = F.d_nl.p; a.n_rec = (int)n; a.row0 = (int)(e * n); a.n_rows = n_rows; a.max_len = fe->max_len;
         a.rec = fe->d_rec[slot].p; a.head = fe->d_head[slot].p; a.hlen = fe->d_hlen[slot].p; a.stat = F.d_stat.p;
+        fqdev::time_begin(2);
         if (fqdev::launch_tok_rec(a) || fqdev::launch_tok_pieces(a)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+        fqdev::time_end(2);
         if (fqdev::copy_pinned(fe->h_stat.p + 32 * e, F.d_stat.p, 4 * FQT_N_STAT, 0)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
       }
       if (fqdev::sync()) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
@@ -542,8 +546,10 @@ void producer_main(fq_frontend *fe) {
         s.text = F.d_text[slot].p; s.rec = fe->d_rec[slot].p; s.n_rec = (int)n; s.row0 = (int)(e * n); s.n_rows = n_rows; s.g0 = F.records_done;
         s.n_slots = n_slots; s.mode = fe->slot_mode; s.slot_base = F.d_slot_base.p; s.slot_len = F.d_slot_len.p; s.slot_name = F.d_slot_name.p;
         s.head = fe->d_head[slot].p; s.names = fe->d_names[slot].p; s.name_stride = name_stride; s.stat = F.d_stat.p;
+        fqdev::time_begin(3);
         if (fe->slot_mode != FQ_FASTQ_SLOTS_FRESH && fqdev::launch_slot_bases(s)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
         if (fqdev::launch_slot_names(s)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+        fqdev::time_end(3);
         if (fqdev::copy_pinned(fe->h_stat.p + 32 * e, F.d_stat.p, 4 * FQT_N_STAT, 0)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
       }
       // the names of every reference batch's first pair, for the caller's order check
@@ -558,7 +564,6 @@ void producer_main(fq_frontend *fe) {
       TB.d_text[0] = fe->f[0].d_text[slot].p; TB.d_text[1] = NF > 1 ? fe->f[1].d_text[slot].p : nullptr;
       TB.d_rec = fe->d_rec[slot].p; TB.d_head = fe->d_head[slot].p; TB.d_hlen = fe->d_hlen[slot].p; TB.d_names = fe->d_names[slot].p;
     }
-    fqdev::time_end(1);
     // ---- what stays for the next chunk: the text behind record n ----
     for (int e = 0; e < NF; ++e) {
       FileSide &F = fe->f[e];
@@ -584,7 +589,8 @@ void producer_main(fq_frontend *fe) {
     }
     fe->pairs_done += n;
     fqdev::time_collect(t_ms, t_n, FQ_K_COUNT);
-    fe->ms_inflate += t_ms[0]; fe->ms_tokenise += t_ms[1];
+    fe->ms_inflate += t_ms[0]; fe->ms_lines += t_ms[1]; fe->ms_records += t_ms[2]; fe->ms_slots += t_ms[3]; fe->ms_tokenise += t_ms[1] + t_ms[2] + t_ms[3];
+    fe->n_launch_inflate += (int64_t)t_n[0]; fe->n_chunks += 1;
     fe->n_members += TB.members; fe->n_refused += TB.refused; fe->text_bytes += TB.text_bytes; fe->comp_bytes += TB.comp_bytes;
     // ---- the end of the stream, or of the device's part of it ----
     bool stream_end = false;
@@ -749,6 +755,7 @@ extern "C" void fq_frontend_stats(const fq_frontend_t *fe, fq_frontend_stats_t *
   if (!fe || !s) return;
   s->ms_inflate = fe->ms_inflate; s->ms_tokenise = fe->ms_tokenise; s->members = fe->n_members; s->refused = fe->n_refused;
   s->text_bytes = fe->text_bytes; s->comp_bytes = fe->comp_bytes; s->pairs = fe->pairs_done;
+  s->ms_lines = fe->ms_lines; s->ms_records = fe->ms_records; s->ms_slots = fe->ms_slots; s->inflate_launches = fe->n_launch_inflate; s->chunks = fe->n_chunks;
 }
 // batch accessors
 extern "C" int32_t fq_text_batch_pairs(const fq_text_batch_t *b) { return b ? b->n_pairs : 0; }

@@ -310,7 +310,12 @@ int fq_bgzf_inflate_device(int device, const uint8_t *file, size_t n, uint8_t *o
 #define FQ_EFALLBACK (-6)
 typedef struct fq_frontend fq_frontend_t;
 typedef struct fq_text_batch fq_text_batch_t;
-typedef struct { double ms_inflate, ms_tokenise; int64_t members, refused, text_bytes, comp_bytes, pairs; } fq_frontend_stats_t;
+typedef struct {
+  double ms_inflate, ms_tokenise;        /* device time (HIP events on the front end's stream): k_inflate_bgzf; everything behind it */
+  int64_t members, refused, text_bytes, comp_bytes, pairs;
+  double ms_lines, ms_records, ms_slots; /* ms_tokenise by kernel group: line index; record checks + filter keys; read slots + names */
+  int64_t inflate_launches, chunks;
+} fq_frontend_stats_t;
 int fq_frontend_open(int device, const char *fq1, const char *fq2, int32_t batch_pairs, int64_t chunk_pairs, int32_t slot_mode, int32_t max_read_len, fq_frontend_t **out);
 int64_t fq_frontend_next(fq_frontend_t *fe, fq_text_batch_t **out);
 void fq_frontend_release(fq_frontend_t *fe, fq_text_batch_t *b);

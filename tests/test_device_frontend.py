@@ -198,3 +198,134 @@ def test_front_end_batches_align_to_the_references_output(tag, golden_cases, lib
     diffs = [d for d in ob.diff_stage_files(g["stages"], st)]
     assert not diffs, "\n".join(diffs)
     assert open(sam, "rb").read() == open(g["sam"], "rb").read()
+
+
+def host_arrays(lib, fq, batch_pairs, slot_mode, stride=256, se=False):
+    """the host path on the same files: fq_fastq_read (kseq_read3_fpc's tokens, read-slot history) + fq_pack_reads_into -> head, len, names"""
+    import ctypes as C
+    files = [api.FastqFile(p, threads=2, batch_pairs=batch_pairs, slot_mode=slot_mode, stride=stride, name_stride=304, lib=lib) for p in (fq[:1] if se else fq)]
+    rows = [f.read(1 << 20) for f in files]
+    for f in files:
+        f.close()
+    n = min(len(r[2]) for r in rows)
+    seq = np.stack([r[0][:n] for r in rows]); qual = np.stack([r[1][:n] for r in rows]); lens = np.stack([r[2][:n] for r in rows])
+    hp = api.HostPacked(seq, qual, lens, None, lib=lib)
+    pb = hp.p.contents
+    rows_n = n * len(files)
+    head = np.ctypeslib.as_array(C.cast(pb.head, C.POINTER(C.c_uint64)), shape=(3 * rows_n,)).reshape(3, rows_n).copy()
+    hp.free()
+    names = np.concatenate([r[3][:n] for r in rows])
+    return n, head, lens.reshape(-1).astype(np.uint16), names
+
+
+def front_end_arrays(lib, fq, batch_pairs, chunk_pairs, slot_mode, max_read_len=256, se=False):
+    fe = api.DeviceFrontEnd(fq[0], None if se else fq[1], batch_pairs=batch_pairs, chunk_pairs=chunk_pairs, slot_mode=slot_mode, max_read_len=max_read_len, lib=lib)
+    heads, lens, names, total = [[], []], [[], []], [[], []], 0
+    while True:
+        n, b = fe.next()
+        if n <= 0:
+            break
+        h, l, nm = fe.fetch(b, n, single_end=se)
+        for e in range(1 if se else 2):
+            heads[e].append(h[:, e * n:(e + 1) * n]); lens[e].append(l[e * n:(e + 1) * n])
+            full = np.zeros((n, 304), dtype=np.uint8); full[:, :nm.shape[1]] = nm[e * n:(e + 1) * n]
+            names[e].append(full)
+        fe.release(b)
+        total += n
+    return n, total, heads, lens, names, fe
+
+
+@pytest.mark.parametrize("slot_mode", [0, 1, 2], ids=["reused_slots", "clean_names", "fresh"])
+@pytest.mark.parametrize("tag", ["basic", "trim76", "example151", "long250", "cfg0_example"])
+def test_front_end_arrays_are_the_host_readers_and_packers(tag, slot_mode, golden_cases, lib, tmp_path):
+    """the filter's keys, lengths and names the device forms from the text == fq_fastq_read + fq_pack_reads_into, bit for bit"""
+    g = golden_cases[tag]
+    fq = bgzf_pair(g, tmp_path, level=1, member=5000)
+    B = 64
+    n, head, lens, names = host_arrays(lib, fq, B, slot_mode, stride=256)
+    end, total, dh, dl, dn, fe = front_end_arrays(lib, fq, B, 3 * B, slot_mode)
+    fe.close()
+    assert end == 0 and total == n == g["n_pairs"]
+    for e in range(2):
+        assert np.array_equal(np.concatenate(dh[e], axis=1), head[:, e * n:(e + 1) * n]), "filter keys of end %d" % e
+        assert np.array_equal(np.concatenate(dl[e]), lens[e * n:(e + 1) * n])
+        assert np.array_equal(np.concatenate(dn[e]), names[e * n:(e + 1) * n]), "names of end %d" % e
+
+
+def test_front_end_hands_over_at_a_reference_batch_boundary(golden_cases, lib, tmp_path):
+    """an odd record in the middle of a file: the device's part ends at the boundary of the reference batch that holds it; the host readers
+    standing there return the rest -- together exactly the records (names, read-slot history included) the host path alone returns"""
+    g = golden_cases["qc"]
+    recs = [open(g[k], "rb").read().split(b"\n") for k in ("fq1", "fq2")]
+    B, odd = 256, 1500
+    fq = []
+    for e in range(2):
+        lines = recs[e]
+        out = []
+        for i in range(len(lines) // 4):
+            nm, s, p, q = lines[4 * i:4 * i + 4]
+            if i % 3 == 1:
+                nm = nm + b":" + b"y" * (i % 40)               # names of many lengths: a slot's earlier, longer name shows behind a shorter one
+            if i % 5 == 2:
+                s, q = s[:60 + i % 80], q[:60 + i % 80]        # short reads: the slot's earlier bases stand behind them in the filter's window
+            if i == odd and e == 0:
+                s = s[:70] + b"\n" + s[70:]                    # a wrapped base line
+            out += [nm, s, p, q]
+        path = str(tmp_path / ("odd_%d.fq.gz" % (e + 1)))
+        with open(path, "wb") as fh:
+            fh.write(synth.bgzf_compress(b"\n".join(out) + b"\n", threads=2, level=6, member=4000))
+        fq.append(path)
+    n, head, lens, names = host_arrays(lib, fq, B, 0)
+    end, total, dh, dl, dn, fe = front_end_arrays(lib, fq, B, 2 * B, 0)
+    assert end == api.FQ_EFALLBACK and total == odd // B * B
+    readers = fe.handover(threads=2, stride=256, name_stride=304)
+    rest = [r.read(1 << 20) for r in readers]
+    for r in readers:
+        r.close()
+    assert fe.unequal_lengths()
+    fe.close()
+    assert min(len(r[2]) for r in rest) == n - total
+    for e in range(2):
+        assert np.array_equal(np.concatenate(dl[e]), lens[e * n:e * n + total])
+        assert np.array_equal(np.concatenate(dh[e], axis=1), head[:, e * n:e * n + total])
+        assert np.array_equal(np.concatenate(dn[e]), names[e * n:e * n + total])
+        assert np.array_equal(rest[e][2][:n - total], lens[e * n + total:(e + 1) * n])
+        assert np.array_equal(rest[e][3][:n - total], names[e * n + total:(e + 1) * n]), "names behind the hand-over (slot history travelled)"
+        hp = api.HostPacked(np.stack([rest[0][0][:n - total], rest[1][0][:n - total]]), np.stack([rest[0][1][:n - total], rest[1][1][:n - total]]),
+                            np.stack([rest[0][2][:n - total], rest[1][2][:n - total]]), None, lib=lib)
+        import ctypes as C
+        hh = np.ctypeslib.as_array(C.cast(hp.p.contents.head, C.POINTER(C.c_uint64)), shape=(3 * 2 * (n - total),)).reshape(3, -1).copy()
+        hp.free()
+        assert np.array_equal(hh[:, e * (n - total):(e + 1) * (n - total)], head[:, e * n + total:(e + 1) * n]), "filter keys behind the hand-over (bases of the slots travelled)"
+
+
+@pytest.mark.gpu
+def test_a_million_pair_bgzf_file_through_the_front_end(tmp_path):
+    """1,048,576 pairs of BGZF FASTQ: every batch's keys equal the host packer's on the same rows"""
+    import ctypes as C
+    n, L = 1 << 20, 150
+    rng = np.random.default_rng(17)
+    seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, (2, n, L), dtype=np.uint8)]
+    seq[0, ::1000, 17] = ord("N")
+    qual = np.frombuffer(b"F:,#", dtype=np.uint8)[rng.choice(4, size=(2, n, L), p=[0.7, 0.15, 0.1, 0.05])]
+    fq = [str(tmp_path / ("big_%d.fq.gz" % (e + 1))) for e in range(2)]
+    for e in range(2):
+        synth.write_fastq_uniform(seq[e], qual[e], L, fq[e], threads=16)
+    hp = api.HostPacked(seq, qual, np.full((2, n), L, dtype=np.int32), None, threads=16)
+    head = np.ctypeslib.as_array(C.cast(hp.p.contents.head, C.POINTER(C.c_uint64)), shape=(3 * 2 * n,)).reshape(3, 2 * n).copy()
+    hp.free()
+    fe = api.DeviceFrontEnd(fq[0], fq[1], batch_pairs=262144, chunk_pairs=2 * 262144, slot_mode=0, max_read_len=160)
+    at = 0
+    while True:
+        m, b = fe.next()
+        if m <= 0:
+            break
+        h, l, nm = fe.fetch(b, m)
+        for e in range(2):
+            assert np.array_equal(h[:, e * m:(e + 1) * m], head[:, e * n + at:e * n + at + m])
+        assert (l == L).all() and bytes(nm[0][:10]) == b"r%09d" % at and bytes(nm[m][:10]) == b"r%09d" % at
+        fe.release(b)
+        at += m
+    st = fe.stats()
+    fe.close()
+    assert m == 0 and at == n and st["refused"] == 0 and st["members"] > 9000
