@@ -113,7 +113,7 @@ int launch_nl_index(const uint8_t *text, uint32_t n, uint32_t *nl, uint32_t cap,
 int launch_tok_rec(const FqTokArgs &a);         // a thread per record
 int launch_tok_pieces(const FqTokArgs &a);      // a thread per (record, 32 bases)
 int launch_slot_bases(const FqSlotArgs &a);     // a thread per read slot
-int launch_slot_names(const FqSlotArgs &a);
+int launch_slot_names(const FqSlotArgs &a);     // (plain_names: a thread per record for the names, a thread per slot for what the slots keep)
 int launch_text_gather(const FqTextGatherArgs &a);   // a thread per 16 bytes of a surviving read's row
 int launch_text_trim_all(const FqTextTrimArgs &a);   // a thread per read
 int dfill32(void *dst, uint32_t v, size_t n_words);  // (hipMemsetD32 on the state's stream)

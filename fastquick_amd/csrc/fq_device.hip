@@ -1092,9 +1092,17 @@ int launch_slot_bases(const FqSlotArgs &a) {
   FQ_HIP(hipGetLastError());
   return 0;
 }
+__global__ void __launch_bounds__(256) k_names_plain(FqSlotArgs a) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < a.n_rec) fqt_names_plain_thread(a, i);
+}
 int launch_slot_names(const FqSlotArgs &a) {
   FQ_PRE();
   if (a.n_rec <= 0) return 0;
+  if (a.plain_names) {
+    hipLaunchKernelGGL(k_names_plain, dim3(nblk((uint64_t)a.n_rec, 256)), dim3(256), 0, g_stream, a);
+    if (a.mode != 0) { FQ_HIP(hipGetLastError()); return 0; }
+  }
   hipLaunchKernelGGL(k_slot_names, dim3(nblk((uint64_t)a.n_slots, 256)), dim3(256), 0, g_stream, a);
   FQ_HIP(hipGetLastError());
   return 0;

@@ -263,7 +263,7 @@ struct fq_frontend {
   DBuf<uint16_t> d_hlen[3];
   DBuf<char> d_names[3];
   HBuf<uint32_t> h_stat;
-  int max_name_ever = 0;
+  int max_name_ever = 0, min_name_ever = INT32_MAX;
   int64_t pairs_done = 0;
   int next_slot = 0;
   // totals (fq_frontend_stats)
@@ -507,7 +507,7 @@ void producer_main(fq_frontend *fe) {
       if (!fe->d_rec[slot].ensure((size_t)n_rows + 1) || !fe->d_head[slot].ensure((size_t)n_rows * 3 + 8) || !fe->d_hlen[slot].ensure((size_t)n_rows + 8)) { finish(FQ_ENOMEM, "out of device memory (records)", false); return; }
       for (int e = 0; e < NF; ++e) {
         FileSide &F = fe->f[e];
-        const uint32_t init[FQT_N_STAT] = {0xffffffffu, 0, 0xffffffffu, 0, 0, 0, 0, 0};
+        const uint32_t init[FQT_N_STAT] = {0xffffffffu, 0, 0xffffffffu, 0, 0, 0xffffffffu, 0, 0};
         if (fqdev::h2d(F.d_stat.p, init, sizeof init)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
         FqTokArgs a{};
         a.text = F.d_text[slot].p; a.nl = F.d_nl.p; a.n_rec = (int)n; a.row0 = (int)(e * n); a.n_rows = n_rows; a.max_len = fe->max_len;
@@ -529,13 +529,18 @@ void producer_main(fq_frontend *fe) {
     if (n > 0) {
       // (min / max over the records that are in the chunk: the statistics above cover records [0, n_checked) of which the chunk may hold
       //  fewer after a cut -- a longer maximum only sizes a buffer more generously; lengths are told apart per row by the aligner)
-      int min_len = INT32_MAX, max_len = 0, max_name = 0;
+      int min_len = INT32_MAX, max_len = 0, max_name = 0, min_name = INT32_MAX;
       for (int e = 0; e < NF; ++e) {
+        min_name = std::min<int>(min_name, (int)std::min<uint32_t>(fe->h_stat.p[32 * e + FQT_MIN_NAME], 0x7fffffffu));
         min_len = std::min<int>(min_len, (int)std::min<uint32_t>(fe->h_stat.p[32 * e + FQT_MIN_LEN], 0x7fffffffu));
         max_len = std::max<int>(max_len, (int)fe->h_stat.p[32 * e + FQT_MAX_LEN]);
         max_name = std::max<int>(max_name, (int)fe->h_stat.p[32 * e + FQT_MAX_NAME]);
       }
       fe->max_name_ever = std::max(fe->max_name_ever, max_name);
+      fe->min_name_ever = std::min(fe->min_name_ever, min_name);
+      // (a cut chunk's statistics cover the records behind the cut too: at worst the general kernels run where the plain ones would have done)
+      const bool plain_names = fe->slot_mode != FQ_FASTQ_SLOTS_REUSED || fe->min_name_ever == fe->max_name_ever;
+      const bool all_long = min_len >= 96;
       const int name_stride = std::min(304, (fe->max_name_ever + 1 + 15) & ~15);
       TB.n_pairs = (int)n; TB.uniform_len = (!fall && min_len == max_len) ? max_len : 0; TB.max_len = max_len; TB.name_stride = name_stride;
       if (!fe->d_names[slot].ensure((size_t)n_rows * (size_t)name_stride + 64)) { finish(FQ_ENOMEM, "out of device memory (names)", false); return; }
@@ -546,6 +551,7 @@ void producer_main(fq_frontend *fe) {
         s.text = F.d_text[slot].p; s.rec = fe->d_rec[slot].p; s.n_rec = (int)n; s.row0 = (int)(e * n); s.n_rows = n_rows; s.g0 = F.records_done;
         s.n_slots = n_slots; s.mode = fe->slot_mode; s.slot_base = F.d_slot_base.p; s.slot_len = F.d_slot_len.p; s.slot_name = F.d_slot_name.p;
         s.head = fe->d_head[slot].p; s.names = fe->d_names[slot].p; s.name_stride = name_stride; s.stat = F.d_stat.p;
+        s.all_long = all_long ? 1 : 0; s.plain_names = plain_names ? 1 : 0;
         fqdev::time_begin(3);
         if (fe->slot_mode != FQ_FASTQ_SLOTS_FRESH && fqdev::launch_slot_bases(s)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
         if (fqdev::launch_slot_names(s)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }

@@ -115,6 +115,7 @@ FQ_HD uint32_t fqz_xpow8(const uint32_t *pow8, uint32_t n) {   // x^(8 n) mod P
 // status: 0 = inflated and checked; 1 = not a stream this decoder takes (the host's decoder, then zlib, decide); 2 = CRC mismatch.
 // =====================================================================================================================================
 #define FQZ_RING 4096
+static_assert(FQZ_RING == 4096, "the hand-written loop of fqz_inflate_member masks ring positions with 0xfff");
 #define FQZ_LROOT 10
 #define FQZ_DROOT 8
 enum { FQZ_OK = 0, FQZ_REFUSED = 1, FQZ_BADCRC = 2 };
@@ -558,6 +559,170 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
     for (;;) {
       int why = 0;
       uint32_t len = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+      if (D.flushed > D.g0 || (D.g0 & 255) == 0) {           // (the member's first line of text, which may begin inside a line, is out)
+        // The fast form, hand-written: hipcc's code for the C++ statement of this loop (the #else arm, which the host-loop tier runs) spends a
+        // third of its ~95 instructions per match on flag registers and copies for the loop's exits; this is 55-60.  Registers:
+        //   s[40:41] bit buffer  s42 bits in it  s43 next dword of the input block  s44 next output position  s45 / s46 the member's first / end position
+        //   s47 why  s48 len  s49 / s50 literal-length / distance entry  s51-s55 scratch  s[56:57] the text buffer  s58 flushed  s[60:61] refill  s[62:63] exec
+        //   v40 the input block's dwords  v41 lane  v42 4 * lane  v43 the LDS address of the tables  v44-v49 scratch  v50 float(lane)
+        uint32_t bb_lo = (uint32_t)D.bb, bb_hi = (uint32_t)(D.bb >> 32), a_bc = (uint32_t)D.bc, a_di = D.di, a_g = D.g, a_why = 0, a_len = 0, a_flushed = D.flushed;
+        const uint32_t out_lo = (uint32_t)(uintptr_t)D.out, out_hi = (uint32_t)((uintptr_t)D.out >> 32);
+        const uint32_t v_lane = threadIdx.x & 63, v_lane4 = 4 * (threadIdx.x & 63);
+        const uint32_t v_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) FqzLds *)&S;
+        const float v_lanef = (float)(threadIdx.x & 63);
+        __asm__ volatile(
+            "s_mov_b32 s47, 0\n"
+            "s_mov_b32 s48, 0\n"
+            ".Lfqz_top_%=:\n"
+            "  s_cmp_gt_i32 s42, 32\n"
+            "  s_cbranch_scc1 .Lfqz_have1_%=\n"
+            "  s_cmp_eq_u32 s43, 64\n"
+            "  s_cbranch_scc1 .Lfqz_exit_%=\n"
+            "  s_mov_b32 s61, 0\n"
+            "  v_readlane_b32 s60, v40, s43\n"
+            "  s_add_i32 s43, s43, 1\n"
+            "  s_lshl_b64 s[60:61], s[60:61], s42\n"
+            "  s_or_b64 s[40:41], s[40:41], s[60:61]\n"
+            "  s_add_i32 s42, s42, 32\n"
+            ".Lfqz_have1_%=:\n"
+            "  s_and_b32 s51, s40, 0x3ff\n"
+            "  v_lshl_add_u32 v44, s51, 2, v43\n"
+            "  ds_read_b32 v44, v44 offset:%[lt_off]\n"
+            "  s_waitcnt lgkmcnt(0)\n"
+            "  v_readfirstlane_b32 s49, v44\n"
+            "  s_bitcmp1_b32 s49, 11\n"
+            "  s_cbranch_scc0 .Lfqz_notmatch_%=\n"
+            // ---- a match: the length, then its distance
+            "  s_bfe_u32 s48, s40, s49\n"
+            "  s_lshr_b32 s51, s49, 23\n"
+            "  s_add_i32 s48, s48, s51\n"
+            "  s_bfe_u32 s51, s49, 0x50005\n"
+            "  s_lshr_b64 s[40:41], s[40:41], s51\n"
+            "  s_sub_i32 s42, s42, s51\n"
+            "  s_mov_b32 s47, 1\n"
+            "  s_cmp_gt_i32 s42, 32\n"
+            "  s_cbranch_scc1 .Lfqz_have2_%=\n"
+            "  s_cmp_eq_u32 s43, 64\n"
+            "  s_cbranch_scc1 .Lfqz_exit_%=\n"
+            "  s_mov_b32 s61, 0\n"
+            "  v_readlane_b32 s60, v40, s43\n"
+            "  s_add_i32 s43, s43, 1\n"
+            "  s_lshl_b64 s[60:61], s[60:61], s42\n"
+            "  s_or_b64 s[40:41], s[40:41], s[60:61]\n"
+            "  s_add_i32 s42, s42, 32\n"
+            ".Lfqz_have2_%=:\n"
+            "  s_and_b32 s51, s40, 0xff\n"
+            "  v_lshl_add_u32 v44, s51, 2, v43\n"
+            "  ds_read_b32 v44, v44 offset:%[dt_off]\n"
+            "  s_waitcnt lgkmcnt(0)\n"
+            "  v_readfirstlane_b32 s50, v44\n"
+            "  s_cmp_gt_u32 s48, 64\n"
+            "  s_cbranch_scc1 .Lfqz_exit_%=\n"
+            "  s_bitcmp1_b32 s50, 11\n"
+            "  s_cbranch_scc0 .Lfqz_exit_%=\n"
+            "  s_bfe_u32 s51, s50, 0x2000d\n"
+            "  s_bfe_u32 s52, s50, 0x40010\n"
+            "  s_lshl_b32 s51, s51, s52\n"
+            "  s_bfe_u32 s52, s40, s50\n"
+            "  s_add_i32 s53, s51, s52\n"
+            "  s_add_i32 s53, s53, 1\n"
+            "  s_sub_i32 s51, s44, s45\n"
+            "  s_cmp_gt_u32 s53, s51\n"
+            "  s_cbranch_scc1 .Lfqz_exit_%=\n"
+            "  s_add_i32 s54, s44, s48\n"
+            "  s_cmp_gt_u32 s54, s46\n"
+            "  s_cbranch_scc1 .Lfqz_exit_%=\n"
+            "  s_bfe_u32 s51, s50, 0x50005\n"
+            "  s_lshr_b64 s[40:41], s[40:41], s51\n"
+            "  s_sub_i32 s42, s42, s51\n"
+            "  s_mov_b32 s47, 0\n"
+            // ---- the copy: lanes below len, byte lane of the match = byte (lane mod dist) of the dist bytes in front of it
+            "  s_sub_i32 s51, s44, s53\n"
+            "  s_cmp_lt_u32 s53, s48\n"
+            "  s_cbranch_scc1 .Lfqz_period_%=\n"
+            "  v_add_u32_e32 v44, s51, v41\n"
+            ".Lfqz_src_%=:\n"
+            "  v_cmp_gt_u32_e32 vcc, s48, v41\n"
+            "  s_and_saveexec_b64 s[62:63], vcc\n"
+            "  v_add_u32_e32 v46, s44, v41\n"
+            "  v_and_b32_e32 v46, 0xfff, v46\n"
+            "  v_add_u32_e32 v46, v46, v43\n"
+            "  s_cmpk_gt_u32 s53, 0xf80\n"
+            "  s_cbranch_scc1 .Lfqz_far_%=\n"
+            "  v_and_b32_e32 v44, 0xfff, v44\n"
+            "  v_add_u32_e32 v44, v44, v43\n"
+            "  ds_read_u8 v45, v44 offset:%[ring_off]\n"
+            "  s_waitcnt lgkmcnt(0)\n"
+            "  ds_write_b8 v46, v45 offset:%[ring_off]\n"
+            "  s_branch .Lfqz_copied_%=\n"
+            ".Lfqz_far_%=:\n"
+            "  global_load_ubyte v45, v44, s[56:57]\n"
+            "  s_waitcnt vmcnt(0)\n"
+            "  ds_write_b8 v46, v45 offset:%[ring_off]\n"
+            ".Lfqz_copied_%=:\n"
+            "  s_or_b64 exec, exec, s[62:63]\n"
+            "  s_xor_b32 s51, s44, s54\n"
+            "  s_mov_b32 s44, s54\n"
+            "  s_cmp_lt_u32 s51, 0x100\n"
+            "  s_cbranch_scc1 .Lfqz_top_%=\n"
+            ".Lfqz_flush_%=:\n"                               // the line below s44's is complete: one coalesced store
+            "  s_and_b32 s51, s44, 0xffffff00\n"
+            "  s_add_u32 s51, s51, 0xffffff00\n"
+            "  s_and_b32 s52, s51, 0xf00\n"
+            "  v_add_u32_e32 v44, s52, v42\n"
+            "  v_add_u32_e32 v44, v44, v43\n"
+            "  ds_read_b32 v45, v44 offset:%[ring_off]\n"
+            "  v_add_u32_e32 v46, s51, v42\n"
+            "  s_add_u32 s58, s51, 0x100\n"
+            "  s_waitcnt lgkmcnt(0)\n"
+            "  global_store_dword v46, v45, s[56:57]\n"
+            "  s_branch .Lfqz_top_%=\n"
+            ".Lfqz_period_%=:\n"                              // dist < len: lane mod dist (lane, dist < 64: the quotient is exact to one either way)
+            "  v_cvt_f32_u32_e32 v47, s53\n"
+            "  v_rcp_iflag_f32_e32 v47, v47\n"
+            "  s_nop 1\n"
+            "  v_mul_f32_e32 v47, v47, v50\n"
+            "  v_cvt_u32_f32_e32 v47, v47\n"
+            "  v_mul_lo_u32 v47, v47, s53\n"
+            "  v_sub_u32_e32 v47, v41, v47\n"
+            "  v_ashrrev_i32_e32 v48, 31, v47\n"
+            "  v_and_b32_e32 v48, s53, v48\n"
+            "  v_add_u32_e32 v47, v47, v48\n"
+            "  v_mov_b32_e32 v48, s53\n"
+            "  v_cmp_le_u32_e32 vcc, s53, v47\n"
+            "  v_cndmask_b32_e32 v48, 0, v48, vcc\n"
+            "  v_sub_u32_e32 v47, v47, v48\n"
+            "  v_add_u32_e32 v44, s51, v47\n"
+            "  s_branch .Lfqz_src_%=\n"
+            ".Lfqz_notmatch_%=:\n"
+            "  s_bitcmp1_b32 s49, 10\n"
+            "  s_cbranch_scc0 .Lfqz_exit_%=\n"                // the end of the block, a code longer than the root
+            "  s_cmp_ge_u32 s44, s46\n"
+            "  s_cbranch_scc1 .Lfqz_exit_%=\n"
+            "  s_bfe_u32 s51, s49, 0x50005\n"
+            "  s_lshr_b64 s[40:41], s[40:41], s51\n"
+            "  s_sub_i32 s42, s42, s51\n"
+            "  s_and_b32 s51, s44, 0xfff\n"
+            "  v_add_u32_e32 v44, s51, v43\n"
+            "  s_lshr_b32 s52, s49, 23\n"
+            "  v_mov_b32_e32 v45, s52\n"
+            "  ds_write_b8 v44, v45 offset:%[ring_off]\n"
+            "  s_add_i32 s44, s44, 1\n"
+            "  s_and_b32 s51, s44, 0xff\n"
+            "  s_cmp_eq_u32 s51, 0\n"
+            "  s_cbranch_scc1 .Lfqz_flush_%=\n"
+            "  s_branch .Lfqz_top_%=\n"
+            ".Lfqz_exit_%=:\n"
+            "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+            : "+{s40}"(bb_lo), "+{s41}"(bb_hi), "+{s42}"(a_bc), "+{s43}"(a_di), "+{s44}"(a_g), "+{s47}"(a_why), "+{s48}"(a_len), "+{s58}"(a_flushed)
+            : "{s45}"(D.g0), "{s46}"(D.g_end), "{s56}"(out_lo), "{s57}"(out_hi), "{v40}"(D.wcur), "{v41}"(v_lane), "{v42}"(v_lane4), "{v43}"(v_lds), "{v50}"(v_lanef),
+              [lt_off] "i"(offsetof(FqzLds, lt)), [dt_off] "i"(offsetof(FqzLds, dt)), [ring_off] "i"(offsetof(FqzLds, ring32))
+            : "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s60", "s61", "s62", "s63", "v44", "v45", "v46", "v47", "v48", "v49", "vcc", "scc", "memory");
+        D.bb = (uint64_t)bb_hi << 32 | bb_lo; D.bc = (int)a_bc; D.di = a_di; D.g = a_g; D.flushed = a_flushed;
+        why = (int)a_why; len = a_len;
+      }
+#else
       if (D.flushed > D.g0 || (D.g0 & 255) == 0) {           // (the member's first line of text, which may begin inside a line, is out)
         uint64_t bb = D.bb;
         int bc = D.bc;
@@ -637,6 +802,7 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
         }
         D.bb = bb; D.bc = bc; D.di = di; D.g = g;
       }
+#endif
       const int r = why ? fqz_general_dist(D, S, len, dent) : fqz_general_symbol(D, S, lent, dent);
       if (r == 1) break;
       if (r == 2) { status = FQZ_REFUSED; break; }
@@ -661,7 +827,7 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
 // fails them is reported (stat[FQT_FIRST_BAD]) and everything from there on goes the host's byte-wise way.
 // =====================================================================================================================================
 struct FqTextRec { uint32_t name_off, seq_off, qual_off; uint16_t len, name_len; };   // offsets into the file's text buffer
-enum { FQT_FIRST_BAD = 0, FQT_MAX_NAME = 1, FQT_MIN_LEN = 2, FQT_MAX_LEN = 3, FQT_SHORTER_AFTER_LONGER = 4, FQT_N_STAT = 8 };
+enum { FQT_FIRST_BAD = 0, FQT_MAX_NAME = 1, FQT_MIN_LEN = 2, FQT_MAX_LEN = 3, FQT_SHORTER_AFTER_LONGER = 4, FQT_MIN_NAME = 5, FQT_N_STAT = 8 };
 FQ_HD bool fqt_is_space(uint32_t c) { return c == ' ' || (c >= 9 && c <= 13); }
 FQ_HD bool fqt_bad_base(uint32_t c) { return !(c > 32 && c < 127) || c == '+' || c == '>' || c == '@'; }   // what kseq would not read as one token of bases
 FQ_HD uint32_t fqt_load32(const uint8_t *p) { uint32_t w; __builtin_memcpy(&w, p, 4); return w; }            // (any alignment: gfx950 reads unaligned dwords)
@@ -696,6 +862,7 @@ FQ_HD void fqt_rec_thread(const FqTokArgs &A, int i) {
   A.hlen[A.row0 + i] = (uint16_t)L;
   if (!ok) { FQF_ATOMIC_MIN32(&A.stat[FQT_FIRST_BAD], (uint32_t)i); return; }
   FQF_ATOMIC_MAX32(&A.stat[FQT_MAX_NAME], name_len);
+  FQF_ATOMIC_MIN32(&A.stat[FQT_MIN_NAME], name_len);
   FQF_ATOMIC_MAX32(&A.stat[FQT_MAX_LEN], L);
   FQF_ATOMIC_MIN32(&A.stat[FQT_MIN_LEN], L);
 }
@@ -742,12 +909,28 @@ struct FqSlotArgs {
   char *names;               // out: [n_rows][name_stride], NUL padded: the name each record prints under
   int32_t name_stride;
   uint32_t *stat;
+  int32_t all_long;          // every read of the chunk has at least 96 bases: a slot keeps the bases of its last record only
+  int32_t plain_names;       // every name of the stream so far has one length: a record prints under its own name, a slot keeps its last record's
 };
 FQ_HD void fqt_slot_bases_thread(const FqSlotArgs &A, int slot) {
   int64_t first = (int64_t)slot - A.g0 % A.n_slots;
   if (first < 0) first += A.n_slots;
+  if (first >= A.n_rec) return;
   uint8_t *h = A.slot_base + (size_t)slot * 96;
   uint32_t longest = A.slot_len[slot];
+  if (A.all_long) {
+    // no read of the chunk is short: nothing reads the slot, and what it holds afterwards is its last record's first 96 bases
+    int64_t lastrec = first;
+    for (int64_t i = first; i < A.n_rec; i += A.n_slots) {
+      const uint32_t n = A.rec[A.row0 + i].len;
+      if (n < longest) A.stat[FQT_SHORTER_AFTER_LONGER] = 1; else longest = n;
+      lastrec = i;
+    }
+    const uint8_t *s = A.text + A.rec[A.row0 + lastrec].seq_off;
+    for (int q = 0; q < 24; ++q) { const uint32_t w = fqt_load32(s + 4 * q); __builtin_memcpy(h + 4 * q, &w, 4); }
+    A.slot_len[slot] = (uint16_t)(longest > 65535 ? 65535 : longest);
+    return;
+  }
   for (int64_t i = first; i < A.n_rec; i += A.n_slots) {
     const FqTextRec r = A.rec[A.row0 + i];
     const uint32_t n = r.len;
@@ -769,10 +952,37 @@ FQ_HD void fqt_slot_bases_thread(const FqSlotArgs &A, int slot) {
   }
   A.slot_len[slot] = (uint16_t)(longest > 65535 ? 65535 : longest);
 }
+// names of one length so far (or slots that keep nothing): a thread per RECORD writes the name it prints under -- its own, without a mate suffix
+FQ_HD void fqt_names_plain_thread(const FqSlotArgs &A, int i) {
+  const FqTextRec r = A.rec[A.row0 + i];
+  const uint8_t *nm = A.text + r.name_off;
+  const uint32_t l = r.name_len;
+  const bool mate_suffix = l > 2 && nm[l - 2] == '/' && (nm[l - 1] == '1' || nm[l - 1] == '2');   // src/BwtMapper.cpp:565-570
+  char *o = A.names + (size_t)(A.row0 + i) * (size_t)A.name_stride;
+  uint32_t keep = mate_suffix ? l - 2 : l;
+  if (keep > (uint32_t)A.name_stride - 1) keep = (uint32_t)A.name_stride - 1;
+  for (uint32_t p = 0; p < (uint32_t)A.name_stride; p += 4) {    // (name_stride is a multiple of 16; the output rows are aligned)
+    uint32_t w = 0;
+    for (uint32_t j = 0; j < 4; ++j) if (p + j < keep) w |= (uint32_t)nm[p + j] << (8 * j);
+    __builtin_memcpy(o + p, &w, 4);
+  }
+}
 FQ_HD void fqt_slot_names_thread(const FqSlotArgs &A, int slot) {
   int64_t first = (int64_t)slot - A.g0 % A.n_slots;
   if (first < 0) first += A.n_slots;
   uint8_t *b = A.slot_name + (size_t)slot * 304;
+  if (A.plain_names) {
+    // (the records' names were written by fqt_names_plain_thread) the slot keeps its last record's name, as the general walk would leave it
+    if (A.mode != 0 || first >= A.n_rec) return;
+    int64_t lastrec = first;
+    for (int64_t i = first; i < A.n_rec; i += A.n_slots) lastrec = i;
+    const FqTextRec r = A.rec[A.row0 + lastrec];
+    const uint8_t *nm = A.text + r.name_off;
+    const uint32_t l = r.name_len;
+    for (uint32_t p = 0; p < l; ++p) b[p] = nm[p];
+    if (l > 2 && nm[l - 2] == '/' && (nm[l - 1] == '1' || nm[l - 1] == '2')) b[l - 2] = 0;
+    return;
+  }
   for (int64_t i = first; i < A.n_rec; i += A.n_slots) {
     const FqTextRec r = A.rec[A.row0 + i];
     const uint8_t *nm = A.text + r.name_off;

@@ -174,7 +174,12 @@ int launch_nl_index(const uint8_t *text, uint32_t n, uint32_t *nl, uint32_t cap,
 int launch_tok_rec(const FqTokArgs &a) { for (int i = 0; i < a.n_rec; ++i) fqt_rec_thread(a, i); return 0; }
 int launch_tok_pieces(const FqTokArgs &a) { const int64_t n = (int64_t)a.n_rec * ((a.max_len + 31) >> 5); for (int64_t g = 0; g < n; ++g) fqt_piece_thread(a, g); return 0; }
 int launch_slot_bases(const FqSlotArgs &a) { if (a.n_rec > 0) for (int s = 0; s < a.n_slots; ++s) fqt_slot_bases_thread(a, s); return 0; }
-int launch_slot_names(const FqSlotArgs &a) { if (a.n_rec > 0) for (int s = 0; s < a.n_slots; ++s) fqt_slot_names_thread(a, s); return 0; }
+int launch_slot_names(const FqSlotArgs &a) {
+  if (a.n_rec <= 0) return 0;
+  if (a.plain_names) { for (int i = 0; i < a.n_rec; ++i) fqt_names_plain_thread(a, i); if (a.mode != 0) return 0; }
+  for (int s = 0; s < a.n_slots; ++s) fqt_slot_names_thread(a, s);
+  return 0;
+}
 int launch_text_gather(const FqTextGatherArgs &a) { const int64_t n = (int64_t)a.n_out * (a.stride >> 4); for (int64_t g = 0; g < n; ++g) fqt_gather_piece(a, g); return 0; }
 int launch_text_trim_all(const FqTextTrimArgs &a) { for (int r = 0; r < a.n_rows; ++r) fqt_trim_all_thread(a, r); return 0; }
 int dfill32(void *dst, uint32_t v, size_t n_words) { for (size_t i = 0; i < n_words; ++i) ((uint32_t *)dst)[i] = v; return 0; }
