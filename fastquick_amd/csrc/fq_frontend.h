@@ -114,9 +114,13 @@ FQ_HD uint32_t fqz_xpow8(const uint32_t *pow8, uint32_t n) {   // x^(8 n) mod P
 //   * The CRC-32 of the output is computed by the wavefront afterwards and compared with the member's trailer.
 // status: 0 = inflated and checked; 1 = not a stream this decoder takes (the host's decoder, then zlib, decide); 2 = CRC mismatch.
 // =====================================================================================================================================
-#define FQZ_RING 4096
-static_assert(FQZ_RING == 4096, "the hand-written loop of fqz_inflate_member masks ring positions with 0xfff");
-#define FQZ_LROOT 10
+#ifndef FQZ_RING
+#define FQZ_RING 2048
+#endif
+#ifndef FQZ_LROOT
+#define FQZ_LROOT 9
+#endif
+static_assert((FQZ_RING & (FQZ_RING - 1)) == 0 && FQZ_RING >= 1024 && FQZ_LROOT >= 9 && FQZ_LROOT <= 11, "ring a power of two that holds a line and the longest match; root table of 9 to 11 bits");
 #define FQZ_DROOT 8
 enum { FQZ_OK = 0, FQZ_REFUSED = 1, FQZ_BADCRC = 2 };
 struct FqzMember { uint64_t in_off; uint32_t out_off, in_len, out_len, crc; uint32_t pad[2]; };   // payload [in_off, in_off + in_len) of `comp`; text at out + out_off (a launch writes at most 4 GiB)
@@ -130,8 +134,7 @@ struct FqInflateArgs {
 };
 struct FqzLds {
   uint32_t lt[1 << FQZ_LROOT];  // literal / length root table; the CRC's slice tables afterwards
-  uint32_t dt[1 << FQZ_DROOT];
-  uint32_t clt[128];            // the code-length code's table
+  uint32_t dt[1 << FQZ_DROOT];   // (its first 128 words hold the code-length code's table while a block's code lengths are read)
   uint16_t lsort[288], dsort[32], csort[20];
   uint16_t lfirst[16], lcount[16], loffs[16];
   uint16_t dfirst[16], dcount[16], doffs[16];
@@ -143,9 +146,9 @@ struct FqzLds {
 // and its width from bits 16-22 of its second operand and ignores the rest):
 //   bits 0-4   code length            bits 16-19 extra bits (20-22 zero)
 //   bits 5-9   bits the whole symbol takes (code + extra; 0: not in the root table)
-//   bit 10 literal, bit 11 length / distance, bit 12 end of block
+//   bit 10 literal, bit 11 length (of at most 64 bytes, extra bits included) / distance, bit 12 end of block, bit 15 a longer length
 //   bits 23-31 literal / length base (<= 258);  distances: bits 13-14 k with base = (k << extra) + 1
-enum { FQZ_K_LIT = 1u << 10, FQZ_K_BASE = 1u << 11, FQZ_K_EOB = 1u << 12 };
+enum { FQZ_K_LIT = 1u << 10, FQZ_K_BASE = 1u << 11, FQZ_K_EOB = 1u << 12, FQZ_K_LONG = 1u << 15 };   // FQZ_K_LONG: a length whose match may exceed 64 bytes (the general form's)
 FQ_HD uint32_t fqz_take_of(uint32_t e) { return (e >> 5) & 31; }
 FQ_HD uint32_t fqz_extra_of(uint64_t bb, uint32_t e) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -165,7 +168,7 @@ FQ_HD uint32_t fqz_lit_entry(uint32_t s, uint32_t l) {
   if (k < 8) base = 3 + k;
   else if (k == 28) base = 258;
   else { xb = (k >> 2) - 1; base = 3 + ((4 + (k & 3)) << xb); }
-  return FQZ_K_BASE | base << 23 | xb << 16 | (l + xb) << 5 | l;
+  return (base + (1u << xb) - 1 <= 64 ? FQZ_K_BASE : FQZ_K_LONG) | base << 23 | xb << 16 | (l + xb) << 5 | l;
 }
 FQ_HD uint32_t fqz_dist_entry(uint32_t s, uint32_t l) {
   if (s > 29) return 0;
@@ -355,6 +358,7 @@ FQ_HD void fqz_copy_pass(FqzSt &D, uint32_t len, uint32_t dist, uint32_t c) {
 // fqz_general_dist: a length has been taken, the distance and the copy follow.
 template <class DE>
 FQ_HD int fqz_general_dist(FqzSt &D, FqzLds &S, uint32_t len, DE dent) {
+  if (D.g > D.g_end) return 2;                               // (the fast form checks the promised size where a line is stored: it may be up to 255 bytes over)
   fqz_need32(D);
   uint32_t f = FQF_UNIFORM32(S.dt[D.bb & ((1u << FQZ_DROOT) - 1)]);
   if (!fqz_take_of(f)) f = FQF_UNIFORM32(fqz_long_code(D.bb, FQZ_DROOT, S.dsort, S.dfirst, S.dcount, S.doffs, dent));
@@ -371,6 +375,7 @@ FQ_HD int fqz_general_dist(FqzSt &D, FqzLds &S, uint32_t len, DE dent) {
 }
 template <class LE, class DE>
 FQ_HD int fqz_general_symbol(FqzSt &D, FqzLds &S, LE lent, DE dent) {
+  if (D.g > D.g_end) return 2;
   fqz_need32(D);
   uint32_t e = FQF_UNIFORM32(S.lt[D.bb & ((1u << FQZ_LROOT) - 1)]);
   if (!fqz_take_of(e)) e = FQF_UNIFORM32(fqz_long_code(D.bb, FQZ_LROOT, S.lsort, S.lfirst, S.lcount, S.loffs, lent));
@@ -387,6 +392,7 @@ FQ_HD int fqz_general_symbol(FqzSt &D, FqzLds &S, LE lent, DE dent) {
     return 0;
   }
   if (e & FQZ_K_EOB) { fqz_take(D, (int)fqz_take_of(e)); return 1; }
+  if (!(e & (FQZ_K_BASE | FQZ_K_LONG))) return 2;
   const uint32_t len = (e >> 23) + fqz_extra_of(D.bb, e);
   fqz_take(D, (int)fqz_take_of(e));
   return fqz_general_dist(D, S, len, dent);
@@ -510,14 +516,14 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
       FQF_WAVE_FENCE();
       int used;
       if (FQF_UNIFORM32((uint32_t)fqz_canon(S.cl, 19, S.csort, S.cfirst, S.ccount, S.coffs, &used)) != 0) { status = FQZ_REFUSED; break; }   // (zlib: the code-length code must be complete)
-      fqz_fill_root(S.clt, 7, S.csort, S.cfirst, S.ccount, S.coffs, cent);
+      fqz_fill_root(S.dt, 7, S.csort, S.cfirst, S.ccount, S.coffs, cent);
       // the literal / length and distance code lengths, run-length coded with that code
       int i = 0;
       bool bad = false;
       while (i < hlit + hdist) {
         fqz_need32(D);
         if (D.overrun) { bad = true; break; }
-        const uint32_t e = FQF_UNIFORM32(S.clt[D.bb & 127]);
+        const uint32_t e = FQF_UNIFORM32(S.dt[D.bb & 127]);
         if (!fqz_take_of(e)) { bad = true; break; }
         fqz_take(D, (int)fqz_take_of(e));
         const int s = (int)(e >> 23);
@@ -586,7 +592,7 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
             "  s_or_b64 s[40:41], s[40:41], s[60:61]\n"
             "  s_add_i32 s42, s42, 32\n"
             ".Lfqz_have1_%=:\n"
-            "  s_and_b32 s51, s40, 0x3ff\n"
+            "  s_and_b32 s51, s40, %[lt_mask]\n"
             "  v_lshl_add_u32 v44, s51, 2, v43\n"
             "  ds_read_b32 v44, v44 offset:%[lt_off]\n"
             "  s_waitcnt lgkmcnt(0)\n"
@@ -617,8 +623,6 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
             "  ds_read_b32 v44, v44 offset:%[dt_off]\n"
             "  s_waitcnt lgkmcnt(0)\n"
             "  v_readfirstlane_b32 s50, v44\n"
-            "  s_cmp_gt_u32 s48, 64\n"
-            "  s_cbranch_scc1 .Lfqz_exit_%=\n"
             "  s_bitcmp1_b32 s50, 11\n"
             "  s_cbranch_scc0 .Lfqz_exit_%=\n"
             "  s_bfe_u32 s51, s50, 0x2000d\n"
@@ -631,8 +635,12 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
             "  s_cmp_gt_u32 s53, s51\n"
             "  s_cbranch_scc1 .Lfqz_exit_%=\n"
             "  s_add_i32 s54, s44, s48\n"
-            "  s_cmp_gt_u32 s54, s46\n"
+            "  s_xor_b32 s55, s44, s54\n"
+            "  s_cmp_lt_u32 s55, 0x100\n"
+            "  s_cbranch_scc1 .Lfqz_fits_%=\n"
+            "  s_cmp_gt_u32 s54, s46\n"                     // a line will be stored: not behind the promised size
             "  s_cbranch_scc1 .Lfqz_exit_%=\n"
+            ".Lfqz_fits_%=:\n"
             "  s_bfe_u32 s51, s50, 0x50005\n"
             "  s_lshr_b64 s[40:41], s[40:41], s51\n"
             "  s_sub_i32 s42, s42, s51\n"
@@ -646,11 +654,11 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
             "  v_cmp_gt_u32_e32 vcc, s48, v41\n"
             "  s_and_saveexec_b64 s[62:63], vcc\n"
             "  v_add_u32_e32 v46, s44, v41\n"
-            "  v_and_b32_e32 v46, 0xfff, v46\n"
+            "  v_and_b32_e32 v46, %[ring_mask], v46\n"
             "  v_add_u32_e32 v46, v46, v43\n"
-            "  s_cmpk_gt_u32 s53, 0xf80\n"
+            "  s_cmpk_gt_u32 s53, %[near_max]\n"
             "  s_cbranch_scc1 .Lfqz_far_%=\n"
-            "  v_and_b32_e32 v44, 0xfff, v44\n"
+            "  v_and_b32_e32 v44, %[ring_mask], v44\n"
             "  v_add_u32_e32 v44, v44, v43\n"
             "  ds_read_u8 v45, v44 offset:%[ring_off]\n"
             "  s_waitcnt lgkmcnt(0)\n"
@@ -662,14 +670,13 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
             "  ds_write_b8 v46, v45 offset:%[ring_off]\n"
             ".Lfqz_copied_%=:\n"
             "  s_or_b64 exec, exec, s[62:63]\n"
-            "  s_xor_b32 s51, s44, s54\n"
             "  s_mov_b32 s44, s54\n"
-            "  s_cmp_lt_u32 s51, 0x100\n"
+            "  s_cmp_lt_u32 s55, 0x100\n"
             "  s_cbranch_scc1 .Lfqz_top_%=\n"
             ".Lfqz_flush_%=:\n"                               // the line below s44's is complete: one coalesced store
             "  s_and_b32 s51, s44, 0xffffff00\n"
             "  s_add_u32 s51, s51, 0xffffff00\n"
-            "  s_and_b32 s52, s51, 0xf00\n"
+            "  s_and_b32 s52, s51, %[line_mask]\n"
             "  v_add_u32_e32 v44, s52, v42\n"
             "  v_add_u32_e32 v44, v44, v43\n"
             "  ds_read_b32 v45, v44 offset:%[ring_off]\n"
@@ -697,18 +704,23 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
             "  s_branch .Lfqz_src_%=\n"
             ".Lfqz_notmatch_%=:\n"
             "  s_bitcmp1_b32 s49, 10\n"
-            "  s_cbranch_scc0 .Lfqz_exit_%=\n"                // the end of the block, a code longer than the root
-            "  s_cmp_ge_u32 s44, s46\n"
+            "  s_cbranch_scc0 .Lfqz_exit_%=\n"                // the end of the block, a code longer than the root, a long match
+            "  s_add_i32 s54, s44, 1\n"
+            "  s_and_b32 s51, s54, 0xff\n"
+            "  s_cmp_eq_u32 s51, 0\n"
+            "  s_cbranch_scc0 .Lfqz_litfits_%=\n"
+            "  s_cmp_ge_u32 s44, s46\n"                     // the literal completes a line: not behind the promised size
             "  s_cbranch_scc1 .Lfqz_exit_%=\n"
+            ".Lfqz_litfits_%=:\n"
             "  s_bfe_u32 s51, s49, 0x50005\n"
             "  s_lshr_b64 s[40:41], s[40:41], s51\n"
             "  s_sub_i32 s42, s42, s51\n"
-            "  s_and_b32 s51, s44, 0xfff\n"
+            "  s_and_b32 s51, s44, %[ring_mask]\n"
             "  v_add_u32_e32 v44, s51, v43\n"
             "  s_lshr_b32 s52, s49, 23\n"
             "  v_mov_b32_e32 v45, s52\n"
             "  ds_write_b8 v44, v45 offset:%[ring_off]\n"
-            "  s_add_i32 s44, s44, 1\n"
+            "  s_mov_b32 s44, s54\n"
             "  s_and_b32 s51, s44, 0xff\n"
             "  s_cmp_eq_u32 s51, 0\n"
             "  s_cbranch_scc1 .Lfqz_flush_%=\n"
@@ -717,7 +729,8 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
             "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
             : "+{s40}"(bb_lo), "+{s41}"(bb_hi), "+{s42}"(a_bc), "+{s43}"(a_di), "+{s44}"(a_g), "+{s47}"(a_why), "+{s48}"(a_len), "+{s58}"(a_flushed)
             : "{s45}"(D.g0), "{s46}"(D.g_end), "{s56}"(out_lo), "{s57}"(out_hi), "{v40}"(D.wcur), "{v41}"(v_lane), "{v42}"(v_lane4), "{v43}"(v_lds), "{v50}"(v_lanef),
-              [lt_off] "i"(offsetof(FqzLds, lt)), [dt_off] "i"(offsetof(FqzLds, dt)), [ring_off] "i"(offsetof(FqzLds, ring32))
+              [lt_off] "i"(offsetof(FqzLds, lt)), [dt_off] "i"(offsetof(FqzLds, dt)), [ring_off] "i"(offsetof(FqzLds, ring32)),
+              [lt_mask] "i"((1 << FQZ_LROOT) - 1), [ring_mask] "i"(FQZ_RING - 1), [near_max] "i"(FQZ_RING - 2 * 64), [line_mask] "i"((FQZ_RING - 1) & ~255)
             : "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s60", "s61", "s62", "s63", "v44", "v45", "v46", "v47", "v48", "v49", "vcc", "scc", "memory");
         D.bb = (uint64_t)bb_hi << 32 | bb_lo; D.bc = (int)a_bc; D.di = a_di; D.g = a_g; D.flushed = a_flushed;
         why = (int)a_why; len = a_len;
@@ -746,11 +759,10 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
             }
             const uint32_t f = FQF_UNIFORM32(S.dt[bb & ((1u << FQZ_DROOT) - 1)]);
             if (!(f & FQZ_K_BASE)) break;
-            if (len > 64) break;
             const uint32_t dist = fqz_dist_of(bb, f);
             if (dist > g - g0) break;
             const uint32_t g1 = g + len;
-            if (g1 > g_end) break;
+            if (((g ^ g1) >> 8) && g1 > g_end) break;        // (the promised size is checked where a line would be stored; the member's end checks the rest)
             const uint32_t t2 = fqz_take_of(f);
             bb >>= t2; bc -= (int)t2;
             why = 0;
@@ -781,8 +793,8 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
             g = g1;
             continue;
           }
-          if (!(e & FQZ_K_LIT)) break;                       // the end of the block, a longer code
-          if (g >= g_end) break;
+          if (!(e & FQZ_K_LIT)) break;                       // the end of the block, a longer code, a long match
+          if (((g + 1) & 255) == 0 && g >= g_end) break;
           {
             const uint32_t t1 = fqz_take_of(e);
             bb >>= t1; bc -= (int)t1;
