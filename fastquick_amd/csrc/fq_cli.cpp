@@ -254,7 +254,7 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
   std::vector<char> sam;
   fq_index_t *ix = nullptr;
   fq_qc_t *qc = nullptr;
-  fq_ctx_t *ctx = nullptr;
+  fq_ctx_t *ctx = nullptr, *ctx_a = nullptr;      // ctx: the context that holds the stream's state; ctx_a: the first one made (a second one may join it: ctx2)
   bool started = false;
   auto start = [&] {                    // from here on: the index, the QC consumer, the sink
     if (started) return;
@@ -266,23 +266,35 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
     o.single_end = se ? 1 : 0;
     const int crc = fq_ctx_create(ix, &o, (int32_t)A.chunk_pairs, &ctx);
     if (crc) die("fq_ctx_create failed (" + std::to_string(crc) + "): option outside the supported range");
+    ctx_a = ctx;
   };
-  // the consumers of a call's records, in the reference's order: StatCollector, then the record writer (src/BwtMapper.cpp:2047-2050, 2075-2085)
-  auto consume = [&](const fq_result_batch_t &res, long long n_reads) {
+  // the consumers of a call's records: StatCollector and the record writer (src/BwtMapper.cpp:2047-2050, 2075-2085).  The reference runs them
+  // one after the other on its main thread; neither reads what the other writes here (each applies AddAlignment's contig-bridging mutation,
+  // SURVEY Q10, to its own view of a record), so consume_on() may run them side by side
+  std::mutex tm_mu;
+  auto consume_qc = [&](fq_ctx_t *cx) {
     const auto tc0 = std::chrono::steady_clock::now();
-    if (qc && (rc = fq_qc_add_last(qc, ctx))) die(std::string("QC consumer failed: ") + fq_qc_last_error(qc));
+    if (qc && fq_qc_add_last(qc, cx)) die(std::string("QC consumer failed: ") + fq_qc_last_error(qc));
+    std::lock_guard<std::mutex> lk(tm_mu);
+    qc_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc0).count();
+  };
+  auto consume_out = [&](fq_ctx_t *cx) {
     const auto tc1 = std::chrono::steady_clock::now();
+    std::vector<char> text;
     if (A.sam_out) {
-      const int64_t sz = fq_sam_format_last(ctx, nullptr, 0);
-      sam.resize((size_t)sz + 1);
-      fq_sam_format_last(ctx, sam.data(), sz + 1);
-      out.sam(sam.data(), (size_t)sz);
-    } else out.bam_add(ctx);
-    const auto tc2 = std::chrono::steady_clock::now();
-    qc_ms += std::chrono::duration<double, std::milli>(tc1 - tc0).count(); out_ms += std::chrono::duration<double, std::milli>(tc2 - tc1).count();
+      const int64_t sz = fq_sam_format_last(cx, nullptr, 0);
+      text.resize((size_t)sz + 1);
+      fq_sam_format_last(cx, text.data(), sz + 1);
+      out.sam(text.data(), (size_t)sz);
+    } else out.bam_add(cx);
+    std::lock_guard<std::mutex> lk(tm_mu);
+    out_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tc1).count();
+  };
+  auto count = [&](const fq_result_batch_t &res, long long n_reads) {
     num_read += n_reads; filtered += res.n_both_filtered; unmapped += res.n_both_unmapped;
     fprintf(stderr, se ? "NOTICE - %lld sequences are loaded.\n" : "NOTICE - %lld sequences are processed.\n", num_read);
   };
+  auto consume = [&](const fq_result_batch_t &res, long long n_reads) { consume_qc(ctx); consume_out(ctx); count(res, n_reads); };
   // src/BwtMapper.cpp:2087-2092: the first pair of a reference batch is compared when the running read count is a multiple of the batch
   // size (every full batch; a short last batch normally is not checked), over read_len name bytes.  Mates whose names differ elsewhere
   // pass, each printed under its own name (the reference's example input has such pairs).
@@ -298,7 +310,17 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
   std::unique_ptr<FastqReader> r1, r2;
   bool unequal_on_device = false;
   fq_frontend_t *fe = open_device_front_end(A, A.fq1, A.fq2, device, slot_mode, stride);
+  fq_ctx_t *ctx2 = nullptr;             // the device's part runs on two contexts in turn: the consumers of one call's records work while the next call runs
   if (fe) {
+    std::thread th_qc, th_out;
+    fq_text_batch_t *tb_prev = nullptr;
+    auto finish_prev = [&] {            // the previous call's consumers are done: its batch may be reused
+      if (th_qc.joinable()) th_qc.join();
+      if (th_out.joinable()) th_out.join();
+      if (tb_prev) { fq_frontend_release(fe, tb_prev); tb_prev = nullptr; }
+    };
+    fq_ctx_t *cur = nullptr, *other = nullptr;
+    std::vector<char> token;
     for (;;) {
       const auto tr0 = std::chrono::steady_clock::now();
       fq_text_batch_t *tb = nullptr;
@@ -306,25 +328,44 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
       const double waited = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count();
       if (!started) read_ms += waited; else read_wait_ms += waited;
       if (n == FQ_EFALLBACK) {
+        finish_prev();
         fq_fastq_t *h[2] = {nullptr, nullptr};
         if ((rc = fq_frontend_handover(fe, reader_threads, h))) die("the device front end could not hand " + A.fq1 + " over to the host reader (" + std::to_string(rc) + ")");
         r1.reset(new FastqReader(A.fq1, h[0]));
         if (!se) r2.reset(new FastqReader(A.fq2, h[1]));
-        if (A.frac < 1.0) die("internal: sampling on the device path");
         fprintf(stderr, "NOTICE - the FASTQ text from record %lld on is not four plain lines per record: read on by the host's reader\n", num_read / (se ? 1 : 2) + 1);
         break;
       }
       if (n < 0) die(std::string(fq_frontend_last_error(fe)).empty() ? "the device front end failed (" + std::to_string(n) + ")" : fq_frontend_last_error(fe));
       if (n == 0) break;
       start();
+      if (!cur) {
+        cur = ctx;
+        fq_opts_t o = A.o;
+        o.single_end = se ? 1 : 0;
+        if (fq_ctx_create(ix, &o, (int32_t)A.chunk_pairs, &ctx2)) die("fq_ctx_create failed: option outside the supported range");
+        other = ctx2;
+      } else {
+        // the stream's order-dependent state -- drand48 stream, last_ii, (k,l) cache -- goes from the context of the last call to this one's
+        const int64_t need = fq_ctx_state_export(other, nullptr, 0);
+        token.resize((size_t)std::max<int64_t>(need, 0));
+        if (need < 0 || fq_ctx_state_export(other, token.data(), need) != need || fq_ctx_state_import(cur, token.data(), need)) die("handing the stream's state from one context to the other failed");
+      }
       if (!se) order_check((int)n, [&](int sb, int e) { const char *nm = fq_text_batch_first_name(tb, sb, e); return nm ? nm : ""; });
       fq_result_batch_t res;
       const auto ta0 = std::chrono::steady_clock::now();
-      if ((rc = fq_align_text(ctx, tb, &res))) die(std::string("fq_align_text failed: ") + fq_ctx_last_error(ctx));
+      if ((rc = fq_align_text(cur, tb, &res))) die(std::string("fq_align_text failed: ") + fq_ctx_last_error(cur));
       align_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta0).count();
-      consume(res, se ? n : 2 * n);
-      fq_frontend_release(fe, tb);
+      finish_prev();
+      count(res, se ? n : 2 * n);
+      fq_ctx_t *cx = cur;
+      th_qc = std::thread([&, cx] { consume_qc(cx); });
+      th_out = std::thread([&, cx] { consume_out(cx); });
+      tb_prev = tb;
+      std::swap(cur, other);            // (`other` now names the context of the call just made: the one whose state goes on)
     }
+    finish_prev();
+    if (other && cur) ctx = other;       // the context that holds the stream's state (the host readers' part, if any, goes on with it)
     unequal_on_device = fq_frontend_unequal_lengths(fe) != 0;
     front_end_notice(fe);
   } else {
@@ -427,13 +468,20 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
     notice("%lld sequences are unmapped.", unmapped * 2);
   }
   fq_stats_t st;
-  fq_stats_get(ctx, &st);
+  fq_stats_get(ctx_a, &st);
+  if (ctx2) {
+    fq_stats_t s2;
+    fq_stats_get(ctx2, &s2);
+    for (int k = 0; k < 6; ++k) st.kernel_ms[k] += s2.kernel_ms[k];
+    st.host_ms_total += s2.host_ms_total; st.wall_ms_total += s2.wall_ms_total;
+  }
   fprintf(stderr, "NOTICE - device time (ms): prep %.1f width %.1f gap %.1f sa %.1f sw %.1f refine %.1f ; host %.1f ; wall %.1f\n", st.kernel_ms[0],
           st.kernel_ms[1], st.kernel_ms[2], st.kernel_ms[3], st.kernel_ms[4], st.kernel_ms[5], st.host_ms_total, st.wall_ms_total);
   fprintf(stderr, "NOTICE - consumers (ms): StatCollector %.1f ; %s writer %.1f ; first chunk read %.1f ; packing %.1f\n", qc_ms, A.sam_out ? "SAM" : "BAM", out_ms, read_ms, pack_ms);
   fprintf(stderr, "NOTICE - reading (ms): all chunks %.1f ; waited for %.1f ; alignment calls %.1f\n", read_all_ms, read_wait_ms, align_ms);
   if (qc) fq_qc_end_file(qc);
-  fq_ctx_destroy(ctx);
+  fq_ctx_destroy(ctx_a);
+  if (ctx2) fq_ctx_destroy(ctx2);
   if (fe) fq_frontend_close(fe);
 }
 

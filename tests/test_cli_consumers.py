@@ -94,3 +94,38 @@ def test_cli_76bp_pairs_with_the_default_read_len(golden_cases, emu_cli, tmp_pat
     run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
     assert run.returncode == 0, run.stderr.decode(errors="replace")[-2000:]
     assert run.stdout == open(g["sam"], "rb").read()
+
+
+def bgzf_copy(g, tmp, member=2500):
+    """the case with its FASTQ files as BGZF: the command line then inflates and tokenises them on the device (fq_frontend_*), runs its calls on
+    two contexts in turn (the stream's state handed from one to the other) and its consumers beside the next call"""
+    from fastquick_amd import synth
+    out = dict(g)
+    for k in ("fq1", "fq2"):
+        path = os.path.join(str(tmp), os.path.basename(g[k]) + ".gz")
+        with open(path, "wb") as fh:
+            fh.write(synth.bgzf_compress(open(g[k], "rb").read(), threads=2, level=6, member=member))
+        out[k] = path
+    return out
+
+
+def test_cli_bgzf_input_writes_the_same_bam_and_qc_files(golden_cases, emu_cli, tmp_path):
+    g = bgzf_copy(golden_cases["qc"], tmp_path)
+    g["batch"] = golden_cases["qc"]["batch"]
+    cli_bam_and_qc(emu_cli, g, str(tmp_path / "cli_qc_bgzf"))
+
+
+def test_cli_bgzf_input_over_several_chunks_prints_the_references_sam(golden_cases, emu_cli, tmp_path):
+    """`repeat`: placements are drawn from the drand48 stream, so a state that did not travel with the calls from context to context would show"""
+    for tag in ("repeat", "wide", "isize"):
+        g = bgzf_copy(golden_cases[tag], tmp_path)
+        cmd = [emu_cli, "align", "--index_prefix", g["prefix"][:-len(".FASTQuick.fa")], "--fastq_1", g["fq1"], "--fastq_2", g["fq2"], "--out_prefix", str(tmp_path / ("sam_" + tag)),
+               "--sam_out", "--batch_pairs", str(g["batch"] // 4), "--chunk_pairs", str(g["batch"] // 4)] + (["--q", str(g["trim_qual"])] if g["trim_qual"] else [])
+        ref = [emu_cli, "align", "--index_prefix", g["prefix"][:-len(".FASTQuick.fa")], "--fastq_1", golden_cases[tag]["fq1"], "--fastq_2", golden_cases[tag]["fq2"], "--out_prefix", str(tmp_path / ("ref_" + tag)),
+               "--sam_out", "--batch_pairs", str(g["batch"] // 4), "--chunk_pairs", str(g["batch"])] + (["--q", str(g["trim_qual"])] if g["trim_qual"] else [])
+        run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert run.returncode == 0, run.stderr.decode(errors="replace")[-2000:]
+        assert b"front end on the device" in run.stderr and b"read on by the host" not in run.stderr
+        host = subprocess.run(ref, stdout=subprocess.PIPE, stderr=subprocess.PIPE)      # the host reader on the plain files, other chunking: the same stream
+        assert host.returncode == 0 and b"front end on the device" not in host.stderr
+        assert run.stdout == host.stdout, tag
