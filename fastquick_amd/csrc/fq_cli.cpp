@@ -41,6 +41,10 @@ void tmp_file(const std::string &p) { std::lock_guard<std::mutex> lk(g_tmp_mu); 
   fflush(nullptr);
   _exit(EXIT_FAILURE);
 }
+// FASTQUICK_TRACE=1: wall-clock marks of the run's phases on stderr (milliseconds since the process began)
+const std::chrono::steady_clock::time_point g_t0 = std::chrono::steady_clock::now();
+const bool g_trace = [] { const char *e = getenv("FASTQUICK_TRACE"); return e && *e && *e != '0'; }();
+void mark(const char *what) { if (g_trace) fprintf(stderr, "TRACE - %9.1f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - g_t0).count(), what); }
 void notice(const char *fmt, long long a) { fprintf(stderr, "NOTICE - "); fprintf(stderr, fmt, a); fputc('\n', stderr); }
 
 // One FASTQ file through the library's front end (fq_fastq_*: parallel inflate + tokeniser with kseq_read3_fpc's tokens)
@@ -259,7 +263,9 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
   auto start = [&] {                    // from here on: the index, the QC consumer, the sink
     if (started) return;
     started = true;
+    mark("first chunk there; waiting for the index");
     ready();
+    mark("index ready");
     ix = ix_ref; qc = qc_ref;
     if (qc) fq_qc_begin_file(qc, A.fq1.c_str(), se ? A.fq1.c_str() : A.fq2.c_str());      // FileStatCollector(fq1[, fq2]): a single file is named twice
     fq_opts_t o = A.o;
@@ -267,6 +273,7 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
     const int crc = fq_ctx_create(ix, &o, (int32_t)A.chunk_pairs, &ctx);
     if (crc) die("fq_ctx_create failed (" + std::to_string(crc) + "): option outside the supported range");
     ctx_a = ctx;
+    mark("context created");
   };
   // the consumers of a call's records: StatCollector and the record writer (src/BwtMapper.cpp:2047-2050, 2075-2085).  The reference runs them
   // one after the other on its main thread; neither reads what the other writes here (each applies AddAlignment's contig-bridging mutation,
@@ -356,7 +363,9 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
       const auto ta0 = std::chrono::steady_clock::now();
       if ((rc = fq_align_text(cur, tb, &res))) die(std::string("fq_align_text failed: ") + fq_ctx_last_error(cur));
       align_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta0).count();
+      mark("call done");
       finish_prev();
+      mark("previous call's consumers done");
       count(res, se ? n : 2 * n);
       fq_ctx_t *cx = cur;
       th_qc = std::thread([&, cx] { consume_qc(cx); });
@@ -480,9 +489,11 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
   fprintf(stderr, "NOTICE - consumers (ms): StatCollector %.1f ; %s writer %.1f ; first chunk read %.1f ; packing %.1f\n", qc_ms, A.sam_out ? "SAM" : "BAM", out_ms, read_ms, pack_ms);
   fprintf(stderr, "NOTICE - reading (ms): all chunks %.1f ; waited for %.1f ; alignment calls %.1f\n", read_all_ms, read_wait_ms, align_ms);
   if (qc) fq_qc_end_file(qc);
+  mark("input done");
   fq_ctx_destroy(ctx_a);
   if (ctx2) fq_ctx_destroy(ctx2);
   if (fe) fq_frontend_close(fe);
+  mark("contexts and front end released");
 }
 
 // ---- ONE FASTQ pair over several devices: chunks of whole reference batches are dealt round-robin; every device runs filter,
@@ -756,6 +767,7 @@ int main(int argc, char **argv) {
   if (A.o.batch_pairs < 1) die("--batch_pairs must be positive");
   A.chunk_pairs = std::max<long long>(A.o.batch_pairs, A.chunk_pairs / A.o.batch_pairs * A.o.batch_pairs);   // whole reference batches per chunk
 
+  mark("options read");
   fq_runtime_configure(20, 1);   // hardware queues for the contexts' streams, sleeping waits: before the first HIP call (fastquick_amd.h)
   const std::string pre = A.index_prefix + ".FASTQuick.fa";
   // <index>.param: REFERENCE_PATH, TARGET_REGION_PATH, DBSNP_VCF_PATH, NUM_VAR_LONG, NUM_VAR_SHORT, SHORT_FLANK_LENGTH, LONG_FLANK_LENGTH
@@ -840,7 +852,9 @@ int main(int argc, char **argv) {
       if (fq_qc_write(K.qc)) die("writing the QC files failed");
       fq_qc_destroy(K.qc);
     }
+    mark("QC files written");
     fq_index_destroy(K.ix);
+    mark("index released");
     return 0;
   }
   if (shard_one_pair) {

@@ -8,6 +8,7 @@
 #include "fq_index.h"
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <memory>
 #include <cstdio>
@@ -102,14 +103,51 @@ std::string revcomp_ref(const std::string &s) {   // BwtIndexer::ReverseCompleme
   }
   return o;
 }
-void bitmap_bits_from_fasta(const std::vector<FastaRec> &recs, std::vector<uint32_t> bits[6]) {
-  for (const auto &r : recs) {
+void bitmap_bits_of_records(const std::vector<FastaRec> &recs, size_t lo, size_t hi, std::vector<uint32_t> bits[6]) {
+  for (size_t k = lo; k < hi; ++k) {
+    const FastaRec &r = recs[k];
     char alleles[2] = {'N', 'N'};
     size_t at = r.name.find('@');
     if (at != std::string::npos && at + 3 < r.name.size() + 1) { alleles[0] = r.name[at + 1]; alleles[1] = r.name[at + 3]; }
     add_seq_bits(bits, r.seq, alleles);
     add_seq_bits(bits, revcomp_ref(r.seq), alleles);
   }
+}
+void bitmap_bits_from_fasta(const std::vector<FastaRec> &recs, std::vector<uint32_t> bits[6]) { bitmap_bits_of_records(recs, 0, recs.size(), bits); }
+// The same set of bits, listed by several threads (one slice of the records each; the order of a list of bits to set does not matter).
+// A base that is not ACGT draws from rand() (code_or_rand), whose stream is one per process and in record order: a reference that
+// holds one -- or an allele pair that is not two of ACGT -- keeps the single-thread walk.
+struct BitParts { std::vector<uint32_t> bits[6]; };
+bool all_plain_bases(const std::vector<FastaRec> &recs) {
+  bool lut[256] = {};
+  for (char c : {'A', 'C', 'G', 'T', 'a', 'c', 'g', 't'}) lut[(unsigned char)c] = true;
+  for (const auto &r : recs) {
+    for (char c : r.seq) if (!lut[(unsigned char)c]) return false;
+    const size_t at = r.name.find('@');
+    if (at == std::string::npos || at + 3 >= r.name.size() + 1 || !lut[(unsigned char)r.name[at + 1]] || !lut[(unsigned char)r.name[at + 3]]) return false;
+  }
+  return true;
+}
+void bitmap_bits_from_fasta_threads(const std::vector<FastaRec> &recs, std::vector<BitParts> &parts) {
+  unsigned nt = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+  if (const char *e = getenv("FASTQUICK_HOST_CPUS")) { const int v = atoi(e); if (v > 0) nt = std::min(nt, (unsigned)v); }
+  if (recs.size() < 64 || !all_plain_bases(recs)) nt = 1;
+  parts.resize(nt);
+  if (nt == 1) { bitmap_bits_of_records(recs, 0, recs.size(), parts[0].bits); return; }
+  // slices of about equal numbers of BASES (the long flanks of the contamination markers sit together at the end of the file)
+  size_t total = 0;
+  for (const auto &r : recs) total += r.seq.size();
+  std::vector<size_t> cut(nt + 1, recs.size());
+  cut[0] = 0;
+  size_t acc = 0, k = 1;
+  for (size_t i = 0; i < recs.size() && k < nt; ++i) {
+    acc += recs[i].seq.size();
+    while (k < nt && acc >= total * k / nt) cut[k++] = i + 1;
+  }
+  std::vector<std::thread> th;
+  for (unsigned t = 0; t < nt; ++t)
+    th.emplace_back([&, t] { for (int q = 0; q < 6; ++q) parts[t].bits[q].reserve((cut[t + 1] - cut[t]) ? 2 * (total / nt) + 4096 : 0); bitmap_bits_of_records(recs, cut[t], cut[t + 1], parts[t].bits); });
+  for (auto &x : th) x.join();
 }
 
 // ---- suffix sorting for the builder ---------------------------------------------------------------------
@@ -392,12 +430,17 @@ int load_fm(const std::string &prefix, const char *bext, const char *sext, fq_in
 extern "C" int fq_index_load(const char *prefix_c, int device_ordinal, fq_index_t **out) {
   if (!prefix_c || !out) return FQ_EINVAL;
   *out = nullptr;
+  // FASTQUICK_TRACE=1: where the load's time goes, on stderr
+  static const bool trace = [] { const char *e = getenv("FASTQUICK_TRACE"); return e && *e && *e != '0'; }();
+  const auto t_load0 = std::chrono::steady_clock::now();
+  auto mark = [&](const char *what) { if (trace) fprintf(stderr, "TRACE -   index load %8.1f ms  %s\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_load0).count(), what); };
   // the load has its own short-lived device state (stream for the staging copies); it ends with the load
   struct DevScope {
     fqdev::State *s;
     ~DevScope() { fqdev::state_destroy(s); }
   } scope{fqdev::state_create(device_ordinal)};
   if (!scope.s || fqdev::bind(scope.s)) return FQ_ENODEV;
+  mark("device state (HIP runtime up)");
   std::unique_ptr<fq_index> ix(new fq_index);
   ix->prefix = prefix_c;
   ix->device = device_ordinal;
@@ -441,9 +484,11 @@ extern "C" int fq_index_load(const char *prefix_c, int device_ordinal, fq_index_
   if (fqdev::h2d(ix->d_pac, ix->pac.data(), ix->pac.size()) || fqdev::sync()) return fail(FQ_ENODEV);
   ix->dev.pac = (const uint8_t *)ix->d_pac;
   ix->dev.l_pac = ix->l_pac;
+  mark("FM index, SA, pac staged");
   // ---- six 2^32-bit filter tables, contiguous in HBM (3 GiB)
   const size_t TB = (size_t)1 << 29;
   ix->d_bitmap = fqdev::dmalloc(6 * TB);
+  mark("3 GiB allocated");
   if (!ix->d_bitmap) return fail(FQ_ENOMEM);
   for (int t = 0; t < 6; ++t) ix->dev.bitmap[t] = (const uint8_t *)ix->d_bitmap + (size_t)t * TB;
   if (exists(P + ".rollhash")) {
@@ -458,33 +503,39 @@ extern "C" int fq_index_load(const char *prefix_c, int device_ordinal, fq_index_
     fclose(fp);
     fqdev::hfree(stage);
   } else {
-    std::vector<uint32_t> bits[6];
+    std::vector<BitParts> parts;
     if (exists(P + ".rollhash.sparse")) {
+      parts.resize(1);
       FILE *fp = fopen((P + ".rollhash.sparse").c_str(), "rb");
       for (int t = 0; t < 6; ++t) {
         uint64_t cnt;
         if (fread(&cnt, 8, 1, fp) != 1) { fclose(fp); return fail(FQ_EIO); }
-        bits[t].resize(cnt);
-        if (cnt && fread(bits[t].data(), 4, cnt, fp) != cnt) { fclose(fp); return fail(FQ_EIO); }
+        parts[0].bits[t].resize(cnt);
+        if (cnt && fread(parts[0].bits[t].data(), 4, cnt, fp) != cnt) { fclose(fp); return fail(FQ_EIO); }
       }
       fclose(fp);
     } else {
       std::vector<FastaRec> recs;
       if (!read_reduced_fasta(P, recs)) return fail(FQ_EIO);
-      bitmap_bits_from_fasta(recs, bits);
+      bitmap_bits_from_fasta_threads(recs, parts);
     }
+    mark("set bits listed (file, or the FASTA's k-mers)");
     if (fqdev::dzero(ix->d_bitmap, 6 * TB)) return fail(FQ_ENODEV);
-    for (int t = 0; t < 6; ++t) {
-      if (bits[t].empty()) continue;
-      uint32_t *d = (uint32_t *)fqdev::dmalloc(bits[t].size() * 4);
-      if (!d) return fail(FQ_ENOMEM);
-      int e = fqdev::h2d(d, bits[t].data(), bits[t].size() * 4);
-      if (!e) e = fqdev::launch_bitmap_scatter((uint8_t *)ix->d_bitmap + (size_t)t * TB, d, bits[t].size());
-      if (!e) e = fqdev::sync();
-      fqdev::dfree(d);
-      if (e) return fail(FQ_ENODEV);
-    }
+    size_t most = 0;
+    for (const auto &p : parts) for (int t = 0; t < 6; ++t) most = std::max(most, p.bits[t].size());
+    uint32_t *d = most ? (uint32_t *)fqdev::dmalloc(most * 4) : nullptr;
+    if (most && !d) return fail(FQ_ENOMEM);
+    for (const auto &p : parts)
+      for (int t = 0; t < 6; ++t) {
+        if (p.bits[t].empty()) continue;
+        int e = fqdev::h2d(d, p.bits[t].data(), p.bits[t].size() * 4);
+        if (!e) e = fqdev::launch_bitmap_scatter((uint8_t *)ix->d_bitmap + (size_t)t * TB, d, p.bits[t].size());
+        if (!e) e = fqdev::sync();
+        if (e) { fqdev::dfree(d); return fail(FQ_ENODEV); }
+      }
+    fqdev::dfree(d);
   }
+  mark("bitmaps filled");
   *out = ix.release();
   return FQ_OK;
 }

@@ -146,7 +146,11 @@ struct fq_qc {
   struct Marker { std::string chrom_raw, id, ref, alt, qual, filter, info; int pos = 0; };
   std::vector<Marker> markers;
   std::map<std::string, std::map<int, unsigned>> vcf_table;
-  std::unordered_map<std::string, std::unordered_map<int, unsigned>> gc, dbsnp;
+  std::unordered_map<std::string, std::unordered_map<int, unsigned>> dbsnp;
+  // GC content per position: the reference keeps a hash of every position of every marker's window (a later marker's window writes over an
+  // earlier one's where they overlap) and reads it at the positions of the flank regions only (GetDepthDist; a position no window covers
+  // reads 0): kept here as one byte per flank-region position, laid out like the depth tables
+  std::vector<uint8_t> gc_flat;
   Regions flank;
   uint64_t NumXorY = 0, NumShort = 0, NumLong = 0;
   // statistics
@@ -203,6 +207,9 @@ int fq_qc::restore(const std::string &ref_prefix) {
   std::ifstream vcf(ref_prefix + ".SelectedSite.vcf"), gcf(ref_prefix + ".gc", std::ios_base::binary), db(ref_prefix + ".dbSNP.subset.vcf");
   if (!vcf.is_open() || !gcf.is_open() || !db.is_open()) { err = "cannot open " + ref_prefix + ".SelectedSite.vcf / .gc / .dbSNP.subset.vcf"; return FQ_EIO; }
   const int chopped = (int)std::floor(o.read_len * 0.65f + 0.5);   // FLANK_EDGE, :28, :1754
+  struct GcWin { std::string chr; int start; uint32_t len; size_t at; };
+  std::vector<GcWin> gc_win;
+  std::vector<uint8_t> gc_bytes;
   std::string line;
   while (std::getline(vcf, line)) {
     if (line.empty() || line[0] == '#') continue;
@@ -217,11 +224,11 @@ int fq_qc::restore(const std::string &ref_prefix) {
     vcf_table[chr][m.pos] = (unsigned)markers.size() - 1;
     uint32_t glen = 0;
     gcf.read(reinterpret_cast<char *>(&glen), 4);
-    std::vector<unsigned char> g(glen);
-    gcf.read(reinterpret_cast<char *>(g.data()), glen);
+    const size_t g_at = gc_bytes.size();
+    gc_bytes.resize(g_at + glen);
+    gcf.read(reinterpret_cast<char *>(gc_bytes.data() + g_at), glen);
     if (!gcf) { err = "short .gc file"; return FQ_EIO; }
-    const int tmp_pos = m.pos - ((int)glen - 1) / 2;
-    for (uint32_t i = 0; i != glen; ++i) gc[chr][tmp_pos + (int)i] = g[i];
+    gc_win.push_back(GcWin{chr, m.pos - ((int)glen - 1) / 2, glen, g_at});
     if (chr == "X" || chr == "Y") { ++NumXorY; flank.add(chr, m.pos - o.flank_len + chopped, m.pos + o.flank_len - chopped); }
     else if (!m.id.empty() && m.id.back() == 'L') { ++NumLong; flank.add(chr, m.pos - o.flank_long_len + chopped, m.pos + o.flank_long_len - chopped); }
     else { ++NumShort; flank.add(chr, m.pos - o.flank_len + chopped, m.pos + o.flank_len - chopped); }
@@ -232,6 +239,19 @@ int fq_qc::restore(const std::string &ref_prefix) {
     size_t at = 0;
     for (const auto &kv : flank.list) for (const auto &r : kv.second) { flank_idx[kv.first][r.first] = std::make_pair(r.second, at); at += (size_t)(r.second - r.first) + 1; }
     depth.assign(at, 0); q20.assign(at, 0); q30.assign(at, 0);
+    gc_flat.assign(at, 0);
+  }
+  for (const GcWin &w : gc_win) {           // in marker order: the later window's values stand where two overlap
+    auto fc = flank_idx.find(w.chr);
+    if (fc == flank_idx.end() || w.len == 0) continue;
+    const int64_t lo = w.start, hi = (int64_t)w.start + w.len - 1;
+    auto it = fc->second.upper_bound((int)std::min<int64_t>(lo, INT32_MAX));
+    if (it != fc->second.begin()) --it;
+    for (; it != fc->second.end() && it->first <= hi; ++it) {
+      const int64_t a = std::max<int64_t>(lo, it->first), b = std::min<int64_t>(hi, it->second.first);
+      if (a > b) continue;
+      memcpy(gc_flat.data() + it->second.second + (size_t)(a - it->first), gc_bytes.data() + w.at + (size_t)(a - lo), (size_t)(b - a + 1));
+    }
   }
   while (std::getline(db, line)) {
     if (line.empty() || line[0] == '#') continue;
@@ -614,14 +634,13 @@ extern "C" int fq_qc_write(fq_qc_t *q) {
   const std::string &pre = q->out_prefix;
   {   // GetDepthDist, :1858-1918
     for (auto &chr : q->flank_idx) {
-      auto &gc_chr = q->gc[chr.first];
       for (auto &reg : chr.second)
         for (int pos = reg.first; pos <= reg.second.first; ++pos) {
           const int d = (int)q->depth[reg.second.second + (size_t)(pos - reg.first)];
           if (d == 0) continue;                 // never touched: not in the reference's PositionTable
           q->NumBaseMapped += d;
           ++q->DepthDist[d > 1023 ? 1023 : d];
-          const unsigned g = gc_chr[pos];
+          const unsigned g = q->gc_flat[reg.second.second + (size_t)(pos - reg.first)];
           q->GCDist[g] += d;
           ++q->PosNum[g];
         }
