@@ -92,7 +92,8 @@ class Stats(C.Structure):
 class FrontEndStats(C.Structure):
     _fields_ = [("ms_inflate", C.c_double), ("ms_tokenise", C.c_double), ("members", C.c_int64), ("refused", C.c_int64),
                 ("text_bytes", C.c_int64), ("comp_bytes", C.c_int64), ("pairs", C.c_int64),
-                ("ms_lines", C.c_double), ("ms_records", C.c_double), ("ms_slots", C.c_double), ("inflate_launches", C.c_int64), ("chunks", C.c_int64)]
+                ("ms_lines", C.c_double), ("ms_records", C.c_double), ("ms_slots", C.c_double), ("inflate_launches", C.c_int64), ("chunks", C.c_int64),
+                ("ms_wait_reader", C.c_double), ("ms_wait_slot", C.c_double), ("ms_read", C.c_double), ("ms_upload", C.c_double)]
 
 
 EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destroy", "fq_index_l_pac",

@@ -94,6 +94,8 @@ int launch_sa(const FqSaArgs &a);
 int stream_aux(int on);
 int stream_fork();
 int stream_join();
+int stream_mark(int k);        // a mark (0..3) on the current stream (main, or aux under stream_aux(1)) behind what it holds so far
+int stream_wait_mark(int k);   // the current stream waits for that mark's work
 // the work items of one queue segment whose search did not complete (status != 0): search indices appended to out[*count ...]
 int launch_collect(const int32_t *order, const uint32_t *split, int n_work, int seg, int n_seg, const uint32_t *status, const int32_t *work, int32_t *out, uint32_t *count);
 // the stages over the device-resident records (fq_records.h): operation FQ_ROP_*, one thread per item
@@ -109,7 +111,7 @@ int launch_refine(const FqRefineArgs &a);
 const FqzCrcConst *crc_const();
 int launch_inflate(const FqInflateArgs &a);     // one wavefront per BGZF member
 // positions of the line ends of text[0, n): nl[0 .. min(count, cap)) ascending, *count (device memory) = how many there are
-int launch_nl_index(const uint8_t *text, uint32_t n, uint32_t *nl, uint32_t cap, uint32_t *count);
+int launch_nl_index(const uint8_t *text, uint32_t n, uint32_t lo, uint32_t *nl, uint32_t cap, uint32_t *count);
 int launch_tok_rec(const FqTokArgs &a);         // a thread per record
 int launch_tok_pieces(const FqTokArgs &a);      // a thread per (record, 32 bases)
 int launch_slot_bases(const FqSlotArgs &a);     // a thread per read slot

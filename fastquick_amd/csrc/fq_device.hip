@@ -27,6 +27,7 @@ struct State {
   hipStream_t stream = nullptr;
   hipStream_t main_stream = nullptr, aux_stream = nullptr;   // `stream` is the one backend calls go to: main_stream, or aux_stream between stream_aux(1) and stream_aux(0)
   hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+  hipEvent_t marks[4] = {nullptr, nullptr, nullptr, nullptr};   // stream_mark / stream_wait_mark
   hipStream_t copy_stream = nullptr;              // one of the device's shared copy streams (not owned)
   hipEvent_t copy_done[2] = {nullptr, nullptr};
   hipEvent_t prep_done = nullptr;                 // completion of this context's most recent filter kernel (chained per device)
@@ -141,6 +142,7 @@ void state_destroy(State *s) {
   if (s->sync_ev) (void)hipEventDestroy(s->sync_ev);
   if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
   if (s->join_ev) (void)hipEventDestroy(s->join_ev);
+  for (hipEvent_t m : s->marks) if (m) (void)hipEventDestroy(m);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);   // (shared: also waits for other contexts' copies enqueued so far)
   {
@@ -214,6 +216,21 @@ int stream_join() {
   if (!g_cur->aux_stream) return 0;
   FQ_HIP(hipEventRecord(g_cur->join_ev, g_cur->aux_stream));
   FQ_HIP(hipStreamWaitEvent(g_cur->main_stream, g_cur->join_ev, 0));
+  return 0;
+}
+// A mark on the current stream (main or aux), and the current stream waiting for a mark: what stream_fork / stream_join do for "everything so
+// far", per piece of work -- the front end's inflate launches run one chunk ahead of the kernels that read their text.
+int stream_mark(int k) {
+  FQ_PRE();
+  hipEvent_t &m = g_cur->marks[k & 3];
+  if (!m) FQ_HIP(hipEventCreateWithFlags(&m, hipEventDisableTiming));
+  FQ_HIP(hipEventRecord(m, g_stream));
+  return 0;
+}
+int stream_wait_mark(int k) {
+  FQ_PRE();
+  hipEvent_t m = g_cur->marks[k & 3];
+  if (m) FQ_HIP(hipStreamWaitEvent(g_stream, m, 0));
   return 0;
 }
 // input prefetch: copies on the context's copy stream run under the compute stream's kernels; slot = which of the two input
@@ -291,13 +308,15 @@ void time_end(int kid) { (void)copy_flush(); hipEvent_t e = get_event(); (void)h
 // rocprofv3 --kernel-trace reports, unaffected by dispatch queueing when several streams share the GPU
 static void kernel_events(int kid, hipEvent_t *a, hipEvent_t *b) { *a = get_event(); *b = get_event(); g_cur->pending.push_back({kid, *a, *b}); }
 void time_collect(double ms[], uint64_t launches[], int n_ids) {
+  std::vector<decltype(g_cur->pending)::value_type> later;
   for (auto &p : g_cur->pending) {
+    if (hipEventQuery(p.b) == hipErrorNotReady) { later.push_back(p); continue; }     // (work on the other stream that is still running: next time)
     float t = 0.f;
     if (hipEventElapsedTime(&t, p.a, p.b) == hipSuccess && p.kid < n_ids) { ms[p.kid] += t; launches[p.kid] += 1; }
     g_cur->free_events.push_back(p.a);
     g_cur->free_events.push_back(p.b);
   }
-  g_cur->pending.clear();
+  g_cur->pending.swap(later);
 }
 
 // ---- kernels --------------------------------------------------------------------------------
@@ -980,7 +999,7 @@ int launch_inflate(const FqInflateArgs &a) {
 
 // Line ends of a text: every thread looks at 16 bytes (one aligned load), a block at 4 KiB; the blocks' counts are scanned (launch_scan)
 // and the positions written in order: ballot-free ranks from a prefix sum over the block's 256 counts in LDS.
-__device__ __forceinline__ uint32_t fqt_nl_mask16(const uint8_t *text, uint32_t n, uint32_t at) {   // bit j: text[at + j] is a line end (at a multiple of 16)
+__device__ __forceinline__ uint32_t fqt_nl_mask16(const uint8_t *text, uint32_t n, uint32_t at, uint32_t lo) {   // bit j: text[at + j] is a line end (at a multiple of 16)
   if (at >= n) return 0;
   const FqU4 v = *(const FqU4 *)(text + at);
   const uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -990,11 +1009,12 @@ __device__ __forceinline__ uint32_t fqt_nl_mask16(const uint8_t *text, uint32_t 
 #pragma unroll
     for (int j = 0; j < 4; ++j) m |= (uint32_t)(((w[q] >> (8 * j)) & 0xffu) == 0x0au) << (4 * q + j);
   if (at + 16 > n) m &= (1u << (n - at)) - 1u;
+  if (at < lo) m &= ~((1u << (lo - at)) - 1u);      // (lo < 16: bytes in front of the text's first, there for the alignment of the loads)
   return m;
 }
-__global__ void __launch_bounds__(256) k_nl_count(const uint8_t *text, uint32_t n, uint32_t *blk_cnt) {
+__global__ void __launch_bounds__(256) k_nl_count(const uint8_t *text, uint32_t n, uint32_t lo, uint32_t *blk_cnt) {
   const uint32_t at = (blockIdx.x * 256u + threadIdx.x) * 16u;
-  uint32_t c = (uint32_t)__popc(fqt_nl_mask16(text, n, at));
+  uint32_t c = (uint32_t)__popc(fqt_nl_mask16(text, n, at, lo));
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) c += (uint32_t)__shfl_xor((int)c, d, 64);
   __shared__ uint32_t s[4];
@@ -1002,9 +1022,9 @@ __global__ void __launch_bounds__(256) k_nl_count(const uint8_t *text, uint32_t 
   __syncthreads();
   if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
-__global__ void __launch_bounds__(256) k_nl_fill(const uint8_t *text, uint32_t n, const uint64_t *blk_off, uint32_t *nl, uint32_t cap) {
+__global__ void __launch_bounds__(256) k_nl_fill(const uint8_t *text, uint32_t n, uint32_t lo, const uint64_t *blk_off, uint32_t *nl, uint32_t cap) {
   const uint32_t at = (blockIdx.x * 256u + threadIdx.x) * 16u;
-  uint32_t m = fqt_nl_mask16(text, n, at);
+  uint32_t m = fqt_nl_mask16(text, n, at, lo);
   const uint32_t c = (uint32_t)__popc(m);
   // exclusive prefix of the counts inside the block: inside the wavefront by shuffles, across the four wavefronts through LDS
   uint32_t x = c;
@@ -1027,7 +1047,7 @@ __global__ void __launch_bounds__(256) k_nl_fill(const uint8_t *text, uint32_t n
 __global__ void __launch_bounds__(64) k_nl_total(const uint64_t *blk_off, uint32_t nb, uint32_t *count) {
   if (threadIdx.x == 0) { const uint64_t t = blk_off[nb]; *count = t > 0xffffffffull ? 0xffffffffu : (uint32_t)t; }
 }
-int launch_nl_index(const uint8_t *text, uint32_t n, uint32_t *nl, uint32_t cap, uint32_t *count) {
+int launch_nl_index(const uint8_t *text, uint32_t n, uint32_t lo, uint32_t *nl, uint32_t cap, uint32_t *count) {
   FQ_PRE();
   const unsigned nb = nblk((uint64_t)n, 4096);
   if (nb == 0) { FQ_HIP(hipMemsetAsync(count, 0, 4, g_stream)); return 0; }
@@ -1038,10 +1058,10 @@ int launch_nl_index(const uint8_t *text, uint32_t n, uint32_t *nl, uint32_t cap,
     g_cmp_off = (uint64_t *)dmalloc((g_cmp_n + 2) * 2 * 8);
     if (!g_cmp_cnt || !g_cmp_off) { g_cmp_n = 0; return -4; }
   }
-  hipLaunchKernelGGL(k_nl_count, dim3(nb), dim3(256), 0, g_stream, text, n, g_cmp_cnt);
+  hipLaunchKernelGGL(k_nl_count, dim3(nb), dim3(256), 0, g_stream, text, n, lo, g_cmp_cnt);
   FQ_HIP(hipGetLastError());
   if (launch_scan(g_cmp_cnt, g_cmp_off, nb)) return -3;
-  hipLaunchKernelGGL(k_nl_fill, dim3(nb), dim3(256), 0, g_stream, text, n, (const uint64_t *)g_cmp_off, nl, cap);
+  hipLaunchKernelGGL(k_nl_fill, dim3(nb), dim3(256), 0, g_stream, text, n, lo, (const uint64_t *)g_cmp_off, nl, cap);
   hipLaunchKernelGGL(k_nl_total, dim3(1), dim3(64), 0, g_stream, (const uint64_t *)g_cmp_off, nb, count);
   FQ_HIP(hipGetLastError());
   return 0;

@@ -8,7 +8,9 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <cerrno>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -151,6 +153,7 @@ extern "C" int fq_bgzf_inflate_device(int device, const uint8_t *file, size_t n,
 // (fq_fastq.cpp) standing exactly there, read slots included; their verdicts stand.
 // =====================================================================================================================================
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <deque>
 #include <mutex>
@@ -197,6 +200,7 @@ template <class T> struct HBuf {
 };
 const size_t kPiece = (size_t)32 << 20;       // pinned staging pieces of the compressed stream
 const uint64_t kMaxText = (uint64_t)3500 << 20;   // text positions are 32-bit inside a launch
+const int kSlots = 4;                          // batches: two with the caller (one under its kernels, one under its consumers), one being tokenised, one being inflated
 
 struct CompChunk {                             // one file's compressed bytes of one chunk, in HBM, with their member table
   DBuf<uint8_t> d_comp;
@@ -227,7 +231,7 @@ struct FileSide {
   bool stop = false;
   int64_t inflated_file_off = 0;               // the file offset behind the last chunk that has been inflated
   // text
-  DBuf<uint8_t> d_text[3];                     // one per batch slot
+  DBuf<uint8_t> d_text[kSlots];                // one per batch slot
   DBuf<uint32_t> d_nl;
   uint64_t carry_off = 0, carry_len = 0;       // the text behind the last chunk's records: in d_text[carry_slot]
   int carry_slot = -1;
@@ -235,12 +239,18 @@ struct FileSide {
   int64_t records_done = 0;                    // records of this file in batches so far
   double text_per_record = 0;
   bool all_read = false;                       // every member of the file has been inflated
+  bool all_launched = false;                   // ... has been handed to the decoder (a chunk ahead of all_read)
   // slots
   DBuf<uint8_t> d_slot_base, d_slot_name;
   DBuf<uint16_t> d_slot_len;
   DBuf<uint32_t> d_stat;
   int shorter_after_longer = 0;
+  uint64_t file_size = 0;
+  double comp_ratio = 0.4;                     // compressed bytes per byte of text (the first member's; then the last chunk's)
+  int read_threads = 1;                        // threads of one pread_threads call
+  double ms_read = 0, ms_upload = 0;           // the reader thread's time in pread / in uploads (fq_frontend_stats)
 };
+inline double ms_since(std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
 }  // namespace
 
 struct fq_frontend {
@@ -253,15 +263,17 @@ struct fq_frontend {
   std::mutex mu;
   std::condition_variable cv;
   std::deque<fq_text_batch *> ready;
-  bool slot_free[3] = {true, true, true};
+  bool slot_free[kSlots] = {true, true, true, true};
+  uint64_t headroom_min = (uint64_t)64 << 20;   // least room kept in front of a chunk's new text for the carried text (FASTQUICK_FE_HEADROOM: tests)
+  bool overlap = true;                         // the next chunk's members are inflated beside this chunk's kernels (FASTQUICK_FE_OVERLAP=0: one after the other)
   bool done = false, fallback = false, stop = false;
   std::string err;
   int rc = FQ_OK;
-  fq_text_batch batch[3];
-  DBuf<FqTextRec> d_rec[3];
-  DBuf<uint64_t> d_head[3];
-  DBuf<uint16_t> d_hlen[3];
-  DBuf<char> d_names[3];
+  fq_text_batch batch[kSlots];
+  DBuf<FqTextRec> d_rec[kSlots];
+  DBuf<uint64_t> d_head[kSlots];
+  DBuf<uint16_t> d_hlen[kSlots];
+  DBuf<char> d_names[kSlots];
   HBuf<uint32_t> h_stat;
   int max_name_ever = 0, min_name_ever = INT32_MAX;
   int64_t pairs_done = 0;
@@ -269,11 +281,43 @@ struct fq_frontend {
   // totals (fq_frontend_stats)
   double ms_inflate = 0, ms_tokenise = 0, ms_lines = 0, ms_records = 0, ms_slots = 0;
   int64_t n_members = 0, n_refused = 0, text_bytes = 0, comp_bytes = 0, n_launch_inflate = 0, n_chunks = 0;
+  double ms_wait_reader = 0, ms_wait_slot = 0;  // the producer's waits: for a chunk's compressed bytes; for a batch slot the caller still holds
   ~fq_frontend();
 };
 
 namespace {
 #define FE_FAIL(fe, code, msg) do { (fe)->rc = (code); (fe)->err = (msg); return false; } while (0)
+
+// A piece of the file into (pinned) memory on several threads: a read from the page cache is a memcpy by the kernel, 8-12 GB/s on one
+// thread -- slower than the device inflates what it brings.  Returns the bytes read from `off` on (short only at the end of the file).
+ssize_t pread_threads(int fd, uint8_t *dst, size_t len, off_t off, int threads) {
+  auto whole = [fd](uint8_t *d, size_t n, off_t o) -> ssize_t {
+    size_t done = 0;
+    while (done < n) {
+      const ssize_t g = pread(fd, d + done, n - done, o + (off_t)done);
+      if (g < 0) { if (errno == EINTR) continue; return -1; }
+      if (g == 0) break;
+      done += (size_t)g;
+    }
+    return (ssize_t)done;
+  };
+  const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(1, threads), len >> 22));
+  if (nt == 1) return whole(dst, len, off);
+  const size_t per = ((len + nt - 1) / nt + 4095) & ~(size_t)4095;
+  std::vector<ssize_t> got((size_t)nt, 0);
+  std::vector<std::thread> th;
+  for (int t = 1; t < nt; ++t)
+    th.emplace_back([&, t] { const size_t lo = per * t; got[(size_t)t] = lo < len ? whole(dst + lo, std::min(per, len - lo), off + (off_t)lo) : 0; });
+  got[0] = whole(dst, std::min(per, len), off);
+  for (auto &x : th) x.join();
+  ssize_t total = 0;
+  for (int t = 0; t < nt; ++t) {
+    if (got[(size_t)t] < 0) return -1;
+    total += got[(size_t)t];
+    if ((size_t)got[(size_t)t] < std::min(per, len - std::min(len, per * t))) break;      // the file ended inside this slice
+  }
+  return total;
+}
 
 // ---- reader thread: the next chunk's compressed bytes -> pinned staging -> HBM, with the member table -------------------------------
 void reader_main(fq_frontend *fe, int e) {
@@ -289,19 +333,25 @@ void reader_main(fq_frontend *fe, int e) {
     }
     CompChunk &C = F.chunk[k];
     C.mem.clear(); C.comp_len = 0; C.text_len = 0; C.err.clear(); C.eof = false;
+    // (sized in one go for what the chunk is expected to hold: growing the buffer under the uploads means waiting for them, and a hipFree waits for the device)
+    (void)C.d_comp.ensure((size_t)std::min<double>((double)F.file_size - (double)F.file_off + (double)F.tail.size(), (double)want * F.comp_ratio * 1.1) + 2 * kPiece);
     // pieces: [tail of the previous read | new bytes] -> whole members go to the device, the rest is the next tail
     uint64_t text = 0;
     size_t dev_at = 0;
     int pin_i = 0;
+    bool pin_used[2] = {false, false};
     bool more = true;
     while (more && C.err.empty()) {
       HBuf<uint8_t> &P = F.pin[pin_i];
       size_t have = F.tail.size();
+      if (pin_used[pin_i]) { if (fqdev::copy_wait(pin_i)) { C.err = "upload failed"; break; } pin_used[pin_i] = false; }   // (the upload that last read this buffer)
       if (!P.ensure(have + kPiece + (1 << 17))) { C.err = "out of pinned host memory"; break; }
       if (have) memcpy(P.p, F.tail.data(), have);
       F.tail.clear();
       if (!F.file_eof && have < kPiece) {                    // (a long tail -- the rest of a piece whose chunk was full -- is used up first)
-        const ssize_t got = pread(F.fd, P.p + have, kPiece, (off_t)F.file_off);
+        const auto t0 = std::chrono::steady_clock::now();
+        const ssize_t got = pread_threads(F.fd, P.p + have, kPiece, (off_t)F.file_off, F.read_threads);
+        F.ms_read += ms_since(t0);
         if (got < 0) { C.err = "read error"; break; }
         if (got == 0) F.file_eof = true;
         F.file_off += got;
@@ -327,8 +377,16 @@ void reader_main(fq_frontend *fe, int e) {
       if (!C.err.empty()) break;
       // the members' bytes go up; what is behind them waits for the next piece
       if (at) {
+        if (C.d_comp.cap < dev_at + at + 2048) {               // (the uploads so far land before the buffer moves)
+          for (int i = 0; i < 2; ++i) if (pin_used[i] && fqdev::copy_wait(i)) C.err = "upload failed";
+          if (!C.err.empty()) break;
+        }
         if (!C.d_comp.ensure_keep(dev_at + at + 2048, dev_at)) { C.err = "out of device memory"; break; }
-        if (fqdev::h2d(C.d_comp.p + dev_at, P.p, at) || fqdev::sync()) { C.err = "upload failed"; break; }
+        // (on the copy stream, with an event per staging buffer: the next piece is read while this one goes up)
+        const auto t0 = std::chrono::steady_clock::now();
+        if (fqdev::h2d_copy(C.d_comp.p + dev_at, P.p, at) || fqdev::copy_record(pin_i)) { C.err = "upload failed"; break; }
+        pin_used[pin_i] = true;
+        F.ms_upload += ms_since(t0);
         dev_at += at;
       }
       F.tail.assign(P.p + at, P.p + have);
@@ -338,10 +396,16 @@ void reader_main(fq_frontend *fe, int e) {
       }
       pin_i ^= 1;
     }
+    {
+      const auto t0 = std::chrono::steady_clock::now();
+      for (int i = 0; i < 2; ++i) if (pin_used[i] && fqdev::copy_wait(i) && C.err.empty()) C.err = "upload failed";
+      F.ms_upload += ms_since(t0);
+    }
     if (C.err.empty()) {
       C.file_off_end = F.file_off - (int64_t)F.tail.size();      // the first byte of the file that is not in this chunk
       C.comp_len = dev_at;
       C.text_len = text;
+      if (text > (1u << 20)) F.comp_ratio = (double)dev_at / (double)text;
       C.eof = F.file_eof && F.tail.empty();
       if (!C.d_mem.ensure(C.mem.size() + 1) || !C.d_status.ensure(C.mem.size() + 1)) C.err = "out of device memory";
       if (C.err.empty() && dev_at && (fqdev::dzero(C.d_comp.p + dev_at, 1024) || fqdev::sync())) C.err = "upload failed";
@@ -356,9 +420,19 @@ void reader_main(fq_frontend *fe, int e) {
   }
 }
 
-struct ChunkPlan { int n = 0; bool last = false, fall = false; };
+// One chunk's inflation, started one chunk ahead of the kernels that read its text (producer_main)
+struct Ahead {
+  bool open = false;                // a batch slot is taken and the members of the files that still have some are being inflated
+  int slot = -1, comp_k = -1;
+  bool has[2] = {false, false};     // the file had a compressed chunk for this one
+  uint64_t H[2] = {0, 0};           // where its new text begins in d_text[slot] (a multiple of 256: the carried text goes in front of it)
+};
 
-// the producer: chunk after chunk until the end of the stream, a failure, or something the device does not take
+// the producer: chunk after chunk until the end of the stream, a failure, or something the device does not take.
+// Two streams: the members of chunk j + 1 are inflated (aux stream) while chunk j's text is indexed, checked and keyed (main stream) -- the
+// decoder is bound by the latency of its own dependent steps and leaves the memory system to the kernels beside it.  A chunk's text begins with
+// what the chunk before it left over behind its last whole reference batch, and how much that is is known only when that chunk has been
+// tokenised: the new text is inflated at a fixed distance H from the buffer's start and the carried text copied in front of it afterwards.
 void producer_main(fq_frontend *fe) {
   auto finish = [&](int rc, const std::string &err, bool fallback) {
     std::lock_guard<std::mutex> lk(fe->mu);
@@ -368,64 +442,127 @@ void producer_main(fq_frontend *fe) {
     fe->cv.notify_all();
   };
   if (fqdev::bind(fe->st)) { finish(FQ_ENODEV, "no device", false); return; }
+  if (fe->overlap && fqdev::stream_aux(1)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }   // (creates the second stream)
+  fqdev::stream_aux(0);
   const int NF = fe->n_files;
   const int B = fe->batch_pairs;
   const int n_slots = 2 * B;
-  int comp_k = 0;
-  for (;;) {
-    // ---- a free batch slot ----
+  int comp_next = 0;                 // the compressed slot the next chunk's members are in
+  int64_t n_started = 0, n_taken = 0;   // chunks whose inflation has been started / whose text has been taken up (their marks alternate)
+  Ahead next;
+  // Starts the next chunk's inflation.  block: wait for a batch slot and for the readers; otherwise only when both are there already.
+  // Returns 1 started (or nothing is left to inflate: the chunk is its carried text), 0 not now, -1 failed / stopped (finish() has been called).
+  auto start_ahead = [&](bool block) -> int {
+    if (next.open) return 1;
+    {
+      const auto t0 = std::chrono::steady_clock::now();
+      std::unique_lock<std::mutex> lk(fe->mu);
+      if (!block && !(fe->stop || fe->slot_free[fe->next_slot])) return 0;
+      fe->cv.wait(lk, [&] { return fe->stop || fe->slot_free[fe->next_slot]; });
+      fe->ms_wait_slot += ms_since(t0);
+      if (fe->stop) return -1;
+    }
+    CompChunk *Cs[2] = {nullptr, nullptr};
+    for (int e = 0; e < NF; ++e) {
+      FileSide &F = fe->f[e];
+      if (F.all_launched) continue;
+      const auto t0 = std::chrono::steady_clock::now();
+      std::unique_lock<std::mutex> lk(F.mu);
+      if (!block && !F.filled[comp_next]) return 0;
+      F.cv.wait(lk, [&] { return F.filled[comp_next]; });
+      fe->ms_wait_reader += ms_since(t0);
+      Cs[e] = &F.chunk[comp_next];
+    }
     int slot;
     {
-      std::unique_lock<std::mutex> lk(fe->mu);
-      fe->cv.wait(lk, [&] { return fe->stop || fe->slot_free[fe->next_slot]; });
-      if (fe->stop) return;
+      std::lock_guard<std::mutex> lk(fe->mu);
       slot = fe->next_slot;
       fe->slot_free[slot] = false;
-      fe->next_slot = (slot + 1) % 3;
+      fe->next_slot = (slot + 1) % kSlots;
     }
+    next = Ahead();
+    next.open = true; next.slot = slot; next.comp_k = comp_next;
+    for (int e = 0; e < NF; ++e) {
+      FileSide &F = fe->f[e];
+      CompChunk *C = Cs[e];
+      if (!C) continue;
+      next.has[e] = true;
+      if (!C->err.empty()) { finish(FQ_EIO, F.path + ": " + C->err, false); return -1; }
+      if (C->eof) F.all_launched = true;
+      // room in front of the new text for what the chunk before leaves over: a reference batch's worth and a half, 64 MB at least
+      const uint64_t H = ((uint64_t)std::max<double>((double)fe->headroom_min, fe->headroom_min ? 1.5 * (double)B * F.text_per_record : 0.0) + 255) & ~(uint64_t)255;
+      next.H[e] = H;
+      if (H + C->text_len > 0xfff00000ull) { finish(FQ_ELIMIT, "a chunk's text exceeds 4 GiB", false); return -1; }
+      if (!F.d_text[slot].ensure((size_t)(H + C->text_len) + 4096)) { finish(FQ_ENOMEM, "out of device memory (text)", false); return -1; }
+      if (C->mem.empty()) continue;
+      if (fe->overlap) fqdev::stream_aux(1);
+      bool bad = false;
+      for (auto &m : C->mem) m.out_off += (uint32_t)H;       // (256-byte alignment of the buffer's base is what the decoder's stores rely on: the shift is in the members' offsets)
+      bad = bad || fqdev::h2d(C->d_mem.p, C->mem.data(), C->mem.size() * sizeof(FqzMember));
+      FqInflateArgs a{};
+      a.comp = C->d_comp.p; a.mem = C->d_mem.p; a.n_mem = (int)C->mem.size(); a.out = F.d_text[slot].p; a.status = C->d_status.p; a.crc = fqdev::crc_const();
+      bad = bad || !a.crc;
+      if (!bad) {
+        fqdev::time_begin(0);
+        bad = fqdev::launch_inflate(a) != 0;
+        fqdev::time_end(0);
+      }
+      fqdev::stream_aux(0);
+      if (bad) { finish(FQ_ENODEV, fqdev::last_error(), false); return -1; }
+    }
+    if (fe->overlap) { fqdev::stream_aux(1); const int rc = fqdev::stream_mark((int)(n_started & 1)); fqdev::stream_aux(0); if (rc) { finish(FQ_ENODEV, fqdev::last_error(), false); return -1; } }
+    ++n_started;
+    comp_next = (comp_next + 1) % 3;
+    return 1;
+  };
+  for (;;) {
+    // ---- this chunk: its members are being inflated already, or are started now ----
+    if (start_ahead(true) < 0) return;
+    const Ahead cur = next;
+    next = Ahead();
+    const int slot = cur.slot;
     fq_text_batch &TB = fe->batch[slot];
     TB = fq_text_batch();
     TB.slot = slot; TB.device = fe->device; TB.single_end = NF == 1; TB.batch_pairs = B; TB.row_cap = fe->max_len;
     uint32_t n_lines[2] = {0, 0};
-    uint64_t n_text[2] = {0, 0};
+    uint64_t n_text[2] = {0, 0};      // bytes of the chunk's view: [0, skip) in front of the text for the alignment, then carried text, then new text
+    uint32_t skip[2] = {0, 0};
+    uint64_t view[2] = {0, 0};        // where the view begins in d_text[slot] (a multiple of 16)
     bool at_eof[2] = {true, true};
-    // ---- inflate both files' chunks behind their carried text ----
     double t_ms[FQ_K_COUNT] = {0};
     uint64_t t_n[FQ_K_COUNT] = {0};
+    if (fe->overlap && fqdev::stream_wait_mark((int)(n_taken & 1))) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+    ++n_taken;
+    // ---- the carried text in front of the new text ----
     for (int e = 0; e < NF; ++e) {
       FileSide &F = fe->f[e];
-      CompChunk *C = nullptr;
-      if (!F.all_read) {
-        std::unique_lock<std::mutex> lk(F.mu);
-        F.cv.wait(lk, [&] { return F.filled[comp_k]; });
-        C = &F.chunk[comp_k];
-      }
-      if (C && !C->err.empty()) { finish(FQ_EIO, F.path + ": " + C->err, false); return; }
+      CompChunk *C = cur.has[e] ? &F.chunk[cur.comp_k] : nullptr;
       const uint64_t new_text = C ? C->text_len : 0;
-      n_text[e] = F.carry_len + new_text;
-      if (n_text[e] > 0xfff00000ull) { finish(FQ_ELIMIT, "a chunk's text exceeds 4 GiB", false); return; }
-      if (!F.d_text[slot].ensure((size_t)n_text[e] + 4096)) { finish(FQ_ENOMEM, "out of device memory (text)", false); return; }
-      if (F.carry_len && fqdev::d2d(F.d_text[slot].p, F.d_text[F.carry_slot].p + F.carry_off, (size_t)F.carry_len)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
-      if (C) F.inflated_file_off = C->file_off_end;
-      if (C && !C->mem.empty()) {
-        // the members' text begins behind the carried text: out_off is rebased by giving the kernel a shifted buffer (256-byte alignment
-        // of the buffer's base is what the decoder's stores rely on: the shift goes into the members' offsets instead)
-        for (auto &m : C->mem) m.out_off += (uint32_t)F.carry_len;
-        if (fqdev::h2d(C->d_mem.p, C->mem.data(), C->mem.size() * sizeof(FqzMember))) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
-        FqInflateArgs a{};
-        a.comp = C->d_comp.p; a.mem = C->d_mem.p; a.n_mem = (int)C->mem.size(); a.out = F.d_text[slot].p; a.status = C->d_status.p; a.crc = fqdev::crc_const();
-        if (!a.crc) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
-        fqdev::time_begin(0);
-        if (fqdev::launch_inflate(a)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
-        fqdev::time_end(0);
+      uint64_t H = C ? cur.H[e] : ((F.carry_len + 255) & ~(uint64_t)255);
+      if (!C && !F.d_text[slot].ensure((size_t)(H + 4096))) { finish(FQ_ENOMEM, "out of device memory (text)", false); return; }
+      if (C && F.carry_len > H) {
+        // more was left over than there is room in front of the new text (reads of kilobytes; files whose records differ much in size): the new
+        // text moves back, through a second buffer
+        const uint64_t H2 = (F.carry_len + 255) & ~(uint64_t)255;
+        DBuf<uint8_t> tmp;
+        if (H2 + new_text > 0xfff00000ull) { finish(FQ_ELIMIT, "a chunk's text exceeds 4 GiB", false); return; }
+        if (!tmp.ensure((size_t)new_text + 256) || fqdev::d2d(tmp.p, F.d_text[slot].p + H, (size_t)new_text) || fqdev::sync() ||
+            !F.d_text[slot].ensure_keep((size_t)(H2 + new_text) + 4096, 0) || fqdev::d2d(F.d_text[slot].p + H2, tmp.p, (size_t)new_text) || fqdev::sync()) { finish(FQ_ENOMEM, "out of device memory (text)", false); return; }
+        for (auto &m : C->mem) m.out_off += (uint32_t)(H2 - H);
+        H = H2;
       }
+      const uint64_t t0 = H - F.carry_len;
+      view[e] = t0 & ~(uint64_t)15; skip[e] = (uint32_t)(t0 & 15);
+      n_text[e] = skip[e] + F.carry_len + new_text;
+      if (F.carry_len && fqdev::d2d(F.d_text[slot].p + t0, F.d_text[F.carry_slot].p + F.carry_off, (size_t)F.carry_len)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+      if (C) F.inflated_file_off = C->file_off_end;
       at_eof[e] = C ? C->eof : true;
     }
     // ---- members the device refused: the host's decoder, then zlib, whose verdict stands ----
     for (int e = 0; e < NF; ++e) {
       FileSide &F = fe->f[e];
-      if (F.all_read) continue;
-      CompChunk &C = F.chunk[comp_k];
+      if (!cur.has[e]) continue;
+      CompChunk &C = F.chunk[cur.comp_k];
       if (C.mem.empty()) continue;
       std::vector<uint32_t> status(C.mem.size());
       if (fqdev::d2h(status.data(), C.d_status.p, status.size() * 4) || fqdev::sync()) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
@@ -460,25 +597,26 @@ void producer_main(fq_frontend *fe) {
     // ---- the compressed slot is free again: the reader threads run up to two chunks ahead ----
     for (int e = 0; e < NF; ++e) {
       FileSide &F = fe->f[e];
-      if (F.all_read) continue;
-      const bool eof = F.chunk[comp_k].eof;
+      if (!cur.has[e]) continue;
+      const bool eof = F.chunk[cur.comp_k].eof;
       std::lock_guard<std::mutex> lk(F.mu);
-      F.filled[comp_k] = false;
+      F.filled[cur.comp_k] = false;
       if (eof) F.all_read = true;
       F.cv.notify_all();
     }
-    comp_k = (comp_k + 1) % 3;
+    // ---- the next chunk's members, beside this chunk's kernels (when its compressed bytes and a batch slot are there already) ----
+    if (fe->overlap && start_ahead(false) < 0) return;
     // ---- line ends ----
     fqdev::time_begin(1);
-    bool t1_open = true;
     for (int e = 0; e < NF; ++e) {
       FileSide &F = fe->f[e];
       const size_t cap = (size_t)(4 * (fe->chunk_pairs + B) + 64);
       if (!F.d_nl.ensure(cap) || !F.d_stat.ensure(FQT_N_STAT + 8)) { finish(FQ_ENOMEM, "out of device memory (line index)", false); return; }
-      if (fqdev::dzero(F.d_text[slot].p + n_text[e], 256)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
-      if (fqdev::launch_nl_index(F.d_text[slot].p, (uint32_t)n_text[e], F.d_nl.p, (uint32_t)cap, F.d_stat.p + FQT_N_STAT)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+      uint8_t *T = F.d_text[slot].p + view[e];
+      if (fqdev::dzero(T + n_text[e], 256)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
+      if (fqdev::launch_nl_index(T, (uint32_t)n_text[e], skip[e], F.d_nl.p, (uint32_t)cap, F.d_stat.p + FQT_N_STAT)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
     }
-    fqdev::time_end(1); t1_open = false; (void)t1_open;
+    fqdev::time_end(1);
     if (!fe->h_stat.ensure(64)) { finish(FQ_ENOMEM, "out of pinned host memory", false); return; }
     for (int e = 0; e < NF; ++e) if (fqdev::copy_pinned(fe->h_stat.p + 32 * e, fe->f[e].d_stat.p + FQT_N_STAT, 4, 0)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
     if (fqdev::sync()) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
@@ -510,7 +648,7 @@ void producer_main(fq_frontend *fe) {
         const uint32_t init[FQT_N_STAT] = {0xffffffffu, 0, 0xffffffffu, 0, 0, 0xffffffffu, 0, 0};
         if (fqdev::h2d(F.d_stat.p, init, sizeof init)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
         FqTokArgs a{};
-        a.text = F.d_text[slot].p; a.nl = F.d_nl.p; a.n_rec = (int)n; a.row0 = (int)(e * n); a.n_rows = n_rows; a.max_len = fe->max_len;
+        a.text = F.d_text[slot].p + view[e]; a.text0 = skip[e]; a.nl = F.d_nl.p; a.n_rec = (int)n; a.row0 = (int)(e * n); a.n_rows = n_rows; a.max_len = fe->max_len;
         a.rec = fe->d_rec[slot].p; a.head = fe->d_head[slot].p; a.hlen = fe->d_hlen[slot].p; a.stat = F.d_stat.p;
         fqdev::time_begin(2);
         if (fqdev::launch_tok_rec(a) || fqdev::launch_tok_pieces(a)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
@@ -548,7 +686,7 @@ void producer_main(fq_frontend *fe) {
       for (int e = 0; e < NF; ++e) {
         FileSide &F = fe->f[e];
         FqSlotArgs s{};
-        s.text = F.d_text[slot].p; s.rec = fe->d_rec[slot].p; s.n_rec = (int)n; s.row0 = (int)(e * n); s.n_rows = n_rows; s.g0 = F.records_done;
+        s.text = F.d_text[slot].p + view[e]; s.rec = fe->d_rec[slot].p; s.n_rec = (int)n; s.row0 = (int)(e * n); s.n_rows = n_rows; s.g0 = F.records_done;
         s.n_slots = n_slots; s.mode = fe->slot_mode; s.slot_base = F.d_slot_base.p; s.slot_len = F.d_slot_len.p; s.slot_name = F.d_slot_name.p;
         s.head = fe->d_head[slot].p; s.names = fe->d_names[slot].p; s.name_stride = name_stride; s.stat = F.d_stat.p;
         s.all_long = all_long ? 1 : 0; s.plain_names = plain_names ? 1 : 0;
@@ -567,25 +705,25 @@ void producer_main(fq_frontend *fe) {
           if (fqdev::d2h(&fn[((size_t)sb * 2 + e) * name_stride], fe->d_names[slot].p + ((size_t)e * n + (size_t)sb * B) * name_stride, (size_t)name_stride)) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
       if (fqdev::sync()) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
       for (int e = 0; e < NF; ++e) if (fe->h_stat.p[32 * e + FQT_SHORTER_AFTER_LONGER]) fe->f[e].shorter_after_longer = 1;
-      TB.d_text[0] = fe->f[0].d_text[slot].p; TB.d_text[1] = NF > 1 ? fe->f[1].d_text[slot].p : nullptr;
+      TB.d_text[0] = fe->f[0].d_text[slot].p + view[0]; TB.d_text[1] = NF > 1 ? fe->f[1].d_text[slot].p + view[1] : nullptr;
       TB.d_rec = fe->d_rec[slot].p; TB.d_head = fe->d_head[slot].p; TB.d_hlen = fe->d_hlen[slot].p; TB.d_names = fe->d_names[slot].p;
     }
     // ---- what stays for the next chunk: the text behind record n ----
     for (int e = 0; e < NF; ++e) {
       FileSide &F = fe->f[e];
-      uint32_t cut = 0;
+      uint32_t cut = skip[e];
       if (n > 0) {
         if (fqdev::d2h(&cut, F.d_nl.p + 4 * (size_t)n - 1, 4) || fqdev::sync()) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
         cut += 1;
       }
-      F.carry_slot = slot; F.carry_off = cut; F.carry_len = n_text[e] - cut;
+      F.carry_slot = slot; F.carry_off = view[e] + cut; F.carry_len = n_text[e] - cut;
       const int64_t recs = (int64_t)(n_lines[e] / 4);
       if (recs > 0 && n_text[e] > 0) {
         uint32_t last_nl = 0;
         const size_t cap_lines = (size_t)(4 * (fe->chunk_pairs + B));
         const size_t idx = std::min<size_t>((size_t)recs * 4, cap_lines) - 1;
         if (fqdev::d2h(&last_nl, F.d_nl.p + idx, 4) || fqdev::sync()) { finish(FQ_ENODEV, fqdev::last_error(), false); return; }
-        F.text_per_record = (double)(last_nl + 1) / (double)((idx + 1) / 4);
+        F.text_per_record = (double)(last_nl + 1 - skip[e]) / (double)((idx + 1) / 4);
       }
       F.records_done += n;
       {
@@ -611,10 +749,18 @@ void producer_main(fq_frontend *fe) {
       // not one whole reference batch in a chunk's worth of text (reads of many kilobytes): not the device's case
       fall = true;
     }
+    if (stream_end || fall) {
+      // (a chunk whose members were started ahead is dropped: the hand-over stands behind this chunk, F.inflated_file_off)
+      if (next.open) { if (fe->overlap) { fqdev::stream_aux(1); (void)fqdev::sync(); fqdev::stream_aux(0); } }
+      (void)fqdev::sync();
+      double t2[FQ_K_COUNT] = {0}; uint64_t n2[FQ_K_COUNT] = {0};
+      fqdev::time_collect(t2, n2, FQ_K_COUNT);
+      if (stream_end) { fe->ms_inflate += t2[0]; fe->n_launch_inflate += (int64_t)n2[0]; }
+    }
     {
       std::lock_guard<std::mutex> lk(fe->mu);
       if (n > 0) fe->ready.push_back(&TB); else fe->slot_free[slot] = true;
-      if (stream_end || fall) { fe->done = true; fe->fallback = fall; }
+      if (stream_end || fall) { fe->done = true; fe->fallback = fall; if (next.open) fe->slot_free[next.slot] = true; }
       fe->cv.notify_all();
     }
     if (stream_end || fall) return;
@@ -646,6 +792,8 @@ extern "C" int fq_frontend_open(int device, const char *fq1, const char *fq2, in
   std::unique_ptr<fq_frontend> fe(new fq_frontend);
   fe->device = device; fe->batch_pairs = batch_pairs; fe->chunk_pairs = chunk_pairs / batch_pairs * batch_pairs; fe->max_len = max_read_len;
   fe->n_files = (fq2 && *fq2) ? 2 : 1;
+  if (const char *ev = getenv("FASTQUICK_FE_HEADROOM")) fe->headroom_min = strtoull(ev, nullptr, 10);                 // (0: none at all -- the carried text always moves the new text back)
+  if (const char *ev = getenv("FASTQUICK_FE_OVERLAP")) fe->overlap = atoi(ev) != 0;      // (0: measurements of the kernels on their own)
   fe->slot_mode = fe->n_files == 1 ? FQ_FASTQ_SLOTS_FRESH : slot_mode;
   const char *paths[2] = {fq1, fq2};
   for (int e = 0; e < fe->n_files; ++e) {
@@ -659,7 +807,9 @@ extern "C" int fq_frontend_open(int device, const char *fq1, const char *fq2, in
     const ssize_t got = pread(F.fd, h, sizeof h, 0);
     size_t hdr = 0;
     const size_t sz = got >= 18 ? bgzf_member(h, (size_t)got, &hdr) : 0;
-    if (sz == 0) return FQ_EIO;                                                     // not BGZF: the host reader's case
+    if (sz == 0) return FQ_EIO;
+    F.file_size = (uint64_t)sb.st_size;
+    if (sz >= hdr + 8 && (size_t)got >= sz && le32(h + sz - 4)) F.comp_ratio = (double)sz / (double)le32(h + sz - 4);                                                     // not BGZF: the host reader's case
     // the text a record takes, from the file's first member (inflated here, on the host: 64 KiB)
     F.text_per_record = 320.0;
     if ((size_t)got >= sz && sz >= hdr + 8) {
@@ -688,6 +838,8 @@ extern "C" int fq_frontend_open(int device, const char *fq1, const char *fq2, in
   if (fqdev::sync()) return FQ_ENODEV;
   for (int e = 0; e < fe->n_files; ++e) {
     fe->f[e].want_text = (uint64_t)std::min<double>((double)kMaxText, (double)fe->chunk_pairs * fe->f[e].text_per_record * 1.005 + (256 << 10));
+    fe->f[e].read_threads = std::max(1, std::min(4, fq_host_cpus() / (2 * fe->n_files)));     // (of the CPUs this process may use: fq_host_cpus)
+    if (const char *ev = getenv("FASTQUICK_FE_READ_THREADS")) fe->f[e].read_threads = std::max(1, std::min(16, atoi(ev)));
     fe->f[e].th = std::thread(reader_main, fe.get(), e);
   }
   fe->producer = std::thread(producer_main, fe.get());
@@ -761,6 +913,7 @@ extern "C" void fq_frontend_stats(const fq_frontend_t *fe, fq_frontend_stats_t *
   if (!fe || !s) return;
   s->ms_inflate = fe->ms_inflate; s->ms_tokenise = fe->ms_tokenise; s->members = fe->n_members; s->refused = fe->n_refused;
   s->text_bytes = fe->text_bytes; s->comp_bytes = fe->comp_bytes; s->pairs = fe->pairs_done;
+  s->ms_wait_reader = fe->ms_wait_reader; s->ms_wait_slot = fe->ms_wait_slot; s->ms_read = fe->f[0].ms_read + fe->f[1].ms_read; s->ms_upload = fe->f[0].ms_upload + fe->f[1].ms_upload;
   s->ms_lines = fe->ms_lines; s->ms_records = fe->ms_records; s->ms_slots = fe->ms_slots; s->inflate_launches = fe->n_launch_inflate; s->chunks = fe->n_chunks;
 }
 // batch accessors

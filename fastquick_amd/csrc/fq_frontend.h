@@ -123,6 +123,13 @@ FQ_HD uint32_t fqz_xpow8(const uint32_t *pow8, uint32_t n) {   // x^(8 n) mod P
 static_assert((FQZ_RING & (FQZ_RING - 1)) == 0 && FQZ_RING >= 1024 && FQZ_LROOT >= 9 && FQZ_LROOT <= 11, "ring a power of two that holds a line and the longest match; root table of 9 to 11 bits");
 #define FQZ_DROOT 8
 enum { FQZ_OK = 0, FQZ_REFUSED = 1, FQZ_BADCRC = 2 };
+#if defined(FQZ_STATS) && !defined(__HIP_DEVICE_COMPILE__)
+// symbol mix of a run through the host statement (tools/inflate_mix.cpp): [0] literals [1] near matches [2] far matches [3] matches over their own bytes [4] general steps [5] refills [6] match bytes
+static unsigned long long fqz_stats[16];
+#define FQZ_STAT(k, n) (fqz_stats[k] += (n))
+#else
+#define FQZ_STAT(k, n) ((void)0)
+#endif
 struct FqzMember { uint64_t in_off; uint32_t out_off, in_len, out_len, crc; uint32_t pad[2]; };   // payload [in_off, in_off + in_len) of `comp`; text at out + out_off (a launch writes at most 4 GiB)
 struct FqInflateArgs {
   const uint8_t *comp;          // compressed bytes, 4-byte aligned, at least 1 KiB of readable slack behind the last member
@@ -748,6 +755,7 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
             bb |= (uint64_t)FQF_UNIFORM32(FQF_RL(D.wcur, di)) << bc; bc += 32; ++di;
           }
           const uint32_t e = FQF_UNIFORM32(S.lt[bb & ((1u << FQZ_LROOT) - 1)]);
+          FQZ_STAT(8 + ((e & 31) <= 6 ? 0 : (e & 31) <= 7 ? 1 : 2), 1);
           if (e & FQZ_K_BASE) {
             len = (e >> 23) + fqz_extra_of(bb, e);
             const uint32_t t1 = fqz_take_of(e);
@@ -758,6 +766,7 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
               bb |= (uint64_t)FQF_UNIFORM32(FQF_RL(D.wcur, di)) << bc; bc += 32; ++di;
             }
             const uint32_t f = FQF_UNIFORM32(S.dt[bb & ((1u << FQZ_DROOT) - 1)]);
+            FQZ_STAT(11 + ((f & 31) <= 6 ? 0 : (f & 31) <= 7 ? 1 : 2), 1);
             if (!(f & FQZ_K_BASE)) break;
             const uint32_t dist = fqz_dist_of(bb, f);
             if (dist > g - g0) break;
@@ -767,6 +776,7 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
             bb >>= t2; bc -= (int)t2;
             why = 0;
             const uint32_t s = g - dist;
+            FQZ_STAT(6, len); FQZ_STAT(dist < len ? 3 : dist <= FQZ_RING - 2 * 64 ? 1 : 2, 1);
             if (dist >= len) {
               if (dist <= FQZ_RING - 2 * 64) {
                 FQF_LANES
@@ -798,6 +808,7 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
           {
             const uint32_t t1 = fqz_take_of(e);
             bb >>= t1; bc -= (int)t1;
+            FQZ_STAT(0, 1);
             FQF_LANES
               ring[g & (FQZ_RING - 1)] = (uint8_t)(e >> 23);
             FQF_LANES_END
@@ -815,6 +826,7 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
         D.bb = bb; D.bc = bc; D.di = di; D.g = g;
       }
 #endif
+      FQZ_STAT(4, 1);
       const int r = why ? fqz_general_dist(D, S, len, dent) : fqz_general_symbol(D, S, lent, dent);
       if (r == 1) break;
       if (r == 2) { status = FQZ_REFUSED; break; }
@@ -851,6 +863,7 @@ struct FqTokArgs {
   int32_t row0;              // the file's first row in the batch's arrays: end * n_pairs
   int32_t n_rows;            // rows of the batch (2 n_pairs; n for a single-end batch)
   int32_t max_len;           // a read longer than this is not taken (the rows the aligner sizes)
+  uint32_t text0;            // where the first record begins (0..15: `text` is 16-byte aligned, the text proper need not be)
   FqTextRec *rec;            // [n_rows]
   uint64_t *head;            // [3][n_rows]: the filter's 32-mers (src/BwtIndexer.cpp:441-456), bases behind a short read as 'A' (fqt_slot_bases_thread puts the slot's there)
   uint16_t *hlen;            // [n_rows]
@@ -859,7 +872,7 @@ struct FqTokArgs {
 // one thread per record: the four lines, the name, the lengths
 FQ_HD void fqt_rec_thread(const FqTokArgs &A, int i) {
   const uint8_t *T = A.text;
-  const uint32_t l0 = i ? A.nl[4 * (size_t)i - 1] + 1 : 0;
+  const uint32_t l0 = i ? A.nl[4 * (size_t)i - 1] + 1 : A.text0;
   const uint32_t e0 = A.nl[4 * (size_t)i], e1 = A.nl[4 * (size_t)i + 1], e2 = A.nl[4 * (size_t)i + 2], e3 = A.nl[4 * (size_t)i + 3];
   const uint32_t l1 = e0 + 1, l2 = e1 + 1, l3 = e2 + 1;
   bool ok = l0 < e0 && T[l0] == '@' && l2 < e2 && T[l2] == '+' && (e1 - l1) == (e3 - l3) && (e1 - l1) <= (uint32_t)A.max_len;

@@ -315,6 +315,8 @@ typedef struct {
   int64_t members, refused, text_bytes, comp_bytes, pairs;
   double ms_lines, ms_records, ms_slots; /* ms_tokenise by kernel group: line index; record checks + filter keys; read slots + names */
   int64_t inflate_launches, chunks;
+  double ms_wait_reader, ms_wait_slot;   /* the producer thread's waits (wall): for a chunk's compressed bytes in HBM; for a batch the caller still holds */
+  double ms_read, ms_upload;             /* the reader threads' time (wall, summed over the files): pread into pinned memory; copies to HBM */
 } fq_frontend_stats_t;
 int fq_frontend_open(int device, const char *fq1, const char *fq2, int32_t batch_pairs, int64_t chunk_pairs, int32_t slot_mode, int32_t max_read_len, fq_frontend_t **out);
 int64_t fq_frontend_next(fq_frontend_t *fe, fq_text_batch_t **out);

@@ -136,6 +136,8 @@ int launch_sa(const FqSaArgs &a) { for (uint64_t q = 0; q < a.n_rows; ++q) fq_sa
 int stream_aux(int) { return 0; }
 int stream_fork() { return 0; }
 int stream_join() { return 0; }
+int stream_mark(int) { return 0; }
+int stream_wait_mark(int) { return 0; }
 int launch_collect(const int32_t *order, const uint32_t *, int n_work, int seg, int n_seg, const uint32_t *status, const int32_t *work, int32_t *out, uint32_t *count) {
   uint32_t lo, hi;
   fq_seg_range((uint32_t)n_work, seg, n_seg, &lo, &hi);   // (one block here, as in launch_gap)
@@ -165,9 +167,9 @@ int launch_inflate(const FqInflateArgs &a) {
   delete lds;
   return 0;
 }
-int launch_nl_index(const uint8_t *text, uint32_t n, uint32_t *nl, uint32_t cap, uint32_t *count) {
+int launch_nl_index(const uint8_t *text, uint32_t n, uint32_t lo, uint32_t *nl, uint32_t cap, uint32_t *count) {
   uint32_t c = 0;
-  for (uint32_t i = 0; i < n; ++i) if (text[i] == '\n') { if (c < cap) nl[c] = i; ++c; }
+  for (uint32_t i = lo; i < n; ++i) if (text[i] == '\n') { if (c < cap) nl[c] = i; ++c; }
   *count = c;
   return 0;
 }

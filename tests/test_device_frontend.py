@@ -237,8 +237,15 @@ def front_end_arrays(lib, fq, batch_pairs, chunk_pairs, slot_mode, max_read_len=
 
 @pytest.mark.parametrize("slot_mode", [0, 1, 2], ids=["reused_slots", "clean_names", "fresh"])
 @pytest.mark.parametrize("tag", ["basic", "trim76", "example151", "long250", "cfg0_example"])
-def test_front_end_arrays_are_the_host_readers_and_packers(tag, slot_mode, golden_cases, lib, tmp_path):
-    """the filter's keys, lengths and names the device forms from the text == fq_fastq_read + fq_pack_reads_into, bit for bit"""
+def test_front_end_arrays_are_the_host_readers_and_packers(tag, slot_mode, golden_cases, lib, tmp_path, monkeypatch):
+    """the filter's keys, lengths and names the device forms from the text == fq_fastq_read + fq_pack_reads_into, bit for bit.
+    (A chunk's new text is inflated before the length of the text carried over from the chunk before is known, a fixed distance into the
+    buffer: with FASTQUICK_FE_HEADROOM that distance is the default -- the carried text fits in front -- , tiny -- it fits some times --, or
+    none -- the new text is always moved back.)"""
+    if slot_mode == 1:
+        monkeypatch.setenv("FASTQUICK_FE_HEADROOM", "0")
+    elif slot_mode == 2:
+        monkeypatch.setenv("FASTQUICK_FE_HEADROOM", "4096")
     g = golden_cases[tag]
     fq = bgzf_pair(g, tmp_path, level=1, member=5000)
     B = 64
@@ -252,9 +259,12 @@ def test_front_end_arrays_are_the_host_readers_and_packers(tag, slot_mode, golde
         assert np.array_equal(np.concatenate(dn[e]), names[e * n:(e + 1) * n]), "names of end %d" % e
 
 
-def test_front_end_hands_over_at_a_reference_batch_boundary(golden_cases, lib, tmp_path):
+@pytest.mark.parametrize("overlap", ["1", "0"], ids=["inflating_ahead", "one_after_the_other"])
+def test_front_end_hands_over_at_a_reference_batch_boundary(overlap, golden_cases, lib, tmp_path, monkeypatch):
     """an odd record in the middle of a file: the device's part ends at the boundary of the reference batch that holds it; the host readers
     standing there return the rest -- together exactly the records (names, read-slot history included) the host path alone returns"""
+    monkeypatch.setenv("FASTQUICK_FE_OVERLAP", overlap)
+    monkeypatch.setenv("FASTQUICK_FE_HEADROOM", "8192")
     g = golden_cases["qc"]
     recs = [open(g[k], "rb").read().split(b"\n") for k in ("fq1", "fq2")]
     B, odd = 256, 1500

@@ -16,4 +16,5 @@ synth.write_qc_inputs(pre, ref); synth.write_param(pre, ref, 1000)
 open(pre + ".genome.fa.fai", "w").write("1\t%d\t3\t60\t61\n" % len(ref.genome))
 PY
 fi
-FASTQUICK_TRACE=1 $R/fastquick_amd/bin/FASTQuick_amd align --index_prefix $P --fastq_1 $F/trace_1.fq.gz --fastq_2 $F/trace_2.fq.gz --out_prefix $F/trace_out --sam_out --read_len 151 --t 32 2>&1 >/dev/null | grep -v "sequences are"
+[ "${4:-}" = stream ] && python3 $R/tools/frontend_stream.py $F/trace_1.fq.gz $F/trace_2.fq.gz
+FASTQUICK_TRACE=1 $R/fastquick_amd/bin/FASTQuick_amd align --index_prefix $P --fastq_1 $F/trace_1.fq.gz --fastq_2 $F/trace_2.fq.gz --out_prefix $F/trace_out --sam_out --read_len 151 --t 32 2>&1 >/dev/null | grep -v "sequences are\|call done\|consumers done\|index load"
