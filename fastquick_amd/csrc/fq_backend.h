@@ -110,6 +110,7 @@ int launch_refine(const FqRefineArgs &a);
 // the CRC tables and powers the member decoder reads, resident on the bound state's device (made once per device)
 const FqzCrcConst *crc_const();
 int launch_inflate(const FqInflateArgs &a);     // one wavefront per BGZF member
+int launch_inflate2(const FqInflateArgs &a, const FqInflateArgs &b);   // two member tables (the two files of a pair) in one launch
 // positions of the line ends of text[0, n): nl[0 .. min(count, cap)) ascending, *count (device memory) = how many there are
 int launch_nl_index(const uint8_t *text, uint32_t n, uint32_t lo, uint32_t *nl, uint32_t cap, uint32_t *count);
 int launch_tok_rec(const FqTokArgs &a);         // a thread per record

@@ -982,20 +982,31 @@ const FqzCrcConst *crc_const() {
   }
   return g_crc_const[dev];
 }
-// One wavefront per BGZF member: tables and the output ring in LDS (10.6 KB per wavefront: fifteen wavefronts per CU).
-__global__ void __launch_bounds__(64) k_inflate_bgzf(FqInflateArgs a) {
-  __shared__ FqzLds lds;
-  const int m = blockIdx.x;
-  const uint32_t st = fqz_inflate_member(a, m, lds);
-  if (threadIdx.x == 0) a.status[m] = st;
+// One wavefront per BGZF member: the output ring and the tables in LDS (6.4 KB per wavefront: twenty-four wavefronts per CU).
+#ifndef FQZ_WAVES_PER_EU
+#define FQZ_WAVES_PER_EU 6
+#endif
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(FQZ_WAVES_PER_EU))) k_inflate_bgzf(FqInflateArgs a, FqInflateArgs b) {
+  __shared__ __attribute__((aligned(FQZ_RING))) FqzLds lds;      // (the ring's LDS address has no bit of a ring offset set: fq_frontend.h)
+  // two member tables in one launch (the two files of a pair): a launch's last round of wavefronts is as full as the member count allows
+  const bool second = (int)blockIdx.x >= a.n_mem;
+  const FqInflateArgs &A = second ? b : a;
+  const int m = second ? (int)blockIdx.x - a.n_mem : (int)blockIdx.x;
+  const uint32_t st = fqz_inflate_member(A, m, lds);
+  if (threadIdx.x == 0) A.status[m] = st;
 }
-int launch_inflate(const FqInflateArgs &a) {
+int launch_inflate2(const FqInflateArgs &a, const FqInflateArgs &b) {
   FQ_PRE();
-  if (a.n_mem <= 0) return 0;
-  hipLaunchKernelGGL(k_inflate_bgzf, dim3((unsigned)a.n_mem), dim3(64), 0, g_stream, a);
+  const int n = (a.n_mem > 0 ? a.n_mem : 0) + (b.n_mem > 0 ? b.n_mem : 0);
+  if (n <= 0) return 0;
+  FqInflateArgs x = a, y = b;
+  if (x.n_mem < 0) x.n_mem = 0;
+  if (y.n_mem < 0) y.n_mem = 0;
+  hipLaunchKernelGGL(k_inflate_bgzf, dim3((unsigned)n), dim3(64), 0, g_stream, x, y);
   FQ_HIP(hipGetLastError());
   return 0;
 }
+int launch_inflate(const FqInflateArgs &a) { FqInflateArgs none{}; return launch_inflate2(a, none); }
 
 // Line ends of a text: every thread looks at 16 bytes (one aligned load), a block at 4 KiB; the blocks' counts are scanned (launch_scan)
 // and the positions written in order: ballot-free ranks from a prefix sum over the block's 256 counts in LDS.

@@ -247,6 +247,7 @@ struct FileSide {
   int shorter_after_longer = 0;
   uint64_t file_size = 0;
   double comp_ratio = 0.4;                     // compressed bytes per byte of text (the first member's; then the last chunk's)
+  int chunks_read = 0;                         // (by the reader thread)
   int read_threads = 1;                        // threads of one pread_threads call
   double ms_read = 0, ms_upload = 0;           // the reader thread's time in pread / in uploads (fq_frontend_stats)
 };
@@ -331,6 +332,10 @@ void reader_main(fq_frontend *fe, int e) {
       if (F.stop) return;
       want = F.want_text;
     }
+    // the stream's first chunks are short ones (an eighth, a quarter, a half of a chunk): the first batch is out after an eighth of the time,
+    // and the kernels behind the reader have work while it reads
+    if (F.chunks_read < 3) want = std::max<uint64_t>(want >> (3 - F.chunks_read), (uint64_t)((double)fe->batch_pairs * F.text_per_record * 1.02) + (1u << 20));   // (a reference batch at least)
+    ++F.chunks_read;
     CompChunk &C = F.chunk[k];
     C.mem.clear(); C.comp_len = 0; C.text_len = 0; C.err.clear(); C.eof = false;
     // (sized in one go for what the chunk is expected to hold: growing the buffer under the uploads means waiting for them, and a hipFree waits for the device)
@@ -482,6 +487,7 @@ void producer_main(fq_frontend *fe) {
     }
     next = Ahead();
     next.open = true; next.slot = slot; next.comp_k = comp_next;
+    FqInflateArgs ia[2] = {FqInflateArgs(), FqInflateArgs()};
     for (int e = 0; e < NF; ++e) {
       FileSide &F = fe->f[e];
       CompChunk *C = Cs[e];
@@ -495,16 +501,24 @@ void producer_main(fq_frontend *fe) {
       if (H + C->text_len > 0xfff00000ull) { finish(FQ_ELIMIT, "a chunk's text exceeds 4 GiB", false); return -1; }
       if (!F.d_text[slot].ensure((size_t)(H + C->text_len) + 4096)) { finish(FQ_ENOMEM, "out of device memory (text)", false); return -1; }
       if (C->mem.empty()) continue;
+      for (auto &m : C->mem) m.out_off += (uint32_t)H;       // (256-byte alignment of the buffer's base is what the decoder's stores rely on: the shift is in the members' offsets)
+      FqInflateArgs &a = ia[e];
+      a.comp = C->d_comp.p; a.mem = C->d_mem.p; a.n_mem = (int)C->mem.size(); a.out = F.d_text[slot].p; a.status = C->d_status.p;
+    }
+    if (ia[0].n_mem > 0 || ia[1].n_mem > 0) {
+      // one launch for the two files' members: the last of a launch's rounds of wavefronts is the fuller for it
       if (fe->overlap) fqdev::stream_aux(1);
       bool bad = false;
-      for (auto &m : C->mem) m.out_off += (uint32_t)H;       // (256-byte alignment of the buffer's base is what the decoder's stores rely on: the shift is in the members' offsets)
-      bad = bad || fqdev::h2d(C->d_mem.p, C->mem.data(), C->mem.size() * sizeof(FqzMember));
-      FqInflateArgs a{};
-      a.comp = C->d_comp.p; a.mem = C->d_mem.p; a.n_mem = (int)C->mem.size(); a.out = F.d_text[slot].p; a.status = C->d_status.p; a.crc = fqdev::crc_const();
-      bad = bad || !a.crc;
+      for (int e = 0; e < NF; ++e) {
+        if (ia[e].n_mem <= 0) continue;
+        CompChunk *C = Cs[e];
+        bad = bad || fqdev::h2d(C->d_mem.p, C->mem.data(), C->mem.size() * sizeof(FqzMember));
+        ia[e].crc = fqdev::crc_const();
+        bad = bad || !ia[e].crc;
+      }
       if (!bad) {
         fqdev::time_begin(0);
-        bad = fqdev::launch_inflate(a) != 0;
+        bad = fqdev::launch_inflate2(ia[0], ia[1]) != 0;
         fqdev::time_end(0);
       }
       fqdev::stream_aux(0);
@@ -746,8 +760,9 @@ void producer_main(fq_frontend *fe) {
       if (clean) stream_end = true; else fall = true;
     }
     if (!last && !fall && n == 0) {
-      // not one whole reference batch in a chunk's worth of text (reads of many kilobytes): not the device's case
-      fall = true;
+      // not one whole reference batch yet: the text is carried into the next chunk -- unless a whole chunk's worth of text is there already
+      // (reads of many kilobytes): not the device's case
+      for (int e = 0; e < NF; ++e) if ((double)n_text[e] >= (double)fe->chunk_pairs * fe->f[e].text_per_record && n_text[e] > ((uint64_t)4 << 20)) fall = true;
     }
     if (stream_end || fall) {
       // (a chunk whose members were started ahead is dropped: the hand-over stands behind this chunk, F.inflated_file_off)

@@ -140,6 +140,7 @@ struct FqInflateArgs {
   const FqzCrcConst *crc;
 };
 struct FqzLds {
+  uint32_t ring32[FQZ_RING / 4]; // first, and the struct aligned to its size: a ring address is (position & (FQZ_RING - 1)) | the struct's LDS address
   uint32_t lt[1 << FQZ_LROOT];  // literal / length root table; the CRC's slice tables afterwards
   uint32_t dt[1 << FQZ_DROOT];   // (its first 128 words hold the code-length code's table while a block's code lengths are read)
   uint16_t lsort[288], dsort[32], csort[20];
@@ -147,7 +148,6 @@ struct FqzLds {
   uint16_t dfirst[16], dcount[16], doffs[16];
   uint16_t cfirst[16], ccount[16], coffs[16];
   uint8_t lens[320], cl[32];
-  uint32_t ring32[FQZ_RING / 4];
 };
 // Table entries, laid out so that S_BFE_U32(bit buffer, entry) IS the symbol's extra bits (the instruction reads its offset from bits 0-4
 // and its width from bits 16-22 of its second operand and ignores the rest):
@@ -155,6 +155,7 @@ struct FqzLds {
 //   bits 5-9   bits the whole symbol takes (code + extra; 0: not in the root table)
 //   bit 10 literal, bit 11 length (of at most 64 bytes, extra bits included) / distance, bit 12 end of block, bit 15 a longer length
 //   bits 23-31 literal / length base (<= 258);  distances: bits 13-14 k with base = (k << extra) + 1
+enum { FQZ_L1_MISS = 31 };     // (a code length no entry has)
 enum { FQZ_K_LIT = 1u << 10, FQZ_K_BASE = 1u << 11, FQZ_K_EOB = 1u << 12, FQZ_K_LONG = 1u << 15 };   // FQZ_K_LONG: a length whose match may exceed 64 bytes (the general form's)
 FQ_HD uint32_t fqz_take_of(uint32_t e) { return (e >> 5) & 31; }
 FQ_HD uint32_t fqz_extra_of(uint64_t bb, uint32_t e) {
@@ -182,6 +183,7 @@ FQ_HD uint32_t fqz_dist_entry(uint32_t s, uint32_t l) {
   const uint32_t xb = s < 4 ? 0 : (s >> 1) - 1, k = s < 4 ? s : 2 + (s & 1);
   return FQZ_K_BASE | k << 13 | xb << 16 | (l + xb) << 5 | l;
 }
+FQ_HD uint32_t fqz_dist_base(uint32_t f) { return (((f >> 13) & 3) << ((f >> 16) & 15)) + 1; }
 FQ_HD uint32_t fqz_dist_of(uint64_t bb, uint32_t f) { return (((f >> 13) & 3) << ((f >> 16) & 15)) + 1 + fqz_extra_of(bb, f); }
 FQ_HD uint32_t fqz_cl_entry(uint32_t s, uint32_t l) { return FQZ_K_LIT | s << 23 | l << 5 | l; }
 
@@ -253,6 +255,11 @@ struct FqzSt {
   FQF_LVAR(uint32_t, wcur);  // dwords [blk * 64 + lane] of the block being read ...
   FQF_LVAR(uint32_t, wnext); // ... of the one behind it ...
   FQF_LVAR(uint32_t, wfar);  // ... and of the one behind that (asked for when `blk` began)
+  // ---- the block's first-level tables: lane i holds the root tables' entry for a bit buffer whose low 6 bits are i, when its code is of 6 bits at
+  //      most (FQZ_L1_MISS otherwise).  In registers, read with v_readlane: no LDS round trip in a symbol's chain of dependent steps.
+  FQF_LVAR(uint32_t, l1e); FQF_LVAR(uint32_t, l1b); FQF_LVAR(uint32_t, l1t);   // literal / length: entry, its base (bits 23-31), the bits it takes
+  FQF_LVAR(uint32_t, d1e); FQF_LVAR(uint32_t, d1b); FQF_LVAR(uint32_t, d1t);   // distance: entry, its base (the distance without the extra bits), the bits it takes
+  FQF_LVAR(uint32_t, l1scratch);                                                // (the host statement's copy register)
   uint32_t blk, di;          // the block; the next dword of it to take (0 .. 64)
   uint32_t blk_top;          // blocks behind this one are not read (the slack the payload is promised ends there)
   uint64_t bb;               // bit buffer, next bit at bit 0
@@ -265,6 +272,14 @@ struct FqzSt {
   uint32_t flushed;          // whole lines below this are in HBM (a multiple of 256)
   uint8_t *ring;
 };
+FQ_HD void fqz_first_level(FqzSt &D, const FqzLds &S) {       // after the root tables of a block have been filled
+  FQF_LANES
+    const uint32_t e = S.lt[lane], f = S.dt[lane];           // (root index = lane: the bits above the low six are zero)
+    const bool e_in = fqz_take_of(e) != 0 && (e & 31) <= 6, f_in = fqz_take_of(f) != 0 && (f & 31) <= 6;
+    FQF_LV(D.l1e) = e_in ? e : (uint32_t)FQZ_L1_MISS; FQF_LV(D.l1b) = e >> 23; FQF_LV(D.l1t) = fqz_take_of(e);
+    FQF_LV(D.d1e) = f_in ? f : (uint32_t)FQZ_L1_MISS; FQF_LV(D.d1b) = fqz_dist_base(f); FQF_LV(D.d1t) = fqz_take_of(f);
+  FQF_LANES_END
+}
 FQ_HD void fqz_load_blocks(FqzSt &D, uint32_t blk) {         // the three input registers for reading at block blk
   D.blk = blk;
   FQF_LANES
@@ -562,6 +577,7 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
       used = (int)FQF_UNIFORM32((uint32_t)used);
       if (rc < 0 || (rc > 0 && !(used == 0 || (used == 1 && FQF_UNIFORM32(S.dcount[1]) == 1)))) { status = FQZ_REFUSED; break; }   // zlib's rule: incomplete only as no code at all or one one-bit code
       fqz_fill_root(S.dt, FQZ_DROOT, S.dsort, S.dfirst, S.dcount, S.doffs, dent);
+      fqz_first_level(D, S);
       tables = type == 1 ? 1 : 2;
     }
     // ---- the block's symbols ----
@@ -574,19 +590,29 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
       uint32_t len = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
       if (D.flushed > D.g0 || (D.g0 & 255) == 0) {           // (the member's first line of text, which may begin inside a line, is out)
-        // The fast form, hand-written: hipcc's code for the C++ statement of this loop (the #else arm, which the host-loop tier runs) spends a
-        // third of its ~95 instructions per match on flag registers and copies for the loop's exits; this is 55-60.  Registers:
-        //   s[40:41] bit buffer  s42 bits in it  s43 next dword of the input block  s44 next output position  s45 / s46 the member's first / end position
-        //   s47 why  s48 len  s49 / s50 literal-length / distance entry  s51-s55 scratch  s[56:57] the text buffer  s58 flushed  s[60:61] refill  s[62:63] exec
-        //   v40 the input block's dwords  v41 lane  v42 4 * lane  v43 the LDS address of the tables  v44-v49 scratch  v50 float(lane)
-        uint32_t bb_lo = (uint32_t)D.bb, bb_hi = (uint32_t)(D.bb >> 32), a_bc = (uint32_t)D.bc, a_di = D.di, a_g = D.g, a_why = 0, a_len = 0, a_flushed = D.flushed;
+        // The fast form, hand-written.  The wavefronts of a CU share ONE scalar unit, and a symbol's decoding is scalar work: with 41 scalar
+        // instructions per match (of 70) the kernel ran at 80 % of that unit's one instruction per cycle whatever else was done
+        // (profiles/round5_inflate_sq_counters_v3.txt).  This form spends about 20: table entries come out of registers by v_readlane (three
+        // words per entry -- flags + extra-bits operand, base, bits taken -- so that no field is shifted out of another), positions are kept as a
+        // vector (position + lane) and as the two scalars the checks need (bytes written, position in the line), every lane copies (the bytes a
+        // match's copy leaves behind the match are overwritten by the next symbols before anything reads them: a ring position ahead of g is
+        // 2048 - 63 behind at least, which no near source reaches), and the promised size is checked where a line is stored.  Registers:
+        //   s36 ring mask  s[40:41] bit buffer  s42 bits in it  s43 next dword of the input block  s44 bytes written (g - g0)  s45 g mod 256 (+ len)
+        //   s46 the member's size  s47 why  s48 len  s49 / s54 / s55 literal-length entry, base, bits  s50 / s53 / s52 distance entry, base -> distance, bits
+        //   s51 scratch  s[56:57] the text buffer  s58 flushed  s59 g0  s[60:61] refill
+        //   v40 the input block's dwords  v41 lane  v42 4 * lane  v43 the LDS address of the ring (and of the tables behind it)  v44-v49 scratch
+        //   v50 float(lane)  v51-v53 / v54-v56 first-level tables  v57 g + lane  v45 / v58 the pending write's bytes / address
+        uint32_t bb_lo = (uint32_t)D.bb, bb_hi = (uint32_t)(D.bb >> 32), a_bc = (uint32_t)D.bc, a_di = D.di, a_avail = D.g - D.g0, a_gl = D.g & 255, a_why = 0, a_len = 0, a_flushed = D.flushed;
         const uint32_t out_lo = (uint32_t)(uintptr_t)D.out, out_hi = (uint32_t)((uintptr_t)D.out >> 32);
         const uint32_t v_lane = threadIdx.x & 63, v_lane4 = 4 * (threadIdx.x & 63);
         const uint32_t v_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) FqzLds *)&S;
         const float v_lanef = (float)(threadIdx.x & 63);
+        uint32_t v_pos = D.g + v_lane;
         __asm__ volatile(
             "s_mov_b32 s47, 0\n"
             "s_mov_b32 s48, 0\n"
+            "v_and_or_b32 v58, v57, s36, v43\n"             // (the write that is always pending: at first a harmless one, ahead of g)
+            "v_mov_b32_e32 v45, 0\n"
             ".Lfqz_top_%=:\n"
             "  s_cmp_gt_i32 s42, 32\n"
             "  s_cbranch_scc1 .Lfqz_have1_%=\n"
@@ -599,25 +625,22 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
             "  s_or_b64 s[40:41], s[40:41], s[60:61]\n"
             "  s_add_i32 s42, s42, 32\n"
             ".Lfqz_have1_%=:\n"
-            "  s_and_b32 s51, s40, %[lt_mask]\n"
-            "  v_lshl_add_u32 v44, s51, 2, v43\n"
-            "  ds_read_b32 v44, v44 offset:%[lt_off]\n"
-            "  s_waitcnt lgkmcnt(0)\n"
-            "  v_readfirstlane_b32 s49, v44\n"
+            "  s_and_b32 s51, s40, 63\n"
+            "  v_readlane_b32 s49, v51, s51\n"
+            "  v_readlane_b32 s54, v52, s51\n"
+            "  v_readlane_b32 s55, v53, s51\n"
+            ".Lfqz_have_e_%=:\n"
             "  s_bitcmp1_b32 s49, 11\n"
             "  s_cbranch_scc0 .Lfqz_notmatch_%=\n"
             // ---- a match: the length, then its distance
             "  s_bfe_u32 s48, s40, s49\n"
-            "  s_lshr_b32 s51, s49, 23\n"
-            "  s_add_i32 s48, s48, s51\n"
-            "  s_bfe_u32 s51, s49, 0x50005\n"
-            "  s_lshr_b64 s[40:41], s[40:41], s51\n"
-            "  s_sub_i32 s42, s42, s51\n"
-            "  s_mov_b32 s47, 1\n"
+            "  s_add_i32 s48, s48, s54\n"
+            "  s_lshr_b64 s[40:41], s[40:41], s55\n"
+            "  s_sub_i32 s42, s42, s55\n"
             "  s_cmp_gt_i32 s42, 32\n"
             "  s_cbranch_scc1 .Lfqz_have2_%=\n"
             "  s_cmp_eq_u32 s43, 64\n"
-            "  s_cbranch_scc1 .Lfqz_exit_%=\n"
+            "  s_cbranch_scc1 .Lfqz_exit_len_%=\n"
             "  s_mov_b32 s61, 0\n"
             "  v_readlane_b32 s60, v40, s43\n"
             "  s_add_i32 s43, s43, 1\n"
@@ -625,73 +648,60 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
             "  s_or_b64 s[40:41], s[40:41], s[60:61]\n"
             "  s_add_i32 s42, s42, 32\n"
             ".Lfqz_have2_%=:\n"
-            "  s_and_b32 s51, s40, 0xff\n"
-            "  v_lshl_add_u32 v44, s51, 2, v43\n"
-            "  ds_read_b32 v44, v44 offset:%[dt_off]\n"
-            "  s_waitcnt lgkmcnt(0)\n"
-            "  v_readfirstlane_b32 s50, v44\n"
+            "  s_and_b32 s51, s40, 63\n"
+            "  v_readlane_b32 s50, v54, s51\n"
+            "  v_readlane_b32 s53, v55, s51\n"
+            "  v_readlane_b32 s52, v56, s51\n"
+            ".Lfqz_have_f_%=:\n"
             "  s_bitcmp1_b32 s50, 11\n"
-            "  s_cbranch_scc0 .Lfqz_exit_%=\n"
-            "  s_bfe_u32 s51, s50, 0x2000d\n"
-            "  s_bfe_u32 s52, s50, 0x40010\n"
-            "  s_lshl_b32 s51, s51, s52\n"
-            "  s_bfe_u32 s52, s40, s50\n"
-            "  s_add_i32 s53, s51, s52\n"
-            "  s_add_i32 s53, s53, 1\n"
-            "  s_sub_i32 s51, s44, s45\n"
-            "  s_cmp_gt_u32 s53, s51\n"
-            "  s_cbranch_scc1 .Lfqz_exit_%=\n"
-            "  s_add_i32 s54, s44, s48\n"
-            "  s_xor_b32 s55, s44, s54\n"
-            "  s_cmp_lt_u32 s55, 0x100\n"
-            "  s_cbranch_scc1 .Lfqz_fits_%=\n"
-            "  s_cmp_gt_u32 s54, s46\n"                     // a line will be stored: not behind the promised size
-            "  s_cbranch_scc1 .Lfqz_exit_%=\n"
-            ".Lfqz_fits_%=:\n"
-            "  s_bfe_u32 s51, s50, 0x50005\n"
-            "  s_lshr_b64 s[40:41], s[40:41], s51\n"
-            "  s_sub_i32 s42, s42, s51\n"
-            "  s_mov_b32 s47, 0\n"
-            // ---- the copy: lanes below len, byte lane of the match = byte (lane mod dist) of the dist bytes in front of it
-            "  s_sub_i32 s51, s44, s53\n"
+            "  s_cbranch_scc0 .Lfqz_dist_other_%=\n"
+            "  s_bfe_u32 s51, s40, s50\n"
+            "  s_add_i32 s53, s53, s51\n"
+            "  s_cmp_gt_u32 s53, s44\n"                     // a distance in front of the member's first byte
+            "  s_cbranch_scc1 .Lfqz_exit_len_%=\n"
+            "  s_lshr_b64 s[40:41], s[40:41], s52\n"
+            "  s_sub_i32 s42, s42, s52\n"
+            // ---- the copy: byte lane of the match = byte (lane mod dist) of the dist bytes in front of it
             "  s_cmp_lt_u32 s53, s48\n"
             "  s_cbranch_scc1 .Lfqz_period_%=\n"
-            "  v_add_u32_e32 v44, s51, v41\n"
+            "  v_subrev_u32_e32 v44, s53, v57\n"
             ".Lfqz_src_%=:\n"
-            "  v_cmp_gt_u32_e32 vcc, s48, v41\n"
-            "  s_and_saveexec_b64 s[62:63], vcc\n"
-            "  v_add_u32_e32 v46, s44, v41\n"
-            "  v_and_b32_e32 v46, %[ring_mask], v46\n"
-            "  v_add_u32_e32 v46, v46, v43\n"
+            // The copy is one symbol behind: the source bytes are asked for here and written when the NEXT symbol has been decoded (LDS works
+            // a wavefront's instructions in order, so that symbol's own source -- which may be these bytes -- is read after them).
+            "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+            "  ds_write_b8 v58, v45\n"
+            "  v_and_or_b32 v58, v57, s36, v43\n"
             "  s_cmpk_gt_u32 s53, %[near_max]\n"
             "  s_cbranch_scc1 .Lfqz_far_%=\n"
-            "  v_and_b32_e32 v44, %[ring_mask], v44\n"
-            "  v_add_u32_e32 v44, v44, v43\n"
-            "  ds_read_u8 v45, v44 offset:%[ring_off]\n"
-            "  s_waitcnt lgkmcnt(0)\n"
-            "  ds_write_b8 v46, v45 offset:%[ring_off]\n"
-            "  s_branch .Lfqz_copied_%=\n"
-            ".Lfqz_far_%=:\n"
-            "  global_load_ubyte v45, v44, s[56:57]\n"
-            "  s_waitcnt vmcnt(0)\n"
-            "  ds_write_b8 v46, v45 offset:%[ring_off]\n"
+            "  v_and_or_b32 v44, v44, s36, v43\n"
+            "  ds_read_u8 v45, v44\n"
             ".Lfqz_copied_%=:\n"
-            "  s_or_b64 exec, exec, s[62:63]\n"
-            "  s_mov_b32 s44, s54\n"
-            "  s_cmp_lt_u32 s55, 0x100\n"
+            "  s_add_i32 s44, s44, s48\n"
+            "  v_add_u32_e32 v57, s48, v57\n"
+            "  s_add_i32 s45, s45, s48\n"
+            "  s_cmp_lt_u32 s45, 0x100\n"
             "  s_cbranch_scc1 .Lfqz_top_%=\n"
-            ".Lfqz_flush_%=:\n"                               // the line below s44's is complete: one coalesced store
-            "  s_and_b32 s51, s44, 0xffffff00\n"
+            ".Lfqz_flush_%=:\n"                               // the line below the position is complete: one coalesced store -- unless more than the promised size has been written
+            "  s_sub_i32 s45, s45, 0x100\n"
+            "  s_cmp_gt_u32 s44, s46\n"
+            "  s_cbranch_scc1 .Lfqz_exit_%=\n"
+            "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+            "  ds_write_b8 v58, v45\n"                       // (the symbol that completed the line; written once more behind the next symbol, to no effect)
+            "  s_add_i32 s51, s59, s44\n"
+            "  s_and_b32 s51, s51, 0xffffff00\n"
             "  s_add_u32 s51, s51, 0xffffff00\n"
             "  s_and_b32 s52, s51, %[line_mask]\n"
             "  v_add_u32_e32 v44, s52, v42\n"
             "  v_add_u32_e32 v44, v44, v43\n"
-            "  ds_read_b32 v45, v44 offset:%[ring_off]\n"
+            "  ds_read_b32 v47, v44\n"
             "  v_add_u32_e32 v46, s51, v42\n"
             "  s_add_u32 s58, s51, 0x100\n"
             "  s_waitcnt lgkmcnt(0)\n"
-            "  global_store_dword v46, v45, s[56:57]\n"
+            "  global_store_dword v46, v47, s[56:57]\n"
             "  s_branch .Lfqz_top_%=\n"
+            ".Lfqz_far_%=:\n"                                 // a source further back than the ring keeps: from the text in HBM (its lines were stored when they were completed)
+            "  global_load_ubyte v45, v44, s[56:57]\n"
+            "  s_branch .Lfqz_copied_%=\n"
             ".Lfqz_period_%=:\n"                              // dist < len: lane mod dist (lane, dist < 64: the quotient is exact to one either way)
             "  v_cvt_f32_u32_e32 v47, s53\n"
             "  v_rcp_iflag_f32_e32 v47, v47\n"
@@ -707,39 +717,63 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
             "  v_cmp_le_u32_e32 vcc, s53, v47\n"
             "  v_cndmask_b32_e32 v48, 0, v48, vcc\n"
             "  v_sub_u32_e32 v47, v47, v48\n"
+            "  s_add_i32 s51, s59, s44\n"
+            "  s_sub_i32 s51, s51, s53\n"
             "  v_add_u32_e32 v44, s51, v47\n"
             "  s_branch .Lfqz_src_%=\n"
             ".Lfqz_notmatch_%=:\n"
             "  s_bitcmp1_b32 s49, 10\n"
-            "  s_cbranch_scc0 .Lfqz_exit_%=\n"                // the end of the block, a code longer than the root, a long match
-            "  s_add_i32 s54, s44, 1\n"
-            "  s_and_b32 s51, s54, 0xff\n"
-            "  s_cmp_eq_u32 s51, 0\n"
-            "  s_cbranch_scc0 .Lfqz_litfits_%=\n"
-            "  s_cmp_ge_u32 s44, s46\n"                     // the literal completes a line: not behind the promised size
-            "  s_cbranch_scc1 .Lfqz_exit_%=\n"
-            ".Lfqz_litfits_%=:\n"
-            "  s_bfe_u32 s51, s49, 0x50005\n"
-            "  s_lshr_b64 s[40:41], s[40:41], s51\n"
-            "  s_sub_i32 s42, s42, s51\n"
-            "  s_and_b32 s51, s44, %[ring_mask]\n"
-            "  v_add_u32_e32 v44, s51, v43\n"
-            "  s_lshr_b32 s52, s49, 23\n"
-            "  v_mov_b32_e32 v45, s52\n"
-            "  ds_write_b8 v44, v45 offset:%[ring_off]\n"
-            "  s_mov_b32 s44, s54\n"
-            "  s_and_b32 s51, s44, 0xff\n"
-            "  s_cmp_eq_u32 s51, 0\n"
-            "  s_cbranch_scc1 .Lfqz_flush_%=\n"
-            "  s_branch .Lfqz_top_%=\n"
+            "  s_cbranch_scc0 .Lfqz_lt_other_%=\n"
+            "  s_lshr_b64 s[40:41], s[40:41], s55\n"       // a literal
+            "  s_sub_i32 s42, s42, s55\n"
+            "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
+            "  ds_write_b8 v58, v45\n"
+            "  v_and_or_b32 v58, v57, s36, v43\n"
+            "  v_mov_b32_e32 v45, s54\n"
+            "  s_add_i32 s44, s44, 1\n"
+            "  v_add_u32_e32 v57, 1, v57\n"
+            "  s_add_i32 s45, s45, 1\n"
+            "  s_cmp_lt_u32 s45, 0x100\n"
+            "  s_cbranch_scc1 .Lfqz_top_%=\n"
+            "  s_branch .Lfqz_flush_%=\n"
+            ".Lfqz_lt_other_%=:\n"
+            "  s_cmp_eq_u32 s49, %[miss]\n"
+            "  s_cbranch_scc0 .Lfqz_exit_%=\n"                // the end of the block, a code longer than the root table, a long match
+            "  s_and_b32 s51, s40, %[lt_mask]\n"             // not in the first-level table: the root table in LDS
+            "  v_lshl_add_u32 v44, s51, 2, v43\n"
+            "  ds_read_b32 v44, v44 offset:%[lt_off]\n"
+            "  s_waitcnt lgkmcnt(0)\n"
+            "  v_readfirstlane_b32 s49, v44\n"
+            "  s_lshr_b32 s54, s49, 23\n"
+            "  s_bfe_u32 s55, s49, 0x50005\n"
+            "  s_branch .Lfqz_have_e_%=\n"
+            ".Lfqz_dist_other_%=:\n"
+            "  s_cmp_eq_u32 s50, %[miss]\n"
+            "  s_cbranch_scc0 .Lfqz_exit_len_%=\n"
+            "  s_and_b32 s51, s40, %[dt_mask]\n"
+            "  v_lshl_add_u32 v44, s51, 2, v43\n"
+            "  ds_read_b32 v44, v44 offset:%[dt_off]\n"
+            "  s_waitcnt lgkmcnt(0)\n"
+            "  v_readfirstlane_b32 s50, v44\n"
+            "  s_bfe_u32 s53, s50, 0x2000d\n"
+            "  s_bfe_u32 s52, s50, 0x40010\n"
+            "  s_lshl_b32 s53, s53, s52\n"
+            "  s_add_i32 s53, s53, 1\n"
+            "  s_bfe_u32 s52, s50, 0x50005\n"
+            "  s_branch .Lfqz_have_f_%=\n"
+            ".Lfqz_exit_len_%=:\n"
+            "  s_mov_b32 s47, 1\n"
             ".Lfqz_exit_%=:\n"
             "  s_waitcnt vmcnt(0) lgkmcnt(0)\n"
-            : "+{s40}"(bb_lo), "+{s41}"(bb_hi), "+{s42}"(a_bc), "+{s43}"(a_di), "+{s44}"(a_g), "+{s47}"(a_why), "+{s48}"(a_len), "+{s58}"(a_flushed)
-            : "{s45}"(D.g0), "{s46}"(D.g_end), "{s56}"(out_lo), "{s57}"(out_hi), "{v40}"(D.wcur), "{v41}"(v_lane), "{v42}"(v_lane4), "{v43}"(v_lds), "{v50}"(v_lanef),
-              [lt_off] "i"(offsetof(FqzLds, lt)), [dt_off] "i"(offsetof(FqzLds, dt)), [ring_off] "i"(offsetof(FqzLds, ring32)),
-              [lt_mask] "i"((1 << FQZ_LROOT) - 1), [ring_mask] "i"(FQZ_RING - 1), [near_max] "i"(FQZ_RING - 2 * 64), [line_mask] "i"((FQZ_RING - 1) & ~255)
-            : "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s60", "s61", "s62", "s63", "v44", "v45", "v46", "v47", "v48", "v49", "vcc", "scc", "memory");
-        D.bb = (uint64_t)bb_hi << 32 | bb_lo; D.bc = (int)a_bc; D.di = a_di; D.g = a_g; D.flushed = a_flushed;
+            "  ds_write_b8 v58, v45\n"
+            "  s_waitcnt lgkmcnt(0)\n"
+            : "+{s40}"(bb_lo), "+{s41}"(bb_hi), "+{s42}"(a_bc), "+{s43}"(a_di), "+{s44}"(a_avail), "+{s45}"(a_gl), "+{s47}"(a_why), "+{s48}"(a_len), "+{s58}"(a_flushed), "+{v57}"(v_pos)
+            : "{s36}"((uint32_t)(FQZ_RING - 1)), "{s46}"(D.g_end - D.g0), "{s59}"(D.g0), "{s56}"(out_lo), "{s57}"(out_hi), "{v40}"(D.wcur), "{v41}"(v_lane), "{v42}"(v_lane4), "{v43}"(v_lds), "{v50}"(v_lanef),
+              "{v51}"(D.l1e), "{v52}"(D.l1b), "{v53}"(D.l1t), "{v54}"(D.d1e), "{v55}"(D.d1b), "{v56}"(D.d1t),
+              [lt_off] "i"(offsetof(FqzLds, lt)), [dt_off] "i"(offsetof(FqzLds, dt)), [miss] "i"(FQZ_L1_MISS),
+              [lt_mask] "i"((1 << FQZ_LROOT) - 1), [dt_mask] "i"((1 << FQZ_DROOT) - 1), [near_max] "i"(FQZ_RING - 2 * 64), [line_mask] "i"((FQZ_RING - 1) & ~255)
+            : "s49", "s50", "s51", "s52", "s53", "s54", "s55", "s60", "s61", "v44", "v45", "v46", "v47", "v48", "v49", "v58", "vcc", "scc", "memory");
+        D.bb = (uint64_t)bb_hi << 32 | bb_lo; D.bc = (int)a_bc; D.di = a_di; D.g = D.g0 + a_avail; D.flushed = a_flushed;
         why = (int)a_why; len = a_len;
       }
 #else
@@ -754,8 +788,10 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
             if (di == 64) break;
             bb |= (uint64_t)FQF_UNIFORM32(FQF_RL(D.wcur, di)) << bc; bc += 32; ++di;
           }
-          const uint32_t e = FQF_UNIFORM32(S.lt[bb & ((1u << FQZ_LROOT) - 1)]);
+          uint32_t e = FQF_RL(D.l1e, bb & 63);               // the first-level table, then the root table
+          if (e == FQZ_L1_MISS) e = FQF_UNIFORM32(S.lt[bb & ((1u << FQZ_LROOT) - 1)]);
           FQZ_STAT(8 + ((e & 31) <= 6 ? 0 : (e & 31) <= 7 ? 1 : 2), 1);
+          uint32_t g1;
           if (e & FQZ_K_BASE) {
             len = (e >> 23) + fqz_extra_of(bb, e);
             const uint32_t t1 = fqz_take_of(e);
@@ -765,62 +801,61 @@ FQ_HD uint32_t fqz_inflate_member(const FqInflateArgs &A, int m, FqzLds &S) {
               if (di == 64) break;
               bb |= (uint64_t)FQF_UNIFORM32(FQF_RL(D.wcur, di)) << bc; bc += 32; ++di;
             }
-            const uint32_t f = FQF_UNIFORM32(S.dt[bb & ((1u << FQZ_DROOT) - 1)]);
+            uint32_t f = FQF_RL(D.d1e, bb & 63);
+            if (f == FQZ_L1_MISS) f = FQF_UNIFORM32(S.dt[bb & ((1u << FQZ_DROOT) - 1)]);
             FQZ_STAT(11 + ((f & 31) <= 6 ? 0 : (f & 31) <= 7 ? 1 : 2), 1);
             if (!(f & FQZ_K_BASE)) break;
             const uint32_t dist = fqz_dist_of(bb, f);
             if (dist > g - g0) break;
-            const uint32_t g1 = g + len;
-            if (((g ^ g1) >> 8) && g1 > g_end) break;        // (the promised size is checked where a line would be stored; the member's end checks the rest)
+            g1 = g + len;
             const uint32_t t2 = fqz_take_of(f);
             bb >>= t2; bc -= (int)t2;
             why = 0;
             const uint32_t s = g - dist;
             FQZ_STAT(6, len); FQZ_STAT(dist < len ? 3 : dist <= FQZ_RING - 2 * 64 ? 1 : 2, 1);
+            // (every lane copies: what lands behind the match is ahead of g, where nothing is read before the next symbols have written it)
             if (dist >= len) {
               if (dist <= FQZ_RING - 2 * 64) {
                 FQF_LANES
-                  if ((uint32_t)lane < len) { const uint8_t b = ring[(s + (uint32_t)lane) & (FQZ_RING - 1)]; ring[(g + (uint32_t)lane) & (FQZ_RING - 1)] = b; }
+                  const uint8_t b = ring[(s + (uint32_t)lane) & (FQZ_RING - 1)];
+                  FQF_LV(D.l1scratch) = b;
                 FQF_LANES_END
               } else {
                 FQF_LANES
-                  if ((uint32_t)lane < len) { const uint8_t b = out[s + (uint32_t)lane]; ring[(g + (uint32_t)lane) & (FQZ_RING - 1)] = b; }
+                  FQF_LV(D.l1scratch) = out[s + (uint32_t)lane];
                 FQF_LANES_END
               }
-              FQF_WAVE_FENCE();
             } else {
-              D.g = g;
-              fqz_copy_pass(D, len, dist, 0);
-            }
-            if ((g ^ g1) >> 8) {                             // a line is complete
-              const uint32_t seg = (g1 & ~255u) - 256;
               FQF_LANES
-                *(uint32_t *)(out + seg + 4 * (uint32_t)lane) = *(const uint32_t *)(ring + ((seg + 4 * (uint32_t)lane) & (FQZ_RING - 1)));
+                const uint8_t b = ring[(s + (uint32_t)lane % dist) & (FQZ_RING - 1)];   // (dist < len <= 64: inside the ring)
+                FQF_LV(D.l1scratch) = b;
               FQF_LANES_END
-              FQF_WAVE_FENCE();
-              D.flushed = seg + 256;
             }
-            g = g1;
-            continue;
-          }
-          if (!(e & FQZ_K_LIT)) break;                       // the end of the block, a longer code, a long match
-          if (((g + 1) & 255) == 0 && g >= g_end) break;
-          {
+            FQF_LANES
+              ring[(g + (uint32_t)lane) & (FQZ_RING - 1)] = (uint8_t)FQF_LV(D.l1scratch);
+            FQF_LANES_END
+            FQF_WAVE_FENCE();
+          } else {
+            if (!(e & FQZ_K_LIT)) break;                     // the end of the block, a longer code, a long match
             const uint32_t t1 = fqz_take_of(e);
             bb >>= t1; bc -= (int)t1;
             FQZ_STAT(0, 1);
             FQF_LANES
-              ring[g & (FQZ_RING - 1)] = (uint8_t)(e >> 23);
+              ring[(g + (uint32_t)lane) & (FQZ_RING - 1)] = (uint8_t)(e >> 23);
             FQF_LANES_END
             FQF_WAVE_FENCE();
-            ++g;
-            if ((g & 255) == 0) {
-              FQF_LANES
-                *(uint32_t *)(out + g - 256 + 4 * (uint32_t)lane) = *(const uint32_t *)(ring + ((g - 256 + 4 * (uint32_t)lane) & (FQZ_RING - 1)));
-              FQF_LANES_END
-              FQF_WAVE_FENCE();
-              D.flushed = g;
-            }
+            g1 = g + 1;
+          }
+          const bool line = ((g ^ g1) >> 8) != 0;
+          g = g1;
+          if (line) {                                        // a line is complete: stored, unless more than the promised size has been written
+            if (g > g_end) break;
+            const uint32_t seg = (g & ~255u) - 256;
+            FQF_LANES
+              *(uint32_t *)(out + seg + 4 * (uint32_t)lane) = *(const uint32_t *)(ring + ((seg + 4 * (uint32_t)lane) & (FQZ_RING - 1)));
+            FQF_LANES_END
+            FQF_WAVE_FENCE();
+            D.flushed = seg + 256;
           }
         }
         D.bb = bb; D.bc = bc; D.di = di; D.g = g;

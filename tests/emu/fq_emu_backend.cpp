@@ -167,6 +167,7 @@ int launch_inflate(const FqInflateArgs &a) {
   delete lds;
   return 0;
 }
+int launch_inflate2(const FqInflateArgs &a, const FqInflateArgs &b) { if (a.n_mem > 0 && launch_inflate(a)) return -3; return b.n_mem > 0 ? launch_inflate(b) : 0; }
 int launch_nl_index(const uint8_t *text, uint32_t n, uint32_t lo, uint32_t *nl, uint32_t cap, uint32_t *count) {
   uint32_t c = 0;
   for (uint32_t i = lo; i < n; ++i) if (text[i] == '\n') { if (c < cap) nl[c] = i; ++c; }
