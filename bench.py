@@ -575,21 +575,32 @@ def main() -> None:
                 # ---- the front end on the device (fq_frontend_*): BGZF files -> filter keys, lengths, names of every read resident in HBM, with
                 #      nothing of the text touched by the host (it reads compressed bytes and walks member headers).  tokenise_inflate_pairs_per_s =
                 #      pairs / wall time from opening the two files to the last batch (batches released as they come: no alignment beside it)
-                import ctypes
-                dfe = api.DeviceFrontEnd(big[0], big[1], batch_pairs=262144, chunk_pairs=16 * 262144, slot_mode=0, max_read_len=stride)
-                t0 = time.perf_counter()
-                got_pairs = 0
-                while True:
-                    m_, b_ = dfe.next()
-                    if m_ <= 0:
-                        break
-                    got_pairs += m_
-                    dfe.release(b_)
-                dt_fe = time.perf_counter() - t0
-                fst = dfe.stats()
-                dfe.close()
-                assert m_ == 0 and got_pairs == nfe * copies, (m_, got_pairs)
+                def run_front_end():
+                    dfe = api.DeviceFrontEnd(big[0], big[1], batch_pairs=262144, chunk_pairs=16 * 262144, slot_mode=0, max_read_len=stride)
+                    t0 = time.perf_counter()
+                    got, t_first = 0, None
+                    while True:
+                        m_, b_ = dfe.next()
+                        if m_ <= 0:
+                            break
+                        if t_first is None:
+                            t_first = time.perf_counter() - t0
+                        got += m_
+                        dfe.release(b_)
+                    dt = time.perf_counter() - t0
+                    st = dfe.stats()
+                    dfe.close()
+                    assert m_ == 0 and got == nfe * copies, (m_, got)
+                    return got, dt, t_first, st
+                # the product's way: the next chunk's members are inflated beside this chunk's kernels (two streams)
+                got_pairs, dt_fe, t_first, fst = run_front_end()
                 fe["tokenise_inflate_pairs_per_s"] = round(got_pairs / dt_fe, 1)
+                # ... and once more with the kernels one after the other (FASTQUICK_FE_OVERLAP=0), for each kernel group's time on its own
+                os.environ["FASTQUICK_FE_OVERLAP"] = "0"
+                try:
+                    _, dt_solo, _, fso = run_front_end()
+                finally:
+                    del os.environ["FASTQUICK_FE_OVERLAP"]
                 tb_, cb_ = float(fst["text_bytes"]), float(fst["comp_bytes"])
 
                 def fe_roof(ms, byts, launches):
@@ -597,14 +608,20 @@ def main() -> None:
                     return {"ms_total": round(ms, 2), "launch_groups": int(launches), "bytes": int(byts), "GBps": round(g_, 2), "frac_of_hbm_peak": round(g_ / HBM_PEAK_GBS, 5)}
                 rows_ = 2.0 * got_pairs
                 fe["tokenise_inflate"] = {"where": "device (k_inflate_bgzf + line index + record / key / slot kernels)", "pairs": got_pairs, "s": round(dt_fe, 3),
+                                          "first_batch_s": round(t_first or 0.0, 3),
                                           "text_GBps": round(tb_ / dt_fe / 1e9, 3), "file_GBps": round(cb_ / dt_fe / 1e9, 3),
                                           "members": fst["members"], "members_left_to_the_host_decoder": fst["refused"], "chunks": fst["chunks"],
-                                          # bytes in + out of each kernel group / its summed device time (HIP events on the front end's stream)
+                                          # the host side of it: the producer thread's waits and the reader threads' time (wall ms; readers summed over the two files)
+                                          "host_side_ms": {"producer_waited_for_compressed_bytes": round(fst["ms_wait_reader"], 1), "producer_waited_for_a_batch_slot": round(fst["ms_wait_slot"], 1),
+                                                           "readers_pread": round(fst["ms_read"], 1), "readers_upload": round(fst["ms_upload"], 1)},
+                                          "device_ms_overlapped": {"inflate": round(fst["ms_inflate"], 1), "lines": round(fst["ms_lines"], 1), "records": round(fst["ms_records"], 1), "slots": round(fst["ms_slots"], 1)},
+                                          "one_after_the_other_s": round(dt_solo, 3),
+                                          # bytes in + out of each kernel group / its summed device time with nothing beside it (HIP events on the front end's stream, second run)
                                           "kernel_rooflines": {
-                                              "fq_inflate": dict(fe_roof(fst["ms_inflate"], tb_ + cb_, fst["inflate_launches"]), model="compressed bytes in + text bytes out; bound by instruction issue (one wavefront decodes one member's symbols in order), not by HBM"),
-                                              "fq_lines": dict(fe_roof(fst["ms_lines"], 2 * tb_ + 4 * 4 * rows_, fst["chunks"]), model="text read twice (count, fill) + 4 B per line end out"),
-                                              "fq_records": dict(fe_roof(fst["ms_records"], 16 * rows_ + 16 * rows_ + (150 + 12) * rows_ + 26 * rows_, fst["chunks"]), model="4 line ends in, 16 B record + 2 B length out; base line + name in, 24 B of filter keys out"),
-                                              "fq_slots": dict(fe_roof(fst["ms_slots"], (16 + 96 + 96 + 12 + 12 + 16) * rows_, fst["chunks"]), model="record in, 96 B of the slot's bases in and out, name in, slot name + printed name out")}}
+                                              "fq_inflate": dict(fe_roof(fso["ms_inflate"], tb_ + cb_, fso["inflate_launches"]), model="compressed bytes in + text bytes out; bound by the CU's one scalar unit (a symbol's decoding is a chain of scalar steps; profiles/round5_inflate_sq_counters_v3.txt), not by HBM"),
+                                              "fq_lines": dict(fe_roof(fso["ms_lines"], 2 * tb_ + 4 * 4 * rows_, fso["chunks"]), model="text read twice (count, fill) + 4 B per line end out"),
+                                              "fq_records": dict(fe_roof(fso["ms_records"], 16 * rows_ + 16 * rows_ + (150 + 12) * rows_ + 26 * rows_, fso["chunks"]), model="4 line ends in, 16 B record + 2 B length out; base line + name in, 24 B of filter keys out"),
+                                              "fq_slots": dict(fe_roof(fso["ms_slots"], (16 + 96 + 96 + 12 + 12 + 16) * rows_, fso["chunks"]), model="record in, 96 B of the slot's bases in and out, name in, slot name + printed name out")}}
                 steady = {"pairs": nfe * copies, "copies": copies, "requested_bytes": need}
                 for label, extra in (("sam_out", ["--sam_out"]), ("bam_and_qc", [])):
                     cmd2 = [exe, "align", "--index_prefix", pre[:-len(".FASTQuick.fa")], "--fastq_1", big[0], "--fastq_2", big[1], "--out_prefix", os.path.join(fdir, "big_out"),

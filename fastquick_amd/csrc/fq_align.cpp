@@ -218,6 +218,7 @@ struct fq_ctx {
   DevBuf<FqGapWork> d_winfo;
   DevBuf<int32_t> d_len, d_len_trim, d_read_list, d_sidx, d_pair_list, d_counts;
   DevBuf<uint64_t> d_counters;
+  std::vector<uint64_t> h_counters;   // (its stripes, as read back)
   DevBuf<uint32_t> d_queue;
   // search workspaces
   DevBuf<int32_t> d_work;
@@ -337,8 +338,8 @@ extern "C" int fq_ctx_create(const fq_index_t *ix, const fq_opts_t *opts, int32_
   k.max_top2 = o.max_top2; k.trim_qual = o.trim_qual; k.filter_thresh = o.filter_thresh; k.n_buckets = FQ_MAX_BUCKETS;
   c->dev = fqdev::state_create(ix->device);
   if (!c->dev || fqdev::bind(c->dev)) return FQ_ENODEV;
-  if (!c->d_maxdiff.ensure(FQ_LMAX + 2) || !c->d_counters.ensure(FQ_C_COUNT) || !c->d_counts.ensure(4) || !c->d_queue.ensure(4) || !c->d_glogn.ensure(256)) return FQ_ENOMEM;
-  if (fqdev::h2d(c->d_maxdiff.p, c->maxdiff_lut, FQ_LMAX + 2) || fqdev::h2d(c->d_glogn.p, c->g_log_n, 256 * 4) || fqdev::dzero(c->d_counters.p, FQ_C_COUNT * 8) || fqdev::sync()) return FQ_ENODEV;
+  if (!c->d_maxdiff.ensure(FQ_LMAX + 2) || !c->d_counters.ensure(FQ_C_STRIPES * FQ_C_STRIDE) || !c->d_counts.ensure(4) || !c->d_queue.ensure(4) || !c->d_glogn.ensure(256)) return FQ_ENOMEM;
+  if (fqdev::h2d(c->d_maxdiff.p, c->maxdiff_lut, FQ_LMAX + 2) || fqdev::h2d(c->d_glogn.p, c->g_log_n, 256 * 4) || fqdev::dzero(c->d_counters.p, (size_t)FQ_C_STRIPES * FQ_C_STRIDE * 8) || fqdev::sync()) return FQ_ENODEV;
   *out = c.release();
   return FQ_OK;
 }
@@ -421,6 +422,15 @@ static int sync_staged(fq_ctx *c) {
   for (auto &o : c->arena.pending) memcpy(o.dst, o.src, o.bytes);
   c->arena.pending.clear();
   return 0;
+}
+// The work counters as the kernels keep them (FQ_C_STRIPES copies, fq_common.h), folded: sums, maxima for the two that are maxima.
+static void fold_counters(const uint64_t *striped, uint64_t *cnt) {
+  for (int k = 0; k < FQ_C_COUNT; ++k) {
+    const bool is_max = k == FQ_C_MAXPOPS || k == FQ_C_MAXTRIPS;
+    uint64_t v = 0;
+    for (int st = 0; st < FQ_C_STRIPES; ++st) { const uint64_t x = striped[(size_t)st * FQ_C_STRIDE + k]; v = is_max ? std::max(v, x) : v + x; }
+    cnt[k] = v;
+  }
 }
 #define CKS(expr) do { const int rc_ = (expr); if (rc_) return rc_; } while (0)
 
@@ -837,12 +847,16 @@ int stage0_packed(Call &K) {
   vector<int32_t> sub_whole(n_sub, 0);          // longest read trimming leaves whole (known without its quality row)
   CKS(d2h_staged(c, counts, c->d_counts.p, 8));
   if (have_qlast) CKS(d2h_staged(c, sub_whole.data(), c->d_sub_max.p + n_sub, (size_t)n_sub * 4));
+  std::vector<uint64_t> striped(ragged ? (size_t)FQ_C_STRIPES * FQ_C_STRIDE : 0);
   if (ragged) {
     CKS(d2h_staged(c, c->h_sub_max.data(), c->d_sub_max.p, (size_t)n_sub * 4));
-    CKS(d2h_staged(c, lcnt, c->d_counters.p + FQ_C_BASES, 16));
+    CKS(d2h_staged(c, striped.data(), c->d_counters.p, striped.size() * 8));
   }
   CKS(sync_staged(c));
   if (ragged) {
+    uint64_t folded[FQ_C_COUNT];
+    fold_counters(striped.data(), folded);
+    lcnt[0] = folded[FQ_C_BASES]; lcnt[1] = folded[FQ_C_BADLEN];
     if (lcnt[1]) { c->err = "read length outside [" + std::to_string(FQ_LMIN) + "," + std::to_string(FQ_LMAX) + "]"; return FQ_ELIMIT; }
     for (int sb = 0; sb < n_sub; ++sb)   // a ragged row longer than its packed row would be unpacked from its neighbour's bytes
       if (((int64_t)c->h_sub_max[sb] + 3) / 4 > (int64_t)pb.body_stride) { c->err = "a read is longer than body_stride holds"; return FQ_EINVAL; }
@@ -1012,12 +1026,16 @@ int stage0_text(Call &K) {
   uint64_t lcnt[2] = {0, 0};
   c->h_sub_max.assign(n_sub, tb.uniform_len);
   CKS(d2h_staged(c, counts, c->d_counts.p, 8));
+  std::vector<uint64_t> striped(ragged ? (size_t)FQ_C_STRIPES * FQ_C_STRIDE : 0);
   if (ragged) {
     CKS(d2h_staged(c, c->h_sub_max.data(), c->d_sub_max.p, (size_t)n_sub * 4));
-    CKS(d2h_staged(c, lcnt, c->d_counters.p + FQ_C_BASES, 16));
+    CKS(d2h_staged(c, striped.data(), c->d_counters.p, striped.size() * 8));
   }
   CKS(sync_staged(c));
   if (ragged) {
+    uint64_t folded[FQ_C_COUNT];
+    fold_counters(striped.data(), folded);
+    lcnt[0] = folded[FQ_C_BASES]; lcnt[1] = folded[FQ_C_BADLEN];
     if (lcnt[1]) { c->err = "read length outside [" + std::to_string(FQ_LMIN) + "," + std::to_string(FQ_LMAX) + "]"; return FQ_ELIMIT; }
     c->n_bases_in = (int64_t)lcnt[0];
   } else c->n_bases_in = (int64_t)n_in * tb.uniform_len;
@@ -1933,9 +1951,11 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
     c->stats.d2h_bytes += N * sizeof(fq_result_t) + cc * 2 + mm + xx * sizeof(fq_multi_t);
   }
   uint64_t cnt[FQ_C_COUNT];
-  CKS(d2h_staged(c, cnt, c->d_counters.p, sizeof cnt));
+  c->h_counters.resize((size_t)FQ_C_STRIPES * FQ_C_STRIDE);
+  CKS(d2h_staged(c, c->h_counters.data(), c->d_counters.p, c->h_counters.size() * 8));
   CKS(sync_staged(c));
-  CK(fqdev::dzero(c->d_counters.p, sizeof cnt));
+  fold_counters(c->h_counters.data(), cnt);
+  CK(fqdev::dzero(c->d_counters.p, c->h_counters.size() * 8));
   if (!cc) c->p_ocig.p[0] = 0;
   if (!mm) c->p_omd.p[0] = 0;
   if (!xx) c->p_omulti.p[0] = fq_multi_t{};
@@ -2011,7 +2031,7 @@ int run_call(fq_ctx *c, fq_result_batch_t *out) {
               // out of range, bases, work counters) to the next one
     fqdev::copy_discard();
     (void)fqdev::stream_aux(0);
-    (void)fqdev::dzero(c->d_counters.p, FQ_C_COUNT * 8);
+    (void)fqdev::dzero(c->d_counters.p, (size_t)FQ_C_STRIPES * FQ_C_STRIDE * 8);
     (void)fqdev::sync();
     // uploads from the caller's pinned batch may still be in flight on the shared copy stream (a prefetched head):
     // the caller is free to repack or free that storage as soon as the failed call has returned

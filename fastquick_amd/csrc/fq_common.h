@@ -149,7 +149,13 @@ struct FqMdTask {
   int32_t len;           // s->len at MD time
 };
 
-// work counters written by kernels (one u64 each, atomically accumulated per wave)
+// work counters written by kernels (one u64 each, atomically accumulated per wave).  On the device the array is kept FQ_C_STRIPES times, a cache
+// line or more apart (FQ_C_STRIDE), and a workgroup adds to the copy blockIdx picks: the atomics on one cache line are worked one after the other by
+// its L2 channel (~7 ns each: 130,000 wavefronts' worth per counter were most of the 3 ms of a filter launch over 8.4 M reads).  The host folds the
+// copies when it reads them (sums; maxima for the two *MAX* counters).
+#define FQ_C_STRIPES 64
+#define FQ_C_STRIDE 64   /* >= FQ_C_COUNT, a multiple of 16 (128 bytes) */
 enum { FQ_C_OCC_WIDTH = 0, FQ_C_OCC_GAP, FQ_C_OCC_SA, FQ_C_PROBES, FQ_C_POPS, FQ_C_PUSHES, FQ_C_MAXPOPS, FQ_C_POPS_GT4K, FQ_C_MAXTRIPS, FQ_C_SUMTRIPS, FQ_C_LANETRIPS, FQ_C_BASES, FQ_C_BADLEN, FQ_C_OCC_NOGAP, FQ_C_DBG0, FQ_C_DBG_END = FQ_C_DBG0 + 16,
        // record stages (fq_records.h): pairs a lane paired, pairs with both ends unmapped, main hits resolved without enumeration, refine / MD slots that were too small
        FQ_C_PAIRS_DEV = FQ_C_DBG_END, FQ_C_UNMAPPED, FQ_C_SA_DIRECT, FQ_C_ERR_CIGAR, FQ_C_ERR_MD, FQ_C_MD_READS, FQ_C_ERR_DRAW0, FQ_C_COUNT };
+static_assert(FQ_C_COUNT <= FQ_C_STRIDE && FQ_C_STRIDE % 16 == 0, "a counter stripe holds every counter and is whole cache lines");

@@ -1079,7 +1079,17 @@ int launch_nl_index(const uint8_t *text, uint32_t n, uint32_t lo, uint32_t *nl, 
 }
 __global__ void __launch_bounds__(256) k_tok_rec(FqTokArgs a) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i < a.n_rec) fqt_rec_thread(a, i);
+  FqTokStat t = i < a.n_rec ? fqt_rec_thread(a, i) : fqt_stat_none();
+  // the wavefront's records folded into one set of statistics, then one atomic each by its first lane
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    t.first_bad = min(t.first_bad, (uint32_t)__shfl_xor((int)t.first_bad, d, 64));
+    t.max_name = max(t.max_name, (uint32_t)__shfl_xor((int)t.max_name, d, 64));
+    t.min_name = min(t.min_name, (uint32_t)__shfl_xor((int)t.min_name, d, 64));
+    t.max_len = max(t.max_len, (uint32_t)__shfl_xor((int)t.max_len, d, 64));
+    t.min_len = min(t.min_len, (uint32_t)__shfl_xor((int)t.min_len, d, 64));
+  }
+  if ((threadIdx.x & 63) == 0) fqt_stat_commit(a, t);
 }
 __global__ void __launch_bounds__(256) k_tok_pieces(FqTokArgs a, int64_t n) {
   const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;

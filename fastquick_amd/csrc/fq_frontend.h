@@ -43,8 +43,10 @@ __device__ __forceinline__ uint32_t fqf_wave_xor32(uint32_t x) {
   for (int d = 32; d >= 1; d >>= 1) x ^= (uint32_t)__shfl_xor((int)x, d, 64);
   return x;
 }
-#define FQF_ATOMIC_MIN32(p, v) atomicMin((unsigned *)(p), (unsigned)(v))
-#define FQF_ATOMIC_MAX32(p, v) atomicMax((unsigned *)(p), (unsigned)(v))
+// (a look first: atomics on one cache line are worked one after the other by its L2 channel, ~8 ns each -- 330,000 of them, five per wavefront of
+//  records, were 2.5 ms of a 2.6 ms launch; the value is almost always there already.  The look goes past the CU's L1, which would keep an old value.)
+#define FQF_ATOMIC_MIN32(p, v) do { const unsigned fqf_v_ = (unsigned)(v); if (fqf_v_ < __hip_atomic_load((const unsigned *)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMin((unsigned *)(p), fqf_v_); } while (0)
+#define FQF_ATOMIC_MAX32(p, v) do { const unsigned fqf_v_ = (unsigned)(v); if (fqf_v_ > __hip_atomic_load((const unsigned *)(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax((unsigned *)(p), fqf_v_); } while (0)
 #define FQF_ATOMIC_OR32(p, v) atomicOr((unsigned *)(p), (unsigned)(v))
 #else
 #define FQF_UNIFORM32(x) ((uint32_t)(x))
@@ -904,15 +906,35 @@ struct FqTokArgs {
   uint16_t *hlen;            // [n_rows]
   uint32_t *stat;            // [FQT_N_STAT] of this file: first bad record (min), longest name (max), shortest / longest read
 };
-// one thread per record: the four lines, the name, the lengths
-FQ_HD void fqt_rec_thread(const FqTokArgs &A, int i) {
+// one thread per record: the four lines, the name, the lengths.  What the record adds to the file's statistics comes back in st (the launcher folds
+// a wavefront's into one atomic each: 4 M records' worth of same-address atomics were most of this kernel's time).
+struct FqTokStat { uint32_t first_bad, max_name, min_name, max_len, min_len; };
+FQ_HD FqTokStat fqt_stat_none() { FqTokStat t; t.first_bad = 0xffffffffu; t.max_name = 0; t.min_name = 0xffffffffu; t.max_len = 0; t.min_len = 0xffffffffu; return t; }
+FQ_HD void fqt_stat_commit(const FqTokArgs &A, const FqTokStat &t) {
+  if (t.first_bad != 0xffffffffu) FQF_ATOMIC_MIN32(&A.stat[FQT_FIRST_BAD], t.first_bad);
+  if (t.min_len == 0xffffffffu) return;                      // (no good record)
+  FQF_ATOMIC_MAX32(&A.stat[FQT_MAX_NAME], t.max_name);
+  FQF_ATOMIC_MIN32(&A.stat[FQT_MIN_NAME], t.min_name);
+  FQF_ATOMIC_MAX32(&A.stat[FQT_MAX_LEN], t.max_len);
+  FQF_ATOMIC_MIN32(&A.stat[FQT_MIN_LEN], t.min_len);
+}
+FQ_HD FqTokStat fqt_rec_thread(const FqTokArgs &A, int i) {
   const uint8_t *T = A.text;
   const uint32_t l0 = i ? A.nl[4 * (size_t)i - 1] + 1 : A.text0;
   const uint32_t e0 = A.nl[4 * (size_t)i], e1 = A.nl[4 * (size_t)i + 1], e2 = A.nl[4 * (size_t)i + 2], e3 = A.nl[4 * (size_t)i + 3];
   const uint32_t l1 = e0 + 1, l2 = e1 + 1, l3 = e2 + 1;
   bool ok = l0 < e0 && T[l0] == '@' && l2 < e2 && T[l2] == '+' && (e1 - l1) == (e3 - l3) && (e1 - l1) <= (uint32_t)A.max_len;
   uint32_t ne = l0 + 1;
-  if (ok) while (ne < e0 && !fqt_is_space(T[ne])) ++ne;
+  if (ok) {                                                  // the name ends at the first white space (four bytes a step; the line end at e0 is one)
+    for (;;) {
+      const uint32_t w = fqt_load32(T + ne);
+      uint32_t k = 0;
+      while (k < 4 && !fqt_is_space((w >> (8 * k)) & 0xff)) ++k;
+      ne += k;
+      if (k < 4) break;
+    }
+    if (ne > e0) ne = e0;
+  }
   uint32_t name_len = ok ? ne - (l0 + 1) : 0;
   if (name_len > 301) name_len = 301;                        // the reference's name buffer holds 2 * read_len = 302 bytes (libbwa/bwaseqio.c:233)
   const uint32_t L = ok ? e1 - l1 : 0;
@@ -920,11 +942,10 @@ FQ_HD void fqt_rec_thread(const FqTokArgs &A, int i) {
   r.name_off = l0 + 1; r.seq_off = l1; r.qual_off = l3; r.len = (uint16_t)L; r.name_len = (uint16_t)name_len;
   A.rec[A.row0 + i] = r;
   A.hlen[A.row0 + i] = (uint16_t)L;
-  if (!ok) { FQF_ATOMIC_MIN32(&A.stat[FQT_FIRST_BAD], (uint32_t)i); return; }
-  FQF_ATOMIC_MAX32(&A.stat[FQT_MAX_NAME], name_len);
-  FQF_ATOMIC_MIN32(&A.stat[FQT_MIN_NAME], name_len);
-  FQF_ATOMIC_MAX32(&A.stat[FQT_MAX_LEN], L);
-  FQF_ATOMIC_MIN32(&A.stat[FQT_MIN_LEN], L);
+  FqTokStat t = fqt_stat_none();
+  if (!ok) { t.first_bad = (uint32_t)i; return t; }
+  t.max_name = t.min_name = name_len; t.max_len = t.min_len = L;
+  return t;
 }
 // one thread per (record, piece of 32 bases): the base line's characters checked; pieces 0 .. 2 are the filter's three 32-mers
 FQ_HD void fqt_piece_thread(const FqTokArgs &A, int64_t idx) {

@@ -14,15 +14,18 @@
 #define FQ_POPC64(x) __popcll(x)
 #define FQ_POPC32(x) __popc(x)
 #define FQ_CTZ32(x) (__ffs((int)(x)) - 1)
-#define FQ_ATOMIC_ADD64(p, v) atomicAdd((unsigned long long *)(p), (unsigned long long)(v))
-#define FQ_ATOMIC_MAX64(p, v) atomicMax((unsigned long long *)(p), (unsigned long long)(v))
-#define FQ_ATOMIC_MAX32(p, v) atomicMax((int *)(p), (int)(v))
+// (the work counters: into the workgroup's stripe of the array, fq_common.h)
+#define FQ_C_STRIPE_OFF ((size_t)(blockIdx.x & (FQ_C_STRIPES - 1)) * FQ_C_STRIDE)
+#define FQ_ATOMIC_ADD64(p, v) atomicAdd((unsigned long long *)(p) + FQ_C_STRIPE_OFF, (unsigned long long)(v))
+#define FQ_ATOMIC_MAX64(p, v) atomicMax((unsigned long long *)(p) + FQ_C_STRIPE_OFF, (unsigned long long)(v))
 #define FQ_LOAD_RELAXED(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+// (a maximum that almost every caller leaves as it is: a look first, past the CU's L1, and the atomic only when it would raise it)
+#define FQ_ATOMIC_MAX32(p, v) do { const int fq_v_ = (int)(v); if (fq_v_ > FQ_LOAD_RELAXED((const int *)(p))) atomicMax((int *)(p), fq_v_); } while (0)
 // counter += number of active lanes for which pred holds: one atomic per wavefront instead of one per lane
 #define FQ_WAVE_COUNT(p, pred)                                                                                      \
   do {                                                                                                              \
     const unsigned long long m_ = __ballot((pred) ? 1 : 0);                                                         \
-    if ((pred) && __lane_id() == (unsigned)(__ffsll((long long)m_) - 1)) atomicAdd((unsigned long long *)(p), (unsigned long long)__popcll(m_)); \
+    if ((pred) && __lane_id() == (unsigned)(__ffsll((long long)m_) - 1)) atomicAdd((unsigned long long *)(p) + FQ_C_STRIPE_OFF, (unsigned long long)__popcll(m_)); \
   } while (0)
 #else
 #define FQ_WAVE_COUNT(p, pred) do { if (pred) *(p) += 1; } while (0)
@@ -251,8 +254,8 @@ FQ_HD void fq_prep_thread(const FqPrepArgs &A, int r) {
       int mx = len;
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
-      if (__builtin_amdgcn_readfirstlane(r) == r) atomicMax(&A.sub_max[slot0], mx);
-    } else atomicMax(&A.sub_max[slot], len);
+      if (__builtin_amdgcn_readfirstlane(r) == r) FQ_ATOMIC_MAX32(&A.sub_max[slot0], mx);
+    } else FQ_ATOMIC_MAX32(&A.sub_max[slot], len);
 #else
     if (A.sub_max[slot] < len) A.sub_max[slot] = len;
 #endif
@@ -358,8 +361,8 @@ FQ_HD void fq_prep_packed_thread(const FqPrepPackedArgs &A, int r) {
     if (__ballot(slot != slot0) == 0) {
 #pragma unroll
       for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(mx, d); mx = o > mx ? o : mx; }
-      if (mx > 0 && __lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) atomicMax(&A.sub_whole[slot0], mx);
-    } else if (mx > 0) atomicMax(&A.sub_whole[slot], mx);
+      if (mx > 0 && __lane_id() == (unsigned)(__ffsll((long long)__ballot(1)) - 1)) FQ_ATOMIC_MAX32(&A.sub_whole[slot0], mx);
+    } else if (mx > 0) FQ_ATOMIC_MAX32(&A.sub_whole[slot], mx);
 #else
     if (whole && A.sub_whole[slot] < len) A.sub_whole[slot] = len;
 #endif

@@ -174,7 +174,7 @@ int launch_nl_index(const uint8_t *text, uint32_t n, uint32_t lo, uint32_t *nl, 
   *count = c;
   return 0;
 }
-int launch_tok_rec(const FqTokArgs &a) { for (int i = 0; i < a.n_rec; ++i) fqt_rec_thread(a, i); return 0; }
+int launch_tok_rec(const FqTokArgs &a) { for (int i = 0; i < a.n_rec; ++i) fqt_stat_commit(a, fqt_rec_thread(a, i)); return 0; }
 int launch_tok_pieces(const FqTokArgs &a) { const int64_t n = (int64_t)a.n_rec * ((a.max_len + 31) >> 5); for (int64_t g = 0; g < n; ++g) fqt_piece_thread(a, g); return 0; }
 int launch_slot_bases(const FqSlotArgs &a) { if (a.n_rec > 0) for (int s = 0; s < a.n_slots; ++s) fqt_slot_bases_thread(a, s); return 0; }
 int launch_slot_names(const FqSlotArgs &a) {
