@@ -67,7 +67,7 @@ def main() -> None:
     ap.add_argument("--ontarget-pairs", type=int, default=0, help="pairs per call of the on-target leg (0: the call shape of the headline leg, --pairs; the search "
                     "stage's second round is a fixed tail plus a term in the number of reads, so its roofline fraction grows with the call: DESIGN.md 9)")
     ap.add_argument("--ontarget-ctxs", type=int, default=2)
-    ap.add_argument("--ontarget-steps", type=int, default=3)
+    ap.add_argument("--ontarget-steps", type=int, default=8)
     ap.add_argument("--ontarget-tput-ctxs", type=int, default=16, help="streams of the on-target throughput leg (1,048,576 pairs per call; 0: skip)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stream-shard", type=int, default=4, help="with --gpus N > 1: also time ONE FASTQ stream sharded over the ranks by reference batch "
@@ -79,7 +79,14 @@ def main() -> None:
     ap.add_argument("--cpu-threads", type=int, default=32, help="independent streams (threads) of the CPU baseline")
     ap.add_argument("--tune", default="", help="key=value,... passed to fq_ctx_set_tuning on every context (experiments)")
     ap.add_argument("--workdir", default=os.environ.get("FQ_BENCH_DIR", "/tmp/fq_bench"))
+    ap.add_argument("--host-cpus", type=int, default=0, help="run inside a host budget of this many CPUs: the process is pinned to them (sched_setaffinity) and the library told its share "
+                    "(FASTQUICK_HOST_CPUS) before anything touches the device; 0: the whole allowance.  The default run times itself once more this way (host_budget)")
+    ap.add_argument("--no-host-budget", action="store_true", help="skip the host_budget leg (the run repeated on 2 CPUs)")
     args = ap.parse_args()
+    if args.host_cpus > 0:
+        cpus = sorted(os.sched_getaffinity(0))[:args.host_cpus]
+        os.sched_setaffinity(0, set(cpus))                      # (inherited by every thread started from here on: the HIP runtime's, the library's, Python's)
+        os.environ["FASTQUICK_HOST_CPUS"] = str(args.host_cpus)
 
     import numpy as np
     import torch
@@ -184,26 +191,22 @@ def main() -> None:
         cur_of = [c % n_distinct for c in range(n_ctx)]     # each context walks the batches round-robin, across run_steps calls
 
         def run_steps(k_steps):
+            if boundary == "host":
+                # the streams' driver loops (prefetch the next batch, align this one) run inside the library: fq_stream_run, one library thread per
+                # stream asleep while the device works; no Python thread per stream
+                t_run0[0] = time.perf_counter()
+                surv = api.stream_run(ctxs, [packs] * n_ctx, k_steps, first=list(cur_of), prefetch_beyond=True)
+                for c in range(n_ctx):
+                    cur_of[c] = (cur_of[c] + k_steps) % n_distinct
+                return sum(surv)
             recs = [0] * n_ctx
             errs = []
 
             def worker(c):
                 try:
-                    t_in = time.perf_counter()
                     al = ctxs[c]
-                    if boundary == "host":
-                        cur = cur_of[c]
-                        for _ in range(k_steps):
-                            nxt = (cur + 1) % n_distinct
-                            al.prefetch(packs[nxt])          # next batch's upload runs under this batch's kernels
-                            recs[c] += al.align_packed(packs[cur]).n_survivors
-                            cur = nxt
-                        cur_of[c] = cur
-                    else:
-                        for _ in range(k_steps):
-                            recs[c] += al.align_resident().n_survivors
-                    if os.environ.get("FQ_BENCH_DEBUG"):
-                        sys.stderr.write("worker %d: start +%.1f ms, end +%.1f ms\n" % (c, 1e3 * (t_in - t_run0[0]), 1e3 * (time.perf_counter() - t_run0[0])))
+                    for _ in range(k_steps):
+                        recs[c] += al.align_resident().n_survivors
                 except Exception as e:      # noqa: BLE001
                     errs.append(e)
             t_run0[0] = time.perf_counter()
@@ -487,6 +490,33 @@ def main() -> None:
             out["ontarget"]["throughput"] = {"value": round(leg["value"], 1), "unit": "pairs/s", "pairs_per_call": 1 << 20, "concurrent_streams": args.ontarget_tput_ctxs,
                                              "steps": 2, "ms_per_step": round(1e3 * leg["elapsed"] / 2, 3),
                                              "host_ms_per_call": round(leg["agg"]["host_ms_total"] / leg["calls"], 3)}
+
+    # ---- host budget: the same run inside a rank's share of the host, 2 CPUs (an 8-GPU node's 16 CPUs over 8 ranks).  A child process of this
+    #      script, pinned to 2 CPUs before it touches the device (sched_setaffinity: every thread it and the HIP runtime start inherit it) and the
+    #      library told so (FASTQUICK_HOST_CPUS=2: what LOCAL_WORLD_SIZE=8 works out to on 16 CPUs); headline and on-target legs.
+    if rank == 0 and world == 1 and args.host_cpus == 0 and not args.no_host_budget:
+        import subprocess
+        hb_cpus = 2
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(max(4, min(args.steps, 12))), "--warmup", str(max(2, min(args.warmup, 4))),
+               "--pairs", str(args.pairs), "--ctxs", str(args.ctxs), "--markers", str(args.markers), "--mix", args.mix, "--read-len", str(args.read_len),
+               "--boundary", args.boundary, "--host-cpus", str(hb_cpus), "--no-resident", "--no-front-end", "--no-cpu-baseline", "--no-host-budget",
+               "--ontarget-tput-ctxs", "0", "--workdir", args.workdir] + (["--no-ontarget"] if args.no_ontarget else []) + (["--tune", args.tune] if args.tune else [])
+        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        t0 = time.perf_counter()
+        run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+        hb = {"cpus": hb_cpus, "how": "child process pinned to %d CPUs (sched_setaffinity) with FASTQUICK_HOST_CPUS=%d; same workload, %d streams" % (hb_cpus, hb_cpus, args.ctxs),
+              "wall_s": round(time.perf_counter() - t0, 1)}
+        line = [l for l in run.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+        if run.returncode == 0 and line:
+            ch = json.loads(line[-1])
+            hb.update({"value": ch["value"], "unit": ch["unit"], "ratio_to_value": round(ch["value"] / out["value"], 4), "steps": ch["steps"], "ms_per_step": ch["ms_per_step"],
+                       "host_cpu_ms_per_call": ch.get("host_cpu_ms_per_call"), "wall_ms_per_call": ch.get("wall_ms_per_call"), "device_wait_ms_per_call": ch.get("device_wait_ms_per_call")})
+            if "ontarget" in ch and "ontarget" in out:
+                hb["ontarget"] = {"value": ch["ontarget"]["value"], "ratio_to_ontarget_value": round(ch["ontarget"]["value"] / out["ontarget"]["value"], 4),
+                                  "ms_per_step": ch["ontarget"]["ms_per_step"], "host_cpu_ms_per_call": ch["ontarget"].get("host_cpu_ms_per_call")}
+        else:
+            hb["error"] = run.stderr.decode(errors="replace")[-500:]
+        out["host_budget"] = hb
 
     # ---- front end: what feeds the packed boundary, measured on this box's host cores beside `value` -----------------
     #   pack_pairs_per_s              fq_pack_reads_into on the headline call's batch (ASCII rows -> packed batch in reused pinned storage)

@@ -100,7 +100,7 @@ EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destr
            "fq_index_n_contigs", "fq_index_contig", "fq_ctx_create", "fq_ctx_destroy", "fq_ctx_last_error",
            "fq_ctx_set_debug", "fq_align_batch", "fq_batch_upload", "fq_align_resident", "fq_sam_header",
            "fq_sam_format_last", "fq_stage_dump_last", "fq_stats_get", "fq_stats_reset", "fq_version", "fq_host_cpus", "fq_runtime_configure", "fq_device_count",
-           "fq_pinned_alloc", "fq_pinned_free", "fq_pack_reads", "fq_packed_free", "fq_packed_create", "fq_pack_reads_into", "fq_pack_single_reads_into", "fq_packed_prefetch", "fq_packed_cancel", "fq_align_packed",
+           "fq_pinned_alloc", "fq_pinned_free", "fq_pack_reads", "fq_packed_free", "fq_packed_create", "fq_pack_reads_into", "fq_pack_single_reads_into", "fq_packed_prefetch", "fq_packed_cancel", "fq_align_packed", "fq_stream_run",
            "fq_ctx_set_tuning", "fq_ctx_set_serial_hooks", "fq_ctx_mark_stream_broken", "fq_ctx_state_export", "fq_ctx_state_import", "fq_qc_default_opts", "fq_qc_create", "fq_qc_destroy", "fq_qc_last_error", "fq_qc_begin_file",
            "fq_qc_add_last", "fq_qc_end_file", "fq_qc_write", "fq_qc_state_reset", "fq_qc_state_export", "fq_qc_merge", "fq_bam_create", "fq_bam_add_last", "fq_bam_format_last", "fq_bam_write_records", "fq_bam_close",
            "fq_fastq_open", "fq_fastq_configure", "fq_fastq_set_sampling", "fq_fastq_read", "fq_fastq_last_error", "fq_fastq_dropped_record", "fq_fastq_unequal_lengths", "fq_fastq_is_bgzf", "fq_fastq_close", "fq_inflate_raw", "fq_crc32", "fq_inflate_device", "fq_bgzf_inflate_device",
@@ -108,6 +108,7 @@ EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destr
            "fq_text_batch_pairs", "fq_text_batch_first_name", "fq_align_text", "fq_text_batch_fetch"]
 
 SERIAL_HOOK = C.CFUNCTYPE(None, C.c_void_p)
+STREAM_CALL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p)      # (user, stream, call, fq_result_batch_t *)
 _libs = {}
 
 
@@ -159,6 +160,8 @@ def load_library(path: str | None = None):
     L.fq_packed_cancel.argtypes = [C.c_void_p, C.POINTER(PackedBatch)]
     L.fq_packed_prefetch.argtypes = [C.c_void_p, C.POINTER(PackedBatch)]
     L.fq_align_packed.argtypes = [C.c_void_p, C.POINTER(PackedBatch), C.POINTER(ResultBatch)]
+    L.fq_stream_run.argtypes = [C.POINTER(C.c_void_p), C.c_int32, C.POINTER(C.POINTER(C.POINTER(PackedBatch))), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32, C.c_int32,
+                                STREAM_CALL, C.c_void_p, C.POINTER(C.c_int64)]
     L.fq_fastq_open.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     L.fq_fastq_configure.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int64]
     L.fq_fastq_set_sampling.argtypes = [C.c_void_p, C.c_double]
@@ -658,6 +661,36 @@ def bgzf_inflate_device(blob: bytes, text_cap: int, device: int = 0, lib=None, r
 
 
 FQ_EFALLBACK = -6
+
+
+def stream_run(aligners, batches, n_calls, first=None, on_call=None, prefetch_beyond=False, lib=None):
+    """fq_stream_run: stream s = aligners[s] over batches[s] (lists of HostPacked), n_calls calls each, inside the library (no Python thread per
+    stream).  on_call(stream, call): called after each call on the stream's thread (the aligner's sam_text() etc. are valid in it).  Returns the
+    surviving pairs per stream."""
+    L = lib or aligners[0].L
+    n = len(aligners)
+    ctxs = (C.c_void_p * n)(*[al.h for al in aligners])
+    rows = [(C.POINTER(PackedBatch) * len(bs))(*[b.p for b in bs]) for bs in batches]
+    tab = (C.POINTER(C.POINTER(PackedBatch)) * n)(*[C.cast(r, C.POINTER(C.POINTER(PackedBatch))) for r in rows])
+    nb = (C.c_int32 * n)(*[len(bs) for bs in batches])
+    fst = (C.c_int32 * n)(*(first or [0] * n))
+    surv = (C.c_int64 * n)()
+    errs = []
+
+    def cb(_user, stream, call, _res):
+        try:
+            on_call(stream, call)
+            return 0
+        except Exception as e:      # noqa: BLE001
+            errs.append(e)
+            return -1
+    fn = STREAM_CALL(cb) if on_call else STREAM_CALL(0)
+    rc = L.fq_stream_run(ctxs, n, tab, nb, fst, n_calls, 1 if prefetch_beyond else 0, fn, None, surv)
+    if errs:
+        raise errs[0]
+    if rc:
+        raise FastquickError("fq_stream_run failed: %d (%s)" % (rc, "; ".join(x for x in (L.fq_ctx_last_error(al.h).decode(errors="replace") for al in aligners) if x)))
+    return list(surv)
 
 
 class DeviceFrontEnd:

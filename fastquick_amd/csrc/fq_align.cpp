@@ -2182,6 +2182,43 @@ extern "C" int fq_align_packed(fq_ctx_t *c, const fq_packed_batch_t *in, fq_resu
   return run_call(c, out);
 }
 
+// Several streams of packed batches run to their ends inside the library: what every host program of more than one stream wrote for itself (a
+// thread per stream: prefetch the next batch, align this one, hand the result on) -- PairEndMapper's producer / consumer pair per FASTQ pair
+// (src/BwtMapper.cpp:232-262, 1840-1845: a thread pool over the lines of --fq_list).  One library thread per stream, asleep while the device
+// works (the waits are blocking events); the caller's thread only waits for them.
+extern "C" int fq_stream_run(fq_ctx_t *const *ctxs, int32_t n_streams, const fq_packed_batch_t *const *const *batches, const int32_t *n_batches, const int32_t *first,
+                             int32_t n_calls, int32_t flags, fq_stream_call_fn on_call, void *user, int64_t *survivors_out) {
+  if (!ctxs || n_streams < 1 || !batches || !n_batches || n_calls < 0) return FQ_EINVAL;
+  for (int s = 0; s < n_streams; ++s) if (!ctxs[s] || !batches[s] || n_batches[s] < 1) return FQ_EINVAL;
+  for (int s = 0; s < n_streams; ++s) for (int t = 0; t < s; ++t) if (ctxs[s] == ctxs[t]) return FQ_EINVAL;      // (a context is one stream's)
+  std::vector<int> rcs((size_t)n_streams, FQ_OK);
+  std::vector<int64_t> surv((size_t)n_streams, 0);
+  auto run = [&](int s) {
+    fq_ctx_t *c = ctxs[s];
+    const int nb = n_batches[s];
+    int cur = (first ? first[s] : 0) % nb;
+    if (cur < 0) cur += nb;
+    fq_result_batch_t res;
+    for (int k = 0; k < n_calls; ++k) {
+      const int nxt = (cur + 1) % nb;
+      int rc = FQ_OK;
+      const bool pre = nxt != cur && (k + 1 < n_calls || (flags & FQ_STREAM_PREFETCH_BEYOND));
+      if (pre) rc = fq_packed_prefetch(c, batches[s][nxt]);      // the next batch's upload runs under this batch's kernels
+      if (!rc) rc = fq_align_packed(c, batches[s][cur], &res);
+      if (!rc) { surv[(size_t)s] += res.n_survivors; if (on_call) rc = on_call(user, s, k, &res); }
+      if (rc) { rcs[(size_t)s] = rc; if (pre) (void)fq_packed_cancel(c, batches[s][nxt]); return; }
+      cur = nxt;
+    }
+  };
+  std::vector<std::thread> th;
+  for (int s = 1; s < n_streams; ++s) th.emplace_back(run, s);
+  run(0);                                                    // (the caller's thread is the first stream's)
+  for (auto &t : th) t.join();
+  if (survivors_out) for (int s = 0; s < n_streams; ++s) survivors_out[s] = surv[(size_t)s];
+  for (int rc : rcs) if (rc) return rc;
+  return FQ_OK;
+}
+
 // The whole hot path on a batch of the device front end (fq_frontend_next): nothing of the input crosses PCIe.  The batch must stay
 // unreleased until the consumers of this call's records (fq_sam_format_last, fq_qc_add_last, fq_bam_*) have run.
 extern "C" int fq_align_text(fq_ctx_t *c, const fq_text_batch *tb, fq_result_batch_t *out) {

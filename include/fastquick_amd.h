@@ -237,6 +237,18 @@ int fq_packed_prefetch(fq_ctx_t *c, const fq_packed_batch_t *next);
 int fq_packed_cancel(fq_ctx_t *c, const fq_packed_batch_t *b);
 /* The whole hot path on a packed batch, host memory in -> host memory out. */
 int fq_align_packed(fq_ctx_t *c, const fq_packed_batch_t *in, fq_result_batch_t *out);
+/* n_streams streams run to their ends inside the library -- the driver loop of a stream (prefetch the next batch, align this one, hand the result
+ * on), which the reference runs as a producer / consumer pair per line of --fq_list on a thread pool (src/BwtMapper.cpp:232-262, 1840-1845).
+ * Stream s aligns batches[s][(first[s] + k) % n_batches[s]] for k = 0 .. n_calls - 1 on ctxs[s] (distinct contexts; first NULL: from 0), the next
+ * batch's upload under the current call's kernels.  on_call (may be NULL) is called after each call on that stream's thread -- the result and the
+ * context's records (fq_sam_format_last ..) are valid until it returns; a non-zero return ends the stream.  survivors_out (may be NULL): per stream,
+ * the surviving pairs of its calls.  The library starts one thread per stream beyond the first (asleep while the device works) and joins them:
+ * the caller needs none.  flags: FQ_STREAM_PREFETCH_BEYOND -- the batch behind a stream's last call is prefetched too (a following fq_stream_run that
+ * continues the walk finds it uploaded; fq_packed_cancel it otherwise).  Returns FQ_OK or the first failing stream's code (fq_ctx_last_error). */
+#define FQ_STREAM_PREFETCH_BEYOND 1
+typedef int (*fq_stream_call_fn)(void *user, int32_t stream, int32_t call, const fq_result_batch_t *result);
+int fq_stream_run(fq_ctx_t *const *ctxs, int32_t n_streams, const fq_packed_batch_t *const *const *batches, const int32_t *n_batches, const int32_t *first,
+                  int32_t n_calls, int32_t flags, fq_stream_call_fn on_call, void *user, int64_t *survivors_out);
 
 /* ---- FASTQ front end ---------------------------------------------------------------------------------------------------------
  * One FASTQ file -> rows of a fq_read_batch_t, with the tokens of kseq_read3_fpc (libbwa/kseq.h:327-371) as

@@ -106,6 +106,68 @@ def test_fq_list_over_two_virtual_devices(golden_cases, tmp_path):
     check_against_one_device(os.path.join(emu, "FASTQuick_emu"), golden_cases["qc"], tmp_path, "0,1")
 
 
+def run_list8(exe, g, tmp, tag, devices=None, sam=True):
+    """the case's pair cut into eight pairs of BGZF files of unequal sizes (the lines of a --fq_list): on a GPU the device front end reads them,
+    one reader set per worker"""
+    from fastquick_amd import synth
+    texts = [open(g[k], "rb").read().split(b"\n") for k in ("fq1", "fq2")]
+    n = (len(texts[0]) - 1) // 4
+    cuts = [0] + [n * k // 11 for k in (1, 2, 4, 5, 7, 8, 10)] + [n]
+    lst = os.path.join(str(tmp), "eight_pairs.list")
+    with open(lst, "w") as fh:
+        for i in range(8):
+            paths = []
+            for e in range(2):
+                path = os.path.join(str(tmp), "part8_%d_%d.fq.gz" % (i, e + 1))
+                if not os.path.exists(path):
+                    with open(path, "wb") as fo:
+                        fo.write(synth.bgzf_compress(b"\n".join(texts[e][4 * cuts[i]:4 * cuts[i + 1]]) + b"\n", threads=2, level=6, member=3000))
+                paths.append(path)
+            fh.write("%s\t%s\n" % tuple(paths))
+    prefix = g["prefix"][:-len(".FASTQuick.fa")]
+    with open(g["prefix"] + ".param", "w") as fh:
+        fh.write("REFERENCE_PATH\t%s\nTARGET_REGION_PATH\tEmpty\nDBSNP_VCF_PATH\tEmpty\nNUM_VAR_LONG\t4\nNUM_VAR_SHORT\t36\n"
+                 "SHORT_FLANK_LENGTH\t250\nLONG_FLANK_LENGTH\t1000\n" % os.path.join(g["dir"], "genome"))
+    out = os.path.join(str(tmp), tag)
+    cmd = [exe, "align", "--index_prefix", prefix, "--fq_list", lst, "--out_prefix", out, "--batch_pairs", str(g["batch"]),
+           "--chunk_pairs", str(2 * g["batch"]), "--q", str(g["trim_qual"]), "--read_len", str(g["qc_read_len"])]
+    if sam:
+        cmd.append("--sam_out")
+    if devices:
+        cmd += ["--devices", devices]
+    run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+    assert run.returncode == 0, run.stderr.decode(errors="replace")[-3000:]
+    return run, out
+
+
+def check_eight_workers(exe, g, tmp, devices):
+    one, out1 = run_list8(exe, g, tmp, "one8")
+    many, outn = run_list8(exe, g, tmp, "many8", devices=devices)
+    assert many.stderr.count(b"takes line") == 8, "every line of the list must have been dealt to a worker"
+    assert len({ln.split(b" takes")[0] for ln in many.stderr.split(b"\n") if b"takes line" in ln}) >= 1
+    assert many.stdout == one.stdout and len(one.stdout) > 1000
+    for f in QC_FILES:
+        assert qc_bytes(outn + "." + f).replace(outn.encode(), b"OUT") == qc_bytes(out1 + "." + f).replace(out1.encode(), b"OUT"), f
+    left = [x for x in os.listdir(str(tmp)) if ".part" in x and ".fq.gz" not in x or ".worker" in x]
+    assert not left, "part files and worker files must be gone: %s" % left
+    one, out1 = run_list8(exe, g, tmp, "one8_bam", sam=False)
+    many, outn = run_list8(exe, g, tmp, "many8_bam", devices=devices, sam=False)
+    assert open(outn + ".bam", "rb").read() == open(out1 + ".bam", "rb").read()
+
+
+def test_eight_line_fq_list_over_eight_workers_on_virtual_devices(golden_cases, tmp_path):
+    emu = os.path.join(HERE, "emu")
+    subprocess.check_call(["make", "-s", "-C", emu, "libfq_emu.so", "FASTQuick_emu"])
+    check_eight_workers(os.path.join(emu, "FASTQuick_emu"), golden_cases["qc"], tmp_path, "0,1,2,3,0,1,2,3")
+
+
+@pytest.mark.gpu
+def test_eight_line_fq_list_over_eight_workers_on_one_gpu(golden_cases, tmp_path):
+    """--devices 0,0,0,0,0,0,0,0 on an 8-line --fq_list == the one-device output (each worker its own index copy, contexts,
+    front end with its readers, consumers)"""
+    check_eight_workers(os.path.join(ROOT, "fastquick_amd", "bin", "FASTQuick_amd"), golden_cases["qc"], tmp_path, "0,0,0,0,0,0,0,0")
+
+
 def _hip_devices():
     import torch
     return torch.cuda.device_count()

@@ -372,3 +372,46 @@ def zero_state_case(steps_before_zero, g, lib, tmp_path, device=None):
     diffs = [d for d in ob.diff_stage_files(str(tmp_path / "o.stages"), st)]
     assert not diffs, "\n".join(diffs)
     assert filecmp.cmp(str(tmp_path / "o.sam"), sam, shallow=False)
+
+
+def test_streams_run_inside_the_library_equal_the_calls_made_one_by_one(golden_cases, emu_lib):
+    """fq_stream_run: three streams (three contexts) walking their reference batches inside the library -- the records of every call, read in
+    the per-call callback, are those of fq_align_packed called by hand in the same order (the stream state: last_ii chain, drand48, (k,l) cache)"""
+    per_stream, want = [], []
+    ix = None
+    for tag in ("basic", "qc", "isize"):
+        g = golden_cases[tag]
+        names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
+        if ix is None or ix.prefix != g["prefix"]:
+            ix = api.Index(g["prefix"], lib=emu_lib)
+        B, n = g["batch"], seq.shape[1]
+        packs = [api.HostPacked(seq[:, a:a + B], qual[:, a:a + B], lens[:, a:a + B], names[a:a + B], lib=emu_lib) for a in range(0, n, B)][:3]
+        al = api.Aligner(ix, api.default_opts(emu_lib, trim_qual=g["trim_qual"]), max_pairs=max(16, B))
+        sams = []
+        for p in packs:
+            al.align_packed(p)
+            sams.append(al.sam_text())
+        al.close()
+        want.append(sams)
+        per_stream.append((ix, g, packs))
+    aligners = [api.Aligner(ix_, api.default_opts(emu_lib, trim_qual=g_["trim_qual"]), max_pairs=max(16, g_["batch"])) for ix_, g_, _ in per_stream]
+    got = [[None] * len(p) for _, _, p in per_stream]
+
+    def on_call(stream, call):
+        if call < len(got[stream]):
+            got[stream][call] = aligners[stream].sam_text()
+    n_calls = min(len(p) for _, _, p in per_stream)
+    surv = api.stream_run(aligners, [p for _, _, p in per_stream], n_calls, on_call=on_call)
+    for s in range(3):
+        assert got[s][:n_calls] == want[s][:n_calls], "stream %d" % s
+        assert surv[s] > 0
+    # a stream that fails (a batch larger than the context takes) reports its code and leaves the others' results standing
+    small = api.Aligner(per_stream[0][0], api.default_opts(emu_lib), max_pairs=16)
+    with pytest.raises(api.FastquickError):
+        api.stream_run([small], [per_stream[0][2]], 1)
+    small.close()
+    for al in aligners:
+        al.close()
+    for _, _, packs in per_stream:
+        for p in packs:
+            p.free()
