@@ -570,6 +570,34 @@ def main() -> None:
         fe["host_reader_pairs_per_s"] = round(nfe / dt, 1)        # (round 4's tokenise_inflate_pairs_per_s: the front end on the host's threads)
         fe["host_reader"] = {"threads_per_file": rt, "s": round(dt, 3), "text_GBps": round(text_bytes / dt / 1e9, 3),
                              "inflate": "zlib" if os.environ.get("FASTQUICK_ZLIB_INFLATE", "0") not in ("", "0") else "fq_inflate.h (zlib for members it refuses)"}
+        # ---- a single-member gzip file (`gzip -6`: what is not bgzip'ed): the stream decoder on the reader's producer thread (fq_fastq.cpp,
+        #      fill_gz_stream) against zlib's gzread (FASTQUICK_ZLIB_INFLATE=1), 8 threads
+        try:
+            n_gz = min(nfe, 400000)
+            gz_path, txt_path = os.path.join(fdir, "single_member.fq.gz"), os.path.join(fdir, "single_member.fq")
+            gz_text = synth.write_fastq_uniform(cpu_batch.seq[0, :n_gz], qual_fe[0, :n_gz], L, txt_path, bgzf=False)
+            subprocess.check_call("gzip -6 -c %s > %s" % (txt_path, gz_path), shell=True)
+            os.remove(txt_path)
+            gz_res = {"reads": n_gz, "threads": 8, "container": "one gzip member, level 6", "text_bytes": gz_text, "file_bytes": os.path.getsize(gz_path)}
+            for mode in ("stream_decoder", "gzread"):
+                if mode == "gzread":
+                    os.environ["FASTQUICK_ZLIB_INFLATE"] = "1"
+                try:
+                    best = 1e9
+                    for _ in range(3):
+                        f_ = api.FastqFile(gz_path, threads=8, stride=stride, name_stride=64)
+                        t0 = time.perf_counter()
+                        got_ = f_.read_into(*rows[0])
+                        best = min(best, time.perf_counter() - t0)
+                        f_.close()
+                        assert got_ == n_gz, got_
+                finally:
+                    os.environ.pop("FASTQUICK_ZLIB_INFLATE", None)
+                gz_res[mode] = {"reads_per_s": round(n_gz / best, 1), "text_MBps": round(gz_text / best / 1e6, 1)}
+            os.remove(gz_path)
+            fe["gzip_single_member"] = gz_res
+        except Exception as e:      # noqa: BLE001
+            fe["gzip_single_member"] = {"error": repr(e)[:300]}
         del rows
         exe = os.path.join(ROOT, "fastquick_amd", "bin", "FASTQuick_amd")
         if os.path.exists(exe):

@@ -5,8 +5,10 @@
 // Here:
 //   * the inflated text arrives in blocks from a producer thread.  BGZF files (bgzip: gzip members with a 'BC' extra field that
 //     states each member's size) are inflated member-parallel straight into place -- the sizes give every member its output offset
-//     before a byte is inflated; any other gzip stream (one member or many) and plain text go through zlib's gzread on that thread,
-//     which overlaps with the tokenising of the previous block;
+//     before a byte is inflated; any other gzip file (one member of any size, or many: what `gzip` and sequencers write) is decoded as a
+//     stream by the same decoder on that thread, block after block with the window carried along (fill_gz_stream: twice gzread's speed,
+//     and gzread's verdict on anything the decoder does not take); plain text and pipes go through zlib's gzread.  Either way the
+//     inflating overlaps with the tokenising of the previous block;
 //   * a block is cut into lines by all threads (memchr), and records are emitted by all threads under the assumption that the
 //     file is what sequencers write -- four lines per record.  Every record is checked against exactly the conditions under which
 //     kseq_read3_fpc would return the same tokens ('@' first, name up to the first white space, a base line of printable characters
@@ -23,6 +25,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <cerrno>
+#include <cstdlib>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -69,6 +73,23 @@ struct fq_fastq {
   std::vector<uint8_t> cbuf;          // BGZF: compressed bytes not yet inflated
   size_t cpos = 0, cend = 0;
   bool file_eof = false;
+  // ---- a gzip file that is not BGZF (one member of any size, or several): the stream decoded by fq_inflate.h's decoder on the producer thread,
+  //      twice zlib's speed, into the blocks as they fill (fill_gz_stream); anything it does not take -- a damaged or truncated stream, a wrong
+  //      check sum, bytes behind the last member -- is gzread's: the file is opened again, the text handed out so far skipped, and what gzread
+  //      makes of the rest (text, end, error message) is the reader's
+  struct GzStream {
+    bool on = false;
+    std::vector<uint8_t> in;            // compressed bytes [pos, end)
+    size_t pos = 0, end = 0;
+    bool eof = false;                   // the file has been read to its end
+    fqz::Inflater Z;
+    fqz::Dec d;
+    bool in_member = false, in_block = false;
+    uint32_t crc = 0;
+    uint64_t member_out = 0;            // text of the current member so far (ISIZE is its low 32 bits)
+    std::vector<uint8_t> win;           // the last 32 KiB of text of the current member (what a block's first matches may reach back into)
+    uint64_t emitted = 0;               // text handed out in earlier blocks
+  } gs;
   // ---- producer thread ----
   std::thread producer;
   std::mutex mu;
@@ -247,6 +268,126 @@ bool fill_gz(fq_fastq *r, Block &b) {
   }
   return true;
 }
+// ---- source: a gzip stream through the fast decoder, block by block ------------------------------------------------------------------
+// (the window a match reaches back into lies in front of the block's text, where the tokeniser later puts its carry: the same bytes)
+bool gz_fallback(fq_fastq *r, Block &b, size_t n_valid) {       // gzread takes over behind the text handed out so far + n_valid bytes of this block
+  fq_fastq::GzStream &G = r->gs;
+  G.on = false;
+  b.n = n_valid;
+  std::vector<uint8_t>().swap(G.in);
+  r->gz = gzopen(r->path.c_str(), "rb");
+  if (!r->gz) { r->src_err = "cannot reopen " + r->path; return false; }
+  gzbuffer(r->gz, 1 << 20);
+  uint64_t skip = G.emitted + n_valid;
+  std::vector<uint8_t> scratch((size_t)4 << 20);
+  while (skip > 0) {
+    const int got = gzread(r->gz, scratch.data(), (unsigned)std::min<uint64_t>(skip, scratch.size()));
+    if (got < 0) { int en = 0; r->src_err = std::string("gzread: ") + gzerror(r->gz, &en); return false; }
+    if (got == 0) { b.last = true; break; }          // (gzread sees the end where the decoder saw text: it is right)
+    skip -= (uint64_t)got;
+  }
+  if (b.n == 0 && !b.last) return fill_gz(r, b);     // (a block must not be handed over empty unless it is the last)
+  return true;
+}
+bool fill_gz_stream(fq_fastq *r, Block &b) {
+  fq_fastq::GzStream &G = r->gs;
+  fqz::Dec &d = G.d;
+  uint8_t *const text = b.data.get() + b.head;
+  b.n = 0;
+  if (!G.win.empty()) memcpy(text - G.win.size(), G.win.data(), G.win.size());
+  d.dst = text - G.win.size(); d.out = text; d.out_end = b.data.get() + b.cap;
+  const uint8_t *crc_from = text;
+  auto more_input = [&]() -> bool {                  // the unread bytes to the front, the buffer filled from the file; false: nothing more came
+    if (G.eof) return false;
+    const size_t used = (size_t)(d.in - G.in.data()), left = G.end - used;
+    memmove(G.in.data(), G.in.data() + used, left);
+    G.end = left;
+    bool any = false;
+    while (G.end < G.in.size()) {
+      const ssize_t got = read(r->fd, G.in.data() + G.end, G.in.size() - G.end);
+      if (got < 0) { if (errno == EINTR) continue; break; }
+      if (got == 0) { G.eof = true; break; }
+      G.end += (size_t)got; any = true;
+    }
+    d.in = G.in.data(); d.in_end = G.in.data() + G.end;
+    return any;
+  };
+  auto have = [&](size_t n) -> bool {                // n unread bytes in the buffer (or everything that is left of the file)
+    while ((size_t)(d.in_end - d.in) < n) if (!more_input()) break;
+    return (size_t)(d.in_end - d.in) >= n;
+  };
+  auto fold_crc = [&] { G.crc = fqz::crc32(crc_from, (size_t)(d.out - crc_from), G.crc); G.member_out += (uint64_t)(d.out - crc_from); crc_from = d.out; };
+  for (;;) {
+    if (!G.in_member) {
+      // ---- a member's header (RFC 1952), or the end of the file
+      if (!have(18) && d.in_end == d.in) { b.last = true; break; }
+      const uint8_t *h = d.in;
+      const size_t avail = (size_t)(d.in_end - d.in);
+      if (avail < 18 || h[0] != 0x1f || h[1] != 0x8b || h[2] != 8 || (h[3] & 0xe0)) return gz_fallback(r, b, (size_t)(d.out - text));
+      (void)have((size_t)1 << 17);                    // (every field of a header a file is likely to have)
+      h = d.in;
+      const size_t av = (size_t)(d.in_end - d.in);
+      size_t p = 10;
+      bool ok = true;
+      if (h[3] & 4) { if (p + 2 > av) ok = false; else { const size_t xl = h[p] | (size_t)h[p + 1] << 8; p += 2 + xl; } }
+      for (int fl : {8, 16}) if (ok && (h[3] & fl)) { while (p < av && h[p]) ++p; ++p; }
+      if (ok && (h[3] & 2)) p += 2;
+      if (!ok || p + 8 > av) return gz_fallback(r, b, (size_t)(d.out - text));
+      d.in += p;
+      d.bb = 0; d.bc = 0; d.over = 0; d.last = false; d.LT = d.DT = nullptr;
+      d.dst = d.out;                                  // (a member's matches do not reach in front of it)
+      G.win.clear();
+      G.in_member = true; G.in_block = false; G.crc = 0; G.member_out = 0;
+      crc_from = d.out;
+    }
+    if (!G.in_block) {
+      // ---- the next block's header: a stored block copies up to 64 KiB, a dynamic block's code lengths are under 1 KiB
+      if ((size_t)(d.out_end - d.out) < ((size_t)1 << 16) + 512) break;       // the block is full
+      (void)have(((size_t)1 << 16) + 4096);
+      const int nb = fqz::dec_next_block(d, true);
+      if (nb < 0 || d.over > ((size_t)d.bc >> 3)) return gz_fallback(r, b, (size_t)(d.out - text));      // (a stored block that was refused copied nothing)
+      if (nb == 2) continue;                          // a stored block has been copied
+      if (nb == 1) {
+        // ---- the member's trailer: CRC-32 and size of its text, at the next byte boundary
+        fold_crc();
+        const size_t back = (size_t)d.bc >> 3;
+        if (d.over > back) return gz_fallback(r, b, (size_t)(d.out - text));
+        d.in -= back - d.over; d.over = 0; d.bb = 0; d.bc = 0;
+        if (!have(8)) return gz_fallback(r, b, (size_t)(d.out - text));
+        const uint32_t crc = d.in[0] | (uint32_t)d.in[1] << 8 | (uint32_t)d.in[2] << 16 | (uint32_t)d.in[3] << 24;
+        const uint32_t isz = d.in[4] | (uint32_t)d.in[5] << 8 | (uint32_t)d.in[6] << 16 | (uint32_t)d.in[7] << 24;
+        if (crc != G.crc || isz != (uint32_t)G.member_out) return gz_fallback(r, b, (size_t)(d.out - text));
+        d.in += 8;
+        G.in_member = false;
+        continue;
+      }
+      G.in_block = true;
+    }
+    // ---- the block's symbols
+    const int fr = fqz::dec_fast_loop(d);
+    if (fr == 1) { G.in_block = false; continue; }
+    if (fr < 0) return gz_fallback(r, b, (size_t)(d.out - text));
+    if ((size_t)(d.out_end - d.out) < 258 + 72) break;                       // the block is full (the symbols go on in the next one)
+    if (more_input()) continue;
+    if ((size_t)(d.in_end - d.in) >= 16) continue;
+    // the file's last bytes: a symbol at a time, every bound checked; a stream that wants bytes behind the file's end is truncated
+    uint8_t *const out0 = d.out;
+    const int cr = fqz::dec_careful_turn(d);
+    if (cr < 0 || d.over > ((size_t)d.bc >> 3)) return gz_fallback(r, b, (size_t)(out0 - text));
+    if (cr == 1) G.in_block = false;
+  }
+  if (G.in_member) fold_crc();
+  b.n = (size_t)(d.out - text);
+  // what the next block's matches may reach back into
+  if (G.in_member) {
+    const size_t span = (size_t)(d.out - d.dst), w = std::min<size_t>(span, 32768);
+    std::vector<uint8_t> nw(d.out - w, d.out);
+    G.win.swap(nw);
+  } else G.win.clear();
+  G.emitted += b.n;
+  if (b.n == 0 && !b.last) { b.last = true; }        // (cannot happen: a block that is not the last holds text)
+  return true;
+}
 void producer_main(fq_fastq *r) {
   for (;;) {
     Block b;
@@ -256,9 +397,10 @@ void producer_main(fq_fastq *r) {
       if (r->stop) return;
       if (!r->spare.empty()) { b = std::move(r->spare.back()); r->spare.pop_back(); }
     }
-    if (b.cap < r->block_bytes + kHeadroom) { b.cap = r->block_bytes + kHeadroom; b.data.reset(new uint8_t[b.cap]); }
+    const size_t want_text = r->gs.on ? std::max<size_t>(r->block_bytes, (size_t)192 << 10) : r->block_bytes;   // (the stream decoder wants room for a stored block between two looks at the block's end)
+    if (b.cap < want_text + kHeadroom) { b.cap = want_text + kHeadroom; b.data.reset(new uint8_t[b.cap]); }
     b.head = kHeadroom; b.n = 0; b.last = false;
-    const bool ok = r->bgzf ? fill_bgzf(r, b) : fill_gz(r, b);
+    const bool ok = r->bgzf ? fill_bgzf(r, b) : r->gs.on ? fill_gz_stream(r, b) : fill_gz(r, b);
     if (!ok) { b.last = true; b.err = r->src_err; }
     const bool done = b.last;
     {
@@ -441,9 +583,15 @@ extern "C" int fq_fastq_open(const char *path, int threads, fq_fastq_t **out) {
     const ssize_t got = read(fd, h, sizeof h);
     hn = got > 0 ? (size_t)got : 0;
     if (looks_bgzf(h, hn)) { r->bgzf = true; r->fd = fd; lseek(fd, 0, SEEK_SET); }
+    else if (hn >= 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && !getenv("FASTQUICK_ZLIB_INFLATE")) {   // gzip, not BGZF: the stream decoder (FASTQUICK_ZLIB_INFLATE=1: gzread, to compare)
+      r->gs.on = true; r->fd = fd; lseek(fd, 0, SEEK_SET);
+      r->gs.in.resize((size_t)8 << 20);
+      r->gs.d.begin(r->gs.Z, r->gs.in.data(), 0, nullptr, 0);
+    }
     else close(fd);
   }
   if (r->bgzf) r->cbuf.resize((size_t)32 << 20);
+  else if (r->gs.on) {}
   else {
     r->gz = gzopen(path, "rb");
     if (!r->gz) return FQ_EIO;

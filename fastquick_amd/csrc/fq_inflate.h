@@ -264,7 +264,7 @@ inline void dec_refill(Dec &d) {
 }
 // Block headers up to the next Huffman block (stored blocks are copied here).  0: a Huffman block begins (LT / DT set); 1: the stream has
 // ended; -1: not a stream this decoder accepts.
-inline int dec_next_block(Dec &d) {
+inline int dec_next_block(Dec &d, bool one_stored = false) {   // one_stored: return 2 after ONE stored block (a caller that looks after the room on both sides between blocks)
   Inflater &Z = *d.Z;
   for (;;) {
     if (d.last) return 1;
@@ -283,6 +283,7 @@ inline int dec_next_block(Dec &d) {
       if ((len ^ nlen) != 0xffffu || (size_t)(d.in_end - d.in) < len || (size_t)(d.out_end - d.out) < len) return -1;
       memcpy(d.out, d.in, len);
       d.in += len; d.out += len;
+      if (one_stored) return 2;
       continue;
     }
     if (type == 1) {
