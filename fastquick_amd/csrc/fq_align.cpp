@@ -377,6 +377,7 @@ extern "C" int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t v) {
   else if (k == "gap_coop_waves") t->gap_coop_waves = (int)v;
   else if (k == "gap_refill_min") t->gap_refill_min = (int)v;
   else if (k == "filter_no_turns") t->filter_no_turns = (int)v;
+  else if (k == "prep_priority") t->prep_priority = (int)v;
   else if (k == "refine_lanes") t->refine_lanes = (int)v;
   else if (k == "gap_generic_opts") t->gap_generic_opts = (int)v;
   else if (k == "sw_serial_reverse") t->sw_serial_reverse = (int)v;

@@ -18,6 +18,7 @@ struct Tune {   // experiment / test knobs (fq_ctx_set_tuning); the defaults are
   int spin_sync = 0;        // 1: sync() spins (hipStreamSynchronize) instead of sleeping on a blocking event
   int gap_generic_opts = 0; // 1: never the kernels specialised for FASTQuick's own option block (FqOptsStock)
   int width_both_strands = 0; // 1: the width kernel with one thread per read walking both strands (round 3's); default: one thread per (read, strand), strands apart by XCD
+  int prep_priority = 0;     // 1: the packed filter kernel on a stream of the highest priority
   int sw_serial_reverse = 0; // 1: the mate-rescue kernel's reverse pass as the serial statement on one lane (the wavefront form is the default)
 };
 int runtime_configure(int hw_queues, int blocking_waits);   // fq_runtime_configure: before the process's first HIP call

@@ -28,6 +28,7 @@ struct State {
   hipStream_t main_stream = nullptr, aux_stream = nullptr;   // `stream` is the one backend calls go to: main_stream, or aux_stream between stream_aux(1) and stream_aux(0)
   hipEvent_t fork_ev = nullptr, join_ev = nullptr;
   hipEvent_t marks[4] = {nullptr, nullptr, nullptr, nullptr};   // stream_mark / stream_wait_mark
+  hipEvent_t prio_fork = nullptr;
   hipStream_t copy_stream = nullptr;              // one of the device's shared copy streams (not owned)
   hipEvent_t copy_done[2] = {nullptr, nullptr};
   hipEvent_t prep_done = nullptr;                 // completion of this context's most recent filter kernel (chained per device)
@@ -83,6 +84,7 @@ static std::mutex g_turn_mu[64];   // device_turn_begin / device_turn_end
 // the devices the library opens, says so with fq_runtime_configure() before its first HIP call (the command line and bench.py do);
 // the library says once when more contexts are created on a device than the queues in effect can keep apart.
 static int g_ctx_count[64];
+static hipStream_t g_prio_stream[64];   // the filter kernels' stream of the highest priority (tuning key prep_priority), one per device
 static bool g_queue_warned = false;
 static int g_rt_blocking_waits = 0;
 int runtime_configure(int hw_queues, int blocking_waits) {
@@ -143,6 +145,7 @@ void state_destroy(State *s) {
   if (s->fork_ev) (void)hipEventDestroy(s->fork_ev);
   if (s->join_ev) (void)hipEventDestroy(s->join_ev);
   for (hipEvent_t m : s->marks) if (m) (void)hipEventDestroy(m);
+  if (s->prio_fork) (void)hipEventDestroy(s->prio_fork);
   if (s->stream) (void)hipStreamSynchronize(s->stream);
   if (s->copy_stream) (void)hipStreamSynchronize(s->copy_stream);   // (shared: also waits for other contexts' copies enqueued so far)
   {
@@ -1209,15 +1212,37 @@ int launch_prep_packed(const FqPrepPackedArgs &a) {
   hipEvent_t e0, e1;
   kernel_events(FQ_K_PREP_KERNEL, &e0, &e1);
   const dim3 grid(nblk((uint64_t)a.n_reads, 256));
+  // The filter kernel is the call's one bandwidth-bound launch; beside other streams' search kernels (latency-bound, long, every CU's wave
+  // slots taken) its workgroups wait for slots.  prep_priority: it goes to a stream of the highest priority, whose workgroups the dispatcher
+  // places first; the call's stream waits for it.
+  hipStream_t st = g_stream;
+  if (g_cur->tune.prep_priority) {
+    // (ONE such stream per device, shared by its contexts -- their filter launches wait for each other anyway; a stream per context would be
+    //  sixteen more streams than there are hardware queues)
+    {
+      std::lock_guard<std::mutex> lk(g_dev_mu);
+      if (!g_prio_stream[g_cur->device]) {
+        int lo = 0, hi = 0;
+        FQ_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        FQ_HIP(hipStreamCreateWithPriority(&g_prio_stream[g_cur->device], hipStreamNonBlocking, hi));
+      }
+    }
+    if (!g_cur->prio_fork) FQ_HIP(hipEventCreateWithFlags(&g_cur->prio_fork, hipEventDisableTiming));
+    FQ_HIP(hipEventRecord(g_cur->prio_fork, g_stream));
+    FQ_HIP(hipStreamWaitEvent(g_prio_stream[g_cur->device], g_cur->prio_fork, 0));
+    st = g_prio_stream[g_cur->device];
+  }
   if (!g_cur->tune.filter_no_turns) {   // chained per device like launch_prep
     const int dev = g_cur->device;
     std::lock_guard<std::mutex> lk(g_dev_mu);
-    if (g_prep_last[dev] && g_prep_owner[dev] != g_cur) FQ_HIP(hipStreamWaitEvent(g_stream, g_prep_last[dev], 0));
-    hipExtLaunchKernelGGL(k_prep_packed, grid, dim3(256), 0, g_stream, e0, e1, 0, a);
-    FQ_HIP(hipEventRecord(g_cur->prep_done, g_stream));
+    if (g_prep_last[dev] && g_prep_owner[dev] != g_cur) FQ_HIP(hipStreamWaitEvent(st, g_prep_last[dev], 0));
+    hipExtLaunchKernelGGL(k_prep_packed, grid, dim3(256), 0, st, e0, e1, 0, a);
+    FQ_HIP(hipEventRecord(g_cur->prep_done, st));
     g_prep_last[dev] = g_cur->prep_done; g_prep_owner[dev] = g_cur;
+    if (st != g_stream) FQ_HIP(hipStreamWaitEvent(g_stream, g_cur->prep_done, 0));
   } else {
-    hipExtLaunchKernelGGL(k_prep_packed, grid, dim3(256), 0, g_stream, e0, e1, 0, a);
+    hipExtLaunchKernelGGL(k_prep_packed, grid, dim3(256), 0, st, e0, e1, 0, a);
+    if (st != g_stream) { FQ_HIP(hipEventRecord(g_cur->prep_done, st)); FQ_HIP(hipStreamWaitEvent(g_stream, g_cur->prep_done, 0)); }
   }
   FQ_HIP(hipGetLastError());
   return 0;

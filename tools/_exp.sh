@@ -1,2 +1,11 @@
-timeout 900 python -m pytest tests/test_cli_multidevice.py -x -q -m gpu 2>&1 | tail -3
-( time python bench.py --workdir /tmp/fq_bench > gpurun_out/bench_r5g.json 2> gpurun_out/bench_r5g.err ) 2>&1 | tail -4; tail -c 300 gpurun_out/bench_r5g.err
+Q="--no-resident --no-ontarget --no-cpu-baseline --no-front-end --ontarget-tput-ctxs 0 --no-host-budget --workdir /tmp/fq_bench"
+sum() { python3 -c "
+import sys, json
+for l in sys.stdin:
+    if l.startswith('{'):
+        d = json.loads(l); r = d['roofline']; print('$1', 'value %.3e' % d['value'], 'ms/step', d['ms_per_step'], 'prep avg ms', r['avg_launch_ms'], 'frac', r['frac'], 'stage', d['stage_ms_per_call'])
+"; }
+
+python bench.py --steps 8 --tune prep_priority=1 $Q 2>/dev/null | sum prio10k
+
+python bench.py --steps 6 --warmup 2 --markers 100000 --tune prep_priority=1 $Q 2>/dev/null | sum prio100k

@@ -29,4 +29,17 @@ for c in FETCH_SIZE WRITE_SIZE; do
   pmc ont $c --mix ontarget --pairs 1048576 --ctxs 1 --steps 2 --warmup 1 $Q
   pmc ont4m $c --mix ontarget --pairs 4194304 --ctxs 1 --steps 2 --warmup 1 $Q
 done
+# ---- the device front end: kernel durations of a 67 M-pair BGZF stream (rocprofv3 --kernel-trace --stats; kernels one after the other so that each
+#      duration is the kernel's own, then the product's overlapped order), the command line's time marks, the member decoder's SQ counters
+cd $R
+python bench.py --steps 2 --warmup 1 --no-resident --no-ontarget --no-cpu-baseline --front-end-copies 0 --ontarget-tput-ctxs 0 --no-host-budget --workdir /tmp/fq_bench > /dev/null 2>&1
+bash tools/cli_trace.sh /tmp/fq_bench 64 qc > $O/${TAG}_cli_trace.txt 2>&1
+F=/tmp/fq_bench/front_end
+cd /tmp && export TMPDIR=/tmp
+FASTQUICK_FE_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_fe_solo -o fe -- python3 $R/tools/frontend_stream.py $F/trace_1.fq.gz $F/trace_2.fq.gz --repeats 1 > $O/${TAG}_fe_solo.json 2> $O/${TAG}_fe_solo.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_fe_overlap -o fe -- python3 $R/tools/frontend_stream.py $F/trace_1.fq.gz $F/trace_2.fq.gz --repeats 1 > $O/${TAG}_fe_overlap.json 2> $O/${TAG}_fe_overlap.err
+find $O/${TAG}_fe_solo $O/${TAG}_fe_overlap -name '*kernel_trace.csv' -delete
+cd $R
+bash tools/frontend_pmc.sh $TAG 2000000 > /dev/null 2>&1
+python3 tools/frontend_bench.py --records 4000000 > $O/${TAG}_inflate_kernel.txt 2>&1
 cat $O/${TAG}_gpu_tests.txt $O/${TAG}_smoke.txt $O/${TAG}_default_bench.time | tail -8
