@@ -508,6 +508,14 @@ def test_gpu_single_end_consumers_match_reference(tag, golden_cases, lib):
 
 
 @pytest.mark.gpu
+def test_streams_run_inside_the_library_on_the_gpu(golden_cases, lib):
+    """fq_stream_run (what bench.py's timed region drives): three streams on three contexts of one device == the calls made one by one"""
+    from test_pipeline_emu import streams_case
+    streams_case(golden_cases, lib)
+
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("steps_before_zero", [1, 3, 100])
 def test_gpu_drand48_stream_through_its_state_zero(steps_before_zero, golden_cases, lib, tmp_path):
     """The once-in-2^48 arm of bwa_aln2seq_core ("taken unless the draw is exactly 0"), reached by importing a stream state that is a

@@ -375,6 +375,10 @@ def zero_state_case(steps_before_zero, g, lib, tmp_path, device=None):
 
 
 def test_streams_run_inside_the_library_equal_the_calls_made_one_by_one(golden_cases, emu_lib):
+    streams_case(golden_cases, emu_lib)
+
+
+def streams_case(golden_cases, emu_lib):
     """fq_stream_run: three streams (three contexts) walking their reference batches inside the library -- the records of every call, read in
     the per-call callback, are those of fq_align_packed called by hand in the same order (the stream state: last_ii chain, drand48, (k,l) cache)"""
     per_stream, want = [], []

@@ -1,11 +1,3 @@
-Q="--no-resident --no-ontarget --no-cpu-baseline --no-front-end --ontarget-tput-ctxs 0 --no-host-budget --workdir /tmp/fq_bench"
-sum() { python3 -c "
-import sys, json
-for l in sys.stdin:
-    if l.startswith('{'):
-        d = json.loads(l); r = d['roofline']; print('$1', 'value %.3e' % d['value'], 'ms/step', d['ms_per_step'], 'prep avg ms', r['avg_launch_ms'], 'frac', r['frac'], 'stage', d['stage_ms_per_call'])
-"; }
-
-python bench.py --steps 8 --tune prep_priority=1 $Q 2>/dev/null | sum prio10k
-
-python bench.py --steps 6 --warmup 2 --markers 100000 --tune prep_priority=1 $Q 2>/dev/null | sum prio100k
+timeout 600 python -m pytest tests/test_device_frontend.py -x -q -m gpu 2>&1 | tail -2
+timeout 300 python3 tools/frontend_bench.py --records 4000000
+timeout 300 python3 tools/frontend_bench.py --records 5200000 --levels 1
