@@ -99,7 +99,7 @@ class FrontEndStats(C.Structure):
 EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destroy", "fq_index_l_pac",
            "fq_index_n_contigs", "fq_index_contig", "fq_ctx_create", "fq_ctx_destroy", "fq_ctx_last_error",
            "fq_ctx_set_debug", "fq_align_batch", "fq_batch_upload", "fq_align_resident", "fq_sam_header",
-           "fq_sam_format_last", "fq_stage_dump_last", "fq_stats_get", "fq_stats_reset", "fq_version", "fq_host_cpus", "fq_runtime_configure", "fq_device_count",
+           "fq_sam_format_last", "fq_stage_dump_last", "fq_stats_get", "fq_stats_reset", "fq_version", "fq_host_cpus", "fq_runtime_configure", "fq_device_count", "fq_index_bitmap_fetch",
            "fq_pinned_alloc", "fq_pinned_free", "fq_pack_reads", "fq_packed_free", "fq_packed_create", "fq_pack_reads_into", "fq_pack_single_reads_into", "fq_packed_prefetch", "fq_packed_cancel", "fq_align_packed", "fq_stream_run",
            "fq_ctx_set_tuning", "fq_ctx_set_serial_hooks", "fq_ctx_mark_stream_broken", "fq_ctx_state_export", "fq_ctx_state_import", "fq_qc_default_opts", "fq_qc_create", "fq_qc_destroy", "fq_qc_last_error", "fq_qc_begin_file",
            "fq_qc_add_last", "fq_qc_end_file", "fq_qc_write", "fq_qc_state_reset", "fq_qc_state_export", "fq_qc_merge", "fq_bam_create", "fq_bam_add_last", "fq_bam_format_last", "fq_bam_write_records", "fq_bam_close",
@@ -128,6 +128,7 @@ def load_library(path: str | None = None):
     L.fq_index_build.argtypes = [C.c_char_p, C.c_int]
     L.fq_index_load.argtypes = [C.c_char_p, C.c_int, C.POINTER(C.c_void_p)]
     L.fq_index_destroy.argtypes = [C.c_void_p]
+    L.fq_index_bitmap_fetch.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     L.fq_index_l_pac.restype = C.c_int64
     L.fq_index_l_pac.argtypes = [C.c_void_p]
     L.fq_index_n_contigs.argtypes = [C.c_void_p]
@@ -249,6 +250,17 @@ class Index:
     @property
     def l_pac(self) -> int:
         return int(self.L.fq_index_l_pac(self.h))
+
+    def bitmap_bits(self, table: int) -> np.ndarray:
+        """(tests) the set bits of filter table `table`, ascending"""
+        buf = np.empty(1 << 29, dtype=np.uint8)
+        rc = self.L.fq_index_bitmap_fetch(self.h, table, buf.ctypes.data)
+        if rc:
+            raise FastquickError("fq_index_bitmap_fetch failed: %d" % rc)
+        nz = np.flatnonzero(buf)
+        bits = np.unpackbits(buf[nz].reshape(-1, 1), axis=1, bitorder="little")
+        r, c = np.nonzero(bits)
+        return (nz[r].astype(np.uint64) * 8 + c.astype(np.uint64)).astype(np.uint32)
 
     def sam_header(self) -> bytes:
         n = self.L.fq_sam_header(self.h, None, 0)

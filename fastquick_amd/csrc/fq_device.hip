@@ -970,6 +970,20 @@ int launch_bitmap_scatter(uint8_t *bitmap, const uint32_t *bits, uint64_t n) {
   return 0;
 }
 
+// ... and straight from the reference in HBM (fq_kernels.h: fq_bitmap_kmer_thread)
+__global__ void __launch_bounds__(256) k_bitmap_kmers(FqBitmapArgs a) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= 2 * a.l_pac) return;
+  fq_bitmap_kmer_thread(a, idx, [&](int t, uint32_t x) { atomicOr(&a.bitmap[t][x >> 5], 1u << (x & 31)); });
+}
+int launch_bitmap_kmers(const FqBitmapArgs &a) {
+  FQ_PRE();
+  if (a.l_pac <= 0 || a.n_rec <= 0) return 0;
+  hipLaunchKernelGGL(k_bitmap_kmers, dim3(nblk((uint64_t)(2 * a.l_pac), 256)), dim3(256), 0, g_stream, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+
 // ---- FASTQ front end (fq_frontend.h) ----------------------------------------------------------------------------------
 static FqzCrcConst *g_crc_const[64];
 const FqzCrcConst *crc_const() {

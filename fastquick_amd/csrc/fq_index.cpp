@@ -21,6 +21,7 @@
 
 namespace fqdev {
 int launch_bitmap_scatter(uint8_t *bitmap, const uint32_t *bits, uint64_t n);
+int launch_bitmap_kmers(const FqBitmapArgs &a);
 }
 
 namespace {
@@ -515,6 +516,40 @@ extern "C" int fq_index_load(const char *prefix_c, int device_ordinal, fq_index_
       }
       fclose(fp);
     } else {
+      // The reference is in HBM already (pac) and every record's alleles are in its name: the device enters the 32-mers itself -- unless a base
+      // or an allele is not one of ACGT (.amb lists the runs of other letters; the reference draws those from rand(), in record order: the host's walk)
+      bool on_device = ix->holes.empty() && !ix->contigs.empty() && !getenv("FASTQUICK_HOST_BITMAPS");
+      std::vector<int64_t> rec_off;
+      std::vector<uint8_t> alle;
+      if (on_device) {
+        for (const auto &c : ix->contigs) {
+          const size_t at = c.name.find('@');
+          const int a0 = at != std::string::npos && at + 3 < c.name.size() + 1 ? nt4(c.name[at + 1]) : 4, a1 = a0 < 4 ? nt4(c.name[at + 3]) : 4;
+          if (a0 > 3 || a1 > 3) { on_device = false; break; }
+          rec_off.push_back(c.offset);
+          alle.push_back((uint8_t)(a0 | a1 << 2));
+        }
+        rec_off.push_back(ix->l_pac);
+        for (size_t k = 0; on_device && k + 1 < rec_off.size(); ++k) if (rec_off[k + 1] - rec_off[k] != ix->contigs[k].len) on_device = false;   // (records back to back)
+      }
+      if (on_device) {
+        if (fqdev::dzero(ix->d_bitmap, 6 * TB)) return fail(FQ_ENODEV);
+        int64_t *d_off = (int64_t *)fqdev::dmalloc(rec_off.size() * 8);
+        uint8_t *d_al = (uint8_t *)fqdev::dmalloc(alle.size() + 8);
+        if (!d_off || !d_al) { fqdev::dfree(d_off); fqdev::dfree(d_al); return fail(FQ_ENOMEM); }
+        FqBitmapArgs ba{};
+        ba.pac = (const uint8_t *)ix->d_pac; ba.l_pac = ix->l_pac; ba.rec_off = d_off; ba.alleles = d_al; ba.n_rec = (int)alle.size();
+        for (int t = 0; t < 6; ++t) ba.bitmap[t] = (uint32_t *)((uint8_t *)ix->d_bitmap + (size_t)t * TB);
+        int e = fqdev::h2d(d_off, rec_off.data(), rec_off.size() * 8);
+        if (!e) e = fqdev::h2d(d_al, alle.data(), alle.size());
+        if (!e) e = fqdev::launch_bitmap_kmers(ba);
+        if (!e) e = fqdev::sync();
+        fqdev::dfree(d_off); fqdev::dfree(d_al);
+        if (e) return fail(FQ_ENODEV);
+        mark("bitmaps filled by the device from the reference in HBM");
+        *out = ix.release();
+        return FQ_OK;
+      }
       std::vector<FastaRec> recs;
       if (!read_reduced_fasta(P, recs)) return fail(FQ_EIO);
       bitmap_bits_from_fasta_threads(recs, parts);
@@ -540,6 +575,14 @@ extern "C" int fq_index_load(const char *prefix_c, int device_ordinal, fq_index_
   return FQ_OK;
 }
 
+// (tests) table t of the filter's six bitmaps as it stands in HBM: 2^29 bytes
+extern "C" int fq_index_bitmap_fetch(const fq_index_t *ix, int32_t t, uint8_t *out) {
+  if (!ix || !out || t < 0 || t > 5 || !ix->d_bitmap) return FQ_EINVAL;
+  struct DevScope { fqdev::State *s; ~DevScope() { fqdev::state_destroy(s); } } scope{fqdev::state_create(ix->device)};
+  if (!scope.s || fqdev::bind(scope.s)) return FQ_ENODEV;
+  if (fqdev::d2h(out, (const uint8_t *)ix->d_bitmap + ((size_t)t << 29), (size_t)1 << 29) || fqdev::sync()) return FQ_ENODEV;
+  return FQ_OK;
+}
 extern "C" void fq_index_destroy(fq_index_t *ix) {
   if (!ix) return;
   for (int j = 0; j < 2; ++j) { fqdev::dfree(ix->d_blk[j]); fqdev::dfree(ix->d_sa[j]); }

@@ -327,6 +327,48 @@ FQ_HD void fq_prep_thread(const FqPrepArgs &A, int r) {
   A.filtered[r] = filt;
 }
 
+// ---- the filter's bitmaps from the reduced reference in HBM (index load) ----------------------------------------------------------------
+// BwtIndexer::AddSeq2HashCore (src/BwtIndexer.cpp:96-160) over a flank record and over its reverse complement: every 32-mer of the string goes
+// into the six tables; the 32-mers that cover the string's middle position L / 2 are entered twice, with the marker's two alleles there (the
+// record's name carries them: CHR:POS@REF/ALT).  One thread per (strand, position of the reference): the 32-mer ENDING at its position.  The
+// host lists the bits the same way where a base or an allele is not one of ACGT (the reference draws those from rand(): fq_index.cpp).
+struct FqBitmapArgs {
+  const uint8_t *pac;        // 2-bit reference, 4 bases per byte, first base in the top bits (bntseq)
+  int64_t l_pac;
+  const int64_t *rec_off;    // [n_rec + 1] first base of every record; rec_off[n_rec] = l_pac
+  const uint8_t *alleles;    // [n_rec] allele codes: a0 | a1 << 2
+  int32_t n_rec;
+  uint32_t *bitmap[6];       // 2^32 bits each, as 32-bit words (bit x of a table = bit x & 31 of word x >> 5: bit x & 7 of byte x >> 3)
+};
+template <class SetBit>
+FQ_HD void fq_bitmap_kmer_thread(const FqBitmapArgs &A, int64_t idx, SetBit set_bit) {
+  const int strand = (int)(idx >= A.l_pac);
+  const int64_t q = strand ? idx - A.l_pac : idx;
+  int lo = 0, hi = A.n_rec;                                   // the record that holds base q
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (A.rec_off[mid] <= q) lo = mid; else hi = mid; }
+  const int64_t r0 = A.rec_off[lo];
+  const int64_t L = A.rec_off[lo + 1] - r0, i = q - r0;       // position i of the record's string (of its reverse complement for strand 1)
+  if (L < 64 || i < 31) return;
+  const int64_t half = L / 2;
+  uint64_t d = 0;
+  for (int j = 31; j >= 0; --j) {                              // bases i - 31 .. i of the string, the oldest in the top bits
+    const int64_t k = i - j;
+    const uint32_t c = strand ? 3u - (uint32_t)fq_pac_base(A.pac, r0 + (L - 1 - k)) : (uint32_t)fq_pac_base(A.pac, r0 + k);
+    d = (d << 2) | c;
+  }
+  const bool var = i >= half && i < half + 32;                // the window covers the middle position: once per allele
+  const int n_ver = var ? 2 : 1;
+  for (int v = 0; v < n_ver; ++v) {
+    uint64_t km = d;
+    if (var) {
+      const int sh = 2 * (int)(i - half);                      // the middle position's base sits (i - half) bases above the newest
+      const uint64_t a = (A.alleles[lo] >> (2 * v)) & 3u;
+      km = (km & ~((uint64_t)3 << sh)) | (a << sh);
+    }
+    for (int t = 0; t < 6; ++t) set_bit(t, fq_kmer_project(km, t));
+  }
+}
+
 // ---- K_prep, packed input: the k-mer filter over the three 32-mers of a read's first 96 bases --------------------------------
 // A packed batch (fq_packed_batch_t) carries, for every read, the three 64-bit k-mers exactly as IsReadInHashByCountMoreChunck
 // forms them (kmer = kmer << 2 | code over S[32i .. 32i+31], a non-ACGT code OR-ed in unmasked: src/BwtIndexer.cpp:441-456): that

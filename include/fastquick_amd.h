@@ -493,6 +493,9 @@ int fq_runtime_configure(int hw_queues, int blocking_waits);
 /* HIP devices the process sees (0: none, or no usable runtime): what a device ordinal of fq_index_load is checked against before
  * anything is started on it.  (No reference counterpart.) */
 int fq_device_count(void);
+/* (tests) table t (0..5) of the read filter's bitmaps as fq_index_load left it on the device: 2^29 bytes into out -- what BwtIndexer keeps in
+ * roll_hash_table[t] (src/BwtIndexer.cpp:96-160, 803-837), whether it came from .rollhash, from a list of bits or from the reference's 32-mers. */
+int fq_index_bitmap_fetch(const fq_index_t *ix, int32_t t, uint8_t *out);
 
 #ifdef __cplusplus
 }

@@ -186,6 +186,10 @@ int launch_slot_names(const FqSlotArgs &a) {
 int launch_text_gather(const FqTextGatherArgs &a) { const int64_t n = (int64_t)a.n_out * (a.stride >> 4); for (int64_t g = 0; g < n; ++g) fqt_gather_piece(a, g); return 0; }
 int launch_text_trim_all(const FqTextTrimArgs &a) { for (int r = 0; r < a.n_rows; ++r) fqt_trim_all_thread(a, r); return 0; }
 int dfill32(void *dst, uint32_t v, size_t n_words) { for (size_t i = 0; i < n_words; ++i) ((uint32_t *)dst)[i] = v; return 0; }
+int launch_bitmap_kmers(const FqBitmapArgs &a) {
+  for (int64_t idx = 0; idx < 2 * a.l_pac; ++idx) fq_bitmap_kmer_thread(a, idx, [&](int t, uint32_t x) { a.bitmap[t][x >> 5] |= 1u << (x & 31); });
+  return 0;
+}
 int launch_bitmap_scatter(uint8_t *bitmap, const uint32_t *bits, uint64_t n) {
   for (uint64_t i = 0; i < n; ++i) bitmap[bits[i] >> 3] |= (uint8_t)(1u << (bits[i] & 7));
   return 0;

@@ -140,7 +140,7 @@ def run_list8(exe, g, tmp, tag, devices=None, sam=True):
     return run, out
 
 
-def check_eight_workers(exe, g, tmp, devices):
+def check_eight_workers(exe, g, tmp, devices, bam=True):
     one, out1 = run_list8(exe, g, tmp, "one8")
     many, outn = run_list8(exe, g, tmp, "many8", devices=devices)
     assert many.stderr.count(b"takes line") == 8, "every line of the list must have been dealt to a worker"
@@ -150,15 +150,16 @@ def check_eight_workers(exe, g, tmp, devices):
         assert qc_bytes(outn + "." + f).replace(outn.encode(), b"OUT") == qc_bytes(out1 + "." + f).replace(out1.encode(), b"OUT"), f
     left = [x for x in os.listdir(str(tmp)) if ".part" in x and ".fq.gz" not in x or ".worker" in x]
     assert not left, "part files and worker files must be gone: %s" % left
-    one, out1 = run_list8(exe, g, tmp, "one8_bam", sam=False)
-    many, outn = run_list8(exe, g, tmp, "many8_bam", devices=devices, sam=False)
-    assert open(outn + ".bam", "rb").read() == open(out1 + ".bam", "rb").read()
+    if bam:
+        one, out1 = run_list8(exe, g, tmp, "one8_bam", sam=False)
+        many, outn = run_list8(exe, g, tmp, "many8_bam", devices=devices, sam=False)
+        assert open(outn + ".bam", "rb").read() == open(out1 + ".bam", "rb").read()
 
 
 def test_eight_line_fq_list_over_eight_workers_on_virtual_devices(golden_cases, tmp_path):
     emu = os.path.join(HERE, "emu")
     subprocess.check_call(["make", "-s", "-C", emu, "libfq_emu.so", "FASTQuick_emu"])
-    check_eight_workers(os.path.join(emu, "FASTQuick_emu"), golden_cases["qc"], tmp_path, "0,1,2,3,0,1,2,3")
+    check_eight_workers(os.path.join(emu, "FASTQuick_emu"), golden_cases["qc"], tmp_path, "0,1,2,3,0,1,2,3", bam=False)   # (BAM as well: the GPU tier)
 
 
 @pytest.mark.gpu

