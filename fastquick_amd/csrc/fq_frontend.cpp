@@ -474,8 +474,9 @@ void producer_main(fq_frontend *fe) {
       const auto t0 = std::chrono::steady_clock::now();
       std::unique_lock<std::mutex> lk(F.mu);
       if (!block && !F.filled[comp_next]) return 0;
-      F.cv.wait(lk, [&] { return F.filled[comp_next]; });
+      F.cv.wait(lk, [&] { return F.stop || F.filled[comp_next]; });
       fe->ms_wait_reader += ms_since(t0);
+      if (!F.filled[comp_next]) return -1;                   // (the front end is being closed in the middle of the stream)
       Cs[e] = &F.chunk[comp_next];
     }
     int slot;

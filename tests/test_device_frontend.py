@@ -339,3 +339,17 @@ def test_a_million_pair_bgzf_file_through_the_front_end(tmp_path):
     st = fe.stats()
     fe.close()
     assert m == 0 and at == n and st["refused"] == 0 and st["members"] > 9000
+
+
+@pytest.mark.timeout(120)
+def test_closing_in_the_middle_of_a_stream_does_not_hang(golden_cases, lib, tmp_path):
+    """a front end closed after its first batch -- and one closed before any batch was taken -- while its reader and producer threads are at
+    work or waiting for each other: fq_frontend_close stops and joins them"""
+    g = golden_cases["qc"]
+    fq = bgzf_pair(g, tmp_path, level=1, member=2000)
+    for take in (1, 0):
+        fe = api.DeviceFrontEnd(fq[0], fq[1], batch_pairs=64, chunk_pairs=64, slot_mode=0, max_read_len=256, lib=lib)
+        for _ in range(take):
+            n, b = fe.next()
+            assert n == 64
+        fe.close()
