@@ -702,7 +702,7 @@ struct Call {
   struct B1Plan { uint64_t *start = nullptr; size_t n_chunks = 0; uint64_t rng_end = 0; } plan;
   std::thread plan_thread;             // the plan is drawn up beside the SA stage when nothing else can move the stream's state
   ~Call() { if (plan_thread.joinable()) plan_thread.join(); }
-  double t_trace = 0, t_wall0 = 0, t_host0 = 0, t_serial1 = 0, t_host1 = 0, cpu_trace = 0;
+  double t_trace = 0, t_wall0 = 0, t_host0 = 0, t_serial1 = 0, t_host1 = 0, cpu_trace = 0, tcpu_trace = 0;
   double w_call0 = 0, w_host0 = 0, w_serial1 = 0, w_host1 = 0, cpu_call0 = 0;   // the context's wait_ms at those marks; the calling thread's CPU time at the start
   int sidx(size_t idx) const { return c->h_surv[idx].sidx; }
   const FqAln *aln_of(size_t idx, int *n_out) const {
@@ -717,8 +717,10 @@ struct Call {
     timespec ts;
     clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ts);
     const double cpu = 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
-    fprintf(stderr, "[fq] %-22s %8.3f ms   cpu %8.1f core-ms\n", label, t - t_trace, cpu - cpu_trace);
-    t_trace = t; cpu_trace = cpu;
+    clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
+    const double tcpu = 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
+    fprintf(stderr, "[fq] %-22s %8.3f ms   cpu %8.1f core-ms   this thread %6.3f ms\n", label, t - t_trace, cpu - cpu_trace, tcpu - tcpu_trace);
+    t_trace = t; cpu_trace = cpu; tcpu_trace = tcpu;
   }
 };
 
