@@ -129,3 +129,56 @@ def test_cli_bgzf_input_over_several_chunks_prints_the_references_sam(golden_cas
         host = subprocess.run(ref, stdout=subprocess.PIPE, stderr=subprocess.PIPE)      # the host reader on the plain files, other chunking: the same stream
         assert host.returncode == 0 and b"front end on the device" not in host.stderr
         assert run.stdout == host.stdout, tag
+
+
+import pytest  # noqa: E402
+
+
+@pytest.mark.gpu
+def test_cli_device_front_end_equals_the_host_reader_on_four_million_pairs(tmp_path):
+    """The command line at the size it is measured at: 4,194,304 + 262,144 + 1,000 pairs of a WGS-like mix in two BGZF files -- several chunks of
+    sixteen reference batches through the front end on the device, two alignment contexts in turn (the stream's state exported / imported
+    between them), the consumers of one call on their own threads beside the next call -- must print the SAM text and write the QC files of
+    the run that reads with the host's reader and packer (`--host_reader`: the path every parity test of round 4 went through)."""
+    import hashlib
+    import numpy as np
+    from fastquick_amd import api, synth
+    ref = synth.make_reference(n_markers=2000, n_long=200, seed=811)
+    pre = str(tmp_path / "ref.FASTQuick.fa")
+    ref.write_fasta(pre)
+    api.build_index(pre)
+    synth.write_qc_inputs(pre, ref)
+    synth.write_param(pre, ref, 1000)
+    with open(pre + ".genome.fa.fai", "w") as fh:
+        fh.write("1\t%d\t3\t60\t61\n" % len(ref.genome))
+    n1 = 1 << 20
+    rb = synth.make_reads(ref, n1, on_target=0.01, seed=812, sub_rate=0.006, del_frac=0.02, ins_frac=0.02, n_rate=0.001, chimera_frac=0.01)
+    fq = []
+    for e in range(2):
+        one = str(tmp_path / ("one_%d.fq.gz" % (e + 1)))
+        synth.write_fastq_uniform(rb.seq[e], rb.qual[e], 150, one, threads=8)
+        blob = open(one, "rb").read()
+        eof = b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00\x1b\x00\x03\x00\x00\x00\x00\x00\x00\x00\x00\x00"
+        body = blob[:-28] if blob.endswith(eof) else blob
+        tail = str(tmp_path / ("tail_%d.fq.gz" % (e + 1)))
+        synth.write_fastq_uniform(rb.seq[e][:263144], rb.qual[e][:263144], 150, tail, name_prefix=b"t", threads=8)
+        path = str(tmp_path / ("big_%d.fq.gz" % (e + 1)))
+        with open(path, "wb") as fo:
+            for _ in range(4):
+                fo.write(body)
+            fo.write(open(tail, "rb").read())
+        os.remove(one); os.remove(tail)
+        fq.append(path)
+    exe = os.path.join(os.path.dirname(HERE), "fastquick_amd", "bin", "FASTQuick_amd")
+    outs = {}
+    for mode, extra in (("device", []), ("host", ["--host_reader"])):
+        out = str(tmp_path / mode)
+        cmd = [exe, "align", "--index_prefix", pre[:-len(".FASTQuick.fa")], "--fastq_1", fq[0], "--fastq_2", fq[1], "--out_prefix", out, "--sam_out", "--read_len", "151"] + extra
+        run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE)
+        assert run.returncode == 0, run.stderr.decode(errors="replace")[-2000:]
+        if mode == "device":
+            assert b"front end on the device: 4457448 pairs" in run.stderr, run.stderr.decode(errors="replace")[-1500:]
+        outs[mode] = (hashlib.sha256(run.stdout).hexdigest(), len(run.stdout), {f: qc_bytes(out + "." + f).replace(out.encode(), b"OUT") for f in QC_FILES})
+    assert outs["device"][1] == outs["host"][1] > 10e6 and outs["device"][0] == outs["host"][0], "SAM text"
+    for f in QC_FILES:
+        assert outs["device"][2][f] == outs["host"][2][f], f
