@@ -1029,7 +1029,15 @@ FQ_HD void fqt_slot_bases_thread(const FqSlotArgs &A, int slot) {
       }
     }
     const uint32_t m = n < 96 ? n : 96;
-    for (uint32_t p = 0; p < m; ++p) h[p] = s[p];
+    uint32_t p = 0;                                          // the read's first 96 bases over the slot's, by words (h is aligned, the read is not)
+    for (; p + 4 <= m; p += 4) { const uint32_t w = fqt_load32(s + p); __builtin_memcpy(h + p, &w, 4); }
+    if (p < m) {
+      uint32_t old_w;
+      __builtin_memcpy(&old_w, h + p, 4);
+      const uint32_t mask = (1u << (8 * (m - p))) - 1u;
+      const uint32_t w = (old_w & ~mask) | (fqt_load32(s + p) & mask);
+      __builtin_memcpy(h + p, &w, 4);
+    }
   }
   A.slot_len[slot] = (uint16_t)(longest > 65535 ? 65535 : longest);
 }
@@ -1076,12 +1084,35 @@ FQ_HD void fqt_slot_names_thread(const FqSlotArgs &A, int slot) {
       if (keep > (uint32_t)A.name_stride - 1) keep = (uint32_t)A.name_stride - 1;
       for (uint32_t p = 0; p < keep; ++p) o[p] = (char)nm[p];
     } else {
-      for (uint32_t p = 0; p < l; ++p) b[p] = nm[p];
-      if (mate_suffix) b[l - 2] = 0;
-      uint32_t pl = 0;
-      while (pl < 303 && b[pl]) ++pl;
+      // the name over the slot's buffer (strncpy without terminator), the printed name = the buffer as a C string: by 4-byte words -- the buffer
+      // and the output row are aligned, the name is read at any alignment (byte by byte this loop was 5 ms per million pairs of Illumina-style names)
+      uint32_t p = 0, pl = 0xffffffffu;                       // pl: the first zero byte of the buffer
+      for (; p + 4 <= l; p += 4) {
+        const uint32_t w = fqt_load32(nm + p);
+        __builtin_memcpy(b + p, &w, 4);
+        if (pl == 0xffffffffu && ((w - 0x01010101u) & ~w & 0x80808080u)) for (uint32_t j = 0; j < 4; ++j) if (((w >> (8 * j)) & 0xff) == 0) { pl = p + j; break; }
+      }
+      if (p < l) {
+        uint32_t old_w;
+        __builtin_memcpy(&old_w, b + p, 4);
+        const uint32_t mask = (1u << (8 * (l - p))) - 1u;
+        const uint32_t w = (old_w & ~mask) | (fqt_load32(nm + p) & mask);    // (reads up to three bytes behind the name: the rest of its line is there)
+        __builtin_memcpy(b + p, &w, 4);
+      }
+      if (mate_suffix) { b[l - 2] = 0; if (pl > l - 2) pl = l - 2; }
+      for (uint32_t q = l & ~3u; pl == 0xffffffffu && q < 304; q += 4) {     // the buffer behind the name (and the name's last, partial word)
+        uint32_t w;
+        __builtin_memcpy(&w, b + q, 4);
+        if ((w - 0x01010101u) & ~w & 0x80808080u) for (uint32_t j = 0; j < 4; ++j) if (((w >> (8 * j)) & 0xff) == 0 && q + j >= (l & ~3u)) { pl = q + j; break; }
+      }
+      if (pl > 303) pl = 303;
       keep = pl < (uint32_t)A.name_stride - 1 ? pl : (uint32_t)A.name_stride - 1;
-      for (uint32_t p = 0; p < keep; ++p) o[p] = (char)b[p];
+      for (uint32_t q = 0; q < (uint32_t)A.name_stride; q += 4) {            // (name_stride is a multiple of 16: whole words, zero behind the name)
+        uint32_t w = 0;
+        if (q < keep) { __builtin_memcpy(&w, b + q, 4); if (q + 4 > keep) w &= (1u << (8 * (keep - q))) - 1u; }
+        __builtin_memcpy(o + q, &w, 4);
+      }
+      continue;
     }
     for (uint32_t p = keep; p < (uint32_t)A.name_stride; ++p) o[p] = 0;
   }
