@@ -22,15 +22,21 @@ def main():
     ap.add_argument("--levels", default="1,6")
     ap.add_argument("--repeats", type=int, default=5)
     ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--names", choices=("plain", "illumina"), default="plain", help="illumina: names with varying coordinates and a comment (the matches of such text reach further back)")
     a = ap.parse_args()
     rng = np.random.default_rng(99)
     n, L = a.records, a.read_len
     seq = np.frombuffer(b"ACGT", dtype=np.uint8)[rng.integers(0, 4, (n, L), dtype=np.uint8)]
     qual = np.frombuffer(b"F:,#", dtype=np.uint8)[rng.choice(4, size=(n, L), p=[0.7, 0.15, 0.1, 0.05])]
-    path = "/tmp/frontend_bench.fq"
-    nbytes = synth.write_fastq_uniform(seq, qual, L, path, bgzf=False)
-    text = open(path, "rb").read()
-    os.remove(path)
+    if a.names == "illumina":
+        xs, ys = rng.integers(1000, 40000, n), rng.integers(1000, 200000, n)
+        text = b"".join(b"@A00123:45:HXXXXXXXX:1:%d:%d:%d 1:N:0:ACGTACGT\n" % (1101 + i % 1000, xs[i], ys[i]) + seq[i].tobytes() + b"\n+\n" + qual[i].tobytes() + b"\n" for i in range(n))
+        nbytes = len(text)
+    else:
+        path = "/tmp/frontend_bench.fq"
+        nbytes = synth.write_fastq_uniform(seq, qual, L, path, bgzf=False)
+        text = open(path, "rb").read()
+        os.remove(path)
     for level in [int(x) for x in a.levels.split(",")]:
         t0 = time.perf_counter()
         blob = synth.bgzf_compress(text, threads=16, level=level)
