@@ -2196,6 +2196,9 @@ extern "C" int fq_stream_run(fq_ctx_t *const *ctxs, int32_t n_streams, const fq_
   for (int s = 0; s < n_streams; ++s) for (int t = 0; t < s; ++t) if (ctxs[s] == ctxs[t]) return FQ_EINVAL;      // (a context is one stream's)
   std::vector<int> rcs((size_t)n_streams, FQ_OK);
   std::vector<int64_t> surv((size_t)n_streams, 0);
+  static const bool trace_cpu = [] { const char *e = getenv("FASTQUICK_TRACE"); return e && *e && *e != '0'; }();     // the stream threads' CPU time, on stderr
+  std::vector<double> cpu_pre((size_t)n_streams, 0.0), cpu_call((size_t)n_streams, 0.0);
+  auto thread_cpu_ms = [] { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec; };
   auto run = [&](int s) {
     fq_ctx_t *c = ctxs[s];
     const int nb = n_batches[s];
@@ -2206,8 +2209,11 @@ extern "C" int fq_stream_run(fq_ctx_t *const *ctxs, int32_t n_streams, const fq_
       const int nxt = (cur + 1) % nb;
       int rc = FQ_OK;
       const bool pre = nxt != cur && (k + 1 < n_calls || (flags & FQ_STREAM_PREFETCH_BEYOND));
+      const double c0 = trace_cpu ? thread_cpu_ms() : 0.0;
       if (pre) rc = fq_packed_prefetch(c, batches[s][nxt]);      // the next batch's upload runs under this batch's kernels
+      const double c1 = trace_cpu ? thread_cpu_ms() : 0.0;
       if (!rc) rc = fq_align_packed(c, batches[s][cur], &res);
+      if (trace_cpu) { cpu_pre[(size_t)s] += c1 - c0; cpu_call[(size_t)s] += thread_cpu_ms() - c1; }
       if (!rc) { surv[(size_t)s] += res.n_survivors; if (on_call) rc = on_call(user, s, k, &res); }
       if (rc) { rcs[(size_t)s] = rc; if (pre) (void)fq_packed_cancel(c, batches[s][nxt]); return; }
       cur = nxt;
@@ -2218,6 +2224,12 @@ extern "C" int fq_stream_run(fq_ctx_t *const *ctxs, int32_t n_streams, const fq_
   run(0);                                                    // (the caller's thread is the first stream's)
   for (auto &t : th) t.join();
   if (survivors_out) for (int s = 0; s < n_streams; ++s) survivors_out[s] = surv[(size_t)s];
+  if (trace_cpu && n_calls > 0) {
+    double a = 0, b = 0;
+    for (int s = 0; s < n_streams; ++s) { a += cpu_pre[(size_t)s]; b += cpu_call[(size_t)s]; }
+    fprintf(stderr, "TRACE - fq_stream_run: %d streams x %d calls; CPU time of a stream's thread per call: prefetch %.3f ms, call %.3f ms\n", n_streams, n_calls,
+            a / ((double)n_streams * n_calls), b / ((double)n_streams * n_calls));
+  }
   for (int rc : rcs) if (rc) return rc;
   return FQ_OK;
 }
