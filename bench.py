@@ -47,6 +47,31 @@ K_PREP_KERNEL, K_GAP_KERNEL, K_GAP_NOGAP = 6, 7, 8     # single-kernel timings (
 STRIDE_PAD = 16                # ASCII rows are padded to 16 bytes: the resident filter kernel loads rows with 16-byte vector loads
 
 
+def host_budget_child(args):
+    """The same run inside a rank's share of the host, 2 CPUs (an 8-GPU node's 16 CPUs over 8 ranks): a child process of this script, pinned to 2 CPUs
+    before it touches the device (sched_setaffinity: every thread it and the HIP runtime start inherit it) and the library told so
+    (FASTQUICK_HOST_CPUS=2: what LOCAL_WORLD_SIZE=8 works out to on 16 CPUs); headline and on-target legs.  It runs BEFORE this process
+    initialises the device: two processes' worth of hardware queues on one device slow both (the library asks for 20 each; 32 or more
+    oversubscribe them), and a child started behind the parent's legs measured 0.82-0.93 of what it measures alone."""
+    import subprocess
+    hb_cpus = 2
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(max(4, min(args.steps, 16))), "--warmup", str(max(2, min(args.warmup, 8))),
+           "--pairs", str(args.pairs), "--ctxs", str(args.ctxs), "--markers", str(args.markers), "--mix", args.mix, "--read-len", str(args.read_len),
+           "--boundary", args.boundary, "--host-cpus", str(hb_cpus), "--no-resident", "--no-front-end", "--no-cpu-baseline", "--no-host-budget",
+           "--ontarget-tput-ctxs", "0", "--workdir", args.workdir] + (["--no-ontarget"] if args.no_ontarget else []) + (["--tune", args.tune] if args.tune else [])
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    t0 = time.perf_counter()
+    run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
+    hb = {"cpus": hb_cpus, "how": "child process pinned to %d CPUs (sched_setaffinity) with FASTQUICK_HOST_CPUS=%d, run before this process touched the device; same workload, %d streams" % (hb_cpus, hb_cpus, args.ctxs),
+          "wall_s": round(time.perf_counter() - t0, 1)}
+    line = [l for l in run.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
+    if run.returncode == 0 and line:
+        hb["child"] = json.loads(line[-1])
+    else:
+        hb["error"] = run.stderr.decode(errors="replace")[-500:]
+    return hb
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -84,9 +109,16 @@ def main() -> None:
     ap.add_argument("--no-host-budget", action="store_true", help="skip the host_budget leg (the run repeated on 2 CPUs)")
     args = ap.parse_args()
     if args.host_cpus > 0:
-        cpus = sorted(os.sched_getaffinity(0))[:args.host_cpus]
+        allowed = sorted(os.sched_getaffinity(0))
+        first = int(os.environ.get("FQ_BENCH_PIN_FIRST", "-1"))
+        if first < 0:
+            first = min(8, max(0, len(allowed) - args.host_cpus))      # (not the box's first CPUs: those take its interrupts)
+        cpus = allowed[first:first + args.host_cpus]
         os.sched_setaffinity(0, set(cpus))                      # (inherited by every thread started from here on: the HIP runtime's, the library's, Python's)
         os.environ["FASTQUICK_HOST_CPUS"] = str(args.host_cpus)
+    hb_result = None
+    if args.host_cpus == 0 and not args.no_host_budget and args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+        hb_result = host_budget_child(args)          # (before anything here touches the device)
 
     import numpy as np
     import torch
@@ -491,31 +523,16 @@ def main() -> None:
                                              "steps": 2, "ms_per_step": round(1e3 * leg["elapsed"] / 2, 3),
                                              "host_ms_per_call": round(leg["agg"]["host_ms_total"] / leg["calls"], 3)}
 
-    # ---- host budget: the same run inside a rank's share of the host, 2 CPUs (an 8-GPU node's 16 CPUs over 8 ranks).  A child process of this
-    #      script, pinned to 2 CPUs before it touches the device (sched_setaffinity: every thread it and the HIP runtime start inherit it) and the
-    #      library told so (FASTQUICK_HOST_CPUS=2: what LOCAL_WORLD_SIZE=8 works out to on 16 CPUs); headline and on-target legs.
-    if rank == 0 and world == 1 and args.host_cpus == 0 and not args.no_host_budget:
-        import subprocess
-        hb_cpus = 2
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", str(max(4, min(args.steps, 12))), "--warmup", str(max(2, min(args.warmup, 4))),
-               "--pairs", str(args.pairs), "--ctxs", str(args.ctxs), "--markers", str(args.markers), "--mix", args.mix, "--read-len", str(args.read_len),
-               "--boundary", args.boundary, "--host-cpus", str(hb_cpus), "--no-resident", "--no-front-end", "--no-cpu-baseline", "--no-host-budget",
-               "--ontarget-tput-ctxs", "0", "--workdir", args.workdir] + (["--no-ontarget"] if args.no_ontarget else []) + (["--tune", args.tune] if args.tune else [])
-        env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "LOCAL_WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
-        t0 = time.perf_counter()
-        run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env)
-        hb = {"cpus": hb_cpus, "how": "child process pinned to %d CPUs (sched_setaffinity) with FASTQUICK_HOST_CPUS=%d; same workload, %d streams" % (hb_cpus, hb_cpus, args.ctxs),
-              "wall_s": round(time.perf_counter() - t0, 1)}
-        line = [l for l in run.stdout.decode(errors="replace").splitlines() if l.startswith("{")]
-        if run.returncode == 0 and line:
-            ch = json.loads(line[-1])
+    # ---- host budget: measured by a child process before this one touched the device (below, host_budget_child)
+    if hb_result is not None:
+        hb = dict(hb_result)
+        ch = hb.pop("child", None)
+        if ch is not None:
             hb.update({"value": ch["value"], "unit": ch["unit"], "ratio_to_value": round(ch["value"] / out["value"], 4), "steps": ch["steps"], "ms_per_step": ch["ms_per_step"],
                        "host_cpu_ms_per_call": ch.get("host_cpu_ms_per_call"), "wall_ms_per_call": ch.get("wall_ms_per_call"), "device_wait_ms_per_call": ch.get("device_wait_ms_per_call")})
             if "ontarget" in ch and "ontarget" in out:
                 hb["ontarget"] = {"value": ch["ontarget"]["value"], "ratio_to_ontarget_value": round(ch["ontarget"]["value"] / out["ontarget"]["value"], 4),
                                   "ms_per_step": ch["ontarget"]["ms_per_step"], "host_cpu_ms_per_call": ch["ontarget"].get("host_cpu_ms_per_call")}
-        else:
-            hb["error"] = run.stderr.decode(errors="replace")[-500:]
         out["host_budget"] = hb
 
     # ---- front end: what feeds the packed boundary, measured on this box's host cores beside `value` -----------------
