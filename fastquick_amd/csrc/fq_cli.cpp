@@ -832,10 +832,12 @@ int main(int argc, char **argv) {
       if (qc_prefix != A.out_prefix) tmp_file(qc_prefix + ".InsertSizeTable");
       rc = fq_qc_create(K.ix, pre.c_str(), qc_prefix.c_str(), &qo, &K.qc);
       if (rc) die("cannot set up the QC consumer from " + pre + ".SelectedSite.vcf / .dbSNP.subset.vcf / .gc (" + std::to_string(rc) + ")");
+      mark("QC consumer set up");
     }
     if (!A.sam_out) {
       rc = fq_bam_create(K.ix, fai.c_str(), bam_path, A.rg.c_str(), &qo, &K.bam);
       if (rc) die("cannot open " + A.out_prefix + ".bam / " + fai + " (" + std::to_string(rc) + ")");
+      mark("BAM writer set up");
     }
   };
   if (W == 1) {

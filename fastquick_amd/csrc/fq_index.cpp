@@ -438,7 +438,7 @@ extern "C" int fq_index_load(const char *prefix_c, int device_ordinal, fq_index_
   // the load has its own short-lived device state (stream for the staging copies); it ends with the load
   struct DevScope {
     fqdev::State *s;
-    ~DevScope() { fqdev::state_destroy(s); }
+    ~DevScope() { if (s) fqdev::state_destroy(s); }
   } scope{fqdev::state_create(device_ordinal)};
   if (!scope.s || fqdev::bind(scope.s)) return FQ_ENODEV;
   mark("device state (HIP runtime up)");
@@ -544,9 +544,10 @@ extern "C" int fq_index_load(const char *prefix_c, int device_ordinal, fq_index_
         if (!e) e = fqdev::h2d(d_al, alle.data(), alle.size());
         if (!e) e = fqdev::launch_bitmap_kmers(ba);
         if (!e) e = fqdev::sync();
-        fqdev::dfree(d_off); fqdev::dfree(d_al);
+        ix->load_scratch.push_back(d_off); ix->load_scratch.push_back(d_al);
         if (e) return fail(FQ_ENODEV);
         mark("bitmaps filled by the device from the reference in HBM");
+        ix->load_state = scope.s; scope.s = nullptr;
         *out = ix.release();
         return FQ_OK;
       }
@@ -571,6 +572,7 @@ extern "C" int fq_index_load(const char *prefix_c, int device_ordinal, fq_index_
     fqdev::dfree(d);
   }
   mark("bitmaps filled");
+  ix->load_state = scope.s; scope.s = nullptr;
   *out = ix.release();
   return FQ_OK;
 }
@@ -585,6 +587,9 @@ extern "C" int fq_index_bitmap_fetch(const fq_index_t *ix, int32_t t, uint8_t *o
 }
 extern "C" void fq_index_destroy(fq_index_t *ix) {
   if (!ix) return;
+  if (ix->load_state) { fqdev::state_destroy((fqdev::State *)ix->load_state); ix->load_state = nullptr; }
+  for (void *p : ix->load_scratch) fqdev::dfree(p);
+  ix->load_scratch.clear();
   for (int j = 0; j < 2; ++j) { fqdev::dfree(ix->d_blk[j]); fqdev::dfree(ix->d_sa[j]); }
   fqdev::dfree(ix->d_pac);
   fqdev::dfree(ix->d_bitmap);

@@ -28,6 +28,9 @@ struct fq_index {
   std::vector<uint8_t> pac;
   // device
   FqDevIndex dev{};
+  std::vector<void *> load_scratch;   // small device buffers of the load, freed with the index (hipFree waits for the device)
+  void *load_state = nullptr;   // the load's device state (fqdev::State): given back with the index -- destroying it frees device memory, which waits for
+                                // every stream of the device, and the load runs beside the first chunk's kernels
   void *d_blk[2] = {nullptr, nullptr};
   void *d_sa[2] = {nullptr, nullptr};
   void *d_pac = nullptr;
