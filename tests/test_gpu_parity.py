@@ -30,6 +30,8 @@ SEARCH_MODES = {"lanes": {}, "wave1": {"gap_long_pops": 1, "gap_long_always": 1}
                 # the packed-batch boundary (fq_pack_reads -> fq_packed_prefetch -> fq_align_packed): survivors' rows gathered on the
                 # host / the whole body uploaded and gathered on the device
                 "packed": {"packed_bulk_min": 1 << 30, "md_mask_min": 0}, "packed_bulk": {"packed_bulk_min": 0, "md_mask_min": 0},
+                # ... with the filter kernel on the device's shared stream of the highest priority (a tuning key: DESIGN section 9, cfg 3)
+                "packed_prio": {"packed_bulk_min": 1 << 30, "md_mask_min": 0, "prep_priority": 1},
                 # every launch begins with the round that searches without gap children, as device-filling launches do
                 "nogap": {"gap_nogap_min": 0},
                 # ... with the kernels that read the options from the launch instead of the ones compiled for FASTQuick's own option block
@@ -207,7 +209,7 @@ OPTION_VARIANTS = [
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,okw", OPTION_VARIANTS, ids=[v[0] for v in OPTION_VARIANTS])
 def test_gpu_matches_oracle_with_option_variants(name, okw, lib, tmp_path, search_mode):
-    if search_mode in ("wave64", "packed_bulk", "generic_opts") or (search_mode == "nogap" and name == "nonstop"):
+    if search_mode in ("wave64", "packed_bulk", "generic_opts", "packed_prio") or (search_mode == "nogap" and name == "nonstop"):
         pytest.skip("covered by lanes, wave1 and packed")
     ref = synth.make_reference(n_markers=120, n_long=12, seed=35, repeat_every=2, tandem_every=7)
     pre = str(tmp_path / "ref.FASTQuick.fa")
