@@ -70,6 +70,8 @@ struct fq_fastq {
   int fd = -1;
   gzFile gz = nullptr;
   bool bgzf = false, src_eof = false;
+  bool gz_regular = false;            // a regular file with a gzip header that is not BGZF (blocks of the stream decoder's size whichever reader reads it)
+  size_t room = 0;                    // text a block takes (set per block by the producer)
   std::vector<uint8_t> cbuf;          // BGZF: compressed bytes not yet inflated
   size_t cpos = 0, cend = 0;
   bool file_eof = false;
@@ -87,7 +89,9 @@ struct fq_fastq {
     bool in_member = false, in_block = false;
     uint32_t crc = 0;
     uint64_t member_out = 0;            // text of the current member so far (ISIZE is its low 32 bits)
-    std::vector<uint8_t> win;           // the last 32 KiB of text of the current member (what a block's first matches may reach back into)
+    std::vector<uint8_t> win;           // what the next block begins with: the window its first matches may reach back into (up to 32 KiB of the
+                                        // current member in front of the block's boundary) and the text decoded beyond the boundary (`excess`)
+    size_t excess = 0, win_member = 0;  // ... of which the last `excess` bytes are the next block's first text; bytes of `win` that are the current member's
     uint64_t emitted = 0;               // text handed out in earlier blocks
   } gs;
   // ---- producer thread ----
@@ -259,7 +263,7 @@ inflate:
 }
 bool fill_gz(fq_fastq *r, Block &b) {
   b.n = 0;
-  const size_t room = b.cap - b.head;
+  const size_t room = r->room;
   while (b.n < room) {
     const int got = gzread(r->gz, b.data.get() + b.head + b.n, (unsigned)std::min<size_t>(room - b.n, (size_t)1 << 30));
     if (got < 0) { int en = 0; r->src_err = std::string("gzread: ") + gzerror(r->gz, &en); return false; }
@@ -270,33 +274,39 @@ bool fill_gz(fq_fastq *r, Block &b) {
 }
 // ---- source: a gzip stream through the fast decoder, block by block ------------------------------------------------------------------
 // (the window a match reaches back into lies in front of the block's text, where the tokeniser later puts its carry: the same bytes)
-bool gz_fallback(fq_fastq *r, Block &b, size_t n_valid) {       // gzread takes over behind the text handed out so far + n_valid bytes of this block
+// gzread takes over.  Blocks have the size gzread's would have (r->room), so what has been handed out so far is what the gzread reader would have
+// handed out in front of the block the trouble is in; that block is read again by gzread, whose text, end or error message is the reader's.
+bool gz_fallback(fq_fastq *r, Block &b, size_t n_valid) {
   fq_fastq::GzStream &G = r->gs;
   G.on = false;
-  b.n = n_valid;
   std::vector<uint8_t>().swap(G.in);
+  const bool whole = n_valid >= r->room;            // the trouble lies behind this block's boundary: the block is good, gzread begins behind it
+  if (whole) G.emitted += r->room;
   r->gz = gzopen(r->path.c_str(), "rb");
   if (!r->gz) { r->src_err = "cannot reopen " + r->path; return false; }
-  gzbuffer(r->gz, 1 << 20);
-  uint64_t skip = G.emitted + n_valid;
+  gzbuffer(r->gz, 1 << 16);                         // (a block's gzread is then a direct one -- 192 KiB at least, twice this and more: what it inflates is the block,
+                                                    //  and a failure loses exactly the block it happens in)
+  uint64_t skip = G.emitted;
   std::vector<uint8_t> scratch((size_t)4 << 20);
   while (skip > 0) {
     const int got = gzread(r->gz, scratch.data(), (unsigned)std::min<uint64_t>(skip, scratch.size()));
-    if (got < 0) { int en = 0; r->src_err = std::string("gzread: ") + gzerror(r->gz, &en); return false; }
-    if (got == 0) { b.last = true; break; }          // (gzread sees the end where the decoder saw text: it is right)
+    if (got <= 0) { int en = 0; r->src_err = std::string("gzread: ") + gzerror(r->gz, &en); return false; }   // (cannot happen: the decoder produced this text from the same bytes)
     skip -= (uint64_t)got;
   }
-  if (b.n == 0 && !b.last) return fill_gz(r, b);     // (a block must not be handed over empty unless it is the last)
-  return true;
+  if (whole) { b.n = r->room; return true; }
+  return fill_gz(r, b);
 }
 bool fill_gz_stream(fq_fastq *r, Block &b) {
   fq_fastq::GzStream &G = r->gs;
   fqz::Dec &d = G.d;
   uint8_t *const text = b.data.get() + b.head;
+  const size_t room = r->room;
   b.n = 0;
-  if (!G.win.empty()) memcpy(text - G.win.size(), G.win.data(), G.win.size());
-  d.dst = text - G.win.size(); d.out = text; d.out_end = b.data.get() + b.cap;
-  const uint8_t *crc_from = text;
+  // in front of the block: the window; at its start: what the block before decoded beyond its boundary
+  const size_t pre = G.win.size() - G.excess;
+  if (!G.win.empty()) memcpy(text - pre, G.win.data(), G.win.size());
+  d.dst = text + G.excess - G.win_member; d.out = text + G.excess; d.out_end = b.data.get() + b.cap;
+  const uint8_t *crc_from = d.out;
   auto more_input = [&]() -> bool {                  // the unread bytes to the front, the buffer filled from the file; false: nothing more came
     if (G.eof) return false;
     const size_t used = (size_t)(d.in - G.in.data()), left = G.end - used;
@@ -318,6 +328,7 @@ bool fill_gz_stream(fq_fastq *r, Block &b) {
   };
   auto fold_crc = [&] { G.crc = fqz::crc32(crc_from, (size_t)(d.out - crc_from), G.crc); G.member_out += (uint64_t)(d.out - crc_from); crc_from = d.out; };
   for (;;) {
+    if ((size_t)(d.out - text) >= room) break;       // the block is full (what lies beyond its boundary begins the next one)
     if (!G.in_member) {
       // ---- a member's header (RFC 1952), or the end of the file
       if (!have(18) && d.in_end == d.in) { b.last = true; break; }
@@ -336,13 +347,12 @@ bool fill_gz_stream(fq_fastq *r, Block &b) {
       d.in += p;
       d.bb = 0; d.bc = 0; d.over = 0; d.last = false; d.LT = d.DT = nullptr;
       d.dst = d.out;                                  // (a member's matches do not reach in front of it)
-      G.win.clear();
       G.in_member = true; G.in_block = false; G.crc = 0; G.member_out = 0;
       crc_from = d.out;
     }
     if (!G.in_block) {
-      // ---- the next block's header: a stored block copies up to 64 KiB, a dynamic block's code lengths are under 1 KiB
-      if ((size_t)(d.out_end - d.out) < ((size_t)1 << 16) + 512) break;       // the block is full
+      // ---- the next block's header: a stored block copies up to 64 KiB, a dynamic block's code lengths are under 1 KiB (the room behind the
+      //      block's boundary is there for that)
       (void)have(((size_t)1 << 16) + 4096);
       const int nb = fqz::dec_next_block(d, true);
       if (nb < 0 || d.over > ((size_t)d.bc >> 3)) return gz_fallback(r, b, (size_t)(d.out - text));      // (a stored block that was refused copied nothing)
@@ -367,7 +377,7 @@ bool fill_gz_stream(fq_fastq *r, Block &b) {
     const int fr = fqz::dec_fast_loop(d);
     if (fr == 1) { G.in_block = false; continue; }
     if (fr < 0) return gz_fallback(r, b, (size_t)(d.out - text));
-    if ((size_t)(d.out_end - d.out) < 258 + 72) break;                       // the block is full (the symbols go on in the next one)
+    if ((size_t)(d.out_end - d.out) < 258 + 72) continue;                    // (behind the block's boundary by now: the loop's first test ends it)
     if (more_input()) continue;
     if ((size_t)(d.in_end - d.in) >= 16) continue;
     // the file's last bytes: a symbol at a time, every bound checked; a stream that wants bytes behind the file's end is truncated
@@ -377,15 +387,19 @@ bool fill_gz_stream(fq_fastq *r, Block &b) {
     if (cr == 1) G.in_block = false;
   }
   if (G.in_member) fold_crc();
-  b.n = (size_t)(d.out - text);
-  // what the next block's matches may reach back into
-  if (G.in_member) {
-    const size_t span = (size_t)(d.out - d.dst), w = std::min<size_t>(span, 32768);
-    std::vector<uint8_t> nw(d.out - w, d.out);
+  const size_t produced = (size_t)(d.out - text);
+  b.n = produced < room ? produced : room;
+  // what the next block begins with: the window in front of the boundary (of the current member) and the text beyond it
+  {
+    const uint8_t *const boundary = text + b.n;
+    const uint8_t *member0 = G.in_member ? d.dst : d.out;                    // (nothing reaches back across a member's end)
+    const uint8_t *c0 = member0 < boundary ? std::max<const uint8_t *>(member0, boundary - std::min<size_t>(32768, (size_t)(boundary - (text - pre)))) : boundary;
+    std::vector<uint8_t> nw(c0, (const uint8_t *)d.out);
+    G.excess = (size_t)(d.out - boundary);
+    G.win_member = G.in_member ? (size_t)(d.out - std::max<const uint8_t *>(member0, c0)) : 0;
     G.win.swap(nw);
-  } else G.win.clear();
+  }
   G.emitted += b.n;
-  if (b.n == 0 && !b.last) { b.last = true; }        // (cannot happen: a block that is not the last holds text)
   return true;
 }
 void producer_main(fq_fastq *r) {
@@ -397,11 +411,16 @@ void producer_main(fq_fastq *r) {
       if (r->stop) return;
       if (!r->spare.empty()) { b = std::move(r->spare.back()); r->spare.pop_back(); }
     }
-    const size_t want_text = r->gs.on ? std::max<size_t>(r->block_bytes, (size_t)192 << 10) : r->block_bytes;   // (the stream decoder wants room for a stored block between two looks at the block's end)
-    if (b.cap < want_text + kHeadroom) { b.cap = want_text + kHeadroom; b.data.reset(new uint8_t[b.cap]); }
+    // (a gzip file's blocks: 192 KiB at least, whichever reader reads it -- the stream decoder wants room; behind a block's text, for that decoder, room
+    //  for a stored block and the fast loop's margin: it stops at the first look behind the boundary and the next block begins with what lies beyond)
+    const size_t want_text = r->gz_regular ? std::max<size_t>(r->block_bytes, (size_t)192 << 10) : r->block_bytes;
+    const size_t slack = r->gs.on ? ((size_t)1 << 16) + 4096 : 0;
+    r->room = want_text;
+    if (b.cap < want_text + kHeadroom + slack) { b.cap = want_text + kHeadroom + slack; b.data.reset(new uint8_t[b.cap]); }
     b.head = kHeadroom; b.n = 0; b.last = false;
     const bool ok = r->bgzf ? fill_bgzf(r, b) : r->gs.on ? fill_gz_stream(r, b) : fill_gz(r, b);
     if (!ok) { b.last = true; b.err = r->src_err; }
+    if (getenv("FASTQUICK_READER_DEBUG")) fprintf(stderr, "[reader] block: %zu bytes, last %d, err '%s' (%s)\n", b.n, (int)b.last, b.err.c_str(), r->bgzf ? "bgzf" : r->gs.on ? "stream" : "gzread");
     const bool done = b.last;
     {
       std::lock_guard<std::mutex> lk(r->mu);
@@ -583,10 +602,15 @@ extern "C" int fq_fastq_open(const char *path, int threads, fq_fastq_t **out) {
     const ssize_t got = read(fd, h, sizeof h);
     hn = got > 0 ? (size_t)got : 0;
     if (looks_bgzf(h, hn)) { r->bgzf = true; r->fd = fd; lseek(fd, 0, SEEK_SET); }
-    else if (hn >= 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8 && !getenv("FASTQUICK_ZLIB_INFLATE")) {   // gzip, not BGZF: the stream decoder (FASTQUICK_ZLIB_INFLATE=1: gzread, to compare)
-      r->gs.on = true; r->fd = fd; lseek(fd, 0, SEEK_SET);
-      r->gs.in.resize((size_t)8 << 20);
-      r->gs.d.begin(r->gs.Z, r->gs.in.data(), 0, nullptr, 0);
+    else if (hn >= 18 && h[0] == 0x1f && h[1] == 0x8b && h[2] == 8) {   // gzip, not BGZF: the stream decoder (FASTQUICK_ZLIB_INFLATE=1: gzread, to compare)
+      r->gz_regular = true;
+      const char *zenv = getenv("FASTQUICK_ZLIB_INFLATE");
+      if (zenv && *zenv && *zenv != '0') close(fd);
+      else {
+        r->gs.on = true; r->fd = fd; lseek(fd, 0, SEEK_SET);
+        r->gs.in.resize((size_t)8 << 20);
+        r->gs.d.begin(r->gs.Z, r->gs.in.data(), 0, nullptr, 0);
+      }
     }
     else close(fd);
   }
@@ -595,7 +619,7 @@ extern "C" int fq_fastq_open(const char *path, int threads, fq_fastq_t **out) {
   else {
     r->gz = gzopen(path, "rb");
     if (!r->gz) return FQ_EIO;
-    gzbuffer(r->gz, 1 << 20);
+    gzbuffer(r->gz, r->gz_regular ? 1 << 16 : 1 << 20);      // (a gzip file's blocks are read by direct gzreads: see gz_fallback)
   }
   *out = r.release();
   return FQ_OK;

@@ -240,3 +240,5 @@ def test_gzip_streams_through_the_fast_decoder_are_gzreads_records(lib, tmp_path
         got, end = _outcome(api, lib, path, 2, 0)
         assert end == ref_end, (name, end, ref_end)
         assert got == ref, (name, len(got), len(ref))
+    # (with blocks smaller than the file the two readers may differ, on a DAMAGED file, in how many of the same records they return before the
+    #  error -- gzread reads up to 128 KiB ahead behind a member's header: tests/fuzz_gzip_stream.py states and soaks that property)
