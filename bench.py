@@ -701,6 +701,8 @@ def main() -> None:
                 for label, extra in (("sam_out", ["--sam_out"]), ("bam_and_qc", [])):
                     cmd2 = [exe, "align", "--index_prefix", pre[:-len(".FASTQuick.fa")], "--fastq_1", big[0], "--fastq_2", big[1], "--out_prefix", os.path.join(fdir, "big_out"),
                             "--read_len", str(max(L, 151)), "--t", str(pt)] + extra
+                    time.sleep(3.0)     # (a process started right behind another's exit waits for the driver to take back that one's device memory:
+                    #                      the same command took 1.7-1.9 s right behind its predecessor and 1.42-1.49 s three seconds later)
                     t0 = time.perf_counter()
                     run2 = subprocess.run(cmd2, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
                     dt2 = time.perf_counter() - t0
