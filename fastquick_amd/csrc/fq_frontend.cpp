@@ -235,11 +235,9 @@ struct FileSide {
   DBuf<uint32_t> d_nl;
   uint64_t carry_off = 0, carry_len = 0;       // the text behind the last chunk's records: in d_text[carry_slot]
   int carry_slot = -1;
-  int64_t carry_records = 0;                   // (whole records among it, as far as known)
   int64_t records_done = 0;                    // records of this file in batches so far
   double text_per_record = 0;
-  bool all_read = false;                       // every member of the file has been inflated
-  bool all_launched = false;                   // ... has been handed to the decoder (a chunk ahead of all_read)
+  bool all_launched = false;                   // every member of the file has been handed to the decoder
   // slots
   DBuf<uint8_t> d_slot_base, d_slot_name;
   DBuf<uint16_t> d_slot_len;
@@ -287,7 +285,6 @@ struct fq_frontend {
 };
 
 namespace {
-#define FE_FAIL(fe, code, msg) do { (fe)->rc = (code); (fe)->err = (msg); return false; } while (0)
 
 // A piece of the file into (pinned) memory on several threads: a read from the page cache is a memcpy by the kernel, 8-12 GB/s on one
 // thread -- slower than the device inflates what it brings.  Returns the bytes read from `off` on (short only at the end of the file).
@@ -613,10 +610,8 @@ void producer_main(fq_frontend *fe) {
     for (int e = 0; e < NF; ++e) {
       FileSide &F = fe->f[e];
       if (!cur.has[e]) continue;
-      const bool eof = F.chunk[cur.comp_k].eof;
       std::lock_guard<std::mutex> lk(F.mu);
       F.filled[cur.comp_k] = false;
-      if (eof) F.all_read = true;
       F.cv.notify_all();
     }
     // ---- the next chunk's members, beside this chunk's kernels (when its compressed bytes and a batch slot are there already) ----
