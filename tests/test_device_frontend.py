@@ -236,7 +236,7 @@ def front_end_arrays(lib, fq, batch_pairs, chunk_pairs, slot_mode, max_read_len=
 
 
 @pytest.mark.parametrize("slot_mode", [0, 1, 2], ids=["reused_slots", "clean_names", "fresh"])
-@pytest.mark.parametrize("tag", ["basic", "trim76", "example151", "long250", "cfg0_example"])
+@pytest.mark.parametrize("tag", golden_util.case_tags())
 def test_front_end_arrays_are_the_host_readers_and_packers(tag, slot_mode, golden_cases, lib, tmp_path, monkeypatch):
     """the filter's keys, lengths and names the device forms from the text == fq_fastq_read + fq_pack_reads_into, bit for bit.
     (A chunk's new text is inflated before the length of the text carried over from the chunk before is known, a fixed distance into the
