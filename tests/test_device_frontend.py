@@ -309,6 +309,31 @@ def test_front_end_hands_over_at_a_reference_batch_boundary(overlap, golden_case
         assert np.array_equal(hh[:, e * (n - total):(e + 1) * (n - total)], head[:, e * n + total:(e + 1) * n]), "filter keys behind the hand-over (bases of the slots travelled)"
 
 
+def test_carriage_returns_are_the_references_refusal(golden_cases, lib, tmp_path):
+    """CR LF line ends from some record on: kseq_read3_fpc (libbwa/kseq.h:361-365) takes len(seq) quality bytes (isgraph() dropped the CR from
+    the bases) and wants a line feed next -- it finds the CR, prints "this fastq file contains reads with different length" and exits. The
+    device's part ends at the reference batch in front of that record; the host reader standing there refuses with the reference's words."""
+    g = golden_cases["qc"]
+    B, odd = 256, 700
+    fq = []
+    for e, k in enumerate(("fq1", "fq2")):
+        lines = open(g[k], "rb").read().split(b"\n")
+        head, tail = lines[:4 * odd], lines[4 * odd:]
+        text = b"\n".join(head) + b"\n" + (b"\r\n".join(tail) if e == 0 else b"\n".join(tail))
+        path = str(tmp_path / ("crlf_%d.fq.gz" % (e + 1)))
+        with open(path, "wb") as fh:
+            fh.write(synth.bgzf_compress(text, threads=2, level=6, member=4000))
+        fq.append(path)
+    end, total, dh, dl, dn, fe = front_end_arrays(lib, fq, B, 2 * B, 0)
+    assert end == api.FQ_EFALLBACK and total == odd // B * B
+    readers = fe.handover(threads=2, stride=256, name_stride=304)
+    with pytest.raises(api.FastquickError, match="this fastq file contains reads with different length"):
+        readers[0].read(1 << 20)
+    for r in readers:
+        r.close()
+    fe.close()
+
+
 @pytest.mark.gpu
 def test_a_million_pair_bgzf_file_through_the_front_end(tmp_path):
     """1,048,576 pairs of BGZF FASTQ: every batch's keys equal the host packer's on the same rows"""
