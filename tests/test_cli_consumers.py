@@ -182,3 +182,36 @@ def test_cli_device_front_end_equals_the_host_reader_on_four_million_pairs(tmp_p
     assert outs["device"][1] == outs["host"][1] > 10e6 and outs["device"][0] == outs["host"][0], "SAM text"
     for f in QC_FILES:
         assert outs["device"][2][f] == outs["host"][2][f], f
+
+
+@pytest.mark.parametrize("n1,n2", [(0, 0), (1, 1), (600, 300), (300, 600), (512, 256)], ids=["empty", "one_pair", "second_file_short", "first_file_short", "short_at_a_batch_boundary"])
+def test_cli_degenerate_inputs_device_front_end_equals_the_host_reader(n1, n2, golden_cases, emu_cli, tmp_path):
+    """no record at all, a single pair, files of unequal record counts (the command line pairs record i with record i and ends with the shorter
+    file; here only that both front ends do the same): BGZF files through the device front end give the SAM text and QC files of the plain
+    files through the host's reader"""
+    from fastquick_amd import synth
+    g = golden_cases["qc"]
+    lines = [open(g[k], "rb").read().split(b"\n") for k in ("fq1", "fq2")]
+    res = {}
+    for mode in ("plain", "bgzf"):
+        work = tmp_path / mode
+        work.mkdir()
+        paths = []
+        for e, n in enumerate((n1, n2)):
+            text = b"".join(x + b"\n" for x in lines[e][:4 * n])
+            p = str(work / ("r%d.fq" % (e + 1) + (".gz" if mode == "bgzf" else "")))
+            with open(p, "wb") as fh:
+                fh.write(text if mode == "plain" else synth.bgzf_compress(text, threads=1, level=6, member=4000))
+            paths.append(p)
+        cmd = [emu_cli, "align", "--index_prefix", g["prefix"][:-len(".FASTQuick.fa")], "--fastq_1", paths[0], "--fastq_2", paths[1], "--out_prefix", str(work / "o"),
+               "--sam_out", "--batch_pairs", "256", "--chunk_pairs", "256"]
+        run = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+        assert run.returncode == 0, run.stderr.decode(errors="replace")[-2000:]
+        assert (b"front end on the device" in run.stderr) == (mode == "bgzf")
+        qc = {f: open(str(work / f), "rb").read() for f in sorted(os.listdir(str(work))) if f.startswith("o.")}
+        qc["o.FASTQ.csv"] = qc["o.FASTQ.csv"].replace(b".fq.gz", b".fq")         # the one place the input files' names are written
+        res[mode] = (run.stdout, qc)
+    assert res["plain"][0] == res["bgzf"][0]
+    assert sorted(res["plain"][1]) == sorted(res["bgzf"][1]) and len(res["plain"][1]) == 13
+    for f in res["plain"][1]:
+        assert res["plain"][1][f] == res["bgzf"][1][f], f
