@@ -309,6 +309,35 @@ def test_front_end_hands_over_at_a_reference_batch_boundary(overlap, golden_case
         assert np.array_equal(hh[:, e * (n - total):(e + 1) * (n - total)], head[:, e * n + total:(e + 1) * n]), "filter keys behind the hand-over (bases of the slots travelled)"
 
 
+@pytest.mark.parametrize("slot_mode", [0, 2], ids=["reused_slots", "fresh"])
+def test_any_printable_byte_in_the_bases_and_qualities(slot_mode, lib, tmp_path):
+    """IUPAC codes, lower case, '.', '-', '*', digits in the base line (kseq_read3_fpc takes every isgraph() byte, libbwa/kseq.h:340; nst_nt4_table
+    makes 4 of all but ACGTacgt) and every byte 33..126 in the quality line, '@', '+' and '>' at its start included: the device's filter keys,
+    lengths and names == the host reader's and packer's"""
+    rng = np.random.default_rng(11 + slot_mode)
+    alpha = np.frombuffer(b"ACGTNacgtnRYKMSWBDHVryu.-*=~!0Z", dtype=np.uint8)
+    fq = []
+    for e in range(2):
+        out = []
+        for i in range(1500):
+            L = int(rng.integers(30, 200))
+            q = rng.integers(33, 127, L).astype(np.uint8)
+            q[0] = (64, 43, 62, q[0])[i % 4]                   # '@', '+', '>' first
+            out.append(b"@r%d/%d\n" % (i, e + 1) + bytes(rng.choice(alpha, L)) + b"\n+\n" + bytes(q) + b"\n")
+        path = str(tmp_path / ("any_%d.fq.gz" % (e + 1)))
+        with open(path, "wb") as fh:
+            fh.write(synth.bgzf_compress(b"".join(out), threads=2, level=6, member=4000))
+        fq.append(path)
+    n, head, lens, names = host_arrays(lib, fq, 64, slot_mode, stride=256)
+    end, total, dh, dl, dn, fe = front_end_arrays(lib, fq, 64, 192, slot_mode)
+    fe.close()
+    assert end == 0 and total == n == 1500
+    for e in range(2):
+        assert np.array_equal(np.concatenate(dh[e], axis=1), head[:, e * n:(e + 1) * n]), "filter keys of end %d" % e
+        assert np.array_equal(np.concatenate(dl[e]), lens[e * n:(e + 1) * n])
+        assert np.array_equal(np.concatenate(dn[e]), names[e * n:(e + 1) * n])
+
+
 def test_carriage_returns_are_the_references_refusal(golden_cases, lib, tmp_path):
     """CR LF line ends from some record on: kseq_read3_fpc (libbwa/kseq.h:361-365) takes len(seq) quality bytes (isgraph() dropped the CR from
     the bases) and wants a line feed next -- it finds the CR, prints "this fastq file contains reads with different length" and exits. The
