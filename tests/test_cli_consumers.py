@@ -215,3 +215,43 @@ def test_cli_degenerate_inputs_device_front_end_equals_the_host_reader(n1, n2, g
     assert sorted(res["plain"][1]) == sorted(res["bgzf"][1]) and len(res["plain"][1]) == 13
     for f in res["plain"][1]:
         assert res["plain"][1][f] == res["bgzf"][1][f], f
+
+
+@pytest.mark.parametrize("kind", ["long_names", "tabs_in_names", "read_longer_than_the_rows", "read_of_one_base"])
+def test_cli_unusual_records_device_front_end_equals_the_host_reader(kind, golden_cases, emu_cli, tmp_path):
+    """names of several hundred bytes, tab-separated fields behind the name, a read longer than --read_len allows, a read below the 15 bases the
+    path takes: BGZF through the device front end == plain files through the host reader -- the same SAM text up to the same refusal"""
+    from fastquick_amd import synth
+    g = golden_cases["qc"]
+    res = {}
+    for mode in ("plain", "bgzf"):
+        work = tmp_path / mode
+        work.mkdir()
+        paths = []
+        for e, k in enumerate(("fq1", "fq2")):
+            lines = open(g[k], "rb").read().split(b"\n")[:4 * 800]
+            if kind == "long_names":
+                for i in (100, 101, 300):
+                    lines[4 * i] += b"_" + b"n" * (200 + i)
+            elif kind == "tabs_in_names":
+                for i in range(0, 800, 7):
+                    lines[4 * i] += b"\tXX:Z:tag more"
+            elif kind == "read_longer_than_the_rows" and e == 0:
+                lines[4 * 400 + 1] *= 2; lines[4 * 400 + 3] *= 2
+            elif kind == "read_of_one_base":
+                lines[4 * 600 + 1] = lines[4 * 600 + 1][:1]; lines[4 * 600 + 3] = lines[4 * 600 + 3][:1]
+            text = b"".join(x + b"\n" for x in lines)
+            p = str(work / ("r%d.fq" % (e + 1) + (".gz" if mode == "bgzf" else "")))
+            with open(p, "wb") as fh:
+                fh.write(text if mode == "plain" else synth.bgzf_compress(text, threads=1, level=6, member=4000))
+            paths.append(p)
+        cmd = [emu_cli, "align", "--index_prefix", g["prefix"][:-len(".FASTQuick.fa")], "--fastq_1", paths[0], "--fastq_2", paths[1], "--out_prefix", str(work / "o"),
+               "--sam_out", "--batch_pairs", "256", "--chunk_pairs", "256"]
+        res[mode] = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    a, b = res["plain"], res["bgzf"]
+    assert b"front end on the device" in b.stderr or b.returncode
+    assert a.returncode == b.returncode == (1 if kind.startswith("read_") else 0)
+    assert a.stdout == b.stdout
+    if kind.startswith("read_"):
+        last = [r.stderr.decode(errors="replace").strip().splitlines()[-1].split("failed: ")[-1] for r in (a, b)]
+        assert last[0] == last[1] and ("longer than the batch rows" in last[0] or "read length outside" in last[0])
