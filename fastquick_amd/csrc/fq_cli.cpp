@@ -861,7 +861,7 @@ int main(int argc, char **argv) {
         fwrite(h.data(), 1, (size_t)n, stdout);
       }
     };
-    for (const auto &input : inputs) align_input(A, input, K.ix, K.qc, out, ready, K.device);
+    for (const auto &input : inputs) align_input(A, input, K.ix, K.qc, out, ready, devices[0]);   // (not K.device: the opener thread is still writing K)
     ready();
     if (K.bam && fq_bam_close(K.bam)) die("closing " + A.out_prefix + ".bam failed");
     if (K.qc) {

@@ -576,7 +576,7 @@ bool next_block(fq_fastq *r) {
     memcpy(nb.data.get() + nb.head, b.data.get() + b.head, b.n);
     b = std::move(nb);
   }
-  memcpy(b.data.get() + b.head - r->carry.size(), r->carry.data(), r->carry.size());
+  if (!r->carry.empty()) memcpy(b.data.get() + b.head - r->carry.size(), r->carry.data(), r->carry.size());
   r->cur_pos = b.head - r->carry.size();
   r->cur_end = b.head + b.n;
   r->carry.clear();
