@@ -270,6 +270,10 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
   fq_qc_t *qc = nullptr;
   fq_ctx_t *ctx = nullptr, *ctx_a = nullptr;      // ctx: the context that holds the stream's state; ctx_a: the first one made (a second one may join it: ctx2)
   bool started = false;
+  // A refusal ends the run behind the records of every call before it (the reference prints the batches before the one that aborts,
+  // src/BwtMapper.cpp:2030-2092): consumers of the previous call that still run on their own threads are waited for, the sink is flushed, then die().
+  std::function<void()> before_die;
+  auto fail = [&](const std::string &m) { if (before_die) before_die(); out.flush(); die(m); };
   auto start = [&] {                    // from here on: the index, the QC consumer, the sink
     if (started) return;
     started = true;
@@ -319,7 +323,7 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
     for (int i = 0; i < n; i += A.o.batch_pairs) {
       order_checked_reads += 2LL * std::min<long long>(A.o.batch_pairs, n - i);
       if (order_checked_reads % A.o.batch_pairs == 0 && strncmp(first_name(i / A.o.batch_pairs, 0), first_name(i / A.o.batch_pairs, 1), (size_t)A.read_len) != 0)
-        die("Abort, please make sure input pair of fastq files are in the same order!");
+        fail("Abort, please make sure input pair of fastq files are in the same order!");
     }
   };
 
@@ -336,6 +340,7 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
       if (th_out.joinable()) th_out.join();
       if (tb_prev) { fq_frontend_release(fe, tb_prev); tb_prev = nullptr; }
     };
+    before_die = [&] { if (th_qc.joinable()) th_qc.join(); if (th_out.joinable()) th_out.join(); };
     fq_ctx_t *cur = nullptr, *other = nullptr;
     std::vector<char> token;
     for (;;) {
@@ -347,31 +352,31 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
       if (n == FQ_EFALLBACK) {
         finish_prev();
         fq_fastq_t *h[2] = {nullptr, nullptr};
-        if ((rc = fq_frontend_handover(fe, reader_threads, h))) die("the device front end could not hand " + A.fq1 + " over to the host reader (" + std::to_string(rc) + ")");
+        if ((rc = fq_frontend_handover(fe, reader_threads, h))) fail("the device front end could not hand " + A.fq1 + " over to the host reader (" + std::to_string(rc) + ")");
         r1.reset(new FastqReader(A.fq1, h[0]));
         if (!se) r2.reset(new FastqReader(A.fq2, h[1]));
         fprintf(stderr, "NOTICE - the FASTQ text from record %lld on is not four plain lines per record: read on by the host's reader\n", num_read / (se ? 1 : 2) + 1);
         break;
       }
-      if (n < 0) die(std::string(fq_frontend_last_error(fe)).empty() ? "the device front end failed (" + std::to_string(n) + ")" : fq_frontend_last_error(fe));
+      if (n < 0) fail(std::string(fq_frontend_last_error(fe)).empty() ? "the device front end failed (" + std::to_string(n) + ")" : fq_frontend_last_error(fe));
       if (n == 0) break;
       start();
       if (!cur) {
         cur = ctx;
         fq_opts_t o = A.o;
         o.single_end = se ? 1 : 0;
-        if (fq_ctx_create(ix, &o, (int32_t)A.chunk_pairs, &ctx2)) die("fq_ctx_create failed: option outside the supported range");
+        if (fq_ctx_create(ix, &o, (int32_t)A.chunk_pairs, &ctx2)) fail("fq_ctx_create failed: option outside the supported range");
         other = ctx2;
       } else {
         // the stream's order-dependent state -- drand48 stream, last_ii, (k,l) cache -- goes from the context of the last call to this one's
         const int64_t need = fq_ctx_state_export(other, nullptr, 0);
         token.resize((size_t)std::max<int64_t>(need, 0));
-        if (need < 0 || fq_ctx_state_export(other, token.data(), need) != need || fq_ctx_state_import(cur, token.data(), need)) die("handing the stream's state from one context to the other failed");
+        if (need < 0 || fq_ctx_state_export(other, token.data(), need) != need || fq_ctx_state_import(cur, token.data(), need)) fail("handing the stream's state from one context to the other failed");
       }
       if (!se) order_check((int)n, [&](int sb, int e) { const char *nm = fq_text_batch_first_name(tb, sb, e); return nm ? nm : ""; });
       fq_result_batch_t res;
       const auto ta0 = std::chrono::steady_clock::now();
-      if ((rc = fq_align_text(cur, tb, &res))) die(std::string("fq_align_text failed: ") + fq_ctx_last_error(cur));
+      if ((rc = fq_align_text(cur, tb, &res))) fail(std::string("fq_align_text failed: ") + fq_ctx_last_error(cur));
       align_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta0).count();
       mark("call done");
       finish_prev();
@@ -384,6 +389,7 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
       std::swap(cur, other);            // (`other` now names the context of the call just made: the one whose state goes on)
     }
     finish_prev();
+    before_die = nullptr;
     if (other && cur) ctx = other;       // the context that holds the stream's state (the host readers' part, if any, goes on with it)
     unequal_on_device = fq_frontend_unequal_lengths(fe) != 0;
     front_end_notice(fe);
@@ -525,6 +531,13 @@ struct ShardRun {
   std::vector<char> token;
   struct Result { std::string sam; std::vector<char> bam, qc; long long pairs = 0, filtered = 0, unmapped = 0; };
   std::map<long long, Result> results;
+  // a refusal (a reader's error, a call that fails on chunk b): the writer still emits every chunk before it, then the run dies with `error`
+  long long fail_at = -1;
+  std::string error;
+  void refuse(long long b, const std::string &m) {
+    { std::lock_guard<std::mutex> lk(mu); if (fail_at < 0 || b < fail_at) { fail_at = b; error = m; } }
+    cv.notify_all();
+  }
 };
 struct ShardHook { ShardRun *run; fq_ctx_t *ctx; long long b; };
 void shard_before(void *u) {
@@ -577,16 +590,18 @@ void align_pair_sharded(const Args &A, const std::pair<std::string, std::string>
       std::thread t0(fill_chunk, std::ref(r1), std::ref(c->e[0]), A.chunk_pairs, stride, name_stride);
       fill_chunk(r2, c->e[1], A.chunk_pairs, stride, name_stride);
       t0.join();
-      if (!c->e[0].error.empty()) die(c->e[0].error);
-      if (!c->e[1].error.empty()) die(c->e[1].error);
+      if (!c->e[0].error.empty()) { R.refuse(b, c->e[0].error); return; }
+      if (!c->e[1].error.empty()) { R.refuse(b, c->e[1].error); return; }
       const int n = std::min(c->e[0].n, c->e[1].n);
       const bool last = n == 0 || c->e[0].eof || c->e[1].eof || c->e[0].n != c->e[1].n;
       if (n) {
         for (int i = 0; i < n; i += A.o.batch_pairs) {      // the name check of src/BwtMapper.cpp:2087-2092, at the reference's cadence
           order_checked_reads += 2LL * std::min<long long>(A.o.batch_pairs, n - i);
           if (order_checked_reads % A.o.batch_pairs == 0 &&
-              strncmp(&c->e[0].names[(size_t)i * name_stride], &c->e[1].names[(size_t)i * name_stride], (size_t)A.read_len) != 0)
-            die("Abort, please make sure input pair of fastq files are in the same order!");
+              strncmp(&c->e[0].names[(size_t)i * name_stride], &c->e[1].names[(size_t)i * name_stride], (size_t)A.read_len) != 0) {
+            R.refuse(b, "Abort, please make sure input pair of fastq files are in the same order!");
+            return;
+          }
         }
         if ((long long)n < A.chunk_pairs) {
           memmove(c->seq.data() + (size_t)n * stride, c->seq.data() + (size_t)A.chunk_pairs * stride, (size_t)n * stride);
@@ -618,7 +633,7 @@ void align_pair_sharded(const Args &A, const std::pair<std::string, std::string>
       ShardRun::Chunk *c = nullptr;
       {
         std::unique_lock<std::mutex> lk(R.mu);
-        R.cv.wait(lk, [&] { for (auto &s : R.slots) if (s.index == b) { c = &s; return true; } return R.n_chunks >= 0 && b >= R.n_chunks; });
+        R.cv.wait(lk, [&] { for (auto &s : R.slots) if (s.index == b) { c = &s; return true; } return (R.n_chunks >= 0 && b >= R.n_chunks) || R.fail_at >= 0; });
         if (!c) break;
       }
       const int n = c->n;
@@ -627,7 +642,7 @@ void align_pair_sharded(const Args &A, const std::pair<std::string, std::string>
       ShardHook hook{&R, ctx, b};
       fq_ctx_set_serial_hooks(ctx, shard_before, shard_after, &hook);
       fq_result_batch_t res;
-      if (fq_align_packed(ctx, pk, &res)) die(std::string("fq_align_packed failed on device ") + std::to_string(K.device) + ": " + fq_ctx_last_error(ctx));
+      if (fq_align_packed(ctx, pk, &res)) { R.refuse(b, std::string("fq_align_packed failed on device ") + std::to_string(K.device) + ": " + fq_ctx_last_error(ctx)); return; }
       ShardRun::Result out;
       out.pairs = n; out.filtered = res.n_both_filtered; out.unmapped = res.n_both_unmapped;
       if (K.qc) {
@@ -664,9 +679,9 @@ void align_pair_sharded(const Args &A, const std::pair<std::string, std::string>
     ShardRun::Result res;
     {
       std::unique_lock<std::mutex> lk(R.mu);
-      R.cv.wait(lk, [&] { return R.results.count(b) || (R.n_chunks >= 0 && b >= R.n_chunks); });
+      R.cv.wait(lk, [&] { return R.results.count(b) || (R.n_chunks >= 0 && b >= R.n_chunks) || (R.fail_at >= 0 && b >= R.fail_at); });
       auto it = R.results.find(b);
-      if (it == R.results.end()) break;
+      if (it == R.results.end() || (R.fail_at >= 0 && b >= R.fail_at)) break;
       res = std::move(it->second);
       R.results.erase(it);
     }
@@ -675,6 +690,11 @@ void align_pair_sharded(const Args &A, const std::pair<std::string, std::string>
     if (qc && fq_qc_merge(qc, res.qc.data(), (int64_t)res.qc.size())) die(std::string("QC consumer: merge failed: ") + fq_qc_last_error(qc));
     num_read += 2 * res.pairs; filtered += res.filtered; unmapped += res.unmapped;
     fprintf(stderr, "NOTICE - %lld sequences are processed.\n", num_read);
+  }
+  {   // a refused run ends here, behind the records of the chunks before the refusal (threads that wait for a state that never comes end with the process)
+    std::string err;
+    { std::lock_guard<std::mutex> lk(R.mu); if (R.fail_at >= 0) err = R.error; }
+    if (!err.empty()) { if (sam_fp) fflush(sam_fp); die(err); }
   }
   reader.join();
   for (auto &t : th) t.join();
