@@ -76,7 +76,7 @@ class ResultBatch(C.Structure):
 
 
 class Stats(C.Structure):
-    _fields_ = [("kernel_ms", C.c_double * 15), ("kernel_launches", C.c_uint64 * 15),
+    _fields_ = [("kernel_ms", C.c_double * 16), ("kernel_launches", C.c_uint64 * 16),
                 ("occ_block_touches", C.c_uint64), ("gap_occ_touches", C.c_uint64), ("gap_nogap_touches", C.c_uint64), ("filter_probes", C.c_uint64),
                 ("stack_pops", C.c_uint64), ("stack_pushes", C.c_uint64), ("sa_rows", C.c_uint64),
                 ("reads_searched", C.c_uint64), ("pairs", C.c_uint64), ("sw_tasks", C.c_uint64),
@@ -105,7 +105,10 @@ EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destr
            "fq_qc_add_last", "fq_qc_end_file", "fq_qc_write", "fq_qc_state_reset", "fq_qc_state_export", "fq_qc_merge", "fq_bam_create", "fq_bam_add_last", "fq_bam_format_last", "fq_bam_write_records", "fq_bam_close",
            "fq_fastq_open", "fq_fastq_configure", "fq_fastq_set_sampling", "fq_fastq_read", "fq_fastq_last_error", "fq_fastq_dropped_record", "fq_fastq_unequal_lengths", "fq_fastq_is_bgzf", "fq_fastq_close", "fq_inflate_raw", "fq_crc32", "fq_inflate_device", "fq_bgzf_inflate_device",
            "fq_frontend_open", "fq_frontend_next", "fq_frontend_release", "fq_frontend_handover", "fq_frontend_unequal_lengths", "fq_frontend_stats", "fq_frontend_last_error", "fq_frontend_close",
-           "fq_text_batch_pairs", "fq_text_batch_first_name", "fq_align_text", "fq_text_batch_fetch"]
+           "fq_text_batch_pairs", "fq_text_batch_first_name", "fq_align_text", "fq_text_batch_fetch",
+           "fq_ctx_set_emit", "fq_sam_device_last", "fq_sam_device_bytes", "fq_ctx_attach_qc"]
+SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
+EMIT_SAM = 1
 
 SERIAL_HOOK = C.CFUNCTYPE(None, C.c_void_p)
 STREAM_CALL = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p)      # (user, stream, call, fq_result_batch_t *)
@@ -144,6 +147,12 @@ def load_library(path: str | None = None):
     L.fq_sam_header.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.fq_sam_format_last.restype = C.c_int64
     L.fq_sam_format_last.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.fq_ctx_set_emit.argtypes = [C.c_void_p, C.c_int32]
+    L.fq_sam_device_last.restype = C.c_int64
+    L.fq_sam_device_last.argtypes = [C.c_void_p, SINK_FN, C.c_void_p]
+    L.fq_sam_device_bytes.restype = C.c_int64
+    L.fq_sam_device_bytes.argtypes = [C.c_void_p]
+    L.fq_ctx_attach_qc.argtypes = [C.c_void_p, C.c_void_p]
     L.fq_stage_dump_last.restype = C.c_int64
     L.fq_stage_dump_last.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.fq_stats_get.argtypes = [C.c_void_p, C.POINTER(Stats)]
@@ -387,7 +396,9 @@ class FastqFile:
 class Aligner:
     """One alignment context == one FASTQ pair stream of the reference (drand48 / last_ii / cache carry over)."""
 
-    def __init__(self, index: Index, opts: Opts | None = None, max_pairs: int = 262144, debug: bool = False, tuning: dict | None = None):
+    def __init__(self, index: Index, opts: Opts | None = None, max_pairs: int = 262144, debug: bool = False, tuning: dict | None = None, emit: int | None = None):
+        """emit: FQ_EMIT_* flags -- the consumers on the device (None: FASTQUICK_API_EMIT, which the test suite sets, so that every sam_text() of
+        every parity test also formats the text on the device and holds it to the host formatter's bytes)"""
         self.L = index.L
         self.index = index
         self.opts = opts or default_opts(self.L)
@@ -404,6 +415,9 @@ class Aligner:
         self._keep = None
         self._keep_packed = None
         self.result = ResultBatch()
+        self.emit = int(os.environ.get("FASTQUICK_API_EMIT", "0") or 0) if emit is None else int(emit)
+        if self.emit and self.L.fq_ctx_set_emit(self.h, self.emit):
+            raise FastquickError("fq_ctx_set_emit(%d) refused" % self.emit)
 
     def _batch(self, seq, qual, lens, names):
         seq = np.ascontiguousarray(seq, dtype=np.uint8)
@@ -488,7 +502,28 @@ class Aligner:
         return buf.raw[:n]
 
     def sam_text(self) -> bytes:
-        return self._text(self.L.fq_sam_format_last)
+        host = self._text(self.L.fq_sam_format_last)
+        if self.emit & EMIT_SAM:       # the same text formatted by the kernels of fq_emit.h: every caller checks both
+            dev = self.sam_text_device()
+            if dev != host:
+                at = next((i for i, (a, b) in enumerate(zip(dev, host)) if a != b), min(len(dev), len(host)))
+                raise FastquickError("SAM text formatted on the device differs from the host formatter's at byte %d of %d / %d: %r vs %r"
+                                     % (at, len(dev), len(host), dev[max(0, at - 60):at + 60], host[max(0, at - 60):at + 60]))
+        return host
+
+    def sam_text_device(self) -> bytes:
+        """the SAM text of the last call as the device formatted it (fq_ctx_set_emit(FQ_EMIT_SAM)), streamed off in slices"""
+        parts = []
+
+        def sink(_user, data, n):
+            parts.append(C.string_at(data, n))
+            return 0
+        n = self.L.fq_sam_device_last(self.h, SINK_FN(sink), None)
+        if n < 0:
+            raise FastquickError("fq_sam_device_last failed: %d (%s)" % (n, self.L.fq_ctx_last_error(self.h).decode()))
+        out = b"".join(parts)
+        assert len(out) == n == self.L.fq_sam_device_bytes(self.h)
+        return out
 
     def stage_text(self) -> bytes:
         return self._text(self.L.fq_stage_dump_last)

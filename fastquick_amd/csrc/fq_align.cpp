@@ -280,6 +280,24 @@ struct fq_ctx {
   DevBuf<FqSurvInfo> d_surv;
   DevBuf<int32_t> d_sub_max;
   int64_t n_bases_in = 0;
+  // the consumers on the device (fq_emit.h; fq_ctx_set_emit): compact qualities and names of the surviving reads where the input kind
+  // leaves them on the host, the SAM text of the last call
+  int emit_flags = 0;
+  DevBuf<uint8_t> d_equal; PinBuf<uint8_t> p_equal;
+  DevBuf<char> d_enames; PinBuf<char> p_enames;
+  DevBuf<uint32_t> d_samlen; DevBuf<uint64_t> d_samoff; DevBuf<char> d_samtext;
+  uint64_t sam_bytes = 0;
+  bool sam_ready = false;
+  fqdev::State *dev_emit = nullptr;    // the consumer side's own streams: the text leaves the device beside the next call
+  PinBuf<char> p_emit[2];
+  // ... StatCollector's part of a call (fq_ctx_attach_qc): per-call lists on the device, what comes back for the consumer's host side
+  fq_qc *qc = nullptr;
+  DevBuf<uint8_t> d_qadded;
+  DevBuf<uint32_t> d_istlen, d_ptcnt;
+  DevBuf<uint64_t> d_istoff, d_ptoff, d_qcnt, d_dupkey;
+  DevBuf<char> d_isttext; DevBuf<FqPileEntry> d_pile;
+  PinBuf<char> p_isttext; PinBuf<FqPileEntry> p_pile; PinBuf<uint64_t> p_qcnt, p_dupkey;
+  FqQcCallOut qc_out;
   // results of the last batch
   FqBatchState st;
   struct CallVecs {            // per-call host arrays of one entry per searched read: kept here so that a call reuses the last call's pages
@@ -343,7 +361,7 @@ extern "C" int fq_ctx_create(const fq_index_t *ix, const fq_opts_t *opts, int32_
   *out = c.release();
   return FQ_OK;
 }
-fq_ctx::~fq_ctx() { fqdev::state_destroy(dev); }   // synchronises the context's streams before the buffers below are freed
+fq_ctx::~fq_ctx() { if (dev_emit) fqdev::state_destroy(dev_emit); fqdev::state_destroy(dev); }   // synchronises the context's streams before the buffers below are freed
 extern "C" void fq_ctx_destroy(fq_ctx_t *c) { delete c; }
 
 extern "C" int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t v) {
@@ -682,6 +700,8 @@ struct Call {
   const uint8_t *dseq = nullptr;
   int dstride = 0;
   const int32_t *dlen_trim = nullptr, *dread_list = nullptr;
+  FqSamArgs emit{};                    // the consumers' view of the call (fq_emit.h), made once per call
+  bool emit_ready = false;
   vector<int> sub_max_len, sub_lo;
   // (the arrays of one entry per searched read live in the batch state and keep their pages)
   vector<uint64_t> &aln_off;           // per search index s: its hit list is S.aln[aln_off[s] .. + aln_n[s])
@@ -1921,6 +1941,136 @@ int snapshot_records(Call &K, vector<FqRead> &dst) {
   return FQ_OK;
 }
 
+// ---- the consumers on the device (fq_emit.h): the SAM text of the call, formatted from the result arrays where they lie ----------------
+// The reads' qualities and names are resident for a text batch (fq_align_text); for ASCII and packed batches the surviving reads' are gathered
+// on the host and uploaded compact (row = 2 * survivor + end).
+int emit_reads(Call &K, const uint8_t **qual, int *qual_stride, const char **names, int *name_stride) {
+  fq_ctx *c = K.c;
+  const size_t N = (size_t)K.n_surv * 2;
+  if (c->in_kind == 3) { *qual = c->d_pqual.p; *qual_stride = c->c_stride; *names = c->d_cnames.p; *name_stride = c->c_name_stride; return FQ_OK; }
+  const FqHostReads hb = fq_ctx_host_reads(c);
+  if (N && !hb.has_qual()) { c->err = "SAM text on the device: the batch carries no qualities"; return FQ_EINVAL; }
+  const int n = K.n;
+  const bool se = c->o.single_end != 0;
+  int max_len = 1, max_name = 1;
+  std::vector<int> tl((size_t)std::max(1, K.host_threads), 1), tn((size_t)std::max(1, K.host_threads), 1);
+  parallel_chunks(N, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int t) {
+    int ml = 1, mn = 1;
+    for (size_t i = lo; i < hi; ++i) {
+      const int e = (int)(i & 1), pair = c->h_pair_list[i >> 1];
+      if (se && e) continue;
+      ml = std::max(ml, hb.len((size_t)e * n + pair));
+      if (hb.has_names()) mn = std::max(mn, (int)strnlen(hb.name_of(pair, e), (size_t)hb.name_stride));
+    }
+    tl[(size_t)t] = ml; tn[(size_t)t] = mn;
+  });
+  for (size_t t = 0; t < tl.size(); ++t) { max_len = std::max(max_len, tl[t]); max_name = std::max(max_name, tn[t]); }
+  const int qs = (max_len + 15) & ~15, ns = (max_name + 1 + 7) & ~7;
+  CKM(c->p_equal.ensure(N * qs + 64) && c->d_equal.ensure(N * qs + 64) && c->p_enames.ensure(N * ns + 64) && c->d_enames.ensure(N * ns + 64));
+  parallel_chunks(N, K.host_threads, K.par_min, [&](size_t lo, size_t hi, int) {
+    for (size_t i = lo; i < hi; ++i) {
+      const int e = (int)(i & 1), pair = c->h_pair_list[i >> 1];
+      uint8_t *q = c->p_equal.p + i * (size_t)qs;
+      char *nm = c->p_enames.p + i * (size_t)ns;
+      memset(nm, 0, (size_t)ns);
+      if (se && e) { memset(q, 0, (size_t)qs); continue; }
+      const size_t r = (size_t)e * n + pair;
+      const int l = hb.len(r);
+      memcpy(q, hb.qual(r), (size_t)l);
+      memset(q + l, 0, (size_t)(qs - l));
+      if (hb.has_names()) { const char *src = hb.name_of(pair, e); memcpy(nm, src, strnlen(src, (size_t)hb.name_stride)); }
+      else nm[0] = '*';
+    }
+  });
+  CK(fqdev::copy_pinned(c->d_equal.p, c->p_equal.p, N * qs, 1));
+  CK(fqdev::copy_pinned(c->d_enames.p, c->p_enames.p, N * ns, 1));
+  c->stats.h2d_bytes += N * ((size_t)qs + (size_t)ns);
+  *qual = c->d_equal.p; *qual_stride = qs; *names = c->d_enames.p; *name_stride = ns;
+  return FQ_OK;
+}
+// the call's records, reads and names as the consumers' kernels see them (qualities and names uploaded once per call)
+int emit_args(Call &K, FqSamArgs &a) {
+  fq_ctx *c = K.c;
+  if (!K.emit_ready) {
+    FqSamArgs &e = K.emit;
+    e = FqSamArgs{};
+    e.cg = c->ix->dev_contigs;
+    e.n_surv = K.n_surv; e.n_pairs = K.n; e.packed = K.ra.packed; e.single_end = c->o.single_end; e.mode = c->o.mode; e.max_top2 = c->o.max_top2;
+    e.pair_list = c->d_pair_list.p;
+    e.rec = c->d_orec.p; e.cigar = c->d_ocig.p; e.md = c->d_omd.p; e.multi = c->d_omulti.p;
+    e.seq = K.ra.seq; e.stride = K.ra.stride;
+    CKS(emit_reads(K, &e.qual, &e.qual_stride, &e.names, &e.name_stride));
+    K.emit_ready = true;
+  }
+  a = K.emit;
+  return FQ_OK;
+}
+int stage_emit_sam(Call &K) {
+  fq_ctx *c = K.c;
+  const size_t N = (size_t)K.n_surv * 2;
+  c->sam_bytes = 0; c->sam_ready = false;
+  if (!N) { c->sam_ready = true; return FQ_OK; }
+  FqSamArgs a{};
+  CKS(emit_args(K, a));
+  CKM(c->d_samlen.ensure(N + 1) && c->d_samoff.ensure(N + 2));
+  a.len = c->d_samlen.p; a.off = c->d_samoff.p;
+  CK(fqdev::launch_sam(FQ_EOP_SAM_LEN, a, (int64_t)N));
+  CK(fqdev::launch_scan(c->d_samlen.p, c->d_samoff.p, (uint32_t)N));
+  uint64_t total = 0;
+  CKS(fetch_u64(c, &total, c->d_samoff.p + N));
+  CKS(sync_staged(c));
+  CKM(c->d_samtext.ensure(total + 64));
+  a.text = c->d_samtext.p;
+  CK(fqdev::launch_sam(FQ_EOP_SAM_FILL, a, (int64_t)N));
+  c->sam_bytes = total;
+  c->sam_ready = true;
+  K.trace("SAM text on the device");
+  return FQ_OK;
+}
+// StatCollector's part of the call (fq_emit.h): decisions per pair, the order-dependent outputs laid out in input order, the per-base sums
+// into the consumer's device tables.  What the consumer's host side needs lands in pinned memory (fq_ctx_qc_out).
+int stage_emit_qc(Call &K) {
+  fq_ctx *c = K.c;
+  const size_t N = (size_t)K.n_surv * 2, P = (size_t)K.n_surv;
+  FqQcCallOut &O = c->qc_out;
+  O = FqQcCallOut();
+  O.owner = c->qc; O.n_surv = K.n_surv;
+  if (!N) { O.ready = true; return FQ_OK; }
+  FqQcArgs a{};
+  CKS(emit_args(K, a.s));
+  a.ix = c->ix->dev;
+  { const int rc = fq_qc_device_prepare(c->qc, &a, K.n_surv); if (rc) { c->err = std::string("the QC consumer could not take the call: ") + fq_qc_last_error(c->qc); return rc; } }
+  const size_t NC = (size_t)FQ_C_STRIPES * FQ_C_STRIDE;
+  CKM(c->d_qadded.ensure(N + 1) && c->d_istlen.ensure(P + 1) && c->d_istoff.ensure(P + 2) && c->d_ptcnt.ensure(N + 1) && c->d_ptoff.ensure(N + 2) && c->d_qcnt.ensure(NC) && c->p_qcnt.ensure(NC));
+  if (a.shard) { CKM(c->d_dupkey.ensure(P + 1) && c->p_dupkey.ensure(P + 1)); }
+  CK(fqdev::dzero(c->d_qcnt.p, NC * 8));
+  a.counters = c->d_qcnt.p; a.added = c->d_qadded.p; a.ist_len = c->d_istlen.p; a.ist_off = c->d_istoff.p; a.pt_cnt = c->d_ptcnt.p; a.pt_off = c->d_ptoff.p;
+  a.dup_key = a.shard ? c->d_dupkey.p : nullptr;
+  CK(fqdev::launch_qc(FQ_QOP_PAIR, a, (int64_t)P));
+  CK(fqdev::launch_scan(c->d_istlen.p, c->d_istoff.p, (uint32_t)P));
+  CK(fqdev::launch_scan(c->d_ptcnt.p, c->d_ptoff.p, (uint32_t)N));
+  uint64_t ist_total = 0, pt_total = 0;
+  CKS(fetch_u64(c, &ist_total, c->d_istoff.p + P));
+  CKS(fetch_u64(c, &pt_total, c->d_ptoff.p + N));
+  CKS(sync_staged(c));
+  CKM(c->d_isttext.ensure(ist_total + 64) && c->p_isttext.ensure(ist_total + 64) && c->d_pile.ensure(pt_total + 1) && c->p_pile.ensure(pt_total + 1));
+  a.ist_text = c->d_isttext.p; a.pt = c->d_pile.p;
+  CK(fqdev::launch_qc(FQ_QOP_IST_FILL, a, (int64_t)P));
+  CK(fqdev::launch_qc(FQ_QOP_PILE_FILL, a, (int64_t)N));
+  CK(fqdev::launch_qc(FQ_QOP_BASE, a, (int64_t)N));
+  CK(fqdev::copy_pinned(c->p_isttext.p, c->d_isttext.p, ist_total, 0));
+  CK(fqdev::copy_pinned(c->p_pile.p, c->d_pile.p, pt_total * sizeof(FqPileEntry), 0));
+  CK(fqdev::copy_pinned(c->p_qcnt.p, c->d_qcnt.p, NC * 8, 0));
+  if (a.shard) CK(fqdev::copy_pinned(c->p_dupkey.p, c->d_dupkey.p, P * 8, 0));
+  c->stats.d2h_bytes += ist_total + pt_total * sizeof(FqPileEntry) + NC * 8 + (a.shard ? P * 8 : 0);
+  CKS(sync_staged(c));
+  for (int k = 0; k < FQ_QC_C_COUNT; ++k) { uint64_t v = 0; for (int st = 0; st < FQ_C_STRIPES; ++st) v += c->p_qcnt.p[(size_t)st * FQ_C_STRIDE + k]; O.cnt[k] = v; }
+  O.ist = c->p_isttext.p; O.ist_bytes = ist_total; O.pile = c->p_pile.p; O.n_pile = pt_total; O.dup_key = a.shard ? c->p_dupkey.p : nullptr;
+  O.ready = true;
+  K.trace("StatCollector on the device");
+  return FQ_OK;
+}
+
 // ---- the C-ABI result arrays (written on the device, landed in pinned host memory), the work counters ---------------------------
 int stage_finish(Call &K, fq_result_batch_t *out) {
   fq_ctx *c = K.c;
@@ -1947,6 +2097,8 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
   if (N) {
     A.o_rec = c->d_orec.p; A.o_cigar = c->d_ocig.p; A.o_md = c->d_omd.p; A.o_multi = c->d_omulti.p;
     REC(FQ_ROP_FLAT_FILL, N);
+    if (c->emit_flags & FQ_EMIT_SAM) CKS(stage_emit_sam(K));
+    if (c->qc) CKS(stage_emit_qc(K));
     CK(fqdev::copy_pinned(c->p_orec.p, c->d_orec.p, N * sizeof(fq_result_t), 0));
     CK(fqdev::copy_pinned(c->p_ocig.p, c->d_ocig.p, cc * 2, 0));
     CK(fqdev::copy_pinned(c->p_omd.p, c->d_omd.p, mm, 0));
@@ -1959,6 +2111,8 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
   CKS(sync_staged(c));
   fold_counters(c->h_counters.data(), cnt);
   CK(fqdev::dzero(c->d_counters.p, c->h_counters.size() * 8));
+  if (!N && (c->emit_flags & FQ_EMIT_SAM)) { c->sam_bytes = 0; c->sam_ready = true; }
+  if (!N && c->qc) { c->qc_out = FqQcCallOut(); c->qc_out.owner = c->qc; c->qc_out.ready = true; }
   if (!cc) c->p_ocig.p[0] = 0;
   if (!mm) c->p_omd.p[0] = 0;
   if (!xx) c->p_omulti.p[0] = fq_multi_t{};
@@ -2318,6 +2472,42 @@ extern "C" int fq_ctx_set_serial_hooks(fq_ctx_t *c, fq_serial_hook before, fq_se
   c->before_serial = before; c->after_serial = after; c->hook_user = user;
   return FQ_OK;
 }
+
+// ---- the consumers on the device ------------------------------------------------------------------------------------------------------
+extern "C" int fq_ctx_set_emit(fq_ctx_t *c, int32_t flags) {
+  if (!c || (flags & ~(FQ_EMIT_SAM))) return FQ_EINVAL;
+  c->emit_flags = flags;
+  return FQ_OK;
+}
+// The SAM text of the last call leaves the device in slices through two pinned buffers on streams of its own, so that it runs beside the
+// next call on another context: sink(user, data, bytes) gets the slices in order.
+extern "C" int64_t fq_sam_device_last(fq_ctx_t *c, fq_sink_fn sink, void *user) {
+  if (!c || !sink) return FQ_EINVAL;
+  if (!(c->emit_flags & FQ_EMIT_SAM) || !c->sam_ready) { c->err = "fq_sam_device_last: the last call did not format its SAM text on the device (fq_ctx_set_emit)"; return FQ_EINVAL; }
+  const uint64_t total = c->sam_bytes;
+  if (!total) return 0;
+  if (!c->dev_emit) c->dev_emit = fqdev::state_create(c->ix->device);
+  if (!c->dev_emit || fqdev::bind(c->dev_emit)) { c->err = std::string("fq_sam_device_last: ") + fqdev::last_error(); return FQ_ENODEV; }
+  const size_t SL = std::min<uint64_t>(total, (uint64_t)32 << 20);
+  if (!c->p_emit[0].ensure(SL) || !c->p_emit[1].ensure(SL)) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
+  const uint64_t n_sl = (total + SL - 1) / SL;
+  auto bytes_of = [&](uint64_t k) { return (size_t)std::min<uint64_t>(SL, total - k * SL); };
+  if (fqdev::copy_pinned(c->p_emit[0].p, c->d_samtext.p, bytes_of(0), 0) || fqdev::sync()) { c->err = std::string("fq_sam_device_last: ") + fqdev::last_error(); return FQ_ENODEV; }
+  for (uint64_t k = 0; k < n_sl; ++k) {
+    if (k + 1 < n_sl && fqdev::copy_pinned(c->p_emit[(k + 1) & 1].p, c->d_samtext.p + (k + 1) * SL, bytes_of(k + 1), 0)) { c->err = std::string("fq_sam_device_last: ") + fqdev::last_error(); return FQ_ENODEV; }
+    if (sink(user, c->p_emit[k & 1].p, (int64_t)bytes_of(k))) { (void)fqdev::sync(); c->err = "fq_sam_device_last: the sink failed"; return FQ_EIO; }
+    if (fqdev::sync()) { c->err = std::string("fq_sam_device_last: ") + fqdev::last_error(); return FQ_ENODEV; }
+  }
+  return (int64_t)total;
+}
+extern "C" int fq_ctx_attach_qc(fq_ctx_t *c, fq_qc_t *q) {
+  if (!c) return FQ_EINVAL;
+  c->qc = q;
+  c->qc_out = FqQcCallOut();
+  return FQ_OK;
+}
+const FqQcCallOut *fq_ctx_qc_out(const fq_ctx_t *c) { return c->qc ? &c->qc_out : nullptr; }
+extern "C" int64_t fq_sam_device_bytes(const fq_ctx_t *c) { return c && (c->emit_flags & FQ_EMIT_SAM) && c->sam_ready ? (int64_t)c->sam_bytes : FQ_EINVAL; }
 
 extern "C" int fq_ctx_set_debug(fq_ctx_t *c, int keep_stage_snapshots) {
   if (!c) return FQ_EINVAL;

@@ -5,6 +5,7 @@
 #include "fq_kernels.h"
 #include "fq_records.h"
 #include "fq_frontend.h"
+#include "fq_emit.h"
 
 namespace fqdev {
 
@@ -103,6 +104,12 @@ int launch_collect(const int32_t *order, const uint32_t *split, int n_work, int 
 int launch_rec(int op, const FqRecArgs &a, int64_t n);
 // by search index: aoff[work[w]] = base + off[w], an[work[w]] = naln[w] for the work items of a launch that completed (status 0)
 int launch_aln_index(const int32_t *work, const uint32_t *status, const uint64_t *off, const uint32_t *naln, uint64_t base, uint64_t *aoff, uint32_t *an, int n);
+// the consumers on the device (fq_emit.h): SAM text -- operation FQ_EOP_SAM_*, one thread per record
+int launch_sam(int op, const FqSamArgs &a, int64_t n);
+// ... StatCollector's part -- operation FQ_QOP_*: a thread per pair (PAIR, IST_FILL) or per record (PILE_FILL); BASE: a wavefront per record,
+// the quality / cycle histograms of a workgroup in LDS
+int launch_qc(int op, const FqQcArgs &a, int64_t n);
+int launch_dup_rehash(const uint64_t *old, uint64_t old_cap, uint64_t *tab, uint64_t mask);   // every key of `old` into `tab` (filled with FQ_QC_DUP_EMPTY)
 int launch_sw(const FqSwArgs &a);          // one task per wavefront (window + query in LDS)
 int launch_sw_serial(const FqSwArgs &a);   // one task per lane out of the task's global scratch: any window size
 int launch_refine(const FqRefineArgs &a);

@@ -53,6 +53,17 @@ struct FqDevIndex {
   const uint8_t *bitmap[6];
 };
 
+// the contigs of the reduced reference (bntseq_t::anns, libbwa/bntseq.h) and its N holes, resident beside the index
+struct FqDevContigs {
+  int32_t n, n_holes;
+  const int64_t *off;          // [n] offset in the concatenated reference
+  const int32_t *len;          // [n]
+  const uint32_t *name_off;    // [n + 1] into names
+  const char *names;
+  const int64_t *hole_off;     // [n_holes]
+  const int32_t *hole_len;
+};
+
 // option block passed by value to kernels
 struct FqKOpts {
   int32_t s_mm, s_gapo, s_gape, mode;

@@ -1558,6 +1558,75 @@ int launch_rec(int op, const FqRecArgs &a, int64_t n) {
   FQ_HIP(hipGetLastError());
   return 0;
 }
+// ---- the consumers on the device (fq_emit.h) ----
+__global__ void __launch_bounds__(256) k_sam_len(FqSamArgs a, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) fq_sam_len_thread(a, i);
+}
+__global__ void __launch_bounds__(256) k_sam_fill(FqSamArgs a, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) fq_sam_fill_thread(a, i);
+}
+int launch_sam(int op, const FqSamArgs &a, int64_t n) {
+  FQ_PRE();
+  if (n <= 0) return 0;
+  if (n > 0x7fffffff) { g_err = "SAM text: more than 2^31 records"; return -5; }
+  hipEvent_t e0, e1;
+  kernel_events(FQ_K_EMIT, &e0, &e1);
+  if (op == FQ_EOP_SAM_LEN) hipExtLaunchKernelGGL(k_sam_len, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
+  else if (op == FQ_EOP_SAM_FILL) hipExtLaunchKernelGGL(k_sam_fill, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
+  else { g_err = "SAM text: unknown operation"; return -1; }
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+__global__ void __launch_bounds__(256) k_qc_pair(FqQcArgs a, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) fq_qc_pair_thread(a, i);
+}
+__global__ void __launch_bounds__(256) k_qc_ist_fill(FqQcArgs a, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) fq_qc_ist_fill_thread(a, i);
+}
+__global__ void __launch_bounds__(256) k_qc_pile_fill(FqQcArgs a, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) fq_qc_pile_fill_thread(a, i);
+}
+// a wavefront per record, resident workgroups walking the records: 64 consecutive positions of a read are one atomic instruction on the depth
+// tables; the quality / cycle histograms are kept per workgroup in LDS and reach the consumer's once, at the end
+__global__ void __launch_bounds__(256) k_qc_base(FqQcArgs a, int n) {
+  __shared__ uint32_t hist[4 * 256];
+  for (int b = threadIdx.x; b < 4 * 256; b += 256) hist[b] = 0;
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (gridDim.x * 256) >> 6;
+  for (int idx = wave; idx < n; idx += n_waves) fq_qc_base_record(a, idx, lane, 64, hist);
+  __syncthreads();
+  for (int b = threadIdx.x; b < 4 * 256; b += 256) if (hist[b]) atomicAdd((unsigned long long *)&a.hist[b], (unsigned long long)hist[b]);
+}
+__global__ void __launch_bounds__(256) k_dup_rehash(const uint64_t *old, uint64_t n, uint64_t *tab, uint64_t mask) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) fq_dupset_rehash_thread(old, tab, mask, (int64_t)i);
+}
+int launch_qc(int op, const FqQcArgs &a, int64_t n) {
+  FQ_PRE();
+  if (n <= 0) return 0;
+  if (n > 0x7fffffff) { g_err = "statistics: more than 2^31 records"; return -5; }
+  hipEvent_t e0, e1;
+  kernel_events(FQ_K_EMIT, &e0, &e1);
+  if (op == FQ_QOP_PAIR) hipExtLaunchKernelGGL(k_qc_pair, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
+  else if (op == FQ_QOP_IST_FILL) hipExtLaunchKernelGGL(k_qc_ist_fill, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
+  else if (op == FQ_QOP_PILE_FILL) hipExtLaunchKernelGGL(k_qc_pile_fill, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
+  else if (op == FQ_QOP_BASE) hipExtLaunchKernelGGL(k_qc_base, dim3(std::min<unsigned>(nblk((uint64_t)n, 4), 256u * 8u)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
+  else { g_err = "statistics: unknown operation"; return -1; }
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+int launch_dup_rehash(const uint64_t *old, uint64_t old_cap, uint64_t *tab, uint64_t mask) {
+  FQ_PRE();
+  if (!old_cap) return 0;
+  hipLaunchKernelGGL(k_dup_rehash, dim3(nblk(old_cap, 256)), dim3(256), 0, g_stream, old, old_cap, tab, mask);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
 __global__ void __launch_bounds__(256) k_aln_index(const int32_t *work, const uint32_t *status, const uint64_t *off, const uint32_t *naln, uint64_t base, uint64_t *aoff, uint32_t *an, int n) {
   const int w = blockIdx.x * blockDim.x + threadIdx.x;
   if (w < n) fq_aln_index_thread(work, status, off, naln, base, aoff, an, w);

@@ -485,6 +485,28 @@ extern "C" int fq_index_load(const char *prefix_c, int device_ordinal, fq_index_
   if (fqdev::h2d(ix->d_pac, ix->pac.data(), ix->pac.size()) || fqdev::sync()) return fail(FQ_ENODEV);
   ix->dev.pac = (const uint8_t *)ix->d_pac;
   ix->dev.l_pac = ix->l_pac;
+  {   // the contig table and the N holes, for the consumers on the device (fq_emit.h)
+    const size_t nc = ix->contigs.size(), nh = ix->holes.size();
+    std::vector<int64_t> off(nc), hoff(nh + 1, 0);
+    std::vector<int32_t> len(nc), hlen(nh + 1, 0);
+    std::vector<uint32_t> noff(nc + 1, 0);
+    std::string names;
+    for (size_t i = 0; i < nc; ++i) { off[i] = ix->contigs[i].offset; len[i] = ix->contigs[i].len; noff[i] = (uint32_t)names.size(); names += ix->contigs[i].name; }
+    noff[nc] = (uint32_t)names.size();
+    names.push_back(0);
+    for (size_t i = 0; i < nh; ++i) { hoff[i] = ix->holes[i].offset; hlen[i] = ix->holes[i].len; }
+    auto up = [&](const void *src, size_t bytes) -> void * {
+      void *d = fqdev::dmalloc(bytes ? bytes : 16);
+      if (d) { ix->load_scratch.push_back(d); if (bytes && fqdev::h2d(d, src, bytes)) return nullptr; }
+      return d;
+    };
+    FqDevContigs &C = ix->dev_contigs;
+    C.n = (int32_t)nc; C.n_holes = (int32_t)nh;
+    C.off = (const int64_t *)up(off.data(), nc * 8); C.len = (const int32_t *)up(len.data(), nc * 4);
+    C.name_off = (const uint32_t *)up(noff.data(), (nc + 1) * 4); C.names = (const char *)up(names.data(), names.size());
+    C.hole_off = (const int64_t *)up(hoff.data(), (nh + 1) * 8); C.hole_len = (const int32_t *)up(hlen.data(), (nh + 1) * 4);
+    if (!C.off || !C.len || !C.name_off || !C.names || !C.hole_off || !C.hole_len || fqdev::sync()) return fail(FQ_ENODEV);
+  }
   mark("FM index, SA, pac staged");
   // ---- six 2^32-bit filter tables, contiguous in HBM (3 GiB)
   const size_t TB = (size_t)1 << 29;

@@ -28,6 +28,7 @@ struct fq_index {
   std::vector<uint8_t> pac;
   // device
   FqDevIndex dev{};
+  FqDevContigs dev_contigs{};   // contig table and N holes in HBM (the consumers on the device: fq_emit.h)
   std::vector<void *> load_scratch;   // small device buffers of the load, freed with the index (hipFree waits for the device)
   void *load_state = nullptr;   // the load's device state (fqdev::State): given back with the index -- destroying it frees device memory, which waits for
                                 // every stream of the device, and the load runs beside the first chunk's kernels

@@ -11,6 +11,7 @@
 #include "../../include/fastquick_amd.h"
 #include "fq_kernels.h"
 #include "fq_records.h"
+#include "fq_emit.h"
 
 struct FqMulti {             // bwt_multi1_t as the consumers read it
   uint32_t pos = 0;
@@ -141,6 +142,20 @@ struct FqHostReads {
   }
 };
 FqHostReads fq_ctx_host_reads(const fq_ctx_t *c);
+// What a call that counted on the device (fq_ctx_attach_qc) leaves for the consumer's host side: the order-dependent outputs in input order,
+// the call's counters.  NULL: the context has no consumer attached.
+struct fq_qc;
+struct FqQcCallOut {
+  const fq_qc *owner = nullptr;
+  bool ready = false;
+  const char *ist = nullptr; uint64_t ist_bytes = 0;           // .InsertSizeTable lines
+  const FqPileEntry *pile = nullptr; uint64_t n_pile = 0;      // pileup entries of the markers
+  const uint64_t *dup_key = nullptr;                           // [n_surv] duplicate keys of a shard consumer's pairs (~0: none), else NULL
+  int n_surv = 0;
+  uint64_t cnt[FQ_QC_C_COUNT] = {};
+};
+const FqQcCallOut *fq_ctx_qc_out(const fq_ctx_t *c);
+int fq_qc_device_prepare(fq_qc *q, FqQcArgs *a, int n_surv);
 int64_t fq_ctx_last_bases(const fq_ctx_t *c);   // sum of the read lengths of the last batch (NumBase increment)
 // the name a record prints under (fq_sam.cpp): `/1` `/2` stripped, a revived mate under its partner's name
 std::string fq_read_name(const FqHostReads *hb, int pair, int end, bool revived);

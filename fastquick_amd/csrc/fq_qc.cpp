@@ -29,6 +29,8 @@
 #include "fq_kernels.h"
 #include "fq_pipeline.h"
 #include "fq_pool.h"
+#include "fq_backend.h"
+#include <mutex>
 
 namespace {
 const int kInsertLimit = 4096;                 // INSERT_SIZE_LIMIT
@@ -185,6 +187,22 @@ struct fq_qc {
   }
   std::string out_prefix;
   std::ofstream table;
+  // ---- the consumer's tables on the device (fq_emit.h): set up by the first call of a context this consumer is attached to (fq_ctx_attach_qc);
+  //      the sums stay there until pull() adds them to the tables above (fq_qc_write, fq_qc_state_export)
+  std::mutex dev_mu;
+  bool dev_on = false;
+  bool device_adds = false, host_adds = false;    // a consumer counts its records on one side only (the duplicate set lives there)
+  fqdev::State *dev = nullptr;                     // this object's own streams: pull / reset from any thread
+  std::vector<void *> d_bufs;                      // geometry
+  FqQcGeom geom{};
+  size_t table_size = 0, n_contigs = 0;
+  uint32_t *d_depth = nullptr, *d_q20 = nullptr, *d_q30 = nullptr, *d_sex_cnt = nullptr;
+  uint64_t *d_hist = nullptr, *d_insert = nullptr, *d_sex_first = nullptr, *d_dup = nullptr;
+  uint64_t dup_cap = 0, ord_next = 0;
+  int device_setup();
+  int pull();                                      // device sums -> host tables; the device tables start again from zero
+  int bind_own();
+  ~fq_qc() { if (dev_on || dev) { if (!bind_own()) { for (void *b : d_bufs) fqdev::dfree(b); for (void *b : {(void *)d_depth, (void *)d_q20, (void *)d_q30, (void *)d_sex_cnt, (void *)d_hist, (void *)d_insert, (void *)d_sex_first, (void *)d_dup}) fqdev::dfree(b); } if (dev) fqdev::state_destroy(dev); } }
 
   int restore(const std::string &ref_prefix);
   bool add_single(const Rec &p, const FqHostReads &hb);
@@ -532,6 +550,141 @@ int fq_qc::add_alignment(Rec &P, Rec &Q, const FqHostReads &hb, long long &faile
   return 0;
 }
 
+// ---- the device side ---------------------------------------------------------------------------------------------------------
+int fq_qc::bind_own() {
+  if (!dev) dev = fqdev::state_create(ix->device);
+  if (!dev || fqdev::bind(dev)) { err = std::string("QC consumer: no device state: ") + fqdev::last_error(); return FQ_ENODEV; }
+  return FQ_OK;
+}
+// RestoreVcfSites' tables flattened for the kernels (FqQcGeom), the sums zeroed.  Runs on the calling context's bound state.
+int fq_qc::device_setup() {
+  if (dev_on) return FQ_OK;
+  const size_t nc = ix->contigs.size();
+  n_contigs = nc;
+  std::vector<std::string> chroms;                  // the chromosomes of the flank regions (the markers' chromosomes: the same keys)
+  std::map<std::string, int> chrom_id;
+  for (const auto &kv : flank_idx) { chrom_id[kv.first] = (int)chroms.size(); chroms.push_back(kv.first); }
+  for (const auto &kv : vcf_table) if (!chrom_id.count(kv.first)) { chrom_id[kv.first] = (int)chroms.size(); chroms.push_back(kv.first); }
+  std::vector<int32_t> ctg_chrom(nc), ctg_g0(nc), chr_reg0(chroms.size() + 1, 0), reg_start, reg_end, chr_mk0(chroms.size() + 1, 0), mk_pos;
+  std::vector<uint8_t> ctg_sex(nc);
+  std::vector<uint32_t> reg_base, mk_idx;
+  for (size_t i = 0; i < nc; ++i) {
+    const std::string &nm = ix->contigs[i].name;
+    ctg_sex[i] = nm.find('Y') != std::string::npos || nm.find('X') != std::string::npos;
+    const size_t colon = nm.find(':');
+    if (colon == std::string::npos) { ctg_chrom[i] = -2; ctg_g0[i] = 0; continue; }
+    const size_t at = nm.find('@');
+    const int refCoord = (int)strtol(nm.substr(colon + 1, at - colon + 1).c_str(), nullptr, 10);     // read_geom
+    const int fl = nm[nm.size() - 1] == 'L' ? o.flank_long_len : o.flank_len;
+    ctg_g0[i] = refCoord - fl;
+    auto it = chrom_id.find(chrom_key(nm.substr(0, colon)));
+    ctg_chrom[i] = it == chrom_id.end() ? -1 : it->second;
+  }
+  for (size_t c = 0; c < chroms.size(); ++c) {
+    chr_reg0[c] = (int32_t)reg_start.size();
+    auto fi = flank_idx.find(chroms[c]);
+    if (fi != flank_idx.end()) for (const auto &r : fi->second) { reg_start.push_back(r.first); reg_end.push_back(r.second.first); reg_base.push_back((uint32_t)r.second.second); }
+    chr_mk0[c] = (int32_t)mk_pos.size();
+    auto vi = vcf_table.find(chroms[c]);
+    if (vi != vcf_table.end()) for (const auto &m : vi->second) { mk_pos.push_back(m.first); mk_idx.push_back(m.second); }
+  }
+  chr_reg0[chroms.size()] = (int32_t)reg_start.size(); chr_mk0[chroms.size()] = (int32_t)mk_pos.size();
+  table_size = depth.size();
+  std::vector<uint8_t> db(table_size + 1, 0);
+  for (const auto &kv : flank_idx) {                 // the known variant sites that lie in a flank region (the only positions the statistics look at)
+    auto di = dbsnp.find(kv.first);
+    if (di == dbsnp.end()) continue;
+    for (const auto &site : di->second) {
+      auto r = kv.second.upper_bound(site.first);
+      if (r == kv.second.begin()) continue;
+      --r;
+      if (site.first >= r->first && site.first <= r->second.first) db[r->second.second + (size_t)(site.first - r->first)] = 1;
+    }
+  }
+  bool ok = true;
+  auto up = [&](const void *src, size_t bytes) -> void * {
+    void *d = fqdev::dmalloc(bytes ? bytes : 16);
+    if (!d) { ok = false; return nullptr; }
+    d_bufs.push_back(d);
+    if (bytes && fqdev::h2d(d, src, bytes)) ok = false;
+    return d;
+  };
+  geom.ctg_chrom = (const int32_t *)up(ctg_chrom.data(), nc * 4); geom.ctg_g0 = (const int32_t *)up(ctg_g0.data(), nc * 4); geom.ctg_sex = (const uint8_t *)up(ctg_sex.data(), nc);
+  geom.chr_reg0 = (const int32_t *)up(chr_reg0.data(), chr_reg0.size() * 4); geom.reg_start = (const int32_t *)up(reg_start.data(), reg_start.size() * 4);
+  geom.reg_end = (const int32_t *)up(reg_end.data(), reg_end.size() * 4); geom.reg_base = (const uint32_t *)up(reg_base.data(), reg_base.size() * 4);
+  geom.chr_mk0 = (const int32_t *)up(chr_mk0.data(), chr_mk0.size() * 4); geom.mk_pos = (const int32_t *)up(mk_pos.data(), mk_pos.size() * 4);
+  geom.mk_idx = (const uint32_t *)up(mk_idx.data(), mk_idx.size() * 4); geom.dbsnp = (const uint8_t *)up(db.data(), db.size());
+  auto zeroed = [&](size_t bytes, int fill) -> void * {
+    void *d = fqdev::dmalloc(bytes ? bytes : 16);
+    if (!d) { ok = false; return nullptr; }
+    if (fqdev::dfill(d, fill, bytes ? bytes : 16)) ok = false;
+    return d;
+  };
+  d_depth = (uint32_t *)zeroed((table_size + 1) * 4, 0); d_q20 = (uint32_t *)zeroed((table_size + 1) * 4, 0); d_q30 = (uint32_t *)zeroed((table_size + 1) * 4, 0);
+  d_hist = (uint64_t *)zeroed(4 * 256 * 8, 0); d_insert = (uint64_t *)zeroed((size_t)kInsertLimit * 8, 0);
+  d_sex_cnt = (uint32_t *)zeroed((nc + 1) * 4 * 4, 0); d_sex_first = (uint64_t *)zeroed((nc + 1) * 8, 0xff);
+  if (!ok || fqdev::sync()) { err = std::string("QC consumer: staging its tables on the device failed: ") + fqdev::last_error(); return FQ_ENODEV; }
+  dev_on = true;
+  return FQ_OK;
+}
+// The consumer's part of a call's kernel arguments, on the calling context's bound state: tables, geometry, where this call's pairs stand in the
+// input; the duplicate set is grown to hold the call's pairs (calls on contexts that share a consumer must not overlap: the command line's do not).
+int fq_qc_device_prepare(fq_qc *q, FqQcArgs *a, int n_surv) {
+  std::lock_guard<std::mutex> lk(q->dev_mu);
+  if (q->host_adds) { q->err = "QC consumer: records were added on the host before (fq_qc_add_last without fq_ctx_attach_qc): a consumer counts on one side only"; return FQ_EINVAL; }
+  int rc = q->device_setup();
+  if (rc) return rc;
+  q->device_adds = true;
+  if (!q->shard) {
+    const uint64_t need = 2 * (q->ord_next + (uint64_t)n_surv) + 1024;
+    if (need > q->dup_cap) {
+      uint64_t cap = 1 << 16;
+      while (cap < 2 * need) cap <<= 1;
+      uint64_t *tab = (uint64_t *)fqdev::dmalloc(cap * 8);
+      if (!tab) { q->err = "QC consumer: out of device memory for the duplicate set"; return FQ_ENOMEM; }
+      if (fqdev::dfill(tab, 0xff, cap * 8) || fqdev::launch_dup_rehash(q->d_dup, q->dup_cap, tab, cap - 1) || fqdev::sync()) { fqdev::dfree(tab); q->err = std::string("QC consumer: growing the duplicate set failed: ") + fqdev::last_error(); return FQ_ENODEV; }
+      fqdev::dfree(q->d_dup);
+      q->d_dup = tab; q->dup_cap = cap;
+    }
+  }
+  a->g = q->geom;
+  a->cal_dup = q->o.cal_dup; a->shard = q->shard ? 1 : 0;
+  a->ord_base = q->ord_next;
+  q->ord_next += (uint64_t)n_surv;
+  a->depth = q->d_depth; a->q20 = q->d_q20; a->q30 = q->d_q30; a->hist = q->d_hist; a->insert_dist = q->d_insert;
+  a->sex_cnt = q->d_sex_cnt; a->sex_first = q->d_sex_first;
+  a->dup_tab = q->d_dup; a->dup_mask = q->dup_cap ? q->dup_cap - 1 : 0;
+  return FQ_OK;
+}
+// what the device has summed since the last pull, added to the host's tables
+int fq_qc::pull() {
+  std::lock_guard<std::mutex> lk(dev_mu);
+  if (!dev_on) return FQ_OK;
+  int rc = bind_own();
+  if (rc) return rc;
+  const size_t T = table_size, nc = n_contigs;
+  std::vector<uint32_t> d(T + 1), a(T + 1), b(T + 1), sc((nc + 1) * 4);
+  std::vector<uint64_t> hist(4 * 256), ins((size_t)kInsertLimit), first(nc + 1);
+  if (fqdev::d2h(d.data(), d_depth, (T + 1) * 4) || fqdev::d2h(a.data(), d_q20, (T + 1) * 4) || fqdev::d2h(b.data(), d_q30, (T + 1) * 4) || fqdev::d2h(hist.data(), d_hist, hist.size() * 8) ||
+      fqdev::d2h(ins.data(), d_insert, ins.size() * 8) || fqdev::d2h(sc.data(), d_sex_cnt, sc.size() * 4) || fqdev::d2h(first.data(), d_sex_first, first.size() * 8) || fqdev::sync() ||
+      fqdev::dzero(d_depth, (T + 1) * 4) || fqdev::dzero(d_q20, (T + 1) * 4) || fqdev::dzero(d_q30, (T + 1) * 4) || fqdev::dzero(d_hist, hist.size() * 8) || fqdev::dzero(d_insert, ins.size() * 8) ||
+      fqdev::dzero(d_sex_cnt, sc.size() * 4) || fqdev::dfill(d_sex_first, 0xff, first.size() * 8) || fqdev::sync()) {
+    err = std::string("QC consumer: reading its tables back failed: ") + fqdev::last_error();
+    return FQ_ENODEV;
+  }
+  for (size_t k = 0; k < T; ++k) { depth[k] += d[k]; q20[k] += a[k]; q30[k] += b[k]; }
+  for (int v = 0; v < 256; ++v) { EmpRep[v] += hist[v]; misEmpRep[v] += hist[256 + v]; EmpCycle[v] += hist[512 + v]; misEmpCycle[v] += hist[768 + v]; }
+  for (int v = 0; v < kInsertLimit; ++v) InsertDist[v] += ins[v];
+  std::vector<std::pair<uint64_t, size_t>> order;     // sex-chromosome contigs in the order of their first count
+  for (size_t c = 0; c < nc; ++c) if (first[c] != ~0ull) order.emplace_back(first[c], c);
+  std::sort(order.begin(), order.end());
+  for (const auto &oc : order) {
+    ContigStatus &st = cs(ix->contigs[oc.second].name);
+    st.overlapped += (int)sc[oc.second * 4]; st.fully += (int)sc[oc.second * 4 + 1]; st.pair_overlapped += (int)sc[oc.second * 4 + 2]; st.fully_paired += (int)sc[oc.second * 4 + 3];
+  }
+  return FQ_OK;
+}
+
 // ---- C ABI ------------------------------------------------------------------------------------------------------------------
 extern "C" void fq_qc_default_opts(fq_qc_opts_t *o) {
   memset(o, 0, sizeof *o);
@@ -600,6 +753,37 @@ extern "C" int fq_qc_add_last(fq_qc_t *q, fq_ctx_t *c) {
   F.NumBase += fq_ctx_last_bases(c);
   F.NumRead += (ao->single_end ? 1LL : 2LL) * S->n_pairs;
   F.TotalFiltered += S->n_pairs - S->n_surv;
+  if (const FqQcCallOut *D = fq_ctx_qc_out(c)) {
+    // the call counted on the device (fq_ctx_attach_qc): the sums are in the consumer's device tables; what depends on the order of the
+    // records came back laid out in input order and is appended here
+    if (D->owner != q || !D->ready) { q->err = "fq_qc_add_last: the context's last call counted for another consumer, or failed"; return FQ_EINVAL; }
+    F.BwaUnmapped += (long long)D->cnt[FQ_QC_C_UNMAPPED];
+    F.TotalRetained += (long long)(D->cnt[FQ_QC_C_RETAINED1] + 2 * D->cnt[FQ_QC_C_RETAINED2]);
+    F.TotalMAPQ += (long long)(D->cnt[FQ_QC_C_FAILED1] + 2 * D->cnt[FQ_QC_C_FAILED2]);
+    q->NumPairReads += 2 * D->cnt[FQ_QC_C_PROPER];
+    q->NumPCRDup += 2 * D->cnt[FQ_QC_C_DUP];
+    if (D->ist_bytes) q->table.write(D->ist, (std::streamsize)D->ist_bytes);
+    for (uint64_t t = 0; t < D->n_pile; ++t) {
+      const FqPileEntry &e = D->pile[t];
+      q->seq_vec[e.k] += (char)e.base; q->qual_vec[e.k] += (char)e.qual;
+      q->cycle_vec[e.k].push_back(e.cyc); q->maq_vec[e.k].push_back(e.maq); q->strand_vec[e.k].push_back(e.strand != 0);
+    }
+    if (q->shard && D->dup_key) {
+      char key[64];
+      for (int sp = 0; sp < D->n_surv; ++sp) {
+        const uint64_t k = D->dup_key[sp];
+        if (k == FQ_QC_DUP_EMPTY) continue;
+        int contig = 0;
+        fq_coor_pac2real(q->ix, (int64_t)(k >> 32), 1, &contig);      // (a proper pair's outer ends lie inside its contig)
+        snprintf(key, sizeof key, "%d:%d:%d", contig, (int)(uint32_t)(k >> 32), (int)(uint32_t)k);
+        q->dup_log.emplace_back(key);
+      }
+    }
+    return FQ_OK;
+  }
+  if (q->device_adds) { q->err = "fq_qc_add_last: this consumer counts on the device (fq_ctx_attach_qc); a batch of a context without it cannot be mixed in"; return FQ_EINVAL; }
+  q->host_adds = true;
+  if (S->n_surv > 0 && !S->rec) { q->err = "fq_qc_add_last: the call's result arrays were left on the device"; return FQ_EINVAL; }
   // the batch's records in the host's vocabulary, from the C-ABI arrays (all threads); they live until the per-base statistics have run
   std::vector<FqRead> recs((size_t)S->n_surv * 2);
   {
@@ -630,6 +814,7 @@ extern "C" int fq_qc_add_last(fq_qc_t *q, fq_ctx_t *c) {
 // ProcessCore, :2012-2028
 extern "C" int fq_qc_write(fq_qc_t *q) {
   if (!q) return FQ_EINVAL;
+  if (int rc = q->pull()) return rc;
   q->table.flush();
   const std::string &pre = q->out_prefix;
   {   // GetDepthDist, :1858-1918
@@ -903,6 +1088,7 @@ void add_file(FileStat &a, const FileStat &b) { a.NumRead += b.NumRead; a.NumBas
 
 extern "C" int fq_qc_state_reset(fq_qc_t *q) {
   if (!q) return FQ_EINVAL;
+  if (int rc = q->pull()) return rc;       // (what the device holds is dropped with the rest: pulled into the tables that are cleared below)
   q->shard = true;
   std::fill(q->depth.begin(), q->depth.end(), 0u); std::fill(q->q20.begin(), q->q20.end(), 0u); std::fill(q->q30.begin(), q->q30.end(), 0u);
   for (auto *v : {&q->EmpRep, &q->misEmpRep, &q->EmpCycle, &q->misEmpCycle, &q->InsertDist, &q->CycleDist}) std::fill(v->begin(), v->end(), (size_t)0);
@@ -920,6 +1106,7 @@ extern "C" int fq_qc_state_reset(fq_qc_t *q) {
 extern "C" int64_t fq_qc_state_export(fq_qc_t *q, void *buf, int64_t cap) {
   if (!q) return FQ_EINVAL;
   if (!q->shard) { q->err = "fq_qc_state_export: not a shard consumer (call fq_qc_state_reset before its first batch)"; return FQ_EINVAL; }
+  if (int rc = q->pull()) return rc;
   Out o;
   o.put(kStateMagic);
   o.put<int32_t>(q->o.mode);

@@ -414,6 +414,15 @@ int fq_qc_write(fq_qc_t *q);                   /* ProcessCore: writes the files 
 int fq_qc_state_reset(fq_qc_t *q);
 int64_t fq_qc_state_export(fq_qc_t *q, void *buf, int64_t cap);
 int fq_qc_merge(fq_qc_t *q, const void *buf, int64_t len);
+/* StatCollector on the device (fq_emit.h).  A context with a consumer attached counts every call inside the call, on the result arrays where
+ * they lie: a thread per pair decides what AddAlignment decides (src/StatCollector.cpp:950-1101) and measures the pair's .InsertSizeTable line and
+ * its pileup entries; prefix sums place them in input order; a wavefront per added read adds its bases to the depth / Q20 / Q30 tables of the
+ * flank regions and to the quality / cycle histograms (AddSingleAlignment, :424-620), which stay in HBM until fq_qc_write / fq_qc_state_export
+ * fetch them; proper pairs' duplicate keys go into a hash set in HBM (ProcessPairStatus, :623-921).  fq_qc_add_last(q, c) then only appends what
+ * came back in input order (lines, pileup entries) and adds the call's counters.  The files are the host path's byte for byte.  A consumer
+ * counts on one side only: every context that feeds it must have it attached (or none); calls of contexts that share a consumer must not
+ * overlap.  q = NULL detaches. */
+int fq_ctx_attach_qc(fq_ctx_t *c, fq_qc_t *q);
 
 /* ---- BAM consumer ---------------------------------------------------------------------------------------------------------
  * BwtMapper::SetSamRecord / SetSamFileHeader (src/BwtMapper.cpp:947-1264) as a BAM file (own BGZF layer): genome coordinates
@@ -428,6 +437,20 @@ int fq_bam_add_last(fq_bam_t *b, fq_ctx_t *c);   /* the records of the context's
 int fq_bam_format_last(fq_bam_t *b, fq_ctx_t *c, const void **data, int64_t *len);
 int fq_bam_write_records(fq_bam_t *b, const void *data, int64_t len);
 int fq_bam_close(fq_bam_t *b);                   /* writes the BGZF end-of-file block, closes and frees */
+
+/* ---- the consumers on the device ---------------------------------------------------------------
+ * The reference hands every record to its consumers on its main thread, one after the other (src/BwtMapper.cpp:2030-2085): bwa_print_sam1
+ * (libbwa/bwase.c:455-581) formats one line at a time.  Here the result arrays of a call are resident in HBM when the call ends, and the
+ * consumers may run there: with FQ_EMIT_SAM the SAM text of a call (the --sam_out dialect, byte for byte what fq_sam_format_last returns) is
+ * formatted by kernels inside the call -- a thread per record measures its line, a prefix sum places the lines, a thread per record writes --
+ * and stays on the device until the next call on the context.  fq_sam_device_last streams it to `sink` in slices, in order, over streams of
+ * its own (it may run on another thread beside the next call on ANOTHER context); returns the bytes handed over or a negative code.
+ * fq_sam_device_bytes: the size of that text. */
+#define FQ_EMIT_SAM 1
+typedef int (*fq_sink_fn)(void *user, const void *data, int64_t bytes);   /* 0: go on; anything else ends the stream with FQ_EIO */
+int fq_ctx_set_emit(fq_ctx_t *c, int32_t flags);
+int64_t fq_sam_device_last(fq_ctx_t *c, fq_sink_fn sink, void *user);
+int64_t fq_sam_device_bytes(const fq_ctx_t *c);
 
 /* ---- measurement -------------------------------------------------------------------------
  * Per-kernel device time (HIP events on the context's stream) and algorithmic work counters
@@ -447,7 +470,8 @@ int fq_bam_close(fq_bam_t *b);                   /* writes the BGZF end-of-file 
 #define FQ_K_REFINE_KERNEL 12 /* the banded global DP kernels */
 #define FQ_K_MD_KERNEL 13    /* MD / NM of every mapped read */
 #define FQ_K_REC_KERNEL 14   /* the record stages (fq_records.h): set-up, main hit, pairing, XA, task lists, flattening */
-#define FQ_K_COUNT 15
+#define FQ_K_EMIT 15         /* the consumers' kernels (fq_emit.h): SAM text, StatCollector's sums */
+#define FQ_K_COUNT 16
 typedef struct {
   double kernel_ms[FQ_K_COUNT];
   uint64_t kernel_launches[FQ_K_COUNT];

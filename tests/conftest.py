@@ -8,6 +8,10 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 
+# every Aligner of the test suite also formats its SAM text on the device (fq_emit.h) and api.Aligner.sam_text() holds it to the host formatter's bytes
+os.environ.setdefault("FASTQUICK_API_EMIT", "1")
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
     config.addinivalue_line("markers", "refbuild: needs oracle/_ref (the reference compiled in the build container)")

@@ -153,6 +153,29 @@ int launch_rec(int op, const FqRecArgs &a, int64_t n) {
   for (int64_t i = 0; i < n; ++i) bodies[op](a, (int)i);
   return 0;
 }
+int launch_sam(int op, const FqSamArgs &a, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) { if (op == FQ_EOP_SAM_LEN) fq_sam_len_thread(a, (int)i); else if (op == FQ_EOP_SAM_FILL) fq_sam_fill_thread(a, (int)i); else return -1; }
+  return 0;
+}
+int launch_qc(int op, const FqQcArgs &a, int64_t n) {
+  if (op == FQ_QOP_BASE) {
+    std::vector<uint32_t> hist(4 * 256, 0);
+    for (int64_t i = 0; i < n; ++i) fq_qc_base_record(a, (int)i, 0, 1, hist.data());
+    for (int b = 0; b < 4 * 256; ++b) a.hist[b] += hist[b];
+    return 0;
+  }
+  for (int64_t i = 0; i < n; ++i) {
+    if (op == FQ_QOP_PAIR) fq_qc_pair_thread(a, (int)i);
+    else if (op == FQ_QOP_IST_FILL) fq_qc_ist_fill_thread(a, (int)i);
+    else if (op == FQ_QOP_PILE_FILL) fq_qc_pile_fill_thread(a, (int)i);
+    else return -1;
+  }
+  return 0;
+}
+int launch_dup_rehash(const uint64_t *old, uint64_t old_cap, uint64_t *tab, uint64_t mask) {
+  for (uint64_t i = 0; i < old_cap; ++i) fq_dupset_rehash_thread(old, tab, mask, (int64_t)i);
+  return 0;
+}
 int launch_aln_index(const int32_t *work, const uint32_t *status, const uint64_t *off, const uint32_t *naln, uint64_t base, uint64_t *aoff, uint32_t *an, int n) {
   for (int w = 0; w < n; ++w) fq_aln_index_thread(work, status, off, naln, base, aoff, an, w);
   return 0;
