@@ -100,6 +100,9 @@ def main() -> None:
     ap.add_argument("--no-front-end", action="store_true", help="skip the front-end leg (packer, FASTQ reader, command line end to end)")
     ap.add_argument("--front-end-pairs", type=int, default=1 << 20, help="pairs of the FASTQ files of the front-end leg")
     ap.add_argument("--front-end-copies", type=int, default=64, help="the steady-state command-line run reads those files concatenated this many times (0 / 1: skip)")
+    ap.add_argument("--no-cli-ontarget", action="store_true", help="skip front_end.cli_e2e_ontarget (the command line on on-target FASTQ files)")
+    ap.add_argument("--cli-ontarget-pairs", type=int, default=1 << 19, help="distinct on-target pairs of that leg's FASTQ files")
+    ap.add_argument("--cli-ontarget-copies", type=int, default=32, help="... concatenated this many times (BGZF members concatenate)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="pairs per slice for the CPU baseline (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=32, help="independent streams (threads) of the CPU baseline")
     ap.add_argument("--tune", default="", help="key=value,... passed to fq_ctx_set_tuning on every context (experiments)")
@@ -117,7 +120,9 @@ def main() -> None:
         os.sched_setaffinity(0, set(cpus))                      # (inherited by every thread started from here on: the HIP runtime's, the library's, Python's)
         os.environ["FASTQUICK_HOST_CPUS"] = str(args.host_cpus)
     hb_result = None
-    if args.host_cpus == 0 and not args.no_host_budget and args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
+    # (under a profiler the preloaded library has initialised the GPU already and a child would write into the same output directory: no host-budget leg there)
+    profiled = "rocprof" in os.environ.get("LD_PRELOAD", "") or any(k.startswith(("ROCPROFILER_", "ROCPROF_", "ROCP_")) for k in os.environ)
+    if args.host_cpus == 0 and not args.no_host_budget and not profiled and args.gpus == 1 and int(os.environ.get("WORLD_SIZE", "1")) == 1:
         hb_result = host_budget_child(args)          # (before anything here touches the device)
 
     import numpy as np
@@ -710,6 +715,20 @@ def main() -> None:
                                      "notices": [l for l in run2.stderr.decode(errors="replace").splitlines() if "consumers" in l or "index staged" in l or "reading (ms)" in l][-3:]}
                 for b_ in big:
                     os.remove(b_)
+                # ---- the command line on ON-TARGET input (BASELINE.json cfg 5's regime; bin/FASTQuick_template.sh:474-481 is the run it stands for): every
+                #      pair survives the filter, so the consumers see every pair -- SAM text and StatCollector's sums come out of the kernels of fq_emit.h
+                if not args.no_cli_ontarget:
+                    sys.path.insert(0, os.path.join(ROOT, "tools"))
+                    import cli_ontarget
+                    ont = {}
+                    for key, rl, n_, cp_ in (("2x150", 150, args.cli_ontarget_pairs, args.cli_ontarget_copies), ("2x76_indel_rich", 76, args.cli_ontarget_pairs, max(1, args.cli_ontarget_copies // 2))):
+                        if args.markers != 10000 and rl != L:
+                            continue
+                        try:
+                            ont[key] = cli_ontarget.measure(exe, pre, ref, os.path.join(fdir, "ont"), pairs=n_, copies=cp_, read_len=rl, threads=pt)
+                        except Exception as e:      # noqa: BLE001
+                            ont[key] = {"error": repr(e)[:300]}
+                    fe["cli_e2e_ontarget"] = ont
                 for ext in (".SelectedSite.vcf", ".dbSNP.subset.vcf", ".gc", ".param", ".genome.fa.fai"):      # (the other legs run without the QC consumer)
                     if os.path.exists(pre + ext):
                         os.remove(pre + ext)

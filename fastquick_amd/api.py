@@ -568,6 +568,10 @@ class QC:
     def begin_file(self, fq1: str, fq2: str):
         self._ck(self.L.fq_qc_begin_file(self.h, fq1.encode(), fq2.encode()), "fq_qc_begin_file")
 
+    def attach(self, aligner: "Aligner"):
+        """StatCollector's part of every later call of `aligner` runs on the device, inside the call (fq_ctx_attach_qc); add() then only appends."""
+        self._ck(self.L.fq_ctx_attach_qc(aligner.h, self.h), "fq_ctx_attach_qc")
+
     def add(self, aligner: "Aligner"):
         self._ck(self.L.fq_qc_add_last(self.h, aligner.h), "fq_qc_add_last")
 

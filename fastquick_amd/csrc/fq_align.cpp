@@ -283,6 +283,7 @@ struct fq_ctx {
   // the consumers on the device (fq_emit.h; fq_ctx_set_emit): compact qualities and names of the surviving reads where the input kind
   // leaves them on the host, the SAM text of the last call
   int emit_flags = 0;
+  bool host_rows = true;               // the last text batch's surviving rows were copied to the host
   DevBuf<uint8_t> d_equal; PinBuf<uint8_t> p_equal;
   DevBuf<char> d_enames; PinBuf<char> p_enames;
   DevBuf<uint32_t> d_samlen; DevBuf<uint64_t> d_samoff; DevBuf<char> d_samtext;
@@ -1075,7 +1076,10 @@ int stage0_text(Call &K) {
   const int ns = tb.name_stride;
   c->c_stride = cstride; c->c_name_stride = ns;
   CKM(c->d_seq.ensure((size_t)nrow * cstride + 64) && c->d_pqual.ensure((size_t)nrow * cstride + 64) && c->d_cnames.ensure((size_t)nrow * ns + 64));
-  CKM(c->p_cseq.ensure((size_t)nrow * cstride + 64) && c->p_cqual.ensure((size_t)nrow * cstride + 64) && c->p_clen.ensure((size_t)nrow + 8) && c->p_cnames.ensure((size_t)nrow * ns + 64));
+  // (the consumers on the device read the rows where they lie: FQ_EMIT_DEVICE_ONLY leaves them there)
+  const bool host_rows = !(c->emit_flags & FQ_EMIT_DEVICE_ONLY) || c->debug;
+  c->host_rows = host_rows;
+  if (host_rows) CKM(c->p_cseq.ensure((size_t)nrow * cstride + 64) && c->p_cqual.ensure((size_t)nrow * cstride + 64) && c->p_clen.ensure((size_t)nrow + 8) && c->p_cnames.ensure((size_t)nrow * ns + 64));
   fqdev::time_begin(FQ_K_PREP);
   if (nrow) {
     FqTextGatherArgs g{};
@@ -1089,11 +1093,13 @@ int stage0_text(Call &K) {
       ta.pair_list = c->d_pair_list.p; ta.batch_pairs = B; ta.sub_max = c->d_sub_max.p + 2 * n_sub;
       CK(fqdev::launch_trim(ta));
     }
-    CK(fqdev::copy_pinned(c->p_cseq.p, c->d_seq.p, (size_t)nrow * cstride, 0));
-    CK(fqdev::copy_pinned(c->p_cqual.p, c->d_pqual.p, (size_t)nrow * cstride, 0));
-    CK(fqdev::copy_pinned(c->p_clen.p, c->d_len_c.p, (size_t)nrow * 4, 0));
-    CK(fqdev::copy_pinned(c->p_cnames.p, c->d_cnames.p, (size_t)nrow * ns, 0));
-    c->stats.d2h_bytes += (size_t)nrow * (2 * (size_t)cstride + 4 + (size_t)ns);
+    if (host_rows) {
+      CK(fqdev::copy_pinned(c->p_cseq.p, c->d_seq.p, (size_t)nrow * cstride, 0));
+      CK(fqdev::copy_pinned(c->p_cqual.p, c->d_pqual.p, (size_t)nrow * cstride, 0));
+      CK(fqdev::copy_pinned(c->p_clen.p, c->d_len_c.p, (size_t)nrow * 4, 0));
+      CK(fqdev::copy_pinned(c->p_cnames.p, c->d_cnames.p, (size_t)nrow * ns, 0));
+      c->stats.d2h_bytes += (size_t)nrow * (2 * (size_t)cstride + 4 + (size_t)ns);
+    }
   }
   fqdev::time_end(FQ_K_PREP);
   // infer_isize's max_len is the longest trimmed read of the whole reference batch, filtered reads included (libbwa/bwape.c:60-61): every
@@ -2092,18 +2098,22 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
     CKS(sync_staged(c));
     if (cc > 0xffffffffull || mm > 0xfffffffeull || xx > 0xffffffffull) { c->err = "result arenas exceed 32-bit offsets"; return FQ_ELIMIT; }
   }
-  CKM(c->d_orec.ensure(N + 1) && c->d_ocig.ensure(cc + 1) && c->d_omd.ensure(mm + 1) && c->d_omulti.ensure(xx + 1) &&
-      c->p_orec.ensure(N + 1) && c->p_ocig.ensure(cc + 1) && c->p_omd.ensure(mm + 1) && c->p_omulti.ensure(xx + 1));
+  // FQ_EMIT_DEVICE_ONLY: the result arrays stay where the consumers' kernels read them (0.55 GB per 4.2 M-pair on-target call stays off PCIe)
+  const bool host_arrays = !(c->emit_flags & FQ_EMIT_DEVICE_ONLY) || c->debug;
+  CKM(c->d_orec.ensure(N + 1) && c->d_ocig.ensure(cc + 1) && c->d_omd.ensure(mm + 1) && c->d_omulti.ensure(xx + 1));
+  if (host_arrays) CKM(c->p_orec.ensure(N + 1) && c->p_ocig.ensure(cc + 1) && c->p_omd.ensure(mm + 1) && c->p_omulti.ensure(xx + 1));
   if (N) {
     A.o_rec = c->d_orec.p; A.o_cigar = c->d_ocig.p; A.o_md = c->d_omd.p; A.o_multi = c->d_omulti.p;
     REC(FQ_ROP_FLAT_FILL, N);
     if (c->emit_flags & FQ_EMIT_SAM) CKS(stage_emit_sam(K));
     if (c->qc) CKS(stage_emit_qc(K));
-    CK(fqdev::copy_pinned(c->p_orec.p, c->d_orec.p, N * sizeof(fq_result_t), 0));
-    CK(fqdev::copy_pinned(c->p_ocig.p, c->d_ocig.p, cc * 2, 0));
-    CK(fqdev::copy_pinned(c->p_omd.p, c->d_omd.p, mm, 0));
-    CK(fqdev::copy_pinned(c->p_omulti.p, c->d_omulti.p, xx * sizeof(fq_multi_t), 0));
-    c->stats.d2h_bytes += N * sizeof(fq_result_t) + cc * 2 + mm + xx * sizeof(fq_multi_t);
+    if (host_arrays) {
+      CK(fqdev::copy_pinned(c->p_orec.p, c->d_orec.p, N * sizeof(fq_result_t), 0));
+      CK(fqdev::copy_pinned(c->p_ocig.p, c->d_ocig.p, cc * 2, 0));
+      CK(fqdev::copy_pinned(c->p_omd.p, c->d_omd.p, mm, 0));
+      CK(fqdev::copy_pinned(c->p_omulti.p, c->d_omulti.p, xx * sizeof(fq_multi_t), 0));
+      c->stats.d2h_bytes += N * sizeof(fq_result_t) + cc * 2 + mm + xx * sizeof(fq_multi_t);
+    }
   }
   uint64_t cnt[FQ_C_COUNT];
   c->h_counters.resize((size_t)FQ_C_STRIPES * FQ_C_STRIDE);
@@ -2113,9 +2123,11 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
   CK(fqdev::dzero(c->d_counters.p, c->h_counters.size() * 8));
   if (!N && (c->emit_flags & FQ_EMIT_SAM)) { c->sam_bytes = 0; c->sam_ready = true; }
   if (!N && c->qc) { c->qc_out = FqQcCallOut(); c->qc_out.owner = c->qc; c->qc_out.ready = true; }
-  if (!cc) c->p_ocig.p[0] = 0;
-  if (!mm) c->p_omd.p[0] = 0;
-  if (!xx) c->p_omulti.p[0] = fq_multi_t{};
+  if (host_arrays) {
+    if (!cc) c->p_ocig.p[0] = 0;
+    if (!mm) c->p_omd.p[0] = 0;
+    if (!xx) c->p_omulti.p[0] = fq_multi_t{};
+  }
   K.trace("result arrays D2H");
   if (cnt[FQ_C_ERR_DRAW0]) {
     c->err = "the drand48 stream drew exactly 0 for the first best hit of a read (once in 2^48 draws): bwa_aln2seq_core then takes no hit and the reference's "
@@ -2124,7 +2136,8 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
   }
   if (cnt[FQ_C_ERR_CIGAR]) { c->err = "refine: CIGAR longer than the device slot"; return FQ_ELIMIT; }
   if (cnt[FQ_C_ERR_MD]) { c->err = "MD string longer than the device slot"; return FQ_ELIMIT; }
-  S.rec = c->p_orec.p; S.cigar = c->p_ocig.p; S.md = c->p_omd.p; S.multi = c->p_omulti.p;
+  if (host_arrays) { S.rec = c->p_orec.p; S.cigar = c->p_ocig.p; S.md = c->p_omd.p; S.multi = c->p_omulti.p; }
+  else { S.rec = nullptr; S.cigar = nullptr; S.md = nullptr; S.multi = nullptr; }
   S.n_both_unmapped = (int)cnt[FQ_C_UNMAPPED];
   out->n_survivors = n_surv;
   out->n_both_filtered = K.n - n_surv;
@@ -2475,7 +2488,7 @@ extern "C" int fq_ctx_set_serial_hooks(fq_ctx_t *c, fq_serial_hook before, fq_se
 
 // ---- the consumers on the device ------------------------------------------------------------------------------------------------------
 extern "C" int fq_ctx_set_emit(fq_ctx_t *c, int32_t flags) {
-  if (!c || (flags & ~(FQ_EMIT_SAM))) return FQ_EINVAL;
+  if (!c || (flags & ~(FQ_EMIT_SAM | FQ_EMIT_DEVICE_ONLY))) return FQ_EINVAL;
   c->emit_flags = flags;
   return FQ_OK;
 }
@@ -2525,7 +2538,8 @@ FqHostReads fq_ctx_host_reads(const fq_ctx_t *c) {
   FqHostReads h;
   if (c->in_kind == 3) {
     h.compact = true; h.n_pairs = c->n_pairs; h.name_stride = c->c_name_stride; h.c_stride = c->c_stride; h.c_n_surv = c->st.n_surv;
-    h.c_seq = c->p_cseq.p; h.c_qual = c->p_cqual.p; h.c_len = c->p_clen.p; h.c_names = c->p_cnames.p; h.c_pair_idx = c->st.pair_idx;
+    if (c->host_rows) { h.c_seq = c->p_cseq.p; h.c_qual = c->p_cqual.p; h.c_len = c->p_clen.p; h.c_names = c->p_cnames.p; }
+    h.c_pair_idx = c->st.pair_idx;
     h.c_len_all = c->h_len_all.empty() ? nullptr : c->h_len_all.data(); h.c_uniform_len = c->tb ? c->tb->uniform_len : 0;
   } else if (c->in_kind == 2) { h.p = &c->pb; h.n_pairs = c->pb.n_pairs; h.names = c->pb.names; h.names_mate = c->pb.names_mate; h.name_stride = c->pb.name_stride; }
   else { h.a = &c->hb; h.n_pairs = c->hb.n_pairs; h.names = c->hb.names; h.names_mate = c->hb.names_mate; h.name_stride = c->hb.name_stride; }

@@ -348,6 +348,7 @@ static int format_last(fq_bam_t *b, fq_ctx_t *c, std::vector<std::vector<uint8_t
   const FqBatchState *S = fq_ctx_state(c);
   const FqHostReads hb = fq_ctx_host_reads(c);
   const fq_opts_t *ao = fq_ctx_opts(c);
+  if (S->n_surv > 0 && !S->rec) { b->err = "the call's result arrays were left on the device (FQ_EMIT_DEVICE_ONLY)"; return FQ_EINVAL; }
   if (S->n_surv > 0 && !hb.has_qual()) { b->err = "the batch carries no qualities"; return FQ_EINVAL; }
   // records are independent of each other: ranges of pairs are formatted on several threads and handed to the BGZF layer in order
   auto format_range = [&](int lo, int hi, std::vector<uint8_t> &dst) {

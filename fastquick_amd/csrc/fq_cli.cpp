@@ -137,6 +137,7 @@ struct Args {
   std::string devices;   // --devices: several devices, the lines of --fq_list dealt over them
   int pack_threads = std::min(32, std::max(1, fq_host_cpus()));     // host threads of the FASTQ readers (half per file) and of the packer, from the CPUs the process may use; --t sets it
   bool clean_names = false;
+  bool host_consumers = false;   // --host_consumers: SAM text and StatCollector's sums on the host's threads from the result arrays (round 5's way; the default runs them in kernels, fq_emit.h)
   bool host_reader = false;   // --host_reader: the FASTQ front end on the host's threads also for BGZF files (the default inflates and tokenises them on the device)
   bool strict = false;   // --strict_reference: stop where the output could differ from the reference's bytes (today: QUAL of reads of unequal lengths)
   std::string fq_list, rg = "@RG\\tID:foo\\tSM:bar";   // runAlign's default --RG (src/FASTQuick.cpp:170)
@@ -149,7 +150,7 @@ int usage() {
   fprintf(stderr, "Usage: FASTQuick_amd align --index_prefix P --fastq_1 R1.fq[.gz] [--fastq_2 R2.fq[.gz]] | --fq_list LIST  --out_prefix O [--sam_out] [--RG STR] [--cal_dup]\n"
                   "                       [--q INT] [--n FLOAT|INT] [--kmer_thresh INT] [--o INT] [--e INT] [--i INT] [--d INT] [--l INT] [--k INT]\n"
                   "                       [--m INT] [--R INT] [--N] [--L] [--I] [--max_isize INT] [--max_occ INT] [--is_sw] [--n_multi INT] [--N_multi INT]\n"
-                  "                       [--ap_prior FLOAT] [--force_isize] [--frac_samp FLOAT] [--t INT] [--chunk_pairs INT] [--batch_pairs INT] [--device INT | --devices LIST] [--read_len INT] [--clean_names] [--strict_reference] [--host_reader]\n"
+                  "                       [--ap_prior FLOAT] [--force_isize] [--frac_samp FLOAT] [--t INT] [--chunk_pairs INT] [--batch_pairs INT] [--device INT | --devices LIST] [--read_len INT] [--clean_names] [--strict_reference] [--host_reader] [--host_consumers]\n"
                   "       FASTQuick_amd index --ref REDUCED.FASTQuick.fa [--rollhash]\n");
   return 1;
 }
@@ -267,9 +268,17 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
   double qc_ms = 0, out_ms = 0, read_all_ms = 0, read_wait_ms = 0, align_ms = 0, read_ms = 0, pack_ms = 0;
   std::vector<char> sam;
   fq_index_t *ix = nullptr;
-  fq_qc_t *qc = nullptr;
   fq_ctx_t *ctx = nullptr, *ctx_a = nullptr;      // ctx: the context that holds the stream's state; ctx_a: the first one made (a second one may join it: ctx2)
   bool started = false;
+  fq_qc_t *qc = nullptr;
+  // the consumers of a context's records run in kernels inside its calls (fq_emit.h): the SAM text is formatted on the device, StatCollector's sums
+  // stay there; the consumer threads below only move text and append
+  auto device_consumers = [&](fq_ctx_t *cx) {
+    if (A.host_consumers) return;
+    // (SAM text: nothing on the host reads the result arrays any more -- they stay in HBM; the BAM writer still formats on the host)
+    if (A.sam_out && fq_ctx_set_emit(cx, FQ_EMIT_SAM | FQ_EMIT_DEVICE_ONLY)) die("fq_ctx_set_emit failed");
+    if (qc && fq_ctx_attach_qc(cx, qc)) die("fq_ctx_attach_qc failed");
+  };
   // A refusal ends the run behind the records of every call before it (the reference prints the batches before the one that aborts,
   // src/BwtMapper.cpp:2030-2092): consumers of the previous call that still run on their own threads are waited for, the sink is flushed, then die().
   std::function<void()> before_die;
@@ -287,6 +296,7 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
     const int crc = fq_ctx_create(ix, &o, (int32_t)A.chunk_pairs, &ctx);
     if (crc) die("fq_ctx_create failed (" + std::to_string(crc) + "): option outside the supported range");
     ctx_a = ctx;
+    device_consumers(ctx);
     mark("context created");
   };
   // the consumers of a call's records: StatCollector and the record writer (src/BwtMapper.cpp:2047-2050, 2075-2085).  The reference runs them
@@ -302,7 +312,11 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
   auto consume_out = [&](fq_ctx_t *cx) {
     const auto tc1 = std::chrono::steady_clock::now();
     std::vector<char> text;
-    if (A.sam_out) {
+    if (A.sam_out && !A.host_consumers) {
+      struct U { Sink *out; } u{&out};
+      if (fq_sam_device_last(cx, [](void *user, const void *data, int64_t n) -> int { ((U *)user)->out->sam((const char *)data, (size_t)n); return 0; }, &u) < 0)
+        die(std::string("fetching the SAM text failed: ") + fq_ctx_last_error(cx));
+    } else if (A.sam_out) {
       const int64_t sz = fq_sam_format_last(cx, nullptr, 0);
       text.resize((size_t)sz + 1);
       fq_sam_format_last(cx, text.data(), sz + 1);
@@ -366,6 +380,7 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
         fq_opts_t o = A.o;
         o.single_end = se ? 1 : 0;
         if (fq_ctx_create(ix, &o, (int32_t)A.chunk_pairs, &ctx2)) fail("fq_ctx_create failed: option outside the supported range");
+        device_consumers(ctx2);
         other = ctx2;
       } else {
         // the stream's order-dependent state -- drand48 stream, last_ii, (k,l) cache -- goes from the context of the last call to this one's
@@ -628,6 +643,10 @@ void align_pair_sharded(const Args &A, const std::pair<std::string, std::string>
     fq_packed_batch_t *pk = nullptr;
     if (fq_packed_create((int32_t)A.chunk_pairs, stride, &pk)) die("out of pinned host memory for the packed batch");
     if (K.qc) { fq_qc_begin_file(K.qc, input.first.c_str(), input.second.c_str()); if (fq_qc_state_reset(K.qc)) die("QC consumer: cannot start a segment"); }
+    if (!A.host_consumers) {
+      if (A.sam_out && fq_ctx_set_emit(ctx, FQ_EMIT_SAM | FQ_EMIT_DEVICE_ONLY)) die("fq_ctx_set_emit failed");
+      if (K.qc && fq_ctx_attach_qc(ctx, K.qc)) die("fq_ctx_attach_qc failed");
+    }
     std::vector<char> sam;
     for (long long b = (long long)w;; b += (long long)NW) {
       ShardRun::Chunk *c = nullptr;
@@ -651,7 +670,10 @@ void align_pair_sharded(const Args &A, const std::pair<std::string, std::string>
         out.qc.resize((size_t)std::max<int64_t>(need, 0));
         if (need < 0 || fq_qc_state_export(K.qc, out.qc.data(), need) != need || fq_qc_state_reset(K.qc)) die("QC consumer: export failed");
       }
-      if (A.sam_out) {
+      if (A.sam_out && !A.host_consumers) {
+        if (fq_sam_device_last(ctx, [](void *user, const void *data, int64_t n) -> int { ((std::string *)user)->append((const char *)data, (size_t)n); return 0; }, &out.sam) < 0)
+          die(std::string("fetching the SAM text failed: ") + fq_ctx_last_error(ctx));
+      } else if (A.sam_out) {
         const int64_t sz = fq_sam_format_last(ctx, nullptr, 0);
         sam.resize((size_t)sz + 1);
         fq_sam_format_last(ctx, sam.data(), sz + 1);
@@ -761,6 +783,7 @@ int main(int argc, char **argv) {
     else if (f == "--clean_names") A.clean_names = true;
     else if (f == "--strict_reference") A.strict = true;
     else if (f == "--host_reader") A.host_reader = true;
+    else if (f == "--host_consumers") A.host_consumers = true;
     else if (f == "--batch_pairs") A.o.batch_pairs = atoi(need(""));   // READ_BUFFER_SIZE of the run to reproduce (default 262144)
     else if (f == "--device") A.device = atoi(need(""));
     else if (f == "--devices") A.devices = need("");

@@ -748,7 +748,6 @@ extern "C" int fq_qc_add_last(fq_qc_t *q, fq_ctx_t *c) {
   const FqHostReads hb = fq_ctx_host_reads(c);
   const fq_opts_t *ao = fq_ctx_opts(c);
   q->o.mode = ao->mode;
-  if (S->n_surv > 0 && !hb.has_qual()) { q->err = "the batch carries no qualities"; return FQ_EINVAL; }
   FileStat &F = q->cur;
   F.NumBase += fq_ctx_last_bases(c);
   F.NumRead += (ao->single_end ? 1LL : 2LL) * S->n_pairs;
@@ -783,7 +782,8 @@ extern "C" int fq_qc_add_last(fq_qc_t *q, fq_ctx_t *c) {
   }
   if (q->device_adds) { q->err = "fq_qc_add_last: this consumer counts on the device (fq_ctx_attach_qc); a batch of a context without it cannot be mixed in"; return FQ_EINVAL; }
   q->host_adds = true;
-  if (S->n_surv > 0 && !S->rec) { q->err = "fq_qc_add_last: the call's result arrays were left on the device"; return FQ_EINVAL; }
+  if (S->n_surv > 0 && !S->rec) { q->err = "fq_qc_add_last: the call's result arrays were left on the device (FQ_EMIT_DEVICE_ONLY)"; return FQ_EINVAL; }
+  if (S->n_surv > 0 && !hb.has_qual()) { q->err = "the batch carries no qualities"; return FQ_EINVAL; }
   // the batch's records in the host's vocabulary, from the C-ABI arrays (all threads); they live until the per-base statistics have run
   std::vector<FqRead> recs((size_t)S->n_surv * 2);
   {

@@ -192,7 +192,7 @@ extern "C" int64_t fq_sam_format_last(fq_ctx_t *c, char *buf, int64_t cap) {
   const fq_index *ix = fq_ctx_index(c);
   const FqHostReads hbv = fq_ctx_host_reads(c), *hb = &hbv;
   const fq_opts_t *o = fq_ctx_opts(c);
-  if (S->n_surv > 0 && !hb->has_qual()) return FQ_EINVAL;
+  if (S->n_surv > 0 && (!S->rec || !hb->has_qual())) return FQ_EINVAL;     // (no result arrays on the host: FQ_EMIT_DEVICE_ONLY -- fq_sam_device_last has the text)
   // records are independent of each other: ranges of pairs are formatted on several threads and concatenated in order
   auto format_range = [&](int lo, int hi, Out &out) {
   out.s.reserve((size_t)(hi - lo) * 900);
@@ -236,6 +236,7 @@ extern "C" int64_t fq_stage_dump_last(fq_ctx_t *c, char *buf, int64_t cap) {
   const uint8_t *filt; const int32_t *ltrim;
   fq_ctx_all_reads(c, &filt, &ltrim);
   if (S->n_pairs > 0 && (!filt || !ltrim)) return FQ_EINVAL;   // per-read arrays of the whole batch are only fetched in debug mode
+  if (S->n_surv > 0 && !S->rec) return FQ_EINVAL;
   const int n = S->n_pairs;
   const fq_opts_t *opts = fq_ctx_opts(c);
   const int n_ends = opts->single_end ? 1 : 2;   // the single-end mapper's dump has one end, no insert-size line and no mate-rescue stage

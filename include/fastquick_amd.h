@@ -447,6 +447,8 @@ int fq_bam_close(fq_bam_t *b);                   /* writes the BGZF end-of-file 
  * its own (it may run on another thread beside the next call on ANOTHER context); returns the bytes handed over or a negative code.
  * fq_sam_device_bytes: the size of that text. */
 #define FQ_EMIT_SAM 1
+#define FQ_EMIT_DEVICE_ONLY 2   /* every consumer of the context's records runs on the device: a call leaves its result arrays and the surviving reads' rows
+                                   in HBM (fq_result_batch_t carries the counts and NULL arrays; the host-side consumers refuse such a batch) */
 typedef int (*fq_sink_fn)(void *user, const void *data, int64_t bytes);   /* 0: go on; anything else ends the stream with FQ_EIO */
 int fq_ctx_set_emit(fq_ctx_t *c, int32_t flags);
 int64_t fq_sam_device_last(fq_ctx_t *c, fq_sink_fn sink, void *user);

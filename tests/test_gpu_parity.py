@@ -327,13 +327,15 @@ def test_trimmed_max_len_of_filtered_reads_gpu(lib, tmp_path):
     trimmed_max_len_case(lib, tmp_path, device=0)
 
 
+@pytest.mark.parametrize("on_device", [False, True], ids=["host_consumer", "device_consumer"])
 @pytest.mark.parametrize("packed", [False, True], ids=["ascii", "packed"])
 @pytest.mark.parametrize("tag", golden_util.case_tags())
-def test_qc_files_match_reference_golden(tag, packed, golden_cases, lib):
+def test_qc_files_match_reference_golden(tag, packed, on_device, golden_cases, lib):
     """StatCollector's files (.InsertSizeTable .Pileup .DepthDist .GCDist .EmpRepDist .EmpCycleDist .RawInsertSizeDist .SexChromInfo
-    .FASTQ.csv .Sequence.csv .Summary) from the QC consumer fed by the HIP path, byte for byte the REAL reference's."""
+    .FASTQ.csv .Sequence.csv .Summary) from the QC consumer fed by the HIP path, byte for byte the REAL reference's -- counted on the host from
+    the result arrays, and counted by the kernels of fq_emit.h inside the calls (fq_ctx_attach_qc)."""
     from test_qc_consumer import qc_case, explain
-    bad = qc_case(golden_cases[tag], lib, device=0, packed=packed)
+    bad = qc_case(golden_cases[tag], lib, device=0, packed=packed, on_device=on_device)
     assert not bad, explain(bad)
 
 
@@ -505,6 +507,8 @@ def test_gpu_single_end_consumers_match_reference(tag, golden_cases, lib):
     from test_qc_consumer import qc_case, explain
     from test_bam_writer import bam_case
     bad = qc_case(golden_cases[tag], lib, device=0, se=True)
+    assert not bad, explain(bad)
+    bad = qc_case(golden_cases[tag], lib, device=0, se=True, on_device=True)
     assert not bad, explain(bad)
     bam_case(golden_cases[tag], lib, device=0, se=True)
 

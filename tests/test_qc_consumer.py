@@ -30,14 +30,17 @@ def emu_lib():
     return api.load_library(os.path.join(EMU_DIR, "libfq_emu.so"))
 
 
-def qc_case(g, lib, device=None, packed=False, tuning=None, se=False):
+def qc_case(g, lib, device=None, packed=False, tuning=None, se=False, on_device=False):
     """Runs case g through the pipeline + QC consumer; returns {file: (got, want)} for the files that differ.
-    se: the single-end mapper on the first FASTQ alone (AddAlignment(p, 0)), against the ref_se.qc.* goldens."""
+    se: the single-end mapper on the first FASTQ alone (AddAlignment(p, 0)), against the ref_se.qc.* goldens.
+    on_device: StatCollector's part of every call runs in the kernels of fq_emit.h (fq_ctx_attach_qc); the consumer's host side only appends."""
     names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
     ix = api.Index(g["prefix"], lib=lib) if device is None else api.Index(g["prefix"], device=device, lib=lib)
     al = api.Aligner(ix, api.default_opts(lib, trim_qual=g["trim_qual"], single_end=1 if se else 0), max_pairs=max(16, g["batch"]), tuning=tuning or {})
     out = os.path.join(g["dir"], "got_qc_se" if se else "got_qc")
     qc = api.QC(ix, g["prefix"], out, genome_size=g["genome_size"], read_len=g["qc_read_len"])
+    if on_device:
+        qc.attach(al)
     qc.begin_file(g["fq1"], g["fq1"] if se else g["fq2"])     # FileStatCollector(fq1) names the one file twice
     if se:
         api.align_stream(al, list(names), seq[:1], qual[:1], lens[:1], g["batch"], None, None, qc=qc, packed=packed)
@@ -65,20 +68,65 @@ def explain(bad):
     return "\n".join(msg)
 
 
+SIDES = pytest.mark.parametrize("on_device", [False, True], ids=["host_consumer", "device_consumer"])
+
+
+@SIDES
 @pytest.mark.parametrize("tag", golden_util.case_tags())
-def test_qc_files_match_reference(tag, golden_cases, emu_lib):
-    bad = qc_case(golden_cases[tag], emu_lib)
+def test_qc_files_match_reference(tag, on_device, golden_cases, emu_lib):
+    bad = qc_case(golden_cases[tag], emu_lib, on_device=on_device)
+    assert not bad, explain(bad)
+
+
+@pytest.mark.parametrize("tag", ["qc", "trim76", "repeat"])
+def test_qc_files_from_packed_batches_on_the_device(tag, golden_cases, emu_lib):
+    """the packed boundary: the surviving reads' qualities and names are uploaded for the consumers' kernels"""
+    if tag not in golden_cases:
+        pytest.skip("no such golden case")
+    bad = qc_case(golden_cases[tag], emu_lib, packed=True, on_device=True)
     assert not bad, explain(bad)
 
 
 SE_CONSUMER_TAGS = [t for t in golden_util.se_case_tags() if os.path.exists(os.path.join(golden_util.GOLD, t, "ref_se.qc.Summary.gz"))]
 
 
+@SIDES
 @pytest.mark.parametrize("packed", [False, True], ids=["ascii", "packed"])
 @pytest.mark.parametrize("tag", SE_CONSUMER_TAGS)
-def test_single_end_qc_files_match_reference(tag, packed, golden_cases, emu_lib):
-    bad = qc_case(golden_cases[tag], emu_lib, se=True, packed=packed)
+def test_single_end_qc_files_match_reference(tag, packed, on_device, golden_cases, emu_lib):
+    bad = qc_case(golden_cases[tag], emu_lib, se=True, packed=packed, on_device=on_device)
     assert not bad, explain(bad)
+
+
+def test_a_consumer_counts_on_one_side_only(golden_cases, emu_lib):
+    """a consumer that counted a call on the device refuses a batch of a context it is not attached to (the duplicate set and the sums live on
+    one side), and the other way round"""
+    g = golden_cases["basic"]
+    names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
+    ix = api.Index(g["prefix"], lib=emu_lib)
+    kw = dict(genome_size=g["genome_size"], read_len=g["qc_read_len"])
+    a1 = api.Aligner(ix, api.default_opts(emu_lib), max_pairs=max(16, g["batch"]))
+    a2 = api.Aligner(ix, api.default_opts(emu_lib), max_pairs=max(16, g["batch"]))
+    B = g["batch"]
+    dev, host = a1, a2
+    host.align(seq[:, :B], qual[:, :B], lens[:, :B], names[:B])
+    qc = api.QC(ix, g["prefix"], os.path.join(g["dir"], "one_side_dev"), **kw)
+    qc.begin_file(g["fq1"], g["fq2"])
+    qc.attach(dev)
+    dev.align(seq[:, :B], qual[:, :B], lens[:, :B], names[:B])
+    qc.add(dev)
+    with pytest.raises(api.FastquickError, match="counts on the device"):
+        qc.add(host)
+    qc.close()
+    qc = api.QC(ix, g["prefix"], os.path.join(g["dir"], "one_side_host"), **kw)
+    qc.begin_file(g["fq1"], g["fq2"])
+    qc.add(host)
+    qc.attach(dev)
+    with pytest.raises(api.FastquickError, match="one side only"):
+        dev.align(seq[:, :B], qual[:, :B], lens[:, :B], names[:B])
+    emu_lib.fq_ctx_attach_qc(dev.h, None)
+    qc.close()
+    a1.close(); a2.close(); ix.close()
 
 
 def _diff(out, g, prefix):
@@ -90,8 +138,9 @@ def _diff(out, g, prefix):
     return bad
 
 
+@SIDES
 @pytest.mark.parametrize("tag", ["qc", "basic", "edge"])
-def test_segments_of_one_stream_merge_to_the_references_files(tag, golden_cases, emu_lib):
+def test_segments_of_one_stream_merge_to_the_references_files(tag, on_device, golden_cases, emu_lib):
     """ONE FASTQ pair whose reference batches go to two shard consumers in turn (what two ranks of a sharded stream hold): every
     batch's segment is exported, and the segments merged in batch order into a third consumer give the reference's 13 files."""
     g = golden_cases[tag]
@@ -108,8 +157,10 @@ def test_segments_of_one_stream_merge_to_the_references_files(tag, golden_cases,
     n, B = seq.shape[1], g["batch"]
     for b, lo in enumerate(range(0, n, B)):
         hi = min(n, lo + B)
-        al.align(seq[:, lo:hi], qual[:, lo:hi], lens[:, lo:hi], names[lo:hi])
         q = shards[b % 2]
+        if on_device:
+            q.attach(al)
+        al.align(seq[:, lo:hi], qual[:, lo:hi], lens[:, lo:hi], names[lo:hi])
         q.add(al)
         root.merge(q.state_export())
         q.state_reset()
@@ -122,7 +173,8 @@ def test_segments_of_one_stream_merge_to_the_references_files(tag, golden_cases,
     assert not bad, explain(bad)
 
 
-def test_two_fastq_pairs_merge_to_the_references_files(golden_cases, emu_lib):
+@SIDES
+def test_two_fastq_pairs_merge_to_the_references_files(on_device, golden_cases, emu_lib):
     """The two lines of a --fq_list on two shard consumers (one FASTQ pair each, closed there); their states merged in list order
     give what the reference writes for the two-pair run (tests/golden/qc/ref_fqlist.*)."""
     g = golden_cases["qc"]
@@ -137,6 +189,8 @@ def test_two_fastq_pairs_merge_to_the_references_files(golden_cases, emu_lib):
         q = api.QC(ix, g["prefix"], os.path.join(g["dir"], "fl_shard%d" % r), **kw)
         q.state_reset()
         q.begin_file(f1, f2)
+        if on_device:
+            q.attach(al)
         for lo in range(0, seq.shape[1], g["batch"]):
             hi = min(seq.shape[1], lo + g["batch"])
             al.align(seq[:, lo:hi], qual[:, lo:hi], lens[:, lo:hi], names[lo:hi])
