@@ -103,6 +103,8 @@ def main() -> None:
     ap.add_argument("--no-cli-ontarget", action="store_true", help="skip front_end.cli_e2e_ontarget (the command line on on-target FASTQ files)")
     ap.add_argument("--cli-ontarget-pairs", type=int, default=1 << 19, help="distinct on-target pairs of that leg's FASTQ files")
     ap.add_argument("--cli-ontarget-copies", type=int, default=32, help="... concatenated this many times (BGZF members concatenate)")
+    ap.add_argument("--no-reference-baseline", action="store_true", help="skip cpu_baseline.reference (the real reference, oracle/_ref, timed on the same input)")
+    ap.add_argument("--reference-sample-pairs", type=int, default=1 << 20, help="pairs of the WGS-mix sample the real reference aligns (a sixteenth of it for the on-target mix)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="pairs per slice for the CPU baseline (0 = auto)")
     ap.add_argument("--cpu-threads", type=int, default=32, help="independent streams (threads) of the CPU baseline")
     ap.add_argument("--tune", default="", help="key=value,... passed to fq_ctx_set_tuning on every context (experiments)")
@@ -799,6 +801,42 @@ def main() -> None:
         for oa in oas[1:]:
             oa.close()
         first.close()
+        # ---- the REAL reference beside the port: oracle/_ref/fq_ref_driver is the reference's own bwa_read_seq_with_hash_dev /
+        #      bwa_cal_sa_reg_gap / bwa_cal_pac_pos_pe / bwa_paired_sw / bwa_refine_gapped / StatCollector / bwa_print_sam1 compiled where they lie; it
+        #      travelled with the snapshot.  Same input as FASTQ text, batches of 262,144 pairs, stage A over the reference's pool geometry with
+        #      --t 4 (its documented invocation) and --t <usable CPUs>; wall time from the first read to the last record (SAM text and StatCollector
+        #      included, as PairEndMapper's loop has them).  Outside every timed region.
+        drv = os.path.join(ROOT, "oracle", "_ref", "fq_ref_driver")
+        if os.path.exists(drv) and not args.no_reference_baseline:
+            try:
+                rdir = os.path.join(args.workdir, "refrun")
+                os.makedirs(rdir, exist_ok=True)
+                rpre = os.path.join(rdir, "m%d.FASTQuick.fa" % args.markers)
+                if not os.path.exists(rpre + ".rollhash.sparse"):
+                    ref.write_fasta(rpre)
+                    subprocess.check_call([drv, "index", rpre], stderr=subprocess.DEVNULL, cwd=rdir)      # the reference's own index builder (its filter tables as a list of set bits)
+                    synth.write_qc_inputs(rpre, ref)
+                n_ref = min(args.pairs, args.reference_sample_pairs if args.mix == "wgs" else args.reference_sample_pairs // 16)
+                rfq = [os.path.join(rdir, "sample_%d.fq" % (e + 1)) for e in range(2)]
+                for e in range(2):
+                    synth.write_fastq_uniform(cpu_seq[e, :n_ref, :L], b.qual[e, :n_ref, :L], L, rfq[e], bgzf=False)
+                usable = int(api.load_library().fq_host_cpus())
+                refres = {"driver": "oracle/_ref/fq_ref_driver align (the reference's own stage functions, StatCollector and bwa_print_sam1)", "pairs": n_ref, "batch": 262144}
+                for label, t_ in (("t4", 4), ("t_cpus", max(4, usable))):
+                    run = subprocess.run([drv, "align", rpre, rfq[0], rfq[1], os.path.join(rdir, "out"), "--batch", "262144", "--t", str(t_), "--bench", "1", "--genome_size", str(len(ref.genome))],
+                                         stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+                    tl = [l for l in run.stderr.decode(errors="replace").splitlines() if l.startswith("TIMING")]
+                    if run.returncode == 0 and tl:
+                        kv = dict(x.split("=") for x in tl[-1].split()[1:])
+                        refres[label] = {"value": round(n_ref / (float(kv["reader_to_records_ms"]) * 1e-3), 1), "unit": "pairs/s", "threads": t_,
+                                         "stage_a_ms": float(kv["stage_a_ms"]), "reader_to_records_ms": float(kv["reader_to_records_ms"])}
+                    else:
+                        refres[label] = {"error": run.stderr.decode(errors="replace")[-300:]}
+                for f_ in rfq:
+                    os.remove(f_)
+                out["cpu_baseline"]["reference"] = refres
+            except Exception as e:      # noqa: BLE001
+                out["cpu_baseline"]["reference"] = {"error": repr(e)[:300]}
     if rank == 0:
         print(json.dumps(out))
     ix.close()

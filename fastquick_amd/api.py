@@ -106,7 +106,7 @@ EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destr
            "fq_fastq_open", "fq_fastq_configure", "fq_fastq_set_sampling", "fq_fastq_read", "fq_fastq_last_error", "fq_fastq_dropped_record", "fq_fastq_unequal_lengths", "fq_fastq_is_bgzf", "fq_fastq_close", "fq_inflate_raw", "fq_crc32", "fq_inflate_device", "fq_bgzf_inflate_device",
            "fq_frontend_open", "fq_frontend_next", "fq_frontend_release", "fq_frontend_handover", "fq_frontend_unequal_lengths", "fq_frontend_stats", "fq_frontend_last_error", "fq_frontend_close",
            "fq_text_batch_pairs", "fq_text_batch_first_name", "fq_align_text", "fq_text_batch_fetch",
-           "fq_ctx_set_emit", "fq_sam_device_last", "fq_sam_device_bytes", "fq_ctx_attach_qc"]
+           "fq_ctx_set_emit", "fq_sam_device_last", "fq_sam_device_bytes", "fq_ctx_attach_qc", "fq_ctx_attach_bam", "fq_bgzf_deflate_device"]
 SINK_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int64)
 EMIT_SAM = 1
 
@@ -153,6 +153,7 @@ def load_library(path: str | None = None):
     L.fq_sam_device_bytes.restype = C.c_int64
     L.fq_sam_device_bytes.argtypes = [C.c_void_p]
     L.fq_ctx_attach_qc.argtypes = [C.c_void_p, C.c_void_p]
+    L.fq_ctx_attach_bam.argtypes = [C.c_void_p, C.c_void_p]
     L.fq_stage_dump_last.restype = C.c_int64
     L.fq_stage_dump_last.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.fq_stats_get.argtypes = [C.c_void_p, C.POINTER(Stats)]
@@ -622,6 +623,11 @@ class BamWriter:
             raise FastquickError("fq_bam_create failed: %d" % rc)
         self.h = h
 
+    def attach(self, aligner: "Aligner"):
+        """the records of every later call of `aligner` are formatted by the kernels of fq_emit.h inside the call (fq_ctx_attach_bam); add() fetches the bytes"""
+        if self.L.fq_ctx_attach_bam(aligner.h, self.h):
+            raise FastquickError("fq_ctx_attach_bam failed")
+
     def add(self, aligner: "Aligner"):
         rc = self.L.fq_bam_add_last(self.h, aligner.h)
         if rc:
@@ -695,6 +701,21 @@ def inflate_device(streams, device: int = 0, lib=None, repeats: int = 1):
     if rc:
         raise FastquickError("fq_inflate_device failed: %d" % rc)
     return [(int(st[k]), outs[k].raw[:streams[k][1]]) for k in range(n)], ms.value
+
+
+def bgzf_deflate_device(data: bytes, device: int = 0, lib=None):
+    """data as BGZF members written by the device's compressor (fq_deflate.h): (members, kernel_ms)"""
+    L = lib or load_library()
+    n = len(data)
+    cap = (n // 0xd000 + 2) * 65536
+    out = np.empty(cap, dtype=np.uint8)
+    src = np.frombuffer(data, dtype=np.uint8) if n else np.zeros(1, np.uint8)
+    ol, ms = C.c_int64(0), C.c_double(0)
+    L.fq_bgzf_deflate_device.argtypes = [C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.POINTER(C.c_int64), C.POINTER(C.c_double)]
+    rc = L.fq_bgzf_deflate_device(device, src.ctypes.data, n, out.ctypes.data, cap, C.byref(ol), C.byref(ms))
+    if rc:
+        raise FastquickError("fq_bgzf_deflate_device failed: %d" % rc)
+    return out[:ol.value].tobytes(), ms.value
 
 
 def bgzf_inflate_device(blob: bytes, text_cap: int, device: int = 0, lib=None, repeats: int = 1):

@@ -291,6 +291,10 @@ struct fq_ctx {
   bool sam_ready = false;
   fqdev::State *dev_emit = nullptr;    // the consumer side's own streams: the text leaves the device beside the next call
   PinBuf<char> p_emit[2];
+  // ... the BAM records of a call (fq_ctx_attach_bam), as bytes in HBM until the writer fetches them
+  fq_bam *bam = nullptr;
+  DevBuf<uint32_t> d_bamlen, d_zsize; DevBuf<uint64_t> d_bamoff, d_zoff; DevBuf<uint8_t> d_bamrec, d_zstage, d_bamz;
+  FqBamCallOut bam_out;
   // ... StatCollector's part of a call (fq_ctx_attach_qc): per-call lists on the device, what comes back for the consumer's host side
   fq_qc *qc = nullptr;
   DevBuf<uint8_t> d_qadded;
@@ -2033,6 +2037,48 @@ int stage_emit_sam(Call &K) {
   K.trace("SAM text on the device");
   return FQ_OK;
 }
+// the BAM records of the call (SetSamRecord's fields and tag order, fq_emit.h), as one run of bytes on the device
+int stage_emit_bam(Call &K) {
+  fq_ctx *c = K.c;
+  const size_t N = (size_t)K.n_surv * 2;
+  FqBamCallOut &O = c->bam_out;
+  O = FqBamCallOut();
+  O.owner = c->bam;
+  if (!N) { O.ready = true; return FQ_OK; }
+  FqBamArgs a{};
+  CKS(emit_args(K, a.s));
+  { const int rc = fq_bam_device_prepare(c->bam, &a); if (rc) { c->err = "the BAM writer could not stage its tables on the device"; return rc; } }
+  CKM(c->d_bamlen.ensure(N + 1) && c->d_bamoff.ensure(N + 2));
+  a.len = c->d_bamlen.p; a.off = c->d_bamoff.p;
+  CK(fqdev::launch_bam(FQ_EOP_BAM_LEN, a, (int64_t)N));
+  CK(fqdev::launch_scan(c->d_bamlen.p, c->d_bamoff.p, (uint32_t)N));
+  uint64_t total = 0;
+  CKS(fetch_u64(c, &total, c->d_bamoff.p + N));
+  CKS(sync_staged(c));
+  CKM(c->d_bamrec.ensure(total + 64));
+  a.out = c->d_bamrec.p;
+  CK(fqdev::launch_bam(FQ_EOP_BAM_FILL, a, (int64_t)N));
+  O.bytes = total;
+  if (total && fq_bam_wants_members(c->bam)) {
+    // the writer has a file: the records leave the device as finished BGZF members (fq_deflate.h: a wavefront per block of the record stream)
+    const uint32_t nb = (uint32_t)((total + FQD_BLOCK - 1) / FQD_BLOCK);
+    CKM(c->d_zstage.ensure((size_t)nb * FQD_SLOT) && c->d_zsize.ensure((size_t)nb + 1) && c->d_zoff.ensure((size_t)nb + 2));
+    FqDeflateArgs z{c->d_bamrec.p, total, c->d_zstage.p, c->d_zsize.p, fqdev::crc_const(), nb};
+    if (!z.crc) { c->err = std::string("BGZF on the device: ") + fqdev::last_error(); return FQ_ENODEV; }
+    CK(fqdev::launch_deflate(z));
+    CK(fqdev::launch_scan(c->d_zsize.p, c->d_zoff.p, nb));
+    uint64_t ztotal = 0;
+    CKS(fetch_u64(c, &ztotal, c->d_zoff.p + nb));
+    CKS(sync_staged(c));
+    CKM(c->d_bamz.ensure(ztotal + 64));
+    FqDeflatePackArgs pk{c->d_zstage.p, c->d_zsize.p, c->d_zoff.p, c->d_bamz.p, nb};
+    CK(fqdev::launch_deflate_pack(pk));
+    O.z_bytes = ztotal;
+  }
+  O.ready = true;
+  K.trace("BAM records on the device");
+  return FQ_OK;
+}
 // StatCollector's part of the call (fq_emit.h): decisions per pair, the order-dependent outputs laid out in input order, the per-base sums
 // into the consumer's device tables.  What the consumer's host side needs lands in pinned memory (fq_ctx_qc_out).
 int stage_emit_qc(Call &K) {
@@ -2107,6 +2153,7 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
     REC(FQ_ROP_FLAT_FILL, N);
     if (c->emit_flags & FQ_EMIT_SAM) CKS(stage_emit_sam(K));
     if (c->qc) CKS(stage_emit_qc(K));
+    if (c->bam) CKS(stage_emit_bam(K));
     if (host_arrays) {
       CK(fqdev::copy_pinned(c->p_orec.p, c->d_orec.p, N * sizeof(fq_result_t), 0));
       CK(fqdev::copy_pinned(c->p_ocig.p, c->d_ocig.p, cc * 2, 0));
@@ -2123,6 +2170,7 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
   CK(fqdev::dzero(c->d_counters.p, c->h_counters.size() * 8));
   if (!N && (c->emit_flags & FQ_EMIT_SAM)) { c->sam_bytes = 0; c->sam_ready = true; }
   if (!N && c->qc) { c->qc_out = FqQcCallOut(); c->qc_out.owner = c->qc; c->qc_out.ready = true; }
+  if (!N && c->bam) { c->bam_out = FqBamCallOut(); c->bam_out.owner = c->bam; c->bam_out.ready = true; }
   if (host_arrays) {
     if (!cc) c->p_ocig.p[0] = 0;
     if (!mm) c->p_omd.p[0] = 0;
@@ -2494,25 +2542,40 @@ extern "C" int fq_ctx_set_emit(fq_ctx_t *c, int32_t flags) {
 }
 // The SAM text of the last call leaves the device in slices through two pinned buffers on streams of its own, so that it runs beside the
 // next call on another context: sink(user, data, bytes) gets the slices in order.
-extern "C" int64_t fq_sam_device_last(fq_ctx_t *c, fq_sink_fn sink, void *user) {
-  if (!c || !sink) return FQ_EINVAL;
-  if (!(c->emit_flags & FQ_EMIT_SAM) || !c->sam_ready) { c->err = "fq_sam_device_last: the last call did not format its SAM text on the device (fq_ctx_set_emit)"; return FQ_EINVAL; }
-  const uint64_t total = c->sam_bytes;
+static int64_t stream_device_bytes(fq_ctx_t *c, const char *src, uint64_t total, fq_sink_fn sink, void *user, const char *what) {
   if (!total) return 0;
   if (!c->dev_emit) c->dev_emit = fqdev::state_create(c->ix->device);
-  if (!c->dev_emit || fqdev::bind(c->dev_emit)) { c->err = std::string("fq_sam_device_last: ") + fqdev::last_error(); return FQ_ENODEV; }
+  if (!c->dev_emit || fqdev::bind(c->dev_emit)) { c->err = std::string(what) + ": " + fqdev::last_error(); return FQ_ENODEV; }
   const size_t SL = std::min<uint64_t>(total, (uint64_t)32 << 20);
   if (!c->p_emit[0].ensure(SL) || !c->p_emit[1].ensure(SL)) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
   const uint64_t n_sl = (total + SL - 1) / SL;
   auto bytes_of = [&](uint64_t k) { return (size_t)std::min<uint64_t>(SL, total - k * SL); };
-  if (fqdev::copy_pinned(c->p_emit[0].p, c->d_samtext.p, bytes_of(0), 0) || fqdev::sync()) { c->err = std::string("fq_sam_device_last: ") + fqdev::last_error(); return FQ_ENODEV; }
+  if (fqdev::copy_pinned(c->p_emit[0].p, src, bytes_of(0), 0) || fqdev::sync()) { c->err = std::string(what) + ": " + fqdev::last_error(); return FQ_ENODEV; }
   for (uint64_t k = 0; k < n_sl; ++k) {
-    if (k + 1 < n_sl && fqdev::copy_pinned(c->p_emit[(k + 1) & 1].p, c->d_samtext.p + (k + 1) * SL, bytes_of(k + 1), 0)) { c->err = std::string("fq_sam_device_last: ") + fqdev::last_error(); return FQ_ENODEV; }
-    if (sink(user, c->p_emit[k & 1].p, (int64_t)bytes_of(k))) { (void)fqdev::sync(); c->err = "fq_sam_device_last: the sink failed"; return FQ_EIO; }
-    if (fqdev::sync()) { c->err = std::string("fq_sam_device_last: ") + fqdev::last_error(); return FQ_ENODEV; }
+    if (k + 1 < n_sl && fqdev::copy_pinned(c->p_emit[(k + 1) & 1].p, src + (k + 1) * SL, bytes_of(k + 1), 0)) { c->err = std::string(what) + ": " + fqdev::last_error(); return FQ_ENODEV; }
+    if (sink(user, c->p_emit[k & 1].p, (int64_t)bytes_of(k))) { (void)fqdev::sync(); c->err = std::string(what) + ": the sink failed"; return FQ_EIO; }
+    if (fqdev::sync()) { c->err = std::string(what) + ": " + fqdev::last_error(); return FQ_ENODEV; }
   }
   return (int64_t)total;
 }
+extern "C" int64_t fq_sam_device_last(fq_ctx_t *c, fq_sink_fn sink, void *user) {
+  if (!c || !sink) return FQ_EINVAL;
+  if (!(c->emit_flags & FQ_EMIT_SAM) || !c->sam_ready) { c->err = "fq_sam_device_last: the last call did not format its SAM text on the device (fq_ctx_set_emit)"; return FQ_EINVAL; }
+  return stream_device_bytes(c, c->d_samtext.p, c->sam_bytes, sink, user, "fq_sam_device_last");
+}
+// the BAM records of the last call (fq_ctx_attach_bam), for the writer they were formatted for
+int64_t fq_ctx_bam_stream(fq_ctx_t *c, fq_sink_fn sink, void *user, int members) {
+  if (!c->bam || !c->bam_out.ready) { c->err = "the last call formatted no BAM records on the device"; return FQ_EINVAL; }
+  if (members) return stream_device_bytes(c, (const char *)c->d_bamz.p, c->bam_out.z_bytes, sink, user, "BGZF members");
+  return stream_device_bytes(c, (const char *)c->d_bamrec.p, c->bam_out.bytes, sink, user, "BAM records");
+}
+extern "C" int fq_ctx_attach_bam(fq_ctx_t *c, fq_bam_t *b) {
+  if (!c) return FQ_EINVAL;
+  c->bam = b;
+  c->bam_out = FqBamCallOut();
+  return FQ_OK;
+}
+const FqBamCallOut *fq_ctx_bam_out(const fq_ctx_t *c) { return c->bam ? &c->bam_out : nullptr; }
 extern "C" int fq_ctx_attach_qc(fq_ctx_t *c, fq_qc_t *q) {
   if (!c) return FQ_EINVAL;
   c->qc = q;

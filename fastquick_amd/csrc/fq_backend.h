@@ -6,6 +6,7 @@
 #include "fq_records.h"
 #include "fq_frontend.h"
 #include "fq_emit.h"
+#include "fq_deflate.h"
 
 namespace fqdev {
 
@@ -106,6 +107,10 @@ int launch_rec(int op, const FqRecArgs &a, int64_t n);
 int launch_aln_index(const int32_t *work, const uint32_t *status, const uint64_t *off, const uint32_t *naln, uint64_t base, uint64_t *aoff, uint32_t *an, int n);
 // the consumers on the device (fq_emit.h): SAM text -- operation FQ_EOP_SAM_*, one thread per record
 int launch_sam(int op, const FqSamArgs &a, int64_t n);
+int launch_bam(int op, const FqBamArgs &a, int64_t n);
+// BGZF members of a byte stream (fq_deflate.h): a wavefront per block of FQD_BLOCK bytes into its staging slot; then the members packed behind each other
+int launch_deflate(const FqDeflateArgs &a);
+int launch_deflate_pack(const FqDeflatePackArgs &a);     // BAM records -- FQ_EOP_BAM_*, one thread per record
 // ... StatCollector's part -- operation FQ_QOP_*: a thread per pair (PAIR, IST_FILL) or per record (PILE_FILL); BASE: a wavefront per record,
 // the quality / cycle histograms of a workgroup in LDS
 int launch_qc(int op, const FqQcArgs &a, int64_t n);

@@ -19,6 +19,8 @@
 #include "fq_index.h"
 #include "fq_kernels.h"
 #include "fq_pipeline.h"
+#include "fq_backend.h"
+#include <mutex>
 
 // What the reference's translation unit sees as PACKAGE_VERSION when SetSamFileHeader is compiled: libbwa's 0.0.1 (bwase.h, included
 // first), not src/Version.h's 1.0.6 -- the header the reference writes says VN:0.0.1 (oracle/_ref/fq_ref_driver --bam_dump).
@@ -79,6 +81,12 @@ struct Bgzf {
       buf.erase(buf.begin(), buf.begin() + nb * kBlock);
     }
   }
+  void flush_all() {                 // what is buffered goes out as blocks now (members made elsewhere follow)
+    const size_t nb = (buf.size() + kBlock - 1) / kBlock;
+    if (nb) flush_blocks(nb, buf.size() - (nb - 1) * kBlock);
+    buf.clear();
+  }
+  void write_members(const void *p, size_t n) { if (n && fwrite(p, 1, n, fp) != n) ok = false; }
   void close() {
     if (!fp) return;
     const size_t nb = (buf.size() + kBlock - 1) / kBlock;
@@ -157,6 +165,14 @@ struct Tags {
 }  // namespace
 
 struct fq_bam {
+  // the formatter's tables on the device (fq_emit.h): per contig the BAM reference id of its chromosome and where it lies in the genome
+  std::mutex dev_mu;
+  bool dev_on = false;
+  bool host_deflate = [] { const char *e = getenv("FASTQUICK_BAM_HOST_DEFLATE"); return e && *e && *e != '0'; }();   // A/B: zlib on the host's threads for device-formatted records too
+  std::vector<void *> d_bufs;
+  const int32_t *d_rid = nullptr, *d_g0 = nullptr;
+  const char *d_rg = nullptr;
+  ~fq_bam() { for (void *p : d_bufs) fqdev::dfree(p); }
   const fq_index *ix = nullptr;
   fq_qc_opts_t o{};
   Bgzf z;
@@ -343,6 +359,35 @@ extern "C" int fq_bam_create(const fq_index_t *ix, const char *fai_path, const c
   return FQ_OK;
 }
 
+bool fq_bam_wants_members(const fq_bam *b) { return b->z.fp != nullptr && !b->host_deflate; }
+// the formatter's part of a call's kernel arguments (on the calling context's bound state)
+int fq_bam_device_prepare(fq_bam *b, FqBamArgs *a) {
+  std::lock_guard<std::mutex> lk(b->dev_mu);
+  if (!b->dev_on) {
+    const size_t nc = b->ix->contigs.size();
+    std::vector<int32_t> rid(nc + 1, -1), g0(nc + 1, 0);
+    for (size_t i = 0; i < nc; ++i) {
+      std::string chrom; int start;
+      b->genome_coord((int)i, 1, &chrom, &start);        // start = refCoord - flank + 1 - 1
+      rid[i] = b->id_of(chrom); g0[i] = start;
+    }
+    bool ok = true;
+    auto up = [&](const void *src, size_t bytes) -> void * {
+      void *d = fqdev::dmalloc(bytes ? bytes : 16);
+      if (!d) { ok = false; return nullptr; }
+      b->d_bufs.push_back(d);
+      if (bytes && fqdev::h2d(d, src, bytes)) ok = false;
+      return d;
+    };
+    b->d_rid = (const int32_t *)up(rid.data(), rid.size() * 4); b->d_g0 = (const int32_t *)up(g0.data(), g0.size() * 4);
+    b->d_rg = (const char *)up(b->rg_id.c_str(), b->rg_id.size() + 1);
+    if (!ok || fqdev::sync()) return FQ_ENODEV;
+    b->dev_on = true;
+  }
+  a->ctg_rid = b->d_rid; a->ctg_g0 = b->d_g0; a->rg = b->d_rg; a->rg_len = (int32_t)b->rg_id.size();
+  return FQ_OK;
+}
+
 // the BAM branch of PairEndMapper's consumer loop over one batch (src/BwtMapper.cpp:2054-2085): the batch's records, in input order
 static int format_last(fq_bam_t *b, fq_ctx_t *c, std::vector<std::vector<uint8_t>> &parts) {
   const FqBatchState *S = fq_ctx_state(c);
@@ -389,6 +434,16 @@ static int format_last(fq_bam_t *b, fq_ctx_t *c, std::vector<std::vector<uint8_t
 }
 extern "C" int fq_bam_add_last(fq_bam_t *b, fq_ctx_t *c) {
   if (!b || !c || !b->z.fp) return FQ_EINVAL;
+  if (const FqBamCallOut *D = fq_ctx_bam_out(c)) {        // the records were formatted by the call's kernels (fq_ctx_attach_bam): they only leave the device here
+    if (D->owner != b || !D->ready) { b->err = "fq_bam_add_last: the context's last call formatted its records for another writer, or failed"; return FQ_EINVAL; }
+    int64_t n;
+    if (D->z_bytes) {       // finished BGZF members (fq_deflate.h): appended behind whatever the host's layer still holds
+      b->z.flush_all();
+      n = fq_ctx_bam_stream(c, [](void *user, const void *data, int64_t len) -> int { ((fq_bam *)user)->z.write_members(data, (size_t)len); return ((fq_bam *)user)->z.ok ? 0 : 1; }, b, 1);
+    } else n = fq_ctx_bam_stream(c, [](void *user, const void *data, int64_t len) -> int { ((fq_bam *)user)->z.write(data, (size_t)len); return ((fq_bam *)user)->z.ok ? 0 : 1; }, b, 0);
+    if (n < 0) { b->err = "fq_bam_add_last: fetching the records from the device failed"; return (int)n; }
+    return b->z.ok ? FQ_OK : FQ_EIO;
+  }
   std::vector<std::vector<uint8_t>> parts;
   const int rc = format_last(b, c, parts);
   if (rc) return rc;
@@ -399,6 +454,15 @@ extern "C" int fq_bam_add_last(fq_bam_t *b, fq_ctx_t *c) {
 // devices format the batches of their FASTQ pairs at once and one writer appends them in input order (fq_bam_write_records).
 extern "C" int fq_bam_format_last(fq_bam_t *b, fq_ctx_t *c, const void **data, int64_t *len) {
   if (!b || !c || !data || !len) return FQ_EINVAL;
+  if (const FqBamCallOut *D = fq_ctx_bam_out(c)) {
+    if (D->owner != b || !D->ready) { b->err = "fq_bam_format_last: the context's last call formatted its records for another writer, or failed"; return FQ_EINVAL; }
+    b->last.clear();
+    b->last.reserve((size_t)D->bytes);
+    const int64_t n = fq_ctx_bam_stream(c, [](void *user, const void *d, int64_t l) -> int { auto *v = (std::vector<uint8_t> *)user; v->insert(v->end(), (const uint8_t *)d, (const uint8_t *)d + l); return 0; }, &b->last, 0);
+    if (n < 0) return (int)n;
+    *data = b->last.data(); *len = (int64_t)b->last.size();
+    return FQ_OK;
+  }
   std::vector<std::vector<uint8_t>> parts;
   const int rc = format_last(b, c, parts);
   if (rc) return rc;
@@ -412,6 +476,38 @@ extern "C" int fq_bam_write_records(fq_bam_t *b, const void *data, int64_t len) 
   if (len) b->z.write(data, (size_t)len);
   return b->z.ok ? FQ_OK : FQ_EIO;
 }
+// (tests, tools) n bytes as BGZF members written by the device's compressor (fq_deflate.h): the members behind each other into out (capacity cap);
+// *out_len their size, *kernel_ms the compressor kernel's time.  FQ_ELIMIT when cap is too small.
+extern "C" int fq_bgzf_deflate_device(int device, const uint8_t *in, int64_t n, uint8_t *out, int64_t cap, int64_t *out_len, double *kernel_ms) {
+  if (!in || !out || !out_len || n < 0) return FQ_EINVAL;
+  struct DevScope { fqdev::State *s; ~DevScope() { fqdev::state_destroy(s); } } scope{fqdev::state_create(device)};
+  if (!scope.s || fqdev::bind(scope.s)) return FQ_ENODEV;
+  const uint32_t nb = (uint32_t)((n + FQD_BLOCK - 1) / FQD_BLOCK);
+  *out_len = 0;
+  if (kernel_ms) *kernel_ms = 0;
+  if (!nb) return FQ_OK;
+  uint8_t *d_in = (uint8_t *)fqdev::dmalloc((size_t)n + 64), *d_stage = (uint8_t *)fqdev::dmalloc((size_t)nb * FQD_SLOT), *d_out = (uint8_t *)fqdev::dmalloc((size_t)nb * FQD_SLOT);
+  uint32_t *d_bs = (uint32_t *)fqdev::dmalloc(((size_t)nb + 1) * 4);
+  uint64_t *d_off = (uint64_t *)fqdev::dmalloc(((size_t)nb + 2) * 8);
+  int rc = FQ_OK;
+  uint64_t total = 0;
+  if (!d_in || !d_stage || !d_out || !d_bs || !d_off) rc = FQ_ENOMEM;
+  else {
+    FqDeflateArgs a{d_in, (uint64_t)n, d_stage, d_bs, fqdev::crc_const(), nb};
+    FqDeflatePackArgs pk{d_stage, d_bs, d_off, d_out, nb};
+    double ms[FQ_K_COUNT] = {0}; uint64_t ln[FQ_K_COUNT] = {0};
+    if (!a.crc || fqdev::h2d(d_in, in, (size_t)n) || fqdev::launch_deflate(a) || fqdev::launch_scan(d_bs, d_off, nb) || fqdev::launch_deflate_pack(pk) ||
+        fqdev::d2h(&total, d_off + nb, 8) || fqdev::sync()) rc = FQ_ENODEV;
+    else if ((int64_t)total > cap) rc = FQ_ELIMIT;
+    else if (fqdev::d2h(out, d_out, (size_t)total) || fqdev::sync()) rc = FQ_ENODEV;
+    fqdev::time_collect(ms, ln, FQ_K_COUNT);
+    if (kernel_ms) *kernel_ms = ms[FQ_K_EMIT];
+  }
+  for (void *p : {(void *)d_in, (void *)d_stage, (void *)d_out, (void *)d_bs, (void *)d_off}) fqdev::dfree(p);
+  *out_len = (int64_t)total;
+  return rc;
+}
+
 extern "C" int fq_bam_close(fq_bam_t *b) {
   if (!b) return FQ_EINVAL;
   b->z.close();

@@ -275,8 +275,9 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
   // stay there; the consumer threads below only move text and append
   auto device_consumers = [&](fq_ctx_t *cx) {
     if (A.host_consumers) return;
-    // (SAM text: nothing on the host reads the result arrays any more -- they stay in HBM; the BAM writer still formats on the host)
-    if (A.sam_out && fq_ctx_set_emit(cx, FQ_EMIT_SAM | FQ_EMIT_DEVICE_ONLY)) die("fq_ctx_set_emit failed");
+    // (nothing on the host reads the result arrays any more: they stay in HBM)
+    if (fq_ctx_set_emit(cx, (A.sam_out ? FQ_EMIT_SAM : 0) | FQ_EMIT_DEVICE_ONLY)) die("fq_ctx_set_emit failed");
+    if (!A.sam_out && out.bam && fq_ctx_attach_bam(cx, out.bam)) die("fq_ctx_attach_bam failed");
     if (qc && fq_ctx_attach_qc(cx, qc)) die("fq_ctx_attach_qc failed");
   };
   // A refusal ends the run behind the records of every call before it (the reference prints the batches before the one that aborts,
@@ -644,7 +645,8 @@ void align_pair_sharded(const Args &A, const std::pair<std::string, std::string>
     if (fq_packed_create((int32_t)A.chunk_pairs, stride, &pk)) die("out of pinned host memory for the packed batch");
     if (K.qc) { fq_qc_begin_file(K.qc, input.first.c_str(), input.second.c_str()); if (fq_qc_state_reset(K.qc)) die("QC consumer: cannot start a segment"); }
     if (!A.host_consumers) {
-      if (A.sam_out && fq_ctx_set_emit(ctx, FQ_EMIT_SAM | FQ_EMIT_DEVICE_ONLY)) die("fq_ctx_set_emit failed");
+      if (fq_ctx_set_emit(ctx, (A.sam_out ? FQ_EMIT_SAM : 0) | FQ_EMIT_DEVICE_ONLY)) die("fq_ctx_set_emit failed");
+      if (!A.sam_out && K.bam && fq_ctx_attach_bam(ctx, K.bam)) die("fq_ctx_attach_bam failed");
       if (K.qc && fq_ctx_attach_qc(ctx, K.qc)) die("fq_ctx_attach_qc failed");
     }
     std::vector<char> sam;

@@ -1579,6 +1579,55 @@ int launch_sam(int op, const FqSamArgs &a, int64_t n) {
   FQ_HIP(hipGetLastError());
   return 0;
 }
+__global__ void __launch_bounds__(256) k_bam_len(FqBamArgs a, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) fq_bam_len_thread(a, i);
+}
+__global__ void __launch_bounds__(256) k_bam_fill(FqBamArgs a, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) fq_bam_fill_thread(a, i);
+}
+int launch_bam(int op, const FqBamArgs &a, int64_t n) {
+  FQ_PRE();
+  if (n <= 0) return 0;
+  if (n > 0x7fffffff) { g_err = "BAM records: more than 2^31 records"; return -5; }
+  hipEvent_t e0, e1;
+  kernel_events(FQ_K_EMIT, &e0, &e1);
+  if (op == FQ_EOP_BAM_LEN) hipExtLaunchKernelGGL(k_bam_len, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
+  else if (op == FQ_EOP_BAM_FILL) hipExtLaunchKernelGGL(k_bam_fill, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
+  else { g_err = "BAM records: unknown operation"; return -1; }
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+// one wavefront per BGZF member (fq_deflate.h)
+__global__ void __launch_bounds__(256) k_bgzf_deflate(FqDeflateArgs a) {
+  __shared__ FqdLds lds[4];
+  const uint32_t b = blockIdx.x * 4u + (threadIdx.x >> 6);
+  if (b >= a.n_blocks) return;
+  const uint32_t bs = fqd_member(a, b, lds[threadIdx.x >> 6]);
+  if ((threadIdx.x & 63) == 0) a.bsize[b] = bs;
+}
+__global__ void __launch_bounds__(256) k_bgzf_pack(FqDeflatePackArgs a, uint64_t n) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < n) fqd_pack_piece(a, t);
+}
+int launch_deflate(const FqDeflateArgs &a) {
+  FQ_PRE();
+  if (!a.n_blocks) return 0;
+  hipEvent_t e0, e1;
+  kernel_events(FQ_K_EMIT, &e0, &e1);
+  hipExtLaunchKernelGGL(k_bgzf_deflate, dim3(nblk(a.n_blocks, 4)), dim3(256), 0, g_stream, e0, e1, 0, a);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
+int launch_deflate_pack(const FqDeflatePackArgs &a) {
+  FQ_PRE();
+  if (!a.n_blocks) return 0;
+  const uint64_t n = (uint64_t)a.n_blocks * (FQD_SLOT / 16);
+  hipLaunchKernelGGL(k_bgzf_pack, dim3(nblk(n, 256)), dim3(256), 0, g_stream, a, n);
+  FQ_HIP(hipGetLastError());
+  return 0;
+}
 __global__ void __launch_bounds__(256) k_qc_pair(FqQcArgs a, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) fq_qc_pair_thread(a, i);

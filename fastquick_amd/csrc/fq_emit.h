@@ -223,7 +223,200 @@ FQ_HD void fq_sam_fill_thread(const FqSamArgs &A, int idx) {
   fq_sam_line(A, idx, o);
 }
 
-enum { FQ_EOP_SAM_LEN = 0, FQ_EOP_SAM_FILL, FQ_EOP_COUNT };
+// ---- BAM records: SetSamRecord (src/BwtMapper.cpp:977-1264), restated field by field as fq_bam.cpp does on the host -----------------------
+struct FqBamArgs {
+  FqSamArgs s;
+  const int32_t *ctg_rid;        // [n contigs] id of the contig's chromosome among the BAM header's references (-1: not there)
+  const int32_t *ctg_g0;         // refCoord - flank: the genome coordinate of offset x of the contig is g0 + x + 1 (1-based)
+  const char *rg; int32_t rg_len;   // the read group's ID ("": none)
+  uint32_t *len; const uint64_t *off; uint8_t *out;
+};
+struct FqBin {                   // bytes that are either measured (dst == nullptr) or written
+  uint8_t *dst;
+  int64_t at;
+  FQ_HD void u8(uint32_t v) { if (dst) dst[at] = (uint8_t)v; ++at; }
+  FQ_HD void u16(uint32_t v) { u8(v & 0xff); u8((v >> 8) & 0xff); }
+  FQ_HD void u32(uint32_t v) { u8(v & 0xff); u8((v >> 8) & 0xff); u8((v >> 16) & 0xff); u8(v >> 24); }
+  FQ_HD void tag(char a, char b, char t) { u8((uint8_t)a); u8((uint8_t)b); u8((uint8_t)t); }
+  FQ_HD void tag_int(char a, char b, long long v) {      // the smallest integer type that holds the value (SamRecord::addIntTag)
+    if (v >= 0 && v <= 255) { tag(a, b, 'C'); u8((uint32_t)v); }
+    else if (v >= -128 && v <= 127) { tag(a, b, 'c'); u8((uint32_t)(int8_t)v); }
+    else if (v >= 0 && v <= 65535) { tag(a, b, 'S'); u16((uint32_t)v); }
+    else if (v >= -32768 && v <= 32767) { tag(a, b, 's'); u16((uint32_t)(uint16_t)(int16_t)v); }
+    else { tag(a, b, 'i'); u32((uint32_t)(int32_t)v); }
+  }
+};
+FQ_HD int fq_bam_reg2bin(int64_t beg, int64_t end) {   // SAM specification 5.3
+  --end;
+  if (beg >> 14 == end >> 14) return (int)(((1 << 15) - 1) / 7 + (beg >> 14));
+  if (beg >> 17 == end >> 17) return (int)(((1 << 12) - 1) / 7 + (beg >> 17));
+  if (beg >> 20 == end >> 20) return (int)(((1 << 9) - 1) / 7 + (beg >> 20));
+  if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
+  if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
+  return 0;
+}
+// the optional fields in the order the reference WRITES them: SamRecord keeps its tags in a 32-slot hash keyed by the tag's first letter (linear
+// probing) and walks the slots (misc/bam/SamRecord.cpp:3308-3340); SetSamRecord adds them in the order of the list below
+enum { FQ_BT_RG = 0, FQ_BT_XC, FQ_BT_XT, FQ_BT_NM, FQ_BT_XN, FQ_BT_SM, FQ_BT_AM, FQ_BT_X0, FQ_BT_X1, FQ_BT_XM, FQ_BT_XO, FQ_BT_XG, FQ_BT_MD, FQ_BT_XA, FQ_BT_COUNT };
+FQ_HD void fq_bam_record(const FqBamArgs &A, int idx, FqBin &o) {
+  const FqSamArgs &S = A.s;
+  const bool se = S.single_end != 0;
+  if (se && (idx & 1)) return;
+  fq_result_t p = S.rec[idx];
+  const fq_result_t mate = se ? p : S.rec[idx ^ 1];
+  if (p.type == FQ_TYPE_NO_MATCH && mate.type == FQ_TYPE_NO_MATCH) return;     // src/BwtMapper.cpp:2038-2042
+  int seqid = 0, m_seqid0 = 0;
+  p.type = (uint8_t)fq_emit_bridged_type(S.cg, p, S.cigar, &seqid);
+  const int mate_type = se ? p.type : fq_emit_bridged_type(S.cg, mate, S.cigar, &m_seqid0);
+  const uint8_t *row = S.seq + (size_t)fq_emit_row(S.packed, S.n_pairs, S.pair_list, idx) * (size_t)S.stride;
+  const uint8_t *hq = S.qual + (size_t)idx * (size_t)S.qual_stride;
+  const int qsub = (S.mode & FQ_MODE_IL13) ? 31 : 0;
+  const int64_t start = o.at;
+  o.u32(0);                                          // block_size: patched below
+  int flag, rid = -1, pos1 = 0, mrid = -1, mpos1 = 0, mapq = 0, n_cig = 0, nn = 0, am = 0;
+  long long isize = 0;
+  const bool any = p.type != FQ_TYPE_NO_MATCH || (!se && mate_type != FQ_TYPE_NO_MATCH);
+  const uint8_t ptype = p.type;
+  if (any) {
+    int j, readRealStart = 0;
+    flag = p.extra_flag;
+    if (p.type == FQ_TYPE_NO_MATCH) { p.pos = mate.pos; p.strand = mate.strand; flag |= 4; j = 1; }
+    else j = (int)(fq_emit_ref_end(p, S.cigar) - p.pos);
+    nn = fq_dev_pac2real(S.cg, p.pos, j, &seqid);
+    if (ptype != FQ_TYPE_NO_MATCH && (int64_t)p.pos + j - S.cg.off[seqid] > S.cg.len[seqid]) flag |= 4;
+    if (p.strand) flag |= 16;
+    if (!se) { if (mate_type != FQ_TYPE_NO_MATCH) { if (mate.strand) flag |= 32; } else flag |= 8; }
+    if (ptype == FQ_TYPE_NO_MATCH) { rid = -1; pos1 = 0; }
+    else { readRealStart = A.ctg_g0[seqid] + (int)((int64_t)p.pos - S.cg.off[seqid] + 1) - 1; rid = A.ctg_rid[seqid]; pos1 = readRealStart; }
+    mapq = p.mapQ;
+    if (ptype != FQ_TYPE_NO_MATCH) n_cig = p.n_cigar ? p.n_cigar : 1;
+    if (se) { mrid = -1; mpos1 = 0; isize = 0; }
+    else if (mate_type != FQ_TYPE_NO_MATCH) {
+      int m_seqid;
+      am = mate.seQ < p.seQ ? mate.seQ : p.seQ;
+      fq_dev_pac2real(S.cg, mate.pos, mate.len, &m_seqid);
+      const int mstart = A.ctg_g0[m_seqid] + (int)((int64_t)mate.pos - S.cg.off[m_seqid] + 1) - 1;
+      const bool same = seqid == m_seqid;
+      mrid = same ? rid : A.ctg_rid[m_seqid];
+      const long long m5 = mate.strand ? (long long)fq_emit_ref_end(mate, S.cigar) : (long long)mate.pos;
+      const long long p5 = ptype != FQ_TYPE_NO_MATCH ? (p.strand ? (long long)fq_emit_ref_end(p, S.cigar) : (long long)p.pos) : -1;
+      isize = same ? m5 - p5 : 0;
+      if (ptype == FQ_TYPE_NO_MATCH) isize = 0;
+      mpos1 = mstart;
+    } else { mrid = rid; mpos1 = readRealStart; isize = 0; }
+  } else flag = p.extra_flag | 4 | (se ? 0 : 8);
+  const int l_seq = any ? p.full_len : p.len;
+  // name
+  FqTxt nm; nm.dst = nullptr; nm.at = 0;
+  fq_emit_name(S.names, S.name_stride, idx, p.revived != 0, nm);
+  const int l_name = (int)nm.at + 1;
+  int64_t end0 = pos1 > 0 ? pos1 - 1 : 0;
+  if (n_cig) {
+    if (p.n_cigar) { const uint16_t *cg = S.cigar + p.cigar_off; for (int k = 0; k < p.n_cigar; ++k) { const int op = cg[k] >> 14; if (op == FQ_OP_M || op == FQ_OP_D) end0 += cg[k] & 0x3fff; } }
+    else end0 += p.len;
+  }
+  const int bin = pos1 > 0 ? fq_bam_reg2bin(pos1 - 1, n_cig == 0 ? pos1 : end0) : 4680;
+  o.u32((uint32_t)rid); o.u32((uint32_t)(pos1 - 1));
+  o.u8((uint32_t)l_name & 0xff); o.u8((uint32_t)mapq); o.u16((uint32_t)bin);
+  o.u16((uint32_t)n_cig); o.u16((uint32_t)flag); o.u32((uint32_t)l_seq);
+  o.u32((uint32_t)mrid); o.u32((uint32_t)(mpos1 - 1)); o.u32((uint32_t)(int32_t)isize);
+  { FqTxt w; w.dst = o.dst ? (char *)o.dst + o.at : nullptr; w.at = 0; fq_emit_name(S.names, S.name_stride, idx, p.revived != 0, w); o.at += w.at; o.u8(0); }
+  if (n_cig) {
+    if (p.n_cigar) { const uint16_t *cg = S.cigar + p.cigar_off; for (int k = 0; k < p.n_cigar; ++k) { const int op = cg[k] >> 14; o.u32((uint32_t)(cg[k] & 0x3fff) << 4 | (uint32_t)(op == 3 ? 4 : op)); } }
+    else o.u32((uint32_t)p.len << 4);
+  }
+  // bases, two per byte (=ACMGRSVTWYHKDBN: A 1, C 2, G 4, T 8, N 15), then qualities
+  for (int j = 0; j < l_seq; j += 2) {
+    int nib[2] = {0, 0};
+    for (int t = 0; t < 2 && j + t < l_seq; ++t) {
+      const int jj = j + t;
+      int cc;
+      if (any) { cc = p.strand == 0 ? fq_nt4(row[jj]) : fq_comp(fq_nt4(row[p.full_len - 1 - jj])); }
+      else { cc = fq_nt4(row[jj]); if (p.strand) { cc = jj < p.clip_len ? fq_nt4(row[p.clip_len - 1 - jj]) : 3; cc = cc < 4 ? 3 - cc : cc; } }
+      nib[t] = cc > 3 ? 15 : (1 << cc);
+    }
+    o.u8((uint32_t)(nib[0] << 4 | nib[1]));
+  }
+  for (int j = 0; j < l_seq; ++j) {
+    int q;
+    if (j >= p.full_len) q = 0xff + 33;              // (a no-match record prints len bases and full_len qualities: the rest of the column is absent)
+    else if (any) { const int src = (p.strand && j < p.len) ? p.len - 1 - j : j; q = j < p.len ? hq[src] : hq[src] - qsub; }
+    else q = hq[(p.strand && j < p.len) ? p.len - 1 - j : j] - qsub;
+    o.u8((uint32_t)(q - 33) & 0xff);
+  }
+  // ---- tags, in the order of the reference's 32-slot hash
+  bool have[FQ_BT_COUNT];
+  for (int t = 0; t < FQ_BT_COUNT; ++t) have[t] = false;
+  have[FQ_BT_RG] = A.rg_len > 0;
+  have[FQ_BT_XC] = p.clip_len < p.full_len;
+  if (any && ptype != FQ_TYPE_NO_MATCH) {
+    have[FQ_BT_XT] = have[FQ_BT_NM] = true;
+    have[FQ_BT_XN] = nn != 0;
+    have[FQ_BT_SM] = have[FQ_BT_AM] = !se;
+    have[FQ_BT_X0] = ptype != FQ_TYPE_MATESW;
+    have[FQ_BT_X1] = have[FQ_BT_X0] && (int)p.c1 <= S.max_top2;
+    have[FQ_BT_XM] = have[FQ_BT_XO] = have[FQ_BT_XG] = true;
+    have[FQ_BT_MD] = p.md_off != 0xffffffffu;
+    have[FQ_BT_XA] = p.n_multi != 0;
+  }
+  const char first_letter[FQ_BT_COUNT] = {'R', 'X', 'X', (S.mode & FQ_MODE_COMPREAD) ? 'N' : 'C', 'X', 'S', 'A', 'X', 'X', 'X', 'X', 'X', 'M', 'X'};
+  int8_t slot[32];
+  for (int h = 0; h < 32; ++h) slot[h] = -1;
+  for (int t = 0; t < FQ_BT_COUNT; ++t) {
+    if (!have[t]) continue;
+    int h = first_letter[t] & 31;
+    while (slot[h] >= 0) h = (h + 1) & 31;
+    slot[h] = (int8_t)t;
+  }
+  for (int h = 0; h < 32; ++h) {
+    switch (slot[h]) {
+      case FQ_BT_RG: o.tag('R', 'G', 'Z'); for (int k = 0; k < A.rg_len; ++k) o.u8((uint8_t)A.rg[k]); o.u8(0); break;
+      case FQ_BT_XC: o.tag_int('X', 'C', p.clip_len); break;
+      case FQ_BT_XT: { char XT = "NURM"[ptype]; if (nn > 10) XT = 'N'; o.tag('X', 'T', 'A'); o.u8((uint8_t)XT); break; }
+      case FQ_BT_NM: o.tag_int((S.mode & FQ_MODE_COMPREAD) ? 'N' : 'C', 'M', p.nm); break;
+      case FQ_BT_XN: o.tag_int('X', 'N', nn); break;
+      case FQ_BT_SM: o.tag_int('S', 'M', p.seQ); break;
+      case FQ_BT_AM: o.tag_int('A', 'M', am); break;
+      case FQ_BT_X0: o.tag_int('X', '0', (long long)p.c1); break;
+      case FQ_BT_X1: o.tag_int('X', '1', (long long)p.c2); break;
+      case FQ_BT_XM: o.tag_int('X', 'M', p.n_mm); break;
+      case FQ_BT_XO: o.tag_int('X', 'O', p.n_gapo); break;
+      case FQ_BT_XG: o.tag_int('X', 'G', p.n_gapo + p.n_gape); break;
+      case FQ_BT_MD: { o.tag('M', 'D', 'Z'); const char *m = S.md + p.md_off; while (*m) o.u8((uint8_t)*m++); o.u8(0); break; }
+      case FQ_BT_XA: {
+        o.tag('X', 'A', 'Z');
+        FqTxt w; w.dst = o.dst ? (char *)o.dst + o.at : nullptr; w.at = 0;
+        for (int t = 0; t < p.n_multi; ++t) {
+          const fq_multi_t q = S.multi[p.multi_off + t];
+          int64_t qe = (int64_t)q.pos + p.len;
+          if (q.n_cigar) { qe = q.pos; const uint16_t *cg = S.cigar + q.cigar_off; for (int k = 0; k < q.n_cigar; ++k) { const int op = cg[k] >> 14; if (op == FQ_OP_M || op == FQ_OP_D) qe += cg[k] & 0x3fff; } }
+          int qs;
+          fq_dev_pac2real(S.cg, q.pos, (int)(qe - q.pos), &qs);
+          w.bytes(S.cg.names + S.cg.name_off[qs], (int)(S.cg.name_off[qs + 1] - S.cg.name_off[qs]));
+          w.ch(','); w.ch(q.strand ? '-' : '+'); w.num((int)((int64_t)q.pos - S.cg.off[qs] + 1)); w.ch(',');
+          if (q.n_cigar) w.cigar(S.cigar + q.cigar_off, q.n_cigar); else { w.num(p.len); w.ch('M'); }
+          w.ch(','); w.num(q.gap + q.mm); w.ch(';');
+        }
+        o.at += w.at; o.u8(0);
+        break;
+      }
+      default: break;
+    }
+  }
+  if (o.dst) { const uint32_t bs = (uint32_t)(o.at - start - 4); o.dst[start] = (uint8_t)bs; o.dst[start + 1] = (uint8_t)(bs >> 8); o.dst[start + 2] = (uint8_t)(bs >> 16); o.dst[start + 3] = (uint8_t)(bs >> 24); }
+}
+FQ_HD void fq_bam_len_thread(const FqBamArgs &A, int idx) {
+  FqBin o; o.dst = nullptr; o.at = 0;
+  fq_bam_record(A, idx, o);
+  A.len[idx] = (uint32_t)o.at;
+}
+FQ_HD void fq_bam_fill_thread(const FqBamArgs &A, int idx) {
+  if (!A.len[idx]) return;
+  FqBin o; o.dst = A.out + A.off[idx]; o.at = 0;
+  fq_bam_record(A, idx, o);
+}
+
+enum { FQ_EOP_SAM_LEN = 0, FQ_EOP_SAM_FILL, FQ_EOP_BAM_LEN, FQ_EOP_BAM_FILL, FQ_EOP_COUNT };
 
 // =====================================================================================================================================
 // StatCollector on the device: AddAlignment (src/StatCollector.cpp:950-1101), AddSingleAlignment (:424-620), ProcessPairStatus (:623-921)
@@ -268,6 +461,8 @@ struct FqQcArgs {
   uint32_t *depth, *q20, *q30;
   uint64_t *hist;                // [4][256] EmpRep, misEmpRep, EmpCycle, misEmpCycle
   uint64_t *insert_dist;         // [FQ_QC_INSERT_LIMIT]
+  uint64_t *est_hist;            // [4][FQ_QC_INSERT_LIMIT] what InsertSizeEstimator reads back from the .InsertSizeTable lines (src/InsertSizeEstimator.cpp:43-143), counted as
+                                 // the lines are decided: observed inserts of PropPair lines; censored ones of FwdOnly, of RevOnly, of half-clipped PartialPair lines
   uint64_t *counters;            // striped like the work counters (FQ_C_STRIPES x FQ_C_STRIDE)
   uint32_t *sex_cnt;             // [n contigs][4] overlapped, fully, pair_overlapped, fully_paired
   uint64_t *sex_first;           // [n contigs] key of the first count (2 * pair ordinal + which), ~0: never
@@ -329,6 +524,29 @@ FQ_HD void fq_span_columns(const FqQcArgs &A, const FqSpan &m, FqTxt &o) {
     if (m.r.n_cigar) o.cigar(A.s.cigar + m.r.cigar_off, m.r.n_cigar); else { o.num(m.r.len); o.ch('M'); }
   } else { o.str("\t*\t*\t"); o.num(m.flag); o.str("\t0\t*"); }
 }
+// what the estimator's reader makes of the line that is being written (InputInsertSizeTable): kind 0 PropPair, 1 FwdOnly, 2 RevOnly, 3 PartialPair; other lines count nothing
+FQ_HD void fq_est_count(const FqQcArgs &A, const FqSpan &a, const FqSpan &b, int lim_fwd, int lim_rev, int insert, int kind) {
+  const int L = FQ_QC_INSERT_LIMIT;
+  int Max = lim_fwd, Max2 = lim_rev, Obs = insert;
+  if (Max >= L || Max == -1) Max = L - 1;
+  if (Max2 >= L || Max2 == -1) Max2 = L - 1;
+  if (Obs >= L || Obs == -1) Obs = L - 1;
+  if (Max < 0 || Max2 < 0 || Obs < 0) return;          // (the reference indexes unchecked; its own writer produces no such line)
+  if (kind == 0) FQ_ATOMIC_ADD64_PLAIN(&A.est_hist[0 * L + Obs], 1);
+  else if (kind == 1) FQ_ATOMIC_ADD64_PLAIN(&A.est_hist[1 * L + Max], 1);
+  else if (kind == 2) FQ_ATOMIC_ADD64_PLAIN(&A.est_hist[2 * L + Max2], 1);
+  else {
+    auto clipped = [&](const FqSpan &m) FQ_LAMBDA_INLINE {     // the CIGAR column holds an 'S'
+      if (!m.placed || !m.r.n_cigar) return false;
+      const uint16_t *cg = A.s.cigar + m.r.cigar_off;
+      for (int k = 0; k < m.r.n_cigar; ++k) if ((cg[k] >> 14) == FQ_OP_S) return true;
+      return false;
+    };
+    const bool s1 = clipped(a), s2 = clipped(b);
+    if (!s1 && s2) FQ_ATOMIC_ADD64_PLAIN(&A.est_hist[3 * L + ((a.flag & 16) ? Max2 : Max)], 1);
+    else if (s1 && !s2) FQ_ATOMIC_ADD64_PLAIN(&A.est_hist[3 * L + ((b.flag & 16) ? Max2 : Max)], 1);
+  }
+}
 FQ_HD void fq_ist_line(const FqQcArgs &A, const FqSpan &a, const FqSpan &b, int name_idx, bool name_revived, int lim_fwd, int lim_rev, int insert, const char *outcome, FqTxt &o) {
   fq_emit_name(A.s.names, A.s.name_stride, name_idx, name_revived, o);
   o.ch('\t'); o.num(lim_fwd); o.ch('\t'); o.num(lim_rev); o.ch('\t'); o.num(insert);
@@ -347,6 +565,7 @@ FQ_HD void fq_pair_status(const FqQcArgs &A, int sp, int tP, int tQ, int type, b
     if (room < 0) return;
     const bool rv = fq_span_reverse(m);
     fq_ist_line(A, a, b, m.idx, m.r.revived != 0, rv ? -1 : room, rv ? room : -1, -1, rv ? "RevOnly" : "FwdOnly", o);
+    if (effects) fq_est_count(A, a, b, rv ? -1 : room, rv ? room : -1, -1, rv ? 2 : 1);
     return;
   }
   const FqSpan *fwd = nullptr, *rev = nullptr;
@@ -362,6 +581,7 @@ FQ_HD void fq_pair_status(const FqQcArgs &A, int sp, int tP, int tQ, int type, b
   if (effects && insert >= 0 && insert < FQ_QC_INSERT_LIMIT) FQ_ATOMIC_ADD64_PLAIN(&A.insert_dist[insert], 1);
   fq_ist_line(A, a, b, a.idx, a.r.revived != 0, lim_fwd, lim_rev, insert, proper ? "PropPair" : "PartialPair", o);
   if (effects) {
+    fq_est_count(A, a, b, lim_fwd, lim_rev, insert, proper ? 0 : 3);
     bool dup = false;
     const bool keyed = proper && unclipped;
     // the duplicate key: contig and both outer ends ("%d:%d:%d" in the reference).  A proper pair's ends lie inside its contig, so the ends alone name it.

@@ -155,6 +155,13 @@ struct FqQcCallOut {
   uint64_t cnt[FQ_QC_C_COUNT] = {};
 };
 const FqQcCallOut *fq_ctx_qc_out(const fq_ctx_t *c);
+// ... and a call that formatted its BAM records on the device (fq_ctx_attach_bam): bytes in HBM, streamed off by the writer
+struct fq_bam;
+struct FqBamCallOut { const fq_bam *owner = nullptr; bool ready = false; uint64_t bytes = 0, z_bytes = 0; };   // z_bytes: the same records as finished BGZF members (0: not made)
+const FqBamCallOut *fq_ctx_bam_out(const fq_ctx_t *c);
+int fq_bam_device_prepare(fq_bam *b, FqBamArgs *a);
+int64_t fq_ctx_bam_stream(fq_ctx_t *c, fq_sink_fn sink, void *user, int members);   // members != 0: the BGZF members instead of the raw records
+bool fq_bam_wants_members(const fq_bam *b);
 int fq_qc_device_prepare(fq_qc *q, FqQcArgs *a, int n_surv);
 int64_t fq_ctx_last_bases(const fq_ctx_t *c);   // sum of the read lengths of the last batch (NumBase increment)
 // the name a record prints under (fq_sam.cpp): `/1` `/2` stripped, a revived mate under its partner's name

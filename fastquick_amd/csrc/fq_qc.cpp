@@ -197,12 +197,16 @@ struct fq_qc {
   FqQcGeom geom{};
   size_t table_size = 0, n_contigs = 0;
   uint32_t *d_depth = nullptr, *d_q20 = nullptr, *d_q30 = nullptr, *d_sex_cnt = nullptr;
-  uint64_t *d_hist = nullptr, *d_insert = nullptr, *d_sex_first = nullptr, *d_dup = nullptr;
+  uint64_t *d_hist = nullptr, *d_insert = nullptr, *d_sex_first = nullptr, *d_dup = nullptr, *d_est = nullptr;
+  // what InsertSizeEstimator would read back from the .InsertSizeTable (counted by the device as the lines were decided): valid while every line of
+  // the table came from the device path of THIS consumer (no merged segment, no host-side batch)
+  std::vector<uint64_t> est_hist = std::vector<uint64_t>(4 * (size_t)kInsertLimit, 0);
+  bool est_valid = true;
   uint64_t dup_cap = 0, ord_next = 0;
   int device_setup();
   int pull();                                      // device sums -> host tables; the device tables start again from zero
   int bind_own();
-  ~fq_qc() { if (dev_on || dev) { if (!bind_own()) { for (void *b : d_bufs) fqdev::dfree(b); for (void *b : {(void *)d_depth, (void *)d_q20, (void *)d_q30, (void *)d_sex_cnt, (void *)d_hist, (void *)d_insert, (void *)d_sex_first, (void *)d_dup}) fqdev::dfree(b); } if (dev) fqdev::state_destroy(dev); } }
+  ~fq_qc() { if (dev_on || dev) { if (!bind_own()) { for (void *b : d_bufs) fqdev::dfree(b); for (void *b : {(void *)d_depth, (void *)d_q20, (void *)d_q30, (void *)d_sex_cnt, (void *)d_hist, (void *)d_insert, (void *)d_sex_first, (void *)d_dup, (void *)d_est}) fqdev::dfree(b); } if (dev) fqdev::state_destroy(dev); } }
 
   int restore(const std::string &ref_prefix);
   bool add_single(const Rec &p, const FqHostReads &hb);
@@ -623,6 +627,7 @@ int fq_qc::device_setup() {
   d_depth = (uint32_t *)zeroed((table_size + 1) * 4, 0); d_q20 = (uint32_t *)zeroed((table_size + 1) * 4, 0); d_q30 = (uint32_t *)zeroed((table_size + 1) * 4, 0);
   d_hist = (uint64_t *)zeroed(4 * 256 * 8, 0); d_insert = (uint64_t *)zeroed((size_t)kInsertLimit * 8, 0);
   d_sex_cnt = (uint32_t *)zeroed((nc + 1) * 4 * 4, 0); d_sex_first = (uint64_t *)zeroed((nc + 1) * 8, 0xff);
+  d_est = (uint64_t *)zeroed(4 * (size_t)kInsertLimit * 8, 0);
   if (!ok || fqdev::sync()) { err = std::string("QC consumer: staging its tables on the device failed: ") + fqdev::last_error(); return FQ_ENODEV; }
   dev_on = true;
   return FQ_OK;
@@ -652,7 +657,7 @@ int fq_qc_device_prepare(fq_qc *q, FqQcArgs *a, int n_surv) {
   a->ord_base = q->ord_next;
   q->ord_next += (uint64_t)n_surv;
   a->depth = q->d_depth; a->q20 = q->d_q20; a->q30 = q->d_q30; a->hist = q->d_hist; a->insert_dist = q->d_insert;
-  a->sex_cnt = q->d_sex_cnt; a->sex_first = q->d_sex_first;
+  a->sex_cnt = q->d_sex_cnt; a->sex_first = q->d_sex_first; a->est_hist = q->d_est;
   a->dup_tab = q->d_dup; a->dup_mask = q->dup_cap ? q->dup_cap - 1 : 0;
   return FQ_OK;
 }
@@ -664,10 +669,10 @@ int fq_qc::pull() {
   if (rc) return rc;
   const size_t T = table_size, nc = n_contigs;
   std::vector<uint32_t> d(T + 1), a(T + 1), b(T + 1), sc((nc + 1) * 4);
-  std::vector<uint64_t> hist(4 * 256), ins((size_t)kInsertLimit), first(nc + 1);
+  std::vector<uint64_t> hist(4 * 256), ins((size_t)kInsertLimit), first(nc + 1), est(4 * (size_t)kInsertLimit);
   if (fqdev::d2h(d.data(), d_depth, (T + 1) * 4) || fqdev::d2h(a.data(), d_q20, (T + 1) * 4) || fqdev::d2h(b.data(), d_q30, (T + 1) * 4) || fqdev::d2h(hist.data(), d_hist, hist.size() * 8) ||
-      fqdev::d2h(ins.data(), d_insert, ins.size() * 8) || fqdev::d2h(sc.data(), d_sex_cnt, sc.size() * 4) || fqdev::d2h(first.data(), d_sex_first, first.size() * 8) || fqdev::sync() ||
-      fqdev::dzero(d_depth, (T + 1) * 4) || fqdev::dzero(d_q20, (T + 1) * 4) || fqdev::dzero(d_q30, (T + 1) * 4) || fqdev::dzero(d_hist, hist.size() * 8) || fqdev::dzero(d_insert, ins.size() * 8) ||
+      fqdev::d2h(ins.data(), d_insert, ins.size() * 8) || fqdev::d2h(est.data(), d_est, est.size() * 8) ||  fqdev::d2h(sc.data(), d_sex_cnt, sc.size() * 4) || fqdev::d2h(first.data(), d_sex_first, first.size() * 8) || fqdev::sync() ||
+      fqdev::dzero(d_depth, (T + 1) * 4) || fqdev::dzero(d_q20, (T + 1) * 4) || fqdev::dzero(d_q30, (T + 1) * 4) || fqdev::dzero(d_hist, hist.size() * 8) || fqdev::dzero(d_insert, ins.size() * 8) || fqdev::dzero(d_est, est.size() * 8) ||
       fqdev::dzero(d_sex_cnt, sc.size() * 4) || fqdev::dfill(d_sex_first, 0xff, first.size() * 8) || fqdev::sync()) {
     err = std::string("QC consumer: reading its tables back failed: ") + fqdev::last_error();
     return FQ_ENODEV;
@@ -675,6 +680,7 @@ int fq_qc::pull() {
   for (size_t k = 0; k < T; ++k) { depth[k] += d[k]; q20[k] += a[k]; q30[k] += b[k]; }
   for (int v = 0; v < 256; ++v) { EmpRep[v] += hist[v]; misEmpRep[v] += hist[256 + v]; EmpCycle[v] += hist[512 + v]; misEmpCycle[v] += hist[768 + v]; }
   for (int v = 0; v < kInsertLimit; ++v) InsertDist[v] += ins[v];
+  for (size_t v = 0; v < est.size(); ++v) est_hist[v] += est[v];
   std::vector<std::pair<uint64_t, size_t>> order;     // sex-chromosome contigs in the order of their first count
   for (size_t c = 0; c < nc; ++c) if (first[c] != ~0ull) order.emplace_back(first[c], c);
   std::sort(order.begin(), order.end());
@@ -782,6 +788,7 @@ extern "C" int fq_qc_add_last(fq_qc_t *q, fq_ctx_t *c) {
   }
   if (q->device_adds) { q->err = "fq_qc_add_last: this consumer counts on the device (fq_ctx_attach_qc); a batch of a context without it cannot be mixed in"; return FQ_EINVAL; }
   q->host_adds = true;
+  q->est_valid = false;
   if (S->n_surv > 0 && !S->rec) { q->err = "fq_qc_add_last: the call's result arrays were left on the device (FQ_EMIT_DEVICE_ONLY)"; return FQ_EINVAL; }
   if (S->n_surv > 0 && !hb.has_qual()) { q->err = "the batch carries no qualities"; return FQ_EINVAL; }
   // the batch's records in the host's vocabulary, from the C-ABI arrays (all threads); they live until the per-base statistics have run
@@ -878,7 +885,17 @@ extern "C" int fq_qc_write(fq_qc_t *q) {
       const std::string skip = pass == 0 ? "FwdOnly" : "RevOnly";
       std::vector<double> Obs(kLimit, 1e-6), Mis(kLimit, 1e-6);
       int totalPair = 0;
-      std::ifstream fin(pre + ".InsertSizeTable");
+      // every line of the table was decided by the device path, which counted what the reader below would take from it: the same additions of 1.0
+      // to the same cells (a cell's value depends on how many there were, not on their order), without reading the table back
+      const bool counted = q->est_valid && q->device_adds && !q->shard;
+      if (counted) {
+        for (int k = 0; k < kLimit; ++k) {
+          for (uint64_t t = q->est_hist[k]; t; --t) Obs[k] += 1.;
+          for (uint64_t t = q->est_hist[(pass == 0 ? 2 : 1) * (size_t)kLimit + k] + q->est_hist[3 * (size_t)kLimit + k]; t; --t) Mis[k] += 1.;
+          totalPair += (int)(q->est_hist[k] + q->est_hist[(pass == 0 ? 2 : 1) * (size_t)kLimit + k] + q->est_hist[3 * (size_t)kLimit + k]);
+        }
+      }
+      std::ifstream fin(counted ? std::string("/dev/null/none") : pre + ".InsertSizeTable");
       std::string line;
       while (std::getline(fin, line)) {
         std::vector<std::string> v;
@@ -1159,6 +1176,7 @@ extern "C" int64_t fq_qc_state_export(fq_qc_t *q, void *buf, int64_t cap) {
 
 extern "C" int fq_qc_merge(fq_qc_t *q, const void *buf, int64_t len) {
   if (!q || !buf || len < 8) return FQ_EINVAL;
+  q->est_valid = false;                    // (a merged segment's lines are only in the table file)
   In in{(const uint8_t *)buf, (const uint8_t *)buf + len};
   if (in.get<uint64_t>() != kStateMagic) { q->err = "fq_qc_merge: not an exported consumer state"; return FQ_EINVAL; }
   q->o.mode = in.get<int32_t>();

@@ -437,6 +437,14 @@ int fq_bam_add_last(fq_bam_t *b, fq_ctx_t *c);   /* the records of the context's
 int fq_bam_format_last(fq_bam_t *b, fq_ctx_t *c, const void **data, int64_t *len);
 int fq_bam_write_records(fq_bam_t *b, const void *data, int64_t len);
 int fq_bam_close(fq_bam_t *b);                   /* writes the BGZF end-of-file block, closes and frees */
+/* BAM records on the device (fq_emit.h): a context with a writer attached formats the records of every call in kernels inside the call
+ * (SetSamRecord's fields, the tags in the order of SamRecord's hash) and leaves them in HBM; fq_bam_add_last / fq_bam_format_last of THAT writer
+ * then fetch the bytes instead of formatting on the host -- the same bytes.  b = NULL detaches. */
+int fq_ctx_attach_bam(fq_ctx_t *c, fq_bam_t *b);
+/* (tests, tools) n bytes as BGZF members written by the device's compressor (one wavefront per block of 53,248 bytes: greedy LZ77, one fixed-Huffman
+ * block, CRC-32 -- csrc/fq_deflate.h), the members behind each other in out; replaces the zlib deflate of the reference's BGZF layer
+ * (VerifyBamID/statgen/BgzfFileType.h over htslib's bgzf_write) for the records a context with a writer attached formats on the device. */
+int fq_bgzf_deflate_device(int device, const uint8_t *in, int64_t n, uint8_t *out, int64_t cap, int64_t *out_len, double *kernel_ms);
 
 /* ---- the consumers on the device ---------------------------------------------------------------
  * The reference hands every record to its consumers on its main thread, one after the other (src/BwtMapper.cpp:2030-2085): bwa_print_sam1

@@ -22,6 +22,8 @@
 //       With --bam_dump 1 --fai <genome.fai> [--RG "@RG\tID:.."] the consumer loop is the BAM branch instead
 //       (src/BwtMapper.cpp:2054-2085): BwtMapper::SetSamRecord for both mates, and every SamRecord it fills is written as one text
 //       line to <out>.bamtxt (fields read back through SamRecord's own getters), the header of SetSamFileHeader to <out>.bamhdr.
+#include <chrono>
+#include <thread>
 #include "BwtMapper.cpp"   // resolved through -I$(REF)/src ; see Makefile
 
 #include <cinttypes>
@@ -142,12 +144,14 @@ static int cmd_align(int argc, char **argv) {
   pe_opt_t *popt = bwa_init_pe_opt();
   int batch = READ_BUFFER_SIZE, thresh = 3;
   long long genome_size = 0, genome_n_size = 0;
-  int bam_dump = 0, se = 0;
+  int bam_dump = 0, se = 0, n_threads = 0, bench = 0;
   std::vector<std::pair<std::string, std::string>> more;
   std::string fai_path, rg = "@RG\tID:foo\tSM:bar";   // runAlign's default --RG (src/FASTQuick.cpp:170)
   for (int i = 6; i + 1 < argc; i += 2) {
     if (!strcmp(argv[i], "--q")) opt->trim_qual = atoi(argv[i + 1]);
     else if (!strcmp(argv[i], "--batch")) batch = atoi(argv[i + 1]);
+    else if (!strcmp(argv[i], "--t")) n_threads = atoi(argv[i + 1]);       // gap_opt_t::n_threads: stage A sliced over the pool as PairEndMapper does (src/BwtMapper.cpp:1840-1845, 1933-1952)
+    else if (!strcmp(argv[i], "--bench")) bench = atoi(argv[i + 1]);       // 1: no stage dump lines (they cost more than the stages), wall times on stderr
     else if (!strcmp(argv[i], "--genome_size")) genome_size = atoll(argv[i + 1]);      // BwtIndexer::LoadContigSize's sums (original .fai / .amb)
     else if (!strcmp(argv[i], "--genome_n_size")) genome_n_size = atoll(argv[i + 1]);
     else if (!strcmp(argv[i], "--flank")) opt->flank_len = atoi(argv[i + 1]);
@@ -309,6 +313,9 @@ static int cmd_align(int argc, char **argv) {
   bwa_print_sam_SQ(ix.bns);
   bwa_print_sam_PG();
   int b = 0;   // batches are numbered through all pairs in the stage dump
+  double stage_a_ms = 0;
+  const auto t_run0 = std::chrono::steady_clock::now();
+  long long pairs_all = 0;
   for (const auto &fq_pair : all_pairs) {
   FileStatCollector FSC(fq_pair.first.c_str(), fq_pair.second.c_str());
   // ---- the set-up part of BwtMapper::PairEndMapper (src/BwtMapper.cpp:1811-1834), once per FASTQ pair
@@ -342,11 +349,34 @@ static int cmd_align(int argc, char **argv) {
     if (n_seqs[0] != n_seqs[1]) die("unequal mate counts");
     const int n = n_seqs[0];
     fprintf(st, "B %d %d\n", b, n);
+    if (!bench)
     for (int j = 0; j < 2; ++j)
       for (int i = 0; i < n; ++i)
         fprintf(st, "F %d %d filt=%d len=%d clip=%d full=%d\n", j, i, seqs[j][i].filtered, seqs[j][i].len, seqs[j][i].clip_len, seqs[j][i].full_len);
-    // stage A (src/BwtMapper.cpp:1933-1952; one slice per end)
-    for (int j = 0; j < 2; ++j) bwa_cal_sa_reg_gap(0, bwt, n, seqs[j], opt, &ix);
+    // stage A (src/BwtMapper.cpp:1933-1952): one slice per end, or -- with --t -- the reference's pool geometry: n_align_thread = max(4, min(--t,
+    // hardware threads)) workers, the first half over end 1 and the rest over end 2 in slices of n / n_first_thread reads, the last slice
+    // of an end taking what is left (the reference pushes them to a ctpl pool of that many threads; here one std::thread per slice)
+    const auto t_a0 = std::chrono::steady_clock::now();
+    if (n_threads <= 0) for (int j = 0; j < 2; ++j) bwa_cal_sa_reg_gap(0, bwt, n, seqs[j], opt, &ix);
+    else {
+      const int hw = (int)std::thread::hardware_concurrency();
+      int n_align_thread = n_threads <= hw ? n_threads : hw;
+      if (n_align_thread < 4) n_align_thread = 4;
+      const int n_first_thread = n_align_thread / 2, n_second_thread = n_align_thread - n_first_thread;
+      const size_t grain_size = (size_t)n / n_first_thread;
+      std::vector<std::thread> pool;
+      for (int j = 0; j < n_first_thread; ++j) {
+        const int cnt = j == n_first_thread - 1 ? n - (int)grain_size * (n_first_thread - 1) : (int)grain_size;
+        pool.emplace_back([&, j, cnt] { bwa_cal_sa_reg_gap(j, bwt, cnt, seqs[0] + j * grain_size, opt, &ix); });
+      }
+      for (int j = n_first_thread; j < n_align_thread; ++j) {
+        const int cnt = j == n_align_thread - 1 ? n - (int)grain_size * (n_second_thread - 1) : (int)grain_size;
+        pool.emplace_back([&, j, cnt] { bwa_cal_sa_reg_gap(j, bwt, cnt, seqs[1] + (j - n_first_thread) * grain_size, opt, &ix); });
+      }
+      for (auto &t : pool) t.join();
+    }
+    stage_a_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_a0).count();
+    if (!bench)
     for (int j = 0; j < 2; ++j)
       for (int i = 0; i < n; ++i) {
         const bwa_seq_t *p = seqs[j] + i;
@@ -359,12 +389,15 @@ static int cmd_align(int argc, char **argv) {
     isize_info_t ii;
     bwa_cal_pac_pos_pe(bwt, n, seqs, &ii, popt, opt, &last_ii, hash);
     dump_ii(st, &ii);
+    if (!bench)
     for (int j = 0; j < 2; ++j)
       for (int i = 0; i < n; ++i) dump_rec(st, 'P', j, i, seqs[j] + i, 0);
     pacseq = bwa_paired_sw(ix.bns, pacseq ? pacseq : ix.pac_buf, n, seqs, popt, &ii, opt->mode);
+    if (!bench)
     for (int j = 0; j < 2; ++j)
       for (int i = 0; i < n; ++i) dump_rec(st, 'S', j, i, seqs[j] + i, 0);
     for (int j = 0; j < 2; ++j) bwa_refine_gapped(ix.bns, n, seqs[j], pacseq, 0);
+    if (!bench)
     for (int j = 0; j < 2; ++j)
       for (int i = 0; i < n; ++i) dump_rec(st, 'R', j, i, seqs[j] + i, 1);
     last_ii = ii;
@@ -398,8 +431,11 @@ static int cmd_align(int argc, char **argv) {
     ++round;
   }
   fprintf(st, "E pairs=%lld filtered=%lld unmapped=%lld\n", n_pairs_total, n_filtered, n_unmapped);
+  pairs_all += n_pairs_total;
   collector.AddFSC(FSC);
   }
+  if (bench) fprintf(stderr, "TIMING pairs=%lld threads=%d stage_a_ms=%.1f reader_to_records_ms=%.1f\n", pairs_all, n_threads, stage_a_ms,
+                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_run0).count());
   fclose(st);
   if (fb) fclose(fb);
   fflush(stdout);

@@ -157,6 +157,19 @@ int launch_sam(int op, const FqSamArgs &a, int64_t n) {
   for (int64_t i = 0; i < n; ++i) { if (op == FQ_EOP_SAM_LEN) fq_sam_len_thread(a, (int)i); else if (op == FQ_EOP_SAM_FILL) fq_sam_fill_thread(a, (int)i); else return -1; }
   return 0;
 }
+int launch_deflate(const FqDeflateArgs &a) {
+  static thread_local FqdLds lds;
+  for (uint32_t b = 0; b < a.n_blocks; ++b) a.bsize[b] = fqd_member(a, b, lds);
+  return 0;
+}
+int launch_deflate_pack(const FqDeflatePackArgs &a) {
+  for (uint64_t t = 0; t < (uint64_t)a.n_blocks * (FQD_SLOT / 16); ++t) fqd_pack_piece(a, t);
+  return 0;
+}
+int launch_bam(int op, const FqBamArgs &a, int64_t n) {
+  for (int64_t i = 0; i < n; ++i) { if (op == FQ_EOP_BAM_LEN) fq_bam_len_thread(a, (int)i); else if (op == FQ_EOP_BAM_FILL) fq_bam_fill_thread(a, (int)i); else return -1; }
+  return 0;
+}
 int launch_qc(int op, const FqQcArgs &a, int64_t n) {
   if (op == FQ_QOP_BASE) {
     std::vector<uint32_t> hist(4 * 256, 0);

@@ -85,13 +85,16 @@ def decode_bam(path, sort_tags=True):
     return text, refs, recs
 
 
-def bam_case(g, lib, device=None, packed=False, se=False):
-    """se: the single-end mapper on the first FASTQ alone (SetSamRecord(p, 0)), against the ref_se.* goldens."""
+def bam_case(g, lib, device=None, packed=False, se=False, on_device=False):
+    """se: the single-end mapper on the first FASTQ alone (SetSamRecord(p, 0)), against the ref_se.* goldens.
+    on_device: the records are formatted by the kernels of fq_emit.h inside the calls (fq_ctx_attach_bam)."""
     names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
     ix = api.Index(g["prefix"], lib=lib) if device is None else api.Index(g["prefix"], device=device, lib=lib)
     al = api.Aligner(ix, api.default_opts(lib, trim_qual=g["trim_qual"], single_end=1 if se else 0), max_pairs=max(16, g["batch"]))
     path = os.path.join(g["dir"], "got_se.bam" if se else "got.bam")
     bam = api.BamWriter(ix, os.path.join(g["dir"], "genome.fai"), path)
+    if on_device:
+        bam.attach(al)
     if se:
         api.align_stream(al, list(names), seq[:1], qual[:1], lens[:1], g["batch"], None, None, bam=bam)
     else:
@@ -112,14 +115,19 @@ def bam_case(g, lib, device=None, packed=False, se=False):
         assert a == b, "record %d:\n got  %s\n want %s" % (i, "\t".join(a)[:400], "\t".join(b)[:400])
 
 
+SIDES = pytest.mark.parametrize("on_device", [False, True], ids=["host_formatter", "device_formatter"])
+
+
+@SIDES
 @pytest.mark.parametrize("tag", golden_util.case_tags())
-def test_bam_records_match_reference(tag, golden_cases, emu_lib):
-    bam_case(golden_cases[tag], emu_lib)
+def test_bam_records_match_reference(tag, on_device, golden_cases, emu_lib):
+    bam_case(golden_cases[tag], emu_lib, on_device=on_device, packed=on_device and tag in ("qc", "trim76"))
 
 
 SE_CONSUMER_TAGS = [t for t in golden_util.se_case_tags() if os.path.exists(os.path.join(golden_util.GOLD, t, "ref_se.bamtxt.gz"))]
 
 
+@SIDES
 @pytest.mark.parametrize("tag", SE_CONSUMER_TAGS)
-def test_single_end_bam_records_match_reference(tag, golden_cases, emu_lib):
-    bam_case(golden_cases[tag], emu_lib, se=True)
+def test_single_end_bam_records_match_reference(tag, on_device, golden_cases, emu_lib):
+    bam_case(golden_cases[tag], emu_lib, se=True, on_device=on_device)
