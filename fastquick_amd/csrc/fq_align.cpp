@@ -289,8 +289,10 @@ struct fq_ctx {
   DevBuf<uint32_t> d_samlen; DevBuf<uint64_t> d_samoff; DevBuf<char> d_samtext;
   uint64_t sam_bytes = 0;
   bool sam_ready = false;
-  fqdev::State *dev_emit = nullptr;    // the consumer side's own streams: the text leaves the device beside the next call
-  PinBuf<char> p_emit[2];
+  // the consumer side's own streams and pinned slices: what a call left in HBM leaves the device beside the next call.  Two lanes, because the
+  // record writer (0: SAM text, BAM records) and StatCollector's host side (1) fetch at the same time on threads of their own
+  fqdev::State *dev_emit[2] = {nullptr, nullptr};
+  PinBuf<char> p_emit[2][2];
   // ... the BAM records of a call (fq_ctx_attach_bam), as bytes in HBM until the writer fetches them
   fq_bam *bam = nullptr;
   DevBuf<uint32_t> d_bamlen, d_zsize; DevBuf<uint64_t> d_bamoff, d_zoff; DevBuf<uint8_t> d_bamrec, d_zstage, d_bamz;
@@ -301,7 +303,7 @@ struct fq_ctx {
   DevBuf<uint32_t> d_istlen, d_ptcnt;
   DevBuf<uint64_t> d_istoff, d_ptoff, d_qcnt, d_dupkey;
   DevBuf<char> d_isttext; DevBuf<FqPileEntry> d_pile;
-  PinBuf<char> p_isttext; PinBuf<FqPileEntry> p_pile; PinBuf<uint64_t> p_qcnt, p_dupkey;
+  PinBuf<uint64_t> p_qcnt, p_dupkey;
   FqQcCallOut qc_out;
   // results of the last batch
   FqBatchState st;
@@ -359,6 +361,7 @@ extern "C" int fq_ctx_create(const fq_index_t *ix, const fq_opts_t *opts, int32_
   k.indel_end_skip = o.indel_end_skip; k.max_del_occ = o.max_del_occ; k.max_entries = o.max_entries;
   k.max_gapo = o.max_gapo; k.max_gape = o.max_gape; k.max_seed_diff = o.max_seed_diff; k.seed_len = o.seed_len;
   k.max_top2 = o.max_top2; k.trim_qual = o.trim_qual; k.filter_thresh = o.filter_thresh; k.n_buckets = FQ_MAX_BUCKETS;
+  if (const char *e = getenv("FASTQUICK_CTX_TRACE")) c->kn.trace = atoi(e);     // per-stage wall times of every call on stderr (as the tuning key `trace`)
   c->dev = fqdev::state_create(ix->device);
   if (!c->dev || fqdev::bind(c->dev)) return FQ_ENODEV;
   if (!c->d_maxdiff.ensure(FQ_LMAX + 2) || !c->d_counters.ensure(FQ_C_STRIPES * FQ_C_STRIDE) || !c->d_counts.ensure(4) || !c->d_queue.ensure(4) || !c->d_glogn.ensure(256)) return FQ_ENOMEM;
@@ -366,7 +369,7 @@ extern "C" int fq_ctx_create(const fq_index_t *ix, const fq_opts_t *opts, int32_
   *out = c.release();
   return FQ_OK;
 }
-fq_ctx::~fq_ctx() { if (dev_emit) fqdev::state_destroy(dev_emit); fqdev::state_destroy(dev); }   // synchronises the context's streams before the buffers below are freed
+fq_ctx::~fq_ctx() { for (auto *e : dev_emit) if (e) fqdev::state_destroy(e); fqdev::state_destroy(dev); }   // synchronises the context's streams before the buffers below are freed
 extern "C" void fq_ctx_destroy(fq_ctx_t *c) { delete c; }
 
 extern "C" int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t v) {
@@ -2105,19 +2108,18 @@ int stage_emit_qc(Call &K) {
   CKS(fetch_u64(c, &ist_total, c->d_istoff.p + P));
   CKS(fetch_u64(c, &pt_total, c->d_ptoff.p + N));
   CKS(sync_staged(c));
-  CKM(c->d_isttext.ensure(ist_total + 64) && c->p_isttext.ensure(ist_total + 64) && c->d_pile.ensure(pt_total + 1) && c->p_pile.ensure(pt_total + 1));
+  CKM(c->d_isttext.ensure(ist_total + 64) && c->d_pile.ensure(pt_total + 1));
   a.ist_text = c->d_isttext.p; a.pt = c->d_pile.p;
   CK(fqdev::launch_qc(FQ_QOP_IST_FILL, a, (int64_t)P));
   CK(fqdev::launch_qc(FQ_QOP_PILE_FILL, a, (int64_t)N));
   CK(fqdev::launch_qc(FQ_QOP_BASE, a, (int64_t)N));
-  CK(fqdev::copy_pinned(c->p_isttext.p, c->d_isttext.p, ist_total, 0));
-  CK(fqdev::copy_pinned(c->p_pile.p, c->d_pile.p, pt_total * sizeof(FqPileEntry), 0));
+  // (the lines and the pileup entries stay in HBM: the consumer's host side fetches them in slices beside the next call -- fq_ctx_qc_stream)
   CK(fqdev::copy_pinned(c->p_qcnt.p, c->d_qcnt.p, NC * 8, 0));
   if (a.shard) CK(fqdev::copy_pinned(c->p_dupkey.p, c->d_dupkey.p, P * 8, 0));
-  c->stats.d2h_bytes += ist_total + pt_total * sizeof(FqPileEntry) + NC * 8 + (a.shard ? P * 8 : 0);
+  c->stats.d2h_bytes += NC * 8 + (a.shard ? P * 8 : 0);
   CKS(sync_staged(c));
   for (int k = 0; k < FQ_QC_C_COUNT; ++k) { uint64_t v = 0; for (int st = 0; st < FQ_C_STRIPES; ++st) v += c->p_qcnt.p[(size_t)st * FQ_C_STRIDE + k]; O.cnt[k] = v; }
-  O.ist = c->p_isttext.p; O.ist_bytes = ist_total; O.pile = c->p_pile.p; O.n_pile = pt_total; O.dup_key = a.shard ? c->p_dupkey.p : nullptr;
+  O.ist_bytes = ist_total; O.n_pile = pt_total; O.dup_key = a.shard ? c->p_dupkey.p : nullptr;
   O.ready = true;
   K.trace("StatCollector on the device");
   return FQ_OK;
@@ -2542,18 +2544,20 @@ extern "C" int fq_ctx_set_emit(fq_ctx_t *c, int32_t flags) {
 }
 // The SAM text of the last call leaves the device in slices through two pinned buffers on streams of its own, so that it runs beside the
 // next call on another context: sink(user, data, bytes) gets the slices in order.
-static int64_t stream_device_bytes(fq_ctx_t *c, const char *src, uint64_t total, fq_sink_fn sink, void *user, const char *what) {
+static int64_t stream_device_bytes(fq_ctx_t *c, int lane, const char *src, uint64_t total, fq_sink_fn sink, void *user, const char *what, size_t granule = 1) {
   if (!total) return 0;
-  if (!c->dev_emit) c->dev_emit = fqdev::state_create(c->ix->device);
-  if (!c->dev_emit || fqdev::bind(c->dev_emit)) { c->err = std::string(what) + ": " + fqdev::last_error(); return FQ_ENODEV; }
-  const size_t SL = std::min<uint64_t>(total, (uint64_t)32 << 20);
-  if (!c->p_emit[0].ensure(SL) || !c->p_emit[1].ensure(SL)) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
+  fqdev::State *&st = c->dev_emit[lane];
+  PinBuf<char> *pin = c->p_emit[lane];
+  if (!st) st = fqdev::state_create(c->ix->device);
+  if (!st || fqdev::bind(st)) { c->err = std::string(what) + ": " + fqdev::last_error(); return FQ_ENODEV; }
+  const size_t SL = std::min<uint64_t>(total, ((uint64_t)32 << 20) / granule * granule);     // (a slice holds whole items)
+  if (!pin[0].ensure(SL) || !pin[1].ensure(SL)) { c->err = "out of pinned host memory"; return FQ_ENOMEM; }
   const uint64_t n_sl = (total + SL - 1) / SL;
   auto bytes_of = [&](uint64_t k) { return (size_t)std::min<uint64_t>(SL, total - k * SL); };
-  if (fqdev::copy_pinned(c->p_emit[0].p, src, bytes_of(0), 0) || fqdev::sync()) { c->err = std::string(what) + ": " + fqdev::last_error(); return FQ_ENODEV; }
+  if (fqdev::copy_pinned(pin[0].p, src, bytes_of(0), 0) || fqdev::sync()) { c->err = std::string(what) + ": " + fqdev::last_error(); return FQ_ENODEV; }
   for (uint64_t k = 0; k < n_sl; ++k) {
-    if (k + 1 < n_sl && fqdev::copy_pinned(c->p_emit[(k + 1) & 1].p, src + (k + 1) * SL, bytes_of(k + 1), 0)) { c->err = std::string(what) + ": " + fqdev::last_error(); return FQ_ENODEV; }
-    if (sink(user, c->p_emit[k & 1].p, (int64_t)bytes_of(k))) { (void)fqdev::sync(); c->err = std::string(what) + ": the sink failed"; return FQ_EIO; }
+    if (k + 1 < n_sl && fqdev::copy_pinned(pin[(k + 1) & 1].p, src + (k + 1) * SL, bytes_of(k + 1), 0)) { c->err = std::string(what) + ": " + fqdev::last_error(); return FQ_ENODEV; }
+    if (sink(user, pin[k & 1].p, (int64_t)bytes_of(k))) { (void)fqdev::sync(); c->err = std::string(what) + ": the sink failed"; return FQ_EIO; }
     if (fqdev::sync()) { c->err = std::string(what) + ": " + fqdev::last_error(); return FQ_ENODEV; }
   }
   return (int64_t)total;
@@ -2561,13 +2565,13 @@ static int64_t stream_device_bytes(fq_ctx_t *c, const char *src, uint64_t total,
 extern "C" int64_t fq_sam_device_last(fq_ctx_t *c, fq_sink_fn sink, void *user) {
   if (!c || !sink) return FQ_EINVAL;
   if (!(c->emit_flags & FQ_EMIT_SAM) || !c->sam_ready) { c->err = "fq_sam_device_last: the last call did not format its SAM text on the device (fq_ctx_set_emit)"; return FQ_EINVAL; }
-  return stream_device_bytes(c, c->d_samtext.p, c->sam_bytes, sink, user, "fq_sam_device_last");
+  return stream_device_bytes(c, 0, c->d_samtext.p, c->sam_bytes, sink, user, "fq_sam_device_last");
 }
 // the BAM records of the last call (fq_ctx_attach_bam), for the writer they were formatted for
 int64_t fq_ctx_bam_stream(fq_ctx_t *c, fq_sink_fn sink, void *user, int members) {
   if (!c->bam || !c->bam_out.ready) { c->err = "the last call formatted no BAM records on the device"; return FQ_EINVAL; }
-  if (members) return stream_device_bytes(c, (const char *)c->d_bamz.p, c->bam_out.z_bytes, sink, user, "BGZF members");
-  return stream_device_bytes(c, (const char *)c->d_bamrec.p, c->bam_out.bytes, sink, user, "BAM records");
+  if (members) return stream_device_bytes(c, 0, (const char *)c->d_bamz.p, c->bam_out.z_bytes, sink, user, "BGZF members");
+  return stream_device_bytes(c, 0, (const char *)c->d_bamrec.p, c->bam_out.bytes, sink, user, "BAM records");
 }
 extern "C" int fq_ctx_attach_bam(fq_ctx_t *c, fq_bam_t *b) {
   if (!c) return FQ_EINVAL;
@@ -2583,6 +2587,12 @@ extern "C" int fq_ctx_attach_qc(fq_ctx_t *c, fq_qc_t *q) {
   return FQ_OK;
 }
 const FqQcCallOut *fq_ctx_qc_out(const fq_ctx_t *c) { return c->qc ? &c->qc_out : nullptr; }
+// what the call left in HBM for the consumer's host side: which = 0 the .InsertSizeTable lines, 1 the pileup entries (whole entries per slice)
+int64_t fq_ctx_qc_stream(fq_ctx_t *c, int which, fq_sink_fn sink, void *user) {
+  if (!c->qc || !c->qc_out.ready) { c->err = "the last call counted nothing on the device"; return FQ_EINVAL; }
+  if (which == 0) return stream_device_bytes(c, 1, c->d_isttext.p, c->qc_out.ist_bytes, sink, user, "InsertSizeTable lines");
+  return stream_device_bytes(c, 1, (const char *)c->d_pile.p, c->qc_out.n_pile * sizeof(FqPileEntry), sink, user, "pileup entries", sizeof(FqPileEntry));
+}
 extern "C" int64_t fq_sam_device_bytes(const fq_ctx_t *c) { return c && (c->emit_flags & FQ_EMIT_SAM) && c->sam_ready ? (int64_t)c->sam_bytes : FQ_EINVAL; }
 
 extern "C" int fq_ctx_set_debug(fq_ctx_t *c, int keep_stage_snapshots) {

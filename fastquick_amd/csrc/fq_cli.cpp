@@ -514,10 +514,12 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
     fq_stats_t s2;
     fq_stats_get(ctx2, &s2);
     for (int k = 0; k < 6; ++k) st.kernel_ms[k] += s2.kernel_ms[k];
+    st.kernel_ms[FQ_K_EMIT] += s2.kernel_ms[FQ_K_EMIT]; st.kernel_ms[FQ_K_REC_KERNEL] += s2.kernel_ms[FQ_K_REC_KERNEL]; st.kernel_ms[FQ_K_MD_KERNEL] += s2.kernel_ms[FQ_K_MD_KERNEL];
+    st.device_wait_ms += s2.device_wait_ms; st.host_cpu_ms += s2.host_cpu_ms;
     st.host_ms_total += s2.host_ms_total; st.wall_ms_total += s2.wall_ms_total;
   }
-  fprintf(stderr, "NOTICE - device time (ms): prep %.1f width %.1f gap %.1f sa %.1f sw %.1f refine %.1f ; host %.1f ; wall %.1f\n", st.kernel_ms[0],
-          st.kernel_ms[1], st.kernel_ms[2], st.kernel_ms[3], st.kernel_ms[4], st.kernel_ms[5], st.host_ms_total, st.wall_ms_total);
+  fprintf(stderr, "NOTICE - device time (ms): prep %.1f width %.1f gap %.1f sa %.1f sw %.1f refine %.1f records %.1f md %.1f consumers' kernels %.1f ; host %.1f ; waited for the device %.1f ; calls' CPU %.1f ; wall %.1f\n", st.kernel_ms[0],
+          st.kernel_ms[1], st.kernel_ms[2], st.kernel_ms[3], st.kernel_ms[4], st.kernel_ms[5], st.kernel_ms[FQ_K_REC_KERNEL], st.kernel_ms[FQ_K_MD_KERNEL], st.kernel_ms[FQ_K_EMIT], st.host_ms_total, st.device_wait_ms, st.host_cpu_ms, st.wall_ms_total);
   fprintf(stderr, "NOTICE - consumers (ms): StatCollector %.1f ; %s writer %.1f ; first chunk read %.1f ; packing %.1f\n", qc_ms, A.sam_out ? "SAM" : "BAM", out_ms, read_ms, pack_ms);
   fprintf(stderr, "NOTICE - reading (ms): all chunks %.1f ; waited for %.1f ; alignment calls %.1f\n", read_all_ms, read_wait_ms, align_ms);
   if (qc) fq_qc_end_file(qc);

@@ -148,8 +148,8 @@ struct fq_qc;
 struct FqQcCallOut {
   const fq_qc *owner = nullptr;
   bool ready = false;
-  const char *ist = nullptr; uint64_t ist_bytes = 0;           // .InsertSizeTable lines
-  const FqPileEntry *pile = nullptr; uint64_t n_pile = 0;      // pileup entries of the markers
+  uint64_t ist_bytes = 0;                                      // .InsertSizeTable lines   } in HBM until the consumer's host side
+  uint64_t n_pile = 0;                                         // pileup entries of the markers } fetches them: fq_ctx_qc_stream
   const uint64_t *dup_key = nullptr;                           // [n_surv] duplicate keys of a shard consumer's pairs (~0: none), else NULL
   int n_surv = 0;
   uint64_t cnt[FQ_QC_C_COUNT] = {};
@@ -163,6 +163,7 @@ int fq_bam_device_prepare(fq_bam *b, FqBamArgs *a);
 int64_t fq_ctx_bam_stream(fq_ctx_t *c, fq_sink_fn sink, void *user, int members);   // members != 0: the BGZF members instead of the raw records
 bool fq_bam_wants_members(const fq_bam *b);
 int fq_qc_device_prepare(fq_qc *q, FqQcArgs *a, int n_surv);
+int64_t fq_ctx_qc_stream(fq_ctx_t *c, int which, fq_sink_fn sink, void *user);
 int64_t fq_ctx_last_bases(const fq_ctx_t *c);   // sum of the read lengths of the last batch (NumBase increment)
 // the name a record prints under (fq_sam.cpp): `/1` `/2` stripped, a revived mate under its partner's name
 std::string fq_read_name(const FqHostReads *hb, int pair, int end, bool revived);

@@ -767,11 +767,21 @@ extern "C" int fq_qc_add_last(fq_qc_t *q, fq_ctx_t *c) {
     F.TotalMAPQ += (long long)(D->cnt[FQ_QC_C_FAILED1] + 2 * D->cnt[FQ_QC_C_FAILED2]);
     q->NumPairReads += 2 * D->cnt[FQ_QC_C_PROPER];
     q->NumPCRDup += 2 * D->cnt[FQ_QC_C_DUP];
-    if (D->ist_bytes) q->table.write(D->ist, (std::streamsize)D->ist_bytes);
-    for (uint64_t t = 0; t < D->n_pile; ++t) {
-      const FqPileEntry &e = D->pile[t];
-      q->seq_vec[e.k] += (char)e.base; q->qual_vec[e.k] += (char)e.qual;
-      q->cycle_vec[e.k].push_back(e.cyc); q->maq_vec[e.k].push_back(e.maq); q->strand_vec[e.k].push_back(e.strand != 0);
+    if (D->ist_bytes && fq_ctx_qc_stream(c, 0, [](void *user, const void *data, int64_t n) -> int { ((fq_qc *)user)->table.write((const char *)data, (std::streamsize)n); return 0; }, q) < 0) {
+      q->err = std::string("fq_qc_add_last: fetching the .InsertSizeTable lines failed: ") + fq_ctx_last_error(c);
+      return FQ_ENODEV;
+    }
+    if (D->n_pile && fq_ctx_qc_stream(c, 1, [](void *user, const void *data, int64_t n) -> int {
+          fq_qc *Q = (fq_qc *)user;
+          const FqPileEntry *e = (const FqPileEntry *)data;
+          for (int64_t t = 0; t < n / (int64_t)sizeof(FqPileEntry); ++t, ++e) {
+            Q->seq_vec[e->k] += (char)e->base; Q->qual_vec[e->k] += (char)e->qual;
+            Q->cycle_vec[e->k].push_back(e->cyc); Q->maq_vec[e->k].push_back(e->maq); Q->strand_vec[e->k].push_back(e->strand != 0);
+          }
+          return 0;
+        }, q) < 0) {
+      q->err = std::string("fq_qc_add_last: fetching the pileup entries failed: ") + fq_ctx_last_error(c);
+      return FQ_ENODEV;
     }
     if (q->shard && D->dup_key) {
       char key[64];

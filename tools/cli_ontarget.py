@@ -55,6 +55,8 @@ def measure(exe, pre, ref, workdir, pairs=1 << 20, copies=8, read_len=150, threa
         res[mode] = {"rc": run.returncode, "wall_s": round(dt, 2), "pairs_per_s": round(total / dt, 1) if run.returncode == 0 else None,
                      "output": "SAM text (to /dev/null) + 13 QC files" if mode == "sam_out" else "BAM file + 13 QC files",
                      "notices": [l for l in err if "consumers" in l or "device time" in l or "reading (ms)" in l or "FATAL" in l][-4:]}
+        if os.environ.get("FASTQUICK_TRACE"):
+            res[mode]["trace"] = [l for l in err if l.startswith("TRACE")][-40:]
     for p in big:
         os.remove(p)
     return res
