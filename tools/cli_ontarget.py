@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 EOF_MEMBER = b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00\x1b\x00\x03\x00\x00\x00\x00\x00\x00\x00\x00\x00"
 
 
-def measure(exe, pre, ref, workdir, pairs=1 << 20, copies=8, read_len=150, threads=16, extra=(), modes=("sam_out", "bam_and_qc"), seed=4242):
+def measure(exe, pre, ref, workdir, pairs=1 << 20, copies=8, read_len=150, threads=16, extra=(), modes=("sam_out", "bam_and_qc"), seed=4242, profile_dir=None):
     """pre: <index prefix>.FASTQuick.fa of `ref` (built).  Writes `pairs` seeded on-target pairs as two BGZF files, concatenated `copies` times
     (BGZF members concatenate), the QC inputs of the index, and runs the command line once per mode with stdout to /dev/null."""
     import numpy as np
@@ -47,6 +47,8 @@ def measure(exe, pre, ref, workdir, pairs=1 << 20, copies=8, read_len=150, threa
     for mode in modes:
         cmd = [exe, "align", "--index_prefix", pre[:-len(".FASTQuick.fa")], "--fastq_1", big[0], "--fastq_2", big[1], "--out_prefix", os.path.join(workdir, "ont_out"),
                "--read_len", str(max(read_len, 151)), "--t", str(threads)] + (["--sam_out"] if mode == "sam_out" else []) + list(extra)
+        if profile_dir:       # rocprofv3 --kernel-trace --stats around the command line itself (FQ_PROFILE_DIR): per-kernel times of the run
+            cmd = ["rocprofv3", "--kernel-trace", "--stats", "-d", os.path.join(profile_dir, mode), "-o", "p", "--"] + cmd
         time.sleep(3.0)       # (a process started right behind another's exit waits for the driver to take that one's device memory back)
         t0 = time.perf_counter()
         run = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
@@ -75,4 +77,4 @@ if __name__ == "__main__":
         ref.write_fasta(fa)
         api.build_index(fa)
     import json
-    print(json.dumps(measure(os.path.join(ROOT, "fastquick_amd", "bin", "FASTQuick_amd"), fa, ref, wd, pairs, copies, read_len, extra=sys.argv[4:])))
+    print(json.dumps(measure(os.path.join(ROOT, "fastquick_amd", "bin", "FASTQuick_amd"), fa, ref, wd, pairs, copies, read_len, extra=sys.argv[4:], profile_dir=os.environ.get("FQ_PROFILE_DIR"))))
