@@ -48,7 +48,7 @@ def measure(exe, pre, ref, workdir, pairs=1 << 20, copies=8, read_len=150, threa
         cmd = [exe, "align", "--index_prefix", pre[:-len(".FASTQuick.fa")], "--fastq_1", big[0], "--fastq_2", big[1], "--out_prefix", os.path.join(workdir, "ont_out"),
                "--read_len", str(max(read_len, 151)), "--t", str(threads)] + (["--sam_out"] if mode == "sam_out" else []) + list(extra)
         if profile_dir:       # rocprofv3 --kernel-trace --stats around the command line itself (FQ_PROFILE_DIR): per-kernel times of the run
-            cmd = ["rocprofv3", "--kernel-trace", "--stats", "-d", os.path.join(profile_dir, mode), "-o", "p", "--"] + cmd
+            cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", os.path.join(profile_dir, mode), "-o", "p", "--"] + cmd
         time.sleep(3.0)       # (a process started right behind another's exit waits for the driver to take that one's device memory back)
         t0 = time.perf_counter()
         run = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
