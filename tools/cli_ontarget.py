@@ -59,6 +59,8 @@ def measure(exe, pre, ref, workdir, pairs=1 << 20, copies=8, read_len=150, threa
                      "notices": [l for l in err if "consumers" in l or "device time" in l or "reading (ms)" in l or "FATAL" in l][-4:]}
         if os.environ.get("FASTQUICK_TRACE"):
             res[mode]["trace"] = [l for l in err if l.startswith("TRACE")][-40:]
+        if os.environ.get("FASTQUICK_CTX_TRACE"):
+            res[mode]["ctx_trace"] = [l for l in err if l.startswith("[fq]")]
     for p in big:
         os.remove(p)
     return res
