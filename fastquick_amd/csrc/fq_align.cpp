@@ -297,6 +297,10 @@ struct fq_ctx {
   fq_bam *bam = nullptr;
   DevBuf<uint32_t> d_bamlen, d_zsize; DevBuf<uint64_t> d_bamoff, d_zoff; DevBuf<uint8_t> d_bamrec, d_zstage, d_bamz;
   FqBamCallOut bam_out;
+  PinBuf<uint64_t> p_ztotal;
+  uint32_t emit_nb = 0;
+  std::mutex emit_mu;                  // the fill kernels of the last call may still run (emit_pending): the first fetcher waits for them
+  bool emit_pending = false;
   // ... StatCollector's part of a call (fq_ctx_attach_qc): per-call lists on the device, what comes back for the consumer's host side
   fq_qc *qc = nullptr;
   DevBuf<uint8_t> d_qadded;
@@ -698,8 +702,13 @@ void pair_penalty_lut(const fq_isize_t &ii, vector<int32_t> &lut) {
 // One call = stage 0 (filter + ordered compaction; the only stage that sees every read), the search over the reads of surviving
 // pairs, then the record stages (fq_records.h) over device-resident records.  The stage functions share the per-call state in `Call`.
 namespace {
+struct EmitPlan {                      // what emit_measure leaves for emit_fill
+  FqSamArgs sam{}; FqBamArgs bam{}; FqQcArgs qc{};
+  uint64_t sam_total = 0, bam_total = 0, ist_total = 0, pt_total = 0;
+};
 struct Call {
   fq_ctx *c;
+  EmitPlan plan_emit;
   explicit Call(fq_ctx *ctx) : c(ctx), aln_off(ctx->st.aln_off), aln_n(ctx->st.aln_n) {}
   int n = 0, n2 = 0, B = 0, n_sub = 0, n_search = 0, n_surv = 0, max_len_all = 1, host_threads = 1;
   size_t par_min = 32768;
@@ -2018,110 +2027,115 @@ int emit_args(Call &K, FqSamArgs &a) {
   a = K.emit;
   return FQ_OK;
 }
-int stage_emit_sam(Call &K) {
-  fq_ctx *c = K.c;
-  const size_t N = (size_t)K.n_surv * 2;
-  c->sam_bytes = 0; c->sam_ready = false;
-  if (!N) { c->sam_ready = true; return FQ_OK; }
-  FqSamArgs a{};
-  CKS(emit_args(K, a));
-  CKM(c->d_samlen.ensure(N + 1) && c->d_samoff.ensure(N + 2));
-  a.len = c->d_samlen.p; a.off = c->d_samoff.p;
-  CK(fqdev::launch_sam(FQ_EOP_SAM_LEN, a, (int64_t)N));
-  CK(fqdev::launch_scan(c->d_samlen.p, c->d_samoff.p, (uint32_t)N));
-  uint64_t total = 0;
-  CKS(fetch_u64(c, &total, c->d_samoff.p + N));
-  CKS(sync_staged(c));
-  CKM(c->d_samtext.ensure(total + 64));
-  a.text = c->d_samtext.p;
-  CK(fqdev::launch_sam(FQ_EOP_SAM_FILL, a, (int64_t)N));
-  c->sam_bytes = total;
-  c->sam_ready = true;
-  K.trace("SAM text on the device");
-  return FQ_OK;
-}
-// the BAM records of the call (SetSamRecord's fields and tag order, fq_emit.h), as one run of bytes on the device
-int stage_emit_bam(Call &K) {
-  fq_ctx *c = K.c;
-  const size_t N = (size_t)K.n_surv * 2;
-  FqBamCallOut &O = c->bam_out;
-  O = FqBamCallOut();
-  O.owner = c->bam;
-  if (!N) { O.ready = true; return FQ_OK; }
-  FqBamArgs a{};
-  CKS(emit_args(K, a.s));
-  { const int rc = fq_bam_device_prepare(c->bam, &a); if (rc) { c->err = "the BAM writer could not stage its tables on the device"; return rc; } }
-  CKM(c->d_bamlen.ensure(N + 1) && c->d_bamoff.ensure(N + 2));
-  a.len = c->d_bamlen.p; a.off = c->d_bamoff.p;
-  CK(fqdev::launch_bam(FQ_EOP_BAM_LEN, a, (int64_t)N));
-  CK(fqdev::launch_scan(c->d_bamlen.p, c->d_bamoff.p, (uint32_t)N));
-  uint64_t total = 0;
-  CKS(fetch_u64(c, &total, c->d_bamoff.p + N));
-  CKS(sync_staged(c));
-  CKM(c->d_bamrec.ensure(total + 64));
-  a.out = c->d_bamrec.p;
-  CK(fqdev::launch_bam(FQ_EOP_BAM_FILL, a, (int64_t)N));
-  O.bytes = total;
-  if (total && fq_bam_wants_members(c->bam)) {
-    // the writer has a file: the records leave the device as finished BGZF members (fq_deflate.h: a wavefront per block of the record stream)
-    const uint32_t nb = (uint32_t)((total + FQD_BLOCK - 1) / FQD_BLOCK);
-    CKM(c->d_zstage.ensure((size_t)nb * FQD_SLOT) && c->d_zsize.ensure((size_t)nb + 1) && c->d_zoff.ensure((size_t)nb + 2));
-    FqDeflateArgs z{c->d_bamrec.p, total, c->d_zstage.p, c->d_zsize.p, fqdev::crc_const(), nb};
-    if (!z.crc) { c->err = std::string("BGZF on the device: ") + fqdev::last_error(); return FQ_ENODEV; }
-    CK(fqdev::launch_deflate(z));
-    CK(fqdev::launch_scan(c->d_zsize.p, c->d_zoff.p, nb));
-    uint64_t ztotal = 0;
-    CKS(fetch_u64(c, &ztotal, c->d_zoff.p + nb));
-    CKS(sync_staged(c));
-    CKM(c->d_bamz.ensure(ztotal + 64));
-    FqDeflatePackArgs pk{c->d_zstage.p, c->d_zsize.p, c->d_zoff.p, c->d_bamz.p, nb};
-    CK(fqdev::launch_deflate_pack(pk));
-    O.z_bytes = ztotal;
-  }
-  O.ready = true;
-  K.trace("BAM records on the device");
-  return FQ_OK;
-}
-// StatCollector's part of the call (fq_emit.h): decisions per pair, the order-dependent outputs laid out in input order, the per-base sums
-// into the consumer's device tables.  What the consumer's host side needs lands in pinned memory (fq_ctx_qc_out).
-int stage_emit_qc(Call &K) {
+// The consumers' kernels run in two steps.  emit_measure, inside the call: every record's line / record length and every pair's decisions, the prefix
+// sums that place them, ONE wait for the totals.  emit_fill, as the call's last act: the buffers, then the kernels that write -- SAM text, BAM records
+// and their BGZF members, .InsertSizeTable lines, pileup entries, the per-base sums -- are only ENQUEUED: the call returns, and they run beside the next
+// call's search kernels on another context.  Whoever fetches what they leave waits for them first (fq_ctx_emit_wait).
+int emit_measure(Call &K) {
   fq_ctx *c = K.c;
   const size_t N = (size_t)K.n_surv * 2, P = (size_t)K.n_surv;
-  FqQcCallOut &O = c->qc_out;
-  O = FqQcCallOut();
-  O.owner = c->qc; O.n_surv = K.n_surv;
-  if (!N) { O.ready = true; return FQ_OK; }
-  FqQcArgs a{};
-  CKS(emit_args(K, a.s));
-  a.ix = c->ix->dev;
-  { const int rc = fq_qc_device_prepare(c->qc, &a, K.n_surv); if (rc) { c->err = std::string("the QC consumer could not take the call: ") + fq_qc_last_error(c->qc); return rc; } }
-  const size_t NC = (size_t)FQ_C_STRIPES * FQ_C_STRIDE;
-  CKM(c->d_qadded.ensure(N + 1) && c->d_istlen.ensure(P + 1) && c->d_istoff.ensure(P + 2) && c->d_ptcnt.ensure(N + 1) && c->d_ptoff.ensure(N + 2) && c->d_qcnt.ensure(NC) && c->p_qcnt.ensure(NC));
-  if (a.shard) { CKM(c->d_dupkey.ensure(P + 1) && c->p_dupkey.ensure(P + 1)); }
-  CK(fqdev::dzero(c->d_qcnt.p, NC * 8));
-  a.counters = c->d_qcnt.p; a.added = c->d_qadded.p; a.ist_len = c->d_istlen.p; a.ist_off = c->d_istoff.p; a.pt_cnt = c->d_ptcnt.p; a.pt_off = c->d_ptoff.p;
-  a.dup_key = a.shard ? c->d_dupkey.p : nullptr;
-  CK(fqdev::launch_qc(FQ_QOP_PAIR, a, (int64_t)P));
-  CK(fqdev::launch_scan(c->d_istlen.p, c->d_istoff.p, (uint32_t)P));
-  CK(fqdev::launch_scan(c->d_ptcnt.p, c->d_ptoff.p, (uint32_t)N));
-  uint64_t ist_total = 0, pt_total = 0;
-  CKS(fetch_u64(c, &ist_total, c->d_istoff.p + P));
-  CKS(fetch_u64(c, &pt_total, c->d_ptoff.p + N));
+  EmitPlan &E = K.plan_emit;
+  E = EmitPlan();
+  c->sam_bytes = 0; c->sam_ready = false;
+  c->bam_out = FqBamCallOut(); c->bam_out.owner = c->bam;
+  c->qc_out = FqQcCallOut(); c->qc_out.owner = c->qc; c->qc_out.n_surv = K.n_surv;
+  if (!N) return FQ_OK;
+  if (c->emit_flags & FQ_EMIT_SAM) {
+    CKS(emit_args(K, E.sam));
+    CKM(c->d_samlen.ensure(N + 1) && c->d_samoff.ensure(N + 2));
+    E.sam.len = c->d_samlen.p; E.sam.off = c->d_samoff.p;
+    CK(fqdev::launch_sam(FQ_EOP_SAM_LEN, E.sam, (int64_t)N));
+    CK(fqdev::launch_scan(c->d_samlen.p, c->d_samoff.p, (uint32_t)N));
+    CKS(fetch_u64(c, &E.sam_total, c->d_samoff.p + N));
+  }
+  if (c->bam) {
+    CKS(emit_args(K, E.bam.s));
+    { const int rc = fq_bam_device_prepare(c->bam, &E.bam); if (rc) { c->err = "the BAM writer could not stage its tables on the device"; return rc; } }
+    CKM(c->d_bamlen.ensure(N + 1) && c->d_bamoff.ensure(N + 2));
+    E.bam.len = c->d_bamlen.p; E.bam.off = c->d_bamoff.p;
+    CK(fqdev::launch_bam(FQ_EOP_BAM_LEN, E.bam, (int64_t)N));
+    CK(fqdev::launch_scan(c->d_bamlen.p, c->d_bamoff.p, (uint32_t)N));
+    CKS(fetch_u64(c, &E.bam_total, c->d_bamoff.p + N));
+  }
+  if (c->qc) {
+    FqQcArgs &a = E.qc;
+    CKS(emit_args(K, a.s));
+    a.ix = c->ix->dev;
+    { const int rc = fq_qc_device_prepare(c->qc, &a, K.n_surv); if (rc) { c->err = std::string("the QC consumer could not take the call: ") + fq_qc_last_error(c->qc); return rc; } }
+    const size_t NC = (size_t)FQ_C_STRIPES * FQ_C_STRIDE;
+    CKM(c->d_qadded.ensure(N + 1) && c->d_istlen.ensure(P + 1) && c->d_istoff.ensure(P + 2) && c->d_ptcnt.ensure(N + 1) && c->d_ptoff.ensure(N + 2) && c->d_qcnt.ensure(NC) && c->p_qcnt.ensure(NC));
+    if (a.shard) { CKM(c->d_dupkey.ensure(P + 1) && c->p_dupkey.ensure(P + 1)); }
+    CK(fqdev::dzero(c->d_qcnt.p, NC * 8));
+    a.counters = c->d_qcnt.p; a.added = c->d_qadded.p; a.ist_len = c->d_istlen.p; a.ist_off = c->d_istoff.p; a.pt_cnt = c->d_ptcnt.p; a.pt_off = c->d_ptoff.p;
+    a.dup_key = a.shard ? c->d_dupkey.p : nullptr;
+    CK(fqdev::launch_qc(FQ_QOP_PAIR, a, (int64_t)P));
+    CK(fqdev::launch_scan(c->d_istlen.p, c->d_istoff.p, (uint32_t)P));
+    CK(fqdev::launch_scan(c->d_ptcnt.p, c->d_ptoff.p, (uint32_t)N));
+    CKS(fetch_u64(c, &E.ist_total, c->d_istoff.p + P));
+    CKS(fetch_u64(c, &E.pt_total, c->d_ptoff.p + N));
+  }
   CKS(sync_staged(c));
-  CKM(c->d_isttext.ensure(ist_total + 64) && c->d_pile.ensure(pt_total + 1));
-  a.ist_text = c->d_isttext.p; a.pt = c->d_pile.p;
-  CK(fqdev::launch_qc(FQ_QOP_IST_FILL, a, (int64_t)P));
-  CK(fqdev::launch_qc(FQ_QOP_PILE_FILL, a, (int64_t)N));
-  CK(fqdev::launch_qc(FQ_QOP_BASE, a, (int64_t)N));
-  // (the lines and the pileup entries stay in HBM: the consumer's host side fetches them in slices beside the next call -- fq_ctx_qc_stream)
-  CK(fqdev::copy_pinned(c->p_qcnt.p, c->d_qcnt.p, NC * 8, 0));
-  if (a.shard) CK(fqdev::copy_pinned(c->p_dupkey.p, c->d_dupkey.p, P * 8, 0));
-  c->stats.d2h_bytes += NC * 8 + (a.shard ? P * 8 : 0);
-  CKS(sync_staged(c));
-  for (int k = 0; k < FQ_QC_C_COUNT; ++k) { uint64_t v = 0; for (int st = 0; st < FQ_C_STRIPES; ++st) v += c->p_qcnt.p[(size_t)st * FQ_C_STRIDE + k]; O.cnt[k] = v; }
-  O.ist_bytes = ist_total; O.n_pile = pt_total; O.dup_key = a.shard ? c->p_dupkey.p : nullptr;
-  O.ready = true;
-  K.trace("StatCollector on the device");
+  K.trace("consumers: lengths, decisions, prefix sums");
+  return FQ_OK;
+}
+int emit_fill(Call &K) {
+  fq_ctx *c = K.c;
+  const size_t N = (size_t)K.n_surv * 2, P = (size_t)K.n_surv;
+  EmitPlan &E = K.plan_emit;
+  if (!N) {
+    if (c->emit_flags & FQ_EMIT_SAM) c->sam_ready = true;
+    c->bam_out.ready = c->bam != nullptr; c->qc_out.ready = c->qc != nullptr;
+    return FQ_OK;
+  }
+  std::lock_guard<std::mutex> lk(c->emit_mu);
+  if (c->emit_flags & FQ_EMIT_SAM) {
+    CKM(c->d_samtext.ensure(E.sam_total + 64));
+    E.sam.text = c->d_samtext.p;
+    CK(fqdev::launch_sam(FQ_EOP_SAM_FILL, E.sam, (int64_t)N));
+    c->sam_bytes = E.sam_total;
+    c->sam_ready = true;
+  }
+  if (c->bam) {
+    const uint64_t total = E.bam_total;
+    CKM(c->d_bamrec.ensure(total + 64));
+    E.bam.out = c->d_bamrec.p;
+    CK(fqdev::launch_bam(FQ_EOP_BAM_FILL, E.bam, (int64_t)N));
+    c->bam_out.bytes = total;
+    c->emit_nb = 0;
+    if (total && fq_bam_wants_members(c->bam)) {
+      // the writer has a file: the records leave the device as finished BGZF members (fq_deflate.h: a wavefront per block of the record stream),
+      // packed behind each other into a buffer sized for the worst case; their size comes back with the wait
+      const uint32_t nb = (uint32_t)((total + FQD_BLOCK - 1) / FQD_BLOCK);
+      CKM(c->d_zstage.ensure((size_t)nb * FQD_SLOT) && c->d_zsize.ensure((size_t)nb + 1) && c->d_zoff.ensure((size_t)nb + 2) && c->d_bamz.ensure((size_t)nb * FQD_SLOT) && c->p_ztotal.ensure(8));
+      FqDeflateArgs z{c->d_bamrec.p, total, c->d_zstage.p, c->d_zsize.p, fqdev::crc_const(), nb};
+      if (!z.crc) { c->err = std::string("BGZF on the device: ") + fqdev::last_error(); return FQ_ENODEV; }
+      CK(fqdev::launch_deflate(z));
+      CK(fqdev::launch_scan(c->d_zsize.p, c->d_zoff.p, nb));
+      FqDeflatePackArgs pk{c->d_zstage.p, c->d_zsize.p, c->d_zoff.p, c->d_bamz.p, nb};
+      CK(fqdev::launch_deflate_pack(pk));
+      CK(fqdev::copy_pinned(c->p_ztotal.p, c->d_zoff.p + nb, 8, 0));
+      c->emit_nb = nb;
+    }
+    c->bam_out.ready = true;
+  }
+  if (c->qc) {
+    FqQcArgs &a = E.qc;
+    const size_t NC = (size_t)FQ_C_STRIPES * FQ_C_STRIDE;
+    CKM(c->d_isttext.ensure(E.ist_total + 64) && c->d_pile.ensure(E.pt_total + 1));
+    a.ist_text = c->d_isttext.p; a.pt = c->d_pile.p;
+    CK(fqdev::launch_qc(FQ_QOP_IST_FILL, a, (int64_t)P));
+    CK(fqdev::launch_qc(FQ_QOP_PILE_FILL, a, (int64_t)N));
+    CK(fqdev::launch_qc(FQ_QOP_BASE, a, (int64_t)N));
+    // (the lines and the pileup entries stay in HBM: the consumer's host side fetches them in slices beside the next call -- fq_ctx_qc_stream)
+    CK(fqdev::copy_pinned(c->p_qcnt.p, c->d_qcnt.p, NC * 8, 0));
+    if (a.shard) CK(fqdev::copy_pinned(c->p_dupkey.p, c->d_dupkey.p, P * 8, 0));
+    c->stats.d2h_bytes += NC * 8 + (a.shard ? P * 8 : 0);
+    c->qc_out.ist_bytes = E.ist_total; c->qc_out.n_pile = E.pt_total; c->qc_out.dup_key = a.shard ? c->p_dupkey.p : nullptr;
+    c->qc_out.ready = true;
+  }
+  CK(fqdev::copy_flush_now());
+  c->emit_pending = true;
+  K.trace("consumers: fill kernels enqueued");
   return FQ_OK;
 }
 
@@ -2153,9 +2167,7 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
   if (N) {
     A.o_rec = c->d_orec.p; A.o_cigar = c->d_ocig.p; A.o_md = c->d_omd.p; A.o_multi = c->d_omulti.p;
     REC(FQ_ROP_FLAT_FILL, N);
-    if (c->emit_flags & FQ_EMIT_SAM) CKS(stage_emit_sam(K));
-    if (c->qc) CKS(stage_emit_qc(K));
-    if (c->bam) CKS(stage_emit_bam(K));
+    if ((c->emit_flags & FQ_EMIT_SAM) || c->qc || c->bam) CKS(emit_measure(K));
     if (host_arrays) {
       CK(fqdev::copy_pinned(c->p_orec.p, c->d_orec.p, N * sizeof(fq_result_t), 0));
       CK(fqdev::copy_pinned(c->p_ocig.p, c->d_ocig.p, cc * 2, 0));
@@ -2170,9 +2182,7 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
   CKS(sync_staged(c));
   fold_counters(c->h_counters.data(), cnt);
   CK(fqdev::dzero(c->d_counters.p, c->h_counters.size() * 8));
-  if (!N && (c->emit_flags & FQ_EMIT_SAM)) { c->sam_bytes = 0; c->sam_ready = true; }
-  if (!N && c->qc) { c->qc_out = FqQcCallOut(); c->qc_out.owner = c->qc; c->qc_out.ready = true; }
-  if (!N && c->bam) { c->bam_out = FqBamCallOut(); c->bam_out.owner = c->bam; c->bam_out.ready = true; }
+  if (!N && ((c->emit_flags & FQ_EMIT_SAM) || c->qc || c->bam)) CKS(emit_measure(K));
   if (host_arrays) {
     if (!cc) c->p_ocig.p[0] = 0;
     if (!mm) c->p_omd.p[0] = 0;
@@ -2231,6 +2241,7 @@ int stage_finish(Call &K, fq_result_batch_t *out) {
   c->stats.device_wait_ms += c->wait_ms - K.w_call0;
   { timespec ts; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts); c->stats.host_cpu_ms += 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec - K.cpu_call0; }
   K.trace("counters+timers");
+  if ((c->emit_flags & FQ_EMIT_SAM) || c->qc || c->bam) CKS(emit_fill(K));
   return FQ_OK;
 }
 #undef REC
@@ -2544,7 +2555,20 @@ extern "C" int fq_ctx_set_emit(fq_ctx_t *c, int32_t flags) {
 }
 // The SAM text of the last call leaves the device in slices through two pinned buffers on streams of its own, so that it runs beside the
 // next call on another context: sink(user, data, bytes) gets the slices in order.
+// The consumers' fill kernels of the last call were only enqueued (emit_fill): whoever fetches what they leave waits here first -- on the context's
+// own stream, which nothing else drives between two calls -- and takes the counts that came back with them.
+int fq_ctx_emit_wait(fq_ctx_t *c) {
+  std::lock_guard<std::mutex> lk(c->emit_mu);
+  if (!c->emit_pending) return FQ_OK;
+  if (fqdev::bind(c->dev) || fqdev::sync()) { c->err = std::string("waiting for the consumers' kernels: ") + fqdev::last_error(); return FQ_ENODEV; }
+  if (c->qc && c->qc_out.ready)
+    for (int k = 0; k < FQ_QC_C_COUNT; ++k) { uint64_t v = 0; for (int st = 0; st < FQ_C_STRIPES; ++st) v += c->p_qcnt.p[(size_t)st * FQ_C_STRIDE + k]; c->qc_out.cnt[k] = v; }
+  if (c->bam && c->emit_nb) c->bam_out.z_bytes = c->p_ztotal.p[0];
+  c->emit_pending = false;
+  return FQ_OK;
+}
 static int64_t stream_device_bytes(fq_ctx_t *c, int lane, const char *src, uint64_t total, fq_sink_fn sink, void *user, const char *what, size_t granule = 1) {
+  if (fq_ctx_emit_wait(c)) return FQ_ENODEV;
   if (!total) return 0;
   fqdev::State *&st = c->dev_emit[lane];
   PinBuf<char> *pin = c->p_emit[lane];
@@ -2570,6 +2594,7 @@ extern "C" int64_t fq_sam_device_last(fq_ctx_t *c, fq_sink_fn sink, void *user) 
 // the BAM records of the last call (fq_ctx_attach_bam), for the writer they were formatted for
 int64_t fq_ctx_bam_stream(fq_ctx_t *c, fq_sink_fn sink, void *user, int members) {
   if (!c->bam || !c->bam_out.ready) { c->err = "the last call formatted no BAM records on the device"; return FQ_EINVAL; }
+  if (fq_ctx_emit_wait(c)) return FQ_ENODEV;
   if (members) return stream_device_bytes(c, 0, (const char *)c->d_bamz.p, c->bam_out.z_bytes, sink, user, "BGZF members");
   return stream_device_bytes(c, 0, (const char *)c->d_bamrec.p, c->bam_out.bytes, sink, user, "BAM records");
 }

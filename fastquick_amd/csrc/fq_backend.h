@@ -56,6 +56,7 @@ int copy_record(int slot);
 int copy_wait(int slot);                 // host waits for the copies recorded for `slot`
 void copy_discard();                     // forget copy_pinned copies that were queued and not yet launched (a call that ends early)
 int compute_wait_copy(int slot);
+int copy_flush_now();                    // launches the small copy_pinned copies that are still queued (a call that ends without a sync)
 
 // HIP-event timing of everything enqueued between begin/end, accumulated per kernel id
 void time_begin(int kid);

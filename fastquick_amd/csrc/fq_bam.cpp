@@ -436,6 +436,7 @@ extern "C" int fq_bam_add_last(fq_bam_t *b, fq_ctx_t *c) {
   if (!b || !c || !b->z.fp) return FQ_EINVAL;
   if (const FqBamCallOut *D = fq_ctx_bam_out(c)) {        // the records were formatted by the call's kernels (fq_ctx_attach_bam): they only leave the device here
     if (D->owner != b || !D->ready) { b->err = "fq_bam_add_last: the context's last call formatted its records for another writer, or failed"; return FQ_EINVAL; }
+    if (fq_ctx_emit_wait(c)) { b->err = "fq_bam_add_last: waiting for the call's kernels failed"; return FQ_ENODEV; }      // (z_bytes comes back with them)
     int64_t n;
     if (D->z_bytes) {       // finished BGZF members (fq_deflate.h): appended behind whatever the host's layer still holds
       b->z.flush_all();

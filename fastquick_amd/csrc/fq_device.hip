@@ -59,6 +59,7 @@ static thread_local std::string g_err;
 int copy_flush();
 #define FQ_PRE() do { if (copy_flush()) return -3; } while (0)      // the queued small copies go first (copy_pinned)
 void copy_discard() { if (g_cur) g_cur->n_small = 0; }
+int copy_flush_now() { FQ_PRE(); return 0; }
 
 const char *last_error() { return g_err.c_str(); }
 bool is_real_gpu() { return true; }

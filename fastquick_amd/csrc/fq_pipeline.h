@@ -164,6 +164,7 @@ int64_t fq_ctx_bam_stream(fq_ctx_t *c, fq_sink_fn sink, void *user, int members)
 bool fq_bam_wants_members(const fq_bam *b);
 int fq_qc_device_prepare(fq_qc *q, FqQcArgs *a, int n_surv);
 int64_t fq_ctx_qc_stream(fq_ctx_t *c, int which, fq_sink_fn sink, void *user);
+int fq_ctx_emit_wait(fq_ctx_t *c);       // the last call's consumer kernels were only enqueued: wait for them (before its counts / sizes are read)
 int64_t fq_ctx_last_bases(const fq_ctx_t *c);   // sum of the read lengths of the last batch (NumBase increment)
 // the name a record prints under (fq_sam.cpp): `/1` `/2` stripped, a revived mate under its partner's name
 std::string fq_read_name(const FqHostReads *hb, int pair, int end, bool revived);

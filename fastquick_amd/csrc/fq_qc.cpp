@@ -762,6 +762,7 @@ extern "C" int fq_qc_add_last(fq_qc_t *q, fq_ctx_t *c) {
     // the call counted on the device (fq_ctx_attach_qc): the sums are in the consumer's device tables; what depends on the order of the
     // records came back laid out in input order and is appended here
     if (D->owner != q || !D->ready) { q->err = "fq_qc_add_last: the context's last call counted for another consumer, or failed"; return FQ_EINVAL; }
+    if (fq_ctx_emit_wait(c)) { q->err = std::string("fq_qc_add_last: ") + fq_ctx_last_error(c); return FQ_ENODEV; }      // (the call only enqueued its kernels)
     F.BwaUnmapped += (long long)D->cnt[FQ_QC_C_UNMAPPED];
     F.TotalRetained += (long long)(D->cnt[FQ_QC_C_RETAINED1] + 2 * D->cnt[FQ_QC_C_RETAINED2]);
     F.TotalMAPQ += (long long)(D->cnt[FQ_QC_C_FAILED1] + 2 * D->cnt[FQ_QC_C_FAILED2]);

@@ -157,6 +157,7 @@ int launch_sam(int op, const FqSamArgs &a, int64_t n) {
   for (int64_t i = 0; i < n; ++i) { if (op == FQ_EOP_SAM_LEN) fq_sam_len_thread(a, (int)i); else if (op == FQ_EOP_SAM_FILL) fq_sam_fill_thread(a, (int)i); else return -1; }
   return 0;
 }
+int copy_flush_now() { return 0; }
 int launch_deflate(const FqDeflateArgs &a) {
   static thread_local FqdLds lds;
   for (uint32_t b = 0; b < a.n_blocks; ++b) a.bsize[b] = fqd_member(a, b, lds);
