@@ -63,6 +63,17 @@ template <class T> struct DevBuf {
     if (!p) { cap = 0; return false; }
     return true;
   }
+  // the consumers' multi-GB buffers (SAM text, BAM records and members): an eighth of slack, so that chunks whose sizes differ by a few per cent do not
+  // free and allocate gigabytes -- hipFree waits for the device -- on every call
+  bool ensure_roomy(size_t n) {
+    if (n <= cap) return true;
+    fqdev::dfree(p);
+    cap = n + n / 8 + 64;
+    p = (T *)fqdev::dmalloc(cap * sizeof(T));
+    if (!p) { cap = n; p = (T *)fqdev::dmalloc(cap * sizeof(T)); }
+    if (!p) { cap = 0; return false; }
+    return true;
+  }
   bool ensure_keep(size_t n, size_t keep) {   // as ensure, but the first `keep` elements survive a reallocation (copied on the compute stream)
     if (n <= cap) return true;
     const size_t ncap = n + std::min<size_t>(n / 4, (size_t)16 << 20) + 64;
@@ -2089,7 +2100,7 @@ int emit_fill(Call &K) {
   }
   std::lock_guard<std::mutex> lk(c->emit_mu);
   if (c->emit_flags & FQ_EMIT_SAM) {
-    CKM(c->d_samtext.ensure(E.sam_total + 64));
+    CKM(c->d_samtext.ensure_roomy(E.sam_total + 64));
     E.sam.text = c->d_samtext.p;
     CK(fqdev::launch_sam(FQ_EOP_SAM_FILL, E.sam, (int64_t)N));
     c->sam_bytes = E.sam_total;
@@ -2097,7 +2108,7 @@ int emit_fill(Call &K) {
   }
   if (c->bam) {
     const uint64_t total = E.bam_total;
-    CKM(c->d_bamrec.ensure(total + 64));
+    CKM(c->d_bamrec.ensure_roomy(total + 64));
     E.bam.out = c->d_bamrec.p;
     CK(fqdev::launch_bam(FQ_EOP_BAM_FILL, E.bam, (int64_t)N));
     c->bam_out.bytes = total;
@@ -2106,7 +2117,7 @@ int emit_fill(Call &K) {
       // the writer has a file: the records leave the device as finished BGZF members (fq_deflate.h: a wavefront per block of the record stream),
       // packed behind each other into a buffer sized for the worst case; their size comes back with the wait
       const uint32_t nb = (uint32_t)((total + FQD_BLOCK - 1) / FQD_BLOCK);
-      CKM(c->d_zstage.ensure((size_t)nb * FQD_SLOT) && c->d_zsize.ensure((size_t)nb + 1) && c->d_zoff.ensure((size_t)nb + 2) && c->d_bamz.ensure((size_t)nb * FQD_SLOT) && c->p_ztotal.ensure(8));
+      CKM(c->d_zstage.ensure_roomy((size_t)nb * FQD_SLOT) && c->d_zsize.ensure((size_t)nb + 1) && c->d_zoff.ensure((size_t)nb + 2) && c->d_bamz.ensure_roomy((size_t)nb * FQD_SLOT) && c->p_ztotal.ensure(8));
       FqDeflateArgs z{c->d_bamrec.p, total, c->d_zstage.p, c->d_zsize.p, fqdev::crc_const(), nb};
       if (!z.crc) { c->err = std::string("BGZF on the device: ") + fqdev::last_error(); return FQ_ENODEV; }
       CK(fqdev::launch_deflate(z));
@@ -2121,7 +2132,7 @@ int emit_fill(Call &K) {
   if (c->qc) {
     FqQcArgs &a = E.qc;
     const size_t NC = (size_t)FQ_C_STRIPES * FQ_C_STRIDE;
-    CKM(c->d_isttext.ensure(E.ist_total + 64) && c->d_pile.ensure(E.pt_total + 1));
+    CKM(c->d_isttext.ensure_roomy(E.ist_total + 64) && c->d_pile.ensure_roomy(E.pt_total + 1));
     a.ist_text = c->d_isttext.p; a.pt = c->d_pile.p;
     CK(fqdev::launch_qc(FQ_QOP_IST_FILL, a, (int64_t)P));
     CK(fqdev::launch_qc(FQ_QOP_PILE_FILL, a, (int64_t)N));

@@ -957,23 +957,36 @@ extern "C" int fq_qc_write(fq_qc_t *q) {
     for (auto &kv : q->contig_status)
       f << kv.first << "\t" << kv.second.overlapped << "\t" << kv.second.fully << "\t" << kv.second.pair_overlapped << "\t" << kv.second.fully_paired << std::endl;
   }
-  {   // GetPileup, :2030-2065
-    std::ofstream f(pre + ".Pileup");
+  {   // GetPileup, :2030-2065 (the same bytes; a marker's line is put together in one buffer: a deep run's file is tens of megabytes of single characters)
+    FILE *fp = fopen((pre + ".Pileup").c_str(), "wb");
     const int qualoffset = (q->o.mode & FQ_MODE_IL13) ? 64 : 33;
+    std::string ln;
+    char num[16];
     for (auto &chr : q->vcf_table)
       for (auto &site : chr.second) {
         const unsigned k = site.second;
         if (q->seq_vec[k].empty()) continue;
-        f << chr.first << "\t" << site.first << "\t.\t" << q->strand_vec[k].size() << "\t";
-        for (uint32_t t = 0; t != q->strand_vec[k].size(); ++t) f << (char)(q->strand_vec[k][t] ? toupper(q->seq_vec[k][t]) : tolower(q->seq_vec[k][t]));
-        f << "\t";
-        for (uint32_t t = 0; t != q->qual_vec[k].size(); ++t) f << char(q->qual_vec[k][t] + qualoffset);
-        f << "\t";
-        for (uint32_t t = 0; t != q->maq_vec[k].size(); ++t) f << q->maq_vec[k][t];
-        f << "\t";
-        for (uint32_t t = 0; t != q->cycle_vec[k].size(); ++t) { f << q->cycle_vec[k][t]; if (t != q->cycle_vec[k].size() - 1) f << ","; }
-        f << std::endl;
+        ln.clear();
+        ln += chr.first; ln += '\t';
+        ln += std::to_string(site.first); ln += "\t.\t";
+        ln += std::to_string(q->strand_vec[k].size()); ln += '\t';
+        for (uint32_t t = 0; t != q->strand_vec[k].size(); ++t) ln += (char)(q->strand_vec[k][t] ? toupper(q->seq_vec[k][t]) : tolower(q->seq_vec[k][t]));
+        ln += '\t';
+        for (uint32_t t = 0; t != q->qual_vec[k].size(); ++t) ln += char(q->qual_vec[k][t] + qualoffset);
+        ln += '\t';
+        ln.append((const char *)q->maq_vec[k].data(), q->maq_vec[k].size());
+        ln += '\t';
+        for (uint32_t t = 0; t != q->cycle_vec[k].size(); ++t) {
+          int v = q->cycle_vec[k][t], n = 0;
+          if (v < 0) { ln += '-'; v = -v; }
+          do { num[n++] = (char)('0' + v % 10); v /= 10; } while (v);
+          while (n) ln += num[--n];
+          if (t != q->cycle_vec[k].size() - 1) ln += ',';
+        }
+        ln += '\n';
+        if (fp) fwrite(ln.data(), 1, ln.size(), fp);
       }
+    if (fp) fclose(fp);
   }
   {   // SummaryOutput, :2343-2483
     std::ofstream fq(pre + ".FASTQ.csv");
@@ -1041,6 +1054,17 @@ extern "C" int fq_qc_write(fq_qc_t *q) {
     f << "##FORMAT=<ID=PL,Number=G,Type=Integer,Description=\"Normalized, Phred-scaled likelihoods for genotypes as defined in the VCF specification\">\n";
     f << "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tIntendedSample\n";
     float alleleFrq = 0.;
+    // CalLikelihood's terms per quality value (the pileups keep `char` qualities), evaluated with the reference's types: float seq_error = pow(10.0, q / -10.0);
+    // std::log10 of a float expression where the expression is float, of a double where it is double
+    struct VcfTerms { float one_minus, third, two_thirds; double half_minus; };     // (0.5 - seq_error / 3 is a double expression: its log10 is added as a double)
+    std::vector<VcfTerms> vcf_terms(256);
+    for (int v = 0; v < 256; ++v) {
+      const char qv = (char)(unsigned char)v;
+      float seq_error = pow(10.0, (qv / (-10.0)));
+      VcfTerms T;
+      T.one_minus = std::log10(1 - seq_error); T.half_minus = std::log10(0.5 - seq_error / 3); T.third = std::log10(seq_error / 3); T.two_thirds = std::log10(2 * seq_error / 3);
+      vcf_terms[(size_t)v] = T;
+    }
     for (auto &chr : q->vcf_table)
       for (auto &site : chr.second) {
         const unsigned k = site.second;
@@ -1061,11 +1085,11 @@ extern "C" int fq_qc_write(fq_qc_t *q) {
         f << "AF=" << af << ";AC=" << seq.size() << "\t" << "GT:PL:GP\t";
         const char maj = m.ref[0], mnr = m.alt[0];
         float GL0(0), GL1(0), GL2(0);
-        for (uint32_t i = 0; i != seq.size(); ++i) {
-          float seq_error = pow(10.0, (qual[i] / (-10.0)));
-          if (seq[i] == maj) { GL0 += std::log10(1 - seq_error); GL1 += std::log10(0.5 - seq_error / 3); GL2 += std::log10(seq_error / 3); }
-          else if (seq[i] == mnr) { GL0 += std::log10(seq_error / 3); GL1 += std::log10(0.5 - seq_error / 3); GL2 += std::log10(1 - seq_error); }
-          else { GL0 += std::log10(2 * seq_error / 3); GL1 += std::log10(2 * seq_error / 3); GL2 += std::log10(2 * seq_error / 3); }
+        for (uint32_t i = 0; i != seq.size(); ++i) {      // (the four terms depend on the quality value alone: looked up, added in the reference's order)
+          const VcfTerms &T = vcf_terms[(unsigned char)qual[i]];
+          if (seq[i] == maj) { GL0 += T.one_minus; GL1 += T.half_minus; GL2 += T.third; }
+          else if (seq[i] == mnr) { GL0 += T.third; GL1 += T.half_minus; GL2 += T.one_minus; }
+          else { GL0 += T.two_thirds; GL1 += T.two_thirds; GL2 += T.two_thirds; }
         }
         float PL[3];
         PL[0] = std::floor(GL0 * (-10) + 0.5); PL[1] = std::floor(GL1 * (-10) + 0.5); PL[2] = std::floor(GL2 * (-10) + 0.5);
