@@ -2146,6 +2146,8 @@ int emit_fill(Call &K) {
   }
   CK(fqdev::copy_flush_now());
   c->emit_pending = true;
+  static const bool emit_sync = [] { const char *e = getenv("FASTQUICK_EMIT_SYNC"); return e && *e && *e != '0'; }();   // A/B: the call waits for its consumers' kernels
+  if (emit_sync) CKS(sync_staged(c));
   K.trace("consumers: fill kernels enqueued");
   return FQ_OK;
 }
