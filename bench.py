@@ -102,7 +102,7 @@ def main() -> None:
     ap.add_argument("--front-end-copies", type=int, default=64, help="the steady-state command-line run reads those files concatenated this many times (0 / 1: skip)")
     ap.add_argument("--no-cli-ontarget", action="store_true", help="skip front_end.cli_e2e_ontarget (the command line on on-target FASTQ files)")
     ap.add_argument("--cli-ontarget-pairs", type=int, default=1 << 19, help="distinct on-target pairs of that leg's FASTQ files")
-    ap.add_argument("--cli-ontarget-copies", type=int, default=32, help="... concatenated this many times (BGZF members concatenate)")
+    ap.add_argument("--cli-ontarget-copies", type=int, default=64, help="... concatenated this many times (BGZF members concatenate)")
     ap.add_argument("--no-reference-baseline", action="store_true", help="skip cpu_baseline.reference (the real reference, oracle/_ref, timed on the same input)")
     ap.add_argument("--reference-sample-pairs", type=int, default=1 << 20, help="pairs of the WGS-mix sample the real reference aligns (a sixteenth of it for the on-target mix)")
     ap.add_argument("--cpu-sample-pairs", type=int, default=0, help="pairs per slice for the CPU baseline (0 = auto)")
@@ -727,7 +727,7 @@ def main() -> None:
                         if args.markers != 10000 and rl != L:
                             continue
                         try:
-                            ont[key] = cli_ontarget.measure(exe, pre, ref, os.path.join(fdir, "ont"), pairs=n_, copies=cp_, read_len=rl, threads=pt)
+                            ont[key] = cli_ontarget.measure(exe, pre, ref, os.path.join(fdir, "ont"), pairs=n_, copies=cp_, read_len=rl, threads=pt, repeats=2)
                         except Exception as e:      # noqa: BLE001
                             ont[key] = {"error": repr(e)[:300]}
                     fe["cli_e2e_ontarget"] = ont

@@ -16,7 +16,7 @@ sys.path.insert(0, ROOT)
 EOF_MEMBER = b"\x1f\x8b\x08\x04\x00\x00\x00\x00\x00\xff\x06\x00BC\x02\x00\x1b\x00\x03\x00\x00\x00\x00\x00\x00\x00\x00\x00"
 
 
-def measure(exe, pre, ref, workdir, pairs=1 << 20, copies=8, read_len=150, threads=16, extra=(), modes=("sam_out", "bam_and_qc"), seed=4242, profile_dir=None):
+def measure(exe, pre, ref, workdir, pairs=1 << 20, copies=8, read_len=150, threads=16, extra=(), modes=("sam_out", "bam_and_qc"), seed=4242, profile_dir=None, repeats=1):
     """pre: <index prefix>.FASTQuick.fa of `ref` (built).  Writes `pairs` seeded on-target pairs as two BGZF files, concatenated `copies` times
     (BGZF members concatenate), the QC inputs of the index, and runs the command line once per mode with stdout to /dev/null."""
     import numpy as np
@@ -49,12 +49,19 @@ def measure(exe, pre, ref, workdir, pairs=1 << 20, copies=8, read_len=150, threa
                "--read_len", str(max(read_len, 151)), "--t", str(threads)] + (["--sam_out"] if mode == "sam_out" else []) + list(extra)
         if profile_dir:       # rocprofv3 --kernel-trace --stats around the command line itself (FQ_PROFILE_DIR): per-kernel times of the run
             cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", os.path.join(profile_dir, mode), "-o", "p", "--"] + cmd
-        time.sleep(3.0)       # (a process started right behind another's exit waits for the driver to take that one's device memory back)
-        t0 = time.perf_counter()
-        run = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
-        dt = time.perf_counter() - t0
+        walls = []
+        for _ in range(max(1, repeats)):      # (whole-process wall time on a shared host: the runs are listed, the best one is the rate)
+            time.sleep(3.0)       # (a process started right behind another's exit waits for the driver to take that one's device memory back)
+            t0 = time.perf_counter()
+            run_ = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
+            walls.append(round(time.perf_counter() - t0, 2))
+            if run_.returncode != 0 or len(walls) == 1 or walls[-1] == min(walls):
+                run = run_
+            if run_.returncode != 0:
+                break
+        dt = min(walls)
         err = run.stderr.decode(errors="replace").splitlines()
-        res[mode] = {"rc": run.returncode, "wall_s": round(dt, 2), "pairs_per_s": round(total / dt, 1) if run.returncode == 0 else None,
+        res[mode] = {"rc": run.returncode, "wall_s": round(dt, 2), "wall_s_runs": walls, "pairs_per_s": round(total / dt, 1) if run.returncode == 0 else None,
                      "output": "SAM text (to /dev/null) + 13 QC files" if mode == "sam_out" else "BAM file + 13 QC files",
                      "notices": [l for l in err if "consumers" in l or "device time" in l or "reading (ms)" in l or "FATAL" in l][-4:]}
         if os.environ.get("FASTQUICK_TRACE"):
