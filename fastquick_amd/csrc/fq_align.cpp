@@ -720,6 +720,13 @@ struct EmitPlan {                      // what emit_measure leaves for emit_fill
 struct Call {
   fq_ctx *c;
   EmitPlan plan_emit;
+  // the call's place among the calls that count for the same QC consumer (taken right behind its order-dependent part); a call that ends early
+  // still takes its turn, so that the calls behind it are not left waiting
+  fq_qc *gate = nullptr; uint64_t gate_ticket = 0; bool gate_entered = false, gate_left = false;
+  void gate_take(fq_qc *q) { if (q) { gate = q; gate_ticket = fq_qc_gate_ticket(q); } }
+  void gate_enter() { if (gate && !gate_entered) { fq_qc_gate_enter(gate, gate_ticket); gate_entered = true; } }
+  void gate_leave() { if (gate && gate_entered && !gate_left) { fq_qc_gate_leave(gate); gate_left = true; } }
+  void gate_release() { if (gate && !gate_left) { gate_enter(); gate_leave(); } }
   explicit Call(fq_ctx *ctx) : c(ctx), aln_off(ctx->st.aln_off), aln_n(ctx->st.aln_n) {}
   int n = 0, n2 = 0, B = 0, n_sub = 0, n_search = 0, n_surv = 0, max_len_all = 1, host_threads = 1;
   size_t par_min = 32768;
@@ -749,7 +756,7 @@ struct Call {
   // the main-hit stage's plan (stageB1_plan): where every chunk of pairs enters the drand48 stream
   struct B1Plan { uint64_t *start = nullptr; size_t n_chunks = 0; uint64_t rng_end = 0; } plan;
   std::thread plan_thread;             // the plan is drawn up beside the SA stage when nothing else can move the stream's state
-  ~Call() { if (plan_thread.joinable()) plan_thread.join(); }
+  ~Call() { if (plan_thread.joinable()) plan_thread.join(); gate_release(); }
   double t_trace = 0, t_wall0 = 0, t_host0 = 0, t_serial1 = 0, t_host1 = 0, cpu_trace = 0, tcpu_trace = 0;
   double w_call0 = 0, w_host0 = 0, w_serial1 = 0, w_host1 = 0, cpu_call0 = 0;   // the context's wait_ms at those marks; the calling thread's CPU time at the start
   int sidx(size_t idx) const { return c->h_surv[idx].sidx; }
@@ -2072,6 +2079,7 @@ int emit_measure(Call &K) {
     FqQcArgs &a = E.qc;
     CKS(emit_args(K, a.s));
     a.ix = c->ix->dev;
+    K.gate_enter();
     { const int rc = fq_qc_device_prepare(c->qc, &a, K.n_surv); if (rc) { c->err = std::string("the QC consumer could not take the call: ") + fq_qc_last_error(c->qc); return rc; } }
     const size_t NC = (size_t)FQ_C_STRIPES * FQ_C_STRIDE;
     CKM(c->d_qadded.ensure(N + 1) && c->d_istlen.ensure(P + 1) && c->d_istoff.ensure(P + 2) && c->d_ptcnt.ensure(N + 1) && c->d_ptoff.ensure(N + 2) && c->d_qcnt.ensure(NC) && c->p_qcnt.ensure(NC));
@@ -2086,6 +2094,7 @@ int emit_measure(Call &K) {
     CKS(fetch_u64(c, &E.pt_total, c->d_ptoff.p + N));
   }
   CKS(sync_staged(c));
+  K.gate_leave();
   K.trace("consumers: lengths, decisions, prefix sums");
   return FQ_OK;
 }
@@ -2339,6 +2348,7 @@ int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
     c->last_ii = K.iis[K.n_sub - 1];
     if ((rc = stage_kl_cache(K))) return rc;
   }
+  K.gate_take(c->qc);               // (inside the order-dependent part: the tickets are in the stream's order)
   if (c->after_serial) c->after_serial(c->hook_user);
   c->serial_done = true;
   if (c->stream_broken) { c->err = "the hook that hands the stream's state on failed (fq_ctx_mark_stream_broken)"; return FQ_EIO; }

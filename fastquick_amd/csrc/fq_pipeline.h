@@ -163,6 +163,10 @@ int fq_bam_device_prepare(fq_bam *b, FqBamArgs *a);
 int64_t fq_ctx_bam_stream(fq_ctx_t *c, fq_sink_fn sink, void *user, int members);   // members != 0: the BGZF members instead of the raw records
 bool fq_bam_wants_members(const fq_bam *b);
 int fq_qc_device_prepare(fq_qc *q, FqQcArgs *a, int n_surv);
+// the counting steps of calls that share a consumer run one at a time, in the order in which the calls passed their order-dependent part
+uint64_t fq_qc_gate_ticket(fq_qc *q);
+void fq_qc_gate_enter(fq_qc *q, uint64_t ticket);
+void fq_qc_gate_leave(fq_qc *q);
 int64_t fq_ctx_qc_stream(fq_ctx_t *c, int which, fq_sink_fn sink, void *user);
 int fq_ctx_emit_wait(fq_ctx_t *c);       // the last call's consumer kernels were only enqueued: wait for them (before its counts / sizes are read)
 int64_t fq_ctx_last_bases(const fq_ctx_t *c);   // sum of the read lengths of the last batch (NumBase increment)

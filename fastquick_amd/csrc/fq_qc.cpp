@@ -31,6 +31,7 @@
 #include "fq_pool.h"
 #include "fq_backend.h"
 #include <mutex>
+#include <condition_variable>
 
 namespace {
 const int kInsertLimit = 4096;                 // INSERT_SIZE_LIMIT
@@ -203,6 +204,11 @@ struct fq_qc {
   std::vector<uint64_t> est_hist = std::vector<uint64_t>(4 * (size_t)kInsertLimit, 0);
   bool est_valid = true;
   uint64_t dup_cap = 0, ord_next = 0;
+  // calls of several contexts that share this consumer may overlap (a stream pipelined over two contexts): their counting steps -- which place
+  // the call's pairs in the input's order and may grow the duplicate set -- run one at a time, in the order of the calls' order-dependent parts
+  std::mutex gate_mu;
+  std::condition_variable gate_cv;
+  uint64_t tickets = 0, serving = 0;
   int device_setup();
   int pull();                                      // device sums -> host tables; the device tables start again from zero
   int bind_own();
@@ -661,6 +667,9 @@ int fq_qc_device_prepare(fq_qc *q, FqQcArgs *a, int n_surv) {
   a->dup_tab = q->d_dup; a->dup_mask = q->dup_cap ? q->dup_cap - 1 : 0;
   return FQ_OK;
 }
+uint64_t fq_qc_gate_ticket(fq_qc *q) { std::lock_guard<std::mutex> lk(q->gate_mu); return q->tickets++; }
+void fq_qc_gate_enter(fq_qc *q, uint64_t ticket) { std::unique_lock<std::mutex> lk(q->gate_mu); q->gate_cv.wait(lk, [&] { return q->serving == ticket; }); }
+void fq_qc_gate_leave(fq_qc *q) { { std::lock_guard<std::mutex> lk(q->gate_mu); ++q->serving; } q->gate_cv.notify_all(); }
 // what the device has summed since the last pull, added to the host's tables
 int fq_qc::pull() {
   std::lock_guard<std::mutex> lk(dev_mu);
