@@ -348,77 +348,24 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
   fq_frontend_t *fe = open_device_front_end(A, A.fq1, A.fq2, device, slot_mode, stride);
   fq_ctx_t *ctx2 = nullptr;             // the device's part runs on two contexts in turn: the consumers of one call's records work while the next call runs
   if (fe) {
-    // Two contexts, two calls in flight: call k + 1 filters, walks and searches (everything per read: the bulk of a call) while call k pairs, rescues,
-    // refines and hands its records to the consumers' kernels.  What a stream carries from batch to batch -- the drand48 stream, last_ii, the (k,l)
-    // cache -- goes from the context of call k to that of call k + 1 around the short order-dependent part of each call (fq_ctx_set_serial_hooks, as
-    // a stream sharded over devices does it); the consumers' host sides take the calls in input order.
-    struct Flight {
-      fq_ctx_t *cx = nullptr; std::thread th; fq_text_batch_t *tb = nullptr;
-      long long k = -1; int64_t n = 0; int rc = 0; std::string err; fq_result_batch_t res{};
-    } fl[2];
-    struct Pipe {
-      std::mutex mu; std::condition_variable cv;
-      long long token_of = -1; std::vector<char> token;      // the stream's state behind call token_of
-      long long turn = 0;                                    // the call whose records the consumers take next
-      long long failed_at = -1; std::string fail_msg;
-    } P;
-    struct Hook { Pipe *P; Flight *F; };
-    auto hook_before = [](void *u) {
-      Hook *h = (Hook *)u;
-      if (h->F->k == 0) return;
-      std::unique_lock<std::mutex> lk(h->P->mu);
-      h->P->cv.wait(lk, [&] { return h->P->token_of == h->F->k - 1; });
-      if (fq_ctx_state_import(h->F->cx, h->P->token.data(), (int64_t)h->P->token.size())) fq_ctx_mark_stream_broken(h->F->cx);
+    std::thread th_qc, th_out;
+    fq_text_batch_t *tb_prev = nullptr;
+    auto finish_prev = [&] {            // the previous call's consumers are done: its batch may be reused
+      if (th_qc.joinable()) th_qc.join();
+      if (th_out.joinable()) th_out.join();
+      if (tb_prev) { fq_frontend_release(fe, tb_prev); tb_prev = nullptr; }
     };
-    auto hook_after = [](void *u) {
-      Hook *h = (Hook *)u;
-      const int64_t need = fq_ctx_state_export(h->F->cx, nullptr, 0);
-      std::vector<char> t((size_t)std::max<int64_t>(need, 0));
-      if (need > 0) fq_ctx_state_export(h->F->cx, t.data(), need);
-      { std::lock_guard<std::mutex> lk(h->P->mu); h->P->token.swap(t); h->P->token_of = h->F->k; }
-      h->P->cv.notify_all();
-    };
-    Hook hooks[2] = {{&P, &fl[0]}, {&P, &fl[1]}};
-    auto fly = [&](Flight &F, Hook *hk) {
-      fq_ctx_set_serial_hooks(F.cx, hook_before, hook_after, hk);
-      const auto ta0 = std::chrono::steady_clock::now();
-      F.rc = fq_align_text(F.cx, F.tb, &F.res);
-      if (F.rc) F.err = std::string("fq_align_text failed: ") + fq_ctx_last_error(F.cx);
-      { std::lock_guard<std::mutex> lk(tm_mu); align_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta0).count(); }
-      mark("call done");
-      {   // the consumers take the calls in input order; a refused call ends the stream behind the records of the calls before it
-        std::unique_lock<std::mutex> lk(P.mu);
-        P.cv.wait(lk, [&] { return P.turn == F.k; });
-        if (F.rc && (P.failed_at < 0 || F.k < P.failed_at)) { P.failed_at = F.k; P.fail_msg = F.err; }
-      }
-      const bool live = P.failed_at < 0 || F.k < P.failed_at;
-      if (live) {
-        count(F.res, se ? F.n : 2 * F.n);
-        std::thread tq([&] { consume_qc(F.cx); });
-        consume_out(F.cx);
-        tq.join();
-      }
-      fq_frontend_release(fe, F.tb);
-      F.tb = nullptr;
-      { std::lock_guard<std::mutex> lk(P.mu); P.turn = F.k + 1; }
-      P.cv.notify_all();
-      mark("call's consumers done");
-    };
-    auto drain = [&] { for (auto &F : fl) if (F.th.joinable()) F.th.join(); };
-    before_die = drain;
-    long long k = 0;
-    for (;; ++k) {
+    before_die = [&] { if (th_qc.joinable()) th_qc.join(); if (th_out.joinable()) th_out.join(); };
+    fq_ctx_t *cur = nullptr, *other = nullptr;
+    std::vector<char> token;
+    for (;;) {
       const auto tr0 = std::chrono::steady_clock::now();
       fq_text_batch_t *tb = nullptr;
       const int64_t n = fq_frontend_next(fe, &tb);
       const double waited = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tr0).count();
       if (!started) read_ms += waited; else read_wait_ms += waited;
-      bool failed;
-      { std::lock_guard<std::mutex> lk(P.mu); failed = P.failed_at >= 0; }
-      if (failed) { if (n > 0 && tb) fq_frontend_release(fe, tb); break; }
       if (n == FQ_EFALLBACK) {
-        drain();
-        { std::lock_guard<std::mutex> lk(P.mu); if (P.failed_at >= 0) break; }
+        finish_prev();
         fq_fastq_t *h[2] = {nullptr, nullptr};
         if ((rc = fq_frontend_handover(fe, reader_threads, h))) fail("the device front end could not hand " + A.fq1 + " over to the host reader (" + std::to_string(rc) + ")");
         r1.reset(new FastqReader(A.fq1, h[0]));
@@ -429,25 +376,37 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
       if (n < 0) fail(std::string(fq_frontend_last_error(fe)).empty() ? "the device front end failed (" + std::to_string(n) + ")" : fq_frontend_last_error(fe));
       if (n == 0) break;
       start();
-      if (!ctx2) {
+      if (!cur) {
+        cur = ctx;
         fq_opts_t o = A.o;
         o.single_end = se ? 1 : 0;
         if (fq_ctx_create(ix, &o, (int32_t)A.chunk_pairs, &ctx2)) fail("fq_ctx_create failed: option outside the supported range");
         device_consumers(ctx2);
-        fl[0].cx = ctx; fl[1].cx = ctx2;
+        other = ctx2;
+      } else {
+        // the stream's order-dependent state -- drand48 stream, last_ii, (k,l) cache -- goes from the context of the last call to this one's
+        const int64_t need = fq_ctx_state_export(other, nullptr, 0);
+        token.resize((size_t)std::max<int64_t>(need, 0));
+        if (need < 0 || fq_ctx_state_export(other, token.data(), need) != need || fq_ctx_state_import(cur, token.data(), need)) fail("handing the stream's state from one context to the other failed");
       }
-      Flight &F = fl[k & 1];
-      if (F.th.joinable()) F.th.join();       // call k - 2 and its consumers are done: its context is free
-      { std::lock_guard<std::mutex> lk(P.mu); if (P.failed_at >= 0) { fq_frontend_release(fe, tb); break; } }
       if (!se) order_check((int)n, [&](int sb, int e) { const char *nm = fq_text_batch_first_name(tb, sb, e); return nm ? nm : ""; });
-      F.k = k; F.n = n; F.tb = tb; F.rc = 0; F.err.clear();
-      F.th = std::thread(fly, std::ref(F), &hooks[k & 1]);
+      fq_result_batch_t res;
+      const auto ta0 = std::chrono::steady_clock::now();
+      if ((rc = fq_align_text(cur, tb, &res))) fail(std::string("fq_align_text failed: ") + fq_ctx_last_error(cur));
+      align_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ta0).count();
+      mark("call done");
+      finish_prev();
+      mark("previous call's consumers done");
+      count(res, se ? n : 2 * n);
+      fq_ctx_t *cx = cur;
+      th_qc = std::thread([&, cx] { consume_qc(cx); });
+      th_out = std::thread([&, cx] { consume_out(cx); });
+      tb_prev = tb;
+      std::swap(cur, other);            // (`other` now names the context of the call just made: the one whose state goes on)
     }
-    drain();
+    finish_prev();
     before_die = nullptr;
-    if (P.failed_at >= 0) { out.flush(); die(P.fail_msg); }
-    for (auto &F : fl) if (F.cx) fq_ctx_set_serial_hooks(F.cx, nullptr, nullptr, nullptr);
-    if (k > 0 && ctx2) ctx = fl[(k - 1) & 1].cx;       // the context that holds the stream's state (the host readers' part, if any, goes on with it)
+    if (other && cur) ctx = other;       // the context that holds the stream's state (the host readers' part, if any, goes on with it)
     unequal_on_device = fq_frontend_unequal_lengths(fe) != 0;
     front_end_notice(fe);
   } else {
