@@ -297,7 +297,7 @@ struct fq_ctx {
   bool host_rows = true;               // the last text batch's surviving rows were copied to the host
   DevBuf<uint8_t> d_equal; PinBuf<uint8_t> p_equal;
   DevBuf<char> d_enames; PinBuf<char> p_enames;
-  DevBuf<uint32_t> d_samlen; DevBuf<uint64_t> d_samoff; DevBuf<char> d_samtext;
+  DevBuf<uint32_t> d_samlen, d_sammeta; DevBuf<uint64_t> d_samoff; DevBuf<char> d_samtext;
   uint64_t sam_bytes = 0;
   bool sam_ready = false;
   // the consumer side's own streams and pinned slices: what a call left in HBM leaves the device beside the next call.  Two lanes, because the
@@ -2060,8 +2060,8 @@ int emit_measure(Call &K) {
   if (!N) return FQ_OK;
   if (c->emit_flags & FQ_EMIT_SAM) {
     CKS(emit_args(K, E.sam));
-    CKM(c->d_samlen.ensure(N + 1) && c->d_samoff.ensure(N + 2));
-    E.sam.len = c->d_samlen.p; E.sam.off = c->d_samoff.p;
+    CKM(c->d_samlen.ensure(N + 1) && c->d_samoff.ensure(N + 2) && c->d_sammeta.ensure(N + 1));
+    E.sam.len = c->d_samlen.p; E.sam.off = c->d_samoff.p; E.sam.meta = c->d_sammeta.p;
     CK(fqdev::launch_sam(FQ_EOP_SAM_LEN, E.sam, (int64_t)N));
     CK(fqdev::launch_scan(c->d_samlen.p, c->d_samoff.p, (uint32_t)N));
     CKS(fetch_u64(c, &E.sam_total, c->d_samoff.p + N));
@@ -2111,7 +2111,8 @@ int emit_fill(Call &K) {
   if (c->emit_flags & FQ_EMIT_SAM) {
     CKM(c->d_samtext.ensure_roomy(E.sam_total + 64));
     E.sam.text = c->d_samtext.p;
-    CK(fqdev::launch_sam(FQ_EOP_SAM_FILL, E.sam, (int64_t)N));
+    CK(fqdev::launch_sam(FQ_EOP_SAM_FILL, E.sam, (int64_t)N));      // heads and tags: a thread per record
+    CK(fqdev::launch_sam(FQ_EOP_SAM_BODY, E.sam, (int64_t)N));      // SEQ / QUAL runs: a thread per sixteen bytes
     c->sam_bytes = E.sam_total;
     c->sam_ready = true;
   }

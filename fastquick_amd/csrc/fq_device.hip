@@ -1568,6 +1568,11 @@ __global__ void __launch_bounds__(256) k_sam_fill(FqSamArgs a, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) fq_sam_fill_thread(a, i);
 }
+__global__ void __launch_bounds__(256) k_sam_body(FqSamArgs a, int n, int pieces) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int idx = (int)(t / pieces), c = (int)(t % pieces);
+  if (idx < n) fq_sam_body_piece(a, idx, c);
+}
 int launch_sam(int op, const FqSamArgs &a, int64_t n) {
   FQ_PRE();
   if (n <= 0) return 0;
@@ -1576,6 +1581,10 @@ int launch_sam(int op, const FqSamArgs &a, int64_t n) {
   kernel_events(FQ_K_EMIT, &e0, &e1);
   if (op == FQ_EOP_SAM_LEN) hipExtLaunchKernelGGL(k_sam_len, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
   else if (op == FQ_EOP_SAM_FILL) hipExtLaunchKernelGGL(k_sam_fill, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
+  else if (op == FQ_EOP_SAM_BODY) {      // a thread per sixteen bytes of a record's SEQ / tab / QUAL run (2 x row stride + 1 bytes at most)
+    const int pieces = (2 * a.stride + 1 + FQ_SAM_PIECE - 1) / FQ_SAM_PIECE;
+    hipExtLaunchKernelGGL(k_sam_body, dim3(nblk((uint64_t)n * (uint64_t)pieces, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n, pieces);
+  }
   else { g_err = "SAM text: unknown operation"; return -1; }
   FQ_HIP(hipGetLastError());
   return 0;

@@ -51,6 +51,8 @@ FQ_HD int fq_dev_pac2real(const FqDevContigs &C, int64_t pos, int len, int *seqi
 struct FqTxt {
   char *dst;
   int64_t at;
+  int32_t body_at = -1;          // where the line's SEQ column begins (fq_sam_line notes it)
+  bool body = true;              // false: the SEQ / tab / QUAL run of a line is stepped over, not produced (k_sam_body writes it, sixteen bytes per thread)
   FQ_HD void ch(char c) { if (dst) dst[at] = c; ++at; }
   FQ_HD void str(const char *s) { while (*s) ch(*s++); }
   FQ_HD void bytes(const char *s, int n) { for (int k = 0; k < n; ++k) ch(s[k]); }
@@ -77,8 +79,39 @@ struct FqSamArgs {
   const char *names; int32_t name_stride;
   uint32_t *len;                 // [2 n_surv] length of the record's line (0: not printed)
   const uint64_t *off;           // ... exclusive prefix sums
+  uint32_t *meta;                // [2 n_surv] where the line's SEQ column begins [0:16), the no-match form [16], the strand the columns are printed in [17]
   char *text;
 };
+// The SEQ column, a tab and the QUAL column of a line: three quarters of its bytes.  One statement of every character, used by the line routine and by the
+// kernel that writes these runs sixteen bytes per thread (coalesced, where a thread per record puts its lanes' bytes 430 apart).
+struct FqSamBody { int nomatch, strand, len, full_len, clip_len, qsub; const uint8_t *row, *qual; };
+FQ_HD int fq_sam_body_len(const FqSamBody &B) { return (B.nomatch ? B.len : B.full_len) + 1 + B.full_len; }
+FQ_HD char fq_sam_body_char(const FqSamBody &B, int b) {
+  const int slen = B.nomatch ? B.len : B.full_len;
+  if (b < slen) {
+    const int j = b;
+    if (B.nomatch) {          // the record of a read without a match (bwase.c:563-579): len bases of seq, or of rseq when the lost hit was on the reverse strand
+      int cc = fq_nt4(B.row[j]);
+      if (B.strand) { cc = j < B.clip_len ? fq_nt4(B.row[B.clip_len - 1 - j]) : 3; cc = cc < 4 ? 3 - cc : cc; }
+      return "ACGTN"[cc > 4 ? 4 : cc];
+    }
+    if (B.strand == 0) { const int cc = fq_nt4(B.row[j]); return "ACGTN"[cc > 4 ? 4 : cc]; }
+    const int cc = fq_nt4(B.row[B.full_len - 1 - j]);
+    return "TGCAN"[cc > 4 ? 4 : cc];
+  }
+  if (b == slen) return '\t';
+  const int j = b - slen - 1;
+  if (B.nomatch) return (char)(B.qual[(B.strand && j < B.len) ? B.len - 1 - j : j] - B.qsub);
+  // Phred+64 input: 31 comes off every quality byte on input (src/BwtMapper.cpp:549-553) and goes back on the first len bytes only when they are printed (bwase.c:516-519)
+  if (j < B.len) return (char)B.qual[B.strand ? B.len - 1 - j : j];
+  return (char)(B.qual[j] - B.qsub);
+}
+FQ_HD void fq_sam_body(const FqSamBody &B, FqTxt &o) {
+  o.body_at = (int32_t)o.at;
+  const int n = fq_sam_body_len(B);
+  if (!o.body) { o.at += n; return; }
+  for (int b = 0; b < n; ++b) o.ch(fq_sam_body_char(B, b));
+}
 
 FQ_HD int fq_emit_row(int packed, int n_pairs, const int32_t *pair_list, int idx) { return packed ? idx : (idx & 1) * n_pairs + pair_list[idx >> 1]; }
 FQ_HD int64_t fq_emit_ref_end(const fq_result_t &p, const uint16_t *cigar) {   // pos_end, libbwa/bwase.c:420-432
@@ -139,13 +172,8 @@ FQ_HD void fq_sam_line(const FqSamArgs &A, int idx, FqTxt &o) {
   if (p.type == FQ_TYPE_NO_MATCH && (se || mate_type == FQ_TYPE_NO_MATCH)) {
     // both hits of the pair hung over a contig end: the record of a read without a match (bwase.c:563-579)
     o.ch('\t'); o.num(p.extra_flag | 4 | (se ? 0 : 8)); o.str("\t*\t0\t0\t*\t*\t0\t0\t");
-    for (int j = 0; j < p.len; ++j) {
-      int cc = fq_nt4(row[j]);
-      if (p.strand) { cc = j < p.clip_len ? fq_nt4(row[p.clip_len - 1 - j]) : 3; cc = cc < 4 ? 3 - cc : cc; }
-      o.ch("ACGTN"[cc > 4 ? 4 : cc]);
-    }
-    o.ch('\t');
-    for (int j = 0; j < p.full_len; ++j) o.ch((char)(qual[(p.strand && j < p.len) ? p.len - 1 - j : j] - qsub));
+    const FqSamBody B = {1, p.strand, p.len, p.full_len, p.clip_len, qsub, row, qual};
+    fq_sam_body(B, o);
     if (p.clip_len < p.full_len) { o.str("\tXC:i:"); o.num(p.clip_len); }
     o.ch('\n');
     return;
@@ -178,13 +206,10 @@ FQ_HD void fq_sam_line(const FqSamArgs &A, int idx, FqTxt &o) {
     if (p.type == FQ_TYPE_NO_MATCH) isize = 0;
     o.num((int)(mate.pos - A.cg.off[m_seqid] + 1)); o.ch('\t'); o.num(isize); o.ch('\t');
   } else { o.str("\t=\t"); o.num((int)(p.pos - A.cg.off[seqid] + 1)); o.str("\t0\t"); }
-  if (p.strand == 0) for (j = 0; j < p.full_len; ++j) { const int cc = fq_nt4(row[j]); o.ch("ACGTN"[cc > 4 ? 4 : cc]); }
-  else for (j = 0; j < p.full_len; ++j) { const int cc = fq_nt4(row[p.full_len - 1 - j]); o.ch("TGCAN"[cc > 4 ? 4 : cc]); }
-  o.ch('\t');
-  // Phred+64 input: 31 comes off every quality byte on input (src/BwtMapper.cpp:549-553) and goes back on the first len bytes only when they
-  // are printed (bwase.c:516-519)
-  if (p.strand) { for (j = 0; j < p.len; ++j) o.ch((char)qual[p.len - 1 - j]); for (; j < p.full_len; ++j) o.ch((char)(qual[j] - qsub)); }
-  else { for (j = 0; j < p.len; ++j) o.ch((char)qual[j]); for (; j < p.full_len; ++j) o.ch((char)(qual[j] - qsub)); }
+  {
+    const FqSamBody B = {0, p.strand, p.len, p.full_len, p.clip_len, qsub, row, qual};
+    fq_sam_body(B, o);
+  }
   if (p.clip_len < p.full_len) { o.str("\tXC:i:"); o.num(p.clip_len); }
   if (p.type != FQ_TYPE_NO_MATCH) {
     char XT = "NURM"[p.type];
@@ -212,15 +237,41 @@ FQ_HD void fq_sam_line(const FqSamArgs &A, int idx, FqTxt &o) {
   }
   o.ch('\n');
 }
+// (the strand the columns are printed in: a read without a match of its own that borrowed its mate's position prints in the mate's)
 FQ_HD void fq_sam_len_thread(const FqSamArgs &A, int idx) {
-  FqTxt o; o.dst = nullptr; o.at = 0;
+  FqTxt o; o.dst = nullptr; o.at = 0; o.body = false;
   fq_sam_line(A, idx, o);
   A.len[idx] = (uint32_t)o.at;
+  A.meta[idx] = (uint32_t)(o.body_at < 0 ? 0 : o.body_at);
 }
+// everything of a line but its SEQ / QUAL run
 FQ_HD void fq_sam_fill_thread(const FqSamArgs &A, int idx) {
   if (!A.len[idx]) return;
-  FqTxt o; o.dst = A.text + A.off[idx]; o.at = 0;
+  FqTxt o; o.dst = A.text + A.off[idx]; o.at = 0; o.body = false;
   fq_sam_line(A, idx, o);
+}
+#define FQ_SAM_PIECE 16
+// piece c of record idx's SEQ / tab / QUAL run: sixteen consecutive bytes of the text per thread.  What the run holds follows from the record as the line
+// routine sees it (its type and its mate's behind AddAlignment's un-mapping decide the form and the strand): recomputed here, by the same statements.
+FQ_HD void fq_sam_body_piece(const FqSamArgs &A, int idx, int c) {
+  if (!A.len[idx]) return;
+  const bool se = A.single_end != 0;
+  fq_result_t p = A.rec[idx];
+  const fq_result_t mate = se ? p : A.rec[idx ^ 1];
+  const int b0 = c * FQ_SAM_PIECE;
+  if (b0 >= 2 * p.full_len + 1) return;              // (no run is longer)
+  int seqid = 0, m_seqid0 = 0;
+  const int ptype = fq_emit_bridged_type(A.cg, p, A.cigar, &seqid);
+  const int mate_type = se ? ptype : fq_emit_bridged_type(A.cg, mate, A.cigar, &m_seqid0);
+  FqSamBody B;
+  B.nomatch = ptype == FQ_TYPE_NO_MATCH && (se || mate_type == FQ_TYPE_NO_MATCH);
+  B.strand = (!B.nomatch && ptype == FQ_TYPE_NO_MATCH) ? mate.strand : p.strand;
+  B.len = p.len; B.full_len = p.full_len; B.clip_len = p.clip_len; B.qsub = (A.mode & FQ_MODE_IL13) ? 31 : 0;
+  B.row = A.seq + (size_t)fq_emit_row(A.packed, A.n_pairs, A.pair_list, idx) * (size_t)A.stride;
+  B.qual = A.qual + (size_t)idx * (size_t)A.qual_stride;
+  const int n = fq_sam_body_len(B);
+  char *dst = A.text + A.off[idx] + (A.meta[idx] & 0xffffu) + b0;
+  for (int t = 0; t < FQ_SAM_PIECE && b0 + t < n; ++t) dst[t] = fq_sam_body_char(B, b0 + t);
 }
 
 // ---- BAM records: SetSamRecord (src/BwtMapper.cpp:977-1264), restated field by field as fq_bam.cpp does on the host -----------------------
@@ -416,7 +467,7 @@ FQ_HD void fq_bam_fill_thread(const FqBamArgs &A, int idx) {
   fq_bam_record(A, idx, o);
 }
 
-enum { FQ_EOP_SAM_LEN = 0, FQ_EOP_SAM_FILL, FQ_EOP_BAM_LEN, FQ_EOP_BAM_FILL, FQ_EOP_COUNT };
+enum { FQ_EOP_SAM_LEN = 0, FQ_EOP_SAM_FILL, FQ_EOP_BAM_LEN, FQ_EOP_BAM_FILL, FQ_EOP_SAM_BODY, FQ_EOP_COUNT };
 
 // =====================================================================================================================================
 // StatCollector on the device: AddAlignment (src/StatCollector.cpp:950-1101), AddSingleAlignment (:424-620), ProcessPairStatus (:623-921)

@@ -154,7 +154,13 @@ int launch_rec(int op, const FqRecArgs &a, int64_t n) {
   return 0;
 }
 int launch_sam(int op, const FqSamArgs &a, int64_t n) {
-  for (int64_t i = 0; i < n; ++i) { if (op == FQ_EOP_SAM_LEN) fq_sam_len_thread(a, (int)i); else if (op == FQ_EOP_SAM_FILL) fq_sam_fill_thread(a, (int)i); else return -1; }
+  const int pieces = (2 * a.stride + 1 + FQ_SAM_PIECE - 1) / FQ_SAM_PIECE;
+  for (int64_t i = 0; i < n; ++i) {
+    if (op == FQ_EOP_SAM_LEN) fq_sam_len_thread(a, (int)i);
+    else if (op == FQ_EOP_SAM_FILL) fq_sam_fill_thread(a, (int)i);
+    else if (op == FQ_EOP_SAM_BODY) { for (int c = 0; c < pieces; ++c) fq_sam_body_piece(a, (int)i, c); }
+    else return -1;
+  }
   return 0;
 }
 int copy_flush_now() { return 0; }
