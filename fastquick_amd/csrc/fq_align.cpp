@@ -2111,8 +2111,10 @@ int emit_fill(Call &K) {
   if (c->emit_flags & FQ_EMIT_SAM) {
     CKM(c->d_samtext.ensure_roomy(E.sam_total + 64));
     E.sam.text = c->d_samtext.p;
+    static const bool body_split = [] { const char *e = getenv("FASTQUICK_SAM_BODY"); return !(e && *e == '0'); }();
+    E.sam.split = body_split ? 1 : 0;
     CK(fqdev::launch_sam(FQ_EOP_SAM_FILL, E.sam, (int64_t)N));      // heads and tags: a thread per record
-    CK(fqdev::launch_sam(FQ_EOP_SAM_BODY, E.sam, (int64_t)N));      // SEQ / QUAL runs: a thread per sixteen bytes
+    if (body_split) CK(fqdev::launch_sam(FQ_EOP_SAM_BODY, E.sam, (int64_t)N));      // SEQ / QUAL runs: a thread per sixteen bytes
     c->sam_bytes = E.sam_total;
     c->sam_ready = true;
   }

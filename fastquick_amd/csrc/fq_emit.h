@@ -79,7 +79,8 @@ struct FqSamArgs {
   const char *names; int32_t name_stride;
   uint32_t *len;                 // [2 n_surv] length of the record's line (0: not printed)
   const uint64_t *off;           // ... exclusive prefix sums
-  uint32_t *meta;                // [2 n_surv] where the line's SEQ column begins [0:16), the no-match form [16], the strand the columns are printed in [17]
+  uint32_t *meta;                // [2 n_surv] where the line's SEQ column begins
+  int32_t split;                 // 1: k_sam_fill leaves the SEQ / QUAL runs to k_sam_body (0: it writes whole lines; A/B, FASTQUICK_SAM_BODY=0)
   char *text;
 };
 // The SEQ column, a tab and the QUAL column of a line: three quarters of its bytes.  One statement of every character, used by the line routine and by the
@@ -247,7 +248,7 @@ FQ_HD void fq_sam_len_thread(const FqSamArgs &A, int idx) {
 // everything of a line but its SEQ / QUAL run
 FQ_HD void fq_sam_fill_thread(const FqSamArgs &A, int idx) {
   if (!A.len[idx]) return;
-  FqTxt o; o.dst = A.text + A.off[idx]; o.at = 0; o.body = false;
+  FqTxt o; o.dst = A.text + A.off[idx]; o.at = 0; o.body = A.split == 0;
   fq_sam_line(A, idx, o);
 }
 #define FQ_SAM_PIECE 16
