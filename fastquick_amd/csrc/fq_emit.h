@@ -51,7 +51,8 @@ FQ_HD int fq_dev_pac2real(const FqDevContigs &C, int64_t pos, int len, int *seqi
 struct FqTxt {
   char *dst;
   int64_t at;
-  int32_t body_at = -1;          // where the line's SEQ column begins (fq_sam_line notes it)
+  int32_t body_at = -1;          // where the line's SEQ column begins (fq_sam_line notes it, and which form and strand the run has)
+  int32_t body_form = 0;         // bit 0: the no-match form; bit 1: the strand the columns are printed in
   bool body = true;              // false: the SEQ / tab / QUAL run of a line is stepped over, not produced (k_sam_body writes it, sixteen bytes per thread)
   FQ_HD void ch(char c) { if (dst) dst[at] = c; ++at; }
   FQ_HD void str(const char *s) { while (*s) ch(*s++); }
@@ -79,7 +80,7 @@ struct FqSamArgs {
   const char *names; int32_t name_stride;
   uint32_t *len;                 // [2 n_surv] length of the record's line (0: not printed)
   const uint64_t *off;           // ... exclusive prefix sums
-  uint32_t *meta;                // [2 n_surv] where the line's SEQ column begins
+  uint32_t *meta;                // [2 n_surv] where the line's SEQ column begins [0:16), the no-match form [16], the strand the columns are printed in [17]
   int32_t split;                 // 1: k_sam_fill leaves the SEQ / QUAL runs to k_sam_body (0: it writes whole lines; A/B, FASTQUICK_SAM_BODY=0)
   char *text;
 };
@@ -109,6 +110,7 @@ FQ_HD char fq_sam_body_char(const FqSamBody &B, int b) {
 }
 FQ_HD void fq_sam_body(const FqSamBody &B, FqTxt &o) {
   o.body_at = (int32_t)o.at;
+  o.body_form = (B.nomatch ? 1 : 0) | (B.strand ? 2 : 0);
   const int n = fq_sam_body_len(B);
   if (!o.body) { o.at += n; return; }
   for (int b = 0; b < n; ++b) o.ch(fq_sam_body_char(B, b));
@@ -243,7 +245,7 @@ FQ_HD void fq_sam_len_thread(const FqSamArgs &A, int idx) {
   FqTxt o; o.dst = nullptr; o.at = 0; o.body = false;
   fq_sam_line(A, idx, o);
   A.len[idx] = (uint32_t)o.at;
-  A.meta[idx] = (uint32_t)(o.body_at < 0 ? 0 : o.body_at);
+  A.meta[idx] = (uint32_t)(o.body_at < 0 ? 0 : o.body_at) | (uint32_t)o.body_form << 16;
 }
 // everything of a line but its SEQ / QUAL run
 FQ_HD void fq_sam_fill_thread(const FqSamArgs &A, int idx) {
@@ -252,26 +254,21 @@ FQ_HD void fq_sam_fill_thread(const FqSamArgs &A, int idx) {
   fq_sam_line(A, idx, o);
 }
 #define FQ_SAM_PIECE 16
-// piece c of record idx's SEQ / tab / QUAL run: sixteen consecutive bytes of the text per thread.  What the run holds follows from the record as the line
-// routine sees it (its type and its mate's behind AddAlignment's un-mapping decide the form and the strand): recomputed here, by the same statements.
+// piece c of record idx's SEQ / tab / QUAL run: sixteen consecutive bytes of the text per thread.  Which form the run has and in which strand it is printed
+// was decided by the line routine when it measured the line (meta).
 FQ_HD void fq_sam_body_piece(const FqSamArgs &A, int idx, int c) {
   if (!A.len[idx]) return;
-  const bool se = A.single_end != 0;
-  fq_result_t p = A.rec[idx];
-  const fq_result_t mate = se ? p : A.rec[idx ^ 1];
+  const fq_result_t p = A.rec[idx];
   const int b0 = c * FQ_SAM_PIECE;
   if (b0 >= 2 * p.full_len + 1) return;              // (no run is longer)
-  int seqid = 0, m_seqid0 = 0;
-  const int ptype = fq_emit_bridged_type(A.cg, p, A.cigar, &seqid);
-  const int mate_type = se ? ptype : fq_emit_bridged_type(A.cg, mate, A.cigar, &m_seqid0);
+  const uint32_t meta = A.meta[idx];
   FqSamBody B;
-  B.nomatch = ptype == FQ_TYPE_NO_MATCH && (se || mate_type == FQ_TYPE_NO_MATCH);
-  B.strand = (!B.nomatch && ptype == FQ_TYPE_NO_MATCH) ? mate.strand : p.strand;
+  B.nomatch = (int)((meta >> 16) & 1u); B.strand = (int)((meta >> 17) & 1u);
   B.len = p.len; B.full_len = p.full_len; B.clip_len = p.clip_len; B.qsub = (A.mode & FQ_MODE_IL13) ? 31 : 0;
   B.row = A.seq + (size_t)fq_emit_row(A.packed, A.n_pairs, A.pair_list, idx) * (size_t)A.stride;
   B.qual = A.qual + (size_t)idx * (size_t)A.qual_stride;
   const int n = fq_sam_body_len(B);
-  char *dst = A.text + A.off[idx] + (A.meta[idx] & 0xffffu) + b0;
+  char *dst = A.text + A.off[idx] + (meta & 0xffffu) + b0;
   for (int t = 0; t < FQ_SAM_PIECE && b0 + t < n; ++t) dst[t] = fq_sam_body_char(B, b0 + t);
 }
 
@@ -475,11 +472,13 @@ enum { FQ_EOP_SAM_LEN = 0, FQ_EOP_SAM_FILL, FQ_EOP_BAM_LEN, FQ_EOP_BAM_FILL, FQ_
 // =====================================================================================================================================
 #if defined(__HIP_DEVICE_COMPILE__)
 #define FQ_ATOMIC_INC32(p) atomicAdd((unsigned int *)(p), 1u)
+#define FQ_ATOMIC_DEC32(p) atomicAdd((unsigned int *)(p), 0xffffffffu)
 #define FQ_ATOMIC_ADD64_PLAIN(p, v) atomicAdd((unsigned long long *)(p), (unsigned long long)(v))
 #define FQ_ATOMIC_MIN64_PLAIN(p, v) atomicMin((unsigned long long *)(p), (unsigned long long)(v))
 #define FQ_ATOMIC_CAS64(p, cmp, v) atomicCAS((unsigned long long *)(p), (unsigned long long)(cmp), (unsigned long long)(v))
 #else
 #define FQ_ATOMIC_INC32(p) (++*(p))
+#define FQ_ATOMIC_DEC32(p) (--*(p))
 #define FQ_ATOMIC_ADD64_PLAIN(p, v) (*(p) += (v))
 #define FQ_ATOMIC_MIN64_PLAIN(p, v) (*(p) = *(p) < (uint64_t)(v) ? *(p) : (uint64_t)(v))
 static inline uint64_t fq_host_cas64(uint64_t *p, uint64_t cmp, uint64_t v) { const uint64_t old = *p; if (old == cmp) *p = v; return old; }
@@ -510,7 +509,7 @@ struct FqQcArgs {
   int32_t cal_dup, shard;
   uint64_t ord_base;             // pairs the consumer has seen before this call (orders the first counts of the sex-chromosome contigs)
   // the consumer's tables
-  uint32_t *depth, *q20, *q30;
+  uint32_t *depth, *q20, *q30;   // DIFFERENCE tables over the flank positions (+1 where a run of counted positions begins, -1 behind its end; modulo 2^32)
   uint64_t *hist;                // [4][256] EmpRep, misEmpRep, EmpCycle, misEmpCycle
   uint64_t *insert_dist;         // [FQ_QC_INSERT_LIMIT]
   uint64_t *est_hist;            // [4][FQ_QC_INSERT_LIMIT] what InsertSizeEstimator reads back from the .InsertSizeTable lines (src/InsertSizeEstimator.cpp:43-143), counted as
@@ -851,19 +850,39 @@ FQ_HD void fq_qc_base_record(const FqQcArgs &A, int idx, int lane, int nl, uint3
   while (fq_blocks_next(it, &abs0, &cl, &cyc0, &on_read, &on_ref)) {
     int lo = r0, hi = r1;                      // first region that ends at or behind abs0
     while (lo < hi) { const int mid = (lo + hi) >> 1; if (A.g.reg_end[mid] < abs0) lo = mid + 1; else hi = mid; }
-    for (int t = lane; t < cl; t += nl) {
+    // Depth, Q20 depth and Q30 depth are kept as DIFFERENCE tables (the consumer's pull() sums them up): a run of consecutive positions that all count
+    // costs two atomic adds -- +1 where it begins, -1 behind its end -- instead of one per position.  A read's aligned block inside a flank region is
+    // one run for the depth; for the quality depths the runs are the stretches of bases at or above the threshold.  A position tells its own run
+    // boundaries from its two neighbours (looked at again here: no lane needs another's registers, and the bytes are in the L1).
+    auto probe = [&](int t, uint32_t *k, int *q) FQ_LAMBDA_INLINE -> bool {      // is base t of the block inside a flank region?  its table index and quality
+      if (t < 0 || t >= cl) return false;
       const int i = abs0 + t;
       int rg = lo;
       while (rg < r1 && A.g.reg_end[rg] < i) ++rg;
-      if (rg >= r1 || A.g.reg_start[rg] > i) continue;          // RegionList::IsOverlapped
-      const uint32_t k = A.g.reg_base[rg] + (uint32_t)(i - A.g.reg_start[rg]);
+      if (rg >= r1 || A.g.reg_start[rg] > i) return false;          // RegionList::IsOverlapped
+      *k = A.g.reg_base[rg] + (uint32_t)(i - A.g.reg_start[rg]);
+      const int rr = on_read + t;
+      *q = p.strand == 0 ? (int8_t)(hq[rr] - qsub - 33) : (int8_t)(hq[p.full_len - 1 - rr] - qsub - 33);
+      return true;
+    };
+    for (int t = lane; t < cl; t += nl) {
+      uint32_t k = 0, kn = 0;
+      int q = 0, qp = 0, qn = 0;
+      if (!probe(t, &k, &q)) continue;
+      const bool prev = probe(t - 1, &kn, &qp), next = probe(t + 1, &kn, &qn);
+      if (!prev) FQ_ATOMIC_INC32(&A.depth[k]);
+      if (!next) FQ_ATOMIC_DEC32(&A.depth[k + 1]);
+      if (q >= 20) {
+        if (!(prev && qp >= 20)) FQ_ATOMIC_INC32(&A.q20[k]);
+        if (!(next && qn >= 20)) FQ_ATOMIC_DEC32(&A.q20[k + 1]);
+        if (q >= 30) {
+          if (!(prev && qp >= 30)) FQ_ATOMIC_INC32(&A.q30[k]);
+          if (!(next && qn >= 30)) FQ_ATOMIC_DEC32(&A.q30[k + 1]);
+        }
+      }
       const int rr = on_read + t, cyc = cyc0 + t * it.sign;
-      int code, q;
-      if (p.strand == 0) { code = fq_nt4(row[rr]); q = (int8_t)(hq[rr] - qsub - 33); }
-      else { code = fq_comp(fq_nt4(row[p.full_len - 1 - rr])); q = (int8_t)(hq[p.full_len - 1 - rr] - qsub - 33); }
+      const int code = p.strand == 0 ? fq_nt4(row[rr]) : fq_comp(fq_nt4(row[p.full_len - 1 - rr]));
       const int rc = fq_pac_base(A.ix.pac, (int64_t)(uint32_t)(p.pos + (uint32_t)(on_ref + t)));   // the reference base under it (what the MD tag spells out)
-      FQ_ATOMIC_INC32(&A.depth[k]);
-      if (q >= 20) { FQ_ATOMIC_INC32(&A.q20[k]); if (q >= 30) FQ_ATOMIC_INC32(&A.q30[k]); }
       FQ_HIST_INC(&hist[0 * 256 + (uint8_t)q]);
       FQ_HIST_INC(&hist[2 * 256 + (uint8_t)cyc]);
       if (code < 4 && rc != code && !A.g.dbsnp[k]) {

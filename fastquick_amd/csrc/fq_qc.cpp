@@ -686,7 +686,10 @@ int fq_qc::pull() {
     err = std::string("QC consumer: reading its tables back failed: ") + fqdev::last_error();
     return FQ_ENODEV;
   }
-  for (size_t k = 0; k < T; ++k) { depth[k] += d[k]; q20[k] += a[k]; q30[k] += b[k]; }
+  {   // the device keeps difference tables (fq_qc_base_record): running sums give the counts
+    uint32_t sd = 0, sa = 0, sb = 0;
+    for (size_t k = 0; k < T; ++k) { sd += d[k]; sa += a[k]; sb += b[k]; depth[k] += sd; q20[k] += sa; q30[k] += sb; }
+  }
   for (int v = 0; v < 256; ++v) { EmpRep[v] += hist[v]; misEmpRep[v] += hist[256 + v]; EmpCycle[v] += hist[512 + v]; misEmpCycle[v] += hist[768 + v]; }
   for (int v = 0; v < kInsertLimit; ++v) InsertDist[v] += ins[v];
   for (size_t v = 0; v < est.size(); ++v) est_hist[v] += est[v];
