@@ -314,7 +314,7 @@ struct fq_ctx {
   bool emit_pending = false;
   // ... StatCollector's part of a call (fq_ctx_attach_qc): per-call lists on the device, what comes back for the consumer's host side
   fq_qc *qc = nullptr;
-  DevBuf<uint8_t> d_qadded;
+  DevBuf<int32_t> d_qadded;
   DevBuf<uint32_t> d_istlen, d_ptcnt;
   DevBuf<uint64_t> d_istoff, d_ptoff, d_qcnt, d_dupkey;
   DevBuf<char> d_isttext; DevBuf<FqPileEntry> d_pile;

@@ -491,6 +491,7 @@ static inline uint64_t fq_host_cas64(uint64_t *p, uint64_t cmp, uint64_t v) { co
 struct FqQcGeom {
   const int32_t *ctg_chrom;      // [n contigs] chromosome of the lists below; -1: none of them; -2: the contig's name has no ':' (AddSingleAlignment does not take it)
   const int32_t *ctg_g0;         // refCoord - flank: the genome coordinate of a read at offset x of the contig is g0 + x
+  const int32_t *ctg_reg_lo;     // the first flank region of the contig's chromosome that ends at or behind the contig's first base (where a read's walk over the regions starts)
   const uint8_t *ctg_sex;        // the name holds an 'X' or a 'Y'
   const int32_t *chr_reg0;       // [n_chrom + 1] first flank region of a chromosome; regions sorted by start, disjoint (RegionList::Collapse)
   const int32_t *reg_start, *reg_end;
@@ -520,7 +521,7 @@ struct FqQcArgs {
   uint64_t *dup_tab; uint64_t dup_mask;   // open-addressing set of the proper pairs' keys (start << 32 | end); a shard consumer lists its keys instead:
   uint64_t *dup_key;             // [n_surv] key or ~0 (shard)
   // per call
-  uint8_t *added;                // [2 n_surv] the record went through AddSingleAlignment
+  int32_t *added;                // [2 n_surv] the contig of a record that went through AddSingleAlignment, or -1
   uint32_t *ist_len; const uint64_t *ist_off; char *ist_text;      // .InsertSizeTable lines per pair
   uint32_t *pt_cnt; const uint64_t *pt_off; FqPileEntry *pt;       // pileup entries per record
 };
@@ -785,17 +786,18 @@ FQ_HD void fq_qc_pair_core(const FqQcArgs &A, int sp, bool effects, FqTxt &o) {
     }
   }
   if (!effects) return;
-  A.added[2 * sp] = addP ? 1 : 0; A.added[2 * sp + 1] = addQ ? 1 : 0;
   A.ist_len[sp] = (uint32_t)o.at;
   for (int e = 0; e < 2; ++e) {
     uint32_t n = 0;
+    int seqid = -1;
     if (e ? addQ : addP) {
       const fq_result_t &r = e ? Q : P;
-      int seqid, rs;
+      int rs;
       fq_dev_pac2real(A.s.cg, r.pos, (int)(fq_emit_ref_end(r, A.s.cigar) - r.pos), &seqid);
       rs = A.g.ctg_g0[seqid] + (int)((int64_t)r.pos - A.s.cg.off[seqid]);
       n = fq_qc_pile(A, 2 * sp + e, r, seqid, rs, nullptr);
     }
+    A.added[2 * sp + e] = seqid;           // (the per-base kernel starts from the contig: no search of its own)
     A.pt_cnt[2 * sp + e] = n;
   }
   if (A.shard && A.dup_key && A.ist_len[sp] == 0) { /* (no line: no key either) */ }
@@ -833,14 +835,14 @@ FQ_HD void fq_qc_pile_fill_thread(const FqQcArgs &A, int idx) {
 #define FQ_HIST_INC(p) (++*(p))
 #endif
 FQ_HD void fq_qc_base_record(const FqQcArgs &A, int idx, int lane, int nl, uint32_t *hist) {
-  if (!A.added[idx]) return;
-  const fq_result_t p = A.s.rec[idx];
-  int seqid;
-  fq_dev_pac2real(A.s.cg, p.pos, (int)(fq_emit_ref_end(p, A.s.cigar) - p.pos), &seqid);
+  const int seqid = A.added[idx];
+  if (seqid < 0) return;
   const int chrom = A.g.ctg_chrom[seqid];
   if (chrom < 0) return;
-  const int r0 = A.g.chr_reg0[chrom], r1 = A.g.chr_reg0[chrom + 1];
-  if (r0 == r1) return;
+  const int r1 = A.g.chr_reg0[chrom + 1];
+  int lo = A.g.ctg_reg_lo[seqid];
+  if (lo >= r1) return;
+  const fq_result_t p = A.s.rec[idx];
   const int rs = A.g.ctg_g0[seqid] + (int)((int64_t)p.pos - A.s.cg.off[seqid]);
   const uint8_t *row = A.s.seq + (size_t)fq_emit_row(A.s.packed, A.s.n_pairs, A.s.pair_list, idx) * (size_t)A.s.stride;
   const uint8_t *hq = A.s.qual + (size_t)idx * (size_t)A.s.qual_stride;
@@ -848,8 +850,12 @@ FQ_HD void fq_qc_base_record(const FqQcArgs &A, int idx, int lane, int nl, uint3
   FqBlockIter it = fq_blocks_begin(p, A.s.cigar, rs);
   int abs0, cl, cyc0, on_read, on_ref;
   while (fq_blocks_next(it, &abs0, &cl, &cyc0, &on_read, &on_ref)) {
-    int lo = r0, hi = r1;                      // first region that ends at or behind abs0
-    while (lo < hi) { const int mid = (lo + hi) >> 1; if (A.g.reg_end[mid] < abs0) lo = mid + 1; else hi = mid; }
+    while (lo < r1 && A.g.reg_end[lo] < abs0) ++lo;            // first region that ends at or behind the block's first base (blocks come in increasing position)
+    // the regions the block touches, in registers (a block of a few hundred bases meets one region, seldom two): what is left is arithmetic per base
+    int rs_[3], re_[3], nr = 0;
+    uint32_t rb_[3];
+    for (int rg = lo; rg < r1 && nr < 3 && A.g.reg_start[rg] < abs0 + cl; ++rg, ++nr) { rs_[nr] = A.g.reg_start[rg]; re_[nr] = A.g.reg_end[rg]; rb_[nr] = A.g.reg_base[rg]; }
+    const bool more = nr == 3 && lo + 3 < r1 && A.g.reg_start[lo + 3] < abs0 + cl;      // (more than three: the general walk below)
     // Depth, Q20 depth and Q30 depth are kept as DIFFERENCE tables (the consumer's pull() sums them up): a run of consecutive positions that all count
     // costs two atomic adds -- +1 where it begins, -1 behind its end -- instead of one per position.  A read's aligned block inside a flank region is
     // one run for the depth; for the quality depths the runs are the stretches of bases at or above the threshold.  A position tells its own run
@@ -857,10 +863,14 @@ FQ_HD void fq_qc_base_record(const FqQcArgs &A, int idx, int lane, int nl, uint3
     auto probe = [&](int t, uint32_t *k, int *q) FQ_LAMBDA_INLINE -> bool {      // is base t of the block inside a flank region?  its table index and quality
       if (t < 0 || t >= cl) return false;
       const int i = abs0 + t;
-      int rg = lo;
-      while (rg < r1 && A.g.reg_end[rg] < i) ++rg;
-      if (rg >= r1 || A.g.reg_start[rg] > i) return false;          // RegionList::IsOverlapped
-      *k = A.g.reg_base[rg] + (uint32_t)(i - A.g.reg_start[rg]);
+      bool in = false;
+      for (int j = 0; j < nr; ++j) if (i >= rs_[j] && i <= re_[j]) { *k = rb_[j] + (uint32_t)(i - rs_[j]); in = true; }      // RegionList::IsOverlapped
+      if (!in && more) {
+        int rg = lo + 3;
+        while (rg < r1 && A.g.reg_end[rg] < i) ++rg;
+        if (rg < r1 && A.g.reg_start[rg] <= i) { *k = A.g.reg_base[rg] + (uint32_t)(i - A.g.reg_start[rg]); in = true; }
+      }
+      if (!in) return false;
       const int rr = on_read + t;
       *q = p.strand == 0 ? (int8_t)(hq[rr] - qsub - 33) : (int8_t)(hq[p.full_len - 1 - rr] - qsub - 33);
       return true;

@@ -575,7 +575,7 @@ int fq_qc::device_setup() {
   std::map<std::string, int> chrom_id;
   for (const auto &kv : flank_idx) { chrom_id[kv.first] = (int)chroms.size(); chroms.push_back(kv.first); }
   for (const auto &kv : vcf_table) if (!chrom_id.count(kv.first)) { chrom_id[kv.first] = (int)chroms.size(); chroms.push_back(kv.first); }
-  std::vector<int32_t> ctg_chrom(nc), ctg_g0(nc), chr_reg0(chroms.size() + 1, 0), reg_start, reg_end, chr_mk0(chroms.size() + 1, 0), mk_pos;
+  std::vector<int32_t> ctg_chrom(nc), ctg_g0(nc), ctg_reg_lo(nc, 0), chr_reg0(chroms.size() + 1, 0), reg_start, reg_end, chr_mk0(chroms.size() + 1, 0), mk_pos;
   std::vector<uint8_t> ctg_sex(nc);
   std::vector<uint32_t> reg_base, mk_idx;
   for (size_t i = 0; i < nc; ++i) {
@@ -599,6 +599,12 @@ int fq_qc::device_setup() {
     if (vi != vcf_table.end()) for (const auto &m : vi->second) { mk_pos.push_back(m.first); mk_idx.push_back(m.second); }
   }
   chr_reg0[chroms.size()] = (int32_t)reg_start.size(); chr_mk0[chroms.size()] = (int32_t)mk_pos.size();
+  for (size_t i = 0; i < nc; ++i) {          // where a read on contig i starts its walk over the flank regions: the first region of its chromosome that ends at or behind the contig's first base
+    if (ctg_chrom[i] < 0) continue;
+    const int r0 = chr_reg0[(size_t)ctg_chrom[i]], r1 = chr_reg0[(size_t)ctg_chrom[i] + 1];
+    const int first = ctg_g0[i];               // (genome coordinate of offset 0 of the contig; a read's bases lie at or behind it)
+    ctg_reg_lo[i] = (int32_t)(std::lower_bound(reg_end.begin() + r0, reg_end.begin() + r1, first) - reg_end.begin());
+  }
   table_size = depth.size();
   std::vector<uint8_t> db(table_size + 1, 0);
   for (const auto &kv : flank_idx) {                 // the known variant sites that lie in a flank region (the only positions the statistics look at)
@@ -620,6 +626,7 @@ int fq_qc::device_setup() {
     return d;
   };
   geom.ctg_chrom = (const int32_t *)up(ctg_chrom.data(), nc * 4); geom.ctg_g0 = (const int32_t *)up(ctg_g0.data(), nc * 4); geom.ctg_sex = (const uint8_t *)up(ctg_sex.data(), nc);
+  geom.ctg_reg_lo = (const int32_t *)up(ctg_reg_lo.data(), nc * 4);
   geom.chr_reg0 = (const int32_t *)up(chr_reg0.data(), chr_reg0.size() * 4); geom.reg_start = (const int32_t *)up(reg_start.data(), reg_start.size() * 4);
   geom.reg_end = (const int32_t *)up(reg_end.data(), reg_end.size() * 4); geom.reg_base = (const uint32_t *)up(reg_base.data(), reg_base.size() * 4);
   geom.chr_mk0 = (const int32_t *)up(chr_mk0.data(), chr_mk0.size() * 4); geom.mk_pos = (const int32_t *)up(mk_pos.data(), mk_pos.size() * 4);
