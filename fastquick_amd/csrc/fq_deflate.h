@@ -113,18 +113,48 @@ FQ_HD uint32_t fqd_member(const FqDeflateArgs &A, uint32_t b, FqdLds &S) {
     FQF_LANES
       if (FQF_LV(hsh) != 0xffffffffu) S.htab[FQF_LV(hsh)] = (uint16_t)(base + (uint32_t)lane + 1);      // (several lanes, one slot: any of them is a valid candidate)
     FQF_LANES_END
-    // ---- the greedy parse of the step, a token per iteration; every token learns its bit offset
+    // ---- the greedy parse of the step.  Only matches make it serial: between two chosen matches every position is a literal, so the loop runs once
+    //      per chosen MATCH (find the next candidate at or behind the parse position in the ballot of the lanes that found one; everything in front
+    //      of it is literals) -- a handful of iterations per step on BAM records, where a token per iteration was sixty.  The tokens' bit offsets are
+    //      a prefix sum over the chosen lanes afterwards.
     const uint32_t step_n = n - base < 64 ? n - base : 64;
-    uint32_t pos = carry, bit = bit_in;
+    uint64_t cand = 0;                         // lanes whose position starts a match
+#if defined(__HIP_DEVICE_COMPILE__)
+    cand = __ballot(mlen != 0);
+#else
+    for (int l = 0; l < 64; ++l) if (mlen[l]) cand |= 1ull << l;
+#endif
+    uint64_t chosen = 0;                       // positions that emit a token
+    uint32_t pos = carry;
     while (pos < step_n) {
-      const uint32_t L = FQF_RL(mlen, pos), nb = FQF_RL(tok_nb, pos);
-      FQF_LANES
-        if ((uint32_t)lane == pos) { FQF_LV(sel) = 1; FQF_LV(off) = bit; }
-      FQF_LANES_END
-      bit += nb;
-      pos += L ? L : 1;
+      const uint64_t ahead = cand >> pos;
+      if (!ahead) { chosen |= (~0ull >> (64 - step_n)) & (~0ull << pos); pos = step_n; break; }      // literals to the end of the step
+#if defined(__HIP_DEVICE_COMPILE__)
+      const uint32_t c = pos + (uint32_t)__builtin_ctzll(ahead);
+#else
+      const uint32_t c = pos + (uint32_t)__builtin_ctzll(ahead);
+#endif
+      if (c >= step_n) { chosen |= (~0ull >> (64 - step_n)) & (~0ull << pos); pos = step_n; break; }
+      if (c > pos) chosen |= (~0ull >> (64 - c)) & (~0ull << pos);      // literals in front of the match
+      chosen |= 1ull << c;
+      pos = c + FQF_RL(mlen, c);
     }
     carry = pos - step_n;
+    uint32_t bit = bit_in;
+#if defined(__HIP_DEVICE_COMPILE__)
+    {
+      const int lane = (int)(threadIdx.x & 63);
+      sel = (uint32_t)((chosen >> lane) & 1ull);
+      const uint32_t nb = sel ? tok_nb : 0u;
+      uint32_t inc = nb;                       // inclusive prefix sum over the wavefront
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) { const uint32_t up = (uint32_t)__shfl_up((int)inc, d, 64); if (lane >= d) inc += up; }
+      off = bit_in + inc - nb;
+      bit = bit_in + (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+    }
+#else
+    for (int l = 0; l < 64; ++l) { sel[l] = (uint32_t)((chosen >> l) & 1ull); off[l] = bit; if (sel[l]) bit += tok_nb[l]; }
+#endif
     // ---- the chosen tokens' bits into the step's buffer
     FQF_LANES
       if (FQF_LV(sel)) {
