@@ -21,14 +21,16 @@
 
 #define FQD_BLOCK 0xd000u          // input bytes per member: 53,248 x 9 / 8 + 27 < 65,536
 #define FQD_SLOT 65536u            // staging bytes per member
-#define FQD_HBITS 12
+#define FQD_HBITS 11              // 2,048 hash slots: 4 KB of LDS per wavefront (with 4,096 twelve wavefronts fit a CU, and the kernel is bound by the latency of a step's dependent loads)
 #define FQD_MIN_MATCH 4
 #define FQD_MAX_MATCH 258
 
 struct FqdLds {
-  uint16_t htab[1 << FQD_HBITS];   // position + 1 of the last occurrence of a hash (0: none)
+  union {
+    uint16_t htab[1 << FQD_HBITS]; // position + 1 of the last occurrence of a hash (0: none)
+    uint32_t crc_tab[1024];        // ... and, when the block is compressed, the CRC's slice tables in the same bytes
+  };
   uint32_t obuf[96];               // the step's bits
-  uint32_t crc_tab[1024];
 };
 struct FqDeflateArgs {
   const uint8_t *in; uint64_t n;   // the record stream
