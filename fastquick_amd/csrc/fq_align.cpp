@@ -306,7 +306,7 @@ struct fq_ctx {
   PinBuf<char> p_emit[2][2];
   // ... the BAM records of a call (fq_ctx_attach_bam), as bytes in HBM until the writer fetches them
   fq_bam *bam = nullptr;
-  DevBuf<uint32_t> d_bamlen, d_zsize; DevBuf<uint64_t> d_bamoff, d_zoff; DevBuf<uint8_t> d_bamrec, d_zstage, d_bamz;
+  DevBuf<uint32_t> d_bamlen, d_bammeta, d_zsize; DevBuf<uint64_t> d_bamoff, d_zoff; DevBuf<uint8_t> d_bamrec, d_zstage, d_bamz;
   FqBamCallOut bam_out;
   PinBuf<uint64_t> p_ztotal;
   uint32_t emit_nb = 0;
@@ -2069,8 +2069,8 @@ int emit_measure(Call &K) {
   if (c->bam) {
     CKS(emit_args(K, E.bam.s));
     { const int rc = fq_bam_device_prepare(c->bam, &E.bam); if (rc) { c->err = "the BAM writer could not stage its tables on the device"; return rc; } }
-    CKM(c->d_bamlen.ensure(N + 1) && c->d_bamoff.ensure(N + 2));
-    E.bam.len = c->d_bamlen.p; E.bam.off = c->d_bamoff.p;
+    CKM(c->d_bamlen.ensure(N + 1) && c->d_bamoff.ensure(N + 2) && c->d_bammeta.ensure(N + 1));
+    E.bam.len = c->d_bamlen.p; E.bam.off = c->d_bamoff.p; E.bam.meta = c->d_bammeta.p; E.bam.split = 1;
     CK(fqdev::launch_bam(FQ_EOP_BAM_LEN, E.bam, (int64_t)N));
     CK(fqdev::launch_scan(c->d_bamlen.p, c->d_bamoff.p, (uint32_t)N));
     CKS(fetch_u64(c, &E.bam_total, c->d_bamoff.p + N));
@@ -2122,7 +2122,8 @@ int emit_fill(Call &K) {
     const uint64_t total = E.bam_total;
     CKM(c->d_bamrec.ensure_roomy(total + 64));
     E.bam.out = c->d_bamrec.p;
-    CK(fqdev::launch_bam(FQ_EOP_BAM_FILL, E.bam, (int64_t)N));
+    CK(fqdev::launch_bam(FQ_EOP_BAM_FILL, E.bam, (int64_t)N));      // fixed fields, name, CIGAR, tags: a thread per record
+    CK(fqdev::launch_bam(FQ_EOP_BAM_BODY, E.bam, (int64_t)N));      // packed bases and qualities: a thread per sixteen bytes
     c->bam_out.bytes = total;
     c->emit_nb = 0;
     if (total && fq_bam_wants_members(c->bam)) {

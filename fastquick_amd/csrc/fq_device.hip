@@ -1597,6 +1597,11 @@ __global__ void __launch_bounds__(256) k_bam_fill(FqBamArgs a, int n) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) fq_bam_fill_thread(a, i);
 }
+__global__ void __launch_bounds__(256) k_bam_body(FqBamArgs a, int n, int pieces) {
+  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int idx = (int)(t / pieces), c = (int)(t % pieces);
+  if (idx < n) fq_bam_body_piece(a, idx, c);
+}
 int launch_bam(int op, const FqBamArgs &a, int64_t n) {
   FQ_PRE();
   if (n <= 0) return 0;
@@ -1605,6 +1610,10 @@ int launch_bam(int op, const FqBamArgs &a, int64_t n) {
   kernel_events(FQ_K_EMIT, &e0, &e1);
   if (op == FQ_EOP_BAM_LEN) hipExtLaunchKernelGGL(k_bam_len, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
   else if (op == FQ_EOP_BAM_FILL) hipExtLaunchKernelGGL(k_bam_fill, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
+  else if (op == FQ_EOP_BAM_BODY) {      // a thread per sixteen bytes of a record's packed bases and qualities (1.5 x row stride + 1 bytes at most)
+    const int pieces = ((a.s.stride + 1) / 2 + a.s.stride + FQ_SAM_PIECE - 1) / FQ_SAM_PIECE;
+    hipExtLaunchKernelGGL(k_bam_body, dim3(nblk((uint64_t)n * (uint64_t)pieces, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n, pieces);
+  }
   else { g_err = "BAM records: unknown operation"; return -1; }
   FQ_HIP(hipGetLastError());
   return 0;

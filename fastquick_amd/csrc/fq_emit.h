@@ -279,10 +279,14 @@ struct FqBamArgs {
   const int32_t *ctg_g0;         // refCoord - flank: the genome coordinate of offset x of the contig is g0 + x + 1 (1-based)
   const char *rg; int32_t rg_len;   // the read group's ID ("": none)
   uint32_t *len; const uint64_t *off; uint8_t *out;
+  uint32_t *meta;                // [2 n_surv] where the record's packed bases begin [0:16), the placed arm [16], the strand they are written in [17]
+  int32_t split;                 // 1: k_bam_fill leaves bases and qualities to k_bam_body
 };
 struct FqBin {                   // bytes that are either measured (dst == nullptr) or written
   uint8_t *dst;
   int64_t at;
+  int32_t body_at = -1, body_form = 0;   // where the record's packed bases begin; bit 0: a mate is placed (SetSamRecord's first arm), bit 1: the strand they are written in
+  bool body = true;              // false: the packed bases and the qualities are stepped over (k_bam_body writes them, sixteen bytes per thread)
   FQ_HD void u8(uint32_t v) { if (dst) dst[at] = (uint8_t)v; ++at; }
   FQ_HD void u16(uint32_t v) { u8(v & 0xff); u8((v >> 8) & 0xff); }
   FQ_HD void u32(uint32_t v) { u8(v & 0xff); u8((v >> 8) & 0xff); u8((v >> 16) & 0xff); u8(v >> 24); }
@@ -303,6 +307,29 @@ FQ_HD int fq_bam_reg2bin(int64_t beg, int64_t end) {   // SAM specification 5.3
   if (beg >> 23 == end >> 23) return (int)(((1 << 6) - 1) / 7 + (beg >> 23));
   if (beg >> 26 == end >> 26) return (int)(((1 << 3) - 1) / 7 + (beg >> 26));
   return 0;
+}
+struct FqBamBody { int any, strand, len, full_len, clip_len, qsub, l_seq; const uint8_t *row, *qual; };
+FQ_HD int fq_bam_body_len(const FqBamBody &B) { return (B.l_seq + 1) / 2 + B.l_seq; }
+FQ_HD int fq_bam_base_code(const FqBamBody &B, int jj) {      // nt4 code of base jj of the SEQ column
+  if (B.any) return B.strand == 0 ? fq_nt4(B.row[jj]) : fq_comp(fq_nt4(B.row[B.full_len - 1 - jj]));
+  int cc = fq_nt4(B.row[jj]);
+  if (B.strand) { cc = jj < B.clip_len ? fq_nt4(B.row[B.clip_len - 1 - jj]) : 3; cc = cc < 4 ? 3 - cc : cc; }
+  return cc;
+}
+FQ_HD uint32_t fq_bam_body_byte(const FqBamBody &B, int b) {
+  const int nseq = (B.l_seq + 1) / 2;
+  if (b < nseq) {
+    const int j = 2 * b;
+    const int c0 = fq_bam_base_code(B, j), c1 = j + 1 < B.l_seq ? fq_bam_base_code(B, j + 1) : -1;
+    const int n0 = c0 > 3 ? 15 : (1 << c0), n1 = c1 < 0 ? 0 : (c1 > 3 ? 15 : (1 << c1));
+    return (uint32_t)(n0 << 4 | n1);
+  }
+  const int j = b - nseq;
+  int q;
+  if (j >= B.full_len) q = 0xff + 33;                // (a no-match record prints len bases and full_len qualities: the rest of the column is absent)
+  else if (B.any) { const int src = (B.strand && j < B.len) ? B.len - 1 - j : j; q = j < B.len ? B.qual[src] : B.qual[src] - B.qsub; }
+  else q = B.qual[(B.strand && j < B.len) ? B.len - 1 - j : j] - B.qsub;
+  return (uint32_t)(q - 33) & 0xffu;
 }
 // the optional fields in the order the reference WRITES them: SamRecord keeps its tags in a 32-slot hash keyed by the tag's first letter (linear
 // probing) and walks the slots (misc/bam/SamRecord.cpp:3308-3340); SetSamRecord adds them in the order of the list below
@@ -374,24 +401,14 @@ FQ_HD void fq_bam_record(const FqBamArgs &A, int idx, FqBin &o) {
     if (p.n_cigar) { const uint16_t *cg = S.cigar + p.cigar_off; for (int k = 0; k < p.n_cigar; ++k) { const int op = cg[k] >> 14; o.u32((uint32_t)(cg[k] & 0x3fff) << 4 | (uint32_t)(op == 3 ? 4 : op)); } }
     else o.u32((uint32_t)p.len << 4);
   }
-  // bases, two per byte (=ACMGRSVTWYHKDBN: A 1, C 2, G 4, T 8, N 15), then qualities
-  for (int j = 0; j < l_seq; j += 2) {
-    int nib[2] = {0, 0};
-    for (int t = 0; t < 2 && j + t < l_seq; ++t) {
-      const int jj = j + t;
-      int cc;
-      if (any) { cc = p.strand == 0 ? fq_nt4(row[jj]) : fq_comp(fq_nt4(row[p.full_len - 1 - jj])); }
-      else { cc = fq_nt4(row[jj]); if (p.strand) { cc = jj < p.clip_len ? fq_nt4(row[p.clip_len - 1 - jj]) : 3; cc = cc < 4 ? 3 - cc : cc; } }
-      nib[t] = cc > 3 ? 15 : (1 << cc);
-    }
-    o.u8((uint32_t)(nib[0] << 4 | nib[1]));
-  }
-  for (int j = 0; j < l_seq; ++j) {
-    int q;
-    if (j >= p.full_len) q = 0xff + 33;              // (a no-match record prints len bases and full_len qualities: the rest of the column is absent)
-    else if (any) { const int src = (p.strand && j < p.len) ? p.len - 1 - j : j; q = j < p.len ? hq[src] : hq[src] - qsub; }
-    else q = hq[(p.strand && j < p.len) ? p.len - 1 - j : j] - qsub;
-    o.u8((uint32_t)(q - 33) & 0xff);
+  // bases, two per byte (=ACMGRSVTWYHKDBN: A 1, C 2, G 4, T 8, N 15), then qualities: two thirds of a record's bytes (fq_bam_body_byte states every one of them)
+  {
+    const FqBamBody B = {any ? 1 : 0, p.strand, p.len, p.full_len, p.clip_len, qsub, l_seq, row, hq};
+    o.body_at = (int32_t)(o.at - start);
+    o.body_form = (B.any ? 1 : 0) | (B.strand ? 2 : 0);
+    const int nb = fq_bam_body_len(B);
+    if (!o.body) o.at += nb;
+    else for (int b = 0; b < nb; ++b) o.u8(fq_bam_body_byte(B, b));
   }
   // ---- tags, in the order of the reference's 32-slot hash
   bool have[FQ_BT_COUNT];
@@ -455,17 +472,34 @@ FQ_HD void fq_bam_record(const FqBamArgs &A, int idx, FqBin &o) {
   if (o.dst) { const uint32_t bs = (uint32_t)(o.at - start - 4); o.dst[start] = (uint8_t)bs; o.dst[start + 1] = (uint8_t)(bs >> 8); o.dst[start + 2] = (uint8_t)(bs >> 16); o.dst[start + 3] = (uint8_t)(bs >> 24); }
 }
 FQ_HD void fq_bam_len_thread(const FqBamArgs &A, int idx) {
-  FqBin o; o.dst = nullptr; o.at = 0;
+  FqBin o; o.dst = nullptr; o.at = 0; o.body = false;
   fq_bam_record(A, idx, o);
   A.len[idx] = (uint32_t)o.at;
+  A.meta[idx] = (uint32_t)(o.body_at < 0 ? 0 : o.body_at) | (uint32_t)o.body_form << 16;
 }
 FQ_HD void fq_bam_fill_thread(const FqBamArgs &A, int idx) {
   if (!A.len[idx]) return;
-  FqBin o; o.dst = A.out + A.off[idx]; o.at = 0;
+  FqBin o; o.dst = A.out + A.off[idx]; o.at = 0; o.body = A.split == 0;
   fq_bam_record(A, idx, o);
 }
+// piece c of record idx's packed bases and qualities: sixteen consecutive bytes per thread
+FQ_HD void fq_bam_body_piece(const FqBamArgs &A, int idx, int c) {
+  if (!A.len[idx]) return;
+  const fq_result_t p = A.s.rec[idx];
+  const uint32_t meta = A.meta[idx];
+  FqBamBody B;
+  B.any = (int)((meta >> 16) & 1u); B.strand = (int)((meta >> 17) & 1u);
+  B.len = p.len; B.full_len = p.full_len; B.clip_len = p.clip_len; B.qsub = (A.s.mode & FQ_MODE_IL13) ? 31 : 0;
+  B.l_seq = B.any ? p.full_len : p.len;
+  B.row = A.s.seq + (size_t)fq_emit_row(A.s.packed, A.s.n_pairs, A.s.pair_list, idx) * (size_t)A.s.stride;
+  B.qual = A.s.qual + (size_t)idx * (size_t)A.s.qual_stride;
+  const int n = fq_bam_body_len(B), b0 = c * FQ_SAM_PIECE;
+  if (b0 >= n) return;
+  uint8_t *dst = A.out + A.off[idx] + (meta & 0xffffu) + b0;
+  for (int t = 0; t < FQ_SAM_PIECE && b0 + t < n; ++t) dst[t] = (uint8_t)fq_bam_body_byte(B, b0 + t);
+}
 
-enum { FQ_EOP_SAM_LEN = 0, FQ_EOP_SAM_FILL, FQ_EOP_BAM_LEN, FQ_EOP_BAM_FILL, FQ_EOP_SAM_BODY, FQ_EOP_COUNT };
+enum { FQ_EOP_SAM_LEN = 0, FQ_EOP_SAM_FILL, FQ_EOP_BAM_LEN, FQ_EOP_BAM_FILL, FQ_EOP_SAM_BODY, FQ_EOP_BAM_BODY, FQ_EOP_COUNT };
 
 // =====================================================================================================================================
 // StatCollector on the device: AddAlignment (src/StatCollector.cpp:950-1101), AddSingleAlignment (:424-620), ProcessPairStatus (:623-921)

@@ -174,7 +174,13 @@ int launch_deflate_pack(const FqDeflatePackArgs &a) {
   return 0;
 }
 int launch_bam(int op, const FqBamArgs &a, int64_t n) {
-  for (int64_t i = 0; i < n; ++i) { if (op == FQ_EOP_BAM_LEN) fq_bam_len_thread(a, (int)i); else if (op == FQ_EOP_BAM_FILL) fq_bam_fill_thread(a, (int)i); else return -1; }
+  const int pieces = ((a.s.stride + 1) / 2 + a.s.stride + FQ_SAM_PIECE - 1) / FQ_SAM_PIECE;
+  for (int64_t i = 0; i < n; ++i) {
+    if (op == FQ_EOP_BAM_LEN) fq_bam_len_thread(a, (int)i);
+    else if (op == FQ_EOP_BAM_FILL) fq_bam_fill_thread(a, (int)i);
+    else if (op == FQ_EOP_BAM_BODY) { for (int c = 0; c < pieces; ++c) fq_bam_body_piece(a, (int)i, c); }
+    else return -1;
+  }
   return 0;
 }
 int launch_qc(int op, const FqQcArgs &a, int64_t n) {

@@ -22,7 +22,7 @@ WHAT=${1:?what}; TAG=${2:?tag}; shift; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out
 mkdir -p $O
-Q="--no-cpu-baseline --no-resident --no-ontarget --no-front-end"
+Q="--no-cpu-baseline --no-resident --no-ontarget --no-front-end --no-host-budget"
 cd /tmp && export TMPDIR=/tmp
 case $WHAT in
 timeline)

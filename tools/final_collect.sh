@@ -11,7 +11,7 @@ python -c 'import __graft_entry__ as g; g.smoke(); print("smoke ok")' > $O/${TAG
 ( time timeout 1200 python bench.py > $O/${TAG}_default_bench.json 2> $O/${TAG}_default_bench.err ) 2> $O/${TAG}_default_bench.time
 bash tools/experiment.sh trace $TAG 4194304 > /dev/null
 bash tools/experiment.sh timeline $TAG 2 > /dev/null
-Q="--no-cpu-baseline --no-resident --no-ontarget --no-front-end"
+Q="--no-cpu-baseline --no-resident --no-ontarget --no-front-end --no-host-budget"
 bash tools/experiment.sh stats $TAG wgs --steps 20 --warmup 5 --no-front-end --no-cpu-baseline > /dev/null
 bash tools/experiment.sh stats $TAG wgs_mainleg --steps 20 --warmup 5 $Q > /dev/null
 bash tools/experiment.sh stats $TAG ont4m --mix ontarget --pairs 4194304 --ctxs 1 --steps 3 --warmup 1 $Q > /dev/null
