@@ -1582,7 +1582,7 @@ int launch_sam(int op, const FqSamArgs &a, int64_t n) {
   if (op == FQ_EOP_SAM_LEN) hipExtLaunchKernelGGL(k_sam_len, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
   else if (op == FQ_EOP_SAM_FILL) hipExtLaunchKernelGGL(k_sam_fill, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
   else if (op == FQ_EOP_SAM_BODY) {      // a thread per sixteen bytes of a record's SEQ / tab / QUAL run (2 x row stride + 1 bytes at most)
-    const int pieces = (2 * a.stride + 1 + FQ_SAM_PIECE - 1) / FQ_SAM_PIECE + 1;      // (aligned windows: one more than the run holds)
+    const int pieces = (2 * a.stride + 1 + FQ_SAM_PIECE - 1) / FQ_SAM_PIECE;
     hipExtLaunchKernelGGL(k_sam_body, dim3(nblk((uint64_t)n * (uint64_t)pieces, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n, pieces);
   }
   else { g_err = "SAM text: unknown operation"; return -1; }
@@ -1611,7 +1611,7 @@ int launch_bam(int op, const FqBamArgs &a, int64_t n) {
   if (op == FQ_EOP_BAM_LEN) hipExtLaunchKernelGGL(k_bam_len, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
   else if (op == FQ_EOP_BAM_FILL) hipExtLaunchKernelGGL(k_bam_fill, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
   else if (op == FQ_EOP_BAM_BODY) {      // a thread per sixteen bytes of a record's packed bases and qualities (1.5 x row stride + 1 bytes at most)
-    const int pieces = ((a.s.stride + 1) / 2 + a.s.stride + FQ_SAM_PIECE - 1) / FQ_SAM_PIECE + 1;
+    const int pieces = ((a.s.stride + 1) / 2 + a.s.stride + FQ_SAM_PIECE - 1) / FQ_SAM_PIECE;
     hipExtLaunchKernelGGL(k_bam_body, dim3(nblk((uint64_t)n * (uint64_t)pieces, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n, pieces);
   }
   else { g_err = "BAM records: unknown operation"; return -1; }

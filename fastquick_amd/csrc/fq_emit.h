@@ -254,32 +254,13 @@ FQ_HD void fq_sam_fill_thread(const FqSamArgs &A, int idx) {
   fq_sam_line(A, idx, o);
 }
 #define FQ_SAM_PIECE 16
-// Window c of a run of n bytes that begins at `run`: the sixteen-byte ALIGNED window of the destination it falls into (window 0 holds the run's first byte).
-// A window that lies inside the run leaves as one 16-byte store; the run's two ragged ends byte by byte.  byte_of(B, b) states byte b of the run.
-template <class Body, auto byte_of>
-FQ_HD void fq_body_window(const Body &B, uint8_t *run, int n, int c) {
-  const uintptr_t S = (uintptr_t)run, W = (S & ~(uintptr_t)15) + (uintptr_t)c * 16;
-  const uintptr_t lo = W > S ? W : S, hi = (W + 16 < S + (uintptr_t)n) ? W + 16 : S + (uintptr_t)n;
-  if (lo >= hi) return;
-  const int b0 = (int)(lo - S);
-  if (hi - lo == 16) {
-    uint32_t w[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k)
-      w[k] = (uint32_t)(uint8_t)byte_of(B, b0 + 4 * k) | (uint32_t)(uint8_t)byte_of(B, b0 + 4 * k + 1) << 8 | (uint32_t)(uint8_t)byte_of(B, b0 + 4 * k + 2) << 16 | (uint32_t)(uint8_t)byte_of(B, b0 + 4 * k + 3) << 24;
-    FqU4 v; v.x = w[0]; v.y = w[1]; v.z = w[2]; v.w = w[3];
-    *(FqU4 *)lo = v;
-    return;
-  }
-  uint8_t *dst = (uint8_t *)lo;
-  for (int t = 0; t < (int)(hi - lo); ++t) dst[t] = (uint8_t)byte_of(B, b0 + t);
-}
 // piece c of record idx's SEQ / tab / QUAL run: sixteen consecutive bytes of the text per thread.  Which form the run has and in which strand it is printed
 // was decided by the line routine when it measured the line (meta).
 FQ_HD void fq_sam_body_piece(const FqSamArgs &A, int idx, int c) {
   if (!A.len[idx]) return;
   const fq_result_t p = A.rec[idx];
-  if ((c - 1) * FQ_SAM_PIECE >= 2 * p.full_len + 1) return;      // (no run is longer)
+  const int b0 = c * FQ_SAM_PIECE;
+  if (b0 >= 2 * p.full_len + 1) return;              // (no run is longer)
   const uint32_t meta = A.meta[idx];
   FqSamBody B;
   B.nomatch = (int)((meta >> 16) & 1u); B.strand = (int)((meta >> 17) & 1u);
@@ -287,7 +268,8 @@ FQ_HD void fq_sam_body_piece(const FqSamArgs &A, int idx, int c) {
   B.row = A.seq + (size_t)fq_emit_row(A.packed, A.n_pairs, A.pair_list, idx) * (size_t)A.stride;
   B.qual = A.qual + (size_t)idx * (size_t)A.qual_stride;
   const int n = fq_sam_body_len(B);
-  fq_body_window<FqSamBody, fq_sam_body_char>(B, (uint8_t *)A.text + A.off[idx] + (meta & 0xffffu), n, c);
+  char *dst = A.text + A.off[idx] + (meta & 0xffffu) + b0;
+  for (int t = 0; t < FQ_SAM_PIECE && b0 + t < n; ++t) dst[t] = fq_sam_body_char(B, b0 + t);
 }
 
 // ---- BAM records: SetSamRecord (src/BwtMapper.cpp:977-1264), restated field by field as fq_bam.cpp does on the host -----------------------
@@ -511,9 +493,10 @@ FQ_HD void fq_bam_body_piece(const FqBamArgs &A, int idx, int c) {
   B.l_seq = B.any ? p.full_len : p.len;
   B.row = A.s.seq + (size_t)fq_emit_row(A.s.packed, A.s.n_pairs, A.s.pair_list, idx) * (size_t)A.s.stride;
   B.qual = A.s.qual + (size_t)idx * (size_t)A.s.qual_stride;
-  const int n = fq_bam_body_len(B);
-  if ((c - 1) * FQ_SAM_PIECE >= n) return;
-  fq_body_window<FqBamBody, fq_bam_body_byte>(B, A.out + A.off[idx] + (meta & 0xffffu), n, c);
+  const int n = fq_bam_body_len(B), b0 = c * FQ_SAM_PIECE;
+  if (b0 >= n) return;
+  uint8_t *dst = A.out + A.off[idx] + (meta & 0xffffu) + b0;
+  for (int t = 0; t < FQ_SAM_PIECE && b0 + t < n; ++t) dst[t] = (uint8_t)fq_bam_body_byte(B, b0 + t);
 }
 
 enum { FQ_EOP_SAM_LEN = 0, FQ_EOP_SAM_FILL, FQ_EOP_BAM_LEN, FQ_EOP_BAM_FILL, FQ_EOP_SAM_BODY, FQ_EOP_BAM_BODY, FQ_EOP_COUNT };

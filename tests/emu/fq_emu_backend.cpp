@@ -154,7 +154,7 @@ int launch_rec(int op, const FqRecArgs &a, int64_t n) {
   return 0;
 }
 int launch_sam(int op, const FqSamArgs &a, int64_t n) {
-  const int pieces = (2 * a.stride + 1 + FQ_SAM_PIECE - 1) / FQ_SAM_PIECE + 1;      // (aligned windows: one more than the run holds)
+  const int pieces = (2 * a.stride + 1 + FQ_SAM_PIECE - 1) / FQ_SAM_PIECE;
   for (int64_t i = 0; i < n; ++i) {
     if (op == FQ_EOP_SAM_LEN) fq_sam_len_thread(a, (int)i);
     else if (op == FQ_EOP_SAM_FILL) fq_sam_fill_thread(a, (int)i);
@@ -174,7 +174,7 @@ int launch_deflate_pack(const FqDeflatePackArgs &a) {
   return 0;
 }
 int launch_bam(int op, const FqBamArgs &a, int64_t n) {
-  const int pieces = ((a.s.stride + 1) / 2 + a.s.stride + FQ_SAM_PIECE - 1) / FQ_SAM_PIECE + 1;
+  const int pieces = ((a.s.stride + 1) / 2 + a.s.stride + FQ_SAM_PIECE - 1) / FQ_SAM_PIECE;
   for (int64_t i = 0; i < n; ++i) {
     if (op == FQ_EOP_BAM_LEN) fq_bam_len_thread(a, (int)i);
     else if (op == FQ_EOP_BAM_FILL) fq_bam_fill_thread(a, (int)i);

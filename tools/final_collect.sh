@@ -40,6 +40,12 @@ FASTQUICK_FE_OVERLAP=0 rocprofv3 --kernel-trace --stats --output-format csv -d $
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_fe_overlap -o fe -- python3 $R/tools/frontend_stream.py $F/trace_1.fq.gz $F/trace_2.fq.gz --repeats 1 > $O/${TAG}_fe_overlap.json 2> $O/${TAG}_fe_overlap.err
 find $O/${TAG}_fe_solo $O/${TAG}_fe_overlap -name '*kernel_trace.csv' -delete
 cd $R
+# ---- the command line on on-target input under rocprofv3 --kernel-trace --stats: the consumers' kernels (fq_emit.h, fq_deflate.h) beside the alignment's
+cd /tmp && export TMPDIR=/tmp
+FQ_PROFILE_DIR=$O/${TAG}_cliont_prof FQ_BENCH_DIR=/tmp/fq_e2e timeout 600 python3 $R/tools/cli_ontarget.py 1048576 8 150 > $O/${TAG}_cli_ontarget_profiled.json 2> $O/${TAG}_cli_ontarget_profiled.err
+for m in sam_out bam_and_qc; do f=$(find $O/${TAG}_cliont_prof/$m -name '*kernel_stats.csv' 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $O/${TAG}_cli_ontarget_${m}_kernel_stats.csv; done
+rm -rf $O/${TAG}_cliont_prof
+cd $R
 bash tools/frontend_pmc.sh $TAG 2000000 > /dev/null 2>&1
 python3 tools/frontend_bench.py --records 4000000 > $O/${TAG}_inflate_kernel.txt 2>&1
 cat $O/${TAG}_gpu_tests.txt $O/${TAG}_smoke.txt $O/${TAG}_default_bench.time | tail -8
