@@ -420,7 +420,8 @@ void producer_main(fq_fastq *r) {
     b.head = kHeadroom; b.n = 0; b.last = false;
     const bool ok = r->bgzf ? fill_bgzf(r, b) : r->gs.on ? fill_gz_stream(r, b) : fill_gz(r, b);
     if (!ok) { b.last = true; b.err = r->src_err; }
-    if (getenv("FASTQUICK_READER_DEBUG")) fprintf(stderr, "[reader] block: %zu bytes, last %d, err '%s' (%s)\n", b.n, (int)b.last, b.err.c_str(), r->bgzf ? "bgzf" : r->gs.on ? "stream" : "gzread");
+    static const bool reader_debug = [] { const char *e = getenv("FASTQUICK_READER_DEBUG"); return e && *e && *e != '0'; }();   // (read once: the host program may change its environment beside this thread)
+    if (reader_debug) fprintf(stderr, "[reader] block: %zu bytes, last %d, err '%s' (%s)\n", b.n, (int)b.last, b.err.c_str(), r->bgzf ? "bgzf" : r->gs.on ? "stream" : "gzread");
     const bool done = b.last;
     {
       std::lock_guard<std::mutex> lk(r->mu);

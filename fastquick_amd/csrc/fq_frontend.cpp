@@ -800,6 +800,9 @@ fq_frontend::~fq_frontend() {
 extern "C" int fq_frontend_open(int device, const char *fq1, const char *fq2, int32_t batch_pairs, int64_t chunk_pairs, int32_t slot_mode, int32_t max_read_len, fq_frontend_t **out) {
   if (!fq1 || !out || batch_pairs < 1 || chunk_pairs < batch_pairs || slot_mode < 0 || slot_mode > 2 || max_read_len < 16 || max_read_len > 4096) return FQ_EINVAL;
   *out = nullptr;
+  // (declared in front of `fe`: destroyed behind it -- the device states of an open that fails go when the members' buffers have been freed;
+  //  ~fq_frontend leaves them to fq_frontend_close, which an object that was never handed out does not reach)
+  struct StatesGuard { fqdev::State *s[3] = {nullptr, nullptr, nullptr}; bool armed = true; ~StatesGuard() { if (armed) for (fqdev::State *x : s) if (x) fqdev::state_destroy(x); } } guard;
   std::unique_ptr<fq_frontend> fe(new fq_frontend);
   fe->device = device; fe->batch_pairs = batch_pairs; fe->chunk_pairs = chunk_pairs / batch_pairs * batch_pairs; fe->max_len = max_read_len;
   fe->n_files = (fq2 && *fq2) ? 2 : 1;
@@ -835,12 +838,12 @@ extern "C" int fq_frontend_open(int device, const char *fq1, const char *fq2, in
     }
   }
   // device side
-  fe->st = fqdev::state_create(device);
+  fe->st = guard.s[0] = fqdev::state_create(device);
   if (!fe->st || fqdev::bind(fe->st)) return FQ_ENODEV;
   const size_t n_slots = (size_t)2 * (size_t)batch_pairs;
   for (int e = 0; e < fe->n_files; ++e) {
     FileSide &F = fe->f[e];
-    F.st = fqdev::state_create(device);
+    F.st = guard.s[1 + e] = fqdev::state_create(device);
     if (!F.st) return FQ_ENODEV;
     if (fqdev::bind(fe->st)) return FQ_ENODEV;
     if (!F.d_slot_base.ensure(n_slots * 96) || !F.d_slot_len.ensure(n_slots) || !F.d_slot_name.ensure(n_slots * 304) || !F.d_stat.ensure(FQT_N_STAT + 8)) return FQ_ENOMEM;
@@ -854,6 +857,7 @@ extern "C" int fq_frontend_open(int device, const char *fq1, const char *fq2, in
     fe->f[e].th = std::thread(reader_main, fe.get(), e);
   }
   fe->producer = std::thread(producer_main, fe.get());
+  guard.armed = false;
   *out = fe.release();
   return FQ_OK;
 }
@@ -939,7 +943,8 @@ extern "C" const char *fq_text_batch_first_name(const fq_text_batch_t *b, int32_
 extern "C" int fq_text_batch_fetch(fq_frontend_t *fe, const fq_text_batch_t *b, uint64_t *head, uint16_t *len, char *names, int64_t names_cap) {
   if (!fe || !b) return FQ_EINVAL;
   const size_t rows = (size_t)b->n_pairs * (b->single_end ? 1 : 2);
-  if (fqdev::bind(fe->f[0].st)) return FQ_ENODEV;             // (a state of this thread's own: the producer's is its thread's)
+  DevScope scope(fe->device);                                  // (a state of this call's own: the readers' and the producer's are their threads')
+  if (!scope.s || fqdev::bind(scope.s)) return FQ_ENODEV;
   if (head && fqdev::d2h(head, b->d_head, rows * 24)) return FQ_ENODEV;
   if (len && fqdev::d2h(len, b->d_hlen, rows * 2)) return FQ_ENODEV;
   if (names) { if ((int64_t)(rows * (size_t)b->name_stride) > names_cap) return FQ_ELIMIT; if (fqdev::d2h(names, b->d_names, rows * (size_t)b->name_stride)) return FQ_ENODEV; }
