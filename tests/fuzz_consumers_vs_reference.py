@@ -5,6 +5,7 @@ fq_bam writes (decoded by the independent reader of tests/test_bam_writer.py, ta
 
     python tests/fuzz_consumers_vs_reference.py --seeds 40 --start 0              # host-loop tier (CPU, build container)
     python tests/fuzz_consumers_vs_reference.py --seeds 40 --start 0 --device 0   # the device path (GPU box; oracle/_ref travels there)
+Since round 6 the consumers themselves run in kernels (--device_consumers 1, the default): the QC files and the BAM records come out of fq_emit.h / fq_deflate.h.
 """
 import argparse, os, random, subprocess, sys, tempfile, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -19,6 +20,8 @@ ap.add_argument("--seeds", type=int, default=20)
 ap.add_argument("--start", type=int, default=0)
 ap.add_argument("--device", type=int, default=-1, help="HIP device (default: the host-loop library of tests/emu)")
 ap.add_argument("--budget", type=float, default=0, help="stop after this many seconds (0: run all seeds)")
+ap.add_argument("--device_consumers", type=int, default=1, help="1 (default since round 6): StatCollector's part and the BAM records / BGZF members in the kernels of fq_emit.h / fq_deflate.h "
+                "(fq_ctx_attach_qc / fq_ctx_attach_bam); 0: the host statements from the result arrays")
 args = ap.parse_args()
 if not os.path.exists(ob.REF_DRIVER):
     sys.exit("oracle/_ref/fq_ref_driver missing: run `make -C oracle ref` in the build container")
@@ -70,6 +73,8 @@ for seed in range(args.start, args.start + args.seeds):
         al = api.Aligner(ix, api.default_opts(lib, single_end=1 if se else 0, **okw), max_pairs=max(16, batch))
         qc = api.QC(ix, pre, os.path.join(d, "got"), genome_size=len(ref.genome), read_len=151, cal_dup=1 if cal_dup else 0)
         bam = api.BamWriter(ix, fai, os.path.join(d, "got.bam"), cal_dup=1 if cal_dup else 0)
+        if args.device_consumers:
+            qc.attach(al); bam.attach(al)
         qc.begin_file(f1, f1 if se else f2)
         if se:
             api.align_stream(al, list(rb.names), rb.seq[:1], rb.qual[:1], rb.lens[:1], batch, None, None, qc=qc, bam=bam, packed=packed)
