@@ -161,6 +161,7 @@ struct FqKnobs {   // experiment / test knobs (fq_ctx_set_tuning); defaults are 
   int gap_no_order = 0;
   int device_turns = 2;            // calls that search at least gap_nogap_min reads take turns on the device: 1 = the search kernels, 2 = the width kernel too, 0 = off.
                                    // Two streams of 4.2 M-pair on-target calls: search kernels 54.1 / 41.7 / 38.8 ms per launch with 0 / 1 / 2 (38.8 alone), 16.8 / 16.3 / 16.7 M pairs/s
+  int device_turn_slots = 1;       // how many contexts may hold a turn at once (experiment: a few small search stages side by side instead of sixteen or one)
   int64_t device_turn_min = 1 << 20; // ... calls that search at least this many reads (launches that fill the device several times over; sixteen streams of a 100k-marker
                                    // WGS mix search 176 k reads per call: one residency of the first round, and taking turns for it serialised the streams)
   int gap_round2_refill = 16;      // refill group of the round after it (see the launch)
@@ -403,6 +404,7 @@ extern "C" int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t v) {
   else if (k == "gap_no_order") c->kn.gap_no_order = (int)v;
   else if (k == "device_turns") c->kn.device_turns = (int)v;
   else if (k == "device_turn_min") c->kn.device_turn_min = v;
+  else if (k == "device_turn_slots") c->kn.device_turn_slots = (int)std::max<int64_t>(1, v);
   else if (k == "gap_round2_waves") c->kn.gap_round2_waves = (int)v;
   else if (k == "gap_round2_lane_major") c->kn.gap_round2_lane_major = (int)v;
   else if (k == "gap_round1_refill") c->kn.gap_round1_refill = (int)v;
@@ -1234,7 +1236,8 @@ int stageA_search(Call &K) {
       wa.work = c->d_work.p; wa.n_work = nw; wa.wfull = c->d_wfull.p; wa.wstride = Lpad;
       wa.prec = c->d_prec.p; wa.pstride = Ppad; wa.winfo = c->d_winfo.p; wa.maxdiff_lut = c->d_maxdiff.p; wa.bid_end = c->d_bid_end.p; wa.counters = c->d_counters.p;
       // device-filling launches of several contexts take turns (fqdev::device_turn_begin)
-      struct Turn { bool held = false; void take() { if (!held) { fqdev::device_turn_begin(); held = true; } } void drop() { if (held) { fqdev::device_turn_end(); held = false; } } ~Turn() { drop(); } } turn;
+      struct Turn { int slots = 1; bool held = false; void take() { if (!held) { fqdev::device_turn_begin(slots); held = true; } } void drop() { if (held) { fqdev::device_turn_end(); held = false; } } ~Turn() { drop(); } } turn;
+      turn.slots = c->kn.device_turn_slots;
       const bool big_call = c->kn.device_turns > 0 && !T.coop && c->kn.gap_nogap_min >= 0 && (int64_t)n_search >= std::max(c->kn.gap_nogap_min, c->kn.device_turn_min) &&
                             (T.nogap || !(c->kn.device_turns == 3 || (c->kn.device_turns == 2 && g_calls_in_flight.load(std::memory_order_relaxed) >= 3)));
       // (The round after the one without gap children is latency-bound -- half of the vector ALUs idle -- and shares the device well: with three or

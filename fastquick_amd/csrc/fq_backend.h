@@ -34,7 +34,7 @@ bool is_real_gpu();                    // true for the HIP backend
 // Device-filling stages of different contexts take turns: a per-device lock held by the context whose search stage owns the
 // device.  (Two such launches side by side share wave slots and L2 and both last longer than they would one after the other; what
 // the other contexts' host threads do meanwhile -- their host phases, their small kernels -- is not held up.)
-void device_turn_begin();
+void device_turn_begin(int slots = 1);   // at most `slots` contexts hold a turn at a time
 void device_turn_end();
 
 void *dmalloc(size_t bytes);           // device memory (nullptr on failure)

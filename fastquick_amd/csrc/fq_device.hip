@@ -4,6 +4,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <condition_variable>
 #include <atomic>
 #include <cstdio>
 #include <cstdlib>
@@ -77,7 +78,10 @@ static State *g_prep_owner[64];
 // queues -- a context's kernels then wait behind another context's long search kernel.
 static hipStream_t g_copy_streams[64][2];
 static unsigned g_copy_next[64];
-static std::mutex g_turn_mu[64];   // device_turn_begin / device_turn_end
+// device_turn_begin / device_turn_end: at most `slots` contexts hold a turn on a device at a time (1: one after the other)
+static std::mutex g_turn_mu[64];
+static std::condition_variable g_turn_cv[64];
+static int g_turn_held[64];
 // Hardware queues: every context drives a stream of its own, and the HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware
 // queues (4 unless the variable says otherwise, read when the runtime initialises).  Contexts that share a queue wait for each
 // other's long kernels (16 streams on 16 queues: two share, and straggle by 25 %; 32 or more queues halve the throughput of 16
@@ -99,8 +103,17 @@ int runtime_configure(int hw_queues, int blocking_waits) {
 }
 
 int device_count() { int n = 0; if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; } return n < 0 ? 0 : n; }
-void device_turn_begin() { g_turn_mu[g_cur->device].lock(); }
-void device_turn_end() { g_turn_mu[g_cur->device].unlock(); }
+void device_turn_begin(int slots) {
+  const int d = g_cur->device;
+  std::unique_lock<std::mutex> lk(g_turn_mu[d]);
+  g_turn_cv[d].wait(lk, [&] { return g_turn_held[d] < (slots < 1 ? 1 : slots); });
+  ++g_turn_held[d];
+}
+void device_turn_end() {
+  const int d = g_cur->device;
+  { std::lock_guard<std::mutex> lk(g_turn_mu[d]); --g_turn_held[d]; }
+  g_turn_cv[d].notify_all();
+}
 
 State *state_create(int dev) {
   int n = 0;

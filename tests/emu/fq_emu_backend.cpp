@@ -22,7 +22,7 @@ State *state_create(int dev) { if (dev < 0 || dev >= device_count()) { g_err = "
 void state_destroy(State *s) { if (g_bound == s) g_bound = nullptr; delete s; }
 int bind(State *s) { g_bound = s; return 0; }
 Tune *tune(State *s) { return &s->tune; }
-void device_turn_begin() {}
+void device_turn_begin(int) {}
 void device_turn_end() {}
 int h2d_copy(void *d, const void *s, size_t n) { if (n) memcpy(d, s, n); return 0; }
 int copy_record(int) { return 0; }
