@@ -50,6 +50,13 @@ int cal_maxdiff(int l, double err, double thres) {
   }
   return 2;
 }
+// A stream's first calls are short ones (the front end hands out an eighth, a quarter, a half of a chunk first): a buffer that has to grow in such a call is
+// sized for the calls that follow (tl_grow = pairs of a steady call / pairs of this one, set by the call; 1 outside), so that a context allocates its device and
+// pinned buffers once instead of at every step of the ramp -- pinning a few hundred megabytes costs 0.4 ms per megabyte, and a hipFree waits for the device.
+thread_local double tl_grow = 1.0;
+struct GrowScope { double prev; explicit GrowScope(double g) : prev(tl_grow) { tl_grow = g; } ~GrowScope() { tl_grow = prev; } };
+inline size_t grown(size_t n) { return tl_grow > 1.0 ? (size_t)((double)n * tl_grow * 1.02) : 0; }
+
 template <class T> struct DevBuf {
   T *p = nullptr;
   size_t cap = 0;
@@ -57,8 +64,9 @@ template <class T> struct DevBuf {
   bool ensure(size_t n) {
     if (n <= cap) return true;
     fqdev::dfree(p);
-    cap = n + std::min<size_t>(n / 4, (size_t)16 << 20) + 64;   // some slack against regrowth, bounded for the multi-GB buffers
-    p = (T *)fqdev::dmalloc(cap * sizeof(T));
+    p = nullptr;
+    if (const size_t g = grown(n)) { cap = g + 64; p = (T *)fqdev::dmalloc(cap * sizeof(T)); }
+    if (!p) { cap = n + std::min<size_t>(n / 4, (size_t)16 << 20) + 64;   /* some slack against regrowth, bounded for the multi-GB buffers */ p = (T *)fqdev::dmalloc(cap * sizeof(T)); }
     if (!p) { cap = n; p = (T *)fqdev::dmalloc(cap * sizeof(T)); }
     if (!p) { cap = 0; return false; }
     return true;
@@ -68,16 +76,18 @@ template <class T> struct DevBuf {
   bool ensure_roomy(size_t n) {
     if (n <= cap) return true;
     fqdev::dfree(p);
-    cap = n + n / 8 + 64;
+    cap = std::max(n + n / 8, grown(n)) + 64;
     p = (T *)fqdev::dmalloc(cap * sizeof(T));
+    if (!p) { cap = n + n / 8 + 64; p = (T *)fqdev::dmalloc(cap * sizeof(T)); }
     if (!p) { cap = n; p = (T *)fqdev::dmalloc(cap * sizeof(T)); }
     if (!p) { cap = 0; return false; }
     return true;
   }
   bool ensure_keep(size_t n, size_t keep) {   // as ensure, but the first `keep` elements survive a reallocation (copied on the compute stream)
     if (n <= cap) return true;
-    const size_t ncap = n + std::min<size_t>(n / 4, (size_t)16 << 20) + 64;
+    size_t ncap = std::max(n + std::min<size_t>(n / 4, (size_t)16 << 20), grown(n)) + 64;
     T *q = (T *)fqdev::dmalloc(ncap * sizeof(T));
+    if (!q) { ncap = n + 64; q = (T *)fqdev::dmalloc(ncap * sizeof(T)); }
     if (!q) return false;
     if (keep && (fqdev::d2d(q, p, keep * sizeof(T)) || fqdev::sync())) { fqdev::dfree(q); return false; }
     fqdev::dfree(p);
@@ -94,15 +104,17 @@ template <class T> struct PinBuf {   // pinned host staging: device <-> host cop
   bool ensure(size_t n) {
     if (n <= cap) return true;
     fqdev::hfree(p);
-    cap = n + n / 4 + 64;
+    cap = std::max(n + n / 4, grown(n)) + 64;
     p = (T *)fqdev::hmalloc(cap * sizeof(T));
+    if (!p) { cap = n + 64; p = (T *)fqdev::hmalloc(cap * sizeof(T)); }
     if (!p) { cap = 0; return false; }
     return true;
   }
   bool ensure_keep(size_t n, size_t keep) {   // as ensure, but the first `keep` elements survive a reallocation
     if (n <= cap) return true;
-    const size_t ncap = n + n / 4 + 64;
+    size_t ncap = std::max(n + n / 4, grown(n)) + 64;
     T *q = (T *)fqdev::hmalloc(ncap * sizeof(T));
+    if (!q) { ncap = n + 64; q = (T *)fqdev::hmalloc(ncap * sizeof(T)); }
     if (!q) return false;
     if (keep) memcpy(q, p, keep * sizeof(T));
     fqdev::hfree(p);
@@ -119,6 +131,7 @@ struct PinArena {
   struct Block { uint8_t *p; size_t cap; };
   std::vector<Block> blocks;
   size_t used = 0, total = 0;
+  double last_grow = 1.0;          // tl_grow of the call `total` was counted in
   struct Out { void *dst; const void *src; size_t bytes; };
   std::vector<Out> pending;
   ~PinArena() { for (auto &b : blocks) fqdev::hfree(b.p); }
@@ -127,16 +140,17 @@ struct PinArena {
     if (blocks.size() > 1) {   // one block of the size the last call needed
       for (auto &b : blocks) fqdev::hfree(b.p);
       blocks.clear();
-      uint8_t *p = (uint8_t *)fqdev::hmalloc(total + total / 4);
-      if (p) blocks.push_back({p, total + total / 4});
+      const size_t want = std::max(total + total / 4, (size_t)((double)total * last_grow * 1.02));
+      uint8_t *p = (uint8_t *)fqdev::hmalloc(want);
+      if (p) blocks.push_back({p, want});
     }
-    used = 0; total = 0;
+    used = 0; total = 0; last_grow = tl_grow;
   }
   void *alloc(size_t bytes) {
     bytes = (bytes + 63) & ~(size_t)63;
     total += bytes;
     if (blocks.empty() || used + bytes > blocks.back().cap) {
-      const size_t cap = std::max<size_t>(bytes, (size_t)4 << 20);
+      const size_t cap = std::max<size_t>(std::max(bytes, grown(bytes)), (size_t)4 << 20);
       uint8_t *p = (uint8_t *)fqdev::hmalloc(cap);
       if (!p) return nullptr;
       blocks.push_back({p, cap});
@@ -759,7 +773,7 @@ struct Call {
   struct B1Plan { uint64_t *start = nullptr; size_t n_chunks = 0; uint64_t rng_end = 0; } plan;
   std::thread plan_thread;             // the plan is drawn up beside the SA stage when nothing else can move the stream's state
   ~Call() { if (plan_thread.joinable()) plan_thread.join(); gate_release(); }
-  double t_trace = 0, t_wall0 = 0, t_host0 = 0, t_serial1 = 0, t_host1 = 0, cpu_trace = 0, tcpu_trace = 0;
+  double t_trace = 0, t_wall0 = 0, t_host0 = 0, t_serial1 = 0, t_host1 = 0, cpu_trace = 0, tcpu_trace = 0, w_trace = 0;
   double w_call0 = 0, w_host0 = 0, w_serial1 = 0, w_host1 = 0, cpu_call0 = 0;   // the context's wait_ms at those marks; the calling thread's CPU time at the start
   int sidx(size_t idx) const { return c->h_surv[idx].sidx; }
   const FqAln *aln_of(size_t idx, int *n_out) const {
@@ -776,8 +790,8 @@ struct Call {
     const double cpu = 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
     clock_gettime(CLOCK_THREAD_CPUTIME_ID, &ts);
     const double tcpu = 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec;
-    fprintf(stderr, "[fq] %-22s %8.3f ms   cpu %8.1f core-ms   this thread %6.3f ms\n", label, t - t_trace, cpu - cpu_trace, tcpu - tcpu_trace);
-    t_trace = t; cpu_trace = cpu; tcpu_trace = tcpu;
+    fprintf(stderr, "[fq] %-22s %8.3f ms   cpu %8.1f core-ms   this thread %6.3f ms   waited for the device %6.3f ms\n", label, t - t_trace, cpu - cpu_trace, tcpu - tcpu_trace, c->wait_ms - w_trace);
+    t_trace = t; cpu_trace = cpu; tcpu_trace = tcpu; w_trace = c->wait_ms;
   }
 };
 
@@ -1092,6 +1106,7 @@ int stage0_text(Call &K) {
     CKS(d2h_staged(c, striped.data(), c->d_counters.p, striped.size() * 8));
   }
   CKS(sync_staged(c));
+  K.trace("  stage0: filter + compaction of the text batch");
   if (ragged) {
     uint64_t folded[FQ_C_COUNT];
     fold_counters(striped.data(), folded);
@@ -1105,6 +1120,7 @@ int stage0_text(Call &K) {
   CK(fqdev::launch_surv_map(c->d_pair_list.p, n_surv, n, c->d_filtered.p, c->d_sidx.p, c->d_surv.p, c->d_row_map.p, c->d_read_list.p, nullptr));
   int rc = stage0_lists(K, false);
   if (rc) return rc;
+  K.trace("  stage0: survivors' lists D2H");
   // ---- the reads of surviving pairs: rows, qualities and names out of the text ----
   int max_full = 1;
   for (int sb = 0; sb < n_sub; ++sb) max_full = std::max(max_full, c->h_sub_max[sb]);
@@ -1161,6 +1177,7 @@ int stage0_text(Call &K) {
   CKS(sync_staged(c));
   if (c->debug && c->h_len_trim.empty()) { c->h_len_trim.resize(n2); for (int r = 0; r < n2; ++r) c->h_len_trim[r] = r >= n_in ? 0 : (int)c->h_len_all[r]; }
   stage0_sub_max(K);
+  K.trace("  stage0: rows, qualities, names gathered");
   K.dseq = c->d_seq.p; K.dstride = cstride; K.dlen_trim = c->d_len_trim.p; K.dread_list = c->d_read_list.p;
   return FQ_OK;
 }
@@ -1244,6 +1261,7 @@ int stageA_search(Call &K) {
       //  more calls in flight there is always another context's stage to run beside it, and it leaves the turn to them: 3.2 -> 3.45 / 3.3 -> 3.6 x 10^7
       //  pairs/s with three / four on-target streams.  With two streams it keeps its turn: +3 % is not worth timing the kernel under a neighbour.
       //  device_turns = 3: never takes it.)
+      K.trace("  A: work list, buffers");
       if (big_call && c->kn.device_turns >= 2) turn.take();
       fqdev::time_begin(FQ_K_WIDTH);
       CK(fqdev::launch_width(wa));
@@ -1269,6 +1287,7 @@ int stageA_search(Call &K) {
       // as many wavefronts as it could run, run fewer (the persistent lanes simply take more reads each)
       for (;;) {
         const size_t slots = (size_t)fqdev::gap_lane_slots(ga);
+        GrowScope as_is(1.0);      // (per lane, not per read)
         if (c->d_heads.ensure(slots * FQ_MAX_BUCKETS) && c->d_pool.ensure(slots * T.pool_cap)) break;
         const int waves = (int)(T.coop ? slots : slots / 64);
         if (waves <= 1) { c->err = "out of device memory for the search pools"; return FQ_ENOMEM; }
@@ -1359,7 +1378,9 @@ int stageA_search(Call &K) {
       // the packed array holds exactly the lists of the reads that completed, in work order (a failed read reports no hits): it
       // lands behind the lists of the earlier launches, and every read finds its list at the offset the device's prefix sum gave it
       const uint64_t base = c->st.aln.n;
-      CKM(c->d_hits.ensure_keep(base + total + 1, base) && c->p_aln.ensure_keep(base + total + 1, base));
+      // (a buffer that has to grow here is given room for the rounds behind this one as well: growing again means copying what it holds)
+      const uint64_t hits_need = base + total + 1, hits_room = hits_need + hits_need / 2;
+      CKM(c->d_hits.ensure_keep(c->d_hits.cap >= hits_need ? hits_need : hits_room, base) && c->p_aln.ensure_keep(c->p_aln.cap >= hits_need ? hits_need : hits_room, base));
       CK(fqdev::launch_pack_aln(c->d_aln.p, c->d_naln.p, c->d_off.p, T.aln_cap, (uint32_t)nw, c->d_hits.p + base));
       CK(fqdev::launch_aln_index(c->d_work.p, c->d_status.p, c->d_off.p, c->d_naln.p, base, c->d_aoff.p, c->d_an.p, nw));   // the device's own index of the lists (the records stay there)
       CK(fqdev::copy_pinned(c->p_aln.p + base, c->d_hits.p + base, total * sizeof(FqAln), 0));
@@ -2309,6 +2330,10 @@ int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
   NodePin pin;
   struct PoolScope { FqWorkPool *prev; explicit PoolScope(FqWorkPool *p) : prev(tl_pool) { tl_pool = p; } ~PoolScope() { tl_pool = prev; } } pool_scope(&c->pool);
   (void)fqdev::stream_aux(0);      // (an error return may have left the context on its second stream)
+  // (a short first call of a long stream sizes what it allocates for the calls behind it: tl_grow)
+  const double grow = c->in_kind == 3 && c->tb && c->n_pairs > 0 && std::min<double>((double)c->max_pairs, (double)c->tb->pairs_behind) > (double)c->n_pairs
+                          ? std::min(16.0, std::min<double>((double)c->max_pairs, (double)c->tb->pairs_behind) / (double)c->n_pairs) : 1.0;
+  GrowScope grow_scope(grow);
   if (c->kn.trace) { fprintf(stderr, "[fq]   arena: %zu blocks, last call used %zu bytes:", c->arena.blocks.size(), c->arena.total); for (auto &b : c->arena.blocks) fprintf(stderr, " %zu", b.cap); fprintf(stderr, "\n"); }
   c->arena.reset();
   const fq_opts_t &o = c->o;
@@ -2317,7 +2342,11 @@ int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
   S.n_pairs = c->n_pairs;
   memset(out, 0, sizeof *out);
   out->n_pairs = c->n_pairs;
-  if (c->n_pairs == 0) return FQ_OK;
+  if (c->n_pairs == 0) {
+    // an empty batch is a call like any other to the consumers: empty text, nothing counted, and not the previous call's outputs
+    const int rc0 = emit_measure(K);
+    return rc0 ? rc0 : emit_fill(K);
+  }
   K.n = c->n_pairs; K.n2 = 2 * K.n; K.B = o.batch_pairs; K.n_sub = (K.n + K.B - 1) / K.B;
   K.par_min = c->kn.host_par_min;
   K.host_threads = c->kn.host_threads >= 0 ? c->kn.host_threads : o.host_threads > 0 ? o.host_threads : default_host_threads(c->ix);

@@ -910,11 +910,15 @@ int main(int argc, char **argv) {
     };
     for (const auto &input : inputs) align_input(A, input, K.ix, K.qc, out, ready, devices[0]);   // (not K.device: the opener thread is still writing K)
     ready();
-    if (K.bam && fq_bam_close(K.bam)) die("closing " + A.out_prefix + ".bam failed");
-    if (K.qc) {
-      if (fq_qc_write(K.qc)) die("writing the QC files failed");
-      fq_qc_destroy(K.qc);
-    }
+    // (the BAM file's last blocks and its close beside the QC files' writing: a third of a second of a deep run's tail)
+    bool bam_bad = false;
+    std::thread closer;
+    if (K.bam) closer = std::thread([&] { bam_bad = fq_bam_close(K.bam) != 0; mark("BAM file closed"); });
+    const bool qc_bad = K.qc && fq_qc_write(K.qc) != 0;
+    if (closer.joinable()) closer.join();
+    if (bam_bad) die("closing " + A.out_prefix + ".bam failed");
+    if (qc_bad) die("writing the QC files failed");
+    if (K.qc) fq_qc_destroy(K.qc);
     mark("QC files written");
     release_join();
     fq_index_destroy(K.ix);

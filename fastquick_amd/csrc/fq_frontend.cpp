@@ -746,6 +746,12 @@ void producer_main(fq_frontend *fe) {
     fe->ms_inflate += t_ms[0]; fe->ms_lines += t_ms[1]; fe->ms_records += t_ms[2]; fe->ms_slots += t_ms[3]; fe->ms_tokenise += t_ms[1] + t_ms[2] + t_ms[3];
     fe->n_launch_inflate += (int64_t)t_n[0]; fe->n_chunks += 1;
     fe->n_members += TB.members; fe->n_refused += TB.refused; fe->text_bytes += TB.text_bytes; fe->comp_bytes += TB.comp_bytes;
+    {   // how many pairs follow this batch, by the files' sizes and the bytes a pair has taken so far (a hint: fq_align_text sizes a short first call's buffers by it)
+      double left = 0;
+      for (int e = 0; e < NF; ++e) left += (double)fe->f[e].file_size;
+      left -= (double)fe->comp_bytes;
+      TB.pairs_behind = fe->comp_bytes > 0 && left > 0 ? (int64_t)(left * (double)fe->pairs_done / (double)fe->comp_bytes) : 0;
+    }
     // ---- the end of the stream, or of the device's part of it ----
     bool stream_end = false;
     if (last) {

@@ -849,10 +849,37 @@ extern "C" int fq_qc_add_last(fq_qc_t *q, fq_ctx_t *c) {
 }
 
 // ProcessCore, :2012-2028
+// x + 1.0 + 1.0 + ... (t times), every sum rounded as the loop would round it -- without the loop.  Between two powers of two every x + j (j whole) is a
+// multiple of the binade's unit, so those additions are exact and may be done at once; the one addition that crosses into the next binade rounds, and is done
+// alone.  (InsertSizeEstimator adds 1.0 per table line to cells that start at 1e-6: tens of millions of dependent additions for a deep run.)
+static double add_ones(double x, uint64_t t) {
+  while (t) {
+    if (!(x >= 1.0) || x >= 4503599627370496.0) { x += 1.0; --t; continue; }      // below 1 (the first addition rounds) or past 2^52 (every one may)
+    int e; (void)std::frexp(x, &e);                    // x in [2^(e-1), 2^e)
+    const double top = std::ldexp(1.0, e);
+    const double room = std::ceil(top - x) - 1.0;      // whole steps that stay below `top` (top - x is exact: same binade)
+    const uint64_t j = room < 1.0 ? 0 : (uint64_t)std::min<double>(room, (double)t);
+    if (j) { x += (double)j; t -= j; }
+    if (t) { x += 1.0; --t; }                          // the crossing
+  }
+  return x;
+}
+extern "C" double fq_qc_add_ones(double x, uint64_t t) { return add_ones(x, t); }      // (for the test that holds it to the loop)
+namespace {
+struct WriteTrace {
+  bool on; double t0, t;
+  WriteTrace() : on(getenv("FASTQUICK_TRACE") != nullptr), t0(now()), t(t0) {}
+  static double now() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return 1e3 * (double)ts.tv_sec + 1e-6 * (double)ts.tv_nsec; }
+  void mark(const char *what) { if (!on) return; const double n = now(); fprintf(stderr, "TRACE -   QC files   %8.1f ms  %s\n", n - t, what); t = n; }
+};
+}  // namespace
 extern "C" int fq_qc_write(fq_qc_t *q) {
   if (!q) return FQ_EINVAL;
+  WriteTrace wt;
   if (int rc = q->pull()) return rc;
+  wt.mark("sums fetched from the device");
   q->table.flush();
+  wt.mark(".InsertSizeTable flushed");
   const std::string &pre = q->out_prefix;
   {   // GetDepthDist, :1858-1918
     for (auto &chr : q->flank_idx) {
@@ -920,8 +947,8 @@ extern "C" int fq_qc_write(fq_qc_t *q) {
       const bool counted = q->est_valid && q->device_adds && !q->shard;
       if (counted) {
         for (int k = 0; k < kLimit; ++k) {
-          for (uint64_t t = q->est_hist[k]; t; --t) Obs[k] += 1.;
-          for (uint64_t t = q->est_hist[(pass == 0 ? 2 : 1) * (size_t)kLimit + k] + q->est_hist[3 * (size_t)kLimit + k]; t; --t) Mis[k] += 1.;
+          Obs[k] = add_ones(Obs[k], q->est_hist[k]);
+          Mis[k] = add_ones(Mis[k], q->est_hist[(pass == 0 ? 2 : 1) * (size_t)kLimit + k] + q->est_hist[3 * (size_t)kLimit + k]);
           totalPair += (int)(q->est_hist[k] + q->est_hist[(pass == 0 ? 2 : 1) * (size_t)kLimit + k] + q->est_hist[3 * (size_t)kLimit + k]);
         }
       }
@@ -967,6 +994,7 @@ extern "C" int fq_qc_write(fq_qc_t *q) {
     std::ofstream f(pre + ".AdjustedInsertSizeDist");
     for (size_t i = 0; i < fsum.size(); ++i) f << i << "\t" << fsum[i] << std::endl;
   }
+  wt.mark("depth, GC, cycle tables; insert size estimate");
   {   // GetInsertSizeDist's raw table, :1998-2002
     std::ofstream f(pre + ".RawInsertSizeDist");
     for (uint32_t i = 0; i != q->InsertDist.size(); ++i) f << i << "\t" << q->InsertDist[i] << std::endl;
@@ -976,37 +1004,51 @@ extern "C" int fq_qc_write(fq_qc_t *q) {
     for (auto &kv : q->contig_status)
       f << kv.first << "\t" << kv.second.overlapped << "\t" << kv.second.fully << "\t" << kv.second.pair_overlapped << "\t" << kv.second.fully_paired << std::endl;
   }
-  {   // GetPileup, :2030-2065 (the same bytes; a marker's line is put together in one buffer: a deep run's file is tens of megabytes of single characters)
+  // the markers in the order the two writers below walk them
+  struct Site { const std::string *chrom; int pos; unsigned k; };
+  std::vector<Site> sites;
+  for (auto &chr : q->vcf_table)
+    for (auto &site : chr.second) sites.push_back({&chr.first, (int)site.first, site.second});
+  const int WT = (int)std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)std::max(1, fq_host_cpus()), sites.size() / 64 + 1}));
+  const size_t per_site = (sites.size() + (size_t)WT - 1) / (size_t)WT;
+  {   // GetPileup, :2030-2065 (the same bytes; a deep run's file is tens of megabytes of single characters: the markers' lines are put together on several threads,
+      // a run of markers each, and written in order)
     FILE *fp = fopen((pre + ".Pileup").c_str(), "wb");
     const int qualoffset = (q->o.mode & FQ_MODE_IL13) ? 64 : 33;
-    std::string ln;
-    char num[16];
-    for (auto &chr : q->vcf_table)
-      for (auto &site : chr.second) {
-        const unsigned k = site.second;
+    std::vector<std::string> part((size_t)WT);
+    auto work = [&](int t) {
+      std::string &ln = part[(size_t)t];
+      char num[16];
+      const size_t lo = (size_t)t * per_site, hi = std::min(sites.size(), lo + per_site);
+      size_t need = 0;
+      for (size_t i = lo; i < hi; ++i) need += 48 + q->seq_vec[sites[i].k].size() * 8;
+      ln.reserve(need);
+      for (size_t i = lo; i < hi; ++i) {
+        const unsigned k = sites[i].k;
         if (q->seq_vec[k].empty()) continue;
-        ln.clear();
-        ln += chr.first; ln += '\t';
-        ln += std::to_string(site.first); ln += "\t.\t";
+        ln += *sites[i].chrom; ln += '\t';
+        ln += std::to_string(sites[i].pos); ln += "\t.\t";
         ln += std::to_string(q->strand_vec[k].size()); ln += '\t';
-        for (uint32_t t = 0; t != q->strand_vec[k].size(); ++t) ln += (char)(q->strand_vec[k][t] ? toupper(q->seq_vec[k][t]) : tolower(q->seq_vec[k][t]));
+        for (uint32_t t2 = 0; t2 != q->strand_vec[k].size(); ++t2) ln += (char)(q->strand_vec[k][t2] ? toupper(q->seq_vec[k][t2]) : tolower(q->seq_vec[k][t2]));
         ln += '\t';
-        for (uint32_t t = 0; t != q->qual_vec[k].size(); ++t) ln += char(q->qual_vec[k][t] + qualoffset);
+        for (uint32_t t2 = 0; t2 != q->qual_vec[k].size(); ++t2) ln += char(q->qual_vec[k][t2] + qualoffset);
         ln += '\t';
         ln.append((const char *)q->maq_vec[k].data(), q->maq_vec[k].size());
         ln += '\t';
-        for (uint32_t t = 0; t != q->cycle_vec[k].size(); ++t) {
-          int v = q->cycle_vec[k][t], n = 0;
+        for (uint32_t t2 = 0; t2 != q->cycle_vec[k].size(); ++t2) {
+          int v = q->cycle_vec[k][t2], n = 0;
           if (v < 0) { ln += '-'; v = -v; }
           do { num[n++] = (char)('0' + v % 10); v /= 10; } while (v);
           while (n) ln += num[--n];
-          if (t != q->cycle_vec[k].size() - 1) ln += ',';
+          if (t2 != q->cycle_vec[k].size() - 1) ln += ',';
         }
         ln += '\n';
-        if (fp) fwrite(ln.data(), 1, ln.size(), fp);
       }
-    if (fp) fclose(fp);
+    };
+    if (WT == 1) work(0); else q->pool.run(WT, work);
+    if (fp) { for (auto &ln : part) if (!ln.empty()) fwrite(ln.data(), 1, ln.size(), fp); fclose(fp); }
   }
+  wt.mark(".Pileup");
   {   // SummaryOutput, :2343-2483
     std::ofstream fq(pre + ".FASTQ.csv");
     fq << "FileIndex,PairEnd1,PairEnd2" << std::endl;
@@ -1063,7 +1105,8 @@ extern "C" int fq_qc_write(fq_qc_t *q) {
   {   // GetVCF, :2185-2275 (CalLikelihood :2113-2155).  The arithmetic types are the reference's: float accumulators and priors,
       // pow / the 0.5-minus term in double, every other log10 on a float (std::log10(float)), PHRED = (-10) * log10(x), REV_PHRED =
       // pow(10.0, x / -10.0); the file carries the day it was written in its second line.
-    std::ofstream f(pre + ".vcf");
+    std::ofstream fout(pre + ".vcf");
+    std::ofstream &f = fout;
     char day[100] = {0};
     { const time_t now = time(nullptr); strftime(day, sizeof day, "%Y%m%d", localtime(&now)); }
     f << "##fileformat=VCFv4.2\n" << "##fileDate=" << day << "\n" << "##source=VerifyBamID2\n";
@@ -1072,7 +1115,6 @@ extern "C" int fq_qc_write(fq_qc_t *q) {
     f << "##FORMAT=<ID=GP,Number=1,Type=String,Description=\"Genotype\">\n";
     f << "##FORMAT=<ID=PL,Number=G,Type=Integer,Description=\"Normalized, Phred-scaled likelihoods for genotypes as defined in the VCF specification\">\n";
     f << "#CHROM\tPOS\tID\tREF\tALT\tQUAL\tFILTER\tINFO\tFORMAT\tIntendedSample\n";
-    float alleleFrq = 0.;
     // CalLikelihood's terms per quality value (the pileups keep `char` qualities), evaluated with the reference's types: float seq_error = pow(10.0, q / -10.0);
     // std::log10 of a float expression where the expression is float, of a double where it is double
     struct VcfTerms { float one_minus, third, two_thirds; double half_minus; };     // (0.5 - seq_error / 3 is a double expression: its log10 is added as a double)
@@ -1084,9 +1126,14 @@ extern "C" int fq_qc_write(fq_qc_t *q) {
       T.one_minus = std::log10(1 - seq_error); T.half_minus = std::log10(0.5 - seq_error / 3); T.third = std::log10(seq_error / 3); T.two_thirds = std::log10(2 * seq_error / 3);
       vcf_terms[(size_t)v] = T;
     }
-    for (auto &chr : q->vcf_table)
-      for (auto &site : chr.second) {
-        const unsigned k = site.second;
+    // (a marker's line depends on its own pileup alone: runs of markers on several threads, each into a stream of its own with the file stream's formatting, written in order)
+    std::vector<std::string> part((size_t)WT);
+    auto work = [&](int t) {
+      std::ostringstream f;
+      float alleleFrq = 0.;
+      const size_t lo = (size_t)t * per_site, hi = std::min(sites.size(), lo + per_site);
+      for (size_t si = lo; si < hi; ++si) {
+        const unsigned k = sites[si].k;
         const fq_qc::Marker &m = q->markers[k];
         std::string af;   // value of the INFO key AF
         bool has_af = false;
@@ -1122,7 +1169,12 @@ extern "C" int fq_qc_write(fq_qc_t *q) {
         const char *gt = post[0] < post[1] ? (post[0] < post[2] ? "0/0:" : "1/1:") : (post[1] < post[2] ? "0/1:" : "1/1:");
         f << gt << PL[0] << "," << PL[1] << "," << PL[2] << ":" << post[0] << "," << post[1] << "," << post[2] << "\n";
       }
+      part[(size_t)t] = f.str();
+    };
+    if (WT == 1) work(0); else q->pool.run(WT, work);
+    for (auto &ln : part) fout.write(ln.data(), (std::streamsize)ln.size());
   }
+  wt.mark("summaries, .vcf");
   return FQ_OK;
 }
 

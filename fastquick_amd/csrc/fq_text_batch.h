@@ -14,6 +14,7 @@ struct fq_text_batch {
   const char *d_names = nullptr;
   std::vector<char> first_names;   // [n_sub][2][name_stride]: the names of every reference batch's first pair (src/BwtMapper.cpp:2087-2092 compares them)
   int64_t text_bytes = 0, comp_bytes = 0, members = 0, refused = 0;
+  int64_t pairs_behind = 0;        // an estimate of the pairs that follow this batch in the stream (0: unknown or none)
   int slot = -1;
 };
 

@@ -205,3 +205,31 @@ def test_two_fastq_pairs_merge_to_the_references_files(on_device, golden_cases, 
     assert not bad, explain(bad)
     want = b"".join(l for l in open(os.path.join(g["dir"], "ref_fqlist.sam"), "rb").read().splitlines(keepends=True) if not l.startswith(b"@"))
     assert sam == want
+
+
+def test_estimator_cells_added_at_once_equal_the_loop(emu_lib):
+    """The estimator's cells start at 1e-6 and take 1.0 per table line (src/InsertSizeEstimator.cpp:43-143); the device path hands over counts, and fq_qc_write adds them
+    binade by binade (fq_qc.cpp: add_ones) instead of one by one: the same roundings, held to the loop here."""
+    import ctypes as C
+    import numpy as np
+    lib = emu_lib
+    lib.fq_qc_add_ones.restype = C.c_double
+    lib.fq_qc_add_ones.argtypes = [C.c_double, C.c_uint64]
+    rng = np.random.default_rng(77)
+    starts = [1e-6, 0.0, 0.3, 0.9999999999, 1.0, 1.000001, 1.5, 2.0 ** 20 - 0.5, 2.0 ** 30 + 0.25, 2.0 ** 52 - 3.5, 2.0 ** 52 - 1.0, 2.0 ** 53 - 2.0] + list(rng.random(6) * 1e-5)
+    counts = [0, 1, 2, 3, 7, 8, 9, 1023, 1024, 1025, 65535, 65537, 1000003] + [int(v) for v in rng.integers(1, 3000000, 8)]
+    for x0 in starts:
+        for t in counts:
+            x = np.float64(x0)
+            one = np.float64(1.0)
+            if t <= 70000:
+                for _ in range(t):
+                    x = x + one
+            else:      # (the loop itself, in blocks the float64 cumsum runs sequentially)
+                left = t
+                while left:
+                    n = min(left, 1 << 20)
+                    x = np.cumsum(np.concatenate(([x], np.ones(n))))[-1]
+                    left -= n
+            got = lib.fq_qc_add_ones(float(x0), t)
+            assert got == float(x), (x0, t, got, float(x))

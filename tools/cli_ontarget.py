@@ -48,7 +48,7 @@ def measure(exe, pre, ref, workdir, pairs=1 << 20, copies=8, read_len=150, threa
         cmd = [exe, "align", "--index_prefix", pre[:-len(".FASTQuick.fa")], "--fastq_1", big[0], "--fastq_2", big[1], "--out_prefix", os.path.join(workdir, "ont_out"),
                "--read_len", str(max(read_len, 151)), "--t", str(threads)] + (["--sam_out"] if mode == "sam_out" else []) + list(extra)
         if profile_dir:       # rocprofv3 --kernel-trace --stats around the command line itself (FQ_PROFILE_DIR): per-kernel times of the run
-            cmd = ["rocprofv3", "--kernel-trace", "--stats", "--output-format", "csv", "-d", os.path.join(profile_dir, mode), "-o", "p", "--"] + cmd
+            cmd = ["rocprofv3", "--kernel-trace"] + (["--memory-copy-trace"] if os.environ.get("FQ_PROFILE_COPIES") else []) + ["--stats", "--output-format", "csv", "-d", os.path.join(profile_dir, mode), "-o", "p", "--"] + cmd
         walls = []
         for _ in range(max(1, repeats)):      # (whole-process wall time on a shared host: the runs are listed, the best one is the rate)
             time.sleep(3.0)       # (a process started right behind another's exit waits for the driver to take that one's device memory back)
