@@ -528,6 +528,7 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
   //  chunk, the QC files: 80 ms of a 67 M-pair run)
   release_later([ctx_a, ctx2, fe] {
     fq_ctx_destroy(ctx_a);
+    mark("first context released");
     if (ctx2) fq_ctx_destroy(ctx2);
     if (fe) fq_frontend_close(fe);
     mark("contexts and front end released");
@@ -918,8 +919,8 @@ int main(int argc, char **argv) {
     if (closer.joinable()) closer.join();
     if (bam_bad) die("closing " + A.out_prefix + ".bam failed");
     if (qc_bad) die("writing the QC files failed");
-    if (K.qc) fq_qc_destroy(K.qc);
     mark("QC files written");
+    if (K.qc) { fq_qc_t *qc = K.qc; release_later([qc] { fq_qc_destroy(qc); mark("QC consumer released"); }); }      // (beside the contexts' release)
     release_join();
     fq_index_destroy(K.ix);
     mark("index released");

@@ -1582,8 +1582,10 @@ __global__ void __launch_bounds__(256) k_sam_fill(FqSamArgs a, int n) {
   if (i < n) fq_sam_fill_thread(a, i);
 }
 __global__ void __launch_bounds__(256) k_sam_body(FqSamArgs a, int n, int pieces) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int idx = (int)(t / pieces), c = (int)(t % pieces);
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int idx, c;
+  if (t < 0x100000000ull) { idx = (int)((uint32_t)t / (uint32_t)pieces); c = (int)((uint32_t)t - (uint32_t)idx * (uint32_t)pieces); }      // (a 64-bit division is a subroutine)
+  else { idx = (int)(t / (uint64_t)pieces); c = (int)(t % (uint64_t)pieces); }
   if (idx < n) fq_sam_body_piece(a, idx, c);
 }
 int launch_sam(int op, const FqSamArgs &a, int64_t n) {
@@ -1611,8 +1613,10 @@ __global__ void __launch_bounds__(256) k_bam_fill(FqBamArgs a, int n) {
   if (i < n) fq_bam_fill_thread(a, i);
 }
 __global__ void __launch_bounds__(256) k_bam_body(FqBamArgs a, int n, int pieces) {
-  const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int idx = (int)(t / pieces), c = (int)(t % pieces);
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int idx, c;
+  if (t < 0x100000000ull) { idx = (int)((uint32_t)t / (uint32_t)pieces); c = (int)((uint32_t)t - (uint32_t)idx * (uint32_t)pieces); }
+  else { idx = (int)(t / (uint64_t)pieces); c = (int)(t % (uint64_t)pieces); }
   if (idx < n) fq_bam_body_piece(a, idx, c);
 }
 int launch_bam(int op, const FqBamArgs &a, int64_t n) {

@@ -84,6 +84,47 @@ struct FqSamArgs {
   int32_t split;                 // 1: k_sam_fill leaves the SEQ / QUAL runs to k_sam_body (0: it writes whole lines; A/B, FASTQUICK_SAM_BODY=0)
   char *text;
 };
+// ---- sixteen bytes at a time ------------------------------------------------------------------------------------------------------------------
+// The SEQ / QUAL runs of a line (and a BAM record's packed bases and qualities) are stated byte by byte below (fq_sam_body_char, fq_bam_body_byte); the kernels that
+// write them take a piece of sixteen bytes that lies wholly inside one run in four 32-bit words: the same bytes, decided four at a time.
+struct FqB16 { uint32_t w[4]; };
+FQ_HD FqB16 fq_load16(const uint8_t *p) { FqB16 v; memcpy(&v, p, 16); return v; }
+FQ_HD void fq_store16(void *p, const FqB16 &v) { memcpy(p, &v, 16); }
+FQ_HD uint32_t fq_bswap32(uint32_t x) { return (x >> 24) | ((x >> 8) & 0xff00u) | ((x << 8) & 0xff0000u) | (x << 24); }
+FQ_HD FqB16 fq_rev16(const FqB16 &v) { FqB16 r; r.w[0] = fq_bswap32(v.w[3]); r.w[1] = fq_bswap32(v.w[2]); r.w[2] = fq_bswap32(v.w[1]); r.w[3] = fq_bswap32(v.w[0]); return r; }
+// 0xff in every byte of w that equals the byte of pat there
+FQ_HD uint32_t fq_swar_eq(uint32_t w, uint32_t pat) {
+  const uint32_t t = w ^ pat;
+  const uint32_t nz = ((((t & 0x7f7f7f7fu) + 0x7f7f7f7fu) | t) >> 7) & 0x01010101u;      // 1 where the byte differs
+  return (nz ^ 0x01010101u) * 0xffu;
+}
+// "ACGTN"[min(nt4(x), 4)] of four bytes (comp: "TGCAN"): nt4 takes A/a C/c G/g T/t and nothing else to 0..3 (fq_nt4), and x & 0xdf is 'A' for 'A' and 'a' alone
+struct FqBaseMasks { uint32_t a, c, g, t; };
+FQ_HD FqBaseMasks fq_swar_bases(uint32_t w) {
+  const uint32_t up = w & 0xdfdfdfdfu;
+  FqBaseMasks m;
+  m.a = fq_swar_eq(up, 0x41414141u); m.c = fq_swar_eq(up, 0x43434343u); m.g = fq_swar_eq(up, 0x47474747u); m.t = fq_swar_eq(up, 0x54545454u);
+  return m;
+}
+FQ_HD uint32_t fq_swar_letters(uint32_t w, bool comp) {
+  const FqBaseMasks m = fq_swar_bases(w);
+  const uint32_t la = comp ? 0x54545454u : 0x41414141u, lc = comp ? 0x47474747u : 0x43434343u, lg = comp ? 0x43434343u : 0x47474747u, lt = comp ? 0x41414141u : 0x54545454u;
+  return (m.a & la) | (m.c & lc) | (m.g & lg) | (m.t & lt) | (~(m.a | m.c | m.g | m.t) & 0x4e4e4e4eu);
+}
+// the BAM codes of four bases (A 1, C 2, G 4, T 8, anything else 15; comp: of their complements), one per byte
+FQ_HD uint32_t fq_swar_codes(uint32_t w, bool comp) {
+  const FqBaseMasks m = fq_swar_bases(w);
+  const uint32_t ca = comp ? 0x08080808u : 0x01010101u, cc = comp ? 0x04040404u : 0x02020202u, cg = comp ? 0x02020202u : 0x04040404u, ct = comp ? 0x01010101u : 0x08080808u;
+  return (m.a & ca) | (m.c & cc) | (m.g & cg) | (m.t & ct) | (~(m.a | m.c | m.g | m.t) & 0x0f0f0f0fu);
+}
+// four codes (bytes b0 b1 b2 b3, b0 at the lowest address) -> the two packed bytes b0 << 4 | b1, b2 << 4 | b3, in bits 0..15
+FQ_HD uint32_t fq_swar_pack2(uint32_t codes) {
+  const uint32_t x = (codes << 4) | (codes >> 8);
+  return (x & 0xffu) | ((x >> 8) & 0xff00u);
+}
+// every byte minus 33, modulo 256
+FQ_HD uint32_t fq_swar_sub33(uint32_t x) { return ((x | 0x80808080u) - 0x21212121u) ^ (~x & 0x80808080u); }
+
 // The SEQ column, a tab and the QUAL column of a line: three quarters of its bytes.  One statement of every character, used by the line routine and by the
 // kernel that writes these runs sixteen bytes per thread (coalesced, where a thread per record puts its lanes' bytes 430 apart).
 struct FqSamBody { int nomatch, strand, len, full_len, clip_len, qsub; const uint8_t *row, *qual; };
@@ -269,6 +310,18 @@ FQ_HD void fq_sam_body_piece(const FqSamArgs &A, int idx, int c) {
   B.qual = A.qual + (size_t)idx * (size_t)A.qual_stride;
   const int n = fq_sam_body_len(B);
   char *dst = A.text + A.off[idx] + (meta & 0xffffu) + b0;
+  const int slen = B.nomatch ? B.len : B.full_len;
+  if (b0 + FQ_SAM_PIECE <= slen && !(B.nomatch && B.strand)) {      // wholly inside SEQ, read off the row forwards or (a hit on the reverse strand) backwards and complemented
+    FqB16 v = B.strand ? fq_rev16(fq_load16(B.row + (B.full_len - FQ_SAM_PIECE - b0))) : fq_load16(B.row + b0);
+    for (int k = 0; k < 4; ++k) v.w[k] = fq_swar_letters(v.w[k], B.strand != 0);
+    fq_store16(dst, v);
+    return;
+  }
+  if (b0 > slen && b0 + FQ_SAM_PIECE <= n && B.qsub == 0) {          // wholly inside QUAL: bytes as they came, the first len of them backwards on the reverse strand
+    const int j0 = b0 - slen - 1;
+    if (!B.strand || j0 >= B.len) { fq_store16(dst, fq_load16(B.qual + j0)); return; }
+    if (j0 + FQ_SAM_PIECE <= B.len) { fq_store16(dst, fq_rev16(fq_load16(B.qual + (B.len - FQ_SAM_PIECE - j0)))); return; }
+  }
   for (int t = 0; t < FQ_SAM_PIECE && b0 + t < n; ++t) dst[t] = fq_sam_body_char(B, b0 + t);
 }
 
@@ -496,6 +549,30 @@ FQ_HD void fq_bam_body_piece(const FqBamArgs &A, int idx, int c) {
   const int n = fq_bam_body_len(B), b0 = c * FQ_SAM_PIECE;
   if (b0 >= n) return;
   uint8_t *dst = A.out + A.off[idx] + (meta & 0xffffu) + b0;
+  const int nseq = (B.l_seq + 1) / 2;
+  if (B.any && 2 * (b0 + FQ_SAM_PIECE) <= B.l_seq) {                 // sixteen bytes of packed bases = 32 bases of the row, forwards or backwards and complemented
+    const uint8_t *src = B.strand ? B.row + (B.full_len - 2 * FQ_SAM_PIECE - 2 * b0) : B.row + 2 * b0;
+    FqB16 lo = fq_load16(src), hi = fq_load16(src + 16);
+    if (B.strand) { const FqB16 t = fq_rev16(hi); hi = fq_rev16(lo); lo = t; }
+    FqB16 o;
+    o.w[0] = fq_swar_pack2(fq_swar_codes(lo.w[0], B.strand != 0)) | fq_swar_pack2(fq_swar_codes(lo.w[1], B.strand != 0)) << 16;
+    o.w[1] = fq_swar_pack2(fq_swar_codes(lo.w[2], B.strand != 0)) | fq_swar_pack2(fq_swar_codes(lo.w[3], B.strand != 0)) << 16;
+    o.w[2] = fq_swar_pack2(fq_swar_codes(hi.w[0], B.strand != 0)) | fq_swar_pack2(fq_swar_codes(hi.w[1], B.strand != 0)) << 16;
+    o.w[3] = fq_swar_pack2(fq_swar_codes(hi.w[2], B.strand != 0)) | fq_swar_pack2(fq_swar_codes(hi.w[3], B.strand != 0)) << 16;
+    fq_store16(dst, o);
+    return;
+  }
+  if (b0 >= nseq && B.qsub == 0) {                                    // wholly inside the qualities that are there: the bytes minus 33
+    const int j0 = b0 - nseq;
+    if (j0 + FQ_SAM_PIECE <= (B.l_seq < B.full_len ? B.l_seq : B.full_len)) {
+      bool ok = true;
+      FqB16 v;
+      if (!B.strand || j0 >= B.len) v = fq_load16(B.qual + j0);
+      else if (j0 + FQ_SAM_PIECE <= B.len) v = fq_rev16(fq_load16(B.qual + (B.len - FQ_SAM_PIECE - j0)));
+      else ok = false;
+      if (ok) { for (int k = 0; k < 4; ++k) v.w[k] = fq_swar_sub33(v.w[k]); fq_store16(dst, v); return; }
+    }
+  }
   for (int t = 0; t < FQ_SAM_PIECE && b0 + t < n; ++t) dst[t] = (uint8_t)fq_bam_body_byte(B, b0 + t);
 }
 

@@ -41,6 +41,7 @@ def measure(exe, pre, ref, workdir, pairs=1 << 20, copies=8, read_len=150, threa
     synth.write_param(pre, ref, sum(1 for n in ref.names if n.endswith("|L")))
     with open(pre + ".genome.fa.fai", "w") as fh:
         fh.write("1\t%d\t3\t60\t61\n" % len(ref.genome))
+    os.sync()      # (the gigabytes of input just written are on their way to the disk: a run timed beside their write-back waits for its own output files' pages)
     total = pairs * copies
     res = {"pairs": total, "distinct_pairs": pairs, "copies": copies, "read_len": read_len, "text_bytes": text_bytes * copies,
            "file_bytes": sum(os.path.getsize(p) for p in big), "input": "two BGZF FASTQ files (zlib level 1), every pair from a marker flank"}
