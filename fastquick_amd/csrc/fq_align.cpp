@@ -57,41 +57,75 @@ thread_local double tl_grow = 1.0;
 struct GrowScope { double prev; explicit GrowScope(double g) : prev(tl_grow) { tl_grow = g; } ~GrowScope() { tl_grow = prev; } };
 inline size_t grown(size_t n) { return tl_grow > 1.0 ? (size_t)((double)n * tl_grow * 1.02) : 0; }
 
+// hipFree and hipHostFree wait for every stream of the device -- the other context's consumers streaming gigabytes of text to the host included: a buffer that
+// had to grow by a hair in the middle of a call cost that call 100-250 ms now and then.  A buffer that grows during a call is therefore not freed there but retired
+// to its context's list (tl_retired, set by the call), from which the growth of a LATER call may take it again (nothing of the call that retired it is in flight
+// by then); the list is freed with the context, or at the start of a call once it holds more than kRetiredMax.
+struct Retired {
+  struct B { void *p; size_t bytes; uint64_t call; bool host; };
+  std::vector<B> v;
+  uint64_t call = 0;
+  static constexpr size_t kRetiredMax = (size_t)12 << 30;
+  size_t bytes(bool host) const { size_t t = 0; for (auto &b : v) if (b.host == host) t += b.bytes; return t; }
+  void drain() { for (auto &b : v) { if (b.host) fqdev::hfree(b.p); else fqdev::dfree(b.p); } v.clear(); }
+  void next_call() { ++call; if (bytes(false) > kRetiredMax || bytes(true) > kRetiredMax / 8) drain(); }
+  ~Retired() { drain(); }
+};
+thread_local Retired *tl_retired = nullptr;
+struct RetiredScope { Retired *prev; explicit RetiredScope(Retired *r) : prev(tl_retired) { tl_retired = r; } ~RetiredScope() { tl_retired = prev; } };
+inline void retire(void *p, size_t bytes, bool host) {
+  if (!p) return;
+  if (tl_retired) tl_retired->v.push_back({p, bytes, tl_retired->call, host});
+  else if (host) fqdev::hfree(p); else fqdev::dfree(p);
+}
+// a block of at least `bytes` (and not half as much again) that an earlier call retired, or a fresh one
+inline void *obtain(size_t bytes, bool host, size_t *got) {
+  if (tl_retired) {
+    int best = -1;
+    for (int i = 0; i < (int)tl_retired->v.size(); ++i) {
+      const Retired::B &b = tl_retired->v[(size_t)i];
+      if (b.host == host && b.call < tl_retired->call && b.bytes >= bytes && b.bytes <= bytes + bytes / 2 && (best < 0 || b.bytes < tl_retired->v[(size_t)best].bytes)) best = i;
+    }
+    if (best >= 0) { void *q = tl_retired->v[(size_t)best].p; *got = tl_retired->v[(size_t)best].bytes; tl_retired->v.erase(tl_retired->v.begin() + best); return q; }
+  }
+  void *q = host ? fqdev::hmalloc(bytes) : fqdev::dmalloc(bytes);
+  if (!q && tl_retired && !tl_retired->v.empty()) { tl_retired->drain(); q = host ? fqdev::hmalloc(bytes) : fqdev::dmalloc(bytes); }      // (out of memory: what was kept goes first)
+  *got = bytes;
+  return q;
+}
+
 template <class T> struct DevBuf {
   T *p = nullptr;
   size_t cap = 0;
   ~DevBuf() { fqdev::dfree(p); }
+  bool take(size_t want) { size_t got = 0; p = (T *)obtain(want * sizeof(T), false, &got); cap = p ? got / sizeof(T) : 0; return p != nullptr; }
+  // slack against regrowth: a quarter for small buffers, a sixteenth for the multi-GB ones (chunks of a stream differ by a per cent or two)
+  static size_t slack(size_t n) { return std::max(std::min<size_t>(n / 4, (size_t)16 << 20), n / 16); }
   bool ensure(size_t n) {
     if (n <= cap) return true;
-    fqdev::dfree(p);
-    p = nullptr;
-    if (const size_t g = grown(n)) { cap = g + 64; p = (T *)fqdev::dmalloc(cap * sizeof(T)); }
-    if (!p) { cap = n + std::min<size_t>(n / 4, (size_t)16 << 20) + 64;   /* some slack against regrowth, bounded for the multi-GB buffers */ p = (T *)fqdev::dmalloc(cap * sizeof(T)); }
-    if (!p) { cap = n; p = (T *)fqdev::dmalloc(cap * sizeof(T)); }
-    if (!p) { cap = 0; return false; }
-    return true;
+    retire(p, cap * sizeof(T), false);
+    p = nullptr; cap = 0;
+    if (const size_t g = grown(n)) { if (take(g + 64)) return true; }
+    if (take(n + slack(n) + 64)) return true;
+    return take(n);
   }
-  // the consumers' multi-GB buffers (SAM text, BAM records and members): an eighth of slack, so that chunks whose sizes differ by a few per cent do not
-  // free and allocate gigabytes -- hipFree waits for the device -- on every call
+  // the consumers' multi-GB buffers (SAM text, BAM records and members): an eighth of slack
   bool ensure_roomy(size_t n) {
     if (n <= cap) return true;
-    fqdev::dfree(p);
-    cap = std::max(n + n / 8, grown(n)) + 64;
-    p = (T *)fqdev::dmalloc(cap * sizeof(T));
-    if (!p) { cap = n + n / 8 + 64; p = (T *)fqdev::dmalloc(cap * sizeof(T)); }
-    if (!p) { cap = n; p = (T *)fqdev::dmalloc(cap * sizeof(T)); }
-    if (!p) { cap = 0; return false; }
-    return true;
+    retire(p, cap * sizeof(T), false);
+    p = nullptr; cap = 0;
+    if (take(std::max(n + n / 8, grown(n)) + 64)) return true;
+    if (take(n + n / 8 + 64)) return true;
+    return take(n);
   }
   bool ensure_keep(size_t n, size_t keep) {   // as ensure, but the first `keep` elements survive a reallocation (copied on the compute stream)
     if (n <= cap) return true;
-    size_t ncap = std::max(n + std::min<size_t>(n / 4, (size_t)16 << 20), grown(n)) + 64;
-    T *q = (T *)fqdev::dmalloc(ncap * sizeof(T));
-    if (!q) { ncap = n + 64; q = (T *)fqdev::dmalloc(ncap * sizeof(T)); }
-    if (!q) return false;
-    if (keep && (fqdev::d2d(q, p, keep * sizeof(T)) || fqdev::sync())) { fqdev::dfree(q); return false; }
-    fqdev::dfree(p);
-    p = q; cap = ncap;
+    DevBuf<T> q;
+    if (!q.take(std::max(n + slack(n), grown(n)) + 64) && !q.take(n + 64)) return false;
+    if (keep && (fqdev::d2d(q.p, p, keep * sizeof(T)) || fqdev::sync())) return false;      // (q's destructor frees the new block)
+    retire(p, cap * sizeof(T), false);
+    p = q.p; cap = q.cap;
+    q.p = nullptr; q.cap = 0;
     return true;
   }
 };
@@ -101,24 +135,22 @@ template <class T> struct PinBuf {   // pinned host staging: device <-> host cop
   T *p = nullptr;
   size_t cap = 0;
   ~PinBuf() { fqdev::hfree(p); }
+  bool take(size_t want) { size_t got = 0; p = (T *)obtain(want * sizeof(T), true, &got); cap = p ? got / sizeof(T) : 0; return p != nullptr; }
   bool ensure(size_t n) {
     if (n <= cap) return true;
-    fqdev::hfree(p);
-    cap = std::max(n + n / 4, grown(n)) + 64;
-    p = (T *)fqdev::hmalloc(cap * sizeof(T));
-    if (!p) { cap = n + 64; p = (T *)fqdev::hmalloc(cap * sizeof(T)); }
-    if (!p) { cap = 0; return false; }
-    return true;
+    retire(p, cap * sizeof(T), true);
+    p = nullptr; cap = 0;
+    if (take(std::max(n + n / 4, grown(n)) + 64)) return true;
+    return take(n + 64);
   }
   bool ensure_keep(size_t n, size_t keep) {   // as ensure, but the first `keep` elements survive a reallocation
     if (n <= cap) return true;
-    size_t ncap = std::max(n + n / 4, grown(n)) + 64;
-    T *q = (T *)fqdev::hmalloc(ncap * sizeof(T));
-    if (!q) { ncap = n + 64; q = (T *)fqdev::hmalloc(ncap * sizeof(T)); }
-    if (!q) return false;
-    if (keep) memcpy(q, p, keep * sizeof(T));
-    fqdev::hfree(p);
-    p = q; cap = ncap;
+    PinBuf<T> q;
+    if (!q.take(std::max(n + n / 4, grown(n)) + 64) && !q.take(n + 64)) return false;
+    if (keep) memcpy(q.p, p, keep * sizeof(T));
+    retire(p, cap * sizeof(T), true);
+    p = q.p; cap = q.cap;
+    q.p = nullptr; q.cap = 0;
     return true;
   }
 };
@@ -138,10 +170,10 @@ struct PinArena {
   void reset() {
     pending.clear();
     if (blocks.size() > 1) {   // one block of the size the last call needed
-      for (auto &b : blocks) fqdev::hfree(b.p);
+      for (auto &b : blocks) retire(b.p, b.cap, true);
       blocks.clear();
-      const size_t want = std::max(total + total / 4, (size_t)((double)total * last_grow * 1.02));
-      uint8_t *p = (uint8_t *)fqdev::hmalloc(want);
+      size_t want = std::max(total + total / 4, (size_t)((double)total * last_grow * 1.02));
+      uint8_t *p = (uint8_t *)obtain(want, true, &want);
       if (p) blocks.push_back({p, want});
     }
     used = 0; total = 0; last_grow = tl_grow;
@@ -150,8 +182,8 @@ struct PinArena {
     bytes = (bytes + 63) & ~(size_t)63;
     total += bytes;
     if (blocks.empty() || used + bytes > blocks.back().cap) {
-      const size_t cap = std::max<size_t>(std::max(bytes, grown(bytes)), (size_t)4 << 20);
-      uint8_t *p = (uint8_t *)fqdev::hmalloc(cap);
+      size_t cap = std::max<size_t>(std::max(bytes, grown(bytes)), (size_t)4 << 20);
+      uint8_t *p = (uint8_t *)obtain(cap, true, &cap);
       if (!p) return nullptr;
       blocks.push_back({p, cap});
       used = 0;
@@ -298,6 +330,7 @@ struct fq_ctx {
   vector<int32_t> h_len_trim, h_sub_max;
   const int32_t *h_pair_list = nullptr;   // survivor pair -> pair of the batch (p_pairs, where the copy engine lands it)
   const FqSurvInfo *h_surv = nullptr;     // ... and the survivors' search indices (p_surv)
+  Retired retired;                     // buffers that grew during a call: freed with the context (hipFree waits for the device)
   PinArena arena;
   PinBuf<int32_t> p_i32;
   PinBuf<FqSurvInfo> p_surv;
@@ -2334,6 +2367,8 @@ int run_call_stages(fq_ctx *c, fq_result_batch_t *out) {
   const double grow = c->in_kind == 3 && c->tb && c->n_pairs > 0 && std::min<double>((double)c->max_pairs, (double)c->tb->pairs_behind) > (double)c->n_pairs
                           ? std::min(16.0, std::min<double>((double)c->max_pairs, (double)c->tb->pairs_behind) / (double)c->n_pairs) : 1.0;
   GrowScope grow_scope(grow);
+  c->retired.next_call();
+  RetiredScope retired_scope(&c->retired);
   if (c->kn.trace) { fprintf(stderr, "[fq]   arena: %zu blocks, last call used %zu bytes:", c->arena.blocks.size(), c->arena.total); for (auto &b : c->arena.blocks) fprintf(stderr, " %zu", b.cap); fprintf(stderr, "\n"); }
   c->arena.reset();
   const fq_opts_t &o = c->o;

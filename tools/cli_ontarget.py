@@ -52,6 +52,12 @@ def measure(exe, pre, ref, workdir, pairs=1 << 20, copies=8, read_len=150, threa
             cmd = ["rocprofv3", "--kernel-trace"] + (["--memory-copy-trace"] if os.environ.get("FQ_PROFILE_COPIES") else []) + ["--stats", "--output-format", "csv", "-d", os.path.join(profile_dir, mode), "-o", "p", "--"] + cmd
         walls = []
         for _ in range(max(1, repeats)):      # (whole-process wall time on a shared host: the runs are listed, the best one is the rate)
+            # the previous run's output files go first, and their pages with them: truncating a gigabyte of dirty pages when the BAM file is opened, or writing beside
+            # their write-back, costs a run up to a second that is not its own
+            for fn in os.listdir(workdir):
+                if fn.startswith("ont_out."):
+                    os.remove(os.path.join(workdir, fn))
+            os.sync()
             time.sleep(3.0)       # (a process started right behind another's exit waits for the driver to take that one's device memory back)
             t0 = time.perf_counter()
             run_ = subprocess.run(cmd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE)
