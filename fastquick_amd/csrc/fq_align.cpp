@@ -65,7 +65,7 @@ struct Retired {
   struct B { void *p; size_t bytes; uint64_t call; bool host; };
   std::vector<B> v;
   uint64_t call = 0;
-  static constexpr size_t kRetiredMax = (size_t)12 << 30;
+  static constexpr size_t kRetiredMax = (size_t)6 << 30;
   size_t bytes(bool host) const { size_t t = 0; for (auto &b : v) if (b.host == host) t += b.bytes; return t; }
   void drain() { for (auto &b : v) { if (b.host) fqdev::hfree(b.p); else fqdev::dfree(b.p); } v.clear(); }
   void next_call() { ++call; if (bytes(false) > kRetiredMax || bytes(true) > kRetiredMax / 8) drain(); }
