@@ -1678,12 +1678,15 @@ __global__ void __launch_bounds__(256) k_qc_pile_fill(FqQcArgs a, int n) {
 }
 // a wavefront per record, resident workgroups walking the records: 64 consecutive positions of a read are one atomic instruction on the depth
 // tables; the quality / cycle histograms are kept per workgroup in LDS and reach the consumer's once, at the end
+// (L lanes per record: what a record costs is the latency of its chain of dependent loads -- its contig, the contig's regions, the CIGAR, the bases --, and a wavefront
+//  that walks 64 / L records side by side pays it once for all of them; the per-base work is a few instructions either way)
+template <int L>
 __global__ void __launch_bounds__(256) k_qc_base(FqQcArgs a, int n) {
   __shared__ uint32_t hist[4 * 256];
   for (int b = threadIdx.x; b < 4 * 256; b += 256) hist[b] = 0;
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = (blockIdx.x * 256 + threadIdx.x) >> 6, n_waves = (gridDim.x * 256) >> 6;
-  for (int idx = wave; idx < n; idx += n_waves) fq_qc_base_record(a, idx, lane, 64, hist);
+  const int lane = threadIdx.x & (L - 1), slot = (blockIdx.x * 256 + threadIdx.x) / L, n_slots = (gridDim.x * 256) / L;
+  for (int idx = slot; idx < n; idx += n_slots) fq_qc_base_record(a, idx, lane, L, hist);
   __syncthreads();
   for (int b = threadIdx.x; b < 4 * 256; b += 256) if (hist[b]) atomicAdd((unsigned long long *)&a.hist[b], (unsigned long long)hist[b]);
 }
@@ -1700,7 +1703,14 @@ int launch_qc(int op, const FqQcArgs &a, int64_t n) {
   if (op == FQ_QOP_PAIR) hipExtLaunchKernelGGL(k_qc_pair, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
   else if (op == FQ_QOP_IST_FILL) hipExtLaunchKernelGGL(k_qc_ist_fill, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
   else if (op == FQ_QOP_PILE_FILL) hipExtLaunchKernelGGL(k_qc_pile_fill, dim3(nblk((uint64_t)n, 256)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
-  else if (op == FQ_QOP_BASE) hipExtLaunchKernelGGL(k_qc_base, dim3(std::min<unsigned>(nblk((uint64_t)n, 4), 256u * 8u)), dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
+  else if (op == FQ_QOP_BASE) {
+    static const int lanes = [] { const char *e = getenv("FASTQUICK_QC_LANES"); const int v = e ? atoi(e) : 16; return v == 64 || v == 32 || v == 8 ? v : 16; }();      // (A/B)
+    const dim3 grid(std::min<unsigned>(nblk((uint64_t)n * (uint64_t)lanes, 256), 256u * 8u));
+    if (lanes == 64) hipExtLaunchKernelGGL(k_qc_base<64>, grid, dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
+    else if (lanes == 32) hipExtLaunchKernelGGL(k_qc_base<32>, grid, dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
+    else if (lanes == 8) hipExtLaunchKernelGGL(k_qc_base<8>, grid, dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
+    else hipExtLaunchKernelGGL(k_qc_base<16>, grid, dim3(256), 0, g_stream, e0, e1, 0, a, (int)n);
+  }
   else { g_err = "statistics: unknown operation"; return -1; }
   FQ_HIP(hipGetLastError());
   return 0;

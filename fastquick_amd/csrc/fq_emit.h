@@ -621,7 +621,7 @@ struct FqQcArgs {
   int32_t cal_dup, shard;
   uint64_t ord_base;             // pairs the consumer has seen before this call (orders the first counts of the sex-chromosome contigs)
   // the consumer's tables
-  uint32_t *depth, *q20, *q30;   // DIFFERENCE tables over the flank positions (+1 where a run of counted positions begins, -1 behind its end; modulo 2^32)
+  uint32_t *depth, *q20, *q30;   // over the flank positions.  depth: a DIFFERENCE table (+1 where a run of counted positions begins, -1 behind its end; modulo 2^32); q20 / q30: the counted bases BELOW the threshold
   uint64_t *hist;                // [4][256] EmpRep, misEmpRep, EmpCycle, misEmpCycle
   uint64_t *insert_dist;         // [FQ_QC_INSERT_LIMIT]
   uint64_t *est_hist;            // [4][FQ_QC_INSERT_LIMIT] what InsertSizeEstimator reads back from the .InsertSizeTable lines (src/InsertSizeEstimator.cpp:43-143), counted as
@@ -967,11 +967,11 @@ FQ_HD void fq_qc_base_record(const FqQcArgs &A, int idx, int lane, int nl, uint3
     uint32_t rb_[3];
     for (int rg = lo; rg < r1 && nr < 3 && A.g.reg_start[rg] < abs0 + cl; ++rg, ++nr) { rs_[nr] = A.g.reg_start[rg]; re_[nr] = A.g.reg_end[rg]; rb_[nr] = A.g.reg_base[rg]; }
     const bool more = nr == 3 && lo + 3 < r1 && A.g.reg_start[lo + 3] < abs0 + cl;      // (more than three: the general walk below)
-    // Depth, Q20 depth and Q30 depth are kept as DIFFERENCE tables (the consumer's pull() sums them up): a run of consecutive positions that all count
-    // costs two atomic adds -- +1 where it begins, -1 behind its end -- instead of one per position.  A read's aligned block inside a flank region is
-    // one run for the depth; for the quality depths the runs are the stretches of bases at or above the threshold.  A position tells its own run
-    // boundaries from its two neighbours (looked at again here: no lane needs another's registers, and the bytes are in the L1).
-    auto probe = [&](int t, uint32_t *k, int *q) FQ_LAMBDA_INLINE -> bool {      // is base t of the block inside a flank region?  its table index and quality
+    // The depth is kept as a DIFFERENCE table (the consumer's pull() sums it up): a read's aligned block inside a flank region is a run of consecutive positions
+    // that all count, and costs two atomic adds -- +1 where it begins, -1 behind its end -- instead of one per position.  The Q20 and Q30 depths are kept as what
+    // is MISSING from the depth: a base below the threshold counts one in q20 / q30 at its position, and pull() takes depth minus that -- bases of low quality are
+    // the few, and an atomic add on a table of millions of positions is what this kernel is bound by.
+    auto inreg = [&](int t, uint32_t *k) FQ_LAMBDA_INLINE -> bool {      // is base t of the block inside a flank region?  its table index
       if (t < 0 || t >= cl) return false;
       const int i = abs0 + t;
       bool in = false;
@@ -981,25 +981,18 @@ FQ_HD void fq_qc_base_record(const FqQcArgs &A, int idx, int lane, int nl, uint3
         while (rg < r1 && A.g.reg_end[rg] < i) ++rg;
         if (rg < r1 && A.g.reg_start[rg] <= i) { *k = A.g.reg_base[rg] + (uint32_t)(i - A.g.reg_start[rg]); in = true; }
       }
-      if (!in) return false;
-      const int rr = on_read + t;
-      *q = p.strand == 0 ? (int8_t)(hq[rr] - qsub - 33) : (int8_t)(hq[p.full_len - 1 - rr] - qsub - 33);
-      return true;
+      return in;
     };
     for (int t = lane; t < cl; t += nl) {
       uint32_t k = 0, kn = 0;
-      int q = 0, qp = 0, qn = 0;
-      if (!probe(t, &k, &q)) continue;
-      const bool prev = probe(t - 1, &kn, &qp), next = probe(t + 1, &kn, &qn);
-      if (!prev) FQ_ATOMIC_INC32(&A.depth[k]);
-      if (!next) FQ_ATOMIC_DEC32(&A.depth[k + 1]);
-      if (q >= 20) {
-        if (!(prev && qp >= 20)) FQ_ATOMIC_INC32(&A.q20[k]);
-        if (!(next && qn >= 20)) FQ_ATOMIC_DEC32(&A.q20[k + 1]);
-        if (q >= 30) {
-          if (!(prev && qp >= 30)) FQ_ATOMIC_INC32(&A.q30[k]);
-          if (!(next && qn >= 30)) FQ_ATOMIC_DEC32(&A.q30[k + 1]);
-        }
+      if (!inreg(t, &k)) continue;
+      const int rr0 = on_read + t;
+      const int q = p.strand == 0 ? (int8_t)(hq[rr0] - qsub - 33) : (int8_t)(hq[p.full_len - 1 - rr0] - qsub - 33);
+      if (!inreg(t - 1, &kn)) FQ_ATOMIC_INC32(&A.depth[k]);
+      if (!inreg(t + 1, &kn)) FQ_ATOMIC_DEC32(&A.depth[k + 1]);
+      if (q < 30) {
+        FQ_ATOMIC_INC32(&A.q30[k]);
+        if (q < 20) FQ_ATOMIC_INC32(&A.q20[k]);
       }
       const int rr = on_read + t, cyc = cyc0 + t * it.sign;
       const int code = p.strand == 0 ? fq_nt4(row[rr]) : fq_comp(fq_nt4(row[p.full_len - 1 - rr]));

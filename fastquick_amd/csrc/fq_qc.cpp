@@ -693,9 +693,10 @@ int fq_qc::pull() {
     err = std::string("QC consumer: reading its tables back failed: ") + fqdev::last_error();
     return FQ_ENODEV;
   }
-  {   // the device keeps difference tables (fq_qc_base_record): running sums give the counts
-    uint32_t sd = 0, sa = 0, sb = 0;
-    for (size_t k = 0; k < T; ++k) { sd += d[k]; sa += a[k]; sb += b[k]; depth[k] += sd; q20[k] += sa; q30[k] += sb; }
+  {   // the device keeps the depth as a difference table and, for Q20 / Q30, the bases BELOW the threshold per position (fq_qc_base_record): a running sum gives the
+      // depth, the depth less those the quality depths
+    uint32_t sd = 0;
+    for (size_t k = 0; k < T; ++k) { sd += d[k]; depth[k] += sd; q20[k] += sd - a[k]; q30[k] += sd - b[k]; }
   }
   for (int v = 0; v < 256; ++v) { EmpRep[v] += hist[v]; misEmpRep[v] += hist[256 + v]; EmpCycle[v] += hist[512 + v]; misEmpCycle[v] += hist[768 + v]; }
   for (int v = 0; v < kInsertLimit; ++v) InsertDist[v] += ins[v];
