@@ -218,7 +218,6 @@ struct FqKnobs {   // experiment / test knobs (fq_ctx_set_tuning); defaults are 
   int sw_wave_max = 4096;          // largest mate-SW window the wavefront kernel takes
   int host_threads = -1;           // -1: fq_opts_t::host_threads
   size_t host_par_min = 32768;     // below this many items a per-pair host phase stays on the calling thread
-  int width_locus = 1;             // the width walks go on against the reference itself once their interval is one row (fq_width_strand, FqLocus); 0: every step an Occ lookup (A/B, tests)
   int64_t md_mask_min = 4096;      // calls with at least this many records of compact rows compare them with the reference piece-wise before MD (fq_md_mask_piece)
   int64_t packed_bulk_min = -1;    // packed batches: upload the whole body instead of gathered survivor rows from this many survivor pairs (-1: n_pairs / 8)
   int trace = 0;
@@ -462,7 +461,6 @@ extern "C" int fq_ctx_set_tuning(fq_ctx_t *c, const char *key, int64_t v) {
   else if (k == "host_par_min") c->kn.host_par_min = (size_t)v;
   else if (k == "packed_bulk_min") c->kn.packed_bulk_min = v;
   else if (k == "md_mask_min") c->kn.md_mask_min = v;
-  else if (k == "width_locus") c->kn.width_locus = v != 0;
   else if (k == "trace") c->kn.trace = (int)v;
   else if (k == "gap_order_asc") t->gap_order_asc = (int)v;
   else if (k == "gap_waves_per_cu") t->gap_waves_per_cu = (int)v;
@@ -1286,7 +1284,7 @@ int stageA_search(Call &K) {
       FqWidthArgs wa{};
       wa.ix = ix->dev; wa.o = c->ko; wa.seq = K.dseq; wa.stride = K.dstride; wa.len_trim = K.dlen_trim; wa.read_list = K.dread_list;
       wa.work = c->d_work.p; wa.n_work = nw; wa.wfull = c->d_wfull.p; wa.wstride = Lpad;
-      wa.prec = c->d_prec.p; wa.pstride = Ppad; wa.winfo = c->d_winfo.p; wa.maxdiff_lut = c->d_maxdiff.p; wa.bid_end = c->d_bid_end.p; wa.counters = c->d_counters.p; wa.locus = c->kn.width_locus;
+      wa.prec = c->d_prec.p; wa.pstride = Ppad; wa.winfo = c->d_winfo.p; wa.maxdiff_lut = c->d_maxdiff.p; wa.bid_end = c->d_bid_end.p; wa.counters = c->d_counters.p;
       // device-filling launches of several contexts take turns (fqdev::device_turn_begin)
       struct Turn { int slots = 1; bool held = false; void take() { if (!held) { fqdev::device_turn_begin(slots); held = true; } } void drop() { if (held) { fqdev::device_turn_end(); held = false; } } ~Turn() { drop(); } } turn;
       turn.slots = c->kn.device_turn_slots;
@@ -1369,7 +1367,7 @@ int stageA_search(Call &K) {
             FqWidthArgs w2{};
             w2.ix = ix->dev; w2.o = c->ko; w2.seq = K.dseq; w2.stride = K.dstride; w2.len_trim = K.dlen_trim; w2.read_list = K.dread_list;
             w2.work = c->d_work2.p + n2_total; w2.n_work = (int32_t)cnt; w2.wfull = c->d_wfull2.p; w2.wstride = Lpad; w2.prec = c->d_prec2.p; w2.pstride = Ppad;
-            w2.winfo = c->d_winfo2.p; w2.maxdiff_lut = c->d_maxdiff.p; w2.bid_end = c->d_bid_end2.p; w2.counters = c->d_counters.p; w2.locus = c->kn.width_locus;
+            w2.winfo = c->d_winfo2.p; w2.maxdiff_lut = c->d_maxdiff.p; w2.bid_end = c->d_bid_end2.p; w2.counters = c->d_counters.p;
             CK(fqdev::launch_width(w2));
             CK(fqdev::launch_order(c->d_bid_end2.p, (int)cnt, 0, c->d_order2.p, c->d_order_cnt2.p));
             FqGapArgs gb{};

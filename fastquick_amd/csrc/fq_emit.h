@@ -90,6 +90,7 @@ struct FqSamArgs {
 struct FqB16 { uint32_t w[4]; };
 FQ_HD FqB16 fq_load16(const uint8_t *p) { FqB16 v; memcpy(&v, p, 16); return v; }
 FQ_HD void fq_store16(void *p, const FqB16 &v) { memcpy(p, &v, 16); }
+FQ_HD uint32_t fq_bswap32(uint32_t x) { return (x >> 24) | ((x >> 8) & 0xff00u) | ((x << 8) & 0xff0000u) | (x << 24); }
 FQ_HD FqB16 fq_rev16(const FqB16 &v) { FqB16 r; r.w[0] = fq_bswap32(v.w[3]); r.w[1] = fq_bswap32(v.w[2]); r.w[2] = fq_bswap32(v.w[1]); r.w[3] = fq_bswap32(v.w[0]); return r; }
 // 0xff in every byte of w that equals the byte of pat there
 FQ_HD uint32_t fq_swar_eq(uint32_t w, uint32_t pat) {

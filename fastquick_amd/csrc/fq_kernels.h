@@ -39,7 +39,6 @@
 #endif
 
 struct FqU4 { uint32_t x, y, z, w; };   // one 16-byte load / store
-FQ_HD uint32_t fq_bswap32(uint32_t x) { return (x >> 24) | ((x >> 8) & 0xff00u) | ((x << 8) & 0xff0000u) | (x << 24); }
 
 // nst_nt4_table, libbwa/bntseq.c:38-55 (A0 C1 G2 T3, '-' 5, anything else 4)
 FQ_HD int fq_nt4(uint8_t ch) {
@@ -634,7 +633,6 @@ struct FqWidthArgs {
   const uint8_t *maxdiff_lut; // [len] -> max_diff (bwa_cal_maxdiff, libbwa/bwtaln.c:43-58)
   uint8_t *bid_end;           // [w][2] lower bound on the differences of the whole read, per strand (width[len-1].bid): scheduling hint
   uint64_t *counters;
-  int32_t locus;              // 1: a walk whose interval has come down to one row goes on against the reference itself (fq_width_strand)
 };
 // One thread walks both strands of its read: the two chains (and the two seed chains before them) are independent, so every step
 // has two Occ requests in flight instead of one -- the kernel is bound by the latency of a dependent step, not by requests.
@@ -744,41 +742,6 @@ FQ_HD void fq_width_read(const FqWidthArgs &A, int w, uint8_t *seed_bits, int se
 // (10k markers) and an XCD's L2 holds 4 MB -- a thread that interleaves both chains makes every XCD cache both tables and miss in half of
 // its lookups.  One thread per (read, strand), the threads of strand a in workgroups that share XCDs (fq_device.hip, k_width_strand):
 // each XCD's L2 then serves one table.  Same arithmetic, same outputs; strand 0's thread also writes the read's start record.
-// A walk whose interval [k, l] has come down to ONE row has found the only place its string occurs in the text: from there on a step succeeds exactly when the
-// text's base in front of that place is the read's next base (the interval stays one row wide), and fails -- the interval is empty, bwt_cal_width starts over
-// with the whole range and counts a difference -- when it is not.  The place is SA[k] (bwt_sa: sa_intv / 2 steps of its own), read once per walk; after a failed
-// step the walk that starts over is, nearly always, the same alignment behind a mismatch: its bases are held against the text at the places the old alignment
-// predicts for them, and when ITS interval comes down to one row and all of them agreed, that place is where it is (a string that occurs once and occurs there),
-// without another look at the suffix array.  Widths and difference counts are those of the plain walk by construction; what is saved is an Occ block per step:
-// a read of 150 bases with one mismatch costs 12 + 16 + 12 of them instead of 150.  (FQ_C_OCC_WIDTH counts one block for such a step: rows k - 1 and k share
-// their 128-row block unless k is a multiple of 128.)
-#define FQ_LOCUS_MIN_LEFT 24      /* steps that must be left for a look at the suffix array to pay */
-struct FqLocus {
-  bool hyp = false, uniq = false, sok = false;
-  uint32_t hp = 0;          // text position of the walk's latest base under the hypothesis
-  uint64_t rw = 0;          // reference bases ahead of it, in the order they are used
-  int rleft = 0;
-};
-// the text of strand a is the packed reference (a = 0, .bwt) or its reverse (a = 1, .rbwt): base j of it
-FQ_HD int64_t fq_text_index(const FqDevIndex &ix, int a, uint32_t j) { return a ? ix.l_pac - 1 - (int64_t)j : (int64_t)j; }
-// the text's base at position hp - 1 (the caller has made sure hp > 0); 29-32 bases come with one 8-byte load
-FQ_HD int fq_locus_next(const FqDevIndex &ix, int a, FqLocus &L) {
-  if (L.rleft == 0) {
-    const int64_t idx = fq_text_index(ix, a, L.hp - 1);          // descends with the steps for a = 0, ascends for a = 1
-    const int64_t nbytes = (ix.l_pac + 3) >> 2, b = idx >> 2;
-    if (a ? b + 8 <= nbytes : b >= 7) {
-      uint64_t v;
-      memcpy(&v, ix.pac + (a ? b : b - 7), 8);
-      v = ((uint64_t)fq_bswap32((uint32_t)v) << 32) | fq_bswap32((uint32_t)(v >> 32));      // bytes in text order, the first in the top bits
-      if (a) { L.rw = v << (2 * (idx & 3)); L.rleft = 32 - (int)(idx & 3); }                  // used from the top
-      else { L.rw = v >> (2 * (3 - (idx & 3))); L.rleft = 29 + (int)(idx & 3); }               // used from the bottom
-    } else { L.rw = a ? (uint64_t)fq_pac_base(ix.pac, idx) << 62 : (uint64_t)fq_pac_base(ix.pac, idx); L.rleft = 1; }
-  }
-  int c;
-  if (a) { c = (int)(L.rw >> 62); L.rw <<= 2; } else { c = (int)(L.rw & 3); L.rw >>= 2; }
-  --L.rleft;
-  return c;
-}
 FQ_HD void fq_width_strand(const FqWidthArgs &A, int w, int a, uint8_t *seed_bits, int seed_bits_stride) {
   const int s = A.work ? A.work[w] : w;
   const int r = A.read_list[s];
@@ -814,7 +777,6 @@ FQ_HD void fq_width_strand(const FqWidthArgs &A, int w, int a, uint8_t *seed_bit
   }
   k = 0; l = f.seq_len; wprev = 0; bid = 0;
   int namb = 0;
-  FqLocus L;
   for (int i0 = 0; i0 < v.len; i0 += 8) {
     uint32_t wv[8], pv[8];
     uint64_t bases8 = 0;
@@ -829,39 +791,15 @@ FQ_HD void fq_width_strand(const FqWidthArgs &A, int w, int a, uint8_t *seed_bit
         if (whole) { const int c0 = (int)fq_nt4_fast((uint32_t)(bases8 >> (8 * (7 - j))) & 0xffu); c = (a && c0 < 4) ? 3 - c0 : c0; }
         else c = fq_base(v, a, i);
         namb += c > 3;
-        // the text's base in front of the place the walk is held to be at (FqLocus)
-        bool hmatch = false;
-        if (L.hyp) {
-          if (L.hp == 0) L.hyp = false;       // (nothing in front of the text's first base)
-          else { const int rc = fq_locus_next(A.ix, a, L); --L.hp; hmatch = c < 4 && rc == c; }
+        if (c < 4) {
+          touches += fq_touch2(f, k - 1, l, true);
+          uint32_t ok, ol;
+          fq_occ1_pair(f, k - 1, l, c, &ok, &ol);
+          k = f.L2[c] + ok + 1;
+          l = f.L2[c] + ol;
         }
-        uint32_t wcur;
-        if (L.uniq) {      // one row wide, at a known place: (k, l) are not kept
-          touches += c < 4;
-          if (hmatch) wcur = 1;
-          else { L.uniq = false; L.sok = true; k = 0; l = f.seq_len; ++bid; wcur = l - k + 1; }
-        } else {
-          if (c < 4) {
-            touches += fq_touch2(f, k - 1, l, true);
-            uint32_t ok, ol;
-            fq_occ1_pair(f, k - 1, l, c, &ok, &ol);
-            k = f.L2[c] + ok + 1;
-            l = f.L2[c] + ol;
-          }
-          if (k > l || c > 3) { k = 0; l = f.seq_len; ++bid; L.sok = true; }
-          else {
-            L.sok = L.sok && hmatch;
-            if (A.locus && k == l) {
-              if (L.hyp && L.sok) L.uniq = true;
-              else if (v.len - 1 - i >= FQ_LOCUS_MIN_LEFT) {
-                uint32_t sa_steps = 0;
-                L.hp = fq_sa_lookup(f, k, &sa_steps);
-                L.hyp = true; L.sok = true; L.uniq = true; L.rleft = 0;
-              }
-            }
-          }
-          wcur = l - k + 1;
-        }
+        if (k > l || c > 3) { k = 0; l = f.seq_len; ++bid; }
+        const uint32_t wcur = l - k + 1;
         const uint32_t seedbits = (use_seed && i >= seed_off) ? (uint32_t)seed_bits[(i - seed_off) * seed_bits_stride] << 6 : 0u;
         wv[j] = wcur;
         pv[j] = seedbits | (uint32_t)(bid < 31 ? bid : 31) | (i >= 1 && wcur == wprev ? 1u << 5 : 0u) | (uint32_t)c << 12;

@@ -74,30 +74,9 @@ int launch_trim(const FqTrimArgs &a) { for (int t = 0; t < a.n_rows; ++t) fq_tri
 int launch_trim_all(const FqTrimAllArgs &a) { for (int r = 0; r < a.n_reads; ++r) fq_trim_all_thread(a, r); return 0; }
 int launch_width(const FqWidthArgs &a) {
   uint8_t seed_bits[2 * FQ_SEED_MAX];
-  // FASTQUICK_WIDTH_CHECK=1 (tests): every read's widths, position records, difference bounds and start record from the walk that goes on against the reference
-  // itself (FqLocus) held to those of the walk that looks up Occ at every step -- the process aborts on the first difference
-  static const bool check = [] { const char *e = getenv("FASTQUICK_WIDTH_CHECK"); return e && *e == '1'; }();
-  std::vector<uint32_t> w0; std::vector<FqPos> p0; uint8_t b0[2] = {0, 0}; FqGapWork g0{};
   for (int w = 0; w < a.n_work; ++w) {
-    if (check && a.locus && !(g_bound && g_bound->tune.width_both_strands)) {
-      FqWidthArgs plain = a; plain.locus = 0;
-      uint64_t scratch_counters[FQ_C_STRIPES * FQ_C_STRIDE] = {0};
-      plain.counters = scratch_counters;
-      fq_width_strand(plain, w, 1, seed_bits, 1); fq_width_strand(plain, w, 0, seed_bits, 1);
-      const uint32_t *ow = a.wfull + (size_t)w * 2 * (size_t)a.wstride; const FqPos *pr = a.prec + (size_t)w * 2 * (size_t)a.pstride;
-      w0.assign(ow, ow + 2 * (size_t)a.wstride); p0.assign(pr, pr + 2 * (size_t)a.pstride); b0[0] = a.bid_end[2 * w]; b0[1] = a.bid_end[2 * w + 1]; g0 = a.winfo[w];
-    }
     if (g_bound && g_bound->tune.width_both_strands) fq_width_read(a, w, seed_bits, 1);
     else { fq_width_strand(a, w, 1, seed_bits, 1); fq_width_strand(a, w, 0, seed_bits, 1); }      // (one strand at a time, as the device's kernel)
-    if (!w0.empty()) {
-      const uint32_t *ow = a.wfull + (size_t)w * 2 * (size_t)a.wstride; const FqPos *pr = a.prec + (size_t)w * 2 * (size_t)a.pstride;
-      const int len = (int)(g0.meta & 0xffff);
-      bool same = b0[0] == a.bid_end[2 * w] && b0[1] == a.bid_end[2 * w + 1] && memcmp(&g0, &a.winfo[w], sizeof g0) == 0;
-      for (int st = 0; st < 2 && same; ++st)
-        for (int i = 0; i < len && same; ++i) same = w0[(size_t)st * a.wstride + i] == ow[(size_t)st * a.wstride + i] && memcmp(&p0[(size_t)st * a.pstride + i], &pr[(size_t)st * a.pstride + i], sizeof(FqPos)) == 0;
-      if (!same) { fprintf(stderr, "FASTQUICK_WIDTH_CHECK: work item %d: the two width walks differ\n", w); abort(); }
-      w0.clear();
-    }
   }
   return 0;
 }
