@@ -45,6 +45,15 @@ cd /tmp && export TMPDIR=/tmp
 FQ_PROFILE_DIR=$O/${TAG}_cliont_prof FQ_BENCH_DIR=/tmp/fq_e2e timeout 600 python3 $R/tools/cli_ontarget.py 1048576 8 150 > $O/${TAG}_cli_ontarget_profiled.json 2> $O/${TAG}_cli_ontarget_profiled.err
 for m in sam_out bam_and_qc; do f=$(find $O/${TAG}_cliont_prof/$m -name '*kernel_stats.csv' 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $O/${TAG}_cli_ontarget_${m}_kernel_stats.csv; done
 rm -rf $O/${TAG}_cliont_prof
+# ... the same with every call waiting for its consumers' kernels (FASTQUICK_EMIT_SYNC=1): the consumers' kernels ALONE on the device, not beside the next call's
+FASTQUICK_EMIT_SYNC=1 FQ_PROFILE_DIR=$O/${TAG}_cliont_alone FQ_BENCH_DIR=/tmp/fq_e2e timeout 600 python3 $R/tools/cli_ontarget.py 1048576 8 150 > $O/${TAG}_cli_ontarget_alone.json 2> $O/${TAG}_cli_ontarget_alone.err
+for m in sam_out bam_and_qc; do f=$(find $O/${TAG}_cliont_alone/$m -name '*kernel_stats.csv' 2>/dev/null | head -1); [ -n "$f" ] && cp "$f" $O/${TAG}_cli_ontarget_alone_${m}_kernel_stats.csv; done
+rm -rf $O/${TAG}_cliont_alone
+# ... how busy the device is over the steady calls of a 33.5 M-pair run (tools/kernel_busy.py over the kernel and copy traces), and the calls' stages (FASTQUICK_CTX_TRACE)
+FQ_PROFILE_COPIES=1 FQ_PROFILE_DIR=$O/${TAG}_cliont_busy FQ_BENCH_DIR=/tmp/fq_e2e timeout 900 python3 $R/tools/cli_ontarget.py 1048576 32 150 > $O/${TAG}_cli_ontarget_busy.json 2> $O/${TAG}_cli_ontarget_busy.err
+for m in sam_out bam_and_qc; do [ -d $O/${TAG}_cliont_busy/$m ] && python3 $R/tools/kernel_busy.py $O/${TAG}_cliont_busy/$m --mid 0.4 --gaps 16 > $O/${TAG}_cli_ontarget_busy_$m.txt 2>&1; done
+rm -rf $O/${TAG}_cliont_busy
+FASTQUICK_TRACE=1 FASTQUICK_CTX_TRACE=1 FQ_BENCH_DIR=/tmp/fq_e2e timeout 900 python3 $R/tools/cli_ontarget.py 1048576 32 150 > $O/${TAG}_cli_ontarget_trace.json 2> $O/${TAG}_cli_ontarget_trace.err
 cd $R
 bash tools/frontend_pmc.sh $TAG 2000000 > /dev/null 2>&1
 python3 tools/frontend_bench.py --records 4000000 > $O/${TAG}_inflate_kernel.txt 2>&1
