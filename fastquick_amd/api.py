@@ -101,7 +101,7 @@ EXPORTS = ["fq_default_opts", "fq_index_build", "fq_index_load", "fq_index_destr
            "fq_ctx_set_debug", "fq_align_batch", "fq_batch_upload", "fq_align_resident", "fq_sam_header",
            "fq_sam_format_last", "fq_stage_dump_last", "fq_stats_get", "fq_stats_reset", "fq_version", "fq_host_cpus", "fq_runtime_configure", "fq_device_count", "fq_index_bitmap_fetch",
            "fq_pinned_alloc", "fq_pinned_free", "fq_pack_reads", "fq_packed_free", "fq_packed_create", "fq_pack_reads_into", "fq_pack_single_reads_into", "fq_packed_prefetch", "fq_packed_cancel", "fq_align_packed", "fq_stream_run",
-           "fq_ctx_set_tuning", "fq_ctx_set_serial_hooks", "fq_ctx_mark_stream_broken", "fq_ctx_state_export", "fq_ctx_state_import", "fq_qc_default_opts", "fq_qc_create", "fq_qc_destroy", "fq_qc_last_error", "fq_qc_begin_file",
+           "fq_ctx_set_tuning", "fq_ctx_set_serial_hooks", "fq_ctx_mark_stream_broken", "fq_ctx_state_export", "fq_ctx_state_import", "fq_ctx_state_move", "fq_qc_default_opts", "fq_qc_create", "fq_qc_destroy", "fq_qc_last_error", "fq_qc_begin_file",
            "fq_qc_add_last", "fq_qc_end_file", "fq_qc_write", "fq_qc_state_reset", "fq_qc_state_export", "fq_qc_merge", "fq_bam_create", "fq_bam_add_last", "fq_bam_format_last", "fq_bam_write_records", "fq_bam_close",
            "fq_fastq_open", "fq_fastq_configure", "fq_fastq_set_sampling", "fq_fastq_read", "fq_fastq_last_error", "fq_fastq_dropped_record", "fq_fastq_unequal_lengths", "fq_fastq_is_bgzf", "fq_fastq_close", "fq_inflate_raw", "fq_crc32", "fq_inflate_device", "fq_bgzf_inflate_device",
            "fq_frontend_open", "fq_frontend_next", "fq_frontend_release", "fq_frontend_handover", "fq_frontend_unequal_lengths", "fq_frontend_stats", "fq_frontend_last_error", "fq_frontend_close",
@@ -215,6 +215,7 @@ def load_library(path: str | None = None):
     L.fq_ctx_state_export.restype = C.c_int64
     L.fq_ctx_state_export.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
     L.fq_ctx_state_import.argtypes = [C.c_void_p, C.c_void_p, C.c_int64]
+    L.fq_ctx_state_move.argtypes = [C.c_void_p, C.c_void_p]
     L.fq_qc_default_opts.argtypes = [C.POINTER(QcOpts)]
     L.fq_qc_create.argtypes = [C.c_void_p, C.c_char_p, C.c_char_p, C.POINTER(QcOpts), C.POINTER(C.c_void_p)]
     L.fq_qc_destroy.argtypes = [C.c_void_p]
@@ -457,6 +458,10 @@ class Aligner:
 
     def import_state(self, blob: bytes) -> None:
         self._check(self.L.fq_ctx_state_import(self.h, blob, len(blob)), "fq_ctx_state_import")
+
+    def take_state_of(self, other: "Aligner") -> None:
+        """fq_ctx_state_move: this context goes on with the stream `other` has aligned so far (one process, nothing serialised)."""
+        self._check(self.L.fq_ctx_state_move(self.h, other.h), "fq_ctx_state_move")
 
     def set_serial_hooks(self, before, after) -> None:
         """before() / after(): Python callables run around the order-dependent part of every call (None clears)."""

@@ -2597,6 +2597,16 @@ extern "C" int64_t fq_ctx_state_export(const fq_ctx_t *c, void *buf, int64_t cap
   }
   return need;
 }
+// the same hand-over between two contexts of ONE process (the command line's two contexts in turn): the state moves, nothing is serialised -- the (k,l)
+// cache of a repeat-rich stream is megabytes.  `from` is left with an empty cache; a broken stream stays broken on both.
+extern "C" int fq_ctx_state_move(fq_ctx_t *to, fq_ctx_t *from) {
+  if (!to || !from || to == from) return FQ_EINVAL;
+  if (from->stream_broken) { to->stream_broken = true; to->err = "the stream's state comes from a call that failed"; return FQ_EIO; }
+  to->rng = from->rng; to->last_ii = from->last_ii;
+  to->kl_cache.swap(from->kl_cache);
+  from->kl_cache.clear();
+  return FQ_OK;
+}
 extern "C" int fq_ctx_state_import(fq_ctx_t *c, const void *buf, int64_t len) {
   if (!c || !buf || len < (int64_t)(24 + sizeof(fq_isize_t))) return FQ_EINVAL;
   const uint8_t *p = (const uint8_t *)buf, *end = p + len;

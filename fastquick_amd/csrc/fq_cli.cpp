@@ -357,7 +357,6 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
     };
     before_die = [&] { if (th_qc.joinable()) th_qc.join(); if (th_out.joinable()) th_out.join(); };
     fq_ctx_t *cur = nullptr, *other = nullptr;
-    std::vector<char> token;
     for (;;) {
       const auto tr0 = std::chrono::steady_clock::now();
       fq_text_batch_t *tb = nullptr;
@@ -385,9 +384,7 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
         other = ctx2;
       } else {
         // the stream's order-dependent state -- drand48 stream, last_ii, (k,l) cache -- goes from the context of the last call to this one's
-        const int64_t need = fq_ctx_state_export(other, nullptr, 0);
-        token.resize((size_t)std::max<int64_t>(need, 0));
-        if (need < 0 || fq_ctx_state_export(other, token.data(), need) != need || fq_ctx_state_import(cur, token.data(), need)) fail("handing the stream's state from one context to the other failed");
+        if (fq_ctx_state_move(cur, other)) fail("handing the stream's state from one context to the other failed");
       }
       if (!se) order_check((int)n, [&](int sb, int e) { const char *nm = fq_text_batch_first_name(tb, sb, e); return nm ? nm : ""; });
       fq_result_batch_t res;

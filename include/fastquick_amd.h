@@ -362,6 +362,8 @@ int fq_ctx_set_serial_hooks(fq_ctx_t *c, fq_serial_hook before, fq_serial_hook a
 int fq_ctx_mark_stream_broken(fq_ctx_t *c);
 int64_t fq_ctx_state_export(const fq_ctx_t *c, void *buf, int64_t cap);   /* bytes written, or needed when buf is NULL / too small */
 int fq_ctx_state_import(fq_ctx_t *c, const void *buf, int64_t len);
+/* the same hand-over between two contexts of one process, without serialising: `to` takes the stream's state, `from` keeps an empty (k,l) cache */
+int fq_ctx_state_move(fq_ctx_t *to, fq_ctx_t *from);
 
 /* Experiment / test knobs by name (defaults are what DESIGN.md measures): gap_long_pops, gap_long_always, gap_pool,
  * gap_nogap_min, gap_pipeline_min, gap_pipeline_segs, gap_long_pops2, gap_split_hard, gap_no_order, gap_order_asc, gap_waves_per_cu, gap_coop_waves, gap_refill_min, sw_wave_max, host_threads, host_par_min, filter_no_turns,

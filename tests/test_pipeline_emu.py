@@ -329,6 +329,35 @@ def test_a_malformed_stream_state_is_refused_whole_and_breaks_the_stream(golden_
     ix.close()
 
 
+def test_two_contexts_in_turn_with_the_state_moved_equal_one(golden_cases, emu_lib):
+    """fq_ctx_state_move (what the command line's two contexts hand to each other): the reference batches of the `wide` golden -- a 1,292-fold repeat through the (k,l)
+    cache -- and of `isize` (the last_ii chain) aligned on two contexts in turn, the state moved before every call, give the golden's text; the context a state was
+    moved from is left with a fresh stream's cache (its export is as long as one without entries)."""
+    for tag in ("wide", "isize"):
+        g = golden_cases[tag]
+        names, seq, qual, lens = ob.read_fastq_pair(g["fq1"], g["fq2"])
+        B = g["batch"]
+        ix = api.Index(g["prefix"], lib=emu_lib)
+        ctx = [api.Aligner(ix, api.default_opts(emu_lib, trim_qual=g["trim_qual"]), max_pairs=max(16, B)) for _ in range(2)]
+        empty = len(ctx[0].export_state())
+        got = b""
+        for k, lo in enumerate(range(0, seq.shape[1], B)):
+            hi = min(seq.shape[1], lo + B)
+            cur, other = ctx[k & 1], ctx[(k & 1) ^ 1]
+            if k:
+                cur.take_state_of(other)
+                assert len(other.export_state()) == empty
+            cur.align(seq[:, lo:hi], qual[:, lo:hi], lens[:, lo:hi], names[lo:hi])
+            got += cur.sam_text()
+        want = b"".join(l for l in open(g["sam"], "rb").read().splitlines(keepends=True) if not l.startswith(b"@"))
+        assert got == want, tag
+        with pytest.raises(api.FastquickError):
+            ctx[0].take_state_of(ctx[0])
+        for a in ctx:
+            a.close()
+        ix.close()
+
+
 def _stream_state(rng: int) -> bytes:
     """fq_ctx_state_export's layout for a fresh stream whose drand48 state is `rng`: mark, rng, last_ii (avg = std = -1, rest 0), no (k,l) entries."""
     import struct
