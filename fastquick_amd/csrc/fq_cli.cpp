@@ -228,6 +228,7 @@ fq_frontend_t *open_device_front_end(const Args &A, const std::string &f1, const
   if (A.host_reader || A.frac < 1.0) return nullptr;       // (--frac_samp: the reference's generator is walked record by record, on the host)
   fq_frontend_t *fe = nullptr;
   const int rc = fq_frontend_open(device, f1.c_str(), f2.empty() ? nullptr : f2.c_str(), A.o.batch_pairs, A.chunk_pairs, slot_mode, stride, &fe);
+  mark("front end open");
   if (rc == FQ_EIO) return nullptr;                          // not a regular BGZF file: the host reader's
   if (rc) die("cannot start the front end on device " + std::to_string(device) + " (" + std::to_string(rc) + ")");
   return fe;
@@ -863,6 +864,7 @@ int main(int argc, char **argv) {
     const int n_dev = fq_device_count();
     if (n_dev <= 0) die("no HIP device is visible; there is no CPU fallback");
     for (int d : devices) if (d >= n_dev) die("device " + std::to_string(d) + " does not exist (" + std::to_string(n_dev) + " visible)");
+    mark("devices counted");
   }
   const size_t W = devices.size();
   std::vector<Worker> wk(W);
