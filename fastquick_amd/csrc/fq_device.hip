@@ -11,7 +11,11 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
+#include <sys/mman.h>
+#include <sys/syscall.h>
+#include <unistd.h>
 
 #include "fq_backend.h"
 
@@ -190,12 +194,69 @@ void *dmalloc(size_t bytes) {
   return p;
 }
 void dfree(void *p) { if (p) (void)hipFree(p); }
+// Pinned host memory.  hipHostMalloc pins 4 KiB pages one by one: 0.15-0.4 ms per megabyte, and a context of a deep run wants 0.4 GB of staging in its first call.  Blocks of
+// kRegisterMin bytes or more are anonymous mappings (huge pages asked for) made known to the runtime with hipHostRegister instead: four times faster to get, the same copy
+// rate, the same address on the device (the staging kernels read and write them in place) -- measured on the box, tools/README.md (pin_bench).  FASTQUICK_PIN_REGISTER=0: hipHostMalloc for all.
+static const size_t kRegisterMin = (size_t)4 << 20;
+static std::mutex g_reg_mu;
+static std::unordered_map<void *, size_t> g_registered;
+// hipHostMalloc places its pages on the host node next to the device; a mapping is placed by whoever touches it first.  The mapping is bound (preferred, not strict) to
+// the node the device's PCI function reports, so that the copy engines do not cross the sockets' link: -1 when the system does not say.
+static int device_numa_node(int dev) {
+  static std::mutex mu;
+  static std::unordered_map<int, int> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = cache.find(dev);
+  if (it != cache.end()) return it->second;
+  int node = -1;
+  char bus[64] = {0};
+  if (hipDeviceGetPCIBusId(bus, (int)sizeof bus, dev) == hipSuccess) {
+    for (char *c = bus; *c; ++c) if (*c >= 'A' && *c <= 'F') *c = (char)(*c - 'A' + 'a');
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/numa_node";
+    if (FILE *f = fopen(path.c_str(), "r")) { if (fscanf(f, "%d", &node) != 1) node = -1; fclose(f); }
+  } else (void)hipGetLastError();
+  cache[dev] = node;
+  return node;
+}
+static void prefer_node(void *m, size_t len, int node) {
+  if (node < 0 || node >= 1024) return;
+  unsigned long mask[16] = {0};
+  mask[node / (8 * sizeof(unsigned long))] |= 1ul << (node % (8 * sizeof(unsigned long)));
+  (void)syscall(SYS_mbind, m, len, 1 /* MPOL_PREFERRED */, mask, (unsigned long)(8 * sizeof mask + 1), 0u);
+}
 void *hmalloc(size_t bytes) {
+  static const bool use_register = [] { const char *e = getenv("FASTQUICK_PIN_REGISTER"); return !(e && *e == '0'); }();
+  if (use_register && bytes >= kRegisterMin) {
+    const size_t len = (bytes + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1);
+    void *m = mmap(nullptr, len, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (m != MAP_FAILED) {
+      (void)madvise(m, len, MADV_HUGEPAGE);
+      int dev = 0;
+      if (hipGetDevice(&dev) == hipSuccess) prefer_node(m, len, device_numa_node(dev)); else (void)hipGetLastError();
+      if (hipHostRegister(m, len, hipHostRegisterDefault) == hipSuccess) {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        g_registered[m] = len;
+        return m;
+      }
+      (void)hipGetLastError();
+      munmap(m, len);      // (a limit on locked memory, a runtime that cannot: the ordinary way below)
+    }
+  }
   void *p = nullptr;
   if (hipHostMalloc(&p, bytes ? bytes : 16, hipHostMallocDefault) != hipSuccess) { g_err = "hipHostMalloc failed"; return nullptr; }
   return p;
 }
-void hfree(void *p) { if (p) (void)hipHostFree(p); }
+void hfree(void *p) {
+  if (!p) return;
+  size_t len = 0;
+  {
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    auto it = g_registered.find(p);
+    if (it != g_registered.end()) { len = it->second; g_registered.erase(it); }
+  }
+  if (len) { (void)hipHostUnregister(p); munmap(p, len); }
+  else (void)hipHostFree(p);
+}
 int h2d(void *dst, const void *src, size_t bytes) { FQ_PRE(); if (bytes) FQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, g_stream)); return 0; }
 int d2h(void *dst, const void *src, size_t bytes) { FQ_PRE(); if (bytes) FQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, g_stream)); return 0; }
 int d2d(void *dst, const void *src, size_t bytes) { FQ_PRE(); if (bytes) FQ_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, g_stream)); return 0; }
