@@ -518,6 +518,8 @@ void align_input(Args A, const std::pair<std::string, std::string> &input, fq_in
   }
   fprintf(stderr, "NOTICE - device time (ms): prep %.1f width %.1f gap %.1f sa %.1f sw %.1f refine %.1f records %.1f md %.1f consumers' kernels %.1f ; host %.1f ; waited for the device %.1f ; calls' CPU %.1f ; wall %.1f\n", st.kernel_ms[0],
           st.kernel_ms[1], st.kernel_ms[2], st.kernel_ms[3], st.kernel_ms[4], st.kernel_ms[5], st.kernel_ms[FQ_K_REC_KERNEL], st.kernel_ms[FQ_K_MD_KERNEL], st.kernel_ms[FQ_K_EMIT], st.host_ms_total, st.device_wait_ms, st.host_cpu_ms, st.wall_ms_total);
+  fprintf(stderr, "NOTICE - the calls of one context moved over PCIe (bytes per pair): to the device %.1f ; to the host %.1f (lists, counts, hit lists; with the consumers on the device their outputs leave it on streams of their own and are not in this figure)\n",
+          st.pairs ? (double)st.h2d_bytes / (double)st.pairs : 0.0, st.pairs ? (double)st.d2h_bytes / (double)st.pairs : 0.0);
   fprintf(stderr, "NOTICE - consumers (ms): StatCollector %.1f ; %s writer %.1f ; first chunk read %.1f ; packing %.1f\n", qc_ms, A.sam_out ? "SAM" : "BAM", out_ms, read_ms, pack_ms);
   fprintf(stderr, "NOTICE - reading (ms): all chunks %.1f ; waited for %.1f ; alignment calls %.1f\n", read_all_ms, read_wait_ms, align_ms);
   if (qc) fq_qc_end_file(qc);
