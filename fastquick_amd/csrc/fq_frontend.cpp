@@ -331,7 +331,8 @@ void reader_main(fq_frontend *fe, int e) {
     }
     // the stream's first chunks are short ones (an eighth, a quarter, a half of a chunk): the first batch is out after an eighth of the time,
     // and the kernels behind the reader have work while it reads
-    if (F.chunks_read < 3) want = std::max<uint64_t>(want >> (3 - F.chunks_read), (uint64_t)((double)fe->batch_pairs * F.text_per_record * 1.02) + (1u << 20));   // (a reference batch at least)
+    static const int ramp = [] { const char *e = getenv("FASTQUICK_FE_RAMP"); const int v = e ? atoi(e) : 3; return v < 0 ? 0 : v > 5 ? 5 : v; }();      // (experiment knob: how many short chunks lead a stream)
+    if (F.chunks_read < ramp) want = std::max<uint64_t>(want >> (ramp - F.chunks_read), (uint64_t)((double)fe->batch_pairs * F.text_per_record * 1.02) + (1u << 20));   // (a reference batch at least)
     ++F.chunks_read;
     CompChunk &C = F.chunk[k];
     C.mem.clear(); C.comp_len = 0; C.text_len = 0; C.err.clear(); C.eof = false;
